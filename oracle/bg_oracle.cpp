@@ -1,0 +1,728 @@
+// bg_oracle.cpp — CPU restatement of the BioGraph seqset-build + overlap-walk hot path.
+//
+// *** TEST INFRASTRUCTURE ONLY ***  Nothing in the product path (biograph_amd/, include/)
+// may link, import or call this file.  It is used by tests/, by __graft_entry__.smoke() as the
+// checker, and by bench.py's `cpu_baseline` leg (kind = "port", single thread).
+//
+// Parity pinning: this restatement is checked by tests/test_oracle_golden.py against the
+// reference's own committed fixtures (copied as data into tests/golden/):
+//   * golden/e_coli_10000snp.fq -> golden/e_coli_10000snp.bg/seqset (7108 kept k-mers,
+//     8444 corrected reads / 288464 bases, 19935 entries, all arrays byte-equal),
+//   * datasets/lambdaToyData/benchmark/father_lambda.bg (row E closed loop, 98006 entries),
+//   * builder_test.cpp:52-123 literal answers, seqset_test.py:17-104 walk answers.
+//
+// Every function cites the reference file:line (relative to the reference tree) it follows.
+// Plain single-threaded C++17, no dependencies.
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace orc {
+
+using kmer_t = uint64_t;
+
+// modules/bio_base/dna_base.h:38-56 — A0 C1 G2 T3 (case-insensitive); anything else is not a base.
+static inline int base_code(char c) {
+  switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return -1;
+  }
+}
+static const char kBases[5] = "ACGT";
+
+// modules/bio_base/dna_sequence.cpp:330-333 — reverse complement of a k-mer (first base in high bits).
+static inline kmer_t rev_comp(kmer_t in, unsigned size) {
+  kmer_t out = 0;
+  for (unsigned i = 0; i < size; ++i) {
+    out = (out << 2) | (3 - (in & 3));
+    in >>= 2;
+  }
+  return out;
+}
+
+// modules/bio_base/dna_sequence.cpp:341-351 — canonical = min(kmer, rc); flipped iff rc < kmer.
+static inline kmer_t canonicalize(kmer_t in, unsigned size, bool& flipped) {
+  kmer_t c = rev_comp(in, size);
+  if (c < in) { flipped = true; return c; }
+  flipped = false;
+  return in;
+}
+
+// modules/bio_base/fast_read_correct.cpp:5-11
+static inline kmer_t kmer_shift_left(kmer_t orig, unsigned k, int b) {
+  kmer_t r = (orig << 2) | kmer_t(b);
+  if (k < 32) r &= ~(~kmer_t(0) << (2 * k));
+  return r;
+}
+
+static std::string revcomp_str(const std::string& s) {
+  std::string r(s.size(), 'A');
+  for (size_t i = 0; i < s.size(); ++i) {
+    int b = base_code(s[s.size() - 1 - i]);
+    r[i] = kBases[3 - b];
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// k-mer counting (rows B1-B4).
+// modules/build_seqset/kmer_counter.h:297-326 (rolling window, N resets and clears first flag),
+// modules/build_seqset/kmer_count_table.h:54-103 (fwd/rev counts, flags swapped when flipped),
+// modules/bio_mapred/kmerize_bf.cpp:290-318 (keep iff fwd+rev >= min_count; skew/overrep inactive
+// at default flags).  The probabilistic pre-pass (kmer_counter.cpp:579-697) only prunes k-mers
+// whose true count is < min(min_count,3) and therefore never changes the kept set.
+struct KmerElem {
+  uint32_t fwd = 0, rev = 0;
+  uint8_t flags = 0;  // bit0 = fwd_starts_read, bit1 = rev_starts_read (kmer_set.h:20-21)
+};
+
+struct KmerSet {
+  unsigned k = 30;
+  std::vector<kmer_t> kmers;  // sorted canonical
+  std::vector<uint8_t> flags;
+  std::vector<uint32_t> fwd, rev;
+  std::unordered_map<kmer_t, uint32_t> index;
+  void finish() {
+    index.reserve(kmers.size() * 2);
+    for (size_t i = 0; i < kmers.size(); ++i) index.emplace(kmers[i], uint32_t(i));
+  }
+  // correct_reads.cpp:163-171 kmer_lookup_f
+  bool lookup(kmer_t kmer, bool* flipped, uint32_t* idx) const {
+    kmer_t canon = canonicalize(kmer, k, *flipped);
+    auto it = index.find(canon);
+    if (it == index.end()) return false;
+    *idx = it->second;
+    return true;
+  }
+};
+
+static int count_kmers(const char* seq, const uint64_t* offs, uint64_t n_reads, unsigned k,
+                       std::unordered_map<kmer_t, KmerElem>& table) {
+  for (uint64_t r = 0; r < n_reads; ++r) {
+    const char* it = seq + offs[r];
+    const char* end = seq + offs[r + 1];
+    bool is_first = true;
+    unsigned left = k;
+    kmer_t kmer = 0;
+    while (it != end) {
+      if (*it == 'N') {  // kmer_counter.h:306-311
+        ++it;
+        left = k;
+        is_first = false;
+        continue;
+      }
+      int b = base_code(*it);
+      if (b < 0) return -1;  // dna_base.h:54 throws
+      kmer = kmer_shift_left(kmer, k, b);
+      ++it;
+      if (left) --left;
+      if (!left) {
+        bool is_last = (it == end);
+        bool flipped;
+        kmer_t canon = canonicalize(kmer, k, flipped);
+        KmerElem& e = table[canon];
+        bool sf = is_first, sr = is_last;
+        if (flipped) std::swap(sf, sr);  // kmer_count_table.h:82-84
+        if (sf) e.flags |= 1;
+        if (sr) e.flags |= 2;
+        if (flipped) e.rev++; else e.fwd++;
+        is_first = false;
+      }
+    }
+  }
+  return 0;
+}
+
+static KmerSet* make_kmer_set(const std::unordered_map<kmer_t, KmerElem>& table, unsigned k,
+                              uint32_t min_count, bool keep_all) {
+  std::vector<std::pair<kmer_t, KmerElem>> v;
+  v.reserve(table.size());
+  for (auto& kv : table) {
+    uint64_t tot = uint64_t(kv.second.fwd) + kv.second.rev;
+    if (keep_all || tot >= min_count) v.push_back(kv);  // kmerize_bf.cpp:291-294
+  }
+  std::sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.first < b.first; });
+  auto* ks = new KmerSet;
+  ks->k = k;
+  for (auto& kv : v) {
+    ks->kmers.push_back(kv.first);
+    ks->flags.push_back(kv.second.flags);
+    ks->fwd.push_back(kv.second.fwd);
+    ks->rev.push_back(kv.second.rev);
+  }
+  ks->finish();
+  return ks;
+}
+
+// ------------------------------------------------------------------------------------------
+// Read correction (rows C1, C2).
+struct FrcParams {
+  unsigned max_corrections = 8;
+  unsigned min_good_run = 2;
+  unsigned kmer_size = 30;
+  const KmerSet* ks = nullptr;
+};
+
+struct FrcKmer { bool flipped; uint32_t index; };
+
+struct FrcOut {
+  std::string corrected;
+  unsigned corrections = 0;
+  std::vector<FrcKmer> kmers;
+};
+
+// modules/bio_base/fast_read_correct.cpp:16-90 — literal port (std::string for dna_sequence).
+static void correct_internal(FrcOut* result, const char* in, size_t n, kmer_t kmer,
+                             const FrcParams& p, unsigned min_good_run_here,
+                             unsigned max_corrections, bool require_run_at_end) {
+  const char* it = in;
+  const char* end = in + n;
+  FrcKmer ki;
+  if (*it != 'N') {
+    kmer_t next = kmer_shift_left(kmer, p.kmer_size, base_code(*it));
+    while (p.ks->lookup(next, &ki.flipped, &ki.index)) {
+      result->corrected.push_back(kBases[base_code(*it)]);
+      result->kmers.push_back(ki);
+      ++it;
+      if (it == end) return;
+      kmer = next;
+      if (*it == 'N') break;
+      next = kmer_shift_left(kmer, p.kmer_size, base_code(*it));
+    }
+  }
+  if (result->corrected.size() < min_good_run_here) return;
+  if (max_corrections == 0) return;
+  ++it;
+  FrcOut tries[4];
+  unsigned best_size = 0;
+  int best_b = 0;
+  size_t input_left = end - it;
+  for (int b = 0; b < 4; ++b) {
+    kmer_t tk = kmer_shift_left(kmer, p.kmer_size, b);
+    if (!p.ks->lookup(tk, &ki.flipped, &ki.index)) continue;
+    tries[b].kmers.push_back(ki);
+    if (it != end) {
+      correct_internal(&tries[b], it, input_left, tk, p, p.min_good_run, max_corrections - 1,
+                       require_run_at_end);
+    }
+    if (require_run_at_end && tries[b].corrected.size() < p.min_good_run) continue;
+    if (tries[b].corrected.size() >= best_size) {  // :74-77 — size+1 so only strictly longer wins later
+      best_size = unsigned(tries[b].corrected.size()) + 1;
+      best_b = b;
+    }
+  }
+  if (best_size) {
+    result->corrected.push_back(kBases[best_b]);
+    result->corrections++;
+    result->corrected += tries[best_b].corrected;
+    result->corrections += tries[best_b].corrections;
+    result->kmers.insert(result->kmers.end(), tries[best_b].kmers.begin(), tries[best_b].kmers.end());
+  }
+}
+
+// modules/bio_base/fast_read_correct.cpp:94-182
+static FrcOut fast_read_correct(const char* in, size_t n, const FrcParams& p) {
+  FrcOut result;
+  const unsigned k = p.kmer_size;
+  if (n < k) return FrcOut{};
+  unsigned max_corrections = p.max_corrections;
+  const char* begin = in;
+  const char* end = in + n;
+  const char* it = begin;
+  kmer_t kmer = 0;
+  unsigned left = k;
+  FrcKmer ki{false, 0};
+  while (left || !p.ks->lookup(kmer, &ki.flipped, &ki.index)) {
+    if (it == end) return FrcOut{};
+    if (*it == 'N') { ++it; left = k; continue; }
+    kmer = kmer_shift_left(kmer, k, base_code(*it));
+    ++it;
+    if (left) --left;
+  }
+  FrcOut right;
+  if (it == begin + k) {
+    for (unsigned i = 0; i < k; ++i) result.corrected.push_back(kBases[base_code(begin[i])]);
+    if (it == end) { result.kmers.push_back(ki); return result; }
+    right.kmers.push_back(ki);
+  } else {
+    const char* kmer_start = it - k;
+    std::string left_to_correct(begin, kmer_start - begin);
+    std::string left_ok;
+    for (unsigned i = 0; i < k; ++i) left_ok.push_back(kBases[base_code(kmer_start[i])]);
+    std::reverse(left_to_correct.begin(), left_to_correct.end());
+    for (char& c : left_to_correct)
+      if (c != 'N') c = kBases[3 - base_code(c)];
+    FrcOut lc;
+    correct_internal(&lc, left_to_correct.data(), left_to_correct.size(), rev_comp(kmer, k), p, 0,
+                     max_corrections, false);
+    if (lc.corrected.size() != left_to_correct.size()) return FrcOut{};
+    result.corrected = revcomp_str(lc.corrected);
+    result.corrected += left_ok;
+    for (auto& x : lc.kmers) x.flipped = !x.flipped;
+    result.kmers = std::move(lc.kmers);
+    std::reverse(result.kmers.begin(), result.kmers.end());
+    result.kmers.push_back(ki);
+    max_corrections -= lc.corrections;
+    result.corrections += lc.corrections;
+  }
+  if (it != end) correct_internal(&right, it, end - it, kmer, p, 0, max_corrections, true);
+  result.corrected += right.corrected;
+  result.corrections += right.corrections;
+  result.kmers.insert(result.kmers.end(), right.kmers.begin(), right.kmers.end());
+  return result;
+}
+
+// modules/build_seqset/correct_reads.cpp:154-231.  trim_after_portion is parsed as float
+// (biograph_create.cpp:489-490), stored in a double field (read_correction.h:42) and multiplied
+// by size_t -> double, truncated to unsigned (correct_reads.cpp:174): 0.7f*150 -> 104.
+struct CorrectStats {
+  uint64_t corrected_reads = 0, corrected_bases = 0, failed = 0, modified = 0, modified_bases = 0,
+           truncated = 0, dropped_bases = 0, ref_records = 0;
+};
+
+static bool correct_read(const char* in, size_t n, const FrcParams& p, float trim_after_portion,
+                         std::string* out, CorrectStats* st) {
+  if (n < p.kmer_size) return false;
+  for (size_t i = 0; i < n; ++i)
+    if (in[i] != 'N' && base_code(in[i]) < 0) return false;
+  FrcOut res = fast_read_correct(in, n, p);
+  unsigned needed = unsigned(double(trim_after_portion) * double(n));
+  if (res.corrected.size() < needed || res.corrected.size() < p.kmer_size) {
+    st->failed++;
+    return false;
+  }
+  if (res.corrected.size() < n) { st->dropped_bases += n - res.corrected.size(); st->truncated++; }
+  if (res.corrections) { st->modified++; st->modified_bases += res.corrections; }
+  // correct_reads.cpp:195-213 — number of suffix records the REFERENCE would emit (stat only; the
+  // final entry set is independent of it).
+  auto starts = [&](const FrcKmer& k) {
+    return (p.ks->flags[k.index] & (k.flipped ? 2 : 1)) != 0;
+  };
+  unsigned nf = 0, nr = 0;
+  for (auto& k : res.kmers) { if (nf > 0 && starts(k)) break; ++nf; }
+  for (auto it = res.kmers.rbegin(); it != res.kmers.rend(); ++it) {
+    FrcKmer k{!it->flipped, it->index};
+    if (nr > 0 && starts(k)) break;
+    ++nr;
+  }
+  st->ref_records += nf + nr;
+  st->corrected_reads++;
+  st->corrected_bases += res.corrected.size();
+  *out = std::move(res.corrected);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// Entry set (row E): prefix-free maxima of every suffix of every read and of its reverse
+// complement, sorted A<C<G<T with a prefix before its extensions
+// (expand.cpp:19-48,285-380; expand_test.cpp:43-75; builder.cpp:95-117).
+static void dedup_sorted(std::vector<std::string>& v) {
+  // expand.cpp:19-48 skip_dups: drop equal entries and entries that are a prefix of the successor.
+  std::vector<std::string> out;
+  out.reserve(v.size());
+  for (size_t i = 0; i < v.size(); ++i) {
+    if (i + 1 < v.size()) {
+      const std::string& a = v[i];
+      const std::string& b = v[i + 1];
+      if (a.size() <= b.size() && std::memcmp(a.data(), b.data(), a.size()) == 0) continue;
+    }
+    out.push_back(std::move(v[i]));
+  }
+  v.swap(out);
+}
+
+static std::vector<std::string> build_entries_simple(const std::vector<std::string>& reads) {
+  std::vector<std::string> all;
+  for (auto& r : reads) {
+    std::string rc = revcomp_str(r);
+    for (size_t j = 0; j < r.size(); ++j) {
+      all.push_back(r.substr(j));
+      all.push_back(rc.substr(j));
+    }
+  }
+  std::sort(all.begin(), all.end());
+  dedup_sorted(all);
+  return all;
+}
+
+// Same set, computed with the exact-cover emission rule the GPU path uses: for an
+// oriented read s, suffix j>=1 and all later ones are skipped as soon as s[j:] is a prefix of some
+// oriented read (found through an index of first-K-mers).  Used as the CPU baseline ("port") and
+// cross-checked against build_entries_simple in tests.
+static std::vector<std::string> build_entries_cover(const std::vector<std::string>& reads, unsigned K,
+                                                   uint64_t* n_records) {
+  std::vector<std::string> o;
+  o.reserve(reads.size() * 2);
+  for (auto& r : reads) { o.push_back(r); o.push_back(revcomp_str(r)); }
+  auto key_at = [&](const std::string& s, size_t j) {
+    kmer_t x = 0;
+    for (unsigned i = 0; i < K; ++i) x = (x << 2) | kmer_t(base_code(s[j + i]));
+    return x;
+  };
+  std::unordered_map<kmer_t, std::vector<uint32_t>> idx;
+  for (size_t i = 0; i < o.size(); ++i)
+    if (o[i].size() >= K) idx[key_at(o[i], 0)].push_back(uint32_t(i));
+  std::vector<std::string> rec;
+  for (size_t i = 0; i < o.size(); ++i) {
+    const std::string& s = o[i];
+    rec.push_back(s);
+    for (size_t j = 1; j < s.size(); ++j) {
+      bool covered = false;
+      size_t rem = s.size() - j;
+      if (rem >= K) {
+        auto it = idx.find(key_at(s, j));
+        if (it != idx.end()) {
+          for (uint32_t c : it->second) {
+            const std::string& t = o[c];
+            if (t.size() >= rem && std::memcmp(t.data(), s.data() + j, rem) == 0) { covered = true; break; }
+          }
+        }
+      }
+      if (covered) break;
+      rec.push_back(s.substr(j));
+    }
+  }
+  if (n_records) *n_records = rec.size();
+  std::sort(rec.begin(), rec.end());
+  dedup_sorted(rec);
+  return rec;
+}
+
+// ------------------------------------------------------------------------------------------
+// Seqset arrays (rows F1, F2) and the walk primitive (row G1).
+struct Seqset {
+  uint64_t n = 0;
+  unsigned max_len = 0;
+  std::vector<uint32_t> sizes, shared;
+  std::vector<uint64_t> bits[4], subaccum[4], accum[4];
+  uint64_t fixed[5] = {0, 0, 0, 0, 0};
+  std::string err;
+
+  // modules/io/bitcount.cpp:84-124 finalize (sizes: :66-78)
+  uint64_t finalize_bitcount(int b) {
+    size_t nw = (n + 63) / 64;
+    bits[b].resize(nw, 0);
+    subaccum[b].assign((n + 511) / 512, 0);
+    accum[b].assign((n + 1 + 511) / 512, 0);
+    if (n == 0) { accum[b].assign(1, 0); return 0; }
+    uint64_t sub = 0, total = 0;
+    for (size_t i = 0; i < nw; ++i) {
+      if (i % 8 == 0) {
+        accum[b][i / 8] = total;
+        if (i != 0) subaccum[b][i / 8 - 1] = sub;
+        sub = 0;
+      }
+      sub <<= 8;
+      uint64_t st = __builtin_popcountll(bits[b][i]);
+      sub |= st;
+      total += st;
+    }
+    size_t left_over = nw % 8;
+    while (left_over != 0) { sub <<= 8; left_over = (left_over + 1) % 8; }
+    subaccum[b][(n + 511) / 512 - 1] = sub;
+    if (n % 512 == 0) accum[b][n / 512] = total;
+    return total;
+  }
+  // modules/bio_base/seqset.cpp:113-129
+  bool finalize() {
+    uint64_t off = 0;
+    for (int b = 0; b < 4; ++b) { fixed[b] = off; off += finalize_bitcount(b); }
+    fixed[4] = off;
+    if (off != n) { err = "Invalid seqset in finalize"; return false; }
+    return true;
+  }
+  // modules/io/bitcount.h:218-270
+  uint64_t count(int b, uint64_t i) const {
+    uint64_t x = (i / 64 < bits[b].size()) ? bits[b][i / 64] : 0;
+    x &= (uint64_t(1) << (i & 63)) - 1;
+    uint64_t bc = __builtin_popcountll(x);
+    size_t group = i / 512, subgroup = (i / 64) & 7;
+    uint64_t sa = (group < subaccum[b].size()) ? subaccum[b][group] : 0;
+    sa >>= 56 - (8 * subgroup);
+    sa &= 0xffffffffffffff00ull;
+    sa = (sa >> 32) + (sa & 0xffffffffull);
+    sa = (sa >> 16) + (sa & 0xffff);
+    sa = (sa >> 8) + (sa & 0xff);
+    return accum[b][group] + sa + bc;
+  }
+  // int_map_interface.cpp:128-197 (semantics only: first pos>=start with shared<v, else n)
+  uint64_t next_forward_lt(uint64_t pos, uint32_t v) const {
+    while (pos < n && shared[pos] >= v) ++pos;
+    return pos;
+  }
+  uint64_t next_backward_lt(uint64_t pos, uint32_t v) const {
+    while (pos > 0 && shared[pos] >= v) --pos;
+    return pos;
+  }
+  struct Range { uint64_t begin, end; uint32_t size; bool valid() const { return begin < end; } };
+  // seqset.cpp:319-338
+  Range push_front(Range r, int b) const {
+    uint64_t nb = fixed[b] + count(b, r.begin), ne = fixed[b] + count(b, r.end);
+    if (nb < ne && sizes[nb] < r.size + 1) nb++;
+    return Range{nb, ne, r.size + 1};
+  }
+  // seqset.cpp:350-429
+  Range push_front_drop(Range r, int b, uint32_t min_ctx) const {
+    uint64_t fx = fixed[b];
+    uint64_t ob = r.begin, oe = r.end;
+    uint32_t octx = r.size;
+    uint64_t sb = count(b, ob), se = count(b, oe);
+    if (octx < min_ctx) return Range{0, 0, 0};
+    while (sb == se || (sb + 1 == se && sizes[fx + sb] < octx + 1)) {
+      uint32_t drop = std::max(shared[ob], (oe == n ? 0u : shared[oe]));
+      if (sb != se) drop = std::max(drop, sizes[fx + sb] - 1);
+      if (drop < min_ctx) return Range{0, 0, 0};
+      bool ub = false, ue = false;
+      if (ob > 0 && shared[ob] >= drop) { ob = next_backward_lt(ob, drop); ub = true; }
+      if (oe < n && shared[oe] >= drop) { oe = next_forward_lt(oe, drop); ue = true; }
+      if (ub) sb = count(b, ob);
+      if (ue) se = count(b, oe);
+      octx = drop;
+    }
+    uint64_t nb = fx + sb, ne = fx + se;
+    if (nb < ne && sizes[nb] < octx + 1) nb++;
+    return Range{nb, ne, octx + 1};
+  }
+  // seqset.cpp:146-155
+  Range find(const std::string& s) const {
+    Range r{0, n, 0};
+    for (size_t i = 0; i < s.size(); ++i) {
+      if (!r.valid()) break;
+      r = push_front(r, base_code(s[s.size() - 1 - i]));
+    }
+    return r;
+  }
+};
+
+static unsigned lcp(const std::string& a, const std::string& b) {
+  size_t m = std::min(a.size(), b.size()), i = 0;
+  while (i < m && a[i] == b[i]) ++i;
+  return unsigned(i);
+}
+
+// builder.cpp:8-164 via the closed form verified in SURVEY row F1: for every entry s set
+// prev_{s[0]}[lower_bound(entries, s[1:])]; the target must have s[1:] as a prefix
+// ("Missing expansion?" builder.cpp:95-96).
+static Seqset* seqset_from_entries(const std::vector<std::string>& e) {
+  auto* ss = new Seqset;
+  ss->n = e.size();
+  ss->sizes.resize(ss->n);
+  ss->shared.resize(ss->n);
+  for (int b = 0; b < 4; ++b) ss->bits[b].assign((ss->n + 63) / 64, 0);
+  for (size_t i = 0; i < e.size(); ++i) {
+    ss->sizes[i] = uint32_t(e[i].size());
+    ss->max_len = std::max<unsigned>(ss->max_len, unsigned(e[i].size()));
+    ss->shared[i] = i ? lcp(e[i - 1], e[i]) : 0;
+  }
+  for (size_t i = 0; i < e.size(); ++i) {
+    std::string tail = e[i].substr(1);
+    size_t t = std::lower_bound(e.begin(), e.end(), tail) - e.begin();
+    if (t >= e.size() || e[t].compare(0, tail.size(), tail) != 0) {
+      ss->err = "Missing expansion: " + e[i];
+      return ss;
+    }
+    int b = base_code(e[i][0]);
+    ss->bits[b][t / 64] |= uint64_t(1) << (t & 63);
+  }
+  ss->finalize();
+  return ss;
+}
+
+// modules/io/packed_varbit_vector.cpp:174-188,80-147: values LSB-first, bits_for_value(max) bits each.
+static unsigned bits_for_value(uint64_t v) { unsigned b = 0; while (v) { ++b; v >>= 1; } return b; }
+static std::vector<uint64_t> pack_varbit(const std::vector<uint32_t>& vals, uint64_t max_value) {
+  unsigned bpv = bits_for_value(max_value);
+  std::vector<uint64_t> out((vals.size() * bpv + 63) / 64, 0);
+  for (size_t i = 0; i < vals.size() && bpv; ++i) {
+    size_t bit = i * bpv;
+    uint64_t v = vals[i];
+    out[bit / 64] |= v << (bit % 64);
+    if (bit % 64 + bpv > 64) out[bit / 64 + 1] |= v >> (64 - bit % 64);
+  }
+  return out;
+}
+
+}  // namespace orc
+
+// ============================================================================================
+// C interface (ctypes).
+using namespace orc;
+
+static std::vector<std::string> split_reads(const char* seq, const uint64_t* offs, uint64_t n) {
+  std::vector<std::string> v(n);
+  for (uint64_t i = 0; i < n; ++i) v[i].assign(seq + offs[i], seq + offs[i + 1]);
+  return v;
+}
+
+extern "C" {
+
+// ---- k-mers
+void* orc_kmer_count(const char* seq, const uint64_t* offs, uint64_t n_reads, int k, uint32_t min_count,
+                     int keep_all) {
+  std::unordered_map<kmer_t, KmerElem> table;
+  if (count_kmers(seq, offs, n_reads, unsigned(k), table) != 0) return nullptr;
+  return make_kmer_set(table, unsigned(k), min_count, keep_all != 0);
+}
+uint64_t orc_kmerset_size(void* h) { return static_cast<KmerSet*>(h)->kmers.size(); }
+void orc_kmerset_get(void* h, uint64_t* kmers, uint8_t* flags, uint32_t* fwd, uint32_t* rev) {
+  auto* ks = static_cast<KmerSet*>(h);
+  size_t n = ks->kmers.size();
+  if (kmers) std::memcpy(kmers, ks->kmers.data(), n * 8);
+  if (flags) std::memcpy(flags, ks->flags.data(), n);
+  if (fwd) std::memcpy(fwd, ks->fwd.data(), n * 4);
+  if (rev) std::memcpy(rev, ks->rev.data(), n * 4);
+}
+void* orc_kmerset_from_arrays(const uint64_t* kmers, const uint8_t* flags, uint64_t n, int k) {
+  auto* ks = new KmerSet;
+  ks->k = unsigned(k);
+  ks->kmers.assign(kmers, kmers + n);
+  ks->flags.assign(flags, flags + n);
+  ks->fwd.assign(n, 0);
+  ks->rev.assign(n, 0);
+  ks->finish();
+  return ks;
+}
+void orc_kmerset_free(void* h) { delete static_cast<KmerSet*>(h); }
+
+// ---- correction.  out_seq must hold offs[n_reads] bytes; out_offs n_reads+1; stats 8 x u64.
+int orc_correct_reads(void* ksh, const char* seq, const uint64_t* offs, uint64_t n_reads,
+                      uint32_t max_corrections, uint32_t min_good_run, float trim_after_portion,
+                      char* out_seq, uint64_t* out_offs, uint8_t* out_keep, uint64_t* stats) {
+  auto* ks = static_cast<KmerSet*>(ksh);
+  FrcParams p;
+  p.max_corrections = max_corrections;
+  p.min_good_run = min_good_run;
+  p.kmer_size = ks->k;
+  p.ks = ks;
+  CorrectStats st;
+  uint64_t pos = 0;
+  for (uint64_t r = 0; r < n_reads; ++r) {
+    out_offs[r] = pos;
+    std::string c;
+    bool ok = correct_read(seq + offs[r], offs[r + 1] - offs[r], p, trim_after_portion, &c, &st);
+    out_keep[r] = ok ? 1 : 0;
+    if (ok) { std::memcpy(out_seq + pos, c.data(), c.size()); pos += c.size(); }
+  }
+  out_offs[n_reads] = pos;
+  if (stats) {
+    stats[0] = st.corrected_reads; stats[1] = st.corrected_bases; stats[2] = st.failed;
+    stats[3] = st.modified; stats[4] = st.modified_bases; stats[5] = st.truncated;
+    stats[6] = st.dropped_bases; stats[7] = st.ref_records;
+  }
+  return 0;
+}
+
+// ---- entries
+struct Entries { std::vector<std::string> e; uint64_t n_records = 0; };
+void* orc_build_entries(const char* seq, const uint64_t* offs, uint64_t n_reads, int mode, int cover_k) {
+  auto reads = split_reads(seq, offs, n_reads);
+  reads.erase(std::remove_if(reads.begin(), reads.end(), [](const std::string& s) { return s.empty(); }),
+              reads.end());
+  auto* en = new Entries;
+  if (mode == 0) {
+    en->e = build_entries_simple(reads);
+    for (auto& r : reads) en->n_records += 2 * r.size();
+  } else {
+    en->e = build_entries_cover(reads, unsigned(cover_k), &en->n_records);
+  }
+  return en;
+}
+void* orc_entries_from_strings(const char* seq, const uint64_t* offs, uint64_t n) {
+  auto* en = new Entries;
+  en->e = split_reads(seq, offs, n);
+  return en;
+}
+uint64_t orc_entries_count(void* h) { return static_cast<Entries*>(h)->e.size(); }
+uint64_t orc_entries_records(void* h) { return static_cast<Entries*>(h)->n_records; }
+uint64_t orc_entries_total_bases(void* h) {
+  uint64_t t = 0;
+  for (auto& s : static_cast<Entries*>(h)->e) t += s.size();
+  return t;
+}
+void orc_entries_get(void* h, char* seq, uint64_t* offs) {
+  auto* en = static_cast<Entries*>(h);
+  uint64_t pos = 0;
+  for (size_t i = 0; i < en->e.size(); ++i) {
+    offs[i] = pos;
+    std::memcpy(seq + pos, en->e[i].data(), en->e[i].size());
+    pos += en->e[i].size();
+  }
+  offs[en->e.size()] = pos;
+}
+void orc_entries_free(void* h) { delete static_cast<Entries*>(h); }
+
+// ---- seqset
+void* orc_seqset_from_entries(void* eh) { return seqset_from_entries(static_cast<Entries*>(eh)->e); }
+// From decoded arrays (golden files): sizes/shared u32[n], bits[b] = ceil(n/64) words each.
+void* orc_seqset_from_arrays(uint64_t n, const uint32_t* sizes, const uint32_t* shared, const uint64_t* bA,
+                             const uint64_t* bC, const uint64_t* bG, const uint64_t* bT) {
+  auto* ss = new Seqset;
+  ss->n = n;
+  ss->sizes.assign(sizes, sizes + n);
+  ss->shared.assign(shared, shared + n);
+  const uint64_t* src[4] = {bA, bC, bG, bT};
+  for (int b = 0; b < 4; ++b) ss->bits[b].assign(src[b], src[b] + (n + 63) / 64);
+  for (uint64_t i = 0; i < n; ++i) ss->max_len = std::max<unsigned>(ss->max_len, sizes[i]);
+  ss->finalize();
+  return ss;
+}
+const char* orc_seqset_error(void* h) {
+  auto* ss = static_cast<Seqset*>(h);
+  return ss->err.empty() ? nullptr : ss->err.c_str();
+}
+uint64_t orc_seqset_size(void* h) { return static_cast<Seqset*>(h)->n; }
+uint32_t orc_seqset_max_len(void* h) { return static_cast<Seqset*>(h)->max_len; }
+void orc_seqset_fixed(void* h, uint64_t* out5) { std::memcpy(out5, static_cast<Seqset*>(h)->fixed, 40); }
+void orc_seqset_arrays(void* h, uint32_t* sizes, uint32_t* shared) {
+  auto* ss = static_cast<Seqset*>(h);
+  std::memcpy(sizes, ss->sizes.data(), ss->n * 4);
+  std::memcpy(shared, ss->shared.data(), ss->n * 4);
+}
+// which: 0 bits, 1 subaccum, 2 accum. Returns word count; copies if out != null.
+uint64_t orc_seqset_prev(void* h, int b, int which, uint64_t* out) {
+  auto* ss = static_cast<Seqset*>(h);
+  auto& v = which == 0 ? ss->bits[b] : which == 1 ? ss->subaccum[b] : ss->accum[b];
+  if (out) std::memcpy(out, v.data(), v.size() * 8);
+  return v.size();
+}
+// which: 0 entry_sizes (max=max_len), 1 shared (max=max_len-1). Returns word count.
+uint64_t orc_seqset_packed(void* h, int which, uint64_t* out) {
+  auto* ss = static_cast<Seqset*>(h);
+  auto v = pack_varbit(which == 0 ? ss->sizes : ss->shared, which == 0 ? ss->max_len : ss->max_len - 1);
+  if (out) std::memcpy(out, v.data(), v.size() * 8);
+  return v.size();
+}
+uint64_t orc_seqset_count(void* h, int b, uint64_t i) { return static_cast<Seqset*>(h)->count(b, i); }
+void orc_seqset_find(void* h, const char* s, uint64_t len, uint64_t* out3) {
+  auto r = static_cast<Seqset*>(h)->find(std::string(s, len));
+  out3[0] = r.begin; out3[1] = r.end; out3[2] = r.size;
+}
+// Batched walk primitives; invalid result = (0,0,0) for push_front_drop (seqset.cpp:366,385).
+void orc_push_front_drop(void* h, uint64_t n, const uint64_t* begin, const uint64_t* end, const uint32_t* size,
+                         const uint8_t* base, const uint32_t* min_ctx, uint64_t* obegin, uint64_t* oend,
+                         uint32_t* osize) {
+  auto* ss = static_cast<Seqset*>(h);
+  for (uint64_t i = 0; i < n; ++i) {
+    auto r = ss->push_front_drop(Seqset::Range{begin[i], end[i], size[i]}, base[i], min_ctx[i]);
+    obegin[i] = r.begin; oend[i] = r.end; osize[i] = r.size;
+  }
+}
+void orc_push_front(void* h, uint64_t n, const uint64_t* begin, const uint64_t* end, const uint32_t* size,
+                    const uint8_t* base, uint64_t* obegin, uint64_t* oend, uint32_t* osize) {
+  auto* ss = static_cast<Seqset*>(h);
+  for (uint64_t i = 0; i < n; ++i) {
+    auto r = ss->push_front(Seqset::Range{begin[i], end[i], size[i]}, base[i]);
+    obegin[i] = r.begin; oend[i] = r.end; osize[i] = r.size;
+  }
+}
+void orc_seqset_free(void* h) { delete static_cast<Seqset*>(h); }
+
+}  // extern "C"

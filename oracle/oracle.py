@@ -1,0 +1,415 @@
+"""ctypes front-end of the CPU oracle (oracle/bg_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  The product package (biograph_amd/) never imports this module.
+
+Also holds the pure-numpy readers used to decode the reference's committed golden `.bg/seqset`
+containers (spiral zip; modules/io/spiral_file_mmap.cpp:372-443) into arrays.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import zipfile
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(_HERE, "libbgoracle.so")
+    src = os.path.join(_HERE, "bg_oracle.cpp")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        build()
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.orc_kmer_count.restype = vp
+    L.orc_kmer_count.argtypes = [u8p, u64p, C.c_uint64, C.c_int, C.c_uint32, C.c_int]
+    L.orc_kmerset_size.restype = C.c_uint64
+    L.orc_kmerset_size.argtypes = [vp]
+    L.orc_kmerset_get.argtypes = [vp, u64p, u8p, u32p, u32p]
+    L.orc_kmerset_from_arrays.restype = vp
+    L.orc_kmerset_from_arrays.argtypes = [u64p, u8p, C.c_uint64, C.c_int]
+    L.orc_kmerset_free.argtypes = [vp]
+    L.orc_correct_reads.restype = C.c_int
+    L.orc_correct_reads.argtypes = [vp, u8p, u64p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, u8p, u64p, u8p,
+                                    u64p]
+    L.orc_build_entries.restype = vp
+    L.orc_build_entries.argtypes = [u8p, u64p, C.c_uint64, C.c_int, C.c_int]
+    L.orc_entries_from_strings.restype = vp
+    L.orc_entries_from_strings.argtypes = [u8p, u64p, C.c_uint64]
+    for f in ("orc_entries_count", "orc_entries_records", "orc_entries_total_bases"):
+        getattr(L, f).restype = C.c_uint64
+        getattr(L, f).argtypes = [vp]
+    L.orc_entries_get.argtypes = [vp, u8p, u64p]
+    L.orc_entries_free.argtypes = [vp]
+    L.orc_seqset_from_entries.restype = vp
+    L.orc_seqset_from_entries.argtypes = [vp]
+    L.orc_seqset_from_arrays.restype = vp
+    L.orc_seqset_from_arrays.argtypes = [C.c_uint64, u32p, u32p, u64p, u64p, u64p, u64p]
+    L.orc_seqset_error.restype = C.c_char_p
+    L.orc_seqset_error.argtypes = [vp]
+    L.orc_seqset_size.restype = C.c_uint64
+    L.orc_seqset_size.argtypes = [vp]
+    L.orc_seqset_max_len.restype = C.c_uint32
+    L.orc_seqset_max_len.argtypes = [vp]
+    L.orc_seqset_fixed.argtypes = [vp, u64p]
+    L.orc_seqset_arrays.argtypes = [vp, u32p, u32p]
+    L.orc_seqset_prev.restype = C.c_uint64
+    L.orc_seqset_prev.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
+    L.orc_seqset_packed.restype = C.c_uint64
+    L.orc_seqset_packed.argtypes = [vp, C.c_int, C.c_void_p]
+    L.orc_seqset_count.restype = C.c_uint64
+    L.orc_seqset_count.argtypes = [vp, C.c_int, C.c_uint64]
+    L.orc_seqset_find.argtypes = [vp, C.c_char_p, C.c_uint64, u64p]
+    L.orc_push_front_drop.argtypes = [vp, C.c_uint64, u64p, u64p, u32p, u8p, u32p, u64p, u64p, u32p]
+    L.orc_push_front.argtypes = [vp, C.c_uint64, u64p, u64p, u32p, u8p, u64p, u64p, u32p]
+    L.orc_seqset_free.argtypes = [vp]
+    _LIB = L
+    return L
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers: reads <-> (concatenated uint8, offsets uint64)
+
+def pack_strings(strs):
+    """list[str|bytes] -> (uint8 concat, uint64 offsets[n+1])."""
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in strs]
+    offs = np.zeros(len(bs) + 1, np.uint64)
+    if bs:
+        offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    seq = np.frombuffer(b"".join(bs), np.uint8).copy() if bs else np.zeros(0, np.uint8)
+    if seq.size == 0:
+        seq = np.zeros(1, np.uint8)[:0].copy()
+    return np.ascontiguousarray(seq), offs
+
+
+def unpack_strings(seq, offs):
+    b = seq.tobytes()
+    return [b[int(offs[i]):int(offs[i + 1])].decode() for i in range(len(offs) - 1)]
+
+
+def read_fastq(path):
+    """Minimal 4-line FASTQ reader -> list[str] of sequences (qualities dropped,
+    modules/build_seqset/read_importer.cpp:22 k_keep_quality_scores=false)."""
+    out = []
+    with open(path, "rb") as f:
+        for i, line in enumerate(f):
+            if i % 4 == 1:
+                out.append(line.strip().decode())
+    return out
+
+
+def _pad(a):
+    return a if a.size else np.zeros(1, a.dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+
+class KmerSet:
+    def __init__(self, h):
+        self.h = h
+
+    @classmethod
+    def count(cls, seq, offs, k=30, min_count=5, keep_all=False):
+        h = lib().orc_kmer_count(_pad(seq), offs, len(offs) - 1, k, min_count, int(keep_all))
+        if not h:
+            raise ValueError("invalid base in reads")
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, kmers, flags, k):
+        return cls(lib().orc_kmerset_from_arrays(_pad(np.ascontiguousarray(kmers, np.uint64)),
+                                                 _pad(np.ascontiguousarray(flags, np.uint8)), len(kmers), k))
+
+    def arrays(self):
+        n = lib().orc_kmerset_size(self.h)
+        k = np.zeros(max(n, 1), np.uint64)
+        fl = np.zeros(max(n, 1), np.uint8)
+        fw = np.zeros(max(n, 1), np.uint32)
+        rv = np.zeros(max(n, 1), np.uint32)
+        lib().orc_kmerset_get(self.h, k, fl, fw, rv)
+        return k[:n], fl[:n], fw[:n], rv[:n]
+
+    def __len__(self):
+        return lib().orc_kmerset_size(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_kmerset_free(self.h)
+            self.h = None
+
+
+STAT_NAMES = ["corrected_reads", "corrected_bases", "failed", "modified", "modified_bases", "truncated",
+              "dropped_bases", "ref_records"]
+
+
+def correct_reads(ks, seq, offs, max_corrections=8, min_good_run=2, trim_after_portion=0.7):
+    """-> (out_seq uint8, out_offs uint64[n+1], keep uint8[n], stats dict)."""
+    n = len(offs) - 1
+    out_seq = np.zeros(max(int(offs[-1]), 1), np.uint8)
+    out_offs = np.zeros(n + 1, np.uint64)
+    keep = np.zeros(max(n, 1), np.uint8)
+    stats = np.zeros(8, np.uint64)
+    lib().orc_correct_reads(ks.h, _pad(seq), offs, n, max_corrections, min_good_run, trim_after_portion, out_seq,
+                            out_offs, keep, stats)
+    return out_seq[:int(out_offs[-1])], out_offs, keep[:n], dict(zip(STAT_NAMES, (int(x) for x in stats)))
+
+
+class Entries:
+    def __init__(self, h):
+        self.h = h
+
+    @classmethod
+    def build(cls, seq, offs, mode="simple", cover_k=30):
+        return cls(lib().orc_build_entries(_pad(seq), offs, len(offs) - 1, 0 if mode == "simple" else 1, cover_k))
+
+    @classmethod
+    def from_strings(cls, strs):
+        seq, offs = pack_strings(strs)
+        return cls(lib().orc_entries_from_strings(_pad(seq), offs, len(strs)))
+
+    def __len__(self):
+        return lib().orc_entries_count(self.h)
+
+    @property
+    def n_records(self):
+        return lib().orc_entries_records(self.h)
+
+    def get(self):
+        n = len(self)
+        seq = np.zeros(max(lib().orc_entries_total_bases(self.h), 1), np.uint8)
+        offs = np.zeros(n + 1, np.uint64)
+        lib().orc_entries_get(self.h, seq, offs)
+        return seq[:int(offs[-1])], offs
+
+    def strings(self):
+        return unpack_strings(*self.get())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_entries_free(self.h)
+            self.h = None
+
+
+class Seqset:
+    """Oracle seqset: arrays + FM navigation (modules/bio_base/seqset.cpp)."""
+
+    def __init__(self, h):
+        self.h = h
+        err = lib().orc_seqset_error(h)
+        if err:
+            raise RuntimeError(err.decode())
+
+    @classmethod
+    def from_entries(cls, entries):
+        return cls(lib().orc_seqset_from_entries(entries.h))
+
+    @classmethod
+    def from_arrays(cls, sizes, shared, bits):
+        n = len(sizes)
+        bb = [_pad(np.ascontiguousarray(b, np.uint64)) for b in bits]
+        return cls(lib().orc_seqset_from_arrays(n, _pad(np.ascontiguousarray(sizes, np.uint32)),
+                                                _pad(np.ascontiguousarray(shared, np.uint32)), *bb))
+
+    def __len__(self):
+        return lib().orc_seqset_size(self.h)
+
+    @property
+    def max_len(self):
+        return lib().orc_seqset_max_len(self.h)
+
+    def fixed(self):
+        out = np.zeros(5, np.uint64)
+        lib().orc_seqset_fixed(self.h, out)
+        return out
+
+    def arrays(self):
+        n = len(self)
+        s = np.zeros(max(n, 1), np.uint32)
+        sh = np.zeros(max(n, 1), np.uint32)
+        lib().orc_seqset_arrays(self.h, s, sh)
+        return s[:n], sh[:n]
+
+    def prev(self, b, which):
+        """which in {'bits','subaccum','accum'} -> uint64 array."""
+        w = {"bits": 0, "subaccum": 1, "accum": 2}[which]
+        n = lib().orc_seqset_prev(self.h, b, w, None)
+        out = np.zeros(max(n, 1), np.uint64)
+        lib().orc_seqset_prev(self.h, b, w, out.ctypes.data)
+        return out[:n]
+
+    def packed(self, which):
+        w = {"entry_sizes": 0, "shared": 1}[which]
+        n = lib().orc_seqset_packed(self.h, w, None)
+        out = np.zeros(max(n, 1), np.uint64)
+        lib().orc_seqset_packed(self.h, w, out.ctypes.data)
+        return out[:n]
+
+    def parts(self):
+        """Payload parts of the spiral container, keyed like the zip member names (format v1.1.0;
+        SURVEY row F3).  file_info.json is never comparable."""
+        n = len(self)
+        p = {"fixed": self.fixed().tobytes(),
+             "seqset.json": json.dumps({"num_entries": n}, separators=(",", ":")).encode(),
+             "entry_sizes/elements": self.packed("entry_sizes").tobytes(),
+             "shared/elements": self.packed("shared").tobytes()}
+        for b, ch in enumerate("ACGT"):
+            for w in ("bits", "subaccum", "accum"):
+                p["prev_%s/%s" % (ch, w)] = self.prev(b, w).tobytes()
+        return p
+
+    def count(self, b, i):
+        return lib().orc_seqset_count(self.h, b, i)
+
+    def find(self, s):
+        out = np.zeros(3, np.uint64)
+        lib().orc_seqset_find(self.h, s.encode(), len(s), out)
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def push_front_drop(self, begin, end, size, base, min_ctx):
+        n = len(begin)
+        ob = np.zeros(max(n, 1), np.uint64)
+        oe = np.zeros(max(n, 1), np.uint64)
+        osz = np.zeros(max(n, 1), np.uint32)
+        lib().orc_push_front_drop(self.h, n, _pad(np.ascontiguousarray(begin, np.uint64)),
+                                  _pad(np.ascontiguousarray(end, np.uint64)),
+                                  _pad(np.ascontiguousarray(size, np.uint32)),
+                                  _pad(np.ascontiguousarray(base, np.uint8)),
+                                  _pad(np.ascontiguousarray(min_ctx, np.uint32)), ob, oe, osz)
+        return ob[:n], oe[:n], osz[:n]
+
+    def push_front(self, begin, end, size, base):
+        n = len(begin)
+        ob = np.zeros(max(n, 1), np.uint64)
+        oe = np.zeros(max(n, 1), np.uint64)
+        osz = np.zeros(max(n, 1), np.uint32)
+        lib().orc_push_front(self.h, n, _pad(np.ascontiguousarray(begin, np.uint64)),
+                             _pad(np.ascontiguousarray(end, np.uint64)), _pad(np.ascontiguousarray(size, np.uint32)),
+                             _pad(np.ascontiguousarray(base, np.uint8)), ob, oe, osz)
+        return ob[:n], oe[:n], osz[:n]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_seqset_free(self.h)
+            self.h = None
+
+
+def build_seqset_from_fastq_reads(reads, k=30, min_count=5, max_corrections=8, min_good_run=2,
+                                  trim_after_portion=0.7, mode="simple"):
+    """Whole create path on the CPU: count -> filter -> correct -> entries -> arrays.
+    Returns (Seqset, Entries, info dict)."""
+    seq, offs = pack_strings(reads)
+    ks = KmerSet.count(seq, offs, k, min_count)
+    cseq, coffs, keep, stats = correct_reads(ks, seq, offs, max_corrections, min_good_run, trim_after_portion)
+    ent = Entries.build(cseq, coffs, mode, k)
+    ss = Seqset.from_entries(ent)
+    info = dict(stats)
+    info["kept_kmers"] = len(ks)
+    info["n_records"] = ent.n_records
+    info["entries"] = len(ent)
+    return ss, ent, info
+
+
+# ------------------------------------------------------------------------------------------------
+# Golden container decoding (numpy only).
+
+def unpack_varbit(buf, n, bits):
+    """modules/io/packed_varbit_vector.cpp:42-78 get(): LSB-first bit-packed ints."""
+    if bits == 0:
+        return np.zeros(n, np.uint32)
+    raw = np.frombuffer(buf, np.uint8)
+    allbits = np.unpackbits(raw, bitorder="little")[: n * bits].reshape(n, bits)
+    w = (1 << np.arange(bits, dtype=np.uint64))
+    return (allbits.astype(np.uint64) * w).sum(axis=1).astype(np.uint32)
+
+
+def read_spiral_members(path):
+    """Member name -> bytes of a spiral zip.  Members written through the mmap path carry CRC 0
+    (spiral_file_mmap.cpp:429), so the CRC check of zipfile.read() must be bypassed: payloads are
+    read straight from behind their local headers (method 0 = stored)."""
+    import struct
+    out = {}
+    with open(path, "rb") as f:
+        data = f.read()
+    for zi in zipfile.ZipFile(path).infolist():
+        o = zi.header_offset
+        assert data[o:o + 4] == b"PK\x03\x04" and zi.compress_type == 0
+        nlen, elen = struct.unpack("<HH", data[o + 26:o + 30])
+        start = o + 30 + nlen + elen
+        out[zi.filename] = data[start:start + zi.file_size]
+    return out
+
+
+def load_seqset_zip(path):
+    """Decode a reference-written `seqset` file (either container generation) into a dict of
+    arrays: n, sizes, shared, bits[4], subaccum[4], accum[4], fixed, raw (member bytes)."""
+    raw = read_spiral_members(path)
+    names = set(raw)
+    n = json.loads(raw["seqset.json"])["num_entries"]
+    out = {"n": n, "raw": raw, "fixed": np.frombuffer(raw["fixed"], np.uint64).copy()}
+    for key in ("entry_sizes", "shared"):
+        if key in names:  # old layout: raw uint8 (int_map_interface.cpp detect_subpart_or_uint8_membuf)
+            out["sizes" if key == "entry_sizes" else "shared"] = np.frombuffer(raw[key], np.uint8).astype(np.uint32)
+        else:
+            md = json.loads(raw[key + "/packed_varbit_vector.json"])
+            arr = unpack_varbit(raw[key + "/elements"], md["element_count"], md["bits_per_value"])
+            out["sizes" if key == "entry_sizes" else "shared"] = arr
+            out[key + "_meta"] = md
+    for w in ("bits", "subaccum", "accum"):
+        out[w] = [np.frombuffer(raw["prev_%s/%s" % (ch, w)], np.uint64).copy() for ch in "ACGT"]
+    return out
+
+
+def decode_entries(d):
+    """Reconstruct every entry string of a decoded seqset by FM walking (pop_front = select on
+    prev_b; modules/bio_base/seqset.cpp:274-311 populate_pop_front_cache)."""
+    n = d["n"]
+    pf = np.zeros(n, np.int64)  # pop_front target of each entry
+    first = np.zeros(n, np.uint8)
+    pos = 0
+    for b in range(4):
+        bits = np.unpackbits(d["bits"][b].view(np.uint8), bitorder="little")[:n]
+        tgt = np.flatnonzero(bits)
+        pf[pos:pos + len(tgt)] = tgt
+        first[pos:pos + len(tgt)] = b
+        pos += len(tgt)
+    assert pos == n
+    sizes = d["sizes"].astype(np.int64)
+    maxlen = int(sizes.max()) if n else 0
+    chars = np.zeros((n, maxlen), np.uint8)
+    cur = np.arange(n)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    for j in range(maxlen):
+        chars[:, j] = letters[first[cur]]
+        cur = pf[cur]
+    return [chars[i, :sizes[i]].tobytes().decode() for i in range(n)]
+
+
+# dna_testutil.cpp:14-33 — tseq("abc"): each char -> 'C' + 8 x {A,T by bit} + 'C'.
+def tseq(s):
+    out = []
+    for c in s.encode():
+        out.append("C" + "".join("T" if (c >> i) & 1 else "A" for i in range(8)) + "C")
+    return "".join(out)
+
+
+def revcomp(s):
+    return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def tseq_rc(s):
+    return revcomp(tseq(s))
