@@ -1,0 +1,410 @@
+"""biograph_amd — MI355X-native seqset construction and overlap walk (BioGraph hot path).
+
+Host-side mirror of the reference's seams for this path:
+
+  * `Context.create(...)`            ~ `bgbinary create` data path (SEQSETMain::run,
+                                       modules/biograph/biograph_create.cpp:431-783)
+  * `Context.pack_reads/kmer_count/correct_reads/build_seqset`
+                                     ~ read_importer / kmerizer::run / correct_reads::correct /
+                                       expander+builder (modules/build_seqset/*)
+  * `Seqset`, `SeqsetEntry`          ~ `biograph.Seqset` / `biograph.SeqsetEntry`
+                                       (python/biograph/seqset.cpp:46-183)
+
+Everything computes through libbgseq.so (HIP, gfx950).  No CPU fallback exists.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import BgError, BuildStats, CorrectParams, CorrectStats, CreateParams  # noqa: F401
+
+__all__ = ["Context", "Reads", "KmerSet", "Seqset", "SeqsetEntry", "BgError"]
+
+
+def _pack_strings(strs):
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in strs]
+    offs = np.zeros(len(bs) + 1, np.uint64)
+    if bs:
+        offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    seq = np.frombuffer(b"".join(bs), np.uint8).copy() if bs else np.zeros(0, np.uint8)
+    return seq, offs
+
+
+def _buf(a):
+    """ctypes pointer of a numpy array (a 1-element dummy when empty)."""
+    if a.size == 0:
+        a = np.zeros(1, a.dtype)
+    return a, capi.np_ptr(a)
+
+
+class DeviceArray:
+    """hipMalloc'ed buffer owned through the C ABI (for hosts without their own allocator)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        capi.check(capi.lib().bg_dev_alloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, ctx, a):
+        a = np.ascontiguousarray(a)
+        d = cls(ctx, a.nbytes)
+        if a.nbytes:
+            capi.check(capi.lib().bg_dev_upload(ctx.h, d.ptr, capi.np_ptr(a), a.nbytes))
+        return d
+
+    def to_numpy(self, dtype, count):
+        out = np.zeros(count, dtype)
+        if out.nbytes:
+            capi.check(capi.lib().bg_dev_download(self.ctx.h, capi.np_ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            capi.lib().bg_dev_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU + one HIP stream (bg_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        capi.check(capi.lib().bg_ctx_create(int(device), C.c_void_p(stream or 0), C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            capi.lib().bg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def trim(self):
+        capi.check(capi.lib().bg_ctx_trim(self.h))
+
+    def set_profiling(self, on=True):
+        capi.check(capi.lib().bg_ctx_set_profiling(self.h, int(bool(on))))
+
+    def timings(self):
+        n = capi.lib().bg_ctx_timings(self.h, None, 0)
+        arr = (capi.Timing * max(n, 1))()
+        n = capi.lib().bg_ctx_timings(self.h, arr, n)
+        return [{"name": arr[i].name.decode(), "ms": arr[i].ms, "launches": int(arr[i].launches),
+                 "bytes": int(arr[i].bytes)} for i in range(n)]
+
+    # ---- staged build -------------------------------------------------------------------------
+    def pack_reads(self, reads):
+        """reads: list of str, or (uint8 concat, uint64 offsets) host arrays."""
+        seq, offs = _pack_strings(reads) if isinstance(reads, (list, tuple)) and (
+            not reads or isinstance(reads[0], (str, bytes))) else reads
+        seq = np.ascontiguousarray(seq, np.uint8)
+        offs = np.ascontiguousarray(offs, np.uint64)
+        h = C.c_void_p()
+        _s, ps = _buf(seq)
+        capi.check(capi.lib().bg_pack_reads_host(self.h, ps, capi.np_ptr(offs), len(offs) - 1, C.byref(h)))
+        return Reads(self, h)
+
+    def pack_reads_device(self, d_seq, d_offs, n_reads):
+        h = C.c_void_p()
+        capi.check(capi.lib().bg_pack_reads(self.h, C.c_void_p(d_seq), C.c_void_p(d_offs), n_reads, C.byref(h)))
+        return Reads(self, h)
+
+    def kmer_count(self, reads, k=30, min_count=5):
+        h = C.c_void_p()
+        capi.check(capi.lib().bg_kmer_count(self.h, reads.h, k, min_count, C.byref(h)))
+        return KmerSet(self, h, k)
+
+    def correct_reads(self, reads, kmerset, max_corrections=8, min_good_run=2, trim_after_portion=0.7):
+        p = CorrectParams(max_corrections, min_good_run, trim_after_portion)
+        st = CorrectStats()
+        h = C.c_void_p()
+        capi.check(capi.lib().bg_correct_reads(self.h, reads.h, kmerset.h, C.byref(p), C.byref(h), C.byref(st)))
+        return Reads(self, h), {n: int(getattr(st, n)) for n, _ in st._fields_}
+
+    def build_seqset(self, corrected, cover_k=30):
+        st = BuildStats()
+        h = C.c_void_p()
+        capi.check(capi.lib().bg_seqset_build(self.h, corrected.h, cover_k, C.byref(h), C.byref(st)))
+        return Seqset(self, h), st.as_dict()
+
+    # ---- whole create path --------------------------------------------------------------------
+    def default_params(self, **kw):
+        p = CreateParams()
+        capi.lib().bg_create_params_default(C.byref(p))
+        for k, v in kw.items():
+            if k in ("max_corrections", "min_good_run", "trim_after_portion"):
+                setattr(p.correct, k, v)
+            else:
+                setattr(p, k, v)
+        return p
+
+    def create_device(self, d_seq, d_offs, n_reads, params=None):
+        """Whole create data path on device-resident ASCII reads (device pointers as ints)."""
+        p = params or self.default_params()
+        st = BuildStats()
+        h = C.c_void_p()
+        capi.check(capi.lib().bg_create(self.h, C.c_void_p(d_seq), C.c_void_p(d_offs), n_reads, C.byref(p),
+                                        C.byref(h), C.byref(st)))
+        return Seqset(self, h), st.as_dict()
+
+    def create(self, reads, **kw):
+        """reads: list of str (host).  Returns (Seqset, stats)."""
+        seq, offs = _pack_strings(reads)
+        dseq = DeviceArray.from_numpy(self, seq)
+        doffs = DeviceArray.from_numpy(self, offs)
+        try:
+            return self.create_device(dseq.ptr, doffs.ptr, len(reads), self.default_params(**kw))
+        finally:
+            dseq.free()
+            doffs.free()
+
+    def open_seqset(self, path):
+        h = C.c_void_p()
+        capi.check(capi.lib().bg_seqset_open(self.h, str(path).encode(), C.byref(h)))
+        return Seqset(self, h)
+
+    def seqset_from_arrays(self, sizes, shared, bits):
+        sizes = np.ascontiguousarray(sizes, np.uint32)
+        shared = np.ascontiguousarray(shared, np.uint32)
+        bb = [_buf(np.ascontiguousarray(b, np.uint64)) for b in bits]
+        arr = (C.c_void_p * 4)(*[p for _, p in bb])
+        h = C.c_void_p()
+        _a, ps = _buf(sizes)
+        _b, psh = _buf(shared)
+        capi.check(capi.lib().bg_seqset_from_arrays(self.h, len(sizes), ps, psh, arr, C.byref(h)))
+        return Seqset(self, h)
+
+
+class _Handle:
+    _free = None
+
+    def __init__(self, ctx, h):
+        self.ctx = ctx
+        self.h = h
+
+    def free(self):
+        if self.h:
+            getattr(capi.lib(), self._free)(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Reads(_Handle):
+    _free = "bg_reads_free"
+
+    def __len__(self):
+        return capi.lib().bg_reads_count(self.h)
+
+    @property
+    def total_bases(self):
+        return capi.lib().bg_reads_total_bases(self.h)
+
+    @property
+    def max_len(self):
+        return capi.lib().bg_reads_max_len(self.h)
+
+    def download(self):
+        """-> (uint8 ASCII concat, uint64 offsets); dropped reads have length 0."""
+        n = len(self)
+        offs = np.zeros(n + 1, np.uint64)
+        seq = np.zeros(max(int(self.total_bases), 1), np.uint8)
+        capi.check(capi.lib().bg_reads_download(self.ctx.h, self.h, capi.np_ptr(seq), capi.np_ptr(offs)))
+        return seq[:int(offs[-1])], offs
+
+
+class KmerSet(_Handle):
+    _free = "bg_kmerset_free"
+
+    def __init__(self, ctx, h, k):
+        super().__init__(ctx, h)
+        self.k = k
+
+    def __len__(self):
+        return capi.lib().bg_kmerset_size(self.h)
+
+    @property
+    def distinct(self):
+        return capi.lib().bg_kmerset_distinct(self.h)
+
+    @property
+    def instances(self):
+        return capi.lib().bg_kmerset_instances(self.h)
+
+    def download(self):
+        """-> (sorted canonical kmers u64, flags u8, total counts u32)."""
+        n = len(self)
+        k = np.zeros(max(n, 1), np.uint64)
+        f = np.zeros(max(n, 1), np.uint8)
+        c = np.zeros(max(n, 1), np.uint32)
+        capi.check(capi.lib().bg_kmerset_download(self.ctx.h, self.h, capi.np_ptr(k), capi.np_ptr(f), capi.np_ptr(c)))
+        return k[:n], f[:n], c[:n]
+
+
+PART_NAMES = ["fixed", "entry_sizes/elements", "shared/elements"] + [
+    "prev_%s/%s" % (b, w) for b in "ACGT" for w in ("bits", "subaccum", "accum")]
+
+
+class Seqset(_Handle):
+    """Resident seqset (modules/bio_base/seqset.h:35-128)."""
+    _free = "bg_seqset_free"
+
+    def size(self):
+        return capi.lib().bg_seqset_size(self.h)
+
+    __len__ = size
+
+    @property
+    def max_len(self):
+        return capi.lib().bg_seqset_max_len(self.h)
+
+    def part(self, name):
+        sz = C.c_uint64(0)
+        capi.check(capi.lib().bg_seqset_part(self.ctx.h, self.h, name.encode(), None, C.byref(sz)))
+        buf = np.zeros(max(sz.value, 1), np.uint8)
+        capi.check(capi.lib().bg_seqset_part(self.ctx.h, self.h, name.encode(), capi.np_ptr(buf), C.byref(sz)))
+        return buf[:sz.value].tobytes()
+
+    def parts(self):
+        """Payload parts keyed like the spiral zip members (everything but the JSON members)."""
+        return {n: self.part(n) for n in PART_NAMES}
+
+    def arrays(self):
+        n = self.size()
+        s = np.zeros(max(n, 1), np.uint32)
+        sh = np.zeros(max(n, 1), np.uint32)
+        capi.check(capi.lib().bg_seqset_arrays(self.ctx.h, self.h, capi.np_ptr(s), capi.np_ptr(sh)))
+        return s[:n], sh[:n]
+
+    def entries(self, first=0, count=None):
+        """Entry sequences as list of str."""
+        n = self.size()
+        count = n - first if count is None else count
+        offs = np.zeros(count + 1, np.uint64)
+        capi.check(capi.lib().bg_seqset_entries(self.ctx.h, self.h, first, count, None, capi.np_ptr(offs)))
+        seq = np.zeros(max(int(offs[-1]), 1), np.uint8)
+        capi.check(capi.lib().bg_seqset_entries(self.ctx.h, self.h, first, count, capi.np_ptr(seq), capi.np_ptr(offs)))
+        b = seq.tobytes()
+        return [b[int(offs[i]):int(offs[i + 1])].decode() for i in range(count)]
+
+    def write(self, path, argv=()):
+        arr = (C.c_char_p * max(len(argv), 1))(*[a.encode() for a in argv])
+        capi.check(capi.lib().bg_seqset_write(self.ctx.h, self.h, str(path).encode(), len(argv), arr))
+
+    # ---- batched walk (host numpy in/out; the C ABI itself takes device pointers) ---------------
+    def _walk(self, fn, begin, end, size, base, min_ctx=None):
+        ctx = self.ctx
+        n = len(begin)
+        ins = [DeviceArray.from_numpy(ctx, np.ascontiguousarray(begin, np.uint64)),
+               DeviceArray.from_numpy(ctx, np.ascontiguousarray(end, np.uint64)),
+               DeviceArray.from_numpy(ctx, np.ascontiguousarray(size, np.uint32)),
+               DeviceArray.from_numpy(ctx, np.ascontiguousarray(base, np.uint8))]
+        if min_ctx is not None:
+            ins.append(DeviceArray.from_numpy(ctx, np.ascontiguousarray(min_ctx, np.uint32)))
+        outs = [DeviceArray(ctx, n * 8), DeviceArray(ctx, n * 8), DeviceArray(ctx, n * 4)]
+        try:
+            capi.check(fn(ctx.h, self.h, n, *[C.c_void_p(a.ptr) for a in ins + outs]))
+            return (outs[0].to_numpy(np.uint64, n), outs[1].to_numpy(np.uint64, n), outs[2].to_numpy(np.uint32, n))
+        finally:
+            for a in ins + outs:
+                a.free()
+
+    def push_front_batch(self, begin, end, size, base):
+        return self._walk(capi.lib().bg_push_front_batch, begin, end, size, base)
+
+    def push_front_drop_batch(self, begin, end, size, base, min_ctx):
+        return self._walk(capi.lib().bg_push_front_drop_batch, begin, end, size, base, min_ctx)
+
+    def find_batch(self, seqs):
+        seq, offs = _pack_strings(seqs)
+        ctx = self.ctx
+        n = len(seqs)
+        dseq = DeviceArray.from_numpy(ctx, seq)
+        doffs = DeviceArray.from_numpy(ctx, offs)
+        ob, oe = DeviceArray(ctx, n * 8), DeviceArray(ctx, n * 8)
+        try:
+            capi.check(capi.lib().bg_find_batch(ctx.h, self.h, n, C.c_void_p(dseq.ptr), C.c_void_p(doffs.ptr),
+                                                C.c_void_p(ob.ptr), C.c_void_p(oe.ptr)))
+            return ob.to_numpy(np.uint64, n), oe.to_numpy(np.uint64, n)
+        finally:
+            for a in (dseq, doffs, ob, oe):
+                a.free()
+
+    # ---- SDK surface of python/biograph/seqset.cpp:46-160 -------------------------------------
+    def empty_entry(self):
+        return SeqsetEntry(self, 0, self.size(), 0)
+
+    def find(self, seq):
+        seq = str(seq)
+        b, e = self.find_batch([seq])
+        return SeqsetEntry(self, int(b[0]), int(e[0]), len(seq)) if e[0] > b[0] else None
+
+    def get_entry_by_id(self, i):
+        if i < 0:
+            raise TypeError("entry id must be non-negative")
+        if i >= self.size():
+            raise RuntimeError("entry id out of range")
+        s, _ = self.arrays()
+        return SeqsetEntry(self, i, i + 1, int(s[i]))
+
+
+_B = {"A": 0, "C": 1, "G": 2, "T": 3}
+
+
+class SeqsetEntry:
+    """A seqset range (seqset_range, bio_base/seqset.h:207-334); invalid results are None
+    (valid_or_none, python/biograph/seqset.cpp:20-42)."""
+
+    def __init__(self, ss, begin, end, size):
+        self.ss, self.begin, self.end, self.size = ss, begin, end, size
+
+    def __len__(self):
+        return self.size
+
+    def __eq__(self, o):
+        return isinstance(o, SeqsetEntry) and (self.begin, self.end, self.size) == (o.begin, o.end, o.size)
+
+    def get_begin_entry_id(self):
+        return self.begin
+
+    def get_end_entry_id(self):
+        return self.end
+
+    def sequence(self, n=None):
+        s = self.ss.entries(self.begin, 1)[0][:self.size] if self.end > self.begin else ""
+        return s if n is None else s[:n]
+
+    def __repr__(self):
+        return "<SeqsetEntry %d-%d: %s>" % (self.begin, self.end, self.sequence())
+
+    def push_front(self, base):
+        b, e, s = self.ss.push_front_batch([self.begin], [self.end], [self.size], [_B[base]])
+        return SeqsetEntry(self.ss, int(b[0]), int(e[0]), int(s[0])) if e[0] > b[0] else None
+
+    def push_front_drop(self, base, min_ctx=0):
+        b, e, s = self.ss.push_front_drop_batch([self.begin], [self.end], [self.size], [_B[base]], [min_ctx])
+        return SeqsetEntry(self.ss, int(b[0]), int(e[0]), int(s[0])) if e[0] > b[0] else None
+
+    def truncate(self, n):
+        if n >= self.size:
+            return self
+        return self.ss.find(self.sequence()[:n])

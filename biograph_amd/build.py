@@ -1,0 +1,69 @@
+"""Builds libbgseq.so (HIP kernels + C ABI) for gfx950 in-tree with hipcc.
+
+    python -m biograph_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  Objects and the shared library stay inside the package
+directory (git-ignored, but shipped to the GPU box by gpurun).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "obj")
+LIB = os.path.join(HERE, "libbgseq.so")
+SOURCES = ["prims.hip", "build_kmer.hip", "build_seqset.hip", "walk.hip", "api.hip", "spiral_zip.cpp"]
+HEADERS = ["bg_internal.h", "bg_device_funcs.h", "compact.h", os.path.join("..", "..", "include", "bgseq.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result",
+         "-x", "hip"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    jobs = []
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([_hipcc()] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stdout))
+        return r.stdout
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        outs = list(ex.map(run, jobs))
+    if verbose:
+        for o in outs:
+            if o.strip():
+                print(o)
+    if jobs or force or _stale(LIB, objs):
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,128 @@
+"""ctypes binding of libbgseq.so (include/bgseq.h).
+
+The library is the product: HIP kernels for gfx950 behind a C ABI.  There is no CPU fallback — if
+the shared library is missing, or no HIP device is usable, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbgseq.so")
+_lib = None
+
+BG_OK = 0
+ERRORS = {-1: "BG_EINVAL", -2: "BG_ENODEV", -3: "BG_ENOMEM", -4: "BG_EBADBASE", -5: "BG_EIO", -6: "BG_EINTERNAL"}
+
+
+class BgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (ERRORS.get(code, code), msg))
+        self.code = code
+
+
+class Timing(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("launches", C.c_uint64), ("bytes", C.c_uint64)]
+
+
+class CorrectParams(C.Structure):
+    _fields_ = [("max_corrections", C.c_uint32), ("min_good_run", C.c_uint32), ("trim_after_portion", C.c_float)]
+
+
+class CorrectStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("corrected_reads", "corrected_bases", "failed", "modified",
+                                          "modified_bases", "truncated", "dropped_bases")]
+
+
+class BuildStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_reads", "n_bases", "n_kmers", "n_distinct_kmers", "n_kept_kmers",
+                                          "n_corrected_reads", "n_corrected_bases", "n_records", "n_tied_records",
+                                          "n_entries")] + [("max_len", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class CreateParams(C.Structure):
+    _fields_ = [("kmer_size", C.c_int), ("min_kmer_count", C.c_uint32), ("correct", CorrectParams)]
+
+
+# every symbol include/bgseq.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "bg_abi_version", "bg_last_error", "bg_ctx_create", "bg_ctx_destroy", "bg_ctx_trim", "bg_ctx_timings",
+    "bg_ctx_set_profiling", "bg_pack_reads", "bg_pack_reads_host", "bg_reads_count", "bg_reads_total_bases",
+    "bg_reads_max_len", "bg_reads_download", "bg_reads_free", "bg_kmer_count", "bg_kmerset_size",
+    "bg_kmerset_distinct", "bg_kmerset_instances", "bg_kmerset_download", "bg_kmerset_free", "bg_correct_reads",
+    "bg_seqset_build", "bg_create_params_default", "bg_create", "bg_seqset_size", "bg_seqset_max_len",
+    "bg_seqset_part", "bg_seqset_arrays", "bg_seqset_entries", "bg_seqset_write", "bg_seqset_open",
+    "bg_seqset_from_arrays", "bg_seqset_free", "bg_push_front_batch", "bg_push_front_drop_batch", "bg_find_batch",
+    "bg_dev_alloc", "bg_dev_free", "bg_dev_upload", "bg_dev_download",
+]
+
+
+def lib():
+    """Loads libbgseq.so (building it is `python -m biograph_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("biograph_amd: %s is missing — build it with `python -m biograph_amd.build` "
+                          "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    P = C.POINTER
+    L.bg_abi_version.restype = i32
+    L.bg_last_error.restype = C.c_char_p
+    L.bg_ctx_create.argtypes = [i32, vp, P(vp)]
+    L.bg_ctx_destroy.argtypes = [vp]
+    L.bg_ctx_destroy.restype = None
+    L.bg_ctx_trim.argtypes = [vp]
+    L.bg_ctx_timings.argtypes = [vp, P(Timing), i32]
+    L.bg_ctx_set_profiling.argtypes = [vp, i32]
+    L.bg_pack_reads.argtypes = [vp, vp, vp, u64, P(vp)]
+    L.bg_pack_reads_host.argtypes = [vp, vp, vp, u64, P(vp)]
+    for f in ("bg_reads_count", "bg_reads_total_bases", "bg_kmerset_size", "bg_kmerset_distinct",
+              "bg_kmerset_instances", "bg_seqset_size"):
+        getattr(L, f).restype = u64
+        getattr(L, f).argtypes = [vp]
+    L.bg_reads_max_len.restype = u32
+    L.bg_reads_max_len.argtypes = [vp]
+    L.bg_seqset_max_len.restype = u32
+    L.bg_seqset_max_len.argtypes = [vp]
+    L.bg_reads_download.argtypes = [vp, vp, vp, vp]
+    for f in ("bg_reads_free", "bg_kmerset_free", "bg_seqset_free"):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = None
+    L.bg_kmer_count.argtypes = [vp, vp, i32, u32, P(vp)]
+    L.bg_kmerset_download.argtypes = [vp, vp, vp, vp, vp]
+    L.bg_correct_reads.argtypes = [vp, vp, vp, P(CorrectParams), P(vp), P(CorrectStats)]
+    L.bg_seqset_build.argtypes = [vp, vp, i32, P(vp), P(BuildStats)]
+    L.bg_create_params_default.argtypes = [P(CreateParams)]
+    L.bg_create_params_default.restype = None
+    L.bg_create.argtypes = [vp, vp, vp, u64, P(CreateParams), P(vp), P(BuildStats)]
+    L.bg_seqset_part.argtypes = [vp, vp, C.c_char_p, vp, P(u64)]
+    L.bg_seqset_arrays.argtypes = [vp, vp, vp, vp]
+    L.bg_seqset_entries.argtypes = [vp, vp, u64, u64, vp, vp]
+    L.bg_seqset_write.argtypes = [vp, vp, C.c_char_p, i32, P(C.c_char_p)]
+    L.bg_seqset_open.argtypes = [vp, C.c_char_p, P(vp)]
+    L.bg_seqset_from_arrays.argtypes = [vp, u64, vp, vp, P(vp), P(vp)]
+    L.bg_push_front_batch.argtypes = [vp, vp, u64, vp, vp, vp, vp, vp, vp, vp]
+    L.bg_push_front_drop_batch.argtypes = [vp, vp, u64, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.bg_find_batch.argtypes = [vp, vp, u64, vp, vp, vp, vp]
+    L.bg_dev_alloc.argtypes = [vp, u64, P(vp)]
+    L.bg_dev_free.argtypes = [vp, vp]
+    L.bg_dev_upload.argtypes = [vp, vp, vp, u64]
+    L.bg_dev_download.argtypes = [vp, vp, vp, u64]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != BG_OK:
+        msg = lib().bg_last_error()
+        raise BgError(rc, msg.decode() if msg else "")
+
+
+def np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)

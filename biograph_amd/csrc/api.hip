@@ -1,0 +1,541 @@
+// api.hip — context, seqset object (parts, container I/O) and the whole-create entry point of the
+// C ABI declared in include/bgseq.h.
+#include <string.h>
+#include <time.h>
+
+#include "bg_device_funcs.h"
+#include "bg_internal.h"
+
+namespace bg {
+const char* last_error_cstr();
+
+// packed_varbit_vector layout (io/packed_varbit_vector.cpp:80-147): value i occupies bits
+// [i*bpv, (i+1)*bpv) of a little-endian bit string stored as uint64 words.  One thread per word.
+__global__ void k_pack_varbit(const uint8_t* __restrict__ vals, uint64_t n, int bpv, uint64_t nwords,
+                              uint64_t* __restrict__ out) {
+  uint64_t w = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  uint64_t bit_lo = w * 64, bit_hi = bit_lo + 64;
+  uint64_t first = bit_lo / bpv;
+  uint64_t word = 0;
+  for (uint64_t i = first; i < n; ++i) {
+    uint64_t b = i * bpv;
+    if (b >= bit_hi) break;
+    uint64_t v = vals[i];
+    if (b >= bit_lo) word |= v << (b - bit_lo);
+    else word |= v >> (bit_lo - b);
+  }
+  out[w] = word;
+}
+
+__global__ void k_unpack_varbit(const uint64_t* __restrict__ words, uint64_t n, int bpv, uint8_t* __restrict__ vals) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (bpv == 0) { vals[i] = 0; return; }
+  uint64_t b = i * bpv;
+  uint64_t v = words[b >> 6] >> (b & 63);
+  if ((b & 63) + bpv > 64) v |= words[(b >> 6) + 1] << (64 - (b & 63));
+  vals[i] = uint8_t(v & ((1ull << bpv) - 1));
+}
+
+__global__ void k_u8_to_u32(const uint8_t* __restrict__ a, uint64_t n, uint32_t* __restrict__ out) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i];
+}
+__global__ void k_u32_to_u8(const uint32_t* __restrict__ a, uint64_t n, uint8_t* __restrict__ out) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = uint8_t(a[i]);
+}
+
+// entry sequences by FM navigation is the reference's way (seqset.cpp:609-721); after a build the
+// keys are resident, so this simply unpacks them.
+__global__ void k_entries_ascii(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ sizes, uint64_t first,
+                                uint64_t count, int W, const uint64_t* __restrict__ offs, uint8_t* __restrict__ seq) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  uint64_t e = first + i;
+  int L = sizes[e];
+  uint8_t* p = seq + offs[i];
+  for (int j = 0; j < L; ++j) p[j] = "ACGT"[read_code(keys + e * W, j)];
+}
+
+// Without resident keys (seqset opened from a file): walk pop_front by select on prev_b.  One thread
+// per entry; select = binary search over accum + word scan.  Used by tests / SDK only.
+__global__ void k_entries_ascii_fm(SeqsetView v, uint64_t first, uint64_t count, const uint64_t* __restrict__ offs,
+                                   uint8_t* __restrict__ seq) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  uint64_t cur = first + i;
+  int L = v.sizes[cur];
+  uint8_t* p = seq + offs[i];
+  for (int j = 0; j < L; ++j) {
+    int b = 0;
+    while (b < 3 && cur >= v.fixed[b + 1]) ++b;
+    p[j] = "ACGT"[b];
+    uint64_t rank = cur - v.fixed[b];  // the (rank)-th set bit of prev_b is the pop_front target
+    uint64_t lo = 0, hi = v.n;         // smallest t with count(b, t+1) > rank
+    while (lo < hi) {
+      uint64_t mid = (lo + hi) >> 1;
+      if (v.count(b, mid + 1) > rank) hi = mid; else lo = mid + 1;
+    }
+    cur = lo;
+  }
+}
+
+static unsigned bits_for_value(uint64_t v) { unsigned b = 0; while (v) { ++b; v >>= 1; } return b; }
+
+static SeqsetView view_of(const bg_seqset* ss) {
+  SeqsetView v;
+  v.n = ss->n;
+  v.sizes = ss->sizes.p;
+  v.shared = ss->shared.p;
+  for (int b = 0; b < 4; ++b) { v.bits[b] = ss->bits[b].p; v.subaccum[b] = ss->subaccum[b].p; v.accum[b] = ss->accum[b].p; }
+  for (int b = 0; b < 5; ++b) v.fixed[b] = ss->fixed[b];
+  v.min1 = ss->min1.p;
+  v.min2 = ss->min2.p;
+  return v;
+}
+
+static int download(bg_ctx* ctx, void* h, const void* d, uint64_t bytes) {
+  if (!bytes) return BG_OK;
+  BG_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+// bytes of one payload part, to host
+static int part_bytes(bg_ctx* ctx, const bg_seqset* ss, const std::string& part, std::string* out) {
+  const uint64_t n = ss->n;
+  if (part == "fixed") { out->assign(reinterpret_cast<const char*>(ss->fixed), 40); return BG_OK; }
+  if (part == "entry_sizes/elements" || part == "shared/elements") {
+    bool is_sizes = part[0] == 'e';
+    uint64_t maxv = is_sizes ? ss->max_len : (ss->max_len ? ss->max_len - 1 : 0);
+    int bpv = int(bits_for_value(maxv));
+    uint64_t nwords = (n * bpv + 63) / 64;
+    out->resize(nwords * 8);
+    if (!nwords) return BG_OK;
+    DevBuf<uint64_t> packed;
+    BG_TRY(packed.alloc(ctx, nwords));
+    k_pack_varbit<<<cdiv(nwords, 256), 256, 0, ctx->stream>>>(is_sizes ? ss->sizes.p : ss->shared.p, n, bpv, nwords,
+                                                               packed.p);
+    BG_LAUNCH_CHECK();
+    return download(ctx, &(*out)[0], packed.p, nwords * 8);
+  }
+  if (part.size() > 7 && part.compare(0, 5, "prev_") == 0) {
+    int b = part[5] == 'A' ? 0 : part[5] == 'C' ? 1 : part[5] == 'G' ? 2 : part[5] == 'T' ? 3 : -1;
+    std::string what = part.substr(7);
+    if (b >= 0) {
+      const DevBuf<uint64_t>* src = what == "bits" ? &ss->bits[b] : what == "subaccum" ? &ss->subaccum[b]
+                                    : what == "accum" ? &ss->accum[b] : nullptr;
+      if (src) {
+        uint64_t words = what == "bits" ? (n + 63) / 64 : what == "subaccum" ? (n + 511) / 512 : (n + 512) / 512;
+        out->resize(words * 8);
+        return download(ctx, &(*out)[0], src->p, words * 8);
+      }
+    }
+  }
+  set_error("bg_seqset_part: unknown part '%s'", part.c_str());
+  return BG_EINVAL;
+}
+
+static std::string json_escape(const std::string& s) {
+  std::string o;
+  for (char c : s) {
+    if (c == '"' || c == '\\') { o.push_back('\\'); o.push_back(c); }
+    else if (c == '\n') o += "\\n";
+    else o.push_back(c);
+  }
+  return o;
+}
+
+static std::string version_json(const char* type, int maj, int min, int pat) {
+  char buf[256];
+  snprintf(buf, sizeof buf,
+           "{\"part_type\":\"%s\",\"version\":{\"build\":\"\",\"major\":%d,\"minor\":%d,\"patch\":%d,\"pre\":\"\"}}", type,
+           maj, min, pat);
+  return buf;
+}
+
+}  // namespace bg
+
+using namespace bg;
+
+extern "C" int bg_abi_version(void) { return BG_ABI_VERSION; }
+extern "C" const char* bg_last_error(void) { return bg::last_error_cstr(); }
+
+extern "C" int bg_ctx_create(int device, void* stream, bg_ctx** out) {
+  if (!out) { set_error("bg_ctx_create: null argument"); return BG_EINVAL; }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) {
+    set_error("bg_ctx_create: no HIP device available (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    (void)hipGetLastError();
+    return BG_ENODEV;
+  }
+  if (device < 0 || device >= count) { set_error("bg_ctx_create: device %d out of range (%d)", device, count); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(device));
+  bg_ctx* c = new bg_ctx;
+  c->device = device;
+  c->stream = static_cast<hipStream_t>(stream);
+  *out = c;
+  return BG_OK;
+}
+
+extern "C" void bg_ctx_destroy(bg_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  ctx->trim();
+  ctx->clear_timings();
+  for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+  delete ctx;
+}
+
+extern "C" int bg_ctx_trim(bg_ctx* ctx) { return ctx ? ctx->trim() : BG_EINVAL; }
+
+extern "C" int bg_ctx_set_profiling(bg_ctx* ctx, int on) {
+  if (!ctx) return BG_EINVAL;
+  ctx->profiling = on != 0;
+  ctx->clear_timings();
+  return BG_OK;
+}
+
+extern "C" int bg_ctx_timings(bg_ctx* ctx, bg_timing* out, int cap) {
+  if (!ctx) return 0;
+  (void)hipStreamSynchronize(ctx->stream);
+  std::vector<std::string> order;
+  std::map<std::string, bg_timing> agg;
+  for (auto& r : ctx->recs) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) { (void)hipGetLastError(); continue; }
+    auto it = agg.find(r.name);
+    if (it == agg.end()) {
+      bg_timing t;
+      memset(&t, 0, sizeof t);
+      snprintf(t.name, sizeof t.name, "%s", r.name.c_str());
+      it = agg.emplace(r.name, t).first;
+      order.push_back(r.name);
+    }
+    it->second.ms += ms;
+    it->second.launches += 1;
+    it->second.bytes += r.bytes;
+  }
+  int k = 0;
+  for (auto& name : order) {
+    if (out && k < cap) out[k] = agg[name];
+    ++k;
+  }
+  return k;
+}
+
+extern "C" int bg_dev_alloc(bg_ctx* ctx, uint64_t bytes, void** d_out) {
+  if (!ctx || !d_out) return BG_EINVAL;
+  BG_HIP(hipSetDevice(ctx->device));
+  BG_HIP(hipMalloc(d_out, bytes ? bytes : 1));
+  return BG_OK;
+}
+extern "C" int bg_dev_free(bg_ctx* ctx, void* p) {
+  if (!ctx) return BG_EINVAL;
+  BG_HIP(hipSetDevice(ctx->device));
+  BG_HIP(hipFree(p));
+  return BG_OK;
+}
+extern "C" int bg_dev_upload(bg_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes) {
+  if (!ctx) return BG_EINVAL;
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!bytes) return BG_OK;
+  BG_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+extern "C" int bg_dev_download(bg_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes) {
+  if (!ctx) return BG_EINVAL;
+  BG_HIP(hipSetDevice(ctx->device));
+  return download(ctx, h_dst, d_src, bytes);
+}
+
+// ---- seqset object
+
+extern "C" uint64_t bg_seqset_size(const bg_seqset* ss) { return ss ? ss->n : 0; }
+extern "C" uint32_t bg_seqset_max_len(const bg_seqset* ss) { return ss ? ss->max_len : 0; }
+extern "C" void bg_seqset_free(bg_seqset* ss) { delete ss; }
+
+extern "C" int bg_seqset_part(bg_ctx* ctx, const bg_seqset* ss, const char* part, void* h_out, uint64_t* size) {
+  if (!ctx || !ss || !part || !size) { set_error("bg_seqset_part: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::string data;
+  BG_TRY(part_bytes(ctx, ss, part, &data));
+  if (h_out) {
+    if (*size < data.size()) { set_error("bg_seqset_part: buffer too small"); *size = data.size(); return BG_EINVAL; }
+    memcpy(h_out, data.data(), data.size());
+  }
+  *size = data.size();
+  return BG_OK;
+}
+
+extern "C" int bg_seqset_arrays(bg_ctx* ctx, const bg_seqset* ss, uint32_t* h_sizes, uint32_t* h_shared) {
+  if (!ctx || !ss) { set_error("bg_seqset_arrays: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  uint64_t n = ss->n;
+  if (!n) return BG_OK;
+  DevBuf<uint32_t> tmp;
+  BG_TRY(tmp.alloc(ctx, n));
+  for (int which = 0; which < 2; ++which) {
+    uint32_t* dst = which ? h_shared : h_sizes;
+    if (!dst) continue;
+    k_u8_to_u32<<<cdiv(n, 256), 256, 0, ctx->stream>>>(which ? ss->shared.p : ss->sizes.p, n, tmp.p);
+    BG_LAUNCH_CHECK();
+    BG_TRY(download(ctx, dst, tmp.p, n * 4));
+  }
+  return BG_OK;
+}
+
+extern "C" int bg_seqset_entries(bg_ctx* ctx, const bg_seqset* ss, uint64_t first, uint64_t count, uint8_t* h_seq,
+                                 uint64_t* h_offs) {
+  if (!ctx || !ss || !h_offs) { set_error("bg_seqset_entries: null argument"); return BG_EINVAL; }
+  if (first + count > ss->n) { set_error("bg_seqset_entries: range past the end"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::vector<uint8_t> sz(count);
+  BG_TRY(download(ctx, sz.data(), ss->sizes.p + first, count));
+  uint64_t pos = 0;
+  for (uint64_t i = 0; i < count; ++i) { h_offs[i] = pos; pos += sz[i]; }
+  h_offs[count] = pos;
+  if (!count || !h_seq) return BG_OK;
+  DevBuf<uint64_t> d_offs;
+  DevBuf<uint8_t> d_seq;
+  BG_TRY(d_offs.alloc(ctx, count + 1));
+  BG_TRY(d_seq.alloc(ctx, pos));
+  BG_HIP(hipMemcpyAsync(d_offs.p, h_offs, (count + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (ss->keys.p && ss->W) {
+    k_entries_ascii<<<cdiv(count, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->sizes.p, first, count, ss->W, d_offs.p,
+                                                              d_seq.p);
+  } else {
+    k_entries_ascii_fm<<<cdiv(count, 64), 64, 0, ctx->stream>>>(view_of(ss), first, count, d_offs.p, d_seq.p);
+  }
+  BG_LAUNCH_CHECK();
+  return download(ctx, h_seq, d_seq.p, pos);
+}
+
+extern "C" int bg_seqset_from_arrays(bg_ctx* ctx, uint64_t n, const uint32_t* h_sizes, const uint32_t* h_shared,
+                                     const uint64_t* const h_bits[4], bg_seqset** out) {
+  if (!ctx || !out || (n && (!h_sizes || !h_shared || !h_bits))) { set_error("bg_seqset_from_arrays: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_seqset> ss(new bg_seqset);
+  ss->ctx = ctx;
+  ss->n = n;
+  ss->uuid = make_uuid();
+  BG_TRY(ss->sizes.alloc(ctx, n));
+  BG_TRY(ss->shared.alloc(ctx, n));
+  uint32_t mx = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (h_sizes[i] > 255 || h_shared[i] > 255) { set_error("bg_seqset_from_arrays: entry longer than 255"); return BG_EINVAL; }
+    mx = h_sizes[i] > mx ? h_sizes[i] : mx;
+  }
+  ss->max_len = mx;
+  if (n) {
+    DevBuf<uint32_t> tmp;
+    BG_TRY(tmp.alloc(ctx, n));
+    BG_HIP(hipMemcpyAsync(tmp.p, h_sizes, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    k_u32_to_u8<<<cdiv(n, 256), 256, 0, ctx->stream>>>(tmp.p, n, ss->sizes.p);
+    BG_LAUNCH_CHECK();
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    BG_HIP(hipMemcpyAsync(tmp.p, h_shared, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    k_u32_to_u8<<<cdiv(n, 256), 256, 0, ctx->stream>>>(tmp.p, n, ss->shared.p);
+    BG_LAUNCH_CHECK();
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  uint64_t nwords = (n + 63) / 64;
+  for (int b = 0; b < 4; ++b) {
+    BG_TRY(ss->bits[b].alloc(ctx, nwords));
+    if (nwords) BG_HIP(hipMemcpyAsync(ss->bits[b].p, h_bits[b], nwords * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  BG_TRY(seqset_finalize_device(ctx, ss.get()));
+  *out = ss.release();
+  return BG_OK;
+}
+
+extern "C" int bg_seqset_write(bg_ctx* ctx, const bg_seqset* ss, const char* path, int argc, const char* const* argv) {
+  if (!ctx || !ss || !path) { set_error("bg_seqset_write: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::vector<ZipPart> parts;
+  // file_info.json (io/spiral_file.cpp:194-222): uuid, timestamps, build stamp, argv — never comparable
+  time_t now = time(nullptr);
+  char tbuf[64];
+  ctime_r(&now, tbuf);
+  std::string ttext(tbuf);
+  if (!ttext.empty() && ttext.back() == '\n') ttext.pop_back();
+  std::string cmd = "[";
+  for (int i = 0; i < argc; ++i) {
+    if (i) cmd += ",";
+    cmd += "\"" + json_escape(argv[i] ? argv[i] : "") + "\"";
+  }
+  cmd += "]";
+  char fi[4096];
+  snprintf(fi, sizeof fi,
+           "{\"build_host\":\"\",\"build_is_clean\":true,\"build_revision\":\"biograph_amd\",\"build_timestamp\":0,"
+           "\"build_timestamp_text\":\"\",\"build_user\":\"\",\"command_line\":%s,\"create_timestamp\":%lld,"
+           "\"create_timestamp_text\":\"%s\",\"uuid\":\"%s\"}",
+           cmd.c_str(), (long long)now, ttext.c_str(), ss->uuid.c_str());
+  parts.push_back(ZipPart{"file_info.json", fi, false});
+  parts.push_back(ZipPart{"part_info.json", version_json("seqset", 1, 1, 0), false});  // seqset.cpp:12
+  char sj[64];
+  snprintf(sj, sizeof sj, "{\"num_entries\":%llu}", (unsigned long long)ss->n);
+  parts.push_back(ZipPart{"seqset.json", sj, false});
+  std::string data;
+  BG_TRY(part_bytes(ctx, ss, "fixed", &data));
+  parts.push_back(ZipPart{"fixed", data, true});
+  for (int which = 0; which < 2; ++which) {
+    std::string dir = which ? "shared" : "entry_sizes";
+    uint64_t maxv = which ? (ss->max_len ? ss->max_len - 1 : 0) : ss->max_len;
+    parts.push_back(ZipPart{dir + "/part_info.json", version_json("packed_varbit_vector", 1, 0, 0), false});
+    char mj[128];
+    snprintf(mj, sizeof mj, "{\"bits_per_value\":%u,\"element_count\":%llu,\"max_value\":%llu}", bits_for_value(maxv),
+             (unsigned long long)ss->n, (unsigned long long)maxv);
+    parts.push_back(ZipPart{dir + "/packed_varbit_vector.json", mj, false});
+    BG_TRY(part_bytes(ctx, ss, dir + "/elements", &data));
+    parts.push_back(ZipPart{dir + "/elements", data, true});
+  }
+  for (int b = 0; b < 4; ++b) {
+    std::string dir = std::string("prev_") + "ACGT"[b];
+    parts.push_back(ZipPart{dir + "/part_info.json", version_json("bitcount", 1, 0, 0), false});
+    char bj[64];
+    snprintf(bj, sizeof bj, "{\"nbits\":%llu}", (unsigned long long)ss->n);
+    parts.push_back(ZipPart{dir + "/bitcount.json", bj, false});
+    for (const char* w : {"bits", "subaccum", "accum"}) {
+      BG_TRY(part_bytes(ctx, ss, dir + "/" + w, &data));
+      parts.push_back(ZipPart{dir + "/" + w, data, true});
+    }
+  }
+  return spiral_zip_write(path, parts);
+}
+
+static bool json_u64(const std::string& js, const char* key, uint64_t* out) {
+  std::string pat = std::string("\"") + key + "\":";
+  size_t p = js.find(pat);
+  if (p == std::string::npos) return false;
+  *out = strtoull(js.c_str() + p + pat.size(), nullptr, 10);
+  return true;
+}
+
+extern "C" int bg_seqset_open(bg_ctx* ctx, const char* path, bg_seqset** out) {
+  if (!ctx || !path || !out) { set_error("bg_seqset_open: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::map<std::string, std::string> parts;
+  BG_TRY(spiral_zip_read(path, &parts));
+  uint64_t n = 0;
+  if (!parts.count("seqset.json") || !json_u64(parts["seqset.json"], "num_entries", &n)) {
+    set_error("%s: no seqset.json", path);
+    return BG_EIO;
+  }
+  std::unique_ptr<bg_seqset> ss(new bg_seqset);
+  ss->ctx = ctx;
+  ss->n = n;
+  {
+    const std::string& fi = parts["file_info.json"];
+    size_t p = fi.find("\"uuid\":\"");
+    if (p != std::string::npos) ss->uuid = fi.substr(p + 8, fi.find('"', p + 8) - (p + 8));
+  }
+  BG_TRY(ss->sizes.alloc(ctx, n));
+  BG_TRY(ss->shared.alloc(ctx, n));
+  for (int which = 0; which < 2; ++which) {
+    std::string dir = which ? "shared" : "entry_sizes";
+    uint8_t* dst = which ? ss->shared.p : ss->sizes.p;
+    if (parts.count(dir)) {  // old layout: raw uint8 (int_map_interface.cpp detect_subpart_or_uint8_membuf)
+      if (parts[dir].size() != n) { set_error("%s: bad %s size", path, dir.c_str()); return BG_EIO; }
+      if (n) BG_HIP(hipMemcpyAsync(dst, parts[dir].data(), n, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+      const std::string& md = parts[dir + "/packed_varbit_vector.json"];
+      const std::string& el = parts[dir + "/elements"];
+      uint64_t bpv = 0, cnt = 0;
+      if (!json_u64(md, "bits_per_value", &bpv) || !json_u64(md, "element_count", &cnt) || cnt != n || bpv > 8 ||
+          el.size() != ((n * bpv + 63) / 64) * 8) {
+        set_error("%s: unsupported %s encoding", path, dir.c_str());
+        return BG_EIO;
+      }
+      DevBuf<uint64_t> packed;
+      BG_TRY(packed.alloc(ctx, el.size() / 8 + 1));
+      if (!el.empty()) BG_HIP(hipMemcpyAsync(packed.p, el.data(), el.size(), hipMemcpyHostToDevice, ctx->stream));
+      if (n) {
+        k_unpack_varbit<<<cdiv(n, 256), 256, 0, ctx->stream>>>(packed.p, n, int(bpv), dst);
+        BG_LAUNCH_CHECK();
+      }
+      BG_HIP(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  uint64_t nwords = (n + 63) / 64;
+  for (int b = 0; b < 4; ++b) {
+    std::string name = std::string("prev_") + "ACGT"[b] + "/bits";
+    if (!parts.count(name) || parts[name].size() != nwords * 8) { set_error("%s: bad %s", path, name.c_str()); return BG_EIO; }
+    BG_TRY(ss->bits[b].alloc(ctx, nwords));
+    if (nwords) BG_HIP(hipMemcpyAsync(ss->bits[b].p, parts[name].data(), nwords * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  // max_len from sizes
+  std::vector<uint8_t> hs(n);
+  BG_TRY(download(ctx, hs.data(), ss->sizes.p, n));
+  uint32_t mx = 0;
+  for (uint8_t v : hs) mx = v > mx ? v : mx;
+  ss->max_len = mx;
+  BG_TRY(seqset_finalize_device(ctx, ss.get()));
+  // cross-check the stored rank index against the recomputed one
+  for (int b = 0; b < 4; ++b) {
+    std::string name = std::string("prev_") + "ACGT"[b] + "/accum";
+    std::string mine;
+    BG_TRY(part_bytes(ctx, ss.get(), name, &mine));
+    if (parts.count(name) && parts[name] != mine) { set_error("%s: %s does not match its bits", path, name.c_str()); return BG_EIO; }
+  }
+  *out = ss.release();
+  return BG_OK;
+}
+
+// ---- whole create path
+
+extern "C" void bg_create_params_default(bg_create_params* p) {
+  if (!p) return;
+  p->kmer_size = 30;                      // biograph_create.cpp:272
+  p->min_kmer_count = 5;                  // :275
+  p->correct.max_corrections = 8;         // :288
+  p->correct.min_good_run = 2;            // :291
+  p->correct.trim_after_portion = 0.7f;   // :281
+}
+
+extern "C" int bg_create(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n_reads,
+                         const bg_create_params* p, bg_seqset** out, bg_build_stats* stats) {
+  if (!ctx || !p || !out) { set_error("bg_create: null argument"); return BG_EINVAL; }
+  ctx->clear_timings();
+  bg_build_stats st;
+  memset(&st, 0, sizeof st);
+  bg_reads* reads = nullptr;
+  bg_kmerset* ks = nullptr;
+  bg_reads* corrected = nullptr;
+  int rc = bg_pack_reads(ctx, d_seq, d_offs, n_reads, &reads);
+  if (rc == BG_OK) {
+    st.n_reads = n_reads;
+    st.n_bases = reads->total_bases;
+    rc = bg_kmer_count(ctx, reads, p->kmer_size, p->min_kmer_count, &ks);
+  }
+  bg_correct_stats cs;
+  memset(&cs, 0, sizeof cs);
+  if (rc == BG_OK) {
+    st.n_kmers = ks->instances;
+    st.n_distinct_kmers = ks->distinct;
+    st.n_kept_kmers = ks->size;
+    rc = bg_correct_reads(ctx, reads, ks, &p->correct, &corrected, &cs);
+  }
+  bg_reads_free(reads);
+  bg_kmerset_free(ks);
+  if (rc == BG_OK) {
+    st.n_corrected_reads = cs.corrected_reads;
+    st.n_corrected_bases = cs.corrected_bases;
+    bg_build_stats s2;
+    memset(&s2, 0, sizeof s2);
+    rc = bg_seqset_build(ctx, corrected, p->kmer_size, out, &s2);
+    st.n_records = s2.n_records;
+    st.n_tied_records = s2.n_tied_records;
+    st.n_entries = s2.n_entries;
+    st.max_len = s2.max_len;
+  }
+  bg_reads_free(corrected);
+  if (stats) *stats = st;
+  return rc;
+}

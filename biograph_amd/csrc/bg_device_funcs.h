@@ -1,0 +1,511 @@
+// bg_device_funcs.h — per-thread logic of the HIP kernels, written as host+device inline functions.
+//
+// Under hipcc these compile into the gfx950 kernels (build_*.hip, walk.hip).  The same header is
+// compiled with g++ by tests/host_harness.cpp ONLY to unit-test the branchy per-thread logic
+// against the oracle on the CPU build (sanitizers are not available on the GPU pool).  The product
+// library never executes the host instantiation.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BG_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define BG_HD inline
+#endif
+
+namespace bg {
+
+constexpr int kMaxWords = 8;         // 8 x 32 = 256 bases >= 255 (biograph_create.cpp:134-139)
+constexpr int kMaxCorrections = 8;   // explicit DFS stack depth (fast_read_correct.cpp recursion)
+constexpr uint64_t kEmptySlot = ~0ull;
+constexpr uint64_t kKmerMask62 = (1ull << 62) - 1;  // kmer_count_table.h:17
+constexpr uint64_t kFwdStartsBit = 1ull << 62;      // stored in hash slot: fwd_starts_read
+constexpr uint64_t kRevStartsBit = 1ull << 63;      // stored in hash slot: rev_starts_read
+
+// ---- 2-bit packed reads.  Read i owns words[i*W .. i*W+W): base j sits in word j/32 at bits
+// (62-2*(j%32)) (first base in the high bits, dna_sequence.h:97 / kmer.h:30-38), zero (=A) padded.
+// nmask[i*W + j/32] bit (31-j%32) is set where the input had 'N' (the base is then stored as A).
+BG_HD int read_code(const uint64_t* words, int p) {
+  return int((words[p >> 5] >> (62 - 2 * (p & 31))) & 3);
+}
+BG_HD int read_isn(const uint32_t* nmask, int p) { return int((nmask[p >> 5] >> (31 - (p & 31))) & 1); }
+
+// 32 bases starting at base offset j of a packed word string of nw words (zero padded past end).
+BG_HD uint64_t window32(const uint64_t* words, int nw, int j) {
+  int q = j >> 5, r = j & 31;
+  uint64_t w0 = q < nw ? words[q] : 0;
+  if (r == 0) return w0;
+  uint64_t w1 = (q + 1) < nw ? words[q + 1] : 0;
+  return (w0 << (2 * r)) | (w1 >> (64 - 2 * r));
+}
+BG_HD uint32_t nwindow32(const uint32_t* nmask, int nw, int j) {
+  int q = j >> 5, r = j & 31;
+  uint32_t w0 = q < nw ? nmask[q] : 0;
+  if (r == 0) return w0;
+  uint32_t w1 = (q + 1) < nw ? nmask[q + 1] : 0;
+  return (w0 << r) | (w1 >> (32 - r));
+}
+
+// Reverse complement of 32 packed bases (A<->T, C<->G = 3-b; dna_base.h:28).
+BG_HD uint64_t revcomp64(uint64_t x) {
+  x = ~x;
+#if defined(__HIP_DEVICE_COMPILE__)
+  x = __brevll(x);
+#else
+  x = ((x >> 32) | (x << 32));
+  x = ((x & 0xffff0000ffff0000ull) >> 16) | ((x & 0x0000ffff0000ffffull) << 16);
+  x = ((x & 0xff00ff00ff00ff00ull) >> 8) | ((x & 0x00ff00ff00ff00ffull) << 8);
+  x = ((x & 0xf0f0f0f0f0f0f0f0ull) >> 4) | ((x & 0x0f0f0f0f0f0f0f0full) << 4);
+  x = ((x & 0xccccccccccccccccull) >> 2) | ((x & 0x3333333333333333ull) << 2);
+  x = ((x & 0xaaaaaaaaaaaaaaaaull) >> 1) | ((x & 0x5555555555555555ull) << 1);
+#endif
+  // the full bit reversal also reversed the two bits inside every base: swap them back
+  return ((x & 0xaaaaaaaaaaaaaaaaull) >> 1) | ((x & 0x5555555555555555ull) << 1);
+}
+// k-mer (right-aligned, kmer.h) reverse complement: dna_sequence.cpp:330-333.
+BG_HD uint64_t kmer_revcomp(uint64_t kmer, int k) { return revcomp64(kmer) >> (64 - 2 * k); }
+// dna_sequence.cpp:341-351
+BG_HD uint64_t kmer_canon(uint64_t kmer, int k, bool* flipped) {
+  uint64_t rc = kmer_revcomp(kmer, k);
+  *flipped = rc < kmer;
+  return rc < kmer ? rc : kmer;
+}
+BG_HD uint64_t kmer_shift(uint64_t kmer, int k, int b) {  // fast_read_correct.cpp:5-11
+  return ((kmer << 2) | uint64_t(b)) & ((k < 32) ? ~(~0ull << (2 * k)) : ~0ull);
+}
+
+// ---- k-mer hash set (open addressing, linear probe; role of kmer_set::find_table_index,
+// bio_mapred/kmer_set.h:60-149).  Slot = canonical k-mer in the low 62 bits + two flag bits.
+BG_HD uint64_t hash_slot(uint64_t canon, int log2cap) {
+  return (canon * 0x9E3779B97F4A7C15ull) >> (64 - log2cap);
+}
+struct KmerTable {
+  const uint64_t* slots;
+  int log2cap;
+  int k;
+  // Returns slot index or -1.
+  BG_HD int64_t find(uint64_t canon) const {
+    uint64_t mask = (1ull << log2cap) - 1;
+    uint64_t s = hash_slot(canon, log2cap);
+    for (;;) {
+      uint64_t v = slots[s];
+      if (v == kEmptySlot) return -1;
+      if ((v & kKmerMask62) == canon) return int64_t(s);
+      s = (s + 1) & mask;
+    }
+  }
+  BG_HD bool has(uint64_t kmer) const {  // correct_reads.cpp:163-171 kmer_lookup_f
+    bool fl;
+    return find(kmer_canon(kmer, k, &fl)) >= 0;
+  }
+};
+
+// ---- read correction (fast_read_correct.cpp:16-182 + correct_reads.cpp:154-178).
+// A corrected read equals the input except at substituted positions, so a DFS result is just
+// (length, substitutions).
+struct FrcRes {
+  int len;
+  int ncorr;
+  uint8_t spos[kMaxCorrections];
+  uint8_t sbase[kMaxCorrections];
+};
+
+struct ReadView {
+  const uint64_t* words;
+  const uint32_t* nmask;
+  int origin;  // original-read position of virtual index 0
+  int dir;     // +1: left-to-right; -1: reverse complement walking left
+  int n;       // virtual length
+  BG_HD int get(int t) const {  // 0..3, or 4 for N
+    int p = dir > 0 ? origin + t : origin - t;
+    if (read_isn(nmask, p)) return 4;
+    int c = read_code(words, p);
+    return dir > 0 ? c : 3 - c;
+  }
+};
+
+// correct_internal (fast_read_correct.cpp:16-90) with the recursion unrolled onto an explicit
+// stack.  `start`: first virtual index to consume; `kmer`: k-mer of the bases before it.
+template <class Table>
+BG_HD void frc_solve(const Table& tab, const ReadView& in, int start0, uint64_t kmer0, int k,
+                     int min_good_run_top, int min_good_run, int max_corrections, bool require_run_at_end,
+                     FrcRes* out) {
+  struct Frame {
+    int start, pos, b, best_size, best_b;
+    uint64_t kmer;
+    FrcRes best;
+  };
+  Frame fr[kMaxCorrections + 1];
+  int depth = 0;
+  fr[0].start = start0;
+  fr[0].kmer = kmer0;
+  FrcRes ret;
+  ret.len = 0;
+  ret.ncorr = 0;
+  bool entering = true;  // true: begin frame[depth]; false: `ret` holds the child result of frame[depth]
+  for (;;) {
+    Frame& f = fr[depth];
+    if (entering) {
+      int pos = f.start;
+      uint64_t cur = f.kmer;
+      while (pos < in.n) {  // :24-38 extend while the next k-mer is present
+        int c = in.get(pos);
+        if (c == 4) break;
+        uint64_t nk = kmer_shift(cur, k, c);
+        if (!tab.has(nk)) break;
+        cur = nk;
+        ++pos;
+      }
+      int runlen = pos - f.start;
+      int mgr = depth == 0 ? min_good_run_top : min_good_run;
+      int maxc = max_corrections - depth;
+      if (pos == in.n || runlen < mgr || maxc == 0) {  // :31-33, :41-47
+        ret.len = runlen;
+        ret.ncorr = 0;
+        if (depth == 0) break;
+        --depth;
+        entering = false;
+        continue;
+      }
+      f.pos = pos;
+      f.kmer = cur;
+      f.b = 0;
+      f.best_size = 0;
+      f.best_b = 0;
+      f.best.len = 0;
+      f.best.ncorr = 0;
+    } else {
+      // child of candidate base f.b returned in `ret` (:67-77)
+      if (!(require_run_at_end && ret.len < min_good_run)) {
+        if (ret.len >= f.best_size) {
+          f.best_size = ret.len + 1;
+          f.best_b = f.b;
+          f.best = ret;
+        }
+      }
+      f.b++;
+    }
+    // try loop (:55-78)
+    bool descended = false;
+    while (f.b < 4) {
+      uint64_t tk = kmer_shift(f.kmer, k, f.b);
+      if (!tab.has(tk)) { f.b++; continue; }
+      if (f.pos + 1 < in.n) {
+        fr[depth + 1].start = f.pos + 1;
+        fr[depth + 1].kmer = tk;
+        ++depth;
+        entering = true;
+        descended = true;
+        break;
+      }
+      // nothing left after the substituted base: empty child
+      if (!(require_run_at_end && 0 < min_good_run)) {
+        if (0 >= f.best_size) {
+          f.best_size = 1;
+          f.best_b = f.b;
+          f.best.len = 0;
+          f.best.ncorr = 0;
+        }
+      }
+      f.b++;
+    }
+    if (descended) continue;
+    // :80-87 combine
+    int runlen = f.pos - f.start;
+    if (f.best_size) {
+      ret.len = runlen + 1 + f.best.len;
+      ret.ncorr = 1 + f.best.ncorr;
+      ret.spos[0] = uint8_t(f.pos);
+      ret.sbase[0] = uint8_t(f.best_b);
+      for (int i = 0; i < f.best.ncorr; ++i) {
+        ret.spos[i + 1] = f.best.spos[i];
+        ret.sbase[i + 1] = f.best.sbase[i];
+      }
+    } else {
+      ret.len = runlen;
+      ret.ncorr = 0;
+    }
+    if (depth == 0) break;
+    --depth;
+    entering = false;
+  }
+  *out = ret;
+}
+
+// fast_read_correct (fast_read_correct.cpp:94-182) + the keep/drop rule of correct_reads::correct
+// (correct_reads.cpp:154-178).  Writes the corrected read (W words, zero padded) and returns its
+// length, or 0 if the read is dropped.  needed_good_bases = unsigned(double(float(trim))*len),
+// precomputed on the host per length (`needed`).  *ncorr_out gets the number of substitutions.
+template <class Table>
+BG_HD int frc_correct_read(const Table& tab, const uint64_t* words, const uint32_t* nmask, int len, int W, int k,
+                           int max_corrections, int min_good_run, int needed, uint64_t* out_words,
+                           int* ncorr_out) {
+  *ncorr_out = 0;
+  if (len < k) return 0;
+  // :107-122 find the first position whose k-mer is present (N resets the window)
+  int it = 0, left = k;
+  uint64_t kmer = 0;
+  for (;;) {
+    if (left == 0 && tab.has(kmer)) break;
+    if (it == len) return 0;
+    if (read_isn(nmask, it)) { ++it; left = k; continue; }
+    kmer = kmer_shift(kmer, k, read_code(words, it));
+    ++it;
+    if (left) --left;
+  }
+  int kmer_start = it - k;
+  FrcRes lres, rres;
+  lres.len = 0; lres.ncorr = 0;
+  rres.len = 0; rres.ncorr = 0;
+  int maxc = max_corrections;
+  if (kmer_start > 0) {  // :134-167 correct the left part on the reverse complement
+    ReadView lv{words, nmask, kmer_start - 1, -1, kmer_start};
+    frc_solve(tab, lv, 0, kmer_revcomp(kmer, k), k, 0, min_good_run, maxc, false, &lres);
+    if (lres.len != kmer_start) return 0;
+    maxc -= lres.ncorr;
+  }
+  if (it != len) {  // :169-172
+    ReadView rv{words, nmask, it, +1, len - it};
+    frc_solve(tab, rv, 0, kmer, k, 0, min_good_run, maxc, true, &rres);
+  }
+  int clen = kmer_start + k + rres.len;
+  if (clen < needed || clen < k) return 0;  // correct_reads.cpp:174-178
+  for (int w = 0; w < W; ++w) out_words[w] = words[w];
+  for (int i = 0; i < lres.ncorr; ++i) {
+    int p = kmer_start - 1 - int(lres.spos[i]);
+    int b = 3 - int(lres.sbase[i]);
+    int sh = 62 - 2 * (p & 31);
+    out_words[p >> 5] = (out_words[p >> 5] & ~(3ull << sh)) | (uint64_t(b) << sh);
+  }
+  for (int i = 0; i < rres.ncorr; ++i) {
+    int p = it + int(rres.spos[i]);
+    int sh = 62 - 2 * (p & 31);
+    out_words[p >> 5] = (out_words[p >> 5] & ~(3ull << sh)) | (uint64_t(rres.sbase[i]) << sh);
+  }
+  // N positions inside the kept part were all substituted (a run never crosses an N), but the
+  // stored base under an N is A: nothing else to fix.  Truncate + zero pad.
+  for (int w = 0; w < W; ++w) {
+    int lo = w * 32;
+    if (clen <= lo) out_words[w] = 0;
+    else if (clen < lo + 32) out_words[w] &= ~0ull << (2 * (lo + 32 - clen));
+  }
+  *ncorr_out = lres.ncorr + rres.ncorr;
+  return clen;
+}
+
+// ---- oriented reads.  Oriented read o = 2*i (forward) or 2*i+1 (reverse complement) of read i.
+// Materialises the W words of the oriented sequence (zero padded).
+BG_HD void oriented_words(const uint64_t* words, int len, int W, bool rc, uint64_t* out) {
+  if (!rc) {
+    for (int w = 0; w < W; ++w) out[w] = words[w];
+    return;
+  }
+  // reverse complement of the first `len` bases: word-reverse + per-word revcomp gives the RC of
+  // the zero-padded 32*W string; shift left by the pad to re-align.
+  int nw = (len + 31) >> 5;
+  uint64_t tmp[kMaxWords];
+  for (int w = 0; w < nw; ++w) tmp[w] = revcomp64(words[nw - 1 - w]);
+  int pad = nw * 32 - len;  // bases of padding now at the FRONT (as T's)
+  for (int w = 0; w < W; ++w) out[w] = w < nw ? window32(tmp, nw, w * 32 + pad) : 0;
+  // bases past len came from zero-fill in window32: already A.
+  int last = len & 31;
+  if (last && nw <= W) out[nw - 1] &= ~0ull << (2 * (32 - last));
+}
+
+// First differing base between two 32-base words (32 if equal).
+BG_HD int lcp_word(uint64_t a, uint64_t b) {
+  uint64_t x = a ^ b;
+  if (x == 0) return 32;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __clzll((long long)x) >> 1;
+#else
+  return __builtin_clzll(x) >> 1;
+#endif
+}
+
+// Does oriented sequence `a` (words aw, zero padded), from base offset j, with `rem` bases, match
+// the first `rem` bases of sequence b (words bw)?
+BG_HD bool suffix_is_prefix(const uint64_t* aw, int anw, int j, int rem, const uint64_t* bw) {
+  int full = rem >> 5, tail = rem & 31;
+  for (int w = 0; w < full; ++w)
+    if (window32(aw, anw, j + 32 * w) != bw[w]) return false;
+  if (tail) {
+    uint64_t m = ~0ull << (2 * (32 - tail));
+    if ((window32(aw, anw, j + 32 * full) & m) != (bw[full] & m)) return false;
+  }
+  return true;
+}
+
+// ---- exact-cover emission: index of the first K bases of every oriented read.
+struct CoverIndex {
+  const uint64_t* slots;
+  const uint32_t* vals;
+  int log2cap;
+  const uint64_t* skeys;  // sorted first-K-mers
+  const uint32_t* soid;   // oriented ids in the same order
+  uint64_t n_o;           // number of oriented reads
+  int K;
+};
+
+// number of suffix records oriented read o emits (0 for a dropped read)
+BG_HD int cover_count(const CoverIndex& ci, const uint64_t* owords,
+                                           const uint16_t* len, uint64_t o, int W) {
+  int L = len[o >> 1];
+  if (L == 0) return 0;
+  const uint64_t* s = owords + o * W;
+  const uint64_t mask = (1ull << ci.log2cap) - 1;
+  int cnt = 1;
+  for (int j = 1; j < L; ++j) {
+    int rem = L - j;
+    if (rem >= ci.K) {
+      uint64_t key = window32(s, W, j) >> (64 - 2 * ci.K);
+      uint64_t h = hash_slot(key, ci.log2cap);
+      bool covered = false;
+      for (;;) {
+        uint64_t v = ci.slots[h];
+        if (v == kEmptySlot) break;
+        if (v == key) {
+          for (uint64_t p = ci.vals[h]; p < ci.n_o && ci.skeys[p] == key; ++p) {
+            uint32_t c = ci.soid[p];
+            if (int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) {
+              covered = true;
+              break;
+            }
+          }
+          break;
+        }
+        h = (h + 1) & mask;
+      }
+      if (covered) break;
+    }
+    ++cnt;
+  }
+  return cnt;
+}
+
+// ---- entry keys: W words (zero padded) + length; order = lexicographic with a prefix before its
+// extensions == (words, len) tuple order because A=0 pads.
+BG_HD int key_compare(const uint64_t* a, int alen, const uint64_t* b, int blen, int W) {
+  for (int w = 0; w < W; ++w) {
+    if (a[w] < b[w]) return -1;
+    if (a[w] > b[w]) return 1;
+  }
+  return alen < blen ? -1 : (alen > blen ? 1 : 0);
+}
+BG_HD int key_lcp(const uint64_t* a, int alen, const uint64_t* b, int blen, int W) {
+  int m = alen < blen ? alen : blen;
+  int l = 0;
+  for (int w = 0; w < W; ++w) {
+    int c = lcp_word(a[w], b[w]);
+    l += c;
+    if (c < 32) break;
+  }
+  return l < m ? l : m;
+}
+
+// ---- seqset walk (bio_base/seqset.cpp:319-429, io/bitcount.h:218-270, io/int_map_interface.cpp:128-197).
+struct SeqsetView {
+  uint64_t n;
+  const uint8_t* sizes;     // entry_sizes, one byte per entry (max read length 255)
+  const uint8_t* shared;
+  const uint64_t* bits[4];
+  const uint64_t* subaccum[4];
+  const uint64_t* accum[4];
+  uint64_t fixed[5];
+  const uint8_t* min1;      // min of shared[] per 64 entries   (less_than_search k_factor1)
+  const uint8_t* min2;      // min of shared[] per 4096 entries (k_factor2)
+
+  BG_HD uint64_t count(int b, uint64_t i) const {  // bitcount.h:218-270
+    uint64_t nw = (n + 63) >> 6;
+    uint64_t x = (i >> 6) < nw ? bits[b][i >> 6] : 0;
+    x &= (1ull << (i & 63)) - 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t bc = __popcll(x);
+#else
+    uint64_t bc = __builtin_popcountll(x);
+#endif
+    uint64_t group = i >> 9, sub = (i >> 6) & 7;
+    uint64_t ngroups = (n + 511) >> 9;
+    uint64_t sa = group < ngroups ? subaccum[b][group] : 0;
+    sa >>= 56 - 8 * sub;
+    sa &= 0xffffffffffffff00ull;
+    sa = (sa >> 32) + (sa & 0xffffffffull);
+    sa = (sa >> 16) + (sa & 0xffff);
+    sa = (sa >> 8) + (sa & 0xff);
+    return accum[b][group] + sa + bc;
+  }
+  // first pos >= start with shared[pos] < v, or n
+  BG_HD uint64_t next_forward_lt(uint64_t pos, unsigned v) const {
+    if (shared[pos] < v) return pos;
+    while (pos < n) {
+      ++pos;
+      if (pos == n) return pos;
+      if ((pos & 63) == 0) {
+        uint64_t f1 = pos >> 6;
+        if ((f1 & 63) == 0 && min2[f1 >> 6] >= v) {
+          pos = ((f1 >> 6) + 1) * 4096 - 1;
+          if (pos >= n) return n;
+          continue;
+        }
+        if (min1[f1] >= v) {
+          pos = (f1 + 1) * 64 - 1;
+          if (pos >= n) return n;
+          continue;
+        }
+      }
+      if (shared[pos] < v) return pos;
+    }
+    return pos;
+  }
+  // last pos <= start with shared[pos] < v, or 0
+  BG_HD uint64_t next_backward_lt(uint64_t pos, unsigned v) const {
+    if (shared[pos] < v) return pos;
+    while (pos > 0) {
+      --pos;
+      if ((pos & 63) == 63) {
+        uint64_t f1 = pos >> 6;
+        if ((f1 & 63) == 63 && min2[f1 >> 6] >= v) { pos = (f1 >> 6) * 4096; continue; }
+        if (min1[f1] >= v) { pos = f1 * 64; continue; }
+      }
+      if (shared[pos] < v) return pos;
+    }
+    return pos;
+  }
+  BG_HD void push_front(uint64_t begin, uint64_t end, uint32_t size, int b, uint64_t* ob, uint64_t* oe,
+                        uint32_t* os) const {  // seqset.cpp:319-338
+    uint64_t nb = fixed[b] + count(b, begin), ne = fixed[b] + count(b, end);
+    if (nb < ne && sizes[nb] < size + 1) nb++;
+    *ob = nb; *oe = ne; *os = size + 1;
+  }
+  BG_HD void push_front_drop(uint64_t begin, uint64_t end, uint32_t size, int b, uint32_t min_ctx,
+                             uint64_t* ob, uint64_t* oe, uint32_t* os) const {  // seqset.cpp:350-429
+    uint64_t fx = fixed[b];
+    uint64_t o_begin = begin, o_end = end;
+    uint32_t octx = size;
+    uint64_t sb = count(b, o_begin), se = count(b, o_end);
+    *ob = 0; *oe = 0; *os = 0;
+    if (octx < min_ctx) return;
+    while (sb == se || (sb + 1 == se && sizes[fx + sb] < octx + 1)) {
+      uint32_t d0 = shared[o_begin];
+      uint32_t d1 = o_end == n ? 0u : uint32_t(shared[o_end]);
+      uint32_t drop = d0 > d1 ? d0 : d1;
+      if (sb != se) {
+        uint32_t d2 = uint32_t(sizes[fx + sb]) - 1;
+        if (d2 > drop) drop = d2;
+      }
+      if (drop < min_ctx) return;
+      bool ub = false, ue = false;
+      if (o_begin > 0 && shared[o_begin] >= drop) { o_begin = next_backward_lt(o_begin, drop); ub = true; }
+      if (o_end < n && shared[o_end] >= drop) { o_end = next_forward_lt(o_end, drop); ue = true; }
+      if (ub) sb = count(b, o_begin);
+      if (ue) se = count(b, o_end);
+      octx = drop;
+    }
+    uint64_t nb = fx + sb, ne = fx + se;
+    if (nb < ne && sizes[nb] < octx + 1) nb++;
+    *ob = nb; *oe = ne; *os = octx + 1;
+  }
+};
+
+}  // namespace bg

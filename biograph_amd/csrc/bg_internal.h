@@ -1,0 +1,156 @@
+// bg_internal.h — host-side plumbing shared by the translation units of libbgseq.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/bgseq.h"
+
+namespace bg {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define BG_HIP(expr)                                                  \
+  do {                                                                \
+    hipError_t e_ = (expr);                                           \
+    if (e_ != hipSuccess) return ::bg::hip_fail(e_, #expr, __FILE__, __LINE__); \
+  } while (0)
+#define BG_TRY(expr)           \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_ != BG_OK) return rc_; \
+  } while (0)
+#define BG_LAUNCH_CHECK() BG_HIP(hipGetLastError())
+
+struct TimingRec {
+  std::string name;
+  hipEvent_t start, stop;
+  uint64_t bytes;
+};
+
+}  // namespace bg
+
+// The opaque C types live in the global namespace (they are named in the extern "C" header).
+struct bg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool profiling = false;
+  // size -> cached free blocks (exact-size reuse: every build of one workload asks for the same sizes)
+  std::multimap<size_t, void*> free_blocks;
+  std::map<void*, size_t> live;
+  size_t cached_bytes = 0, live_bytes = 0, peak_bytes = 0;
+  std::vector<bg::TimingRec> recs;
+  std::vector<hipEvent_t> event_pool;
+
+  int alloc(size_t bytes, void** out);
+  void release(void* p);
+  int trim();
+  // profiling bracket around one kernel family
+  void tic(const char* name);
+  void toc(uint64_t bytes);
+  void clear_timings();
+  hipEvent_t get_event();
+};
+
+namespace bg {
+
+// RAII device buffer drawn from the context cache.
+template <class T>
+struct DevBuf {
+  bg_ctx* ctx = nullptr;
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : ctx(o.ctx), p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { reset(); ctx = o.ctx; p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+  ~DevBuf() { reset(); }
+  int alloc(bg_ctx* c, size_t count) {
+    reset();
+    ctx = c;
+    n = count;
+    void* q = nullptr;
+    int rc = c->alloc((count ? count : 1) * sizeof(T), &q);
+    p = static_cast<T*>(q);
+    return rc;
+  }
+  void reset() {
+    if (p && ctx) ctx->release(p);
+    p = nullptr;
+    n = 0;
+  }
+  T* release_ownership() { T* q = p; p = nullptr; n = 0; return q; }
+  size_t bytes() const { return n * sizeof(T); }
+};
+
+inline unsigned cdiv(uint64_t a, uint64_t b) { return unsigned((a + b - 1) / b); }
+
+// ---- primitives (prims.hip)
+// Exclusive scan of n uint32 counters into uint64 offsets (out may not alias in).  If d_total is
+// non-null the grand total is stored there (device).
+int exclusive_scan_u32_to_u64(bg_ctx* ctx, const uint32_t* d_in, uint64_t* d_out, uint64_t n, uint64_t* d_total);
+// Same with 32-bit outputs (total must fit).
+int exclusive_scan_u32(bg_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, uint64_t n, uint32_t* d_total);
+// Stable LSD radix sort of 64-bit keys (optionally carrying 32-bit values) on key bits
+// [bit_lo, bit_hi).  keys_a/vals_a hold the input; *_b are scratch of the same size.  On return
+// *in_b tells which buffer holds the result.  vals_* may be null (keys only).
+int radix_sort_u64(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                   uint64_t n, int bit_lo, int bit_hi, bool* in_b);
+
+// ---- device-side object layouts
+}  // namespace bg
+
+struct bg_reads {
+  bg_ctx* ctx = nullptr;
+  uint64_t n = 0;
+  int W = 0;                 // words per read (fixed stride)
+  uint32_t max_len = 0;
+  uint64_t total_bases = 0;
+  bg::DevBuf<uint64_t> words;   // n*W
+  bg::DevBuf<uint32_t> nmask;   // n*W   (all zero for corrected reads)
+  bg::DevBuf<uint16_t> len;     // n
+};
+
+struct bg_kmerset {
+  bg_ctx* ctx = nullptr;
+  int k = 0;
+  uint64_t size = 0, distinct = 0, instances = 0;
+  bg::DevBuf<uint64_t> kmers;    // sorted canonical kept k-mers
+  bg::DevBuf<uint32_t> counts;   // total count per kept k-mer
+  bg::DevBuf<uint64_t> slots;    // hash table (1 << log2cap)
+  int log2cap = 0;
+};
+
+struct bg_seqset {
+  bg_ctx* ctx = nullptr;
+  uint64_t n = 0;
+  uint32_t max_len = 0;
+  int W = 0;                        // words per entry key (0 when opened from a file)
+  bg::DevBuf<uint64_t> keys;        // n*W entry sequences (only after a build)
+  bg::DevBuf<uint8_t> sizes, shared;
+  bg::DevBuf<uint64_t> bits[4], subaccum[4], accum[4];
+  bg::DevBuf<uint8_t> min1, min2;
+  uint64_t fixed[5] = {0, 0, 0, 0, 0};
+  std::string uuid;
+};
+
+namespace bg {
+// build.hip
+int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss);  // bitcount finalize + min index + fixed
+// spiral_zip.cpp
+struct ZipPart { std::string name; std::string data; bool raw_crc0; };
+int spiral_zip_write(const char* path, const std::vector<ZipPart>& parts);
+int spiral_zip_read(const char* path, std::map<std::string, std::string>* parts);
+std::string make_uuid();
+}  // namespace bg

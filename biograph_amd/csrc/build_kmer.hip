@@ -1,0 +1,650 @@
+// build_kmer.hip — S1 (2-bit packing), S2 (canonical k-mer count + filter + hash set) and S3 (read
+// correction) of the seqset build, for gfx950.
+//
+// Reference rows: A2 dna_base.h:38-56 / dna_sequence.h:97; B1 kmer_counter.h:275-326;
+// B3 kmer_count_table.h:54-103; B4 kmerize_bf.cpp:290-318; C1 fast_read_correct.cpp:16-182;
+// C2 correct_reads.cpp:154-178.
+#include "bg_device_funcs.h"
+#include "bg_internal.h"
+#include "compact.h"
+
+namespace bg {
+
+// ------------------------------------------------------------------------------------------------
+// S1: lengths, then one thread per (read, 32-base word).
+
+__global__ void k_read_lengths(const uint64_t* __restrict__ offs, uint64_t n, uint16_t* __restrict__ len,
+                               uint32_t* __restrict__ max_len, uint32_t* __restrict__ err) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  uint64_t l = 0;
+  if (i < n) {  // no early return: every lane takes part in the wave reduction below
+    l = offs[i + 1] - offs[i];
+    if (offs[i + 1] < offs[i] || l > 255) {  // biograph_create.cpp:134-139 (no --allow-long-reads)
+      atomicOr(err, 1u);
+      l = 0;
+    }
+    len[i] = uint16_t(l);
+  }
+  // one atomic per wave
+  uint32_t m = uint32_t(l);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    uint32_t t = __shfl_xor(m, d, 64);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(max_len, m);
+}
+
+__global__ void k_pack_reads(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs,
+                             const uint16_t* __restrict__ len, uint64_t n, int W, uint64_t* __restrict__ words,
+                             uint32_t* __restrict__ nmask, uint32_t* __restrict__ err) {
+  uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= n * uint64_t(W)) return;
+  uint64_t i = g / uint64_t(W);
+  int w = int(g - i * uint64_t(W));
+  int L = len[i];
+  int lo = w * 32;
+  uint64_t word = 0;
+  uint32_t nm = 0;
+  if (lo < L) {
+    const uint8_t* p = seq + offs[i] + lo;
+    int cnt = L - lo < 32 ? L - lo : 32;
+    bool bad = false;
+    for (int j = 0; j < cnt; ++j) {
+      uint32_t c = p[j];
+      uint32_t u = c & 0xDFu;  // upper-case letters
+      uint32_t code = (c >> 1) & 3;
+      code ^= code >> 1;  // A0 C1 G2 T3 (dna_base.h:38-56)
+      bool acgt = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
+      if (!acgt) {
+        code = 0;
+        if (c == 'N') nm |= 1u << (31 - j);  // only upper-case N is special (kmer_counter.h:306)
+        else bad = true;                      // dna_base.h:54 throws
+      }
+      word |= uint64_t(code) << (62 - 2 * j);
+    }
+    if (bad) atomicOr(err, 2u);
+  }
+  words[g] = word;
+  nmask[g] = nm;
+}
+
+// ------------------------------------------------------------------------------------------------
+// S2: k-mer extraction — one wave per read, one lane per window.
+
+__global__ void k_kmer_counts_per_read(const uint16_t* __restrict__ len, uint64_t n, int k,
+                                       uint32_t* __restrict__ nk) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int L = len[i];
+  nk[i] = L >= k ? uint32_t(L - k + 1) : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_extract_kmers(const uint64_t* __restrict__ words,
+                                                       const uint32_t* __restrict__ nmask,
+                                                       const uint16_t* __restrict__ len,
+                                                       const uint64_t* __restrict__ koff, uint64_t n, int W, int k,
+                                                       uint64_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  uint64_t i = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;  // wave-uniform
+  int L = len[i];
+  if (L < k) return;
+  int nk = L - k + 1;
+  uint64_t myw = lane < W ? words[i * W + lane] : 0;
+  uint32_t myn = lane < W ? nmask[i * W + lane] : 0;
+  uint64_t base = koff[i];
+  for (int j0 = 0; j0 < nk; j0 += 64) {
+    int j = j0 + lane;
+    int q = j >> 5, r = j & 31;
+    int q0 = q < 63 ? q : 63, q1 = q + 1 < 63 ? q + 1 : 63;
+    uint64_t w0 = __shfl(myw, q0, 64), w1 = __shfl(myw, q1, 64);
+    uint32_t n0 = __shfl(myn, q0, 64), n1 = __shfl(myn, q1, 64);
+    if (j < nk) {
+      uint64_t x = r ? ((w0 << (2 * r)) | (w1 >> (64 - 2 * r))) : w0;
+      uint32_t nm = r ? ((n0 << r) | (n1 >> (32 - r))) : n0;
+      uint64_t kmer = x >> (64 - 2 * k);
+      bool invalid = (nm >> (32 - k)) != 0;  // any N inside the window (kmer_counter.h:306-311)
+      bool fl;
+      uint64_t canon = kmer_canon(kmer, k, &fl);
+      out[base + j] = invalid ? ~0ull : canon;
+    }
+  }
+}
+
+// heads of equal-key runs in the sorted instance array (the all-ones sentinel run is a head too)
+__global__ void k_flag_heads(const uint64_t* __restrict__ keys, uint64_t n, uint8_t* __restrict__ flags) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+// keep iff run length >= min_count (kmerize_bf.cpp:291-294) and not the sentinel
+__global__ void k_flag_kept(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ head_pos, uint64_t nheads,
+                            uint64_t n, uint32_t min_count, uint8_t* __restrict__ flags) {
+  uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= nheads) return;
+  uint64_t s = head_pos[r];
+  uint64_t e = r + 1 < nheads ? head_pos[r + 1] : n;
+  flags[r] = (keys[s] != ~0ull && (e - s) >= uint64_t(min_count)) ? 1 : 0;
+}
+
+__global__ void k_gather_kept(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ head_pos,
+                              uint64_t nheads, uint64_t n, const uint64_t* __restrict__ kept_r, uint64_t nkept,
+                              uint64_t* __restrict__ kmers, uint32_t* __restrict__ counts) {
+  uint64_t j = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= nkept) return;
+  uint64_t r = kept_r[j];
+  uint64_t s = head_pos[r];
+  uint64_t e = r + 1 < nheads ? head_pos[r + 1] : n;
+  kmers[j] = keys[s];
+  uint64_t c = e - s;
+  counts[j] = c > 0xffffffffull ? 0xffffffffu : uint32_t(c);
+}
+
+__global__ void k_hash_insert(const uint64_t* __restrict__ kmers, uint64_t n, uint64_t* __restrict__ slots,
+                              int log2cap) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t km = kmers[i];
+  uint64_t mask = (1ull << log2cap) - 1;
+  uint64_t s = hash_slot(km, log2cap);
+  for (;;) {
+    unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&slots[s]),
+                                       (unsigned long long)kEmptySlot, (unsigned long long)km);
+    if (old == kEmptySlot) return;
+    s = (s + 1) & mask;
+  }
+}
+
+// fwd_starts_read / rev_starts_read (kmer_counter.h:316-320, kmer_count_table.h:82-88): first
+// window of a read (position 0, no N) sets fwd unless flipped; last window sets rev unless flipped.
+__global__ void k_set_start_flags(const uint64_t* __restrict__ words, const uint32_t* __restrict__ nmask,
+                                  const uint16_t* __restrict__ len, uint64_t n, int W, int k,
+                                  uint64_t* __restrict__ slots, int log2cap) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int L = len[i];
+  if (L < k) return;
+  KmerTable tab{slots, log2cap, k};
+  const uint64_t* w = words + i * W;
+  const uint32_t* nm = nmask + i * W;
+  for (int which = 0; which < 2; ++which) {
+    if (which == 1 && L == k) break;  // the single window was handled as first AND last
+    int j = which ? L - k : 0;
+    if ((nwindow32(nm, W, j) >> (32 - k)) != 0) continue;
+    uint64_t kmer = window32(w, W, j) >> (64 - 2 * k);
+    bool fl;
+    uint64_t canon = kmer_canon(kmer, k, &fl);
+    int64_t s = tab.find(canon);
+    if (s < 0) continue;
+    bool set_fwd = (which == 0);              // is_first_kmer
+    bool set_rev = (which == 1) || (L == k);  // is_last_kmer
+    if (fl) { bool t = set_fwd; set_fwd = set_rev; set_rev = t; }
+    uint64_t bits = (set_fwd ? kFwdStartsBit : 0) | (set_rev ? kRevStartsBit : 0);
+    atomicOr(reinterpret_cast<unsigned long long*>(&slots[s]), (unsigned long long)bits);
+  }
+}
+
+__global__ void k_gather_flags(const uint64_t* __restrict__ kmers, uint64_t n, const uint64_t* __restrict__ slots,
+                               int log2cap, int k, uint8_t* __restrict__ flags) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  KmerTable tab{slots, log2cap, k};
+  int64_t s = tab.find(kmers[i]);
+  uint8_t f = 0;
+  if (s >= 0) {
+    uint64_t v = slots[s];
+    if (v & kFwdStartsBit) f |= 1;
+    if (v & kRevStartsBit) f |= 2;
+  }
+  flags[i] = f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// S3: correction.  Screen (wave per read, all windows looked up in parallel), then DFS for the
+// reads that need it.
+
+__global__ __launch_bounds__(256) void k_correct_screen(const uint64_t* __restrict__ words,
+                                                        const uint32_t* __restrict__ nmask,
+                                                        const uint16_t* __restrict__ len, uint64_t n, int W, int k,
+                                                        const uint64_t* __restrict__ slots, int log2cap,
+                                                        uint64_t* __restrict__ out_words,
+                                                        uint16_t* __restrict__ out_len,
+                                                        uint8_t* __restrict__ need_dfs) {
+  const int lane = threadIdx.x & 63;
+  uint64_t i = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  int L = len[i];
+  uint64_t myw = lane < W ? words[i * W + lane] : 0;
+  uint32_t myn = lane < W ? nmask[i * W + lane] : 0;
+  if (L < k) {  // correct_reads.cpp:155
+    if (lane < W) out_words[i * W + lane] = 0;
+    if (lane == 0) { out_len[i] = 0; need_dfs[i] = 0; }
+    return;
+  }
+  KmerTable tab{slots, log2cap, k};
+  int nk = L - k + 1;
+  bool all_ok = true;
+  for (int j0 = 0; j0 < nk; j0 += 64) {
+    int j = j0 + lane;
+    int q = j >> 5, r = j & 31;
+    int q0 = q < 63 ? q : 63, q1 = q + 1 < 63 ? q + 1 : 63;
+    uint64_t w0 = __shfl(myw, q0, 64), w1 = __shfl(myw, q1, 64);
+    uint32_t n0 = __shfl(myn, q0, 64), n1 = __shfl(myn, q1, 64);
+    bool ok = true;
+    if (j < nk) {
+      uint64_t x = r ? ((w0 << (2 * r)) | (w1 >> (64 - 2 * r))) : w0;
+      uint32_t nm = r ? ((n0 << r) | (n1 >> (32 - r))) : n0;
+      ok = ((nm >> (32 - k)) == 0) && tab.has(x >> (64 - 2 * k));
+    }
+    if (!__all(ok)) all_ok = false;
+  }
+  if (all_ok) {  // nothing to correct: output == input
+    if (lane < W) out_words[i * W + lane] = myw;
+    if (lane == 0) { out_len[i] = uint16_t(L); need_dfs[i] = 0; }
+  } else if (lane == 0) {
+    need_dfs[i] = 1;
+  }
+}
+
+struct CorrectCounters {
+  unsigned long long modified, modified_bases;
+};
+
+__global__ __launch_bounds__(64) void k_correct_dfs(const uint64_t* __restrict__ words,
+                                                    const uint32_t* __restrict__ nmask,
+                                                    const uint16_t* __restrict__ len,
+                                                    const uint64_t* __restrict__ list, uint64_t nlist, int W, int k,
+                                                    const uint64_t* __restrict__ slots, int log2cap,
+                                                    int max_corrections, int min_good_run,
+                                                    const uint16_t* __restrict__ needed_by_len,
+                                                    uint64_t* __restrict__ out_words, uint16_t* __restrict__ out_len,
+                                                    CorrectCounters* __restrict__ ctr) {
+  uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= nlist) return;
+  uint64_t i = list[t];
+  KmerTable tab{slots, log2cap, k};
+  int L = len[i];
+  uint64_t ow[kMaxWords];
+  int ncorr = 0;
+  int clen = frc_correct_read(tab, words + i * W, nmask + i * W, L, W, k, max_corrections, min_good_run,
+                              int(needed_by_len[L]), ow, &ncorr);
+  for (int w = 0; w < W; ++w) out_words[i * W + w] = clen ? ow[w] : 0;
+  out_len[i] = uint16_t(clen);
+  if (clen && ncorr) {
+    atomicAdd(&ctr->modified, 1ull);
+    atomicAdd(&ctr->modified_bases, (unsigned long long)ncorr);
+  }
+}
+
+struct CorrectTotals {
+  unsigned long long corrected_reads, corrected_bases, failed, truncated, dropped_bases, max_len;
+};
+
+__global__ __launch_bounds__(256) void k_correct_stats(const uint16_t* __restrict__ len,
+                                                       const uint16_t* __restrict__ out_len, uint64_t n, int k,
+                                                       CorrectTotals* __restrict__ tot) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  unsigned long long v[5] = {0, 0, 0, 0, 0};
+  unsigned mx = 0;
+  if (i < n) {
+    int L = len[i], C = out_len[i];
+    if (C > 0) {
+      v[0] = 1;
+      v[1] = C;
+      if (C < L) { v[3] = 1; v[4] = L - C; }
+      mx = C;
+    } else if (L >= k) {
+      v[2] = 1;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) v[q] += __shfl_xor(v[q], d, 64);
+    unsigned t = __shfl_xor(mx, d, 64);
+    mx = t > mx ? t : mx;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (v[0]) atomicAdd(&tot->corrected_reads, v[0]);
+    if (v[1]) atomicAdd(&tot->corrected_bases, v[1]);
+    if (v[2]) atomicAdd(&tot->failed, v[2]);
+    if (v[3]) atomicAdd(&tot->truncated, v[3]);
+    if (v[4]) atomicAdd(&tot->dropped_bases, v[4]);
+    if (mx) atomicMax(&tot->max_len, (unsigned long long)mx);
+  }
+}
+
+__global__ void k_unpack_reads(const uint64_t* __restrict__ words, const uint16_t* __restrict__ len,
+                               const uint64_t* __restrict__ offs, uint64_t n, int W, uint8_t* __restrict__ seq) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int L = len[i];
+  uint8_t* p = seq + offs[i];
+  for (int j = 0; j < L; ++j) p[j] = "ACGT"[read_code(words + i * W, j)];
+}
+
+__global__ void k_len_to_u32(const uint16_t* __restrict__ len, uint64_t n, uint32_t* __restrict__ out) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = len[i];
+}
+
+}  // namespace bg
+
+using namespace bg;
+
+// ================================================================================================
+// C ABI: S1
+
+static int pack_reads_impl(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n, bg_reads** out) {
+  if (!ctx || !out || (n && (!d_offs))) { set_error("bg_pack_reads: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_reads> r(new bg_reads);
+  r->ctx = ctx;
+  r->n = n;
+  BG_TRY(r->len.alloc(ctx, n));
+  DevBuf<uint32_t> scal;  // [0]=max_len [1]=err
+  BG_TRY(scal.alloc(ctx, 2));
+  BG_HIP(hipMemsetAsync(scal.p, 0, 8, ctx->stream));
+  uint64_t h_offs[2] = {0, 0};
+  if (n) {
+    ctx->tic("pack_lengths");
+    k_read_lengths<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_offs, n, r->len.p, scal.p, scal.p + 1);
+    BG_LAUNCH_CHECK();
+    ctx->toc(n * 10);
+    BG_HIP(hipMemcpyAsync(&h_offs[0], d_offs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipMemcpyAsync(&h_offs[1], d_offs + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  uint32_t h_scal[2] = {0, 0};
+  BG_HIP(hipMemcpyAsync(h_scal, scal.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_scal[1]) {
+    set_error("bg_pack_reads: read longer than 255 bases or unsorted offsets");
+    return BG_EINVAL;
+  }
+  r->max_len = h_scal[0];
+  r->total_bases = h_offs[1] - h_offs[0];
+  r->W = int((r->max_len + 31) / 32);
+  if (r->W == 0) r->W = 1;
+  BG_TRY(r->words.alloc(ctx, n * r->W));
+  BG_TRY(r->nmask.alloc(ctx, n * r->W));
+  if (n) {
+    ctx->tic("pack_reads");
+    k_pack_reads<<<cdiv(n * r->W, 256), 256, 0, ctx->stream>>>(d_seq, d_offs, r->len.p, n, r->W, r->words.p,
+                                                                r->nmask.p, scal.p + 1);
+    BG_LAUNCH_CHECK();
+    ctx->toc(r->total_bases + n * r->W * 12);
+    BG_HIP(hipMemcpyAsync(h_scal, scal.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    if (h_scal[1] & 2) {
+      set_error("bg_pack_reads: read contains a character outside ACGTN");
+      return BG_EBADBASE;
+    }
+  }
+  *out = r.release();
+  return BG_OK;
+}
+
+extern "C" int bg_pack_reads(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n_reads,
+                             bg_reads** out) {
+  return pack_reads_impl(ctx, d_seq, d_offs, n_reads, out);
+}
+
+extern "C" int bg_pack_reads_host(bg_ctx* ctx, const uint8_t* h_seq, const uint64_t* h_offs, uint64_t n,
+                                  bg_reads** out) {
+  if (!ctx || !out || !h_offs) { set_error("bg_pack_reads_host: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  uint64_t total = h_offs[n];
+  DevBuf<uint8_t> dseq;
+  DevBuf<uint64_t> doffs;
+  BG_TRY(dseq.alloc(ctx, total));
+  BG_TRY(doffs.alloc(ctx, n + 1));
+  if (total) BG_HIP(hipMemcpyAsync(dseq.p, h_seq, total, hipMemcpyHostToDevice, ctx->stream));
+  BG_HIP(hipMemcpyAsync(doffs.p, h_offs, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  int rc = pack_reads_impl(ctx, dseq.p, doffs.p, n, out);
+  (void)hipStreamSynchronize(ctx->stream);
+  return rc;
+}
+
+extern "C" uint64_t bg_reads_count(const bg_reads* r) { return r ? r->n : 0; }
+extern "C" uint64_t bg_reads_total_bases(const bg_reads* r) { return r ? r->total_bases : 0; }
+extern "C" uint32_t bg_reads_max_len(const bg_reads* r) { return r ? r->max_len : 0; }
+extern "C" void bg_reads_free(bg_reads* r) { delete r; }
+
+extern "C" int bg_reads_download(bg_ctx* ctx, const bg_reads* r, uint8_t* h_seq, uint64_t* h_offs) {
+  if (!ctx || !r || !h_offs) { set_error("bg_reads_download: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  uint64_t n = r->n;
+  DevBuf<uint32_t> l32;
+  DevBuf<uint64_t> offs, total;
+  DevBuf<uint8_t> seq;
+  BG_TRY(l32.alloc(ctx, n));
+  BG_TRY(offs.alloc(ctx, n + 1));
+  BG_TRY(total.alloc(ctx, 1));
+  if (n) {
+    k_len_to_u32<<<cdiv(n, 256), 256, 0, ctx->stream>>>(r->len.p, n, l32.p);
+    BG_LAUNCH_CHECK();
+  }
+  BG_TRY(exclusive_scan_u32_to_u64(ctx, l32.p, offs.p, n, total.p));
+  BG_HIP(hipMemcpyAsync(offs.p + n, total.p, 8, hipMemcpyDeviceToDevice, ctx->stream));
+  uint64_t h_total = 0;
+  BG_HIP(hipMemcpyAsync(&h_total, total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  BG_TRY(seq.alloc(ctx, h_total));
+  if (n) {
+    k_unpack_reads<<<cdiv(n, 256), 256, 0, ctx->stream>>>(r->words.p, r->len.p, offs.p, n, r->W, seq.p);
+    BG_LAUNCH_CHECK();
+  }
+  if (h_total && h_seq) BG_HIP(hipMemcpyAsync(h_seq, seq.p, h_total, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipMemcpyAsync(h_offs, offs.p, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+// ================================================================================================
+// C ABI: S2
+
+extern "C" int bg_kmer_count(bg_ctx* ctx, const bg_reads* reads, int k, uint32_t min_count, bg_kmerset** out) {
+  if (!ctx || !reads || !out) { set_error("bg_kmer_count: null argument"); return BG_EINVAL; }
+  if (k < 1 || k > 31) { set_error("bg_kmer_count: kmer size %d outside 1..31", k); return BG_EINVAL; }
+  if (min_count < 1) min_count = 1;
+  BG_HIP(hipSetDevice(ctx->device));
+  const uint64_t n = reads->n;
+  const int W = reads->W;
+  std::unique_ptr<bg_kmerset> ks(new bg_kmerset);
+  ks->ctx = ctx;
+  ks->k = k;
+
+  // windows per read -> offsets
+  DevBuf<uint32_t> nk;
+  DevBuf<uint64_t> koff, total;
+  BG_TRY(nk.alloc(ctx, n));
+  BG_TRY(koff.alloc(ctx, n));
+  BG_TRY(total.alloc(ctx, 1));
+  if (n) {
+    k_kmer_counts_per_read<<<cdiv(n, 256), 256, 0, ctx->stream>>>(reads->len.p, n, k, nk.p);
+    BG_LAUNCH_CHECK();
+  }
+  BG_TRY(exclusive_scan_u32_to_u64(ctx, nk.p, koff.p, n, total.p));
+  uint64_t N = 0;
+  BG_HIP(hipMemcpyAsync(&N, total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  ks->instances = N;
+  nk.reset();
+
+  uint64_t nkept = 0, nheads = 0;
+  if (N) {
+    DevBuf<uint64_t> ka, kb;
+    BG_TRY(ka.alloc(ctx, N));
+    BG_TRY(kb.alloc(ctx, N));
+    ctx->tic("kmer_extract");
+    k_extract_kmers<<<cdiv(n, 4), 256, 0, ctx->stream>>>(reads->words.p, reads->nmask.p, reads->len.p, koff.p, n, W, k,
+                                                         ka.p);
+    BG_LAUNCH_CHECK();
+    ctx->toc(n * W * 12 + N * 8);
+    bool in_b = false;
+    // sort on the full key so that the all-ones sentinel of N-windows lands at the end; the census
+    // skips the constant high bytes when there is none.
+    BG_TRY(radix_sort_u64(ctx, ka.p, kb.p, nullptr, nullptr, N, 0, 64, &in_b));
+    uint64_t* sorted = in_b ? kb.p : ka.p;
+    if (in_b) ka.reset(); else kb.reset();
+
+    ctx->tic("kmer_runs");
+    DevBuf<uint64_t> head_pos, kept_r;
+    {
+      DevBuf<uint8_t> flags;
+      BG_TRY(flags.alloc(ctx, N));
+      k_flag_heads<<<cdiv(N, 256), 256, 0, ctx->stream>>>(sorted, N, flags.p);
+      BG_LAUNCH_CHECK();
+      BG_TRY(compact_flagged<uint64_t>(ctx, flags.p, N, &head_pos, &nheads));
+    }
+    {
+      DevBuf<uint8_t> flags;
+      BG_TRY(flags.alloc(ctx, nheads));
+      k_flag_kept<<<cdiv(nheads, 256), 256, 0, ctx->stream>>>(sorted, head_pos.p, nheads, N, min_count, flags.p);
+      BG_LAUNCH_CHECK();
+      BG_TRY(compact_flagged<uint64_t>(ctx, flags.p, nheads, &kept_r, &nkept));
+    }
+    BG_TRY(ks->kmers.alloc(ctx, nkept));
+    BG_TRY(ks->counts.alloc(ctx, nkept));
+    if (nkept) {
+      k_gather_kept<<<cdiv(nkept, 256), 256, 0, ctx->stream>>>(sorted, head_pos.p, nheads, N, kept_r.p, nkept,
+                                                              ks->kmers.p, ks->counts.p);
+      BG_LAUNCH_CHECK();
+    }
+    // distinct = heads minus the sentinel run (if any): the last key tells
+    uint64_t last_key = 0;
+    BG_HIP(hipMemcpyAsync(&last_key, sorted + (N - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    ks->distinct = nheads - (last_key == ~0ull ? 1 : 0);
+    ctx->toc(N * 10 + nheads * 9 + nkept * 12);
+  } else {
+    BG_TRY(ks->kmers.alloc(ctx, 0));
+    BG_TRY(ks->counts.alloc(ctx, 0));
+  }
+  ks->size = nkept;
+
+  // hash set
+  int lg = 10;
+  while ((1ull << lg) < 2 * nkept) ++lg;
+  ks->log2cap = lg;
+  BG_TRY(ks->slots.alloc(ctx, 1ull << lg));
+  BG_HIP(hipMemsetAsync(ks->slots.p, 0xff, (1ull << lg) * 8, ctx->stream));
+  ctx->tic("kmer_hash_build");
+  if (nkept) {
+    k_hash_insert<<<cdiv(nkept, 256), 256, 0, ctx->stream>>>(ks->kmers.p, nkept, ks->slots.p, lg);
+    BG_LAUNCH_CHECK();
+  }
+  if (n) {
+    k_set_start_flags<<<cdiv(n, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->nmask.p, reads->len.p, n, W, k,
+                                                             ks->slots.p, lg);
+    BG_LAUNCH_CHECK();
+  }
+  ctx->toc((1ull << lg) * 8 + nkept * 16 + n * 2 * 64);
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  *out = ks.release();
+  return BG_OK;
+}
+
+extern "C" uint64_t bg_kmerset_size(const bg_kmerset* ks) { return ks ? ks->size : 0; }
+extern "C" uint64_t bg_kmerset_distinct(const bg_kmerset* ks) { return ks ? ks->distinct : 0; }
+extern "C" uint64_t bg_kmerset_instances(const bg_kmerset* ks) { return ks ? ks->instances : 0; }
+extern "C" void bg_kmerset_free(bg_kmerset* ks) { delete ks; }
+
+extern "C" int bg_kmerset_download(bg_ctx* ctx, const bg_kmerset* ks, uint64_t* h_kmers, uint8_t* h_flags,
+                                   uint32_t* h_counts) {
+  if (!ctx || !ks) { set_error("bg_kmerset_download: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  uint64_t n = ks->size;
+  if (!n) return BG_OK;
+  if (h_kmers) BG_HIP(hipMemcpyAsync(h_kmers, ks->kmers.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (h_counts) BG_HIP(hipMemcpyAsync(h_counts, ks->counts.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (h_flags) {
+    DevBuf<uint8_t> fl;
+    BG_TRY(fl.alloc(ctx, n));
+    k_gather_flags<<<cdiv(n, 256), 256, 0, ctx->stream>>>(ks->kmers.p, n, ks->slots.p, ks->log2cap, ks->k, fl.p);
+    BG_LAUNCH_CHECK();
+    BG_HIP(hipMemcpyAsync(h_flags, fl.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+// ================================================================================================
+// C ABI: S3
+
+extern "C" int bg_correct_reads(bg_ctx* ctx, const bg_reads* reads, const bg_kmerset* ks,
+                                const bg_correct_params* params, bg_reads** out, bg_correct_stats* stats) {
+  if (!ctx || !reads || !ks || !params || !out) { set_error("bg_correct_reads: null argument"); return BG_EINVAL; }
+  if (params->max_corrections > uint32_t(kMaxCorrections)) {
+    set_error("bg_correct_reads: max_corrections %u > %d", params->max_corrections, kMaxCorrections);
+    return BG_EINVAL;
+  }
+  BG_HIP(hipSetDevice(ctx->device));
+  const uint64_t n = reads->n;
+  const int W = reads->W, k = ks->k;
+  std::unique_ptr<bg_reads> r(new bg_reads);
+  r->ctx = ctx;
+  r->n = n;
+  r->W = W;
+  BG_TRY(r->words.alloc(ctx, n * W));
+  BG_TRY(r->nmask.alloc(ctx, n * W));
+  BG_TRY(r->len.alloc(ctx, n));
+  if (n) BG_HIP(hipMemsetAsync(r->nmask.p, 0, n * W * 4, ctx->stream));
+
+  // needed_good_bases per length: unsigned(double(float trim) * double(len)), correct_reads.cpp:174
+  uint16_t needed[256];
+  for (int L = 0; L < 256; ++L) needed[L] = uint16_t(unsigned(double(params->trim_after_portion) * double(L)));
+  DevBuf<uint16_t> d_needed;
+  BG_TRY(d_needed.alloc(ctx, 256));
+  BG_HIP(hipMemcpyAsync(d_needed.p, needed, sizeof needed, hipMemcpyHostToDevice, ctx->stream));
+
+  DevBuf<uint8_t> need;
+  BG_TRY(need.alloc(ctx, n));
+  DevBuf<CorrectCounters> ctr;
+  DevBuf<CorrectTotals> tot;
+  BG_TRY(ctr.alloc(ctx, 1));
+  BG_TRY(tot.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(ctr.p, 0, sizeof(CorrectCounters), ctx->stream));
+  BG_HIP(hipMemsetAsync(tot.p, 0, sizeof(CorrectTotals), ctx->stream));
+  uint64_t nlist = 0;
+  if (n) {
+    ctx->tic("correct_screen");
+    k_correct_screen<<<cdiv(n, 4), 256, 0, ctx->stream>>>(reads->words.p, reads->nmask.p, reads->len.p, n, W, k,
+                                                          ks->slots.p, ks->log2cap, r->words.p, r->len.p, need.p);
+    BG_LAUNCH_CHECK();
+    ctx->toc(n * W * 20 + ks->instances * 8);
+    DevBuf<uint64_t> list;
+    BG_TRY(compact_flagged<uint64_t>(ctx, need.p, n, &list, &nlist));
+    if (nlist) {
+      ctx->tic("correct_dfs");
+      k_correct_dfs<<<cdiv(nlist, 64), 64, 0, ctx->stream>>>(
+          reads->words.p, reads->nmask.p, reads->len.p, list.p, nlist, W, k, ks->slots.p, ks->log2cap,
+          int(params->max_corrections), int(params->min_good_run), d_needed.p, r->words.p, r->len.p, ctr.p);
+      BG_LAUNCH_CHECK();
+      ctx->toc(nlist * W * 20);
+    }
+    k_correct_stats<<<cdiv(n, 256), 256, 0, ctx->stream>>>(reads->len.p, r->len.p, n, k, tot.p);
+    BG_LAUNCH_CHECK();
+  }
+  CorrectCounters hc;
+  CorrectTotals ht;
+  BG_HIP(hipMemcpyAsync(&hc, ctr.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipMemcpyAsync(&ht, tot.p, sizeof ht, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  r->total_bases = ht.corrected_bases;
+  r->max_len = uint32_t(ht.max_len);
+  if (stats) {
+    stats->corrected_reads = ht.corrected_reads;
+    stats->corrected_bases = ht.corrected_bases;
+    stats->failed = ht.failed;
+    stats->modified = hc.modified;
+    stats->modified_bases = hc.modified_bases;
+    stats->truncated = ht.truncated;
+    stats->dropped_bases = ht.dropped_bases;
+  }
+  *out = r.release();
+  return BG_OK;
+}

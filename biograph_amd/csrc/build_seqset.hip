@@ -1,0 +1,650 @@
+// build_seqset.hip — S4 (suffix records: exact-cover emission, sort, prefix-dedup) and S5 (seqset
+// arrays: sizes/shared/prev_{ACGT} rank vectors/fixed) for gfx950.
+//
+// Reference rows: D1-D5 repo_seq.h:85-183, part_repo.cpp:32-126, expand.cpp:180-380,
+// 581-661 — replaced by their net semantics, row E: the entry set is the prefix-free maxima of
+// every suffix of every corrected read and of its reverse complement; F1 builder.cpp:8-164;
+// F2 builder.cpp:207-263, seqset.cpp:19-44,113-129, bitcount.cpp:84-124.
+//
+// Emission rule: for an oriented read s, suffix j>=1 and every later one are skipped
+// as soon as s[j:] is a prefix of some oriented read.  Covered suffixes are prefixes of suffixes of
+// the covering read at strictly smaller offsets, so the prefix-free maxima are unchanged and no
+// expansion passes (expand.cpp:581) are needed.
+#include "bg_device_funcs.h"
+#include "bg_internal.h"
+#include "compact.h"
+
+namespace bg {
+
+// ------------------------------------------------------------------------------------------------
+// oriented reads
+
+__global__ void k_oriented_words(const uint64_t* __restrict__ words, const uint16_t* __restrict__ len, uint64_t n,
+                                 int W, int K, uint64_t* __restrict__ owords, uint64_t* __restrict__ okey,
+                                 uint32_t* __restrict__ oid) {
+  uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (o >= 2 * n) return;
+  uint64_t i = o >> 1;
+  int L = len[i];
+  uint64_t tmp[kMaxWords];
+  oriented_words(words + i * W, L, W, (o & 1) != 0, tmp);
+  for (int w = 0; w < W; ++w) owords[o * W + w] = L ? tmp[w] : 0;
+  okey[o] = (L >= K) ? (tmp[0] >> (64 - 2 * K)) : ~0ull;  // sentinel: cannot act as a cover
+  oid[o] = uint32_t(o);
+}
+
+__global__ void k_flag_key_heads(const uint64_t* __restrict__ keys, uint64_t n, uint8_t* __restrict__ flags) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t k = keys[i];
+  flags[i] = (k != ~0ull && (i == 0 || k != keys[i - 1])) ? 1 : 0;
+}
+
+// cover index: hash from first-K-mer to the start of its run in the sorted (key, oriented id) list
+__global__ void k_cover_insert(const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ head_pos,
+                               uint64_t nheads, uint64_t* __restrict__ slots, uint32_t* __restrict__ vals,
+                               int log2cap) {
+  uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= nheads) return;
+  uint32_t pos = head_pos[r];
+  uint64_t key = skeys[pos];
+  uint64_t mask = (1ull << log2cap) - 1;
+  uint64_t s = hash_slot(key, log2cap);
+  for (;;) {
+    unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&slots[s]),
+                                       (unsigned long long)kEmptySlot, (unsigned long long)key);
+    if (old == kEmptySlot) { vals[s] = pos; return; }
+    s = (s + 1) & mask;
+  }
+}
+
+__global__ __launch_bounds__(128) void k_cover_count(CoverIndex ci, const uint64_t* __restrict__ owords,
+                                                     const uint16_t* __restrict__ len, uint64_t n_o, int W,
+                                                     uint32_t* __restrict__ cnt) {
+  uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (o >= n_o) return;
+  cnt[o] = uint32_t(cover_count(ci, owords, len, o, W));
+}
+
+// records: rec[r*W + w] (zero padded words), rlen[r], k0[r] = first word (sort key), ridx[r] = r
+__global__ __launch_bounds__(128) void k_emit_records(const uint64_t* __restrict__ owords,
+                                                      const uint16_t* __restrict__ len,
+                                                      const uint32_t* __restrict__ cnt,
+                                                      const uint64_t* __restrict__ roff, uint64_t n_o, int W,
+                                                      uint64_t* __restrict__ rec, uint8_t* __restrict__ rlen,
+                                                      uint64_t* __restrict__ k0, uint32_t* __restrict__ ridx) {
+  uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (o >= n_o) return;
+  int c = int(cnt[o]);
+  if (!c) return;
+  int L = len[o >> 1];
+  const uint64_t* s = owords + o * W;
+  uint64_t r = roff[o];
+  for (int j = 0; j < c; ++j, ++r) {
+    for (int w = 0; w < W; ++w) {
+      uint64_t x = window32(s, W, j + 32 * w);
+      rec[r * W + w] = x;
+      if (w == 0) k0[r] = x;
+    }
+    rlen[r] = uint8_t(L - j);
+    ridx[r] = uint32_t(r);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tie refinement after the first-word sort
+
+// flags positions whose sort key equals a neighbour's
+__global__ void k_flag_ties(const uint64_t* __restrict__ skeys, uint64_t n, uint8_t* __restrict__ flags) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t k = skeys[i];
+  bool t = (i > 0 && skeys[i - 1] == k) || (i + 1 < n && skeys[i + 1] == k);
+  flags[i] = t ? 1 : 0;
+}
+
+// subset element t sits at sorted position tpos[t]; it starts a group unless it continues the run of
+// its predecessor (adjacent position, same previous-round group and same key).
+__global__ void k_group_heads(const uint32_t* __restrict__ tpos, const uint64_t* __restrict__ tkey,
+                              const uint32_t* __restrict__ prev_gid, uint64_t T, uint32_t* __restrict__ head) {
+  uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  bool cont = t > 0 && tpos[t] == tpos[t - 1] + 1 && tkey[t] == tkey[t - 1] &&
+              (prev_gid == nullptr || prev_gid[t] == prev_gid[t - 1]);
+  head[t] = cont ? 0u : 1u;
+}
+
+__global__ void k_gid_from_scan(const uint32_t* __restrict__ excl, const uint32_t* __restrict__ head, uint64_t T,
+                                uint32_t* __restrict__ gid) {
+  uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  gid[t] = excl[t] + head[t] - 1;
+}
+
+__global__ void k_gather_u64_by_u32(const uint64_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n,
+                                    uint64_t* __restrict__ dst) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void k_gather_u32_by_u32(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n,
+                                    uint32_t* __restrict__ dst) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void k_iota_u32(uint32_t* __restrict__ dst, uint64_t n) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = uint32_t(i);
+}
+
+// next-round key of subset element t: word `w` of its record (or the length when w == W)
+__global__ void k_round_keys(const uint64_t* __restrict__ rec, const uint8_t* __restrict__ rlen,
+                             const uint32_t* __restrict__ sidx, const uint32_t* __restrict__ tpos, uint64_t T, int W,
+                             int w, uint64_t* __restrict__ key) {
+  uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  uint32_t r = sidx[tpos[t]];
+  key[t] = (w < W) ? rec[uint64_t(r) * W + w] : uint64_t(rlen[r]);
+}
+
+__global__ void k_u32_to_u64(const uint32_t* __restrict__ src, uint64_t n, uint64_t* __restrict__ dst) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+// after the two stable sorts: perm[u] = subset element that belongs at subset slot u.
+// new_sidx[u] = record of that element; written back to sidx[tpos[u]].
+__global__ void k_apply_perm(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tpos,
+                             const uint32_t* __restrict__ old_rec_of_t, uint64_t T, uint32_t* __restrict__ sidx) {
+  uint64_t u = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u >= T) return;
+  sidx[tpos[u]] = old_rec_of_t[perm[u]];
+}
+
+// still tied: same group and same round key as a neighbour (in the re-sorted subset order)
+__global__ void k_flag_subset_ties(const uint32_t* __restrict__ gid, const uint64_t* __restrict__ key, uint64_t T,
+                                   uint8_t* __restrict__ flags) {
+  uint64_t u = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u >= T) return;
+  bool t = (u > 0 && gid[u - 1] == gid[u] && key[u - 1] == key[u]) ||
+           (u + 1 < T && gid[u + 1] == gid[u] && key[u + 1] == key[u]);
+  flags[u] = t ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dedup + arrays
+
+// sorted order -> contiguous keys/len
+__global__ void k_gather_records(const uint64_t* __restrict__ rec, const uint8_t* __restrict__ rlen,
+                                 const uint32_t* __restrict__ sidx, uint64_t n, int W, uint64_t* __restrict__ skeys,
+                                 uint8_t* __restrict__ slen) {
+  uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= n * uint64_t(W)) return;
+  uint64_t i = g / uint64_t(W);
+  int w = int(g - i * uint64_t(W));
+  uint32_t r = sidx[i];
+  skeys[g] = rec[uint64_t(r) * W + w];
+  if (w == 0) slen[i] = rlen[r];
+}
+
+// lcp with the predecessor, and "is a prefix of (or equal to) the successor" -> dropped
+// (expand.cpp:19-48 skip_dups)
+__global__ void k_lcp_and_keep(const uint64_t* __restrict__ skeys, const uint8_t* __restrict__ slen, uint64_t n, int W,
+                               uint8_t* __restrict__ lcp_prev, uint8_t* __restrict__ keep,
+                               uint32_t* __restrict__ err) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t* a = skeys + i * W;
+  int alen = slen[i];
+  int lp = 0;
+  if (i > 0) {
+    lp = key_lcp(skeys + (i - 1) * W, slen[i - 1], a, alen, W);
+    if (key_compare(skeys + (i - 1) * W, slen[i - 1], a, alen, W) > 0) atomicOr(err, 1u);  // not sorted
+  }
+  lcp_prev[i] = uint8_t(lp);
+  bool drop = false;
+  if (i + 1 < n) {
+    int ln = key_lcp(a, alen, skeys + (i + 1) * W, slen[i + 1], W);
+    drop = (ln == alen);
+  }
+  keep[i] = drop ? 0 : 1;
+}
+
+// entry e = kept position p: sizes, shared = min lcp over the dropped run before p (lcp is
+// "transitive" through prefixes), keys.
+__global__ void k_build_entries(const uint64_t* __restrict__ skeys, const uint8_t* __restrict__ slen,
+                                const uint8_t* __restrict__ lcp_prev, const uint32_t* __restrict__ kept_pos,
+                                uint64_t n_ent, int W, uint64_t* __restrict__ ekeys, uint8_t* __restrict__ sizes,
+                                uint8_t* __restrict__ shared) {
+  uint64_t e = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n_ent) return;
+  uint32_t p = kept_pos[e];
+  uint32_t lo = e ? kept_pos[e - 1] + 1 : 0;  // first position after the previous kept one
+  int sh = lcp_prev[p];
+  for (uint32_t q = p; q > lo; --q) {
+    int v = lcp_prev[q - 1];
+    sh = v < sh ? v : sh;
+  }
+  if (e == 0) sh = 0;
+  sizes[e] = slen[p];
+  shared[e] = uint8_t(sh);
+  for (int w = 0; w < W; ++w) ekeys[e * W + w] = skeys[uint64_t(p) * W + w];
+}
+
+// prev bits (builder.cpp:85-108, closed form of SURVEY row F1): entry s sets
+// prev_{s[0]}[lower_bound(entries, s[1:])]; the target must extend s[1:] ("Missing expansion?").
+__global__ __launch_bounds__(256) void k_prev_bits(const uint64_t* __restrict__ ekeys,
+                                                   const uint8_t* __restrict__ sizes, uint64_t n, int W,
+                                                   unsigned long long* __restrict__ bA,
+                                                   unsigned long long* __restrict__ bC,
+                                                   unsigned long long* __restrict__ bG,
+                                                   unsigned long long* __restrict__ bT, uint32_t* __restrict__ err) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t* s = ekeys + i * W;
+  int b = int(s[0] >> 62);
+  int tl = int(sizes[i]) - 1;
+  uint64_t tail[kMaxWords];
+  for (int w = 0; w < W; ++w) tail[w] = window32(s, W, 1 + 32 * w);
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) >> 1;
+    if (key_compare(ekeys + mid * W, sizes[mid], tail, tl, W) < 0) lo = mid + 1;
+    else hi = mid;
+  }
+  if (lo >= n || key_lcp(ekeys + lo * W, sizes[lo], tail, tl, W) < tl) {
+    atomicOr(err, 2u);
+    return;
+  }
+  unsigned long long* bits = b == 0 ? bA : b == 1 ? bC : b == 2 ? bG : bT;
+  atomicOr(&bits[lo >> 6], 1ull << (lo & 63));
+}
+
+// bitcount::finalize (io/bitcount.cpp:84-124): one thread per 512-bit group.
+__global__ void k_bitcount_groups(const uint64_t* __restrict__ bits, uint64_t nwords, uint64_t ngroups,
+                                  uint64_t* __restrict__ subaccum, uint32_t* __restrict__ group_pop) {
+  uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= ngroups) return;
+  uint64_t sub = 0;
+  uint32_t tot = 0;
+  for (int j = 0; j < 8; ++j) {
+    uint64_t wi = g * 8 + j;
+    uint32_t pc = wi < nwords ? uint32_t(__popcll(bits[wi])) : 0u;
+    sub = (sub << 8) | pc;
+    tot += pc;
+  }
+  subaccum[g] = sub;
+  group_pop[g] = tot;
+}
+
+// less_than_search index (io/int_map_interface.cpp:87-126): min of shared[] per 64 and per 4096
+__global__ void k_min_index1(const uint8_t* __restrict__ shared, uint64_t n, uint64_t n1, uint8_t* __restrict__ min1) {
+  uint64_t f = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (f >= n1) return;
+  uint64_t lo = f * 64, hi = lo + 64 < n ? lo + 64 : n;
+  unsigned m = 255;
+  for (uint64_t p = lo; p < hi; ++p) m = shared[p] < m ? shared[p] : m;
+  min1[f] = uint8_t(m);
+}
+__global__ void k_min_index2(const uint8_t* __restrict__ min1, uint64_t n1, uint64_t n2, uint8_t* __restrict__ min2) {
+  uint64_t f = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (f >= n2) return;
+  uint64_t lo = f * 64, hi = lo + 64 < n1 ? lo + 64 : n1;
+  unsigned m = 255;
+  for (uint64_t p = lo; p < hi; ++p) m = min1[p] < m ? min1[p] : m;
+  min2[f] = uint8_t(m);
+}
+
+__global__ void k_max_u8(const uint8_t* __restrict__ v, uint64_t n, uint32_t* __restrict__ out) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  uint32_t m = i < n ? v[i] : 0;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    uint32_t t = __shfl_xor(m, d, 64);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// ------------------------------------------------------------------------------------------------
+
+// Allocates and fills subaccum/accum/fixed and the min index from bits/shared (device).
+int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss) {
+  const uint64_t n = ss->n;
+  const uint64_t nwords = (n + 63) / 64, ngroups = (n + 511) / 512, naccum = (n + 1 + 511) / 512;
+  DevBuf<uint32_t> gp;
+  DevBuf<uint64_t> total;
+  BG_TRY(gp.alloc(ctx, ngroups));
+  BG_TRY(total.alloc(ctx, 4));
+  uint64_t h_total[4] = {0, 0, 0, 0};
+  for (int b = 0; b < 4; ++b) {
+    BG_TRY(ss->subaccum[b].alloc(ctx, ngroups));
+    BG_TRY(ss->accum[b].alloc(ctx, naccum));
+    BG_HIP(hipMemsetAsync(ss->accum[b].p, 0, naccum * 8, ctx->stream));
+    if (ngroups) {
+      k_bitcount_groups<<<cdiv(ngroups, 256), 256, 0, ctx->stream>>>(ss->bits[b].p, nwords, ngroups,
+                                                                    ss->subaccum[b].p, gp.p);
+      BG_LAUNCH_CHECK();
+    }
+    BG_TRY(exclusive_scan_u32_to_u64(ctx, gp.p, ss->accum[b].p, ngroups, total.p + b));
+    if (naccum > ngroups)  // n % 512 == 0: the extra slot holds the grand total (bitcount.cpp:118-121)
+      BG_HIP(hipMemcpyAsync(ss->accum[b].p + ngroups, total.p + b, 8, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  BG_HIP(hipMemcpyAsync(h_total, total.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+  uint64_t n1 = (n + 63) / 64, n2 = (n1 + 63) / 64;
+  BG_TRY(ss->min1.alloc(ctx, n1));
+  BG_TRY(ss->min2.alloc(ctx, n2));
+  if (n) {
+    k_min_index1<<<cdiv(n1, 256), 256, 0, ctx->stream>>>(ss->shared.p, n, n1, ss->min1.p);
+    BG_LAUNCH_CHECK();
+    k_min_index2<<<cdiv(n2, 256), 256, 0, ctx->stream>>>(ss->min1.p, n1, n2, ss->min2.p);
+    BG_LAUNCH_CHECK();
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  uint64_t off = 0;
+  for (int b = 0; b < 4; ++b) { ss->fixed[b] = off; off += h_total[b]; }  // seqset.cpp:113-129
+  ss->fixed[4] = off;
+  if (off != n) {
+    set_error("Invalid seqset in finalize: %llu != %llu", (unsigned long long)off, (unsigned long long)n);
+    return BG_EINTERNAL;
+  }
+  return BG_OK;
+}
+
+}  // namespace bg
+
+using namespace bg;
+
+extern "C" int bg_seqset_build(bg_ctx* ctx, const bg_reads* reads, int cover_k, bg_seqset** out,
+                               bg_build_stats* stats) {
+  if (!ctx || !reads || !out) { set_error("bg_seqset_build: null argument"); return BG_EINVAL; }
+  if (cover_k < 1 || cover_k > 31) { set_error("bg_seqset_build: cover_k %d outside 1..31", cover_k); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  const uint64_t n = reads->n;
+  const uint64_t n_o = 2 * n;
+  const int W = reads->W;
+  if (n_o >= (1ull << 32)) { set_error("bg_seqset_build: too many reads for one shard (%llu)", (unsigned long long)n); return BG_EINVAL; }
+  std::unique_ptr<bg_seqset> ss(new bg_seqset);
+  ss->ctx = ctx;
+  ss->W = W;
+  ss->uuid = make_uuid();
+
+  uint64_t n_rec = 0, n_tied = 0, n_ent = 0;
+  DevBuf<uint64_t> rec;       // n_rec * W
+  DevBuf<uint8_t> rlen;       // n_rec
+  DevBuf<uint32_t> sidx;      // sorted order -> record
+  {
+    // ---- oriented reads + cover index
+    DevBuf<uint64_t> owords, okey_a, okey_b;
+    DevBuf<uint32_t> oid_a, oid_b;
+    BG_TRY(owords.alloc(ctx, n_o * W));
+    BG_TRY(okey_a.alloc(ctx, n_o));
+    BG_TRY(okey_b.alloc(ctx, n_o));
+    BG_TRY(oid_a.alloc(ctx, n_o));
+    BG_TRY(oid_b.alloc(ctx, n_o));
+    if (n_o) {
+      ctx->tic("suffix_oriented");
+      k_oriented_words<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->len.p, n, W, cover_k, owords.p,
+                                                                okey_a.p, oid_a.p);
+      BG_LAUNCH_CHECK();
+      ctx->toc(n * W * 8 + n_o * W * 8 + n_o * 12);
+    }
+    bool in_b = false;
+    BG_TRY(radix_sort_u64(ctx, okey_a.p, okey_b.p, oid_a.p, oid_b.p, n_o, 0, 64, &in_b));
+    uint64_t* skeys = in_b ? okey_b.p : okey_a.p;
+    uint32_t* soid = in_b ? oid_b.p : oid_a.p;
+    DevBuf<uint32_t> head_pos;
+    uint64_t nheads = 0;
+    {
+      DevBuf<uint8_t> flags;
+      BG_TRY(flags.alloc(ctx, n_o));
+      if (n_o) {
+        k_flag_key_heads<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(skeys, n_o, flags.p);
+        BG_LAUNCH_CHECK();
+      }
+      BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, n_o, &head_pos, &nheads));
+    }
+    int lg = 10;
+    while ((1ull << lg) < 2 * nheads) ++lg;
+    DevBuf<uint64_t> slots;
+    DevBuf<uint32_t> vals;
+    BG_TRY(slots.alloc(ctx, 1ull << lg));
+    BG_TRY(vals.alloc(ctx, 1ull << lg));
+    BG_HIP(hipMemsetAsync(slots.p, 0xff, (1ull << lg) * 8, ctx->stream));
+    if (nheads) {
+      k_cover_insert<<<cdiv(nheads, 256), 256, 0, ctx->stream>>>(skeys, head_pos.p, nheads, slots.p, vals.p, lg);
+      BG_LAUNCH_CHECK();
+    }
+    CoverIndex ci{slots.p, vals.p, lg, skeys, soid, n_o, cover_k};
+
+    // ---- emission
+    DevBuf<uint32_t> cnt;
+    DevBuf<uint64_t> roff, total;
+    BG_TRY(cnt.alloc(ctx, n_o));
+    BG_TRY(roff.alloc(ctx, n_o));
+    BG_TRY(total.alloc(ctx, 1));
+    if (n_o) {
+      ctx->tic("suffix_cover_count");
+      k_cover_count<<<cdiv(n_o, 128), 128, 0, ctx->stream>>>(ci, owords.p, reads->len.p, n_o, W, cnt.p);
+      BG_LAUNCH_CHECK();
+      ctx->toc(n_o * W * 8 * 2);
+    }
+    BG_TRY(exclusive_scan_u32_to_u64(ctx, cnt.p, roff.p, n_o, total.p));
+    BG_HIP(hipMemcpyAsync(&n_rec, total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_rec >= (1ull << 32)) {
+      set_error("bg_seqset_build: %llu suffix records exceed one shard", (unsigned long long)n_rec);
+      return BG_EINVAL;
+    }
+    BG_TRY(rec.alloc(ctx, n_rec * W));
+    BG_TRY(rlen.alloc(ctx, n_rec));
+    DevBuf<uint64_t> k0a, k0b;
+    DevBuf<uint32_t> ia, ib;
+    BG_TRY(k0a.alloc(ctx, n_rec));
+    BG_TRY(ia.alloc(ctx, n_rec));
+    if (n_rec) {
+      ctx->tic("suffix_emit");
+      k_emit_records<<<cdiv(n_o, 128), 128, 0, ctx->stream>>>(owords.p, reads->len.p, cnt.p, roff.p, n_o, W, rec.p,
+                                                              rlen.p, k0a.p, ia.p);
+      BG_LAUNCH_CHECK();
+      ctx->toc(n_o * W * 8 + n_rec * (W * 8 + 13));
+    }
+    // the cover index and oriented words are no longer needed
+    owords.reset(); okey_a.reset(); okey_b.reset(); oid_a.reset(); oid_b.reset();
+    slots.reset(); vals.reset(); cnt.reset(); roff.reset(); head_pos.reset();
+
+    // ---- sort by the first 32 bases
+    BG_TRY(k0b.alloc(ctx, n_rec));
+    BG_TRY(ib.alloc(ctx, n_rec));
+    BG_TRY(radix_sort_u64(ctx, k0a.p, k0b.p, ia.p, ib.p, n_rec, 0, 64, &in_b));
+    DevBuf<uint64_t>& ks = in_b ? k0b : k0a;
+    sidx = std::move(in_b ? ib : ia);
+    (in_b ? ia : ib).reset();
+    (in_b ? k0a : k0b).reset();
+
+    // ---- refine ties word by word, then by length
+    DevBuf<uint32_t> tpos;   // subset slot -> sorted position
+    DevBuf<uint64_t> tkey;   // current-round key per subset slot
+    DevBuf<uint32_t> gid;    // group ordinal per subset slot
+    uint64_t T = 0;
+    {
+      DevBuf<uint8_t> flags;
+      BG_TRY(flags.alloc(ctx, n_rec));
+      if (n_rec) {
+        k_flag_ties<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(ks.p, n_rec, flags.p);
+        BG_LAUNCH_CHECK();
+      }
+      BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, n_rec, &tpos, &T));
+    }
+    n_tied = T;
+    if (T) {
+      BG_TRY(tkey.alloc(ctx, T));
+      k_gather_u64_by_u32<<<cdiv(T, 256), 256, 0, ctx->stream>>>(ks.p, tpos.p, T, tkey.p);
+      BG_LAUNCH_CHECK();
+    }
+    ks.reset();
+    bool have_gid = false;
+    for (int w = 1; w <= W && T; ++w) {
+      // groups of this round = runs of equal (previous group, previous key) at adjacent positions
+      DevBuf<uint32_t> head, excl, ngid;
+      BG_TRY(head.alloc(ctx, T));
+      BG_TRY(excl.alloc(ctx, T));
+      BG_TRY(ngid.alloc(ctx, T));
+      k_group_heads<<<cdiv(T, 256), 256, 0, ctx->stream>>>(tpos.p, tkey.p, have_gid ? gid.p : nullptr, T, head.p);
+      BG_LAUNCH_CHECK();
+      BG_TRY(exclusive_scan_u32(ctx, head.p, excl.p, T, nullptr));
+      k_gid_from_scan<<<cdiv(T, 256), 256, 0, ctx->stream>>>(excl.p, head.p, T, ngid.p);
+      BG_LAUNCH_CHECK();
+      gid = std::move(ngid);
+      have_gid = true;
+      head.reset(); excl.reset();
+
+      // sort subset by (gid, key_w): LSD = key_w first, then gid (stable)
+      DevBuf<uint64_t> ka, kb;
+      DevBuf<uint32_t> va, vb, rec_of_t;
+      BG_TRY(ka.alloc(ctx, T));
+      BG_TRY(kb.alloc(ctx, T));
+      BG_TRY(va.alloc(ctx, T));
+      BG_TRY(vb.alloc(ctx, T));
+      BG_TRY(rec_of_t.alloc(ctx, T));
+      k_round_keys<<<cdiv(T, 256), 256, 0, ctx->stream>>>(rec.p, rlen.p, sidx.p, tpos.p, T, W, w, ka.p);
+      BG_LAUNCH_CHECK();
+      k_gather_u32_by_u32<<<cdiv(T, 256), 256, 0, ctx->stream>>>(sidx.p, tpos.p, T, rec_of_t.p);
+      BG_LAUNCH_CHECK();
+      k_iota_u32<<<cdiv(T, 256), 256, 0, ctx->stream>>>(va.p, T);
+      BG_LAUNCH_CHECK();
+      bool b1 = false;
+      BG_TRY(radix_sort_u64(ctx, ka.p, kb.p, va.p, vb.p, T, 0, 64, &b1));
+      uint64_t* k1 = b1 ? kb.p : ka.p;   // keys sorted by word
+      uint32_t* p1 = b1 ? vb.p : va.p;   // subset element per rank
+      uint64_t* k1o = b1 ? ka.p : kb.p;  // scratch
+      uint32_t* p1o = b1 ? va.p : vb.p;
+      // second key = gid of the element; carry the element id
+      DevBuf<uint32_t> g32;
+      DevBuf<uint64_t> g64a, g64b;
+      BG_TRY(g32.alloc(ctx, T));
+      BG_TRY(g64a.alloc(ctx, T));
+      BG_TRY(g64b.alloc(ctx, T));
+      k_gather_u32_by_u32<<<cdiv(T, 256), 256, 0, ctx->stream>>>(gid.p, p1, T, g32.p);
+      BG_LAUNCH_CHECK();
+      k_u32_to_u64<<<cdiv(T, 256), 256, 0, ctx->stream>>>(g32.p, T, g64a.p);
+      BG_LAUNCH_CHECK();
+      bool b2 = false;
+      BG_TRY(radix_sort_u64(ctx, g64a.p, g64b.p, p1, p1o, T, 0, 32, &b2));
+      uint32_t* perm = b2 ? p1o : p1;        // subset element per final slot
+      uint64_t* gsorted = b2 ? g64b.p : g64a.p;
+      // write the new order back and fetch this round's keys in the new order
+      k_apply_perm<<<cdiv(T, 256), 256, 0, ctx->stream>>>(perm, tpos.p, rec_of_t.p, T, sidx.p);
+      BG_LAUNCH_CHECK();
+      // keys in new order: re-read from the records through the updated sidx
+      k_round_keys<<<cdiv(T, 256), 256, 0, ctx->stream>>>(rec.p, rlen.p, sidx.p, tpos.p, T, W, w, k1o);
+      BG_LAUNCH_CHECK();
+      // gid in new order (as u32)
+      DevBuf<uint32_t> gnew;
+      BG_TRY(gnew.alloc(ctx, T));
+      k_gather_u32_by_u32<<<cdiv(T, 256), 256, 0, ctx->stream>>>(gid.p, perm, T, gnew.p);
+      BG_LAUNCH_CHECK();
+      (void)gsorted; (void)k1;
+      // which subset slots are still tied after this word?
+      DevBuf<uint8_t> flags;
+      DevBuf<uint32_t> keep_t;
+      uint64_t T2 = 0;
+      BG_TRY(flags.alloc(ctx, T));
+      k_flag_subset_ties<<<cdiv(T, 256), 256, 0, ctx->stream>>>(gnew.p, k1o, T, flags.p);
+      BG_LAUNCH_CHECK();
+      BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, T, &keep_t, &T2));
+      DevBuf<uint32_t> tpos2, gid2;
+      DevBuf<uint64_t> tkey2;
+      BG_TRY(tpos2.alloc(ctx, T2));
+      BG_TRY(gid2.alloc(ctx, T2));
+      BG_TRY(tkey2.alloc(ctx, T2));
+      if (T2) {
+        k_gather_u32_by_u32<<<cdiv(T2, 256), 256, 0, ctx->stream>>>(tpos.p, keep_t.p, T2, tpos2.p);
+        BG_LAUNCH_CHECK();
+        k_gather_u32_by_u32<<<cdiv(T2, 256), 256, 0, ctx->stream>>>(gnew.p, keep_t.p, T2, gid2.p);
+        BG_LAUNCH_CHECK();
+        k_gather_u64_by_u32<<<cdiv(T2, 256), 256, 0, ctx->stream>>>(k1o, keep_t.p, T2, tkey2.p);
+        BG_LAUNCH_CHECK();
+      }
+      BG_HIP(hipStreamSynchronize(ctx->stream));
+      tpos = std::move(tpos2);
+      gid = std::move(gid2);
+      tkey = std::move(tkey2);
+      T = T2;
+    }
+  }
+
+  // ---- dedup + entries
+  DevBuf<uint32_t> err;
+  BG_TRY(err.alloc(ctx, 2));
+  BG_HIP(hipMemsetAsync(err.p, 0, 8, ctx->stream));
+  {
+    DevBuf<uint64_t> skeys;
+    DevBuf<uint8_t> slen, lcp_prev, keep;
+    BG_TRY(skeys.alloc(ctx, n_rec * W));
+    BG_TRY(slen.alloc(ctx, n_rec));
+    BG_TRY(lcp_prev.alloc(ctx, n_rec));
+    BG_TRY(keep.alloc(ctx, n_rec));
+    DevBuf<uint32_t> kept_pos;
+    if (n_rec) {
+      ctx->tic("entries_dedup");
+      k_gather_records<<<cdiv(n_rec * W, 256), 256, 0, ctx->stream>>>(rec.p, rlen.p, sidx.p, n_rec, W, skeys.p, slen.p);
+      BG_LAUNCH_CHECK();
+      k_lcp_and_keep<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(skeys.p, slen.p, n_rec, W, lcp_prev.p, keep.p, err.p);
+      BG_LAUNCH_CHECK();
+      ctx->toc(n_rec * (W * 8 * 4 + 8));
+    }
+    rec.reset(); rlen.reset(); sidx.reset();
+    BG_TRY(compact_flagged<uint32_t>(ctx, keep.p, n_rec, &kept_pos, &n_ent));
+    ss->n = n_ent;
+    BG_TRY(ss->keys.alloc(ctx, n_ent * W));
+    BG_TRY(ss->sizes.alloc(ctx, n_ent));
+    BG_TRY(ss->shared.alloc(ctx, n_ent));
+    if (n_ent) {
+      ctx->tic("entries_build");
+      k_build_entries<<<cdiv(n_ent, 256), 256, 0, ctx->stream>>>(skeys.p, slen.p, lcp_prev.p, kept_pos.p, n_ent, W,
+                                                                ss->keys.p, ss->sizes.p, ss->shared.p);
+      BG_LAUNCH_CHECK();
+      ctx->toc(n_ent * (W * 16 + 8));
+    }
+  }
+
+  // ---- prev bits + rank index
+  const uint64_t nwords = (n_ent + 63) / 64;
+  for (int b = 0; b < 4; ++b) {
+    BG_TRY(ss->bits[b].alloc(ctx, nwords));
+    if (nwords) BG_HIP(hipMemsetAsync(ss->bits[b].p, 0, nwords * 8, ctx->stream));
+  }
+  DevBuf<uint32_t> mx;
+  BG_TRY(mx.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(mx.p, 0, 4, ctx->stream));
+  if (n_ent) {
+    ctx->tic("prev_bits");
+    k_prev_bits<<<cdiv(n_ent, 256), 256, 0, ctx->stream>>>(
+        ss->keys.p, ss->sizes.p, n_ent, W, reinterpret_cast<unsigned long long*>(ss->bits[0].p),
+        reinterpret_cast<unsigned long long*>(ss->bits[1].p), reinterpret_cast<unsigned long long*>(ss->bits[2].p),
+        reinterpret_cast<unsigned long long*>(ss->bits[3].p), err.p);
+    BG_LAUNCH_CHECK();
+    ctx->toc(n_ent * (W * 8 + 1 + 8));
+    k_max_u8<<<cdiv(n_ent, 256), 256, 0, ctx->stream>>>(ss->sizes.p, n_ent, mx.p);
+    BG_LAUNCH_CHECK();
+  }
+  uint32_t h_err[2] = {0, 0}, h_mx = 0;
+  BG_HIP(hipMemcpyAsync(h_err, err.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipMemcpyAsync(&h_mx, mx.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_err[0] & 1) { set_error("bg_seqset_build: suffix records not sorted (internal error)"); return BG_EINTERNAL; }
+  if (h_err[0] & 2) { set_error("bg_seqset_build: missing expansion (entry set not closed under pop_front)"); return BG_EINTERNAL; }
+  ss->max_len = h_mx;
+  ctx->tic("seqset_finalize");
+  BG_TRY(seqset_finalize_device(ctx, ss.get()));
+  ctx->toc(n_ent * 3);
+
+  if (stats) {
+    stats->n_records = n_rec;
+    stats->n_tied_records = n_tied;
+    stats->n_entries = n_ent;
+    stats->max_len = ss->max_len;
+  }
+  *out = ss.release();
+  return BG_OK;
+}

@@ -1,0 +1,522 @@
+// prims.hip — context, device-wide scan and LSD radix sort for gfx950 (wave64).
+//
+// The radix sort is the bandwidth-dominant primitive of the build: it orders the canonical k-mer
+// instances (row B of SURVEY §8a; reference = hash tables kmer_count_table.h:54-103) and the suffix
+// records (row D3; reference = std::sort of 14-byte records, repo_seq.cpp:660-684).
+//
+// One pass over an 8-bit digit = 3 kernels:
+//   rs_hist     per-tile digit histogram                      (reads keys once)
+//   scan        exclusive scan of the [bin][tile] table
+//   rs_scatter  stable rank inside the tile via wave64 match-any ballots, LDS-staged reorder, then
+//               coalesced runs to HBM                          (reads keys once, writes once)
+// A one-off rs_digit_census pass finds digits on which all keys agree so those passes are skipped.
+#include "bg_internal.h"
+
+namespace bg {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+const char* last_error_cstr() { return g_err.c_str(); }
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) at %s:%d: %s", int(e), hipGetErrorString(e), file, line, what);
+  return e == hipErrorOutOfMemory ? BG_ENOMEM : BG_ENODEV;
+}
+
+}  // namespace bg
+
+// ------------------------------------------------------------------------------------------------
+// context
+
+int bg_ctx::alloc(size_t bytes, void** out) {
+  bytes = (bytes + 255) & ~size_t(255);
+  auto it = free_blocks.find(bytes);
+  if (it != free_blocks.end()) {
+    *out = it->second;
+    free_blocks.erase(it);
+    cached_bytes -= bytes;
+  } else {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess && cached_bytes) {  // give cached blocks back and retry once
+      trim();
+      e = hipMalloc(out, bytes);
+    }
+    if (e != hipSuccess) {
+      bg::set_error("hipMalloc(%zu) failed: %s (live %zu MiB)", bytes, hipGetErrorString(e), live_bytes >> 20);
+      (void)hipGetLastError();
+      return BG_ENOMEM;
+    }
+  }
+  live[*out] = bytes;
+  live_bytes += bytes;
+  if (live_bytes > peak_bytes) peak_bytes = live_bytes;
+  return BG_OK;
+}
+
+void bg_ctx::release(void* p) {
+  auto it = live.find(p);
+  if (it == live.end()) return;
+  size_t bytes = it->second;
+  live.erase(it);
+  live_bytes -= bytes;
+  free_blocks.emplace(bytes, p);
+  cached_bytes += bytes;
+}
+
+int bg_ctx::trim() {
+  (void)hipStreamSynchronize(stream);
+  for (auto& kv : free_blocks) (void)hipFree(kv.second);
+  free_blocks.clear();
+  cached_bytes = 0;
+  return BG_OK;
+}
+
+hipEvent_t bg_ctx::get_event() {
+  if (!event_pool.empty()) {
+    hipEvent_t e = event_pool.back();
+    event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+void bg_ctx::tic(const char* name) {
+  if (!profiling) return;
+  bg::TimingRec r;
+  r.name = name;
+  r.start = get_event();
+  r.stop = get_event();
+  r.bytes = 0;
+  (void)hipEventRecord(r.start, stream);
+  recs.push_back(r);
+}
+
+void bg_ctx::toc(uint64_t bytes) {
+  if (!profiling || recs.empty()) return;
+  bg::TimingRec& r = recs.back();
+  r.bytes = bytes;
+  (void)hipEventRecord(r.stop, stream);
+}
+
+void bg_ctx::clear_timings() {
+  for (auto& r : recs) {
+    event_pool.push_back(r.start);
+    event_pool.push_back(r.stop);
+  }
+  recs.clear();
+}
+
+namespace bg {
+
+// ------------------------------------------------------------------------------------------------
+// wave / block helpers (wave = 64 lanes)
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint64_t t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// Exclusive scan of one value per thread over a 256-thread block; returns the exclusive prefix and
+// the block total through *total.  sm must hold 4 elements.
+template <class T>
+__device__ __forceinline__ T block_excl_scan_256(T v, T* sm, T* total) {
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  T inc;
+  if constexpr (sizeof(T) == 8) inc = wave_incl_scan_u64(v, lane);
+  else inc = wave_incl_scan_u32(v, lane);
+  if (lane == 63) sm[w] = inc;
+  __syncthreads();
+  T base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    T s = sm[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-wide exclusive scan: reduce -> spine -> apply
+
+constexpr int SC_THREADS = 256;
+constexpr int SC_ITEMS = 8;
+constexpr int SC_TILE = SC_THREADS * SC_ITEMS;  // 2048
+
+template <class OutT>
+__global__ __launch_bounds__(SC_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ in, uint64_t n,
+                                                                 OutT* __restrict__ partial) {
+  __shared__ OutT sm[4];
+  uint64_t base = uint64_t(blockIdx.x) * SC_TILE + uint64_t(threadIdx.x) * SC_ITEMS;
+  OutT s = 0;
+#pragma unroll
+  for (int i = 0; i < SC_ITEMS; ++i)
+    if (base + i < n) s += in[base + i];
+  OutT tot;
+  (void)block_excl_scan_256<OutT>(s, sm, &tot);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// Single block: exclusive scan of up to SC_TILE partials in place; writes total.
+template <class OutT>
+__global__ __launch_bounds__(SC_THREADS) void scan_spine_kernel(OutT* __restrict__ partial, uint32_t np,
+                                                                OutT* __restrict__ total) {
+  __shared__ OutT sm[4];
+  OutT v[SC_ITEMS];
+  uint32_t base = threadIdx.x * SC_ITEMS;
+  OutT s = 0;
+#pragma unroll
+  for (int i = 0; i < SC_ITEMS; ++i) {
+    v[i] = (base + i < np) ? partial[base + i] : 0;
+    s += v[i];
+  }
+  OutT tot;
+  OutT ex = block_excl_scan_256<OutT>(s, sm, &tot);
+#pragma unroll
+  for (int i = 0; i < SC_ITEMS; ++i) {
+    if (base + i < np) partial[base + i] = ex;
+    ex += v[i];
+  }
+  if (threadIdx.x == 0 && total) *total = tot;
+}
+
+template <class OutT>
+__global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(const uint32_t* __restrict__ in, uint64_t n,
+                                                                const OutT* __restrict__ partial,
+                                                                OutT* __restrict__ out) {
+  __shared__ OutT sm[4];
+  uint64_t base = uint64_t(blockIdx.x) * SC_TILE + uint64_t(threadIdx.x) * SC_ITEMS;
+  uint32_t v[SC_ITEMS];
+  OutT s = 0;
+#pragma unroll
+  for (int i = 0; i < SC_ITEMS; ++i) {
+    v[i] = (base + i < n) ? in[base + i] : 0;
+    s += v[i];
+  }
+  OutT tot;
+  OutT ex = block_excl_scan_256<OutT>(s, sm, &tot) + partial[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SC_ITEMS; ++i) {
+    if (base + i < n) out[base + i] = ex;
+    ex += v[i];
+  }
+}
+
+// Scan an array of OutT partials in place (recursive when it does not fit one spine block).
+template <class OutT>
+__global__ __launch_bounds__(SC_THREADS) void scan_reduce_wide_kernel(const OutT* __restrict__ in, uint64_t n,
+                                                                      OutT* __restrict__ partial) {
+  __shared__ OutT sm[4];
+  uint64_t base = uint64_t(blockIdx.x) * SC_TILE + uint64_t(threadIdx.x) * SC_ITEMS;
+  OutT s = 0;
+#pragma unroll
+  for (int i = 0; i < SC_ITEMS; ++i)
+    if (base + i < n) s += in[base + i];
+  OutT tot;
+  (void)block_excl_scan_256<OutT>(s, sm, &tot);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+template <class OutT>
+__global__ __launch_bounds__(SC_THREADS) void scan_apply_wide_kernel(OutT* __restrict__ data, uint64_t n,
+                                                                     const OutT* __restrict__ partial) {
+  __shared__ OutT sm[4];
+  uint64_t base = uint64_t(blockIdx.x) * SC_TILE + uint64_t(threadIdx.x) * SC_ITEMS;
+  OutT v[SC_ITEMS];
+  OutT s = 0;
+#pragma unroll
+  for (int i = 0; i < SC_ITEMS; ++i) {
+    v[i] = (base + i < n) ? data[base + i] : 0;
+    s += v[i];
+  }
+  OutT tot;
+  OutT ex = block_excl_scan_256<OutT>(s, sm, &tot) + partial[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SC_ITEMS; ++i) {
+    if (base + i < n) data[base + i] = ex;
+    ex += v[i];
+  }
+}
+
+template <class OutT>
+static int scan_partials_inplace(bg_ctx* ctx, OutT* d_part, uint64_t np, OutT* d_total) {
+  if (np <= SC_TILE) {
+    scan_spine_kernel<OutT><<<1, SC_THREADS, 0, ctx->stream>>>(d_part, uint32_t(np), d_total);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+  }
+  uint64_t np2 = (np + SC_TILE - 1) / SC_TILE;
+  DevBuf<OutT> p2;
+  BG_TRY(p2.alloc(ctx, np2));
+  scan_reduce_wide_kernel<OutT><<<unsigned(np2), SC_THREADS, 0, ctx->stream>>>(d_part, np, p2.p);
+  BG_LAUNCH_CHECK();
+  BG_TRY(scan_partials_inplace<OutT>(ctx, p2.p, np2, d_total));
+  scan_apply_wide_kernel<OutT><<<unsigned(np2), SC_THREADS, 0, ctx->stream>>>(d_part, np, p2.p);
+  BG_LAUNCH_CHECK();
+  return BG_OK;
+}
+
+template <class OutT>
+static int exclusive_scan_impl(bg_ctx* ctx, const uint32_t* d_in, OutT* d_out, uint64_t n, OutT* d_total) {
+  if (n == 0) {
+    if (d_total) BG_HIP(hipMemsetAsync(d_total, 0, sizeof(OutT), ctx->stream));
+    return BG_OK;
+  }
+  uint64_t nb = (n + SC_TILE - 1) / SC_TILE;
+  DevBuf<OutT> part;
+  BG_TRY(part.alloc(ctx, nb));
+  scan_reduce_kernel<OutT><<<unsigned(nb), SC_THREADS, 0, ctx->stream>>>(d_in, n, part.p);
+  BG_LAUNCH_CHECK();
+  BG_TRY(scan_partials_inplace<OutT>(ctx, part.p, nb, d_total));
+  scan_apply_kernel<OutT><<<unsigned(nb), SC_THREADS, 0, ctx->stream>>>(d_in, n, part.p, d_out);
+  BG_LAUNCH_CHECK();
+  return BG_OK;
+}
+
+int exclusive_scan_u32_to_u64(bg_ctx* ctx, const uint32_t* d_in, uint64_t* d_out, uint64_t n, uint64_t* d_total) {
+  return exclusive_scan_impl<uint64_t>(ctx, d_in, d_out, n, d_total);
+}
+int exclusive_scan_u32(bg_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, uint64_t n, uint32_t* d_total) {
+  return exclusive_scan_impl<uint32_t>(ctx, d_in, d_out, n, d_total);
+}
+
+// ------------------------------------------------------------------------------------------------
+// radix sort
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
+constexpr int RS_BINS = 256;
+
+// Census: for each of the 8 byte positions, the histogram of that byte over all keys.  Lets the
+// host skip passes on which every key agrees.  Grid-stride, LDS histograms, one flush per block.
+__global__ __launch_bounds__(RS_THREADS) void rs_digit_census_kernel(const uint64_t* __restrict__ keys, uint64_t n,
+                                                                     unsigned long long* __restrict__ census) {
+  __shared__ uint32_t h[8][RS_BINS];
+  for (int i = threadIdx.x; i < 8 * RS_BINS; i += RS_THREADS) (&h[0][0])[i] = 0;
+  __syncthreads();
+  uint64_t stride = uint64_t(gridDim.x) * RS_THREADS;
+  for (uint64_t i = uint64_t(blockIdx.x) * RS_THREADS + threadIdx.x; i < n; i += stride) {
+    uint64_t k = keys[i];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) atomicAdd(&h[b][(k >> (8 * b)) & 0xff], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 8 * RS_BINS; i += RS_THREADS) {
+    uint32_t v = (&h[0][0])[i];
+    if (v) atomicAdd(&census[i], (unsigned long long)v);
+  }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift,
+                                                             uint32_t dmask, uint32_t* __restrict__ hist,
+                                                             uint32_t ntiles) {
+  __shared__ uint32_t h[RS_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  uint64_t base = uint64_t(blockIdx.x) * RS_TILE;
+#pragma unroll 4
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    uint64_t idx = base + uint64_t(it) * RS_THREADS + threadIdx.x;
+    if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & dmask], 1u);
+  }
+  __syncthreads();
+  hist[uint64_t(threadIdx.x) * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// Lanes of the wave holding the same 8-bit digit (and the same validity) as this lane.
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
+  uint64_t m = ~0ull;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    bool bit = (d >> b) & 1;
+    uint64_t bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  uint64_t bv = __ballot(valid);
+  m &= valid ? bv : ~bv;
+  return m;
+}
+
+template <class OffT, bool HAS_VAL>
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t* __restrict__ kin,
+                                                                const uint32_t* __restrict__ vin,
+                                                                uint64_t* __restrict__ kout,
+                                                                uint32_t* __restrict__ vout, uint64_t n, int shift,
+                                                                uint32_t dmask, const OffT* __restrict__ offs,
+                                                                uint32_t ntiles) {
+  __shared__ uint64_t skeys[RS_TILE];
+  __shared__ uint32_t svals[HAS_VAL ? RS_TILE : 1];
+  __shared__ uint32_t whist[4][RS_BINS];
+  __shared__ uint32_t binstart[RS_BINS];
+  __shared__ OffT goff[RS_BINS];
+  __shared__ uint32_t scan_sm[4];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint64_t base = uint64_t(blockIdx.x) * RS_TILE;
+  const uint64_t lane_lt = (1ull << lane) - 1;
+
+  for (int i = tid; i < 4 * RS_BINS; i += RS_THREADS) (&whist[0][0])[i] = 0;
+  __syncthreads();
+
+  uint64_t key[RS_ITEMS];
+  uint32_t val[RS_ITEMS];
+  uint16_t rnk[RS_ITEMS];
+  volatile uint32_t* wh = &whist[w][0];
+
+  // phase 1: load (each wave owns a contiguous 1024-key chunk, so tile order == global order) and
+  // rank every key among equal digits seen so far by this wave.
+#pragma unroll
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    uint64_t idx = base + uint64_t(w) * (RS_ITEMS * 64) + uint64_t(it) * 64 + lane;
+    bool valid = idx < n;
+    key[it] = valid ? kin[idx] : ~0ull;
+    if (HAS_VAL) val[it] = valid ? vin[idx] : 0u;
+    uint32_t d = uint32_t(key[it] >> shift) & dmask;
+    uint64_t m = match_digit(d, valid);
+    uint32_t before = wh[d];
+    uint32_t lt = __popcll(m & lane_lt);
+    rnk[it] = uint16_t(before + lt);
+    if (valid && lt == 0) wh[d] = before + uint32_t(__popcll(m));
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+
+  // phase 2: thread = bin.  Wave bases, bin starts inside the tile, global run offsets.
+  {
+    uint32_t c0 = whist[0][tid], c1 = whist[1][tid], c2 = whist[2][tid], c3 = whist[3][tid];
+    uint32_t tot = c0 + c1 + c2 + c3;
+    whist[0][tid] = 0;
+    whist[1][tid] = c0;
+    whist[2][tid] = c0 + c1;
+    whist[3][tid] = c0 + c1 + c2;
+    uint32_t dummy;
+    uint32_t ex = block_excl_scan_256<uint32_t>(tot, scan_sm, &dummy);
+    binstart[tid] = ex;
+    goff[tid] = offs[uint64_t(tid) * ntiles + blockIdx.x] - OffT(ex);
+  }
+  __syncthreads();
+
+  // phase 3: reorder inside LDS.
+#pragma unroll
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    uint64_t idx = base + uint64_t(w) * (RS_ITEMS * 64) + uint64_t(it) * 64 + lane;
+    if (idx < n) {
+      uint32_t d = uint32_t(key[it] >> shift) & dmask;
+      uint32_t pos = binstart[d] + whist[w][d] + rnk[it];
+      skeys[pos] = key[it];
+      if (HAS_VAL) svals[pos] = val[it];
+    }
+  }
+  __syncthreads();
+
+  // phase 4: coalesced runs out.
+  uint32_t cnt = (n - base) < uint64_t(RS_TILE) ? uint32_t(n - base) : uint32_t(RS_TILE);
+  for (uint32_t i = tid; i < cnt; i += RS_THREADS) {
+    uint64_t k = skeys[i];
+    uint32_t d = uint32_t(k >> shift) & dmask;
+    OffT o = goff[d] + OffT(i);
+    kout[o] = k;
+    if (HAS_VAL) vout[o] = svals[i];
+  }
+}
+
+template <class OffT>
+static int radix_sort_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                           uint64_t n, int bit_lo, int bit_hi, bool* in_b) {
+  *in_b = false;
+  if (n <= 1 || bit_hi <= bit_lo) return BG_OK;
+  const bool has_val = vals_a != nullptr;
+  const uint64_t ntiles = (n + RS_TILE - 1) / RS_TILE;
+
+  // census -> which byte-aligned digits actually vary
+  DevBuf<unsigned long long> census;
+  BG_TRY(census.alloc(ctx, 8 * RS_BINS));
+  BG_HIP(hipMemsetAsync(census.p, 0, census.bytes(), ctx->stream));
+  unsigned cgrid = unsigned(ntiles < 2048 ? ntiles : 2048);
+  ctx->tic("radix_census");
+  rs_digit_census_kernel<<<cgrid, RS_THREADS, 0, ctx->stream>>>(keys_a, n, census.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n * 8);
+  std::vector<unsigned long long> hc(8 * RS_BINS);
+  BG_HIP(hipMemcpyAsync(hc.data(), census.p, census.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+
+  DevBuf<uint32_t> hist;
+  DevBuf<OffT> offs;
+  BG_TRY(hist.alloc(ctx, size_t(RS_BINS) * ntiles));
+  BG_TRY(offs.alloc(ctx, size_t(RS_BINS) * ntiles));
+
+  uint64_t* kin = keys_a;
+  uint64_t* kout = keys_b;
+  uint32_t* vin = vals_a;
+  uint32_t* vout = vals_b;
+  bool flipped = false;
+  for (int shift = bit_lo; shift < bit_hi; shift += 8) {
+    int bits = bit_hi - shift < 8 ? bit_hi - shift : 8;
+    uint32_t dmask = (1u << bits) - 1;
+    // skip when every key has the same value in this digit (only checkable for byte-aligned digits)
+    if ((shift & 7) == 0) {
+      const unsigned long long* h = &hc[(shift >> 3) * RS_BINS];
+      // fold bins that alias under dmask
+      bool single = false;
+      unsigned long long folded[RS_BINS] = {0};
+      for (int b = 0; b < RS_BINS; ++b) folded[b & dmask] += h[b];
+      for (int b = 0; b <= int(dmask); ++b)
+        if (folded[b] == n) single = true;
+      if (single) continue;
+    }
+    ctx->tic("radix_hist");
+    rs_hist_kernel<<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(kin, n, shift, dmask, hist.p, uint32_t(ntiles));
+    BG_LAUNCH_CHECK();
+    ctx->toc(n * 8);
+    ctx->tic("radix_scan");
+    BG_TRY(exclusive_scan_impl<OffT>(ctx, hist.p, offs.p, uint64_t(RS_BINS) * ntiles, nullptr));
+    ctx->toc(uint64_t(RS_BINS) * ntiles * (4 + sizeof(OffT)));
+    ctx->tic(has_val ? "radix_scatter_kv" : "radix_scatter_k");
+    if (has_val)
+      rs_scatter_kernel<OffT, true><<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(kin, vin, kout, vout, n, shift,
+                                                                                      dmask, offs.p, uint32_t(ntiles));
+    else
+      rs_scatter_kernel<OffT, false><<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(
+          kin, nullptr, kout, nullptr, n, shift, dmask, offs.p, uint32_t(ntiles));
+    BG_LAUNCH_CHECK();
+    ctx->toc(n * (has_val ? 24 : 16));
+    uint64_t* tk = kin; kin = kout; kout = tk;
+    uint32_t* tv = vin; vin = vout; vout = tv;
+    flipped = !flipped;
+  }
+  *in_b = flipped;
+  return BG_OK;
+}
+
+int radix_sort_u64(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint64_t n,
+                   int bit_lo, int bit_hi, bool* in_b) {
+  if (n < (1ull << 32)) return radix_sort_impl<uint32_t>(ctx, keys_a, keys_b, vals_a, vals_b, n, bit_lo, bit_hi, in_b);
+  return radix_sort_impl<uint64_t>(ctx, keys_a, keys_b, vals_a, vals_b, n, bit_lo, bit_hi, in_b);
+}
+
+}  // namespace bg

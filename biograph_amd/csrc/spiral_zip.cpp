@@ -1,0 +1,224 @@
+// spiral_zip.cpp — writer/reader of the "spiral file" zip container the reference stores a seqset in
+// (modules/io/spiral_file_mmap.cpp:350-457 over the forked vendor/minizip): zip64-flavoured local
+// headers, method 0 (stored), members created through the mmap path carry CRC 0 (:429), JSON members
+// carry their real CRC.  Byte layout of the headers reproduces what the reference's goldens contain
+// (golden/e_coli_10000snp.bg/seqset, father_lambda.bg/seqset).
+#include <errno.h>
+#include <string.h>
+#include <time.h>
+
+#include <fstream>
+#include <random>
+
+#include "bg_internal.h"
+
+namespace bg {
+
+static uint32_t crc32_of(const std::string& s) {
+  static uint32_t table[256];
+  static bool init = false;
+  if (!init) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      table[i] = c;
+    }
+    init = true;
+  }
+  uint32_t c = 0xFFFFFFFFu;
+  for (unsigned char ch : s) c = table[(c ^ ch) & 0xff] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}
+
+static void put16(std::string& o, uint16_t v) { o.push_back(char(v & 0xff)); o.push_back(char(v >> 8)); }
+static void put32(std::string& o, uint32_t v) { for (int i = 0; i < 4; ++i) o.push_back(char((v >> (8 * i)) & 0xff)); }
+static void put64(std::string& o, uint64_t v) { for (int i = 0; i < 8; ++i) o.push_back(char((v >> (8 * i)) & 0xff)); }
+
+std::string make_uuid() {
+  std::random_device rd;
+  std::mt19937_64 g((uint64_t(rd()) << 32) ^ rd() ^ uint64_t(time(nullptr)));
+  uint64_t a = g(), b = g();
+  char buf[40];
+  snprintf(buf, sizeof buf, "%08x-%04x-%04x-%04x-%012llx", uint32_t(a >> 32), uint32_t((a >> 16) & 0xffff),
+           uint32_t(a & 0xffff), uint32_t(b >> 48), (unsigned long long)(b & 0xffffffffffffull));
+  return buf;
+}
+
+int spiral_zip_write(const char* path, const std::vector<ZipPart>& parts) {
+  FILE* f = fopen(path, "wb");
+  if (!f) { set_error("Could not open zip for writing: %s: %s", path, strerror(errno)); return BG_EIO; }
+  struct Cd { std::string name; uint32_t crc; uint64_t size, offset; };
+  std::vector<Cd> cds;
+  uint64_t pos = 0;
+  for (const ZipPart& p : parts) {
+    uint64_t size = p.data.size();
+    bool big = size >= 0xffffffffull;
+    uint32_t crc = p.raw_crc0 ? 0u : crc32_of(p.data);
+    std::string h;
+    put32(h, 0x04034b50);
+    put16(h, 45);  // version needed (zip64)
+    put16(h, 0);   // flags
+    put16(h, 0);   // method: stored
+    put16(h, 0);   // time
+    put16(h, 0);   // date
+    put32(h, crc);
+    put32(h, big ? 0xffffffffu : uint32_t(size));
+    put32(h, big ? 0xffffffffu : uint32_t(size));
+    put16(h, uint16_t(p.name.size()));
+    put16(h, 20);  // zip64 extra placeholder
+    h += p.name;
+    put16(h, 0x0001);
+    put16(h, 16);
+    put64(h, big ? size : 0);
+    put64(h, big ? size : 0);
+    if (fwrite(h.data(), 1, h.size(), f) != h.size() ||
+        (size && fwrite(p.data.data(), 1, size, f) != size)) {
+      set_error("write error on %s: %s", path, strerror(errno));
+      fclose(f);
+      return BG_EIO;
+    }
+    cds.push_back(Cd{p.name, crc, size, pos});
+    pos += h.size() + size;
+  }
+  uint64_t cd_start = pos;
+  std::string cd;
+  for (const Cd& c : cds) {
+    bool big_size = c.size >= 0xffffffffull, big_off = c.offset >= 0xffffffffull;
+    std::string extra;
+    if (big_size || big_off) {
+      std::string body;
+      if (big_size) { put64(body, c.size); put64(body, c.size); }
+      if (big_off) put64(body, c.offset);
+      put16(extra, 0x0001);
+      put16(extra, uint16_t(body.size()));
+      extra += body;
+    }
+    put32(cd, 0x02014b50);
+    put16(cd, (big_size || big_off) ? 45 : 0);   // version made by
+    put16(cd, (big_size || big_off) ? 45 : 20);  // version needed
+    put16(cd, 0);
+    put16(cd, 0);
+    put16(cd, 0);
+    put16(cd, 0);
+    put32(cd, c.crc);
+    put32(cd, big_size ? 0xffffffffu : uint32_t(c.size));
+    put32(cd, big_size ? 0xffffffffu : uint32_t(c.size));
+    put16(cd, uint16_t(c.name.size()));
+    put16(cd, uint16_t(extra.size()));
+    put16(cd, 0);
+    put16(cd, 0);
+    put16(cd, 0);
+    put32(cd, 0);
+    put32(cd, big_off ? 0xffffffffu : uint32_t(c.offset));
+    cd += c.name;
+    cd += extra;
+  }
+  uint64_t cd_size = cd.size();
+  bool z64 = cd_start >= 0xffffffffull || cds.size() >= 0xffff;
+  if (z64) {
+    put32(cd, 0x06064b50);
+    put64(cd, 44);
+    put16(cd, 45);
+    put16(cd, 45);
+    put32(cd, 0);
+    put32(cd, 0);
+    put64(cd, cds.size());
+    put64(cd, cds.size());
+    put64(cd, cd_size);
+    put64(cd, cd_start);
+    put32(cd, 0x07064b50);
+    put32(cd, 0);
+    put64(cd, cd_start + cd_size);
+    put32(cd, 1);
+  }
+  put32(cd, 0x06054b50);
+  put16(cd, 0);
+  put16(cd, 0);
+  put16(cd, z64 ? 0xffff : uint16_t(cds.size()));
+  put16(cd, z64 ? 0xffff : uint16_t(cds.size()));
+  put32(cd, uint32_t(cd_size));
+  put32(cd, z64 ? 0xffffffffu : uint32_t(cd_start));
+  put16(cd, 0);
+  bool ok = fwrite(cd.data(), 1, cd.size(), f) == cd.size();
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) { set_error("write error on %s: %s", path, strerror(errno)); return BG_EIO; }
+  return BG_OK;
+}
+
+static uint16_t get16(const unsigned char* p) { return uint16_t(p[0] | (p[1] << 8)); }
+static uint32_t get32(const unsigned char* p) { return uint32_t(p[0]) | (uint32_t(p[1]) << 8) | (uint32_t(p[2]) << 16) | (uint32_t(p[3]) << 24); }
+static uint64_t get64(const unsigned char* p) { return uint64_t(get32(p)) | (uint64_t(get32(p + 4)) << 32); }
+
+int spiral_zip_read(const char* path, std::map<std::string, std::string>* parts) {
+  std::ifstream in(path, std::ios::binary | std::ios::ate);
+  if (!in) { set_error("Could not open %s", path); return BG_EIO; }
+  uint64_t fsize = uint64_t(in.tellg());
+  auto read_at = [&](uint64_t off, uint64_t len, std::string* out) -> bool {
+    if (off + len > fsize) return false;
+    out->resize(len);
+    in.seekg(std::streamoff(off));
+    in.read(&(*out)[0], std::streamsize(len));
+    return bool(in);
+  };
+  // end of central directory: scan the tail
+  uint64_t tail_len = fsize < 66000 ? fsize : 66000;
+  std::string tail;
+  if (!read_at(fsize - tail_len, tail_len, &tail)) { set_error("%s: short file", path); return BG_EIO; }
+  int64_t eocd = -1;
+  for (int64_t i = int64_t(tail.size()) - 22; i >= 0; --i)
+    if (get32(reinterpret_cast<const unsigned char*>(tail.data()) + i) == 0x06054b50) { eocd = i; break; }
+  if (eocd < 0) { set_error("%s: not a zip file", path); return BG_EIO; }
+  const unsigned char* e = reinterpret_cast<const unsigned char*>(tail.data()) + eocd;
+  uint64_t n_entries = get16(e + 10), cd_size = get32(e + 12), cd_start = get32(e + 16);
+  if (n_entries == 0xffff || cd_start == 0xffffffffu) {
+    // zip64 locator sits right before the EOCD
+    if (eocd < 20 || get32(e - 20) != 0x07064b50) { set_error("%s: missing zip64 locator", path); return BG_EIO; }
+    uint64_t z64_off = get64(e - 20 + 8);
+    std::string z;
+    if (!read_at(z64_off, 56, &z) || get32(reinterpret_cast<const unsigned char*>(z.data())) != 0x06064b50) {
+      set_error("%s: bad zip64 end record", path);
+      return BG_EIO;
+    }
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(z.data());
+    n_entries = get64(zp + 32);
+    cd_size = get64(zp + 40);
+    cd_start = get64(zp + 48);
+  }
+  std::string cd;
+  if (!read_at(cd_start, cd_size, &cd)) { set_error("%s: bad central directory", path); return BG_EIO; }
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(cd.data());
+  const unsigned char* pend = p + cd.size();
+  for (uint64_t i = 0; i < n_entries; ++i) {
+    if (p + 46 > pend || get32(p) != 0x02014b50) { set_error("%s: bad central entry", path); return BG_EIO; }
+    uint16_t method = get16(p + 10);
+    uint64_t csize = get32(p + 20), usize = get32(p + 24);
+    uint16_t nlen = get16(p + 28), elen = get16(p + 30), clen = get16(p + 32);
+    uint64_t off = get32(p + 42);
+    std::string name(reinterpret_cast<const char*>(p + 46), nlen);
+    const unsigned char* x = p + 46 + nlen;
+    const unsigned char* xend = x + elen;
+    while (x + 4 <= xend) {
+      uint16_t id = get16(x), sz = get16(x + 2);
+      const unsigned char* b = x + 4;
+      if (id == 0x0001) {
+        if (usize == 0xffffffffu && b + 8 <= x + 4 + sz) { usize = get64(b); b += 8; }
+        if (csize == 0xffffffffu && b + 8 <= x + 4 + sz) { csize = get64(b); b += 8; }
+        if (off == 0xffffffffu && b + 8 <= x + 4 + sz) { off = get64(b); b += 8; }
+      }
+      x += 4 + sz;
+    }
+    if (method != 0) { set_error("%s: member %s is compressed", path, name.c_str()); return BG_EIO; }
+    std::string lh;
+    if (!read_at(off, 30, &lh)) { set_error("%s: bad local header", path); return BG_EIO; }
+    const unsigned char* l = reinterpret_cast<const unsigned char*>(lh.data());
+    if (get32(l) != 0x04034b50) { set_error("%s: bad local header signature", path); return BG_EIO; }
+    uint64_t data_off = off + 30 + get16(l + 26) + get16(l + 28);
+    std::string data;
+    if (!read_at(data_off, usize, &data)) { set_error("%s: member %s truncated", path, name.c_str()); return BG_EIO; }
+    (*parts)[name] = std::move(data);
+    p += 46 + nlen + elen + clen;
+  }
+  return BG_OK;
+}
+
+}  // namespace bg

@@ -1,0 +1,183 @@
+/* bgseq.h — C ABI of libbgseq.so: MI355X-native seqset construction and overlap walk.
+ *
+ * The reference (spiralgenetics/biograph) exposes no FFI for this path: it is linked C++
+ * (SURVEY.md §8b).  Each entry point below names the reference seam (file:line under the
+ * reference tree) whose work it replaces; INTEGRATION.md shows the C++ façade a maintainer
+ * would put behind `SEQSETMain::run` / `seqset_range` to call it.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; `d_` parameters are DEVICE pointers (hipMalloc'ed or the
+ *     data_ptr of a torch tensor on the same device), `h_` parameters are HOST pointers;
+ *   - every call returns 0 on success or a negative BG_E* code; bg_last_error() returns a
+ *     thread-local message for the last failure on the calling thread;
+ *   - all device work of a context is issued on the HIP stream given at bg_ctx_create() and the
+ *     call returns after that work has completed unless stated otherwise;
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails
+ *     with BG_ENODEV.
+ */
+#ifndef BGSEQ_H_
+#define BGSEQ_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BG_OK 0
+#define BG_EINVAL (-1)   /* bad argument (reference: io_exception / CHECK failure)            */
+#define BG_ENODEV (-2)   /* no HIP device / HIP runtime error                                  */
+#define BG_ENOMEM (-3)   /* device or host allocation failed                                   */
+#define BG_EBADBASE (-4) /* read contains a character outside ACGTN (dna_base.h:54 throws)     */
+#define BG_EIO (-5)      /* file I/O error                                                     */
+#define BG_EINTERNAL (-6)/* invariant violated (reference: "Missing expansion?" builder.cpp:96)*/
+
+#define BG_ABI_VERSION 1
+
+typedef struct bg_ctx bg_ctx;         /* device context: stream + workspace cache              */
+typedef struct bg_reads bg_reads;     /* 2-bit packed reads resident in HBM                    */
+typedef struct bg_kmerset bg_kmerset; /* filtered canonical k-mer set resident in HBM          */
+typedef struct bg_seqset bg_seqset;   /* seqset arrays resident in HBM (+ host copies on demand)*/
+
+int bg_abi_version(void);
+const char* bg_last_error(void);
+
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the default
+ * stream. */
+int bg_ctx_create(int device, void* stream, bg_ctx** out);
+void bg_ctx_destroy(bg_ctx* ctx);
+/* Releases cached workspace blocks back to the driver. */
+int bg_ctx_trim(bg_ctx* ctx);
+
+/* Per-stage device time of the most recent build call on this context (HIP events on the
+ * context's stream).  Names follow runtime_stats stages of biograph_create.cpp:540-783 plus the
+ * kernel families.  Fills up to cap entries; returns the number available. */
+typedef struct bg_timing {
+  char name[48];
+  double ms;        /* summed device time                                                      */
+  uint64_t launches;/* kernel launches accounted                                               */
+  uint64_t bytes;   /* algorithmic bytes moved by those launches, 0 if n/a  */
+} bg_timing;
+int bg_ctx_timings(bg_ctx* ctx, bg_timing* out, int cap);
+/* Enable (1) / disable (0) per-kernel-family event timing (off by default; costs event pairs). */
+int bg_ctx_set_profiling(bg_ctx* ctx, int on);
+
+/* ---- S1: import.  Replaces read_importer + dna_sequence packing
+ * (modules/build_seqset/read_importer.h:65-141, modules/bio_base/dna_sequence.h:97).
+ * d_seq: concatenated read characters (ACGTN, either case for ACGT); d_offs: n_reads+1 offsets. */
+int bg_pack_reads(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n_reads,
+                  bg_reads** out);
+/* Convenience for host callers (CLI, tests): uploads then packs. */
+int bg_pack_reads_host(bg_ctx* ctx, const uint8_t* h_seq, const uint64_t* h_offs, uint64_t n_reads,
+                       bg_reads** out);
+uint64_t bg_reads_count(const bg_reads* r);
+uint64_t bg_reads_total_bases(const bg_reads* r); /* sum of lengths (0-length = dropped read)   */
+uint32_t bg_reads_max_len(const bg_reads* r);
+/* Unpacks to ASCII on the host: h_seq must hold bg_reads_total_bases() bytes, h_offs n+1. */
+int bg_reads_download(bg_ctx* ctx, const bg_reads* r, uint8_t* h_seq, uint64_t* h_offs);
+void bg_reads_free(bg_reads* r);
+
+/* ---- S2: k-mer counting + filter.  Replaces kmer_counter + kmerizer::run + kmer_set
+ * (modules/build_seqset/kmer_counter.h:123-326, modules/bio_mapred/kmerize_bf.cpp:267-429).
+ * Keeps canonical k-mers with fwd+rev >= min_count; flags bit0 = fwd_starts_read,
+ * bit1 = rev_starts_read (kmer_set.h:20-21).  1 <= k <= 31. */
+int bg_kmer_count(bg_ctx* ctx, const bg_reads* reads, int k, uint32_t min_count, bg_kmerset** out);
+uint64_t bg_kmerset_size(const bg_kmerset* ks);
+uint64_t bg_kmerset_distinct(const bg_kmerset* ks);  /* distinct canonical k-mers before filter */
+uint64_t bg_kmerset_instances(const bg_kmerset* ks); /* k-mer instances counted (N_kmers)       */
+/* Sorted canonical k-mers, their flags and total counts, to host arrays of bg_kmerset_size(). */
+int bg_kmerset_download(bg_ctx* ctx, const bg_kmerset* ks, uint64_t* h_kmers, uint8_t* h_flags,
+                        uint32_t* h_counts);
+void bg_kmerset_free(bg_kmerset* ks);
+
+/* ---- S3: read correction.  Replaces correct_reads::correct + fast_read_correct
+ * (modules/build_seqset/correct_reads.cpp:154-231, modules/bio_base/fast_read_correct.cpp:16-182).
+ * Dropped reads come back with length 0.  max_corrections <= 8. */
+typedef struct bg_correct_params {
+  uint32_t max_corrections;   /* --max-corrections, default 8   (biograph_create.cpp:288)      */
+  uint32_t min_good_run;      /* --min-good-run, default 2                                      */
+  float trim_after_portion;   /* --trim-after-portion, default 0.7f (parsed as float, :489)     */
+} bg_correct_params;
+typedef struct bg_correct_stats {
+  uint64_t corrected_reads, corrected_bases, failed, modified, modified_bases, truncated,
+      dropped_bases;
+} bg_correct_stats;
+int bg_correct_reads(bg_ctx* ctx, const bg_reads* reads, const bg_kmerset* ks,
+                     const bg_correct_params* params, bg_reads** out, bg_correct_stats* stats);
+
+/* ---- S4+S5: seqset from corrected reads.  Replaces part_repo/expander/builder
+ * (modules/build_seqset/expand.cpp:418,581; builder.cpp:8,207; bio_base/seqset.cpp:19-44,113-129).
+ * Result = prefix-free maxima of all suffixes of all reads and their reverse complements
+ * (SURVEY row E), with sizes/shared/prev_{ACGT} rank vectors/fixed. */
+typedef struct bg_build_stats {
+  uint64_t n_reads, n_bases;         /* input                                                  */
+  uint64_t n_kmers, n_distinct_kmers, n_kept_kmers;
+  uint64_t n_corrected_reads, n_corrected_bases;
+  uint64_t n_records;                /* suffix records sorted (N_rec)                          */
+  uint64_t n_tied_records;           /* records that needed refinement beyond the first word  */
+  uint64_t n_entries;                /* N_ent                                                  */
+  uint32_t max_len;
+} bg_build_stats;
+int bg_seqset_build(bg_ctx* ctx, const bg_reads* corrected, int cover_k, bg_seqset** out,
+                    bg_build_stats* stats);
+
+/* Whole `biograph create` data path on device-resident input: S1..S5
+ * (SEQSETMain::run, modules/biograph/biograph_create.cpp:431-783 minus readmap/metadata). */
+typedef struct bg_create_params {
+  int kmer_size;               /* --kmer-size 30        */
+  uint32_t min_kmer_count;     /* --min-kmer-count 5    */
+  bg_correct_params correct;
+} bg_create_params;
+void bg_create_params_default(bg_create_params* p);
+int bg_create(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n_reads,
+              const bg_create_params* p, bg_seqset** out, bg_build_stats* stats);
+
+/* ---- seqset object (modules/bio_base/seqset.h:35-128). */
+uint64_t bg_seqset_size(const bg_seqset* ss);
+uint32_t bg_seqset_max_len(const bg_seqset* ss);
+/* Host copies of the payload parts exactly as stored in the spiral container (format 1.1.0):
+ * part in {"fixed","entry_sizes/elements","shared/elements","prev_A/bits","prev_A/subaccum",
+ * "prev_A/accum", ... "prev_T/accum"}.  Call with h_out=NULL to get the byte size in *size. */
+int bg_seqset_part(bg_ctx* ctx, const bg_seqset* ss, const char* part, void* h_out, uint64_t* size);
+/* Unpacked arrays (uint32 per entry) for tests / SDK: sizes and shared. */
+int bg_seqset_arrays(bg_ctx* ctx, const bg_seqset* ss, uint32_t* h_sizes, uint32_t* h_shared);
+/* Sequences of entries [first, first+count) as ASCII (seqset_range::sequence, seqset.cpp:609). */
+int bg_seqset_entries(bg_ctx* ctx, const bg_seqset* ss, uint64_t first, uint64_t count,
+                      uint8_t* h_seq, uint64_t* h_offs);
+/* Spiral zip container (modules/io/spiral_file_mmap.cpp:350-457, spiral_file.cpp:194-222).
+ * argv/argc go to file_info.json "command_line". */
+int bg_seqset_write(bg_ctx* ctx, const bg_seqset* ss, const char* path, int argc,
+                    const char* const* argv);
+int bg_seqset_open(bg_ctx* ctx, const char* path, bg_seqset** out);
+/* Upload from host arrays (tests, goldens in the old raw-uint8 layout). bits: 4 arrays of
+ * ceil(n/64) words. */
+int bg_seqset_from_arrays(bg_ctx* ctx, uint64_t n, const uint32_t* h_sizes, const uint32_t* h_shared,
+                          const uint64_t* const h_bits[4], bg_seqset** out);
+void bg_seqset_free(bg_seqset* ss);
+
+/* ---- G1: batched walk primitives over a resident seqset.  Replace seqset_range::push_front
+ * (seqset.cpp:319-338), push_front_drop (:350-429) and seqset::find (:146-155).
+ * All arrays are DEVICE pointers of n elements; base in 0..3 (A,C,G,T).  Invalid result ranges
+ * are (0,0,0) for push_front_drop and begin>=end for push_front, as in the reference. */
+int bg_push_front_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n, const uint64_t* d_begin,
+                        const uint64_t* d_end, const uint32_t* d_size, const uint8_t* d_base,
+                        uint64_t* d_obegin, uint64_t* d_oend, uint32_t* d_osize);
+int bg_push_front_drop_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n, const uint64_t* d_begin,
+                             const uint64_t* d_end, const uint32_t* d_size, const uint8_t* d_base,
+                             const uint32_t* d_min_ctx, uint64_t* d_obegin, uint64_t* d_oend,
+                             uint32_t* d_osize);
+/* find: queries are concatenated ACGT strings (device), n+1 offsets; result ranges (begin,end). */
+int bg_find_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n, const uint8_t* d_seq,
+                  const uint64_t* d_offs, uint64_t* d_obegin, uint64_t* d_oend);
+
+/* ---- device memory helpers for hosts without their own allocator (CLI, ctypes tests). */
+int bg_dev_alloc(bg_ctx* ctx, uint64_t bytes, void** d_out);
+int bg_dev_free(bg_ctx* ctx, void* d_ptr);
+int bg_dev_upload(bg_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes);
+int bg_dev_download(bg_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BGSEQ_H_ */

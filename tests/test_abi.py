@@ -1,0 +1,49 @@
+"""C-ABI surface checks that need no GPU: the library builds, loads, exports every symbol
+include/bgseq.h declares, and fails loudly (no CPU fallback) when no HIP device is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from biograph_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(capi.LIB_PATH):
+        from biograph_amd import build
+        build.build()
+    return capi.lib()
+
+
+def test_header_symbols_are_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "bgseq.h")).read()
+    declared = set(re.findall(r"\b(bg_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(capi.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.bg_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_device(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    rc = lib.bg_ctx_create(0, None, C.byref(h))
+    assert rc == -2  # BG_ENODEV
+    assert b"no HIP device" in lib.bg_last_error()
+    import biograph_amd
+    with pytest.raises(biograph_amd.BgError):
+        biograph_amd.Context(0)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "biograph_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "bgoracle" not in text, f

@@ -1,0 +1,231 @@
+"""GPU parity tests: every stage of the HIP path, called through the C ABI (libbgseq.so), compared
+bit-for-bit with the CPU oracle on the same seeded inputs and with the reference's golden files."""
+import os
+
+import numpy as np
+import pytest
+
+import biograph_amd as bg
+from oracle import oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = bg.Context(0)
+    yield c
+    c.close()
+
+
+def _oracle_stage(reads, k, min_count, maxc=8, mgr=2, trim=0.7):
+    seq, offs = O.pack_strings(reads)
+    ks = O.KmerSet.count(seq, offs, k, min_count)
+    cseq, coffs, keep, stats = O.correct_reads(ks, seq, offs, maxc, mgr, trim)
+    return ks, cseq, coffs, keep, stats
+
+
+def test_pack_roundtrip_and_errors(ctx):
+    reads = util.synth_reads(3, n_reads=500, read_len=97, var_len=True, n_rate=0.0, err=0.0)
+    reads += ["", "A", "acgtACGT", "T" * 255]
+    r = ctx.pack_reads(reads)
+    seq, offs = r.download()
+    assert O.unpack_strings(seq, offs) == [s.upper() for s in reads]
+    assert r.max_len == 255 and r.total_bases == sum(map(len, reads))
+    with pytest.raises(bg.BgError) as e:
+        ctx.pack_reads(["ACGTXACGT"])
+    assert e.value.code == -4
+    with pytest.raises(bg.BgError):
+        ctx.pack_reads(["A" * 256])
+    empty = ctx.pack_reads([])
+    assert len(empty) == 0
+
+
+@pytest.mark.parametrize("seed,k,mc,rl,nrate", [(1, 30, 5, 150, 0.001), (2, 15, 3, 80, 0.01), (3, 31, 2, 100, 0.0),
+                                                (4, 5, 1, 40, 0.02), (5, 21, 4, 255, 0.002)])
+def test_kmer_count_matches_oracle(ctx, seed, k, mc, rl, nrate):
+    reads = util.synth_reads(seed, genome_len=4000, n_reads=1500, read_len=rl, err=0.01, n_rate=nrate, var_len=True)
+    seq, offs = O.pack_strings(reads)
+    oks = O.KmerSet.count(seq, offs, k, mc)
+    ok, of, ofw, orv = oks.arrays()
+    r = ctx.pack_reads(reads)
+    ks = ctx.kmer_count(r, k, mc)
+    gk, gf, gc = ks.download()
+    assert len(gk) == len(ok)
+    assert (gk == ok).all()
+    assert (gf == of).all()
+    assert (gc == ofw + orv).all()
+    allk = O.KmerSet.count(seq, offs, k, 1, keep_all=True)
+    assert ks.distinct == len(allk)
+    a = allk.arrays()
+    assert ks.instances >= int(a[2].sum() + a[3].sum())
+
+
+@pytest.mark.parametrize("seed,k,err,nrate,maxc,mgr,trim", [(1, 30, 0.004, 0.0005, 8, 2, 0.7),
+                                                            (2, 15, 0.03, 0.01, 8, 2, 0.7),
+                                                            (3, 21, 0.02, 0.005, 2, 3, 0.9),
+                                                            (4, 12, 0.05, 0.02, 8, 0, 0.0),
+                                                            (5, 30, 0.01, 0.0, 0, 2, 0.5)])
+def test_correction_matches_oracle(ctx, seed, k, err, nrate, maxc, mgr, trim):
+    reads = util.synth_reads(seed, genome_len=3000, n_reads=2000, read_len=120, err=err, n_rate=nrate, var_len=True)
+    oks, cseq, coffs, keep, stats = _oracle_stage(reads, k, 3, maxc, mgr, trim)
+    r = ctx.pack_reads(reads)
+    ks = ctx.kmer_count(r, k, 3)
+    c, st = ctx.correct_reads(r, ks, maxc, mgr, trim)
+    gseq, goffs = c.download()
+    assert (goffs == coffs).all()
+    assert (gseq == cseq).all()
+    for key in ("corrected_reads", "corrected_bases", "failed", "modified", "modified_bases", "truncated",
+                "dropped_bases"):
+        assert st[key] == stats[key], key
+
+
+def _check_seqset_against_oracle(ss, reads_corrected):
+    seq, offs = O.pack_strings(reads_corrected)
+    ent = O.Entries.build(seq, offs, "simple")
+    oss = O.Seqset.from_entries(ent)
+    assert ss.size() == len(ent)
+    assert ss.entries() == ent.strings()
+    s, sh = ss.arrays()
+    os_, osh = oss.arrays()
+    assert (s == os_).all() and (sh == osh).all()
+    want = oss.parts()
+    got = ss.parts()
+    for name in bg.PART_NAMES:
+        assert got[name] == want[name], name
+    return oss
+
+
+@pytest.mark.parametrize("seed,alphabet,K,rl,var", [(1, "ACGT", 30, 150, False), (2, "AC", 8, 70, True),
+                                                     (3, "A", 5, 40, True), (4, "ACGT", 12, 100, True),
+                                                     (5, "AT", 31, 255, True), (6, "ACGT", 4, 33, True),
+                                                     (7, "AG", 20, 200, False)])
+def test_seqset_build_matches_oracle(ctx, seed, alphabet, K, rl, var):
+    """Entry set, sizes, shared, prev bits, rank index and packed parts; low-entropy alphabets force
+    long equal prefixes (tie refinement rounds) and tandem repeats force self-covering reads."""
+    reads = util.synth_reads(seed, genome_len=1500, n_reads=400, read_len=rl, err=0.01, n_rate=0.0,
+                             alphabet=alphabet, var_len=var, repeat=(7, 20))
+    r = ctx.pack_reads(reads)
+    ss, st = ctx.build_seqset(r, K)
+    _check_seqset_against_oracle(ss, reads)
+    assert st["n_entries"] == ss.size() and st["n_records"] >= st["n_entries"]
+
+
+def test_builder_test_known_answers(ctx):
+    # modules/build_seqset/builder_test.cpp:52-123 through the HIP path
+    t, trc = O.tseq, O.tseq_rc
+    ss, _ = ctx.build_seqset(ctx.pack_reads([t("a")]), 30)
+    assert ss.entries() == ["AAAATTAC", "AAATTAC", "AATTAC", "AATTTTAG", "AC", "AG", "ATTAC", "ATTTTAG",
+                            "CTAAAATTAC", "GTAATTTTAG", "TAAAATTAC", "TAATTTTAG", "TAC", "TAG", "TTAC", "TTAG",
+                            "TTTAG", "TTTTAG"]
+    for reads, n in [([t("abcdefg")], 129), ([t("abcd"), t("cdef"), trc("efgh")], 152),
+                     ([t("ab"), t("bc"), t("cd"), t("be")], 91), ([t("abc"), t("cde")], 89),
+                     ([t("abc"), t("efg")], 99)]:
+        for K in (5, 30):
+            ss, _ = ctx.build_seqset(ctx.pack_reads(reads), K)
+            assert ss.size() == n
+
+
+def test_empty_and_degenerate_inputs(ctx):
+    ss, st = ctx.create([])
+    assert ss.size() == 0 and ss.part("fixed") == bytes(40)
+    ss, st = ctx.create(["ACGT"])  # shorter than k: nothing survives
+    assert ss.size() == 0
+    ss, _ = ctx.build_seqset(ctx.pack_reads(["A"]), 30)
+    assert ss.entries() == ["A", "T"]
+    ss, _ = ctx.build_seqset(ctx.pack_reads(["A" * 255, "A" * 255]), 30)
+    _check_seqset_against_oracle(ss, ["A" * 255, "A" * 255])
+
+
+def test_create_reproduces_golden_ecoli(ctx, golden_dir, tmp_path):
+    """golden/e_coli_10000snp.fq -> golden/e_coli_10000snp.bg/seqset, whole create path on the GPU."""
+    reads = O.read_fastq(golden_dir + "/e_coli_10000snp/reads.fq")
+    ss, st = ctx.create(reads)
+    assert st["n_kept_kmers"] == 7108 and st["n_corrected_reads"] == 8444 and st["n_corrected_bases"] == 288464
+    assert st["n_entries"] == 19935
+    d = O.load_seqset_zip(golden_dir + "/e_coli_10000snp/seqset")
+    s, sh = ss.arrays()
+    assert (s == d["sizes"]).all() and (sh == d["shared"]).all()
+    assert ss.part("fixed") == d["raw"]["fixed"]
+    for ch in "ACGT":
+        for w in ("bits", "subaccum", "accum"):
+            assert ss.part("prev_%s/%s" % (ch, w)) == d["raw"]["prev_%s/%s" % (ch, w)]
+    assert ss.entries() == O.decode_entries(d)
+    # container round trip + SDK answers of python/biograph/seqset_test.py
+    path = str(tmp_path / "seqset")
+    ss.write(path, ["biograph", "create", "--in", "reads.fq"])
+    members = O.read_spiral_members(path)
+    for name, blob in ss.parts().items():
+        assert members[name] == blob
+    assert members["seqset.json"] == b'{"num_entries":19935}'
+    ss2 = ctx.open_seqset(path)
+    assert ss2.parts() == ss.parts()
+    g = ss2.find("GATTACA")
+    assert repr(g) == "<SeqsetEntry 11076-11077: GATTACA>"
+    assert ss2.find("GATTACAGATTACA") is None
+    assert g.push_front("G") is None
+    assert g.push_front("T") == ss2.find("TGATTACA")
+    assert g.push_front_drop("G").sequence() == "GGATTAC"
+    assert g.push_front_drop("G", 8) is None and g.push_front_drop("G", 7) is None
+    assert g.push_front_drop("G", 6).sequence() == "GGATTAC"
+    assert ss2.get_entry_by_id(6645).sequence() == "CCCCACCTGACGCGAAAGGATCGCAGT"
+
+
+def test_open_lambda_golden_current_format(ctx, golden_dir):
+    ss = ctx.open_seqset(golden_dir + "/father_lambda/seqset")
+    d = O.load_seqset_zip(golden_dir + "/father_lambda/seqset")
+    assert ss.size() == 98006 and ss.max_len == 150
+    for name, blob in ss.parts().items():
+        assert blob == d["raw"][name], name
+    want = O.decode_entries(d)
+    assert ss.entries(0, 2000) == want[:2000]
+    assert ss.entries(97000, 1006) == want[97000:]
+
+
+def test_walk_matches_oracle(ctx, golden_dir):
+    d = O.load_seqset_zip(golden_dir + "/father_lambda/seqset")
+    oss = O.Seqset.from_arrays(d["sizes"], d["shared"], d["bits"])
+    ss = ctx.seqset_from_arrays(d["sizes"], d["shared"], d["bits"])
+    n = d["n"]
+    rng = np.random.default_rng(9)
+    q = 200_000
+    begin = rng.integers(0, n, q).astype(np.uint64)
+    end = begin + 1
+    size = d["sizes"][begin.astype(np.int64)].astype(np.uint32)
+    for rounds in range(6):
+        base = rng.integers(0, 4, len(begin)).astype(np.uint8)
+        minctx = rng.integers(0, 120, len(begin)).astype(np.uint32)
+        ob, oe, osz = oss.push_front_drop(begin, end, size, base, minctx)
+        gb, ge, gs = ss.push_front_drop_batch(begin, end, size, base, minctx)
+        assert (gb == ob).all() and (ge == oe).all() and (gs == osz).all()
+        pb, pe, ps = oss.push_front(begin, end, size, base)
+        hb, he, hs = ss.push_front_batch(begin, end, size, base)
+        assert (hb == pb).all() and (he == pe).all() and (hs == ps).all()
+        ok = oe > ob
+        begin, end, size = ob[ok], oe[ok], osz[ok]
+        assert len(begin) > 0
+    ent = O.decode_entries(d)
+    qs = [ent[int(i)][int(j):int(j) + 40] for i, j in zip(rng.integers(0, n, 500), rng.integers(0, 60, 500))]
+    qs += ["GATTACA" * 3, "", "A"]
+    fb, fe = ss.find_batch(qs)
+    for s, b, e in zip(qs, fb, fe):
+        wb, we, _ = oss.find(s)
+        assert (int(b), int(e)) == (wb, we) or (b >= e and wb >= we)
+
+
+def test_synthetic_wgs_shape_full_path(ctx):
+    """30x 150 bp paired reads with errors and N's through the whole create path, vs the oracle."""
+    import torch
+    from biograph_amd import synth
+    seq, offs, n = synth.make_reads(genome_len=20000, coverage=30, read_len=150, seed=11, device="cpu")
+    reads = O.unpack_strings(seq.numpy(), offs.numpy().astype(np.uint64))
+    oss, oent, info = O.build_seqset_from_fastq_reads(reads)
+    ss, st = ctx.create(reads)
+    assert st["n_kept_kmers"] == info["kept_kmers"]
+    assert st["n_corrected_reads"] == info["corrected_reads"] and st["n_corrected_bases"] == info["corrected_bases"]
+    assert ss.size() == len(oent)
+    want = oss.parts()
+    for name, blob in ss.parts().items():
+        assert blob == want[name], name
+    assert info["modified"] > 0

@@ -1,0 +1,131 @@
+"""Pins the CPU oracle to the reference's own committed fixtures and known-answer tests
+(SURVEY.md §8c).  No GPU."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+@pytest.fixture(scope="module")
+def ecoli(golden_dir):
+    reads = O.read_fastq(golden_dir + "/e_coli_10000snp/reads.fq")
+    ss, ent, info = O.build_seqset_from_fastq_reads(reads)
+    d = O.load_seqset_zip(golden_dir + "/e_coli_10000snp/seqset")
+    return reads, ss, ent, info, d
+
+
+def test_create_path_reproduces_golden_ecoli(ecoli, golden_dir):
+    reads, ss, ent, info, d = ecoli
+    stats = json.load(open(golden_dir + "/e_coli_10000snp/create_stats.json"))
+    assert info["kept_kmers"] == 7108  # qc/create_log.txt:68 "keeping 7108/9383 kmers"
+    assert info["corrected_reads"] == stats["corrected_reads"] == 8444
+    assert info["corrected_bases"] == stats["corrected_bases"] == 288464
+    assert len(ent) == d["n"] == 19935
+    assert ent.strings() == O.decode_entries(d)
+    sizes, shared = ss.arrays()
+    assert (sizes == d["sizes"]).all() and (shared == d["shared"]).all()
+    assert (ss.fixed() == d["fixed"]).all()
+    for b in range(4):
+        for w in ("bits", "subaccum", "accum"):
+            assert (ss.prev(b, w) == d[w][b]).all(), (b, w)
+
+
+def test_cover_mode_equals_all_suffix_mode(ecoli):
+    reads, ss, ent, info, d = ecoli
+    ss2, ent2, info2 = O.build_seqset_from_fastq_reads(reads, mode="cover")
+    assert ent2.strings() == ent.strings()
+    assert info2["n_records"] < info["n_records"]
+
+
+def test_seqset_py_walk_answers(ecoli):
+    # python/biograph/seqset_test.py:17-104
+    _, ss, ent, _, _ = ecoli
+    assert len(ss) == 19935
+    assert ss.find("GATTACA") == (11076, 11077, 7)
+    b, e, _ = ss.find("GATTACAGATTACA")
+    assert b >= e
+    es = ent.strings()
+    assert es[0] == "AAAAAAAAGCCCGCACTGTCAGGTGCGGGC"
+    assert es[6645] == "CCCCACCTGACGCGAAAGGATCGCAGT"
+    assert es[19934] == "TTTTTTTTCGACCAAAGGTAACGAGGTAACAACCA"
+    g = ss.find("GATTACA")
+    one = lambda x: np.array([x])
+    # push_front("G") invalid; push_front("T") == find("TGATTACA")
+    ob, oe, osz = ss.push_front(one(g[0]).astype(np.uint64), one(g[1]).astype(np.uint64), one(7).astype(np.uint32),
+                                one(2).astype(np.uint8))
+    assert ob[0] >= oe[0]
+    ob, oe, osz = ss.push_front(one(g[0]).astype(np.uint64), one(g[1]).astype(np.uint64), one(7).astype(np.uint32),
+                                one(3).astype(np.uint8))
+    assert (int(ob[0]), int(oe[0]), int(osz[0])) == ss.find("TGATTACA")
+    # push_front_drop("G") -> GGATTAC; min_ctx 8,7 -> invalid; 6 -> GGATTAC
+    want = ss.find("GGATTAC")
+    for mc, ok in [(0, True), (8, False), (7, False), (6, True)]:
+        ob, oe, osz = ss.push_front_drop(one(g[0]).astype(np.uint64), one(g[1]).astype(np.uint64),
+                                         one(7).astype(np.uint32), one(2).astype(np.uint8), one(mc).astype(np.uint32))
+        if ok:
+            assert (int(ob[0]), int(oe[0]), int(osz[0])) == want
+        else:
+            assert (int(ob[0]), int(oe[0]), int(osz[0])) == (0, 0, 0)
+
+
+def test_lambda_golden_row_e_closed_loop_and_container_parts(golden_dir):
+    """father_lambda.bg (current container format): re-deriving the arrays from the decoded entry
+    strings reproduces every payload part byte for byte."""
+    d = O.load_seqset_zip(golden_dir + "/father_lambda/seqset")
+    assert d["n"] == 98006 and d["entry_sizes_meta"]["max_value"] == 150 and d["shared_meta"]["max_value"] == 149
+    entries = O.decode_entries(d)
+    assert entries == sorted(entries)
+    ss = O.Seqset.from_entries(O.Entries.from_strings(entries))
+    parts = ss.parts()
+    for name, blob in parts.items():
+        assert blob == d["raw"][name], name
+    # the set is closed: all suffixes of entries are represented (row E), spot-check by find()
+    rng = np.random.default_rng(1)
+    for i in rng.integers(0, len(entries), 200):
+        e = entries[int(i)]
+        j = int(rng.integers(0, len(e)))
+        b, en, _ = ss.find(e[j:])
+        assert en > b
+
+
+def test_builder_test_known_answers():
+    # modules/build_seqset/builder_test.cpp:52-123
+    t, trc = O.tseq, O.tseq_rc
+
+    def entries(reads, mode):
+        seq, offs = O.pack_strings(reads)
+        return O.Entries.build(seq, offs, mode, 10).strings()
+
+    for mode in ("simple", "cover"):
+        assert entries([t("a")], mode) == [
+            "AAAATTAC", "AAATTAC", "AATTAC", "AATTTTAG", "AC", "AG", "ATTAC", "ATTTTAG", "CTAAAATTAC", "GTAATTTTAG",
+            "TAAAATTAC", "TAATTTTAG", "TAC", "TAG", "TTAC", "TTAG", "TTTAG", "TTTTAG"]
+        assert len(entries([t("abcdefg")], mode)) == 129
+        assert len(entries([t("abcd"), t("cdef"), trc("efgh")], mode)) == 152
+        assert len(entries([t("ab"), t("bc"), t("cd"), t("be")], mode)) == 91
+        assert len(entries([t("AB"), t("BC"), t("CD"), t("BE")], mode)) == 91
+        assert len(entries([t("abc"), t("cde")], mode)) == 89
+        assert len(entries([t("abc"), t("efg")], mode)) == 99
+
+
+def test_kmer_counter_semantics():
+    # kmer_counter.h:297-326: N resets the window and clears the first-kmer flag; flags swap when flipped
+    reads = ["ACGTACGTAC", "NACGTACGTA", "ACGTNACGTACG"]
+    seq, offs = O.pack_strings(reads)
+    ks = O.KmerSet.count(seq, offs, k=5, min_count=1)
+    kmers, flags, fwd, rev = ks.arrays()
+    tot = int(fwd.sum() + rev.sum())
+    assert tot == 6 + 5 + 3
+    code = {c: i for i, c in enumerate("ACGT")}
+    def enc(s):
+        v = 0
+        for c in s:
+            v = v * 4 + code[c]
+        return v
+    idx = {int(k): i for i, k in enumerate(kmers)}
+    # "ACGTA" is its own... rc(ACGTA)=TACGT > ACGTA so canonical is ACGTA, first kmer of read 0 -> fwd flag
+    assert flags[idx[enc("ACGTA")]] & 1
+    # last kmer of read 0 is "CGTAC": rc = GTACG > CGTAC, not flipped -> rev_starts flag
+    assert flags[idx[enc("CGTAC")]] & 2
