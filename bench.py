@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py — seqset build throughput on synthetic 30x WGS-shaped 150 bp reads.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the whole create data path (pack -> k-mer count -> correct -> suffix sort ->
+seqset arrays; bg_create in include/bgseq.h) over one batch of reads that is already resident in HBM
+as ASCII.  Rank 0 prints ONE JSON line.  See DESIGN.md §Measurement for the byte accounting.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(sample_genome, coverage, read_len, seed):
+    """Times the oracle (single thread, kind="port") on a bounded sample of the same workload shape."""
+    import numpy as np
+    from biograph_amd import synth
+    from oracle import oracle as O
+    seq, offs, n = synth.make_reads(genome_len=sample_genome, coverage=coverage, read_len=read_len, seed=seed,
+                                    device="cpu")
+    seq = np.ascontiguousarray(seq.numpy())
+    offs = offs.numpy().astype(np.uint64)
+    t0 = time.perf_counter()
+    ks = O.KmerSet.count(seq, offs, 30, 5)
+    cseq, coffs, keep, stats = O.correct_reads(ks, seq, offs, 8, 2, 0.7)
+    ent = O.Entries.build(cseq, coffs, "cover", 30)
+    ss = O.Seqset.from_entries(ent)
+    dt = time.perf_counter() - t0
+    bases = int(offs[-1])
+    return {"value": bases / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
+            "sample": "%d reads x %d bp (%.1f Mbases, %dx of a %d bp synthetic genome), %.1f s, %d entries" % (
+                n, read_len, bases / 1e6, coverage, sample_genome, dt, len(ss))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--shape", default="chr20", choices=["tiny", "ecoli", "chr20"])
+    ap.add_argument("--genome-len", type=int, default=0, help="override the shape's genome length")
+    ap.add_argument("--coverage", type=int, default=30)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--seed", type=int, default=20261002)
+    ap.add_argument("--cpu-sample-genome", type=int, default=600_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import biograph_amd as bg
+    from biograph_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: launch with torch.distributed.run for --gpus > 1", file=sys.stderr)
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU (the HIP path has no CPU fallback)", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    genome_len = args.genome_len or synth.SHAPES[args.shape]
+    # N>1: the build of one sample does not yet exchange records between GPUs:
+    # every rank builds the seqset of its own independent sample (seed + rank), weak scaling.
+    seq, offs, n_reads = synth.make_reads(genome_len=genome_len, coverage=args.coverage, read_len=args.read_len,
+                                          seed=args.seed + 1000 * rank, device=dev)
+    torch.cuda.synchronize()
+    n_bases = int(seq.numel())
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ctx = bg.Context(local_rank, stream)
+    params = ctx.default_params()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stats = None
+    for _ in range(args.warmup):
+        ss, stats = ctx.create_device(seq.data_ptr(), offs.data_ptr(), n_reads, params)
+        ss.free()
+    ctx.set_profiling(True)  # HIP events around every kernel family, on the stream the kernels run on
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ss, stats = ctx.create_device(seq.data_ptr(), offs.data_ptr(), n_reads, params)
+        ss.free()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timings = ctx.timings()
+    ctx.set_profiling(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tb = torch.tensor([n_bases], device=dev, dtype=torch.float64)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        total_bases = float(tb.item())
+    else:
+        total_bases = float(n_bases)
+
+    if rank == 0:
+        # dominant kernel family by device time
+        fam = max(timings, key=lambda t: t["ms"]) if timings else None
+        roofline = None
+        if fam and fam["launches"]:
+            avg_ms = fam["ms"] / fam["launches"]
+            bytes_per_launch = fam["bytes"] / fam["launches"]
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": fam["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_launch_ms": round(avg_ms, 4), "launches_per_step": fam["launches"] / max(args.steps, 1),
+                        "algorithmic_bytes_per_launch": int(bytes_per_launch)}
+        total_ms = sum(t["ms"] for t in timings) or 1.0
+        kernels = {t["name"]: {"ms_per_step": round(t["ms"] / max(args.steps, 1), 3),
+                               "launches_per_step": t["launches"] / max(args.steps, 1),
+                               "GBps": round(t["bytes"] / (t["ms"] * 1e-3) / 1e9, 1) if t["ms"] > 0 else None}
+                   for t in sorted(timings, key=lambda t: -t["ms"])}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.cpu_sample_genome, args.coverage, args.read_len, args.seed)
+        # whole-build algorithmic bytes: 1.25 N_bases + 16 N_kmers + (0.5 N_bases + 8 N_kmers)
+        # + 28 N_rec + 2.625 N_ent
+        alg = (1.25 * stats["n_bases"] + 16 * stats["n_kmers"] + 0.5 * stats["n_bases"] + 8 * stats["n_kmers"]
+               + 28 * stats["n_records"] + 2.625 * stats["n_entries"])
+        step_s = elapsed / max(args.steps, 1)
+        line = {
+            "metric": "seqset_build_gbases_per_s", "value": round(total_bases * args.steps / elapsed / 1e9, 4),
+            "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(step_s * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "synthetic 30x %s-shaped 150 bp paired reads: seqset build (create data path)"
+                                   % args.shape,
+                       "genome_len": genome_len, "coverage": args.coverage, "read_len": args.read_len,
+                       "reads_per_gpu": n_reads, "bases_per_gpu": n_bases, "kmer_size": 30, "min_kmer_count": 5,
+                       "parallelism": "1 GPU" if world == 1 else "%d independent samples, one per GPU" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "build_roofline": {"algorithmic_bytes_per_step": int(alg), "bytes_per_base": round(alg / n_bases, 2),
+                               "achieved_GBps": round(alg / step_s / 1e9, 1),
+                               "frac_of_hbm_peak": round(alg / step_s / 1e9 / HBM_PEAK_GBS, 5),
+                               "kernel_time_frac_of_wall": round(total_ms / 1e3 / elapsed, 3)},
+            "counters": stats, "kernels": kernels,
+        }
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

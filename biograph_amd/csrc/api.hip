@@ -502,7 +502,6 @@ extern "C" void bg_create_params_default(bg_create_params* p) {
 extern "C" int bg_create(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n_reads,
                          const bg_create_params* p, bg_seqset** out, bg_build_stats* stats) {
   if (!ctx || !p || !out) { set_error("bg_create: null argument"); return BG_EINVAL; }
-  ctx->clear_timings();
   bg_build_stats st;
   memset(&st, 0, sizeof st);
   bg_reads* reads = nullptr;
