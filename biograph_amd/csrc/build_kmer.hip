@@ -13,26 +13,34 @@ namespace bg {
 // ------------------------------------------------------------------------------------------------
 // S1: lengths, then one thread per (read, 32-base word).
 
-__global__ void k_read_lengths(const uint64_t* __restrict__ offs, uint64_t n, uint16_t* __restrict__ len,
-                               uint32_t* __restrict__ max_len, uint32_t* __restrict__ err) {
-  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  uint64_t l = 0;
-  if (i < n) {  // no early return: every lane takes part in the wave reduction below
-    l = offs[i + 1] - offs[i];
+__global__ __launch_bounds__(256) void k_read_lengths(const uint64_t* __restrict__ offs, uint64_t n,
+                                                      uint16_t* __restrict__ len, uint32_t* __restrict__ max_len,
+                                                      uint32_t* __restrict__ err) {
+  __shared__ uint32_t sm[4];
+  uint32_t m = 0;
+  bool bad = false;
+  for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x) {
+    uint64_t l = offs[i + 1] - offs[i];
     if (offs[i + 1] < offs[i] || l > 255) {  // biograph_create.cpp:134-139 (no --allow-long-reads)
-      atomicOr(err, 1u);
+      bad = true;
       l = 0;
     }
     len[i] = uint16_t(l);
+    m = uint32_t(l) > m ? uint32_t(l) : m;
   }
-  // one atomic per wave
-  uint32_t m = uint32_t(l);
+  if (bad) atomicOr(err, 1u);
+  // block reduction -> one atomic per block (every lane takes part: no early return above)
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     uint32_t t = __shfl_xor(m, d, 64);
     m = t > m ? t : m;
   }
-  if ((threadIdx.x & 63) == 0) atomicMax(max_len, m);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t a = sm[0] > sm[1] ? sm[0] : sm[1], b = sm[2] > sm[3] ? sm[2] : sm[3];
+    atomicMax(max_len, a > b ? a : b);
+  }
 }
 
 __global__ void k_pack_reads(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs,
@@ -285,34 +293,40 @@ struct CorrectTotals {
 __global__ __launch_bounds__(256) void k_correct_stats(const uint16_t* __restrict__ len,
                                                        const uint16_t* __restrict__ out_len, uint64_t n, int k,
                                                        CorrectTotals* __restrict__ tot) {
-  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  unsigned long long v[5] = {0, 0, 0, 0, 0};
-  unsigned mx = 0;
-  if (i < n) {
+  __shared__ unsigned long long sm[4][6];
+  unsigned long long v[6] = {0, 0, 0, 0, 0, 0};  // [5] = max corrected length
+  for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x) {
     int L = len[i], C = out_len[i];
     if (C > 0) {
-      v[0] = 1;
-      v[1] = C;
-      if (C < L) { v[3] = 1; v[4] = L - C; }
-      mx = C;
+      v[0] += 1;
+      v[1] += C;
+      if (C < L) { v[3] += 1; v[4] += L - C; }
+      v[5] = (unsigned long long)C > v[5] ? C : v[5];
     } else if (L >= k) {
-      v[2] = 1;
+      v[2] += 1;
     }
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
 #pragma unroll
     for (int q = 0; q < 5; ++q) v[q] += __shfl_xor(v[q], d, 64);
-    unsigned t = __shfl_xor(mx, d, 64);
-    mx = t > mx ? t : mx;
+    unsigned long long t = __shfl_xor(v[5], d, 64);
+    v[5] = t > v[5] ? t : v[5];
   }
-  if ((threadIdx.x & 63) == 0) {
-    if (v[0]) atomicAdd(&tot->corrected_reads, v[0]);
-    if (v[1]) atomicAdd(&tot->corrected_bases, v[1]);
-    if (v[2]) atomicAdd(&tot->failed, v[2]);
-    if (v[3]) atomicAdd(&tot->truncated, v[3]);
-    if (v[4]) atomicAdd(&tot->dropped_bases, v[4]);
-    if (mx) atomicMax(&tot->max_len, (unsigned long long)mx);
+  if ((threadIdx.x & 63) == 0)
+    for (int q = 0; q < 6; ++q) sm[threadIdx.x >> 6][q] = v[q];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long r[6];
+    for (int q = 0; q < 5; ++q) r[q] = sm[0][q] + sm[1][q] + sm[2][q] + sm[3][q];
+    r[5] = 0;
+    for (int w = 0; w < 4; ++w) r[5] = sm[w][5] > r[5] ? sm[w][5] : r[5];
+    if (r[0]) atomicAdd(&tot->corrected_reads, r[0]);
+    if (r[1]) atomicAdd(&tot->corrected_bases, r[1]);
+    if (r[2]) atomicAdd(&tot->failed, r[2]);
+    if (r[3]) atomicAdd(&tot->truncated, r[3]);
+    if (r[4]) atomicAdd(&tot->dropped_bases, r[4]);
+    if (r[5]) atomicMax(&tot->max_len, r[5]);
   }
 }
 
@@ -350,7 +364,7 @@ static int pack_reads_impl(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_
   uint64_t h_offs[2] = {0, 0};
   if (n) {
     ctx->tic("pack_lengths");
-    k_read_lengths<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_offs, n, r->len.p, scal.p, scal.p + 1);
+    k_read_lengths<<<(cdiv(n, 256) < 2048u ? cdiv(n, 256) : 2048u), 256, 0, ctx->stream>>>(d_offs, n, r->len.p, scal.p, scal.p + 1);
     BG_LAUNCH_CHECK();
     ctx->toc(n * 10);
     BG_HIP(hipMemcpyAsync(&h_offs[0], d_offs, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -626,7 +640,7 @@ extern "C" int bg_correct_reads(bg_ctx* ctx, const bg_reads* reads, const bg_kme
       BG_LAUNCH_CHECK();
       ctx->toc(nlist * W * 20);
     }
-    k_correct_stats<<<cdiv(n, 256), 256, 0, ctx->stream>>>(reads->len.p, r->len.p, n, k, tot.p);
+    k_correct_stats<<<(cdiv(n, 256) < 2048u ? cdiv(n, 256) : 2048u), 256, 0, ctx->stream>>>(reads->len.p, r->len.p, n, k, tot.p);
     BG_LAUNCH_CHECK();
   }
   CorrectCounters hc;

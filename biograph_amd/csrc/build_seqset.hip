@@ -103,6 +103,47 @@ __global__ void k_flag_ties(const uint64_t* __restrict__ skeys, uint64_t n, uint
   flags[i] = t ? 1 : 0;
 }
 
+// Tie groups (runs of equal first word) of at most kSmallGroup records are ordered right here by
+// one lane with full-key comparisons (insertion sort on record ids; the keys are gathered from the
+// record store).  Only larger groups are flagged for the word-by-word radix rounds below.
+constexpr int kSmallGroup = 32;
+__global__ __launch_bounds__(256) void k_sort_small_groups(const uint64_t* __restrict__ skeys, uint64_t n,
+                                                           const uint64_t* __restrict__ rec,
+                                                           const uint8_t* __restrict__ rlen, int W,
+                                                           uint32_t* __restrict__ sidx, uint8_t* __restrict__ flags) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) {
+    uint64_t k = skeys[i];
+    bool tied = (i > 0 && skeys[i - 1] == k) || (i + 1 < n && skeys[i + 1] == k);
+    uint8_t big = 0;
+    if (tied) {
+      uint64_t s = i, e = i + 1;
+      while (s > 0 && i - s <= uint64_t(kSmallGroup) && skeys[s - 1] == k) --s;
+      while (e < n && e - s <= uint64_t(kSmallGroup) && skeys[e] == k) ++e;
+      if (e - s > uint64_t(kSmallGroup)) {
+        big = 1;
+      } else if (s == i) {  // head of a small group: sort its members
+        int g = int(e - s);
+        uint32_t idx[kSmallGroup];
+        for (int a = 0; a < g; ++a) idx[a] = sidx[s + a];
+        for (int a = 1; a < g; ++a) {
+          uint32_t x = idx[a];
+          const uint64_t* xk = rec + uint64_t(x) * W;
+          int xl = rlen[x];
+          int b = a - 1;
+          while (b >= 0 && key_compare(rec + uint64_t(idx[b]) * W, rlen[idx[b]], xk, xl, W) > 0) {
+            idx[b + 1] = idx[b];
+            --b;
+          }
+          idx[b + 1] = x;
+        }
+        for (int a = 0; a < g; ++a) sidx[s + a] = idx[a];
+      }
+    }
+    flags[i] = big;
+  }
+}
+
 // subset element t sits at sorted position tpos[t]; it starts a group unless it continues the run of
 // its predecessor (adjacent position, same previous-round group and same key).
 __global__ void k_group_heads(const uint32_t* __restrict__ tpos, const uint64_t* __restrict__ tkey,
@@ -294,17 +335,6 @@ __global__ void k_min_index2(const uint8_t* __restrict__ min1, uint64_t n1, uint
   min2[f] = uint8_t(m);
 }
 
-__global__ void k_max_u8(const uint8_t* __restrict__ v, uint64_t n, uint32_t* __restrict__ out) {
-  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  uint32_t m = i < n ? v[i] : 0;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    uint32_t t = __shfl_xor(m, d, 64);
-    m = t > m ? t : m;
-  }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
-}
-
 // ------------------------------------------------------------------------------------------------
 
 // Allocates and fills subaccum/accum/fixed and the min index from bits/shared (device).
@@ -470,12 +500,14 @@ extern "C" int bg_seqset_build(bg_ctx* ctx, const bg_reads* reads, int cover_k, 
       DevBuf<uint8_t> flags;
       BG_TRY(flags.alloc(ctx, n_rec));
       if (n_rec) {
-        k_flag_ties<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(ks.p, n_rec, flags.p);
+        ctx->tic("suffix_small_ties");
+        k_sort_small_groups<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(ks.p, n_rec, rec.p, rlen.p, W, sidx.p, flags.p);
         BG_LAUNCH_CHECK();
+        ctx->toc(n_rec * 13);
       }
       BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, n_rec, &tpos, &T));
+      n_tied = T;  // records in tie groups larger than kSmallGroup (refined by the radix rounds)
     }
-    n_tied = T;
     if (T) {
       BG_TRY(tkey.alloc(ctx, T));
       k_gather_u64_by_u32<<<cdiv(T, 256), 256, 0, ctx->stream>>>(ks.p, tpos.p, T, tkey.p);
@@ -614,9 +646,6 @@ extern "C" int bg_seqset_build(bg_ctx* ctx, const bg_reads* reads, int cover_k, 
     BG_TRY(ss->bits[b].alloc(ctx, nwords));
     if (nwords) BG_HIP(hipMemsetAsync(ss->bits[b].p, 0, nwords * 8, ctx->stream));
   }
-  DevBuf<uint32_t> mx;
-  BG_TRY(mx.alloc(ctx, 1));
-  BG_HIP(hipMemsetAsync(mx.p, 0, 4, ctx->stream));
   if (n_ent) {
     ctx->tic("prev_bits");
     k_prev_bits<<<cdiv(n_ent, 256), 256, 0, ctx->stream>>>(
@@ -625,16 +654,14 @@ extern "C" int bg_seqset_build(bg_ctx* ctx, const bg_reads* reads, int cover_k, 
         reinterpret_cast<unsigned long long*>(ss->bits[3].p), err.p);
     BG_LAUNCH_CHECK();
     ctx->toc(n_ent * (W * 8 + 1 + 8));
-    k_max_u8<<<cdiv(n_ent, 256), 256, 0, ctx->stream>>>(ss->sizes.p, n_ent, mx.p);
-    BG_LAUNCH_CHECK();
   }
-  uint32_t h_err[2] = {0, 0}, h_mx = 0;
+  uint32_t h_err[2] = {0, 0};
   BG_HIP(hipMemcpyAsync(h_err, err.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-  BG_HIP(hipMemcpyAsync(&h_mx, mx.p, 4, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
   if (h_err[0] & 1) { set_error("bg_seqset_build: suffix records not sorted (internal error)"); return BG_EINTERNAL; }
   if (h_err[0] & 2) { set_error("bg_seqset_build: missing expansion (entry set not closed under pop_front)"); return BG_EINTERNAL; }
-  ss->max_len = h_mx;
+  // the longest read is never a proper prefix of anything longer, so it survives as an entry
+  ss->max_len = n_ent ? reads->max_len : 0;
   ctx->tic("seqset_finalize");
   BG_TRY(seqset_finalize_device(ctx, ss.get()));
   ctx->toc(n_ent * 3);

@@ -115,7 +115,7 @@ typedef struct bg_build_stats {
   uint64_t n_kmers, n_distinct_kmers, n_kept_kmers;
   uint64_t n_corrected_reads, n_corrected_bases;
   uint64_t n_records;                /* suffix records sorted (N_rec)                          */
-  uint64_t n_tied_records;           /* records that needed refinement beyond the first word  */
+  uint64_t n_tied_records;           /* records in first-word tie groups > 32 (radix-refined)  */
   uint64_t n_entries;                /* N_ent                                                  */
   uint32_t max_len;
 } bg_build_stats;
