@@ -64,6 +64,11 @@ def pmc_traffic(family):
 
 
 def main():
+    # stdout must carry exactly ONE JSON line: native libraries (RCCL prints a version banner) write to
+    # fd 1 too, so fd 1 is pointed at stderr for the whole run and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -75,6 +80,8 @@ def main():
     ap.add_argument("--seed", type=int, default=20261002)
     ap.add_argument("--cpu-sample-genome", type=int, default=600_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the sharded (RCCL) build path even with one rank (smoke test of the collectives)")
     args = ap.parse_args()
 
     import torch
@@ -94,16 +101,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    genome_len = args.genome_len or synth.SHAPES[args.shape]
-    # N>1: the build of one sample does not yet exchange records between GPUs:
-    # every rank builds the seqset of its own independent sample (seed + rank), weak scaling.
+    # Weak scaling: ONE sample whose genome is `world` x the shape's length; every rank holds 1/world of
+    # its read pairs (per-GPU reads fixed) and the ranks build ONE seqset together (biograph_amd/sharded.py:
+    # k-mers, records and tails cross GPUs by RCCL all_to_all, kept k-mers / corrected reads by all_gather).
+    genome_len = (args.genome_len or synth.SHAPES[args.shape]) * world
     seq, offs, n_reads = synth.make_reads(genome_len=genome_len, coverage=args.coverage, read_len=args.read_len,
-                                          seed=args.seed + 1000 * rank, device=dev)
+                                          seed=args.seed, device=dev, shard=(rank, world))
     torch.cuda.synchronize()
     n_bases = int(seq.numel())
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -115,16 +126,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1 or args.force_sharded:
+        from biograph_amd import sharded
+        comm = sharded.TorchDistComm(dev)
+
+        def step():
+            out = sharded.sharded_create(comm, {rank: ctx}, {rank: (seq, offs, n_reads)}, params)
+            ss, st = out[rank]
+            if ss is not None:
+                ss.free()
+            return st
+    else:
+        def step():
+            ss, st = ctx.create_device(seq.data_ptr(), offs.data_ptr(), n_reads, params)
+            ss.free()
+            return st
+
     stats = None
     for _ in range(args.warmup):
-        ss, stats = ctx.create_device(seq.data_ptr(), offs.data_ptr(), n_reads, params)
-        ss.free()
+        stats = step()
     ctx.set_profiling(True)  # HIP events around every kernel family, on the stream the kernels run on
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ss, stats = ctx.create_device(seq.data_ptr(), offs.data_ptr(), n_reads, params)
-        ss.free()
+        stats = step()
     barrier()
     elapsed = time.perf_counter() - t0
     timings = ctx.timings()
@@ -173,17 +198,19 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "synthetic 30x %s-shaped 150 bp paired reads: seqset build (create data path)"
                                    % args.shape,
-                       "genome_len": genome_len, "coverage": args.coverage, "read_len": args.read_len,
+                       "genome_len_total": genome_len, "coverage": args.coverage, "read_len": args.read_len,
                        "reads_per_gpu": n_reads, "bases_per_gpu": n_bases, "kmer_size": 30, "min_kmer_count": 5,
-                       "parallelism": "1 GPU" if world == 1 else "%d independent samples, one per GPU" % world},
+                       "parallelism": "1 GPU" if world == 1 else
+                       "%d GPUs, one sample sharded: all_to_all(k-mers, records, tails) + all_gather(kept k-mers, "
+                       "corrected reads) over RCCL" % world},
             "roofline": roofline, "cpu_baseline": cpu,
-            "build_roofline": {"algorithmic_bytes_per_step": int(alg), "bytes_per_base": round(alg / n_bases, 2),
+            "build_roofline": {"algorithmic_bytes_per_step": int(alg), "bytes_per_base": round(alg / max(stats["n_bases"], 1), 2),
                                "achieved_GBps": round(alg / step_s / 1e9, 1),
-                               "frac_of_hbm_peak": round(alg / step_s / 1e9 / HBM_PEAK_GBS, 5),
+                               "frac_of_hbm_peak": round(alg / step_s / 1e9 / (HBM_PEAK_GBS * world), 5),
                                "kernel_time_frac_of_wall": round(total_ms / 1e3 / elapsed, 3)},
             "counters": stats, "kernels": kernels,
         }
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     ctx.close()
     if dist is not None:
         dist.barrier()

@@ -58,7 +58,15 @@ SYMBOLS = [
     "bg_seqset_part", "bg_seqset_arrays", "bg_seqset_entries", "bg_seqset_write", "bg_seqset_open",
     "bg_seqset_from_arrays", "bg_seqset_free", "bg_push_front_batch", "bg_push_front_drop_batch", "bg_find_batch",
     "bg_dev_alloc", "bg_dev_free", "bg_dev_upload", "bg_dev_download",
+    # sharded build
+    "bg_partition_rows", "bg_kmer_instances", "bg_kmer_extract", "bg_kmer_count_keys", "bg_kmerset_export",
+    "bg_kmerset_from_kmers", "bg_reads_words", "bg_reads_export", "bg_reads_import", "bg_suffix_records",
+    "bg_records_count", "bg_records_words", "bg_records_rows", "bg_records_from_rows", "bg_records_free",
+    "bg_entries_from_records", "bg_seqset_words", "bg_seqset_boundary_rows", "bg_seqset_fix_boundary",
+    "bg_seqset_tail_rows", "bg_seqset_apply_tails", "bg_seqset_slice_export", "bg_seqset_assemble",
 ]
+
+PART_KMER_HASH, PART_PREFIX, PART_KEY_BOUNDS = 0, 1, 2
 
 
 def lib():
@@ -114,6 +122,31 @@ def lib():
     L.bg_dev_free.argtypes = [vp, vp]
     L.bg_dev_upload.argtypes = [vp, vp, vp, u64]
     L.bg_dev_download.argtypes = [vp, vp, vp, u64]
+    L.bg_partition_rows.argtypes = [vp, vp, u64, i32, i32, u32, vp, vp, vp]
+    L.bg_kmer_instances.argtypes = [vp, vp, i32, P(u64)]
+    L.bg_kmer_extract.argtypes = [vp, vp, i32, vp, u64]
+    L.bg_kmer_count_keys.argtypes = [vp, vp, u64, i32, u32, P(vp)]
+    L.bg_kmerset_export.argtypes = [vp, vp, vp]
+    L.bg_kmerset_from_kmers.argtypes = [vp, vp, u64, i32, vp, P(vp)]
+    L.bg_reads_words.argtypes = [vp]
+    L.bg_reads_export.argtypes = [vp, vp, i32, vp, vp]
+    L.bg_reads_import.argtypes = [vp, u64, i32, u32, vp, vp, P(vp)]
+    L.bg_suffix_records.argtypes = [vp, vp, u64, u64, i32, P(vp)]
+    L.bg_records_count.restype = u64
+    L.bg_records_count.argtypes = [vp]
+    L.bg_records_words.argtypes = [vp]
+    L.bg_records_rows.argtypes = [vp, vp, vp]
+    L.bg_records_from_rows.argtypes = [vp, vp, u64, i32, P(vp)]
+    L.bg_records_free.argtypes = [vp]
+    L.bg_records_free.restype = None
+    L.bg_entries_from_records.argtypes = [vp, vp, P(vp), P(BuildStats)]
+    L.bg_seqset_words.argtypes = [vp]
+    L.bg_seqset_boundary_rows.argtypes = [vp, vp, vp, vp]
+    L.bg_seqset_fix_boundary.argtypes = [vp, vp, vp, vp]
+    L.bg_seqset_tail_rows.argtypes = [vp, vp, vp]
+    L.bg_seqset_apply_tails.argtypes = [vp, vp, vp, u64]
+    L.bg_seqset_slice_export.argtypes = [vp, vp, vp, vp, vp]
+    L.bg_seqset_assemble.argtypes = [vp, u32, vp, vp, vp, vp, u32, P(vp)]
     _lib = L
     return L
 

@@ -105,8 +105,11 @@ int exclusive_scan_u32(bg_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, uint6
 // Stable LSD radix sort of 64-bit keys (optionally carrying 32-bit values) on key bits
 // [bit_lo, bit_hi).  keys_a/vals_a hold the input; *_b are scratch of the same size.  On return
 // *in_b tells which buffer holds the result.  vals_* may be null (keys only).
+// flags: RS_LOW_ENTROPY = keys take few distinct values in the sorted bits (no census, ballot-aggregated
+// histogram).
+constexpr int RS_LOW_ENTROPY = 1;
 int radix_sort_u64(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
-                   uint64_t n, int bit_lo, int bit_hi, bool* in_b);
+                   uint64_t n, int bit_lo, int bit_hi, bool* in_b, int flags = 0);
 
 // ---- device-side object layouts
 }  // namespace bg
@@ -145,9 +148,23 @@ struct bg_seqset {
   std::string uuid;
 };
 
+struct bg_records {
+  bg_ctx* ctx = nullptr;
+  uint64_t n = 0;
+  int W = 0;
+  bg::DevBuf<uint64_t> rec;   // n*W zero-padded key words
+  bg::DevBuf<uint8_t> rlen;   // n
+};
+
 namespace bg {
-// build.hip
+// build_seqset.hip
 int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss);  // bitcount finalize + min index + fixed
+int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t hi, int cover_k,
+                        DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out);
+int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t>& rlen, uint64_t n_rec, int W,
+                              bg_seqset* ss, uint64_t* n_tied_out);
+int alloc_prev_bits(bg_ctx* ctx, bg_seqset* ss);
+int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss);
 // spiral_zip.cpp
 struct ZipPart { std::string name; std::string data; bool raw_crc0; };
 int spiral_zip_write(const char* path, const std::vector<ZipPart>& parts);

@@ -459,51 +459,50 @@ extern "C" int bg_reads_download(bg_ctx* ctx, const bg_reads* r, uint8_t* h_seq,
 // ================================================================================================
 // C ABI: S2
 
-extern "C" int bg_kmer_count(bg_ctx* ctx, const bg_reads* reads, int k, uint32_t min_count, bg_kmerset** out) {
-  if (!ctx || !reads || !out) { set_error("bg_kmer_count: null argument"); return BG_EINVAL; }
-  if (k < 1 || k > 31) { set_error("bg_kmer_count: kmer size %d outside 1..31", k); return BG_EINVAL; }
-  if (min_count < 1) min_count = 1;
-  BG_HIP(hipSetDevice(ctx->device));
-  const uint64_t n = reads->n;
-  const int W = reads->W;
-  std::unique_ptr<bg_kmerset> ks(new bg_kmerset);
-  ks->ctx = ctx;
-  ks->k = k;
+namespace bg {
 
-  // windows per read -> offsets
+// number of k-mer windows of every read and their total
+static int kmer_offsets(bg_ctx* ctx, const bg_reads* reads, int k, DevBuf<uint64_t>* koff, uint64_t* N) {
+  const uint64_t n = reads->n;
   DevBuf<uint32_t> nk;
-  DevBuf<uint64_t> koff, total;
+  DevBuf<uint64_t> total;
   BG_TRY(nk.alloc(ctx, n));
-  BG_TRY(koff.alloc(ctx, n));
+  BG_TRY(koff->alloc(ctx, n));
   BG_TRY(total.alloc(ctx, 1));
   if (n) {
     k_kmer_counts_per_read<<<cdiv(n, 256), 256, 0, ctx->stream>>>(reads->len.p, n, k, nk.p);
     BG_LAUNCH_CHECK();
   }
-  BG_TRY(exclusive_scan_u32_to_u64(ctx, nk.p, koff.p, n, total.p));
-  uint64_t N = 0;
-  BG_HIP(hipMemcpyAsync(&N, total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_TRY(exclusive_scan_u32_to_u64(ctx, nk.p, koff->p, n, total.p));
+  BG_HIP(hipMemcpyAsync(N, total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
-  ks->instances = N;
-  nk.reset();
+  return BG_OK;
+}
 
+// canonical k-mer of every window (all-ones for windows holding an N) into d_keys[N]
+int kmer_extract_impl(bg_ctx* ctx, const bg_reads* reads, int k, const uint64_t* d_koff, uint64_t N,
+                      uint64_t* d_keys) {
+  const uint64_t n = reads->n;
+  if (!N) return BG_OK;
+  ctx->tic("kmer_extract");
+  k_extract_kmers<<<cdiv(n, 4), 256, 0, ctx->stream>>>(reads->words.p, reads->nmask.p, reads->len.p, d_koff, n,
+                                                       reads->W, k, d_keys);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n * reads->W * 12 + N * 8);
+  return BG_OK;
+}
+
+// sort the instances (ka = data, kb = scratch, both N) and keep canonical k-mers seen >= min_count
+// times: fills ks->kmers / counts / size / distinct.
+int kmer_count_keys_impl(bg_ctx* ctx, uint64_t* ka, uint64_t* kb, uint64_t N, uint32_t min_count, bg_kmerset* ks) {
   uint64_t nkept = 0, nheads = 0;
+  ks->distinct = 0;
   if (N) {
-    DevBuf<uint64_t> ka, kb;
-    BG_TRY(ka.alloc(ctx, N));
-    BG_TRY(kb.alloc(ctx, N));
-    ctx->tic("kmer_extract");
-    k_extract_kmers<<<cdiv(n, 4), 256, 0, ctx->stream>>>(reads->words.p, reads->nmask.p, reads->len.p, koff.p, n, W, k,
-                                                         ka.p);
-    BG_LAUNCH_CHECK();
-    ctx->toc(n * W * 12 + N * 8);
     bool in_b = false;
     // sort on the full key so that the all-ones sentinel of N-windows lands at the end; the census
     // skips the constant high bytes when there is none.
-    BG_TRY(radix_sort_u64(ctx, ka.p, kb.p, nullptr, nullptr, N, 0, 64, &in_b));
-    uint64_t* sorted = in_b ? kb.p : ka.p;
-    if (in_b) ka.reset(); else kb.reset();
-
+    BG_TRY(radix_sort_u64(ctx, ka, kb, nullptr, nullptr, N, 0, 64, &in_b));
+    uint64_t* sorted = in_b ? kb : ka;
     ctx->tic("kmer_runs");
     DevBuf<uint64_t> head_pos, kept_r;
     {
@@ -538,8 +537,12 @@ extern "C" int bg_kmer_count(bg_ctx* ctx, const bg_reads* reads, int k, uint32_t
     BG_TRY(ks->counts.alloc(ctx, 0));
   }
   ks->size = nkept;
+  return BG_OK;
+}
 
-  // hash set
+// hash set over ks->kmers; start flags from `reads` when given
+int kmer_hash_build_impl(bg_ctx* ctx, bg_kmerset* ks, const bg_reads* reads) {
+  const uint64_t nkept = ks->size;
   int lg = 10;
   while ((1ull << lg) < 2 * nkept) ++lg;
   ks->log2cap = lg;
@@ -550,13 +553,108 @@ extern "C" int bg_kmer_count(bg_ctx* ctx, const bg_reads* reads, int k, uint32_t
     k_hash_insert<<<cdiv(nkept, 256), 256, 0, ctx->stream>>>(ks->kmers.p, nkept, ks->slots.p, lg);
     BG_LAUNCH_CHECK();
   }
-  if (n) {
-    k_set_start_flags<<<cdiv(n, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->nmask.p, reads->len.p, n, W, k,
-                                                             ks->slots.p, lg);
+  if (reads && reads->n) {
+    k_set_start_flags<<<cdiv(reads->n, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->nmask.p, reads->len.p,
+                                                                    reads->n, reads->W, ks->k, ks->slots.p, lg);
     BG_LAUNCH_CHECK();
   }
-  ctx->toc((1ull << lg) * 8 + nkept * 16 + n * 2 * 64);
+  ctx->toc((1ull << lg) * 8 + nkept * 16 + (reads ? reads->n : 0) * 2 * 64);
   BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+}  // namespace bg
+
+extern "C" int bg_kmer_count(bg_ctx* ctx, const bg_reads* reads, int k, uint32_t min_count, bg_kmerset** out) {
+  if (!ctx || !reads || !out) { set_error("bg_kmer_count: null argument"); return BG_EINVAL; }
+  if (k < 1 || k > 31) { set_error("bg_kmer_count: kmer size %d outside 1..31", k); return BG_EINVAL; }
+  if (min_count < 1) min_count = 1;
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_kmerset> ks(new bg_kmerset);
+  ks->ctx = ctx;
+  ks->k = k;
+  DevBuf<uint64_t> koff;
+  uint64_t N = 0;
+  BG_TRY(kmer_offsets(ctx, reads, k, &koff, &N));
+  ks->instances = N;
+  {
+    DevBuf<uint64_t> ka, kb;
+    BG_TRY(ka.alloc(ctx, N));
+    BG_TRY(kb.alloc(ctx, N));
+    BG_TRY(kmer_extract_impl(ctx, reads, k, koff.p, N, ka.p));
+    BG_TRY(kmer_count_keys_impl(ctx, ka.p, kb.p, N, min_count, ks.get()));
+  }
+  BG_TRY(kmer_hash_build_impl(ctx, ks.get(), reads));
+  *out = ks.release();
+  return BG_OK;
+}
+
+// ---- sharded build: the same phases with the exchange points exposed
+
+extern "C" int bg_kmer_instances(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t* n_out) {
+  if (!ctx || !reads || !n_out) { set_error("bg_kmer_instances: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  DevBuf<uint64_t> koff;
+  return kmer_offsets(ctx, reads, k, &koff, n_out);
+}
+
+extern "C" int bg_kmer_extract(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t* d_keys, uint64_t cap) {
+  if (!ctx || !reads || (!d_keys && cap)) { set_error("bg_kmer_extract: null argument"); return BG_EINVAL; }
+  if (k < 1 || k > 31) { set_error("bg_kmer_extract: kmer size %d outside 1..31", k); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  DevBuf<uint64_t> koff;
+  uint64_t N = 0;
+  BG_TRY(kmer_offsets(ctx, reads, k, &koff, &N));
+  if (N > cap) { set_error("bg_kmer_extract: buffer holds %llu of %llu keys", (unsigned long long)cap, (unsigned long long)N); return BG_EINVAL; }
+  BG_TRY(kmer_extract_impl(ctx, reads, k, koff.p, N, d_keys));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+extern "C" int bg_kmer_count_keys(bg_ctx* ctx, uint64_t* d_keys, uint64_t n, int k, uint32_t min_count,
+                                  bg_kmerset** out) {
+  if (!ctx || !out || (n && !d_keys)) { set_error("bg_kmer_count_keys: null argument"); return BG_EINVAL; }
+  if (k < 1 || k > 31) { set_error("bg_kmer_count_keys: kmer size %d outside 1..31", k); return BG_EINVAL; }
+  if (min_count < 1) min_count = 1;
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_kmerset> ks(new bg_kmerset);
+  ks->ctx = ctx;
+  ks->k = k;
+  ks->instances = n;
+  DevBuf<uint64_t> kb;
+  BG_TRY(kb.alloc(ctx, n));
+  BG_TRY(kmer_count_keys_impl(ctx, d_keys, kb.p, n, min_count, ks.get()));
+  *out = ks.release();
+  return BG_OK;
+}
+
+extern "C" int bg_kmerset_export(bg_ctx* ctx, const bg_kmerset* ks, uint64_t* d_kmers_out) {
+  if (!ctx || !ks) { set_error("bg_kmerset_export: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (ks->size) {
+    BG_HIP(hipMemcpyAsync(d_kmers_out, ks->kmers.p, ks->size * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return BG_OK;
+}
+
+extern "C" int bg_kmerset_from_kmers(bg_ctx* ctx, const uint64_t* d_kmers, uint64_t n, int k,
+                                     const bg_reads* reads_for_flags, bg_kmerset** out) {
+  if (!ctx || !out || (n && !d_kmers)) { set_error("bg_kmerset_from_kmers: null argument"); return BG_EINVAL; }
+  if (k < 1 || k > 31) { set_error("bg_kmerset_from_kmers: kmer size %d outside 1..31", k); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_kmerset> ks(new bg_kmerset);
+  ks->ctx = ctx;
+  ks->k = k;
+  ks->size = n;
+  ks->distinct = n;
+  BG_TRY(ks->kmers.alloc(ctx, n));
+  BG_TRY(ks->counts.alloc(ctx, n));
+  if (n) {
+    BG_HIP(hipMemcpyAsync(ks->kmers.p, d_kmers, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    BG_HIP(hipMemsetAsync(ks->counts.p, 0, n * 4, ctx->stream));
+  }
+  BG_TRY(kmer_hash_build_impl(ctx, ks.get(), reads_for_flags));
   *out = ks.release();
   return BG_OK;
 }

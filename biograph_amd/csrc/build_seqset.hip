@@ -59,36 +59,41 @@ __global__ void k_cover_insert(const uint64_t* __restrict__ skeys, const uint32_
 }
 
 __global__ __launch_bounds__(128) void k_cover_count(CoverIndex ci, const uint64_t* __restrict__ owords,
-                                                     const uint16_t* __restrict__ len, uint64_t n_o, int W,
-                                                     uint32_t* __restrict__ cnt) {
-  uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (o >= n_o) return;
-  cnt[o] = uint32_t(cover_count(ci, owords, len, o, W));
+                                                     const uint16_t* __restrict__ len, uint64_t o_base,
+                                                     uint64_t n_emit, int W, uint32_t* __restrict__ cnt) {
+  uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n_emit) return;
+  cnt[t] = uint32_t(cover_count(ci, owords, len, o_base + t, W));
 }
 
-// records: rec[r*W + w] (zero padded words), rlen[r], k0[r] = first word (sort key), ridx[r] = r
+// records: rec[r*W + w] (zero padded words), rlen[r]
 __global__ __launch_bounds__(128) void k_emit_records(const uint64_t* __restrict__ owords,
                                                       const uint16_t* __restrict__ len,
                                                       const uint32_t* __restrict__ cnt,
-                                                      const uint64_t* __restrict__ roff, uint64_t n_o, int W,
-                                                      uint64_t* __restrict__ rec, uint8_t* __restrict__ rlen,
-                                                      uint64_t* __restrict__ k0, uint32_t* __restrict__ ridx) {
-  uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (o >= n_o) return;
-  int c = int(cnt[o]);
+                                                      const uint64_t* __restrict__ roff, uint64_t o_base,
+                                                      uint64_t n_emit, int W, uint64_t* __restrict__ rec,
+                                                      uint8_t* __restrict__ rlen) {
+  uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n_emit) return;
+  int c = int(cnt[t]);
   if (!c) return;
+  uint64_t o = o_base + t;
   int L = len[o >> 1];
   const uint64_t* s = owords + o * W;
-  uint64_t r = roff[o];
+  uint64_t r = roff[t];
   for (int j = 0; j < c; ++j, ++r) {
-    for (int w = 0; w < W; ++w) {
-      uint64_t x = window32(s, W, j + 32 * w);
-      rec[r * W + w] = x;
-      if (w == 0) k0[r] = x;
-    }
+    for (int w = 0; w < W; ++w) rec[r * W + w] = window32(s, W, j + 32 * w);
     rlen[r] = uint8_t(L - j);
-    ridx[r] = uint32_t(r);
   }
+}
+
+// sort input: first word of every record + its index
+__global__ void k_first_words(const uint64_t* __restrict__ rec, uint64_t n, int W, uint64_t* __restrict__ k0,
+                              uint32_t* __restrict__ ridx) {
+  uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  k0[r] = rec[r * W];
+  ridx[r] = uint32_t(r);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -382,116 +387,121 @@ int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss) {
 
 }  // namespace bg
 
-using namespace bg;
 
-extern "C" int bg_seqset_build(bg_ctx* ctx, const bg_reads* reads, int cover_k, bg_seqset** out,
-                               bg_build_stats* stats) {
-  if (!ctx || !reads || !out) { set_error("bg_seqset_build: null argument"); return BG_EINVAL; }
-  if (cover_k < 1 || cover_k > 31) { set_error("bg_seqset_build: cover_k %d outside 1..31", cover_k); return BG_EINVAL; }
-  BG_HIP(hipSetDevice(ctx->device));
+namespace bg {
+
+// Phase A: suffix records of reads [lo, hi) under the exact-cover rule; the cover index spans ALL
+// reads of `reads` (in a sharded build every rank holds the gathered corrected reads).
+int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t hi, int cover_k,
+                        DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out) {
   const uint64_t n = reads->n;
   const uint64_t n_o = 2 * n;
   const int W = reads->W;
-  if (n_o >= (1ull << 32)) { set_error("bg_seqset_build: too many reads for one shard (%llu)", (unsigned long long)n); return BG_EINVAL; }
-  std::unique_ptr<bg_seqset> ss(new bg_seqset);
-  ss->ctx = ctx;
-  ss->W = W;
-  ss->uuid = make_uuid();
-
-  uint64_t n_rec = 0, n_tied = 0, n_ent = 0;
-  DevBuf<uint64_t> rec;       // n_rec * W
-  DevBuf<uint8_t> rlen;       // n_rec
-  DevBuf<uint32_t> sidx;      // sorted order -> record
+  if (n_o >= (1ull << 32)) { set_error("too many reads for one cover index (%llu)", (unsigned long long)n); return BG_EINVAL; }
+  if (lo > hi || hi > n) { set_error("bad read range"); return BG_EINVAL; }
+  const uint64_t o_base = 2 * lo, n_emit = 2 * (hi - lo);
+  uint64_t n_rec = 0;
+  // ---- oriented reads + cover index
+  DevBuf<uint64_t> owords, okey_a, okey_b;
+  DevBuf<uint32_t> oid_a, oid_b;
+  BG_TRY(owords.alloc(ctx, n_o * W));
+  BG_TRY(okey_a.alloc(ctx, n_o));
+  BG_TRY(okey_b.alloc(ctx, n_o));
+  BG_TRY(oid_a.alloc(ctx, n_o));
+  BG_TRY(oid_b.alloc(ctx, n_o));
+  if (n_o) {
+    ctx->tic("suffix_oriented");
+    k_oriented_words<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->len.p, n, W, cover_k, owords.p,
+                                                              okey_a.p, oid_a.p);
+    BG_LAUNCH_CHECK();
+    ctx->toc(n * W * 8 + n_o * W * 8 + n_o * 12);
+  }
+  bool in_b = false;
+  BG_TRY(radix_sort_u64(ctx, okey_a.p, okey_b.p, oid_a.p, oid_b.p, n_o, 0, 64, &in_b));
+  uint64_t* skeys = in_b ? okey_b.p : okey_a.p;
+  uint32_t* soid = in_b ? oid_b.p : oid_a.p;
+  DevBuf<uint32_t> head_pos;
+  uint64_t nheads = 0;
   {
-    // ---- oriented reads + cover index
-    DevBuf<uint64_t> owords, okey_a, okey_b;
-    DevBuf<uint32_t> oid_a, oid_b;
-    BG_TRY(owords.alloc(ctx, n_o * W));
-    BG_TRY(okey_a.alloc(ctx, n_o));
-    BG_TRY(okey_b.alloc(ctx, n_o));
-    BG_TRY(oid_a.alloc(ctx, n_o));
-    BG_TRY(oid_b.alloc(ctx, n_o));
+    DevBuf<uint8_t> flags;
+    BG_TRY(flags.alloc(ctx, n_o));
     if (n_o) {
-      ctx->tic("suffix_oriented");
-      k_oriented_words<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->len.p, n, W, cover_k, owords.p,
-                                                                okey_a.p, oid_a.p);
-      BG_LAUNCH_CHECK();
-      ctx->toc(n * W * 8 + n_o * W * 8 + n_o * 12);
-    }
-    bool in_b = false;
-    BG_TRY(radix_sort_u64(ctx, okey_a.p, okey_b.p, oid_a.p, oid_b.p, n_o, 0, 64, &in_b));
-    uint64_t* skeys = in_b ? okey_b.p : okey_a.p;
-    uint32_t* soid = in_b ? oid_b.p : oid_a.p;
-    DevBuf<uint32_t> head_pos;
-    uint64_t nheads = 0;
-    {
-      DevBuf<uint8_t> flags;
-      BG_TRY(flags.alloc(ctx, n_o));
-      if (n_o) {
-        k_flag_key_heads<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(skeys, n_o, flags.p);
-        BG_LAUNCH_CHECK();
-      }
-      BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, n_o, &head_pos, &nheads));
-    }
-    int lg = 10;
-    while ((1ull << lg) < 2 * nheads) ++lg;
-    DevBuf<uint64_t> slots;
-    DevBuf<uint32_t> vals;
-    BG_TRY(slots.alloc(ctx, 1ull << lg));
-    BG_TRY(vals.alloc(ctx, 1ull << lg));
-    BG_HIP(hipMemsetAsync(slots.p, 0xff, (1ull << lg) * 8, ctx->stream));
-    if (nheads) {
-      k_cover_insert<<<cdiv(nheads, 256), 256, 0, ctx->stream>>>(skeys, head_pos.p, nheads, slots.p, vals.p, lg);
+      k_flag_key_heads<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(skeys, n_o, flags.p);
       BG_LAUNCH_CHECK();
     }
-    CoverIndex ci{slots.p, vals.p, lg, skeys, soid, n_o, cover_k};
+    BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, n_o, &head_pos, &nheads));
+  }
+  int lg = 10;
+  while ((1ull << lg) < 2 * nheads) ++lg;
+  DevBuf<uint64_t> slots;
+  DevBuf<uint32_t> vals;
+  BG_TRY(slots.alloc(ctx, 1ull << lg));
+  BG_TRY(vals.alloc(ctx, 1ull << lg));
+  BG_HIP(hipMemsetAsync(slots.p, 0xff, (1ull << lg) * 8, ctx->stream));
+  if (nheads) {
+    k_cover_insert<<<cdiv(nheads, 256), 256, 0, ctx->stream>>>(skeys, head_pos.p, nheads, slots.p, vals.p, lg);
+    BG_LAUNCH_CHECK();
+  }
+  CoverIndex ci{slots.p, vals.p, lg, skeys, soid, n_o, cover_k};
 
-    // ---- emission
-    DevBuf<uint32_t> cnt;
-    DevBuf<uint64_t> roff, total;
-    BG_TRY(cnt.alloc(ctx, n_o));
-    BG_TRY(roff.alloc(ctx, n_o));
-    BG_TRY(total.alloc(ctx, 1));
-    if (n_o) {
-      ctx->tic("suffix_cover_count");
-      k_cover_count<<<cdiv(n_o, 128), 128, 0, ctx->stream>>>(ci, owords.p, reads->len.p, n_o, W, cnt.p);
-      BG_LAUNCH_CHECK();
-      ctx->toc(n_o * W * 8 * 2);
-    }
-    BG_TRY(exclusive_scan_u32_to_u64(ctx, cnt.p, roff.p, n_o, total.p));
-    BG_HIP(hipMemcpyAsync(&n_rec, total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    BG_HIP(hipStreamSynchronize(ctx->stream));
-    if (n_rec >= (1ull << 32)) {
-      set_error("bg_seqset_build: %llu suffix records exceed one shard", (unsigned long long)n_rec);
-      return BG_EINVAL;
-    }
-    BG_TRY(rec.alloc(ctx, n_rec * W));
-    BG_TRY(rlen.alloc(ctx, n_rec));
+  // ---- emission
+  DevBuf<uint32_t> cnt;
+  DevBuf<uint64_t> roff, total;
+  BG_TRY(cnt.alloc(ctx, n_emit));
+  BG_TRY(roff.alloc(ctx, n_emit));
+  BG_TRY(total.alloc(ctx, 1));
+  if (n_emit) {
+    ctx->tic("suffix_cover_count");
+    k_cover_count<<<cdiv(n_emit, 128), 128, 0, ctx->stream>>>(ci, owords.p, reads->len.p, o_base, n_emit, W, cnt.p);
+    BG_LAUNCH_CHECK();
+    ctx->toc(n_emit * W * 8 * 2);
+  }
+  BG_TRY(exclusive_scan_u32_to_u64(ctx, cnt.p, roff.p, n_emit, total.p));
+  BG_HIP(hipMemcpyAsync(&n_rec, total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  BG_TRY(rec->alloc(ctx, n_rec * W));
+  BG_TRY(rlen->alloc(ctx, n_rec));
+  if (n_rec) {
+    ctx->tic("suffix_emit");
+    k_emit_records<<<cdiv(n_emit, 128), 128, 0, ctx->stream>>>(owords.p, reads->len.p, cnt.p, roff.p, o_base, n_emit, W,
+                                                               rec->p, rlen->p);
+    BG_LAUNCH_CHECK();
+    ctx->toc(n_emit * W * 8 + n_rec * (W * 8 + 1));
+  }
+  *n_rec_out = n_rec;
+  return BG_OK;
+}
+
+// Phase B: sort the records, drop prefixes/duplicates, build keys/sizes/shared of the surviving
+// entries into `ss`.  Consumes rec/rlen.
+int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t>& rlen, uint64_t n_rec, int W,
+                              bg_seqset* ss, uint64_t* n_tied_out) {
+  if (n_rec >= (1ull << 32)) {
+    set_error("%llu suffix records exceed one shard", (unsigned long long)n_rec);
+    return BG_EINVAL;
+  }
+  uint64_t n_tied = 0, n_ent = 0;
+  DevBuf<uint32_t> sidx;  // sorted order -> record
+  {
+    // ---- sort by the first 32 bases
     DevBuf<uint64_t> k0a, k0b;
     DevBuf<uint32_t> ia, ib;
     BG_TRY(k0a.alloc(ctx, n_rec));
     BG_TRY(ia.alloc(ctx, n_rec));
-    if (n_rec) {
-      ctx->tic("suffix_emit");
-      k_emit_records<<<cdiv(n_o, 128), 128, 0, ctx->stream>>>(owords.p, reads->len.p, cnt.p, roff.p, n_o, W, rec.p,
-                                                              rlen.p, k0a.p, ia.p);
-      BG_LAUNCH_CHECK();
-      ctx->toc(n_o * W * 8 + n_rec * (W * 8 + 13));
-    }
-    // the cover index and oriented words are no longer needed
-    owords.reset(); okey_a.reset(); okey_b.reset(); oid_a.reset(); oid_b.reset();
-    slots.reset(); vals.reset(); cnt.reset(); roff.reset(); head_pos.reset();
-
-    // ---- sort by the first 32 bases
     BG_TRY(k0b.alloc(ctx, n_rec));
     BG_TRY(ib.alloc(ctx, n_rec));
+    if (n_rec) {
+      k_first_words<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(rec.p, n_rec, W, k0a.p, ia.p);
+      BG_LAUNCH_CHECK();
+    }
+    bool in_b = false;
     BG_TRY(radix_sort_u64(ctx, k0a.p, k0b.p, ia.p, ib.p, n_rec, 0, 64, &in_b));
     DevBuf<uint64_t>& ks = in_b ? k0b : k0a;
     sidx = std::move(in_b ? ib : ia);
     (in_b ? ia : ib).reset();
     (in_b ? k0a : k0b).reset();
 
-    // ---- refine ties word by word, then by length
+    // ---- small tie groups in-lane; larger ones word by word, then by length
     DevBuf<uint32_t> tpos;   // subset slot -> sorted position
     DevBuf<uint64_t> tkey;   // current-round key per subset slot
     DevBuf<uint32_t> gid;    // group ordinal per subset slot
@@ -514,95 +524,95 @@ extern "C" int bg_seqset_build(bg_ctx* ctx, const bg_reads* reads, int cover_k, 
       BG_LAUNCH_CHECK();
     }
     ks.reset();
-    bool have_gid = false;
-    for (int w = 1; w <= W && T; ++w) {
-      // groups of this round = runs of equal (previous group, previous key) at adjacent positions
-      DevBuf<uint32_t> head, excl, ngid;
-      BG_TRY(head.alloc(ctx, T));
-      BG_TRY(excl.alloc(ctx, T));
-      BG_TRY(ngid.alloc(ctx, T));
-      k_group_heads<<<cdiv(T, 256), 256, 0, ctx->stream>>>(tpos.p, tkey.p, have_gid ? gid.p : nullptr, T, head.p);
-      BG_LAUNCH_CHECK();
-      BG_TRY(exclusive_scan_u32(ctx, head.p, excl.p, T, nullptr));
-      k_gid_from_scan<<<cdiv(T, 256), 256, 0, ctx->stream>>>(excl.p, head.p, T, ngid.p);
-      BG_LAUNCH_CHECK();
-      gid = std::move(ngid);
-      have_gid = true;
-      head.reset(); excl.reset();
+  bool have_gid = false;
+  for (int w = 1; w <= W && T; ++w) {
+    // groups of this round = runs of equal (previous group, previous key) at adjacent positions
+    DevBuf<uint32_t> head, excl, ngid;
+    BG_TRY(head.alloc(ctx, T));
+    BG_TRY(excl.alloc(ctx, T));
+    BG_TRY(ngid.alloc(ctx, T));
+    k_group_heads<<<cdiv(T, 256), 256, 0, ctx->stream>>>(tpos.p, tkey.p, have_gid ? gid.p : nullptr, T, head.p);
+    BG_LAUNCH_CHECK();
+    BG_TRY(exclusive_scan_u32(ctx, head.p, excl.p, T, nullptr));
+    k_gid_from_scan<<<cdiv(T, 256), 256, 0, ctx->stream>>>(excl.p, head.p, T, ngid.p);
+    BG_LAUNCH_CHECK();
+    gid = std::move(ngid);
+    have_gid = true;
+    head.reset(); excl.reset();
 
-      // sort subset by (gid, key_w): LSD = key_w first, then gid (stable)
-      DevBuf<uint64_t> ka, kb;
-      DevBuf<uint32_t> va, vb, rec_of_t;
-      BG_TRY(ka.alloc(ctx, T));
-      BG_TRY(kb.alloc(ctx, T));
-      BG_TRY(va.alloc(ctx, T));
-      BG_TRY(vb.alloc(ctx, T));
-      BG_TRY(rec_of_t.alloc(ctx, T));
-      k_round_keys<<<cdiv(T, 256), 256, 0, ctx->stream>>>(rec.p, rlen.p, sidx.p, tpos.p, T, W, w, ka.p);
+    // sort subset by (gid, key_w): LSD = key_w first, then gid (stable)
+    DevBuf<uint64_t> ka, kb;
+    DevBuf<uint32_t> va, vb, rec_of_t;
+    BG_TRY(ka.alloc(ctx, T));
+    BG_TRY(kb.alloc(ctx, T));
+    BG_TRY(va.alloc(ctx, T));
+    BG_TRY(vb.alloc(ctx, T));
+    BG_TRY(rec_of_t.alloc(ctx, T));
+    k_round_keys<<<cdiv(T, 256), 256, 0, ctx->stream>>>(rec.p, rlen.p, sidx.p, tpos.p, T, W, w, ka.p);
+    BG_LAUNCH_CHECK();
+    k_gather_u32_by_u32<<<cdiv(T, 256), 256, 0, ctx->stream>>>(sidx.p, tpos.p, T, rec_of_t.p);
+    BG_LAUNCH_CHECK();
+    k_iota_u32<<<cdiv(T, 256), 256, 0, ctx->stream>>>(va.p, T);
+    BG_LAUNCH_CHECK();
+    bool b1 = false;
+    BG_TRY(radix_sort_u64(ctx, ka.p, kb.p, va.p, vb.p, T, 0, 64, &b1));
+    uint64_t* k1 = b1 ? kb.p : ka.p;   // keys sorted by word
+    uint32_t* p1 = b1 ? vb.p : va.p;   // subset element per rank
+    uint64_t* k1o = b1 ? ka.p : kb.p;  // scratch
+    uint32_t* p1o = b1 ? va.p : vb.p;
+    // second key = gid of the element; carry the element id
+    DevBuf<uint32_t> g32;
+    DevBuf<uint64_t> g64a, g64b;
+    BG_TRY(g32.alloc(ctx, T));
+    BG_TRY(g64a.alloc(ctx, T));
+    BG_TRY(g64b.alloc(ctx, T));
+    k_gather_u32_by_u32<<<cdiv(T, 256), 256, 0, ctx->stream>>>(gid.p, p1, T, g32.p);
+    BG_LAUNCH_CHECK();
+    k_u32_to_u64<<<cdiv(T, 256), 256, 0, ctx->stream>>>(g32.p, T, g64a.p);
+    BG_LAUNCH_CHECK();
+    bool b2 = false;
+    BG_TRY(radix_sort_u64(ctx, g64a.p, g64b.p, p1, p1o, T, 0, 32, &b2));
+    uint32_t* perm = b2 ? p1o : p1;        // subset element per final slot
+    uint64_t* gsorted = b2 ? g64b.p : g64a.p;
+    // write the new order back and fetch this round's keys in the new order
+    k_apply_perm<<<cdiv(T, 256), 256, 0, ctx->stream>>>(perm, tpos.p, rec_of_t.p, T, sidx.p);
+    BG_LAUNCH_CHECK();
+    // keys in new order: re-read from the records through the updated sidx
+    k_round_keys<<<cdiv(T, 256), 256, 0, ctx->stream>>>(rec.p, rlen.p, sidx.p, tpos.p, T, W, w, k1o);
+    BG_LAUNCH_CHECK();
+    // gid in new order (as u32)
+    DevBuf<uint32_t> gnew;
+    BG_TRY(gnew.alloc(ctx, T));
+    k_gather_u32_by_u32<<<cdiv(T, 256), 256, 0, ctx->stream>>>(gid.p, perm, T, gnew.p);
+    BG_LAUNCH_CHECK();
+    (void)gsorted; (void)k1;
+    // which subset slots are still tied after this word?
+    DevBuf<uint8_t> flags;
+    DevBuf<uint32_t> keep_t;
+    uint64_t T2 = 0;
+    BG_TRY(flags.alloc(ctx, T));
+    k_flag_subset_ties<<<cdiv(T, 256), 256, 0, ctx->stream>>>(gnew.p, k1o, T, flags.p);
+    BG_LAUNCH_CHECK();
+    BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, T, &keep_t, &T2));
+    DevBuf<uint32_t> tpos2, gid2;
+    DevBuf<uint64_t> tkey2;
+    BG_TRY(tpos2.alloc(ctx, T2));
+    BG_TRY(gid2.alloc(ctx, T2));
+    BG_TRY(tkey2.alloc(ctx, T2));
+    if (T2) {
+      k_gather_u32_by_u32<<<cdiv(T2, 256), 256, 0, ctx->stream>>>(tpos.p, keep_t.p, T2, tpos2.p);
       BG_LAUNCH_CHECK();
-      k_gather_u32_by_u32<<<cdiv(T, 256), 256, 0, ctx->stream>>>(sidx.p, tpos.p, T, rec_of_t.p);
+      k_gather_u32_by_u32<<<cdiv(T2, 256), 256, 0, ctx->stream>>>(gnew.p, keep_t.p, T2, gid2.p);
       BG_LAUNCH_CHECK();
-      k_iota_u32<<<cdiv(T, 256), 256, 0, ctx->stream>>>(va.p, T);
+      k_gather_u64_by_u32<<<cdiv(T2, 256), 256, 0, ctx->stream>>>(k1o, keep_t.p, T2, tkey2.p);
       BG_LAUNCH_CHECK();
-      bool b1 = false;
-      BG_TRY(radix_sort_u64(ctx, ka.p, kb.p, va.p, vb.p, T, 0, 64, &b1));
-      uint64_t* k1 = b1 ? kb.p : ka.p;   // keys sorted by word
-      uint32_t* p1 = b1 ? vb.p : va.p;   // subset element per rank
-      uint64_t* k1o = b1 ? ka.p : kb.p;  // scratch
-      uint32_t* p1o = b1 ? va.p : vb.p;
-      // second key = gid of the element; carry the element id
-      DevBuf<uint32_t> g32;
-      DevBuf<uint64_t> g64a, g64b;
-      BG_TRY(g32.alloc(ctx, T));
-      BG_TRY(g64a.alloc(ctx, T));
-      BG_TRY(g64b.alloc(ctx, T));
-      k_gather_u32_by_u32<<<cdiv(T, 256), 256, 0, ctx->stream>>>(gid.p, p1, T, g32.p);
-      BG_LAUNCH_CHECK();
-      k_u32_to_u64<<<cdiv(T, 256), 256, 0, ctx->stream>>>(g32.p, T, g64a.p);
-      BG_LAUNCH_CHECK();
-      bool b2 = false;
-      BG_TRY(radix_sort_u64(ctx, g64a.p, g64b.p, p1, p1o, T, 0, 32, &b2));
-      uint32_t* perm = b2 ? p1o : p1;        // subset element per final slot
-      uint64_t* gsorted = b2 ? g64b.p : g64a.p;
-      // write the new order back and fetch this round's keys in the new order
-      k_apply_perm<<<cdiv(T, 256), 256, 0, ctx->stream>>>(perm, tpos.p, rec_of_t.p, T, sidx.p);
-      BG_LAUNCH_CHECK();
-      // keys in new order: re-read from the records through the updated sidx
-      k_round_keys<<<cdiv(T, 256), 256, 0, ctx->stream>>>(rec.p, rlen.p, sidx.p, tpos.p, T, W, w, k1o);
-      BG_LAUNCH_CHECK();
-      // gid in new order (as u32)
-      DevBuf<uint32_t> gnew;
-      BG_TRY(gnew.alloc(ctx, T));
-      k_gather_u32_by_u32<<<cdiv(T, 256), 256, 0, ctx->stream>>>(gid.p, perm, T, gnew.p);
-      BG_LAUNCH_CHECK();
-      (void)gsorted; (void)k1;
-      // which subset slots are still tied after this word?
-      DevBuf<uint8_t> flags;
-      DevBuf<uint32_t> keep_t;
-      uint64_t T2 = 0;
-      BG_TRY(flags.alloc(ctx, T));
-      k_flag_subset_ties<<<cdiv(T, 256), 256, 0, ctx->stream>>>(gnew.p, k1o, T, flags.p);
-      BG_LAUNCH_CHECK();
-      BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, T, &keep_t, &T2));
-      DevBuf<uint32_t> tpos2, gid2;
-      DevBuf<uint64_t> tkey2;
-      BG_TRY(tpos2.alloc(ctx, T2));
-      BG_TRY(gid2.alloc(ctx, T2));
-      BG_TRY(tkey2.alloc(ctx, T2));
-      if (T2) {
-        k_gather_u32_by_u32<<<cdiv(T2, 256), 256, 0, ctx->stream>>>(tpos.p, keep_t.p, T2, tpos2.p);
-        BG_LAUNCH_CHECK();
-        k_gather_u32_by_u32<<<cdiv(T2, 256), 256, 0, ctx->stream>>>(gnew.p, keep_t.p, T2, gid2.p);
-        BG_LAUNCH_CHECK();
-        k_gather_u64_by_u32<<<cdiv(T2, 256), 256, 0, ctx->stream>>>(k1o, keep_t.p, T2, tkey2.p);
-        BG_LAUNCH_CHECK();
-      }
-      BG_HIP(hipStreamSynchronize(ctx->stream));
-      tpos = std::move(tpos2);
-      gid = std::move(gid2);
-      tkey = std::move(tkey2);
-      T = T2;
     }
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    tpos = std::move(tpos2);
+    gid = std::move(gid2);
+    tkey = std::move(tkey2);
+    T = T2;
+  }
   }
 
   // ---- dedup + entries
@@ -628,6 +638,7 @@ extern "C" int bg_seqset_build(bg_ctx* ctx, const bg_reads* reads, int cover_k, 
     rec.reset(); rlen.reset(); sidx.reset();
     BG_TRY(compact_flagged<uint32_t>(ctx, keep.p, n_rec, &kept_pos, &n_ent));
     ss->n = n_ent;
+    ss->W = W;
     BG_TRY(ss->keys.alloc(ctx, n_ent * W));
     BG_TRY(ss->sizes.alloc(ctx, n_ent));
     BG_TRY(ss->shared.alloc(ctx, n_ent));
@@ -639,37 +650,74 @@ extern "C" int bg_seqset_build(bg_ctx* ctx, const bg_reads* reads, int cover_k, 
       ctx->toc(n_ent * (W * 16 + 8));
     }
   }
+  uint32_t h_err[2] = {0, 0};
+  BG_HIP(hipMemcpyAsync(h_err, err.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_err[0] & 1) { set_error("suffix records not sorted (internal error)"); return BG_EINTERNAL; }
+  if (n_tied_out) *n_tied_out = n_tied;
+  return BG_OK;
+}
 
-  // ---- prev bits + rank index
-  const uint64_t nwords = (n_ent + 63) / 64;
+int alloc_prev_bits(bg_ctx* ctx, bg_seqset* ss) {
+  const uint64_t nwords = (ss->n + 63) / 64;
   for (int b = 0; b < 4; ++b) {
     BG_TRY(ss->bits[b].alloc(ctx, nwords));
     if (nwords) BG_HIP(hipMemsetAsync(ss->bits[b].p, 0, nwords * 8, ctx->stream));
   }
+  return BG_OK;
+}
+
+// Phase C (single shard): prev bits from the shard's own entries.
+int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss) {
+  const uint64_t n_ent = ss->n;
+  BG_TRY(alloc_prev_bits(ctx, ss));
+  DevBuf<uint32_t> err;
+  BG_TRY(err.alloc(ctx, 2));
+  BG_HIP(hipMemsetAsync(err.p, 0, 8, ctx->stream));
   if (n_ent) {
     ctx->tic("prev_bits");
     k_prev_bits<<<cdiv(n_ent, 256), 256, 0, ctx->stream>>>(
-        ss->keys.p, ss->sizes.p, n_ent, W, reinterpret_cast<unsigned long long*>(ss->bits[0].p),
+        ss->keys.p, ss->sizes.p, n_ent, ss->W, reinterpret_cast<unsigned long long*>(ss->bits[0].p),
         reinterpret_cast<unsigned long long*>(ss->bits[1].p), reinterpret_cast<unsigned long long*>(ss->bits[2].p),
         reinterpret_cast<unsigned long long*>(ss->bits[3].p), err.p);
     BG_LAUNCH_CHECK();
-    ctx->toc(n_ent * (W * 8 + 1 + 8));
+    ctx->toc(n_ent * (ss->W * 8 + 1 + 8));
   }
   uint32_t h_err[2] = {0, 0};
   BG_HIP(hipMemcpyAsync(h_err, err.p, 8, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
-  if (h_err[0] & 1) { set_error("bg_seqset_build: suffix records not sorted (internal error)"); return BG_EINTERNAL; }
-  if (h_err[0] & 2) { set_error("bg_seqset_build: missing expansion (entry set not closed under pop_front)"); return BG_EINTERNAL; }
+  if (h_err[0] & 2) { set_error("missing expansion (entry set not closed under pop_front)"); return BG_EINTERNAL; }
+  return BG_OK;
+}
+
+}  // namespace bg
+
+using namespace bg;
+
+extern "C" int bg_seqset_build(bg_ctx* ctx, const bg_reads* reads, int cover_k, bg_seqset** out,
+                               bg_build_stats* stats) {
+  if (!ctx || !reads || !out) { set_error("bg_seqset_build: null argument"); return BG_EINVAL; }
+  if (cover_k < 1 || cover_k > 31) { set_error("bg_seqset_build: cover_k %d outside 1..31", cover_k); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_seqset> ss(new bg_seqset);
+  ss->ctx = ctx;
+  ss->W = reads->W;
+  ss->uuid = make_uuid();
+  uint64_t n_rec = 0, n_tied = 0;
+  DevBuf<uint64_t> rec;
+  DevBuf<uint8_t> rlen;
+  BG_TRY(suffix_records_impl(ctx, reads, 0, reads->n, cover_k, &rec, &rlen, &n_rec));
+  BG_TRY(entries_from_records_impl(ctx, rec, rlen, n_rec, reads->W, ss.get(), &n_tied));
+  BG_TRY(prev_bits_local_impl(ctx, ss.get()));
   // the longest read is never a proper prefix of anything longer, so it survives as an entry
-  ss->max_len = n_ent ? reads->max_len : 0;
+  ss->max_len = ss->n ? reads->max_len : 0;
   ctx->tic("seqset_finalize");
   BG_TRY(seqset_finalize_device(ctx, ss.get()));
-  ctx->toc(n_ent * 3);
-
+  ctx->toc(ss->n * 3);
   if (stats) {
     stats->n_records = n_rec;
     stats->n_tied_records = n_tied;
-    stats->n_entries = n_ent;
+    stats->n_entries = ss->n;
     stats->max_len = ss->max_len;
   }
   *out = ss.release();

@@ -331,6 +331,20 @@ __global__ __launch_bounds__(RS_THREADS) void rs_digit_census_kernel(const uint6
   }
 }
 
+// Lanes of the wave holding the same 8-bit digit (and the same validity) as this lane.
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
+  uint64_t m = ~0ull;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    bool bit = (d >> b) & 1;
+    uint64_t bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  uint64_t bv = __ballot(valid);
+  m &= valid ? bv : ~bv;
+  return m;
+}
+
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift,
                                                              uint32_t dmask, uint32_t* __restrict__ hist,
                                                              uint32_t ntiles) {
@@ -347,19 +361,29 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t* __r
   hist[uint64_t(threadIdx.x) * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
-// Lanes of the wave holding the same 8-bit digit (and the same validity) as this lane.
-__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
-  uint64_t m = ~0ull;
-#pragma unroll
-  for (int b = 0; b < 8; ++b) {
-    bool bit = (d >> b) & 1;
-    uint64_t bal = __ballot(bit);
-    m &= bit ? bal : ~bal;
+// Same histogram for keys with few distinct digit values (partition destinations, group ids): lanes
+// holding the same digit are found with ballots and one lane adds the whole group, so a wave costs
+// at most (#distinct digits) LDS atomics instead of 64 serialised ones on one address.
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_agg_kernel(const uint64_t* __restrict__ keys, uint64_t n,
+                                                                 int shift, uint32_t dmask,
+                                                                 uint32_t* __restrict__ hist, uint32_t ntiles) {
+  __shared__ uint32_t h[RS_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const uint64_t lane_lt = (1ull << lane) - 1;
+  uint64_t base = uint64_t(blockIdx.x) * RS_TILE;
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    uint64_t idx = base + uint64_t(it) * RS_THREADS + threadIdx.x;
+    bool valid = idx < n;
+    uint32_t d = valid ? uint32_t(keys[idx] >> shift) & dmask : 0u;
+    uint64_t m = match_digit(d, valid);
+    if (valid && (m & lane_lt) == 0) atomicAdd(&h[d], uint32_t(__popcll(m)));
   }
-  uint64_t bv = __ballot(valid);
-  m &= valid ? bv : ~bv;
-  return m;
+  __syncthreads();
+  hist[uint64_t(threadIdx.x) * ntiles + blockIdx.x] = h[threadIdx.x];
 }
+
 
 template <class OffT, bool HAS_VAL>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t* __restrict__ kin,
@@ -446,24 +470,28 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t* 
 
 template <class OffT>
 static int radix_sort_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
-                           uint64_t n, int bit_lo, int bit_hi, bool* in_b) {
+                           uint64_t n, int bit_lo, int bit_hi, bool* in_b, int flags) {
   *in_b = false;
   if (n <= 1 || bit_hi <= bit_lo) return BG_OK;
   const bool has_val = vals_a != nullptr;
   const uint64_t ntiles = (n + RS_TILE - 1) / RS_TILE;
 
-  // census -> which byte-aligned digits actually vary
-  DevBuf<unsigned long long> census;
-  BG_TRY(census.alloc(ctx, 8 * RS_BINS));
-  BG_HIP(hipMemsetAsync(census.p, 0, census.bytes(), ctx->stream));
-  unsigned cgrid = unsigned(ntiles < 2048 ? ntiles : 2048);
-  ctx->tic("radix_census");
-  rs_digit_census_kernel<<<cgrid, RS_THREADS, 0, ctx->stream>>>(keys_a, n, census.p);
-  BG_LAUNCH_CHECK();
-  ctx->toc(n * 8);
-  std::vector<unsigned long long> hc(8 * RS_BINS);
-  BG_HIP(hipMemcpyAsync(hc.data(), census.p, census.bytes(), hipMemcpyDeviceToHost, ctx->stream));
-  BG_HIP(hipStreamSynchronize(ctx->stream));
+  // census -> which byte-aligned digits actually vary (skipped for low-entropy keys, whose single
+  // pass is always needed and whose census would serialise on one LDS address)
+  const bool low_entropy = (flags & RS_LOW_ENTROPY) != 0;
+  std::vector<unsigned long long> hc(8 * RS_BINS, 0);
+  if (!low_entropy) {
+    DevBuf<unsigned long long> census;
+    BG_TRY(census.alloc(ctx, 8 * RS_BINS));
+    BG_HIP(hipMemsetAsync(census.p, 0, census.bytes(), ctx->stream));
+    unsigned cgrid = unsigned(ntiles < 2048 ? ntiles : 2048);
+    ctx->tic("radix_census");
+    rs_digit_census_kernel<<<cgrid, RS_THREADS, 0, ctx->stream>>>(keys_a, n, census.p);
+    BG_LAUNCH_CHECK();
+    ctx->toc(n * 8);
+    BG_HIP(hipMemcpyAsync(hc.data(), census.p, census.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
 
   DevBuf<uint32_t> hist;
   DevBuf<OffT> offs;
@@ -479,7 +507,7 @@ static int radix_sort_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint
     int bits = bit_hi - shift < 8 ? bit_hi - shift : 8;
     uint32_t dmask = (1u << bits) - 1;
     // skip when every key has the same value in this digit (only checkable for byte-aligned digits)
-    if ((shift & 7) == 0) {
+    if (!low_entropy && (shift & 7) == 0) {
       const unsigned long long* h = &hc[(shift >> 3) * RS_BINS];
       // fold bins that alias under dmask
       bool single = false;
@@ -490,7 +518,11 @@ static int radix_sort_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint
       if (single) continue;
     }
     ctx->tic("radix_hist");
-    rs_hist_kernel<<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(kin, n, shift, dmask, hist.p, uint32_t(ntiles));
+    if (low_entropy)
+      rs_hist_agg_kernel<<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(kin, n, shift, dmask, hist.p,
+                                                                           uint32_t(ntiles));
+    else
+      rs_hist_kernel<<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(kin, n, shift, dmask, hist.p, uint32_t(ntiles));
     BG_LAUNCH_CHECK();
     ctx->toc(n * 8);
     ctx->tic("radix_scan");
@@ -514,9 +546,10 @@ static int radix_sort_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint
 }
 
 int radix_sort_u64(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint64_t n,
-                   int bit_lo, int bit_hi, bool* in_b) {
-  if (n < (1ull << 32)) return radix_sort_impl<uint32_t>(ctx, keys_a, keys_b, vals_a, vals_b, n, bit_lo, bit_hi, in_b);
-  return radix_sort_impl<uint64_t>(ctx, keys_a, keys_b, vals_a, vals_b, n, bit_lo, bit_hi, in_b);
+                   int bit_lo, int bit_hi, bool* in_b, int flags) {
+  if (n < (1ull << 32))
+    return radix_sort_impl<uint32_t>(ctx, keys_a, keys_b, vals_a, vals_b, n, bit_lo, bit_hi, in_b, flags);
+  return radix_sort_impl<uint64_t>(ctx, keys_a, keys_b, vals_a, vals_b, n, bit_lo, bit_hi, in_b, flags);
 }
 
 }  // namespace bg

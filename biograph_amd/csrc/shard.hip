@@ -1,0 +1,503 @@
+// shard.hip — exchange points of the sharded (multi-GPU) seqset build.
+//
+// One process per GPU; the host side (biograph_amd/sharded.py) moves the buffers these entry points
+// fill with torch.distributed (RCCL all_to_all / all_gather over xGMI).  The library itself never
+// communicates: every function here works on one rank's device memory.
+//
+//   k-mer instances --bg_partition_rows(KMER_HASH)--> all_to_all --> bg_kmer_count_keys --> all_gather kept
+//   corrected reads --bg_reads_export--> all_gather --> bg_reads_import (cover index needs all reads)
+//   suffix records  --bg_partition_rows(PREFIX)--> all_to_all --> bg_entries_from_records
+//   boundary rows   --all_gather--> bg_seqset_fix_boundary      (part_repo.cpp:294-303, expand.cpp:318-327)
+//   tails s[1:]     --bg_partition_rows(KEY_BOUNDS)--> all_to_all --> bg_seqset_apply_tails (builder.cpp:85-108)
+//   slices          --gather--> bg_seqset_assemble --> seqset::finalize (seqset.cpp:113-129)
+#include "bg_device_funcs.h"
+#include "bg_internal.h"
+
+namespace bg {
+
+constexpr uint64_t kDropDest = 255;
+
+// ---- destination kernels: dest[i] (as a u64 radix key) and idx[i] = i
+
+__global__ void k_dest_kmer_hash(const uint64_t* __restrict__ rows, uint64_t n, uint32_t nparts,
+                                 uint64_t* __restrict__ dest, uint32_t* __restrict__ idx) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t k = rows[i];
+  // owner = floor(hash * nparts / 2^32) of the top 32 hash bits: uniform, independent of the table hash
+  uint64_t h = (k * 0xD6E8FEB86659FD93ull) >> 32;
+  dest[i] = (k == ~0ull) ? kDropDest : ((h * nparts) >> 32);
+  idx[i] = uint32_t(i);
+}
+
+// rows = W+1 words; bin = leading `hb` bases of word 0; dest = number of splitters <= bin
+__global__ void k_dest_prefix(const uint64_t* __restrict__ rows, uint64_t n, int row_words, int hb,
+                              const uint32_t* __restrict__ splitters, uint32_t nparts, uint64_t* __restrict__ dest,
+                              uint32_t* __restrict__ idx) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t bin = uint32_t(rows[i * row_words] >> (64 - 2 * hb));
+  uint32_t d = 0;
+  for (uint32_t s = 0; s + 1 < nparts; ++s) d += (splitters[s] <= bin) ? 1u : 0u;
+  dest[i] = d;
+  idx[i] = uint32_t(i);
+}
+
+// rows = W+1 words (last word: low 8 bits = length); bounds = nparts rows (last word ~0 = rank holds no
+// entries).  dest = first rank whose last entry is >= the row (global lower_bound lands there).
+__global__ void k_dest_key_bounds(const uint64_t* __restrict__ rows, uint64_t n, int W,
+                                  const uint64_t* __restrict__ bounds, uint32_t nparts, uint64_t* __restrict__ dest,
+                                  uint32_t* __restrict__ idx, uint32_t* __restrict__ err) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t* r = rows + i * (W + 1);
+  int rl = int(r[W] & 0xff);
+  uint64_t d = kDropDest;
+  for (uint32_t p = 0; p < nparts; ++p) {
+    const uint64_t* b = bounds + uint64_t(p) * (W + 1);
+    if (b[W] == ~0ull) continue;
+    if (key_compare(r, rl, b, int(b[W] & 0xff), W) <= 0) { d = p; break; }
+  }
+  if (d == kDropDest) atomicOr(err, 2u);  // no entry extends this tail anywhere: closure violated
+  dest[i] = d;
+  idx[i] = uint32_t(i);
+}
+
+// destinations take few distinct values: lanes with equal dest are grouped with ballots and one lane
+// adds the group's size (no serialised same-address LDS atomics)
+__global__ __launch_bounds__(256) void k_dest_counts(const uint64_t* __restrict__ dest, uint64_t n,
+                                                     unsigned long long* __restrict__ counts) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t lane_lt = (1ull << (threadIdx.x & 63)) - 1;
+  const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
+  const uint64_t rounds = (n + stride - 1) / stride;
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (uint64_t t = 0; t < rounds; ++t, i += stride) {  // every lane runs every round (ballots below)
+    bool valid = i < n;
+    uint32_t d = valid ? uint32_t(dest[i] & 0xff) : 0u;
+    uint64_t m = ~0ull;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      bool bit = (d >> b) & 1;
+      uint64_t bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    uint64_t bv = __ballot(valid);
+    m &= valid ? bv : ~bv;
+    if (valid && (m & lane_lt) == 0) atomicAdd(&h[d], uint32_t(__popcll(m)));
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+__global__ void k_gather_rows(const uint64_t* __restrict__ rows, const uint32_t* __restrict__ perm, uint64_t n_out,
+                              int row_words, uint64_t* __restrict__ out) {
+  uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= n_out * uint64_t(row_words)) return;
+  uint64_t i = g / uint64_t(row_words);
+  int w = int(g - i * uint64_t(row_words));
+  out[g] = rows[uint64_t(perm[i]) * row_words + w];
+}
+
+// ---- rows <-> records / tails
+
+__global__ void k_records_to_rows(const uint64_t* __restrict__ rec, const uint8_t* __restrict__ rlen, uint64_t n, int W,
+                                  uint64_t* __restrict__ rows) {
+  uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= n * uint64_t(W + 1)) return;
+  uint64_t i = g / uint64_t(W + 1);
+  int w = int(g - i * uint64_t(W + 1));
+  rows[g] = w < W ? rec[i * W + w] : uint64_t(rlen[i]);
+}
+__global__ void k_rows_to_records(const uint64_t* __restrict__ rows, uint64_t n, int W, uint64_t* __restrict__ rec,
+                                  uint8_t* __restrict__ rlen) {
+  uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= n * uint64_t(W + 1)) return;
+  uint64_t i = g / uint64_t(W + 1);
+  int w = int(g - i * uint64_t(W + 1));
+  uint64_t v = rows[g];
+  if (w < W) rec[i * W + w] = v; else rlen[i] = uint8_t(v);
+}
+
+// tail row of entry i: s[1:] zero padded, last word = (len-1) | first base << 8
+__global__ void k_tail_rows(const uint64_t* __restrict__ ekeys, const uint8_t* __restrict__ sizes, uint64_t n, int W,
+                            uint64_t* __restrict__ rows) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t* s = ekeys + i * W;
+  uint64_t* r = rows + i * (W + 1);
+  for (int w = 0; w < W; ++w) r[w] = window32(s, W, 1 + 32 * w);
+  r[W] = uint64_t(sizes[i] - 1) | ((s[0] >> 62) << 8);
+}
+
+// received tails -> prev bits of this rank's entries (same search as k_prev_bits)
+__global__ __launch_bounds__(256) void k_apply_tails(const uint64_t* __restrict__ rows, uint64_t nt,
+                                                     const uint64_t* __restrict__ ekeys,
+                                                     const uint8_t* __restrict__ sizes, uint64_t n, int W,
+                                                     unsigned long long* __restrict__ bA,
+                                                     unsigned long long* __restrict__ bC,
+                                                     unsigned long long* __restrict__ bG,
+                                                     unsigned long long* __restrict__ bT, uint32_t* __restrict__ err) {
+  uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= nt) return;
+  const uint64_t* tail = rows + t * (W + 1);
+  int tl = int(tail[W] & 0xff), b = int((tail[W] >> 8) & 3);
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) >> 1;
+    if (key_compare(ekeys + mid * W, sizes[mid], tail, tl, W) < 0) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= n || key_lcp(ekeys + lo * W, sizes[lo], tail, tl, W) < tl) { atomicOr(err, 2u); return; }
+  unsigned long long* bits = b == 0 ? bA : b == 1 ? bC : b == 2 ? bG : bT;
+  atomicOr(&bits[lo >> 6], 1ull << (lo & 63));
+}
+
+// local bit words of one slice OR-ed into the global bit vector at bit offset `off`
+__global__ void k_place_bits(const uint64_t* __restrict__ local, uint64_t n_local_bits, uint64_t off,
+                             unsigned long long* __restrict__ global) {
+  uint64_t w = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  uint64_t nw = (n_local_bits + 63) / 64;
+  if (w >= nw) return;
+  uint64_t v = local[w];
+  uint64_t valid = n_local_bits - w * 64;
+  if (valid < 64) v &= (1ull << valid) - 1;
+  if (!v) return;
+  uint64_t bit = off + w * 64;
+  uint64_t gw = bit >> 6;
+  int sh = int(bit & 63);
+  atomicOr(&global[gw], (unsigned long long)(v << sh));
+  if (sh && (v >> (64 - sh))) atomicOr(&global[gw + 1], (unsigned long long)(v >> (64 - sh)));
+}
+
+__global__ void k_copy_len_u16(const uint16_t* __restrict__ in, uint64_t n, uint16_t* __restrict__ out) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+__global__ void k_restride_words(const uint64_t* __restrict__ in, uint64_t n, int W_in, int W_out,
+                                 uint64_t* __restrict__ out) {
+  uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= n * uint64_t(W_out)) return;
+  uint64_t i = g / uint64_t(W_out);
+  int w = int(g - i * uint64_t(W_out));
+  out[g] = w < W_in ? in[i * W_in + w] : 0;
+}
+
+}  // namespace bg
+
+using namespace bg;
+
+// ---- generic row partition ----------------------------------------------------------------------
+
+extern "C" int bg_partition_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int row_words, int mode,
+                                 uint32_t nparts, const uint64_t* h_params, uint64_t* d_out_rows,
+                                 uint64_t* h_counts) {
+  if (!ctx || !h_counts || (n && (!d_rows || !d_out_rows))) { set_error("bg_partition_rows: null argument"); return BG_EINVAL; }
+  if (nparts < 1 || nparts > 128 || row_words < 1 || row_words > kMaxWords + 1) { set_error("bg_partition_rows: bad geometry"); return BG_EINVAL; }
+  if (n >= (1ull << 32)) { set_error("bg_partition_rows: %llu rows exceed one call", (unsigned long long)n); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  for (uint32_t p = 0; p < nparts; ++p) h_counts[p] = 0;
+  if (!n) return BG_OK;
+  DevBuf<uint64_t> da, db;
+  DevBuf<uint32_t> ia, ib, err;
+  DevBuf<unsigned long long> counts;
+  BG_TRY(da.alloc(ctx, n));
+  BG_TRY(db.alloc(ctx, n));
+  BG_TRY(ia.alloc(ctx, n));
+  BG_TRY(ib.alloc(ctx, n));
+  BG_TRY(err.alloc(ctx, 1));
+  BG_TRY(counts.alloc(ctx, 256));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+  BG_HIP(hipMemsetAsync(counts.p, 0, 256 * 8, ctx->stream));
+  ctx->tic("partition_dest");
+  if (mode == BG_PART_KMER_HASH) {
+    if (row_words != 1) { set_error("bg_partition_rows: KMER_HASH takes 1-word rows"); return BG_EINVAL; }
+    k_dest_kmer_hash<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_rows, n, nparts, da.p, ia.p);
+  } else if (mode == BG_PART_PREFIX) {
+    if (!h_params) { set_error("bg_partition_rows: PREFIX needs params"); return BG_EINVAL; }
+    int hb = int(h_params[0]);
+    if (hb < 1 || hb > 16) { set_error("bg_partition_rows: prefix bases %d outside 1..16", hb); return BG_EINVAL; }
+    std::vector<uint32_t> sp(nparts ? nparts : 1, 0);
+    for (uint32_t s = 0; s + 1 < nparts; ++s) sp[s] = uint32_t(h_params[1 + s]);
+    DevBuf<uint32_t> dsp;
+    BG_TRY(dsp.alloc(ctx, nparts));
+    BG_HIP(hipMemcpyAsync(dsp.p, sp.data(), nparts * 4, hipMemcpyHostToDevice, ctx->stream));
+    k_dest_prefix<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_rows, n, row_words, hb, dsp.p, nparts, da.p, ia.p);
+    BG_LAUNCH_CHECK();
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  } else if (mode == BG_PART_KEY_BOUNDS) {
+    if (!h_params) { set_error("bg_partition_rows: KEY_BOUNDS needs params"); return BG_EINVAL; }
+    DevBuf<uint64_t> dbounds;
+    BG_TRY(dbounds.alloc(ctx, uint64_t(nparts) * row_words));
+    BG_HIP(hipMemcpyAsync(dbounds.p, h_params, uint64_t(nparts) * row_words * 8, hipMemcpyHostToDevice, ctx->stream));
+    k_dest_key_bounds<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_rows, n, row_words - 1, dbounds.p, nparts, da.p, ia.p,
+                                                             err.p);
+    BG_LAUNCH_CHECK();
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  } else {
+    set_error("bg_partition_rows: unknown mode %d", mode);
+    return BG_EINVAL;
+  }
+  BG_LAUNCH_CHECK();
+  unsigned grid = cdiv(n, 256) < 1024u ? cdiv(n, 256) : 1024u;
+  k_dest_counts<<<grid, 256, 0, ctx->stream>>>(da.p, n, counts.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n * (uint64_t(row_words) * 8 + 12));
+  bool in_b = false;
+  BG_TRY(radix_sort_u64(ctx, da.p, db.p, ia.p, ib.p, n, 0, 8, &in_b, RS_LOW_ENTROPY));
+  unsigned long long hc[256];
+  uint32_t h_err = 0;
+  BG_HIP(hipMemcpyAsync(hc, counts.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_err) { set_error("bg_partition_rows: a tail is not extended by any entry (missing expansion)"); return BG_EINTERNAL; }
+  uint64_t n_out = 0;
+  for (uint32_t p = 0; p < nparts; ++p) { h_counts[p] = hc[p]; n_out += hc[p]; }
+  if (n_out) {
+    ctx->tic("partition_gather");
+    k_gather_rows<<<cdiv(n_out * row_words, 256), 256, 0, ctx->stream>>>(d_rows, in_b ? ib.p : ia.p, n_out, row_words,
+                                                                         d_out_rows);
+    BG_LAUNCH_CHECK();
+    ctx->toc(n_out * uint64_t(row_words) * 16);
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+// ---- reads export / import ----------------------------------------------------------------------
+
+extern "C" int bg_reads_words(const bg_reads* r) { return r ? r->W : 0; }
+
+extern "C" int bg_reads_export(bg_ctx* ctx, const bg_reads* r, int W_out, uint64_t* d_words, uint16_t* d_len) {
+  if (!ctx || !r || (r->n && (!d_words || !d_len))) { set_error("bg_reads_export: null argument"); return BG_EINVAL; }
+  if (W_out < r->W || W_out > kMaxWords) { set_error("bg_reads_export: W_out %d < W %d", W_out, r->W); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (r->n) {
+    k_restride_words<<<cdiv(r->n * W_out, 256), 256, 0, ctx->stream>>>(r->words.p, r->n, r->W, W_out, d_words);
+    BG_LAUNCH_CHECK();
+    BG_HIP(hipMemcpyAsync(d_len, r->len.p, r->n * 2, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+extern "C" int bg_reads_import(bg_ctx* ctx, uint64_t n, int W, uint32_t max_len, const uint64_t* d_words,
+                               const uint16_t* d_len, bg_reads** out) {
+  if (!ctx || !out || (n && (!d_words || !d_len))) { set_error("bg_reads_import: null argument"); return BG_EINVAL; }
+  if (W < 1 || W > kMaxWords || max_len > uint32_t(32 * W)) { set_error("bg_reads_import: bad geometry"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_reads> r(new bg_reads);
+  r->ctx = ctx;
+  r->n = n;
+  r->W = W;
+  r->max_len = max_len;
+  BG_TRY(r->words.alloc(ctx, n * W));
+  BG_TRY(r->nmask.alloc(ctx, n * W));
+  BG_TRY(r->len.alloc(ctx, n));
+  if (n) {
+    BG_HIP(hipMemcpyAsync(r->words.p, d_words, n * W * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    BG_HIP(hipMemsetAsync(r->nmask.p, 0, n * W * 4, ctx->stream));
+    BG_HIP(hipMemcpyAsync(r->len.p, d_len, n * 2, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  *out = r.release();
+  return BG_OK;
+}
+
+// ---- records ------------------------------------------------------------------------------------
+
+extern "C" int bg_suffix_records(bg_ctx* ctx, const bg_reads* reads, uint64_t read_lo, uint64_t read_hi, int cover_k,
+                                 bg_records** out) {
+  if (!ctx || !reads || !out) { set_error("bg_suffix_records: null argument"); return BG_EINVAL; }
+  if (cover_k < 1 || cover_k > 31) { set_error("bg_suffix_records: cover_k %d outside 1..31", cover_k); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_records> rec(new bg_records);
+  rec->ctx = ctx;
+  rec->W = reads->W;
+  BG_TRY(suffix_records_impl(ctx, reads, read_lo, read_hi, cover_k, &rec->rec, &rec->rlen, &rec->n));
+  *out = rec.release();
+  return BG_OK;
+}
+extern "C" uint64_t bg_records_count(const bg_records* r) { return r ? r->n : 0; }
+extern "C" int bg_records_words(const bg_records* r) { return r ? r->W : 0; }
+extern "C" void bg_records_free(bg_records* r) { delete r; }
+
+extern "C" int bg_records_rows(bg_ctx* ctx, const bg_records* r, uint64_t* d_rows) {
+  if (!ctx || !r || (r->n && !d_rows)) { set_error("bg_records_rows: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (r->n) {
+    k_records_to_rows<<<cdiv(r->n * (r->W + 1), 256), 256, 0, ctx->stream>>>(r->rec.p, r->rlen.p, r->n, r->W, d_rows);
+    BG_LAUNCH_CHECK();
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+extern "C" int bg_records_from_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int W, bg_records** out) {
+  if (!ctx || !out || (n && !d_rows)) { set_error("bg_records_from_rows: null argument"); return BG_EINVAL; }
+  if (W < 1 || W > kMaxWords) { set_error("bg_records_from_rows: bad W"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_records> r(new bg_records);
+  r->ctx = ctx;
+  r->n = n;
+  r->W = W;
+  BG_TRY(r->rec.alloc(ctx, n * W));
+  BG_TRY(r->rlen.alloc(ctx, n));
+  if (n) {
+    k_rows_to_records<<<cdiv(n * (W + 1), 256), 256, 0, ctx->stream>>>(d_rows, n, W, r->rec.p, r->rlen.p);
+    BG_LAUNCH_CHECK();
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  *out = r.release();
+  return BG_OK;
+}
+
+// sorted, prefix-free entries of one shard (keys/sizes/shared; no prev bits yet).  Consumes records.
+extern "C" int bg_entries_from_records(bg_ctx* ctx, bg_records* rec, bg_seqset** out, bg_build_stats* stats) {
+  if (!ctx || !rec || !out) { set_error("bg_entries_from_records: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_seqset> ss(new bg_seqset);
+  ss->ctx = ctx;
+  ss->W = rec->W;
+  ss->uuid = make_uuid();
+  uint64_t n_rec = rec->n, n_tied = 0;
+  BG_TRY(entries_from_records_impl(ctx, rec->rec, rec->rlen, n_rec, rec->W, ss.get(), &n_tied));
+  rec->n = 0;
+  if (stats) { stats->n_records = n_rec; stats->n_tied_records = n_tied; stats->n_entries = ss->n; }
+  *out = ss.release();
+  return BG_OK;
+}
+
+// first / last entry as rows of W+1 words (last word = length, or ~0 when the shard is empty)
+extern "C" int bg_seqset_boundary_rows(bg_ctx* ctx, const bg_seqset* ss, uint64_t* h_first_row, uint64_t* h_last_row) {
+  if (!ctx || !ss || !h_first_row || !h_last_row) { set_error("bg_seqset_boundary_rows: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  const int W = ss->W;
+  for (int w = 0; w <= W; ++w) { h_first_row[w] = 0; h_last_row[w] = 0; }
+  h_first_row[W] = h_last_row[W] = ~0ull;
+  if (!ss->n) return BG_OK;
+  uint8_t l0 = 0, l1 = 0;
+  BG_HIP(hipMemcpyAsync(h_first_row, ss->keys.p, W * 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipMemcpyAsync(h_last_row, ss->keys.p + (ss->n - 1) * W, W * 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipMemcpyAsync(&l0, ss->sizes.p, 1, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipMemcpyAsync(&l1, ss->sizes.p + (ss->n - 1), 1, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  h_first_row[W] = l0;
+  h_last_row[W] = l1;
+  return BG_OK;
+}
+
+// next_first: first entry of the next non-empty shard (or NULL): drop our last entry if it is a prefix
+// of it (part_repo.cpp:294-303 min_next_entry).  prev_last: last entry of the previous non-empty
+// shard (or NULL): shared[0] = their common prefix length (builder.cpp:225).
+extern "C" int bg_seqset_fix_boundary(bg_ctx* ctx, bg_seqset* ss, const uint64_t* h_prev_last_row,
+                                      const uint64_t* h_next_first_row) {
+  if (!ctx || !ss) { set_error("bg_seqset_fix_boundary: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  const int W = ss->W;
+  if (!ss->n) return BG_OK;
+  std::vector<uint64_t> first(W + 1), last(W + 1);
+  BG_TRY(bg_seqset_boundary_rows(ctx, ss, first.data(), last.data()));
+  if (h_next_first_row && h_next_first_row[W] != ~0ull) {
+    int ll = int(last[W]), nl = int(h_next_first_row[W] & 0xff);
+    if (key_lcp(last.data(), ll, h_next_first_row, nl, W) == ll) ss->n -= 1;
+  }
+  if (ss->n && h_prev_last_row && h_prev_last_row[W] != ~0ull) {
+    uint8_t sh = uint8_t(key_lcp(h_prev_last_row, int(h_prev_last_row[W] & 0xff), first.data(), int(first[W]), W));
+    BG_HIP(hipMemcpyAsync(ss->shared.p, &sh, 1, hipMemcpyHostToDevice, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return BG_OK;
+}
+
+extern "C" int bg_seqset_words(const bg_seqset* ss) { return ss ? ss->W : 0; }
+
+extern "C" int bg_seqset_tail_rows(bg_ctx* ctx, const bg_seqset* ss, uint64_t* d_rows) {
+  if (!ctx || !ss || (ss->n && !d_rows)) { set_error("bg_seqset_tail_rows: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (ss->n) {
+    k_tail_rows<<<cdiv(ss->n, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->sizes.p, ss->n, ss->W, d_rows);
+    BG_LAUNCH_CHECK();
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+extern "C" int bg_seqset_apply_tails(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows) {
+  if (!ctx || !ss || (n_rows && !d_rows)) { set_error("bg_seqset_apply_tails: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!ss->bits[0].p) BG_TRY(alloc_prev_bits(ctx, ss));
+  if (!n_rows) return BG_OK;
+  DevBuf<uint32_t> err;
+  BG_TRY(err.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+  ctx->tic("prev_bits");
+  k_apply_tails<<<cdiv(n_rows, 256), 256, 0, ctx->stream>>>(
+      d_rows, n_rows, ss->keys.p, ss->sizes.p, ss->n, ss->W, reinterpret_cast<unsigned long long*>(ss->bits[0].p),
+      reinterpret_cast<unsigned long long*>(ss->bits[1].p), reinterpret_cast<unsigned long long*>(ss->bits[2].p),
+      reinterpret_cast<unsigned long long*>(ss->bits[3].p), err.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n_rows * (ss->W * 8 + 1 + 8));
+  uint32_t h_err = 0;
+  BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_err) { set_error("bg_seqset_apply_tails: missing expansion (entry set not closed under pop_front)"); return BG_EINTERNAL; }
+  return BG_OK;
+}
+
+// raw slice of one shard: sizes[n], shared[n] (bytes) and 4 x ceil(n/64) bit words (A,C,G,T)
+extern "C" int bg_seqset_slice_export(bg_ctx* ctx, const bg_seqset* ss, uint8_t* d_sizes, uint8_t* d_shared,
+                                      uint64_t* d_bits) {
+  if (!ctx || !ss) { set_error("bg_seqset_slice_export: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  const uint64_t n = ss->n, nw = (n + 63) / 64;
+  if (n) {
+    if (!ss->bits[0].p) { set_error("bg_seqset_slice_export: prev bits not built"); return BG_EINVAL; }
+    BG_HIP(hipMemcpyAsync(d_sizes, ss->sizes.p, n, hipMemcpyDeviceToDevice, ctx->stream));
+    BG_HIP(hipMemcpyAsync(d_shared, ss->shared.p, n, hipMemcpyDeviceToDevice, ctx->stream));
+    for (int b = 0; b < 4; ++b)
+      BG_HIP(hipMemcpyAsync(d_bits + b * nw, ss->bits[b].p, nw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+// Final merge: concatenation of the shards' slices in rank order (shards are lexicographic ranges, so
+// no k-way merge), then seqset::finalize.  d_bits holds, shard after shard, 4 x ceil(n_p/64) words.
+extern "C" int bg_seqset_assemble(bg_ctx* ctx, uint32_t nparts, const uint64_t* h_part_n, const uint8_t* d_sizes,
+                                  const uint8_t* d_shared, const uint64_t* d_bits, uint32_t max_len, bg_seqset** out) {
+  if (!ctx || !out || !h_part_n) { set_error("bg_seqset_assemble: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  uint64_t n = 0;
+  for (uint32_t p = 0; p < nparts; ++p) n += h_part_n[p];
+  std::unique_ptr<bg_seqset> ss(new bg_seqset);
+  ss->ctx = ctx;
+  ss->n = n;
+  ss->W = 0;
+  ss->max_len = n ? max_len : 0;
+  ss->uuid = make_uuid();
+  BG_TRY(ss->sizes.alloc(ctx, n));
+  BG_TRY(ss->shared.alloc(ctx, n));
+  if (n) {
+    BG_HIP(hipMemcpyAsync(ss->sizes.p, d_sizes, n, hipMemcpyDeviceToDevice, ctx->stream));
+    BG_HIP(hipMemcpyAsync(ss->shared.p, d_shared, n, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  BG_TRY(alloc_prev_bits(ctx, ss.get()));
+  uint64_t off = 0, woff = 0;
+  for (uint32_t p = 0; p < nparts; ++p) {
+    uint64_t np = h_part_n[p], nw = (np + 63) / 64;
+    for (int b = 0; b < 4 && np; ++b) {
+      k_place_bits<<<cdiv(nw, 256), 256, 0, ctx->stream>>>(d_bits + woff + b * nw, np, off,
+                                                           reinterpret_cast<unsigned long long*>(ss->bits[b].p));
+      BG_LAUNCH_CHECK();
+    }
+    off += np;
+    woff += 4 * nw;
+  }
+  ctx->tic("seqset_finalize");
+  BG_TRY(seqset_finalize_device(ctx, ss.get()));
+  ctx->toc(n * 3);
+  *out = ss.release();
+  return BG_OK;
+}

@@ -1,0 +1,385 @@
+"""Sharded (multi-GPU) seqset build: one process per GPU, buffers exchanged with torch.distributed
+(backend "nccl" = RCCL over xGMI).  SURVEY.md §8e / DESIGN.md §7.
+
+Reads are sharded arbitrarily across ranks.  Exchange steps (everything else is rank-local HIP work
+behind the C ABI):
+
+  1. k-mer instances   partition by hash(kmer) -> all_to_all  -> per-rank exact counts + filter
+  2. kept k-mers       all_gather                              -> replicated hash set
+  3. corrected reads   all_gather (packed 2-bit)               -> replicated cover index
+  4. suffix records    partition by leading bases (balanced splitters from an all-reduced
+                       histogram) -> all_to_all                -> per-rank sort + prefix-dedup
+  5. boundary entries  all_gather of first/last entries        -> cross-shard prefix drop, shared[0]
+  6. tails s[1:]       partition by owner of lower_bound -> all_to_all -> prev_{ACGT} bits
+  7. slices            gather -> concatenation (shards are lexicographic ranges) + finalize
+
+`Comm` abstracts "the ranks this process drives": `TorchDistComm` (one rank, real collectives) and
+`LocalSimComm` (all ranks in one process on one GPU — used by the 1-GPU parity tests, where RCCL
+cannot run two ranks on one device).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .capi import BuildStats
+
+PREFIX_BASES = 8  # splitter resolution: 4^8 bins of leading bases
+
+
+# ------------------------------------------------------------------------------------------------
+# communicators
+
+class LocalSimComm:
+    """All `world` ranks live in this process; collectives are plain tensor shuffles."""
+
+    def __init__(self, world):
+        self.world = world
+        self.local_ranks = list(range(world))
+
+    def all_to_all_v(self, send):
+        """send[r] = (rows [n, width], counts list[world]) -> recv[r] = rows from all sources in rank order."""
+        pieces = {r: [] for r in self.local_ranks}
+        for src in self.local_ranks:
+            rows, counts = send[src]
+            off = 0
+            for dst in range(self.world):
+                pieces[dst].append(rows[off:off + counts[dst]])
+                off += counts[dst]
+        return {r: torch.cat(pieces[r], dim=0) for r in self.local_ranks}
+
+    def all_gather_v(self, send):
+        """send[r] = tensor -> every rank gets the list [tensor of rank 0, ...]."""
+        lst = [send[r] for r in range(self.world)]
+        return {r: lst for r in self.local_ranks}
+
+    def all_gather_obj(self, send):
+        lst = [send[r] for r in range(self.world)]
+        return {r: lst for r in self.local_ranks}
+
+    def all_reduce_sum(self, send):
+        tot = None
+        for r in self.local_ranks:
+            tot = send[r].clone() if tot is None else tot + send[r]
+        return {r: tot for r in self.local_ranks}
+
+    def barrier(self):
+        pass
+
+
+class TorchDistComm:
+    """One rank per process over an initialised torch.distributed process group."""
+
+    def __init__(self, device):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.local_ranks = [self.rank]
+        self.device = device
+
+    # RCCL 2.26 (ROCm 7.0 build shipped with torch 2.10) returned corrupt data for all_to_all pieces of
+    # exactly 2^31 / 2^32 / 2^33 bytes on MI355X (tools/debug_nccl_big.py); every piece is therefore
+    # kept <= 1 GiB - 4 KiB and large exchanges run as several rounds.
+    MAX_PIECE_BYTES = (1 << 30) - 4096
+
+    def all_to_all_v(self, send):
+        dist = self.dist
+        rows, counts = send[self.rank]
+        rows = rows.contiguous()
+        counts = [int(c) for c in counts]
+        cin = torch.tensor(counts, dtype=torch.int64, device=self.device)
+        cout = torch.empty_like(cin)
+        dist.all_to_all_single(cout, cin)
+        out_counts = [int(x) for x in cout.tolist()]
+        row_bytes = rows.element_size()
+        for d in rows.shape[1:]:
+            row_bytes *= int(d)
+        max_rows = max(1, self.MAX_PIECE_BYTES // max(row_bytes, 1))
+        mx = torch.tensor([max(counts + [0])], dtype=torch.int64, device=self.device)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        rounds = max(1, -(-int(mx.item()) // max_rows))
+        starts = [0]
+        for c in counts:
+            starts.append(starts[-1] + c)
+        outs = []
+        for t in range(rounds):
+            in_split = [max(0, min(c - t * max_rows, max_rows)) for c in counts]
+            out_split = [max(0, min(c - t * max_rows, max_rows)) for c in out_counts]
+            if rounds == 1:
+                chunk = rows
+            else:
+                chunk = torch.cat([rows[starts[d] + t * max_rows: starts[d] + t * max_rows + in_split[d]]
+                                   for d in range(self.world)], dim=0)
+            out = torch.empty((sum(out_split),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=self.device)
+            dist.all_to_all_single(out, chunk, output_split_sizes=out_split, input_split_sizes=in_split)
+            outs.append(out)
+        return {self.rank: outs[0] if rounds == 1 else torch.cat(outs, dim=0)}
+
+    def all_gather_v(self, send):
+        dist = self.dist
+        t = send[self.rank].contiguous()
+        n = torch.tensor([t.shape[0]], dtype=torch.int64, device=self.device)
+        sizes = [torch.empty_like(n) for _ in range(self.world)]
+        dist.all_gather(sizes, n)
+        sizes = [int(s.item()) for s in sizes]
+        mx = max(sizes + [1])
+        pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
+        pad[:t.shape[0]] = t
+        outs = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(outs, pad)
+        return {self.rank: [outs[i][:sizes[i]] for i in range(self.world)]}
+
+    def all_gather_obj(self, send):
+        lst = [None] * self.world
+        self.dist.all_gather_object(lst, send[self.rank])
+        return {self.rank: lst}
+
+    def all_reduce_sum(self, send):
+        t = send[self.rank].clone()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return {self.rank: t}
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+# ------------------------------------------------------------------------------------------------
+# thin wrappers over the sharded C ABI working on torch tensors (int64 tensors carry u64 bits)
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr() if t.numel() else 0)
+
+
+def _partition(ctx, rows, mode, nparts, params):
+    """rows: int64 [n, width] -> (partitioned rows, counts list)."""
+    n, width = rows.shape
+    out = torch.empty_like(rows)
+    counts = (C.c_uint64 * nparts)()
+    p = None
+    if params is not None:
+        params = np.ascontiguousarray(params, np.uint64)
+        p = capi.np_ptr(params)
+    capi.check(capi.lib().bg_partition_rows(ctx.h, _ptr(rows), n, width, mode, nparts, p, _ptr(out), counts))
+    counts = [int(c) for c in counts]
+    return out[:sum(counts)], counts
+
+
+def choose_splitters(hist, nparts):
+    """Balanced contiguous bin ranges from the global leading-bases histogram: splitter j = first bin
+    at which the running count reaches j/nparts of the total (ascending, may repeat)."""
+    h = np.asarray(hist, np.float64)
+    cum = np.cumsum(h)
+    total = cum[-1] if len(cum) else 0.0
+    sp = []
+    for j in range(1, nparts):
+        target = total * j / nparts
+        b = int(np.searchsorted(cum, target, side="left")) + 1 if total > 0 else len(h)
+        sp.append(min(max(b, sp[-1] if sp else 0), len(h)))
+    return sp
+
+
+def _next_nonempty(rows, r, step):
+    q = r + step
+    while 0 <= q < len(rows):
+        if rows[q][-1] != 0xFFFFFFFFFFFFFFFF:
+            return rows[q]
+        q += step
+    return None
+
+
+# ------------------------------------------------------------------------------------------------
+
+def sharded_create(comm, ctxs, inputs, params=None, device=None):
+    """comm: communicator; ctxs[r]: biograph_amd.Context of local rank r; inputs[r] = (seq uint8 tensor,
+    offs int64 tensor, n_reads) resident on that rank's device.  Returns {r: (Seqset | None, stats)};
+    the assembled seqset lives on rank 0."""
+    import biograph_amd as bg
+    L = capi.lib()
+    P = comm.world
+    ranks = comm.local_ranks
+    any_ctx = ctxs[ranks[0]]
+    prm = params or any_ctx.default_params()
+    k = prm.kmer_size
+    dev = {r: inputs[r][0].device for r in ranks}
+    i64 = torch.int64
+
+    # ---- S1 pack (local)
+    reads = {r: ctxs[r].pack_reads_device(inputs[r][0].data_ptr(), inputs[r][1].data_ptr(), inputs[r][2])
+             for r in ranks}
+    n_bases = comm.all_gather_obj({r: int(reads[r].total_bases) for r in ranks})[ranks[0]]
+
+    # ---- S2 k-mer instances -> owner ranks
+    send = {}
+    n_inst = {}
+    for r in ranks:
+        n = C.c_uint64()
+        capi.check(L.bg_kmer_instances(ctxs[r].h, reads[r].h, k, C.byref(n)))
+        n_inst[r] = n.value
+        keys = torch.empty((n.value, 1), dtype=i64, device=dev[r])
+        capi.check(L.bg_kmer_extract(ctxs[r].h, reads[r].h, k, _ptr(keys), n.value))
+        send[r] = _partition(ctxs[r], keys, capi.PART_KMER_HASH, P, None)
+        del keys
+    recv = comm.all_to_all_v(send)
+    del send
+    kept = {}
+    distinct = {}
+    for r in ranks:
+        keys = recv[r].contiguous()
+        h = C.c_void_p()
+        capi.check(L.bg_kmer_count_keys(ctxs[r].h, _ptr(keys), keys.shape[0], k, prm.min_kmer_count, C.byref(h)))
+        ks = bg.KmerSet(ctxs[r], h, k)
+        distinct[r] = ks.distinct
+        t = torch.empty((len(ks),), dtype=i64, device=dev[r])
+        capi.check(L.bg_kmerset_export(ctxs[r].h, ks.h, _ptr(t)))
+        kept[r] = t
+        ks.free()
+    del recv
+    gathered = comm.all_gather_v(kept)
+    tot_inst = sum(comm.all_gather_obj(n_inst)[ranks[0]])
+    tot_distinct = sum(comm.all_gather_obj(distinct)[ranks[0]])
+    ksets = {}
+    for r in ranks:
+        allk = torch.cat([g.to(dev[r]) for g in gathered[r]]).contiguous()
+        h = C.c_void_p()
+        capi.check(L.bg_kmerset_from_kmers(ctxs[r].h, _ptr(allk), allk.shape[0], k, reads[r].h, C.byref(h)))
+        ksets[r] = bg.KmerSet(ctxs[r], h, k)
+        n_kept = allk.shape[0]
+    del gathered, kept
+
+    # ---- S3 correction (local, replicated k-mer set)
+    corrected = {}
+    cstats = {}
+    for r in ranks:
+        corrected[r], cstats[r] = ctxs[r].correct_reads(reads[r], ksets[r], prm.correct.max_corrections,
+                                                        prm.correct.min_good_run, prm.correct.trim_after_portion)
+        reads[r].free()
+        ksets[r].free()
+    all_cs = comm.all_gather_obj(cstats)[ranks[0]]
+    max_len = max(comm.all_gather_obj({r: int(corrected[r].max_len) for r in ranks})[ranks[0]])
+    W = max(1, (max_len + 31) // 32)
+
+    # ---- corrected reads replicated (cover index spans all reads)
+    words, lens = {}, {}
+    for r in ranks:
+        n = len(corrected[r])
+        words[r] = torch.empty((n, W), dtype=i64, device=dev[r])
+        lens[r] = torch.empty((n, 2), dtype=torch.uint8, device=dev[r])  # u16 lengths as bytes (RCCL has no int16)
+        capi.check(L.bg_reads_export(ctxs[r].h, corrected[r].h, W, _ptr(words[r]), _ptr(lens[r])))
+        corrected[r].free()
+    gw = comm.all_gather_v(words)
+    gl = comm.all_gather_v(lens)
+    del words, lens
+    send = {}
+    hists = {}
+    for r in ranks:
+        aw = torch.cat([g.to(dev[r]) for g in gw[r]]).contiguous()
+        al = torch.cat([g.to(dev[r]) for g in gl[r]]).contiguous()
+        counts = [g.shape[0] for g in gl[r]]
+        lo = sum(counts[:r])
+        hi = lo + counts[r]
+        h = C.c_void_p()
+        capi.check(L.bg_reads_import(ctxs[r].h, aw.shape[0], W, max_len, _ptr(aw), _ptr(al), C.byref(h)))
+        all_reads = bg.Reads(ctxs[r], h)
+        del aw, al
+        # ---- S4 suffix records of own reads
+        rh = C.c_void_p()
+        capi.check(L.bg_suffix_records(ctxs[r].h, all_reads.h, lo, hi, k, C.byref(rh)))
+        all_reads.free()
+        n_rec = L.bg_records_count(rh)
+        rows = torch.empty((n_rec, W + 1), dtype=i64, device=dev[r])
+        capi.check(L.bg_records_rows(ctxs[r].h, rh, _ptr(rows)))
+        L.bg_records_free(rh)
+        bins = (rows[:, 0] >> (64 - 2 * PREFIX_BASES)) & ((1 << (2 * PREFIX_BASES)) - 1)
+        hists[r] = torch.bincount(bins, minlength=4 ** PREFIX_BASES).to(i64)
+        send[r] = rows
+    del gw, gl
+    ghist = comm.all_reduce_sum(hists)
+    splitters = choose_splitters(ghist[ranks[0]].cpu().numpy(), P)
+    n_records = int(ghist[ranks[0]].sum().item())
+    for r in ranks:
+        send[r] = _partition(ctxs[r], send[r], capi.PART_PREFIX, P, [PREFIX_BASES] + splitters)
+    recv = comm.all_to_all_v(send)
+    del send
+    shards = {}
+    for r in ranks:
+        rows = recv[r].contiguous()
+        rh = C.c_void_p()
+        capi.check(L.bg_records_from_rows(ctxs[r].h, _ptr(rows), rows.shape[0], W, C.byref(rh)))
+        h = C.c_void_p()
+        st = BuildStats()
+        capi.check(L.bg_entries_from_records(ctxs[r].h, rh, C.byref(h), C.byref(st)))
+        L.bg_records_free(rh)
+        shards[r] = bg.Seqset(ctxs[r], h)
+    del recv
+
+    # ---- shard boundaries
+    def boundary(r):
+        f = np.zeros(W + 1, np.uint64)
+        la = np.zeros(W + 1, np.uint64)
+        capi.check(L.bg_seqset_boundary_rows(ctxs[r].h, shards[r].h, capi.np_ptr(f), capi.np_ptr(la)))
+        return [int(x) for x in f], [int(x) for x in la]
+
+    firsts = comm.all_gather_obj({r: boundary(r)[0] for r in ranks})[ranks[0]]
+    for r in ranks:
+        nxt = _next_nonempty(firsts, r, +1)
+        if nxt is not None:
+            a = np.array(nxt, np.uint64)
+            capi.check(L.bg_seqset_fix_boundary(ctxs[r].h, shards[r].h, None, capi.np_ptr(a)))
+    lasts = comm.all_gather_obj({r: boundary(r)[1] for r in ranks})[ranks[0]]
+    for r in ranks:
+        prv = _next_nonempty(lasts, r, -1)
+        if prv is not None:
+            a = np.array(prv, np.uint64)
+            capi.check(L.bg_seqset_fix_boundary(ctxs[r].h, shards[r].h, capi.np_ptr(a), None))
+
+    # ---- S5 prev bits: route every entry's tail to the shard holding lower_bound(tail)
+    bounds = np.array(lasts, np.uint64).reshape(P, W + 1)
+    send = {}
+    for r in ranks:
+        n = shards[r].size()
+        rows = torch.empty((n, W + 1), dtype=i64, device=dev[r])
+        capi.check(L.bg_seqset_tail_rows(ctxs[r].h, shards[r].h, _ptr(rows)))
+        send[r] = _partition(ctxs[r], rows, capi.PART_KEY_BOUNDS, P, bounds.reshape(-1))
+    recv = comm.all_to_all_v(send)
+    del send
+    sl_sizes, sl_shared, sl_bits, sl_n = {}, {}, {}, {}
+    for r in ranks:
+        rows = recv[r].contiguous()
+        capi.check(L.bg_seqset_apply_tails(ctxs[r].h, shards[r].h, _ptr(rows), rows.shape[0]))
+        n = shards[r].size()
+        nw = (n + 63) // 64
+        sl_sizes[r] = torch.empty((n,), dtype=torch.uint8, device=dev[r])
+        sl_shared[r] = torch.empty((n,), dtype=torch.uint8, device=dev[r])
+        sl_bits[r] = torch.empty((4 * nw,), dtype=i64, device=dev[r])
+        capi.check(L.bg_seqset_slice_export(ctxs[r].h, shards[r].h, _ptr(sl_sizes[r]), _ptr(sl_shared[r]),
+                                            _ptr(sl_bits[r])))
+        sl_n[r] = n
+        shards[r].free()
+    del recv
+
+    # ---- final merge on rank 0: concatenation in rank order + finalize
+    g_sizes = comm.all_gather_v(sl_sizes)
+    g_shared = comm.all_gather_v(sl_shared)
+    g_bits = comm.all_gather_v(sl_bits)
+    part_n = comm.all_gather_obj(sl_n)[ranks[0]]
+    n_entries = sum(part_n)
+    stats = {"n_reads": sum(comm.all_gather_obj({r: inputs[r][2] for r in ranks})[ranks[0]]),
+             "n_bases": sum(n_bases), "n_kmers": tot_inst, "n_distinct_kmers": tot_distinct, "n_kept_kmers": n_kept,
+             "n_corrected_reads": sum(c["corrected_reads"] for c in all_cs),
+             "n_corrected_bases": sum(c["corrected_bases"] for c in all_cs), "n_records": n_records,
+             "n_entries": n_entries, "max_len": max_len, "shard_entries": part_n}
+    out = {}
+    for r in ranks:
+        if r != 0:
+            out[r] = (None, stats)
+            continue
+        sz = torch.cat([g.to(dev[r]) for g in g_sizes[r]]).contiguous()
+        sh = torch.cat([g.to(dev[r]) for g in g_shared[r]]).contiguous()
+        bt = torch.cat([g.to(dev[r]) for g in g_bits[r]]).contiguous()
+        pn = (C.c_uint64 * P)(*part_n)
+        h = C.c_void_p()
+        capi.check(L.bg_seqset_assemble(ctxs[r].h, P, pn, _ptr(sz), _ptr(sh), _ptr(bt), max_len, C.byref(h)))
+        out[r] = (bg.Seqset(ctxs[r], h), stats)
+    return out

@@ -33,8 +33,11 @@ def make_genome(n, seed, device):
 
 
 def make_reads(genome_len=SHAPES["tiny"], coverage=30, read_len=150, seed=20261002, device="cpu", err=0.002,
-               n_rate=0.0001, snp_rate=0.001, chunk_pairs=1 << 20):
-    """Returns (seq uint8 [n_reads*read_len], offs int64 [n_reads+1], n_reads)."""
+               n_rate=0.0001, snp_rate=0.001, chunk_pairs=1 << 20, shard=(0, 1)):
+    """Returns (seq uint8 [n_reads*read_len], offs int64 [n_reads+1], n_reads).
+
+    shard=(rank, world): the same sample (genome + haplotypes from `seed`) on every rank, each rank
+    drawing its own 1/world of the read pairs (read RNG seeded with seed + 2 + 1000*rank)."""
     dev = torch.device(device)
     hap_a = make_genome(genome_len, seed, dev)
     g = torch.Generator(device=dev)
@@ -45,11 +48,13 @@ def make_reads(genome_len=SHAPES["tiny"], coverage=30, read_len=150, seed=202610
     haps = torch.stack([hap_a, hap_b])  # [2, G]
     del snp, shift
 
+    rank, world = shard
     n_pairs = int(coverage * genome_len // (2 * read_len))
+    n_pairs = n_pairs // world + (1 if rank < n_pairs % world else 0)
     n_reads = 2 * n_pairs
     out = torch.empty(n_reads * read_len, dtype=torch.uint8, device=dev)
     letters = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)  # ACGT
-    g.manual_seed(seed + 2)
+    g.manual_seed(seed + 2 + 1000 * rank)
     ar = torch.arange(read_len, device=dev)
     done = 0
     while done < n_pairs:

@@ -39,6 +39,7 @@ typedef struct bg_ctx bg_ctx;         /* device context: stream + workspace cach
 typedef struct bg_reads bg_reads;     /* 2-bit packed reads resident in HBM                    */
 typedef struct bg_kmerset bg_kmerset; /* filtered canonical k-mer set resident in HBM          */
 typedef struct bg_seqset bg_seqset;   /* seqset arrays resident in HBM (+ host copies on demand)*/
+typedef struct bg_records bg_records; /* suffix records (materialised keys) of one shard           */
 
 int bg_abi_version(void);
 const char* bg_last_error(void);
@@ -170,6 +171,64 @@ int bg_push_front_drop_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n, const
 /* find: queries are concatenated ACGT strings (device), n+1 offsets; result ranges (begin,end). */
 int bg_find_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n, const uint8_t* d_seq,
                   const uint64_t* d_offs, uint64_t* d_obegin, uint64_t* d_oend);
+
+/* ---- Sharded build (one process per GPU).  The library never communicates: these
+ * entry points expose the phases of bg_create() at the exchange points; the host moves the buffers
+ * with RCCL (torch.distributed all_to_all / all_gather) — see biograph_amd/sharded.py.
+ * "Rows" are fixed-width records of u64 words on the device. */
+#define BG_PART_KMER_HASH 0  /* 1-word rows = canonical k-mers; dest = hash(kmer) mod nparts (the 256-way
+                                kmer_partition of kmer_counter.h:167-178); all-ones rows are dropped   */
+#define BG_PART_PREFIX 1     /* rows of W+1 words; h_params = {prefix_bases, nparts-1 ascending bin
+                                splitters}; dest = #splitters <= leading-bases bin
+                                (part_repo::partition_for_sequence, part_repo.cpp:32-45)              */
+#define BG_PART_KEY_BOUNDS 2 /* rows of W+1 words (last = len | base<<8); h_params = nparts rows: last
+                                entry of each shard (last word ~0 = empty); dest = first shard whose
+                                last entry >= row                                                       */
+/* Stable partition of n rows into nparts destination groups written back to back into d_out_rows;
+ * h_counts[p] = rows of group p. */
+int bg_partition_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int row_words, int mode,
+                      uint32_t nparts, const uint64_t* h_params, uint64_t* d_out_rows, uint64_t* h_counts);
+
+/* k-mer phases of bg_kmer_count(): windows -> keys; keys (after the exchange) -> kept k-mers of this
+ * shard's hash range; all kept k-mers (after the all-gather) -> hash set. */
+int bg_kmer_instances(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t* n_out);
+int bg_kmer_extract(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t* d_keys, uint64_t cap);
+int bg_kmer_count_keys(bg_ctx* ctx, uint64_t* d_keys /* clobbered */, uint64_t n, int k, uint32_t min_count,
+                       bg_kmerset** out /* kmers+counts only, no hash */);
+int bg_kmerset_export(bg_ctx* ctx, const bg_kmerset* ks, uint64_t* d_kmers_out);
+int bg_kmerset_from_kmers(bg_ctx* ctx, const uint64_t* d_kmers, uint64_t n, int k,
+                          const bg_reads* reads_for_flags /* may be NULL */, bg_kmerset** out);
+
+/* corrected reads travel as (words[n*W], len[n]) */
+int bg_reads_words(const bg_reads* r);
+int bg_reads_export(bg_ctx* ctx, const bg_reads* r, int W_out, uint64_t* d_words, uint16_t* d_len);
+int bg_reads_import(bg_ctx* ctx, uint64_t n, int W, uint32_t max_len, const uint64_t* d_words,
+                    const uint16_t* d_len, bg_reads** out);
+
+/* suffix records of reads [read_lo, read_hi) of `reads`; the cover index spans all of `reads` */
+int bg_suffix_records(bg_ctx* ctx, const bg_reads* reads, uint64_t read_lo, uint64_t read_hi, int cover_k,
+                      bg_records** out);
+uint64_t bg_records_count(const bg_records* r);
+int bg_records_words(const bg_records* r);
+int bg_records_rows(bg_ctx* ctx, const bg_records* r, uint64_t* d_rows /* n*(W+1): words, len */);
+int bg_records_from_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int W, bg_records** out);
+void bg_records_free(bg_records* r);
+/* sort + prefix-dedup of one shard's records -> entries (keys/sizes/shared, no prev bits); consumes r */
+int bg_entries_from_records(bg_ctx* ctx, bg_records* r, bg_seqset** out, bg_build_stats* stats);
+
+/* shard boundaries (part_repo.cpp:294-303, builder.cpp:225): rows of W+1 host words */
+int bg_seqset_words(const bg_seqset* ss);
+int bg_seqset_boundary_rows(bg_ctx* ctx, const bg_seqset* ss, uint64_t* h_first_row, uint64_t* h_last_row);
+int bg_seqset_fix_boundary(bg_ctx* ctx, bg_seqset* ss, const uint64_t* h_prev_last_row,
+                           const uint64_t* h_next_first_row);
+/* prev bits across shards: tails s[1:] of own entries out, tails owned by this shard in */
+int bg_seqset_tail_rows(bg_ctx* ctx, const bg_seqset* ss, uint64_t* d_rows /* n*(W+1) */);
+int bg_seqset_apply_tails(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows);
+/* final merge = concatenation of the shards' slices in rank order + seqset::finalize */
+int bg_seqset_slice_export(bg_ctx* ctx, const bg_seqset* ss, uint8_t* d_sizes, uint8_t* d_shared,
+                           uint64_t* d_bits /* 4 x ceil(n/64) */);
+int bg_seqset_assemble(bg_ctx* ctx, uint32_t nparts, const uint64_t* h_part_n, const uint8_t* d_sizes,
+                       const uint8_t* d_shared, const uint64_t* d_bits, uint32_t max_len, bg_seqset** out);
 
 /* ---- device memory helpers for hosts without their own allocator (CLI, ctypes tests). */
 int bg_dev_alloc(bg_ctx* ctx, uint64_t bytes, void** d_out);
