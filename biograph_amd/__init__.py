@@ -63,9 +63,9 @@ class DeviceArray:
         return out
 
     def free(self):
-        if self.ptr:
+        if self.ptr and self.ctx.h:
             capi.lib().bg_dev_free(self.ctx.h, self.ptr)
-            self.ptr = None
+        self.ptr = None
 
     def __del__(self):
         try:
@@ -198,9 +198,10 @@ class _Handle:
         self.h = h
 
     def free(self):
-        if self.h:
+        # objects must be freed before their context (bgseq.h); one that outlives it is simply dropped
+        if self.h and self.ctx is not None and self.ctx.h:
             getattr(capi.lib(), self._free)(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -348,6 +349,94 @@ class Seqset(_Handle):
         finally:
             for a in (dseq, doffs, ob, oe):
                 a.free()
+
+    # ---- frontier walks (graph_discover rows G2, G3; ref_map G7) --------------------------------------
+    @staticmethod
+    def _flatten_frontiers(frontiers):
+        foff = np.zeros(len(frontiers) + 1, np.uint32)
+        foff[1:] = np.cumsum([len(f) for f in frontiers])
+        flat = [t for f in frontiers for t in f]
+        b = np.array([t[0] for t in flat], np.uint64)
+        e = np.array([t[1] for t in flat], np.uint64)
+        s = np.array([t[2] for t in flat], np.uint32)
+        return foff, b, e, s
+
+    def trace_one_base_batch(self, frontiers, min_ctx):
+        """frontiers: list of lists of (begin,end,size); min_ctx: per frontier.
+        -> list of (best rc base or -1, [(range, dropped)], [next ranges])."""
+        ctx, n = self.ctx, len(frontiers)
+        foff, b, e, s = self._flatten_frontiers(frontiers)
+        D = DeviceArray
+        ins = [D.from_numpy(ctx, foff), D.from_numpy(ctx, b), D.from_numpy(ctx, e), D.from_numpy(ctx, s),
+               D.from_numpy(ctx, np.ascontiguousarray(min_ctx, np.uint32))]
+        outs = [D(ctx, n), D(ctx, n), D(ctx, n * 128), D(ctx, n * 128), D(ctx, n * 64), D(ctx, n * 16), D(ctx, n),
+                D(ctx, n * 128), D(ctx, n * 128), D(ctx, n * 64)]
+        try:
+            capi.check(capi.lib().bg_trace_one_base_batch(ctx.h, self.h, n, *[C.c_void_p(a.ptr) for a in ins + outs]))
+            best = outs[0].to_numpy(np.uint8, n)
+            nc = outs[1].to_numpy(np.uint8, n)
+            cb, ce = outs[2].to_numpy(np.uint64, n * 16), outs[3].to_numpy(np.uint64, n * 16)
+            cs, cd = outs[4].to_numpy(np.uint32, n * 16), outs[5].to_numpy(np.uint8, n * 16)
+            nn = outs[6].to_numpy(np.uint8, n)
+            nb, ne = outs[7].to_numpy(np.uint64, n * 16), outs[8].to_numpy(np.uint64, n * 16)
+            ns = outs[9].to_numpy(np.uint32, n * 16)
+        finally:
+            for a in ins + outs:
+                a.free()
+        res = []
+        for f in range(n):
+            cands = [((int(cb[f * 16 + i]), int(ce[f * 16 + i]), int(cs[f * 16 + i])), bool(cd[f * 16 + i]))
+                     for i in range(int(nc[f]))]
+            nxt = [(int(nb[f * 16 + i]), int(ne[f * 16 + i]), int(ns[f * 16 + i])) for i in range(int(nn[f]))]
+            res.append((-1 if best[f] == 255 else int(best[f]), cands, nxt))
+        return res
+
+    def branch_trace_batch(self, seqs, frontiers, min_overlap, ev_cap=256):
+        """seqs: list of uint8 code arrays (0..3) -> list of (n_events, [(offset, base)], final frontier)."""
+        ctx, n = self.ctx, len(seqs)
+        soff = np.zeros(n + 1, np.uint64)
+        soff[1:] = np.cumsum([len(x) for x in seqs])
+        codes = np.concatenate([np.asarray(x, np.uint8) for x in seqs]) if n else np.zeros(0, np.uint8)
+        foff, b, e, s = self._flatten_frontiers(frontiers)
+        D = DeviceArray
+        ins = [D.from_numpy(ctx, soff), D.from_numpy(ctx, codes), D.from_numpy(ctx, foff), D.from_numpy(ctx, b),
+               D.from_numpy(ctx, e), D.from_numpy(ctx, s)]
+        outs = [D(ctx, n * ev_cap * 4), D(ctx, n * ev_cap), D(ctx, n * 4), D(ctx, n), D(ctx, n * 128), D(ctx, n * 128),
+                D(ctx, n * 64)]
+        try:
+            args = [C.c_void_p(a.ptr) for a in ins] + [min_overlap, ev_cap] + [C.c_void_p(a.ptr) for a in outs]
+            capi.check(capi.lib().bg_branch_trace_batch(ctx.h, self.h, n, *args))
+            eo = outs[0].to_numpy(np.uint32, n * ev_cap)
+            eb = outs[1].to_numpy(np.uint8, n * ev_cap)
+            nev = outs[2].to_numpy(np.uint32, n)
+            no = outs[3].to_numpy(np.uint8, n)
+            ob, oe = outs[4].to_numpy(np.uint64, n * 16), outs[5].to_numpy(np.uint64, n * 16)
+            os_ = outs[6].to_numpy(np.uint32, n * 16)
+        finally:
+            for a in ins + outs:
+                a.free()
+        res = []
+        for a in range(n):
+            ev = [(int(eo[a * ev_cap + i]), int(eb[a * ev_cap + i])) for i in range(min(int(nev[a]), ev_cap))]
+            cur = [(int(ob[a * 16 + i]), int(oe[a * 16 + i]), int(os_[a * 16 + i])) for i in range(int(no[a]))]
+            res.append((int(nev[a]), ev, cur))
+        return res
+
+    def ref_map_build(self, ref_codes, ext_start, ext_size, chain_bases=0):
+        """ref_codes: uint8 array of bases 0..3; extents = N-free stretches.  -> uint8[n] ref_map cells."""
+        ctx = self.ctx
+        dref = DeviceArray.from_numpy(ctx, np.ascontiguousarray(ref_codes, np.uint8))
+        n = self.size()
+        out = DeviceArray(ctx, max(n, 1))
+        es = np.ascontiguousarray(ext_start, np.uint64)
+        ez = np.ascontiguousarray(ext_size, np.uint64)
+        try:
+            capi.check(capi.lib().bg_ref_map_build(ctx.h, self.h, C.c_void_p(dref.ptr), len(es), capi.np_ptr(es),
+                                                   capi.np_ptr(ez), chain_bases, C.c_void_p(out.ptr)))
+            return out.to_numpy(np.uint8, n)
+        finally:
+            dref.free()
+            out.free()
 
     # ---- SDK surface of python/biograph/seqset.cpp:46-160 -------------------------------------
     def empty_entry(self):

@@ -58,6 +58,7 @@ SYMBOLS = [
     "bg_seqset_part", "bg_seqset_arrays", "bg_seqset_entries", "bg_seqset_write", "bg_seqset_open",
     "bg_seqset_from_arrays", "bg_seqset_free", "bg_push_front_batch", "bg_push_front_drop_batch", "bg_find_batch",
     "bg_dev_alloc", "bg_dev_free", "bg_dev_upload", "bg_dev_download",
+    "bg_trace_one_base_batch", "bg_branch_trace_batch", "bg_ref_map_build",
     # sharded build
     "bg_partition_rows", "bg_kmer_instances", "bg_kmer_extract", "bg_kmer_count_keys", "bg_kmerset_export",
     "bg_kmerset_from_kmers", "bg_reads_words", "bg_reads_export", "bg_reads_import", "bg_suffix_records",
@@ -122,6 +123,9 @@ def lib():
     L.bg_dev_free.argtypes = [vp, vp]
     L.bg_dev_upload.argtypes = [vp, vp, vp, u64]
     L.bg_dev_download.argtypes = [vp, vp, vp, u64]
+    L.bg_trace_one_base_batch.argtypes = [vp, vp, u64] + [vp] * 15
+    L.bg_branch_trace_batch.argtypes = [vp, vp, u64, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp, vp, vp]
+    L.bg_ref_map_build.argtypes = [vp, vp, vp, u64, vp, vp, u32, vp]
     L.bg_partition_rows.argtypes = [vp, vp, u64, i32, i32, u32, vp, vp, vp]
     L.bg_kmer_instances.argtypes = [vp, vp, i32, P(u64)]
     L.bg_kmer_extract.argtypes = [vp, vp, i32, vp, u64]

@@ -2,6 +2,8 @@
 // One lane per query: push_front (bio_base/seqset.cpp:319-338), push_front_drop (:350-429) and
 // find (:146-155).  Pure integer, latency-bound random access: 2 rank queries (bits + subaccum +
 // accum words) and <= 2 entry-size bytes per step, plus shared[] / min-index probes when dropping.
+#include <vector>
+
 #include "bg_device_funcs.h"
 #include "bg_internal.h"
 
@@ -122,6 +124,356 @@ extern "C" int bg_find_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n, const
   k_find<<<cdiv(n, 256), 256, 0, ctx->stream>>>(make_view(ss), n, d_seq, d_offs, d_obegin, d_oend);
   BG_LAUNCH_CHECK();
   ctx->toc(n * 52);
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+// =================================================================================================
+// Frontier kernels (rows G2, G3, G7): one wave per frontier / assembly, lane = (pushed base, range).
+
+namespace bg {
+
+constexpr int kFrontierMax = 16;  // ranges per frontier ("#rs typically 1-10")
+
+struct Tri {
+  uint64_t b, e;
+  uint32_t s;
+};
+
+__device__ __forceinline__ bool tri_precedes(const Tri& x, const Tri& y) {  // seqset.h:211-218
+  if (x.b != y.b) return x.b < y.b;
+  if (x.e != y.e) return x.e > y.e;
+  return x.s < y.s;
+}
+
+// Lanes 0..15 hold candidate ranges (cv = valid).  Removes exact duplicates (keeping the lowest lane,
+// OR-ing `flag`), optionally removes ranges that contain another one (seqset_set_dedup_prefixes,
+// variants/assemble.cpp:1473-1498) and returns, for surviving lanes, their rank in set order.
+__device__ __forceinline__ void frontier_dedup(Tri& c, bool& cv, bool& flag, bool prefixes, int lane, int* rank,
+                                               int* count) {
+  bool dup = false, f = flag;
+  for (int j = 0; j < kFrontierMax; ++j) {
+    uint64_t jb = __shfl(c.b, j, 64), je = __shfl(c.e, j, 64);
+    uint32_t js = __shfl(c.s, j, 64);
+    bool jv = __shfl(int(cv), j, 64) != 0, jf = __shfl(int(flag), j, 64) != 0;
+    bool same = cv && jv && jb == c.b && je == c.e && js == c.s;
+    if (same && j < lane) dup = true;
+    if (same && jf) f = true;
+  }
+  cv = cv && !dup && lane < kFrontierMax;
+  flag = f;
+  if (prefixes) {
+    bool discard = false;
+    for (int j = 0; j < kFrontierMax; ++j) {
+      uint64_t jb = __shfl(c.b, j, 64), je = __shfl(c.e, j, 64);
+      uint32_t js = __shfl(c.s, j, 64);
+      bool jv = __shfl(int(cv), j, 64) != 0;
+      if (!cv || !jv || j == lane) continue;
+      bool contained = jb >= c.b && je <= c.e;
+      bool strictly = jb > c.b || je < c.e;
+      if (contained && (strictly || js > c.s)) discard = true;
+    }
+    // every lane is judged against the pre-discard set: containment is transitive, so this equals the
+    // fixpoint of the reference's repeat-until-stable loop
+    cv = cv && !discard;
+  }
+  int r = 0, n = 0;
+  for (int j = 0; j < kFrontierMax; ++j) {
+    Tri t{__shfl(c.b, j, 64), __shfl(c.e, j, 64), __shfl(c.s, j, 64)};
+    bool jv = __shfl(int(cv), j, 64) != 0;
+    if (jv) {
+      ++n;
+      if (j != lane && tri_precedes(t, c)) ++r;
+    }
+  }
+  *rank = r;
+  *count = n;
+}
+
+// push_to_pair_discover::trace_one_base (graph_discover/push_to_pair.cpp:159-240) minus the per-trace
+// state (m_seen_ranges, readmap) which stays with the host driver.
+__global__ __launch_bounds__(256) void k_trace_one_base(SeqsetView v, uint64_t nf, const uint32_t* __restrict__ foff,
+                                                        const uint64_t* __restrict__ fbegin,
+                                                        const uint64_t* __restrict__ fend,
+                                                        const uint32_t* __restrict__ fsize,
+                                                        const uint32_t* __restrict__ min_ctx,
+                                                        uint8_t* __restrict__ best_base, uint8_t* __restrict__ n_cand,
+                                                        uint64_t* __restrict__ cb, uint64_t* __restrict__ ce,
+                                                        uint32_t* __restrict__ cs, uint8_t* __restrict__ cdrop,
+                                                        uint8_t* __restrict__ n_next, uint64_t* __restrict__ nb,
+                                                        uint64_t* __restrict__ ne, uint32_t* __restrict__ ns,
+                                                        uint32_t* __restrict__ err) {
+  const int lane = threadIdx.x & 63;
+  uint64_t f = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (f >= nf) return;  // wave-uniform
+  uint32_t lo = foff[f], hi = foff[f + 1];
+  if (hi - lo > uint32_t(kFrontierMax)) {
+    if (lane == 0) { atomicOr(err, 1u); best_base[f] = 255; n_cand[f] = 0; n_next[f] = 0; }
+    return;
+  }
+  const int r = lane & 15, b = lane >> 4;
+  bool rv = uint32_t(r) < hi - lo;
+  uint64_t rb = rv ? fbegin[lo + r] : 0, re = rv ? fend[lo + r] : 0;
+  uint32_t rs = rv ? fsize[lo + r] : 0;
+  rv = rv && rb < re && re <= v.n;
+  uint64_t ob = 0, oe = 0;
+  uint32_t os = 0;
+  if (rv) v.push_front_drop(rb, re, rs, b, min_ctx[f], &ob, &oe, &os);
+  bool valid = oe > ob;
+  bool drop = valid && os != rs + 1;
+  uint32_t m = valid ? os : 0;
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) {
+    uint32_t t = __shfl_xor(m, d, 64);
+    m = t > m ? t : m;
+  }
+  uint32_t best_len = 0;
+  int best = -1;
+  for (int bb = 0; bb < 4; ++bb) {  // strict > : first base wins ties (:196)
+    uint32_t l = __shfl(m, bb * 16, 64);
+    if (l > best_len) { best_len = l; best = bb; }
+  }
+  if (best < 0) {
+    if (lane == 0) { best_base[f] = 255; n_cand[f] = 0; n_next[f] = 0; }
+    return;
+  }
+  int src = best * 16 + (lane & 15);
+  Tri c{__shfl(ob, src, 64), __shfl(oe, src, 64), __shfl(os, src, 64)};
+  bool cv = (__shfl(int(valid), src, 64) != 0) && lane < kFrontierMax;
+  bool cd = __shfl(int(drop), src, 64) != 0;
+  int rank, count;
+  frontier_dedup(c, cv, cd, false, lane, &rank, &count);
+  if (cv) {
+    uint64_t o = f * kFrontierMax + rank;
+    cb[o] = c.b; ce[o] = c.e; cs[o] = c.s; cdrop[o] = cd ? 1 : 0;
+  }
+  if (lane == 0) { best_base[f] = uint8_t(best); n_cand[f] = uint8_t(count); }
+  frontier_dedup(c, cv, cd, true, lane, &rank, &count);
+  if (cv) {
+    uint64_t o = f * kFrontierMax + rank;
+    nb[o] = c.b; ne[o] = c.e; ns[o] = c.s;
+  }
+  if (lane == 0) n_next[f] = uint8_t(count);
+}
+
+// branch_discover::on_trace (graph_discover/branch.cpp:20-80): walk the assembly's bases from frontier
+// `cur`; report the first alternative base with any valid push_front_drop(rc_b, min_overlap) at each
+// offset; advance cur along the reference base.
+__global__ __launch_bounds__(256) void k_branch_trace(SeqsetView v, uint64_t na, const uint64_t* __restrict__ soff,
+                                                      const uint8_t* __restrict__ seq,
+                                                      const uint32_t* __restrict__ foff,
+                                                      const uint64_t* __restrict__ fbegin,
+                                                      const uint64_t* __restrict__ fend,
+                                                      const uint32_t* __restrict__ fsize, uint32_t min_overlap,
+                                                      uint32_t ev_cap, uint32_t* __restrict__ ev_off,
+                                                      uint8_t* __restrict__ ev_base, uint32_t* __restrict__ n_ev,
+                                                      uint8_t* __restrict__ n_out, uint64_t* __restrict__ outb,
+                                                      uint64_t* __restrict__ oute, uint32_t* __restrict__ outs,
+                                                      uint32_t* __restrict__ err) {
+  const int lane = threadIdx.x & 63;
+  uint64_t a = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (a >= na) return;
+  uint32_t lo = foff[a], hi = foff[a + 1];
+  if (hi - lo > uint32_t(kFrontierMax)) {
+    if (lane == 0) { atomicOr(err, 1u); n_ev[a] = 0; n_out[a] = 0; }
+    return;
+  }
+  Tri cur{0, 0, 0};
+  bool cv = uint32_t(lane) < hi - lo;
+  if (cv) { cur.b = fbegin[lo + lane]; cur.e = fend[lo + lane]; cur.s = fsize[lo + lane]; }
+  cv = cv && cur.b < cur.e && cur.e <= v.n;
+  const int r = lane & 15, p = lane >> 4;  // p = pushed (rc) base
+  uint32_t nev = 0;
+  for (uint64_t off = soff[a]; off < soff[a + 1]; ++off) {
+    int rc_ref = 3 - int(seq[off] & 3);
+    uint64_t rb = __shfl(cur.b, r, 64), re = __shfl(cur.e, r, 64);
+    uint32_t rs = __shfl(cur.s, r, 64);
+    bool rv = __shfl(int(cv), r, 64) != 0;
+    uint64_t ob = 0, oe = 0;
+    uint32_t os = 0;
+    if (rv) v.push_front_drop(rb, re, rs, p, p == rc_ref ? 0u : min_overlap, &ob, &oe, &os);
+    bool valid = oe > ob;
+    uint64_t ball = __ballot(valid);
+    for (int b = 0; b < 4; ++b) {  // :41-68 alternatives in base order
+      int rc_b = 3 - b;
+      if (rc_b == rc_ref) continue;
+      if ((ball >> (rc_b * 16)) & 0xffffull) {
+        if (lane == 0 && nev < ev_cap) {
+          ev_off[a * ev_cap + nev] = uint32_t(off - soff[a]);
+          ev_base[a * ev_cap + nev] = uint8_t(b);
+        }
+        ++nev;
+        break;
+      }
+    }
+    int src = rc_ref * 16 + (lane & 15);
+    Tri c{__shfl(ob, src, 64), __shfl(oe, src, 64), __shfl(os, src, 64)};
+    bool nv = (__shfl(int(valid), src, 64) != 0) && lane < kFrontierMax;
+    bool dummy = false;
+    int rank, count;
+    frontier_dedup(c, nv, dummy, true, lane, &rank, &count);
+    // re-seat survivors by rank so the frontier stays in set order
+    Tri nxt{0, 0, 0};
+    bool nxv = false;
+    for (int j = 0; j < kFrontierMax; ++j) {
+      Tri t{__shfl(c.b, j, 64), __shfl(c.e, j, 64), __shfl(c.s, j, 64)};
+      bool jv = __shfl(int(nv), j, 64) != 0;
+      int jr = __shfl(rank, j, 64);
+      if (jv && jr == lane) { nxt = t; nxv = true; }
+    }
+    cur = nxt;
+    cv = nxv;
+  }
+  if (cv) { outb[a * kFrontierMax + lane] = cur.b; oute[a * kFrontierMax + lane] = cur.e; outs[a * kFrontierMax + lane] = cur.s; }
+  uint64_t live = __ballot(cv);
+  if (lane == 0) { n_ev[a] = nev; n_out[a] = uint8_t(__popcll(live)); }
+}
+
+// ref_map::build (variants/ref_map.cpp:72-185): one lane per chain.  A chain pushes the complement of
+// `len` reference bases (walking +1 or, for the reverse strand, -1 and complemented) starting from the
+// empty context; after `pre` warm-up bases every position whose range is exactly one full entry
+// bumps that entry.  Chains are finer than the reference's chunks (same 256-base warm-up): the walk
+// state after >= max_read_len pushes does not depend on where the chain began.
+__global__ __launch_bounds__(64) void k_ref_map_chains(SeqsetView v, uint64_t nchains,
+                                                      const uint64_t* __restrict__ cstart,
+                                                      const uint32_t* __restrict__ clen,
+                                                      const uint32_t* __restrict__ cpre,
+                                                      const int8_t* __restrict__ cdir,
+                                                      const uint8_t* __restrict__ ref, uint32_t* __restrict__ cnt,
+                                                      uint32_t* __restrict__ flags) {
+  uint64_t c = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= nchains) return;
+  uint64_t pos = cstart[c];
+  int dir = cdir[c];
+  uint32_t len = clen[c], pre = cpre[c];
+  uint64_t b = 0, e = v.n;
+  uint32_t s = 0;
+  for (uint32_t i = 0; i < len; ++i) {
+    int base = ref[pos] & 3;
+    if (dir < 0) base = 3 - base;   // reverse-complement slice
+    pos += dir;
+    v.push_front_drop(b, e, s, 3 - base, 0, &b, &e, &s);
+    if (e <= b) { b = 0; e = v.n; s = 0; continue; }  // cannot happen on a closed seqset (CHECK(r.valid()))
+    if (i < pre) continue;
+    if (b + 1 != e || s != v.sizes[b]) continue;
+    atomicAdd(&cnt[b], 1u);
+    atomicOr(&flags[b], dir < 0 ? 0x80u : 0x40u);  // rc slice sets k_fwd_flag, forward slice k_rev_flag (:61-65)
+  }
+}
+
+__global__ void k_ref_map_pack(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ flags, uint64_t n,
+                               uint8_t* __restrict__ out) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t c = cnt[i];
+  out[i] = uint8_t((c > 63 ? 63 : c) | flags[i]);
+}
+
+}  // namespace bg
+
+extern "C" int bg_trace_one_base_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n_frontiers, const uint32_t* d_foff,
+                                       const uint64_t* d_begin, const uint64_t* d_end, const uint32_t* d_size,
+                                       const uint32_t* d_min_ctx, uint8_t* d_best_base, uint8_t* d_n_cand,
+                                       uint64_t* d_cbegin, uint64_t* d_cend, uint32_t* d_csize, uint8_t* d_cdrop,
+                                       uint8_t* d_n_next, uint64_t* d_nbegin, uint64_t* d_nend, uint32_t* d_nsize) {
+  BG_TRY(check_ss(ctx, ss, "bg_trace_one_base_batch"));
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!n_frontiers) return BG_OK;
+  DevBuf<uint32_t> err;
+  BG_TRY(err.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+  ctx->tic("walk_trace_one_base");
+  k_trace_one_base<<<cdiv(n_frontiers, 4), 256, 0, ctx->stream>>>(make_view(ss), n_frontiers, d_foff, d_begin, d_end,
+                                                                  d_size, d_min_ctx, d_best_base, d_n_cand, d_cbegin,
+                                                                  d_cend, d_csize, d_cdrop, d_n_next, d_nbegin, d_nend,
+                                                                  d_nsize, err.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n_frontiers * 4 * 52);
+  uint32_t h_err = 0;
+  BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_err) { set_error("bg_trace_one_base_batch: a frontier holds more than %d ranges", kFrontierMax); return BG_EINVAL; }
+  return BG_OK;
+}
+
+extern "C" int bg_branch_trace_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n_asm, const uint64_t* d_seq_off,
+                                     const uint8_t* d_seq_codes, const uint32_t* d_foff, const uint64_t* d_begin,
+                                     const uint64_t* d_end, const uint32_t* d_size, uint32_t min_overlap,
+                                     uint32_t ev_cap, uint32_t* d_ev_off, uint8_t* d_ev_base, uint32_t* d_n_ev,
+                                     uint8_t* d_n_out, uint64_t* d_obegin, uint64_t* d_oend, uint32_t* d_osize) {
+  BG_TRY(check_ss(ctx, ss, "bg_branch_trace_batch"));
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!n_asm) return BG_OK;
+  DevBuf<uint32_t> err;
+  BG_TRY(err.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+  ctx->tic("walk_branch_trace");
+  k_branch_trace<<<cdiv(n_asm, 4), 256, 0, ctx->stream>>>(make_view(ss), n_asm, d_seq_off, d_seq_codes, d_foff, d_begin,
+                                                          d_end, d_size, min_overlap, ev_cap, d_ev_off, d_ev_base,
+                                                          d_n_ev, d_n_out, d_obegin, d_oend, d_osize, err.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(0);
+  uint32_t h_err = 0;
+  BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_err) { set_error("bg_branch_trace_batch: a frontier holds more than %d ranges", kFrontierMax); return BG_EINVAL; }
+  return BG_OK;
+}
+
+extern "C" int bg_ref_map_build(bg_ctx* ctx, const bg_seqset* ss, const uint8_t* d_ref_codes, uint64_t n_extents,
+                                const uint64_t* h_ext_start, const uint64_t* h_ext_size, uint32_t chain_bases,
+                                uint8_t* d_out) {
+  BG_TRY(check_ss(ctx, ss, "bg_ref_map_build"));
+  if ((n_extents && (!h_ext_start || !h_ext_size || !d_ref_codes)) || (ss->n && !d_out)) {
+    set_error("bg_ref_map_build: null argument");
+    return BG_EINVAL;
+  }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (chain_bases < 256) chain_bases = 4096;
+  std::vector<uint64_t> cstart;
+  std::vector<uint32_t> clen, cpre;
+  std::vector<int8_t> cdir;
+  uint64_t total = 0;
+  for (uint64_t x = 0; x < n_extents; ++x) {
+    uint64_t st = h_ext_start[x], len = h_ext_size[x];
+    for (uint64_t cs = 0; cs < len; cs += chain_bases) {
+      uint64_t ce = cs + chain_bases < len ? cs + chain_bases : len;
+      uint64_t pre = cs >= 256 ? cs - 256 : 0;                 // ref_map.cpp:95-100
+      uint64_t pre_rc = ce + 256 < len ? ce + 256 : len;       // :102-106
+      cstart.push_back(st + pre); clen.push_back(uint32_t(ce - pre)); cpre.push_back(uint32_t(cs - pre)); cdir.push_back(1);
+      cstart.push_back(st + pre_rc - 1); clen.push_back(uint32_t(pre_rc - cs)); cpre.push_back(uint32_t(pre_rc - ce)); cdir.push_back(-1);
+      total += (ce - pre) + (pre_rc - cs);
+    }
+  }
+  const uint64_t nch = cstart.size(), n = ss->n;
+  DevBuf<uint64_t> dstart;
+  DevBuf<uint32_t> dlen, dpre, cnt, flags;
+  DevBuf<int8_t> ddir;
+  BG_TRY(dstart.alloc(ctx, nch));
+  BG_TRY(dlen.alloc(ctx, nch));
+  BG_TRY(dpre.alloc(ctx, nch));
+  BG_TRY(ddir.alloc(ctx, nch));
+  BG_TRY(cnt.alloc(ctx, n));
+  BG_TRY(flags.alloc(ctx, n));
+  if (n) {
+    BG_HIP(hipMemsetAsync(cnt.p, 0, n * 4, ctx->stream));
+    BG_HIP(hipMemsetAsync(flags.p, 0, n * 4, ctx->stream));
+  }
+  if (nch) {
+    BG_HIP(hipMemcpyAsync(dstart.p, cstart.data(), nch * 8, hipMemcpyHostToDevice, ctx->stream));
+    BG_HIP(hipMemcpyAsync(dlen.p, clen.data(), nch * 4, hipMemcpyHostToDevice, ctx->stream));
+    BG_HIP(hipMemcpyAsync(dpre.p, cpre.data(), nch * 4, hipMemcpyHostToDevice, ctx->stream));
+    BG_HIP(hipMemcpyAsync(ddir.p, cdir.data(), nch, hipMemcpyHostToDevice, ctx->stream));
+    ctx->tic("walk_ref_map");
+    k_ref_map_chains<<<cdiv(nch, 64), 64, 0, ctx->stream>>>(make_view(ss), nch, dstart.p, dlen.p, dpre.p, ddir.p,
+                                                            d_ref_codes, cnt.p, flags.p);
+    BG_LAUNCH_CHECK();
+    ctx->toc(total * 52);
+  }
+  if (n) {
+    k_ref_map_pack<<<cdiv(n, 256), 256, 0, ctx->stream>>>(cnt.p, flags.p, n, d_out);
+    BG_LAUNCH_CHECK();
+  }
   BG_HIP(hipStreamSynchronize(ctx->stream));
   return BG_OK;
 }

@@ -47,6 +47,8 @@ const char* bg_last_error(void);
 /* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the default
  * stream. */
 int bg_ctx_create(int device, void* stream, bg_ctx** out);
+/* Every object created from a context (reads, k-mer sets, records, seqsets) must be freed BEFORE the
+ * context is destroyed. */
 void bg_ctx_destroy(bg_ctx* ctx);
 /* Releases cached workspace blocks back to the driver. */
 int bg_ctx_trim(bg_ctx* ctx);
@@ -171,6 +173,34 @@ int bg_push_front_drop_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n, const
 /* find: queries are concatenated ACGT strings (device), n+1 offsets; result ranges (begin,end). */
 int bg_find_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n, const uint8_t* d_seq,
                   const uint64_t* d_offs, uint64_t* d_obegin, uint64_t* d_oend);
+
+/* ---- G2/G3/G7: frontier walks.  A frontier is a set of at most 16 ranges; frontier f owns ranges
+ * [d_foff[f], d_foff[f+1]) of (d_begin, d_end, d_size).  Output frontiers use slots f*16 .. f*16+15. */
+/* One step of push_to_pair_discover::trace_one_base (graph_discover/push_to_pair.cpp:159-240) for every
+ * frontier: all 4 bases x ranges push_front_drop(rc_b, d_min_ctx[f]); the base with the longest result
+ * wins (first base on ties); d_best_base = that rc base or 255; candidates = results of that base
+ * before prefix-dedup with their "dropped" flag (the host keeps m_seen_ranges, :220-224); next = the
+ * returned frontier after seqset_set_dedup_prefixes (variants/assemble.cpp:1473-1498), in set order. */
+int bg_trace_one_base_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n_frontiers, const uint32_t* d_foff,
+                            const uint64_t* d_begin, const uint64_t* d_end, const uint32_t* d_size,
+                            const uint32_t* d_min_ctx, uint8_t* d_best_base, uint8_t* d_n_cand,
+                            uint64_t* d_cbegin, uint64_t* d_cend, uint32_t* d_csize, uint8_t* d_cdrop,
+                            uint8_t* d_n_next, uint64_t* d_nbegin, uint64_t* d_nend, uint32_t* d_nsize);
+/* branch_discover::on_trace (graph_discover/branch.cpp:20-80) for n_asm assemblies: assembly a walks bases
+ * d_seq_codes[d_seq_off[a] .. d_seq_off[a+1]) (0..3) from its frontier; events = (offset, alternative base)
+ * of every 1-base branch (first ev_cap stored per assembly, d_n_ev = total); out = final frontier. */
+int bg_branch_trace_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n_asm, const uint64_t* d_seq_off,
+                          const uint8_t* d_seq_codes, const uint32_t* d_foff, const uint64_t* d_begin,
+                          const uint64_t* d_end, const uint32_t* d_size, uint32_t min_overlap, uint32_t ev_cap,
+                          uint32_t* d_ev_off, uint8_t* d_ev_base, uint32_t* d_n_ev, uint8_t* d_n_out,
+                          uint64_t* d_obegin, uint64_t* d_oend, uint32_t* d_osize);
+/* ref_map::build (variants/ref_map.cpp:72-185): marks seqset entries that are full-entry matches of the
+ * reference (both strands).  d_ref_codes = reference bases 0..3; extents = N-free supercontigs
+ * (flat_ref index, bio_base/flat_ref.h).  d_out[n] = [fwd_flag:1|rev_flag:1|count:6 saturating]
+ * (ref_map.h:49-53).  chain_bases = bases per GPU chain (0 = default 4096). */
+int bg_ref_map_build(bg_ctx* ctx, const bg_seqset* ss, const uint8_t* d_ref_codes, uint64_t n_extents,
+                     const uint64_t* h_ext_start, const uint64_t* h_ext_size, uint32_t chain_bases,
+                     uint8_t* d_out);
 
 /* ---- Sharded build (one process per GPU).  The library never communicates: these
  * entry points expose the phases of bg_create() at the exchange points; the host moves the buffers

@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -550,6 +551,142 @@ static std::vector<uint64_t> pack_varbit(const std::vector<uint32_t>& vals, uint
   return out;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Overlap-walk drivers (rows G2, G3, G7).
+using Range = Seqset::Range;
+struct RangeLess {  // seqset_range::operator< (bio_base/seqset.h:211-218)
+  bool operator()(const Range& a, const Range& b) const {
+    if (a.begin != b.begin) return a.begin < b.begin;
+    if (a.end != b.end) return a.end > b.end;
+    return a.size < b.size;
+  }
+};
+using RangeSet = std::set<Range, RangeLess>;
+
+// variants/assemble.cpp:1473-1498 — literal
+static void dedup_prefixes(RangeSet& rs) {
+  if (rs.empty()) return;
+  bool again = true;
+  while (again) {
+    again = false;
+    for (auto it = rs.begin(); it != rs.end(); ++it) {
+      auto next = it;
+      ++next;
+      for (; next != rs.end(); ++next) {
+        if (next->begin >= it->end) break;
+        if (it->begin <= next->begin && it->end >= next->end) {
+          it = rs.erase(it);
+          again = true;
+          break;
+        }
+      }
+      if (it == rs.end()) break;
+    }
+  }
+}
+
+// graph_discover/push_to_pair.cpp:159-240 without the per-trace state (m_seen_ranges, readmap;
+// k_check_reads=false :14).  Returns the chosen rc base (-1 = none); cands = best_rs U best_rs_drop
+// before prefix-dedup (set order) with their drop flag; next = the returned frontier.
+static int trace_one_base(const Seqset& ss, const RangeSet& rs, uint32_t min_ctx,
+                          std::vector<std::pair<Range, bool>>* cands, RangeSet* next) {
+  RangeSet nrs[4], nrs_drop[4];
+  for (int b = 0; b < 4; ++b)
+    for (const Range& r : rs) {
+      Range n = ss.push_front_drop(r, b, min_ctx);
+      if (!n.valid()) continue;
+      bool drop = n.size != r.size + 1;
+      (drop ? nrs_drop[b] : nrs[b]).insert(n);
+    }
+  unsigned best_len = 0;
+  int best = -1;
+  for (int b = 0; b < 4; ++b) {
+    unsigned nl = 0;
+    for (auto& r : nrs[b]) nl = std::max(nl, r.size);
+    for (auto& r : nrs_drop[b]) nl = std::max(nl, r.size);
+    if (nl > best_len) { best_len = nl; best = b; }
+  }
+  cands->clear();
+  next->clear();
+  if (!best_len) return -1;
+  std::map<Range, bool, RangeLess> all;
+  for (auto& r : nrs[best]) all[r] = false;
+  for (auto& r : nrs_drop[best]) {
+    auto it = all.find(r);
+    if (it == all.end()) all[r] = true; else it->second = true;  // same range reached both ways: in both sets
+  }
+  for (auto& kv : all) cands->push_back(kv);
+  *next = nrs[best];
+  next->insert(nrs_drop[best].begin(), nrs_drop[best].end());
+  dedup_prefixes(*next);
+  return best;
+}
+
+// graph_discover/branch.cpp:20-80: walk `seq` (codes 0..3) from frontier `cur`; at each offset the first
+// non-reference base (order A,C,G,T over b, pushing its complement) with any valid
+// push_front_drop(rc_b, min_overlap) is reported; then cur advances along the reference base.
+static void branch_trace(const Seqset& ss, const uint8_t* seq, size_t n, RangeSet cur, uint32_t min_overlap,
+                         std::vector<std::pair<uint32_t, uint8_t>>* events, RangeSet* final_cur) {
+  for (size_t off = 0; off < n; ++off) {
+    int ref_b = seq[off], rc_ref_b = 3 - ref_b;
+    for (int b = 0; b < 4; ++b) {
+      int rc_b = 3 - b;
+      if (rc_b == rc_ref_b) continue;
+      bool extend = false;
+      for (const Range& r : cur)
+        if (ss.push_front_drop(r, rc_b, min_overlap).valid()) extend = true;
+      if (extend) { events->emplace_back(uint32_t(off), uint8_t(b)); break; }
+    }
+    RangeSet nc;
+    for (const Range& r : cur) nc.insert(ss.push_front_drop(r, rc_ref_b, 0));
+    cur = std::move(nc);
+    dedup_prefixes(cur);
+  }
+  *final_cur = cur;
+}
+
+// variants/ref_map.cpp:72-185 + flush_updates :44-70 — literal chunking (max(extent/100, 25600) bases,
+// 256-base warm-up), both strands; NB the forward slice sets k_rev_flag and the rc slice k_fwd_flag.
+static void ref_map_build(const Seqset& ss, const uint8_t* ref, const uint64_t* ext_start, const uint64_t* ext_size,
+                          size_t n_ext, uint8_t* out) {
+  const unsigned k_fwd_flag = 1 << 7, k_rev_flag = 1 << 6, k_count_mask = 63;
+  const size_t k_min_chunk = 25600;
+  std::memset(out, 0, ss.n);
+  auto mark = [&](uint64_t id, bool is_rc) {
+    uint8_t v = out[id];
+    unsigned c = v & k_count_mask;
+    if (c != k_count_mask) ++c;
+    v = uint8_t((v & ~k_count_mask) | c);
+    v |= is_rc ? k_fwd_flag : k_rev_flag;
+    out[id] = v;
+  };
+  auto walk = [&](const std::vector<uint8_t>& slice, size_t prestart, bool is_rc) {
+    Range r{0, ss.n, 0};
+    for (size_t i = 0; i < slice.size(); ++i) {
+      r = ss.push_front_drop(r, 3 - slice[i], 0);
+      if (i < prestart) continue;
+      if (r.begin + 1 != r.end) continue;
+      if (r.size != ss.sizes[r.begin]) continue;
+      mark(r.begin, is_rc);
+    }
+  };
+  for (size_t e = 0; e < n_ext; ++e) {
+    const uint8_t* seq = ref + ext_start[e];
+    size_t len = ext_size[e];
+    size_t chunk = std::max(len / 100, k_min_chunk);
+    for (size_t cs = 0; cs < len; cs += chunk) {
+      size_t ce = std::min(cs + chunk, len);
+      size_t pre = cs >= 256 ? cs - 256 : 0;
+      size_t pre_rc = std::min(ce + 256, len);
+      walk(std::vector<uint8_t>(seq + pre, seq + ce), cs - pre, false);
+      std::vector<uint8_t> rc;
+      for (size_t i = pre_rc; i > cs; --i) rc.push_back(uint8_t(3 - seq[i - 1]));
+      walk(rc, pre_rc - ce, true);
+    }
+  }
+}
+
 }  // namespace orc
 
 // ============================================================================================
@@ -724,5 +861,58 @@ void orc_push_front(void* h, uint64_t n, const uint64_t* begin, const uint64_t* 
   }
 }
 void orc_seqset_free(void* h) { delete static_cast<Seqset*>(h); }
+
+// ---- walk drivers.  Ranges travel as (begin,end,size) triples of u64.
+static RangeSet to_set(const uint64_t* tri, uint64_t n) {
+  RangeSet rs;
+  for (uint64_t i = 0; i < n; ++i) rs.insert(Range{tri[3 * i], tri[3 * i + 1], uint32_t(tri[3 * i + 2])});
+  return rs;
+}
+// out_cands: up to cap triples + drop flags; out_next: up to cap triples.  Returns best rc base or -1.
+int orc_trace_one_base(void* h, const uint64_t* tri, uint64_t n, uint32_t min_ctx, uint64_t cap, uint64_t* out_cands,
+                       uint8_t* out_drop, uint64_t* n_cands, uint64_t* out_next, uint64_t* n_next) {
+  auto* ss = static_cast<Seqset*>(h);
+  std::vector<std::pair<Range, bool>> cands;
+  RangeSet next;
+  int best = trace_one_base(*ss, to_set(tri, n), min_ctx, &cands, &next);
+  *n_cands = cands.size();
+  *n_next = next.size();
+  uint64_t i = 0;
+  for (auto& c : cands) {
+    if (i >= cap) break;
+    out_cands[3 * i] = c.first.begin; out_cands[3 * i + 1] = c.first.end; out_cands[3 * i + 2] = c.first.size;
+    out_drop[i] = c.second;
+    ++i;
+  }
+  i = 0;
+  for (auto& r : next) {
+    if (i >= cap) break;
+    out_next[3 * i] = r.begin; out_next[3 * i + 1] = r.end; out_next[3 * i + 2] = r.size;
+    ++i;
+  }
+  return best;
+}
+// events: (offset, base) pairs up to cap; final frontier triples up to cap.
+void orc_branch_trace(void* h, const uint8_t* seq, uint64_t n, const uint64_t* tri, uint64_t n_cur, uint32_t min_overlap,
+                      uint64_t cap, uint32_t* ev_off, uint8_t* ev_base, uint64_t* n_events, uint64_t* out_cur,
+                      uint64_t* n_out_cur) {
+  auto* ss = static_cast<Seqset*>(h);
+  std::vector<std::pair<uint32_t, uint8_t>> ev;
+  RangeSet fin;
+  branch_trace(*ss, seq, n, to_set(tri, n_cur), min_overlap, &ev, &fin);
+  *n_events = ev.size();
+  for (uint64_t i = 0; i < ev.size() && i < cap; ++i) { ev_off[i] = ev[i].first; ev_base[i] = ev[i].second; }
+  *n_out_cur = fin.size();
+  uint64_t i = 0;
+  for (auto& r : fin) {
+    if (i >= cap) break;
+    out_cur[3 * i] = r.begin; out_cur[3 * i + 1] = r.end; out_cur[3 * i + 2] = r.size;
+    ++i;
+  }
+}
+void orc_ref_map_build(void* h, const uint8_t* ref_codes, const uint64_t* ext_start, const uint64_t* ext_size,
+                       uint64_t n_ext, uint8_t* out) {
+  ref_map_build(*static_cast<Seqset*>(h), ref_codes, ext_start, ext_size, n_ext, out);
+}
 
 }  // extern "C"

@@ -78,6 +78,11 @@ def lib():
     L.orc_push_front_drop.argtypes = [vp, C.c_uint64, u64p, u64p, u32p, u8p, u32p, u64p, u64p, u32p]
     L.orc_push_front.argtypes = [vp, C.c_uint64, u64p, u64p, u32p, u8p, u64p, u64p, u32p]
     L.orc_seqset_free.argtypes = [vp]
+    L.orc_trace_one_base.restype = C.c_int
+    L.orc_trace_one_base.argtypes = [vp, u64p, C.c_uint64, C.c_uint32, C.c_uint64, u64p, u8p, u64p, u64p, u64p]
+    L.orc_branch_trace.argtypes = [vp, u8p, C.c_uint64, u64p, C.c_uint64, C.c_uint32, C.c_uint64, u32p, u8p, u64p,
+                                   u64p, u64p]
+    L.orc_ref_map_build.argtypes = [vp, u8p, u64p, u64p, C.c_uint64, u8p]
     _LIB = L
     return L
 
@@ -301,6 +306,41 @@ class Seqset:
                              _pad(np.ascontiguousarray(end, np.uint64)), _pad(np.ascontiguousarray(size, np.uint32)),
                              _pad(np.ascontiguousarray(base, np.uint8)), ob, oe, osz)
         return ob[:n], oe[:n], osz[:n]
+
+    # ---- walk drivers (rows G2, G3, G7)
+    def trace_one_base(self, ranges, min_ctx, cap=64):
+        """ranges: list of (begin,end,size).  -> (best rc base or -1, [(range, dropped)], [next ranges])."""
+        tri = _pad(np.array(ranges, np.uint64).reshape(-1))
+        oc = np.zeros(3 * cap, np.uint64)
+        od = np.zeros(cap, np.uint8)
+        on = np.zeros(3 * cap, np.uint64)
+        nc = np.zeros(1, np.uint64)
+        nn = np.zeros(1, np.uint64)
+        best = lib().orc_trace_one_base(self.h, tri, len(ranges), min_ctx, cap, oc, od, nc, on, nn)
+        cands = [((int(oc[3 * i]), int(oc[3 * i + 1]), int(oc[3 * i + 2])), bool(od[i])) for i in range(int(nc[0]))]
+        nxt = [(int(on[3 * i]), int(on[3 * i + 1]), int(on[3 * i + 2])) for i in range(int(nn[0]))]
+        return best, cands, nxt
+
+    def branch_trace(self, seq_codes, ranges, min_overlap, cap=4096):
+        tri = _pad(np.array(ranges, np.uint64).reshape(-1))
+        seq_codes = np.ascontiguousarray(seq_codes, np.uint8)
+        eo = np.zeros(cap, np.uint32)
+        eb = np.zeros(cap, np.uint8)
+        ne = np.zeros(1, np.uint64)
+        oc = np.zeros(3 * 64, np.uint64)
+        no = np.zeros(1, np.uint64)
+        lib().orc_branch_trace(self.h, _pad(seq_codes), len(seq_codes), tri, len(ranges), min_overlap, cap, eo, eb, ne,
+                               oc, no)
+        ev = [(int(eo[i]), int(eb[i])) for i in range(min(int(ne[0]), cap))]
+        cur = [(int(oc[3 * i]), int(oc[3 * i + 1]), int(oc[3 * i + 2])) for i in range(int(no[0]))]
+        return int(ne[0]), ev, cur
+
+    def ref_map_build(self, ref_codes, ext_start, ext_size):
+        out = np.zeros(max(len(self), 1), np.uint8)
+        lib().orc_ref_map_build(self.h, np.ascontiguousarray(ref_codes, np.uint8),
+                                np.ascontiguousarray(ext_start, np.uint64), np.ascontiguousarray(ext_size, np.uint64),
+                                len(ext_start), out)
+        return out[:len(self)]
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -1,0 +1,96 @@
+"""GPU parity of the frontier walks the graph_discover drivers are built on
+against the oracle's literal restatements, on the reference's lambda golden seqset + reference."""
+import numpy as np
+import pytest
+
+import biograph_amd as bg
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CODE = {c: i for i, c in enumerate("ACGT")}
+
+
+@pytest.fixture(scope="module")
+def world(golden_dir):
+    ctx = bg.Context(0)
+    d = O.load_seqset_zip(golden_dir + "/father_lambda/seqset")
+    oss = O.Seqset.from_arrays(d["sizes"], d["shared"], d["bits"])
+    ss = ctx.seqset_from_arrays(d["sizes"], d["shared"], d["bits"])
+    fa = "".join(l.strip() for l in open(golden_dir + "/father_lambda/reference.fasta") if not l.startswith(">"))
+    ref = np.array([CODE[c] for c in fa.upper()], np.uint8)
+    yield ctx, d, oss, ss, ref
+    ctx.close()
+
+
+def _frontiers_from_ref(oss, ref, rng, count, width):
+    """Frontiers the drivers really see: the ranges reached by walking `width` reference windows."""
+    fr = []
+    for _ in range(count):
+        k = int(rng.integers(1, 6))
+        cur = set()
+        for _ in range(k):
+            p = int(rng.integers(0, len(ref) - width))
+            r = (0, len(oss), 0)
+            for j in range(width):
+                b, e, s = oss.push_front_drop(np.array([r[0]], np.uint64), np.array([r[1]], np.uint64),
+                                              np.array([r[2]], np.uint32), np.array([3 - ref[p + j]], np.uint8),
+                                              np.array([0], np.uint32))
+                r = (int(b[0]), int(e[0]), int(s[0]))
+            cur.add(r)
+        fr.append(sorted(cur))
+    return fr
+
+
+def test_ref_map_build_matches_reference_chunking(world):
+    ctx, d, oss, ss, ref = world
+    want = oss.ref_map_build(ref, [0], [len(ref)])
+    for chain in (0, 300, 1000, 25600):
+        got = ss.ref_map_build(ref, [0], [len(ref)], chain)
+        assert (got == want).all(), chain
+    assert (want & 63).max() >= 1 and ((want & 0x80) != 0).any() and ((want & 0x40) != 0).any()
+    # two extents (an N gap in the middle) and a tiny one
+    es, ez = [0, 20000, 48000], [15000, 25000, 100]
+    assert (ss.ref_map_build(ref, es, ez, 2048) == oss.ref_map_build(ref, es, ez)).all()
+
+
+def test_trace_one_base_matches_oracle(world):
+    ctx, d, oss, ss, ref = world
+    rng = np.random.default_rng(4)
+    fr = _frontiers_from_ref(oss, ref, rng, 300, 60)
+    fr += [[(0, len(oss), 0)], [], [(5, 6, int(d["sizes"][5]))]]
+    for rounds in range(5):
+        min_ctx = [int(x) for x in rng.integers(0, 80, len(fr))]
+        got = ss.trace_one_base_batch(fr, min_ctx)
+        nxt = []
+        for f, mc, g in zip(fr, min_ctx, got):
+            best, cands, n2 = oss.trace_one_base(f, mc)
+            assert g[0] == best
+            assert g[1] == cands
+            assert g[2] == n2
+            nxt.append(n2 if n2 else f)
+        fr = nxt
+
+
+def test_branch_trace_matches_oracle(world):
+    ctx, d, oss, ss, ref = world
+    rng = np.random.default_rng(8)
+    seqs, fronts = [], []
+    for _ in range(120):
+        p = int(rng.integers(200, len(ref) - 500))
+        L = int(rng.integers(1, 300))
+        # frontier = walk of the 150 bases before the assembly (what rc_seqset_entries.ends() holds)
+        r = (0, len(oss), 0)
+        for j in range(150):
+            b, e, s = oss.push_front_drop(np.array([r[0]], np.uint64), np.array([r[1]], np.uint64),
+                                          np.array([r[2]], np.uint32), np.array([3 - ref[p - 150 + j]], np.uint8),
+                                          np.array([0], np.uint32))
+            r = (int(b[0]), int(e[0]), int(s[0]))
+        seqs.append(ref[p:p + L].copy())
+        fronts.append([r])
+    for mo in (20, 70, 105):
+        got = ss.branch_trace_batch(seqs, fronts, mo, ev_cap=512)
+        for s_, f, g in zip(seqs, fronts, got):
+            n, ev, cur = oss.branch_trace(s_, f, mo)
+            assert g[0] == n and g[1] == ev and g[2] == cur
+    assert any(g[0] > 0 for g in got)
