@@ -42,6 +42,73 @@ def cpu_baseline(sample_genome, coverage, read_len, seed):
                 n, read_len, bases / 1e6, coverage, sample_genome, dt, len(ss))}
 
 
+def discover_leg(ctx, seq, offs, n_reads, params, genome, dev):
+    """Overlap-walk throughput on the seqset just built (N=1 only, outside the build's timed region):
+    ref_map::build over both strands of the reference haplotype (2 x G dependent push_front_drop calls in
+    4096-base chains) and branch_discover::on_trace over the whole reference in 1000-base assemblies
+    (every 1-base branch = a candidate variant site)."""
+    import ctypes as C
+    import torch
+    from biograph_amd import capi
+    L = capi.lib()
+    ss, st = ctx.create_device(seq.data_ptr(), offs.data_ptr(), n_reads, params)
+    G = int(genome.numel())
+    n = ss.size()
+    out = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+    es = (C.c_uint64 * 1)(0)
+    ez = (C.c_uint64 * 1)(G)
+    vp = C.c_void_p
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    capi.check(L.bg_ref_map_build(ctx.h, ss.h, vp(genome.data_ptr()), 1, es, ez, 4096, vp(out.data_ptr())))
+    torch.cuda.synchronize()
+    t_ref = time.perf_counter() - t0
+    marked = int((out[:n] & 63 != 0).sum().item())
+    unique = int(((out[:n] & 63) == 1).sum().item())
+    # branch trace: assemblies of 1000 reference bases, each preceded by a 256-base warm-up walk from the
+    # empty frontier (events inside the warm-up are not counted)
+    A, WARM = 1000, 256
+    starts = torch.arange(0, G - A - WARM, A, device=dev, dtype=torch.int64)
+    na = int(starts.numel())
+    soff = (torch.arange(0, na + 1, device=dev, dtype=torch.int64) * (A + WARM)).contiguous()
+    idx = (starts[:, None] + torch.arange(0, A + WARM, device=dev)[None, :]).reshape(-1)
+    codes = genome[idx].contiguous()
+    foff = torch.arange(0, na + 1, device=dev, dtype=torch.int32)
+    fb = torch.zeros(na, dtype=torch.int64, device=dev)
+    fe = torch.full((na,), n, dtype=torch.int64, device=dev)
+    fs = torch.zeros(na, dtype=torch.int32, device=dev)
+    cap = 64
+    ev_off = torch.empty(na * cap, dtype=torch.int32, device=dev)
+    ev_base = torch.empty(na * cap, dtype=torch.uint8, device=dev)
+    n_ev = torch.empty(na, dtype=torch.int32, device=dev)
+    n_out = torch.empty(na, dtype=torch.uint8, device=dev)
+    ob = torch.empty(na * 16, dtype=torch.int64, device=dev)
+    oe = torch.empty(na * 16, dtype=torch.int64, device=dev)
+    osz = torch.empty(na * 16, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    capi.check(L.bg_branch_trace_batch(ctx.h, ss.h, na, vp(soff.data_ptr()), vp(codes.data_ptr()), vp(foff.data_ptr()),
+                                       vp(fb.data_ptr()), vp(fe.data_ptr()), vp(fs.data_ptr()), 105, cap,
+                                       vp(ev_off.data_ptr()), vp(ev_base.data_ptr()), vp(n_ev.data_ptr()),
+                                       vp(n_out.data_ptr()), vp(ob.data_ptr()), vp(oe.data_ptr()), vp(osz.data_ptr())))
+    torch.cuda.synchronize()
+    t_br = time.perf_counter() - t0
+    k = torch.minimum(n_ev, torch.full_like(n_ev, cap))
+    mask = torch.arange(cap, device=dev)[None, :] < k[:, None]
+    sites = int(((ev_off.view(na, cap) >= WARM) & mask).sum().item())
+    ss.free()
+    pfd_ref = 2 * G + 2 * 256 * (G // 4096 + 1)
+    pfd_br = na * (A + WARM) * 4
+    return {"ref_map": {"seconds": round(t_ref, 4), "ref_bases_per_s": round(2 * G / t_ref / 1e9, 3),
+                        "unit": "Gbases/s (both strands)", "push_front_drop_per_s": round(pfd_ref / t_ref / 1e9, 3),
+                        "entries_marked": marked, "entries_unique": unique,
+                        "algorithmic_GBps": round(pfd_ref * 52 / t_ref / 1e9, 1)},
+            "branch_discover": {"seconds": round(t_br, 4), "assemblies": na, "min_overlap": 105,
+                                "variants_per_s": round(sites / t_br, 1), "branch_sites": sites,
+                                "push_front_drop_per_s": round(pfd_br / t_br / 1e9, 3),
+                                "algorithmic_GBps": round(pfd_br * 52 / t_br / 1e9, 1)}}
+
+
 KERNEL_OF_FAMILY = {"radix_scatter_k": "rs_scatter_kernel<unsigned int, false>",
                     "radix_scatter_kv": "rs_scatter_kernel<unsigned int, true>", "radix_hist": "rs_hist_kernel",
                     "correct_screen": "k_correct_screen"}
@@ -80,6 +147,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20261002)
     ap.add_argument("--cpu-sample-genome", type=int, default=600_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-discover", action="store_true", help="skip the overlap-walk (discover) leg")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the sharded (RCCL) build path even with one rank (smoke test of the collectives)")
     args = ap.parse_args()
@@ -113,8 +181,9 @@ def main():
     # its read pairs (per-GPU reads fixed) and the ranks build ONE seqset together (biograph_amd/sharded.py:
     # k-mers, records and tails cross GPUs by RCCL all_to_all, kept k-mers / corrected reads by all_gather).
     genome_len = (args.genome_len or synth.SHAPES[args.shape]) * world
-    seq, offs, n_reads = synth.make_reads(genome_len=genome_len, coverage=args.coverage, read_len=args.read_len,
-                                          seed=args.seed, device=dev, shard=(rank, world))
+    seq, offs, n_reads, genome = synth.make_reads(genome_len=genome_len, coverage=args.coverage,
+                                                  read_len=args.read_len, seed=args.seed, device=dev,
+                                                  shard=(rank, world), return_genome=True)
     torch.cuda.synchronize()
     n_bases = int(seq.numel())
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -164,6 +233,9 @@ def main():
     else:
         total_bases = float(n_bases)
 
+    discover = None
+    if world == 1 and not args.no_discover:
+        discover = discover_leg(ctx, seq, offs, n_reads, params, genome, dev)
     if rank == 0:
         # dominant kernel family by device time
         fam = max(timings, key=lambda t: t["ms"]) if timings else None
@@ -208,7 +280,7 @@ def main():
                                "achieved_GBps": round(alg / step_s / 1e9, 1),
                                "frac_of_hbm_peak": round(alg / step_s / 1e9 / (HBM_PEAK_GBS * world), 5),
                                "kernel_time_frac_of_wall": round(total_ms / 1e3 / elapsed, 3)},
-            "counters": stats, "kernels": kernels,
+            "discover": discover, "counters": stats, "kernels": kernels,
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     ctx.close()

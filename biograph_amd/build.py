@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libbgseq.so")
+CLI = os.path.join(HERE, "bgbinary")
 SOURCES = ["prims.hip", "build_kmer.hip", "build_seqset.hip", "walk.hip", "shard.hip", "api.hip", "spiral_zip.cpp"]
 HEADERS = ["bg_internal.h", "bg_device_funcs.h", "compact.h", os.path.join("..", "..", "include", "bgseq.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result",
@@ -62,6 +63,11 @@ def build(force=False, verbose=False):
                 print(o)
     if jobs or force or _stale(LIB, objs):
         run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    # bgbinary: host-only C++ front end over the C ABI (FASTQ in, .bg directory out)
+    cli_src = os.path.join(CSRC, "cli", "bgbinary.cpp")
+    if force or _stale(CLI, [cli_src, LIB] + hdrs):
+        run(["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI, cli_src, "-L" + HERE, "-lbgseq", "-lz",
+             "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")])
     return LIB
 
 

@@ -1,0 +1,268 @@
+// bgbinary — command-line front end over libbgseq.so mirroring the reference's `bgbinary create`
+// (modules/biograph/biograph_create.cpp:258-335 flags, :516-527 output layout) and the reference-map
+// stage of `bgbinary discovery` (modules/biograph/biograph_variants.cpp:642-667).
+//
+//   bgbinary create --reads X.fq[.gz] [--pair Y.fq] [--interleaved] [--ref DIR] --out S.bg [--id ID] [-f]
+//                   [--kmer-size 30] [--min-kmer-count 5] [--trim-after-portion 0.7]
+//                   [--max-corrections 8] [--min-good-run 2] [--min-reads 0.4] [--warn-reads 0.7] [--stats FILE]
+//   bgbinary refmap --in S.bg --ref DIR|FASTA --out FILE          (ref_map::build -> one byte per entry)
+//
+// Host work here is file I/O only (FASTQ parsing with zlib, output directory); every computation is a
+// C-ABI call that runs on the GPU.  Readmap creation is a "next" row: the coverage/
+// directory is left empty and bg_info.json lists no sample readmap.
+#include <errno.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../../include/bgseq.h"
+
+static void die(const std::string& msg) {
+  fprintf(stderr, "%s\n", msg.c_str());
+  exit(1);
+}
+static void check(int rc, const char* what) {
+  if (rc != BG_OK) die(std::string(what) + ": " + bg_last_error());
+}
+
+struct Args {
+  std::map<std::string, std::vector<std::string>> opt;
+  bool has(const std::string& k) const { return opt.count(k) != 0; }
+  std::string get(const std::string& k, const std::string& dflt = "") const {
+    auto it = opt.find(k);
+    return it == opt.end() || it->second.empty() ? dflt : it->second.back();
+  }
+};
+
+static Args parse(int argc, char** argv, int first) {
+  static const char* flags[] = {"interleaved", "force", "f", "allow-long-reads", nullptr};
+  Args a;
+  for (int i = first; i < argc; ++i) {
+    std::string s = argv[i];
+    if (s.rfind("--", 0) != 0 && s != "-f") die("unexpected argument: " + s);
+    std::string key = s == "-f" ? "force" : s.substr(2), val;
+    size_t eq = key.find('=');
+    bool is_flag = false;
+    for (const char** f = flags; *f; ++f) is_flag |= key == *f;
+    if (eq != std::string::npos) { val = key.substr(eq + 1); key = key.substr(0, eq); }
+    else if (!is_flag) { if (i + 1 >= argc) die("missing value for --" + key); val = argv[++i]; }
+    if (key == "in") key = "reads";  // --reads,in (biograph_create.cpp:263)
+    a.opt[key].push_back(val);
+  }
+  return a;
+}
+
+// FASTQ (plain or gzip) -> sequences; qualities dropped (read_importer.cpp:22)
+static void read_fastq(const std::string& path, std::vector<std::string>* out) {
+  gzFile f = gzopen(path == "-" ? "/dev/stdin" : path.c_str(), "rb");
+  if (!f) die("Could not open " + path + ": " + strerror(errno));
+  gzbuffer(f, 1 << 20);
+  std::vector<char> buf(1 << 16);
+  std::string line;
+  uint64_t lineno = 0;
+  auto getline = [&](std::string* l) -> bool {
+    l->clear();
+    for (;;) {
+      if (!gzgets(f, buf.data(), int(buf.size()))) return !l->empty();
+      l->append(buf.data());
+      if (!l->empty() && l->back() == '\n') { l->pop_back(); if (!l->empty() && l->back() == '\r') l->pop_back(); return true; }
+    }
+  };
+  while (getline(&line)) {
+    if (lineno % 4 == 0 && !line.empty() && line[0] != '@') die(path + ": malformed FASTQ record at line " + std::to_string(lineno + 1));
+    if (lineno % 4 == 1) out->push_back(line);
+    ++lineno;
+  }
+  gzclose(f);
+}
+
+static void read_fasta(const std::string& path, std::string* seq) {
+  gzFile f = gzopen(path.c_str(), "rb");
+  if (!f) die("Could not open " + path + ": " + strerror(errno));
+  std::vector<char> buf(1 << 16);
+  while (gzgets(f, buf.data(), int(buf.size()))) {
+    if (buf[0] == '>') continue;
+    for (char* p = buf.data(); *p; ++p)
+      if (*p != '\n' && *p != '\r') seq->push_back(*p);
+  }
+  gzclose(f);
+}
+
+static bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+static void mkdirs(const std::string& p) {
+  if (mkdir(p.c_str(), 0777) != 0 && errno != EEXIST) die("Could not create " + p + ": " + strerror(errno));
+}
+static void write_file(const std::string& p, const std::string& data) {
+  FILE* f = fopen(p.c_str(), "wb");
+  if (!f || fwrite(data.data(), 1, data.size(), f) != data.size()) die("Could not write " + p);
+  fclose(f);
+}
+
+static double now_s() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+static int cmd_create(int argc, char** argv) {
+  Args a = parse(argc, argv, 2);
+  if (!a.has("reads") || !a.has("out")) die("create: --reads and --out are required");
+  std::string out = a.get("out");
+  if (out.size() < 3 || out.substr(out.size() - 3) != ".bg") out += ".bg";  // biograph_dir appends .bg
+  if (exists(out + "/seqset") && !a.has("force")) die("Refusing to overwrite " + out + ". Use --force to override.");
+  bg_create_params p;
+  bg_create_params_default(&p);
+  p.kmer_size = atoi(a.get("kmer-size", "30").c_str());
+  p.min_kmer_count = uint32_t(atoi(a.get("min-kmer-count", "5").c_str()));
+  p.correct.trim_after_portion = strtof(a.get("trim-after-portion", "0.7").c_str(), nullptr);
+  p.correct.max_corrections = uint32_t(atoi(a.get("max-corrections", "8").c_str()));
+  p.correct.min_good_run = uint32_t(atoi(a.get("min-good-run", "2").c_str()));
+  double min_reads = atof(a.get("min-reads", "0.4").c_str()), warn_reads = atof(a.get("warn-reads", "0.7").c_str());
+  if (p.min_kmer_count < 1) die("--min-kmer-count must be at least 1");
+
+  double t0 = now_s();
+  fprintf(stderr, "Importing reads\n");
+  std::vector<std::string> reads;
+  const auto& ins = a.opt["reads"];
+  const auto& pairs = a.has("pair") ? a.opt["pair"] : std::vector<std::string>();
+  if (!pairs.empty() && pairs.size() != ins.size()) die("--pair must be given once per --reads");
+  for (size_t i = 0; i < ins.size(); ++i) {
+    std::vector<std::string> r1, r2;
+    read_fastq(ins[i], &r1);
+    if (!pairs.empty()) {
+      read_fastq(pairs[i], &r2);
+      if (r1.size() != r2.size()) die("Pair files hold different numbers of reads");
+      for (size_t j = 0; j < r1.size(); ++j) { reads.push_back(std::move(r1[j])); reads.push_back(std::move(r2[j])); }
+    } else {
+      for (auto& s : r1) reads.push_back(std::move(s));
+    }
+  }
+  if (reads.empty()) die("\nNo reads were imported, exiting.");
+  fprintf(stderr, "\nTotal reads imported: %zu\n", reads.size());
+  double t_import = now_s() - t0;
+
+  bg_ctx* ctx = nullptr;
+  check(bg_ctx_create(0, nullptr, &ctx), "bg_ctx_create");
+  std::string seq;
+  std::vector<uint64_t> offs{0};
+  size_t total = 0;
+  for (auto& r : reads) total += r.size();
+  seq.reserve(total);
+  for (auto& r : reads) { seq += r; offs.push_back(seq.size()); }
+  void *d_seq = nullptr, *d_offs = nullptr;
+  check(bg_dev_alloc(ctx, seq.size(), &d_seq), "bg_dev_alloc");
+  check(bg_dev_alloc(ctx, offs.size() * 8, &d_offs), "bg_dev_alloc");
+  check(bg_dev_upload(ctx, d_seq, seq.data(), seq.size()), "upload");
+  check(bg_dev_upload(ctx, d_offs, offs.data(), offs.size() * 8), "upload");
+  fprintf(stderr, "\nRunning kmerization, read correction and seqset build on the GPU\n");
+  double t1 = now_s();
+  bg_seqset* ss = nullptr;
+  bg_build_stats st;
+  check(bg_create(ctx, static_cast<const uint8_t*>(d_seq), static_cast<const uint64_t*>(d_offs), reads.size(), &p, &ss, &st),
+        "bg_create");
+  double t_build = now_s() - t1;
+  double pct = double(st.n_corrected_reads) / double(reads.size());
+  char msg[256];
+  if (pct < min_reads) {  // biograph_create.cpp:748-757
+    snprintf(msg, sizeof msg, "Fewer than %2.0f%% of reads (set by --min-reads) were kept after correction (%llu / %zu remain). Cannot continue.",
+             min_reads * 100.0, (unsigned long long)st.n_corrected_reads, reads.size());
+    die(msg);
+  }
+  if (pct < warn_reads)
+    fprintf(stderr, "Warning: Fewer than %2.0f%% of reads (set by --warn-reads) survived correction (%llu / %zu remain)\n",
+            warn_reads * 100.0, (unsigned long long)st.n_corrected_reads, reads.size());
+
+  mkdirs(out);
+  mkdirs(out + "/qc");
+  mkdirs(out + "/metadata");
+  mkdirs(out + "/coverage");
+  std::vector<const char*> av(argv, argv + argc);
+  check(bg_seqset_write(ctx, ss, (out + "/seqset").c_str(), argc, av.data()), "bg_seqset_write");
+  double t_total = now_s() - t0;
+
+  std::string id = a.get("id");
+  char js[2048];
+  snprintf(js, sizeof js,
+           "{\"command\":\"create\",\"version\":\"biograph_amd-r1\",\"accession_id\":\"%s\",\"imported_reads\":%zu,"
+           "\"corrected_reads\":%llu,\"corrected_bases\":%llu,\"avg_bases_per_read\":%.6f,\"corrected_pct\":%.6f,"
+           "\"kept_kmers\":%llu,\"seqset_entries\":%llu,\"timings\":[{\"import\":%.0f},{\"gpu_build\":%.3f},{\"total\":%.0f}]}",
+           id.c_str(), reads.size(), (unsigned long long)st.n_corrected_reads, (unsigned long long)st.n_corrected_bases,
+           st.n_corrected_reads ? double(st.n_corrected_bases) / double(st.n_corrected_reads) : 0.0, pct,
+           (unsigned long long)st.n_kept_kmers, (unsigned long long)st.n_entries, t_import, t_build, t_total);
+  write_file(out + "/qc/create_stats.json", js);
+  if (a.has("stats")) write_file(a.get("stats"), js);
+  snprintf(js, sizeof js, "{\"accession_id\":\"%s\",\"command_history\":[],\"samples\":{},\"version\":\"biograph_amd-r1\"}", id.c_str());
+  write_file(out + "/metadata/bg_info.json", js);
+  fprintf(stderr, "%llu / %zu reads survived read correction; %llu seqset entries; GPU build %.3f s\n",
+          (unsigned long long)st.n_corrected_reads, reads.size(), (unsigned long long)st.n_entries, t_build);
+  bg_seqset_free(ss);
+  bg_dev_free(ctx, d_seq);
+  bg_dev_free(ctx, d_offs);
+  bg_ctx_destroy(ctx);
+  return 0;
+}
+
+static int cmd_refmap(int argc, char** argv) {
+  Args a = parse(argc, argv, 2);
+  if (!a.has("in") && !a.has("reads")) die("refmap: --in S.bg is required");
+  if (!a.has("ref") || !a.has("out")) die("refmap: --ref and --out are required");
+  std::string bgdir = a.has("reads") ? a.get("reads") : a.get("in");
+  std::string ref = a.get("ref");
+  if (exists(ref + "/reference.fasta")) ref += "/reference.fasta";  // reference directory (io/defaults.h:17-50)
+  std::string fa;
+  read_fasta(ref, &fa);
+  // extents = maximal N-free stretches (supercontigs, bio_base/reference.cpp:27-40)
+  std::vector<uint8_t> codes(fa.size(), 0);
+  std::vector<uint64_t> es, ez;
+  uint64_t run = 0;
+  for (size_t i = 0; i < fa.size(); ++i) {
+    char c = fa[i] & 0xDF;
+    int code = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
+    if (code < 0) { if (run) { es.push_back(i - run); ez.push_back(run); } run = 0; continue; }
+    codes[i] = uint8_t(code);
+    ++run;
+  }
+  if (run) { es.push_back(fa.size() - run); ez.push_back(run); }
+  bg_ctx* ctx = nullptr;
+  check(bg_ctx_create(0, nullptr, &ctx), "bg_ctx_create");
+  bg_seqset* ss = nullptr;
+  check(bg_seqset_open(ctx, (bgdir + "/seqset").c_str(), &ss), "bg_seqset_open");
+  uint64_t n = bg_seqset_size(ss);
+  void *d_ref = nullptr, *d_out = nullptr;
+  check(bg_dev_alloc(ctx, codes.size(), &d_ref), "bg_dev_alloc");
+  check(bg_dev_alloc(ctx, n, &d_out), "bg_dev_alloc");
+  check(bg_dev_upload(ctx, d_ref, codes.data(), codes.size()), "upload");
+  double t0 = now_s();
+  check(bg_ref_map_build(ctx, ss, static_cast<const uint8_t*>(d_ref), es.size(), es.data(), ez.data(), 0,
+                         static_cast<uint8_t*>(d_out)), "bg_ref_map_build");
+  double dt = now_s() - t0;
+  std::string out(n, '\0');
+  check(bg_dev_download(ctx, &out[0], d_out, n), "download");
+  write_file(a.get("out"), out);
+  uint64_t marked = 0;
+  for (unsigned char v : out) marked += (v & 63) != 0;
+  fprintf(stderr, "%llu nodes marked by walking reference (%.2f%%) in %.3f s\n", (unsigned long long)marked,
+          n ? marked * 100.0 / n : 0.0, dt);
+  bg_seqset_free(ss);
+  bg_dev_free(ctx, d_ref);
+  bg_dev_free(ctx, d_out);
+  bg_ctx_destroy(ctx);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) die("usage: bgbinary {create|refmap} [options]   (MI355X build of the seqset path)");
+  std::string cmd = argv[1];
+  if (cmd == "create") return cmd_create(argc, argv);
+  if (cmd == "refmap") return cmd_refmap(argc, argv);
+  die("bgbinary: unknown command '" + cmd + "' (this build provides: create, refmap)");
+  return 1;
+}

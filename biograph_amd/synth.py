@@ -33,7 +33,7 @@ def make_genome(n, seed, device):
 
 
 def make_reads(genome_len=SHAPES["tiny"], coverage=30, read_len=150, seed=20261002, device="cpu", err=0.002,
-               n_rate=0.0001, snp_rate=0.001, chunk_pairs=1 << 20, shard=(0, 1)):
+               n_rate=0.0001, snp_rate=0.001, chunk_pairs=1 << 20, shard=(0, 1), return_genome=False):
     """Returns (seq uint8 [n_reads*read_len], offs int64 [n_reads+1], n_reads).
 
     shard=(rank, world): the same sample (genome + haplotypes from `seed`) on every rank, each rank
@@ -80,4 +80,6 @@ def make_reads(genome_len=SHAPES["tiny"], coverage=30, read_len=150, seed=202610
         out[2 * done * read_len: 2 * (done + m) * read_len] = asc.reshape(-1)
         done += m
     offs = torch.arange(0, (n_reads + 1) * read_len, read_len, dtype=torch.int64, device=dev)
+    if return_genome:
+        return out, offs, n_reads, hap_a
     return out, offs, n_reads

@@ -229,3 +229,31 @@ def test_synthetic_wgs_shape_full_path(ctx):
     for name, blob in ss.parts().items():
         assert blob == want[name], name
     assert info["modified"] > 0
+
+
+def test_bgbinary_create_cli_matches_golden(golden_dir, tmp_path):
+    """`bgbinary create` (C++ host over the C ABI) on the reference's golden FASTQ: the written spiral
+    container holds byte-identical payload parts to golden/e_coli_10000snp.bg/seqset (old layout
+    stores sizes/shared raw: compare decoded arrays) and `bgbinary refmap` runs on the result."""
+    import json
+    import subprocess
+    import sys
+    out = tmp_path / "ecoli.bg"
+    r = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "create", "--reads",
+                        golden_dir + "/e_coli_10000snp/reads.fq", "--out", str(out), "--id", "test_accession_id"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    stats = json.load(open(out / "qc" / "create_stats.json"))
+    assert stats["corrected_reads"] == 8444 and stats["corrected_bases"] == 288464 and stats["imported_reads"] == 10000
+    mine = O.load_seqset_zip(str(out / "seqset"))
+    gold = O.load_seqset_zip(golden_dir + "/e_coli_10000snp/seqset")
+    assert mine["n"] == gold["n"] == 19935
+    assert (mine["sizes"] == gold["sizes"]).all() and (mine["shared"] == gold["shared"]).all()
+    for w in ("bits", "subaccum", "accum"):
+        for b in range(4):
+            assert (mine[w][b] == gold[w][b]).all()
+    assert (mine["fixed"] == gold["fixed"]).all()
+    # refusing to overwrite without --force (biograph_create.cpp:497-506)
+    r2 = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "create", "--reads",
+                         golden_dir + "/e_coli_10000snp/reads.fq", "--out", str(out)], capture_output=True, text=True)
+    assert r2.returncode == 1 and "overwrite" in r2.stderr
