@@ -117,11 +117,21 @@ struct ReadView {
   int origin;  // original-read position of virtual index 0
   int dir;     // +1: left-to-right; -1: reverse complement walking left
   int n;       // virtual length
+  int k;
+  // Optional: bit j set <=> the UNMODIFIED read's window starting at base j holds no N and its k-mer is
+  // in the set (filled by the screening kernel).  Lets the search skip look-ups of windows no
+  // substitution has touched; null = always look up.
+  const uint64_t* present;
   BG_HD int get(int t) const {  // 0..3, or 4 for N
     int p = dir > 0 ? origin + t : origin - t;
     if (read_isn(nmask, p)) return 4;
     int c = read_code(words, p);
     return dir > 0 ? c : 3 - c;
+  }
+  // presence of the original window whose newest base is virtual index t
+  BG_HD bool window_present(int t) const {
+    int j = dir > 0 ? origin + t - k + 1 : origin - t;  // window start in read coordinates
+    return (present[j >> 6] >> (j & 63)) & 1;
   }
 };
 
@@ -133,6 +143,7 @@ BG_HD void frc_solve(const Table& tab, const ReadView& in, int start0, uint64_t 
                      FrcRes* out) {
   struct Frame {
     int start, pos, b, best_size, best_b;
+    int last_sub;  // virtual index of the latest substitution on the path into this frame
     uint64_t kmer;
     FrcRes best;
   };
@@ -140,6 +151,7 @@ BG_HD void frc_solve(const Table& tab, const ReadView& in, int start0, uint64_t 
   int depth = 0;
   fr[0].start = start0;
   fr[0].kmer = kmer0;
+  fr[0].last_sub = -(1 << 20);
   FrcRes ret;
   ret.len = 0;
   ret.ncorr = 0;
@@ -153,7 +165,9 @@ BG_HD void frc_solve(const Table& tab, const ReadView& in, int start0, uint64_t 
         int c = in.get(pos);
         if (c == 4) break;
         uint64_t nk = kmer_shift(cur, k, c);
-        if (!tab.has(nk)) break;
+        // a window no substitution reaches (>= k bases past the last one) is the read's own window
+        bool has = (in.present && pos - f.last_sub >= k) ? in.window_present(pos) : tab.has(nk);
+        if (!has) break;
         cur = nk;
         ++pos;
       }
@@ -194,6 +208,7 @@ BG_HD void frc_solve(const Table& tab, const ReadView& in, int start0, uint64_t 
       if (f.pos + 1 < in.n) {
         fr[depth + 1].start = f.pos + 1;
         fr[depth + 1].kmer = tk;
+        fr[depth + 1].last_sub = f.pos;
         ++depth;
         entering = true;
         descended = true;
@@ -240,19 +255,37 @@ BG_HD void frc_solve(const Table& tab, const ReadView& in, int start0, uint64_t 
 template <class Table>
 BG_HD int frc_correct_read(const Table& tab, const uint64_t* words, const uint32_t* nmask, int len, int W, int k,
                            int max_corrections, int min_good_run, int needed, uint64_t* out_words,
-                           int* ncorr_out) {
+                           int* ncorr_out, const uint64_t* present = nullptr) {
   *ncorr_out = 0;
   if (len < k) return 0;
   // :107-122 find the first position whose k-mer is present (N resets the window)
-  int it = 0, left = k;
+  int it = 0;
   uint64_t kmer = 0;
-  for (;;) {
-    if (left == 0 && tab.has(kmer)) break;
-    if (it == len) return 0;
-    if (read_isn(nmask, it)) { ++it; left = k; continue; }
-    kmer = kmer_shift(kmer, k, read_code(words, it));
-    ++it;
-    if (left) --left;
+  if (present) {  // = the lowest set presence bit
+    int nwin = len - k + 1, j = -1;
+    for (int w = 0; w * 64 < nwin && j < 0; ++w) {
+      uint64_t bits = present[w];
+      if (bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        j = w * 64 + (__ffsll((long long)bits) - 1);
+#else
+        j = w * 64 + __builtin_ctzll(bits);
+#endif
+      }
+    }
+    if (j < 0 || j >= nwin) return 0;
+    it = j + k;
+    kmer = window32(words, W, j) >> (64 - 2 * k);
+  } else {
+    int left = k;
+    for (;;) {
+      if (left == 0 && tab.has(kmer)) break;
+      if (it == len) return 0;
+      if (read_isn(nmask, it)) { ++it; left = k; continue; }
+      kmer = kmer_shift(kmer, k, read_code(words, it));
+      ++it;
+      if (left) --left;
+    }
   }
   int kmer_start = it - k;
   FrcRes lres, rres;
@@ -260,13 +293,13 @@ BG_HD int frc_correct_read(const Table& tab, const uint64_t* words, const uint32
   rres.len = 0; rres.ncorr = 0;
   int maxc = max_corrections;
   if (kmer_start > 0) {  // :134-167 correct the left part on the reverse complement
-    ReadView lv{words, nmask, kmer_start - 1, -1, kmer_start};
+    ReadView lv{words, nmask, kmer_start - 1, -1, kmer_start, k, present};
     frc_solve(tab, lv, 0, kmer_revcomp(kmer, k), k, 0, min_good_run, maxc, false, &lres);
     if (lres.len != kmer_start) return 0;
     maxc -= lres.ncorr;
   }
   if (it != len) {  // :169-172
-    ReadView rv{words, nmask, it, +1, len - it};
+    ReadView rv{words, nmask, it, +1, len - it, k, present};
     frc_solve(tab, rv, 0, kmer, k, 0, min_good_run, maxc, true, &rres);
   }
   int clen = kmer_start + k + rres.len;

@@ -111,6 +111,10 @@ constexpr int RS_LOW_ENTROPY = 1;
 int radix_sort_u64(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                    uint64_t n, int bit_lo, int bit_hi, bool* in_b, int flags = 0);
 
+// Stable partition of keys into 65536 buckets by the top 16 bits of key * kPartitionMult.
+constexpr uint64_t kPartitionMult = 0x9E3779B97F4A7C15ull;
+int radix_partition_hash16(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, bool* in_b);
+
 // ---- device-side object layouts
 }  // namespace bg
 
@@ -129,7 +133,8 @@ struct bg_kmerset {
   bg_ctx* ctx = nullptr;
   int k = 0;
   uint64_t size = 0, distinct = 0, instances = 0;
-  bg::DevBuf<uint64_t> kmers;    // sorted canonical kept k-mers
+  bool sorted = true;            // kmers ascending (the LDS counting path leaves them unordered)
+  bg::DevBuf<uint64_t> kmers;    // canonical kept k-mers
   bg::DevBuf<uint32_t> counts;   // total count per kept k-mer
   bg::DevBuf<uint64_t> slots;    // hash table (1 << log2cap)
   int log2cap = 0;
@@ -165,6 +170,8 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
                               bg_seqset* ss, uint64_t* n_tied_out);
 int alloc_prev_bits(bg_ctx* ctx, bg_seqset* ss);
 int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss);
+int apply_tails_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint32_t* d_err);
+int kmerset_sort(bg_ctx* ctx, bg_kmerset* ks);
 // spiral_zip.cpp
 struct ZipPart { std::string name; std::string data; bool raw_crc0; };
 int spiral_zip_write(const char* path, const std::vector<ZipPart>& parts);

@@ -8,6 +8,10 @@
 #include "bg_internal.h"
 #include "compact.h"
 
+#include <stdlib.h>
+
+#include <vector>
+
 namespace bg {
 
 // ------------------------------------------------------------------------------------------------
@@ -209,6 +213,89 @@ __global__ void k_gather_flags(const uint64_t* __restrict__ kmers, uint64_t n, c
   flags[i] = f;
 }
 
+// ---- counting by hash partition + LDS tables (the default path) ---------------------------------
+// After radix_partition_hash16 all instances of a k-mer sit in one of 65536 buckets (avg N/65536
+// instances, a few thousand distinct keys).  One workgroup streams a bucket once from HBM and counts it
+// in an LDS open-addressing table (64-bit CAS + 32-bit add); keys seen >= min_count times leave through
+// one global cursor.  A bucket whose distinct keys do not fit sets its overflow flag and is recounted
+// by the sort-based path.  Role of kmer_count_table<uint8_t>::increment (kmer_count_table.h:54-103).
+
+__global__ void k_bucket_bounds(const uint64_t* __restrict__ keys, uint64_t n, uint64_t* __restrict__ bounds) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;  // 0..65536
+  if (b > 65536u) return;
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {  // first position whose hash prefix is >= b
+    uint64_t mid = (lo + hi) >> 1;
+    if (((keys[mid] * kPartitionMult) >> 48) < uint64_t(b)) lo = mid + 1; else hi = mid;
+  }
+  bounds[b] = lo;
+}
+
+constexpr int KC_THREADS = 512;
+
+__global__ __launch_bounds__(KC_THREADS) void k_kmer_count_lds(const uint64_t* __restrict__ keys,
+                                                               const uint64_t* __restrict__ bounds, int log2cap,
+                                                               uint32_t min_count, uint64_t out_cap,
+                                                               uint64_t* __restrict__ out_kmers,
+                                                               uint32_t* __restrict__ out_counts,
+                                                               unsigned long long* __restrict__ out_n,
+                                                               unsigned long long* __restrict__ distinct_total,
+                                                               uint8_t* __restrict__ overflow) {
+  extern __shared__ __align__(16) unsigned char kc_smem[];
+  const uint32_t cap = 1u << log2cap;
+  unsigned long long* tkeys = reinterpret_cast<unsigned long long*>(kc_smem);
+  uint32_t* tcnt = reinterpret_cast<uint32_t*>(kc_smem + size_t(cap) * 8);
+  __shared__ uint32_t s_over, s_kept, s_distinct, s_cursor;
+  __shared__ unsigned long long s_base;
+  const uint32_t bucket = blockIdx.x;
+  const uint64_t lo = bounds[bucket], hi = bounds[bucket + 1];
+  if (lo == hi) return;  // block-uniform
+  for (uint32_t i = threadIdx.x; i < cap; i += KC_THREADS) { tkeys[i] = ~0ull; tcnt[i] = 0; }
+  if (threadIdx.x == 0) { s_over = 0; s_kept = 0; s_distinct = 0; s_cursor = 0; }
+  __syncthreads();
+  const uint32_t mask = cap - 1;
+  const uint32_t max_probe = cap < 256u ? cap : 256u;
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += KC_THREADS) {
+    unsigned long long k = keys[i];
+    if (k == ~0ull) continue;  // window held an N (kmer_counter.h:306-311)
+    uint32_t slot = uint32_t((k * kPartitionMult) >> (48 - log2cap)) & mask;  // hash bits below the bucket's
+    uint32_t probes = 0;
+    for (;;) {
+      unsigned long long old = atomicCAS(&tkeys[slot], ~0ull, k);
+      if (old == ~0ull || old == k) { atomicAdd(&tcnt[slot], 1u); break; }
+      slot = (slot + 1) & mask;
+      if (++probes >= max_probe) { s_over = 1; break; }
+    }
+  }
+  __syncthreads();
+  if (s_over) {
+    if (threadIdx.x == 0) overflow[bucket] = 1;
+    return;
+  }
+  uint32_t my_kept = 0, my_distinct = 0;
+  for (uint32_t i = threadIdx.x; i < cap; i += KC_THREADS) {
+    if (tkeys[i] != ~0ull) {
+      ++my_distinct;
+      if (tcnt[i] >= min_count) ++my_kept;
+    }
+  }
+  if (my_distinct) atomicAdd(&s_distinct, my_distinct);
+  if (my_kept) atomicAdd(&s_kept, my_kept);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_base = s_kept ? atomicAdd(out_n, (unsigned long long)s_kept) : 0ull;
+    if (s_distinct) atomicAdd(distinct_total, (unsigned long long)s_distinct);
+  }
+  __syncthreads();
+  if (!s_kept) return;
+  for (uint32_t i = threadIdx.x; i < cap; i += KC_THREADS) {
+    if (tkeys[i] != ~0ull && tcnt[i] >= min_count) {
+      uint64_t o = s_base + atomicAdd(&s_cursor, 1u);
+      if (o < out_cap) { out_kmers[o] = tkeys[i]; out_counts[o] = tcnt[i]; }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // S3: correction.  Screen (wave per read, all windows looked up in parallel), then DFS for the
 // reads that need it.
@@ -219,7 +306,8 @@ __global__ __launch_bounds__(256) void k_correct_screen(const uint64_t* __restri
                                                         const uint64_t* __restrict__ slots, int log2cap,
                                                         uint64_t* __restrict__ out_words,
                                                         uint16_t* __restrict__ out_len,
-                                                        uint8_t* __restrict__ need_dfs) {
+                                                        uint8_t* __restrict__ need_dfs,
+                                                        uint64_t* __restrict__ present) {
   const int lane = threadIdx.x & 63;
   uint64_t i = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
@@ -246,6 +334,8 @@ __global__ __launch_bounds__(256) void k_correct_screen(const uint64_t* __restri
       uint32_t nm = r ? ((n0 << r) | (n1 >> (32 - r))) : n0;
       ok = ((nm >> (32 - k)) == 0) && tab.has(x >> (64 - 2 * k));
     }
+    uint64_t bal = __ballot(ok && j < nk);
+    if (lane == 0) present[i * 4 + (j0 >> 6)] = bal;  // presence bits of the unmodified windows
     if (!__all(ok)) all_ok = false;
   }
   if (all_ok) {  // nothing to correct: output == input
@@ -268,7 +358,8 @@ __global__ __launch_bounds__(64) void k_correct_dfs(const uint64_t* __restrict__
                                                     int max_corrections, int min_good_run,
                                                     const uint16_t* __restrict__ needed_by_len,
                                                     uint64_t* __restrict__ out_words, uint16_t* __restrict__ out_len,
-                                                    CorrectCounters* __restrict__ ctr) {
+                                                    CorrectCounters* __restrict__ ctr,
+                                                    const uint64_t* __restrict__ present) {
   uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= nlist) return;
   uint64_t i = list[t];
@@ -277,7 +368,7 @@ __global__ __launch_bounds__(64) void k_correct_dfs(const uint64_t* __restrict__
   uint64_t ow[kMaxWords];
   int ncorr = 0;
   int clen = frc_correct_read(tab, words + i * W, nmask + i * W, L, W, k, max_corrections, min_good_run,
-                              int(needed_by_len[L]), ow, &ncorr);
+                              int(needed_by_len[L]), ow, &ncorr, present + i * 4);
   for (int w = 0; w < W; ++w) out_words[i * W + w] = clen ? ow[w] : 0;
   out_len[i] = uint16_t(clen);
   if (clen && ncorr) {
@@ -492,9 +583,11 @@ int kmer_extract_impl(bg_ctx* ctx, const bg_reads* reads, int k, const uint64_t*
   return BG_OK;
 }
 
-// sort the instances (ka = data, kb = scratch, both N) and keep canonical k-mers seen >= min_count
-// times: fills ks->kmers / counts / size / distinct.
-int kmer_count_keys_impl(bg_ctx* ctx, uint64_t* ka, uint64_t* kb, uint64_t N, uint32_t min_count, bg_kmerset* ks) {
+// Sort-based counting (fallback for buckets whose distinct keys overflow the LDS table, and the
+// reference point of the tests): full radix sort of the instances (ka = data, kb = scratch) + run
+// lengths; keeps canonical k-mers seen >= min_count times: fills ks->kmers / counts / size / distinct.
+int kmer_count_keys_sort_impl(bg_ctx* ctx, uint64_t* ka, uint64_t* kb, uint64_t N, uint32_t min_count,
+                              bg_kmerset* ks) {
   uint64_t nkept = 0, nheads = 0;
   ks->distinct = 0;
   if (N) {
@@ -537,6 +630,126 @@ int kmer_count_keys_impl(bg_ctx* ctx, uint64_t* ka, uint64_t* kb, uint64_t N, ui
     BG_TRY(ks->counts.alloc(ctx, 0));
   }
   ks->size = nkept;
+  return BG_OK;
+}
+
+static int kmer_lds_log2cap() {
+  // BG_KMER_LDS_LOG2CAP shrinks the table (tests force the overflow path with it)
+  const char* e = getenv("BG_KMER_LDS_LOG2CAP");
+  int v = e ? atoi(e) : 12;
+  return v < 1 ? 1 : (v > 13 ? 13 : v);
+}
+
+// Default counting path: hash partition (2 radix passes on 16 hash bits) + one LDS counting pass.
+// ka = instances (clobbered), kb = scratch, both N.  Output k-mers are sorted ascending.
+int kmer_count_keys_impl(bg_ctx* ctx, uint64_t* ka, uint64_t* kb, uint64_t N, uint32_t min_count, bg_kmerset* ks) {
+  ks->distinct = 0;
+  ks->size = 0;
+  if (!N) {
+    BG_TRY(ks->kmers.alloc(ctx, 0));
+    BG_TRY(ks->counts.alloc(ctx, 0));
+    return BG_OK;
+  }
+  bool in_b = false;
+  BG_TRY(radix_partition_hash16(ctx, ka, kb, N, &in_b));
+  uint64_t* part = in_b ? kb : ka;
+  uint64_t* scratch = in_b ? ka : kb;
+  const uint32_t NB = 65536;
+  DevBuf<uint64_t> bounds;
+  DevBuf<uint8_t> overflow;
+  DevBuf<unsigned long long> ctr;  // [0] kept cursor, [1] distinct
+  BG_TRY(bounds.alloc(ctx, NB + 1));
+  BG_TRY(overflow.alloc(ctx, NB));
+  BG_TRY(ctr.alloc(ctx, 2));
+  BG_HIP(hipMemsetAsync(overflow.p, 0, NB, ctx->stream));
+  BG_HIP(hipMemsetAsync(ctr.p, 0, 16, ctx->stream));
+  const uint64_t out_cap = N / min_count + 1;
+  DevBuf<uint64_t> ok_a, ok_b;
+  DevBuf<uint32_t> oc_a, oc_b;
+  BG_TRY(ok_a.alloc(ctx, out_cap));
+  BG_TRY(oc_a.alloc(ctx, out_cap));
+  ctx->tic("kmer_count_lds");
+  k_bucket_bounds<<<cdiv(NB + 1, 256), 256, 0, ctx->stream>>>(part, N, bounds.p);
+  BG_LAUNCH_CHECK();
+  const int lg = kmer_lds_log2cap();
+  const size_t smem = (size_t(1) << lg) * 12;
+  BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_kmer_count_lds),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
+  k_kmer_count_lds<<<NB, KC_THREADS, smem, ctx->stream>>>(part, bounds.p, lg, min_count, out_cap, ok_a.p, oc_a.p,
+                                                          ctr.p, ctr.p + 1, overflow.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(N * 8);
+  unsigned long long h_ctr[2] = {0, 0};
+  std::vector<uint8_t> h_over(NB);
+  std::vector<uint64_t> h_bounds(NB + 1);
+  BG_HIP(hipMemcpyAsync(h_ctr, ctr.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipMemcpyAsync(h_over.data(), overflow.p, NB, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  uint64_t nkept = h_ctr[0], distinct = h_ctr[1];
+  // overflowed buckets: recount them together with the sort-based path
+  uint64_t n_over = 0;
+  for (uint32_t b = 0; b < NB; ++b) n_over += h_over[b];
+  if (n_over) {
+    BG_HIP(hipMemcpyAsync(h_bounds.data(), bounds.p, (NB + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    uint64_t tot = 0;
+    for (uint32_t b = 0; b < NB; ++b)
+      if (h_over[b]) tot += h_bounds[b + 1] - h_bounds[b];
+    DevBuf<uint64_t> ta, tb;
+    BG_TRY(ta.alloc(ctx, tot));
+    BG_TRY(tb.alloc(ctx, tot));
+    uint64_t pos = 0;
+    for (uint32_t b = 0; b < NB; ++b) {
+      if (!h_over[b]) continue;
+      uint64_t len = h_bounds[b + 1] - h_bounds[b];
+      BG_HIP(hipMemcpyAsync(ta.p + pos, part + h_bounds[b], len * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      pos += len;
+    }
+    bg_kmerset tmp;
+    tmp.ctx = ctx;
+    tmp.k = ks->k;
+    BG_TRY(kmer_count_keys_sort_impl(ctx, ta.p, tb.p, tot, min_count, &tmp));
+    if (nkept + tmp.size > out_cap) { set_error("k-mer output overflow (internal error)"); return BG_EINTERNAL; }
+    if (tmp.size) {
+      BG_HIP(hipMemcpyAsync(ok_a.p + nkept, tmp.kmers.p, tmp.size * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      BG_HIP(hipMemcpyAsync(oc_a.p + nkept, tmp.counts.p, tmp.size * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    nkept += tmp.size;
+    distinct += tmp.distinct;
+  }
+  (void)scratch;
+  if (nkept > out_cap) { set_error("k-mer output overflow (internal error)"); return BG_EINTERNAL; }
+  // blocks finish in any order: the set is exact but unordered; kmerset_sort() orders it when a caller
+  // wants the sorted view (download), the build itself only needs the hash set.
+  BG_TRY(ks->kmers.alloc(ctx, nkept));
+  BG_TRY(ks->counts.alloc(ctx, nkept));
+  if (nkept) {
+    BG_HIP(hipMemcpyAsync(ks->kmers.p, ok_a.p, nkept * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    BG_HIP(hipMemcpyAsync(ks->counts.p, oc_a.p, nkept * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  ks->size = nkept;
+  ks->distinct = distinct;
+  ks->sorted = false;
+  return BG_OK;
+}
+
+// ascending k-mers (+ their counts)
+int kmerset_sort(bg_ctx* ctx, bg_kmerset* ks) {
+  if (ks->sorted || ks->size < 2) { ks->sorted = true; return BG_OK; }
+  DevBuf<uint64_t> kb;
+  DevBuf<uint32_t> cb;
+  BG_TRY(kb.alloc(ctx, ks->size));
+  BG_TRY(cb.alloc(ctx, ks->size));
+  bool sb = false;
+  BG_TRY(radix_sort_u64(ctx, ks->kmers.p, kb.p, ks->counts.p, cb.p, ks->size, 0, 64, &sb));
+  if (sb) {
+    BG_HIP(hipMemcpyAsync(ks->kmers.p, kb.p, ks->size * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    BG_HIP(hipMemcpyAsync(ks->counts.p, cb.p, ks->size * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  ks->sorted = true;
   return BG_OK;
 }
 
@@ -670,6 +883,7 @@ extern "C" int bg_kmerset_download(bg_ctx* ctx, const bg_kmerset* ks, uint64_t* 
   BG_HIP(hipSetDevice(ctx->device));
   uint64_t n = ks->size;
   if (!n) return BG_OK;
+  BG_TRY(kmerset_sort(ctx, const_cast<bg_kmerset*>(ks)));
   if (h_kmers) BG_HIP(hipMemcpyAsync(h_kmers, ks->kmers.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (h_counts) BG_HIP(hipMemcpyAsync(h_counts, ks->counts.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (h_flags) {
@@ -714,7 +928,9 @@ extern "C" int bg_correct_reads(bg_ctx* ctx, const bg_reads* reads, const bg_kme
   BG_HIP(hipMemcpyAsync(d_needed.p, needed, sizeof needed, hipMemcpyHostToDevice, ctx->stream));
 
   DevBuf<uint8_t> need;
+  DevBuf<uint64_t> present;  // 4 x 64 window bits per read (reads are <= 255 bases)
   BG_TRY(need.alloc(ctx, n));
+  BG_TRY(present.alloc(ctx, n * 4));
   DevBuf<CorrectCounters> ctr;
   DevBuf<CorrectTotals> tot;
   BG_TRY(ctr.alloc(ctx, 1));
@@ -725,7 +941,8 @@ extern "C" int bg_correct_reads(bg_ctx* ctx, const bg_reads* reads, const bg_kme
   if (n) {
     ctx->tic("correct_screen");
     k_correct_screen<<<cdiv(n, 4), 256, 0, ctx->stream>>>(reads->words.p, reads->nmask.p, reads->len.p, n, W, k,
-                                                          ks->slots.p, ks->log2cap, r->words.p, r->len.p, need.p);
+                                                          ks->slots.p, ks->log2cap, r->words.p, r->len.p, need.p,
+                                                          present.p);
     BG_LAUNCH_CHECK();
     ctx->toc(n * W * 20 + ks->instances * 8);
     DevBuf<uint64_t> list;
@@ -734,7 +951,8 @@ extern "C" int bg_correct_reads(bg_ctx* ctx, const bg_reads* reads, const bg_kme
       ctx->tic("correct_dfs");
       k_correct_dfs<<<cdiv(nlist, 64), 64, 0, ctx->stream>>>(
           reads->words.p, reads->nmask.p, reads->len.p, list.p, nlist, W, k, ks->slots.p, ks->log2cap,
-          int(params->max_corrections), int(params->min_good_run), d_needed.p, r->words.p, r->len.p, ctr.p);
+          int(params->max_corrections), int(params->min_good_run), d_needed.p, r->words.p, r->len.p, ctr.p,
+          present.p);
       BG_LAUNCH_CHECK();
       ctx->toc(nlist * W * 20);
     }

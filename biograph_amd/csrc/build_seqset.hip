@@ -276,14 +276,40 @@ __global__ void k_build_entries(const uint64_t* __restrict__ skeys, const uint8_
   for (int w = 0; w < W; ++w) ekeys[e * W + w] = skeys[uint64_t(p) * W + w];
 }
 
+// Directory over the leading kPrefixBases bases of the sorted entries: dir[p] = first entry whose
+// (zero padded) leading bases are >= p, dir[4^kPrefixBases] = n.  Narrows every lower_bound below to
+// the handful of entries sharing the query's prefix.
+constexpr int kPrefixBases = 12;
+__global__ void k_prefix_dir(const uint64_t* __restrict__ ekeys, uint64_t n, int W, uint32_t* __restrict__ dir) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  const uint32_t nb = 1u << (2 * kPrefixBases);
+  uint32_t cur = i < n ? uint32_t(ekeys[i * W] >> (64 - 2 * kPrefixBases)) : nb;
+  uint32_t prev = i ? uint32_t(ekeys[(i - 1) * W] >> (64 - 2 * kPrefixBases)) + 1 : 0u;
+  for (uint32_t p = prev; p <= cur; ++p) dir[p] = uint32_t(i);  // empty range when cur < prev
+}
+
+// lower_bound of (tail, tl) in the entries, searched inside its prefix bucket only
+__device__ __forceinline__ uint64_t entries_lower_bound(const uint64_t* __restrict__ ekeys,
+                                                        const uint8_t* __restrict__ sizes, uint64_t n, int W,
+                                                        const uint32_t* __restrict__ dir, const uint64_t* tail,
+                                                        int tl) {
+  uint32_t p = uint32_t(tail[0] >> (64 - 2 * kPrefixBases));
+  uint64_t lo = dir[p], hi = dir[p + 1];
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) >> 1;
+    if (key_compare(ekeys + mid * W, sizes[mid], tail, tl, W) < 0) lo = mid + 1; else hi = mid;
+  }
+  (void)n;
+  return lo;
+}
+
 // prev bits (builder.cpp:85-108, closed form of SURVEY row F1): entry s sets
 // prev_{s[0]}[lower_bound(entries, s[1:])]; the target must extend s[1:] ("Missing expansion?").
 __global__ __launch_bounds__(256) void k_prev_bits(const uint64_t* __restrict__ ekeys,
                                                    const uint8_t* __restrict__ sizes, uint64_t n, int W,
-                                                   unsigned long long* __restrict__ bA,
-                                                   unsigned long long* __restrict__ bC,
-                                                   unsigned long long* __restrict__ bG,
-                                                   unsigned long long* __restrict__ bT, uint32_t* __restrict__ err) {
+                                                   const uint32_t* __restrict__ dir, uint8_t* __restrict__ marks,
+                                                   uint32_t* __restrict__ err) {
   uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t* s = ekeys + i * W;
@@ -291,18 +317,49 @@ __global__ __launch_bounds__(256) void k_prev_bits(const uint64_t* __restrict__ 
   int tl = int(sizes[i]) - 1;
   uint64_t tail[kMaxWords];
   for (int w = 0; w < W; ++w) tail[w] = window32(s, W, 1 + 32 * w);
-  uint64_t lo = 0, hi = n;
-  while (lo < hi) {
-    uint64_t mid = (lo + hi) >> 1;
-    if (key_compare(ekeys + mid * W, sizes[mid], tail, tl, W) < 0) lo = mid + 1;
-    else hi = mid;
-  }
+  uint64_t lo = entries_lower_bound(ekeys, sizes, n, W, dir, tail, tl);
   if (lo >= n || key_lcp(ekeys + lo * W, sizes[lo], tail, tl, W) < tl) {
     atomicOr(err, 2u);
     return;
   }
-  unsigned long long* bits = b == 0 ? bA : b == 1 ? bC : b == 2 ? bG : bT;
-  atomicOr(&bits[lo >> 6], 1ull << (lo & 63));
+  // one byte per (base, target): neighbouring entries hit neighbouring targets, so a shared 64-bit word
+  // would serialise 64 same-address atomics per wave; bytes are plain coalesced stores, packed below
+  marks[uint64_t(b) * n + lo] = 1;
+}
+
+// marks[b*n + t] -> bit t of prev_b (OR-ed into the existing words)
+__global__ __launch_bounds__(256) void k_pack_marks(const uint8_t* __restrict__ marks, uint64_t n,
+                                                    unsigned long long* __restrict__ bA,
+                                                    unsigned long long* __restrict__ bC,
+                                                    unsigned long long* __restrict__ bG,
+                                                    unsigned long long* __restrict__ bT) {
+  const uint64_t nwords = (n + 63) / 64;
+  uint64_t g = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);  // one wave per output word
+  if (g >= 4 * nwords) return;
+  int b = int(g / nwords);
+  uint64_t w = g - uint64_t(b) * nwords;
+  uint64_t t = w * 64 + (threadIdx.x & 63);
+  bool bit = t < n && marks[uint64_t(b) * n + t] != 0;
+  uint64_t word = __ballot(bit);
+  if ((threadIdx.x & 63) == 0 && word) {
+    unsigned long long* bits = b == 0 ? bA : b == 1 ? bC : b == 2 ? bG : bT;
+    bits[w] |= word;
+  }
+}
+
+// tails received from other shards (rows of W+1 words: s[1:], (len-1) | base << 8) -> prev bits
+__global__ __launch_bounds__(256) void k_apply_tails(const uint64_t* __restrict__ rows, uint64_t nt,
+                                                     const uint64_t* __restrict__ ekeys,
+                                                     const uint8_t* __restrict__ sizes, uint64_t n, int W,
+                                                     const uint32_t* __restrict__ dir, uint8_t* __restrict__ marks,
+                                                     uint32_t* __restrict__ err) {
+  uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= nt) return;
+  const uint64_t* tail = rows + t * (W + 1);
+  int tl = int(tail[W] & 0xff), b = int((tail[W] >> 8) & 3);
+  uint64_t lo = entries_lower_bound(ekeys, sizes, n, W, dir, tail, tl);
+  if (lo >= n || key_lcp(ekeys + lo * W, sizes[lo], tail, tl, W) < tl) { atomicOr(err, 2u); return; }
+  marks[uint64_t(b) * n + lo] = 1;
 }
 
 // bitcount::finalize (io/bitcount.cpp:84-124): one thread per 512-bit group.
@@ -658,6 +715,41 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
   return BG_OK;
 }
 
+// leading-bases directory of a shard's entries (needs resident keys)
+int build_prefix_dir(bg_ctx* ctx, const bg_seqset* ss, DevBuf<uint32_t>* dir) {
+  const uint64_t nb = 1ull << (2 * kPrefixBases);
+  BG_TRY(dir->alloc(ctx, nb + 1));
+  if (ss->n >= (1ull << 32)) { set_error("shard of %llu entries exceeds the prefix directory", (unsigned long long)ss->n); return BG_EINVAL; }
+  k_prefix_dir<<<cdiv(ss->n + 1, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->n, ss->W, dir->p);
+  BG_LAUNCH_CHECK();
+  return BG_OK;
+}
+
+static int pack_marks(bg_ctx* ctx, bg_seqset* ss, const uint8_t* marks) {
+  const uint64_t nwords = (ss->n + 63) / 64;
+  if (!nwords) return BG_OK;
+  k_pack_marks<<<cdiv(4 * nwords, 4), 256, 0, ctx->stream>>>(
+      marks, ss->n, reinterpret_cast<unsigned long long*>(ss->bits[0].p),
+      reinterpret_cast<unsigned long long*>(ss->bits[1].p), reinterpret_cast<unsigned long long*>(ss->bits[2].p),
+      reinterpret_cast<unsigned long long*>(ss->bits[3].p));
+  BG_LAUNCH_CHECK();
+  return BG_OK;
+}
+
+int apply_tails_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint32_t* d_err) {
+  DevBuf<uint32_t> dir;
+  DevBuf<uint8_t> marks;
+  BG_TRY(build_prefix_dir(ctx, ss, &dir));
+  BG_TRY(marks.alloc(ctx, 4 * ss->n));
+  if (ss->n) BG_HIP(hipMemsetAsync(marks.p, 0, 4 * ss->n, ctx->stream));
+  k_apply_tails<<<cdiv(n_rows, 256), 256, 0, ctx->stream>>>(d_rows, n_rows, ss->keys.p, ss->sizes.p, ss->n, ss->W, dir.p,
+                                                            marks.p, d_err);
+  BG_LAUNCH_CHECK();
+  BG_TRY(pack_marks(ctx, ss, marks.p));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
 int alloc_prev_bits(bg_ctx* ctx, bg_seqset* ss) {
   const uint64_t nwords = (ss->n + 63) / 64;
   for (int b = 0; b < 4; ++b) {
@@ -674,13 +766,16 @@ int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss) {
   DevBuf<uint32_t> err;
   BG_TRY(err.alloc(ctx, 2));
   BG_HIP(hipMemsetAsync(err.p, 0, 8, ctx->stream));
+  DevBuf<uint32_t> dir;
+  DevBuf<uint8_t> marks;
   if (n_ent) {
     ctx->tic("prev_bits");
-    k_prev_bits<<<cdiv(n_ent, 256), 256, 0, ctx->stream>>>(
-        ss->keys.p, ss->sizes.p, n_ent, ss->W, reinterpret_cast<unsigned long long*>(ss->bits[0].p),
-        reinterpret_cast<unsigned long long*>(ss->bits[1].p), reinterpret_cast<unsigned long long*>(ss->bits[2].p),
-        reinterpret_cast<unsigned long long*>(ss->bits[3].p), err.p);
+    BG_TRY(build_prefix_dir(ctx, ss, &dir));
+    BG_TRY(marks.alloc(ctx, 4 * n_ent));
+    BG_HIP(hipMemsetAsync(marks.p, 0, 4 * n_ent, ctx->stream));
+    k_prev_bits<<<cdiv(n_ent, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->sizes.p, n_ent, ss->W, dir.p, marks.p, err.p);
     BG_LAUNCH_CHECK();
+    BG_TRY(pack_marks(ctx, ss, marks.p));
     ctx->toc(n_ent * (ss->W * 8 + 1 + 8));
   }
   uint32_t h_err[2] = {0, 0};

@@ -345,6 +345,14 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
   return m;
 }
 
+// digit of a key; HASHED sorts on the bits of key * kPartitionMult instead (hash partitioning)
+template <bool HASHED>
+__device__ __forceinline__ uint32_t rs_digit(uint64_t key, int shift, uint32_t dmask) {
+  if (HASHED) key *= kPartitionMult;
+  return uint32_t(key >> shift) & dmask;
+}
+
+template <bool HASHED>
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift,
                                                              uint32_t dmask, uint32_t* __restrict__ hist,
                                                              uint32_t ntiles) {
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t* __r
 #pragma unroll 4
   for (int it = 0; it < RS_ITEMS; ++it) {
     uint64_t idx = base + uint64_t(it) * RS_THREADS + threadIdx.x;
-    if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & dmask], 1u);
+    if (idx < n) atomicAdd(&h[rs_digit<HASHED>(keys[idx], shift, dmask)], 1u);
   }
   __syncthreads();
   hist[uint64_t(threadIdx.x) * ntiles + blockIdx.x] = h[threadIdx.x];
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_agg_kernel(const uint64_t*
 }
 
 
-template <class OffT, bool HAS_VAL>
+template <class OffT, bool HAS_VAL, bool HASHED>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t* __restrict__ kin,
                                                                 const uint32_t* __restrict__ vin,
                                                                 uint64_t* __restrict__ kout,
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t* 
     bool valid = idx < n;
     key[it] = valid ? kin[idx] : ~0ull;
     if (HAS_VAL) val[it] = valid ? vin[idx] : 0u;
-    uint32_t d = uint32_t(key[it] >> shift) & dmask;
+    uint32_t d = rs_digit<HASHED>(key[it], shift, dmask);
     uint64_t m = match_digit(d, valid);
     uint32_t before = wh[d];
     uint32_t lt = __popcll(m & lane_lt);
@@ -449,7 +457,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t* 
   for (int it = 0; it < RS_ITEMS; ++it) {
     uint64_t idx = base + uint64_t(w) * (RS_ITEMS * 64) + uint64_t(it) * 64 + lane;
     if (idx < n) {
-      uint32_t d = uint32_t(key[it] >> shift) & dmask;
+      uint32_t d = rs_digit<HASHED>(key[it], shift, dmask);
       uint32_t pos = binstart[d] + whist[w][d] + rnk[it];
       skeys[pos] = key[it];
       if (HAS_VAL) svals[pos] = val[it];
@@ -461,7 +469,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t* 
   uint32_t cnt = (n - base) < uint64_t(RS_TILE) ? uint32_t(n - base) : uint32_t(RS_TILE);
   for (uint32_t i = tid; i < cnt; i += RS_THREADS) {
     uint64_t k = skeys[i];
-    uint32_t d = uint32_t(k >> shift) & dmask;
+    uint32_t d = rs_digit<HASHED>(k, shift, dmask);
     OffT o = goff[d] + OffT(i);
     kout[o] = k;
     if (HAS_VAL) vout[o] = svals[i];
@@ -522,7 +530,8 @@ static int radix_sort_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint
       rs_hist_agg_kernel<<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(kin, n, shift, dmask, hist.p,
                                                                            uint32_t(ntiles));
     else
-      rs_hist_kernel<<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(kin, n, shift, dmask, hist.p, uint32_t(ntiles));
+      rs_hist_kernel<false><<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(kin, n, shift, dmask, hist.p,
+                                                                              uint32_t(ntiles));
     BG_LAUNCH_CHECK();
     ctx->toc(n * 8);
     ctx->tic("radix_scan");
@@ -530,10 +539,10 @@ static int radix_sort_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint
     ctx->toc(uint64_t(RS_BINS) * ntiles * (4 + sizeof(OffT)));
     ctx->tic(has_val ? "radix_scatter_kv" : "radix_scatter_k");
     if (has_val)
-      rs_scatter_kernel<OffT, true><<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(kin, vin, kout, vout, n, shift,
+      rs_scatter_kernel<OffT, true, false><<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(kin, vin, kout, vout, n, shift,
                                                                                       dmask, offs.p, uint32_t(ntiles));
     else
-      rs_scatter_kernel<OffT, false><<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(
+      rs_scatter_kernel<OffT, false, false><<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(
           kin, nullptr, kout, nullptr, n, shift, dmask, offs.p, uint32_t(ntiles));
     BG_LAUNCH_CHECK();
     ctx->toc(n * (has_val ? 24 : 16));
@@ -550,6 +559,44 @@ int radix_sort_u64(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* va
   if (n < (1ull << 32))
     return radix_sort_impl<uint32_t>(ctx, keys_a, keys_b, vals_a, vals_b, n, bit_lo, bit_hi, in_b, flags);
   return radix_sort_impl<uint64_t>(ctx, keys_a, keys_b, vals_a, vals_b, n, bit_lo, bit_hi, in_b, flags);
+}
+
+// Groups equal keys' neighbourhoods: stable partition of the keys into 65536 buckets by the top 16 bits
+// of key * kPartitionMult (two 8-bit passes, least significant byte first).  Equal keys land in the
+// same bucket; bucket b = keys whose hash prefix is b, buckets ascending.
+template <class OffT>
+static int radix_partition_hash16_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, bool* in_b) {
+  *in_b = false;
+  if (n <= 1) return BG_OK;
+  const uint64_t ntiles = (n + RS_TILE - 1) / RS_TILE;
+  DevBuf<uint32_t> hist;
+  DevBuf<OffT> offs;
+  BG_TRY(hist.alloc(ctx, size_t(RS_BINS) * ntiles));
+  BG_TRY(offs.alloc(ctx, size_t(RS_BINS) * ntiles));
+  uint64_t* kin = keys_a;
+  uint64_t* kout = keys_b;
+  for (int shift = 48; shift < 64; shift += 8) {
+    ctx->tic("radix_hist");
+    rs_hist_kernel<true><<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(kin, n, shift, 0xffu, hist.p, uint32_t(ntiles));
+    BG_LAUNCH_CHECK();
+    ctx->toc(n * 8);
+    ctx->tic("radix_scan");
+    BG_TRY(exclusive_scan_impl<OffT>(ctx, hist.p, offs.p, uint64_t(RS_BINS) * ntiles, nullptr));
+    ctx->toc(uint64_t(RS_BINS) * ntiles * (4 + sizeof(OffT)));
+    ctx->tic("radix_scatter_k");
+    rs_scatter_kernel<OffT, false, true><<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(
+        kin, nullptr, kout, nullptr, n, shift, 0xffu, offs.p, uint32_t(ntiles));
+    BG_LAUNCH_CHECK();
+    ctx->toc(n * 16);
+    uint64_t* t = kin; kin = kout; kout = t;
+    *in_b = !*in_b;
+  }
+  return BG_OK;
+}
+
+int radix_partition_hash16(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, bool* in_b) {
+  if (n < (1ull << 32)) return radix_partition_hash16_impl<uint32_t>(ctx, keys_a, keys_b, n, in_b);
+  return radix_partition_hash16_impl<uint64_t>(ctx, keys_a, keys_b, n, in_b);
 }
 
 }  // namespace bg

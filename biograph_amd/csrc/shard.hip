@@ -132,28 +132,6 @@ __global__ void k_tail_rows(const uint64_t* __restrict__ ekeys, const uint8_t* _
   r[W] = uint64_t(sizes[i] - 1) | ((s[0] >> 62) << 8);
 }
 
-// received tails -> prev bits of this rank's entries (same search as k_prev_bits)
-__global__ __launch_bounds__(256) void k_apply_tails(const uint64_t* __restrict__ rows, uint64_t nt,
-                                                     const uint64_t* __restrict__ ekeys,
-                                                     const uint8_t* __restrict__ sizes, uint64_t n, int W,
-                                                     unsigned long long* __restrict__ bA,
-                                                     unsigned long long* __restrict__ bC,
-                                                     unsigned long long* __restrict__ bG,
-                                                     unsigned long long* __restrict__ bT, uint32_t* __restrict__ err) {
-  uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= nt) return;
-  const uint64_t* tail = rows + t * (W + 1);
-  int tl = int(tail[W] & 0xff), b = int((tail[W] >> 8) & 3);
-  uint64_t lo = 0, hi = n;
-  while (lo < hi) {
-    uint64_t mid = (lo + hi) >> 1;
-    if (key_compare(ekeys + mid * W, sizes[mid], tail, tl, W) < 0) lo = mid + 1; else hi = mid;
-  }
-  if (lo >= n || key_lcp(ekeys + lo * W, sizes[lo], tail, tl, W) < tl) { atomicOr(err, 2u); return; }
-  unsigned long long* bits = b == 0 ? bA : b == 1 ? bC : b == 2 ? bG : bT;
-  atomicOr(&bits[lo >> 6], 1ull << (lo & 63));
-}
-
 // local bit words of one slice OR-ed into the global bit vector at bit offset `off`
 __global__ void k_place_bits(const uint64_t* __restrict__ local, uint64_t n_local_bits, uint64_t off,
                              unsigned long long* __restrict__ global) {
@@ -433,11 +411,7 @@ extern "C" int bg_seqset_apply_tails(bg_ctx* ctx, bg_seqset* ss, const uint64_t*
   BG_TRY(err.alloc(ctx, 1));
   BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
   ctx->tic("prev_bits");
-  k_apply_tails<<<cdiv(n_rows, 256), 256, 0, ctx->stream>>>(
-      d_rows, n_rows, ss->keys.p, ss->sizes.p, ss->n, ss->W, reinterpret_cast<unsigned long long*>(ss->bits[0].p),
-      reinterpret_cast<unsigned long long*>(ss->bits[1].p), reinterpret_cast<unsigned long long*>(ss->bits[2].p),
-      reinterpret_cast<unsigned long long*>(ss->bits[3].p), err.p);
-  BG_LAUNCH_CHECK();
+  BG_TRY(apply_tails_impl(ctx, ss, d_rows, n_rows, err.p));
   ctx->toc(n_rows * (ss->W * 8 + 1 + 8));
   uint32_t h_err = 0;
   BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -64,7 +64,7 @@ extern "C" {
 // Read correction through frc_correct_read.  out_seq capacity = offs[n].
 int hh_correct_reads(const uint64_t* kmers, uint64_t nk, int k, const char* seq, const uint64_t* offs, uint64_t n,
                      uint32_t max_corrections, uint32_t min_good_run, float trim, char* out_seq, uint64_t* out_offs,
-                     uint8_t* keep, uint64_t* ncorr_total) {
+                     uint8_t* keep, uint64_t* ncorr_total, int use_presence) {
   std::vector<uint64_t> slots;
   int lg;
   build_table(kmers, nk, slots, lg);
@@ -77,8 +77,16 @@ int hh_correct_reads(const uint64_t* kmers, uint64_t nk, int k, const char* seq,
     int ncorr = 0;
     int L = p.len[i];
     int needed = int(unsigned(double(trim) * double(L)));
+    uint64_t present[4] = {0, 0, 0, 0};
+    if (use_presence) {  // what k_correct_screen hands to the DFS kernel
+      for (int j = 0; j + k <= L; ++j) {
+        bool ok = (nwindow32(&p.nmask[i * p.W], p.W, j) >> (32 - k)) == 0 &&
+                  tab.has(window32(&p.words[i * p.W], p.W, j) >> (64 - 2 * k));
+        if (ok) present[j >> 6] |= 1ull << (j & 63);
+      }
+    }
     int clen = frc_correct_read(tab, &p.words[i * p.W], &p.nmask[i * p.W], L, p.W, k, int(max_corrections),
-                                int(min_good_run), needed, ow, &ncorr);
+                                int(min_good_run), needed, ow, &ncorr, use_presence ? present : nullptr);
     keep[i] = clen > 0;
     if (clen > 0) nc += ncorr;
     for (int j = 0; j < clen; ++j) out_seq[pos++] = "ACGT"[read_code(ow, j)];

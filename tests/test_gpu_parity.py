@@ -257,3 +257,22 @@ def test_bgbinary_create_cli_matches_golden(golden_dir, tmp_path):
     r2 = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "create", "--reads",
                          golden_dir + "/e_coli_10000snp/reads.fq", "--out", str(out)], capture_output=True, text=True)
     assert r2.returncode == 1 and "overwrite" in r2.stderr
+
+
+def test_kmer_count_overflow_fallback_path(ctx, monkeypatch):
+    """Buckets whose distinct k-mers do not fit the LDS table are recounted by the sort-based path:
+    force it with a 2-slot table and compare with the oracle (and with the default table)."""
+    import torch  # noqa: F401
+    from biograph_amd import synth
+    seq, offs, n = synth.make_reads(genome_len=150000, coverage=20, read_len=100, seed=3, device="cpu")
+    reads = O.unpack_strings(seq.numpy(), offs.numpy().astype(np.uint64))
+    s, o = O.pack_strings(reads)
+    ok, of, ofw, orv = O.KmerSet.count(s, o, 25, 4).arrays()
+    r = ctx.pack_reads(reads)
+    for lg in ("1", "3", "13"):
+        monkeypatch.setenv("BG_KMER_LDS_LOG2CAP", lg)
+        ks = ctx.kmer_count(r, 25, 4)
+        gk, gf, gc = ks.download()
+        assert len(gk) == len(ok) and (gk == ok).all() and (gf == of).all() and (gc == ofw + orv).all(), lg
+        allk = O.KmerSet.count(s, o, 25, 1, keep_all=True)
+        assert ks.distinct == len(allk)

@@ -7,7 +7,7 @@ from oracle import oracle as O
 from tests import util
 
 
-def _correct_via_harness(reads, k, min_count, maxc=8, mgr=2, trim=0.7):
+def _correct_via_harness(reads, k, min_count, maxc=8, mgr=2, trim=0.7, use_presence=1):
     hh = util.host_harness()
     seq, offs = O.pack_strings(reads)
     ks = O.KmerSet.count(seq, offs, k, min_count)
@@ -17,7 +17,7 @@ def _correct_via_harness(reads, k, min_count, maxc=8, mgr=2, trim=0.7):
     keep = np.zeros(max(len(reads), 1), np.uint8)
     nc = np.zeros(1, np.uint64)
     hh.hh_correct_reads(O._pad(kmers), len(kmers), k, O._pad(seq), offs, len(reads), maxc, mgr, trim, out_seq,
-                        out_offs, keep, nc)
+                        out_offs, keep, nc, use_presence)
     oseq, ooffs, okeep, stats = O.correct_reads(ks, seq, offs, maxc, mgr, trim)
     return (out_seq[:int(out_offs[-1])], out_offs, keep[:len(reads)], int(nc[0])), (oseq, ooffs, okeep, stats)
 
@@ -26,12 +26,13 @@ def _correct_via_harness(reads, k, min_count, maxc=8, mgr=2, trim=0.7):
                                               (4, 12, 0.05, 0.02), (5, 30, 0.02, 0.005)])
 def test_correction_dfs_matches_oracle(seed, k, err, nrate):
     reads = util.synth_reads(seed, genome_len=2000, n_reads=800, read_len=80, err=err, n_rate=nrate, var_len=True)
-    (hs, ho, hk, hn), (os_, oo, ok, st) = _correct_via_harness(reads, k, 3)
-    assert (hk == ok).all()
-    assert (ho == oo).all()
-    assert (hs == os_).all()
-    assert hn == st["modified_bases"]
-    assert st["modified"] > 0  # the case actually exercises substitutions
+    for use_presence in (0, 1):
+        (hs, ho, hk, hn), (os_, oo, ok, st) = _correct_via_harness(reads, k, 3, use_presence=use_presence)
+        assert (hk == ok).all()
+        assert (ho == oo).all()
+        assert (hs == os_).all()
+        assert hn == st["modified_bases"]
+        assert st["modified"] > 0  # the case actually exercises substitutions
 
 
 @pytest.mark.parametrize("maxc,mgr,trim", [(0, 2, 0.7), (1, 1, 0.5), (2, 3, 0.9), (8, 0, 0.0), (4, 2, 1.0)])

@@ -26,7 +26,7 @@ def host_harness():
     L = C.CDLL(out)
     vp = C.c_void_p
     L.hh_correct_reads.argtypes = [u64p, C.c_uint64, C.c_int, u8p, u64p, C.c_uint64, C.c_uint32, C.c_uint32,
-                                   C.c_float, u8p, u64p, u8p, u64p]
+                                   C.c_float, u8p, u64p, u8p, u64p, C.c_int]
     L.hh_build_entries.restype = vp
     L.hh_build_entries.argtypes = [u8p, u64p, C.c_uint64, C.c_int]
     for f in ("hh_entries_count", "hh_entries_records", "hh_entries_total"):
