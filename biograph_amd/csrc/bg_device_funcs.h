@@ -23,6 +23,14 @@ constexpr uint64_t kKmerMask62 = (1ull << 62) - 1;  // kmer_count_table.h:17
 constexpr uint64_t kFwdStartsBit = 1ull << 62;      // stored in hash slot: fwd_starts_read
 constexpr uint64_t kRevStartsBit = 1ull << 63;      // stored in hash slot: rev_starts_read
 
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2; MI355X_MICROARCH.md).  Maps
+// physical workgroup p of an nb-workgroup grid to a logical chunk so that each XCD walks one contiguous
+// eighth of the work.  Only locality depends on it.
+BG_HD uint64_t xcd_chunk(uint64_t p, uint64_t nb) {
+  uint64_t q = nb >> 3;
+  return p < (q << 3) ? (p & 7) * q + (p >> 3) : p;
+}
+
 // ---- 2-bit packed reads.  Read i owns words[i*W .. i*W+W): base j sits in word j/32 at bits
 // (62-2*(j%32)) (first base in the high bits, dna_sequence.h:97 / kmer.h:30-38), zero (=A) padded.
 // nmask[i*W + j/32] bit (31-j%32) is set where the input had 'N' (the base is then stored as A).

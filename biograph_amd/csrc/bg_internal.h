@@ -172,6 +172,7 @@ int alloc_prev_bits(bg_ctx* ctx, bg_seqset* ss);
 int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss);
 int apply_tails_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint32_t* d_err);
 int kmerset_sort(bg_ctx* ctx, bg_kmerset* ks);
+int read_locus_order(bg_ctx* ctx, const bg_reads* reads, uint64_t first, uint64_t count, DevBuf<uint32_t>* perm);
 // spiral_zip.cpp
 struct ZipPart { std::string name; std::string data; bool raw_crc0; };
 int spiral_zip_write(const char* path, const std::vector<ZipPart>& parts);

@@ -296,6 +296,69 @@ __global__ __launch_bounds__(KC_THREADS) void k_kmer_count_lds(const uint64_t* _
   }
 }
 
+// ---- locus order ---------------------------------------------------------------------------------
+// Reads are processed in the order of a per-read minimiser (the smallest hash over the read's canonical
+// 20-mers): reads covering the same genome position become neighbours, so the ~coverage look-ups of
+// each k-mer (hash-set probes of the screen / search, cover-index probes) happen close together in time
+// and are served by L2 / Infinity Cache instead of HBM.  Purely a schedule: every output is written at
+// the read's own index.
+constexpr int kLocusM = 20;
+
+__global__ __launch_bounds__(256) void k_read_locus_key(const uint64_t* __restrict__ words,
+                                                        const uint16_t* __restrict__ len, uint64_t first,
+                                                        uint64_t count, int W, uint64_t* __restrict__ key,
+                                                        uint32_t* __restrict__ idx) {
+  const int lane = threadIdx.x & 63;
+  uint64_t t = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (t >= count) return;  // wave-uniform
+  uint64_t i = first + t;
+  int L = len[i];
+  uint64_t myw = lane < W ? words[i * W + lane] : 0;
+  uint64_t best = ~0ull;
+  int nw = L - kLocusM + 1;
+  for (int j0 = 0; j0 < nw; j0 += 64) {
+    int j = j0 + lane;
+    int q = j >> 5, r = j & 31;
+    int q0 = q < 63 ? q : 63, q1 = q + 1 < 63 ? q + 1 : 63;
+    uint64_t w0 = __shfl(myw, q0, 64), w1 = __shfl(myw, q1, 64);
+    if (j < nw) {
+      uint64_t x = r ? ((w0 << (2 * r)) | (w1 >> (64 - 2 * r))) : w0;
+      bool fl;
+      uint64_t c = kmer_canon(x >> (64 - 2 * kLocusM), kLocusM, &fl);
+      uint64_t h = c * 0xD6E8FEB86659FD93ull;
+      h ^= h >> 32;
+      best = h < best ? h : best;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    uint64_t o = __shfl_xor(best, d, 64);
+    best = o < best ? o : best;
+  }
+  if (lane == 0) { key[t] = best; idx[t] = uint32_t(i); }
+}
+
+// perm[t] = index of the t-th read of [first, first+count) in locus order
+int read_locus_order(bg_ctx* ctx, const bg_reads* reads, uint64_t first, uint64_t count, DevBuf<uint32_t>* perm) {
+  DevBuf<uint64_t> ka, kb;
+  DevBuf<uint32_t> ia, ib;
+  BG_TRY(ka.alloc(ctx, count));
+  BG_TRY(kb.alloc(ctx, count));
+  BG_TRY(ia.alloc(ctx, count));
+  BG_TRY(ib.alloc(ctx, count));
+  if (count) {
+    ctx->tic("locus_order");
+    k_read_locus_key<<<cdiv(count, 4), 256, 0, ctx->stream>>>(reads->words.p, reads->len.p, first, count, reads->W,
+                                                              ka.p, ia.p);
+    BG_LAUNCH_CHECK();
+    ctx->toc(count * (reads->W * 8 + 12));
+  }
+  bool in_b = false;
+  BG_TRY(radix_sort_u64(ctx, ka.p, kb.p, ia.p, ib.p, count, 0, 64, &in_b));
+  *perm = std::move(in_b ? ib : ia);
+  return BG_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // S3: correction.  Screen (wave per read, all windows looked up in parallel), then DFS for the
 // reads that need it.
@@ -307,10 +370,14 @@ __global__ __launch_bounds__(256) void k_correct_screen(const uint64_t* __restri
                                                         uint64_t* __restrict__ out_words,
                                                         uint16_t* __restrict__ out_len,
                                                         uint8_t* __restrict__ need_dfs,
-                                                        uint64_t* __restrict__ present) {
+                                                        uint64_t* __restrict__ present,
+                                                        const uint32_t* __restrict__ perm) {
   const int lane = threadIdx.x & 63;
-  uint64_t i = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  if (i >= n) return;
+  // slot in locus order; XCD-aware: workgroups b, b+8, ... share an L2, so each XCD takes one contiguous
+  // eighth of the order (placement is a speed matter only)
+  uint64_t slot = xcd_chunk(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  if (slot >= n) return;
+  uint64_t i = perm[slot];
   int L = len[i];
   uint64_t myw = lane < W ? words[i * W + lane] : 0;
   uint32_t myn = lane < W ? nmask[i * W + lane] : 0;
@@ -362,6 +429,8 @@ __global__ __launch_bounds__(64) void k_correct_dfs(const uint64_t* __restrict__
                                                     const uint64_t* __restrict__ present) {
   uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= nlist) return;
+  // read-index order on purpose: in locus order the expensive reads (shared SNP / error loci) pile up in
+  // the same waves and the divergent search loses more to imbalance than it gains in locality
   uint64_t i = list[t];
   KmerTable tab{slots, log2cap, k};
   int L = len[i];
@@ -938,11 +1007,14 @@ extern "C" int bg_correct_reads(bg_ctx* ctx, const bg_reads* reads, const bg_kme
   BG_HIP(hipMemsetAsync(ctr.p, 0, sizeof(CorrectCounters), ctx->stream));
   BG_HIP(hipMemsetAsync(tot.p, 0, sizeof(CorrectTotals), ctx->stream));
   uint64_t nlist = 0;
+  if (n >= (1ull << 32)) { set_error("bg_correct_reads: too many reads for one shard"); return BG_EINVAL; }
+  DevBuf<uint32_t> perm;
+  BG_TRY(read_locus_order(ctx, reads, 0, n, &perm));
   if (n) {
     ctx->tic("correct_screen");
     k_correct_screen<<<cdiv(n, 4), 256, 0, ctx->stream>>>(reads->words.p, reads->nmask.p, reads->len.p, n, W, k,
                                                           ks->slots.p, ks->log2cap, r->words.p, r->len.p, need.p,
-                                                          present.p);
+                                                          present.p, perm.p);
     BG_LAUNCH_CHECK();
     ctx->toc(n * W * 20 + ks->instances * 8);
     DevBuf<uint64_t> list;
