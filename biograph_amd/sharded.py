@@ -71,13 +71,22 @@ class LocalSimComm:
 class TorchDistComm:
     """One rank per process over an initialised torch.distributed process group."""
 
-    def __init__(self, device):
+    def __init__(self, device, stage_through_host=False):
+        """stage_through_host: run every collective on CPU copies (gloo backend; lets several ranks share
+        one GPU in tests — RCCL refuses two ranks on one device)."""
         import torch.distributed as dist
         self.dist = dist
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.local_ranks = [self.rank]
-        self.device = device
+        self.out_device = device
+        self.device = torch.device("cpu") if stage_through_host else device
+
+    def _in(self, t):
+        return t.to(self.device) if t.device != self.device else t
+
+    def _out(self, t):
+        return t.to(self.out_device) if t.device != self.out_device else t
 
     # RCCL 2.26 (ROCm 7.0 build shipped with torch 2.10) returned corrupt data for all_to_all pieces of
     # exactly 2^31 / 2^32 / 2^33 bytes on MI355X (tools/debug_nccl_big.py); every piece is therefore
@@ -87,7 +96,7 @@ class TorchDistComm:
     def all_to_all_v(self, send):
         dist = self.dist
         rows, counts = send[self.rank]
-        rows = rows.contiguous()
+        rows = self._in(rows).contiguous()
         counts = [int(c) for c in counts]
         cin = torch.tensor(counts, dtype=torch.int64, device=self.device)
         cout = torch.empty_like(cin)
@@ -115,11 +124,11 @@ class TorchDistComm:
             out = torch.empty((sum(out_split),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=self.device)
             dist.all_to_all_single(out, chunk, output_split_sizes=out_split, input_split_sizes=in_split)
             outs.append(out)
-        return {self.rank: outs[0] if rounds == 1 else torch.cat(outs, dim=0)}
+        return {self.rank: self._out(outs[0] if rounds == 1 else torch.cat(outs, dim=0))}
 
     def all_gather_v(self, send):
         dist = self.dist
-        t = send[self.rank].contiguous()
+        t = self._in(send[self.rank]).contiguous()
         n = torch.tensor([t.shape[0]], dtype=torch.int64, device=self.device)
         sizes = [torch.empty_like(n) for _ in range(self.world)]
         dist.all_gather(sizes, n)
@@ -129,7 +138,7 @@ class TorchDistComm:
         pad[:t.shape[0]] = t
         outs = [torch.empty_like(pad) for _ in range(self.world)]
         dist.all_gather(outs, pad)
-        return {self.rank: [outs[i][:sizes[i]] for i in range(self.world)]}
+        return {self.rank: [self._out(outs[i][:sizes[i]]) for i in range(self.world)]}
 
     def all_gather_obj(self, send):
         lst = [None] * self.world
@@ -137,9 +146,9 @@ class TorchDistComm:
         return {self.rank: lst}
 
     def all_reduce_sum(self, send):
-        t = send[self.rank].clone()
+        t = self._in(send[self.rank]).clone()
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return {self.rank: t}
+        return {self.rank: self._out(t)}
 
     def barrier(self):
         self.dist.barrier()

@@ -687,6 +687,130 @@ static void ref_map_build(const Seqset& ss, const uint8_t* ref, const uint64_t* 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Readmap: bio_mapred/make_readmap.cpp:120-366.
+struct Readmap {
+  uint64_t n_reads = 0;        // read ids (4 per pair, 2 per single)
+  unsigned max_read_len = 0;
+  std::vector<uint64_t> entry_id;      // per read id (sorted), not stored directly
+  std::vector<uint32_t> read_len;
+  std::vector<uint64_t> mate_loop_ptr;
+  std::vector<uint8_t> is_forward;
+  Seqset s2m, d2m;  // only bits[0]/subaccum[0]/accum[0] used as plain bitcounts
+};
+
+struct LoopRow {  // make_readmap.h:56-90
+  uint64_t entry_id;
+  int type;  // LOOP_START 0, RC 1, MATE 2, MATE_RC 3
+  uint32_t read_length, mate_read_length;
+  uint64_t loop_entry_id;
+};
+static const uint64_t kNoLoop = (1ull << 37) - 1;
+static bool row_less(const LoopRow& a, const LoopRow& b) {  // make_readmap.h:187-213
+  if (a.entry_id != b.entry_id) return a.entry_id < b.entry_id;
+  if (a.type != b.type) return a.type < b.type;
+  if (a.read_length != b.read_length) return a.read_length < b.read_length;
+  if (a.mate_read_length != b.mate_read_length) return a.mate_read_length < b.mate_read_length;
+  return a.loop_entry_id < b.loop_entry_id;
+}
+
+// records: record r holds reads [rec_first[r], rec_first[r+1]) (1 or 2 corrected sequences).
+static Readmap* readmap_build(const Seqset& ss, const std::vector<std::string>& entries,
+                              const std::vector<std::string>& reads, const std::vector<uint64_t>& rec_first,
+                              bool is_paired, bool canonicalize, std::string* err) {
+  auto find_existing = [&](const std::string& s) -> uint64_t {  // seqset.cpp:173-188 == first entry with prefix s
+    size_t t = std::lower_bound(entries.begin(), entries.end(), s) - entries.begin();
+    if (t >= entries.size() || entries[t].compare(0, s.size(), s) != 0) { *err = "read not found in seqset: " + s; return 0; }
+    return t;
+  };
+  std::vector<LoopRow> rows;
+  unsigned max_len = 0;
+  for (size_t r = 0; r + 1 < rec_first.size(); ++r) {
+    size_t cnt = rec_first[r + 1] - rec_first[r];
+    std::string seq = reads[rec_first[r]];
+    std::string mate = (cnt == 2 && is_paired) ? reads[rec_first[r] + 1] : std::string();
+    if (cnt != 1 && !(cnt == 2 && is_paired)) { *err = "Unexpected read pairing"; return nullptr; }
+    unsigned read_len = unsigned(seq.size());
+    uint64_t e = find_existing(seq), erc = find_existing(revcomp_str(seq));
+    unsigned mate_len = unsigned(mate.size());
+    max_len = std::max(max_len, std::max(read_len, mate_len));
+    if (mate_len) {
+      uint64_t me = find_existing(mate), merc = find_existing(revcomp_str(mate));
+      if (canonicalize && seq > mate) { std::swap(me, e); std::swap(mate_len, read_len); std::swap(merc, erc); }  // :171-176
+      rows.push_back({e, 0, read_len, 0, erc});
+      rows.push_back({erc, 1, read_len, mate_len, me});
+      rows.push_back({me, 2, mate_len, 0, merc});
+      rows.push_back({merc, 3, mate_len, 0, kNoLoop});
+    } else {
+      rows.push_back({e, 0, read_len, 0, erc});
+      rows.push_back({erc, 1, read_len, 0, kNoLoop});
+    }
+    if (!err->empty()) return nullptr;
+  }
+  std::stable_sort(rows.begin(), rows.end(), row_less);
+  auto* rm = new Readmap;
+  const size_t n = rows.size();
+  rm->n_reads = n;
+  rm->max_read_len = max_len;
+  rm->read_len.resize(n);
+  rm->entry_id.resize(n);
+  rm->mate_loop_ptr.assign(n, 0);
+  rm->is_forward.assign(n, 0);
+  // sparse_multi (io/sparse_multi.h): bit per seqset entry with reads; bit per read id starting a group
+  rm->s2m.n = ss.n;
+  rm->s2m.bits[0].assign((ss.n + 63) / 64, 0);
+  rm->d2m.n = n;
+  rm->d2m.bits[0].assign((n + 63) / 64, 0);
+  for (size_t i = 0; i < n; ++i) {
+    rm->read_len[i] = rows[i].read_length;
+    rm->entry_id[i] = rows[i].entry_id;
+    rm->s2m.bits[0][rows[i].entry_id / 64] |= 1ull << (rows[i].entry_id & 63);
+    if (i == 0 || rows[i].entry_id != rows[i - 1].entry_id) rm->d2m.bits[0][i / 64] |= 1ull << (i & 63);
+  }
+  rm->s2m.finalize_bitcount(0);
+  rm->d2m.finalize_bitcount(0);
+  auto find_first_of = [&](int type, uint64_t entry_id, unsigned len) -> uint64_t {  // :283-289
+    LoopRow probe{entry_id, type, len, 0, 0};
+    return std::lower_bound(rows.begin(), rows.end(), probe, row_less) - rows.begin();
+  };
+  for (size_t i = 0; i < n; ++i) {  // first pass :293-326
+    const LoopRow& r = rows[i];
+    switch (r.type) {
+      case 0: rm->is_forward[i] = 1; rm->mate_loop_ptr[i] = find_first_of(1, r.loop_entry_id, r.read_length); break;
+      case 1: if (r.loop_entry_id != kNoLoop) rm->mate_loop_ptr[i] = find_first_of(2, r.loop_entry_id, r.mate_read_length); break;
+      case 2: rm->is_forward[i] = 1; rm->mate_loop_ptr[i] = find_first_of(3, r.loop_entry_id, r.read_length); break;
+      default: break;
+    }
+  }
+  std::vector<uint8_t> claimed(n, 0);  // second pass, sequential on purpose :330-392
+  auto claim_next = [&](uint64_t t, int type, uint64_t entry_id, unsigned len) -> uint64_t {
+    while (t < n && claimed[t]) ++t;
+    if (t >= n || rows[t].entry_id != entry_id || rows[t].read_length != len || rows[t].type != type) {
+      *err = "mate loop claim failed";
+      return 0;
+    }
+    claimed[t] = 1;
+    return t;
+  };
+  for (size_t i = 0; i < n && err->empty(); ++i) {
+    const LoopRow& r = rows[i];
+    if (r.type != 0) continue;
+    uint64_t rc = claim_next(rm->mate_loop_ptr[i], 1, r.loop_entry_id, r.read_length);
+    rm->mate_loop_ptr[i] = rc;
+    const LoopRow& rr = rows[rc];
+    if (rr.loop_entry_id == kNoLoop) { rm->mate_loop_ptr[rc] = i; continue; }
+    uint64_t mi = claim_next(rm->mate_loop_ptr[rc], 2, rr.loop_entry_id, rr.mate_read_length);
+    rm->mate_loop_ptr[rc] = mi;
+    const LoopRow& mr = rows[mi];
+    uint64_t mrc = claim_next(rm->mate_loop_ptr[mi], 3, mr.loop_entry_id, rr.mate_read_length);
+    rm->mate_loop_ptr[mi] = mrc;
+    rm->mate_loop_ptr[mrc] = i;
+  }
+  if (!err->empty()) { delete rm; return nullptr; }
+  return rm;
+}
+
 }  // namespace orc
 
 // ============================================================================================
@@ -914,5 +1038,45 @@ void orc_ref_map_build(void* h, const uint8_t* ref_codes, const uint64_t* ext_st
                        uint64_t n_ext, uint8_t* out) {
   ref_map_build(*static_cast<Seqset*>(h), ref_codes, ext_start, ext_size, n_ext, out);
 }
+
+// ---- readmap.  reads = concatenated corrected reads; rec_first[n_rec+1] delimits records (1 or 2 reads).
+static std::string g_rm_err;
+void* orc_readmap_build(void* ssh, void* eh, const char* seq, const uint64_t* offs, uint64_t n_reads,
+                        const uint64_t* rec_first, uint64_t n_rec, int is_paired, int canonicalize) {
+  auto reads = split_reads(seq, offs, n_reads);
+  std::vector<uint64_t> rf(rec_first, rec_first + n_rec + 1);
+  g_rm_err.clear();
+  return readmap_build(*static_cast<Seqset*>(ssh), static_cast<Entries*>(eh)->e, reads, rf, is_paired != 0, canonicalize != 0, &g_rm_err);
+}
+const char* orc_readmap_error() { return g_rm_err.c_str(); }
+uint64_t orc_readmap_size(void* h) { return static_cast<Readmap*>(h)->n_reads; }
+uint32_t orc_readmap_max_len(void* h) { return static_cast<Readmap*>(h)->max_read_len; }
+// which: 0 read_len(u32->u64), 1 mate_loop_ptr, 2 is_forward, 3 entry_id ; out = n u64
+void orc_readmap_get(void* h, int which, uint64_t* out) {
+  auto* rm = static_cast<Readmap*>(h);
+  for (uint64_t i = 0; i < rm->n_reads; ++i)
+    out[i] = which == 0 ? rm->read_len[i] : which == 1 ? rm->mate_loop_ptr[i] : which == 2 ? rm->is_forward[i] : rm->entry_id[i];
+}
+// bitcounts: sel 0 = source_to_mid, 1 = dest_to_mid; which 0 bits / 1 subaccum / 2 accum
+uint64_t orc_readmap_bitcount(void* h, int sel, int which, uint64_t* out) {
+  auto* rm = static_cast<Readmap*>(h);
+  Seqset& b = sel == 0 ? rm->s2m : rm->d2m;
+  auto& v = which == 0 ? b.bits[0] : which == 1 ? b.subaccum[0] : b.accum[0];
+  if (out) std::memcpy(out, v.data(), v.size() * 8);
+  return v.size();
+}
+// generic LSB-first packing of n values at `bits` bits each (packed_varbit_vector / packed_vector layout)
+uint64_t orc_pack_bits(const uint64_t* vals, uint64_t n, int bits, uint64_t* out) {
+  uint64_t nw = (n * bits + 63) / 64;
+  if (!out) return nw;
+  std::memset(out, 0, nw * 8);
+  for (uint64_t i = 0; i < n && bits; ++i) {
+    uint64_t bit = i * bits;
+    out[bit / 64] |= vals[i] << (bit % 64);
+    if (bit % 64 + bits > 64) out[bit / 64 + 1] |= vals[i] >> (64 - bit % 64);
+  }
+  return nw;
+}
+void orc_readmap_free(void* h) { delete static_cast<Readmap*>(h); }
 
 }  // extern "C"

@@ -83,6 +83,19 @@ def lib():
     L.orc_branch_trace.argtypes = [vp, u8p, C.c_uint64, u64p, C.c_uint64, C.c_uint32, C.c_uint64, u32p, u8p, u64p,
                                    u64p, u64p]
     L.orc_ref_map_build.argtypes = [vp, u8p, u64p, u64p, C.c_uint64, u8p]
+    L.orc_readmap_build.restype = vp
+    L.orc_readmap_build.argtypes = [vp, vp, u8p, u64p, C.c_uint64, u64p, C.c_uint64, C.c_int, C.c_int]
+    L.orc_readmap_error.restype = C.c_char_p
+    L.orc_readmap_size.restype = C.c_uint64
+    L.orc_readmap_size.argtypes = [vp]
+    L.orc_readmap_max_len.restype = C.c_uint32
+    L.orc_readmap_max_len.argtypes = [vp]
+    L.orc_readmap_get.argtypes = [vp, C.c_int, u64p]
+    L.orc_readmap_bitcount.restype = C.c_uint64
+    L.orc_readmap_bitcount.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
+    L.orc_pack_bits.restype = C.c_uint64
+    L.orc_pack_bits.argtypes = [u64p, C.c_uint64, C.c_int, C.c_void_p]
+    L.orc_readmap_free.argtypes = [vp]
     _LIB = L
     return L
 
@@ -453,3 +466,111 @@ def revcomp(s):
 
 def tseq_rc(s):
     return revcomp(tseq(s))
+
+
+# ------------------------------------------------------------------------------------------------
+# readmap
+
+def bits_for_value(v):
+    b = 0
+    while v:
+        b += 1
+        v >>= 1
+    return b
+
+
+def pack_bits(vals, bits):
+    vals = np.ascontiguousarray(vals, np.uint64)
+    nw = lib().orc_pack_bits(_pad(vals), len(vals), bits, None)
+    out = np.zeros(max(nw, 1), np.uint64)
+    lib().orc_pack_bits(_pad(vals), len(vals), bits, out.ctypes.data)
+    return out[:nw]
+
+
+class Readmap:
+    """Oracle readmap: records = list of 1- or 2-tuples of corrected read strings."""
+
+    def __init__(self, seqset, entries, records, is_paired=True, canonicalize=True):
+        reads = [r for rec in records for r in rec]
+        rec_first = np.zeros(len(records) + 1, np.uint64)
+        rec_first[1:] = np.cumsum([len(rec) for rec in records])
+        seq, offs = pack_strings(reads)
+        self.h = lib().orc_readmap_build(seqset.h, entries.h, _pad(seq), offs, len(reads), rec_first, len(records),
+                                         int(is_paired), int(canonicalize))
+        if not self.h:
+            raise RuntimeError(lib().orc_readmap_error().decode())
+        self.n_entries = len(seqset)
+
+    def __len__(self):
+        return lib().orc_readmap_size(self.h)
+
+    @property
+    def max_read_len(self):
+        return lib().orc_readmap_max_len(self.h)
+
+    def get(self, which):
+        w = {"read_len": 0, "mate_loop_ptr": 1, "is_forward": 2, "entry_id": 3}[which]
+        out = np.zeros(max(len(self), 1), np.uint64)
+        lib().orc_readmap_get(self.h, w, out)
+        return out[:len(self)]
+
+    def bitcount(self, sel, which):
+        s = {"source_to_mid": 0, "dest_to_mid": 1}[sel]
+        w = {"bits": 0, "subaccum": 1, "accum": 2}[which]
+        n = lib().orc_readmap_bitcount(self.h, s, w, None)
+        out = np.zeros(max(n, 1), np.uint64)
+        lib().orc_readmap_bitcount(self.h, s, w, out.ctypes.data)
+        return out[:n]
+
+    def parts(self):
+        """Payload members of the readmap container (make_readmap.cpp:221-260, format 1.2.0)."""
+        n = len(self)
+        p = {}
+        for sel in ("source_to_mid", "dest_to_mid"):
+            for w in ("bits", "subaccum", "accum"):
+                p["read_ids/%s/%s" % (sel, w)] = self.bitcount(sel, w).tobytes()
+        p["read_lengths/elements"] = pack_bits(self.get("read_len"), bits_for_value(self.max_read_len)).tobytes()
+        p["mate_loop_ptr/elements"] = pack_bits(self.get("mate_loop_ptr"), bits_for_value(n)).tobytes()
+        p["is_forward/packed_data"] = pack_bits(self.get("is_forward"), 1).tobytes()
+        return p
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_readmap_free(self.h)
+            self.h = None
+
+
+def decode_readmap(path, seqset_dict):
+    """Decode a reference-written readmap into arrays + the records (pairs / singles of read strings) it
+    was built from (reads are entry prefixes; pairing from the mate loops)."""
+    m = read_spiral_members(path)
+    n = seqset_dict["n"]
+    nr = json.loads(m["read_lengths/packed_varbit_vector.json"])["element_count"]
+
+    def bits(buf, nb):
+        return np.unpackbits(np.frombuffer(buf, np.uint8), bitorder="little")[:nb]
+    s2m = bits(m["read_ids/source_to_mid/bits"], n)
+    d2m = bits(m["read_ids/dest_to_mid/bits"], nr)
+    rl = unpack_varbit(m["read_lengths/elements"],
+                       nr, json.loads(m["read_lengths/packed_varbit_vector.json"])["bits_per_value"])
+    mlp = unpack_varbit(m["mate_loop_ptr/elements"],
+                        nr, json.loads(m["mate_loop_ptr/packed_varbit_vector.json"])["bits_per_value"])
+    isf = bits(m["is_forward/packed_data"], nr)
+    entry = np.flatnonzero(s2m)[np.cumsum(d2m) - 1]
+    ent = decode_entries(seqset_dict)
+    records = []
+    seen = np.zeros(nr, bool)
+    for i in range(nr):
+        if seen[i] or not isf[i]:
+            continue
+        cyc = [i]
+        j = int(mlp[i])
+        while j != i:
+            cyc.append(j)
+            j = int(mlp[j])
+        for c in cyc:
+            seen[c] = True
+        fw = [c for c in cyc if isf[c]]
+        records.append(tuple(ent[entry[c]][:rl[c]] for c in fw))
+    return {"raw": m, "n_reads": nr, "entry": entry, "read_len": rl, "mate_loop_ptr": mlp, "is_forward": isf,
+            "records": records}

@@ -1,0 +1,49 @@
+"""Worker of tests/test_gpu_sharded_mp.py: one rank of a real multi-process sharded build.  All ranks
+share cuda:0; collectives run over gloo on host copies (TorchDistComm(stage_through_host=True))."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import biograph_amd as bg  # noqa: E402
+from biograph_amd import sharded, synth  # noqa: E402
+
+
+def main():
+    out_path = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    seq, offs, n = synth.make_reads(genome_len=40000, coverage=30, read_len=150, seed=9, device=dev,
+                                    shard=(rank, world))
+    ctx = bg.Context(0, torch.cuda.current_stream(dev).cuda_stream)
+    comm = sharded.TorchDistComm(dev, stage_through_host=True)
+    out = sharded.sharded_create(comm, {rank: ctx}, {rank: (seq, offs, n)})
+    ss, st = out[rank]
+    # every rank also ships its reads to rank 0 so the single-GPU build of the same sample can be compared
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (seq.cpu().numpy(), n))
+    if rank == 0:
+        allseq = np.concatenate([g[0] for g in gathered])
+        total = sum(g[1] for g in gathered)
+        dseq = torch.from_numpy(allseq).to(dev)
+        doffs = torch.arange(0, (total + 1) * 150, 150, dtype=torch.int64, device=dev)
+        ref, rst = ctx.create_device(dseq.data_ptr(), doffs.data_ptr(), total)
+        same = all(ss.part(p) == ref.part(p) for p in bg.PART_NAMES)
+        json.dump({"same": bool(same), "n_entries": ss.size(), "ref_entries": ref.size(), "stats": st,
+                   "shards": st["shard_entries"]}, open(out_path, "w"))
+        ref.free()
+        ss.free()
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -129,3 +129,51 @@ def test_kmer_counter_semantics():
     assert flags[idx[enc("ACGTA")]] & 1
     # last kmer of read 0 is "CGTAC": rc = GTACG > CGTAC, not flipped -> rev_starts flag
     assert flags[idx[enc("CGTAC")]] & 2
+
+
+def test_readmap_oracle_against_lambda_golden(golden_dir):
+    """Readmap (make_readmap.cpp:120-366) — groundwork for the next row.  The only committed
+    readmap in the current container format (father_lambda, written by v4.0.1-dev) predates the total
+    row order of make_readmap.h:187-213 (rows inside one seqset entry follow input-file order there), so
+    it pins: the sparse_multi rank vectors byte for byte, the per-entry multiset of (read length,
+    is_forward), and the mate-loop cycle structure — not the row order inside an entry group."""
+    d = O.load_seqset_zip(golden_dir + "/father_lambda/seqset")
+    g = O.decode_readmap(golden_dir + "/father_lambda/readmap", d)
+    assert g["n_reads"] == 97860 and len(g["records"]) == 28939 and sum(len(r) for r in g["records"]) == 48930
+    ent = O.Entries.from_strings(O.decode_entries(d))
+    ss = O.Seqset.from_entries(ent)
+    rm = O.Readmap(ss, ent, g["records"], True)
+    assert len(rm) == 97860 and rm.max_read_len == 150
+    parts = rm.parts()
+    for sel in ("source_to_mid", "dest_to_mid"):
+        for w in ("bits", "subaccum", "accum"):
+            name = "read_ids/%s/%s" % (sel, w)
+            assert parts[name] == g["raw"][name], name
+    for name in ("read_lengths/elements", "mate_loop_ptr/elements", "is_forward/packed_data"):
+        assert len(parts[name]) == len(g["raw"][name])
+    e, rl, isf, mlp = rm.get("entry_id"), rm.get("read_len"), rm.get("is_forward"), rm.get("mate_loop_ptr")
+    assert (e == g["entry"]).all()
+    mine = sorted(zip(e.tolist(), rl.tolist(), isf.tolist()))
+    gold = sorted(zip(g["entry"].tolist(), g["read_len"].tolist(), g["is_forward"].tolist()))
+    assert mine == gold
+
+    def cycles(entry, rlen, fwd, ptr):
+        seen = np.zeros(len(ptr), bool)
+        out = []
+        for i in range(len(ptr)):
+            if seen[i]:
+                continue
+            c, j = [], i
+            while not seen[j]:
+                seen[j] = True
+                c.append((int(entry[j]), int(rlen[j]), int(fwd[j])))
+                j = int(ptr[j])
+            assert j == i  # closed loop
+            k = c.index(min(c))
+            out.append(tuple(c[k:] + c[:k]))
+        return sorted(out)
+    cm = cycles(e, rl, isf, mlp)
+    cg = cycles(g["entry"], g["read_len"], g["is_forward"], g["mate_loop_ptr"])
+    assert len(cm) == len(cg) == 28939
+    # same loops up to rotation: a loop is fwd -> rc -> mate fwd -> mate rc (or fwd -> rc)
+    assert sorted(tuple(sorted(c)) for c in cm) == sorted(tuple(sorted(c)) for c in cg)
