@@ -142,6 +142,12 @@ class Context:
         capi.check(capi.lib().bg_seqset_build(self.h, corrected.h, cover_k, C.byref(h), C.byref(st)))
         return Seqset(self, h), st.as_dict()
 
+    def build_readmap(self, seqset, corrected, is_paired=True):
+        """make_readmap::create_from_reads (bio_mapred/make_readmap.cpp:120-392) on the GPU."""
+        h = C.c_void_p()
+        capi.check(capi.lib().bg_readmap_build(self.h, seqset.h, corrected.h, int(bool(is_paired)), C.byref(h)))
+        return Readmap(self, h)
+
     # ---- whole create path --------------------------------------------------------------------
     def default_params(self, **kw):
         p = CreateParams()
@@ -263,6 +269,42 @@ class KmerSet(_Handle):
 
 PART_NAMES = ["fixed", "entry_sizes/elements", "shared/elements"] + [
     "prev_%s/%s" % (b, w) for b in "ACGT" for w in ("bits", "subaccum", "accum")]
+
+
+READMAP_PART_NAMES = ["read_ids/%s/%s" % (s, w) for s in ("source_to_mid", "dest_to_mid")
+                      for w in ("bits", "subaccum", "accum")] + [
+    "read_lengths/elements", "mate_loop_ptr/elements", "is_forward/packed_data"]
+
+
+class Readmap(_Handle):
+    """Resident readmap of one sample (modules/bio_base/readmap.h); built by Context.build_readmap."""
+    _free = "bg_readmap_free"
+
+    def size(self):
+        return capi.lib().bg_readmap_size(self.h)
+
+    __len__ = size
+
+    @property
+    def max_read_len(self):
+        return capi.lib().bg_readmap_max_read_len(self.h)
+
+    def part(self, name):
+        sz = C.c_uint64(0)
+        capi.check(capi.lib().bg_readmap_part(self.ctx.h, self.h, name.encode(), None, C.byref(sz)))
+        buf = np.zeros(max(sz.value, 1), np.uint8)
+        capi.check(capi.lib().bg_readmap_part(self.ctx.h, self.h, name.encode(), capi.np_ptr(buf), C.byref(sz)))
+        return buf[:sz.value].tobytes()
+
+    def parts(self):
+        return {n: self.part(n) for n in READMAP_PART_NAMES}
+
+    def write(self, path, argv=()):
+        """Writes the container and returns its SHA-1 (the name it takes under coverage/)."""
+        arr = (C.c_char_p * max(len(argv), 1))(*[a.encode() for a in argv])
+        sha = C.create_string_buffer(41)
+        capi.check(capi.lib().bg_readmap_write(self.ctx.h, self.h, str(path).encode(), len(argv), arr, sha))
+        return sha.value.decode()
 
 
 class Seqset(_Handle):

@@ -59,6 +59,8 @@ SYMBOLS = [
     "bg_seqset_from_arrays", "bg_seqset_free", "bg_push_front_batch", "bg_push_front_drop_batch", "bg_find_batch",
     "bg_dev_alloc", "bg_dev_free", "bg_dev_upload", "bg_dev_download",
     "bg_trace_one_base_batch", "bg_branch_trace_batch", "bg_ref_map_build",
+    "bg_readmap_build", "bg_readmap_size", "bg_readmap_max_read_len", "bg_readmap_part", "bg_readmap_write",
+    "bg_readmap_free", "bg_create_sample",
     # sharded build
     "bg_partition_rows", "bg_kmer_instances", "bg_kmer_extract", "bg_kmer_count_keys", "bg_kmerset_export",
     "bg_kmerset_from_kmers", "bg_reads_words", "bg_reads_export", "bg_reads_import", "bg_suffix_records",
@@ -126,6 +128,16 @@ def lib():
     L.bg_trace_one_base_batch.argtypes = [vp, vp, u64] + [vp] * 15
     L.bg_branch_trace_batch.argtypes = [vp, vp, u64, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp, vp, vp]
     L.bg_ref_map_build.argtypes = [vp, vp, vp, u64, vp, vp, u32, vp]
+    L.bg_readmap_build.argtypes = [vp, vp, vp, i32, P(vp)]
+    L.bg_readmap_size.restype = u64
+    L.bg_readmap_size.argtypes = [vp]
+    L.bg_readmap_max_read_len.restype = u32
+    L.bg_readmap_max_read_len.argtypes = [vp]
+    L.bg_readmap_part.argtypes = [vp, vp, C.c_char_p, vp, P(u64)]
+    L.bg_readmap_write.argtypes = [vp, vp, C.c_char_p, i32, P(C.c_char_p), C.c_char_p]
+    L.bg_readmap_free.argtypes = [vp]
+    L.bg_readmap_free.restype = None
+    L.bg_create_sample.argtypes = [vp, vp, vp, u64, P(CreateParams), i32, P(vp), P(vp), P(BuildStats)]
     L.bg_partition_rows.argtypes = [vp, vp, u64, i32, i32, u32, vp, vp, vp]
     L.bg_kmer_instances.argtypes = [vp, vp, i32, P(u64)]
     L.bg_kmer_extract.argtypes = [vp, vp, i32, vp, u64]

@@ -499,8 +499,9 @@ extern "C" void bg_create_params_default(bg_create_params* p) {
   p->correct.trim_after_portion = 0.7f;   // :281
 }
 
-extern "C" int bg_create(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n_reads,
-                         const bg_create_params* p, bg_seqset** out, bg_build_stats* stats) {
+static int create_impl(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n_reads,
+                       const bg_create_params* p, int is_paired, bg_seqset** out, bg_readmap** out_rm,
+                       bg_build_stats* stats) {
   if (!ctx || !p || !out) { set_error("bg_create: null argument"); return BG_EINVAL; }
   bg_build_stats st;
   memset(&st, 0, sizeof st);
@@ -534,7 +535,23 @@ extern "C" int bg_create(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_of
     st.n_entries = s2.n_entries;
     st.max_len = s2.max_len;
   }
+  if (rc == BG_OK && out_rm) {
+    rc = bg_readmap_build(ctx, *out, corrected, is_paired, out_rm);
+    if (rc != BG_OK) { bg_seqset_free(*out); *out = nullptr; }
+  }
   bg_reads_free(corrected);
   if (stats) *stats = st;
   return rc;
+}
+
+extern "C" int bg_create(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n_reads,
+                         const bg_create_params* p, bg_seqset** out, bg_build_stats* stats) {
+  return create_impl(ctx, d_seq, d_offs, n_reads, p, 0, out, nullptr, stats);
+}
+
+extern "C" int bg_create_sample(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n_reads,
+                                const bg_create_params* p, int is_paired, bg_seqset** out, bg_readmap** out_rm,
+                                bg_build_stats* stats) {
+  if (!out_rm) { set_error("bg_create_sample: null argument"); return BG_EINVAL; }
+  return create_impl(ctx, d_seq, d_offs, n_reads, p, is_paired, out, out_rm, stats);
 }

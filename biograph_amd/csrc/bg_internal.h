@@ -178,4 +178,5 @@ struct ZipPart { std::string name; std::string data; bool raw_crc0; };
 int spiral_zip_write(const char* path, const std::vector<ZipPart>& parts);
 int spiral_zip_read(const char* path, std::map<std::string, std::string>* parts);
 std::string make_uuid();
+int sha1_file_hex(const char* path, char* hex41);
 }  // namespace bg

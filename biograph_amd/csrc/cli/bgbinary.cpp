@@ -8,8 +8,8 @@
 //   bgbinary refmap --in S.bg --ref DIR|FASTA --out FILE          (ref_map::build -> one byte per entry)
 //
 // Host work here is file I/O only (FASTQ parsing with zlib, output directory); every computation is a
-// C-ABI call that runs on the GPU.  Readmap creation is a "next" row: the coverage/
-// directory is left empty and bg_info.json lists no sample readmap.
+// C-ABI call that runs on the GPU.  The sample's readmap lands in coverage/<sha1>.readmap and is listed
+// under "samples" in metadata/bg_info.json (biograph_create.cpp:812-831, biograph_dir.cpp).
 #include <errno.h>
 #include <string.h>
 #include <sys/stat.h>
@@ -162,12 +162,14 @@ static int cmd_create(int argc, char** argv) {
   check(bg_dev_alloc(ctx, offs.size() * 8, &d_offs), "bg_dev_alloc");
   check(bg_dev_upload(ctx, d_seq, seq.data(), seq.size()), "upload");
   check(bg_dev_upload(ctx, d_offs, offs.data(), offs.size() * 8), "upload");
-  fprintf(stderr, "\nRunning kmerization, read correction and seqset build on the GPU\n");
+  fprintf(stderr, "\nRunning kmerization, read correction, seqset and readmap build on the GPU\n");
   double t1 = now_s();
   bg_seqset* ss = nullptr;
+  bg_readmap* rm = nullptr;
   bg_build_stats st;
-  check(bg_create(ctx, static_cast<const uint8_t*>(d_seq), static_cast<const uint64_t*>(d_offs), reads.size(), &p, &ss, &st),
-        "bg_create");
+  check(bg_create_sample(ctx, static_cast<const uint8_t*>(d_seq), static_cast<const uint64_t*>(d_offs), reads.size(), &p,
+                         pairs.empty() ? 0 : 1, &ss, &rm, &st),
+        "bg_create_sample");
   double t_build = now_s() - t1;
   double pct = double(st.n_corrected_reads) / double(reads.size());
   char msg[256];
@@ -186,6 +188,10 @@ static int cmd_create(int argc, char** argv) {
   mkdirs(out + "/coverage");
   std::vector<const char*> av(argv, argv + argc);
   check(bg_seqset_write(ctx, ss, (out + "/seqset").c_str(), argc, av.data()), "bg_seqset_write");
+  char sha[41];
+  std::string rm_tmp = out + "/coverage/tmp.readmap";
+  check(bg_readmap_write(ctx, rm, rm_tmp.c_str(), argc, av.data(), sha), "bg_readmap_write");
+  if (rename(rm_tmp.c_str(), (out + "/coverage/" + sha + ".readmap").c_str()) != 0) die("Could not rename " + rm_tmp);
   double t_total = now_s() - t0;
 
   std::string id = a.get("id");
@@ -199,10 +205,12 @@ static int cmd_create(int argc, char** argv) {
            (unsigned long long)st.n_kept_kmers, (unsigned long long)st.n_entries, t_import, t_build, t_total);
   write_file(out + "/qc/create_stats.json", js);
   if (a.has("stats")) write_file(a.get("stats"), js);
-  snprintf(js, sizeof js, "{\"accession_id\":\"%s\",\"command_history\":[],\"samples\":{},\"version\":\"biograph_amd-r1\"}", id.c_str());
+  snprintf(js, sizeof js, "{\"accession_id\":\"%s\",\"command_history\":[],\"samples\":{\"%s\":\"%s\"},\"version\":\"biograph_amd-r1\"}",
+           id.c_str(), id.c_str(), sha);
   write_file(out + "/metadata/bg_info.json", js);
   fprintf(stderr, "%llu / %zu reads survived read correction; %llu seqset entries; GPU build %.3f s\n",
           (unsigned long long)st.n_corrected_reads, reads.size(), (unsigned long long)st.n_entries, t_build);
+  bg_readmap_free(rm);
   bg_seqset_free(ss);
   bg_dev_free(ctx, d_seq);
   bg_dev_free(ctx, d_offs);

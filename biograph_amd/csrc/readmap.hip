@@ -1,0 +1,619 @@
+// readmap.hip — readmap construction on the GPU (the first "next" row):
+// make_readmap::create_from_reads (modules/bio_mapred/make_readmap.cpp:120-392).
+//
+//   1. entry id of every kept read and of its reverse complement = first seqset entry having it as a
+//      prefix (seqset::find_existing_unique, bio_base/seqset.cpp:173-188) — one lower_bound on the
+//      resident entry keys through the leading-bases directory;
+//   2. mate-loop rows (LOOP_START, RC, MATE, MATE_RC; make_readmap.h:56-90) packed into two sort words
+//      hi = entry:37|type:2|read_len:10|mate_len:10 and lo = loop_entry:37, sorted (hi, lo) — the
+//      total order of make_readmap.h:187-213;
+//   3. sparse_multi bit vectors, read lengths, is_forward;
+//   4. the mate loops.  The reference claims rows sequentially "to stay deterministic"
+//      (:328-392): the k-th LOOP_START (in row order) that targets a group of identical
+//      (entry, type, length) rows takes the k-th row of that group.  That rank is computed here with one
+//      stable sort per hop (RC, MATE, MATE_RC), which reproduces the sequential result exactly.
+#include <string.h>
+#include <time.h>
+
+#include "bg_device_funcs.h"
+#include "bg_internal.h"
+#include "compact.h"
+
+namespace bg {
+
+constexpr uint64_t kNoLoopEntry = (1ull << 37) - 1;  // make_readmap.h:54
+constexpr int kPrefixBasesRm = 12;
+
+__device__ __forceinline__ uint64_t rm_hi(uint64_t entry, int type, uint32_t len, uint32_t mate_len) {
+  return (entry << 22) | (uint64_t(type) << 20) | (uint64_t(len) << 10) | uint64_t(mate_len);
+}
+__device__ __forceinline__ uint64_t hi_entry(uint64_t hi) { return hi >> 22; }
+__device__ __forceinline__ int hi_type(uint64_t hi) { return int((hi >> 20) & 3); }
+__device__ __forceinline__ uint32_t hi_len(uint64_t hi) { return uint32_t((hi >> 10) & 1023); }
+__device__ __forceinline__ uint32_t hi_mate_len(uint64_t hi) { return uint32_t(hi & 1023); }
+
+__global__ void k_rm_prefix_dir(const uint64_t* __restrict__ ekeys, uint64_t n, int W, uint32_t* __restrict__ dir) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  const uint32_t nb = 1u << (2 * kPrefixBasesRm);
+  uint32_t cur = i < n ? uint32_t(ekeys[i * W] >> (64 - 2 * kPrefixBasesRm)) : nb;
+  uint32_t prev = i ? uint32_t(ekeys[(i - 1) * W] >> (64 - 2 * kPrefixBasesRm)) + 1 : 0u;
+  for (uint32_t p = prev; p <= cur; ++p) dir[p] = uint32_t(i);
+}
+
+// entry id of oriented read o (2i = read i, 2i+1 = its reverse complement); ~0 for dropped reads
+__global__ __launch_bounds__(128) void k_rm_entry_ids(const uint64_t* __restrict__ words,
+                                                     const uint16_t* __restrict__ len, uint64_t n_o, int W,
+                                                     const uint64_t* __restrict__ ekeys,
+                                                     const uint8_t* __restrict__ esizes, uint64_t n_ent, int EW,
+                                                     const uint32_t* __restrict__ dir, uint64_t* __restrict__ eid,
+                                                     uint32_t* __restrict__ err) {
+  uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (o >= n_o) return;
+  int L = len[o >> 1];
+  if (!L) { eid[o] = ~0ull; return; }
+  uint64_t key[kMaxWords];
+  oriented_words(words + (o >> 1) * W, L, W, (o & 1) != 0, key);
+  for (int w = W; w < EW; ++w) key[w] = 0;
+  uint32_t p = uint32_t(key[0] >> (64 - 2 * kPrefixBasesRm));
+  uint64_t lo = dir[p], hi = dir[p + 1];
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) >> 1;
+    if (key_compare(ekeys + mid * EW, esizes[mid], key, L, EW) < 0) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= n_ent || key_lcp(ekeys + lo * EW, esizes[lo], key, L, EW) < L) {
+    atomicOr(err, 1u);  // "Read ... was not found in seqset" (make_readmap.cpp:147-151)
+    lo = 0;
+  }
+  eid[o] = lo;
+}
+
+// rows of record r (pair r = reads 2r, 2r+1 when paired, else read r); unused slots get hi = ~0
+__global__ void k_rm_rows(const uint64_t* __restrict__ words, const uint16_t* __restrict__ len, uint64_t n_rec, int W,
+                          int paired, const uint64_t* __restrict__ eid, uint64_t* __restrict__ hi,
+                          uint64_t* __restrict__ lo) {
+  uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= n_rec) return;
+  const int per = paired ? 4 : 2;
+  uint64_t* h = hi + r * per;
+  uint64_t* l = lo + r * per;
+  for (int t = 0; t < per; ++t) { h[t] = ~0ull; l[t] = 0; }
+  uint64_t a = paired ? 2 * r : r, b = a + 1;
+  int la = len[a], lb = paired ? int(len[b]) : 0;
+  if (!la && !lb) return;
+  if (!la) { a = b; la = lb; lb = 0; }  // the surviving mate alone (biograph_create.cpp:880-889)
+  uint64_t e = eid[2 * a], erc = eid[2 * a + 1];
+  if (lb) {
+    uint64_t me = eid[2 * b], merc = eid[2 * b + 1];
+    uint32_t rl = uint32_t(la), ml = uint32_t(lb);
+    if (key_compare(words + a * W, la, words + b * W, lb, W) > 0) {  // canonical order (:171-176)
+      uint64_t t = me; me = e; e = t;
+      t = merc; merc = erc; erc = t;
+      uint32_t u = ml; ml = rl; rl = u;
+    }
+    h[0] = rm_hi(e, 0, rl, 0);      l[0] = erc;
+    h[1] = rm_hi(erc, 1, rl, ml);   l[1] = me;
+    h[2] = rm_hi(me, 2, ml, 0);     l[2] = merc;
+    h[3] = rm_hi(merc, 3, ml, 0);   l[3] = kNoLoopEntry;
+  } else {
+    h[0] = rm_hi(e, 0, uint32_t(la), 0);    l[0] = erc;
+    h[1] = rm_hi(erc, 1, uint32_t(la), 0);  l[1] = kNoLoopEntry;
+  }
+}
+
+__global__ void k_rm_flag_valid(const uint64_t* __restrict__ hi, uint64_t n, uint8_t* __restrict__ f) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) f[i] = hi[i] != ~0ull;
+}
+__global__ void k_rm_flag_type(const uint64_t* __restrict__ hi, uint64_t n, int type, uint8_t* __restrict__ f) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) f[i] = hi_type(hi[i]) == type;
+}
+
+// per sorted row: read length, is_forward, group-head flag, entry marks
+__global__ void k_rm_row_fields(const uint64_t* __restrict__ hi, uint64_t n, uint64_t* __restrict__ read_len,
+                                uint64_t* __restrict__ is_fwd, uint8_t* __restrict__ head,
+                                uint8_t* __restrict__ entry_marks) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t h = hi[i];
+  read_len[i] = hi_len(h);
+  int t = hi_type(h);
+  is_fwd[i] = (t == 0 || t == 2) ? 1 : 0;
+  head[i] = (i == 0 || hi_entry(hi[i - 1]) != hi_entry(h)) ? 1 : 0;
+  entry_marks[hi_entry(h)] = 1;
+}
+
+// bytes -> bits (bit i = word i/64 bit i%64), one wave per word
+__global__ __launch_bounds__(256) void k_bytes_to_bits(const uint8_t* __restrict__ marks, uint64_t n,
+                                                       unsigned long long* __restrict__ bits) {
+  uint64_t w = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (w >= (n + 63) / 64) return;
+  uint64_t t = w * 64 + (threadIdx.x & 63);
+  uint64_t word = __ballot(t < n && marks[t] != 0);
+  if ((threadIdx.x & 63) == 0) bits[w] = word;
+}
+
+__device__ __forceinline__ uint64_t lower_bound_u64(const uint64_t* __restrict__ a, uint64_t n, uint64_t v) {
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// hop 1: LOOP_START row i -> first RC row of (loop_entry, read_len)                 (:283-302)
+__global__ void k_rm_group_rc(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, uint64_t n,
+                              const uint32_t* __restrict__ starts, uint64_t ns, uint64_t* __restrict__ g,
+                              uint32_t* __restrict__ ord) {
+  uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  uint32_t i = starts[s];
+  g[s] = lower_bound_u64(hi, n, rm_hi(lo[i], 1, hi_len(hi[i]), 0));
+  ord[s] = uint32_t(s);
+}
+
+// claimed row = group start + rank among the claimers of that group (claimers sorted stably by group,
+// i.e. in row order inside a group)
+__global__ void k_rm_claim(const uint64_t* __restrict__ gs, const uint32_t* __restrict__ ords, uint64_t ns,
+                           uint64_t n_rows, uint32_t* __restrict__ claimed) {
+  uint64_t p = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= ns) return;
+  uint64_t g = gs[p];
+  if (g >= n_rows) { claimed[ords[p]] = 0xffffffffu; return; }  // claimer without this hop
+  uint64_t first = lower_bound_u64(gs, ns, g);
+  claimed[ords[p]] = uint32_t(g + (p - first));
+}
+
+// after hop 1: check the RC row, close unpaired loops, open hop 2                     (:352-365)
+__global__ void k_rm_after_rc(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, uint64_t n,
+                              const uint32_t* __restrict__ starts, const uint32_t* __restrict__ rc, uint64_t ns,
+                              uint64_t* __restrict__ ptr, uint64_t* __restrict__ g, uint32_t* __restrict__ ord,
+                              uint32_t* __restrict__ err) {
+  uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  uint32_t i = starts[s], r = rc[s];
+  ord[s] = uint32_t(s);
+  if (r >= n || hi_type(hi[r]) != 1 || hi_entry(hi[r]) != lo[i] || hi_len(hi[r]) != hi_len(hi[i])) {
+    atomicOr(err, 2u);
+    g[s] = ~0ull;
+    return;
+  }
+  ptr[i] = r;
+  if (lo[r] == kNoLoopEntry) {  // no mate: RC points back to the start
+    ptr[r] = i;
+    g[s] = ~0ull;
+    return;
+  }
+  g[s] = lower_bound_u64(hi, n, rm_hi(lo[r], 2, hi_mate_len(hi[r]), 0));
+}
+
+__global__ void k_rm_after_mate(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, uint64_t n,
+                                const uint32_t* __restrict__ rc, const uint32_t* __restrict__ mate, uint64_t ns,
+                                uint64_t* __restrict__ ptr, uint64_t* __restrict__ g, uint32_t* __restrict__ ord,
+                                uint32_t* __restrict__ err) {
+  uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  ord[s] = uint32_t(s);
+  uint32_t m = mate[s];
+  if (m == 0xffffffffu) { g[s] = ~0ull; return; }
+  uint32_t r = rc[s];
+  if (m >= n || hi_type(hi[m]) != 2 || hi_entry(hi[m]) != lo[r] || hi_len(hi[m]) != hi_mate_len(hi[r])) {
+    atomicOr(err, 2u);
+    g[s] = ~0ull;
+    return;
+  }
+  ptr[r] = m;
+  g[s] = lower_bound_u64(hi, n, rm_hi(lo[m], 3, hi_mate_len(hi[r]), 0));
+}
+
+__global__ void k_rm_after_mate_rc(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, uint64_t n,
+                                   const uint32_t* __restrict__ starts, const uint32_t* __restrict__ rc,
+                                   const uint32_t* __restrict__ mate, const uint32_t* __restrict__ mrc, uint64_t ns,
+                                   uint64_t* __restrict__ ptr, uint32_t* __restrict__ err) {
+  uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  uint32_t x = mrc[s];
+  if (x == 0xffffffffu) return;
+  uint32_t m = mate[s], r = rc[s];
+  if (x >= n || hi_type(hi[x]) != 3 || hi_entry(hi[x]) != lo[m] || hi_len(hi[x]) != hi_mate_len(hi[r])) {
+    atomicOr(err, 2u);
+    return;
+  }
+  ptr[m] = x;
+  ptr[x] = starts[s];  // loop back to the beginning (:389)
+}
+
+// LSB-first packing of n values at `bits` bits each (packed_varbit_vector.cpp:80-147, packed_vector.h)
+__global__ void k_pack_bits_u64(const uint64_t* __restrict__ vals, uint64_t n, int bits, uint64_t nwords,
+                                uint64_t* __restrict__ out) {
+  uint64_t w = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  uint64_t bit_lo = w * 64, bit_hi = bit_lo + 64;
+  uint64_t word = 0;
+  for (uint64_t i = bit_lo / bits; i < n; ++i) {
+    uint64_t b = i * bits;
+    if (b >= bit_hi) break;
+    uint64_t v = vals[i];
+    if (b >= bit_lo) word |= v << (b - bit_lo);
+    else word |= v >> (bit_lo - b);
+  }
+  out[w] = word;
+}
+
+__global__ void k_iota32(uint32_t* __restrict__ a, uint64_t n) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = uint32_t(i);
+}
+__global__ void k_gather64(const uint64_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n,
+                           uint64_t* __restrict__ dst) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void k_bitcount_groups_rm(const uint64_t* __restrict__ bits, uint64_t nwords, uint64_t ngroups,
+                                     uint64_t* __restrict__ subaccum, uint32_t* __restrict__ group_pop) {
+  uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= ngroups) return;
+  uint64_t sub = 0;
+  uint32_t tot = 0;
+  for (int j = 0; j < 8; ++j) {
+    uint64_t wi = g * 8 + j;
+    uint32_t pc = wi < nwords ? uint32_t(__popcll(bits[wi])) : 0u;
+    sub = (sub << 8) | pc;
+    tot += pc;
+  }
+  subaccum[g] = sub;
+  group_pop[g] = tot;
+}
+
+// bitcount::finalize (io/bitcount.cpp:84-124) for a plain bit vector
+static int bitcount_finalize(bg_ctx* ctx, const DevBuf<uint64_t>& bits, uint64_t nbits, DevBuf<uint64_t>* subaccum,
+                             DevBuf<uint64_t>* accum) {
+  const uint64_t nwords = (nbits + 63) / 64, ngroups = (nbits + 511) / 512, naccum = (nbits + 512) / 512;
+  DevBuf<uint32_t> gp;
+  DevBuf<uint64_t> total;
+  BG_TRY(gp.alloc(ctx, ngroups));
+  BG_TRY(total.alloc(ctx, 1));
+  BG_TRY(subaccum->alloc(ctx, ngroups));
+  BG_TRY(accum->alloc(ctx, naccum));
+  BG_HIP(hipMemsetAsync(accum->p, 0, naccum * 8, ctx->stream));
+  if (ngroups) {
+    k_bitcount_groups_rm<<<cdiv(ngroups, 256), 256, 0, ctx->stream>>>(bits.p, nwords, ngroups, subaccum->p, gp.p);
+    BG_LAUNCH_CHECK();
+  }
+  BG_TRY(exclusive_scan_u32_to_u64(ctx, gp.p, accum->p, ngroups, total.p));
+  if (naccum > ngroups)
+    BG_HIP(hipMemcpyAsync(accum->p + ngroups, total.p, 8, hipMemcpyDeviceToDevice, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+// stable sort of (key, payload) pairs; returns pointers to the sorted arrays
+static int sort_pairs(bg_ctx* ctx, DevBuf<uint64_t>& ka, DevBuf<uint64_t>& kb, DevBuf<uint32_t>& va,
+                      DevBuf<uint32_t>& vb, uint64_t n, int bit_hi, uint64_t** ks, uint32_t** vs) {
+  bool in_b = false;
+  BG_TRY(radix_sort_u64(ctx, ka.p, kb.p, va.p, vb.p, n, 0, bit_hi, &in_b));
+  *ks = in_b ? kb.p : ka.p;
+  *vs = in_b ? vb.p : va.p;
+  return BG_OK;
+}
+
+}  // namespace bg
+
+struct bg_readmap {
+  bg_ctx* ctx = nullptr;
+  uint64_t n_reads = 0, n_entries = 0;
+  uint32_t max_read_len = 0;
+  std::string seqset_uuid;
+  bg::DevBuf<uint64_t> read_len, mate_loop_ptr, is_forward;  // one u64 per read id (packed on demand)
+  bg::DevBuf<uint64_t> s2m_bits, s2m_sub, s2m_acc, d2m_bits, d2m_sub, d2m_acc;
+};
+
+using namespace bg;
+
+extern "C" int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads* reads, int is_paired,
+                                bg_readmap** out) {
+  if (!ctx || !ss || !reads || !out) { set_error("bg_readmap_build: null argument"); return BG_EINVAL; }
+  if (ss->n && (!ss->keys.p || !ss->W)) { set_error("bg_readmap_build: the seqset has no resident entry keys (build it in this process)"); return BG_EINVAL; }
+  if (reads->W > ss->W && ss->n) { set_error("bg_readmap_build: reads longer than the seqset's entries"); return BG_EINVAL; }
+  if (is_paired && (reads->n & 1)) { set_error("bg_readmap_build: paired input needs an even number of reads"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  const uint64_t n = reads->n, n_o = 2 * n, n_ent = ss->n;
+  const int W = reads->W, EW = ss->W ? ss->W : W;
+  if (n_o >= (1ull << 32) || n_ent >= (1ull << 32)) { set_error("bg_readmap_build: shard too large"); return BG_EINVAL; }
+  std::unique_ptr<bg_readmap> rm(new bg_readmap);
+  rm->ctx = ctx;
+  rm->n_entries = n_ent;
+  rm->seqset_uuid = ss->uuid;
+  rm->max_read_len = ss->max_len;  // seqset::max_read_len() (biograph_create.cpp:825)
+  DevBuf<uint32_t> err;
+  BG_TRY(err.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+
+  // ---- 1. entry ids
+  DevBuf<uint64_t> eid;
+  BG_TRY(eid.alloc(ctx, n_o));
+  {
+    DevBuf<uint32_t> dir;
+    const uint64_t nb = 1ull << (2 * kPrefixBasesRm);
+    BG_TRY(dir.alloc(ctx, nb + 1));
+    ctx->tic("readmap_entry_ids");
+    k_rm_prefix_dir<<<cdiv(n_ent + 1, 256), 256, 0, ctx->stream>>>(ss->keys.p, n_ent, EW, dir.p);
+    BG_LAUNCH_CHECK();
+    if (n_o) {
+      k_rm_entry_ids<<<cdiv(n_o, 128), 128, 0, ctx->stream>>>(reads->words.p, reads->len.p, n_o, W, ss->keys.p,
+                                                              ss->sizes.p, n_ent, EW, dir.p, eid.p, err.p);
+      BG_LAUNCH_CHECK();
+    }
+    ctx->toc(n_o * (W * 8 + 64));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+
+  // ---- 2. rows, sorted by (hi, lo)
+  const uint64_t n_rec = is_paired ? n / 2 : n;
+  const uint64_t n_slots = n_rec * (is_paired ? 4 : 2);
+  DevBuf<uint64_t> hi_s, lo_s;  // sorted rows
+  uint64_t n_rows = 0;
+  {
+    DevBuf<uint64_t> hi, lo, ka, kb;
+    DevBuf<uint32_t> va, vb;
+    BG_TRY(hi.alloc(ctx, n_slots));
+    BG_TRY(lo.alloc(ctx, n_slots));
+    BG_TRY(ka.alloc(ctx, n_slots));
+    BG_TRY(kb.alloc(ctx, n_slots));
+    BG_TRY(va.alloc(ctx, n_slots));
+    BG_TRY(vb.alloc(ctx, n_slots));
+    if (n_rec) {
+      k_rm_rows<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->len.p, n_rec, W, is_paired ? 1 : 0,
+                                                          eid.p, hi.p, lo.p);
+      BG_LAUNCH_CHECK();
+      // LSD: by lo (37 bits) then by hi (stable)
+      BG_HIP(hipMemcpyAsync(ka.p, lo.p, n_slots * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      k_iota32<<<cdiv(n_slots, 256), 256, 0, ctx->stream>>>(va.p, n_slots);
+      BG_LAUNCH_CHECK();
+    }
+    uint64_t* ks = nullptr;
+    uint32_t* vs = nullptr;
+    BG_TRY(sort_pairs(ctx, ka, kb, va, vb, n_slots, 37, &ks, &vs));
+    uint64_t* k2 = ks == ka.p ? kb.p : ka.p;
+    uint32_t* v2 = vs == va.p ? vb.p : va.p;
+    if (n_slots) {
+      k_gather64<<<cdiv(n_slots, 256), 256, 0, ctx->stream>>>(hi.p, vs, n_slots, k2);
+      BG_LAUNCH_CHECK();
+    }
+    // second sort: keys k2 (hi), payload vs; scratch = the other pair
+    bool in_b = false;
+    BG_TRY(radix_sort_u64(ctx, k2, ks, vs, v2, n_slots, 0, 64, &in_b));
+    uint64_t* hsorted = in_b ? ks : k2;
+    uint32_t* perm = in_b ? v2 : vs;
+    DevBuf<uint8_t> f;
+    DevBuf<uint32_t> valid_pos;
+    BG_TRY(f.alloc(ctx, n_slots));
+    if (n_slots) {
+      k_rm_flag_valid<<<cdiv(n_slots, 256), 256, 0, ctx->stream>>>(hsorted, n_slots, f.p);
+      BG_LAUNCH_CHECK();
+    }
+    BG_TRY(compact_flagged<uint32_t>(ctx, f.p, n_slots, &valid_pos, &n_rows));  // valid rows are a prefix
+    BG_TRY(hi_s.alloc(ctx, n_rows));
+    BG_TRY(lo_s.alloc(ctx, n_rows));
+    if (n_rows) {
+      BG_HIP(hipMemcpyAsync(hi_s.p, hsorted, n_rows * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      k_gather64<<<cdiv(n_rows, 256), 256, 0, ctx->stream>>>(lo.p, perm, n_rows, lo_s.p);
+      BG_LAUNCH_CHECK();
+    }
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  eid.reset();
+  rm->n_reads = n_rows;
+  if (n_rows >= (1ull << 32)) { set_error("bg_readmap_build: too many read ids"); return BG_EINVAL; }
+
+  // ---- 3. per-row fields + sparse_multi
+  BG_TRY(rm->read_len.alloc(ctx, n_rows));
+  BG_TRY(rm->is_forward.alloc(ctx, n_rows));
+  BG_TRY(rm->mate_loop_ptr.alloc(ctx, n_rows));
+  BG_TRY(rm->s2m_bits.alloc(ctx, (n_ent + 63) / 64));
+  BG_TRY(rm->d2m_bits.alloc(ctx, (n_rows + 63) / 64));
+  {
+    DevBuf<uint8_t> head, marks;
+    BG_TRY(head.alloc(ctx, n_rows));
+    BG_TRY(marks.alloc(ctx, n_ent));
+    if (n_ent) BG_HIP(hipMemsetAsync(marks.p, 0, n_ent, ctx->stream));
+    if (n_rows) {
+      BG_HIP(hipMemsetAsync(rm->mate_loop_ptr.p, 0, n_rows * 8, ctx->stream));
+      k_rm_row_fields<<<cdiv(n_rows, 256), 256, 0, ctx->stream>>>(hi_s.p, n_rows, rm->read_len.p, rm->is_forward.p,
+                                                                 head.p, marks.p);
+      BG_LAUNCH_CHECK();
+      k_bytes_to_bits<<<cdiv((n_rows + 63) / 64, 4), 256, 0, ctx->stream>>>(
+          head.p, n_rows, reinterpret_cast<unsigned long long*>(rm->d2m_bits.p));
+      BG_LAUNCH_CHECK();
+    }
+    if (n_ent) {
+      k_bytes_to_bits<<<cdiv((n_ent + 63) / 64, 4), 256, 0, ctx->stream>>>(
+          marks.p, n_ent, reinterpret_cast<unsigned long long*>(rm->s2m_bits.p));
+      BG_LAUNCH_CHECK();
+    }
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  BG_TRY(bitcount_finalize(ctx, rm->s2m_bits, n_ent, &rm->s2m_sub, &rm->s2m_acc));
+  BG_TRY(bitcount_finalize(ctx, rm->d2m_bits, n_rows, &rm->d2m_sub, &rm->d2m_acc));
+
+  // ---- 4. mate loops: three claim hops
+  if (n_rows) {
+    DevBuf<uint8_t> f;
+    DevBuf<uint32_t> starts;
+    uint64_t ns = 0;
+    BG_TRY(f.alloc(ctx, n_rows));
+    k_rm_flag_type<<<cdiv(n_rows, 256), 256, 0, ctx->stream>>>(hi_s.p, n_rows, 0, f.p);
+    BG_LAUNCH_CHECK();
+    BG_TRY(compact_flagged<uint32_t>(ctx, f.p, n_rows, &starts, &ns));
+    DevBuf<uint64_t> ga, gb;
+    DevBuf<uint32_t> oa, ob, rc, mate, mrc;
+    BG_TRY(ga.alloc(ctx, ns));
+    BG_TRY(gb.alloc(ctx, ns));
+    BG_TRY(oa.alloc(ctx, ns));
+    BG_TRY(ob.alloc(ctx, ns));
+    BG_TRY(rc.alloc(ctx, ns));
+    BG_TRY(mate.alloc(ctx, ns));
+    BG_TRY(mrc.alloc(ctx, ns));
+    if (ns) {
+      ctx->tic("readmap_mate_loops");
+      uint64_t* gs = nullptr;
+      uint32_t* os = nullptr;
+      k_rm_group_rc<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(hi_s.p, lo_s.p, n_rows, starts.p, ns, ga.p, oa.p);
+      BG_LAUNCH_CHECK();
+      BG_TRY(sort_pairs(ctx, ga, gb, oa, ob, ns, 64, &gs, &os));
+      k_rm_claim<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(gs, os, ns, n_rows, rc.p);
+      BG_LAUNCH_CHECK();
+      k_rm_after_rc<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(hi_s.p, lo_s.p, n_rows, starts.p, rc.p, ns,
+                                                             rm->mate_loop_ptr.p, ga.p, oa.p, err.p);
+      BG_LAUNCH_CHECK();
+      BG_TRY(sort_pairs(ctx, ga, gb, oa, ob, ns, 64, &gs, &os));
+      k_rm_claim<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(gs, os, ns, n_rows, mate.p);
+      BG_LAUNCH_CHECK();
+      k_rm_after_mate<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(hi_s.p, lo_s.p, n_rows, rc.p, mate.p, ns,
+                                                               rm->mate_loop_ptr.p, ga.p, oa.p, err.p);
+      BG_LAUNCH_CHECK();
+      BG_TRY(sort_pairs(ctx, ga, gb, oa, ob, ns, 64, &gs, &os));
+      k_rm_claim<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(gs, os, ns, n_rows, mrc.p);
+      BG_LAUNCH_CHECK();
+      k_rm_after_mate_rc<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(hi_s.p, lo_s.p, n_rows, starts.p, rc.p, mate.p, mrc.p,
+                                                                  ns, rm->mate_loop_ptr.p, err.p);
+      BG_LAUNCH_CHECK();
+      ctx->toc(ns * 64);
+    }
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  uint32_t h_err = 0;
+  BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_err & 1) { set_error("bg_readmap_build: a read was not found in the seqset"); return BG_EINTERNAL; }
+  if (h_err & 2) { set_error("bg_readmap_build: mate loop claim failed (inconsistent rows)"); return BG_EINTERNAL; }
+  *out = rm.release();
+  return BG_OK;
+}
+
+extern "C" uint64_t bg_readmap_size(const bg_readmap* rm) { return rm ? rm->n_reads : 0; }
+extern "C" uint32_t bg_readmap_max_read_len(const bg_readmap* rm) { return rm ? rm->max_read_len : 0; }
+extern "C" void bg_readmap_free(bg_readmap* rm) { delete rm; }
+
+static unsigned rm_bits_for_value(uint64_t v) { unsigned b = 0; while (v) { ++b; v >>= 1; } return b; }
+
+static int rm_part_bytes(bg_ctx* ctx, const bg_readmap* rm, const std::string& part, std::string* out) {
+  auto dl = [&](const uint64_t* d, uint64_t words) -> int {
+    out->resize(words * 8);
+    if (!words) return BG_OK;
+    BG_HIP(hipMemcpyAsync(&(*out)[0], d, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    return BG_OK;
+  };
+  const uint64_t n = rm->n_reads, ne = rm->n_entries;
+  if (part == "read_ids/source_to_mid/bits") return dl(rm->s2m_bits.p, (ne + 63) / 64);
+  if (part == "read_ids/source_to_mid/subaccum") return dl(rm->s2m_sub.p, (ne + 511) / 512);
+  if (part == "read_ids/source_to_mid/accum") return dl(rm->s2m_acc.p, (ne + 512) / 512);
+  if (part == "read_ids/dest_to_mid/bits") return dl(rm->d2m_bits.p, (n + 63) / 64);
+  if (part == "read_ids/dest_to_mid/subaccum") return dl(rm->d2m_sub.p, (n + 511) / 512);
+  if (part == "read_ids/dest_to_mid/accum") return dl(rm->d2m_acc.p, (n + 512) / 512);
+  const uint64_t* src = nullptr;
+  int bits = 0;
+  if (part == "read_lengths/elements") { src = rm->read_len.p; bits = int(rm_bits_for_value(rm->max_read_len)); }
+  else if (part == "mate_loop_ptr/elements") { src = rm->mate_loop_ptr.p; bits = int(rm_bits_for_value(n)); }
+  else if (part == "is_forward/packed_data") { src = rm->is_forward.p; bits = 1; }
+  else { set_error("bg_readmap_part: unknown part '%s'", part.c_str()); return BG_EINVAL; }
+  uint64_t nwords = (n * uint64_t(bits) + 63) / 64;
+  out->resize(nwords * 8);
+  if (!nwords) return BG_OK;
+  DevBuf<uint64_t> packed;
+  BG_TRY(packed.alloc(ctx, nwords));
+  k_pack_bits_u64<<<cdiv(nwords, 256), 256, 0, ctx->stream>>>(src, n, bits, nwords, packed.p);
+  BG_LAUNCH_CHECK();
+  return dl(packed.p, nwords);
+}
+
+extern "C" int bg_readmap_part(bg_ctx* ctx, const bg_readmap* rm, const char* part, void* h_out, uint64_t* size) {
+  if (!ctx || !rm || !part || !size) { set_error("bg_readmap_part: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::string data;
+  BG_TRY(rm_part_bytes(ctx, rm, part, &data));
+  if (h_out) {
+    if (*size < data.size()) { *size = data.size(); set_error("bg_readmap_part: buffer too small"); return BG_EINVAL; }
+    memcpy(h_out, data.data(), data.size());
+  }
+  *size = data.size();
+  return BG_OK;
+}
+
+static std::string rm_version_json(const char* type, int maj, int min, int pat) {
+  char buf[256];
+  snprintf(buf, sizeof buf,
+           "{\"part_type\":\"%s\",\"version\":{\"build\":\"\",\"major\":%d,\"minor\":%d,\"patch\":%d,\"pre\":\"\"}}", type,
+           maj, min, pat);
+  return buf;
+}
+
+// Spiral container of the readmap (member order of make_readmap::create_common / create_from_reads,
+// as found in father_lambda.bg/coverage/*.readmap).  h_sha1_hex (41 bytes) receives the SHA-1 of the
+// written file: the reference names the file after it (biograph_create.cpp:827-828).
+extern "C" int bg_readmap_write(bg_ctx* ctx, const bg_readmap* rm, const char* path, int argc,
+                                const char* const* argv, char* h_sha1_hex) {
+  if (!ctx || !rm || !path) { set_error("bg_readmap_write: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::vector<ZipPart> parts;
+  time_t now = time(nullptr);
+  char tbuf[64];
+  ctime_r(&now, tbuf);
+  std::string ttext(tbuf);
+  if (!ttext.empty() && ttext.back() == '\n') ttext.pop_back();
+  std::string cmd = "[";
+  for (int i = 0; i < argc; ++i) {
+    if (i) cmd += ",";
+    cmd += "\"";
+    for (const char* c = argv[i] ? argv[i] : ""; *c; ++c) {
+      if (*c == '"' || *c == '\\') cmd.push_back('\\');
+      cmd.push_back(*c);
+    }
+    cmd += "\"";
+  }
+  cmd += "]";
+  std::string uuid = make_uuid();
+  char fi[4096];
+  snprintf(fi, sizeof fi,
+           "{\"build_host\":\"\",\"build_is_clean\":true,\"build_revision\":\"biograph_amd\",\"build_timestamp\":0,"
+           "\"build_timestamp_text\":\"\",\"build_user\":\"\",\"command_line\":%s,\"create_timestamp\":%lld,"
+           "\"create_timestamp_text\":\"%s\",\"uuid\":\"%s\"}",
+           cmd.c_str(), (long long)now, ttext.c_str(), uuid.c_str());
+  parts.push_back(ZipPart{"file_info.json", fi, false});
+  parts.push_back(ZipPart{"part_info.json", rm_version_json("readmap", 1, 2, 0), false});
+  parts.push_back(ZipPart{"readmap.json", "{\"seqset_uuid\":\"" + rm->seqset_uuid + "\"}", false});
+  parts.push_back(ZipPart{"read_ids/part_info.json", rm_version_json("sparse_multi", 1, 0, 0), false});
+  std::string data;
+  char js[128];
+  for (int sel = 0; sel < 2; ++sel) {
+    std::string dir = sel ? "read_ids/dest_to_mid" : "read_ids/source_to_mid";
+    parts.push_back(ZipPart{dir + "/part_info.json", rm_version_json("bitcount", 1, 0, 0), false});
+    snprintf(js, sizeof js, "{\"nbits\":%llu}", (unsigned long long)(sel ? rm->n_reads : rm->n_entries));
+    parts.push_back(ZipPart{dir + "/bitcount.json", js, false});
+    for (const char* w : {"bits", "subaccum", "accum"}) {
+      BG_TRY(rm_part_bytes(ctx, rm, dir + "/" + w, &data));
+      parts.push_back(ZipPart{dir + "/" + w, data, true});
+    }
+  }
+  for (int which = 0; which < 2; ++which) {
+    std::string dir = which ? "mate_loop_ptr" : "read_lengths";
+    uint64_t maxv = which ? rm->n_reads : rm->max_read_len;
+    parts.push_back(ZipPart{dir + "/part_info.json", rm_version_json("packed_varbit_vector", 1, 0, 0), false});
+    snprintf(js, sizeof js, "{\"bits_per_value\":%u,\"element_count\":%llu,\"max_value\":%llu}", rm_bits_for_value(maxv),
+             (unsigned long long)rm->n_reads, (unsigned long long)maxv);
+    parts.push_back(ZipPart{dir + "/packed_varbit_vector.json", js, false});
+    BG_TRY(rm_part_bytes(ctx, rm, dir + "/elements", &data));
+    parts.push_back(ZipPart{dir + "/elements", data, true});
+  }
+  parts.push_back(ZipPart{"is_forward/part_info.json", rm_version_json("packed_vector", 1, 0, 0), false});
+  BG_TRY(rm_part_bytes(ctx, rm, "is_forward/packed_data", &data));
+  parts.push_back(ZipPart{"is_forward/packed_data", data, true});
+  snprintf(js, sizeof js, "{\"value_count\":%llu,\"value_width_bits\":1}", (unsigned long long)rm->n_reads);
+  parts.push_back(ZipPart{"is_forward/packed_vector.json", js, false});
+  BG_TRY(spiral_zip_write(path, parts));
+  if (h_sha1_hex) BG_TRY(sha1_file_hex(path, h_sha1_hex));
+  return BG_OK;
+}

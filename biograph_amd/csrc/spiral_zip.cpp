@@ -221,4 +221,57 @@ int spiral_zip_read(const char* path, std::map<std::string, std::string>* parts)
   return BG_OK;
 }
 
+// SHA-1 of a file (FIPS 180-1): the reference names coverage/<sha1>.readmap after the digest of the
+// written container (biograph_create.cpp:827-828, sha1_hash over the file).
+int sha1_file_hex(const char* path, char* hex41) {
+  FILE* f = fopen(path, "rb");
+  if (!f) { set_error("%s: %s", path, strerror(errno)); return BG_EIO; }
+  uint32_t h[5] = {0x67452301u, 0xEFCDAB89u, 0x98BADCFEu, 0x10325476u, 0xC3D2E1F0u};
+  auto block = [&](const uint8_t* b) {
+    uint32_t w[80];
+    for (int i = 0; i < 16; ++i)
+      w[i] = uint32_t(b[4 * i]) << 24 | uint32_t(b[4 * i + 1]) << 16 | uint32_t(b[4 * i + 2]) << 8 | b[4 * i + 3];
+    for (int i = 16; i < 80; ++i) {
+      uint32_t x = w[i - 3] ^ w[i - 8] ^ w[i - 14] ^ w[i - 16];
+      w[i] = x << 1 | x >> 31;
+    }
+    uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4];
+    for (int i = 0; i < 80; ++i) {
+      uint32_t fn, k;
+      if (i < 20) { fn = (bb & c) | (~bb & d); k = 0x5A827999u; }
+      else if (i < 40) { fn = bb ^ c ^ d; k = 0x6ED9EBA1u; }
+      else if (i < 60) { fn = (bb & c) | (bb & d) | (c & d); k = 0x8F1BBCDCu; }
+      else { fn = bb ^ c ^ d; k = 0xCA62C1D6u; }
+      uint32_t t = (a << 5 | a >> 27) + fn + e + k + w[i];
+      e = d; d = c; c = bb << 30 | bb >> 2; bb = a; a = t;
+    }
+    h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e;
+  };
+  std::vector<uint8_t> buf(1 << 20);
+  uint8_t tail[128];
+  size_t ntail = 0;
+  uint64_t total = 0;
+  for (;;) {
+    size_t got = fread(buf.data(), 1, buf.size(), f);
+    total += got;
+    size_t full = got / 64 * 64;
+    for (size_t o = 0; o < full; o += 64) block(buf.data() + o);
+    if (got < buf.size()) {
+      ntail = got - full;
+      memcpy(tail, buf.data() + full, ntail);
+      break;
+    }
+  }
+  bool bad = ferror(f) != 0;
+  fclose(f);
+  if (bad) { set_error("%s: read error", path); return BG_EIO; }
+  tail[ntail++] = 0x80;
+  while (ntail % 64 != 56) tail[ntail++] = 0;
+  uint64_t bits = total * 8;
+  for (int i = 7; i >= 0; --i) tail[ntail++] = uint8_t(bits >> (8 * i));
+  for (size_t o = 0; o < ntail; o += 64) block(tail + o);
+  snprintf(hex41, 41, "%08x%08x%08x%08x%08x", h[0], h[1], h[2], h[3], h[4]);
+  return BG_OK;
+}
+
 }  // namespace bg

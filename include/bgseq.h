@@ -202,6 +202,36 @@ int bg_ref_map_build(bg_ctx* ctx, const bg_seqset* ss, const uint8_t* d_ref_code
                      const uint64_t* h_ext_start, const uint64_t* h_ext_size, uint32_t chain_bases,
                      uint8_t* d_out);
 
+/* ---- Readmap: make_readmap::create_from_reads
+ * (modules/bio_mapred/make_readmap.cpp:120-392) over the corrected reads of one sample.
+ * `ss` must hold resident entry keys (a seqset built in this process by bg_seqset_build / bg_create);
+ * `corrected` is what bg_correct_reads returned (dropped reads have length 0).  With is_paired != 0,
+ * reads 2i and 2i+1 are mates (the order bg_pack_reads received them in; unpaired_reads / paired_reads
+ * of corrected_reads.h); a pair whose mate was dropped contributes the surviving read unpaired
+ * (biograph_create.cpp:880-889).  Read ids are the rows of the (entry, type, lengths, loop entry)
+ * total order (make_readmap.h:187-213).  BG_EINTERNAL if a read is absent from the seqset (:147-151). */
+typedef struct bg_readmap bg_readmap;
+int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads* corrected, int is_paired,
+                     bg_readmap** out);
+uint64_t bg_readmap_size(const bg_readmap* rm);         /* readmap::size(), number of read ids */
+uint32_t bg_readmap_max_read_len(const bg_readmap* rm); /* readmap::max_read_len() */
+/* Raw bytes of one mmap part of the container, named as in the spiral file:
+ * "read_ids/{source_to_mid,dest_to_mid}/{bits,subaccum,accum}", "read_lengths/elements",
+ * "mate_loop_ptr/elements", "is_forward/packed_data".  Same size protocol as bg_seqset_part. */
+int bg_readmap_part(bg_ctx* ctx, const bg_readmap* rm, const char* part, void* h_out, uint64_t* size);
+/* Writes the readmap container (readmap 1.2.0: sparse_multi read_ids, packed_varbit_vector
+ * read_lengths / mate_loop_ptr, 1-bit is_forward; readmap.json binds it to the seqset uuid).
+ * h_sha1_hex (41 bytes, may be null) receives the SHA-1 of the file, which names it
+ * coverage/<sha1>.readmap in a .bg directory (biograph_create.cpp:827-828). */
+int bg_readmap_write(bg_ctx* ctx, const bg_readmap* rm, const char* path, int argc, const char* const* argv,
+                     char* h_sha1_hex);
+void bg_readmap_free(bg_readmap* rm);
+/* bg_create() plus the sample's readmap: the whole data path of SEQSETMain::run
+ * (biograph_create.cpp:431-831: kmerize, correct, make_seqset, make_readmap). */
+int bg_create_sample(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n_reads,
+                     const bg_create_params* p, int is_paired, bg_seqset** out, bg_readmap** out_rm,
+                     bg_build_stats* stats);
+
 /* ---- Sharded build (one process per GPU).  The library never communicates: these
  * entry points expose the phases of bg_create() at the exchange points; the host moves the buffers
  * with RCCL (torch.distributed all_to_all / all_gather) — see biograph_amd/sharded.py.

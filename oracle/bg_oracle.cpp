@@ -752,6 +752,7 @@ static Readmap* readmap_build(const Seqset& ss, const std::vector<std::string>& 
   auto* rm = new Readmap;
   const size_t n = rows.size();
   rm->n_reads = n;
+  for (const auto& e : entries) max_len = std::max<unsigned>(max_len, unsigned(e.size()));  // seqset::max_read_len() (biograph_create.cpp:825)
   rm->max_read_len = max_len;
   rm->read_len.resize(n);
   rm->entry_id.resize(n);

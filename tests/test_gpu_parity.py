@@ -253,6 +253,24 @@ def test_bgbinary_create_cli_matches_golden(golden_dir, tmp_path):
         for b in range(4):
             assert (mine[w][b] == gold[w][b]).all()
     assert (mine["fixed"] == gold["fixed"]).all()
+    # the sample's readmap: coverage/<sha1>.readmap, listed in bg_info.json, bound to the seqset's uuid,
+    # and equal to the oracle's readmap of the same corrected reads (unpaired)
+    import hashlib
+    info = json.load(open(out / "metadata" / "bg_info.json"))
+    sha = info["samples"]["test_accession_id"]
+    rm_path = out / "coverage" / (sha + ".readmap")
+    assert hashlib.sha1(rm_path.read_bytes()).hexdigest() == sha
+    rmm = O.read_spiral_members(str(rm_path))
+    ss_uuid = json.loads(O.read_spiral_members(str(out / "seqset"))["file_info.json"])["uuid"]
+    assert json.loads(rmm["readmap.json"]) == {"seqset_uuid": ss_uuid}
+    reads = [l.strip() for i, l in enumerate(open(golden_dir + "/e_coli_10000snp/reads.fq")) if i % 4 == 1]
+    _, cseq, coffs, keep, _ = _oracle_stage(reads, 30, 5)
+    kept = [s for s in O.unpack_strings(cseq, coffs) if s]
+    ent = O.Entries.from_strings(O.decode_entries(gold))
+    orm = O.Readmap(O.Seqset.from_entries(ent), ent, [(s,) for s in kept], False)
+    assert json.loads(rmm["read_lengths/packed_varbit_vector.json"])["element_count"] == len(orm) == 2 * 8444
+    for name, data in orm.parts().items():
+        assert rmm[name] == data, name
     # refusing to overwrite without --force (biograph_create.cpp:497-506)
     r2 = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "create", "--reads",
                          golden_dir + "/e_coli_10000snp/reads.fq", "--out", str(out)], capture_output=True, text=True)

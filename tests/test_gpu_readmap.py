@@ -1,0 +1,133 @@
+"""GPU parity of the readmap build: bg_readmap_build through the C ABI against the oracle's
+restatement of make_readmap::create_from_reads, and against the lambda golden's container."""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+import biograph_amd as bg
+from oracle import oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = bg.Context(0)
+    yield c
+    c.close()
+
+
+def _oracle_readmap(corrected, paired):
+    """corrected: list of str ('' = dropped).  Returns (oracle Readmap, entries)."""
+    kept = [s for s in corrected if s]
+    seq, offs = O.pack_strings(kept)
+    ent = O.Entries.build(seq, offs, "simple")
+    oss = O.Seqset.from_entries(ent)
+    if paired:
+        records = []
+        for i in range(0, len(corrected), 2):
+            rec = tuple(s for s in corrected[i:i + 2] if s)
+            if rec:
+                records.append(rec)
+    else:
+        records = [(s,) for s in kept]
+    return O.Readmap(oss, ent, records, paired), ent
+
+
+def _compare(rm, orm):
+    assert rm.size() == len(orm)
+    assert rm.max_read_len == orm.max_read_len
+    want = orm.parts()
+    got = rm.parts()
+    assert sorted(want) == sorted(bg.READMAP_PART_NAMES)
+    for name in bg.READMAP_PART_NAMES:
+        assert got[name] == want[name], name
+
+
+@pytest.mark.parametrize("seed,paired,rl,var,glen,n", [(1, True, 100, False, 600, 3000), (2, True, 80, True, 2000, 2000),
+                                                        (3, False, 60, True, 1500, 1500), (4, True, 40, False, 120, 4000),
+                                                        (5, False, 33, False, 90, 2000)])
+def test_readmap_matches_oracle(ctx, seed, paired, rl, var, glen, n):
+    """Small genomes with many reads give many identical reads, i.e. big groups of identical rows: the
+    deterministic claim ranks (make_readmap.cpp:328-392) are what is under test."""
+    reads = util.synth_reads(seed, genome_len=glen, n_reads=n, read_len=rl, err=0.004, n_rate=0.0, var_len=var)
+    r = ctx.pack_reads(reads)
+    ks = ctx.kmer_count(r, 20, 3)
+    c, st = ctx.correct_reads(r, ks)
+    cseq, coffs = c.download()
+    corrected = O.unpack_strings(cseq, coffs)
+    assert any(not s for s in corrected) and sum(1 for s in corrected if s) > n // 2
+    ss, _ = ctx.build_seqset(c, 20)
+    rm = ctx.build_readmap(ss, c, paired)
+    orm, ent = _oracle_readmap(corrected, paired)
+    assert ss.entries() == ent.strings()
+    _compare(rm, orm)
+
+
+def test_readmap_degenerate(ctx):
+    c = ctx.pack_reads([])
+    ss, _ = ctx.build_seqset(c, 30)
+    rm = ctx.build_readmap(ss, c, True)
+    assert rm.size() == 0 and rm.part("read_lengths/elements") == b""
+    # a palindromic read is its own reverse complement; identical mates
+    reads = ["ACGT" * 10, "ACGT" * 10, "AAAACCCCGGGGTTTT", "", "", "TTTTTTTTTT"]
+    c = ctx.pack_reads(reads)
+    ss, _ = ctx.build_seqset(c, 30)
+    for paired in (True, False):
+        rm = ctx.build_readmap(ss, c, paired)
+        orm, _ = _oracle_readmap(reads, paired)
+        _compare(rm, orm)
+    with pytest.raises(bg.BgError):
+        ctx.build_readmap(ss, ctx.pack_reads(["ACGT"] * 3), True)  # odd count
+    with pytest.raises(bg.BgError) as e:
+        ctx.build_readmap(ss, ctx.pack_reads(["GGGGGGGGGGGGGGGGGGGG", "ACGT"]), True)  # not in the seqset
+    assert "not found" in str(e.value)
+
+
+def test_readmap_lambda_golden(ctx, golden_dir, tmp_path):
+    """The reads of the lambda golden (decoded from its readmap) through the GPU build: the seqset is the
+    golden's, the sparse_multi vectors are byte-equal to the golden file, every part equals the oracle's
+    (whose pinning against this golden is in test_oracle_golden.py), and the written container has the
+    golden's member list."""
+    d = O.load_seqset_zip(golden_dir + "/father_lambda/seqset")
+    g = O.decode_readmap(golden_dir + "/father_lambda/readmap", d)
+    flat = []
+    for rec in g["records"]:
+        flat += [rec[0], rec[1] if len(rec) == 2 else ""]
+    c = ctx.pack_reads(flat)
+    ss, _ = ctx.build_seqset(c, 30)
+    assert ss.size() == d["n"]
+    gold_parts = O.read_spiral_members(golden_dir + "/father_lambda/seqset")
+    for name in bg.PART_NAMES:
+        assert ss.part(name) == gold_parts[name], name
+    rm = ctx.build_readmap(ss, c, True)
+    assert rm.size() == 97860 and rm.max_read_len == 150
+    for sel in ("source_to_mid", "dest_to_mid"):
+        for w in ("bits", "subaccum", "accum"):
+            name = "read_ids/%s/%s" % (sel, w)
+            assert rm.part(name) == g["raw"][name], name
+    ent = O.Entries.from_strings(O.decode_entries(d))
+    orm = O.Readmap(O.Seqset.from_entries(ent), ent, g["records"], True)
+    _compare(rm, orm)
+    # container
+    ss_path, rm_path = tmp_path / "seqset", tmp_path / "readmap"
+    ss.write(ss_path, ["test"])
+    sha = rm.write(rm_path, ["bgbinary", "create"])
+    assert sha == hashlib.sha1(rm_path.read_bytes()).hexdigest()
+    mine = O.read_spiral_members(str(rm_path))
+    gold = O.read_spiral_members(golden_dir + "/father_lambda/readmap")
+    assert list(mine) == list(gold)
+    for name, data in gold.items():
+        if name in ("file_info.json", "readmap.json"):
+            continue
+        if name.endswith(".json"):
+            assert json.loads(mine[name]) == json.loads(data), name
+        elif name.startswith("read_ids/"):
+            assert mine[name] == data, name
+        else:
+            assert len(mine[name]) == len(data), name
+    ss_uuid = json.loads(O.read_spiral_members(str(ss_path))["file_info.json"])["uuid"]
+    assert json.loads(mine["readmap.json"]) == {"seqset_uuid": ss_uuid}
