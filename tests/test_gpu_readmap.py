@@ -131,3 +131,40 @@ def test_readmap_lambda_golden(ctx, golden_dir, tmp_path):
             assert len(mine[name]) == len(data), name
     ss_uuid = json.loads(O.read_spiral_members(str(ss_path))["file_info.json"])["uuid"]
     assert json.loads(mine["readmap.json"]) == {"seqset_uuid": ss_uuid}
+
+
+def test_readmap_wgs_shape_vs_oracle_and_loop_properties(ctx):
+    """30x 150 bp paired reads with errors and N's (the bench workload's shape, 200 kb genome): all parts
+    equal the oracle's; and the size-independent properties the bench-size run relies on: mate_loop_ptr is
+    a permutation made of 2- and 4-cycles fwd -> rc (-> mate fwd -> mate rc), lengths agree inside each
+    (fwd, rc) hop."""
+    from biograph_amd import synth
+    seq, offs, n = synth.make_reads(genome_len=200000, coverage=30, read_len=150, seed=5, device="cpu")
+    reads = O.unpack_strings(seq.numpy(), offs.numpy().astype(np.uint64))
+    r = ctx.pack_reads(reads)
+    ks = ctx.kmer_count(r, 30, 5)
+    c, st = ctx.correct_reads(r, ks)
+    ss, _ = ctx.build_seqset(c, 30)
+    rm = ctx.build_readmap(ss, c, True)
+    cseq, coffs = c.download()
+    corrected = O.unpack_strings(cseq, coffs)
+    orm, ent = _oracle_readmap(corrected, True)
+    _compare(rm, orm)
+    nid = rm.size()
+
+    def unpack(blob, bits):
+        w = np.frombuffer(blob, np.uint64)
+        allbits = np.unpackbits(w.view(np.uint8), bitorder="little")[:nid * bits].reshape(nid, bits)
+        return (allbits.astype(np.uint64) << np.arange(bits, dtype=np.uint64)).sum(axis=1)
+    ptr = unpack(rm.part("mate_loop_ptr/elements"), int(nid).bit_length()).astype(np.int64)
+    rl = unpack(rm.part("read_lengths/elements"), int(rm.max_read_len).bit_length())
+    fwd = unpack(rm.part("is_forward/packed_data"), 1)
+    assert sorted(ptr.tolist()) == list(range(nid))
+    p2 = ptr[ptr]
+    p4 = p2[p2]
+    assert (p4 == np.arange(nid)).all()
+    assert (fwd[ptr] != fwd).all()                       # orientation alternates along a loop
+    f = fwd == 1
+    assert (rl[ptr[f]] == rl[f]).all()                   # forward row -> its own reverse complement
+    assert int((p2 == np.arange(nid)).sum()) + int((p2 != np.arange(nid)).sum()) == nid
+    assert (p2 != np.arange(nid)).any() and (p2 == np.arange(nid)).any()   # pairs and orphans both occur
