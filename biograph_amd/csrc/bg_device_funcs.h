@@ -85,24 +85,54 @@ BG_HD uint64_t kmer_shift(uint64_t kmer, int k, int b) {  // fast_read_correct.c
 
 // ---- k-mer hash set (open addressing, linear probe; role of kmer_set::find_table_index,
 // bio_mapred/kmer_set.h:60-149).  Slot = canonical k-mer in the low 62 bits + two flag bits.
+// Probing is linear from a line-aligned start, i.e. a scan of 8-slot (64-byte) buckets: a lookup costs
+// one memory round trip unless its bucket is full, and a 64-byte line is what a probe drags from HBM
+// anyway.  (The dependent round trips of slot-at-a-time probing, taken by the slowest of a wave's 64
+// lanes, were the larger half of the read-correction screen's time.)
+constexpr int kBucketSlots = 8;
 BG_HD uint64_t hash_slot(uint64_t canon, int log2cap) {
-  return (canon * 0x9E3779B97F4A7C15ull) >> (64 - log2cap);
+  return ((canon * 0x9E3779B97F4A7C15ull) >> (64 - log2cap)) & ~uint64_t(kBucketSlots - 1);
+}
+// Inserts take the first bucket along the chain that has a free slot, any free slot of it (they start at a
+// hashed offset so that concurrent inserts do not all fight for slot 0).
+BG_HD int hash_slot_offset(uint64_t canon, int log2cap) {
+  return int(((canon * 0x9E3779B97F4A7C15ull) >> (64 - log2cap)) & uint64_t(kBucketSlots - 1));
+}
+// Slot holding `key` (compared under keymask) or -1.  Tables have at least kBucketSlots slots.
+BG_HD int64_t table_find(const uint64_t* slots, int log2cap, uint64_t key, uint64_t keymask) {
+  const uint64_t mask = (1ull << log2cap) - 1;
+  uint64_t s = hash_slot(key, log2cap);
+  for (;;) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ulonglong2* p = reinterpret_cast<const ulonglong2*>(slots + s);
+    ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
+    uint64_t v[kBucketSlots] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+    uint32_t hit = 0, empty = 0;
+#pragma unroll
+    for (int u = 0; u < kBucketSlots; ++u) {
+      hit |= uint32_t((v[u] & keymask) == key && v[u] != kEmptySlot) << u;
+      empty |= uint32_t(v[u] == kEmptySlot) << u;
+    }
+    if (hit) return int64_t(s) + (__ffs(int(hit)) - 1);
+    if (empty) return -1;
+#else
+    bool empty = false;
+    for (int u = 0; u < kBucketSlots; ++u) {
+      uint64_t v = slots[s + u];
+      if (v == kEmptySlot) empty = true;
+      else if ((v & keymask) == key) return int64_t(s + u);
+    }
+    if (empty) return -1;
+#endif
+    s = (s + kBucketSlots) & mask;
+  }
 }
 struct KmerTable {
   const uint64_t* slots;
   int log2cap;
   int k;
   // Returns slot index or -1.
-  BG_HD int64_t find(uint64_t canon) const {
-    uint64_t mask = (1ull << log2cap) - 1;
-    uint64_t s = hash_slot(canon, log2cap);
-    for (;;) {
-      uint64_t v = slots[s];
-      if (v == kEmptySlot) return -1;
-      if ((v & kKmerMask62) == canon) return int64_t(s);
-      s = (s + 1) & mask;
-    }
-  }
+  BG_HD int64_t find(uint64_t canon) const { return table_find(slots, log2cap, canon, kKmerMask62); }
   BG_HD bool has(uint64_t kmer) const {  // correct_reads.cpp:163-171 kmer_lookup_f
     bool fl;
     return find(kmer_canon(kmer, k, &fl)) >= 0;
@@ -395,28 +425,21 @@ BG_HD int cover_count(const CoverIndex& ci, const uint64_t* owords,
   int L = len[o >> 1];
   if (L == 0) return 0;
   const uint64_t* s = owords + o * W;
-  const uint64_t mask = (1ull << ci.log2cap) - 1;
   int cnt = 1;
   for (int j = 1; j < L; ++j) {
     int rem = L - j;
     if (rem >= ci.K) {
       uint64_t key = window32(s, W, j) >> (64 - 2 * ci.K);
-      uint64_t h = hash_slot(key, ci.log2cap);
       bool covered = false;
-      for (;;) {
-        uint64_t v = ci.slots[h];
-        if (v == kEmptySlot) break;
-        if (v == key) {
-          for (uint64_t p = ci.vals[h]; p < ci.n_o && ci.skeys[p] == key; ++p) {
-            uint32_t c = ci.soid[p];
-            if (int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) {
-              covered = true;
-              break;
-            }
+      int64_t h = table_find(ci.slots, ci.log2cap, key, ~0ull);
+      if (h >= 0) {
+        for (uint64_t p = ci.vals[h]; p < ci.n_o && ci.skeys[p] == key; ++p) {
+          uint32_t c = ci.soid[p];
+          if (int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) {
+            covered = true;
+            break;
           }
-          break;
         }
-        h = (h + 1) & mask;
       }
       if (covered) break;
     }

@@ -161,11 +161,16 @@ __global__ void k_hash_insert(const uint64_t* __restrict__ kmers, uint64_t n, ui
   uint64_t km = kmers[i];
   uint64_t mask = (1ull << log2cap) - 1;
   uint64_t s = hash_slot(km, log2cap);
+  const int off = hash_slot_offset(km, log2cap);
   for (;;) {
-    unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&slots[s]),
-                                       (unsigned long long)kEmptySlot, (unsigned long long)km);
-    if (old == kEmptySlot) return;
-    s = (s + 1) & mask;
+    for (int u = 0; u < kBucketSlots; ++u) {
+      uint64_t t = s + ((off + u) & (kBucketSlots - 1));
+      if (slots[t] != kEmptySlot) continue;
+      unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&slots[t]),
+                                         (unsigned long long)kEmptySlot, (unsigned long long)km);
+      if (old == kEmptySlot) return;
+    }
+    s = (s + kBucketSlots) & mask;
   }
 }
 

@@ -50,11 +50,16 @@ __global__ void k_cover_insert(const uint64_t* __restrict__ skeys, const uint32_
   uint64_t key = skeys[pos];
   uint64_t mask = (1ull << log2cap) - 1;
   uint64_t s = hash_slot(key, log2cap);
+  const int off = hash_slot_offset(key, log2cap);
   for (;;) {
-    unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&slots[s]),
-                                       (unsigned long long)kEmptySlot, (unsigned long long)key);
-    if (old == kEmptySlot) { vals[s] = pos; return; }
-    s = (s + 1) & mask;
+    for (int u = 0; u < kBucketSlots; ++u) {
+      uint64_t t = s + ((off + u) & (kBucketSlots - 1));
+      if (slots[t] != kEmptySlot) continue;
+      unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&slots[t]),
+                                         (unsigned long long)kEmptySlot, (unsigned long long)key);
+      if (old == kEmptySlot) { vals[t] = pos; return; }
+    }
+    s = (s + kBucketSlots) & mask;
   }
 }
 
