@@ -564,30 +564,178 @@ int radix_sort_u64(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* va
 // Groups equal keys' neighbourhoods: stable partition of the keys into 65536 buckets by the top 16 bits
 // of key * kPartitionMult (two 8-bit passes, least significant byte first).  Equal keys land in the
 // same bucket; bucket b = keys whose hash prefix is b, buckets ascending.
+// The partition only has to GROUP keys, so it runs most-significant byte first and unstable: a key's
+// rank inside its (tile, bin) run is the return value of one LDS atomic instead of the ballot match
+// a stable sort needs.  Pass 1 splits the whole array on hash bits 56..63; pass 2 splits each of the
+// 256 buckets on bits 48..55 with tiles that do not straddle buckets (segments), so one flat scan of
+// the [segment][bin][tile] counts yields the final offsets.
+constexpr int PT_ITEMS = 16;
+constexpr int PT_TILE = RS_THREADS * PT_ITEMS;  // keys per partition tile (runs of PT_TILE/256 keys per bin)
+struct __attribute__((aligned(8))) Key2 { uint64_t a, b; };  // 8-byte aligned 16-byte access
+struct PartSegs {
+  const uint64_t* seg_key0;   // S+1 key offsets
+  const uint32_t* seg_tile0;  // S+1 tile offsets
+  int nseg;
+};
+
+__device__ __forceinline__ void part_locate(const PartSegs& sg, uint32_t tile, int* seg, uint64_t* lo, uint64_t* hi,
+                                            uint64_t* hist_base, uint32_t* tiles_in_seg, uint32_t* tile_in_seg) {
+  int a = 0, b = sg.nseg;  // last segment with seg_tile0 <= tile
+  while (b - a > 1) {
+    int m = (a + b) >> 1;
+    if (sg.seg_tile0[m] <= tile) a = m; else b = m;
+  }
+  uint32_t t0 = sg.seg_tile0[a];
+  *seg = a;
+  *tiles_in_seg = sg.seg_tile0[a + 1] - t0;
+  *tile_in_seg = tile - t0;
+  *lo = sg.seg_key0[a] + uint64_t(tile - t0) * PT_TILE;
+  uint64_t end = sg.seg_key0[a + 1];
+  *hi = *lo + PT_TILE < end ? *lo + PT_TILE : end;
+  *hist_base = uint64_t(t0) * RS_BINS;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_part_hist_kernel(const uint64_t* __restrict__ keys, PartSegs sg,
+                                                                  int shift, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[RS_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  int seg;
+  uint64_t lo, hi, hbase;
+  uint32_t nt, ti;
+  part_locate(sg, blockIdx.x, &seg, &lo, &hi, &hbase, &nt, &ti);
+#pragma unroll 4
+  for (int it = 0; it < PT_ITEMS / 2; ++it) {  // two keys (16 bytes) per lane and load
+    uint64_t idx = lo + (uint64_t(it) * RS_THREADS + threadIdx.x) * 2;
+    if (idx + 1 < hi) {
+      Key2 v = *reinterpret_cast<const Key2*>(keys + idx);
+      atomicAdd(&h[rs_digit<true>(v.a, shift, 0xffu)], 1u);
+      atomicAdd(&h[rs_digit<true>(v.b, shift, 0xffu)], 1u);
+    } else if (idx < hi) {
+      atomicAdd(&h[rs_digit<true>(keys[idx], shift, 0xffu)], 1u);
+    }
+  }
+  __syncthreads();
+  hist[hbase + uint64_t(threadIdx.x) * nt + ti] = h[threadIdx.x];
+}
+
+template <class OffT>
+__global__ __launch_bounds__(RS_THREADS) void rs_part_scatter_kernel(const uint64_t* __restrict__ kin,
+                                                                     uint64_t* __restrict__ kout, PartSegs sg,
+                                                                     int shift, const OffT* __restrict__ offs) {
+  __shared__ uint64_t skeys[PT_TILE];
+  __shared__ uint32_t h[RS_BINS];
+  __shared__ uint32_t binstart[RS_BINS];
+  __shared__ OffT goff[RS_BINS];
+  __shared__ uint32_t scan_sm[4];
+  const int tid = threadIdx.x;
+  h[tid] = 0;
+  int seg;
+  uint64_t lo, hi, hbase;
+  uint32_t nt, ti;
+  part_locate(sg, blockIdx.x, &seg, &lo, &hi, &hbase, &nt, &ti);
+  __syncthreads();
+  uint64_t key[PT_ITEMS];
+  uint16_t rnk[PT_ITEMS];
+#pragma unroll
+  for (int it = 0; it < PT_ITEMS; it += 2) {  // two keys (16 bytes) per lane and load
+    uint64_t idx = lo + (uint64_t(it / 2) * RS_THREADS + tid) * 2;
+    if (idx + 1 < hi) {
+      Key2 v = *reinterpret_cast<const Key2*>(kin + idx);
+      key[it] = v.a;
+      key[it + 1] = v.b;
+    } else {
+      key[it] = idx < hi ? kin[idx] : 0;
+      key[it + 1] = 0;
+    }
+    rnk[it] = idx < hi ? uint16_t(atomicAdd(&h[rs_digit<true>(key[it], shift, 0xffu)], 1u)) : uint16_t(0);
+    rnk[it + 1] = idx + 1 < hi ? uint16_t(atomicAdd(&h[rs_digit<true>(key[it + 1], shift, 0xffu)], 1u)) : uint16_t(0);
+  }
+  __syncthreads();
+  {
+    uint32_t tot = h[tid], dummy;
+    uint32_t ex = block_excl_scan_256<uint32_t>(tot, scan_sm, &dummy);
+    binstart[tid] = ex;
+    goff[tid] = offs[hbase + uint64_t(tid) * nt + ti] - OffT(ex);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < PT_ITEMS; ++it) {
+    uint64_t idx = lo + (uint64_t(it / 2) * RS_THREADS + tid) * 2 + (it & 1);
+    if (idx < hi) skeys[binstart[rs_digit<true>(key[it], shift, 0xffu)] + rnk[it]] = key[it];
+  }
+  __syncthreads();
+  uint32_t cnt = uint32_t(hi - lo);
+  for (uint32_t i = tid; i < cnt; i += RS_THREADS) {
+    uint64_t k = skeys[i];
+    kout[goff[rs_digit<true>(k, shift, 0xffu)] + OffT(i)] = k;
+  }
+}
+
+template <class OffT>
+__global__ void rs_part_bucket_starts_kernel(const OffT* __restrict__ offs, uint32_t ntiles, uint64_t n,
+                                             uint64_t* __restrict__ starts) {
+  int b = threadIdx.x;
+  starts[b] = uint64_t(offs[uint64_t(b) * ntiles]);
+  if (b == 0) starts[RS_BINS] = n;
+}
+
 template <class OffT>
 static int radix_partition_hash16_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, bool* in_b) {
   *in_b = false;
   if (n <= 1) return BG_OK;
-  const uint64_t ntiles = (n + RS_TILE - 1) / RS_TILE;
+  const uint64_t ntiles1 = (n + PT_TILE - 1) / PT_TILE;
+  const uint64_t max_tiles = ntiles1 + RS_BINS;
   DevBuf<uint32_t> hist;
   DevBuf<OffT> offs;
-  BG_TRY(hist.alloc(ctx, size_t(RS_BINS) * ntiles));
-  BG_TRY(offs.alloc(ctx, size_t(RS_BINS) * ntiles));
+  DevBuf<uint64_t> seg_key;
+  DevBuf<uint32_t> seg_tile;
+  BG_TRY(hist.alloc(ctx, size_t(RS_BINS) * max_tiles));
+  BG_TRY(offs.alloc(ctx, size_t(RS_BINS) * max_tiles));
+  BG_TRY(seg_key.alloc(ctx, RS_BINS + 1));
+  BG_TRY(seg_tile.alloc(ctx, RS_BINS + 1));
+  std::vector<uint64_t> h_key(RS_BINS + 1, 0);
+  std::vector<uint32_t> h_tile(RS_BINS + 1, 0);
   uint64_t* kin = keys_a;
   uint64_t* kout = keys_b;
-  for (int shift = 48; shift < 64; shift += 8) {
+  for (int pass = 0; pass < 2; ++pass) {
+    const int shift = pass == 0 ? 56 : 48;
+    int nseg;
+    if (pass == 0) {
+      nseg = 1;
+      h_key[0] = 0; h_key[1] = n;
+      h_tile[0] = 0; h_tile[1] = uint32_t(ntiles1);
+    } else {
+      nseg = RS_BINS;
+      uint32_t t = 0;
+      for (int b = 0; b < RS_BINS; ++b) {
+        h_tile[b] = t;
+        t += uint32_t((h_key[b + 1] - h_key[b] + PT_TILE - 1) / PT_TILE);
+      }
+      h_tile[RS_BINS] = t;
+    }
+    const uint32_t ntiles = h_tile[nseg];
+    BG_HIP(hipMemcpyAsync(seg_key.p, h_key.data(), (nseg + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    BG_HIP(hipMemcpyAsync(seg_tile.p, h_tile.data(), (nseg + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors are rewritten below
+    PartSegs sg{seg_key.p, seg_tile.p, nseg};
     ctx->tic("radix_hist");
-    rs_hist_kernel<true><<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(kin, n, shift, 0xffu, hist.p, uint32_t(ntiles));
+    rs_part_hist_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, sg, shift, hist.p);
     BG_LAUNCH_CHECK();
     ctx->toc(n * 8);
     ctx->tic("radix_scan");
     BG_TRY(exclusive_scan_impl<OffT>(ctx, hist.p, offs.p, uint64_t(RS_BINS) * ntiles, nullptr));
     ctx->toc(uint64_t(RS_BINS) * ntiles * (4 + sizeof(OffT)));
     ctx->tic("radix_scatter_k");
-    rs_scatter_kernel<OffT, false, true><<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(
-        kin, nullptr, kout, nullptr, n, shift, 0xffu, offs.p, uint32_t(ntiles));
+    rs_part_scatter_kernel<OffT><<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, kout, sg, shift, offs.p);
     BG_LAUNCH_CHECK();
     ctx->toc(n * 16);
+    if (pass == 0) {
+      rs_part_bucket_starts_kernel<OffT><<<1, RS_BINS, 0, ctx->stream>>>(offs.p, uint32_t(ntiles1), n, seg_key.p);
+      BG_LAUNCH_CHECK();
+      BG_HIP(hipMemcpyAsync(h_key.data(), seg_key.p, (RS_BINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+      BG_HIP(hipStreamSynchronize(ctx->stream));
+    }
     uint64_t* t = kin; kin = kout; kout = t;
     *in_b = !*in_b;
   }
