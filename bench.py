@@ -126,7 +126,7 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev):
                                 "algorithmic_GBps": round(pfd_br * 52 / t_br / 1e9, 1)}}
 
 
-KERNEL_OF_FAMILY = {"radix_scatter_k": "rs_scatter_kernel<unsigned int, false>",
+KERNEL_OF_FAMILY = {"radix_scatter_k": "rs_part_scatter_kernel",
                     "radix_scatter_kv": "rs_scatter_kernel<unsigned int, true>", "radix_hist": "rs_hist_kernel",
                     "correct_screen": "k_correct_screen"}
 
@@ -143,6 +143,8 @@ def pmc_traffic(family):
     for e in json.load(open(files[-1])):
         if pat in e["kernel"] and "fetch_bytes_per_launch_x2" in e:
             return {"traffic": int(e["fetch_bytes_per_launch_x2"] + e.get("write_bytes_per_launch", 0)),
+                    "traffic_fetch_raw": int(e["fetch_bytes_per_launch_raw"]),
+                    "traffic_write": int(e.get("write_bytes_per_launch", 0)),
                     "traffic_source": os.path.basename(files[-1])}
     return {"traffic": None}
 
