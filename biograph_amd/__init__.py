@@ -179,6 +179,11 @@ class Context:
             dseq.free()
             doffs.free()
 
+    def open_readmap(self, path):
+        h = C.c_void_p()
+        capi.check(capi.lib().bg_readmap_open(self.h, str(path).encode(), C.byref(h)))
+        return Readmap(self, h)
+
     def open_seqset(self, path):
         h = C.c_void_p()
         capi.check(capi.lib().bg_seqset_open(self.h, str(path).encode(), C.byref(h)))
@@ -298,6 +303,15 @@ class Readmap(_Handle):
 
     def parts(self):
         return {n: self.part(n) for n in READMAP_PART_NAMES}
+
+    def arrays(self):
+        """(entry id, read length, mate loop pointer, is_forward) per read id."""
+        n = self.size()
+        e, rl, ml = (np.zeros(max(n, 1), np.uint32) for _ in range(3))
+        f = np.zeros(max(n, 1), np.uint8)
+        capi.check(capi.lib().bg_readmap_arrays(self.ctx.h, self.h, capi.np_ptr(e), capi.np_ptr(rl), capi.np_ptr(ml),
+                                                capi.np_ptr(f)))
+        return e[:n], rl[:n], ml[:n], f[:n]
 
     def write(self, path, argv=()):
         """Writes the container and returns its SHA-1 (the name it takes under coverage/)."""
@@ -479,6 +493,100 @@ class Seqset(_Handle):
         finally:
             dref.free()
             out.free()
+
+    # ---- row G4: readmap queries and propagate_from_end ------------------------------------------
+    def prefix_reads_batch(self, readmap, ranges, read_len_limit=0, cap=256):
+        """readmap::get_prefix_reads for each (begin, end, size) -> list of read-id lists (iteration order)."""
+        ctx, n = self.ctx, len(ranges)
+        b = np.array([r[0] for r in ranges], np.uint64)
+        e = np.array([r[1] for r in ranges], np.uint64)
+        sz = np.array([r[2] for r in ranges], np.uint32)
+        D = DeviceArray
+        ins = [D.from_numpy(ctx, b), D.from_numpy(ctx, e), D.from_numpy(ctx, sz)]
+        outs = [D(ctx, max(n * cap, 1) * 4), D(ctx, max(n, 1) * 4)]
+        try:
+            capi.check(capi.lib().bg_prefix_reads_batch(ctx.h, self.h, readmap.h, n, *[C.c_void_p(a.ptr) for a in ins],
+                                                        read_len_limit, cap, C.c_void_p(outs[0].ptr),
+                                                        C.c_void_p(outs[1].ptr)))
+            ids = outs[0].to_numpy(np.uint32, n * cap)
+            cnt = outs[1].to_numpy(np.uint32, n)
+        finally:
+            for a in ins + outs:
+                a.free()
+        if (cnt > cap).any():
+            raise BgError(-1, "prefix_reads_batch: more than cap=%d reads for a range" % cap)
+        return [[int(x) for x in ids[q * cap:q * cap + int(cnt[q])]] for q in range(n)]
+
+    def read_info_batch(self, readmap, read_ids):
+        """-> list of (has_mate, mate_rc id or None, rev_comp id, (begin, end, size) of get_seqset_entry())."""
+        ctx, n = self.ctx, len(read_ids)
+        D = DeviceArray
+        ins = [D.from_numpy(ctx, np.ascontiguousarray(read_ids, np.uint32))]
+        outs = [D(ctx, max(n, 1)), D(ctx, max(n, 1) * 4), D(ctx, max(n, 1) * 4), D(ctx, max(n, 1) * 8),
+                D(ctx, max(n, 1) * 8), D(ctx, max(n, 1) * 4)]
+        try:
+            capi.check(capi.lib().bg_read_info_batch(ctx.h, self.h, readmap.h, n,
+                                                     *[C.c_void_p(a.ptr) for a in ins + outs]))
+            hm = outs[0].to_numpy(np.uint8, n)
+            mrc, rc = outs[1].to_numpy(np.uint32, n), outs[2].to_numpy(np.uint32, n)
+            b, e, sz = outs[3].to_numpy(np.uint64, n), outs[4].to_numpy(np.uint64, n), outs[5].to_numpy(np.uint32, n)
+        finally:
+            for a in ins + outs:
+                a.free()
+        return [(bool(hm[i]), int(mrc[i]) if hm[i] else None, int(rc[i]), (int(b[i]), int(e[i]), int(sz[i])))
+                for i in range(n)]
+
+    def propagate_from_end_batch(self, seqs, ends, readmap=None, max_pairs_per_read=20, marks=None, mate_cap=4096):
+        """seqset_path::propagate_from_end for many assemblies.  seqs[a] = codes of the `seq` argument
+        (pushed from its last base to its first); ends[a] = list of (begin, end, size); marks[a] = offsets
+        strictly inside (0, len) whose sets are wanted.  -> list of ({offset: [ranges]}, sorted mate set)."""
+        ctx, n = self.ctx, len(seqs)
+        soff = np.zeros(n + 1, np.uint64)
+        soff[1:] = np.cumsum([len(x) for x in seqs])
+        codes = np.concatenate([np.asarray(x, np.uint8) for x in seqs]) if n else np.zeros(0, np.uint8)
+        foff, b, e, s = self._flatten_frontiers(ends)
+        marks = [sorted(m) for m in marks] if marks is not None else [[] for _ in range(n)]
+        moff = np.zeros(n + 1, np.uint32)
+        moff[1:] = np.cumsum([len(m) for m in marks])
+        mflat = np.array([x for m in marks for x in m], np.uint32)
+        nmk = len(mflat)
+        D = DeviceArray
+        ins = [D.from_numpy(ctx, soff), D.from_numpy(ctx, codes), D.from_numpy(ctx, foff), D.from_numpy(ctx, b),
+               D.from_numpy(ctx, e), D.from_numpy(ctx, s)]
+        mk = [D.from_numpy(ctx, moff), D.from_numpy(ctx, mflat)]
+        mouts = [D(ctx, max(nmk, 1)), D(ctx, max(nmk, 1) * 128), D(ctx, max(nmk, 1) * 128), D(ctx, max(nmk, 1) * 64)]
+        outs = [D(ctx, max(n, 1)), D(ctx, max(n, 1) * 128), D(ctx, max(n, 1) * 128), D(ctx, max(n, 1) * 64)]
+        mates = [D(ctx, max(n, 1) * 4), D(ctx, max(n * mate_cap, 1) * 8), D(ctx, max(n * mate_cap, 1) * 8),
+                 D(ctx, max(n * mate_cap, 1) * 4)]
+        try:
+            vp = C.c_void_p
+            capi.check(capi.lib().bg_propagate_from_end_batch(
+                ctx.h, self.h, readmap.h if readmap is not None else None, n, *[vp(a.ptr) for a in ins],
+                max_pairs_per_read, *[vp(a.ptr) for a in mk + mouts + outs], mate_cap, *[vp(a.ptr) for a in mates]))
+            mn = mouts[0].to_numpy(np.uint8, nmk)
+            mb, me = mouts[1].to_numpy(np.uint64, nmk * 16), mouts[2].to_numpy(np.uint64, nmk * 16)
+            ms = mouts[3].to_numpy(np.uint32, nmk * 16)
+            no = outs[0].to_numpy(np.uint8, n)
+            ob, oe = outs[1].to_numpy(np.uint64, n * 16), outs[2].to_numpy(np.uint64, n * 16)
+            os_ = outs[3].to_numpy(np.uint32, n * 16)
+            nm = mates[0].to_numpy(np.uint32, n)
+            tb, te = mates[1].to_numpy(np.uint64, n * mate_cap), mates[2].to_numpy(np.uint64, n * mate_cap)
+            ts = mates[3].to_numpy(np.uint32, n * mate_cap)
+        finally:
+            for a in ins + mk + mouts + outs + mates:
+                a.free()
+        if (nm > mate_cap).any():
+            raise BgError(-1, "propagate_from_end_batch: more than mate_cap=%d mates for an assembly" % mate_cap)
+        res = []
+        for a in range(n):
+            ent = {0: [(int(ob[a * 16 + i]), int(oe[a * 16 + i]), int(os_[a * 16 + i])) for i in range(int(no[a]))]}
+            for k in range(int(moff[a]), int(moff[a + 1])):
+                ent[int(mflat[k])] = [(int(mb[k * 16 + i]), int(me[k * 16 + i]), int(ms[k * 16 + i]))
+                                      for i in range(int(mn[k]))]
+            ms_set = sorted({(int(tb[a * mate_cap + i]), int(te[a * mate_cap + i]), int(ts[a * mate_cap + i]))
+                             for i in range(int(nm[a]))}, key=lambda r: (r[0], -r[1], r[2]))
+            res.append((ent, ms_set))
+        return res
 
     # ---- SDK surface of python/biograph/seqset.cpp:46-160 -------------------------------------
     def empty_entry(self):

@@ -161,6 +161,17 @@ struct bg_records {
   bg::DevBuf<uint8_t> rlen;   // n
 };
 
+struct bg_readmap {
+  bg_ctx* ctx = nullptr;
+  uint64_t n_reads = 0, n_entries = 0;
+  uint32_t max_read_len = 0;
+  std::string seqset_uuid;
+  uint32_t min_read_len = 0;    // readmap::min_read_len()
+  bg::DevBuf<uint64_t> read_len, mate_loop_ptr, is_forward;  // one u64 per read id (packed on demand)
+  bg::DevBuf<uint32_t> entry_id;                              // seqset entry of every read id (sparse_multi::reverse_lookup)
+  bg::DevBuf<uint64_t> s2m_bits, s2m_sub, s2m_acc, d2m_bits, d2m_sub, d2m_acc;
+};
+
 namespace bg {
 // build_seqset.hip
 int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss);  // bitcount finalize + min index + fixed

@@ -113,7 +113,7 @@ __global__ void k_rm_flag_type(const uint64_t* __restrict__ hi, uint64_t n, int 
 // per sorted row: read length, is_forward, group-head flag, entry marks
 __global__ void k_rm_row_fields(const uint64_t* __restrict__ hi, uint64_t n, uint64_t* __restrict__ read_len,
                                 uint64_t* __restrict__ is_fwd, uint8_t* __restrict__ head,
-                                uint8_t* __restrict__ entry_marks) {
+                                uint8_t* __restrict__ entry_marks, uint32_t* __restrict__ entry_id) {
   uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint64_t h = hi[i];
@@ -122,6 +122,16 @@ __global__ void k_rm_row_fields(const uint64_t* __restrict__ hi, uint64_t n, uin
   is_fwd[i] = (t == 0 || t == 2) ? 1 : 0;
   head[i] = (i == 0 || hi_entry(hi[i - 1]) != hi_entry(h)) ? 1 : 0;
   entry_marks[hi_entry(h)] = 1;
+  entry_id[i] = uint32_t(hi_entry(h));
+}
+
+__global__ __launch_bounds__(256) void k_rm_min_len(const uint64_t* __restrict__ read_len, uint64_t n,
+                                                    uint32_t* __restrict__ out) {
+  uint32_t m = ~0u;
+  for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256)
+    m = min(m, uint32_t(read_len[i]));
+  for (int d = 32; d; d >>= 1) m = min(m, uint32_t(__shfl_xor(int(m), d, 64)));
+  if ((threadIdx.x & 63) == 0) atomicMin(out, m);
 }
 
 // bytes -> bits (bit i = word i/64 bit i%64), one wave per word
@@ -289,6 +299,8 @@ static int bitcount_finalize(bg_ctx* ctx, const DevBuf<uint64_t>& bits, uint64_t
   return BG_OK;
 }
 
+static int readmap_min_len(bg_ctx* ctx, bg_readmap* rm);
+
 // stable sort of (key, payload) pairs; returns pointers to the sorted arrays
 static int sort_pairs(bg_ctx* ctx, DevBuf<uint64_t>& ka, DevBuf<uint64_t>& kb, DevBuf<uint32_t>& va,
                       DevBuf<uint32_t>& vb, uint64_t n, int bit_hi, uint64_t** ks, uint32_t** vs) {
@@ -301,16 +313,21 @@ static int sort_pairs(bg_ctx* ctx, DevBuf<uint64_t>& ka, DevBuf<uint64_t>& kb, D
 
 }  // namespace bg
 
-struct bg_readmap {
-  bg_ctx* ctx = nullptr;
-  uint64_t n_reads = 0, n_entries = 0;
-  uint32_t max_read_len = 0;
-  std::string seqset_uuid;
-  bg::DevBuf<uint64_t> read_len, mate_loop_ptr, is_forward;  // one u64 per read id (packed on demand)
-  bg::DevBuf<uint64_t> s2m_bits, s2m_sub, s2m_acc, d2m_bits, d2m_sub, d2m_acc;
-};
 
 using namespace bg;
+
+static int bg::readmap_min_len(bg_ctx* ctx, bg_readmap* rm) {
+  rm->min_read_len = 0;
+  if (!rm->n_reads) return BG_OK;
+  DevBuf<uint32_t> m;
+  BG_TRY(m.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(m.p, 0xff, 4, ctx->stream));
+  k_rm_min_len<<<unsigned(std::min<uint64_t>(cdiv(rm->n_reads, 256), 1024)), 256, 0, ctx->stream>>>(rm->read_len.p, rm->n_reads, m.p);
+  BG_LAUNCH_CHECK();
+  BG_HIP(hipMemcpyAsync(&rm->min_read_len, m.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
 
 extern "C" int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads* reads, int is_paired,
                                 bg_readmap** out) {
@@ -412,6 +429,7 @@ extern "C" int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads
   BG_TRY(rm->read_len.alloc(ctx, n_rows));
   BG_TRY(rm->is_forward.alloc(ctx, n_rows));
   BG_TRY(rm->mate_loop_ptr.alloc(ctx, n_rows));
+  BG_TRY(rm->entry_id.alloc(ctx, n_rows));
   BG_TRY(rm->s2m_bits.alloc(ctx, (n_ent + 63) / 64));
   BG_TRY(rm->d2m_bits.alloc(ctx, (n_rows + 63) / 64));
   {
@@ -422,7 +440,7 @@ extern "C" int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads
     if (n_rows) {
       BG_HIP(hipMemsetAsync(rm->mate_loop_ptr.p, 0, n_rows * 8, ctx->stream));
       k_rm_row_fields<<<cdiv(n_rows, 256), 256, 0, ctx->stream>>>(hi_s.p, n_rows, rm->read_len.p, rm->is_forward.p,
-                                                                 head.p, marks.p);
+                                                                 head.p, marks.p, rm->entry_id.p);
       BG_LAUNCH_CHECK();
       k_bytes_to_bits<<<cdiv((n_rows + 63) / 64, 4), 256, 0, ctx->stream>>>(
           head.p, n_rows, reinterpret_cast<unsigned long long*>(rm->d2m_bits.p));
@@ -437,6 +455,7 @@ extern "C" int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads
   }
   BG_TRY(bitcount_finalize(ctx, rm->s2m_bits, n_ent, &rm->s2m_sub, &rm->s2m_acc));
   BG_TRY(bitcount_finalize(ctx, rm->d2m_bits, n_rows, &rm->d2m_sub, &rm->d2m_acc));
+  BG_TRY(readmap_min_len(ctx, rm.get()));
 
   // ---- 4. mate loops: three claim hops
   if (n_rows) {
@@ -615,5 +634,127 @@ extern "C" int bg_readmap_write(bg_ctx* ctx, const bg_readmap* rm, const char* p
   parts.push_back(ZipPart{"is_forward/packed_vector.json", js, false});
   BG_TRY(spiral_zip_write(path, parts));
   if (h_sha1_hex) BG_TRY(sha1_file_hex(path, h_sha1_hex));
+  return BG_OK;
+}
+
+// ---- open a readmap container (readmap::readmap / open_spiral_file, bio_base/readmap.cpp) ----------
+static bool rm_json_u64(const std::string& js, const char* key, uint64_t* out) {
+  std::string pat = std::string("\"") + key + "\":";
+  size_t p = js.find(pat);
+  if (p == std::string::npos) return false;
+  *out = strtoull(js.c_str() + p + pat.size(), nullptr, 10);
+  return true;
+}
+
+static void rm_unpack_bits(const std::string& blob, uint64_t n, unsigned bits, std::vector<uint64_t>* out) {
+  out->assign(n, 0);
+  if (!bits) return;
+  const uint64_t* w = reinterpret_cast<const uint64_t*>(blob.data());
+  const uint64_t nw = blob.size() / 8;
+  const uint64_t mask = bits == 64 ? ~0ull : ((1ull << bits) - 1);
+  for (uint64_t i = 0; i < n; ++i) {
+    uint64_t bit = i * bits, q = bit >> 6, r = bit & 63;
+    uint64_t x = q < nw ? w[q] >> r : 0;
+    if (r + bits > 64 && q + 1 < nw) x |= w[q + 1] << (64 - r);
+    (*out)[i] = x & mask;
+  }
+}
+
+extern "C" int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out) {
+  if (!ctx || !path || !out) { set_error("bg_readmap_open: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::map<std::string, std::string> parts;
+  BG_TRY(spiral_zip_read(path, &parts));
+  auto need = [&](const char* name) -> const std::string* {
+    auto it = parts.find(name);
+    if (it == parts.end()) { set_error("%s: member %s missing (readmaps older than format 1.2.0 carry no mate loop table; `biograph upgrade` them)", path, name); return nullptr; }
+    return &it->second;
+  };
+  const std::string *s2m_js = need("read_ids/source_to_mid/bitcount.json"), *s2m = need("read_ids/source_to_mid/bits"),
+                    *d2m = need("read_ids/dest_to_mid/bits"), *rl_js = need("read_lengths/packed_varbit_vector.json"),
+                    *rl = need("read_lengths/elements"), *ml_js = need("mate_loop_ptr/packed_varbit_vector.json"),
+                    *ml = need("mate_loop_ptr/elements"), *isf = need("is_forward/packed_data"), *rmj = need("readmap.json");
+  if (!s2m_js || !s2m || !d2m || !rl_js || !rl || !ml_js || !ml || !isf || !rmj) return BG_EIO;
+  uint64_t n_ent = 0, n = 0, rl_bits = 0, ml_bits = 0, max_len = 0;
+  if (!rm_json_u64(*s2m_js, "nbits", &n_ent) || !rm_json_u64(*rl_js, "element_count", &n) ||
+      !rm_json_u64(*rl_js, "bits_per_value", &rl_bits) || !rm_json_u64(*ml_js, "bits_per_value", &ml_bits) ||
+      !rm_json_u64(*rl_js, "max_value", &max_len)) {
+    set_error("%s: malformed readmap metadata", path);
+    return BG_EIO;
+  }
+  if (n >= (1ull << 32) || n_ent >= (1ull << 32)) { set_error("bg_readmap_open: readmap too large for one device shard"); return BG_EINVAL; }
+  std::unique_ptr<bg_readmap> rm(new bg_readmap);
+  rm->ctx = ctx;
+  rm->n_reads = n;
+  rm->n_entries = n_ent;
+  rm->max_read_len = uint32_t(max_len);
+  size_t p = rmj->find("\"seqset_uuid\":\"");
+  if (p != std::string::npos) rm->seqset_uuid = rmj->substr(p + 15, rmj->find('"', p + 15) - (p + 15));
+  std::vector<uint64_t> v_len, v_ptr, v_fwd, v_head, v_src;
+  rm_unpack_bits(*rl, n, unsigned(rl_bits), &v_len);
+  rm_unpack_bits(*ml, n, unsigned(ml_bits), &v_ptr);
+  rm_unpack_bits(*isf, n, 1, &v_fwd);
+  rm_unpack_bits(*d2m, n, 1, &v_head);
+  rm_unpack_bits(*s2m, n_ent, 1, &v_src);
+  // sparse_multi::reverse_lookup for every read id: k-th group head -> k-th marked entry
+  std::vector<uint32_t> mid_to_entry, v_entry(n, 0);
+  for (uint64_t e = 0; e < n_ent; ++e)
+    if (v_src[e]) mid_to_entry.push_back(uint32_t(e));
+  uint64_t mid = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (v_head[i]) ++mid;
+    if (mid == 0 || mid > mid_to_entry.size() || v_ptr[i] >= n) { set_error("%s: inconsistent sparse_multi / mate loop table", path); return BG_EIO; }
+    v_entry[i] = mid_to_entry[mid - 1];
+  }
+  auto up64 = [&](DevBuf<uint64_t>& d, const void* src, uint64_t words) -> int {
+    BG_TRY(d.alloc(ctx, words));
+    if (words) BG_HIP(hipMemcpyAsync(d.p, src, words * 8, hipMemcpyHostToDevice, ctx->stream));
+    return BG_OK;
+  };
+  BG_TRY(up64(rm->read_len, v_len.data(), n));
+  BG_TRY(up64(rm->mate_loop_ptr, v_ptr.data(), n));
+  BG_TRY(up64(rm->is_forward, v_fwd.data(), n));
+  BG_TRY(up64(rm->s2m_bits, s2m->data(), (n_ent + 63) / 64));
+  BG_TRY(up64(rm->d2m_bits, d2m->data(), (n + 63) / 64));
+  if (s2m->size() < (n_ent + 63) / 64 * 8 || d2m->size() < (n + 63) / 64 * 8) { set_error("%s: truncated bit vectors", path); return BG_EIO; }
+  BG_TRY(rm->entry_id.alloc(ctx, n));
+  if (n) BG_HIP(hipMemcpyAsync(rm->entry_id.p, v_entry.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  BG_TRY(bitcount_finalize(ctx, rm->s2m_bits, n_ent, &rm->s2m_sub, &rm->s2m_acc));
+  BG_TRY(bitcount_finalize(ctx, rm->d2m_bits, n, &rm->d2m_sub, &rm->d2m_acc));
+  BG_TRY(readmap_min_len(ctx, rm.get()));
+  *out = rm.release();
+  return BG_OK;
+}
+
+__global__ void k_rm_narrow(const uint64_t* __restrict__ a, uint64_t n, uint32_t* __restrict__ o) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = uint32_t(a[i]);
+}
+
+// Per read id: seqset entry (sparse_multi::reverse_lookup), read length, mate loop pointer, orientation
+// (readmap.h:120-138 accessors as whole arrays).  Any output may be null.
+extern "C" int bg_readmap_arrays(bg_ctx* ctx, const bg_readmap* rm, uint32_t* h_entry_id, uint32_t* h_read_len,
+                                 uint32_t* h_mate_loop_ptr, uint8_t* h_is_forward) {
+  if (!ctx || !rm) { set_error("bg_readmap_arrays: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  const uint64_t n = rm->n_reads;
+  if (!n) return BG_OK;
+  DevBuf<uint32_t> tmp;
+  BG_TRY(tmp.alloc(ctx, n));
+  if (h_entry_id) BG_HIP(hipMemcpyAsync(h_entry_id, rm->entry_id.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  const uint64_t* srcs[3] = {rm->read_len.p, rm->mate_loop_ptr.p, rm->is_forward.p};
+  std::vector<uint32_t> fw(h_is_forward ? n : 0);
+  void* dsts[3] = {h_read_len, h_mate_loop_ptr, h_is_forward ? fw.data() : nullptr};
+  for (int k = 0; k < 3; ++k) {
+    if (!dsts[k]) continue;
+    k_rm_narrow<<<cdiv(n, 256), 256, 0, ctx->stream>>>(srcs[k], n, tmp.p);
+    BG_LAUNCH_CHECK();
+    BG_HIP(hipMemcpyAsync(dsts[k], tmp.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_is_forward)
+    for (uint64_t i = 0; i < n; ++i) h_is_forward[i] = uint8_t(fw[i]);
   return BG_OK;
 }

@@ -477,3 +477,291 @@ extern "C" int bg_ref_map_build(bg_ctx* ctx, const bg_seqset* ss, const uint8_t*
   BG_HIP(hipStreamSynchronize(ctx->stream));
   return BG_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Row G4: readmap queries and seqset_path::propagate_from_end.
+
+struct ReadmapView {
+  uint64_t n;
+  const uint32_t* entry_id;
+  const uint64_t* read_len;
+  const uint64_t* ptr;
+  const uint64_t* is_fwd;
+  int min_read_len;
+};
+
+static ReadmapView make_rm_view(const bg_readmap* rm) {
+  ReadmapView r;
+  r.n = rm->n_reads;
+  r.entry_id = rm->entry_id.p;
+  r.read_len = rm->read_len.p;
+  r.ptr = rm->mate_loop_ptr.p;
+  r.is_fwd = rm->is_forward.p;
+  r.min_read_len = int(rm->min_read_len);
+  return r;
+}
+
+__device__ __forceinline__ bool rm_has_mate(const ReadmapView& rm, uint64_t id) {  // readmap.cpp:207-218
+  return rm.ptr[rm.ptr[id]] != id;
+}
+__device__ __forceinline__ uint64_t rm_follow(const ReadmapView& rm, uint64_t id, int n) {
+  for (int c = 0; c < n; ++c) id = rm.ptr[id];
+  return id;
+}
+// read::get_seqset_entry (readmap.h:249-251): ctx_entry(id).truncate(read length) (seqset.cpp:630-661)
+__device__ __forceinline__ Tri rm_read_entry(const SeqsetView& v, const ReadmapView& rm, uint64_t id) {
+  uint64_t e = rm.entry_id[id];
+  uint32_t len = uint32_t(rm.read_len[id]);
+  Tri t{e, e + 1, v.sizes[e]};
+  if (t.s > len) {
+    t.b = v.next_backward_lt(e, len);
+    t.e = e + 1 < v.n ? v.next_forward_lt(e + 1, len) : v.n;
+    t.s = len;
+  }
+  return t;
+}
+
+// readmap::get_prefix_reads (readmap.cpp:434-447) + read_iterator (:538-649): reads whose sequence is a
+// prefix of the range's, first scanning read ids upward from the range's first entry, then downward;
+// the admissible read length shrinks to the running minimum of `shared` over the entries passed.
+// f(read_id) returns false to stop.
+template <class F>
+__device__ __forceinline__ void for_prefix_reads(const SeqsetView& v, const ReadmapView& rm, const Tri& r,
+                                                 int read_len_limit, F f) {
+  const int min_size = read_len_limit > rm.min_read_len ? read_len_limit : rm.min_read_len;
+  if (int(r.s) < min_size || rm.n == 0 || r.b >= r.e) return;
+  uint64_t lo = 0, hi = rm.n;  // sparse_multi::lookup_lower_bound (io/sparse_multi.cpp:32-38)
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) >> 1;
+    if (uint64_t(rm.entry_id[mid]) < r.b) lo = mid + 1; else hi = mid;
+  }
+  const uint64_t id0 = lo;
+  uint64_t sid = r.b;
+  int max_len = int(r.s);
+  for (uint64_t id = id0; id < rm.n; ++id) {
+    const uint64_t e = rm.entry_id[id];
+    bool stop = false;
+    while (sid != e) {
+      ++sid;
+      int sh = v.shared[sid];
+      if (sh < min_size) { stop = true; break; }
+      if (sh < max_len) max_len = sh;
+    }
+    if (stop) break;
+    if (int(rm.read_len[id]) <= max_len && !f(id)) return;
+  }
+  sid = r.b;
+  max_len = int(r.s);
+  for (uint64_t id = id0; id-- > 0;) {
+    const uint64_t e = rm.entry_id[id];
+    bool stop = false;
+    while (sid != e) {
+      int sh = v.shared[sid];
+      --sid;
+      if (sh < min_size) { stop = true; break; }
+      if (sh < max_len) max_len = sh;
+    }
+    if (stop) break;
+    if (int(rm.read_len[id]) <= max_len && !f(id)) return;
+  }
+}
+
+__global__ void k_prefix_reads(SeqsetView v, ReadmapView rm, uint64_t n, const uint64_t* __restrict__ qb,
+                               const uint64_t* __restrict__ qe, const uint32_t* __restrict__ qs, int limit,
+                               uint32_t cap, uint32_t* __restrict__ ids, uint32_t* __restrict__ count) {
+  uint64_t q = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  uint32_t c = 0;
+  Tri r{qb[q], qe[q], qs[q]};
+  if (r.e <= v.n)
+    for_prefix_reads(v, rm, r, limit, [&](uint64_t id) {
+      if (c < cap) ids[q * cap + c] = uint32_t(id);
+      ++c;
+      return true;
+    });
+  count[q] = c;
+}
+
+__global__ void k_read_info(SeqsetView v, ReadmapView rm, uint64_t n, const uint32_t* __restrict__ read_ids,
+                            uint8_t* __restrict__ has_mate, uint32_t* __restrict__ mate_rc,
+                            uint32_t* __restrict__ rev_comp, uint64_t* __restrict__ ob, uint64_t* __restrict__ oe,
+                            uint32_t* __restrict__ os) {
+  uint64_t q = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  uint64_t id = read_ids[q];
+  if (id >= rm.n) { has_mate[q] = 0; mate_rc[q] = 0xffffffffu; rev_comp[q] = 0xffffffffu; ob[q] = oe[q] = 0; os[q] = 0; return; }
+  bool fwd = rm.is_fwd[id] != 0;
+  bool hm = rm_has_mate(rm, id);
+  has_mate[q] = hm ? 1 : 0;
+  mate_rc[q] = hm ? uint32_t(rm_follow(rm, id, fwd ? 3 : 1)) : 0xffffffffu;  // readmap.cpp:270-290
+  rev_comp[q] = uint32_t(rm_follow(rm, id, fwd ? 1 : 3));                      // :248-268
+  Tri t = rm_read_entry(v, rm, id);
+  ob[q] = t.b; oe[q] = t.e; os[q] = t.s;
+}
+
+// seqset_path::propagate_from_end (variants/assemble.cpp:1345-1418): one wave per assembly.  The set
+// `cur` lives in lanes 0..15; each step pushes seq[offset] (offset descending) on every range, removes
+// ranges that contain another one, records the set at the marked offsets and at 0, and — with a
+// readmap — collects get_mate_rc().get_seqset_entry() of the mated prefix reads of every range that has
+// at most max_pairs_per_read of them (:1394-1414).  Mates are emitted unsorted with repeats (the
+// reference keeps a set; the host folds them).
+__global__ __launch_bounds__(256) void k_propagate_from_end(
+    SeqsetView v, ReadmapView rm, int use_rm, uint64_t na, const uint64_t* __restrict__ soff,
+    const uint8_t* __restrict__ seq, const uint32_t* __restrict__ foff, const uint64_t* __restrict__ fbegin,
+    const uint64_t* __restrict__ fend, const uint32_t* __restrict__ fsize, uint32_t max_pairs,
+    const uint32_t* __restrict__ mark_off, const uint32_t* __restrict__ marks, uint8_t* __restrict__ mark_n,
+    uint64_t* __restrict__ mb, uint64_t* __restrict__ me, uint32_t* __restrict__ ms, uint8_t* __restrict__ n_out,
+    uint64_t* __restrict__ outb, uint64_t* __restrict__ oute, uint32_t* __restrict__ outs, uint32_t mate_cap,
+    uint32_t* __restrict__ n_mates, uint64_t* __restrict__ mateb, uint64_t* __restrict__ matee,
+    uint32_t* __restrict__ mates, uint32_t* __restrict__ err) {
+  const int lane = threadIdx.x & 63;
+  uint64_t a = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (a >= na) return;
+  uint32_t lo = foff[a], hi = foff[a + 1];
+  if (hi - lo > uint32_t(kFrontierMax)) {
+    if (lane == 0) { atomicOr(err, 1u); n_out[a] = 0; n_mates[a] = 0; }
+    return;
+  }
+  auto reseat = [&](Tri& c, bool& cvalid, int rank) {  // survivors move to lane == rank (set order)
+    Tri nxt{0, 0, 0};
+    bool nxv = false;
+    for (int j = 0; j < kFrontierMax; ++j) {
+      Tri t{__shfl(c.b, j, 64), __shfl(c.e, j, 64), __shfl(c.s, j, 64)};
+      bool jv = __shfl(int(cvalid), j, 64) != 0;
+      int jr = __shfl(rank, j, 64);
+      if (jv && jr == lane) { nxt = t; nxv = true; }
+    }
+    c = nxt;
+    cvalid = nxv;
+  };
+  Tri cur{0, 0, 0};
+  bool cv = uint32_t(lane) < hi - lo;
+  if (cv) { cur.b = fbegin[lo + lane]; cur.e = fend[lo + lane]; cur.s = fsize[lo + lane]; }
+  cv = cv && cur.b < cur.e && cur.e <= v.n;
+  bool dummy = false;
+  int rank, count;
+  frontier_dedup(cur, cv, dummy, true, lane, &rank, &count);  // :1360-1361
+  reseat(cur, cv, rank);
+  const uint64_t s0 = soff[a];
+  const uint64_t len = soff[a + 1] - s0;
+  const int64_t mlo = mark_off ? int64_t(mark_off[a]) : 0;
+  int64_t mi = mark_off ? int64_t(mark_off[a + 1]) - 1 : -1;
+  uint32_t nm = 0;
+  for (uint64_t off = len; off-- > 0;) {
+    const int base = seq[s0 + off] & 3;
+    Tri c{0, 0, 0};
+    if (cv) v.push_front_drop(cur.b, cur.e, cur.s, base, 0u, &c.b, &c.e, &c.s);
+    bool nv = cv && c.e > c.b;
+    dummy = false;
+    frontier_dedup(c, nv, dummy, true, lane, &rank, &count);
+    reseat(c, nv, rank);
+    cur = c;
+    cv = nv;
+    if (mi >= mlo && marks[mi] == uint32_t(off)) {
+      if (cv) { mb[uint64_t(mi) * kFrontierMax + lane] = cur.b; me[uint64_t(mi) * kFrontierMax + lane] = cur.e; ms[uint64_t(mi) * kFrontierMax + lane] = cur.s; }
+      if (lane == 0) mark_n[mi] = uint8_t(count);
+      --mi;
+    }
+    if (use_rm) {
+      uint32_t cnt = 0;
+      if (cv)
+        for_prefix_reads(v, rm, cur, 0, [&](uint64_t id) {
+          if (rm_has_mate(rm, id)) { ++cnt; if (cnt > max_pairs) return false; }
+          return true;
+        });
+      uint32_t want = (cv && cnt <= max_pairs) ? cnt : 0u;
+      uint32_t incl = want;
+      for (int d = 1; d < kFrontierMax; d <<= 1) {
+        uint32_t t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+      }
+      uint32_t total = __shfl(incl, kFrontierMax - 1, 64);
+      uint32_t slot = nm + incl - want;
+      if (want)
+        for_prefix_reads(v, rm, cur, 0, [&](uint64_t id) {
+          if (rm_has_mate(rm, id)) {
+            uint64_t m = rm_follow(rm, id, rm.is_fwd[id] ? 3 : 1);
+            Tri t = rm_read_entry(v, rm, m);
+            if (slot < mate_cap) {
+              uint64_t o = a * uint64_t(mate_cap) + slot;
+              mateb[o] = t.b; matee[o] = t.e; mates[o] = t.s;
+            }
+            ++slot;
+          }
+          return true;
+        });
+      nm += total;
+    }
+  }
+  if (cv) { outb[a * kFrontierMax + lane] = cur.b; oute[a * kFrontierMax + lane] = cur.e; outs[a * kFrontierMax + lane] = cur.s; }
+  uint64_t live = __ballot(cv);
+  if (lane == 0) { n_out[a] = uint8_t(__popcll(live)); n_mates[a] = nm; }
+}
+
+static int check_rm(const bg_seqset* ss, const bg_readmap* rm, const char* who) {
+  if (!rm) { set_error("%s: null readmap", who); return BG_EINVAL; }
+  if (rm->n_entries != ss->n) { set_error("%s: Cannot use a readmap with a seqset it doesn't belong to.", who); return BG_EINVAL; }
+  return BG_OK;
+}
+
+extern "C" int bg_prefix_reads_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n,
+                                     const uint64_t* d_begin, const uint64_t* d_end, const uint32_t* d_size,
+                                     int read_len_limit, uint32_t cap, uint32_t* d_ids, uint32_t* d_count) {
+  BG_TRY(check_ss(ctx, ss, "bg_prefix_reads_batch"));
+  BG_TRY(check_rm(ss, rm, "bg_prefix_reads_batch"));
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!n) return BG_OK;
+  ctx->tic("readmap_prefix_reads");
+  k_prefix_reads<<<cdiv(n, 64), 64, 0, ctx->stream>>>(make_view(ss), make_rm_view(rm), n, d_begin, d_end, d_size,
+                                                      read_len_limit, cap, d_ids, d_count);
+  BG_LAUNCH_CHECK();
+  ctx->toc(0);
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+extern "C" int bg_read_info_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n,
+                                  const uint32_t* d_read_ids, uint8_t* d_has_mate, uint32_t* d_mate_rc,
+                                  uint32_t* d_rev_comp, uint64_t* d_begin, uint64_t* d_end, uint32_t* d_size) {
+  BG_TRY(check_ss(ctx, ss, "bg_read_info_batch"));
+  BG_TRY(check_rm(ss, rm, "bg_read_info_batch"));
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!n) return BG_OK;
+  k_read_info<<<cdiv(n, 128), 128, 0, ctx->stream>>>(make_view(ss), make_rm_view(rm), n, d_read_ids, d_has_mate,
+                                                     d_mate_rc, d_rev_comp, d_begin, d_end, d_size);
+  BG_LAUNCH_CHECK();
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+extern "C" int bg_propagate_from_end_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n_asm,
+                                           const uint64_t* d_seq_off, const uint8_t* d_seq_codes,
+                                           const uint32_t* d_foff, const uint64_t* d_begin, const uint64_t* d_end,
+                                           const uint32_t* d_size, uint32_t max_pairs_per_read,
+                                           const uint32_t* d_mark_off, const uint32_t* d_marks, uint8_t* d_mark_n,
+                                           uint64_t* d_mbegin, uint64_t* d_mend, uint32_t* d_msize, uint8_t* d_n_out,
+                                           uint64_t* d_obegin, uint64_t* d_oend, uint32_t* d_osize, uint32_t mate_cap,
+                                           uint32_t* d_n_mates, uint64_t* d_mate_begin, uint64_t* d_mate_end,
+                                           uint32_t* d_mate_size) {
+  BG_TRY(check_ss(ctx, ss, "bg_propagate_from_end_batch"));
+  if (rm) BG_TRY(check_rm(ss, rm, "bg_propagate_from_end_batch"));
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!n_asm) return BG_OK;
+  DevBuf<uint32_t> err;
+  BG_TRY(err.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+  ReadmapView rv{};
+  if (rm) rv = make_rm_view(rm);
+  ctx->tic("walk_propagate_from_end");
+  k_propagate_from_end<<<cdiv(n_asm, 4), 256, 0, ctx->stream>>>(
+      make_view(ss), rv, rm ? 1 : 0, n_asm, d_seq_off, d_seq_codes, d_foff, d_begin, d_end, d_size, max_pairs_per_read,
+      d_mark_off, d_marks, d_mark_n, d_mbegin, d_mend, d_msize, d_n_out, d_obegin, d_oend, d_osize, mate_cap, d_n_mates,
+      d_mate_begin, d_mate_end, d_mate_size, err.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(0);
+  uint32_t h_err = 0;
+  BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_err) { set_error("bg_propagate_from_end_batch: a frontier holds more than %d ranges", kFrontierMax); return BG_EINVAL; }
+  return BG_OK;
+}

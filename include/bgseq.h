@@ -226,6 +226,45 @@ int bg_readmap_part(bg_ctx* ctx, const bg_readmap* rm, const char* part, void* h
 int bg_readmap_write(bg_ctx* ctx, const bg_readmap* rm, const char* path, int argc, const char* const* argv,
                      char* h_sha1_hex);
 void bg_readmap_free(bg_readmap* rm);
+/* Opens a readmap container (format 1.2.0 with the mate loop table) and keeps it resident. */
+int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out);
+/* Whole-array form of the per-read accessors (readmap.h:120-138): seqset entry of the read id
+ * (sparse_multi::reverse_lookup), get_readlength, the mate loop pointer, get_is_forward.  Host buffers of
+ * bg_readmap_size() elements; any may be null. */
+int bg_readmap_arrays(bg_ctx* ctx, const bg_readmap* rm, uint32_t* h_entry_id, uint32_t* h_read_len,
+                      uint32_t* h_mate_loop_ptr, uint8_t* h_is_forward);
+/* readmap::get_prefix_reads (bio_base/readmap.cpp:434-447, read_iterator :538-649) for n ranges: the ids
+ * of the reads whose sequence is a prefix of the range's sequence, in iteration order (upward from the
+ * range's first entry, then downward).  d_ids[q*cap ..] receives up to cap ids, d_count[q] the full
+ * number.  BG_EINVAL if the readmap belongs to another seqset (:436-438). */
+int bg_prefix_reads_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n,
+                          const uint64_t* d_begin, const uint64_t* d_end, const uint32_t* d_size,
+                          int read_len_limit, uint32_t cap, uint32_t* d_ids, uint32_t* d_count);
+/* readmap::read accessors for n read ids: has_mate (readmap.cpp:207-218), get_mate_rc (:270-290; ~0 when
+ * unmated), get_rev_comp (:248-268), get_seqset_entry() = ctx_entry(id).truncate(length)
+ * (readmap.h:249-251, seqset.cpp:630-661). */
+int bg_read_info_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n,
+                       const uint32_t* d_read_ids, uint8_t* d_has_mate, uint32_t* d_mate_rc, uint32_t* d_rev_comp,
+                       uint64_t* d_begin, uint64_t* d_end, uint32_t* d_size);
+/* seqset_path::propagate_from_end (variants/assemble.cpp:1345-1418) for n_asm assemblies at once — the
+ * kernel of update_rc_seqset_entries::propagate (graph_discover/update_rc_seqset_entries.cpp:66-73).
+ * Assembly a pushes d_seq_codes[d_seq_off[a] .. d_seq_off[a+1]) from its LAST base to its first (the
+ * caller passes the `seq` argument, i.e. the reverse complement of the assembly) starting from the range
+ * set new_ends = ranges d_foff[a] .. d_foff[a+1] (<= 16).  Outputs: the set at offset 0 (starts) in
+ * d_obegin/d_oend/d_osize[a*16 ..] with d_n_out[a]; the sets at the marked offsets (d_marks ascending
+ * inside d_mark_off[a] .. d_mark_off[a+1], strictly between 0 and the length; d_mark_off may be null)
+ * in d_mbegin/...[mark*16 ..] with d_mark_n[mark]; and, when rm != NULL, the seqset entries of
+ * get_mate_rc() of the mated prefix reads of every range that has at most max_pairs_per_read of them
+ * (:1394-1414): up to mate_cap ranges per assembly, unsorted and with repeats, d_n_mates[a] = full
+ * number (the reference keeps them in a set — fold on the host). */
+int bg_propagate_from_end_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n_asm,
+                                const uint64_t* d_seq_off, const uint8_t* d_seq_codes, const uint32_t* d_foff,
+                                const uint64_t* d_begin, const uint64_t* d_end, const uint32_t* d_size,
+                                uint32_t max_pairs_per_read, const uint32_t* d_mark_off, const uint32_t* d_marks,
+                                uint8_t* d_mark_n, uint64_t* d_mbegin, uint64_t* d_mend, uint32_t* d_msize,
+                                uint8_t* d_n_out, uint64_t* d_obegin, uint64_t* d_oend, uint32_t* d_osize,
+                                uint32_t mate_cap, uint32_t* d_n_mates, uint64_t* d_mate_begin,
+                                uint64_t* d_mate_end, uint32_t* d_mate_size);
 /* bg_create() plus the sample's readmap: the whole data path of SEQSETMain::run
  * (biograph_create.cpp:431-831: kmerize, correct, make_seqset, make_readmap). */
 int bg_create_sample(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n_reads,

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <set>
 #include <string>
@@ -824,6 +825,132 @@ static std::vector<std::string> split_reads(const char* seq, const uint64_t* off
   return v;
 }
 
+// ------------------------------------------------------------------------------------------
+// Readmap queries and seqset_path::propagate_from_end (row G4).
+// bio_base/readmap.cpp:207-218 (has_mate), :248-290 (get_rev_comp / get_mate_rc), :434-447 +
+// :538-649 (get_prefix_reads: the read_iterator state machine, literal), readmap.h:249-251
+// (read::get_seqset_entry), bio_base/seqset.cpp:630-661 (pop_back / truncate).
+static bool rm_has_mate(const Readmap& rm, uint64_t id) { return rm.mate_loop_ptr[rm.mate_loop_ptr[id]] != id; }
+static uint64_t rm_follow(const Readmap& rm, uint64_t id, int n) {
+  for (int c = 0; c < n; ++c) id = rm.mate_loop_ptr[id];
+  return id;
+}
+static uint64_t rm_get_rev_comp(const Readmap& rm, uint64_t id) { return rm_follow(rm, id, rm.is_forward[id] ? 1 : 3); }
+static uint64_t rm_get_mate_rc(const Readmap& rm, uint64_t id) { return rm_follow(rm, id, rm.is_forward[id] ? 3 : 1); }
+static unsigned rm_min_read_len(const Readmap& rm) {
+  unsigned m = ~0u;
+  for (uint32_t l : rm.read_len) m = std::min(m, l);
+  return rm.read_len.empty() ? 0 : m;
+}
+static Range ss_truncate(const Seqset& ss, Range r, uint32_t count) {  // seqset.cpp:630-661
+  if (r.size <= count) return r;
+  uint64_t nb = r.begin, ne = r.end;
+  while (nb && ss.shared[nb] >= count) nb--;
+  while (ne < ss.n && ss.shared[ne] >= count) ne++;
+  return Range{nb, ne, count};
+}
+static Range rm_read_entry(const Seqset& ss, const Readmap& rm, uint64_t id) {  // readmap.h:249-251
+  uint64_t e = rm.entry_id[id];
+  return ss_truncate(ss, Range{e, e + 1, ss.sizes[e]}, rm.read_len[id]);
+}
+static bool rm_d2m_bit(const Readmap& rm, uint64_t id) { return (rm.d2m.bits[0][id / 64] >> (id & 63)) & 1; }
+static std::vector<uint64_t> rm_prefix_reads(const Seqset& ss, const Readmap& rm, Range r, int read_len_limit) {
+  std::vector<uint64_t> out;
+  read_len_limit = std::max<int>(read_len_limit, int(rm_min_read_len(rm)));
+  if (int(r.size) < read_len_limit || rm.n_reads == 0) return out;
+  // sparse_multi::lookup_lower_bound (io/sparse_multi.cpp:32-38): first read id of the first group at or
+  // after entry r.begin
+  const uint64_t n = rm.n_reads;
+  uint64_t id0 = std::lower_bound(rm.entry_id.begin(), rm.entry_id.end(), r.begin) - rm.entry_id.begin();
+  enum { FORWARD, BACKWARD, DONE } phase = FORWARD;
+  uint64_t read_id = id0, seqset_id = r.begin;
+  const int min_size = read_len_limit;
+  int max_len = int(r.size);
+  auto advance = [&](auto& done_direction) {
+    if (phase == FORWARD) { ++read_id; return; }
+    if (read_id == 0) { done_direction(); return; }
+    --read_id;
+  };
+  std::function<void()> done_direction = [&]() {
+    if (phase == FORWARD) {
+      phase = BACKWARD;
+      read_id = id0;
+      seqset_id = r.begin;
+      max_len = int(r.size);
+      advance(done_direction);
+    } else {
+      phase = DONE;
+    }
+  };
+  auto skip_once = [&]() -> bool {
+    bool forward = phase == FORWARD;
+    bool first_in_group;
+    if (forward) {
+      if (read_id == n) { done_direction(); return false; }
+      first_in_group = read_id == 0 || rm_d2m_bit(rm, read_id);
+    } else {
+      uint64_t prev = read_id + 1;
+      first_in_group = prev == n || rm_d2m_bit(rm, prev);
+    }
+    if (first_in_group) {
+      uint64_t new_sid = rm.entry_id[read_id];  // sparse_multi::reverse_lookup
+      while (seqset_id != new_sid) {
+        int shared;
+        if (forward) { ++seqset_id; shared = ss.shared[seqset_id]; }
+        else { shared = ss.shared[seqset_id]; --seqset_id; }
+        if (shared < min_size) { done_direction(); return false; }
+        if (shared < max_len) max_len = shared;
+      }
+    }
+    if (int(rm.read_len[read_id]) > max_len) { advance(done_direction); return false; }
+    return true;
+  };
+  for (;;) {
+    while (phase != DONE && !skip_once()) {}
+    if (phase == DONE) break;
+    out.push_back(read_id);
+    advance(done_direction);
+  }
+  return out;
+}
+
+struct PathOut {
+  std::map<uint32_t, RangeSet> entries;  // offset -> ranges (0 and seq size always present)
+  RangeSet mates;
+};
+// variants/assemble.cpp:1345-1418.  marks = offsets already present in m_entries (refreshed on the way).
+static void propagate_from_end(const Seqset& ss, const Readmap* rm, RangeSet new_ends, const uint8_t* seq, size_t n,
+                               unsigned max_pairs_per_read, const std::set<uint32_t>& marks, PathOut* out) {
+  RangeSet cur = new_ends;
+  dedup_prefixes(cur);
+  out->entries[uint32_t(n)] = cur;
+  out->entries[0];
+  size_t offset = n;
+  while (offset) {
+    --offset;
+    RangeSet nc;
+    for (const Range& r : cur) nc.insert(ss.push_front_drop(r, seq[offset], 0));
+    dedup_prefixes(nc);
+    cur = std::move(nc);
+    if (offset == 0 || marks.count(uint32_t(offset))) out->entries[uint32_t(offset)] = cur;
+    if (rm) {
+      for (const Range& r : cur) {
+        unsigned nreads = 0;
+        std::vector<Range> found;
+        for (uint64_t id : rm_prefix_reads(ss, *rm, r, 0)) {
+          if (!rm_has_mate(*rm, id)) continue;
+          ++nreads;
+          if (nreads > max_pairs_per_read) break;
+          found.push_back(rm_read_entry(ss, *rm, rm_get_mate_rc(*rm, id)));
+        }
+        if (nreads > max_pairs_per_read) continue;
+        out->mates.insert(found.begin(), found.end());
+      }
+    }
+  }
+}
+
+
 extern "C" {
 
 // ---- k-mers
@@ -1077,6 +1204,73 @@ uint64_t orc_pack_bits(const uint64_t* vals, uint64_t n, int bits, uint64_t* out
     if (bit % 64 + bits > 64) out[bit / 64 + 1] |= vals[i] >> (64 - bit % 64);
   }
   return nw;
+}
+// readmap from decoded arrays (a readmap file read back): entry ids, lengths, loop pointers, orientation
+void* orc_readmap_from_arrays(uint64_t n, const uint64_t* entry_id, const uint64_t* read_len, const uint64_t* ptr,
+                              const uint64_t* is_fwd, uint32_t max_read_len) {
+  auto* rm = new Readmap;
+  rm->n_reads = n;
+  rm->max_read_len = max_read_len;
+  rm->entry_id.assign(entry_id, entry_id + n);
+  rm->read_len.resize(n);
+  rm->mate_loop_ptr.assign(ptr, ptr + n);
+  rm->is_forward.resize(n);
+  rm->d2m.n = n;
+  rm->d2m.bits[0].assign((n + 63) / 64, 0);
+  for (uint64_t i = 0; i < n; ++i) {
+    rm->read_len[i] = uint32_t(read_len[i]);
+    rm->is_forward[i] = uint8_t(is_fwd[i]);
+    if (i == 0 || entry_id[i] != entry_id[i - 1]) rm->d2m.bits[0][i / 64] |= 1ull << (i & 63);
+  }
+  return rm;
+}
+uint64_t orc_readmap_prefix_reads(void* rmh, void* ssh, uint64_t begin, uint64_t end, uint32_t size, int limit,
+                                  uint64_t cap, uint64_t* out) {
+  auto ids = rm_prefix_reads(*static_cast<Seqset*>(ssh), *static_cast<Readmap*>(rmh), Range{begin, end, size}, limit);
+  for (uint64_t i = 0; i < ids.size() && i < cap; ++i) out[i] = ids[i];
+  return ids.size();
+}
+// out[6] = has_mate, mate_rc id (or ~0), rev_comp id, entry range begin/end/size
+void orc_readmap_read_info(void* rmh, void* ssh, uint64_t id, uint64_t* out) {
+  auto& rm = *static_cast<Readmap*>(rmh);
+  auto& ss = *static_cast<Seqset*>(ssh);
+  out[0] = rm_has_mate(rm, id);
+  out[1] = out[0] ? rm_get_mate_rc(rm, id) : ~0ull;
+  out[2] = rm_get_rev_comp(rm, id);
+  Range r = rm_read_entry(ss, rm, id);
+  out[3] = r.begin; out[4] = r.end; out[5] = r.size;
+}
+// marks: ascending offsets in (0, n).  Outputs: for offset 0, each mark, and n (in that order) a count
+// in out_counts[] and up to cap triples in out_tri[slot*cap*3 ..]; mates likewise (count returned).
+uint64_t orc_propagate_from_end(void* ssh, void* rmh, const uint8_t* seq, uint64_t n, const uint64_t* tri,
+                                uint64_t n_ends, uint32_t max_pairs, const uint32_t* marks, uint64_t n_marks,
+                                uint64_t cap, uint64_t* out_counts, uint64_t* out_tri, uint64_t mate_cap,
+                                uint64_t* out_mates) {
+  PathOut po;
+  std::set<uint32_t> mk(marks, marks + n_marks);
+  propagate_from_end(*static_cast<Seqset*>(ssh), static_cast<Readmap*>(rmh), to_set(tri, n_ends), seq, n, max_pairs, mk,
+                     &po);
+  std::vector<uint32_t> slots{0};
+  for (uint64_t i = 0; i < n_marks; ++i) slots.push_back(marks[i]);
+  slots.push_back(uint32_t(n));
+  for (size_t sidx = 0; sidx < slots.size(); ++sidx) {
+    const RangeSet& rs = po.entries[slots[sidx]];
+    out_counts[sidx] = rs.size();
+    uint64_t i = 0;
+    for (auto& r : rs) {
+      if (i >= cap) break;
+      uint64_t* o = out_tri + (sidx * cap + i) * 3;
+      o[0] = r.begin; o[1] = r.end; o[2] = r.size;
+      ++i;
+    }
+  }
+  uint64_t i = 0;
+  for (auto& r : po.mates) {
+    if (i >= mate_cap) break;
+    out_mates[3 * i] = r.begin; out_mates[3 * i + 1] = r.end; out_mates[3 * i + 2] = r.size;
+    ++i;
+  }
+  return po.mates.size();
 }
 void orc_readmap_free(void* h) { delete static_cast<Readmap*>(h); }
 

@@ -96,6 +96,14 @@ def lib():
     L.orc_pack_bits.restype = C.c_uint64
     L.orc_pack_bits.argtypes = [u64p, C.c_uint64, C.c_int, C.c_void_p]
     L.orc_readmap_free.argtypes = [vp]
+    L.orc_readmap_from_arrays.restype = vp
+    L.orc_readmap_from_arrays.argtypes = [C.c_uint64, u64p, u64p, u64p, u64p, C.c_uint32]
+    L.orc_readmap_prefix_reads.restype = C.c_uint64
+    L.orc_readmap_prefix_reads.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_uint64, u64p]
+    L.orc_readmap_read_info.argtypes = [vp, vp, C.c_uint64, u64p]
+    L.orc_propagate_from_end.restype = C.c_uint64
+    L.orc_propagate_from_end.argtypes = [vp, vp, u8p, C.c_uint64, u64p, C.c_uint64, C.c_uint32, u32p, C.c_uint64,
+                                         C.c_uint64, u64p, u64p, C.c_uint64, u64p]
     _LIB = L
     return L
 
@@ -348,6 +356,30 @@ class Seqset:
         cur = [(int(oc[3 * i]), int(oc[3 * i + 1]), int(oc[3 * i + 2])) for i in range(int(no[0]))]
         return int(ne[0]), ev, cur
 
+    def propagate_from_end(self, seq_codes, ends, readmap=None, max_pairs_per_read=20, marks=(), cap=64,
+                           mate_cap=65536):
+        """seqset_path::propagate_from_end (variants/assemble.cpp:1345-1418).  seq_codes = the `seq`
+        argument (bases pushed from its end to its start); returns ({offset: [ranges]}, [mates])."""
+        tri = _pad(np.array(ends, np.uint64).reshape(-1))
+        seq_codes = np.ascontiguousarray(seq_codes, np.uint8)
+        marks = np.ascontiguousarray(sorted(marks), np.uint32)
+        ns = len(marks) + 2
+        counts = np.zeros(ns, np.uint64)
+        out = np.zeros(ns * cap * 3, np.uint64)
+        mates = np.zeros(mate_cap * 3, np.uint64)
+        nm = lib().orc_propagate_from_end(self.h, readmap.h if readmap is not None else None, _pad(seq_codes),
+                                          len(seq_codes), tri, len(ends), max_pairs_per_read, _pad(marks), len(marks),
+                                          cap, counts, out, mate_cap, mates)
+        slots = [0] + [int(m) for m in marks] + [len(seq_codes)]
+        ent = {}
+        for i, off in enumerate(slots):
+            c = int(counts[i])
+            assert c <= cap
+            o = out[i * cap * 3:(i * cap + c) * 3].reshape(-1, 3)
+            ent[off] = [tuple(int(x) for x in row) for row in o]
+        assert nm <= mate_cap
+        return ent, [tuple(int(x) for x in mates[3 * i:3 * i + 3]) for i in range(int(nm))]
+
     def ref_map_build(self, ref_codes, ext_start, ext_size):
         out = np.zeros(max(len(self), 1), np.uint8)
         lib().orc_ref_map_build(self.h, np.ascontiguousarray(ref_codes, np.uint8),
@@ -500,6 +532,29 @@ class Readmap:
         if not self.h:
             raise RuntimeError(lib().orc_readmap_error().decode())
         self.n_entries = len(seqset)
+
+    @classmethod
+    def from_arrays(cls, n_entries, entry_id, read_len, mate_loop_ptr, is_forward, max_read_len):
+        """A readmap read back from its container (decode_readmap) — for the query functions."""
+        self = cls.__new__(cls)
+        a = [np.ascontiguousarray(x, np.uint64) for x in (entry_id, read_len, mate_loop_ptr, is_forward)]
+        self.h = lib().orc_readmap_from_arrays(len(a[0]), _pad(a[0]), _pad(a[1]), _pad(a[2]), _pad(a[3]),
+                                               int(max_read_len))
+        self.n_entries = n_entries
+        return self
+
+    # ---- queries (bio_base/readmap.cpp:207-290,434-447,538-649; readmap.h:249-251) ----------------
+    def prefix_reads(self, seqset, rng, read_len_limit=0, cap=4096):
+        """Read ids of get_prefix_reads(range) in iteration order (forward, then backward)."""
+        out = np.zeros(cap, np.uint64)
+        n = lib().orc_readmap_prefix_reads(self.h, seqset.h, rng[0], rng[1], rng[2], read_len_limit, cap, out)
+        return [int(x) for x in out[:min(n, cap)]]
+
+    def read_info(self, seqset, read_id):
+        """(has_mate, mate_rc id or None, rev_comp id, (begin, end, size) of read.get_seqset_entry())."""
+        o = np.zeros(6, np.uint64)
+        lib().orc_readmap_read_info(self.h, seqset.h, read_id, o)
+        return bool(o[0]), (int(o[1]) if o[0] else None), int(o[2]), (int(o[3]), int(o[4]), int(o[5]))
 
     def __len__(self):
         return lib().orc_readmap_size(self.h)

@@ -177,3 +177,83 @@ def test_readmap_oracle_against_lambda_golden(golden_dir):
     assert len(cm) == len(cg) == 28939
     # same loops up to rotation: a loop is fwd -> rc -> mate fwd -> mate rc (or fwd -> rc)
     assert sorted(tuple(sorted(c)) for c in cm) == sorted(tuple(sorted(c)) for c in cg)
+
+
+@pytest.fixture(scope="module")
+def lambda_world(golden_dir):
+    d = O.load_seqset_zip(golden_dir + "/father_lambda/seqset")
+    g = O.decode_readmap(golden_dir + "/father_lambda/readmap", d)
+    ent_strs = O.decode_entries(d)
+    ent = O.Entries.from_strings(ent_strs)
+    ss = O.Seqset.from_entries(ent)
+    rm = O.Readmap.from_arrays(d["n"], g["entry"], g["read_len"], g["mate_loop_ptr"], g["is_forward"], 150)
+    return d, g, ent_strs, ss, rm
+
+
+def test_readmap_queries_on_lambda_golden(lambda_world):
+    """Oracle restatement of readmap::get_prefix_reads / has_mate / get_mate_rc / get_rev_comp /
+    read::get_seqset_entry (bio_base/readmap.cpp:207-290,434-447,538-649) on the reference-written
+    lambda readmap, against brute force over the decoded sequences."""
+    d, g, ent, ss, rm = lambda_world
+    n_ids = g["n_reads"]
+    rl, entry = g["read_len"], g["entry"]
+    seqs = [ent[int(entry[i])][:int(rl[i])] for i in range(n_ids)]
+    comp = str.maketrans("ACGT", "TGCA")
+    rng = np.random.default_rng(3)
+    ids = rng.choice(n_ids, 300, replace=False)
+    by_seq = {}
+    for i, s in enumerate(seqs):
+        by_seq.setdefault(s, []).append(i)
+    for i in map(int, ids):
+        has_mate, mate_rc, rev, r = rm.read_info(ss, i)
+        assert seqs[rev] == seqs[i].translate(comp)[::-1]
+        assert rm.read_info(ss, rev)[2] == i
+        assert r == ss.find(seqs[i])                     # ctx_entry(id).truncate(len) == find(read)
+        assert bool(g["is_forward"][rev]) != bool(g["is_forward"][i])
+        if has_mate:
+            # mate_rc of mate_rc is the read itself; the mate's reverse complement is a different read id
+            assert rm.read_info(ss, mate_rc)[1] == i
+        # get_prefix_reads(range of this read) = every read whose sequence is a prefix of it
+        got = rm.prefix_reads(ss, r)
+        want = sorted(j for L in range(1, len(seqs[i]) + 1) for j in by_seq.get(seqs[i][:L], []))
+        assert sorted(got) == want and i in got
+        assert len(set(got)) == len(got)
+    # ranges shorter than every read give nothing (readmap.cpp:439-442)
+    assert rm.prefix_reads(ss, ss.find("ACGT")) == []
+    assert int(rl.min()) >= 30
+
+
+def test_propagate_from_end_on_lambda_golden(lambda_world, golden_dir):
+    """seqset_path::propagate_from_end (variants/assemble.cpp:1345-1418) over slices of the lambda
+    reference, against a plain Python walk with the oracle's push_front_drop and brute-force mates."""
+    d, g, ent, ss, rm = lambda_world
+    ref = "".join(l.strip() for l in open(golden_dir + "/father_lambda/reference.fasta") if not l.startswith(">"))
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    n = d["n"]
+    seqs_len = g["read_len"]
+
+    def dedup(rs):
+        rs = set(rs)
+        return sorted(r for r in rs if not any(o != r and o[0] >= r[0] and o[1] <= r[1] and
+                                               (o[0] > r[0] or o[1] < r[1] or o[2] > r[2]) for o in rs))
+    for a, ln in [(1000, 400), (20000, 333), (48000, 200)]:
+        seq = np.array([3 - code[c] for c in reversed(ref[a:a + ln])], np.uint8)   # rev_comp of the slice
+        marks = [7, ln // 2]
+        got, mates = ss.propagate_from_end(seq, [(0, n, 0)], rm, 20, marks)
+        cur = [(0, n, 0)]
+        want, want_mates = {ln: cur}, set()
+        for off in range(ln - 1, -1, -1):
+            b, e, s = (np.array(x) for x in zip(*cur))
+            ob, oe, osz = ss.push_front_drop(b, e, s, np.full(len(cur), seq[off], np.uint8), np.zeros(len(cur), np.uint32))
+            cur = dedup([(int(x), int(y), int(z)) for x, y, z in zip(ob, oe, osz)])
+            if off == 0 or off in marks:
+                want[off] = cur
+            for r in cur:
+                ids = [i for i in rm.prefix_reads(ss, r) if rm.read_info(ss, i)[0]]
+                if len(ids) <= 20:
+                    want_mates.update(rm.read_info(ss, rm.read_info(ss, i)[1])[3] for i in ids)
+        assert got == want
+        assert set(mates) == want_mates and len(mates) == len(want_mates)
+        assert len(mates) > 0
+        # the walk ends on the reference's own bases
+        assert all(sz >= 100 for _, _, sz in got[0])
