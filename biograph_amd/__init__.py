@@ -494,6 +494,41 @@ class Seqset(_Handle):
             dref.free()
             out.free()
 
+    def push_to_pair_trace_batch(self, frontiers, min_overlap, max_steps=512, range_cap=None, seen_cap=256):
+        """Extension traces of push_to_pair_discover::on_trace -> list of (reason, [bases], [frontier per step])."""
+        ctx, n = self.ctx, len(frontiers)
+        range_cap = range_cap or 4 * max_steps
+        foff, b, e, s = self._flatten_frontiers(frontiers)
+        D = DeviceArray
+        ins = [D.from_numpy(ctx, foff), D.from_numpy(ctx, b), D.from_numpy(ctx, e), D.from_numpy(ctx, s)]
+        m = max(n, 1)
+        outs = [D(ctx, m * 4), D(ctx, m), D(ctx, m * max_steps), D(ctx, m * max_steps), D(ctx, m * 4),
+                D(ctx, m * range_cap * 8), D(ctx, m * range_cap * 8), D(ctx, m * range_cap * 4)]
+        try:
+            vp = C.c_void_p
+            capi.check(capi.lib().bg_push_to_pair_trace_batch(ctx.h, self.h, n, *[vp(a.ptr) for a in ins], min_overlap,
+                                                              max_steps, range_cap, seen_cap,
+                                                              *[vp(a.ptr) for a in outs]))
+            ns = outs[0].to_numpy(np.uint32, n)
+            why = outs[1].to_numpy(np.uint8, n)
+            bases = outs[2].to_numpy(np.uint8, n * max_steps)
+            counts = outs[3].to_numpy(np.uint8, n * max_steps)
+            rb, re_ = outs[5].to_numpy(np.uint64, n * range_cap), outs[6].to_numpy(np.uint64, n * range_cap)
+            rs = outs[7].to_numpy(np.uint32, n * range_cap)
+        finally:
+            for a in ins + outs:
+                a.free()
+        res = []
+        for a in range(n):
+            k = int(ns[a])
+            fr, pos = [], a * range_cap
+            for t in range(k):
+                c = int(counts[a * max_steps + t])
+                fr.append([(int(rb[pos + i]), int(re_[pos + i]), int(rs[pos + i])) for i in range(c)])
+                pos += c
+            res.append((int(why[a]), [int(x) for x in bases[a * max_steps:a * max_steps + k]], fr))
+        return res
+
     # ---- row G4: readmap queries and propagate_from_end ------------------------------------------
     def prefix_reads_batch(self, readmap, ranges, read_len_limit=0, cap=256):
         """readmap::get_prefix_reads for each (begin, end, size) -> list of read-id lists (iteration order)."""

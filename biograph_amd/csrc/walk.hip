@@ -765,3 +765,148 @@ extern "C" int bg_propagate_from_end_batch(bg_ctx* ctx, const bg_seqset* ss, con
   if (h_err) { set_error("bg_propagate_from_end_batch: a frontier holds more than %d ranges", kFrontierMax); return BG_EINVAL; }
   return BG_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Row G2 driver loop: the extension trace of push_to_pair_discover::on_trace
+// (graph_discover/push_to_pair.cpp:271-343) — repeat trace_one_base from the assembly's rc start ranges
+// until nothing extends (reason 0), a dropped range of the chosen base repeats (m_seen_ranges, :221-225;
+// reason 1), max_steps is reached (2), or one of the bounded per-assembly buffers is full (3 = seen list,
+// 4 = range buffer; the host resumes from the last recorded frontier).  One wave per assembly; a step is
+// 64 concurrent push_front_drop calls (4 bases x 16 ranges).  The frontier after every step is recorded
+// for the host's mate / anchor bookkeeping (:289-342), which cuts the path but never changes it.
+__global__ __launch_bounds__(256) void k_push_to_pair_trace(
+    SeqsetView v, uint64_t na, const uint32_t* __restrict__ foff, const uint64_t* __restrict__ fbegin,
+    const uint64_t* __restrict__ fend, const uint32_t* __restrict__ fsize, uint32_t min_overlap, uint32_t max_steps,
+    uint32_t range_cap, uint32_t seen_cap, uint64_t* __restrict__ seen_b, uint64_t* __restrict__ seen_e,
+    uint32_t* __restrict__ seen_s, uint32_t* __restrict__ n_steps, uint8_t* __restrict__ reason,
+    uint8_t* __restrict__ bases, uint8_t* __restrict__ counts, uint32_t* __restrict__ n_ranges,
+    uint64_t* __restrict__ rb_out, uint64_t* __restrict__ re_out, uint32_t* __restrict__ rs_out,
+    uint32_t* __restrict__ err) {
+  const int lane = threadIdx.x & 63;
+  uint64_t a = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (a >= na) return;
+  uint32_t lo = foff[a], hi = foff[a + 1];
+  if (hi - lo > uint32_t(kFrontierMax)) {
+    if (lane == 0) { atomicOr(err, 1u); n_steps[a] = 0; reason[a] = 0; n_ranges[a] = 0; }
+    return;
+  }
+  Tri cur{0, 0, 0};
+  bool cv = uint32_t(lane) < hi - lo;
+  if (cv) { cur.b = fbegin[lo + lane]; cur.e = fend[lo + lane]; cur.s = fsize[lo + lane]; }
+  cv = cv && cur.b < cur.e && cur.e <= v.n;
+  const int r = lane & 15, b = lane >> 4;
+  uint32_t steps = 0, nseen = 0, nr = 0;
+  int why = 0;
+  uint64_t* sb = seen_b + a * uint64_t(seen_cap);
+  uint64_t* se = seen_e + a * uint64_t(seen_cap);
+  uint32_t* ssz = seen_s + a * uint64_t(seen_cap);
+  for (;;) {
+    if (!__ballot(cv)) { why = 0; break; }
+    if (steps >= max_steps) { why = 2; break; }
+    uint64_t qb = __shfl(cur.b, r, 64), qe = __shfl(cur.e, r, 64);
+    uint32_t qs = __shfl(cur.s, r, 64);
+    bool qv = __shfl(int(cv), r, 64) != 0;
+    uint64_t ob = 0, oe = 0;
+    uint32_t os = 0;
+    if (qv) v.push_front_drop(qb, qe, qs, b, min_overlap, &ob, &oe, &os);
+    bool valid = oe > ob;
+    bool drop = valid && os != qs + 1;
+    uint32_t m = valid ? os : 0;
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) {
+      uint32_t t = __shfl_xor(m, d, 64);
+      m = t > m ? t : m;
+    }
+    uint32_t best_len = 0;
+    int best = -1;
+    for (int bb = 0; bb < 4; ++bb) {  // strict > : first base wins ties (:196)
+      uint32_t l = __shfl(m, bb * 16, 64);
+      if (l > best_len) { best_len = l; best = bb; }
+    }
+    if (best < 0) { why = 0; break; }
+    int src = best * 16 + (lane & 15);
+    Tri c{__shfl(ob, src, 64), __shfl(oe, src, 64), __shfl(os, src, 64)};
+    bool nv = (__shfl(int(valid), src, 64) != 0) && lane < kFrontierMax;
+    bool cd = __shfl(int(drop), src, 64) != 0;
+    int rank, count;
+    frontier_dedup(c, nv, cd, false, lane, &rank, &count);
+    // m_seen_ranges: every dropped candidate must be new
+    uint64_t dmask = __ballot(nv && cd);
+    bool dup = false, full = false;
+    while (dmask) {
+      int j = __ffsll((long long)dmask) - 1;
+      dmask &= dmask - 1;
+      Tri t{__shfl(c.b, j, 64), __shfl(c.e, j, 64), __shfl(c.s, j, 64)};
+      bool hit = false;
+      for (uint32_t i = lane; i < nseen; i += 64)  // agent-scope loads: lane 0's stores below must be seen
+        hit |= __hip_atomic_load(&sb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == t.b &&
+               __hip_atomic_load(&se[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == t.e &&
+               __hip_atomic_load(&ssz[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == t.s;
+      if (__ballot(hit)) { dup = true; break; }
+      if (nseen >= seen_cap) { full = true; break; }
+      if (lane == 0) {
+        __hip_atomic_store(&sb[nseen], t.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&se[nseen], t.e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ssz[nseen], t.s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      ++nseen;
+      __threadfence();
+    }
+    if (dup) { why = 1; break; }
+    if (full) { why = 3; break; }
+    frontier_dedup(c, nv, cd, true, lane, &rank, &count);
+    if (nr + uint32_t(count) > range_cap) { why = 4; break; }
+    if (nv) {
+      uint64_t o = a * uint64_t(range_cap) + nr + rank;
+      rb_out[o] = c.b; re_out[o] = c.e; rs_out[o] = c.s;
+    }
+    if (lane == 0) {
+      bases[a * uint64_t(max_steps) + steps] = uint8_t(3 - best);  // appended base = complement (:236)
+      counts[a * uint64_t(max_steps) + steps] = uint8_t(count);
+    }
+    nr += uint32_t(count);
+    ++steps;
+    // re-seat survivors by rank so the frontier stays in set order
+    Tri nxt{0, 0, 0};
+    bool nxv = false;
+    for (int j = 0; j < kFrontierMax; ++j) {
+      Tri t{__shfl(c.b, j, 64), __shfl(c.e, j, 64), __shfl(c.s, j, 64)};
+      bool jv = __shfl(int(nv), j, 64) != 0;
+      int jr = __shfl(rank, j, 64);
+      if (jv && jr == lane) { nxt = t; nxv = true; }
+    }
+    cur = nxt;
+    cv = nxv;
+  }
+  if (lane == 0) { n_steps[a] = steps; reason[a] = uint8_t(why); n_ranges[a] = nr; }
+}
+
+extern "C" int bg_push_to_pair_trace_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n_asm, const uint32_t* d_foff,
+                                           const uint64_t* d_begin, const uint64_t* d_end, const uint32_t* d_size,
+                                           uint32_t min_overlap, uint32_t max_steps, uint32_t range_cap,
+                                           uint32_t seen_cap, uint32_t* d_n_steps, uint8_t* d_reason,
+                                           uint8_t* d_bases, uint8_t* d_counts, uint32_t* d_n_ranges,
+                                           uint64_t* d_rbegin, uint64_t* d_rend, uint32_t* d_rsize) {
+  BG_TRY(check_ss(ctx, ss, "bg_push_to_pair_trace_batch"));
+  if (!max_steps || !range_cap || !seen_cap) { set_error("bg_push_to_pair_trace_batch: zero capacity"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!n_asm) return BG_OK;
+  DevBuf<uint32_t> err, seen_s;
+  DevBuf<uint64_t> seen_b, seen_e;
+  BG_TRY(err.alloc(ctx, 1));
+  BG_TRY(seen_b.alloc(ctx, n_asm * seen_cap));
+  BG_TRY(seen_e.alloc(ctx, n_asm * seen_cap));
+  BG_TRY(seen_s.alloc(ctx, n_asm * seen_cap));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+  ctx->tic("walk_push_to_pair_trace");
+  k_push_to_pair_trace<<<cdiv(n_asm, 4), 256, 0, ctx->stream>>>(
+      make_view(ss), n_asm, d_foff, d_begin, d_end, d_size, min_overlap, max_steps, range_cap, seen_cap, seen_b.p,
+      seen_e.p, seen_s.p, d_n_steps, d_reason, d_bases, d_counts, d_n_ranges, d_rbegin, d_rend, d_rsize, err.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(0);
+  uint32_t h_err = 0;
+  BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_err) { set_error("bg_push_to_pair_trace_batch: a frontier holds more than %d ranges", kFrontierMax); return BG_EINVAL; }
+  return BG_OK;
+}

@@ -194,6 +194,21 @@ int bg_branch_trace_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n_asm, cons
                           const uint64_t* d_end, const uint32_t* d_size, uint32_t min_overlap, uint32_t ev_cap,
                           uint32_t* d_ev_off, uint8_t* d_ev_base, uint32_t* d_n_ev, uint8_t* d_n_out,
                           uint64_t* d_obegin, uint64_t* d_oend, uint32_t* d_osize);
+/* The extension trace of push_to_pair_discover::on_trace (graph_discover/push_to_pair.cpp:271-343) for
+ * n_asm assemblies at once: from the assembly's rc start ranges (d_foff / d_begin / d_end / d_size as in
+ * bg_trace_one_base_batch, min context = min_overlap: k_check_reads is false, :14,203-232) repeat
+ * trace_one_base until it returns nothing.  Per assembly a: d_n_steps[a] steps were taken; step t
+ * appended base d_bases[a*max_steps+t] and left a frontier of d_counts[a*max_steps+t] ranges, stored
+ * consecutively in d_rbegin/d_rend/d_rsize[a*range_cap ..] (d_n_ranges[a] in total).  d_reason[a]:
+ * 0 nothing extends, 1 a dropped range repeated (m_seen_ranges, :221-225), 2 max_steps reached,
+ * 3 more than seen_cap dropped ranges, 4 range buffer full (resume from the last frontier for 2-4).
+ * The mate / anchor checks between the steps (:289-342) stay with the host: they cut the path, they do
+ * not change it. */
+int bg_push_to_pair_trace_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n_asm, const uint32_t* d_foff,
+                                const uint64_t* d_begin, const uint64_t* d_end, const uint32_t* d_size,
+                                uint32_t min_overlap, uint32_t max_steps, uint32_t range_cap, uint32_t seen_cap,
+                                uint32_t* d_n_steps, uint8_t* d_reason, uint8_t* d_bases, uint8_t* d_counts,
+                                uint32_t* d_n_ranges, uint64_t* d_rbegin, uint64_t* d_rend, uint32_t* d_rsize);
 /* ref_map::build (variants/ref_map.cpp:72-185): marks seqset entries that are full-entry matches of the
  * reference (both strands).  d_ref_codes = reference bases 0..3; extents = N-free supercontigs
  * (flat_ref index, bio_base/flat_ref.h).  d_out[n] = [fwd_flag:1|rev_flag:1|count:6 saturating]

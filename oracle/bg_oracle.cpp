@@ -624,6 +624,30 @@ static int trace_one_base(const Seqset& ss, const RangeSet& rs, uint32_t min_ctx
   return best;
 }
 
+// The extension loop of push_to_pair_discover::on_trace (graph_discover/push_to_pair.cpp:271-343) as far
+// as it depends on the seqset alone: repeat trace_one_base from `rs` (k_check_reads=false => the
+// min context is always min_overlap), stop when nothing extends (reason 0), when a dropped range of the
+// chosen base was already seen in this trace (m_seen_ranges, :221-225; reason 1) or after max_steps
+// (reason 2).  The mate / anchor checks between the steps (:289-342) only decide where the host cuts
+// the path; they do not alter it.
+static int push_to_pair_trace(const Seqset& ss, RangeSet rs, uint32_t min_overlap, size_t max_steps,
+                              std::vector<uint8_t>* bases, std::vector<RangeSet>* fronts) {
+  std::set<Range, RangeLess> seen;
+  while (!rs.empty()) {
+    if (bases->size() >= max_steps) return 2;
+    std::vector<std::pair<Range, bool>> cands;
+    RangeSet next;
+    int best = trace_one_base(ss, rs, min_overlap, &cands, &next);
+    if (best < 0) return 0;
+    for (auto& c : cands)
+      if (c.second && !seen.insert(c.first).second) return 1;
+    bases->push_back(uint8_t(3 - best));  // the appended base is the complement of the pushed one (:236)
+    fronts->push_back(next);
+    rs = std::move(next);
+  }
+  return 0;
+}
+
 // graph_discover/branch.cpp:20-80: walk `seq` (codes 0..3) from frontier `cur`; at each offset the first
 // non-reference base (order A,C,G,T over b, pushing its complement) with any valid
 // push_front_drop(rc_b, min_overlap) is reported; then cur advances along the reference base.
@@ -1161,6 +1185,27 @@ void orc_branch_trace(void* h, const uint8_t* seq, uint64_t n, const uint64_t* t
     out_cur[3 * i] = r.begin; out_cur[3 * i + 1] = r.end; out_cur[3 * i + 2] = r.size;
     ++i;
   }
+}
+// out_bases[cap_steps], out_counts[cap_steps], out_tri[cap_steps*cap*3]; returns the stop reason, *n_steps
+int orc_push_to_pair_trace(void* h, const uint64_t* tri, uint64_t n, uint32_t min_overlap, uint64_t max_steps,
+                           uint64_t cap, uint8_t* out_bases, uint64_t* out_counts, uint64_t* out_tri,
+                           uint64_t* n_steps) {
+  std::vector<uint8_t> bases;
+  std::vector<RangeSet> fronts;
+  int reason = push_to_pair_trace(*static_cast<Seqset*>(h), to_set(tri, n), min_overlap, max_steps, &bases, &fronts);
+  *n_steps = bases.size();
+  for (size_t st = 0; st < bases.size(); ++st) {
+    out_bases[st] = bases[st];
+    out_counts[st] = fronts[st].size();
+    uint64_t i = 0;
+    for (auto& r : fronts[st]) {
+      if (i >= cap) break;
+      uint64_t* o = out_tri + (st * cap + i) * 3;
+      o[0] = r.begin; o[1] = r.end; o[2] = r.size;
+      ++i;
+    }
+  }
+  return reason;
 }
 void orc_ref_map_build(void* h, const uint8_t* ref_codes, const uint64_t* ext_start, const uint64_t* ext_size,
                        uint64_t n_ext, uint8_t* out) {

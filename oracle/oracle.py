@@ -82,6 +82,9 @@ def lib():
     L.orc_trace_one_base.argtypes = [vp, u64p, C.c_uint64, C.c_uint32, C.c_uint64, u64p, u8p, u64p, u64p, u64p]
     L.orc_branch_trace.argtypes = [vp, u8p, C.c_uint64, u64p, C.c_uint64, C.c_uint32, C.c_uint64, u32p, u8p, u64p,
                                    u64p, u64p]
+    L.orc_push_to_pair_trace.restype = C.c_int
+    L.orc_push_to_pair_trace.argtypes = [vp, u64p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, u8p, u64p, u64p,
+                                         u64p]
     L.orc_ref_map_build.argtypes = [vp, u8p, u64p, u64p, C.c_uint64, u8p]
     L.orc_readmap_build.restype = vp
     L.orc_readmap_build.argtypes = [vp, vp, u8p, u64p, C.c_uint64, u64p, C.c_uint64, C.c_int, C.c_int]
@@ -355,6 +358,23 @@ class Seqset:
         ev = [(int(eo[i]), int(eb[i])) for i in range(min(int(ne[0]), cap))]
         cur = [(int(oc[3 * i]), int(oc[3 * i + 1]), int(oc[3 * i + 2])) for i in range(int(no[0]))]
         return int(ne[0]), ev, cur
+
+    def push_to_pair_trace(self, ranges, min_overlap, max_steps=1000, cap=16):
+        """Extension loop of push_to_pair_discover::on_trace -> (reason, [base codes], [frontier per step])."""
+        tri = _pad(np.array(ranges, np.uint64).reshape(-1))
+        bases = np.zeros(max(max_steps, 1), np.uint8)
+        counts = np.zeros(max(max_steps, 1), np.uint64)
+        out = np.zeros(max(max_steps, 1) * cap * 3, np.uint64)
+        ns = np.zeros(1, np.uint64)
+        reason = lib().orc_push_to_pair_trace(self.h, tri, len(ranges), min_overlap, max_steps, cap, bases, counts, out,
+                                              ns)
+        n = int(ns[0])
+        fronts = []
+        for st in range(n):
+            c = int(counts[st])
+            assert c <= cap
+            fronts.append([tuple(int(x) for x in out[(st * cap + i) * 3:(st * cap + i) * 3 + 3]) for i in range(c)])
+        return reason, [int(b) for b in bases[:n]], fronts
 
     def propagate_from_end(self, seq_codes, ends, readmap=None, max_pairs_per_read=20, marks=(), cap=64,
                            mate_cap=65536):

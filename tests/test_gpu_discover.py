@@ -94,3 +94,40 @@ def test_branch_trace_matches_oracle(world):
             n, ev, cur = oss.branch_trace(s_, f, mo)
             assert g[0] == n and g[1] == ev and g[2] == cur
     assert any(g[0] > 0 for g in got)
+
+
+def test_push_to_pair_trace_matches_oracle(world):
+    """Extension traces (the loop of push_to_pair_discover::on_trace) from rc frontiers of the lambda
+    reference — a trace from there re-walks the sample's haplotype — incl. the bounded-buffer stop
+    reasons and resuming from the last recorded frontier."""
+    ctx, d, oss, ss, ref = world
+    n = len(oss)
+    rng = np.random.default_rng(21)
+    fronts = []
+    for _ in range(150):
+        p = int(rng.integers(200, len(ref) - 200))
+        cur = [(0, n, 0)]
+        for c in ref[p - 150:p]:   # rc context of ref[p-150:p]: push the complement of the forward bases
+            b, e, s = (np.array(x) for x in zip(*cur))
+            ob, oe, osz = oss.push_front_drop(b, e, s, np.full(len(cur), 3 - c, np.uint8),
+                                              np.zeros(len(cur), np.uint32))
+            cur = sorted({(int(x), int(y), int(z)) for x, y, z in zip(ob, oe, osz) if y > x})[:16]
+        fronts.append(cur)
+    fronts += _frontiers_from_ref(oss, ref, rng, 50, 60)
+    fronts.append([])
+    fronts.append([(0, n, 0)])
+    reasons = set()
+    for mo, steps in [(70, 64), (105, 300), (30, 40)]:
+        got = ss.push_to_pair_trace_batch(fronts, mo, max_steps=steps)
+        for f, g in zip(fronts, got):
+            want = oss.push_to_pair_trace(f, mo, steps)
+            assert g == want, (f, mo)
+            reasons.add(g[0])
+    assert {0, 2} <= reasons
+    f = fronts[0]
+    full = oss.push_to_pair_trace(f, 70, 64)
+    assert len(full[1]) > 20
+    part = ss.push_to_pair_trace_batch([f], 70, max_steps=64, range_cap=10)[0]
+    assert part[0] == 4 and 0 < len(part[1]) < len(full[1])
+    rest = ss.push_to_pair_trace_batch([part[2][-1]], 70, max_steps=64 - len(part[1]))[0]
+    assert part[1] + rest[1] == full[1] and part[2] + rest[2] == full[2]
