@@ -111,6 +111,69 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev):
     k = torch.minimum(n_ev, torch.full_like(n_ev, cap))
     mask = torch.arange(cap, device=dev)[None, :] < k[:, None]
     sites = int(((ev_off.view(na, cap) >= WARM) & mask).sum().item())
+    # every branch site -> its 1-base branch assembly (discover_extend_right, discover.cpp:157-175): rc
+    # ranges by propagate_from_end over the 255 reference bases before the site + the alt base (row G4),
+    # then the push-to-pair extension trace from there (row G2 loop), up to 256 bases
+    ev_ok = ((ev_off.view(na, cap) >= WARM) & mask)
+    aidx, eidx = torch.nonzero(ev_ok, as_tuple=True)
+    ns = int(aidx.numel())
+    ext = None
+    if ns:
+        pos = starts[aidx] + ev_off.view(na, cap)[aidx, eidx].to(torch.int64)       # absolute site position
+        alt = ev_base.view(na, cap)[aidx, eidx]
+        LW = 256
+        win = (pos[:, None] - (LW - 1) + torch.arange(0, LW - 1, device=dev)[None, :]).clamp_(min=0)
+        fwd = torch.cat([genome[win], alt[:, None]], dim=1)                          # assembly sequence
+        pcodes = (3 - fwd.flip(1)).to(torch.uint8).contiguous().view(-1)             # its reverse complement
+        psoff = (torch.arange(0, ns + 1, device=dev, dtype=torch.int64) * LW).contiguous()
+        pfoff = torch.arange(0, ns + 1, device=dev, dtype=torch.int32)
+        pfb = torch.zeros(ns, dtype=torch.int64, device=dev)
+        pfe = torch.full((ns,), n, dtype=torch.int64, device=dev)
+        pfs = torch.zeros(ns, dtype=torch.int32, device=dev)
+        pn = torch.empty(ns, dtype=torch.uint8, device=dev)
+        pb = torch.empty(ns * 16, dtype=torch.int64, device=dev)
+        pe = torch.empty(ns * 16, dtype=torch.int64, device=dev)
+        ps = torch.empty(ns * 16, dtype=torch.int32, device=dev)
+        nmates = torch.empty(ns, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        capi.check(L.bg_propagate_from_end_batch(ctx.h, ss.h, None, ns, vp(psoff.data_ptr()), vp(pcodes.data_ptr()),
+                                                 vp(pfoff.data_ptr()), vp(pfb.data_ptr()), vp(pfe.data_ptr()),
+                                                 vp(pfs.data_ptr()), 20, None, None, None, None, None, None,
+                                                 vp(pn.data_ptr()), vp(pb.data_ptr()), vp(pe.data_ptr()),
+                                                 vp(ps.data_ptr()), 1, vp(nmates.data_ptr()), None, None, None))
+        torch.cuda.synchronize()
+        t_prop = time.perf_counter() - t0
+        keep = torch.arange(16, device=dev)[None, :] < pn[:, None].to(torch.int64)
+        tfoff = torch.zeros(ns + 1, dtype=torch.int32, device=dev)
+        tfoff[1:] = torch.cumsum(pn.to(torch.int32), 0)
+        tb, te, tz = pb.view(ns, 16)[keep].contiguous(), pe.view(ns, 16)[keep].contiguous(), ps.view(ns, 16)[keep].contiguous()
+        MAXS, RC, SC = 256, 1024, 256
+        o_ns = torch.empty(ns, dtype=torch.int32, device=dev)
+        o_why = torch.empty(ns, dtype=torch.uint8, device=dev)
+        o_bases = torch.empty(ns * MAXS, dtype=torch.uint8, device=dev)
+        o_cnt = torch.empty(ns * MAXS, dtype=torch.uint8, device=dev)
+        o_nr = torch.empty(ns, dtype=torch.int32, device=dev)
+        o_rb = torch.empty(ns * RC, dtype=torch.int64, device=dev)
+        o_re = torch.empty(ns * RC, dtype=torch.int64, device=dev)
+        o_rs = torch.empty(ns * RC, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        capi.check(L.bg_push_to_pair_trace_batch(ctx.h, ss.h, ns, vp(tfoff.data_ptr()), vp(tb.data_ptr()),
+                                                 vp(te.data_ptr()), vp(tz.data_ptr()), 105, MAXS, RC, SC,
+                                                 vp(o_ns.data_ptr()), vp(o_why.data_ptr()), vp(o_bases.data_ptr()),
+                                                 vp(o_cnt.data_ptr()), vp(o_nr.data_ptr()), vp(o_rb.data_ptr()),
+                                                 vp(o_re.data_ptr()), vp(o_rs.data_ptr())))
+        torch.cuda.synchronize()
+        t_tr = time.perf_counter() - t0
+        steps_total = int(o_ns.sum().item())
+        ext = {"sites": ns, "propagate_seconds": round(t_prop, 4), "propagate_pfd_per_s": round(ns * LW / t_prop / 1e9, 3),
+               "trace_seconds": round(t_tr, 4), "trace_steps": steps_total,
+               "trace_pfd_per_s": round(steps_total * 4 / t_tr / 1e9, 3),
+               "traces_reaching_max_steps": int((o_why == 2).sum().item()),
+               "traces_ended_no_extension": int((o_why == 0).sum().item()),
+               "traces_ended_seen_range": int((o_why == 1).sum().item()),
+               "variants_per_s_end_to_end": round(ns / (t_br + t_prop + t_tr), 1)}
     ss.free()
     pfd_ref = 2 * G + 2 * 256 * (G // 4096 + 1)
     pfd_br = na * (A + WARM) * 4
@@ -123,7 +186,8 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev):
             "branch_discover": {"seconds": round(t_br, 4), "assemblies": na, "min_overlap": 105,
                                 "variants_per_s": round(sites / t_br, 1), "branch_sites": sites,
                                 "push_front_drop_per_s": round(pfd_br / t_br / 1e9, 3),
-                                "algorithmic_GBps": round(pfd_br * 52 / t_br / 1e9, 1)}}
+                                "algorithmic_GBps": round(pfd_br * 52 / t_br / 1e9, 1)},
+            "push_to_pair_extension": ext}
 
 
 KERNEL_OF_FAMILY = {"radix_scatter_k": "rs_part_scatter_kernel",

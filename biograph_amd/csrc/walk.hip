@@ -151,6 +151,16 @@ __device__ __forceinline__ bool tri_precedes(const Tri& x, const Tri& y) {  // s
 // variants/assemble.cpp:1473-1498) and returns, for surviving lanes, their rank in set order.
 __device__ __forceinline__ void frontier_dedup(Tri& c, bool& cv, bool& flag, bool prefixes, int lane, int* rank,
                                                int* count) {
+  {  // the common frontier holds a single range: nothing to compare
+    bool in = cv && lane < kFrontierMax;
+    uint64_t vm = __ballot(in);
+    if (__popcll(vm) <= 1) {
+      cv = in;
+      *rank = 0;
+      *count = __popcll(vm);
+      return;
+    }
+  }
   bool dup = false, f = flag;
   for (int j = 0; j < kFrontierMax; ++j) {
     uint64_t jb = __shfl(c.b, j, 64), je = __shfl(c.e, j, 64);
@@ -188,6 +198,28 @@ __device__ __forceinline__ void frontier_dedup(Tri& c, bool& cv, bool& flag, boo
   }
   *rank = r;
   *count = n;
+}
+
+// Moves the surviving ranges to lane == rank, so that the frontier sits in set order in lanes 0..count-1.
+__device__ __forceinline__ void frontier_reseat(Tri& c, bool& cv, int rank, int lane) {
+  uint64_t vm = __ballot(cv);
+  if (__popcll(vm) <= 1) {
+    int src = vm ? __ffsll((long long)vm) - 1 : 0;
+    Tri t{__shfl(c.b, src, 64), __shfl(c.e, src, 64), __shfl(c.s, src, 64)};
+    c = t;
+    cv = vm != 0 && lane == 0;
+    return;
+  }
+  Tri nxt{0, 0, 0};
+  bool nxv = false;
+  for (int j = 0; j < kFrontierMax; ++j) {
+    Tri t{__shfl(c.b, j, 64), __shfl(c.e, j, 64), __shfl(c.s, j, 64)};
+    bool jv = __shfl(int(cv), j, 64) != 0;
+    int jr = __shfl(rank, j, 64);
+    if (jv && jr == lane) { nxt = t; nxv = true; }
+  }
+  c = nxt;
+  cv = nxv;
 }
 
 // push_to_pair_discover::trace_one_base (graph_discover/push_to_pair.cpp:159-240) minus the per-trace
@@ -312,17 +344,9 @@ __global__ __launch_bounds__(256) void k_branch_trace(SeqsetView v, uint64_t na,
     bool dummy = false;
     int rank, count;
     frontier_dedup(c, nv, dummy, true, lane, &rank, &count);
-    // re-seat survivors by rank so the frontier stays in set order
-    Tri nxt{0, 0, 0};
-    bool nxv = false;
-    for (int j = 0; j < kFrontierMax; ++j) {
-      Tri t{__shfl(c.b, j, 64), __shfl(c.e, j, 64), __shfl(c.s, j, 64)};
-      bool jv = __shfl(int(nv), j, 64) != 0;
-      int jr = __shfl(rank, j, 64);
-      if (jv && jr == lane) { nxt = t; nxv = true; }
-    }
-    cur = nxt;
-    cv = nxv;
+    frontier_reseat(c, nv, rank, lane);  // the frontier stays in set order
+    cur = c;
+    cv = nv;
   }
   if (cv) { outb[a * kFrontierMax + lane] = cur.b; oute[a * kFrontierMax + lane] = cur.e; outs[a * kFrontierMax + lane] = cur.s; }
   uint64_t live = __ballot(cv);
@@ -622,18 +646,6 @@ __global__ __launch_bounds__(256) void k_propagate_from_end(
     if (lane == 0) { atomicOr(err, 1u); n_out[a] = 0; n_mates[a] = 0; }
     return;
   }
-  auto reseat = [&](Tri& c, bool& cvalid, int rank) {  // survivors move to lane == rank (set order)
-    Tri nxt{0, 0, 0};
-    bool nxv = false;
-    for (int j = 0; j < kFrontierMax; ++j) {
-      Tri t{__shfl(c.b, j, 64), __shfl(c.e, j, 64), __shfl(c.s, j, 64)};
-      bool jv = __shfl(int(cvalid), j, 64) != 0;
-      int jr = __shfl(rank, j, 64);
-      if (jv && jr == lane) { nxt = t; nxv = true; }
-    }
-    c = nxt;
-    cvalid = nxv;
-  };
   Tri cur{0, 0, 0};
   bool cv = uint32_t(lane) < hi - lo;
   if (cv) { cur.b = fbegin[lo + lane]; cur.e = fend[lo + lane]; cur.s = fsize[lo + lane]; }
@@ -641,7 +653,7 @@ __global__ __launch_bounds__(256) void k_propagate_from_end(
   bool dummy = false;
   int rank, count;
   frontier_dedup(cur, cv, dummy, true, lane, &rank, &count);  // :1360-1361
-  reseat(cur, cv, rank);
+  frontier_reseat(cur, cv, rank, lane);
   const uint64_t s0 = soff[a];
   const uint64_t len = soff[a + 1] - s0;
   const int64_t mlo = mark_off ? int64_t(mark_off[a]) : 0;
@@ -654,7 +666,7 @@ __global__ __launch_bounds__(256) void k_propagate_from_end(
     bool nv = cv && c.e > c.b;
     dummy = false;
     frontier_dedup(c, nv, dummy, true, lane, &rank, &count);
-    reseat(c, nv, rank);
+    frontier_reseat(c, nv, rank, lane);
     cur = c;
     cv = nv;
     if (mi >= mlo && marks[mi] == uint32_t(off)) {
@@ -866,17 +878,9 @@ __global__ __launch_bounds__(256) void k_push_to_pair_trace(
     }
     nr += uint32_t(count);
     ++steps;
-    // re-seat survivors by rank so the frontier stays in set order
-    Tri nxt{0, 0, 0};
-    bool nxv = false;
-    for (int j = 0; j < kFrontierMax; ++j) {
-      Tri t{__shfl(c.b, j, 64), __shfl(c.e, j, 64), __shfl(c.s, j, 64)};
-      bool jv = __shfl(int(nv), j, 64) != 0;
-      int jr = __shfl(rank, j, 64);
-      if (jv && jr == lane) { nxt = t; nxv = true; }
-    }
-    cur = nxt;
-    cv = nxv;
+    frontier_reseat(c, nv, rank, lane);  // the frontier stays in set order
+    cur = c;
+    cv = nv;
   }
   if (lane == 0) { n_steps[a] = steps; reason[a] = uint8_t(why); n_ranges[a] = nr; }
 }
