@@ -620,16 +620,20 @@ def decode_readmap(path, seqset_dict):
     was built from (reads are entry prefixes; pairing from the mate loops)."""
     m = read_spiral_members(path)
     n = seqset_dict["n"]
-    nr = json.loads(m["read_lengths/packed_varbit_vector.json"])["element_count"]
+    nr = json.loads(m["read_ids/dest_to_mid/bitcount.json"])["nbits"]
 
     def bits(buf, nb):
         return np.unpackbits(np.frombuffer(buf, np.uint8), bitorder="little")[:nb]
     s2m = bits(m["read_ids/source_to_mid/bits"], n)
     d2m = bits(m["read_ids/dest_to_mid/bits"], nr)
-    rl = unpack_varbit(m["read_lengths/elements"],
-                       nr, json.loads(m["read_lengths/packed_varbit_vector.json"])["bits_per_value"])
-    mlp = unpack_varbit(m["mate_loop_ptr/elements"],
-                        nr, json.loads(m["mate_loop_ptr/packed_varbit_vector.json"])["bits_per_value"])
+    if "read_lengths" in m:  # readmap 1.1.0 (v3.x): raw uint8 lengths, 32-bit packed_vector loop pointers
+        rl = np.frombuffer(m["read_lengths"], np.uint8).astype(np.uint64)
+        mlp = np.frombuffer(m["mate_loop_ptr/packed_data"], np.uint32)[:nr].astype(np.uint64)
+    else:
+        rl = unpack_varbit(m["read_lengths/elements"],
+                           nr, json.loads(m["read_lengths/packed_varbit_vector.json"])["bits_per_value"])
+        mlp = unpack_varbit(m["mate_loop_ptr/elements"],
+                            nr, json.loads(m["mate_loop_ptr/packed_varbit_vector.json"])["bits_per_value"])
     isf = bits(m["is_forward/packed_data"], nr)
     entry = np.flatnonzero(s2m)[np.cumsum(d2m) - 1]
     ent = decode_entries(seqset_dict)

@@ -257,3 +257,30 @@ def test_propagate_from_end_on_lambda_golden(lambda_world, golden_dir):
         assert len(mates) > 0
         # the walk ends on the reference's own bases
         assert all(sz >= 100 for _, _, sz in got[0])
+
+
+def test_readmap_oracle_reproduces_ecoli_golden_exactly(golden_dir):
+    """golden/e_coli_10000snp.bg/coverage/*.readmap (readmap 1.1.0, unpaired reads): the oracle's readmap of
+    the corrected reads reproduces the reference's read ids one for one — entry of every read id, lengths,
+    orientation and the mate loop pointers (fwd <-> rc 2-cycles claimed in the reference's sequential
+    order).  This pins the row order and the claim ranks for unpaired input; pairs are pinned by the
+    lambda golden only up to the order inside an entry group (test above)."""
+    d = O.load_seqset_zip(golden_dir + "/e_coli_10000snp/seqset")
+    g = O.decode_readmap(golden_dir + "/e_coli_10000snp/readmap", d)
+    assert g["n_reads"] == 2 * 8444
+    reads = [l.strip() for i, l in enumerate(open(golden_dir + "/e_coli_10000snp/reads.fq")) if i % 4 == 1]
+    seq, offs = O.pack_strings(reads)
+    ks = O.KmerSet.count(seq, offs, 30, 5)
+    cseq, coffs, keep, stats = O.correct_reads(ks, seq, offs, 8, 2, 0.7)
+    kept = [s for s in O.unpack_strings(cseq, coffs) if s]
+    ent = O.Entries.from_strings(O.decode_entries(d))
+    rm = O.Readmap(O.Seqset.from_entries(ent), ent, [(s,) for s in kept], False)
+    assert len(rm) == g["n_reads"]
+    assert (rm.get("entry_id") == g["entry"]).all()
+    assert (rm.get("read_len") == g["read_len"]).all()
+    assert (rm.get("is_forward") == g["is_forward"]).all()
+    assert (rm.get("mate_loop_ptr") == g["mate_loop_ptr"]).all()
+    for sel in ("source_to_mid", "dest_to_mid"):
+        for w in ("bits", "subaccum", "accum"):
+            name = "read_ids/%s/%s" % (sel, w)
+            assert rm.parts()[name] == g["raw"][name], name
