@@ -179,6 +179,31 @@ class Context:
             dseq.free()
             doffs.free()
 
+    def merge_seqsets(self, seqsets, want_maps=True):
+        """`biograph merge` of resident seqsets -> (merged Seqset, [np.uint64 map per input] or None)."""
+        n = len(seqsets)
+        arr = (C.c_void_p * n)(*[s.h for s in seqsets])
+        maps = [DeviceArray(self, max(s.size(), 1) * 8) for s in seqsets] if want_maps else None
+        marr = (C.c_void_p * n)(*[m.ptr for m in maps]) if want_maps else None
+        h = C.c_void_p()
+        try:
+            capi.check(capi.lib().bg_seqset_merge(self.h, n, arr, C.byref(h), marr))
+            out = [m.to_numpy(np.uint64, s.size()) for m, s in zip(maps, seqsets)] if want_maps else None
+        finally:
+            for m in maps or []:
+                m.free()
+        return Seqset(self, h), out
+
+    def migrate_readmap(self, readmap, entry_map, merged):
+        """make_readmap::create_from_fast_migrate: the sample's readmap on the merged seqset."""
+        d = DeviceArray.from_numpy(self, np.ascontiguousarray(entry_map, np.uint64))
+        h = C.c_void_p()
+        try:
+            capi.check(capi.lib().bg_readmap_migrate(self.h, readmap.h, C.c_void_p(d.ptr), merged.h, C.byref(h)))
+        finally:
+            d.free()
+        return Readmap(self, h)
+
     def open_readmap(self, path):
         h = C.c_void_p()
         capi.check(capi.lib().bg_readmap_open(self.h, str(path).encode(), C.byref(h)))

@@ -62,6 +62,7 @@ SYMBOLS = [
     "bg_readmap_build", "bg_readmap_size", "bg_readmap_max_read_len", "bg_readmap_part", "bg_readmap_write",
     "bg_readmap_free", "bg_create_sample", "bg_readmap_open", "bg_readmap_arrays", "bg_prefix_reads_batch",
     "bg_read_info_batch", "bg_propagate_from_end_batch", "bg_push_to_pair_trace_batch",
+    "bg_seqset_merge", "bg_readmap_migrate",
     # sharded build
     "bg_partition_rows", "bg_kmer_instances", "bg_kmer_extract", "bg_kmer_count_keys", "bg_kmerset_export",
     "bg_kmerset_from_kmers", "bg_reads_words", "bg_reads_export", "bg_reads_import", "bg_suffix_records",
@@ -145,6 +146,8 @@ def lib():
     L.bg_propagate_from_end_batch.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp,
                                               vp, vp, vp, vp, u32, vp, vp, vp, vp]
     L.bg_push_to_pair_trace_batch.argtypes = [vp, vp, u64, vp, vp, vp, vp, u32, u32, u32, u32] + [vp] * 8
+    L.bg_seqset_merge.argtypes = [vp, u32, P(vp), P(vp), P(vp)]
+    L.bg_readmap_migrate.argtypes = [vp, vp, vp, vp, P(vp)]
     L.bg_create_sample.argtypes = [vp, vp, vp, u64, P(CreateParams), i32, P(vp), P(vp), P(BuildStats)]
     L.bg_partition_rows.argtypes = [vp, vp, u64, i32, i32, u32, vp, vp, vp]
     L.bg_kmer_instances.argtypes = [vp, vp, i32, P(u64)]

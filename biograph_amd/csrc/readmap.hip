@@ -300,6 +300,8 @@ static int bitcount_finalize(bg_ctx* ctx, const DevBuf<uint64_t>& bits, uint64_t
 }
 
 static int readmap_min_len(bg_ctx* ctx, bg_readmap* rm);
+int bitcount_finalize_plain(bg_ctx* ctx, const DevBuf<uint64_t>& bits, uint64_t nbits, DevBuf<uint64_t>* subaccum,
+                            DevBuf<uint64_t>* accum);
 
 // stable sort of (key, payload) pairs; returns pointers to the sorted arrays
 static int sort_pairs(bg_ctx* ctx, DevBuf<uint64_t>& ka, DevBuf<uint64_t>& kb, DevBuf<uint32_t>& va,
@@ -313,6 +315,11 @@ static int sort_pairs(bg_ctx* ctx, DevBuf<uint64_t>& ka, DevBuf<uint64_t>& kb, D
 
 }  // namespace bg
 
+
+int bg::bitcount_finalize_plain(bg_ctx* ctx, const DevBuf<uint64_t>& bits, uint64_t nbits,
+                                DevBuf<uint64_t>* subaccum, DevBuf<uint64_t>* accum) {
+  return bitcount_finalize(ctx, bits, nbits, subaccum, accum);
+}
 
 using namespace bg;
 

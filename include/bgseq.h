@@ -280,6 +280,22 @@ int bg_propagate_from_end_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_readm
                                 uint8_t* d_n_out, uint64_t* d_obegin, uint64_t* d_oend, uint32_t* d_osize,
                                 uint32_t mate_cap, uint32_t* d_n_mates, uint64_t* d_mate_begin,
                                 uint64_t* d_mate_end, uint32_t* d_mate_size);
+/* ---- Merge: `biograph merge` = seqset_flat + make_mergemap + seqset_merger
+ * (modules/biograph/biograph_merge.cpp:189-290, bio_base/make_mergemap.cpp:150-220,
+ * seqset_merger.cpp:50-185).  The merged seqset holds the prefix-free maxima of the union of the
+ * inputs' entries.  Inputs built in this process use their resident keys; inputs opened from files are
+ * flattened by FM navigation first (seqset_flat).  d_maps (may be null) = one device array per input of
+ * bg_seqset_size(in[i]) u64: the merged id of every input entry, i.e. seqset_mergemap's
+ * find_count(entry) (the mergemap bit vector is the set of those ids).  NB the reference's sweep may put
+ * the prev bit of an entry whose tail is a proper prefix of several merged entries on a later one of
+ * them, depending on its parallel_for chunking (seqset_merger.cpp:89-106); here it is always the first
+ * (the builder's rule, builder.cpp:85-108). */
+int bg_seqset_merge(bg_ctx* ctx, uint32_t n_in, const bg_seqset* const* in, bg_seqset** out,
+                    uint64_t* const* d_maps);
+/* make_readmap::create_from_fast_migrate (bio_mapred/make_readmap.cpp:455-519): the same read ids
+ * (lengths, mate loop pointers, orientation) on the merged seqset, entries translated through d_map. */
+int bg_readmap_migrate(bg_ctx* ctx, const bg_readmap* old_rm, const uint64_t* d_map, const bg_seqset* merged,
+                       bg_readmap** out);
 /* bg_create() plus the sample's readmap: the whole data path of SEQSETMain::run
  * (biograph_create.cpp:431-831: kmerize, correct, make_seqset, make_readmap). */
 int bg_create_sample(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n_reads,

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <queue>
 #include <set>
 #include <string>
 #include <unordered_map>
@@ -975,6 +976,53 @@ static void propagate_from_end(const Seqset& ss, const Readmap* rm, RangeSet new
 }
 
 
+// ------------------------------------------------------------------------------------------
+// Merge: make_mergemap::count_range (bio_base/make_mergemap.cpp:150-220) over the whole
+// range — a k-way merge of the sorted entry lists in which an entry that equals or is a prefix of the
+// next one in merged order joins its chain; a chain becomes ONE merged entry (its longest member) and
+// sets the mergemap bit of every input that contributed.  make_readmap::create_from_fast_migrate
+// (bio_mapred/make_readmap.cpp:455-519): read ids keep their order, lengths, loop pointers and
+// orientation; the entry of a read id becomes mergemap.find_count(old entry) = the position of the
+// old-entry-th set bit of that input's mergemap.
+struct MergeOut {
+  std::vector<std::string> entries;
+  std::vector<std::vector<uint64_t>> maps;  // per input: merged index of every input entry (ascending)
+};
+static void merge_entries(const std::vector<const std::vector<std::string>*>& in, MergeOut* out) {
+  struct QE {
+    const std::string* s;
+    unsigned flat;
+    size_t id;
+    bool operator<(const QE& r) const { return *s > *r.s; }  // make_mergemap.h:65-69
+  };
+  auto is_equal_or_prefix = [](const std::string& p, const std::string& l) {
+    return p.size() <= l.size() && l.compare(0, p.size(), p) == 0;
+  };
+  std::priority_queue<QE> q;
+  auto add = [&](unsigned f, size_t id) {
+    if (id < in[f]->size()) q.push(QE{&(*in[f])[id], f, id});
+  };
+  out->maps.assign(in.size(), {});
+  for (unsigned f = 0; f < in.size(); ++f) add(f, 0);
+  while (!q.empty()) {
+    QE e = q.top();
+    q.pop();
+    const std::string* slice = e.s;
+    const uint64_t merged = out->entries.size();
+    out->maps[e.flat].push_back(merged);
+    add(e.flat, e.id + 1);
+    while (!q.empty() && is_equal_or_prefix(*slice, *q.top().s)) {
+      e = q.top();
+      q.pop();
+      slice = e.s;
+      out->maps[e.flat].push_back(merged);
+      add(e.flat, e.id + 1);
+    }
+    out->entries.push_back(*slice);
+  }
+}
+
+
 extern "C" {
 
 // ---- k-mers
@@ -1316,6 +1364,44 @@ uint64_t orc_propagate_from_end(void* ssh, void* rmh, const uint8_t* seq, uint64
     ++i;
   }
   return po.mates.size();
+}
+// ---- merge: handles of Entries in, MergeOut out
+void* orc_merge(void* const* entry_handles, uint64_t n_in) {
+  std::vector<const std::vector<std::string>*> in;
+  for (uint64_t i = 0; i < n_in; ++i) in.push_back(&static_cast<Entries*>(entry_handles[i])->e);
+  auto* mo = new MergeOut;
+  merge_entries(in, mo);
+  return mo;
+}
+void* orc_merge_entries(void* h) {
+  auto* en = new Entries;
+  en->e = static_cast<MergeOut*>(h)->entries;
+  return en;
+}
+uint64_t orc_merge_map(void* h, uint64_t input, uint64_t* out) {
+  auto& m = static_cast<MergeOut*>(h)->maps[input];
+  if (out) std::copy(m.begin(), m.end(), out);
+  return m.size();
+}
+void orc_merge_free(void* h) { delete static_cast<MergeOut*>(h); }
+// fast_migrate: same read ids, entry ids translated through map[]
+void* orc_readmap_migrate(void* rmh, const uint64_t* map, uint64_t n_new_entries) {
+  auto* o = static_cast<Readmap*>(rmh);
+  auto* rm = new Readmap(*o);
+  for (auto& e : rm->entry_id) e = map[e];
+  rm->s2m = Seqset();
+  rm->s2m.n = n_new_entries;
+  rm->s2m.bits[0].assign((n_new_entries + 63) / 64, 0);
+  rm->d2m = Seqset();
+  rm->d2m.n = rm->n_reads;
+  rm->d2m.bits[0].assign((rm->n_reads + 63) / 64, 0);
+  for (uint64_t i = 0; i < rm->n_reads; ++i) {
+    rm->s2m.bits[0][rm->entry_id[i] / 64] |= 1ull << (rm->entry_id[i] & 63);
+    if (i == 0 || rm->entry_id[i] != rm->entry_id[i - 1]) rm->d2m.bits[0][i / 64] |= 1ull << (i & 63);
+  }
+  rm->s2m.finalize_bitcount(0);
+  rm->d2m.finalize_bitcount(0);
+  return rm;
 }
 void orc_readmap_free(void* h) { delete static_cast<Readmap*>(h); }
 

@@ -107,6 +107,15 @@ def lib():
     L.orc_propagate_from_end.restype = C.c_uint64
     L.orc_propagate_from_end.argtypes = [vp, vp, u8p, C.c_uint64, u64p, C.c_uint64, C.c_uint32, u32p, C.c_uint64,
                                          C.c_uint64, u64p, u64p, C.c_uint64, u64p]
+    L.orc_merge.restype = vp
+    L.orc_merge.argtypes = [C.POINTER(vp), C.c_uint64]
+    L.orc_merge_entries.restype = vp
+    L.orc_merge_entries.argtypes = [vp]
+    L.orc_merge_map.restype = C.c_uint64
+    L.orc_merge_map.argtypes = [vp, C.c_uint64, C.c_void_p]
+    L.orc_merge_free.argtypes = [vp]
+    L.orc_readmap_migrate.restype = vp
+    L.orc_readmap_migrate.argtypes = [vp, u64p, C.c_uint64]
     _LIB = L
     return L
 
@@ -232,6 +241,23 @@ class Entries:
         if getattr(self, "h", None):
             lib().orc_entries_free(self.h)
             self.h = None
+
+
+def merge_entries(entry_sets):
+    """make_mergemap over whole inputs: list of Entries -> (merged Entries, [map per input])."""
+    arr = (C.c_void_p * len(entry_sets))(*[e.h for e in entry_sets])
+    h = lib().orc_merge(arr, len(entry_sets))
+    try:
+        merged = Entries(lib().orc_merge_entries(h))
+        maps = []
+        for i in range(len(entry_sets)):
+            n = lib().orc_merge_map(h, i, None)
+            m = np.zeros(max(n, 1), np.uint64)
+            lib().orc_merge_map(h, i, m.ctypes.data)
+            maps.append(m[:n])
+    finally:
+        lib().orc_merge_free(h)
+    return merged, maps
 
 
 class Seqset:
@@ -563,6 +589,14 @@ class Readmap:
         self.n_entries = n_entries
         return self
 
+    def migrate(self, entry_map, n_new_entries):
+        """make_readmap::create_from_fast_migrate: same read ids on the merged seqset."""
+        new = Readmap.__new__(Readmap)
+        m = np.ascontiguousarray(entry_map, np.uint64)
+        new.h = lib().orc_readmap_migrate(self.h, _pad(m), n_new_entries)
+        new.n_entries = n_new_entries
+        return new
+
     # ---- queries (bio_base/readmap.cpp:207-290,434-447,538-649; readmap.h:249-251) ----------------
     def prefix_reads(self, seqset, rng, read_len_limit=0, cap=4096):
         """Read ids of get_prefix_reads(range) in iteration order (forward, then backward)."""
@@ -628,7 +662,10 @@ def decode_readmap(path, seqset_dict):
     d2m = bits(m["read_ids/dest_to_mid/bits"], nr)
     if "read_lengths" in m:  # readmap 1.1.0 (v3.x): raw uint8 lengths, 32-bit packed_vector loop pointers
         rl = np.frombuffer(m["read_lengths"], np.uint8).astype(np.uint64)
-        mlp = np.frombuffer(m["mate_loop_ptr/packed_data"], np.uint32)[:nr].astype(np.uint64)
+        if "mate_loop_ptr/packed_data" in m:
+            mlp = np.frombuffer(m["mate_loop_ptr/packed_data"], np.uint32)[:nr].astype(np.uint64)
+        else:  # even older: mate_pair_ptr (no loop table); the reads are still entry prefixes
+            mlp = None
     else:
         rl = unpack_varbit(m["read_lengths/elements"],
                            nr, json.loads(m["read_lengths/packed_varbit_vector.json"])["bits_per_value"])
@@ -639,6 +676,9 @@ def decode_readmap(path, seqset_dict):
     ent = decode_entries(seqset_dict)
     records = []
     seen = np.zeros(nr, bool)
+    if mlp is None:
+        return {"raw": m, "n_reads": nr, "entry": entry, "read_len": rl, "mate_loop_ptr": None, "is_forward": isf,
+                "records": None, "read_seqs": [ent[int(e)][:int(l)] for e, l in zip(entry, rl)]}
     for i in range(nr):
         if seen[i] or not isf[i]:
             continue

@@ -1,0 +1,124 @@
+"""GPU parity of the merge row: bg_seqset_merge / bg_readmap_migrate through the C ABI
+against the reference's golden merged biograph and against the oracle's make_mergemap restatement."""
+import numpy as np
+import pytest
+
+import biograph_amd as bg
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = bg.Context(0)
+    yield c
+    c.close()
+
+
+def _bits(a, n):
+    return np.unpackbits(np.asarray(a).view(np.uint8), bitorder="little")[:n]
+
+
+def test_merge_reproduces_golden_merged_biograph(ctx, golden_dir):
+    d1 = O.load_seqset_zip(golden_dir + "/e_coli_10000snp/seqset")
+    dm = O.load_seqset_zip(golden_dir + "/e_coli_merged/seqset")
+    em = O.decode_entries(dm)
+    # sample 1: the whole GPU create path on the golden FASTQ (+ its readmap, unpaired)
+    reads1 = [l.strip() for i, l in enumerate(open(golden_dir + "/e_coli_10000snp/reads.fq")) if i % 4 == 1]
+    r = ctx.pack_reads(reads1)
+    ks = ctx.kmer_count(r, 30, 5)
+    c, _ = ctx.correct_reads(r, ks)
+    s1, _ = ctx.build_seqset(c, 30)
+    rm1 = ctx.build_readmap(s1, c, False)
+    assert s1.size() == d1["n"]
+    # sample 2: its corrected reads come back out of its readmap inside the merged golden
+    r2 = O.decode_readmap(golden_dir + "/e_coli_merged/readmap_e_coli_test", dm)
+    reads2 = sorted(set(r2["read_seqs"]))
+    s2, _ = ctx.build_seqset(ctx.pack_reads(reads2), 30)
+    merged, maps = ctx.merge_seqsets([s1, s2])
+    assert merged.size() == dm["n"] == 232745 and merged.max_len == 100
+    assert merged.entries() == em
+    sz, sh = merged.arrays()
+    assert (sz == dm["sizes"]).all() and (sh == dm["shared"]).all()
+    assert merged.part("fixed") == np.asarray(dm["fixed"], np.uint64).tobytes()
+    # prev bits: the builder's closed form (== oracle) ...
+    oss = O.Seqset.from_entries(O.Entries.from_strings(em))
+    want = oss.parts()
+    for name in bg.PART_NAMES:
+        assert merged.part(name) == want[name], name
+    # ... which differs from the golden file in a handful of bits only where the reference's chunked sweep
+    # had a choice (an entry whose tail is a proper prefix of several merged entries; seqset_merger.cpp:89-106)
+    ndiff = 0
+    for b in range(4):
+        mine = _bits(np.frombuffer(merged.part("prev_%s/bits" % "ACGT"[b]), np.uint64), dm["n"])
+        gold = _bits(dm["bits"][b], dm["n"])
+        assert mine.sum() == gold.sum()
+        only_m, only_g = np.flatnonzero(mine & ~gold), np.flatnonzero(gold & ~mine)
+        assert len(only_m) == len(only_g) <= 8
+        for i, j in zip(only_m, only_g):
+            assert i < j
+            lcp = min(int(x) for x in sh[i + 1:j + 1])          # bases shared by entries i..j
+            assert lcp >= 1 and any(_is_entry(em, "ACGT"[b] + em[i][:L]) for L in range(1, lcp + 1))
+        ndiff += len(only_m)
+    assert ndiff == 5
+    # mergemaps == oracle; migration of sample 1's readmap == the golden's migrated readmap
+    om, omaps = O.merge_entries([O.Entries.from_strings(s1.entries()), O.Entries.from_strings(s2.entries())])
+    assert (maps[0] == omaps[0]).all() and (maps[1] == omaps[1]).all()
+    mig = ctx.migrate_readmap(rm1, maps[0], merged)
+    gm = O.decode_readmap(golden_dir + "/e_coli_merged/readmap_test_accession_id", dm)
+    e, rl, ml, f = mig.arrays()
+    assert (e == gm["entry"]).all() and (rl == gm["read_len"]).all()
+    assert (ml == gm["mate_loop_ptr"]).all() and (f == gm["is_forward"]).all()
+    for sel in ("source_to_mid", "dest_to_mid"):
+        for w in ("bits", "subaccum", "accum"):
+            name = "read_ids/%s/%s" % (sel, w)
+            assert mig.part(name) == gm["raw"][name], name
+    # inputs opened from arrays (no resident keys): flattened by FM navigation, same result
+    f1 = ctx.seqset_from_arrays(d1["sizes"], d1["shared"], d1["bits"])
+    merged2, maps2 = ctx.merge_seqsets([f1, s2])
+    assert merged2.parts() == merged.parts() and (maps2[0] == maps[0]).all()
+
+
+def _is_entry(em, s):
+    import bisect
+    k = bisect.bisect_left(em, s)
+    return k < len(em) and em[k] == s
+
+
+def test_merge_three_synthetic_samples_matches_oracle(ctx):
+    from biograph_amd import synth
+    seqsets, readmaps, oents, orms = [], [], [], []
+    for seed in (1, 2, 3):
+        seq, offs, n = synth.make_reads(genome_len=20000, coverage=12, read_len=120, seed=100 + seed, device="cpu")
+        reads = O.unpack_strings(seq.numpy(), offs.numpy().astype(np.uint64))
+        r = ctx.pack_reads(reads)
+        ks = ctx.kmer_count(r, 25, 3)
+        c, _ = ctx.correct_reads(r, ks)
+        ss, _ = ctx.build_seqset(c, 25)
+        rm = ctx.build_readmap(ss, c, True)
+        seqsets.append(ss)
+        readmaps.append(rm)
+        ent = O.Entries.from_strings(ss.entries())
+        oents.append(ent)
+        e, rl, ml, f = rm.arrays()
+        orms.append(O.Readmap.from_arrays(ss.size(), e, rl, ml, f, rm.max_read_len))
+    merged, maps = ctx.merge_seqsets(seqsets)
+    om, omaps = O.merge_entries(oents)
+    assert merged.entries() == om.strings()
+    want = O.Seqset.from_entries(om).parts()
+    for name in bg.PART_NAMES:
+        assert merged.part(name) == want[name], name
+    for i in range(3):
+        assert (maps[i] == omaps[i]).all()
+        mig = ctx.migrate_readmap(readmaps[i], maps[i], merged)
+        omig = orms[i].migrate(omaps[i], len(om))
+        want_rm = omig.parts()
+        for name in bg.READMAP_PART_NAMES:
+            assert mig.part(name) == want_rm[name], (i, name)
+    # idempotence / absorption: merging the result with any input changes nothing
+    again, maps2 = ctx.merge_seqsets([merged, seqsets[1]])
+    assert again.parts() == merged.parts()
+    assert (maps2[0] == np.arange(merged.size(), dtype=np.uint64)).all() and (maps2[1] == maps[1]).all()
+    one, m1 = ctx.merge_seqsets([seqsets[0]])
+    assert one.parts() == seqsets[0].parts() and (m1[0] == np.arange(seqsets[0].size(), dtype=np.uint64)).all()

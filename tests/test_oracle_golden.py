@@ -284,3 +284,71 @@ def test_readmap_oracle_reproduces_ecoli_golden_exactly(golden_dir):
         for w in ("bits", "subaccum", "accum"):
             name = "read_ids/%s/%s" % (sel, w)
             assert rm.parts()[name] == g["raw"][name], name
+
+
+def test_merge_and_readmap_migration_reproduce_merged_golden(golden_dir):
+    """SURVEY §8f.3, pinned on golden/e_coli_merged.bg (`biograph merge` of e_coli_10000snp.bg and a second
+    sample whose .bg is not in the tree).  The second sample's corrected reads are recoverable from ITS
+    readmap inside the merged biograph (a read = entry prefix), so: row E on those 100-bp reads gives its
+    seqset; the oracle's make_mergemap restatement merges it with the e_coli seqset; the result must be
+    the golden merged seqset entry for entry; and fast_migrate of the e_coli readmap through the mergemap
+    must be the golden's migrated readmap read id for read id."""
+    d1 = O.load_seqset_zip(golden_dir + "/e_coli_10000snp/seqset")
+    dm = O.load_seqset_zip(golden_dir + "/e_coli_merged/seqset")
+    e1 = O.Entries.from_strings(O.decode_entries(d1))
+    em = O.decode_entries(dm)
+    assert dm["n"] == 232745
+    r2 = O.decode_readmap(golden_dir + "/e_coli_merged/readmap_e_coli_test", dm)
+    reads2 = sorted(set(r2["read_seqs"]))
+    assert r2["n_reads"] == 76094 and len(reads2) == 63808 and {len(s) for s in reads2} == {100}
+    seq, offs = O.pack_strings(reads2)
+    e2 = O.Entries.build(seq, offs, "simple")
+    merged, maps = O.merge_entries([e1, e2])
+    assert merged.strings() == em
+    assert len(maps[0]) == d1["n"] and len(maps[1]) == len(e2)
+    for m in maps:
+        assert (np.diff(m.astype(np.int64)) > 0).all()          # injective and order preserving
+    # the merged seqset's arrays, rebuilt from the merged entries, are the golden's
+    oss = O.Seqset.from_entries(merged)
+    s, sh = oss.arrays()
+    assert (s == dm["sizes"]).all() and (sh == dm["shared"]).all()
+    # prev bits: equal to the golden except where the reference's chunked sweep had a choice — an entry
+    # b+t whose tail t is a proper prefix of SEVERAL merged entries gets its bit on the first of them by
+    # the builder's rule (builder.cpp:85-108, used here) but on the first entry of a parallel_for chunk
+    # when a chunk boundary falls inside that block (seqset_merger.cpp:89-106,111-131): 5 such bits in
+    # this file, all verified to be exactly that situation.
+    import bisect
+    ndiff = 0
+    for b in range(4):
+        mine = np.unpackbits(oss.prev(b, "bits").view(np.uint8), bitorder="little")[:dm["n"]]
+        gold = np.unpackbits(np.asarray(dm["bits"][b]).view(np.uint8), bitorder="little")[:dm["n"]]
+        assert mine.sum() == gold.sum()
+        only_m, only_g = np.flatnonzero(mine & ~gold), np.flatnonzero(gold & ~mine)
+        assert len(only_m) == len(only_g)
+        for i, j in zip(only_m, only_g):
+            assert i < j
+            lcp = min(int(x) for x in sh[i + 1:j + 1])
+            cands = ["ACGT"[b] + em[i][:L] for L in range(1, lcp + 1)]
+            assert any(em[bisect.bisect_left(em, c)] == c for c in cands)
+        ndiff += len(only_m)
+    assert ndiff == 5
+    # readmap migration of sample 1
+    g1 = O.decode_readmap(golden_dir + "/e_coli_10000snp/readmap", d1)
+    gm = O.decode_readmap(golden_dir + "/e_coli_merged/readmap_test_accession_id", dm)
+    rm1 = O.Readmap.from_arrays(d1["n"], g1["entry"], g1["read_len"], g1["mate_loop_ptr"], g1["is_forward"], 35)
+    mig = rm1.migrate(maps[0], dm["n"])
+    assert (mig.get("entry_id") == gm["entry"]).all()
+    assert (mig.get("read_len") == gm["read_len"]).all()
+    assert (mig.get("mate_loop_ptr") == gm["mate_loop_ptr"]).all()
+    assert (mig.get("is_forward") == gm["is_forward"]).all()
+    for sel in ("source_to_mid", "dest_to_mid"):
+        for w in ("bits", "subaccum", "accum"):
+            name = "read_ids/%s/%s" % (sel, w)
+            assert mig.bitcount(sel, w).tobytes() == gm["raw"][name], name
+    # sample 2's own readmap: every read id sits on the merged entry its sequence maps to
+    ent2 = e2.strings()
+    import bisect
+    for i in range(0, r2["n_reads"], 97):
+        s_ = r2["read_seqs"][i]
+        j = bisect.bisect_left(ent2, s_)
+        assert ent2[j].startswith(s_) and int(maps[1][j]) == int(r2["entry"][i])
