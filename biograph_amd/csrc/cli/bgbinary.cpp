@@ -6,6 +6,7 @@
 //                   [--kmer-size 30] [--min-kmer-count 5] [--trim-after-portion 0.7]
 //                   [--max-corrections 8] [--min-good-run 2] [--min-reads 0.4] [--warn-reads 0.7] [--stats FILE]
 //   bgbinary refmap --in S.bg --ref DIR|FASTA --out FILE          (ref_map::build -> one byte per entry)
+//   bgbinary merge --in A.bg --in B.bg [...] --out M.bg [--id ID] [-f]   (biograph_merge.cpp:189-400)
 //
 // Host work here is file I/O only (FASTQ parsing with zlib, output directory); every computation is a
 // C-ABI call that runs on the GPU.  The sample's readmap lands in coverage/<sha1>.readmap and is listed
@@ -16,6 +17,7 @@
 #include <time.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -266,11 +268,113 @@ static int cmd_refmap(int argc, char** argv) {
   return 0;
 }
 
+// Minimal reader of metadata/bg_info.json: accession id and the sample -> readmap sha map.
+static std::string read_text(const std::string& p) {
+  FILE* f = fopen(p.c_str(), "rb");
+  if (!f) die("Could not open " + p);
+  std::string out;
+  char buf[65536];
+  size_t got;
+  while ((got = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, got);
+  fclose(f);
+  return out;
+}
+static std::string json_string(const std::string& js, const std::string& key) {
+  std::string pat = "\"" + key + "\":\"";
+  size_t p = js.find(pat);
+  if (p == std::string::npos) return "";
+  p += pat.size();
+  return js.substr(p, js.find('"', p) - p);
+}
+static std::map<std::string, std::string> json_samples(const std::string& js) {
+  std::map<std::string, std::string> out;
+  size_t p = js.find("\"samples\":{");
+  if (p == std::string::npos) return out;
+  p += 11;
+  size_t end = js.find('}', p);
+  while (p < end) {
+    size_t k0 = js.find('"', p);
+    if (k0 == std::string::npos || k0 >= end) break;
+    size_t k1 = js.find('"', k0 + 1), v0 = js.find('"', k1 + 1), v1 = js.find('"', v0 + 1);
+    out[js.substr(k0 + 1, k1 - k0 - 1)] = js.substr(v0 + 1, v1 - v0 - 1);
+    p = v1 + 1;
+  }
+  return out;
+}
+
+// bgbinary merge --in A.bg --in B.bg [...] --out M.bg [--id ID] [-f]   (biograph_merge.cpp:189-400)
+static int cmd_merge(int argc, char** argv) {
+  Args a = parse(argc, argv, 2);
+  if (!a.has("reads") || !a.has("out")) die("merge: --in (at least once) and --out are required");
+  const auto& ins = a.opt["reads"];  // the parser files --in under --reads
+  std::string out = a.get("out");
+  if (out.size() < 3 || out.substr(out.size() - 3) != ".bg") out += ".bg";
+  if (exists(out + "/seqset") && !a.has("force")) die("Refusing to overwrite " + out + ". Use --force to override.");
+  bg_ctx* ctx = nullptr;
+  check(bg_ctx_create(0, nullptr, &ctx), "bg_ctx_create");
+  std::vector<bg_seqset*> ss(ins.size(), nullptr);
+  std::vector<const bg_seqset*> css;
+  std::vector<void*> maps(ins.size(), nullptr);
+  std::vector<uint64_t*> mapp;
+  std::vector<std::string> infos;
+  std::string merged_id;
+  for (size_t i = 0; i < ins.size(); ++i) {
+    check(bg_seqset_open(ctx, (ins[i] + "/seqset").c_str(), &ss[i]), "bg_seqset_open");
+    css.push_back(ss[i]);
+    check(bg_dev_alloc(ctx, std::max<uint64_t>(bg_seqset_size(ss[i]), 1) * 8, &maps[i]), "bg_dev_alloc");
+    mapp.push_back(static_cast<uint64_t*>(maps[i]));
+    infos.push_back(read_text(ins[i] + "/metadata/bg_info.json"));
+    std::string acc = json_string(infos[i], "accession_id");
+    merged_id += (i ? "+" : "") + acc;  // :334-342
+  }
+  if (a.has("id")) merged_id = a.get("id");
+  double t0 = now_s();
+  bg_seqset* merged = nullptr;
+  check(bg_seqset_merge(ctx, uint32_t(ins.size()), css.data(), &merged, mapp.data()), "bg_seqset_merge");
+  fprintf(stderr, "Merged seqset: %llu entries (%.3f s)\n", (unsigned long long)bg_seqset_size(merged), now_s() - t0);
+  mkdirs(out);
+  mkdirs(out + "/qc");
+  mkdirs(out + "/metadata");
+  mkdirs(out + "/coverage");
+  std::vector<const char*> av(argv, argv + argc);
+  check(bg_seqset_write(ctx, merged, (out + "/seqset").c_str(), argc, av.data()), "bg_seqset_write");
+  std::string samples_json;
+  size_t n_samples = 0;
+  for (size_t i = 0; i < ins.size(); ++i) {
+    for (auto& kv : json_samples(infos[i])) {
+      bg_readmap *rm = nullptr, *mig = nullptr;
+      check(bg_readmap_open(ctx, (ins[i] + "/coverage/" + kv.second + ".readmap").c_str(), &rm), "bg_readmap_open");
+      check(bg_readmap_migrate(ctx, rm, mapp[i], merged, &mig), "bg_readmap_migrate");
+      char sha[41];
+      std::string tmp = out + "/coverage/tmp.readmap";
+      check(bg_readmap_write(ctx, mig, tmp.c_str(), argc, av.data(), sha), "bg_readmap_write");
+      if (rename(tmp.c_str(), (out + "/coverage/" + sha + ".readmap").c_str()) != 0) die("Could not rename " + tmp);
+      samples_json += std::string(n_samples ? "," : "") + "\"" + kv.first + "\":\"" + sha + "\"";
+      ++n_samples;
+      bg_readmap_free(mig);
+      bg_readmap_free(rm);
+    }
+  }
+  std::string meta = "{\"accession_id\":\"" + merged_id + "\",\"command_history\":[],\"samples\":{" + samples_json +
+                     "},\"version\":\"biograph_amd-r1\"}";
+  write_file(out + "/metadata/bg_info.json", meta);
+  char js[1024];
+  snprintf(js, sizeof js, "{\"command\":\"merge\",\"version\":\"biograph_amd-r1\",\"accession_id\":\"%s\",\"samples\":%zu,"
+           "\"seqset_entries\":%llu}", merged_id.c_str(), n_samples, (unsigned long long)bg_seqset_size(merged));
+  write_file(out + "/qc/merge_stats.json", js);
+  fprintf(stderr, "\n%s created.\n", out.c_str());
+  bg_seqset_free(merged);
+  for (size_t i = 0; i < ins.size(); ++i) { bg_seqset_free(ss[i]); bg_dev_free(ctx, maps[i]); }
+  bg_ctx_destroy(ctx);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 2) die("usage: bgbinary {create|refmap} [options]   (MI355X build of the seqset path)");
+  if (argc < 2) die("usage: bgbinary {create|merge|refmap} [options]   (MI355X build of the seqset path)");
   std::string cmd = argv[1];
   if (cmd == "create") return cmd_create(argc, argv);
   if (cmd == "refmap") return cmd_refmap(argc, argv);
-  die("bgbinary: unknown command '" + cmd + "' (this build provides: create, refmap)");
+  if (cmd == "merge") return cmd_merge(argc, argv);
+  die("bgbinary: unknown command '" + cmd + "' (this build provides: create, merge, refmap)");
   return 1;
 }

@@ -122,3 +122,51 @@ def test_merge_three_synthetic_samples_matches_oracle(ctx):
     assert (maps2[0] == np.arange(merged.size(), dtype=np.uint64)).all() and (maps2[1] == maps[1]).all()
     one, m1 = ctx.merge_seqsets([seqsets[0]])
     assert one.parts() == seqsets[0].parts() and (m1[0] == np.arange(seqsets[0].size(), dtype=np.uint64)).all()
+
+
+def test_bgbinary_merge_cli(ctx, tmp_path):
+    """`bgbinary create` twice (paired FASTQ) then `bgbinary merge`: the merged directory holds the seqset
+    the API merge gives and one migrated readmap per sample, named by SHA-1 and listed in bg_info.json."""
+    import hashlib
+    import json
+    import subprocess
+    import sys
+    from biograph_amd import synth
+    dirs = []
+    for k, seed in enumerate((7, 8)):
+        seq, offs, n = synth.make_reads(genome_len=15000, coverage=20, read_len=100, seed=seed, device="cpu")
+        reads = O.unpack_strings(seq.numpy(), offs.numpy().astype(np.uint64))
+        fq = [tmp_path / ("s%d_%d.fq" % (k, m)) for m in (1, 2)]
+        for m in (0, 1):
+            with open(fq[m], "w") as f:
+                for i, s in enumerate(reads[m::2]):
+                    f.write("@r%d/%d\n%s\n+\n%s\n" % (i, m + 1, s, "I" * len(s)))
+        out = tmp_path / ("s%d.bg" % k)
+        r = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "create", "--reads", str(fq[0]), "--pair", str(fq[1]),
+                            "--out", str(out), "--id", "sample%d" % k], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        dirs.append(out)
+    mdir = tmp_path / "merged.bg"
+    r = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "merge", "--in", str(dirs[0]), "--in", str(dirs[1]),
+                        "--out", str(mdir)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    info = json.load(open(mdir / "metadata" / "bg_info.json"))
+    assert info["accession_id"] == "sample0+sample1" and sorted(info["samples"]) == ["sample0", "sample1"]
+    ins = [ctx.open_seqset(d / "seqset") for d in dirs]
+    want, maps = ctx.merge_seqsets(ins)
+    got = ctx.open_seqset(mdir / "seqset")
+    assert got.parts() == want.parts()
+    muuid = json.loads(O.read_spiral_members(str(mdir / "seqset"))["file_info.json"])["uuid"]
+    for k in range(2):
+        sha = info["samples"]["sample%d" % k]
+        path = mdir / "coverage" / (sha + ".readmap")
+        assert hashlib.sha1(path.read_bytes()).hexdigest() == sha
+        old_info = json.load(open(dirs[k] / "metadata" / "bg_info.json"))
+        old = ctx.open_readmap(dirs[k] / "coverage" / (old_info["samples"]["sample%d" % k] + ".readmap"))
+        mig = ctx.migrate_readmap(old, maps[k], want)
+        new = ctx.open_readmap(path)
+        assert new.parts() == mig.parts()
+        assert json.loads(O.read_spiral_members(str(path))["readmap.json"]) == {"seqset_uuid": muuid}
+    r2 = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "merge", "--in", str(dirs[0]), "--out", str(mdir)],
+                        capture_output=True, text=True)
+    assert r2.returncode == 1 and "overwrite" in r2.stderr
