@@ -656,8 +656,10 @@ static bool rm_json_u64(const std::string& js, const char* key, uint64_t* out) {
 static void rm_unpack_bits(const std::string& blob, uint64_t n, unsigned bits, std::vector<uint64_t>* out) {
   out->assign(n, 0);
   if (!bits) return;
-  const uint64_t* w = reinterpret_cast<const uint64_t*>(blob.data());
-  const uint64_t nw = blob.size() / 8;
+  std::vector<uint64_t> padded((blob.size() + 7) / 8 + 1, 0);  // raw uint8 members are not word multiples
+  memcpy(padded.data(), blob.data(), blob.size());
+  const uint64_t* w = padded.data();
+  const uint64_t nw = padded.size();
   const uint64_t mask = bits == 64 ? ~0ull : ((1ull << bits) - 1);
   for (uint64_t i = 0; i < n; ++i) {
     uint64_t bit = i * bits, q = bit >> 6, r = bit & 63;
@@ -677,15 +679,29 @@ extern "C" int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out) 
     if (it == parts.end()) { set_error("%s: member %s missing (readmaps older than format 1.2.0 carry no mate loop table; `biograph upgrade` them)", path, name); return nullptr; }
     return &it->second;
   };
+  // format 1.1.0 (v3.x): read_lengths = raw uint8, mate_loop_ptr = 32-bit packed_vector; format 1.2.0: both
+  // packed_varbit_vectors (readmap.cpp open path, int_map_interface.cpp detect_subpart_or_uint8_membuf)
+  const bool legacy = parts.count("read_lengths") != 0;
+  if (legacy && !parts.count("mate_loop_ptr/packed_data")) {
+    set_error("%s: readmap has no mate loop table; use \"biograph upgrade\" to construct it", path);  // readmap.cpp:249-253
+    return BG_EIO;
+  }
   const std::string *s2m_js = need("read_ids/source_to_mid/bitcount.json"), *s2m = need("read_ids/source_to_mid/bits"),
-                    *d2m = need("read_ids/dest_to_mid/bits"), *rl_js = need("read_lengths/packed_varbit_vector.json"),
-                    *rl = need("read_lengths/elements"), *ml_js = need("mate_loop_ptr/packed_varbit_vector.json"),
-                    *ml = need("mate_loop_ptr/elements"), *isf = need("is_forward/packed_data"), *rmj = need("readmap.json");
-  if (!s2m_js || !s2m || !d2m || !rl_js || !rl || !ml_js || !ml || !isf || !rmj) return BG_EIO;
-  uint64_t n_ent = 0, n = 0, rl_bits = 0, ml_bits = 0, max_len = 0;
-  if (!rm_json_u64(*s2m_js, "nbits", &n_ent) || !rm_json_u64(*rl_js, "element_count", &n) ||
-      !rm_json_u64(*rl_js, "bits_per_value", &rl_bits) || !rm_json_u64(*ml_js, "bits_per_value", &ml_bits) ||
-      !rm_json_u64(*rl_js, "max_value", &max_len)) {
+                    *d2m_js = need("read_ids/dest_to_mid/bitcount.json"), *d2m = need("read_ids/dest_to_mid/bits"),
+                    *rl = need(legacy ? "read_lengths" : "read_lengths/elements"),
+                    *ml = need(legacy ? "mate_loop_ptr/packed_data" : "mate_loop_ptr/elements"),
+                    *isf = need("is_forward/packed_data"), *rmj = need("readmap.json");
+  if (!s2m_js || !s2m || !d2m_js || !d2m || !rl || !ml || !isf || !rmj) return BG_EIO;
+  uint64_t n_ent = 0, n = 0, rl_bits = 8, ml_bits = 32, max_len = 0;
+  bool ok = rm_json_u64(*s2m_js, "nbits", &n_ent) && rm_json_u64(*d2m_js, "nbits", &n);
+  if (ok && !legacy) {
+    const std::string *rl_js = need("read_lengths/packed_varbit_vector.json"),
+                      *ml_js = need("mate_loop_ptr/packed_varbit_vector.json");
+    if (!rl_js || !ml_js) return BG_EIO;
+    ok = rm_json_u64(*rl_js, "bits_per_value", &rl_bits) && rm_json_u64(*ml_js, "bits_per_value", &ml_bits) &&
+         rm_json_u64(*rl_js, "max_value", &max_len);
+  }
+  if (!ok) {
     set_error("%s: malformed readmap metadata", path);
     return BG_EIO;
   }
@@ -698,7 +714,11 @@ extern "C" int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out) 
   size_t p = rmj->find("\"seqset_uuid\":\"");
   if (p != std::string::npos) rm->seqset_uuid = rmj->substr(p + 15, rmj->find('"', p + 15) - (p + 15));
   std::vector<uint64_t> v_len, v_ptr, v_fwd, v_head, v_src;
+  if (rl->size() < (n * rl_bits + 7) / 8 || ml->size() < (n * ml_bits + 7) / 8) { set_error("%s: truncated vectors", path); return BG_EIO; }
   rm_unpack_bits(*rl, n, unsigned(rl_bits), &v_len);
+  if (legacy)
+    for (uint64_t v : v_len) max_len = std::max(max_len, v);
+  rm->max_read_len = uint32_t(max_len);
   rm_unpack_bits(*ml, n, unsigned(ml_bits), &v_ptr);
   rm_unpack_bits(*isf, n, 1, &v_fwd);
   rm_unpack_bits(*d2m, n, 1, &v_head);

@@ -119,3 +119,23 @@ def test_readmap_built_on_gpu_answers_like_oracle(world):
     for k in range(len(seqs)):
         we, wm = oss.propagate_from_end(seqs[k], ends[k], orm, 20)
         assert res[k][0] == {0: we[0]} and res[k][1] == sorted(wm, key=lambda r: (r[0], -r[1], r[2]))
+
+
+def test_open_legacy_readmap_and_seqset(world, golden_dir):
+    """Containers written by v3.1.1 (seqset 1.0.0 with raw uint8 sizes, readmap 1.1.0 with raw lengths and
+    32-bit loop pointers) open through the same entry points."""
+    ctx = world[0]
+    d = O.load_seqset_zip(golden_dir + "/e_coli_10000snp/seqset")
+    g = O.decode_readmap(golden_dir + "/e_coli_10000snp/readmap", d)
+    ss = ctx.open_seqset(golden_dir + "/e_coli_10000snp/seqset")
+    rm = ctx.open_readmap(golden_dir + "/e_coli_10000snp/readmap")
+    assert ss.size() == 19935 and rm.size() == 16888 and rm.max_read_len == 35
+    e, rl, ml, f = rm.arrays()
+    assert (e == g["entry"]).all() and (rl == g["read_len"]).all()
+    assert (ml == g["mate_loop_ptr"]).all() and (f == g["is_forward"]).all()
+    # unpaired: nobody has a mate; rev_comp is the loop partner
+    info = ss.read_info_batch(rm, list(range(0, 16888, 211)))
+    assert all(not hm and ml[i] == rc for (hm, _, rc, _), i in zip(info, range(0, 16888, 211)))
+    with pytest.raises(bg.BgError) as err:   # mate_pair_ptr-only readmaps need `biograph upgrade`
+        ctx.open_readmap(golden_dir + "/e_coli_merged/readmap_e_coli_test")
+    assert "upgrade" in str(err.value)
