@@ -114,6 +114,9 @@ int radix_sort_u64(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* va
 // Stable partition of keys into 65536 buckets by the top 16 bits of key * kPartitionMult.
 constexpr uint64_t kPartitionMult = 0x9E3779B97F4A7C15ull;
 int radix_partition_hash16(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, bool* in_b);
+// Same for the k-mer instances of packed reads, generated inside pass 1 (n = their number); result in keys_b.
+int radix_partition_hash16_reads(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t n, uint64_t* keys_a,
+                                 uint64_t* keys_b);
 
 // ---- device-side object layouts
 }  // namespace bg

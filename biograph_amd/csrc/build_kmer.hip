@@ -716,7 +716,9 @@ static int kmer_lds_log2cap() {
 
 // Default counting path: hash partition (2 radix passes on 16 hash bits) + one LDS counting pass.
 // ka = instances (clobbered), kb = scratch, both N.  Output k-mers are sorted ascending.
-int kmer_count_keys_impl(bg_ctx* ctx, uint64_t* ka, uint64_t* kb, uint64_t N, uint32_t min_count, bg_kmerset* ks) {
+// partitioned = the instances already sit in kb grouped by 16 hash bits (radix_partition_hash16_reads)
+int kmer_count_keys_impl(bg_ctx* ctx, uint64_t* ka, uint64_t* kb, uint64_t N, uint32_t min_count, bg_kmerset* ks,
+                         bool partitioned = false) {
   ks->distinct = 0;
   ks->size = 0;
   if (!N) {
@@ -724,8 +726,8 @@ int kmer_count_keys_impl(bg_ctx* ctx, uint64_t* ka, uint64_t* kb, uint64_t N, ui
     BG_TRY(ks->counts.alloc(ctx, 0));
     return BG_OK;
   }
-  bool in_b = false;
-  BG_TRY(radix_partition_hash16(ctx, ka, kb, N, &in_b));
+  bool in_b = partitioned;
+  if (!partitioned) BG_TRY(radix_partition_hash16(ctx, ka, kb, N, &in_b));
   uint64_t* part = in_b ? kb : ka;
   uint64_t* scratch = in_b ? ka : kb;
   const uint32_t NB = 65536;
@@ -868,8 +870,16 @@ extern "C" int bg_kmer_count(bg_ctx* ctx, const bg_reads* reads, int k, uint32_t
     DevBuf<uint64_t> ka, kb;
     BG_TRY(ka.alloc(ctx, N));
     BG_TRY(kb.alloc(ctx, N));
-    BG_TRY(kmer_extract_impl(ctx, reads, k, koff.p, N, ka.p));
-    BG_TRY(kmer_count_keys_impl(ctx, ka.p, kb.p, N, min_count, ks.get()));
+    // extraction fused into the first partition pass (instances written once, never re-read by a histogram);
+    // BG_KMER_UNFUSED=1 keeps the separate extraction kernel (A/B measurements)
+    const char* unfused = getenv("BG_KMER_UNFUSED");
+    if (unfused && unfused[0] == '1') {
+      BG_TRY(kmer_extract_impl(ctx, reads, k, koff.p, N, ka.p));
+      BG_TRY(kmer_count_keys_impl(ctx, ka.p, kb.p, N, min_count, ks.get()));
+    } else {
+      BG_TRY(radix_partition_hash16_reads(ctx, reads, k, N, ka.p, kb.p));
+      BG_TRY(kmer_count_keys_impl(ctx, ka.p, kb.p, N, min_count, ks.get(), true));
+    }
   }
   BG_TRY(kmer_hash_build_impl(ctx, ks.get(), reads));
   *out = ks.release();

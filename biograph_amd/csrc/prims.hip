@@ -10,6 +10,7 @@
 //   rs_scatter  stable rank inside the tile via wave64 match-any ballots, LDS-staged reorder, then
 //               coalesced runs to HBM                          (reads keys once, writes once)
 // A one-off rs_digit_census pass finds digits on which all keys agree so those passes are skipped.
+#include "bg_device_funcs.h"
 #include "bg_internal.h"
 
 namespace bg {
@@ -740,6 +741,167 @@ static int radix_partition_hash16_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* 
     *in_b = !*in_b;
   }
   return BG_OK;
+}
+
+// ---- the same partition with pass 1 generating its keys straight from the packed reads: the canonical
+// k-mers of a tile of reads are produced in registers (wave per read, lane per window, as k_extract_kmers
+// does), so the 8-byte instances are written once (by pass 1's scatter) instead of written by an
+// extraction kernel and read back twice.
+struct ReadKeySource {
+  const uint64_t* words;
+  const uint32_t* nmask;
+  const uint16_t* len;
+  uint64_t n_reads;
+  int W, k, reads_per_tile;
+};
+
+// calls f(key) for every window of reads [r_lo, r_hi): canonical k-mer, or all-ones when the window holds
+// an N (kmer_counter.h:306-311).  Wave w takes reads r_lo + w, r_lo + w + 4, ...
+template <class F>
+__device__ __forceinline__ void tile_kmers(const ReadKeySource& src, uint64_t r_lo, uint64_t r_hi, F f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int W = src.W, k = src.k;
+  for (uint64_t i = r_lo + wave; i < r_hi; i += RS_THREADS / 64) {
+    const int L = src.len[i];
+    if (L < k) continue;
+    const int nk = L - k + 1;
+    uint64_t myw = lane < W ? src.words[i * W + lane] : 0;
+    uint32_t myn = lane < W ? src.nmask[i * W + lane] : 0;
+    for (int j0 = 0; j0 < nk; j0 += 64) {
+      int j = j0 + lane;
+      int q = j >> 5, r = j & 31;
+      int q0 = q < 63 ? q : 63, q1 = q + 1 < 63 ? q + 1 : 63;
+      uint64_t w0 = __shfl(myw, q0, 64), w1 = __shfl(myw, q1, 64);
+      uint32_t n0 = __shfl(myn, q0, 64), n1 = __shfl(myn, q1, 64);
+      if (j < nk) {
+        uint64_t x = r ? ((w0 << (2 * r)) | (w1 >> (64 - 2 * r))) : w0;
+        uint32_t nm = r ? ((n0 << r) | (n1 >> (32 - r))) : n0;
+        bool fl;
+        uint64_t canon = kmer_canon(x >> (64 - 2 * k), k, &fl);
+        f((nm >> (32 - k)) != 0 ? ~0ull : canon);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_part_hist_reads_kernel(ReadKeySource src, int shift,
+                                                                        uint32_t* __restrict__ hist, uint32_t ntiles) {
+  __shared__ uint32_t h[RS_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  uint64_t r_lo = uint64_t(blockIdx.x) * src.reads_per_tile;
+  uint64_t r_hi = r_lo + src.reads_per_tile < src.n_reads ? r_lo + src.reads_per_tile : src.n_reads;
+  tile_kmers(src, r_lo, r_hi, [&](uint64_t key) { atomicAdd(&h[rs_digit<true>(key, shift, 0xffu)], 1u); });
+  __syncthreads();
+  hist[uint64_t(threadIdx.x) * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+template <class OffT>
+__global__ __launch_bounds__(RS_THREADS) void rs_part_scatter_reads_kernel(ReadKeySource src,
+                                                                           uint64_t* __restrict__ kout, int shift,
+                                                                           const OffT* __restrict__ offs,
+                                                                           const uint32_t* __restrict__ hist,
+                                                                           uint32_t ntiles) {
+  __shared__ uint64_t skeys[PT_TILE];
+  __shared__ uint32_t cursor[RS_BINS];
+  __shared__ OffT goff[RS_BINS];
+  __shared__ uint32_t scan_sm[4];
+  const int tid = threadIdx.x;
+  uint64_t r_lo = uint64_t(blockIdx.x) * src.reads_per_tile;
+  uint64_t r_hi = r_lo + src.reads_per_tile < src.n_reads ? r_lo + src.reads_per_tile : src.n_reads;
+  uint32_t total;
+  {
+    uint32_t tot = hist[uint64_t(tid) * ntiles + blockIdx.x];  // this tile's column of the histogram pass
+    uint32_t ex = block_excl_scan_256<uint32_t>(tot, scan_sm, &total);
+    cursor[tid] = ex;
+    goff[tid] = offs[uint64_t(tid) * ntiles + blockIdx.x] - OffT(ex);
+  }
+  __syncthreads();
+  // arrival order inside a bin is free: one LDS atomic gives a key its slot
+  tile_kmers(src, r_lo, r_hi, [&](uint64_t key) {
+    skeys[atomicAdd(&cursor[rs_digit<true>(key, shift, 0xffu)], 1u)] = key;
+  });
+  __syncthreads();
+  for (uint32_t i = tid; i < total; i += RS_THREADS) {
+    uint64_t k = skeys[i];
+    kout[goff[rs_digit<true>(k, shift, 0xffu)] + OffT(i)] = k;
+  }
+}
+
+template <class OffT>
+static int radix_partition_hash16_second(bg_ctx* ctx, uint64_t* kin, uint64_t* kout, uint64_t n,
+                                         const uint64_t* h_key /* 257 bucket starts */) {
+  std::vector<uint32_t> h_tile(RS_BINS + 1, 0);
+  uint32_t t = 0;
+  for (int b = 0; b < RS_BINS; ++b) {
+    h_tile[b] = t;
+    t += uint32_t((h_key[b + 1] - h_key[b] + PT_TILE - 1) / PT_TILE);
+  }
+  h_tile[RS_BINS] = t;
+  const uint32_t ntiles = t;
+  DevBuf<uint32_t> hist, seg_tile;
+  DevBuf<OffT> offs;
+  DevBuf<uint64_t> seg_key;
+  BG_TRY(hist.alloc(ctx, size_t(RS_BINS) * ntiles));
+  BG_TRY(offs.alloc(ctx, size_t(RS_BINS) * ntiles));
+  BG_TRY(seg_key.alloc(ctx, RS_BINS + 1));
+  BG_TRY(seg_tile.alloc(ctx, RS_BINS + 1));
+  BG_HIP(hipMemcpyAsync(seg_key.p, h_key, (RS_BINS + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  BG_HIP(hipMemcpyAsync(seg_tile.p, h_tile.data(), (RS_BINS + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  PartSegs sg{seg_key.p, seg_tile.p, RS_BINS};
+  ctx->tic("radix_hist");
+  rs_part_hist_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, sg, 48, hist.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n * 8);
+  ctx->tic("radix_scan");
+  BG_TRY(exclusive_scan_impl<OffT>(ctx, hist.p, offs.p, uint64_t(RS_BINS) * ntiles, nullptr));
+  ctx->toc(uint64_t(RS_BINS) * ntiles * (4 + sizeof(OffT)));
+  ctx->tic("radix_scatter_k");
+  rs_part_scatter_kernel<OffT><<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, kout, sg, 48, offs.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n * 16);
+  return BG_OK;
+}
+
+template <class OffT>
+static int radix_partition_hash16_reads_impl(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t n,
+                                             uint64_t* keys_a, uint64_t* keys_b) {
+  const int maxw = int(reads->max_len) - k + 1;
+  ReadKeySource src{reads->words.p, reads->nmask.p, reads->len.p, reads->n, reads->W, k,
+                    maxw > 0 ? std::max(1, PT_TILE / maxw) : 1};
+  const uint32_t ntiles = uint32_t((reads->n + src.reads_per_tile - 1) / src.reads_per_tile);
+  DevBuf<uint32_t> hist;
+  DevBuf<OffT> offs;
+  DevBuf<uint64_t> starts;
+  BG_TRY(hist.alloc(ctx, size_t(RS_BINS) * ntiles));
+  BG_TRY(offs.alloc(ctx, size_t(RS_BINS) * ntiles));
+  BG_TRY(starts.alloc(ctx, RS_BINS + 1));
+  ctx->tic("radix_hist");
+  rs_part_hist_reads_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(src, 56, hist.p, ntiles);
+  BG_LAUNCH_CHECK();
+  ctx->toc(reads->n * uint64_t(reads->W) * 12);
+  ctx->tic("radix_scan");
+  BG_TRY(exclusive_scan_impl<OffT>(ctx, hist.p, offs.p, uint64_t(RS_BINS) * ntiles, nullptr));
+  ctx->toc(uint64_t(RS_BINS) * ntiles * (4 + sizeof(OffT)));
+  ctx->tic("kmer_extract_partition");
+  rs_part_scatter_reads_kernel<OffT><<<ntiles, RS_THREADS, 0, ctx->stream>>>(src, keys_a, 56, offs.p, hist.p, ntiles);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n * 8 + reads->n * uint64_t(reads->W) * 12);
+  rs_part_bucket_starts_kernel<OffT><<<1, RS_BINS, 0, ctx->stream>>>(offs.p, ntiles, n, starts.p);
+  BG_LAUNCH_CHECK();
+  std::vector<uint64_t> h_key(RS_BINS + 1, 0);
+  BG_HIP(hipMemcpyAsync(h_key.data(), starts.p, (RS_BINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return radix_partition_hash16_second<OffT>(ctx, keys_a, keys_b, n, h_key.data());
+}
+
+// Partition of the k-mer instances of `reads` (n of them in all, sentinels included) into keys_b.
+int radix_partition_hash16_reads(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t n, uint64_t* keys_a,
+                                 uint64_t* keys_b) {
+  if (!n) return BG_OK;
+  if (n < (1ull << 32)) return radix_partition_hash16_reads_impl<uint32_t>(ctx, reads, k, n, keys_a, keys_b);
+  return radix_partition_hash16_reads_impl<uint64_t>(ctx, reads, k, n, keys_a, keys_b);
 }
 
 int radix_partition_hash16(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, bool* in_b) {
