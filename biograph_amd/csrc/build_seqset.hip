@@ -93,11 +93,16 @@ __global__ __launch_bounds__(128) void k_emit_records(const uint64_t* __restrict
 }
 
 // sort input: first word of every record + its index
+// The first sort covers the leading 24 bases only (6 radix passes instead of 8): records that agree on them
+// are almost always suffixes at the same genome position, which the tie handling orders by full-key
+// compares anyway; the low 16 bits of the first word are left to it.
+constexpr int kSortSkipBits = 16;
+
 __global__ void k_first_words(const uint64_t* __restrict__ rec, uint64_t n, int W, uint64_t* __restrict__ k0,
                               uint32_t* __restrict__ ridx) {
   uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r >= n) return;
-  k0[r] = rec[r * W];
+  k0[r] = rec[r * W] & ~((1ull << kSortSkipBits) - 1);
   ridx[r] = uint32_t(r);
 }
 
@@ -557,7 +562,7 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
       BG_LAUNCH_CHECK();
     }
     bool in_b = false;
-    BG_TRY(radix_sort_u64(ctx, k0a.p, k0b.p, ia.p, ib.p, n_rec, 0, 64, &in_b));
+    BG_TRY(radix_sort_u64(ctx, k0a.p, k0b.p, ia.p, ib.p, n_rec, kSortSkipBits, 64, &in_b));
     DevBuf<uint64_t>& ks = in_b ? k0b : k0a;
     sidx = std::move(in_b ? ib : ia);
     (in_b ? ia : ib).reset();
@@ -587,7 +592,7 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
     }
     ks.reset();
   bool have_gid = false;
-  for (int w = 1; w <= W && T; ++w) {
+  for (int w = 0; w <= W && T; ++w) {  // w = 0: the bits of the first word the sort skipped
     // groups of this round = runs of equal (previous group, previous key) at adjacent positions
     DevBuf<uint32_t> head, excl, ngid;
     BG_TRY(head.alloc(ctx, T));
