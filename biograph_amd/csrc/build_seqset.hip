@@ -93,10 +93,10 @@ __global__ __launch_bounds__(128) void k_emit_records(const uint64_t* __restrict
 }
 
 // sort input: first word of every record + its index
-// The first sort covers the leading 24 bases only (6 radix passes instead of 8): records that agree on them
+// The first sort covers the leading 20 bases only (5 radix passes instead of 8): records that agree on them
 // are almost always suffixes at the same genome position, which the tie handling orders by full-key
-// compares anyway; the low 16 bits of the first word are left to it.
-constexpr int kSortSkipBits = 16;
+// compares anyway; the low 24 bits of the first word are left to it.
+constexpr int kSortSkipBits = 24;
 
 __global__ void k_first_words(const uint64_t* __restrict__ rec, uint64_t n, int W, uint64_t* __restrict__ k0,
                               uint32_t* __restrict__ ridx) {
