@@ -92,6 +92,103 @@ __global__ __launch_bounds__(256) void k_dest_counts(const uint64_t* __restrict_
   if (h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
 
+// ---- stable multi-way split of rows by destination (<= 256 destinations): per-tile counts -> device scan
+// of the [dest][tile] table -> direct row writes.  Replaces sort-by-destination + gather.
+constexpr int MS_ITEMS = 8;
+constexpr int MS_TILE = 256 * MS_ITEMS;
+
+__device__ __forceinline__ uint64_t ms_match(uint32_t d, bool valid) {  // lanes with the same destination
+  uint64_t m = ~0ull;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    bool bit = (d >> b) & 1;
+    uint64_t bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  uint64_t bv = __ballot(valid);
+  m &= valid ? bv : ~bv;
+  return m;
+}
+
+__global__ __launch_bounds__(256) void k_msplit_count(const uint64_t* __restrict__ dest, uint64_t n, uint32_t nparts,
+                                                      uint32_t* __restrict__ counts, uint32_t ntiles) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint64_t lane_lt = (1ull << lane) - 1;
+  const uint64_t base = uint64_t(blockIdx.x) * MS_TILE + uint64_t(w) * (MS_ITEMS * 64);
+  for (int it = 0; it < MS_ITEMS; ++it) {
+    uint64_t i = base + uint64_t(it) * 64 + lane;
+    uint64_t dv = i < n ? dest[i] : uint64_t(kDropDest);
+    bool valid = i < n && dv < nparts;
+    uint32_t d = valid ? uint32_t(dv) : 0u;
+    uint64_t m = ms_match(d, valid);
+    if (valid && (m & lane_lt) == 0) atomicAdd(&h[d], uint32_t(__popcll(m)));
+  }
+  __syncthreads();
+  if (threadIdx.x < nparts) counts[uint64_t(threadIdx.x) * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_msplit_scatter(const uint64_t* __restrict__ rows,
+                                                        const uint64_t* __restrict__ dest, uint64_t n, int row_words,
+                                                        uint32_t nparts, const uint64_t* __restrict__ offs,
+                                                        uint32_t ntiles, uint64_t* __restrict__ out) {
+  __shared__ uint32_t whist[4][256];
+  __shared__ uint64_t goff[256];
+  for (int i = threadIdx.x; i < 4 * 256; i += 256) (&whist[0][0])[i] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint64_t lane_lt = (1ull << lane) - 1;
+  const uint64_t base = uint64_t(blockIdx.x) * MS_TILE + uint64_t(w) * (MS_ITEMS * 64);
+  volatile uint32_t* wh = &whist[w][0];
+  uint16_t rnk[MS_ITEMS];
+  uint8_t dd[MS_ITEMS];
+#pragma unroll
+  for (int it = 0; it < MS_ITEMS; ++it) {
+    uint64_t i = base + uint64_t(it) * 64 + lane;
+    uint64_t dv = i < n ? dest[i] : uint64_t(kDropDest);
+    bool valid = i < n && dv < nparts;
+    uint32_t d = valid ? uint32_t(dv) : 0u;
+    uint64_t m = ms_match(d, valid);
+    uint32_t before = wh[d];
+    uint32_t lt = __popcll(m & lane_lt);
+    rnk[it] = uint16_t(before + lt);
+    dd[it] = valid ? uint8_t(d) : uint8_t(255);
+    if (valid && lt == 0) wh[d] = before + uint32_t(__popcll(m));
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  {  // thread = destination: wave bases inside the tile, global offset of the tile's run
+    int t = threadIdx.x;
+    uint32_t c0 = whist[0][t], c1 = whist[1][t], c2 = whist[2][t];
+    whist[0][t] = 0;
+    whist[1][t] = c0;
+    whist[2][t] = c0 + c1;
+    whist[3][t] = c0 + c1 + c2;
+    goff[t] = uint32_t(t) < nparts ? offs[uint64_t(t) * ntiles + blockIdx.x] : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < MS_ITEMS; ++it) {
+    // the wave's 64 rows of this round are contiguous in the source: copy them word-interleaved (lane =
+    // word index), fetching each row's destination from the lane that ranked it
+    const uint64_t i0 = base + uint64_t(it) * 64;
+    if (i0 >= n) break;
+    bool keep = dd[it] != 255;
+    uint32_t d = keep ? dd[it] : 0u;
+    uint64_t pos = keep ? goff[d] + whist[w][d] + rnk[it] : 0;
+    const uint64_t nwords = (n - i0 < 64 ? n - i0 : 64) * uint64_t(row_words);
+    for (uint64_t j = lane; j < uint64_t(64) * row_words; j += 64) {  // uniform trip count (shuffles inside)
+      int row = int(j / uint64_t(row_words));
+      int wd = int(j - uint64_t(row) * row_words);
+      uint64_t p = __shfl(pos, row, 64);
+      bool k = __shfl(int(keep), row, 64) != 0;
+      if (j < nwords && k) out[p * uint64_t(row_words) + wd] = rows[i0 * uint64_t(row_words) + j];
+    }
+  }
+}
+
 __global__ void k_gather_rows(const uint64_t* __restrict__ rows, const uint32_t* __restrict__ perm, uint64_t n_out,
                               int row_words, uint64_t* __restrict__ out) {
   uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -177,13 +274,11 @@ extern "C" int bg_partition_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n
   BG_HIP(hipSetDevice(ctx->device));
   for (uint32_t p = 0; p < nparts; ++p) h_counts[p] = 0;
   if (!n) return BG_OK;
-  DevBuf<uint64_t> da, db;
-  DevBuf<uint32_t> ia, ib, err;
+  DevBuf<uint64_t> da;
+  DevBuf<uint32_t> ia, err;
   DevBuf<unsigned long long> counts;
   BG_TRY(da.alloc(ctx, n));
-  BG_TRY(db.alloc(ctx, n));
   BG_TRY(ia.alloc(ctx, n));
-  BG_TRY(ib.alloc(ctx, n));
   BG_TRY(err.alloc(ctx, 1));
   BG_TRY(counts.alloc(ctx, 256));
   BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
@@ -222,8 +317,15 @@ extern "C" int bg_partition_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n
   k_dest_counts<<<grid, 256, 0, ctx->stream>>>(da.p, n, counts.p);
   BG_LAUNCH_CHECK();
   ctx->toc(n * (uint64_t(row_words) * 8 + 12));
-  bool in_b = false;
-  BG_TRY(radix_sort_u64(ctx, da.p, db.p, ia.p, ib.p, n, 0, 8, &in_b, RS_LOW_ENTROPY));
+  const uint32_t ntiles = uint32_t((n + MS_TILE - 1) / MS_TILE);
+  DevBuf<uint32_t> tcounts;
+  DevBuf<uint64_t> toffs;
+  BG_TRY(tcounts.alloc(ctx, uint64_t(nparts) * ntiles));
+  BG_TRY(toffs.alloc(ctx, uint64_t(nparts) * ntiles));
+  ctx->tic("partition_split");
+  k_msplit_count<<<ntiles, 256, 0, ctx->stream>>>(da.p, n, nparts, tcounts.p, ntiles);
+  BG_LAUNCH_CHECK();
+  BG_TRY(exclusive_scan_u32_to_u64(ctx, tcounts.p, toffs.p, uint64_t(nparts) * ntiles, nullptr));
   unsigned long long hc[256];
   uint32_t h_err = 0;
   BG_HIP(hipMemcpyAsync(hc, counts.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
@@ -233,12 +335,10 @@ extern "C" int bg_partition_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n
   uint64_t n_out = 0;
   for (uint32_t p = 0; p < nparts; ++p) { h_counts[p] = hc[p]; n_out += hc[p]; }
   if (n_out) {
-    ctx->tic("partition_gather");
-    k_gather_rows<<<cdiv(n_out * row_words, 256), 256, 0, ctx->stream>>>(d_rows, in_b ? ib.p : ia.p, n_out, row_words,
-                                                                         d_out_rows);
+    k_msplit_scatter<<<ntiles, 256, 0, ctx->stream>>>(d_rows, da.p, n, row_words, nparts, toffs.p, ntiles, d_out_rows);
     BG_LAUNCH_CHECK();
-    ctx->toc(n_out * uint64_t(row_words) * 16);
   }
+  ctx->toc(n * (uint64_t(row_words) * 16 + 16));
   BG_HIP(hipStreamSynchronize(ctx->stream));
   return BG_OK;
 }

@@ -200,6 +200,33 @@ def _next_nonempty(rows, r, step):
 
 # ------------------------------------------------------------------------------------------------
 
+class _Phases:
+    """BG_SHARD_TIMING=1: wall time per phase of sharded_create on stderr (device synchronised)."""
+
+    def __init__(self):
+        import os
+        self.on = os.environ.get("BG_SHARD_TIMING") == "1"
+        self.t = None
+        self.rows = []
+
+    def mark(self, name):
+        if not self.on:
+            return
+        import time
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        now = time.perf_counter()
+        if self.t is not None:
+            self.rows.append((self.name, (now - self.t) * 1e3))
+        self.t, self.name = now, name
+
+    def done(self):
+        if self.on:
+            import sys
+            self.mark("end")
+            sys.stderr.write("sharded_create phases (ms): " + ", ".join("%s %.1f" % r for r in self.rows) + "\n")
+
+
 def sharded_create(comm, ctxs, inputs, params=None, device=None):
     """comm: communicator; ctxs[r]: biograph_amd.Context of local rank r; inputs[r] = (seq uint8 tensor,
     offs int64 tensor, n_reads) resident on that rank's device.  Returns {r: (Seqset | None, stats)};
@@ -214,11 +241,14 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
     dev = {r: inputs[r][0].device for r in ranks}
     i64 = torch.int64
 
+    ph = _Phases()
+    ph.mark("pack")
     # ---- S1 pack (local)
     reads = {r: ctxs[r].pack_reads_device(inputs[r][0].data_ptr(), inputs[r][1].data_ptr(), inputs[r][2])
              for r in ranks}
     n_bases = comm.all_gather_obj({r: int(reads[r].total_bases) for r in ranks})[ranks[0]]
 
+    ph.mark("kmer_extract_partition")
     # ---- S2 k-mer instances -> owner ranks
     send = {}
     n_inst = {}
@@ -230,8 +260,10 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
         capi.check(L.bg_kmer_extract(ctxs[r].h, reads[r].h, k, _ptr(keys), n.value))
         send[r] = _partition(ctxs[r], keys, capi.PART_KMER_HASH, P, None)
         del keys
+    ph.mark("kmer_all_to_all")
     recv = comm.all_to_all_v(send)
     del send
+    ph.mark("kmer_count")
     kept = {}
     distinct = {}
     for r in ranks:
@@ -245,6 +277,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
         kept[r] = t
         ks.free()
     del recv
+    ph.mark("kmerset_all_gather_build")
     gathered = comm.all_gather_v(kept)
     tot_inst = sum(comm.all_gather_obj(n_inst)[ranks[0]])
     tot_distinct = sum(comm.all_gather_obj(distinct)[ranks[0]])
@@ -257,6 +290,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
         n_kept = allk.shape[0]
     del gathered, kept
 
+    ph.mark("correct")
     # ---- S3 correction (local, replicated k-mer set)
     corrected = {}
     cstats = {}
@@ -269,6 +303,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
     max_len = max(comm.all_gather_obj({r: int(corrected[r].max_len) for r in ranks})[ranks[0]])
     W = max(1, (max_len + 31) // 32)
 
+    ph.mark("reads_all_gather")
     # ---- corrected reads replicated (cover index spans all reads)
     words, lens = {}, {}
     for r in ranks:
@@ -280,6 +315,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
     gw = comm.all_gather_v(words)
     gl = comm.all_gather_v(lens)
     del words, lens
+    ph.mark("suffix_records")
     send = {}
     hists = {}
     for r in ranks:
@@ -304,13 +340,16 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
         hists[r] = torch.bincount(bins, minlength=4 ** PREFIX_BASES).to(i64)
         send[r] = rows
     del gw, gl
+    ph.mark("records_partition")
     ghist = comm.all_reduce_sum(hists)
     splitters = choose_splitters(ghist[ranks[0]].cpu().numpy(), P)
     n_records = int(ghist[ranks[0]].sum().item())
     for r in ranks:
         send[r] = _partition(ctxs[r], send[r], capi.PART_PREFIX, P, [PREFIX_BASES] + splitters)
+    ph.mark("records_all_to_all")
     recv = comm.all_to_all_v(send)
     del send
+    ph.mark("entries_from_records")
     shards = {}
     for r in ranks:
         rows = recv[r].contiguous()
@@ -323,6 +362,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
         shards[r] = bg.Seqset(ctxs[r], h)
     del recv
 
+    ph.mark("boundaries")
     # ---- shard boundaries
     def boundary(r):
         f = np.zeros(W + 1, np.uint64)
@@ -343,6 +383,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
             a = np.array(prv, np.uint64)
             capi.check(L.bg_seqset_fix_boundary(ctxs[r].h, shards[r].h, capi.np_ptr(a), None))
 
+    ph.mark("tails_partition")
     # ---- S5 prev bits: route every entry's tail to the shard holding lower_bound(tail)
     bounds = np.array(lasts, np.uint64).reshape(P, W + 1)
     send = {}
@@ -351,8 +392,10 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
         rows = torch.empty((n, W + 1), dtype=i64, device=dev[r])
         capi.check(L.bg_seqset_tail_rows(ctxs[r].h, shards[r].h, _ptr(rows)))
         send[r] = _partition(ctxs[r], rows, capi.PART_KEY_BOUNDS, P, bounds.reshape(-1))
+    ph.mark("tails_all_to_all")
     recv = comm.all_to_all_v(send)
     del send
+    ph.mark("apply_tails_export")
     sl_sizes, sl_shared, sl_bits, sl_n = {}, {}, {}, {}
     for r in ranks:
         rows = recv[r].contiguous()
@@ -368,6 +411,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
         shards[r].free()
     del recv
 
+    ph.mark("gather_assemble")
     # ---- final merge on rank 0: concatenation in rank order + finalize
     g_sizes = comm.all_gather_v(sl_sizes)
     g_shared = comm.all_gather_v(sl_shared)
@@ -391,4 +435,5 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
         h = C.c_void_p()
         capi.check(L.bg_seqset_assemble(ctxs[r].h, P, pn, _ptr(sz), _ptr(sh), _ptr(bt), max_len, C.byref(h)))
         out[r] = (bg.Seqset(ctxs[r], h), stats)
+    ph.done()
     return out
