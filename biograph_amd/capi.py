@@ -64,7 +64,7 @@ SYMBOLS = [
     "bg_read_info_batch", "bg_propagate_from_end_batch", "bg_push_to_pair_trace_batch",
     "bg_seqset_merge", "bg_readmap_migrate",
     # sharded build
-    "bg_partition_rows", "bg_kmer_instances", "bg_kmer_extract", "bg_kmer_count_keys", "bg_kmerset_export",
+    "bg_partition_rows", "bg_kmer_instances", "bg_kmer_extract", "bg_kmer_extract_by_owner", "bg_kmer_count_keys", "bg_kmerset_export",
     "bg_kmerset_from_kmers", "bg_reads_words", "bg_reads_export", "bg_reads_import", "bg_suffix_records",
     "bg_records_count", "bg_records_words", "bg_records_rows", "bg_records_from_rows", "bg_records_free",
     "bg_entries_from_records", "bg_seqset_words", "bg_seqset_boundary_rows", "bg_seqset_fix_boundary",
@@ -152,6 +152,7 @@ def lib():
     L.bg_partition_rows.argtypes = [vp, vp, u64, i32, i32, u32, vp, vp, vp]
     L.bg_kmer_instances.argtypes = [vp, vp, i32, P(u64)]
     L.bg_kmer_extract.argtypes = [vp, vp, i32, vp, u64]
+    L.bg_kmer_extract_by_owner.argtypes = [vp, vp, i32, u32, vp, u64, vp]
     L.bg_kmer_count_keys.argtypes = [vp, vp, u64, i32, u32, P(vp)]
     L.bg_kmerset_export.argtypes = [vp, vp, vp]
     L.bg_kmerset_from_kmers.argtypes = [vp, vp, u64, i32, vp, P(vp)]

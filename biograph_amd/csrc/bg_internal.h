@@ -115,6 +115,9 @@ int radix_sort_u64(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* va
 constexpr uint64_t kPartitionMult = 0x9E3779B97F4A7C15ull;
 int radix_partition_hash16(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, bool* in_b);
 // Same for the k-mer instances of packed reads, generated inside pass 1 (n = their number); result in keys_b.
+// First pass alone: keys grouped by the top hash byte, h_starts[257] = bucket starts.
+int radix_partition_first_reads(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t n, uint64_t* keys_out,
+                                uint64_t* h_starts);
 int radix_partition_hash16_reads(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t n, uint64_t* keys_a,
                                  uint64_t* keys_b);
 

@@ -908,6 +908,26 @@ extern "C" int bg_kmer_extract(bg_ctx* ctx, const bg_reads* reads, int k, uint64
   return BG_OK;
 }
 
+extern "C" int bg_kmer_extract_by_owner(bg_ctx* ctx, const bg_reads* reads, int k, uint32_t nparts, uint64_t* d_keys,
+                                        uint64_t cap, uint64_t* h_counts) {
+  if (!ctx || !reads || !h_counts || (!d_keys && cap)) { set_error("bg_kmer_extract_by_owner: null argument"); return BG_EINVAL; }
+  if (k < 1 || k > 31) { set_error("bg_kmer_extract_by_owner: kmer size %d outside 1..31", k); return BG_EINVAL; }
+  if (nparts < 1 || nparts > 256) { set_error("bg_kmer_extract_by_owner: nparts %u outside 1..256", nparts); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  DevBuf<uint64_t> koff;
+  uint64_t N = 0;
+  BG_TRY(kmer_offsets(ctx, reads, k, &koff, &N));
+  if (N > cap) { set_error("bg_kmer_extract_by_owner: buffer holds %llu of %llu keys", (unsigned long long)cap, (unsigned long long)N); return BG_EINVAL; }
+  uint64_t starts[257];
+  BG_TRY(radix_partition_first_reads(ctx, reads, k, N, d_keys, starts));
+  // owner of hash byte b = b * nparts / 256: contiguous bucket ranges, so the rows of a rank are contiguous
+  for (uint32_t p = 0; p < nparts; ++p) {
+    uint32_t lo = (p * 256u + nparts - 1) / nparts, hi = ((p + 1) * 256u + nparts - 1) / nparts;
+    h_counts[p] = (N ? starts[hi] : 0) - (N ? starts[lo] : 0);
+  }
+  return BG_OK;
+}
+
 extern "C" int bg_kmer_count_keys(bg_ctx* ctx, uint64_t* d_keys, uint64_t n, int k, uint32_t min_count,
                                   bg_kmerset** out) {
   if (!ctx || !out || (n && !d_keys)) { set_error("bg_kmer_count_keys: null argument"); return BG_EINVAL; }

@@ -864,9 +864,10 @@ static int radix_partition_hash16_second(bg_ctx* ctx, uint64_t* kin, uint64_t* k
   return BG_OK;
 }
 
+// pass 1 alone: instances grouped by hash bits 56..63 in keys_out, bucket starts (257) on the host
 template <class OffT>
-static int radix_partition_hash16_reads_impl(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t n,
-                                             uint64_t* keys_a, uint64_t* keys_b) {
+static int radix_partition_first_reads_impl(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t n, uint64_t* keys_out,
+                                            uint64_t* h_starts) {
   const int maxw = int(reads->max_len) - k + 1;
   ReadKeySource src{reads->words.p, reads->nmask.p, reads->len.p, reads->n, reads->W, k,
                     maxw > 0 ? std::max(1, PT_TILE / maxw) : 1};
@@ -885,15 +886,31 @@ static int radix_partition_hash16_reads_impl(bg_ctx* ctx, const bg_reads* reads,
   BG_TRY(exclusive_scan_impl<OffT>(ctx, hist.p, offs.p, uint64_t(RS_BINS) * ntiles, nullptr));
   ctx->toc(uint64_t(RS_BINS) * ntiles * (4 + sizeof(OffT)));
   ctx->tic("kmer_extract_partition");
-  rs_part_scatter_reads_kernel<OffT><<<ntiles, RS_THREADS, 0, ctx->stream>>>(src, keys_a, 56, offs.p, hist.p, ntiles);
+  rs_part_scatter_reads_kernel<OffT><<<ntiles, RS_THREADS, 0, ctx->stream>>>(src, keys_out, 56, offs.p, hist.p, ntiles);
   BG_LAUNCH_CHECK();
   ctx->toc(n * 8 + reads->n * uint64_t(reads->W) * 12);
   rs_part_bucket_starts_kernel<OffT><<<1, RS_BINS, 0, ctx->stream>>>(offs.p, ntiles, n, starts.p);
   BG_LAUNCH_CHECK();
-  std::vector<uint64_t> h_key(RS_BINS + 1, 0);
-  BG_HIP(hipMemcpyAsync(h_key.data(), starts.p, (RS_BINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipMemcpyAsync(h_starts, starts.p, (RS_BINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+template <class OffT>
+static int radix_partition_hash16_reads_impl(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t n,
+                                             uint64_t* keys_a, uint64_t* keys_b) {
+  std::vector<uint64_t> h_key(RS_BINS + 1, 0);
+  BG_TRY(radix_partition_first_reads_impl<OffT>(ctx, reads, k, n, keys_a, h_key.data()));
   return radix_partition_hash16_second<OffT>(ctx, keys_a, keys_b, n, h_key.data());
+}
+
+// First pass only (the sharded build sends whole hash-byte buckets to their owner ranks).
+int radix_partition_first_reads(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t n, uint64_t* keys_out,
+                                uint64_t* h_starts) {
+  for (int b = 0; b <= RS_BINS; ++b) h_starts[b] = 0;
+  if (!n) return BG_OK;
+  if (n < (1ull << 32)) return radix_partition_first_reads_impl<uint32_t>(ctx, reads, k, n, keys_out, h_starts);
+  return radix_partition_first_reads_impl<uint64_t>(ctx, reads, k, n, keys_out, h_starts);
 }
 
 // Partition of the k-mer instances of `reads` (n of them in all, sentinels included) into keys_b.

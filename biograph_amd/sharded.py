@@ -257,8 +257,10 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
         capi.check(L.bg_kmer_instances(ctxs[r].h, reads[r].h, k, C.byref(n)))
         n_inst[r] = n.value
         keys = torch.empty((n.value, 1), dtype=i64, device=dev[r])
-        capi.check(L.bg_kmer_extract(ctxs[r].h, reads[r].h, k, _ptr(keys), n.value))
-        send[r] = _partition(ctxs[r], keys, capi.PART_KMER_HASH, P, None)
+        counts = (C.c_uint64 * P)()
+        # extraction + owner partition in one pass: whole hash-byte buckets go to their owner rank
+        capi.check(L.bg_kmer_extract_by_owner(ctxs[r].h, reads[r].h, k, P, _ptr(keys), n.value, counts))
+        send[r] = (keys, [int(c) for c in counts])
         del keys
     ph.mark("kmer_all_to_all")
     recv = comm.all_to_all_v(send)

@@ -323,6 +323,13 @@ int bg_partition_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int row_w
  * shard's hash range; all kept k-mers (after the all-gather) -> hash set. */
 int bg_kmer_instances(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t* n_out);
 int bg_kmer_extract(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t* d_keys, uint64_t cap);
+/* bg_kmer_extract with the exchange partition fused in: the instances leave grouped by owner rank
+ * (owner of a k-mer = top byte of kmer * 0x9E3779B97F4A7C15, times nparts, over 256 — whole buckets of
+ * the counting partition, i.e. the role of the 256-way kmer_partition of kmer_counter.h:167-178);
+ * h_counts[nparts] = rows per owner, consecutive in d_keys.  The all-ones rows of windows holding an N
+ * travel with their bucket and are ignored by bg_kmer_count_keys. */
+int bg_kmer_extract_by_owner(bg_ctx* ctx, const bg_reads* reads, int k, uint32_t nparts, uint64_t* d_keys,
+                             uint64_t cap, uint64_t* h_counts);
 int bg_kmer_count_keys(bg_ctx* ctx, uint64_t* d_keys /* clobbered */, uint64_t n, int k, uint32_t min_count,
                        bg_kmerset** out /* kmers+counts only, no hash */);
 int bg_kmerset_export(bg_ctx* ctx, const bg_kmerset* ks, uint64_t* d_kmers_out);
