@@ -42,7 +42,42 @@ def cpu_baseline(sample_genome, coverage, read_len, seed):
                 n, read_len, bases / 1e6, coverage, sample_genome, dt, len(ss))}
 
 
-def discover_leg(ctx, seq, offs, n_reads, params, genome, dev):
+def driver_leg(ctx, ss, genome, dev, args, region=200000):
+    """The whole graph-discover pipeline of the reference's graph_discover_test.py (make_ref_assemblies ->
+    trim/update -> discover_branch -> ... -> discover_push_to_pair; host drivers biograph_amd/variants.py over
+    the kernels) on the first `region` bases of the reference, scored against the SNPs synth.py planted on
+    the second haplotype.  Host-bound (Python bookkeeping, one launch per reference position in
+    update_rc_seqset_entries): a correctness demonstration at WGS depth, not a throughput figure."""
+    import torch
+    from biograph_amd import variants as V
+    G = int(genome.numel())
+    region = min(region, G)
+    ref = "".join("ACGT"[int(c)] for c in genome[:region].cpu().tolist())
+    g = torch.Generator(device=dev)
+    g.manual_seed(args.seed + 1)
+    snp = torch.rand(G, generator=g, device=dev) < 0.001
+    shift = torch.randint(1, 4, (G,), generator=g, device=dev, dtype=torch.uint8)
+    pos = torch.nonzero(snp[:region]).flatten().cpu().tolist()
+    truth = {p: "ACGT"[(int(genome[p]) + int(shift[p])) & 3] for p in pos if 300 < p < region - 300}
+    w = V.Walker(ss, None)
+    ext = [(0, ref)]
+    t0 = time.perf_counter()
+
+    def trim_and_update(asms):
+        return V.update_rc_seqset_entries(V.dedup_assemblies(V.graph_trim_ref(asms, ext)), w)
+    asms = trim_and_update(V.make_ref_assemblies(ext, 0, region))
+    asms = trim_and_update(V.discover_branch(asms, w, 105, "BRANCH"))
+    asms = trim_and_update(V.discover_push_to_pair(asms, w, 105, 1000, "PUSH_TO_PAIR", ["BRANCH"]))
+    found = [a for a in asms if a.left_offset is not None and a.right_offset is not None and not a.matches_reference]
+    dt = time.perf_counter() - t0
+    snps = {a.left_offset: a.seq for a in found if a.right_offset == a.left_offset + 1 and len(a.seq) == 1}
+    hit = sum(1 for p, b in truth.items() if snps.get(p) == b)
+    return {"region_bases": region, "seconds": round(dt, 2), "anchored_variants": len(found),
+            "planted_snps_in_region": len(truth), "planted_snps_found": hit,
+            "other_calls": len(found) - hit, "min_overlap": 105}
+
+
+def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
     """Overlap-walk throughput on the seqset just built (N=1 only, outside the build's timed region):
     ref_map::build over both strands of the reference haplotype (2 x G dependent push_front_drop calls in
     4096-base chains) and branch_discover::on_trace over the whole reference in 1000-base assemblies
@@ -174,6 +209,7 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev):
                "traces_ended_no_extension": int((o_why == 0).sum().item()),
                "traces_ended_seen_range": int((o_why == 1).sum().item()),
                "variants_per_s_end_to_end": round(ns / (t_br + t_prop + t_tr), 1)}
+    drv = driver_leg(ctx, ss, genome, dev, args) if args is not None else None
     ss.free()
     pfd_ref = 2 * G + 2 * 256 * (G // 4096 + 1)
     pfd_br = na * (A + WARM) * 4
@@ -187,7 +223,7 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev):
                                 "variants_per_s": round(sites / t_br, 1), "branch_sites": sites,
                                 "push_front_drop_per_s": round(pfd_br / t_br / 1e9, 3),
                                 "algorithmic_GBps": round(pfd_br * 52 / t_br / 1e9, 1)},
-            "push_to_pair_extension": ext}
+            "push_to_pair_extension": ext, "graph_discover_driver": drv}
 
 
 KERNEL_OF_FAMILY = {"radix_scatter_k": "rs_part_scatter_kernel",
@@ -318,7 +354,7 @@ def main():
 
     discover = None
     if world == 1 and not args.no_discover:
-        discover = discover_leg(ctx, seq, offs, n_reads, params, genome, dev)
+        discover = discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args)
     if rank == 0:
         # dominant kernel family by device time
         fam = max(timings, key=lambda t: t["ms"]) if timings else None
