@@ -290,13 +290,82 @@ __global__ void k_build_entries(const uint64_t* __restrict__ skeys, const uint8_
 // (zero padded) leading bases are >= p, dir[4^kPrefixBases] = n.  Narrows every lower_bound below to
 // the handful of entries sharing the query's prefix.
 constexpr int kPrefixBases = 12;
-__global__ void k_prefix_dir(const uint64_t* __restrict__ ekeys, uint64_t n, int W, uint32_t* __restrict__ dir) {
+// Directory over the leading kPrefixBases bases: dir[p] = first entry whose prefix is >= p, dir[4^B] = n.
+// Built without serial fills (a shard of a sharded build, or a small seqset, leaves most prefixes empty):
+// heads of non-empty prefixes, then a suffix-min over the table in 2048-prefix chunks.
+constexpr int kDirChunk = 2048;
+
+__global__ void k_dir_heads(const uint64_t* __restrict__ ekeys, uint64_t n, int W, uint32_t* __restrict__ dir) {
   uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i > n) return;
-  const uint32_t nb = 1u << (2 * kPrefixBases);
-  uint32_t cur = i < n ? uint32_t(ekeys[i * W] >> (64 - 2 * kPrefixBases)) : nb;
-  uint32_t prev = i ? uint32_t(ekeys[(i - 1) * W] >> (64 - 2 * kPrefixBases)) + 1 : 0u;
-  for (uint32_t p = prev; p <= cur; ++p) dir[p] = uint32_t(i);  // empty range when cur < prev
+  if (i >= n) return;
+  uint32_t cur = uint32_t(ekeys[i * W] >> (64 - 2 * kPrefixBases));
+  if (i == 0 || uint32_t(ekeys[(i - 1) * W] >> (64 - 2 * kPrefixBases)) != cur) dir[cur] = uint32_t(i);
+}
+
+__global__ __launch_bounds__(256) void k_dir_chunk_min(const uint32_t* __restrict__ dir, uint32_t* __restrict__ cmin) {
+  __shared__ uint32_t sm[4];
+  uint64_t base = uint64_t(blockIdx.x) * kDirChunk + threadIdx.x * 8;
+  uint32_t m = 0xffffffffu;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m = min(m, dir[base + j]);
+  for (int d = 32; d; d >>= 1) m = min(m, uint32_t(__shfl_xor(int(m), d, 64)));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) cmin[blockIdx.x] = min(min(sm[0], sm[1]), min(sm[2], sm[3]));
+}
+
+// carry[c] = first entry of the first non-empty prefix after chunk c (n if none); one thread, 8192 steps
+__global__ void k_dir_chunk_carry(const uint32_t* __restrict__ cmin, uint32_t nchunks, uint32_t n,
+                                  uint32_t* __restrict__ carry) {
+  uint32_t run = n;
+  for (int c = int(nchunks) - 1; c >= 0; --c) {
+    carry[c] = run;
+    run = min(run, cmin[c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dir_fill(uint32_t* __restrict__ dir, const uint32_t* __restrict__ carry) {
+  __shared__ uint32_t tmin[256];
+  uint64_t base = uint64_t(blockIdx.x) * kDirChunk + threadIdx.x * 8;
+  uint32_t v[8];
+  uint32_t m = 0xffffffffu;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { v[j] = dir[base + j]; m = min(m, v[j]); }
+  tmin[threadIdx.x] = m;
+  __syncthreads();
+  uint32_t run = carry[blockIdx.x];
+  for (int t = 255; t > int(threadIdx.x); --t) run = min(run, tmin[t]);  // values only grow with the prefix
+#pragma unroll
+  for (int j = 7; j >= 0; --j) {
+    run = min(run, v[j]);
+    dir[base + j] = run;
+  }
+}
+
+int build_prefix_dir_keys(bg_ctx* ctx, const uint64_t* keys, uint64_t n, int W, DevBuf<uint32_t>* dir) {
+  const uint64_t nb = 1ull << (2 * kPrefixBases);
+  static_assert((1ull << (2 * kPrefixBases)) % kDirChunk == 0, "directory chunks");
+  const uint32_t nchunks = uint32_t(nb / kDirChunk);
+  if (n >= 0xffffffffull) { set_error("shard of %llu entries exceeds the prefix directory", (unsigned long long)n); return BG_EINVAL; }
+  BG_TRY(dir->alloc(ctx, nb + 1));
+  DevBuf<uint32_t> cmin, carry;
+  BG_TRY(cmin.alloc(ctx, nchunks));
+  BG_TRY(carry.alloc(ctx, nchunks));
+  BG_HIP(hipMemsetAsync(dir->p, 0xff, nb * 4, ctx->stream));
+  const uint32_t n32 = uint32_t(n);
+  BG_HIP(hipMemcpyAsync(dir->p + nb, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
+  if (n) {
+    k_dir_heads<<<cdiv(n, 256), 256, 0, ctx->stream>>>(keys, n, W, dir->p);
+    BG_LAUNCH_CHECK();
+  }
+  k_dir_chunk_min<<<nchunks, 256, 0, ctx->stream>>>(dir->p, cmin.p);
+  BG_LAUNCH_CHECK();
+  k_dir_chunk_carry<<<1, 1, 0, ctx->stream>>>(cmin.p, nchunks, n32, carry.p);
+  BG_LAUNCH_CHECK();
+  k_dir_fill<<<nchunks, 256, 0, ctx->stream>>>(dir->p, carry.p);
+  BG_LAUNCH_CHECK();
+  BG_HIP(hipStreamSynchronize(ctx->stream));  // n32 is read by the async copy above
+  return BG_OK;
 }
 
 // lower_bound of (tail, tl) in the entries, searched inside its prefix bucket only
@@ -727,12 +796,7 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
 
 // leading-bases directory of a shard's entries (needs resident keys)
 int build_prefix_dir(bg_ctx* ctx, const bg_seqset* ss, DevBuf<uint32_t>* dir) {
-  const uint64_t nb = 1ull << (2 * kPrefixBases);
-  BG_TRY(dir->alloc(ctx, nb + 1));
-  if (ss->n >= (1ull << 32)) { set_error("shard of %llu entries exceeds the prefix directory", (unsigned long long)ss->n); return BG_EINVAL; }
-  k_prefix_dir<<<cdiv(ss->n + 1, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->n, ss->W, dir->p);
-  BG_LAUNCH_CHECK();
-  return BG_OK;
+  return build_prefix_dir_keys(ctx, ss->keys.p, ss->n, ss->W, dir);
 }
 
 static int pack_marks(bg_ctx* ctx, bg_seqset* ss, const uint8_t* marks) {

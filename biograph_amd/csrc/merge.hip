@@ -49,15 +49,6 @@ __global__ void k_merge_keys_fm(SeqsetView v, int W, uint64_t* __restrict__ dst,
   dlen[i] = uint8_t(L);
 }
 
-__global__ void k_merge_dir(const uint64_t* __restrict__ ekeys, uint64_t n, int W, uint32_t* __restrict__ dir) {
-  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i > n) return;
-  const uint32_t nb = 1u << (2 * kMergeDirBases);
-  uint32_t cur = i < n ? uint32_t(ekeys[i * W] >> (64 - 2 * kMergeDirBases)) : nb;
-  uint32_t prev = i ? uint32_t(ekeys[(i - 1) * W] >> (64 - 2 * kMergeDirBases)) + 1 : 0u;
-  for (uint32_t p = prev; p <= cur; ++p) dir[p] = uint32_t(i);
-}
-
 // merged index of every input entry = first merged entry having it as a prefix
 __global__ __launch_bounds__(128) void k_merge_map(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ klen,
                                                    uint64_t n, int W, const uint64_t* __restrict__ ekeys,
@@ -169,13 +160,10 @@ extern "C" int bg_seqset_merge(bg_ctx* ctx, uint32_t n_in, const bg_seqset* cons
   BG_TRY(seqset_finalize_device(ctx, ss.get()));
   if (d_maps && total) {
     DevBuf<uint32_t> dir, err;
-    const uint64_t nb = 1ull << (2 * kMergeDirBases);
-    BG_TRY(dir.alloc(ctx, nb + 1));
     BG_TRY(err.alloc(ctx, 1));
     BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
     ctx->tic("merge_maps");
-    k_merge_dir<<<cdiv(ss->n + 1, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->n, W, dir.p);
-    BG_LAUNCH_CHECK();
+    BG_TRY(build_prefix_dir_keys(ctx, ss->keys.p, ss->n, W, &dir));
     pos = 0;
     for (uint32_t i = 0; i < n_in; ++i) {
       uint64_t n = in[i]->n;

@@ -32,15 +32,6 @@ __device__ __forceinline__ int hi_type(uint64_t hi) { return int((hi >> 20) & 3)
 __device__ __forceinline__ uint32_t hi_len(uint64_t hi) { return uint32_t((hi >> 10) & 1023); }
 __device__ __forceinline__ uint32_t hi_mate_len(uint64_t hi) { return uint32_t(hi & 1023); }
 
-__global__ void k_rm_prefix_dir(const uint64_t* __restrict__ ekeys, uint64_t n, int W, uint32_t* __restrict__ dir) {
-  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i > n) return;
-  const uint32_t nb = 1u << (2 * kPrefixBasesRm);
-  uint32_t cur = i < n ? uint32_t(ekeys[i * W] >> (64 - 2 * kPrefixBasesRm)) : nb;
-  uint32_t prev = i ? uint32_t(ekeys[(i - 1) * W] >> (64 - 2 * kPrefixBasesRm)) + 1 : 0u;
-  for (uint32_t p = prev; p <= cur; ++p) dir[p] = uint32_t(i);
-}
-
 // entry id of oriented read o (2i = read i, 2i+1 = its reverse complement); ~0 for dropped reads
 __global__ __launch_bounds__(128) void k_rm_entry_ids(const uint64_t* __restrict__ words,
                                                      const uint16_t* __restrict__ len, uint64_t n_o, int W,
@@ -360,11 +351,8 @@ extern "C" int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads
   BG_TRY(eid.alloc(ctx, n_o));
   {
     DevBuf<uint32_t> dir;
-    const uint64_t nb = 1ull << (2 * kPrefixBasesRm);
-    BG_TRY(dir.alloc(ctx, nb + 1));
     ctx->tic("readmap_entry_ids");
-    k_rm_prefix_dir<<<cdiv(n_ent + 1, 256), 256, 0, ctx->stream>>>(ss->keys.p, n_ent, EW, dir.p);
-    BG_LAUNCH_CHECK();
+    BG_TRY(build_prefix_dir_keys(ctx, ss->keys.p, n_ent, EW, &dir));
     if (n_o) {
       k_rm_entry_ids<<<cdiv(n_o, 128), 128, 0, ctx->stream>>>(reads->words.p, reads->len.p, n_o, W, ss->keys.p,
                                                               ss->sizes.p, n_ent, EW, dir.p, eid.p, err.p);

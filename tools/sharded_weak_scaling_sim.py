@@ -1,0 +1,37 @@
+"""Weak-scaling estimate of the sharded build WITHOUT the links: P simulated ranks in one process on one GPU
+(LocalSimComm), each holding 1/P of the pairs of a P x G genome.  Per-rank time = total / P; the growth over
+P = 1 is the replicated work (hash-set build, cover index over all reads).  Usage: python
+tools/sharded_weak_scaling_sim.py [G_per_rank]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, ".")
+os.environ["BG_SHARD_TIMING"] = "1"
+import torch
+
+import biograph_amd as bg
+from biograph_amd import sharded, synth
+
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
+ctx = bg.Context(0)
+base = None
+for P in (1, 2, 4, 8):
+    inputs = {}
+    for r in range(P):
+        seq, offs, n = synth.make_reads(genome_len=G * P, coverage=30, read_len=150, seed=7, device="cuda", shard=(r, P))
+        inputs[r] = (seq, offs, n)
+    ctxs = {r: ctx for r in range(P)}
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        out = sharded.sharded_create(sharded.LocalSimComm(P), ctxs, inputs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        out[0][0].free()
+    per_rank = dt / P
+    base = base or per_rank
+    print("P=%d  total %.1f ms  per rank %.1f ms  efficiency (no links) %.2f" % (P, dt * 1e3, per_rank * 1e3, base / per_rank),
+          flush=True)
+    del inputs
+    ctx.trim()
