@@ -63,6 +63,9 @@ SYMBOLS = [
     "bg_readmap_free", "bg_create_sample", "bg_readmap_open", "bg_readmap_arrays", "bg_prefix_reads_batch",
     "bg_read_info_batch", "bg_propagate_from_end_batch", "bg_push_to_pair_trace_batch",
     "bg_seqset_merge", "bg_readmap_migrate",
+    "bg_asm_list_create", "bg_asm_list_free", "bg_asm_list_size", "bg_asm_list_add", "bg_asm_list_sort",
+    "bg_asm_list_get", "bg_asm_list_rc_path", "bg_make_ref_assemblies", "bg_graph_trim_ref", "bg_dedup_assemblies",
+    "bg_update_rc_seqset_entries", "bg_discover_branch", "bg_discover_push_to_pair",
     # sharded build
     "bg_partition_rows", "bg_kmer_instances", "bg_kmer_extract", "bg_kmer_extract_by_owner", "bg_kmer_count_keys", "bg_kmerset_export",
     "bg_kmerset_from_kmers", "bg_reads_words", "bg_reads_export", "bg_reads_import", "bg_suffix_records",
@@ -148,6 +151,22 @@ def lib():
     L.bg_push_to_pair_trace_batch.argtypes = [vp, vp, u64, vp, vp, vp, vp, u32, u32, u32, u32] + [vp] * 8
     L.bg_seqset_merge.argtypes = [vp, u32, P(vp), P(vp), P(vp)]
     L.bg_readmap_migrate.argtypes = [vp, vp, vp, vp, P(vp)]
+    i64 = C.c_int64
+    L.bg_asm_list_create.argtypes = [P(vp)]
+    L.bg_asm_list_free.argtypes = [vp]
+    L.bg_asm_list_free.restype = None
+    L.bg_asm_list_size.argtypes = [vp]
+    L.bg_asm_list_size.restype = u64
+    L.bg_asm_list_add.argtypes = [vp, i64, i64, C.c_char_p, u64, i32, C.c_char_p]
+    L.bg_asm_list_sort.argtypes = [vp]
+    L.bg_asm_list_get.argtypes = [vp, u64, P(i64), P(i64), P(C.c_char_p), P(u64), P(i32), P(C.c_char_p)]
+    L.bg_asm_list_rc_path.argtypes = [vp, u64, P(u64), P(u64), vp, vp, vp]
+    L.bg_make_ref_assemblies.argtypes = [vp, u64, P(i64), P(C.c_char_p), P(u64), i64, i64, i64]
+    L.bg_graph_trim_ref.argtypes = [vp, u64, P(i64), P(C.c_char_p), P(u64), i64]
+    L.bg_dedup_assemblies.argtypes = [vp]
+    L.bg_update_rc_seqset_entries.argtypes = [vp, vp, vp, vp, u32]
+    L.bg_discover_branch.argtypes = [vp, vp, vp, vp, u32, C.c_char_p, C.c_char_p]
+    L.bg_discover_push_to_pair.argtypes = [vp, vp, vp, vp, u32, i64, C.c_char_p, C.c_char_p]
     L.bg_create_sample.argtypes = [vp, vp, vp, u64, P(CreateParams), i32, P(vp), P(vp), P(BuildStats)]
     L.bg_partition_rows.argtypes = [vp, vp, u64, i32, i32, u32, vp, vp, vp]
     L.bg_kmer_instances.argtypes = [vp, vp, i32, P(u64)]

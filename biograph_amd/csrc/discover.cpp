@@ -1,0 +1,1045 @@
+// discover.cpp — host drivers of the graph-discover path in C++ over the batched
+// kernels of walk.hip: the reference-offset sweep of graph_discover (graph_discover/discover.cpp:84-197),
+// branch_discover (branch.cpp:20-80), push_to_pair_discover (push_to_pair.cpp:41-157,242-526),
+// update_rc_seqset_entries (update_rc_seqset_entries.cpp) on apply_edges_step (variants/apply_edges.cpp),
+// graph_trim_ref (graph_trim_ref.cpp), make_ref_assemblies (make_ref.cpp) and the canonical assembly
+// order (variants/assemble.cpp:1029-1085).
+//
+// A step takes a list of assemblies in canonical order and leaves one: the reference streams them with
+// flush points only to bound memory — the order handed to the next step is the same
+// (sorted_output_pipeline_step, assemble.cpp:297-345).  The walks do not depend on the sweep's state (the
+// mate / anchor checks only CUT an extension trace), so a step computes them for all its assemblies in
+// one kernel launch before the sweep consumes them.  biograph_amd/variants.py is the same logic in
+// Python (kept as the readable twin; tests require both to agree).
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <functional>
+#include <limits>
+#include <map>
+#include <set>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "bg_internal.h"
+
+namespace {
+
+using bg::DevBuf;
+using bg::set_error;
+
+constexpr int64_t kNone = std::numeric_limits<int64_t>::min();  // optional_aoffset::none
+constexpr int64_t kInf = std::numeric_limits<int64_t>::max();
+
+struct Range {
+  uint64_t b, e;
+  uint32_t s;
+  bool operator<(const Range& o) const {  // seqset_range::operator< (bio_base/seqset.h:211-218)
+    if (b != o.b) return b < o.b;
+    if (e != o.e) return e > o.e;
+    return s < o.s;
+  }
+  bool operator==(const Range& o) const { return b == o.b && e == o.e && s == o.s; }
+};
+using RangeSet = std::set<Range>;
+
+void dedup_prefixes(RangeSet& rs) {  // variants/assemble.cpp:1473-1498
+  std::vector<Range> v(rs.begin(), rs.end());
+  RangeSet out;
+  for (size_t i = 0; i < v.size(); ++i) {
+    bool contains_other = false;
+    for (size_t j = 0; j < v.size() && !contains_other; ++j)
+      if (j != i && v[j].b >= v[i].b && v[j].e <= v[i].e) contains_other = true;
+    if (!contains_other) out.insert(v[i]);
+  }
+  rs.swap(out);
+}
+
+struct Assembly {
+  int64_t left = kNone, right = kNone;
+  std::string seq;
+  bool matches_reference = false;
+  std::set<std::string> tags;
+  std::map<int64_t, RangeSet> rc_entries;  // seqset_path::m_entries
+  RangeSet rc_mates;                        // seqset_path::m_mates
+  uint64_t id = 0;
+
+  int64_t min_off() const { return left == kNone ? right : right == kNone ? left : std::min(left, right); }
+  int64_t max_off() const { return left == kNone ? right : right == kNone ? left : std::max(left, right); }
+  const RangeSet& rc_starts() const { static const RangeSet e; return rc_entries.empty() ? e : rc_entries.begin()->second; }
+  const RangeSet& rc_ends() const { static const RangeSet e; return rc_entries.empty() ? e : rc_entries.rbegin()->second; }
+};
+
+bool canon_less(const Assembly& a, const Assembly& b) {  // canon_assembly_order, GRAPH_DISCOVER (assemble.cpp:1029-1085)
+  if (a.min_off() != b.min_off()) return a.min_off() < b.min_off();
+  if (a.matches_reference != b.matches_reference) return a.matches_reference < b.matches_reference;
+  if ((a.left != kNone) != (b.left != kNone)) return a.left != kNone;
+  if ((a.right != kNone) != (b.right != kNone)) return a.right != kNone;
+  if (a.max_off() != b.max_off()) return a.max_off() > b.max_off();
+  if (a.seq != b.seq) return a.seq < b.seq;
+  return a.tags < b.tags;
+}
+
+void canon_sort(std::vector<Assembly>& v) { std::stable_sort(v.begin(), v.end(), canon_less); }
+
+int code_of(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3; }
+std::string rev_comp(const std::string& s) {
+  std::string o(s.rbegin(), s.rend());
+  for (char& c : o) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
+  return o;
+}
+
+}  // namespace
+
+struct bg_asm_list {
+  std::vector<Assembly> a;
+  uint64_t next_id = 1;
+  std::string scratch_tags;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Batched walks: thin host wrappers (upload, launch, download) over the C ABI of walk.hip.
+struct Walker {
+  bg_ctx* ctx;
+  const bg_seqset* ss;
+  const bg_readmap* rm;
+  uint64_t n;
+  std::vector<uint8_t> shared;  // host copy for truncate / shared_prefix_length
+
+  int init() {
+    n = bg_seqset_size(ss);
+    shared.resize(n);
+    if (n) {
+      if (hipMemcpy(shared.data(), ss->shared.p, n, hipMemcpyDeviceToHost) != hipSuccess) { set_error("discover: download failed"); return BG_EINTERNAL; }
+    }
+    return BG_OK;
+  }
+  Range ctx_begin() const { return Range{0, n, 0}; }
+  Range truncate(Range r, uint32_t count) const {  // seqset.cpp:630-661
+    if (r.s <= count) return r;
+    uint64_t b = r.b, e = r.e;
+    while (b && shared[b] >= count) --b;
+    while (e < n && shared[e] >= count) ++e;
+    return Range{b, e, count};
+  }
+  uint32_t shared_prefix_length(Range a, Range b) const {  // seqset.cpp:723-748
+    uint32_t s = std::min(a.s, b.s);
+    if (a.e > b.b && b.e > a.b) return s;
+    uint64_t lo, hi;
+    if (a.e > b.b) { lo = b.e; hi = a.b; } else { lo = a.e; hi = b.b; }
+    for (uint64_t i = lo; i <= hi && i < n; ++i) s = std::min<uint32_t>(s, shared[i]);
+    return s;
+  }
+
+  template <class T>
+  int up(DevBuf<T>& d, const std::vector<T>& h) {
+    BG_TRY(d.alloc(ctx, h.size()));
+    if (!h.empty()) BG_HIP(hipMemcpy(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return BG_OK;
+  }
+  template <class T>
+  int down(std::vector<T>& h, const DevBuf<T>& d, size_t count) {
+    h.resize(count);
+    if (count) BG_HIP(hipMemcpy(h.data(), d.p, count * sizeof(T), hipMemcpyDeviceToHost));
+    return BG_OK;
+  }
+  static void flatten(const std::vector<std::vector<Range>>& fr, std::vector<uint32_t>* foff, std::vector<uint64_t>* b,
+                      std::vector<uint64_t>* e, std::vector<uint32_t>* s) {
+    foff->assign(1, 0);
+    for (auto& f : fr) {
+      for (auto& r : f) { b->push_back(r.b); e->push_back(r.e); s->push_back(r.s); }
+      foff->push_back(uint32_t(b->size()));
+    }
+  }
+  static void seq_arrays(const std::vector<std::string>& seqs, std::vector<uint64_t>* soff, std::vector<uint8_t>* codes) {
+    soff->assign(1, 0);
+    for (auto& q : seqs) {
+      for (char c : q) codes->push_back(uint8_t(code_of(c)));
+      soff->push_back(codes->size());
+    }
+  }
+
+  struct PropOut { std::map<int64_t, RangeSet> ent; std::vector<Range> mates; };
+  int propagate(const std::vector<std::string>& seqs_rc, const std::vector<std::vector<Range>>& ends,
+                const std::vector<std::vector<uint32_t>>& marks, bool with_mates, uint32_t max_pairs,
+                std::vector<PropOut>* out) {
+    const uint64_t na = seqs_rc.size();
+    out->assign(na, PropOut());
+    if (!na) return BG_OK;
+    std::vector<uint64_t> soff, fb, fe;
+    std::vector<uint8_t> codes;
+    std::vector<uint32_t> foff, fs, moff{0}, mflat;
+    seq_arrays(seqs_rc, &soff, &codes);
+    flatten(ends, &foff, &fb, &fe, &fs);
+    for (auto& m : marks) { for (uint32_t x : m) mflat.push_back(x); moff.push_back(uint32_t(mflat.size())); }
+    const uint64_t nmk = mflat.size();
+    uint32_t mate_cap = with_mates ? 4096 : 1;
+    for (;;) {
+      DevBuf<uint64_t> d_soff, d_fb, d_fe, d_mb, d_me, d_ob, d_oe, d_tb, d_te;
+      DevBuf<uint8_t> d_codes, d_mn, d_no;
+      DevBuf<uint32_t> d_foff, d_fs, d_moff, d_marks, d_ms, d_os, d_nm, d_ts;
+      BG_TRY(up(d_soff, soff)); BG_TRY(up(d_codes, codes)); BG_TRY(up(d_foff, foff));
+      BG_TRY(up(d_fb, fb)); BG_TRY(up(d_fe, fe)); BG_TRY(up(d_fs, fs));
+      BG_TRY(up(d_moff, moff)); BG_TRY(up(d_marks, mflat));
+      BG_TRY(d_mn.alloc(ctx, nmk)); BG_TRY(d_mb.alloc(ctx, nmk * 16)); BG_TRY(d_me.alloc(ctx, nmk * 16)); BG_TRY(d_ms.alloc(ctx, nmk * 16));
+      BG_TRY(d_no.alloc(ctx, na)); BG_TRY(d_ob.alloc(ctx, na * 16)); BG_TRY(d_oe.alloc(ctx, na * 16)); BG_TRY(d_os.alloc(ctx, na * 16));
+      BG_TRY(d_nm.alloc(ctx, na)); BG_TRY(d_tb.alloc(ctx, na * mate_cap)); BG_TRY(d_te.alloc(ctx, na * mate_cap)); BG_TRY(d_ts.alloc(ctx, na * mate_cap));
+      BG_TRY(bg_propagate_from_end_batch(ctx, ss, with_mates ? rm : nullptr, na, d_soff.p, d_codes.p, d_foff.p, d_fb.p, d_fe.p,
+                                         d_fs.p, max_pairs, d_moff.p, d_marks.p, d_mn.p, d_mb.p, d_me.p, d_ms.p, d_no.p,
+                                         d_ob.p, d_oe.p, d_os.p, mate_cap, d_nm.p, d_tb.p, d_te.p, d_ts.p));
+      std::vector<uint32_t> nm;
+      BG_TRY(down(nm, d_nm, na));
+      uint32_t worst = 0;
+      for (uint32_t x : nm) worst = std::max(worst, x);
+      if (with_mates && worst > mate_cap) { mate_cap = worst; continue; }  // rerun with room for every mate
+      std::vector<uint8_t> mn, no;
+      std::vector<uint64_t> mb, me, ob, oe, tb, te;
+      std::vector<uint32_t> ms, os, ts;
+      BG_TRY(down(mn, d_mn, nmk)); BG_TRY(down(mb, d_mb, nmk * 16)); BG_TRY(down(me, d_me, nmk * 16)); BG_TRY(down(ms, d_ms, nmk * 16));
+      BG_TRY(down(no, d_no, na)); BG_TRY(down(ob, d_ob, na * 16)); BG_TRY(down(oe, d_oe, na * 16)); BG_TRY(down(os, d_os, na * 16));
+      if (with_mates) { BG_TRY(down(tb, d_tb, na * mate_cap)); BG_TRY(down(te, d_te, na * mate_cap)); BG_TRY(down(ts, d_ts, na * mate_cap)); }
+      for (uint64_t a = 0; a < na; ++a) {
+        PropOut& po = (*out)[a];
+        RangeSet& st = po.ent[0];
+        for (int i = 0; i < no[a]; ++i) st.insert(Range{ob[a * 16 + i], oe[a * 16 + i], os[a * 16 + i]});
+        for (uint32_t k = moff[a]; k < moff[a + 1]; ++k) {
+          RangeSet& ms_ = po.ent[int64_t(mflat[k])];
+          for (int i = 0; i < mn[k]; ++i) ms_.insert(Range{mb[uint64_t(k) * 16 + i], me[uint64_t(k) * 16 + i], ms[uint64_t(k) * 16 + i]});
+        }
+        if (with_mates)
+          for (uint32_t i = 0; i < nm[a]; ++i)
+            po.mates.push_back(Range{tb[a * mate_cap + i], te[a * mate_cap + i], ts[a * mate_cap + i]});
+      }
+      return BG_OK;
+    }
+  }
+
+  struct BranchOut { std::vector<std::pair<uint32_t, uint8_t>> ev; RangeSet final_; };
+  int branch_trace(const std::vector<std::string>& seqs, const std::vector<std::vector<Range>>& fronts,
+                   uint32_t min_overlap, std::vector<BranchOut>* out) {
+    const uint64_t na = seqs.size();
+    out->assign(na, BranchOut());
+    if (!na) return BG_OK;
+    std::vector<uint64_t> soff, fb, fe;
+    std::vector<uint8_t> codes;
+    std::vector<uint32_t> foff, fs;
+    seq_arrays(seqs, &soff, &codes);
+    flatten(fronts, &foff, &fb, &fe, &fs);
+    uint32_t cap = 1;
+    for (auto& q : seqs) cap = std::max<uint32_t>(cap, uint32_t(q.size()));
+    DevBuf<uint64_t> d_soff, d_fb, d_fe, d_ob, d_oe;
+    DevBuf<uint8_t> d_codes, d_evb, d_no;
+    DevBuf<uint32_t> d_foff, d_fs, d_evo, d_nev, d_os;
+    BG_TRY(up(d_soff, soff)); BG_TRY(up(d_codes, codes)); BG_TRY(up(d_foff, foff));
+    BG_TRY(up(d_fb, fb)); BG_TRY(up(d_fe, fe)); BG_TRY(up(d_fs, fs));
+    BG_TRY(d_evo.alloc(ctx, na * cap)); BG_TRY(d_evb.alloc(ctx, na * cap)); BG_TRY(d_nev.alloc(ctx, na)); BG_TRY(d_no.alloc(ctx, na));
+    BG_TRY(d_ob.alloc(ctx, na * 16)); BG_TRY(d_oe.alloc(ctx, na * 16)); BG_TRY(d_os.alloc(ctx, na * 16));
+    BG_TRY(bg_branch_trace_batch(ctx, ss, na, d_soff.p, d_codes.p, d_foff.p, d_fb.p, d_fe.p, d_fs.p, min_overlap, cap, d_evo.p,
+                                 d_evb.p, d_nev.p, d_no.p, d_ob.p, d_oe.p, d_os.p));
+    std::vector<uint32_t> evo, nev, os;
+    std::vector<uint8_t> evb, no;
+    std::vector<uint64_t> ob, oe;
+    BG_TRY(down(evo, d_evo, na * cap)); BG_TRY(down(evb, d_evb, na * cap)); BG_TRY(down(nev, d_nev, na)); BG_TRY(down(no, d_no, na));
+    BG_TRY(down(ob, d_ob, na * 16)); BG_TRY(down(oe, d_oe, na * 16)); BG_TRY(down(os, d_os, na * 16));
+    for (uint64_t a = 0; a < na; ++a) {
+      for (uint32_t i = 0; i < std::min(nev[a], cap); ++i) (*out)[a].ev.emplace_back(evo[a * cap + i], evb[a * cap + i]);
+      for (int i = 0; i < no[a]; ++i) (*out)[a].final_.insert(Range{ob[a * 16 + i], oe[a * 16 + i], os[a * 16 + i]});
+    }
+    return BG_OK;
+  }
+
+  struct TraceOut { int reason = 0; std::string bases; std::vector<std::vector<Range>> fronts; };
+  int push_trace(const std::vector<std::vector<Range>>& fronts, uint32_t min_overlap, uint32_t max_steps,
+                 std::vector<TraceOut>* out) {
+    const uint64_t na = fronts.size();
+    out->assign(na, TraceOut());
+    if (!na) return BG_OK;
+    std::vector<uint64_t> fb, fe;
+    std::vector<uint32_t> foff, fs;
+    flatten(fronts, &foff, &fb, &fe, &fs);
+    const uint32_t range_cap = 4 * max_steps, seen_cap = 256;
+    DevBuf<uint64_t> d_fb, d_fe, d_rb, d_re;
+    DevBuf<uint32_t> d_foff, d_fs, d_ns, d_nr, d_rs;
+    DevBuf<uint8_t> d_why, d_bases, d_cnt;
+    BG_TRY(up(d_foff, foff)); BG_TRY(up(d_fb, fb)); BG_TRY(up(d_fe, fe)); BG_TRY(up(d_fs, fs));
+    BG_TRY(d_ns.alloc(ctx, na)); BG_TRY(d_why.alloc(ctx, na)); BG_TRY(d_bases.alloc(ctx, na * max_steps)); BG_TRY(d_cnt.alloc(ctx, na * max_steps));
+    BG_TRY(d_nr.alloc(ctx, na)); BG_TRY(d_rb.alloc(ctx, na * range_cap)); BG_TRY(d_re.alloc(ctx, na * range_cap)); BG_TRY(d_rs.alloc(ctx, na * range_cap));
+    BG_TRY(bg_push_to_pair_trace_batch(ctx, ss, na, d_foff.p, d_fb.p, d_fe.p, d_fs.p, min_overlap, max_steps, range_cap, seen_cap,
+                                       d_ns.p, d_why.p, d_bases.p, d_cnt.p, d_nr.p, d_rb.p, d_re.p, d_rs.p));
+    std::vector<uint32_t> ns, rs;
+    std::vector<uint8_t> why, bases, cnt;
+    std::vector<uint64_t> rb, re;
+    BG_TRY(down(ns, d_ns, na)); BG_TRY(down(why, d_why, na)); BG_TRY(down(bases, d_bases, na * max_steps)); BG_TRY(down(cnt, d_cnt, na * max_steps));
+    BG_TRY(down(rb, d_rb, na * range_cap)); BG_TRY(down(re, d_re, na * range_cap)); BG_TRY(down(rs, d_rs, na * range_cap));
+    for (uint64_t a = 0; a < na; ++a) {
+      TraceOut& t = (*out)[a];
+      t.reason = why[a];
+      uint64_t pos = a * range_cap;
+      for (uint32_t st = 0; st < ns[a]; ++st) {
+        t.bases.push_back("ACGT"[bases[a * max_steps + st] & 3]);
+        std::vector<Range> f;
+        for (int i = 0; i < cnt[a * max_steps + st]; ++i, ++pos) f.push_back(Range{rb[pos], re[pos], rs[pos]});
+        t.fronts.push_back(std::move(f));
+      }
+    }
+    return BG_OK;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// apply_edges_step (variants/apply_edges.cpp:17-125) over a canonical list.  on_edges(pos or kNone, left
+// edges, inserts, right edges) receives indices into `asms`.
+using EdgeFn = std::function<int(int64_t, const std::vector<size_t>&, const std::vector<size_t>&, const std::vector<size_t>&)>;
+
+int apply_edges(std::vector<Assembly>& asms, const EdgeFn& on_edges) {
+  std::vector<size_t> order;  // output order before the final canonical sort
+  int64_t cur = kNone;
+  bool started = false;
+  std::multimap<int64_t, size_t> active;
+  std::vector<size_t> cur_inserts, cur_non_inserts, cur_left_unanchored;
+  auto flush_active_to_here = [&]() -> int {
+    std::vector<size_t> cur_left;
+    if (!cur_left_unanchored.empty()) {
+      BG_TRY(on_edges(kNone, {}, {}, cur_left_unanchored));
+      cur_left = cur_left_unanchored;
+      cur_left_unanchored.clear();
+    }
+    while (started && !active.empty() && active.begin()->first == cur) {
+      cur_left.push_back(active.begin()->second);
+      active.erase(active.begin());
+    }
+    if (!cur_left.empty() || !cur_inserts.empty() || !cur_non_inserts.empty())
+      BG_TRY(on_edges(started ? cur : kNone, cur_left, cur_inserts, cur_non_inserts));
+    order.insert(order.end(), cur_left.begin(), cur_left.end());
+    order.insert(order.end(), cur_inserts.begin(), cur_inserts.end());
+    cur_inserts.clear();
+    std::vector<size_t> right_unanchored;
+    for (size_t i : cur_non_inserts) {
+      if (asms[i].right != kNone) active.emplace(asms[i].right, i);
+      else right_unanchored.push_back(i);
+    }
+    cur_non_inserts.clear();
+    if (!right_unanchored.empty()) {
+      BG_TRY(on_edges(kNone, right_unanchored, {}, {}));
+      order.insert(order.end(), right_unanchored.begin(), right_unanchored.end());
+    }
+    return BG_OK;
+  };
+  auto advance_to = [&](int64_t offset) -> int {
+    while (!started || cur < offset) {
+      BG_TRY(flush_active_to_here());
+      int64_t target = offset;
+      if (!active.empty() && target > active.begin()->first) target = active.begin()->first;
+      cur = target;
+      started = true;
+    }
+    return BG_OK;
+  };
+  for (size_t i = 0; i < asms.size(); ++i) {
+    BG_TRY(advance_to(asms[i].min_off()));
+    if (asms[i].left == asms[i].right) cur_inserts.push_back(i);
+    else if (asms[i].left != kNone) cur_non_inserts.push_back(i);
+    else cur_left_unanchored.push_back(i);
+  }
+  BG_TRY(advance_to(kInf));
+  std::vector<Assembly> out;
+  out.reserve(asms.size());
+  for (size_t i : order) out.push_back(std::move(asms[i]));
+  canon_sort(out);
+  asms.swap(out);
+  return BG_OK;
+}
+
+int update_rc(Walker& w, std::vector<Assembly>& asms, bool with_mates, uint32_t max_pairs) {
+  auto propagate = [&](const RangeSet& incoming, const std::vector<size_t>& targets) -> int {
+    RangeSet inc_d = incoming;
+    dedup_prefixes(inc_d);
+    std::vector<size_t> todo;
+    for (size_t t : targets) {
+      Assembly& a = asms[t];
+      if (!a.rc_entries.empty() && inc_d == a.rc_ends() && int64_t(a.seq.size()) == a.rc_entries.rbegin()->first) continue;
+      todo.push_back(t);
+    }
+    if (todo.empty()) return BG_OK;
+    std::vector<std::string> seqs;
+    std::vector<std::vector<Range>> ends;
+    std::vector<std::vector<uint32_t>> marks;
+    for (size_t t : todo) {
+      seqs.push_back(rev_comp(asms[t].seq));
+      ends.emplace_back(incoming.begin(), incoming.end());
+      std::vector<uint32_t> m;
+      for (auto& kv : asms[t].rc_entries)
+        if (kv.first > 0 && kv.first < int64_t(asms[t].seq.size())) m.push_back(uint32_t(kv.first));
+      marks.push_back(m);
+    }
+    std::vector<Walker::PropOut> res;
+    BG_TRY(w.propagate(seqs, ends, marks, with_mates, max_pairs, &res));
+    for (size_t k = 0; k < todo.size(); ++k) {
+      Assembly& a = asms[todo[k]];
+      std::map<int64_t, RangeSet> ne;
+      ne[int64_t(a.seq.size())] = inc_d;
+      for (auto& kv : res[k].ent) ne[kv.first] = kv.second;
+      if (a.seq.empty()) ne[0] = inc_d;
+      a.rc_entries.swap(ne);
+      a.rc_mates.insert(res[k].mates.begin(), res[k].mates.end());
+    }
+    return BG_OK;
+  };
+  return apply_edges(asms, [&](int64_t, const std::vector<size_t>& left, const std::vector<size_t>& inserts,
+                               const std::vector<size_t>& right) -> int {
+    RangeSet incoming;
+    for (size_t i : left) {
+      if (asms[i].rc_entries.empty()) { set_error("update_rc_seqset_entries: an assembly has no rc path yet"); return BG_EINTERNAL; }
+      incoming.insert(asms[i].rc_starts().begin(), asms[i].rc_starts().end());
+    }
+    if (incoming.empty()) incoming.insert(w.ctx_begin());
+    if (!inserts.empty()) {
+      BG_TRY(propagate(incoming, inserts));
+      for (size_t i : inserts) incoming.insert(asms[i].rc_starts().begin(), asms[i].rc_starts().end());
+    }
+    return propagate(incoming, right);
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// graph_discover sweep (discover.cpp:84-150)
+struct Act;
+struct PotentialAnchor { Act* act = nullptr; int64_t offset = 0; };
+struct AnchorInfo { Range truncated, orig; PotentialAnchor anchor; };
+struct Act {
+  Assembly* a = nullptr;
+  RangeSet mates;
+  std::vector<AnchorInfo> rc_anchors;
+};
+
+struct Options {
+  uint32_t min_overlap = 70;
+  int64_t max_pair_distance = 1000;
+  int64_t read_ahead_distance = 100000;
+  std::string tag;
+  std::set<std::string> discover_tags;
+};
+
+class GraphDiscover {
+ public:
+  GraphDiscover(Walker& w, const Options& o) : w_(w), o_(o) {}
+  virtual ~GraphDiscover() = default;
+
+  int run(std::vector<Assembly>& asms, uint64_t* next_id) {
+    next_id_ = next_id;
+    BG_TRY(precompute(asms));
+    std::vector<Act> acts(asms.size());
+    for (size_t i = 0; i < asms.size(); ++i) {
+      BG_TRY(advance_trace_to(asms[i].min_off() - o_.read_ahead_distance));
+      Act* act = &acts[i];
+      act->a = &asms[i];
+      on_walk(act);
+      on_readahead(act);
+      readahead_done_.emplace(asms[i].min_off(), act);
+    }
+    BG_TRY(advance_trace_to(kInf));
+    std::vector<Assembly> out;
+    out.reserve(out_order_.size() + found_.size());
+    // pass-through assemblies in trace order interleaved with the discovered ones in emission order: the
+    // canonical sort below is stable, so only the relative emission order of equal keys matters
+    for (auto& e : emitted_) out.push_back(e.second ? std::move(found_[e.first]) : std::move(asms[e.first]));
+    canon_sort(out);
+    asms.swap(out);
+    return BG_OK;
+  }
+
+ protected:
+  virtual int precompute(std::vector<Assembly>&) { return BG_OK; }
+  virtual void on_walk(Act*) {}
+  virtual void on_readahead(Act*) {}
+  virtual int on_readahead_done(Act*) { return BG_OK; }
+  virtual void on_advance_trace(int64_t) {}
+  virtual int on_trace(Act*) = 0;
+
+  bool wants_trace(const Assembly& a) const {
+    if (o_.discover_tags.empty()) return true;
+    for (auto& t : a.tags) if (o_.discover_tags.count(t)) return true;
+    return false;
+  }
+  void emit(Assembly&& a) {
+    a.id = (*next_id_)++;
+    found_.push_back(std::move(a));
+    emitted_.emplace_back(found_.size() - 1, true);
+  }
+  Assembly extend_right(const Act* act, int64_t offset, const std::string& seq) const {  // discover.cpp:157-175
+    Assembly a;
+    a.left = act->a->left;
+    a.right = kNone;
+    a.seq = act->a->seq.substr(0, size_t(offset)) + seq;
+    a.tags.insert(o_.tag);
+    return a;
+  }
+  Assembly anchor(const Act* act, int64_t offset, const std::string& seq, const PotentialAnchor& anc) const {  // :177-197
+    Assembly a;
+    a.left = act->a->left;
+    a.right = anc.act->a->right;
+    a.seq = act->a->seq.substr(0, size_t(offset)) + seq + anc.act->a->seq.substr(size_t(anc.offset));
+    a.tags.insert(o_.tag);
+    return a;
+  }
+
+  Walker& w_;
+  Options o_;
+
+ private:
+  int advance_trace_to(int64_t pos) {
+    while (!trace_started_ || trace_offset_ < pos) BG_TRY(advance_trace_towards(pos));
+    return BG_OK;
+  }
+  int advance_trace_towards(int64_t pos) {
+    if (!trace_pending_.empty() && trace_pending_.begin()->first < pos) pos = trace_pending_.begin()->first;
+    while (!readahead_done_.empty() && readahead_done_.begin()->first < pos) {
+      Act* act = readahead_done_.begin()->second;
+      readahead_done_.erase(readahead_done_.begin());
+      BG_TRY(on_readahead_done(act));
+      int64_t mx = act->a->max_off();
+      trace_pending_.emplace(mx, act);
+      if (mx < pos) pos = mx;
+    }
+    trace_offset_ = pos;
+    trace_started_ = true;
+    on_advance_trace(pos);
+    while (!trace_pending_.empty() && trace_pending_.begin()->first == pos) {
+      Act* act = trace_pending_.begin()->second;
+      trace_pending_.erase(trace_pending_.begin());
+      if (wants_trace(*act->a)) BG_TRY(on_trace(act));
+      emitted_.emplace_back(size_t(act->a - base_), false);
+    }
+    return BG_OK;
+  }
+
+ public:
+  void set_base(Assembly* b) { base_ = b; }
+
+ private:
+  Assembly* base_ = nullptr;
+  std::multimap<int64_t, Act*> readahead_done_, trace_pending_;
+  int64_t trace_offset_ = 0;
+  bool trace_started_ = false;
+  std::vector<Assembly> found_;
+  std::vector<std::pair<size_t, bool>> emitted_;  // (index, is_found)
+  std::vector<size_t> out_order_;
+  uint64_t* next_id_ = nullptr;
+};
+
+class BranchDiscover : public GraphDiscover {  // branch.cpp:20-80
+ public:
+  using GraphDiscover::GraphDiscover;
+
+ protected:
+  int precompute(std::vector<Assembly>& asms) override {
+    std::vector<size_t> todo;
+    std::vector<std::string> seqs;
+    std::vector<std::vector<Range>> fronts;
+    for (size_t i = 0; i < asms.size(); ++i) {
+      if (!wants_trace(asms[i]) || asms[i].left == kNone || asms[i].seq.empty()) continue;
+      todo.push_back(i);
+      seqs.push_back(asms[i].seq);
+      fronts.emplace_back(asms[i].rc_ends().begin(), asms[i].rc_ends().end());
+    }
+    std::vector<Walker::BranchOut> res;
+    BG_TRY(w_.branch_trace(seqs, fronts, o_.min_overlap, &res));
+    for (size_t k = 0; k < todo.size(); ++k) {
+      if (!(res[k].final_ == asms[todo[k]].rc_starts())) {  // CHECK at :77-78
+        set_error("discover_branch: the walk of an assembly does not end on its rc start ranges");
+        return BG_EINTERNAL;
+      }
+      events_[&asms[todo[k]]] = std::move(res[k].ev);
+    }
+    return BG_OK;
+  }
+  int on_trace(Act* act) override {
+    if (act->a->left == kNone) return BG_OK;
+    auto it = events_.find(act->a);
+    if (it == events_.end()) return BG_OK;
+    for (auto& ev : it->second) emit(extend_right(act, ev.first, std::string(1, "ACGT"[ev.second & 3])));
+    return BG_OK;
+  }
+
+ private:
+  std::map<const Assembly*, std::vector<std::pair<uint32_t, uint8_t>>> events_;
+};
+
+class PushToPair : public GraphDiscover {  // push_to_pair.cpp
+ public:
+  using GraphDiscover::GraphDiscover;
+  static constexpr uint32_t kMaxSteps = 512;
+
+ protected:
+  int precompute(std::vector<Assembly>& asms) override {
+    std::vector<size_t> todo;
+    std::vector<std::vector<Range>> fronts;
+    for (size_t i = 0; i < asms.size(); ++i) {
+      if (!wants_trace(asms[i]) || asms[i].right != kNone) continue;
+      todo.push_back(i);
+      fronts.emplace_back(asms[i].rc_starts().begin(), asms[i].rc_starts().end());
+    }
+    std::vector<Walker::TraceOut> res;
+    BG_TRY(w_.push_trace(fronts, o_.min_overlap, kMaxSteps, &res));
+    for (size_t k = 0; k < todo.size(); ++k) traces_[&asms[todo[k]]] = std::move(res[k]);
+    return BG_OK;
+  }
+  void on_walk(Act* act) override {  // :41-73
+    const Assembly& a = *act->a;
+    act->mates = a.rc_mates;
+    const int64_t n = int64_t(a.seq.size());
+    if (a.right == kNone) return;
+    for (auto& kv : a.rc_entries) {
+      if (kv.first == n) continue;
+      for (const Range& r : kv.second) {
+        if (r.s < o_.min_overlap) continue;
+        AnchorInfo info;
+        info.truncated = w_.truncate(r, o_.min_overlap);
+        info.orig = r;
+        info.anchor.act = act;
+        info.anchor.offset = n - kv.first;
+        act->rc_anchors.push_back(info);
+      }
+    }
+  }
+  void on_advance_trace(int64_t offset) override {  // :75-103
+    while (!mate_expiry_.empty() && mate_expiry_.begin()->first < offset) {
+      for (const Range& m : mate_expiry_.begin()->second) {
+        auto it = mates_.find(m);
+        if (it != mates_.end() && --it->second == 0) mates_.erase(it);
+      }
+      mate_expiry_.erase(mate_expiry_.begin());
+    }
+  }
+  void on_readahead(Act* act) override {  // :105-131
+    RangeSet& expiry = mate_expiry_[act->a->max_off() + o_.max_pair_distance];
+    for (const AnchorInfo& info : act->rc_anchors) rc_entry_anchors_[info.truncated].emplace(info.orig, info.anchor);
+    for (const Range& m : act->mates)
+      if (expiry.insert(m).second) ++mates_[m];
+  }
+  int on_readahead_done(Act* act) override {  // :133-157
+    if (act->a->right == kNone) return BG_OK;
+    for (const AnchorInfo& info : act->rc_anchors) {
+      auto ii = rc_entry_anchors_.find(info.truncated);
+      if (ii == rc_entry_anchors_.end()) { set_error("push_to_pair: entry anchor map lost a key"); return BG_EINTERNAL; }
+      auto range = ii->second.equal_range(info.orig);
+      bool erased = false;
+      for (auto it = range.first; it != range.second; ++it) {
+        if (it->second.act == info.anchor.act && it->second.offset == info.anchor.offset) {
+          ii->second.erase(it);
+          erased = true;
+          break;
+        }
+      }
+      if (!erased) { set_error("push_to_pair: Could not find entry anchor to delete"); return BG_EINTERNAL; }
+      if (ii->second.empty()) rc_entry_anchors_.erase(ii);
+    }
+    return BG_OK;
+  }
+
+  struct EntryAnchor : PotentialAnchor { Range r; int64_t shared_bases = 0; };
+  using RcStarts = std::multimap<Range, PotentialAnchor>;
+
+  std::vector<EntryAnchor> get_entry_anchors(const std::vector<Range>& rs, int64_t approx_ref_offset) const {  // :393-457
+    std::vector<EntryAnchor> anchors;
+    int64_t best = kInf;
+    auto add = [&](const Range& orig_r, const Range& r, const PotentialAnchor& anc) {
+      const Assembly& other = *anc.act->a;
+      int64_t anchor_offset = other.right - int64_t(other.seq.size()) + anc.offset;
+      int64_t svlen = std::llabs(anchor_offset - approx_ref_offset);
+      if (svlen > best) return;
+      best = svlen;
+      EntryAnchor ea;
+      ea.act = anc.act;
+      ea.offset = anc.offset;
+      ea.r = r;
+      ea.shared_bases = w_.shared_prefix_length(r, orig_r);
+      anchors.push_back(ea);
+    };
+    struct Search { const RcStarts* m; RcStarts::const_iterator rev, fwd; Range r; };
+    std::vector<Search> searches;
+    for (const Range& r : rs) {
+      if (r.s < o_.min_overlap) continue;
+      auto it = rc_entry_anchors_.upper_bound(r);
+      if (it == rc_entry_anchors_.begin()) continue;
+      --it;
+      if (it->first.e <= r.b) continue;
+      Search s{&it->second, it->second.upper_bound(r), it->second.upper_bound(r), r};
+      searches.push_back(s);
+    }
+    while (!searches.empty()) {
+      std::vector<Search> nxt;
+      for (Search& s : searches) {
+        bool more = false;
+        if (s.rev != s.m->begin()) { --s.rev; add(s.r, s.rev->first, s.rev->second); more = true; }
+        if (s.fwd != s.m->end()) { add(s.r, s.fwd->first, s.fwd->second); ++s.fwd; more = true; }
+        if (more) nxt.push_back(s);
+      }
+      searches.swap(nxt);
+    }
+    return anchors;
+  }
+  static std::map<int64_t, RangeSet> path_entries_to_rc_path(const std::map<int64_t, std::vector<Range>>& pe, int64_t end_pos) {  // :459-470
+    std::map<int64_t, RangeSet> rc;
+    for (auto& kv : pe) {
+      RangeSet& e = rc[end_pos - kv.first];
+      e.insert(kv.second.begin(), kv.second.end());
+      dedup_prefixes(e);
+    }
+    return rc;
+  }
+  struct Best { int64_t abs_svlen = kInf, shared_bases = 0; bool has_svlen = false, has_shared = false; Assembly svlen_a, shared_a; };
+
+  int64_t save_anchors(Act* act, const std::vector<Range>& rs, const std::string& seq,
+                       const std::map<int64_t, std::vector<Range>>& path_entries, Best& best) {  // :472-526
+    const Assembly& a = *act->a;
+    const int64_t ref_offset = a.left + int64_t(a.seq.size()) + int64_t(seq.size());
+    std::vector<EntryAnchor> anchors = get_entry_anchors(rs, ref_offset);
+    if (anchors.empty()) return 0;
+    auto abs_svlen = [&](const EntryAnchor& x) {
+      const Assembly& other = *x.act->a;
+      return std::llabs(other.right - int64_t(other.seq.size()) + x.offset - ref_offset);
+    };
+    const int64_t end_pos = int64_t(a.seq.size()) + int64_t(seq.size());
+    std::map<int64_t, RangeSet> new_rc = path_entries_to_rc_path(path_entries, end_pos);
+    {
+      RangeSet& e = new_rc[end_pos];
+      e.insert(rs.begin(), rs.end());
+      dedup_prefixes(e);
+    }
+    std::stable_sort(anchors.begin(), anchors.end(), [&](const EntryAnchor& x, const EntryAnchor& y) {
+      if (x.shared_bases != y.shared_bases) return x.shared_bases > y.shared_bases;
+      return abs_svlen(x) < abs_svlen(y);
+    });
+    int64_t shared_here = 0;
+    for (const EntryAnchor& anc : anchors) {
+      if (anc.act->a->right == kNone) continue;
+      int64_t cur = abs_svlen(anc);
+      if (cur < best.abs_svlen || anc.shared_bases > best.shared_bases) {
+        if (cur < best.abs_svlen) {
+          best.abs_svlen = cur;
+          best.svlen_a = anchor(act, int64_t(a.seq.size()), seq, anc);
+          best.svlen_a.rc_entries = new_rc;
+          best.has_svlen = true;
+        }
+        if (anc.shared_bases > best.shared_bases) {
+          if (!shared_here) shared_here = anc.shared_bases;
+          best.shared_bases = anc.shared_bases;
+          best.shared_a = anchor(act, int64_t(a.seq.size()), seq, anc);
+          best.shared_a.rc_entries = new_rc;
+          best.has_shared = true;
+        }
+      }
+    }
+    return shared_here;
+  }
+
+  int on_trace(Act* act) override {  // :242-343
+    const Assembly& a = *act->a;
+    if (a.right != kNone) return BG_OK;
+    std::vector<Range> rs(a.rc_starts().begin(), a.rc_starts().end());
+    const int64_t n = int64_t(a.seq.size());
+    std::map<int64_t, std::vector<Range>> path_entries;
+    for (auto& kv : a.rc_entries) path_entries[n - kv.first] = std::vector<Range>(kv.second.begin(), kv.second.end());
+    Best best;
+    Walker::TraceOut tr;
+    auto it = traces_.find(act->a);
+    if (it != traces_.end()) tr = it->second;
+    std::string seq;
+    size_t step = 0;
+    while (!rs.empty()) {
+      if (step >= tr.bases.size()) {
+        if (tr.reason >= 2) {  // a bounded buffer ended the kernel's trace: resume from here
+          std::vector<Walker::TraceOut> more;
+          BG_TRY(w_.push_trace({rs}, o_.min_overlap, kMaxSteps, &more));
+          tr = more[0];
+          step = 0;
+          if (!tr.bases.empty()) continue;
+        }
+        path_entries[n + int64_t(seq.size())] = rs;  // nothing found pushing here (:276-283)
+        break;
+      }
+      seq.push_back(tr.bases[step]);
+      rs = tr.fronts[step];
+      ++step;
+      bool found_mate = false;
+      uint32_t max_size = 0;
+      for (const Range& r : rs) {
+        if (mates_.count(r)) found_mate = true;
+        max_size = std::max(max_size, r.s);
+      }
+      int64_t shared_here = save_anchors(act, rs, seq, path_entries, best);
+      if (found_mate || shared_here) path_entries[n + int64_t(seq.size())] = rs;
+      if (shared_here && shared_here == int64_t(max_size)) break;
+    }
+    if (best.has_shared) emit(std::move(best.shared_a));
+    if (best.has_svlen) emit(std::move(best.svlen_a));
+    if (!path_entries.empty()) {
+      Assembly e = extend_right(act, n, seq);
+      e.rc_entries = path_entries_to_rc_path(path_entries, n + int64_t(seq.size()));
+      emit(std::move(e));
+    }
+    return BG_OK;
+  }
+
+ private:
+  std::map<const Assembly*, Walker::TraceOut> traces_;
+  std::map<Range, int> mates_;
+  std::map<int64_t, RangeSet> mate_expiry_;
+  std::map<Range, RcStarts> rc_entry_anchors_;
+};
+
+int parse_tags(const char* csv, std::set<std::string>* out) {
+  out->clear();
+  if (!csv) return BG_OK;
+  std::string cur;
+  for (const char* p = csv;; ++p) {
+    if (*p == ',' || *p == 0) {
+      if (!cur.empty()) out->insert(cur);
+      cur.clear();
+      if (!*p) break;
+    } else {
+      cur.push_back(*p);
+    }
+  }
+  return BG_OK;
+}
+
+int check_seq(const char* seq, uint64_t len) {
+  for (uint64_t i = 0; i < len; ++i)
+    if (seq[i] != 'A' && seq[i] != 'C' && seq[i] != 'G' && seq[i] != 'T') { set_error("assembly sequences must be upper-case ACGT"); return BG_EINVAL; }
+  return BG_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" int bg_asm_list_create(bg_asm_list** out) {
+  if (!out) { set_error("bg_asm_list_create: null argument"); return BG_EINVAL; }
+  *out = new bg_asm_list;
+  return BG_OK;
+}
+extern "C" void bg_asm_list_free(bg_asm_list* l) { delete l; }
+extern "C" uint64_t bg_asm_list_size(const bg_asm_list* l) { return l ? l->a.size() : 0; }
+
+extern "C" int bg_asm_list_add(bg_asm_list* l, int64_t left_offset, int64_t right_offset, const char* seq, uint64_t seq_len,
+                               int matches_reference, const char* tags_csv) {
+  if (!l || (!seq && seq_len)) { set_error("bg_asm_list_add: null argument"); return BG_EINVAL; }
+  BG_TRY(check_seq(seq, seq_len));
+  Assembly a;
+  a.left = left_offset;
+  a.right = right_offset;
+  a.seq.assign(seq ? seq : "", seq_len);
+  a.matches_reference = matches_reference != 0;
+  BG_TRY(parse_tags(tags_csv, &a.tags));
+  a.id = l->next_id++;
+  l->a.push_back(std::move(a));
+  return BG_OK;
+}
+
+extern "C" int bg_asm_list_get(bg_asm_list* l, uint64_t i, int64_t* left_offset, int64_t* right_offset, const char** seq,
+                               uint64_t* seq_len, int* matches_reference, const char** tags_csv) {
+  if (!l || i >= l->a.size()) { set_error("bg_asm_list_get: index out of range"); return BG_EINVAL; }
+  const Assembly& a = l->a[i];
+  if (left_offset) *left_offset = a.left;
+  if (right_offset) *right_offset = a.right;
+  if (seq) *seq = a.seq.c_str();
+  if (seq_len) *seq_len = a.seq.size();
+  if (matches_reference) *matches_reference = a.matches_reference;
+  if (tags_csv) {
+    l->scratch_tags.clear();
+    for (auto& t : a.tags) { if (!l->scratch_tags.empty()) l->scratch_tags += ","; l->scratch_tags += t; }
+    *tags_csv = l->scratch_tags.c_str();
+  }
+  return BG_OK;
+}
+
+// rc range path of assembly i, flattened: h_offsets[k], h_counts[k] and count triples (begin, end, size) per
+// marked offset in ascending order; sizes returned through n_offsets / n_ranges (call with nulls first).
+extern "C" int bg_asm_list_rc_path(const bg_asm_list* l, uint64_t i, uint64_t* n_offsets, uint64_t* n_ranges,
+                                   int64_t* h_offsets, uint32_t* h_counts, uint64_t* h_triples) {
+  if (!l || i >= l->a.size() || !n_offsets || !n_ranges) { set_error("bg_asm_list_rc_path: bad argument"); return BG_EINVAL; }
+  const Assembly& a = l->a[i];
+  uint64_t k = 0, r = 0;
+  for (auto& kv : a.rc_entries) {
+    if (h_offsets) h_offsets[k] = kv.first;
+    if (h_counts) h_counts[k] = uint32_t(kv.second.size());
+    for (const Range& x : kv.second) {
+      if (h_triples) { h_triples[3 * r] = x.b; h_triples[3 * r + 1] = x.e; h_triples[3 * r + 2] = x.s; }
+      ++r;
+    }
+    ++k;
+  }
+  *n_offsets = k;
+  *n_ranges = r;
+  return BG_OK;
+}
+
+extern "C" int bg_make_ref_assemblies(bg_asm_list* l, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                                      const uint64_t* ext_len, int64_t start_offset, int64_t end_offset,
+                                      int64_t max_chunk_size) {  // make_ref.cpp:9-35
+  if (!l || (n_extents && (!ext_offset || !ext_seq || !ext_len))) { set_error("bg_make_ref_assemblies: null argument"); return BG_EINVAL; }
+  for (uint64_t x = 0; x < n_extents; ++x) {
+    BG_TRY(check_seq(ext_seq[x], ext_len[x]));
+    int64_t lo = std::max(ext_offset[x], start_offset), hi = std::min(ext_offset[x] + int64_t(ext_len[x]), end_offset);
+    for (int64_t pos = lo; pos < hi;) {
+      int64_t chunk = hi - pos;
+      if (max_chunk_size && chunk > max_chunk_size) chunk = max_chunk_size;
+      Assembly a;
+      a.left = pos;
+      a.right = pos + chunk;
+      a.seq.assign(ext_seq[x] + (pos - ext_offset[x]), size_t(chunk));
+      a.matches_reference = true;
+      a.tags.insert("MAKE_REF");
+      a.id = l->next_id++;
+      l->a.push_back(std::move(a));
+      pos += chunk;
+    }
+  }
+  return BG_OK;
+}
+
+extern "C" int bg_graph_trim_ref(bg_asm_list* l, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                                 const uint64_t* ext_len, int64_t max_backtrack) {  // graph_trim_ref.cpp
+  if (!l || (n_extents && (!ext_offset || !ext_seq || !ext_len))) { set_error("bg_graph_trim_ref: null argument"); return BG_EINVAL; }
+  if (max_backtrack <= 0) max_backtrack = 300;
+  auto split_extent_at = [&](int64_t start, std::string* left, std::string* right) {  // scaffold.cpp:189-203
+    left->clear();
+    right->clear();
+    for (uint64_t x = 0; x < n_extents; ++x) {
+      if (ext_offset[x] > start) break;
+      if (ext_offset[x] + int64_t(ext_len[x]) < start) continue;
+      size_t k = size_t(start - ext_offset[x]);
+      left->assign(ext_seq[x], k);
+      right->assign(ext_seq[x] + k, size_t(ext_len[x]) - k);
+      return;
+    }
+  };
+  auto shared_prefix = [](const std::string& a, const std::string& b) {
+    size_t n = std::min(a.size(), b.size()), i = 0;
+    while (i < n && a[i] == b[i]) ++i;
+    return int64_t(i);
+  };
+  std::vector<Assembly> out;
+  std::vector<Assembly> ref_asms;
+  size_t ref_head = 0;
+  std::set<int64_t> ref_stops;
+  auto split_and_output_ref = [&](Assembly a) {
+    for (int64_t stop : std::vector<int64_t>(ref_stops.begin(), ref_stops.end())) {
+      if (stop <= a.left) continue;
+      if (stop >= a.right) break;
+      size_t k = size_t(stop - a.left);
+      Assembly left = a;
+      left.right = stop;
+      left.seq = a.seq.substr(0, k);
+      left.rc_entries.clear();
+      left.rc_mates.clear();
+      out.push_back(std::move(left));
+      a.left = stop;
+      a.seq = a.seq.substr(k);
+      a.rc_entries.clear();
+      a.rc_mates.clear();
+    }
+    out.push_back(std::move(a));
+  };
+  auto advance_to = [&](int64_t offset) {
+    while (ref_head < ref_asms.size() && ref_asms[ref_head].right <= offset) split_and_output_ref(std::move(ref_asms[ref_head++]));
+  };
+  for (Assembly& a : l->a) {
+    int64_t mo = a.min_off();
+    advance_to(mo == kNone ? kNone : mo - max_backtrack);
+    if (a.matches_reference) { ref_asms.push_back(std::move(a)); continue; }
+    int64_t shared_left = 0, shared_right = 0;
+    std::string le, ri;
+    if (a.left != kNone) { split_extent_at(a.left, &le, &ri); shared_left = shared_prefix(ri, a.seq); }
+    if (a.right != kNone) { split_extent_at(a.right, &le, &ri); shared_right = shared_prefix(rev_comp(le), rev_comp(a.seq)); }
+    int64_t max_anchor = int64_t(a.seq.size());
+    if (a.left != kNone && a.right != kNone) max_anchor = std::min(max_anchor, a.right - a.left);
+    if (a.left == kNone) max_anchor = std::min(max_anchor, max_backtrack);
+    shared_right = std::min(shared_right, max_anchor);
+    if (shared_right + shared_left > max_anchor) shared_left = max_anchor - shared_right;
+    Assembly b;
+    b.left = a.left == kNone ? kNone : a.left + shared_left;
+    b.right = a.right == kNone ? kNone : a.right - shared_right;
+    b.seq = a.seq.substr(size_t(shared_left), a.seq.size() - size_t(shared_left) - size_t(shared_right));
+    b.tags = a.tags;
+    b.id = a.id;
+    if (b.seq.empty() && (b.left == b.right || b.left == kNone || b.right == kNone)) continue;  // entirely reference
+    if (b.left != kNone) ref_stops.insert(b.left);
+    if (b.right != kNone) ref_stops.insert(b.right);
+    out.push_back(std::move(b));
+  }
+  advance_to(kInf);
+  canon_sort(out);
+  l->a.swap(out);
+  return BG_OK;
+}
+
+extern "C" int bg_dedup_assemblies(bg_asm_list* l) {  // graph_discover_test.py:23-35
+  if (!l) { set_error("bg_dedup_assemblies: null argument"); return BG_EINVAL; }
+  std::vector<Assembly> out;
+  for (Assembly& a : l->a) {
+    if (!out.empty() && out.back().left == a.left && out.back().right == a.right && out.back().seq == a.seq) continue;
+    out.push_back(std::move(a));
+  }
+  l->a.swap(out);
+  return BG_OK;
+}
+
+extern "C" int bg_asm_list_sort(bg_asm_list* l) {
+  if (!l) { set_error("bg_asm_list_sort: null argument"); return BG_EINVAL; }
+  canon_sort(l->a);
+  return BG_OK;
+}
+
+static int make_walker(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, Walker* w, const char* who) {
+  if (!ctx || !ss) { set_error("%s: null argument", who); return BG_EINVAL; }
+  if (rm && rm->n_entries != ss->n) { set_error("%s: Cannot use a readmap with a seqset it doesn't belong to.", who); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  w->ctx = ctx;
+  w->ss = ss;
+  w->rm = rm;
+  return w->init();
+}
+
+extern "C" int bg_update_rc_seqset_entries(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, bg_asm_list* l,
+                                           uint32_t max_pairs_per_read) {
+  if (!l) { set_error("bg_update_rc_seqset_entries: null argument"); return BG_EINVAL; }
+  Walker w;
+  BG_TRY(make_walker(ctx, ss, rm, &w, "bg_update_rc_seqset_entries"));
+  return update_rc(w, l->a, rm != nullptr, max_pairs_per_read ? max_pairs_per_read : 20);
+}
+
+extern "C" int bg_discover_branch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, bg_asm_list* l, uint32_t min_overlap,
+                                  const char* tag, const char* discover_tags_csv) {
+  if (!l) { set_error("bg_discover_branch: null argument"); return BG_EINVAL; }
+  Walker w;
+  BG_TRY(make_walker(ctx, ss, rm, &w, "bg_discover_branch"));
+  Options o;
+  o.min_overlap = min_overlap;
+  o.tag = tag ? tag : "GRAPH_BRANCH";
+  BG_TRY(parse_tags(discover_tags_csv, &o.discover_tags));
+  BranchDiscover d(w, o);
+  d.set_base(l->a.data());
+  return d.run(l->a, &l->next_id);
+}
+
+extern "C" int bg_discover_push_to_pair(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, bg_asm_list* l,
+                                        uint32_t min_overlap, int64_t max_pair_distance, const char* tag,
+                                        const char* discover_tags_csv) {
+  if (!l) { set_error("bg_discover_push_to_pair: null argument"); return BG_EINVAL; }
+  Walker w;
+  BG_TRY(make_walker(ctx, ss, rm, &w, "bg_discover_push_to_pair"));
+  Options o;
+  o.min_overlap = min_overlap;
+  o.max_pair_distance = max_pair_distance;
+  o.tag = tag ? tag : "GRAPH_PUSH_TO_PAIR";
+  BG_TRY(parse_tags(discover_tags_csv, &o.discover_tags));
+  PushToPair d(w, o);
+  d.set_base(l->a.data());
+  return d.run(l->a, &l->next_id);
+}

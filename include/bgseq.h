@@ -280,6 +280,48 @@ int bg_propagate_from_end_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_readm
                                 uint8_t* d_n_out, uint64_t* d_obegin, uint64_t* d_oend, uint32_t* d_osize,
                                 uint32_t mate_cap, uint32_t* d_n_mates, uint64_t* d_mate_begin,
                                 uint64_t* d_mate_end, uint32_t* d_mate_size);
+/* ---- Graph-discover host drivers (C++ in csrc/discover.cpp over the batched walks
+ * above).  An assembly list mirrors the stream of variants::assembly the reference's pipeline steps pass
+ * along (variants/assemble.h:285-420: left_offset / right_offset with INT64_MIN = optional_aoffset::none,
+ * seq, matches_reference, tags, rc_seqset_entries).  Every step takes the list in canonical order
+ * (canon_assembly_order, assemble.cpp:1029-1085) and leaves it so.  Sequences are upper-case ACGT. */
+typedef struct bg_asm_list bg_asm_list;
+#define BG_OFFSET_NONE INT64_MIN
+int bg_asm_list_create(bg_asm_list** out);
+void bg_asm_list_free(bg_asm_list* l);
+uint64_t bg_asm_list_size(const bg_asm_list* l);
+int bg_asm_list_add(bg_asm_list* l, int64_t left_offset, int64_t right_offset, const char* seq, uint64_t seq_len,
+                    int matches_reference, const char* tags_csv);
+int bg_asm_list_sort(bg_asm_list* l);
+/* Pointers stay valid until the list changes (tags_csv until the next bg_asm_list_get). */
+int bg_asm_list_get(bg_asm_list* l, uint64_t i, int64_t* left_offset, int64_t* right_offset, const char** seq,
+                    uint64_t* seq_len, int* matches_reference, const char** tags_csv);
+/* rc_seqset_entries of assembly i (seqset_path::entries()): offsets ascending, a count and that many
+ * (begin, end, size) triples per offset.  Call with null arrays to size them. */
+int bg_asm_list_rc_path(const bg_asm_list* l, uint64_t i, uint64_t* n_offsets, uint64_t* n_ranges, int64_t* h_offsets,
+                        uint32_t* h_counts, uint64_t* h_triples);
+/* make_ref_assemblies (graph_discover/make_ref.cpp:9-35) over scaffold extents; appends. */
+int bg_make_ref_assemblies(bg_asm_list* l, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                           const uint64_t* ext_len, int64_t start_offset, int64_t end_offset, int64_t max_chunk_size);
+/* graph_trim_ref (graph_discover/graph_trim_ref.cpp): trims reference-matching ends off variant assemblies
+ * and cuts reference assemblies where they attach.  max_backtrack 0 = 300 (graph_trim_ref.h:31). */
+int bg_graph_trim_ref(bg_asm_list* l, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                      const uint64_t* ext_len, int64_t max_backtrack);
+/* The dedup of python/biograph/variants/graph_discover_test.py:23-35. */
+int bg_dedup_assemblies(bg_asm_list* l);
+/* update_rc_seqset_entries (graph_discover/update_rc_seqset_entries.cpp) on apply_edges_step
+ * (variants/apply_edges.cpp); rm != NULL also collects mates (assemble.cpp:1394-1414). */
+int bg_update_rc_seqset_entries(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, bg_asm_list* l,
+                                uint32_t max_pairs_per_read);
+/* discover_branch / discover_push_to_pair (python/biograph/variants/graph_discover.cpp:110-122;
+ * graph_discover/branch.cpp, push_to_pair.cpp on the sweep of discover.cpp:84-197).  discover_tags_csv
+ * null or "" = trace every assembly. */
+int bg_discover_branch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, bg_asm_list* l, uint32_t min_overlap,
+                       const char* tag, const char* discover_tags_csv);
+int bg_discover_push_to_pair(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, bg_asm_list* l,
+                             uint32_t min_overlap, int64_t max_pair_distance, const char* tag,
+                             const char* discover_tags_csv);
+
 /* ---- Merge: `biograph merge` = seqset_flat + make_mergemap + seqset_merger
  * (modules/biograph/biograph_merge.cpp:189-290, bio_base/make_mergemap.cpp:150-220,
  * seqset_merger.cpp:50-185).  The merged seqset holds the prefix-free maxima of the union of the

@@ -56,3 +56,77 @@ def test_graph_discover_on_lambda_golden_gpu(ctx, golden_dir):
     want = T.lambda_pipeline(OracleWalker(oss, orm), ref)
     assert [(a.left_offset, a.seq, a.right_offset, a.rc_entries) for a in found] == \
         [(a.left_offset, a.seq, a.right_offset, a.rc_entries) for a in want]
+
+
+# ---- the C++ drivers (csrc/discover.cpp) ---------------------------------------------------------------
+def _sig(asms):
+    return [(a.left_offset, a.seq, a.right_offset, a.matches_reference, tuple(sorted(a.tags)), a.rc_entries) for a in asms]
+
+
+def test_native_drivers_known_answers(ctx):
+    """branch_test.cpp / push_to_pair_test.cpp through the C++ drivers; every step's full assembly list (incl.
+    rc paths) equals the Python twin's."""
+    make = gpu_walker_for_reads(ctx)
+    t = O.tseq
+
+    def both(w, asms, step):
+        py = V.update_rc_seqset_entries(sorted(asms, key=V.canon_key), w, with_mates=True)
+        nat = V.AssemblyList(asms).update_rc_seqset_entries(w.ss, w.rm)
+        assert _sig(nat.to_python()) == _sig(py)
+        py = step(py, w)
+        if step is branch_py:
+            nat.discover_branch(w.ss, w.rm, w._mo, "branch_discover")
+        else:
+            nat.discover_push_to_pair(w.ss, w.rm, w._mo, w._mpd, "push_to_pair")
+        assert _sig(nat.to_python()) == _sig(py)
+        py = V.update_rc_seqset_entries(py, w, with_mates=True)
+        nat.update_rc_seqset_entries(w.ss, w.rm)
+        assert _sig(nat.to_python()) == _sig(py)
+        return [(a.left_offset, a.seq, a.right_offset) for a in nat.to_python(False) if a.tags & {"branch_discover", "push_to_pair"}]
+
+    def branch_py(asms, w):
+        return V.discover_branch(asms, w, w._mo, "branch_discover")
+
+    def push_py(asms, w):
+        return V.discover_push_to_pair(asms, w, w._mo, w._mpd, "push_to_pair")
+
+    w = make(T.BRANCH_READS + [t("ef") + "G" + t("gh")])
+    w._mo, w._mpd = len(t("ef")), 1000
+    assert both(w, [T.ref_asm(len(t("a")), t("bcdefghijklm"))], branch_py) == [(len(t("a")), t("bcdef") + "G", None)]
+    w = make(T.BRANCH_READS + [t("ef") + "G" + t("gh"), t("ghijklmno")])
+    w._mo, w._mpd = len(t("ef")), 1000
+    got = both(w, [T.var_asm(len(t("abcd")), t("ef") + "G", None), T.ref_asm(len(t("abcde")), t("fghi"))], push_py)
+    anchor = (len(t("abcd")), t("ef") + "G" + t("ghi"), len(t("abcdefghi")))
+    cont = (len(t("abcd")), t("ef") + "G" + t("ghi"), None)
+    assert anchor in got and cont in got and all(g in (anchor, cont) for g in got)
+    w = make([t("pqrst") + "G" + t("uv")], [(t("abc"), V.rev_comp("G" + t("uvw")))])
+    w._mo, w._mpd = len(t("ef")), len(t("abcdefghijklmnopqrst"))
+    got = both(w, [T.ref_asm(0, t("abcd")), T.ref_asm(len(t("abcd")), t("efghijklmnopqr")),
+                   T.var_asm(len(t("abcdefghijklmnopqr")), t("st") + "G", None)], push_py)
+    assert got == [(len(t("abcdefghijklmnopqr")), t("st") + "G" + t("uvw"), None)]
+
+
+def test_native_graph_discover_on_lambda_golden(ctx, golden_dir):
+    ss = ctx.open_seqset(golden_dir + "/father_lambda/seqset")
+    rm = ctx.open_readmap(golden_dir + "/father_lambda/readmap")
+    ref = "".join(l.strip() for l in open(golden_dir + "/father_lambda/reference.fasta") if not l.startswith(">")).upper()
+    ext = [(0, ref)]
+    lst = V.AssemblyList().make_ref_assemblies(ext, 0, len(ref))
+    lst.graph_trim_ref(ext).dedup().update_rc_seqset_entries(ss)
+    lst.discover_branch(ss, rm, 70, "BRANCH")
+    lst.graph_trim_ref(ext).dedup().update_rc_seqset_entries(ss)
+    lst.discover_push_to_pair(ss, rm, 70, 1000, "PUSH_TO_PAIR", ["BRANCH"])
+    lst.graph_trim_ref(ext).dedup().update_rc_seqset_entries(ss)
+    allasm = lst.to_python()
+    found = [a for a in allasm if a.left_offset is not None and a.right_offset is not None and not a.matches_reference]
+    assert len(found) == 8
+    T.check_against_father_vcf(found, ref, golden_dir)
+    # identical, assembly for assembly and rc path for rc path, to the Python twin over the same kernels
+    w = V.Walker(ss, rm)
+
+    def trim_and_update(asms):
+        return V.update_rc_seqset_entries(V.dedup_assemblies(V.graph_trim_ref(asms, ext)), w)
+    py = trim_and_update(V.make_ref_assemblies(ext, 0, len(ref)))
+    py = trim_and_update(V.discover_branch(py, w, 70, "BRANCH"))
+    py = trim_and_update(V.discover_push_to_pair(py, w, 70, 1000, "PUSH_TO_PAIR", ["BRANCH"]))
+    assert _sig(allasm) == _sig(py)
