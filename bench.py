@@ -42,12 +42,12 @@ def cpu_baseline(sample_genome, coverage, read_len, seed):
                 n, read_len, bases / 1e6, coverage, sample_genome, dt, len(ss))}
 
 
-def driver_leg(ctx, ss, genome, dev, args, region=200000):
+def driver_leg(ctx, ss, genome, dev, args, region=500000):
     """The whole graph-discover pipeline of the reference's graph_discover_test.py (make_ref_assemblies ->
     trim/update -> discover_branch -> ... -> discover_push_to_pair; host drivers biograph_amd/variants.py over
     the kernels) on the first `region` bases of the reference, scored against the SNPs synth.py planted on
-    the second haplotype.  Host-bound (Python bookkeeping, one launch per reference position in
-    update_rc_seqset_entries): a correctness demonstration at WGS depth, not a throughput figure."""
+    the second haplotype.  Host-bound (one kernel launch per reference position in update_rc_seqset_entries:
+    the rc paths chain from assembly to assembly)."""
     import torch
     from biograph_amd import variants as V
     G = int(genome.numel())
@@ -59,20 +59,21 @@ def driver_leg(ctx, ss, genome, dev, args, region=200000):
     shift = torch.randint(1, 4, (G,), generator=g, device=dev, dtype=torch.uint8)
     pos = torch.nonzero(snp[:region]).flatten().cpu().tolist()
     truth = {p: "ACGT"[(int(genome[p]) + int(shift[p])) & 3] for p in pos if 300 < p < region - 300}
-    w = V.Walker(ss, None)
     ext = [(0, ref)]
     t0 = time.perf_counter()
-
-    def trim_and_update(asms):
-        return V.update_rc_seqset_entries(V.dedup_assemblies(V.graph_trim_ref(asms, ext)), w)
-    asms = trim_and_update(V.make_ref_assemblies(ext, 0, region))
-    asms = trim_and_update(V.discover_branch(asms, w, 105, "BRANCH"))
-    asms = trim_and_update(V.discover_push_to_pair(asms, w, 105, 1000, "PUSH_TO_PAIR", ["BRANCH"]))
-    found = [a for a in asms if a.left_offset is not None and a.right_offset is not None and not a.matches_reference]
+    lst = V.AssemblyList().make_ref_assemblies(ext, 0, region)          # C++ drivers (csrc/discover.cpp)
+    lst.graph_trim_ref(ext).dedup().update_rc_seqset_entries(ss)
+    lst.discover_branch(ss, None, 105, "BRANCH")
+    lst.graph_trim_ref(ext).dedup().update_rc_seqset_entries(ss)
+    lst.discover_push_to_pair(ss, None, 105, 1000, "PUSH_TO_PAIR", ["BRANCH"])
+    lst.graph_trim_ref(ext).dedup().update_rc_seqset_entries(ss)
     dt = time.perf_counter() - t0
+    found = [a for a in lst.to_python(False)
+             if a.left_offset is not None and a.right_offset is not None and not a.matches_reference]
     snps = {a.left_offset: a.seq for a in found if a.right_offset == a.left_offset + 1 and len(a.seq) == 1}
     hit = sum(1 for p, b in truth.items() if snps.get(p) == b)
     return {"region_bases": region, "seconds": round(dt, 2), "anchored_variants": len(found),
+            "anchored_variants_per_s": round(len(found) / dt, 1),
             "planted_snps_in_region": len(truth), "planted_snps_found": hit,
             "other_calls": len(found) - hit, "min_overlap": 105}
 
