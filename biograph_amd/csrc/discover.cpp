@@ -179,29 +179,53 @@ struct Walker {
     const uint64_t nmk = mflat.size();
     uint32_t mate_cap = with_mates ? 4096 : 1;
     for (;;) {
-      DevBuf<uint64_t> d_soff, d_fb, d_fe, d_mb, d_me, d_ob, d_oe, d_tb, d_te;
-      DevBuf<uint8_t> d_codes, d_mn, d_no;
-      DevBuf<uint32_t> d_foff, d_fs, d_moff, d_marks, d_ms, d_os, d_nm, d_ts;
-      BG_TRY(up(d_soff, soff)); BG_TRY(up(d_codes, codes)); BG_TRY(up(d_foff, foff));
-      BG_TRY(up(d_fb, fb)); BG_TRY(up(d_fe, fe)); BG_TRY(up(d_fs, fs));
-      BG_TRY(up(d_moff, moff)); BG_TRY(up(d_marks, mflat));
-      BG_TRY(d_mn.alloc(ctx, nmk)); BG_TRY(d_mb.alloc(ctx, nmk * 16)); BG_TRY(d_me.alloc(ctx, nmk * 16)); BG_TRY(d_ms.alloc(ctx, nmk * 16));
-      BG_TRY(d_no.alloc(ctx, na)); BG_TRY(d_ob.alloc(ctx, na * 16)); BG_TRY(d_oe.alloc(ctx, na * 16)); BG_TRY(d_os.alloc(ctx, na * 16));
-      BG_TRY(d_nm.alloc(ctx, na)); BG_TRY(d_tb.alloc(ctx, na * mate_cap)); BG_TRY(d_te.alloc(ctx, na * mate_cap)); BG_TRY(d_ts.alloc(ctx, na * mate_cap));
-      BG_TRY(bg_propagate_from_end_batch(ctx, ss, with_mates ? rm : nullptr, na, d_soff.p, d_codes.p, d_foff.p, d_fb.p, d_fe.p,
-                                         d_fs.p, max_pairs, d_moff.p, d_marks.p, d_mn.p, d_mb.p, d_me.p, d_ms.p, d_no.p,
-                                         d_ob.p, d_oe.p, d_os.p, mate_cap, d_nm.p, d_tb.p, d_te.p, d_ts.p));
-      std::vector<uint32_t> nm;
-      BG_TRY(down(nm, d_nm, na));
+      // one upload and one download per call: update_rc_seqset_entries launches once per reference position
+      // (the rc paths chain from assembly to assembly), so the per-call fixed cost is what matters
+      struct Slot { size_t off, bytes; };
+      size_t in_bytes = 0, out_bytes = 0;
+      auto place = [](size_t* total, size_t bytes) { Slot s{*total, bytes}; *total += (bytes + 15) & ~size_t(15); return s; };
+      Slot i_soff = place(&in_bytes, soff.size() * 8), i_codes = place(&in_bytes, codes.size()),
+           i_foff = place(&in_bytes, foff.size() * 4), i_fb = place(&in_bytes, fb.size() * 8),
+           i_fe = place(&in_bytes, fe.size() * 8), i_fs = place(&in_bytes, fs.size() * 4),
+           i_moff = place(&in_bytes, moff.size() * 4), i_marks = place(&in_bytes, mflat.size() * 4);
+      Slot o_mn = place(&out_bytes, nmk), o_mb = place(&out_bytes, nmk * 16 * 8), o_me = place(&out_bytes, nmk * 16 * 8),
+           o_ms = place(&out_bytes, nmk * 16 * 4), o_no = place(&out_bytes, na), o_ob = place(&out_bytes, na * 16 * 8),
+           o_oe = place(&out_bytes, na * 16 * 8), o_os = place(&out_bytes, na * 16 * 4), o_nm = place(&out_bytes, na * 4),
+           o_tb = place(&out_bytes, na * mate_cap * 8), o_te = place(&out_bytes, na * mate_cap * 8),
+           o_ts = place(&out_bytes, na * mate_cap * 4);
+      std::vector<uint8_t> hin(in_bytes + 16, 0), hout(out_bytes + 16, 0);
+      auto put = [&](const Slot& sl, const void* src) { if (sl.bytes) memcpy(hin.data() + sl.off, src, sl.bytes); };
+      put(i_soff, soff.data()); put(i_codes, codes.data()); put(i_foff, foff.data()); put(i_fb, fb.data());
+      put(i_fe, fe.data()); put(i_fs, fs.data()); put(i_moff, moff.data()); put(i_marks, mflat.data());
+      DevBuf<uint8_t> din, dout;
+      BG_TRY(din.alloc(ctx, hin.size()));
+      BG_TRY(dout.alloc(ctx, hout.size()));
+      BG_HIP(hipMemcpy(din.p, hin.data(), hin.size(), hipMemcpyHostToDevice));
+      auto I = [&](const Slot& sl) { return din.p + sl.off; };
+      auto Od = [&](const Slot& sl) { return dout.p + sl.off; };
+      BG_TRY(bg_propagate_from_end_batch(
+          ctx, ss, with_mates ? rm : nullptr, na, reinterpret_cast<const uint64_t*>(I(i_soff)), I(i_codes),
+          reinterpret_cast<const uint32_t*>(I(i_foff)), reinterpret_cast<const uint64_t*>(I(i_fb)),
+          reinterpret_cast<const uint64_t*>(I(i_fe)), reinterpret_cast<const uint32_t*>(I(i_fs)), max_pairs,
+          reinterpret_cast<const uint32_t*>(I(i_moff)), reinterpret_cast<const uint32_t*>(I(i_marks)), Od(o_mn),
+          reinterpret_cast<uint64_t*>(Od(o_mb)), reinterpret_cast<uint64_t*>(Od(o_me)), reinterpret_cast<uint32_t*>(Od(o_ms)),
+          Od(o_no), reinterpret_cast<uint64_t*>(Od(o_ob)), reinterpret_cast<uint64_t*>(Od(o_oe)),
+          reinterpret_cast<uint32_t*>(Od(o_os)), mate_cap, reinterpret_cast<uint32_t*>(Od(o_nm)),
+          reinterpret_cast<uint64_t*>(Od(o_tb)), reinterpret_cast<uint64_t*>(Od(o_te)), reinterpret_cast<uint32_t*>(Od(o_ts))));
+      // without mates only the head of the output block is needed
+      size_t need = with_mates ? out_bytes : o_tb.off;
+      BG_HIP(hipMemcpy(hout.data(), dout.p, need, hipMemcpyDeviceToHost));
+      auto H = [&](const Slot& sl) { return hout.data() + sl.off; };
+      const uint32_t* nm = reinterpret_cast<const uint32_t*>(H(o_nm));
       uint32_t worst = 0;
-      for (uint32_t x : nm) worst = std::max(worst, x);
+      for (uint64_t a = 0; a < na; ++a) worst = std::max(worst, nm[a]);
       if (with_mates && worst > mate_cap) { mate_cap = worst; continue; }  // rerun with room for every mate
-      std::vector<uint8_t> mn, no;
-      std::vector<uint64_t> mb, me, ob, oe, tb, te;
-      std::vector<uint32_t> ms, os, ts;
-      BG_TRY(down(mn, d_mn, nmk)); BG_TRY(down(mb, d_mb, nmk * 16)); BG_TRY(down(me, d_me, nmk * 16)); BG_TRY(down(ms, d_ms, nmk * 16));
-      BG_TRY(down(no, d_no, na)); BG_TRY(down(ob, d_ob, na * 16)); BG_TRY(down(oe, d_oe, na * 16)); BG_TRY(down(os, d_os, na * 16));
-      if (with_mates) { BG_TRY(down(tb, d_tb, na * mate_cap)); BG_TRY(down(te, d_te, na * mate_cap)); BG_TRY(down(ts, d_ts, na * mate_cap)); }
+      const uint8_t *mn = H(o_mn), *no = H(o_no);
+      const uint64_t *mb = reinterpret_cast<const uint64_t*>(H(o_mb)), *me = reinterpret_cast<const uint64_t*>(H(o_me)),
+                     *ob = reinterpret_cast<const uint64_t*>(H(o_ob)), *oe = reinterpret_cast<const uint64_t*>(H(o_oe)),
+                     *tb = reinterpret_cast<const uint64_t*>(H(o_tb)), *te = reinterpret_cast<const uint64_t*>(H(o_te));
+      const uint32_t *ms = reinterpret_cast<const uint32_t*>(H(o_ms)), *os = reinterpret_cast<const uint32_t*>(H(o_os)),
+                     *ts = reinterpret_cast<const uint32_t*>(H(o_ts));
       for (uint64_t a = 0; a < na; ++a) {
         PropOut& po = (*out)[a];
         RangeSet& st = po.ent[0];
@@ -355,6 +379,55 @@ int apply_edges(std::vector<Assembly>& asms, const EdgeFn& on_edges) {
 }
 
 int update_rc(Walker& w, std::vector<Assembly>& asms, bool with_mates, uint32_t max_pairs) {
+  // The rc paths chain from assembly to assembly (incoming of one = starts of those ending where it
+  // begins), which would mean one launch per reference position.  Speculation breaks the chain: for every
+  // assembly still without a path, walk the >= 256 reference bases before it from the empty context plus
+  // the assembly itself, all assemblies in ONE launch; the frontier at the boundary is the predicted
+  // `incoming`.  The sweep below uses a prediction only when the actual incoming set equals it (the result
+  // is a function of (incoming, sequence)), and falls back to a launch otherwise (after variants).  Not
+  // with mates: the warm-up walk would collect the mates of the wrong bases.
+  struct Spec { bool valid = false; RangeSet incoming; RangeSet starts; };
+  std::vector<Spec> spec(asms.size());
+  if (!with_mates) {
+    std::map<int64_t, std::vector<size_t>> ref_by_right;
+    for (size_t i = 0; i < asms.size(); ++i)
+      if (asms[i].matches_reference && asms[i].right != kNone && asms[i].left != kNone) ref_by_right[asms[i].right].push_back(i);
+    std::vector<size_t> who;
+    std::vector<std::string> seqs;
+    std::vector<std::vector<Range>> ends;
+    std::vector<std::vector<uint32_t>> marks;
+    for (size_t i = 0; i < asms.size(); ++i) {
+      const Assembly& a = asms[i];
+      if (!a.rc_entries.empty() || a.left == kNone || a.seq.empty()) continue;
+      std::string warm;
+      int64_t pos = a.left;
+      bool broken = false;
+      while (warm.size() < 256) {
+        auto it = ref_by_right.find(pos);
+        if (it == ref_by_right.end()) break;                 // start of the walked region: empty context there
+        if (it->second.size() != 1) { broken = true; break; }  // ambiguous predecessor
+        const Assembly& p = asms[it->second[0]];
+        if (p.seq.empty() || int64_t(p.seq.size()) != p.right - p.left) { broken = true; break; }
+        warm = p.seq + warm;
+        pos = p.left;
+      }
+      if (broken) continue;
+      who.push_back(i);
+      seqs.push_back(rev_comp(warm + a.seq));
+      ends.push_back({w.ctx_begin()});
+      marks.push_back(warm.empty() ? std::vector<uint32_t>() : std::vector<uint32_t>{uint32_t(a.seq.size())});
+    }
+    std::vector<Walker::PropOut> res;
+    BG_TRY(w.propagate(seqs, ends, marks, false, max_pairs, &res));
+    for (size_t k = 0; k < who.size(); ++k) {
+      Spec& sp = spec[who[k]];
+      sp.valid = true;
+      sp.starts = res[k].ent[0];
+      if (marks[k].empty()) { sp.incoming.insert(w.ctx_begin()); }
+      else sp.incoming = res[k].ent[int64_t(marks[k][0])];
+    }
+  }
+  const Assembly* base = asms.data();
   auto propagate = [&](const RangeSet& incoming, const std::vector<size_t>& targets) -> int {
     RangeSet inc_d = incoming;
     dedup_prefixes(inc_d);
@@ -362,6 +435,12 @@ int update_rc(Walker& w, std::vector<Assembly>& asms, bool with_mates, uint32_t 
     for (size_t t : targets) {
       Assembly& a = asms[t];
       if (!a.rc_entries.empty() && inc_d == a.rc_ends() && int64_t(a.seq.size()) == a.rc_entries.rbegin()->first) continue;
+      const Spec& sp = spec[size_t(&a - base)];
+      if (sp.valid && a.rc_entries.empty() && sp.incoming == inc_d) {  // the prediction holds
+        a.rc_entries[int64_t(a.seq.size())] = inc_d;
+        a.rc_entries[0] = sp.starts;
+        continue;
+      }
       todo.push_back(t);
     }
     if (todo.empty()) return BG_OK;
