@@ -6,6 +6,7 @@
 //                   [--kmer-size 30] [--min-kmer-count 5] [--trim-after-portion 0.7]
 //                   [--max-corrections 8] [--min-good-run 2] [--min-reads 0.4] [--warn-reads 0.7] [--stats FILE]
 //   bgbinary refmap --in S.bg --ref DIR|FASTA --out FILE          (ref_map::build -> one byte per entry)
+//   bgbinary discovery --in S.bg --ref DIR|FASTA --out V.vcf [--sample ID] [--min-overlap 0.7|N]   (graph_discover pipeline)
 //   bgbinary merge --in A.bg --in B.bg [...] --out M.bg [--id ID] [-f]   (biograph_merge.cpp:189-400)
 //
 // Host work here is file I/O only (FASTQ parsing with zlib, output directory); every computation is a
@@ -369,12 +370,121 @@ static int cmd_merge(int argc, char** argv) {
   return 0;
 }
 
+// FASTA records: (name, sequence upper-cased)
+static void read_fasta_records(const std::string& path, std::vector<std::pair<std::string, std::string>>* recs) {
+  gzFile f = gzopen(path.c_str(), "rb");
+  if (!f) die("Could not open " + path + ": " + strerror(errno));
+  std::vector<char> buf(1 << 16);
+  while (gzgets(f, buf.data(), int(buf.size()))) {
+    if (buf[0] == '>') {
+      std::string name;
+      for (char* p = buf.data() + 1; *p && *p != ' ' && *p != '\t' && *p != '\n' && *p != '\r'; ++p) name.push_back(*p);
+      recs->emplace_back(name, std::string());
+      continue;
+    }
+    if (recs->empty()) recs->emplace_back("ref", std::string());
+    for (char* p = buf.data(); *p; ++p)
+      if (*p != '\n' && *p != '\r') recs->back().second.push_back(char(*p >= 'a' && *p <= 'z' ? *p - 32 : *p));
+  }
+  gzclose(f);
+}
+
+// bgbinary discovery --in S.bg --ref DIR|FASTA --out V.vcf [--sample ID] [--min-overlap 0.7|N] [--max-pair-distance 1000]
+// The graph-discover pipeline of python/biograph/variants/graph_discover_test.py:41-56 (make_ref_assemblies ->
+// graph_trim_ref -> update_rc_seqset_entries -> discover_branch -> ... -> discover_push_to_pair) per scaffold;
+// every anchored non-reference assembly becomes one VCF record.  (The reference's `bgbinary discovery` runs
+// the production tracer + genotyper on top of the same walks: SURVEY §8f.2, not built.)
+static int cmd_discovery(int argc, char** argv) {
+  Args a = parse(argc, argv, 2);
+  if (!a.has("reads") || !a.has("ref") || !a.has("out")) die("discovery: --in S.bg, --ref and --out are required");
+  std::string bgdir = a.get("reads"), ref = a.get("ref");
+  if (exists(ref + "/reference.fasta")) ref += "/reference.fasta";
+  std::vector<std::pair<std::string, std::string>> recs;
+  read_fasta_records(ref, &recs);
+  bg_ctx* ctx = nullptr;
+  check(bg_ctx_create(0, nullptr, &ctx), "bg_ctx_create");
+  bg_seqset* ss = nullptr;
+  check(bg_seqset_open(ctx, (bgdir + "/seqset").c_str(), &ss), "bg_seqset_open");
+  auto samples = json_samples(read_text(bgdir + "/metadata/bg_info.json"));
+  std::string sample = a.get("sample");
+  if (samples.empty()) die("No samples found in BioGraph metadata.");                           // biograph_dir.cpp:104-107
+  if (sample.empty()) {
+    if (samples.size() > 1) die("Multiple samples are present. You must specify a readmap or accession ID.");  // :108-111
+    sample = samples.begin()->first;
+  }
+  if (!samples.count(sample)) die("Sample " + sample + " not found in " + bgdir);
+  bg_readmap* rm = nullptr;
+  check(bg_readmap_open(ctx, (bgdir + "/coverage/" + samples[sample] + ".readmap").c_str(), &rm), "bg_readmap_open");
+  double mo = atof(a.get("min-overlap", "0.7").c_str());
+  uint32_t min_overlap = mo < 1.0 ? uint32_t(mo * bg_readmap_max_read_len(rm)) : uint32_t(mo);  // biograph_variants.cpp:674
+  int64_t max_pair_distance = atoll(a.get("max-pair-distance", "1000").c_str());
+  double t0 = now_s();
+  std::string vcf = "##fileformat=VCFv4.1\n##source=biograph_amd graph_discover\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n";
+  uint64_t n_var = 0;
+  for (auto& rec : recs) {
+    const std::string& seq = rec.second;
+    std::vector<int64_t> eo;
+    std::vector<std::string> es;
+    size_t run = 0;
+    for (size_t i = 0; i <= seq.size(); ++i) {  // extents = maximal ACGT stretches (supercontigs)
+      bool acgt = i < seq.size() && (seq[i] == 'A' || seq[i] == 'C' || seq[i] == 'G' || seq[i] == 'T');
+      if (acgt) { ++run; continue; }
+      if (run) { eo.push_back(int64_t(i - run)); es.push_back(seq.substr(i - run, run)); }
+      run = 0;
+    }
+    if (es.empty()) continue;
+    std::vector<const char*> ep;
+    std::vector<uint64_t> el;
+    for (auto& x : es) { ep.push_back(x.c_str()); el.push_back(x.size()); }
+    bg_asm_list* l = nullptr;
+    check(bg_asm_list_create(&l), "bg_asm_list_create");
+    check(bg_make_ref_assemblies(l, es.size(), eo.data(), ep.data(), el.data(), 0, int64_t(seq.size()), 100), "make_ref_assemblies");
+    auto trim_and_update = [&]() {
+      check(bg_graph_trim_ref(l, es.size(), eo.data(), ep.data(), el.data(), 0), "graph_trim_ref");
+      check(bg_dedup_assemblies(l), "dedup");
+      check(bg_update_rc_seqset_entries(ctx, ss, nullptr, l, 20), "update_rc_seqset_entries");
+    };
+    trim_and_update();
+    check(bg_discover_branch(ctx, ss, rm, l, min_overlap, "BRANCH", ""), "discover_branch");
+    trim_and_update();
+    check(bg_discover_push_to_pair(ctx, ss, rm, l, min_overlap, max_pair_distance, "PUSH_TO_PAIR", "BRANCH"), "discover_push_to_pair");
+    trim_and_update();
+    for (uint64_t i = 0; i < bg_asm_list_size(l); ++i) {
+      int64_t lo, ro;
+      const char* sq;
+      uint64_t ln;
+      int mr;
+      check(bg_asm_list_get(l, i, &lo, &ro, &sq, &ln, &mr, nullptr), "bg_asm_list_get");
+      if (mr || lo == BG_OFFSET_NONE || ro == BG_OFFSET_NONE) continue;
+      std::string r = seq.substr(size_t(lo), size_t(ro - lo)), alt(sq, ln);
+      int64_t pos = lo + 1;
+      if (r.empty() || alt.empty() || r.size() != alt.size()) {  // indel: pad with the preceding base
+        if (lo == 0) continue;
+        r = seq[size_t(lo) - 1] + r;
+        alt = seq[size_t(lo) - 1] + alt;
+        pos = lo;
+      }
+      vcf += rec.first + "\t" + std::to_string(pos) + "\t.\t" + r + "\t" + alt + "\t.\t.\t.\n";
+      ++n_var;
+    }
+    bg_asm_list_free(l);
+  }
+  write_file(a.get("out"), vcf);
+  fprintf(stderr, "%llu anchored variants over %zu scaffold(s), min overlap %u, %.2f s\n", (unsigned long long)n_var,
+          recs.size(), min_overlap, now_s() - t0);
+  bg_readmap_free(rm);
+  bg_seqset_free(ss);
+  bg_ctx_destroy(ctx);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 2) die("usage: bgbinary {create|merge|refmap} [options]   (MI355X build of the seqset path)");
+  if (argc < 2) die("usage: bgbinary {create|merge|refmap|discovery} [options]   (MI355X build of the seqset path)");
   std::string cmd = argv[1];
   if (cmd == "create") return cmd_create(argc, argv);
   if (cmd == "refmap") return cmd_refmap(argc, argv);
   if (cmd == "merge") return cmd_merge(argc, argv);
-  die("bgbinary: unknown command '" + cmd + "' (this build provides: create, merge, refmap)");
+  if (cmd == "discovery") return cmd_discovery(argc, argv);
+  die("bgbinary: unknown command '" + cmd + "' (this build provides: create, merge, refmap, discovery)");
   return 1;
 }

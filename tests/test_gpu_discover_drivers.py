@@ -130,3 +130,38 @@ def test_native_graph_discover_on_lambda_golden(ctx, golden_dir):
     py = trim_and_update(V.discover_branch(py, w, 70, "BRANCH"))
     py = trim_and_update(V.discover_push_to_pair(py, w, 70, 1000, "PUSH_TO_PAIR", ["BRANCH"]))
     assert _sig(allasm) == _sig(py)
+
+
+def test_bgbinary_discovery_cli_on_lambda(golden_dir, tmp_path):
+    """`bgbinary discovery` on the lambda golden laid out as a .bg directory: 8 VCF records, the variants of
+    lambdaToyData/benchmark/father.vcf."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    bgd = tmp_path / "father.bg"
+    (bgd / "coverage").mkdir(parents=True)
+    (bgd / "metadata").mkdir()
+    shutil.copy(golden_dir + "/father_lambda/seqset", bgd / "seqset")
+    shutil.copy(golden_dir + "/father_lambda/readmap", bgd / "coverage" / "abc.readmap")
+    json.dump({"accession_id": "father", "samples": {"father": "abc"}}, open(bgd / "metadata" / "bg_info.json", "w"),
+              separators=(",", ":"))
+    out = tmp_path / "v.vcf"
+    r = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "discovery", "--in", str(bgd), "--ref",
+                        golden_dir + "/father_lambda/reference.fasta", "--out", str(out), "--min-overlap", "70"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    ref = "".join(l.strip() for l in open(golden_dir + "/father_lambda/reference.fasta") if not l.startswith(">")).upper()
+
+    def edits(path):
+        res = []
+        for line in open(path):
+            if line.startswith("#"):
+                continue
+            f = line.rstrip("\n").split("\t")
+            pos, rr, alt = int(f[1]) - 1, f[3], f[4]
+            assert ref[pos:pos + len(rr)] == rr
+            res.append(ref[:pos] + alt + ref[pos + len(rr):])
+        return sorted(res)
+    mine, gold = edits(out), edits(golden_dir + "/father_lambda/father.vcf")
+    assert len(mine) == 8 and mine == gold
