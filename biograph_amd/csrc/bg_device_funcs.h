@@ -145,8 +145,12 @@ struct KmerTable {
 struct FrcRes {
   int len;
   int ncorr;
-  uint8_t spos[kMaxCorrections];
-  uint8_t sbase[kMaxCorrections];
+  // substitution i: position in bits 8i..8i+7 of spos, base in bits 2i..2i+1 of sbase (packed so that a
+  // result stays in registers: arrays indexed by a run-time count would live in scratch memory)
+  uint64_t spos;
+  uint32_t sbase;
+  BG_HD int pos_of(int i) const { return int((spos >> (8 * i)) & 255); }
+  BG_HD int base_of(int i) const { return int((sbase >> (2 * i)) & 3); }
 };
 
 struct ReadView {
@@ -179,23 +183,32 @@ template <class Table>
 BG_HD void frc_solve(const Table& tab, const ReadView& in, int start0, uint64_t kmer0, int k,
                      int min_good_run_top, int min_good_run, int max_corrections, bool require_run_at_end,
                      FrcRes* out) {
+  // The frame being worked on lives in locals (registers); the array below is touched only when the
+  // search descends into a substitution or returns from one.  (With the current frame addressed as
+  // stack[depth] every field access went to scratch memory: 47 of the kernel's 54 GB of HBM traffic.)
   struct Frame {
     int start, pos, b, best_size, best_b;
     int last_sub;  // virtual index of the latest substitution on the path into this frame
     uint64_t kmer;
     FrcRes best;
   };
-  Frame fr[kMaxCorrections + 1];
+  Frame stack[kMaxCorrections + 1];
+  Frame f;
   int depth = 0;
-  fr[0].start = start0;
-  fr[0].kmer = kmer0;
-  fr[0].last_sub = -(1 << 20);
+  f.start = start0;
+  f.kmer = kmer0;
+  f.last_sub = -(1 << 20);
+  f.pos = 0;
+  f.b = 0;
+  f.best_size = 0;
+  f.best_b = 0;
+  f.best.len = 0;
+  f.best.ncorr = 0;
   FrcRes ret;
   ret.len = 0;
   ret.ncorr = 0;
-  bool entering = true;  // true: begin frame[depth]; false: `ret` holds the child result of frame[depth]
+  bool entering = true;  // true: begin frame f; false: `ret` holds the result of f's child
   for (;;) {
-    Frame& f = fr[depth];
     if (entering) {
       int pos = f.start;
       uint64_t cur = f.kmer;
@@ -216,7 +229,7 @@ BG_HD void frc_solve(const Table& tab, const ReadView& in, int start0, uint64_t 
         ret.len = runlen;
         ret.ncorr = 0;
         if (depth == 0) break;
-        --depth;
+        f = stack[--depth];
         entering = false;
         continue;
       }
@@ -244,10 +257,11 @@ BG_HD void frc_solve(const Table& tab, const ReadView& in, int start0, uint64_t 
       uint64_t tk = kmer_shift(f.kmer, k, f.b);
       if (!tab.has(tk)) { f.b++; continue; }
       if (f.pos + 1 < in.n) {
-        fr[depth + 1].start = f.pos + 1;
-        fr[depth + 1].kmer = tk;
-        fr[depth + 1].last_sub = f.pos;
-        ++depth;
+        stack[depth++] = f;
+        int child_start = f.pos + 1, child_last = f.pos;
+        f.start = child_start;
+        f.kmer = tk;
+        f.last_sub = child_last;
         entering = true;
         descended = true;
         break;
@@ -269,18 +283,14 @@ BG_HD void frc_solve(const Table& tab, const ReadView& in, int start0, uint64_t 
     if (f.best_size) {
       ret.len = runlen + 1 + f.best.len;
       ret.ncorr = 1 + f.best.ncorr;
-      ret.spos[0] = uint8_t(f.pos);
-      ret.sbase[0] = uint8_t(f.best_b);
-      for (int i = 0; i < f.best.ncorr; ++i) {
-        ret.spos[i + 1] = f.best.spos[i];
-        ret.sbase[i + 1] = f.best.sbase[i];
-      }
+      ret.spos = (f.best.ncorr ? f.best.spos << 8 : 0ull) | uint64_t(f.pos & 255);
+      ret.sbase = (f.best.ncorr ? f.best.sbase << 2 : 0u) | uint32_t(f.best_b & 3);
     } else {
       ret.len = runlen;
       ret.ncorr = 0;
     }
     if (depth == 0) break;
-    --depth;
+    f = stack[--depth];
     entering = false;
   }
   *out = ret;
@@ -344,15 +354,15 @@ BG_HD int frc_correct_read(const Table& tab, const uint64_t* words, const uint32
   if (clen < needed || clen < k) return 0;  // correct_reads.cpp:174-178
   for (int w = 0; w < W; ++w) out_words[w] = words[w];
   for (int i = 0; i < lres.ncorr; ++i) {
-    int p = kmer_start - 1 - int(lres.spos[i]);
-    int b = 3 - int(lres.sbase[i]);
+    int p = kmer_start - 1 - lres.pos_of(i);
+    int b = 3 - lres.base_of(i);
     int sh = 62 - 2 * (p & 31);
     out_words[p >> 5] = (out_words[p >> 5] & ~(3ull << sh)) | (uint64_t(b) << sh);
   }
   for (int i = 0; i < rres.ncorr; ++i) {
-    int p = it + int(rres.spos[i]);
+    int p = it + rres.pos_of(i);
     int sh = 62 - 2 * (p & 31);
-    out_words[p >> 5] = (out_words[p >> 5] & ~(3ull << sh)) | (uint64_t(rres.sbase[i]) << sh);
+    out_words[p >> 5] = (out_words[p >> 5] & ~(3ull << sh)) | (uint64_t(rres.base_of(i)) << sh);
   }
   // N positions inside the kept part were all substituted (a run never crosses an N), but the
   // stored base under an N is A: nothing else to fix.  Truncate + zero pad.
