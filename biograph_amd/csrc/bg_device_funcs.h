@@ -429,6 +429,8 @@ struct CoverIndex {
   int K;
 };
 
+constexpr uint32_t kCoverSingle = 0x80000000u;  // vals[]: bit 31 = the run is this one oriented id
+
 // number of suffix records oriented read o emits (0 for a dropped read)
 BG_HD int cover_count(const CoverIndex& ci, const uint64_t* owords,
                                            const uint16_t* len, uint64_t o, int W) {
@@ -443,11 +445,17 @@ BG_HD int cover_count(const CoverIndex& ci, const uint64_t* owords,
       bool covered = false;
       int64_t h = table_find(ci.slots, ci.log2cap, key, ~0ull);
       if (h >= 0) {
-        for (uint64_t p = ci.vals[h]; p < ci.n_o && ci.skeys[p] == key; ++p) {
-          uint32_t c = ci.soid[p];
-          if (int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) {
-            covered = true;
-            break;
+        const uint32_t v = ci.vals[h];
+        if (v & kCoverSingle) {
+          uint32_t c = v & ~kCoverSingle;
+          covered = int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W);
+        } else {
+          for (uint64_t p = v; p < ci.n_o && ci.skeys[p] == key; ++p) {
+            uint32_t c = ci.soid[p];
+            if (int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) {
+              covered = true;
+              break;
+            }
           }
         }
       }

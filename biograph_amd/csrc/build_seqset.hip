@@ -41,13 +41,17 @@ __global__ void k_flag_key_heads(const uint64_t* __restrict__ keys, uint64_t n, 
 }
 
 // cover index: hash from first-K-mer to the start of its run in the sorted (key, oriented id) list
-__global__ void k_cover_insert(const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ head_pos,
-                               uint64_t nheads, uint64_t* __restrict__ slots, uint32_t* __restrict__ vals,
-                               int log2cap) {
+// A run of one candidate (the usual case) stores the candidate's oriented id itself, flagged in bit 31, so
+// that a hit costs one dependent load less than going through the sorted list.
+__global__ void k_cover_insert(const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ soid,
+                               uint64_t n_o, const uint32_t* __restrict__ head_pos, uint64_t nheads,
+                               uint64_t* __restrict__ slots, uint32_t* __restrict__ vals, int log2cap) {
   uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r >= nheads) return;
   uint32_t pos = head_pos[r];
   uint64_t key = skeys[pos];
+  const bool single = n_o < (1ull << 31) && (uint64_t(pos) + 1 >= n_o || skeys[pos + 1] != key);
+  if (single) pos = kCoverSingle | soid[pos];
   uint64_t mask = (1ull << log2cap) - 1;
   uint64_t s = hash_slot(key, log2cap);
   const int off = hash_slot_offset(key, log2cap);
@@ -575,7 +579,7 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   BG_TRY(vals.alloc(ctx, 1ull << lg));
   BG_HIP(hipMemsetAsync(slots.p, 0xff, (1ull << lg) * 8, ctx->stream));
   if (nheads) {
-    k_cover_insert<<<cdiv(nheads, 256), 256, 0, ctx->stream>>>(skeys, head_pos.p, nheads, slots.p, vals.p, lg);
+    k_cover_insert<<<cdiv(nheads, 256), 256, 0, ctx->stream>>>(skeys, soid, n_o, head_pos.p, nheads, slots.p, vals.p, lg);
     BG_LAUNCH_CHECK();
   }
   CoverIndex ci{slots.p, vals.p, lg, skeys, soid, n_o, cover_k};
