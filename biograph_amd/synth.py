@@ -61,7 +61,8 @@ def make_reads(genome_len=SHAPES["tiny"], coverage=30, read_len=150, seed=202610
         m = min(chunk_pairs, n_pairs - done)
         insert = (torch.randn(m, generator=g, device=dev) * 50 + 400).clamp(200, 800).long()
         insert = torch.maximum(insert, torch.full_like(insert, read_len))
-        start = (torch.rand(m, generator=g, device=dev) * (genome_len - 800)).long().clamp(0, genome_len - 801)
+        # integer draw: float32 uniforms have 24 bits, which would quantise the starts of a >16 Mb genome
+        start = torch.randint(0, max(genome_len - 800, 1), (m,), generator=g, device=dev)
         hap = torch.randint(0, 2, (m,), generator=g, device=dev)
         flip = torch.rand(m, generator=g, device=dev) < 0.5  # which strand the fragment came from
         # mate 1: forward from fragment start; mate 2: reverse complement from fragment end (FR)
