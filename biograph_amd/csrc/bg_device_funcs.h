@@ -160,6 +160,7 @@ struct ReadView {
   int dir;     // +1: left-to-right; -1: reverse complement walking left
   int n;       // virtual length
   int k;
+  int W;       // words per read
   // Optional: bit j set <=> the UNMODIFIED read's window starting at base j holds no N and its k-mer is
   // in the set (filled by the screening kernel).  Lets the search skip look-ups of windows no
   // substitution has touched; null = always look up.
@@ -174,6 +175,44 @@ struct ReadView {
   BG_HD bool window_present(int t) const {
     int j = dir > 0 ? origin + t - k + 1 : origin - t;  // window start in read coordinates
     return (present[j >> 6] >> (j & 63)) & 1;
+  }
+  // number of consecutive original windows present from virtual index t on (at most `limit`): what the
+  // extension loop would find one look-up at a time, by bit scans
+  BG_HD int present_run(int t, int limit) const {
+    const int j = dir > 0 ? origin + t - k + 1 : origin - t;
+    int run = 0;
+    while (run < limit) {
+      int ones, avail;
+      if (dir > 0) {
+        const int jj = j + run;
+        avail = 64 - (jj & 63);
+        const uint64_t inv = ~(present[jj >> 6] >> (jj & 63));
+#if defined(__HIP_DEVICE_COMPILE__)
+        ones = inv ? __ffsll((long long)inv) - 1 : 64;
+#else
+        ones = inv ? __builtin_ctzll(inv) : 64;
+#endif
+      } else {
+        const int jj = j - run;
+        if (jj < 0) break;
+        avail = (jj & 63) + 1;
+        const uint64_t inv = ~(present[jj >> 6] << (63 - (jj & 63)));
+#if defined(__HIP_DEVICE_COMPILE__)
+        ones = inv ? __clzll((long long)inv) : 64;
+#else
+        ones = inv ? __builtin_clzll(inv) : 64;
+#endif
+      }
+      if (ones > avail) ones = avail;
+      run += ones;
+      if (ones < avail) break;
+    }
+    return run < limit ? run : limit;
+  }
+  // k-mer (in the view's orientation) of the k original bases ending at virtual index t
+  BG_HD uint64_t kmer_ending_at(int t) const {
+    if (dir > 0) return window32(words, W, origin + t - k + 1) >> (64 - 2 * k);
+    return kmer_revcomp(window32(words, W, origin - t) >> (64 - 2 * k), k);
   }
 };
 
@@ -213,6 +252,15 @@ BG_HD void frc_solve(const Table& tab, const ReadView& in, int start0, uint64_t 
       int pos = f.start;
       uint64_t cur = f.kmer;
       while (pos < in.n) {  // :24-38 extend while the next k-mer is present
+        if (in.present && pos - f.last_sub >= k) {
+          // from here to the end of the run every window is one of the read's own: skip ahead by bit scan
+          int run = in.present_run(pos, in.n - pos);
+          if (run > 0) {
+            pos += run;
+            cur = in.kmer_ending_at(pos - 1);
+          }
+          break;  // the end of the read, or an absent window (or an N): what the loop below would stop at
+        }
         int c = in.get(pos);
         if (c == 4) break;
         uint64_t nk = kmer_shift(cur, k, c);
@@ -341,13 +389,13 @@ BG_HD int frc_correct_read(const Table& tab, const uint64_t* words, const uint32
   rres.len = 0; rres.ncorr = 0;
   int maxc = max_corrections;
   if (kmer_start > 0) {  // :134-167 correct the left part on the reverse complement
-    ReadView lv{words, nmask, kmer_start - 1, -1, kmer_start, k, present};
+    ReadView lv{words, nmask, kmer_start - 1, -1, kmer_start, k, W, present};
     frc_solve(tab, lv, 0, kmer_revcomp(kmer, k), k, 0, min_good_run, maxc, false, &lres);
     if (lres.len != kmer_start) return 0;
     maxc -= lres.ncorr;
   }
   if (it != len) {  // :169-172
-    ReadView rv{words, nmask, it, +1, len - it, k, present};
+    ReadView rv{words, nmask, it, +1, len - it, k, W, present};
     frc_solve(tab, rv, 0, kmer, k, 0, min_good_run, maxc, true, &rres);
   }
   int clen = kmer_start + k + rres.len;
