@@ -479,6 +479,25 @@ struct CoverIndex {
 
 constexpr uint32_t kCoverSingle = 0x80000000u;  // vals[]: bit 31 = the run is this one oriented id
 
+// is suffix j (>= K bases long) of the oriented read s a prefix of some oriented read?
+BG_HD bool cover_probe(const CoverIndex& ci, const uint64_t* owords, const uint16_t* len, const uint64_t* s, int L,
+                       int j, int W) {
+  const int rem = L - j;
+  uint64_t key = window32(s, W, j) >> (64 - 2 * ci.K);
+  int64_t h = table_find(ci.slots, ci.log2cap, key, ~0ull);
+  if (h < 0) return false;
+  const uint32_t v = ci.vals[h];
+  if (v & kCoverSingle) {
+    uint32_t c = v & ~kCoverSingle;
+    return int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W);
+  }
+  for (uint64_t p = v; p < ci.n_o && ci.skeys[p] == key; ++p) {
+    uint32_t c = ci.soid[p];
+    if (int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) return true;
+  }
+  return false;
+}
+
 // number of suffix records oriented read o emits (0 for a dropped read)
 BG_HD int cover_count(const CoverIndex& ci, const uint64_t* owords,
                                            const uint16_t* len, uint64_t o, int W) {
@@ -488,27 +507,8 @@ BG_HD int cover_count(const CoverIndex& ci, const uint64_t* owords,
   int cnt = 1;
   for (int j = 1; j < L; ++j) {
     int rem = L - j;
-    if (rem >= ci.K) {
-      uint64_t key = window32(s, W, j) >> (64 - 2 * ci.K);
-      bool covered = false;
-      int64_t h = table_find(ci.slots, ci.log2cap, key, ~0ull);
-      if (h >= 0) {
-        const uint32_t v = ci.vals[h];
-        if (v & kCoverSingle) {
-          uint32_t c = v & ~kCoverSingle;
-          covered = int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W);
-        } else {
-          for (uint64_t p = v; p < ci.n_o && ci.skeys[p] == key; ++p) {
-            uint32_t c = ci.soid[p];
-            if (int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) {
-              covered = true;
-              break;
-            }
-          }
-        }
-      }
-      if (covered) break;
-    }
+    if (rem < ci.K) { cnt += rem; break; }  // suffixes shorter than K are never looked up: all emitted
+    if (cover_probe(ci, owords, len, s, L, j, W)) break;
     ++cnt;
   }
   return cnt;

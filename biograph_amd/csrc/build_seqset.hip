@@ -67,12 +67,54 @@ __global__ void k_cover_insert(const uint64_t* __restrict__ skeys, const uint32_
   }
 }
 
-__global__ __launch_bounds__(128) void k_cover_count(CoverIndex ci, const uint64_t* __restrict__ owords,
+// One suffix look-up per lane and round; a lane whose read is finished takes the next read of its wave's
+// chunk at once (the reads need 1..L rounds each — without the refill a wave runs as long as its slowest
+// read with most lanes idle).
+constexpr int kCoverChunk = 1024;  // oriented reads per wave
+
+__global__ __launch_bounds__(256) void k_cover_count(CoverIndex ci, const uint64_t* __restrict__ owords,
                                                      const uint16_t* __restrict__ len, uint64_t o_base,
                                                      uint64_t n_emit, int W, uint32_t* __restrict__ cnt) {
-  uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= n_emit) return;
-  cnt[t] = uint32_t(cover_count(ci, owords, len, o_base + t, W));
+  const int lane = threadIdx.x & 63;
+  const uint64_t lane_lt = (1ull << lane) - 1;
+  const uint64_t wave = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  uint64_t next = wave * kCoverChunk;
+  const uint64_t end = next + kCoverChunk < n_emit ? next + kCoverChunk : n_emit;
+  bool active = false;
+  uint64_t t = 0;
+  const uint64_t* s = nullptr;
+  int L = 0, j = 0, c = 0;
+  for (;;) {
+    const uint64_t need = __ballot(!active);
+    if (need) {
+      if (!active) {
+        const uint64_t mine = next + uint64_t(__popcll(need & lane_lt));
+        if (mine < end) {
+          t = mine;
+          const uint64_t o = o_base + t;
+          L = len[o >> 1];
+          s = owords + o * uint64_t(W);
+          j = 1;
+          c = 1;
+          if (L <= 1) cnt[t] = uint32_t(L);  // dropped read: nothing; one base: itself
+          else active = true;
+        }
+      }
+      next += uint64_t(__popcll(need));
+    }
+    if (!__ballot(active)) {
+      if (next >= end) break;
+      continue;
+    }
+    if (active) {
+      const int rem = L - j;
+      bool fin;
+      if (rem < ci.K) { c += rem; fin = true; }
+      else if (cover_probe(ci, owords, len, s, L, j, W)) fin = true;
+      else { ++c; ++j; fin = j >= L; }
+      if (fin) { cnt[t] = uint32_t(c); active = false; }
+    }
+  }
 }
 
 // records: rec[r*W + w] (zero padded words), rlen[r]
@@ -592,7 +634,8 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   BG_TRY(total.alloc(ctx, 1));
   if (n_emit) {
     ctx->tic("suffix_cover_count");
-    k_cover_count<<<cdiv(n_emit, 128), 128, 0, ctx->stream>>>(ci, owords.p, reads->len.p, o_base, n_emit, W, cnt.p);
+    k_cover_count<<<cdiv(cdiv(n_emit, kCoverChunk), 4), 256, 0, ctx->stream>>>(ci, owords.p, reads->len.p, o_base, n_emit, W,
+                                                                             cnt.p);
     BG_LAUNCH_CHECK();
     ctx->toc(n_emit * W * 8 * 2);
   }
