@@ -118,23 +118,56 @@ __global__ __launch_bounds__(256) void k_cover_count(CoverIndex ci, const uint64
 }
 
 // records: rec[r*W + w] (zero padded words), rlen[r]
-__global__ __launch_bounds__(128) void k_emit_records(const uint64_t* __restrict__ owords,
+// One wave expands 64 oriented reads: its records are contiguous in the output, so the lanes walk the
+// output WORDS (lane = consecutive word), find the read a word belongs to by a 6-step search over the
+// 64 record offsets held one per lane, and write fully coalesced — instead of one lane looping over all
+// the records of its read.
+__global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict__ owords,
                                                       const uint16_t* __restrict__ len,
                                                       const uint32_t* __restrict__ cnt,
                                                       const uint64_t* __restrict__ roff, uint64_t o_base,
                                                       uint64_t n_emit, int W, uint64_t* __restrict__ rec,
                                                       uint8_t* __restrict__ rlen) {
-  uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= n_emit) return;
-  int c = int(cnt[t]);
-  if (!c) return;
-  uint64_t o = o_base + t;
-  int L = len[o >> 1];
-  const uint64_t* s = owords + o * W;
-  uint64_t r = roff[t];
-  for (int j = 0; j < c; ++j, ++r) {
-    for (int w = 0; w < W; ++w) rec[r * W + w] = window32(s, W, j + 32 * w);
-    rlen[r] = uint8_t(L - j);
+  const int lane = threadIdx.x & 63;
+  const uint64_t t0 = (uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 64;
+  if (t0 >= n_emit) return;
+  const uint64_t t = t0 + lane;
+  const bool live = t < n_emit;
+  const uint64_t my_off = live ? roff[t] : ~0ull;  // ascending over the lanes (exclusive scan), ~0 past the end
+  const uint32_t my_cnt = live ? cnt[t] : 0u;
+  const int my_len = live ? int(len[(o_base + t) >> 1]) : 0;
+  const uint64_t r0 = __shfl(my_off, 0, 64);
+  uint64_t r1 = my_off + my_cnt;  // end of the wave's records = max over live lanes
+  {
+    uint64_t e = live ? r1 : 0;
+#pragma unroll
+    for (int d = 32; d; d >>= 1) {
+      uint64_t o = __shfl_xor(e, d, 64);
+      e = o > e ? o : e;
+    }
+    r1 = e;
+  }
+  const uint64_t nwords = (r1 - r0) * uint64_t(W);
+  for (uint64_t x0 = 0; x0 < nwords; x0 += 64) {
+    const uint64_t x = x0 + lane;
+    const uint64_t q = r0 + x / uint64_t(W);
+    const int w = int(x % uint64_t(W));
+    int lo = 0;  // last lane whose first record is <= q
+#pragma unroll
+    for (int step = 32; step; step >>= 1) {
+      uint64_t v = __shfl(my_off, lo + step, 64);
+      if (v <= q) lo += step;
+    }
+    // reads without records share their offset with the next read: the search lands on the last of them,
+    // which is the one that owns the record
+    const uint64_t off = __shfl(my_off, lo, 64);
+    const int L = __shfl(my_len, lo, 64);
+    if (x < nwords) {
+      const int j = int(q - off);
+      const uint64_t* s = owords + (o_base + t0 + uint64_t(lo)) * uint64_t(W);
+      rec[q * uint64_t(W) + w] = window32(s, W, j + 32 * w);
+      if (w == 0) rlen[q] = uint8_t(L - j);
+    }
   }
 }
 
@@ -646,7 +679,7 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   BG_TRY(rlen->alloc(ctx, n_rec));
   if (n_rec) {
     ctx->tic("suffix_emit");
-    k_emit_records<<<cdiv(n_emit, 128), 128, 0, ctx->stream>>>(owords.p, reads->len.p, cnt.p, roff.p, o_base, n_emit, W,
+    k_emit_records<<<cdiv(cdiv(n_emit, 64), 4), 256, 0, ctx->stream>>>(owords.p, reads->len.p, cnt.p, roff.p, o_base, n_emit, W,
                                                                rec->p, rlen->p);
     BG_LAUNCH_CHECK();
     ctx->toc(n_emit * W * 8 + n_rec * (W * 8 + 1));
