@@ -185,8 +185,9 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
                         DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out);
 int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t>& rlen, uint64_t n_rec, int W,
                               bg_seqset* ss, uint64_t* n_tied_out);
-// 12-leading-bases directory over sorted W-word keys: dir[p] = first key with prefix >= p, dir[4^12] = n
-int build_prefix_dir_keys(bg_ctx* ctx, const uint64_t* keys, uint64_t n, int W, DevBuf<uint32_t>* dir);
+// leading-bases directory over sorted W-word keys (*bases = 8..13 chosen from n): dir[p] = first key with
+// prefix >= p, dir[4^bases] = n
+int build_prefix_dir_keys(bg_ctx* ctx, const uint64_t* keys, uint64_t n, int W, DevBuf<uint32_t>* dir, int* bases);
 int alloc_prev_bits(bg_ctx* ctx, bg_seqset* ss);
 int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss);
 int apply_tails_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint32_t* d_err);

@@ -368,17 +368,24 @@ __global__ void k_build_entries(const uint64_t* __restrict__ skeys, const uint8_
 // Directory over the leading kPrefixBases bases of the sorted entries: dir[p] = first entry whose
 // (zero padded) leading bases are >= p, dir[4^kPrefixBases] = n.  Narrows every lower_bound below to
 // the handful of entries sharing the query's prefix.
-constexpr int kPrefixBases = 12;
+// bases of the directory, chosen per build: 4^B <= n/4, 8..12 (measured on 144 M entries: 11 and 12 bases
+// 14.0 ms for the whole prev-bit stage, 13 bases 14.8 — the bigger table falls out of cache)
+int prefix_dir_bases(uint64_t n) {
+  int b = 8;
+  while (b < 12 && (1ull << (2 * (b + 1))) <= n / 4 + 1) ++b;
+  return b;
+}
 // Directory over the leading kPrefixBases bases: dir[p] = first entry whose prefix is >= p, dir[4^B] = n.
 // Built without serial fills (a shard of a sharded build, or a small seqset, leaves most prefixes empty):
 // heads of non-empty prefixes, then a suffix-min over the table in 2048-prefix chunks.
 constexpr int kDirChunk = 2048;
 
-__global__ void k_dir_heads(const uint64_t* __restrict__ ekeys, uint64_t n, int W, uint32_t* __restrict__ dir) {
+__global__ void k_dir_heads(const uint64_t* __restrict__ ekeys, uint64_t n, int W, int bases,
+                            uint32_t* __restrict__ dir) {
   uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint32_t cur = uint32_t(ekeys[i * W] >> (64 - 2 * kPrefixBases));
-  if (i == 0 || uint32_t(ekeys[(i - 1) * W] >> (64 - 2 * kPrefixBases)) != cur) dir[cur] = uint32_t(i);
+  uint32_t cur = uint32_t(ekeys[i * W] >> (64 - 2 * bases));
+  if (i == 0 || uint32_t(ekeys[(i - 1) * W] >> (64 - 2 * bases)) != cur) dir[cur] = uint32_t(i);
 }
 
 __global__ __launch_bounds__(256) void k_dir_chunk_min(const uint32_t* __restrict__ dir, uint32_t* __restrict__ cmin) {
@@ -421,9 +428,10 @@ __global__ __launch_bounds__(256) void k_dir_fill(uint32_t* __restrict__ dir, co
   }
 }
 
-int build_prefix_dir_keys(bg_ctx* ctx, const uint64_t* keys, uint64_t n, int W, DevBuf<uint32_t>* dir) {
-  const uint64_t nb = 1ull << (2 * kPrefixBases);
-  static_assert((1ull << (2 * kPrefixBases)) % kDirChunk == 0, "directory chunks");
+int build_prefix_dir_keys(bg_ctx* ctx, const uint64_t* keys, uint64_t n, int W, DevBuf<uint32_t>* dir, int* bases_out) {
+  const int bases = prefix_dir_bases(n);
+  *bases_out = bases;
+  const uint64_t nb = 1ull << (2 * bases);  // >= 4^8, a multiple of kDirChunk
   const uint32_t nchunks = uint32_t(nb / kDirChunk);
   if (n >= 0xffffffffull) { set_error("shard of %llu entries exceeds the prefix directory", (unsigned long long)n); return BG_EINVAL; }
   BG_TRY(dir->alloc(ctx, nb + 1));
@@ -434,7 +442,7 @@ int build_prefix_dir_keys(bg_ctx* ctx, const uint64_t* keys, uint64_t n, int W, 
   const uint32_t n32 = uint32_t(n);
   BG_HIP(hipMemcpyAsync(dir->p + nb, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
   if (n) {
-    k_dir_heads<<<cdiv(n, 256), 256, 0, ctx->stream>>>(keys, n, W, dir->p);
+    k_dir_heads<<<cdiv(n, 256), 256, 0, ctx->stream>>>(keys, n, W, bases, dir->p);
     BG_LAUNCH_CHECK();
   }
   k_dir_chunk_min<<<nchunks, 256, 0, ctx->stream>>>(dir->p, cmin.p);
@@ -450,9 +458,9 @@ int build_prefix_dir_keys(bg_ctx* ctx, const uint64_t* keys, uint64_t n, int W, 
 // lower_bound of (tail, tl) in the entries, searched inside its prefix bucket only
 __device__ __forceinline__ uint64_t entries_lower_bound(const uint64_t* __restrict__ ekeys,
                                                         const uint8_t* __restrict__ sizes, uint64_t n, int W,
-                                                        const uint32_t* __restrict__ dir, const uint64_t* tail,
-                                                        int tl) {
-  uint32_t p = uint32_t(tail[0] >> (64 - 2 * kPrefixBases));
+                                                        const uint32_t* __restrict__ dir, int bases,
+                                                        const uint64_t* tail, int tl) {
+  uint32_t p = uint32_t(tail[0] >> (64 - 2 * bases));
   uint64_t lo = dir[p], hi = dir[p + 1];
   while (lo < hi) {
     uint64_t mid = (lo + hi) >> 1;
@@ -466,8 +474,8 @@ __device__ __forceinline__ uint64_t entries_lower_bound(const uint64_t* __restri
 // prev_{s[0]}[lower_bound(entries, s[1:])]; the target must extend s[1:] ("Missing expansion?").
 __global__ __launch_bounds__(256) void k_prev_bits(const uint64_t* __restrict__ ekeys,
                                                    const uint8_t* __restrict__ sizes, uint64_t n, int W,
-                                                   const uint32_t* __restrict__ dir, uint8_t* __restrict__ marks,
-                                                   uint32_t* __restrict__ err) {
+                                                   const uint32_t* __restrict__ dir, int bases,
+                                                   uint8_t* __restrict__ marks, uint32_t* __restrict__ err) {
   uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t* s = ekeys + i * W;
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(256) void k_prev_bits(const uint64_t* __restrict__ 
   int tl = int(sizes[i]) - 1;
   uint64_t tail[kMaxWords];
   for (int w = 0; w < W; ++w) tail[w] = window32(s, W, 1 + 32 * w);
-  uint64_t lo = entries_lower_bound(ekeys, sizes, n, W, dir, tail, tl);
+  uint64_t lo = entries_lower_bound(ekeys, sizes, n, W, dir, bases, tail, tl);
   if (lo >= n || key_lcp(ekeys + lo * W, sizes[lo], tail, tl, W) < tl) {
     atomicOr(err, 2u);
     return;
@@ -486,36 +494,43 @@ __global__ __launch_bounds__(256) void k_prev_bits(const uint64_t* __restrict__ 
 }
 
 // marks[b*n + t] -> bit t of prev_b (OR-ed into the existing words)
+constexpr int kPackWordsPerWave = 16;
+
 __global__ __launch_bounds__(256) void k_pack_marks(const uint8_t* __restrict__ marks, uint64_t n,
                                                     unsigned long long* __restrict__ bA,
                                                     unsigned long long* __restrict__ bC,
                                                     unsigned long long* __restrict__ bG,
                                                     unsigned long long* __restrict__ bT) {
   const uint64_t nwords = (n + 63) / 64;
-  uint64_t g = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);  // one wave per output word
-  if (g >= 4 * nwords) return;
-  int b = int(g / nwords);
-  uint64_t w = g - uint64_t(b) * nwords;
-  uint64_t t = w * 64 + (threadIdx.x & 63);
-  bool bit = t < n && marks[uint64_t(b) * n + t] != 0;
-  uint64_t word = __ballot(bit);
-  if ((threadIdx.x & 63) == 0 && word) {
-    unsigned long long* bits = b == 0 ? bA : b == 1 ? bC : b == 2 ? bG : bT;
-    bits[w] |= word;
+  const uint64_t chunks = (nwords + kPackWordsPerWave - 1) / kPackWordsPerWave;  // per base
+  uint64_t g = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);  // one wave per 16 output words of one base
+  if (g >= 4 * chunks) return;
+  const int b = int(g / chunks);
+  const uint64_t w0 = (g - uint64_t(b) * chunks) * kPackWordsPerWave;
+  const int lane = threadIdx.x & 63;
+  unsigned long long* bits = b == 0 ? bA : b == 1 ? bC : b == 2 ? bG : bT;
+  const uint8_t* m = marks + uint64_t(b) * n;
+  uint64_t mine = 0;
+#pragma unroll
+  for (int it = 0; it < kPackWordsPerWave; ++it) {
+    uint64_t t = (w0 + it) * 64 + lane;
+    uint64_t word = __ballot(t < n && m[t] != 0);
+    if (lane == it) mine = word;
   }
+  if (lane < kPackWordsPerWave && w0 + lane < nwords && mine) bits[w0 + lane] |= mine;
 }
 
 // tails received from other shards (rows of W+1 words: s[1:], (len-1) | base << 8) -> prev bits
 __global__ __launch_bounds__(256) void k_apply_tails(const uint64_t* __restrict__ rows, uint64_t nt,
                                                      const uint64_t* __restrict__ ekeys,
                                                      const uint8_t* __restrict__ sizes, uint64_t n, int W,
-                                                     const uint32_t* __restrict__ dir, uint8_t* __restrict__ marks,
-                                                     uint32_t* __restrict__ err) {
+                                                     const uint32_t* __restrict__ dir, int bases,
+                                                     uint8_t* __restrict__ marks, uint32_t* __restrict__ err) {
   uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= nt) return;
   const uint64_t* tail = rows + t * (W + 1);
   int tl = int(tail[W] & 0xff), b = int((tail[W] >> 8) & 3);
-  uint64_t lo = entries_lower_bound(ekeys, sizes, n, W, dir, tail, tl);
+  uint64_t lo = entries_lower_bound(ekeys, sizes, n, W, dir, bases, tail, tl);
   if (lo >= n || key_lcp(ekeys + lo * W, sizes[lo], tail, tl, W) < tl) { atomicOr(err, 2u); return; }
   marks[uint64_t(b) * n + lo] = 1;
 }
@@ -875,14 +890,14 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
 }
 
 // leading-bases directory of a shard's entries (needs resident keys)
-int build_prefix_dir(bg_ctx* ctx, const bg_seqset* ss, DevBuf<uint32_t>* dir) {
-  return build_prefix_dir_keys(ctx, ss->keys.p, ss->n, ss->W, dir);
+int build_prefix_dir(bg_ctx* ctx, const bg_seqset* ss, DevBuf<uint32_t>* dir, int* bases) {
+  return build_prefix_dir_keys(ctx, ss->keys.p, ss->n, ss->W, dir, bases);
 }
 
 static int pack_marks(bg_ctx* ctx, bg_seqset* ss, const uint8_t* marks) {
   const uint64_t nwords = (ss->n + 63) / 64;
   if (!nwords) return BG_OK;
-  k_pack_marks<<<cdiv(4 * nwords, 4), 256, 0, ctx->stream>>>(
+  k_pack_marks<<<cdiv(4 * cdiv(nwords, kPackWordsPerWave), 4), 256, 0, ctx->stream>>>(
       marks, ss->n, reinterpret_cast<unsigned long long*>(ss->bits[0].p),
       reinterpret_cast<unsigned long long*>(ss->bits[1].p), reinterpret_cast<unsigned long long*>(ss->bits[2].p),
       reinterpret_cast<unsigned long long*>(ss->bits[3].p));
@@ -893,11 +908,12 @@ static int pack_marks(bg_ctx* ctx, bg_seqset* ss, const uint8_t* marks) {
 int apply_tails_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint32_t* d_err) {
   DevBuf<uint32_t> dir;
   DevBuf<uint8_t> marks;
-  BG_TRY(build_prefix_dir(ctx, ss, &dir));
+  int bases = 0;
+  BG_TRY(build_prefix_dir(ctx, ss, &dir, &bases));
   BG_TRY(marks.alloc(ctx, 4 * ss->n));
   if (ss->n) BG_HIP(hipMemsetAsync(marks.p, 0, 4 * ss->n, ctx->stream));
   k_apply_tails<<<cdiv(n_rows, 256), 256, 0, ctx->stream>>>(d_rows, n_rows, ss->keys.p, ss->sizes.p, ss->n, ss->W, dir.p,
-                                                            marks.p, d_err);
+                                                            bases, marks.p, d_err);
   BG_LAUNCH_CHECK();
   BG_TRY(pack_marks(ctx, ss, marks.p));
   BG_HIP(hipStreamSynchronize(ctx->stream));
@@ -924,10 +940,12 @@ int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss) {
   DevBuf<uint8_t> marks;
   if (n_ent) {
     ctx->tic("prev_bits");
-    BG_TRY(build_prefix_dir(ctx, ss, &dir));
+    int bases = 0;
+    BG_TRY(build_prefix_dir(ctx, ss, &dir, &bases));
     BG_TRY(marks.alloc(ctx, 4 * n_ent));
     BG_HIP(hipMemsetAsync(marks.p, 0, 4 * n_ent, ctx->stream));
-    k_prev_bits<<<cdiv(n_ent, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->sizes.p, n_ent, ss->W, dir.p, marks.p, err.p);
+    k_prev_bits<<<cdiv(n_ent, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->sizes.p, n_ent, ss->W, dir.p, bases, marks.p,
+                                                           err.p);
     BG_LAUNCH_CHECK();
     BG_TRY(pack_marks(ctx, ss, marks.p));
     ctx->toc(n_ent * (ss->W * 8 + 1 + 8));

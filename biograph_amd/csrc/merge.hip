@@ -14,7 +14,6 @@
 
 namespace bg {
 
-constexpr int kMergeDirBases = 12;
 
 __global__ void k_merge_copy_keys(const uint64_t* __restrict__ src, const uint8_t* __restrict__ sizes, uint64_t n,
                                   int Ws, int Wd, uint64_t* __restrict__ dst, uint8_t* __restrict__ dlen) {
@@ -53,13 +52,13 @@ __global__ void k_merge_keys_fm(SeqsetView v, int W, uint64_t* __restrict__ dst,
 __global__ __launch_bounds__(128) void k_merge_map(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ klen,
                                                    uint64_t n, int W, const uint64_t* __restrict__ ekeys,
                                                    const uint8_t* __restrict__ esizes, uint64_t n_ent,
-                                                   const uint32_t* __restrict__ dir, uint64_t* __restrict__ map,
-                                                   uint32_t* __restrict__ err) {
+                                                   const uint32_t* __restrict__ dir, int bases,
+                                                   uint64_t* __restrict__ map, uint32_t* __restrict__ err) {
   uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t* key = keys + i * W;
   int L = klen[i];
-  uint32_t p = uint32_t(key[0] >> (64 - 2 * kMergeDirBases));
+  uint32_t p = uint32_t(key[0] >> (64 - 2 * bases));
   uint64_t lo = dir[p], hi = dir[p + 1];
   while (lo < hi) {
     uint64_t mid = (lo + hi) >> 1;
@@ -163,13 +162,14 @@ extern "C" int bg_seqset_merge(bg_ctx* ctx, uint32_t n_in, const bg_seqset* cons
     BG_TRY(err.alloc(ctx, 1));
     BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
     ctx->tic("merge_maps");
-    BG_TRY(build_prefix_dir_keys(ctx, ss->keys.p, ss->n, W, &dir));
+    int bases = 0;
+    BG_TRY(build_prefix_dir_keys(ctx, ss->keys.p, ss->n, W, &dir, &bases));
     pos = 0;
     for (uint32_t i = 0; i < n_in; ++i) {
       uint64_t n = in[i]->n;
       if (n && d_maps[i]) {
         k_merge_map<<<cdiv(n, 128), 128, 0, ctx->stream>>>(keep.p + pos * W, keep_len.p + pos, n, W, ss->keys.p,
-                                                           ss->sizes.p, ss->n, dir.p, d_maps[i], err.p);
+                                                           ss->sizes.p, ss->n, dir.p, bases, d_maps[i], err.p);
         BG_LAUNCH_CHECK();
       }
       pos += n;

@@ -22,7 +22,6 @@
 namespace bg {
 
 constexpr uint64_t kNoLoopEntry = (1ull << 37) - 1;  // make_readmap.h:54
-constexpr int kPrefixBasesRm = 12;
 
 __device__ __forceinline__ uint64_t rm_hi(uint64_t entry, int type, uint32_t len, uint32_t mate_len) {
   return (entry << 22) | (uint64_t(type) << 20) | (uint64_t(len) << 10) | uint64_t(mate_len);
@@ -37,8 +36,8 @@ __global__ __launch_bounds__(128) void k_rm_entry_ids(const uint64_t* __restrict
                                                      const uint16_t* __restrict__ len, uint64_t n_o, int W,
                                                      const uint64_t* __restrict__ ekeys,
                                                      const uint8_t* __restrict__ esizes, uint64_t n_ent, int EW,
-                                                     const uint32_t* __restrict__ dir, uint64_t* __restrict__ eid,
-                                                     uint32_t* __restrict__ err) {
+                                                     const uint32_t* __restrict__ dir, int bases,
+                                                     uint64_t* __restrict__ eid, uint32_t* __restrict__ err) {
   uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (o >= n_o) return;
   int L = len[o >> 1];
@@ -46,7 +45,7 @@ __global__ __launch_bounds__(128) void k_rm_entry_ids(const uint64_t* __restrict
   uint64_t key[kMaxWords];
   oriented_words(words + (o >> 1) * W, L, W, (o & 1) != 0, key);
   for (int w = W; w < EW; ++w) key[w] = 0;
-  uint32_t p = uint32_t(key[0] >> (64 - 2 * kPrefixBasesRm));
+  uint32_t p = uint32_t(key[0] >> (64 - 2 * bases));
   uint64_t lo = dir[p], hi = dir[p + 1];
   while (lo < hi) {
     uint64_t mid = (lo + hi) >> 1;
@@ -352,10 +351,11 @@ extern "C" int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads
   {
     DevBuf<uint32_t> dir;
     ctx->tic("readmap_entry_ids");
-    BG_TRY(build_prefix_dir_keys(ctx, ss->keys.p, n_ent, EW, &dir));
+    int bases = 0;
+    BG_TRY(build_prefix_dir_keys(ctx, ss->keys.p, n_ent, EW, &dir, &bases));
     if (n_o) {
       k_rm_entry_ids<<<cdiv(n_o, 128), 128, 0, ctx->stream>>>(reads->words.p, reads->len.p, n_o, W, ss->keys.p,
-                                                              ss->sizes.p, n_ent, EW, dir.p, eid.p, err.p);
+                                                              ss->sizes.p, n_ent, EW, dir.p, bases, eid.p, err.p);
       BG_LAUNCH_CHECK();
     }
     ctx->toc(n_o * (W * 8 + 64));
