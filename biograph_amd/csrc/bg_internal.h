@@ -114,6 +114,8 @@ int radix_sort_u64(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* va
 // Stable partition of keys into 65536 buckets by the top 16 bits of key * kPartitionMult.
 constexpr uint64_t kPartitionMult = 0x9E3779B97F4A7C15ull;
 int radix_partition_hash16(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, bool* in_b);
+// One more level: keys grouped by 16 hash bits (kin) -> by 16 + extra_bits (kout), extra_bits in 1..8.
+int radix_partition_hash_refine(bg_ctx* ctx, uint64_t* kin, uint64_t* kout, uint64_t n, int extra_bits);
 // Same for the k-mer instances of packed reads, generated inside pass 1 (n = their number); result in keys_b.
 // First pass alone: keys grouped by the top hash byte, h_starts[257] = bucket starts.
 int radix_partition_first_reads(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t n, uint64_t* keys_out,

@@ -225,13 +225,14 @@ __global__ void k_gather_flags(const uint64_t* __restrict__ kmers, uint64_t n, c
 // one global cursor.  A bucket whose distinct keys do not fit sets its overflow flag and is recounted
 // by the sort-based path.  Role of kmer_count_table<uint8_t>::increment (kmer_count_table.h:54-103).
 
-__global__ void k_bucket_bounds(const uint64_t* __restrict__ keys, uint64_t n, uint64_t* __restrict__ bounds) {
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;  // 0..65536
-  if (b > 65536u) return;
+__global__ void k_bucket_bounds(const uint64_t* __restrict__ keys, uint64_t n, int bits,
+                                uint64_t* __restrict__ bounds) {
+  uint64_t b = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;  // 0 .. 2^bits
+  if (b > (1ull << bits)) return;
   uint64_t lo = 0, hi = n;
   while (lo < hi) {  // first position whose hash prefix is >= b
     uint64_t mid = (lo + hi) >> 1;
-    if (((keys[mid] * kPartitionMult) >> 48) < uint64_t(b)) lo = mid + 1; else hi = mid;
+    if (((keys[mid] * kPartitionMult) >> (64 - bits)) < b) lo = mid + 1; else hi = mid;
   }
   bounds[b] = lo;
 }
@@ -240,7 +241,7 @@ constexpr int KC_THREADS = 512;
 
 __global__ __launch_bounds__(KC_THREADS) void k_kmer_count_lds(const uint64_t* __restrict__ keys,
                                                                const uint64_t* __restrict__ bounds, int log2cap,
-                                                               uint32_t min_count, uint64_t out_cap,
+                                                               int bucket_bits, uint32_t min_count, uint64_t out_cap,
                                                                uint64_t* __restrict__ out_kmers,
                                                                uint32_t* __restrict__ out_counts,
                                                                unsigned long long* __restrict__ out_n,
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_kmer_count_lds(const uint64_t* _
   for (uint64_t i = lo + threadIdx.x; i < hi; i += KC_THREADS) {
     unsigned long long k = keys[i];
     if (k == ~0ull) continue;  // window held an N (kmer_counter.h:306-311)
-    uint32_t slot = uint32_t((k * kPartitionMult) >> (48 - log2cap)) & mask;  // hash bits below the bucket's
+    uint32_t slot = uint32_t((k * kPartitionMult) >> (64 - bucket_bits - log2cap)) & mask;  // hash bits below the bucket's
     uint32_t probes = 0;
     for (;;) {
       unsigned long long old = atomicCAS(&tkeys[slot], ~0ull, k);
@@ -728,13 +729,24 @@ int kmer_count_keys_impl(bg_ctx* ctx, uint64_t* ka, uint64_t* kb, uint64_t N, ui
   }
   bool in_b = partitioned;
   if (!partitioned) BG_TRY(radix_partition_hash16(ctx, ka, kb, N, &in_b));
+  // One LDS table holds a few thousand distinct k-mers: 65536 buckets carry about 1.6 G instances at 30x
+  // (chr20-sized input).  Bigger inputs get one more partition level so that a bucket stays around 24 k
+  // instances (BG_KMER_EXTRA_BITS overrides, for tests).
+  int extra = 0;
+  while (extra < 8 && (N >> (16 + extra)) > 24000) ++extra;
+  if (const char* e = getenv("BG_KMER_EXTRA_BITS")) extra = std::max(0, std::min(8, atoi(e)));
+  if (extra) {
+    BG_TRY(radix_partition_hash_refine(ctx, in_b ? kb : ka, in_b ? ka : kb, N, extra));
+    in_b = !in_b;
+  }
   uint64_t* part = in_b ? kb : ka;
   uint64_t* scratch = in_b ? ka : kb;
-  const uint32_t NB = 65536;
+  const int bucket_bits = 16 + extra;
+  const uint32_t NB = 1u << bucket_bits;
   DevBuf<uint64_t> bounds;
   DevBuf<uint8_t> overflow;
   DevBuf<unsigned long long> ctr;  // [0] kept cursor, [1] distinct
-  BG_TRY(bounds.alloc(ctx, NB + 1));
+  BG_TRY(bounds.alloc(ctx, uint64_t(NB) + 1));
   BG_TRY(overflow.alloc(ctx, NB));
   BG_TRY(ctr.alloc(ctx, 2));
   BG_HIP(hipMemsetAsync(overflow.p, 0, NB, ctx->stream));
@@ -745,13 +757,13 @@ int kmer_count_keys_impl(bg_ctx* ctx, uint64_t* ka, uint64_t* kb, uint64_t N, ui
   BG_TRY(ok_a.alloc(ctx, out_cap));
   BG_TRY(oc_a.alloc(ctx, out_cap));
   ctx->tic("kmer_count_lds");
-  k_bucket_bounds<<<cdiv(NB + 1, 256), 256, 0, ctx->stream>>>(part, N, bounds.p);
+  k_bucket_bounds<<<cdiv(uint64_t(NB) + 1, 256), 256, 0, ctx->stream>>>(part, N, bucket_bits, bounds.p);
   BG_LAUNCH_CHECK();
   const int lg = kmer_lds_log2cap();
   const size_t smem = (size_t(1) << lg) * 12;
   BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_kmer_count_lds),
                              hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
-  k_kmer_count_lds<<<NB, KC_THREADS, smem, ctx->stream>>>(part, bounds.p, lg, min_count, out_cap, ok_a.p, oc_a.p,
+  k_kmer_count_lds<<<NB, KC_THREADS, smem, ctx->stream>>>(part, bounds.p, lg, bucket_bits, min_count, out_cap, ok_a.p, oc_a.p,
                                                           ctr.p, ctr.p + 1, overflow.p);
   BG_LAUNCH_CHECK();
   ctx->toc(N * 8);
@@ -771,6 +783,11 @@ int kmer_count_keys_impl(bg_ctx* ctx, uint64_t* ka, uint64_t* kb, uint64_t N, ui
     uint64_t tot = 0;
     for (uint32_t b = 0; b < NB; ++b)
       if (h_over[b]) tot += h_bounds[b + 1] - h_bounds[b];
+    if (tot >= (1ull << 32)) {  // the recount below is sized for stragglers, not for a whole input
+      set_error("k-mer counting: %llu buckets of %u overflowed their tables (%llu instances); raise BG_KMER_EXTRA_BITS",
+                (unsigned long long)n_over, NB, (unsigned long long)tot);
+      return BG_EINTERNAL;
+    }
     DevBuf<uint64_t> ta, tb;
     BG_TRY(ta.alloc(ctx, tot));
     BG_TRY(tb.alloc(ctx, tot));

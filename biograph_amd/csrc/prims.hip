@@ -304,6 +304,13 @@ int exclusive_scan_u32(bg_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, uint6
   return exclusive_scan_impl<uint32_t>(ctx, d_in, d_out, n, d_total);
 }
 
+// BG_FORCE_OFF64=1 runs the 64-bit-offset instantiations at any size (they are otherwise reached only
+// beyond 2^32 keys, which no test can afford)
+static bool use_off32(uint64_t n) {
+  static const bool force64 = [] { const char* e = getenv("BG_FORCE_OFF64"); return e && e[0] == '1'; }();
+  return n < (1ull << 32) && !force64;
+}
+
 // ------------------------------------------------------------------------------------------------
 // radix sort
 
@@ -557,7 +564,7 @@ static int radix_sort_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint
 
 int radix_sort_u64(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint64_t n,
                    int bit_lo, int bit_hi, bool* in_b, int flags) {
-  if (n < (1ull << 32))
+  if (use_off32(n))
     return radix_sort_impl<uint32_t>(ctx, keys_a, keys_b, vals_a, vals_b, n, bit_lo, bit_hi, in_b, flags);
   return radix_sort_impl<uint64_t>(ctx, keys_a, keys_b, vals_a, vals_b, n, bit_lo, bit_hi, in_b, flags);
 }
@@ -597,7 +604,8 @@ __device__ __forceinline__ void part_locate(const PartSegs& sg, uint32_t tile, i
 }
 
 __global__ __launch_bounds__(RS_THREADS) void rs_part_hist_kernel(const uint64_t* __restrict__ keys, PartSegs sg,
-                                                                  int shift, uint32_t* __restrict__ hist) {
+                                                                  int shift, uint32_t dmask,
+                                                                  uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[RS_BINS];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -610,10 +618,10 @@ __global__ __launch_bounds__(RS_THREADS) void rs_part_hist_kernel(const uint64_t
     uint64_t idx = lo + (uint64_t(it) * RS_THREADS + threadIdx.x) * 2;
     if (idx + 1 < hi) {
       Key2 v = *reinterpret_cast<const Key2*>(keys + idx);
-      atomicAdd(&h[rs_digit<true>(v.a, shift, 0xffu)], 1u);
-      atomicAdd(&h[rs_digit<true>(v.b, shift, 0xffu)], 1u);
+      atomicAdd(&h[rs_digit<true>(v.a, shift, dmask)], 1u);
+      atomicAdd(&h[rs_digit<true>(v.b, shift, dmask)], 1u);
     } else if (idx < hi) {
-      atomicAdd(&h[rs_digit<true>(keys[idx], shift, 0xffu)], 1u);
+      atomicAdd(&h[rs_digit<true>(keys[idx], shift, dmask)], 1u);
     }
   }
   __syncthreads();
@@ -623,7 +631,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_part_hist_kernel(const uint64_t
 template <class OffT>
 __global__ __launch_bounds__(RS_THREADS) void rs_part_scatter_kernel(const uint64_t* __restrict__ kin,
                                                                      uint64_t* __restrict__ kout, PartSegs sg,
-                                                                     int shift, const OffT* __restrict__ offs) {
+                                                                     int shift, uint32_t dmask,
+                                                                     const OffT* __restrict__ offs) {
   __shared__ uint64_t skeys[PT_TILE];
   __shared__ uint32_t h[RS_BINS];
   __shared__ uint32_t binstart[RS_BINS];
@@ -649,8 +658,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_part_scatter_kernel(const uint6
       key[it] = idx < hi ? kin[idx] : 0;
       key[it + 1] = 0;
     }
-    rnk[it] = idx < hi ? uint16_t(atomicAdd(&h[rs_digit<true>(key[it], shift, 0xffu)], 1u)) : uint16_t(0);
-    rnk[it + 1] = idx + 1 < hi ? uint16_t(atomicAdd(&h[rs_digit<true>(key[it + 1], shift, 0xffu)], 1u)) : uint16_t(0);
+    rnk[it] = idx < hi ? uint16_t(atomicAdd(&h[rs_digit<true>(key[it], shift, dmask)], 1u)) : uint16_t(0);
+    rnk[it + 1] = idx + 1 < hi ? uint16_t(atomicAdd(&h[rs_digit<true>(key[it + 1], shift, dmask)], 1u)) : uint16_t(0);
   }
   __syncthreads();
   {
@@ -663,13 +672,13 @@ __global__ __launch_bounds__(RS_THREADS) void rs_part_scatter_kernel(const uint6
 #pragma unroll
   for (int it = 0; it < PT_ITEMS; ++it) {
     uint64_t idx = lo + (uint64_t(it / 2) * RS_THREADS + tid) * 2 + (it & 1);
-    if (idx < hi) skeys[binstart[rs_digit<true>(key[it], shift, 0xffu)] + rnk[it]] = key[it];
+    if (idx < hi) skeys[binstart[rs_digit<true>(key[it], shift, dmask)] + rnk[it]] = key[it];
   }
   __syncthreads();
   uint32_t cnt = uint32_t(hi - lo);
   for (uint32_t i = tid; i < cnt; i += RS_THREADS) {
     uint64_t k = skeys[i];
-    kout[goff[rs_digit<true>(k, shift, 0xffu)] + OffT(i)] = k;
+    kout[goff[rs_digit<true>(k, shift, dmask)] + OffT(i)] = k;
   }
 }
 
@@ -721,14 +730,14 @@ static int radix_partition_hash16_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* 
     BG_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors are rewritten below
     PartSegs sg{seg_key.p, seg_tile.p, nseg};
     ctx->tic("radix_hist");
-    rs_part_hist_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, sg, shift, hist.p);
+    rs_part_hist_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, sg, shift, 0xffu, hist.p);
     BG_LAUNCH_CHECK();
     ctx->toc(n * 8);
     ctx->tic("radix_scan");
     BG_TRY(exclusive_scan_impl<OffT>(ctx, hist.p, offs.p, uint64_t(RS_BINS) * ntiles, nullptr));
     ctx->toc(uint64_t(RS_BINS) * ntiles * (4 + sizeof(OffT)));
     ctx->tic("radix_scatter_k");
-    rs_part_scatter_kernel<OffT><<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, kout, sg, shift, offs.p);
+    rs_part_scatter_kernel<OffT><<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, kout, sg, shift, 0xffu, offs.p);
     BG_LAUNCH_CHECK();
     ctx->toc(n * 16);
     if (pass == 0) {
@@ -828,40 +837,63 @@ __global__ __launch_bounds__(RS_THREADS) void rs_part_scatter_reads_kernel(ReadK
   }
 }
 
+// One unstable partition pass over `nseg` segments (key offsets h_key[0..nseg]) on hash bits
+// shift..shift+7 under dmask: tiles never straddle segments, so the flat scan of [segment][bin][tile]
+// counts yields final offsets.
 template <class OffT>
-static int radix_partition_hash16_second(bg_ctx* ctx, uint64_t* kin, uint64_t* kout, uint64_t n,
-                                         const uint64_t* h_key /* 257 bucket starts */) {
-  std::vector<uint32_t> h_tile(RS_BINS + 1, 0);
-  uint32_t t = 0;
-  for (int b = 0; b < RS_BINS; ++b) {
-    h_tile[b] = t;
-    t += uint32_t((h_key[b + 1] - h_key[b] + PT_TILE - 1) / PT_TILE);
+static int radix_partition_segmented(bg_ctx* ctx, uint64_t* kin, uint64_t* kout, uint64_t n, uint32_t nseg,
+                                     const uint64_t* h_key, int shift, uint32_t dmask) {
+  std::vector<uint32_t> h_tile(size_t(nseg) + 1, 0);
+  uint64_t t = 0;
+  for (uint32_t b = 0; b < nseg; ++b) {
+    h_tile[b] = uint32_t(t);
+    t += (h_key[b + 1] - h_key[b] + PT_TILE - 1) / PT_TILE;
   }
-  h_tile[RS_BINS] = t;
-  const uint32_t ntiles = t;
+  if (t >= (1ull << 31)) { set_error("partition of %llu keys needs too many tiles", (unsigned long long)n); return BG_EINVAL; }
+  h_tile[nseg] = uint32_t(t);
+  const uint32_t ntiles = uint32_t(t);
+  if (!ntiles) return BG_OK;
   DevBuf<uint32_t> hist, seg_tile;
   DevBuf<OffT> offs;
   DevBuf<uint64_t> seg_key;
   BG_TRY(hist.alloc(ctx, size_t(RS_BINS) * ntiles));
   BG_TRY(offs.alloc(ctx, size_t(RS_BINS) * ntiles));
-  BG_TRY(seg_key.alloc(ctx, RS_BINS + 1));
-  BG_TRY(seg_tile.alloc(ctx, RS_BINS + 1));
-  BG_HIP(hipMemcpyAsync(seg_key.p, h_key, (RS_BINS + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-  BG_HIP(hipMemcpyAsync(seg_tile.p, h_tile.data(), (RS_BINS + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  BG_TRY(seg_key.alloc(ctx, size_t(nseg) + 1));
+  BG_TRY(seg_tile.alloc(ctx, size_t(nseg) + 1));
+  BG_HIP(hipMemcpyAsync(seg_key.p, h_key, (size_t(nseg) + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  BG_HIP(hipMemcpyAsync(seg_tile.p, h_tile.data(), (size_t(nseg) + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
-  PartSegs sg{seg_key.p, seg_tile.p, RS_BINS};
+  PartSegs sg{seg_key.p, seg_tile.p, int(nseg)};
   ctx->tic("radix_hist");
-  rs_part_hist_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, sg, 48, hist.p);
+  rs_part_hist_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, sg, shift, dmask, hist.p);
   BG_LAUNCH_CHECK();
   ctx->toc(n * 8);
   ctx->tic("radix_scan");
   BG_TRY(exclusive_scan_impl<OffT>(ctx, hist.p, offs.p, uint64_t(RS_BINS) * ntiles, nullptr));
   ctx->toc(uint64_t(RS_BINS) * ntiles * (4 + sizeof(OffT)));
   ctx->tic("radix_scatter_k");
-  rs_part_scatter_kernel<OffT><<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, kout, sg, 48, offs.p);
+  rs_part_scatter_kernel<OffT><<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, kout, sg, shift, dmask, offs.p);
   BG_LAUNCH_CHECK();
   ctx->toc(n * 16);
   return BG_OK;
+}
+
+template <class OffT>
+static int radix_partition_hash16_second(bg_ctx* ctx, uint64_t* kin, uint64_t* kout, uint64_t n,
+                                         const uint64_t* h_key /* 257 bucket starts */) {
+  return radix_partition_segmented<OffT>(ctx, kin, kout, n, RS_BINS, h_key, 48, 0xffu);
+}
+
+// first position whose top `bits` hash bits are >= b, for b = 0 .. 2^bits (keys grouped by those bits)
+__global__ void rs_part_bounds_kernel(const uint64_t* __restrict__ keys, uint64_t n, int bits, uint64_t* __restrict__ bounds) {
+  uint64_t b = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (b > (1ull << bits)) return;
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) >> 1;
+    if (((keys[mid] * kPartitionMult) >> (64 - bits)) < b) lo = mid + 1; else hi = mid;
+  }
+  bounds[b] = lo;
 }
 
 // pass 1 alone: instances grouped by hash bits 56..63 in keys_out, bucket starts (257) on the host
@@ -909,7 +941,7 @@ int radix_partition_first_reads(bg_ctx* ctx, const bg_reads* reads, int k, uint6
                                 uint64_t* h_starts) {
   for (int b = 0; b <= RS_BINS; ++b) h_starts[b] = 0;
   if (!n) return BG_OK;
-  if (n < (1ull << 32)) return radix_partition_first_reads_impl<uint32_t>(ctx, reads, k, n, keys_out, h_starts);
+  if (use_off32(n)) return radix_partition_first_reads_impl<uint32_t>(ctx, reads, k, n, keys_out, h_starts);
   return radix_partition_first_reads_impl<uint64_t>(ctx, reads, k, n, keys_out, h_starts);
 }
 
@@ -917,12 +949,27 @@ int radix_partition_first_reads(bg_ctx* ctx, const bg_reads* reads, int k, uint6
 int radix_partition_hash16_reads(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t n, uint64_t* keys_a,
                                  uint64_t* keys_b) {
   if (!n) return BG_OK;
-  if (n < (1ull << 32)) return radix_partition_hash16_reads_impl<uint32_t>(ctx, reads, k, n, keys_a, keys_b);
+  if (use_off32(n)) return radix_partition_hash16_reads_impl<uint32_t>(ctx, reads, k, n, keys_a, keys_b);
   return radix_partition_hash16_reads_impl<uint64_t>(ctx, reads, k, n, keys_a, keys_b);
 }
 
+// Keys grouped by 16 hash bits (kin) -> grouped by 16 + extra_bits (kout), extra_bits in 1..8.
+int radix_partition_hash_refine(bg_ctx* ctx, uint64_t* kin, uint64_t* kout, uint64_t n, int extra_bits) {
+  if (!n) return BG_OK;
+  DevBuf<uint64_t> bounds;
+  BG_TRY(bounds.alloc(ctx, 65537));
+  rs_part_bounds_kernel<<<cdiv(65537, 256), 256, 0, ctx->stream>>>(kin, n, 16, bounds.p);
+  BG_LAUNCH_CHECK();
+  std::vector<uint64_t> h(65537);
+  BG_HIP(hipMemcpyAsync(h.data(), bounds.p, 65537 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  const uint32_t dmask = (1u << extra_bits) - 1;
+  if (use_off32(n)) return radix_partition_segmented<uint32_t>(ctx, kin, kout, n, 65536, h.data(), 48 - extra_bits, dmask);
+  return radix_partition_segmented<uint64_t>(ctx, kin, kout, n, 65536, h.data(), 48 - extra_bits, dmask);
+}
+
 int radix_partition_hash16(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, bool* in_b) {
-  if (n < (1ull << 32)) return radix_partition_hash16_impl<uint32_t>(ctx, keys_a, keys_b, n, in_b);
+  if (use_off32(n)) return radix_partition_hash16_impl<uint32_t>(ctx, keys_a, keys_b, n, in_b);
   return radix_partition_hash16_impl<uint64_t>(ctx, keys_a, keys_b, n, in_b);
 }
 
