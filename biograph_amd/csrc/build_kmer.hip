@@ -850,7 +850,9 @@ int kmerset_sort(bg_ctx* ctx, bg_kmerset* ks) {
 int kmer_hash_build_impl(bg_ctx* ctx, bg_kmerset* ks, const bg_reads* reads) {
   const uint64_t nkept = ks->size;
   int lg = 10;
-  while ((1ull << lg) < 2 * nkept) ++lg;
+  // load factor <= 0.7 (8-slot buckets keep chains short) rather than <= 0.5: half the table, which matters
+  // beyond 2 GiB where random probes fall off the TLB reach (tools/probe_rate.hip: 55 -> 22 G probes/s at 4 GiB)
+  while ((1ull << lg) * 7 < nkept * 10) ++lg;
   ks->log2cap = lg;
   BG_TRY(ks->slots.alloc(ctx, 1ull << lg));
   BG_HIP(hipMemsetAsync(ks->slots.p, 0xff, (1ull << lg) * 8, ctx->stream));

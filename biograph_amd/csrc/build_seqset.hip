@@ -669,7 +669,9 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
     BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, n_o, &head_pos, &nheads));
   }
   int lg = 10;
-  while ((1ull << lg) < 2 * nheads) ++lg;
+  // load factor <= 0.7 (8-slot buckets keep chains short) rather than <= 0.5: half the table, which matters
+  // beyond 2 GiB where random probes fall off the TLB reach (tools/probe_rate.hip: 55 -> 22 G probes/s at 4 GiB)
+  while ((1ull << lg) * 7 < nheads * 10) ++lg;
   DevBuf<uint64_t> slots;
   DevBuf<uint32_t> vals;
   BG_TRY(slots.alloc(ctx, 1ull << lg));
