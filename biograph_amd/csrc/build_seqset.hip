@@ -315,40 +315,47 @@ __global__ void k_flag_subset_ties(const uint32_t* __restrict__ gid, const uint6
 // ------------------------------------------------------------------------------------------------
 // dedup + arrays
 
-// sorted order -> contiguous keys/len
-__global__ void k_gather_records(const uint64_t* __restrict__ rec, const uint8_t* __restrict__ rlen,
-                                 const uint32_t* __restrict__ sidx, uint64_t n, int W, uint64_t* __restrict__ skeys,
-                                 uint8_t* __restrict__ slen) {
-  uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (g >= n * uint64_t(W)) return;
-  uint64_t i = g / uint64_t(W);
-  int w = int(g - i * uint64_t(W));
-  uint32_t r = sidx[i];
-  skeys[g] = rec[uint64_t(r) * W + w];
-  if (w == 0) slen[i] = rlen[r];
-}
-
-// lcp with the predecessor, and "is a prefix of (or equal to) the successor" -> dropped
-// (expand.cpp:19-48 skip_dups)
-__global__ void k_lcp_and_keep(const uint64_t* __restrict__ skeys, const uint8_t* __restrict__ slen, uint64_t n, int W,
-                               uint8_t* __restrict__ lcp_prev, uint8_t* __restrict__ keep,
-                               uint32_t* __restrict__ err) {
-  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t* a = skeys + i * W;
-  int alen = slen[i];
+// Sorted order -> contiguous keys/len, and in the same pass (the tile is in LDS anyway) the lcp with the
+// predecessor and "is a prefix of (or equal to) the successor" -> dropped (expand.cpp:19-48 skip_dups).
+// One block = 256 sorted positions + one halo record on each side.
+constexpr int kGatherTile = 256;
+__global__ __launch_bounds__(kGatherTile) void k_gather_lcp_keep(
+    const uint64_t* __restrict__ rec, const uint8_t* __restrict__ rlen, const uint32_t* __restrict__ sidx, uint64_t n,
+    int W, uint64_t* __restrict__ skeys, uint8_t* __restrict__ slen, uint8_t* __restrict__ lcp_prev,
+    uint8_t* __restrict__ keep, uint32_t* __restrict__ err) {
+  extern __shared__ uint64_t tile[];  // (kGatherTile + 2) * W words, then the lengths
+  uint8_t* tlen = reinterpret_cast<uint8_t*>(tile + (kGatherTile + 2) * W);
+  const uint64_t b0 = uint64_t(blockIdx.x) * kGatherTile;
+  for (int g = threadIdx.x; g < (kGatherTile + 2) * W; g += kGatherTile) {
+    int i = g / W, w = g - i * W;
+    uint64_t pos = b0 + uint64_t(i) - 1;  // wraps for the missing predecessor of position 0
+    if (pos < n) {
+      uint32_t r = sidx[pos];
+      uint64_t v = rec[uint64_t(r) * W + w];
+      tile[g] = v;
+      bool own = i >= 1 && i <= kGatherTile;
+      if (own) skeys[pos * W + w] = v;
+      if (w == 0) {
+        uint8_t l = rlen[r];
+        tlen[i] = l;
+        if (own) slen[pos] = l;
+      }
+    }
+  }
+  __syncthreads();
+  const uint64_t pos = b0 + threadIdx.x;
+  if (pos >= n) return;
+  const uint64_t* a = tile + (threadIdx.x + 1) * W;
+  const int alen = tlen[threadIdx.x + 1];
   int lp = 0;
-  if (i > 0) {
-    lp = key_lcp(skeys + (i - 1) * W, slen[i - 1], a, alen, W);
-    if (key_compare(skeys + (i - 1) * W, slen[i - 1], a, alen, W) > 0) atomicOr(err, 1u);  // not sorted
+  if (pos > 0) {
+    lp = key_lcp(a - W, tlen[threadIdx.x], a, alen, W);
+    if (key_compare(a - W, tlen[threadIdx.x], a, alen, W) > 0) atomicOr(err, 1u);  // not sorted
   }
-  lcp_prev[i] = uint8_t(lp);
+  lcp_prev[pos] = uint8_t(lp);
   bool drop = false;
-  if (i + 1 < n) {
-    int ln = key_lcp(a, alen, skeys + (i + 1) * W, slen[i + 1], W);
-    drop = (ln == alen);
-  }
-  keep[i] = drop ? 0 : 1;
+  if (pos + 1 < n) drop = key_lcp(a, alen, a + W, tlen[threadIdx.x + 2], W) == alen;
+  keep[pos] = drop ? 0 : 1;
 }
 
 // entry e = kept position p: sizes, shared = min lcp over the dropped run before p (lcp is
@@ -869,11 +876,11 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
     DevBuf<uint32_t> kept_pos;
     if (n_rec) {
       ctx->tic("entries_dedup");
-      k_gather_records<<<cdiv(n_rec * W, 256), 256, 0, ctx->stream>>>(rec.p, rlen.p, sidx.p, n_rec, W, skeys.p, slen.p);
+      const size_t lds = size_t(kGatherTile + 2) * W * 8 + kGatherTile + 2;
+      k_gather_lcp_keep<<<cdiv(n_rec, kGatherTile), kGatherTile, lds, ctx->stream>>>(rec.p, rlen.p, sidx.p, n_rec, W, skeys.p,
+                                                                                  slen.p, lcp_prev.p, keep.p, err.p);
       BG_LAUNCH_CHECK();
-      k_lcp_and_keep<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(skeys.p, slen.p, n_rec, W, lcp_prev.p, keep.p, err.p);
-      BG_LAUNCH_CHECK();
-      ctx->toc(n_rec * (W * 8 * 4 + 8));
+      ctx->toc(n_rec * (W * 8 * 2 + 8));
     }
     rec.reset(); rlen.reset(); sidx.reset();
     BG_TRY(compact_flagged<uint32_t>(ctx, keep.p, n_rec, &kept_pos, &n_ent));

@@ -45,6 +45,8 @@ int bg_ctx::alloc(size_t bytes, void** out) {
     free_blocks.erase(it);
     cached_bytes -= bytes;
   } else {
+    static const bool trace = getenv("BG_ALLOC_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[bg alloc] hipMalloc %zu MiB (live %zu MiB, cached %zu MiB)\n", bytes >> 20, live_bytes >> 20, cached_bytes >> 20);
     hipError_t e = hipMalloc(out, bytes);
     if (e != hipSuccess && cached_bytes) {  // give cached blocks back and retry once
       trim();
