@@ -267,8 +267,14 @@ __global__ __launch_bounds__(KC_THREADS) void k_kmer_count_lds(const uint64_t* _
     uint32_t slot = uint32_t((k * kPartitionMult) >> (64 - bucket_bits - log2cap)) & mask;  // hash bits below the bucket's
     uint32_t probes = 0;
     for (;;) {
-      unsigned long long old = atomicCAS(&tkeys[slot], ~0ull, k);
-      if (old == ~0ull || old == k) { atomicAdd(&tcnt[slot], 1u); break; }
+      // LDS atomics run at about a lane per clock: most occurrences find their key already in place, and a
+      // plain read (full rate) spares them the compare-and-swap
+      unsigned long long cur = __atomic_load_n(&tkeys[slot], __ATOMIC_RELAXED);
+      if (cur == ~0ull) {
+        cur = atomicCAS(&tkeys[slot], ~0ull, k);
+        if (cur == ~0ull) cur = k;
+      }
+      if (cur == k) { atomicAdd(&tcnt[slot], 1u); break; }
       slot = (slot + 1) & mask;
       if (++probes >= max_probe) { s_over = 1; break; }
     }
@@ -718,6 +724,8 @@ static int kmer_lds_log2cap() {
 // Default counting path: hash partition (2 radix passes on 16 hash bits) + one LDS counting pass.
 // ka = instances (clobbered), kb = scratch, both N.  Output k-mers are sorted ascending.
 // partitioned = the instances already sit in kb grouped by 16 hash bits (radix_partition_hash16_reads)
+int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32_t min_count, bg_kmerset* ks, bool* done);
+
 int kmer_count_keys_impl(bg_ctx* ctx, uint64_t* ka, uint64_t* kb, uint64_t N, uint32_t min_count, bg_kmerset* ks,
                          bool partitioned = false) {
   ks->distinct = 0;
@@ -885,7 +893,14 @@ extern "C" int bg_kmer_count(bg_ctx* ctx, const bg_reads* reads, int k, uint32_t
   uint64_t N = 0;
   BG_TRY(kmer_offsets(ctx, reads, k, &koff, &N));
   ks->instances = N;
+  // default: super-k-mer path (kmer_skm.hip); BG_KMER_SKM=0 keeps the instance path below (A/B measurements,
+  // and what k < 14 falls back to)
+  bool done = false;
   {
+    const char* skm = getenv("BG_KMER_SKM");
+    if (!(skm && skm[0] == '0')) BG_TRY(kmer_count_skm(ctx, reads, k, N, min_count, ks.get(), &done));
+  }
+  if (!done) {
     DevBuf<uint64_t> ka, kb;
     BG_TRY(ka.alloc(ctx, N));
     BG_TRY(kb.alloc(ctx, N));

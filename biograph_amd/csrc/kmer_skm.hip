@@ -1,0 +1,622 @@
+// kmer_skm.hip — canonical k-mer counting (S2) through super-k-mers, for gfx950.
+//
+// Same result as the instance path in build_kmer.hip (rows B1-B3 of SURVEY.md §8a: kmer_counter.h:275-326,
+// kmer_count_table.h:54-103, kmerize_bf.cpp:290-294) with a fifth of its memory traffic.  The instance path
+// moves every k-mer occurrence (8 bytes) through two partition passes and the counting pass; here the unit
+// that moves is a *super-k-mer*: a run of consecutive windows of one read that share their minimiser (the
+// smallest order value over the canonical 12-mers of the window), stored as its bases (2 bits each) in one
+// 16-byte record.  A window and its reverse complement have the same minimiser, so all occurrences of a
+// canonical k-mer meet in the bucket its minimiser hashes to; a bucket is counted in an LDS table exactly as
+// before, the windows being unrolled from the records on the fly.  At k = 30 a record carries ~10 windows:
+// 16 bytes instead of 80.
+//
+// Record (two 64-bit words): a = bases 0..31; b = bases 32..50 (38 bits) | bucket (21 bits) | windows-1 (5 bits).
+// A bucket whose distinct k-mers overflow the LDS table is unrolled into plain instances and counted by the
+// sort-based path (kmer_count_keys_sort_impl), so the result never depends on how minimisers spread.
+#include "bg_device_funcs.h"
+#include "bg_internal.h"
+
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace bg {
+
+int kmer_count_keys_sort_impl(bg_ctx* ctx, uint64_t* ka, uint64_t* kb, uint64_t N, uint32_t min_count, bg_kmerset* ks);
+
+constexpr int SK_M = 12;          // minimiser length
+constexpr int SK_THREADS = 256;
+constexpr int SK_BINS = 256;
+constexpr int SK_CAP = 1536;      // records one tile can stage in LDS
+constexpr int SK_TARGET = 1024;   // records a tile is sized for (expected)
+constexpr uint32_t SK_INF = 0xffffffffu;
+constexpr int SK_BUCKET_FIELD = 21;
+constexpr int SK_WORDS = 12;       // 8 words of a 255-base read + zero padding for the look-ahead fetches
+
+struct __attribute__((aligned(16))) SkRec { uint64_t a, b; };
+
+BG_HD int sk_windows(uint64_t b) { return int(b & 31) + 1; }
+BG_HD uint32_t sk_bucket(uint64_t b) { return uint32_t(b >> 5) & ((1u << SK_BUCKET_FIELD) - 1); }
+// order of a canonical m-mer: a fixed pseudo-random permutation, so that low-complexity m-mers are not
+// everybody's minimiser; 31 bits, SK_INF marks "holds an N"
+BG_HD uint32_t sk_order(uint32_t canon) {
+  uint32_t x = canon * 0x9E3779B1u;
+  x ^= x >> 15;
+  return x >> 1;
+}
+BG_HD uint32_t sk_bucket_of(uint32_t order) { return (order * 0x85EBCA6Bu) >> (32 - SK_BUCKET_FIELD); }
+
+struct SkSource {
+  const uint64_t* words;
+  const uint32_t* nmask;
+  const uint16_t* len;
+  uint64_t n_reads;
+  int W, k, reads_per_tile, nmax;
+};
+
+__device__ __forceinline__ uint32_t sk_block_excl_scan(uint32_t v, uint32_t* sm, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) sm[wave] = x;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += sm[w];
+  *total = sm[0] + sm[1] + sm[2] + sm[3];
+  return base + x - v;
+}
+
+__device__ __forceinline__ uint64_t sk_readlane64(uint64_t v, int l) {
+  const uint32_t lo = __builtin_amdgcn_readlane(int(uint32_t(v)), l), hi = __builtin_amdgcn_readlane(int(uint32_t(v >> 32)), l);
+  return (uint64_t(hi) << 32) | lo;
+}
+// LDS written by some lanes of a wave, read by others: keep the compiler from moving accesses across
+__device__ __forceinline__ void sk_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Calls f(a, b) for every super-k-mer record of reads [r_lo, r_hi).  Wave w takes reads r_lo + w, + 4, ...
+// Windows holding an N (kmer_counter.h:306-311) belong to no record.  A chunk of 64 lanes computes the order
+// values of 64 consecutive 12-mers and, by log-step shuffles, the minimisers of 65 - (k - 11) windows; the
+// last of them only serves as look-ahead, so chunks advance by 64 - (k - 11).  sw / sn = this wave's LDS copy
+// of the read's words and N masks.  The lane of a
+// record's LAST window emits it: it needs the start of its run (a bit scan, or a carry from earlier chunks)
+// and whether the next window starts a new one.
+template <class F>
+__device__ __forceinline__ void tile_skms(const SkSource& src, uint64_t r_lo, uint64_t r_hi, uint64_t* sw, uint32_t* sn, F f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int W = src.W, k = src.k, w = src.k - SK_M + 1, nmax = src.nmax;
+  const int S = 65 - w, stride = S - 1;
+  int pw = 1;
+  while (pw * 2 <= w) pw *= 2;
+  const uint32_t rcp = (65536u + uint32_t(nmax) - 1) / uint32_t(nmax);  // x / nmax = (x * rcp) >> 16 for x < 400
+  for (uint64_t i = r_lo + wave; i < r_hi; i += SK_THREADS / 64) {
+    const int L = src.len[i];
+    if (L < k) continue;  // wave-uniform
+    const int nk = L - k + 1, nm = L - SK_M + 1;
+    sk_wave_sync();  // the previous read's words are no longer needed
+    if (lane < SK_WORDS) {  // the read's words (zero padded) where every lane can fetch the ones it needs
+      sw[lane] = lane < W ? src.words[i * W + lane] : 0;
+      sn[lane] = lane < W ? src.nmask[i * W + lane] : 0;
+    }
+    sk_wave_sync();
+    uint32_t carry_mz = SK_INF;
+    int carry_rs = -1;
+    for (int base = 0; base < nk; base += stride) {
+      const int p = base + lane;
+      const int q = p >> 5, r = p & 31;
+      const uint64_t w0 = sw[q], w1 = sw[q + 1];
+      const uint32_t n0 = sn[q], n1 = sn[q + 1];
+      const uint64_t x = r ? ((w0 << (2 * r)) | (w1 >> (64 - 2 * r))) : w0;
+      const uint32_t nw = r ? ((n0 << r) | (n1 >> (32 - r))) : n0;
+      uint32_t m = SK_INF;
+      if (p < nm && (nw >> (32 - SK_M)) == 0) {
+        bool fl;
+        m = sk_order(uint32_t(kmer_canon(x >> (64 - 2 * SK_M), SK_M, &fl)));
+      }
+      // minimum over the w order values from this lane on: log steps (lanes >= S end up with partial windows
+      // and are not used)
+      for (int st = 1; st < pw; st <<= 1) {
+        const uint32_t t = __shfl_down(m, st, 64);
+        m = t < m ? t : m;
+      }
+      if (w > pw) {
+        const uint32_t t = __shfl_down(m, w - pw, 64);
+        m = t < m ? t : m;
+      }
+      const bool inwin = lane < S && p < nk;
+      const bool valid = inwin && (nw >> (32 - k)) == 0;
+      const uint32_t mz = valid ? m : SK_INF;  // a valid window's minimiser is never SK_INF
+      uint32_t prev = __shfl_up(mz, 1, 64);
+      if (lane == 0) prev = carry_mz;
+      // boundary = window that starts a run of equal minimisers, or holds an N
+      const uint64_t bm = __ballot(inwin && (!valid || prev != mz));
+      const uint64_t le = bm & (~0ull >> (63 - lane));
+      const int rs = le ? base + 63 - __clzll((long long)le) : carry_rs;  // start of this window's run, if valid
+      const uint32_t dd = uint32_t(p - rs);
+      const uint32_t full = ((dd + 1) * rcp) >> 16;  // records of nmax windows ending at or before this one
+      const bool next_starts = p + 1 >= nk || ((bm >> ((lane + 1) & 63)) & 1);
+      const bool emit = valid && lane < stride && (next_starts || full * uint32_t(nmax) == dd + 1);
+      if (emit) {
+        const int s0 = rs + int(((dd * rcp) >> 16) * uint32_t(nmax));  // the record's first window
+        const int qs = s0 >> 5, rr = s0 & 31;
+        const uint64_t r0 = sw[qs], r1 = sw[qs + 1], r2 = sw[qs + 2];
+        const int n = p - s0 + 1;
+        const int nbases = n + k - 1;  // <= 51
+        uint64_t a = rr ? ((r0 << (2 * rr)) | (r1 >> (64 - 2 * rr))) : r0;
+        uint64_t bw = rr ? ((r1 << (2 * rr)) | (r2 >> (64 - 2 * rr))) : r1;
+        if (nbases < 32) a &= ~0ull << (64 - 2 * nbases);
+        bw = nbases > 32 ? (bw & (~0ull << (64 - 2 * (nbases - 32)))) : 0ull;
+        f(a, bw | (uint64_t(sk_bucket_of(mz)) << 5) | uint64_t(n - 1));
+      }
+      carry_mz = uint32_t(__builtin_amdgcn_readlane(int(mz), stride - 1));
+      const uint64_t lo = bm & ((1ull << stride) - 1);
+      if (lo) carry_rs = base + 63 - __clzll((long long)lo);
+    }
+  }
+}
+
+// Level 0: the records of a tile of reads are staged in LDS and appended to `out` as one block (one global
+// atomic per tile; the order of tiles is whatever the scheduler makes it — only grouping matters downstream).
+__global__ __launch_bounds__(SK_THREADS) void sk_generate_kernel(SkSource src, SkRec* __restrict__ out, uint64_t cap,
+                                                                 unsigned long long* __restrict__ cursor) {
+  __shared__ SkRec srec[SK_CAP];
+  __shared__ uint64_t sw[SK_THREADS / 64][SK_WORDS];
+  __shared__ uint32_t sn[SK_THREADS / 64][SK_WORDS];
+  __shared__ uint32_t s_cnt;
+  __shared__ unsigned long long s_base;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  const uint64_t r_lo = uint64_t(blockIdx.x) * src.reads_per_tile;
+  const uint64_t r_hi = r_lo + src.reads_per_tile < src.n_reads ? r_lo + src.reads_per_tile : src.n_reads;
+  tile_skms(src, r_lo, r_hi, sw[tid >> 6], sn[tid >> 6], [&](uint64_t a, uint64_t b) {
+    const uint32_t s = atomicAdd(&s_cnt, 1u);
+    if (s < uint32_t(SK_CAP)) {
+      srec[s].a = a;
+      srec[s].b = b;
+    } else {  // the staging area is full (minimisers changing at nearly every window): one record at a time
+      const unsigned long long g = atomicAdd(cursor, 1ull);
+      if (g < cap) {
+        SkRec r;
+        r.a = a;
+        r.b = b;
+        out[g] = r;
+      }
+    }
+  });
+  __syncthreads();
+  const uint32_t total = s_cnt < uint32_t(SK_CAP) ? s_cnt : uint32_t(SK_CAP);
+  if (tid == 0) s_base = atomicAdd(cursor, (unsigned long long)total);
+  __syncthreads();
+  const uint64_t base = s_base;
+  for (uint32_t i = tid; i < total; i += SK_THREADS)
+    if (base + i < cap) out[base + i] = srec[i];
+}
+
+// ---- further levels: one unstable pass over records already grouped into segments ------------------
+constexpr int SK2_ITEMS = 8;
+constexpr int SK2_TILE = SK_THREADS * SK2_ITEMS;
+struct SkSegs {
+  const uint64_t* seg_rec0;   // S+1 record offsets
+  const uint32_t* seg_tile0;  // S+1 tile offsets
+  int nseg;
+};
+
+__device__ __forceinline__ void sk_locate(const SkSegs& sg, uint32_t tile, uint64_t* lo, uint64_t* hi, uint64_t* hist_base,
+                                          uint32_t* tiles_in_seg, uint32_t* tile_in_seg) {
+  int a = 0, b = sg.nseg;  // last segment with seg_tile0 <= tile
+  while (b - a > 1) {
+    int m = (a + b) >> 1;
+    if (sg.seg_tile0[m] <= tile) a = m; else b = m;
+  }
+  const uint32_t t0 = sg.seg_tile0[a];
+  *tiles_in_seg = sg.seg_tile0[a + 1] - t0;
+  *tile_in_seg = tile - t0;
+  *lo = sg.seg_rec0[a] + uint64_t(tile - t0) * SK2_TILE;
+  const uint64_t end = sg.seg_rec0[a + 1];
+  *hi = *lo + SK2_TILE < end ? *lo + SK2_TILE : end;
+  *hist_base = uint64_t(t0) * SK_BINS;
+}
+
+__global__ __launch_bounds__(SK_THREADS) void sk_part_hist_kernel(const SkRec* __restrict__ recs, SkSegs sg, int shift,
+                                                                  uint32_t dmask, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[SK_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  uint64_t lo, hi, hbase;
+  uint32_t nt, ti;
+  sk_locate(sg, blockIdx.x, &lo, &hi, &hbase, &nt, &ti);
+#pragma unroll
+  for (int it = 0; it < SK2_ITEMS; ++it) {
+    const uint64_t idx = lo + uint64_t(it) * SK_THREADS + threadIdx.x;
+    if (idx < hi) atomicAdd(&h[(sk_bucket(recs[idx].b) >> shift) & dmask], 1u);
+  }
+  __syncthreads();
+  hist[hbase + uint64_t(threadIdx.x) * nt + ti] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(SK_THREADS) void sk_part_scatter_kernel(const SkRec* __restrict__ in, SkRec* __restrict__ out,
+                                                                     SkSegs sg, int shift, uint32_t dmask,
+                                                                     const uint64_t* __restrict__ offs) {
+  __shared__ SkRec srec[SK2_TILE];
+  __shared__ uint32_t h[SK_BINS];
+  __shared__ uint32_t binstart[SK_BINS];
+  __shared__ uint64_t goff[SK_BINS];
+  __shared__ uint32_t scan_sm[4];
+  const int tid = threadIdx.x;
+  h[tid] = 0;
+  uint64_t lo, hi, hbase;
+  uint32_t nt, ti;
+  sk_locate(sg, blockIdx.x, &lo, &hi, &hbase, &nt, &ti);
+  __syncthreads();
+  SkRec rec[SK2_ITEMS];
+  uint16_t rnk[SK2_ITEMS];
+#pragma unroll
+  for (int it = 0; it < SK2_ITEMS; ++it) {
+    const uint64_t idx = lo + uint64_t(it) * SK_THREADS + tid;
+    if (idx < hi) {
+      rec[it] = in[idx];
+      rnk[it] = uint16_t(atomicAdd(&h[(sk_bucket(rec[it].b) >> shift) & dmask], 1u));
+    } else {
+      rec[it].a = 0;
+      rec[it].b = 0;
+      rnk[it] = 0;
+    }
+  }
+  __syncthreads();
+  {
+    uint32_t dummy;
+    const uint32_t ex = sk_block_excl_scan(h[tid], scan_sm, &dummy);
+    binstart[tid] = ex;
+    goff[tid] = offs[hbase + uint64_t(tid) * nt + ti] - ex;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < SK2_ITEMS; ++it) {
+    const uint64_t idx = lo + uint64_t(it) * SK_THREADS + tid;
+    if (idx < hi) srec[binstart[(sk_bucket(rec[it].b) >> shift) & dmask] + rnk[it]] = rec[it];
+  }
+  __syncthreads();
+  const uint32_t cnt = uint32_t(hi - lo);
+  for (uint32_t i = tid; i < cnt; i += SK_THREADS) {
+    const SkRec r = srec[i];
+    out[goff[(sk_bucket(r.b) >> shift) & dmask] + i] = r;
+  }
+}
+
+// first record whose leading `bits` bucket bits are >= v, for v = 0 .. 2^bits (records grouped by those bits)
+__global__ void sk_bounds_kernel(const SkRec* __restrict__ recs, uint64_t n, int bits, uint64_t* __restrict__ bounds) {
+  const uint64_t v = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (v > (1ull << bits)) return;
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if ((sk_bucket(recs[mid].b) >> (SK_BUCKET_FIELD - bits)) < v) lo = mid + 1; else hi = mid;
+  }
+  bounds[v] = lo;
+}
+
+__global__ void sk_bucket_starts_kernel(const uint64_t* __restrict__ offs, uint32_t ntiles, uint64_t n,
+                                        uint64_t* __restrict__ starts) {
+  const int b = threadIdx.x;
+  starts[b] = offs[uint64_t(b) * ntiles];
+  if (b == 0) starts[SK_BINS] = n;
+}
+
+// ---- counting: one workgroup per bucket, windows unrolled from the records into an LDS table ---------
+constexpr int SKC_THREADS = 1024;
+
+__global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* __restrict__ recs,
+                                                                   const uint64_t* __restrict__ bounds, uint32_t cap,
+                                                                   int k, uint32_t min_count, uint64_t out_cap,
+                                                                   uint64_t* __restrict__ out_kmers,
+                                                                   uint32_t* __restrict__ out_counts,
+                                                                   unsigned long long* __restrict__ out_n,
+                                                                   unsigned long long* __restrict__ distinct_total,
+                                                                   uint8_t* __restrict__ overflow) {
+  extern __shared__ __align__(16) unsigned char skc_smem[];
+  unsigned long long* tkeys = reinterpret_cast<unsigned long long*>(skc_smem);
+  uint32_t* tcnt = reinterpret_cast<uint32_t*>(skc_smem + size_t(cap) * 8);
+  __shared__ uint32_t s_over, s_kept, s_distinct, s_cursor;
+  __shared__ unsigned long long s_base;
+  const uint32_t bucket = blockIdx.x;
+  const uint64_t lo = bounds[bucket], hi = bounds[bucket + 1];
+  if (lo == hi) return;  // block-uniform
+  for (uint32_t i = threadIdx.x; i < cap; i += SKC_THREADS) { tkeys[i] = ~0ull; tcnt[i] = 0; }
+  if (threadIdx.x == 0) { s_over = 0; s_kept = 0; s_distinct = 0; s_cursor = 0; }
+  __syncthreads();
+  const uint32_t max_probe = cap < 256u ? cap : 256u;
+  const uint64_t kmask = ~(~0ull << (2 * k));
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += SKC_THREADS) {
+    const SkRec r = recs[i];
+    const int n = sk_windows(r.b);
+    uint64_t fwd = r.a >> (64 - 2 * k);
+    uint64_t rc = kmer_revcomp(fwd, k);
+    for (int t = 0;; ++t) {
+      const unsigned long long key = rc < fwd ? rc : fwd;
+      // 32-bit multiplies run at quarter rate: fold the key to 32 bits, one multiply, one multiply-high
+      uint32_t slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
+      uint32_t probes = 0;
+      for (;;) {
+        // LDS atomics run at about a lane per clock: most occurrences find their key already in place, and a
+        // plain read (full rate) spares them the compare-and-swap
+        unsigned long long cur = __atomic_load_n(&tkeys[slot], __ATOMIC_RELAXED);
+        if (cur == ~0ull) {
+          cur = atomicCAS(&tkeys[slot], ~0ull, key);
+          if (cur == ~0ull) cur = key;
+        }
+        if (cur == key) { atomicAdd(&tcnt[slot], 1u); break; }
+        slot = slot + 1 == cap ? 0 : slot + 1;
+        if (++probes >= max_probe) { s_over = 1; break; }
+      }
+      if (t + 1 >= n) break;
+      const int idx = k + t;  // the base that enters the window
+      const uint64_t base = idx < 32 ? (r.a >> (62 - 2 * idx)) & 3 : (r.b >> (62 - 2 * (idx - 32))) & 3;
+      fwd = ((fwd << 2) | base) & kmask;
+      rc = (rc >> 2) | ((3 - base) << (2 * (k - 1)));
+    }
+  }
+  __syncthreads();
+  if (s_over) {
+    if (threadIdx.x == 0) overflow[bucket] = 1;
+    return;
+  }
+  uint32_t my_kept = 0, my_distinct = 0;
+  for (uint32_t i = threadIdx.x; i < cap; i += SKC_THREADS) {
+    if (tkeys[i] != ~0ull) {
+      ++my_distinct;
+      if (tcnt[i] >= min_count) ++my_kept;
+    }
+  }
+  if (my_distinct) atomicAdd(&s_distinct, my_distinct);
+  if (my_kept) atomicAdd(&s_kept, my_kept);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_base = s_kept ? atomicAdd(out_n, (unsigned long long)s_kept) : 0ull;
+    if (s_distinct) atomicAdd(distinct_total, (unsigned long long)s_distinct);
+  }
+  __syncthreads();
+  if (!s_kept) return;
+  for (uint32_t i = threadIdx.x; i < cap; i += SKC_THREADS) {
+    if (tkeys[i] != ~0ull && tcnt[i] >= min_count) {
+      const uint64_t o = s_base + atomicAdd(&s_cursor, 1u);
+      if (o < out_cap) { out_kmers[o] = tkeys[i]; out_counts[o] = tcnt[i]; }
+    }
+  }
+}
+
+// windows of records [lo, lo + cnt) as plain canonical instances, nmax slots per record (unused slots keep
+// the all-ones sentinel the sort-based count skips)
+__global__ void sk_expand_kernel(const SkRec* __restrict__ recs, uint64_t lo, uint64_t cnt, int k, int nmax,
+                                 uint64_t* __restrict__ keys) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  const SkRec r = recs[lo + i];
+  const int n = sk_windows(r.b);
+  const uint64_t kmask = ~(~0ull << (2 * k));
+  uint64_t fwd = r.a >> (64 - 2 * k);
+  uint64_t rc = kmer_revcomp(fwd, k);
+  for (int t = 0; t < n; ++t) {
+    keys[i * nmax + t] = rc < fwd ? rc : fwd;
+    const int idx = k + t;
+    const uint64_t base = idx < 32 ? (r.a >> (62 - 2 * idx)) & 3 : (r.b >> (62 - 2 * (idx - 32))) & 3;
+    fwd = ((fwd << 2) | base) & kmask;
+    rc = (rc >> 2) | ((3 - base) << (2 * (k - 1)));
+  }
+}
+
+static int sk_partition_segmented(bg_ctx* ctx, const SkRec* in, SkRec* out, uint64_t n, uint32_t nseg,
+                                  const uint64_t* h_rec0, int shift, uint32_t dmask) {
+  std::vector<uint32_t> h_tile(size_t(nseg) + 1, 0);
+  uint64_t t = 0;
+  for (uint32_t b = 0; b < nseg; ++b) {
+    h_tile[b] = uint32_t(t);
+    t += (h_rec0[b + 1] - h_rec0[b] + SK2_TILE - 1) / SK2_TILE;
+  }
+  if (t >= (1ull << 31)) { set_error("partition of %llu super-k-mers needs too many tiles", (unsigned long long)n); return BG_EINVAL; }
+  h_tile[nseg] = uint32_t(t);
+  const uint32_t ntiles = uint32_t(t);
+  if (!ntiles) return BG_OK;
+  DevBuf<uint32_t> hist, seg_tile;
+  DevBuf<uint64_t> offs, seg_rec;
+  BG_TRY(hist.alloc(ctx, size_t(SK_BINS) * ntiles));
+  BG_TRY(offs.alloc(ctx, size_t(SK_BINS) * ntiles));
+  BG_TRY(seg_rec.alloc(ctx, size_t(nseg) + 1));
+  BG_TRY(seg_tile.alloc(ctx, size_t(nseg) + 1));
+  BG_HIP(hipMemcpyAsync(seg_rec.p, h_rec0, (size_t(nseg) + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  BG_HIP(hipMemcpyAsync(seg_tile.p, h_tile.data(), (size_t(nseg) + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  SkSegs sg{seg_rec.p, seg_tile.p, int(nseg)};
+  ctx->tic("skm_part_hist");
+  sk_part_hist_kernel<<<ntiles, SK_THREADS, 0, ctx->stream>>>(in, sg, shift, dmask, hist.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n * 16);
+  ctx->tic("radix_scan");
+  BG_TRY(exclusive_scan_u32_to_u64(ctx, hist.p, offs.p, uint64_t(SK_BINS) * ntiles, nullptr));
+  ctx->toc(uint64_t(SK_BINS) * ntiles * 12);
+  ctx->tic("skm_part_scatter");
+  sk_part_scatter_kernel<<<ntiles, SK_THREADS, 0, ctx->stream>>>(in, out, sg, shift, dmask, offs.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n * 32);
+  return BG_OK;
+}
+
+// slots of a bucket's LDS table: 6400 x 12 bytes lets two 1024-thread workgroups share a CU's 160 KB
+// (BG_KMER_LDS_LOG2CAP shrinks the table: tests force the overflow path with it)
+static uint32_t sk_lds_slots() {
+  const char* e = getenv("BG_KMER_LDS_LOG2CAP");
+  if (!e) return 6400;
+  const int v = atoi(e);
+  return 1u << (v < 1 ? 1 : (v > 13 ? 13 : v));
+}
+
+// Counts the canonical k-mers of `reads` (N windows in all, for sizing) into ks->kmers / counts / distinct.
+// *done = false when this path does not apply (k too small for a 12-base minimiser) and nothing was done.
+int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32_t min_count, bg_kmerset* ks, bool* done) {
+  *done = false;
+  const int maxw = int(reads->max_len) - k + 1;
+  if (k < SK_M + 2 || k > 31 || maxw <= 0 || !N) return BG_OK;
+  const int nmax = std::min(32, 52 - k);
+  const int w = k - SK_M + 1;
+  const double per_read = double(maxw) * 2.0 / double(w + 1) + 1.5;
+  SkSource src{reads->words.p, reads->nmask.p, reads->len.p, reads->n, reads->W, k,
+               std::max(1, int(double(SK_TARGET) / per_read)), nmax};
+  const uint64_t ntiles64 = (reads->n + src.reads_per_tile - 1) / src.reads_per_tile;
+  if (ntiles64 >= (1ull << 31)) return BG_OK;
+  const uint32_t ntiles = uint32_t(ntiles64);
+
+  // level 0: records straight from the packed reads.  Their number is not known beforehand: room for 3x the
+  // expected density (2 / (w + 1) records per window); an input that beats it takes the instance path.
+  const uint64_t cap = std::min<uint64_t>(N, uint64_t(double(N) * 6.0 / double(w + 1)) + reads->n + 1024);
+  DevBuf<SkRec> ra, rb;
+  DevBuf<unsigned long long> cursor;
+  BG_TRY(ra.alloc(ctx, cap));
+  BG_TRY(cursor.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(cursor.p, 0, 8, ctx->stream));
+  ctx->tic("skm_generate");
+  sk_generate_kernel<<<ntiles, SK_THREADS, 0, ctx->stream>>>(src, ra.p, cap, cursor.p);
+  BG_LAUNCH_CHECK();
+  unsigned long long R = 0;
+  BG_HIP(hipMemcpyAsync(&R, cursor.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->toc(R * 16 + reads->n * uint64_t(reads->W) * 12);
+  if (R > cap) return BG_OK;  // *done stays false
+  *done = true;
+  ks->distinct = 0;
+  ks->size = 0;
+  if (!R) {  // every window holds an N
+    BG_TRY(ks->kmers.alloc(ctx, 0));
+    BG_TRY(ks->counts.alloc(ctx, 0));
+    return BG_OK;
+  }
+  BG_TRY(rb.alloc(ctx, R));
+  DevBuf<SkRec> rc;
+  BG_TRY(rc.alloc(ctx, R));
+  // level 1: the top 8 bucket bits
+  std::vector<uint64_t> h_starts(SK_BINS + 1);
+  {
+    const uint64_t whole[2] = {0, R};
+    BG_TRY(sk_partition_segmented(ctx, ra.p, rb.p, R, 1, whole, SK_BUCKET_FIELD - 8, 0xffu));
+    DevBuf<uint64_t> b8;
+    BG_TRY(b8.alloc(ctx, SK_BINS + 1));
+    sk_bounds_kernel<<<cdiv(SK_BINS + 1, 256), 256, 0, ctx->stream>>>(rb.p, R, 8, b8.p);
+    BG_LAUNCH_CHECK();
+    BG_HIP(hipMemcpyAsync(h_starts.data(), b8.p, (SK_BINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  ra.reset();
+
+  // level 2: the next 8 bits inside each of the 256 groups; bigger inputs take up to 5 more bits so that a
+  // bucket stays around 24 k windows (BG_KMER_EXTRA_BITS overrides, for tests)
+  BG_TRY(sk_partition_segmented(ctx, rb.p, rc.p, R, SK_BINS, h_starts.data(), SK_BUCKET_FIELD - 16, 0xffu));
+  int extra = 0;
+  while (extra < SK_BUCKET_FIELD - 16 && (N >> (16 + extra)) > 24000) ++extra;
+  if (const char* e = getenv("BG_KMER_EXTRA_BITS")) extra = std::max(0, std::min(SK_BUCKET_FIELD - 16, atoi(e)));
+  SkRec* part = rc.p;
+  if (extra) {
+    DevBuf<uint64_t> b16;
+    BG_TRY(b16.alloc(ctx, 65537));
+    sk_bounds_kernel<<<cdiv(65537, 256), 256, 0, ctx->stream>>>(rc.p, R, 16, b16.p);
+    BG_LAUNCH_CHECK();
+    std::vector<uint64_t> h(65537);
+    BG_HIP(hipMemcpyAsync(h.data(), b16.p, 65537 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    BG_TRY(sk_partition_segmented(ctx, rc.p, rb.p, R, 65536, h.data(), SK_BUCKET_FIELD - 16 - extra, (1u << extra) - 1));
+    part = rb.p;
+  }
+  const int bucket_bits = 16 + extra;
+  const uint32_t NB = 1u << bucket_bits;
+
+  DevBuf<uint64_t> bounds;
+  DevBuf<uint8_t> overflow;
+  DevBuf<unsigned long long> ctr;  // [0] kept cursor, [1] distinct
+  BG_TRY(bounds.alloc(ctx, uint64_t(NB) + 1));
+  BG_TRY(overflow.alloc(ctx, NB));
+  BG_TRY(ctr.alloc(ctx, 2));
+  BG_HIP(hipMemsetAsync(overflow.p, 0, NB, ctx->stream));
+  BG_HIP(hipMemsetAsync(ctr.p, 0, 16, ctx->stream));
+  const uint64_t out_cap = N / min_count + 1;
+  DevBuf<uint64_t> ok_a;
+  DevBuf<uint32_t> oc_a;
+  BG_TRY(ok_a.alloc(ctx, out_cap));
+  BG_TRY(oc_a.alloc(ctx, out_cap));
+  ctx->tic("skm_count_lds");
+  sk_bounds_kernel<<<cdiv(uint64_t(NB) + 1, 256), 256, 0, ctx->stream>>>(part, R, bucket_bits, bounds.p);
+  BG_LAUNCH_CHECK();
+  const uint32_t slots = sk_lds_slots();
+  const size_t smem = size_t(slots) * 12;
+  BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sk_count_lds_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
+  sk_count_lds_kernel<<<NB, SKC_THREADS, smem, ctx->stream>>>(part, bounds.p, slots, k, min_count, out_cap, ok_a.p, oc_a.p, ctr.p,
+                                                             ctr.p + 1, overflow.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(R * 16);
+  unsigned long long h_ctr[2] = {0, 0};
+  std::vector<uint8_t> h_over(NB);
+  BG_HIP(hipMemcpyAsync(h_ctr, ctr.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipMemcpyAsync(h_over.data(), overflow.p, NB, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  uint64_t nkept = h_ctr[0], distinct = h_ctr[1];
+  uint64_t n_over = 0;
+  for (uint32_t b = 0; b < NB; ++b) n_over += h_over[b];
+  if (n_over) {  // unroll the overflowed buckets into plain instances and count those by sorting
+    std::vector<uint64_t> h_bounds(size_t(NB) + 1);
+    BG_HIP(hipMemcpyAsync(h_bounds.data(), bounds.p, (size_t(NB) + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    uint64_t tot_rec = 0;
+    for (uint32_t b = 0; b < NB; ++b)
+      if (h_over[b]) tot_rec += h_bounds[b + 1] - h_bounds[b];
+    const uint64_t tot = tot_rec * uint64_t(nmax);
+    if (tot >= (1ull << 32)) {
+      set_error("k-mer counting: %llu buckets of %u overflowed their tables (%llu super-k-mers); raise BG_KMER_EXTRA_BITS",
+                (unsigned long long)n_over, NB, (unsigned long long)tot_rec);
+      return BG_EINTERNAL;
+    }
+    DevBuf<uint64_t> ta, tb;
+    BG_TRY(ta.alloc(ctx, tot));
+    BG_TRY(tb.alloc(ctx, tot));
+    BG_HIP(hipMemsetAsync(ta.p, 0xff, tot * 8, ctx->stream));
+    uint64_t pos = 0;
+    for (uint32_t b = 0; b < NB; ++b) {
+      if (!h_over[b]) continue;
+      const uint64_t cnt = h_bounds[b + 1] - h_bounds[b];
+      sk_expand_kernel<<<cdiv(cnt, 256), 256, 0, ctx->stream>>>(part, h_bounds[b], cnt, k, nmax, ta.p + pos * nmax);
+      BG_LAUNCH_CHECK();
+      pos += cnt;
+    }
+    bg_kmerset tmp;
+    tmp.ctx = ctx;
+    tmp.k = k;
+    BG_TRY(kmer_count_keys_sort_impl(ctx, ta.p, tb.p, tot, min_count, &tmp));
+    if (nkept + tmp.size > out_cap) { set_error("k-mer output overflow (internal error)"); return BG_EINTERNAL; }
+    if (tmp.size) {
+      BG_HIP(hipMemcpyAsync(ok_a.p + nkept, tmp.kmers.p, tmp.size * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      BG_HIP(hipMemcpyAsync(oc_a.p + nkept, tmp.counts.p, tmp.size * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    nkept += tmp.size;
+    distinct += tmp.distinct;
+  }
+  if (nkept > out_cap) { set_error("k-mer output overflow (internal error)"); return BG_EINTERNAL; }
+  BG_TRY(ks->kmers.alloc(ctx, nkept));
+  BG_TRY(ks->counts.alloc(ctx, nkept));
+  if (nkept) {
+    BG_HIP(hipMemcpyAsync(ks->kmers.p, ok_a.p, nkept * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    BG_HIP(hipMemcpyAsync(ks->counts.p, oc_a.p, nkept * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  ks->size = nkept;
+  ks->distinct = distinct;
+  ks->sorted = false;
+  return BG_OK;
+}
+
+}  // namespace bg
