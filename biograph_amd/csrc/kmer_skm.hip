@@ -41,9 +41,20 @@ BG_HD uint32_t sk_bucket(uint64_t b) { return uint32_t(b >> 5) & ((1u << SK_BUCK
 // order of a canonical m-mer: a fixed pseudo-random permutation, so that low-complexity m-mers are not
 // everybody's minimiser; 31 bits, SK_INF marks "holds an N"
 BG_HD uint32_t sk_order(uint32_t canon) {
-  uint32_t x = canon * 0x9E3779B1u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t x = __umul24(canon, 0x9E3779u);  // 24-bit multiplies run at full rate, 32-bit ones at a quarter
+#else
+  uint32_t x = (canon & 0xffffffu) * 0x9E3779u;
+#endif
   x ^= x >> 15;
   return x >> 1;
+}
+// canonical form of a 12-mer in 32-bit arithmetic (the 64-bit kmer_canon costs three times as much)
+__device__ __forceinline__ uint32_t sk_canon_mmer(uint32_t mm) {
+  uint32_t rc = __brev(~mm);  // the 24 payload bits, complemented and reversed, now sit in bits 31..8
+  rc = ((rc & 0xAAAAAAAAu) >> 1) | ((rc & 0x55555555u) << 1);
+  rc >>= 32 - 2 * SK_M;
+  return rc < mm ? rc : mm;
 }
 BG_HD uint32_t sk_bucket_of(uint32_t order) { return (order * 0x85EBCA6Bu) >> (32 - SK_BUCKET_FIELD); }
 
@@ -82,7 +93,8 @@ __device__ __forceinline__ void sk_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Calls f(a, b) for every super-k-mer record of reads [r_lo, r_hi).  Wave w takes reads r_lo + w, + 4, ...
+// Calls f(emit, read, first window, windows, minimiser order) for every super-k-mer of reads [r_lo, r_hi), from
+// the lane of its last window.  Wave w takes reads r_lo + w, + 4, ...
 // Windows holding an N (kmer_counter.h:306-311) belong to no record.  A chunk of 64 lanes computes the order
 // values of 64 consecutive 12-mers and, by log-step shuffles, the minimisers of 65 - (k - 11) windows; the
 // last of them only serves as look-ahead, so chunks advance by 64 - (k - 11).  sw / sn = this wave's LDS copy
@@ -97,6 +109,12 @@ __device__ __forceinline__ void tile_skms(const SkSource& src, uint64_t r_lo, ui
   int pw = 1;
   while (pw * 2 <= w) pw *= 2;
   const uint32_t rcp = (65536u + uint32_t(nmax) - 1) / uint32_t(nmax);  // x / nmax = (x * rcp) >> 16 for x < 400
+  // byte addresses of the lanes the log-step minimum pulls from (loop invariant; lanes past the end pull
+  // from lane 63 and end up with partial windows, which are not used)
+  auto lane_addr = [&](int l) { return (l < 0 ? 0 : (l > 63 ? 63 : l)) << 2; };
+  const int a1 = lane_addr(lane + 1), a2 = lane_addr(lane + 2), a4 = lane_addr(lane + 4), a8 = lane_addr(lane + 8),
+            ax = lane_addr(lane + w - pw), aup = lane_addr(lane - 1);
+  auto pull = [](int addr, uint32_t v) { return uint32_t(__builtin_amdgcn_ds_bpermute(addr, int(v))); };
   for (uint64_t i = r_lo + wave; i < r_hi; i += SK_THREADS / 64) {
     const int L = src.len[i];
     if (L < k) continue;  // wave-uniform
@@ -114,27 +132,21 @@ __device__ __forceinline__ void tile_skms(const SkSource& src, uint64_t r_lo, ui
       const int q = p >> 5, r = p & 31;
       const uint64_t w0 = sw[q], w1 = sw[q + 1];
       const uint32_t n0 = sn[q], n1 = sn[q + 1];
-      const uint64_t x = r ? ((w0 << (2 * r)) | (w1 >> (64 - 2 * r))) : w0;
-      const uint32_t nw = r ? ((n0 << r) | (n1 >> (32 - r))) : n0;
+      const uint64_t x = (w0 << (2 * r)) | ((w1 >> 1) >> (63 - 2 * r));
+      const uint32_t nw = (n0 << r) | ((n1 >> 1) >> (31 - r));
       uint32_t m = SK_INF;
-      if (p < nm && (nw >> (32 - SK_M)) == 0) {
-        bool fl;
-        m = sk_order(uint32_t(kmer_canon(x >> (64 - 2 * SK_M), SK_M, &fl)));
-      }
-      // minimum over the w order values from this lane on: log steps (lanes >= S end up with partial windows
-      // and are not used)
-      for (int st = 1; st < pw; st <<= 1) {
-        const uint32_t t = __shfl_down(m, st, 64);
-        m = t < m ? t : m;
-      }
-      if (w > pw) {
-        const uint32_t t = __shfl_down(m, w - pw, 64);
-        m = t < m ? t : m;
-      }
+      if (p < nm && (nw >> (32 - SK_M)) == 0) m = sk_order(sk_canon_mmer(uint32_t(x >> (64 - 2 * SK_M))));
+      // minimum over the w order values from this lane on, in log steps
+      uint32_t t;
+      if (pw > 1) { t = pull(a1, m); m = t < m ? t : m; }
+      if (pw > 2) { t = pull(a2, m); m = t < m ? t : m; }
+      if (pw > 4) { t = pull(a4, m); m = t < m ? t : m; }
+      if (pw > 8) { t = pull(a8, m); m = t < m ? t : m; }
+      if (w > pw) { t = pull(ax, m); m = t < m ? t : m; }
       const bool inwin = lane < S && p < nk;
       const bool valid = inwin && (nw >> (32 - k)) == 0;
       const uint32_t mz = valid ? m : SK_INF;  // a valid window's minimiser is never SK_INF
-      uint32_t prev = __shfl_up(mz, 1, 64);
+      uint32_t prev = pull(aup, mz);
       if (lane == 0) prev = carry_mz;
       // boundary = window that starts a run of equal minimisers, or holds an N
       const uint64_t bm = __ballot(inwin && (!valid || prev != mz));
@@ -144,18 +156,9 @@ __device__ __forceinline__ void tile_skms(const SkSource& src, uint64_t r_lo, ui
       const uint32_t full = ((dd + 1) * rcp) >> 16;  // records of nmax windows ending at or before this one
       const bool next_starts = p + 1 >= nk || ((bm >> ((lane + 1) & 63)) & 1);
       const bool emit = valid && lane < stride && (next_starts || full * uint32_t(nmax) == dd + 1);
-      if (emit) {
-        const int s0 = rs + int(((dd * rcp) >> 16) * uint32_t(nmax));  // the record's first window
-        const int qs = s0 >> 5, rr = s0 & 31;
-        const uint64_t r0 = sw[qs], r1 = sw[qs + 1], r2 = sw[qs + 2];
-        const int n = p - s0 + 1;
-        const int nbases = n + k - 1;  // <= 51
-        uint64_t a = rr ? ((r0 << (2 * rr)) | (r1 >> (64 - 2 * rr))) : r0;
-        uint64_t bw = rr ? ((r1 << (2 * rr)) | (r2 >> (64 - 2 * rr))) : r1;
-        if (nbases < 32) a &= ~0ull << (64 - 2 * nbases);
-        bw = nbases > 32 ? (bw & (~0ull << (64 - 2 * (nbases - 32)))) : 0ull;
-        f(a, bw | (uint64_t(sk_bucket_of(mz)) << 5) | uint64_t(n - 1));
-      }
+      // the record's first window; the whole wave calls f (so that it can aggregate over the emitting lanes)
+      const int s0 = rs + int(((dd * rcp) >> 16) * uint32_t(nmax));
+      f(emit, i, s0, p - s0 + 1, mz);
       carry_mz = uint32_t(__builtin_amdgcn_readlane(int(mz), stride - 1));
       const uint64_t lo = bm & ((1ull << stride) - 1);
       if (lo) carry_rs = base + 63 - __clzll((long long)lo);
@@ -163,11 +166,28 @@ __device__ __forceinline__ void tile_skms(const SkSource& src, uint64_t r_lo, ui
   }
 }
 
-// Level 0: the records of a tile of reads are staged in LDS and appended to `out` as one block (one global
-// atomic per tile; the order of tiles is whatever the scheduler makes it — only grouping matters downstream).
+// record of windows [s0, s0 + n) of a read (words = its W packed words)
+__device__ __forceinline__ SkRec sk_build_record(const uint64_t* __restrict__ words, int W, int s0, int n, int k,
+                                                 uint32_t order) {
+  const int qs = s0 >> 5, rr = s0 & 31;
+  const uint64_t r0 = words[qs], r1 = qs + 1 < W ? words[qs + 1] : 0, r2 = qs + 2 < W ? words[qs + 2] : 0;
+  const int nbases = n + k - 1;  // <= 51
+  SkRec r;
+  r.a = (r0 << (2 * rr)) | ((r1 >> 1) >> (63 - 2 * rr));
+  uint64_t bw = (r1 << (2 * rr)) | ((r2 >> 1) >> (63 - 2 * rr));
+  if (nbases < 32) r.a &= ~0ull << (64 - 2 * nbases);
+  bw = nbases > 32 ? (bw & (~0ull << (64 - 2 * (nbases - 32)))) : 0ull;
+  r.b = bw | (uint64_t(sk_bucket_of(order)) << 5) | uint64_t(n - 1);
+  return r;
+}
+
+// Level 0.  Phase 1 finds the super-k-mers of a tile of reads (one lane per window, most lanes idle when a
+// record is cut) and only notes (read, first window, windows, minimiser) in LDS; phase 2 builds the records
+// with every lane busy and appends them to `out` as one block (one global atomic per tile; the order of tiles
+// is whatever the scheduler makes it — only grouping matters downstream).
 __global__ __launch_bounds__(SK_THREADS) void sk_generate_kernel(SkSource src, SkRec* __restrict__ out, uint64_t cap,
                                                                  unsigned long long* __restrict__ cursor) {
-  __shared__ SkRec srec[SK_CAP];
+  __shared__ uint64_t sdesc[SK_CAP];  // read in tile : 16 | first window : 8 | windows - 1 : 8 | order : 32
   __shared__ uint64_t sw[SK_THREADS / 64][SK_WORDS];
   __shared__ uint32_t sn[SK_THREADS / 64][SK_WORDS];
   __shared__ uint32_t s_cnt;
@@ -177,19 +197,21 @@ __global__ __launch_bounds__(SK_THREADS) void sk_generate_kernel(SkSource src, S
   __syncthreads();
   const uint64_t r_lo = uint64_t(blockIdx.x) * src.reads_per_tile;
   const uint64_t r_hi = r_lo + src.reads_per_tile < src.n_reads ? r_lo + src.reads_per_tile : src.n_reads;
-  tile_skms(src, r_lo, r_hi, sw[tid >> 6], sn[tid >> 6], [&](uint64_t a, uint64_t b) {
-    const uint32_t s = atomicAdd(&s_cnt, 1u);
+  tile_skms(src, r_lo, r_hi, sw[tid >> 6], sn[tid >> 6], [&](bool emit, uint64_t read, int s0, int n, uint32_t order) {
+    const uint64_t em = __ballot(emit);
+    if (!em) return;  // wave-uniform
+    // one LDS atomic per wave and chunk (the counter is a single address: per-lane atomics on it serialise)
+    const int lane = tid & 63, leader = __ffsll((unsigned long long)em) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&s_cnt, uint32_t(__popcll(em)));
+    base = uint32_t(__builtin_amdgcn_readlane(int(base), leader));
+    if (!emit) return;
+    const uint32_t s = base + uint32_t(__popcll(em & ((1ull << lane) - 1)));
     if (s < uint32_t(SK_CAP)) {
-      srec[s].a = a;
-      srec[s].b = b;
+      sdesc[s] = (uint64_t(read - r_lo) << 48) | (uint64_t(s0) << 40) | (uint64_t(n - 1) << 32) | order;
     } else {  // the staging area is full (minimisers changing at nearly every window): one record at a time
       const unsigned long long g = atomicAdd(cursor, 1ull);
-      if (g < cap) {
-        SkRec r;
-        r.a = a;
-        r.b = b;
-        out[g] = r;
-      }
+      if (g < cap) out[g] = sk_build_record(src.words + read * src.W, src.W, s0, n, src.k, order);
     }
   });
   __syncthreads();
@@ -197,8 +219,13 @@ __global__ __launch_bounds__(SK_THREADS) void sk_generate_kernel(SkSource src, S
   if (tid == 0) s_base = atomicAdd(cursor, (unsigned long long)total);
   __syncthreads();
   const uint64_t base = s_base;
-  for (uint32_t i = tid; i < total; i += SK_THREADS)
-    if (base + i < cap) out[base + i] = srec[i];
+  for (uint32_t i = tid; i < total; i += SK_THREADS) {
+    const uint64_t d = sdesc[i];
+    const uint64_t read = r_lo + (d >> 48);
+    const SkRec r = sk_build_record(src.words + read * src.W, src.W, int(d >> 40) & 0xff, (int(d >> 32) & 0xff) + 1, src.k,
+                                    uint32_t(d));
+    if (base + i < cap) out[base + i] = r;
+  }
 }
 
 // ---- further levels: one unstable pass over records already grouped into segments ------------------

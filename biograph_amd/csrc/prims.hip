@@ -321,23 +321,26 @@ constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
 constexpr int RS_BINS = 256;
 
-// Census: for each of the 8 byte positions, the histogram of that byte over all keys.  Lets the
-// host skip passes on which every key agrees.  Grid-stride, LDS histograms, one flush per block.
-__global__ __launch_bounds__(RS_THREADS) void rs_digit_census_kernel(const uint64_t* __restrict__ keys, uint64_t n,
-                                                                     unsigned long long* __restrict__ census) {
-  __shared__ uint32_t h[8][RS_BINS];
-  for (int i = threadIdx.x; i < 8 * RS_BINS; i += RS_THREADS) (&h[0][0])[i] = 0;
-  __syncthreads();
-  uint64_t stride = uint64_t(gridDim.x) * RS_THREADS;
+// Census: the AND and the OR of all keys.  A bit position on which they agree is constant over the input, so
+// the host skips the passes whose digit is constant (tie rounds sort keys that agree almost everywhere; a
+// per-byte histogram of such keys serialises on one LDS address).
+__global__ __launch_bounds__(RS_THREADS) void rs_and_or_kernel(const uint64_t* __restrict__ keys, uint64_t n,
+                                                               unsigned long long* __restrict__ and_or) {
+  unsigned long long a = ~0ull, o = 0ull;
+  const uint64_t stride = uint64_t(gridDim.x) * RS_THREADS;
   for (uint64_t i = uint64_t(blockIdx.x) * RS_THREADS + threadIdx.x; i < n; i += stride) {
-    uint64_t k = keys[i];
-#pragma unroll
-    for (int b = 0; b < 8; ++b) atomicAdd(&h[b][(k >> (8 * b)) & 0xff], 1u);
+    const unsigned long long k = keys[i];
+    a &= k;
+    o |= k;
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 8 * RS_BINS; i += RS_THREADS) {
-    uint32_t v = (&h[0][0])[i];
-    if (v) atomicAdd(&census[i], (unsigned long long)v);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    a &= __shfl_xor(a, d, 64);
+    o |= __shfl_xor(o, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAnd(&and_or[0], a);
+    atomicOr(&and_or[1], o);
   }
 }
 
@@ -497,17 +500,17 @@ static int radix_sort_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint
   // census -> which byte-aligned digits actually vary (skipped for low-entropy keys, whose single
   // pass is always needed and whose census would serialise on one LDS address)
   const bool low_entropy = (flags & RS_LOW_ENTROPY) != 0;
-  std::vector<unsigned long long> hc(8 * RS_BINS, 0);
+  unsigned long long h_ao[2] = {~0ull, 0ull};  // AND, OR of the keys
   if (!low_entropy) {
-    DevBuf<unsigned long long> census;
-    BG_TRY(census.alloc(ctx, 8 * RS_BINS));
-    BG_HIP(hipMemsetAsync(census.p, 0, census.bytes(), ctx->stream));
+    DevBuf<unsigned long long> ao;
+    BG_TRY(ao.alloc(ctx, 2));
+    BG_HIP(hipMemcpyAsync(ao.p, h_ao, 16, hipMemcpyHostToDevice, ctx->stream));
     unsigned cgrid = unsigned(ntiles < 2048 ? ntiles : 2048);
     ctx->tic("radix_census");
-    rs_digit_census_kernel<<<cgrid, RS_THREADS, 0, ctx->stream>>>(keys_a, n, census.p);
+    rs_and_or_kernel<<<cgrid, RS_THREADS, 0, ctx->stream>>>(keys_a, n, ao.p);
     BG_LAUNCH_CHECK();
     ctx->toc(n * 8);
-    BG_HIP(hipMemcpyAsync(hc.data(), census.p, census.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipMemcpyAsync(h_ao, ao.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     BG_HIP(hipStreamSynchronize(ctx->stream));
   }
 
@@ -524,17 +527,8 @@ static int radix_sort_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint
   for (int shift = bit_lo; shift < bit_hi; shift += 8) {
     int bits = bit_hi - shift < 8 ? bit_hi - shift : 8;
     uint32_t dmask = (1u << bits) - 1;
-    // skip when every key has the same value in this digit (only checkable for byte-aligned digits)
-    if (!low_entropy && (shift & 7) == 0) {
-      const unsigned long long* h = &hc[(shift >> 3) * RS_BINS];
-      // fold bins that alias under dmask
-      bool single = false;
-      unsigned long long folded[RS_BINS] = {0};
-      for (int b = 0; b < RS_BINS; ++b) folded[b & dmask] += h[b];
-      for (int b = 0; b <= int(dmask); ++b)
-        if (folded[b] == n) single = true;
-      if (single) continue;
-    }
+    // skip when every key has the same value in this digit
+    if (!low_entropy && (((h_ao[0] ^ h_ao[1]) >> shift) & dmask) == 0) continue;
     ctx->tic("radix_hist");
     if (low_entropy)
       rs_hist_agg_kernel<<<unsigned(ntiles), RS_THREADS, 0, ctx->stream>>>(kin, n, shift, dmask, hist.p,
