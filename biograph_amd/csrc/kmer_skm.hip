@@ -362,17 +362,27 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
   __syncthreads();
   const uint32_t max_probe = cap < 256u ? cap : 256u;
   const uint64_t kmask = ~(~0ull << (2 * k));
-  for (uint64_t i = lo + threadIdx.x; i < hi; i += SKC_THREADS) {
-    const SkRec r = recs[i];
+  // One flat loop per batch of records: every iteration is one probe of every live lane, and a lane whose
+  // probe hits moves on to its next window by itself.  (Nesting "for each window { probe until placed }" makes
+  // the whole wave wait for its slowest lane at every window, and its exec-mask bookkeeping saturated the
+  // scalar unit.)
+  for (uint64_t i0 = lo; i0 < hi; i0 += SKC_THREADS) {  // block-uniform trip count
+    const uint64_t i = i0 + threadIdx.x;
+    bool live = i < hi;
+    SkRec r;
+    r.a = 0;
+    r.b = 0;
+    if (live) r = recs[i];
     const int n = sk_windows(r.b);
+    int t = 0;
     uint64_t fwd = r.a >> (64 - 2 * k);
     uint64_t rc = kmer_revcomp(fwd, k);
-    for (int t = 0;; ++t) {
-      const unsigned long long key = rc < fwd ? rc : fwd;
-      // 32-bit multiplies run at quarter rate: fold the key to 32 bits, one multiply, one multiply-high
-      uint32_t slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
-      uint32_t probes = 0;
-      for (;;) {
+    unsigned long long key = rc < fwd ? rc : fwd;
+    // 32-bit multiplies run at quarter rate: fold the key to 32 bits, one multiply, one multiply-high
+    uint32_t slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
+    uint32_t probes = 0;
+    while (__any(live)) {
+      if (live) {
         // LDS atomics run at about a lane per clock: most occurrences find their key already in place, and a
         // plain read (full rate) spares them the compare-and-swap
         unsigned long long cur = __atomic_load_n(&tkeys[slot], __ATOMIC_RELAXED);
@@ -380,15 +390,24 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
           cur = atomicCAS(&tkeys[slot], ~0ull, key);
           if (cur == ~0ull) cur = key;
         }
-        if (cur == key) { atomicAdd(&tcnt[slot], 1u); break; }
-        slot = slot + 1 == cap ? 0 : slot + 1;
-        if (++probes >= max_probe) { s_over = 1; break; }
+        if (cur == key) {
+          atomicAdd(&tcnt[slot], 1u);
+          if (++t >= n) {
+            live = false;
+          } else {
+            const int idx = k + t - 1;  // the base that enters the window
+            const uint64_t base = idx < 32 ? (r.a >> (62 - 2 * idx)) & 3 : (r.b >> (62 - 2 * (idx - 32))) & 3;
+            fwd = ((fwd << 2) | base) & kmask;
+            rc = (rc >> 2) | ((3 - base) << (2 * (k - 1)));
+            key = rc < fwd ? rc : fwd;
+            slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
+            probes = 0;
+          }
+        } else {
+          slot = slot + 1 == cap ? 0 : slot + 1;
+          if (++probes >= max_probe) { s_over = 1; live = false; }
+        }
       }
-      if (t + 1 >= n) break;
-      const int idx = k + t;  // the base that enters the window
-      const uint64_t base = idx < 32 ? (r.a >> (62 - 2 * idx)) & 3 : (r.b >> (62 - 2 * (idx - 32))) & 3;
-      fwd = ((fwd << 2) | base) & kmask;
-      rc = (rc >> 2) | ((3 - base) << (2 * (k - 1)));
     }
   }
   __syncthreads();
