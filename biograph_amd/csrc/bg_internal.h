@@ -146,6 +146,16 @@ struct bg_kmerset {
   bg::DevBuf<uint32_t> counts;   // total count per kept k-mer
   bg::DevBuf<uint64_t> slots;    // hash table (1 << log2cap)
   int log2cap = 0;
+  // Window presence of the reads the set was counted from (4 x 64 bits per read: bit j = window j holds no N
+  // and its canonical k-mer is kept): a by-product of the super-k-mer count that spares bg_correct_reads the
+  // look-up of every window.  Valid for the reads object identified by present_of / present_n only.
+  bg::DevBuf<uint64_t> present;
+  const void* present_of = nullptr;
+  uint64_t present_n = 0;
+  // records (2 words each) + origins of the buckets the LDS count gave up on: their presence bits are set
+  // from the finished hash set (kmer_skm_finish_present)
+  bg::DevBuf<uint64_t> pend_rec, pend_org;
+  uint64_t pend_n = 0;
 };
 
 struct bg_seqset {

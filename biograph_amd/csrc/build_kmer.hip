@@ -425,6 +425,41 @@ __global__ __launch_bounds__(256) void k_correct_screen(const uint64_t* __restri
   }
 }
 
+// The same decision from presence bits that came with the k-mer count (bg_kmerset::present): no look-ups.
+__global__ __launch_bounds__(256) void k_screen_from_present(const uint64_t* __restrict__ words,
+                                                             const uint16_t* __restrict__ len, uint64_t n, int W, int k,
+                                                             const uint64_t* __restrict__ present,
+                                                             uint64_t* __restrict__ out_words,
+                                                             uint16_t* __restrict__ out_len,
+                                                             uint8_t* __restrict__ need_dfs) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int L = len[i];
+  bool all_ok = L >= k;
+  if (all_ok) {
+    const int nk = L - k + 1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int cnt = nk - c * 64;  // windows of this word
+      if (cnt > 0) {
+        const uint64_t want = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1);
+        if ((present[i * 4 + c] & want) != want) all_ok = false;
+      }
+    }
+  }
+  if (L < k) {  // correct_reads.cpp:155
+    for (int w = 0; w < W; ++w) out_words[i * W + w] = 0;
+    out_len[i] = 0;
+    need_dfs[i] = 0;
+  } else if (all_ok) {  // nothing to correct: output == input
+    for (int w = 0; w < W; ++w) out_words[i * W + w] = words[i * W + w];
+    out_len[i] = uint16_t(L);
+    need_dfs[i] = 0;
+  } else {
+    need_dfs[i] = 1;
+  }
+}
+
 struct CorrectCounters {
   unsigned long long modified, modified_bases;
 };
@@ -725,6 +760,7 @@ static int kmer_lds_log2cap() {
 // ka = instances (clobbered), kb = scratch, both N.  Output k-mers are sorted ascending.
 // partitioned = the instances already sit in kb grouped by 16 hash bits (radix_partition_hash16_reads)
 int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32_t min_count, bg_kmerset* ks, bool* done);
+int kmer_skm_finish_present(bg_ctx* ctx, bg_kmerset* ks);
 
 int kmer_count_keys_impl(bg_ctx* ctx, uint64_t* ka, uint64_t* kb, uint64_t N, uint32_t min_count, bg_kmerset* ks,
                          bool partitioned = false) {
@@ -740,8 +776,22 @@ int kmer_count_keys_impl(bg_ctx* ctx, uint64_t* ka, uint64_t* kb, uint64_t N, ui
   // One LDS table holds a few thousand distinct k-mers: 65536 buckets carry about 1.6 G instances at 30x
   // (chr20-sized input).  Bigger inputs get one more partition level so that a bucket stays around 24 k
   // instances (BG_KMER_EXTRA_BITS overrides, for tests).
+  // A rank of a sharded build owns a slice of the hash space: its N keys fill only that slice's buckets, so the
+  // level is chosen from the average over the non-empty buckets, not from N / 65536.
   int extra = 0;
-  while (extra < 8 && (N >> (16 + extra)) > 24000) ++extra;
+  {
+    DevBuf<uint64_t> b16;
+    BG_TRY(b16.alloc(ctx, 65537));
+    k_bucket_bounds<<<cdiv(65537, 256), 256, 0, ctx->stream>>>(in_b ? kb : ka, N, 16, b16.p);
+    BG_LAUNCH_CHECK();
+    std::vector<uint64_t> hb(65537);
+    BG_HIP(hipMemcpyAsync(hb.data(), b16.p, 65537 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    uint64_t used = 0;
+    for (int b = 0; b < 65536; ++b) used += hb[b + 1] > hb[b];
+    const uint64_t avg = N / (used ? used : 1);
+    while (extra < 8 && (avg >> extra) > 24000) ++extra;
+  }
   if (const char* e = getenv("BG_KMER_EXTRA_BITS")) extra = std::max(0, std::min(8, atoi(e)));
   if (extra) {
     BG_TRY(radix_partition_hash_refine(ctx, in_b ? kb : ka, in_b ? ka : kb, N, extra));
@@ -916,6 +966,7 @@ extern "C" int bg_kmer_count(bg_ctx* ctx, const bg_reads* reads, int k, uint32_t
     }
   }
   BG_TRY(kmer_hash_build_impl(ctx, ks.get(), reads));
+  BG_TRY(kmer_skm_finish_present(ctx, ks.get()));
   *out = ks.release();
   return BG_OK;
 }
@@ -1066,9 +1117,12 @@ extern "C" int bg_correct_reads(bg_ctx* ctx, const bg_reads* reads, const bg_kme
   BG_HIP(hipMemcpyAsync(d_needed.p, needed, sizeof needed, hipMemcpyHostToDevice, ctx->stream));
 
   DevBuf<uint8_t> need;
-  DevBuf<uint64_t> present;  // 4 x 64 window bits per read (reads are <= 255 bases)
+  DevBuf<uint64_t> present_own;  // 4 x 64 window bits per read (reads are <= 255 bases)
   BG_TRY(need.alloc(ctx, n));
-  BG_TRY(present.alloc(ctx, n * 4));
+  // presence bits that came with the count of these very reads (super-k-mer path), else look every window up
+  const bool have_present = ks->present.p && ks->present_of == reads && ks->present_n == n && !getenv("BG_SCREEN_LOOKUP");
+  if (!have_present) BG_TRY(present_own.alloc(ctx, n * 4));
+  const uint64_t* present = have_present ? ks->present.p : present_own.p;
   DevBuf<CorrectCounters> ctr;
   DevBuf<CorrectTotals> tot;
   BG_TRY(ctr.alloc(ctx, 1));
@@ -1077,15 +1131,23 @@ extern "C" int bg_correct_reads(bg_ctx* ctx, const bg_reads* reads, const bg_kme
   BG_HIP(hipMemsetAsync(tot.p, 0, sizeof(CorrectTotals), ctx->stream));
   uint64_t nlist = 0;
   if (n >= (1ull << 32)) { set_error("bg_correct_reads: too many reads for one shard"); return BG_EINVAL; }
-  DevBuf<uint32_t> perm;
-  BG_TRY(read_locus_order(ctx, reads, 0, n, &perm));
   if (n) {
-    ctx->tic("correct_screen");
-    k_correct_screen<<<cdiv(n, 4), 256, 0, ctx->stream>>>(reads->words.p, reads->nmask.p, reads->len.p, n, W, k,
-                                                          ks->slots.p, ks->log2cap, r->words.p, r->len.p, need.p,
-                                                          present.p, perm.p);
-    BG_LAUNCH_CHECK();
-    ctx->toc(n * W * 20 + ks->instances * 8);
+    if (have_present) {
+      ctx->tic("correct_screen_bits");
+      k_screen_from_present<<<cdiv(n, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->len.p, n, W, k, present,
+                                                                    r->words.p, r->len.p, need.p);
+      BG_LAUNCH_CHECK();
+      ctx->toc(n * (W * 16 + 32 + 5));
+    } else {
+      DevBuf<uint32_t> perm;
+      BG_TRY(read_locus_order(ctx, reads, 0, n, &perm));
+      ctx->tic("correct_screen");
+      k_correct_screen<<<cdiv(n, 4), 256, 0, ctx->stream>>>(reads->words.p, reads->nmask.p, reads->len.p, n, W, k,
+                                                            ks->slots.p, ks->log2cap, r->words.p, r->len.p, need.p,
+                                                            present_own.p, perm.p);
+      BG_LAUNCH_CHECK();
+      ctx->toc(n * W * 20 + ks->instances * 8);
+    }
     DevBuf<uint64_t> list;
     BG_TRY(compact_flagged<uint64_t>(ctx, need.p, n, &list, &nlist));
     if (nlist) {
@@ -1093,7 +1155,7 @@ extern "C" int bg_correct_reads(bg_ctx* ctx, const bg_reads* reads, const bg_kme
       k_correct_dfs<<<cdiv(nlist, 64), 64, 0, ctx->stream>>>(
           reads->words.p, reads->nmask.p, reads->len.p, list.p, nlist, W, k, ks->slots.p, ks->log2cap,
           int(params->max_corrections), int(params->min_good_run), d_needed.p, r->words.p, r->len.p, ctr.p,
-          present.p);
+          present);
       BG_LAUNCH_CHECK();
       ctx->toc(nlist * W * 20);
     }

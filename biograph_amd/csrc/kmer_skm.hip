@@ -185,7 +185,8 @@ __device__ __forceinline__ SkRec sk_build_record(const uint64_t* __restrict__ wo
 // record is cut) and only notes (read, first window, windows, minimiser) in LDS; phase 2 builds the records
 // with every lane busy and appends them to `out` as one block (one global atomic per tile; the order of tiles
 // is whatever the scheduler makes it — only grouping matters downstream).
-__global__ __launch_bounds__(SK_THREADS) void sk_generate_kernel(SkSource src, SkRec* __restrict__ out, uint64_t cap,
+__global__ __launch_bounds__(SK_THREADS) void sk_generate_kernel(SkSource src, SkRec* __restrict__ out,
+                                                                 uint64_t* __restrict__ org, uint64_t cap,
                                                                  unsigned long long* __restrict__ cursor) {
   __shared__ uint64_t sdesc[SK_CAP];  // read in tile : 16 | first window : 8 | windows - 1 : 8 | order : 32
   __shared__ uint64_t sw[SK_THREADS / 64][SK_WORDS];
@@ -211,7 +212,10 @@ __global__ __launch_bounds__(SK_THREADS) void sk_generate_kernel(SkSource src, S
       sdesc[s] = (uint64_t(read - r_lo) << 48) | (uint64_t(s0) << 40) | (uint64_t(n - 1) << 32) | order;
     } else {  // the staging area is full (minimisers changing at nearly every window): one record at a time
       const unsigned long long g = atomicAdd(cursor, 1ull);
-      if (g < cap) out[g] = sk_build_record(src.words + read * src.W, src.W, s0, n, src.k, order);
+      if (g < cap) {
+        out[g] = sk_build_record(src.words + read * src.W, src.W, s0, n, src.k, order);
+        org[g] = (read << 8) | uint64_t(s0);
+      }
     }
   });
   __syncthreads();
@@ -224,7 +228,10 @@ __global__ __launch_bounds__(SK_THREADS) void sk_generate_kernel(SkSource src, S
     const uint64_t read = r_lo + (d >> 48);
     const SkRec r = sk_build_record(src.words + read * src.W, src.W, int(d >> 40) & 0xff, (int(d >> 32) & 0xff) + 1, src.k,
                                     uint32_t(d));
-    if (base + i < cap) out[base + i] = r;
+    if (base + i < cap) {
+      out[base + i] = r;
+      org[base + i] = (read << 8) | ((d >> 40) & 0xff);  // origin: read : first window
+    }
   }
 }
 
@@ -271,9 +278,11 @@ __global__ __launch_bounds__(SK_THREADS) void sk_part_hist_kernel(const SkRec* _
 }
 
 __global__ __launch_bounds__(SK_THREADS) void sk_part_scatter_kernel(const SkRec* __restrict__ in, SkRec* __restrict__ out,
-                                                                     SkSegs sg, int shift, uint32_t dmask,
-                                                                     const uint64_t* __restrict__ offs) {
+                                                                     const uint64_t* __restrict__ oin,
+                                                                     uint64_t* __restrict__ oout, SkSegs sg, int shift,
+                                                                     uint32_t dmask, const uint64_t* __restrict__ offs) {
   __shared__ SkRec srec[SK2_TILE];
+  __shared__ uint64_t sorg[SK2_TILE];
   __shared__ uint32_t h[SK_BINS];
   __shared__ uint32_t binstart[SK_BINS];
   __shared__ uint64_t goff[SK_BINS];
@@ -285,12 +294,15 @@ __global__ __launch_bounds__(SK_THREADS) void sk_part_scatter_kernel(const SkRec
   sk_locate(sg, blockIdx.x, &lo, &hi, &hbase, &nt, &ti);
   __syncthreads();
   SkRec rec[SK2_ITEMS];
+  uint64_t og[SK2_ITEMS];
   uint16_t rnk[SK2_ITEMS];
 #pragma unroll
   for (int it = 0; it < SK2_ITEMS; ++it) {
     const uint64_t idx = lo + uint64_t(it) * SK_THREADS + tid;
+    og[it] = 0;
     if (idx < hi) {
       rec[it] = in[idx];
+      og[it] = oin[idx];
       rnk[it] = uint16_t(atomicAdd(&h[(sk_bucket(rec[it].b) >> shift) & dmask], 1u));
     } else {
       rec[it].a = 0;
@@ -309,13 +321,19 @@ __global__ __launch_bounds__(SK_THREADS) void sk_part_scatter_kernel(const SkRec
 #pragma unroll
   for (int it = 0; it < SK2_ITEMS; ++it) {
     const uint64_t idx = lo + uint64_t(it) * SK_THREADS + tid;
-    if (idx < hi) srec[binstart[(sk_bucket(rec[it].b) >> shift) & dmask] + rnk[it]] = rec[it];
+    if (idx < hi) {
+      const uint32_t at = binstart[(sk_bucket(rec[it].b) >> shift) & dmask] + rnk[it];
+      srec[at] = rec[it];
+      sorg[at] = og[it];
+    }
   }
   __syncthreads();
   const uint32_t cnt = uint32_t(hi - lo);
   for (uint32_t i = tid; i < cnt; i += SK_THREADS) {
     const SkRec r = srec[i];
-    out[goff[(sk_bucket(r.b) >> shift) & dmask] + i] = r;
+    const uint64_t o = goff[(sk_bucket(r.b) >> shift) & dmask] + i;
+    out[o] = r;
+    oout[o] = sorg[i];
   }
 }
 
@@ -348,7 +366,9 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
                                                                    uint32_t* __restrict__ out_counts,
                                                                    unsigned long long* __restrict__ out_n,
                                                                    unsigned long long* __restrict__ distinct_total,
-                                                                   uint8_t* __restrict__ overflow) {
+                                                                   uint8_t* __restrict__ overflow,
+                                                                   const uint64_t* __restrict__ org,
+                                                                   unsigned long long* __restrict__ present) {
   extern __shared__ __align__(16) unsigned char skc_smem[];
   unsigned long long* tkeys = reinterpret_cast<unsigned long long*>(skc_smem);
   uint32_t* tcnt = reinterpret_cast<uint32_t*>(skc_smem + size_t(cap) * 8);
@@ -415,6 +435,49 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
     if (threadIdx.x == 0) overflow[bucket] = 1;
     return;
   }
+  // Second sweep, the table being final: which windows of each record hold a kept k-mer -> presence bits of the
+  // read they came from (what the read-correction screen would otherwise look up window by window in HBM).
+  for (uint64_t i0 = lo; i0 < hi; i0 += SKC_THREADS) {
+    const uint64_t i = i0 + threadIdx.x;
+    bool live = i < hi;
+    SkRec r;
+    r.a = 0;
+    r.b = 0;
+    if (live) r = recs[i];
+    const int n = sk_windows(r.b);
+    int t = 0;
+    uint32_t bits = 0;
+    uint64_t fwd = r.a >> (64 - 2 * k);
+    uint64_t rc = kmer_revcomp(fwd, k);
+    unsigned long long key = rc < fwd ? rc : fwd;
+    uint32_t slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
+    while (__any(live)) {
+      if (live) {
+        if (tkeys[slot] == key) {  // every window's key is in the table (no overflow)
+          if (tcnt[slot] >= min_count) bits |= 1u << t;
+          if (++t >= n) {
+            live = false;
+          } else {
+            const int idx = k + t - 1;
+            const uint64_t base = idx < 32 ? (r.a >> (62 - 2 * idx)) & 3 : (r.b >> (62 - 2 * (idx - 32))) & 3;
+            fwd = ((fwd << 2) | base) & kmask;
+            rc = (rc >> 2) | ((3 - base) << (2 * (k - 1)));
+            key = rc < fwd ? rc : fwd;
+            slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
+          }
+        } else {
+          slot = slot + 1 == cap ? 0 : slot + 1;
+        }
+      }
+    }
+    if (i < hi && bits) {
+      const uint64_t o = org[i];
+      const uint64_t read = o >> 8;
+      const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
+      atomicOr(&present[read * 4 + wi], (unsigned long long)bits << sh);
+      if (sh + n > 64) atomicOr(&present[read * 4 + wi + 1], (unsigned long long)bits >> (64 - sh));
+    }
+  }
   uint32_t my_kept = 0, my_distinct = 0;
   for (uint32_t i = threadIdx.x; i < cap; i += SKC_THREADS) {
     if (tkeys[i] != ~0ull) {
@@ -459,8 +522,51 @@ __global__ void sk_expand_kernel(const SkRec* __restrict__ recs, uint64_t lo, ui
   }
 }
 
-static int sk_partition_segmented(bg_ctx* ctx, const SkRec* in, SkRec* out, uint64_t n, uint32_t nseg,
-                                  const uint64_t* h_rec0, int shift, uint32_t dmask) {
+// presence bits of records the LDS count gave up on, from the finished hash set
+__global__ void sk_present_lookup_kernel(const SkRec* __restrict__ recs, const uint64_t* __restrict__ org, uint64_t n_rec,
+                                         int k, const uint64_t* __restrict__ slots, int log2cap,
+                                         unsigned long long* __restrict__ present) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_rec) return;
+  const SkRec r = recs[i];
+  const int n = sk_windows(r.b);
+  KmerTable tab{slots, log2cap, k};
+  const uint64_t kmask = ~(~0ull << (2 * k));
+  uint64_t fwd = r.a >> (64 - 2 * k);
+  uint64_t rc = kmer_revcomp(fwd, k);
+  uint32_t bits = 0;
+  for (int t = 0; t < n; ++t) {
+    if (tab.find(rc < fwd ? rc : fwd) >= 0) bits |= 1u << t;
+    const int idx = k + t;
+    const uint64_t base = idx < 32 ? (r.a >> (62 - 2 * idx)) & 3 : (r.b >> (62 - 2 * (idx - 32))) & 3;
+    fwd = ((fwd << 2) | base) & kmask;
+    rc = (rc >> 2) | ((3 - base) << (2 * (k - 1)));
+  }
+  if (bits) {
+    const uint64_t o = org[i];
+    const uint64_t read = o >> 8;
+    const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
+    atomicOr(&present[read * 4 + wi], (unsigned long long)bits << sh);
+    if (sh + n > 64) atomicOr(&present[read * 4 + wi + 1], (unsigned long long)bits >> (64 - sh));
+  }
+}
+
+// after kmer_hash_build_impl: presence bits of the pending records (overflowed buckets)
+int kmer_skm_finish_present(bg_ctx* ctx, bg_kmerset* ks) {
+  if (ks->pend_n && ks->present.p) {
+    sk_present_lookup_kernel<<<cdiv(ks->pend_n, 256), 256, 0, ctx->stream>>>(
+        reinterpret_cast<const SkRec*>(ks->pend_rec.p), ks->pend_org.p, ks->pend_n, ks->k, ks->slots.p, ks->log2cap,
+        reinterpret_cast<unsigned long long*>(ks->present.p));
+    BG_LAUNCH_CHECK();
+  }
+  ks->pend_rec.reset();
+  ks->pend_org.reset();
+  ks->pend_n = 0;
+  return BG_OK;
+}
+
+static int sk_partition_segmented(bg_ctx* ctx, const SkRec* in, SkRec* out, const uint64_t* oin, uint64_t* oout, uint64_t n,
+                                  uint32_t nseg, const uint64_t* h_rec0, int shift, uint32_t dmask) {
   std::vector<uint32_t> h_tile(size_t(nseg) + 1, 0);
   uint64_t t = 0;
   for (uint32_t b = 0; b < nseg; ++b) {
@@ -489,9 +595,9 @@ static int sk_partition_segmented(bg_ctx* ctx, const SkRec* in, SkRec* out, uint
   BG_TRY(exclusive_scan_u32_to_u64(ctx, hist.p, offs.p, uint64_t(SK_BINS) * ntiles, nullptr));
   ctx->toc(uint64_t(SK_BINS) * ntiles * 12);
   ctx->tic("skm_part_scatter");
-  sk_part_scatter_kernel<<<ntiles, SK_THREADS, 0, ctx->stream>>>(in, out, sg, shift, dmask, offs.p);
+  sk_part_scatter_kernel<<<ntiles, SK_THREADS, 0, ctx->stream>>>(in, out, oin, oout, sg, shift, dmask, offs.p);
   BG_LAUNCH_CHECK();
-  ctx->toc(n * 32);
+  ctx->toc(n * 48);
   return BG_OK;
 }
 
@@ -523,17 +629,19 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
   // expected density (2 / (w + 1) records per window); an input that beats it takes the instance path.
   const uint64_t cap = std::min<uint64_t>(N, uint64_t(double(N) * 6.0 / double(w + 1)) + reads->n + 1024);
   DevBuf<SkRec> ra, rb;
+  DevBuf<uint64_t> oa, ob, oc;  // origin (read : first window) of every record, moved along with it
   DevBuf<unsigned long long> cursor;
   BG_TRY(ra.alloc(ctx, cap));
+  BG_TRY(oa.alloc(ctx, cap));
   BG_TRY(cursor.alloc(ctx, 1));
   BG_HIP(hipMemsetAsync(cursor.p, 0, 8, ctx->stream));
   ctx->tic("skm_generate");
-  sk_generate_kernel<<<ntiles, SK_THREADS, 0, ctx->stream>>>(src, ra.p, cap, cursor.p);
+  sk_generate_kernel<<<ntiles, SK_THREADS, 0, ctx->stream>>>(src, ra.p, oa.p, cap, cursor.p);
   BG_LAUNCH_CHECK();
   unsigned long long R = 0;
   BG_HIP(hipMemcpyAsync(&R, cursor.p, 8, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
-  ctx->toc(R * 16 + reads->n * uint64_t(reads->W) * 12);
+  ctx->toc(R * 24 + reads->n * uint64_t(reads->W) * 12);
   if (R > cap) return BG_OK;  // *done stays false
   *done = true;
   ks->distinct = 0;
@@ -544,13 +652,19 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
     return BG_OK;
   }
   BG_TRY(rb.alloc(ctx, R));
+  BG_TRY(ob.alloc(ctx, R));
   DevBuf<SkRec> rc;
   BG_TRY(rc.alloc(ctx, R));
+  BG_TRY(oc.alloc(ctx, R));
+  BG_TRY(ks->present.alloc(ctx, reads->n * 4));
+  BG_HIP(hipMemsetAsync(ks->present.p, 0, reads->n * 32, ctx->stream));
+  ks->present_of = reads;
+  ks->present_n = reads->n;
   // level 1: the top 8 bucket bits
   std::vector<uint64_t> h_starts(SK_BINS + 1);
   {
     const uint64_t whole[2] = {0, R};
-    BG_TRY(sk_partition_segmented(ctx, ra.p, rb.p, R, 1, whole, SK_BUCKET_FIELD - 8, 0xffu));
+    BG_TRY(sk_partition_segmented(ctx, ra.p, rb.p, oa.p, ob.p, R, 1, whole, SK_BUCKET_FIELD - 8, 0xffu));
     DevBuf<uint64_t> b8;
     BG_TRY(b8.alloc(ctx, SK_BINS + 1));
     sk_bounds_kernel<<<cdiv(SK_BINS + 1, 256), 256, 0, ctx->stream>>>(rb.p, R, 8, b8.p);
@@ -559,14 +673,16 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
     BG_HIP(hipStreamSynchronize(ctx->stream));
   }
   ra.reset();
+  oa.reset();
 
   // level 2: the next 8 bits inside each of the 256 groups; bigger inputs take up to 5 more bits so that a
   // bucket stays around 24 k windows (BG_KMER_EXTRA_BITS overrides, for tests)
-  BG_TRY(sk_partition_segmented(ctx, rb.p, rc.p, R, SK_BINS, h_starts.data(), SK_BUCKET_FIELD - 16, 0xffu));
+  BG_TRY(sk_partition_segmented(ctx, rb.p, rc.p, ob.p, oc.p, R, SK_BINS, h_starts.data(), SK_BUCKET_FIELD - 16, 0xffu));
   int extra = 0;
   while (extra < SK_BUCKET_FIELD - 16 && (N >> (16 + extra)) > 24000) ++extra;
   if (const char* e = getenv("BG_KMER_EXTRA_BITS")) extra = std::max(0, std::min(SK_BUCKET_FIELD - 16, atoi(e)));
   SkRec* part = rc.p;
+  uint64_t* part_org = oc.p;
   if (extra) {
     DevBuf<uint64_t> b16;
     BG_TRY(b16.alloc(ctx, 65537));
@@ -575,8 +691,10 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
     std::vector<uint64_t> h(65537);
     BG_HIP(hipMemcpyAsync(h.data(), b16.p, 65537 * 8, hipMemcpyDeviceToHost, ctx->stream));
     BG_HIP(hipStreamSynchronize(ctx->stream));
-    BG_TRY(sk_partition_segmented(ctx, rc.p, rb.p, R, 65536, h.data(), SK_BUCKET_FIELD - 16 - extra, (1u << extra) - 1));
+    BG_TRY(sk_partition_segmented(ctx, rc.p, rb.p, oc.p, ob.p, R, 65536, h.data(), SK_BUCKET_FIELD - 16 - extra,
+                                  (1u << extra) - 1));
     part = rb.p;
+    part_org = ob.p;
   }
   const int bucket_bits = 16 + extra;
   const uint32_t NB = 1u << bucket_bits;
@@ -602,9 +720,10 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
   BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sk_count_lds_kernel),
                              hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
   sk_count_lds_kernel<<<NB, SKC_THREADS, smem, ctx->stream>>>(part, bounds.p, slots, k, min_count, out_cap, ok_a.p, oc_a.p, ctr.p,
-                                                             ctr.p + 1, overflow.p);
+                                                             ctr.p + 1, overflow.p, part_org,
+                                                             reinterpret_cast<unsigned long long*>(ks->present.p));
   BG_LAUNCH_CHECK();
-  ctx->toc(R * 16);
+  ctx->toc(R * 40);
   unsigned long long h_ctr[2] = {0, 0};
   std::vector<uint8_t> h_over(NB);
   BG_HIP(hipMemcpyAsync(h_ctr, ctr.p, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -630,12 +749,17 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
     BG_TRY(ta.alloc(ctx, tot));
     BG_TRY(tb.alloc(ctx, tot));
     BG_HIP(hipMemsetAsync(ta.p, 0xff, tot * 8, ctx->stream));
+    BG_TRY(ks->pend_rec.alloc(ctx, tot_rec * 2));  // their presence bits wait for the finished hash set
+    BG_TRY(ks->pend_org.alloc(ctx, tot_rec));
+    ks->pend_n = tot_rec;
     uint64_t pos = 0;
     for (uint32_t b = 0; b < NB; ++b) {
       if (!h_over[b]) continue;
       const uint64_t cnt = h_bounds[b + 1] - h_bounds[b];
       sk_expand_kernel<<<cdiv(cnt, 256), 256, 0, ctx->stream>>>(part, h_bounds[b], cnt, k, nmax, ta.p + pos * nmax);
       BG_LAUNCH_CHECK();
+      BG_HIP(hipMemcpyAsync(ks->pend_rec.p + pos * 2, part + h_bounds[b], cnt * 16, hipMemcpyDeviceToDevice, ctx->stream));
+      BG_HIP(hipMemcpyAsync(ks->pend_org.p + pos, part_org + h_bounds[b], cnt * 8, hipMemcpyDeviceToDevice, ctx->stream));
       pos += cnt;
     }
     bg_kmerset tmp;
