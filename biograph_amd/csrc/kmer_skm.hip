@@ -236,7 +236,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_generate_kernel(SkSource src, S
 }
 
 // ---- further levels: one unstable pass over records already grouped into segments ------------------
-constexpr int SK2_ITEMS = 8;
+constexpr int SK2_ITEMS = 12;
 constexpr int SK2_TILE = SK_THREADS * SK2_ITEMS;
 struct SkSegs {
   const uint64_t* seg_rec0;   // S+1 record offsets
