@@ -621,13 +621,17 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
   const double per_read = double(maxw) * 2.0 / double(w + 1) + 1.5;
   SkSource src{reads->words.p, reads->nmask.p, reads->len.p, reads->n, reads->W, k,
                std::max(1, int(double(SK_TARGET) / per_read)), nmax};
+  // test hooks: BG_SKM_READS_PER_TILE overfills the LDS staging area (one-record-at-a-time path),
+  // BG_SKM_CAP shrinks the record buffer (fallback to the instance path)
+  if (const char* e = getenv("BG_SKM_READS_PER_TILE")) src.reads_per_tile = std::max(1, std::min(60000, atoi(e)));
   const uint64_t ntiles64 = (reads->n + src.reads_per_tile - 1) / src.reads_per_tile;
   if (ntiles64 >= (1ull << 31)) return BG_OK;
   const uint32_t ntiles = uint32_t(ntiles64);
 
   // level 0: records straight from the packed reads.  Their number is not known beforehand: room for 3x the
   // expected density (2 / (w + 1) records per window); an input that beats it takes the instance path.
-  const uint64_t cap = std::min<uint64_t>(N, uint64_t(double(N) * 6.0 / double(w + 1)) + reads->n + 1024);
+  uint64_t cap = std::min<uint64_t>(N, uint64_t(double(N) * 6.0 / double(w + 1)) + reads->n + 1024);
+  if (const char* e = getenv("BG_SKM_CAP")) cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
   DevBuf<SkRec> ra, rb;
   DevBuf<uint64_t> oa, ob, oc;  // origin (read : first window) of every record, moved along with it
   DevBuf<unsigned long long> cursor;

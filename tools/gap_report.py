@@ -21,6 +21,13 @@ def main():
     span = rows[-1][1] - rows[0][0]
     busy = sum(e - s for s, e, _ in rows)
     print(f"kernels {len(rows)} span {span/1e6:.2f} ms busy {busy/1e6:.2f} ms idle {(span-busy)/1e6:.2f} ms")
+    by_name = {}
+    for st, en, nm in rows:
+        c = by_name.setdefault(nm, [0, 0])
+        c[0] += en - st; c[1] += 1
+    print("busy time by kernel:")
+    for nm, (t, c) in sorted(by_name.items(), key=lambda kv: -kv[1][0])[:45]:
+        print(f"  {t/1e6:8.3f} ms  x{c:<4d} {nm}")
     gaps = []
     for a, b in zip(rows, rows[1:]):
         gaps.append((b[0] - a[1], a[2], b[2]))
