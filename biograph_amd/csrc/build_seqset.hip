@@ -14,6 +14,8 @@
 #include "bg_internal.h"
 #include "compact.h"
 
+#include <stdlib.h>
+
 namespace bg {
 
 // ------------------------------------------------------------------------------------------------
@@ -243,6 +245,72 @@ __global__ __launch_bounds__(256) void k_sort_small_groups(const uint64_t* __res
     }
     flags[i] = big;
   }
+}
+
+// Medium tie groups (kSmallGroup < size <= kMediumGroup): one workgroup per group stages the group's keys in
+// LDS and orders them with a bitonic network of full-key compares.  Only larger groups go to the radix rounds
+// (dozens of tiny launches per round, whatever the number of records).
+constexpr int kMediumGroup = 1024;
+
+__global__ void k_tied_run_heads(const uint32_t* __restrict__ tpos, const uint64_t* __restrict__ tkey, uint64_t T,
+                                 uint8_t* __restrict__ head) {
+  uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  head[t] = (t == 0 || tpos[t] != tpos[t - 1] + 1 || tkey[t] != tkey[t - 1]) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_sort_medium_groups(const uint32_t* __restrict__ hpos, uint64_t G, uint64_t T,
+                                                            const uint32_t* __restrict__ tpos,
+                                                            const uint64_t* __restrict__ rec,
+                                                            const uint8_t* __restrict__ rlen, int W,
+                                                            uint32_t* __restrict__ sidx, uint8_t* __restrict__ still) {
+  extern __shared__ uint64_t mg_smem[];
+  uint64_t* skey = mg_smem;                                                  // kMediumGroup * W
+  uint32_t* sid = reinterpret_cast<uint32_t*>(skey + size_t(kMediumGroup) * W);  // record of each member
+  uint16_t* perm = reinterpret_cast<uint16_t*>(sid + kMediumGroup);          // sorted order -> member
+  uint8_t* slen = reinterpret_cast<uint8_t*>(perm + kMediumGroup);
+  const uint64_t g = blockIdx.x;
+  const uint32_t t0 = hpos[g];
+  const uint32_t t1 = g + 1 < G ? hpos[g + 1] : uint32_t(T);
+  const uint32_t size = t1 - t0;
+  const int tid = threadIdx.x;
+  if (size > uint32_t(kMediumGroup)) {  // block-uniform
+    for (uint32_t i = tid; i < size; i += 256) still[t0 + i] = 1;
+    return;
+  }
+  const uint32_t p0 = tpos[t0];  // the group occupies sorted positions p0 .. p0 + size
+  for (uint32_t i = tid; i < size; i += 256) {
+    const uint32_t r = sidx[p0 + i];
+    sid[i] = r;
+    slen[i] = rlen[r];
+  }
+  uint32_t P = 1;
+  while (P < size) P <<= 1;
+  for (uint32_t i = tid; i < P; i += 256) perm[i] = i < size ? uint16_t(i) : uint16_t(0xffff);
+  __syncthreads();
+  for (uint32_t x = tid; x < size * uint32_t(W); x += 256) {
+    const uint32_t i = x / uint32_t(W), w = x - i * uint32_t(W);
+    skey[x] = rec[uint64_t(sid[i]) * W + w];
+  }
+  __syncthreads();
+  for (uint32_t k2 = 2; k2 <= P; k2 <<= 1) {
+    for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = tid; i < P; i += 256) {
+        const uint32_t x = i ^ j;
+        if (x > i) {
+          const uint16_t a = perm[i], b = perm[x];
+          // padding (0xffff) sorts after every member
+          const bool gt = a == 0xffff ? b != 0xffff
+                                      : (b != 0xffff && key_compare(skey + size_t(a) * W, slen[a], skey + size_t(b) * W,
+                                                                    slen[b], W) > 0);
+          const bool up = (i & k2) == 0;
+          if (gt == up) { perm[i] = b; perm[x] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t i = tid; i < size; i += 256) sidx[p0 + i] = sid[perm[i]];
 }
 
 // subset element t sits at sorted position tpos[t]; it starts a group unless it continues the run of
@@ -771,6 +839,40 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
       BG_LAUNCH_CHECK();
     }
     ks.reset();
+    if (T && !getenv("BG_NO_MEDIUM_GROUPS")) {
+      // groups up to kMediumGroup are finished here; what is left for the rounds below is usually nothing
+      DevBuf<uint8_t> head, still;
+      DevBuf<uint32_t> hpos, keep_t;
+      uint64_t G = 0, T2 = 0;
+      BG_TRY(head.alloc(ctx, T));
+      BG_TRY(still.alloc(ctx, T));
+      BG_HIP(hipMemsetAsync(still.p, 0, T, ctx->stream));
+      k_tied_run_heads<<<cdiv(T, 256), 256, 0, ctx->stream>>>(tpos.p, tkey.p, T, head.p);
+      BG_LAUNCH_CHECK();
+      BG_TRY(compact_flagged<uint32_t>(ctx, head.p, T, &hpos, &G));
+      const size_t smem = size_t(kMediumGroup) * (size_t(W) * 8 + 4 + 2 + 1);
+      BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_medium_groups),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
+      ctx->tic("suffix_medium_ties");
+      k_sort_medium_groups<<<unsigned(G), 256, smem, ctx->stream>>>(hpos.p, G, T, tpos.p, rec.p, rlen.p, W, sidx.p, still.p);
+      BG_LAUNCH_CHECK();
+      ctx->toc(T * (uint64_t(W) * 8 + 9));
+      BG_TRY(compact_flagged<uint32_t>(ctx, still.p, T, &keep_t, &T2));
+      DevBuf<uint32_t> tpos2;
+      DevBuf<uint64_t> tkey2;
+      BG_TRY(tpos2.alloc(ctx, T2));
+      BG_TRY(tkey2.alloc(ctx, T2));
+      if (T2) {
+        k_gather_u32_by_u32<<<cdiv(T2, 256), 256, 0, ctx->stream>>>(tpos.p, keep_t.p, T2, tpos2.p);
+        BG_LAUNCH_CHECK();
+        k_gather_u64_by_u32<<<cdiv(T2, 256), 256, 0, ctx->stream>>>(tkey.p, keep_t.p, T2, tkey2.p);
+        BG_LAUNCH_CHECK();
+      }
+      BG_HIP(hipStreamSynchronize(ctx->stream));
+      tpos = std::move(tpos2);
+      tkey = std::move(tkey2);
+      T = T2;
+    }
   bool have_gid = false;
   for (int w = 0; w <= W && T; ++w) {  // w = 0: the bits of the first word the sort skipped
     // groups of this round = runs of equal (previous group, previous key) at adjacent positions
