@@ -124,12 +124,14 @@ __global__ __launch_bounds__(256) void k_cover_count(CoverIndex ci, const uint64
 // output WORDS (lane = consecutive word), find the read a word belongs to by a 6-step search over the
 // 64 record offsets held one per lane, and write fully coalesced — instead of one lane looping over all
 // the records of its read.
+constexpr int kSortSkipBits = 32;  // the sort key keeps the leading 16 bases of a record (see k_first_words)
+
 __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict__ owords,
                                                       const uint16_t* __restrict__ len,
                                                       const uint32_t* __restrict__ cnt,
                                                       const uint64_t* __restrict__ roff, uint64_t o_base,
                                                       uint64_t n_emit, int W, uint64_t* __restrict__ rec,
-                                                      uint8_t* __restrict__ rlen) {
+                                                      uint8_t* __restrict__ rlen, uint64_t* __restrict__ k0) {
   const int lane = threadIdx.x & 63;
   const uint64_t t0 = (uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 64;
   if (t0 >= n_emit) return;
@@ -167,8 +169,12 @@ __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict
     if (x < nwords) {
       const int j = int(q - off);
       const uint64_t* s = owords + (o_base + t0 + uint64_t(lo)) * uint64_t(W);
-      rec[q * uint64_t(W) + w] = window32(s, W, j + 32 * w);
-      if (w == 0) rlen[q] = uint8_t(L - j);
+      const uint64_t word = window32(s, W, j + 32 * w);
+      rec[q * uint64_t(W) + w] = word;
+      if (w == 0) {
+        rlen[q] = uint8_t(L - j);
+        if (k0) k0[q] = (word & ~((1ull << kSortSkipBits) - 1)) | q;  // the sort key (k_first_words), for free
+      }
     }
   }
 }
@@ -177,8 +183,6 @@ __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict
 // half — a keys-only sort on bits 32..63 (4 radix passes moving 8 bytes per record instead of 5-8 passes
 // moving 12).  Records that agree on their leading 16 bases are almost always suffixes at the same genome
 // position, which the tie handling orders by full-key compares anyway.
-constexpr int kSortSkipBits = 32;
-
 __global__ void k_first_words(const uint64_t* __restrict__ rec, uint64_t n, int W, uint64_t* __restrict__ k0) {
   uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r >= n) return;
@@ -210,39 +214,48 @@ __global__ void k_flag_ties(const uint64_t* __restrict__ skeys, uint64_t n, uint
 // one lane with full-key comparisons (insertion sort on record ids; the keys are gathered from the
 // record store).  Only larger groups are flagged for the word-by-word radix rounds below.
 constexpr int kSmallGroup = 32;
+// skeys = the sorted packed keys (leading bases in the high half, record index in the low half): this kernel
+// also splits them, i.e. writes sidx for every position.
 __global__ __launch_bounds__(256) void k_sort_small_groups(const uint64_t* __restrict__ skeys, uint64_t n,
                                                            const uint64_t* __restrict__ rec,
                                                            const uint8_t* __restrict__ rlen, int W,
                                                            uint32_t* __restrict__ sidx, uint8_t* __restrict__ flags) {
   uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) {
-    uint64_t k = skeys[i];
-    bool tied = (i > 0 && skeys[i - 1] == k) || (i + 1 < n && skeys[i + 1] == k);
+    const uint64_t kv = skeys[i];
+    const uint32_t k = uint32_t(kv >> kSortSkipBits);
+    auto hi = [&](uint64_t p) { return uint32_t(skeys[p] >> kSortSkipBits); };
+    bool tied = (i > 0 && hi(i - 1) == k) || (i + 1 < n && hi(i + 1) == k);
     uint8_t big = 0;
+    bool small_member = false;
     if (tied) {
       uint64_t s = i, e = i + 1;
-      while (s > 0 && i - s <= uint64_t(kSmallGroup) && skeys[s - 1] == k) --s;
-      while (e < n && e - s <= uint64_t(kSmallGroup) && skeys[e] == k) ++e;
+      while (s > 0 && i - s <= uint64_t(kSmallGroup) && hi(s - 1) == k) --s;
+      while (e < n && e - s <= uint64_t(kSmallGroup) && hi(e) == k) ++e;
       if (e - s > uint64_t(kSmallGroup)) {
         big = 1;
-      } else if (s == i) {  // head of a small group: sort its members
-        int g = int(e - s);
-        uint32_t idx[kSmallGroup];
-        for (int a = 0; a < g; ++a) idx[a] = sidx[s + a];
-        for (int a = 1; a < g; ++a) {
-          uint32_t x = idx[a];
-          const uint64_t* xk = rec + uint64_t(x) * W;
-          int xl = rlen[x];
-          int b = a - 1;
-          while (b >= 0 && key_compare(rec + uint64_t(idx[b]) * W, rlen[idx[b]], xk, xl, W) > 0) {
-            idx[b + 1] = idx[b];
-            --b;
+      } else {
+        small_member = true;
+        if (s == i) {  // head of a small group: sort its members
+          int g = int(e - s);
+          uint32_t idx[kSmallGroup];
+          for (int a = 0; a < g; ++a) idx[a] = uint32_t(skeys[s + a]);
+          for (int a = 1; a < g; ++a) {
+            uint32_t x = idx[a];
+            const uint64_t* xk = rec + uint64_t(x) * W;
+            int xl = rlen[x];
+            int b = a - 1;
+            while (b >= 0 && key_compare(rec + uint64_t(idx[b]) * W, rlen[idx[b]], xk, xl, W) > 0) {
+              idx[b + 1] = idx[b];
+              --b;
+            }
+            idx[b + 1] = x;
           }
-          idx[b + 1] = x;
+          for (int a = 0; a < g; ++a) sidx[s + a] = idx[a];
         }
-        for (int a = 0; a < g; ++a) sidx[s + a] = idx[a];
       }
     }
+    if (!small_member) sidx[i] = uint32_t(kv);  // members of small groups are written by their head
     flags[i] = big;
   }
 }
@@ -335,6 +348,12 @@ __global__ void k_gather_u64_by_u32(const uint64_t* __restrict__ src, const uint
                                     uint64_t* __restrict__ dst) {
   uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[idx[i]];
+}
+// leading-bases part of the packed sort keys at the given positions
+__global__ void k_gather_key_prefix(const uint64_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n,
+                                    uint64_t* __restrict__ dst) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]] & ~((1ull << kSortSkipBits) - 1);
 }
 __global__ void k_gather_u32_by_u32(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n,
                                     uint32_t* __restrict__ dst) {
@@ -705,7 +724,7 @@ namespace bg {
 // Phase A: suffix records of reads [lo, hi) under the exact-cover rule; the cover index spans ALL
 // reads of `reads` (in a sharded build every rank holds the gathered corrected reads).
 int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t hi, int cover_k,
-                        DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out) {
+                        DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out, DevBuf<uint64_t>* k0) {
   const uint64_t n = reads->n;
   const uint64_t n_o = 2 * n;
   const int W = reads->W;
@@ -776,12 +795,14 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   BG_HIP(hipStreamSynchronize(ctx->stream));
   BG_TRY(rec->alloc(ctx, n_rec * W));
   BG_TRY(rlen->alloc(ctx, n_rec));
+  const bool want_k0 = k0 && n_rec < (1ull << 32);
+  if (want_k0) BG_TRY(k0->alloc(ctx, n_rec));
   if (n_rec) {
     ctx->tic("suffix_emit");
     k_emit_records<<<cdiv(cdiv(n_emit, 64), 4), 256, 0, ctx->stream>>>(owords.p, reads->len.p, cnt.p, roff.p, o_base, n_emit, W,
-                                                               rec->p, rlen->p);
+                                                               rec->p, rlen->p, want_k0 ? k0->p : nullptr);
     BG_LAUNCH_CHECK();
-    ctx->toc(n_emit * W * 8 + n_rec * (W * 8 + 1));
+    ctx->toc(n_emit * W * 8 + n_rec * (W * 8 + 1 + (want_k0 ? 8 : 0)));
   }
   *n_rec_out = n_rec;
   return BG_OK;
@@ -790,7 +811,7 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
 // Phase B: sort the records, drop prefixes/duplicates, build keys/sizes/shared of the surviving
 // entries into `ss`.  Consumes rec/rlen.
 int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t>& rlen, uint64_t n_rec, int W,
-                              bg_seqset* ss, uint64_t* n_tied_out) {
+                              bg_seqset* ss, uint64_t* n_tied_out, DevBuf<uint64_t>* k0) {
   if (n_rec >= (1ull << 32)) {
     set_error("%llu suffix records exceed one shard", (unsigned long long)n_rec);
     return BG_EINVAL;
@@ -800,21 +821,21 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
   {
     // ---- sort by the leading 16 bases (record index packed into the key)
     DevBuf<uint64_t> k0a, k0b;
-    BG_TRY(k0a.alloc(ctx, n_rec));
-    BG_TRY(k0b.alloc(ctx, n_rec));
-    if (n_rec) {
-      k_first_words<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(rec.p, n_rec, W, k0a.p);
-      BG_LAUNCH_CHECK();
+    if (k0 && k0->p && k0->n == n_rec) {  // the emission wrote the sort keys along with the records
+      k0a = std::move(*k0);
+    } else {
+      BG_TRY(k0a.alloc(ctx, n_rec));
+      if (n_rec) {
+        k_first_words<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(rec.p, n_rec, W, k0a.p);
+        BG_LAUNCH_CHECK();
+      }
     }
+    BG_TRY(k0b.alloc(ctx, n_rec));
     bool in_b = false;
     BG_TRY(radix_sort_u64(ctx, k0a.p, k0b.p, nullptr, nullptr, n_rec, kSortSkipBits, 64, &in_b));
     DevBuf<uint64_t>& ks = in_b ? k0b : k0a;
     (in_b ? k0a : k0b).reset();
-    BG_TRY(sidx.alloc(ctx, n_rec));
-    if (n_rec) {
-      k_split_sorted<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(ks.p, n_rec, sidx.p);
-      BG_LAUNCH_CHECK();
-    }
+    BG_TRY(sidx.alloc(ctx, n_rec));  // written by k_sort_small_groups
 
     // ---- small tie groups in-lane; larger ones word by word, then by length
     DevBuf<uint32_t> tpos;   // subset slot -> sorted position
@@ -835,7 +856,7 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
     }
     if (T) {
       BG_TRY(tkey.alloc(ctx, T));
-      k_gather_u64_by_u32<<<cdiv(T, 256), 256, 0, ctx->stream>>>(ks.p, tpos.p, T, tkey.p);
+      k_gather_key_prefix<<<cdiv(T, 256), 256, 0, ctx->stream>>>(ks.p, tpos.p, T, tkey.p);
       BG_LAUNCH_CHECK();
     }
     ks.reset();
@@ -1091,8 +1112,9 @@ extern "C" int bg_seqset_build(bg_ctx* ctx, const bg_reads* reads, int cover_k, 
   uint64_t n_rec = 0, n_tied = 0;
   DevBuf<uint64_t> rec;
   DevBuf<uint8_t> rlen;
-  BG_TRY(suffix_records_impl(ctx, reads, 0, reads->n, cover_k, &rec, &rlen, &n_rec));
-  BG_TRY(entries_from_records_impl(ctx, rec, rlen, n_rec, reads->W, ss.get(), &n_tied));
+  DevBuf<uint64_t> k0;
+  BG_TRY(suffix_records_impl(ctx, reads, 0, reads->n, cover_k, &rec, &rlen, &n_rec, &k0));
+  BG_TRY(entries_from_records_impl(ctx, rec, rlen, n_rec, reads->W, ss.get(), &n_tied, &k0));
   BG_TRY(prev_bits_local_impl(ctx, ss.get()));
   // the longest read is never a proper prefix of anything longer, so it survives as an entry
   ss->max_len = ss->n ? reads->max_len : 0;
