@@ -164,6 +164,7 @@ struct bg_seqset {
   uint32_t max_len = 0;
   int W = 0;                        // words per entry key (0 when opened from a file)
   bg::DevBuf<uint64_t> keys;        // n*W entry sequences (only after a build)
+  bg::DevBuf<uint64_t> pre2;        // n*2: the first two words of every entry, dense (search accelerator of the build)
   bg::DevBuf<uint8_t> sizes, shared;
   bg::DevBuf<uint64_t> bits[4], subaccum[4], accum[4];
   bg::DevBuf<uint8_t> min1, min2;

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_lcp_keep(
 __global__ void k_build_entries(const uint64_t* __restrict__ skeys, const uint8_t* __restrict__ slen,
                                 const uint8_t* __restrict__ lcp_prev, const uint32_t* __restrict__ kept_pos,
                                 uint64_t n_ent, int W, uint64_t* __restrict__ ekeys, uint8_t* __restrict__ sizes,
-                                uint8_t* __restrict__ shared) {
+                                uint8_t* __restrict__ shared, uint64_t* __restrict__ pre2) {
   uint64_t e = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (e >= n_ent) return;
   uint32_t p = kept_pos[e];
@@ -463,7 +463,15 @@ __global__ void k_build_entries(const uint64_t* __restrict__ skeys, const uint8_
   if (e == 0) sh = 0;
   sizes[e] = slen[p];
   shared[e] = uint8_t(sh);
-  for (int w = 0; w < W; ++w) ekeys[e * W + w] = skeys[uint64_t(p) * W + w];
+  uint64_t k0 = 0, k1 = 0;
+  for (int w = 0; w < W; ++w) {
+    const uint64_t v = skeys[uint64_t(p) * W + w];
+    ekeys[e * W + w] = v;
+    if (w == 0) k0 = v;
+    if (w == 1) k1 = v;
+  }
+  pre2[e * 2] = k0;
+  pre2[e * 2 + 1] = k1;
 }
 
 // Directory over the leading kPrefixBases bases of the sorted entries: dir[p] = first entry whose
@@ -591,6 +599,51 @@ __global__ __launch_bounds__(256) void k_prev_bits(const uint64_t* __restrict__ 
   }
   // one byte per (base, target): neighbouring entries hit neighbouring targets, so a shared 64-bit word
   // would serialise 64 same-address atomics per wave; bytes are plain coalesced stores, packed below
+  marks[uint64_t(b) * n + lo] = 1;
+}
+
+// The same with the search run on the dense two-word prefixes (16 bytes per entry instead of W*8: the
+// candidates of one search share a line or two, and neighbouring threads' windows overlap).  A tail of at
+// least 64 bases whose two leading words occur in exactly one entry has found its target; anything else
+// (short tails, entries that agree on their first 64 bases) takes the full-key search.  `verify` re-checks
+// the unambiguous targets against the full keys as well (BG_VERIFY_CLOSURE=1; the tests run both ways).
+__global__ __launch_bounds__(256) void k_prev_bits_pre2(const uint64_t* __restrict__ ekeys,
+                                                        const uint64_t* __restrict__ pre2,
+                                                        const uint8_t* __restrict__ sizes, uint64_t n, int W,
+                                                        const uint32_t* __restrict__ dir, int bases,
+                                                        uint8_t* __restrict__ marks, uint32_t* __restrict__ err,
+                                                        int verify) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t* s = ekeys + i * W;
+  const int b = int(s[0] >> 62);
+  const int tl = int(sizes[i]) - 1;
+  uint64_t tail[kMaxWords];
+  for (int w = 0; w < W; ++w) tail[w] = window32(s, W, 1 + 32 * w);
+  const uint64_t t0 = tail[0], t1 = W > 1 ? tail[1] : 0;
+  uint64_t lo;
+  bool sure = false;
+  if (tl >= 64) {
+    const uint32_t p = uint32_t(t0 >> (64 - 2 * bases));
+    uint64_t a = dir[p], z = dir[p + 1];
+    while (a < z) {  // first entry whose two leading words are >= the tail's
+      const uint64_t mid = (a + z) >> 1;
+      const uint64_t m0 = pre2[mid * 2], m1 = pre2[mid * 2 + 1];
+      if (m0 < t0 || (m0 == t0 && m1 < t1)) a = mid + 1; else z = mid;
+    }
+    lo = a;
+    sure = lo < n && pre2[lo * 2] == t0 && pre2[lo * 2 + 1] == t1 &&
+           (lo + 1 >= n || pre2[lo * 2 + 2] != t0 || pre2[lo * 2 + 3] != t1);
+  }
+  if (!sure || verify) {
+    const uint64_t full = entries_lower_bound(ekeys, sizes, n, W, dir, bases, tail, tl);
+    if (sure && full != lo) atomicOr(err, 4u);  // the shortcut disagrees with the full search
+    lo = full;
+    if (lo >= n || key_lcp(ekeys + lo * W, sizes[lo], tail, tl, W) < tl) {
+      atomicOr(err, 2u);
+      return;
+    }
+  }
   marks[uint64_t(b) * n + lo] = 1;
 }
 
@@ -1010,14 +1063,15 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
     ss->n = n_ent;
     ss->W = W;
     BG_TRY(ss->keys.alloc(ctx, n_ent * W));
+    BG_TRY(ss->pre2.alloc(ctx, n_ent * 2));
     BG_TRY(ss->sizes.alloc(ctx, n_ent));
     BG_TRY(ss->shared.alloc(ctx, n_ent));
     if (n_ent) {
       ctx->tic("entries_build");
       k_build_entries<<<cdiv(n_ent, 256), 256, 0, ctx->stream>>>(skeys.p, slen.p, lcp_prev.p, kept_pos.p, n_ent, W,
-                                                                ss->keys.p, ss->sizes.p, ss->shared.p);
+                                                                ss->keys.p, ss->sizes.p, ss->shared.p, ss->pre2.p);
       BG_LAUNCH_CHECK();
-      ctx->toc(n_ent * (W * 16 + 8));
+      ctx->toc(n_ent * (W * 16 + 8 + 16));
     }
   }
   uint32_t h_err[2] = {0, 0};
@@ -1080,11 +1134,19 @@ int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss) {
   if (n_ent) {
     ctx->tic("prev_bits");
     int bases = 0;
-    BG_TRY(build_prefix_dir(ctx, ss, &dir, &bases));
+    const bool use_pre2 = ss->pre2.p && ss->pre2.n == 2 * n_ent && !getenv("BG_PREV_FULL_SEARCH");
+    if (use_pre2) BG_TRY(build_prefix_dir_keys(ctx, ss->pre2.p, n_ent, 2, &dir, &bases));
+    else BG_TRY(build_prefix_dir(ctx, ss, &dir, &bases));
     BG_TRY(marks.alloc(ctx, 4 * n_ent));
     BG_HIP(hipMemsetAsync(marks.p, 0, 4 * n_ent, ctx->stream));
-    k_prev_bits<<<cdiv(n_ent, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->sizes.p, n_ent, ss->W, dir.p, bases, marks.p,
-                                                           err.p);
+    if (use_pre2) {
+      const char* v = getenv("BG_VERIFY_CLOSURE");
+      k_prev_bits_pre2<<<cdiv(n_ent, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->pre2.p, ss->sizes.p, n_ent, ss->W, dir.p,
+                                                                  bases, marks.p, err.p, v && v[0] == '1');
+    } else {
+      k_prev_bits<<<cdiv(n_ent, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->sizes.p, n_ent, ss->W, dir.p, bases, marks.p,
+                                                             err.p);
+    }
     BG_LAUNCH_CHECK();
     BG_TRY(pack_marks(ctx, ss, marks.p));
     ctx->toc(n_ent * (ss->W * 8 + 1 + 8));
@@ -1093,6 +1155,7 @@ int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss) {
   BG_HIP(hipMemcpyAsync(h_err, err.p, 8, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
   if (h_err[0] & 2) { set_error("missing expansion (entry set not closed under pop_front)"); return BG_EINTERNAL; }
+  if (h_err[0] & 4) { set_error("prev bits: the two-word search disagrees with the full-key search (internal error)"); return BG_EINTERNAL; }
   return BG_OK;
 }
 

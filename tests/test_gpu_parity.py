@@ -112,6 +112,19 @@ def test_seqset_build_matches_oracle(ctx, seed, alphabet, K, rl, var):
     assert st["n_entries"] == ss.size() and st["n_records"] >= st["n_entries"]
 
 
+@pytest.mark.parametrize("env", [{"BG_VERIFY_CLOSURE": "1"}, {"BG_PREV_FULL_SEARCH": "1"}, {"BG_NO_MEDIUM_GROUPS": "1"}])
+@pytest.mark.parametrize("seed,alphabet,rl", [(11, "ACGT", 150), (12, "AC", 200), (13, "AT", 255)])
+def test_seqset_build_search_modes(ctx, monkeypatch, env, seed, alphabet, rl):
+    """The prev-bit search on two-word prefixes re-checked against the full-key search (BG_VERIFY_CLOSURE),
+    the full-key search alone, and the tie handling without the medium-group kernel: same seqset."""
+    for a, b in env.items():
+        monkeypatch.setenv(a, b)
+    reads = util.synth_reads(seed, genome_len=2500, n_reads=700, read_len=rl, err=0.01, n_rate=0.0,
+                             alphabet=alphabet, var_len=True, repeat=(9, 40))
+    ss, _ = ctx.build_seqset(ctx.pack_reads(reads), 20)
+    _check_seqset_against_oracle(ss, reads)
+
+
 def test_builder_test_known_answers(ctx):
     # modules/build_seqset/builder_test.cpp:52-123 through the HIP path
     t, trc = O.tseq, O.tseq_rc
