@@ -445,6 +445,140 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_lcp_keep(
   keep[pos] = drop ? 0 : 1;
 }
 
+// The three steps above and below in one pass (gather, lcp / keep, compaction + entry build): the gathered tile
+// never leaves LDS.  The position of a tile's first surviving record in the output is the number of survivors
+// in all earlier tiles: a single-pass scan with decoupled look-back — a tile publishes its own count at once
+// (state = AGG | count), adds up its predecessors' states until it meets one that already carries its inclusive
+// prefix, then publishes its own (INCL | prefix).  Tiles take their number from a ticket counter, so every
+// predecessor a tile waits for is already running.
+// shared[e] = LCP of consecutive survivors (= min of the LCPs over the dropped run between them, LCP being
+// transitive through prefixes); a tile's first survivor gets it from k_fix_tile_first_shared.
+constexpr uint64_t kScanAgg = 1ull << 62, kScanIncl = 2ull << 62, kScanVal = (1ull << 62) - 1;
+
+__global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
+    const uint64_t* __restrict__ rec, const uint8_t* __restrict__ rlen, const uint32_t* __restrict__ sidx, uint64_t n,
+    int W, unsigned long long* __restrict__ state, uint32_t* __restrict__ ticket, uint64_t* __restrict__ ekeys,
+    uint8_t* __restrict__ sizes, uint8_t* __restrict__ shared, uint64_t* __restrict__ pre2,
+    uint64_t* __restrict__ tile_first, uint32_t* __restrict__ err) {
+  extern __shared__ uint64_t tile[];  // (kGatherTile + 2) * W words, then lengths, per-position lcp, keep flags
+  uint8_t* tlen = reinterpret_cast<uint8_t*>(tile + (kGatherTile + 2) * W);
+  uint8_t* tlcp = tlen + kGatherTile + 2;
+  uint8_t* tkeep = tlcp + kGatherTile;
+  __shared__ uint32_t s_tile, s_wave[kGatherTile / 64];
+  __shared__ unsigned long long s_excl;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const uint64_t t = s_tile;
+  const uint64_t b0 = t * kGatherTile;
+  for (int g = tid; g < (kGatherTile + 2) * W; g += kGatherTile) {
+    int i = g / W, w = g - i * W;
+    uint64_t pos = b0 + uint64_t(i) - 1;  // wraps for the missing predecessor of position 0
+    if (pos < n) {
+      uint32_t r = sidx[pos];
+      tile[g] = rec[uint64_t(r) * W + w];
+      if (w == 0) tlen[i] = rlen[r];
+    }
+  }
+  __syncthreads();
+  const uint64_t pos = b0 + tid;
+  const uint64_t* a = tile + (tid + 1) * W;
+  const int alen = tlen[tid + 1];
+  bool keep = false;
+  if (pos < n) {
+    int lp = 0;
+    if (pos > 0) {
+      lp = key_lcp(a - W, tlen[tid], a, alen, W);
+      if (key_compare(a - W, tlen[tid], a, alen, W) > 0) atomicOr(err, 1u);  // not sorted
+    }
+    tlcp[tid] = uint8_t(lp);
+    // a record that is a prefix of (or equal to) its successor is dropped (expand.cpp:19-48 skip_dups)
+    keep = !(pos + 1 < n && key_lcp(a, alen, a + W, tlen[tid + 2], W) == alen);
+  }
+  tkeep[tid] = keep ? 1 : 0;
+  // rank of the survivors inside the tile
+  const uint64_t km = __ballot(keep);
+  if (lane == 0) s_wave[wave] = uint32_t(__popcll(km));
+  __syncthreads();
+  uint32_t before = uint32_t(__popcll(km & ((1ull << lane) - 1))), count = 0;
+  for (int w2 = 0; w2 < kGatherTile / 64; ++w2) {
+    if (w2 < wave) before += s_wave[w2];
+    count += s_wave[w2];
+  }
+  // decoupled look-back (wave 0)
+  if (wave == 0) {
+    if (lane == 0)
+      __hip_atomic_store(&state[t], (t == 0 ? kScanIncl : kScanAgg) | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long excl = 0;
+    if (t > 0) {
+      int64_t j = int64_t(t) - 1;
+      for (;;) {
+        const int64_t idx = j - lane;
+        // (the state words are self-contained: relaxed accesses are enough)
+        const unsigned long long v =
+            idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kScanIncl;
+        const int flag = int(v >> 62);
+        const uint64_t incl = __ballot(flag == 2), inval = __ballot(flag == 0);
+        const int first = incl ? __ffsll((unsigned long long)incl) - 1 : 64;  // nearest predecessor with a prefix
+        const uint64_t upto = first >= 63 ? ~0ull : ((2ull << first) - 1);     // lanes 0..first
+        if (inval & upto) {
+          // someone in between has not published yet: one lane polls that one state, with a pause between polls
+          // (thousands of tiles polling 64 states each at full speed take the L2 away from the gathers)
+          const int64_t widx = j - (__ffsll((unsigned long long)(inval & upto)) - 1);
+          if (lane == 0)
+            while ((__hip_atomic_load(&state[widx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 62) == 0)
+              __builtin_amdgcn_s_sleep(32);
+          continue;
+        }
+        unsigned long long part = (lane <= first) ? (v & kScanVal) : 0ull;
+#pragma unroll
+        for (int d = 32; d; d >>= 1) part += __shfl_xor(part, d, 64);
+        excl += part;
+        if (incl) break;
+        j -= 64;
+      }
+      if (lane == 0)
+        __hip_atomic_store(&state[t], kScanIncl | (excl + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) {
+      s_excl = excl;
+      tile_first[t] = count ? excl : ~0ull;
+    }
+  }
+  __syncthreads();
+  if (!keep) return;
+  const uint64_t e = s_excl + before;
+  sizes[e] = uint8_t(alen);
+  uint64_t k0 = 0, k1 = 0;
+  for (int w = 0; w < W; ++w) {
+    const uint64_t v = a[w];
+    ekeys[e * W + w] = v;
+    if (w == 0) k0 = v;
+    if (w == 1) k1 = v;
+  }
+  pre2[e * 2] = k0;
+  pre2[e * 2 + 1] = k1;
+  if (before) {  // min lcp over the dropped run back to the previous survivor (which is in this tile)
+    int sh = tlcp[tid];
+    for (int q = tid - 1; !tkeep[q]; --q) {
+      const int v = tlcp[q];
+      sh = v < sh ? v : sh;
+    }
+    shared[e] = uint8_t(sh);
+  }
+}
+
+// shared of every tile's first survivor: LCP with the survivor before it (in an earlier tile)
+__global__ void k_fix_tile_first_shared(const uint64_t* __restrict__ tile_first, uint64_t ntiles,
+                                        const uint64_t* __restrict__ ekeys, const uint8_t* __restrict__ sizes, int W,
+                                        uint8_t* __restrict__ shared) {
+  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= ntiles) return;
+  const uint64_t e = tile_first[t];
+  if (e == ~0ull) return;
+  shared[e] = e ? uint8_t(key_lcp(ekeys + (e - 1) * W, sizes[e - 1], ekeys + e * W, sizes[e], W)) : uint8_t(0);
+}
+
 // entry e = kept position p: sizes, shared = min lcp over the dropped run before p (lcp is
 // "transitive" through prefixes), keys.
 __global__ void k_build_entries(const uint64_t* __restrict__ skeys, const uint8_t* __restrict__ slen,
@@ -1042,7 +1176,41 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
   DevBuf<uint32_t> err;
   BG_TRY(err.alloc(ctx, 2));
   BG_HIP(hipMemsetAsync(err.p, 0, 8, ctx->stream));
-  {
+  if (!getenv("BG_ENTRIES_UNFUSED")) {
+    // one pass: gather + dedup + entry build (the arrays are sized for n_rec entries, ~10 % more than survive)
+    ss->W = W;
+    BG_TRY(ss->keys.alloc(ctx, n_rec * W));
+    BG_TRY(ss->pre2.alloc(ctx, n_rec * 2));
+    BG_TRY(ss->sizes.alloc(ctx, n_rec));
+    BG_TRY(ss->shared.alloc(ctx, n_rec));
+    if (n_rec) {
+      const uint64_t ntiles = (n_rec + kGatherTile - 1) / kGatherTile;
+      DevBuf<unsigned long long> state;
+      DevBuf<uint64_t> tile_first;
+      DevBuf<uint32_t> ticket;
+      BG_TRY(state.alloc(ctx, ntiles));
+      BG_TRY(tile_first.alloc(ctx, ntiles));
+      BG_TRY(ticket.alloc(ctx, 1));
+      BG_HIP(hipMemsetAsync(state.p, 0, ntiles * 8, ctx->stream));
+      BG_HIP(hipMemsetAsync(ticket.p, 0, 4, ctx->stream));
+      ctx->tic("entries_dedup_build");
+      const size_t lds = size_t(kGatherTile + 2) * W * 8 + (kGatherTile + 2) + 2 * kGatherTile;
+      k_gather_dedup_build<<<unsigned(ntiles), kGatherTile, lds, ctx->stream>>>(rec.p, rlen.p, sidx.p, n_rec, W, state.p,
+                                                                             ticket.p, ss->keys.p, ss->sizes.p, ss->shared.p,
+                                                                             ss->pre2.p, tile_first.p, err.p);
+      BG_LAUNCH_CHECK();
+      k_fix_tile_first_shared<<<cdiv(ntiles, 256), 256, 0, ctx->stream>>>(tile_first.p, ntiles, ss->keys.p, ss->sizes.p, W,
+                                                                          ss->shared.p);
+      BG_LAUNCH_CHECK();
+      ctx->toc(n_rec * (W * 8 * 2 + 8 + 16));
+      unsigned long long last = 0;
+      BG_HIP(hipMemcpyAsync(&last, state.p + (ntiles - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+      BG_HIP(hipStreamSynchronize(ctx->stream));
+      n_ent = last & kScanVal;
+    }
+    rec.reset(); rlen.reset(); sidx.reset();
+    ss->n = n_ent;
+  } else {
     DevBuf<uint64_t> skeys;
     DevBuf<uint8_t> slen, lcp_prev, keep;
     BG_TRY(skeys.alloc(ctx, n_rec * W));
@@ -1134,7 +1302,7 @@ int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss) {
   if (n_ent) {
     ctx->tic("prev_bits");
     int bases = 0;
-    const bool use_pre2 = ss->pre2.p && ss->pre2.n == 2 * n_ent && !getenv("BG_PREV_FULL_SEARCH");
+    const bool use_pre2 = ss->pre2.p && ss->pre2.n >= 2 * n_ent && !getenv("BG_PREV_FULL_SEARCH");
     if (use_pre2) BG_TRY(build_prefix_dir_keys(ctx, ss->pre2.p, n_ent, 2, &dir, &bases));
     else BG_TRY(build_prefix_dir(ctx, ss, &dir, &bases));
     BG_TRY(marks.alloc(ctx, 4 * n_ent));
