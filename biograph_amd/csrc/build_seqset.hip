@@ -464,6 +464,7 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
   uint8_t* tlen = reinterpret_cast<uint8_t*>(tile + (kGatherTile + 2) * W);
   uint8_t* tlcp = tlen + kGatherTile + 2;
   uint8_t* tkeep = tlcp + kGatherTile;
+  __shared__ uint32_t tidx[kGatherTile + 2];
   __shared__ uint32_t s_tile, s_wave[kGatherTile / 64];
   __shared__ unsigned long long s_excl;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -471,13 +472,37 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
   __syncthreads();
   const uint64_t t = s_tile;
   const uint64_t b0 = t * kGatherTile;
-  for (int g = tid; g < (kGatherTile + 2) * W; g += kGatherTile) {
-    int i = g / W, w = g - i * W;
-    uint64_t pos = b0 + uint64_t(i) - 1;  // wraps for the missing predecessor of position 0
+  // record of every position of the tile (+ halo) first, so that the word loads below are independent of
+  // each other and all in flight at once (a dependent sidx -> rec chain per word made a tile ten memory
+  // round trips long)
+  for (int i = tid; i < kGatherTile + 2; i += kGatherTile) {
+    const uint64_t pos = b0 + uint64_t(i) - 1;  // wraps for the missing predecessor of position 0
+    uint32_t r = 0xffffffffu;
     if (pos < n) {
-      uint32_t r = sidx[pos];
-      tile[g] = rec[uint64_t(r) * W + w];
-      if (w == 0) tlen[i] = rlen[r];
+      r = sidx[pos];
+      tlen[i] = rlen[r];
+    }
+    tidx[i] = r;
+  }
+  __syncthreads();
+  {
+    const uint32_t rcp = (65536u + uint32_t(W) - 1) / uint32_t(W);  // g / W = (g * rcp) >> 16 for g < 2100, W <= 8
+    const int total = (kGatherTile + 2) * W;
+    uint64_t v[kMaxWords + 1];
+#pragma unroll
+    for (int it = 0; it <= kMaxWords; ++it) {
+      const int g = tid + it * kGatherTile;
+      v[it] = 0;
+      if (g < total) {
+        const int i = int((uint32_t(g) * rcp) >> 16), w = g - i * W;
+        const uint32_t r = tidx[i];
+        if (r != 0xffffffffu) v[it] = rec[uint64_t(r) * W + w];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it <= kMaxWords; ++it) {
+      const int g = tid + it * kGatherTile;
+      if (g < total) tile[g] = v[it];
     }
   }
   __syncthreads();
