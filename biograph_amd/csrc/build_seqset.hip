@@ -465,6 +465,8 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
   uint8_t* tlcp = tlen + kGatherTile + 2;
   uint8_t* tkeep = tlcp + kGatherTile;
   __shared__ uint32_t tidx[kGatherTile + 2];
+  __shared__ uint16_t tsrc[kGatherTile];  // survivor rank -> position in the tile
+  __shared__ uint8_t tsh[kGatherTile];    // survivor rank -> shared
   __shared__ uint32_t s_tile, s_wave[kGatherTile / 64];
   __shared__ unsigned long long s_excl;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -570,26 +572,34 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
       tile_first[t] = count ? excl : ~0ull;
     }
   }
-  __syncthreads();
-  if (!keep) return;
-  const uint64_t e = s_excl + before;
-  sizes[e] = uint8_t(alen);
-  uint64_t k0 = 0, k1 = 0;
-  for (int w = 0; w < W; ++w) {
-    const uint64_t v = a[w];
-    ekeys[e * W + w] = v;
-    if (w == 0) k0 = v;
-    if (w == 1) k1 = v;
-  }
-  pre2[e * 2] = k0;
-  pre2[e * 2 + 1] = k1;
-  if (before) {  // min lcp over the dropped run back to the previous survivor (which is in this tile)
-    int sh = tlcp[tid];
-    for (int q = tid - 1; !tkeep[q]; --q) {
-      const int v = tlcp[q];
-      sh = v < sh ? v : sh;
+  // survivors compacted through LDS so that every output array is written in whole lines (a thread writing
+  // its own 40-byte entry leaves the lanes of a store 40 bytes apart)
+  if (keep) {
+    tsrc[before] = uint16_t(tid);
+    int sh = 0;
+    if (before) {  // min lcp over the dropped run back to the previous survivor (which is in this tile)
+      sh = tlcp[tid];
+      for (int q = tid - 1; !tkeep[q]; --q) {
+        const int v = tlcp[q];
+        sh = v < sh ? v : sh;
+      }
     }
-    shared[e] = uint8_t(sh);
+    tsh[before] = uint8_t(sh);  // slot 0 (the tile's first survivor) is set by k_fix_tile_first_shared
+  }
+  __syncthreads();
+  const uint64_t e0 = s_excl;
+  const uint32_t rcpw = (65536u + uint32_t(W) - 1) / uint32_t(W);
+  for (uint32_t x = tid; x < count * uint32_t(W); x += kGatherTile) {
+    const uint32_t slot = (x * rcpw) >> 16, w = x - slot * uint32_t(W);
+    ekeys[e0 * W + x] = tile[(uint32_t(tsrc[slot]) + 1) * W + w];
+  }
+  for (uint32_t x = tid; x < count * 2; x += kGatherTile) {
+    const uint32_t slot = x >> 1, w = x & 1;
+    pre2[e0 * 2 + x] = int(w) < W ? tile[(uint32_t(tsrc[slot]) + 1) * W + w] : 0ull;
+  }
+  for (uint32_t x = tid; x < count; x += kGatherTile) {
+    sizes[e0 + x] = tlen[uint32_t(tsrc[x]) + 1];
+    shared[e0 + x] = tsh[x];
   }
 }
 
