@@ -368,7 +368,8 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
                                                                    unsigned long long* __restrict__ distinct_total,
                                                                    uint8_t* __restrict__ overflow,
                                                                    const uint64_t* __restrict__ org,
-                                                                   unsigned long long* __restrict__ present) {
+                                                                   unsigned long long* __restrict__ present,
+                                                                   uint32_t* __restrict__ undet) {
   extern __shared__ __align__(16) unsigned char skc_smem[];
   unsigned long long* tkeys = reinterpret_cast<unsigned long long*>(skc_smem);
   uint32_t* tcnt = reinterpret_cast<uint32_t*>(skc_smem + size_t(cap) * 8);
@@ -386,15 +387,23 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
   // probe hits moves on to its next window by itself.  (Nesting "for each window { probe until placed }" makes
   // the whole wave wait for its slowest lane at every window, and its exec-mask bookkeeping saturated the
   // scalar unit.)
+  // Presence bits (what the read-correction screen would otherwise look up window by window in HBM): counts
+  // only grow, so a window whose own increment reaches min_count is known to be kept right away — with 30x
+  // coverage that settles five windows in six.  The others are noted in undet[] for the second sweep.
   for (uint64_t i0 = lo; i0 < hi; i0 += SKC_THREADS) {  // block-uniform trip count
     const uint64_t i = i0 + threadIdx.x;
     bool live = i < hi;
     SkRec r;
     r.a = 0;
     r.b = 0;
-    if (live) r = recs[i];
+    uint64_t o = 0;
+    if (live) {
+      r = recs[i];
+      o = org[i];
+    }
     const int n = sk_windows(r.b);
     int t = 0;
+    uint32_t bits = 0, und = 0;
     uint64_t fwd = r.a >> (64 - 2 * k);
     uint64_t rc = kmer_revcomp(fwd, k);
     unsigned long long key = rc < fwd ? rc : fwd;
@@ -411,7 +420,8 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
           if (cur == ~0ull) cur = key;
         }
         if (cur == key) {
-          atomicAdd(&tcnt[slot], 1u);
+          const uint32_t seen = atomicAdd(&tcnt[slot], 1u) + 1;
+          if (seen >= min_count) bits |= 1u << t; else und |= 1u << t;
           if (++t >= n) {
             live = false;
           } else {
@@ -429,48 +439,55 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
         }
       }
     }
+    if (i < hi) {
+      undet[i] = und;
+      if (bits) {  // a k-mer that reached min_count is kept whatever happens to the rest of the bucket
+        const uint64_t read = o >> 8;
+        const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
+        atomicOr(&present[read * 4 + wi], (unsigned long long)bits << sh);
+        if (sh + n > 64) atomicOr(&present[read * 4 + wi + 1], (unsigned long long)bits >> (64 - sh));
+      }
+    }
   }
   __syncthreads();
   if (s_over) {
     if (threadIdx.x == 0) overflow[bucket] = 1;
     return;
   }
-  // Second sweep, the table being final: which windows of each record hold a kept k-mer -> presence bits of the
-  // read they came from (what the read-correction screen would otherwise look up window by window in HBM).
+  // Second sweep, the table being final: the windows that were not settled above (the first min_count - 1
+  // occurrences of every k-mer, and the k-mers that stay below min_count).
   for (uint64_t i0 = lo; i0 < hi; i0 += SKC_THREADS) {
     const uint64_t i = i0 + threadIdx.x;
-    bool live = i < hi;
+    uint32_t und = i < hi ? undet[i] : 0u;
+    if (!__any(und != 0)) continue;  // wave-uniform
     SkRec r;
     r.a = 0;
     r.b = 0;
-    if (live) r = recs[i];
+    if (und) r = recs[i];
     const int n = sk_windows(r.b);
-    int t = 0;
-    uint32_t bits = 0;
-    uint64_t fwd = r.a >> (64 - 2 * k);
-    uint64_t rc = kmer_revcomp(fwd, k);
-    unsigned long long key = rc < fwd ? rc : fwd;
-    uint32_t slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
-    while (__any(live)) {
-      if (live) {
+    uint32_t bits = 0, slot = 0;
+    int t = -1;  // window being looked up, -1: take the next one
+    unsigned long long key = 0;
+    while (__any(und != 0)) {
+      if (und) {
+        if (t < 0) {
+          t = __ffs(und) - 1;
+          const uint64_t x = t ? ((r.a << (2 * t)) | (r.b >> (64 - 2 * t))) : r.a;  // t <= 21: only base bits of b
+          const uint64_t fwd = x >> (64 - 2 * k);
+          const uint64_t rc = kmer_revcomp(fwd, k);
+          key = rc < fwd ? rc : fwd;
+          slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
+        }
         if (tkeys[slot] == key) {  // every window's key is in the table (no overflow)
           if (tcnt[slot] >= min_count) bits |= 1u << t;
-          if (++t >= n) {
-            live = false;
-          } else {
-            const int idx = k + t - 1;
-            const uint64_t base = idx < 32 ? (r.a >> (62 - 2 * idx)) & 3 : (r.b >> (62 - 2 * (idx - 32))) & 3;
-            fwd = ((fwd << 2) | base) & kmask;
-            rc = (rc >> 2) | ((3 - base) << (2 * (k - 1)));
-            key = rc < fwd ? rc : fwd;
-            slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
-          }
+          und &= und - 1;
+          t = -1;
         } else {
           slot = slot + 1 == cap ? 0 : slot + 1;
         }
       }
     }
-    if (i < hi && bits) {
+    if (bits) {
       const uint64_t o = org[i];
       const uint64_t read = o >> 8;
       const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
@@ -716,6 +733,8 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
   DevBuf<uint32_t> oc_a;
   BG_TRY(ok_a.alloc(ctx, out_cap));
   BG_TRY(oc_a.alloc(ctx, out_cap));
+  DevBuf<uint32_t> undet;  // per record: windows whose presence the first sweep could not settle
+  BG_TRY(undet.alloc(ctx, R));
   ctx->tic("skm_count_lds");
   sk_bounds_kernel<<<cdiv(uint64_t(NB) + 1, 256), 256, 0, ctx->stream>>>(part, R, bucket_bits, bounds.p);
   BG_LAUNCH_CHECK();
@@ -725,7 +744,7 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
                              hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
   sk_count_lds_kernel<<<NB, SKC_THREADS, smem, ctx->stream>>>(part, bounds.p, slots, k, min_count, out_cap, ok_a.p, oc_a.p, ctr.p,
                                                              ctr.p + 1, overflow.p, part_org,
-                                                             reinterpret_cast<unsigned long long*>(ks->present.p));
+                                                             reinterpret_cast<unsigned long long*>(ks->present.p), undet.p);
   BG_LAUNCH_CHECK();
   ctx->toc(R * 40);
   unsigned long long h_ctr[2] = {0, 0};
