@@ -369,17 +369,17 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
                                                                    uint8_t* __restrict__ overflow,
                                                                    const uint64_t* __restrict__ org,
                                                                    unsigned long long* __restrict__ present,
-                                                                   uint32_t* __restrict__ undet) {
+                                                                   uint64_t* __restrict__ ulist) {
   extern __shared__ __align__(16) unsigned char skc_smem[];
   unsigned long long* tkeys = reinterpret_cast<unsigned long long*>(skc_smem);
   uint32_t* tcnt = reinterpret_cast<uint32_t*>(skc_smem + size_t(cap) * 8);
-  __shared__ uint32_t s_over, s_kept, s_distinct, s_cursor;
+  __shared__ uint32_t s_over, s_kept, s_distinct, s_cursor, s_unsettled;
   __shared__ unsigned long long s_base;
   const uint32_t bucket = blockIdx.x;
   const uint64_t lo = bounds[bucket], hi = bounds[bucket + 1];
   if (lo == hi) return;  // block-uniform
   for (uint32_t i = threadIdx.x; i < cap; i += SKC_THREADS) { tkeys[i] = ~0ull; tcnt[i] = 0; }
-  if (threadIdx.x == 0) { s_over = 0; s_kept = 0; s_distinct = 0; s_cursor = 0; }
+  if (threadIdx.x == 0) { s_over = 0; s_kept = 0; s_distinct = 0; s_cursor = 0; s_unsettled = 0; }
   __syncthreads();
   const uint32_t max_probe = cap < 256u ? cap : 256u;
   const uint64_t kmask = ~(~0ull << (2 * k));
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
   // scalar unit.)
   // Presence bits (what the read-correction screen would otherwise look up window by window in HBM): counts
   // only grow, so a window whose own increment reaches min_count is known to be kept right away — with 30x
-  // coverage that settles five windows in six.  The others are noted in undet[] for the second sweep.
+  // coverage that settles five windows in six.  The others are listed for the second sweep.
   for (uint64_t i0 = lo; i0 < hi; i0 += SKC_THREADS) {  // block-uniform trip count
     const uint64_t i = i0 + threadIdx.x;
     bool live = i < hi;
@@ -440,7 +440,9 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
       }
     }
     if (i < hi) {
-      undet[i] = und;
+      // the unsettled records are listed densely (in the bucket's own slice of ulist) so that the second
+      // sweep keeps every lane busy
+      if (und) ulist[lo + atomicAdd(&s_unsettled, 1u)] = (uint64_t(i - lo) << 32) | und;
       if (bits) {  // a k-mer that reached min_count is kept whatever happens to the rest of the bucket
         const uint64_t read = o >> 8;
         const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
@@ -456,10 +458,12 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
   }
   // Second sweep, the table being final: the windows that were not settled above (the first min_count - 1
   // occurrences of every k-mer, and the k-mers that stay below min_count).
-  for (uint64_t i0 = lo; i0 < hi; i0 += SKC_THREADS) {
-    const uint64_t i = i0 + threadIdx.x;
-    uint32_t und = i < hi ? undet[i] : 0u;
-    if (!__any(und != 0)) continue;  // wave-uniform
+  const uint32_t n_unsettled = s_unsettled;
+  for (uint32_t q0 = 0; q0 < n_unsettled; q0 += SKC_THREADS) {
+    const uint32_t q = q0 + threadIdx.x;
+    const uint64_t ent = q < n_unsettled ? ulist[lo + q] : 0ull;
+    uint32_t und = uint32_t(ent);
+    const uint64_t i = lo + (ent >> 32);
     SkRec r;
     r.a = 0;
     r.b = 0;
@@ -733,8 +737,8 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
   DevBuf<uint32_t> oc_a;
   BG_TRY(ok_a.alloc(ctx, out_cap));
   BG_TRY(oc_a.alloc(ctx, out_cap));
-  DevBuf<uint32_t> undet;  // per record: windows whose presence the first sweep could not settle
-  BG_TRY(undet.alloc(ctx, R));
+  DevBuf<uint64_t> ulist;  // per bucket: (record : windows) whose presence the first sweep could not settle
+  BG_TRY(ulist.alloc(ctx, R));
   ctx->tic("skm_count_lds");
   sk_bounds_kernel<<<cdiv(uint64_t(NB) + 1, 256), 256, 0, ctx->stream>>>(part, R, bucket_bits, bounds.p);
   BG_LAUNCH_CHECK();
@@ -744,7 +748,7 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
                              hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
   sk_count_lds_kernel<<<NB, SKC_THREADS, smem, ctx->stream>>>(part, bounds.p, slots, k, min_count, out_cap, ok_a.p, oc_a.p, ctr.p,
                                                              ctr.p + 1, overflow.p, part_org,
-                                                             reinterpret_cast<unsigned long long*>(ks->present.p), undet.p);
+                                                             reinterpret_cast<unsigned long long*>(ks->present.p), ulist.p);
   BG_LAUNCH_CHECK();
   ctx->toc(R * 40);
   unsigned long long h_ctr[2] = {0, 0};
