@@ -404,6 +404,9 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
     const int n = sk_windows(r.b);
     int t = 0;
     uint32_t bits = 0, und = 0;
+    // the bases that enter the window, next one on top (k <= 31: bases k.. of the record; field bits of b
+    // only come up after the last window)
+    uint64_t nb = (r.a << (2 * k)) | (r.b >> (64 - 2 * k));
     uint64_t fwd = r.a >> (64 - 2 * k);
     uint64_t rc = kmer_revcomp(fwd, k);
     unsigned long long key = rc < fwd ? rc : fwd;
@@ -425,10 +428,10 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
           if (++t >= n) {
             live = false;
           } else {
-            const int idx = k + t - 1;  // the base that enters the window
-            const uint64_t base = idx < 32 ? (r.a >> (62 - 2 * idx)) & 3 : (r.b >> (62 - 2 * (idx - 32))) & 3;
+            const uint64_t base = nb >> 62;  // the base that enters the window
+            nb <<= 2;
             fwd = ((fwd << 2) | base) & kmask;
-            rc = (rc >> 2) | ((3 - base) << (2 * (k - 1)));
+            rc = (rc >> 2) | ((base ^ 3) << (2 * (k - 1)));
             key = rc < fwd ? rc : fwd;
             slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
             probes = 0;
