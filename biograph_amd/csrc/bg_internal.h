@@ -152,6 +152,8 @@ struct bg_kmerset {
   bg::DevBuf<uint64_t> present;
   const void* present_of = nullptr;
   uint64_t present_n = 0;
+  int present_stride = 4;  // words per read: ceil(windows of the longest read / 64) — 150-base reads take 2, and
+                           // a 206 MB bitmap stays in the Infinity Cache under the count's atomics where 412 MB did not
   // records (2 words each) + origins of the buckets the LDS count gave up on: their presence bits are set
   // from the finished hash set (kmer_skm_finish_present)
   bg::DevBuf<uint64_t> pend_rec, pend_org;

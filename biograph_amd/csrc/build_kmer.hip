@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void k_correct_screen(const uint64_t* __restri
 // The same decision from presence bits that came with the k-mer count (bg_kmerset::present): no look-ups.
 __global__ __launch_bounds__(256) void k_screen_from_present(const uint64_t* __restrict__ words,
                                                              const uint16_t* __restrict__ len, uint64_t n, int W, int k,
-                                                             const uint64_t* __restrict__ present,
+                                                             const uint64_t* __restrict__ present, int pstride,
                                                              uint64_t* __restrict__ out_words,
                                                              uint16_t* __restrict__ out_len,
                                                              uint8_t* __restrict__ need_dfs) {
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void k_screen_from_present(const uint64_t* __r
       const int cnt = nk - c * 64;  // windows of this word
       if (cnt > 0) {
         const uint64_t want = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1);
-        if ((present[i * 4 + c] & want) != want) all_ok = false;
+        if ((present[i * pstride + c] & want) != want) all_ok = false;
       }
     }
   }
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64) void k_correct_dfs(const uint64_t* __restrict__
                                                     const uint16_t* __restrict__ needed_by_len,
                                                     uint64_t* __restrict__ out_words, uint16_t* __restrict__ out_len,
                                                     CorrectCounters* __restrict__ ctr,
-                                                    const uint64_t* __restrict__ present) {
+                                                    const uint64_t* __restrict__ present, int pstride) {
   uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= nlist) return;
   // read-index order on purpose: in locus order the expensive reads (shared SNP / error loci) pile up in
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(64) void k_correct_dfs(const uint64_t* __restrict__
   uint64_t ow[kMaxWords];
   int ncorr = 0;
   int clen = frc_correct_read(tab, words + i * W, nmask + i * W, L, W, k, max_corrections, min_good_run,
-                              int(needed_by_len[L]), ow, &ncorr, present + i * 4);
+                              int(needed_by_len[L]), ow, &ncorr, present + i * pstride);
   for (int w = 0; w < W; ++w) out_words[i * W + w] = clen ? ow[w] : 0;
   out_len[i] = uint16_t(clen);
   if (clen && ncorr) {
@@ -1123,6 +1123,7 @@ extern "C" int bg_correct_reads(bg_ctx* ctx, const bg_reads* reads, const bg_kme
   const bool have_present = ks->present.p && ks->present_of == reads && ks->present_n == n && !getenv("BG_SCREEN_LOOKUP");
   if (!have_present) BG_TRY(present_own.alloc(ctx, n * 4));
   const uint64_t* present = have_present ? ks->present.p : present_own.p;
+  const int pstride = have_present ? ks->present_stride : 4;
   DevBuf<CorrectCounters> ctr;
   DevBuf<CorrectTotals> tot;
   BG_TRY(ctr.alloc(ctx, 1));
@@ -1135,7 +1136,7 @@ extern "C" int bg_correct_reads(bg_ctx* ctx, const bg_reads* reads, const bg_kme
     if (have_present) {
       ctx->tic("correct_screen_bits");
       k_screen_from_present<<<cdiv(n, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->len.p, n, W, k, present,
-                                                                    r->words.p, r->len.p, need.p);
+                                                                    pstride, r->words.p, r->len.p, need.p);
       BG_LAUNCH_CHECK();
       ctx->toc(n * (W * 16 + 32 + 5));
     } else {
@@ -1155,7 +1156,7 @@ extern "C" int bg_correct_reads(bg_ctx* ctx, const bg_reads* reads, const bg_kme
       k_correct_dfs<<<cdiv(nlist, 64), 64, 0, ctx->stream>>>(
           reads->words.p, reads->nmask.p, reads->len.p, list.p, nlist, W, k, ks->slots.p, ks->log2cap,
           int(params->max_corrections), int(params->min_good_run), d_needed.p, r->words.p, r->len.p, ctr.p,
-          present);
+          present, pstride);
       BG_LAUNCH_CHECK();
       ctx->toc(nlist * W * 20);
     }

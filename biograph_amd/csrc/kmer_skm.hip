@@ -369,7 +369,7 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
                                                                    uint8_t* __restrict__ overflow,
                                                                    const uint64_t* __restrict__ org,
                                                                    unsigned long long* __restrict__ present,
-                                                                   uint64_t* __restrict__ ulist) {
+                                                                   int pstride, uint64_t* __restrict__ ulist) {
   extern __shared__ __align__(16) unsigned char skc_smem[];
   unsigned long long* tkeys = reinterpret_cast<unsigned long long*>(skc_smem);
   uint32_t* tcnt = reinterpret_cast<uint32_t*>(skc_smem + size_t(cap) * 8);
@@ -449,8 +449,8 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
       if (bits) {  // a k-mer that reached min_count is kept whatever happens to the rest of the bucket
         const uint64_t read = o >> 8;
         const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
-        atomicOr(&present[read * 4 + wi], (unsigned long long)bits << sh);
-        if (sh + n > 64) atomicOr(&present[read * 4 + wi + 1], (unsigned long long)bits >> (64 - sh));
+        atomicOr(&present[read * pstride + wi], (unsigned long long)bits << sh);
+        if (sh + n > 64) atomicOr(&present[read * pstride + wi + 1], (unsigned long long)bits >> (64 - sh));
       }
     }
   }
@@ -498,8 +498,8 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
       const uint64_t o = org[i];
       const uint64_t read = o >> 8;
       const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
-      atomicOr(&present[read * 4 + wi], (unsigned long long)bits << sh);
-      if (sh + n > 64) atomicOr(&present[read * 4 + wi + 1], (unsigned long long)bits >> (64 - sh));
+      atomicOr(&present[read * pstride + wi], (unsigned long long)bits << sh);
+      if (sh + n > 64) atomicOr(&present[read * pstride + wi + 1], (unsigned long long)bits >> (64 - sh));
     }
   }
   uint32_t my_kept = 0, my_distinct = 0;
@@ -549,7 +549,7 @@ __global__ void sk_expand_kernel(const SkRec* __restrict__ recs, uint64_t lo, ui
 // presence bits of records the LDS count gave up on, from the finished hash set
 __global__ void sk_present_lookup_kernel(const SkRec* __restrict__ recs, const uint64_t* __restrict__ org, uint64_t n_rec,
                                          int k, const uint64_t* __restrict__ slots, int log2cap,
-                                         unsigned long long* __restrict__ present) {
+                                         unsigned long long* __restrict__ present, int pstride) {
   const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n_rec) return;
   const SkRec r = recs[i];
@@ -570,8 +570,8 @@ __global__ void sk_present_lookup_kernel(const SkRec* __restrict__ recs, const u
     const uint64_t o = org[i];
     const uint64_t read = o >> 8;
     const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
-    atomicOr(&present[read * 4 + wi], (unsigned long long)bits << sh);
-    if (sh + n > 64) atomicOr(&present[read * 4 + wi + 1], (unsigned long long)bits >> (64 - sh));
+    atomicOr(&present[read * pstride + wi], (unsigned long long)bits << sh);
+    if (sh + n > 64) atomicOr(&present[read * pstride + wi + 1], (unsigned long long)bits >> (64 - sh));
   }
 }
 
@@ -580,7 +580,7 @@ int kmer_skm_finish_present(bg_ctx* ctx, bg_kmerset* ks) {
   if (ks->pend_n && ks->present.p) {
     sk_present_lookup_kernel<<<cdiv(ks->pend_n, 256), 256, 0, ctx->stream>>>(
         reinterpret_cast<const SkRec*>(ks->pend_rec.p), ks->pend_org.p, ks->pend_n, ks->k, ks->slots.p, ks->log2cap,
-        reinterpret_cast<unsigned long long*>(ks->present.p));
+        reinterpret_cast<unsigned long long*>(ks->present.p), ks->present_stride);
     BG_LAUNCH_CHECK();
   }
   ks->pend_rec.reset();
@@ -684,8 +684,9 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
   DevBuf<SkRec> rc;
   BG_TRY(rc.alloc(ctx, R));
   BG_TRY(oc.alloc(ctx, R));
-  BG_TRY(ks->present.alloc(ctx, reads->n * 4));
-  BG_HIP(hipMemsetAsync(ks->present.p, 0, reads->n * 32, ctx->stream));
+  ks->present_stride = std::max(1, (maxw + 63) / 64);
+  BG_TRY(ks->present.alloc(ctx, reads->n * ks->present_stride));
+  BG_HIP(hipMemsetAsync(ks->present.p, 0, reads->n * ks->present_stride * 8, ctx->stream));
   ks->present_of = reads;
   ks->present_n = reads->n;
   // level 1: the top 8 bucket bits
@@ -751,7 +752,7 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
                              hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
   sk_count_lds_kernel<<<NB, SKC_THREADS, smem, ctx->stream>>>(part, bounds.p, slots, k, min_count, out_cap, ok_a.p, oc_a.p, ctr.p,
                                                              ctr.p + 1, overflow.p, part_org,
-                                                             reinterpret_cast<unsigned long long*>(ks->present.p), ulist.p);
+                                                             reinterpret_cast<unsigned long long*>(ks->present.p), ks->present_stride, ulist.p);
   BG_LAUNCH_CHECK();
   ctx->toc(R * 40);
   unsigned long long h_ctr[2] = {0, 0};
