@@ -229,7 +229,10 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
 
 KERNEL_OF_FAMILY = {"radix_scatter_k": "rs_part_scatter_kernel",
                     "radix_scatter_kv": "rs_scatter_kernel<unsigned int, true>", "radix_hist": "rs_hist_kernel",
-                    "correct_screen": "k_correct_screen"}
+                    "correct_screen": "k_correct_screen", "entries_dedup_build": "k_gather_dedup_build",
+                    "skm_count_lds": "sk_count_lds_kernel", "skm_generate": "sk_generate_kernel",
+                    "suffix_cover_count": "k_cover_count", "prev_bits": "k_prev_bits_pre2",
+                    "suffix_small_ties": "k_sort_small_groups", "entries_dedup": "k_gather_lcp_keep"}
 
 
 def pmc_traffic(family):
