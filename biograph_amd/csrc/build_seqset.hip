@@ -771,26 +771,14 @@ __global__ __launch_bounds__(256) void k_prev_bits(const uint64_t* __restrict__ 
   marks[uint64_t(b) * n + lo] = 1;
 }
 
-// The same with the search run on the dense two-word prefixes (16 bytes per entry instead of W*8: the
-// candidates of one search share a line or two, and neighbouring threads' windows overlap).  A tail of at
-// least 64 bases whose two leading words occur in exactly one entry has found its target; anything else
-// (short tails, entries that agree on their first 64 bases) takes the full-key search.  `verify` re-checks
-// the unambiguous targets against the full keys as well (BG_VERIFY_CLOSURE=1; the tests run both ways).
-__global__ __launch_bounds__(256) void k_prev_bits_pre2(const uint64_t* __restrict__ ekeys,
-                                                        const uint64_t* __restrict__ pre2,
-                                                        const uint8_t* __restrict__ sizes, uint64_t n, int W,
-                                                        const uint32_t* __restrict__ dir, int bases,
-                                                        uint8_t* __restrict__ marks, uint32_t* __restrict__ err,
-                                                        int verify) {
-  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t* s = ekeys + i * W;
-  const int b = int(s[0] >> 62);
-  const int tl = int(sizes[i]) - 1;
-  uint64_t tail[kMaxWords];
-  for (int w = 0; w < W; ++w) tail[w] = window32(s, W, 1 + 32 * w);
+// target of a tail (s[1:], tl bases) among the entries: the search on the dense two-word prefixes, the
+// full-key search where that is not conclusive (see k_prev_bits_pre2).  false = no entry extends the tail.
+__device__ __forceinline__ bool prev_target_pre2(const uint64_t* __restrict__ ekeys, const uint64_t* __restrict__ pre2,
+                                                 const uint8_t* __restrict__ sizes, uint64_t n, int W,
+                                                 const uint32_t* __restrict__ dir, int bases, const uint64_t* tail, int tl,
+                                                 int verify, uint32_t* __restrict__ err, uint64_t* out) {
   const uint64_t t0 = tail[0], t1 = W > 1 ? tail[1] : 0;
-  uint64_t lo;
+  uint64_t lo = 0;
   bool sure = false;
   if (tl >= 64) {
     const uint32_t p = uint32_t(t0 >> (64 - 2 * bases));
@@ -810,9 +798,33 @@ __global__ __launch_bounds__(256) void k_prev_bits_pre2(const uint64_t* __restri
     lo = full;
     if (lo >= n || key_lcp(ekeys + lo * W, sizes[lo], tail, tl, W) < tl) {
       atomicOr(err, 2u);
-      return;
+      return false;
     }
   }
+  *out = lo;
+  return true;
+}
+
+// The same with the search run on the dense two-word prefixes (16 bytes per entry instead of W*8: the
+// candidates of one search share a line or two, and neighbouring threads' windows overlap).  A tail of at
+// least 64 bases whose two leading words occur in exactly one entry has found its target; anything else
+// (short tails, entries that agree on their first 64 bases) takes the full-key search.  `verify` re-checks
+// the unambiguous targets against the full keys as well (BG_VERIFY_CLOSURE=1; the tests run both ways).
+__global__ __launch_bounds__(256) void k_prev_bits_pre2(const uint64_t* __restrict__ ekeys,
+                                                        const uint64_t* __restrict__ pre2,
+                                                        const uint8_t* __restrict__ sizes, uint64_t n, int W,
+                                                        const uint32_t* __restrict__ dir, int bases,
+                                                        uint8_t* __restrict__ marks, uint32_t* __restrict__ err,
+                                                        int verify) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t* s = ekeys + i * W;
+  const int b = int(s[0] >> 62);
+  const int tl = int(sizes[i]) - 1;
+  uint64_t tail[kMaxWords];
+  for (int w = 0; w < W; ++w) tail[w] = window32(s, W, 1 + 32 * w);
+  uint64_t lo;
+  if (!prev_target_pre2(ekeys, pre2, sizes, n, W, dir, bases, tail, tl, verify, err, &lo)) return;
   marks[uint64_t(b) * n + lo] = 1;
 }
 
@@ -1301,15 +1313,41 @@ static int pack_marks(bg_ctx* ctx, bg_seqset* ss, const uint8_t* marks) {
   return BG_OK;
 }
 
+__global__ __launch_bounds__(256) void k_apply_tails_pre2(const uint64_t* __restrict__ rows, uint64_t nt,
+                                                          const uint64_t* __restrict__ ekeys,
+                                                          const uint64_t* __restrict__ pre2,
+                                                          const uint8_t* __restrict__ sizes, uint64_t n, int W,
+                                                          const uint32_t* __restrict__ dir, int bases,
+                                                          uint8_t* __restrict__ marks, uint32_t* __restrict__ err,
+                                                          int verify) {
+  uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= nt) return;
+  const uint64_t* row = rows + t * (W + 1);
+  uint64_t tail[kMaxWords];
+  for (int w = 0; w < W; ++w) tail[w] = row[w];
+  const int tl = int(row[W] & 0xff), b = int((row[W] >> 8) & 3);
+  uint64_t lo;
+  if (!prev_target_pre2(ekeys, pre2, sizes, n, W, dir, bases, tail, tl, verify, err, &lo)) return;
+  marks[uint64_t(b) * n + lo] = 1;
+}
+
 int apply_tails_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint32_t* d_err) {
   DevBuf<uint32_t> dir;
   DevBuf<uint8_t> marks;
   int bases = 0;
-  BG_TRY(build_prefix_dir(ctx, ss, &dir, &bases));
+  const bool use_pre2 = ss->pre2.p && ss->pre2.n >= 2 * ss->n && !getenv("BG_PREV_FULL_SEARCH");
+  if (use_pre2) BG_TRY(build_prefix_dir_keys(ctx, ss->pre2.p, ss->n, 2, &dir, &bases));
+  else BG_TRY(build_prefix_dir(ctx, ss, &dir, &bases));
   BG_TRY(marks.alloc(ctx, 4 * ss->n));
   if (ss->n) BG_HIP(hipMemsetAsync(marks.p, 0, 4 * ss->n, ctx->stream));
-  k_apply_tails<<<cdiv(n_rows, 256), 256, 0, ctx->stream>>>(d_rows, n_rows, ss->keys.p, ss->sizes.p, ss->n, ss->W, dir.p,
-                                                            bases, marks.p, d_err);
+  if (use_pre2) {
+    const char* v = getenv("BG_VERIFY_CLOSURE");
+    k_apply_tails_pre2<<<cdiv(n_rows, 256), 256, 0, ctx->stream>>>(d_rows, n_rows, ss->keys.p, ss->pre2.p, ss->sizes.p, ss->n,
+                                                                   ss->W, dir.p, bases, marks.p, d_err, v && v[0] == '1');
+  } else {
+    k_apply_tails<<<cdiv(n_rows, 256), 256, 0, ctx->stream>>>(d_rows, n_rows, ss->keys.p, ss->sizes.p, ss->n, ss->W, dir.p,
+                                                              bases, marks.p, d_err);
+  }
   BG_LAUNCH_CHECK();
   BG_TRY(pack_marks(ctx, ss, marks.p));
   BG_HIP(hipStreamSynchronize(ctx->stream));
