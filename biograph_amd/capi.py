@@ -68,6 +68,7 @@ SYMBOLS = [
     "bg_update_rc_seqset_entries", "bg_discover_branch", "bg_discover_push_to_pair",
     # sharded build
     "bg_partition_rows", "bg_kmer_instances", "bg_kmer_extract", "bg_kmer_extract_by_owner", "bg_kmer_count_keys", "bg_kmerset_export",
+    "bg_skm_supported", "bg_skm_capacity", "bg_skm_extract_by_owner", "bg_skm_count", "bg_kmerset_attach_presence",
     "bg_kmerset_from_kmers", "bg_reads_words", "bg_reads_export", "bg_reads_import", "bg_suffix_records",
     "bg_records_count", "bg_records_words", "bg_records_rows", "bg_records_from_rows", "bg_records_free",
     "bg_entries_from_records", "bg_seqset_words", "bg_seqset_boundary_rows", "bg_seqset_fix_boundary",
@@ -173,6 +174,11 @@ def lib():
     L.bg_kmer_extract.argtypes = [vp, vp, i32, vp, u64]
     L.bg_kmer_extract_by_owner.argtypes = [vp, vp, i32, u32, vp, u64, vp]
     L.bg_kmer_count_keys.argtypes = [vp, vp, u64, i32, u32, P(vp)]
+    L.bg_skm_supported.argtypes = [i32]
+    L.bg_skm_capacity.argtypes = [vp, vp, i32, u64, P(u64)]
+    L.bg_skm_extract_by_owner.argtypes = [vp, vp, i32, u64, u32, vp, vp, u64, vp, P(u64)]
+    L.bg_skm_count.argtypes = [vp, vp, u64, i32, u32, P(vp), vp]
+    L.bg_kmerset_attach_presence.argtypes = [vp, vp, vp, vp, vp, vp, u64]
     L.bg_kmerset_export.argtypes = [vp, vp, vp]
     L.bg_kmerset_from_kmers.argtypes = [vp, vp, u64, i32, vp, P(vp)]
     L.bg_reads_words.argtypes = [vp]

@@ -358,6 +358,7 @@ __global__ void sk_bucket_starts_kernel(const uint64_t* __restrict__ offs, uint3
 
 // ---- counting: one workgroup per bucket, windows unrolled from the records into an LDS table ---------
 constexpr int SKC_THREADS = 1024;
+constexpr uint32_t kSkUnknown = 0x80000000u;  // bits_out: the record's bucket overflowed, look its windows up
 
 __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* __restrict__ recs,
                                                                    const uint64_t* __restrict__ bounds, uint32_t cap,
@@ -369,7 +370,8 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
                                                                    uint8_t* __restrict__ overflow,
                                                                    const uint64_t* __restrict__ org,
                                                                    unsigned long long* __restrict__ present,
-                                                                   int pstride, uint64_t* __restrict__ ulist) {
+                                                                   int pstride, uint64_t* __restrict__ ulist,
+                                                                   uint32_t* __restrict__ bits_out) {
   extern __shared__ __align__(16) unsigned char skc_smem[];
   unsigned long long* tkeys = reinterpret_cast<unsigned long long*>(skc_smem);
   uint32_t* tcnt = reinterpret_cast<uint32_t*>(skc_smem + size_t(cap) * 8);
@@ -446,7 +448,9 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
       // the unsettled records are listed densely (in the bucket's own slice of ulist) so that the second
       // sweep keeps every lane busy
       if (und) ulist[lo + atomicAdd(&s_unsettled, 1u)] = (uint64_t(i - lo) << 32) | und;
-      if (bits) {  // a k-mer that reached min_count is kept whatever happens to the rest of the bucket
+      if (bits_out) {  // remote records: the bits go back to the rank the record came from (o = its index)
+        bits_out[o] = bits;
+      } else if (bits) {  // a k-mer that reached min_count is kept whatever happens to the rest of the bucket
         const uint64_t read = o >> 8;
         const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
         atomicOr(&present[read * pstride + wi], (unsigned long long)bits << sh);
@@ -457,6 +461,8 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
   __syncthreads();
   if (s_over) {
     if (threadIdx.x == 0) overflow[bucket] = 1;
+    if (bits_out)
+      for (uint64_t i = lo + threadIdx.x; i < hi; i += SKC_THREADS) bits_out[org[i]] = kSkUnknown;
     return;
   }
   // Second sweep, the table being final: the windows that were not settled above (the first min_count - 1
@@ -496,10 +502,14 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
     }
     if (bits) {
       const uint64_t o = org[i];
-      const uint64_t read = o >> 8;
-      const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
-      atomicOr(&present[read * pstride + wi], (unsigned long long)bits << sh);
-      if (sh + n > 64) atomicOr(&present[read * pstride + wi + 1], (unsigned long long)bits >> (64 - sh));
+      if (bits_out) {
+        bits_out[o] |= bits;  // this thread is the only one touching the record in this sweep
+      } else {
+        const uint64_t read = o >> 8;
+        const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
+        atomicOr(&present[read * pstride + wi], (unsigned long long)bits << sh);
+        if (sh + n > 64) atomicOr(&present[read * pstride + wi + 1], (unsigned long long)bits >> (64 - sh));
+      }
     }
   }
   uint32_t my_kept = 0, my_distinct = 0;
@@ -634,81 +644,127 @@ static uint32_t sk_lds_slots() {
   return 1u << (v < 1 ? 1 : (v > 13 ? 13 : v));
 }
 
-// Counts the canonical k-mers of `reads` (N windows in all, for sizing) into ks->kmers / counts / distinct.
-// *done = false when this path does not apply (k too small for a 12-base minimiser) and nothing was done.
-int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32_t min_count, bg_kmerset* ks, bool* done) {
-  *done = false;
-  const int maxw = int(reads->max_len) - k + 1;
-  if (k < SK_M + 2 || k > 31 || maxw <= 0 || !N) return BG_OK;
-  const int nmax = std::min(32, 52 - k);
-  const int w = k - SK_M + 1;
-  const double per_read = double(maxw) * 2.0 / double(w + 1) + 1.5;
-  SkSource src{reads->words.p, reads->nmask.p, reads->len.p, reads->n, reads->W, k,
-               std::max(1, int(double(SK_TARGET) / per_read)), nmax};
+// ---- host side ----------------------------------------------------------------------------------------
+
+struct SkGeometry {
+  int nmax, w, maxw;
+  SkSource src;
+  uint32_t ntiles;
+  uint64_t cap;
+};
+
+// false: the super-k-mer path does not apply (k too small for a 12-base minimiser, no windows)
+static bool sk_geometry(const bg_reads* reads, int k, uint64_t N, SkGeometry* g) {
+  g->maxw = int(reads->max_len) - k + 1;
+  if (k < SK_M + 2 || k > 31 || g->maxw <= 0 || !N) return false;
+  g->nmax = std::min(32, 52 - k);
+  g->w = k - SK_M + 1;
+  const double per_read = double(g->maxw) * 2.0 / double(g->w + 1) + 1.5;
+  g->src = SkSource{reads->words.p, reads->nmask.p, reads->len.p, reads->n, reads->W, k,
+                    std::max(1, int(double(SK_TARGET) / per_read)), g->nmax};
   // test hooks: BG_SKM_READS_PER_TILE overfills the LDS staging area (one-record-at-a-time path),
   // BG_SKM_CAP shrinks the record buffer (fallback to the instance path)
-  if (const char* e = getenv("BG_SKM_READS_PER_TILE")) src.reads_per_tile = std::max(1, std::min(60000, atoi(e)));
-  const uint64_t ntiles64 = (reads->n + src.reads_per_tile - 1) / src.reads_per_tile;
-  if (ntiles64 >= (1ull << 31)) return BG_OK;
-  const uint32_t ntiles = uint32_t(ntiles64);
+  if (const char* e = getenv("BG_SKM_READS_PER_TILE")) g->src.reads_per_tile = std::max(1, std::min(60000, atoi(e)));
+  const uint64_t ntiles64 = (reads->n + g->src.reads_per_tile - 1) / g->src.reads_per_tile;
+  if (ntiles64 >= (1ull << 31)) return false;
+  g->ntiles = uint32_t(ntiles64);
+  // The number of records is not known beforehand: room for 3x the expected density (2 / (w + 1) records per
+  // window); an input that beats it takes the instance path.
+  g->cap = std::min<uint64_t>(N, uint64_t(double(N) * 6.0 / double(g->w + 1)) + reads->n + 1024);
+  if (const char* e = getenv("BG_SKM_CAP")) g->cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+  return true;
+}
 
-  // level 0: records straight from the packed reads.  Their number is not known beforehand: room for 3x the
-  // expected density (2 / (w + 1) records per window); an input that beats it takes the instance path.
-  uint64_t cap = std::min<uint64_t>(N, uint64_t(double(N) * 6.0 / double(w + 1)) + reads->n + 1024);
-  if (const char* e = getenv("BG_SKM_CAP")) cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
-  DevBuf<SkRec> ra, rb;
-  DevBuf<uint64_t> oa, ob, oc;  // origin (read : first window) of every record, moved along with it
+// level 0: records (+ origins) straight from the packed reads into ra / oa (g.cap slots); *R = their number
+// (> g.cap: the buffer was too small and its content is incomplete)
+static int sk_generate(bg_ctx* ctx, const bg_reads* reads, const SkGeometry& g, SkRec* ra, uint64_t* oa, uint64_t* R_out) {
   DevBuf<unsigned long long> cursor;
-  BG_TRY(ra.alloc(ctx, cap));
-  BG_TRY(oa.alloc(ctx, cap));
   BG_TRY(cursor.alloc(ctx, 1));
   BG_HIP(hipMemsetAsync(cursor.p, 0, 8, ctx->stream));
   ctx->tic("skm_generate");
-  sk_generate_kernel<<<ntiles, SK_THREADS, 0, ctx->stream>>>(src, ra.p, oa.p, cap, cursor.p);
+  sk_generate_kernel<<<g.ntiles, SK_THREADS, 0, ctx->stream>>>(g.src, ra, oa, g.cap, cursor.p);
   BG_LAUNCH_CHECK();
   unsigned long long R = 0;
   BG_HIP(hipMemcpyAsync(&R, cursor.p, 8, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
   ctx->toc(R * 24 + reads->n * uint64_t(reads->W) * 12);
-  if (R > cap) return BG_OK;  // *done stays false
+  *R_out = R;
+  return BG_OK;
+}
+
+// level 1: the top 8 bucket bits (in -> out); h_starts[257] = group starts
+static int sk_level1(bg_ctx* ctx, const SkRec* in, SkRec* out, const uint64_t* oin, uint64_t* oout, uint64_t R,
+                     uint64_t* h_starts) {
+  const uint64_t whole[2] = {0, R};
+  BG_TRY(sk_partition_segmented(ctx, in, out, oin, oout, R, 1, whole, SK_BUCKET_FIELD - 8, 0xffu));
+  DevBuf<uint64_t> b8;
+  BG_TRY(b8.alloc(ctx, SK_BINS + 1));
+  sk_bounds_kernel<<<cdiv(SK_BINS + 1, 256), 256, 0, ctx->stream>>>(out, R, 8, b8.p);
+  BG_LAUNCH_CHECK();
+  BG_HIP(hipMemcpyAsync(h_starts, b8.p, (SK_BINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, uint64_t R, uint64_t N, int k,
+                            uint32_t min_count, bg_kmerset* ks, uint32_t* bits_out);
+
+// Counts the canonical k-mers of `reads` (N windows in all, for sizing) into ks->kmers / counts / distinct and
+// fills ks->present.  *done = false when this path does not apply and nothing was done.
+int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32_t min_count, bg_kmerset* ks, bool* done) {
+  *done = false;
+  SkGeometry g;
+  if (!sk_geometry(reads, k, N, &g)) return BG_OK;
+  DevBuf<SkRec> ra;
+  DevBuf<uint64_t> oa;  // origin (read : first window) of every record, moved along with it
+  BG_TRY(ra.alloc(ctx, g.cap));
+  BG_TRY(oa.alloc(ctx, g.cap));
+  uint64_t R = 0;
+  BG_TRY(sk_generate(ctx, reads, g, ra.p, oa.p, &R));
+  if (R > g.cap) return BG_OK;  // *done stays false
   *done = true;
+  ks->present_stride = std::max(1, (g.maxw + 63) / 64);
+  BG_TRY(ks->present.alloc(ctx, reads->n * ks->present_stride));
+  BG_HIP(hipMemsetAsync(ks->present.p, 0, reads->n * ks->present_stride * 8, ctx->stream));
+  ks->present_of = reads;
+  ks->present_n = reads->n;
+  return sk_count_records(ctx, ra.p, oa.p, R, N, k, min_count, ks, nullptr);
+}
+
+// Partition + count of R records (in / oin are only read).  bits_out == nullptr: oin holds origins and the
+// presence bits go to ks->present (local count); else oin holds indices into bits_out, which receives the
+// presence bits of every record's windows (kSkUnknown for the records of overflowed buckets).
+static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, uint64_t R, uint64_t N, int k,
+                            uint32_t min_count, bg_kmerset* ks, uint32_t* bits_out) {
+  const int nmax = std::min(32, 52 - k);
   ks->distinct = 0;
   ks->size = 0;
+  ks->sorted = false;
   if (!R) {  // every window holds an N
     BG_TRY(ks->kmers.alloc(ctx, 0));
     BG_TRY(ks->counts.alloc(ctx, 0));
     return BG_OK;
   }
+  DevBuf<SkRec> rb, rc;
+  DevBuf<uint64_t> ob, oc;
   BG_TRY(rb.alloc(ctx, R));
   BG_TRY(ob.alloc(ctx, R));
-  DevBuf<SkRec> rc;
   BG_TRY(rc.alloc(ctx, R));
   BG_TRY(oc.alloc(ctx, R));
-  ks->present_stride = std::max(1, (maxw + 63) / 64);
-  BG_TRY(ks->present.alloc(ctx, reads->n * ks->present_stride));
-  BG_HIP(hipMemsetAsync(ks->present.p, 0, reads->n * ks->present_stride * 8, ctx->stream));
-  ks->present_of = reads;
-  ks->present_n = reads->n;
-  // level 1: the top 8 bucket bits
   std::vector<uint64_t> h_starts(SK_BINS + 1);
-  {
-    const uint64_t whole[2] = {0, R};
-    BG_TRY(sk_partition_segmented(ctx, ra.p, rb.p, oa.p, ob.p, R, 1, whole, SK_BUCKET_FIELD - 8, 0xffu));
-    DevBuf<uint64_t> b8;
-    BG_TRY(b8.alloc(ctx, SK_BINS + 1));
-    sk_bounds_kernel<<<cdiv(SK_BINS + 1, 256), 256, 0, ctx->stream>>>(rb.p, R, 8, b8.p);
-    BG_LAUNCH_CHECK();
-    BG_HIP(hipMemcpyAsync(h_starts.data(), b8.p, (SK_BINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    BG_HIP(hipStreamSynchronize(ctx->stream));
-  }
-  ra.reset();
-  oa.reset();
+  BG_TRY(sk_level1(ctx, in, rb.p, oin, ob.p, R, h_starts.data()));
 
   // level 2: the next 8 bits inside each of the 256 groups; bigger inputs take up to 5 more bits so that a
-  // bucket stays around 24 k windows (BG_KMER_EXTRA_BITS overrides, for tests)
+  // bucket stays around 24 k windows (BG_KMER_EXTRA_BITS overrides, for tests).  A rank of a sharded build
+  // owns a slice of the bucket space: the level is chosen from the groups that are in use.
   BG_TRY(sk_partition_segmented(ctx, rb.p, rc.p, ob.p, oc.p, R, SK_BINS, h_starts.data(), SK_BUCKET_FIELD - 16, 0xffu));
   int extra = 0;
-  while (extra < SK_BUCKET_FIELD - 16 && (N >> (16 + extra)) > 24000) ++extra;
+  {
+    uint64_t used = 0;
+    for (int b8 = 0; b8 < SK_BINS; ++b8) used += h_starts[b8 + 1] > h_starts[b8];
+    const uint64_t per_bucket = N / (256 * (used ? used : 1));
+    while (extra < SK_BUCKET_FIELD - 16 && (per_bucket >> extra) > 24000) ++extra;
+  }
   if (const char* e = getenv("BG_KMER_EXTRA_BITS")) extra = std::max(0, std::min(SK_BUCKET_FIELD - 16, atoi(e)));
   SkRec* part = rc.p;
   uint64_t* part_org = oc.p;
@@ -752,7 +808,8 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
                              hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
   sk_count_lds_kernel<<<NB, SKC_THREADS, smem, ctx->stream>>>(part, bounds.p, slots, k, min_count, out_cap, ok_a.p, oc_a.p, ctr.p,
                                                              ctr.p + 1, overflow.p, part_org,
-                                                             reinterpret_cast<unsigned long long*>(ks->present.p), ks->present_stride, ulist.p);
+                                                             reinterpret_cast<unsigned long long*>(ks->present.p), ks->present_stride, ulist.p,
+                                                             bits_out);
   BG_LAUNCH_CHECK();
   ctx->toc(R * 40);
   unsigned long long h_ctr[2] = {0, 0};
@@ -780,17 +837,21 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
     BG_TRY(ta.alloc(ctx, tot));
     BG_TRY(tb.alloc(ctx, tot));
     BG_HIP(hipMemsetAsync(ta.p, 0xff, tot * 8, ctx->stream));
-    BG_TRY(ks->pend_rec.alloc(ctx, tot_rec * 2));  // their presence bits wait for the finished hash set
-    BG_TRY(ks->pend_org.alloc(ctx, tot_rec));
-    ks->pend_n = tot_rec;
+    if (!bits_out) {  // their presence bits wait for the finished hash set
+      BG_TRY(ks->pend_rec.alloc(ctx, tot_rec * 2));
+      BG_TRY(ks->pend_org.alloc(ctx, tot_rec));
+      ks->pend_n = tot_rec;
+    }
     uint64_t pos = 0;
     for (uint32_t b = 0; b < NB; ++b) {
       if (!h_over[b]) continue;
       const uint64_t cnt = h_bounds[b + 1] - h_bounds[b];
       sk_expand_kernel<<<cdiv(cnt, 256), 256, 0, ctx->stream>>>(part, h_bounds[b], cnt, k, nmax, ta.p + pos * nmax);
       BG_LAUNCH_CHECK();
-      BG_HIP(hipMemcpyAsync(ks->pend_rec.p + pos * 2, part + h_bounds[b], cnt * 16, hipMemcpyDeviceToDevice, ctx->stream));
-      BG_HIP(hipMemcpyAsync(ks->pend_org.p + pos, part_org + h_bounds[b], cnt * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      if (!bits_out) {
+        BG_HIP(hipMemcpyAsync(ks->pend_rec.p + pos * 2, part + h_bounds[b], cnt * 16, hipMemcpyDeviceToDevice, ctx->stream));
+        BG_HIP(hipMemcpyAsync(ks->pend_org.p + pos, part_org + h_bounds[b], cnt * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      }
       pos += cnt;
     }
     bg_kmerset tmp;
@@ -820,4 +881,154 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
   return BG_OK;
 }
 
+// ---- sharded build: super-k-mers cross the GPUs instead of k-mer instances -------------------------------
+
+__global__ void sk_iota_kernel(uint64_t* __restrict__ dst, uint64_t n) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = i;
+}
+
+__global__ __launch_bounds__(256) void sk_sum_windows_kernel(const SkRec* __restrict__ recs, uint64_t n,
+                                                             unsigned long long* __restrict__ total) {
+  unsigned long long v = 0;
+  for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x)
+    v += uint64_t(sk_windows(recs[i].b));
+#pragma unroll
+  for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, v);
+}
+
+// presence bits of one rank's own records, as returned by their owners (kSkUnknown: look the windows up)
+__global__ void sk_present_apply_kernel(const SkRec* __restrict__ recs, const uint64_t* __restrict__ org,
+                                        const uint32_t* __restrict__ bits_in, uint64_t n_rec, int k,
+                                        const uint64_t* __restrict__ slots, int log2cap,
+                                        unsigned long long* __restrict__ present, int pstride) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_rec) return;
+  uint32_t bits = bits_in[i];
+  const SkRec r = recs[i];
+  const int n = sk_windows(r.b);
+  if (bits & kSkUnknown) {
+    KmerTable tab{slots, log2cap, k};
+    const uint64_t kmask = ~(~0ull << (2 * k));
+    uint64_t fwd = r.a >> (64 - 2 * k);
+    uint64_t rc = kmer_revcomp(fwd, k);
+    bits = 0;
+    for (int t = 0; t < n; ++t) {
+      if (tab.find(rc < fwd ? rc : fwd) >= 0) bits |= 1u << t;
+      const int idx = k + t;
+      const uint64_t base = idx < 32 ? (r.a >> (62 - 2 * idx)) & 3 : (r.b >> (62 - 2 * (idx - 32))) & 3;
+      fwd = ((fwd << 2) | base) & kmask;
+      rc = (rc >> 2) | ((3 - base) << (2 * (k - 1)));
+    }
+  }
+  if (bits) {
+    const uint64_t o = org[i];
+    const uint64_t read = o >> 8;
+    const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
+    atomicOr(&present[read * pstride + wi], (unsigned long long)bits << sh);
+    if (sh + n > 64) atomicOr(&present[read * pstride + wi + 1], (unsigned long long)bits >> (64 - sh));
+  }
+}
+
 }  // namespace bg
+
+using namespace bg;
+
+extern "C" int bg_skm_supported(int k) { return k >= SK_M + 2 && k <= 31; }
+
+extern "C" int bg_skm_capacity(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t n_windows, uint64_t* cap_out) {
+  if (!ctx || !reads || !cap_out) { set_error("bg_skm_capacity: null argument"); return BG_EINVAL; }
+  SkGeometry g;
+  *cap_out = sk_geometry(reads, k, n_windows, &g) ? g.cap : 0;
+  return BG_OK;
+}
+
+extern "C" int bg_skm_extract_by_owner(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t n_windows, uint32_t nparts,
+                                       uint64_t* d_recs, uint64_t* d_org, uint64_t cap, uint64_t* counts,
+                                       uint64_t* n_out) {
+  if (!ctx || !reads || !counts || !n_out || (cap && (!d_recs || !d_org))) { set_error("bg_skm_extract_by_owner: null argument"); return BG_EINVAL; }
+  if (nparts < 1 || nparts > 256) { set_error("bg_skm_extract_by_owner: %u parts outside 1..256", nparts); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  for (uint32_t p = 0; p < nparts; ++p) counts[p] = 0;
+  *n_out = 0;
+  SkGeometry g;
+  if (!sk_geometry(reads, k, n_windows, &g)) {
+    if (!n_windows || int(reads->max_len) - k + 1 <= 0) return BG_OK;  // no windows at all
+    set_error("bg_skm_extract_by_owner: k = %d is outside the super-k-mer path (see bg_skm_supported)", k);
+    return BG_EINVAL;
+  }
+  if (cap < g.cap) { set_error("bg_skm_extract_by_owner: room for %llu records, %llu needed (bg_skm_capacity)",
+                               (unsigned long long)cap, (unsigned long long)g.cap); return BG_EINVAL; }
+  DevBuf<SkRec> ra;
+  DevBuf<uint64_t> oa;
+  BG_TRY(ra.alloc(ctx, g.cap));
+  BG_TRY(oa.alloc(ctx, g.cap));
+  uint64_t R = 0;
+  BG_TRY(sk_generate(ctx, reads, g, ra.p, oa.p, &R));
+  if (R > g.cap) { set_error("bg_skm_extract_by_owner: more super-k-mers than 3x the expected density"); return BG_ENOMEM; }
+  *n_out = R;
+  if (!R) return BG_OK;
+  // whole groups of the top bucket byte go to their owner: owner = (byte * nparts) >> 8
+  std::vector<uint64_t> h_starts(SK_BINS + 1);
+  BG_TRY(sk_level1(ctx, ra.p, reinterpret_cast<SkRec*>(d_recs), oa.p, d_org, R, h_starts.data()));
+  for (int b = 0; b < SK_BINS; ++b) counts[(uint32_t(b) * nparts) >> 8] += h_starts[b + 1] - h_starts[b];
+  return BG_OK;
+}
+
+extern "C" int bg_skm_count(bg_ctx* ctx, const uint64_t* d_recs, uint64_t n, int k, uint32_t min_count,
+                            bg_kmerset** out, uint32_t* d_bits) {
+  if (!ctx || !out || (n && !d_recs)) { set_error("bg_skm_count: null argument"); return BG_EINVAL; }
+  if (!bg_skm_supported(k)) { set_error("bg_skm_count: k = %d is outside the super-k-mer path", k); return BG_EINVAL; }
+  if (min_count < 1) min_count = 1;
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_kmerset> ks(new bg_kmerset);
+  ks->ctx = ctx;
+  ks->k = k;
+  const SkRec* recs = reinterpret_cast<const SkRec*>(d_recs);
+  DevBuf<uint64_t> idx;
+  DevBuf<unsigned long long> tot;
+  DevBuf<uint32_t> own_bits;
+  BG_TRY(idx.alloc(ctx, n));
+  BG_TRY(tot.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(tot.p, 0, 8, ctx->stream));
+  if (!d_bits) {  // the caller does not want them
+    BG_TRY(own_bits.alloc(ctx, n));
+    d_bits = own_bits.p;
+  }
+  unsigned long long N = 0;
+  if (n) {
+    sk_iota_kernel<<<cdiv(n, 256), 256, 0, ctx->stream>>>(idx.p, n);
+    BG_LAUNCH_CHECK();
+    sk_sum_windows_kernel<<<(cdiv(n, 256) < 2048u ? cdiv(n, 256) : 2048u), 256, 0, ctx->stream>>>(recs, n, tot.p);
+    BG_LAUNCH_CHECK();
+    BG_HIP(hipMemcpyAsync(&N, tot.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  ks->instances = N;
+  BG_TRY(sk_count_records(ctx, recs, idx.p, n, N, k, min_count, ks.get(), d_bits));
+  *out = ks.release();
+  return BG_OK;
+}
+
+extern "C" int bg_kmerset_attach_presence(bg_ctx* ctx, bg_kmerset* ks, const bg_reads* reads, const uint64_t* d_recs,
+                                          const uint64_t* d_org, const uint32_t* d_bits, uint64_t n) {
+  if (!ctx || !ks || !reads || (n && (!d_recs || !d_org || !d_bits))) { set_error("bg_kmerset_attach_presence: null argument"); return BG_EINVAL; }
+  if (!ks->slots.p) { set_error("bg_kmerset_attach_presence: the k-mer set has no hash table"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  const int maxw = int(reads->max_len) - ks->k + 1;
+  ks->present_stride = std::max(1, (maxw + 63) / 64);
+  BG_TRY(ks->present.alloc(ctx, reads->n * ks->present_stride));
+  BG_HIP(hipMemsetAsync(ks->present.p, 0, reads->n * ks->present_stride * 8, ctx->stream));
+  if (n) {
+    sk_present_apply_kernel<<<cdiv(n, 256), 256, 0, ctx->stream>>>(reinterpret_cast<const SkRec*>(d_recs), d_org, d_bits, n,
+                                                                 ks->k, ks->slots.p, ks->log2cap,
+                                                                 reinterpret_cast<unsigned long long*>(ks->present.p),
+                                                                 ks->present_stride);
+    BG_LAUNCH_CHECK();
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  ks->present_of = reads;
+  ks->present_n = reads->n;
+  return BG_OK;
+}

@@ -18,6 +18,7 @@ behind the C ABI):
 cannot run two ranks on one device).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -249,29 +250,54 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
     n_bases = comm.all_gather_obj({r: int(reads[r].total_bases) for r in ranks})[ranks[0]]
 
     ph.mark("kmer_extract_partition")
-    # ---- S2 k-mer instances -> owner ranks
+    # ---- S2 windows -> owner ranks: super-k-mer records (16 B per ~10 windows) when the k-mer size allows a
+    # 12-base minimiser, else k-mer instances (8 B per window)
+    use_skm = bool(L.bg_skm_supported(k)) and not os.environ.get("BG_KMER_SKM") == "0"
     send = {}
     n_inst = {}
+    skm_org = {}
+    skm_recs = {}
     for r in ranks:
         n = C.c_uint64()
         capi.check(L.bg_kmer_instances(ctxs[r].h, reads[r].h, k, C.byref(n)))
         n_inst[r] = n.value
-        keys = torch.empty((n.value, 1), dtype=i64, device=dev[r])
         counts = (C.c_uint64 * P)()
-        # extraction + owner partition in one pass: whole hash-byte buckets go to their owner rank
-        capi.check(L.bg_kmer_extract_by_owner(ctxs[r].h, reads[r].h, k, P, _ptr(keys), n.value, counts))
-        send[r] = (keys, [int(c) for c in counts])
-        del keys
+        if use_skm:
+            cap = C.c_uint64()
+            capi.check(L.bg_skm_capacity(ctxs[r].h, reads[r].h, k, n.value, C.byref(cap)))
+            recs = torch.empty((max(cap.value, 1), 2), dtype=i64, device=dev[r])
+            org = torch.empty((max(cap.value, 1),), dtype=i64, device=dev[r])
+            nrec = C.c_uint64()
+            capi.check(L.bg_skm_extract_by_owner(ctxs[r].h, reads[r].h, k, n.value, P, _ptr(recs), _ptr(org), cap.value,
+                                                 counts, C.byref(nrec)))
+            recs = recs[:nrec.value]
+            skm_recs[r] = recs
+            skm_org[r] = org[:nrec.value]
+            send[r] = (recs, [int(c) for c in counts])
+        else:
+            keys = torch.empty((n.value, 1), dtype=i64, device=dev[r])
+            # extraction + owner partition in one pass: whole hash-byte buckets go to their owner rank
+            capi.check(L.bg_kmer_extract_by_owner(ctxs[r].h, reads[r].h, k, P, _ptr(keys), n.value, counts))
+            send[r] = (keys, [int(c) for c in counts])
+            del keys
     ph.mark("kmer_all_to_all")
     recv = comm.all_to_all_v(send)
+    sent_counts = comm.all_gather_obj({r: send[r][1] for r in ranks})[ranks[0]]  # [source][owner]
     del send
     ph.mark("kmer_count")
     kept = {}
     distinct = {}
+    bits_back = {}
     for r in ranks:
         keys = recv[r].contiguous()
         h = C.c_void_p()
-        capi.check(L.bg_kmer_count_keys(ctxs[r].h, _ptr(keys), keys.shape[0], k, prm.min_kmer_count, C.byref(h)))
+        if use_skm:
+            bits = torch.empty((max(keys.shape[0], 1),), dtype=torch.int32, device=dev[r])
+            capi.check(L.bg_skm_count(ctxs[r].h, _ptr(keys), keys.shape[0], k, prm.min_kmer_count, C.byref(h), _ptr(bits)))
+            # the presence bits of every record go back to the rank it came from
+            bits_back[r] = (bits[:keys.shape[0]].view(-1, 1), [int(sent_counts[s][r]) for s in range(P)])
+        else:
+            capi.check(L.bg_kmer_count_keys(ctxs[r].h, _ptr(keys), keys.shape[0], k, prm.min_kmer_count, C.byref(h)))
         ks = bg.KmerSet(ctxs[r], h, k)
         distinct[r] = ks.distinct
         t = torch.empty((len(ks),), dtype=i64, device=dev[r])
@@ -279,6 +305,8 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
         kept[r] = t
         ks.free()
     del recv
+    skm_bits = comm.all_to_all_v(bits_back) if use_skm else None
+    del bits_back
     ph.mark("kmerset_all_gather_build")
     gathered = comm.all_gather_v(kept)
     tot_inst = sum(comm.all_gather_obj(n_inst)[ranks[0]])
@@ -290,7 +318,11 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
         capi.check(L.bg_kmerset_from_kmers(ctxs[r].h, _ptr(allk), allk.shape[0], k, reads[r].h, C.byref(h)))
         ksets[r] = bg.KmerSet(ctxs[r], h, k)
         n_kept = allk.shape[0]
-    del gathered, kept
+        if use_skm:  # window presence of this rank's reads: the correction looks nothing up
+            b = skm_bits[r].contiguous().view(-1)
+            capi.check(L.bg_kmerset_attach_presence(ctxs[r].h, h, reads[r].h, _ptr(skm_recs[r]), _ptr(skm_org[r]), _ptr(b),
+                                                    b.shape[0]))
+    del gathered, kept, skm_bits, skm_recs, skm_org
 
     ph.mark("correct")
     # ---- S3 correction (local, replicated k-mer set)

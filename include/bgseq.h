@@ -374,6 +374,26 @@ int bg_kmer_extract_by_owner(bg_ctx* ctx, const bg_reads* reads, int k, uint32_t
                              uint64_t cap, uint64_t* h_counts);
 int bg_kmer_count_keys(bg_ctx* ctx, uint64_t* d_keys /* clobbered */, uint64_t n, int k, uint32_t min_count,
                        bg_kmerset** out /* kmers+counts only, no hash */);
+/* The same exchange with super-k-mers instead of k-mer instances (k >= 14; csrc/kmer_skm.hip): a record is 16
+ * bytes = the bases of a run of windows of one read that share their minimiser, i.e. ~1.6 bytes per window
+ * instead of 8 across the links.  Owner of a record = top byte of its bucket hash, times nparts, over 256.
+ *   bg_skm_extract_by_owner: records of `reads` grouped by owner into d_recs (2 words each) with their origins
+ *     (read << 8 | first window) in d_org, both with room for `cap` records (bg_skm_capacity);
+ *     h_counts[nparts] = records per owner, *n_out = their sum.  n_windows = bg_kmer_instances().
+ *   bg_skm_count: the records a rank owns (from all ranks, any order) -> its kept k-mers (kmers + counts, no
+ *     hash) and, in d_bits[n] (may be NULL), for every record the windows whose k-mer is kept (bit t = window
+ *     t; 0x80000000 = not known here, the record's bucket overflowed the counting table).
+ *   bg_kmerset_attach_presence: the bits, sent back to the rank the records came from, become the per-read
+ *     window presence of a hash-carrying k-mer set (unknown records are looked up in it), which lets
+ *     bg_correct_reads(reads, ks) skip the look-up of every window (as after bg_kmer_count). */
+int bg_skm_supported(int k);
+int bg_skm_capacity(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t n_windows, uint64_t* cap_out);
+int bg_skm_extract_by_owner(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t n_windows, uint32_t nparts,
+                            uint64_t* d_recs, uint64_t* d_org, uint64_t cap, uint64_t* h_counts, uint64_t* n_out);
+int bg_skm_count(bg_ctx* ctx, const uint64_t* d_recs, uint64_t n, int k, uint32_t min_count, bg_kmerset** out,
+                 uint32_t* d_bits);
+int bg_kmerset_attach_presence(bg_ctx* ctx, bg_kmerset* ks, const bg_reads* reads, const uint64_t* d_recs,
+                               const uint64_t* d_org, const uint32_t* d_bits, uint64_t n);
 int bg_kmerset_export(bg_ctx* ctx, const bg_kmerset* ks, uint64_t* d_kmers_out);
 int bg_kmerset_from_kmers(bg_ctx* ctx, const uint64_t* d_kmers, uint64_t n, int k,
                           const bg_reads* reads_for_flags /* may be NULL */, bg_kmerset** out);
