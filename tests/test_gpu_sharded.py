@@ -79,3 +79,25 @@ def test_sharded_low_entropy_and_short_entries(ctx, alphabet, P):
     assert ss.size() == ref.size()
     assert ss.parts() == ref.parts()
     assert len(st["shard_entries"]) == P and sum(st["shard_entries"]) == ss.size()
+
+
+@pytest.mark.parametrize("env", [{"BG_KMER_SKM": "0"}, {"BG_KMER_LDS_LOG2CAP": "3"}, {"BG_KMER_EXTRA_BITS": "2"},
+                                 {"BG_SCREEN_LOOKUP": "1"}])
+def test_sharded_kmer_exchange_modes(ctx, monkeypatch, env):
+    """The k-mer exchange as instances (BG_KMER_SKM=0) and as super-k-mers, with the owners' counting tables
+    overflowing (every record comes back "unknown" and is looked up by its sender), with extra partition
+    levels, and with the returned presence bits ignored: same seqset as the single-GPU build."""
+    for a, b in env.items():
+        monkeypatch.setenv(a, b)
+    P = 3
+    seq, offs, n = synth.make_reads(genome_len=9000, coverage=25, read_len=120, seed=11, device="cpu")
+    reads = O.unpack_strings(seq.numpy(), offs.numpy().astype(np.uint64))
+    prm = ctx.default_params(kmer_size=22, min_kmer_count=3)
+    out = sharded.sharded_create(sharded.LocalSimComm(P), {r: ctx for r in range(P)},
+                                 _shard_inputs(reads, P, np.random.default_rng(2)), prm)
+    ss, st = out[0]
+    monkeypatch.undo()
+    ref, rst = ctx.create(reads, kmer_size=22, min_kmer_count=3)
+    for key in ("n_kept_kmers", "n_distinct_kmers", "n_kmers", "n_corrected_reads", "n_corrected_bases", "n_entries"):
+        assert st[key] == rst[key], key
+    assert ss.parts() == ref.parts()
