@@ -707,3 +707,53 @@ class SeqsetEntry:
         if n >= self.size:
             return self
         return self.ss.find(self.sequence()[:n])
+
+
+class Reference:
+    """The reference the discovery walks along (python/biograph/reference.cpp `biograph.Reference`): a BioGraph
+    reference directory (karyotype.json + reference.ref | reference.fasta), a bare .ref (SPR000) or a FASTA.
+    Host-only; needs no Context.  scaffolds = chromosomes in order; supercontigs = their N-free stretches in
+    flat order as (scaffold name, start, end) with 0-based [start, end)."""
+
+    def __init__(self, path):
+        self.path = str(path)
+        self.h = C.c_void_p()
+        capi.check(capi.lib().bg_reference_open(self.path.encode(), C.byref(self.h)))
+        L = capi.lib()
+        self.scaffolds = [L.bg_reference_scaffold_name(self.h, i).decode() for i in range(L.bg_reference_scaffold_count(self.h))]
+        self.scaffold_lens = {n: int(L.bg_reference_scaffold_len(self.h, i)) for i, n in enumerate(self.scaffolds)}
+        self._sc = []
+        for i in range(L.bg_reference_supercontig_count(self.h)):
+            s, o, n, f = C.c_uint32(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+            capi.check(L.bg_reference_supercontig(self.h, i, C.byref(s), C.byref(o), C.byref(n), C.byref(f)))
+            self._sc.append((s.value, o.value, n.value, f.value))
+        self.supercontigs = [(self.scaffolds[s], o, o + n) for s, o, n, f in self._sc]
+
+    def size(self):
+        return int(capi.lib().bg_reference_size(self.h))
+
+    def flat_bases(self, pos, n):
+        buf = C.create_string_buffer(max(n, 1))
+        capi.check(capi.lib().bg_reference_bases(self.h, pos, n, buf))
+        return buf.raw[:n].decode()
+
+    def sequence(self, scaffold, start, end):
+        """Bases [start, end) of a scaffold; the range must lie inside one supercontig (reference.cpp make_range)."""
+        for (s, o, n, f) in self._sc:
+            if self.scaffolds[s] == scaffold and o <= start and end <= o + n:
+                return self.flat_bases(f + (start - o), end - start)
+        raise ValueError("%s:[%d-%d) is not inside one supercontig" % (scaffold, start, end))
+
+    def close(self):
+        if self.h:
+            capi.lib().bg_reference_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __repr__(self):
+        return "<biograph_amd.Reference %s>" % self.path

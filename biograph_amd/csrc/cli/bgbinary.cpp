@@ -87,18 +87,6 @@ static void read_fastq(const std::string& path, std::vector<std::string>* out) {
   gzclose(f);
 }
 
-static void read_fasta(const std::string& path, std::string* seq) {
-  gzFile f = gzopen(path.c_str(), "rb");
-  if (!f) die("Could not open " + path + ": " + strerror(errno));
-  std::vector<char> buf(1 << 16);
-  while (gzgets(f, buf.data(), int(buf.size()))) {
-    if (buf[0] == '>') continue;
-    for (char* p = buf.data(); *p; ++p)
-      if (*p != '\n' && *p != '\r') seq->push_back(*p);
-  }
-  gzclose(f);
-}
-
 static bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 static void mkdirs(const std::string& p) {
   if (mkdir(p.c_str(), 0777) != 0 && errno != EEXIST) die("Could not create " + p + ": " + strerror(errno));
@@ -226,22 +214,22 @@ static int cmd_refmap(int argc, char** argv) {
   if (!a.has("in") && !a.has("reads")) die("refmap: --in S.bg is required");
   if (!a.has("ref") || !a.has("out")) die("refmap: --ref and --out are required");
   std::string bgdir = a.has("reads") ? a.get("reads") : a.get("in");
-  std::string ref = a.get("ref");
-  if (exists(ref + "/reference.fasta")) ref += "/reference.fasta";  // reference directory (io/defaults.h:17-50)
-  std::string fa;
-  read_fasta(ref, &fa);
-  // extents = maximal N-free stretches (supercontigs, bio_base/reference.cpp:27-40)
+  // reference directory (karyotype.json + reference.ref | reference.fasta), .ref or FASTA; extents = its
+  // supercontigs = maximal N-free stretches (bio_base/reference.cpp:27-40), walked over the flat genome
+  bg_reference* rf = nullptr;
+  check(bg_reference_open(a.get("ref").c_str(), &rf), "bg_reference_open");
+  std::string fa(bg_reference_size(rf), '\0');
+  check(bg_reference_bases(rf, 0, fa.size(), &fa[0]), "bg_reference_bases");
   std::vector<uint8_t> codes(fa.size(), 0);
+  for (size_t i = 0; i < fa.size(); ++i) codes[i] = uint8_t(fa[i] == 'A' ? 0 : fa[i] == 'C' ? 1 : fa[i] == 'G' ? 2 : 3);
   std::vector<uint64_t> es, ez;
-  uint64_t run = 0;
-  for (size_t i = 0; i < fa.size(); ++i) {
-    char c = fa[i] & 0xDF;
-    int code = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
-    if (code < 0) { if (run) { es.push_back(i - run); ez.push_back(run); } run = 0; continue; }
-    codes[i] = uint8_t(code);
-    ++run;
+  for (uint32_t i = 0; i < bg_reference_supercontig_count(rf); ++i) {
+    uint64_t len = 0, flat = 0;
+    check(bg_reference_supercontig(rf, i, nullptr, nullptr, &len, &flat), "bg_reference_supercontig");
+    es.push_back(flat);
+    ez.push_back(len);
   }
-  if (run) { es.push_back(fa.size() - run); ez.push_back(run); }
+  bg_reference_free(rf);
   bg_ctx* ctx = nullptr;
   check(bg_ctx_create(0, nullptr, &ctx), "bg_ctx_create");
   bg_seqset* ss = nullptr;
@@ -370,25 +358,6 @@ static int cmd_merge(int argc, char** argv) {
   return 0;
 }
 
-// FASTA records: (name, sequence upper-cased)
-static void read_fasta_records(const std::string& path, std::vector<std::pair<std::string, std::string>>* recs) {
-  gzFile f = gzopen(path.c_str(), "rb");
-  if (!f) die("Could not open " + path + ": " + strerror(errno));
-  std::vector<char> buf(1 << 16);
-  while (gzgets(f, buf.data(), int(buf.size()))) {
-    if (buf[0] == '>') {
-      std::string name;
-      for (char* p = buf.data() + 1; *p && *p != ' ' && *p != '\t' && *p != '\n' && *p != '\r'; ++p) name.push_back(*p);
-      recs->emplace_back(name, std::string());
-      continue;
-    }
-    if (recs->empty()) recs->emplace_back("ref", std::string());
-    for (char* p = buf.data(); *p; ++p)
-      if (*p != '\n' && *p != '\r') recs->back().second.push_back(char(*p >= 'a' && *p <= 'z' ? *p - 32 : *p));
-  }
-  gzclose(f);
-}
-
 // bgbinary discovery --in S.bg --ref DIR|FASTA --out V.vcf [--sample ID] [--min-overlap 0.7|N] [--max-pair-distance 1000]
 // The graph-discover pipeline of python/biograph/variants/graph_discover_test.py:41-56 (make_ref_assemblies ->
 // graph_trim_ref -> update_rc_seqset_entries -> discover_branch -> ... -> discover_push_to_pair) per scaffold;
@@ -397,10 +366,22 @@ static void read_fasta_records(const std::string& path, std::vector<std::pair<st
 static int cmd_discovery(int argc, char** argv) {
   Args a = parse(argc, argv, 2);
   if (!a.has("reads") || !a.has("ref") || !a.has("out")) die("discovery: --in S.bg, --ref and --out are required");
-  std::string bgdir = a.get("reads"), ref = a.get("ref");
-  if (exists(ref + "/reference.fasta")) ref += "/reference.fasta";
+  std::string bgdir = a.get("reads");
+  // scaffolds (chromosomes) and their N-free supercontigs from the reference directory / .ref / FASTA; a
+  // scaffold is rebuilt with N between its supercontigs so that VCF positions are scaffold coordinates
+  bg_reference* rf = nullptr;
+  check(bg_reference_open(a.get("ref").c_str(), &rf), "bg_reference_open");
   std::vector<std::pair<std::string, std::string>> recs;
-  read_fasta_records(ref, &recs);
+  for (uint32_t c = 0; c < bg_reference_scaffold_count(rf); ++c)
+    recs.emplace_back(bg_reference_scaffold_name(rf, c), std::string(bg_reference_scaffold_len(rf, c), 'N'));
+  for (uint32_t i = 0; i < bg_reference_supercontig_count(rf); ++i) {
+    uint32_t sc = 0;
+    uint64_t off = 0, len = 0, flat = 0;
+    check(bg_reference_supercontig(rf, i, &sc, &off, &len, &flat), "bg_reference_supercontig");
+    if (off + len > recs[sc].second.size()) recs[sc].second.resize(off + len, 'N');
+    check(bg_reference_bases(rf, flat, len, &recs[sc].second[off]), "bg_reference_bases");
+  }
+  bg_reference_free(rf);
   bg_ctx* ctx = nullptr;
   check(bg_ctx_create(0, nullptr, &ctx), "bg_ctx_create");
   bg_seqset* ss = nullptr;

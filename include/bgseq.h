@@ -356,6 +356,25 @@ int bg_create_sample(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, 
 #define BG_PART_KEY_BOUNDS 2 /* rows of W+1 words (last = len | base<<8); h_params = nparts rows: last
                                 entry of each shard (last word ~0 = empty); dest = first shard whose
                                 last entry >= row                                                       */
+/* ---- reference: what the discovery walks along ------------------------------------
+ * bg_reference_open reads a BioGraph reference directory (karyotype.json + reference.ref, or reference.fasta
+ * when the .ref is absent; modules/io/defaults.h:17-50, bio_base/reference.cpp:27-40), a bare .ref file
+ * (bio_base/flat_ref.cpp:140-165: "SPR000", 2-bit flat genome, msgpack index) or a FASTA (flat_ref.cpp:18-24).
+ * Scaffolds = chromosomes (reference_assembly::scaffold_order); supercontigs = their N-free stretches in flat
+ * order (reference_assembly::supercontigs): scaffold index, offset inside it, length, flat position.
+ * bg_reference_bases copies ASCII bases of the flat genome.  Host only: no bg_ctx needed. */
+typedef struct bg_reference bg_reference;
+int bg_reference_open(const char* path, bg_reference** out);
+void bg_reference_free(bg_reference* ref);
+uint64_t bg_reference_size(const bg_reference* ref);
+uint32_t bg_reference_scaffold_count(const bg_reference* ref);
+const char* bg_reference_scaffold_name(const bg_reference* ref, uint32_t i);
+uint64_t bg_reference_scaffold_len(const bg_reference* ref, uint32_t i);
+uint32_t bg_reference_supercontig_count(const bg_reference* ref);
+int bg_reference_supercontig(const bg_reference* ref, uint32_t i, uint32_t* scaffold, uint64_t* offset, uint64_t* len,
+                             uint64_t* flat);
+int bg_reference_bases(const bg_reference* ref, uint64_t flat_pos, uint64_t n, char* out);
+
 /* Stable partition of n rows into nparts destination groups written back to back into d_out_rows;
  * h_counts[p] = rows of group p. */
 int bg_partition_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int row_words, int mode,

@@ -132,7 +132,11 @@ def test_native_graph_discover_on_lambda_golden(ctx, golden_dir):
     assert _sig(allasm) == _sig(py)
 
 
-def test_bgbinary_discovery_cli_on_lambda(golden_dir, tmp_path):
+@pytest.mark.parametrize("ref_arg,chrom", [("/father_lambda/reference.fasta", "lambda:0"), ("/ref_lambda", "lambda"),
+                                           ("/ref_lambda/reference.ref", "lambda:0")])
+def test_bgbinary_discovery_cli_on_lambda(golden_dir, tmp_path, ref_arg, chrom):
+    """--ref takes a FASTA, a reference directory (karyotype.json + reference.ref: scaffold names from the
+    karyotype) or a bare .ref"""
     """`bgbinary discovery` on the lambda golden laid out as a .bg directory: 8 VCF records, the variants of
     lambdaToyData/benchmark/father.vcf."""
     import json
@@ -148,7 +152,7 @@ def test_bgbinary_discovery_cli_on_lambda(golden_dir, tmp_path):
               separators=(",", ":"))
     out = tmp_path / "v.vcf"
     r = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "discovery", "--in", str(bgd), "--ref",
-                        golden_dir + "/father_lambda/reference.fasta", "--out", str(out), "--min-overlap", "70"],
+                        golden_dir + ref_arg, "--out", str(out), "--min-overlap", "70"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     ref = "".join(l.strip() for l in open(golden_dir + "/father_lambda/reference.fasta") if not l.startswith(">")).upper()
@@ -165,3 +169,4 @@ def test_bgbinary_discovery_cli_on_lambda(golden_dir, tmp_path):
         return sorted(res)
     mine, gold = edits(out), edits(golden_dir + "/father_lambda/father.vcf")
     assert len(mine) == 8 and mine == gold
+    assert {l.split("\t")[0] for l in open(out) if not l.startswith("#")} == {chrom}

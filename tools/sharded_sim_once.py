@@ -1,3 +1,5 @@
+"""One timed sharded build with P ranks simulated in this process (LocalSimComm): phase times (BG_SHARD_TIMING)
+and kernel-family times.  Usage: python tools/sharded_sim_once.py <genome bases per rank> <P[,P...]>"""
 import os, sys, time
 sys.path.insert(0, ".")
 os.environ["BG_SHARD_TIMING"] = "1"
@@ -13,9 +15,13 @@ for P in Ps:
         inputs[r] = (seq, offs, n)
     ctxs = {r: ctx for r in range(P)}
     for rep in range(2):
+        ctx.set_profiling(rep == 1)
         torch.cuda.synchronize(); t = time.perf_counter()
         out = sharded.sharded_create(sharded.LocalSimComm(P), ctxs, inputs)
         torch.cuda.synchronize(); dt = time.perf_counter() - t
         out[0][0].free()
+    tm = ctx.timings()
+    ctx.set_profiling(False)
+    print("kernel families (ms, all ranks): " + ", ".join("%s %.1f" % (x["name"], x["ms"]) for x in sorted(tm, key=lambda x: -x["ms"])[:24]))
     print("P=%d total %.1f ms per rank %.1f ms" % (P, dt * 1e3, dt / P * 1e3), flush=True)
     del inputs; ctx.trim()
