@@ -346,6 +346,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timings = ctx.timings()
     ctx.set_profiling(False)
+    mem = ctx.memory()
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -399,6 +400,7 @@ def main():
                        "%d GPUs, one sample sharded: all_to_all(k-mers, records, tails) + all_gather(kept k-mers, "
                        "corrected reads) over RCCL" % world},
             "roofline": roofline, "cpu_baseline": cpu,
+            "device_memory": {"peak_live_GB": round(mem["peak"] / 1e9, 2), "cached_GB": round(mem["cached"] / 1e9, 2)},
             "build_roofline": {"algorithmic_bytes_per_step": int(alg), "bytes_per_base": round(alg / max(stats["n_bases"], 1), 2),
                                "achieved_GBps": round(alg / step_s / 1e9, 1),
                                "frac_of_hbm_peak": round(alg / step_s / 1e9 / (HBM_PEAK_GBS * world), 5),

@@ -97,6 +97,12 @@ class Context:
     def trim(self):
         capi.check(capi.lib().bg_ctx_trim(self.h))
 
+    def memory(self, reset_peak=False):
+        """Device bytes of this context's allocator: {'live', 'cached', 'peak'} (peak = high-water mark of live)."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        capi.check(capi.lib().bg_ctx_memory(self.h, C.byref(a), C.byref(b), C.byref(c), int(bool(reset_peak))))
+        return {"live": a.value, "cached": b.value, "peak": c.value}
+
     def set_profiling(self, on=True):
         capi.check(capi.lib().bg_ctx_set_profiling(self.h, int(bool(on))))
 

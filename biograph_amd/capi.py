@@ -66,7 +66,7 @@ SYMBOLS = [
     "bg_asm_list_create", "bg_asm_list_free", "bg_asm_list_size", "bg_asm_list_add", "bg_asm_list_sort",
     "bg_asm_list_get", "bg_asm_list_rc_path", "bg_make_ref_assemblies", "bg_graph_trim_ref", "bg_dedup_assemblies",
     "bg_update_rc_seqset_entries", "bg_discover_branch", "bg_discover_push_to_pair",
-    "bg_reference_open", "bg_reference_free", "bg_reference_size", "bg_reference_scaffold_count",
+    "bg_ctx_memory", "bg_reference_open", "bg_reference_free", "bg_reference_size", "bg_reference_scaffold_count",
     "bg_reference_scaffold_name", "bg_reference_scaffold_len", "bg_reference_supercontig_count", "bg_reference_supercontig",
     "bg_reference_bases",
     # sharded build
@@ -173,6 +173,7 @@ def lib():
     L.bg_discover_push_to_pair.argtypes = [vp, vp, vp, vp, u32, i64, C.c_char_p, C.c_char_p]
     L.bg_create_sample.argtypes = [vp, vp, vp, u64, P(CreateParams), i32, P(vp), P(vp), P(BuildStats)]
     L.bg_partition_rows.argtypes = [vp, vp, u64, i32, i32, u32, vp, vp, vp]
+    L.bg_ctx_memory.argtypes = [vp, P(u64), P(u64), P(u64), i32]
     L.bg_reference_open.argtypes = [C.c_char_p, P(vp)]
     L.bg_reference_free.argtypes = [vp]
     L.bg_reference_free.restype = None

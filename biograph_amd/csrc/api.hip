@@ -192,6 +192,15 @@ extern "C" void bg_ctx_destroy(bg_ctx* ctx) {
 
 extern "C" int bg_ctx_trim(bg_ctx* ctx) { return ctx ? ctx->trim() : BG_EINVAL; }
 
+extern "C" int bg_ctx_memory(bg_ctx* ctx, uint64_t* live, uint64_t* cached, uint64_t* peak, int reset_peak) {
+  if (!ctx) return BG_EINVAL;
+  if (live) *live = ctx->live_bytes;
+  if (cached) *cached = ctx->cached_bytes;
+  if (peak) *peak = ctx->peak_bytes;
+  if (reset_peak) ctx->peak_bytes = ctx->live_bytes;
+  return BG_OK;
+}
+
 extern "C" int bg_ctx_set_profiling(bg_ctx* ctx, int on) {
   if (!ctx) return BG_EINVAL;
   ctx->profiling = on != 0;

@@ -52,6 +52,9 @@ int bg_ctx_create(int device, void* stream, bg_ctx** out);
 void bg_ctx_destroy(bg_ctx* ctx);
 /* Releases cached workspace blocks back to the driver. */
 int bg_ctx_trim(bg_ctx* ctx);
+/* Device memory of the context's allocator, bytes: in use now, cached for reuse, high-water mark of the
+ * in-use figure (reset = 1 restarts the mark from the current figure).  Any pointer may be NULL. */
+int bg_ctx_memory(bg_ctx* ctx, uint64_t* live, uint64_t* cached, uint64_t* peak, int reset_peak);
 
 /* Per-stage device time of the most recent build call on this context (HIP events on the
  * context's stream).  Names follow runtime_stats stages of biograph_create.cpp:540-783 plus the
