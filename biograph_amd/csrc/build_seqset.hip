@@ -455,29 +455,32 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_lcp_keep(
 // transitive through prefixes); a tile's first survivor gets it from k_fix_tile_first_shared.
 constexpr uint64_t kScanAgg = 1ull << 62, kScanIncl = 2ull << 62, kScanVal = (1ull << 62) - 1;
 
+constexpr int kFusedPos = 2;                           // sorted positions per thread
+constexpr int kFusedTile = kGatherTile * kFusedPos;    // positions per tile: twice the data in flight per wave and
+                                                       // half the look-backs of a 256-position tile
 __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
     const uint64_t* __restrict__ rec, const uint8_t* __restrict__ rlen, const uint32_t* __restrict__ sidx, uint64_t n,
     int W, unsigned long long* __restrict__ state, uint32_t* __restrict__ ticket, uint64_t* __restrict__ ekeys,
     uint8_t* __restrict__ sizes, uint8_t* __restrict__ shared, uint64_t* __restrict__ pre2,
     uint64_t* __restrict__ tile_first, uint32_t* __restrict__ err) {
-  extern __shared__ uint64_t tile[];  // (kGatherTile + 2) * W words, then lengths, per-position lcp, keep flags
-  uint8_t* tlen = reinterpret_cast<uint8_t*>(tile + (kGatherTile + 2) * W);
-  uint8_t* tlcp = tlen + kGatherTile + 2;
-  uint8_t* tkeep = tlcp + kGatherTile;
-  __shared__ uint32_t tidx[kGatherTile + 2];
-  __shared__ uint16_t tsrc[kGatherTile];  // survivor rank -> position in the tile
-  __shared__ uint8_t tsh[kGatherTile];    // survivor rank -> shared
-  __shared__ uint32_t s_tile, s_wave[kGatherTile / 64];
+  extern __shared__ uint64_t tile[];  // (kFusedTile + 2) * W words, then lengths, per-position lcp, keep flags
+  uint8_t* tlen = reinterpret_cast<uint8_t*>(tile + (kFusedTile + 2) * W);
+  uint8_t* tlcp = tlen + kFusedTile + 2;
+  uint8_t* tkeep = tlcp + kFusedTile;
+  __shared__ uint32_t tidx[kFusedTile + 2];
+  __shared__ uint16_t tsrc[kFusedTile];  // survivor rank -> position in the tile
+  __shared__ uint8_t tsh[kFusedTile];    // survivor rank -> shared
+  __shared__ uint32_t s_tile, s_wave[kFusedTile / 64];
   __shared__ unsigned long long s_excl;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_tile = atomicAdd(ticket, 1u);
   __syncthreads();
   const uint64_t t = s_tile;
-  const uint64_t b0 = t * kGatherTile;
+  const uint64_t b0 = t * kFusedTile;
   // record of every position of the tile (+ halo) first, so that the word loads below are independent of
   // each other and all in flight at once (a dependent sidx -> rec chain per word made a tile ten memory
   // round trips long)
-  for (int i = tid; i < kGatherTile + 2; i += kGatherTile) {
+  for (int i = tid; i < kFusedTile + 2; i += kGatherTile) {
     const uint64_t pos = b0 + uint64_t(i) - 1;  // wraps for the missing predecessor of position 0
     uint32_t r = 0xffffffffu;
     if (pos < n) {
@@ -488,11 +491,12 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
   }
   __syncthreads();
   {
-    const uint32_t rcp = (65536u + uint32_t(W) - 1) / uint32_t(W);  // g / W = (g * rcp) >> 16 for g < 2100, W <= 8
-    const int total = (kGatherTile + 2) * W;
-    uint64_t v[kMaxWords + 1];
+    const uint32_t rcp = (65536u + uint32_t(W) - 1) / uint32_t(W);  // g / W = (g * rcp) >> 16 for g < 9000, W <= 8
+    const int total = (kFusedTile + 2) * W;
+    constexpr int kIters = ((kFusedTile + 2) * kMaxWords + kGatherTile - 1) / kGatherTile;
+    uint64_t v[kIters];
 #pragma unroll
-    for (int it = 0; it <= kMaxWords; ++it) {
+    for (int it = 0; it < kIters; ++it) {
       const int g = tid + it * kGatherTile;
       v[it] = 0;
       if (g < total) {
@@ -502,35 +506,47 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
       }
     }
 #pragma unroll
-    for (int it = 0; it <= kMaxWords; ++it) {
+    for (int it = 0; it < kIters; ++it) {
       const int g = tid + it * kGatherTile;
       if (g < total) tile[g] = v[it];
     }
   }
   __syncthreads();
-  const uint64_t pos = b0 + tid;
-  const uint64_t* a = tile + (tid + 1) * W;
-  const int alen = tlen[tid + 1];
-  bool keep = false;
-  if (pos < n) {
-    int lp = 0;
-    if (pos > 0) {
-      lp = key_lcp(a - W, tlen[tid], a, alen, W);
-      if (key_compare(a - W, tlen[tid], a, alen, W) > 0) atomicOr(err, 1u);  // not sorted
+  // position p of the tile = thread (p % 256), slice (p / 256)
+  bool keep[kFusedPos];
+  uint64_t km[kFusedPos];
+#pragma unroll
+  for (int sl = 0; sl < kFusedPos; ++sl) {
+    const int p = sl * kGatherTile + tid;
+    const uint64_t pos = b0 + p;
+    const uint64_t* a = tile + (p + 1) * W;
+    const int alen = tlen[p + 1];
+    keep[sl] = false;
+    if (pos < n) {
+      int lp = 0;
+      if (pos > 0) {
+        lp = key_lcp(a - W, tlen[p], a, alen, W);
+        if (key_compare(a - W, tlen[p], a, alen, W) > 0) atomicOr(err, 1u);  // not sorted
+      }
+      tlcp[p] = uint8_t(lp);
+      // a record that is a prefix of (or equal to) its successor is dropped (expand.cpp:19-48 skip_dups)
+      keep[sl] = !(pos + 1 < n && key_lcp(a, alen, a + W, tlen[p + 2], W) == alen);
     }
-    tlcp[tid] = uint8_t(lp);
-    // a record that is a prefix of (or equal to) its successor is dropped (expand.cpp:19-48 skip_dups)
-    keep = !(pos + 1 < n && key_lcp(a, alen, a + W, tlen[tid + 2], W) == alen);
+    tkeep[p] = keep[sl] ? 1 : 0;
+    km[sl] = __ballot(keep[sl]);
+    if (lane == 0) s_wave[sl * (kGatherTile / 64) + wave] = uint32_t(__popcll(km[sl]));
   }
-  tkeep[tid] = keep ? 1 : 0;
-  // rank of the survivors inside the tile
-  const uint64_t km = __ballot(keep);
-  if (lane == 0) s_wave[wave] = uint32_t(__popcll(km));
   __syncthreads();
-  uint32_t before = uint32_t(__popcll(km & ((1ull << lane) - 1))), count = 0;
-  for (int w2 = 0; w2 < kGatherTile / 64; ++w2) {
-    if (w2 < wave) before += s_wave[w2];
-    count += s_wave[w2];
+  // rank of the survivors inside the tile
+  uint32_t before[kFusedPos], count = 0;
+#pragma unroll
+  for (int sl = 0; sl < kFusedPos; ++sl) before[sl] = uint32_t(__popcll(km[sl] & ((1ull << lane) - 1)));
+  for (int v2 = 0; v2 < kFusedTile / 64; ++v2) {
+    const uint32_t c = s_wave[v2];
+#pragma unroll
+    for (int sl = 0; sl < kFusedPos; ++sl)
+      if (v2 < sl * (kGatherTile / 64) + wave) before[sl] += c;
+    count += c;
   }
   // decoupled look-back (wave 0)
   if (wave == 0) {
@@ -574,17 +590,21 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
   }
   // survivors compacted through LDS so that every output array is written in whole lines (a thread writing
   // its own 40-byte entry leaves the lanes of a store 40 bytes apart)
-  if (keep) {
-    tsrc[before] = uint16_t(tid);
-    int sh = 0;
-    if (before) {  // min lcp over the dropped run back to the previous survivor (which is in this tile)
-      sh = tlcp[tid];
-      for (int q = tid - 1; !tkeep[q]; --q) {
-        const int v = tlcp[q];
-        sh = v < sh ? v : sh;
+#pragma unroll
+  for (int sl = 0; sl < kFusedPos; ++sl) {
+    if (keep[sl]) {
+      const int p = sl * kGatherTile + tid;
+      tsrc[before[sl]] = uint16_t(p);
+      int sh = 0;
+      if (before[sl]) {  // min lcp over the dropped run back to the previous survivor (which is in this tile)
+        sh = tlcp[p];
+        for (int q = p - 1; !tkeep[q]; --q) {
+          const int v = tlcp[q];
+          sh = v < sh ? v : sh;
+        }
       }
+      tsh[before[sl]] = uint8_t(sh);  // slot 0 (the tile's first survivor) is set by k_fix_tile_first_shared
     }
-    tsh[before] = uint8_t(sh);  // slot 0 (the tile's first survivor) is set by k_fix_tile_first_shared
   }
   __syncthreads();
   const uint64_t e0 = s_excl;
@@ -1231,7 +1251,7 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
     BG_TRY(ss->sizes.alloc(ctx, n_rec));
     BG_TRY(ss->shared.alloc(ctx, n_rec));
     if (n_rec) {
-      const uint64_t ntiles = (n_rec + kGatherTile - 1) / kGatherTile;
+      const uint64_t ntiles = (n_rec + kFusedTile - 1) / kFusedTile;
       DevBuf<unsigned long long> state;
       DevBuf<uint64_t> tile_first;
       DevBuf<uint32_t> ticket;
@@ -1241,7 +1261,7 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
       BG_HIP(hipMemsetAsync(state.p, 0, ntiles * 8, ctx->stream));
       BG_HIP(hipMemsetAsync(ticket.p, 0, 4, ctx->stream));
       ctx->tic("entries_dedup_build");
-      const size_t lds = size_t(kGatherTile + 2) * W * 8 + (kGatherTile + 2) + 2 * kGatherTile;
+      const size_t lds = size_t(kFusedTile + 2) * W * 8 + (kFusedTile + 2) + 2 * kFusedTile;
       k_gather_dedup_build<<<unsigned(ntiles), kGatherTile, lds, ctx->stream>>>(rec.p, rlen.p, sidx.p, n_rec, W, state.p,
                                                                              ticket.p, ss->keys.p, ss->sizes.p, ss->shared.p,
                                                                              ss->pre2.p, tile_first.p, err.p);
