@@ -235,6 +235,11 @@ KERNEL_OF_FAMILY = {"radix_scatter_k": "rs_part_scatter_kernel",
                     "suffix_small_ties": "k_sort_small_groups", "entries_dedup": "k_gather_lcp_keep"}
 
 
+LIMITER_OF_FAMILY = {"skm_count_lds": "VALU issue (rolling canonical k-mer + LDS probe per window)",
+                     "skm_generate": "VALU issue (minimiser of every window)",
+                     "radix_scatter_k": "hbm stream", "skm_part_scatter": "hbm stream", "suffix_emit": "hbm stream"}
+
+
 def pmc_traffic(family):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
     command (profiles/, separate FETCH_SIZE / WRITE_SIZE runs; KiB units; FETCH_SIZE doubled as
@@ -371,7 +376,11 @@ def main():
             roofline = {"bound": "hbm", "kernel": fam["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                         "avg_launch_ms": round(avg_ms, 4), "launches_per_step": fam["launches"] / max(args.steps, 1),
-                        "algorithmic_bytes_per_launch": int(bytes_per_launch)}
+                        "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                        # what actually limits the kernel (SQ counters via tools/pmc_kernel.sh):
+                        # the super-k-mer kernels issue one wave64 VALU instruction per CU clock, the rest wait on
+                        # dependent random 128-byte lines
+                        "limiter": LIMITER_OF_FAMILY.get(fam["name"], "hbm random access (latency / line granularity)")}
         if roofline and args.shape == "chr20" and not args.genome_len:
             roofline.update(pmc_traffic(roofline["kernel"]))
         total_ms = sum(t["ms"] for t in timings) or 1.0
