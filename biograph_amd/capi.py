@@ -73,7 +73,7 @@ SYMBOLS = [
     "bg_partition_rows", "bg_kmer_instances", "bg_kmer_extract", "bg_kmer_extract_by_owner", "bg_kmer_count_keys", "bg_kmerset_export",
     "bg_skm_supported", "bg_skm_capacity", "bg_skm_extract_by_owner", "bg_skm_count", "bg_kmerset_attach_presence",
     "bg_kmerset_from_kmers", "bg_reads_words", "bg_reads_export", "bg_reads_import", "bg_suffix_records",
-    "bg_records_count", "bg_records_words", "bg_records_rows", "bg_records_from_rows", "bg_records_free",
+    "bg_records_count", "bg_records_words", "bg_records_rows", "bg_records_prefix_hist", "bg_records_from_rows", "bg_records_free",
     "bg_entries_from_records", "bg_seqset_words", "bg_seqset_boundary_rows", "bg_seqset_fix_boundary",
     "bg_seqset_tail_rows", "bg_seqset_apply_tails", "bg_seqset_slice_export", "bg_seqset_assemble",
 ]
@@ -204,6 +204,7 @@ def lib():
     L.bg_reads_export.argtypes = [vp, vp, i32, vp, vp]
     L.bg_reads_import.argtypes = [vp, u64, i32, u32, vp, vp, P(vp)]
     L.bg_suffix_records.argtypes = [vp, vp, u64, u64, i32, P(vp)]
+    L.bg_records_prefix_hist.argtypes = [vp, vp, i32, vp]
     L.bg_records_count.restype = u64
     L.bg_records_count.argtypes = [vp]
     L.bg_records_words.argtypes = [vp]

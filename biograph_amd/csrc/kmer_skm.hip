@@ -536,19 +536,33 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
   }
 }
 
-// windows of records [lo, lo + cnt) as plain canonical instances, nmax slots per record (unused slots keep
-// the all-ones sentinel the sort-based count skips)
-__global__ void sk_expand_kernel(const SkRec* __restrict__ recs, uint64_t lo, uint64_t cnt, int k, int nmax,
-                                 uint64_t* __restrict__ keys) {
-  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= cnt) return;
-  const SkRec r = recs[lo + i];
+// windows of the records of the overflowed buckets as plain canonical instances, nmax slots per record (unused
+// slots keep the all-ones sentinel the sort-based count skips).  Segment s = records [seg_start[s], +len) of the
+// partitioned array, placed at seg_prefix[s] of the output; also copies records and origins for the presence
+// look-ups that follow the hash build (pend_* may be null).
+__global__ void sk_expand_kernel(const SkRec* __restrict__ recs, const uint64_t* __restrict__ org,
+                                 const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ seg_prefix,
+                                 uint32_t nseg, uint64_t total, int k, int nmax, uint64_t* __restrict__ keys,
+                                 SkRec* __restrict__ pend_rec, uint64_t* __restrict__ pend_org) {
+  const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  uint32_t a = 0, b = nseg;  // last segment whose prefix is <= g
+  while (b - a > 1) {
+    const uint32_t m = (a + b) >> 1;
+    if (seg_prefix[m] <= g) a = m; else b = m;
+  }
+  const uint64_t i = seg_start[a] + (g - seg_prefix[a]);
+  const SkRec r = recs[i];
+  if (pend_rec) {
+    pend_rec[g] = r;
+    pend_org[g] = org[i];
+  }
   const int n = sk_windows(r.b);
   const uint64_t kmask = ~(~0ull << (2 * k));
   uint64_t fwd = r.a >> (64 - 2 * k);
   uint64_t rc = kmer_revcomp(fwd, k);
   for (int t = 0; t < n; ++t) {
-    keys[i * nmax + t] = rc < fwd ? rc : fwd;
+    keys[g * nmax + t] = rc < fwd ? rc : fwd;
     const int idx = k + t;
     const uint64_t base = idx < 32 ? (r.a >> (62 - 2 * idx)) & 3 : (r.b >> (62 - 2 * (idx - 32))) & 3;
     fwd = ((fwd << 2) | base) & kmask;
@@ -842,18 +856,24 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
       BG_TRY(ks->pend_org.alloc(ctx, tot_rec));
       ks->pend_n = tot_rec;
     }
+    std::vector<uint64_t> seg_start, seg_prefix;
     uint64_t pos = 0;
     for (uint32_t b = 0; b < NB; ++b) {
       if (!h_over[b]) continue;
-      const uint64_t cnt = h_bounds[b + 1] - h_bounds[b];
-      sk_expand_kernel<<<cdiv(cnt, 256), 256, 0, ctx->stream>>>(part, h_bounds[b], cnt, k, nmax, ta.p + pos * nmax);
-      BG_LAUNCH_CHECK();
-      if (!bits_out) {
-        BG_HIP(hipMemcpyAsync(ks->pend_rec.p + pos * 2, part + h_bounds[b], cnt * 16, hipMemcpyDeviceToDevice, ctx->stream));
-        BG_HIP(hipMemcpyAsync(ks->pend_org.p + pos, part_org + h_bounds[b], cnt * 8, hipMemcpyDeviceToDevice, ctx->stream));
-      }
-      pos += cnt;
+      seg_start.push_back(h_bounds[b]);
+      seg_prefix.push_back(pos);
+      pos += h_bounds[b + 1] - h_bounds[b];
     }
+    DevBuf<uint64_t> d_seg;
+    BG_TRY(d_seg.alloc(ctx, seg_start.size() * 2));
+    BG_HIP(hipMemcpyAsync(d_seg.p, seg_start.data(), seg_start.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    BG_HIP(hipMemcpyAsync(d_seg.p + seg_start.size(), seg_prefix.data(), seg_start.size() * 8, hipMemcpyHostToDevice,
+                          ctx->stream));
+    sk_expand_kernel<<<cdiv(tot_rec, 256), 256, 0, ctx->stream>>>(
+        part, part_org, d_seg.p, d_seg.p + seg_start.size(), uint32_t(seg_start.size()), tot_rec, k, nmax, ta.p,
+        bits_out ? nullptr : reinterpret_cast<SkRec*>(ks->pend_rec.p), bits_out ? nullptr : ks->pend_org.p);
+    BG_LAUNCH_CHECK();
+    BG_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors go out of scope
     bg_kmerset tmp;
     tmp.ctx = ctx;
     tmp.k = k;

@@ -369,9 +369,9 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
         n_rec = L.bg_records_count(rh)
         rows = torch.empty((n_rec, W + 1), dtype=i64, device=dev[r])
         capi.check(L.bg_records_rows(ctxs[r].h, rh, _ptr(rows)))
+        hists[r] = torch.empty((4 ** PREFIX_BASES,), dtype=i64, device=dev[r])
+        capi.check(L.bg_records_prefix_hist(ctxs[r].h, rh, PREFIX_BASES, _ptr(hists[r])))
         L.bg_records_free(rh)
-        bins = (rows[:, 0] >> (64 - 2 * PREFIX_BASES)) & ((1 << (2 * PREFIX_BASES)) - 1)
-        hists[r] = torch.bincount(bins, minlength=4 ** PREFIX_BASES).to(i64)
         send[r] = rows
     del gw, gl
     ph.mark("records_partition")

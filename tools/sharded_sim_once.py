@@ -1,7 +1,7 @@
 """One timed sharded build with P ranks simulated in this process (LocalSimComm): phase times (BG_SHARD_TIMING)
 and kernel-family times.  Usage: python tools/sharded_sim_once.py <genome bases per rank> <P[,P...]>"""
 import os, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["BG_SHARD_TIMING"] = "1"
 import torch
 import biograph_amd as bg

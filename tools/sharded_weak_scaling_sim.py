@@ -6,7 +6,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["BG_SHARD_TIMING"] = "1"
 import torch
 
