@@ -469,11 +469,12 @@ BG_HD bool suffix_is_prefix(const uint64_t* aw, int anw, int j, int rem, const u
 // ---- exact-cover emission: index of the first K bases of every oriented read.
 struct CoverIndex {
   const uint64_t* slots;
-  const uint32_t* vals;
+  const uint32_t* vals;   // per slot: start of the K-mer's run in skeys / soid (or the one candidate, kCoverSingle)
+  const uint32_t* vlen;   // per slot: length of the run
   int log2cap;
-  const uint64_t* skeys;  // sorted first-K-mers
+  const uint64_t* skeys;  // first-K-mers of the candidate reads, which are sorted by their FULL key
   const uint32_t* soid;   // oriented ids in the same order
-  uint64_t n_o;           // number of oriented reads
+  uint64_t n_o;           // number of candidate reads
   int K;
 };
 
@@ -491,11 +492,32 @@ BG_HD bool cover_probe(const CoverIndex& ci, const uint64_t* owords, const uint1
     uint32_t c = v & ~kCoverSingle;
     return int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W);
   }
-  for (uint64_t p = v; p < ci.n_o && ci.skeys[p] == key; ++p) {
-    uint32_t c = ci.soid[p];
-    if (int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) return true;
+  // the candidates of this K-mer are in full-key order: the first one that is not smaller than the suffix is
+  // the only one that can have it as a prefix (anything between a string and one of its extensions extends it)
+  uint64_t lo = v, hi = uint64_t(v) + ci.vlen[h];
+  const uint64_t end = hi;
+  if (hi - lo <= 4) {  // a handful (mates, duplicates): just try them
+    for (uint64_t p = lo; p < hi; ++p) {
+      const uint32_t c = ci.soid[p];
+      if (int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) return true;
+    }
+    return false;
   }
-  return false;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    const uint32_t c = ci.soid[mid];
+    const uint64_t* cw = owords + uint64_t(c) * W;
+    int cmp = 0;  // candidate vs suffix in (words, length) order; the suffix's words are zero padded like any key
+    for (int w = 0; w < W && cmp == 0; ++w) {
+      const uint64_t a = cw[w], b = window32(s, W, j + 32 * w);
+      cmp = a < b ? -1 : (a > b ? 1 : 0);
+    }
+    if (cmp == 0) cmp = int(len[c >> 1]) < rem ? -1 : 0;
+    if (cmp < 0) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= end) return false;
+  const uint32_t c = ci.soid[lo];
+  return int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W);
 }
 
 // number of suffix records oriented read o emits (0 for a dropped read)

@@ -18,12 +18,14 @@
 
 namespace bg {
 
+constexpr int kSortSkipBits = 32;  // the sort key keeps the leading 16 bases of a record (see k_first_words)
+
 // ------------------------------------------------------------------------------------------------
-// oriented reads
+// oriented reads (+ their lengths as bytes and their sort keys: leading 16 bases | oriented id)
 
 __global__ void k_oriented_words(const uint64_t* __restrict__ words, const uint16_t* __restrict__ len, uint64_t n,
-                                 int W, int K, uint64_t* __restrict__ owords, uint64_t* __restrict__ okey,
-                                 uint32_t* __restrict__ oid) {
+                                 int W, uint64_t* __restrict__ owords, uint8_t* __restrict__ olen,
+                                 uint64_t* __restrict__ k0) {
   uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (o >= 2 * n) return;
   uint64_t i = o >> 1;
@@ -31,8 +33,24 @@ __global__ void k_oriented_words(const uint64_t* __restrict__ words, const uint1
   uint64_t tmp[kMaxWords];
   oriented_words(words + i * W, L, W, (o & 1) != 0, tmp);
   for (int w = 0; w < W; ++w) owords[o * W + w] = L ? tmp[w] : 0;
-  okey[o] = (L >= K) ? (tmp[0] >> (64 - 2 * K)) : ~0ull;  // sentinel: cannot act as a cover
-  oid[o] = uint32_t(o);
+  olen[o] = uint8_t(L);
+  k0[o] = ((L ? tmp[0] : 0ull) & ~((1ull << kSortSkipBits) - 1)) | o;
+}
+
+// reads at least K bases long, in sorted order (shorter ones cannot act as a cover)
+__global__ void k_flag_long_enough(const uint32_t* __restrict__ sidx, const uint8_t* __restrict__ olen, uint64_t n, int K,
+                                   uint8_t* __restrict__ flags) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = olen[sidx[i]] >= K ? 1 : 0;
+}
+__global__ void k_cover_keys(const uint32_t* __restrict__ sidx, const uint32_t* __restrict__ keep, uint64_t m,
+                             const uint64_t* __restrict__ owords, int W, int K, uint64_t* __restrict__ skeys,
+                             uint32_t* __restrict__ soid) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t o = sidx[keep[i]];
+  soid[i] = o;
+  skeys[i] = owords[uint64_t(o) * W] >> (64 - 2 * K);
 }
 
 __global__ void k_flag_key_heads(const uint64_t* __restrict__ keys, uint64_t n, uint8_t* __restrict__ flags) {
@@ -47,12 +65,14 @@ __global__ void k_flag_key_heads(const uint64_t* __restrict__ keys, uint64_t n, 
 // that a hit costs one dependent load less than going through the sorted list.
 __global__ void k_cover_insert(const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ soid,
                                uint64_t n_o, const uint32_t* __restrict__ head_pos, uint64_t nheads,
-                               uint64_t* __restrict__ slots, uint32_t* __restrict__ vals, int log2cap) {
+                               uint64_t* __restrict__ slots, uint32_t* __restrict__ vals, uint32_t* __restrict__ vlen,
+                               int log2cap) {
   uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r >= nheads) return;
   uint32_t pos = head_pos[r];
   uint64_t key = skeys[pos];
-  const bool single = n_o < (1ull << 31) && (uint64_t(pos) + 1 >= n_o || skeys[pos + 1] != key);
+  const uint32_t run = uint32_t((r + 1 < nheads ? uint64_t(head_pos[r + 1]) : n_o) - pos);
+  const bool single = n_o < (1ull << 31) && run == 1;
   if (single) pos = kCoverSingle | soid[pos];
   uint64_t mask = (1ull << log2cap) - 1;
   uint64_t s = hash_slot(key, log2cap);
@@ -63,7 +83,7 @@ __global__ void k_cover_insert(const uint64_t* __restrict__ skeys, const uint32_
       if (slots[t] != kEmptySlot) continue;
       unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&slots[t]),
                                          (unsigned long long)kEmptySlot, (unsigned long long)key);
-      if (old == kEmptySlot) { vals[t] = pos; return; }
+      if (old == kEmptySlot) { vals[t] = pos; vlen[t] = run; return; }
     }
     s = (s + kBucketSlots) & mask;
   }
@@ -124,8 +144,6 @@ __global__ __launch_bounds__(256) void k_cover_count(CoverIndex ci, const uint64
 // output WORDS (lane = consecutive word), find the read a word belongs to by a 6-step search over the
 // 64 record offsets held one per lane, and write fully coalesced — instead of one lane looping over all
 // the records of its read.
-constexpr int kSortSkipBits = 32;  // the sort key keeps the leading 16 bases of a record (see k_first_words)
-
 __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict__ owords,
                                                       const uint16_t* __restrict__ len,
                                                       const uint32_t* __restrict__ cnt,
@@ -975,6 +993,9 @@ int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss) {
 
 namespace bg {
 
+int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p, uint64_t n_rec, int W,
+                      DevBuf<uint64_t>* k0, DevBuf<uint32_t>* sidx_out, uint64_t* n_tied_out);
+
 // Phase A: suffix records of reads [lo, hi) under the exact-cover rule; the cover index spans ALL
 // reads of `reads` (in a sharded build every rank holds the gathered corrected reads).
 int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t hi, int cover_k,
@@ -986,50 +1007,61 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   if (lo > hi || hi > n) { set_error("bad read range"); return BG_EINVAL; }
   const uint64_t o_base = 2 * lo, n_emit = 2 * (hi - lo);
   uint64_t n_rec = 0;
-  // ---- oriented reads + cover index
-  DevBuf<uint64_t> owords, okey_a, okey_b;
-  DevBuf<uint32_t> oid_a, oid_b;
+  // ---- oriented reads + cover index.  The oriented reads are sorted by their full key (the machinery of the
+  // record sort): reads with the same first K-mer are then consecutive AND in key order, so a look-up among
+  // the candidates of one K-mer is a binary search — a repeat family puts thousands of reads behind one K-mer,
+  // and scanning them made the look-ups quadratic (tools/stress_repeats.py: 3.5 s for a 20 Mb genome).
+  DevBuf<uint64_t> owords, skeys_b;
+  DevBuf<uint32_t> soid_b, head_pos;
+  DevBuf<uint8_t> olen;
   BG_TRY(owords.alloc(ctx, n_o * W));
-  BG_TRY(okey_a.alloc(ctx, n_o));
-  BG_TRY(okey_b.alloc(ctx, n_o));
-  BG_TRY(oid_a.alloc(ctx, n_o));
-  BG_TRY(oid_b.alloc(ctx, n_o));
-  if (n_o) {
-    ctx->tic("suffix_oriented");
-    k_oriented_words<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->len.p, n, W, cover_k, owords.p,
-                                                              okey_a.p, oid_a.p);
-    BG_LAUNCH_CHECK();
-    ctx->toc(n * W * 8 + n_o * W * 8 + n_o * 12);
-  }
-  bool in_b = false;
-  BG_TRY(radix_sort_u64(ctx, okey_a.p, okey_b.p, oid_a.p, oid_b.p, n_o, 0, 64, &in_b));
-  uint64_t* skeys = in_b ? okey_b.p : okey_a.p;
-  uint32_t* soid = in_b ? oid_b.p : oid_a.p;
-  DevBuf<uint32_t> head_pos;
-  uint64_t nheads = 0;
+  BG_TRY(olen.alloc(ctx, n_o));
+  uint64_t m = 0, nheads = 0;  // reads that can act as a cover, distinct first K-mers
   {
+    DevBuf<uint64_t> k0o;
+    DevBuf<uint32_t> sidx_all, keep;
     DevBuf<uint8_t> flags;
+    BG_TRY(k0o.alloc(ctx, n_o));
+    if (n_o) {
+      ctx->tic("suffix_oriented");
+      k_oriented_words<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->len.p, n, W, owords.p, olen.p, k0o.p);
+      BG_LAUNCH_CHECK();
+      ctx->toc(n * W * 8 + n_o * W * 8 + n_o * 9);
+    }
+    BG_TRY(sort_records_impl(ctx, owords.p, olen.p, n_o, W, &k0o, &sidx_all, nullptr));
     BG_TRY(flags.alloc(ctx, n_o));
     if (n_o) {
-      k_flag_key_heads<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(skeys, n_o, flags.p);
+      k_flag_long_enough<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(sidx_all.p, olen.p, n_o, cover_k, flags.p);
       BG_LAUNCH_CHECK();
     }
-    BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, n_o, &head_pos, &nheads));
+    BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, n_o, &keep, &m));
+    BG_TRY(skeys_b.alloc(ctx, m));
+    BG_TRY(soid_b.alloc(ctx, m));
+    if (m) {
+      k_cover_keys<<<cdiv(m, 256), 256, 0, ctx->stream>>>(sidx_all.p, keep.p, m, owords.p, W, cover_k, skeys_b.p, soid_b.p);
+      BG_LAUNCH_CHECK();
+      k_flag_key_heads<<<cdiv(m, 256), 256, 0, ctx->stream>>>(skeys_b.p, m, flags.p);
+      BG_LAUNCH_CHECK();
+    }
+    BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, m, &head_pos, &nheads));
   }
+  uint64_t* skeys = skeys_b.p;
+  uint32_t* soid = soid_b.p;
   int lg = 10;
   // load factor <= 0.7 (8-slot buckets keep chains short) rather than <= 0.5: half the table, which matters
   // beyond 2 GiB where random probes fall off the TLB reach (tools/probe_rate.hip: 55 -> 22 G probes/s at 4 GiB)
   while ((1ull << lg) * 7 < nheads * 10) ++lg;
   DevBuf<uint64_t> slots;
-  DevBuf<uint32_t> vals;
+  DevBuf<uint32_t> vals, vlen;
   BG_TRY(slots.alloc(ctx, 1ull << lg));
   BG_TRY(vals.alloc(ctx, 1ull << lg));
+  BG_TRY(vlen.alloc(ctx, 1ull << lg));
   BG_HIP(hipMemsetAsync(slots.p, 0xff, (1ull << lg) * 8, ctx->stream));
   if (nheads) {
-    k_cover_insert<<<cdiv(nheads, 256), 256, 0, ctx->stream>>>(skeys, soid, n_o, head_pos.p, nheads, slots.p, vals.p, lg);
+    k_cover_insert<<<cdiv(nheads, 256), 256, 0, ctx->stream>>>(skeys, soid, m, head_pos.p, nheads, slots.p, vals.p, vlen.p, lg);
     BG_LAUNCH_CHECK();
   }
-  CoverIndex ci{slots.p, vals.p, lg, skeys, soid, n_o, cover_k};
+  CoverIndex ci{slots.p, vals.p, vlen.p, lg, skeys, soid, m, cover_k};
 
   // ---- emission
   DevBuf<uint32_t> cnt;
@@ -1062,16 +1094,15 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   return BG_OK;
 }
 
-// Phase B: sort the records, drop prefixes/duplicates, build keys/sizes/shared of the surviving
-// entries into `ss`.  Consumes rec/rlen.
-int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t>& rlen, uint64_t n_rec, int W,
-                              bg_seqset* ss, uint64_t* n_tied_out, DevBuf<uint64_t>* k0) {
-  if (n_rec >= (1ull << 32)) {
-    set_error("%llu suffix records exceed one shard", (unsigned long long)n_rec);
-    return BG_EINVAL;
-  }
-  uint64_t n_tied = 0, n_ent = 0;
-  DevBuf<uint32_t> sidx;  // sorted order -> record
+// Order of records by full key (words, length): sidx[i] = record (row of rec / rlen) at sorted position i.
+// The n_keys sort keys are (leading 16 bases | record), taken from *k0 when it holds them (consumed), else made
+// from rec rows 0 .. n_keys-1.  *n_tied_out = records in tie groups larger than kSmallGroup.
+int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p, uint64_t n_rec, int W,
+                      DevBuf<uint64_t>* k0, DevBuf<uint32_t>* sidx_out, uint64_t* n_tied_out) {
+  struct { const uint64_t* p; } rec{rec_p};
+  struct { const uint8_t* p; } rlen{rlen_p};
+  DevBuf<uint32_t>& sidx = *sidx_out;
+  uint64_t n_tied = 0;
   {
     // ---- sort by the leading 16 bases (record index packed into the key)
     DevBuf<uint64_t> k0a, k0b;
@@ -1238,6 +1269,22 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
     T = T2;
   }
   }
+
+  if (n_tied_out) *n_tied_out = n_tied;
+  return BG_OK;
+}
+
+// Phase B: sort the records, drop prefixes/duplicates, build keys/sizes/shared of the surviving
+// entries into `ss`.  Consumes rec/rlen.
+int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t>& rlen, uint64_t n_rec, int W,
+                              bg_seqset* ss, uint64_t* n_tied_out, DevBuf<uint64_t>* k0) {
+  if (n_rec >= (1ull << 32)) {
+    set_error("%llu suffix records exceed one shard", (unsigned long long)n_rec);
+    return BG_EINVAL;
+  }
+  uint64_t n_tied = 0, n_ent = 0;
+  DevBuf<uint32_t> sidx;  // sorted order -> record
+  BG_TRY(sort_records_impl(ctx, rec.p, rlen.p, n_rec, W, k0, &sidx, &n_tied));
 
   // ---- dedup + entries
   DevBuf<uint32_t> err;

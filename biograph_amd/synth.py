@@ -33,13 +33,20 @@ def make_genome(n, seed, device):
 
 
 def make_reads(genome_len=SHAPES["tiny"], coverage=30, read_len=150, seed=20261002, device="cpu", err=0.002,
-               n_rate=0.0001, snp_rate=0.001, chunk_pairs=1 << 20, shard=(0, 1), return_genome=False):
+               n_rate=0.0001, snp_rate=0.001, chunk_pairs=1 << 20, shard=(0, 1), return_genome=False, repeats=None):
     """Returns (seq uint8 [n_reads*read_len], offs int64 [n_reads+1], n_reads).
 
     shard=(rank, world): the same sample (genome + haplotypes from `seed`) on every rank, each rank
     drawing its own 1/world of the read pairs (read RNG seeded with seed + 2 + 1000*rank)."""
     dev = torch.device(device)
     hap_a = make_genome(genome_len, seed, dev)
+    if repeats:  # (unit_len, copies): an exact high-copy element (stress input, tools/stress_repeats.py)
+        unit_len, copies = repeats
+        cg = torch.Generator()
+        cg.manual_seed(seed + 9)
+        unit = torch.randint(0, 4, (unit_len,), generator=cg, dtype=torch.uint8).to(dev)
+        for st in torch.randint(0, genome_len - unit_len, (copies,), generator=cg).tolist():
+            hap_a[st:st + unit_len] = unit
     g = torch.Generator(device=dev)
     g.manual_seed(seed + 1)
     snp = torch.rand(genome_len, generator=g, device=dev) < snp_rate

@@ -45,17 +45,20 @@ static Packed pack(const char* seq, const uint64_t* offs, uint64_t n) {
 }
 
 static void build_table(const uint64_t* keys, uint64_t n, std::vector<uint64_t>& slots, int& lg,
-                        std::vector<uint32_t>* vals = nullptr, const uint32_t* valsrc = nullptr) {
+                        std::vector<uint32_t>* vals = nullptr, const uint32_t* valsrc = nullptr,
+                        std::vector<uint32_t>* vals2 = nullptr, const uint32_t* valsrc2 = nullptr) {
   lg = 10;
   while ((1ull << lg) < 2 * n) ++lg;
   slots.assign(1ull << lg, kEmptySlot);
   if (vals) vals->assign(1ull << lg, 0);
+  if (vals2) vals2->assign(1ull << lg, 0);
   uint64_t mask = (1ull << lg) - 1;
   for (uint64_t i = 0; i < n; ++i) {
     uint64_t s = hash_slot(keys[i], lg);
     while (slots[s] != kEmptySlot) s = (s + 1) & mask;
     slots[s] = keys[i];
     if (vals) (*vals)[s] = valsrc[i];
+    if (vals2) (*vals2)[s] = valsrc2[i];
   }
 }
 
@@ -119,20 +122,25 @@ void* hh_build_entries(const char* seq, const uint64_t* offs, uint64_t n, int K)
     for (int w = 0; w < W; ++w) owords[o * W + w] = L ? tmp[w] : 0;
     if (L >= K) keyed.emplace_back(tmp[0] >> (64 - 2 * K), uint32_t(o));
   }
-  std::stable_sort(keyed.begin(), keyed.end(), [](auto& a, auto& b) { return a.first < b.first; });
+  // candidates in full-key order (which implies first-K-mer order): cover_probe searches a K-mer's run by key
+  std::stable_sort(keyed.begin(), keyed.end(), [&](auto& a, auto& b) {
+    return key_compare(&owords[uint64_t(a.second) * W], p.len[a.second >> 1], &owords[uint64_t(b.second) * W],
+                       p.len[b.second >> 1], W) < 0;
+  });
   std::vector<uint64_t> skeys, ukeys;
-  std::vector<uint32_t> soid, upos;
+  std::vector<uint32_t> soid, upos, ulen;
   for (size_t i = 0; i < keyed.size(); ++i) {
     skeys.push_back(keyed[i].first);
     soid.push_back(keyed[i].second);
-    if (i == 0 || keyed[i].first != keyed[i - 1].first) { ukeys.push_back(keyed[i].first); upos.push_back(uint32_t(i)); }
+    if (i == 0 || keyed[i].first != keyed[i - 1].first) { ukeys.push_back(keyed[i].first); upos.push_back(uint32_t(i)); ulen.push_back(0); }
+    ++ulen.back();
   }
   std::vector<uint64_t> slots;
-  std::vector<uint32_t> vals;
+  std::vector<uint32_t> vals, vlen;
   int lg;
-  build_table(ukeys.data(), ukeys.size(), slots, lg, &vals, upos.data());
-  // the device keeps sentinel keys of short reads at the end of skeys; here they are simply absent
-  CoverIndex ci{slots.data(), vals.data(), lg, skeys.data(), soid.data(), uint64_t(skeys.size()), K};
+  build_table(ukeys.data(), ukeys.size(), slots, lg, &vals, upos.data(), &vlen, ulen.data());
+  // reads shorter than K cannot act as a cover: they are simply absent
+  CoverIndex ci{slots.data(), vals.data(), vlen.data(), lg, skeys.data(), soid.data(), uint64_t(skeys.size()), K};
   struct Rec { uint64_t w[kMaxWords]; int len; };
   std::vector<Rec> recs;
   for (uint64_t o = 0; o < n_o; ++o) {
