@@ -371,7 +371,7 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
                                                                    const uint64_t* __restrict__ org,
                                                                    unsigned long long* __restrict__ present,
                                                                    int pstride, uint64_t* __restrict__ ulist,
-                                                                   uint32_t* __restrict__ bits_out) {
+                                                                   uint32_t* __restrict__ bits_out, uint64_t giant) {
   extern __shared__ __align__(16) unsigned char skc_smem[];
   unsigned long long* tkeys = reinterpret_cast<unsigned long long*>(skc_smem);
   uint32_t* tcnt = reinterpret_cast<uint32_t*>(skc_smem + size_t(cap) * 8);
@@ -380,6 +380,14 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
   const uint32_t bucket = blockIdx.x;
   const uint64_t lo = bounds[bucket], hi = bounds[bucket + 1];
   if (lo == hi) return;  // block-uniform
+  if (hi - lo > giant) {
+    // a repeat family: one workgroup would spend tens of milliseconds serialising on a few LDS counters while
+    // the rest of the GPU idles — such a bucket goes to the sort-based count with the overflowed ones
+    if (threadIdx.x == 0) overflow[bucket] = 1;
+    if (bits_out)
+      for (uint64_t i = lo + threadIdx.x; i < hi; i += SKC_THREADS) bits_out[org[i]] = kSkUnknown;
+    return;
+  }
   for (uint32_t i = threadIdx.x; i < cap; i += SKC_THREADS) { tkeys[i] = ~0ull; tcnt[i] = 0; }
   if (threadIdx.x == 0) { s_over = 0; s_kept = 0; s_distinct = 0; s_cursor = 0; s_unsettled = 0; }
   __syncthreads();
@@ -818,12 +826,15 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
   BG_LAUNCH_CHECK();
   const uint32_t slots = sk_lds_slots();
   const size_t smem = size_t(slots) * 12;
+  // buckets with more than 64 records per thread (30x the average at chr20) are not counted in LDS
+  uint64_t giant = 64ull * SKC_THREADS;
+  if (const char* e = getenv("BG_SKM_GIANT")) giant = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
   BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sk_count_lds_kernel),
                              hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
   sk_count_lds_kernel<<<NB, SKC_THREADS, smem, ctx->stream>>>(part, bounds.p, slots, k, min_count, out_cap, ok_a.p, oc_a.p, ctr.p,
                                                              ctr.p + 1, overflow.p, part_org,
                                                              reinterpret_cast<unsigned long long*>(ks->present.p), ks->present_stride, ulist.p,
-                                                             bits_out);
+                                                             bits_out, giant);
   BG_LAUNCH_CHECK();
   ctx->toc(R * 40);
   unsigned long long h_ctr[2] = {0, 0};
