@@ -40,13 +40,20 @@ def make_reads(genome_len=SHAPES["tiny"], coverage=30, read_len=150, seed=202610
     drawing its own 1/world of the read pairs (read RNG seeded with seed + 2 + 1000*rank)."""
     dev = torch.device(device)
     hap_a = make_genome(genome_len, seed, dev)
-    if repeats:  # (unit_len, copies): an exact high-copy element (stress input, tools/stress_repeats.py)
-        unit_len, copies = repeats
+    if repeats:  # (unit_len, copies[, divergence]): a high-copy element (stress input, tools/stress_repeats.py)
+        unit_len, copies = repeats[0], repeats[1]
+        div = repeats[2] if len(repeats) > 2 else 0.0
         cg = torch.Generator()
         cg.manual_seed(seed + 9)
-        unit = torch.randint(0, 4, (unit_len,), generator=cg, dtype=torch.uint8).to(dev)
-        for st in torch.randint(0, genome_len - unit_len, (copies,), generator=cg).tolist():
-            hap_a[st:st + unit_len] = unit
+        unit = torch.randint(0, 4, (unit_len,), generator=cg, dtype=torch.uint8)
+        starts = torch.randint(0, genome_len - unit_len, (copies,), generator=cg)
+        copies_t = unit[None, :].repeat(copies, 1)
+        if div > 0:  # every copy carries its own substitutions
+            mut = torch.rand(copies_t.shape, generator=cg) < div
+            copies_t = torch.where(mut, (copies_t + torch.randint(1, 4, copies_t.shape, generator=cg, dtype=torch.uint8)) & 3,
+                                   copies_t)
+        idx = (starts[:, None] + torch.arange(unit_len)[None, :]).reshape(-1).to(dev)
+        hap_a[idx] = copies_t.reshape(-1).to(dev)
     g = torch.Generator(device=dev)
     g.manual_seed(seed + 1)
     snp = torch.rand(genome_len, generator=g, device=dev) < snp_rate
