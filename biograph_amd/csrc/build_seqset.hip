@@ -207,26 +207,10 @@ __global__ void k_first_words(const uint64_t* __restrict__ rec, uint64_t n, int 
   k0[r] = (rec[r * W] & ~((1ull << kSortSkipBits) - 1)) | r;
 }
 
-// sorted packed keys -> group key (leading bases only) in place + record index
-__global__ void k_split_sorted(uint64_t* __restrict__ k, uint64_t n, uint32_t* __restrict__ sidx) {
-  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint64_t v = k[i];
-  sidx[i] = uint32_t(v);
-  k[i] = v & ~((1ull << kSortSkipBits) - 1);
-}
 
 // ------------------------------------------------------------------------------------------------
 // tie refinement after the first-word sort
 
-// flags positions whose sort key equals a neighbour's
-__global__ void k_flag_ties(const uint64_t* __restrict__ skeys, uint64_t n, uint8_t* __restrict__ flags) {
-  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint64_t k = skeys[i];
-  bool t = (i > 0 && skeys[i - 1] == k) || (i + 1 < n && skeys[i + 1] == k);
-  flags[i] = t ? 1 : 0;
-}
 
 // Tie groups (runs of equal first word) of at most kSmallGroup records are ordered right here by
 // one lane with full-key comparisons (insertion sort on record ids; the keys are gathered from the

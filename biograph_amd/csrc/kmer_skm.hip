@@ -349,12 +349,6 @@ __global__ void sk_bounds_kernel(const SkRec* __restrict__ recs, uint64_t n, int
   bounds[v] = lo;
 }
 
-__global__ void sk_bucket_starts_kernel(const uint64_t* __restrict__ offs, uint32_t ntiles, uint64_t n,
-                                        uint64_t* __restrict__ starts) {
-  const int b = threadIdx.x;
-  starts[b] = offs[uint64_t(b) * ntiles];
-  if (b == 0) starts[SK_BINS] = n;
-}
 
 // ---- counting: one workgroup per bucket, windows unrolled from the records into an LDS table ---------
 constexpr int SKC_THREADS = 1024;

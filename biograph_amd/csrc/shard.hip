@@ -189,14 +189,6 @@ __global__ __launch_bounds__(256) void k_msplit_scatter(const uint64_t* __restri
   }
 }
 
-__global__ void k_gather_rows(const uint64_t* __restrict__ rows, const uint32_t* __restrict__ perm, uint64_t n_out,
-                              int row_words, uint64_t* __restrict__ out) {
-  uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (g >= n_out * uint64_t(row_words)) return;
-  uint64_t i = g / uint64_t(row_words);
-  int w = int(g - i * uint64_t(row_words));
-  out[g] = rows[uint64_t(perm[i]) * row_words + w];
-}
 
 // ---- rows <-> records / tails
 
@@ -246,10 +238,6 @@ __global__ void k_place_bits(const uint64_t* __restrict__ local, uint64_t n_loca
   if (sh && (v >> (64 - sh))) atomicOr(&global[gw + 1], (unsigned long long)(v >> (64 - sh)));
 }
 
-__global__ void k_copy_len_u16(const uint16_t* __restrict__ in, uint64_t n, uint16_t* __restrict__ out) {
-  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = in[i];
-}
 __global__ void k_restride_words(const uint64_t* __restrict__ in, uint64_t n, int W_in, int W_out,
                                  uint64_t* __restrict__ out) {
   uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
