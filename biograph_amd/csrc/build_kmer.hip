@@ -60,20 +60,42 @@ __global__ void k_pack_reads(const uint8_t* __restrict__ seq, const uint64_t* __
   uint32_t nm = 0;
   if (lo < L) {
     const uint8_t* p = seq + offs[i] + lo;
-    int cnt = L - lo < 32 ? L - lo : 32;
+    const int cnt = L - lo < 32 ? L - lo : 32;
     bool bad = false;
-    for (int j = 0; j < cnt; ++j) {
-      uint32_t c = p[j];
-      uint32_t u = c & 0xDFu;  // upper-case letters
-      uint32_t code = (c >> 1) & 3;
-      code ^= code >> 1;  // A0 C1 G2 T3 (dna_base.h:38-56)
-      bool acgt = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
-      if (!acgt) {
-        code = 0;
-        if (c == 'N') nm |= 1u << (31 - j);  // only upper-case N is special (kmer_counter.h:306)
-        else bad = true;                      // dna_base.h:54 throws
+    // eight characters at a time (SWAR): 2-bit codes A0 C1 G2 T3 (dna_base.h:38-56) from bits 1..2 of the
+    // letter, exact byte compares for the ACGT / acgt test and for 'N' (only upper-case N is special,
+    // kmer_counter.h:306; anything else makes dna_base.h:54 throw)
+    constexpr uint64_t kOnes = 0x0101010101010101ull, kLow7 = 0x7f7f7f7f7f7f7f7full;
+    auto eq = [&](uint64_t v, uint64_t c) {  // 0x80 in every byte of v that equals c
+      const uint64_t z = v ^ (c * kOnes);
+      return ~(((z & kLow7) + kLow7) | z | kLow7);
+    };
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8) {
+      const int m = cnt - 8 * c8;  // characters of this chunk
+      if (m <= 0) break;
+      uint64_t x = 0;
+      if (m >= 8) {
+        __builtin_memcpy(&x, p + 8 * c8, 8);  // unaligned 8-byte load
+      } else {
+        for (int j = 0; j < m; ++j) x |= uint64_t(p[8 * c8 + j]) << (8 * j);
       }
-      word |= uint64_t(code) << (62 - 2 * j);
+      const uint64_t y = __builtin_bswap64(x);  // first character in the top byte
+      const uint64_t t = (y >> 1) & 0x0303030303030303ull;
+      uint64_t code = t ^ ((t >> 1) & kOnes);
+      const uint64_t u = y & 0xDFDFDFDFDFDFDFDFull;
+      const uint64_t acgt = eq(u, 'A') | eq(u, 'C') | eq(u, 'G') | eq(u, 'T');
+      const uint64_t isn = eq(y, 'N');
+      code &= (acgt >> 7) * 3;
+      uint64_t c1 = (code | (code >> 6)) & 0x000F000F000F000Full;
+      c1 = (c1 | (c1 >> 12)) & 0x000000FF000000FFull;
+      c1 = (c1 | (c1 >> 24)) & 0xFFFFull;
+      const uint32_t valid8 = uint32_t((((acgt >> 7) & kOnes) * 0x0102040810204080ull) >> 56);
+      const uint32_t n8 = uint32_t((((isn >> 7) & kOnes) * 0x0102040810204080ull) >> 56);
+      const uint32_t in8 = m >= 8 ? 0xFFu : ((0xFFu << (8 - m)) & 0xFFu);  // characters that exist
+      if ((~valid8 & ~n8 & in8) != 0) bad = true;
+      word |= c1 << (48 - 16 * c8);
+      nm |= (n8 & in8) << (24 - 8 * c8);
     }
     if (bad) atomicOr(err, 2u);
   }
