@@ -804,15 +804,23 @@ __device__ __forceinline__ bool prev_target_pre2(const uint64_t* __restrict__ ek
   bool sure = false;
   if (tl >= 64) {
     const uint32_t p = uint32_t(t0 >> (64 - 2 * bases));
+    // these look-ups run into the memory pipeline's address rate: one 16-byte load per prefix, not two of 8
+    const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(pre2);
     uint64_t a = dir[p], z = dir[p + 1];
     while (a < z) {  // first entry whose two leading words are >= the tail's
       const uint64_t mid = (a + z) >> 1;
-      const uint64_t m0 = pre2[mid * 2], m1 = pre2[mid * 2 + 1];
-      if (m0 < t0 || (m0 == t0 && m1 < t1)) a = mid + 1; else z = mid;
+      const ulonglong2 m = p2[mid];
+      if (m.x < t0 || (m.x == t0 && m.y < t1)) a = mid + 1; else z = mid;
     }
     lo = a;
-    sure = lo < n && pre2[lo * 2] == t0 && pre2[lo * 2 + 1] == t1 &&
-           (lo + 1 >= n || pre2[lo * 2 + 2] != t0 || pre2[lo * 2 + 3] != t1);
+    if (lo < n) {
+      const ulonglong2 c0 = p2[lo];
+      sure = c0.x == t0 && c0.y == t1;
+      if (sure && lo + 1 < n) {
+        const ulonglong2 c1 = p2[lo + 1];
+        sure = c1.x != t0 || c1.y != t1;
+      }
+    }
   }
   if (!sure || verify) {
     const uint64_t full = entries_lower_bound(ekeys, sizes, n, W, dir, bases, tail, tl);
