@@ -467,10 +467,15 @@ BG_HD bool suffix_is_prefix(const uint64_t* aw, int anw, int j, int rem, const u
 }
 
 // ---- exact-cover emission: index of the first K bases of every oriented read.
+// The look-ups of k_cover_count run into the L1 -> L2 request rate (≈64 G requests/s under load; SQ / TCP counters
+// via tools/pmc_kernel.sh).  The table keeps the 64-byte buckets of the k-mer table (the four 16-byte loads of a
+// bucket merge into one request; 16-byte pairs were tried and need two dependent requests per miss: 9.4 -> 11.4 ms),
+// and what a hit needs next — run start or the one candidate, run length or that candidate's length — sits in one
+// 8-byte word per slot instead of three arrays.
 struct CoverIndex {
-  const uint64_t* slots;
-  const uint32_t* vals;   // per slot: start of the K-mer's run in skeys / soid (or the one candidate, kCoverSingle)
-  const uint32_t* vlen;   // per slot: length of the run
+  const uint64_t* slots;  // first-K-mers (hash table, 8-slot buckets)
+  const uint64_t* vv;     // per slot: low 32 = start of the K-mer's run in skeys / soid, or kCoverSingle | the one
+                          // candidate; high 32 = length of the run, or of that candidate
   int log2cap;
   const uint64_t* skeys;  // first-K-mers of the candidate reads, which are sorted by their FULL key
   const uint32_t* soid;   // oriented ids in the same order
@@ -478,7 +483,7 @@ struct CoverIndex {
   int K;
 };
 
-constexpr uint32_t kCoverSingle = 0x80000000u;  // vals[]: bit 31 = the run is this one oriented id
+constexpr uint32_t kCoverSingle = 0x80000000u;  // vv[] low word: bit 31 = the run is this one oriented id
 
 // is suffix j (>= K bases long) of the oriented read s a prefix of some oriented read?
 BG_HD bool cover_probe(const CoverIndex& ci, const uint64_t* owords, const uint16_t* len, const uint64_t* s, int L,
@@ -487,14 +492,15 @@ BG_HD bool cover_probe(const CoverIndex& ci, const uint64_t* owords, const uint1
   uint64_t key = window32(s, W, j) >> (64 - 2 * ci.K);
   int64_t h = table_find(ci.slots, ci.log2cap, key, ~0ull);
   if (h < 0) return false;
-  const uint32_t v = ci.vals[h];
+  const uint64_t vv = ci.vv[h];
+  const uint32_t v = uint32_t(vv);
   if (v & kCoverSingle) {
     uint32_t c = v & ~kCoverSingle;
-    return int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W);
+    return int(vv >> 32) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W);
   }
   // the candidates of this K-mer are in full-key order: the first one that is not smaller than the suffix is
   // the only one that can have it as a prefix (anything between a string and one of its extensions extends it)
-  uint64_t lo = v, hi = uint64_t(v) + ci.vlen[h];
+  uint64_t lo = v, hi = uint64_t(v) + (vv >> 32);
   const uint64_t end = hi;
   if (hi - lo <= 4) {  // a handful (mates, duplicates): just try them
     for (uint64_t p = lo; p < hi; ++p) {

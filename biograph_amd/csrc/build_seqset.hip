@@ -64,16 +64,19 @@ __global__ void k_flag_key_heads(const uint64_t* __restrict__ keys, uint64_t n, 
 // A run of one candidate (the usual case) stores the candidate's oriented id itself, flagged in bit 31, so
 // that a hit costs one dependent load less than going through the sorted list.
 __global__ void k_cover_insert(const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ soid,
-                               uint64_t n_o, const uint32_t* __restrict__ head_pos, uint64_t nheads,
-                               uint64_t* __restrict__ slots, uint32_t* __restrict__ vals, uint32_t* __restrict__ vlen,
-                               int log2cap) {
+                               const uint8_t* __restrict__ olen, uint64_t n_o, const uint32_t* __restrict__ head_pos,
+                               uint64_t nheads, uint64_t* __restrict__ slots, uint64_t* __restrict__ vv, int log2cap) {
   uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r >= nheads) return;
   uint32_t pos = head_pos[r];
   uint64_t key = skeys[pos];
-  const uint32_t run = uint32_t((r + 1 < nheads ? uint64_t(head_pos[r + 1]) : n_o) - pos);
-  const bool single = n_o < (1ull << 31) && run == 1;
-  if (single) pos = kCoverSingle | soid[pos];
+  uint64_t second = (r + 1 < nheads ? uint64_t(head_pos[r + 1]) : n_o) - pos;  // run length
+  const bool single = n_o < (1ull << 31) && second == 1;
+  if (single) {
+    const uint32_t c = soid[pos];
+    pos = kCoverSingle | c;
+    second = olen[c];  // the candidate's length: a hit needs it before anything else
+  }
   uint64_t mask = (1ull << log2cap) - 1;
   uint64_t s = hash_slot(key, log2cap);
   const int off = hash_slot_offset(key, log2cap);
@@ -83,7 +86,7 @@ __global__ void k_cover_insert(const uint64_t* __restrict__ skeys, const uint32_
       if (slots[t] != kEmptySlot) continue;
       unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&slots[t]),
                                          (unsigned long long)kEmptySlot, (unsigned long long)key);
-      if (old == kEmptySlot) { vals[t] = pos; vlen[t] = run; return; }
+      if (old == kEmptySlot) { vv[t] = (second << 32) | pos; return; }
     }
     s = (s + kBucketSlots) & mask;
   }
@@ -1043,17 +1046,15 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   // load factor <= 0.7 (8-slot buckets keep chains short) rather than <= 0.5: half the table, which matters
   // beyond 2 GiB where random probes fall off the TLB reach (tools/probe_rate.hip: 55 -> 22 G probes/s at 4 GiB)
   while ((1ull << lg) * 7 < nheads * 10) ++lg;
-  DevBuf<uint64_t> slots;
-  DevBuf<uint32_t> vals, vlen;
+  DevBuf<uint64_t> slots, vv;
   BG_TRY(slots.alloc(ctx, 1ull << lg));
-  BG_TRY(vals.alloc(ctx, 1ull << lg));
-  BG_TRY(vlen.alloc(ctx, 1ull << lg));
+  BG_TRY(vv.alloc(ctx, 1ull << lg));
   BG_HIP(hipMemsetAsync(slots.p, 0xff, (1ull << lg) * 8, ctx->stream));
   if (nheads) {
-    k_cover_insert<<<cdiv(nheads, 256), 256, 0, ctx->stream>>>(skeys, soid, m, head_pos.p, nheads, slots.p, vals.p, vlen.p, lg);
+    k_cover_insert<<<cdiv(nheads, 256), 256, 0, ctx->stream>>>(skeys, soid, olen.p, m, head_pos.p, nheads, slots.p, vv.p, lg);
     BG_LAUNCH_CHECK();
   }
-  CoverIndex ci{slots.p, vals.p, vlen.p, lg, skeys, soid, m, cover_k};
+  CoverIndex ci{slots.p, vv.p, lg, skeys, soid, m, cover_k};
 
   // ---- emission
   DevBuf<uint32_t> cnt;
