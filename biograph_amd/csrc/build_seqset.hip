@@ -849,7 +849,9 @@ __global__ __launch_bounds__(256) void k_prev_bits_pre2(const uint64_t* __restri
                                                         const uint32_t* __restrict__ dir, int bases,
                                                         uint8_t* __restrict__ marks, uint32_t* __restrict__ err,
                                                         int verify) {
-  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  // XCD-aware: workgroups b, b + 8, ... share an L2, so each XCD takes one contiguous eighth of the entries —
+  // neighbouring entries search neighbouring targets
+  uint64_t i = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t* s = ekeys + i * W;
   const int b = int(s[0] >> 62);
