@@ -267,7 +267,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_part_hist_kernel(const SkRec* _
   __syncthreads();
   uint64_t lo, hi, hbase;
   uint32_t nt, ti;
-  sk_locate(sg, blockIdx.x, &lo, &hi, &hbase, &nt, &ti);
+  sk_locate(sg, uint32_t(xcd_chunk(blockIdx.x, gridDim.x)), &lo, &hi, &hbase, &nt, &ti);  // XCD-contiguous tiles
 #pragma unroll
   for (int it = 0; it < SK2_ITEMS; ++it) {
     const uint64_t idx = lo + uint64_t(it) * SK_THREADS + threadIdx.x;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_part_scatter_kernel(const SkRec
   h[tid] = 0;
   uint64_t lo, hi, hbase;
   uint32_t nt, ti;
-  sk_locate(sg, blockIdx.x, &lo, &hi, &hbase, &nt, &ti);
+  sk_locate(sg, uint32_t(xcd_chunk(blockIdx.x, gridDim.x)), &lo, &hi, &hbase, &nt, &ti);  // XCD-contiguous tiles
   __syncthreads();
   SkRec rec[SK2_ITEMS];
   uint64_t og[SK2_ITEMS];
