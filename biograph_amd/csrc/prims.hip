@@ -369,17 +369,18 @@ template <bool HASHED>
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift,
                                                              uint32_t dmask, uint32_t* __restrict__ hist,
                                                              uint32_t ntiles) {
+  const uint64_t tile_x = xcd_chunk(blockIdx.x, gridDim.x);  // XCD-contiguous tiles: adjacent runs of a bin meet in one L2
   __shared__ uint32_t h[RS_BINS];
   h[threadIdx.x] = 0;
   __syncthreads();
-  uint64_t base = uint64_t(blockIdx.x) * RS_TILE;
+  uint64_t base = tile_x * RS_TILE;
 #pragma unroll 4
   for (int it = 0; it < RS_ITEMS; ++it) {
     uint64_t idx = base + uint64_t(it) * RS_THREADS + threadIdx.x;
     if (idx < n) atomicAdd(&h[rs_digit<HASHED>(keys[idx], shift, dmask)], 1u);
   }
   __syncthreads();
-  hist[uint64_t(threadIdx.x) * ntiles + blockIdx.x] = h[threadIdx.x];
+  hist[uint64_t(threadIdx.x) * ntiles + tile_x] = h[threadIdx.x];
 }
 
 // Same histogram for keys with few distinct digit values (partition destinations, group ids): lanes
@@ -388,12 +389,13 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t* __r
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_agg_kernel(const uint64_t* __restrict__ keys, uint64_t n,
                                                                  int shift, uint32_t dmask,
                                                                  uint32_t* __restrict__ hist, uint32_t ntiles) {
+  const uint64_t tile_x = xcd_chunk(blockIdx.x, gridDim.x);  // XCD-contiguous tiles: adjacent runs of a bin meet in one L2
   __shared__ uint32_t h[RS_BINS];
   h[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const uint64_t lane_lt = (1ull << lane) - 1;
-  uint64_t base = uint64_t(blockIdx.x) * RS_TILE;
+  uint64_t base = tile_x * RS_TILE;
   for (int it = 0; it < RS_ITEMS; ++it) {
     uint64_t idx = base + uint64_t(it) * RS_THREADS + threadIdx.x;
     bool valid = idx < n;
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_agg_kernel(const uint64_t*
     if (valid && (m & lane_lt) == 0) atomicAdd(&h[d], uint32_t(__popcll(m)));
   }
   __syncthreads();
-  hist[uint64_t(threadIdx.x) * ntiles + blockIdx.x] = h[threadIdx.x];
+  hist[uint64_t(threadIdx.x) * ntiles + tile_x] = h[threadIdx.x];
 }
 
 
@@ -413,6 +415,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t* 
                                                                 uint32_t* __restrict__ vout, uint64_t n, int shift,
                                                                 uint32_t dmask, const OffT* __restrict__ offs,
                                                                 uint32_t ntiles) {
+  const uint64_t tile_x = xcd_chunk(blockIdx.x, gridDim.x);  // XCD-contiguous tiles: adjacent runs of a bin meet in one L2
   __shared__ uint64_t skeys[RS_TILE];
   __shared__ uint32_t svals[HAS_VAL ? RS_TILE : 1];
   __shared__ uint32_t whist[4][RS_BINS];
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t* 
   __shared__ uint32_t scan_sm[4];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const uint64_t base = uint64_t(blockIdx.x) * RS_TILE;
+  const uint64_t base = tile_x * RS_TILE;
   const uint64_t lane_lt = (1ull << lane) - 1;
 
   for (int i = tid; i < 4 * RS_BINS; i += RS_THREADS) (&whist[0][0])[i] = 0;
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t* 
     uint32_t dummy;
     uint32_t ex = block_excl_scan_256<uint32_t>(tot, scan_sm, &dummy);
     binstart[tid] = ex;
-    goff[tid] = offs[uint64_t(tid) * ntiles + blockIdx.x] - OffT(ex);
+    goff[tid] = offs[uint64_t(tid) * ntiles + tile_x] - OffT(ex);
   }
   __syncthreads();
 
