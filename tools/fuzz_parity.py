@@ -1,0 +1,62 @@
+"""Randomised differential test of the whole create path: random genomes (alphabet, repeats, duplications), read
+lengths, error / N rates, k, min_count and correction parameters -> bg_create on the GPU vs the oracle on the CPU,
+every container part compared.  Runs until the time budget is used.  Usage: python tools/fuzz_parity.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import biograph_amd as bg
+from oracle import oracle as O
+from tests import util
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    ctx = bg.Context(0)
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < budget:
+        seed = seed0 * 100000 + n
+        rng = np.random.default_rng(seed)
+        k = int(rng.choice([14, 15, 18, 22, 25, 30, 31, 12, 9]))
+        rl = int(rng.choice([40, 70, 100, 150, 200, 255]))
+        if rl < k + 5:
+            rl = k + 20
+        alphabet = str(rng.choice(["ACGT", "ACGT", "ACGT", "AC", "ACG", "AT"]))
+        glen = int(rng.integers(300, 4000))
+        cov = int(rng.integers(5, 40))
+        n_reads = max(20, glen * cov // rl)
+        repeat = (int(rng.integers(3, 40)), int(rng.integers(5, 60))) if rng.random() < 0.5 else None
+        reads = util.synth_reads(seed, genome_len=glen, n_reads=n_reads, read_len=rl, err=float(rng.choice([0.0, 0.005, 0.02])),
+                                 n_rate=float(rng.choice([0.0, 0.002, 0.02])), alphabet=alphabet, var_len=bool(rng.random() < 0.6),
+                                 repeat=repeat)
+        if rng.random() < 0.3:  # PCR pile-up
+            reads += [reads[int(rng.integers(0, len(reads)))]] * int(rng.integers(10, 300))
+        if rng.random() < 0.2:
+            reads += ["N" * rl, "A" * rl, "ACGT"[: min(4, rl)], ""]
+        mc = int(rng.choice([1, 2, 3, 5]))
+        maxc = int(rng.choice([0, 2, 8]))
+        mgr = int(rng.choice([0, 2, 3]))
+        trim = float(rng.choice([0.0, 0.5, 0.7, 0.9]))
+        prm = dict(kmer_size=k, min_kmer_count=mc, max_corrections=maxc, min_good_run=mgr, trim_after_portion=trim)
+        ss, st = ctx.create(reads, **prm)
+        oss, oent, info = O.build_seqset_from_fastq_reads(reads, k, mc, maxc, mgr, trim)
+        ok = ss.size() == len(oent)
+        if ok:
+            got, want = ss.parts(), oss.parts()
+            ok = all(got[name] == want[name] for name in bg.PART_NAMES)
+        ok = ok and st["n_kept_kmers"] == info["kept_kmers"] and st["n_corrected_reads"] == info["corrected_reads"]
+        if not ok:
+            print("MISMATCH seed", seed, prm, "rl", rl, alphabet, glen, cov, repeat, "entries", ss.size(), len(oent), flush=True)
+            return 1
+        ss.free()
+        n += 1
+    print("fuzz: %d random builds equal to the oracle in %.0f s (seed %d)" % (n, time.time() - t0, seed0))
+    return 0
+
+
+sys.exit(main())
