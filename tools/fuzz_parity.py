@@ -1,6 +1,7 @@
 """Randomised differential test of the whole create path: random genomes (alphabet, repeats, duplications), read
 lengths, error / N rates, k, min_count and correction parameters -> bg_create on the GPU vs the oracle on the CPU,
-every container part compared.  Runs until the time budget is used.  Usage: python tools/fuzz_parity.py [seconds] [seed]"""
+every container part compared.  Runs until the time budget is used (FUZZ_SCALE=50 multiplies the genome sizes:
+fewer, multi-tile / multi-bucket cases).  Usage: python tools/fuzz_parity.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -27,7 +28,7 @@ def main():
         if rl < k + 5:
             rl = k + 20
         alphabet = str(rng.choice(["ACGT", "ACGT", "ACGT", "AC", "ACG", "AT"]))
-        glen = int(rng.integers(300, 4000))
+        glen = int(rng.integers(300, 4000)) * int(os.environ.get("FUZZ_SCALE", "1"))
         cov = int(rng.integers(5, 40))
         n_reads = max(20, glen * cov // rl)
         repeat = (int(rng.integers(3, 40)), int(rng.integers(5, 60))) if rng.random() < 0.5 else None
