@@ -5,6 +5,7 @@ the shared library is missing, or no HIP device is usable, calls raise.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -89,6 +90,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("biograph_amd: %s is missing — build it with `python -m biograph_amd.build` "
                           "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    # When torch is part of the process (bench, sharded driver, tests) its bundled HIP runtime must be the one
+    # that gets loaded: with libbgseq's /opt/rocm runtime in first, torch.cuda finds "no HIP GPUs".
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     P = C.POINTER

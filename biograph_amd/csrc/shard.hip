@@ -337,7 +337,12 @@ extern "C" int bg_reads_words(const bg_reads* r) { return r ? r->W : 0; }
 
 extern "C" int bg_reads_export(bg_ctx* ctx, const bg_reads* r, int W_out, uint64_t* d_words, uint16_t* d_len) {
   if (!ctx || !r || (r->n && (!d_words || !d_len))) { set_error("bg_reads_export: null argument"); return BG_EINVAL; }
-  if (W_out < r->W || W_out > kMaxWords) { set_error("bg_reads_export: W_out %d < W %d", W_out, r->W); return BG_EINVAL; }
+  // narrower than the stored stride is fine as long as every read fits (corrected reads keep their input's
+  // stride, and truncation can leave the last word of all of them empty)
+  if (W_out < 1 || W_out > kMaxWords || uint32_t(W_out) * 32 < r->max_len) {
+    set_error("bg_reads_export: %d words do not hold reads of up to %u bases", W_out, r->max_len);
+    return BG_EINVAL;
+  }
   BG_HIP(hipSetDevice(ctx->device));
   if (r->n) {
     k_restride_words<<<cdiv(r->n * W_out, 256), 256, 0, ctx->stream>>>(r->words.p, r->n, r->W, W_out, d_words);

@@ -101,3 +101,26 @@ def test_sharded_kmer_exchange_modes(ctx, monkeypatch, env):
     for key in ("n_kept_kmers", "n_distinct_kmers", "n_kmers", "n_corrected_reads", "n_corrected_bases", "n_entries"):
         assert st[key] == rst[key], key
     assert ss.parts() == ref.parts()
+
+
+def test_sharded_truncation_narrows_the_word_stride(ctx):
+    """Every read ends in NNNN: the corrected reads are 96 bases (3 words) in objects that keep the input's 4-word
+    stride — the corrected-read exchange must narrow them (found by tools/fuzz_parity.py)."""
+    rng = np.random.default_rng(4)
+    g = "".join(rng.choice(list("ACGT"), size=3000))
+    comp = str.maketrans("ACGT", "TGCA")
+    reads = []
+    for _ in range(1200):
+        s = int(rng.integers(0, len(g) - 96))
+        r = g[s:s + 96]
+        if rng.random() < 0.5:
+            r = r[::-1].translate(comp)
+        reads.append(r + "NNNN")
+    prm = ctx.default_params(kmer_size=20, min_kmer_count=2)
+    P = 3
+    out = sharded.sharded_create(sharded.LocalSimComm(P), {r: ctx for r in range(P)},
+                                 _shard_inputs(reads, P, np.random.default_rng(3)), prm)
+    ss, st = out[0]
+    ref, rst = ctx.create(reads, kmer_size=20, min_kmer_count=2)
+    assert rst["max_len"] == 96 and st["n_entries"] == rst["n_entries"] == ss.size()
+    assert ss.parts() == ref.parts()

@@ -45,6 +45,24 @@ def main():
         trim = float(rng.choice([0.0, 0.5, 0.7, 0.9]))
         prm = dict(kmer_size=k, min_kmer_count=mc, max_corrections=maxc, min_good_run=mgr, trim_after_portion=trim)
         ss, st = ctx.create(reads, **prm)
+        if os.environ.get("FUZZ_SHARDED"):  # the multi-rank build (ranks simulated in this process) vs the single-GPU one
+            import torch
+            from biograph_amd import sharded
+            P = int(rng.integers(1, 7))
+            cuts = sorted(int(x) for x in rng.integers(0, len(reads) + 1, P - 1))
+            bounds = [0] + cuts + [len(reads)]
+            inputs = {}
+            for r in range(P):
+                sq, of = O.pack_strings(reads[bounds[r]:bounds[r + 1]])
+                dsq = torch.from_numpy(sq.copy()).cuda() if len(sq) else torch.zeros(0, dtype=torch.uint8, device="cuda")
+                inputs[r] = (dsq, torch.from_numpy(of.astype(np.int64)).cuda(), bounds[r + 1] - bounds[r])
+            p2 = ctx.default_params(**prm)
+            out = sharded.sharded_create(sharded.LocalSimComm(P), {r: ctx for r in range(P)}, inputs, p2)
+            s2 = out[0][0]
+            if s2.size() != ss.size() or s2.parts() != ss.parts():
+                print("SHARDED MISMATCH seed", seed, prm, "P", P, flush=True)
+                return 1
+            s2.free()
         oss, oent, info = O.build_seqset_from_fastq_reads(reads, k, mc, maxc, mgr, trim)
         ok = ss.size() == len(oent)
         if ok:
