@@ -63,6 +63,36 @@ def main():
                 print("SHARDED MISMATCH seed", seed, prm, "P", P, flush=True)
                 return 1
             s2.free()
+        if os.environ.get("FUZZ_READMAP"):  # staged path + readmap (paired or not) + merge of two halves
+            r = ctx.pack_reads(reads)
+            ks = ctx.kmer_count(r, k, mc)
+            c, _ = ctx.correct_reads(r, ks, maxc, mgr, trim)
+            cseq, coffs = c.download()
+            corrected = O.unpack_strings(cseq, coffs)
+            s3, _ = ctx.build_seqset(c, k)
+            paired = bool(rng.random() < 0.5) and len(reads) % 2 == 0
+            rm = ctx.build_readmap(s3, c, paired)
+            kept = [x for x in corrected if x]
+            sq, of = O.pack_strings(kept)
+            ent = O.Entries.build(sq, of, "simple", k)
+            oss3 = O.Seqset.from_entries(ent)
+            if paired:
+                records = [tuple(x for x in corrected[i:i + 2] if x) for i in range(0, len(corrected), 2)]
+                records = [t for t in records if t]
+            else:
+                records = [(x,) for x in kept]
+            orm = O.Readmap(oss3, ent, records, paired)
+            if rm.size() != len(orm) or any(rm.parts()[nm] != orm.parts()[nm] for nm in bg.READMAP_PART_NAMES):
+                print("READMAP MISMATCH seed", seed, prm, "paired", paired, flush=True)
+                return 1
+            half = len(kept) // 2
+            if half >= 2:
+                sa, _ = ctx.build_seqset(ctx.pack_reads(kept[:half]), k)
+                sb, _ = ctx.build_seqset(ctx.pack_reads(kept[half:]), k)
+                merged, maps = ctx.merge_seqsets([sa, sb])
+                if merged.size() != s3.size() or merged.parts() != s3.parts():
+                    print("MERGE MISMATCH seed", seed, prm, flush=True)
+                    return 1
         oss, oent, info = O.build_seqset_from_fastq_reads(reads, k, mc, maxc, mgr, trim)
         ok = ss.size() == len(oent)
         if ok:
