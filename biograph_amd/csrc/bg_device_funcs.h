@@ -645,6 +645,10 @@ struct SeqsetView {
     *ob = 0; *oe = 0; *os = 0;
     if (octx < min_ctx) return;
     while (sb == se || (sb + 1 == se && sizes[fx + sb] < octx + 1)) {
+      // No entry starts with base b at all (a seqset of a two-letter genome, a toy input): with min_ctx == 0 the
+      // reference's loop reaches the whole range and spins there for ever (seqset.cpp:368-421 has no exit for
+      // it); the extension simply does not exist.  Found by tools/fuzz_parity.py (FUZZ_WALK).
+      if (o_begin == 0 && o_end == n && sb == se) return;
       uint32_t d0 = shared[o_begin];
       uint32_t d1 = o_end == n ? 0u : uint32_t(shared[o_end]);
       uint32_t drop = d0 > d1 ? d0 : d1;

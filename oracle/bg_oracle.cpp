@@ -480,6 +480,9 @@ struct Seqset {
     uint64_t sb = count(b, ob), se = count(b, oe);
     if (octx < min_ctx) return Range{0, 0, 0};
     while (sb == se || (sb + 1 == se && sizes[fx + sb] < octx + 1)) {
+      // DEVIATION from the reference: when no entry starts with base b and min_ctx == 0, its loop reaches the whole
+      // range and never leaves it (seqset.cpp:368-421).  The extension does not exist: invalid range.
+      if (ob == 0 && oe == n && sb == se) return Range{0, 0, 0};
       uint32_t drop = std::max(shared[ob], (oe == n ? 0u : shared[oe]));
       if (sb != se) drop = std::max(drop, sizes[fx + sb] - 1);
       if (drop < min_ctx) return Range{0, 0, 0};

@@ -94,6 +94,39 @@ def main():
                     print("MERGE MISMATCH seed", seed, prm, flush=True)
                     return 1
         oss, oent, info = O.build_seqset_from_fastq_reads(reads, k, mc, maxc, mgr, trim)
+        if os.environ.get("FUZZ_WALK") and ss.size() == len(oent) and ss.size() > 4:
+            # chained push_front / push_front_drop and find on the seqset just built vs the oracle's walk
+            nn = ss.size()
+            q = min(4000, 20 * nn)
+            begin = rng.integers(0, nn, q).astype(np.uint64)  # whole entries: valid (range, context) triples
+            end = begin + 1
+            sizes_all, _ = ss.arrays()
+            size = sizes_all[begin.astype(np.int64)].astype(np.uint32)
+            for _round in range(5):
+                if not len(begin):
+                    break
+                base = rng.integers(0, 4, len(begin)).astype(np.uint8)
+                minctx = rng.integers(0, rl, len(begin)).astype(np.uint32)
+                ob, oe, osz = oss.push_front_drop(begin, end, size, base, minctx)
+                gb, ge, gs = ss.push_front_drop_batch(begin, end, size, base, minctx)
+                pb, pe, ps = oss.push_front(begin, end, size, base)
+                hb, he, hs = ss.push_front_batch(begin, end, size, base)
+                if not ((gb == ob).all() and (ge == oe).all() and (gs == osz).all() and (hb == pb).all() and
+                        (he == pe).all() and (hs == ps).all()):
+                    print("WALK MISMATCH seed", seed, prm, flush=True)
+                    return 1
+                okm = oe > ob
+                begin, end, size = ob[okm], oe[okm], osz[okm]
+            strs = oent.strings()
+            qs = [strs[int(i)][int(j):int(j) + int(l)] for i, j, l in zip(rng.integers(0, nn, 60), rng.integers(0, 30, 60),
+                                                                       rng.integers(1, 50, 60))]
+            qs = [x for x in qs if x] + ["ACGT", "T"]
+            fb, fe = ss.find_batch(qs)
+            for sq_, b_, e_ in zip(qs, fb, fe):
+                wb, we, _ = oss.find(sq_)
+                if not ((int(b_), int(e_)) == (wb, we) or (b_ >= e_ and wb >= we)):
+                    print("FIND MISMATCH seed", seed, prm, sq_, flush=True)
+                    return 1
         ok = ss.size() == len(oent)
         if ok:
             got, want = ss.parts(), oss.parts()
