@@ -668,7 +668,12 @@ static void branch_trace(const Seqset& ss, const uint8_t* seq, size_t n, RangeSe
       if (extend) { events->emplace_back(uint32_t(off), uint8_t(b)); break; }
     }
     RangeSet nc;
-    for (const Range& r : cur) nc.insert(ss.push_front_drop(r, rc_ref_b, 0));
+    // (an invalid result can only come from the deviation in push_front_drop — a base no entry starts with — where
+    // the reference never returns; such a range leaves the frontier)
+    for (const Range& r : cur) {
+      const Range x = ss.push_front_drop(r, rc_ref_b, 0);
+      if (x.valid()) nc.insert(x);
+    }
     cur = std::move(nc);
     dedup_prefixes(cur);
   }
@@ -957,7 +962,10 @@ static void propagate_from_end(const Seqset& ss, const Readmap* rm, RangeSet new
   while (offset) {
     --offset;
     RangeSet nc;
-    for (const Range& r : cur) nc.insert(ss.push_front_drop(r, seq[offset], 0));
+    for (const Range& r : cur) {
+      const Range x = ss.push_front_drop(r, seq[offset], 0);
+      if (x.valid()) nc.insert(x);  // see branch_trace
+    }
     dedup_prefixes(nc);
     cur = std::move(nc);
     if (offset == 0 || marks.count(uint32_t(offset))) out->entries[uint32_t(offset)] = cur;

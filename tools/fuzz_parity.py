@@ -19,7 +19,7 @@ def main():
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     ctx = bg.Context(0)
     t0 = time.time()
-    n = 0
+    n = int(os.environ.get("FUZZ_FIRST", "0"))
     while time.time() - t0 < budget:
         seed = seed0 * 100000 + n
         rng = np.random.default_rng(seed)
@@ -127,6 +127,48 @@ def main():
                 if not ((int(b_), int(e_)) == (wb, we) or (b_ >= e_ and wb >= we)):
                     print("FIND MISMATCH seed", seed, prm, sq_, flush=True)
                     return 1
+        if os.environ.get("FUZZ_DISCOVER") and ss.size() == len(oent) and ss.size() > 4:
+            # frontier kernels (G2 one step, G3 branch trace) vs the oracle, from frontiers reached by walking reads
+            code = {c: i for i, c in enumerate("ACGT")}
+            nn = ss.size()
+            clean = [x for x in reads if len(x) >= 24 and "N" not in x]
+            if clean:
+                fr = []
+                seqs, fronts = [], []
+                for _ in range(24):
+                    rd = clean[int(rng.integers(0, len(clean)))]
+                    arr = np.array([code[c] for c in rd], np.uint8)
+                    cut = int(rng.integers(8, len(arr) - 4))
+                    cur = (0, nn, 0)
+                    for c in arr[:cut]:  # rc context: push the complement of the forward bases
+                        b_, e_, s_ = oss.push_front_drop(np.array([cur[0]], np.uint64), np.array([cur[1]], np.uint64),
+                                                         np.array([cur[2]], np.uint32), np.array([3 - c], np.uint8),
+                                                         np.array([0], np.uint32))
+                        cur = (int(b_[0]), int(e_[0]), int(s_[0]))
+                        if cur[1] <= cur[0]:
+                            break
+                    if cur[1] > cur[0]:
+                        fr.append([cur])
+                        seqs.append(arr[cut:].copy())
+                        fronts.append([cur])
+                fr += [[(0, nn, 0)], []]
+                min_ctx = [int(x) for x in rng.integers(0, 40, len(fr))]
+                got = ss.trace_one_base_batch(fr, min_ctx)
+                for f_, mc_, g_ in zip(fr, min_ctx, got):
+                    best, cands, n2 = oss.trace_one_base(f_, mc_)
+                    if not (g_[0] == best and g_[1] == cands and g_[2] == n2):
+                        print("TRACE MISMATCH seed", seed, prm, flush=True)
+                        return 1
+                if seqs:
+                    mo = int(rng.integers(5, 40))
+                    gotb = ss.branch_trace_batch(seqs, fronts, mo, ev_cap=512)
+                    for s_, f_, g_ in zip(seqs, fronts, gotb):
+                        nb_, ev_, cur_ = oss.branch_trace(s_, f_, mo)
+                        if not (g_[0] == nb_ and g_[1] == ev_ and g_[2] == cur_):
+                            print("BRANCH MISMATCH seed", seed, prm, "mo", mo, "front", f_, "len", len(s_), flush=True)
+                            print(" gpu   ", g_[0], g_[1][:6], g_[2][:4], flush=True)
+                            print(" oracle", nb_, ev_[:6], cur_[:4], flush=True)
+                            return 1
         ok = ss.size() == len(oent)
         if ok:
             got, want = ss.parts(), oss.parts()
