@@ -85,6 +85,27 @@ def main():
             if rm.size() != len(orm) or any(rm.parts()[nm] != orm.parts()[nm] for nm in bg.READMAP_PART_NAMES):
                 print("READMAP MISMATCH seed", seed, prm, "paired", paired, flush=True)
                 return 1
+            clean = [x for x in kept if len(x) >= 12 and "N" not in x]
+            if clean and paired and s3.size() > 4:  # G4: rc range paths + mates of propagate_from_end
+                code = {c: i for i, c in enumerate("ACGT")}
+                n3 = s3.size()
+                seqs, ends, marks = [], [], []
+                for _ in range(12):
+                    rd = clean[int(rng.integers(0, len(clean)))]
+                    ln = int(rng.integers(1, len(rd)))
+                    sq_ = np.array([3 - code[c] for c in reversed(rd[:ln])], np.uint8)
+                    seqs.append(sq_)
+                    ends.append([(0, n3, 0)])
+                    marks.append(sorted(set(int(x) for x in rng.integers(1, max(len(sq_), 2), 3) if 0 < x < len(sq_))))
+                gotp = s3.propagate_from_end_batch(seqs, ends, rm, 20, marks, mate_cap=8192)
+                for kk in range(len(seqs)):
+                    want_ent, want_mates = oss3.propagate_from_end(seqs[kk], ends[kk], orm, 20, marks[kk])
+                    want_ent.pop(len(seqs[kk]), None) if len(seqs[kk]) else None
+                    ent_, mates_ = gotp[kk]
+                    if ent_ != {o_: v_ for o_, v_ in want_ent.items() if o_ != len(seqs[kk]) or o_ == 0} or \
+                            mates_ != sorted(want_mates, key=lambda r_: (r_[0], -r_[1], r_[2])):
+                        print("PROPAGATE MISMATCH seed", seed, prm, "case", kk, flush=True)
+                        return 1
             half = len(kept) // 2
             if half >= 2:
                 sa, _ = ctx.build_seqset(ctx.pack_reads(kept[:half]), k)
