@@ -212,7 +212,7 @@ def lib():
     L.bg_reads_export.argtypes = [vp, vp, i32, vp, vp]
     L.bg_reads_import.argtypes = [vp, u64, i32, u32, vp, vp, P(vp)]
     L.bg_suffix_records.argtypes = [vp, vp, u64, u64, i32, P(vp)]
-    L.bg_records_prefix_hist.argtypes = [vp, vp, i32, vp]
+    L.bg_records_prefix_hist.argtypes = [vp, vp, i32, u64, vp]
     L.bg_records_count.restype = u64
     L.bg_records_count.argtypes = [vp]
     L.bg_records_words.argtypes = [vp]

@@ -27,6 +27,9 @@ from . import capi
 from .capi import BuildStats
 
 PREFIX_BASES = 8  # splitter resolution: 4^8 bins of leading bases
+# the splitter histogram counts every PREFIX_SAMPLE-th record of every rank (balance needs no more; the same step
+# on all ranks, so that the all-reduced bins weigh every rank alike)
+PREFIX_SAMPLE = max(1, int(os.environ.get("BG_PREFIX_SAMPLE", "8")))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -369,15 +372,17 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
         n_rec = L.bg_records_count(rh)
         rows = torch.empty((n_rec, W + 1), dtype=i64, device=dev[r])
         capi.check(L.bg_records_rows(ctxs[r].h, rh, _ptr(rows)))
-        hists[r] = torch.empty((4 ** PREFIX_BASES,), dtype=i64, device=dev[r])
-        capi.check(L.bg_records_prefix_hist(ctxs[r].h, rh, PREFIX_BASES, _ptr(hists[r])))
+        hists[r] = torch.empty((4 ** PREFIX_BASES + 1,), dtype=i64, device=dev[r])
+        capi.check(L.bg_records_prefix_hist(ctxs[r].h, rh, PREFIX_BASES, PREFIX_SAMPLE, _ptr(hists[r])))
+        hists[r][-1] = n_rec  # the record total rides along with the bins
         L.bg_records_free(rh)
         send[r] = rows
     del gw, gl
     ph.mark("records_partition")
     ghist = comm.all_reduce_sum(hists)
-    splitters = choose_splitters(ghist[ranks[0]].cpu().numpy(), P)
-    n_records = int(ghist[ranks[0]].sum().item())
+    gh = ghist[ranks[0]].cpu().numpy()
+    splitters = choose_splitters(gh[:-1], P)
+    n_records = int(gh[-1])
     for r in ranks:
         send[r] = _partition(ctxs[r], send[r], capi.PART_PREFIX, P, [PREFIX_BASES] + splitters)
     ph.mark("records_all_to_all")

@@ -432,9 +432,10 @@ int bg_suffix_records(bg_ctx* ctx, const bg_reads* reads, uint64_t read_lo, uint
 uint64_t bg_records_count(const bg_records* r);
 int bg_records_words(const bg_records* r);
 int bg_records_rows(bg_ctx* ctx, const bg_records* r, uint64_t* d_rows /* n*(W+1): words, len */);
-/* d_hist[4^bases] (u64, device): how many records start with each `bases`-base prefix — what the ranks
- * all-reduce to choose balanced splitters for the records exchange (part_counts.h:8-45). */
-int bg_records_prefix_hist(bg_ctx* ctx, const bg_records* r, int bases, uint64_t* d_hist);
+/* d_hist[4^bases] (u64, device): how many of the records 0, every, 2*every, ... start with each `bases`-base
+ * prefix (every = 1: all of them) — what the ranks all-reduce to choose balanced splitters for the records
+ * exchange (part_counts.h:8-45); a sample is enough to balance and costs 1/every of the global atomics. */
+int bg_records_prefix_hist(bg_ctx* ctx, const bg_records* r, int bases, uint64_t every, uint64_t* d_hist);
 int bg_records_from_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int W, bg_records** out);
 void bg_records_free(bg_records* r);
 /* sort + prefix-dedup of one shard's records -> entries (keys/sizes/shared, no prev bits); consumes r */

@@ -103,6 +103,23 @@ def test_sharded_kmer_exchange_modes(ctx, monkeypatch, env):
     assert ss.parts() == ref.parts()
 
 
+@pytest.mark.parametrize("every", [1, 3, 1000000])
+def test_sharded_splitter_sample_step(ctx, monkeypatch, every):
+    """The records exchange chooses its splitters from a sampled prefix histogram; any sampling step (all records,
+    every third, a single record per rank: hence empty shards) gives the same seqset and the same record total."""
+    monkeypatch.setattr(sharded, "PREFIX_SAMPLE", every)
+    P = 4
+    seq, offs, n = synth.make_reads(genome_len=7000, coverage=25, read_len=110, seed=13, device="cpu")
+    reads = O.unpack_strings(seq.numpy(), offs.numpy().astype(np.uint64))
+    prm = ctx.default_params(kmer_size=20, min_kmer_count=3)
+    out = sharded.sharded_create(sharded.LocalSimComm(P), {r: ctx for r in range(P)},
+                                 _shard_inputs(reads, P, np.random.default_rng(3)), prm)
+    ss, st = out[0]
+    ref, rst = ctx.create(reads, kmer_size=20, min_kmer_count=3)
+    assert st["n_records"] == rst["n_records"] and st["n_entries"] == rst["n_entries"]
+    assert ss.parts() == ref.parts()
+
+
 def test_sharded_truncation_narrows_the_word_stride(ctx):
     """Every read ends in NNNN: the corrected reads are 96 bases (3 words) in objects that keep the input's 4-word
     stride — the corrected-read exchange must narrow them (found by tools/fuzz_parity.py)."""
