@@ -85,6 +85,8 @@ class TorchDistComm:
         self.local_ranks = [self.rank]
         self.out_device = device
         self.device = torch.device("cpu") if stage_through_host else device
+        if os.environ.get("BG_COMM_MAX_PIECE"):  # tests: force the multi-round exchange
+            self.MAX_PIECE_BYTES = int(os.environ["BG_COMM_MAX_PIECE"])
 
     def _in(self, t):
         return t.to(self.device) if t.device != self.device else t
@@ -116,19 +118,36 @@ class TorchDistComm:
         starts = [0]
         for c in counts:
             starts.append(starts[-1] + c)
-        outs = []
+        if rounds == 1:
+            out = torch.empty((sum(out_counts),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=self.device)
+            dist.all_to_all_single(out, rows, output_split_sizes=out_counts, input_split_sizes=counts)
+            return {self.rank: self._out(out)}
+        # Several rounds.  The result keeps the single-round layout (all rows of source 0, then source 1, ...,
+        # each in the order they were sent): the presence bits of the k-mer exchange travel back by position.
+        ostarts = [0]
+        for c in out_counts:
+            ostarts.append(ostarts[-1] + c)
+        out = torch.empty((ostarts[-1],) + tuple(rows.shape[1:]), dtype=rows.dtype, device=self.device)
         for t in range(rounds):
-            in_split = [max(0, min(c - t * max_rows, max_rows)) for c in counts]
-            out_split = [max(0, min(c - t * max_rows, max_rows)) for c in out_counts]
-            if rounds == 1:
-                chunk = rows
-            else:
-                chunk = torch.cat([rows[starts[d] + t * max_rows: starts[d] + t * max_rows + in_split[d]]
-                                   for d in range(self.world)], dim=0)
-            out = torch.empty((sum(out_split),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=self.device)
-            dist.all_to_all_single(out, chunk, output_split_sizes=out_split, input_split_sizes=in_split)
-            outs.append(out)
-        return {self.rank: self._out(outs[0] if rounds == 1 else torch.cat(outs, dim=0))}
+            lo = t * max_rows
+            ins = [rows[starts[d] + min(lo, counts[d]): starts[d] + min(lo + max_rows, counts[d])]
+                   for d in range(self.world)]
+            rcv = [out[ostarts[d] + min(lo, out_counts[d]): ostarts[d] + min(lo + max_rows, out_counts[d])]
+                   for d in range(self.world)]
+            if dist.get_backend() == "nccl":
+                # RCCL: grouped send/recv on views - every piece leaves from where it lies and lands where it
+                # belongs, no staging copies of a multi-GB exchange
+                dist.all_to_all(rcv, ins)
+            else:  # gloo has only the single-buffer form
+                tmp = torch.empty((sum(x.shape[0] for x in rcv),) + tuple(rows.shape[1:]), dtype=rows.dtype,
+                                  device=self.device)
+                dist.all_to_all_single(tmp, torch.cat(ins, dim=0), output_split_sizes=[x.shape[0] for x in rcv],
+                                       input_split_sizes=[x.shape[0] for x in ins])
+                off = 0
+                for x in rcv:
+                    x.copy_(tmp[off: off + x.shape[0]])
+                    off += x.shape[0]
+        return {self.rank: self._out(out)}
 
     def all_gather_v(self, send):
         dist = self.dist

@@ -1,5 +1,6 @@
 """Worker of tests/test_gpu_sharded_mp.py: one rank of a real multi-process sharded build.  All ranks
-share cuda:0; collectives run over gloo on host copies (TorchDistComm(stage_through_host=True))."""
+share cuda:0; collectives run over gloo on host copies (TorchDistComm(stage_through_host=True)), or, with
+"rccl" as the second argument, over RCCL itself (one rank per GPU)."""
 import json
 import os
 import sys
@@ -16,14 +17,18 @@ from biograph_amd import sharded, synth  # noqa: E402
 
 def main():
     out_path = sys.argv[1]
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    rccl = len(sys.argv) > 2 and sys.argv[2] == "rccl"  # the real backend (one rank per GPU: world 1 on a 1-GPU box)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
+    if rccl:
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
     seq, offs, n = synth.make_reads(genome_len=40000, coverage=30, read_len=150, seed=9, device=dev,
                                     shard=(rank, world))
     ctx = bg.Context(0, torch.cuda.current_stream(dev).cuda_stream)
-    comm = sharded.TorchDistComm(dev, stage_through_host=True)
+    comm = sharded.TorchDistComm(dev, stage_through_host=not rccl)
     out = sharded.sharded_create(comm, {rank: ctx}, {rank: (seq, offs, n)})
     ss, st = out[rank]
     # every rank also ships its reads to rank 0 so the single-GPU build of the same sample can be compared

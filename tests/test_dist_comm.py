@@ -25,10 +25,11 @@ WORKER = textwrap.dedent("""
         off = sum(c[:r])
         exp.append(full[off:off + c[r]])
     assert torch.equal(out, torch.cat(exp)), (r, out)
-    # multi-round exchange (pieces capped): same multiset of rows per destination
+    # multi-round exchange (pieces capped): the same rows in the same order (source-major, sent order) - the
+    # presence bits of the k-mer exchange are matched to their records by position
     comm.MAX_PIECE_BYTES = 24  # one 3-word row per piece and round
     out2 = comm.all_to_all_v({r: (rows, counts)})[r]
-    assert sorted(map(tuple, out2.tolist())) == sorted(map(tuple, torch.cat(exp).tolist()))
+    assert torch.equal(out2, torch.cat(exp)), (r, out2)
     comm.MAX_PIECE_BYTES = (1 << 30) - 4096
     g = comm.all_gather_v({r: torch.full((r + 2, 2), r, dtype=torch.uint8)})[r]
     assert [t.shape[0] for t in g] == [2, 3] and all(int(t[0, 0]) == i for i, t in enumerate(g))

@@ -12,10 +12,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_multiprocess_sharded_build_matches_single_gpu(tmp_path, world):
+@pytest.mark.parametrize("world,max_piece", [(2, 0), (3, 0), (2, 4096), (3, 1000)])
+def test_multiprocess_sharded_build_matches_single_gpu(tmp_path, world, max_piece):
+    """max_piece > 0 caps every all_to_all piece at that many bytes: all exchanges run in several rounds (what a
+    chr20-sized rank does at 2 and 4 GPUs), and the presence bits must still find their records by position."""
     out = tmp_path / "result.json"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    if max_piece:
+        env["BG_COMM_MAX_PIECE"] = str(max_piece)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
                         "--master-addr", "127.0.0.1", "--master-port", str(29600 + world),
                         os.path.join(ROOT, "tests", "mp_sharded_worker.py"), str(out)],
@@ -24,3 +28,21 @@ def test_multiprocess_sharded_build_matches_single_gpu(tmp_path, world):
     res = json.load(open(out))
     assert res["same"], res
     assert res["n_entries"] == res["ref_entries"] and len(res["shards"]) == world
+
+
+@pytest.mark.parametrize("max_piece", [0, 2000])
+def test_rccl_backend_world1_sharded_build(tmp_path, max_piece):
+    """The sharded build over RCCL itself (world 1: the box has one GPU), single-round and multi-round
+    (grouped send/recv on views) exchanges: same seqset as the fused build."""
+    out = tmp_path / "result.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if max_piece:
+        env["BG_COMM_MAX_PIECE"] = str(max_piece)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29611",
+                        os.path.join(ROOT, "tests", "mp_sharded_worker.py"), str(out), "rccl"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.load(open(out))
+    assert res["same"], res
+    assert res["n_entries"] == res["ref_entries"] and len(res["shards"]) == 1
