@@ -1,11 +1,13 @@
 """Seeded synthetic WGS-shaped reads, generated with torch on any device.
 
-Genome: i.i.d. uniform ACGT with 0.5 % of its length copied as exact 2-5 kb duplications.  Sample:
-two haplotypes, the second carrying substitutions at 1/1000 bp (SNPs; indels/SVs of the full plan
-are not planted yet — DESIGN.md "synthetic input").  Reads: paired 2x`read_len`, insert
+Genome: i.i.d. uniform ACGT with 0.5 % of its length copied as exact 2-5 kb duplications.  Sample: a diploid
+copy of it with planted variants (seed + 1): SNPs 1/1000 bp, indels of 1-50 bp 1/10 000 bp, structural
+insertions / deletions of 50-1000 bp 1/1 000 000 bp, two thirds of the sites heterozygous (on one random
+haplotype), the rest on both.  Reads: paired 2x`read_len`, insert
 N(400,50) clipped to [200,800], FR orientation, `coverage`x, substitution error 0.2 %/base, N 0.01 %.
 Output = concatenated ASCII (uint8) + offsets (int64 holding the uint64 values), mates adjacent.
 """
+import numpy as np
 import torch
 
 SHAPES = {
@@ -32,8 +34,65 @@ def make_genome(n, seed, device):
     return genome
 
 
+def plant_variants(reference, seed, g, snp_rate=0.001, indel_rate=1e-4, sv_rate=1e-6, het_frac=2.0 / 3.0):
+    """The two haplotypes of the sample.  Sites are drawn on the host (numpy, seed + 1: the same on every rank),
+    the bases on `reference`'s device with generator `g`.  Indels and structural variants do not overlap and keep
+    2 kb clear of the ends; genomes under 8 kb get SNPs only."""
+    dev = reference.device
+    G = int(reference.numel())
+    rng = np.random.default_rng(seed + 1)
+    haps = []
+    # SNPs: site mask, substituted base, zygosity
+    snp = torch.rand(G, generator=g, device=dev) < snp_rate
+    shift = torch.randint(1, 4, (G,), generator=g, device=dev, dtype=torch.uint8)
+    zyg = torch.rand(G, generator=g, device=dev)  # < het_frac: heterozygous, on the haplotype `which` names
+    which = torch.rand(G, generator=g, device=dev) < 0.5
+    alt = (reference + shift) & 3
+    for h in (0, 1):
+        on = snp & ((zyg >= het_frac) | (which == bool(h)))
+        haps.append(torch.where(on, alt, reference))
+    del snp, shift, zyg, which, alt
+    if G < 8000 or (indel_rate <= 0 and sv_rate <= 0):
+        return haps[0], haps[1]
+    n_indel = int(rng.binomial(G, indel_rate)) if indel_rate > 0 else 0
+    n_sv = int(rng.binomial(G, sv_rate)) if sv_rate > 0 else 0
+    pos = rng.integers(2000, G - 3000, n_indel + n_sv)
+    length = np.concatenate([rng.integers(1, 51, n_indel), rng.integers(50, 1001, n_sv)])
+    is_ins = rng.random(n_indel + n_sv) < 0.5
+    het = rng.random(n_indel + n_sv) < het_frac
+    hap_of = rng.integers(0, 2, n_indel + n_sv)
+    order = np.argsort(pos, kind="stable")
+    sites, last_end = [], 0
+    for i in order:
+        p, ln = int(pos[i]), int(length[i])
+        if p < last_end + 10:
+            continue  # would touch the previous site
+        sites.append((p, ln, bool(is_ins[i]), bool(het[i]), int(hap_of[i])))
+        last_end = p + (0 if is_ins[i] else ln)
+    ins_total = sum(ln for _, ln, ins, _, _ in sites if ins)
+    ins_bases = torch.randint(0, 4, (max(ins_total, 1),), generator=g, device=dev, dtype=torch.uint8)
+    out = []
+    for h in (0, 1):
+        pieces, cur, used = [], 0, 0
+        for p, ln, ins, is_het, hp in sites:
+            mine = (not is_het) or hp == h
+            if ins:
+                if mine:
+                    pieces.append(haps[h][cur:p])
+                    pieces.append(ins_bases[used:used + ln])
+                    cur = p
+                used += ln  # both haplotypes of a homozygous insertion carry the same bases
+            elif mine:
+                pieces.append(haps[h][cur:p])
+                cur = p + ln
+        pieces.append(haps[h][cur:])
+        out.append(torch.cat(pieces))
+    return out[0], out[1]
+
+
 def make_reads(genome_len=SHAPES["tiny"], coverage=30, read_len=150, seed=20261002, device="cpu", err=0.002,
-               n_rate=0.0001, snp_rate=0.001, chunk_pairs=1 << 20, shard=(0, 1), return_genome=False, repeats=None):
+               n_rate=0.0001, snp_rate=0.001, chunk_pairs=1 << 20, shard=(0, 1), return_genome=False, repeats=None,
+               indel_rate=1e-4, sv_rate=1e-6, het_frac=2.0 / 3.0):
     """Returns (seq uint8 [n_reads*read_len], offs int64 [n_reads+1], n_reads).
 
     shard=(rank, world): the same sample (genome + haplotypes from `seed`) on every rank, each rank
@@ -56,11 +115,14 @@ def make_reads(genome_len=SHAPES["tiny"], coverage=30, read_len=150, seed=202610
         hap_a[idx] = copies_t.reshape(-1).to(dev)
     g = torch.Generator(device=dev)
     g.manual_seed(seed + 1)
-    snp = torch.rand(genome_len, generator=g, device=dev) < snp_rate
-    shift = torch.randint(1, 4, (genome_len,), generator=g, device=dev, dtype=torch.uint8)
-    hap_b = torch.where(snp, (hap_a + shift) & 3, hap_a)
-    haps = torch.stack([hap_a, hap_b])  # [2, G]
-    del snp, shift
+    reference = hap_a
+    hap_a, hap_b = plant_variants(reference, seed, g, snp_rate, indel_rate, sv_rate, het_frac)
+    len_a, len_b = int(hap_a.numel()), int(hap_b.numel())
+    haps = torch.zeros((2, max(len_a, len_b)), dtype=torch.uint8, device=dev)  # [2, longest haplotype]
+    haps[0, :len_a] = hap_a
+    haps[1, :len_b] = hap_b
+    del hap_a, hap_b
+    hap_len = min(len_a, len_b)  # fragments start where both haplotypes have 800 bases ahead
 
     rank, world = shard
     n_pairs = int(coverage * genome_len // (2 * read_len))
@@ -76,7 +138,7 @@ def make_reads(genome_len=SHAPES["tiny"], coverage=30, read_len=150, seed=202610
         insert = (torch.randn(m, generator=g, device=dev) * 50 + 400).clamp(200, 800).long()
         insert = torch.maximum(insert, torch.full_like(insert, read_len))
         # integer draw: float32 uniforms have 24 bits, which would quantise the starts of a >16 Mb genome
-        start = torch.randint(0, max(genome_len - 800, 1), (m,), generator=g, device=dev)
+        start = torch.randint(0, max(hap_len - 800, 1), (m,), generator=g, device=dev)
         hap = torch.randint(0, 2, (m,), generator=g, device=dev)
         flip = torch.rand(m, generator=g, device=dev) < 0.5  # which strand the fragment came from
         # mate 1: forward from fragment start; mate 2: reverse complement from fragment end (FR)
@@ -96,5 +158,5 @@ def make_reads(genome_len=SHAPES["tiny"], coverage=30, read_len=150, seed=202610
         done += m
     offs = torch.arange(0, (n_reads + 1) * read_len, read_len, dtype=torch.int64, device=dev)
     if return_genome:
-        return out, offs, n_reads, hap_a
+        return out, offs, n_reads, reference
     return out, offs, n_reads
