@@ -46,8 +46,9 @@ def driver_leg(ctx, ss, genome, dev, args, region=2000000):
     """The whole graph-discover pipeline of the reference's graph_discover_test.py (make_ref_assemblies ->
     trim/update -> discover_branch -> ... -> discover_push_to_pair; host drivers biograph_amd/variants.py over
     the kernels) on the first `region` bases of the reference, scored against the SNPs synth.py planted (on one
-    haplotype or both; its indels and structural variants land in `other_calls`).  Host bookkeeping in C++ (csrc/discover.cpp); the chain of rc paths is broken by
-    verified speculation, so a step is a few large launches plus single ones around variants."""
+    haplotype or both; its indels and structural variants land in `other_calls`).  Host bookkeeping in C++
+    (csrc/discover.cpp); the chain of rc paths is broken by verified speculation, so a step is a few large
+    launches plus single ones around variants."""
     import torch
     from biograph_amd import variants as V
     G = int(genome.numel())
