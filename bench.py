@@ -51,6 +51,7 @@ def driver_leg(ctx, ss, genome, dev, args, region=2000000):
     launches plus single ones around variants."""
     import torch
     from biograph_amd import variants as V
+    from biograph_amd.synth import variant_sites as synth_sites
     G = int(genome.numel())
     region = min(region, G)
     ref = "".join("ACGT"[int(c)] for c in genome[:region].cpu().tolist())
@@ -73,10 +74,26 @@ def driver_leg(ctx, ss, genome, dev, args, region=2000000):
              if a.left_offset is not None and a.right_offset is not None and not a.matches_reference]
     snps = {a.left_offset: a.seq for a in found if a.right_offset == a.left_offset + 1 and len(a.seq) == 1}
     hit = sum(1 for p, b in truth.items() if snps.get(p) == b)
+    # planted indels / structural variants: a call with the same net length within 60 bases of the site (a
+    # call may sit anywhere in the repeat the event can slide along, and may carry flanking matches)
+    import bisect
+    planted = [(p, (ln if ins else -ln)) for p, ln, ins, _, _ in synth_sites(G, args.seed) if p + ln < region - 100]
+    nets = sorted((a.left_offset, len(a.seq) - (a.right_offset - a.left_offset)) for a in found
+                  if len(a.seq) != a.right_offset - a.left_offset)
+    lefts = [x[0] for x in nets]
+    indel_hit = 0
+    for p, net in planted:
+        i = bisect.bisect_left(lefts, p - 60)
+        while i < len(nets) and nets[i][0] <= p + 60:
+            if nets[i][1] == net:
+                indel_hit += 1
+                break
+            i += 1
     return {"region_bases": region, "seconds": round(dt, 2), "anchored_variants": len(found),
             "anchored_variants_per_s": round(len(found) / dt, 1),
             "planted_snps_in_region": len(truth), "planted_snps_found": hit,
-            "other_calls": len(found) - hit, "min_overlap": 105}
+            "planted_indels_svs_in_region": len(planted), "planted_indels_svs_found": indel_hit,
+            "other_calls": len(found) - hit - indel_hit, "min_overlap": 105}
 
 
 def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):

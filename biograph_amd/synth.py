@@ -34,6 +34,32 @@ def make_genome(n, seed, device):
     return genome
 
 
+def variant_sites(G, seed, indel_rate=1e-4, sv_rate=1e-6, het_frac=2.0 / 3.0, rng=None):
+    """The planted indels and structural variants of a G-base genome, in position order:
+    (position, length, is_insertion, heterozygous, haplotype of a heterozygous site).  Host-side and seeded, so
+    a scorer can ask for the truth set without the haplotypes (bench.py)."""
+    if rng is None:
+        rng = np.random.default_rng(seed + 1)
+    if G < 8000:
+        return []
+    n_indel = int(rng.binomial(G, indel_rate)) if indel_rate > 0 else 0
+    n_sv = int(rng.binomial(G, sv_rate)) if sv_rate > 0 else 0
+    pos = rng.integers(2000, G - 3000, n_indel + n_sv)
+    length = np.concatenate([rng.integers(1, 51, n_indel), rng.integers(50, 1001, n_sv)])
+    is_ins = rng.random(n_indel + n_sv) < 0.5
+    het = rng.random(n_indel + n_sv) < het_frac
+    hap_of = rng.integers(0, 2, n_indel + n_sv)
+    order = np.argsort(pos, kind="stable")
+    sites, last_end = [], 0
+    for i in order:
+        p, ln = int(pos[i]), int(length[i])
+        if p < last_end + 10:
+            continue  # would touch the previous site
+        sites.append((p, ln, bool(is_ins[i]), bool(het[i]), int(hap_of[i])))
+        last_end = p + (0 if is_ins[i] else ln)
+    return sites
+
+
 def plant_variants(reference, seed, g, snp_rate=0.001, indel_rate=1e-4, sv_rate=1e-6, het_frac=2.0 / 3.0):
     """The two haplotypes of the sample.  Sites are drawn on the host (numpy, seed + 1: the same on every rank),
     the bases on `reference`'s device with generator `g`.  Indels and structural variants do not overlap and keep
@@ -54,21 +80,7 @@ def plant_variants(reference, seed, g, snp_rate=0.001, indel_rate=1e-4, sv_rate=
     del snp, shift, zyg, which, alt
     if G < 8000 or (indel_rate <= 0 and sv_rate <= 0):
         return haps[0], haps[1]
-    n_indel = int(rng.binomial(G, indel_rate)) if indel_rate > 0 else 0
-    n_sv = int(rng.binomial(G, sv_rate)) if sv_rate > 0 else 0
-    pos = rng.integers(2000, G - 3000, n_indel + n_sv)
-    length = np.concatenate([rng.integers(1, 51, n_indel), rng.integers(50, 1001, n_sv)])
-    is_ins = rng.random(n_indel + n_sv) < 0.5
-    het = rng.random(n_indel + n_sv) < het_frac
-    hap_of = rng.integers(0, 2, n_indel + n_sv)
-    order = np.argsort(pos, kind="stable")
-    sites, last_end = [], 0
-    for i in order:
-        p, ln = int(pos[i]), int(length[i])
-        if p < last_end + 10:
-            continue  # would touch the previous site
-        sites.append((p, ln, bool(is_ins[i]), bool(het[i]), int(hap_of[i])))
-        last_end = p + (0 if is_ins[i] else ln)
+    sites = variant_sites(G, seed, indel_rate, sv_rate, het_frac, rng)
     ins_total = sum(ln for _, ln, ins, _, _ in sites if ins)
     ins_bases = torch.randint(0, 4, (max(ins_total, 1),), generator=g, device=dev, dtype=torch.uint8)
     out = []
