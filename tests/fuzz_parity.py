@@ -1,7 +1,7 @@
 """Randomised differential test of the whole create path: random genomes (alphabet, repeats, duplications), read
 lengths, error / N rates, k, min_count and correction parameters -> bg_create on the GPU vs the oracle on the CPU,
 every container part compared.  Runs until the time budget is used (FUZZ_SCALE=50 multiplies the genome sizes:
-fewer, multi-tile / multi-bucket cases).  Usage: python tools/fuzz_parity.py [seconds] [seed]"""
+fewer, multi-tile / multi-bucket cases).  Usage: python tests/fuzz_parity.py [seconds] [seed]"""
 import os
 import sys
 import time

@@ -1,6 +1,6 @@
 """Build time and oracle parity on low-complexity input: a 2 Mb random genome with a 5 kb poly-A tract, a 5 kb
 (AC)n tract and a 3 kb (AAT)n tract, 30x reads, plus one read duplicated 20 000 times (PCR pile-up) and 2 000
-all-N reads.  Usage: python tools/stress_lowcomplexity.py [check]   (check = compare a 200 kb version with the oracle)"""
+all-N reads.  Usage: python tests/stress_lowcomplexity.py [check]   (check = compare a 200 kb version with the oracle)"""
 import os
 import sys
 import time

@@ -1,4 +1,4 @@
-"""A short run of every mode of tools/fuzz_parity.py (randomised differential tests of the build, the multi-rank
+"""A short run of every mode of tests/fuzz_parity.py (randomised differential tests of the build, the multi-rank
 build, readmap + merge + propagate_from_end, the walk and the frontier kernels against the oracle).  Long runs are
 made with the tool itself; this keeps the modes alive."""
 import os
@@ -16,7 +16,7 @@ def test_fuzz_mode(mode):
     env = dict(os.environ)
     if mode:
         env[mode] = "1"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "6", "3"], env=env, cwd=ROOT,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "6", "3"], env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "random builds equal to the oracle" in r.stdout

@@ -122,7 +122,7 @@ def test_sharded_splitter_sample_step(ctx, monkeypatch, every):
 
 def test_sharded_truncation_narrows_the_word_stride(ctx):
     """Every read ends in NNNN: the corrected reads are 96 bases (3 words) in objects that keep the input's 4-word
-    stride — the corrected-read exchange must narrow them (found by tools/fuzz_parity.py)."""
+    stride — the corrected-read exchange must narrow them (found by tests/fuzz_parity.py)."""
     rng = np.random.default_rng(4)
     g = "".join(rng.choice(list("ACGT"), size=3000))
     comp = str.maketrans("ACGT", "TGCA")
