@@ -1,0 +1,95 @@
+"""The bench workload at its full size (30x chr20-shaped, 1.93 Gbases: BASELINE.json configs[2]) — too big for the
+oracle, so the seqset is checked through properties that do not depend on size: the invariants of seqset.cpp /
+builder.cpp (sorted, prefix-free, sum of prev popcounts = n, every tail closed), FM navigation (find(entry) lands
+on that entry, pop/push round trip), and agreement of two independent code paths (the fused single-GPU build and
+the multi-rank build with its exchanges) part for part."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import biograph_amd as bg
+from biograph_amd import sharded, synth
+
+pytestmark = pytest.mark.gpu
+G = synth.SHAPES["chr20"]
+
+
+@pytest.fixture(scope="module")
+def built():
+    os.environ["BG_VERIFY_CLOSURE"] = "1"  # every entry's tail is looked up and must be a prefix of what it finds
+    try:
+        ctx = bg.Context(0)
+        seq, offs, n = synth.make_reads(genome_len=G, coverage=30, read_len=150, seed=20261002, device="cuda")
+        ss, st = ctx.create_device(seq.data_ptr(), offs.data_ptr(), n, ctx.default_params())
+    finally:
+        del os.environ["BG_VERIFY_CLOSURE"]
+    yield ctx, ss, st, (seq, offs, n)
+    ss.free()
+    ctx.close()
+
+
+def test_fullsize_counters_and_invariants(built):
+    ctx, ss, st, (seq, offs, n) = built
+    assert st["n_reads"] == n == 2 * (30 * G // 300) and st["n_bases"] == n * 150
+    assert st["n_kmers"] == n * (150 - 30 + 1)
+    assert 0.95 * n < st["n_corrected_reads"] <= n
+    assert G < st["n_kept_kmers"] < 1.05 * G  # the distinct 30-mers of a diploid genome with 1/1000 variants
+    N = ss.size()
+    assert N == st["n_entries"] and 2 * G < N < 2.4 * G  # both strands
+    parts = ss.parts()
+    total = 0
+    for b in "ACGT":
+        bits = np.frombuffer(parts["prev_%s/bits" % b], np.uint8)
+        total += int(np.unpackbits(bits).sum(dtype=np.int64))
+    assert total == N  # seqset.cpp:123-126: every entry is the pop_front of exactly one (entry, base)
+    sizes = np.frombuffer(parts["entry_sizes/elements"], np.uint8)
+    shared = np.frombuffer(parts["shared/elements"], np.uint8)
+    assert len(sizes) >= N and int(sizes[:N].max()) == 150 and int(sizes[:N].min()) >= 1
+    assert shared[0] == 0 and bool((shared[1:N] < sizes[1:N]).all())  # prefix-free: never the whole entry
+    assert bool((shared[1:N] <= sizes[:N - 1]).all())
+
+
+def test_fullsize_sorted_windows_and_navigation(built):
+    ctx, ss, st, _ = built
+    N = ss.size()
+    rng = np.random.default_rng(5)
+    for first in [0, N - 4000] + [int(x) for x in rng.integers(0, N - 4000, 6)]:
+        ent = ss.entries(first, 4000)
+        for a, b in zip(ent, ent[1:]):
+            assert a < b and not b.startswith(a)
+        b, e = ss.find_batch(ent[::16])
+        assert b.tolist() == list(range(first, first + 4000, 16))  # find(entry) begins at the entry itself
+        assert bool((e > b).all())
+    # pop_front then push_front of the dropped base comes back to a range holding the entry
+    first = int(rng.integers(0, N - 2000))
+    ent = [s for s in ss.entries(first, 2000) if len(s) > 40]
+    tb, te = ss.find_batch([s[1:] for s in ent])
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    nb, ne, nz = ss.push_front_batch(tb, te, np.array([len(s) - 1 for s in ent], np.uint32),
+                                     np.array([code[s[0]] for s in ent], np.uint8))
+    eb, ee = ss.find_batch(ent)
+    assert nb.tolist() == eb.tolist() and ne.tolist() == ee.tolist() and nz.tolist() == [len(s) for s in ent]
+
+
+def test_fullsize_sharded_build_equals_fused(built):
+    """Two ranks (simulated on the one GPU, every buffer through the exchange phases of the C ABI) build the same
+    sample: every container part equal to the fused build's."""
+    ctx, ss, st, (seq, offs, n) = built
+    want = {k: hashlib.sha256(v).hexdigest() for k, v in ss.parts().items()}
+    half = (n // 4) * 2
+    cut = half * 150
+    inputs = {0: (seq[:cut], offs[:half + 1], half),
+              1: (seq[cut:], (offs[half:] - cut).contiguous(), n - half)}
+    out = sharded.sharded_create(sharded.LocalSimComm(2), {0: ctx, 1: ctx}, inputs, ctx.default_params())
+    ss2, st2 = out[0]
+    try:
+        for key in ("n_kept_kmers", "n_distinct_kmers", "n_kmers", "n_corrected_reads", "n_corrected_bases",
+                    "n_records", "n_entries"):
+            assert st2[key] == st[key], key
+        got = {k: hashlib.sha256(v).hexdigest() for k, v in ss2.parts().items()}
+        assert got == want
+    finally:
+        ss2.free()
