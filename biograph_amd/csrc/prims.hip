@@ -49,6 +49,7 @@ int bg_ctx::alloc(size_t bytes, void** out) {
     if (trace) fprintf(stderr, "[bg alloc] hipMalloc %zu MiB (live %zu MiB, cached %zu MiB)\n", bytes >> 20, live_bytes >> 20, cached_bytes >> 20);
     hipError_t e = hipMalloc(out, bytes);
     if (e != hipSuccess && cached_bytes) {  // give cached blocks back and retry once
+      (void)hipGetLastError();  // the failed attempt must not surface at the next launch check
       trim();
       e = hipMalloc(out, bytes);
     }

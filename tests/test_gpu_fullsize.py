@@ -14,7 +14,8 @@ import biograph_amd as bg
 from biograph_amd import sharded, synth
 
 pytestmark = pytest.mark.gpu
-G = synth.SHAPES["chr20"]
+# BG_FULLSIZE_GENOME=180000000 runs the same checks past 2^32 windows and base offsets (5.4 Gbases; ~150 GB of HBM)
+G = int(os.environ.get("BG_FULLSIZE_GENOME", synth.SHAPES["chr20"]))
 
 
 @pytest.fixture(scope="module")
