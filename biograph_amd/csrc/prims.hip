@@ -71,6 +71,18 @@ void bg_ctx::release(void* p) {
   size_t bytes = it->second;
   live.erase(it);
   live_bytes -= bytes;
+  // The cache is bounded (BG_POOL_CAP_GB, default 35 % of the device): the caller's own allocator (torch in the
+  // multi-GPU driver) lives beside this pool and cannot ask it to trim.
+  static const size_t cap = [] {
+    if (const char* e = getenv("BG_POOL_CAP_GB")) return size_t(atof(e) * 1e9);
+    size_t fr = 0, total = 0;
+    if (hipMemGetInfo(&fr, &total) != hipSuccess) { (void)hipGetLastError(); return ~size_t(0); }
+    return size_t(double(total) * 0.35);
+  }();
+  if (cached_bytes + bytes > cap) {
+    (void)hipFree(p);  // waits for the device: nothing in flight still uses the block
+    return;
+  }
   free_blocks.emplace(bytes, p);
   cached_bytes += bytes;
 }

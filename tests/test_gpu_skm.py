@@ -2,6 +2,8 @@
 replaces: minimiser runs cut at the record capacity (low-complexity reads), every k the path accepts, the
 staging-area and record-buffer overflow paths, extra partition levels, and the presence bits it hands to the
 read correction (including the buckets whose LDS table overflows)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -95,3 +97,27 @@ def test_presence_bits_drive_the_correction(ctx, monkeypatch, env):
     cseq2, coffs2, _, _ = O.correct_reads(oks, s2, o2, 8, 2, 0.7)
     g2, go2 = c2.download()
     assert (go2 == coffs2).all() and (g2 == cseq2).all()
+
+
+def test_pool_cache_cap_env():
+    """BG_POOL_CAP_GB bounds the allocator's cache (blocks beyond it go back to the device at once): the build
+    still runs and gives the same seqset; the cache stays under the cap."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "import biograph_amd as bg\nfrom biograph_amd import synth\n"
+            "ctx = bg.Context(0)\n"
+            "seq, offs, n = synth.make_reads(genome_len=300000, coverage=20, read_len=150, seed=4, device='cuda')\n"
+            "ss, st = ctx.create_device(seq.data_ptr(), offs.data_ptr(), n, ctx.default_params())\n"
+            "h = hashlib.sha256(b''.join(ss.parts()[k] for k in bg.PART_NAMES)).hexdigest()\n"
+            "print('RESULT', h, ctx.memory()['cached'])\n") % root
+    outs = []
+    for cap in ("0.002", "64"):
+        env = dict(os.environ, BG_POOL_CAP_GB=cap)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        line = [x for x in r.stdout.splitlines() if x.startswith("RESULT")][0].split()
+        outs.append((line[1], int(line[2])))
+    assert outs[0][0] == outs[1][0]
+    assert outs[0][1] <= 2_000_000 < outs[1][1]
