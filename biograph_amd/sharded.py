@@ -250,6 +250,16 @@ class _Phases:
             sys.stderr.write("sharded_create phases (ms): " + ", ".join("%s %.1f" % r for r in self.rows) + "\n")
 
 
+def _relieve(ctxs, dev):
+    """Two allocators share the GPU (torch for the exchange buffers, the library's pool for everything else) and
+    neither can ask the other to trim: when the device runs low between phases, both give their caches back."""
+    for r, c in ctxs.items():
+        free, total = torch.cuda.mem_get_info(dev[r])
+        if free < 0.15 * total:
+            torch.cuda.empty_cache()
+            c.trim()
+
+
 def sharded_create(comm, ctxs, inputs, params=None, device=None):
     """comm: communicator; ctxs[r]: biograph_amd.Context of local rank r; inputs[r] = (seq uint8 tensor,
     offs int64 tensor, n_reads) resident on that rank's device.  Returns {r: (Seqset | None, stats)};
@@ -330,6 +340,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
     skm_bits = comm.all_to_all_v(bits_back) if use_skm else None
     del bits_back
     ph.mark("kmerset_all_gather_build")
+    _relieve(ctxs, dev)
     gathered = comm.all_gather_v(kept)
     tot_inst = sum(comm.all_gather_obj(n_inst)[ranks[0]])
     tot_distinct = sum(comm.all_gather_obj(distinct)[ranks[0]])
@@ -360,6 +371,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
     W = max(1, (max_len + 31) // 32)
 
     ph.mark("reads_all_gather")
+    _relieve(ctxs, dev)
     # ---- corrected reads replicated (cover index spans all reads)
     words, lens = {}, {}
     for r in ranks:
@@ -398,6 +410,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
         send[r] = rows
     del gw, gl
     ph.mark("records_partition")
+    _relieve(ctxs, dev)
     ghist = comm.all_reduce_sum(hists)
     gh = ghist[ranks[0]].cpu().numpy()
     splitters = choose_splitters(gh[:-1], P)
@@ -421,6 +434,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
     del recv
 
     ph.mark("boundaries")
+    _relieve(ctxs, dev)
     # ---- shard boundaries
     def boundary(r):
         f = np.zeros(W + 1, np.uint64)
@@ -470,6 +484,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
     del recv
 
     ph.mark("gather_assemble")
+    _relieve(ctxs, dev)
     # ---- final merge on rank 0: concatenation in rank order + finalize
     g_sizes = comm.all_gather_v(sl_sizes)
     g_shared = comm.all_gather_v(sl_shared)
