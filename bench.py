@@ -407,7 +407,7 @@ def main():
                                "GBps": round(t["bytes"] / (t["ms"] * 1e-3) / 1e9, 1) if t["ms"] > 0 else None}
                    for t in sorted(timings, key=lambda t: -t["ms"])}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             cpu = cpu_baseline(args.cpu_sample_genome, args.coverage, args.read_len, args.seed)
         # whole-build algorithmic bytes: 1.25 N_bases + 16 N_kmers + (0.5 N_bases + 8 N_kmers)
         # + 28 N_rec + 2.625 N_ent
