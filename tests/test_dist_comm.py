@@ -30,6 +30,16 @@ WORKER = textwrap.dedent("""
     comm.MAX_PIECE_BYTES = 24  # one 3-word row per piece and round
     out2 = comm.all_to_all_v({r: (rows, counts)})[r]
     assert torch.equal(out2, torch.cat(exp)), (r, out2)
+    # pieces of different lengths, some empty: rank 0 sends nothing to itself and 5 rows to rank 1, rank 1 sends
+    # 3 rows to rank 0 and nothing to itself -> 5 rounds, most of them with empty pieces
+    c2 = [0, 5] if r == 0 else [3, 0]
+    rows2 = torch.arange(sum(c2) * 3, dtype=torch.int64).reshape(-1, 3) + 500 * (r + 1)
+    out3 = comm.all_to_all_v({r: (rows2, c2)})[r]
+    if r == 0:
+        want3 = torch.arange(9, dtype=torch.int64).reshape(-1, 3) + 1000
+    else:
+        want3 = torch.arange(15, dtype=torch.int64).reshape(-1, 3) + 500
+    assert torch.equal(out3, want3), (r, out3)
     comm.MAX_PIECE_BYTES = (1 << 30) - 4096
     g = comm.all_gather_v({r: torch.full((r + 2, 2), r, dtype=torch.uint8)})[r]
     assert [t.shape[0] for t in g] == [2, 3] and all(int(t[0, 0]) == i for i, t in enumerate(g))
