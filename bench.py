@@ -276,6 +276,35 @@ def pmc_traffic(family):
     return {"traffic": None}
 
 
+def self_launch(n, json_fd):
+    """Runs `python -m torch.distributed.run --nproc-per-node n bench.py <same flags>` as a child process and
+    relays the child's single JSON line (fd 1 of the child) and its exit code.  The parent never touches the GPU."""
+    import socket
+    import subprocess
+    dc = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                        stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    try:
+        have = int(dc.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        have = 0
+    if have < n:
+        print("bench.py: --gpus %d needs %d devices, this node has %d" % (n, n, have), file=sys.stderr)
+        return 4
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env)
+    out, _ = p.communicate()
+    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if lines:
+        os.write(json_fd, (lines[-1] + "\n").encode())
+    return p.returncode if p.returncode or lines else 5
+
+
 def main():
     # stdout must carry exactly ONE JSON line: native libraries (RCCL prints a version banner) write to
     # fd 1 too, so fd 1 is pointed at stderr for the whole run and the line goes to the saved descriptor.
@@ -298,20 +327,28 @@ def main():
                     help="run the sharded (RCCL) build path even with one rank (smoke test of the collectives)")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as the driver invokes it: this process stays GPU-free (no torch import, no
+        # HIP call) and starts one rank per GPU as a CHILD process, relaying its one JSON line and exit code.
+        sys.exit(self_launch(args.gpus, json_fd))
+    if world != args.gpus:
+        print("bench.py: WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus), file=sys.stderr)
+        sys.exit(2)
+
     import torch
     import biograph_amd as bg
     from biograph_amd import synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: launch with torch.distributed.run for --gpus > 1", file=sys.stderr)
-            sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(3)
+    if torch.cuda.device_count() < world and not os.environ.get("BG_BENCH_SHARE_DEVICE"):
+        print("bench.py: --gpus %d needs %d devices, this node has %d" % (world, world, torch.cuda.device_count()),
+              file=sys.stderr)
+        sys.exit(4)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
