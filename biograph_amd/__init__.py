@@ -82,6 +82,7 @@ class Context:
         capi.check(capi.lib().bg_ctx_create(int(device), C.c_void_p(stream or 0), C.byref(h)))
         self.h = h
         self.device = device
+        self.stream = stream or 0  # the HIP stream every call of this context is issued on (0 = the null stream)
 
     def close(self):
         if self.h:

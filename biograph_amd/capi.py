@@ -77,6 +77,11 @@ SYMBOLS = [
     "bg_records_count", "bg_records_words", "bg_records_rows", "bg_records_prefix_hist", "bg_records_from_rows", "bg_records_free",
     "bg_entries_from_records", "bg_seqset_words", "bg_seqset_boundary_rows", "bg_seqset_fix_boundary",
     "bg_seqset_tail_rows", "bg_seqset_apply_tails", "bg_seqset_slice_export", "bg_seqset_assemble",
+    "bg_oriented_rows", "bg_rows_prefix_hist", "bg_cover_build", "bg_cover_test", "bg_cover_free",
+    "bg_cover_query_begin", "bg_cover_query_pending", "bg_cover_query_candidates", "bg_cover_query_answers",
+    "bg_cover_query_plain", "bg_cover_query_free",
+    "bg_kmerset_build_hash", "bg_skm_lookup", "bg_corr_begin", "bg_corr_step", "bg_corr_answers", "bg_corr_finish",
+    "bg_corr_probes", "bg_corr_free",
 ]
 
 PART_KMER_HASH, PART_PREFIX, PART_KEY_BOUNDS = 0, 1, 2
@@ -228,6 +233,30 @@ def lib():
     L.bg_seqset_apply_tails.argtypes = [vp, vp, vp, u64]
     L.bg_seqset_slice_export.argtypes = [vp, vp, vp, vp, vp]
     L.bg_seqset_assemble.argtypes = [vp, u32, vp, vp, vp, vp, u32, P(vp)]
+    L.bg_oriented_rows.argtypes = [vp, vp, i32, vp]
+    L.bg_rows_prefix_hist.argtypes = [vp, vp, u64, i32, i32, u64, vp]
+    L.bg_cover_build.argtypes = [vp, vp, u64, i32, i32, P(vp)]
+    L.bg_cover_test.argtypes = [vp, vp, vp, u64, vp]
+    L.bg_cover_free.argtypes = [vp]
+    L.bg_cover_free.restype = None
+    L.bg_cover_query_begin.argtypes = [vp, vp, u64, i32, i32, P(vp)]
+    L.bg_cover_query_pending.argtypes = [vp]
+    L.bg_cover_query_pending.restype = u64
+    L.bg_cover_query_candidates.argtypes = [vp, vp, i32, i32, vp, u64, P(u64)]
+    L.bg_cover_query_answers.argtypes = [vp, vp, vp, vp, u64, vp]
+    L.bg_cover_query_plain.argtypes = [vp, vp, vp, u64, P(u64)]
+    L.bg_cover_query_free.argtypes = [vp]
+    L.bg_cover_query_free.restype = None
+    L.bg_kmerset_build_hash.argtypes = [vp, vp]
+    L.bg_skm_lookup.argtypes = [vp, vp, vp, u64, vp, i32]
+    L.bg_corr_begin.argtypes = [vp, vp, i32, P(CorrectParams), vp, vp, vp, u64, P(vp)]
+    L.bg_corr_step.argtypes = [vp, vp, P(u64), P(vp)]
+    L.bg_corr_answers.argtypes = [vp, vp, vp, vp, u64]
+    L.bg_corr_finish.argtypes = [vp, vp, P(vp), P(CorrectStats)]
+    L.bg_corr_probes.argtypes = [vp]
+    L.bg_corr_probes.restype = u64
+    L.bg_corr_free.argtypes = [vp]
+    L.bg_corr_free.restype = None
     _lib = L
     return L
 

@@ -137,6 +137,10 @@ struct KmerTable {
     bool fl;
     return find(kmer_canon(kmer, k, &fl)) >= 0;
   }
+  // the search says where a look-up happens (view, virtual index of the k-mer's newest base); a table that
+  // holds the whole set does not care
+  template <class View>
+  BG_HD bool has_at(uint64_t kmer, const View&, int) const { return has(kmer); }
 };
 
 // ---- read correction (fast_read_correct.cpp:16-182 + correct_reads.cpp:154-178).
@@ -209,10 +213,66 @@ struct ReadView {
     }
     return run < limit ? run : limit;
   }
+  // the t (>= 1) original bases at virtual indices idx0 .. idx0 + t - 1, right-aligned (no N among them)
+  BG_HD uint64_t own_bases(int idx0, int t) const {
+    if (dir > 0) return window32(words, W, origin + idx0) >> (64 - 2 * t);
+    return revcomp64(window32(words, W, origin - idx0 - t + 1) >> (64 - 2 * t)) >> (64 - 2 * t);
+  }
   // k-mer (in the view's orientation) of the k original bases ending at virtual index t
   BG_HD uint64_t kmer_ending_at(int t) const {
     if (dir > 0) return window32(words, W, origin + t - k + 1) >> (64 - 2 * k);
     return kmer_revcomp(window32(words, W, origin - t) >> (64 - 2 * k), k);
+  }
+};
+
+// ---- the k-mer set of a sharded build stays with the ranks that counted it (kmer_counter.h:167-178: a
+// k-mer lives in one partition); the search of a read runs where the read is.  What it looks up beyond the
+// read's own windows (those come as presence bits) are the windows around a substituted base.  They are
+// fetched a *probe* at a time: a probe (q, pos, view) stands for the 4 x (run + 1) k-mers that end at virtual
+// indices pos .. pos + run of the view when the base at pos is replaced by b = 0..3, the bases before it are
+// the first k - 1 bases of q and the bases after it are the read's own (run < k, cut at an N or the read's
+// end): the window the search missed, its three alternatives and the runs they start.  mask[b] bit t = the
+// k-mer ending at pos + t is kept.  The search is re-run from scratch with the probes it has (a look-up no
+// probe answers is a miss: it is noted as a new probe and taken as "absent"); a run without a miss made
+// exactly the look-ups of the search over the whole set, with the same answers.
+struct ProbeDesc {
+  uint64_t q;
+  uint32_t mask[4];
+  uint32_t meta;  // pos : 8 | run : 8 | view : 1 (bit 16: the left view)
+  uint32_t next;  // older probe of the same read, ~0u = none
+};
+constexpr uint32_t kNoProbe = ~0u;
+constexpr int kMaxNewProbes = 4;  // per read and round
+
+struct RoutedTable {
+  const ProbeDesc* pool;
+  uint32_t head;
+  int k;
+  mutable uint64_t newq[kMaxNewProbes];
+  mutable uint32_t newmeta[kMaxNewProbes];
+  mutable int n_new;
+  mutable bool missed;
+  BG_HD bool has(uint64_t) const { missed = true; return false; }  // only reached without presence bits: never
+  template <class View>
+  BG_HD bool has_at(uint64_t kmer, const View& in, int pos) const {
+    const uint32_t view = in.dir < 0 ? 1u : 0u;
+    const uint64_t kmask = ~(~0ull << (2 * k));
+    for (uint32_t d = head; d != kNoProbe; d = pool[d].next) {
+      const uint32_t meta = pool[d].meta;
+      if (((meta >> 16) & 1u) != view) continue;
+      const int t = pos - int(meta & 255u);
+      if (t < 0 || t > int((meta >> 8) & 255u)) continue;
+      const uint32_t b = uint32_t(kmer >> (2 * t)) & 3u;
+      uint64_t z = (pool[d].q & ~3ull) | b;
+      if (t) z = ((z << (2 * t)) | in.own_bases(int(meta & 255u) + 1, t)) & kmask;
+      if (z == kmer) return (pool[d].mask[b] >> t) & 1u;
+    }
+    missed = true;
+    const uint32_t m = uint32_t(pos) | (view << 16);
+    for (int i = 0; i < n_new; ++i)
+      if (newmeta[i] == m && (newq[i] >> 2) == (kmer >> 2)) return false;
+    if (n_new < kMaxNewProbes) { newq[n_new] = kmer; newmeta[n_new] = m; ++n_new; }
+    return false;
   }
 };
 
@@ -265,7 +325,7 @@ BG_HD void frc_solve(const Table& tab, const ReadView& in, int start0, uint64_t 
         if (c == 4) break;
         uint64_t nk = kmer_shift(cur, k, c);
         // a window no substitution reaches (>= k bases past the last one) is the read's own window
-        bool has = (in.present && pos - f.last_sub >= k) ? in.window_present(pos) : tab.has(nk);
+        bool has = (in.present && pos - f.last_sub >= k) ? in.window_present(pos) : tab.has_at(nk, in, pos);
         if (!has) break;
         cur = nk;
         ++pos;
@@ -303,7 +363,7 @@ BG_HD void frc_solve(const Table& tab, const ReadView& in, int start0, uint64_t 
     bool descended = false;
     while (f.b < 4) {
       uint64_t tk = kmer_shift(f.kmer, k, f.b);
-      if (!tab.has(tk)) { f.b++; continue; }
+      if (!tab.has_at(tk, in, f.pos)) { f.b++; continue; }
       if (f.pos + 1 < in.n) {
         stack[depth++] = f;
         int child_start = f.pos + 1, child_last = f.pos;
@@ -423,6 +483,66 @@ BG_HD int frc_correct_read(const Table& tab, const uint64_t* words, const uint32
   return clen;
 }
 
+// ---- probes of the routed search (RoutedTable above): the two views of a read and the k-mers of a probe.
+// first window whose k-mer is kept (the anchor of fast_read_correct.cpp:107-122), or -1
+BG_HD int frc_anchor(const uint64_t* present, int len, int k) {
+  const int nwin = len - k + 1;
+  for (int w = 0; w * 64 < nwin; ++w) {
+    const uint64_t bits = present[w];
+    if (bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      const int j = w * 64 + (__ffsll((long long)bits) - 1);
+#else
+      const int j = w * 64 + __builtin_ctzll(bits);
+#endif
+      return j < nwin ? j : -1;
+    }
+  }
+  return -1;
+}
+// view 0: right of the anchor k-mer, left to right; view 1: left of it, on the reverse complement
+// (exactly the views frc_correct_read builds)
+BG_HD ReadView frc_view(const uint64_t* words, const uint32_t* nmask, int len, int W, int k, const uint64_t* present,
+                        int anchor, int view) {
+  if (view == 0) return ReadView{words, nmask, anchor + k, +1, len - (anchor + k), k, W, present};
+  return ReadView{words, nmask, anchor - 1, -1, anchor, k, W, present};
+}
+// own bases that follow virtual index pos inside the k - 1 windows a substitution at pos reaches
+BG_HD int probe_run(const ReadView& in, int pos, int k) {
+  int run = 0;
+  for (int t = 1; t < k; ++t) {
+    const int idx = pos + t;
+    if (idx >= in.n || in.get(idx) == 4) break;
+    run = t;
+  }
+  return run;
+}
+// the k-mer of probe (q, pos) that ends at pos + t with base b at pos
+BG_HD uint64_t probe_window(const ReadView& in, uint64_t q, int pos, int b, int t, int k) {
+  uint64_t z = (q & ~3ull) | uint64_t(b);
+  if (t) z = ((z << (2 * t)) | in.own_bases(pos + 1, t)) & ~(~0ull << (2 * k));
+  return z;
+}
+// the k + run bases whose windows are probe_window(.., t), t = 0..run, as two left-aligned words
+BG_HD void probe_string(const ReadView& in, uint64_t q, int pos, int b, int run, int k, uint64_t out[2]) {
+  const uint64_t head = (q & ~3ull) | uint64_t(b);  // k bases, right-aligned
+  const int nb = k + run;                            // <= 2k - 1 <= 61
+  uint64_t hi = head << (64 - 2 * k), lo = 0;        // left-aligned k bases
+  if (run) {
+    const uint64_t own = in.own_bases(pos + 1, run);  // run bases, right-aligned; they follow at base offset k
+    const int room = 32 - k;                          // bases of the first word still free (>= 1)
+    if (run <= room) {
+      hi |= own << (2 * (room - run));
+    } else {
+      hi |= own >> (2 * (run - room));
+      lo = own << (64 - 2 * (run - room));
+    }
+  }
+  (void)nb;
+  out[0] = hi;
+  out[1] = lo;
+}
+
 // ---- oriented reads.  Oriented read o = 2*i (forward) or 2*i+1 (reverse complement) of read i.
 // Materialises the W words of the oriented sequence (zero padded).
 BG_HD void oriented_words(const uint64_t* words, int len, int W, bool rc, uint64_t* out) {
@@ -481,13 +601,13 @@ struct CoverIndex {
   const uint32_t* soid;   // oriented ids in the same order
   uint64_t n_o;           // number of candidate reads
   int K;
+  const uint8_t* olen;    // length of every oriented read (by oriented id)
 };
 
 constexpr uint32_t kCoverSingle = 0x80000000u;  // vv[] low word: bit 31 = the run is this one oriented id
 
 // is suffix j (>= K bases long) of the oriented read s a prefix of some oriented read?
-BG_HD bool cover_probe(const CoverIndex& ci, const uint64_t* owords, const uint16_t* len, const uint64_t* s, int L,
-                       int j, int W) {
+BG_HD bool cover_probe(const CoverIndex& ci, const uint64_t* owords, const uint64_t* s, int L, int j, int W) {
   const int rem = L - j;
   uint64_t key = window32(s, W, j) >> (64 - 2 * ci.K);
   int64_t h = table_find(ci.slots, ci.log2cap, key, ~0ull);
@@ -505,7 +625,7 @@ BG_HD bool cover_probe(const CoverIndex& ci, const uint64_t* owords, const uint1
   if (hi - lo <= 4) {  // a handful (mates, duplicates): just try them
     for (uint64_t p = lo; p < hi; ++p) {
       const uint32_t c = ci.soid[p];
-      if (int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) return true;
+      if (int(ci.olen[c]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) return true;
     }
     return false;
   }
@@ -518,25 +638,24 @@ BG_HD bool cover_probe(const CoverIndex& ci, const uint64_t* owords, const uint1
       const uint64_t a = cw[w], b = window32(s, W, j + 32 * w);
       cmp = a < b ? -1 : (a > b ? 1 : 0);
     }
-    if (cmp == 0) cmp = int(len[c >> 1]) < rem ? -1 : 0;
+    if (cmp == 0) cmp = int(ci.olen[c]) < rem ? -1 : 0;
     if (cmp < 0) lo = mid + 1; else hi = mid;
   }
   if (lo >= end) return false;
   const uint32_t c = ci.soid[lo];
-  return int(len[c >> 1]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W);
+  return int(ci.olen[c]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W);
 }
 
 // number of suffix records oriented read o emits (0 for a dropped read)
-BG_HD int cover_count(const CoverIndex& ci, const uint64_t* owords,
-                                           const uint16_t* len, uint64_t o, int W) {
-  int L = len[o >> 1];
+BG_HD int cover_count(const CoverIndex& ci, const uint64_t* owords, uint64_t o, int W) {
+  int L = ci.olen[o];
   if (L == 0) return 0;
   const uint64_t* s = owords + o * W;
   int cnt = 1;
   for (int j = 1; j < L; ++j) {
     int rem = L - j;
     if (rem < ci.K) { cnt += rem; break; }  // suffixes shorter than K are never looked up: all emitted
-    if (cover_probe(ci, owords, len, s, L, j, W)) break;
+    if (cover_probe(ci, owords, s, L, j, W)) break;
     ++cnt;
   }
   return cnt;

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/bgseq.h"
+#include "bg_device_funcs.h"
 
 namespace bg {
 
@@ -195,6 +196,14 @@ struct bg_readmap {
 
 namespace bg {
 // build_seqset.hip
+struct CoverStore {  // device buffers behind a CoverIndex (bg_device_funcs.h)
+  DevBuf<uint64_t> skeys, slots, vv;
+  DevBuf<uint32_t> soid;
+  CoverIndex ci;
+  const uint64_t* owords = nullptr;
+};
+int cover_index_build(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, uint64_t n_o, int W, int cover_k,
+                      DevBuf<uint64_t>* k0o, CoverStore* cs);
 int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss);  // bitcount finalize + min index + fixed
 int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t hi, int cover_k,
                         DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out,

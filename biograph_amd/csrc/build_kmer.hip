@@ -1204,3 +1204,309 @@ extern "C" int bg_correct_reads(bg_ctx* ctx, const bg_reads* reads, const bg_kme
   *out = r.release();
   return BG_OK;
 }
+
+// ================================================================================================
+// Routed correction of the sharded build: the kept k-mers stay with their owner ranks; the search of a
+// read runs where the read is and fetches what it needs beyond the read's own windows as probes
+// (RoutedTable, bg_device_funcs.h).  One step = the search of every pending read with the probes it has;
+// reads that missed a look-up hand out new probes (strings whose windows are the probe's k-mers: they
+// travel as super-k-mers like the reads themselves, csrc/kmer_skm.hip) and run again next step.
+
+namespace bg {
+
+int skm_presence_from_bits(bg_ctx* ctx, const bg_reads* reads, int k, const uint64_t* d_recs, const uint64_t* d_org,
+                           const uint32_t* d_bits, uint64_t n, DevBuf<uint64_t>* present, int* stride);
+int skm_probe_answers(bg_ctx* ctx, const uint64_t* d_org, const uint32_t* d_bits, uint64_t n, ProbeDesc* pool, uint64_t base,
+                      uint64_t n_probes);
+
+__global__ __launch_bounds__(64) void k_correct_dfs_routed(const uint64_t* __restrict__ words,
+                                                           const uint32_t* __restrict__ nmask,
+                                                           const uint16_t* __restrict__ len,
+                                                           const uint64_t* __restrict__ list,
+                                                           const uint32_t* __restrict__ pend, uint64_t n_pend, int W, int k,
+                                                           int max_corrections, int min_good_run,
+                                                           const uint16_t* __restrict__ needed_by_len,
+                                                           uint64_t* __restrict__ out_words, uint16_t* __restrict__ out_len,
+                                                           CorrectCounters* __restrict__ ctr,
+                                                           const uint64_t* __restrict__ present, int pstride,
+                                                           ProbeDesc* __restrict__ pool, uint32_t* __restrict__ head,
+                                                           unsigned long long* __restrict__ cursor, uint64_t round_base,
+                                                           uint32_t* __restrict__ desc_slot, uint8_t* __restrict__ still) {
+  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n_pend) return;
+  const uint32_t slot = pend[t];
+  const uint64_t i = list[slot];
+  RoutedTable rt;
+  rt.pool = pool;
+  rt.head = head[slot];
+  rt.k = k;
+  rt.n_new = 0;
+  rt.missed = false;
+  const int L = len[i];
+  uint64_t ow[kMaxWords];
+  int ncorr = 0;
+  const int clen = frc_correct_read(rt, words + i * W, nmask + i * W, L, W, k, max_corrections, min_good_run,
+                                    int(needed_by_len[L]), ow, &ncorr, present + i * pstride);
+  if (!rt.missed) {
+    for (int w = 0; w < W; ++w) out_words[i * W + w] = clen ? ow[w] : 0;
+    out_len[i] = uint16_t(clen);
+    if (clen && ncorr) {
+      atomicAdd(&ctr->modified, 1ull);
+      atomicAdd(&ctr->modified_bases, (unsigned long long)ncorr);
+    }
+    still[t] = 0;
+    return;
+  }
+  // rt.n_new >= 1: the first miss of a run is never one of this run's own new probes
+  const uint64_t base = atomicAdd(cursor, (unsigned long long)rt.n_new);
+  uint32_t prev = rt.head;
+  for (int q = 0; q < rt.n_new; ++q) {
+    ProbeDesc d;
+    d.q = rt.newq[q];
+    d.mask[0] = d.mask[1] = d.mask[2] = d.mask[3] = 0;
+    d.meta = rt.newmeta[q];  // the run is filled in by k_probe_strings
+    d.next = prev;
+    pool[base + q] = d;
+    desc_slot[base + q - round_base] = slot;
+    prev = uint32_t(base + q);
+  }
+  head[slot] = prev;
+  still[t] = 1;
+}
+
+// the 4 strings of every new probe (W = 2 words each) and the probe's run
+__global__ void k_probe_strings(const uint64_t* __restrict__ words, const uint32_t* __restrict__ nmask,
+                                const uint16_t* __restrict__ len, const uint64_t* __restrict__ list, int W, int k,
+                                const uint64_t* __restrict__ present, int pstride, ProbeDesc* __restrict__ pool,
+                                uint64_t round_base, uint64_t n_new, const uint32_t* __restrict__ desc_slot,
+                                uint64_t* __restrict__ pwords, uint16_t* __restrict__ plen) {
+  const uint64_t d = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (d >= n_new) return;
+  const uint64_t i = list[desc_slot[d]];
+  ProbeDesc& pd = pool[round_base + d];
+  const int L = len[i];
+  const int anchor = frc_anchor(present + i * pstride, L, k);  // >= 0: the search got as far as a look-up
+  const int view = int((pd.meta >> 16) & 1u), pos = int(pd.meta & 255u);
+  const ReadView in = frc_view(words + i * W, nmask + i * W, L, W, k, present + i * pstride, anchor, view);
+  const int run = probe_run(in, pos, k);
+  pd.meta |= uint32_t(run) << 8;
+  for (int b = 0; b < 4; ++b) {
+    uint64_t s[2];
+    probe_string(in, pd.q, pos, b, run, k, s);
+    pwords[(4 * d + b) * 2] = s[0];
+    pwords[(4 * d + b) * 2 + 1] = s[1];
+    plen[4 * d + b] = uint16_t(k + run);
+  }
+}
+
+__global__ void k_iota_u32_corr(uint32_t* __restrict__ dst, uint64_t n) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = uint32_t(i);
+}
+__global__ void k_fill_u32_corr(uint32_t* __restrict__ dst, uint64_t n, uint32_t v) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = v;
+}
+__global__ void k_gather_u32_corr(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n,
+                                  uint32_t* __restrict__ dst) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+
+}  // namespace bg
+
+struct bg_correction {
+  bg_ctx* ctx = nullptr;
+  const bg_reads* reads = nullptr;
+  int k = 0;
+  bg_correct_params prm{};
+  std::unique_ptr<bg_reads> out;
+  bg::DevBuf<uint64_t> present;
+  int pstride = 1;
+  bg::DevBuf<uint16_t> needed;
+  bg::DevBuf<uint64_t> list;       // reads that need the search
+  uint64_t nlist = 0;
+  bg::DevBuf<uint32_t> head;       // newest probe of every list slot
+  bg::DevBuf<uint32_t> pend;       // list slots still searching
+  uint64_t n_pend = 0;
+  bg::DevBuf<bg::ProbeDesc> pool;
+  uint64_t pool_used = 0;
+  bg::DevBuf<uint32_t> desc_slot;  // list slot of every probe of the round in flight
+  uint64_t round_base = 0, round_new = 0;
+  bg::DevBuf<bg::CorrectCounters> ctr;
+  uint64_t steps = 0, probes = 0;
+};
+
+extern "C" int bg_corr_begin(bg_ctx* ctx, const bg_reads* reads, int k, const bg_correct_params* params,
+                             const uint64_t* d_recs, const uint64_t* d_org, const uint32_t* d_bits, uint64_t n_recs,
+                             bg_correction** out) {
+  if (!ctx || !reads || !params || !out || (n_recs && (!d_recs || !d_org || !d_bits))) { set_error("bg_corr_begin: null argument"); return BG_EINVAL; }
+  if (k < 1 || k > 31) { set_error("bg_corr_begin: kmer size %d outside 1..31", k); return BG_EINVAL; }
+  if (params->max_corrections > uint32_t(kMaxCorrections)) { set_error("bg_corr_begin: max_corrections %u > %d", params->max_corrections, kMaxCorrections); return BG_EINVAL; }
+  const uint64_t n = reads->n;
+  if (n >= (1ull << 32)) { set_error("bg_corr_begin: too many reads for one shard"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_correction> c(new bg_correction);
+  c->ctx = ctx;
+  c->reads = reads;
+  c->k = k;
+  c->prm = *params;
+  const int W = reads->W;
+  c->out.reset(new bg_reads);
+  bg_reads* r = c->out.get();
+  r->ctx = ctx;
+  r->n = n;
+  r->W = W;
+  BG_TRY(r->words.alloc(ctx, n * W));
+  BG_TRY(r->nmask.alloc(ctx, n * W));
+  BG_TRY(r->len.alloc(ctx, n));
+  if (n) BG_HIP(hipMemsetAsync(r->nmask.p, 0, n * W * 4, ctx->stream));
+  uint16_t needed[256];
+  for (int L = 0; L < 256; ++L) needed[L] = uint16_t(unsigned(double(params->trim_after_portion) * double(L)));
+  BG_TRY(c->needed.alloc(ctx, 256));
+  BG_HIP(hipMemcpyAsync(c->needed.p, needed, sizeof needed, hipMemcpyHostToDevice, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));  // `needed` is on this frame
+  BG_TRY(skm_presence_from_bits(ctx, reads, k, d_recs, d_org, d_bits, n_recs, &c->present, &c->pstride));
+  BG_TRY(c->ctr.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(c->ctr.p, 0, sizeof(CorrectCounters), ctx->stream));
+  DevBuf<uint8_t> need;
+  BG_TRY(need.alloc(ctx, n));
+  if (n) {
+    ctx->tic("correct_screen_bits");
+    k_screen_from_present<<<cdiv(n, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->len.p, n, W, k, c->present.p, c->pstride,
+                                                                  r->words.p, r->len.p, need.p);
+    BG_LAUNCH_CHECK();
+    ctx->toc(n * (W * 16 + 32 + 5));
+  }
+  BG_TRY(compact_flagged<uint64_t>(ctx, need.p, n, &c->list, &c->nlist));
+  BG_TRY(c->head.alloc(ctx, c->nlist));
+  BG_TRY(c->pend.alloc(ctx, c->nlist));
+  if (c->nlist) {
+    k_fill_u32_corr<<<cdiv(c->nlist, 256), 256, 0, ctx->stream>>>(c->head.p, c->nlist, kNoProbe);
+    BG_LAUNCH_CHECK();
+    k_iota_u32_corr<<<cdiv(c->nlist, 256), 256, 0, ctx->stream>>>(c->pend.p, c->nlist);
+    BG_LAUNCH_CHECK();
+  }
+  c->n_pend = c->nlist;
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  *out = c.release();
+  return BG_OK;
+}
+
+extern "C" void bg_corr_free(bg_correction* c) { delete c; }
+
+// One step.  *n_pending_out = reads that still miss look-ups after it; *probes_out = the strings of their new
+// probes as a reads object (4 per probe; NULL when there are none) — the caller ships their super-k-mers to
+// the owners (bg_skm_extract_by_owner), gets the windows' presence back (bg_skm_lookup on the owner) and hands
+// it to bg_corr_answers before the next step.  Ranks without pending reads still take part in the exchange.
+extern "C" int bg_corr_step(bg_ctx* ctx, bg_correction* c, uint64_t* n_pending_out, bg_reads** probes_out) {
+  if (!ctx || !c || !n_pending_out || !probes_out) { set_error("bg_corr_step: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  *probes_out = nullptr;
+  *n_pending_out = 0;
+  c->round_new = 0;
+  if (!c->n_pend) return BG_OK;
+  const bg_reads* reads = c->reads;
+  const int W = reads->W, k = c->k;
+  const uint64_t room = c->pool_used + uint64_t(kMaxNewProbes) * c->n_pend;
+  if (room >= (1ull << 32)) { set_error("bg_corr_step: probe pool exceeds 2^32 entries"); return BG_ENOMEM; }
+  if (c->pool.n < room) {
+    DevBuf<ProbeDesc> np;
+    BG_TRY(np.alloc(ctx, room + room / 2));
+    if (c->pool_used) BG_HIP(hipMemcpyAsync(np.p, c->pool.p, c->pool_used * sizeof(ProbeDesc), hipMemcpyDeviceToDevice, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    c->pool = std::move(np);
+  }
+  BG_TRY(c->desc_slot.alloc(ctx, uint64_t(kMaxNewProbes) * c->n_pend));
+  DevBuf<unsigned long long> cursor;
+  DevBuf<uint8_t> still;
+  BG_TRY(cursor.alloc(ctx, 1));
+  BG_TRY(still.alloc(ctx, c->n_pend));
+  unsigned long long h_cur = c->pool_used;
+  BG_HIP(hipMemcpyAsync(cursor.p, &h_cur, 8, hipMemcpyHostToDevice, ctx->stream));
+  ctx->tic("correct_dfs");
+  k_correct_dfs_routed<<<cdiv(c->n_pend, 64), 64, 0, ctx->stream>>>(
+      reads->words.p, reads->nmask.p, reads->len.p, c->list.p, c->pend.p, c->n_pend, W, k, int(c->prm.max_corrections),
+      int(c->prm.min_good_run), c->needed.p, c->out->words.p, c->out->len.p, c->ctr.p, c->present.p, c->pstride, c->pool.p,
+      c->head.p, cursor.p, c->pool_used, c->desc_slot.p, still.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(c->n_pend * W * 20);
+  BG_HIP(hipMemcpyAsync(&h_cur, cursor.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  DevBuf<uint32_t> keep_t, np;
+  uint64_t m = 0;
+  BG_TRY(compact_flagged<uint32_t>(ctx, still.p, c->n_pend, &keep_t, &m));  // synchronises
+  BG_TRY(np.alloc(ctx, m));
+  if (m) {
+    k_gather_u32_corr<<<cdiv(m, 256), 256, 0, ctx->stream>>>(c->pend.p, keep_t.p, m, np.p);
+    BG_LAUNCH_CHECK();
+  }
+  c->round_base = c->pool_used;
+  c->round_new = h_cur - c->pool_used;
+  c->pool_used = h_cur;
+  c->steps += 1;
+  c->probes += c->round_new;
+  if (c->round_new) {
+    std::unique_ptr<bg_reads> pr(new bg_reads);
+    pr->ctx = ctx;
+    pr->n = 4 * c->round_new;
+    pr->W = 2;
+    pr->max_len = uint32_t(2 * k - 1);
+    BG_TRY(pr->words.alloc(ctx, pr->n * 2));
+    BG_TRY(pr->nmask.alloc(ctx, pr->n * 2));
+    BG_TRY(pr->len.alloc(ctx, pr->n));
+    BG_HIP(hipMemsetAsync(pr->nmask.p, 0, pr->n * 2 * 4, ctx->stream));
+    k_probe_strings<<<cdiv(c->round_new, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->nmask.p, reads->len.p, c->list.p, W, k,
+                                                                    c->present.p, c->pstride, c->pool.p, c->round_base,
+                                                                    c->round_new, c->desc_slot.p, pr->words.p, pr->len.p);
+    BG_LAUNCH_CHECK();
+    *probes_out = pr.release();
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  c->pend = std::move(np);
+  c->n_pend = m;
+  *n_pending_out = m;
+  return BG_OK;
+}
+
+// d_org / d_bits: origins (bg_skm_extract_by_owner on the probes of the last step) and the owners' answers in
+// the same order.
+extern "C" int bg_corr_answers(bg_ctx* ctx, bg_correction* c, const uint64_t* d_org, const uint32_t* d_bits, uint64_t n) {
+  if (!ctx || !c || (n && (!d_org || !d_bits))) { set_error("bg_corr_answers: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  return skm_probe_answers(ctx, d_org, d_bits, n, c->pool.p, c->round_base, c->round_new);
+}
+
+extern "C" int bg_corr_finish(bg_ctx* ctx, bg_correction* c, bg_reads** out, bg_correct_stats* stats) {
+  if (!ctx || !c || !out) { set_error("bg_corr_finish: null argument"); return BG_EINVAL; }
+  if (c->n_pend) { set_error("bg_corr_finish: %llu reads still miss look-ups", (unsigned long long)c->n_pend); return BG_EINVAL; }
+  if (!c->out) { set_error("bg_corr_finish: already finished"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  const uint64_t n = c->reads->n;
+  DevBuf<CorrectTotals> tot;
+  BG_TRY(tot.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(tot.p, 0, sizeof(CorrectTotals), ctx->stream));
+  if (n) {
+    k_correct_stats<<<(cdiv(n, 256) < 2048u ? cdiv(n, 256) : 2048u), 256, 0, ctx->stream>>>(c->reads->len.p, c->out->len.p, n, c->k, tot.p);
+    BG_LAUNCH_CHECK();
+  }
+  CorrectCounters hc;
+  CorrectTotals ht;
+  BG_HIP(hipMemcpyAsync(&hc, c->ctr.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipMemcpyAsync(&ht, tot.p, sizeof ht, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  c->out->total_bases = ht.corrected_bases;
+  c->out->max_len = uint32_t(ht.max_len);
+  if (stats) {
+    stats->corrected_reads = ht.corrected_reads;
+    stats->corrected_bases = ht.corrected_bases;
+    stats->failed = ht.failed;
+    stats->modified = hc.modified;
+    stats->modified_bases = hc.modified_bases;
+    stats->truncated = ht.truncated;
+    stats->dropped_bases = ht.dropped_bases;
+  }
+  *out = c->out.release();
+  return BG_OK;
+}
+
+extern "C" uint64_t bg_corr_probes(const bg_correction* c) { return c ? c->probes : 0; }

@@ -98,8 +98,8 @@ __global__ void k_cover_insert(const uint64_t* __restrict__ skeys, const uint32_
 constexpr int kCoverChunk = 1024;  // oriented reads per wave
 
 __global__ __launch_bounds__(256) void k_cover_count(CoverIndex ci, const uint64_t* __restrict__ owords,
-                                                     const uint16_t* __restrict__ len, uint64_t o_base,
-                                                     uint64_t n_emit, int W, uint32_t* __restrict__ cnt) {
+                                                     uint64_t o_base, uint64_t n_emit, int W,
+                                                     uint32_t* __restrict__ cnt) {
   const int lane = threadIdx.x & 63;
   const uint64_t lane_lt = (1ull << lane) - 1;
   const uint64_t wave = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_cover_count(CoverIndex ci, const uint64
         if (mine < end) {
           t = mine;
           const uint64_t o = o_base + t;
-          L = len[o >> 1];
+          L = ci.olen[o];
           s = owords + o * uint64_t(W);
           j = 1;
           c = 1;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_cover_count(CoverIndex ci, const uint64
       const int rem = L - j;
       bool fin;
       if (rem < ci.K) { c += rem; fin = true; }
-      else if (cover_probe(ci, owords, len, s, L, j, W)) fin = true;
+      else if (cover_probe(ci, owords, s, L, j, W)) fin = true;
       else { ++c; ++j; fin = j >= L; }
       if (fin) { cnt[t] = uint32_t(c); active = false; }
     }
@@ -993,8 +993,57 @@ namespace bg {
 int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p, uint64_t n_rec, int W,
                       DevBuf<uint64_t>* k0, DevBuf<uint32_t>* sidx_out, uint64_t* n_tied_out);
 
+// Cover index over n_o oriented reads (owords: n_o x W zero-padded words, olen: their lengths).  The reads are
+// sorted by their full key (the machinery of the record sort): reads with the same first K-mer are then
+// consecutive AND in key order, so a look-up among the candidates of one K-mer is a binary search — a repeat
+// family puts thousands of reads behind one K-mer, and scanning them made the look-ups quadratic
+// (tools/stress_repeats.py: 3.5 s for a 20 Mb genome).  k0o (optional, consumed): sort keys written by whoever
+// made the oriented words.  The store keeps pointers into owords / olen: they must outlive it.
+int cover_index_build(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, uint64_t n_o, int W, int cover_k,
+                      DevBuf<uint64_t>* k0o, CoverStore* cs) {
+  if (n_o >= (1ull << 32)) { set_error("too many reads for one cover index (%llu oriented)", (unsigned long long)n_o); return BG_EINVAL; }
+  DevBuf<uint32_t> head_pos;
+  uint64_t m = 0, nheads = 0;  // reads that can act as a cover, distinct first K-mers
+  {
+    DevBuf<uint32_t> sidx_all, keep;
+    DevBuf<uint8_t> flags;
+    BG_TRY(sort_records_impl(ctx, owords, olen, n_o, W, k0o, &sidx_all, nullptr));
+    BG_TRY(flags.alloc(ctx, n_o));
+    if (n_o) {
+      k_flag_long_enough<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(sidx_all.p, olen, n_o, cover_k, flags.p);
+      BG_LAUNCH_CHECK();
+    }
+    BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, n_o, &keep, &m));
+    BG_TRY(cs->skeys.alloc(ctx, m));
+    BG_TRY(cs->soid.alloc(ctx, m));
+    if (m) {
+      k_cover_keys<<<cdiv(m, 256), 256, 0, ctx->stream>>>(sidx_all.p, keep.p, m, owords, W, cover_k, cs->skeys.p, cs->soid.p);
+      BG_LAUNCH_CHECK();
+      k_flag_key_heads<<<cdiv(m, 256), 256, 0, ctx->stream>>>(cs->skeys.p, m, flags.p);
+      BG_LAUNCH_CHECK();
+    }
+    BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, m, &head_pos, &nheads));
+  }
+  int lg = 10;
+  // load factor <= 0.7 (8-slot buckets keep chains short) rather than <= 0.5: half the table, which matters
+  // beyond 2 GiB where random probes fall off the TLB reach (tools/probe_rate.hip: 55 -> 22 G probes/s at 4 GiB)
+  while ((1ull << lg) * 7 < nheads * 10) ++lg;
+  BG_TRY(cs->slots.alloc(ctx, 1ull << lg));
+  BG_TRY(cs->vv.alloc(ctx, 1ull << lg));
+  BG_HIP(hipMemsetAsync(cs->slots.p, 0xff, (1ull << lg) * 8, ctx->stream));
+  if (nheads) {
+    k_cover_insert<<<cdiv(nheads, 256), 256, 0, ctx->stream>>>(cs->skeys.p, cs->soid.p, olen, m, head_pos.p, nheads, cs->slots.p,
+                                                               cs->vv.p, lg);
+    BG_LAUNCH_CHECK();
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));  // head_pos goes out of scope
+  cs->ci = CoverIndex{cs->slots.p, cs->vv.p, lg, cs->skeys.p, cs->soid.p, m, cover_k, olen};
+  cs->owords = owords;
+  return BG_OK;
+}
+
 // Phase A: suffix records of reads [lo, hi) under the exact-cover rule; the cover index spans ALL
-// reads of `reads` (in a sharded build every rank holds the gathered corrected reads).
+// reads of `reads`.
 int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t hi, int cover_k,
                         DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out, DevBuf<uint64_t>* k0) {
   const uint64_t n = reads->n;
@@ -1004,20 +1053,13 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   if (lo > hi || hi > n) { set_error("bad read range"); return BG_EINVAL; }
   const uint64_t o_base = 2 * lo, n_emit = 2 * (hi - lo);
   uint64_t n_rec = 0;
-  // ---- oriented reads + cover index.  The oriented reads are sorted by their full key (the machinery of the
-  // record sort): reads with the same first K-mer are then consecutive AND in key order, so a look-up among
-  // the candidates of one K-mer is a binary search — a repeat family puts thousands of reads behind one K-mer,
-  // and scanning them made the look-ups quadratic (tools/stress_repeats.py: 3.5 s for a 20 Mb genome).
-  DevBuf<uint64_t> owords, skeys_b;
-  DevBuf<uint32_t> soid_b, head_pos;
+  DevBuf<uint64_t> owords;
   DevBuf<uint8_t> olen;
   BG_TRY(owords.alloc(ctx, n_o * W));
   BG_TRY(olen.alloc(ctx, n_o));
-  uint64_t m = 0, nheads = 0;  // reads that can act as a cover, distinct first K-mers
+  CoverStore cs;
   {
     DevBuf<uint64_t> k0o;
-    DevBuf<uint32_t> sidx_all, keep;
-    DevBuf<uint8_t> flags;
     BG_TRY(k0o.alloc(ctx, n_o));
     if (n_o) {
       ctx->tic("suffix_oriented");
@@ -1025,38 +1067,9 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
       BG_LAUNCH_CHECK();
       ctx->toc(n * W * 8 + n_o * W * 8 + n_o * 9);
     }
-    BG_TRY(sort_records_impl(ctx, owords.p, olen.p, n_o, W, &k0o, &sidx_all, nullptr));
-    BG_TRY(flags.alloc(ctx, n_o));
-    if (n_o) {
-      k_flag_long_enough<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(sidx_all.p, olen.p, n_o, cover_k, flags.p);
-      BG_LAUNCH_CHECK();
-    }
-    BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, n_o, &keep, &m));
-    BG_TRY(skeys_b.alloc(ctx, m));
-    BG_TRY(soid_b.alloc(ctx, m));
-    if (m) {
-      k_cover_keys<<<cdiv(m, 256), 256, 0, ctx->stream>>>(sidx_all.p, keep.p, m, owords.p, W, cover_k, skeys_b.p, soid_b.p);
-      BG_LAUNCH_CHECK();
-      k_flag_key_heads<<<cdiv(m, 256), 256, 0, ctx->stream>>>(skeys_b.p, m, flags.p);
-      BG_LAUNCH_CHECK();
-    }
-    BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, m, &head_pos, &nheads));
+    BG_TRY(cover_index_build(ctx, owords.p, olen.p, n_o, W, cover_k, &k0o, &cs));
   }
-  uint64_t* skeys = skeys_b.p;
-  uint32_t* soid = soid_b.p;
-  int lg = 10;
-  // load factor <= 0.7 (8-slot buckets keep chains short) rather than <= 0.5: half the table, which matters
-  // beyond 2 GiB where random probes fall off the TLB reach (tools/probe_rate.hip: 55 -> 22 G probes/s at 4 GiB)
-  while ((1ull << lg) * 7 < nheads * 10) ++lg;
-  DevBuf<uint64_t> slots, vv;
-  BG_TRY(slots.alloc(ctx, 1ull << lg));
-  BG_TRY(vv.alloc(ctx, 1ull << lg));
-  BG_HIP(hipMemsetAsync(slots.p, 0xff, (1ull << lg) * 8, ctx->stream));
-  if (nheads) {
-    k_cover_insert<<<cdiv(nheads, 256), 256, 0, ctx->stream>>>(skeys, soid, olen.p, m, head_pos.p, nheads, slots.p, vv.p, lg);
-    BG_LAUNCH_CHECK();
-  }
-  CoverIndex ci{slots.p, vv.p, lg, skeys, soid, m, cover_k};
+  const CoverIndex ci = cs.ci;
 
   // ---- emission
   DevBuf<uint32_t> cnt;
@@ -1066,8 +1079,7 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   BG_TRY(total.alloc(ctx, 1));
   if (n_emit) {
     ctx->tic("suffix_cover_count");
-    k_cover_count<<<cdiv(cdiv(n_emit, kCoverChunk), 4), 256, 0, ctx->stream>>>(ci, owords.p, reads->len.p, o_base, n_emit, W,
-                                                                             cnt.p);
+    k_cover_count<<<cdiv(cdiv(n_emit, kCoverChunk), 4), 256, 0, ctx->stream>>>(ci, owords.p, o_base, n_emit, W, cnt.p);
     BG_LAUNCH_CHECK();
     ctx->toc(n_emit * W * 8 * 2);
   }

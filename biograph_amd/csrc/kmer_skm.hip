@@ -1057,3 +1057,125 @@ extern "C" int bg_kmerset_attach_presence(bg_ctx* ctx, bg_kmerset* ks, const bg_
   ks->present_n = reads->n;
   return BG_OK;
 }
+
+// ---- sharded build, routed look-ups: the kept k-mers stay with the rank that counted them ---------------
+
+namespace bg {
+
+// bits_out[i] bit t = window t of record i is in the set (the owner's answer to a probe record; with
+// only_unknown, just the records its counting table gave up on — bits_out[i] & kSkUnknown — are looked up)
+__global__ void sk_lookup_bits_kernel(const SkRec* __restrict__ recs, uint64_t n_rec, int k, const uint64_t* __restrict__ slots,
+                                      int log2cap, uint32_t* __restrict__ bits_out, int only_unknown) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_rec) return;
+  if (only_unknown && !(bits_out[i] & kSkUnknown)) return;
+  const SkRec r = recs[i];
+  const int n = sk_windows(r.b);
+  KmerTable tab{slots, log2cap, k};
+  const uint64_t kmask = ~(~0ull << (2 * k));
+  uint64_t fwd = r.a >> (64 - 2 * k);
+  uint64_t rc = kmer_revcomp(fwd, k);
+  uint32_t bits = 0;
+  for (int t = 0; t < n; ++t) {
+    if (tab.find(rc < fwd ? rc : fwd) >= 0) bits |= 1u << t;
+    const int idx = k + t;
+    const uint64_t base = idx < 32 ? (r.a >> (62 - 2 * idx)) & 3 : (r.b >> (62 - 2 * (idx - 32))) & 3;
+    fwd = ((fwd << 2) | base) & kmask;
+    rc = (rc >> 2) | ((3 - base) << (2 * (k - 1)));
+  }
+  bits_out[i] = bits;
+}
+
+// presence bits of a rank's own records as their owners returned them (every record known)
+__global__ void sk_present_from_bits_kernel(const SkRec* __restrict__ recs, const uint64_t* __restrict__ org,
+                                            const uint32_t* __restrict__ bits_in, uint64_t n_rec,
+                                            unsigned long long* __restrict__ present, int pstride, uint32_t* __restrict__ err) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_rec) return;
+  const uint32_t bits = bits_in[i];
+  if (bits & kSkUnknown) { atomicOr(err, 1u); return; }
+  if (!bits) return;
+  const int n = sk_windows(recs[i].b);
+  const uint64_t o = org[i];
+  const uint64_t read = o >> 8;
+  const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
+  atomicOr(&present[read * pstride + wi], (unsigned long long)bits << sh);
+  if (sh + n > 64) atomicOr(&present[read * pstride + wi + 1], (unsigned long long)bits >> (64 - sh));
+}
+
+// answers of a probe exchange: record i covers windows s0.. of probe string p (origin = p << 8 | s0); string
+// 4 d + b belongs to alternative b of probe base + d
+__global__ void sk_probe_answers_kernel(const uint64_t* __restrict__ org, const uint32_t* __restrict__ bits_in, uint64_t n_rec,
+                                        ProbeDesc* __restrict__ pool, uint64_t base, uint64_t n_probes, uint32_t* __restrict__ err) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_rec) return;
+  const uint32_t bits = bits_in[i];
+  const uint64_t o = org[i];
+  const uint64_t p = o >> 8;
+  const int s0 = int(o & 0xff);
+  if ((bits & kSkUnknown) || (p >> 2) >= n_probes || s0 > 31) { atomicOr(err, 1u); return; }
+  if (bits) atomicOr(&pool[base + (p >> 2)].mask[p & 3], bits << s0);
+}
+
+int skm_presence_from_bits(bg_ctx* ctx, const bg_reads* reads, int k, const uint64_t* d_recs, const uint64_t* d_org,
+                           const uint32_t* d_bits, uint64_t n, DevBuf<uint64_t>* present, int* stride) {
+  const int maxw = int(reads->max_len) - k + 1;
+  *stride = std::max(1, (maxw + 63) / 64);
+  BG_TRY(present->alloc(ctx, reads->n * uint64_t(*stride)));
+  BG_HIP(hipMemsetAsync(present->p, 0, reads->n * uint64_t(*stride) * 8, ctx->stream));
+  DevBuf<uint32_t> err;
+  BG_TRY(err.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+  if (n) {
+    sk_present_from_bits_kernel<<<cdiv(n, 256), 256, 0, ctx->stream>>>(reinterpret_cast<const SkRec*>(d_recs), d_org, d_bits, n,
+                                                                     reinterpret_cast<unsigned long long*>(present->p), *stride, err.p);
+    BG_LAUNCH_CHECK();
+  }
+  uint32_t h_err = 0;
+  BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_err) { set_error("presence bits: a record came back unresolved (the owner must look it up: bg_skm_lookup)"); return BG_EINVAL; }
+  return BG_OK;
+}
+
+int skm_probe_answers(bg_ctx* ctx, const uint64_t* d_org, const uint32_t* d_bits, uint64_t n, ProbeDesc* pool, uint64_t base,
+                      uint64_t n_probes) {
+  if (!n) return BG_OK;
+  DevBuf<uint32_t> err;
+  BG_TRY(err.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+  sk_probe_answers_kernel<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_org, d_bits, n, pool, base, n_probes, err.p);
+  BG_LAUNCH_CHECK();
+  uint32_t h_err = 0;
+  BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_err) { set_error("probe answers do not match the probes in flight"); return BG_EINVAL; }
+  return BG_OK;
+}
+
+int kmer_hash_build_impl(bg_ctx* ctx, bg_kmerset* ks, const bg_reads* reads);
+
+}  // namespace bg
+
+extern "C" int bg_kmerset_build_hash(bg_ctx* ctx, bg_kmerset* ks) {
+  if (!ctx || !ks) { set_error("bg_kmerset_build_hash: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (ks->slots.p) return BG_OK;
+  return kmer_hash_build_impl(ctx, ks, nullptr);
+}
+
+extern "C" int bg_skm_lookup(bg_ctx* ctx, const bg_kmerset* ks, const uint64_t* d_recs, uint64_t n, uint32_t* d_bits,
+                             int only_unknown) {
+  if (!ctx || !ks || (n && (!d_recs || !d_bits))) { set_error("bg_skm_lookup: null argument"); return BG_EINVAL; }
+  if (!ks->slots.p) { set_error("bg_skm_lookup: the k-mer set has no hash table (bg_kmerset_build_hash)"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (n) {
+    ctx->tic("kmer_probe_lookup");
+    sk_lookup_bits_kernel<<<cdiv(n, 256), 256, 0, ctx->stream>>>(reinterpret_cast<const SkRec*>(d_recs), n, ks->k, ks->slots.p,
+                                                               ks->log2cap, d_bits, only_unknown);
+    BG_LAUNCH_CHECK();
+    ctx->toc(n * 20);
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}

@@ -39,7 +39,8 @@ __global__ void k_dest_prefix(const uint64_t* __restrict__ rows, uint64_t n, int
   uint32_t bin = uint32_t(rows[i * row_words] >> (64 - 2 * hb));
   uint32_t d = 0;
   for (uint32_t s = 0; s + 1 < nparts; ++s) d += (splitters[s] <= bin) ? 1u : 0u;
-  dest[i] = d;
+  // a row of length 0 is nothing (a dropped read, an unused candidate slot): it goes nowhere
+  dest[i] = (rows[i * row_words + row_words - 1] & 0xff) ? uint64_t(d) : kDropDest;
   idx[i] = uint32_t(i);
 }
 

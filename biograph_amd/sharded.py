@@ -260,10 +260,210 @@ def _relieve(ctxs, dev):
             c.trim()
 
 
-def sharded_create(comm, ctxs, inputs, params=None, device=None):
-    """comm: communicator; ctxs[r]: biograph_amd.Context of local rank r; inputs[r] = (seq uint8 tensor,
-    offs int64 tensor, n_reads) resident on that rank's device.  Returns {r: (Seqset | None, stats)};
-    the assembled seqset lives on rank 0."""
+# suffix offsets at which a new round of cover candidates starts (the last round runs to the longest read):
+# most reads are covered within a few bases at 30x, so early rounds are narrow and few reads reach the late ones
+COVER_ROUNDS = "1,5,13,29,61,256"
+
+
+def _all_sum(comm, vals):
+    """Sum of one python int per local rank over all ranks."""
+    lst = comm.all_gather_obj(vals)[comm.local_ranks[0]]
+    return sum(int(x) for x in lst)
+
+
+def _skm_extract(ctx, reads_h, k, P, dev):
+    """Super-k-mer records of a reads object grouped by owner rank -> (recs [n,2], org [n], counts)."""
+    L = capi.lib()
+    n = C.c_uint64()
+    capi.check(L.bg_kmer_instances(ctx.h, reads_h, k, C.byref(n)))
+    cap = C.c_uint64()
+    capi.check(L.bg_skm_capacity(ctx.h, reads_h, k, n.value, C.byref(cap)))
+    recs = torch.empty((max(cap.value, 1), 2), dtype=torch.int64, device=dev)
+    org = torch.empty((max(cap.value, 1),), dtype=torch.int64, device=dev)
+    counts = (C.c_uint64 * P)()
+    nrec = C.c_uint64()
+    if cap.value:
+        capi.check(L.bg_skm_extract_by_owner(ctx.h, reads_h, k, n.value, P, _ptr(recs), _ptr(org), cap.value, counts,
+                                             C.byref(nrec)))
+    return recs[:nrec.value], org[:nrec.value], [int(c) for c in counts], n.value
+
+
+def _correct_routed(comm, ctxs, reads, owned, skm_recs, skm_org, skm_bits, prm, dev, ph):
+    """Read correction with the kept k-mers left on their owner ranks: every rank searches
+    its own reads; the k-mers a search needs beyond the read's own windows travel as probe strings to their
+    owners and come back as presence bits, one exchange per step, until no read misses a look-up."""
+    L = capi.lib()
+    P = comm.world
+    ranks = comm.local_ranks
+    k = prm.kmer_size
+    corr = {}
+    for r in ranks:
+        h = C.c_void_p()
+        b = skm_bits[r].contiguous().view(-1)
+        capi.check(L.bg_corr_begin(ctxs[r].h, reads[r].h, k, C.byref(prm.correct), _ptr(skm_recs[r]), _ptr(skm_org[r]),
+                                   _ptr(b), b.shape[0], C.byref(h)))
+        corr[r] = h
+    steps = 0
+    while True:
+        ph.mark("correct_step")
+        probes, pend = {}, {}
+        for r in ranks:
+            npend = C.c_uint64()
+            pr = C.c_void_p()
+            capi.check(L.bg_corr_step(ctxs[r].h, corr[r], C.byref(npend), C.byref(pr)))
+            pend[r] = npend.value
+            probes[r] = pr
+        steps += 1
+        if _all_sum(comm, pend) == 0:
+            break
+        ph.mark("correct_probe_exchange")
+        send, porg = {}, {}
+        for r in ranks:
+            if probes[r]:
+                recs, org, counts, _ = _skm_extract(ctxs[r], probes[r], k, P, dev[r])
+                L.bg_reads_free(probes[r])
+            else:
+                recs = torch.empty((0, 2), dtype=torch.int64, device=dev[r])
+                org = torch.empty((0,), dtype=torch.int64, device=dev[r])
+                counts = [0] * P
+            send[r] = (recs, counts)
+            porg[r] = org
+        recv = comm.all_to_all_v(send)
+        sent_counts = comm.all_gather_obj({r: send[r][1] for r in ranks})[ranks[0]]
+        back = {}
+        for r in ranks:
+            rows = recv[r].contiguous()
+            bits = torch.empty((max(rows.shape[0], 1),), dtype=torch.int32, device=dev[r])
+            capi.check(L.bg_skm_lookup(ctxs[r].h, owned[r].h, _ptr(rows), rows.shape[0], _ptr(bits), 0))
+            back[r] = (bits[:rows.shape[0]].view(-1, 1), [int(sent_counts[s][r]) for s in range(P)])
+        ans = comm.all_to_all_v(back)
+        for r in ranks:
+            a = ans[r].contiguous().view(-1)
+            capi.check(L.bg_corr_answers(ctxs[r].h, corr[r], _ptr(porg[r]), _ptr(a), a.shape[0]))
+        del send, recv, back, ans, porg
+    corrected, cstats, nprobes = {}, {}, {}
+    import biograph_amd as bg
+    for r in ranks:
+        h = C.c_void_p()
+        st = capi.CorrectStats()
+        capi.check(L.bg_corr_finish(ctxs[r].h, corr[r], C.byref(h), C.byref(st)))
+        nprobes[r] = int(L.bg_corr_probes(corr[r]))
+        L.bg_corr_free(corr[r])
+        corrected[r] = bg.Reads(ctxs[r], h)
+        cstats[r] = {n: int(getattr(st, n)) for n, _ in st._fields_}
+    return corrected, cstats, steps, nprobes
+
+
+def _records_sharded_cover(comm, ctxs, corrected, W, k, dev, ph):
+    """Suffix records of a sharded build without a replicated cover index (csrc/shard_cover.hip): oriented reads
+    and candidate suffixes meet on the rank that owns their leading bases.  Returns ({r: record rows}, n_records)."""
+    L = capi.lib()
+    P = comm.world
+    ranks = comm.local_ranks
+    i64 = torch.int64
+    rw = W + 1
+    ph.mark("cover_oriented_rows")
+    rows, hists, qs = {}, {}, {}
+    for r in ranks:
+        n = len(corrected[r])
+        rows[r] = torch.empty((2 * n, rw), dtype=i64, device=dev[r])
+        capi.check(L.bg_oriented_rows(ctxs[r].h, corrected[r].h, W, _ptr(rows[r])))
+        corrected[r].free()
+        hists[r] = torch.empty((4 ** PREFIX_BASES,), dtype=i64, device=dev[r])
+        capi.check(L.bg_rows_prefix_hist(ctxs[r].h, _ptr(rows[r]), 2 * n, rw, PREFIX_BASES, PREFIX_SAMPLE, _ptr(hists[r])))
+        qh = C.c_void_p()
+        capi.check(L.bg_cover_query_begin(ctxs[r].h, _ptr(rows[r]), 2 * n, W, k, C.byref(qh)))
+        qs[r] = qh
+    gh = comm.all_reduce_sum(hists)[ranks[0]].cpu().numpy()
+    pparams = [PREFIX_BASES] + choose_splitters(gh, P)
+    ph.mark("cover_index_exchange")
+    send = {r: _partition(ctxs[r], rows[r], capi.PART_PREFIX, P, pparams) for r in ranks}
+    del rows, hists
+    recv = comm.all_to_all_v(send)
+    del send
+    _relieve(ctxs, dev)
+    ph.mark("cover_index_build")
+    covers, parts = {}, {}
+    for r in ranks:
+        t = recv[r].contiguous()
+        ch = C.c_void_p()
+        capi.check(L.bg_cover_build(ctxs[r].h, _ptr(t), t.shape[0], W, k, C.byref(ch)))
+        covers[r] = ch
+        parts[r] = [t]  # the oriented reads a rank indexes are its j = 0 records
+    del recv
+    bounds = [int(x) for x in os.environ.get("BG_COVER_ROUNDS", COVER_ROUNDS).split(",")]
+    if bounds[-1] < 256:
+        bounds.append(256)
+    for j_lo, j_hi in zip(bounds[:-1], bounds[1:]):
+        ph.mark("cover_round_%d" % j_lo)
+        pend = {r: int(L.bg_cover_query_pending(qs[r])) for r in ranks}
+        if _all_sum(comm, pend) == 0:
+            break
+        cand = {}
+        for r in ranks:
+            cap = pend[r] * (j_hi - j_lo)
+            t = torch.empty((max(cap, 1), rw), dtype=i64, device=dev[r])
+            n = C.c_uint64()
+            capi.check(L.bg_cover_query_candidates(ctxs[r].h, qs[r], j_lo, j_hi, _ptr(t), cap, C.byref(n)))
+            cand[r] = _partition(ctxs[r], t[:n.value], capi.PART_PREFIX, P, pparams)
+            del t
+        got = comm.all_to_all_v(cand)
+        sent_counts = comm.all_gather_obj({r: cand[r][1] for r in ranks})[ranks[0]]
+        back = {}
+        for r in ranks:
+            t = got[r].contiguous()
+            got[r] = t
+            cv = torch.empty((max(t.shape[0], 1),), dtype=torch.uint8, device=dev[r])
+            capi.check(L.bg_cover_test(ctxs[r].h, covers[r], _ptr(t), t.shape[0], _ptr(cv)))
+            back[r] = (cv[:t.shape[0]].view(-1, 1), [int(sent_counts[s][r]) for s in range(P)])
+        ans = comm.all_to_all_v(back)
+        keep_send = {}
+        for r in ranks:
+            a = ans[r].contiguous().view(-1)
+            sent = cand[r][0]
+            kp = torch.empty((max(sent.shape[0], 1),), dtype=torch.uint8, device=dev[r])
+            capi.check(L.bg_cover_query_answers(ctxs[r].h, qs[r], _ptr(sent), _ptr(a), sent.shape[0], _ptr(kp)))
+            keep_send[r] = (kp[:sent.shape[0]].view(-1, 1), cand[r][1])
+        keeps = comm.all_to_all_v(keep_send)
+        for r in ranks:
+            m = keeps[r].view(-1) != 0
+            parts[r].append(got[r][m])
+        del cand, got, back, ans, keep_send, keeps
+        _relieve(ctxs, dev)
+    ph.mark("cover_plain_tails")
+    pend = {r: int(L.bg_cover_query_pending(qs[r])) for r in ranks}
+    if _all_sum(comm, pend) and k > 1:
+        plain = {}
+        for r in ranks:
+            cap = pend[r] * (k - 1)
+            t = torch.empty((max(cap, 1), rw), dtype=i64, device=dev[r])
+            n = C.c_uint64()
+            capi.check(L.bg_cover_query_plain(ctxs[r].h, qs[r], _ptr(t), cap, C.byref(n)))
+            plain[r] = _partition(ctxs[r], t[:n.value], capi.PART_PREFIX, P, pparams)
+            del t
+        got = comm.all_to_all_v(plain)
+        for r in ranks:
+            parts[r].append(got[r])
+        del plain, got
+    out = {}
+    for r in ranks:
+        L.bg_cover_query_free(qs[r])
+        L.bg_cover_free(covers[r])
+        out[r] = torch.cat(parts[r], dim=0).contiguous() if len(parts[r]) > 1 else parts[r][0]
+    del parts
+    n_records = _all_sum(comm, {r: out[r].shape[0] for r in ranks})
+    return out, n_records
+
+
+def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None):
+    """comm: communicator; ctxs[r]: biograph_amd.Context of local rank r (its HIP stream must be torch's current
+    stream on that device: the exchange buffers are torch tensors handed to the library by pointer); inputs[r] =
+    (seq uint8 tensor, offs int64 tensor, n_reads) resident on that rank's device.  Returns {r: (Seqset | None,
+    stats)}; the assembled seqset lives on rank 0.
+
+    mode "routed" (default; k >= 14): nothing is replicated — the kept k-mers stay with the rank that counted
+    them and the cover index is range-partitioned like the records; "replicated" (BG_SHARD_REPLICATED=1, and
+    what k < 14 falls back to): kept k-mers and corrected reads are all-gathered on every rank."""
     import biograph_amd as bg
     L = capi.lib()
     P = comm.world
@@ -273,6 +473,12 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
     k = prm.kmer_size
     dev = {r: inputs[r][0].device for r in ranks}
     i64 = torch.int64
+    for r in ranks:
+        if dev[r].type == "cuda" and ctxs[r].stream is not None:
+            cur = torch.cuda.current_stream(dev[r]).cuda_stream
+            if int(ctxs[r].stream or 0) != int(cur or 0):
+                raise ValueError("sharded_create: the Context of rank %d runs on another HIP stream than torch's current "
+                                 "one — the exchange buffers would be read before they are complete" % r)
 
     ph = _Phases()
     ph.mark("pack")
@@ -285,28 +491,26 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
     # ---- S2 windows -> owner ranks: super-k-mer records (16 B per ~10 windows) when the k-mer size allows a
     # 12-base minimiser, else k-mer instances (8 B per window)
     use_skm = bool(L.bg_skm_supported(k)) and not os.environ.get("BG_KMER_SKM") == "0"
+    if mode is None:
+        mode = "replicated" if os.environ.get("BG_SHARD_REPLICATED") == "1" else "routed"
+    if not use_skm:
+        mode = "replicated"
     send = {}
     n_inst = {}
     skm_org = {}
     skm_recs = {}
     for r in ranks:
-        n = C.c_uint64()
-        capi.check(L.bg_kmer_instances(ctxs[r].h, reads[r].h, k, C.byref(n)))
-        n_inst[r] = n.value
         counts = (C.c_uint64 * P)()
         if use_skm:
-            cap = C.c_uint64()
-            capi.check(L.bg_skm_capacity(ctxs[r].h, reads[r].h, k, n.value, C.byref(cap)))
-            recs = torch.empty((max(cap.value, 1), 2), dtype=i64, device=dev[r])
-            org = torch.empty((max(cap.value, 1),), dtype=i64, device=dev[r])
-            nrec = C.c_uint64()
-            capi.check(L.bg_skm_extract_by_owner(ctxs[r].h, reads[r].h, k, n.value, P, _ptr(recs), _ptr(org), cap.value,
-                                                 counts, C.byref(nrec)))
-            recs = recs[:nrec.value]
+            recs, org, cnts, n = _skm_extract(ctxs[r], reads[r].h, k, P, dev[r])
+            n_inst[r] = n
             skm_recs[r] = recs
-            skm_org[r] = org[:nrec.value]
-            send[r] = (recs, [int(c) for c in counts])
+            skm_org[r] = org
+            send[r] = (recs, cnts)
         else:
+            n = C.c_uint64()
+            capi.check(L.bg_kmer_instances(ctxs[r].h, reads[r].h, k, C.byref(n)))
+            n_inst[r] = n.value
             keys = torch.empty((n.value, 1), dtype=i64, device=dev[r])
             # extraction + owner partition in one pass: whole hash-byte buckets go to their owner rank
             capi.check(L.bg_kmer_extract_by_owner(ctxs[r].h, reads[r].h, k, P, _ptr(keys), n.value, counts))
@@ -318,7 +522,9 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
     del send
     ph.mark("kmer_count")
     kept = {}
+    owned = {}
     distinct = {}
+    n_kept_local = {}
     bits_back = {}
     for r in ranks:
         keys = recv[r].contiguous()
@@ -332,94 +538,117 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
             capi.check(L.bg_kmer_count_keys(ctxs[r].h, _ptr(keys), keys.shape[0], k, prm.min_kmer_count, C.byref(h)))
         ks = bg.KmerSet(ctxs[r], h, k)
         distinct[r] = ks.distinct
-        t = torch.empty((len(ks),), dtype=i64, device=dev[r])
-        capi.check(L.bg_kmerset_export(ctxs[r].h, ks.h, _ptr(t)))
-        kept[r] = t
-        ks.free()
+        n_kept_local[r] = len(ks)
+        if mode == "routed":
+            # the owner keeps its k-mers (hash set) and settles the records its counting tables gave up on
+            capi.check(L.bg_kmerset_build_hash(ctxs[r].h, ks.h))
+            capi.check(L.bg_skm_lookup(ctxs[r].h, ks.h, _ptr(keys), keys.shape[0], _ptr(bits), 1))
+            owned[r] = ks
+        else:
+            t = torch.empty((len(ks),), dtype=i64, device=dev[r])
+            capi.check(L.bg_kmerset_export(ctxs[r].h, ks.h, _ptr(t)))
+            kept[r] = t
+            ks.free()
     del recv
     skm_bits = comm.all_to_all_v(bits_back) if use_skm else None
     del bits_back
-    ph.mark("kmerset_all_gather_build")
-    _relieve(ctxs, dev)
-    gathered = comm.all_gather_v(kept)
     tot_inst = sum(comm.all_gather_obj(n_inst)[ranks[0]])
     tot_distinct = sum(comm.all_gather_obj(distinct)[ranks[0]])
-    ksets = {}
-    for r in ranks:
-        allk = torch.cat([g.to(dev[r]) for g in gathered[r]]).contiguous()
-        h = C.c_void_p()
-        capi.check(L.bg_kmerset_from_kmers(ctxs[r].h, _ptr(allk), allk.shape[0], k, reads[r].h, C.byref(h)))
-        ksets[r] = bg.KmerSet(ctxs[r], h, k)
-        n_kept = allk.shape[0]
-        if use_skm:  # window presence of this rank's reads: the correction looks nothing up
-            b = skm_bits[r].contiguous().view(-1)
-            capi.check(L.bg_kmerset_attach_presence(ctxs[r].h, h, reads[r].h, _ptr(skm_recs[r]), _ptr(skm_org[r]), _ptr(b),
-                                                    b.shape[0]))
-    del gathered, kept, skm_bits, skm_recs, skm_org
+    n_kept = _all_sum(comm, n_kept_local)
+    extra_stats = {"mode": mode}
 
-    ph.mark("correct")
-    # ---- S3 correction (local, replicated k-mer set)
-    corrected = {}
-    cstats = {}
-    for r in ranks:
-        corrected[r], cstats[r] = ctxs[r].correct_reads(reads[r], ksets[r], prm.correct.max_corrections,
-                                                        prm.correct.min_good_run, prm.correct.trim_after_portion)
-        reads[r].free()
-        ksets[r].free()
+    if mode == "routed":
+        _relieve(ctxs, dev)
+        corrected, cstats, steps, nprobes = _correct_routed(comm, ctxs, reads, owned, skm_recs, skm_org, skm_bits, prm,
+                                                            dev, ph)
+        for r in ranks:
+            reads[r].free()
+            owned[r].free()
+        del skm_bits, skm_recs, skm_org
+        extra_stats["correct_steps"] = steps
+        extra_stats["correct_probes"] = _all_sum(comm, nprobes)
+    else:
+        ph.mark("kmerset_all_gather_build")
+        _relieve(ctxs, dev)
+        gathered = comm.all_gather_v(kept)
+        ksets = {}
+        for r in ranks:
+            allk = torch.cat([g.to(dev[r]) for g in gathered[r]]).contiguous()
+            h = C.c_void_p()
+            capi.check(L.bg_kmerset_from_kmers(ctxs[r].h, _ptr(allk), allk.shape[0], k, reads[r].h, C.byref(h)))
+            ksets[r] = bg.KmerSet(ctxs[r], h, k)
+            if use_skm:  # window presence of this rank's reads: the correction looks nothing up
+                b = skm_bits[r].contiguous().view(-1)
+                capi.check(L.bg_kmerset_attach_presence(ctxs[r].h, h, reads[r].h, _ptr(skm_recs[r]), _ptr(skm_org[r]),
+                                                        _ptr(b), b.shape[0]))
+        del gathered, kept, skm_bits, skm_recs, skm_org
+
+        ph.mark("correct")
+        # ---- S3 correction (local, replicated k-mer set)
+        corrected = {}
+        cstats = {}
+        for r in ranks:
+            corrected[r], cstats[r] = ctxs[r].correct_reads(reads[r], ksets[r], prm.correct.max_corrections,
+                                                            prm.correct.min_good_run, prm.correct.trim_after_portion)
+            reads[r].free()
+            ksets[r].free()
     all_cs = comm.all_gather_obj(cstats)[ranks[0]]
     max_len = max(comm.all_gather_obj({r: int(corrected[r].max_len) for r in ranks})[ranks[0]])
     W = max(1, (max_len + 31) // 32)
 
-    ph.mark("reads_all_gather")
     _relieve(ctxs, dev)
-    # ---- corrected reads replicated (cover index spans all reads)
-    words, lens = {}, {}
-    for r in ranks:
-        n = len(corrected[r])
-        words[r] = torch.empty((n, W), dtype=i64, device=dev[r])
-        lens[r] = torch.empty((n, 2), dtype=torch.uint8, device=dev[r])  # u16 lengths as bytes (RCCL has no int16)
-        capi.check(L.bg_reads_export(ctxs[r].h, corrected[r].h, W, _ptr(words[r]), _ptr(lens[r])))
-        corrected[r].free()
-    gw = comm.all_gather_v(words)
-    gl = comm.all_gather_v(lens)
-    del words, lens
-    ph.mark("suffix_records")
-    send = {}
-    hists = {}
-    for r in ranks:
-        aw = torch.cat([g.to(dev[r]) for g in gw[r]]).contiguous()
-        al = torch.cat([g.to(dev[r]) for g in gl[r]]).contiguous()
-        counts = [g.shape[0] for g in gl[r]]
-        lo = sum(counts[:r])
-        hi = lo + counts[r]
-        h = C.c_void_p()
-        capi.check(L.bg_reads_import(ctxs[r].h, aw.shape[0], W, max_len, _ptr(aw), _ptr(al), C.byref(h)))
-        all_reads = bg.Reads(ctxs[r], h)
-        del aw, al
-        # ---- S4 suffix records of own reads
-        rh = C.c_void_p()
-        capi.check(L.bg_suffix_records(ctxs[r].h, all_reads.h, lo, hi, k, C.byref(rh)))
-        all_reads.free()
-        n_rec = L.bg_records_count(rh)
-        rows = torch.empty((n_rec, W + 1), dtype=i64, device=dev[r])
-        capi.check(L.bg_records_rows(ctxs[r].h, rh, _ptr(rows)))
-        hists[r] = torch.empty((4 ** PREFIX_BASES + 1,), dtype=i64, device=dev[r])
-        capi.check(L.bg_records_prefix_hist(ctxs[r].h, rh, PREFIX_BASES, PREFIX_SAMPLE, _ptr(hists[r])))
-        hists[r][-1] = n_rec  # the record total rides along with the bins
-        L.bg_records_free(rh)
-        send[r] = rows
-    del gw, gl
-    ph.mark("records_partition")
-    _relieve(ctxs, dev)
-    ghist = comm.all_reduce_sum(hists)
-    gh = ghist[ranks[0]].cpu().numpy()
-    splitters = choose_splitters(gh[:-1], P)
-    n_records = int(gh[-1])
-    for r in ranks:
-        send[r] = _partition(ctxs[r], send[r], capi.PART_PREFIX, P, [PREFIX_BASES] + splitters)
-    ph.mark("records_all_to_all")
-    recv = comm.all_to_all_v(send)
-    del send
+    if mode == "routed":
+        recv, n_records = _records_sharded_cover(comm, ctxs, corrected, W, k, dev, ph)
+    else:
+        ph.mark("reads_all_gather")
+        # ---- corrected reads replicated (cover index spans all reads)
+        words, lens = {}, {}
+        for r in ranks:
+            n = len(corrected[r])
+            words[r] = torch.empty((n, W), dtype=i64, device=dev[r])
+            lens[r] = torch.empty((n, 2), dtype=torch.uint8, device=dev[r])  # u16 lengths as bytes (RCCL has no int16)
+            capi.check(L.bg_reads_export(ctxs[r].h, corrected[r].h, W, _ptr(words[r]), _ptr(lens[r])))
+            corrected[r].free()
+        gw = comm.all_gather_v(words)
+        gl = comm.all_gather_v(lens)
+        del words, lens
+        ph.mark("suffix_records")
+        send = {}
+        hists = {}
+        for r in ranks:
+            aw = torch.cat([g.to(dev[r]) for g in gw[r]]).contiguous()
+            al = torch.cat([g.to(dev[r]) for g in gl[r]]).contiguous()
+            counts = [g.shape[0] for g in gl[r]]
+            lo = sum(counts[:r])
+            hi = lo + counts[r]
+            h = C.c_void_p()
+            capi.check(L.bg_reads_import(ctxs[r].h, aw.shape[0], W, max_len, _ptr(aw), _ptr(al), C.byref(h)))
+            all_reads = bg.Reads(ctxs[r], h)
+            del aw, al
+            # ---- S4 suffix records of own reads
+            rh = C.c_void_p()
+            capi.check(L.bg_suffix_records(ctxs[r].h, all_reads.h, lo, hi, k, C.byref(rh)))
+            all_reads.free()
+            n_rec = L.bg_records_count(rh)
+            rows = torch.empty((n_rec, W + 1), dtype=i64, device=dev[r])
+            capi.check(L.bg_records_rows(ctxs[r].h, rh, _ptr(rows)))
+            hists[r] = torch.empty((4 ** PREFIX_BASES + 1,), dtype=i64, device=dev[r])
+            capi.check(L.bg_records_prefix_hist(ctxs[r].h, rh, PREFIX_BASES, PREFIX_SAMPLE, _ptr(hists[r])))
+            hists[r][-1] = n_rec  # the record total rides along with the bins
+            L.bg_records_free(rh)
+            send[r] = rows
+        del gw, gl
+        ph.mark("records_partition")
+        _relieve(ctxs, dev)
+        ghist = comm.all_reduce_sum(hists)
+        gh = ghist[ranks[0]].cpu().numpy()
+        splitters = choose_splitters(gh[:-1], P)
+        n_records = int(gh[-1])
+        for r in ranks:
+            send[r] = _partition(ctxs[r], send[r], capi.PART_PREFIX, P, [PREFIX_BASES] + splitters)
+        ph.mark("records_all_to_all")
+        recv = comm.all_to_all_v(send)
+        del send
     ph.mark("entries_from_records")
     shards = {}
     for r in ranks:
@@ -496,6 +725,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None):
              "n_corrected_reads": sum(c["corrected_reads"] for c in all_cs),
              "n_corrected_bases": sum(c["corrected_bases"] for c in all_cs), "n_records": n_records,
              "n_entries": n_entries, "max_len": max_len, "shard_entries": part_n}
+    stats.update(extra_stats)
     out = {}
     for r in ranks:
         if r != 0:

@@ -455,6 +455,59 @@ int bg_seqset_slice_export(bg_ctx* ctx, const bg_seqset* ss, uint8_t* d_sizes, u
 int bg_seqset_assemble(bg_ctx* ctx, uint32_t nparts, const uint64_t* h_part_n, const uint8_t* d_sizes,
                        const uint8_t* d_shared, const uint64_t* d_bits, uint32_t max_len, bg_seqset** out);
 
+/* ---- Routed read correction of the sharded build: the kept k-mers stay with the rank that counted them (a
+ * k-mer lives in ONE partition, kmer_counter.h:167-178) instead of being gathered on every rank.
+ *   bg_kmerset_build_hash   owner: hash table over the kept k-mers bg_skm_count left
+ *   bg_skm_lookup           owner: d_bits[i] bit t = window t of record i is kept (only_unknown: just the
+ *                           records bg_skm_count marked 0x80000000 — its counting table overflowed)
+ *   bg_corr_begin           the rank that holds the reads: window presence of its reads from the bits its
+ *                           records got back (all resolved), screen (correct_reads.cpp:154-178)
+ *   bg_corr_step            fast_read_correct (fast_read_correct.cpp:16-182) of every pending read over the
+ *                           probes it has; *probes = strings whose windows are the k-mers the searches missed
+ *                           (a reads object: ship its super-k-mers like the reads', bg_skm_extract_by_owner)
+ *   bg_corr_answers         the owners' bits for those records, in sent order
+ *   bg_corr_finish          corrected reads + stats once no read is pending (same result as bg_correct_reads) */
+typedef struct bg_correction bg_correction;
+int bg_kmerset_build_hash(bg_ctx* ctx, bg_kmerset* ks);
+int bg_skm_lookup(bg_ctx* ctx, const bg_kmerset* ks, const uint64_t* d_recs, uint64_t n, uint32_t* d_bits,
+                  int only_unknown);
+int bg_corr_begin(bg_ctx* ctx, const bg_reads* reads, int k, const bg_correct_params* params, const uint64_t* d_recs,
+                  const uint64_t* d_org, const uint32_t* d_bits, uint64_t n_recs, bg_correction** out);
+int bg_corr_step(bg_ctx* ctx, bg_correction* c, uint64_t* n_pending_out, bg_reads** probes_out);
+int bg_corr_answers(bg_ctx* ctx, bg_correction* c, const uint64_t* d_org, const uint32_t* d_bits, uint64_t n);
+int bg_corr_finish(bg_ctx* ctx, bg_correction* c, bg_reads** out, bg_correct_stats* stats);
+uint64_t bg_corr_probes(const bg_correction* c);
+void bg_corr_free(bg_correction* c);
+
+/* ---- Sharded exact-cover emission (csrc/shard_cover.hip): the cover index is range-partitioned by leading
+ * bases like the suffix records (part_repo::partition_for_sequence, part_repo.cpp:32-45) instead of being
+ * replicated.  Rows are W+1 words: W key words, last word = length (bits 0-7) | plain flag (bit 16) | tag
+ * (bits 24-63); a row of length 0 is dropped by bg_partition_rows(BG_PART_PREFIX).
+ *   bg_oriented_rows        2 rows per read of `reads` (forward, reverse complement; length 0 = dropped read)
+ *   bg_rows_prefix_hist     sampled histogram of the rows' leading bases (splitters, part_counts.h:8-45)
+ *   bg_cover_build          owner: index over the oriented rows it received (they are also its j = 0 records)
+ *   bg_cover_test           owner: d_covered[i] = row i is a prefix of an indexed read (plain rows: never)
+ *   bg_cover_query_*        sender: candidate suffixes [j_lo, j_hi) of the reads still uncovered, tagged;
+ *                           answers (in sent order) -> which candidates the owner keeps as records (j below the
+ *                           read's first covered suffix); plain = the untested tails (< K bases) of the reads
+ *                           that stay uncovered after the last round (the last round must reach j_hi = 256). */
+typedef struct bg_cover bg_cover;
+typedef struct bg_cover_query bg_cover_query;
+int bg_oriented_rows(bg_ctx* ctx, const bg_reads* reads, int W_out, uint64_t* d_rows /* 2n x (W_out+1) */);
+int bg_rows_prefix_hist(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int row_words, int bases, uint64_t every,
+                        uint64_t* d_hist);
+int bg_cover_build(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int W, int cover_k, bg_cover** out);
+int bg_cover_test(bg_ctx* ctx, const bg_cover* c, const uint64_t* d_rows, uint64_t n, uint8_t* d_covered);
+void bg_cover_free(bg_cover* c);
+int bg_cover_query_begin(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int W, int cover_k, bg_cover_query** out);
+uint64_t bg_cover_query_pending(const bg_cover_query* q);
+int bg_cover_query_candidates(bg_ctx* ctx, bg_cover_query* q, int j_lo, int j_hi, uint64_t* d_rows, uint64_t cap,
+                              uint64_t* n_out);
+int bg_cover_query_answers(bg_ctx* ctx, bg_cover_query* q, const uint64_t* d_rows_sent, const uint8_t* d_covered,
+                           uint64_t n, uint8_t* d_keep_out);
+int bg_cover_query_plain(bg_ctx* ctx, bg_cover_query* q, uint64_t* d_rows, uint64_t cap, uint64_t* n_out);
+void bg_cover_query_free(bg_cover_query* q);
+
 /* ---- device memory helpers for hosts without their own allocator (CLI, ctypes tests). */
 int bg_dev_alloc(bg_ctx* ctx, uint64_t bytes, void** d_out);
 int bg_dev_free(bg_ctx* ctx, void* d_ptr);

@@ -88,8 +88,54 @@ int hh_correct_reads(const uint64_t* kmers, uint64_t nk, int k, const char* seq,
         if (ok) present[j >> 6] |= 1ull << (j & 63);
       }
     }
-    int clen = frc_correct_read(tab, &p.words[i * p.W], &p.nmask[i * p.W], L, p.W, k, int(max_corrections),
-                                int(min_good_run), needed, ow, &ncorr, use_presence ? present : nullptr);
+    int clen;
+    if (use_presence == 2) {
+      // the routed search of the sharded build (RoutedTable): re-run with the probes gathered so far until a run
+      // misses nothing; a probe's masks are what the owners of its k-mers would answer
+      const uint64_t* w = &p.words[i * p.W];
+      const uint32_t* nm = &p.nmask[i * p.W];
+      std::vector<ProbeDesc> pool;
+      uint32_t head = kNoProbe;
+      clen = 0;
+      for (int round = 0;; ++round) {
+        if (round > 4000) return -7;
+        RoutedTable rt;
+        rt.pool = pool.data();
+        rt.head = head;
+        rt.k = k;
+        rt.n_new = 0;
+        rt.missed = false;
+        clen = frc_correct_read(rt, w, nm, L, p.W, k, int(max_corrections), int(min_good_run), needed, ow, &ncorr, present);
+        if (!rt.missed) break;
+        if (rt.n_new == 0) return -8;  // a miss always leaves a new probe
+        const int anchor = frc_anchor(present, L, k);
+        if (anchor < 0) return -9;
+        for (int q = 0; q < rt.n_new; ++q) {
+          const int view = int((rt.newmeta[q] >> 16) & 1u), ppos = int(rt.newmeta[q] & 255u);
+          ReadView in = frc_view(w, nm, L, p.W, k, present, anchor, view);
+          const int run = probe_run(in, ppos, k);
+          ProbeDesc d;
+          d.q = rt.newq[q];
+          d.meta = uint32_t(ppos) | (uint32_t(run) << 8) | (uint32_t(view) << 16);
+          d.next = head;
+          for (int b = 0; b < 4; ++b) {
+            d.mask[b] = 0;
+            uint64_t str[2];
+            probe_string(in, d.q, ppos, b, run, k, str);
+            for (int t = 0; t <= run; ++t) {
+              const uint64_t z = probe_window(in, d.q, ppos, b, t, k);
+              if ((window32(str, 2, t) >> (64 - 2 * k)) != z) return -10;  // the string's windows are the probe's k-mers
+              if (tab.has(z)) d.mask[b] |= 1u << t;
+            }
+          }
+          head = uint32_t(pool.size());
+          pool.push_back(d);
+        }
+      }
+    } else {
+      clen = frc_correct_read(tab, &p.words[i * p.W], &p.nmask[i * p.W], L, p.W, k, int(max_corrections),
+                              int(min_good_run), needed, ow, &ncorr, use_presence ? present : nullptr);
+    }
     keep[i] = clen > 0;
     if (clen > 0) nc += ncorr;
     for (int j = 0; j < clen; ++j) out_seq[pos++] = "ACGT"[read_code(ow, j)];
@@ -114,12 +160,14 @@ void* hh_build_entries(const char* seq, const uint64_t* offs, uint64_t n, int K)
   const int W = p.W;
   const uint64_t n_o = 2 * n;
   std::vector<uint64_t> owords(n_o * W);
+  std::vector<uint8_t> olen(n_o);
   std::vector<std::pair<uint64_t, uint32_t>> keyed;
   for (uint64_t o = 0; o < n_o; ++o) {
     uint64_t tmp[kMaxWords];
     int L = p.len[o >> 1];
     oriented_words(&p.words[(o >> 1) * W], L, W, (o & 1) != 0, tmp);
     for (int w = 0; w < W; ++w) owords[o * W + w] = L ? tmp[w] : 0;
+    olen[o] = uint8_t(L);
     if (L >= K) keyed.emplace_back(tmp[0] >> (64 - 2 * K), uint32_t(o));
   }
   // candidates in full-key order (which implies first-K-mer order): cover_probe searches a K-mer's run by key
@@ -148,11 +196,11 @@ void* hh_build_entries(const char* seq, const uint64_t* offs, uint64_t n, int K)
     vv[t] = single ? ((uint64_t(p.len[c >> 1]) << 32) | kCoverSingle | c) : ((uint64_t(ulen[i]) << 32) | upos[i]);
   }
   // reads shorter than K cannot act as a cover: they are simply absent
-  CoverIndex ci{slots.data(), vv.data(), lg, skeys.data(), soid.data(), uint64_t(skeys.size()), K};
+  CoverIndex ci{slots.data(), vv.data(), lg, skeys.data(), soid.data(), uint64_t(skeys.size()), K, olen.data()};
   struct Rec { uint64_t w[kMaxWords]; int len; };
   std::vector<Rec> recs;
   for (uint64_t o = 0; o < n_o; ++o) {
-    int c = cover_count(ci, owords.data(), p.len.data(), o, W);
+    int c = cover_count(ci, owords.data(), o, W);
     int L = p.len[o >> 1];
     for (int j = 0; j < c; ++j) {
       Rec r;

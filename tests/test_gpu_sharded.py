@@ -38,15 +38,20 @@ def _shard_inputs(reads, P, rng):
     return inputs
 
 
+@pytest.mark.parametrize("mode", ["routed", "replicated"])
 @pytest.mark.parametrize("P", [1, 2, 3, 4, 8])
-def test_sharded_build_equals_single_gpu_and_oracle(ctx, P):
+def test_sharded_build_equals_single_gpu_and_oracle(ctx, P, mode):
+    """routed: nothing replicated (kept k-mers stay with their owners, the cover index is range-partitioned);
+    replicated: the round-1 design (all-gathered k-mer set and corrected reads)."""
     seq, offs, n = synth.make_reads(genome_len=12000, coverage=30, read_len=150, seed=5, device="cpu")
     reads = O.unpack_strings(seq.numpy(), offs.numpy().astype(np.uint64))
     rng = np.random.default_rng(P)
     comm = sharded.LocalSimComm(P)
-    out = sharded.sharded_create(comm, {r: ctx for r in range(P)}, _shard_inputs(reads, P, rng))
+    out = sharded.sharded_create(comm, {r: ctx for r in range(P)}, _shard_inputs(reads, P, rng), mode=mode)
     ss, st = out[0]
+    assert st["mode"] == mode
     ref, rst = ctx.create(reads)
+    assert st["n_records"] == rst["n_records"]  # the sharded cover rule emits exactly the single-GPU records
     assert st["n_kept_kmers"] == rst["n_kept_kmers"] and st["n_distinct_kmers"] == rst["n_distinct_kmers"]
     assert st["n_kmers"] == rst["n_kmers"]
     assert st["n_corrected_reads"] == rst["n_corrected_reads"] and st["n_corrected_bases"] == rst["n_corrected_bases"]
@@ -63,26 +68,31 @@ def test_sharded_build_equals_single_gpu_and_oracle(ctx, P):
     assert ss.entries(0, 500) == oent.strings()[:500]  # FM navigation over the assembled arrays
 
 
+@pytest.mark.parametrize("mode", ["routed", "replicated"])
 @pytest.mark.parametrize("alphabet,P", [("AC", 3), ("A", 2), ("ACGT", 5)])
-def test_sharded_low_entropy_and_short_entries(ctx, alphabet, P):
+def test_sharded_low_entropy_and_short_entries(ctx, alphabet, P, mode):
     """Low-entropy genomes put most records in few leading-base bins (empty shards, cross-shard prefix
     drops, short tails that resolve on a later shard)."""
     reads = util.synth_reads(3, genome_len=900, n_reads=300, read_len=60, err=0.0, n_rate=0.0, alphabet=alphabet,
                              var_len=True, repeat=(5, 30))
     reads += ["ACG", "A", "T", "ACGTA", "GG"]
-    prm = ctx.default_params(kmer_size=12, min_kmer_count=1)
+    kk = 14 if mode == "routed" else 12  # the routed path needs a 12-base minimiser inside the k-mer
+    prm = ctx.default_params(kmer_size=kk, min_kmer_count=1)
     rng = np.random.default_rng(1)
     comm = sharded.LocalSimComm(P)
-    out = sharded.sharded_create(comm, {r: ctx for r in range(P)}, _shard_inputs(reads, P, rng), prm)
+    out = sharded.sharded_create(comm, {r: ctx for r in range(P)}, _shard_inputs(reads, P, rng), prm, mode=mode)
     ss, st = out[0]
-    ref, rst = ctx.create(reads, kmer_size=12, min_kmer_count=1)
+    assert st["mode"] == mode
+    ref, rst = ctx.create(reads, kmer_size=kk, min_kmer_count=1)
     assert ss.size() == ref.size()
     assert ss.parts() == ref.parts()
     assert len(st["shard_entries"]) == P and sum(st["shard_entries"]) == ss.size()
 
 
 @pytest.mark.parametrize("env", [{"BG_KMER_SKM": "0"}, {"BG_KMER_LDS_LOG2CAP": "3"}, {"BG_KMER_EXTRA_BITS": "2"},
-                                 {"BG_SCREEN_LOOKUP": "1"}])
+                                 {"BG_SCREEN_LOOKUP": "1", "BG_SHARD_REPLICATED": "1"},
+                                 {"BG_KMER_LDS_LOG2CAP": "3", "BG_SHARD_REPLICATED": "1"},
+                                 {"BG_COVER_ROUNDS": "1,2,3,256"}, {"BG_COVER_ROUNDS": "1,256"}])
 def test_sharded_kmer_exchange_modes(ctx, monkeypatch, env):
     """The k-mer exchange as instances (BG_KMER_SKM=0) and as super-k-mers, with the owners' counting tables
     overflowing (every record comes back "unknown" and is looked up by its sender), with extra partition

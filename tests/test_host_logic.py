@@ -16,8 +16,9 @@ def _correct_via_harness(reads, k, min_count, maxc=8, mgr=2, trim=0.7, use_prese
     out_offs = np.zeros(len(reads) + 1, np.uint64)
     keep = np.zeros(max(len(reads), 1), np.uint8)
     nc = np.zeros(1, np.uint64)
-    hh.hh_correct_reads(O._pad(kmers), len(kmers), k, O._pad(seq), offs, len(reads), maxc, mgr, trim, out_seq,
-                        out_offs, keep, nc, use_presence)
+    rc = hh.hh_correct_reads(O._pad(kmers), len(kmers), k, O._pad(seq), offs, len(reads), maxc, mgr, trim, out_seq,
+                             out_offs, keep, nc, use_presence)
+    assert rc == 0, rc
     oseq, ooffs, okeep, stats = O.correct_reads(ks, seq, offs, maxc, mgr, trim)
     return (out_seq[:int(out_offs[-1])], out_offs, keep[:len(reads)], int(nc[0])), (oseq, ooffs, okeep, stats)
 
@@ -26,7 +27,7 @@ def _correct_via_harness(reads, k, min_count, maxc=8, mgr=2, trim=0.7, use_prese
                                               (4, 12, 0.05, 0.02), (5, 30, 0.02, 0.005)])
 def test_correction_dfs_matches_oracle(seed, k, err, nrate):
     reads = util.synth_reads(seed, genome_len=2000, n_reads=800, read_len=80, err=err, n_rate=nrate, var_len=True)
-    for use_presence in (0, 1):
+    for use_presence in (0, 1, 2):  # 2 = the routed search of the sharded build (RoutedTable, probes)
         (hs, ho, hk, hn), (os_, oo, ok, st) = _correct_via_harness(reads, k, 3, use_presence=use_presence)
         assert (hk == ok).all()
         assert (ho == oo).all()
@@ -38,15 +39,17 @@ def test_correction_dfs_matches_oracle(seed, k, err, nrate):
 @pytest.mark.parametrize("maxc,mgr,trim", [(0, 2, 0.7), (1, 1, 0.5), (2, 3, 0.9), (8, 0, 0.0), (4, 2, 1.0)])
 def test_correction_params(maxc, mgr, trim):
     reads = util.synth_reads(11, genome_len=1500, n_reads=500, read_len=70, err=0.02, n_rate=0.004)
-    (hs, ho, hk, hn), (os_, oo, ok, st) = _correct_via_harness(reads, 17, 3, maxc, mgr, trim)
-    assert (hk == ok).all() and (ho == oo).all() and (hs == os_).all()
+    for use_presence in (1, 2):
+        (hs, ho, hk, hn), (os_, oo, ok, st) = _correct_via_harness(reads, 17, 3, maxc, mgr, trim, use_presence)
+        assert (hk == ok).all() and (ho == oo).all() and (hs == os_).all()
 
 
 def test_correction_golden_ecoli(golden_dir):
     reads = O.read_fastq(golden_dir + "/e_coli_10000snp/reads.fq")
-    (hs, ho, hk, hn), (os_, oo, ok, st) = _correct_via_harness(reads, 30, 5)
-    assert st["corrected_reads"] == 8444 and st["corrected_bases"] == 288464
-    assert (hk == ok).all() and (ho == oo).all() and (hs == os_).all()
+    for use_presence in (1, 2):
+        (hs, ho, hk, hn), (os_, oo, ok, st) = _correct_via_harness(reads, 30, 5, use_presence=use_presence)
+        assert st["corrected_reads"] == 8444 and st["corrected_bases"] == 288464
+        assert (hk == ok).all() and (ho == oo).all() and (hs == os_).all()
 
 
 def _entries_via_harness(reads, K):
