@@ -1092,10 +1092,11 @@ __global__ void sk_present_from_bits_kernel(const SkRec* __restrict__ recs, cons
                                             unsigned long long* __restrict__ present, int pstride, uint32_t* __restrict__ err) {
   const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n_rec) return;
+  // every record is resolved by its owner (bg_skm_lookup); bit 31 is window 31 of a 32-window record here
   const uint32_t bits = bits_in[i];
-  if (bits & kSkUnknown) { atomicOr(err, 1u); return; }
   if (!bits) return;
   const int n = sk_windows(recs[i].b);
+  if (n < 32 && (bits >> n)) { atomicOr(err, 1u); return; }
   const uint64_t o = org[i];
   const uint64_t read = o >> 8;
   const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
@@ -1113,7 +1114,7 @@ __global__ void sk_probe_answers_kernel(const uint64_t* __restrict__ org, const 
   const uint64_t o = org[i];
   const uint64_t p = o >> 8;
   const int s0 = int(o & 0xff);
-  if ((bits & kSkUnknown) || (p >> 2) >= n_probes || s0 > 31) { atomicOr(err, 1u); return; }
+  if ((p >> 2) >= n_probes || s0 > 31 || (s0 && (bits >> (32 - s0)))) { atomicOr(err, 1u); return; }
   if (bits) atomicOr(&pool[base + (p >> 2)].mask[p & 3], bits << s0);
 }
 
@@ -1134,7 +1135,7 @@ int skm_presence_from_bits(bg_ctx* ctx, const bg_reads* reads, int k, const uint
   uint32_t h_err = 0;
   BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
-  if (h_err) { set_error("presence bits: a record came back unresolved (the owner must look it up: bg_skm_lookup)"); return BG_EINVAL; }
+  if (h_err) { set_error("presence bits: bits beyond a record's windows (unresolved by the owner? see bg_skm_lookup)"); return BG_EINVAL; }
   return BG_OK;
 }
 
