@@ -82,6 +82,8 @@ SYMBOLS = [
     "bg_cover_query_plain", "bg_cover_query_free",
     "bg_kmerset_build_hash", "bg_skm_lookup", "bg_corr_begin", "bg_corr_step", "bg_corr_answers", "bg_corr_finish",
     "bg_corr_probes", "bg_corr_free",
+    "bg_seqset_slice_masks", "bg_seqset_slice_build", "bg_seqset_slice_popcounts", "bg_seqset_sharded_create_file",
+    "bg_seqset_slice_write",
 ]
 
 PART_KMER_HASH, PART_PREFIX, PART_KEY_BOUNDS = 0, 1, 2
@@ -233,6 +235,11 @@ def lib():
     L.bg_seqset_apply_tails.argtypes = [vp, vp, vp, u64]
     L.bg_seqset_slice_export.argtypes = [vp, vp, vp, vp, vp]
     L.bg_seqset_assemble.argtypes = [vp, u32, vp, vp, vp, vp, u32, P(vp)]
+    L.bg_seqset_slice_masks.argtypes = [vp, vp, vp, vp, vp]
+    L.bg_seqset_slice_build.argtypes = [vp, u64, vp, vp, vp, u32, P(vp)]
+    L.bg_seqset_slice_popcounts.argtypes = [vp, P(u64)]
+    L.bg_seqset_sharded_create_file.argtypes = [C.c_char_p, u64, u32, P(u64), i32, P(C.c_char_p), P(u64)]
+    L.bg_seqset_slice_write.argtypes = [vp, vp, C.c_char_p, P(u64), u64, i32, P(u64)]
     L.bg_oriented_rows.argtypes = [vp, vp, i32, vp]
     L.bg_rows_prefix_hist.argtypes = [vp, vp, u64, i32, i32, u64, vp]
     L.bg_cover_build.argtypes = [vp, vp, u64, i32, i32, P(vp)]

@@ -4,6 +4,9 @@
 #include <time.h>
 
 #include "bg_device_funcs.h"
+#include <errno.h>
+#include <string.h>
+
 #include "bg_internal.h"
 
 namespace bg {
@@ -363,11 +366,8 @@ extern "C" int bg_seqset_from_arrays(bg_ctx* ctx, uint64_t n, const uint32_t* h_
   return BG_OK;
 }
 
-extern "C" int bg_seqset_write(bg_ctx* ctx, const bg_seqset* ss, const char* path, int argc, const char* const* argv) {
-  if (!ctx || !ss || !path) { set_error("bg_seqset_write: null argument"); return BG_EINVAL; }
-  BG_HIP(hipSetDevice(ctx->device));
-  std::vector<ZipPart> parts;
-  // file_info.json (io/spiral_file.cpp:194-222): uuid, timestamps, build stamp, argv — never comparable
+// file_info.json (io/spiral_file.cpp:194-222): uuid, timestamps, build stamp, argv — never comparable
+static std::string file_info_json(const std::string& uuid, int argc, const char* const* argv) {
   time_t now = time(nullptr);
   char tbuf[64];
   ctime_r(&now, tbuf);
@@ -379,43 +379,228 @@ extern "C" int bg_seqset_write(bg_ctx* ctx, const bg_seqset* ss, const char* pat
     cmd += "\"" + json_escape(argv[i] ? argv[i] : "") + "\"";
   }
   cmd += "]";
-  char fi[4096];
-  snprintf(fi, sizeof fi,
-           "{\"build_host\":\"\",\"build_is_clean\":true,\"build_revision\":\"biograph_amd\",\"build_timestamp\":0,"
-           "\"build_timestamp_text\":\"\",\"build_user\":\"\",\"command_line\":%s,\"create_timestamp\":%lld,"
-           "\"create_timestamp_text\":\"%s\",\"uuid\":\"%s\"}",
-           cmd.c_str(), (long long)now, ttext.c_str(), ss->uuid.c_str());
-  parts.push_back(ZipPart{"file_info.json", fi, false});
-  parts.push_back(ZipPart{"part_info.json", version_json("seqset", 1, 1, 0), false});  // seqset.cpp:12
+  char num[32];
+  snprintf(num, sizeof num, "%lld", (long long)now);
+  return std::string("{\"build_host\":\"\",\"build_is_clean\":true,\"build_revision\":\"biograph_amd\",\"build_timestamp\":0,"
+                     "\"build_timestamp_text\":\"\",\"build_user\":\"\",\"command_line\":") + cmd +
+         ",\"create_timestamp\":" + num + ",\"create_timestamp_text\":\"" + ttext + "\",\"uuid\":\"" + json_escape(uuid) + "\"}";
+}
+
+constexpr int kPayloadParts = 15;  // fixed, entry_sizes/elements, shared/elements, prev_{A,C,G,T}/{bits,subaccum,accum}
+
+// The members of a seqset container in creation order (spiral_file_mmap.cpp:350-457).  payload(name, &data) fills a
+// payload member; with hole_sizes (kPayloadParts entries, payload order) the payload members only get room.
+template <class F>
+static int seqset_members(uint64_t n, uint32_t max_len, const std::string& uuid, int argc, const char* const* argv, F payload,
+                          const uint64_t* hole_sizes, std::vector<ZipPart>* parts) {
+  int pi = 0;
+  auto add_payload = [&](const std::string& name) -> int {
+    ZipPart p{name, std::string(), true};
+    if (hole_sizes) {
+      p.hole_size = hole_sizes[pi];
+      if (!p.hole_size) p.data.clear();
+    } else {
+      BG_TRY(payload(name, &p.data));
+    }
+    ++pi;
+    parts->push_back(std::move(p));
+    return BG_OK;
+  };
+  parts->push_back(ZipPart{"file_info.json", file_info_json(uuid, argc, argv), false});
+  parts->push_back(ZipPart{"part_info.json", version_json("seqset", 1, 1, 0), false});  // seqset.cpp:12
   char sj[64];
-  snprintf(sj, sizeof sj, "{\"num_entries\":%llu}", (unsigned long long)ss->n);
-  parts.push_back(ZipPart{"seqset.json", sj, false});
-  std::string data;
-  BG_TRY(part_bytes(ctx, ss, "fixed", &data));
-  parts.push_back(ZipPart{"fixed", data, true});
+  snprintf(sj, sizeof sj, "{\"num_entries\":%llu}", (unsigned long long)n);
+  parts->push_back(ZipPart{"seqset.json", sj, false});
+  BG_TRY(add_payload("fixed"));
   for (int which = 0; which < 2; ++which) {
     std::string dir = which ? "shared" : "entry_sizes";
-    uint64_t maxv = which ? (ss->max_len ? ss->max_len - 1 : 0) : ss->max_len;
-    parts.push_back(ZipPart{dir + "/part_info.json", version_json("packed_varbit_vector", 1, 0, 0), false});
+    uint64_t maxv = which ? (max_len ? max_len - 1 : 0) : max_len;
+    parts->push_back(ZipPart{dir + "/part_info.json", version_json("packed_varbit_vector", 1, 0, 0), false});
     char mj[128];
     snprintf(mj, sizeof mj, "{\"bits_per_value\":%u,\"element_count\":%llu,\"max_value\":%llu}", bits_for_value(maxv),
-             (unsigned long long)ss->n, (unsigned long long)maxv);
-    parts.push_back(ZipPart{dir + "/packed_varbit_vector.json", mj, false});
-    BG_TRY(part_bytes(ctx, ss, dir + "/elements", &data));
-    parts.push_back(ZipPart{dir + "/elements", data, true});
+             (unsigned long long)n, (unsigned long long)maxv);
+    parts->push_back(ZipPart{dir + "/packed_varbit_vector.json", mj, false});
+    BG_TRY(add_payload(dir + "/elements"));
   }
   for (int b = 0; b < 4; ++b) {
     std::string dir = std::string("prev_") + "ACGT"[b];
-    parts.push_back(ZipPart{dir + "/part_info.json", version_json("bitcount", 1, 0, 0), false});
+    parts->push_back(ZipPart{dir + "/part_info.json", version_json("bitcount", 1, 0, 0), false});
     char bj[64];
-    snprintf(bj, sizeof bj, "{\"nbits\":%llu}", (unsigned long long)ss->n);
-    parts.push_back(ZipPart{dir + "/bitcount.json", bj, false});
-    for (const char* w : {"bits", "subaccum", "accum"}) {
-      BG_TRY(part_bytes(ctx, ss, dir + "/" + w, &data));
-      parts.push_back(ZipPart{dir + "/" + w, data, true});
+    snprintf(bj, sizeof bj, "{\"nbits\":%llu}", (unsigned long long)n);
+    parts->push_back(ZipPart{dir + "/bitcount.json", bj, false});
+    for (const char* w : {"bits", "subaccum", "accum"}) BG_TRY(add_payload(dir + "/" + w));
+  }
+  return BG_OK;
+}
+
+extern "C" int bg_seqset_write(bg_ctx* ctx, const bg_seqset* ss, const char* path, int argc, const char* const* argv) {
+  if (!ctx || !ss || !path) { set_error("bg_seqset_write: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::vector<ZipPart> parts;
+  BG_TRY(seqset_members(ss->n, ss->max_len, ss->uuid, argc, argv,
+                        [&](const std::string& name, std::string* data) { return part_bytes(ctx, ss, name, data); }, nullptr,
+                        &parts));
+  return spiral_zip_write(path, parts);
+}
+
+// ---- a sharded seqset leaves as slices: every rank holds a 512-aligned stretch of the entries and writes its
+// bytes of every member in place (no gather; biograph_amd/sharded.py).  An aligned slice is a seqset of its own
+// whose packed members are byte for byte the global members' stretch; only accum needs the popcounts of the
+// ranks before it added, and `fixed` is global.
+
+namespace bg {
+__global__ void k_bits_to_masks(const uint64_t* __restrict__ b0, const uint64_t* __restrict__ b1, const uint64_t* __restrict__ b2,
+                                const uint64_t* __restrict__ b3, uint64_t n, uint8_t* __restrict__ mask) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t w = i >> 6;
+  const int s = int(i & 63);
+  mask[i] = uint8_t(((b0[w] >> s) & 1) | (((b1[w] >> s) & 1) << 1) | (((b2[w] >> s) & 1) << 2) | (((b3[w] >> s) & 1) << 3));
+}
+__global__ __launch_bounds__(256) void k_masks_to_bits(const uint8_t* __restrict__ mask, uint64_t n, uint64_t* __restrict__ b0,
+                                                       uint64_t* __restrict__ b1, uint64_t* __restrict__ b2,
+                                                       uint64_t* __restrict__ b3) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;  // one wave = one word of each vector
+  const uint32_t m = i < n ? mask[i] : 0u;
+  const uint64_t w0 = __ballot(m & 1u), w1 = __ballot(m & 2u), w2 = __ballot(m & 4u), w3 = __ballot(m & 8u);
+  if ((threadIdx.x & 63) == 0 && i < n) {
+    b0[i >> 6] = w0;
+    b1[i >> 6] = w1;
+    b2[i >> 6] = w2;
+    b3[i >> 6] = w3;
+  }
+}
+__global__ void k_add_u64(uint64_t* __restrict__ a, uint64_t n, uint64_t v) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += v;
+}
+}  // namespace bg
+
+extern "C" int bg_seqset_slice_masks(bg_ctx* ctx, const bg_seqset* ss, uint8_t* d_sizes, uint8_t* d_shared, uint8_t* d_mask) {
+  if (!ctx || !ss || (ss->n && (!d_sizes || !d_shared || !d_mask))) { set_error("bg_seqset_slice_masks: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  const uint64_t n = ss->n;
+  if (n) {
+    if (!ss->bits[0].p) { set_error("bg_seqset_slice_masks: prev bits not built"); return BG_EINVAL; }
+    BG_HIP(hipMemcpyAsync(d_sizes, ss->sizes.p, n, hipMemcpyDeviceToDevice, ctx->stream));
+    BG_HIP(hipMemcpyAsync(d_shared, ss->shared.p, n, hipMemcpyDeviceToDevice, ctx->stream));
+    k_bits_to_masks<<<cdiv(n, 256), 256, 0, ctx->stream>>>(ss->bits[0].p, ss->bits[1].p, ss->bits[2].p, ss->bits[3].p, n, d_mask);
+    BG_LAUNCH_CHECK();
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+extern "C" int bg_seqset_slice_build(bg_ctx* ctx, uint64_t m, const uint8_t* d_sizes, const uint8_t* d_shared,
+                                     const uint8_t* d_mask, uint32_t max_len, bg_seqset** out) {
+  if (!ctx || !out || (m && (!d_sizes || !d_shared || !d_mask))) { set_error("bg_seqset_slice_build: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_seqset> ss(new bg_seqset);
+  ss->ctx = ctx;
+  ss->n = m;
+  ss->W = 0;
+  ss->max_len = max_len;  // of the WHOLE seqset: it fixes the packed widths
+  ss->uuid = make_uuid();
+  BG_TRY(ss->sizes.alloc(ctx, m));
+  BG_TRY(ss->shared.alloc(ctx, m));
+  BG_TRY(alloc_prev_bits(ctx, ss.get()));
+  if (m) {
+    BG_HIP(hipMemcpyAsync(ss->sizes.p, d_sizes, m, hipMemcpyDeviceToDevice, ctx->stream));
+    BG_HIP(hipMemcpyAsync(ss->shared.p, d_shared, m, hipMemcpyDeviceToDevice, ctx->stream));
+    k_masks_to_bits<<<cdiv(m, 256), 256, 0, ctx->stream>>>(d_mask, m, ss->bits[0].p, ss->bits[1].p, ss->bits[2].p, ss->bits[3].p);
+    BG_LAUNCH_CHECK();
+  }
+  ctx->tic("seqset_finalize");
+  BG_TRY(seqset_finalize_device(ctx, ss.get(), true));
+  ctx->toc(m * 3);
+  *out = ss.release();
+  return BG_OK;
+}
+
+// set prev bits per base inside the slice (what the ranks after it add to their accum)
+extern "C" int bg_seqset_slice_popcounts(const bg_seqset* ss, uint64_t* h_out4) {
+  if (!ss || !h_out4) { set_error("bg_seqset_slice_popcounts: null argument"); return BG_EINVAL; }
+  for (int b = 0; b < 4; ++b) h_out4[b] = ss->fixed[b + 1] - ss->fixed[b];
+  return BG_OK;
+}
+
+static void payload_sizes(uint64_t n, uint32_t max_len, uint64_t* sz) {
+  const int bs = int(bits_for_value(max_len)), bh = int(bits_for_value(max_len ? max_len - 1 : 0));
+  sz[0] = 40;
+  sz[1] = (n * bs + 63) / 64 * 8;
+  sz[2] = (n * bh + 63) / 64 * 8;
+  for (int b = 0; b < 4; ++b) {
+    sz[3 + 3 * b] = (n + 63) / 64 * 8;
+    sz[4 + 3 * b] = (n + 511) / 512 * 8;
+    sz[5 + 3 * b] = (n + 512) / 512 * 8;
+  }
+}
+
+// Rank 0: the container with room for every payload member; h_offsets[15] = file offset of each member's data
+// (payload order: fixed, entry_sizes/elements, shared/elements, prev_A/bits, prev_A/subaccum, prev_A/accum, ...).
+// `fixed` is written here.
+extern "C" int bg_seqset_sharded_create_file(const char* path, uint64_t n_total, uint32_t max_len, const uint64_t* h_fixed5,
+                                             int argc, const char* const* argv, uint64_t* h_offsets) {
+  if (!path || !h_fixed5 || !h_offsets) { set_error("bg_seqset_sharded_create_file: null argument"); return BG_EINVAL; }
+  uint64_t sz[kPayloadParts];
+  payload_sizes(n_total, n_total ? max_len : 0, sz);
+  std::vector<ZipPart> parts;
+  BG_TRY(seqset_members(n_total, n_total ? max_len : 0, make_uuid(), argc, argv,
+                        [](const std::string&, std::string*) { return BG_OK; }, sz, &parts));
+  for (ZipPart& p : parts)
+    if (p.name == "fixed") { p.hole_size = 0; p.data.assign(reinterpret_cast<const char*>(h_fixed5), 40); }
+  std::vector<uint64_t> offs;
+  BG_TRY(spiral_zip_write_layout(path, parts, &offs));
+  int pi = 0;
+  for (size_t i = 0; i < parts.size(); ++i)
+    if (parts[i].raw_crc0) h_offsets[pi++] = offs[i];
+  return BG_OK;
+}
+
+// Every rank: the slice's bytes of every member, in place.  first_entry = global index of the slice's first
+// entry (a multiple of 512); is_last: this rank also owns the closing accum slot; h_base_pop[4] = set prev bits
+// per base in all entries before first_entry.
+extern "C" int bg_seqset_slice_write(bg_ctx* ctx, const bg_seqset* slice, const char* path, const uint64_t* h_offsets,
+                                     uint64_t first_entry, int is_last, const uint64_t* h_base_pop4) {
+  if (!ctx || !slice || !path || !h_offsets || !h_base_pop4) { set_error("bg_seqset_slice_write: null argument"); return BG_EINVAL; }
+  if (first_entry % 512) { set_error("bg_seqset_slice_write: slice starts at entry %llu, not a multiple of 512", (unsigned long long)first_entry); return BG_EINVAL; }
+  if (!is_last && slice->n % 512) { set_error("bg_seqset_slice_write: an inner slice of %llu entries is not 512-aligned", (unsigned long long)slice->n); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  FILE* f = fopen(path, "r+b");
+  if (!f) { set_error("Could not open %s for writing: %s", path, strerror(errno)); return BG_EIO; }
+  const uint64_t m = slice->n;
+  const int bs = int(bits_for_value(slice->max_len)), bh = int(bits_for_value(slice->max_len ? slice->max_len - 1 : 0));
+  auto put = [&](int member, uint64_t byte_off, const std::string& data) -> int {
+    if (data.empty()) return BG_OK;
+    if (fseeko(f, off_t(h_offsets[member] + byte_off), SEEK_SET) != 0 || fwrite(data.data(), 1, data.size(), f) != data.size()) {
+      set_error("write error on %s: %s", path, strerror(errno));
+      return BG_EIO;
+    }
+    return BG_OK;
+  };
+  int rc = BG_OK;
+  std::string data;
+  if (rc == BG_OK) rc = part_bytes(ctx, slice, "entry_sizes/elements", &data);
+  if (rc == BG_OK) rc = put(1, first_entry * bs / 8, data);
+  if (rc == BG_OK) rc = part_bytes(ctx, slice, "shared/elements", &data);
+  if (rc == BG_OK) rc = put(2, first_entry * bh / 8, data);
+  for (int b = 0; b < 4 && rc == BG_OK; ++b) {
+    const std::string dir = std::string("prev_") + "ACGT"[b];
+    rc = part_bytes(ctx, slice, dir + "/bits", &data);
+    if (rc == BG_OK) rc = put(3 + 3 * b, first_entry / 8, data);
+    if (rc == BG_OK) rc = part_bytes(ctx, slice, dir + "/subaccum", &data);
+    if (rc == BG_OK) rc = put(4 + 3 * b, first_entry / 512 * 8, data);
+    if (rc == BG_OK) rc = part_bytes(ctx, slice, dir + "/accum", &data);
+    if (rc == BG_OK) {
+      uint64_t* a = reinterpret_cast<uint64_t*>(&data[0]);
+      const uint64_t na = data.size() / 8, keep = is_last ? na : m / 512;
+      for (uint64_t i = 0; i < keep; ++i) a[i] += h_base_pop4[b];
+      data.resize(keep * 8);
+      rc = put(5 + 3 * b, first_entry / 512 * 8, data);
     }
   }
-  return spiral_zip_write(path, parts);
+  if (fclose(f) != 0 && rc == BG_OK) { set_error("write error on %s: %s", path, strerror(errno)); rc = BG_EIO; }
+  return rc;
 }
 
 static bool json_u64(const std::string& js, const char* key, uint64_t* out) {

@@ -204,7 +204,7 @@ struct CoverStore {  // device buffers behind a CoverIndex (bg_device_funcs.h)
 };
 int cover_index_build(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, uint64_t n_o, int W, int cover_k,
                       DevBuf<uint64_t>* k0o, CoverStore* cs);
-int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss);  // bitcount finalize + min index + fixed
+int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss, bool slice = false);  // bitcount finalize + min index + fixed
 int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t hi, int cover_k,
                         DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out,
                         DevBuf<uint64_t>* k0 = nullptr);  // k0: also the sort keys of the records (optional)
@@ -219,8 +219,9 @@ int apply_tails_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_
 int kmerset_sort(bg_ctx* ctx, bg_kmerset* ks);
 int read_locus_order(bg_ctx* ctx, const bg_reads* reads, uint64_t first, uint64_t count, DevBuf<uint32_t>* perm);
 // spiral_zip.cpp
-struct ZipPart { std::string name; std::string data; bool raw_crc0; };
+struct ZipPart { std::string name; std::string data; bool raw_crc0; uint64_t hole_size = 0; };
 int spiral_zip_write(const char* path, const std::vector<ZipPart>& parts);
+int spiral_zip_write_layout(const char* path, const std::vector<ZipPart>& parts, std::vector<uint64_t>* data_offsets);
 int spiral_zip_read(const char* path, std::map<std::string, std::string>* parts);
 std::string make_uuid();
 int sha1_file_hex(const char* path, char* hex41);

@@ -943,7 +943,9 @@ __global__ void k_min_index2(const uint8_t* __restrict__ min1, uint64_t n1, uint
 // ------------------------------------------------------------------------------------------------
 
 // Allocates and fills subaccum/accum/fixed and the min index from bits/shared (device).
-int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss) {
+// slice: the entries are a stretch of a larger seqset (prev bits point anywhere): fixed[] = the slice's own
+// cumulative popcounts, no sum check.
+int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss, bool slice) {
   const uint64_t n = ss->n;
   const uint64_t nwords = (n + 63) / 64, ngroups = (n + 511) / 512, naccum = (n + 1 + 511) / 512;
   DevBuf<uint32_t> gp;
@@ -978,7 +980,7 @@ int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss) {
   uint64_t off = 0;
   for (int b = 0; b < 4; ++b) { ss->fixed[b] = off; off += h_total[b]; }  // seqset.cpp:113-129
   ss->fixed[4] = off;
-  if (off != n) {
+  if (!slice && off != n) {
     set_error("Invalid seqset in finalize: %llu != %llu", (unsigned long long)off, (unsigned long long)n);
     return BG_EINTERNAL;
   }

@@ -4,6 +4,7 @@
 // carry their real CRC.  Byte layout of the headers reproduces what the reference's goldens contain
 // (golden/e_coli_10000snp.bg/seqset, father_lambda.bg/seqset).
 #include <errno.h>
+#include <stdio.h>
 #include <string.h>
 #include <time.h>
 
@@ -44,14 +45,20 @@ std::string make_uuid() {
   return buf;
 }
 
-int spiral_zip_write(const char* path, const std::vector<ZipPart>& parts) {
+int spiral_zip_write(const char* path, const std::vector<ZipPart>& parts) { return spiral_zip_write_layout(path, parts, nullptr); }
+
+// A part with hole_size != 0 gets its headers and hole_size bytes of room, which the caller fills in place
+// afterwards (the slices of a sharded seqset, written by every rank at data_offsets[part] + its own offset).
+int spiral_zip_write_layout(const char* path, const std::vector<ZipPart>& parts, std::vector<uint64_t>* data_offsets) {
   FILE* f = fopen(path, "wb");
   if (!f) { set_error("Could not open zip for writing: %s: %s", path, strerror(errno)); return BG_EIO; }
   struct Cd { std::string name; uint32_t crc; uint64_t size, offset; };
   std::vector<Cd> cds;
   uint64_t pos = 0;
+  if (data_offsets) data_offsets->clear();
   for (const ZipPart& p : parts) {
-    uint64_t size = p.data.size();
+    const bool hole = p.hole_size != 0;
+    uint64_t size = hole ? p.hole_size : p.data.size();
     bool big = size >= 0xffffffffull;
     uint32_t crc = p.raw_crc0 ? 0u : crc32_of(p.data);
     std::string h;
@@ -72,11 +79,13 @@ int spiral_zip_write(const char* path, const std::vector<ZipPart>& parts) {
     put64(h, big ? size : 0);
     put64(h, big ? size : 0);
     if (fwrite(h.data(), 1, h.size(), f) != h.size() ||
-        (size && fwrite(p.data.data(), 1, size, f) != size)) {
+        (!hole && size && fwrite(p.data.data(), 1, size, f) != size) ||
+        (hole && fseeko(f, off_t(size), SEEK_CUR) != 0)) {
       set_error("write error on %s: %s", path, strerror(errno));
       fclose(f);
       return BG_EIO;
     }
+    if (data_offsets) data_offsets->push_back(pos + h.size());
     cds.push_back(Cd{p.name, crc, size, pos});
     pos += h.size() + size;
   }

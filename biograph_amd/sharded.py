@@ -455,11 +455,111 @@ def _records_sharded_cover(comm, ctxs, corrected, W, k, dev, ph):
     return out, n_records
 
 
-def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None):
+class SeqsetSlice:
+    """One rank's stretch of a sharded seqset: entries [first, first + size()) of n_total."""
+
+    def __init__(self, ctx, seqset, first, n_total, max_len, is_last, base_pop, fixed):
+        self.ctx, self.seqset, self.first, self.n_total, self.max_len = ctx, seqset, first, n_total, max_len
+        self.is_last, self.base_pop, self.fixed = is_last, base_pop, fixed
+
+    def size(self):
+        return self.seqset.size()
+
+    def free(self):
+        self.seqset.free()
+
+
+def _aligned_slices(comm, ctxs, shards, part_n, max_len, dev):
+    """Shards hold arbitrary numbers of entries; container members are addressed in 64-bit words and 512-bit
+    groups.  Every rank passes its last < 512 entries on (sizes, shared, one prev-mask byte each: a few KB through
+    all_gather) so that rank r holds the entries [B_r, B_r+1) with B_r = its global start rounded down to 512."""
+    import biograph_amd as bg
+    L = capi.lib()
+    P = comm.world
+    ranks = comm.local_ranks
+    off = [0]
+    for n in part_n:
+        off.append(off[-1] + n)
+    n_total = off[-1]
+    B = [(off[r] // 512) * 512 for r in range(P)] + [n_total]
+    cols, tails = {}, {}
+    for r in ranks:
+        n = part_n[r]
+        t = torch.empty((3, max(n, 1)), dtype=torch.uint8, device=dev[r])
+        capi.check(L.bg_seqset_slice_masks(ctxs[r].h, shards[r].h, _ptr(t[0]), _ptr(t[1]), _ptr(t[2])))
+        cols[r] = t[:, :n]
+        tails[r] = cols[r][:, max(0, n - 511):].t().contiguous()  # [<=511, 3]
+    gt = comm.all_gather_v(tails)
+    slices, pops = {}, {}
+    for r in ranks:
+        pre = []
+        for q in range(r):  # entries [B_r, off_r) sit in the tails of the ranks before r
+            tq = gt[r][q].to(dev[r])
+            start = off[q + 1] - tq.shape[0]
+            lo = max(B[r] - start, 0)
+            if lo < tq.shape[0]:
+                pre.append(tq[lo:].t())
+        n_own = part_n[r] - (off[r + 1] - B[r + 1]) if r + 1 < P else part_n[r]
+        own = cols[r][:, :max(n_own, 0)]
+        if n_own < 0:  # this rank's entries and some of the inherited ones belong to the next rank
+            allc = torch.cat(pre + [cols[r]], dim=1) if pre else cols[r]
+            allc = allc[:, :B[r + 1] - B[r]]
+        else:
+            allc = torch.cat(pre + [own], dim=1) if pre else own
+        allc = allc.contiguous()
+        m = allc.shape[1]
+        assert m == B[r + 1] - B[r], (r, m, B[r], B[r + 1])
+        h = C.c_void_p()
+        capi.check(L.bg_seqset_slice_build(ctxs[r].h, m, _ptr(allc[0]), _ptr(allc[1]), _ptr(allc[2]), max_len if n_total else 0,
+                                           C.byref(h)))
+        slices[r] = bg.Seqset(ctxs[r], h)
+        pc = (C.c_uint64 * 4)()
+        capi.check(L.bg_seqset_slice_popcounts(h, pc))
+        pops[r] = [int(x) for x in pc]
+    allp = comm.all_gather_obj(pops)[ranks[0]]
+    tot = [sum(allp[q][b] for q in range(P)) for b in range(4)]
+    fixed = [0]
+    for b in range(4):
+        fixed.append(fixed[-1] + tot[b])
+    if fixed[4] != n_total:
+        raise RuntimeError("Invalid seqset in finalize: %d != %d" % (fixed[4], n_total))  # seqset.cpp:123-126
+    out = {}
+    for r in ranks:
+        base = [sum(allp[q][b] for q in range(r)) for b in range(4)]
+        out[r] = SeqsetSlice(ctxs[r], slices[r], B[r], n_total, max_len if n_total else 0, r == P - 1, base, fixed)
+    return out
+
+
+def write_slices(comm, slices, path, argv=()):
+    """All ranks write ONE seqset container: rank 0 lays the file out (headers, JSON members, `fixed`, room for the
+    rest), every rank then writes its bytes of every member in place.  slices = {local rank: SeqsetSlice}."""
+    L = capi.lib()
+    ranks = comm.local_ranks
+    offs = None
+    if 0 in ranks:
+        s0 = slices[0]
+        fx = (C.c_uint64 * 5)(*s0.fixed)
+        av = (C.c_char_p * max(len(argv), 1))(*[a.encode() for a in argv])
+        ho = (C.c_uint64 * 15)()
+        capi.check(L.bg_seqset_sharded_create_file(path.encode(), s0.n_total, s0.max_len, fx, len(argv), av, ho))
+        offs = [int(x) for x in ho]
+    offs = [o for o in comm.all_gather_obj({r: offs if r == 0 else None for r in ranks})[ranks[0]] if o is not None][0]
+    comm.barrier()
+    ho = (C.c_uint64 * 15)(*offs)
+    for r in ranks:
+        s = slices[r]
+        bp = (C.c_uint64 * 4)(*s.base_pop)
+        capi.check(L.bg_seqset_slice_write(s.ctx.h, s.seqset.h, path.encode(), ho, s.first, int(s.is_last), bp))
+    comm.barrier()
+
+
+def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gather=True):
     """comm: communicator; ctxs[r]: biograph_amd.Context of local rank r (its HIP stream must be torch's current
     stream on that device: the exchange buffers are torch tensors handed to the library by pointer); inputs[r] =
-    (seq uint8 tensor, offs int64 tensor, n_reads) resident on that rank's device.  Returns {r: (Seqset | None,
-    stats)}; the assembled seqset lives on rank 0.
+    (seq uint8 tensor, offs int64 tensor, n_reads) resident on that rank's device.  gather=True (small outputs,
+    tests): returns {r: (Seqset | None, stats)}, the assembled seqset lives on rank 0.  gather=False (what scales):
+    returns {r: (SeqsetSlice, stats)} — every rank keeps a 512-aligned stretch of the entries and write_slices()
+    lets all ranks write one container in place.
 
     mode "routed" (default; k >= 14): nothing is replicated — the kept k-mers stay with the rank that counted
     them and the cover index is range-partitioned like the records; "replicated" (BG_SHARD_REPLICATED=1, and
@@ -696,29 +796,12 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None):
     ph.mark("tails_all_to_all")
     recv = comm.all_to_all_v(send)
     del send
-    ph.mark("apply_tails_export")
-    sl_sizes, sl_shared, sl_bits, sl_n = {}, {}, {}, {}
+    ph.mark("apply_tails")
     for r in ranks:
         rows = recv[r].contiguous()
         capi.check(L.bg_seqset_apply_tails(ctxs[r].h, shards[r].h, _ptr(rows), rows.shape[0]))
-        n = shards[r].size()
-        nw = (n + 63) // 64
-        sl_sizes[r] = torch.empty((n,), dtype=torch.uint8, device=dev[r])
-        sl_shared[r] = torch.empty((n,), dtype=torch.uint8, device=dev[r])
-        sl_bits[r] = torch.empty((4 * nw,), dtype=i64, device=dev[r])
-        capi.check(L.bg_seqset_slice_export(ctxs[r].h, shards[r].h, _ptr(sl_sizes[r]), _ptr(sl_shared[r]),
-                                            _ptr(sl_bits[r])))
-        sl_n[r] = n
-        shards[r].free()
     del recv
-
-    ph.mark("gather_assemble")
-    _relieve(ctxs, dev)
-    # ---- final merge on rank 0: concatenation in rank order + finalize
-    g_sizes = comm.all_gather_v(sl_sizes)
-    g_shared = comm.all_gather_v(sl_shared)
-    g_bits = comm.all_gather_v(sl_bits)
-    part_n = comm.all_gather_obj(sl_n)[ranks[0]]
+    part_n = comm.all_gather_obj({r: int(shards[r].size()) for r in ranks})[ranks[0]]
     n_entries = sum(part_n)
     stats = {"n_reads": sum(comm.all_gather_obj({r: inputs[r][2] for r in ranks})[ranks[0]]),
              "n_bases": sum(n_bases), "n_kmers": tot_inst, "n_distinct_kmers": tot_distinct, "n_kept_kmers": n_kept,
@@ -727,6 +810,33 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None):
              "n_entries": n_entries, "max_len": max_len, "shard_entries": part_n}
     stats.update(extra_stats)
     out = {}
+    if not gather:
+        ph.mark("slices")
+        sl = _aligned_slices(comm, ctxs, shards, part_n, max_len, dev)
+        for r in ranks:
+            shards[r].free()
+            out[r] = (sl[r], stats)
+        ph.done()
+        return out
+
+    ph.mark("slice_export")
+    sl_sizes, sl_shared, sl_bits = {}, {}, {}
+    for r in ranks:
+        n = shards[r].size()
+        nw = (n + 63) // 64
+        sl_sizes[r] = torch.empty((n,), dtype=torch.uint8, device=dev[r])
+        sl_shared[r] = torch.empty((n,), dtype=torch.uint8, device=dev[r])
+        sl_bits[r] = torch.empty((4 * nw,), dtype=i64, device=dev[r])
+        capi.check(L.bg_seqset_slice_export(ctxs[r].h, shards[r].h, _ptr(sl_sizes[r]), _ptr(sl_shared[r]),
+                                            _ptr(sl_bits[r])))
+        shards[r].free()
+
+    ph.mark("gather_assemble")
+    _relieve(ctxs, dev)
+    # ---- small outputs / tests: concatenation in rank order + finalize on rank 0
+    g_sizes = comm.all_gather_v(sl_sizes)
+    g_shared = comm.all_gather_v(sl_shared)
+    g_bits = comm.all_gather_v(sl_bits)
     for r in ranks:
         if r != 0:
             out[r] = (None, stats)

@@ -455,6 +455,26 @@ int bg_seqset_slice_export(bg_ctx* ctx, const bg_seqset* ss, uint8_t* d_sizes, u
 int bg_seqset_assemble(bg_ctx* ctx, uint32_t nparts, const uint64_t* h_part_n, const uint8_t* d_sizes,
                        const uint8_t* d_shared, const uint64_t* d_bits, uint32_t max_len, bg_seqset** out);
 
+/* ---- A sharded seqset leaves as slices (no gather on one rank): after the prev bits are applied every rank
+ * re-aligns its entries to multiples of 512 with its neighbours (sizes, shared and one mask byte per entry:
+ * bit b = prev_b), builds its slice and writes its bytes of every container member in place.
+ *   bg_seqset_slice_masks          per-entry arrays of a shard (device): sizes, shared, prev mask
+ *   bg_seqset_slice_build          seqset::finalize (seqset.cpp:113-129, bitcount.cpp:84-124) of an aligned stretch;
+ *                                  max_len = of the whole seqset (it fixes the packed widths)
+ *   bg_seqset_slice_popcounts      set prev bits per base inside the slice
+ *   bg_seqset_sharded_create_file  rank 0: container with room for every payload member (spiral_file_mmap.cpp:350-457);
+ *                                  h_offsets[15] = file offsets of the members' data; writes `fixed`
+ *   bg_seqset_slice_write          every rank: its bytes in place (first_entry % 512 == 0; inner slices hold a
+ *                                  multiple of 512 entries; h_base_pop4 = set bits per base before first_entry) */
+int bg_seqset_slice_masks(bg_ctx* ctx, const bg_seqset* ss, uint8_t* d_sizes, uint8_t* d_shared, uint8_t* d_mask);
+int bg_seqset_slice_build(bg_ctx* ctx, uint64_t m, const uint8_t* d_sizes, const uint8_t* d_shared, const uint8_t* d_mask,
+                          uint32_t max_len, bg_seqset** out);
+int bg_seqset_slice_popcounts(const bg_seqset* ss, uint64_t* h_out4);
+int bg_seqset_sharded_create_file(const char* path, uint64_t n_total, uint32_t max_len, const uint64_t* h_fixed5, int argc,
+                                  const char* const* argv, uint64_t* h_offsets);
+int bg_seqset_slice_write(bg_ctx* ctx, const bg_seqset* slice, const char* path, const uint64_t* h_offsets,
+                          uint64_t first_entry, int is_last, const uint64_t* h_base_pop4);
+
 /* ---- Routed read correction of the sharded build: the kept k-mers stay with the rank that counted them (a
  * k-mer lives in ONE partition, kmer_counter.h:167-178) instead of being gathered on every rank.
  *   bg_kmerset_build_hash   owner: hash table over the kept k-mers bg_skm_count left

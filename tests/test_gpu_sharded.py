@@ -151,3 +151,39 @@ def test_sharded_truncation_narrows_the_word_stride(ctx):
     ref, rst = ctx.create(reads, kmer_size=20, min_kmer_count=2)
     assert rst["max_len"] == 96 and st["n_entries"] == rst["n_entries"] == ss.size()
     assert ss.parts() == ref.parts()
+
+
+@pytest.mark.parametrize("P,alphabet", [(1, "ACGT"), (2, "ACGT"), (3, "ACGT"), (8, "ACGT"), (5, "AC"), (4, "A")])
+def test_sharded_slices_written_in_place_equal_single_gpu(ctx, tmp_path, P, alphabet):
+    """gather=False: nothing is collected on one rank.  Every rank re-aligns its entries to 512 with its
+    neighbours, finalizes its stretch and writes its bytes of every container member in place; the file opens as
+    the seqset of the single-GPU build, member for member (uneven and empty shards, shards of a few entries)."""
+    if alphabet == "ACGT":
+        seq, offs, n = synth.make_reads(genome_len=9000, coverage=30, read_len=150, seed=17, device="cpu")
+        reads = O.unpack_strings(seq.numpy(), offs.numpy().astype(np.uint64))
+        prm = ctx.default_params()
+        kw = {}
+    else:
+        reads = util.synth_reads(7, genome_len=700, n_reads=260, read_len=60, err=0.0, n_rate=0.0, alphabet=alphabet,
+                                 var_len=True, repeat=(5, 30))
+        reads += ["ACG", "A", "T", "ACGTA", "GG"]
+        prm = ctx.default_params(kmer_size=14, min_kmer_count=1)
+        kw = {"kmer_size": 14, "min_kmer_count": 1}
+    comm = sharded.LocalSimComm(P)
+    out = sharded.sharded_create(comm, {r: ctx for r in range(P)}, _shard_inputs(reads, P, np.random.default_rng(P)), prm,
+                                 gather=False)
+    slices = {r: out[r][0] for r in range(P)}
+    st = out[0][1]
+    assert sum(s.size() for s in slices.values()) == st["n_entries"]
+    assert all(s.first % 512 == 0 for s in slices.values())
+    path = str(tmp_path / "seqset")
+    sharded.write_slices(comm, slices, path, ["bgbinary", "create"])
+    for s in slices.values():
+        s.free()
+    got = ctx.open_seqset(path)
+    ref, rst = ctx.create(reads, **kw)
+    assert got.size() == ref.size() == st["n_entries"]
+    want = ref.parts()
+    have = got.parts()
+    for name in bg.PART_NAMES:
+        assert have[name] == want[name], name
