@@ -315,7 +315,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--shape", default="chr20", choices=["tiny", "ecoli", "chr20"])
+    ap.add_argument("--shape", default="chr20", choices=["tiny", "ecoli", "chr20", "human"],
+                    help="human = ONE 3.1 Gb sample (24 contigs) over all ranks: BASELINE.json configs[3], needs 8 GPUs")
     ap.add_argument("--genome-len", type=int, default=0, help="override the shape's genome length")
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--read-len", type=int, default=150)
@@ -363,10 +364,16 @@ def main():
     # Weak scaling: ONE sample whose genome is `world` x the shape's length; every rank holds 1/world of
     # its read pairs (per-GPU reads fixed) and the ranks build ONE seqset together (biograph_amd/sharded.py:
     # k-mers, records and tails cross GPUs by RCCL all_to_all, kept k-mers / corrected reads by all_gather).
-    genome_len = (args.genome_len or synth.SHAPES[args.shape]) * world
+    # "human" is the whole-human configuration itself (3.1 Gb over however many ranks there are), not a per-rank size.
+    genome_len = (args.genome_len or synth.SHAPES[args.shape]) * (1 if args.shape == "human" else world)
+    if args.shape == "human" and not args.genome_len and world < 8:
+        print("bench.py: --shape human is the 8-GPU configuration (93 Gbases; %d rank(s) cannot hold it)" % world,
+              file=sys.stderr)
+        sys.exit(2)
     seq, offs, n_reads, genome = synth.make_reads(genome_len=genome_len, coverage=args.coverage,
                                                   read_len=args.read_len, seed=args.seed, device=dev,
-                                                  shard=(rank, world), return_genome=True)
+                                                  shard=(rank, world), return_genome=True,
+                                                  contigs=synth.contig_lengths(genome_len, args.shape))
     torch.cuda.synchronize()
     n_bases = int(seq.numel())
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -383,10 +390,10 @@ def main():
         comm = sharded.TorchDistComm(dev)
 
         def step():
-            out = sharded.sharded_create(comm, {rank: ctx}, {rank: (seq, offs, n_reads)}, params)
-            ss, st = out[rank]
-            if ss is not None:
-                ss.free()
+            # nothing is gathered: every rank ends the step with its 512-aligned slice of the seqset in HBM
+            out = sharded.sharded_create(comm, {rank: ctx}, {rank: (seq, offs, n_reads)}, params, gather=False)
+            sl, st = out[rank]
+            sl.free()
             return st
     else:
         def step():
@@ -407,6 +414,7 @@ def main():
     timings = ctx.timings()
     ctx.set_profiling(False)
     mem = ctx.memory()
+    mem["torch_peak"] = int(torch.cuda.max_memory_allocated(dev))
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -464,7 +472,11 @@ def main():
                        "%d GPUs, one sample sharded: all_to_all(k-mers, records, tails) + all_gather(kept k-mers, "
                        "corrected reads) over RCCL" % world},
             "roofline": roofline, "cpu_baseline": cpu,
-            "device_memory": {"peak_live_GB": round(mem["peak"] / 1e9, 2), "cached_GB": round(mem["cached"] / 1e9, 2)},
+            "device_memory": {"peak_live_GB": round(mem["peak"] / 1e9, 2), "cached_GB": round(mem["cached"] / 1e9, 2),
+                              "torch_peak_GB": round(mem["torch_peak"] / 1e9, 2),
+                              "note": "rank 0; peak_live = the library's allocator, torch_peak = input reads + exchange "
+                                      "buffers (torch allocator); their sum bounds the rank's footprint"},
+            "rccl_ranks": world if dist is not None else 0,
             "build_roofline": {"algorithmic_bytes_per_step": int(alg), "bytes_per_base": round(alg / max(stats["n_bases"], 1), 2),
                                "achieved_GBps": round(alg / step_s / 1e9, 1),
                                "frac_of_hbm_peak": round(alg / step_s / 1e9 / (HBM_PEAK_GBS * world), 5),

@@ -14,7 +14,23 @@ SHAPES = {
     "tiny": 200_000,
     "ecoli": 4_641_652,
     "chr20": 64_444_167,
+    "human": 3_100_000_000,
 }
+
+# GRCh38 primary assembly, chr1..22, X, Y (bases): the 24 contigs of the "human" shape are proportional to these
+GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
+          135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167,
+          46709983, 50818468, 156040895, 57227415]
+
+
+def contig_lengths(genome_len, shape):
+    """Contigs of a shape: one, except "human" (24, proportional to GRCh38)."""
+    if shape != "human":
+        return [genome_len]
+    tot = float(sum(GRCH38))
+    lens = [int(genome_len * x / tot) for x in GRCH38]
+    lens[0] += genome_len - sum(lens)
+    return lens
 
 
 def make_genome(n, seed, device):
@@ -104,8 +120,10 @@ def plant_variants(reference, seed, g, snp_rate=0.001, indel_rate=1e-4, sv_rate=
 
 def make_reads(genome_len=SHAPES["tiny"], coverage=30, read_len=150, seed=20261002, device="cpu", err=0.002,
                n_rate=0.0001, snp_rate=0.001, chunk_pairs=1 << 20, shard=(0, 1), return_genome=False, repeats=None,
-               indel_rate=1e-4, sv_rate=1e-6, het_frac=2.0 / 3.0):
+               indel_rate=1e-4, sv_rate=1e-6, het_frac=2.0 / 3.0, contigs=None):
     """Returns (seq uint8 [n_reads*read_len], offs int64 [n_reads+1], n_reads).
+
+    contigs: lengths of the contigs the genome is cut into (fragments do not span a contig end).
 
     shard=(rank, world): the same sample (genome + haplotypes from `seed`) on every rank, each rank
     drawing its own 1/world of the read pairs (read RNG seeded with seed + 2 + 1000*rank)."""
@@ -151,6 +169,10 @@ def make_reads(genome_len=SHAPES["tiny"], coverage=30, read_len=150, seed=202610
         insert = torch.maximum(insert, torch.full_like(insert, read_len))
         # integer draw: float32 uniforms have 24 bits, which would quantise the starts of a >16 Mb genome
         start = torch.randint(0, max(hap_len - 800, 1), (m,), generator=g, device=dev)
+        if contigs is not None and len(contigs) > 1:  # a fragment that would cross a contig end is moved inside
+            ends = torch.cumsum(torch.tensor(contigs, dtype=torch.int64, device=dev), 0)
+            cid = torch.searchsorted(ends, start, right=True).clamp_(max=len(contigs) - 1)
+            start = torch.minimum(start, (ends[cid] - 800).clamp_(min=0))
         hap = torch.randint(0, 2, (m,), generator=g, device=dev)
         flip = torch.rand(m, generator=g, device=dev) < 0.5  # which strand the fragment came from
         # mate 1: forward from fragment start; mate 2: reverse complement from fragment end (FR)

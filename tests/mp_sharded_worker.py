@@ -31,6 +31,11 @@ def main():
     comm = sharded.TorchDistComm(dev, stage_through_host=not rccl)
     out = sharded.sharded_create(comm, {rank: ctx}, {rank: (seq, offs, n)})
     ss, st = out[rank]
+    # the same build again without the gather: every process writes its slice of one container in place
+    out2 = sharded.sharded_create(comm, {rank: ctx}, {rank: (seq, offs, n)}, gather=False)
+    sliced_path = out_path + ".seqset"
+    sharded.write_slices(comm, {rank: out2[rank][0]}, sliced_path, ["mp_sharded_worker"])
+    out2[rank][0].free()
     # every rank also ships its reads to rank 0 so the single-GPU build of the same sample can be compared
     gathered = [None] * world
     dist.all_gather_object(gathered, (seq.cpu().numpy(), n))
@@ -41,7 +46,10 @@ def main():
         doffs = torch.arange(0, (total + 1) * 150, 150, dtype=torch.int64, device=dev)
         ref, rst = ctx.create_device(dseq.data_ptr(), doffs.data_ptr(), total)
         same = all(ss.part(p) == ref.part(p) for p in bg.PART_NAMES)
-        json.dump({"same": bool(same), "n_entries": ss.size(), "ref_entries": ref.size(), "stats": st,
+        opened = ctx.open_seqset(sliced_path)
+        same_sliced = all(opened.part(p) == ref.part(p) for p in bg.PART_NAMES)
+        opened.free()
+        json.dump({"same": bool(same), "same_sliced": bool(same_sliced), "n_entries": ss.size(), "ref_entries": ref.size(), "stats": st,
                    "shards": st["shard_entries"]}, open(out_path, "w"))
         ref.free()
         ss.free()

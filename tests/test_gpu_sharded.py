@@ -187,3 +187,46 @@ def test_sharded_slices_written_in_place_equal_single_gpu(ctx, tmp_path, P, alph
     have = got.parts()
     for name in bg.PART_NAMES:
         assert have[name] == want[name], name
+
+
+def _sim_build_memory(P, genome_len, mode):
+    """Per-rank peak of the library's allocator (one Context per simulated rank) and the process-wide peak of
+    torch's (inputs + exchange buffers of ALL simulated ranks) for one sharded build."""
+    ctxs = {r: bg.Context(0) for r in range(P)}
+    inputs = {}
+    for r in range(P):
+        seq, offs, n = synth.make_reads(genome_len=genome_len, coverage=30, read_len=150, seed=23, device="cuda",
+                                        shard=(r, P))
+        inputs[r] = (seq, offs, n)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    for c in ctxs.values():
+        c.memory(reset_peak=True)
+    out = sharded.sharded_create(sharded.LocalSimComm(P), ctxs, inputs, mode=mode, gather=False)
+    n_entries = out[0][1]["n_entries"]
+    for r in range(P):
+        out[r][0].free()
+    peaks = [ctxs[r].memory()["peak"] for r in range(P)]
+    tpeak = torch.cuda.max_memory_allocated() - base
+    for c in ctxs.values():
+        c.close()
+    del inputs, out
+    torch.cuda.empty_cache()
+    return max(peaks), tpeak, n_entries
+
+
+def test_routed_per_rank_memory_does_not_grow_with_the_total():
+    """Same reads per rank (1 Mb of genome at 30x each), total doubled (4 ranks -> 8 ranks, simulated): in the routed
+    build no per-rank allocation follows the TOTAL number of reads or kept k-mers — the library peak of the
+    fullest rank and the exchange buffers per rank stay put; the replicated build (all-gathered k-mer set and
+    cover index on every rank) grows, which is what the test would catch."""
+    per_rank = 1_000_000
+    p4, t4, n4 = _sim_build_memory(4, 4 * per_rank, "routed")
+    p8, t8, n8 = _sim_build_memory(8, 8 * per_rank, "routed")
+    assert n8 > 1.8 * n4
+    assert p8 <= 1.15 * p4, (p4, p8)            # the fullest rank's library allocations
+    assert t8 / 8 <= 1.15 * t4 / 4, (t4, t8)    # torch side: inputs + exchange buffers, per rank
+    q4, u4, _ = _sim_build_memory(4, 4 * per_rank, "replicated")
+    q8, u8, _ = _sim_build_memory(8, 8 * per_rank, "replicated")
+    assert q8 > 1.3 * q4, (q4, q8)              # the replicated structures follow the total
