@@ -126,6 +126,44 @@ class Context:
         capi.check(capi.lib().bg_pack_reads_host(self.h, ps, capi.np_ptr(offs), len(offs) - 1, C.byref(h)))
         return Reads(self, h)
 
+    def import_fastq(self, texts, paired_files=False, interleaved=False, cut=None, pinned=True):
+        """FASTQ import on the device (bg_fastq_import): texts = the bytes of every file (plain text; mate files
+        alternate when paired_files).  Returns (uint8 concatenated bases, uint64 offsets) on the host — mates are
+        reads 2i, 2i+1 when paired."""
+        L = capi.lib()
+        bufs = []
+        try:
+            for t in texts:
+                a = np.frombuffer(bytes(t), np.uint8)
+                d = DeviceArray(self, max(a.nbytes, 1))
+                if a.nbytes:
+                    if pinned:
+                        capi.check(L.bg_dev_upload_pinned(self.h, d.ptr, capi.np_ptr(a), a.nbytes, 0))
+                    else:
+                        capi.check(L.bg_dev_upload(self.h, d.ptr, capi.np_ptr(a), a.nbytes))
+                bufs.append((d, a.nbytes))
+            n = len(bufs)
+            ptrs = (C.c_void_p * max(n, 1))(*[b[0].ptr for b in bufs])
+            sizes = (C.c_uint64 * max(n, 1))(*[b[1] for b in bufs])
+            d_seq, d_offs = C.c_void_p(), C.c_void_p()
+            n_reads, n_bases = C.c_uint64(), C.c_uint64()
+            cs, ce = cut if cut else (0, 0)
+            capi.check(L.bg_fastq_import(self.h, n, ptrs, sizes, int(bool(paired_files)), int(bool(interleaved)), cs, ce,
+                                         C.byref(d_seq), C.byref(d_offs), C.byref(n_reads), C.byref(n_bases)))
+            try:
+                seq = np.zeros(max(n_bases.value, 1), np.uint8)
+                offs = np.zeros(n_reads.value + 1, np.uint64)
+                if n_bases.value:
+                    capi.check(L.bg_dev_download(self.h, capi.np_ptr(seq), d_seq, n_bases.value))
+                capi.check(L.bg_dev_download(self.h, capi.np_ptr(offs), d_offs, offs.nbytes))
+            finally:
+                L.bg_dev_free(self.h, d_seq)
+                L.bg_dev_free(self.h, d_offs)
+            return seq[:n_bases.value], offs
+        finally:
+            for d, _ in bufs:
+                d.free()
+
     def pack_reads_device(self, d_seq, d_offs, n_reads):
         h = C.c_void_p()
         capi.check(capi.lib().bg_pack_reads(self.h, C.c_void_p(d_seq), C.c_void_p(d_offs), n_reads, C.byref(h)))

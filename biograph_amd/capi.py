@@ -83,10 +83,11 @@ SYMBOLS = [
     "bg_kmerset_build_hash", "bg_skm_lookup", "bg_corr_begin", "bg_corr_step", "bg_corr_answers", "bg_corr_finish",
     "bg_corr_probes", "bg_corr_free",
     "bg_seqset_slice_masks", "bg_seqset_slice_build", "bg_seqset_slice_popcounts", "bg_seqset_sharded_create_file",
-    "bg_seqset_slice_write",
+    "bg_seqset_slice_write", "bg_fastq_import", "bg_dev_upload_pinned",
+    "bg_seqset_uuid", "bg_seqset_tail_rows2", "bg_seqset_apply_tails2", "bg_seqset_tail_rows_full", "bg_records_from_row_parts",
 ]
 
-PART_KMER_HASH, PART_PREFIX, PART_KEY_BOUNDS = 0, 1, 2
+PART_KMER_HASH, PART_PREFIX, PART_KEY_BOUNDS, PART_ROW_DEST = 0, 1, 2, 3
 
 
 def lib():
@@ -240,6 +241,13 @@ def lib():
     L.bg_seqset_slice_popcounts.argtypes = [vp, P(u64)]
     L.bg_seqset_sharded_create_file.argtypes = [C.c_char_p, u64, u32, P(u64), i32, P(C.c_char_p), P(u64)]
     L.bg_seqset_slice_write.argtypes = [vp, vp, C.c_char_p, P(u64), u64, i32, P(u64)]
+    L.bg_seqset_uuid.argtypes = [vp, C.c_char_p, u64]
+    L.bg_seqset_tail_rows2.argtypes = [vp, vp, u32, vp, vp]
+    L.bg_seqset_apply_tails2.argtypes = [vp, vp, vp, u64, vp]
+    L.bg_seqset_tail_rows_full.argtypes = [vp, vp, vp, vp, u64, vp, u64, P(u64)]
+    L.bg_records_from_row_parts.argtypes = [vp, u32, P(vp), P(u64), i32, P(vp)]
+    L.bg_fastq_import.argtypes = [vp, u32, P(vp), P(u64), i32, i32, u32, u32, P(vp), P(vp), P(u64), P(u64)]
+    L.bg_dev_upload_pinned.argtypes = [vp, vp, vp, u64, i32]
     L.bg_oriented_rows.argtypes = [vp, vp, i32, vp]
     L.bg_rows_prefix_hist.argtypes = [vp, vp, u64, i32, i32, u64, vp]
     L.bg_cover_build.argtypes = [vp, vp, u64, i32, i32, P(vp)]

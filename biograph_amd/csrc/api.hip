@@ -269,6 +269,11 @@ extern "C" int bg_dev_download(bg_ctx* ctx, void* h_dst, const void* d_src, uint
 
 extern "C" uint64_t bg_seqset_size(const bg_seqset* ss) { return ss ? ss->n : 0; }
 extern "C" uint32_t bg_seqset_max_len(const bg_seqset* ss) { return ss ? ss->max_len : 0; }
+extern "C" int bg_seqset_uuid(const bg_seqset* ss, char* h_out, uint64_t cap) {
+  if (!ss || !h_out || cap < ss->uuid.size() + 1) { set_error("bg_seqset_uuid: buffer too small"); return BG_EINVAL; }
+  memcpy(h_out, ss->uuid.c_str(), ss->uuid.size() + 1);
+  return BG_OK;
+}
 extern "C" void bg_seqset_free(bg_seqset* ss) { delete ss; }
 
 extern "C" int bg_seqset_part(bg_ctx* ctx, const bg_seqset* ss, const char* part, void* h_out, uint64_t* size) {

@@ -216,6 +216,7 @@ int build_prefix_dir_keys(bg_ctx* ctx, const uint64_t* keys, uint64_t n, int W, 
 int alloc_prev_bits(bg_ctx* ctx, bg_seqset* ss);
 int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss);
 int apply_tails_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint32_t* d_err);
+int apply_tails2_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint8_t* d_need_full, uint32_t* d_err);
 int kmerset_sort(bg_ctx* ctx, bg_kmerset* ks);
 int read_locus_order(bg_ctx* ctx, const bg_reads* reads, uint64_t first, uint64_t count, DevBuf<uint32_t>* perm);
 // spiral_zip.cpp

@@ -1407,6 +1407,79 @@ __global__ __launch_bounds__(256) void k_apply_tails_pre2(const uint64_t* __rest
   marks[uint64_t(b) * n + lo] = 1;
 }
 
+// short tails (3 words: two leading words of the tail, meta): a tail shorter than 64 bases is all there in its
+// two words; a longer one whose leading words occur in exactly one entry has found its target (the test of
+// k_prev_bits_pre2); the rest need the whole tail
+__global__ __launch_bounds__(256) void k_apply_tails_short(const uint64_t* __restrict__ rows, uint64_t nt,
+                                                           const uint64_t* __restrict__ ekeys,
+                                                           const uint64_t* __restrict__ pre2,
+                                                           const uint8_t* __restrict__ sizes, uint64_t n, int W,
+                                                           const uint32_t* __restrict__ dir, int bases,
+                                                           uint8_t* __restrict__ marks, uint8_t* __restrict__ need_full,
+                                                           uint32_t* __restrict__ err, int verify) {
+  uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= nt) return;
+  const uint64_t t0 = rows[t * 3], t1 = rows[t * 3 + 1], meta = rows[t * 3 + 2];
+  const int tl = int(meta & 0xff), b = int((meta >> 8) & 3);
+  need_full[t] = 0;
+  if (tl >= 64 && (verify || W <= 2)) { need_full[t] = 1; return; }  // W <= 2 cannot hold 64 + bases: never
+  if (tl < 64) {
+    uint64_t tail[kMaxWords];
+    tail[0] = t0;
+    tail[1] = t1;
+    for (int w = 2; w < kMaxWords; ++w) tail[w] = 0;
+    uint64_t lo;
+    if (!prev_target_pre2(ekeys, pre2, sizes, n, W, dir, bases, tail, tl, 0, err, &lo)) return;
+    marks[uint64_t(b) * n + lo] = 1;
+    return;
+  }
+  const uint32_t p = uint32_t(t0 >> (64 - 2 * bases));
+  const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(pre2);
+  uint64_t a = dir[p], z = dir[p + 1];
+  while (a < z) {
+    const uint64_t mid = (a + z) >> 1;
+    const ulonglong2 m = p2[mid];
+    if (m.x < t0 || (m.x == t0 && m.y < t1)) a = mid + 1; else z = mid;
+  }
+  bool sure = false;
+  if (a < n) {
+    const ulonglong2 c0 = p2[a];
+    sure = c0.x == t0 && c0.y == t1;
+    if (sure && a + 1 < n) {
+      const ulonglong2 c1 = p2[a + 1];
+      sure = c1.x != t0 || c1.y != t1;
+    }
+  }
+  // the one entry with these 64 leading bases: it is the target if it is long enough to extend the tail at all
+  // (an entry that agrees on 64 bases but is shorter than the tail cannot be: ask for the whole tail)
+  if (sure && int(sizes[a]) >= tl) {
+    // NB equal leading words do not prove the entry extends the tail beyond base 64: the closure of the entry set
+    // does (some entry extends the tail, and this is the only one that starts like it)
+    marks[uint64_t(b) * n + a] = 1;
+  } else {
+    need_full[t] = 1;
+  }
+}
+
+int apply_tails2_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint8_t* d_need_full, uint32_t* d_err) {
+  DevBuf<uint32_t> dir;
+  DevBuf<uint8_t> marks;
+  int bases = 0;
+  const bool use_pre2 = ss->pre2.p && ss->pre2.n >= 2 * ss->n;
+  if (!use_pre2) { set_error("short tails need the entries' two-word prefixes"); return BG_EINVAL; }
+  BG_TRY(build_prefix_dir_keys(ctx, ss->pre2.p, ss->n, 2, &dir, &bases));
+  BG_TRY(marks.alloc(ctx, 4 * ss->n));
+  if (ss->n) BG_HIP(hipMemsetAsync(marks.p, 0, 4 * ss->n, ctx->stream));
+  const char* v = getenv("BG_VERIFY_CLOSURE");
+  const bool full = (v && v[0] == '1') || getenv("BG_PREV_FULL_SEARCH");
+  k_apply_tails_short<<<cdiv(n_rows, 256), 256, 0, ctx->stream>>>(d_rows, n_rows, ss->keys.p, ss->pre2.p, ss->sizes.p, ss->n, ss->W,
+                                                                 dir.p, bases, marks.p, d_need_full, d_err, full ? 1 : 0);
+  BG_LAUNCH_CHECK();
+  BG_TRY(pack_marks(ctx, ss, marks.p));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
 int apply_tails_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint32_t* d_err) {
   DevBuf<uint32_t> dir;
   DevBuf<uint8_t> marks;

@@ -13,8 +13,12 @@
 // C-ABI call that runs on the GPU.  The sample's readmap lands in coverage/<sha1>.readmap and is listed
 // under "samples" in metadata/bg_info.json (biograph_create.cpp:812-831, biograph_dir.cpp).
 #include <errno.h>
+#include <fcntl.h>
+#include <stdarg.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <time.h>
 #include <zlib.h>
 
@@ -45,7 +49,9 @@ struct Args {
   }
 };
 
-static Args parse(int argc, char** argv, int first) {
+// Options every command understands are listed per command: anything else is an error, never silently
+// ignored (an interleaved FASTQ imported as unpaired, a --cut-reads that cuts nothing).
+static Args parse(int argc, char** argv, int first, const std::vector<std::string>& known) {
   static const char* flags[] = {"interleaved", "force", "f", "allow-long-reads", nullptr};
   Args a;
   for (int i = first; i < argc; ++i) {
@@ -53,38 +59,78 @@ static Args parse(int argc, char** argv, int first) {
     if (s.rfind("--", 0) != 0 && s != "-f") die("unexpected argument: " + s);
     std::string key = s == "-f" ? "force" : s.substr(2), val;
     size_t eq = key.find('=');
+    if (eq != std::string::npos) { val = key.substr(eq + 1); key = key.substr(0, eq); }
     bool is_flag = false;
     for (const char** f = flags; *f; ++f) is_flag |= key == *f;
-    if (eq != std::string::npos) { val = key.substr(eq + 1); key = key.substr(0, eq); }
-    else if (!is_flag) { if (i + 1 >= argc) die("missing value for --" + key); val = argv[++i]; }
+    if (eq == std::string::npos && !is_flag) { if (i + 1 >= argc) die("missing value for --" + key); val = argv[++i]; }
     if (key == "in") key = "reads";  // --reads,in (biograph_create.cpp:263)
+    if (std::find(known.begin(), known.end(), key) == known.end())
+      die("unknown or unsupported option --" + key + " (this build does not implement it; refusing to ignore it)");
     a.opt[key].push_back(val);
   }
   return a;
 }
 
-// FASTQ (plain or gzip) -> sequences; qualities dropped (read_importer.cpp:22)
-static void read_fastq(const std::string& path, std::vector<std::string>* out) {
-  gzFile f = gzopen(path == "-" ? "/dev/stdin" : path.c_str(), "rb");
-  if (!f) die("Could not open " + path + ": " + strerror(errno));
-  gzbuffer(f, 1 << 20);
-  std::vector<char> buf(1 << 16);
-  std::string line;
-  uint64_t lineno = 0;
-  auto getline = [&](std::string* l) -> bool {
-    l->clear();
-    for (;;) {
-      if (!gzgets(f, buf.data(), int(buf.size()))) return !l->empty();
-      l->append(buf.data());
-      if (!l->empty() && l->back() == '\n') { l->pop_back(); if (!l->empty() && l->back() == '\r') l->pop_back(); return true; }
-    }
-  };
-  while (getline(&line)) {
-    if (lineno % 4 == 0 && !line.empty() && line[0] != '@') die(path + ": malformed FASTQ record at line " + std::to_string(lineno + 1));
-    if (lineno % 4 == 1) out->push_back(line);
-    ++lineno;
+static std::string json_escape(const std::string& s) {
+  std::string o;
+  for (unsigned char c : s) {
+    if (c == '"' || c == '\\') { o.push_back('\\'); o.push_back(char(c)); }
+    else if (c == '\n') o += "\\n";
+    else if (c == '\t') o += "\\t";
+    else if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; }
+    else o.push_back(char(c));
   }
+  return o;
+}
+static std::string json_str(const std::string& s) { return "\"" + json_escape(s) + "\""; }
+static std::string json_argv(int argc, char** argv) {
+  std::string cmd;
+  for (int i = 0; i < argc; ++i) cmd += std::string(i ? " " : "") + argv[i];
+  return json_str(cmd);
+}
+
+// One input file in host memory: plain text is mapped, gzip is inflated (zlib; GPU-side gzip is out of scope,
+// SURVEY.md section 8 f.4b).
+struct HostText {
+  const char* p = nullptr;
+  size_t n = 0;
+  void* map = nullptr;
+  size_t map_len = 0;
+  std::string inflated;
+};
+static void load_text(const std::string& path, HostText* t) {
+  int fd = open(path == "-" ? "/dev/stdin" : path.c_str(), O_RDONLY);
+  if (fd < 0) die("Could not open " + path + ": " + strerror(errno));
+  unsigned char magic[2] = {0, 0};
+  struct stat st;
+  const bool regular = fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+  if (regular && pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b) && st.st_size > 0) {
+    void* m = mmap(nullptr, size_t(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m != MAP_FAILED) {
+      t->map = m;
+      t->map_len = size_t(st.st_size);
+      t->p = static_cast<const char*>(m);
+      t->n = t->map_len;
+      close(fd);
+      return;
+    }
+  }
+  close(fd);
+  gzFile f = gzopen(path == "-" ? "/dev/stdin" : path.c_str(), "rb");  // transparent for plain text (pipes)
+  if (!f) die("Could not open " + path + ": " + strerror(errno));
+  gzbuffer(f, 1 << 22);
+  std::vector<char> buf(1 << 24);
+  int got;
+  while ((got = gzread(f, buf.data(), unsigned(buf.size()))) > 0) t->inflated.append(buf.data(), size_t(got));
+  if (got < 0) die(path + ": read error (truncated gzip?)");
   gzclose(f);
+  t->p = t->inflated.data();
+  t->n = t->inflated.size();
+}
+static void free_text(HostText* t) {
+  if (t->map) munmap(t->map, t->map_len);
+  t->map = nullptr;
+  std::string().swap(t->inflated);
 }
 
 static bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
@@ -103,12 +149,40 @@ static double now_s() {
   return ts.tv_sec + ts.tv_nsec * 1e-9;
 }
 
+static std::string g_log;  // qc/create_log.txt (biograph_create.cpp:527): what went to stderr, with times
+static void logf(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  fprintf(stderr, "%s\n", buf);
+  time_t now = time(nullptr);
+  char tb[32];
+  struct tm tmv;
+  localtime_r(&now, &tmv);
+  strftime(tb, sizeof tb, "%Y-%m-%d %H:%M:%S", &tmv);
+  g_log += std::string(tb) + " " + buf + "\n";
+}
+
+static std::string stem_of(std::string p) {  // accession id default: stem of the output directory (:518-520)
+  while (p.size() > 1 && p.back() == '/') p.pop_back();
+  size_t sl = p.rfind('/');
+  if (sl != std::string::npos) p = p.substr(sl + 1);
+  size_t dot = p.rfind('.');
+  return dot == std::string::npos || dot == 0 ? p : p.substr(0, dot);
+}
+
 static int cmd_create(int argc, char** argv) {
-  Args a = parse(argc, argv, 2);
+  Args a = parse(argc, argv, 2, {"reads", "pair", "interleaved", "ref", "out", "id", "force", "kmer-size", "min-kmer-count",
+                                 "trim-after-portion", "max-corrections", "min-good-run", "min-reads", "warn-reads", "stats",
+                                 "cut-reads", "threads", "tmp", "max-mem", "format", "allow-long-reads"});
   if (!a.has("reads") || !a.has("out")) die("create: --reads and --out are required");
   std::string out = a.get("out");
   if (out.size() < 3 || out.substr(out.size() - 3) != ".bg") out += ".bg";  // biograph_dir appends .bg
-  if (exists(out + "/seqset") && !a.has("force")) die("Refusing to overwrite " + out + ". Use --force to override.");
+  if (exists(out + "/seqset") && !a.has("force")) die("Refusing to overwrite '" + out + "'. Use --force to override.");
+  const std::string fmt = a.get("format", "auto");
+  if (fmt != "auto" && fmt != "fastq") die("Invalid input format '" + fmt + "' (this build reads FASTQ, plain or gzip; BAM/CRAM need htslib)");
   bg_create_params p;
   bg_create_params_default(&p);
   p.kmer_size = atoi(a.get("kmer-size", "30").c_str());
@@ -118,99 +192,126 @@ static int cmd_create(int argc, char** argv) {
   p.correct.min_good_run = uint32_t(atoi(a.get("min-good-run", "2").c_str()));
   double min_reads = atof(a.get("min-reads", "0.4").c_str()), warn_reads = atof(a.get("warn-reads", "0.7").c_str());
   if (p.min_kmer_count < 1) die("--min-kmer-count must be at least 1");
-
-  double t0 = now_s();
-  fprintf(stderr, "Importing reads\n");
-  std::vector<std::string> reads;
+  uint32_t cut_start = 0, cut_end = 0;
+  if (a.has("cut-reads") && !a.get("cut-reads").empty()) {  // validate_cut_param, biograph_create.cpp:376-420
+    const std::string v = a.get("cut-reads");
+    size_t dash = v.find('-');
+    if (dash == std::string::npos) die("cut-reads must specify a range separated by a dash");
+    char* e1 = nullptr;
+    char* e2 = nullptr;
+    unsigned long s0 = strtoul(v.substr(0, dash).c_str(), &e1, 10), s1 = strtoul(v.substr(dash + 1).c_str(), &e2, 10);
+    if (dash == 0 || dash + 1 == v.size() || *e1 || *e2) die("cut-reads must specify a numerical range; couldn't parse " + v);
+    if (s1 <= s0) die("cut-reads: the end of the range must be greater than its start");
+    cut_start = uint32_t(s0);
+    cut_end = uint32_t(s1);
+  }
   const auto& ins = a.opt["reads"];
   const auto& pairs = a.has("pair") ? a.opt["pair"] : std::vector<std::string>();
-  if (!pairs.empty() && pairs.size() != ins.size()) die("--pair must be given once per --reads");
-  for (size_t i = 0; i < ins.size(); ++i) {
-    std::vector<std::string> r1, r2;
-    read_fastq(ins[i], &r1);
-    if (!pairs.empty()) {
-      read_fastq(pairs[i], &r2);
-      if (r1.size() != r2.size()) die("Pair files hold different numbers of reads");
-      for (size_t j = 0; j < r1.size(); ++j) { reads.push_back(std::move(r1[j])); reads.push_back(std::move(r2[j])); }
-    } else {
-      for (auto& s : r1) reads.push_back(std::move(s));
-    }
-  }
-  if (reads.empty()) die("\nNo reads were imported, exiting.");
-  fprintf(stderr, "\nTotal reads imported: %zu\n", reads.size());
-  double t_import = now_s() - t0;
+  const bool interleaved = a.has("interleaved");
+  if (!pairs.empty() && pairs.size() != ins.size()) die("If pair files are present, there must be the same number of them as read files.");
+  if (interleaved && !pairs.empty()) die("--interleaved and --pair exclude each other");
+  const int threads = atoi(a.get("threads", "0").c_str());
 
+  double t0 = now_s();
+  logf("Importing reads");
   bg_ctx* ctx = nullptr;
   check(bg_ctx_create(0, nullptr, &ctx), "bg_ctx_create");
-  std::string seq;
-  std::vector<uint64_t> offs{0};
-  size_t total = 0;
-  for (auto& r : reads) total += r.size();
-  seq.reserve(total);
-  for (auto& r : reads) { seq += r; offs.push_back(seq.size()); }
-  void *d_seq = nullptr, *d_offs = nullptr;
-  check(bg_dev_alloc(ctx, seq.size(), &d_seq), "bg_dev_alloc");
-  check(bg_dev_alloc(ctx, offs.size() * 8, &d_offs), "bg_dev_alloc");
-  check(bg_dev_upload(ctx, d_seq, seq.data(), seq.size()), "upload");
-  check(bg_dev_upload(ctx, d_offs, offs.data(), offs.size() * 8), "upload");
-  fprintf(stderr, "\nRunning kmerization, read correction, seqset and readmap build on the GPU\n");
+  // the bytes of every file go to HBM as they are; records are found and paired there (csrc/fastq.hip)
+  std::vector<std::string> files;
+  for (size_t i = 0; i < ins.size(); ++i) { files.push_back(ins[i]); if (!pairs.empty()) files.push_back(pairs[i]); }
+  std::vector<void*> d_text(files.size(), nullptr);
+  std::vector<uint64_t> n_text(files.size(), 0);
+  uint64_t text_bytes = 0;
+  for (size_t i = 0; i < files.size(); ++i) {
+    HostText t;
+    load_text(files[i], &t);
+    n_text[i] = t.n;
+    text_bytes += t.n;
+    check(bg_dev_alloc(ctx, t.n ? t.n : 1, &d_text[i]), "bg_dev_alloc");
+    check(bg_dev_upload_pinned(ctx, d_text[i], t.p, t.n, threads), "upload");
+    free_text(&t);
+  }
+  double t_upload = now_s() - t0;
+  uint8_t* d_seq = nullptr;
+  uint64_t* d_offs = nullptr;
+  uint64_t n_reads = 0, n_bases = 0;
+  std::vector<const uint8_t*> tp;
+  for (void* q : d_text) tp.push_back(static_cast<const uint8_t*>(q));
+  check(bg_fastq_import(ctx, uint32_t(files.size()), tp.data(), n_text.data(), pairs.empty() ? 0 : 1, interleaved ? 1 : 0, cut_start,
+                        cut_end, &d_seq, &d_offs, &n_reads, &n_bases),
+        "import");
+  for (void* q : d_text) bg_dev_free(ctx, q);
+  if (!n_reads) die("\nNo reads were imported, exiting.");
+  double t_import = now_s() - t0;
+  logf("Total reads imported: %llu (%llu bases, %.2f GB of FASTQ; %.3f s, of which %.3f s moving the files to the GPU)",
+       (unsigned long long)n_reads, (unsigned long long)n_bases, text_bytes / 1e9, t_import, t_upload);
+
+  logf("Running kmerization, read correction, seqset and readmap build on the GPU");
   double t1 = now_s();
   bg_seqset* ss = nullptr;
   bg_readmap* rm = nullptr;
   bg_build_stats st;
-  check(bg_create_sample(ctx, static_cast<const uint8_t*>(d_seq), static_cast<const uint64_t*>(d_offs), reads.size(), &p,
-                         pairs.empty() ? 0 : 1, &ss, &rm, &st),
-        "bg_create_sample");
+  const int is_paired = (!pairs.empty() || interleaved) ? 1 : 0;
+  check(bg_create_sample(ctx, d_seq, d_offs, n_reads, &p, is_paired, &ss, &rm, &st), "bg_create_sample");
   double t_build = now_s() - t1;
-  double pct = double(st.n_corrected_reads) / double(reads.size());
+  bg_dev_free(ctx, d_seq);
+  bg_dev_free(ctx, d_offs);
+  double pct = double(st.n_corrected_reads) / double(n_reads);
   char msg[256];
   if (pct < min_reads) {  // biograph_create.cpp:748-757
-    snprintf(msg, sizeof msg, "Fewer than %2.0f%% of reads (set by --min-reads) were kept after correction (%llu / %zu remain). Cannot continue.",
-             min_reads * 100.0, (unsigned long long)st.n_corrected_reads, reads.size());
+    snprintf(msg, sizeof msg, "Fewer than %2.0f%% of reads (set by --min-reads) were kept after correction (%llu / %llu remain). Cannot continue.",
+             min_reads * 100.0, (unsigned long long)st.n_corrected_reads, (unsigned long long)n_reads);
     die(msg);
   }
   if (pct < warn_reads)
-    fprintf(stderr, "Warning: Fewer than %2.0f%% of reads (set by --warn-reads) survived correction (%llu / %zu remain)\n",
-            warn_reads * 100.0, (unsigned long long)st.n_corrected_reads, reads.size());
+    logf("Warning: Fewer than %2.0f%% of reads (set by --warn-reads) survived correction (%llu / %llu remain)",
+         warn_reads * 100.0, (unsigned long long)st.n_corrected_reads, (unsigned long long)n_reads);
 
   mkdirs(out);
   mkdirs(out + "/qc");
   mkdirs(out + "/metadata");
   mkdirs(out + "/coverage");
+  double t2 = now_s();
   std::vector<const char*> av(argv, argv + argc);
   check(bg_seqset_write(ctx, ss, (out + "/seqset").c_str(), argc, av.data()), "bg_seqset_write");
   char sha[41];
   std::string rm_tmp = out + "/coverage/tmp.readmap";
   check(bg_readmap_write(ctx, rm, rm_tmp.c_str(), argc, av.data(), sha), "bg_readmap_write");
   if (rename(rm_tmp.c_str(), (out + "/coverage/" + sha + ".readmap").c_str()) != 0) die("Could not rename " + rm_tmp);
-  double t_total = now_s() - t0;
+  double t_write = now_s() - t2, t_total = now_s() - t0;
 
   std::string id = a.get("id");
-  char js[2048];
-  snprintf(js, sizeof js,
-           "{\"command\":\"create\",\"version\":\"biograph_amd-r1\",\"accession_id\":\"%s\",\"imported_reads\":%zu,"
-           "\"corrected_reads\":%llu,\"corrected_bases\":%llu,\"avg_bases_per_read\":%.6f,\"corrected_pct\":%.6f,"
-           "\"kept_kmers\":%llu,\"seqset_entries\":%llu,\"timings\":[{\"import\":%.0f},{\"gpu_build\":%.3f},{\"total\":%.0f}]}",
-           id.c_str(), reads.size(), (unsigned long long)st.n_corrected_reads, (unsigned long long)st.n_corrected_bases,
+  if (id.empty()) id = stem_of(out);
+  char uuid[64] = "";
+  bg_seqset_uuid(ss, uuid, sizeof uuid);
+  char nums[1024];
+  snprintf(nums, sizeof nums,
+           "\"imported_reads\":%llu,\"imported_bases\":%llu,\"corrected_reads\":%llu,\"corrected_bases\":%llu,"
+           "\"avg_bases_per_read\":%.6f,\"corrected_pct\":%.6f,\"kept_kmers\":%llu,\"seqset_entries\":%llu,"
+           "\"timings\":[{\"import\":%.3f},{\"gpu_build\":%.3f},{\"write\":%.3f},{\"total\":%.3f}]",
+           (unsigned long long)n_reads, (unsigned long long)n_bases, (unsigned long long)st.n_corrected_reads,
+           (unsigned long long)st.n_corrected_bases,
            st.n_corrected_reads ? double(st.n_corrected_bases) / double(st.n_corrected_reads) : 0.0, pct,
-           (unsigned long long)st.n_kept_kmers, (unsigned long long)st.n_entries, t_import, t_build, t_total);
+           (unsigned long long)st.n_kept_kmers, (unsigned long long)st.n_entries, t_import, t_build, t_write, t_total);
+  std::string js = "{\"command\":\"create\",\"version\":\"biograph_amd-r2\",\"accession_id\":" + json_str(id) + ",\"uuid\":" +
+                   json_str(uuid) + "," + nums + "}";
   write_file(out + "/qc/create_stats.json", js);
   if (a.has("stats")) write_file(a.get("stats"), js);
-  snprintf(js, sizeof js, "{\"accession_id\":\"%s\",\"command_history\":[],\"samples\":{\"%s\":\"%s\"},\"version\":\"biograph_amd-r1\"}",
-           id.c_str(), id.c_str(), sha);
-  write_file(out + "/metadata/bg_info.json", js);
-  fprintf(stderr, "%llu / %zu reads survived read correction; %llu seqset entries; GPU build %.3f s\n",
-          (unsigned long long)st.n_corrected_reads, reads.size(), (unsigned long long)st.n_entries, t_build);
+  std::string meta = "{\"accession_id\":" + json_str(id) + ",\"biograph_id\":" + json_str(uuid) + ",\"command_history\":[" +
+                     json_argv(argc, argv) + "],\"samples\":{" + json_str(id) + ":" + json_str(sha) +
+                     "},\"version\":\"biograph_amd-r2\"}";
+  write_file(out + "/metadata/bg_info.json", meta);
+  logf("%llu / %llu reads survived read correction; %llu seqset entries; GPU build %.3f s; %.3f s in all",
+       (unsigned long long)st.n_corrected_reads, (unsigned long long)n_reads, (unsigned long long)st.n_entries, t_build, t_total);
+  write_file(out + "/qc/create_log.txt", g_log);
   bg_readmap_free(rm);
   bg_seqset_free(ss);
-  bg_dev_free(ctx, d_seq);
-  bg_dev_free(ctx, d_offs);
   bg_ctx_destroy(ctx);
   return 0;
 }
 
 static int cmd_refmap(int argc, char** argv) {
-  Args a = parse(argc, argv, 2);
+  Args a = parse(argc, argv, 2, {"reads", "ref", "out"});
   if (!a.has("in") && !a.has("reads")) die("refmap: --in S.bg is required");
   if (!a.has("ref") || !a.has("out")) die("refmap: --ref and --out are required");
   std::string bgdir = a.has("reads") ? a.get("reads") : a.get("in");
@@ -268,32 +369,50 @@ static std::string read_text(const std::string& p) {
   fclose(f);
   return out;
 }
+// a JSON string starting at the opening quote js[p]: its unescaped value; *end = index past the closing quote
+static std::string json_take_string(const std::string& js, size_t p, size_t* end) {
+  std::string v;
+  size_t i = p + 1;
+  for (; i < js.size() && js[i] != '"'; ++i) {
+    if (js[i] == '\\' && i + 1 < js.size()) {
+      ++i;
+      v.push_back(js[i] == 'n' ? '\n' : js[i] == 't' ? '\t' : js[i]);
+    } else {
+      v.push_back(js[i]);
+    }
+  }
+  *end = i + 1;
+  return v;
+}
 static std::string json_string(const std::string& js, const std::string& key) {
   std::string pat = "\"" + key + "\":\"";
   size_t p = js.find(pat);
   if (p == std::string::npos) return "";
-  p += pat.size();
-  return js.substr(p, js.find('"', p) - p);
+  size_t e;
+  return json_take_string(js, p + pat.size() - 1, &e);
 }
 static std::map<std::string, std::string> json_samples(const std::string& js) {
   std::map<std::string, std::string> out;
   size_t p = js.find("\"samples\":{");
   if (p == std::string::npos) return out;
   p += 11;
-  size_t end = js.find('}', p);
-  while (p < end) {
-    size_t k0 = js.find('"', p);
-    if (k0 == std::string::npos || k0 >= end) break;
-    size_t k1 = js.find('"', k0 + 1), v0 = js.find('"', k1 + 1), v1 = js.find('"', v0 + 1);
-    out[js.substr(k0 + 1, k1 - k0 - 1)] = js.substr(v0 + 1, v1 - v0 - 1);
-    p = v1 + 1;
+  while (p < js.size()) {
+    while (p < js.size() && (js[p] == ',' || js[p] == ' ' || js[p] == '\n')) ++p;
+    if (p >= js.size() || js[p] != '"') break;  // '}' closes the object
+    size_t e;
+    std::string k = json_take_string(js, p, &e);
+    size_t v0 = js.find('"', e);
+    if (v0 == std::string::npos) break;
+    std::string v = json_take_string(js, v0, &e);
+    out[k] = v;
+    p = e;
   }
   return out;
 }
 
 // bgbinary merge --in A.bg --in B.bg [...] --out M.bg [--id ID] [-f]   (biograph_merge.cpp:189-400)
 static int cmd_merge(int argc, char** argv) {
-  Args a = parse(argc, argv, 2);
+  Args a = parse(argc, argv, 2, {"reads", "out", "id", "force"});
   if (!a.has("reads") || !a.has("out")) die("merge: --in (at least once) and --out are required");
   const auto& ins = a.opt["reads"];  // the parser files --in under --reads
   std::string out = a.get("out");
@@ -329,8 +448,14 @@ static int cmd_merge(int argc, char** argv) {
   check(bg_seqset_write(ctx, merged, (out + "/seqset").c_str(), argc, av.data()), "bg_seqset_write");
   std::string samples_json;
   size_t n_samples = 0;
+  std::map<std::string, bool> seen_samples;
   for (size_t i = 0; i < ins.size(); ++i) {
     for (auto& kv : json_samples(infos[i])) {
+      if (seen_samples.count(kv.first)) {  // biograph_merge.cpp:116-134: a sample that is already in is skipped
+        fprintf(stderr, "Sample %s of %s is already present in the merge: skipped\n", kv.first.c_str(), ins[i].c_str());
+        continue;
+      }
+      seen_samples[kv.first] = true;
       bg_readmap *rm = nullptr, *mig = nullptr;
       check(bg_readmap_open(ctx, (ins[i] + "/coverage/" + kv.second + ".readmap").c_str(), &rm), "bg_readmap_open");
       check(bg_readmap_migrate(ctx, rm, mapp[i], merged, &mig), "bg_readmap_migrate");
@@ -338,18 +463,19 @@ static int cmd_merge(int argc, char** argv) {
       std::string tmp = out + "/coverage/tmp.readmap";
       check(bg_readmap_write(ctx, mig, tmp.c_str(), argc, av.data(), sha), "bg_readmap_write");
       if (rename(tmp.c_str(), (out + "/coverage/" + sha + ".readmap").c_str()) != 0) die("Could not rename " + tmp);
-      samples_json += std::string(n_samples ? "," : "") + "\"" + kv.first + "\":\"" + sha + "\"";
+      samples_json += std::string(n_samples ? "," : "") + json_str(kv.first) + ":" + json_str(sha);
       ++n_samples;
       bg_readmap_free(mig);
       bg_readmap_free(rm);
     }
   }
-  std::string meta = "{\"accession_id\":\"" + merged_id + "\",\"command_history\":[],\"samples\":{" + samples_json +
-                     "},\"version\":\"biograph_amd-r1\"}";
+  char uuid[64] = "";
+  bg_seqset_uuid(merged, uuid, sizeof uuid);
+  std::string meta = "{\"accession_id\":" + json_str(merged_id) + ",\"biograph_id\":" + json_str(uuid) + ",\"command_history\":[" +
+                     json_argv(argc, argv) + "],\"samples\":{" + samples_json + "},\"version\":\"biograph_amd-r2\"}";
   write_file(out + "/metadata/bg_info.json", meta);
-  char js[1024];
-  snprintf(js, sizeof js, "{\"command\":\"merge\",\"version\":\"biograph_amd-r1\",\"accession_id\":\"%s\",\"samples\":%zu,"
-           "\"seqset_entries\":%llu}", merged_id.c_str(), n_samples, (unsigned long long)bg_seqset_size(merged));
+  std::string js = "{\"command\":\"merge\",\"version\":\"biograph_amd-r2\",\"accession_id\":" + json_str(merged_id) +
+                   ",\"samples\":" + std::to_string(n_samples) + ",\"seqset_entries\":" + std::to_string(bg_seqset_size(merged)) + "}";
   write_file(out + "/qc/merge_stats.json", js);
   fprintf(stderr, "\n%s created.\n", out.c_str());
   bg_seqset_free(merged);
@@ -364,7 +490,7 @@ static int cmd_merge(int argc, char** argv) {
 // every anchored non-reference assembly becomes one VCF record.  (The reference's `bgbinary discovery` runs
 // the production tracer + genotyper on top of the same walks: SURVEY §8f.2, not built.)
 static int cmd_discovery(int argc, char** argv) {
-  Args a = parse(argc, argv, 2);
+  Args a = parse(argc, argv, 2, {"reads", "ref", "out", "sample", "min-overlap", "max-pair-distance", "bed"});
   if (!a.has("reads") || !a.has("ref") || !a.has("out")) die("discovery: --in S.bg, --ref and --out are required");
   std::string bgdir = a.get("reads");
   // scaffolds (chromosomes) and their N-free supercontigs from the reference directory / .ref / FASTA; a
@@ -378,7 +504,8 @@ static int cmd_discovery(int argc, char** argv) {
     uint32_t sc = 0;
     uint64_t off = 0, len = 0, flat = 0;
     check(bg_reference_supercontig(rf, i, &sc, &off, &len, &flat), "bg_reference_supercontig");
-    if (off + len > recs[sc].second.size()) recs[sc].second.resize(off + len, 'N');
+    if (sc >= recs.size() || off > recs[sc].second.size() || len > recs[sc].second.size() - off)
+      die("reference: a supercontig lies outside its scaffold (corrupt reference?)");
     check(bg_reference_bases(rf, flat, len, &recs[sc].second[off]), "bg_reference_bases");
   }
   bg_reference_free(rf);
@@ -399,6 +526,23 @@ static int cmd_discovery(int argc, char** argv) {
   double mo = atof(a.get("min-overlap", "0.7").c_str());
   uint32_t min_overlap = mo < 1.0 ? uint32_t(mo * bg_readmap_max_read_len(rm)) : uint32_t(mo);  // biograph_variants.cpp:674
   int64_t max_pair_distance = atoll(a.get("max-pair-distance", "1000").c_str());
+  // --bed FILE: only these regions are walked (chrom, start, end; biograph_variants.cpp:144-211)
+  std::map<std::string, std::vector<std::pair<int64_t, int64_t>>> bed;
+  if (a.has("bed")) {
+    std::string txt = read_text(a.get("bed"));
+    size_t p0 = 0;
+    while (p0 < txt.size()) {
+      size_t e = txt.find('\n', p0);
+      if (e == std::string::npos) e = txt.size();
+      std::string line = txt.substr(p0, e - p0);
+      p0 = e + 1;
+      if (line.empty() || line[0] == '#' || line.compare(0, 5, "track") == 0 || line.compare(0, 7, "browser") == 0) continue;
+      char chrom[256];
+      long long b0 = 0, b1 = 0;
+      if (sscanf(line.c_str(), "%255s %lld %lld", chrom, &b0, &b1) != 3 || b1 <= b0 || b0 < 0) die("--bed: malformed line: " + line);
+      bed[chrom].emplace_back(b0, b1);
+    }
+  }
   double t0 = now_s();
   std::string vcf = "##fileformat=VCFv4.1\n##source=biograph_amd graph_discover\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n";
   uint64_t n_var = 0;
@@ -419,7 +563,16 @@ static int cmd_discovery(int argc, char** argv) {
     for (auto& x : es) { ep.push_back(x.c_str()); el.push_back(x.size()); }
     bg_asm_list* l = nullptr;
     check(bg_asm_list_create(&l), "bg_asm_list_create");
-    check(bg_make_ref_assemblies(l, es.size(), eo.data(), ep.data(), el.data(), 0, int64_t(seq.size()), 100), "make_ref_assemblies");
+    if (a.has("bed")) {
+      auto it = bed.find(rec.first);
+      if (it == bed.end()) { bg_asm_list_free(l); continue; }
+      for (auto& iv : it->second)
+        check(bg_make_ref_assemblies(l, es.size(), eo.data(), ep.data(), el.data(), iv.first, std::min<int64_t>(iv.second, int64_t(seq.size())), 100),
+              "make_ref_assemblies");
+      check(bg_asm_list_sort(l), "bg_asm_list_sort");
+    } else {
+      check(bg_make_ref_assemblies(l, es.size(), eo.data(), ep.data(), el.data(), 0, int64_t(seq.size()), 100), "make_ref_assemblies");
+    }
     auto trim_and_update = [&]() {
       check(bg_graph_trim_ref(l, es.size(), eo.data(), ep.data(), el.data(), 0), "graph_trim_ref");
       check(bg_dedup_assemblies(l), "dedup");

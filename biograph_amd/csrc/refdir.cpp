@@ -266,8 +266,15 @@ int load_spec(const std::string& path, SpecRef* sr) {
   if (!mp.ok) { set_error("%s: malformed msgpack index", path.c_str()); return BG_EIO; }
   const uint64_t dna_bytes = uint64_t(idx - u) - 6;
   uint64_t flat_end = 0;
-  for (auto& x : sr->extents) flat_end = std::max(flat_end, x.flat + x.size);
-  if ((flat_end + 3) / 4 > dna_bytes) { set_error("%s: extents past the end of the DNA buffer", path.c_str()); return BG_EIO; }
+  const uint64_t dna_bases = dna_bytes > (~0ull >> 2) ? ~0ull : dna_bytes * 4;
+  for (auto& x : sr->extents) {
+    // every extent must lie inside the 2-bit payload (checked without letting flat + size wrap) and name a scaffold
+    if (x.flat > dna_bases || x.size > dna_bases - x.flat) { set_error("%s: an extent lies past the end of the DNA buffer", path.c_str()); return BG_EIO; }
+    if (x.scaffold >= sr->scaffolds.size()) { set_error("%s: extent of unknown scaffold %llu", path.c_str(), (unsigned long long)x.scaffold); return BG_EIO; }
+    const uint64_t slen = sr->scaffolds[x.scaffold].second;
+    if (x.offset > slen || x.size > slen - x.offset) { set_error("%s: an extent lies past the end of its scaffold", path.c_str()); return BG_EIO; }
+    flat_end = std::max(flat_end, x.flat + x.size);
+  }
   sr->bases.resize(flat_end);
   const unsigned char* dna = u + 6;
   for (uint64_t i = 0; i < flat_end; ++i) sr->bases[i] = "ACGT"[(dna[i >> 2] >> (6 - 2 * (i & 3))) & 3];

@@ -12,6 +12,7 @@
 //   slices          --gather--> bg_seqset_assemble --> seqset::finalize (seqset.cpp:113-129)
 #include "bg_device_funcs.h"
 #include "bg_internal.h"
+#include "compact.h"
 
 namespace bg {
 
@@ -61,6 +62,16 @@ __global__ void k_dest_key_bounds(const uint64_t* __restrict__ rows, uint64_t n,
   }
   if (d == kDropDest) atomicOr(err, 2u);  // no entry extends this tail anywhere: closure violated
   dest[i] = d;
+  idx[i] = uint32_t(i);
+}
+
+// rows whose last word names their destination (bits 10..16; 127 = nowhere): tails routed by bg_seqset_tail_rows2
+__global__ void k_dest_from_row(const uint64_t* __restrict__ rows, uint64_t n, int row_words, uint32_t nparts,
+                                uint64_t* __restrict__ dest, uint32_t* __restrict__ idx) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t d = (rows[i * row_words + row_words - 1] >> 10) & 0x7f;
+  dest[i] = d < nparts ? d : kDropDest;
   idx[i] = uint32_t(i);
 }
 
@@ -222,6 +233,50 @@ __global__ void k_tail_rows(const uint64_t* __restrict__ ekeys, const uint8_t* _
   r[W] = uint64_t(sizes[i] - 1) | ((s[0] >> 62) << 8);
 }
 
+// Short tail row of entry i: the tail's two leading words and meta = (len-1) | first base << 8 | destination
+// shard << 10 | i << 17.  The destination (first shard whose last entry is >= the tail) is settled here, where
+// the whole key is at hand: the two leading words decide it unless they tie with a shard's last entry.
+__global__ void k_tail_rows2(const uint64_t* __restrict__ ekeys, const uint8_t* __restrict__ sizes, uint64_t n, int W,
+                             const uint64_t* __restrict__ bounds, uint32_t nparts, uint64_t* __restrict__ rows,
+                             uint32_t* __restrict__ err) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t* s = ekeys + i * W;
+  const uint64_t t0 = window32(s, W, 1), t1 = W > 1 ? window32(s, W, 33) : 0;
+  const int tl = int(sizes[i]) - 1;
+  uint64_t d = 127;
+  for (uint32_t p = 0; p < nparts; ++p) {
+    const uint64_t* b = bounds + uint64_t(p) * (W + 1);
+    if (b[W] == ~0ull) continue;
+    const uint64_t b0 = b[0], b1 = W > 1 ? b[1] : 0;
+    if (t0 < b0 || (t0 == b0 && t1 < b1)) { d = p; break; }
+    if (t0 == b0 && t1 == b1) {
+      uint64_t tail[kMaxWords];
+      for (int w = 0; w < W; ++w) tail[w] = window32(s, W, 1 + 32 * w);
+      if (key_compare(tail, tl, b, int(b[W] & 0xff), W) <= 0) { d = p; break; }
+    }
+  }
+  if (d == 127) atomicOr(err, 2u);  // no entry extends this tail anywhere: closure violated
+  uint64_t* r = rows + i * 3;
+  r[0] = t0;
+  r[1] = t1;
+  r[2] = uint64_t(tl) | ((s[0] >> 62) << 8) | (d << 10) | (i << 17);
+}
+
+// full tail rows (W+1 words, meta as in the short row) of the entries named by the short rows flagged in `need`
+__global__ void k_tail_rows_full(const uint64_t* __restrict__ ekeys, uint64_t n, int W, const uint64_t* __restrict__ short_rows,
+                                 const uint32_t* __restrict__ pick, uint64_t m, uint64_t* __restrict__ rows) {
+  uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= m) return;
+  const uint64_t meta = short_rows[uint64_t(pick[t]) * 3 + 2];
+  const uint64_t i = meta >> 17;
+  const uint64_t* s = ekeys + i * W;
+  uint64_t* r = rows + t * uint64_t(W + 1);
+  for (int w = 0; w < W; ++w) r[w] = window32(s, W, 1 + 32 * w);
+  r[W] = meta;
+  (void)n;
+}
+
 // local bit words of one slice OR-ed into the global bit vector at bit offset `off`
 __global__ void k_place_bits(const uint64_t* __restrict__ local, uint64_t n_local_bits, uint64_t off,
                              unsigned long long* __restrict__ global) {
@@ -297,6 +352,8 @@ extern "C" int bg_partition_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n
                                                              err.p);
     BG_LAUNCH_CHECK();
     BG_HIP(hipStreamSynchronize(ctx->stream));
+  } else if (mode == BG_PART_ROW_DEST) {
+    k_dest_from_row<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_rows, n, row_words, nparts, da.p, ia.p);
   } else {
     set_error("bg_partition_rows: unknown mode %d", mode);
     return BG_EINVAL;
@@ -449,6 +506,33 @@ extern "C" int bg_records_from_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_
   return BG_OK;
 }
 
+extern "C" int bg_records_from_row_parts(bg_ctx* ctx, uint32_t n_parts, const uint64_t* const* d_rows, const uint64_t* h_counts,
+                                         int W, bg_records** out) {
+  if (!ctx || !out || (n_parts && (!d_rows || !h_counts))) { set_error("bg_records_from_row_parts: null argument"); return BG_EINVAL; }
+  if (W < 1 || W > kMaxWords) { set_error("bg_records_from_row_parts: bad W"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  uint64_t n = 0;
+  for (uint32_t p = 0; p < n_parts; ++p) n += h_counts[p];
+  std::unique_ptr<bg_records> r(new bg_records);
+  r->ctx = ctx;
+  r->n = n;
+  r->W = W;
+  BG_TRY(r->rec.alloc(ctx, n * W));
+  BG_TRY(r->rlen.alloc(ctx, n));
+  uint64_t off = 0;
+  for (uint32_t p = 0; p < n_parts; ++p) {
+    const uint64_t m = h_counts[p];
+    if (!m) continue;
+    if (!d_rows[p]) { set_error("bg_records_from_row_parts: null part"); return BG_EINVAL; }
+    k_rows_to_records<<<cdiv(m * (W + 1), 256), 256, 0, ctx->stream>>>(d_rows[p], m, W, r->rec.p + off * W, r->rlen.p + off);
+    BG_LAUNCH_CHECK();
+    off += m;
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  *out = r.release();
+  return BG_OK;
+}
+
 // sorted, prefix-free entries of one shard (keys/sizes/shared; no prev bits yet).  Consumes records.
 extern "C" int bg_entries_from_records(bg_ctx* ctx, bg_records* rec, bg_seqset** out, bg_build_stats* stats) {
   if (!ctx || !rec || !out) { set_error("bg_entries_from_records: null argument"); return BG_EINVAL; }
@@ -517,6 +601,74 @@ extern "C" int bg_seqset_tail_rows(bg_ctx* ctx, const bg_seqset* ss, uint64_t* d
     BG_LAUNCH_CHECK();
   }
   BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+// Short tails (3 words: see k_tail_rows2) of all entries, each with its destination shard in the row;
+// h_bounds = nparts rows of W+1 words: the last entry of every shard (last word ~0 = empty shard).
+extern "C" int bg_seqset_tail_rows2(bg_ctx* ctx, const bg_seqset* ss, uint32_t nparts, const uint64_t* h_bounds,
+                                    uint64_t* d_rows) {
+  if (!ctx || !ss || !h_bounds || (ss->n && !d_rows)) { set_error("bg_seqset_tail_rows2: null argument"); return BG_EINVAL; }
+  if (nparts < 1 || nparts > 126) { set_error("bg_seqset_tail_rows2: %u shards outside 1..126", nparts); return BG_EINVAL; }
+  if (ss->n >= (1ull << 47)) { set_error("bg_seqset_tail_rows2: too many entries"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!ss->n) return BG_OK;
+  const int W = ss->W;
+  DevBuf<uint64_t> db;
+  DevBuf<uint32_t> err;
+  BG_TRY(db.alloc(ctx, uint64_t(nparts) * (W + 1)));
+  BG_TRY(err.alloc(ctx, 1));
+  BG_HIP(hipMemcpyAsync(db.p, h_bounds, uint64_t(nparts) * (W + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+  ctx->tic("tails_rows");
+  k_tail_rows2<<<cdiv(ss->n, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->sizes.p, ss->n, W, db.p, nparts, d_rows, err.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(ss->n * (uint64_t(W) * 8 + 25));
+  uint32_t h_err = 0;
+  BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_err) { set_error("bg_seqset_tail_rows2: a tail is not extended by any entry (missing expansion)"); return BG_EINTERNAL; }
+  return BG_OK;
+}
+
+// Full tails of the short rows i with d_need[i] != 0 (d_short_rows: this shard's short rows in the order the
+// flags refer to): *n_out rows of W+1 words into d_rows_out (room for n rows).
+extern "C" int bg_seqset_tail_rows_full(bg_ctx* ctx, const bg_seqset* ss, const uint64_t* d_short_rows, const uint8_t* d_need,
+                                        uint64_t n, uint64_t* d_rows_out, uint64_t cap, uint64_t* n_out) {
+  if (!ctx || !ss || !n_out || (n && (!d_short_rows || !d_need))) { set_error("bg_seqset_tail_rows_full: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  *n_out = 0;
+  if (!n) return BG_OK;
+  DevBuf<uint32_t> pick;
+  uint64_t m = 0;
+  BG_TRY(compact_flagged<uint32_t>(ctx, d_need, n, &pick, &m));
+  if (m > cap || (m && !d_rows_out)) { set_error("bg_seqset_tail_rows_full: room for %llu rows, %llu needed", (unsigned long long)cap, (unsigned long long)m); return BG_EINVAL; }
+  if (m) {
+    k_tail_rows_full<<<cdiv(m, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->n, ss->W, d_short_rows, pick.p, m, d_rows_out);
+    BG_LAUNCH_CHECK();
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  *n_out = m;
+  return BG_OK;
+}
+
+// Short tails received from all shards: those the two-word prefixes of this shard's entries settle set their prev
+// bit; d_need_full[i] = 1 asks the sender for the whole tail (bg_seqset_tail_rows_full -> bg_seqset_apply_tails).
+extern "C" int bg_seqset_apply_tails2(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint8_t* d_need_full) {
+  if (!ctx || !ss || (n_rows && (!d_rows || !d_need_full))) { set_error("bg_seqset_apply_tails2: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!ss->bits[0].p) BG_TRY(alloc_prev_bits(ctx, ss));
+  if (!n_rows) return BG_OK;
+  DevBuf<uint32_t> err;
+  BG_TRY(err.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+  ctx->tic("prev_bits");
+  BG_TRY(apply_tails2_impl(ctx, ss, d_rows, n_rows, d_need_full, err.p));
+  ctx->toc(n_rows * (24 + 16 + 1));
+  uint32_t h_err = 0;
+  BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_err) { set_error("bg_seqset_apply_tails2: missing expansion (entry set not closed under pop_front)"); return BG_EINTERNAL; }
   return BG_OK;
 }
 

@@ -445,14 +445,12 @@ def _records_sharded_cover(comm, ctxs, corrected, W, k, dev, ph):
         for r in ranks:
             parts[r].append(got[r])
         del plain, got
-    out = {}
     for r in ranks:
         L.bg_cover_query_free(qs[r])
         L.bg_cover_free(covers[r])
-        out[r] = torch.cat(parts[r], dim=0).contiguous() if len(parts[r]) > 1 else parts[r][0]
-    del parts
-    n_records = _all_sum(comm, {r: out[r].shape[0] for r in ranks})
-    return out, n_records
+        parts[r] = [t.contiguous() for t in parts[r] if t.shape[0]]
+    n_records = _all_sum(comm, {r: sum(t.shape[0] for t in parts[r]) for r in ranks})
+    return parts, n_records  # a list of row arrays per rank: bg_records_from_row_parts takes them as they are
 
 
 class SeqsetSlice:
@@ -752,9 +750,16 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gath
     ph.mark("entries_from_records")
     shards = {}
     for r in ranks:
-        rows = recv[r].contiguous()
         rh = C.c_void_p()
-        capi.check(L.bg_records_from_rows(ctxs[r].h, _ptr(rows), rows.shape[0], W, C.byref(rh)))
+        if isinstance(recv[r], list):
+            np_ = len(recv[r])
+            ptrs = (C.c_void_p * max(np_, 1))(*[t.data_ptr() for t in recv[r]])
+            cnts = (C.c_uint64 * max(np_, 1))(*[t.shape[0] for t in recv[r]])
+            capi.check(L.bg_records_from_row_parts(ctxs[r].h, np_, ptrs, cnts, W, C.byref(rh)))
+        else:
+            rows = recv[r].contiguous()
+            capi.check(L.bg_records_from_rows(ctxs[r].h, _ptr(rows), rows.shape[0], W, C.byref(rh)))
+        recv[r] = None  # the rows are in the library now
         h = C.c_void_p()
         st = BuildStats()
         capi.check(L.bg_entries_from_records(ctxs[r].h, rh, C.byref(h), C.byref(st)))
@@ -785,22 +790,54 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gath
             capi.check(L.bg_seqset_fix_boundary(ctxs[r].h, shards[r].h, capi.np_ptr(a), None))
 
     ph.mark("tails_partition")
-    # ---- S5 prev bits: route every entry's tail to the shard holding lower_bound(tail)
-    bounds = np.array(lasts, np.uint64).reshape(P, W + 1)
-    send = {}
+    # ---- S5 prev bits: every entry's tail goes to the shard holding lower_bound(tail).  Short form first (the
+    # tail's two leading words; the destination is settled by the sender, who has the whole key): the receiving
+    # shard's two-word prefixes settle nearly all of them; it asks for the whole tail of the rest.
+    bounds = np.ascontiguousarray(np.array(lasts, np.uint64).reshape(P, W + 1))
+    send, short = {}, {}
     for r in ranks:
         n = shards[r].size()
-        rows = torch.empty((n, W + 1), dtype=i64, device=dev[r])
-        capi.check(L.bg_seqset_tail_rows(ctxs[r].h, shards[r].h, _ptr(rows)))
-        send[r] = _partition(ctxs[r], rows, capi.PART_KEY_BOUNDS, P, bounds.reshape(-1))
+        rows = torch.empty((n, 3), dtype=i64, device=dev[r])
+        capi.check(L.bg_seqset_tail_rows2(ctxs[r].h, shards[r].h, P, capi.np_ptr(bounds), _ptr(rows)))
+        send[r] = _partition(ctxs[r], rows, capi.PART_ROW_DEST, P, None)
+        short[r] = send[r][0]
+        del rows
     ph.mark("tails_all_to_all")
     recv = comm.all_to_all_v(send)
+    sent_counts = comm.all_gather_obj({r: send[r][1] for r in ranks})[ranks[0]]
     del send
     ph.mark("apply_tails")
+    back = {}
     for r in ranks:
         rows = recv[r].contiguous()
-        capi.check(L.bg_seqset_apply_tails(ctxs[r].h, shards[r].h, _ptr(rows), rows.shape[0]))
+        need = torch.empty((max(rows.shape[0], 1),), dtype=torch.uint8, device=dev[r])
+        capi.check(L.bg_seqset_apply_tails2(ctxs[r].h, shards[r].h, _ptr(rows), rows.shape[0], _ptr(need)))
+        back[r] = (need[:rows.shape[0]].view(-1, 1), [int(sent_counts[s][r]) for s in range(P)])
     del recv
+    needs = comm.all_to_all_v(back)
+    del back
+    ph.mark("tails_full")
+    full = {}
+    n_full = {}
+    for r in ranks:
+        nd = needs[r].contiguous().view(-1)
+        cap = int(nd.sum().item()) if nd.shape[0] else 0
+        t = torch.empty((max(cap, 1), W + 1), dtype=i64, device=dev[r])
+        m = C.c_uint64()
+        capi.check(L.bg_seqset_tail_rows_full(ctxs[r].h, shards[r].h, _ptr(short[r]), _ptr(nd), nd.shape[0], _ptr(t), cap,
+                                              C.byref(m)))
+        n_full[r] = m.value
+        full[r] = _partition(ctxs[r], t[:m.value], capi.PART_ROW_DEST, P, None)
+        del t
+    del short, needs
+    if _all_sum(comm, n_full):
+        recv = comm.all_to_all_v(full)
+        for r in ranks:
+            rows = recv[r].contiguous()
+            capi.check(L.bg_seqset_apply_tails(ctxs[r].h, shards[r].h, _ptr(rows), rows.shape[0]))
+        del recv
+    del full
+    extra_stats["tails_sent_in_full"] = _all_sum(comm, n_full)
     part_n = comm.all_gather_obj({r: int(shards[r].size()) for r in ranks})[ranks[0]]
     n_entries = sum(part_n)
     stats = {"n_reads": sum(comm.all_gather_obj({r: inputs[r][2] for r in ranks})[ranks[0]]),

@@ -84,6 +84,22 @@ uint32_t bg_reads_max_len(const bg_reads* r);
 int bg_reads_download(bg_ctx* ctx, const bg_reads* r, uint8_t* h_seq, uint64_t* h_offs);
 void bg_reads_free(bg_reads* r);
 
+/* FASTQ import on the device (csrc/fastq.hip).  Replaces fastq_reader + read_importer_base::read_fastq
+ * (modules/build_seqset/read_importer.cpp:604, read_importer.h:65-141): d_text[s] = the bytes of source s as
+ * they are in the file (plain text; gzip is inflated by the caller), resident in HBM.  Four lines per record,
+ * '@' / '+' lines checked, qualities dropped (read_importer.cpp:22), "\r\n" accepted, blank lines at the end
+ * ignored.  paired_files: sources 2i and 2i+1 are mate files read in lock step; interleaved: records 2i, 2i+1
+ * of a source are mates; either way mates are reads 2i, 2i+1 of the result.  cut_end != 0: bases
+ * [cut_start, min(cut_end, len)) of every read (--cut-reads, read_importer.cpp:157-169).  The results
+ * (*d_seq_out: concatenated bases, *d_offs_out: n+1 offsets — what bg_pack_reads takes) are allocated from
+ * the context: release them with bg_dev_free. */
+int bg_fastq_import(bg_ctx* ctx, uint32_t n_src, const uint8_t* const* d_text, const uint64_t* h_bytes, int paired_files,
+                    int interleaved, uint32_t cut_start, uint32_t cut_end, uint8_t** d_seq_out, uint64_t** d_offs_out,
+                    uint64_t* n_reads_out, uint64_t* n_bases_out);
+/* Host -> device copy through two pinned staging buffers filled by `threads` host threads (0 = all cores)
+ * while the DMA engine drains the other one. */
+int bg_dev_upload_pinned(bg_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes, int threads);
+
 /* ---- S2: k-mer counting + filter.  Replaces kmer_counter + kmerizer::run + kmer_set
  * (modules/build_seqset/kmer_counter.h:123-326, modules/bio_mapred/kmerize_bf.cpp:267-429).
  * Keeps canonical k-mers with fwd+rev >= min_count; flags bit0 = fwd_starts_read,
@@ -142,6 +158,8 @@ int bg_create(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, uint64_
 /* ---- seqset object (modules/bio_base/seqset.h:35-128). */
 uint64_t bg_seqset_size(const bg_seqset* ss);
 uint32_t bg_seqset_max_len(const bg_seqset* ss);
+/* seqset::uuid() (seqset.h:35-128; file_info.json of the container): NUL-terminated into h_out[cap]. */
+int bg_seqset_uuid(const bg_seqset* ss, char* h_out, uint64_t cap);
 /* Host copies of the payload parts exactly as stored in the spiral container (format 1.1.0):
  * part in {"fixed","entry_sizes/elements","shared/elements","prev_A/bits","prev_A/subaccum",
  * "prev_A/accum", ... "prev_T/accum"}.  Call with h_out=NULL to get the byte size in *size. */
@@ -359,6 +377,7 @@ int bg_create_sample(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, 
 #define BG_PART_KEY_BOUNDS 2 /* rows of W+1 words (last = len | base<<8); h_params = nparts rows: last
                                 entry of each shard (last word ~0 = empty); dest = first shard whose
                                 last entry >= row                                                       */
+#define BG_PART_ROW_DEST 3   /* the row names its destination itself: bits 10..16 of its last word (127 = nowhere) */
 /* ---- reference: what the discovery walks along ------------------------------------
  * bg_reference_open reads a BioGraph reference directory (karyotype.json + reference.ref, or reference.fasta
  * when the .ref is absent; modules/io/defaults.h:17-50, bio_base/reference.cpp:27-40), a bare .ref file
@@ -437,6 +456,9 @@ int bg_records_rows(bg_ctx* ctx, const bg_records* r, uint64_t* d_rows /* n*(W+1
  * exchange (part_counts.h:8-45); a sample is enough to balance and costs 1/every of the global atomics. */
 int bg_records_prefix_hist(bg_ctx* ctx, const bg_records* r, int bases, uint64_t every, uint64_t* d_hist);
 int bg_records_from_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int W, bg_records** out);
+/* the same from several row arrays (n_parts device pointers and row counts, host arrays): no concatenated copy */
+int bg_records_from_row_parts(bg_ctx* ctx, uint32_t n_parts, const uint64_t* const* d_rows, const uint64_t* h_counts, int W,
+                              bg_records** out);
 void bg_records_free(bg_records* r);
 /* sort + prefix-dedup of one shard's records -> entries (keys/sizes/shared, no prev bits); consumes r */
 int bg_entries_from_records(bg_ctx* ctx, bg_records* r, bg_seqset** out, bg_build_stats* stats);
@@ -449,6 +471,15 @@ int bg_seqset_fix_boundary(bg_ctx* ctx, bg_seqset* ss, const uint64_t* h_prev_la
 /* prev bits across shards: tails s[1:] of own entries out, tails owned by this shard in */
 int bg_seqset_tail_rows(bg_ctx* ctx, const bg_seqset* ss, uint64_t* d_rows /* n*(W+1) */);
 int bg_seqset_apply_tails(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows);
+/* The same with short tails: 3-word rows (the tail's two leading words, meta = len-1 | base << 8 | destination
+ * shard << 10 | entry << 17; route them with BG_PART_ROW_DEST).  The receiving shard settles what its entries'
+ * two-word prefixes decide and asks for the whole tail of the rest (d_need_full, sent back in order);
+ * bg_seqset_tail_rows_full builds those (same meta) for bg_seqset_apply_tails.  40 % of the bytes of full tails. */
+int bg_seqset_tail_rows2(bg_ctx* ctx, const bg_seqset* ss, uint32_t nparts, const uint64_t* h_bounds /* nparts x (W+1) */,
+                         uint64_t* d_rows /* n*3 */);
+int bg_seqset_apply_tails2(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint8_t* d_need_full);
+int bg_seqset_tail_rows_full(bg_ctx* ctx, const bg_seqset* ss, const uint64_t* d_short_rows, const uint8_t* d_need,
+                             uint64_t n, uint64_t* d_rows_out, uint64_t cap, uint64_t* n_out);
 /* final merge = concatenation of the shards' slices in rank order + seqset::finalize */
 int bg_seqset_slice_export(bg_ctx* ctx, const bg_seqset* ss, uint8_t* d_sizes, uint8_t* d_shared,
                            uint64_t* d_bits /* 4 x ceil(n/64) */);
