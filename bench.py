@@ -21,25 +21,85 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(sample_genome, coverage, read_len, seed):
-    """Times the oracle (single thread, kind="port") on a bounded sample of the same workload shape."""
+def cpu_baseline(ctx, sample_genome, coverage, read_len, seed, dev):
+    """The CPU restatement of the path (oracle/, kind="port": the reference itself needs Bazel + Boost + abseil,
+    DESIGN.md section 2) on the node's host cores, SURVEY.md section 8(d): every stage on a std::thread pool of
+    hardware_concurrency() threads, wall time per stage under the reference's stage names
+    (modules/io/runtime_stats.h:13 as used by biograph_create.cpp:540-783), on a bounded sample of the same workload
+    shape (E. coli-sized by default: 139 Mbases), and its seqset + readmap compared part by part with the GPU
+    build of the same reads in the same run.  Also times the graph-discover drivers over the oracle's walks on a
+    stretch of the sample's reference (the CPU baseline of the discover leg)."""
     import numpy as np
+    import biograph_amd as bg
     from biograph_amd import synth
     from oracle import oracle as O
-    seq, offs, n = synth.make_reads(genome_len=sample_genome, coverage=coverage, read_len=read_len, seed=seed,
-                                    device="cpu")
-    seq = np.ascontiguousarray(seq.numpy())
-    offs = offs.numpy().astype(np.uint64)
+    threads = O.hardware_threads()
+    dseq, doffs, n, genome = synth.make_reads(genome_len=sample_genome, coverage=coverage, read_len=read_len, seed=seed,
+                                              device=dev, return_genome=True)
     t0 = time.perf_counter()
-    ks = O.KmerSet.count(seq, offs, 30, 5)
-    cseq, coffs, keep, stats = O.correct_reads(ks, seq, offs, 8, 2, 0.7)
-    ent = O.Entries.build(cseq, coffs, "cover", 30)
-    ss = O.Seqset.from_entries(ent)
-    dt = time.perf_counter() - t0
+    seq = np.ascontiguousarray(dseq.cpu().numpy())
+    offs = doffs.cpu().numpy().astype(np.uint64)
+    t_import = time.perf_counter() - t0
+    stages = {}
+    t0 = time.perf_counter()
+    ks = O.KmerSet.count(seq, offs, 30, 5, threads=threads)
+    stages["kmerization"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cseq, coffs, keep, cstats = O.correct_reads(ks, seq, offs, 8, 2, 0.7, threads=threads)
+    stages["read_correction"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ent = O.Entries.build(cseq, coffs, "cover", 30, threads=threads)
+    oss = O.Seqset.from_entries(ent, threads=threads)
+    stages["make_seqset"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    corrected = O.unpack_strings(cseq, coffs)
+    records = [tuple(s for s in corrected[i:i + 2] if s) for i in range(0, len(corrected), 2)]
+    orm = O.Readmap(oss, ent, [rec for rec in records if rec], True)
+    stages["make_readmap"] = time.perf_counter() - t0
+    dt = sum(stages.values())
     bases = int(offs[-1])
-    return {"value": bases / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
-            "sample": "%d reads x %d bp (%.1f Mbases, %dx of a %d bp synthetic genome), %.1f s, %d entries" % (
-                n, read_len, bases / 1e6, coverage, sample_genome, dt, len(ss))}
+    # the same reads through the GPU path: every container part of seqset and readmap must be equal
+    r = ctx.pack_reads_device(dseq.data_ptr(), doffs.data_ptr(), n)
+    gks = ctx.kmer_count(r, 30, 5)
+    gc, _ = ctx.correct_reads(r, gks)
+    gss, _ = ctx.build_seqset(gc, 30)
+    grm = ctx.build_readmap(gss, gc, True)
+    want = oss.parts()
+    same = all(gss.part(p) == want[p] for p in bg.PART_NAMES)
+    want_rm = orm.parts()
+    same_rm = all(grm.part(p) == want_rm[p] for p in bg.READMAP_PART_NAMES)
+    for h in (grm, gss, gc, gks, r):
+        h.free()
+    out = {"value": bases / dt / 1e9, "unit": "Gbases/s", "cores": threads, "node_cores": os.cpu_count(), "kind": "port",
+           "sample": "%d reads x %d bp (%.1f Mbases, %dx of a %d bp synthetic genome), %.1f s on %d threads, %d entries" % (
+               n, read_len, bases / 1e6, coverage, sample_genome, dt, threads, len(oss)),
+           "stage_seconds": {k: round(v, 3) for k, v in stages.items()},
+           "import_seconds_device_to_host": round(t_import, 3),
+           "equals_gpu_build": {"seqset_parts": bool(same), "readmap_parts": bool(same_rm)}}
+    # discover leg on the CPU: the drivers (tests/variants_twin.py, the Python twin of csrc/discover.cpp) over the
+    # oracle's literal walks, on the first stretch of the sample's reference
+    try:
+        from tests import variants_twin as V
+        from tests.discover_backend import OracleWalker
+        region = min(30000, int(genome.numel()))
+        ref = "".join("ACGT"[int(c)] for c in genome[:region].cpu().tolist())
+        ext = [(0, ref)]
+        w = OracleWalker(oss, orm)
+        t0 = time.perf_counter()
+        asms = V.make_ref_assemblies(ext, 0, region)
+        asms = V.update_rc_seqset_entries(V.dedup_assemblies(V.graph_trim_ref(asms, ext)), w)
+        asms = V.discover_branch(asms, w, 105, "BRANCH")
+        asms = V.update_rc_seqset_entries(V.dedup_assemblies(V.graph_trim_ref(asms, ext)), w)
+        asms = V.discover_push_to_pair(asms, w, 105, 1000, "PUSH_TO_PAIR", ["BRANCH"])
+        asms = V.update_rc_seqset_entries(V.dedup_assemblies(V.graph_trim_ref(asms, ext)), w)
+        ddt = time.perf_counter() - t0
+        found = [a for a in asms if a.left_offset is not None and a.right_offset is not None and not a.matches_reference]
+        out["discover"] = {"region_bases": region, "seconds": round(ddt, 2), "anchored_variants": len(found),
+                           "anchored_variants_per_s": round(len(found) / ddt, 2), "cores": 1,
+                           "what": "graph-discover drivers (Python twin) over the oracle's walks, min_overlap 105"}
+    except Exception as e:  # the baseline of the discover leg must not take the build's line down
+        out["discover"] = {"error": repr(e)}
+    return out
 
 
 def driver_leg(ctx, ss, genome, dev, args, region=2000000):
@@ -50,7 +110,7 @@ def driver_leg(ctx, ss, genome, dev, args, region=2000000):
     (csrc/discover.cpp); the chain of rc paths is broken by verified speculation, so a step is a few large
     launches plus single ones around variants."""
     import torch
-    from biograph_amd import variants as V
+    from biograph_amd import variants as V  # AssemblyList: the C++ drivers (csrc/discover.cpp)
     from biograph_amd.synth import variant_sites as synth_sites
     G = int(genome.numel())
     region = min(region, G)
@@ -321,7 +381,8 @@ def main():
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--seed", type=int, default=20261002)
-    ap.add_argument("--cpu-sample-genome", type=int, default=600_000)
+    ap.add_argument("--cpu-sample-genome", type=int, default=4_641_652,
+                    help="genome of the CPU baseline sample (default: E. coli-sized, 139 Mbases at 30x)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-discover", action="store_true", help="skip the overlap-walk (discover) leg")
     ap.add_argument("--force-sharded", action="store_true",
@@ -453,7 +514,7 @@ def main():
                    for t in sorted(timings, key=lambda t: -t["ms"])}
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            cpu = cpu_baseline(args.cpu_sample_genome, args.coverage, args.read_len, args.seed)
+            cpu = cpu_baseline(ctx, args.cpu_sample_genome, args.coverage, args.read_len, args.seed, dev)
         # whole-build algorithmic bytes: 1.25 N_bases + 16 N_kmers + (0.5 N_bases + 8 N_kmers)
         # + 28 N_rec + 2.625 N_ent
         alg = (1.25 * stats["n_bases"] + 16 * stats["n_kmers"] + 0.5 * stats["n_bases"] + 8 * stats["n_kmers"]

@@ -224,13 +224,24 @@ def _next_nonempty(rows, r, step):
 # ------------------------------------------------------------------------------------------------
 
 class _Phases:
-    """BG_SHARD_TIMING=1: wall time per phase of sharded_create on stderr (device synchronised)."""
+    """BG_SHARD_TIMING=1: wall time per phase of sharded_create on stderr (device synchronised), with the peak of
+    torch's allocator and of the library's (context `ctx`) inside the phase, in GB."""
 
-    def __init__(self):
+    def __init__(self, ctx=None):
         import os
         self.on = os.environ.get("BG_SHARD_TIMING") == "1"
         self.t = None
         self.rows = []
+        self.ctx = ctx
+
+    def _mem(self):
+        tp = torch.cuda.max_memory_allocated() / 1e9 if torch.cuda.is_available() else 0.0
+        lp = self.ctx.memory()["peak"] / 1e9 if self.ctx is not None else 0.0
+        if torch.cuda.is_available():
+            torch.cuda.reset_peak_memory_stats()
+        if self.ctx is not None:
+            self.ctx.memory(reset_peak=True)
+        return tp, lp
 
     def mark(self, name):
         if not self.on:
@@ -239,15 +250,17 @@ class _Phases:
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         now = time.perf_counter()
+        tp, lp = self._mem()
         if self.t is not None:
-            self.rows.append((self.name, (now - self.t) * 1e3))
+            self.rows.append((self.name, (now - self.t) * 1e3, tp, lp))
         self.t, self.name = now, name
 
     def done(self):
         if self.on:
             import sys
             self.mark("end")
-            sys.stderr.write("sharded_create phases (ms): " + ", ".join("%s %.1f" % r for r in self.rows) + "\n")
+            sys.stderr.write("sharded_create phases (ms | torch peak GB | library peak GB): " +
+                             ", ".join("%s %.1f|%.1f|%.1f" % r for r in self.rows) + "\n")
 
 
 def _relieve(ctxs, dev):
@@ -578,7 +591,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gath
                 raise ValueError("sharded_create: the Context of rank %d runs on another HIP stream than torch's current "
                                  "one — the exchange buffers would be read before they are complete" % r)
 
-    ph = _Phases()
+    ph = _Phases(ctxs[ranks[0]])
     ph.mark("pack")
     # ---- S1 pack (local)
     reads = {r: ctxs[r].pack_reads_device(inputs[r][0].data_ptr(), inputs[r][1].data_ptr(), inputs[r][2])

@@ -1092,6 +1092,272 @@ int orc_correct_reads(void* ksh, const char* seq, const uint64_t* offs, uint64_t
   return 0;
 }
 
+// ---- the same stages on a std::thread pool: the CPU baseline SURVEY.md section 8(d) asks for (the reference's own
+// parallel_for over reads / partitions, biograph_create.cpp:553-693).  Same algorithms, same results as the
+// single-threaded functions above (tests/test_oracle_mt.py compares them); only the loop structure differs:
+// k-mers are routed to hash partitions (kmer_counter.h:167-178) and each partition is counted by one thread;
+// reads are corrected in ranges; suffix records are bucketed by their leading bases and the buckets sorted
+// in parallel (part_repo.cpp:32-45).
+}  // extern "C"
+
+#include <atomic>
+#include <thread>
+
+namespace orc {
+
+template <class F>
+static void parallel_ranges(uint64_t n, unsigned nthreads, F f) {  // f(thread, lo, hi)
+  if (nthreads < 1) nthreads = 1;
+  std::vector<std::thread> pool;
+  const uint64_t per = (n + nthreads - 1) / nthreads;
+  for (unsigned t = 0; t < nthreads; ++t) {
+    const uint64_t lo = std::min<uint64_t>(n, uint64_t(t) * per), hi = std::min<uint64_t>(n, lo + per);
+    pool.emplace_back([=] { f(t, lo, hi); });
+  }
+  for (auto& th : pool) th.join();
+}
+
+struct KmerInst { kmer_t canon; uint8_t bits; };  // bits: 1 fwd_starts, 2 rev_starts, 4 flipped
+
+static KmerSet* kmer_count_mt(const char* seq, const uint64_t* offs, uint64_t n_reads, unsigned k, uint32_t min_count,
+                              bool keep_all, unsigned T) {
+  const unsigned NP = 256;  // kmer_counter.h:167-178
+  std::vector<std::vector<std::vector<KmerInst>>> routed(T, std::vector<std::vector<KmerInst>>(NP));
+  std::atomic<int> bad{0};
+  parallel_ranges(n_reads, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
+    auto& mine = routed[t];
+    for (uint64_t r = lo; r < hi; ++r) {
+      const char* it = seq + offs[r];
+      const char* end = seq + offs[r + 1];
+      bool is_first = true;
+      unsigned left = k;
+      kmer_t kmer = 0;
+      while (it != end) {
+        if (*it == 'N') { ++it; left = k; is_first = false; continue; }
+        int b = base_code(*it);
+        if (b < 0) { bad = 1; return; }
+        kmer = kmer_shift_left(kmer, k, b);
+        ++it;
+        if (left) --left;
+        if (!left) {
+          bool is_last = (it == end), flipped;
+          kmer_t canon = canonicalize(kmer, k, flipped);
+          bool sf = is_first, sr = is_last;
+          if (flipped) std::swap(sf, sr);
+          mine[(canon * 0x9E3779B97F4A7C15ull) >> 56].push_back(KmerInst{canon, uint8_t((sf ? 1 : 0) | (sr ? 2 : 0) | (flipped ? 4 : 0))});
+          is_first = false;
+        }
+      }
+    }
+  });
+  if (bad) return nullptr;
+  std::vector<std::vector<std::pair<kmer_t, KmerElem>>> kept(NP);
+  std::atomic<unsigned> next{0};
+  parallel_ranges(T, T, [&](unsigned, uint64_t, uint64_t) {
+    for (;;) {
+      const unsigned p = next++;
+      if (p >= NP) break;
+      std::unordered_map<kmer_t, KmerElem> table;
+      for (unsigned t = 0; t < T; ++t)
+        for (const KmerInst& x : routed[t][p]) {
+          KmerElem& e = table[x.canon];
+          e.flags |= x.bits & 3;
+          if (x.bits & 4) e.rev++; else e.fwd++;
+        }
+      for (auto& kv : table)
+        if (keep_all || uint64_t(kv.second.fwd) + kv.second.rev >= min_count) kept[p].push_back(kv);
+    }
+  });
+  std::vector<std::pair<kmer_t, KmerElem>> v;
+  for (auto& part : kept) v.insert(v.end(), part.begin(), part.end());
+  std::sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.first < b.first; });
+  auto* ks = new KmerSet;
+  ks->k = k;
+  for (auto& kv : v) {
+    ks->kmers.push_back(kv.first);
+    ks->flags.push_back(kv.second.flags);
+    ks->fwd.push_back(kv.second.fwd);
+    ks->rev.push_back(kv.second.rev);
+  }
+  ks->finish();
+  return ks;
+}
+
+static std::vector<std::string> build_entries_cover_mt(const std::vector<std::string>& reads, unsigned K, uint64_t* n_records,
+                                                      unsigned T) {
+  std::vector<std::string> o(reads.size() * 2);
+  parallel_ranges(reads.size(), T, [&](unsigned, uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; ++i) { o[2 * i] = reads[i]; o[2 * i + 1] = revcomp_str(reads[i]); }
+  });
+  auto key_at = [&](const std::string& s, size_t j) {
+    kmer_t x = 0;
+    for (unsigned i = 0; i < K; ++i) x = (x << 2) | kmer_t(base_code(s[j + i]));
+    return x;
+  };
+  const unsigned NP = 256;
+  std::vector<std::unordered_map<kmer_t, std::vector<uint32_t>>> idx(NP);
+  {
+    // first K-mers routed to index partitions by the threads that own the reads, each partition built by one thread
+    std::vector<std::vector<std::vector<std::pair<kmer_t, uint32_t>>>> routed(T, std::vector<std::vector<std::pair<kmer_t, uint32_t>>>(NP));
+    parallel_ranges(o.size(), T, [&](unsigned t, uint64_t lo, uint64_t hi) {
+      for (uint64_t i = lo; i < hi; ++i)
+        if (o[i].size() >= K) {
+          const kmer_t key = key_at(o[i], 0);
+          routed[t][(key * 0x9E3779B97F4A7C15ull) >> 56].emplace_back(key, uint32_t(i));
+        }
+    });
+    std::atomic<unsigned> next{0};
+    parallel_ranges(T, T, [&](unsigned, uint64_t, uint64_t) {
+      for (;;) {
+        const unsigned p = next++;
+        if (p >= NP) break;
+        for (unsigned t = 0; t < T; ++t)  // thread order = read order: candidates stay in ascending id order
+          for (auto& kv : routed[t][p]) idx[p][kv.first].push_back(kv.second);
+      }
+    });
+  }
+  // records bucketed by their leading 4 bases (a shorter record goes by its zero-padded prefix)
+  const unsigned NB = 256;
+  std::vector<std::vector<std::vector<std::string>>> rec(T, std::vector<std::vector<std::string>>(NB));
+  auto bucket_of = [](const char* p, size_t n) {
+    unsigned b = 0;
+    for (unsigned i = 0; i < 4; ++i) b = (b << 2) | (i < n ? unsigned(base_code(p[i])) : 0u);
+    return b;
+  };
+  parallel_ranges(o.size(), T, [&](unsigned t, uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; ++i) {
+      const std::string& s = o[i];
+      if (s.empty()) continue;
+      rec[t][bucket_of(s.data(), s.size())].push_back(s);
+      for (size_t j = 1; j < s.size(); ++j) {
+        bool covered = false;
+        const size_t rem = s.size() - j;
+        if (rem >= K) {
+          const kmer_t key = key_at(s, j);
+          auto& part = idx[(key * 0x9E3779B97F4A7C15ull) >> 56];
+          auto it = part.find(key);
+          if (it != part.end())
+            for (uint32_t c : it->second) {
+              const std::string& tt = o[c];
+              if (tt.size() >= rem && std::memcmp(tt.data(), s.data() + j, rem) == 0) { covered = true; break; }
+            }
+        }
+        if (covered) break;
+        rec[t][bucket_of(s.data() + j, rem)].push_back(s.substr(j));
+      }
+    }
+  });
+  std::vector<std::vector<std::string>> sorted(NB);
+  std::atomic<uint64_t> total{0};
+  {
+    std::atomic<unsigned> next{0};
+    parallel_ranges(T, T, [&](unsigned, uint64_t, uint64_t) {
+      for (;;) {
+        const unsigned b = next++;
+        if (b >= NB) break;
+        auto& v = sorted[b];
+        for (unsigned t = 0; t < T; ++t) {
+          for (auto& x : rec[t][b]) v.push_back(std::move(x));
+          std::vector<std::string>().swap(rec[t][b]);
+        }
+        total += v.size();
+        std::sort(v.begin(), v.end());
+      }
+    });
+  }
+  if (n_records) *n_records = total;
+  // buckets are lexicographic ranges: concatenation is sorted (a record shorter than 4 bases sorts before the longer
+  // ones of its padded bucket only if it is their prefix or smaller, which the bucket's own sort has settled)
+  std::vector<std::string> all;
+  all.reserve(total);
+  for (auto& v : sorted) { for (auto& x : v) all.push_back(std::move(x)); std::vector<std::string>().swap(v); }
+  if (!std::is_sorted(all.begin(), all.end())) std::sort(all.begin(), all.end());  // short records across padded buckets
+  dedup_sorted(all);
+  return all;
+}
+
+static Seqset* seqset_from_entries_mt(const std::vector<std::string>& e, unsigned T) {
+  auto* ss = new Seqset;
+  ss->n = e.size();
+  ss->sizes.resize(ss->n);
+  ss->shared.resize(ss->n);
+  for (int b = 0; b < 4; ++b) ss->bits[b].assign((ss->n + 63) / 64, 0);
+  std::vector<unsigned> maxes(T, 0);
+  std::atomic<int> missing{0};
+  parallel_ranges(e.size(), T, [&](unsigned t, uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; ++i) {
+      ss->sizes[i] = uint32_t(e[i].size());
+      maxes[t] = std::max<unsigned>(maxes[t], unsigned(e[i].size()));
+      ss->shared[i] = i ? lcp(e[i - 1], e[i]) : 0;
+      std::string tail = e[i].substr(1);
+      size_t tg = std::lower_bound(e.begin(), e.end(), tail) - e.begin();
+      if (tg >= e.size() || e[tg].compare(0, tail.size(), tail) != 0) { missing = 1; continue; }
+      int b = base_code(e[i][0]);
+      __atomic_fetch_or(&ss->bits[b][tg / 64], uint64_t(1) << (tg & 63), __ATOMIC_RELAXED);
+    }
+  });
+  for (unsigned m : maxes) ss->max_len = std::max(ss->max_len, m);
+  if (missing) { ss->err = "Missing expansion"; return ss; }
+  ss->finalize();
+  return ss;
+}
+
+}  // namespace orc
+
+extern "C" {
+
+unsigned orc_hardware_threads() { unsigned n = std::thread::hardware_concurrency(); return n ? n : 1; }
+
+void* orc_kmer_count_mt(const char* seq, const uint64_t* offs, uint64_t n_reads, int k, uint32_t min_count, int keep_all,
+                        unsigned nthreads) {
+  return kmer_count_mt(seq, offs, n_reads, unsigned(k), min_count, keep_all != 0, nthreads ? nthreads : 1);
+}
+
+int orc_correct_reads_mt(void* ksh, const char* seq, const uint64_t* offs, uint64_t n_reads, uint32_t max_corrections,
+                         uint32_t min_good_run, float trim_after_portion, char* out_seq, uint64_t* out_offs, uint8_t* out_keep,
+                         uint64_t* stats, unsigned nthreads) {
+  auto* ks = static_cast<KmerSet*>(ksh);
+  FrcParams p;
+  p.max_corrections = max_corrections;
+  p.min_good_run = min_good_run;
+  p.kmer_size = ks->k;
+  p.ks = ks;
+  const unsigned T = nthreads ? nthreads : 1;
+  std::vector<CorrectStats> sts(T);
+  std::vector<std::string> outs(T);
+  std::vector<std::vector<uint32_t>> lens(T);
+  std::vector<uint64_t> los(T, 0);
+  parallel_ranges(n_reads, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
+    los[t] = lo;
+    lens[t].reserve(hi - lo);
+    for (uint64_t r = lo; r < hi; ++r) {
+      std::string c;
+      bool ok = correct_read(seq + offs[r], offs[r + 1] - offs[r], p, trim_after_portion, &c, &sts[t]);
+      out_keep[r] = ok ? 1 : 0;
+      lens[t].push_back(ok ? uint32_t(c.size()) : 0u);
+      if (ok) outs[t] += c;
+    }
+  });
+  uint64_t pos = 0;
+  CorrectStats st;
+  for (unsigned t = 0; t < T; ++t) {
+    uint64_t r = los[t];
+    for (uint32_t l : lens[t]) { out_offs[r++] = pos; pos += l; }
+    st.corrected_reads += sts[t].corrected_reads; st.corrected_bases += sts[t].corrected_bases; st.failed += sts[t].failed;
+    st.modified += sts[t].modified; st.modified_bases += sts[t].modified_bases; st.truncated += sts[t].truncated;
+    st.dropped_bases += sts[t].dropped_bases; st.ref_records += sts[t].ref_records;
+  }
+  out_offs[n_reads] = pos;
+  pos = 0;
+  for (unsigned t = 0; t < T; ++t) { std::memcpy(out_seq + pos, outs[t].data(), outs[t].size()); pos += outs[t].size(); }
+  if (stats) {
+    stats[0] = st.corrected_reads; stats[1] = st.corrected_bases; stats[2] = st.failed;
+    stats[3] = st.modified; stats[4] = st.modified_bases; stats[5] = st.truncated;
+    stats[6] = st.dropped_bases; stats[7] = st.ref_records;
+  }
+  return 0;
+}
+
 // ---- entries
 struct Entries { std::vector<std::string> e; uint64_t n_records = 0; };
 void* orc_build_entries(const char* seq, const uint64_t* offs, uint64_t n_reads, int mode, int cover_k) {
@@ -1105,6 +1371,13 @@ void* orc_build_entries(const char* seq, const uint64_t* offs, uint64_t n_reads,
   } else {
     en->e = build_entries_cover(reads, unsigned(cover_k), &en->n_records);
   }
+  return en;
+}
+void* orc_build_entries_mt(const char* seq, const uint64_t* offs, uint64_t n_reads, int cover_k, unsigned nthreads) {
+  auto reads = split_reads(seq, offs, n_reads);
+  reads.erase(std::remove_if(reads.begin(), reads.end(), [](const std::string& s) { return s.empty(); }), reads.end());
+  auto* en = new Entries;
+  en->e = build_entries_cover_mt(reads, unsigned(cover_k), &en->n_records, nthreads ? nthreads : 1);
   return en;
 }
 void* orc_entries_from_strings(const char* seq, const uint64_t* offs, uint64_t n) {
@@ -1133,6 +1406,9 @@ void orc_entries_free(void* h) { delete static_cast<Entries*>(h); }
 
 // ---- seqset
 void* orc_seqset_from_entries(void* eh) { return seqset_from_entries(static_cast<Entries*>(eh)->e); }
+void* orc_seqset_from_entries_mt(void* eh, unsigned nthreads) {
+  return seqset_from_entries_mt(static_cast<Entries*>(eh)->e, nthreads ? nthreads : 1);
+}
 // From decoded arrays (golden files): sizes/shared u32[n], bits[b] = ceil(n/64) words each.
 void* orc_seqset_from_arrays(uint64_t n, const uint32_t* sizes, const uint32_t* shared, const uint64_t* bA,
                              const uint64_t* bC, const uint64_t* bG, const uint64_t* bT) {

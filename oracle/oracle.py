@@ -58,6 +58,16 @@ def lib():
     L.orc_entries_free.argtypes = [vp]
     L.orc_seqset_from_entries.restype = vp
     L.orc_seqset_from_entries.argtypes = [vp]
+    L.orc_hardware_threads.restype = C.c_uint
+    L.orc_kmer_count_mt.restype = vp
+    L.orc_kmer_count_mt.argtypes = [u8p, u64p, C.c_uint64, C.c_int, C.c_uint32, C.c_int, C.c_uint]
+    L.orc_correct_reads_mt.restype = C.c_int
+    L.orc_correct_reads_mt.argtypes = [vp, u8p, u64p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, u8p, u64p, u8p,
+                                       u64p, C.c_uint]
+    L.orc_build_entries_mt.restype = vp
+    L.orc_build_entries_mt.argtypes = [u8p, u64p, C.c_uint64, C.c_int, C.c_uint]
+    L.orc_seqset_from_entries_mt.restype = vp
+    L.orc_seqset_from_entries_mt.argtypes = [vp, C.c_uint]
     L.orc_seqset_from_arrays.restype = vp
     L.orc_seqset_from_arrays.argtypes = [C.c_uint64, u32p, u32p, u64p, u64p, u64p, u64p]
     L.orc_seqset_error.restype = C.c_char_p
@@ -162,8 +172,12 @@ class KmerSet:
         self.h = h
 
     @classmethod
-    def count(cls, seq, offs, k=30, min_count=5, keep_all=False):
-        h = lib().orc_kmer_count(_pad(seq), offs, len(offs) - 1, k, min_count, int(keep_all))
+    def count(cls, seq, offs, k=30, min_count=5, keep_all=False, threads=0):
+        """threads > 0: the same count on a std::thread pool (CPU baseline; same result)."""
+        if threads:
+            h = lib().orc_kmer_count_mt(_pad(seq), offs, len(offs) - 1, k, min_count, int(keep_all), threads)
+        else:
+            h = lib().orc_kmer_count(_pad(seq), offs, len(offs) - 1, k, min_count, int(keep_all))
         if not h:
             raise ValueError("invalid base in reads")
         return cls(h)
@@ -195,15 +209,23 @@ STAT_NAMES = ["corrected_reads", "corrected_bases", "failed", "modified", "modif
               "dropped_bases", "ref_records"]
 
 
-def correct_reads(ks, seq, offs, max_corrections=8, min_good_run=2, trim_after_portion=0.7):
+def hardware_threads():
+    return int(lib().orc_hardware_threads())
+
+
+def correct_reads(ks, seq, offs, max_corrections=8, min_good_run=2, trim_after_portion=0.7, threads=0):
     """-> (out_seq uint8, out_offs uint64[n+1], keep uint8[n], stats dict)."""
     n = len(offs) - 1
     out_seq = np.zeros(max(int(offs[-1]), 1), np.uint8)
     out_offs = np.zeros(n + 1, np.uint64)
     keep = np.zeros(max(n, 1), np.uint8)
     stats = np.zeros(8, np.uint64)
-    lib().orc_correct_reads(ks.h, _pad(seq), offs, n, max_corrections, min_good_run, trim_after_portion, out_seq,
-                            out_offs, keep, stats)
+    if threads:
+        lib().orc_correct_reads_mt(ks.h, _pad(seq), offs, n, max_corrections, min_good_run, trim_after_portion, out_seq,
+                                   out_offs, keep, stats, threads)
+    else:
+        lib().orc_correct_reads(ks.h, _pad(seq), offs, n, max_corrections, min_good_run, trim_after_portion, out_seq,
+                                out_offs, keep, stats)
     return out_seq[:int(out_offs[-1])], out_offs, keep[:n], dict(zip(STAT_NAMES, (int(x) for x in stats)))
 
 
@@ -212,7 +234,9 @@ class Entries:
         self.h = h
 
     @classmethod
-    def build(cls, seq, offs, mode="simple", cover_k=30):
+    def build(cls, seq, offs, mode="simple", cover_k=30, threads=0):
+        if threads:
+            return cls(lib().orc_build_entries_mt(_pad(seq), offs, len(offs) - 1, cover_k, threads))
         return cls(lib().orc_build_entries(_pad(seq), offs, len(offs) - 1, 0 if mode == "simple" else 1, cover_k))
 
     @classmethod
@@ -270,7 +294,9 @@ class Seqset:
             raise RuntimeError(err.decode())
 
     @classmethod
-    def from_entries(cls, entries):
+    def from_entries(cls, entries, threads=0):
+        if threads:
+            return cls(lib().orc_seqset_from_entries_mt(entries.h, threads))
         return cls(lib().orc_seqset_from_entries(entries.h))
 
     @classmethod

@@ -1,9 +1,9 @@
-"""TEST ONLY: a stand-in for biograph_amd.variants.Walker that answers the three batched walks with the
-oracle's literal restatements instead of the GPU kernels, so the host drivers of biograph_amd/variants.py
+"""TEST ONLY: a stand-in for tests.variants_twin.Walker that answers the three batched walks with the
+oracle's literal restatements instead of the GPU kernels, so the host drivers of tests/variants_twin.py
 can be checked on the CPU against the reference's own known answers."""
 import numpy as np
 
-from biograph_amd import variants as V
+from tests import variants_twin as V
 from oracle import oracle as O
 
 

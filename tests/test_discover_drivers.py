@@ -1,11 +1,11 @@
-"""The host drivers of biograph_amd/variants.py against the reference's own known answers:
+"""The host drivers of tests/variants_twin.py against the reference's own known answers:
 graph_discover/branch_test.cpp:63-98, push_to_pair_test.cpp:63-150 (tseq fixtures) and
 python/biograph/variants/graph_discover_test.py:41-56 (8 anchored variants on father_lambda).
 The walks are answered by the oracle here (tests/discover_backend.py); tests/test_gpu_discover_drivers.py
 repeats them with the GPU kernels behind the same drivers."""
 import pytest
 
-from biograph_amd import variants as V
+from tests import variants_twin as V
 from oracle import oracle as O
 from tests.discover_backend import OracleWalker, world_for_reads
 

@@ -1,10 +1,11 @@
-"""The discover drivers (biograph_amd/variants.py) with the GPU kernels behind them, against the same known
+"""The discover drivers (tests/variants_twin.py) with the GPU kernels behind them, against the same known
 answers of the reference as tests/test_discover_drivers.py (branch_test.cpp, push_to_pair_test.cpp,
 graph_discover_test.py + father.vcf), plus GPU == oracle on every intermediate assembly list."""
 import pytest
 
 import biograph_amd as bg
-from biograph_amd import variants as V
+from biograph_amd.variants import AssemblyList
+from tests import variants_twin as V
 from oracle import oracle as O
 from tests import test_discover_drivers as T
 from tests.discover_backend import OracleWalker
@@ -71,7 +72,7 @@ def test_native_drivers_known_answers(ctx):
 
     def both(w, asms, step):
         py = V.update_rc_seqset_entries(sorted(asms, key=V.canon_key), w, with_mates=True)
-        nat = V.AssemblyList(asms).update_rc_seqset_entries(w.ss, w.rm)
+        nat = AssemblyList(asms).update_rc_seqset_entries(w.ss, w.rm)
         assert _sig(nat.to_python()) == _sig(py)
         py = step(py, w)
         if step is branch_py:
@@ -111,7 +112,7 @@ def test_native_graph_discover_on_lambda_golden(ctx, golden_dir):
     rm = ctx.open_readmap(golden_dir + "/father_lambda/readmap")
     ref = "".join(l.strip() for l in open(golden_dir + "/father_lambda/reference.fasta") if not l.startswith(">")).upper()
     ext = [(0, ref)]
-    lst = V.AssemblyList().make_ref_assemblies(ext, 0, len(ref))
+    lst = AssemblyList().make_ref_assemblies(ext, 0, len(ref))
     lst.graph_trim_ref(ext).dedup().update_rc_seqset_entries(ss)
     lst.discover_branch(ss, rm, 70, "BRANCH")
     lst.graph_trim_ref(ext).dedup().update_rc_seqset_entries(ss)

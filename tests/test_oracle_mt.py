@@ -1,0 +1,41 @@
+"""The threaded stages of the oracle (the CPU baseline bench.py times) give exactly what the
+single-threaded restatement gives — which tests/test_oracle_golden.py pins on the reference's fixtures."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import util
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_threaded_stages_equal_single_threaded(threads):
+    reads = util.synth_reads(31, genome_len=20000, n_reads=5000, read_len=100, err=0.01, n_rate=0.002, var_len=True)
+    seq, offs = O.pack_strings(reads)
+    ks1 = O.KmerSet.count(seq, offs, 25, 3)
+    ksT = O.KmerSet.count(seq, offs, 25, 3, threads=threads)
+    for a, b in zip(ks1.arrays(), ksT.arrays()):
+        assert (a == b).all()
+    c1 = O.correct_reads(ks1, seq, offs, 8, 2, 0.7)
+    cT = O.correct_reads(ksT, seq, offs, 8, 2, 0.7, threads=threads)
+    assert (c1[0] == cT[0]).all() and (c1[1] == cT[1]).all() and (c1[2] == cT[2]).all() and c1[3] == cT[3]
+    e1 = O.Entries.build(c1[0], c1[1], "cover", 25)
+    eT = O.Entries.build(c1[0], c1[1], "cover", 25, threads=threads)
+    assert len(e1) == len(eT) and e1.n_records == eT.n_records
+    assert e1.strings() == eT.strings()
+    s1 = O.Seqset.from_entries(e1)
+    sT = O.Seqset.from_entries(eT, threads=threads)
+    assert s1.parts() == sT.parts()
+
+
+def test_threaded_golden_ecoli(golden_dir):
+    reads = O.read_fastq(golden_dir + "/e_coli_10000snp/reads.fq")
+    seq, offs = O.pack_strings(reads)
+    ks = O.KmerSet.count(seq, offs, 30, 5, threads=4)
+    assert len(ks) == 7108
+    cseq, coffs, keep, st = O.correct_reads(ks, seq, offs, threads=4)
+    assert st["corrected_reads"] == 8444 and st["corrected_bases"] == 288464
+    ent = O.Entries.build(cseq, coffs, "cover", 30, threads=4)
+    assert len(ent) == 19935
+    ss = O.Seqset.from_entries(ent, threads=4)
+    ref = O.Seqset.from_entries(O.Entries.build(cseq, coffs, "cover", 30))
+    assert ss.parts() == ref.parts()
