@@ -180,6 +180,19 @@ extern "C" int bg_ctx_create(int device, void* stream, bg_ctx** out) {
   bg_ctx* c = new bg_ctx;
   c->device = device;
   c->stream = static_cast<hipStream_t>(stream);
+  {
+    // what the arena may keep from the driver without using it (BG_POOL_CAP_GB, default 35 % of the device): the
+    // caller's own allocator (torch in the multi-GPU driver) lives beside it and cannot ask it to trim
+    size_t cap = ~size_t(0);
+    if (const char* e = getenv("BG_POOL_CAP_GB")) {
+      cap = size_t(atof(e) * 1e9);
+    } else {
+      size_t fr = 0, total = 0;
+      if (hipMemGetInfo(&fr, &total) == hipSuccess) cap = size_t(double(total) * 0.35);
+      else (void)hipGetLastError();
+    }
+    c->arena.set_cap(cap);
+  }
   *out = c;
   return BG_OK;
 }
@@ -197,10 +210,10 @@ extern "C" int bg_ctx_trim(bg_ctx* ctx) { return ctx ? ctx->trim() : BG_EINVAL; 
 
 extern "C" int bg_ctx_memory(bg_ctx* ctx, uint64_t* live, uint64_t* cached, uint64_t* peak, int reset_peak) {
   if (!ctx) return BG_EINVAL;
-  if (live) *live = ctx->live_bytes;
-  if (cached) *cached = ctx->cached_bytes;
-  if (peak) *peak = ctx->peak_bytes;
-  if (reset_peak) ctx->peak_bytes = ctx->live_bytes;
+  if (live) *live = ctx->arena.live();
+  if (cached) *cached = ctx->arena.cached();
+  if (peak) *peak = ctx->arena.peak();
+  if (reset_peak) ctx->arena.reset_peak();
   return BG_OK;
 }
 

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/bgseq.h"
+#include "arena.h"
 #include "bg_device_funcs.h"
 
 namespace bg {
@@ -43,10 +44,12 @@ struct bg_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool profiling = false;
-  // size -> cached free blocks (exact-size reuse: every build of one workload asks for the same sizes)
-  std::multimap<size_t, void*> free_blocks;
-  std::map<void*, size_t> live;
-  size_t cached_bytes = 0, live_bytes = 0, peak_bytes = 0;
+  // device memory: segments from hipMalloc, sub-allocated best-fit with coalescing (arena.h)
+  struct HipSegments {
+    void* seg_alloc(size_t n);
+    void seg_free(void* p);
+  };
+  bg::Arena<HipSegments> arena;
   std::vector<bg::TimingRec> recs;
   std::vector<hipEvent_t> event_pool;
 

@@ -983,15 +983,18 @@ extern "C" int bg_skm_extract_by_owner(bg_ctx* ctx, const bg_reads* reads, int k
     set_error("bg_skm_extract_by_owner: k = %d is outside the super-k-mer path (see bg_skm_supported)", k);
     return BG_EINVAL;
   }
-  if (cap < g.cap) { set_error("bg_skm_extract_by_owner: room for %llu records, %llu needed (bg_skm_capacity)",
-                               (unsigned long long)cap, (unsigned long long)g.cap); return BG_EINVAL; }
+  // cap may be smaller than bg_skm_capacity()'s worst case (3x the expected density): the caller sizes its buffers for
+  // what an ordinary input produces and comes back with the full capacity if this one produces more (BG_ENOMEM)
+  if (!cap) { set_error("bg_skm_extract_by_owner: no room for records"); return BG_EINVAL; }
+  g.cap = std::min<uint64_t>(cap, g.cap);
   DevBuf<SkRec> ra;
   DevBuf<uint64_t> oa;
   BG_TRY(ra.alloc(ctx, g.cap));
   BG_TRY(oa.alloc(ctx, g.cap));
   uint64_t R = 0;
   BG_TRY(sk_generate(ctx, reads, g, ra.p, oa.p, &R));
-  if (R > g.cap) { set_error("bg_skm_extract_by_owner: more super-k-mers than 3x the expected density"); return BG_ENOMEM; }
+  if (R > g.cap) { set_error("bg_skm_extract_by_owner: %llu super-k-mers do not fit the %llu the caller made room for",
+                             (unsigned long long)R, (unsigned long long)g.cap); return BG_ENOMEM; }
   *n_out = R;
   if (!R) return BG_OK;
   // whole groups of the top bucket byte go to their owner: owner = (byte * nparts) >> 8

@@ -11,6 +11,8 @@
 //               coalesced runs to HBM                          (reads keys once, writes once)
 // A one-off rs_digit_census pass finds digits on which all keys agree so those passes are skipped.
 #include "bg_device_funcs.h"
+#include <chrono>
+
 #include "bg_internal.h"
 
 namespace bg {
@@ -37,61 +39,44 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 // ------------------------------------------------------------------------------------------------
 // context
 
-int bg_ctx::alloc(size_t bytes, void** out) {
-  bytes = (bytes + 255) & ~size_t(255);
-  auto it = free_blocks.find(bytes);
-  if (it != free_blocks.end()) {
-    *out = it->second;
-    free_blocks.erase(it);
-    cached_bytes -= bytes;
-  } else {
-    static const bool trace = getenv("BG_ALLOC_TRACE") != nullptr;
-    if (trace) fprintf(stderr, "[bg alloc] hipMalloc %zu MiB (live %zu MiB, cached %zu MiB)\n", bytes >> 20, live_bytes >> 20, cached_bytes >> 20);
-    hipError_t e = hipMalloc(out, bytes);
-    if (e != hipSuccess && cached_bytes) {  // give cached blocks back and retry once
-      (void)hipGetLastError();  // the failed attempt must not surface at the next launch check
-      trim();
-      e = hipMalloc(out, bytes);
-    }
-    if (e != hipSuccess) {
-      bg::set_error("hipMalloc(%zu) failed: %s (live %zu MiB)", bytes, hipGetErrorString(e), live_bytes >> 20);
-      (void)hipGetLastError();
-      return BG_ENOMEM;
-    }
+void* bg_ctx::HipSegments::seg_alloc(size_t n) {
+  static const bool trace = getenv("BG_ALLOC_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, n);
+  if (trace)
+    fprintf(stderr, "[bg alloc] hipMalloc %zu MiB: %.2f ms%s\n", n >> 20,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+            e == hipSuccess ? "" : " FAILED");
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // the failed attempt must not surface at the next launch check
+    return nullptr;
   }
-  live[*out] = bytes;
-  live_bytes += bytes;
-  if (live_bytes > peak_bytes) peak_bytes = live_bytes;
+  return p;
+}
+
+void bg_ctx::HipSegments::seg_free(void* p) { (void)hipFree(p); }  // waits for the device
+
+int bg_ctx::alloc(size_t bytes, void** out) {
+  void* p = arena.alloc(bytes);
+  if (!p) {
+    (void)hipStreamSynchronize(stream);
+    bg::set_error("device allocation of %zu bytes failed (live %zu MiB, held %zu MiB)", bytes, arena.live() >> 20,
+                  arena.reserved() >> 20);
+    return BG_ENOMEM;
+  }
+  *out = p;
   return BG_OK;
 }
 
-void bg_ctx::release(void* p) {
-  auto it = live.find(p);
-  if (it == live.end()) return;
-  size_t bytes = it->second;
-  live.erase(it);
-  live_bytes -= bytes;
-  // The cache is bounded (BG_POOL_CAP_GB, default 35 % of the device): the caller's own allocator (torch in the
-  // multi-GPU driver) lives beside this pool and cannot ask it to trim.
-  static const size_t cap = [] {
-    if (const char* e = getenv("BG_POOL_CAP_GB")) return size_t(atof(e) * 1e9);
-    size_t fr = 0, total = 0;
-    if (hipMemGetInfo(&fr, &total) != hipSuccess) { (void)hipGetLastError(); return ~size_t(0); }
-    return size_t(double(total) * 0.35);
-  }();
-  if (cached_bytes + bytes > cap) {
-    (void)hipFree(p);  // waits for the device: nothing in flight still uses the block
-    return;
-  }
-  free_blocks.emplace(bytes, p);
-  cached_bytes += bytes;
-}
+// The chunk goes back to the arena at once: everything a context does is ordered on its one stream, so whoever gets
+// the chunk next is ordered after the work that used it; a wholly free segment may go back to the driver
+// (hipFree waits for the device).
+void bg_ctx::release(void* p) { (void)arena.release(p); }
 
 int bg_ctx::trim() {
   (void)hipStreamSynchronize(stream);
-  for (auto& kv : free_blocks) (void)hipFree(kv.second);
-  free_blocks.clear();
-  cached_bytes = 0;
+  arena.trim();
   return BG_OK;
 }
 

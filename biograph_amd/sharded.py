@@ -285,20 +285,34 @@ def _all_sum(comm, vals):
 
 
 def _skm_extract(ctx, reads_h, k, P, dev):
-    """Super-k-mer records of a reads object grouped by owner rank -> (recs [n,2], org [n], counts)."""
+    """Super-k-mer records of a reads object grouped by owner rank -> (recs [n,2], org [n], counts, windows).
+    The buffers are sized for 1.5x the expected record density (bg_skm_capacity is the 3x worst case, tried only
+    when an input beats that) and trimmed to what was produced: they live until the presence bits are back."""
     L = capi.lib()
     n = C.c_uint64()
     capi.check(L.bg_kmer_instances(ctx.h, reads_h, k, C.byref(n)))
     cap = C.c_uint64()
     capi.check(L.bg_skm_capacity(ctx.h, reads_h, k, n.value, C.byref(cap)))
-    recs = torch.empty((max(cap.value, 1), 2), dtype=torch.int64, device=dev)
-    org = torch.empty((max(cap.value, 1),), dtype=torch.int64, device=dev)
     counts = (C.c_uint64 * P)()
     nrec = C.c_uint64()
-    if cap.value:
-        capi.check(L.bg_skm_extract_by_owner(ctx.h, reads_h, k, n.value, P, _ptr(recs), _ptr(org), cap.value, counts,
-                                             C.byref(nrec)))
-    return recs[:nrec.value], org[:nrec.value], [int(c) for c in counts], n.value
+    if not cap.value:
+        return (torch.empty((0, 2), dtype=torch.int64, device=dev), torch.empty((0,), dtype=torch.int64, device=dev),
+                [0] * P, n.value)
+    for room in (cap.value // 2 + 1024, cap.value):
+        room = min(room, cap.value)
+        recs = torch.empty((room, 2), dtype=torch.int64, device=dev)
+        org = torch.empty((room,), dtype=torch.int64, device=dev)
+        rc = L.bg_skm_extract_by_owner(ctx.h, reads_h, k, n.value, P, _ptr(recs), _ptr(org), room, counts, C.byref(nrec))
+        if rc == -3 and room < cap.value:  # BG_ENOMEM: more records than 1.5x the expected density
+            del recs, org
+            continue
+        capi.check(rc)
+        break
+    if nrec.value * 4 < room * 3:  # give the unused tail back (a view would keep the whole buffer alive)
+        recs, org = recs[:nrec.value].clone(), org[:nrec.value].clone()
+    else:
+        recs, org = recs[:nrec.value], org[:nrec.value]
+    return recs, org, [int(c) for c in counts], n.value
 
 
 def _correct_routed(comm, ctxs, reads, owned, skm_recs, skm_org, skm_bits, prm, dev, ph):
@@ -627,6 +641,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gath
             capi.check(L.bg_kmer_extract_by_owner(ctxs[r].h, reads[r].h, k, P, _ptr(keys), n.value, counts))
             send[r] = (keys, [int(c) for c in counts])
             del keys
+    recs = org = None  # loop locals would keep the last rank's buffers alive to the end of the build
     ph.mark("kmer_all_to_all")
     recv = comm.all_to_all_v(send)
     sent_counts = comm.all_gather_obj({r: send[r][1] for r in ranks})[ranks[0]]  # [source][owner]
@@ -661,6 +676,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gath
             kept[r] = t
             ks.free()
     del recv
+    keys = bits = t = ks = None
     skm_bits = comm.all_to_all_v(bits_back) if use_skm else None
     del bits_back
     tot_inst = sum(comm.all_gather_obj(n_inst)[ranks[0]])
