@@ -255,13 +255,13 @@ extern "C" int bg_ctx_timings(bg_ctx* ctx, bg_timing* out, int cap) {
 extern "C" int bg_dev_alloc(bg_ctx* ctx, uint64_t bytes, void** d_out) {
   if (!ctx || !d_out) return BG_EINVAL;
   BG_HIP(hipSetDevice(ctx->device));
-  BG_HIP(hipMalloc(d_out, bytes ? bytes : 1));
-  return BG_OK;
+  return ctx->alloc(bytes ? bytes : 1, d_out);  // from the context's arena, like everything else
 }
 extern "C" int bg_dev_free(bg_ctx* ctx, void* p) {
   if (!ctx) return BG_EINVAL;
+  if (!p) return BG_OK;
   BG_HIP(hipSetDevice(ctx->device));
-  BG_HIP(hipFree(p));
+  if (!ctx->arena.release(p)) { set_error("bg_dev_free: %p was not allocated by this context", p); return BG_EINVAL; }
   return BG_OK;
 }
 extern "C" int bg_dev_upload(bg_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes) {

@@ -100,8 +100,9 @@ def test_presence_bits_drive_the_correction(ctx, monkeypatch, env):
 
 
 def test_pool_cache_cap_env():
-    """BG_POOL_CAP_GB bounds the allocator's cache (blocks beyond it go back to the device at once): the build
-    still runs and gives the same seqset; the cache stays under the cap."""
+    """BG_POOL_CAP_GB bounds what the allocator keeps from the driver without using it (a segment that becomes wholly
+    free beyond the cap goes back at once): the build still runs and gives the same seqset; once its result is
+    freed, what is held stays under the cap."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -111,6 +112,7 @@ def test_pool_cache_cap_env():
             "seq, offs, n = synth.make_reads(genome_len=300000, coverage=20, read_len=150, seed=4, device='cuda')\n"
             "ss, st = ctx.create_device(seq.data_ptr(), offs.data_ptr(), n, ctx.default_params())\n"
             "h = hashlib.sha256(b''.join(ss.parts()[k] for k in bg.PART_NAMES)).hexdigest()\n"
+            "ss.free()\n"
             "print('RESULT', h, ctx.memory()['cached'])\n") % root
     outs = []
     for cap in ("0.002", "64"):
