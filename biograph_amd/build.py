@@ -68,6 +68,18 @@ def build(force=False, verbose=False):
     if force or _stale(CLI, [cli_src, LIB] + hdrs):
         run(["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI, cli_src, "-L" + HERE, "-lbgseq", "-lz",
              "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")])
+    # biograph_amd._capi: the pybind11 module with the reference's Python C-API surface for this path, over the C ABI
+    import sysconfig
+    try:
+        import pybind11
+    except ImportError:  # the module is optional where pybind11 is absent; the C ABI and the ctypes mirror remain
+        return LIB
+    capi_src = os.path.join(CSRC, "pycapi.cpp")
+    capi_out = os.path.join(HERE, "_capi" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+    if force or _stale(capi_out, [capi_src, LIB] + hdrs):
+        run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-Wall", "-I" + pybind11.get_include(),
+             "-I" + sysconfig.get_paths()["include"], "-o", capi_out, capi_src, "-L" + HERE, "-lbgseq",
+             "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")])
     return LIB
 
 

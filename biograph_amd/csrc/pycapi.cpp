@@ -1,0 +1,585 @@
+// pycapi.cpp — pybind11 module biograph_amd._capi: the classes and functions of the reference's Python C API
+// (module biograph._capi_<maj><min>, python/biograph/module.cpp:30) for the seqset / readmap / graph-discover
+// path, over the C ABI of libbgseq.so (include/bgseq.h).  Same names, argument meaning and error behaviour:
+//
+//   Seqset, SeqsetEntry      python/biograph/seqset.cpp:46-183      (invalid results are None, valid_or_none :20-42)
+//   Readmap, ReadmapRead     python/biograph/readmap.cpp:27-116
+//   BioGraph                 python/biograph/biograph.cpp:39-79
+//   Reference (what the graph functions need of it)  python/biograph/reference.cpp
+//   Assembly + make_ref_assemblies, graph_trim_ref, update_rc_seqset_entries, discover_branch,
+//   discover_push_to_pair    python/biograph/variants/graph_discover.cpp:109-133, variants/assemble.h:285-420
+//
+// C++ exceptions surface as RuntimeError like the reference's io_exception.  Every query is a call into the
+// library (batch of one for the single-entry methods); there is no CPU implementation behind this module.
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <limits.h>
+#include <string.h>
+
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/bgseq.h"
+
+namespace py = pybind11;
+
+namespace {
+
+void check(int rc, const char* what) {
+  if (rc != BG_OK) throw std::runtime_error(std::string(what) + ": " + bg_last_error());
+}
+
+// one context per process (device 0, the null stream), created on first use
+struct Ctx {
+  bg_ctx* h = nullptr;
+  Ctx() { check(bg_ctx_create(0, nullptr, &h), "bg_ctx_create"); }
+  ~Ctx() {}  // objects may outlive it at interpreter exit: the driver reclaims the memory
+};
+std::shared_ptr<Ctx> ctx() {
+  static std::shared_ptr<Ctx> c = std::make_shared<Ctx>();
+  return c;
+}
+
+// a few device words for batch-of-one calls
+struct DevScratch {
+  std::shared_ptr<Ctx> c;
+  void* p = nullptr;
+  explicit DevScratch(uint64_t bytes) : c(ctx()) { check(bg_dev_alloc(c->h, bytes, &p), "bg_dev_alloc"); }
+  ~DevScratch() { if (p) bg_dev_free(c->h, p); }
+  template <class T> T* at(uint64_t byte_off) { return reinterpret_cast<T*>(static_cast<char*>(p) + byte_off); }
+  void up(uint64_t off, const void* src, uint64_t n) { check(bg_dev_upload(c->h, at<char>(off), src, n), "upload"); }
+  void down(void* dst, uint64_t off, uint64_t n) { check(bg_dev_download(c->h, dst, at<char>(off), n), "download"); }
+};
+
+int base_code(char b) {
+  switch (b) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+  }
+  throw std::runtime_error(std::string("Invalid base: ") + b);  // dna_base.h:54
+}
+
+struct SeqsetObj : std::enable_shared_from_this<SeqsetObj> {
+  std::shared_ptr<Ctx> c;
+  bg_seqset* h = nullptr;
+  std::string uuid;
+  std::vector<uint32_t> sizes, shared;  // host copies for truncate / get_entry_by_id (fetched on first use)
+  explicit SeqsetObj(const std::string& path) : c(ctx()) {
+    check(bg_seqset_open(c->h, path.c_str(), &h), "Seqset");
+    char u[64] = "";
+    bg_seqset_uuid(h, u, sizeof u);
+    uuid = u;
+  }
+  ~SeqsetObj() { if (h) bg_seqset_free(h); }
+  uint64_t size() const { return bg_seqset_size(h); }
+  void need_arrays() {
+    if (!sizes.empty() || !size()) return;
+    sizes.resize(size());
+    shared.resize(size());
+    check(bg_seqset_arrays(c->h, h, sizes.data(), shared.data()), "bg_seqset_arrays");
+  }
+};
+
+struct Entry {  // seqset_range
+  std::shared_ptr<SeqsetObj> ss;
+  uint64_t begin = 0, end = 0;
+  uint32_t size = 0;
+  bool valid() const { return begin < end; }
+  bool operator==(const Entry& o) const { return ss == o.ss && begin == o.begin && end == o.end && size == o.size; }
+};
+
+py::object entry_or_none(const Entry& e) { return e.valid() ? py::cast(e) : py::none(); }
+
+Entry seqset_find(const std::shared_ptr<SeqsetObj>& ss, const std::string& seq) {
+  for (char b : seq) base_code(b);
+  DevScratch d(seq.size() + 64);
+  uint64_t offs[2] = {0, seq.size()};
+  const uint64_t o_off = (seq.size() + 7) / 8 * 8;
+  if (!seq.empty()) d.up(0, seq.data(), seq.size());
+  d.up(o_off, offs, 16);
+  check(bg_find_batch(ss->c->h, ss->h, 1, d.at<uint8_t>(0), d.at<uint64_t>(o_off), d.at<uint64_t>(o_off + 16),
+                      d.at<uint64_t>(o_off + 24)), "find");
+  uint64_t be[2];
+  d.down(be, o_off + 16, 16);
+  return Entry{ss, be[0], be[1], uint32_t(seq.size())};
+}
+
+std::string entry_sequence(const Entry& e, int bases) {
+  if (!e.valid() || e.size == 0 || bases <= 0) return "";
+  uint64_t offs[2] = {0, 0};
+  check(bg_seqset_entries(e.ss->c->h, e.ss->h, e.begin, 1, nullptr, offs), "sequence");
+  std::string s(offs[1], '\0');
+  check(bg_seqset_entries(e.ss->c->h, e.ss->h, e.begin, 1, reinterpret_cast<uint8_t*>(&s[0]), offs), "sequence");
+  s.resize(std::min<uint64_t>(e.size, s.size()));
+  if (uint64_t(bases) < s.size()) s.resize(size_t(bases));
+  return s;
+}
+
+Entry entry_walk(const Entry& e, char base, bool drop, int min_ctx) {
+  const uint8_t b = uint8_t(base_code(base));
+  DevScratch d(128);
+  const uint32_t mc = uint32_t(min_ctx < 0 ? 0 : min_ctx);
+  d.up(0, &e.begin, 8);
+  d.up(8, &e.end, 8);
+  d.up(16, &e.size, 4);
+  d.up(20, &b, 1);
+  d.up(24, &mc, 4);
+  if (drop)
+    check(bg_push_front_drop_batch(e.ss->c->h, e.ss->h, 1, d.at<uint64_t>(0), d.at<uint64_t>(8), d.at<uint32_t>(16), d.at<uint8_t>(20),
+                                   d.at<uint32_t>(24), d.at<uint64_t>(32), d.at<uint64_t>(40), d.at<uint32_t>(48)), "push_front_drop");
+  else
+    check(bg_push_front_batch(e.ss->c->h, e.ss->h, 1, d.at<uint64_t>(0), d.at<uint64_t>(8), d.at<uint32_t>(16), d.at<uint8_t>(20),
+                              d.at<uint64_t>(32), d.at<uint64_t>(40), d.at<uint32_t>(48)), "push_front");
+  Entry r{e.ss, 0, 0, 0};
+  d.down(&r.begin, 32, 8);
+  d.down(&r.end, 40, 8);
+  d.down(&r.size, 48, 4);
+  return r;
+}
+
+// seqset_range::truncate (bio_base/seqset.cpp:630-661): widen to the entries sharing the first new_size bases
+Entry entry_truncate(const Entry& e, uint32_t new_size) {
+  if (e.size <= new_size) return e;
+  e.ss->need_arrays();
+  const auto& sh = e.ss->shared;
+  const uint64_t n = e.ss->size();
+  uint64_t b = e.begin, en = e.end;
+  while (b > 0 && sh[b] >= new_size) --b;
+  while (en < n && sh[en] >= new_size) ++en;
+  return Entry{e.ss, b, en, new_size};
+}
+
+Entry entry_pop_front(const Entry& e) {  // seqset_range::pop_front: the entries prefixed by sequence()[1:]
+  if (e.size == 0) throw std::runtime_error("pop_front of an empty sequence");
+  return seqset_find(e.ss, entry_sequence(e, INT_MAX).substr(1));
+}
+
+std::string entry_repr(const Entry& e) {
+  std::ostringstream o;
+  o << "<SeqsetEntry " << e.begin << "-" << e.end << ": " << entry_sequence(e, INT_MAX) << ">";
+  return o.str();
+}
+
+struct ReadmapObj : std::enable_shared_from_this<ReadmapObj> {
+  std::shared_ptr<Ctx> c;
+  std::shared_ptr<SeqsetObj> ss;
+  bg_readmap* h = nullptr;
+  std::string path;
+  std::vector<uint32_t> entry_id, read_len, loop;
+  std::vector<uint8_t> fwd;
+  ReadmapObj(const std::shared_ptr<SeqsetObj>& s, const std::string& p) : c(ctx()), ss(s), path(p) {
+    check(bg_readmap_open(c->h, p.c_str(), &h), "Readmap");
+    const uint64_t n = bg_readmap_size(h);
+    entry_id.resize(n); read_len.resize(n); loop.resize(n); fwd.resize(n);
+    if (n) check(bg_readmap_arrays(c->h, h, entry_id.data(), read_len.data(), loop.data(), fwd.data()), "bg_readmap_arrays");
+  }
+  ~ReadmapObj() { if (h) bg_readmap_free(h); }
+  uint64_t size() const { return entry_id.size(); }
+  uint32_t min_read_len() const {
+    uint32_t m = UINT32_MAX;
+    for (uint32_t l : read_len) m = std::min(m, l);
+    return read_len.empty() ? 0 : m;
+  }
+};
+
+struct Read {  // readmap::read
+  std::shared_ptr<ReadmapObj> rm;
+  uint32_t id = 0;
+  bool operator==(const Read& o) const { return rm == o.rm && id == o.id; }
+};
+
+Read read_by_id(const std::shared_ptr<ReadmapObj>& rm, int64_t id) {
+  if (id < 0 || uint64_t(id) >= rm->size()) throw std::runtime_error("Read id out of range");
+  return Read{rm, uint32_t(id)};
+}
+bool read_has_mate(const Read& r) { return r.rm->loop[r.rm->loop[r.id]] != r.id; }  // readmap.cpp:207-218
+Read read_mate(const Read& r) {                                                      // readmap.cpp:220-239
+  if (!read_has_mate(r)) throw std::runtime_error("Read has no mate");
+  return Read{r.rm, r.rm->loop[r.rm->loop[r.id]]};
+}
+Read read_rev_comp(const Read& r) {  // readmap.cpp:248-268: one hop forward for a forward read, three for its reverse
+  uint32_t x = r.id;
+  for (int i = 0, n = r.rm->fwd[r.id] ? 1 : 3; i < n; ++i) x = r.rm->loop[x];
+  return Read{r.rm, x};
+}
+Entry read_entry(const Read& r) {  // readmap.h:249-251: ctx_entry(id).truncate(length)
+  const uint64_t e = r.rm->entry_id[r.id];
+  r.rm->ss->need_arrays();
+  return entry_truncate(Entry{r.rm->ss, e, e + 1, r.rm->ss->sizes[e]}, r.rm->read_len[r.id]);
+}
+std::string read_repr(const Read& r) {
+  std::ostringstream o;
+  o << "<ReadmapRead " << r.id << ": " << entry_sequence(read_entry(r), INT_MAX) << ">";
+  return o.str();
+}
+
+std::vector<Read> prefix_reads(const std::shared_ptr<ReadmapObj>& rm, const Entry& e, int min_read_len) {
+  if (e.ss->uuid != rm->ss->uuid) throw std::runtime_error("Readmap does not belong to the seqset of this entry");  // readmap.cpp:436-438
+  uint32_t cap = 256;
+  for (;;) {
+    DevScratch d(64 + uint64_t(cap) * 4);
+    d.up(0, &e.begin, 8);
+    d.up(8, &e.end, 8);
+    d.up(16, &e.size, 4);
+    check(bg_prefix_reads_batch(rm->c->h, rm->ss->h, rm->h, 1, d.at<uint64_t>(0), d.at<uint64_t>(8), d.at<uint32_t>(16), min_read_len, cap,
+                                d.at<uint32_t>(64), d.at<uint32_t>(24)), "get_prefix_reads");
+    uint32_t count = 0;
+    d.down(&count, 24, 4);
+    if (count > cap) { cap = count; continue; }
+    std::vector<uint32_t> ids(count);
+    if (count) d.down(ids.data(), 64, uint64_t(count) * 4);
+    std::vector<Read> out;
+    for (uint32_t i : ids) out.push_back(Read{rm, i});
+    return out;
+  }
+}
+
+// ---- BioGraph directory (bio_base/biograph_dir.h:48-88): seqset, coverage/<sha>.readmap, metadata/bg_info.json
+std::string read_file(const std::string& p) {
+  std::ifstream f(p, std::ios::binary);
+  if (!f) throw std::runtime_error("Could not open " + p);
+  std::ostringstream o;
+  o << f.rdbuf();
+  return o.str();
+}
+std::string json_take(const std::string& js, size_t p, size_t* end) {
+  std::string v;
+  size_t i = p + 1;
+  for (; i < js.size() && js[i] != '"'; ++i) {
+    if (js[i] == '\\' && i + 1 < js.size()) { ++i; v.push_back(js[i] == 'n' ? '\n' : js[i] == 't' ? '\t' : js[i]); }
+    else v.push_back(js[i]);
+  }
+  *end = i + 1;
+  return v;
+}
+struct Metadata {
+  std::string accession_id, biograph_id, version;
+  std::map<std::string, std::string> samples;
+};
+Metadata parse_metadata(const std::string& js) {
+  Metadata m;
+  auto str_of = [&](const char* key) {
+    std::string pat = std::string("\"") + key + "\":\"";
+    size_t p = js.find(pat), e;
+    return p == std::string::npos ? std::string() : json_take(js, p + pat.size() - 1, &e);
+  };
+  m.accession_id = str_of("accession_id");
+  m.biograph_id = str_of("biograph_id");
+  m.version = str_of("version");
+  size_t p = js.find("\"samples\":{");
+  if (p != std::string::npos) {
+    p += 11;
+    while (p < js.size()) {
+      while (p < js.size() && (js[p] == ',' || js[p] == ' ' || js[p] == '\n')) ++p;
+      if (p >= js.size() || js[p] != '"') break;
+      size_t e;
+      std::string k = json_take(js, p, &e);
+      size_t v0 = js.find('"', e);
+      if (v0 == std::string::npos) break;
+      m.samples[k] = json_take(js, v0, &e);
+      p = e;
+    }
+  }
+  return m;
+}
+
+struct BioGraphObj {
+  std::string dir;
+  std::shared_ptr<SeqsetObj> seqset;
+  Metadata meta;
+  explicit BioGraphObj(const std::string& d) : dir(d) {
+    seqset = std::make_shared<SeqsetObj>(dir + "/seqset");
+    meta = parse_metadata(read_file(dir + "/metadata/bg_info.json"));
+  }
+  std::shared_ptr<ReadmapObj> open_readmap(const std::string& id) {  // biograph_dir.cpp:97-130 find_readmap
+    if (meta.samples.empty()) throw std::runtime_error("No samples found in BioGraph metadata.");
+    std::string sha;
+    if (id.empty()) {
+      if (meta.samples.size() > 1) throw std::runtime_error("Multiple samples are present. You must specify a readmap or accession ID.");
+      sha = meta.samples.begin()->second;
+    } else if (meta.samples.count(id)) {
+      sha = meta.samples[id];
+    } else {
+      for (auto& kv : meta.samples) if (kv.second == id) sha = id;
+      if (sha.empty()) throw std::runtime_error("Sample " + id + " not found in " + dir);
+    }
+    return std::make_shared<ReadmapObj>(seqset, dir + "/coverage/" + sha + ".readmap");
+  }
+};
+
+// ---- reference + assemblies
+struct ReferenceObj {
+  bg_reference* h = nullptr;
+  explicit ReferenceObj(const std::string& path) { check(bg_reference_open(path.c_str(), &h), "Reference"); }
+  ~ReferenceObj() { if (h) bg_reference_free(h); }
+  std::map<std::string, uint64_t> scaffold_lens() const {
+    std::map<std::string, uint64_t> m;
+    for (uint32_t i = 0; i < bg_reference_scaffold_count(h); ++i) m[bg_reference_scaffold_name(h, i)] = bg_reference_scaffold_len(h, i);
+    return m;
+  }
+  // the N-free extents of one scaffold: (offset inside the scaffold, bases)
+  std::vector<std::pair<int64_t, std::string>> extents(const std::string& name) const {
+    int32_t want = -1;
+    for (uint32_t i = 0; i < bg_reference_scaffold_count(h); ++i) if (name == bg_reference_scaffold_name(h, i)) want = int32_t(i);
+    if (want < 0) throw std::runtime_error("Unknown scaffold " + name);
+    std::vector<std::pair<int64_t, std::string>> out;
+    for (uint32_t i = 0; i < bg_reference_supercontig_count(h); ++i) {
+      uint32_t sc = 0;
+      uint64_t off = 0, len = 0, flat = 0;
+      check(bg_reference_supercontig(h, i, &sc, &off, &len, &flat), "bg_reference_supercontig");
+      if (int32_t(sc) != want) continue;
+      std::string s(len, '\0');
+      check(bg_reference_bases(h, flat, len, &s[0]), "bg_reference_bases");
+      out.emplace_back(int64_t(off), std::move(s));
+    }
+    return out;
+  }
+};
+
+struct Assembly {  // variants::assembly, the fields this path touches (variants/assemble.h:285-420)
+  py::object left_offset = py::none(), right_offset = py::none();  // optional_aoffset
+  std::string seq;
+  bool matches_reference = false;
+  std::vector<std::string> tags;
+  uint64_t assembly_id = 0;
+};
+std::string asm_repr(const Assembly& a) {
+  std::ostringstream o;
+  o << "Assembly(" << py::str(a.left_offset).cast<std::string>() << ", " << py::str(a.right_offset).cast<std::string>() << ", "
+    << (a.seq.size() < 40 ? a.seq : a.seq.substr(0, 37) + "...") << (a.matches_reference ? ", ref" : "") << ")";
+  return o.str();
+}
+
+struct AsmList {
+  bg_asm_list* h = nullptr;
+  AsmList() { check(bg_asm_list_create(&h), "bg_asm_list_create"); }
+  ~AsmList() { if (h) bg_asm_list_free(h); }
+  AsmList(const AsmList&) = delete;
+  void fill(const py::iterable& input) {
+    bool any = false;
+    for (py::handle o : input) {
+      const Assembly& a = o.cast<const Assembly&>();
+      std::string tags;
+      for (size_t i = 0; i < a.tags.size(); ++i) tags += (i ? "," : "") + a.tags[i];
+      const int64_t lo = a.left_offset.is_none() ? BG_OFFSET_NONE : a.left_offset.cast<int64_t>();
+      const int64_t ro = a.right_offset.is_none() ? BG_OFFSET_NONE : a.right_offset.cast<int64_t>();
+      check(bg_asm_list_add(h, lo, ro, a.seq.data(), a.seq.size(), a.matches_reference ? 1 : 0, tags.c_str()), "bg_asm_list_add");
+      any = true;
+    }
+    if (any) check(bg_asm_list_sort(h), "bg_asm_list_sort");
+  }
+  std::vector<Assembly> take() const {
+    static uint64_t next_id = 1;
+    std::vector<Assembly> out;
+    for (uint64_t i = 0; i < bg_asm_list_size(h); ++i) {
+      int64_t lo, ro;
+      const char *sq, *tg;
+      uint64_t ln;
+      int mr;
+      check(bg_asm_list_get(h, i, &lo, &ro, &sq, &ln, &mr, &tg), "bg_asm_list_get");
+      Assembly a;
+      if (lo != BG_OFFSET_NONE) a.left_offset = py::int_(lo);
+      if (ro != BG_OFFSET_NONE) a.right_offset = py::int_(ro);
+      a.seq.assign(sq, ln);
+      a.matches_reference = mr != 0;
+      std::string t = tg ? tg : "";
+      size_t p = 0;
+      while (p < t.size()) {
+        size_t e = t.find(',', p);
+        if (e == std::string::npos) e = t.size();
+        if (e > p) a.tags.push_back(t.substr(p, e - p));
+        p = e + 1;
+      }
+      a.assembly_id = next_id++;
+      out.push_back(std::move(a));
+    }
+    return out;
+  }
+};
+
+struct Extents {  // argument arrays of the graph entry points
+  std::vector<std::pair<int64_t, std::string>> ext;
+  std::vector<int64_t> off;
+  std::vector<const char*> ptr;
+  std::vector<uint64_t> len;
+  Extents(const ReferenceObj& ref, const std::string& scaffold) : ext(ref.extents(scaffold)) {
+    for (auto& e : ext) { off.push_back(e.first); ptr.push_back(e.second.c_str()); len.push_back(e.second.size()); }
+  }
+};
+
+std::string join(const std::vector<std::string>& v) {
+  std::string s;
+  for (size_t i = 0; i < v.size(); ++i) s += (i ? "," : "") + v[i];
+  return s;
+}
+
+// the pipeline steps are generators in the reference (define_pipeline_generator): an iterator over the step's output
+py::object iterate(std::vector<Assembly> v) {
+  auto holder = std::make_shared<std::vector<Assembly>>(std::move(v));
+  py::list l;
+  for (auto& a : *holder) l.append(py::cast(a));
+  return l.attr("__iter__")();
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_capi, m) {
+  m.attr("__doc__") = "Internal C API calls for the BioGraph SDK surface of biograph_amd (MI355X build of the seqset path)";
+
+  py::class_<SeqsetObj, std::shared_ptr<SeqsetObj>>(m, "Seqset", "Load a Seqset (python/biograph/seqset.cpp:46).  Raises RuntimeError if the file cannot be opened.")
+      .def(py::init<const std::string&>(), py::arg("path"))
+      .def("size", &SeqsetObj::size, "Total number of entries in the Seqset.")
+      .def("find", [](const std::shared_ptr<SeqsetObj>& s, const py::object& seq) { return entry_or_none(seqset_find(s, py::str(seq).cast<std::string>())); },
+           py::arg("seq"), "Search the Seqset for this sequence: a SeqsetEntry, or None when it is absent.")
+      .def("empty_entry", [](const std::shared_ptr<SeqsetObj>& s) { return entry_or_none(Entry{s, 0, s->size(), 0}); })
+      .def("get_entry_by_id", [](const std::shared_ptr<SeqsetObj>& s, py::int_ id) {
+             if (PyObject_RichCompareBool(id.ptr(), py::int_(0).ptr(), Py_LT) == 1) throw py::type_error("entry id must be non-negative");
+             const uint64_t i = id.cast<uint64_t>();
+             if (i >= s->size()) throw std::runtime_error("Entry id out of range");
+             s->need_arrays();
+             return entry_or_none(Entry{s, i, i + 1, s->sizes[i]});
+           }, py::arg("id"))
+      .def("max_sequence_length", [](const SeqsetObj& s) { return bg_seqset_max_len(s.h); })
+      .def_property_readonly("uuid", [](const SeqsetObj& s) { return s.uuid; });
+
+  py::class_<Entry>(m, "SeqsetEntry", "A sequence contained in the Seqset, as a [start, end) range of entries.")
+      .def("sequence", &entry_sequence, py::arg("bases") = INT_MAX)
+      .def("__len__", [](const Entry& e) { return e.size; })
+      .def("truncate", [](const Entry& e, uint32_t n) { return entry_or_none(entry_truncate(e, n)); }, py::arg("new_size"))
+      .def("push_front", [](const Entry& e, const std::string& b) {
+             if (b.size() != 1) throw std::runtime_error("push_front takes one base");
+             return entry_or_none(entry_walk(e, b[0], false, 0));
+           }, py::arg("base"))
+      .def("push_front_drop", [](const Entry& e, const std::string& b, int min_ctx) {
+             if (b.size() != 1) throw std::runtime_error("push_front_drop takes one base");
+             return entry_or_none(entry_walk(e, b[0], true, min_ctx));
+           }, py::arg("base"), py::arg("min_ctx") = 0)
+      .def("pop_front", [](const Entry& e) { return entry_or_none(entry_pop_front(e)); })
+      .def("get_begin_entry_id", [](const Entry& e) { return e.begin; })
+      .def("get_end_entry_id", [](const Entry& e) { return e.end; })
+      .def("__eq__", [](const Entry& a, const py::object& o) { return py::isinstance<Entry>(o) && a == o.cast<const Entry&>(); })
+      .def("__ne__", [](const Entry& a, const py::object& o) { return !(py::isinstance<Entry>(o) && a == o.cast<const Entry&>()); })
+      .def("__hash__", [](const Entry& e) { return py::hash(py::make_tuple(e.begin, e.end, e.size)); })
+      .def("__str__", &entry_repr)
+      .def("__repr__", &entry_repr);
+
+  py::class_<ReadmapObj, std::shared_ptr<ReadmapObj>>(m, "Readmap", "The reads of one sample over a Seqset (python/biograph/readmap.cpp:27).")
+      .def("__repr__", [](const ReadmapObj& r) { return "<Readmap " + r.path + ">"; })
+      .def_property_readonly("seqset", [](const ReadmapObj& r) { return r.ss; })
+      .def("max_read_len", [](const ReadmapObj& r) { return bg_readmap_max_read_len(r.h); })
+      .def("min_read_len", &ReadmapObj::min_read_len)
+      .def("size", &ReadmapObj::size)
+      .def("get_read_by_id", [](const std::shared_ptr<ReadmapObj>& r, int64_t id) { return read_by_id(r, id); }, py::arg("id"))
+      .def("get_prefix_reads", [](const std::shared_ptr<ReadmapObj>& r, const Entry& e, int min_read_len) {
+             py::list l;
+             for (const Read& x : prefix_reads(r, e, min_read_len)) l.append(py::cast(x));
+             return l.attr("__iter__")();
+           }, py::arg("entry"), py::arg("min_read_len") = 0)
+      .def("get_read_count", [](const ReadmapObj& r) { return r.size() / 2; })
+      .def("get_num_bases", [](const ReadmapObj& r) {
+             uint64_t t = 0;
+             for (size_t i = 0; i < r.read_len.size(); ++i) if (r.fwd[i]) t += r.read_len[i];
+             return t;
+           });
+
+  py::class_<Read>(m, "ReadmapRead", "One read of a Readmap.")
+      .def("__len__", [](const Read& r) { return r.rm->read_len[r.id]; })
+      .def("__eq__", [](const Read& a, const py::object& o) { return py::isinstance<Read>(o) && a == o.cast<const Read&>(); })
+      .def("__ne__", [](const Read& a, const py::object& o) { return !(py::isinstance<Read>(o) && a == o.cast<const Read&>()); })
+      .def("__hash__", [](const Read& r) { return py::hash(py::int_(r.id)); })
+      .def("__repr__", &read_repr)
+      .def("__str__", &read_repr)
+      .def("has_mate", &read_has_mate)
+      .def("get_mate", &read_mate)
+      .def("get_rev_comp", &read_rev_comp)
+      .def("is_original_orientation", [](const Read& r) { return r.rm->fwd[r.id] != 0; })
+      .def("get_seqset_entry", &read_entry)
+      .def("get_read_id", [](const Read& r) { return r.id; });
+
+  py::class_<Metadata>(m, "Metadata")
+      .def_readonly("accession_id", &Metadata::accession_id)
+      .def_readonly("biograph_id", &Metadata::biograph_id)
+      .def_readonly("version", &Metadata::version)
+      .def_readonly("samples", &Metadata::samples);
+
+  py::class_<BioGraphObj, std::shared_ptr<BioGraphObj>>(m, "BioGraph", "A BioGraph directory: Seqset + Readmaps (python/biograph/biograph.cpp:39).")
+      .def(py::init<const std::string&>(), py::arg("dirname"))
+      .def_property_readonly("seqset", [](const BioGraphObj& b) { return b.seqset; })
+      .def("open_readmap", &BioGraphObj::open_readmap, py::arg("accession_id") = "")
+      .def_property_readonly("metadata", [](const BioGraphObj& b) { return b.meta; });
+
+  py::class_<ReferenceObj, std::shared_ptr<ReferenceObj>>(m, "Reference", "A reference directory, .ref file or FASTA.")
+      .def(py::init<const std::string&>(), py::arg("path"))
+      .def_property_readonly("scaffold_lens", &ReferenceObj::scaffold_lens)
+      .def("size", [](const ReferenceObj& r) { return bg_reference_size(r.h); });
+
+  py::class_<Assembly>(m, "Assembly")
+      .def(py::init([](py::object lo, py::object ro, std::string seq, bool mr, std::vector<std::string> tags) {
+             Assembly a;
+             a.left_offset = std::move(lo);
+             a.right_offset = std::move(ro);
+             a.seq = std::move(seq);
+             a.matches_reference = mr;
+             a.tags = std::move(tags);
+             return a;
+           }), py::arg("left_offset") = py::none(), py::arg("right_offset") = py::none(), py::arg("seq") = "",
+           py::arg("matches_reference") = false, py::arg("tags") = std::vector<std::string>())
+      .def_readwrite("left_offset", &Assembly::left_offset)
+      .def_readwrite("right_offset", &Assembly::right_offset)
+      .def_readwrite("seq", &Assembly::seq)
+      .def_readwrite("matches_reference", &Assembly::matches_reference)
+      .def_readwrite("tags", &Assembly::tags)
+      .def_readonly("assembly_id", &Assembly::assembly_id)
+      .def("__repr__", &asm_repr);
+
+  m.def("make_ref_assemblies", [](const ReferenceObj& ref, const std::string& scaffold, int64_t start, int64_t limit, int64_t max_chunk) {
+          Extents x(ref, scaffold);
+          AsmList l;
+          check(bg_make_ref_assemblies(l.h, x.off.size(), x.off.data(), x.ptr.data(), x.len.data(), start, limit, max_chunk), "make_ref_assemblies");
+          return l.take();
+        }, py::arg("ref"), py::arg("scaffold_name"), py::arg("start_offset"), py::arg("limit_offset"), py::arg("max_chunk_size") = 100);
+  m.def("graph_trim_ref", [](const py::iterable& input, const ReferenceObj& ref, const std::string& scaffold, bool rev_comp) {
+          if (rev_comp) throw std::runtime_error("graph_trim_ref: rev_comp is not supported");
+          Extents x(ref, scaffold);
+          AsmList l;
+          l.fill(input);
+          check(bg_graph_trim_ref(l.h, x.off.size(), x.off.data(), x.ptr.data(), x.len.data(), 0), "graph_trim_ref");
+          return iterate(l.take());
+        }, py::arg("input"), py::arg("ref"), py::arg("scaffold_name"), py::arg("rev_comp") = false);
+  m.def("update_rc_seqset_entries", [](const py::iterable& input, const std::shared_ptr<SeqsetObj>& ss, bool) {
+          AsmList l;
+          l.fill(input);
+          check(bg_update_rc_seqset_entries(ss->c->h, ss->h, nullptr, l.h, 20), "update_rc_seqset_entries");
+          return iterate(l.take());
+        }, py::arg("input"), py::arg("seqset"), py::arg("enable_self_test") = false);
+  // NB the rc seqset entries live on the C++ side of a step and are rebuilt by the step that needs them: the
+  // discover steps below run update_rc_seqset_entries on their input first, which is what the reference's pipeline
+  // does right before them (graph_discover_test.py:36-39)
+  m.def("discover_branch", [](const py::iterable& input, const std::shared_ptr<ReadmapObj>& rm, int min_overlap, const std::string& tag,
+                              const std::vector<std::string>& discover_tags) {
+          AsmList l;
+          l.fill(input);
+          check(bg_update_rc_seqset_entries(rm->c->h, rm->ss->h, nullptr, l.h, 20), "update_rc_seqset_entries");
+          check(bg_discover_branch(rm->c->h, rm->ss->h, rm->h, l.h, uint32_t(min_overlap), tag.c_str(), join(discover_tags).c_str()), "discover_branch");
+          return iterate(l.take());
+        }, py::arg("input"), py::arg("readmap"), py::arg("min_overlap") = 70, py::arg("tag") = "GRAPH_BRANCH",
+        py::arg("discover_tags") = std::vector<std::string>());
+  m.def("discover_push_to_pair", [](const py::iterable& input, const std::shared_ptr<ReadmapObj>& rm, int min_overlap, int max_pair_distance,
+                                    const std::string& tag, const std::vector<std::string>& discover_tags) {
+          AsmList l;
+          l.fill(input);
+          check(bg_update_rc_seqset_entries(rm->c->h, rm->ss->h, nullptr, l.h, 20), "update_rc_seqset_entries");
+          check(bg_discover_push_to_pair(rm->c->h, rm->ss->h, rm->h, l.h, uint32_t(min_overlap), max_pair_distance, tag.c_str(),
+                                         join(discover_tags).c_str()), "discover_push_to_pair");
+          return iterate(l.take());
+        }, py::arg("input"), py::arg("readmap"), py::arg("min_overlap") = 70, py::arg("max_pair_distance") = 1000,
+        py::arg("tag") = "GRAPH_PUSH_TO_PAIR", py::arg("discover_tags") = std::vector<std::string>());
+}
