@@ -188,6 +188,7 @@ extern "C" int bg_seqset_merge(bg_ctx* ctx, uint32_t n_in, const bg_seqset* cons
 extern "C" int bg_readmap_migrate(bg_ctx* ctx, const bg_readmap* old_rm, const uint64_t* d_map, const bg_seqset* merged,
                                   bg_readmap** out) {
   if (!ctx || !old_rm || !merged || !out || (old_rm->n_entries && !d_map)) { set_error("bg_readmap_migrate: null argument"); return BG_EINVAL; }
+  if (old_rm->pair_mode) { set_error("bg_readmap_migrate: readmap has no mate loop table; use \"biograph upgrade\" to construct it"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));
   const uint64_t n = old_rm->n_reads, n_ent = merged->n;
   std::unique_ptr<bg_readmap> rm(new bg_readmap);

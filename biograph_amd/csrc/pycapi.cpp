@@ -175,11 +175,13 @@ struct ReadmapObj : std::enable_shared_from_this<ReadmapObj> {
   std::string path;
   std::vector<uint32_t> entry_id, read_len, loop;
   std::vector<uint8_t> fwd;
+  bool has_loops = true;  // false: `loop` holds the legacy pair table (readmap.cpp:48-51)
   ReadmapObj(const std::shared_ptr<SeqsetObj>& s, const std::string& p) : c(ctx()), ss(s), path(p) {
     check(bg_readmap_open(c->h, p.c_str(), &h), "Readmap");
     const uint64_t n = bg_readmap_size(h);
     entry_id.resize(n); read_len.resize(n); loop.resize(n); fwd.resize(n);
     if (n) check(bg_readmap_arrays(c->h, h, entry_id.data(), read_len.data(), loop.data(), fwd.data()), "bg_readmap_arrays");
+    has_loops = bg_readmap_has_mate_loop(h) != 0;
   }
   ~ReadmapObj() { if (h) bg_readmap_free(h); }
   uint64_t size() const { return entry_id.size(); }
@@ -200,12 +202,17 @@ Read read_by_id(const std::shared_ptr<ReadmapObj>& rm, int64_t id) {
   if (id < 0 || uint64_t(id) >= rm->size()) throw std::runtime_error("Read id out of range");
   return Read{rm, uint32_t(id)};
 }
-bool read_has_mate(const Read& r) { return r.rm->loop[r.rm->loop[r.id]] != r.id; }  // readmap.cpp:207-218
-Read read_mate(const Read& r) {                                                      // readmap.cpp:220-239
+bool read_has_mate(const Read& r) {  // readmap.cpp:207-218
+  if (!r.rm->has_loops) return r.rm->loop[r.id] != 0xffffffffu;
+  return r.rm->loop[r.rm->loop[r.id]] != r.id;
+}
+Read read_mate(const Read& r) {  // readmap.cpp:220-239
   if (!read_has_mate(r)) throw std::runtime_error("Read has no mate");
-  return Read{r.rm, r.rm->loop[r.rm->loop[r.id]]};
+  return Read{r.rm, r.rm->has_loops ? r.rm->loop[r.rm->loop[r.id]] : r.rm->loop[r.id]};
 }
 Read read_rev_comp(const Read& r) {  // readmap.cpp:248-268: one hop forward for a forward read, three for its reverse
+  if (!r.rm->has_loops)
+    throw std::runtime_error("Readmap has no mate loop table; use \"biograph upgrade\" to construct it");
   uint32_t x = r.id;
   for (int i = 0, n = r.rm->fwd[r.id] ? 1 : 3; i < n; ++i) x = r.rm->loop[x];
   return Read{r.rm, x};

@@ -509,6 +509,7 @@ extern "C" int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads
 
 extern "C" uint64_t bg_readmap_size(const bg_readmap* rm) { return rm ? rm->n_reads : 0; }
 extern "C" uint32_t bg_readmap_max_read_len(const bg_readmap* rm) { return rm ? rm->max_read_len : 0; }
+extern "C" int bg_readmap_has_mate_loop(const bg_readmap* rm) { return rm && !rm->pair_mode ? 1 : 0; }
 extern "C" void bg_readmap_free(bg_readmap* rm) { delete rm; }
 
 static unsigned rm_bits_for_value(uint64_t v) { unsigned b = 0; while (v) { ++b; v >>= 1; } return b; }
@@ -568,9 +569,15 @@ static std::string rm_version_json(const char* type, int maj, int min, int pat) 
 // Spiral container of the readmap (member order of make_readmap::create_common / create_from_reads,
 // as found in father_lambda.bg/coverage/*.readmap).  h_sha1_hex (41 bytes) receives the SHA-1 of the
 // written file: the reference names the file after it (biograph_create.cpp:827-828).
+static int rm_no_loops(const char* what) {
+  set_error("%s: readmap has no mate loop table; use \"biograph upgrade\" to construct it", what);  // readmap.cpp:249-253
+  return BG_EINVAL;
+}
+
 extern "C" int bg_readmap_write(bg_ctx* ctx, const bg_readmap* rm, const char* path, int argc,
                                 const char* const* argv, char* h_sha1_hex) {
   if (!ctx || !rm || !path) { set_error("bg_readmap_write: null argument"); return BG_EINVAL; }
+  if (rm->pair_mode) return rm_no_loops("bg_readmap_write");
   BG_HIP(hipSetDevice(ctx->device));
   std::vector<ZipPart> parts;
   time_t now = time(nullptr);
@@ -670,14 +677,18 @@ extern "C" int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out) 
   // format 1.1.0 (v3.x): read_lengths = raw uint8, mate_loop_ptr = 32-bit packed_vector; format 1.2.0: both
   // packed_varbit_vectors (readmap.cpp open path, int_map_interface.cpp detect_subpart_or_uint8_membuf)
   const bool legacy = parts.count("read_lengths") != 0;
-  if (legacy && !parts.count("mate_loop_ptr/packed_data")) {
-    set_error("%s: readmap has no mate loop table; use \"biograph upgrade\" to construct it", path);  // readmap.cpp:249-253
+  // older still: mates as a pair table instead of the loop table (readmap.cpp:48-51).  has_mate / get_mate answer from
+  // it (readmap.cpp:207-239); everything that follows loops (get_rev_comp, get_mate_rc, migrate, write) refuses
+  // such a readmap like the reference does (readmap.cpp:249-253).
+  const bool pair_mode = legacy && !parts.count("mate_loop_ptr/packed_data") && parts.count("mate_pair_ptr/packed_data");
+  if (legacy && !pair_mode && !parts.count("mate_loop_ptr/packed_data")) {
+    set_error("%s: readmap has no pairing data", path);
     return BG_EIO;
   }
   const std::string *s2m_js = need("read_ids/source_to_mid/bitcount.json"), *s2m = need("read_ids/source_to_mid/bits"),
                     *d2m_js = need("read_ids/dest_to_mid/bitcount.json"), *d2m = need("read_ids/dest_to_mid/bits"),
                     *rl = need(legacy ? "read_lengths" : "read_lengths/elements"),
-                    *ml = need(legacy ? "mate_loop_ptr/packed_data" : "mate_loop_ptr/elements"),
+                    *ml = need(pair_mode ? "mate_pair_ptr/packed_data" : legacy ? "mate_loop_ptr/packed_data" : "mate_loop_ptr/elements"),
                     *isf = need("is_forward/packed_data"), *rmj = need("readmap.json");
   if (!s2m_js || !s2m || !d2m_js || !d2m || !rl || !ml || !isf || !rmj) return BG_EIO;
   uint64_t n_ent = 0, n = 0, rl_bits = 8, ml_bits = 32, max_len = 0;
@@ -699,6 +710,7 @@ extern "C" int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out) 
   rm->n_reads = n;
   rm->n_entries = n_ent;
   rm->max_read_len = uint32_t(max_len);
+  rm->pair_mode = pair_mode;
   size_t p = rmj->find("\"seqset_uuid\":\"");
   if (p != std::string::npos) rm->seqset_uuid = rmj->substr(p + 15, rmj->find('"', p + 15) - (p + 15));
   std::vector<uint64_t> v_len, v_ptr, v_fwd, v_head, v_src;
@@ -718,7 +730,7 @@ extern "C" int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out) 
   uint64_t mid = 0;
   for (uint64_t i = 0; i < n; ++i) {
     if (v_head[i]) ++mid;
-    if (mid == 0 || mid > mid_to_entry.size() || v_ptr[i] >= n) { set_error("%s: inconsistent sparse_multi / mate loop table", path); return BG_EIO; }
+    if (mid == 0 || mid > mid_to_entry.size() || (v_ptr[i] >= n && !(pair_mode && v_ptr[i] == 0xffffffffull))) { set_error("%s: inconsistent sparse_multi / mate loop table", path); return BG_EIO; }
     v_entry[i] = mid_to_entry[mid - 1];
   }
   auto up64 = [&](DevBuf<uint64_t>& d, const void* src, uint64_t words) -> int {

@@ -737,6 +737,7 @@ extern "C" int bg_read_info_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_rea
                                   uint32_t* d_rev_comp, uint64_t* d_begin, uint64_t* d_end, uint32_t* d_size) {
   BG_TRY(check_ss(ctx, ss, "bg_read_info_batch"));
   BG_TRY(check_rm(ss, rm, "bg_read_info_batch"));
+  if (rm->pair_mode) { set_error("bg_read_info_batch: readmap has no mate loop table; use \"biograph upgrade\" to construct it"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));
   if (!n) return BG_OK;
   k_read_info<<<cdiv(n, 128), 128, 0, ctx->stream>>>(make_view(ss), make_rm_view(rm), n, d_read_ids, d_has_mate,
@@ -757,6 +758,7 @@ extern "C" int bg_propagate_from_end_batch(bg_ctx* ctx, const bg_seqset* ss, con
                                            uint32_t* d_mate_size) {
   BG_TRY(check_ss(ctx, ss, "bg_propagate_from_end_batch"));
   if (rm) BG_TRY(check_rm(ss, rm, "bg_propagate_from_end_batch"));
+  if (rm && rm->pair_mode) { set_error("bg_propagate_from_end_batch: readmap has no mate loop table; use \"biograph upgrade\" to construct it"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));
   if (!n_asm) return BG_OK;
   DevBuf<uint32_t> err;

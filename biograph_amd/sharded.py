@@ -275,6 +275,213 @@ def _relieve(ctxs, dev):
             c.trim()
 
 
+# suffix offsets at which a new round of cover candidates starts (the last round runs to the longest read):
+# most reads are covered within a few bases at 30x, so early rounds are narrow and few reads reach the late ones
+COVER_ROUNDS = "1,5,13,29,61,256"
+
+
+def _all_sum(comm, vals):
+    """Sum of one python int per local rank over all ranks."""
+    lst = comm.all_gather_obj(vals)[comm.local_ranks[0]]
+    return sum(int(x) for x in lst)
+
+
+def _skm_extract(ctx, reads_h, k, P, dev):
+    """Super-k-mer records of a reads object grouped by owner rank -> (recs [n,2], org [n], counts, windows).
+    The buffers are sized for 1.5x the expected record density (bg_skm_capacity is the 3x worst case, tried only
+    when an input beats that) and trimmed to what was produced: they live until the presence bits are back."""
+    L = capi.lib()
+    n = C.c_uint64()
+    capi.check(L.bg_kmer_instances(ctx.h, reads_h, k, C.byref(n)))
+    cap = C.c_uint64()
+    capi.check(L.bg_skm_capacity(ctx.h, reads_h, k, n.value, C.byref(cap)))
+    counts = (C.c_uint64 * P)()
+    nrec = C.c_uint64()
+    if not cap.value:
+        return (torch.empty((0, 2), dtype=torch.int64, device=dev), torch.empty((0,), dtype=torch.int64, device=dev),
+                [0] * P, n.value)
+    for room in (cap.value // 2 + 1024, cap.value):
+        room = min(room, cap.value)
+        recs = torch.empty((room, 2), dtype=torch.int64, device=dev)
+        org = torch.empty((room,), dtype=torch.int64, device=dev)
+        rc = L.bg_skm_extract_by_owner(ctx.h, reads_h, k, n.value, P, _ptr(recs), _ptr(org), room, counts, C.byref(nrec))
+        if rc == -3 and room < cap.value:  # BG_ENOMEM: more records than 1.5x the expected density
+            del recs, org
+            continue
+        capi.check(rc)
+        break
+    if nrec.value * 4 < room * 3:  # give the unused tail back (a view would keep the whole buffer alive)
+        recs, org = recs[:nrec.value].clone(), org[:nrec.value].clone()
+    else:
+        recs, org = recs[:nrec.value], org[:nrec.value]
+    return recs, org, [int(c) for c in counts], n.value
+
+
+def _correct_routed(comm, ctxs, reads, owned, skm_recs, skm_org, skm_bits, prm, dev, ph):
+    """Read correction with the kept k-mers left on their owner ranks: every rank searches
+    its own reads; the k-mers a search needs beyond the read's own windows travel as probe strings to their
+    owners and come back as presence bits, one exchange per step, until no read misses a look-up."""
+    L = capi.lib()
+    P = comm.world
+    ranks = comm.local_ranks
+    k = prm.kmer_size
+    corr = {}
+    for r in ranks:
+        h = C.c_void_p()
+        b = skm_bits[r].contiguous().view(-1)
+        capi.check(L.bg_corr_begin(ctxs[r].h, reads[r].h, k, C.byref(prm.correct), _ptr(skm_recs[r]), _ptr(skm_org[r]),
+                                   _ptr(b), b.shape[0], C.byref(h)))
+        corr[r] = h
+    steps = 0
+    while True:
+        ph.mark("correct_step")
+        probes, pend = {}, {}
+        for r in ranks:
+            npend = C.c_uint64()
+            pr = C.c_void_p()
+            capi.check(L.bg_corr_step(ctxs[r].h, corr[r], C.byref(npend), C.byref(pr)))
+            pend[r] = npend.value
+            probes[r] = pr
+        steps += 1
+        if _all_sum(comm, pend) == 0:
+            break
+        ph.mark("correct_probe_exchange")
+        send, porg = {}, {}
+        for r in ranks:
+            if probes[r]:
+                recs, org, counts, _ = _skm_extract(ctxs[r], probes[r], k, P, dev[r])
+                L.bg_reads_free(probes[r])
+            else:
+                recs = torch.empty((0, 2), dtype=torch.int64, device=dev[r])
+                org = torch.empty((0,), dtype=torch.int64, device=dev[r])
+                counts = [0] * P
+            send[r] = (recs, counts)
+            porg[r] = org
+        recv = comm.all_to_all_v(send)
+        sent_counts = comm.all_gather_obj({r: send[r][1] for r in ranks})[ranks[0]]
+        back = {}
+        for r in ranks:
+            rows = recv[r].contiguous()
+            bits = torch.empty((max(rows.shape[0], 1),), dtype=torch.int32, device=dev[r])
+            capi.check(L.bg_skm_lookup(ctxs[r].h, owned[r].h, _ptr(rows), rows.shape[0], _ptr(bits), 0))
+            back[r] = (bits[:rows.shape[0]].view(-1, 1), [int(sent_counts[s][r]) for s in range(P)])
+        ans = comm.all_to_all_v(back)
+        for r in ranks:
+            a = ans[r].contiguous().view(-1)
+            capi.check(L.bg_corr_answers(ctxs[r].h, corr[r], _ptr(porg[r]), _ptr(a), a.shape[0]))
+        del send, recv, back, ans, porg
+    corrected, cstats, nprobes = {}, {}, {}
+    import biograph_amd as bg
+    for r in ranks:
+        h = C.c_void_p()
+        st = capi.CorrectStats()
+        capi.check(L.bg_corr_finish(ctxs[r].h, corr[r], C.byref(h), C.byref(st)))
+        nprobes[r] = int(L.bg_corr_probes(corr[r]))
+        L.bg_corr_free(corr[r])
+        corrected[r] = bg.Reads(ctxs[r], h)
+        cstats[r] = {n: int(getattr(st, n)) for n, _ in st._fields_}
+    return corrected, cstats, steps, nprobes
+
+
+def _records_sharded_cover(comm, ctxs, corrected, W, k, dev, ph):
+    """Suffix records of a sharded build without a replicated cover index (csrc/shard_cover.hip): oriented reads
+    and candidate suffixes meet on the rank that owns their leading bases.  Returns ({r: record rows}, n_records)."""
+    L = capi.lib()
+    P = comm.world
+    ranks = comm.local_ranks
+    i64 = torch.int64
+    rw = W + 1
+    ph.mark("cover_oriented_rows")
+    rows, hists, qs = {}, {}, {}
+    for r in ranks:
+        n = len(corrected[r])
+        rows[r] = torch.empty((2 * n, rw), dtype=i64, device=dev[r])
+        capi.check(L.bg_oriented_rows(ctxs[r].h, corrected[r].h, W, _ptr(rows[r])))
+        corrected[r].free()
+        hists[r] = torch.empty((4 ** PREFIX_BASES,), dtype=i64, device=dev[r])
+        capi.check(L.bg_rows_prefix_hist(ctxs[r].h, _ptr(rows[r]), 2 * n, rw, PREFIX_BASES, PREFIX_SAMPLE, _ptr(hists[r])))
+        qh = C.c_void_p()
+        capi.check(L.bg_cover_query_begin(ctxs[r].h, _ptr(rows[r]), 2 * n, W, k, C.byref(qh)))
+        qs[r] = qh
+    gh = comm.all_reduce_sum(hists)[ranks[0]].cpu().numpy()
+    pparams = [PREFIX_BASES] + choose_splitters(gh, P)
+    ph.mark("cover_index_exchange")
+    send = {r: _partition(ctxs[r], rows[r], capi.PART_PREFIX, P, pparams) for r in ranks}
+    del rows, hists
+    recv = comm.all_to_all_v(send)
+    del send
+    _relieve(ctxs, dev)
+    ph.mark("cover_index_build")
+    covers, parts = {}, {}
+    for r in ranks:
+        t = recv[r].contiguous()
+        ch = C.c_void_p()
+        capi.check(L.bg_cover_build(ctxs[r].h, _ptr(t), t.shape[0], W, k, C.byref(ch)))
+        covers[r] = ch
+        parts[r] = [t]  # the oriented reads a rank indexes are its j = 0 records
+    del recv
+    bounds = [int(x) for x in os.environ.get("BG_COVER_ROUNDS", COVER_ROUNDS).split(",")]
+    if bounds[-1] < 256:
+        bounds.append(256)
+    for j_lo, j_hi in zip(bounds[:-1], bounds[1:]):
+        ph.mark("cover_round_%d" % j_lo)
+        pend = {r: int(L.bg_cover_query_pending(qs[r])) for r in ranks}
+        if _all_sum(comm, pend) == 0:
+            break
+        cand = {}
+        for r in ranks:
+            cap = pend[r] * (j_hi - j_lo)
+            t = torch.empty((max(cap, 1), rw), dtype=i64, device=dev[r])
+            n = C.c_uint64()
+            capi.check(L.bg_cover_query_candidates(ctxs[r].h, qs[r], j_lo, j_hi, _ptr(t), cap, C.byref(n)))
+            cand[r] = _partition(ctxs[r], t[:n.value], capi.PART_PREFIX, P, pparams)
+            del t
+        got = comm.all_to_all_v(cand)
+        sent_counts = comm.all_gather_obj({r: cand[r][1] for r in ranks})[ranks[0]]
+        back = {}
+        for r in ranks:
+            t = got[r].contiguous()
+            got[r] = t
+            cv = torch.empty((max(t.shape[0], 1),), dtype=torch.uint8, device=dev[r])
+            capi.check(L.bg_cover_test(ctxs[r].h, covers[r], _ptr(t), t.shape[0], _ptr(cv)))
+            back[r] = (cv[:t.shape[0]].view(-1, 1), [int(sent_counts[s][r]) for s in range(P)])
+        ans = comm.all_to_all_v(back)
+        keep_send = {}
+        for r in ranks:
+            a = ans[r].contiguous().view(-1)
+            sent = cand[r][0]
+            kp = torch.empty((max(sent.shape[0], 1),), dtype=torch.uint8, device=dev[r])
+            capi.check(L.bg_cover_query_answers(ctxs[r].h, qs[r], _ptr(sent), _ptr(a), sent.shape[0], _ptr(kp)))
+            keep_send[r] = (kp[:sent.shape[0]].view(-1, 1), cand[r][1])
+        keeps = comm.all_to_all_v(keep_send)
+        for r in ranks:
+            m = keeps[r].view(-1) != 0
+            parts[r].append(got[r][m])
+        del cand, got, back, ans, keep_send, keeps
+        _relieve(ctxs, dev)
+    ph.mark("cover_plain_tails")
+    pend = {r: int(L.bg_cover_query_pending(qs[r])) for r in ranks}
+    if _all_sum(comm, pend) and k > 1:
+        plain = {}
+        for r in ranks:
+            cap = pend[r] * (k - 1)
+            t = torch.empty((max(cap, 1), rw), dtype=i64, device=dev[r])
+            n = C.c_uint64()
+            capi.check(L.bg_cover_query_plain(ctxs[r].h, qs[r], _ptr(t), cap, C.byref(n)))
+            plain[r] = _partition(ctxs[r], t[:n.value], capi.PART_PREFIX, P, pparams)
+            del t
+        got = comm.all_to_all_v(plain)
+        for r in ranks:
+            parts[r].append(got[r])
+        del plain, got
+    for r in ranks:
+        L.bg_cover_query_free(qs[r])
+        L.bg_cover_free(covers[r])
+        parts[r] = [t.contiguous() for t in parts[r] if t.shape[0]]
+    n_records = _all_sum(comm, {r: sum(t.shape[0] for t in parts[r]) for r in ranks})
+    return parts, n_records  # a list of row arrays per rank: bg_records_from_row_parts takes them as they are
+
+
 class SeqsetSlice:
     """One rank's stretch of a sharded seqset: entries [first, first + size()) of n_total."""
 

@@ -251,6 +251,9 @@ int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads* corrected
                      bg_readmap** out);
 uint64_t bg_readmap_size(const bg_readmap* rm);         /* readmap::size(), number of read ids */
 uint32_t bg_readmap_max_read_len(const bg_readmap* rm); /* readmap::max_read_len() */
+/* 0 for a legacy readmap that stores mates as a pair table (readmap.cpp:48-51): bg_readmap_arrays then returns the pair
+ * pointer (0xffffffff = no mate) in place of the loop pointer, and whatever follows loops refuses the readmap. */
+int bg_readmap_has_mate_loop(const bg_readmap* rm);
 /* Raw bytes of one mmap part of the container, named as in the spiral file:
  * "read_ids/{source_to_mid,dest_to_mid}/{bits,subaccum,accum}", "read_lengths/elements",
  * "mate_loop_ptr/elements", "is_forward/packed_data".  Same size protocol as bg_seqset_part. */
