@@ -385,6 +385,8 @@ def main():
                     help="genome of the CPU baseline sample (default: E. coli-sized, 139 Mbases at 30x)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-discover", action="store_true", help="skip the overlap-walk (discover) leg")
+    ap.add_argument("--no-shared-arena", action="store_true",
+                    help="sharded runs: keep torch's own caching allocator beside the library's arena")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the sharded (RCCL) build path even with one rank (smoke test of the collectives)")
     args = ap.parse_args()
@@ -404,6 +406,10 @@ def main():
     import biograph_amd as bg
     from biograph_amd import synth
 
+    shared_arena = False
+    if (world > 1 or args.force_sharded) and not args.no_shared_arena:
+        # the exchange buffers (torch tensors) and the library's buffers come out of one arena per device
+        shared_arena = bg.use_shared_arena()
     if not torch.cuda.is_available():
         print("bench.py: no GPU (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(3)
@@ -475,7 +481,10 @@ def main():
     timings = ctx.timings()
     ctx.set_profiling(False)
     mem = ctx.memory()
-    mem["torch_peak"] = int(torch.cuda.max_memory_allocated(dev))
+    try:
+        mem["torch_peak"] = 0 if shared_arena else int(torch.cuda.max_memory_allocated(dev))
+    except Exception:
+        mem["torch_peak"] = 0
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -535,8 +544,10 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "device_memory": {"peak_live_GB": round(mem["peak"] / 1e9, 2), "cached_GB": round(mem["cached"] / 1e9, 2),
                               "torch_peak_GB": round(mem["torch_peak"] / 1e9, 2),
-                              "note": "rank 0; peak_live = the library's allocator, torch_peak = input reads + exchange "
-                                      "buffers (torch allocator); their sum bounds the rank's footprint"},
+                              "shared_arena": shared_arena,
+                              "note": "rank 0; shared_arena: torch allocates from the library's arena and peak_live is the "
+                                      "rank's whole footprint; else peak_live = the library's allocator, torch_peak = input "
+                                      "reads + exchange buffers, and their sum bounds the footprint"},
             "rccl_ranks": world if dist is not None else 0,
             "build_roofline": {"algorithmic_bytes_per_step": int(alg), "bytes_per_base": round(alg / max(stats["n_bases"], 1), 2),
                                "achieved_GBps": round(alg / step_s / 1e9, 1),

@@ -38,6 +38,21 @@ def _buf(a):
     return a, capi.np_ptr(a)
 
 
+def use_shared_arena():
+    """Makes torch allocate device memory from the library's arena (one per device, shared by every Context created
+    afterwards) instead of its own caching allocator: the multi-GPU driver's exchange buffers and the library's
+    buffers then never starve each other.  Must run before torch touches the GPU; returns False (and changes
+    nothing) when it is too late for that."""
+    import torch
+    try:
+        alloc = torch.cuda.memory.CUDAPluggableAllocator(capi.LIB_PATH, "bg_torch_malloc", "bg_torch_free")
+        torch.cuda.memory.change_current_allocator(alloc)
+    except Exception:
+        return False
+    capi.lib().bg_torch_allocator_enable()
+    return True
+
+
 class DeviceArray:
     """hipMalloc'ed buffer owned through the C ABI (for hosts without their own allocator)."""
 

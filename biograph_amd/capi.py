@@ -84,6 +84,7 @@ SYMBOLS = [
     "bg_corr_probes", "bg_corr_free",
     "bg_seqset_slice_masks", "bg_seqset_slice_build", "bg_seqset_slice_popcounts", "bg_seqset_sharded_create_file",
     "bg_seqset_slice_write", "bg_fastq_import", "bg_dev_upload_pinned",
+    "bg_torch_allocator_enable", "bg_torch_allocator_enabled", "bg_torch_malloc", "bg_torch_free",
     "bg_seqset_uuid", "bg_readmap_has_mate_loop", "bg_seqset_tail_rows2", "bg_seqset_apply_tails2", "bg_seqset_tail_rows_full", "bg_records_from_row_parts",
 ]
 

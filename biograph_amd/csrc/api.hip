@@ -191,7 +191,8 @@ extern "C" int bg_ctx_create(int device, void* stream, bg_ctx** out) {
       if (hipMemGetInfo(&fr, &total) == hipSuccess) cap = size_t(double(total) * 0.35);
       else (void)hipGetLastError();
     }
-    c->arena.set_cap(cap);
+    if (bg_ctx::DeviceArena* sh = shared_arena(device)) c->arena = sh;  // one arena with torch: nothing to cap
+    else c->own_arena.set_cap(cap);
   }
   *out = c;
   return BG_OK;
@@ -210,10 +211,11 @@ extern "C" int bg_ctx_trim(bg_ctx* ctx) { return ctx ? ctx->trim() : BG_EINVAL; 
 
 extern "C" int bg_ctx_memory(bg_ctx* ctx, uint64_t* live, uint64_t* cached, uint64_t* peak, int reset_peak) {
   if (!ctx) return BG_EINVAL;
-  if (live) *live = ctx->arena.live();
-  if (cached) *cached = ctx->arena.cached();
-  if (peak) *peak = ctx->arena.peak();
-  if (reset_peak) ctx->arena.reset_peak();
+  std::lock_guard<std::mutex> lock(g_arena_mutex);
+  if (live) *live = ctx->arena->live();
+  if (cached) *cached = ctx->arena->cached();
+  if (peak) *peak = ctx->arena->peak();
+  if (reset_peak) ctx->arena->reset_peak();
   return BG_OK;
 }
 
@@ -261,7 +263,12 @@ extern "C" int bg_dev_free(bg_ctx* ctx, void* p) {
   if (!ctx) return BG_EINVAL;
   if (!p) return BG_OK;
   BG_HIP(hipSetDevice(ctx->device));
-  if (!ctx->arena.release(p)) { set_error("bg_dev_free: %p was not allocated by this context", p); return BG_EINVAL; }
+  bool ok;
+  {
+    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    ok = ctx->arena->release(p);
+  }
+  if (!ok) { set_error("bg_dev_free: %p was not allocated by this context", p); return BG_EINVAL; }
   return BG_OK;
 }
 extern "C" int bg_dev_upload(bg_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes) {

@@ -11,6 +11,8 @@
 #include <vector>
 
 #include "../../include/bgseq.h"
+#include <mutex>
+
 #include "arena.h"
 #include "bg_device_funcs.h"
 
@@ -49,7 +51,9 @@ struct bg_ctx {
     void* seg_alloc(size_t n);
     void seg_free(void* p);
   };
-  bg::Arena<HipSegments> arena;
+  using DeviceArena = bg::Arena<HipSegments>;
+  DeviceArena own_arena;
+  DeviceArena* arena = &own_arena;  // the process-wide arena of the device when torch shares it (bg_torch_malloc)
   std::vector<bg::TimingRec> recs;
   std::vector<hipEvent_t> event_pool;
 
@@ -199,6 +203,10 @@ struct bg_readmap {
 };
 
 namespace bg {
+// prims.hip: one arena per device shared by torch's allocator hook and every context created after the hook was
+// installed (bg_torch_allocator_enable); g_arena_mutex guards every arena call in that mode
+extern std::mutex g_arena_mutex;
+bg_ctx::DeviceArena* shared_arena(int device);  // null unless the hook is installed
 // build_seqset.hip
 struct CoverStore {  // device buffers behind a CoverIndex (bg_device_funcs.h)
   DevBuf<uint64_t> skeys, slots, vv;

@@ -58,11 +58,15 @@ void* bg_ctx::HipSegments::seg_alloc(size_t n) {
 void bg_ctx::HipSegments::seg_free(void* p) { (void)hipFree(p); }  // waits for the device
 
 int bg_ctx::alloc(size_t bytes, void** out) {
-  void* p = arena.alloc(bytes);
+  void* p;
+  {
+    std::lock_guard<std::mutex> lock(bg::g_arena_mutex);
+    p = arena->alloc(bytes);
+  }
   if (!p) {
     (void)hipStreamSynchronize(stream);
-    bg::set_error("device allocation of %zu bytes failed (live %zu MiB, held %zu MiB)", bytes, arena.live() >> 20,
-                  arena.reserved() >> 20);
+    bg::set_error("device allocation of %zu bytes failed (live %zu MiB, held %zu MiB)", bytes, arena->live() >> 20,
+                  arena->reserved() >> 20);
     return BG_ENOMEM;
   }
   *out = p;
@@ -72,12 +76,60 @@ int bg_ctx::alloc(size_t bytes, void** out) {
 // The chunk goes back to the arena at once: everything a context does is ordered on its one stream, so whoever gets
 // the chunk next is ordered after the work that used it; a wholly free segment may go back to the driver
 // (hipFree waits for the device).
-void bg_ctx::release(void* p) { (void)arena.release(p); }
+void bg_ctx::release(void* p) {
+  std::lock_guard<std::mutex> lock(bg::g_arena_mutex);
+  (void)arena->release(p);
+}
 
 int bg_ctx::trim() {
   (void)hipStreamSynchronize(stream);
-  arena.trim();
+  std::lock_guard<std::mutex> lock(bg::g_arena_mutex);
+  arena->trim();
   return BG_OK;
+}
+
+// ---- torch's allocator hook (torch.cuda.memory.CUDAPluggableAllocator): the exchange buffers of the multi-GPU
+// driver and the library's own buffers come out of ONE arena per device, so that neither allocator sits on memory the
+// other needs (with two, each keeps its cache until one of its own requests fails, and the driver maps memory at
+// ~30 us per MiB: a build of 11.6 Gbases per rank spent seconds re-acquiring what the other side had just let go).
+// Everything is ordered on one stream per process here (torch's current stream = the context's stream; torch waits
+// for a collective before the call returns), so a freed chunk may be handed out again at once.
+namespace bg {
+std::mutex g_arena_mutex;
+static bg_ctx::DeviceArena* g_shared[16] = {};
+static bool g_share = false;
+bg_ctx::DeviceArena* shared_arena(int device) {
+  if (!g_share || device < 0 || device >= 16) return nullptr;
+  std::lock_guard<std::mutex> lock(g_arena_mutex);
+  if (!g_shared[device]) g_shared[device] = new bg_ctx::DeviceArena();  // lives as long as the process
+  return g_shared[device];
+}
+}  // namespace bg
+
+extern "C" void bg_torch_allocator_enable(void) { bg::g_share = true; }
+extern "C" int bg_torch_allocator_enabled(void) { return bg::g_share ? 1 : 0; }
+
+extern "C" void* bg_torch_malloc(ssize_t size, int device, void*) {
+  bg::g_share = true;
+  bg_ctx::DeviceArena* a = bg::shared_arena(device);
+  if (!a) return nullptr;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (cur != device) (void)hipSetDevice(device);
+  void* p;
+  {
+    std::lock_guard<std::mutex> lock(bg::g_arena_mutex);
+    p = a->alloc(size > 0 ? size_t(size) : 1);
+  }
+  if (cur != device) (void)hipSetDevice(cur);
+  return p;  // null: torch raises its out-of-memory error
+}
+
+extern "C" void bg_torch_free(void* ptr, ssize_t, int device, void*) {
+  bg_ctx::DeviceArena* a = bg::shared_arena(device);
+  if (!a || !ptr) return;
+  std::lock_guard<std::mutex> lock(bg::g_arena_mutex);
+  (void)a->release(ptr);
 }
 
 hipEvent_t bg_ctx::get_event() {

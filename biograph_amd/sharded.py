@@ -235,10 +235,12 @@ class _Phases:
         self.ctx = ctx
 
     def _mem(self):
-        tp = torch.cuda.max_memory_allocated() / 1e9 if torch.cuda.is_available() else 0.0
-        lp = self.ctx.memory()["peak"] / 1e9 if self.ctx is not None else 0.0
-        if torch.cuda.is_available():
+        try:  # (a pluggable allocator keeps no statistics: the library's figure is then the whole footprint)
+            tp = torch.cuda.max_memory_allocated() / 1e9 if torch.cuda.is_available() else 0.0
             torch.cuda.reset_peak_memory_stats()
+        except Exception:
+            tp = 0.0
+        lp = self.ctx.memory()["peak"] / 1e9 if self.ctx is not None else 0.0
         if self.ctx is not None:
             self.ctx.memory(reset_peak=True)
         return tp, lp
@@ -269,6 +271,8 @@ def _relieve(ctxs, dev):
     own requests fails; what is left to do here is to return the library's wholly free segments when the device is
     nearly full, so that torch's next large buffer finds room.  (Emptying torch's cache as a routine cost seconds per
     build: the driver maps memory at ~30 us per MiB, and the next phase asked for all of it again.)"""
+    if capi.lib().bg_torch_allocator_enabled():
+        return  # one arena for both: nothing is stranded
     for r, c in ctxs.items():
         free, total = torch.cuda.mem_get_info(dev[r])
         if free < 0.08 * total:

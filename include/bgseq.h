@@ -20,6 +20,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <sys/types.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -561,6 +562,15 @@ int bg_cover_query_answers(bg_ctx* ctx, bg_cover_query* q, const uint64_t* d_row
                            uint64_t n, uint8_t* d_keep_out);
 int bg_cover_query_plain(bg_ctx* ctx, bg_cover_query* q, uint64_t* d_rows, uint64_t cap, uint64_t* n_out);
 void bg_cover_query_free(bg_cover_query* q);
+
+/* ---- One device arena for the library AND torch (optional; biograph_amd.use_shared_arena()).  bg_torch_malloc /
+ * bg_torch_free have the signature torch.cuda.memory.CUDAPluggableAllocator expects; once torch allocates through
+ * them (or after bg_torch_allocator_enable), every context created afterwards takes its memory from the same
+ * per-device arena, and bg_ctx_memory reports that arena (library and torch together). */
+void bg_torch_allocator_enable(void);
+int bg_torch_allocator_enabled(void);
+void* bg_torch_malloc(ssize_t size, int device, void* stream);
+void bg_torch_free(void* ptr, ssize_t size, int device, void* stream);
 
 /* ---- device memory helpers for hosts without their own allocator (CLI, ctypes tests). */
 int bg_dev_alloc(bg_ctx* ctx, uint64_t bytes, void** d_out);
