@@ -305,6 +305,64 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
             "push_to_pair_extension": ext, "graph_discover_driver": drv}
 
 
+def end_to_end_leg(seq, n_reads, read_len, dev, args):
+    """`bgbinary create` from FASTQ FILES ("report both"): the reads of the bench sample written
+    as two mate files, then the CLI as a user runs it — files mapped, their bytes moved to the GPU through pinned
+    staging buffers, records parsed and paired on the GPU (csrc/fastq.hip), build, seqset + readmap written.
+    Reported: the CLI's own stage timers (qc/create_stats.json) and the wall time of the whole process."""
+    import shutil
+    import subprocess
+    import tempfile
+    import torch
+    if n_reads % 2 or int(seq.numel()) != n_reads * read_len:
+        return None
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 6 * n_reads * read_len else None
+    tmp = tempfile.mkdtemp(prefix="bg_e2e_", dir=base)
+    try:
+        n = n_reads // 2
+        rec = 1 + 12 + 1 + read_len + 3 + read_len + 1
+        reads = seq.view(n_reads, read_len)
+        paths = []
+        for mate in (0, 1):
+            t = torch.empty((n, rec), dtype=torch.uint8, device=dev)
+            t[:, 0] = 64  # '@'
+            ids = torch.arange(n, device=dev, dtype=torch.int64)
+            for d in range(12):
+                t[:, 1 + d] = ((ids // (10 ** (11 - d))) % 10 + 48).to(torch.uint8)
+            t[:, 13] = 10
+            t[:, 14:14 + read_len] = reads[mate::2]
+            t[:, 14 + read_len] = 10
+            t[:, 15 + read_len] = 43  # '+'
+            t[:, 16 + read_len] = 10
+            t[:, 17 + read_len:17 + 2 * read_len] = 73  # 'I'
+            t[:, 17 + 2 * read_len] = 10
+            p = os.path.join(tmp, "reads_%d.fq" % (mate + 1))
+            t.cpu().numpy().tofile(p)
+            del t
+            paths.append(p)
+        fastq_bytes = sum(os.path.getsize(p) for p in paths)
+        exe = os.path.join(ROOT, "biograph_amd", "bgbinary")
+        out = os.path.join(tmp, "sample.bg")
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "create", "--reads", paths[0], "--pair", paths[1], "--out", out], capture_output=True, text=True)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": r.stderr[-500:]}
+        st = json.load(open(os.path.join(out, "qc", "create_stats.json")))
+        tm = {k: v for d in st["timings"] for k, v in d.items()}
+        bases = st["imported_bases"]
+        return {"command": "bgbinary create --reads R1.fq --pair R2.fq --out S.bg", "fastq_bytes": fastq_bytes,
+                "files_on": "tmpfs" if base else "disk", "imported_reads": st["imported_reads"], "seqset_entries": st["seqset_entries"],
+                "seconds": {"import_files_to_gpu_and_parse": tm["import"], "gpu_build_incl_readmap": tm["gpu_build"],
+                            "write_seqset_and_readmap": tm["write"], "cli_total": tm["total"], "process_wall": round(wall, 3)},
+                "gbases_per_s_import_plus_build": round(bases / (tm["import"] + tm["gpu_build"]) / 1e9, 3),
+                "gbases_per_s_process_wall": round(bases / wall / 1e9, 3),
+                "note": "cold process: includes HIP start-up and first-touch hipMalloc (30 us/MiB), which a warm "
+                        "bench step does not pay"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 KERNEL_OF_FAMILY = {"radix_scatter_k": "rs_part_scatter_kernel",
                     "radix_scatter_kv": "rs_scatter_kernel<unsigned int, true>", "radix_hist": "rs_hist_kernel",
                     "correct_screen": "k_correct_screen", "entries_dedup_build": "k_gather_dedup_build",
@@ -385,6 +443,7 @@ def main():
                     help="genome of the CPU baseline sample (default: E. coli-sized, 139 Mbases at 30x)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-discover", action="store_true", help="skip the overlap-walk (discover) leg")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the `bgbinary create` from FASTQ files leg")
     ap.add_argument("--no-shared-arena", action="store_true",
                     help="sharded runs: keep torch's own caching allocator beside the library's arena")
     ap.add_argument("--force-sharded", action="store_true",
@@ -495,6 +554,9 @@ def main():
     else:
         total_bases = float(n_bases)
 
+    e2e = None
+    if world == 1 and not args.force_sharded and not args.no_end_to_end:
+        e2e = end_to_end_leg(seq, n_reads, args.read_len, dev, args)
     discover = None
     if world == 1 and not args.no_discover:
         discover = discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args)
@@ -553,7 +615,7 @@ def main():
                                "achieved_GBps": round(alg / step_s / 1e9, 1),
                                "frac_of_hbm_peak": round(alg / step_s / 1e9 / (HBM_PEAK_GBS * world), 5),
                                "kernel_time_frac_of_wall": round(total_ms / 1e3 / elapsed, 3)},
-            "discover": discover, "counters": stats, "kernels": kernels,
+            "end_to_end_from_fastq": e2e, "discover": discover, "counters": stats, "kernels": kernels,
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     ctx.close()
