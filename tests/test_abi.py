@@ -48,3 +48,17 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "bgoracle" not in text, f
+
+
+def test_build_files_list_the_same_sources():
+    """CMakeLists.txt and BUILD.bazel name exactly the translation units biograph_amd/build.py compiles."""
+    import re
+    from biograph_amd import build as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = sorted(B.SOURCES)
+    cm = open(os.path.join(root, "CMakeLists.txt")).read()
+    got = sorted(re.search(r"set\(BGSEQ_SOURCES ([^)]*)\)", cm).group(1).split())
+    assert got == want
+    bz = open(os.path.join(root, "BUILD.bazel")).read()
+    blk = bz[bz.index("for f in ["):bz.index("BGSEQ_HDRS")]
+    assert sorted(re.findall(r'"([\w]+\.(?:hip|cpp))"', blk)) == want
