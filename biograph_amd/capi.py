@@ -85,7 +85,7 @@ SYMBOLS = [
     "bg_seqset_slice_masks", "bg_seqset_slice_build", "bg_seqset_slice_popcounts", "bg_seqset_sharded_create_file",
     "bg_seqset_slice_write", "bg_fastq_import", "bg_dev_upload_pinned",
     "bg_torch_allocator_enable", "bg_torch_allocator_enabled", "bg_torch_malloc", "bg_torch_free",
-    "bg_seqset_uuid", "bg_readmap_has_mate_loop", "bg_seqset_tail_rows2", "bg_seqset_apply_tails2", "bg_seqset_tail_rows_full", "bg_records_from_row_parts",
+    "bg_rows_select", "bg_seqset_uuid", "bg_readmap_has_mate_loop", "bg_seqset_tail_rows2", "bg_seqset_apply_tails2", "bg_seqset_tail_rows_full", "bg_records_from_row_parts",
 ]
 
 PART_KMER_HASH, PART_PREFIX, PART_KEY_BOUNDS, PART_ROW_DEST = 0, 1, 2, 3
@@ -243,6 +243,7 @@ def lib():
     L.bg_seqset_sharded_create_file.argtypes = [C.c_char_p, u64, u32, P(u64), i32, P(C.c_char_p), P(u64)]
     L.bg_seqset_slice_write.argtypes = [vp, vp, C.c_char_p, P(u64), u64, i32, P(u64)]
     L.bg_readmap_has_mate_loop.argtypes = [vp]
+    L.bg_rows_select.argtypes = [vp, vp, u64, i32, vp, vp, u64, P(u64)]
     L.bg_seqset_uuid.argtypes = [vp, C.c_char_p, u64]
     L.bg_seqset_tail_rows2.argtypes = [vp, vp, u32, vp, vp]
     L.bg_seqset_apply_tails2.argtypes = [vp, vp, vp, u64, vp]

@@ -731,7 +731,7 @@ static int create_impl(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs
   if (rc == BG_OK) {
     st.n_reads = n_reads;
     st.n_bases = reads->total_bases;
-    rc = bg_kmer_count(ctx, reads, p->kmer_size, p->min_kmer_count, &ks);
+    rc = kmer_count_impl(ctx, reads, p->kmer_size, p->min_kmer_count, false, &ks);  // nobody reads the start flags here
   }
   bg_correct_stats cs;
   memset(&cs, 0, sizeof cs);

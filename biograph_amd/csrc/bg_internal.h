@@ -230,6 +230,7 @@ int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss);
 int apply_tails_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint32_t* d_err);
 int apply_tails2_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint8_t* d_need_full, uint32_t* d_err);
 int kmerset_sort(bg_ctx* ctx, bg_kmerset* ks);
+int kmer_count_impl(bg_ctx* ctx, const bg_reads* reads, int k, uint32_t min_count, bool with_flags, bg_kmerset** out);
 int read_locus_order(bg_ctx* ctx, const bg_reads* reads, uint64_t first, uint64_t count, DevBuf<uint32_t>* perm);
 // spiral_zip.cpp
 struct ZipPart { std::string name; std::string data; bool raw_crc0; uint64_t hole_size = 0; };

@@ -954,6 +954,12 @@ int kmer_hash_build_impl(bg_ctx* ctx, bg_kmerset* ks, const bg_reads* reads) {
 }  // namespace bg
 
 extern "C" int bg_kmer_count(bg_ctx* ctx, const bg_reads* reads, int k, uint32_t min_count, bg_kmerset** out) {
+  return bg::kmer_count_impl(ctx, reads, k, min_count, true, out);
+}
+
+// with_flags = false: the fwd/rev_starts_read flags (kmer_set.h:20-21) are not set — the whole-create path never
+// reads them (the entry set does not depend on them), only bg_kmerset_download reports them
+int bg::kmer_count_impl(bg_ctx* ctx, const bg_reads* reads, int k, uint32_t min_count, bool with_flags, bg_kmerset** out) {
   if (!ctx || !reads || !out) { set_error("bg_kmer_count: null argument"); return BG_EINVAL; }
   if (k < 1 || k > 31) { set_error("bg_kmer_count: kmer size %d outside 1..31", k); return BG_EINVAL; }
   if (min_count < 1) min_count = 1;
@@ -987,7 +993,7 @@ extern "C" int bg_kmer_count(bg_ctx* ctx, const bg_reads* reads, int k, uint32_t
       BG_TRY(kmer_count_keys_impl(ctx, ka.p, kb.p, N, min_count, ks.get(), true));
     }
   }
-  BG_TRY(kmer_hash_build_impl(ctx, ks.get(), reads));
+  BG_TRY(kmer_hash_build_impl(ctx, ks.get(), with_flags ? reads : nullptr));
   BG_TRY(kmer_skm_finish_present(ctx, ks.get()));
   *out = ks.release();
   return BG_OK;

@@ -389,6 +389,39 @@ extern "C" int bg_partition_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n
   return BG_OK;
 }
 
+// rows[i] for the ascending positions i in pick: lane = word, so reads and writes are contiguous runs
+__global__ void k_select_rows(const uint64_t* __restrict__ rows, const uint32_t* __restrict__ pick, uint64_t m, int row_words,
+                              uint64_t* __restrict__ out) {
+  const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= m * uint64_t(row_words)) return;
+  const uint64_t i = g / uint64_t(row_words);
+  const int w = int(g - i * uint64_t(row_words));
+  out[g] = rows[uint64_t(pick[i]) * row_words + w];
+}
+
+// The rows whose flag byte is non-zero, in order, into d_out (room for cap rows): stream compaction of rows.
+extern "C" int bg_rows_select(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int row_words, const uint8_t* d_flags,
+                              uint64_t* d_out, uint64_t cap, uint64_t* n_out) {
+  if (!ctx || !n_out || (n && (!d_rows || !d_flags))) { set_error("bg_rows_select: null argument"); return BG_EINVAL; }
+  if (n >= (1ull << 32) || row_words < 1) { set_error("bg_rows_select: bad geometry"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  *n_out = 0;
+  if (!n) return BG_OK;
+  DevBuf<uint32_t> pick;
+  uint64_t m = 0;
+  BG_TRY(compact_flagged<uint32_t>(ctx, d_flags, n, &pick, &m));
+  if (m > cap || (m && !d_out)) { set_error("bg_rows_select: room for %llu rows, %llu selected", (unsigned long long)cap, (unsigned long long)m); return BG_EINVAL; }
+  if (m) {
+    ctx->tic("rows_select");
+    k_select_rows<<<cdiv(m * uint64_t(row_words), 256), 256, 0, ctx->stream>>>(d_rows, pick.p, m, row_words, d_out);
+    BG_LAUNCH_CHECK();
+    ctx->toc(m * uint64_t(row_words) * 16 + n);
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  *n_out = m;
+  return BG_OK;
+}
+
 // ---- reads export / import ----------------------------------------------------------------------
 
 extern "C" int bg_reads_words(const bg_reads* r) { return r ? r->W : 0; }

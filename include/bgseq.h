@@ -406,6 +406,10 @@ int bg_reference_bases(const bg_reference* ref, uint64_t flat_pos, uint64_t n, c
 int bg_partition_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int row_words, int mode,
                       uint32_t nparts, const uint64_t* h_params, uint64_t* d_out_rows, uint64_t* h_counts);
 
+/* The rows whose flag byte is non-zero, in order, into d_out (room for cap rows; *n_out = how many). */
+int bg_rows_select(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int row_words, const uint8_t* d_flags, uint64_t* d_out,
+                   uint64_t cap, uint64_t* n_out);
+
 /* k-mer phases of bg_kmer_count(): windows -> keys; keys (after the exchange) -> kept k-mers of this
  * shard's hash range; all kept k-mers (after the all-gather) -> hash set. */
 int bg_kmer_instances(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t* n_out);

@@ -17,7 +17,9 @@ WORKER = textwrap.dedent("""
     # all_to_all_v with uneven splits: rank r sends (r+1) rows to rank 0 and 2*(r+1) rows to rank 1
     counts = [r + 1, 2 * (r + 1)]
     rows = torch.arange(sum(counts) * 3, dtype=torch.int64).reshape(-1, 3) + 1000 * r
-    out = comm.all_to_all_v({r: (rows, counts)})[r]
+    out, cm = comm.all_to_all_v({r: (rows, counts)})
+    out = out[r]
+    assert cm == [[1, 2], [2, 4]], cm   # cm[source][destination], the same on every rank
     exp = []
     for src in range(P):
         c = [src + 1, 2 * (src + 1)]
@@ -28,13 +30,21 @@ WORKER = textwrap.dedent("""
     # multi-round exchange (pieces capped): the same rows in the same order (source-major, sent order) - the
     # presence bits of the k-mer exchange are matched to their records by position
     comm.MAX_PIECE_BYTES = 24  # one 3-word row per piece and round
-    out2 = comm.all_to_all_v({r: (rows, counts)})[r]
+    out2 = comm.all_to_all_v({r: (rows, counts)})[0][r]
     assert torch.equal(out2, torch.cat(exp)), (r, out2)
+    # the way back: one byte per received row (its first word modulo 251) returns to the sender in sent order, with no
+    # exchange of counts; and a second exchange in the forward direction with the same counts
+    back = (out2[:, 0] %% 251).to(torch.uint8).view(-1, 1)
+    got = comm.all_to_all_reply({r: back}, cm)[r]
+    assert torch.equal(got.view(-1), (rows[:, 0] %% 251).to(torch.uint8)), (r, got)
+    again = comm.all_to_all_again({r: (rows[:, :1] * 2).contiguous()}, cm)[r]
+    assert torch.equal(again.view(-1), torch.cat(exp)[:, 0] * 2), (r, again)
+    assert comm.gather_ints({r: [r, 10 * r + 1]}) == [[0, 1], [1, 11]]
     # pieces of different lengths, some empty: rank 0 sends nothing to itself and 5 rows to rank 1, rank 1 sends
     # 3 rows to rank 0 and nothing to itself -> 5 rounds, most of them with empty pieces
     c2 = [0, 5] if r == 0 else [3, 0]
     rows2 = torch.arange(sum(c2) * 3, dtype=torch.int64).reshape(-1, 3) + 500 * (r + 1)
-    out3 = comm.all_to_all_v({r: (rows2, c2)})[r]
+    out3 = comm.all_to_all_v({r: (rows2, c2)})[0][r]
     if r == 0:
         want3 = torch.arange(9, dtype=torch.int64).reshape(-1, 3) + 1000
     else:
