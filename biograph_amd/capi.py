@@ -78,7 +78,7 @@ SYMBOLS = [
     "bg_entries_from_records", "bg_seqset_words", "bg_seqset_boundary_rows", "bg_seqset_fix_boundary",
     "bg_seqset_tail_rows", "bg_seqset_apply_tails", "bg_seqset_slice_export", "bg_seqset_assemble",
     "bg_oriented_rows", "bg_rows_prefix_hist", "bg_cover_build", "bg_cover_test", "bg_cover_free",
-    "bg_cover_query_begin", "bg_cover_query_pending", "bg_cover_query_candidates", "bg_cover_query_answers",
+    "bg_cover_query_begin", "bg_cover_query_pending", "bg_cover_query_candidates", "bg_cover_query_candidates_split", "bg_cover_query_answers",
     "bg_cover_query_plain", "bg_cover_query_free",
     "bg_kmerset_build_hash", "bg_skm_lookup", "bg_corr_begin", "bg_corr_step", "bg_corr_answers", "bg_corr_finish",
     "bg_corr_probes", "bg_corr_free",
@@ -261,6 +261,7 @@ def lib():
     L.bg_cover_query_pending.argtypes = [vp]
     L.bg_cover_query_pending.restype = u64
     L.bg_cover_query_candidates.argtypes = [vp, vp, i32, i32, vp, u64, P(u64)]
+    L.bg_cover_query_candidates_split.argtypes = [vp, vp, i32, i32, u32, vp, vp, u64, vp, P(u64)]
     L.bg_cover_query_answers.argtypes = [vp, vp, vp, vp, u64, vp]
     L.bg_cover_query_plain.argtypes = [vp, vp, vp, u64, P(u64)]
     L.bg_cover_query_free.argtypes = [vp]

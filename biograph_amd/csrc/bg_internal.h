@@ -203,17 +203,39 @@ struct bg_readmap {
 };
 
 namespace bg {
-// prims.hip: one arena per device shared by torch's allocator hook and every context created after the hook was
-// installed (bg_torch_allocator_enable); g_arena_mutex guards every arena call in that mode
-extern std::mutex g_arena_mutex;
-bg_ctx::DeviceArena* shared_arena(int device);  // null unless the hook is installed
-// build_seqset.hip
 struct CoverStore {  // device buffers behind a CoverIndex (bg_device_funcs.h)
   DevBuf<uint64_t> skeys, slots, vv;
   DevBuf<uint32_t> soid;
   CoverIndex ci;
   const uint64_t* owords = nullptr;
 };
+}  // namespace bg
+
+struct bg_cover {
+  bg_ctx* ctx = nullptr;
+  uint64_t n = 0;
+  int W = 0, K = 0;
+  bg::DevBuf<uint64_t> owords;
+  bg::DevBuf<uint8_t> olen;
+  bg::CoverStore cs;
+};
+
+struct bg_cover_query {
+  bg_ctx* ctx = nullptr;
+  uint64_t n = 0, n_pending = 0;
+  int W = 0, K = 0;
+  int j_lo = 0, span = 0;  // the round in flight
+  bg::DevBuf<uint64_t> owords;
+  bg::DevBuf<uint8_t> olen;
+  bg::DevBuf<uint32_t> pending;
+};
+
+namespace bg {
+// prims.hip: one arena per device shared by torch's allocator hook and every context created after the hook was
+// installed (bg_torch_allocator_enable); g_arena_mutex guards every arena call in that mode
+extern std::mutex g_arena_mutex;
+bg_ctx::DeviceArena* shared_arena(int device);  // null unless the hook is installed
+// build_seqset.hip
 int cover_index_build(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, uint64_t n_o, int W, int cover_k,
                       DevBuf<uint64_t>* k0o, CoverStore* cs);
 int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss, bool slice = false);  // bitcount finalize + min index + fixed

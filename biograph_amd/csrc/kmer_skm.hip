@@ -1066,9 +1066,12 @@ extern "C" int bg_kmerset_attach_presence(bg_ctx* ctx, bg_kmerset* ks, const bg_
 namespace bg {
 
 // bits_out[i] bit t = window t of record i is in the set (the owner's answer to a probe record; with
-// only_unknown, just the records its counting table gave up on — bits_out[i] & kSkUnknown — are looked up)
+// only_unknown, just the records its counting table gave up on — bits_out[i] & kSkUnknown — are looked up).
+// stop_at_absent: the windows of a PROBE are consumed in order and the search stops at the first absent one
+// (fast_read_correct.cpp:24-38), so nothing past it is ever asked for: three of the four alternatives of a probe
+// end at their first window, and looking the other ~29 up was most of this kernel's time.
 __global__ void sk_lookup_bits_kernel(const SkRec* __restrict__ recs, uint64_t n_rec, int k, const uint64_t* __restrict__ slots,
-                                      int log2cap, uint32_t* __restrict__ bits_out, int only_unknown) {
+                                      int log2cap, uint32_t* __restrict__ bits_out, int only_unknown, int stop_at_absent) {
   const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n_rec) return;
   if (only_unknown && !(bits_out[i] & kSkUnknown)) return;
@@ -1081,6 +1084,7 @@ __global__ void sk_lookup_bits_kernel(const SkRec* __restrict__ recs, uint64_t n
   uint32_t bits = 0;
   for (int t = 0; t < n; ++t) {
     if (tab.find(rc < fwd ? rc : fwd) >= 0) bits |= 1u << t;
+    else if (stop_at_absent) break;
     const int idx = k + t;
     const uint64_t base = idx < 32 ? (r.a >> (62 - 2 * idx)) & 3 : (r.b >> (62 - 2 * (idx - 32))) & 3;
     fwd = ((fwd << 2) | base) & kmask;
@@ -1176,7 +1180,7 @@ extern "C" int bg_skm_lookup(bg_ctx* ctx, const bg_kmerset* ks, const uint64_t* 
   if (n) {
     ctx->tic("kmer_probe_lookup");
     sk_lookup_bits_kernel<<<cdiv(n, 256), 256, 0, ctx->stream>>>(reinterpret_cast<const SkRec*>(d_recs), n, ks->k, ks->slots.p,
-                                                               ks->log2cap, d_bits, only_unknown);
+                                                               ks->log2cap, d_bits, only_unknown & 1, (only_unknown >> 1) & 1);
     BG_LAUNCH_CHECK();
     ctx->toc(n * 20);
   }

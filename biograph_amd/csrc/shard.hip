@@ -142,8 +142,28 @@ __global__ __launch_bounds__(256) void k_msplit_count(const uint64_t* __restrict
   if (threadIdx.x < nparts) counts[uint64_t(threadIdx.x) * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void k_msplit_scatter(const uint64_t* __restrict__ rows,
-                                                        const uint64_t* __restrict__ dest, uint64_t n, int row_words,
+// where the rows of a split come from: an array, or the candidate suffixes of a cover round generated on the fly
+struct RowsSource {
+  const uint64_t* rows;
+  int row_words;
+  __device__ __forceinline__ uint64_t word(uint64_t i, int w) const { return rows[i * uint64_t(row_words) + w]; }
+};
+struct CandidateSource {  // row t = suffix j_lo + t % span of pending read t / span (k_query_candidates of shard_cover.hip)
+  const uint64_t* owords;
+  const uint8_t* olen;
+  const uint32_t* pending;
+  int W, K, j_lo, span;
+  __device__ __forceinline__ uint64_t word(uint64_t t, int w) const {
+    const uint64_t slot = t / uint64_t(span);
+    const int j = j_lo + int(t - slot * uint64_t(span));
+    const uint32_t o = pending[slot];
+    if (w == W) return uint64_t(int(olen[o]) - j) | (t << 24);
+    return window32(owords + uint64_t(o) * W, W, j + 32 * w);
+  }
+};
+
+template <class Source>
+__global__ __launch_bounds__(256) void k_msplit_scatter(Source src, const uint64_t* __restrict__ dest, uint64_t n, int row_words,
                                                         uint32_t nparts, const uint64_t* __restrict__ offs,
                                                         uint32_t ntiles, uint64_t* __restrict__ out) {
   __shared__ uint32_t whist[4][256];
@@ -196,7 +216,7 @@ __global__ __launch_bounds__(256) void k_msplit_scatter(const uint64_t* __restri
       int wd = int(j - uint64_t(row) * row_words);
       uint64_t p = __shfl(pos, row, 64);
       bool k = __shfl(int(keep), row, 64) != 0;
-      if (j < nwords && k) out[p * uint64_t(row_words) + wd] = rows[i0 * uint64_t(row_words) + j];
+      if (j < nwords && k) out[p * uint64_t(row_words) + wd] = src.word(i0 + uint64_t(row), wd);
     }
   }
 }
@@ -381,7 +401,8 @@ extern "C" int bg_partition_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n
   uint64_t n_out = 0;
   for (uint32_t p = 0; p < nparts; ++p) { h_counts[p] = hc[p]; n_out += hc[p]; }
   if (n_out) {
-    k_msplit_scatter<<<ntiles, 256, 0, ctx->stream>>>(d_rows, da.p, n, row_words, nparts, toffs.p, ntiles, d_out_rows);
+    k_msplit_scatter<<<ntiles, 256, 0, ctx->stream>>>(RowsSource{d_rows, row_words}, da.p, n, row_words, nparts, toffs.p, ntiles,
+                                                      d_out_rows);
     BG_LAUNCH_CHECK();
   }
   ctx->toc(n * (uint64_t(row_words) * 16 + 16));
@@ -419,6 +440,86 @@ extern "C" int bg_rows_select(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, i
   }
   BG_HIP(hipStreamSynchronize(ctx->stream));
   *n_out = m;
+  return BG_OK;
+}
+
+// destination of candidate t of a cover round (see CandidateSource): owner of its leading bases, or nowhere when
+// the read has no suffix j with at least K bases left
+__global__ void k_dest_candidates(CandidateSource cs, uint64_t total, int hb, const uint32_t* __restrict__ splitters,
+                                  uint32_t nparts, uint64_t* __restrict__ dest) {
+  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const uint64_t slot = t / uint64_t(cs.span);
+  const int j = cs.j_lo + int(t - slot * uint64_t(cs.span));
+  const uint32_t o = cs.pending[slot];
+  const int rem = int(cs.olen[o]) - j;
+  if (rem < cs.K || rem <= 0) { dest[t] = kDropDest; return; }
+  const uint32_t bin = uint32_t(window32(cs.owords + uint64_t(o) * cs.W, cs.W, j) >> (64 - 2 * hb));
+  uint32_t d = 0;
+  for (uint32_t q = 0; q + 1 < nparts; ++q) d += (splitters[q] <= bin) ? 1u : 0u;
+  dest[t] = d;
+}
+
+// bg_cover_query_candidates + bg_partition_rows(BG_PART_PREFIX) in one: the candidate rows of the round are written
+// once, at their place in the partitioned order (the unpartitioned rows — 12 GB for a chr20-sized rank's first
+// rounds — are never materialised).  h_params = {prefix bases, nparts - 1 splitters}; h_counts[nparts].
+extern "C" int bg_cover_query_candidates_split(bg_ctx* ctx, bg_cover_query* q, int j_lo, int j_hi, uint32_t nparts,
+                                               const uint64_t* h_params, uint64_t* d_out_rows, uint64_t cap, uint64_t* h_counts,
+                                               uint64_t* n_out) {
+  if (!ctx || !q || !h_params || !h_counts || !n_out) { set_error("bg_cover_query_candidates_split: null argument"); return BG_EINVAL; }
+  if (j_lo < 1 || j_hi <= j_lo || j_hi > 256) { set_error("bg_cover_query_candidates_split: bad suffix range [%d, %d)", j_lo, j_hi); return BG_EINVAL; }
+  if (nparts < 1 || nparts > 128) { set_error("bg_cover_query_candidates_split: bad geometry"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  const int span = j_hi - j_lo, rw = q->W + 1;
+  const uint64_t total = q->n_pending * uint64_t(span);
+  for (uint32_t p = 0; p < nparts; ++p) h_counts[p] = 0;
+  *n_out = 0;
+  q->j_lo = j_lo;
+  q->span = span;
+  if (!total) return BG_OK;
+  if (total >= (1ull << 32)) { set_error("bg_cover_query_candidates_split: round too large"); return BG_EINVAL; }
+  const int hb = int(h_params[0]);
+  if (hb < 1 || hb > 16) { set_error("bg_cover_query_candidates_split: prefix bases %d outside 1..16", hb); return BG_EINVAL; }
+  std::vector<uint32_t> sp(nparts, 0);
+  for (uint32_t x = 0; x + 1 < nparts; ++x) sp[x] = uint32_t(h_params[1 + x]);
+  DevBuf<uint32_t> dsp, tcounts;
+  DevBuf<uint64_t> da, toffs;
+  DevBuf<unsigned long long> counts;
+  const uint32_t ntiles = uint32_t((total + MS_TILE - 1) / MS_TILE);
+  BG_TRY(dsp.alloc(ctx, nparts));
+  BG_TRY(da.alloc(ctx, total));
+  BG_TRY(counts.alloc(ctx, 256));
+  BG_TRY(tcounts.alloc(ctx, uint64_t(nparts) * ntiles));
+  BG_TRY(toffs.alloc(ctx, uint64_t(nparts) * ntiles));
+  BG_HIP(hipMemcpyAsync(dsp.p, sp.data(), nparts * 4, hipMemcpyHostToDevice, ctx->stream));
+  BG_HIP(hipMemsetAsync(counts.p, 0, 256 * 8, ctx->stream));
+  const CandidateSource cs{q->owords.p, q->olen.p, q->pending.p, q->W, q->K, j_lo, span};
+  ctx->tic("partition_dest");
+  k_dest_candidates<<<cdiv(total, 256), 256, 0, ctx->stream>>>(cs, total, hb, dsp.p, nparts, da.p);
+  BG_LAUNCH_CHECK();
+  BG_HIP(hipStreamSynchronize(ctx->stream));  // sp goes out of scope with the function, dsp is read by then
+  unsigned grid = cdiv(total, 256) < 1024u ? cdiv(total, 256) : 1024u;
+  k_dest_counts<<<grid, 256, 0, ctx->stream>>>(da.p, total, counts.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(total * 24);
+  ctx->tic("partition_split");
+  k_msplit_count<<<ntiles, 256, 0, ctx->stream>>>(da.p, total, nparts, tcounts.p, ntiles);
+  BG_LAUNCH_CHECK();
+  BG_TRY(exclusive_scan_u32_to_u64(ctx, tcounts.p, toffs.p, uint64_t(nparts) * ntiles, nullptr));
+  unsigned long long hc[256];
+  BG_HIP(hipMemcpyAsync(hc, counts.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  uint64_t n_rows = 0;
+  for (uint32_t p = 0; p < nparts; ++p) { h_counts[p] = hc[p]; n_rows += hc[p]; }
+  if (n_rows > cap || (n_rows && !d_out_rows)) { set_error("bg_cover_query_candidates_split: room for %llu rows, %llu needed",
+                                                           (unsigned long long)cap, (unsigned long long)n_rows); return BG_EINVAL; }
+  if (n_rows) {
+    k_msplit_scatter<<<ntiles, 256, 0, ctx->stream>>>(cs, da.p, total, rw, nparts, toffs.p, ntiles, d_out_rows);
+    BG_LAUNCH_CHECK();
+  }
+  ctx->toc(n_rows * uint64_t(rw) * 8 + total * 16);
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  *n_out = n_rows;
   return BG_OK;
 }
 

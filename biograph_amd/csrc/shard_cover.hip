@@ -159,25 +159,6 @@ __global__ void k_query_plain(const uint64_t* __restrict__ owords, const uint8_t
 
 using namespace bg;
 
-struct bg_cover {
-  bg_ctx* ctx = nullptr;
-  uint64_t n = 0;
-  int W = 0, K = 0;
-  DevBuf<uint64_t> owords;
-  DevBuf<uint8_t> olen;
-  CoverStore cs;
-};
-
-struct bg_cover_query {
-  bg_ctx* ctx = nullptr;
-  uint64_t n = 0, n_pending = 0;
-  int W = 0, K = 0;
-  int j_lo = 0, span = 0;  // the round in flight
-  DevBuf<uint64_t> owords;
-  DevBuf<uint8_t> olen;
-  DevBuf<uint32_t> pending;
-};
-
 extern "C" int bg_oriented_rows(bg_ctx* ctx, const bg_reads* reads, int W_out, uint64_t* d_rows) {
   if (!ctx || !reads || (reads->n && !d_rows)) { set_error("bg_oriented_rows: null argument"); return BG_EINVAL; }
   if (W_out < 1 || W_out > kMaxWords || uint32_t(W_out) * 32 < reads->max_len) {

@@ -408,7 +408,7 @@ def _correct_routed(comm, ctxs, reads, owned, skm_recs, skm_org, skm_bits, prm, 
         for r in ranks:
             rows = recv[r].contiguous()
             bits = torch.empty((max(rows.shape[0], 1),), dtype=torch.int32, device=dev[r])
-            capi.check(L.bg_skm_lookup(ctxs[r].h, owned[r].h, _ptr(rows), rows.shape[0], _ptr(bits), 0))
+            capi.check(L.bg_skm_lookup(ctxs[r].h, owned[r].h, _ptr(rows), rows.shape[0], _ptr(bits), 2))  # probes: stop at absent
             back[r] = bits[:rows.shape[0]].view(-1, 1)
         ans = comm.all_to_all_reply(back, cm)
         for r in ranks:
@@ -474,12 +474,17 @@ def _records_sharded_cover(comm, ctxs, corrected, W, k, dev, ph):
         if _all_sum(comm, pend) == 0:
             break
         cand = {}
+        pp = np.ascontiguousarray(pparams, np.uint64)
         for r in ranks:
+            # candidates are generated straight into partitioned order (no unpartitioned copy); the buffer holds every
+            # slot of the round, the rows actually produced (suffixes with >= K bases left) are its head
             cap = pend[r] * (j_hi - j_lo)
             t = torch.empty((max(cap, 1), rw), dtype=i64, device=dev[r])
             n = C.c_uint64()
-            capi.check(L.bg_cover_query_candidates(ctxs[r].h, qs[r], j_lo, j_hi, _ptr(t), cap, C.byref(n)))
-            cand[r] = _partition(ctxs[r], t[:n.value], capi.PART_PREFIX, P, pparams)
+            counts = (C.c_uint64 * P)()
+            capi.check(L.bg_cover_query_candidates_split(ctxs[r].h, qs[r], j_lo, j_hi, P, capi.np_ptr(pp), _ptr(t), cap, counts,
+                                                         C.byref(n)))
+            cand[r] = (t[:n.value], [int(c) for c in counts])
             del t
         got, cm = comm.all_to_all_v(cand)
         back = {}

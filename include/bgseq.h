@@ -517,8 +517,10 @@ int bg_seqset_slice_write(bg_ctx* ctx, const bg_seqset* slice, const char* path,
 /* ---- Routed read correction of the sharded build: the kept k-mers stay with the rank that counted them (a
  * k-mer lives in ONE partition, kmer_counter.h:167-178) instead of being gathered on every rank.
  *   bg_kmerset_build_hash   owner: hash table over the kept k-mers bg_skm_count left
- *   bg_skm_lookup           owner: d_bits[i] bit t = window t of record i is kept (only_unknown: just the
- *                           records bg_skm_count marked 0x80000000 — its counting table overflowed)
+ *   bg_skm_lookup           owner: d_bits[i] bit t = window t of record i is kept (mode bit 0: just the records
+ *                           bg_skm_count marked 0x80000000 — its counting table overflowed; mode bit 1: a record's
+ *                           windows are only looked up as far as the first absent one — probe records, whose
+ *                           windows the search consumes in order)
  *   bg_corr_begin           the rank that holds the reads: window presence of its reads from the bits its
  *                           records got back (all resolved), screen (correct_reads.cpp:154-178)
  *   bg_corr_step            fast_read_correct (fast_read_correct.cpp:16-182) of every pending read over the
@@ -529,7 +531,7 @@ int bg_seqset_slice_write(bg_ctx* ctx, const bg_seqset* slice, const char* path,
 typedef struct bg_correction bg_correction;
 int bg_kmerset_build_hash(bg_ctx* ctx, bg_kmerset* ks);
 int bg_skm_lookup(bg_ctx* ctx, const bg_kmerset* ks, const uint64_t* d_recs, uint64_t n, uint32_t* d_bits,
-                  int only_unknown);
+                  int mode);
 int bg_corr_begin(bg_ctx* ctx, const bg_reads* reads, int k, const bg_correct_params* params, const uint64_t* d_recs,
                   const uint64_t* d_org, const uint32_t* d_bits, uint64_t n_recs, bg_correction** out);
 int bg_corr_step(bg_ctx* ctx, bg_correction* c, uint64_t* n_pending_out, bg_reads** probes_out);
@@ -562,6 +564,11 @@ int bg_cover_query_begin(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int W,
 uint64_t bg_cover_query_pending(const bg_cover_query* q);
 int bg_cover_query_candidates(bg_ctx* ctx, bg_cover_query* q, int j_lo, int j_hi, uint64_t* d_rows, uint64_t cap,
                               uint64_t* n_out);
+/* the two in one (candidates + BG_PART_PREFIX partition): rows are written once, already grouped by destination;
+ * h_params = {prefix bases, nparts - 1 ascending splitters}, h_counts[nparts] = rows per destination */
+int bg_cover_query_candidates_split(bg_ctx* ctx, bg_cover_query* q, int j_lo, int j_hi, uint32_t nparts,
+                                    const uint64_t* h_params, uint64_t* d_out_rows, uint64_t cap, uint64_t* h_counts,
+                                    uint64_t* n_out);
 int bg_cover_query_answers(bg_ctx* ctx, bg_cover_query* q, const uint64_t* d_rows_sent, const uint8_t* d_covered,
                            uint64_t n, uint8_t* d_keep_out);
 int bg_cover_query_plain(bg_ctx* ctx, bg_cover_query* q, uint64_t* d_rows, uint64_t cap, uint64_t* n_out);
