@@ -1067,9 +1067,9 @@ namespace bg {
 
 // bits_out[i] bit t = window t of record i is in the set (the owner's answer to a probe record; with
 // only_unknown, just the records its counting table gave up on — bits_out[i] & kSkUnknown — are looked up).
-// stop_at_absent: the windows of a PROBE are consumed in order and the search stops at the first absent one
-// (fast_read_correct.cpp:24-38), so nothing past it is ever asked for: three of the four alternatives of a probe
-// end at their first window, and looking the other ~29 up was most of this kernel's time.
+// stop_at_absent: windows past the first absent one are left 0.  Only for callers that consume a record's windows
+// strictly in order and never ask past an absent one — NOT the routed correction: its probes answer by k-mer, and a
+// search reaches a probe's later windows by other routes too.
 __global__ void sk_lookup_bits_kernel(const SkRec* __restrict__ recs, uint64_t n_rec, int k, const uint64_t* __restrict__ slots,
                                       int log2cap, uint32_t* __restrict__ bits_out, int only_unknown, int stop_at_absent) {
   const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;

@@ -408,7 +408,10 @@ def _correct_routed(comm, ctxs, reads, owned, skm_recs, skm_org, skm_bits, prm, 
         for r in ranks:
             rows = recv[r].contiguous()
             bits = torch.empty((max(rows.shape[0], 1),), dtype=torch.int32, device=dev[r])
-            capi.check(L.bg_skm_lookup(ctxs[r].h, owned[r].h, _ptr(rows), rows.shape[0], _ptr(bits), 2))  # probes: stop at absent
+            # every window of a probe is looked up: a probe answers by K-MER, so a search that reaches one of its later
+            # windows by another route (other substitutions further left) must find the true answer there, not the
+            # "absent" an early exit at an earlier window would leave (tests/fuzz_parity.py seed 300028 found that)
+            capi.check(L.bg_skm_lookup(ctxs[r].h, owned[r].h, _ptr(rows), rows.shape[0], _ptr(bits), 0))
             back[r] = bits[:rows.shape[0]].view(-1, 1)
         ans = comm.all_to_all_reply(back, cm)
         for r in ranks:
