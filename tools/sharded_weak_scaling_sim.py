@@ -1,7 +1,8 @@
 """Weak-scaling estimate of the sharded build WITHOUT the links: P simulated ranks in one process on one GPU
 (LocalSimComm), each holding 1/P of the pairs of a P x G genome.  Per-rank time = total / P; the growth over
-P = 1 is the replicated work (hash-set build, cover index over all reads).  Usage: python
-tools/sharded_weak_scaling_sim.py [G_per_rank]"""
+P = 1 is work that follows the TOTAL instead of the rank's share (in the replicated mode: the hash set over all kept
+k-mers and the cover index over all reads; the routed mode has none).  Usage: python
+tools/sharded_weak_scaling_sim.py [G_per_rank] [routed|replicated]"""
 import os
 import sys
 import time
@@ -14,6 +15,8 @@ import biograph_amd as bg
 from biograph_amd import sharded, synth
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
+MODE = sys.argv[2] if len(sys.argv) > 2 else "routed"
+os.environ.pop("BG_SHARD_TIMING", None)
 ctx = bg.Context(0)
 base = None
 for P in (1, 2, 4, 8):
@@ -25,13 +28,14 @@ for P in (1, 2, 4, 8):
     for rep in range(2):
         torch.cuda.synchronize()
         t = time.perf_counter()
-        out = sharded.sharded_create(sharded.LocalSimComm(P), ctxs, inputs)
+        out = sharded.sharded_create(sharded.LocalSimComm(P), ctxs, inputs, mode=MODE, gather=False)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
-        out[0][0].free()
+        for r in range(P):
+            out[r][0].free()
     per_rank = dt / P
     base = base or per_rank
-    print("P=%d  total %.1f ms  per rank %.1f ms  efficiency (no links) %.2f" % (P, dt * 1e3, per_rank * 1e3, base / per_rank),
+    print("%s P=%d  total %.1f ms  per rank %.1f ms  efficiency (no links) %.2f" % (MODE, P, dt * 1e3, per_rank * 1e3, base / per_rank),
           flush=True)
     del inputs
     ctx.trim()
