@@ -386,102 +386,243 @@ int update_rc(Walker& w, std::vector<Assembly>& asms, bool with_mates, uint32_t 
   // `incoming`.  The sweep below uses a prediction only when the actual incoming set equals it (the result
   // is a function of (incoming, sequence)), and falls back to a launch otherwise (after variants).  Not
   // with mates: the warm-up walk would collect the mates of the wrong bases.
-  struct Spec { bool valid = false; RangeSet incoming; RangeSet starts; };
+  // Around a variant the incoming set of an assembly is the union over several left contexts (the reference path
+  // and the variant's), so the warm-up is enumerated over the PATHS of assemblies that end where the assembly
+  // begins (up to kMaxPaths of them, each >= 256 bases or back to the start of the walked region); all paths of all
+  // assemblies are one launch, and the assemblies with more than one path get their starts from a second launch on
+  // the union of what the paths predict.  (With reference paths only, every assembly within a read length of a
+  // variant fell back to a launch of its own: 1.65 s of a 2 Mb region's 3.6 s.)
+  struct Spec { bool valid = false; RangeSet incoming; std::map<int64_t, RangeSet> ent; };
   std::vector<Spec> spec(asms.size());
   if (!with_mates) {
-    std::map<int64_t, std::vector<size_t>> ref_by_right;
+    constexpr size_t kMaxPaths = 16, kWarm = 256, kMaxCtx = 65536;
+    std::map<int64_t, std::vector<size_t>> by_right;
     for (size_t i = 0; i < asms.size(); ++i)
-      if (asms[i].matches_reference && asms[i].right != kNone && asms[i].left != kNone) ref_by_right[asms[i].right].push_back(i);
-    std::vector<size_t> who;
+      if (asms[i].right != kNone && asms[i].left != kNone) by_right[asms[i].right].push_back(i);
+    // left contexts of position `pos`: strings of >= kWarm bases ending at pos (complete = reached the region start)
+    struct Ctx { std::string seq; int64_t pos; std::set<size_t> used_inserts; };
+    auto contexts_of = [&](int64_t start, std::vector<std::string>* out) -> bool {
+      std::vector<Ctx> open{Ctx{std::string(), start, {}}};
+      std::set<std::string> seen;  // different routes that spell the same last kWarm bases are one context
+      out->clear();
+      while (!open.empty()) {
+        Ctx c = std::move(open.back());
+        open.pop_back();
+        if (c.seq.size() >= kWarm) {
+          // only the last kWarm bases matter (no entry is longer): what lies further left is dropped
+          std::string tail = c.seq.substr(c.seq.size() - kWarm);
+          if (seen.insert(tail).second) { out->push_back(std::move(tail)); if (out->size() > kMaxPaths) return false; }
+          continue;
+        }
+        auto it = by_right.find(c.pos);
+        bool any = false;
+        if (it != by_right.end()) {
+          for (size_t pi : it->second) {
+            const Assembly& p = asms[pi];
+            const bool insert = p.left == p.right;
+            if (insert && (p.seq.empty() || c.used_inserts.count(pi))) continue;
+            if (p.seq.size() + c.seq.size() > kMaxCtx) return false;
+            Ctx n{p.seq + c.seq, p.left, c.used_inserts};
+            if (insert) n.used_inserts.insert(pi);
+            open.push_back(std::move(n));
+            any = true;
+            if (open.size() > 16 * kMaxPaths) return false;
+          }
+        }
+        if (!any) {  // nothing ends here: the start of the walked region, empty context there
+          if (seen.insert(c.seq).second) { out->push_back(std::move(c.seq)); if (out->size() > kMaxPaths) return false; }
+        }
+      }
+      return !out->empty();
+    };
+    // launch 1: the frontier every context leaves at its position (contexts are shared by the assemblies that begin
+    // there); launch 2: every assembly from the predicted incoming set of its position, with the interior offsets its
+    // stored path has (push_to_pair assemblies come with one)
+    std::map<int64_t, std::vector<std::string>> ctx_of;  // position -> contexts (empty vector: no prediction there)
+    for (size_t i = 0; i < asms.size(); ++i) {
+      const Assembly& a = asms[i];
+      if (a.left == kNone || ctx_of.count(a.left)) continue;
+      std::vector<std::string> paths;
+      if (!contexts_of(a.left, &paths)) paths.clear();
+      ctx_of.emplace(a.left, std::move(paths));
+    }
     std::vector<std::string> seqs;
     std::vector<std::vector<Range>> ends;
     std::vector<std::vector<uint32_t>> marks;
-    for (size_t i = 0; i < asms.size(); ++i) {
-      const Assembly& a = asms[i];
-      if (!a.rc_entries.empty() || a.left == kNone || a.seq.empty()) continue;
-      std::string warm;
-      int64_t pos = a.left;
-      bool broken = false;
-      while (warm.size() < 256) {
-        auto it = ref_by_right.find(pos);
-        if (it == ref_by_right.end()) break;                 // start of the walked region: empty context there
-        if (it->second.size() != 1) { broken = true; break; }  // ambiguous predecessor
-        const Assembly& p = asms[it->second[0]];
-        if (p.seq.empty() || int64_t(p.seq.size()) != p.right - p.left) { broken = true; break; }
-        warm = p.seq + warm;
-        pos = p.left;
+    std::vector<std::pair<int64_t, size_t>> walk_of;  // (position, first walk) per position with contexts
+    for (auto& kv : ctx_of) {
+      if (kv.second.empty()) continue;
+      walk_of.emplace_back(kv.first, seqs.size());
+      for (const std::string& warm : kv.second) {
+        seqs.push_back(rev_comp(warm));  // (an empty context walks nothing: the frontier is the empty context)
+        ends.push_back({w.ctx_begin()});
+        marks.emplace_back();
       }
-      if (broken) continue;
-      who.push_back(i);
-      seqs.push_back(rev_comp(warm + a.seq));
-      ends.push_back({w.ctx_begin()});
-      marks.push_back(warm.empty() ? std::vector<uint32_t>() : std::vector<uint32_t>{uint32_t(a.seq.size())});
     }
     std::vector<Walker::PropOut> res;
     BG_TRY(w.propagate(seqs, ends, marks, false, max_pairs, &res));
-    for (size_t k = 0; k < who.size(); ++k) {
-      Spec& sp = spec[who[k]];
-      sp.valid = true;
-      sp.starts = res[k].ent[0];
-      if (marks[k].empty()) { sp.incoming.insert(w.ctx_begin()); }
-      else sp.incoming = res[k].ent[int64_t(marks[k][0])];
-    }
-  }
-  const Assembly* base = asms.data();
-  auto propagate = [&](const RangeSet& incoming, const std::vector<size_t>& targets) -> int {
-    RangeSet inc_d = incoming;
-    dedup_prefixes(inc_d);
-    std::vector<size_t> todo;
-    for (size_t t : targets) {
-      Assembly& a = asms[t];
-      if (!a.rc_entries.empty() && inc_d == a.rc_ends() && int64_t(a.seq.size()) == a.rc_entries.rbegin()->first) continue;
-      const Spec& sp = spec[size_t(&a - base)];
-      if (sp.valid && a.rc_entries.empty() && sp.incoming == inc_d) {  // the prediction holds
-        a.rc_entries[int64_t(a.seq.size())] = inc_d;
-        a.rc_entries[0] = sp.starts;
-        continue;
+    std::map<int64_t, RangeSet> incoming_at;
+    for (size_t k = 0; k < walk_of.size(); ++k) {
+      const size_t p0 = walk_of[k].second, p1 = k + 1 < walk_of.size() ? walk_of[k + 1].second : seqs.size();
+      RangeSet inc;
+      for (size_t q = p0; q < p1; ++q) {
+        if (seqs[q].empty()) inc.insert(w.ctx_begin());
+        else inc.insert(res[q].ent[0].begin(), res[q].ent[0].end());
       }
-      todo.push_back(t);
+      dedup_prefixes(inc);
+      incoming_at.emplace(walk_of[k].first, std::move(inc));
     }
-    if (todo.empty()) return BG_OK;
+    std::vector<size_t> who;
+    seqs.clear();
+    ends.clear();
+    marks.clear();
+    for (size_t i = 0; i < asms.size(); ++i) {
+      const Assembly& a = asms[i];
+      RangeSet inc;
+      if (a.left == kNone) {
+        inc.insert(w.ctx_begin());  // anchored on the right only: it starts from the empty context (apply_edges)
+      } else {
+        auto it = incoming_at.find(a.left);
+        if (it == incoming_at.end() || it->second.size() > 16) continue;
+        inc = it->second;
+      }
+      Spec& sp = spec[i];
+      sp.valid = true;
+      sp.incoming = inc;
+      if (a.seq.empty()) continue;  // a deletion carries its incoming set through
+      who.push_back(i);
+      seqs.push_back(rev_comp(a.seq));
+      ends.emplace_back(inc.begin(), inc.end());
+      std::vector<uint32_t> m;
+      for (auto& kv : a.rc_entries)
+        if (kv.first > 0 && kv.first < int64_t(a.seq.size())) m.push_back(uint32_t(kv.first));
+      marks.push_back(std::move(m));
+    }
+    BG_TRY(w.propagate(seqs, ends, marks, false, max_pairs, &res));
+    for (size_t k = 0; k < who.size(); ++k) spec[who[k]].ent = std::move(res[k].ent);
+  }
+  // The sweep.  An assembly whose prediction does not hold needs a walk of its own from its actual incoming set, and
+  // what lies downstream of it needs its result.  Instead of one launch per such assembly (1226 of them in a 2 Mb
+  // region: 0.4 s), the sweep defers it, blocks what depends on it, and carries on; all deferred walks of a pass are
+  // ONE launch, and the sweep is repeated until nothing is left (the chains behind a variant are a few assemblies
+  // deep).  With a readmap the walks also collect mates, which the deferral does not track: launched on the spot.
+  size_t n_fallback_launches = 0, n_fallback_items = 0, n_no_spec = 0, n_mismatch = 0, n_passes = 0;
+  struct Deferred { size_t t; RangeSet incoming, inc_d; };
+  std::vector<Deferred> deferred;
+  std::vector<uint8_t> pending(asms.size(), 0);
+  const bool defer = !with_mates;
+  auto walk_now = [&](const std::vector<Deferred>& items) -> int {
     std::vector<std::string> seqs;
     std::vector<std::vector<Range>> ends;
     std::vector<std::vector<uint32_t>> marks;
-    for (size_t t : todo) {
-      seqs.push_back(rev_comp(asms[t].seq));
-      ends.emplace_back(incoming.begin(), incoming.end());
+    for (const Deferred& d : items) {
+      seqs.push_back(rev_comp(asms[d.t].seq));
+      ends.emplace_back(d.incoming.begin(), d.incoming.end());
       std::vector<uint32_t> m;
-      for (auto& kv : asms[t].rc_entries)
-        if (kv.first > 0 && kv.first < int64_t(asms[t].seq.size())) m.push_back(uint32_t(kv.first));
+      for (auto& kv : asms[d.t].rc_entries)
+        if (kv.first > 0 && kv.first < int64_t(asms[d.t].seq.size())) m.push_back(uint32_t(kv.first));
       marks.push_back(m);
     }
     std::vector<Walker::PropOut> res;
     BG_TRY(w.propagate(seqs, ends, marks, with_mates, max_pairs, &res));
-    for (size_t k = 0; k < todo.size(); ++k) {
-      Assembly& a = asms[todo[k]];
+    ++n_fallback_launches;
+    n_fallback_items += items.size();
+    for (size_t k = 0; k < items.size(); ++k) {
+      Assembly& a = asms[items[k].t];
       std::map<int64_t, RangeSet> ne;
-      ne[int64_t(a.seq.size())] = inc_d;
+      ne[int64_t(a.seq.size())] = items[k].inc_d;
       for (auto& kv : res[k].ent) ne[kv.first] = kv.second;
-      if (a.seq.empty()) ne[0] = inc_d;
+      if (a.seq.empty()) ne[0] = items[k].inc_d;
       a.rc_entries.swap(ne);
       a.rc_mates.insert(res[k].mates.begin(), res[k].mates.end());
     }
     return BG_OK;
   };
-  return apply_edges(asms, [&](int64_t, const std::vector<size_t>& left, const std::vector<size_t>& inserts,
-                               const std::vector<size_t>& right) -> int {
-    RangeSet incoming;
-    for (size_t i : left) {
-      if (asms[i].rc_entries.empty()) { set_error("update_rc_seqset_entries: an assembly has no rc path yet"); return BG_EINTERNAL; }
-      incoming.insert(asms[i].rc_starts().begin(), asms[i].rc_starts().end());
+  auto propagate = [&](const RangeSet& incoming, const std::vector<size_t>& targets) -> int {
+    RangeSet inc_d = incoming;
+    dedup_prefixes(inc_d);
+    const bool raw_is_deduped = inc_d == incoming;
+    std::vector<Deferred> todo;
+    for (size_t t : targets) {
+      Assembly& a = asms[t];
+      if (!a.rc_entries.empty() && inc_d == a.rc_ends() && int64_t(a.seq.size()) == a.rc_entries.rbegin()->first) continue;
+      Spec& sp = spec[t];
+      // the prediction was walked from the prefix-deduplicated set; the walk of the assembly itself starts from the
+      // raw union (as the reference does) — they are the same walk only if the union has nothing to deduplicate
+      if (sp.valid && raw_is_deduped && sp.incoming == inc_d) {  // what the walk would compute is there
+        std::map<int64_t, RangeSet> ne;
+        ne[int64_t(a.seq.size())] = inc_d;
+        for (auto& kv : sp.ent) ne[kv.first] = kv.second;
+        if (a.seq.empty()) ne[0] = inc_d;
+        a.rc_entries.swap(ne);
+        sp.valid = false;  // used
+        continue;
+      }
+      if (!sp.valid) ++n_no_spec; else ++n_mismatch;
+      sp.valid = false;
+      todo.push_back(Deferred{t, incoming, inc_d});
     }
-    if (incoming.empty()) incoming.insert(w.ctx_begin());
-    if (!inserts.empty()) {
-      BG_TRY(propagate(incoming, inserts));
-      for (size_t i : inserts) incoming.insert(asms[i].rc_starts().begin(), asms[i].rc_starts().end());
+    if (todo.empty()) return BG_OK;
+    if (!defer) return walk_now(todo);
+    for (Deferred& d : todo) { pending[d.t] = 1; deferred.push_back(std::move(d)); }
+    return BG_OK;
+  };
+  int rc_sweep = BG_OK;
+  for (;;) {
+    ++n_passes;
+    bool blocked_any = false;
+    deferred.clear();
+    std::fill(pending.begin(), pending.end(), uint8_t(0));
+    rc_sweep = apply_edges(asms, [&](int64_t, const std::vector<size_t>& left, const std::vector<size_t>& inserts,
+                                     const std::vector<size_t>& right) -> int {
+      // What depends on a deferred walk cannot be checked in this pass.  It takes its prediction on trust (the next
+      // pass checks it against the actual incoming set like any stored path) so that the chain stops there instead of
+      // blocking everything downstream; only an assembly with neither a prediction nor a path has to wait.
+      auto block = [&](const std::vector<size_t>& v) {
+        for (size_t i : v) {
+          Assembly& a = asms[i];
+          Spec& sp = spec[i];
+          if (sp.valid) {
+            std::map<int64_t, RangeSet> ne;
+            ne[int64_t(a.seq.size())] = sp.incoming;
+            for (auto& kv : sp.ent) ne[kv.first] = kv.second;
+            if (a.seq.empty()) ne[0] = sp.incoming;
+            a.rc_entries.swap(ne);
+            sp.valid = false;
+          } else if (a.rc_entries.empty()) {
+            pending[i] = 1;
+          }
+          blocked_any = true;
+        }
+      };
+      for (size_t i : left)
+        if (pending[i]) { block(inserts); block(right); return BG_OK; }  // what ends here is not known yet
+      RangeSet incoming;
+      for (size_t i : left) {
+        if (asms[i].rc_entries.empty()) { set_error("update_rc_seqset_entries: an assembly has no rc path yet"); return BG_EINTERNAL; }
+        incoming.insert(asms[i].rc_starts().begin(), asms[i].rc_starts().end());
+      }
+      if (incoming.empty()) incoming.insert(w.ctx_begin());
+      if (!inserts.empty()) {
+        BG_TRY(propagate(incoming, inserts));
+        for (size_t i : inserts)
+          if (pending[i]) { block(right); return BG_OK; }
+        for (size_t i : inserts) incoming.insert(asms[i].rc_starts().begin(), asms[i].rc_starts().end());
+      }
+      return propagate(incoming, right);
+    });
+    if (rc_sweep != BG_OK) break;
+    if (deferred.empty()) {
+      if (!blocked_any) break;  // a pass that deferred nothing and took nothing on trust: every path was checked
+      continue;                  // (unreachable: something is only taken on trust behind a deferred walk)
     }
-    return propagate(incoming, right);
-  });
+    rc_sweep = walk_now(deferred);
+    if (rc_sweep != BG_OK) break;
+  }
+  if (getenv("BG_DISCOVER_TRACE"))
+    fprintf(stderr, "[update_rc] %zu assemblies, %zu sweeps, %zu extra launches for %zu assemblies whose prediction did not hold "
+            "(%zu had none, %zu did not match)\n", asms.size(), n_passes, n_fallback_launches, n_fallback_items, n_no_spec, n_mismatch);
+  return rc_sweep;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -986,21 +1127,37 @@ extern "C" int bg_graph_trim_ref(bg_asm_list* l, uint64_t n_extents, const int64
                                  const uint64_t* ext_len, int64_t max_backtrack) {  // graph_trim_ref.cpp
   if (!l || (n_extents && (!ext_offset || !ext_seq || !ext_len))) { set_error("bg_graph_trim_ref: null argument"); return BG_EINVAL; }
   if (max_backtrack <= 0) max_backtrack = 300;
-  auto split_extent_at = [&](int64_t start, std::string* left, std::string* right) {  // scaffold.cpp:189-203
-    left->clear();
-    right->clear();
+  // scaffold::split_extent_at (scaffold.cpp:189-203) without materialising the two halves (an extent is a whole
+  // supercontig: copying it per variant made this step quadratic): the extent holding `start` and the offset in it
+  auto extent_at = [&](int64_t start, const char** base, size_t* k, size_t* len) -> bool {
     for (uint64_t x = 0; x < n_extents; ++x) {
       if (ext_offset[x] > start) break;
       if (ext_offset[x] + int64_t(ext_len[x]) < start) continue;
-      size_t k = size_t(start - ext_offset[x]);
-      left->assign(ext_seq[x], k);
-      right->assign(ext_seq[x] + k, size_t(ext_len[x]) - k);
-      return;
+      *base = ext_seq[x];
+      *k = size_t(start - ext_offset[x]);
+      *len = size_t(ext_len[x]);
+      return true;
     }
+    return false;
   };
-  auto shared_prefix = [](const std::string& a, const std::string& b) {
-    size_t n = std::min(a.size(), b.size()), i = 0;
-    while (i < n && a[i] == b[i]) ++i;
+  // bases the assembly shares with the reference to the right of `start` (from its first base on) ...
+  auto shared_with_right = [&](int64_t start, const std::string& seq) -> int64_t {
+    const char* base;
+    size_t k, len;
+    if (!extent_at(start, &base, &k, &len)) return 0;
+    const size_t n = std::min(len - k, seq.size());
+    size_t i = 0;
+    while (i < n && base[k + i] == seq[i]) ++i;
+    return int64_t(i);
+  };
+  // ... and to the left of it (from its last base back): the common prefix of the two reverse complements
+  auto shared_with_left = [&](int64_t start, const std::string& seq) -> int64_t {
+    const char* base;
+    size_t k, len;
+    if (!extent_at(start, &base, &k, &len)) return 0;
+    const size_t n = std::min(k, seq.size());
+    size_t i = 0;
+    while (i < n && base[k - 1 - i] == seq[seq.size() - 1 - i]) ++i;
     return int64_t(i);
   };
   std::vector<Assembly> out;
@@ -1008,9 +1165,9 @@ extern "C" int bg_graph_trim_ref(bg_asm_list* l, uint64_t n_extents, const int64
   size_t ref_head = 0;
   std::set<int64_t> ref_stops;
   auto split_and_output_ref = [&](Assembly a) {
-    for (int64_t stop : std::vector<int64_t>(ref_stops.begin(), ref_stops.end())) {
-      if (stop <= a.left) continue;
-      if (stop >= a.right) break;
+    // (the stops inside this assembly: taken out of the set first, the loop below edits `a`)
+    std::vector<int64_t> inside(ref_stops.upper_bound(a.left), ref_stops.lower_bound(a.right));
+    for (int64_t stop : inside) {
       size_t k = size_t(stop - a.left);
       Assembly left = a;
       left.right = stop;
@@ -1033,9 +1190,8 @@ extern "C" int bg_graph_trim_ref(bg_asm_list* l, uint64_t n_extents, const int64
     advance_to(mo == kNone ? kNone : mo - max_backtrack);
     if (a.matches_reference) { ref_asms.push_back(std::move(a)); continue; }
     int64_t shared_left = 0, shared_right = 0;
-    std::string le, ri;
-    if (a.left != kNone) { split_extent_at(a.left, &le, &ri); shared_left = shared_prefix(ri, a.seq); }
-    if (a.right != kNone) { split_extent_at(a.right, &le, &ri); shared_right = shared_prefix(rev_comp(le), rev_comp(a.seq)); }
+    if (a.left != kNone) shared_left = shared_with_right(a.left, a.seq);
+    if (a.right != kNone) shared_right = shared_with_left(a.right, a.seq);
     int64_t max_anchor = int64_t(a.seq.size());
     if (a.left != kNone && a.right != kNone) max_anchor = std::min(max_anchor, a.right - a.left);
     if (a.left == kNone) max_anchor = std::min(max_anchor, max_backtrack);

@@ -171,3 +171,59 @@ def test_bgbinary_discovery_cli_on_lambda(golden_dir, tmp_path, ref_arg, chrom):
     mine, gold = edits(out), edits(golden_dir + "/father_lambda/father.vcf")
     assert len(mine) == 8 and mine == gold
     assert {l.split("\t")[0] for l in open(out) if not l.startswith("#")} == {chrom}
+
+
+def test_native_drivers_equal_oracle_twin_on_a_240kb_sample(ctx):
+    """A 240 kb diploid sample with SNPs, indels (1-50 bp) and structural insertions / deletions (50-1000 bp), 30x paired
+    150 bp reads with errors: the whole pipeline through the C++ drivers over the GPU walks (batched predictions,
+    deferred walks, multi-pass sweep of update_rc_seqset_entries) gives, assembly for assembly and rc path for rc path,
+    what the Python twin gives over the ORACLE's literal walks on the oracle's own seqset and readmap of the same
+    reads — at every step of the pipeline, with mates."""
+    import numpy as np
+    import torch
+    from biograph_amd import synth
+    G = 240_000
+    seq, offs, n, genome = synth.make_reads(genome_len=G, coverage=30, read_len=150, seed=77, device="cuda", return_genome=True,
+                                            indel_rate=3e-4, sv_rate=5e-5)
+    r = ctx.pack_reads_device(seq.data_ptr(), offs.data_ptr(), n)
+    ks = ctx.kmer_count(r, 30, 5)
+    c, _ = ctx.correct_reads(r, ks)
+    ss, _ = ctx.build_seqset(c, 30)
+    rm = ctx.build_readmap(ss, c, True)
+    # the oracle's world from the same corrected reads (the builds themselves are compared elsewhere)
+    cseq, coffs = c.download()
+    corrected = O.unpack_strings(cseq, coffs)
+    ent = O.Entries.build(cseq, coffs, "cover", 30, threads=8)
+    oss = O.Seqset.from_entries(ent, threads=8)
+    records = [tuple(s for s in corrected[i:i + 2] if s) for i in range(0, len(corrected), 2)]
+    orm = O.Readmap(oss, ent, [rec for rec in records if rec], True)
+    op = oss.parts()
+    assert all(op[k] == ss.part(k) for k in bg.PART_NAMES)
+    ref = "".join("ACGT"[int(x)] for x in genome.cpu().tolist())
+    ext = [(0, ref)]
+    w = OracleWalker(oss, orm)
+
+    def trim_and_update(asms):
+        return V.update_rc_seqset_entries(V.dedup_assemblies(V.graph_trim_ref(asms, ext)), w)
+
+    lst = AssemblyList().make_ref_assemblies(ext, 0, len(ref))
+    lst.graph_trim_ref(ext).dedup().update_rc_seqset_entries(ss)
+    py = trim_and_update(V.make_ref_assemblies(ext, 0, len(ref)))
+    assert _sig(lst.to_python()) == _sig(py)
+    lst.discover_branch(ss, rm, 105, "BRANCH")
+    lst.graph_trim_ref(ext).dedup().update_rc_seqset_entries(ss)
+    py = trim_and_update(V.discover_branch(py, w, 105, "BRANCH"))
+    assert _sig(lst.to_python()) == _sig(py)
+    lst.discover_push_to_pair(ss, rm, 105, 1000, "PUSH_TO_PAIR", ["BRANCH"])
+    lst.graph_trim_ref(ext).dedup().update_rc_seqset_entries(ss)
+    py = trim_and_update(V.discover_push_to_pair(py, w, 105, 1000, "PUSH_TO_PAIR", ["BRANCH"]))
+    got = lst.to_python()
+    assert _sig(got) == _sig(py)
+    found = [a for a in got if a.left_offset is not None and a.right_offset is not None and not a.matches_reference]
+    sizes = sorted(abs(len(a.seq) - (a.right_offset - a.left_offset)) for a in found)
+    assert len(found) > 150 and sizes[-1] >= 50  # SNPs, indels and at least one structural variant were anchored
+    # the pipeline with the readmap at the update steps too (mates collected on the rc paths)
+    lst2 = AssemblyList().make_ref_assemblies(ext, 0, 40000)
+    lst2.graph_trim_ref(ext).dedup().update_rc_seqset_entries(ss, rm)
+    py2 = V.update_rc_seqset_entries(V.dedup_assemblies(V.graph_trim_ref(V.make_ref_assemblies(ext, 0, 40000), ext)), w, with_mates=True)
+    assert _sig(lst2.to_python()) == _sig(py2)
