@@ -102,7 +102,7 @@ def cpu_baseline(ctx, sample_genome, coverage, read_len, seed, dev):
     return out
 
 
-def driver_leg(ctx, ss, genome, dev, args, region=2000000):
+def driver_leg(ctx, ss, genome, dev, args, region=None, rm=None):
     """The whole graph-discover pipeline of the reference's graph_discover_test.py (make_ref_assemblies ->
     trim/update -> discover_branch -> ... -> discover_push_to_pair; host drivers biograph_amd/variants.py over
     the kernels) on the first `region` bases of the reference, scored against the SNPs synth.py planted (on one
@@ -112,22 +112,24 @@ def driver_leg(ctx, ss, genome, dev, args, region=2000000):
     import torch
     from biograph_amd import variants as V  # AssemblyList: the C++ drivers (csrc/discover.cpp)
     from biograph_amd.synth import variant_sites as synth_sites
+    import numpy as np
     G = int(genome.numel())
-    region = min(region, G)
-    ref = "".join("ACGT"[int(c)] for c in genome[:region].cpu().tolist())
+    region = G if region is None else min(region, G)   # the whole reference of the configuration by default
+    ref = np.frombuffer(b"ACGT", np.uint8)[genome[:region].cpu().numpy()].tobytes().decode()
     g = torch.Generator(device=dev)
     g.manual_seed(args.seed + 1)
     snp = torch.rand(G, generator=g, device=dev) < 0.001
     shift = torch.randint(1, 4, (G,), generator=g, device=dev, dtype=torch.uint8)
-    pos = torch.nonzero(snp[:region]).flatten().cpu().tolist()
-    truth = {p: "ACGT"[(int(genome[p]) + int(shift[p])) & 3] for p in pos if 300 < p < region - 300}
+    pos_t = torch.nonzero(snp[:region]).flatten()
+    alt_t = ((genome[pos_t].to(torch.int64) + shift[pos_t].to(torch.int64)) & 3).cpu().tolist()
+    truth = {p: "ACGT"[a] for p, a in zip(pos_t.cpu().tolist(), alt_t) if 300 < p < region - 300}
     ext = [(0, ref)]
     t0 = time.perf_counter()
     lst = V.AssemblyList().make_ref_assemblies(ext, 0, region)          # C++ drivers (csrc/discover.cpp)
     lst.graph_trim_ref(ext).dedup().update_rc_seqset_entries(ss)
-    lst.discover_branch(ss, None, 105, "BRANCH")
+    lst.discover_branch(ss, rm, 105, "BRANCH")
     lst.graph_trim_ref(ext).dedup().update_rc_seqset_entries(ss)
-    lst.discover_push_to_pair(ss, None, 105, 1000, "PUSH_TO_PAIR", ["BRANCH"])
+    lst.discover_push_to_pair(ss, rm, 105, 1000, "PUSH_TO_PAIR", ["BRANCH"])  # with the readmap: mates anchor the traces
     lst.graph_trim_ref(ext).dedup().update_rc_seqset_entries(ss)
     dt = time.perf_counter() - t0
     found = [a for a in lst.to_python(False)
@@ -149,7 +151,7 @@ def driver_leg(ctx, ss, genome, dev, args, region=2000000):
                 indel_hit += 1
                 break
             i += 1
-    return {"region_bases": region, "seconds": round(dt, 2), "anchored_variants": len(found),
+    return {"region_bases": region, "whole_reference": region == G, "seconds": round(dt, 2), "anchored_variants": len(found),
             "anchored_variants_per_s": round(len(found) / dt, 1),
             "planted_snps_in_region": len(truth), "planted_snps_found": hit,
             "planted_indels_svs_in_region": len(planted), "planted_indels_svs_found": indel_hit,
@@ -179,7 +181,6 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
     torch.cuda.synchronize()
     t_rm = time.perf_counter() - t0
     n_ids = rm.size()
-    rm.free()
     corrected.free()
     G = int(genome.numel())
     n = ss.size()
@@ -287,8 +288,11 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
                "traces_reaching_max_steps": int((o_why == 2).sum().item()),
                "traces_ended_no_extension": int((o_why == 0).sum().item()),
                "traces_ended_seen_range": int((o_why == 1).sum().item()),
-               "variants_per_s_end_to_end": round(ns / (t_br + t_prop + t_tr), 1)}
-    drv = driver_leg(ctx, ss, genome, dev, args) if args is not None else None
+               # candidate SITES (one-base branches) through branch -> propagate -> extension; the anchored variants of the
+               # whole pipeline, host bookkeeping included, are graph_discover_driver.anchored_variants_per_s
+               "candidate_sites_per_s_kernels_only": round(ns / (t_br + t_prop + t_tr), 1)}
+    drv = driver_leg(ctx, ss, genome, dev, args, rm=rm) if args is not None else None
+    rm.free()
     ss.free()
     pfd_ref = 2 * G + 2 * 256 * (G // 4096 + 1)
     pfd_br = na * (A + WARM) * 4
