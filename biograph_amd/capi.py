@@ -83,7 +83,7 @@ SYMBOLS = [
     "bg_kmerset_build_hash", "bg_skm_lookup", "bg_corr_begin", "bg_corr_step", "bg_corr_answers", "bg_corr_finish",
     "bg_corr_probes", "bg_corr_free",
     "bg_seqset_slice_masks", "bg_seqset_slice_build", "bg_seqset_slice_popcounts", "bg_seqset_sharded_create_file",
-    "bg_seqset_slice_write", "bg_fastq_import", "bg_dev_upload_pinned",
+    "bg_seqset_slice_write", "bg_fastq_import", "bg_dev_upload_pinned", "bg_dev_upload_file",
     "bg_torch_allocator_enable", "bg_torch_allocator_enabled", "bg_torch_malloc", "bg_torch_free",
     "bg_rows_select", "bg_seqset_uuid", "bg_readmap_has_mate_loop", "bg_seqset_tail_rows2", "bg_seqset_apply_tails2", "bg_seqset_tail_rows_full", "bg_records_from_row_parts",
 ]
@@ -251,6 +251,7 @@ def lib():
     L.bg_records_from_row_parts.argtypes = [vp, u32, P(vp), P(u64), i32, P(vp)]
     L.bg_fastq_import.argtypes = [vp, u32, P(vp), P(u64), i32, i32, u32, u32, P(vp), P(vp), P(u64), P(u64)]
     L.bg_dev_upload_pinned.argtypes = [vp, vp, vp, u64, i32]
+    L.bg_dev_upload_file.argtypes = [vp, vp, i32, u64, u64, i32]
     L.bg_oriented_rows.argtypes = [vp, vp, i32, vp]
     L.bg_rows_prefix_hist.argtypes = [vp, vp, u64, i32, i32, u64, vp]
     L.bg_cover_build.argtypes = [vp, vp, u64, i32, i32, P(vp)]

@@ -16,7 +16,6 @@
 #include <fcntl.h>
 #include <stdarg.h>
 #include <string.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <time.h>
@@ -89,13 +88,11 @@ static std::string json_argv(int argc, char** argv) {
   return json_str(cmd);
 }
 
-// One input file in host memory: plain text is mapped, gzip is inflated (zlib; GPU-side gzip is out of scope,
-// SURVEY.md section 8 f.4b).
+// One input file: plain text stays in the file (its bytes go from the descriptor to the GPU, bg_dev_upload_file), gzip
+// and pipes are inflated / read into host memory (zlib; GPU-side gzip is out of scope).
 struct HostText {
-  const char* p = nullptr;
+  int fd = -1;          // >= 0: a plain regular file of n bytes
   size_t n = 0;
-  void* map = nullptr;
-  size_t map_len = 0;
   std::string inflated;
 };
 static void load_text(const std::string& path, HostText* t) {
@@ -104,16 +101,10 @@ static void load_text(const std::string& path, HostText* t) {
   unsigned char magic[2] = {0, 0};
   struct stat st;
   const bool regular = fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
-  if (regular && pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b) && st.st_size > 0) {
-    void* m = mmap(nullptr, size_t(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
-    if (m != MAP_FAILED) {
-      t->map = m;
-      t->map_len = size_t(st.st_size);
-      t->p = static_cast<const char*>(m);
-      t->n = t->map_len;
-      close(fd);
-      return;
-    }
+  if (regular && st.st_size > 0 && pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+    t->fd = fd;
+    t->n = size_t(st.st_size);
+    return;
   }
   close(fd);
   gzFile f = gzopen(path == "-" ? "/dev/stdin" : path.c_str(), "rb");  // transparent for plain text (pipes)
@@ -124,12 +115,11 @@ static void load_text(const std::string& path, HostText* t) {
   while ((got = gzread(f, buf.data(), unsigned(buf.size()))) > 0) t->inflated.append(buf.data(), size_t(got));
   if (got < 0) die(path + ": read error (truncated gzip?)");
   gzclose(f);
-  t->p = t->inflated.data();
   t->n = t->inflated.size();
 }
 static void free_text(HostText* t) {
-  if (t->map) munmap(t->map, t->map_len);
-  t->map = nullptr;
+  if (t->fd >= 0) close(t->fd);
+  t->fd = -1;
   std::string().swap(t->inflated);
 }
 
@@ -228,7 +218,8 @@ static int cmd_create(int argc, char** argv) {
     n_text[i] = t.n;
     text_bytes += t.n;
     check(bg_dev_alloc(ctx, t.n ? t.n : 1, &d_text[i]), "bg_dev_alloc");
-    check(bg_dev_upload_pinned(ctx, d_text[i], t.p, t.n, threads), "upload");
+    if (t.fd >= 0) check(bg_dev_upload_file(ctx, d_text[i], t.fd, 0, t.n, threads), "upload");
+    else check(bg_dev_upload_pinned(ctx, d_text[i], t.inflated.data(), t.n, threads), "upload");
     free_text(&t);
   }
   double t_upload = now_s() - t0;

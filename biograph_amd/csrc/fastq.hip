@@ -10,6 +10,7 @@
 // Pairing follows the reference: two files read in lock step (mates = records of equal index) or one
 // interleaved file (mates = records 2i, 2i + 1); mates end up adjacent (reads 2i, 2i + 1).
 #include <string.h>
+#include <unistd.h>
 
 #include <thread>
 #include <vector>
@@ -128,10 +129,11 @@ __global__ void fq_set_last_offset(const uint64_t* __restrict__ offs, const uint
 
 using namespace bg;
 
-// Copies h_src to device memory through two pinned staging buffers: `threads` host threads fill one while the
-// DMA engine drains the other (a pageable hipMemcpy stages through one small internal buffer, single-threaded).
-extern "C" int bg_dev_upload_pinned(bg_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes, int threads) {
-  if (!ctx || (bytes && (!d_dst || !h_src))) { set_error("bg_dev_upload_pinned: null argument"); return BG_EINVAL; }
+// Host -> device through two pinned staging buffers: `threads` host threads fill one (fill(dst, offset, bytes))
+// while the DMA engine drains the other (a pageable hipMemcpy stages through one small internal buffer,
+// single-threaded).
+template <class Fill>
+static int staged_upload(bg_ctx* ctx, void* d_dst, uint64_t bytes, int threads, Fill fill, const char* who) {
   BG_HIP(hipSetDevice(ctx->device));
   if (!bytes) return BG_OK;
   if (threads < 1) threads = int(std::thread::hardware_concurrency());
@@ -150,31 +152,58 @@ extern "C" int bg_dev_upload_pinned(bg_ctx* ctx, void* d_dst, const void* h_src,
     const int b = c & 1;
     const uint64_t sz = bytes - done < chunk ? bytes - done : chunk;
     if (c >= 2 && hipEventSynchronize(ev[b]) != hipSuccess) { rc = BG_ENODEV; break; }
-    const char* src = static_cast<const char*>(h_src) + done;
     char* dst = static_cast<char*>(pin[b]);
     const int nt = sz < (8u << 20) ? 1 : threads;
+    std::vector<int> ok(nt, 1);
     if (nt == 1) {
-      memcpy(dst, src, sz);
+      ok[0] = fill(dst, done, sz) ? 1 : 0;
     } else {
       std::vector<std::thread> pool;
       const uint64_t per = (sz + nt - 1) / nt;
       for (int t = 0; t < nt; ++t) {
         const uint64_t lo = uint64_t(t) * per, hi = lo + per < sz ? lo + per : sz;
-        if (lo < hi) pool.emplace_back([=] { memcpy(dst + lo, src + lo, hi - lo); });
+        if (lo < hi) pool.emplace_back([&, t, lo, hi] { ok[t] = fill(dst + lo, done + lo, hi - lo) ? 1 : 0; });
       }
       for (auto& th : pool) th.join();
     }
+    for (int v : ok) if (!v) rc = BG_EIO;
+    if (rc != BG_OK) break;
     if (hipMemcpyAsync(static_cast<char*>(d_dst) + done, pin[b], sz, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
         hipEventRecord(ev[b], ctx->stream) != hipSuccess) { rc = BG_ENODEV; break; }
     done += sz;
   }
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BG_ENODEV;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == BG_OK) rc = BG_ENODEV;
   (void)hipEventDestroy(ev[0]);
   (void)hipEventDestroy(ev[1]);
   (void)hipHostFree(pin[0]);
   (void)hipHostFree(pin[1]);
-  if (rc != BG_OK) set_error("bg_dev_upload_pinned: HIP error during the staged copy");
+  if (rc == BG_EIO) set_error("%s: read error", who);
+  else if (rc != BG_OK) set_error("%s: HIP error during the staged copy", who);
   return rc;
+}
+
+extern "C" int bg_dev_upload_pinned(bg_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes, int threads) {
+  if (!ctx || (bytes && (!d_dst || !h_src))) { set_error("bg_dev_upload_pinned: null argument"); return BG_EINVAL; }
+  const char* src = static_cast<const char*>(h_src);
+  return staged_upload(ctx, d_dst, bytes, threads,
+                       [src](char* dst, uint64_t off, uint64_t n) { memcpy(dst, src + off, n); return true; }, "bg_dev_upload_pinned");
+}
+
+// The same from an open file: every thread pread()s its slice of a chunk straight into the pinned buffer (no mapping
+// of the file, so no page-table faults on 4 KiB pages of a multi-gigabyte FASTQ).
+extern "C" int bg_dev_upload_file(bg_ctx* ctx, void* d_dst, int fd, uint64_t file_offset, uint64_t bytes, int threads) {
+  if (!ctx || fd < 0 || (bytes && !d_dst)) { set_error("bg_dev_upload_file: bad argument"); return BG_EINVAL; }
+  return staged_upload(ctx, d_dst, bytes, threads,
+                       [fd, file_offset](char* dst, uint64_t off, uint64_t n) {
+                         while (n) {
+                           const ssize_t got = pread(fd, dst, n, off_t(file_offset + off));
+                           if (got <= 0) return false;
+                           dst += got;
+                           off += uint64_t(got);
+                           n -= uint64_t(got);
+                         }
+                         return true;
+                       }, "bg_dev_upload_file");
 }
 
 extern "C" int bg_fastq_import(bg_ctx* ctx, uint32_t n_src, const uint8_t* const* d_text, const uint64_t* h_bytes, int paired_files,

@@ -100,6 +100,8 @@ int bg_fastq_import(bg_ctx* ctx, uint32_t n_src, const uint8_t* const* d_text, c
 /* Host -> device copy through two pinned staging buffers filled by `threads` host threads (0 = all cores)
  * while the DMA engine drains the other one. */
 int bg_dev_upload_pinned(bg_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes, int threads);
+/* the same from an open file descriptor: `bytes` bytes from file_offset, pread() by the filling threads */
+int bg_dev_upload_file(bg_ctx* ctx, void* d_dst, int fd, uint64_t file_offset, uint64_t bytes, int threads);
 
 /* ---- S2: k-mer counting + filter.  Replaces kmer_counter + kmerizer::run + kmer_set
  * (modules/build_seqset/kmer_counter.h:123-326, modules/bio_mapred/kmerize_bf.cpp:267-429).
