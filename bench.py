@@ -380,22 +380,28 @@ LIMITER_OF_FAMILY = {"skm_count_lds": "VALU issue (rolling canonical k-mer + LDS
                      "radix_scatter_k": "hbm stream", "skm_part_scatter": "hbm stream", "suffix_emit": "hbm stream"}
 
 
-def pmc_traffic(family):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/, separate FETCH_SIZE / WRITE_SIZE runs; KiB units; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md §HBM prescribes for gfx950).  bench.py cannot collect PMC counters itself."""
+def pmc_traffic(family, avg_launch_ms):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/r*_chr20_rocprofv3_summary.json: separate FETCH_SIZE / WRITE_SIZE runs; KiB units; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md section HBM prescribes for gfx950).  bench.py cannot collect PMC counters itself, so the figure is
+    only attached when the profile is of THIS kernel as it runs now: same kernel name and an average duration within
+    15 % of the one just measured; otherwise traffic stays null and traffic_source says why."""
     import glob
     pat = KERNEL_OF_FAMILY.get(family)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_chr20_rocprofv3_summary.json")))
     if not pat or not files:
-        return {"traffic": None}
+        return {"traffic": None, "traffic_source": "no committed PMC profile for this kernel"}
     for e in json.load(open(files[-1])):
         if pat in e["kernel"] and "fetch_bytes_per_launch_x2" in e:
+            prof_ms = e["avg_us"] / 1e3
+            if abs(prof_ms - avg_launch_ms) > 0.15 * avg_launch_ms:
+                return {"traffic": None, "traffic_source": "%s is stale: %s took %.2f ms there, %.2f ms now" % (
+                    os.path.basename(files[-1]), pat, prof_ms, avg_launch_ms)}
             return {"traffic": int(e["fetch_bytes_per_launch_x2"] + e.get("write_bytes_per_launch", 0)),
                     "traffic_fetch_raw": int(e["fetch_bytes_per_launch_raw"]),
                     "traffic_write": int(e.get("write_bytes_per_launch", 0)),
-                    "traffic_source": os.path.basename(files[-1])}
-    return {"traffic": None}
+                    "traffic_source": os.path.basename(files[-1]) + " (kernel name and duration match this run)"}
+    return {"traffic": None, "traffic_source": "%s has no PMC entry for %s" % (os.path.basename(files[-1]), pat)}
 
 
 def self_launch(n, json_fd):
@@ -581,7 +587,7 @@ def main():
                         # dependent random 128-byte lines
                         "limiter": LIMITER_OF_FAMILY.get(fam["name"], "hbm random access (latency / line granularity)")}
         if roofline and args.shape == "chr20" and not args.genome_len:
-            roofline.update(pmc_traffic(roofline["kernel"]))
+            roofline.update(pmc_traffic(roofline["kernel"], roofline["avg_launch_ms"]))
         total_ms = sum(t["ms"] for t in timings) or 1.0
         kernels = {t["name"]: {"ms_per_step": round(t["ms"] / max(args.steps, 1), 3),
                                "launches_per_step": t["launches"] / max(args.steps, 1),

@@ -7,7 +7,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-discover"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-discover --no-end-to-end"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o run -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_stats.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -o run -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/${TAG}_fetch.log
