@@ -76,7 +76,7 @@ SYMBOLS = [
     "bg_kmerset_from_kmers", "bg_reads_words", "bg_reads_export", "bg_reads_import", "bg_suffix_records",
     "bg_records_count", "bg_records_words", "bg_records_rows", "bg_records_prefix_hist", "bg_records_from_rows", "bg_records_free",
     "bg_entries_from_records", "bg_seqset_words", "bg_seqset_boundary_rows", "bg_seqset_fix_boundary",
-    "bg_seqset_tail_rows", "bg_seqset_apply_tails", "bg_seqset_slice_export", "bg_seqset_assemble",
+    "bg_seqset_tail_rows", "bg_seqset_entry_rows", "bg_seqset_apply_tails", "bg_seqset_slice_export", "bg_seqset_assemble",
     "bg_oriented_rows", "bg_rows_prefix_hist", "bg_cover_build", "bg_cover_test", "bg_cover_free",
     "bg_cover_query_begin", "bg_cover_query_pending", "bg_cover_query_candidates", "bg_cover_query_candidates_split", "bg_cover_query_answers",
     "bg_cover_query_plain", "bg_cover_query_free",
@@ -234,6 +234,7 @@ def lib():
     L.bg_seqset_boundary_rows.argtypes = [vp, vp, vp, vp]
     L.bg_seqset_fix_boundary.argtypes = [vp, vp, vp, vp]
     L.bg_seqset_tail_rows.argtypes = [vp, vp, vp]
+    L.bg_seqset_entry_rows.argtypes = [vp, vp, vp]
     L.bg_seqset_apply_tails.argtypes = [vp, vp, vp, u64]
     L.bg_seqset_slice_export.argtypes = [vp, vp, vp, vp, vp]
     L.bg_seqset_assemble.argtypes = [vp, u32, vp, vp, vp, vp, u32, P(vp)]

@@ -58,6 +58,42 @@ __global__ __launch_bounds__(128) void k_rm_entry_ids(const uint64_t* __restrict
   eid[o] = lo;
 }
 
+// The same for a seqset opened from a file (no resident keys): seqset::find (bio_base/seqset.cpp:149-153) by
+// push_front from the read's last base; the entry id is the start of the range found.
+__global__ __launch_bounds__(128) void k_rm_entry_ids_fm(SeqsetView v, const uint64_t* __restrict__ words,
+                                                        const uint16_t* __restrict__ len, uint64_t n_o, int W,
+                                                        uint64_t* __restrict__ eid, uint32_t* __restrict__ err) {
+  uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (o >= n_o) return;
+  int L = len[o >> 1];
+  if (!L) { eid[o] = ~0ull; return; }
+  uint64_t key[kMaxWords];
+  oriented_words(words + (o >> 1) * W, L, W, (o & 1) != 0, key);
+  uint64_t rb = 0, re = v.n;
+  uint32_t rs = 0;
+  for (int p = L - 1; p >= 0 && rb < re; --p) {
+    const int b = int((key[p >> 5] >> (62 - 2 * (p & 31))) & 3);
+    v.push_front(rb, re, rs, b, &rb, &re, &rs);
+  }
+  if (rb >= re) {
+    atomicOr(err, 1u);  // "Read ... was not found in seqset" (make_readmap.cpp:147-151)
+    rb = 0;
+  }
+  eid[o] = rb;
+}
+
+static SeqsetView rm_seqset_view(const bg_seqset* ss) {
+  SeqsetView v;
+  v.n = ss->n;
+  v.sizes = ss->sizes.p;
+  v.shared = ss->shared.p;
+  for (int b = 0; b < 4; ++b) { v.bits[b] = ss->bits[b].p; v.subaccum[b] = ss->subaccum[b].p; v.accum[b] = ss->accum[b].p; }
+  for (int b = 0; b < 5; ++b) v.fixed[b] = ss->fixed[b];
+  v.min1 = ss->min1.p;
+  v.min2 = ss->min2.p;
+  return v;
+}
+
 // rows of record r (pair r = reads 2r, 2r+1 when paired, else read r); unused slots get hi = ~0
 __global__ void k_rm_rows(const uint64_t* __restrict__ words, const uint16_t* __restrict__ len, uint64_t n_rec, int W,
                           int paired, const uint64_t* __restrict__ eid, uint64_t* __restrict__ hi,
@@ -329,8 +365,9 @@ static int bg::readmap_min_len(bg_ctx* ctx, bg_readmap* rm) {
 extern "C" int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads* reads, int is_paired,
                                 bg_readmap** out) {
   if (!ctx || !ss || !reads || !out) { set_error("bg_readmap_build: null argument"); return BG_EINVAL; }
-  if (ss->n && (!ss->keys.p || !ss->W)) { set_error("bg_readmap_build: the seqset has no resident entry keys (build it in this process)"); return BG_EINVAL; }
-  if (reads->W > ss->W && ss->n) { set_error("bg_readmap_build: reads longer than the seqset's entries"); return BG_EINVAL; }
+  const bool have_keys = ss->keys.p && ss->W;
+  if (ss->n && !have_keys && !ss->accum[0].p) { set_error("bg_readmap_build: the seqset is not finalized"); return BG_EINVAL; }
+  if (have_keys && reads->W > ss->W && ss->n) { set_error("bg_readmap_build: reads longer than the seqset's entries"); return BG_EINVAL; }
   if (is_paired && (reads->n & 1)) { set_error("bg_readmap_build: paired input needs an even number of reads"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));
   const uint64_t n = reads->n, n_o = 2 * n, n_ent = ss->n;
@@ -352,10 +389,16 @@ extern "C" int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads
     DevBuf<uint32_t> dir;
     ctx->tic("readmap_entry_ids");
     int bases = 0;
-    BG_TRY(build_prefix_dir_keys(ctx, ss->keys.p, n_ent, EW, &dir, &bases));
-    if (n_o) {
-      k_rm_entry_ids<<<cdiv(n_o, 128), 128, 0, ctx->stream>>>(reads->words.p, reads->len.p, n_o, W, ss->keys.p,
-                                                              ss->sizes.p, n_ent, EW, dir.p, bases, eid.p, err.p);
+    if (have_keys) {
+      BG_TRY(build_prefix_dir_keys(ctx, ss->keys.p, n_ent, EW, &dir, &bases));
+      if (n_o) {
+        k_rm_entry_ids<<<cdiv(n_o, 128), 128, 0, ctx->stream>>>(reads->words.p, reads->len.p, n_o, W, ss->keys.p,
+                                                                ss->sizes.p, n_ent, EW, dir.p, bases, eid.p, err.p);
+        BG_LAUNCH_CHECK();
+      }
+    } else if (n_o) {  // opened from a file (a replica of a merged seqset): FM search
+      k_rm_entry_ids_fm<<<cdiv(n_o, 128), 128, 0, ctx->stream>>>(rm_seqset_view(ss), reads->words.p, reads->len.p, n_o, W,
+                                                                 eid.p, err.p);
       BG_LAUNCH_CHECK();
     }
     ctx->toc(n_o * (W * 8 + 64));

@@ -727,6 +727,21 @@ extern "C" int bg_seqset_fix_boundary(bg_ctx* ctx, bg_seqset* ss, const uint64_t
 
 extern "C" int bg_seqset_words(const bg_seqset* ss) { return ss ? ss->W : 0; }
 
+// The entries as rows of W+1 words (key words, then the length): the input of a sharded merge, which sends the
+// entries of several seqsets through the records exchange (biograph_merge.cpp:189-290 merges by entry).  Works on a
+// finished seqset as well as on a shard that has entries only.
+extern "C" int bg_seqset_entry_rows(bg_ctx* ctx, const bg_seqset* ss, uint64_t* d_rows) {
+  if (!ctx || !ss || (ss->n && !d_rows)) { set_error("bg_seqset_entry_rows: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (ss->n) {
+    if (!ss->keys.p || !ss->sizes.p) { set_error("bg_seqset_entry_rows: the seqset holds no keys"); return BG_EINVAL; }
+    k_records_to_rows<<<cdiv(ss->n * (ss->W + 1), 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->sizes.p, ss->n, ss->W, d_rows);
+    BG_LAUNCH_CHECK();
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
 extern "C" int bg_seqset_tail_rows(bg_ctx* ctx, const bg_seqset* ss, uint64_t* d_rows) {
   if (!ctx || !ss || (ss->n && !d_rows)) { set_error("bg_seqset_tail_rows: null argument"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));

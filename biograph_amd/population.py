@@ -1,0 +1,177 @@
+"""The population configuration (BASELINE.json configs[4]): several samples of one genome,
+each built sharded over the ranks, merged into one seqset without leaving the GPUs, and discovered per sample over
+the merged seqset with the reference cut into chunks that the ranks share out.
+
+  build    sharded.sharded_create per sample (keep_entry_rows, keep_corrected)         -> slices per rank
+  merge    sharded.sharded_merge: the samples' entries through the records exchange     -> merged slices, written
+           in place into one container (sharded.write_slices); = `biograph merge` (biograph_merge.cpp:189-290)
+  readmaps every rank opens the merged seqset (a replica: discover reads it at random) and builds each sample's
+           readmap on it from the all-gathered corrected reads.  The reference migrates the per-sample readmaps
+           through the merge maps (make_readmap.cpp:455-519); looking the reads up in the merged seqset directly
+           gives the same rows (tests/test_gpu_population.py) and needs no map exchange.
+  discover trace_ref cuts every scaffold into scaffold_split_size pieces (trace_ref.cpp:27-63), orders them
+           (trace_ref.cpp:77-105) and hands them to a thread pool; here the pieces go round-robin to the ranks, every
+           rank runs the graph-discover pipeline on its pieces (no data-path collective), the calls are gathered at
+           the end.
+
+The communicators are those of sharded.py (LocalSimComm in tests, TorchDistComm = RCCL)."""
+import torch
+
+from . import sharded
+
+
+SCAFFOLD_SPLIT_SIZE = 1_000_000  # assemble_options::scaffold_split_size (assemble.h)
+
+
+def _scaffold_order_key(name):
+    """trace_ref::assemble's order of scaffolds (trace_ref.cpp:77-105): numeric names in numeric order, then the
+    rest, shorter names first ("X", "Y" before "hs37d5"), equal lengths in DESCENDING name order."""
+    try:
+        num = int(name)
+    except ValueError:
+        num = 2 ** 31 - 1
+    return (num, len(name), tuple(-ord(c) for c in name))
+
+
+def ref_chunks(scaffolds, split_size=SCAFFOLD_SPLIT_SIZE, read_ahead_distance=0, bidir=False):
+    """The work list of trace_ref: scaffolds = [(name, start, limit)] (add_scaffold_range; limit is clipped by the
+    caller to the scaffold's end) -> [(name, start, limit)] in execution order.  With the bidirectional tracer
+    consecutive pieces overlap by read_ahead_distance (trace_ref.cpp:54-59)."""
+    if split_size <= 0:
+        raise ValueError("ref_chunks: split_size must be positive")
+    if bidir and read_ahead_distance >= split_size:
+        raise ValueError("ref_chunks: read_ahead_distance must be smaller than split_size")
+    work = []
+    for name, start, limit in scaffolds:
+        if limit < start:
+            raise ValueError("ref_chunks: scaffold %s: limit %d < start %d" % (name, limit, start))
+        a = start
+        while a < limit:
+            lim = min(limit, a + split_size)
+            work.append((name, a, lim))
+            a = min(lim, a + split_size - read_ahead_distance) if bidir else lim
+    work.sort(key=lambda w: (_scaffold_order_key(w[0]), w[1]))
+    return work
+
+
+def chunks_of_rank(work, rank, world):
+    """Round-robin: neighbouring pieces (similar cost) land on different ranks."""
+    return work[rank::world]
+
+
+def extents_of(seq):
+    """The N-free stretches of a scaffold (the reference's supercontigs): [(offset, bases)]."""
+    ext, run = [], 0
+    for i, c in enumerate(seq + "N"):
+        if c in "ACGT":
+            run += 1
+            continue
+        if run:
+            ext.append((i - run, seq[i - run:i]))
+        run = 0
+    return ext
+
+
+def discover_chunk(ss, rm, extents, start, limit, min_overlap, max_pair_distance=1000):
+    """The graph-discover pipeline (python/biograph tests' graph_discover flow; bgbinary discovery runs the same
+    calls per scaffold) on reference positions [start, limit) -> [(left_offset, right_offset, seq)] of the anchored
+    non-reference assemblies, scaffold coordinates."""
+    from . import variants as V
+    lst = V.AssemblyList().make_ref_assemblies(extents, start, limit)
+    lst.graph_trim_ref(extents).dedup().update_rc_seqset_entries(ss)
+    lst.discover_branch(ss, rm, min_overlap, "BRANCH")
+    lst.graph_trim_ref(extents).dedup().update_rc_seqset_entries(ss)
+    lst.discover_push_to_pair(ss, rm, min_overlap, max_pair_distance, "PUSH_TO_PAIR", ["BRANCH"])
+    lst.graph_trim_ref(extents).dedup().update_rc_seqset_entries(ss)
+    return [(a.left_offset, a.right_offset, a.seq) for a in lst.to_python(False)
+            if a.left_offset is not None and a.right_offset is not None and not a.matches_reference]
+
+
+def sharded_discover(comm, seqsets, readmaps, scaffolds, min_overlap, split_size=SCAFFOLD_SPLIT_SIZE,
+                     max_pair_distance=1000, gather=True):
+    """seqsets[r] = rank r's replica of the (merged) seqset, readmaps[r] = {sample: Readmap on that replica},
+    scaffolds = {name: bases}.  Work items = (sample, chunk), shared out round-robin.  Returns, on every rank,
+    {sample: [(scaffold, left, right, seq)]} sorted (gather=True), or each rank's own calls {r: {...}}."""
+    ranks = comm.local_ranks
+    samples = sorted(readmaps[ranks[0]])
+    chunks = ref_chunks([(name, 0, len(seq)) for name, seq in scaffolds.items()], split_size)
+    work = [(s, c) for s in samples for c in chunks]
+    ext = {name: extents_of(seq) for name, seq in scaffolds.items()}
+    mine = {}
+    for r in ranks:
+        calls = {s: [] for s in samples}
+        for s, (name, a, lim) in chunks_of_rank(work, r, comm.world):
+            for lo, ro, sq in discover_chunk(seqsets[r], readmaps[r][s], ext[name], a, lim, min_overlap, max_pair_distance):
+                calls[s].append((name, lo, ro, sq))
+        mine[r] = calls
+    if not gather:
+        return mine
+    every = comm.all_gather_obj(mine)[ranks[0]]
+    return {s: sorted(x for part in every for x in part[s]) for s in samples}
+
+
+def gathered_readmap(comm, ctxs, seqsets, corrected, is_paired=True):
+    """One sample's readmap on every rank's replica of the merged seqset.  corrected[r] = (words, lens, max_len) of
+    rank r's corrected reads (SeqsetSlice.corrected of sharded_create(keep_corrected=True)); read ids run through the
+    ranks in rank order, as if the shards' FASTQ files had been given to one `biograph create` one after the other."""
+    ranks = comm.local_ranks
+    W = max(row[0] for row in comm.gather_ints({r: [int(corrected[r][0].shape[1])] for r in ranks}))
+    max_len = max(row[0] for row in comm.gather_ints({r: [int(corrected[r][2])] for r in ranks}))
+
+    def widen(t):
+        if t.shape[1] == W:
+            return t
+        return torch.cat([t, torch.zeros((t.shape[0], W - t.shape[1]), dtype=t.dtype, device=t.device)], dim=1)
+
+    gw = comm.all_gather_v({r: widen(corrected[r][0]) for r in ranks})
+    gl = comm.all_gather_v({r: corrected[r][1] for r in ranks})
+    out = {}
+    for r in ranks:
+        dev = corrected[r][0].device
+        words = torch.cat([g.to(dev) for g in gw[r]])
+        lens = torch.cat([g.to(dev) for g in gl[r]])
+        reads = sharded.import_reads(ctxs[r], words, lens, max_len)
+        del words, lens
+        out[r] = ctxs[r].build_readmap(seqsets[r], reads, is_paired)
+        reads.free()
+    return out
+
+
+def population_create(comm, ctxs, sample_inputs, path, params=None, mode=None, argv=("bgbinary", "merge")):
+    """sample_inputs = {sample: inputs of sharded_create}.  Builds every sample, merges, writes the merged seqset
+    to `path` (a file all ranks of the node can open; /dev/shm for a bench) and returns
+    (per-rank replicas {r: Seqset}, {r: {sample: Readmap}}, stats)."""
+    ranks = comm.local_ranks
+    rows = {r: [] for r in ranks}
+    kept = {}
+    stats = {"samples": {}}
+    max_len = 0
+    for name in sorted(sample_inputs):
+        out = sharded.sharded_create(comm, ctxs, sample_inputs[name], params, mode=mode, gather=False,
+                                     keep_entry_rows=True, keep_corrected=True)
+        st = out[ranks[0]][1]
+        stats["samples"][name] = st
+        max_len = max(max_len, st["max_len"])
+        kept[name] = {}
+        for r in ranks:
+            sl = out[r][0]
+            rows[r].append(sl.entry_rows)
+            kept[name][r] = sl.corrected
+            sl.entry_rows = sl.corrected = None
+            sl.free()
+    merged = sharded.sharded_merge(comm, ctxs, rows, max_len, gather=False)
+    del rows
+    slices = {r: merged[r][0] for r in ranks}
+    stats["merge"] = merged[ranks[0]][1]
+    sharded.write_slices(comm, slices, path, list(argv))
+    for sl in slices.values():
+        sl.free()
+    comm.barrier()
+    replicas = {r: ctxs[r].open_seqset(path) for r in ranks}
+    readmaps = {r: {} for r in ranks}
+    for name in sorted(sample_inputs):
+        rms = gathered_readmap(comm, ctxs, replicas, kept[name])
+        kept[name] = None
+        for r in ranks:
+            readmaps[r][name] = rms[r]
+    return replicas, readmaps, stats

@@ -631,7 +631,8 @@ def write_slices(comm, slices, path, argv=()):
     comm.barrier()
 
 
-def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gather=True):
+def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gather=True, keep_entry_rows=False,
+                   keep_corrected=False):
     """comm: communicator; ctxs[r]: biograph_amd.Context of local rank r (its HIP stream must be torch's current
     stream on that device: the exchange buffers are torch tensors handed to the library by pointer); inputs[r] =
     (seq uint8 tensor, offs int64 tensor, n_reads) resident on that rank's device.  gather=True (small outputs,
@@ -775,6 +776,10 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gath
     max_len = max(comm.all_gather_obj({r: int(corrected[r].max_len) for r in ranks})[ranks[0]])
     W = max(1, (max_len + 31) // 32)
 
+    kept_reads = {}
+    if keep_corrected:  # this rank's corrected reads, packed (the readmaps of a population run are built from them)
+        for r in ranks:
+            kept_reads[r] = export_reads(ctxs[r], corrected[r], W, dev[r]) + (max_len,)
     _relieve(ctxs, dev)
     if mode == "routed":
         recv, n_records = _records_sharded_cover(comm, ctxs, corrected, W, k, dev, ph)
@@ -828,6 +833,48 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gath
         ph.mark("records_all_to_all")
         recv, _ = comm.all_to_all_v(send)
         del send
+    stats = {"n_reads": sum(row[0] for row in comm.gather_ints({r: [int(inputs[r][2])] for r in ranks})),
+             "n_bases": sum(n_bases), "n_kmers": tot_inst, "n_distinct_kmers": tot_distinct, "n_kept_kmers": n_kept,
+             "n_corrected_reads": sum(c["corrected_reads"] for c in all_cs),
+             "n_corrected_bases": sum(c["corrected_bases"] for c in all_cs), "n_records": n_records}
+    stats.update(extra_stats)
+    out = _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats, keep_entry_rows=keep_entry_rows)
+    for r in kept_reads:
+        if out[r][0] is not None:
+            out[r][0].corrected = kept_reads[r]
+    return out
+
+
+def export_reads(ctx, reads, W, device):
+    """Packed reads as tensors: (words int64 [n, W], lengths uint8 [n, 2] = little-endian u16)."""
+    n = len(reads)
+    words = torch.empty((n, W), dtype=torch.int64, device=device)
+    lens = torch.empty((n, 2), dtype=torch.uint8, device=device)
+    capi.check(capi.lib().bg_reads_export(ctx.h, reads.h, W, _ptr(words), _ptr(lens)))
+    return words, lens
+
+
+def import_reads(ctx, words, lens, max_len):
+    """The inverse of export_reads -> Reads."""
+    import biograph_amd as bg
+    h = C.c_void_p()
+    words = words.contiguous()
+    lens = lens.contiguous()
+    capi.check(capi.lib().bg_reads_import(ctx.h, words.shape[0], words.shape[1], max_len, _ptr(words), _ptr(lens), C.byref(h)))
+    return bg.Reads(ctx, h)
+
+
+def _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats, keep_entry_rows=False):
+    """The back half of a sharded build, shared with sharded_merge: per-rank record rows (already on the rank that owns
+    their leading bases) -> sorted prefix-free entries -> cross-shard boundaries -> prev bits through the tails
+    exchange -> 512-aligned slices (or, gather=True, one seqset assembled on rank 0).  recv[r] = a rows tensor or a list
+    of row tensors.  stats is completed in place (n_entries, shard_entries, tails_sent_in_full)."""
+    import biograph_amd as bg
+    L = capi.lib()
+    P = comm.world
+    ranks = comm.local_ranks
+    i64 = torch.int64
+    extra_stats = {}
     ph.mark("entries_from_records")
     shards = {}
     for r in ranks:
@@ -918,20 +965,24 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gath
         del recv
     del full
     extra_stats["tails_sent_in_full"] = _all_sum(comm, n_full)
-    part_n = comm.all_gather_obj({r: int(shards[r].size()) for r in ranks})[ranks[0]]
+    part_n = [row[0] for row in comm.gather_ints({r: [int(shards[r].size())] for r in ranks})]
     n_entries = sum(part_n)
-    stats = {"n_reads": sum(comm.all_gather_obj({r: inputs[r][2] for r in ranks})[ranks[0]]),
-             "n_bases": sum(n_bases), "n_kmers": tot_inst, "n_distinct_kmers": tot_distinct, "n_kept_kmers": n_kept,
-             "n_corrected_reads": sum(c["corrected_reads"] for c in all_cs),
-             "n_corrected_bases": sum(c["corrected_bases"] for c in all_cs), "n_records": n_records,
-             "n_entries": n_entries, "max_len": max_len, "shard_entries": part_n}
+    stats.update({"n_entries": n_entries, "max_len": max_len, "shard_entries": part_n})
     stats.update(extra_stats)
+    entry_rows = {}
+    if keep_entry_rows:  # the shard's entries as rows (W key words + length): what sharded_merge takes
+        for r in ranks:
+            n = shards[r].size()
+            t = torch.empty((n, W + 1), dtype=i64, device=dev[r])
+            capi.check(L.bg_seqset_entry_rows(ctxs[r].h, shards[r].h, _ptr(t)))
+            entry_rows[r] = t
     out = {}
     if not gather:
         ph.mark("slices")
         sl = _aligned_slices(comm, ctxs, shards, part_n, max_len, dev)
         for r in ranks:
             shards[r].free()
+            sl[r].entry_rows = entry_rows.get(r)
             out[r] = (sl[r], stats)
         ph.done()
         return out
@@ -967,3 +1018,42 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gath
         out[r] = (bg.Seqset(ctxs[r], h), stats)
     ph.done()
     return out
+
+
+def sharded_merge(comm, ctxs, entry_rows, max_len, gather=False):
+    """`biograph merge` of several samples' seqsets sharded over the ranks (SURVEY.md section 8e, configs[4];
+    biograph_merge.cpp:189-290): the merged entry set is the prefix-free maxima of the union of the inputs' entries, so
+    the inputs' entries (entry_rows[r] = list of row tensors [n, W+1], one per input: the slices' entry_rows of
+    sharded_create(keep_entry_rows=True)) go through the records exchange with common splitters and the back half of
+    the build.  Returns what sharded_create returns."""
+    L = capi.lib()
+    P = comm.world
+    ranks = comm.local_ranks
+    dev = {r: entry_rows[r][0].device for r in ranks}
+    ph = _Phases(ctxs[ranks[0]])
+    ph.mark("merge_partition")
+    rw = max(int(t.shape[1]) for r in ranks for t in entry_rows[r])
+    rw = max(row[0] for row in comm.gather_ints({r: [rw] for r in ranks}))  # seqset_merger.cpp:57-60: the longest input
+    W = rw - 1
+
+    def widen(t):  # an input of shorter entries: zero key words before the length word
+        if t.shape[1] == rw:
+            return t
+        pad = torch.zeros((t.shape[0], rw - t.shape[1]), dtype=t.dtype, device=t.device)
+        return torch.cat([t[:, :-1], pad, t[:, -1:]], dim=1)
+
+    hists, rows = {}, {}
+    for r in ranks:
+        rows[r] = torch.cat([widen(t) for t in entry_rows[r]], dim=0).contiguous()
+        hists[r] = torch.empty((4 ** PREFIX_BASES,), dtype=torch.int64, device=dev[r])
+        capi.check(L.bg_rows_prefix_hist(ctxs[r].h, _ptr(rows[r]), rows[r].shape[0], rw, PREFIX_BASES, PREFIX_SAMPLE, _ptr(hists[r])))
+    gh = comm.all_reduce_sum(hists)[ranks[0]].cpu().numpy()
+    pparams = [PREFIX_BASES] + choose_splitters(gh, P)
+    send = {r: _partition(ctxs[r], rows[r], capi.PART_PREFIX, P, pparams) for r in ranks}
+    n_in = _all_sum(comm, {r: rows[r].shape[0] for r in ranks})
+    del rows, hists
+    ph.mark("merge_all_to_all")
+    recv, _ = comm.all_to_all_v(send)
+    del send
+    stats = {"n_input_entries": n_in, "n_records": n_in, "mode": "merge"}
+    return _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats)

@@ -118,16 +118,27 @@ def plant_variants(reference, seed, g, snp_rate=0.001, indel_rate=1e-4, sv_rate=
     return out[0], out[1]
 
 
+def sample_seed(seed, sample):
+    """The seed of sample `sample` of the population config: variant_sites(G, sample_seed(seed, i) - 1) is its truth set
+    (variant_sites and plant_variants add the 1 themselves)."""
+    return seed + 10 + int(sample)
+
+
 def make_reads(genome_len=SHAPES["tiny"], coverage=30, read_len=150, seed=20261002, device="cpu", err=0.002,
                n_rate=0.0001, snp_rate=0.001, chunk_pairs=1 << 20, shard=(0, 1), return_genome=False, repeats=None,
-               indel_rate=1e-4, sv_rate=1e-6, het_frac=2.0 / 3.0, contigs=None):
+               indel_rate=1e-4, sv_rate=1e-6, het_frac=2.0 / 3.0, contigs=None, sample=None):
     """Returns (seq uint8 [n_reads*read_len], offs int64 [n_reads+1], n_reads).
 
     contigs: lengths of the contigs the genome is cut into (fragments do not span a contig end).
 
     shard=(rank, world): the same sample (genome + haplotypes from `seed`) on every rank, each rank
-    drawing its own 1/world of the read pairs (read RNG seeded with seed + 2 + 1000*rank)."""
+    drawing its own 1/world of the read pairs (read RNG seeded with seed + 2 + 1000*rank).
+
+    sample=i (population config, SURVEY.md section 8d: "4 samples from the same genome, seeds +10...+13"): the genome
+    still comes from `seed`; the sample's variants are drawn with seed + 10 + i and its reads with
+    seed + 110 + i + 1000*rank."""
     dev = torch.device(device)
+    sseed = seed if sample is None else sample_seed(seed, sample) - 1
     hap_a = make_genome(genome_len, seed, dev)
     if repeats:  # (unit_len, copies[, divergence]): a high-copy element (stress input, tools/stress_repeats.py)
         unit_len, copies = repeats[0], repeats[1]
@@ -144,9 +155,9 @@ def make_reads(genome_len=SHAPES["tiny"], coverage=30, read_len=150, seed=202610
         idx = (starts[:, None] + torch.arange(unit_len)[None, :]).reshape(-1).to(dev)
         hap_a[idx] = copies_t.reshape(-1).to(dev)
     g = torch.Generator(device=dev)
-    g.manual_seed(seed + 1)
+    g.manual_seed(sseed + 1)
     reference = hap_a
-    hap_a, hap_b = plant_variants(reference, seed, g, snp_rate, indel_rate, sv_rate, het_frac)
+    hap_a, hap_b = plant_variants(reference, sseed, g, snp_rate, indel_rate, sv_rate, het_frac)
     len_a, len_b = int(hap_a.numel()), int(hap_b.numel())
     haps = torch.zeros((2, max(len_a, len_b)), dtype=torch.uint8, device=dev)  # [2, longest haplotype]
     haps[0, :len_a] = hap_a
@@ -160,7 +171,7 @@ def make_reads(genome_len=SHAPES["tiny"], coverage=30, read_len=150, seed=202610
     n_reads = 2 * n_pairs
     out = torch.empty(n_reads * read_len, dtype=torch.uint8, device=dev)
     letters = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)  # ACGT
-    g.manual_seed(seed + 2 + 1000 * rank)
+    g.manual_seed(sseed + 2 + 1000 * rank + (0 if sample is None else 99))
     ar = torch.arange(read_len, device=dev)
     done = 0
     while done < n_pairs:

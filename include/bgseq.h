@@ -479,6 +479,9 @@ int bg_seqset_boundary_rows(bg_ctx* ctx, const bg_seqset* ss, uint64_t* h_first_
 int bg_seqset_fix_boundary(bg_ctx* ctx, bg_seqset* ss, const uint64_t* h_prev_last_row,
                            const uint64_t* h_next_first_row);
 /* prev bits across shards: tails s[1:] of own entries out, tails owned by this shard in */
+/* The entries as rows of W+1 words (key words, length): what a sharded merge exchanges (replaces the per-entry
+ * merge of biograph_merge.cpp:189-290 for seqsets that live as slices on several GPUs). */
+int bg_seqset_entry_rows(bg_ctx* ctx, const bg_seqset* ss, uint64_t* d_rows /* n*(W+1) */);
 int bg_seqset_tail_rows(bg_ctx* ctx, const bg_seqset* ss, uint64_t* d_rows /* n*(W+1) */);
 int bg_seqset_apply_tails(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows);
 /* The same with short tails: 3-word rows (the tail's two leading words, meta = len-1 | base << 8 | destination

@@ -1,0 +1,137 @@
+"""The population configuration (BASELINE.json configs[4]) with all ranks simulated on one GPU (LocalSimComm): samples
+of one genome built sharded, merged through the records exchange, readmaps built on the merged replica, discover
+shared out by reference chunk.  Parity: the sharded merge gives the single-GPU `bg_seqset_merge` (itself pinned on the
+reference's golden merged biograph, tests/test_gpu_merge.py) member for member; a readmap built on the merged seqset
+equals the sample's readmap migrated through the merge map (make_readmap.cpp:455-519); chunked discover gives the same
+calls whatever the number of ranks."""
+import numpy as np
+import pytest
+import torch
+
+import biograph_amd as bg
+from biograph_amd import population, sharded, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SEED = 31
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = bg.Context(0)
+    yield c
+    c.close()
+
+
+def _sample_inputs(G, cov, L, sample, P):
+    """Each rank's share of one sample's read pairs (the bench's generator, shard=(r, P)) + all of them in rank order."""
+    inputs, every = {}, []
+    for r in range(P):
+        seq, offs, n = synth.make_reads(genome_len=G, coverage=cov, read_len=L, seed=SEED, device="cpu", shard=(r, P),
+                                        sample=sample)
+        every += O.unpack_strings(seq.numpy(), offs.numpy().astype(np.uint64))
+        inputs[r] = (seq.cuda(), offs.cuda(), n)
+    return inputs, every
+
+
+def _single_gpu_sample(ctx, reads, prm):
+    r = ctx.pack_reads(reads)
+    ks = ctx.kmer_count(r, prm.kmer_size, prm.min_kmer_count)
+    cor, _ = ctx.correct_reads(r, ks, prm.correct.max_corrections, prm.correct.min_good_run, prm.correct.trim_after_portion)
+    ss, _ = ctx.build_seqset(cor, prm.kmer_size)
+    rm = ctx.build_readmap(ss, cor, True)
+    return ss, rm, cor
+
+
+@pytest.mark.parametrize("P,n_samples,read_lens", [(1, 2, None), (3, 4, None), (8, 3, None), (2, 2, (150, 100))])
+def test_sharded_merge_equals_single_gpu_merge(ctx, P, n_samples, read_lens):
+    """read_lens: samples of different read lengths (the merged key width is the widest input's,
+    seqset_merger.cpp:57-60)."""
+    prm = ctx.default_params()
+    comm = sharded.LocalSimComm(P)
+    ctxs = {r: ctx for r in range(P)}
+    rows = {r: [] for r in range(P)}
+    singles, max_len = [], 0
+    for s in range(n_samples):
+        L = read_lens[s] if read_lens else 150
+        inputs, every = _sample_inputs(9000, 30, L, s, P)
+        out = sharded.sharded_create(comm, ctxs, inputs, prm, gather=False, keep_entry_rows=True)
+        st = out[0][1]
+        max_len = max(max_len, st["max_len"])
+        ss, _ = ctx.create(every)
+        assert st["n_entries"] == ss.size() == sum(out[r][0].entry_rows.shape[0] for r in range(P))
+        singles.append(ss)
+        for r in range(P):
+            rows[r].append(out[r][0].entry_rows)
+            out[r][0].free()
+    want, _ = ctx.merge_seqsets(singles, want_maps=False)
+    got = sharded.sharded_merge(comm, ctxs, rows, max_len, gather=True)
+    ms, mst = got[0]
+    assert mst["n_entries"] == want.size() == ms.size() and mst["n_input_entries"] == sum(s.size() for s in singles)
+    assert want.size() > max(s.size() for s in singles)  # the samples differ: the union is larger than any of them
+    have, ref = ms.parts(), want.parts()
+    for name in bg.PART_NAMES:
+        assert have[name] == ref[name], name
+
+
+def test_population_create_readmaps_equal_migrated_readmaps(ctx, tmp_path):
+    """The whole flow at P=3: merged container written in place by the ranks, replicas opened from it, every sample's
+    readmap built on the replica by FM search from the all-gathered corrected reads == the single-GPU readmap of the
+    sample migrated onto the single-GPU merge."""
+    P, n_samples = 3, 4
+    prm = ctx.default_params()
+    comm = sharded.LocalSimComm(P)
+    ctxs = {r: ctx for r in range(P)}
+    sample_inputs, singles = {}, {}
+    for s in range(n_samples):
+        name = "sample%d" % s
+        sample_inputs[name], every = _sample_inputs(9000, 30, 150, s, P)
+        singles[name] = _single_gpu_sample(ctx, every, prm)
+    names = sorted(sample_inputs)
+    path = str(tmp_path / "merged_seqset")
+    replicas, readmaps, stats = population.population_create(comm, ctxs, sample_inputs, path, prm)
+    want, maps = ctx.merge_seqsets([singles[n][0] for n in names])
+    assert stats["merge"]["n_entries"] == want.size()
+    for r in range(P):
+        assert replicas[r].size() == want.size()
+    have, ref = replicas[0].parts(), want.parts()
+    for name in bg.PART_NAMES:
+        assert have[name] == ref[name], name
+    for i, n in enumerate(names):
+        mig = ctx.migrate_readmap(singles[n][1], maps[i], want)
+        wparts = mig.parts()
+        for r in (0, P - 1):
+            gparts = readmaps[r][n].parts()
+            for part in bg.READMAP_PART_NAMES:
+                assert gparts[part] == wparts[part], (n, r, part)
+        # and the direct build on the resident merge (lower_bound on keys) agrees with the FM search on the replica
+        direct = ctx.build_readmap(want, singles[n][2], True)
+        assert direct.parts() == wparts
+
+
+def test_sharded_discover_is_independent_of_the_rank_count(ctx):
+    """The calls of chunked discover = the union over chunks, whoever ran them; chunking itself only loses calls at
+    the piece ends (trace_ref.cpp:44-63 cuts the same way)."""
+    G = 60_000
+    seq, offs, n, genome = synth.make_reads(genome_len=G, coverage=30, read_len=150, seed=SEED, device="cpu", sample=1,
+                                            return_genome=True)
+    reads = O.unpack_strings(seq.numpy(), offs.numpy().astype(np.uint64))
+    prm = ctx.default_params()
+    ss, rm, cor = _single_gpu_sample(ctx, reads, prm)
+    ref = np.frombuffer(b"ACGT", np.uint8)[genome.numpy()].tobytes().decode()
+    scaffolds = {"1": ref[:35_000], "X": ref[35_000:]}
+    results = []
+    for P in (1, 2, 5):
+        comm = sharded.LocalSimComm(P)
+        got = population.sharded_discover(comm, {r: ss for r in range(P)}, {r: {"s": rm} for r in range(P)}, scaffolds,
+                                          min_overlap=105, split_size=10_000)
+        results.append(got["s"])
+    assert results[0] == results[1] == results[2] and len(results[0]) > 30
+    whole = population.sharded_discover(sharded.LocalSimComm(1), {0: ss}, {0: {"s": rm}}, scaffolds, min_overlap=105,
+                                        split_size=10 ** 9)["s"]
+    lost = set(whole) - set(results[0])
+    assert len(lost) <= 0.1 * len(whole)
+    # SNPs planted by the generator for sample 1 are found
+    sites = {x[1] for x in results[0] if x[0] == "1" and x[2] == x[1] + 1 and len(x[3]) == 1}
+    assert len(sites) > 10

@@ -60,3 +60,18 @@ def test_planted_variants_match_the_truth_list():
 def test_small_genomes_get_snps_only():
     ref, a, b = _haps(5000, 2)
     assert a.numel() == b.numel() == 5000 and synth.variant_sites(5000, 2) == []
+
+
+def test_population_samples_share_the_genome_and_differ_in_variants():
+    """4 samples from the same genome, seeds +10..+13."""
+    seed, G = 77, 60_000
+    outs = [synth.make_reads(G, coverage=2, read_len=100, seed=seed, sample=i, return_genome=True) for i in range(4)]
+    base = synth.make_reads(G, coverage=2, read_len=100, seed=seed, return_genome=True)
+    for o in outs:
+        assert torch.equal(o[3], base[3])  # one reference
+    seqs = [bytes(o[0].numpy().tobytes()) for o in outs]
+    assert len(set(seqs)) == 4 and bytes(base[0].numpy().tobytes()) not in seqs
+    sites = [synth.variant_sites(G, synth.sample_seed(seed, i) - 1) for i in range(4)]
+    assert len({tuple(s) for s in sites}) == 4
+    again = synth.make_reads(G, coverage=2, read_len=100, seed=seed, sample=2)
+    assert torch.equal(again[0], outs[2][0])
