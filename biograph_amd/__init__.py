@@ -202,10 +202,13 @@ class Context:
         capi.check(capi.lib().bg_seqset_build(self.h, corrected.h, cover_k, C.byref(h), C.byref(st)))
         return Seqset(self, h), st.as_dict()
 
-    def build_readmap(self, seqset, corrected, is_paired=True):
-        """make_readmap::create_from_reads (bio_mapred/make_readmap.cpp:120-392) on the GPU."""
+    def build_readmap(self, seqset, corrected, is_paired=True, marks=None):
+        """make_readmap::create_from_reads (bio_mapred/make_readmap.cpp:120-392) on the GPU.  marks (device pointer or
+        a torch uint8 tensor, one byte per entry): `seqset` is a merged seqset and the result is the sample's readmap
+        as create_from_fast_migrate would give it (bg_readmap_build_marked)."""
         h = C.c_void_p()
-        capi.check(capi.lib().bg_readmap_build(self.h, seqset.h, corrected.h, int(bool(is_paired)), C.byref(h)))
+        mp = None if marks is None else C.c_void_p(marks if isinstance(marks, int) else marks.data_ptr())
+        capi.check(capi.lib().bg_readmap_build_marked(self.h, seqset.h, corrected.h, int(bool(is_paired)), mp, C.byref(h)))
         return Readmap(self, h)
 
     # ---- whole create path --------------------------------------------------------------------

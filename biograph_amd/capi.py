@@ -60,7 +60,7 @@ SYMBOLS = [
     "bg_seqset_from_arrays", "bg_seqset_free", "bg_push_front_batch", "bg_push_front_drop_batch", "bg_find_batch",
     "bg_dev_alloc", "bg_dev_free", "bg_dev_upload", "bg_dev_download",
     "bg_trace_one_base_batch", "bg_branch_trace_batch", "bg_ref_map_build",
-    "bg_readmap_build", "bg_readmap_size", "bg_readmap_max_read_len", "bg_readmap_part", "bg_readmap_write",
+    "bg_readmap_build", "bg_readmap_build_marked", "bg_seqset_mark_inputs", "bg_readmap_size", "bg_readmap_max_read_len", "bg_readmap_part", "bg_readmap_write",
     "bg_readmap_free", "bg_create_sample", "bg_readmap_open", "bg_readmap_arrays", "bg_prefix_reads_batch",
     "bg_read_info_batch", "bg_propagate_from_end_batch", "bg_push_to_pair_trace_batch",
     "bg_seqset_merge", "bg_readmap_migrate",
@@ -155,6 +155,8 @@ def lib():
     L.bg_branch_trace_batch.argtypes = [vp, vp, u64, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp, vp, vp]
     L.bg_ref_map_build.argtypes = [vp, vp, vp, u64, vp, vp, u32, vp]
     L.bg_readmap_build.argtypes = [vp, vp, vp, i32, P(vp)]
+    L.bg_readmap_build_marked.argtypes = [vp, vp, vp, i32, vp, P(vp)]
+    L.bg_seqset_mark_inputs.argtypes = [vp, vp, vp, u64, u32, vp, P(u32)]
     L.bg_readmap_size.restype = u64
     L.bg_readmap_size.argtypes = [vp]
     L.bg_readmap_max_read_len.restype = u32

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(128) void k_rm_entry_ids(const uint64_t* __restrict
                                                      const uint64_t* __restrict__ ekeys,
                                                      const uint8_t* __restrict__ esizes, uint64_t n_ent, int EW,
                                                      const uint32_t* __restrict__ dir, int bases,
+                                                     const uint8_t* __restrict__ marks,
                                                      uint64_t* __restrict__ eid, uint32_t* __restrict__ err) {
   uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (o >= n_o) return;
@@ -54,6 +55,11 @@ __global__ __launch_bounds__(128) void k_rm_entry_ids(const uint64_t* __restrict
   if (lo >= n_ent || key_lcp(ekeys + lo * EW, esizes[lo], key, L, EW) < L) {
     atomicOr(err, 1u);  // "Read ... was not found in seqset" (make_readmap.cpp:147-151)
     lo = 0;
+  } else if (marks) {  // see bg_readmap_build_marked
+    while (!marks[lo]) {
+      ++lo;
+      if (lo >= n_ent || key_lcp(ekeys + lo * EW, esizes[lo], key, L, EW) < L) { atomicOr(err, 4u); lo = 0; break; }
+    }
   }
   eid[o] = lo;
 }
@@ -62,6 +68,7 @@ __global__ __launch_bounds__(128) void k_rm_entry_ids(const uint64_t* __restrict
 // push_front from the read's last base; the entry id is the start of the range found.
 __global__ __launch_bounds__(128) void k_rm_entry_ids_fm(SeqsetView v, const uint64_t* __restrict__ words,
                                                         const uint16_t* __restrict__ len, uint64_t n_o, int W,
+                                                        const uint8_t* __restrict__ marks,
                                                         uint64_t* __restrict__ eid, uint32_t* __restrict__ err) {
   uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (o >= n_o) return;
@@ -78,6 +85,9 @@ __global__ __launch_bounds__(128) void k_rm_entry_ids_fm(SeqsetView v, const uin
   if (rb >= re) {
     atomicOr(err, 1u);  // "Read ... was not found in seqset" (make_readmap.cpp:147-151)
     rb = 0;
+  } else if (marks) {
+    while (rb < re && !marks[rb]) ++rb;
+    if (rb >= re) { atomicOr(err, 4u); rb = 0; }
   }
   eid[o] = rb;
 }
@@ -364,6 +374,17 @@ static int bg::readmap_min_len(bg_ctx* ctx, bg_readmap* rm) {
 
 extern "C" int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads* reads, int is_paired,
                                 bg_readmap** out) {
+  return bg_readmap_build_marked(ctx, ss, reads, is_paired, nullptr, out);
+}
+
+// d_marks (one byte per entry of ss, or NULL): ss is a MERGED seqset and the bytes mark the images of the sample's own
+// entries under the merge map (bg_seqset_mark_inputs).  A read then goes to the first MARKED entry having it as a
+// prefix, which is where make_readmap::create_from_fast_migrate (make_readmap.cpp:455-519) puts it: the read's entry
+// in its sample's seqset, carried through the map.  (Sample entries with the read R as a prefix map, in order, to
+// marked entries that have R as a prefix; a marked entry with prefix R comes from a sample entry x with x and R both
+// prefixes of it, and x cannot be a proper prefix of R in a prefix-free set that covers R.)
+extern "C" int bg_readmap_build_marked(bg_ctx* ctx, const bg_seqset* ss, const bg_reads* reads, int is_paired,
+                                       const uint8_t* d_marks, bg_readmap** out) {
   if (!ctx || !ss || !reads || !out) { set_error("bg_readmap_build: null argument"); return BG_EINVAL; }
   const bool have_keys = ss->keys.p && ss->W;
   if (ss->n && !have_keys && !ss->accum[0].p) { set_error("bg_readmap_build: the seqset is not finalized"); return BG_EINVAL; }
@@ -393,12 +414,12 @@ extern "C" int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads
       BG_TRY(build_prefix_dir_keys(ctx, ss->keys.p, n_ent, EW, &dir, &bases));
       if (n_o) {
         k_rm_entry_ids<<<cdiv(n_o, 128), 128, 0, ctx->stream>>>(reads->words.p, reads->len.p, n_o, W, ss->keys.p,
-                                                                ss->sizes.p, n_ent, EW, dir.p, bases, eid.p, err.p);
+                                                                ss->sizes.p, n_ent, EW, dir.p, bases, d_marks, eid.p, err.p);
         BG_LAUNCH_CHECK();
       }
     } else if (n_o) {  // opened from a file (a replica of a merged seqset): FM search
       k_rm_entry_ids_fm<<<cdiv(n_o, 128), 128, 0, ctx->stream>>>(rm_seqset_view(ss), reads->words.p, reads->len.p, n_o, W,
-                                                                 eid.p, err.p);
+                                                                 d_marks, eid.p, err.p);
       BG_LAUNCH_CHECK();
     }
     ctx->toc(n_o * (W * 8 + 64));
@@ -546,6 +567,7 @@ extern "C" int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads
   BG_HIP(hipStreamSynchronize(ctx->stream));
   if (h_err & 1) { set_error("bg_readmap_build: a read was not found in the seqset"); return BG_EINTERNAL; }
   if (h_err & 2) { set_error("bg_readmap_build: mate loop claim failed (inconsistent rows)"); return BG_EINTERNAL; }
+  if (h_err & 4) { set_error("bg_readmap_build: a read has no marked entry (the marks are not this sample's)"); return BG_EINVAL; }
   *out = rm.release();
   return BG_OK;
 }

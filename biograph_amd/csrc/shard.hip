@@ -242,6 +242,38 @@ __global__ void k_rows_to_records(const uint64_t* __restrict__ rows, uint64_t n,
   if (w < W) rec[i * W + w] = v; else rlen[i] = uint8_t(v);
 }
 
+// A merge input's entry (a received row; last word = length | input << 8) marks the first entry of this shard that
+// has it as a prefix: the image of make_mergemap (bio_base/make_mergemap.cpp:150-220) as one byte per (input, entry).
+// An entry whose extension is not in this shard (it was dropped at the boundary as a prefix of the next shard's first
+// entry) raises the input's carry flag instead.
+__global__ __launch_bounds__(128) void k_mark_inputs(const uint64_t* __restrict__ rows, uint64_t n, int W,
+                                                     const uint64_t* __restrict__ ekeys,
+                                                     const uint8_t* __restrict__ esizes, uint64_t n_ent,
+                                                     const uint32_t* __restrict__ dir, int bases, uint32_t n_inputs,
+                                                     uint8_t* __restrict__ marks, uint32_t* __restrict__ carry,
+                                                     uint32_t* __restrict__ err) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t* key = rows + i * (W + 1);
+  const int L = int(key[W] & 0xff);
+  const uint32_t input = uint32_t((key[W] >> 8) & 0xff);
+  if (!L) return;
+  if (input >= n_inputs) { atomicOr(err, 1u); return; }
+  uint64_t lo = 0, hi = n_ent;
+  if (n_ent) {
+    uint32_t p = uint32_t(key[0] >> (64 - 2 * bases));
+    lo = dir[p];
+    hi = dir[p + 1];
+  }
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) >> 1;
+    if (key_compare(ekeys + mid * W, esizes[mid], key, L, W) < 0) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= n_ent) { atomicOr(carry + input, 1u); return; }
+  if (key_lcp(ekeys + lo * W, esizes[lo], key, L, W) < L) { atomicOr(err, 2u); return; }
+  marks[uint64_t(input) * n_ent + lo] = 1;
+}
+
 // tail row of entry i: s[1:] zero padded, last word = (len-1) | first base << 8
 __global__ void k_tail_rows(const uint64_t* __restrict__ ekeys, const uint8_t* __restrict__ sizes, uint64_t n, int W,
                             uint64_t* __restrict__ rows) {
@@ -726,6 +758,37 @@ extern "C" int bg_seqset_fix_boundary(bg_ctx* ctx, bg_seqset* ss, const uint64_t
 }
 
 extern "C" int bg_seqset_words(const bg_seqset* ss) { return ss ? ss->W : 0; }
+
+// Sharded merge: d_rows = the rows this shard received (n rows of W+1 words, last word = length | input << 8),
+// ss = the shard's entries after bg_seqset_fix_boundary.  d_marks[input * n_entries + e] = 1 when entry e is the
+// image of one of that input's entries under the merge map; h_carry[input] = 1 when an entry of the input maps past
+// the end of this shard (= to the first entry of the next non-empty shard).
+extern "C" int bg_seqset_mark_inputs(bg_ctx* ctx, const bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows,
+                                     uint32_t n_inputs, uint8_t* d_marks, uint32_t* h_carry) {
+  if (!ctx || !ss || !h_carry || (n_rows && !d_rows) || (ss->n && !d_marks)) { set_error("bg_seqset_mark_inputs: null argument"); return BG_EINVAL; }
+  if (!n_inputs || n_inputs > 256) { set_error("bg_seqset_mark_inputs: %u inputs outside 1..256", n_inputs); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  for (uint32_t i = 0; i < n_inputs; ++i) h_carry[i] = 0;
+  if (ss->n) BG_HIP(hipMemsetAsync(d_marks, 0, uint64_t(n_inputs) * ss->n, ctx->stream));
+  if (!n_rows) { BG_HIP(hipStreamSynchronize(ctx->stream)); return BG_OK; }
+  DevBuf<uint32_t> dir, flags;
+  int bases = 0;
+  BG_TRY(flags.alloc(ctx, n_inputs + 1));
+  BG_HIP(hipMemsetAsync(flags.p, 0, (n_inputs + 1) * 4, ctx->stream));
+  if (ss->n) BG_TRY(build_prefix_dir_keys(ctx, ss->keys.p, ss->n, ss->W, &dir, &bases));
+  ctx->tic("merge_mark_inputs");
+  k_mark_inputs<<<cdiv(n_rows, 128), 128, 0, ctx->stream>>>(d_rows, n_rows, ss->W, ss->keys.p, ss->sizes.p, ss->n, dir.p, bases,
+                                                          n_inputs, d_marks, flags.p, flags.p + n_inputs);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n_rows * ((ss->W + 1) * 8 + 64));
+  std::vector<uint32_t> h(n_inputs + 1);
+  BG_HIP(hipMemcpyAsync(h.data(), flags.p, (n_inputs + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h[n_inputs] & 1) { set_error("bg_seqset_mark_inputs: a row names an input >= %u", n_inputs); return BG_EINVAL; }
+  if (h[n_inputs] & 2) { set_error("bg_seqset_mark_inputs: an input entry has no extension among the merged entries"); return BG_EINTERNAL; }
+  for (uint32_t i = 0; i < n_inputs; ++i) h_carry[i] = h[i];
+  return BG_OK;
+}
 
 // The entries as rows of W+1 words (key words, then the length): the input of a sharded merge, which sends the
 // entries of several seqsets through the records exchange (biograph_merge.cpp:189-290 merges by entry).  Works on a

@@ -7,8 +7,11 @@ the merged seqset with the reference cut into chunks that the ranks share out.
            in place into one container (sharded.write_slices); = `biograph merge` (biograph_merge.cpp:189-290)
   readmaps every rank opens the merged seqset (a replica: discover reads it at random) and builds each sample's
            readmap on it from the all-gathered corrected reads.  The reference migrates the per-sample readmaps
-           through the merge maps (make_readmap.cpp:455-519); looking the reads up in the merged seqset directly
-           gives the same rows (tests/test_gpu_population.py) and needs no map exchange.
+           through the merge maps (make_readmap.cpp:455-519): a read goes to the image of ITS SAMPLE's entry, which
+           need not be the first merged entry that has the read as a prefix.  The merge therefore leaves one byte per
+           (sample, merged entry) -- "an entry of the sample maps here" (bg_seqset_mark_inputs) -- and the reads
+           are looked up among the marked entries (bg_readmap_build_marked): same rows as the migration
+           (tests/test_gpu_population.py), no per-entry map exchanged.
   discover trace_ref cuts every scaffold into scaffold_split_size pieces (trace_ref.cpp:27-63), orders them
            (trace_ref.cpp:77-105) and hands them to a thread pool; here the pieces go round-robin to the ranks, every
            rank runs the graph-discover pipeline on its pieces (no data-path collective), the calls are gathered at
@@ -110,8 +113,9 @@ def sharded_discover(comm, seqsets, readmaps, scaffolds, min_overlap, split_size
     return {s: sorted(x for part in every for x in part[s]) for s in samples}
 
 
-def gathered_readmap(comm, ctxs, seqsets, corrected, is_paired=True):
-    """One sample's readmap on every rank's replica of the merged seqset.  corrected[r] = (words, lens, max_len) of
+def gathered_readmap(comm, ctxs, seqsets, corrected, marks=None, is_paired=True):
+    """One sample's readmap on every rank's replica of the merged seqset.  marks[r] = uint8 [shard entries]: the
+    sample's row of SeqsetSlice.input_marks (None: the seqset is the sample's own).  corrected[r] = (words, lens, max_len) of
     rank r's corrected reads (SeqsetSlice.corrected of sharded_create(keep_corrected=True)); read ids run through the
     ranks in rank order, as if the shards' FASTQ files had been given to one `biograph create` one after the other."""
     ranks = comm.local_ranks
@@ -125,6 +129,7 @@ def gathered_readmap(comm, ctxs, seqsets, corrected, is_paired=True):
 
     gw = comm.all_gather_v({r: widen(corrected[r][0]) for r in ranks})
     gl = comm.all_gather_v({r: corrected[r][1] for r in ranks})
+    gm = comm.all_gather_v({r: marks[r].contiguous() for r in ranks}) if marks is not None else None
     out = {}
     for r in ranks:
         dev = corrected[r][0].device
@@ -132,8 +137,12 @@ def gathered_readmap(comm, ctxs, seqsets, corrected, is_paired=True):
         lens = torch.cat([g.to(dev) for g in gl[r]])
         reads = sharded.import_reads(ctxs[r], words, lens, max_len)
         del words, lens
-        out[r] = ctxs[r].build_readmap(seqsets[r], reads, is_paired)
+        m = torch.cat([g.to(dev) for g in gm[r]]).contiguous() if gm is not None else None
+        if m is not None and m.shape[0] != seqsets[r].size():
+            raise ValueError("gathered_readmap: %d marks for %d entries" % (m.shape[0], seqsets[r].size()))
+        out[r] = ctxs[r].build_readmap(seqsets[r], reads, is_paired, marks=m)
         reads.free()
+        del m
     return out
 
 
@@ -162,6 +171,7 @@ def population_create(comm, ctxs, sample_inputs, path, params=None, mode=None, a
     merged = sharded.sharded_merge(comm, ctxs, rows, max_len, gather=False)
     del rows
     slices = {r: merged[r][0] for r in ranks}
+    marks = {r: slices[r].input_marks[0] for r in ranks}
     stats["merge"] = merged[ranks[0]][1]
     sharded.write_slices(comm, slices, path, list(argv))
     for sl in slices.values():
@@ -169,8 +179,8 @@ def population_create(comm, ctxs, sample_inputs, path, params=None, mode=None, a
     comm.barrier()
     replicas = {r: ctxs[r].open_seqset(path) for r in ranks}
     readmaps = {r: {} for r in ranks}
-    for name in sorted(sample_inputs):
-        rms = gathered_readmap(comm, ctxs, replicas, kept[name])
+    for i, name in enumerate(sorted(sample_inputs)):  # input i of the merge = the i-th name
+        rms = gathered_readmap(comm, ctxs, replicas, kept[name], {r: marks[r][i] for r in ranks})
         kept[name] = None
         for r in ranks:
             readmaps[r][name] = rms[r]

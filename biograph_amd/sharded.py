@@ -864,11 +864,14 @@ def import_reads(ctx, words, lens, max_len):
     return bg.Reads(ctx, h)
 
 
-def _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats, keep_entry_rows=False):
+def _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats, keep_entry_rows=False, mark_inputs=0):
     """The back half of a sharded build, shared with sharded_merge: per-rank record rows (already on the rank that owns
     their leading bases) -> sorted prefix-free entries -> cross-shard boundaries -> prev bits through the tails
     exchange -> 512-aligned slices (or, gather=True, one seqset assembled on rank 0).  recv[r] = a rows tensor or a list
-    of row tensors.  stats is completed in place (n_entries, shard_entries, tails_sent_in_full)."""
+    of row tensors.  stats is completed in place (n_entries, shard_entries, tails_sent_in_full).
+    mark_inputs=n (sharded merge): the rows carry their input's number (last word, bits 8..15) and every slice comes
+    back with input_marks = (uint8 [n, shard entries], global index of the shard's first entry): the image of each
+    input's entries under the merge map, by shard (before the slices were re-aligned)."""
     import biograph_amd as bg
     L = capi.lib()
     P = comm.world
@@ -876,7 +879,7 @@ def _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats, kee
     i64 = torch.int64
     extra_stats = {}
     ph.mark("entries_from_records")
-    shards = {}
+    shards, kept_rows = {}, {}
     for r in ranks:
         rh = C.c_void_p()
         if isinstance(recv[r], list):
@@ -887,6 +890,8 @@ def _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats, kee
         else:
             rows = recv[r].contiguous()
             capi.check(L.bg_records_from_rows(ctxs[r].h, _ptr(rows), rows.shape[0], W, C.byref(rh)))
+        if mark_inputs:
+            kept_rows[r] = recv[r] if not isinstance(recv[r], list) else list(recv[r])
         recv[r] = None  # the rows are in the library now
         h = C.c_void_p()
         st = BuildStats()
@@ -916,6 +921,44 @@ def _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats, kee
         if prv is not None:
             a = np.array(prv, np.uint64)
             capi.check(L.bg_seqset_fix_boundary(ctxs[r].h, shards[r].h, capi.np_ptr(a), None))
+
+    marks = {}
+    if mark_inputs:
+        ph.mark("merge_marks")
+        carry = {}
+        for r in ranks:
+            n = shards[r].size()
+            marks[r] = torch.empty((mark_inputs, n), dtype=torch.uint8, device=dev[r])
+            carry[r] = [0] * mark_inputs
+            parts = kept_rows[r] if isinstance(kept_rows[r], list) else [kept_rows[r]]
+            first = True
+            for t in parts:
+                t = t.contiguous()
+                m = marks[r] if first else torch.empty_like(marks[r])
+                hc = (C.c_uint32 * mark_inputs)()
+                capi.check(L.bg_seqset_mark_inputs(ctxs[r].h, shards[r].h, _ptr(t), t.shape[0], mark_inputs, _ptr(m), hc))
+                if not first:
+                    marks[r] |= m
+                first = False
+                carry[r] = [a | int(b) for a, b in zip(carry[r], hc)]
+            kept_rows[r] = None
+        # an entry dropped at a shard's end as a prefix of the next shard's first entry maps to that entry
+        every = comm.gather_ints(carry)
+        sizes = [row[0] for row in comm.gather_ints({r: [int(shards[r].size())] for r in ranks})]
+        for r in ranks:
+            if not sizes[r]:
+                continue
+            q = r - 1
+            while q >= 0:
+                for i in range(mark_inputs):
+                    if every[q][i]:
+                        marks[r][i, 0] = 1
+                if sizes[q]:
+                    break
+                q -= 1
+        if any(any(every[q]) for q in range(P) if not any(sizes[q + 1:])):
+            raise RuntimeError("sharded merge: an input entry has no extension among the merged entries")
+    del kept_rows
 
     ph.mark("tails_partition")
     # ---- S5 prev bits: every entry's tail goes to the shard holding lower_bound(tail).  Short form first (the
@@ -983,6 +1026,7 @@ def _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats, kee
         for r in ranks:
             shards[r].free()
             sl[r].entry_rows = entry_rows.get(r)
+            sl[r].input_marks = (marks[r], sum(part_n[:r])) if mark_inputs else None
             out[r] = (sl[r], stats)
         ph.done()
         return out
@@ -1025,7 +1069,11 @@ def sharded_merge(comm, ctxs, entry_rows, max_len, gather=False):
     biograph_merge.cpp:189-290): the merged entry set is the prefix-free maxima of the union of the inputs' entries, so
     the inputs' entries (entry_rows[r] = list of row tensors [n, W+1], one per input: the slices' entry_rows of
     sharded_create(keep_entry_rows=True)) go through the records exchange with common splitters and the back half of
-    the build.  Returns what sharded_create returns."""
+    the build.  Returns what sharded_create returns; with gather=False every slice also carries input_marks (see
+    _records_to_output): which merged entries are the images of each input's entries, what the readmaps of the inputs
+    need to move onto the merged seqset (population.gathered_readmap)."""
+    if len(entry_rows[comm.local_ranks[0]]) > 256:
+        raise ValueError("sharded_merge: more than 256 inputs")
     L = capi.lib()
     P = comm.world
     ranks = comm.local_ranks
@@ -1045,6 +1093,10 @@ def sharded_merge(comm, ctxs, entry_rows, max_len, gather=False):
     hists, rows = {}, {}
     for r in ranks:
         rows[r] = torch.cat([widen(t) for t in entry_rows[r]], dim=0).contiguous()
+        at = 0
+        for i, t in enumerate(entry_rows[r]):  # the input's number rides in the length word (whose low byte is read)
+            rows[r][at:at + t.shape[0], -1] |= i << 8
+            at += t.shape[0]
         hists[r] = torch.empty((4 ** PREFIX_BASES,), dtype=torch.int64, device=dev[r])
         capi.check(L.bg_rows_prefix_hist(ctxs[r].h, _ptr(rows[r]), rows[r].shape[0], rw, PREFIX_BASES, PREFIX_SAMPLE, _ptr(hists[r])))
     gh = comm.all_reduce_sum(hists)[ranks[0]].cpu().numpy()
@@ -1056,4 +1108,5 @@ def sharded_merge(comm, ctxs, entry_rows, max_len, gather=False):
     recv, _ = comm.all_to_all_v(send)
     del send
     stats = {"n_input_entries": n_in, "n_records": n_in, "mode": "merge"}
-    return _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats)
+    return _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats,
+                              mark_inputs=0 if gather else len(entry_rows[ranks[0]]))

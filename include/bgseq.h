@@ -252,6 +252,12 @@ int bg_ref_map_build(bg_ctx* ctx, const bg_seqset* ss, const uint8_t* d_ref_code
 typedef struct bg_readmap bg_readmap;
 int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads* corrected, int is_paired,
                      bg_readmap** out);
+/* The same on a MERGED seqset for one of its input samples: d_marks (one byte per entry, from
+ * bg_seqset_mark_inputs; NULL = bg_readmap_build) marks the images of the sample's entries under the merge map, and
+ * every read goes to the first marked entry that has it as a prefix -- the row make_readmap::create_from_fast_migrate
+ * (bio_mapred/make_readmap.cpp:455-519) gives it.  ss may have been opened from a file (FM search instead of keys). */
+int bg_readmap_build_marked(bg_ctx* ctx, const bg_seqset* ss, const bg_reads* corrected, int is_paired,
+                            const uint8_t* d_marks, bg_readmap** out);
 uint64_t bg_readmap_size(const bg_readmap* rm);         /* readmap::size(), number of read ids */
 uint32_t bg_readmap_max_read_len(const bg_readmap* rm); /* readmap::max_read_len() */
 /* 0 for a legacy readmap that stores mates as a pair table (readmap.cpp:48-51): bg_readmap_arrays then returns the pair
@@ -479,6 +485,12 @@ int bg_seqset_boundary_rows(bg_ctx* ctx, const bg_seqset* ss, uint64_t* h_first_
 int bg_seqset_fix_boundary(bg_ctx* ctx, bg_seqset* ss, const uint64_t* h_prev_last_row,
                            const uint64_t* h_next_first_row);
 /* prev bits across shards: tails s[1:] of own entries out, tails owned by this shard in */
+/* Sharded merge (replaces make_mergemap, bio_base/make_mergemap.cpp:150-220, for inputs that live as shards):
+ * d_rows = the rows this shard received, last word = length | input << 8; d_marks[input * n + e] = 1 when entry e of
+ * the shard is the image of an entry of that input; h_carry[input] = 1 when an entry of the input maps to the first
+ * entry of the next non-empty shard. */
+int bg_seqset_mark_inputs(bg_ctx* ctx, const bg_seqset* shard, const uint64_t* d_rows, uint64_t n_rows,
+                          uint32_t n_inputs, uint8_t* d_marks /* n_inputs * n */, uint32_t* h_carry /* n_inputs */);
 /* The entries as rows of W+1 words (key words, length): what a sharded merge exchanges (replaces the per-entry
  * merge of biograph_merge.cpp:189-290 for seqsets that live as slices on several GPUs). */
 int bg_seqset_entry_rows(bg_ctx* ctx, const bg_seqset* ss, uint64_t* d_rows /* n*(W+1) */);

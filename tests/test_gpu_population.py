@@ -75,11 +75,12 @@ def test_sharded_merge_equals_single_gpu_merge(ctx, P, n_samples, read_lens):
         assert have[name] == ref[name], name
 
 
-def test_population_create_readmaps_equal_migrated_readmaps(ctx, tmp_path):
-    """The whole flow at P=3: merged container written in place by the ranks, replicas opened from it, every sample's
+@pytest.mark.parametrize("P", [1, 3])
+def test_population_create_readmaps_equal_migrated_readmaps(ctx, tmp_path, P):
+    """The whole flow: merged container written in place by the ranks, replicas opened from it, every sample's
     readmap built on the replica by FM search from the all-gathered corrected reads == the single-GPU readmap of the
     sample migrated onto the single-GPU merge."""
-    P, n_samples = 3, 4
+    n_samples = 4
     prm = ctx.default_params()
     comm = sharded.LocalSimComm(P)
     ctxs = {r: ctx for r in range(P)}
@@ -105,9 +106,42 @@ def test_population_create_readmaps_equal_migrated_readmaps(ctx, tmp_path):
             gparts = readmaps[r][n].parts()
             for part in bg.READMAP_PART_NAMES:
                 assert gparts[part] == wparts[part], (n, r, part)
-        # and the direct build on the resident merge (lower_bound on keys) agrees with the FM search on the replica
-        direct = ctx.build_readmap(want, singles[n][2], True)
-        assert direct.parts() == wparts
+
+
+def test_marked_readmap_build_equals_migration_where_plain_lookup_does_not(ctx):
+    """A read R of sample 1 whose sample entry is R+T while the merged seqset also holds R+A... from sample 2: the
+    migrated row sits on R+T (the image of the sample's entry), the first merged entry with prefix R is R+A.  The marks
+    of bg_seqset_mark_inputs select the right one, on resident keys and by FM search on an opened seqset."""
+    rng = np.random.default_rng(5)
+    core = "".join("ACGT"[x] for x in rng.integers(0, 4, 60))
+    s1 = [core + "TTGCA", core, core[5:] + "TTGCAGGA"]           # `core` alone is a read of sample 1
+    s2 = [core + "AACCG", core[3:] + "AACCGTT"]
+    prm = ctx.default_params(kmer_size=16, min_kmer_count=1)
+
+    def build(reads):
+        r = ctx.pack_reads(reads)
+        ks = ctx.kmer_count(r, prm.kmer_size, prm.min_kmer_count)
+        cor, _ = ctx.correct_reads(r, ks, prm.correct.max_corrections, prm.correct.min_good_run, prm.correct.trim_after_portion)
+        ss, _ = ctx.build_seqset(cor, prm.kmer_size)
+        return ss, ctx.build_readmap(ss, cor, False), cor
+
+    a, b = build(s1), build(s2)
+    merged, maps = ctx.merge_seqsets([a[0], b[0]])
+    mig = ctx.migrate_readmap(a[1], maps[0], merged)
+    plain = ctx.build_readmap(merged, a[2], False)
+    assert plain.parts() != mig.parts()                          # the case is real
+    marks = np.zeros(merged.size(), np.uint8)
+    marks[maps[0]] = 1
+    dm = torch.from_numpy(marks).cuda()
+    assert ctx.build_readmap(merged, a[2], False, marks=dm).parts() == mig.parts()
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        merged.write(d + "/seqset")
+        opened = ctx.open_seqset(d + "/seqset")
+        assert ctx.build_readmap(opened, a[2], False, marks=dm).parts() == mig.parts()
+        wrong = torch.zeros_like(dm)
+        with pytest.raises(bg.capi.BgError):
+            ctx.build_readmap(opened, a[2], False, marks=wrong)
 
 
 def test_sharded_discover_is_independent_of_the_rank_count(ctx):

@@ -47,3 +47,23 @@ def test_rccl_backend_world1_sharded_build(tmp_path, max_piece):
     res = json.load(open(out))
     assert res["same"] and res["same_sliced"], res
     assert res["n_entries"] == res["ref_entries"] and len(res["shards"]) == 1
+
+
+@pytest.mark.parametrize("world,backend", [(1, "gloo"), (2, "gloo"), (3, "gloo"), (1, "rccl")])
+def test_multiprocess_population(tmp_path, world, backend):
+    """configs[4] as separate processes: two samples built sharded, merged through the records exchange into one
+    container written in place, readmaps built on every process's replica, discover shared out by reference chunk.
+    Rank 0 checks against the single-GPU merge, the migrated readmaps and discover run by one rank."""
+    out = tmp_path / "result.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+           "--master-addr", "127.0.0.1", "--master-port", str(29620 + world),
+           os.path.join(ROOT, "tests", "mp_population_worker.py"), str(out)]
+    if backend == "rccl":
+        cmd.append("rccl")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.load(open(out))
+    assert res["same_seqset"] and res["same_readmaps"] and res["same_calls"], (res, r.stderr[-2000:])
+    assert res["n_entries"] == res["want_entries"] and len(res["shards"]) == world
+    assert min(res["n_calls"].values()) > 10, res
