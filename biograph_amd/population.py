@@ -146,15 +146,30 @@ def gathered_readmap(comm, ctxs, seqsets, corrected, marks=None, is_paired=True)
     return out
 
 
-def population_create(comm, ctxs, sample_inputs, path, params=None, mode=None, argv=("bgbinary", "merge")):
+def population_create(comm, ctxs, sample_inputs, path, params=None, mode=None, argv=("bgbinary", "merge"), timings=False):
     """sample_inputs = {sample: inputs of sharded_create}.  Builds every sample, merges, writes the merged seqset
     to `path` (a file all ranks of the node can open; /dev/shm for a bench) and returns
-    (per-rank replicas {r: Seqset}, {r: {sample: Readmap}}, stats)."""
+    (per-rank replicas {r: Seqset}, {r: {sample: Readmap}}, stats).  timings: stats["seconds"] = wall time of the
+    stages (device synchronised and ranks at a barrier between stages)."""
+    import time
     ranks = comm.local_ranks
     rows = {r: [] for r in ranks}
     kept = {}
-    stats = {"samples": {}}
+    stats = {"samples": {}, "seconds": {}}
     max_len = 0
+    last = [None]
+
+    def stage(name):
+        if not timings:
+            return
+        torch.cuda.synchronize()
+        comm.barrier()
+        now = time.perf_counter()
+        if last[0] is not None:
+            stats["seconds"][last[0][0]] = stats["seconds"].get(last[0][0], 0.0) + now - last[0][1]
+        last[0] = (name, now) if name else None
+
+    stage("build")
     for name in sorted(sample_inputs):
         out = sharded.sharded_create(comm, ctxs, sample_inputs[name], params, mode=mode, gather=False,
                                      keep_entry_rows=True, keep_corrected=True)
@@ -168,20 +183,25 @@ def population_create(comm, ctxs, sample_inputs, path, params=None, mode=None, a
             kept[name][r] = sl.corrected
             sl.entry_rows = sl.corrected = None
             sl.free()
+    stage("merge")
     merged = sharded.sharded_merge(comm, ctxs, rows, max_len, gather=False)
     del rows
     slices = {r: merged[r][0] for r in ranks}
     marks = {r: slices[r].input_marks[0] for r in ranks}
     stats["merge"] = merged[ranks[0]][1]
+    stage("write")
     sharded.write_slices(comm, slices, path, list(argv))
     for sl in slices.values():
         sl.free()
     comm.barrier()
+    stage("open_replicas")
     replicas = {r: ctxs[r].open_seqset(path) for r in ranks}
+    stage("readmaps")
     readmaps = {r: {} for r in ranks}
     for i, name in enumerate(sorted(sample_inputs)):  # input i of the merge = the i-th name
         rms = gathered_readmap(comm, ctxs, replicas, kept[name], {r: marks[r][i] for r in ranks})
         kept[name] = None
         for r in ranks:
             readmaps[r][name] = rms[r]
+    stage(None)
     return replicas, readmaps, stats
