@@ -119,6 +119,8 @@ class TorchDistComm:
     def gather_ints(self, vals):
         """vals[rank] = list of ints -> the lists of all ranks (one small tensor collective, no pickling)."""
         dist = self.dist
+        if self.world == 1:
+            return [[int(v) for v in vals[self.rank]]]
         mine = torch.tensor([int(v) for v in vals[self.rank]], dtype=torch.int64, device=self.device)
         out = torch.empty((self.world, mine.numel()), dtype=torch.int64, device=self.device)
         dist.all_gather_into_tensor(out, mine.view(1, -1)) if mine.numel() else None
@@ -140,32 +142,35 @@ class TorchDistComm:
 
     def _exchange(self, rows, counts, cm):
         dist = self.dist
+        if self.world == 1:  # everything stays: the rows are where they belong already (callers give `send` up)
+            return self._out(self._in(rows).contiguous())
         rows = self._in(rows).contiguous()
-        out_counts = [cm[s][self.rank] for s in range(self.world)]
+        me = self.rank
+        out_counts = [cm[s][me] for s in range(self.world)]
         row_bytes = rows.element_size()
         for d in rows.shape[1:]:
             row_bytes *= int(d)
         max_rows = max(1, self.MAX_PIECE_BYTES // max(row_bytes, 1))
-        rounds = max(1, -(-max(max(r) for r in cm) // max_rows))
+        # the piece a rank keeps never enters the collective: one device copy, and no link or RCCL channel for it
+        biggest = max(cm[s][d] for s in range(self.world) for d in range(self.world) if s != d)
+        rounds = max(1, -(-biggest // max_rows))
         starts = [0]
         for c in counts:
             starts.append(starts[-1] + c)
-        if rounds == 1:
-            out = torch.empty((sum(out_counts),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=self.device)
-            dist.all_to_all_single(out, rows, output_split_sizes=out_counts, input_split_sizes=counts)
-            return self._out(out)
-        # Several rounds.  The result keeps the single-round layout (all rows of source 0, then source 1, ...,
-        # each in the order they were sent): the presence bits of the k-mer exchange travel back by position.
         ostarts = [0]
         for c in out_counts:
             ostarts.append(ostarts[-1] + c)
         out = torch.empty((ostarts[-1],) + tuple(rows.shape[1:]), dtype=rows.dtype, device=self.device)
+        if counts[me]:
+            out[ostarts[me]: ostarts[me] + counts[me]].copy_(rows[starts[me]: starts[me] + counts[me]])
+        # The result keeps the layout "all rows of source 0, then source 1, ...", each in the order they were
+        # sent, whatever the number of rounds: the presence bits of the k-mer exchange travel back by position.
         for t in range(rounds):
             lo = t * max_rows
             ins = [rows[starts[d] + min(lo, counts[d]): starts[d] + min(lo + max_rows, counts[d])]
-                   for d in range(self.world)]
+                   if d != me else rows[:0] for d in range(self.world)]
             rcv = [out[ostarts[d] + min(lo, out_counts[d]): ostarts[d] + min(lo + max_rows, out_counts[d])]
-                   for d in range(self.world)]
+                   if d != me else out[:0] for d in range(self.world)]
             if dist.get_backend() == "nccl":
                 # RCCL: grouped send/recv on views - every piece leaves from where it lies and lands where it
                 # belongs, no staging copies of a multi-GB exchange
@@ -183,6 +188,8 @@ class TorchDistComm:
 
     def all_gather_v(self, send):
         dist = self.dist
+        if self.world == 1:
+            return {self.rank: [send[self.rank]]}
         t = self._in(send[self.rank]).contiguous()
         n = torch.tensor([t.shape[0]], dtype=torch.int64, device=self.device)
         sizes = [torch.empty_like(n) for _ in range(self.world)]
@@ -196,11 +203,15 @@ class TorchDistComm:
         return {self.rank: [self._out(outs[i][:sizes[i]]) for i in range(self.world)]}
 
     def all_gather_obj(self, send):
+        if self.world == 1:
+            return {self.rank: [send[self.rank]]}
         lst = [None] * self.world
         self.dist.all_gather_object(lst, send[self.rank])
         return {self.rank: lst}
 
     def all_reduce_sum(self, send):
+        if self.world == 1:
+            return {self.rank: send[self.rank]}
         t = self._in(send[self.rank]).clone()
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return {self.rank: self._out(t)}
