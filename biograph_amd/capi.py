@@ -59,7 +59,8 @@ SYMBOLS = [
     "bg_seqset_part", "bg_seqset_arrays", "bg_seqset_entries", "bg_seqset_write", "bg_seqset_open",
     "bg_seqset_from_arrays", "bg_seqset_free", "bg_push_front_batch", "bg_push_front_drop_batch", "bg_find_batch",
     "bg_dev_alloc", "bg_dev_free", "bg_dev_upload", "bg_dev_download",
-    "bg_trace_one_base_batch", "bg_branch_trace_batch", "bg_ref_map_build",
+    "bg_trace_one_base_batch", "bg_ref_walk_entries", "bg_tracer_extend_batch", "bg_trace_options_default",
+    "bg_push_trace", "bg_trace_result_size", "bg_trace_result_get", "bg_trace_result_stats", "bg_trace_result_free", "bg_branch_trace_batch", "bg_ref_map_build",
     "bg_readmap_build", "bg_readmap_build_marked", "bg_seqset_mark_inputs", "bg_readmap_size", "bg_readmap_max_read_len", "bg_readmap_part", "bg_readmap_write",
     "bg_readmap_free", "bg_create_sample", "bg_readmap_open", "bg_readmap_arrays", "bg_prefix_reads_batch",
     "bg_read_info_batch", "bg_propagate_from_end_batch", "bg_push_to_pair_trace_batch",
@@ -154,6 +155,17 @@ def lib():
     L.bg_trace_one_base_batch.argtypes = [vp, vp, u64] + [vp] * 15
     L.bg_branch_trace_batch.argtypes = [vp, vp, u64, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp, vp, vp]
     L.bg_ref_map_build.argtypes = [vp, vp, vp, u64, vp, vp, u32, vp]
+    L.bg_ref_walk_entries.argtypes = [vp, vp, vp, u64, i32, vp]
+    L.bg_tracer_extend_batch.argtypes = [vp, vp, vp, u64, vp, u32, vp, vp]
+    L.bg_trace_options_default.argtypes = [vp]
+    L.bg_trace_options_default.restype = None
+    L.bg_push_trace.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, i32, i32, vp, P(vp)]
+    L.bg_trace_result_size.argtypes = [vp]
+    L.bg_trace_result_size.restype = u64
+    L.bg_trace_result_get.argtypes = [vp, u64, vp]
+    L.bg_trace_result_stats.argtypes = [vp, vp]
+    L.bg_trace_result_free.argtypes = [vp]
+    L.bg_trace_result_free.restype = None
     L.bg_readmap_build.argtypes = [vp, vp, vp, i32, P(vp)]
     L.bg_readmap_build_marked.argtypes = [vp, vp, vp, i32, vp, P(vp)]
     L.bg_seqset_mark_inputs.argtypes = [vp, vp, vp, u64, u32, vp, P(u32)]

@@ -1,0 +1,919 @@
+// tracer.cpp — row f.2, first slice: the reference's production "push" tracer (modules/variants/tracer.cpp) with the
+// direction wrapper of reversable_tracer.cpp:76-145 and the pair_counter step (pair_counter.cpp), as a host state
+// machine over two device walks.
+//
+// The reference sweeps a scaffold chunk base by base; at every offset where the read-ahead range is a read it runs one
+// cost-ordered search ("trace") through the seqset and emits up to max_rejoins assemblies.  What couples one offset to
+// the next is small and computable up front:
+//   * the read-ahead itself (tracer.cpp:346-400): a chain of push_front_drop along the reference.  A chain started
+//     anywhere catches up with the sequential walk within max_read_len bases, so the chunk is walked in 1024-base
+//     chains on the device (bg_ref_walk_entries) and gives the entry id at every offset;
+//   * the sliding tables m_entry_positions / m_rc_mate_read_positions (:372-394, :402-445): at the trace of offset c
+//     they hold the offsets in [c - 1 - max_pair_distance, c - 1 + read_ahead_distance]; kept here as whole-chunk
+//     tables that are asked with the window;
+//   * m_cur_left_anchor and m_cur_ref_ambiguous_bases (:262-296, :493-503): one sequential pass over the offsets.
+// Given those, the traces of different offsets are independent (the path storage is reset per trace, :478-481), so all
+// traces of a chunk advance in lock step: every round each live trace asks for one extension
+// (bg_tracer_extend_batch: the push_front_drop fan-out of :553-554 and the run of forced steps after it) and the
+// host does the cost bookkeeping, the pairing look-ups and the queues exactly as the reference orders them
+// (std::push_heap / pop_heap on the next paths, the multiset of rejoins, dead_end_sorter).
+//
+// Not here: anchor_dropper (anchor_drop.cpp) between tracer and pair_counter -- dead-end assemblies come out as the
+// tracer emits them (right_anchor_len == 0); the pop tracer, the bidirectional tracer and everything downstream
+// (align, genotype, VCF).
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <algorithm>
+#include <deque>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "bg_internal.h"
+
+using namespace bg;
+
+extern "C" void bg_trace_options_default(bg_trace_options* o) {
+  if (!o) return;
+  o->ambiguous_branch_cost = 1;          // assemble.h:488-
+  o->rejoin_local_cost = 1;
+  o->base_cost = 1;
+  o->increase_max_between_pair_cost = 1;
+  o->max_cost = 1000 * 1000;
+  o->pairs_used_cost = -100;
+  o->traverse_ref_cost = 100 * 1000;
+  o->decrease_overlap_cost = 1000;
+  o->size_change_cost = 5;
+  o->dead_end_cost = 500 * 1000;
+  o->anchor_drop_score = -10000;
+  o->pair_match_score = 130;
+  o->min_overlap_score = 100;
+  o->max_pairs_per_read = 20;
+  o->max_next_paths = 1024;
+  o->max_ambiguous_bases = 300;
+  o->min_overlap = 100;
+  o->read_ahead_distance = 100000;
+  o->scaffold_split_size = 1000 * 1000;
+  o->max_branches_between_pairs = 2;
+  o->max_rejoins = 5;
+  o->max_bases_between_pairs = 300;
+  o->max_search_steps = 1000;
+  o->max_ambiguous_search_steps = 100;
+  o->initial_search_steps = 100;
+  o->max_search_steps_per_read = 3;
+  o->max_pair_distance = 1000;
+  o->forward_pairs_face_inward = 1;
+  o->ignore_ambiguous_ref_pairs = 1;
+  o->trace_ambiguous_ref = 0;
+  o->trace_dead_ends = 1;
+  o->only_trace_forward = 0;
+  o->trace_reference_assemblies = 0;
+  o->anchor_drop_size_multiplier = 1.5;
+}
+
+namespace {
+
+constexpr uint64_t kNoEntry = ~0ull;
+
+struct TRange {
+  uint64_t b = 0, e = 0;
+  uint32_t s = 0;
+};
+
+struct Path {  // tracer::path (tracer.h:131-157)
+  int prev = -1;
+  int64_t cost = 0;
+  uint8_t min_overlap = 0;
+  TRange range;
+  std::string seq;
+  bool part_of_assembly = false;
+  std::vector<std::pair<uint32_t, int32_t>> seen_pairs;  // (read id, offset)
+  std::vector<uint32_t> seen_read_ids;
+};
+
+struct NextPath {  // tracer::next_path (tracer.h:159-176)
+  int path = -1;
+  unsigned path_bases = 0, pushed_since_read = 0, pushed_since_pair = 0, ambiguous_bases = 0, branch_count_since_pair = 0,
+           max_between_pairs = 0, pairs_used = 0, num_reads = 0;
+  uint64_t loop_check_seqset_id = ~0ull;
+  unsigned reads_until_loop_check = 0;
+};
+
+struct Rejoin {  // tracer::rejoin (tracer.h:178-185)
+  int path = -1;
+  int64_t rejoin_cost = 0;
+  int32_t right_offset = 0x7fffffff;
+  int right_anchor_len = 0;
+  bool anchor_drop = false;
+};
+
+std::string rev_comp_str(const std::string& s) {
+  std::string o(s.rbegin(), s.rend());
+  for (char& c : o) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
+  return o;
+}
+
+}  // namespace
+
+struct bg_trace_assembly_rec {
+  int64_t left_offset = 0, right_offset = 0;
+  int left_anchor_len = 0, right_anchor_len = 0;
+  std::string seq;
+  unsigned min_overlap = 0, trace_steps = 0, left_anchor_ambiguous_bases = 0;
+  bool matches_reference = false;
+  int64_t score = 0;
+  std::vector<uint32_t> rc_read_ids, left_pair_matches, right_pair_matches;
+};
+
+struct bg_trace_result {
+  std::vector<bg_trace_assembly_rec> a;
+  bg_trace_stats stats;
+};
+
+namespace {
+
+// Everything the traces of one chunk share.
+struct World {
+  bg_ctx* ctx;
+  const bg_seqset* ss;
+  const bg_readmap* rm;
+  bg_trace_options o;
+  uint64_t n_entries = 0;
+  std::vector<uint8_t> sizes;        // entry sizes
+  std::vector<uint8_t> ref_map;      // ref_map bytes (match count = & 63)
+  std::vector<uint32_t> entry_id;    // per read id, ascending
+  std::vector<uint32_t> mate_loop;   // per read id
+  std::vector<uint8_t> is_forward;   // per read id
+  int64_t scaffold_end = 0;
+  // reads along the (oriented) scaffold: offset (after the base) -> entry, ascending by offset
+  std::vector<std::pair<int32_t, uint64_t>> position_entries;
+  std::unordered_map<uint64_t, std::vector<int32_t>> entry_positions;        // entry -> offsets, ascending
+  std::unordered_map<uint32_t, std::vector<int32_t>> rc_mate_read_positions;  // read -> offsets, ascending
+  bg_trace_stats stats;
+
+  unsigned match_count(uint64_t e) const { return ref_map[e] & 63u; }
+  std::pair<uint32_t, uint32_t> entry_to_index(uint64_t e) const {  // readmap.h:114-116
+    auto lo = std::lower_bound(entry_id.begin(), entry_id.end(), uint32_t(e));
+    auto hi = std::upper_bound(lo, entry_id.end(), uint32_t(e));
+    return {uint32_t(lo - entry_id.begin()), uint32_t(hi - entry_id.begin())};
+  }
+  bool get_bit(uint64_t e) const { auto r = entry_to_index(e); return r.first != r.second; }
+  bool is_entry(const TRange& r) const { return r.b + 1 == r.e && r.s == sizes[r.b]; }     // seqset.h:298-300
+  bool is_read(const TRange& r) const { return is_entry(r) && get_bit(r.b); }                // tracer.cpp:521-526
+  bool has_mate(uint32_t id) const { return mate_loop[mate_loop[id]] != id; }               // readmap.cpp:207-218
+  uint32_t get_mate(uint32_t id) const { return mate_loop[mate_loop[id]]; }                  // :220-239
+  uint32_t get_rev_comp(uint32_t id) const {                                                  // :248-268
+    for (int c = is_forward[id] ? 1 : 3; c; --c) id = mate_loop[id];
+    return id;
+  }
+  bool pairing_skipped(uint64_t e) const { return o.ignore_ambiguous_ref_pairs && match_count(e) > 1; }
+};
+
+// One trace (tracer::trace + trace_next_paths + output_rejoins for one offset) as a resumable machine.
+struct Trace {
+  World* w;
+  int32_t cur_offset = 0;
+  TRange cur_range;
+  std::string left_anchor;
+  unsigned ref_ambiguous_bases = 0;
+  // window of the sliding tables at this offset
+  int32_t win_lo = 0, win_hi = 0;
+
+  std::deque<Path> paths;
+  std::vector<NextPath> next_paths;
+  std::vector<Rejoin> rejoins;   // std::multiset order: worst first, best last
+  std::vector<int> dead_ends;    // std::set<const path*>: kept in allocation order
+  size_t search_steps = 0, ambiguous_steps = 0;
+  bool done = false;
+  // expansion in flight
+  bool expanding = false;
+  NextPath np;
+  bool pushed_any = false;
+  std::vector<bg_trace_assembly_rec> out;
+
+  int alloc() { paths.emplace_back(); return int(paths.size()) - 1; }
+  const bg_trace_options& o() const { return w->o; }
+
+  // ---- tables through the window
+  template <class Map, class Key>
+  static const std::vector<int32_t>* find(const Map& m, Key k) {
+    auto it = m.find(k);
+    return it == m.end() ? nullptr : &it->second;
+  }
+  bool has_rc_mate_in_range(uint32_t read_id, int64_t start, int64_t limit) const {  // tracer.cpp:466-475
+    const auto* v = find(w->rc_mate_read_positions, read_id);
+    if (!v) return false;
+    const int64_t lo = std::max<int64_t>(start, win_lo), hi = std::min<int64_t>(limit, int64_t(win_hi) + 1);
+    if (lo >= hi) return false;
+    auto it = std::lower_bound(v->begin(), v->end(), int32_t(lo));
+    return it != v->end() && *it < hi;
+  }
+
+  // ---- tracer.cpp:847-877
+  void add_base(NextPath& x, int base) {
+    Path& p = paths[x.path];
+    p.seq.push_back("ACGT"[base]);
+    ++x.pushed_since_read;
+    ++x.path_bases;
+    if (x.ambiguous_bases) ++x.ambiguous_bases;
+    p.cost += o().base_cost;
+    const unsigned overlap = p.range.s - x.pushed_since_read;
+    if (overlap < p.min_overlap) {
+      const unsigned dec = p.min_overlap - overlap;
+      p.cost += o().decrease_overlap_cost * int64_t(dec);
+      p.min_overlap = uint8_t(overlap);
+      x.max_between_pairs += dec * 2;
+    }
+    ++x.pushed_since_pair;
+    if (x.pushed_since_pair > x.max_between_pairs) {
+      ++x.max_between_pairs;
+      p.cost += o().increase_max_between_pair_cost;
+    }
+    add_pairs(x);
+  }
+
+  bool path_has_read_in_range(int start_path, uint32_t read_id, int64_t start, int64_t limit) const {  // :1129-1160
+    // (as written there: every hop re-reads the START path's pairs and length)
+    const Path& sp = paths[start_path];
+    int64_t cur_distance = 0;
+    int cur = start_path;
+    while (cur >= 0) {
+      const int64_t last_offset = int64_t(sp.seq.size());
+      for (auto it = sp.seen_pairs.rbegin(); it != sp.seen_pairs.rend(); ++it) {
+        cur_distance += last_offset - it->second;
+        if (cur_distance >= limit) return false;
+        if (cur_distance < start) continue;
+        if (it->first == read_id && cur_distance > 0) return true;
+      }
+      cur_distance += last_offset;
+      if (cur_distance >= limit) return false;
+      cur = paths[cur].prev;
+    }
+    return false;
+  }
+
+  void add_pairs(NextPath& x) {  // :737-845
+    Path& p = paths[x.path];
+    if (!w->is_read(p.range)) return;
+    const uint64_t sid = p.range.b;
+    ++x.num_reads;
+    if (x.reads_until_loop_check) {
+      --x.reads_until_loop_check;
+    } else {
+      x.loop_check_seqset_id = sid;
+      x.reads_until_loop_check = x.num_reads / 2;
+    }
+    const auto reads = w->entry_to_index(sid);
+    if (reads.first != reads.second) {
+      x.pushed_since_read = 0;
+      const unsigned ref_count = w->match_count(sid);
+      if (ref_count > 1) {
+        x.ambiguous_bases = std::max<unsigned>(x.ambiguous_bases, p.range.s);
+        if (!o().trace_ambiguous_ref) {
+          p.cost += o().max_cost;
+          ++w->stats.prune_ambiguous_ref;
+        }
+      } else if (ref_count == 1) {
+        p.cost += o().traverse_ref_cost;
+      }
+    }
+    bool matched_pair = false;
+    unsigned added_pairs = 0, added_reads = 0;
+    for (uint32_t rid = reads.first; rid != reads.second; ++rid) {
+      if (!w->has_mate(rid)) continue;
+      if (added_reads < o().max_pairs_per_read) {
+        p.seen_read_ids.push_back(rid);
+        ++added_reads;
+      }
+      if (bool(w->is_forward[rid]) == bool(o().forward_pairs_face_inward)) {
+        if (matched_pair) continue;
+        int64_t ambiguous_in_ref = 0;
+        if (x.ambiguous_bases > x.path_bases) ambiguous_in_ref = x.ambiguous_bases - x.path_bases;
+        if (has_rc_mate_in_range(rid, int64_t(cur_offset) + x.path_bases - o().max_pair_distance,
+                                 int64_t(cur_offset) - std::max<int64_t>(0, ambiguous_in_ref))) {
+          matched_pair = true;
+          continue;
+        }
+        if (path_has_read_in_range(x.path, rid, x.ambiguous_bases, o().max_pair_distance)) {
+          matched_pair = true;
+          continue;
+        }
+      } else {
+        if (added_pairs < o().max_pairs_per_read) {
+          p.seen_pairs.emplace_back(w->get_rev_comp(w->get_mate(rid)), int32_t(p.seq.size()));
+          ++added_pairs;
+          ++w->stats.found_pairs;
+        }
+        if (matched_pair) continue;
+        if (has_rc_mate_in_range(rid, cur_offset, int64_t(cur_offset) + x.path_bases + o().max_pair_distance)) {
+          matched_pair = true;
+          continue;
+        }
+      }
+    }
+    if (matched_pair) {
+      x.pushed_since_pair = 0;
+      x.branch_count_since_pair = 0;
+      x.ambiguous_bases = 0;
+      ++x.pairs_used;
+      p.cost += o().pairs_used_cost;
+      ++w->stats.matched_pairs;
+    }
+  }
+
+  // ---- queues (:879-941); the heap moves are those of libstdc++'s std::push_heap / std::pop_heap
+  void push_next_path(NextPath x) {
+    const Path& p = paths[x.path];
+    if (p.cost > o().max_cost) { ++w->stats.max_branch_cost; return; }
+    if (!rejoins.empty() && rejoins.size() >= o().max_rejoins) {
+      const unsigned worst = unsigned(paths[rejoins.front().path].cost + rejoins.front().rejoin_cost);  // "unsigned" (:888)
+      if (p.cost > int64_t(worst)) { ++w->stats.suboptimal_path_prune; return; }
+    }
+    next_paths.push_back(x);
+    std::push_heap(next_paths.begin(), next_paths.end(),
+                   [this](const NextPath& a, const NextPath& b) { return paths[a.path].cost > paths[b.path].cost; });
+    if (next_paths.size() > o().max_next_paths) {
+      next_paths.pop_back();
+      ++w->stats.next_paths_too_big;
+    }
+  }
+  NextPath pop_next_path() {
+    std::pop_heap(next_paths.begin(), next_paths.end(),
+                  [this](const NextPath& a, const NextPath& b) { return paths[a.path].cost > paths[b.path].cost; });
+    NextPath x = next_paths.back();
+    next_paths.pop_back();
+    return x;
+  }
+  int64_t total(const Rejoin& r) const { return paths[r.path].cost + r.rejoin_cost; }
+  void push_rejoin(const Rejoin& r) {
+    const int64_t t = total(r);
+    if (t > o().max_cost) { ++w->stats.max_branch_cost; return; }
+    size_t i = 0;  // multiset with "a before b when a's total is larger": equal elements go after their equals
+    while (i < rejoins.size() && total(rejoins[i]) >= t) ++i;
+    rejoins.insert(rejoins.begin() + i, r);
+    if (rejoins.size() > o().max_rejoins) rejoins.erase(rejoins.begin());
+  }
+
+  bool add_rejoins(const NextPath& x) {  // :675-724
+    const Path& p = paths[x.path];
+    if (!w->is_read(p.range)) return false;
+    const auto* v = find(w->entry_positions, p.range.b);
+    if (!v) return false;
+    int64_t best_distance = -1;
+    int32_t best_offset = -1;
+    // candidates after cur_offset, inside the read-ahead window, in the order they were inserted (ascending)
+    for (auto it = std::upper_bound(v->begin(), v->end(), cur_offset); it != v->end() && *it <= win_hi; ++it) {
+      const int64_t distance = std::llabs(int64_t(cur_offset) + x.path_bases - *it);
+      if (best_distance < 0 || distance < best_distance) { best_distance = distance; best_offset = *it; }
+    }
+    if (best_distance < 0) return false;
+    if (x.ambiguous_bases && best_distance > int64_t(x.ambiguous_bases)) { ++w->stats.extend_ambiguous_rejoin; return false; }
+    Rejoin r;
+    r.path = x.path;
+    r.rejoin_cost = o().rejoin_local_cost + best_distance * o().size_change_cost - o().traverse_ref_cost;
+    r.right_offset = best_offset;
+    r.right_anchor_len = int(p.range.s);
+    push_rejoin(r);
+    return true;
+  }
+
+  void add_dead_end_rejoin(const NextPath& x) {  // :726-735
+    if (x.num_reads <= 1 || !o().trace_dead_ends) return;
+    if (std::find(dead_ends.begin(), dead_ends.end(), x.path) == dead_ends.end()) dead_ends.push_back(x.path);
+    const Path& p = paths[x.path];
+    if (p.prev >= 0 && paths[p.prev].min_overlap == p.min_overlap) {
+      auto it = std::find(dead_ends.begin(), dead_ends.end(), p.prev);
+      if (it != dead_ends.end()) dead_ends.erase(it);
+    }
+  }
+
+  // ---- the machine.  start() / resume() return true when a query is pending in `q`.
+  bool start(bg_trace_query* q) {  // tracer::trace (:477-519)
+    if (w->match_count(cur_range.b) > 1) {
+      ++w->stats.ambiguous_ref_reads;
+      if (!o().trace_ambiguous_ref) return finish();
+    } else {
+      ++w->stats.ref_reads;
+    }
+    NextPath x;
+    x.path = alloc();
+    paths[x.path].range = cur_range;
+    paths[x.path].seq = left_anchor;
+    x.ambiguous_bases = ref_ambiguous_bases;
+    paths[x.path].min_overlap = uint8_t(left_anchor.size());
+    push_next_path(x);
+    return next_expansion(q);
+  }
+
+  bool finish() {
+    output_rejoins();
+    done = true;
+    return false;
+  }
+
+  void ask(bg_trace_query* q) {
+    const Path& p = paths[np.path];
+    q->begin = p.range.b;
+    q->end = p.range.e;
+    q->size = p.range.s;
+    q->loop_check = np.loop_check_seqset_id;
+    q->min_ctx = uint32_t(o().min_overlap) + np.pushed_since_read;
+    q->flags = pushed_any ? 1u : 0u;
+    q->max_steps = 0xffffffffu;
+  }
+
+  bool next_expansion(bg_trace_query* q) {  // trace_next_paths (:943-1021) up to the next expand_next_path
+    while (!next_paths.empty()) {
+      NextPath x = pop_next_path();
+      if (!rejoins.empty() && rejoins.size() >= o().max_rejoins && paths[x.path].cost > total(rejoins.front())) {
+        ++w->stats.suboptimal_path_prune;
+        continue;
+      }
+      if (search_steps > size_t(o().max_search_steps_per_read) * x.num_reads + o().initial_search_steps) {
+        ++w->stats.search_not_fast_enough;
+        continue;
+      }
+      if (x.ambiguous_bases > o().max_ambiguous_bases) { ++w->stats.too_many_ambiguous_bases; continue; }
+      ++w->stats.step_count;
+      ++search_steps;
+      if (search_steps > o().max_search_steps) { ++w->stats.too_many_steps; return finish(); }
+      if (ambiguous_steps > o().max_ambiguous_search_steps) { ++w->stats.too_many_ambiguous_steps; return finish(); }
+      np = x;
+      pushed_any = false;
+      expanding = true;
+      ask(q);
+      return true;
+    }
+    return finish();
+  }
+
+  // the reply to the pending query: the forced steps taken, then where the walk stopped
+  bool resume(const bg_trace_reply& r, const uint32_t* steps, bg_trace_query* q) {  // expand_next_path (:528-673)
+    for (uint32_t i = 0; i < r.n_steps; ++i) {
+      const int base = int(steps[i] & 3);
+      Path& p = paths[np.path];
+      // the range after this step: only its size matters until the last one (no read in between)
+      if (i + 1 == r.n_steps) { p.range.b = r.begin; p.range.e = r.end; p.range.s = r.size; }
+      else { p.range.b = 0; p.range.e = 0; p.range.s = steps[i] >> 8; }
+      add_base(np, base);
+      pushed_any = true;
+      if (np.pushed_since_pair > o().max_bases_between_pairs) { ++w->stats.too_far_without_pair; return next_expansion(q); }
+      if (i + 1 == r.n_steps && add_rejoins(np)) return next_expansion(q);
+    }
+    if (r.reason == BG_TRACE_STEPPED_ON_READ || r.reason == BG_TRACE_STEP_CAP) {
+      ask(q);
+      return true;
+    }
+    if (r.reason == BG_TRACE_AMBIGUOUS) ++ambiguous_steps;
+    const int new_path = np.path;
+    if (paths[new_path].prev >= 0) add_dead_end_rejoin(np);
+    unsigned lens[4];
+    int nl = 0;
+    for (int b = 0; b < 4; ++b)
+      if (r.valid_mask & (1u << b)) lens[nl++] = r.ps[b];
+    if (!nl) return next_expansion(q);
+    std::sort(lens, lens + nl);
+    unsigned unambiguous_len = lens[nl - 1];
+    if (nl > 1 && lens[nl - 2] == unambiguous_len) ++unambiguous_len;  // two with the same length: all ambiguous
+    for (int b = 0; b < 4; ++b) {
+      if (!(r.valid_mask & (1u << b))) continue;
+      NextPath x = np;
+      x.path = alloc();
+      {
+        Path& np_ = paths[x.path];
+        const Path& old = paths[new_path];
+        np_.prev = new_path;
+        np_.min_overlap = old.min_overlap;
+        np_.cost = old.cost;
+        np_.range.b = r.pb[b];
+        np_.range.e = r.pe[b];
+        np_.range.s = r.ps[b];
+      }
+      add_base(x, b);
+      if (r.ps[b] < unambiguous_len) {
+        paths[x.path].cost += o().ambiguous_branch_cost;
+        ++x.branch_count_since_pair;
+        if (x.branch_count_since_pair > o().max_branches_between_pairs) { ++w->stats.exceeded_branch_limit; continue; }
+      }
+      if (!add_rejoins(x)) push_next_path(x);
+    }
+    return next_expansion(q);
+  }
+
+  // ---- output (:1023-1250)
+  void output_assembly(const Rejoin& r) {
+    bg_trace_assembly_rec a;
+    std::string seq;
+    std::set<uint32_t> ids;
+    for (int cur = r.path; cur >= 0; cur = paths[cur].prev) {
+      Path& p = paths[cur];
+      seq += rev_comp_str(p.seq);
+      p.part_of_assembly = true;
+      ids.insert(p.seen_read_ids.begin(), p.seen_read_ids.end());
+      p.seen_read_ids.clear();
+    }
+    a.rc_read_ids.assign(ids.begin(), ids.end());
+    a.left_offset = int64_t(cur_offset) - int64_t(left_anchor.size());
+    a.left_anchor_len = int(left_anchor.size());
+    if (r.anchor_drop) {
+      a.right_offset = int32_t(cur_offset + seq.size() * o().anchor_drop_size_multiplier);
+      a.right_anchor_len = 0;
+      a.score += o().anchor_drop_score;
+    } else {
+      a.right_offset = r.right_offset;
+      a.right_anchor_len = r.right_anchor_len;
+    }
+    a.min_overlap = paths[r.path].min_overlap;
+    a.trace_steps = unsigned(search_steps);
+    a.left_anchor_ambiguous_bases = ref_ambiguous_bases;
+    a.seq = rev_comp_str(seq);
+    a.matches_reference = (a.left_anchor_len + a.right_anchor_len) >= (a.right_offset - a.left_offset) &&
+                          (a.right_offset - a.left_offset) == int64_t(a.seq.size());
+    if (a.matches_reference) a.left_anchor_len = a.right_anchor_len = 0;
+    const int64_t max_tot_anchor = std::min<int64_t>(int64_t(a.seq.size()), a.right_offset - a.left_offset);
+    if (a.right_anchor_len + a.left_anchor_len > max_tot_anchor) {
+      a.right_anchor_len = int(std::min<int64_t>(a.right_anchor_len, max_tot_anchor / 2));
+      a.left_anchor_len = int(std::min<int64_t>(a.left_anchor_len, max_tot_anchor / 2));
+    }
+    ++w->stats.output_count;
+    out.push_back(std::move(a));
+  }
+
+  bool dead_end_less(int ia, int ib) const {  // dead_end_sorter (:1062-1097)
+    for (;;) {
+      const Path &a = paths[ia], &b = paths[ib];
+      if (a.min_overlap != b.min_overlap) return a.min_overlap > b.min_overlap;
+      if (a.cost != b.cost) return a.cost < b.cost;
+      if (a.range.b != b.range.b || a.range.e != b.range.e || a.range.s != b.range.s) {
+        if (a.range.s != b.range.s) return a.range.s > b.range.s;
+        return a.range.b < b.range.b;
+      }
+      if (a.part_of_assembly != b.part_of_assembly) return b.part_of_assembly;
+      if (a.seen_pairs != b.seen_pairs) return a.seen_pairs < b.seen_pairs;
+      if (a.seen_read_ids != b.seen_read_ids) return a.seen_read_ids < b.seen_read_ids;
+      if (a.seq != b.seq) {  // dna_sequence order = base codes; A < C < G < T as characters too
+        return a.seq < b.seq;
+      }
+      if (a.prev == b.prev) return false;
+      if ((a.prev >= 0) != (b.prev >= 0)) return (a.prev >= 0) < (b.prev >= 0);
+      ia = a.prev;
+      ib = b.prev;
+    }
+  }
+
+  void output_rejoins() {
+    unsigned output_count = 0;
+    while (output_count < o().max_rejoins && !rejoins.empty()) {
+      Rejoin r = rejoins.back();
+      rejoins.pop_back();
+      if (paths[r.path].part_of_assembly) continue;
+      output_assembly(r);
+      ++output_count;
+    }
+    if (output_count >= o().max_rejoins) return;
+    const unsigned max_to_output = unsigned(o().max_rejoins) - output_count;
+    std::vector<int> de = dead_ends;
+    dead_ends.clear();
+    std::stable_sort(de.begin(), de.end(), [this](int a, int b) { return dead_end_less(a, b); });
+    output_count = 0;
+    for (int p : de) {
+      if (output_count >= max_to_output) return;
+      if (paths[p].part_of_assembly) continue;
+      Rejoin r;
+      r.path = p;
+      r.rejoin_cost = o().dead_end_cost + paths[p].cost;
+      r.anchor_drop = true;
+      output_assembly(r);
+      ++output_count;
+    }
+  }
+};
+
+struct Extent { int64_t offset; std::string seq; };
+
+int fail(const char* msg) { set_error("%s", msg); return BG_EINVAL; }
+
+// tracer::assemble(start, limit) over an already oriented scaffold -> assemblies in output order
+int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t limit,
+                std::vector<bg_trace_assembly_rec>* out) {
+  bg_ctx* ctx = w.ctx;
+  const bg_trace_options& o = w.o;
+  const int64_t max_read_len = w.ss->max_len;
+  if (limit > start + int64_t(o.scaffold_split_size)) return fail("bg_push_trace: the range is longer than scaffold_split_size");
+  // ---- 1. read ahead over [skip, limit + read_ahead_distance]
+  const int64_t skip = start - int64_t(o.max_pair_distance) - max_read_len;  // skip_ahead_to (:230)
+  const int64_t ahead_limit = limit + int64_t(o.read_ahead_distance);         // no trace looks further
+  w.position_entries.clear();
+  w.entry_positions.clear();
+  w.rc_mate_read_positions.clear();
+  int64_t prev_end = -1;
+  for (const Extent& x : ext) {
+    if (x.offset < prev_end) return fail("bg_push_trace: extents must be sorted and disjoint");
+    prev_end = x.offset + int64_t(x.seq.size());
+    int64_t lo = x.offset, hi = prev_end;  // bases [lo, hi) of this extent are walked
+    bool dup_first = false;
+    if (skip > lo && !ext.empty() && skip > ext.front().offset) {
+      // skip_ahead_to only runs when the target lies beyond the scaffold's first base (:328-330)
+      if (skip >= hi) continue;
+      lo = skip;
+      dup_first = true;  // landed inside the extent: the base is pushed twice (:341 and :362)
+    }
+    if (hi > ahead_limit) hi = ahead_limit;
+    if (lo >= hi) continue;
+    const uint64_t n = uint64_t(hi - lo);
+    std::vector<uint8_t> codes(n);
+    for (uint64_t i = 0; i < n; ++i) {
+      const char c = x.seq[size_t(lo - x.offset) + i];
+      codes[i] = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3;
+    }
+    DevBuf<uint8_t> d_codes;
+    DevBuf<uint64_t> d_ent;
+    BG_TRY(d_codes.alloc(ctx, n));
+    BG_TRY(d_ent.alloc(ctx, n));
+    BG_HIP(hipMemcpy(d_codes.p, codes.data(), n, hipMemcpyHostToDevice));
+    BG_TRY(bg_ref_walk_entries(ctx, w.ss, d_codes.p, n, dup_first ? 1 : 0, d_ent.p));
+    std::vector<uint64_t> ent(n);
+    BG_HIP(hipMemcpy(ent.data(), d_ent.p, n * 8, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; ++i) {
+      if (ent[i] == kNoEntry || !w.get_bit(ent[i])) continue;
+      const int32_t off = int32_t(lo + int64_t(i) + 1);  // the offset after the base (:365)
+      w.position_entries.emplace_back(off, ent[i]);
+      if (!w.pairing_skipped(ent[i])) {
+        const auto reads = w.entry_to_index(ent[i]);
+        for (uint32_t rid = reads.first; rid != reads.second; ++rid)
+          if (w.has_mate(rid)) w.rc_mate_read_positions[w.get_rev_comp(w.get_mate(rid))].push_back(off);
+      }
+      w.entry_positions[ent[i]].push_back(off);
+    }
+  }
+  // ---- 2. the sequential state of the sweep (:236-296): which offsets trace, with which anchor
+  std::vector<std::unique_ptr<Trace>> traces;
+  size_t pe = 0;
+  int64_t cur_offset = 0;
+  bool stop = false;
+  for (const Extent& x : ext) {
+    if (stop) break;
+    cur_offset = x.offset;
+    if (x.offset + int64_t(x.seq.size()) <= start) continue;
+    if (x.offset > limit) break;
+    size_t from = 0;
+    if (x.offset + max_read_len < start) {
+      from = size_t(start - x.offset - max_read_len);
+      cur_offset += int64_t(from);
+    }
+    size_t anchor_from = from;  // left anchor = x.seq[anchor_from, i]
+    unsigned ambiguous = 0;
+    for (size_t i = from; i < x.seq.size(); ++i) {
+      ++ambiguous;
+      if (cur_offset >= limit) { stop = true; break; }
+      ++cur_offset;
+      if (cur_offset < start) continue;
+      while (pe < w.position_entries.size() && w.position_entries[pe].first < cur_offset) ++pe;
+      if (pe >= w.position_entries.size() || w.position_entries[pe].first != cur_offset) continue;
+      const uint64_t e = w.position_entries[pe].second;
+      const uint32_t size = w.sizes[e];
+      if (i + 1 - anchor_from < size) continue;
+      anchor_from = i + 1 - size;
+      // tracer::trace (:477-503): the window check is always true here (start <= cur_offset < limit is implied by the
+      // loop above except at cur_offset == limit)
+      if (cur_offset < start || cur_offset >= limit) continue;
+      const bool ref_ambiguous = w.match_count(e) > 1;
+      std::unique_ptr<Trace> t(new Trace);
+      t->w = &w;
+      t->cur_offset = int32_t(cur_offset);
+      t->cur_range.b = e; t->cur_range.e = e + 1; t->cur_range.s = size;
+      t->left_anchor = x.seq.substr(anchor_from, size);
+      if (!ref_ambiguous) ambiguous = 0;
+      t->ref_ambiguous_bases = ambiguous;
+      t->win_lo = int32_t(cur_offset - 1 - int64_t(o.max_pair_distance));
+      t->win_hi = int32_t(cur_offset - 1 + int64_t(o.read_ahead_distance));
+      traces.push_back(std::move(t));
+    }
+  }
+  // ---- 3. all traces in lock step
+  const uint32_t step_cap = 64;
+  const size_t wave = 1 << 16;
+  for (size_t w0 = 0; w0 < traces.size(); w0 += wave) {
+    const size_t w1 = std::min(traces.size(), w0 + wave);
+    std::vector<Trace*> live;
+    std::vector<bg_trace_query> q;
+    for (size_t i = w0; i < w1; ++i) {
+      bg_trace_query qq;
+      if (traces[i]->start(&qq)) { live.push_back(traces[i].get()); q.push_back(qq); }
+    }
+    DevBuf<uint8_t> dq, dr;
+    DevBuf<uint32_t> ds;
+    std::vector<bg_trace_reply> replies;
+    std::vector<uint32_t> steps;
+    while (!live.empty()) {
+      const size_t n = live.size();
+      BG_TRY(dq.alloc(ctx, n * sizeof(bg_trace_query)));
+      BG_TRY(dr.alloc(ctx, n * sizeof(bg_trace_reply)));
+      BG_TRY(ds.alloc(ctx, n * step_cap));
+      BG_HIP(hipMemcpy(dq.p, q.data(), n * sizeof(bg_trace_query), hipMemcpyHostToDevice));
+      BG_TRY(bg_tracer_extend_batch(ctx, w.ss, w.rm, n, reinterpret_cast<const bg_trace_query*>(dq.p), step_cap,
+                                    reinterpret_cast<bg_trace_reply*>(dr.p), ds.p));
+      replies.resize(n);
+      steps.resize(n * step_cap);
+      BG_HIP(hipMemcpy(replies.data(), dr.p, n * sizeof(bg_trace_reply), hipMemcpyDeviceToHost));
+      BG_HIP(hipMemcpy(steps.data(), ds.p, n * step_cap * 4, hipMemcpyDeviceToHost));
+      ++w.stats.device_rounds;
+      w.stats.device_queries += n;
+      std::vector<Trace*> next_live;
+      std::vector<bg_trace_query> next_q;
+      for (size_t i = 0; i < n; ++i) {
+        bg_trace_query qq;
+        if (live[i]->resume(replies[i], steps.data() + i * step_cap, &qq)) { next_live.push_back(live[i]); next_q.push_back(qq); }
+      }
+      live.swap(next_live);
+      q.swap(next_q);
+    }
+    for (size_t i = w0; i < w1; ++i) {
+      for (auto& a : traces[i]->out) out->push_back(std::move(a));
+      traces[i].reset();
+    }
+  }
+  w.stats.traces += traces.size();
+  return BG_OK;
+}
+
+// pair_counter.cpp (calc_score without the coverage terms: the tracer computes no coverage)
+struct PairCounter {
+  const World& w;
+  std::vector<bg_trace_assembly_rec>* sink;
+  int64_t cur_offset = 0;
+  std::multimap<int64_t, std::vector<uint32_t>> left;
+  std::multimap<int64_t, bg_trace_assembly_rec> active, right;
+  std::unordered_map<uint32_t, int> left_ids, right_ids;
+
+  static void dec(std::unordered_map<uint32_t, int>& m, uint32_t k) { if (--m[k] == 0) m.erase(k); }
+  std::vector<uint32_t> matches(const bg_trace_assembly_rec& a, const std::unordered_map<uint32_t, int>& ids, bool forward) const {
+    std::vector<uint32_t> out;
+    for (uint32_t rid : a.rc_read_ids) {
+      if (!w.has_mate(rid) || bool(w.is_forward[rid]) != forward) continue;
+      if (ids.count(w.get_rev_comp(w.get_mate(rid)))) out.push_back(rid);
+    }
+    return out;
+  }
+  void add(bg_trace_assembly_rec a) {
+    while (advance_some(a.left_offset - int64_t(w.o.max_pair_distance))) {}
+    for (uint32_t rid : a.rc_read_ids) ++right_ids[rid];
+    const int64_t lo = a.left_offset;
+    right.emplace(lo, std::move(a));
+  }
+  void flush() { while (advance_some(0x7fffffff)) {} }
+  bool advance_some(int64_t target) {
+    if (cur_offset >= target) return false;
+    int64_t amount = target - cur_offset;
+    if (!left.empty()) amount = std::min(amount, left.begin()->first + int64_t(w.o.max_pair_distance) - cur_offset + 1);
+    if (!active.empty()) amount = std::min(amount, active.begin()->first - cur_offset + 1);
+    if (!right.empty()) amount = std::min(amount, right.begin()->first - cur_offset + 1);
+    cur_offset += amount;
+    while (!right.empty() && right.begin()->first < cur_offset) {
+      bg_trace_assembly_rec a = std::move(right.begin()->second);
+      right.erase(right.begin());
+      for (uint32_t rid : a.rc_read_ids) dec(right_ids, rid);
+      a.left_pair_matches = matches(a, left_ids, w.o.forward_pairs_face_inward != 0);
+      const int64_t ro = a.right_offset;
+      active.emplace(ro, std::move(a));
+    }
+    while (!active.empty() && active.begin()->first < cur_offset) {
+      bg_trace_assembly_rec a = std::move(active.begin()->second);
+      active.erase(active.begin());
+      a.right_pair_matches = matches(a, right_ids, w.o.forward_pairs_face_inward == 0);
+      std::vector<uint32_t> ids = std::move(a.rc_read_ids);
+      a.rc_read_ids.clear();
+      for (uint32_t rid : ids) ++left_ids[rid];
+      left.emplace(a.right_offset, std::move(ids));
+      if (a.matches_reference && !w.o.trace_reference_assemblies) continue;
+      a.score += int64_t(a.min_overlap) * w.o.min_overlap_score;
+      a.score += int64_t(a.left_pair_matches.size() + a.right_pair_matches.size()) * w.o.pair_match_score;
+      sink->push_back(std::move(a));
+    }
+    while (!left.empty() && left.begin()->first < cur_offset - int64_t(w.o.max_pair_distance)) {
+      for (uint32_t rid : left.begin()->second) dec(left_ids, rid);
+      left.erase(left.begin());
+    }
+    return true;
+  }
+};
+
+template <class T>
+int download(std::vector<T>& h, const T* d, size_t n) {
+  h.resize(n);
+  if (n) BG_HIP(hipMemcpy(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost));
+  return BG_OK;
+}
+
+}  // namespace
+
+// reversable_tracer::assemble(start, limit) (reversable_tracer.cpp:76-145) with the push tracer.
+extern "C" int bg_push_trace(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const uint8_t* d_ref_map,
+                             uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                             const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset,
+                             int rev_comp, int pair_count, const bg_trace_options* options, bg_trace_result** out) {
+  if (!ctx || !ss || !rm || !out || (n_extents && (!ext_offset || !ext_seq || !ext_len))) return fail("bg_push_trace: null argument");
+  if (ss->n && !d_ref_map) return fail("bg_push_trace: the ref_map is required (bg_ref_map_build)");
+  if (rm->n_entries != ss->n) return fail("bg_push_trace: the readmap belongs to another seqset");
+  if (rm->pair_mode) return fail("bg_push_trace: the readmap has no mate loop table");
+  if (ss->max_len > 255) return fail("bg_push_trace: reads longer than 255 bases");
+  BG_HIP(hipSetDevice(ctx->device));
+  World w;
+  w.ctx = ctx;
+  w.ss = ss;
+  w.rm = rm;
+  if (options) w.o = *options; else bg_trace_options_default(&w.o);
+  memset(&w.stats, 0, sizeof(w.stats));
+  w.n_entries = ss->n;
+  BG_TRY(download(w.sizes, ss->sizes.p, ss->n));
+  BG_TRY(download(w.ref_map, d_ref_map, ss->n));
+  BG_TRY(download(w.entry_id, rm->entry_id.p, rm->n_reads));
+  {
+    std::vector<uint64_t> tmp;
+    BG_TRY(download(tmp, rm->mate_loop_ptr.p, rm->n_reads));
+    w.mate_loop.assign(tmp.begin(), tmp.end());
+    BG_TRY(download(tmp, rm->is_forward.p, rm->n_reads));
+    w.is_forward.resize(rm->n_reads);
+    for (size_t i = 0; i < tmp.size(); ++i) w.is_forward[i] = uint8_t(tmp[i] & 1);
+  }
+  std::vector<Extent> ext;
+  int64_t calc_end = 0;
+  for (uint64_t i = 0; i < n_extents; ++i) {
+    ext.push_back(Extent{ext_offset[i], std::string(ext_seq[i], ext_len[i])});
+    for (char c : ext.back().seq)
+      if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return fail("bg_push_trace: extents hold ACGT only");
+    calc_end = std::max<int64_t>(calc_end, ext_offset[i] + int64_t(ext_len[i]));
+  }
+  if (end_pos < calc_end) return fail("bg_push_trace: end_pos lies before the end of the last extent");
+  w.scaffold_end = end_pos;
+  if (limit_offset > end_pos) limit_offset = end_pos;
+  std::unique_ptr<bg_trace_result> res(new bg_trace_result);
+  if (rev_comp && w.o.only_trace_forward) { memset(&res->stats, 0, sizeof(res->stats)); *out = res.release(); return BG_OK; }
+  std::vector<bg_trace_assembly_rec> raw;
+  if (rev_comp) {  // scaffold::rev_comp (scaffold.cpp:163-175)
+    std::vector<Extent> rc;
+    for (auto it = ext.rbegin(); it != ext.rend(); ++it)
+      rc.push_back(Extent{end_pos - it->offset - int64_t(it->seq.size()), rev_comp_str(it->seq)});
+    BG_TRY(trace_chunk(w, rc, end_pos - limit_offset, end_pos - start_offset, &raw));
+  } else {
+    BG_TRY(trace_chunk(w, ext, start_offset, limit_offset, &raw));
+  }
+  std::vector<bg_trace_assembly_rec> counted;
+  if (pair_count) {
+    PairCounter pc{w, &counted};
+    for (auto& a : raw) pc.add(std::move(a));
+    pc.flush();
+  } else {
+    counted = std::move(raw);
+  }
+  if (rev_comp) {  // reverse_assembly_in_place (assemble.cpp:933-960)
+    for (auto& a : counted) {
+      a.seq = rev_comp_str(a.seq);
+      std::swap(a.left_anchor_len, a.right_anchor_len);
+      const int64_t lo = a.left_offset, ro = a.right_offset;
+      a.left_offset = end_pos - ro;
+      a.right_offset = end_pos - lo;
+      std::swap(a.left_pair_matches, a.right_pair_matches);
+      for (auto* m : {&a.left_pair_matches, &a.right_pair_matches})
+        for (uint32_t& rid : *m) rid = w.get_rev_comp(rid);
+    }
+  }
+  res->a = std::move(counted);
+  res->stats = w.stats;
+  *out = res.release();
+  return BG_OK;
+}
+
+extern "C" uint64_t bg_trace_result_size(const bg_trace_result* r) { return r ? r->a.size() : 0; }
+extern "C" void bg_trace_result_free(bg_trace_result* r) { delete r; }
+extern "C" int bg_trace_result_stats(const bg_trace_result* r, bg_trace_stats* out) {
+  if (!r || !out) return fail("bg_trace_result_stats: null argument");
+  *out = r->stats;
+  return BG_OK;
+}
+extern "C" int bg_trace_result_get(const bg_trace_result* r, uint64_t i, bg_trace_assembly* out) {
+  if (!r || !out || i >= r->a.size()) return fail("bg_trace_result_get: bad argument");
+  const bg_trace_assembly_rec& a = r->a[i];
+  out->left_offset = a.left_offset;
+  out->right_offset = a.right_offset;
+  out->left_anchor_len = a.left_anchor_len;
+  out->right_anchor_len = a.right_anchor_len;
+  out->seq = a.seq.data();
+  out->seq_len = a.seq.size();
+  out->min_overlap = a.min_overlap;
+  out->trace_steps = a.trace_steps;
+  out->left_anchor_ambiguous_bases = a.left_anchor_ambiguous_bases;
+  out->matches_reference = a.matches_reference ? 1 : 0;
+  out->score = a.score;
+  out->rc_read_ids = a.rc_read_ids.data();
+  out->n_rc_read_ids = a.rc_read_ids.size();
+  out->left_pair_matches = a.left_pair_matches.data();
+  out->n_left_pair_matches = a.left_pair_matches.size();
+  out->right_pair_matches = a.right_pair_matches.data();
+  out->n_right_pair_matches = a.right_pair_matches.size();
+  return BG_OK;
+}

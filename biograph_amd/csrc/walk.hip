@@ -385,6 +385,83 @@ __global__ __launch_bounds__(64) void k_ref_map_chains(SeqsetView v, uint64_t nc
   }
 }
 
+// tracer::advance_read_ahead_to (variants/tracer.cpp:346-400) for one extent of a scaffold: the range after pushing
+// the complement of every base in turn, from the empty context, reduced to what the tracer keeps -- the entry id when
+// the range is exactly one full entry (seqset_range::is_seqset_entry, seqset.h:298-300), ~0 otherwise.  Chain c covers
+// positions [c * chain, ...) and warms up on the `warm` bases before them: a chain's context is always a prefix of the
+// sequential walk's and grows by one base per step until they are equal, so after max_read_len steps they are.
+// dup_first: the first base of the extent is pushed twice (tracer::skip_ahead_to pushes the base it lands on and
+// advance_read_ahead_to pushes it again, tracer.cpp:327-345).
+__global__ __launch_bounds__(64) void k_ref_walk_entries(SeqsetView v, const uint8_t* __restrict__ codes, uint64_t n,
+                                                        uint32_t chain, uint32_t warm, int dup_first,
+                                                        uint64_t* __restrict__ out) {
+  const uint64_t c = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t p0 = c * chain;
+  if (p0 >= n) return;
+  const uint64_t p1 = p0 + chain < n ? p0 + chain : n;
+  uint64_t pos = p0 >= warm ? p0 - warm : 0;
+  uint64_t b = 0, e = v.n;
+  uint32_t s = 0;
+  if (pos == 0 && dup_first) {
+    v.push_front_drop(b, e, s, 3 - (codes[0] & 3), 0, &b, &e, &s);
+    if (e <= b) { b = 0; e = v.n; s = 0; }
+  }
+  for (; pos < p1; ++pos) {
+    v.push_front_drop(b, e, s, 3 - (codes[pos] & 3), 0, &b, &e, &s);
+    if (e <= b) { b = 0; e = v.n; s = 0; if (pos >= p0) out[pos] = ~0ull; continue; }
+    if (pos >= p0) out[pos] = (b + 1 == e && s == v.sizes[b]) ? b : ~0ull;
+  }
+}
+
+// The base-by-base loop of tracer::expand_next_path (variants/tracer.cpp:545-620) for as long as it needs nothing but
+// the seqset: the four push_front_drop(complement, min_overlap + pushed_since_read) of :553-554 with the loop check of
+// :568-577, and, while exactly one of them is valid and the path has not reached a read, the step onto it.  One
+// lane per path; the host (csrc/tracer.cpp) replays the costs of the steps and does everything that touches the
+// readmap and the reference positions.
+__global__ __launch_bounds__(64) void k_tracer_extend(SeqsetView v, const uint64_t* __restrict__ has_reads, uint64_t n,
+                                                     const bg_trace_query* __restrict__ q, uint32_t step_cap,
+                                                     bg_trace_reply* __restrict__ r, uint32_t* __restrict__ steps) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bg_trace_query qq = q[i];
+  uint64_t b = qq.begin, e = qq.end;
+  uint32_t s = qq.size, min_ctx = qq.min_ctx;
+  bool pushed_any = (qq.flags & 1u) != 0;
+  const uint32_t cap = qq.max_steps < step_cap ? qq.max_steps : step_cap;
+  auto is_read = [&](uint64_t rb, uint64_t re, uint32_t rs) {
+    return rb + 1 == re && rs == v.sizes[rb] && ((has_reads[rb >> 6] >> (rb & 63)) & 1);
+  };
+  bg_trace_reply out;
+  uint32_t n_steps = 0;
+  for (;;) {
+    uint32_t valid = 0;
+    int count = 0, next = 0;
+    for (int base = 0; base < 4; ++base) {
+      uint64_t pb, pe;
+      uint32_t ps;
+      v.push_front_drop(b, e, s, 3 - base, min_ctx, &pb, &pe, &ps);
+      out.pb[base] = pb; out.pe[base] = pe; out.ps[base] = ps;
+      if (pe <= pb) continue;
+      if (pb + 1 == pe && ps == v.sizes[pb] && pb == qq.loop_check) { out.pb[base] = 0; out.pe[base] = 0; continue; }  // a loop
+      valid |= 1u << base;
+      ++count;
+      next = base;
+    }
+    out.valid_mask = valid;
+    if (count != 1) { out.reason = BG_TRACE_AMBIGUOUS; break; }
+    if (pushed_any && is_read(b, e, s)) { out.reason = BG_TRACE_AT_READ; break; }
+    if (n_steps >= cap) { out.reason = BG_TRACE_STEP_CAP; break; }
+    b = out.pb[next]; e = out.pe[next]; s = out.ps[next];
+    steps[i * step_cap + n_steps] = uint32_t(next) | (s << 8);
+    ++n_steps;
+    ++min_ctx;  // pushed_since_read grows with every base that does not land on a read
+    pushed_any = true;
+    if (is_read(b, e, s)) { out.reason = BG_TRACE_STEPPED_ON_READ; break; }
+  }
+  out.begin = b; out.end = e; out.size = s; out.n_steps = n_steps;
+  r[i] = out;
+}
+
 __global__ void k_ref_map_pack(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ flags, uint64_t n,
                                uint8_t* __restrict__ out) {
   uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -498,6 +575,41 @@ extern "C" int bg_ref_map_build(bg_ctx* ctx, const bg_seqset* ss, const uint8_t*
     k_ref_map_pack<<<cdiv(n, 256), 256, 0, ctx->stream>>>(cnt.p, flags.p, n, d_out);
     BG_LAUNCH_CHECK();
   }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+// See k_tracer_extend.  rm supplies "this entry has reads" (readmap::get_bit, bio_base/readmap.cpp:197-200).
+extern "C" int bg_tracer_extend_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n,
+                                      const bg_trace_query* d_queries, uint32_t step_cap, bg_trace_reply* d_replies,
+                                      uint32_t* d_steps) {
+  BG_TRY(check_ss(ctx, ss, "bg_tracer_extend_batch"));
+  if (!rm || (n && (!d_queries || !d_replies || !d_steps)) || !step_cap) { set_error("bg_tracer_extend_batch: null argument"); return BG_EINVAL; }
+  if (rm->n_entries != ss->n) { set_error("bg_tracer_extend_batch: the readmap belongs to another seqset"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!n) return BG_OK;
+  ctx->tic("walk_tracer_extend");
+  k_tracer_extend<<<cdiv(n, 64), 64, 0, ctx->stream>>>(make_view(ss), rm->s2m_bits.p, n, d_queries, step_cap, d_replies, d_steps);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n * 4 * 52);
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+// d_codes = the n bases (codes 0..3) of ONE extent in walking order; d_entry[i] = the full entry the read-ahead range
+// is after base i, or ~0.  See k_ref_walk_entries.
+extern "C" int bg_ref_walk_entries(bg_ctx* ctx, const bg_seqset* ss, const uint8_t* d_codes, uint64_t n, int dup_first,
+                                   uint64_t* d_entry) {
+  BG_TRY(check_ss(ctx, ss, "bg_ref_walk_entries"));
+  if (n && (!d_codes || !d_entry)) { set_error("bg_ref_walk_entries: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!n) return BG_OK;
+  const uint32_t chain = 1024, warm = ss->max_len + 1;
+  ctx->tic("walk_ref_entries");
+  k_ref_walk_entries<<<cdiv(cdiv(n, chain), 64), 64, 0, ctx->stream>>>(make_view(ss), d_codes, n, chain, warm, dup_first ? 1 : 0,
+                                                                   d_entry);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n * 52);
   BG_HIP(hipStreamSynchronize(ctx->stream));
   return BG_OK;
 }

@@ -1,0 +1,131 @@
+"""Row f.2, first slice: the reference's production push tracer behind the C ABI (csrc/tracer.cpp, kernels in
+csrc/walk.hip).  `push_trace` = reversable_tracer::assemble(start, limit) (variants/reversable_tracer.cpp:76-145 ->
+tracer::assemble, tracer.cpp:195-318) followed by pair_counter; anchor_dropper is not part of the slice.  The work
+list of a whole reference is population.ref_chunks (trace_ref.cpp:27-105)."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+_I64_FIELDS = ["ambiguous_branch_cost", "rejoin_local_cost", "base_cost", "increase_max_between_pair_cost", "max_cost",
+               "pairs_used_cost", "traverse_ref_cost", "decrease_overlap_cost", "size_change_cost", "dead_end_cost",
+               "anchor_drop_score", "pair_match_score", "min_overlap_score"]
+_U64_FIELDS = ["max_pairs_per_read", "max_next_paths", "max_ambiguous_bases", "min_overlap", "read_ahead_distance",
+               "scaffold_split_size", "max_branches_between_pairs", "max_rejoins", "max_bases_between_pairs",
+               "max_search_steps", "max_ambiguous_search_steps", "initial_search_steps", "max_search_steps_per_read",
+               "max_pair_distance"]
+_INT_FIELDS = ["forward_pairs_face_inward", "ignore_ambiguous_ref_pairs", "trace_ambiguous_ref", "trace_dead_ends",
+               "only_trace_forward", "trace_reference_assemblies"]
+
+
+class TraceOptions(C.Structure):
+    """bg_trace_options = the assemble_options the push tracer reads (variants/assemble.h:475-720)."""
+    _fields_ = ([(n, C.c_int64) for n in _I64_FIELDS] + [(n, C.c_uint64) for n in _U64_FIELDS] +
+                [(n, C.c_int) for n in _INT_FIELDS] + [("anchor_drop_size_multiplier", C.c_double)])
+
+    def __init__(self, **kw):
+        super().__init__()
+        capi.lib().bg_trace_options_default(C.byref(self))
+        for k, v in kw.items():
+            if k not in dict(self._fields_):
+                raise AttributeError("no assemble option %r" % k)
+            setattr(self, k, v)
+
+
+_STAT_FIELDS = ["traces", "ref_reads", "ambiguous_ref_reads", "step_count", "output_count", "found_pairs", "matched_pairs",
+                "max_branch_cost", "suboptimal_path_prune", "next_paths_too_big", "extend_ambiguous_rejoin",
+                "search_not_fast_enough", "too_many_ambiguous_bases", "too_many_steps", "too_many_ambiguous_steps",
+                "too_far_without_pair", "exceeded_branch_limit", "prune_ambiguous_ref", "device_rounds", "device_queries"]
+
+
+class _Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in _STAT_FIELDS]
+
+
+class _Asm(C.Structure):
+    _fields_ = [("left_offset", C.c_int64), ("right_offset", C.c_int64), ("score", C.c_int64),
+                ("left_anchor_len", C.c_int32), ("right_anchor_len", C.c_int32), ("seq", C.c_void_p), ("seq_len", C.c_uint64),
+                ("min_overlap", C.c_uint32), ("trace_steps", C.c_uint32), ("left_anchor_ambiguous_bases", C.c_uint32),
+                ("matches_reference", C.c_int32), ("rc_read_ids", C.POINTER(C.c_uint32)),
+                ("left_pair_matches", C.POINTER(C.c_uint32)), ("right_pair_matches", C.POINTER(C.c_uint32)),
+                ("n_rc_read_ids", C.c_uint64), ("n_left_pair_matches", C.c_uint64), ("n_right_pair_matches", C.c_uint64)]
+
+
+class TraceAssembly:
+    """variants::assembly as the tracer and pair_counter fill it."""
+
+    def __init__(self, a):
+        self.left_offset, self.right_offset = int(a.left_offset), int(a.right_offset)
+        self.left_anchor_len, self.right_anchor_len = int(a.left_anchor_len), int(a.right_anchor_len)
+        self.seq = C.string_at(a.seq, a.seq_len).decode() if a.seq_len else ""
+        self.min_overlap, self.trace_steps = int(a.min_overlap), int(a.trace_steps)
+        self.left_anchor_ambiguous_bases = int(a.left_anchor_ambiguous_bases)
+        self.matches_reference = bool(a.matches_reference)
+        self.score = int(a.score)
+        self.rc_read_ids = [int(a.rc_read_ids[i]) for i in range(a.n_rc_read_ids)]
+        self.left_pair_matches = [int(a.left_pair_matches[i]) for i in range(a.n_left_pair_matches)]
+        self.right_pair_matches = [int(a.right_pair_matches[i]) for i in range(a.n_right_pair_matches)]
+
+    def key(self):
+        return (self.left_offset, self.right_offset, self.left_anchor_len, self.right_anchor_len, self.seq,
+                self.matches_reference, self.min_overlap)
+
+    def __repr__(self):
+        return "TraceAssembly[%d:%d) anchors %d/%d %s%s" % (self.left_offset, self.right_offset, self.left_anchor_len,
+                                                            self.right_anchor_len, self.seq,
+                                                            " REF" if self.matches_reference else "")
+
+
+def reference_ref_map(seqset, sequences):
+    """ref_map::build over a whole reference = list of ACGT strings (N-free stretches) -> device array of n bytes
+    (DeviceArray; the caller frees it)."""
+    import biograph_amd as bg
+    ctx = seqset.ctx
+    codes = np.concatenate([np.frombuffer(s.encode(), np.uint8) for s in sequences]) if sequences else np.zeros(0, np.uint8)
+    lut = np.zeros(256, np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        lut[c] = i
+    dref = bg.DeviceArray.from_numpy(ctx, np.ascontiguousarray(lut[codes]))
+    out = bg.DeviceArray(ctx, max(seqset.size(), 1))
+    es = np.cumsum([0] + [len(s) for s in sequences[:-1]]).astype(np.uint64) if sequences else np.zeros(0, np.uint64)
+    ez = np.array([len(s) for s in sequences], np.uint64)
+    try:
+        capi.check(capi.lib().bg_ref_map_build(ctx.h, seqset.h, C.c_void_p(dref.ptr), len(ez), capi.np_ptr(es), capi.np_ptr(ez),
+                                               0, C.c_void_p(out.ptr)))
+    finally:
+        dref.free()
+    return out
+
+
+def push_trace(seqset, readmap, ref_map, extents, start=0, limit=None, end_pos=None, rev_comp=False, pair_count=True,
+               options=None, with_stats=False):
+    """extents = [(offset, ACGT string)] of one scaffold, ascending; ref_map = reference_ref_map(...).
+    -> [TraceAssembly] in output order (and the stats dict)."""
+    L = capi.lib()
+    ctx = seqset.ctx
+    n = len(extents)
+    offs = (C.c_int64 * max(n, 1))(*[int(o) for o, _ in extents])
+    bufs = [s.encode() for _, s in extents]
+    ptrs = (C.c_char_p * max(n, 1))(*bufs)
+    lens = (C.c_uint64 * max(n, 1))(*[len(b) for b in bufs])
+    calc_end = max([o + len(s) for o, s in extents] + [0])
+    end_pos = calc_end if end_pos is None else end_pos
+    limit = end_pos if limit is None else limit
+    opt = options if options is not None else TraceOptions()
+    h = C.c_void_p()
+    capi.check(L.bg_push_trace(ctx.h, seqset.h, readmap.h, C.c_void_p(ref_map.ptr), n, offs, ptrs, lens, end_pos, start, limit,
+                               int(bool(rev_comp)), int(bool(pair_count)), C.byref(opt), C.byref(h)))
+    try:
+        out = []
+        a = _Asm()
+        for i in range(L.bg_trace_result_size(h)):
+            capi.check(L.bg_trace_result_get(h, i, C.byref(a)))
+            out.append(TraceAssembly(a))
+        if not with_stats:
+            return out
+        st = _Stats()
+        capi.check(L.bg_trace_result_stats(h, C.byref(st)))
+        return out, {k: int(getattr(st, k)) for k in _STAT_FIELDS}
+    finally:
+        L.bg_trace_result_free(h)

@@ -355,6 +355,77 @@ int bg_discover_push_to_pair(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap*
                              uint32_t min_overlap, int64_t max_pair_distance, const char* tag,
                              const char* discover_tags_csv);
 
+/* ---- row f.2, first slice: the production "push" tracer (modules/variants/tracer.cpp) --------------------------
+ * Device part 1: tracer::advance_read_ahead_to (tracer.cpp:346-400) over one extent: d_entry[i] = the seqset entry the
+ * read-ahead range is after base i when it is exactly one full entry, else ~0.  dup_first reproduces the double push
+ * after tracer::skip_ahead_to (tracer.cpp:327-345). */
+int bg_ref_walk_entries(bg_ctx* ctx, const bg_seqset* ss, const uint8_t* d_codes, uint64_t n, int dup_first,
+                        uint64_t* d_entry);
+/* Device part 2: the inner loop of tracer::expand_next_path (tracer.cpp:545-620) for a batch of paths, as far as it
+ * depends on the seqset only. */
+typedef struct bg_trace_query {
+  uint64_t begin, end;   /* the path's range */
+  uint64_t loop_check;   /* next_path::loop_check_seqset_id (~0 = none) */
+  uint32_t size;
+  uint32_t min_ctx;      /* assemble_options::min_overlap + next_path::pushed_since_read */
+  uint32_t flags;        /* bit 0: pushed_any */
+  uint32_t max_steps;
+} bg_trace_query;
+enum { BG_TRACE_AMBIGUOUS = 0, BG_TRACE_AT_READ = 1, BG_TRACE_STEPPED_ON_READ = 2, BG_TRACE_STEP_CAP = 3 };
+typedef struct bg_trace_reply {
+  uint64_t begin, end;   /* the range after the steps taken */
+  uint64_t pb[4], pe[4]; /* where it stopped: the four pushes (valid_mask says which exist; loops removed) */
+  uint32_t ps[4];
+  uint32_t size, n_steps, reason, valid_mask;
+} bg_trace_reply;
+int bg_tracer_extend_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n,
+                           const bg_trace_query* d_queries, uint32_t step_cap, bg_trace_reply* d_replies,
+                           uint32_t* d_steps /* n * step_cap: base | size << 8 per step */);
+/* Host part (csrc/tracer.cpp): reversable_tracer::assemble(start, limit) with the push tracer
+ * (variants/reversable_tracer.cpp:76-145 -> tracer::assemble, tracer.cpp:195-318) followed by pair_counter
+ * (pair_counter.cpp); anchor_dropper is not part of this slice.  Fields = assemble_options (assemble.h:475-720). */
+typedef struct bg_trace_options {
+  int64_t ambiguous_branch_cost, rejoin_local_cost, base_cost, increase_max_between_pair_cost, max_cost, pairs_used_cost,
+      traverse_ref_cost, decrease_overlap_cost, size_change_cost, dead_end_cost, anchor_drop_score, pair_match_score,
+      min_overlap_score;
+  uint64_t max_pairs_per_read, max_next_paths, max_ambiguous_bases, min_overlap, read_ahead_distance, scaffold_split_size,
+      max_branches_between_pairs, max_rejoins, max_bases_between_pairs, max_search_steps, max_ambiguous_search_steps,
+      initial_search_steps, max_search_steps_per_read, max_pair_distance;
+  int forward_pairs_face_inward, ignore_ambiguous_ref_pairs, trace_ambiguous_ref, trace_dead_ends, only_trace_forward,
+      trace_reference_assemblies;
+  double anchor_drop_size_multiplier;
+} bg_trace_options;
+void bg_trace_options_default(bg_trace_options* o);
+typedef struct bg_trace_stats {  /* assemble_stats of the tracer + the device rounds this implementation took */
+  uint64_t traces, ref_reads, ambiguous_ref_reads, step_count, output_count, found_pairs, matched_pairs, max_branch_cost,
+      suboptimal_path_prune, next_paths_too_big, extend_ambiguous_rejoin, search_not_fast_enough, too_many_ambiguous_bases,
+      too_many_steps, too_many_ambiguous_steps, too_far_without_pair, exceeded_branch_limit, prune_ambiguous_ref,
+      device_rounds, device_queries;
+} bg_trace_stats;
+typedef struct bg_trace_assembly {  /* variants::assembly as the tracer and pair_counter fill it (assemble.h:285-380) */
+  int64_t left_offset, right_offset, score;
+  int32_t left_anchor_len, right_anchor_len;
+  const char* seq;
+  uint64_t seq_len;
+  uint32_t min_overlap, trace_steps, left_anchor_ambiguous_bases;
+  int32_t matches_reference;
+  const uint32_t *rc_read_ids, *left_pair_matches, *right_pair_matches;  /* rc_read_ids is empty after pair_count */
+  uint64_t n_rc_read_ids, n_left_pair_matches, n_right_pair_matches;
+} bg_trace_assembly;
+typedef struct bg_trace_result bg_trace_result;
+/* Extents: the N-free stretches of the scaffold in scaffold coordinates, ascending; end_pos = scaffold::end_pos().
+ * d_ref_map = bg_ref_map_build over the whole reference.  rev_comp: trace the reverse strand and report in forward
+ * coordinates (reverse_assembly_in_place, assemble.cpp:933-960).  limit_offset - start_offset <= scaffold_split_size. */
+int bg_push_trace(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const uint8_t* d_ref_map, uint64_t n_extents,
+                  const int64_t* ext_offset, const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos,
+                  int64_t start_offset, int64_t limit_offset, int rev_comp, int pair_count,
+                  const bg_trace_options* options /* NULL = defaults */, bg_trace_result** out);
+uint64_t bg_trace_result_size(const bg_trace_result* r);
+int bg_trace_result_get(const bg_trace_result* r, uint64_t i, bg_trace_assembly* out);  /* pointers live as long as r */
+int bg_trace_result_stats(const bg_trace_result* r, bg_trace_stats* out);
+void bg_trace_result_free(bg_trace_result* r);
+
+
 /* ---- Merge: `biograph merge` = seqset_flat + make_mergemap + seqset_merger
  * (modules/biograph/biograph_merge.cpp:189-290, bio_base/make_mergemap.cpp:150-220,
  * seqset_merger.cpp:50-185).  The merged seqset holds the prefix-free maxima of the union of the

@@ -472,7 +472,7 @@ class Tracer:
         np_.new_path.range = self.cur_range
         np_.new_path.seq = self.cur_left_anchor
         np_.ambiguous_bases = self.cur_ref_ambiguous_bases
-        np_.new_path.min_overlap = len(self.cur_left_anchor)
+        np_.new_path.min_overlap = len(self.cur_left_anchor) & 0xFF  # path::min_overlap is a uint8_t (tracer.h:135)
         self._push_next_path(np_)
         self._trace_next_paths()
 
