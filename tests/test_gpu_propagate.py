@@ -136,6 +136,11 @@ def test_open_legacy_readmap_and_seqset(world, golden_dir):
     # unpaired: nobody has a mate; rev_comp is the loop partner
     info = ss.read_info_batch(rm, list(range(0, 16888, 211)))
     assert all(not hm and ml[i] == rc for (hm, _, rc, _), i in zip(info, range(0, 16888, 211)))
-    with pytest.raises(bg.BgError) as err:   # mate_pair_ptr-only readmaps need `biograph upgrade`
-        ctx.open_readmap(golden_dir + "/e_coli_merged/readmap_e_coli_test")
+    # a mate_pair_ptr-only readmap opens (pairing queries work on it), but what needs the mate loop table says what
+    # readmap::get_rev_comp says (bio_base/readmap.cpp:248-253)
+    legacy = ctx.open_readmap(golden_dir + "/e_coli_merged/readmap_e_coli_test")
+    assert legacy.size() > 0
+    merged = ctx.open_seqset(golden_dir + "/e_coli_merged/seqset")
+    with pytest.raises(bg.BgError) as err:
+        merged.read_info_batch(legacy, [0])
     assert "upgrade" in str(err.value)
