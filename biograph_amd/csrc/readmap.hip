@@ -398,7 +398,9 @@ extern "C" int bg_readmap_build_marked(bg_ctx* ctx, const bg_seqset* ss, const b
   rm->ctx = ctx;
   rm->n_entries = n_ent;
   rm->seqset_uuid = ss->uuid;
-  rm->max_read_len = ss->max_len;  // seqset::max_read_len() (biograph_create.cpp:825)
+  // seqset::max_read_len() of the sample's own seqset (biograph_create.cpp:825) = its longest read; a migrated readmap
+  // keeps that value on the merged seqset (make_readmap.cpp:459-461)
+  rm->max_read_len = d_marks ? reads->max_len : ss->max_len;
   DevBuf<uint32_t> err;
   BG_TRY(err.alloc(ctx, 1));
   BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
