@@ -2,7 +2,7 @@
 // (modules/biograph/biograph_create.cpp:258-335 flags, :516-527 output layout) and the reference-map
 // stage of `bgbinary discovery` (modules/biograph/biograph_variants.cpp:642-667).
 //
-//   bgbinary create --reads X.fq[.gz] [--pair Y.fq] [--interleaved] [--ref DIR] --out S.bg [--id ID] [-f]
+//   bgbinary create --reads X.fq[.gz]|X.bam [--pair Y.fq] [--interleaved] [--ref DIR] --out S.bg [--id ID] [-f]
 //                   [--kmer-size 30] [--min-kmer-count 5] [--trim-after-portion 0.7]
 //                   [--max-corrections 8] [--min-good-run 2] [--min-reads 0.4] [--warn-reads 0.7] [--stats FILE]
 //   bgbinary refmap --in S.bg --ref DIR|FASTA --out FILE          (ref_map::build -> one byte per entry)
@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../../include/bgseq.h"
@@ -123,6 +124,110 @@ static void free_text(HostText* t) {
   std::string().swap(t->inflated);
 }
 
+// ---- BAM input (read_importer.cpp:182-264,387-470 without htslib).  A BAM file is a BGZF stream, i.e. concatenated
+// gzip members, which zlib's gzread inflates as one stream (load_text); the records are decoded here into the FASTQ text
+// the GPU importer takes: secondary / supplementary alignments are skipped, a read aligned to the reverse strand is
+// turned back (reverse_complement_iupac_string, dna_base_set.cpp:79-94), paired reads are matched by name through a
+// cache shared by all input files (the later mate first, as add_paired_read receives them), and paired reads whose mate
+// never shows up are treated as unpaired ("entries remaining in pair cache").  CRAM needs the reference-based codecs of
+// htslib and is not read.
+struct BamState {
+  std::unordered_map<std::string, std::string> cache;  // qname -> sequence of the first mate seen
+  std::string pairs_text;                              // interleaved FASTQ records of completed pairs
+  std::vector<std::pair<std::string, std::string>> unpaired;
+  bool got_paired = false;
+  uint64_t n_records = 0, n_skipped = 0;
+};
+static bool is_bam(const std::string& data) { return data.size() >= 4 && memcmp(data.data(), "BAM\1", 4) == 0; }
+static void fastq_record(std::string* out, const std::string& name, const std::string& seq) {
+  out->push_back('@');
+  out->append(name);
+  out->push_back('\n');
+  out->append(seq);
+  out->append("\n+\n");
+  out->append(seq.size(), 'I');
+  out->push_back('\n');
+}
+static void iupac_reverse_complement(std::string* s) {
+  static const char comp[] = "TVGH..CD..M.KN...YSA.BW.R.";  //  ABCD..GH..K.MN...RST.VW.Y.
+  std::reverse(s->begin(), s->end());
+  for (char& c : *s) {
+    const int idx = int(c) - 'A';
+    if (idx >= 0 && idx < int(sizeof comp) - 1) c = comp[idx];
+  }
+}
+static void bam_records(const std::string& data, const std::string& path, BamState* st) {
+  auto rd32 = [&](size_t at) -> int32_t {
+    if (at + 4 > data.size()) die(path + ": truncated BAM");
+    uint32_t v;
+    memcpy(&v, data.data() + at, 4);
+    return int32_t(v);
+  };
+  size_t at = 4;
+  const int32_t l_text = rd32(at);
+  at += 4;
+  if (l_text < 0 || at + size_t(l_text) > data.size()) die(path + ": truncated BAM header");
+  at += size_t(l_text);
+  const int32_t n_ref = rd32(at);
+  at += 4;
+  for (int32_t i = 0; i < n_ref; ++i) {
+    const int32_t l_name = rd32(at);
+    if (l_name < 0) die(path + ": corrupt BAM reference list");
+    at += 4 + size_t(l_name) + 4;
+  }
+  if (at > data.size()) die(path + ": truncated BAM reference list");
+  static const char nt16[] = "=ACMGRSVTWYHKDBN";
+  while (at < data.size()) {
+    const int32_t block = rd32(at);
+    at += 4;
+    if (block < 32 || at + size_t(block) > data.size()) die(path + ": truncated BAM record");
+    const unsigned char* r = reinterpret_cast<const unsigned char*>(data.data()) + at;
+    const unsigned l_read_name = r[8];
+    const unsigned n_cigar = unsigned(r[12]) | unsigned(r[13]) << 8;
+    const unsigned flag = unsigned(r[14]) | unsigned(r[15]) << 8;
+    int32_t l_seq;
+    memcpy(&l_seq, r + 16, 4);
+    const size_t need = 32 + size_t(l_read_name) + 4 * size_t(n_cigar) + (size_t(l_seq < 0 ? 0 : l_seq) + 1) / 2 + size_t(l_seq < 0 ? 0 : l_seq);
+    if (l_seq < 0 || need > size_t(block) || !l_read_name) die(path + ": corrupt BAM record");
+    at += size_t(block);
+    ++st->n_records;
+    if (flag & (0x100 | 0x800)) { ++st->n_skipped; continue; }  // BAM_FSECONDARY | BAM_FSUPPLEMENTARY
+    std::string qname(reinterpret_cast<const char*>(r + 32), l_read_name - 1);
+    const unsigned char* sq = r + 32 + l_read_name + 4 * size_t(n_cigar);
+    std::string seq(size_t(l_seq), 'N');
+    for (int32_t i = 0; i < l_seq; ++i) seq[size_t(i)] = nt16[(sq[i >> 1] >> ((~i & 1) << 2)) & 15];
+    if (flag & 0x10) iupac_reverse_complement(&seq);  // BAM_FREVERSE
+    if (flag & 0x1) {                                 // BAM_FPAIRED
+      st->got_paired = true;
+      auto it = st->cache.find(qname);
+      if (it != st->cache.end()) {
+        fastq_record(&st->pairs_text, qname, seq);
+        fastq_record(&st->pairs_text, qname, it->second);
+        st->cache.erase(it);
+      } else {
+        st->cache.emplace(std::move(qname), std::move(seq));
+      }
+    } else {
+      st->unpaired.emplace_back(std::move(qname), std::move(seq));
+    }
+  }
+}
+// -> the text for bg_fastq_import: interleaved pairs (an unpaired read = a pair whose mate is an empty record) when any
+// read was flagged paired, else plain records
+static std::string bam_finish(BamState* st, uint64_t* n_lacking) {
+  *n_lacking = st->cache.size();
+  std::vector<std::pair<std::string, std::string>> rest(st->cache.begin(), st->cache.end());
+  std::sort(rest.begin(), rest.end());  // (the reference walks hash buckets here; any order gives the same biograph)
+  st->cache.clear();
+  std::string text = std::move(st->pairs_text);
+  for (auto* lst : {&st->unpaired, &rest})
+    for (auto& u : *lst) {
+      fastq_record(&text, u.first, u.second);
+      if (st->got_paired) fastq_record(&text, u.first, std::string());
+    }
+  return text;
+}
+
 static bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 static void mkdirs(const std::string& p) {
   if (mkdir(p.c_str(), 0777) != 0 && errno != EEXIST) die("Could not create " + p + ": " + strerror(errno));
@@ -163,6 +268,28 @@ static std::string stem_of(std::string p) {  // accession id default: stem of th
   return dot == std::string::npos || dot == 0 ? p : p.substr(0, dot);
 }
 
+// bgbinary bam2fastq --reads X.bam [--reads Y.bam] --out R.fq: the text `create` hands to the GPU importer for BAM input
+// (interleaved when the BAM holds paired reads).  Host only; also what the CPU tests check the decoder with.
+static int cmd_bam2fastq(int argc, char** argv) {
+  Args a = parse(argc, argv, 2, {"reads", "out"});
+  if (!a.has("reads") || !a.has("out")) die("bam2fastq: --reads and --out are required");
+  BamState bam;
+  for (auto& f : a.opt["reads"]) {
+    HostText t;
+    load_text(f, &t);
+    if (t.fd >= 0 || !is_bam(t.inflated)) die(f + ": not a BAM file");
+    bam_records(t.inflated, f, &bam);
+    free_text(&t);
+  }
+  uint64_t lacking = 0;
+  const bool paired = bam.got_paired;
+  const uint64_t n_rec = bam.n_records, n_skip = bam.n_skipped;
+  write_file(a.get("out"), bam_finish(&bam, &lacking));
+  fprintf(stderr, "%llu records, %llu skipped, %llu without mate, %s\n", (unsigned long long)n_rec, (unsigned long long)n_skip,
+          (unsigned long long)lacking, paired ? "paired (interleaved)" : "unpaired");
+  return 0;
+}
+
 static int cmd_create(int argc, char** argv) {
   Args a = parse(argc, argv, 2, {"reads", "pair", "interleaved", "ref", "out", "id", "force", "kmer-size", "min-kmer-count",
                                  "trim-after-portion", "max-corrections", "min-good-run", "min-reads", "warn-reads", "stats",
@@ -172,7 +299,8 @@ static int cmd_create(int argc, char** argv) {
   if (out.size() < 3 || out.substr(out.size() - 3) != ".bg") out += ".bg";  // biograph_dir appends .bg
   if (exists(out + "/seqset") && !a.has("force")) die("Refusing to overwrite '" + out + "'. Use --force to override.");
   const std::string fmt = a.get("format", "auto");
-  if (fmt != "auto" && fmt != "fastq") die("Invalid input format '" + fmt + "' (this build reads FASTQ, plain or gzip; BAM/CRAM need htslib)");
+  if (fmt != "auto" && fmt != "fastq" && fmt != "bam")
+    die("Invalid input format '" + fmt + "' (this build reads FASTQ, plain or gzip / BGZF, and BAM; CRAM needs htslib)");
   bg_create_params p;
   bg_create_params_default(&p);
   p.kmer_size = atoi(a.get("kmer-size", "30").c_str());
@@ -212,9 +340,37 @@ static int cmd_create(int argc, char** argv) {
   std::vector<void*> d_text(files.size(), nullptr);
   std::vector<uint64_t> n_text(files.size(), 0);
   uint64_t text_bytes = 0;
+  BamState bam;
+  bool any_bam = false;
+  std::string bam_text;
   for (size_t i = 0; i < files.size(); ++i) {
     HostText t;
     load_text(files[i], &t);
+    const bool this_bam = t.fd < 0 && is_bam(t.inflated);
+    if (fmt == "bam" && !this_bam) die(files[i] + ": not a BAM file");
+    if (this_bam) {
+      if (fmt == "fastq") die(files[i] + ": a BAM file was given with --format fastq");
+      if (!pairs.empty() || interleaved) die("--pair / --interleaved do not apply to BAM input (mates are matched by name)");
+      if (i && !any_bam) die("BAM and FASTQ inputs cannot be mixed in one run");
+      any_bam = true;
+      bam_records(t.inflated, files[i], &bam);
+      free_text(&t);
+      if (i + 1 < files.size()) continue;
+      uint64_t lacking = 0;
+      bam_text = bam_finish(&bam, &lacking);
+      logf("BAM: %llu records (%llu secondary / supplementary skipped)%s", (unsigned long long)bam.n_records,
+           (unsigned long long)bam.n_skipped, bam.got_paired ? ", paired" : ", unpaired");
+      if (lacking) logf("WARNING: %llu entries remaining in pair cache from paired reads; treating as unpaired reads", (unsigned long long)lacking);
+      // one source holding everything
+      d_text.assign(1, nullptr);
+      n_text.assign(1, bam_text.size());
+      text_bytes = bam_text.size();
+      check(bg_dev_alloc(ctx, bam_text.size() ? bam_text.size() : 1, &d_text[0]), "bg_dev_alloc");
+      check(bg_dev_upload_pinned(ctx, d_text[0], bam_text.data(), bam_text.size(), threads), "upload");
+      std::string().swap(bam_text);
+      break;
+    }
+    if (any_bam) die("BAM and FASTQ inputs cannot be mixed in one run");
     n_text[i] = t.n;
     text_bytes += t.n;
     check(bg_dev_alloc(ctx, t.n ? t.n : 1, &d_text[i]), "bg_dev_alloc");
@@ -228,7 +384,8 @@ static int cmd_create(int argc, char** argv) {
   uint64_t n_reads = 0, n_bases = 0;
   std::vector<const uint8_t*> tp;
   for (void* q : d_text) tp.push_back(static_cast<const uint8_t*>(q));
-  check(bg_fastq_import(ctx, uint32_t(files.size()), tp.data(), n_text.data(), pairs.empty() ? 0 : 1, interleaved ? 1 : 0, cut_start,
+  const bool bam_paired = any_bam && bam.got_paired;
+  check(bg_fastq_import(ctx, uint32_t(tp.size()), tp.data(), n_text.data(), pairs.empty() ? 0 : 1, (interleaved || bam_paired) ? 1 : 0, cut_start,
                         cut_end, &d_seq, &d_offs, &n_reads, &n_bases),
         "import");
   for (void* q : d_text) bg_dev_free(ctx, q);
@@ -242,7 +399,7 @@ static int cmd_create(int argc, char** argv) {
   bg_seqset* ss = nullptr;
   bg_readmap* rm = nullptr;
   bg_build_stats st;
-  const int is_paired = (!pairs.empty() || interleaved) ? 1 : 0;
+  const int is_paired = (!pairs.empty() || interleaved || bam_paired) ? 1 : 0;
   check(bg_create_sample(ctx, d_seq, d_offs, n_reads, &p, is_paired, &ss, &rm, &st), "bg_create_sample");
   double t_build = now_s() - t1;
   bg_dev_free(ctx, d_seq);
@@ -606,6 +763,7 @@ static int cmd_discovery(int argc, char** argv) {
 int main(int argc, char** argv) {
   if (argc < 2) die("usage: bgbinary {create|merge|refmap|discovery} [options]   (MI355X build of the seqset path)");
   std::string cmd = argv[1];
+  if (cmd == "bam2fastq") return cmd_bam2fastq(argc, argv);
   if (cmd == "create") return cmd_create(argc, argv);
   if (cmd == "refmap") return cmd_refmap(argc, argv);
   if (cmd == "merge") return cmd_merge(argc, argv);

@@ -152,3 +152,41 @@ def test_cli_interleaved_gzip_cut_reads_and_unknown_options(ctx, tmp_path):
         r = _run(["create", "--reads", fi, "--out", str(tmp_path / "bad.bg")] + bad + common, ok=False)
         assert r.stderr.strip()
     assert not os.path.exists(str(tmp_path / "bad.bg"))
+
+
+def test_cli_create_from_bam(ctx, tmp_path):
+    """`bgbinary create --reads X.bam`: the records are decoded on the host (tests/test_bam_import.py pins the decoder on
+    the reference's golden BAM / SAM pair), matched by name and imported as interleaved text: same biograph as `create`
+    on that text, same seqset as the mate files the BAM was made from; reverse-strand records are turned back."""
+    from tests.test_bam_import import iupac_rc, write_bam
+    reads = util.synth_reads(22, genome_len=6000, n_reads=2400, read_len=100, err=0.004, n_rate=0.0005)
+    a, b = reads[0::2], reads[1::2]
+    recs = []
+    for i, (x, y) in enumerate(zip(a, b)):
+        fx = 0x1 | 0x40 | (0x10 if i % 3 == 0 else 0)
+        fy = 0x1 | 0x80 | (0x10 if i % 5 == 0 else 0)
+        recs.append(("r%d" % i, fx, iupac_rc(x) if fx & 0x10 else x))
+        if i % 7 == 0:
+            recs.append(("r%d" % i, 0x1 | 0x100, "ACGTACGT"))  # a secondary alignment: ignored
+        recs.append(("r%d" % i, fy, iupac_rc(y) if fy & 0x10 else y))
+    bam = str(tmp_path / "reads.bam")
+    write_bam(bam, recs, bgzf_blocks=5)
+    fa, fb, fq = (str(tmp_path / n) for n in ("a.fq", "b.fq", "from_bam.fq"))
+    open(fa, "wb").write(_fastq(a))
+    open(fb, "wb").write(_fastq(b))
+    common = ["--kmer-size", "24", "--min-kmer-count", "3"]
+    _run(["bam2fastq", "--reads", bam, "--out", fq])
+    _run(["create", "--reads", bam, "--out", str(tmp_path / "bam.bg")] + common)
+    _run(["create", "--reads", fq, "--interleaved", "--out", str(tmp_path / "text.bg")] + common)
+    _run(["create", "--reads", fa, "--pair", fb, "--out", str(tmp_path / "pair.bg")] + common)
+    bp, binfo, bn = _bgdir_parts(ctx, str(tmp_path / "bam.bg"))
+    tp, _, tn = _bgdir_parts(ctx, str(tmp_path / "text.bg"))
+    pp, _, pn = _bgdir_parts(ctx, str(tmp_path / "pair.bg"))
+    assert bp == tp and bn == tn == pn
+    assert all(bp[k] == pp[k] for k in bg.PART_NAMES)
+    log = open(str(tmp_path / "bam.bg" / "qc" / "create_log.txt")).read()
+    assert "BAM: %d records" % len(recs) in log and "paired" in log
+    stats = json.load(open(str(tmp_path / "bam.bg" / "qc" / "create_stats.json")))
+    assert stats["imported_reads"] == len(reads)
+    r = _run(["create", "--reads", bam, "--pair", fb, "--out", str(tmp_path / "bad.bg")] + common, ok=False)
+    assert "BAM" in r.stderr
