@@ -52,7 +52,7 @@ struct Args {
 // Options every command understands are listed per command: anything else is an error, never silently
 // ignored (an interleaved FASTQ imported as unpaired, a --cut-reads that cuts nothing).
 static Args parse(int argc, char** argv, int first, const std::vector<std::string>& known) {
-  static const char* flags[] = {"interleaved", "force", "f", "allow-long-reads", nullptr};
+  static const char* flags[] = {"interleaved", "force", "f", "allow-long-reads", "no-bwt", nullptr};
   Args a;
   for (int i = first; i < argc; ++i) {
     std::string s = argv[i];
@@ -458,6 +458,79 @@ static int cmd_create(int argc, char** argv) {
   return 0;
 }
 
+// bgbinary reference --in X.fasta[.gz] --refdir DIR [--min-n-run 50] [-f]: `biograph reference`
+// (modules/main/make_ref.cpp:88-167).  source.fasta = the input (inflated), reference.fasta / karyotype.json /
+// reference.ref on the host (bg_reference_build), reference.bwt on the GPU (bg_bwt_build).  The bwa index files the
+// reference's wrapper adds with an external `bwa index` are not written.
+static int cmd_reference(int argc, char** argv) {
+  Args a = parse(argc, argv, 2, {"reads", "refdir", "min-n-run", "force", "no-bwt"});  // --in is parsed as --reads
+  if (!a.has("reads") || !a.has("refdir")) die("reference: --in <fasta> and --refdir <ref dir> are required");
+  const std::string in = a.get("reads"), dir = a.get("refdir");
+  if (exists(dir)) {
+    if (!a.has("force")) die("Refusing to overwrite '" + dir + "'. Use --force to override.");
+    if (!exists(dir + "/source.fasta")) die(dir + " is not a BioGraph reference. Remove it manually or specify a different location.");
+    for (const char* f : {"source.fasta", "reference.fasta", "karyotype.json", "reference.ref", "reference.bwt"}) {
+      chmod((dir + "/" + f).c_str(), 0644);
+      unlink((dir + "/" + f).c_str());
+    }
+  }
+  mkdirs(dir);
+  printf("%s\n", in.size() > 3 && in.substr(in.size() - 3) == ".gz" ? "Unzipping source fasta" : "Preparing source fasta");
+  {
+    HostText t;
+    load_text(in, &t);
+    std::string text;
+    if (t.fd >= 0) {
+      text.resize(t.n);
+      size_t got = 0;
+      while (got < t.n) {
+        const ssize_t r = pread(t.fd, &text[got], t.n - got, off_t(got));
+        if (r <= 0) die(in + ": read error");
+        got += size_t(r);
+      }
+    } else {
+      text.swap(t.inflated);
+    }
+    free_text(&t);
+    write_file(dir + "/source.fasta", text);
+    chmod((dir + "/source.fasta").c_str(), 0444);
+  }
+  printf("Building reference\n");
+  const uint64_t min_n_run = strtoull(a.get("min-n-run", "50").c_str(), nullptr, 10);
+  check(bg_reference_build((dir + "/source.fasta").c_str(), dir.c_str(), min_n_run), "bg_reference_build");
+  if (!a.has("no-bwt")) {
+    bg_reference* rf = nullptr;
+    check(bg_reference_open(dir.c_str(), &rf), "bg_reference_open");
+    std::string fa(bg_reference_size(rf), '\0');
+    check(bg_reference_bases(rf, 0, fa.size(), &fa[0]), "bg_reference_bases");
+    std::vector<uint8_t> codes(fa.size(), 0);
+    for (size_t i = 0; i < fa.size(); ++i) codes[i] = uint8_t(fa[i] == 'A' ? 0 : fa[i] == 'C' ? 1 : fa[i] == 'G' ? 2 : 3);
+    std::vector<uint64_t> es, ez;
+    for (uint32_t i = 0; i < bg_reference_supercontig_count(rf); ++i) {
+      uint64_t len = 0, flat = 0;
+      check(bg_reference_supercontig(rf, i, nullptr, nullptr, &len, &flat), "bg_reference_supercontig");
+      es.push_back(flat);
+      ez.push_back(len);
+    }
+    bg_reference_free(rf);
+    bg_ctx* ctx = nullptr;
+    check(bg_ctx_create(0, nullptr, &ctx), "bg_ctx_create");
+    void* d_ref = nullptr;
+    check(bg_dev_alloc(ctx, codes.size() ? codes.size() : 1, &d_ref), "bg_dev_alloc");
+    check(bg_dev_upload(ctx, d_ref, codes.data(), codes.size()), "upload");
+    double t0 = now_s();
+    bg_bwt_stats st;
+    check(bg_bwt_build(ctx, static_cast<const uint8_t*>(d_ref), uint32_t(es.size()), es.data(), ez.data(), 64,
+                       (dir + "/reference.bwt").c_str(), &st), "bg_bwt_build");
+    fprintf(stderr, "BWT: %llu entries, %llu century marks, %u doubling rounds, %.3f s\n", (unsigned long long)st.n_entries,
+            (unsigned long long)st.n_century, st.doubling_rounds, now_s() - t0);
+    bg_dev_free(ctx, d_ref);
+    bg_ctx_destroy(ctx);
+  }
+  printf("Results saved to %s\n", dir.c_str());
+  return 0;
+}
+
 static int cmd_refmap(int argc, char** argv) {
   Args a = parse(argc, argv, 2, {"reads", "ref", "out"});
   if (!a.has("in") && !a.has("reads")) die("refmap: --in S.bg is required");
@@ -766,8 +839,9 @@ int main(int argc, char** argv) {
   if (cmd == "bam2fastq") return cmd_bam2fastq(argc, argv);
   if (cmd == "create") return cmd_create(argc, argv);
   if (cmd == "refmap") return cmd_refmap(argc, argv);
+  if (cmd == "reference") return cmd_reference(argc, argv);
   if (cmd == "merge") return cmd_merge(argc, argv);
   if (cmd == "discovery") return cmd_discovery(argc, argv);
-  die("bgbinary: unknown command '" + cmd + "' (this build provides: create, merge, refmap, discovery)");
+  die("bgbinary: unknown command '" + cmd + "' (this build provides: create, merge, refmap, discovery, reference, bam2fastq)");
   return 1;
 }

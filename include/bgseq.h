@@ -480,6 +480,17 @@ int bg_reference_supercontig(const bg_reference* ref, uint32_t i, uint32_t* scaf
                              uint64_t* flat);
 int bg_reference_bases(const bg_reference* ref, uint64_t flat_pos, uint64_t n, char* out);
 
+/* ---- `biograph reference` (modules/main/make_ref.cpp -> pipeline/build_reference_task.cpp): building a reference
+ * directory.  bg_reference_build = IMPORT_FASTA + MAKE_FLAT on the host (bio_format/fasta_ref_importer.cpp,
+ * bio_base/flat_ref.cpp:224-360): reads plain FASTA text and writes <refdir>/reference.fasta, karyotype.json and
+ * reference.ref.  bg_bwt_build = MAKE_BWT on the GPU (bio_mapred/make_bwt.cpp:33-141): the suffix array of all extents
+ * by prefix doubling and the .bwt file of bio_base/bwt_file.h (cent_mod = 64 in the reference). */
+int bg_reference_build(const char* source_fasta, const char* refdir, uint64_t min_n_run /* 50 */);
+typedef struct bg_bwt_stats { uint64_t n_entries, n_century; uint32_t doubling_rounds; } bg_bwt_stats;
+int bg_bwt_build(bg_ctx* ctx, const uint8_t* d_codes /* flat reference, one code 0..3 per byte */, uint32_t n_extents,
+                 const uint64_t* h_ext_flat, const uint64_t* h_ext_size, uint64_t cent_mod, const char* path,
+                 bg_bwt_stats* stats /* may be NULL */);
+
 /* Stable partition of n rows into nparts destination groups written back to back into d_out_rows;
  * h_counts[p] = rows of group p. */
 int bg_partition_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int row_words, int mode,
