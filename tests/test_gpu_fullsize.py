@@ -94,3 +94,36 @@ def test_fullsize_sharded_build_equals_fused(built):
         assert got == want
     finally:
         ss2.free()
+
+
+def test_fullsize_eight_rank_routed_build_written_in_slices_equals_fused(built, tmp_path):
+    """The shape of BASELINE.json configs[3] at chr20 size: EIGHT ranks (simulated on the one GPU), uneven shards, the routed
+    build with nothing replicated and nothing gathered -- every rank writes its slice of one container in place -- and
+    the file opens as the fused build's seqset, member for member."""
+    ctx, ss, st, (seq, offs, n) = built
+    want = {k: hashlib.sha256(v).hexdigest() for k, v in ss.parts().items()}
+    P = 8
+    rng = np.random.default_rng(8)
+    cuts = sorted(int(x) * 2 for x in rng.integers(0, n // 2 + 1, P - 1))
+    bounds = [0] + cuts + [n]
+    inputs = {}
+    for r in range(P):
+        a, b = bounds[r], bounds[r + 1]
+        inputs[r] = (seq[a * 150:b * 150], (offs[a:b + 1] - a * 150).contiguous(), b - a)
+    comm = sharded.LocalSimComm(P)
+    out = sharded.sharded_create(comm, {r: ctx for r in range(P)}, inputs, ctx.default_params(), mode="routed", gather=False)
+    st8 = out[0][1]
+    for key in ("n_kept_kmers", "n_distinct_kmers", "n_kmers", "n_corrected_reads", "n_corrected_bases", "n_records", "n_entries"):
+        assert st8[key] == st[key], key
+    assert len(st8["shard_entries"]) == P and min(st8["shard_entries"]) > 0.8 * st["n_entries"] / P  # balanced splitters
+    path = str(tmp_path / "seqset")
+    slices = {r: out[r][0] for r in range(P)}
+    sharded.write_slices(comm, slices, path, ["test_gpu_fullsize"])
+    for s in slices.values():
+        s.free()
+    opened = ctx.open_seqset(path)
+    try:
+        got = {k: hashlib.sha256(v).hexdigest() for k, v in opened.parts().items()}
+        assert {k: got[k] for k in bg.PART_NAMES} == {k: want[k] for k in bg.PART_NAMES}
+    finally:
+        opened.free()
