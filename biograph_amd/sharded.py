@@ -41,6 +41,7 @@ class LocalSimComm:
     def __init__(self, world):
         self.world = world
         self.local_ranks = list(range(world))
+        self.off_rank_bytes = [0] * world  # what each rank would put on its links (all_to_all pieces not kept + gathers)
 
     def all_to_all_v(self, send):
         """send[r] = (rows [n, width], counts list[world]) -> (recv, cm): recv[r] = rows from all sources in rank
@@ -50,9 +51,12 @@ class LocalSimComm:
         for src in self.local_ranks:
             rows, counts = send[src]
             off = 0
+            row_bytes = rows.element_size() * (rows.numel() // max(rows.shape[0], 1)) if rows.shape[0] else 0
             for dst in range(self.world):
                 pieces[dst].append(rows[off:off + counts[dst]])
                 cm[src][dst] = int(counts[dst])
+                if dst != src:
+                    self.off_rank_bytes[src] += int(counts[dst]) * row_bytes
                 off += counts[dst]
         return {r: torch.cat(pieces[r], dim=0) for r in self.local_ranks}, cm
 
@@ -72,6 +76,8 @@ class LocalSimComm:
 
     def all_gather_v(self, send):
         """send[r] = tensor -> every rank gets the list [tensor of rank 0, ...]."""
+        for r in range(self.world):
+            self.off_rank_bytes[r] += send[r].numel() * send[r].element_size() * (self.world - 1)
         lst = [send[r] for r in range(self.world)]
         return {r: lst for r in self.local_ranks}
 

@@ -17,7 +17,8 @@ from biograph_amd import sharded, synth
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
 MODE = sys.argv[2] if len(sys.argv) > 2 else "routed"
 os.environ.pop("BG_SHARD_TIMING", None)
-ctx = bg.Context(0)
+bg.use_shared_arena()  # as bench.py does for sharded runs: torch's buffers come out of the library's arena
+ctx = bg.Context(0, torch.cuda.current_stream().cuda_stream)
 base = None
 for P in (1, 2, 4, 8):
     inputs = {}
@@ -28,14 +29,17 @@ for P in (1, 2, 4, 8):
     for rep in range(2):
         torch.cuda.synchronize()
         t = time.perf_counter()
-        out = sharded.sharded_create(sharded.LocalSimComm(P), ctxs, inputs, mode=MODE, gather=False)
+        comm = sharded.LocalSimComm(P)
+        out = sharded.sharded_create(comm, ctxs, inputs, mode=MODE, gather=False)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
         for r in range(P):
             out[r][0].free()
     per_rank = dt / P
     base = base or per_rank
-    print("%s P=%d  total %.1f ms  per rank %.1f ms  efficiency (no links) %.2f" % (MODE, P, dt * 1e3, per_rank * 1e3, base / per_rank),
-          flush=True)
+    off = max(comm.off_rank_bytes) / 1e9
+    # link time if nothing overlapped: 7 xGMI links x ~50 GB/s usable each way per GPU
+    print("%s P=%d  total %.1f ms  per rank %.1f ms  efficiency (no links) %.2f  | off-rank bytes of the fullest rank %.2f GB"
+          " = %.1f ms at 350 GB/s" % (MODE, P, dt * 1e3, per_rank * 1e3, base / per_rank, off, off / 350 * 1e3), flush=True)
     del inputs
     ctx.trim()
