@@ -151,32 +151,31 @@ class TorchDistComm:
         if self.world == 1:  # everything stays: the rows are where they belong already (callers give `send` up)
             return self._out(self._in(rows).contiguous())
         rows = self._in(rows).contiguous()
-        me = self.rank
-        out_counts = [cm[s][me] for s in range(self.world)]
+        out_counts = [cm[s][self.rank] for s in range(self.world)]
         row_bytes = rows.element_size()
         for d in rows.shape[1:]:
             row_bytes *= int(d)
         max_rows = max(1, self.MAX_PIECE_BYTES // max(row_bytes, 1))
-        # the piece a rank keeps never enters the collective: one device copy, and no link or RCCL channel for it
-        biggest = max(cm[s][d] for s in range(self.world) for d in range(self.world) if s != d)
-        rounds = max(1, -(-biggest // max_rows))
+        rounds = max(1, -(-max(max(r) for r in cm) // max_rows))
         starts = [0]
         for c in counts:
             starts.append(starts[-1] + c)
+        if rounds == 1:  # the one collective every backend implements natively (the piece a rank keeps is a local copy in it)
+            out = torch.empty((sum(out_counts),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=self.device)
+            dist.all_to_all_single(out, rows, output_split_sizes=out_counts, input_split_sizes=counts)
+            return self._out(out)
+        # Several rounds.  The result keeps the single-round layout (all rows of source 0, then source 1, ...,
+        # each in the order they were sent): the presence bits of the k-mer exchange travel back by position.
         ostarts = [0]
         for c in out_counts:
             ostarts.append(ostarts[-1] + c)
         out = torch.empty((ostarts[-1],) + tuple(rows.shape[1:]), dtype=rows.dtype, device=self.device)
-        if counts[me]:
-            out[ostarts[me]: ostarts[me] + counts[me]].copy_(rows[starts[me]: starts[me] + counts[me]])
-        # The result keeps the layout "all rows of source 0, then source 1, ...", each in the order they were
-        # sent, whatever the number of rounds: the presence bits of the k-mer exchange travel back by position.
         for t in range(rounds):
             lo = t * max_rows
             ins = [rows[starts[d] + min(lo, counts[d]): starts[d] + min(lo + max_rows, counts[d])]
-                   if d != me else rows[:0] for d in range(self.world)]
+                   for d in range(self.world)]
             rcv = [out[ostarts[d] + min(lo, out_counts[d]): ostarts[d] + min(lo + max_rows, out_counts[d])]
-                   if d != me else out[:0] for d in range(self.world)]
+                   for d in range(self.world)]
             if dist.get_backend() == "nccl":
                 # RCCL: grouped send/recv on views - every piece leaves from where it lies and lands where it
                 # belongs, no staging copies of a multi-GB exchange
