@@ -22,7 +22,9 @@
 // tracer emits them (right_anchor_len == 0); the pop tracer, the bidirectional tracer and everything downstream
 // (align, genotype, VCF).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <deque>
@@ -30,6 +32,7 @@
 #include <memory>
 #include <set>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -151,9 +154,11 @@ struct World {
   int64_t scaffold_end = 0;
   // reads along the (oriented) scaffold: offset (after the base) -> entry, ascending by offset
   std::vector<std::pair<int32_t, uint64_t>> position_entries;
-  std::unordered_map<uint64_t, std::vector<int32_t>> entry_positions;        // entry -> offsets, ascending
-  std::unordered_map<uint32_t, std::vector<int32_t>> rc_mate_read_positions;  // read -> offsets, ascending
+  std::vector<std::pair<uint64_t, int32_t>> entry_positions;        // (entry, offset), sorted
+  std::vector<std::pair<uint32_t, int32_t>> rc_mate_read_positions;  // (read, offset), sorted
   bg_trace_stats stats;
+  double seconds_device = 0, seconds_host = 0, seconds_tables = 0, seconds_start = 0, seconds_teardown = 0;
+  int threads = 1;
 
   unsigned match_count(uint64_t e) const { return ref_map[e] & 63u; }
   std::pair<uint32_t, uint32_t> entry_to_index(uint64_t e) const {  // readmap.h:114-116
@@ -161,7 +166,8 @@ struct World {
     auto hi = std::upper_bound(lo, entry_id.end(), uint32_t(e));
     return {uint32_t(lo - entry_id.begin()), uint32_t(hi - entry_id.begin())};
   }
-  bool get_bit(uint64_t e) const { auto r = entry_to_index(e); return r.first != r.second; }
+  std::vector<uint64_t> has_reads;   // readmap::get_bit as a bit per entry
+  bool get_bit(uint64_t e) const { return (has_reads[e >> 6] >> (e & 63)) & 1; }
   bool is_entry(const TRange& r) const { return r.b + 1 == r.e && r.s == sizes[r.b]; }     // seqset.h:298-300
   bool is_read(const TRange& r) const { return is_entry(r) && get_bit(r.b); }                // tracer.cpp:521-526
   bool has_mate(uint32_t id) const { return mate_loop[mate_loop[id]] != id; }               // readmap.cpp:207-218
@@ -176,6 +182,7 @@ struct World {
 // One trace (tracer::trace + trace_next_paths + output_rejoins for one offset) as a resumable machine.
 struct Trace {
   World* w;
+  bg_trace_stats st = {};  // this trace's share of assemble_stats (traces run on several host threads)
   int32_t cur_offset = 0;
   TRange cur_range;
   std::string left_anchor;
@@ -199,18 +206,12 @@ struct Trace {
   const bg_trace_options& o() const { return w->o; }
 
   // ---- tables through the window
-  template <class Map, class Key>
-  static const std::vector<int32_t>* find(const Map& m, Key k) {
-    auto it = m.find(k);
-    return it == m.end() ? nullptr : &it->second;
-  }
   bool has_rc_mate_in_range(uint32_t read_id, int64_t start, int64_t limit) const {  // tracer.cpp:466-475
-    const auto* v = find(w->rc_mate_read_positions, read_id);
-    if (!v) return false;
     const int64_t lo = std::max<int64_t>(start, win_lo), hi = std::min<int64_t>(limit, int64_t(win_hi) + 1);
     if (lo >= hi) return false;
-    auto it = std::lower_bound(v->begin(), v->end(), int32_t(lo));
-    return it != v->end() && *it < hi;
+    const auto& v = w->rc_mate_read_positions;
+    auto it = std::lower_bound(v.begin(), v.end(), std::make_pair(read_id, int32_t(lo)));
+    return it != v.end() && it->first == read_id && it->second < hi;
   }
 
   // ---- tracer.cpp:847-877
@@ -275,7 +276,7 @@ struct Trace {
         x.ambiguous_bases = std::max<unsigned>(x.ambiguous_bases, p.range.s);
         if (!o().trace_ambiguous_ref) {
           p.cost += o().max_cost;
-          ++w->stats.prune_ambiguous_ref;
+          ++st.prune_ambiguous_ref;
         }
       } else if (ref_count == 1) {
         p.cost += o().traverse_ref_cost;
@@ -306,7 +307,7 @@ struct Trace {
         if (added_pairs < o().max_pairs_per_read) {
           p.seen_pairs.emplace_back(w->get_rev_comp(w->get_mate(rid)), int32_t(p.seq.size()));
           ++added_pairs;
-          ++w->stats.found_pairs;
+          ++st.found_pairs;
         }
         if (matched_pair) continue;
         if (has_rc_mate_in_range(rid, cur_offset, int64_t(cur_offset) + x.path_bases + o().max_pair_distance)) {
@@ -321,24 +322,24 @@ struct Trace {
       x.ambiguous_bases = 0;
       ++x.pairs_used;
       p.cost += o().pairs_used_cost;
-      ++w->stats.matched_pairs;
+      ++st.matched_pairs;
     }
   }
 
   // ---- queues (:879-941); the heap moves are those of libstdc++'s std::push_heap / std::pop_heap
   void push_next_path(NextPath x) {
     const Path& p = paths[x.path];
-    if (p.cost > o().max_cost) { ++w->stats.max_branch_cost; return; }
+    if (p.cost > o().max_cost) { ++st.max_branch_cost; return; }
     if (!rejoins.empty() && rejoins.size() >= o().max_rejoins) {
       const unsigned worst = unsigned(paths[rejoins.front().path].cost + rejoins.front().rejoin_cost);  // "unsigned" (:888)
-      if (p.cost > int64_t(worst)) { ++w->stats.suboptimal_path_prune; return; }
+      if (p.cost > int64_t(worst)) { ++st.suboptimal_path_prune; return; }
     }
     next_paths.push_back(x);
     std::push_heap(next_paths.begin(), next_paths.end(),
                    [this](const NextPath& a, const NextPath& b) { return paths[a.path].cost > paths[b.path].cost; });
     if (next_paths.size() > o().max_next_paths) {
       next_paths.pop_back();
-      ++w->stats.next_paths_too_big;
+      ++st.next_paths_too_big;
     }
   }
   NextPath pop_next_path() {
@@ -351,7 +352,7 @@ struct Trace {
   int64_t total(const Rejoin& r) const { return paths[r.path].cost + r.rejoin_cost; }
   void push_rejoin(const Rejoin& r) {
     const int64_t t = total(r);
-    if (t > o().max_cost) { ++w->stats.max_branch_cost; return; }
+    if (t > o().max_cost) { ++st.max_branch_cost; return; }
     size_t i = 0;  // multiset with "a before b when a's total is larger": equal elements go after their equals
     while (i < rejoins.size() && total(rejoins[i]) >= t) ++i;
     rejoins.insert(rejoins.begin() + i, r);
@@ -361,17 +362,17 @@ struct Trace {
   bool add_rejoins(const NextPath& x) {  // :675-724
     const Path& p = paths[x.path];
     if (!w->is_read(p.range)) return false;
-    const auto* v = find(w->entry_positions, p.range.b);
-    if (!v) return false;
     int64_t best_distance = -1;
     int32_t best_offset = -1;
-    // candidates after cur_offset, inside the read-ahead window, in the order they were inserted (ascending)
-    for (auto it = std::upper_bound(v->begin(), v->end(), cur_offset); it != v->end() && *it <= win_hi; ++it) {
-      const int64_t distance = std::llabs(int64_t(cur_offset) + x.path_bases - *it);
-      if (best_distance < 0 || distance < best_distance) { best_distance = distance; best_offset = *it; }
+    // candidates after cur_offset, inside the read-ahead window, in ascending order (the order they were inserted)
+    const auto& v = w->entry_positions;
+    for (auto it = std::upper_bound(v.begin(), v.end(), std::make_pair(uint64_t(p.range.b), cur_offset));
+         it != v.end() && it->first == p.range.b && it->second <= win_hi; ++it) {
+      const int64_t distance = std::llabs(int64_t(cur_offset) + x.path_bases - it->second);
+      if (best_distance < 0 || distance < best_distance) { best_distance = distance; best_offset = it->second; }
     }
     if (best_distance < 0) return false;
-    if (x.ambiguous_bases && best_distance > int64_t(x.ambiguous_bases)) { ++w->stats.extend_ambiguous_rejoin; return false; }
+    if (x.ambiguous_bases && best_distance > int64_t(x.ambiguous_bases)) { ++st.extend_ambiguous_rejoin; return false; }
     Rejoin r;
     r.path = x.path;
     r.rejoin_cost = o().rejoin_local_cost + best_distance * o().size_change_cost - o().traverse_ref_cost;
@@ -394,10 +395,10 @@ struct Trace {
   // ---- the machine.  start() / resume() return true when a query is pending in `q`.
   bool start(bg_trace_query* q) {  // tracer::trace (:477-519)
     if (w->match_count(cur_range.b) > 1) {
-      ++w->stats.ambiguous_ref_reads;
+      ++st.ambiguous_ref_reads;
       if (!o().trace_ambiguous_ref) return finish();
     } else {
-      ++w->stats.ref_reads;
+      ++st.ref_reads;
     }
     NextPath x;
     x.path = alloc();
@@ -430,18 +431,18 @@ struct Trace {
     while (!next_paths.empty()) {
       NextPath x = pop_next_path();
       if (!rejoins.empty() && rejoins.size() >= o().max_rejoins && paths[x.path].cost > total(rejoins.front())) {
-        ++w->stats.suboptimal_path_prune;
+        ++st.suboptimal_path_prune;
         continue;
       }
       if (search_steps > size_t(o().max_search_steps_per_read) * x.num_reads + o().initial_search_steps) {
-        ++w->stats.search_not_fast_enough;
+        ++st.search_not_fast_enough;
         continue;
       }
-      if (x.ambiguous_bases > o().max_ambiguous_bases) { ++w->stats.too_many_ambiguous_bases; continue; }
-      ++w->stats.step_count;
+      if (x.ambiguous_bases > o().max_ambiguous_bases) { ++st.too_many_ambiguous_bases; continue; }
+      ++st.step_count;
       ++search_steps;
-      if (search_steps > o().max_search_steps) { ++w->stats.too_many_steps; return finish(); }
-      if (ambiguous_steps > o().max_ambiguous_search_steps) { ++w->stats.too_many_ambiguous_steps; return finish(); }
+      if (search_steps > o().max_search_steps) { ++st.too_many_steps; return finish(); }
+      if (ambiguous_steps > o().max_ambiguous_search_steps) { ++st.too_many_ambiguous_steps; return finish(); }
       np = x;
       pushed_any = false;
       expanding = true;
@@ -461,7 +462,7 @@ struct Trace {
       else { p.range.b = 0; p.range.e = 0; p.range.s = steps[i] >> 8; }
       add_base(np, base);
       pushed_any = true;
-      if (np.pushed_since_pair > o().max_bases_between_pairs) { ++w->stats.too_far_without_pair; return next_expansion(q); }
+      if (np.pushed_since_pair > o().max_bases_between_pairs) { ++st.too_far_without_pair; return next_expansion(q); }
       if (i + 1 == r.n_steps && add_rejoins(np)) return next_expansion(q);
     }
     if (r.reason == BG_TRACE_STEPPED_ON_READ || r.reason == BG_TRACE_STEP_CAP) {
@@ -497,7 +498,7 @@ struct Trace {
       if (r.ps[b] < unambiguous_len) {
         paths[x.path].cost += o().ambiguous_branch_cost;
         ++x.branch_count_since_pair;
-        if (x.branch_count_since_pair > o().max_branches_between_pairs) { ++w->stats.exceeded_branch_limit; continue; }
+        if (x.branch_count_since_pair > o().max_branches_between_pairs) { ++st.exceeded_branch_limit; continue; }
       }
       if (!add_rejoins(x)) push_next_path(x);
     }
@@ -539,7 +540,7 @@ struct Trace {
       a.right_anchor_len = int(std::min<int64_t>(a.right_anchor_len, max_tot_anchor / 2));
       a.left_anchor_len = int(std::min<int64_t>(a.left_anchor_len, max_tot_anchor / 2));
     }
-    ++w->stats.output_count;
+    ++st.output_count;
     out.push_back(std::move(a));
   }
 
@@ -593,6 +594,40 @@ struct Trace {
   }
 };
 
+double now_seconds() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return double(ts.tv_sec) + 1e-9 * double(ts.tv_nsec);
+}
+
+int g_tracer_threads = 0;  // 0: hardware_concurrency (BG_TRACER_THREADS overrides)
+template <class F>
+void parallel_over(size_t n, F f, size_t min_per_thread = 256) {
+  int nt = g_tracer_threads;
+  if (nt <= 0) {
+    const char* e = getenv("BG_TRACER_THREADS");
+    nt = e ? atoi(e) : int(std::thread::hardware_concurrency());
+    if (nt < 1) nt = 1;
+    if (nt > 64) nt = 64;
+    g_tracer_threads = nt;
+  }
+  if (size_t(nt) > n / min_per_thread + 1) nt = int(n / min_per_thread + 1);  // a few hundred traces per thread at least
+  if (nt <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+  std::vector<std::thread> pool;
+  const size_t per = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; ++t) {
+    const size_t lo = size_t(t) * per, hi = std::min(n, lo + per);
+    if (lo < hi) pool.emplace_back([lo, hi, &f] { for (size_t i = lo; i < hi; ++i) f(i); });
+  }
+  for (auto& th : pool) th.join();
+}
+
+void add_stats(bg_trace_stats* to, const bg_trace_stats& from) {
+  const uint64_t* a = reinterpret_cast<const uint64_t*>(&from);
+  uint64_t* b = reinterpret_cast<uint64_t*>(to);
+  for (size_t i = 0; i < sizeof(bg_trace_stats) / 8; ++i) b[i] += a[i];
+}
+
 struct Extent { int64_t offset; std::string seq; };
 
 int fail(const char* msg) { set_error("%s", msg); return BG_EINVAL; }
@@ -604,6 +639,7 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
   const bg_trace_options& o = w.o;
   const int64_t max_read_len = w.ss->max_len;
   if (limit > start + int64_t(o.scaffold_split_size)) return fail("bg_push_trace: the range is longer than scaffold_split_size");
+  const double t_tables = now_seconds();
   // ---- 1. read ahead over [skip, limit + read_ahead_distance]
   const int64_t skip = start - int64_t(o.max_pair_distance) - max_read_len;  // skip_ahead_to (:230)
   const int64_t ahead_limit = limit + int64_t(o.read_ahead_distance);         // no trace looks further
@@ -638,18 +674,31 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
     BG_TRY(bg_ref_walk_entries(ctx, w.ss, d_codes.p, n, dup_first ? 1 : 0, d_ent.p));
     std::vector<uint64_t> ent(n);
     BG_HIP(hipMemcpy(ent.data(), d_ent.p, n * 8, hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < n; ++i) {
-      if (ent[i] == kNoEntry || !w.get_bit(ent[i])) continue;
-      const int32_t off = int32_t(lo + int64_t(i) + 1);  // the offset after the base (:365)
-      w.position_entries.emplace_back(off, ent[i]);
-      if (!w.pairing_skipped(ent[i])) {
-        const auto reads = w.entry_to_index(ent[i]);
-        for (uint32_t rid = reads.first; rid != reads.second; ++rid)
-          if (w.has_mate(rid)) w.rc_mate_read_positions[w.get_rev_comp(w.get_mate(rid))].push_back(off);
+    // positions that are reads, and for those the (rc mate, offset) pairs: per-thread lists over slices of the extent
+    {
+      int nt = int(std::min<uint64_t>(64, n / 65536 + 1));
+      std::vector<std::vector<std::pair<int32_t, uint64_t>>> pe(nt);
+      std::vector<std::vector<std::pair<uint32_t, int32_t>>> mates(nt);
+      parallel_over(size_t(nt), [&](size_t t) {
+        const uint64_t a = n * t / uint64_t(nt), b = n * (t + 1) / uint64_t(nt);
+        for (uint64_t i = a; i < b; ++i) {
+          if (ent[i] == kNoEntry || !w.get_bit(ent[i])) continue;
+          const int32_t off = int32_t(lo + int64_t(i) + 1);  // the offset after the base (:365)
+          pe[t].emplace_back(off, ent[i]);
+          if (w.pairing_skipped(ent[i])) continue;
+          const auto reads = w.entry_to_index(ent[i]);
+          for (uint32_t rid = reads.first; rid != reads.second; ++rid)
+            if (w.has_mate(rid)) mates[t].emplace_back(w.get_rev_comp(w.get_mate(rid)), off);
+        }
+      }, 1);
+      for (int t = 0; t < nt; ++t) {
+        for (auto& y : pe[t]) { w.position_entries.push_back(y); w.entry_positions.emplace_back(y.second, y.first); }
+        w.rc_mate_read_positions.insert(w.rc_mate_read_positions.end(), mates[t].begin(), mates[t].end());
       }
-      w.entry_positions[ent[i]].push_back(off);
     }
   }
+  std::sort(w.entry_positions.begin(), w.entry_positions.end());
+  std::sort(w.rc_mate_read_positions.begin(), w.rc_mate_read_positions.end());
   // ---- 2. the sequential state of the sweep (:236-296): which offsets trace, with which anchor
   std::vector<std::unique_ptr<Trace>> traces;
   size_t pe = 0;
@@ -694,16 +743,24 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
       traces.push_back(std::move(t));
     }
   }
+  w.seconds_tables += now_seconds() - t_tables;
   // ---- 3. all traces in lock step
   const uint32_t step_cap = 64;
   const size_t wave = 1 << 16;
   for (size_t w0 = 0; w0 < traces.size(); w0 += wave) {
     const size_t w1 = std::min(traces.size(), w0 + wave);
+    // start / resume of different traces are independent: they run on the host's threads, each over a contiguous share
     std::vector<Trace*> live;
     std::vector<bg_trace_query> q;
-    for (size_t i = w0; i < w1; ++i) {
-      bg_trace_query qq;
-      if (traces[i]->start(&qq)) { live.push_back(traces[i].get()); q.push_back(qq); }
+    {
+      const size_t n = w1 - w0;
+      std::vector<bg_trace_query> qs(n);
+      std::vector<uint8_t> pending(n, 0);
+      const double t_start = now_seconds();
+      parallel_over(n, [&](size_t i) { pending[i] = traces[w0 + i]->start(&qs[i]) ? 1 : 0; });
+      w.seconds_start += now_seconds() - t_start;
+      for (size_t i = 0; i < n; ++i)
+        if (pending[i]) { live.push_back(traces[w0 + i].get()); q.push_back(qs[i]); }
     }
     DevBuf<uint8_t> dq, dr;
     DevBuf<uint32_t> ds;
@@ -711,6 +768,7 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
     std::vector<uint32_t> steps;
     while (!live.empty()) {
       const size_t n = live.size();
+      const double t_dev = now_seconds();
       BG_TRY(dq.alloc(ctx, n * sizeof(bg_trace_query)));
       BG_TRY(dr.alloc(ctx, n * sizeof(bg_trace_reply)));
       BG_TRY(ds.alloc(ctx, n * step_cap));
@@ -721,21 +779,28 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
       steps.resize(n * step_cap);
       BG_HIP(hipMemcpy(replies.data(), dr.p, n * sizeof(bg_trace_reply), hipMemcpyDeviceToHost));
       BG_HIP(hipMemcpy(steps.data(), ds.p, n * step_cap * 4, hipMemcpyDeviceToHost));
+      w.seconds_device += now_seconds() - t_dev;
       ++w.stats.device_rounds;
       w.stats.device_queries += n;
+      const double t_host = now_seconds();
+      std::vector<bg_trace_query> qs(n);
+      std::vector<uint8_t> pending(n, 0);
+      parallel_over(n, [&](size_t i) { pending[i] = live[i]->resume(replies[i], steps.data() + i * step_cap, &qs[i]) ? 1 : 0; });
       std::vector<Trace*> next_live;
       std::vector<bg_trace_query> next_q;
-      for (size_t i = 0; i < n; ++i) {
-        bg_trace_query qq;
-        if (live[i]->resume(replies[i], steps.data() + i * step_cap, &qq)) { next_live.push_back(live[i]); next_q.push_back(qq); }
-      }
+      for (size_t i = 0; i < n; ++i)
+        if (pending[i]) { next_live.push_back(live[i]); next_q.push_back(qs[i]); }
       live.swap(next_live);
       q.swap(next_q);
+      w.seconds_host += now_seconds() - t_host;
     }
     for (size_t i = w0; i < w1; ++i) {
+      add_stats(&w.stats, traces[i]->st);
       for (auto& a : traces[i]->out) out->push_back(std::move(a));
-      traces[i].reset();
     }
+    const double t_down = now_seconds();
+    for (size_t i = w0; i < w1; ++i) traces[i].reset();  // (in order on this thread: frees from other threads contend in malloc)
+    w.seconds_teardown += now_seconds() - t_down;
   }
   w.stats.traces += traces.size();
   return BG_OK;
@@ -812,17 +877,20 @@ int download(std::vector<T>& h, const T* d, size_t n) {
 }  // namespace
 
 // reversable_tracer::assemble(start, limit) (reversable_tracer.cpp:76-145) with the push tracer.
-extern "C" int bg_push_trace(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const uint8_t* d_ref_map,
-                             uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
-                             const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset,
-                             int rev_comp, int pair_count, const bg_trace_options* options, bg_trace_result** out) {
-  if (!ctx || !ss || !rm || !out || (n_extents && (!ext_offset || !ext_seq || !ext_len))) return fail("bg_push_trace: null argument");
-  if (ss->n && !d_ref_map) return fail("bg_push_trace: the ref_map is required (bg_ref_map_build)");
-  if (rm->n_entries != ss->n) return fail("bg_push_trace: the readmap belongs to another seqset");
-  if (rm->pair_mode) return fail("bg_push_trace: the readmap has no mate loop table");
-  if (ss->max_len > 255) return fail("bg_push_trace: reads longer than 255 bases");
+struct bg_tracer { World w; };
+
+// The host copies a tracer needs of the seqset, the readmap and the ref_map are made once per session
+// (assemble_options::seqset / readmap / rmap of a trace_ref object); bg_tracer_trace is one work item of trace_ref.
+extern "C" int bg_tracer_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const uint8_t* d_ref_map,
+                              const bg_trace_options* options, bg_tracer** out) {
+  if (!ctx || !ss || !rm || !out) return fail("bg_tracer_open: null argument");
+  if (ss->n && !d_ref_map) return fail("bg_tracer_open: the ref_map is required (bg_ref_map_build)");
+  if (rm->n_entries != ss->n) return fail("bg_tracer_open: the readmap belongs to another seqset");
+  if (rm->pair_mode) return fail("bg_tracer_open: the readmap has no mate loop table");
+  if (ss->max_len > 255) return fail("bg_tracer_open: reads longer than 255 bases");
   BG_HIP(hipSetDevice(ctx->device));
-  World w;
+  std::unique_ptr<bg_tracer> t(new bg_tracer);
+  World& w = t->w;
   w.ctx = ctx;
   w.ss = ss;
   w.rm = rm;
@@ -832,6 +900,8 @@ extern "C" int bg_push_trace(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap*
   BG_TRY(download(w.sizes, ss->sizes.p, ss->n));
   BG_TRY(download(w.ref_map, d_ref_map, ss->n));
   BG_TRY(download(w.entry_id, rm->entry_id.p, rm->n_reads));
+  w.has_reads.assign((ss->n + 63) / 64 + 1, 0);
+  for (uint32_t e : w.entry_id) w.has_reads[e >> 6] |= 1ull << (e & 63);
   {
     std::vector<uint64_t> tmp;
     BG_TRY(download(tmp, rm->mate_loop_ptr.p, rm->n_reads));
@@ -840,15 +910,30 @@ extern "C" int bg_push_trace(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap*
     w.is_forward.resize(rm->n_reads);
     for (size_t i = 0; i < tmp.size(); ++i) w.is_forward[i] = uint8_t(tmp[i] & 1);
   }
+  *out = t.release();
+  return BG_OK;
+}
+
+extern "C" void bg_tracer_close(bg_tracer* t) { delete t; }
+
+extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                               const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset,
+                               int rev_comp, int pair_count, bg_trace_result** out) {
+  if (!t || !out || (n_extents && (!ext_offset || !ext_seq || !ext_len))) return fail("bg_tracer_trace: null argument");
+  World& w = t->w;
+  const double t_call = now_seconds();
+  BG_HIP(hipSetDevice(w.ctx->device));
+  memset(&w.stats, 0, sizeof(w.stats));
+  w.seconds_device = w.seconds_host = w.seconds_tables = w.seconds_start = w.seconds_teardown = 0;
   std::vector<Extent> ext;
   int64_t calc_end = 0;
   for (uint64_t i = 0; i < n_extents; ++i) {
     ext.push_back(Extent{ext_offset[i], std::string(ext_seq[i], ext_len[i])});
     for (char c : ext.back().seq)
-      if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return fail("bg_push_trace: extents hold ACGT only");
+      if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return fail("bg_tracer_trace: extents hold ACGT only");
     calc_end = std::max<int64_t>(calc_end, ext_offset[i] + int64_t(ext_len[i]));
   }
-  if (end_pos < calc_end) return fail("bg_push_trace: end_pos lies before the end of the last extent");
+  if (end_pos < calc_end) return fail("bg_tracer_trace: end_pos lies before the end of the last extent");
   w.scaffold_end = end_pos;
   if (limit_offset > end_pos) limit_offset = end_pos;
   std::unique_ptr<bg_trace_result> res(new bg_trace_result);
@@ -884,8 +969,28 @@ extern "C" int bg_push_trace(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap*
   }
   res->a = std::move(counted);
   res->stats = w.stats;
+  if (getenv("BG_TRACER_TIMING"))
+    fprintf(stderr, "bg_tracer_trace: %.3f s in all: tables %.3f s, start %.3f s, device rounds %.3f s, host replay %.3f s, teardown %.3f s (%d threads), %llu traces\n",
+            now_seconds() - t_call, w.seconds_tables, w.seconds_start, w.seconds_device, w.seconds_host, w.seconds_teardown, g_tracer_threads, (unsigned long long)w.stats.traces);
+  // the chunk's tables are not kept between work items
+  std::vector<std::pair<int32_t, uint64_t>>().swap(w.position_entries);
+  std::vector<std::pair<uint64_t, int32_t>>().swap(w.entry_positions);
+  std::vector<std::pair<uint32_t, int32_t>>().swap(w.rc_mate_read_positions);
   *out = res.release();
   return BG_OK;
+}
+
+// reversable_tracer::assemble(start, limit) (reversable_tracer.cpp:76-145) with the push tracer: one session, one work item.
+extern "C" int bg_push_trace(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const uint8_t* d_ref_map,
+                             uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                             const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset,
+                             int rev_comp, int pair_count, const bg_trace_options* options, bg_trace_result** out) {
+  bg_tracer* t = nullptr;
+  BG_TRY(bg_tracer_open(ctx, ss, rm, d_ref_map, options, &t));
+  const int rc = bg_tracer_trace(t, n_extents, ext_offset, ext_seq, ext_len, end_pos, start_offset, limit_offset, rev_comp,
+                                 pair_count, out);
+  bg_tracer_close(t);
+  return rc;
 }
 
 extern "C" uint64_t bg_trace_result_size(const bg_trace_result* r) { return r ? r->a.size() : 0; }

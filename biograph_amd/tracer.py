@@ -98,34 +98,62 @@ def reference_ref_map(seqset, sequences):
     return out
 
 
+class PushTracer:
+    """A tracer session (bg_tracer_open): the seqset / readmap / ref_map arrays the host part consults are copied once,
+    trace() is one work item of trace_ref (a scaffold piece in one direction)."""
+
+    def __init__(self, seqset, readmap, ref_map, options=None):
+        self.ctx = seqset.ctx
+        self._keep = (seqset, readmap, ref_map)
+        self.h = C.c_void_p()
+        opt = options if options is not None else TraceOptions()
+        capi.check(capi.lib().bg_tracer_open(self.ctx.h, seqset.h, readmap.h, C.c_void_p(ref_map.ptr), C.byref(opt), C.byref(self.h)))
+
+    def trace(self, extents, start=0, limit=None, end_pos=None, rev_comp=False, pair_count=True, with_stats=False):
+        """extents = [(offset, ACGT string)] of one scaffold, ascending.  -> [TraceAssembly] in output order (+ stats)."""
+        L = capi.lib()
+        n = len(extents)
+        offs = (C.c_int64 * max(n, 1))(*[int(o) for o, _ in extents])
+        bufs = [s.encode() for _, s in extents]
+        ptrs = (C.c_char_p * max(n, 1))(*bufs)
+        lens = (C.c_uint64 * max(n, 1))(*[len(b) for b in bufs])
+        calc_end = max([o + len(s) for o, s in extents] + [0])
+        end_pos = calc_end if end_pos is None else end_pos
+        limit = end_pos if limit is None else limit
+        h = C.c_void_p()
+        capi.check(L.bg_tracer_trace(self.h, n, offs, ptrs, lens, end_pos, start, limit, int(bool(rev_comp)), int(bool(pair_count)),
+                                     C.byref(h)))
+        try:
+            out = []
+            a = _Asm()
+            for i in range(L.bg_trace_result_size(h)):
+                capi.check(L.bg_trace_result_get(h, i, C.byref(a)))
+                out.append(TraceAssembly(a))
+            if not with_stats:
+                return out
+            st = _Stats()
+            capi.check(L.bg_trace_result_stats(h, C.byref(st)))
+            return out, {k: int(getattr(st, k)) for k in _STAT_FIELDS}
+        finally:
+            L.bg_trace_result_free(h)
+
+    def close(self):
+        if self.h:
+            capi.lib().bg_tracer_close(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def push_trace(seqset, readmap, ref_map, extents, start=0, limit=None, end_pos=None, rev_comp=False, pair_count=True,
                options=None, with_stats=False):
-    """extents = [(offset, ACGT string)] of one scaffold, ascending; ref_map = reference_ref_map(...).
-    -> [TraceAssembly] in output order (and the stats dict)."""
-    L = capi.lib()
-    ctx = seqset.ctx
-    n = len(extents)
-    offs = (C.c_int64 * max(n, 1))(*[int(o) for o, _ in extents])
-    bufs = [s.encode() for _, s in extents]
-    ptrs = (C.c_char_p * max(n, 1))(*bufs)
-    lens = (C.c_uint64 * max(n, 1))(*[len(b) for b in bufs])
-    calc_end = max([o + len(s) for o, s in extents] + [0])
-    end_pos = calc_end if end_pos is None else end_pos
-    limit = end_pos if limit is None else limit
-    opt = options if options is not None else TraceOptions()
-    h = C.c_void_p()
-    capi.check(L.bg_push_trace(ctx.h, seqset.h, readmap.h, C.c_void_p(ref_map.ptr), n, offs, ptrs, lens, end_pos, start, limit,
-                               int(bool(rev_comp)), int(bool(pair_count)), C.byref(opt), C.byref(h)))
+    """One-shot form (bg_push_trace semantics): ref_map = reference_ref_map(...)."""
+    t = PushTracer(seqset, readmap, ref_map, options)
     try:
-        out = []
-        a = _Asm()
-        for i in range(L.bg_trace_result_size(h)):
-            capi.check(L.bg_trace_result_get(h, i, C.byref(a)))
-            out.append(TraceAssembly(a))
-        if not with_stats:
-            return out
-        st = _Stats()
-        capi.check(L.bg_trace_result_stats(h, C.byref(st)))
-        return out, {k: int(getattr(st, k)) for k in _STAT_FIELDS}
+        return t.trace(extents, start, limit, end_pos, rev_comp, pair_count, with_stats)
     finally:
-        L.bg_trace_result_free(h)
+        t.close()

@@ -420,6 +420,15 @@ int bg_push_trace(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const 
                   const int64_t* ext_offset, const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos,
                   int64_t start_offset, int64_t limit_offset, int rev_comp, int pair_count,
                   const bg_trace_options* options /* NULL = defaults */, bg_trace_result** out);
+/* The same as a session: the host copies of the seqset / readmap / ref_map arrays the tracer consults are made once
+ * (a trace_ref object and its assemble_options), bg_tracer_trace is one work item (scaffold piece x direction). */
+typedef struct bg_tracer bg_tracer;
+int bg_tracer_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const uint8_t* d_ref_map,
+                   const bg_trace_options* options /* NULL = defaults */, bg_tracer** out);
+int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                    const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset, int rev_comp,
+                    int pair_count, bg_trace_result** out);
+void bg_tracer_close(bg_tracer* t);
 uint64_t bg_trace_result_size(const bg_trace_result* r);
 int bg_trace_result_get(const bg_trace_result* r, uint64_t i, bg_trace_assembly* out);  /* pointers live as long as r */
 int bg_trace_result_stats(const bg_trace_result* r, bg_trace_stats* out);

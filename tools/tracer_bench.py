@@ -41,12 +41,15 @@ def main():
     rmap = tracer.reference_ref_map(ss, [ref])
     t_rmap = time.perf_counter() - t0
     opt = tracer.TraceOptions(min_overlap=int(0.7 * args.read_len))
+    t0 = time.perf_counter()
+    session = tracer.PushTracer(ss, rm, rmap, opt)
+    t_open = time.perf_counter() - t0
     g = torch.Generator(device=dev)
     g.manual_seed(args.seed + 1)
     snp = torch.rand(G, generator=g, device=dev) < 0.001
     snp_pos = set(torch.nonzero(snp).flatten().cpu().tolist())
     out = {"genome_len": G, "entries": ss.size(), "reads": len(rm) // 2 if hasattr(rm, "__len__") else None,
-           "ref_map_seconds": round(t_rmap, 3), "chunk_size": args.chunk_size, "chunks": []}
+           "ref_map_seconds": round(t_rmap, 3), "session_open_seconds": round(t_open, 3), "chunk_size": args.chunk_size, "chunks": []}
     for c in range(args.chunks):
         start = c * args.chunk_size
         limit = min(G, start + args.chunk_size)
@@ -55,8 +58,7 @@ def main():
         row = {"start": start, "limit": limit}
         for rev in (False, True):
             t0 = time.perf_counter()
-            asms, st = tracer.push_trace(ss, rm, rmap, [(0, ref)], start=start, limit=limit, rev_comp=rev, options=opt,
-                                         with_stats=True)
+            asms, st = session.trace([(0, ref)], start=start, limit=limit, rev_comp=rev, with_stats=True)
             dt = time.perf_counter() - t0
             var = [a for a in asms if not a.matches_reference]
             hit = set()
@@ -74,6 +76,7 @@ def main():
                 "planted_snps_in_chunk": planted, "planted_snps_in_assemblies": len(hit),
                 "traces_per_s": round(st["traces"] / dt, 1), "ref_bases_per_s": round((limit - start) / dt, 1)}
         out["chunks"].append(row)
+    session.close()
     rmap.free()
     print(json.dumps(out))
 
