@@ -158,6 +158,54 @@ def driver_leg(ctx, ss, genome, dev, args, region=None, rm=None):
             "other_calls": len(found) - hit - indel_hit, "min_overlap": 105}
 
 
+def push_tracer_leg(ss, rm, ref_map_dev, genome, args, chunks=2, chunk_size=1_000_000):
+    """The production push tracer (first slice: csrc/tracer.cpp) on the first `chunks` work items of
+    trace_ref (scaffold_split_size pieces), forward and reverse, with pair_counter: seconds per piece and direction, and how
+    many of the planted SNPs of the pieces lie inside the non-reference assemblies it emits."""
+    import numpy as np
+    import torch
+    from biograph_amd import tracer
+
+    class _Dev:  # reference_ref_map's return type: the ref_map bytes are resident already
+        ptr = ref_map_dev.data_ptr()
+    G = int(genome.numel())
+    region = min(G, chunks * chunk_size)
+    ref = np.frombuffer(b"ACGT", np.uint8)[genome[:min(G, region + 200_000)].cpu().numpy()].tobytes().decode()
+    g = torch.Generator(device=genome.device)
+    g.manual_seed(args.seed + 1)
+    snp = torch.rand(G, generator=g, device=genome.device) < 0.001
+    snp_pos = set(torch.nonzero(snp[:region]).flatten().cpu().tolist())
+    t0 = time.perf_counter()
+    session = tracer.PushTracer(ss, rm, _Dev, tracer.TraceOptions(min_overlap=int(0.7 * args.read_len)))
+    t_open = time.perf_counter() - t0
+    secs, traces, rounds, asms_n, hit = [], 0, 0, 0, set()
+    for c in range(chunks):
+        start, limit = c * chunk_size, min(region, (c + 1) * chunk_size)
+        if start >= limit:
+            break
+        for rev in (False, True):
+            t0 = time.perf_counter()
+            asms, st = session.trace([(0, ref)], start=start, limit=limit, rev_comp=rev, with_stats=True)
+            secs.append(round(time.perf_counter() - t0, 3))
+            traces += st["traces"]
+            rounds += st["device_rounds"]
+            for a in asms:
+                if a.matches_reference:
+                    continue
+                asms_n += 1
+                if a.right_anchor_len and len(a.seq) == a.right_offset - a.left_offset:
+                    for i, (x, y) in enumerate(zip(a.seq, ref[a.left_offset:a.right_offset])):
+                        if x != y and (a.left_offset + i) in snp_pos:
+                            hit.add(a.left_offset + i)
+    session.close()
+    total = sum(secs)
+    return {"reference_bases": region, "pieces": len(secs) // 2, "directions": 2, "session_open_seconds": round(t_open, 3),
+            "seconds_per_piece_and_direction": secs, "traces": traces, "device_rounds": rounds,
+            "non_reference_assemblies": asms_n, "planted_snps_in_region": len(snp_pos),
+            "planted_snps_inside_assemblies": len(hit), "ref_bases_per_s_per_direction": round(2 * region / max(total, 1e-9), 1),
+            "min_overlap": int(0.7 * args.read_len), "what": "tracer + pair_counter (anchor_dropper and the later steps are not built)"}
+
+
 def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
     """Overlap-walk throughput on the seqset just built (N=1 only, outside the build's timed region):
     ref_map::build over both strands of the reference haplotype (2 x G dependent push_front_drop calls in
@@ -292,6 +340,7 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
                # whole pipeline, host bookkeeping included, are graph_discover_driver.anchored_variants_per_s
                "candidate_sites_per_s_kernels_only": round(ns / (t_br + t_prop + t_tr), 1)}
     drv = driver_leg(ctx, ss, genome, dev, args, rm=rm) if args is not None else None
+    push = push_tracer_leg(ss, rm, out, genome, args) if args is not None else None
     rm.free()
     ss.free()
     pfd_ref = 2 * G + 2 * 256 * (G // 4096 + 1)
@@ -306,7 +355,7 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
                                 "variants_per_s": round(sites / t_br, 1), "branch_sites": sites,
                                 "push_front_drop_per_s": round(pfd_br / t_br / 1e9, 3),
                                 "algorithmic_GBps": round(pfd_br * 52 / t_br / 1e9, 1)},
-            "push_to_pair_extension": ext, "graph_discover_driver": drv}
+            "push_to_pair_extension": ext, "graph_discover_driver": drv, "push_tracer": push}
 
 
 def end_to_end_leg(seq, n_reads, read_len, dev, args):
