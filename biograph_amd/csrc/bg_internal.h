@@ -56,6 +56,11 @@ struct bg_ctx {
   DeviceArena* arena = &own_arena;  // the process-wide arena of the device when torch shares it (bg_torch_malloc)
   std::vector<bg::TimingRec> recs;
   std::vector<hipEvent_t> event_pool;
+  // two pinned host staging buffers for large host <-> device copies (allocated at first use: pinning 128 MiB costs tens
+  // of milliseconds; released with the context)
+  void* pinned[2] = {nullptr, nullptr};
+  static constexpr size_t kPinnedChunk = size_t(64) << 20;
+  int pinned_buffers();
 
   int alloc(size_t bytes, void** out);
   void release(void* p);
@@ -68,6 +73,10 @@ struct bg_ctx {
 };
 
 namespace bg {
+
+// Large copies through the context's pinned buffers, double-buffered, the host side of every piece spread over threads
+// (csrc/fastq.hip).  threads <= 0: hardware_concurrency (at most 32).
+int staged_download(bg_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes, int threads);
 
 // RAII device buffer drawn from the context cache.
 template <class T>

@@ -422,11 +422,13 @@ static int cmd_create(int argc, char** argv) {
   double t2 = now_s();
   std::vector<const char*> av(argv, argv + argc);
   check(bg_seqset_write(ctx, ss, (out + "/seqset").c_str(), argc, av.data()), "bg_seqset_write");
+  const double t_ss_written = now_s() - t2;
   char sha[41];
   std::string rm_tmp = out + "/coverage/tmp.readmap";
   check(bg_readmap_write(ctx, rm, rm_tmp.c_str(), argc, av.data(), sha), "bg_readmap_write");
   if (rename(rm_tmp.c_str(), (out + "/coverage/" + sha + ".readmap").c_str()) != 0) die("Could not rename " + rm_tmp);
   double t_write = now_s() - t2, t_total = now_s() - t0;
+  logf("Written: seqset %.3f s, readmap + digest %.3f s", t_ss_written, t_write - t_ss_written);
 
   std::string id = a.get("id");
   if (id.empty()) id = stem_of(out);

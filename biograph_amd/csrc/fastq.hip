@@ -132,6 +132,16 @@ using namespace bg;
 // Host -> device through two pinned staging buffers: `threads` host threads fill one (fill(dst, offset, bytes))
 // while the DMA engine drains the other (a pageable hipMemcpy stages through one small internal buffer,
 // single-threaded).
+int bg_ctx::pinned_buffers() {
+  for (int b = 0; b < 2; ++b)
+    if (!pinned[b] && hipHostMalloc(&pinned[b], kPinnedChunk, hipHostMallocDefault) != hipSuccess) {
+      pinned[b] = nullptr;
+      bg::set_error("pinned staging buffer: out of memory");
+      return BG_ENOMEM;
+    }
+  return BG_OK;
+}
+
 template <class Fill>
 static int staged_upload(bg_ctx* ctx, void* d_dst, uint64_t bytes, int threads, Fill fill, const char* who) {
   BG_HIP(hipSetDevice(ctx->device));
@@ -139,11 +149,10 @@ static int staged_upload(bg_ctx* ctx, void* d_dst, uint64_t bytes, int threads, 
   if (threads < 1) threads = int(std::thread::hardware_concurrency());
   if (threads < 1) threads = 1;
   if (threads > 32) threads = 32;
-  const uint64_t chunk = 64ull << 20;
-  void* pin[2] = {nullptr, nullptr};
+  const uint64_t chunk = bg_ctx::kPinnedChunk;
+  BG_TRY(ctx->pinned_buffers());
+  void* const* pin = ctx->pinned;
   hipEvent_t ev[2];
-  BG_HIP(hipHostMalloc(&pin[0], chunk, hipHostMallocDefault));
-  if (hipHostMalloc(&pin[1], chunk, hipHostMallocDefault) != hipSuccess) { (void)hipHostFree(pin[0]); set_error("pinned staging buffer: out of memory"); return BG_ENOMEM; }
   BG_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
   BG_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
   int rc = BG_OK;
@@ -175,11 +184,48 @@ static int staged_upload(bg_ctx* ctx, void* d_dst, uint64_t bytes, int threads, 
   if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == BG_OK) rc = BG_ENODEV;
   (void)hipEventDestroy(ev[0]);
   (void)hipEventDestroy(ev[1]);
-  (void)hipHostFree(pin[0]);
-  (void)hipHostFree(pin[1]);
   if (rc == BG_EIO) set_error("%s: read error", who);
   else if (rc != BG_OK) set_error("%s: HIP error during the staged copy", who);
   return rc;
+}
+
+// device -> host the same way round: piece c + 1 crosses the bus into one pinned buffer while the host's threads copy
+// piece c out of the other
+int bg::staged_download(bg_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes, int threads) {
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!bytes) return BG_OK;
+  if (threads < 1) threads = int(std::thread::hardware_concurrency());
+  if (threads < 1) threads = 1;
+  if (threads > 32) threads = 32;
+  const uint64_t chunk = bg_ctx::kPinnedChunk;
+  BG_TRY(ctx->pinned_buffers());
+  void* const* pin = ctx->pinned;
+  auto drain = [&](int b, uint64_t off, uint64_t sz) {
+    char* dst = static_cast<char*>(h_dst) + off;
+    const char* src = static_cast<const char*>(pin[b]);
+    const int nt = sz < (8u << 20) ? 1 : threads;
+    if (nt == 1) { memcpy(dst, src, sz); return; }
+    std::vector<std::thread> pool;
+    const uint64_t per = (sz + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+      const uint64_t lo = uint64_t(t) * per, hi = lo + per < sz ? lo + per : sz;
+      if (lo < hi) pool.emplace_back([=] { memcpy(dst + lo, src + lo, hi - lo); });
+    }
+    for (auto& th : pool) th.join();
+  };
+  uint64_t issued = 0, prev_off = 0, prev_sz = 0;
+  for (int c = 0; issued < bytes; ++c) {
+    const int b = c & 1;
+    const uint64_t sz = bytes - issued < chunk ? bytes - issued : chunk;
+    BG_HIP(hipMemcpyAsync(pin[b], static_cast<const char*>(d_src) + issued, sz, hipMemcpyDeviceToHost, ctx->stream));
+    if (c) drain(b ^ 1, prev_off, prev_sz);  // the previous piece is complete (synchronised below, one iteration ago)
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    prev_off = issued;
+    prev_sz = sz;
+    issued += sz;
+  }
+  drain(int(((issued + chunk - 1) / chunk - 1) & 1), prev_off, prev_sz);
+  return BG_OK;
 }
 
 extern "C" int bg_dev_upload_pinned(bg_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes, int threads) {

@@ -585,6 +585,7 @@ static int rm_part_bytes(bg_ctx* ctx, const bg_readmap* rm, const std::string& p
   auto dl = [&](const uint64_t* d, uint64_t words) -> int {
     out->resize(words * 8);
     if (!words) return BG_OK;
+    if (words * 8 >= (8u << 20)) return staged_download(ctx, &(*out)[0], d, words * 8, 0);
     BG_HIP(hipMemcpyAsync(&(*out)[0], d, words * 8, hipMemcpyDeviceToHost, ctx->stream));
     BG_HIP(hipStreamSynchronize(ctx->stream));
     return BG_OK;

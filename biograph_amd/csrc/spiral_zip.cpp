@@ -8,26 +8,50 @@
 #include <string.h>
 #include <time.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+#include <atomic>
 #include <fstream>
+#include <mutex>
 #include <random>
+#include <thread>
 
 #include "bg_internal.h"
 
 namespace bg {
 
+// CRC-32 (zip), slicing by 8: ~2 GB/s per host thread instead of ~0.4 byte-at-a-time; the members of a container are
+// checksummed on separate threads.
 static uint32_t crc32_of(const std::string& s) {
-  static uint32_t table[256];
-  static bool init = false;
-  if (!init) {
+  static uint32_t T[8][256];
+  static std::once_flag once;
+  std::call_once(once, [] {
     for (uint32_t i = 0; i < 256; ++i) {
       uint32_t c = i;
       for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-      table[i] = c;
+      T[0][i] = c;
     }
-    init = true;
-  }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xff];
+  });
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(s.data());
+  size_t n = s.size();
   uint32_t c = 0xFFFFFFFFu;
-  for (unsigned char ch : s) c = table[(c ^ ch) & 0xff] ^ (c >> 8);
+  while (n >= 8) {
+    uint32_t a, b;
+    memcpy(&a, p, 4);
+    memcpy(&b, p + 4, 4);
+    a ^= c;
+    c = T[7][a & 0xff] ^ T[6][(a >> 8) & 0xff] ^ T[5][(a >> 16) & 0xff] ^ T[4][a >> 24] ^ T[3][b & 0xff] ^ T[2][(b >> 8) & 0xff] ^
+        T[1][(b >> 16) & 0xff] ^ T[0][b >> 24];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) c = T[0][(c ^ *p++) & 0xff] ^ (c >> 8);
   return c ^ 0xFFFFFFFFu;
 }
 
@@ -56,11 +80,33 @@ int spiral_zip_write_layout(const char* path, const std::vector<ZipPart>& parts,
   std::vector<Cd> cds;
   uint64_t pos = 0;
   if (data_offsets) data_offsets->clear();
+  // checksums of the members on the host's threads (largest first), then the headers in one stream with room left for
+  // the bodies, which threads fill in place in 8 MiB pieces: a page-cache / tmpfs write is page allocation, and that
+  // scales with threads
+  std::vector<uint32_t> crcs(parts.size(), 0);
+  {
+    std::vector<size_t> order;
+    for (size_t i = 0; i < parts.size(); ++i)
+      if (!parts[i].raw_crc0 && !parts[i].hole_size && parts[i].data.size() >= (1u << 20)) order.push_back(i);
+      else if (!parts[i].raw_crc0 && !parts[i].hole_size) crcs[i] = crc32_of(parts[i].data);
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return parts[a].data.size() > parts[b].data.size(); });
+    std::atomic<size_t> next{0};
+    auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < order.size();) crcs[order[k]] = crc32_of(parts[order[k]].data); };
+    std::vector<std::thread> pool;
+    const size_t nt = std::min<size_t>(order.size(), std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+    for (size_t t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+  }
+  struct Body { const std::string* data; uint64_t offset; };
+  std::vector<Body> bodies;
+  size_t part_index = 0;
   for (const ZipPart& p : parts) {
     const bool hole = p.hole_size != 0;
     uint64_t size = hole ? p.hole_size : p.data.size();
     bool big = size >= 0xffffffffull;
-    uint32_t crc = p.raw_crc0 ? 0u : crc32_of(p.data);
+    uint32_t crc = crcs[part_index++];
+    const bool later = !hole && size >= (4u << 20);  // written in place below
     std::string h;
     put32(h, 0x04034b50);
     put16(h, 45);  // version needed (zip64)
@@ -78,9 +124,10 @@ int spiral_zip_write_layout(const char* path, const std::vector<ZipPart>& parts,
     put16(h, 16);
     put64(h, big ? size : 0);
     put64(h, big ? size : 0);
+    if (later) bodies.push_back(Body{&p.data, pos + h.size()});
     if (fwrite(h.data(), 1, h.size(), f) != h.size() ||
-        (!hole && size && fwrite(p.data.data(), 1, size, f) != size) ||
-        (hole && fseeko(f, off_t(size), SEEK_CUR) != 0)) {
+        (!hole && !later && size && fwrite(p.data.data(), 1, size, f) != size) ||
+        ((hole || later) && fseeko(f, off_t(size), SEEK_CUR) != 0)) {
       set_error("write error on %s: %s", path, strerror(errno));
       fclose(f);
       return BG_EIO;
@@ -151,6 +198,35 @@ int spiral_zip_write_layout(const char* path, const std::vector<ZipPart>& parts,
   bool ok = fwrite(cd.data(), 1, cd.size(), f) == cd.size();
   ok = (fclose(f) == 0) && ok;
   if (!ok) { set_error("write error on %s: %s", path, strerror(errno)); return BG_EIO; }
+  if (!bodies.empty()) {
+    const int fd = open(path, O_WRONLY);
+    if (fd < 0) { set_error("write error on %s: %s", path, strerror(errno)); return BG_EIO; }
+    struct Piece { const char* src; uint64_t off, len; };
+    std::vector<Piece> pieces;
+    const uint64_t kPiece = 8ull << 20;
+    for (const Body& b : bodies)
+      for (uint64_t o = 0; o < b.data->size(); o += kPiece)
+        pieces.push_back(Piece{b.data->data() + o, b.offset + o, std::min<uint64_t>(kPiece, b.data->size() - o)});
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    auto work = [&] {
+      for (size_t k; (k = next.fetch_add(1)) < pieces.size();) {
+        const Piece& pc = pieces[k];
+        uint64_t done = 0;
+        while (done < pc.len) {
+          const ssize_t w = pwrite(fd, pc.src + done, pc.len - done, off_t(pc.off + done));
+          if (w <= 0) { failed = 1; return; }
+          done += uint64_t(w);
+        }
+      }
+    };
+    std::vector<std::thread> pool;
+    const size_t nt = std::min<size_t>(pieces.size(), std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+    for (size_t t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+    if (close(fd) != 0 || failed) { set_error("write error on %s: %s", path, strerror(errno)); return BG_EIO; }
+  }
   return BG_OK;
 }
 
@@ -230,13 +306,51 @@ int spiral_zip_read(const char* path, std::map<std::string, std::string>* parts)
   return BG_OK;
 }
 
+// SHA-1 with the x86 SHA extensions (sha1rnds4 does four rounds, sha1msg1/2 the message schedule): 2-3 GB/s instead of
+// the 0.5 GB/s of the portable rounds below -- a 130 MB readmap's digest was a quarter of a second of `bgbinary create`.
+#if defined(__x86_64__)
+__attribute__((target("sha,sse4.1,ssse3"))) static void sha1_blocks_ni(uint32_t h[5], const uint8_t* data, size_t nblocks) {
+  const __m128i mask = _mm_set_epi64x(0x0001020304050607ll, 0x08090a0b0c0d0e0fll);
+  __m128i abcd = _mm_shuffle_epi32(_mm_loadu_si128(reinterpret_cast<const __m128i*>(h)), 0x1B);
+  __m128i e0 = _mm_set_epi32(int(h[4]), 0, 0, 0);
+  for (; nblocks; --nblocks, data += 64) {
+    const __m128i abcd_save = abcd, e_save = e0;
+    __m128i w[20];
+    for (int g = 0; g < 4; ++g) w[g] = _mm_shuffle_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(data + 16 * g)), mask);
+    for (int g = 4; g < 20; ++g)
+      w[g] = _mm_sha1msg2_epu32(_mm_xor_si128(_mm_sha1msg1_epu32(w[g - 4], w[g - 3]), w[g - 2]), w[g - 1]);
+    __m128i save = abcd, t = _mm_add_epi32(e0, w[0]);
+    abcd = _mm_sha1rnds4_epu32(abcd, t, 0);
+#define BG_SHA1_STEP(G, F)                    \
+    t = _mm_sha1nexte_epu32(save, w[G]);      \
+    save = abcd;                              \
+    abcd = _mm_sha1rnds4_epu32(abcd, t, F);
+    BG_SHA1_STEP(1, 0) BG_SHA1_STEP(2, 0) BG_SHA1_STEP(3, 0) BG_SHA1_STEP(4, 0)
+    BG_SHA1_STEP(5, 1) BG_SHA1_STEP(6, 1) BG_SHA1_STEP(7, 1) BG_SHA1_STEP(8, 1) BG_SHA1_STEP(9, 1)
+    BG_SHA1_STEP(10, 2) BG_SHA1_STEP(11, 2) BG_SHA1_STEP(12, 2) BG_SHA1_STEP(13, 2) BG_SHA1_STEP(14, 2)
+    BG_SHA1_STEP(15, 3) BG_SHA1_STEP(16, 3) BG_SHA1_STEP(17, 3) BG_SHA1_STEP(18, 3) BG_SHA1_STEP(19, 3)
+#undef BG_SHA1_STEP
+    e0 = _mm_sha1nexte_epu32(save, e_save);
+    abcd = _mm_add_epi32(abcd, abcd_save);
+  }
+  _mm_storeu_si128(reinterpret_cast<__m128i*>(h), _mm_shuffle_epi32(abcd, 0x1B));
+  h[4] = uint32_t(_mm_extract_epi32(e0, 3));
+}
+static bool sha1_have_ni() { return __builtin_cpu_supports("sha") && !getenv("BG_SHA1_PORTABLE"); }
+#else
+static void sha1_blocks_ni(uint32_t*, const uint8_t*, size_t) {}
+static bool sha1_have_ni() { return false; }
+#endif
+
 // SHA-1 of a file (FIPS 180-1): the reference names coverage/<sha1>.readmap after the digest of the
 // written container (biograph_create.cpp:827-828, sha1_hash over the file).
 int sha1_file_hex(const char* path, char* hex41) {
   FILE* f = fopen(path, "rb");
   if (!f) { set_error("%s: %s", path, strerror(errno)); return BG_EIO; }
   uint32_t h[5] = {0x67452301u, 0xEFCDAB89u, 0x98BADCFEu, 0x10325476u, 0xC3D2E1F0u};
+  const bool ni = sha1_have_ni();
   auto block = [&](const uint8_t* b) {
+    if (ni) { sha1_blocks_ni(h, b, 1); return; }
     uint32_t w[80];
     for (int i = 0; i < 16; ++i)
       w[i] = uint32_t(b[4 * i]) << 24 | uint32_t(b[4 * i + 1]) << 16 | uint32_t(b[4 * i + 2]) << 8 | b[4 * i + 3];
@@ -264,7 +378,8 @@ int sha1_file_hex(const char* path, char* hex41) {
     size_t got = fread(buf.data(), 1, buf.size(), f);
     total += got;
     size_t full = got / 64 * 64;
-    for (size_t o = 0; o < full; o += 64) block(buf.data() + o);
+    if (ni) sha1_blocks_ni(h, buf.data(), full / 64);
+    else for (size_t o = 0; o < full; o += 64) block(buf.data() + o);
     if (got < buf.size()) {
       ntail = got - full;
       memcpy(tail, buf.data() + full, ntail);
@@ -284,3 +399,9 @@ int sha1_file_hex(const char* path, char* hex41) {
 }
 
 }  // namespace bg
+
+// SHA-1 of a file as 40 hex digits + NUL: how a readmap is named inside a .bg directory.  Host only.
+extern "C" int bg_sha1_file(const char* path, char* hex41) {
+  if (!path || !hex41) { bg::set_error("bg_sha1_file: null argument"); return BG_EINVAL; }
+  return bg::sha1_file_hex(path, hex41);
+}

@@ -273,6 +273,9 @@ int bg_readmap_part(bg_ctx* ctx, const bg_readmap* rm, const char* part, void* h
  * coverage/<sha1>.readmap in a .bg directory (biograph_create.cpp:827-828). */
 int bg_readmap_write(bg_ctx* ctx, const bg_readmap* rm, const char* path, int argc, const char* const* argv,
                      char* h_sha1_hex);
+/* The digest bg_readmap_write reports, for any file (sha1_hash over the file, biograph_create.cpp:827-828); uses the x86
+ * SHA extensions when the host has them.  Host only. */
+int bg_sha1_file(const char* path, char* hex41);
 void bg_readmap_free(bg_readmap* rm);
 /* Opens a readmap container (format 1.2.0 with the mate loop table) and keeps it resident. */
 int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out);

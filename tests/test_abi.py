@@ -62,3 +62,28 @@ def test_build_files_list_the_same_sources():
     bz = open(os.path.join(root, "BUILD.bazel")).read()
     blk = bz[bz.index("for f in ["):bz.index("BGSEQ_HDRS")]
     assert sorted(re.findall(r'"([\w]+\.(?:hip|cpp))"', blk)) == want
+
+
+def test_sha1_file_both_code_paths(tmp_path, monkeypatch):
+    """bg_sha1_file (the name of a readmap inside a .bg directory) against hashlib, through the SHA-extension rounds and
+    through the portable ones, at the padding edges."""
+    import ctypes as C
+    import hashlib
+    import random
+    from biograph_amd import capi
+    L = capi.lib()
+    rnd = random.Random(1)
+    for n in (0, 1, 55, 56, 57, 63, 64, 65, 119, 120, 128, (1 << 20) - 1, 1 << 20, (1 << 20) + 77, 3 * (1 << 20) + 5):
+        data = bytes(rnd.getrandbits(8) for _ in range(min(n, 4096))) * (n // 4096 + 1)
+        data = data[:n]
+        p = tmp_path / "blob"
+        p.write_bytes(data)
+        want = hashlib.sha1(data).hexdigest()
+        for portable in ("", "1"):
+            if portable:
+                monkeypatch.setenv("BG_SHA1_PORTABLE", "1")
+            else:
+                monkeypatch.delenv("BG_SHA1_PORTABLE", raising=False)
+            buf = C.create_string_buffer(41)
+            capi.check(L.bg_sha1_file(str(p).encode(), buf))
+            assert buf.value.decode() == want, (n, portable)
