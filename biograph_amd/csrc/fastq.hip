@@ -148,7 +148,7 @@ static int staged_upload(bg_ctx* ctx, void* d_dst, uint64_t bytes, int threads, 
   if (!bytes) return BG_OK;
   if (threads < 1) threads = int(std::thread::hardware_concurrency());
   if (threads < 1) threads = 1;
-  if (threads > 32) threads = 32;
+  if (threads > 12) threads = 12;  // 8 threads fill a 64 MiB piece as fast as the bus drains it (tools/upload_rate.py); more only add start-up
   const uint64_t chunk = bg_ctx::kPinnedChunk;
   BG_TRY(ctx->pinned_buffers());
   void* const* pin = ctx->pinned;
