@@ -27,7 +27,6 @@
 #include <time.h>
 
 #include <algorithm>
-#include <deque>
 #include <map>
 #include <memory>
 #include <set>
@@ -190,7 +189,7 @@ struct Trace {
   // window of the sliding tables at this offset
   int32_t win_lo = 0, win_hi = 0;
 
-  std::deque<Path> paths;
+  std::vector<Path> paths;   // referenced by index only (no reference is held across alloc())
   std::vector<NextPath> next_paths;
   std::vector<Rejoin> rejoins;   // std::multiset order: worst first, best last
   std::vector<int> dead_ends;    // std::set<const path*>: kept in allocation order
@@ -413,6 +412,12 @@ struct Trace {
   bool finish() {
     output_rejoins();
     done = true;
+    // give the search state back on the thread that allocated it (frees from another thread contend in malloc)
+    std::vector<Path>().swap(paths);
+    std::vector<NextPath>().swap(next_paths);
+    std::vector<Rejoin>().swap(rejoins);
+    std::vector<int>().swap(dead_ends);
+    std::string().swap(left_anchor);
     return false;
   }
 
@@ -927,6 +932,7 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
   w.seconds_device = w.seconds_host = w.seconds_tables = w.seconds_start = w.seconds_teardown = 0;
   std::vector<Extent> ext;
   int64_t calc_end = 0;
+  const double t_ext = now_seconds();
   for (uint64_t i = 0; i < n_extents; ++i) {
     ext.push_back(Extent{ext_offset[i], std::string(ext_seq[i], ext_len[i])});
     for (char c : ext.back().seq)
@@ -939,6 +945,8 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
   std::unique_ptr<bg_trace_result> res(new bg_trace_result);
   if (rev_comp && w.o.only_trace_forward) { memset(&res->stats, 0, sizeof(res->stats)); *out = res.release(); return BG_OK; }
   std::vector<bg_trace_assembly_rec> raw;
+  const double s_ext = now_seconds() - t_ext;
+  const double t_chunk = now_seconds();
   if (rev_comp) {  // scaffold::rev_comp (scaffold.cpp:163-175)
     std::vector<Extent> rc;
     for (auto it = ext.rbegin(); it != ext.rend(); ++it)
@@ -947,6 +955,7 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
   } else {
     BG_TRY(trace_chunk(w, ext, start_offset, limit_offset, &raw));
   }
+  const double s_chunk = now_seconds() - t_chunk;
   std::vector<bg_trace_assembly_rec> counted;
   if (pair_count) {
     PairCounter pc{w, &counted};
@@ -970,8 +979,8 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
   res->a = std::move(counted);
   res->stats = w.stats;
   if (getenv("BG_TRACER_TIMING"))
-    fprintf(stderr, "bg_tracer_trace: %.3f s in all: tables %.3f s, start %.3f s, device rounds %.3f s, host replay %.3f s, teardown %.3f s (%d threads), %llu traces\n",
-            now_seconds() - t_call, w.seconds_tables, w.seconds_start, w.seconds_device, w.seconds_host, w.seconds_teardown, g_tracer_threads, (unsigned long long)w.stats.traces);
+    fprintf(stderr, "bg_tracer_trace: %.3f s in all (extents %.3f, chunk %.3f): tables %.3f s, start %.3f s, device rounds %.3f s, host replay %.3f s, teardown %.3f s (%d threads), %llu traces\n",
+            now_seconds() - t_call, s_ext, s_chunk, w.seconds_tables, w.seconds_start, w.seconds_device, w.seconds_host, w.seconds_teardown, g_tracer_threads, (unsigned long long)w.stats.traces);
   // the chunk's tables are not kept between work items
   std::vector<std::pair<int32_t, uint64_t>>().swap(w.position_entries);
   std::vector<std::pair<uint64_t, int32_t>>().swap(w.entry_positions);
