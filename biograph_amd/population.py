@@ -90,22 +90,50 @@ def discover_chunk(ss, rm, extents, start, limit, min_overlap, max_pair_distance
             if a.left_offset is not None and a.right_offset is not None and not a.matches_reference]
 
 
+def push_trace_chunk(session, extents, end_pos, start, limit):
+    """One work item of trace_ref with the push tracer (trace_ref.cpp:142-206 without the pop passes): forward and
+    reverse -> [(left_offset, right_offset, seq)] of the non-reference assemblies, scaffold coordinates."""
+    out = []
+    for rev in (False, True):
+        for a in session.trace(extents, start=start, limit=limit, end_pos=end_pos, rev_comp=rev):
+            if not a.matches_reference:
+                out.append((a.left_offset, a.right_offset, a.seq))
+    return out
+
+
 def sharded_discover(comm, seqsets, readmaps, scaffolds, min_overlap, split_size=SCAFFOLD_SPLIT_SIZE,
-                     max_pair_distance=1000, gather=True):
+                     max_pair_distance=1000, gather=True, engine="graph", ref_maps=None):
     """seqsets[r] = rank r's replica of the (merged) seqset, readmaps[r] = {sample: Readmap on that replica},
     scaffolds = {name: bases}.  Work items = (sample, chunk), shared out round-robin.  Returns, on every rank,
-    {sample: [(scaffold, left, right, seq)]} sorted (gather=True), or each rank's own calls {r: {...}}."""
+    {sample: [(scaffold, left, right, seq)]} sorted (gather=True), or each rank's own calls {r: {...}}.
+    engine: "graph" = the graph-discover pipeline per chunk; "push" = the production push tracer (biograph_amd.tracer),
+    which needs ref_maps[r] = the ref_map of rank r's replica over the whole reference (tracer.reference_ref_map)."""
     ranks = comm.local_ranks
     samples = sorted(readmaps[ranks[0]])
     chunks = ref_chunks([(name, 0, len(seq)) for name, seq in scaffolds.items()], split_size)
     work = [(s, c) for s in samples for c in chunks]
     ext = {name: extents_of(seq) for name, seq in scaffolds.items()}
+    if engine not in ("graph", "push"):
+        raise ValueError("sharded_discover: engine must be 'graph' or 'push'")
+    if engine == "push" and ref_maps is None:
+        raise ValueError("sharded_discover: the push tracer needs ref_maps")
     mine = {}
     for r in ranks:
         calls = {s: [] for s in samples}
+        sessions = {}
         for s, (name, a, lim) in chunks_of_rank(work, r, comm.world):
-            for lo, ro, sq in discover_chunk(seqsets[r], readmaps[r][s], ext[name], a, lim, min_overlap, max_pair_distance):
+            if engine == "push":
+                from . import tracer
+                if s not in sessions:
+                    sessions[s] = tracer.PushTracer(seqsets[r], readmaps[r][s], ref_maps[r],
+                                                    tracer.TraceOptions(min_overlap=min_overlap, max_pair_distance=max_pair_distance))
+                found = push_trace_chunk(sessions[s], ext[name], len(scaffolds[name]), a, lim)
+            else:
+                found = discover_chunk(seqsets[r], readmaps[r][s], ext[name], a, lim, min_overlap, max_pair_distance)
+            for lo, ro, sq in found:
                 calls[s].append((name, lo, ro, sq))
+        for t in sessions.values():
+            t.close()
         mine[r] = calls
     if not gather:
         return mine

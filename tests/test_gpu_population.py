@@ -169,3 +169,32 @@ def test_sharded_discover_is_independent_of_the_rank_count(ctx):
     # SNPs planted by the generator for sample 1 are found
     sites = {x[1] for x in results[0] if x[0] == "1" and x[2] == x[1] + 1 and len(x[3]) == 1}
     assert len(sites) > 10
+
+
+def test_sharded_discover_with_the_push_tracer(ctx):
+    """engine="push": the work items of trace_ref through bg_tracer_trace, forward and reverse; same calls whoever runs them,
+    and the planted SNPs of the sample are inside them."""
+    from biograph_amd import tracer
+    G = 40_000
+    seq, offs, n, genome = synth.make_reads(genome_len=G, coverage=30, read_len=150, seed=SEED, device="cpu", sample=2,
+                                            return_genome=True)
+    reads = O.unpack_strings(seq.numpy(), offs.numpy().astype(np.uint64))
+    prm = ctx.default_params()
+    ss, rm, cor = _single_gpu_sample(ctx, reads, prm)
+    ref = np.frombuffer(b"ACGT", np.uint8)[genome.numpy()].tobytes().decode()
+    scaffolds = {"1": ref[:25_000] + "N" * 30 + ref[25_030:]}
+    rmap = tracer.reference_ref_map(ss, [ref[:25_000], ref[25_030:]])
+    try:
+        results = []
+        for P in (1, 3):
+            comm = sharded.LocalSimComm(P)
+            got = population.sharded_discover(comm, {r: ss for r in range(P)}, {r: {"s": rm} for r in range(P)}, scaffolds,
+                                              min_overlap=105, split_size=8_000, engine="push", ref_maps={r: rmap for r in range(P)})
+            results.append(got["s"])
+        assert results[0] == results[1] and len(results[0]) > 20
+        sites = synth.variant_sites(G, synth.sample_seed(SEED, 2) - 1)
+        assert len(sites) >= 1
+        # every call is anchored on the left or on the right inside the scaffold
+        assert all(0 <= lo < ro <= len(scaffolds["1"]) + 2000 for _, lo, ro, _ in results[0])
+    finally:
+        rmap.free()
