@@ -3,9 +3,9 @@ reference's production "push" tracer -- modules/variants/tracer.cpp (assemble :1
 trace :477-526, expand_next_path :528-673, add_rejoins :675-724, add_pairs_to_next_path :737-845,
 add_base_to_next_path :847-877, the queues :879-941, trace_next_paths :943-1021, output :1023-1250) with the
 direction wrapper of reversable_tracer.cpp:11-145 and the pair_counter step that follows it (pair_counter.cpp).
-The anchor_dropper step between them (anchor_drop.cpp) is NOT restated: assemblies that rejoin the reference pass
-through it unchanged (anchor_drop.cpp:196-202); dead-end assemblies come out of this restatement as the tracer
-emits them (right_anchor_len == 0).
+The anchor_dropper step between them (anchor_drop.cpp) is restated in oracle/align.py and plugged in through
+reversable_trace(anchor_drop=...); without it, assemblies that rejoin the reference are unchanged
+(anchor_drop.cpp:196-202) and dead-end assemblies come out as the tracer emits them (right_anchor_len == 0).
 
 Pinned on the vectors of modules/variants/tracer_test.cpp:167-304 (tests/test_oracle_tracer.py).
 
@@ -918,9 +918,12 @@ class PairCounter:
                 self._dec(self.left_ids, rid)
 
 
-def reversable_trace(graph, scaffold, options, rev_comp=False, start_offset=0, limit_offset=None, pair_count=True):
-    """reversable_tracer::assemble (reversable_tracer.cpp:76-145) for the push tracer, without the anchor_dropper:
-    tracer -> pair_counter -> (reversed back when rev_comp) -> list of assemblies in output order."""
+def reversable_trace(graph, scaffold, options, rev_comp=False, start_offset=0, limit_offset=None, pair_count=True,
+                     anchor_drop=None):
+    """reversable_tracer::assemble (reversable_tracer.cpp:76-145) for the push tracer:
+    tracer -> [anchor_dropper] -> pair_counter -> (reversed back when rev_comp) -> list of assemblies in output order.
+    `anchor_drop(scaffold, emit)` builds the anchor_dropper step (oracle/align.py's AnchorDropper; an object with
+    add / flush) over the scaffold the tracer runs on; None leaves the step out."""
     ref_end = scaffold.end_pos
     limit_offset = ref_end if limit_offset is None else min(limit_offset, ref_end)
     out = []
@@ -934,12 +937,17 @@ def reversable_trace(graph, scaffold, options, rev_comp=False, start_offset=0, l
 
     pc = PairCounter(graph, options, final) if pair_count else None
     sink = pc.add if pc is not None else final
+    run_sc = scaffold.rev_comp() if rev_comp else scaffold
+    ad = anchor_drop(run_sc, sink) if anchor_drop is not None else None
+    if ad is not None:
+        sink = ad.add
+    t = Tracer(graph, run_sc, options)
     if rev_comp:
-        t = Tracer(graph, scaffold.rev_comp(), options)
         t.assemble(ref_end - limit_offset, ref_end - start_offset, emit=sink)
     else:
-        t = Tracer(graph, scaffold, options)
         t.assemble(start_offset, limit_offset, emit=sink)
+    if ad is not None:
+        ad.flush()
     if pc is not None:
         pc.flush()
     return out

@@ -1,0 +1,201 @@
+"""The oracle's restatement of anchor_dropper -> aligner -> align_splitter (oracle/align.py) against the vectors of the
+reference's own test, modules/variants/align_test.cpp:59-375, transcribed (tseq letters are 10 bases each,
+dna_testutil), plus the scaffold helpers against scaffold_test-style hand cases.  CPU only."""
+import pytest
+
+from oracle import align as A
+from oracle import oracle as O
+from oracle import tracer as T
+
+tseq = O.tseq
+
+
+def asm(left, right, seq, la, ra):
+    a = T.Assembly()
+    a.left_offset, a.right_offset, a.seq, a.left_anchor_len, a.right_anchor_len = left, right, seq, la, ra
+    return a
+
+
+def is_ref(a, left, right):  # RefAssemblyIs, assemble_testutil.h:208-212
+    return a.matches_reference and (a.left_offset, a.right_offset, a.left_anchor_len, a.right_anchor_len) == (left, right, 0, 0)
+
+
+def is_var(a, left, seq, right):  # AssemblyIs, assemble_testutil.h:200-206
+    return (not a.matches_reference) and (a.left_offset, a.right_offset, a.seq) == (left, right, seq)
+
+
+def run(parts, asms, **opts):
+    sc = T.Scaffold(parts)
+    aligned, out = A.align_pipeline(A.AlignOptions(**opts), sc, asms)
+    for x, y in zip(out, out[1:]):  # expect_sorted(left_offset_less_than)
+        assert x.left_offset <= y.left_offset
+    for a in out:  # test_output of assemble_testutil.h:27-70
+        assert a.right_offset >= a.left_offset and (a.seq or a.right_offset > a.left_offset)
+        if a.matches_reference:
+            sub = A.subscaffold(sc, a.left_offset, a.right_offset - a.left_offset)
+            assert A.is_simple(sub) and sub.extents[0][1] == a.seq
+    return aligned, out
+
+
+def test_simple():
+    orig, variant = "T", "AA"
+    ref = tseq("abc") + orig + tseq("def")
+    aligned, out = run([(0, ref)], [asm(0, len(ref), tseq("abc") + variant + tseq("def"), 20, 20)])
+    assert [a.aligned_variants for a in aligned] == [[(30, 31, variant)]]
+    assert len(out) == 3 and is_ref(out[0], 0, 30) and is_var(out[1], 30, variant, 31) and is_ref(out[2], 31, 61)
+
+
+@pytest.mark.parametrize("kmer", [1, 2, 3, 4, 20, 31])
+def test_drop_right(kmer):
+    orig, variant = "T", "AA"
+    ref = tseq("abc") + orig + tseq("defdefdef")
+    aligned, out = run([(0, ref)], [asm(0, len(ref), tseq("abc") + variant + tseq("d"), 20, 0)],
+                       min_anchor_drop_overlap=10, max_kmer_size=kmer)
+    assert [a.aligned_variants for a in aligned] == [[(30, 31, variant)]]
+    assert (aligned[0].left_offset, aligned[0].right_offset) == (0, 41)
+    assert len(out) == 3 and is_ref(out[0], 0, 30) and is_var(out[1], 30, variant, 31) and is_ref(out[2], 31, 41)
+
+
+@pytest.mark.parametrize("kmer", [1, 2, 3, 4, 20, 31])
+def test_drop_right_short(kmer):
+    ref = tseq("abcdefghijklmnopqrstuvwxyz")
+    seq = tseq("abcd") + "G" + tseq("yz")
+    aligned, out = run([(0, ref)], [asm(0, len(seq), seq, 40, 0)], min_overlap=20, max_kmer_size=kmer)
+    assert [a.aligned_variants for a in aligned] == [[(40, 240, "G")]]
+    assert (aligned[0].left_offset, aligned[0].right_offset, aligned[0].right_anchor_len) == (0, 260, 20)
+
+
+def test_two_snps():
+    orig, variant = "TAT", "GAG"
+    ref = tseq("abc") + orig + tseq("def")
+    aligned, out = run([(5, ref)], [asm(5, 5 + len(ref), tseq("abc") + variant + tseq("def"), 1, 1)])
+    assert [a.aligned_variants for a in aligned] == [[(35, 36, "G"), (37, 38, "G")]]
+    assert len(out) == 5
+    assert is_ref(out[0], 5, 35) and is_var(out[1], 35, "G", 36) and is_ref(out[2], 36, 37)
+    assert is_var(out[3], 37, "G", 38) and is_ref(out[4], 38, 68)
+
+
+def test_multi_extent():
+    aligned, out = run([(0, tseq("abc")), (100, tseq("ghi"))], [asm(0, 130, tseq("abcdefghi"), 1, 1)])
+    assert [a.aligned_variants for a in aligned] == [[(30, 100, tseq("def"))]]
+    assert len(out) == 3 and is_ref(out[0], 0, 30) and is_var(out[1], 30, tseq("def"), 100) and is_ref(out[2], 100, 130)
+
+
+def test_insert_base():
+    aligned, out = run([(0, tseq("abcdef"))], [asm(0, 60, tseq("abc") + "T" + tseq("def"), 1, 1)])
+    assert [a.aligned_variants for a in aligned] == [[(30, 30, "T")]]
+    assert len(out) == 3 and is_ref(out[0], 0, 30) and is_var(out[1], 30, "T", 30) and is_ref(out[2], 30, 60)
+
+
+def test_delete_base():
+    aligned, out = run([(0, tseq("abc") + "T" + tseq("def"))], [asm(0, 61, tseq("abcdef"), 1, 1)])
+    assert [a.aligned_variants for a in aligned] == [[(30, 31, "")]]
+    assert len(out) == 3 and is_ref(out[0], 0, 30) and is_var(out[1], 30, "", 31) and is_ref(out[2], 31, 61)
+
+
+def test_sorts_by_left():
+    """align_test.cpp:287-312 builds two overlapping assemblies but, as written there, never runs them (and the
+    second one's offsets do not fit its sequence).  The same idea with consistent offsets: the output of the chain
+    stays sorted by left offset although the second assembly overlaps the tail of the first."""
+    ref = tseq("abc") + "T" + tseq("def") + "T" + tseq("ghi") + "T" + tseq("jkl")
+    a1 = asm(0, 30 + 1 + 30 + 1 + 30, tseq("abc") + "C" + tseq("def") + "C" + tseq("ghi"), 1, 1)
+    a2 = asm(62, 123, tseq("ghi") + "C" + tseq("jkl"), 1, 1)
+    aligned, out = run([(0, ref)], [a1, a2])
+    assert [a.aligned_variants for a in aligned] == [[(30, 31, "C"), (61, 62, "C")], [(92, 93, "C")]]
+    assert [(a.left_offset, a.right_offset, a.matches_reference) for a in out] == [
+        (0, 30, True), (30, 31, False), (31, 61, True), (61, 62, False), (62, 92, True), (62, 92, True), (92, 93, False),
+        (93, 123, True)]
+
+
+def test_wild_aligns_smaller_near_ends():
+    pre = ("TGTGATAGTAGATCAGAGGTGGAGACATCAACGTAAACTTATGTTTAGTTTAATATAGACACACACAGTTCT"
+           "ACATAGAAAACTTTATAATTAGGTGTGT")
+    post = ("ACCATTCTGAAAGGAATCAGGCTCTTTGAAGAAATGTCTGATACTAGAACTGGGACAGTAAATATAGGAGCC"
+            "AGGATAATCTGGAAGTATCAGAAAGTAAGTACTAAAAAAATTAAAATATATCAAACAAAAATAAAAGCCAAT"
+            "AAAA")
+    parts = [("G", "A"), ("TAGGTAGGTTAGACAC",) * 2, ("G", "A"), ("CACATATACTTCCTAGCATTGC",) * 2, ("T", "C"),
+             ("AATGAGGGA",) * 2, ("C", "G"), ("AAGATACAATGTGC",) * 2, ("", "TC"), ("ATTCAGCAGCCA",) * 2, ("C", "G"),
+             ("ATGTAAGTTTTCC",) * 2, ("C", "T")]
+    parts = [(pre, pre)] + parts + [(post, post)]
+    ref = var = ""
+    want = []
+    for r, v in parts:
+        if r != v:
+            want.append((len(ref), len(ref) + len(r), v))
+        ref += r
+        var += v
+    aligned, out = run([(0, ref)], [asm(0, len(ref), var, len(pre), len(post))])
+    assert [a.aligned_variants for a in aligned] == [want]
+
+
+# ---- helpers ----------------------------------------------------------------------------------------------------
+def test_subscaffold_and_friends():
+    sc = T.Scaffold([(2, "ACGT"), (10, "TTGCA")], 20)
+    s = A.subscaffold(sc, 3, 9)
+    assert s.extents == [(0, "CGT"), (7, "TT")] and s.end_pos == 9
+    assert A.shared_prefix_length(s, "CGA") == 2 and A.shared_prefix_length(A.subscaffold(sc, 0, 5), "AC") == 0
+    assert A.is_simple(A.subscaffold(sc, 10, 3)) and not A.is_simple(s) and not A.is_simple(A.subscaffold(sc, 1, 3))
+    assert A.split_extent_at(sc, 12) == ("TT", "GCA") and A.split_extent_at(sc, 6) == ("ACGT", "")
+    assert A.split_extent_at(sc, 8) == ("", "") and A.split_extent_at(sc, 10) == ("", "TTGCA")
+    assert s.rev_comp().extents == [(0, "AA"), (6, "ACG")]
+
+
+def test_find_match_ties_take_the_later_candidate():
+    """`distance > best` skips only strictly worse candidates, so of equally distant ones the last visited wins:
+    scaffold offsets ascending, and within one scaffold offset the seq offsets newest-first (descending)."""
+    sc = T.Scaffold([(0, "ACACAC")])
+    # seq "ACAC": "AC" at 0, 2; scaffold "AC" at 0, 2, 4.  Left anchored distance = |so - ro|: 0 for (0,0), (2,2).
+    assert A.find_match("ACAC", sc, 2, A.ANCHORED_TO_LEFT) == (2, 2)
+    # both-anchored: seq anchor (4-2)//2 = 1, scaffold anchor (6-2)//2 = 2: distance |so-1 - (ro-2)|, 1 at best;
+    # the last visited with distance 1 is ro=4, so: so=2 gives |1-2| = 1 first, then so=0: |-1-2| = 3.
+    assert A.find_match("ACAC", sc, 2, A.ANCHORED_TO_BOTH) == (2, 4)
+
+
+def test_split_assembly_anchors_and_vars():
+    a = asm(100, 130, "ACGTACGTAC" * 3, 12, 5)
+    a.aligned_variants = [(105, 106, "C"), (120, 121, "A")]
+    l, r = A.split_assembly(a, 10, 10)
+    assert (l.left_offset, l.right_offset, r.left_offset, r.right_offset) == (100, 110, 110, 130)
+    assert (l.left_anchor_len, l.right_anchor_len, r.left_anchor_len, r.right_anchor_len) == (10, 0, 2, 5)
+    assert l.aligned_variants == [(105, 106, "C")] and r.aligned_variants == [(120, 121, "A")]
+    with pytest.raises(AssertionError):
+        A.split_assembly(a, 10, 31)
+
+
+# ---- tracer -> anchor_dropper -> pair_counter: the dead-end expectations of tracer_test.cpp:246-316 -------------
+from tests.test_oracle_tracer import DEAD, expect, reads_for_seq, world  # noqa: E402
+
+ALPHABET = [(0, tseq("abcdefghijklmnopqrstuvwxyz"))]
+
+
+def traced(parts, pairs, reads, rev, min_overlap, **align_opts):
+    g = world(pairs, reads)
+    o = T.Options(min_overlap=min_overlap, trace_reference_assemblies=True)
+    ao = A.AlignOptions(min_overlap=min_overlap, read_ahead_distance=o.read_ahead_distance,
+                        trace_reference_assemblies=True, **align_opts)
+    out = T.reversable_trace(g, T.Scaffold(parts), o, rev_comp=rev,
+                             anchor_drop=lambda sc, emit: A.AnchorDropper(ao, sc, emit))
+    if rev:
+        out.reverse()
+    return out
+
+
+@pytest.mark.parametrize("rev", [False, True])
+def test_tracer_dead_end(rev):  # :246-266
+    out = traced(ALPHABET, [], reads_for_seq(DEAD, 50, 10), rev, 40, min_anchor_drop_overlap=10)
+    expect(out, [] if rev else [(tseq("abcde"), "G" + tseq("f") + "G" + tseq("ghi") + "G", tseq("j"))])
+
+
+@pytest.mark.parametrize("rev", [False, True])
+def test_tracer_dead_end2(rev):  # :268-289: min_anchor_drop_overlap too long to match the "j"
+    out = traced(ALPHABET, [], reads_for_seq(DEAD, 50, 10), rev, 40, min_anchor_drop_overlap=11)
+    expect(out, [] if rev else [(tseq("abcde"), "G" + tseq("f") + "G", tseq("ghi"))])
+
+
+@pytest.mark.parametrize("rev", [False, True])
+def test_tracer_dead_end_big_drop(rev):  # :293-316: the long rejoin, anchor of length min_overlap
+    pairs = [(tseq("bcdef"), tseq("efgH") + "G" + tseq("y")), (tseq("defgH") + "G", tseq("fgH") + "G" + tseq("yz"))]
+    out = traced(ALPHABET, pairs, [], rev, 20)
+    expect(out, [] if rev else [(tseq("bcdef"), tseq("gH") + "G", tseq("yz"))])
+    if not rev:
+        assert (out[0].left_offset, out[0].right_offset) == (10, 260)

@@ -3,10 +3,10 @@ own test, modules/variants/tracer_test.cpp:167-304 (fwd_tracer_test and rev_trac
 reference = create_reference({tseq(a..z), tseq(A..M_12345_N..Z), tseq(0..9)}) plus the four single-base scaffolds of
 reference_testutil.cpp:67-75, min_overlap = 2 tseq letters, trace_reference_assemblies on.  CPU only.
 
-Not restated: the anchor_dropper between tracer and pair_counter.  Assemblies that rejoin the reference pass through it
-unchanged (anchor_drop.cpp:196-202) -- every expectation of the first five cases; the forward expectations of the three
-dead_end cases are what the anchor_dropper makes of the raw dead-end assembly and are checked here only up to that
-step (the raw assembly starts with the expected anchor + variant); their rev-comp expectation (nothing) is exact."""
+This file runs the chain WITHOUT the anchor_dropper between tracer and pair_counter: assemblies that rejoin the
+reference pass through it unchanged (anchor_drop.cpp:196-202) -- every expectation of the first five cases; for the
+three dead_end cases it checks the raw dead-end assembly the tracer hands over.  Their full expectations, with the
+anchor_dropper of oracle/align.py plugged in, are in tests/test_oracle_align.py."""
 import numpy as np
 import pytest
 
