@@ -5,6 +5,9 @@ that follow the push tracer in the reference's assembly pipeline --
   aligner          modules/variants/align.cpp:11-385        (first step of add_standard_variants_pipeline, pipeline.cpp:92-95)
   align_splitter   modules/variants/align.cpp:387-460
   split_assembly   modules/variants/assemble.cpp:128-231
+  sorter           modules/variants/sort.cpp:6-13           (head of the serial pipeline, pipeline.cpp:48)
+  ref_trimmer      modules/variants/trim_ref.cpp:10-113     (pipeline.cpp:52; fully anchored assemblies only)
+  deduper          modules/variants/dedup.cpp:7-144         (pipeline.cpp:53)
   the sorted output queue every one of them emits through (assemble.cpp:291-346, canon order :1029-1085)
   scaffold helpers modules/variants/scaffold.cpp:39-203
 
@@ -18,9 +21,13 @@ As written in the reference, advance_trail_behind_to advances the READ-AHEAD ite
 already past the target, so k-mers are never removed from the window table; candidates left of the assembly are
 filtered at use (:131).  The restatement keeps that.
 
-Pinned on the vectors of modules/variants/align_test.cpp:59-375 (tests/test_oracle_align.py) and, through the tracer,
-on the dead-end expectations of tracer_test.cpp:232-304."""
-from .tracer import Assembly, Scaffold, _ScaffoldIt, revcomp, INT_MAX
+The sorter is std::sort there (order among assemblies that compare equal in canon order is unspecified); here and in
+the product it is a stable sort.  Half-anchored assemblies (one offset absent) do not occur behind the push tracer --
+it reports those through report_half_aligned_func (anchor_drop.cpp:303-339) -- and are not modelled.
+
+Pinned on the vectors of modules/variants/align_test.cpp:59-375, trim_ref_test.cpp:24-112, dedup_test.cpp:24-131
+(tests/test_oracle_align.py) and, through the tracer, on the dead-end expectations of tracer_test.cpp:246-316."""
+from .tracer import Assembly, Scaffold, _ScaffoldIt, revcomp, INT_MAX, INT_MIN
 
 I64_MAX = 2 ** 63 - 1
 ANCHORED_TO_BOTH, ANCHORED_TO_LEFT, ANCHORED_TO_RIGHT = 0, 1, 2
@@ -157,7 +164,7 @@ class SortedOutput:
     def __init__(self, emit):
         self.emit = emit
         self.queue = []
-        self.flush_point = 0
+        self.flush_point = INT_MIN  # assemble.h:902
 
     def flush_sorted_to(self, offset):
         check(offset >= self.flush_point, "flush goes backwards")
@@ -464,6 +471,128 @@ class AnchorDropper(SortedOutput):
                 self.half_aligned(discard.left_offset, discard.seq)
         elif self.half_aligned:
             self.half_aligned(a.left_offset + a.left_anchor_len, a.seq[a.left_anchor_len:])
+
+
+# ---- sorter / ref_trimmer / deduper: the head of the serial pipeline (pipeline.cpp:40-57) -------------------------
+K_MAX_BACKTRACK_LEN = 1000  # trim_ref.h:31
+
+
+class RefTrimmer(SortedOutput):  # trim_ref.cpp:10-113
+    def __init__(self, scaffold, emit):
+        SortedOutput.__init__(self, emit)
+        self.sc = scaffold
+
+    def add(self, a):
+        self.flush_sorted_to(min(a.left_offset, a.right_offset) - K_MAX_BACKTRACK_LEN)
+        if a.matches_reference:
+            return
+        s = subscaffold(self.sc, a.left_offset, a.right_offset - a.left_offset)
+        if not s.extents:
+            self.sort_and_output(a)
+            return
+        shared_left = shared_prefix_length(s, a.seq)
+        check(shared_left >= a.left_anchor_len, "left anchor does not match reference")
+        shared_right = shared_prefix_length(s.rev_comp(), revcomp(a.seq))
+        check(shared_right >= a.right_anchor_len, "right anchor does not match reference")
+        max_anchor = min(len(a.seq), a.right_offset - a.left_offset)
+        if shared_right + shared_left > max_anchor and shared_right + a.left_anchor_len <= max_anchor:
+            shared_left = max_anchor - shared_right
+        if shared_right + shared_left > max_anchor and a.right_anchor_len + shared_left <= max_anchor:
+            shared_right = max_anchor - shared_left
+        if shared_right + shared_left <= max_anchor:
+            a.left_anchor_len, a.right_anchor_len = shared_left, shared_right
+        new_size = len(a.seq) - a.left_anchor_len - a.right_anchor_len
+        check(new_size >= 0, "anchors longer than the sequence")
+        a.seq = a.seq[a.left_anchor_len:a.left_anchor_len + new_size]
+        a.left_offset += a.left_anchor_len
+        a.right_offset -= a.right_anchor_len
+        a.left_anchor_len = a.right_anchor_len = 0
+        check(a.right_offset >= a.left_offset, "trimmed past itself")
+        if new_size == 0 and a.left_offset == a.right_offset:
+            return
+        self.sort_and_output(a)
+
+
+class Deduper:  # dedup.cpp:7-144
+    def __init__(self, emit):
+        self.emit = emit
+        self.queued = []  # multimap<left_offset, assembly>: by key, equal keys in arrival order
+
+    @staticmethod
+    def _combine(a, target):  # :7-80
+        if a.left_offset < target.left_offset:
+            a, target = target, a
+        add = a.right_offset - target.right_offset
+        if add > 0:
+            check(add < len(a.seq), "combine adds the whole sequence")
+            target.seq += a.seq[len(a.seq) - add:]
+            target.right_anchor_len += add
+            target.right_offset += add
+        target.left_pair_matches = sorted(set(target.left_pair_matches) | set(a.left_pair_matches))
+        target.right_pair_matches = sorted(set(target.right_pair_matches) | set(a.right_pair_matches))
+        check(target.left_anchor_len >= a.left_anchor_len and target.right_anchor_len >= a.right_anchor_len,
+              "combined anchors shrink")
+        for f in ("trace_steps", "min_overlap", "left_anchor_ambiguous_bases"):
+            setattr(target, f, max(getattr(target, f), getattr(a, f)))
+        return target
+
+    def _advance_to(self, offset):  # :131-141
+        while self.queued:
+            q = self.queued[0][1]
+            if q.left_offset + q.left_anchor_len >= offset:
+                break
+            self.queued.pop(0)
+            self.emit(q)
+
+    def add(self, a):  # :82-129
+        self._advance_to(a.left_offset)
+        for i, (_, q) in enumerate(self.queued):
+            if q.left_offset > a.left_offset + a.left_anchor_len:
+                break
+            if a.matches_reference or q.matches_reference:
+                continue
+            if a.left_offset + a.left_anchor_len != q.left_offset + q.left_anchor_len:
+                continue
+            if a.right_offset - a.right_anchor_len != q.right_offset - q.right_anchor_len:
+                continue
+            check(len(a.seq) >= a.left_anchor_len + a.right_anchor_len and
+                  len(q.seq) >= q.left_anchor_len + q.right_anchor_len, "anchors longer than the sequence")
+            if a.seq[a.left_anchor_len:len(a.seq) - a.right_anchor_len] != q.seq[q.left_anchor_len:len(q.seq) - q.right_anchor_len]:
+                continue
+            self.queued.pop(i)
+            a = self._combine(q, a)
+            break
+        i = len(self.queued)
+        while i > 0 and self.queued[i - 1][0] > a.left_offset:
+            i -= 1
+        self.queued.insert(i, (a.left_offset, a))
+
+    def flush(self):
+        self._advance_to(INT_MAX)
+        check(not self.queued, "deduper keeps assemblies after its flush")
+
+
+def variants_pipeline(options, scaffold, assemblies):
+    """The serial pipeline of pipeline.cpp:40-57 + :92-95 up to the align_splitter, fed with everything the tracers of
+    one scaffold produced (both directions): sorter(canon) -> ref_trimmer -> deduper -> aligner -> align_splitter.
+    -> (deduped, split): the assemblies entering the aligner, and leaving the splitter."""
+    deduped, out = [], []
+    split = AlignSplitter(out.append)
+    al = Aligner(options, scaffold, split.add)
+
+    def save(a):
+        deduped.append(copy_assembly(a))
+        al.add(a)
+
+    dd = Deduper(save)
+    tr = RefTrimmer(scaffold, dd.add)
+    for a in sorted((copy_assembly(a) for a in assemblies), key=canon_key):
+        tr.add(a)
+    tr.flush()
+    dd.flush()
+    al.flush()
+    split.flush()
+    return deduped, out
 
 
 def align_pipeline(options, scaffold, assemblies, half_aligned=None):

@@ -199,3 +199,86 @@ def test_tracer_dead_end_big_drop(rev):  # :293-316: the long rejoin, anchor of 
     expect(out, [] if rev else [(tseq("bcdef"), tseq("gH") + "G", tseq("yz"))])
     if not rev:
         assert (out[0].left_offset, out[0].right_offset) == (10, 260)
+
+
+# ---- ref_trimmer (trim_ref_test.cpp:24-112) and deduper (dedup_test.cpp:24-131) ------------------------------------
+def trim(parts, asms):
+    out = []
+    tr = A.RefTrimmer(T.Scaffold(parts), out.append)
+    for a in asms:
+        tr.add(a)
+    tr.flush()
+    return out
+
+
+def dedup(asms):
+    out = []
+    dd = A.Deduper(out.append)
+    for a in asms:
+        dd.add(A.copy_assembly(a))
+    dd.flush()
+    for x, y in zip(out, out[1:]):
+        assert x.left_offset <= y.left_offset
+    return out
+
+
+def test_trim_ref_ignores_reference_and_reference_equivalents():
+    a = asm(0, 30, tseq("abc"), 0, 0)
+    a.matches_reference = True
+    assert trim(ALPHABET, [a]) == []
+    assert trim(ALPHABET, [asm(0, 30, tseq("abc"), 0, 0)]) == []
+
+
+def test_trim_ref_expands():
+    out = trim(ALPHABET, [asm(30, 140, tseq("de") + "G" + tseq("FGHI") + "G" + tseq("jklmn"), 10, 20)])
+    assert len(out) == 1 and is_var(out[0], 50, "G" + tseq("FGHI") + "G", 90)
+    assert (out[0].left_anchor_len, out[0].right_anchor_len) == (0, 0)
+
+
+def test_trim_ref_duplicate_insert_and_delete_call_leftmost():
+    ref = tseq("abc") + "G" + tseq("defghijklmnopqrstuvwxyz")
+    out = trim([(0, ref)], [asm(0, 91, tseq("abc") + "GG" + tseq("defghi"), 1, 1)])
+    assert len(out) == 1 and is_var(out[0], 30, "G", 30) and (out[0].left_anchor_len, out[0].right_anchor_len) == (0, 0)
+    ref = tseq("abc") + "GG" + tseq("defghijklmnopqrstuvwxyz")
+    out = trim([(0, ref)], [asm(0, 92, tseq("abc") + "G" + tseq("defghi"), 1, 1)])
+    assert len(out) == 1 and is_var(out[0], 30, "", 31) and (out[0].left_anchor_len, out[0].right_anchor_len) == (0, 0)
+
+
+def test_dedup_duplicate_and_non_duplicate():
+    a = asm(1, 5, tseq("abc"), 0, 0)
+    out = dedup([a, a])
+    assert len(out) == 1 and is_var(out[0], 1, tseq("abc"), 5)
+    b = asm(1, 5, tseq("def"), 0, 0)
+    c = asm(1, 6, tseq("def"), 0, 0)
+    d = asm(2, 6, tseq("def"), 0, 0)
+    out = dedup([a, b, b, c, d])
+    assert sorted((x.left_offset, x.seq, x.right_offset) for x in out) == sorted(
+        [(1, tseq("abc"), 5), (1, tseq("def"), 5), (1, tseq("def"), 6), (2, tseq("def"), 6)])
+    assert out[-1].left_offset == 2
+
+
+@pytest.mark.parametrize("order", ["overlapping", "encompassing"])
+def test_dedup_overlapping_and_encompassing(order):
+    if order == "overlapping":
+        asms = [asm(0, 40, tseq("ab") + "G" + tseq("d"), 20, 10), asm(10, 50, tseq("b") + "G" + tseq("de"), 10, 20)]
+    else:
+        asms = [asm(0, 50, tseq("ab") + "G" + tseq("de"), 20, 20), asm(10, 40, tseq("b") + "G" + tseq("d"), 10, 10)]
+    out = dedup(asms)
+    assert len(out) == 1 and is_var(out[0], 0, tseq("ab") + "G" + tseq("de"), 50)
+    assert (out[0].left_anchor_len, out[0].right_anchor_len) == (20, 20)
+
+
+def test_variants_pipeline_merges_the_two_directions():
+    """What the serial pipeline does with a forward and a reverse discovery of the same SNP plus the tracers'
+    reference assemblies: the reference assembly is dropped by the ref_trimmer, the two discoveries trim to the same
+    anchor-free variant and are merged (pair matches united), and nothing is left for the splitter to cut."""
+    ref = tseq("abcdefgh")
+    var = tseq("abc") + "T" + tseq("defgh")[1:]
+    f = asm(10, 70, var[10:70], 10, 10)
+    r = asm(0, 80, var, 25, 30)
+    r.left_pair_matches = [7]
+    refa = asm(0, 40, ref[:40], 0, 0)
+    refa.matches_reference = True
+    deduped, out = A.variants_pipeline(A.AlignOptions(), T.Scaffold([(0, ref)]), [r, refa, f])
+    assert [(a.left_offset, a.right_offset, a.seq, a.left_pair_matches) for a in deduped] == [(30, 31, "T", [7])]
+    assert [(a.left_offset, a.right_offset, a.matches_reference) for a in out] == [(30, 31, False)]
