@@ -159,9 +159,10 @@ def driver_leg(ctx, ss, genome, dev, args, region=None, rm=None):
 
 
 def push_tracer_leg(ss, rm, ref_map_dev, genome, args, chunks=2, chunk_size=1_000_000):
-    """The production push tracer (first slice: csrc/tracer.cpp) on the first `chunks` work items of
-    trace_ref (scaffold_split_size pieces), forward and reverse, with pair_counter: seconds per piece and direction, and how
-    many of the planted SNPs of the pieces lie inside the non-reference assemblies it emits."""
+    """The production push tracer (csrc/tracer.cpp + csrc/align.cpp) on the first `chunks` work
+    items of trace_ref (scaffold_split_size pieces), forward and reverse, with anchor_dropper and pair_counter: seconds per
+    piece and direction, how many of the planted SNPs of the pieces lie inside the non-reference assemblies it emits, and
+    how many come out of the serial pipeline (sort, ref trim, dedup, align, split) as 1-base variant sections."""
     import numpy as np
     import torch
     from biograph_amd import tracer
@@ -179,6 +180,7 @@ def push_tracer_leg(ss, rm, ref_map_dev, genome, args, chunks=2, chunk_size=1_00
     session = tracer.PushTracer(ss, rm, _Dev, tracer.TraceOptions(min_overlap=int(0.7 * args.read_len)))
     t_open = time.perf_counter() - t0
     secs, traces, rounds, asms_n, hit = [], 0, 0, 0, set()
+    everything = []
     for c in range(chunks):
         start, limit = c * chunk_size, min(region, (c + 1) * chunk_size)
         if start >= limit:
@@ -189,6 +191,7 @@ def push_tracer_leg(ss, rm, ref_map_dev, genome, args, chunks=2, chunk_size=1_00
             secs.append(round(time.perf_counter() - t0, 3))
             traces += st["traces"]
             rounds += st["device_rounds"]
+            everything += asms
             for a in asms:
                 if a.matches_reference:
                     continue
@@ -198,12 +201,22 @@ def push_tracer_leg(ss, rm, ref_map_dev, genome, args, chunks=2, chunk_size=1_00
                         if x != y and (a.left_offset + i) in snp_pos:
                             hit.add(a.left_offset + i)
     session.close()
+    # the serial pipeline behind the tracers (csrc/align.cpp): sort, ref trim, dedup, align, split
+    t0 = time.perf_counter()
+    sections = tracer.process_assemblies(everything, [(0, ref)], steps=tracer.STEP_PIPELINE)
+    t_pipe = time.perf_counter() - t0
+    variants = [a for a in sections if not a.matches_reference]
+    called = {a.left_offset for a in variants if a.right_offset == a.left_offset + 1 and len(a.seq) == 1}
     total = sum(secs)
     return {"reference_bases": region, "pieces": len(secs) // 2, "directions": 2, "session_open_seconds": round(t_open, 3),
             "seconds_per_piece_and_direction": secs, "traces": traces, "device_rounds": rounds,
             "non_reference_assemblies": asms_n, "planted_snps_in_region": len(snp_pos),
             "planted_snps_inside_assemblies": len(hit), "ref_bases_per_s_per_direction": round(2 * region / max(total, 1e-9), 1),
-            "min_overlap": int(0.7 * args.read_len), "what": "tracer + pair_counter (anchor_dropper and the later steps are not built)"}
+            "pipeline_seconds": round(t_pipe, 3), "pipeline_assemblies_in": len(everything),
+            "pipeline_variant_sections": len(variants), "planted_snps_called_as_1_base_variants": len(called & snp_pos),
+            "min_overlap": int(0.7 * args.read_len),
+            "what": "tracer + anchor_dropper + pair_counter per piece and direction, then sorter + ref_trimmer + deduper + "
+                    "aligner + align_splitter over all of them (normalize / coverage / genotype / VCF are not built)"}
 
 
 def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):

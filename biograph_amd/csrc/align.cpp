@@ -1,0 +1,729 @@
+// align.cpp — row f.2, second slice: what the reference does with the tracers' assemblies before anything is counted
+// or genotyped, as host steps over bg_trace_result:
+//
+//   anchor_dropper   modules/variants/anchor_drop.cpp      between tracer and pair_counter (reversable_tracer.cpp:124-125)
+//   sorter           modules/variants/sort.cpp             head of the serial pipeline (pipeline.cpp:48)
+//   ref_trimmer      modules/variants/trim_ref.cpp         pipeline.cpp:52
+//   deduper          modules/variants/dedup.cpp:7-144      pipeline.cpp:53
+//   aligner          modules/variants/align.cpp:11-385     add_standard_variants_pipeline, pipeline.cpp:92-95
+//   align_splitter   modules/variants/align.cpp:387-460
+//
+// These are per-assembly string work on a few thousand assemblies per megabase, orders of magnitude below the
+// tracer's device walks; they run on the host, single threaded, in the reference's order.  Where the reference's
+// result depends on a container's iteration order it is written out: std::upper_bound's probes over the match sizes
+// (align.cpp:262-278) and unordered_multimap::equal_range returning a key's values newest first (libstdc++).
+//
+// Half-anchored assemblies do not occur behind the push tracer (it reports them through report_half_aligned_func,
+// anchor_drop.cpp:303-339, which this library drops) and are not modelled.  The sorter is a stable sort (std::sort in
+// the reference: the order of assemblies that compare equal in canon order is unspecified there).
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <memory>
+
+#include "assembly.h"
+#include "bg_internal.h"
+
+namespace bg {
+
+namespace {
+
+void check(bool cond, const char* what) {
+  if (!cond) throw CheckFailed{what};
+}
+
+int64_t shared_prefix(const char* a, int64_t na, const char* b, int64_t nb) {
+  const int64_t n = std::min(na, nb);
+  int64_t i = 0;
+  while (i < n && a[i] == b[i]) ++i;
+  return i;
+}
+int64_t shared_suffix(const char* a, int64_t na, const char* b, int64_t nb) {
+  const int64_t n = std::min(na, nb);
+  int64_t i = 0;
+  while (i < n && a[na - 1 - i] == b[nb - 1 - i]) ++i;
+  return i;
+}
+
+inline unsigned code_of(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3; }
+
+// canon_assembly_order, GRAPH_DISCOVER flavour (assemble.cpp:1046-1082) for fully anchored, untagged assemblies.
+bool canon_less(const bg_trace_assembly_rec& a, const bg_trace_assembly_rec& b) {
+  const int64_t amin = std::min(a.left_offset, a.right_offset), bmin = std::min(b.left_offset, b.right_offset);
+  if (amin != bmin) return amin < bmin;
+  if (a.matches_reference != b.matches_reference) return a.matches_reference < b.matches_reference;
+  const int64_t amax = std::max(a.left_offset, a.right_offset), bmax = std::max(b.left_offset, b.right_offset);
+  if (amax != bmax) return amax > bmax;
+  if (a.seq != b.seq) return a.seq < b.seq;
+  if (a.left_anchor_len != b.left_anchor_len) return a.left_anchor_len < b.left_anchor_len;
+  if (a.right_anchor_len != b.right_anchor_len) return a.right_anchor_len < b.right_anchor_len;
+  if (a.score != b.score) return a.score < b.score;
+  if (a.left_pair_matches.size() != b.left_pair_matches.size()) return a.left_pair_matches.size() < b.left_pair_matches.size();
+  if (a.right_pair_matches.size() != b.right_pair_matches.size()) return a.right_pair_matches.size() < b.right_pair_matches.size();
+  if (a.rc_read_ids.size() != b.rc_read_ids.size()) return a.rc_read_ids.size() < b.rc_read_ids.size();
+  return false;
+}
+
+// split_assembly (assemble.cpp:128-231)
+std::pair<bg_trace_assembly_rec, bg_trace_assembly_rec> split_assembly(const bg_trace_assembly_rec& a, int64_t split_pos,
+                                                                      int64_t offset_split_pos) {
+  check(offset_split_pos >= 0 && offset_split_pos <= a.right_offset - a.left_offset, "split_assembly: reference offset outside the assembly");
+  check(split_pos >= 0 && split_pos <= int64_t(a.seq.size()), "split_assembly: position outside the sequence");
+  bg_trace_assembly_rec left = a, right = a;
+  left.right_offset = right.left_offset = a.left_offset + offset_split_pos;
+  left.seq = a.seq.substr(0, split_pos);
+  right.seq = a.seq.substr(split_pos);
+  if (a.left_anchor_len > split_pos) {
+    right.left_anchor_len = int(a.left_anchor_len - split_pos);
+    left.left_anchor_len = int(split_pos);
+  } else {
+    right.left_anchor_len = 0;
+  }
+  const int64_t rest = int64_t(a.seq.size()) - split_pos;
+  if (a.right_anchor_len > rest) {
+    left.right_anchor_len = int(a.right_anchor_len - rest);
+    right.right_anchor_len = int(rest);
+  } else {
+    left.right_anchor_len = 0;
+  }
+  for (const bg_trace_assembly_rec* part : {&left, &right}) {
+    check(part->left_anchor_len + part->right_anchor_len <= int64_t(part->seq.size()), "split_assembly: anchors longer than a part's sequence");
+    check(part->left_anchor_len + part->right_anchor_len <= part->right_offset - part->left_offset, "split_assembly: anchors longer than a part's reference span");
+  }
+  left.aligned_variants.clear();
+  right.aligned_variants.clear();
+  int64_t seq_offset = 0, ref_offset = a.left_offset;
+  for (const auto& v : a.aligned_variants) {
+    seq_offset += v.left_offset - ref_offset;
+    ref_offset = v.left_offset;
+    if (seq_offset >= int64_t(left.seq.size()) && v.left_offset >= right.left_offset) {
+      right.aligned_variants.push_back(v);
+    } else {
+      check(seq_offset + int64_t(v.seq.size()) <= int64_t(left.seq.size()), "split_assembly: a variant crosses the split (sequence)");
+      check(v.right_offset <= left.right_offset, "split_assembly: a variant crosses the split (reference)");
+      left.aligned_variants.push_back(v);
+    }
+    seq_offset += int64_t(v.seq.size());
+    ref_offset = v.right_offset;
+  }
+  return {std::move(left), std::move(right)};
+}
+
+// ---- aligner::find_match and friends (align.cpp:156-385) ------------------------------------------------------------
+enum Anchor { ANCHORED_TO_BOTH, ANCHORED_TO_LEFT, ANCHORED_TO_RIGHT };
+
+struct Slice { const char* p; int64_t n; };
+
+bool find_match(Slice seq, const ScaffoldView& s, int64_t match_len, int64_t* seq_match_start, int64_t* scaffold_match_start,
+                Anchor anchor) {
+  if (match_len > s.end_pos || match_len > seq.n) return false;
+  int64_t seq_anchor = 0, scaffold_anchor = 0;
+  if (anchor == ANCHORED_TO_BOTH) {
+    seq_anchor = (seq.n - match_len) / 2;
+    scaffold_anchor = (s.end_pos - match_len) / 2;
+  } else if (anchor == ANCHORED_TO_RIGHT) {
+    seq_anchor = seq.n;
+    scaffold_anchor = s.end_pos;
+  }
+  const int k = int(std::min<int64_t>(match_len, 30));
+  const uint64_t mask = ~((~uint64_t(0)) << (k * 2));
+  std::unordered_map<uint64_t, std::vector<int64_t>> seq_kmers;  // offsets ascending; equal_range visits them descending
+  {
+    uint64_t km = 0;
+    for (int64_t i = 0; i < seq.n; ++i) {
+      km = ((km << 2) | code_of(seq.p[i])) & mask;
+      const int64_t off = i + 1 - k;
+      if (off < 0) continue;
+      if (off + match_len > seq.n) break;
+      seq_kmers[km].push_back(off);
+    }
+  }
+  int64_t best = INT64_MAX;
+  for (const auto& e : s.ext) {
+    uint64_t km = 0;
+    for (int64_t i = 0; i < e.n; ++i) {
+      km = ((km << 2) | code_of(e.p[i])) & mask;
+      const int64_t in_ext = i + 1 - k;
+      if (in_ext < 0) continue;
+      if (in_ext + match_len > e.n) break;
+      auto it = seq_kmers.find(km);
+      if (it == seq_kmers.end()) continue;
+      const int64_t scaffold_offset = e.offset + in_ext;
+      const int64_t scaffold_distance = scaffold_offset - scaffold_anchor;
+      for (auto so = it->second.rbegin(); so != it->second.rend(); ++so) {
+        const int64_t distance = llabs((*so - seq_anchor) - scaffold_distance);
+        if (distance > best) continue;
+        if (match_len > k && memcmp(e.p + in_ext + k, seq.p + *so + k, size_t(match_len - k)) != 0) continue;
+        best = distance;
+        *seq_match_start = *so;
+        *scaffold_match_start = scaffold_offset;
+      }
+    }
+  }
+  return best != INT64_MAX;
+}
+
+bool find_biggest_match(const AlignParams& o, Slice seq, const ScaffoldView& s, int64_t* match_len, int64_t* seq_match_start,
+                        int64_t* scaffold_match_start, int64_t* min_match_size, Anchor anchor) {
+  *min_match_size = std::max<int64_t>(seq.n, s.end_pos) / o.ref_align_factor;
+  if (*min_match_size < 1) *min_match_size = 1;
+  if (*min_match_size > o.max_ref_align_bases) *min_match_size = o.max_ref_align_bases;
+  if (anchor != ANCHORED_TO_BOTH && *min_match_size < int64_t(o.min_anchor_drop_overlap)) *min_match_size = int64_t(o.min_anchor_drop_overlap);
+  const int64_t max_match_size = std::min<int64_t>(seq.n, s.end_pos);
+  if (max_match_size < *min_match_size) return false;
+  *match_len = 0;
+  // std::upper_bound(irange(min, max + 1), false, comp): comp(false, size) is true when `size` has no match
+  int64_t first = *min_match_size, n = max_match_size + 1 - *min_match_size;
+  while (n > 0) {
+    const int64_t half = n >> 1, size = first + half;
+    int64_t so, ro;
+    bool go_left;
+    if (find_match(seq, s, size, &so, &ro, anchor)) {
+      if (size > *match_len) { *match_len = size; *seq_match_start = so; *scaffold_match_start = ro; }
+      go_left = false;
+    } else {
+      go_left = true;
+    }
+    if (go_left) {
+      n = half;
+    } else {
+      first = size + 1;
+      n = n - half - 1;
+    }
+  }
+  if (!*match_len) {
+    check(first == *min_match_size, "find_biggest_match: no match, yet the search moved");
+    return false;
+  }
+  check(first == *match_len + 1, "find_biggest_match: match sizes are not monotone");
+  return true;
+}
+
+bool find_end_matches(const AlignParams& o, Slice seq, const ScaffoldView& s, int64_t* match_len, int64_t* seq_match_start,
+                      int64_t* scaffold_match_start, int64_t max_match_size) {
+  const int64_t shortest = std::min<int64_t>(seq.n, s.end_pos);
+  max_match_size = std::min(shortest, max_match_size);
+  for (*match_len = max_match_size; *match_len >= 1; --*match_len) {
+    int64_t search_len;
+    switch (*match_len) {
+      case 1: search_len = 2; break;
+      case 2: search_len = 3; break;
+      case 3: search_len = 5; break;
+      case 4: search_len = 7; break;
+      default: search_len = *match_len * o.ref_align_factor;
+    }
+    search_len = std::min(shortest, search_len);
+    if (find_match(Slice{seq.p, search_len}, s.sub(0, search_len), *match_len, seq_match_start, scaffold_match_start, ANCHORED_TO_LEFT))
+      return true;
+    // as written there: match_len bases (not search_len) from search_len before the ends
+    if (find_match(Slice{seq.p + (seq.n - search_len), *match_len}, s.sub(s.end_pos - search_len, *match_len), *match_len,
+                   seq_match_start, scaffold_match_start, ANCHORED_TO_RIGHT)) {
+      *seq_match_start += seq.n - search_len;
+      *scaffold_match_start += s.end_pos - search_len;
+      return true;
+    }
+  }
+  return false;
+}
+
+bool find_biggest_match_with_ends(const AlignParams& o, Slice seq, const ScaffoldView& s, int64_t* match_len,
+                                  int64_t* seq_match_start, int64_t* scaffold_match_start) {
+  int64_t min_match_size;
+  if (find_biggest_match(o, seq, s, match_len, seq_match_start, scaffold_match_start, &min_match_size, ANCHORED_TO_BOTH)) return true;
+  return find_end_matches(o, seq, s, match_len, seq_match_start, scaffold_match_start, min_match_size - 1);
+}
+
+// ---- aligner (align.cpp:11-154) ---------------------------------------------------------------------------------------
+class Aligner : public SortedOutput {
+ public:
+  Aligner(const AlignParams& p, const ScaffoldView& sc, AssemblySink out) : SortedOutput(std::move(out)), p_(p), sc_(sc) {}
+  void add(bg_trace_assembly_rec&& a) {
+    flush_sorted_to(a.left_offset);
+    if (a.matches_reference) { sort_and_output(std::move(a)); return; }
+    check(a.left_anchor_len >= 0 && a.right_anchor_len >= 0, "aligner: negative anchor length");
+    check(a.right_offset >= a.left_offset, "aligner: right offset before the left one");
+    const ScaffoldView s = sc_.sub(a.left_offset, a.right_offset - a.left_offset);
+    const int64_t max_len = std::min<int64_t>(int64_t(a.seq.size()), a.right_offset - a.left_offset);
+    int64_t shared_left = s.shared_prefix_length(a.seq.data(), int64_t(a.seq.size()));
+    check(shared_left >= a.left_anchor_len, "aligner: the left anchor does not match the reference");
+    const int64_t shared_right = s.shared_suffix_length(a.seq.data(), int64_t(a.seq.size()));
+    check(shared_right >= a.right_anchor_len, "aligner: the right anchor does not match the reference");
+    if (shared_left + shared_right > max_len) shared_left = max_len - shared_right;
+    a.left_anchor_len = int(shared_left);
+    a.right_anchor_len = int(shared_right);
+    a.aligned_variants.clear();
+    struct Work { int64_t left, right; Slice seq; ScaffoldView s; };
+    std::vector<Work> work;
+    work.push_back(Work{a.left_offset + shared_left, a.right_offset - shared_right,
+                        Slice{a.seq.data() + shared_left, int64_t(a.seq.size()) - shared_right - shared_left},
+                        s.sub(shared_left, a.right_offset - shared_right - shared_left - a.left_offset)});
+    while (!work.empty()) {
+      Work w = std::move(work.back());
+      work.pop_back();
+      int64_t match_len, so, ro;
+      if (find_biggest_match_with_ends(p_, w.seq, w.s, &match_len, &so, &ro)) {
+        check(match_len >= 0 && ro >= 0, "aligner: negative match");
+        check(ro + match_len <= w.s.end_pos, "aligner: match past the end of the scaffold");
+        Work left{w.left, w.left + ro, Slice{w.seq.p, so}, w.s.sub(0, ro)};
+        Work right{w.left + ro + match_len, w.right, Slice{w.seq.p + so + match_len, w.seq.n - (so + match_len)},
+                   w.s.sub(ro + match_len, w.s.end_pos - (ro + match_len))};
+        if (!(left.left == left.right && left.seq.n == 0)) work.push_back(std::move(left));
+        if (!(right.left == right.right && right.seq.n == 0)) work.push_back(std::move(right));
+      } else if (!(w.left == w.right && w.seq.n == 0)) {
+        a.aligned_variants.push_back(bg_aligned_var_rec{w.left, w.right, std::string(w.seq.p, size_t(w.seq.n))});
+      }
+    }
+    std::sort(a.aligned_variants.begin(), a.aligned_variants.end());
+    if (a.aligned_variants.empty()) {
+      check(int64_t(a.seq.size()) == a.right_offset - a.left_offset, "aligner: no variants, yet the lengths differ");
+      if (!p_.trace_reference_assemblies) return;
+      a.matches_reference = true;
+      a.left_anchor_len = a.right_anchor_len = 0;
+    }
+    sort_and_output(std::move(a));
+  }
+
+ private:
+  AlignParams p_;
+  const ScaffoldView& sc_;
+};
+
+// ---- align_splitter (align.cpp:387-460) -------------------------------------------------------------------------------
+class AlignSplitter : public SortedOutput {
+ public:
+  explicit AlignSplitter(AssemblySink out) : SortedOutput(std::move(out)) {}
+  void add(bg_trace_assembly_rec&& a) {
+    flush_sorted_to(a.left_offset);
+    int64_t ref_offset = a.left_offset;
+    const int64_t orig_left = a.left_offset, orig_right = a.right_offset;
+    const std::vector<bg_aligned_var_rec> vars = a.aligned_variants;
+    for (const auto& v : vars) {
+      check(v.left_offset >= orig_left && v.right_offset <= orig_right && v.left_offset >= ref_offset, "align_splitter: a variant lies outside its assembly");
+      if (v.left_offset != ref_offset) {
+        const int64_t chunk = v.left_offset - ref_offset;
+        check(int64_t(a.seq.size()) >= chunk, "align_splitter: reference section longer than the sequence");
+        auto parts = split_assembly(a, chunk, chunk);
+        set_matches_reference(parts.first);
+        sort_and_output(std::move(parts.first));
+        a = std::move(parts.second);
+        ref_offset = v.left_offset;
+      }
+      auto parts = split_assembly(a, int64_t(v.seq.size()), v.right_offset - v.left_offset);
+      check(parts.first.seq == v.seq, "align_splitter: the split-off variant differs from the aligned one");
+      sort_and_output(std::move(parts.first));
+      a = std::move(parts.second);
+      ref_offset = a.left_offset;
+    }
+    check(ref_offset == a.left_offset, "align_splitter: lost its place");
+    if (a.left_offset == a.right_offset && a.seq.empty()) return;
+    set_matches_reference(a);
+    sort_and_output(std::move(a));
+  }
+
+ private:
+  static void set_matches_reference(bg_trace_assembly_rec& a) {
+    check(int64_t(a.seq.size()) == a.right_offset - a.left_offset, "align_splitter: a reference section changes length");
+    a.matches_reference = true;
+    a.left_anchor_len = a.right_anchor_len = 0;
+  }
+};
+
+// ---- ref_trimmer (trim_ref.cpp:10-113) ----------------------------------------------------------------------------------
+class RefTrimmer : public SortedOutput {
+ public:
+  RefTrimmer(const ScaffoldView& sc, AssemblySink out) : SortedOutput(std::move(out)), sc_(sc) {}
+  void add(bg_trace_assembly_rec&& a) {
+    flush_sorted_to(std::min(a.left_offset, a.right_offset) - 1000 /* k_max_backtrack_len, trim_ref.h:31 */);
+    if (a.matches_reference) return;
+    check(a.right_offset >= a.left_offset, "ref_trimmer: right offset before the left one");
+    const ScaffoldView s = sc_.sub(a.left_offset, a.right_offset - a.left_offset);
+    if (s.ext.empty()) { sort_and_output(std::move(a)); return; }
+    int64_t shared_left = s.shared_prefix_length(a.seq.data(), int64_t(a.seq.size()));
+    check(shared_left >= a.left_anchor_len, "ref_trimmer: the left anchor does not match the reference");
+    int64_t shared_right = s.shared_suffix_length(a.seq.data(), int64_t(a.seq.size()));
+    check(shared_right >= a.right_anchor_len, "ref_trimmer: the right anchor does not match the reference");
+    const int64_t max_anchor = std::min<int64_t>(int64_t(a.seq.size()), a.right_offset - a.left_offset);
+    if (shared_right + shared_left > max_anchor && shared_right + a.left_anchor_len <= max_anchor) shared_left = max_anchor - shared_right;
+    if (shared_right + shared_left > max_anchor && a.right_anchor_len + shared_left <= max_anchor) shared_right = max_anchor - shared_left;
+    if (shared_right + shared_left <= max_anchor) {
+      a.left_anchor_len = int(shared_left);
+      a.right_anchor_len = int(shared_right);
+    }
+    const int64_t new_size = int64_t(a.seq.size()) - a.left_anchor_len - a.right_anchor_len;
+    check(new_size >= 0, "ref_trimmer: anchors longer than the sequence");
+    a.seq = a.seq.substr(size_t(a.left_anchor_len), size_t(new_size));
+    a.left_offset += a.left_anchor_len;
+    a.right_offset -= a.right_anchor_len;
+    a.left_anchor_len = a.right_anchor_len = 0;
+    check(a.right_offset >= a.left_offset, "ref_trimmer: trimmed past itself");
+    if (new_size == 0 && a.left_offset == a.right_offset) return;
+    sort_and_output(std::move(a));
+  }
+
+ private:
+  const ScaffoldView& sc_;
+};
+
+// ---- deduper (dedup.cpp:7-144) ------------------------------------------------------------------------------------------
+class Deduper {
+ public:
+  explicit Deduper(AssemblySink out) : out_(std::move(out)) {}
+  void add(bg_trace_assembly_rec&& a) {
+    advance_to(a.left_offset);
+    for (auto it = queued_.begin(); it != queued_.end(); ++it) {
+      const bg_trace_assembly_rec& q = it->second;
+      if (q.left_offset > a.left_offset + a.left_anchor_len) break;
+      if (a.matches_reference || q.matches_reference) continue;
+      if (a.left_offset + a.left_anchor_len != q.left_offset + q.left_anchor_len) continue;
+      if (a.right_offset - a.right_anchor_len != q.right_offset - q.right_anchor_len) continue;
+      check(int64_t(a.seq.size()) >= a.left_anchor_len + a.right_anchor_len && int64_t(q.seq.size()) >= q.left_anchor_len + q.right_anchor_len,
+            "deduper: anchors longer than the sequence");
+      const size_t an = a.seq.size() - size_t(a.left_anchor_len + a.right_anchor_len), qn = q.seq.size() - size_t(q.left_anchor_len + q.right_anchor_len);
+      if (an != qn || a.seq.compare(size_t(a.left_anchor_len), an, q.seq, size_t(q.left_anchor_len), qn) != 0) continue;
+      bg_trace_assembly_rec old = std::move(it->second);
+      queued_.erase(it);
+      a = combine(std::move(old), std::move(a));
+      break;
+    }
+    const int64_t lo = a.left_offset;
+    queued_.emplace(lo, std::move(a));
+  }
+  void flush() {
+    advance_to(0x7fffffff);
+    check(queued_.empty(), "deduper: assemblies left after the flush");
+  }
+
+ private:
+  static bg_trace_assembly_rec combine(bg_trace_assembly_rec a, bg_trace_assembly_rec target) {  // :7-80
+    if (a.left_offset < target.left_offset) std::swap(a, target);
+    const int64_t add = a.right_offset - target.right_offset;
+    if (add > 0) {
+      check(add < int64_t(a.seq.size()), "deduper: combining would add the whole sequence");
+      target.seq += a.seq.substr(a.seq.size() - size_t(add));
+      target.right_anchor_len += int(add);
+      target.right_offset += add;
+    }
+    for (auto m : {&bg_trace_assembly_rec::left_pair_matches, &bg_trace_assembly_rec::right_pair_matches}) {
+      auto& pm = target.*m;
+      pm.insert(pm.end(), (a.*m).begin(), (a.*m).end());
+      std::sort(pm.begin(), pm.end());
+      pm.erase(std::unique(pm.begin(), pm.end()), pm.end());
+    }
+    check(target.left_anchor_len >= a.left_anchor_len && target.right_anchor_len >= a.right_anchor_len, "deduper: combined anchors shrink");
+    target.trace_steps = std::max(target.trace_steps, a.trace_steps);
+    target.min_overlap = std::max(target.min_overlap, a.min_overlap);
+    target.left_anchor_ambiguous_bases = std::max(target.left_anchor_ambiguous_bases, a.left_anchor_ambiguous_bases);
+    return target;
+  }
+  void advance_to(int64_t offset) {  // :131-141
+    while (!queued_.empty()) {
+      auto it = queued_.begin();
+      if (it->second.left_offset + it->second.left_anchor_len >= offset) break;
+      out_(std::move(it->second));
+      queued_.erase(it);
+    }
+  }
+  AssemblySink out_;
+  std::multimap<int64_t, bg_trace_assembly_rec> queued_;
+};
+
+}  // namespace
+
+// ---- scaffold.cpp -----------------------------------------------------------------------------------------------------
+ScaffoldView ScaffoldView::sub(int64_t start, int64_t len) const {
+  const int64_t limit = start + len;
+  check(start >= 0 && len >= 0 && limit >= 0, "subscaffold: negative range");
+  ScaffoldView r;
+  for (const Ext& e : ext) {
+    if (e.offset >= limit) continue;
+    if (e.offset + e.n <= start) continue;
+    const int64_t rs = std::max<int64_t>(start - e.offset, 0), rl = std::min<int64_t>(limit - e.offset, e.n);
+    r.ext.push_back(Ext{e.offset + rs - start, e.p + rs, rl - rs});
+  }
+  r.end_pos = len;
+  return r;
+}
+int64_t ScaffoldView::shared_prefix_length(const char* s, int64_t n) const {
+  if (ext.empty() || ext[0].offset != 0) return 0;
+  return shared_prefix(s, n, ext[0].p, ext[0].n);
+}
+int64_t ScaffoldView::shared_suffix_length(const char* s, int64_t n) const {
+  if (ext.empty() || ext.back().offset + ext.back().n != end_pos) return 0;
+  return shared_suffix(s, n, ext.back().p, ext.back().n);
+}
+
+// ---- sorted_output_pipeline_step ----------------------------------------------------------------------------------------
+void SortedOutput::flush_sorted_to(int64_t offset) {
+  check(offset >= flush_point_, "sorted output: flush goes backwards (input not sorted by left offset)");
+  size_t n = 0;
+  while (n < queue_.size() && std::min(queue_[n].left_offset, queue_[n].right_offset) < offset) ++n;
+  for (size_t i = 0; i < n; ++i) out_(std::move(queue_[i]));
+  queue_.erase(queue_.begin(), queue_.begin() + n);
+  if (queue_.empty()) flush_point_ = offset;  // the reference returns before this when something stays queued
+}
+void SortedOutput::sort_and_output(bg_trace_assembly_rec&& a) {
+  check(std::min(a.left_offset, a.right_offset) >= flush_point_, "sorted output: assembly behind the flush point");
+  auto at = std::upper_bound(queue_.begin(), queue_.end(), a, canon_less);
+  queue_.insert(at, std::move(a));
+}
+
+AlignParams AlignParams::from(const bg_trace_options& o) {
+  AlignParams p;
+  p.min_overlap = o.min_overlap;
+  p.read_ahead_distance = o.read_ahead_distance;
+  p.min_anchor_drop_overlap = o.min_anchor_drop_overlap;
+  p.ref_align_factor = o.ref_align_factor;
+  p.max_ref_align_bases = o.max_ref_align_bases;
+  p.max_kmer_size = o.max_anchor_kmer_size;
+  p.trace_reference_assemblies = o.trace_reference_assemblies != 0;
+  return p;
+}
+
+// ---- anchor_dropper (anchor_drop.cpp) -----------------------------------------------------------------------------------
+AnchorDropper::AnchorDropper(const AlignParams& p, const ScaffoldView& sc, AssemblySink out)
+    : SortedOutput(std::move(out)), p_(p), sc_(sc) {
+  kmer_size_ = int(std::min<uint64_t>(p.min_overlap, uint64_t(p.max_kmer_size)));  // :21
+  check(kmer_size_ >= 1 && kmer_size_ <= 31, "anchor_dropper: k-mer size outside 1..31");
+  kmer_mask_ = ~((~uint64_t(0)) << (kmer_size_ * 2));
+  kmer_skip_len_ = int64_t(p.min_overlap) - kmer_size_;
+  it_offset_ = sc.ext.empty() ? sc.end_pos : sc.ext[0].offset;
+}
+
+void AnchorDropper::advance_range_to(int64_t trail_behind, int64_t read_ahead) {  // :76-84 with :30-63
+  auto at_end = [&] { return it_ext_ >= sc_.ext.size(); };
+  auto next_extent = [&] {
+    ++it_ext_;
+    it_pos_ = 0;
+    it_offset_ = at_end() ? sc_.end_pos : sc_.ext[it_ext_].offset;
+  };
+  const int64_t target = trail_behind - kmer_size_;
+  if (it_offset_ < target && !at_end()) {  // skip_to: scaffold.cpp:205-247
+    while (it_offset_ < target) {
+      const int64_t adv = std::min(target - it_offset_, sc_.ext[it_ext_].n - it_pos_);
+      it_pos_ += adv;
+      it_offset_ += adv;
+      if (it_pos_ == sc_.ext[it_ext_].n) {
+        next_extent();
+        if (at_end()) break;
+      }
+    }
+    kmer_needed_ = kmer_size_ - 1;
+  }
+  while (it_offset_ < read_ahead) {  // advance_read_ahead_to
+    if (at_end()) break;
+    if (it_pos_ == 0) kmer_needed_ = kmer_size_ - 1;
+    kmer_ = (kmer_ << 2) | code_of(sc_.ext[it_ext_].p[it_pos_]);
+    if (kmer_needed_) {
+      --kmer_needed_;
+    } else {
+      kmers_[kmer_ & kmer_mask_].push_back(it_offset_ + 1 - kmer_size_);
+      kmer_needed_ = kmer_skip_len_;
+    }
+    ++it_pos_;
+    ++it_offset_;
+    if (it_pos_ == sc_.ext[it_ext_].n) next_extent();
+  }
+  // advance_trail_behind_to(trail_behind) advances the read-ahead iterator there (:86), which is already past it:
+  // no k-mer is ever taken out of the table; candidates left of the assembly are filtered where they are used.
+}
+
+bool AnchorDropper::try_long_rejoin(bg_trace_assembly_rec& a) {  // :107-192
+  if (a.seq.size() < p_.min_overlap + uint64_t(a.left_anchor_len)) return false;
+  int64_t best_len = 0, best_seq = 0, best_ref = 0;
+  const int64_t n = int64_t(a.seq.size());
+  uint64_t km = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    km = ((km << 2) | code_of(a.seq[size_t(i)])) & kmer_mask_;
+    const int64_t seq_offset = i + 1 - kmer_size_;
+    if (seq_offset < a.left_anchor_len) continue;
+    auto found = kmers_.find(km);
+    if (found == kmers_.end()) continue;
+    for (auto at = found->second.rbegin(); at != found->second.rend(); ++at) {
+      const int64_t ref_at = *at;
+      if (ref_at < a.left_offset + a.left_anchor_len) continue;
+      const int64_t max_before = std::min<int64_t>(seq_offset - a.left_anchor_len, ref_at - a.left_offset - a.left_anchor_len);
+      // split_extent_at (scaffold.cpp:189-203)
+      const char *before_p = nullptr, *after_p = nullptr;
+      int64_t before_n = 0, after_n = 0;
+      for (const auto& e : sc_.ext) {
+        if (e.offset > ref_at) break;
+        if (e.offset + e.n < ref_at) continue;
+        before_p = e.p;
+        before_n = ref_at - e.offset;
+        after_p = e.p + before_n;
+        after_n = e.n - before_n;
+        break;
+      }
+      int64_t before = shared_suffix(before_p, before_n, a.seq.data() + a.left_anchor_len, seq_offset - a.left_anchor_len);
+      if (before > max_before) before = max_before;
+      const int64_t shared = before + shared_prefix(after_p, after_n, a.seq.data() + seq_offset, n - seq_offset);
+      if (shared <= best_len || shared < int64_t(p_.min_overlap)) continue;
+      best_len = shared;
+      best_seq = seq_offset - before;
+      best_ref = ref_at - before;
+    }
+  }
+  if (best_len == 0) return false;
+  check(best_ref > a.left_offset, "anchor_dropper: long rejoin at the left anchor");
+  a.right_offset = best_ref + best_len;
+  bg_trace_assembly_rec anchored = split_assembly(a, best_seq + best_len, a.right_offset - a.left_offset).first;
+  anchored.right_anchor_len = int(best_len);
+  if (anchored.right_anchor_len + anchored.left_anchor_len > anchored.right_offset - anchored.left_offset)
+    anchored.right_anchor_len = int(anchored.right_offset - anchored.left_offset - anchored.left_anchor_len);
+  sort_and_output(std::move(anchored));
+  return true;
+}
+
+void AnchorDropper::add(bg_trace_assembly_rec&& a) {  // on_assembly :194-341
+  flush_sorted_to(a.left_offset);
+  if (a.right_anchor_len || a.matches_reference) {
+    if (!a.matches_reference) check(a.left_anchor_len != 0, "anchor_dropper: right anchor without a left one");
+    sort_and_output(std::move(a));
+    return;
+  }
+  check(a.left_anchor_len != 0, "anchor_dropper: dead end without a left anchor");
+  advance_range_to(a.left_offset, a.left_offset + int64_t(p_.read_ahead_distance));
+  if (a.left_anchor_len >= int64_t(a.seq.size())) return;
+  if (try_long_rejoin(a)) return;
+  bool have = false;
+  int64_t new_seq_len = 0, new_ref_len = 0, new_match_len = 0;
+  int64_t seq_start = 0, ref_start = a.left_offset;
+  const int64_t n = int64_t(a.seq.size());
+  for (;;) {
+    const int64_t shared = sc_.sub(ref_start, n - seq_start).shared_prefix_length(a.seq.data() + seq_start, n - seq_start);
+    seq_start += shared;
+    check(seq_start >= a.left_anchor_len, "anchor_dropper: the left anchor does not match the reference");
+    ref_start += shared;
+    const Slice variant{a.seq.data() + seq_start, n - seq_start};
+    if (variant.n == 0) break;
+    const ScaffoldView variant_s = sc_.sub(ref_start, variant.n * 5 / 4 + 3);
+    int64_t match_len, so, ro, min_match;
+    if (!find_biggest_match(p_, variant, variant_s, &match_len, &so, &ro, &min_match, ANCHORED_TO_LEFT)) break;
+    seq_start += so + match_len;
+    ref_start += ro + match_len;
+    have = true;
+    new_seq_len = seq_start;
+    new_ref_len = ref_start - a.left_offset;
+    new_match_len = match_len;
+  }
+  if (!have) return;  // the reference reports a half-aligned assembly here; nothing goes down the pipeline
+  a.right_offset = a.left_offset + new_ref_len;
+  bg_trace_assembly_rec anchored = split_assembly(a, new_seq_len, new_ref_len).first;
+  anchored.right_anchor_len = int(new_match_len);
+  sort_and_output(std::move(anchored));
+}
+
+}  // namespace bg
+
+using namespace bg;
+
+// ---- C ABI ---------------------------------------------------------------------------------------------------------------
+extern "C" int bg_trace_result_new(bg_trace_result** out) {
+  if (!out) { set_error("bg_trace_result_new: null argument"); return BG_EINVAL; }
+  *out = new bg_trace_result;
+  memset(&(*out)->stats, 0, sizeof((*out)->stats));
+  return BG_OK;
+}
+
+extern "C" int bg_trace_result_add(bg_trace_result* r, const bg_trace_assembly* a) {
+  if (!r || !a || (a->seq_len && !a->seq)) { set_error("bg_trace_result_add: null argument"); return BG_EINVAL; }
+  for (uint64_t i = 0; i < a->seq_len; ++i)
+    if (a->seq[i] != 'A' && a->seq[i] != 'C' && a->seq[i] != 'G' && a->seq[i] != 'T') { set_error("bg_trace_result_add: sequences hold ACGT only"); return BG_EINVAL; }
+  bg_trace_assembly_rec x;
+  x.left_offset = a->left_offset;
+  x.right_offset = a->right_offset;
+  x.left_anchor_len = a->left_anchor_len;
+  x.right_anchor_len = a->right_anchor_len;
+  x.seq.assign(a->seq ? a->seq : "", size_t(a->seq_len));
+  x.min_overlap = a->min_overlap;
+  x.trace_steps = a->trace_steps;
+  x.left_anchor_ambiguous_bases = a->left_anchor_ambiguous_bases;
+  x.matches_reference = a->matches_reference != 0;
+  x.score = a->score;
+  if (a->n_rc_read_ids) x.rc_read_ids.assign(a->rc_read_ids, a->rc_read_ids + a->n_rc_read_ids);
+  if (a->n_left_pair_matches) x.left_pair_matches.assign(a->left_pair_matches, a->left_pair_matches + a->n_left_pair_matches);
+  if (a->n_right_pair_matches) x.right_pair_matches.assign(a->right_pair_matches, a->right_pair_matches + a->n_right_pair_matches);
+  r->a.push_back(std::move(x));
+  return BG_OK;
+}
+
+extern "C" uint64_t bg_trace_result_var_count(const bg_trace_result* r, uint64_t i) {
+  return (r && i < r->a.size()) ? r->a[i].aligned_variants.size() : 0;
+}
+
+extern "C" int bg_trace_result_var(const bg_trace_result* r, uint64_t i, uint64_t j, int64_t* left_offset, int64_t* right_offset,
+                                   const char** seq, uint64_t* seq_len) {
+  if (!r || i >= r->a.size() || j >= r->a[i].aligned_variants.size() || !left_offset || !right_offset || !seq || !seq_len) {
+    set_error("bg_trace_result_var: bad argument");
+    return BG_EINVAL;
+  }
+  const bg_aligned_var_rec& v = r->a[i].aligned_variants[j];
+  *left_offset = v.left_offset;
+  *right_offset = v.right_offset;
+  *seq = v.seq.data();
+  *seq_len = v.seq.size();
+  return BG_OK;
+}
+
+extern "C" int bg_assemblies_process(const bg_trace_result* const* in, uint32_t n_in, uint64_t n_extents, const int64_t* ext_offset,
+                                     const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos,
+                                     const bg_trace_options* options, uint32_t steps, bg_trace_result** out) {
+  if (!out || (n_in && !in) || (n_extents && (!ext_offset || !ext_seq || !ext_len))) { set_error("bg_assemblies_process: null argument"); return BG_EINVAL; }
+  if (steps & ~uint32_t(BG_STEP_ALL)) { set_error("bg_assemblies_process: unknown step bits"); return BG_EINVAL; }
+  bg_trace_options o;
+  if (options) o = *options; else bg_trace_options_default(&o);
+  if (o.ref_align_factor < 1) { set_error("bg_assemblies_process: ref_align_factor must be at least 1"); return BG_EINVAL; }
+  ScaffoldView sc;
+  int64_t calc_end = 0;
+  for (uint64_t i = 0; i < n_extents; ++i) {
+    if (ext_offset[i] < calc_end) { set_error("bg_assemblies_process: extents must ascend without overlap"); return BG_EINVAL; }
+    for (uint64_t j = 0; j < ext_len[i]; ++j) {
+      const char c = ext_seq[i][j];
+      if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { set_error("bg_assemblies_process: extents hold ACGT only"); return BG_EINVAL; }
+    }
+    sc.ext.push_back(ScaffoldView::Ext{ext_offset[i], ext_seq[i], int64_t(ext_len[i])});
+    calc_end = ext_offset[i] + int64_t(ext_len[i]);
+  }
+  if (end_pos < calc_end) { set_error("bg_assemblies_process: end_pos lies before the end of the last extent"); return BG_EINVAL; }
+  sc.end_pos = end_pos;
+  const AlignParams p = AlignParams::from(o);
+  std::unique_ptr<bg_trace_result> res(new bg_trace_result);
+  memset(&res->stats, 0, sizeof(res->stats));
+  try {
+    // the chain, built back to front like assemble_pipeline::make_pipeline (pipeline.cpp:81-90)
+    AssemblySink sink = [&](bg_trace_assembly_rec&& a) { res->a.push_back(std::move(a)); };
+    std::unique_ptr<AlignSplitter> split;
+    std::unique_ptr<Aligner> align;
+    std::unique_ptr<Deduper> dedup;
+    std::unique_ptr<RefTrimmer> trim;
+    std::unique_ptr<AnchorDropper> drop;
+    if (steps & BG_STEP_SPLIT) { split.reset(new AlignSplitter(sink)); sink = [&](bg_trace_assembly_rec&& a) { split->add(std::move(a)); }; }
+    if (steps & BG_STEP_ALIGN) { align.reset(new Aligner(p, sc, sink)); sink = [&](bg_trace_assembly_rec&& a) { align->add(std::move(a)); }; }
+    if (steps & BG_STEP_DEDUP) { dedup.reset(new Deduper(sink)); sink = [&](bg_trace_assembly_rec&& a) { dedup->add(std::move(a)); }; }
+    if (steps & BG_STEP_TRIM_REF) { trim.reset(new RefTrimmer(sc, sink)); sink = [&](bg_trace_assembly_rec&& a) { trim->add(std::move(a)); }; }
+    std::vector<bg_trace_assembly_rec> all;
+    AssemblySink collect = [&](bg_trace_assembly_rec&& a) { all.push_back(std::move(a)); };
+    if (steps & BG_STEP_ANCHOR_DROP) drop.reset(new AnchorDropper(p, sc, collect));
+    for (uint32_t i = 0; i < n_in; ++i) {
+      if (!in[i]) { set_error("bg_assemblies_process: null input"); return BG_EINVAL; }
+      for (const auto& a : in[i]->a) {
+        bg_trace_assembly_rec copy = a;
+        if (drop) drop->add(std::move(copy)); else all.push_back(std::move(copy));
+      }
+    }
+    if (drop) drop->flush();
+    if (steps & BG_STEP_SORT) std::stable_sort(all.begin(), all.end(), canon_less);
+    for (auto& a : all) sink(std::move(a));
+    if (trim) trim->flush();
+    if (dedup) dedup->flush();
+    if (align) align->flush();
+    if (split) split->flush();
+  } catch (const CheckFailed& f) {
+    set_error("bg_assemblies_process: %s (the reference aborts on this input)", f.what.c_str());
+    return BG_EINVAL;
+  }
+  *out = res.release();
+  return BG_OK;
+}

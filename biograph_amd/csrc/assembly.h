@@ -1,0 +1,103 @@
+// assembly.h — what tracer.cpp and align.cpp share: the assembly record behind bg_trace_result, the scaffold view and
+// the steps of align.cpp that the tracer session runs itself (the anchor_dropper sits between tracer and pair_counter,
+// reversable_tracer.cpp:124-125).  Internal; the C ABI is in include/bgseq.h.
+#pragma once
+#include <stdint.h>
+
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/bgseq.h"
+
+struct bg_aligned_var_rec {  // variants::aligned_var (assemble.h:124-152)
+  int64_t left_offset = 0, right_offset = 0;
+  std::string seq;
+  bool operator<(const bg_aligned_var_rec& r) const {
+    if (left_offset != r.left_offset) return left_offset < r.left_offset;
+    if (right_offset != r.right_offset) return right_offset < r.right_offset;
+    return seq < r.seq;
+  }
+  bool empty() const { return left_offset == right_offset && seq.empty(); }
+};
+
+struct bg_trace_assembly_rec {  // variants::assembly (assemble.h:285-380), the fields this path fills
+  int64_t left_offset = 0, right_offset = 0;
+  int left_anchor_len = 0, right_anchor_len = 0;
+  std::string seq;
+  unsigned min_overlap = 0, trace_steps = 0, left_anchor_ambiguous_bases = 0;
+  bool matches_reference = false;
+  int64_t score = 0;
+  std::vector<uint32_t> rc_read_ids, left_pair_matches, right_pair_matches;
+  std::vector<bg_aligned_var_rec> aligned_variants;
+};
+
+struct bg_trace_result {
+  std::vector<bg_trace_assembly_rec> a;
+  bg_trace_stats stats;
+};
+
+namespace bg {
+
+// variants::scaffold (scaffold.h) as a view: extents point into storage the caller keeps alive.
+struct ScaffoldView {
+  struct Ext { int64_t offset; const char* p; int64_t n; };
+  std::vector<Ext> ext;
+  int64_t end_pos = 0;
+  ScaffoldView sub(int64_t start, int64_t len) const;           // scaffold::subscaffold (scaffold.cpp:46-80)
+  int64_t shared_prefix_length(const char* s, int64_t n) const;  // scaffold.cpp:150-161
+  int64_t shared_suffix_length(const char* s, int64_t n) const;  // rev_comp().shared_prefix_length(rev_comp(seq)), align.cpp:34-35
+};
+
+struct CheckFailed { std::string what; };  // a CHECK(...) of the reference: it aborts there; here the ABI call fails
+
+using AssemblySink = std::function<void(bg_trace_assembly_rec&&)>;
+
+// sorted_output_pipeline_step (assemble.cpp:291-346): a queue in canon order drained up to a left offset.
+class SortedOutput {
+ public:
+  explicit SortedOutput(AssemblySink out) : out_(std::move(out)) {}
+  void flush() { flush_sorted_to(0x7fffffff); }
+
+ protected:
+  void flush_sorted_to(int64_t offset);
+  void sort_and_output(bg_trace_assembly_rec&& a);
+
+ private:
+  AssemblySink out_;
+  std::vector<bg_trace_assembly_rec> queue_;  // ascending canon order, equal keys in arrival order
+  int64_t flush_point_ = INT32_MIN;
+};
+
+struct AlignParams {  // the assemble_options fields the steps of align.cpp read
+  uint64_t min_overlap = 100, read_ahead_distance = 100000, min_anchor_drop_overlap = 15;
+  int ref_align_factor = 4, max_ref_align_bases = 30, max_kmer_size = 31;
+  bool trace_reference_assemblies = false;
+  static AlignParams from(const bg_trace_options& o);
+};
+
+// anchor_dropper (anchor_drop.cpp): gives dead-end assemblies (right_anchor_len == 0) a right anchor on the
+// reference ahead of them, or drops them.
+class AnchorDropper : public SortedOutput {
+ public:
+  AnchorDropper(const AlignParams& p, const ScaffoldView& sc, AssemblySink out);
+  void add(bg_trace_assembly_rec&& a);
+
+ private:
+  void advance_range_to(int64_t trail_behind, int64_t read_ahead);
+  bool try_long_rejoin(bg_trace_assembly_rec& a);
+  AlignParams p_;
+  const ScaffoldView& sc_;
+  int kmer_size_;
+  int64_t kmer_skip_len_;
+  uint64_t kmer_mask_;
+  // scaffold::iterator of m_read_ahead (scaffold.h:14-60)
+  size_t it_ext_ = 0;
+  int64_t it_pos_ = 0, it_offset_ = 0;
+  int64_t kmer_needed_ = 0;
+  uint64_t kmer_ = 0;
+  std::unordered_map<uint64_t, std::vector<int64_t>> kmers_;  // values in insertion order; equal_range order = backwards
+};
+
+}  // namespace bg

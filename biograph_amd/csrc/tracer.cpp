@@ -18,9 +18,9 @@
 // host does the cost bookkeeping, the pairing look-ups and the queues exactly as the reference orders them
 // (std::push_heap / pop_heap on the next paths, the multiset of rejoins, dead_end_sorter).
 //
-// Not here: anchor_dropper (anchor_drop.cpp) between tracer and pair_counter -- dead-end assemblies come out as the
-// tracer emits them (right_anchor_len == 0); the pop tracer, the bidirectional tracer and everything downstream
-// (align, genotype, VCF).
+// The anchor_dropper between tracer and pair_counter (anchor_drop.cpp) and the head of the serial pipeline behind the
+// tracers (sort, ref trim, dedup, align, split) are in align.cpp.  Not here: the pop tracer, the bidirectional tracer
+// and what follows the align_splitter (normalize, coverage, genotype, VCF).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
@@ -35,6 +35,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "assembly.h"
 #include "bg_internal.h"
 
 using namespace bg;
@@ -75,6 +76,11 @@ extern "C" void bg_trace_options_default(bg_trace_options* o) {
   o->only_trace_forward = 0;
   o->trace_reference_assemblies = 0;
   o->anchor_drop_size_multiplier = 1.5;
+  o->min_anchor_drop_overlap = 15;       // assemble.h:504
+  o->ref_align_factor = 4;               // assemble.h:677
+  o->max_ref_align_bases = 30;           // assemble.h:682
+  o->anchor_drop = 1;                    // reversable_tracer.cpp:124-125 always has the step
+  o->max_anchor_kmer_size = 31;          // anchor_dropper::g_max_kmer_size (anchor_drop.cpp:9)
 }
 
 namespace {
@@ -120,21 +126,6 @@ std::string rev_comp_str(const std::string& s) {
 }
 
 }  // namespace
-
-struct bg_trace_assembly_rec {
-  int64_t left_offset = 0, right_offset = 0;
-  int left_anchor_len = 0, right_anchor_len = 0;
-  std::string seq;
-  unsigned min_overlap = 0, trace_steps = 0, left_anchor_ambiguous_bases = 0;
-  bool matches_reference = false;
-  int64_t score = 0;
-  std::vector<uint32_t> rc_read_ids, left_pair_matches, right_pair_matches;
-};
-
-struct bg_trace_result {
-  std::vector<bg_trace_assembly_rec> a;
-  bg_trace_stats stats;
-};
 
 namespace {
 
@@ -947,15 +938,31 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
   std::vector<bg_trace_assembly_rec> raw;
   const double s_ext = now_seconds() - t_ext;
   const double t_chunk = now_seconds();
+  std::vector<Extent> rc;
   if (rev_comp) {  // scaffold::rev_comp (scaffold.cpp:163-175)
-    std::vector<Extent> rc;
     for (auto it = ext.rbegin(); it != ext.rend(); ++it)
       rc.push_back(Extent{end_pos - it->offset - int64_t(it->seq.size()), rev_comp_str(it->seq)});
     BG_TRY(trace_chunk(w, rc, end_pos - limit_offset, end_pos - start_offset, &raw));
   } else {
     BG_TRY(trace_chunk(w, ext, start_offset, limit_offset, &raw));
   }
+  const std::vector<Extent>& run_ext = rev_comp ? rc : ext;
   const double s_chunk = now_seconds() - t_chunk;
+  if (w.o.anchor_drop) {  // anchor_dropper over the scaffold the tracer ran on (reversable_tracer.cpp:124-133)
+    ScaffoldView sc;
+    for (const Extent& e : run_ext) sc.ext.push_back(ScaffoldView::Ext{e.offset, e.seq.data(), int64_t(e.seq.size())});
+    sc.end_pos = end_pos;
+    std::vector<bg_trace_assembly_rec> dropped;
+    try {
+      AnchorDropper ad(AlignParams::from(w.o), sc, [&](bg_trace_assembly_rec&& a) { dropped.push_back(std::move(a)); });
+      for (auto& a : raw) ad.add(std::move(a));
+      ad.flush();
+    } catch (const CheckFailed& f) {
+      set_error("bg_tracer_trace: anchor_dropper: %s (the reference aborts on this input)", f.what.c_str());
+      return BG_EINVAL;
+    }
+    raw = std::move(dropped);
+  }
   std::vector<bg_trace_assembly_rec> counted;
   if (pair_count) {
     PairCounter pc{w, &counted};

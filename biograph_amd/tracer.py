@@ -1,7 +1,8 @@
-"""Row f.2, first slice: the reference's production push tracer behind the C ABI (csrc/tracer.cpp, kernels in
-csrc/walk.hip).  `push_trace` = reversable_tracer::assemble(start, limit) (variants/reversable_tracer.cpp:76-145 ->
-tracer::assemble, tracer.cpp:195-318) followed by pair_counter; anchor_dropper is not part of the slice.  The work
-list of a whole reference is population.ref_chunks (trace_ref.cpp:27-105)."""
+"""Row f.2: the reference's production push tracer behind the C ABI (csrc/tracer.cpp, kernels in csrc/walk.hip) and the
+head of the assembly pipeline behind it (csrc/align.cpp).  `push_trace` = reversable_tracer::assemble(start, limit)
+(variants/reversable_tracer.cpp:76-145 -> tracer::assemble, tracer.cpp:195-318): tracer -> anchor_dropper ->
+pair_counter.  `process_assemblies` = the serial pipeline of variants/pipeline.cpp:40-57,92-95 up to the
+align_splitter.  The work list of a whole reference is population.ref_chunks (trace_ref.cpp:27-105)."""
 import ctypes as C
 
 import numpy as np
@@ -22,7 +23,10 @@ _INT_FIELDS = ["forward_pairs_face_inward", "ignore_ambiguous_ref_pairs", "trace
 class TraceOptions(C.Structure):
     """bg_trace_options = the assemble_options the push tracer reads (variants/assemble.h:475-720)."""
     _fields_ = ([(n, C.c_int64) for n in _I64_FIELDS] + [(n, C.c_uint64) for n in _U64_FIELDS] +
-                [(n, C.c_int) for n in _INT_FIELDS] + [("anchor_drop_size_multiplier", C.c_double)])
+                [(n, C.c_int) for n in _INT_FIELDS] + [("anchor_drop_size_multiplier", C.c_double),
+                                                        ("min_anchor_drop_overlap", C.c_uint64),
+                                                        ("ref_align_factor", C.c_int32), ("max_ref_align_bases", C.c_int32),
+                                                        ("anchor_drop", C.c_int32), ("max_anchor_kmer_size", C.c_int32)])
 
     def __init__(self, **kw):
         super().__init__()
@@ -53,9 +57,21 @@ class _Asm(C.Structure):
 
 
 class TraceAssembly:
-    """variants::assembly as the tracer and pair_counter fill it."""
+    """variants::assembly as the tracer, pair_counter and the steps of csrc/align.cpp fill it.  aligned_variants =
+    [(left_offset, right_offset, seq)] (variants::aligned_var) after the aligner."""
 
-    def __init__(self, a):
+    def __init__(self, a=None, **kw):
+        self.aligned_variants = []
+        if a is None:  # a hand-made assembly (the reference's unit tests build them this way)
+            self.left_offset = self.right_offset = self.left_anchor_len = self.right_anchor_len = 0
+            self.seq, self.min_overlap, self.trace_steps, self.left_anchor_ambiguous_bases = "", 0, 0, 0
+            self.matches_reference, self.score = False, 0
+            self.rc_read_ids, self.left_pair_matches, self.right_pair_matches = [], [], []
+            for k, v in kw.items():
+                if not hasattr(self, k):
+                    raise AttributeError("no assembly field %r" % k)
+                setattr(self, k, v)
+            return
         self.left_offset, self.right_offset = int(a.left_offset), int(a.right_offset)
         self.left_anchor_len, self.right_anchor_len = int(a.left_anchor_len), int(a.right_anchor_len)
         self.seq = C.string_at(a.seq, a.seq_len).decode() if a.seq_len else ""
@@ -98,6 +114,62 @@ def reference_ref_map(seqset, sequences):
     return out
 
 
+def _read_result(h):
+    L = capi.lib()
+    out = []
+    a = _Asm()
+    lo, ro, sp, sl = C.c_int64(), C.c_int64(), C.c_void_p(), C.c_uint64()
+    for i in range(L.bg_trace_result_size(h)):
+        capi.check(L.bg_trace_result_get(h, i, C.byref(a)))
+        t = TraceAssembly(a)
+        for j in range(L.bg_trace_result_var_count(h, i)):
+            capi.check(L.bg_trace_result_var(h, i, j, C.byref(lo), C.byref(ro), C.byref(sp), C.byref(sl)))
+            t.aligned_variants.append((int(lo.value), int(ro.value), C.string_at(sp.value, sl.value).decode() if sl.value else ""))
+        out.append(t)
+    return out
+
+
+def _u32_array(xs):
+    return (C.c_uint32 * max(len(xs), 1))(*[int(x) for x in xs])
+
+
+STEP_ANCHOR_DROP, STEP_SORT, STEP_TRIM_REF, STEP_DEDUP, STEP_ALIGN, STEP_SPLIT = 1, 2, 4, 8, 16, 32
+STEP_PIPELINE = STEP_SORT | STEP_TRIM_REF | STEP_DEDUP | STEP_ALIGN | STEP_SPLIT
+
+
+def process_assemblies(assemblies, extents, end_pos=None, options=None, steps=STEP_PIPELINE):
+    """bg_assemblies_process: the assemblies of one scaffold's work items (TraceAssembly objects, forward coordinates)
+    through the chosen steps of the pipeline behind the tracers, in the pipeline's order: anchor_dropper, sorter,
+    ref_trimmer, deduper, aligner, align_splitter.  -> [TraceAssembly] as they leave the last step."""
+    L = capi.lib()
+    src = C.c_void_p()
+    capi.check(L.bg_trace_result_new(C.byref(src)))
+    out = C.c_void_p()
+    try:
+        for t in assemblies:
+            seq = t.seq.encode()
+            ids, lm, rm = _u32_array(t.rc_read_ids), _u32_array(t.left_pair_matches), _u32_array(t.right_pair_matches)
+            a = _Asm(t.left_offset, t.right_offset, t.score, t.left_anchor_len, t.right_anchor_len,
+                     C.cast(C.c_char_p(seq), C.c_void_p), len(seq), t.min_overlap, t.trace_steps, t.left_anchor_ambiguous_bases,
+                     int(t.matches_reference), ids, lm, rm, len(t.rc_read_ids), len(t.left_pair_matches), len(t.right_pair_matches))
+            capi.check(L.bg_trace_result_add(src, C.byref(a)))
+        n = len(extents)
+        offs = (C.c_int64 * max(n, 1))(*[int(o) for o, _ in extents])
+        bufs = [s.encode() for _, s in extents]
+        ptrs = (C.c_char_p * max(n, 1))(*bufs)
+        lens = (C.c_uint64 * max(n, 1))(*[len(b) for b in bufs])
+        calc_end = max([o + len(s) for o, s in extents] + [0])
+        end_pos = calc_end if end_pos is None else end_pos
+        ins = (C.c_void_p * 1)(src)
+        opt = options if options is not None else TraceOptions()
+        capi.check(L.bg_assemblies_process(ins, 1, n, offs, ptrs, lens, end_pos, C.byref(opt), int(steps), C.byref(out)))
+        return _read_result(out)
+    finally:
+        L.bg_trace_result_free(src)
+        if out:
+            L.bg_trace_result_free(out)
+
+
 class PushTracer:
     """A tracer session (bg_tracer_open): the seqset / readmap / ref_map arrays the host part consults are copied once,
     trace() is one work item of trace_ref (a scaffold piece in one direction)."""
@@ -124,11 +196,7 @@ class PushTracer:
         capi.check(L.bg_tracer_trace(self.h, n, offs, ptrs, lens, end_pos, start, limit, int(bool(rev_comp)), int(bool(pair_count)),
                                      C.byref(h)))
         try:
-            out = []
-            a = _Asm()
-            for i in range(L.bg_trace_result_size(h)):
-                capi.check(L.bg_trace_result_get(h, i, C.byref(a)))
-                out.append(TraceAssembly(a))
+            out = _read_result(h)
             if not with_stats:
                 return out
             st = _Stats()

@@ -386,7 +386,8 @@ int bg_tracer_extend_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* r
                            uint32_t* d_steps /* n * step_cap: base | size << 8 per step */);
 /* Host part (csrc/tracer.cpp): reversable_tracer::assemble(start, limit) with the push tracer
  * (variants/reversable_tracer.cpp:76-145 -> tracer::assemble, tracer.cpp:195-318) followed by pair_counter
- * (pair_counter.cpp); anchor_dropper is not part of this slice.  Fields = assemble_options (assemble.h:475-720). */
+ * (pair_counter.cpp), with the anchor_dropper (anchor_drop.cpp) between them.  Fields = assemble_options
+ * (assemble.h:475-720). */
 typedef struct bg_trace_options {
   int64_t ambiguous_branch_cost, rejoin_local_cost, base_cost, increase_max_between_pair_cost, max_cost, pairs_used_cost,
       traverse_ref_cost, decrease_overlap_cost, size_change_cost, dead_end_cost, anchor_drop_score, pair_match_score,
@@ -397,6 +398,13 @@ typedef struct bg_trace_options {
   int forward_pairs_face_inward, ignore_ambiguous_ref_pairs, trace_ambiguous_ref, trace_dead_ends, only_trace_forward,
       trace_reference_assemblies;
   double anchor_drop_size_multiplier;
+  /* the anchor_dropper and aligner steps (csrc/align.cpp) */
+  uint64_t min_anchor_drop_overlap;                 /* assemble.h:504 (15)                                            */
+  int32_t ref_align_factor, max_ref_align_bases;    /* assemble.h:677-682 (4, 30)                                     */
+  int32_t anchor_drop;            /* 1: run the anchor_dropper between tracer and pair_counter, as
+                                     reversable_tracer.cpp:124-125 always does; 0 hands out the tracer's raw
+                                     dead-end assemblies (right_anchor_len == 0) -- a test hook                       */
+  int32_t max_anchor_kmer_size;   /* anchor_dropper::set_max_kmer_size_for_testing (anchor_drop.h:15-19); 31          */
 } bg_trace_options;
 void bg_trace_options_default(bg_trace_options* o);
 typedef struct bg_trace_stats {  /* assemble_stats of the tracer + the device rounds this implementation took */
@@ -436,6 +444,41 @@ uint64_t bg_trace_result_size(const bg_trace_result* r);
 int bg_trace_result_get(const bg_trace_result* r, uint64_t i, bg_trace_assembly* out);  /* pointers live as long as r */
 int bg_trace_result_stats(const bg_trace_result* r, bg_trace_stats* out);
 void bg_trace_result_free(bg_trace_result* r);
+
+/* ---- row f.2, second slice (csrc/align.cpp): the head of the serial pipeline every tracer's output runs through
+ * (variants/pipeline.cpp:40-57 and add_standard_variants_pipeline :92-95), as steps over bg_trace_result.
+ * bg_assemblies_process takes the results of the work items of ONE scaffold (all pieces, both directions; forward
+ * coordinates), runs the chosen steps in the pipeline's order and returns what leaves the last one:
+ *   BG_STEP_ANCHOR_DROP  anchor_dropper (anchor_drop.cpp) -- bg_tracer_trace has run it already unless
+ *                        options.anchor_drop was 0; for hand-made input (align_test.cpp:31-52)
+ *   BG_STEP_SORT         sorter(canon_assembly_order) (sort.cpp:6-13, assemble.cpp:1029-1085); stable
+ *   BG_STEP_TRIM_REF     ref_trimmer (trim_ref.cpp): drops reference assemblies, strips the anchors
+ *   BG_STEP_DEDUP        deduper (dedup.cpp:7-144): merges assemblies with the same variant part
+ *   BG_STEP_ALIGN        aligner (align.cpp:11-385): fills each assembly's aligned variants (bg_trace_result_var)
+ *   BG_STEP_SPLIT        align_splitter (align.cpp:387-460): cuts into reference and variant sections
+ * Steps other than SORT need their input sorted by left offset, as the reference's do; a condition the reference
+ * CHECK-aborts on (anchors that do not match the reference, unsorted input ...) fails the call with BG_EINVAL.
+ * Extents as for bg_push_trace.  Host only: no bg_ctx, no device work. */
+#define BG_STEP_ANCHOR_DROP 1u
+#define BG_STEP_SORT 2u
+#define BG_STEP_TRIM_REF 4u
+#define BG_STEP_DEDUP 8u
+#define BG_STEP_ALIGN 16u
+#define BG_STEP_SPLIT 32u
+#define BG_STEP_ALL 63u
+#define BG_STEP_PIPELINE (BG_STEP_SORT | BG_STEP_TRIM_REF | BG_STEP_DEDUP | BG_STEP_ALIGN | BG_STEP_SPLIT)
+int bg_assemblies_process(const bg_trace_result* const* in, uint32_t n_in, uint64_t n_extents, const int64_t* ext_offset,
+                          const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos,
+                          const bg_trace_options* options /* NULL = defaults */, uint32_t steps, bg_trace_result** out);
+/* Hand-made input for the steps (the reference's unit tests build assemblies by hand): an empty result, and a copy
+ * of *a appended to it. */
+int bg_trace_result_new(bg_trace_result** out);
+int bg_trace_result_add(bg_trace_result* r, const bg_trace_assembly* a);
+/* aligned_variants of assembly i (variants::aligned_var, assemble.h:124-152): filled by BG_STEP_ALIGN, consumed by
+ * BG_STEP_SPLIT.  seq points into r. */
+uint64_t bg_trace_result_var_count(const bg_trace_result* r, uint64_t i);
+int bg_trace_result_var(const bg_trace_result* r, uint64_t i, uint64_t j, int64_t* left_offset, int64_t* right_offset,
+                        const char** seq, uint64_t* seq_len);
 
 
 /* ---- Merge: `biograph merge` = seqset_flat + make_mergemap + seqset_merger

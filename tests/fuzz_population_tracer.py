@@ -82,23 +82,33 @@ def tracer_case(ctx, seed):
               trace_ambiguous_ref=int(rng.random() < 0.3), ignore_ambiguous_ref_pairs=int(rng.random() < 0.7),
               trace_dead_ends=int(rng.random() < 0.8), forward_pairs_face_inward=int(rng.random() < 0.8),
               trace_reference_assemblies=int(rng.random() < 0.7), max_pairs_per_read=int(rng.choice([1, 20])))
-    o_gpu = tracer.TraceOptions(**kw)
+    akw = dict(anchor_drop=int(rng.random() < 0.8), min_anchor_drop_overlap=int(rng.choice([5, 15, 30])),
+               max_anchor_kmer_size=int(rng.choice([2, 12, 31])), ref_align_factor=int(rng.choice([2, 4])),
+               max_ref_align_bases=int(rng.choice([10, 30])))
+    o_gpu = tracer.TraceOptions(**kw, **akw)
     o_cpu = T.Options(**{k: (bool(v) if k in ("trace_ambiguous_ref", "ignore_ambiguous_ref_pairs", "trace_dead_ends",
                                               "forward_pairs_face_inward", "trace_reference_assemblies") else v)
                          for k, v in kw.items()})
     sc = T.Scaffold(parts)
     end = sc.end_pos
     ok = True
+    ad = None
+    if akw["anchor_drop"]:
+        ao = A.AlignOptions(min_overlap=kw["min_overlap"], read_ahead_distance=kw["read_ahead_distance"],
+                            trace_reference_assemblies=bool(kw["trace_reference_assemblies"]),
+                            min_anchor_drop_overlap=akw["min_anchor_drop_overlap"], max_kmer_size=akw["max_anchor_kmer_size"],
+                            ref_align_factor=akw["ref_align_factor"], max_ref_align_bases=akw["max_ref_align_bases"])
+        ad = lambda s_, emit: A.AnchorDropper(ao, s_, emit)  # noqa: E731
     try:
         for rev in (False, True):
             ranges = [(0, None)]
             a = int(rng.integers(0, end))
             ranges.append((a, min(end, a + int(rng.integers(50, 2500)))))
             for start, limit in ranges:
-                want = T.reversable_trace(g, sc, o_cpu, rev_comp=rev, start_offset=start, limit_offset=limit)
+                want = T.reversable_trace(g, sc, o_cpu, rev_comp=rev, start_offset=start, limit_offset=limit, anchor_drop=ad)
                 got = tracer.push_trace(ss, rm, rmap, parts, start=start, limit=limit, rev_comp=rev, options=o_gpu)
                 if [full_key(x) for x in got] != [full_key(x) for x in want]:
-                    print("TRACER MISMATCH seed", seed, "rev", rev, "range", start, limit, kw, "G", G, "rl", rl, "parts",
+                    print("TRACER MISMATCH seed", seed, "rev", rev, "range", start, limit, kw, "G", G, "rl", rl, akw, "parts",
                           [(o, len(s)) for o, s in parts], flush=True)
                     for i, (x, y) in enumerate(zip(got, want)):
                         if full_key(x) != full_key(y):

@@ -1,7 +1,8 @@
-"""Row f.2, first slice, on the GPU: bg_push_trace (host state machine csrc/tracer.cpp over the device walks
-bg_ref_walk_entries / bg_tracer_extend_batch) against (1) the vectors of the reference's tracer_test.cpp:167-304 and
-(2) the oracle's literal restatement of tracer.cpp (oracle/tracer.py, itself pinned on those vectors) on synthetic reads
-with planted variants, errors and repeats -- assembly for assembly, forward and reverse, whole scaffold and chunked."""
+"""Row f.2 on the GPU: bg_push_trace (host state machine csrc/tracer.cpp over the device walks bg_ref_walk_entries /
+bg_tracer_extend_batch, anchor_dropper of csrc/align.cpp, pair_counter) against (1) the vectors of the reference's
+tracer_test.cpp:167-316 and (2) the oracle's literal restatement (oracle/tracer.py + oracle/align.py, themselves pinned
+on those vectors) on synthetic reads with planted variants, errors and repeats -- assembly for assembly, forward and
+reverse, whole scaffold and chunked, with the anchor_dropper (the reference's chain) and without it (the raw tracer)."""
 import numpy as np
 import pytest
 
@@ -73,7 +74,9 @@ CASES = {
                          [(tseq("abcde"), tseq_rc("cdefg")), (tseq("efghi"), tseq_rc("ghijk")), (tseq("ijklm"), tseq_rc("klmno"))],
                          [], {}),
     "dead_end": ([(0, tseq("abcdefghijklmnopqrstuvwxyz"))], [], V.reads_for_seq(V.DEAD, len(tseq("abcde")), len(tseq("a"))),
-                 {"min_overlap": len(tseq("abcd"))}),
+                 {"min_overlap": len(tseq("abcd")), "min_anchor_drop_overlap": 10}),
+    "dead_end2": ([(0, tseq("abcdefghijklmnopqrstuvwxyz"))], [], V.reads_for_seq(V.DEAD, len(tseq("abcde")), len(tseq("a"))),
+                  {"min_overlap": len(tseq("abcd")), "min_anchor_drop_overlap": 11}),
     "dead_end_big_drop": ([(0, tseq("abcdefghijklmnopqrstuvwxyz"))],
                           [(tseq("bcdef"), tseq("efgH") + "G" + tseq("y")), (tseq("defgH") + "G", tseq("fgH") + "G" + tseq("yz"))],
                           [], {}),
@@ -84,6 +87,10 @@ WANT = {
     "simple_variant": [(tseq("bcdef"), tseq("gHij"), tseq("klmno")), tseq("klmnopqr"), tseq("nopqrstu"), tseq("qrstuvw")],
     "cross_ref_sections": [(tseq("abcde"), tseq("fgh"), tseq("ijklm")), tseq("ijklmno")],
     "cross_ref_delete": [tseq("abcdefg"), (tseq("cdefg"), tseq("h"), tseq("ijklm")), tseq("ijklmno")],
+    # tracer_test.cpp:246-316, forward; nothing in the reverse direction
+    "dead_end": [(tseq("abcde"), "G" + tseq("f") + "G" + tseq("ghi") + "G", tseq("j"))],
+    "dead_end2": [(tseq("abcde"), "G" + tseq("f") + "G", tseq("ghi"))],
+    "dead_end_big_drop": [(tseq("bcdef"), tseq("gH") + "G", tseq("yz"))],
 }
 
 
@@ -92,14 +99,17 @@ def full_key(a):
                       a.left_anchor_ambiguous_bases)
 
 
+@pytest.mark.parametrize("drop", [True, False])
 @pytest.mark.parametrize("rev", [False, True])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_tracer_test_vectors(ctx, name, rev):
+def test_tracer_test_vectors(ctx, name, rev, drop):
     parts, pairs, reads, opts = CASES[name]
-    out = run_gpu(ctx, parts, pairs, reads, rev_comp=rev, **opts)
-    # (1) the reference's own expectations where the slice covers them
-    if name in WANT:
-        V.expect(out, WANT[name])
+    out = run_gpu(ctx, parts, pairs, reads, rev_comp=rev, anchor_drop=int(drop), **opts)
+    # (1) the reference's own expectations (the dead-end ones are what the anchor_dropper makes of them)
+    if name in WANT and (drop or not name.startswith("dead_end")):
+        V.expect(out, [] if (rev and name.startswith("dead_end")) else WANT[name])
+    if name.startswith("dead_end") and not drop and not rev:
+        assert len(out) == 1 and out[0].right_anchor_len == 0  # the raw dead end of the tracer
     if name == "only_reference":
         assert [len(a.right_pair_matches) for a in out] == [1, 1, 1, 0, 0, 0, 0]
         assert [len(a.left_pair_matches) for a in out] == [0, 0, 0, 0, 1, 1, 1]
@@ -109,7 +119,9 @@ def test_tracer_test_vectors(ctx, name, rev):
     if name.startswith("dead_end") and rev:
         assert out == []
     # (2) the oracle, field for field
-    want = V.run(parts, pairs, reads, rev_comp=rev, **opts)
+    align_keys = ("min_anchor_drop_overlap",)
+    want = V.run(parts, pairs, reads, rev_comp=rev, drop={k: opts[k] for k in align_keys if k in opts} if drop else None,
+                 **{k: v for k, v in opts.items() if k not in align_keys})
     assert [full_key(a) for a in out] == [full_key(a) for a in want]
 
 
@@ -144,22 +156,65 @@ def test_synthetic_equals_oracle(ctx, seed, G, repeats):
     op, gp = oss.parts(), ss.parts()
     assert all(op[n] == gp[n] for n in bg.PART_NAMES)
     kw = dict(min_overlap=70, max_pair_distance=600, read_ahead_distance=3000, trace_reference_assemblies=1)
-    o_gpu = tracer.TraceOptions(**kw)
     o_cpu = T.Options(**dict(kw, trace_reference_assemblies=True))
     sc = T.Scaffold(parts)
     try:
-        for rev in (False, True):
-            want = T.reversable_trace(g, sc, o_cpu, rev_comp=rev)
+        for rev, drop in ((False, True), (True, True), (False, False), (True, False)):
+            o_gpu = tracer.TraceOptions(anchor_drop=int(drop), **kw)
+            ad = V.dropper(o_cpu) if drop else None
+            want = T.reversable_trace(g, sc, o_cpu, rev_comp=rev, anchor_drop=ad)
             got, st = tracer.push_trace(ss, rm, rmap, parts, rev_comp=rev, options=o_gpu, with_stats=True)
             assert [full_key(a) for a in got] == [full_key(a) for a in want]
             assert len([a for a in got if not a.matches_reference]) > 3 and st["traces"] > G // 10
             assert st["device_rounds"] < 40 * 50  # lock step: rounds follow the longest trace, not the number of traces
             for start in range(0, G, 2000):
-                wc = T.reversable_trace(g, sc, o_cpu, rev_comp=rev, start_offset=start, limit_offset=start + 2000)
+                wc = T.reversable_trace(g, sc, o_cpu, rev_comp=rev, start_offset=start, limit_offset=start + 2000, anchor_drop=ad)
                 gc = tracer.push_trace(ss, rm, rmap, parts, start=start, limit=start + 2000, rev_comp=rev, options=o_gpu)
-                assert [full_key(a) for a in gc] == [full_key(a) for a in wc], (rev, start)
+                assert [full_key(a) for a in gc] == [full_key(a) for a in wc], (rev, drop, start)
     finally:
         rmap.free()
+
+
+def test_pipeline_behind_the_tracers_equals_oracle(ctx):
+    """Both directions of a synthetic scaffold through bg_assemblies_process (sort, ref trim, dedup, align, split)
+    against the oracle's variants_pipeline over the oracle's traces; the planted SNPs come out as 1-base variant
+    sections between reference sections."""
+    G = 8000
+    pairs, ref = synthetic_world(ctx, G, 11)
+    parts = [(0, ref)]
+    ss, rm, rmap = gpu_world(ctx, pairs, [], [ref])
+    all_reads = [r for p in pairs for r in p]
+    seq, offs = O.pack_strings(all_reads)
+    ent = O.Entries.build(seq, offs, "simple")
+    oss = O.Seqset.from_entries(ent)
+    orm = O.Readmap(oss, ent, [tuple(p) for p in pairs], True)
+    codes = np.array([b"ACGT".index(bytes([c])) for c in ref.encode()], np.uint8)
+    g = T.Graph(oss, orm, oss.ref_map_build(codes, np.array([0], np.uint64), np.array([len(ref)], np.uint64)))
+    from oracle import align as A
+    for tra in (0, 1):
+        kw = dict(min_overlap=70, max_pair_distance=600, read_ahead_distance=3000, trace_reference_assemblies=tra)
+        o_gpu = tracer.TraceOptions(**kw)
+        o_cpu = T.Options(**dict(kw, trace_reference_assemblies=bool(tra)))
+        sc = T.Scaffold(parts)
+        want_in, got_in = [], []
+        for rev in (False, True):
+            want_in += T.reversable_trace(g, sc, o_cpu, rev_comp=rev, anchor_drop=V.dropper(o_cpu))
+            got_in += tracer.push_trace(ss, rm, rmap, parts, rev_comp=rev, options=o_gpu)
+        ao = A.AlignOptions(min_overlap=70, read_ahead_distance=3000, trace_reference_assemblies=bool(tra))
+        _, want = A.variants_pipeline(ao, sc, want_in)
+        got = tracer.process_assemblies(got_in, parts, options=o_gpu)
+
+        def key(a):
+            return (a.left_offset, a.right_offset, a.seq, bool(a.matches_reference), a.left_anchor_len, a.right_anchor_len,
+                    sorted(a.left_pair_matches), sorted(a.right_pair_matches), a.score, a.min_overlap, a.trace_steps)
+        assert [key(a) for a in got] == [key(a) for a in want]
+        variants = [a for a in got if not a.matches_reference]
+        assert len(variants) >= 3
+        for a in variants:  # a variant section differs from the reference it replaces
+            assert a.seq != ref[a.left_offset:a.right_offset]
+        for x, y in zip(got, got[1:]):
+            assert x.left_offset <= y.left_offset
+    rmap.free()
 
 
 def test_ref_walk_entries_equals_sequential_walk(ctx):

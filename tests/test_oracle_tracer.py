@@ -31,11 +31,20 @@ def world(pairs, reads=()):
     return T.Graph(ss, rm, ss.ref_map_build(codes, starts, sizes))
 
 
-def run(parts, pairs, reads=(), rev_comp=False, **opts):
+def dropper(o, **align_opts):
+    """The anchor_dropper of oracle/align.py with the tracer's options, as reversable_trace's anchor_drop argument."""
+    from oracle import align as A
+    ao = A.AlignOptions(min_overlap=o.min_overlap, read_ahead_distance=o.read_ahead_distance,
+                        trace_reference_assemblies=bool(o.trace_reference_assemblies), **align_opts)
+    return lambda sc, emit: A.AnchorDropper(ao, sc, emit)
+
+
+def run(parts, pairs, reads=(), rev_comp=False, drop=None, **opts):
+    """drop: None = no anchor_dropper (the raw tracer output); a dict = AlignOptions overrides for the step."""
     g = world(pairs, reads)
     o = T.Options(**dict(dict(min_overlap=20, trace_reference_assemblies=True), **opts))
     sc = T.Scaffold(parts)
-    out = T.reversable_trace(g, sc, o, rev_comp=rev_comp)
+    out = T.reversable_trace(g, sc, o, rev_comp=rev_comp, anchor_drop=None if drop is None else dropper(o, **drop))
     if rev_comp:  # tracer_test.cpp:128-133
         out.reverse()
     for a in out:  # the lambda of tracer_test.cpp:94-113
