@@ -948,6 +948,7 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
   }
   const std::vector<Extent>& run_ext = rev_comp ? rc : ext;
   const double s_chunk = now_seconds() - t_chunk;
+  const double t_drop = now_seconds();
   if (w.o.anchor_drop) {  // anchor_dropper over the scaffold the tracer ran on (reversable_tracer.cpp:124-133)
     ScaffoldView sc;
     for (const Extent& e : run_ext) sc.ext.push_back(ScaffoldView::Ext{e.offset, e.seq.data(), int64_t(e.seq.size())});
@@ -963,6 +964,7 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
     }
     raw = std::move(dropped);
   }
+  const double s_drop = now_seconds() - t_drop;
   std::vector<bg_trace_assembly_rec> counted;
   if (pair_count) {
     PairCounter pc{w, &counted};
@@ -986,8 +988,8 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
   res->a = std::move(counted);
   res->stats = w.stats;
   if (getenv("BG_TRACER_TIMING"))
-    fprintf(stderr, "bg_tracer_trace: %.3f s in all (extents %.3f, chunk %.3f): tables %.3f s, start %.3f s, device rounds %.3f s, host replay %.3f s, teardown %.3f s (%d threads), %llu traces\n",
-            now_seconds() - t_call, s_ext, s_chunk, w.seconds_tables, w.seconds_start, w.seconds_device, w.seconds_host, w.seconds_teardown, g_tracer_threads, (unsigned long long)w.stats.traces);
+    fprintf(stderr, "bg_tracer_trace: %.3f s in all (extents %.3f, chunk %.3f, anchor drop %.3f): tables %.3f s, start %.3f s, device rounds %.3f s, host replay %.3f s, teardown %.3f s (%d threads), %llu traces\n",
+            now_seconds() - t_call, s_ext, s_chunk, s_drop, w.seconds_tables, w.seconds_start, w.seconds_device, w.seconds_host, w.seconds_teardown, g_tracer_threads, (unsigned long long)w.stats.traces);
   // the chunk's tables are not kept between work items
   std::vector<std::pair<int32_t, uint64_t>>().swap(w.position_entries);
   std::vector<std::pair<uint64_t, int32_t>>().swap(w.entry_positions);

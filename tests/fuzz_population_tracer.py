@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 import biograph_amd as bg  # noqa: E402
 from biograph_amd import sharded, synth, tracer  # noqa: E402
 from oracle import oracle as O  # noqa: E402
+from oracle import align as A  # noqa: E402
 from oracle import tracer as T  # noqa: E402
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times the push tracer (bg_push_trace, row f.2 first slice) on reference chunks of a synthetic sample: seqset +
+"""Times the push tracer (bg_push_trace, row f.2) on reference chunks of a synthetic sample: seqset +
 readmap built on the GPU, ref_map over the reference, then --chunks chunks of --chunk-size bases, forward and reverse.
 Prints one JSON object (traces, device rounds, assemblies, planted SNPs recovered among the non-reference assemblies)."""
 import argparse
@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20261002)
     ap.add_argument("--chunk-size", type=int, default=1_000_000)
     ap.add_argument("--chunks", type=int, default=1)
+    ap.add_argument("--no-anchor-drop", action="store_true", help="leave the anchor_dropper step out (raw dead ends)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -40,7 +41,7 @@ def main():
     t0 = time.perf_counter()
     rmap = tracer.reference_ref_map(ss, [ref])
     t_rmap = time.perf_counter() - t0
-    opt = tracer.TraceOptions(min_overlap=int(0.7 * args.read_len))
+    opt = tracer.TraceOptions(min_overlap=int(0.7 * args.read_len), anchor_drop=0 if args.no_anchor_drop else 1)
     t0 = time.perf_counter()
     session = tracer.PushTracer(ss, rm, rmap, opt)
     t_open = time.perf_counter() - t0
