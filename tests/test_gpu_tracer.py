@@ -10,6 +10,7 @@ import biograph_amd as bg
 from biograph_amd import synth, tracer
 from oracle import oracle as O
 from oracle import tracer as T
+from tests import test_oracle_align as VA
 from tests import test_oracle_tracer as V
 
 pytestmark = pytest.mark.gpu
@@ -173,6 +174,28 @@ def test_synthetic_equals_oracle(ctx, seed, G, repeats):
                 assert [full_key(a) for a in gc] == [full_key(a) for a in wc], (rev, drop, start)
     finally:
         rmap.free()
+
+
+@pytest.mark.parametrize("rev", [False, True])
+@pytest.mark.parametrize("name", sorted(VA.PIPE_CASES))
+def test_pipeline_test_vectors(ctx, name, rev):
+    """modules/variants/pipeline_test.cpp:158-213 end to end through the library: bg_push_trace (one direction, as the
+    test's skip_push_trace_* does) -> bg_assemblies_process(sort, ref trim, dedup, align, split); the expectations are
+    the variant sections.  (The test's ploid_limiter, not a production step, is left out: see tests/test_oracle_align.py.)"""
+    reads, want = VA.PIPE_CASES[name]
+    ss, rm, rmap = gpu_world(ctx, [], reads, VA.PIPE_REF)
+    o = tracer.TraceOptions(min_overlap=20, trace_reference_assemblies=1)
+    try:
+        traced = tracer.push_trace(ss, rm, rmap, VA.PIPE_PARTS, rev_comp=rev, options=o)
+    finally:
+        rmap.free()
+    out = tracer.process_assemblies(traced, VA.PIPE_PARTS, options=o)
+    got = [(a.left_offset, a.seq, a.right_offset) for a in out if not a.matches_reference]
+    assert sorted(got) == sorted(want)
+    sc = T.Scaffold(VA.PIPE_PARTS)
+    for a in out:
+        if a.matches_reference:
+            assert sc.sub(a.left_offset, a.right_offset - a.left_offset) == a.seq
 
 
 def test_pipeline_behind_the_tracers_equals_oracle(ctx):

@@ -282,3 +282,54 @@ def test_variants_pipeline_merges_the_two_directions():
     deduped, out = A.variants_pipeline(A.AlignOptions(), T.Scaffold([(0, ref)]), [r, refa, f])
     assert [(a.left_offset, a.right_offset, a.seq, a.left_pair_matches) for a in deduped] == [(30, 31, "T", [7])]
     assert [(a.left_offset, a.right_offset, a.matches_reference) for a in out] == [(30, 31, False)]
+
+
+# ---- end to end: the vectors of modules/variants/pipeline_test.cpp:158-213 --------------------------------------
+# trace_ref (one direction) -> sorter -> ref_trimmer -> deduper -> aligner -> [ploid_limiter] -> align_splitter.
+# The ploid_limiter of that test (max_ploids = 2; not a step of the production pipeline, pipeline.cpp:92-105) is left
+# out: no case here has more than two alleles at a site, and the expectations are about the variant sections only.
+import numpy as np  # noqa: E402
+
+PIPE_REF = [tseq("abc"), tseq("defg") + "G" + tseq("hijkl") + "GG" + tseq("mnopqrstuvwxyz") + tseq("ABCD") + "A" +
+            tseq("EFGH") + "T" + tseq("EFGHIJKL")]
+PIPE_PARTS = [(0, PIPE_REF[0]), (30 + 100, PIPE_REF[1])]
+DEF = 130
+PIPE_CASES = {
+    "ref_only": ([tseq("mnopq"), tseq("opqrst"), tseq("rstuv"), tseq("uvwxy")], []),
+    "homozygous_snp": ([tseq("defg"), tseq("fg") + "C" + tseq("hi"), tseq("hijk")], [(DEF + 40, "C", DEF + 41)]),
+    "hetrozygous_snp": ([tseq("defg"), tseq("fg") + "A" + tseq("hi"), tseq("fg") + "G" + tseq("hi"), tseq("hijk")],
+                        [(DEF + 40, "A", DEF + 41)]),
+    "compound_hetrozygous_snp": ([tseq("defg"), tseq("fg") + "A" + tseq("hi"), tseq("fg") + "T" + tseq("hi"), tseq("hijk")],
+                                 [(DEF + 40, "A", DEF + 41), (DEF + 40, "T", DEF + 41)]),
+    "interscaffold_delete": ([tseq("abc"), tseq("bcd"), tseq("cde"), tseq("def"), tseq("efg")], [(30, "", DEF)]),
+    "interscaffold_insert": ([tseq("abc"), tseq("bc") + "C" + tseq("d"), tseq("c") + "C" + tseq("de"), tseq("def"), tseq("efg")],
+                             [(30, "C", DEF)]),
+}
+
+
+def pipe_world(reads, reference=PIPE_REF):
+    seq, offs = O.pack_strings(list(reads))
+    ent = O.Entries.build(seq, offs, "simple")
+    ss = O.Seqset.from_entries(ent)
+    rm = O.Readmap(ss, ent, [(r,) for r in reads], True)
+    codes = np.array([b"ACGT".index(bytes([c])) for c in "".join(reference).encode()], np.uint8)
+    starts = np.cumsum([0] + [len(s) for s in reference[:-1]]).astype(np.uint64)
+    sizes = np.array([len(s) for s in reference], np.uint64)
+    return T.Graph(ss, rm, ss.ref_map_build(codes, starts, sizes))
+
+
+@pytest.mark.parametrize("rev", [False, True])
+@pytest.mark.parametrize("name", sorted(PIPE_CASES))
+def test_pipeline_test_vectors(name, rev):
+    reads, want = PIPE_CASES[name]
+    g = pipe_world(reads)
+    o = T.Options(min_overlap=20, trace_reference_assemblies=True)
+    ao = A.AlignOptions(min_overlap=20, trace_reference_assemblies=True)
+    sc = T.Scaffold(PIPE_PARTS)
+    traced_ = T.reversable_trace(g, sc, o, rev_comp=rev, anchor_drop=lambda s_, emit: A.AnchorDropper(ao, s_, emit))
+    _, out = A.variants_pipeline(ao, sc, traced_)
+    got = [(a.left_offset, a.seq, a.right_offset) for a in out if not a.matches_reference]
+    assert sorted(got) == sorted(want)
+    for a in out:
+        if a.matches_reference:
+            assert sc.sub(a.left_offset, a.right_offset - a.left_offset) == a.seq
