@@ -7,6 +7,9 @@
 //   deduper          modules/variants/dedup.cpp:7-144      pipeline.cpp:53
 //   aligner          modules/variants/align.cpp:11-385     add_standard_variants_pipeline, pipeline.cpp:92-95
 //   align_splitter   modules/variants/align.cpp:387-460
+//   normalizer       modules/variants/normalize.cpp:7-126  pipeline.cpp:96
+//   exact_deduper    modules/variants/dedup.cpp:146-216    pipeline.cpp:97
+//   vcf_padder       modules/variants/normalize.cpp:128-162 pipeline.cpp:98
 //
 // These are per-assembly string work on a few thousand assemblies per megabase, orders of magnitude below the
 // tracer's device walks; they run on the host, single threaded, in the reference's order.  Where the reference's
@@ -429,6 +432,109 @@ class Deduper {
   std::multimap<int64_t, bg_trace_assembly_rec> queued_;
 };
 
+// ---- normalizer (normalize.cpp:7-126) -----------------------------------------------------------------------------------
+class Normalizer : public SortedOutput {
+ public:
+  Normalizer(const ScaffoldView& sc, AssemblySink out) : SortedOutput(std::move(out)), sc_(sc) {}
+  void add(bg_trace_assembly_rec&& a) {
+    if (a.matches_reference) { sort_and_output(std::move(a)); return; }
+    a.aligned_variants.clear();
+    for (;;) {
+      // split_extent_at(a.left_offset) (scaffold.cpp:189-203)
+      const char *left_p = nullptr, *after_p = nullptr;
+      int64_t left_n = 0, after_n = 0;
+      for (const auto& e : sc_.ext) {
+        if (e.offset > a.left_offset) break;
+        if (e.offset + e.n < a.left_offset) continue;
+        left_p = e.p;
+        left_n = a.left_offset - e.offset;
+        after_p = e.p + left_n;
+        after_n = e.n - left_n;
+        break;
+      }
+      advance_to(a.left_offset - left_n - 1);
+      const int64_t span = a.right_offset - a.left_offset;
+      if (left_n == 0 || after_n < span) break;
+      check(span != 0 || !a.seq.empty(), "normalizer: empty variant");
+      const char left_base = left_p[left_n - 1];
+      if (span != 0 && !a.seq.empty() && after_p[span - 1] != a.seq.back()) break;
+      const char right_base = span != 0 ? after_p[span - 1] : a.seq.back();
+      if (left_base != right_base) break;
+      --a.left_offset;
+      --a.right_offset;
+      if (!a.seq.empty()) {
+        a.seq.pop_back();
+        a.seq.insert(a.seq.begin(), left_base);
+      }
+    }
+    sort_and_output(std::move(a));
+  }
+
+ private:
+  void advance_to(int64_t new_offset) {
+    if (new_offset < cur_offset_) return;
+    cur_offset_ = new_offset;
+    flush_sorted_to(new_offset);
+  }
+  const ScaffoldView& sc_;
+  int64_t cur_offset_ = 0;
+};
+
+// ---- exact_deduper (dedup.cpp:146-216) ------------------------------------------------------------------------------------
+class ExactDeduper {
+ public:
+  explicit ExactDeduper(AssemblySink out) : out_(std::move(out)) {}
+  void add(bg_trace_assembly_rec&& a) {
+    advance_to(a.left_offset);
+    for (auto& kv : queued_) {
+      bg_trace_assembly_rec& q = kv.second;
+      if (a.left_offset != q.left_offset || a.right_offset != q.right_offset || a.seq != q.seq || a.matches_reference != q.matches_reference) continue;
+      for (auto m : {&bg_trace_assembly_rec::left_pair_matches, &bg_trace_assembly_rec::right_pair_matches}) {
+        auto& pm = q.*m;
+        pm.insert(pm.end(), (a.*m).begin(), (a.*m).end());
+        std::sort(pm.begin(), pm.end());
+        pm.erase(std::unique(pm.begin(), pm.end()), pm.end());
+      }
+      return;
+    }
+    const int64_t lo = a.left_offset;
+    queued_.emplace(lo, std::move(a));
+  }
+  void flush() {
+    advance_to(0x7fffffff);
+    check(queued_.empty(), "exact_deduper: assemblies left after the flush");
+  }
+
+ private:
+  void advance_to(int64_t offset) {
+    while (!queued_.empty() && queued_.begin()->first < offset) {
+      out_(std::move(queued_.begin()->second));
+      queued_.erase(queued_.begin());
+    }
+  }
+  AssemblySink out_;
+  std::multimap<int64_t, bg_trace_assembly_rec> queued_;
+};
+
+// ---- vcf_padder (normalize.cpp:128-162) -----------------------------------------------------------------------------------
+class VcfPadder : public SortedOutput {
+ public:
+  VcfPadder(const ScaffoldView& sc, AssemblySink out) : SortedOutput(std::move(out)), sc_(sc) {}
+  void add(bg_trace_assembly_rec&& a) {
+    if (a.left_offset > 3) flush_sorted_to(a.left_offset - 2);
+    if ((a.left_offset < a.right_offset && !a.seq.empty()) || a.left_offset <= 0) { sort_and_output(std::move(a)); return; }
+    const ScaffoldView s = sc_.sub(a.left_offset - 1, 1);
+    if (!(s.ext.size() == 1 && s.ext[0].offset == 0)) { sort_and_output(std::move(a)); return; }  // is_simple
+    check(s.ext[0].n == 1, "vcf_padder: reference base missing");
+    --a.left_offset;
+    a.seq.insert(a.seq.begin(), s.ext[0].p[0]);
+    sort_and_output(std::move(a));
+  }
+
+ private:
+  const ScaffoldView& sc_;
+};
+
 }  // namespace
 
 // ---- scaffold.cpp -----------------------------------------------------------------------------------------------------
@@ -694,6 +800,12 @@ extern "C" int bg_assemblies_process(const bg_trace_result* const* in, uint32_t 
   try {
     // the chain, built back to front like assemble_pipeline::make_pipeline (pipeline.cpp:81-90)
     AssemblySink sink = [&](bg_trace_assembly_rec&& a) { res->a.push_back(std::move(a)); };
+    std::unique_ptr<VcfPadder> pad;
+    std::unique_ptr<ExactDeduper> xdedup;
+    std::unique_ptr<Normalizer> norm;
+    if (steps & BG_STEP_VCF_PAD) { pad.reset(new VcfPadder(sc, sink)); sink = [&](bg_trace_assembly_rec&& a) { pad->add(std::move(a)); }; }
+    if (steps & BG_STEP_EXACT_DEDUP) { xdedup.reset(new ExactDeduper(sink)); sink = [&](bg_trace_assembly_rec&& a) { xdedup->add(std::move(a)); }; }
+    if (steps & BG_STEP_NORMALIZE) { norm.reset(new Normalizer(sc, sink)); sink = [&](bg_trace_assembly_rec&& a) { norm->add(std::move(a)); }; }
     std::unique_ptr<AlignSplitter> split;
     std::unique_ptr<Aligner> align;
     std::unique_ptr<Deduper> dedup;
@@ -720,6 +832,9 @@ extern "C" int bg_assemblies_process(const bg_trace_result* const* in, uint32_t 
     if (dedup) dedup->flush();
     if (align) align->flush();
     if (split) split->flush();
+    if (norm) norm->flush();
+    if (xdedup) xdedup->flush();
+    if (pad) pad->flush();
   } catch (const CheckFailed& f) {
     set_error("bg_assemblies_process: %s (the reference aborts on this input)", f.what.c_str());
     return BG_EINVAL;

@@ -134,13 +134,16 @@ def _u32_array(xs):
 
 
 STEP_ANCHOR_DROP, STEP_SORT, STEP_TRIM_REF, STEP_DEDUP, STEP_ALIGN, STEP_SPLIT = 1, 2, 4, 8, 16, 32
-STEP_PIPELINE = STEP_SORT | STEP_TRIM_REF | STEP_DEDUP | STEP_ALIGN | STEP_SPLIT
+STEP_NORMALIZE, STEP_EXACT_DEDUP, STEP_VCF_PAD = 64, 128, 256
+STEP_THROUGH_SPLIT = STEP_SORT | STEP_TRIM_REF | STEP_DEDUP | STEP_ALIGN | STEP_SPLIT
+STEP_PIPELINE = STEP_THROUGH_SPLIT | STEP_NORMALIZE | STEP_EXACT_DEDUP | STEP_VCF_PAD  # pipeline.cpp:40-57,92-98
 
 
 def process_assemblies(assemblies, extents, end_pos=None, options=None, steps=STEP_PIPELINE):
     """bg_assemblies_process: the assemblies of one scaffold's work items (TraceAssembly objects, forward coordinates)
     through the chosen steps of the pipeline behind the tracers, in the pipeline's order: anchor_dropper, sorter,
-    ref_trimmer, deduper, aligner, align_splitter.  -> [TraceAssembly] as they leave the last step."""
+    ref_trimmer, deduper, aligner, align_splitter, normalizer, exact_deduper, vcf_padder.  -> [TraceAssembly] as they
+    leave the last step."""
     L = capi.lib()
     src = C.c_void_p()
     capi.check(L.bg_trace_result_new(C.byref(src)))

@@ -456,6 +456,9 @@ void bg_trace_result_free(bg_trace_result* r);
  *   BG_STEP_DEDUP        deduper (dedup.cpp:7-144): merges assemblies with the same variant part
  *   BG_STEP_ALIGN        aligner (align.cpp:11-385): fills each assembly's aligned variants (bg_trace_result_var)
  *   BG_STEP_SPLIT        align_splitter (align.cpp:387-460): cuts into reference and variant sections
+ *   BG_STEP_NORMALIZE    normalizer (normalize.cpp:7-126): shifts a variant left through repeats
+ *   BG_STEP_EXACT_DEDUP  exact_deduper (dedup.cpp:146-216): one assembly per (left, right, seq, is-reference)
+ *   BG_STEP_VCF_PAD      vcf_padder (normalize.cpp:128-162): inserts and deletions take the reference base to their left
  * Steps other than SORT need their input sorted by left offset, as the reference's do; a condition the reference
  * CHECK-aborts on (anchors that do not match the reference, unsorted input ...) fails the call with BG_EINVAL.
  * Extents as for bg_push_trace.  Host only: no bg_ctx, no device work. */
@@ -465,8 +468,13 @@ void bg_trace_result_free(bg_trace_result* r);
 #define BG_STEP_DEDUP 8u
 #define BG_STEP_ALIGN 16u
 #define BG_STEP_SPLIT 32u
-#define BG_STEP_ALL 63u
-#define BG_STEP_PIPELINE (BG_STEP_SORT | BG_STEP_TRIM_REF | BG_STEP_DEDUP | BG_STEP_ALIGN | BG_STEP_SPLIT)
+#define BG_STEP_NORMALIZE 64u
+#define BG_STEP_EXACT_DEDUP 128u
+#define BG_STEP_VCF_PAD 256u
+#define BG_STEP_ALL 511u
+/* what pipeline.cpp:40-57,92-98 runs between the tracers and the coverage / genotype steps */
+#define BG_STEP_PIPELINE (BG_STEP_SORT | BG_STEP_TRIM_REF | BG_STEP_DEDUP | BG_STEP_ALIGN | BG_STEP_SPLIT | \
+                          BG_STEP_NORMALIZE | BG_STEP_EXACT_DEDUP | BG_STEP_VCF_PAD)
 int bg_assemblies_process(const bg_trace_result* const* in, uint32_t n_in, uint64_t n_extents, const int64_t* ext_offset,
                           const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos,
                           const bg_trace_options* options /* NULL = defaults */, uint32_t steps, bg_trace_result** out);

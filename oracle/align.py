@@ -8,6 +8,9 @@ that follow the push tracer in the reference's assembly pipeline --
   sorter           modules/variants/sort.cpp:6-13           (head of the serial pipeline, pipeline.cpp:48)
   ref_trimmer      modules/variants/trim_ref.cpp:10-113     (pipeline.cpp:52; fully anchored assemblies only)
   deduper          modules/variants/dedup.cpp:7-144         (pipeline.cpp:53)
+  normalizer       modules/variants/normalize.cpp:9-118     (pipeline.cpp:96)  } no reference test holds vectors for
+  exact_deduper    modules/variants/dedup.cpp:146-216       (pipeline.cpp:97)  } these three: PARITY UNPINNED for them
+  vcf_padder       modules/variants/normalize.cpp:128-162   (pipeline.cpp:98)  } (product == this restatement by fuzz)
   the sorted output queue every one of them emits through (assemble.cpp:291-346, canon order :1029-1085)
   scaffold helpers modules/variants/scaffold.cpp:39-203
 
@@ -572,12 +575,102 @@ class Deduper:  # dedup.cpp:7-144
         check(not self.queued, "deduper keeps assemblies after its flush")
 
 
-def variants_pipeline(options, scaffold, assemblies):
-    """The serial pipeline of pipeline.cpp:40-57 + :92-95 up to the align_splitter, fed with everything the tracers of
-    one scaffold produced (both directions): sorter(canon) -> ref_trimmer -> deduper -> aligner -> align_splitter.
-    -> (deduped, split): the assemblies entering the aligner, and leaving the splitter."""
+class Normalizer(SortedOutput):  # normalize.cpp:7-126: shift a variant left while the base it drops equals the one it gains
+    def __init__(self, scaffold, emit):
+        SortedOutput.__init__(self, emit)
+        self.sc = scaffold
+        self.cur_offset = 0  # normalize.h:24
+
+    def _advance_to(self, new_offset):  # :120-126
+        if new_offset < self.cur_offset:
+            return
+        self.cur_offset = new_offset
+        self.flush_sorted_to(new_offset)
+
+    def add(self, a):
+        if a.matches_reference:
+            self.sort_and_output(a)
+            return
+        a.aligned_variants = []
+        while True:
+            left_ref, after = split_extent_at(self.sc, a.left_offset)
+            self._advance_to(a.left_offset - len(left_ref) - 1)
+            if not left_ref or len(after) < a.right_offset - a.left_offset:
+                break
+            asm_ref = after[:a.right_offset - a.left_offset]
+            left_base = left_ref[-1]
+            check(asm_ref or a.seq, "normalizer: empty variant")
+            if asm_ref and a.seq and asm_ref[-1] != a.seq[-1]:
+                break
+            right_base = asm_ref[-1] if asm_ref else a.seq[-1]
+            if left_base != right_base:
+                break
+            a.left_offset -= 1
+            a.right_offset -= 1
+            if a.seq:
+                a.seq = left_base + a.seq[:-1]
+        self.sort_and_output(a)
+
+
+class ExactDeduper:  # dedup.cpp:146-216
+    def __init__(self, emit):
+        self.emit = emit
+        self.queued = []  # multimap<left_offset, assembly>
+
+    def _advance_to(self, offset):
+        while self.queued and self.queued[0][0] < offset:
+            self.emit(self.queued.pop(0)[1])
+
+    def add(self, a):
+        self._advance_to(a.left_offset)
+        for _, q in self.queued:
+            if (a.left_offset, a.right_offset, a.seq, a.matches_reference) == (q.left_offset, q.right_offset, q.seq, q.matches_reference):
+                q.left_pair_matches = sorted(set(q.left_pair_matches) | set(a.left_pair_matches))
+                q.right_pair_matches = sorted(set(q.right_pair_matches) | set(a.right_pair_matches))
+                return
+        i = len(self.queued)
+        while i > 0 and self.queued[i - 1][0] > a.left_offset:
+            i -= 1
+        self.queued.insert(i, (a.left_offset, a))
+
+    def flush(self):
+        self._advance_to(INT_MAX)
+        check(not self.queued, "exact_deduper keeps assemblies after its flush")
+
+
+class VcfPadder(SortedOutput):  # normalize.cpp:128-162: empty seq or empty ref span gets the reference base to its left
+    def __init__(self, scaffold, emit):
+        SortedOutput.__init__(self, emit)
+        self.sc = scaffold
+
+    def add(self, a):
+        if a.left_offset > 3:
+            self.flush_sorted_to(a.left_offset - 2)
+        if (a.left_offset < a.right_offset and a.seq) or a.left_offset <= 0:
+            self.sort_and_output(a)
+            return
+        s = subscaffold(self.sc, a.left_offset - 1, 1)
+        if not is_simple(s):
+            self.sort_and_output(a)
+            return
+        a.left_offset -= 1
+        a.seq = s.extents[0][1] + a.seq
+        self.sort_and_output(a)
+
+
+def variants_pipeline(options, scaffold, assemblies, through_vcf_pad=False):
+    """The serial pipeline of pipeline.cpp:40-57 + :92-98, fed with everything the tracers of one scaffold produced (both
+    directions): sorter(canon) -> ref_trimmer -> deduper -> aligner -> align_splitter [-> normalizer -> exact_deduper ->
+    vcf_padder].  -> (deduped, out): the assemblies entering the aligner, and leaving the last step."""
     deduped, out = [], []
-    split = AlignSplitter(out.append)
+    tail = []
+    sink = out.append
+    if through_vcf_pad:  # pipeline.cpp:96-98: normalizer -> exact_deduper -> vcf_padder
+        pad = VcfPadder(scaffold, sink)
+        xd = ExactDeduper(pad.add)
+        norm = Normalizer(scaffold, xd.add)
+        sink, tail = norm.add, [norm.flush, xd.flush, pad.flush]
+    split = AlignSplitter(sink)
     al = Aligner(options, scaffold, split.add)
 
     def save(a):
@@ -592,6 +685,8 @@ def variants_pipeline(options, scaffold, assemblies):
     dd.flush()
     al.flush()
     split.flush()
+    for f in tail:
+        f()
     return deduped, out
 
 

@@ -1,4 +1,5 @@
-"""csrc/align.cpp (bg_assemblies_process: anchor_dropper, sorter, ref_trimmer, deduper, aligner, align_splitter)
+"""csrc/align.cpp (bg_assemblies_process: anchor_dropper, sorter, ref_trimmer, deduper, aligner, align_splitter,
+normalizer, exact_deduper, vcf_padder)
 against the reference's own vectors -- modules/variants/align_test.cpp:59-375, trim_ref_test.cpp:24-112,
 dedup_test.cpp:24-131 -- and, on random assemblies, against the oracle's restatement (oracle/align.py).
 Host-only entry points: runs without a GPU."""
@@ -246,6 +247,15 @@ def oracle_steps(sc, asms, kw, steps):
     out = []
     chain = out.append
     flush = []
+    if steps & BT.STEP_VCF_PAD:
+        pad = A.VcfPadder(sc, chain)
+        chain, flush = pad.add, [pad.flush] + flush
+    if steps & BT.STEP_EXACT_DEDUP:
+        xd = A.ExactDeduper(chain)
+        chain, flush = xd.add, [xd.flush] + flush
+    if steps & BT.STEP_NORMALIZE:
+        nm = A.Normalizer(sc, chain)
+        chain, flush = nm.add, [nm.flush] + flush
     if steps & BT.STEP_SPLIT:
         sp = A.AlignSplitter(chain)
         chain, flush = sp.add, [sp.flush] + flush
@@ -265,7 +275,19 @@ def oracle_steps(sc, asms, kw, steps):
     return out
 
 
-STEP_SETS = [BT.STEP_ANCHOR_DROP, DROP_ALIGN, CHAIN, BT.STEP_ANCHOR_DROP | BT.STEP_PIPELINE,
+def test_normalizer_padder_exact_deduper_hand_cases():
+    ref = "ACGTTTTTGCA"
+    out = run([(0, ref)], [asm(7, 8, "", 0, 0), asm(8, 8, "T", 0, 0), asm(9, 10, "A", 0, 0)], BT.STEP_NORMALIZE)
+    assert sorted((a.left_offset, a.right_offset, a.seq) for a in out) == [(3, 3, "T"), (3, 4, ""), (9, 10, "A")]
+    out = run([(5, ref)], [asm(5, 5, "G", 0, 0), asm(8, 8, "T", 0, 0), asm(8, 9, "", 0, 0), asm(9, 10, "A", 0, 0)], BT.STEP_VCF_PAD)
+    assert [(a.left_offset, a.right_offset, a.seq) for a in out] == [(5, 5, "G"), (7, 9, "G"), (7, 8, "GT"), (9, 10, "A")]
+    a, b = asm(3, 4, "G", 0, 0, left_pair_matches=[1, 5]), asm(3, 4, "G", 0, 0, left_pair_matches=[2, 5])
+    out = run([(0, ref)], [a, b, asm(3, 4, "T", 0, 0), asm(4, 5, "G", 0, 0)], BT.STEP_EXACT_DEDUP)
+    assert [(x.left_offset, x.seq, x.left_pair_matches) for x in out] == [(3, "G", [1, 2, 5]), (3, "T", []), (4, "G", [])]
+
+
+STEP_SETS = [BT.STEP_ANCHOR_DROP, DROP_ALIGN, CHAIN, BT.STEP_ANCHOR_DROP | BT.STEP_PIPELINE, BT.STEP_ANCHOR_DROP | BT.STEP_THROUGH_SPLIT,
+             CHAIN | BT.STEP_NORMALIZE, CHAIN | BT.STEP_NORMALIZE | BT.STEP_EXACT_DEDUP,
              BT.STEP_ANCHOR_DROP | BT.STEP_SORT | BT.STEP_TRIM_REF | BT.STEP_DEDUP,
              BT.STEP_ANCHOR_DROP | BT.STEP_SORT | BT.STEP_TRIM_REF | BT.STEP_DEDUP | BT.STEP_ALIGN]
 

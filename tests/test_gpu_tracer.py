@@ -189,7 +189,7 @@ def test_pipeline_test_vectors(ctx, name, rev):
         traced = tracer.push_trace(ss, rm, rmap, VA.PIPE_PARTS, rev_comp=rev, options=o)
     finally:
         rmap.free()
-    out = tracer.process_assemblies(traced, VA.PIPE_PARTS, options=o)
+    out = tracer.process_assemblies(traced, VA.PIPE_PARTS, options=o, steps=tracer.STEP_THROUGH_SPLIT)
     got = [(a.left_offset, a.seq, a.right_offset) for a in out if not a.matches_reference]
     assert sorted(got) == sorted(want)
     sc = T.Scaffold(VA.PIPE_PARTS)
@@ -224,17 +224,20 @@ def test_pipeline_behind_the_tracers_equals_oracle(ctx):
             want_in += T.reversable_trace(g, sc, o_cpu, rev_comp=rev, anchor_drop=V.dropper(o_cpu))
             got_in += tracer.push_trace(ss, rm, rmap, parts, rev_comp=rev, options=o_gpu)
         ao = A.AlignOptions(min_overlap=70, read_ahead_distance=3000, trace_reference_assemblies=bool(tra))
-        _, want = A.variants_pipeline(ao, sc, want_in)
+        _, want = A.variants_pipeline(ao, sc, want_in, through_vcf_pad=True)
         got = tracer.process_assemblies(got_in, parts, options=o_gpu)
+        _, want_split = A.variants_pipeline(ao, sc, want_in)
+        got_split = tracer.process_assemblies(got_in, parts, options=o_gpu, steps=tracer.STEP_THROUGH_SPLIT)
 
         def key(a):
             return (a.left_offset, a.right_offset, a.seq, bool(a.matches_reference), a.left_anchor_len, a.right_anchor_len,
                     sorted(a.left_pair_matches), sorted(a.right_pair_matches), a.score, a.min_overlap, a.trace_steps)
         assert [key(a) for a in got] == [key(a) for a in want]
+        assert [key(a) for a in got_split] == [key(a) for a in want_split]
         variants = [a for a in got if not a.matches_reference]
         assert len(variants) >= 3
-        for a in variants:  # a variant section differs from the reference it replaces
-            assert a.seq != ref[a.left_offset:a.right_offset]
+        for a in variants:  # a variant differs from the reference it replaces, and (VCF) neither side is empty
+            assert a.seq != ref[a.left_offset:a.right_offset] and a.seq and a.right_offset > a.left_offset
         for x, y in zip(got, got[1:]):
             assert x.left_offset <= y.left_offset
     rmap.free()

@@ -333,3 +333,35 @@ def test_pipeline_test_vectors(name, rev):
     for a in out:
         if a.matches_reference:
             assert sc.sub(a.left_offset, a.right_offset - a.left_offset) == a.seq
+
+
+# ---- normalizer / exact_deduper / vcf_padder: no reference vectors exist; hand cases from the code's own rules ----
+def test_normalizer_shifts_left_in_repeats():
+    ref = "ACGTTTTTGCA"
+    out = []
+    n = A.Normalizer(T.Scaffold([(0, ref)]), out.append)
+    n.add(asm(8, 8, "T", 0, 0))      # insert of a T after the run of T's: slides to the run's start
+    n.add(asm(7, 8, "", 0, 0))       # deletion of the last T of the run: slides to the first
+    n.add(asm(9, 10, "A", 0, 0))     # SNP C->A: bases differ, stays
+    n.flush()
+    assert sorted((a.left_offset, a.right_offset, a.seq) for a in out) == [(3, 3, "T"), (3, 4, ""), (9, 10, "A")]
+
+
+def test_vcf_padder_and_exact_deduper():
+    ref = "ACGTTTTTGCA"
+    out = []
+    p = A.VcfPadder(T.Scaffold([(5, ref)]), out.append)
+    for a in (asm(5, 5, "G", 0, 0), asm(8, 8, "T", 0, 0), asm(8, 9, "", 0, 0), asm(9, 10, "A", 0, 0)):
+        p.add(a)
+    p.flush()
+    # nothing to the left of the extent's first base to pad with; the others take the base at left - 1 (scaffold
+    # position 7 is ref[2] = G); equal left offsets leave in canon order: the longer reference span first
+    assert [(a.left_offset, a.right_offset, a.seq) for a in out] == [(5, 5, "G"), (7, 9, "G"), (7, 8, "GT"), (9, 10, "A")]
+    out = []
+    d = A.ExactDeduper(out.append)
+    a, b = asm(3, 4, "G", 0, 0), asm(3, 4, "G", 0, 0)
+    a.left_pair_matches, b.left_pair_matches = [1, 5], [2, 5]
+    for x in (a, b, asm(3, 4, "T", 0, 0), asm(4, 5, "G", 0, 0)):
+        d.add(x)
+    d.flush()
+    assert [(x.left_offset, x.seq, x.left_pair_matches) for x in out] == [(3, "G", [1, 2, 5]), (3, "T", []), (4, "G", [])]
