@@ -198,6 +198,26 @@ def test_pipeline_test_vectors(ctx, name, rev):
             assert sc.sub(a.left_offset, a.right_offset - a.left_offset) == a.seq
 
 
+def test_father_vcf_records_from_the_golden_biograph(ctx, golden_dir):
+    """The library's whole chain on the reference's own sample (golden father_lambda seqset + readmap as written by the
+    reference): bg_push_trace both directions (tracer, anchor_dropper, pair_counter) -> bg_assemblies_process(sort ...
+    vcf_padder), min_overlap = 0.7 x read length as the discovery command sets it: POS, REF, ALT and OV of every
+    record of lambdaToyData/benchmark/father.vcf, and nothing else."""
+    ss = ctx.open_seqset(golden_dir + "/father_lambda/seqset")
+    rm = ctx.open_readmap(golden_dir + "/father_lambda/readmap")
+    ref = "".join(x.strip() for x in open(golden_dir + "/father_lambda/reference.fasta") if not x.startswith(">")).upper()
+    rmap = tracer.reference_ref_map(ss, [ref])
+    o = tracer.TraceOptions(min_overlap=int(0.7 * 150))
+    try:
+        traced = []
+        for rev in (False, True):
+            traced += tracer.push_trace(ss, rm, rmap, [(0, ref)], rev_comp=rev, options=o)
+    finally:
+        rmap.free()
+    out = tracer.process_assemblies(traced, [(0, ref)], options=o)
+    assert VA.vcf_columns(out, ref) == VA.father_vcf_records(golden_dir)
+
+
 def test_pipeline_behind_the_tracers_equals_oracle(ctx):
     """Both directions of a synthetic scaffold through bg_assemblies_process (sort, ref trim, dedup, align, split)
     against the oracle's variants_pipeline over the oracle's traces; the planted SNPs come out as 1-base variant

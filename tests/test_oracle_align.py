@@ -365,3 +365,44 @@ def test_vcf_padder_and_exact_deduper():
         d.add(x)
     d.flush()
     assert [(x.left_offset, x.seq, x.left_pair_matches) for x in out] == [(3, "G", [1, 2, 5]), (3, "T", []), (4, "G", [])]
+
+
+# ---- the whole chain on the reference's own sample: lambdaToyData/benchmark/father.vcf -----------------------------
+def father_vcf_records(golden_dir):
+    """(POS, REF, ALT, OV) of the 8 records of datasets/lambdaToyData/benchmark/father.vcf (a fixture: the output of
+    the reference's discovery on father_lambda.bg; columns of ploidless_vcf_export.cpp:77-85,150)."""
+    out = []
+    for line in open(golden_dir + "/father_lambda/father.vcf"):
+        if line.startswith("#"):
+            continue
+        f = line.rstrip("\n").split("\t")
+        assert f[8] == "GT:PG:GQ:PI:OV:DP:AD:PDP:PAD"
+        out.append((int(f[1]), f[3], f[4], int(f[9].split(":")[4])))
+    assert len(out) == 8
+    return out
+
+
+def vcf_columns(out, ref):
+    """POS / REF / ALT / OV as ploidless_vcf_export.cpp:12-43,77-85,150 derives them from a padded variant section."""
+    return [(a.left_offset + 1, ref[a.left_offset:a.right_offset], a.seq, a.min_overlap) for a in out if not a.matches_reference]
+
+
+def test_father_vcf_records_from_the_golden_biograph(golden_dir):
+    """tracer -> anchor_dropper -> pair_counter (both directions) -> sorter -> ref_trimmer -> deduper -> aligner ->
+    align_splitter -> normalizer -> exact_deduper -> vcf_padder over the golden father_lambda seqset + readmap, with the
+    discovery command's option (min_overlap = 0.7 x read length, biograph_variants.cpp:674-678): position, REF, ALT and
+    the OV (minimum overlap) column of every record of father.vcf, and nothing else."""
+    d = O.load_seqset_zip(golden_dir + "/father_lambda/seqset")
+    g = O.decode_readmap(golden_dir + "/father_lambda/readmap", d)
+    oss = O.Seqset.from_arrays(d["sizes"], d["shared"], d["bits"])
+    orm = O.Readmap.from_arrays(d["n"], g["entry"], g["read_len"], g["mate_loop_ptr"], g["is_forward"], 150)
+    ref = "".join(x.strip() for x in open(golden_dir + "/father_lambda/reference.fasta") if not x.startswith(">")).upper()
+    codes = np.array([b"ACGT".index(bytes([c])) for c in ref.encode()], np.uint8)
+    graph = T.Graph(oss, orm, oss.ref_map_build(codes, np.array([0], np.uint64), np.array([len(ref)], np.uint64)))
+    mo = int(0.7 * 150)
+    o, ao, sc = T.Options(min_overlap=mo), A.AlignOptions(min_overlap=mo), T.Scaffold([(0, ref)])
+    traced_ = []
+    for rev in (False, True):
+        traced_ += T.reversable_trace(graph, sc, o, rev_comp=rev, anchor_drop=lambda s_, emit: A.AnchorDropper(ao, s_, emit))
+    _, out = A.variants_pipeline(ao, sc, traced_, through_vcf_pad=True)
+    assert vcf_columns(out, ref) == father_vcf_records(golden_dir)
