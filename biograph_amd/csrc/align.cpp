@@ -537,6 +537,8 @@ class VcfPadder : public SortedOutput {
 
 }  // namespace
 
+bool canon_assembly_less(const bg_trace_assembly_rec& a, const bg_trace_assembly_rec& b) { return canon_less(a, b); }
+
 // ---- scaffold.cpp -----------------------------------------------------------------------------------------------------
 ScaffoldView ScaffoldView::sub(int64_t start, int64_t len) const {
   const int64_t limit = start + len;

@@ -31,6 +31,11 @@ struct bg_trace_assembly_rec {  // variants::assembly (assemble.h:285-380), the 
   int64_t score = 0;
   std::vector<uint32_t> rc_read_ids, left_pair_matches, right_pair_matches;
   std::vector<bg_aligned_var_rec> aligned_variants;
+  // calc_coverage / simple_genotype_filter (csrc/coverage.cpp)
+  bool has_coverage = false;
+  std::vector<int> coverage, pair_coverage;  // interbase: seq.size() + 1 values
+  int other_depth = 0, other_pair_depth = 0, ref_depth = 0, strand_count = 0;
+  double genotype_quality = 0;
 };
 
 struct bg_trace_result {
@@ -49,6 +54,8 @@ struct ScaffoldView {
   int64_t shared_prefix_length(const char* s, int64_t n) const;  // scaffold.cpp:150-161
   int64_t shared_suffix_length(const char* s, int64_t n) const;  // rev_comp().shared_prefix_length(rev_comp(seq)), align.cpp:34-35
 };
+
+bool canon_assembly_less(const bg_trace_assembly_rec& a, const bg_trace_assembly_rec& b);  // canon_assembly_order (align.cpp)
 
 struct CheckFailed { std::string what; };  // a CHECK(...) of the reference: it aborts there; here the ABI call fails
 

@@ -1,0 +1,641 @@
+// coverage.cpp — row f.2, third slice: the coverage and genotype end of the reference's assembly pipeline
+// (pipeline.cpp:99-101) and the VCF record line:
+//
+//   path_group              modules/variants/path_group.cpp:21-277
+//   calc_coverage           modules/variants/calc_coverage.cpp:9-533
+//   simple_genotype_filter  modules/variants/simple_genotype_filter.cpp:27-151
+//   ploidless_vcf_export    modules/variants/ploidless_vcf_export.cpp:12-166 (on_assembly: one record line)
+//
+// calc_coverage walks "path groups" through the seqset: the reference path group follows the scaffold around every
+// variant section (max_read_len bases to either side), a variant's path group splits off at its left end, follows the
+// variant's sequence and joins the reference group again at its right end; wherever a path stands on a seqset entry
+// that carries reads, the reads are counted into the coverage trackers ("distant objects") still within reach.
+// A path is a chain of push_front_drop(complement, 0) and paths only merge, so a whole stretch of bases is ONE device
+// call for all paths of a group (bg_walk_chains, csrc/walk.hip): the ranges after every base come back and the host
+// replays the merging, the trimming to max_coverage_paths and the tracker bookkeeping in the reference's order.
+//
+// The reference reports from destructors (a tracker when the last path lets go of it, an assembly when its last
+// tracker has reported).  What a tracker holds cannot change after the last path dropped it and everything reported is
+// a minimum or a sum, so trackers are kept to the end and reported then; the output is put in canon order, the order
+// the reference's sorted output queue with its tracked left offsets produces.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <set>
+
+#include "assembly.h"
+#include "bg_internal.h"
+
+using namespace bg;
+
+extern "C" void bg_coverage_options_default(bg_coverage_options* o) {
+  if (!o) return;
+  o->max_coverage_paths = 4;             // assemble.h:715
+  o->penalize_directional_coverage = 1;  // assemble.h:719
+  o->simple_genotype_filter = 1;         // assemble.h:607
+  o->min_depth_portion = .23;            // assemble.h:704
+  o->min_avg_pair_depth = 1;             // assemble.h:711
+  o->min_pair_depth = 0;                 // assemble.h:710
+  o->min_read_depth = 1;                 // assemble.h:707
+  o->vcf_sv_size_threshold = 20;         // assemble.h:724
+}
+
+namespace {
+
+void check(bool cond, const char* what) {
+  if (!cond) throw CheckFailed{what};
+}
+
+struct Range { uint64_t b = 0, e = 0; uint32_t s = 0; };
+
+struct Accum {  // coverage_accum (calc_coverage.cpp:23-88)
+  std::vector<int> starts, ends;
+  explicit Accum(size_t n = 0) : starts(n, 0), ends(n, 0) {}
+  int size() const { return int(starts.size()); }
+  bool add(int64_t start, int64_t end) {
+    const int64_t n = size();
+    if (start < 0) start = 0;
+    if (end >= n) end = n - 1;
+    if (start > n - 1 || end < 0) return false;
+    ++starts[size_t(start)];
+    ++ends[size_t(end)];
+    return true;
+  }
+  std::vector<int> coverage() const {
+    std::vector<int> out;
+    int cur = 0;
+    const size_t n = starts.size();
+    for (size_t i = 0; i <= n; ++i) {
+      if (i < n) cur += starts[i];
+      if (i > 0) cur -= ends[i - 1];
+      if (i == n) check(cur == 0, "coverage_accum: starts and ends do not balance"); else out.push_back(cur);
+    }
+    return out;
+  }
+};
+
+struct Shared {  // shared_assembly (calc_coverage.h:44-58)
+  bg_trace_assembly_rec a;
+  std::set<uint32_t> pair_read_ids;
+  std::vector<std::pair<int, int>> other_min;
+  std::vector<std::vector<int>> other_ref_coverage;
+};
+
+struct Tracker {  // cov_tracker (calc_coverage.h:60-69)
+  int var = -1;  // index into shared, -1: a stretch of reference
+  std::vector<int> others;
+  Accum fwd, rev, pair;
+};
+
+using DobjSet = std::vector<int>;  // tracker ids in insertion order, no duplicates (path_group.h dobj_set)
+
+void dobj_add(DobjSet& s, int d) {  // path_group.cpp:231-241
+  auto it = std::find(s.begin(), s.end(), d);
+  if (it != s.end()) s.erase(it);
+  s.push_back(d);
+}
+void dobj_add_all(DobjSet& s, DobjSet&& more) {  // :243-268
+  if (more.empty()) return;
+  if (s.empty()) { s = std::move(more); return; }
+  DobjSet kept;
+  for (int d : s)
+    if (std::find(more.begin(), more.end(), d) == more.end()) kept.push_back(d);
+  kept.insert(kept.end(), more.begin(), more.end());
+  s = std::move(kept);
+}
+
+struct Path {
+  std::map<int, DobjSet> objects;
+  int unprop = 0;
+};
+
+struct CurKey {  // cur_comparer (path_group.h:111-121): longest context first, then by begin
+  uint32_t size;
+  uint64_t begin;
+  bool operator<(const CurKey& r) const { return size != r.size ? size > r.size : begin < r.begin; }
+};
+
+class Coverage;
+
+class PathGroup {
+ public:
+  PathGroup(Coverage* c, size_t max_size) : c_(c), max_size_(max_size) {}
+  void start(const Range& r) { add_path(r, Path{}); }
+  void add_distant_object(int dobj, int size) {  // :97-104
+    for (auto& kv : cur_) dobj_add(kv.second.second.objects[-(kv.second.second.unprop + size)], dobj);
+  }
+  void add_sequence(const char* seq, size_t len);  // add_base (:113-151) for every base, one device call
+  void flush() {
+    for (auto& kv : cur_) flush_path(kv.second.first, kv.second.second);
+  }
+  void join(PathGroup& rhs) {  // :203-220
+    for (auto& kv : rhs.cur_) add_path(kv.second.first, std::move(kv.second.second));
+    rhs.cur_.clear();
+  }
+  std::unique_ptr<PathGroup> split() const {  // :222-234
+    std::unique_ptr<PathGroup> out(new PathGroup(c_, max_size_));
+    out->cur_ = cur_;
+    return out;
+  }
+  template <class F>
+  void visit_distant_objects(const Range& r, F&& visit) {  // :171-201
+    auto it = cur_.find(CurKey{r.s, r.b});
+    check(it != cur_.end(), "path_group: visiting a range that is not a head");
+    const Path& p = it->second.second;
+    std::set<int> done;
+    for (const auto& o : p.objects) {
+      const int dist = o.first + p.unprop;
+      if (dist > int(r.s)) break;
+      for (int d : o.second)
+        if (done.insert(d).second) visit(d, dist);
+    }
+  }
+
+ private:
+  static void flush_path(const Range& r, Path& p) {  // :82-95
+    if (!p.unprop) return;
+    std::map<int, DobjSet> old;
+    std::swap(old, p.objects);
+    for (auto& o : old)
+      if (o.first + p.unprop <= int(r.s)) p.objects.emplace(o.first + p.unprop, std::move(o.second));
+    p.unprop = 0;
+  }
+  void add_path(const Range& r, Path p) {  // :41-52
+    const CurKey k{r.s, r.b};
+    auto it = cur_.find(k);
+    if (it == cur_.end()) {
+      cur_.emplace(k, std::make_pair(r, std::move(p)));
+      return;
+    }
+    Path& other = it->second.second;  // merge_paths(r, p, existing) :60-80
+    if (p.unprop != other.unprop) {
+      if (p.unprop) flush_path(r, p);
+      if (other.unprop) flush_path(r, other);
+    }
+    check(p.unprop == other.unprop, "path_group: merged paths keep different distances");
+    for (auto& o : other.objects) dobj_add_all(p.objects[o.first], std::move(o.second));
+    it->second.second = std::move(p);
+  }
+
+  Coverage* c_;
+  size_t max_size_;
+  std::map<CurKey, std::pair<Range, Path>> cur_;
+};
+
+class Coverage {
+ public:
+  Coverage(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const ScaffoldView& sc, const bg_coverage_options& o)
+      : ctx_(ctx), ss_(ss), rm_(rm), sc_(sc), o_(o) {}
+
+  int load() {
+    // the readmap columns on_seqset_entry reads (readmap::entry_to_index, get_readlength, get_is_forward)
+    entry_id_.resize(rm_->n_reads);
+    std::vector<uint64_t> tmp(rm_->n_reads);
+    if (rm_->n_reads) {
+      BG_HIP(hipMemcpy(entry_id_.data(), rm_->entry_id.p, rm_->n_reads * 4, hipMemcpyDeviceToHost));
+      BG_HIP(hipMemcpy(tmp.data(), rm_->read_len.p, rm_->n_reads * 8, hipMemcpyDeviceToHost));
+    }
+    read_len_.assign(tmp.begin(), tmp.end());
+    if (rm_->n_reads) BG_HIP(hipMemcpy(tmp.data(), rm_->is_forward.p, rm_->n_reads * 8, hipMemcpyDeviceToHost));
+    is_forward_.resize(rm_->n_reads);
+    for (size_t i = 0; i < tmp.size(); ++i) is_forward_[i] = uint8_t(tmp[i] & 1);
+    min_read_len_ = read_len_.empty() ? 0 : *std::min_element(read_len_.begin(), read_len_.end());
+    max_read_len_ = int64_t(ss_->max_len);  // seqset::max_read_len() = the longest entry (seqset.h:71)
+    it_offset_ = sc_.ext.empty() ? sc_.end_pos : sc_.ext[0].offset;
+    cur_offset_ = it_offset_;
+    init_ref_pg();
+    return BG_OK;
+  }
+
+  // the device walk of a path group's heads along `len` bases
+  void walk(const std::vector<Range>& starts, const char* seq, size_t len, std::vector<uint64_t>* out) {
+    std::vector<uint64_t> in(starts.size() * 3);
+    for (size_t i = 0; i < starts.size(); ++i) { in[3 * i] = starts[i].b; in[3 * i + 1] = starts[i].e; in[3 * i + 2] = starts[i].s; }
+    std::vector<uint8_t> codes(len);
+    for (size_t i = 0; i < len; ++i) codes[i] = seq[i] == 'A' ? 0 : seq[i] == 'C' ? 1 : seq[i] == 'G' ? 2 : 3;
+    out->resize(len * starts.size() * 3);
+    if (bg_walk_chains(ctx_, ss_, uint32_t(starts.size()), in.data(), codes.data(), uint32_t(len), out->data()) != BG_OK)
+      throw CheckFailed{std::string("bg_walk_chains: ") + bg_last_error()};
+    ++device_calls_;
+    device_steps_ += len * starts.size();
+  }
+
+  void on_seqset_entry(const Range& r, PathGroup* pg) {  // calc_coverage.cpp:455-527
+    if (r.s < min_read_len_) return;
+    const auto lo = std::lower_bound(entry_id_.begin(), entry_id_.end(), uint32_t(r.b));
+    const auto hi = std::upper_bound(lo, entry_id_.end(), uint32_t(r.b));
+    if (lo == hi) return;
+    const uint32_t first = uint32_t(lo - entry_id_.begin()), last = uint32_t(hi - entry_id_.begin());
+    pg->visit_distant_objects(r, [&](int d, int distance) {
+      Tracker& cov = trackers_[size_t(d)];
+      for (uint32_t rid = first; rid != last; ++rid) {
+        const int64_t rl = int64_t(read_len_[rid]);
+        if (rl > int64_t(r.s)) continue;
+        Accum& acc = is_forward_[rid] ? cov.fwd : cov.rev;
+        const int64_t start = int64_t(distance) - rl + 1 + acc.size() - 1, end = int64_t(distance) - 1 + acc.size() - 1;
+        if (acc.add(start, end) && cov.var >= 0 && shared_[size_t(cov.var)].pair_read_ids.count(rid))
+          check(cov.pair.add(start, end), "calc_coverage: pair coverage outside the read coverage");
+      }
+    });
+  }
+
+  void add(bg_trace_assembly_rec&& a) {  // on_assembly :206-279
+    if (a.matches_reference) return;
+    check(a.left_offset >= last_left_, "calc_coverage: input not sorted by left offset");
+    last_left_ = a.left_offset;
+    skip_to(a.left_offset - max_read_len_);
+    while (cur_offset_ < a.left_offset) advance_towards(a.left_offset);
+    const int sa = int(shared_.size());
+    shared_.emplace_back();
+    Shared& s = shared_.back();
+    s.pair_read_ids.insert(a.left_pair_matches.begin(), a.left_pair_matches.end());
+    s.pair_read_ids.insert(a.right_pair_matches.begin(), a.right_pair_matches.end());
+    s.a = std::move(a);
+    const int t = int(trackers_.size());
+    trackers_.emplace_back();
+    Tracker& tr = trackers_.back();
+    tr.var = sa;
+    for (const auto& x : active_) tr.others.push_back(x.second.first);
+    const size_t n = s.a.seq.size();
+    tr.fwd = Accum(n + 1);
+    tr.rev = Accum(n + 1);
+    tr.pair = Accum(n + 1);
+    std::unique_ptr<PathGroup> pg = ref_pg_->split();
+    pg->add_distant_object(t, int(n));
+    pg->add_sequence(s.a.seq.data(), n);
+    pg->flush();
+    const int64_t right = shared_[size_t(sa)].a.right_offset;
+    need_coverage_to_ = std::max(need_coverage_to_, right + max_read_len_);
+    active_.emplace(right, std::make_pair(sa, std::move(pg)));
+    need_ref_dobj_ = true;
+  }
+
+  void finish(std::vector<bg_trace_assembly_rec>* out) {  // ~calc_coverage, then the destructors' reports (:105-204)
+    skip_to(0x7fffffff);
+    check(active_.empty(), "calc_coverage: assemblies still active at the end");
+    for (Tracker& t : trackers_) {
+      const std::vector<int> f = t.fwd.coverage(), r = t.rev.coverage();
+      std::vector<int> both(f.size());
+      for (size_t i = 0; i < f.size(); ++i) both[i] = sum_dir_depth(f[i], r[i]);
+      if (t.var >= 0) {
+        std::vector<int> pair = t.pair.coverage();
+        const std::pair<int, int> m{*std::min_element(both.begin(), both.end()), *std::min_element(pair.begin(), pair.end())};
+        for (int other : t.others) shared_[size_t(other)].other_min.push_back(m);
+        shared_[size_t(t.var)].a.coverage = std::move(both);
+        shared_[size_t(t.var)].a.pair_coverage = std::move(pair);
+      } else {
+        check(!t.others.empty(), "calc_coverage: reference coverage nobody asked for");
+        for (int other : t.others) shared_[size_t(other)].other_ref_coverage.push_back(both);
+      }
+    }
+    for (Shared& s : shared_) {
+      bg_trace_assembly_rec& a = s.a;
+      a.other_depth = a.other_pair_depth = 0;
+      if (!s.other_min.empty()) {
+        a.other_depth = s.other_min[0].first;
+        a.other_pair_depth = s.other_min[0].second;
+        for (const auto& m : s.other_min) { a.other_depth = std::min(a.other_depth, m.first); a.other_pair_depth = std::min(a.other_pair_depth, m.second); }
+      }
+      check(!s.other_ref_coverage.empty(), "calc_coverage: an assembly without reference coverage");
+      int min_ref = 0x7fffffff;
+      for (const auto& c : s.other_ref_coverage) min_ref = std::min(min_ref, *std::min_element(c.begin(), c.end()));
+      a.ref_depth = min_ref;
+      a.has_coverage = true;
+      out->push_back(std::move(a));
+    }
+  }
+
+  uint64_t device_calls_ = 0, device_steps_ = 0;
+
+ private:
+  friend class PathGroup;
+  int sum_dir_depth(int fwd, int rev) const {  // :9-21
+    if (o_.penalize_directional_coverage) {
+      const int total = fwd + rev;
+      if (abs(fwd - rev) * 4 > total * 3) return std::min(fwd, rev) * 2;
+      return total;
+    }
+    return fwd + rev;
+  }
+  void init_ref_pg() {  // :362-370
+    ref_pg_.reset(new PathGroup(this, o_.max_coverage_paths));
+    Range r;
+    r.b = 0;
+    r.e = ss_->n;
+    r.s = 0;
+    ref_pg_->start(r);
+  }
+  void add_ref_dobj(int64_t ref_len) {  // :289-319
+    if (!active_.empty()) {
+      const int t = int(trackers_.size());
+      trackers_.emplace_back();
+      Tracker& tr = trackers_.back();
+      tr.fwd = Accum(size_t(ref_len) + 1);
+      tr.rev = Accum(size_t(ref_len) + 1);
+      for (const auto& x : active_) tr.others.push_back(x.second.first);
+      ref_pg_->add_distant_object(t, int(ref_len));
+    }
+    need_ref_dobj_ = false;
+  }
+  void flush_active_to_here() {  // :321-343
+    while (!active_.empty() && active_.begin()->first <= cur_offset_) {
+      if (need_ref_dobj_) add_ref_dobj(0);
+      ref_pg_->join(*active_.begin()->second.second);
+      active_.erase(active_.begin());
+    }
+  }
+  // scaffold::iterator (scaffold.h:14-60)
+  bool it_at_end() const { return it_ext_ >= sc_.ext.size(); }
+  void it_next_extent() {
+    ++it_ext_;
+    it_pos_ = 0;
+    it_offset_ = it_at_end() ? sc_.end_pos : sc_.ext[it_ext_].offset;
+  }
+  void it_skip_to(int64_t target) {  // scaffold.cpp:205-247
+    while (it_offset_ < target) {
+      const int64_t adv = std::min(target - it_offset_, sc_.ext[it_ext_].n - it_pos_);
+      it_pos_ += adv;
+      it_offset_ += adv;
+      if (it_pos_ == sc_.ext[it_ext_].n) {
+        it_next_extent();
+        if (it_at_end()) return;
+      }
+    }
+  }
+  void skip_to(int64_t offset) {  // :345-360
+    while (cur_offset_ < offset) {
+      if (active_.empty() && cur_offset_ >= need_coverage_to_) {
+        if (!it_at_end() && it_offset_ < offset) {
+          it_skip_to(offset);
+          cur_offset_ = it_offset_;
+        } else {
+          cur_offset_ = offset;
+        }
+        init_ref_pg();
+      } else {
+        advance_towards(offset);
+      }
+    }
+  }
+  void advance_towards(int64_t target) {  // :372-453
+    flush_active_to_here();
+    check(target > cur_offset_, "calc_coverage: advancing backwards");
+    if (!active_.empty() && target > active_.begin()->first) target = active_.begin()->first;
+    check(target > cur_offset_, "calc_coverage: an active assembly ends behind the cursor");
+    if (it_at_end()) { cur_offset_ = target; return; }
+    if (it_pos_ == 0 && cur_offset_ < it_offset_) {
+      if (target >= it_offset_) {
+        cur_offset_ = it_offset_;
+        init_ref_pg();
+      } else {
+        cur_offset_ = target;
+      }
+      return;
+    }
+    flush_active_to_here();
+    const int64_t extent_end = sc_.ext[it_ext_].offset + sc_.ext[it_ext_].n;
+    if (extent_end < target) target = extent_end;
+    if (need_coverage_to_ > cur_offset_ && need_coverage_to_ < target) target = need_coverage_to_;
+    const int64_t ref_len = target - cur_offset_;
+    check(ref_len > 0, "calc_coverage: empty reference stretch");
+    add_ref_dobj(ref_len);
+    ref_pg_->add_sequence(sc_.ext[it_ext_].p + it_pos_, size_t(ref_len));
+    it_pos_ += ref_len;
+    it_offset_ += ref_len;
+    cur_offset_ += ref_len;
+    if (it_pos_ == sc_.ext[it_ext_].n) it_next_extent();
+    ref_pg_->flush();
+  }
+
+  bg_ctx* ctx_;
+  const bg_seqset* ss_;
+  const bg_readmap* rm_;
+  const ScaffoldView& sc_;
+  bg_coverage_options o_;
+  std::vector<uint32_t> entry_id_, read_len_;
+  std::vector<uint8_t> is_forward_;
+  uint32_t min_read_len_ = 0;
+  int64_t max_read_len_ = 0;
+  size_t it_ext_ = 0;
+  int64_t it_pos_ = 0, it_offset_ = 0, cur_offset_ = 0, need_coverage_to_ = 0, last_left_ = INT32_MIN;
+  bool need_ref_dobj_ = false;
+  std::multimap<int64_t, std::pair<int, std::unique_ptr<PathGroup>>> active_;
+  std::unique_ptr<PathGroup> ref_pg_;
+  std::vector<Tracker> trackers_;
+  std::vector<Shared> shared_;
+};
+
+void PathGroup::add_sequence(const char* seq, size_t len) {
+  if (!len || cur_.empty()) return;
+  // chain i = the i-th head in order; a merged path keeps following either of its (equal) chains
+  std::vector<Range> starts;
+  std::vector<std::pair<int, Path>> heads;  // (chain, path) in cur order
+  for (auto& kv : cur_) {
+    heads.emplace_back(int(starts.size()), std::move(kv.second.second));
+    starts.push_back(kv.second.first);
+  }
+  std::vector<uint64_t> ranges;
+  c_->walk(starts, seq, len, &ranges);
+  const size_t n = starts.size();
+  for (size_t t = 0; t < len; ++t) {
+    cur_.clear();
+    std::map<CurKey, int> next_chain;
+    for (auto& h : heads) {
+      h.second.unprop += 1;
+      const uint64_t* o = &ranges[(t * n + size_t(h.first)) * 3];
+      Range r;
+      r.b = o[0];
+      r.e = o[1];
+      r.s = uint32_t(o[2]);
+      check(r.e > r.b, "path_group: no entry starts with a base of the sequence (the reference would not return)");
+      next_chain.emplace(CurKey{r.s, r.b}, h.first);
+      add_path(r, std::move(h.second));
+    }
+    if (max_size_ && cur_.size() > max_size_) {  // trim_cur :153-169: the shortest contexts go
+      while (cur_.size() > max_size_) cur_.erase(std::prev(cur_.end()));
+    }
+    for (auto& kv : cur_) {
+      Path& p = kv.second.second;
+      const Range& r = kv.second.first;
+      if (!p.objects.empty() && p.objects.begin()->first + p.unprop > int(r.s)) flush_path(r, p);
+      c_->on_seqset_entry(r, this);
+    }
+    if (t + 1 < len) {
+      heads.clear();
+      for (auto& kv : cur_) heads.emplace_back(next_chain[kv.first], std::move(kv.second.second));
+    }
+  }
+}
+
+std::string subscaffold_str(const ScaffoldView& sc, int64_t start, int64_t len) {  // scaffold.cpp:82-131: gaps read as N
+  std::string out(size_t(std::max<int64_t>(len, 0)), 'N');
+  for (const auto& e : sc.ext) {
+    const int64_t lo = std::max(start, e.offset), hi = std::min(start + len, e.offset + e.n);
+    for (int64_t p = lo; p < hi; ++p) out[size_t(p - start)] = e.p[p - e.offset];
+  }
+  return out;
+}
+
+int build_scaffold(const char* who, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                   const uint64_t* ext_len, int64_t end_pos, ScaffoldView* sc) {
+  int64_t calc_end = 0;
+  for (uint64_t i = 0; i < n_extents; ++i) {
+    if (ext_offset[i] < calc_end) { set_error("%s: extents must ascend without overlap", who); return BG_EINVAL; }
+    for (uint64_t j = 0; j < ext_len[i]; ++j) {
+      const char c = ext_seq[i][j];
+      if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { set_error("%s: extents hold ACGT only", who); return BG_EINVAL; }
+    }
+    sc->ext.push_back(ScaffoldView::Ext{ext_offset[i], ext_seq[i], int64_t(ext_len[i])});
+    calc_end = ext_offset[i] + int64_t(ext_len[i]);
+  }
+  if (end_pos < calc_end) { set_error("%s: end_pos lies before the end of the last extent", who); return BG_EINVAL; }
+  sc->end_pos = end_pos;
+  return BG_OK;
+}
+
+// simple_genotype_filter::on_assembly (simple_genotype_filter.cpp:27-151): false = discarded
+bool genotype(const bg_coverage_options& o, bg_trace_assembly_rec& a) {
+  if (a.matches_reference) return false;
+  if (!o.simple_genotype_filter) return true;
+  check(!a.coverage.empty(), "simple_genotype_filter: assembly without coverage");
+  const int min_depth = *std::min_element(a.coverage.begin(), a.coverage.end());
+  int min_pair = 0;
+  double avg_pair = 0;
+  if (!a.pair_coverage.empty()) {
+    min_pair = *std::min_element(a.pair_coverage.begin(), a.pair_coverage.end());
+    int tot = 0;
+    for (int c : a.pair_coverage) tot += c;
+    avg_pair = tot * 1. / double(a.pair_coverage.size());
+  }
+  if (avg_pair < o.min_avg_pair_depth || min_pair < o.min_pair_depth || min_depth < o.min_read_depth) return false;
+  const int total = min_depth + a.other_depth + a.ref_depth;
+  if (!total) return false;
+  const double min_p = min_depth * 1. / total, alt_p = a.other_depth * 1. / total, ref_p = a.ref_depth * 1. / total;
+  const double f = o.min_depth_portion;
+  if (min_p < f) return false;
+  if (ref_p > f) {
+    a.strand_count = 1;
+    a.genotype_quality = std::min(min_p, ref_p) / (min_p + ref_p);
+  } else if (alt_p > f) {
+    a.strand_count = 1;
+    a.genotype_quality = std::min(min_p, alt_p) / (min_p + alt_p);
+  } else {
+    a.strand_count = 2;
+    a.genotype_quality = min_p;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" int bg_assemblies_coverage(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const bg_trace_result* in,
+                                      uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                                      const uint64_t* ext_len, int64_t end_pos, const bg_coverage_options* options,
+                                      int genotype_filter, bg_trace_result** out) {
+  if (!ctx || !ss || !rm || !in || !out || (n_extents && (!ext_offset || !ext_seq || !ext_len))) {
+    set_error("bg_assemblies_coverage: null argument");
+    return BG_EINVAL;
+  }
+  if (rm->n_entries != ss->n) { set_error("bg_assemblies_coverage: the readmap belongs to another seqset"); return BG_EINVAL; }
+  bg_coverage_options o;
+  if (options) o = *options; else bg_coverage_options_default(&o);
+  ScaffoldView sc;
+  BG_TRY(build_scaffold("bg_assemblies_coverage", n_extents, ext_offset, ext_seq, ext_len, end_pos, &sc));
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_trace_result> res(new bg_trace_result);
+  memset(&res->stats, 0, sizeof(res->stats));
+  try {
+    Coverage c(ctx, ss, rm, sc, o);
+    BG_TRY(c.load());
+    for (const auto& a : in->a) {
+      bg_trace_assembly_rec copy = a;
+      c.add(std::move(copy));
+    }
+    std::vector<bg_trace_assembly_rec> covered;
+    c.finish(&covered);
+    std::stable_sort(covered.begin(), covered.end(), bg::canon_assembly_less);
+    for (auto& a : covered)
+      if (!genotype_filter || genotype(o, a)) res->a.push_back(std::move(a));
+    res->stats.device_rounds = c.device_calls_;
+    res->stats.device_queries = c.device_steps_;
+  } catch (const CheckFailed& f) {
+    set_error("bg_assemblies_coverage: %s", f.what.c_str());
+    return BG_EINVAL;
+  }
+  *out = res.release();
+  return BG_OK;
+}
+
+extern "C" int bg_trace_result_coverage(const bg_trace_result* r, uint64_t i, bg_assembly_coverage* out) {
+  if (!r || !out || i >= r->a.size()) { set_error("bg_trace_result_coverage: bad argument"); return BG_EINVAL; }
+  const bg_trace_assembly_rec& a = r->a[i];
+  out->has_coverage = a.has_coverage ? 1 : 0;
+  out->coverage = a.coverage.data();
+  out->pair_coverage = a.pair_coverage.data();
+  out->n_coverage = a.coverage.size();
+  out->n_pair_coverage = a.pair_coverage.size();
+  out->other_depth = a.other_depth;
+  out->other_pair_depth = a.other_pair_depth;
+  out->ref_depth = a.ref_depth;
+  out->strand_count = a.strand_count;
+  out->genotype_quality = a.genotype_quality;
+  return BG_OK;
+}
+
+// ploidless_vcf_export::on_assembly (ploidless_vcf_export.cpp:12-166) without assembly ids and ML features.
+extern "C" int bg_vcf_record(const bg_trace_result* r, uint64_t i, const char* scaffold_name, uint64_t n_extents,
+                             const int64_t* ext_offset, const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos,
+                             const bg_coverage_options* options, uint64_t assembly_id, char* buf, uint64_t cap, uint64_t* len) {
+  if (!r || i >= r->a.size() || !scaffold_name || !len || (n_extents && (!ext_offset || !ext_seq || !ext_len))) {
+    set_error("bg_vcf_record: bad argument");
+    return BG_EINVAL;
+  }
+  bg_coverage_options o;
+  if (options) o = *options; else bg_coverage_options_default(&o);
+  ScaffoldView sc;
+  BG_TRY(build_scaffold("bg_vcf_record", n_extents, ext_offset, ext_seq, ext_len, end_pos, &sc));
+  const bg_trace_assembly_rec& a = r->a[i];
+  if (a.matches_reference) { *len = 0; return BG_OK; }
+  if (a.strand_count < 0 || a.strand_count > 2) { set_error("bg_vcf_record: more than 2 strands"); return BG_EINVAL; }
+  const int min_depth = a.coverage.empty() ? 0 : *std::min_element(a.coverage.begin(), a.coverage.end());
+  const int min_pair = a.pair_coverage.empty() ? 0 : *std::min_element(a.pair_coverage.begin(), a.pair_coverage.end());
+  std::string var_seq = a.seq, ref_seq = subscaffold_str(sc, a.left_offset, a.right_offset - a.left_offset);
+  int64_t left = a.left_offset;
+  if (var_seq.empty() || ref_seq.empty()) {
+    if (left == 0) {
+      const std::string b = subscaffold_str(sc, a.right_offset, 1);
+      var_seq += b;
+      ref_seq += b;
+    } else {
+      const std::string b = subscaffold_str(sc, a.left_offset - 1, 1);
+      var_seq = b + var_seq;
+      ref_seq = b + ref_seq;
+      --left;
+    }
+  }
+  const char* gt = a.strand_count == 2 ? "1/1" : "0/1";
+  const char* pg = a.strand_count == 2 ? "1|1" : "0|1";
+  std::string line = std::string(scaffold_name) + "\t" + std::to_string(left + 1) + "\t.\t" + ref_seq + "\t" + var_seq + "\t100\tPASS\tNS=1";
+  if (var_seq.size() >= o.vcf_sv_size_threshold || ref_seq.size() >= o.vcf_sv_size_threshold) {
+    const int64_t svlen = int64_t(var_seq.size()) - int64_t(ref_seq.size());
+    line += ";END=" + std::to_string(left + int64_t(ref_seq.size())) + ";SVLEN=" + std::to_string(svlen) + ";SVTYPE=" +
+            (svlen < 0 ? "DEL" : svlen > 0 ? "INS" : "CPX");
+  }
+  char sample[256];
+  snprintf(sample, sizeof(sample), "%s:%s:%d:%llu:%u:%d:%d,%d:%d:%d,%d", gt, pg, int(a.genotype_quality * 100),
+           (unsigned long long)assembly_id, a.min_overlap, a.other_depth + min_depth + a.ref_depth, a.ref_depth, min_depth,
+           a.other_pair_depth + min_pair, 0, min_pair);
+  line += "\tGT:PG:GQ:PI:OV:DP:AD:PDP:PAD\t";
+  line += sample;
+  line += "\n";
+  *len = line.size();
+  if (buf && cap) {
+    const size_t n = std::min<size_t>(line.size(), size_t(cap - 1));
+    memcpy(buf, line.data(), n);
+    buf[n] = 0;
+  }
+  return BG_OK;
+}

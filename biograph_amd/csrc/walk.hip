@@ -413,6 +413,26 @@ __global__ __launch_bounds__(64) void k_ref_walk_entries(SeqsetView v, const uin
   }
 }
 
+// path_group::add_base (variants/path_group.cpp:113-127) for a whole sequence: every path of a path group is a chain of
+// push_front_drop(complement, 0) along the same bases, and paths only ever merge (equal ranges stay equal), so the
+// chains are independent: one lane per path, the range after every base is written out and the host
+// (csrc/coverage.cpp) replays the merging and the distant-object bookkeeping.  io: 3 words per range (begin, end, size).
+__global__ __launch_bounds__(64) void k_walk_chains(SeqsetView v, uint32_t n, const uint64_t* __restrict__ start,
+                                                   const uint8_t* __restrict__ codes, uint32_t len,
+                                                   uint64_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t b = start[3 * i], e = start[3 * i + 1];
+  uint32_t s = uint32_t(start[3 * i + 2]);
+  for (uint32_t t = 0; t < len; ++t) {
+    if (e > b) v.push_front_drop(b, e, s, 3 - (codes[t] & 3), 0, &b, &e, &s);
+    uint64_t* o = out + (size_t(t) * n + i) * 3;
+    o[0] = b;
+    o[1] = e;
+    o[2] = s;
+  }
+}
+
 // The base-by-base loop of tracer::expand_next_path (variants/tracer.cpp:545-620) for as long as it needs nothing but
 // the seqset: the four push_front_drop(complement, min_overlap + pushed_since_read) of :553-554 with the loop check of
 // :568-577, and, while exactly one of them is valid and the path has not reached a read, the step onto it.  One
@@ -592,6 +612,32 @@ extern "C" int bg_tracer_extend_batch(bg_ctx* ctx, const bg_seqset* ss, const bg
   k_tracer_extend<<<cdiv(n, 64), 64, 0, ctx->stream>>>(make_view(ss), rm->s2m_bits.p, n, d_queries, step_cap, d_replies, d_steps);
   BG_LAUNCH_CHECK();
   ctx->toc(n * 4 * 52);
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+// The ranges of n_chains paths after each of `len` bases (2-bit codes): h_start / h_out hold (begin, end, size) as three
+// u64 per range, h_out[(t * n_chains + i) * 3 ..] = chain i after base t.  The buffers are the host's: the caller is
+// a host state machine that needs the answer before its next step.  An invalid range (end <= begin: no entry starts
+// with the base; the reference would not return) stays invalid for the rest of the chain.
+extern "C" int bg_walk_chains(bg_ctx* ctx, const bg_seqset* ss, uint32_t n_chains, const uint64_t* h_start,
+                              const uint8_t* h_codes, uint32_t len, uint64_t* h_out) {
+  BG_TRY(check_ss(ctx, ss, "bg_walk_chains"));
+  if (!n_chains || !len) return BG_OK;
+  if (!h_start || !h_codes || !h_out) { set_error("bg_walk_chains: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  const size_t in_words = size_t(n_chains) * 3, code_words = (size_t(len) + 7) / 8, out_words = size_t(len) * n_chains * 3;
+  DevBuf<uint64_t> buf;
+  BG_TRY(buf.alloc(ctx, in_words + code_words + out_words));
+  BG_HIP(hipMemcpyAsync(buf.p, h_start, in_words * 8, hipMemcpyHostToDevice, ctx->stream));
+  BG_HIP(hipMemcpyAsync(buf.p + in_words, h_codes, len, hipMemcpyHostToDevice, ctx->stream));
+  ctx->tic("walk_chains");
+  k_walk_chains<<<cdiv(n_chains, 64), 64, 0, ctx->stream>>>(make_view(ss), n_chains, buf.p,
+                                                            reinterpret_cast<const uint8_t*>(buf.p + in_words), len,
+                                                            buf.p + in_words + code_words);
+  BG_LAUNCH_CHECK();
+  ctx->toc(uint64_t(n_chains) * len * 52);
+  BG_HIP(hipMemcpyAsync(h_out, buf.p + in_words + code_words, out_words * 8, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
   return BG_OK;
 }

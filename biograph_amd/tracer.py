@@ -114,14 +114,43 @@ def reference_ref_map(seqset, sequences):
     return out
 
 
+class CoverageOptions(C.Structure):
+    """bg_coverage_options = the assemble_options calc_coverage, simple_genotype_filter and the VCF export read."""
+    _fields_ = [("max_coverage_paths", C.c_uint32), ("penalize_directional_coverage", C.c_int32),
+                ("simple_genotype_filter", C.c_int32), ("min_pair_depth", C.c_int32), ("min_read_depth", C.c_int32),
+                ("vcf_sv_size_threshold", C.c_uint32), ("min_depth_portion", C.c_double), ("min_avg_pair_depth", C.c_double)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        capi.lib().bg_coverage_options_default(C.byref(self))
+        for k, v in kw.items():
+            if k not in dict(self._fields_):
+                raise AttributeError("no coverage option %r" % k)
+            setattr(self, k, v)
+
+
+class _Cov(C.Structure):
+    _fields_ = [("coverage", C.POINTER(C.c_int32)), ("pair_coverage", C.POINTER(C.c_int32)), ("n_coverage", C.c_uint64),
+                ("n_pair_coverage", C.c_uint64), ("has_coverage", C.c_int32), ("other_depth", C.c_int32),
+                ("other_pair_depth", C.c_int32), ("ref_depth", C.c_int32), ("strand_count", C.c_int32),
+                ("genotype_quality", C.c_double)]
+
+
 def _read_result(h):
     L = capi.lib()
     out = []
     a = _Asm()
+    cv = _Cov()
     lo, ro, sp, sl = C.c_int64(), C.c_int64(), C.c_void_p(), C.c_uint64()
     for i in range(L.bg_trace_result_size(h)):
         capi.check(L.bg_trace_result_get(h, i, C.byref(a)))
         t = TraceAssembly(a)
+        capi.check(L.bg_trace_result_coverage(h, i, C.byref(cv)))
+        if cv.has_coverage:
+            t.coverage = [int(cv.coverage[j]) for j in range(cv.n_coverage)]
+            t.pair_coverage = [int(cv.pair_coverage[j]) for j in range(cv.n_pair_coverage)]
+            t.other_depth, t.other_pair_depth, t.ref_depth = int(cv.other_depth), int(cv.other_pair_depth), int(cv.ref_depth)
+            t.strand_count, t.genotype_quality = int(cv.strand_count), float(cv.genotype_quality)
         for j in range(L.bg_trace_result_var_count(h, i)):
             capi.check(L.bg_trace_result_var(h, i, j, C.byref(lo), C.byref(ro), C.byref(sp), C.byref(sl)))
             t.aligned_variants.append((int(lo.value), int(ro.value), C.string_at(sp.value, sl.value).decode() if sl.value else ""))
@@ -137,6 +166,64 @@ STEP_ANCHOR_DROP, STEP_SORT, STEP_TRIM_REF, STEP_DEDUP, STEP_ALIGN, STEP_SPLIT =
 STEP_NORMALIZE, STEP_EXACT_DEDUP, STEP_VCF_PAD = 64, 128, 256
 STEP_THROUGH_SPLIT = STEP_SORT | STEP_TRIM_REF | STEP_DEDUP | STEP_ALIGN | STEP_SPLIT
 STEP_PIPELINE = STEP_THROUGH_SPLIT | STEP_NORMALIZE | STEP_EXACT_DEDUP | STEP_VCF_PAD  # pipeline.cpp:40-57,92-98
+
+
+def _make_result(assemblies):
+    L = capi.lib()
+    src = C.c_void_p()
+    capi.check(L.bg_trace_result_new(C.byref(src)))
+    try:
+        for t in assemblies:
+            seq = t.seq.encode()
+            ids, lm, rm = _u32_array(t.rc_read_ids), _u32_array(t.left_pair_matches), _u32_array(t.right_pair_matches)
+            a = _Asm(t.left_offset, t.right_offset, t.score, t.left_anchor_len, t.right_anchor_len,
+                     C.cast(C.c_char_p(seq), C.c_void_p), len(seq), t.min_overlap, t.trace_steps, t.left_anchor_ambiguous_bases,
+                     int(t.matches_reference), ids, lm, rm, len(t.rc_read_ids), len(t.left_pair_matches), len(t.right_pair_matches))
+            capi.check(L.bg_trace_result_add(src, C.byref(a)))
+    except Exception:
+        L.bg_trace_result_free(src)
+        raise
+    return src
+
+
+def _extent_arrays(extents, end_pos):
+    n = len(extents)
+    offs = (C.c_int64 * max(n, 1))(*[int(o) for o, _ in extents])
+    bufs = [s.encode() for _, s in extents]
+    ptrs = (C.c_char_p * max(n, 1))(*bufs)
+    lens = (C.c_uint64 * max(n, 1))(*[len(b) for b in bufs])
+    calc_end = max([o + len(s) for o, s in extents] + [0])
+    return n, offs, ptrs, lens, (calc_end if end_pos is None else end_pos), bufs
+
+
+def assemblies_coverage(seqset, readmap, sections, extents, end_pos=None, options=None, genotype_filter=True, vcf_name=None):
+    """bg_assemblies_coverage: calc_coverage (+ simple_genotype_filter) over the sections that leave process_assemblies
+    for one scaffold.  -> [TraceAssembly] with coverage / pair_coverage / other_depth / other_pair_depth / ref_depth
+    (/ strand_count / genotype_quality); with vcf_name also the VCF record lines (bg_vcf_record, PI = 0) as a second list."""
+    L = capi.lib()
+    src = _make_result(sections)
+    out = C.c_void_p()
+    try:
+        n, offs, ptrs, lens, end_pos, _keep = _extent_arrays(extents, end_pos)
+        opt = options if options is not None else CoverageOptions()
+        capi.check(L.bg_assemblies_coverage(seqset.ctx.h, seqset.h, readmap.h, src, n, offs, ptrs, lens, end_pos, C.byref(opt),
+                                            int(bool(genotype_filter)), C.byref(out)))
+        res = _read_result(out)
+        if vcf_name is None:
+            return res
+        lines = []
+        ln = C.c_uint64()
+        for i in range(len(res)):
+            capi.check(L.bg_vcf_record(out, i, vcf_name.encode(), n, offs, ptrs, lens, end_pos, C.byref(opt), 0, None, 0, C.byref(ln)))
+            buf = C.create_string_buffer(ln.value + 1)
+            capi.check(L.bg_vcf_record(out, i, vcf_name.encode(), n, offs, ptrs, lens, end_pos, C.byref(opt), 0, buf, ln.value + 1,
+                                       C.byref(ln)))
+            lines.append(buf.value.decode())
+        return res, lines
+    finally:
+        L.bg_trace_result_free(src)
+        if out:
+            L.bg_trace_result_free(out)
 
 
 def process_assemblies(assemblies, extents, end_pos=None, options=None, steps=STEP_PIPELINE):

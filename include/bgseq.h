@@ -482,6 +482,44 @@ int bg_assemblies_process(const bg_trace_result* const* in, uint32_t n_in, uint6
  * of *a appended to it. */
 int bg_trace_result_new(bg_trace_result** out);
 int bg_trace_result_add(bg_trace_result* r, const bg_trace_assembly* a);
+/* ---- row f.2, third slice (csrc/coverage.cpp): calc_coverage (with path_group), simple_genotype_filter and the VCF
+ * record line (variants/pipeline.cpp:99-101, calc_coverage.cpp, path_group.cpp, simple_genotype_filter.cpp,
+ * ploidless_vcf_export.cpp:12-166).  bg_assemblies_coverage takes the sections that leave BG_STEP_PIPELINE for one
+ * scaffold (sorted by left offset), drops the reference sections and gives every variant section its interbase read
+ * and pair coverage (seq_len + 1 values), the depth of the reference beside it and of the other alleles; with
+ * genotype_filter != 0 the simple_genotype_filter runs too (strand count, genotype quality; failing assemblies are
+ * dropped).  The path groups' walks run on the device (bg_walk_chains), one call per stretch of bases. */
+typedef struct bg_coverage_options {
+  uint32_t max_coverage_paths;             /* assemble.h:715 (4)    */
+  int32_t penalize_directional_coverage;   /* assemble.h:719 (1)    */
+  int32_t simple_genotype_filter;          /* assemble.h:607 (1)    */
+  int32_t min_pair_depth, min_read_depth;  /* assemble.h:707-710 (0, 1) */
+  uint32_t vcf_sv_size_threshold;          /* assemble.h:724 (20)   */
+  double min_depth_portion;                /* assemble.h:704 (.23)  */
+  double min_avg_pair_depth;               /* assemble.h:711 (1)    */
+} bg_coverage_options;
+void bg_coverage_options_default(bg_coverage_options* o);
+int bg_assemblies_coverage(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const bg_trace_result* in,
+                           uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                           const uint64_t* ext_len, int64_t end_pos, const bg_coverage_options* options /* NULL = defaults */,
+                           int genotype_filter, bg_trace_result** out);
+typedef struct bg_assembly_coverage {  /* assembly::coverage ... genotype_quality (assemble.h:330-370) */
+  const int32_t *coverage, *pair_coverage;
+  uint64_t n_coverage, n_pair_coverage;
+  int32_t has_coverage, other_depth, other_pair_depth, ref_depth, strand_count;
+  double genotype_quality;
+} bg_assembly_coverage;
+int bg_trace_result_coverage(const bg_trace_result* r, uint64_t i, bg_assembly_coverage* out);  /* pointers live as long as r */
+/* One VCF record line of ploidless_vcf_export::on_assembly for assembly i (nothing for a reference section: *len = 0);
+ * assembly_id fills the PI column.  The line (with its newline) is *len bytes; at most cap - 1 of them are copied to buf. */
+int bg_vcf_record(const bg_trace_result* r, uint64_t i, const char* scaffold_name, uint64_t n_extents,
+                  const int64_t* ext_offset, const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos,
+                  const bg_coverage_options* options, uint64_t assembly_id, char* buf, uint64_t cap, uint64_t* len);
+/* path_group::add_base for a whole sequence: the ranges of n_chains paths after each of len bases (2-bit codes), every
+ * step a push_front_drop(complement, 0).  h_start / h_out: (begin, end, size) as three u64 per range, HOST buffers (the
+ * caller is a host state machine); h_out[(t * n_chains + i) * 3 ..] = chain i after base t. */
+int bg_walk_chains(bg_ctx* ctx, const bg_seqset* ss, uint32_t n_chains, const uint64_t* h_start, const uint8_t* h_codes,
+                   uint32_t len, uint64_t* h_out);
 /* aligned_variants of assembly i (variants::aligned_var, assemble.h:124-152): filled by BG_STEP_ALIGN, consumed by
  * BG_STEP_SPLIT.  seq points into r. */
 uint64_t bg_trace_result_var_count(const bg_trace_result* r, uint64_t i);
