@@ -207,6 +207,11 @@ def push_tracer_leg(ss, rm, ref_map_dev, genome, args, chunks=2, chunk_size=1_00
     t_pipe = time.perf_counter() - t0
     variants = [a for a in sections if not a.matches_reference]
     called = {a.left_offset for a in variants if a.right_offset == a.left_offset + 1 and len(a.seq) == 1}
+    # calc_coverage + simple_genotype_filter (csrc/coverage.cpp: path groups walked on the device)
+    t0 = time.perf_counter()
+    kept = tracer.assemblies_coverage(ss, rm, sections, [(0, ref)])
+    t_cov = time.perf_counter() - t0
+    genotyped = {a.left_offset: a.strand_count for a in kept if a.right_offset == a.left_offset + 1 and len(a.seq) == 1}
     total = sum(secs)
     return {"reference_bases": region, "pieces": len(secs) // 2, "directions": 2, "session_open_seconds": round(t_open, 3),
             "seconds_per_piece_and_direction": secs, "traces": traces, "device_rounds": rounds,
@@ -214,9 +219,13 @@ def push_tracer_leg(ss, rm, ref_map_dev, genome, args, chunks=2, chunk_size=1_00
             "planted_snps_inside_assemblies": len(hit), "ref_bases_per_s_per_direction": round(2 * region / max(total, 1e-9), 1),
             "pipeline_seconds": round(t_pipe, 3), "pipeline_assemblies_in": len(everything),
             "pipeline_variant_sections": len(variants), "planted_snps_called_as_1_base_variants": len(called & snp_pos),
+            "coverage_genotype_seconds": round(t_cov, 3), "vcf_records": len(kept),
+            "planted_snps_in_vcf_records": len(set(genotyped) & snp_pos),
+            "planted_snps_genotyped_homozygous": sum(1 for p, sc in genotyped.items() if p in snp_pos and sc == 2),
             "min_overlap": int(0.7 * args.read_len),
             "what": "tracer + anchor_dropper + pair_counter per piece and direction, then sorter + ref_trimmer + deduper + "
-                    "aligner + align_splitter over all of them (normalize / coverage / genotype / VCF are not built)"}
+                    "aligner + align_splitter + normalizer + exact_deduper + vcf_padder over all of them, then calc_coverage + "
+                    "simple_genotype_filter (the records ploidless_vcf_export writes)"}
 
 
 def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):

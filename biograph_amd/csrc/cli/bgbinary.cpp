@@ -712,10 +712,142 @@ static int cmd_merge(int argc, char** argv) {
 // graph_trim_ref -> update_rc_seqset_entries -> discover_branch -> ... -> discover_push_to_pair) per scaffold;
 // every anchored non-reference assembly becomes one VCF record.  (The reference's `bgbinary discovery` runs
 // the production tracer + genotyper on top of the same walks: SURVEY §8f.2, not built.)
+// The reference's discovery engine over one sample (biograph_variants.cpp:598-830 with the push tracer): ref_map, one
+// tracer session, trace_ref's work list (scaffold_split_size pieces, both directions; trace_ref.cpp:27-105), then per
+// scaffold the serial pipeline (pipeline.cpp:40-57,92-101) and one VCF record per surviving variant
+// (ploidless_vcf_export.cpp).  PI is the record's ordinal (the reference's process-wide assembly counter is not
+// reproducible); the header's static lines are the reference's, the source line names this program.
+static int discovery_push(Args& a, const std::vector<std::pair<std::string, std::string>>& recs,
+                          const std::map<std::string, std::vector<std::pair<int64_t, int64_t>>>& bed, bg_ctx* ctx, bg_seqset* ss,
+                          bg_readmap* rm, uint32_t min_overlap, int64_t max_pair_distance, const std::string& sample,
+                          const std::vector<uint8_t>& flat_codes, const std::vector<uint64_t>& flat_start,
+                          const std::vector<uint64_t>& flat_size) {
+  const double t0 = now_s();
+  const uint64_t n = bg_seqset_size(ss);
+  void *d_ref = nullptr, *d_map = nullptr;
+  check(bg_dev_alloc(ctx, flat_codes.size() ? flat_codes.size() : 1, &d_ref), "bg_dev_alloc");
+  check(bg_dev_alloc(ctx, n ? n : 1, &d_map), "bg_dev_alloc");
+  check(bg_dev_upload(ctx, d_ref, flat_codes.data(), flat_codes.size()), "upload");
+  check(bg_ref_map_build(ctx, ss, static_cast<const uint8_t*>(d_ref), flat_start.size(), flat_start.data(), flat_size.data(), 0,
+                         static_cast<uint8_t*>(d_map)), "bg_ref_map_build");
+  bg_dev_free(ctx, d_ref);
+  const double t_refmap = now_s() - t0;
+  bg_trace_options opt;
+  bg_trace_options_default(&opt);
+  opt.min_overlap = min_overlap;
+  opt.max_pair_distance = uint64_t(max_pair_distance);
+  bg_coverage_options cov;
+  bg_coverage_options_default(&cov);
+  bg_tracer* tracer = nullptr;
+  check(bg_tracer_open(ctx, ss, rm, static_cast<const uint8_t*>(d_map), &opt, &tracer), "bg_tracer_open");
+  time_t now = time(nullptr);
+  char date[16];
+  strftime(date, sizeof date, "%Y%m%d", localtime(&now));
+  std::string vcf = std::string("##fileformat=VCFv4.1\n##fileDate=") + date + "\n##source=\"biograph_amd bgbinary discovery (push tracer engine)\"\n" +
+                    "##reference=" + a.get("ref") + "\n"
+                    "##INFO=<ID=NS,Number=1,Type=Integer,Description=\"Number of Samples\">\n"
+                    "##INFO=<ID=SVTYPE,Number=1,Type=String,Description=\"Structural Variant Type\">\n"
+                    "##INFO=<ID=SVLEN,Number=1,Type=Integer,Description=\"Difference in length between REF and ALT alleles\">\n"
+                    "##INFO=<ID=END,Number=1,Type=Integer,Description=\"End position of the variant described in this record\">\n"
+                    "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"
+                    "##FORMAT=<ID=DP,Number=1,Type=Integer,Description=\"Sample Depth\">\n"
+                    "##FORMAT=<ID=AD,Number=.,Type=Integer,Description=\"Allelic depths for the ref and alt alleles in the order listed\">\n"
+                    "##FORMAT=<ID=PDP,Number=1,Type=Integer,Description=\"Sample Pair Depth\">\n"
+                    "##FORMAT=<ID=PAD,Number=.,Type=Integer,Description=\"Allelic pair depths for the ref and alt alleles in the order listed\">\n"
+                    "##FORMAT=<ID=OV,Number=1,Type=Integer,Description=\"Minimum read overlap in assembly\">\n"
+                    "##FORMAT=<ID=PG,Number=1,Type=String,Description=\"Phased genotype\">\n"
+                    "##FORMAT=<ID=PI,Number=1,Type=Integer,Description=\"Phase group\">\n"
+                    "##FORMAT=<ID=GQ,Number=1,Type=Integer,Description=\"Genotype quality\">\n"
+                    "##ALT=<ID=INS,Description=\"Insertion\">\n##ALT=<ID=DEL,Description=\"Deletion\">\n";
+  for (auto& rec : recs) vcf += "##contig=<ID=" + rec.first + ",length=" + std::to_string(rec.second.size()) + ">\n";
+  vcf += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + sample + "\n";
+  uint64_t n_var = 0, n_traced = 0, n_sections = 0, pieces = 0;
+  double t_trace = 0, t_pipe = 0, t_cov = 0;
+  for (auto& rec : recs) {
+    const std::string& seq = rec.second;
+    std::vector<int64_t> eo;
+    std::vector<std::string> es;
+    size_t run = 0;
+    for (size_t i = 0; i <= seq.size(); ++i) {  // extents = maximal ACGT stretches (supercontigs)
+      const bool acgt = i < seq.size() && (seq[i] == 'A' || seq[i] == 'C' || seq[i] == 'G' || seq[i] == 'T');
+      if (acgt) { ++run; continue; }
+      if (run) { eo.push_back(int64_t(i - run)); es.push_back(seq.substr(i - run, run)); }
+      run = 0;
+    }
+    if (es.empty()) continue;
+    std::vector<const char*> ep;
+    std::vector<uint64_t> el;
+    for (auto& x : es) { ep.push_back(x.c_str()); el.push_back(x.size()); }
+    std::vector<std::pair<int64_t, int64_t>> ranges;  // trace_ref::add_scaffold_range
+    if (a.has("bed")) {
+      auto it = bed.find(rec.first);
+      if (it == bed.end()) continue;
+      for (auto& iv : it->second) ranges.emplace_back(iv.first, std::min<int64_t>(iv.second, int64_t(seq.size())));
+    } else {
+      ranges.emplace_back(0, int64_t(seq.size()));
+    }
+    std::vector<bg_trace_result*> items;
+    double t1 = now_s();
+    for (auto& rg : ranges)
+      for (int64_t start = rg.first; start < rg.second; start += int64_t(opt.scaffold_split_size)) {
+        const int64_t limit = std::min<int64_t>(rg.second, start + int64_t(opt.scaffold_split_size));
+        ++pieces;
+        for (int rev = 0; rev < 2; ++rev) {
+          bg_trace_result* r = nullptr;
+          check(bg_tracer_trace(tracer, es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), start, limit, rev, 1, &r),
+                "bg_tracer_trace");
+          n_traced += bg_trace_result_size(r);
+          items.push_back(r);
+        }
+      }
+    t_trace += now_s() - t1;
+    t1 = now_s();
+    bg_trace_result *sections = nullptr, *kept = nullptr;
+    check(bg_assemblies_process(items.data(), uint32_t(items.size()), es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()),
+                                &opt, BG_STEP_PIPELINE, &sections), "bg_assemblies_process");
+    for (auto* r : items) bg_trace_result_free(r);
+    n_sections += bg_trace_result_size(sections);
+    t_pipe += now_s() - t1;
+    t1 = now_s();
+    check(bg_assemblies_coverage(ctx, ss, rm, sections, es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), &cov, 1, &kept),
+          "bg_assemblies_coverage");
+    bg_trace_result_free(sections);
+    t_cov += now_s() - t1;
+    std::vector<char> buf(1 << 16);
+    for (uint64_t i = 0; i < bg_trace_result_size(kept); ++i) {
+      uint64_t len = 0;
+      check(bg_vcf_record(kept, i, rec.first.c_str(), es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), &cov, n_var + 1,
+                          buf.data(), buf.size(), &len), "bg_vcf_record");
+      if (len + 1 > buf.size()) {
+        buf.resize(len + 1);
+        check(bg_vcf_record(kept, i, rec.first.c_str(), es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), &cov, n_var + 1,
+                            buf.data(), buf.size(), &len), "bg_vcf_record");
+      }
+      if (!len) continue;
+      vcf.append(buf.data(), len);
+      ++n_var;
+    }
+    bg_trace_result_free(kept);
+  }
+  bg_tracer_close(tracer);
+  bg_dev_free(ctx, d_map);
+  write_file(a.get("out"), vcf);
+  fprintf(stderr, "%llu variants over %zu scaffold(s) in %llu piece(s) x 2 directions, min overlap %u: %.2f s (refmap %.2f, tracing %.2f "
+                  "[%llu assemblies], pipeline %.2f [%llu sections], coverage + genotype %.2f)\n",
+          (unsigned long long)n_var, recs.size(), (unsigned long long)pieces, min_overlap, now_s() - t0, t_refmap, t_trace,
+          (unsigned long long)n_traced, t_pipe, (unsigned long long)n_sections, t_cov);
+  return 0;
+}
+
 static int cmd_discovery(int argc, char** argv) {
-  Args a = parse(argc, argv, 2, {"reads", "ref", "out", "sample", "min-overlap", "max-pair-distance", "bed"});
+  Args a = parse(argc, argv, 2, {"reads", "ref", "out", "sample", "min-overlap", "max-pair-distance", "bed", "engine"});
   if (!a.has("reads") || !a.has("ref") || !a.has("out")) die("discovery: --in S.bg, --ref and --out are required");
   std::string bgdir = a.get("reads");
+  // --engine push (default): the reference's discovery engine -- push tracer, anchor_dropper, pair_counter, the
+  // serial pipeline, calc_coverage, simple_genotype_filter, ploidless VCF records (biograph_variants.cpp:598-830);
+  // --engine graph: the graph_discover pipeline (branch + push_to_pair), positions and alleles only
+  const std::string engine = a.get("engine", "push");
+  if (engine != "push" && engine != "graph") die("discovery: --engine takes push or graph");
   // scaffolds (chromosomes) and their N-free supercontigs from the reference directory / .ref / FASTA; a
   // scaffold is rebuilt with N between its supercontigs so that VCF positions are scaffold coordinates
   bg_reference* rf = nullptr;
@@ -730,6 +862,21 @@ static int cmd_discovery(int argc, char** argv) {
     if (sc >= recs.size() || off > recs[sc].second.size() || len > recs[sc].second.size() - off)
       die("reference: a supercontig lies outside its scaffold (corrupt reference?)");
     check(bg_reference_bases(rf, flat, len, &recs[sc].second[off]), "bg_reference_bases");
+  }
+  // the flat genome and its supercontigs, for the ref_map of the push engine (ref_map::build, ref_map.cpp:72-185)
+  std::vector<uint8_t> flat_codes;
+  std::vector<uint64_t> flat_start, flat_size;
+  if (engine == "push") {
+    std::string fa(bg_reference_size(rf), '\0');
+    check(bg_reference_bases(rf, 0, fa.size(), &fa[0]), "bg_reference_bases");
+    flat_codes.resize(fa.size());
+    for (size_t i = 0; i < fa.size(); ++i) flat_codes[i] = uint8_t(fa[i] == 'A' ? 0 : fa[i] == 'C' ? 1 : fa[i] == 'G' ? 2 : 3);
+    for (uint32_t i = 0; i < bg_reference_supercontig_count(rf); ++i) {
+      uint64_t len = 0, flat = 0;
+      check(bg_reference_supercontig(rf, i, nullptr, nullptr, &len, &flat), "bg_reference_supercontig");
+      flat_start.push_back(flat);
+      flat_size.push_back(len);
+    }
   }
   bg_reference_free(rf);
   bg_ctx* ctx = nullptr;
@@ -767,6 +914,13 @@ static int cmd_discovery(int argc, char** argv) {
     }
   }
   double t0 = now_s();
+  if (engine == "push") {
+    const int rc = discovery_push(a, recs, bed, ctx, ss, rm, min_overlap, max_pair_distance, sample, flat_codes, flat_start, flat_size);
+    bg_readmap_free(rm);
+    bg_seqset_free(ss);
+    bg_ctx_destroy(ctx);
+    return rc;
+  }
   std::string vcf = "##fileformat=VCFv4.1\n##source=biograph_amd graph_discover\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n";
   uint64_t n_var = 0;
   for (auto& rec : recs) {

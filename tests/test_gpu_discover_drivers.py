@@ -135,7 +135,8 @@ def test_native_graph_discover_on_lambda_golden(ctx, golden_dir):
 
 @pytest.mark.parametrize("ref_arg,chrom", [("/father_lambda/reference.fasta", "lambda:0"), ("/ref_lambda", "lambda"),
                                            ("/ref_lambda/reference.ref", "lambda:0")])
-def test_bgbinary_discovery_cli_on_lambda(golden_dir, tmp_path, ref_arg, chrom):
+@pytest.mark.parametrize("engine", ["push", "graph"])
+def test_bgbinary_discovery_cli_on_lambda(golden_dir, tmp_path, ref_arg, chrom, engine):
     """--ref takes a FASTA, a reference directory (karyotype.json + reference.ref: scaffold names from the
     karyotype) or a bare .ref"""
     """`bgbinary discovery` on the lambda golden laid out as a .bg directory: 8 VCF records, the variants of
@@ -153,7 +154,8 @@ def test_bgbinary_discovery_cli_on_lambda(golden_dir, tmp_path, ref_arg, chrom):
               separators=(",", ":"))
     out = tmp_path / "v.vcf"
     r = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "discovery", "--in", str(bgd), "--ref",
-                        golden_dir + ref_arg, "--out", str(out), "--min-overlap", "70"],
+                        golden_dir + ref_arg, "--out", str(out), "--engine", engine] +
+                       (["--min-overlap", "70"] if engine == "graph" else []),  # push: the command's default, 0.7 x read length
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     ref = "".join(l.strip() for l in open(golden_dir + "/father_lambda/reference.fasta") if not l.startswith(">")).upper()
@@ -171,6 +173,23 @@ def test_bgbinary_discovery_cli_on_lambda(golden_dir, tmp_path, ref_arg, chrom):
     mine, gold = edits(out), edits(golden_dir + "/father_lambda/father.vcf")
     assert len(mine) == 8 and mine == gold
     assert {l.split("\t")[0] for l in open(out) if not l.startswith("#")} == {chrom}
+    if engine == "push":
+        # the reference's engine: every record line of father.vcf but for the scaffold name given by --ref and the PI
+        # column (the reference's process-wide assembly counter; here the record's ordinal)
+        def fields(path):
+            res = []
+            for line in open(path):
+                if line.startswith("#"):
+                    continue
+                f = line.rstrip("\n").split("\t")
+                smp = f[9].split(":")
+                smp[3] = "PI"
+                res.append(f[1:9] + [":".join(smp)])
+            return res
+        assert fields(out) == fields(golden_dir + "/father_lambda/father.vcf")
+        head = [l for l in open(out) if l.startswith("#")]
+        assert head[0] == "##fileformat=VCFv4.1\n" and head[-1] == "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tfather\n"
+        assert "##contig=<ID=%s,length=48502>\n" % chrom in head
 
 
 def test_native_drivers_equal_oracle_twin_on_a_240kb_sample(ctx):
