@@ -22,6 +22,7 @@ import biograph_amd as bg  # noqa: E402
 from biograph_amd import sharded, synth, tracer  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from oracle import align as A  # noqa: E402
+from oracle import coverage as CV  # noqa: E402
 from oracle import tracer as T  # noqa: E402
 
 
@@ -94,6 +95,7 @@ def tracer_case(ctx, seed):
     end = sc.end_pos
     ok = True
     ad = None
+    whole_want, whole_got = [], []
     if akw["anchor_drop"]:
         ao = A.AlignOptions(min_overlap=kw["min_overlap"], read_ahead_distance=kw["read_ahead_distance"],
                             trace_reference_assemblies=bool(kw["trace_reference_assemblies"]),
@@ -108,6 +110,9 @@ def tracer_case(ctx, seed):
             for start, limit in ranges:
                 want = T.reversable_trace(g, sc, o_cpu, rev_comp=rev, start_offset=start, limit_offset=limit, anchor_drop=ad)
                 got = tracer.push_trace(ss, rm, rmap, parts, start=start, limit=limit, rev_comp=rev, options=o_gpu)
+                if (start, limit) == (0, None):
+                    whole_want += want
+                    whole_got += got
                 if [full_key(x) for x in got] != [full_key(x) for x in want]:
                     print("TRACER MISMATCH seed", seed, "rev", rev, "range", start, limit, kw, "G", G, "rl", rl, akw, "parts",
                           [(o, len(s)) for o, s in parts], flush=True)
@@ -121,9 +126,91 @@ def tracer_case(ctx, seed):
                     break
             if not ok:
                 break
+        if ok and akw["anchor_drop"]:
+            ok = pipeline_and_coverage(rng, seed, g, orm, sc, parts, ss, rm, kw, akw, o_gpu, whole_want, whole_got)
     finally:
         rmap.free()
     return ok, sum(1 for _ in [0])
+
+
+COUNTS = {"sections": 0, "covered": 0, "vcf_lines": 0, "refused": 0}
+
+
+def pipeline_and_coverage(rng, seed, g, orm, sc, parts, ss, rm, kw, akw, o_gpu, want_in, got_in):
+    """Both directions of the whole scaffold through the serial pipeline, calc_coverage, simple_genotype_filter and the
+    VCF record line: library == oracle (oracle/align.py, oracle/coverage.py)."""
+    ao = A.AlignOptions(min_overlap=kw["min_overlap"], read_ahead_distance=kw["read_ahead_distance"],
+                        trace_reference_assemblies=bool(kw["trace_reference_assemblies"]),
+                        min_anchor_drop_overlap=akw["min_anchor_drop_overlap"], max_kmer_size=akw["max_anchor_kmer_size"],
+                        ref_align_factor=akw["ref_align_factor"], max_ref_align_bases=akw["max_ref_align_bases"])
+    try:
+        _, want_sections = A.variants_pipeline(ao, sc, want_in, through_vcf_pad=True)
+    except AssertionError:
+        want_sections = None  # a CHECK of the reference: the library must refuse as well
+    try:
+        got_sections = tracer.process_assemblies(got_in, parts, end_pos=sc.end_pos, options=o_gpu)
+    except Exception:
+        got_sections = None
+    if (want_sections is None) != (got_sections is None):
+        print("PIPELINE MISMATCH seed", seed, "one side refused", want_sections is None, got_sections is None, flush=True)
+        return False
+    if want_sections is None:
+        COUNTS["refused"] += 1
+        return True
+    COUNTS["sections"] += len(want_sections)
+
+    def skey(a):
+        return (a.left_offset, a.right_offset, a.seq, bool(a.matches_reference), sorted(a.left_pair_matches),
+                sorted(a.right_pair_matches), a.score, a.min_overlap, a.trace_steps)
+    if [skey(a) for a in got_sections] != [skey(a) for a in want_sections]:
+        print("PIPELINE MISMATCH seed", seed, kw, akw, len(got_sections), len(want_sections), flush=True)
+        return False
+    ckw = dict(max_coverage_paths=int(rng.choice([1, 2, 4, 64])), penalize_directional_coverage=int(rng.random() < 0.7),
+               min_depth_portion=float(rng.choice([0.05, 0.23, 0.4])), min_avg_pair_depth=float(rng.choice([0, 1, 3])),
+               min_read_depth=int(rng.choice([0, 1, 3])), vcf_sv_size_threshold=int(rng.choice([5, 20])))
+    co = CV.CoverageOptions(**{k: (bool(v) if k == "penalize_directional_coverage" else v) for k, v in ckw.items()})
+    for filt in (False, True):
+        try:
+            want = CV.calc_coverage(g, [int(x) for x in orm.get("read_len")], sc, co, want_sections)
+            if filt:
+                want = CV.simple_genotype_filter(co, want)
+        except AssertionError:
+            want = None
+        try:
+            got, lines = tracer.assemblies_coverage(ss, rm, got_sections, parts, end_pos=sc.end_pos,
+                                                    options=tracer.CoverageOptions(**ckw), genotype_filter=filt, vcf_name="s")
+        except Exception:
+            got = None
+        if (want is None) != (got is None):
+            print("COVERAGE MISMATCH seed", seed, "one side refused", want is None, got is None, ckw, flush=True)
+            return False
+        if want is None:
+            continue
+
+        def ckey(a):
+            return (a.left_offset, a.right_offset, a.seq, list(a.coverage), list(a.pair_coverage), a.other_depth,
+                    a.other_pair_depth, a.ref_depth) + ((a.strand_count, round(a.genotype_quality, 12)) if filt else ())
+        if [ckey(a) for a in got] != [ckey(a) for a in want]:
+            print("COVERAGE MISMATCH seed", seed, ckw, kw, akw, len(got), len(want), flush=True)
+            for x, y in zip(got, want):
+                if ckey(x) != ckey(y):
+                    print("   gpu   ", ckey(x), "\n   oracle", ckey(y), flush=True)
+                    break
+            return False
+        COUNTS["covered"] += len(want)
+        if filt:
+            COUNTS["vcf_lines"] += len(want)
+
+            def sub(off, n):
+                out = ["N"] * n
+                for o_, s_ in parts:
+                    for p_ in range(max(off, o_), min(off + n, o_ + len(s_))):
+                        out[p_ - off] = s_[p_ - o_]
+                return "".join(out)
+            if lines != [CV.vcf_line(co, "s", sub, a) for a in want]:
+                print("VCF LINE MISMATCH seed", seed, ckw, flush=True)
+                return False
+    return True
 
 
 def population_case(ctx, seed):
@@ -187,6 +274,9 @@ def main():
         done += 1
     print("%d random %s cases equal (%.0f s)" % (done, "population" if case is population_case else "tracer", time.time() - t0),
           flush=True)
+    if case is not population_case:
+        print("  behind the tracers: %(sections)d pipeline sections, %(covered)d coverage results, %(vcf_lines)d VCF lines equal; "
+              "%(refused)d inputs refused by both sides" % COUNTS, flush=True)
     return 0
 
 
