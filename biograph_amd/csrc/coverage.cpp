@@ -11,8 +11,10 @@
 // variant's sequence and joins the reference group again at its right end; wherever a path stands on a seqset entry
 // that carries reads, the reads are counted into the coverage trackers ("distant objects") still within reach.
 // A path is a chain of push_front_drop(complement, 0) and paths only merge, so a whole stretch of bases is ONE device
-// call for all paths of a group (bg_walk_chains, csrc/walk.hip): the ranges after every base come back and the host
-// replays the merging, the trimming to max_coverage_paths and the tracker bookkeeping in the reference's order.
+// call for all paths of a group (bg_walk_chains_batch, csrc/walk.hip): the ranges after every base come back and the
+// host replays the merging, the trimming to max_coverage_paths and the tracker bookkeeping in the reference's order.
+// Runs of variants further apart than 2 x max_read_len share nothing (the reference path group is re-initialised
+// between them): such islands advance in lock step on worker threads and every round is one launch for all of them.
 //
 // The reference reports from destructors (a tracker when the last path lets go of it, an assembly when its last
 // tracker has reported).  What a tracker holds cannot change after the last path dropped it and everything reported is
@@ -22,9 +24,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
+#include <thread>
 
 #include "assembly.h"
 #include "bg_internal.h"
@@ -120,6 +125,112 @@ struct CurKey {  // cur_comparer (path_group.h:111-121): longest context first, 
 
 class Coverage;
 
+// One stretch of bases for the heads of one path group, waiting for the device.
+struct WalkRequest {
+  const std::vector<bg_walk_chain>* chains = nullptr;  // offsets relative to this request's codes / out
+  const uint8_t* codes = nullptr;
+  size_t n_codes = 0;
+  std::vector<uint64_t>* out = nullptr;
+  bool done = false;
+};
+
+// The islands of a scaffold advance in lock step: every worker thread runs one island's state machine and stops at each
+// stretch of bases it needs walked; when all live workers have stopped, the caller's thread (the only one that talks
+// to HIP) ships all stretches in one bg_walk_chains_batch and wakes them.
+class Batcher {
+ public:
+  Batcher(bg_ctx* ctx, const bg_seqset* ss, int workers) : ctx_(ctx), ss_(ss), live_(workers) {}
+  void submit_and_wait(WalkRequest* r) {
+    std::unique_lock<std::mutex> l(mu_);
+    pending_.push_back(r);
+    if (int(pending_.size()) == live_) cv_all_.notify_one();
+    cv_done_.wait(l, [&] { return r->done; });
+    if (!error_.empty()) throw CheckFailed{error_};
+  }
+  void worker_exit() {
+    std::unique_lock<std::mutex> l(mu_);
+    --live_;
+    cv_all_.notify_one();
+  }
+  void run() {  // on the calling thread
+    std::unique_lock<std::mutex> l(mu_);
+    for (;;) {
+      cv_all_.wait(l, [&] { return live_ == 0 || int(pending_.size()) == live_; });
+      if (live_ == 0) return;
+      std::vector<WalkRequest*> batch;
+      batch.swap(pending_);
+      l.unlock();
+      const std::string err = launch(batch);
+      l.lock();
+      if (!err.empty() && error_.empty()) error_ = err;
+      for (WalkRequest* r : batch) r->done = true;
+      cv_done_.notify_all();
+    }
+  }
+  uint64_t launches = 0, steps = 0;
+
+ private:
+  std::string launch(const std::vector<WalkRequest*>& batch) {
+    std::vector<bg_walk_chain> chains;
+    std::vector<uint8_t> codes;
+    std::vector<size_t> out_at;
+    size_t out_words = 0;
+    for (WalkRequest* r : batch) {
+      out_at.push_back(out_words);
+      for (bg_walk_chain c : *r->chains) {
+        c.code_offset += codes.size();
+        c.out_offset += out_words;
+        chains.push_back(c);
+        steps += c.len;
+      }
+      codes.insert(codes.end(), r->codes, r->codes + r->n_codes);
+      out_words += r->out->size();
+    }
+    std::vector<uint64_t> out(out_words);
+    if (bg_walk_chains_batch(ctx_, ss_, uint32_t(chains.size()), chains.data(), codes.data(), codes.size(), out.data(), out_words) != BG_OK)
+      return std::string("bg_walk_chains_batch: ") + bg_last_error();
+    ++launches;
+    for (size_t i = 0; i < batch.size(); ++i)
+      std::copy(out.begin() + out_at[i], out.begin() + out_at[i] + batch[i]->out->size(), batch[i]->out->begin());
+    return std::string();
+  }
+  bg_ctx* ctx_;
+  const bg_seqset* ss_;
+  std::mutex mu_;
+  std::condition_variable cv_all_, cv_done_;
+  std::vector<WalkRequest*> pending_;
+  int live_;
+  std::string error_;
+};
+
+// What the islands share, read-only: the readmap columns on_seqset_entry reads (readmap::entry_to_index,
+// get_readlength, get_is_forward), the scaffold, the options.
+struct CovWorld {
+  const bg_seqset* ss = nullptr;
+  const ScaffoldView* sc = nullptr;
+  bg_coverage_options o;
+  std::vector<uint32_t> entry_id, read_len;
+  std::vector<uint8_t> is_forward;
+  uint32_t min_read_len = 0;
+  int64_t max_read_len = 0;
+  Batcher* batcher = nullptr;
+  int load(const bg_readmap* rm) {
+    entry_id.resize(rm->n_reads);
+    std::vector<uint64_t> tmp(rm->n_reads);
+    if (rm->n_reads) {
+      BG_HIP(hipMemcpy(entry_id.data(), rm->entry_id.p, rm->n_reads * 4, hipMemcpyDeviceToHost));
+      BG_HIP(hipMemcpy(tmp.data(), rm->read_len.p, rm->n_reads * 8, hipMemcpyDeviceToHost));
+    }
+    read_len.assign(tmp.begin(), tmp.end());
+    if (rm->n_reads) BG_HIP(hipMemcpy(tmp.data(), rm->is_forward.p, rm->n_reads * 8, hipMemcpyDeviceToHost));
+    is_forward.resize(rm->n_reads);
+    for (size_t i = 0; i < tmp.size(); ++i) is_forward[i] = uint8_t(tmp[i] & 1);
+    min_read_len = read_len.empty() ? 0 : *std::min_element(read_len.begin(), read_len.end());
+    max_read_len = int64_t(ss->max_len);  // seqset::max_read_len() = the longest entry (seqset.h:71)
+    return BG_OK;
+  }
+};
+
 class PathGroup {
  public:
   PathGroup(Coverage* c, size_t max_size) : c_(c), max_size_(max_size) {}
@@ -187,40 +298,36 @@ class PathGroup {
 
 class Coverage {
  public:
-  Coverage(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const ScaffoldView& sc, const bg_coverage_options& o)
-      : ctx_(ctx), ss_(ss), rm_(rm), sc_(sc), o_(o) {}
-
-  int load() {
-    // the readmap columns on_seqset_entry reads (readmap::entry_to_index, get_readlength, get_is_forward)
-    entry_id_.resize(rm_->n_reads);
-    std::vector<uint64_t> tmp(rm_->n_reads);
-    if (rm_->n_reads) {
-      BG_HIP(hipMemcpy(entry_id_.data(), rm_->entry_id.p, rm_->n_reads * 4, hipMemcpyDeviceToHost));
-      BG_HIP(hipMemcpy(tmp.data(), rm_->read_len.p, rm_->n_reads * 8, hipMemcpyDeviceToHost));
-    }
-    read_len_.assign(tmp.begin(), tmp.end());
-    if (rm_->n_reads) BG_HIP(hipMemcpy(tmp.data(), rm_->is_forward.p, rm_->n_reads * 8, hipMemcpyDeviceToHost));
-    is_forward_.resize(rm_->n_reads);
-    for (size_t i = 0; i < tmp.size(); ++i) is_forward_[i] = uint8_t(tmp[i] & 1);
-    min_read_len_ = read_len_.empty() ? 0 : *std::min_element(read_len_.begin(), read_len_.end());
-    max_read_len_ = int64_t(ss_->max_len);  // seqset::max_read_len() = the longest entry (seqset.h:71)
+  explicit Coverage(const CovWorld& w)
+      : ss_(w.ss), sc_(*w.sc), o_(w.o), entry_id_(w.entry_id), read_len_(w.read_len), is_forward_(w.is_forward),
+        min_read_len_(w.min_read_len), max_read_len_(w.max_read_len), batcher_(w.batcher) {
     it_offset_ = sc_.ext.empty() ? sc_.end_pos : sc_.ext[0].offset;
     cur_offset_ = it_offset_;
     init_ref_pg();
-    return BG_OK;
   }
 
-  // the device walk of a path group's heads along `len` bases
+  // the device walk of a path group's heads along `len` bases: stops here until the batch of all islands has run
   void walk(const std::vector<Range>& starts, const char* seq, size_t len, std::vector<uint64_t>* out) {
-    std::vector<uint64_t> in(starts.size() * 3);
-    for (size_t i = 0; i < starts.size(); ++i) { in[3 * i] = starts[i].b; in[3 * i + 1] = starts[i].e; in[3 * i + 2] = starts[i].s; }
+    const size_t n = starts.size();
+    std::vector<bg_walk_chain> chains(n);
+    for (size_t i = 0; i < n; ++i) {
+      chains[i].begin = starts[i].b;
+      chains[i].end = starts[i].e;
+      chains[i].size = starts[i].s;
+      chains[i].len = uint32_t(len);
+      chains[i].code_offset = 0;
+      chains[i].out_offset = uint64_t(i) * 3;
+      chains[i].out_stride = uint64_t(n) * 3;
+    }
     std::vector<uint8_t> codes(len);
     for (size_t i = 0; i < len; ++i) codes[i] = seq[i] == 'A' ? 0 : seq[i] == 'C' ? 1 : seq[i] == 'G' ? 2 : 3;
-    out->resize(len * starts.size() * 3);
-    if (bg_walk_chains(ctx_, ss_, uint32_t(starts.size()), in.data(), codes.data(), uint32_t(len), out->data()) != BG_OK)
-      throw CheckFailed{std::string("bg_walk_chains: ") + bg_last_error()};
-    ++device_calls_;
-    device_steps_ += len * starts.size();
+    out->assign(len * n * 3, 0);
+    WalkRequest r;
+    r.chains = &chains;
+    r.codes = codes.data();
+    r.n_codes = len;
+    r.out = out;
+    batcher_->submit_and_wait(&r);
   }
 
   void on_seqset_entry(const Range& r, PathGroup* pg) {  // calc_coverage.cpp:455-527
@@ -307,8 +414,6 @@ class Coverage {
       out->push_back(std::move(a));
     }
   }
-
-  uint64_t device_calls_ = 0, device_steps_ = 0;
 
  private:
   friend class PathGroup;
@@ -410,15 +515,14 @@ class Coverage {
     ref_pg_->flush();
   }
 
-  bg_ctx* ctx_;
   const bg_seqset* ss_;
-  const bg_readmap* rm_;
   const ScaffoldView& sc_;
   bg_coverage_options o_;
-  std::vector<uint32_t> entry_id_, read_len_;
-  std::vector<uint8_t> is_forward_;
+  const std::vector<uint32_t>&entry_id_, &read_len_;
+  const std::vector<uint8_t>& is_forward_;
   uint32_t min_read_len_ = 0;
   int64_t max_read_len_ = 0;
+  Batcher* batcher_;
   size_t it_ext_ = 0;
   int64_t it_pos_ = 0, it_offset_ = 0, cur_offset_ = 0, need_coverage_to_ = 0, last_left_ = INT32_MIN;
   bool need_ref_dobj_ = false;
@@ -548,19 +652,61 @@ extern "C" int bg_assemblies_coverage(bg_ctx* ctx, const bg_seqset* ss, const bg
   std::unique_ptr<bg_trace_result> res(new bg_trace_result);
   memset(&res->stats, 0, sizeof(res->stats));
   try {
-    Coverage c(ctx, ss, rm, sc, o);
-    BG_TRY(c.load());
+    CovWorld w;
+    w.ss = ss;
+    w.sc = &sc;
+    w.o = o;
+    BG_TRY(w.load(rm));
+    // Islands: calc_coverage re-initialises its reference path group whenever nothing is active and the next variant
+    // starts more than max_read_len behind everything still owed coverage (skip_to, calc_coverage.cpp:345-360), so
+    // runs of variants separated like that share nothing and each gets its own state machine.
+    std::vector<std::vector<const bg_trace_assembly_rec*>> islands;
+    int64_t need_to = INT64_MIN, last_left = INT64_MIN;
     for (const auto& a : in->a) {
-      bg_trace_assembly_rec copy = a;
-      c.add(std::move(copy));
+      if (a.matches_reference) continue;
+      check(a.left_offset >= last_left, "calc_coverage: input not sorted by left offset");
+      check(a.right_offset >= a.left_offset, "calc_coverage: right offset before the left one");
+      last_left = a.left_offset;
+      if (islands.empty() || a.left_offset - w.max_read_len > need_to) islands.emplace_back();
+      islands.back().push_back(&a);
+      need_to = std::max(need_to, a.right_offset + w.max_read_len);
     }
+    std::vector<std::vector<bg_trace_assembly_rec>> done(islands.size());
+    const int workers = int(std::min<size_t>(islands.size(), 128));
+    Batcher batcher(ctx, ss, workers);
+    w.batcher = &batcher;
+    std::mutex err_mu;
+    std::string first_error;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < workers; ++t)
+      pool.emplace_back([&, t] {
+        try {
+          for (size_t i = size_t(t); i < islands.size(); i += size_t(workers)) {
+            Coverage c(w);
+            for (const bg_trace_assembly_rec* a : islands[i]) {
+              bg_trace_assembly_rec copy = *a;
+              c.add(std::move(copy));
+            }
+            c.finish(&done[i]);
+          }
+        } catch (const CheckFailed& f) {
+          std::lock_guard<std::mutex> l(err_mu);
+          if (first_error.empty()) first_error = f.what;
+        }
+        batcher.worker_exit();
+      });
+    batcher.run();
+    for (auto& th : pool) th.join();
+    if (!first_error.empty()) throw CheckFailed{first_error};
     std::vector<bg_trace_assembly_rec> covered;
-    c.finish(&covered);
+    for (auto& d : done)
+      for (auto& a : d) covered.push_back(std::move(a));
     std::stable_sort(covered.begin(), covered.end(), bg::canon_assembly_less);
     for (auto& a : covered)
       if (!genotype_filter || genotype(o, a)) res->a.push_back(std::move(a));
-    res->stats.device_rounds = c.device_calls_;
-    res->stats.device_queries = c.device_steps_;
+    res->stats.device_rounds = batcher.launches;
+    res->stats.device_queries = batcher.steps;
+    res->stats.traces = islands.size();
   } catch (const CheckFailed& f) {
     set_error("bg_assemblies_coverage: %s", f.what.c_str());
     return BG_EINVAL;

@@ -413,23 +413,25 @@ __global__ __launch_bounds__(64) void k_ref_walk_entries(SeqsetView v, const uin
   }
 }
 
-// path_group::add_base (variants/path_group.cpp:113-127) for a whole sequence: every path of a path group is a chain of
-// push_front_drop(complement, 0) along the same bases, and paths only ever merge (equal ranges stay equal), so the
-// chains are independent: one lane per path, the range after every base is written out and the host
-// (csrc/coverage.cpp) replays the merging and the distant-object bookkeeping.  io: 3 words per range (begin, end, size).
-__global__ __launch_bounds__(64) void k_walk_chains(SeqsetView v, uint32_t n, const uint64_t* __restrict__ start,
-                                                   const uint8_t* __restrict__ codes, uint32_t len,
-                                                   uint64_t* __restrict__ out) {
+// path_group::add_base (variants/path_group.cpp:113-127) for whole sequences: every head of a path group is a chain of
+// push_front_drop(complement, 0) along its group's bases, and heads only ever merge (equal ranges stay equal), so the
+// chains are independent: one lane per chain, the range after every base is written out and the host
+// (csrc/coverage.cpp) replays the merging and the distant-object bookkeeping.  Ranges are 3 words (begin, end, size).
+__global__ __launch_bounds__(64) void k_walk_chains(SeqsetView v, uint32_t n, const bg_walk_chain* __restrict__ chains,
+                                                   const uint8_t* __restrict__ codes, uint64_t* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint64_t b = start[3 * i], e = start[3 * i + 1];
-  uint32_t s = uint32_t(start[3 * i + 2]);
-  for (uint32_t t = 0; t < len; ++t) {
-    if (e > b) v.push_front_drop(b, e, s, 3 - (codes[t] & 3), 0, &b, &e, &s);
-    uint64_t* o = out + (size_t(t) * n + i) * 3;
+  const bg_walk_chain c = chains[i];
+  uint64_t b = c.begin, e = c.end;
+  uint32_t s = c.size;
+  const uint8_t* cd = codes + c.code_offset;
+  uint64_t* o = out + c.out_offset;
+  for (uint32_t t = 0; t < c.len; ++t) {
+    if (e > b) v.push_front_drop(b, e, s, 3 - (cd[t] & 3), 0, &b, &e, &s);
     o[0] = b;
     o[1] = e;
     o[2] = s;
+    o += c.out_stride;
   }
 }
 
@@ -616,30 +618,57 @@ extern "C" int bg_tracer_extend_batch(bg_ctx* ctx, const bg_seqset* ss, const bg
   return BG_OK;
 }
 
-// The ranges of n_chains paths after each of `len` bases (2-bit codes): h_start / h_out hold (begin, end, size) as three
-// u64 per range, h_out[(t * n_chains + i) * 3 ..] = chain i after base t.  The buffers are the host's: the caller is
-// a host state machine that needs the answer before its next step.  An invalid range (end <= begin: no entry starts
-// with the base; the reference would not return) stays invalid for the rest of the chain.
-extern "C" int bg_walk_chains(bg_ctx* ctx, const bg_seqset* ss, uint32_t n_chains, const uint64_t* h_start,
-                              const uint8_t* h_codes, uint32_t len, uint64_t* h_out) {
-  BG_TRY(check_ss(ctx, ss, "bg_walk_chains"));
-  if (!n_chains || !len) return BG_OK;
-  if (!h_start || !h_codes || !h_out) { set_error("bg_walk_chains: null argument"); return BG_EINVAL; }
+// Chains of push_front_drop(complement, 0): chain i starts at (begin, end, size), follows len bases (2-bit codes at
+// h_codes + code_offset) and writes the range after base t as three u64 at h_out + out_offset + t * out_stride.  All
+// buffers are the HOST's: the callers are host state machines that need the answer before their next step; one call =
+// one upload, one launch, one download.  An invalid range (end <= begin: no entry starts with the base; the reference
+// would not return) stays invalid for the rest of its chain.
+extern "C" int bg_walk_chains_batch(bg_ctx* ctx, const bg_seqset* ss, uint32_t n_chains, const bg_walk_chain* h_chains,
+                                    const uint8_t* h_codes, uint64_t n_codes, uint64_t* h_out, uint64_t out_words) {
+  BG_TRY(check_ss(ctx, ss, "bg_walk_chains_batch"));
+  if (!n_chains) return BG_OK;
+  if (!h_chains || (n_codes && !h_codes) || (out_words && !h_out)) { set_error("bg_walk_chains_batch: null argument"); return BG_EINVAL; }
+  for (uint32_t i = 0; i < n_chains; ++i) {
+    const bg_walk_chain& c = h_chains[i];
+    if (c.code_offset + c.len > n_codes || (c.len && (c.out_stride < 3 || c.out_offset + uint64_t(c.len - 1) * c.out_stride + 3 > out_words))) {
+      set_error("bg_walk_chains_batch: chain %u reaches outside the buffers", i);
+      return BG_EINVAL;
+    }
+  }
   BG_HIP(hipSetDevice(ctx->device));
-  const size_t in_words = size_t(n_chains) * 3, code_words = (size_t(len) + 7) / 8, out_words = size_t(len) * n_chains * 3;
+  const size_t chain_words = (size_t(n_chains) * sizeof(bg_walk_chain) + 7) / 8, code_words = (size_t(n_codes) + 7) / 8;
   DevBuf<uint64_t> buf;
-  BG_TRY(buf.alloc(ctx, in_words + code_words + out_words));
-  BG_HIP(hipMemcpyAsync(buf.p, h_start, in_words * 8, hipMemcpyHostToDevice, ctx->stream));
-  BG_HIP(hipMemcpyAsync(buf.p + in_words, h_codes, len, hipMemcpyHostToDevice, ctx->stream));
+  BG_TRY(buf.alloc(ctx, chain_words + code_words + size_t(out_words)));
+  BG_HIP(hipMemcpyAsync(buf.p, h_chains, size_t(n_chains) * sizeof(bg_walk_chain), hipMemcpyHostToDevice, ctx->stream));
+  if (n_codes) BG_HIP(hipMemcpyAsync(buf.p + chain_words, h_codes, n_codes, hipMemcpyHostToDevice, ctx->stream));
   ctx->tic("walk_chains");
-  k_walk_chains<<<cdiv(n_chains, 64), 64, 0, ctx->stream>>>(make_view(ss), n_chains, buf.p,
-                                                            reinterpret_cast<const uint8_t*>(buf.p + in_words), len,
-                                                            buf.p + in_words + code_words);
+  k_walk_chains<<<cdiv(n_chains, 64), 64, 0, ctx->stream>>>(make_view(ss), n_chains, reinterpret_cast<const bg_walk_chain*>(buf.p),
+                                                            reinterpret_cast<const uint8_t*>(buf.p + chain_words),
+                                                            buf.p + chain_words + code_words);
   BG_LAUNCH_CHECK();
-  ctx->toc(uint64_t(n_chains) * len * 52);
-  BG_HIP(hipMemcpyAsync(h_out, buf.p + in_words + code_words, out_words * 8, hipMemcpyDeviceToHost, ctx->stream));
+  ctx->toc(uint64_t(out_words) / 3 * 52);
+  if (out_words) BG_HIP(hipMemcpyAsync(h_out, buf.p + chain_words + code_words, out_words * 8, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
   return BG_OK;
+}
+
+// The heads of ONE path group along one sequence: h_start / h_out hold (begin, end, size) as three u64 per range,
+// h_out[(t * n_chains + i) * 3 ..] = chain i after base t.
+extern "C" int bg_walk_chains(bg_ctx* ctx, const bg_seqset* ss, uint32_t n_chains, const uint64_t* h_start,
+                              const uint8_t* h_codes, uint32_t len, uint64_t* h_out) {
+  if (!n_chains || !len) return BG_OK;
+  if (!h_start || !h_codes || !h_out) { set_error("bg_walk_chains: null argument"); return BG_EINVAL; }
+  std::vector<bg_walk_chain> chains(n_chains);
+  for (uint32_t i = 0; i < n_chains; ++i) {
+    chains[i].begin = h_start[3 * i];
+    chains[i].end = h_start[3 * i + 1];
+    chains[i].size = uint32_t(h_start[3 * i + 2]);
+    chains[i].len = len;
+    chains[i].code_offset = 0;
+    chains[i].out_offset = uint64_t(i) * 3;
+    chains[i].out_stride = uint64_t(n_chains) * 3;
+  }
+  return bg_walk_chains_batch(ctx, ss, n_chains, chains.data(), h_codes, len, h_out, uint64_t(len) * n_chains * 3);
 }
 
 // d_codes = the n bases (codes 0..3) of ONE extent in walking order; d_entry[i] = the full entry the read-ahead range

@@ -520,6 +520,17 @@ int bg_vcf_record(const bg_trace_result* r, uint64_t i, const char* scaffold_nam
  * caller is a host state machine); h_out[(t * n_chains + i) * 3 ..] = chain i after base t. */
 int bg_walk_chains(bg_ctx* ctx, const bg_seqset* ss, uint32_t n_chains, const uint64_t* h_start, const uint8_t* h_codes,
                    uint32_t len, uint64_t* h_out);
+/* The same for chains of many groups at once (calc_coverage advances independent stretches of the scaffold in lock
+ * step): every chain names its own bases and where its ranges go; one upload, one launch, one download. */
+typedef struct bg_walk_chain {
+  uint64_t begin, end;      /* start range                                                     */
+  uint64_t code_offset;     /* its bases: h_codes[code_offset .. code_offset + len)            */
+  uint64_t out_offset;      /* range after base t: h_out[out_offset + t * out_stride .. + 3)   */
+  uint64_t out_stride;      /* in u64 words, >= 3                                              */
+  uint32_t size, len;
+} bg_walk_chain;
+int bg_walk_chains_batch(bg_ctx* ctx, const bg_seqset* ss, uint32_t n_chains, const bg_walk_chain* h_chains,
+                         const uint8_t* h_codes, uint64_t n_codes, uint64_t* h_out, uint64_t out_words);
 /* aligned_variants of assembly i (variants::aligned_var, assemble.h:124-152): filled by BG_STEP_ALIGN, consumed by
  * BG_STEP_SPLIT.  seq points into r. */
 uint64_t bg_trace_result_var_count(const bg_trace_result* r, uint64_t i);
