@@ -739,7 +739,9 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   bg_coverage_options cov;
   bg_coverage_options_default(&cov);
   bg_tracer* tracer = nullptr;
+  const double t_open0 = now_s();
   check(bg_tracer_open(ctx, ss, rm, static_cast<const uint8_t*>(d_map), &opt, &tracer), "bg_tracer_open");
+  const double t_open = now_s() - t_open0;
   time_t now = time(nullptr);
   char date[16];
   strftime(date, sizeof date, "%Y%m%d", localtime(&now));
@@ -832,9 +834,9 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   bg_tracer_close(tracer);
   bg_dev_free(ctx, d_map);
   write_file(a.get("out"), vcf);
-  fprintf(stderr, "%llu variants over %zu scaffold(s) in %llu piece(s) x 2 directions, min overlap %u: %.2f s (refmap %.2f, tracing %.2f "
+  fprintf(stderr, "%llu variants over %zu scaffold(s) in %llu piece(s) x 2 directions, min overlap %u: %.2f s (refmap %.2f, session %.2f, tracing %.2f "
                   "[%llu assemblies], pipeline %.2f [%llu sections], coverage + genotype %.2f)\n",
-          (unsigned long long)n_var, recs.size(), (unsigned long long)pieces, min_overlap, now_s() - t0, t_refmap, t_trace,
+          (unsigned long long)n_var, recs.size(), (unsigned long long)pieces, min_overlap, now_s() - t0, t_refmap, t_open, t_trace,
           (unsigned long long)n_traced, t_pipe, (unsigned long long)n_sections, t_cov);
   return 0;
 }
@@ -850,6 +852,7 @@ static int cmd_discovery(int argc, char** argv) {
   if (engine != "push" && engine != "graph") die("discovery: --engine takes push or graph");
   // scaffolds (chromosomes) and their N-free supercontigs from the reference directory / .ref / FASTA; a
   // scaffold is rebuilt with N between its supercontigs so that VCF positions are scaffold coordinates
+  const double t_begin = now_s();
   bg_reference* rf = nullptr;
   check(bg_reference_open(a.get("ref").c_str(), &rf), "bg_reference_open");
   std::vector<std::pair<std::string, std::string>> recs;
@@ -914,6 +917,7 @@ static int cmd_discovery(int argc, char** argv) {
     }
   }
   double t0 = now_s();
+  fprintf(stderr, "discovery: reference, seqset and readmap open in %.2f s\n", t0 - t_begin);
   if (engine == "push") {
     const int rc = discovery_push(a, recs, bed, ctx, ss, rm, min_overlap, max_pair_distance, sample, flat_codes, flat_start, flat_size);
     bg_readmap_free(rm);

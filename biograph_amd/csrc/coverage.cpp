@@ -584,11 +584,11 @@ std::string subscaffold_str(const ScaffoldView& sc, int64_t start, int64_t len) 
 }
 
 int build_scaffold(const char* who, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
-                   const uint64_t* ext_len, int64_t end_pos, ScaffoldView* sc) {
+                   const uint64_t* ext_len, int64_t end_pos, ScaffoldView* sc, bool check_bases = true) {
   int64_t calc_end = 0;
   for (uint64_t i = 0; i < n_extents; ++i) {
     if (ext_offset[i] < calc_end) { set_error("%s: extents must ascend without overlap", who); return BG_EINVAL; }
-    for (uint64_t j = 0; j < ext_len[i]; ++j) {
+    for (uint64_t j = 0; check_bases && j < ext_len[i]; ++j) {
       const char c = ext_seq[i][j];
       if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { set_error("%s: extents hold ACGT only", who); return BG_EINVAL; }
     }
@@ -742,7 +742,8 @@ extern "C" int bg_vcf_record(const bg_trace_result* r, uint64_t i, const char* s
   bg_coverage_options o;
   if (options) o = *options; else bg_coverage_options_default(&o);
   ScaffoldView sc;
-  BG_TRY(build_scaffold("bg_vcf_record", n_extents, ext_offset, ext_seq, ext_len, end_pos, &sc));
+  // one record reads a few bases around its own position: the extents are not scanned (bg_assemblies_coverage did)
+  BG_TRY(build_scaffold("bg_vcf_record", n_extents, ext_offset, ext_seq, ext_len, end_pos, &sc, false));
   const bg_trace_assembly_rec& a = r->a[i];
   if (a.matches_reference) { *len = 0; return BG_OK; }
   if (a.strand_count < 0 || a.strand_count > 2) { set_error("bg_vcf_record: more than 2 strands"); return BG_EINVAL; }
