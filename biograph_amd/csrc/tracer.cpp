@@ -27,6 +27,9 @@
 #include <time.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <map>
 #include <memory>
 #include <set>
@@ -596,26 +599,88 @@ double now_seconds() {
   return double(ts.tv_sec) + 1e-9 * double(ts.tv_nsec);
 }
 
-int g_tracer_threads = 0;  // 0: hardware_concurrency (BG_TRACER_THREADS overrides)
-template <class F>
-void parallel_over(size_t n, F f, size_t min_per_thread = 256) {
-  int nt = g_tracer_threads;
-  if (nt <= 0) {
+// The host side of a round is a microsecond or two per trace: threads only pay off on big rounds, and only a few of
+// them (measured on a 256-core box, 1 Mb piece: host replay 0.29 s on one thread, 0.21 s on 16, 0.50 s on 64 when every
+// round spawned its threads).  So: a persistent pool of at most 16 (BG_TRACER_THREADS overrides), each taking a
+// contiguous share, and rounds below a few thousand traces per thread run on fewer threads or inline.
+int g_tracer_threads = 0;
+
+class HostPool {
+ public:
+  static HostPool& get() {
+    static HostPool p;
+    return p;
+  }
+  int size() const { return int(workers_.size()) + 1; }
+  // f(t) for t in [0, parts): part 0 on the calling thread, the rest on the workers
+  void run(int parts, const std::function<void(int)>& f) {
+    if (parts <= 1) { f(0); return; }
+    {
+      std::unique_lock<std::mutex> l(mu_);
+      fn_ = &f;
+      parts_ = parts;
+      left_ = parts - 1;
+      ++gen_;
+    }
+    cv_work_.notify_all();
+    f(0);
+    std::unique_lock<std::mutex> l(mu_);
+    cv_done_.wait(l, [&] { return left_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  HostPool() {
     const char* e = getenv("BG_TRACER_THREADS");
-    nt = e ? atoi(e) : int(std::thread::hardware_concurrency());
+    int nt = e ? atoi(e) : int(std::min(16u, std::thread::hardware_concurrency()));
     if (nt < 1) nt = 1;
     if (nt > 64) nt = 64;
     g_tracer_threads = nt;
+    for (int t = 1; t < nt; ++t) workers_.emplace_back([this, t] { loop(t); });
   }
-  if (size_t(nt) > n / min_per_thread + 1) nt = int(n / min_per_thread + 1);  // a few hundred traces per thread at least
+  ~HostPool() {
+    {
+      std::unique_lock<std::mutex> l(mu_);
+      stop_ = true;
+    }
+    cv_work_.notify_all();
+    for (auto& th : workers_) th.join();
+  }
+  void loop(int t) {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> l(mu_);
+    for (;;) {
+      cv_work_.wait(l, [&] { return stop_ || gen_ != seen; });
+      if (stop_) return;
+      seen = gen_;
+      if (t >= parts_) continue;  // this round uses fewer threads
+      const std::function<void(int)>* f = fn_;
+      l.unlock();
+      (*f)(t);
+      l.lock();
+      if (--left_ == 0) cv_done_.notify_one();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_work_, cv_done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int parts_ = 0, left_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
+template <class F>
+void parallel_over(size_t n, F f, size_t min_per_thread = 4096) {
+  HostPool& pool = HostPool::get();
+  int nt = pool.size();
+  if (size_t(nt) > n / min_per_thread + 1) nt = int(n / min_per_thread + 1);
   if (nt <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
-  std::vector<std::thread> pool;
-  const size_t per = (n + nt - 1) / nt;
-  for (int t = 0; t < nt; ++t) {
+  const size_t per = (n + size_t(nt) - 1) / size_t(nt);
+  pool.run(nt, [&](int t) {
     const size_t lo = size_t(t) * per, hi = std::min(n, lo + per);
-    if (lo < hi) pool.emplace_back([lo, hi, &f] { for (size_t i = lo; i < hi; ++i) f(i); });
-  }
-  for (auto& th : pool) th.join();
+    for (size_t i = lo; i < hi; ++i) f(i);
+  });
 }
 
 void add_stats(bg_trace_stats* to, const bg_trace_stats& from) {
@@ -672,7 +737,7 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
     BG_HIP(hipMemcpy(ent.data(), d_ent.p, n * 8, hipMemcpyDeviceToHost));
     // positions that are reads, and for those the (rc mate, offset) pairs: per-thread lists over slices of the extent
     {
-      int nt = int(std::min<uint64_t>(64, n / 65536 + 1));
+      int nt = int(std::min<uint64_t>(uint64_t(HostPool::get().size()), n / 65536 + 1));
       std::vector<std::vector<std::pair<int32_t, uint64_t>>> pe(nt);
       std::vector<std::vector<std::pair<uint32_t, int32_t>>> mates(nt);
       parallel_over(size_t(nt), [&](size_t t) {
