@@ -202,3 +202,31 @@ def test_synthetic_equals_oracle(ctx):
         assert len(got) >= 3
         if filt:
             assert lines == [C.vcf_line(co, "chrS", lambda off, n: ref[off:off + n], a) for a in want]
+
+
+@pytest.mark.parametrize("paths", [3, 2, 1])
+def test_max_coverage_paths(ctx, paths):  # calc_coverage_test.cpp:323-355
+    ref, reads, vs = VC.snp_with_other_coverage_case()
+    out = run(ctx, reads, [asm(l, r, s) for l, r, s in vs], parts=[(0, ref)], max_coverage_paths=paths)
+    assert VC.snp_with_other_coverage_expected(out) == (paths >= 2)
+
+
+@pytest.mark.parametrize("n_vars", [1, 2, 3, 5, 8, 12])
+def test_stress_recipe(ctx, n_vars):  # calc_coverage_test.cpp:370-520
+    ref, reads, variants, paired, is_delete, var_count, pair_count, ref_count = VC.stress_case(n_vars, 77 + n_vars)
+    ss, rm = world(ctx, reads)
+    entry_id, read_len, _, _ = rm.arrays()
+    asms = []
+    for i, (l, r, s) in enumerate(variants):
+        ids = []
+        for x in sorted(paired[i]):
+            b, e = ss.find_batch([T.revcomp(x)])
+            assert int(e[0]) == int(b[0]) + 1
+            ids.append([j for j in range(len(entry_id)) if int(entry_id[j]) == int(b[0]) and int(read_len[j]) == len(x)][0])
+        asms.append(asm(l, r, s, left_pair_matches=ids))
+    o = tracer.CoverageOptions(penalize_directional_coverage=0, max_coverage_paths=1 << min(n_vars, 30))
+    out = tracer.assemblies_coverage(ss, rm, asms, [(0, ref)], options=o, genotype_filter=False)
+    assert [(a.left_offset, a.right_offset) for a in out] == [(l, r) for l, r, _ in variants]
+    for i, a in enumerate(out):
+        n = 1 if is_delete[i] else 2
+        assert (a.coverage, a.pair_coverage, a.ref_depth) == ([var_count[i]] * n, [pair_count[i]] * n, ref_count[i]), i

@@ -165,3 +165,88 @@ def test_father_vcf_lines_from_the_golden_biograph(golden_dir):
         s[3] = "PI"
         return f[:9] + [":".join(s)]
     assert [without_pi(x) for x in got] == [without_pi(x) for x in want]
+
+
+# ---- calc_coverage_test.cpp:323-355 (max_coverage_paths) and :370-520 (the stress recipe) --------------------------
+def snp_with_other_coverage_case():
+    ref = tseq("abcd") + "G" + tseq("efghijklmnopqrstuvwxyz")
+    reads = [tseq("abcd") + "T" + tseq("efg"), tseq("abcd") + "A" + tseq("efg"), tseq("bcd") + "A" + tseq("efgh")]
+    return ref, reads, [(40, 41, "T"), (40, 41, "A")]
+
+
+def snp_with_other_coverage_expected(out):
+    """The expectation of the test for max_coverage_paths >= 2 (other depth of the second "should be 1?" there)."""
+    got = sorted((a.seq, a.coverage, a.other_depth, a.ref_depth) for a in out)
+    return got == [("A", [2, 2], 0, 0), ("T", [1, 1], 2, 0)]
+
+
+@pytest.mark.parametrize("paths", [3, 2, 1])
+def test_max_coverage_paths(paths):
+    ref, reads, vs = snp_with_other_coverage_case()
+    out = run(reads, [asm(l, r, s) for l, r, s in vs], parts=[(0, ref)], max_coverage_paths=paths)
+    assert snp_with_other_coverage_expected(out) == (paths >= 2)
+
+
+def stress_case(n_vars, seed):
+    """The construction of calc_coverage_stress_test: n_vars sites, each a SNP / insert / delete of one base against
+    the reference, reads spanning all sites that carry a random subset of the variants; by construction every variant's
+    coverage is its read count, its pair coverage the number of distinct pair-supported reads, the reference depth beside
+    it the number of reads without it."""
+    rng = np.random.default_rng(seed)
+    alpha = "abcdefghijklmnopqrstuvwxyz"
+    is_delete = [bool(rng.integers(0, 2)) for _ in range(n_vars)]
+    is_insert = [(not d) and bool(rng.integers(0, 2)) for d in is_delete]
+    var_count = [int(rng.integers(1, 6)) for _ in range(n_vars)]
+    total = sum(var_count)
+    ref, variants = tseq("X"), []
+    for i in range(n_vars):
+        ref += tseq(alpha[i])
+        left = len(ref)
+        if not is_insert[i]:
+            ref += "T"
+        variants.append((left, len(ref), "" if is_delete[i] else "A"))
+    ref += tseq(alpha[n_vars]) + tseq("X")
+    left_counts = list(var_count)
+    pair_count, ref_count = [0] * n_vars, [0] * n_vars
+    reads, paired = [], [set() for _ in range(n_vars)]
+    while total:
+        pair_matches = bool(rng.integers(0, 2))
+        present = []
+        for i in range(n_vars):
+            if left_counts[i] and rng.integers(0, 2):
+                present.append(True)
+                left_counts[i] -= 1
+                total -= 1
+            else:
+                present.append(False)
+                ref_count[i] += 1
+        seq = tseq("X")
+        for i in range(n_vars):
+            seq += tseq(alpha[i]) + (variants[i][2] if present[i] else ref[variants[i][0]:variants[i][1]])
+        seq += tseq(alpha[n_vars]) + tseq("X")
+        off = int(rng.integers(0, 11))
+        seq = seq[off:off + len(seq) - 10]
+        reads.append(seq)
+        if pair_matches:
+            for i in range(n_vars):
+                if present[i] and seq not in paired[i]:
+                    paired[i].add(seq)
+                    pair_count[i] += 1
+    return ref, reads, variants, paired, is_delete, var_count, pair_count, ref_count
+
+
+@pytest.mark.parametrize("n_vars", [1, 2, 3, 5, 8])
+def test_stress_recipe(n_vars):
+    ref, reads, variants, paired, is_delete, var_count, pair_count, ref_count = stress_case(n_vars, 77 + n_vars)
+    g, rl, ss, rm = world(reads)
+    asms = []
+    for i, (l, r, s) in enumerate(variants):
+        a = asm(l, r, s)
+        a.left_pair_matches = [read_id_for_seq(g, rl, ss, T.revcomp(x)) for x in sorted(paired[i])]
+        asms.append(a)
+    o = C.CoverageOptions(penalize_directional_coverage=False, max_coverage_paths=1 << min(n_vars, 60))
+    out = C.calc_coverage(g, rl, T.Scaffold([(0, ref)]), o, asms)
+    assert [(a.left_offset, a.right_offset) for a in out] == [(l, r) for l, r, _ in variants]
+    for i, a in enumerate(out):
+        n = 1 if is_delete[i] else 2
+        assert (a.coverage, a.pair_coverage, a.ref_depth) == ([var_count[i]] * n, [pair_count[i]] * n, ref_count[i]), i
