@@ -842,7 +842,8 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
 }
 
 static int cmd_discovery(int argc, char** argv) {
-  Args a = parse(argc, argv, 2, {"reads", "ref", "out", "sample", "min-overlap", "max-pair-distance", "bed", "engine"});
+  Args a = parse(argc, argv, 2, {"reads", "ref", "out", "sample", "min-overlap", "max-pair-distance", "bed", "engine", "max-ploids",
+                                 "enable-pop-tracer"});
   if (!a.has("reads") || !a.has("ref") || !a.has("out")) die("discovery: --in S.bg, --ref and --out are required");
   std::string bgdir = a.get("reads");
   // --engine push (default): the reference's discovery engine -- push tracer, anchor_dropper, pair_counter, the
@@ -850,6 +851,15 @@ static int cmd_discovery(int argc, char** argv) {
   // --engine graph: the graph_discover pipeline (branch + push_to_pair), positions and alleles only
   const std::string engine = a.get("engine", "push");
   if (engine != "push" && engine != "graph") die("discovery: --engine takes push or graph");
+  // --max-ploids (biograph_variants.cpp:162) feeds genotyper / ploid_limiter, neither of which is a step of the standard
+  // pipeline (pipeline.cpp:92-105): accepted, without effect there either.  --enable-pop-tracer (:188, default true
+  // there) adds a pop-tracer pass over the anchor drops, which this build does not have.
+  if (a.has("max-ploids") && atoi(a.get("max-ploids").c_str()) < 1) die("discovery: --max-ploids must be at least 1");
+  {
+    const std::string pop = a.get("enable-pop-tracer", "");
+    if (pop == "1" || pop == "true" || pop == "on" || pop == "yes") die("discovery: the pop tracer is not part of this build (--enable-pop-tracer false)");
+    if (pop.empty() && engine == "push") fprintf(stderr, "discovery: running as --enable-pop-tracer=false (no pop-tracer pass over anchor drops in this build)\n");
+  }
   // scaffolds (chromosomes) and their N-free supercontigs from the reference directory / .ref / FASTA; a
   // scaffold is rebuilt with N between its supercontigs so that VCF positions are scaffold coordinates
   const double t_begin = now_s();
