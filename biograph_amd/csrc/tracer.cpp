@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <mutex>
 #include <map>
@@ -868,41 +869,97 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
 }
 
 // pair_counter.cpp (calc_score without the coverage terms: the tracer computes no coverage)
+// read id -> how many live assemblies carry it: the ids in flight are the reads of a couple of thousand bases, so a
+// small open-addressing table that lives in cache (a std::unordered_map spent 0.2 s per 1 Mb piece on its nodes)
+struct IdCounter {
+  std::vector<uint32_t> key, cnt;
+  size_t mask = 0, used = 0;
+  IdCounter() { reset(1 << 12); }
+  void reset(size_t cap) {
+    key.assign(cap, ~0u);
+    cnt.assign(cap, 0);
+    mask = cap - 1;
+    used = 0;
+  }
+  size_t slot_of(uint32_t k) const {
+    size_t s = (size_t(k) * 0x9E3779B1u) & mask;
+    while (key[s] != ~0u && key[s] != k) s = (s + 1) & mask;
+    return s;
+  }
+  void inc(uint32_t k) {
+    size_t s = slot_of(k);
+    if (key[s] == ~0u) {
+      if ((used + 1) * 2 > key.size()) { regrow(); s = slot_of(k); }
+      key[s] = k;
+      ++used;
+    }
+    ++cnt[s];
+  }
+  void dec(uint32_t k) {
+    const size_t s = slot_of(k);
+    if (key[s] == k && cnt[s]) --cnt[s];
+  }
+  bool has(uint32_t k) const {
+    const size_t s = slot_of(k);
+    return key[s] == k && cnt[s] != 0;
+  }
+  void regrow() {  // drop the ids that went back to zero; double when the live ones fill a quarter
+    std::vector<std::pair<uint32_t, uint32_t>> live;
+    for (size_t i = 0; i < key.size(); ++i)
+      if (key[i] != ~0u && cnt[i]) live.emplace_back(key[i], cnt[i]);
+    size_t cap = key.size();
+    while (live.size() * 4 > cap) cap *= 2;
+    reset(cap);
+    for (auto& kv : live) {
+      const size_t s = slot_of(kv.first);
+      key[s] = kv.first;
+      cnt[s] = kv.second;
+      ++used;
+    }
+  }
+};
+
 struct PairCounter {
   const World& w;
   std::vector<bg_trace_assembly_rec>* sink;
   int64_t cur_offset = 0;
-  std::multimap<int64_t, std::vector<uint32_t>> left;
-  std::multimap<int64_t, bg_trace_assembly_rec> active, right;
-  std::unordered_map<uint32_t, int> left_ids, right_ids;
+  // pair_counter.h: m_left / m_right are multimaps that only ever receive non-decreasing keys here (assemblies
+  // arrive by left offset, leave `active` by right offset), so they are queues
+  std::deque<std::pair<int64_t, std::vector<uint32_t>>> left;
+  std::deque<std::pair<int64_t, bg_trace_assembly_rec>> right;
+  std::multimap<int64_t, bg_trace_assembly_rec> active;
+  IdCounter left_ids, right_ids;
+  int64_t last_left = INT64_MIN;
 
-  static void dec(std::unordered_map<uint32_t, int>& m, uint32_t k) { if (--m[k] == 0) m.erase(k); }
-  std::vector<uint32_t> matches(const bg_trace_assembly_rec& a, const std::unordered_map<uint32_t, int>& ids, bool forward) const {
+  std::vector<uint32_t> matches(const bg_trace_assembly_rec& a, const IdCounter& ids, bool forward) const {
     std::vector<uint32_t> out;
     for (uint32_t rid : a.rc_read_ids) {
       if (!w.has_mate(rid) || bool(w.is_forward[rid]) != forward) continue;
-      if (ids.count(w.get_rev_comp(w.get_mate(rid)))) out.push_back(rid);
+      if (ids.has(w.get_rev_comp(w.get_mate(rid)))) out.push_back(rid);
     }
     return out;
   }
-  void add(bg_trace_assembly_rec a) {
+  bool add(bg_trace_assembly_rec a) {
+    if (a.left_offset < last_left) return false;  // pair_counter expects left_offset order (pair_counter.cpp: set_expected_order)
+    last_left = a.left_offset;
     while (advance_some(a.left_offset - int64_t(w.o.max_pair_distance))) {}
-    for (uint32_t rid : a.rc_read_ids) ++right_ids[rid];
+    for (uint32_t rid : a.rc_read_ids) right_ids.inc(rid);
     const int64_t lo = a.left_offset;
-    right.emplace(lo, std::move(a));
+    right.emplace_back(lo, std::move(a));
+    return true;
   }
   void flush() { while (advance_some(0x7fffffff)) {} }
   bool advance_some(int64_t target) {
     if (cur_offset >= target) return false;
     int64_t amount = target - cur_offset;
-    if (!left.empty()) amount = std::min(amount, left.begin()->first + int64_t(w.o.max_pair_distance) - cur_offset + 1);
+    if (!left.empty()) amount = std::min(amount, left.front().first + int64_t(w.o.max_pair_distance) - cur_offset + 1);
     if (!active.empty()) amount = std::min(amount, active.begin()->first - cur_offset + 1);
-    if (!right.empty()) amount = std::min(amount, right.begin()->first - cur_offset + 1);
+    if (!right.empty()) amount = std::min(amount, right.front().first - cur_offset + 1);
     cur_offset += amount;
-    while (!right.empty() && right.begin()->first < cur_offset) {
-      bg_trace_assembly_rec a = std::move(right.begin()->second);
-      right.erase(right.begin());
-      for (uint32_t rid : a.rc_read_ids) dec(right_ids, rid);
+    while (!right.empty() && right.front().first < cur_offset) {
+      bg_trace_assembly_rec a = std::move(right.front().second);
+      right.pop_front();
+      for (uint32_t rid : a.rc_read_ids) right_ids.dec(rid);
       a.left_pair_matches = matches(a, left_ids, w.o.forward_pairs_face_inward != 0);
       const int64_t ro = a.right_offset;
       active.emplace(ro, std::move(a));
@@ -913,16 +970,16 @@ struct PairCounter {
       a.right_pair_matches = matches(a, right_ids, w.o.forward_pairs_face_inward == 0);
       std::vector<uint32_t> ids = std::move(a.rc_read_ids);
       a.rc_read_ids.clear();
-      for (uint32_t rid : ids) ++left_ids[rid];
-      left.emplace(a.right_offset, std::move(ids));
+      for (uint32_t rid : ids) left_ids.inc(rid);
+      left.emplace_back(a.right_offset, std::move(ids));
       if (a.matches_reference && !w.o.trace_reference_assemblies) continue;
       a.score += int64_t(a.min_overlap) * w.o.min_overlap_score;
       a.score += int64_t(a.left_pair_matches.size() + a.right_pair_matches.size()) * w.o.pair_match_score;
       sink->push_back(std::move(a));
     }
-    while (!left.empty() && left.begin()->first < cur_offset - int64_t(w.o.max_pair_distance)) {
-      for (uint32_t rid : left.begin()->second) dec(left_ids, rid);
-      left.erase(left.begin());
+    while (!left.empty() && left.front().first < cur_offset - int64_t(w.o.max_pair_distance)) {
+      for (uint32_t rid : left.front().second) left_ids.dec(rid);
+      left.pop_front();
     }
     return true;
   }
@@ -938,7 +995,13 @@ int download(std::vector<T>& h, const T* d, size_t n) {
 }  // namespace
 
 // reversable_tracer::assemble(start, limit) (reversable_tracer.cpp:76-145) with the push tracer.
-struct bg_tracer { World w; };
+struct bg_tracer {
+  World w;
+  // the scaffold of the last work item (see bg_tracer_trace)
+  std::vector<Extent> ext, ext_rc;
+  std::vector<uint64_t> ext_hash;
+  int64_t ext_end = -1;
+};
 
 // The host copies a tracer needs of the seqset, the readmap and the ref_map are made once per session
 // (assemble_options::seqset / readmap / rmap of a trace_ref object); bg_tracer_trace is one work item of trace_ref.
@@ -986,16 +1049,40 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
   BG_HIP(hipSetDevice(w.ctx->device));
   memset(&w.stats, 0, sizeof(w.stats));
   w.seconds_device = w.seconds_host = w.seconds_tables = w.seconds_start = w.seconds_teardown = 0;
-  std::vector<Extent> ext;
-  int64_t calc_end = 0;
+  // The pieces of a scaffold come with the same extents: the checked copy and its reverse complement are kept in the
+  // session and recognised by a hash of the bases (a whole chromosome per call otherwise: 35 ms to copy and check,
+  // 100 ms to reverse).
   const double t_ext = now_seconds();
+  std::vector<uint64_t> hashes(n_extents);
+  int64_t calc_end = 0;
   for (uint64_t i = 0; i < n_extents; ++i) {
-    ext.push_back(Extent{ext_offset[i], std::string(ext_seq[i], ext_len[i])});
-    for (char c : ext.back().seq)
-      if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return fail("bg_tracer_trace: extents hold ACGT only");
+    uint64_t h = 0xcbf29ce484222325ull ^ uint64_t(ext_offset[i]) ^ (ext_len[i] << 20);
+    const char* p = ext_seq[i];
+    uint64_t j = 0;
+    for (; j + 8 <= ext_len[i]; j += 8) {
+      uint64_t x;
+      memcpy(&x, p + j, 8);
+      h = (h ^ x) * 0x100000001b3ull;
+      h ^= h >> 29;
+    }
+    for (; j < ext_len[i]; ++j) h = (h ^ uint64_t(uint8_t(p[j]))) * 0x100000001b3ull;
+    hashes[i] = h;
     calc_end = std::max<int64_t>(calc_end, ext_offset[i] + int64_t(ext_len[i]));
   }
   if (end_pos < calc_end) return fail("bg_tracer_trace: end_pos lies before the end of the last extent");
+  if (t->ext_hash != hashes || t->ext_end != end_pos || t->ext.size() != n_extents) {
+    std::vector<Extent> fresh;
+    for (uint64_t i = 0; i < n_extents; ++i) {
+      fresh.push_back(Extent{ext_offset[i], std::string(ext_seq[i], ext_len[i])});
+      for (char c : fresh.back().seq)
+        if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return fail("bg_tracer_trace: extents hold ACGT only");
+    }
+    t->ext = std::move(fresh);
+    t->ext_rc.clear();
+    t->ext_hash = hashes;
+    t->ext_end = end_pos;
+  }
+  const std::vector<Extent>& ext = t->ext;
   w.scaffold_end = end_pos;
   if (limit_offset > end_pos) limit_offset = end_pos;
   std::unique_ptr<bg_trace_result> res(new bg_trace_result);
@@ -1003,10 +1090,11 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
   std::vector<bg_trace_assembly_rec> raw;
   const double s_ext = now_seconds() - t_ext;
   const double t_chunk = now_seconds();
-  std::vector<Extent> rc;
-  if (rev_comp) {  // scaffold::rev_comp (scaffold.cpp:163-175)
+  if (rev_comp && t->ext_rc.empty())  // scaffold::rev_comp (scaffold.cpp:163-175)
     for (auto it = ext.rbegin(); it != ext.rend(); ++it)
-      rc.push_back(Extent{end_pos - it->offset - int64_t(it->seq.size()), rev_comp_str(it->seq)});
+      t->ext_rc.push_back(Extent{end_pos - it->offset - int64_t(it->seq.size()), rev_comp_str(it->seq)});
+  const std::vector<Extent>& rc = t->ext_rc;
+  if (rev_comp) {
     BG_TRY(trace_chunk(w, rc, end_pos - limit_offset, end_pos - start_offset, &raw));
   } else {
     BG_TRY(trace_chunk(w, ext, start_offset, limit_offset, &raw));
@@ -1030,10 +1118,12 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
     raw = std::move(dropped);
   }
   const double s_drop = now_seconds() - t_drop;
+  const double t_pair = now_seconds();
   std::vector<bg_trace_assembly_rec> counted;
   if (pair_count) {
     PairCounter pc{w, &counted};
-    for (auto& a : raw) pc.add(std::move(a));
+    for (auto& a : raw)
+      if (!pc.add(std::move(a))) return fail("bg_tracer_trace: pair_counter: assemblies out of left-offset order");
     pc.flush();
   } else {
     counted = std::move(raw);
@@ -1050,11 +1140,12 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
         for (uint32_t& rid : *m) rid = w.get_rev_comp(rid);
     }
   }
+  const double s_pair = now_seconds() - t_pair;
   res->a = std::move(counted);
   res->stats = w.stats;
   if (getenv("BG_TRACER_TIMING"))
-    fprintf(stderr, "bg_tracer_trace: %.3f s in all (extents %.3f, chunk %.3f, anchor drop %.3f): tables %.3f s, start %.3f s, device rounds %.3f s, host replay %.3f s, teardown %.3f s (%d threads), %llu traces\n",
-            now_seconds() - t_call, s_ext, s_chunk, s_drop, w.seconds_tables, w.seconds_start, w.seconds_device, w.seconds_host, w.seconds_teardown, g_tracer_threads, (unsigned long long)w.stats.traces);
+    fprintf(stderr, "bg_tracer_trace: %.3f s in all (extents %.3f, chunk %.3f, anchor drop %.3f, pair counter + reverse %.3f): tables %.3f s, start %.3f s, device rounds %.3f s, host replay %.3f s, teardown %.3f s (%d threads), %llu traces\n",
+            now_seconds() - t_call, s_ext, s_chunk, s_drop, s_pair, w.seconds_tables, w.seconds_start, w.seconds_device, w.seconds_host, w.seconds_teardown, g_tracer_threads, (unsigned long long)w.stats.traces);
   // the chunk's tables are not kept between work items
   std::vector<std::pair<int32_t, uint64_t>>().swap(w.position_entries);
   std::vector<std::pair<uint64_t, int32_t>>().swap(w.entry_positions);
