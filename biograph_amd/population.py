@@ -141,6 +141,70 @@ def sharded_discover(comm, seqsets, readmaps, scaffolds, min_overlap, split_size
     return {s: sorted(x for part in every for x in part[s]) for s in samples}
 
 
+_ASM_FIELDS = ("left_offset", "right_offset", "seq", "left_anchor_len", "right_anchor_len", "min_overlap", "trace_steps",
+               "left_anchor_ambiguous_bases", "matches_reference", "score", "left_pair_matches", "right_pair_matches")
+
+
+def sharded_discovery_vcf(comm, seqsets, readmaps, scaffolds, min_overlap=None, split_size=SCAFFOLD_SPLIT_SIZE,
+                          max_pair_distance=1000, ref_maps=None, trace_options=None, coverage_options=None):
+    """The reference's discovery engine over a population (configs[4]): every rank traces its share of the work items
+    (sample, reference piece) with the push tracer in both directions; the assemblies of a (sample, scaffold) go to
+    the rank that owns that pair, which runs the serial pipeline, calc_coverage and the genotype filter on its replica
+    and formats the VCF records (what one `bgbinary discovery --engine push` does per sample).  Returns, on every rank,
+    {sample: [VCF record lines in scaffold order]}.  Assemblies cross ranks as Python objects (a few kB per piece):
+    all_gather_obj; the GPU work (tracing, coverage walks) never leaves its rank.  The result does not depend on the
+    number of ranks: the owner orders what it receives by (piece start, direction, position in the piece's output)."""
+    from . import tracer
+    ranks = comm.local_ranks
+    samples = sorted(readmaps[ranks[0]])
+    names = list(scaffolds)
+    chunks = ref_chunks([(name, 0, len(seq)) for name, seq in scaffolds.items()], split_size)
+    work = [(s, c) for s in samples for c in chunks]
+    ext = {name: extents_of(seq) for name, seq in scaffolds.items()}
+    if ref_maps is None:
+        raise ValueError("sharded_discovery_vcf: the push tracer needs ref_maps")
+
+    def options_for(rm):
+        if trace_options is not None:
+            return trace_options
+        mo = min_overlap if min_overlap is not None else int(0.7 * rm.max_read_len())  # biograph_variants.cpp:674
+        return tracer.TraceOptions(min_overlap=mo, max_pair_distance=max_pair_distance)
+
+    traced = {}
+    for r in ranks:
+        mine, sessions = [], {}
+        for s, (name, a, lim) in chunks_of_rank(work, r, comm.world):
+            if s not in sessions:
+                sessions[s] = tracer.PushTracer(seqsets[r], readmaps[r][s], ref_maps[r], options_for(readmaps[r][s]))
+            for rev in (False, True):
+                found = sessions[s].trace(ext[name], start=a, limit=lim, end_pos=len(scaffolds[name]), rev_comp=rev)
+                for i, x in enumerate(found):
+                    mine.append(((s, name), (a, int(rev), i), tuple(getattr(x, f) for f in _ASM_FIELDS)))
+        for t in sessions.values():
+            t.close()
+        traced[r] = mine
+    every = comm.all_gather_obj(traced)[ranks[0]]
+    pairs = [(s, name) for s in samples for name in names]
+    lines = {}
+    for r in ranks:
+        out = {}
+        for k, (s, name) in enumerate(pairs):
+            if k % comm.world != r:
+                continue
+            items = sorted((order, fields) for part in every for key, order, fields in part if key == (s, name))
+            asms = [tracer.TraceAssembly(**dict(zip(_ASM_FIELDS, fields))) for _, fields in items]
+            opt = options_for(readmaps[r][s])
+            sections = tracer.process_assemblies(asms, ext[name], end_pos=len(scaffolds[name]), options=opt)
+            _, recs = tracer.assemblies_coverage(seqsets[r], readmaps[r][s], sections, ext[name], end_pos=len(scaffolds[name]),
+                                                 options=coverage_options, vcf_name=name)
+            out[(s, name)] = recs
+        lines[r] = out
+    merged = {}
+    for part in comm.all_gather_obj(lines)[ranks[0]]:
+        merged.update(part)
+    return {s: [x for name in names for x in merged[(s, name)]] for s in samples}
+
+
 def gathered_readmap(comm, ctxs, seqsets, corrected, marks=None, is_paired=True):
     """One sample's readmap on every rank's replica of the merged seqset.  marks[r] = uint8 [shard entries]: the
     sample's row of SeqsetSlice.input_marks (None: the seqset is the sample's own).  corrected[r] = (words, lens, max_len) of

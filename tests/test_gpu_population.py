@@ -198,3 +198,46 @@ def test_sharded_discover_with_the_push_tracer(ctx):
         assert all(0 <= lo < ro <= len(scaffolds["1"]) + 2000 for _, lo, ro, _ in results[0])
     finally:
         rmap.free()
+
+
+def test_sharded_discovery_vcf_is_the_engine_of_one_process(ctx):
+    """configs[4]'s discover step with the reference's engine: (sample, piece) work items traced on P simulated ranks,
+    pipeline + coverage + genotype on the owner of (sample, scaffold): the VCF records do not depend on P and equal what
+    one process gets by tracing all pieces itself (the flow of `bgbinary discovery --engine push`)."""
+    from biograph_amd import tracer
+    G = 40_000
+    seq, offs, n, genome = synth.make_reads(genome_len=G, coverage=30, read_len=150, seed=SEED, device="cpu", sample=2,
+                                            return_genome=True)
+    reads = O.unpack_strings(seq.numpy(), offs.numpy().astype(np.uint64))
+    prm = ctx.default_params()
+    ss, rm, cor = _single_gpu_sample(ctx, reads, prm)
+    ref = np.frombuffer(b"ACGT", np.uint8)[genome.numpy()].tobytes().decode()
+    scaffolds = {"1": ref[:25_000] + "N" * 30 + ref[25_030:], "2": ref[30_000:38_000]}
+    rmap = tracer.reference_ref_map(ss, [ref[:25_000], ref[25_030:], ref[30_000:38_000]])
+    try:
+        results = []
+        for P in (1, 3):
+            comm = sharded.LocalSimComm(P)
+            got = population.sharded_discovery_vcf(comm, {r: ss for r in range(P)}, {r: {"a": rm, "b": rm} for r in range(P)},
+                                                   scaffolds, split_size=8_000, ref_maps={r: rmap for r in range(P)})
+            results.append(got)
+        assert results[0] == results[1]
+        assert results[0]["a"] == results[0]["b"] and len(results[0]["a"]) > 20
+        # the same by hand in one process
+        opt = tracer.TraceOptions(min_overlap=105)
+        want = []
+        session = tracer.PushTracer(ss, rm, rmap, opt)
+        for name, sq in scaffolds.items():
+            ext = population.extents_of(sq)
+            asms = []
+            for start in range(0, len(sq), 8_000):
+                for rev in (False, True):
+                    asms += session.trace(ext, start=start, limit=min(len(sq), start + 8_000), end_pos=len(sq), rev_comp=rev)
+            sections = tracer.process_assemblies(asms, ext, end_pos=len(sq), options=opt)
+            want += tracer.assemblies_coverage(ss, rm, sections, ext, end_pos=len(sq), vcf_name=name)[1]
+        session.close()
+        assert results[0]["a"] == want
+        snps = [x.split("\t") for x in want if len(x.split("\t")[3]) == 1 and len(x.split("\t")[4]) == 1]
+        assert len(snps) > 10 and all(f[6] == "PASS" and f[8] == "GT:PG:GQ:PI:OV:DP:AD:PDP:PAD" for f in snps)
+    finally:
+        rmap.free()
