@@ -167,7 +167,7 @@ def sharded_discovery_vcf(comm, seqsets, readmaps, scaffolds, min_overlap=None, 
     def options_for(rm):
         if trace_options is not None:
             return trace_options
-        mo = min_overlap if min_overlap is not None else int(0.7 * rm.max_read_len())  # biograph_variants.cpp:674
+        mo = min_overlap if min_overlap is not None else int(0.7 * rm.max_read_len)  # biograph_variants.cpp:674
         return tracer.TraceOptions(min_overlap=mo, max_pair_distance=max_pair_distance)
 
     traced = {}
