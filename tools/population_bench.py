@@ -30,8 +30,9 @@ def main():
     ap.add_argument("--sim-ranks", type=int, default=0, help="simulate this many ranks in one process (LocalSimComm)")
     ap.add_argument("--discover-bases", type=int, default=-1, help="reference bases walked per sample (0 = skip)")
     ap.add_argument("--split-size", type=int, default=1_000_000)
-    ap.add_argument("--engine", default="graph", choices=["graph", "push"],
-                    help="graph = the graph-discover pipeline per chunk; push = the production push tracer (both directions)")
+    ap.add_argument("--engine", default="graph", choices=["graph", "push", "vcf"],
+                    help="graph = the graph-discover pipeline per chunk; push = the production push tracer (both directions); "
+                         "vcf = push tracer + pipeline + coverage + genotype: VCF records per sample")
     ap.add_argument("--out", default="/dev/shm/bg_population_seqset")
     ap.add_argument("--check", action="store_true", help="compare with the single-GPU merge (small inputs only)")
     args = ap.parse_args()
@@ -129,16 +130,22 @@ def main():
                 scaffolds[str(i + 1)] = ref[at:min(at + ln, region)]
                 at += ln
         ref_maps = None
-        if args.engine == "push":
+        if args.engine in ("push", "vcf"):
             from biograph_amd import tracer
             whole = [x for name in scaffolds for _, x in population.extents_of(scaffolds[name])]
             ref_maps = {r: tracer.reference_ref_map(replicas[r], whole) for r in ranks}
         t0 = clock()
-        mine = population.sharded_discover(comm, replicas, readmaps, scaffolds, min_overlap=int(0.7 * args.read_len),
-                                           split_size=args.split_size, gather=False, engine=args.engine, ref_maps=ref_maps)
-        t_rank = time.perf_counter() - t0
-        t_disc = clock() - t0
-        n_calls = sharded._all_sum(comm, {r: sum(len(v) for v in mine[r].values()) for r in ranks})
+        if args.engine == "vcf":  # the reference's engine end to end: VCF records per sample
+            vcf = population.sharded_discovery_vcf(comm, replicas, readmaps, scaffolds, split_size=args.split_size, ref_maps=ref_maps)
+            t_rank = time.perf_counter() - t0
+            t_disc = clock() - t0
+            n_calls = sum(len(v) for v in vcf.values())
+        else:
+            mine = population.sharded_discover(comm, replicas, readmaps, scaffolds, min_overlap=int(0.7 * args.read_len),
+                                               split_size=args.split_size, gather=False, engine=args.engine, ref_maps=ref_maps)
+            t_rank = time.perf_counter() - t0
+            t_disc = clock() - t0
+            n_calls = sharded._all_sum(comm, {r: sum(len(v) for v in mine[r].values()) for r in ranks})
         out["discover"] = {"engine": args.engine, "reference_bases_per_sample": region, "split_size": args.split_size,
                            "work_items": args.samples * len(population.ref_chunks([(k, 0, len(v)) for k, v in scaffolds.items()],
                                                                                   args.split_size)),
