@@ -68,7 +68,7 @@ def cpu_baseline(ctx, sample_genome, coverage, read_len, seed, dev):
     same = all(gss.part(p) == want[p] for p in bg.PART_NAMES)
     want_rm = orm.parts()
     same_rm = all(grm.part(p) == want_rm[p] for p in bg.READMAP_PART_NAMES)
-    for h in (grm, gss, gc, gks, r):
+    for h in (gc, gks, r):
         h.free()
     out = {"value": bases / dt / 1e9, "unit": "Gbases/s", "cores": threads, "node_cores": os.cpu_count(), "kind": "port",
            "sample": "%d reads x %d bp (%.1f Mbases, %dx of a %d bp synthetic genome), %.1f s on %d threads, %d entries" % (
@@ -99,6 +99,47 @@ def cpu_baseline(ctx, sample_genome, coverage, read_len, seed, dev):
                            "what": "graph-discover drivers (Python twin) over the oracle's walks, min_overlap 105"}
     except Exception as e:  # the baseline of the discover leg must not take the build's line down
         out["discover"] = {"error": repr(e)}
+    # the reference's discovery engine on the CPU: the oracle's push tracer (both directions, anchor_dropper,
+    # pair_counter), serial pipeline, calc_coverage, genotype filter and VCF lines on the first stretch of the
+    # reference, and the same through the library on the GPU build of the same reads: the lines must be equal
+    try:
+        from oracle import align as OA
+        from oracle import coverage as OC
+        from oracle import tracer as OT
+        from biograph_amd import tracer as GT
+        region = min(12000, int(genome.numel()))
+        codes = genome[:region].cpu().numpy().astype(np.uint8)
+        ref = np.frombuffer(b"ACGT", np.uint8)[codes].tobytes().decode()
+        mo = int(0.7 * read_len)
+        t0 = time.perf_counter()
+        graph = OT.Graph(oss, orm, oss.ref_map_build(codes, np.array([0], np.uint64), np.array([region], np.uint64)))
+        o, ao, sc = OT.Options(min_overlap=mo), OA.AlignOptions(min_overlap=mo), OT.Scaffold([(0, ref)])
+        traced = []
+        for rev in (False, True):
+            traced += OT.reversable_trace(graph, sc, o, rev_comp=rev, anchor_drop=lambda s_, emit: OA.AnchorDropper(ao, s_, emit))
+        _, sections = OA.variants_pipeline(ao, sc, traced, through_vcf_pad=True)
+        co = OC.CoverageOptions()
+        kept = OC.simple_genotype_filter(co, OC.calc_coverage(graph, [int(x) for x in orm.get("read_len")], sc, co, sections))
+        want = [OC.vcf_line(co, "chrS", lambda off, k: ref[off:off + k], a) for a in kept]
+        edt = time.perf_counter() - t0
+        rmap = GT.reference_ref_map(gss, [ref])
+        t0 = time.perf_counter()
+        gopt = GT.TraceOptions(min_overlap=mo)
+        gtraced = []
+        for rev in (False, True):
+            gtraced += GT.push_trace(gss, grm, rmap, [(0, ref)], rev_comp=rev, options=gopt)
+        gsections = GT.process_assemblies(gtraced, [(0, ref)], options=gopt)
+        _, got = GT.assemblies_coverage(gss, grm, gsections, [(0, ref)], vcf_name="chrS")
+        gdt = time.perf_counter() - t0
+        rmap.free()
+        out["discovery_engine"] = {"region_bases": region, "seconds": round(edt, 2), "vcf_records": len(want), "cores": 1,
+                                   "vcf_records_per_s": round(len(want) / max(edt, 1e-9), 2),
+                                   "gpu_seconds_same_region": round(gdt, 3), "equals_gpu_vcf_lines": bool(got == want),
+                                   "what": "oracle/tracer.py + align.py + coverage.py (pure Python restatement), min_overlap %d" % mo}
+    except Exception as e:
+        out["discovery_engine"] = {"error": repr(e)}
+    for h in (grm, gss):
+        h.free()
     return out
 
 
