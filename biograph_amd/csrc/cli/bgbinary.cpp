@@ -22,6 +22,9 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -738,9 +741,19 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   opt.max_pair_distance = uint64_t(max_pair_distance);
   bg_coverage_options cov;
   bg_coverage_options_default(&cov);
-  bg_tracer* tracer = nullptr;
+  // trace_ref runs its work items on the process's thread pool (trace_ref.cpp:105-140); here: --threads sessions
+  // (default 8), each with its own context (stream + allocator) and its own host copies, side by side on the one GPU
+  int n_threads = atoi(a.get("threads", "8").c_str());
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 64) n_threads = 64;
   const double t_open0 = now_s();
-  check(bg_tracer_open(ctx, ss, rm, static_cast<const uint8_t*>(d_map), &opt, &tracer), "bg_tracer_open");
+  std::vector<bg_ctx*> wctx(size_t(n_threads), nullptr);
+  std::vector<bg_tracer*> tracers(size_t(n_threads), nullptr);
+  for (int t = 0; t < n_threads; ++t) {
+    wctx[size_t(t)] = t == 0 ? ctx : nullptr;
+    if (t) check(bg_ctx_create(0, nullptr, &wctx[size_t(t)]), "bg_ctx_create");
+    check(bg_tracer_open(wctx[size_t(t)], ss, rm, static_cast<const uint8_t*>(d_map), &opt, &tracers[size_t(t)]), "bg_tracer_open");
+  }
   const double t_open = now_s() - t_open0;
   time_t now = time(nullptr);
   char date[16];
@@ -788,20 +801,41 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     } else {
       ranges.emplace_back(0, int64_t(seq.size()));
     }
-    std::vector<bg_trace_result*> items;
-    double t1 = now_s();
+    struct Work { int64_t start, limit; int rev; };
+    std::vector<Work> work;
     for (auto& rg : ranges)
       for (int64_t start = rg.first; start < rg.second; start += int64_t(opt.scaffold_split_size)) {
         const int64_t limit = std::min<int64_t>(rg.second, start + int64_t(opt.scaffold_split_size));
         ++pieces;
-        for (int rev = 0; rev < 2; ++rev) {
-          bg_trace_result* r = nullptr;
-          check(bg_tracer_trace(tracer, es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), start, limit, rev, 1, &r),
-                "bg_tracer_trace");
-          n_traced += bg_trace_result_size(r);
-          items.push_back(r);
-        }
+        for (int rev = 0; rev < 2; ++rev) work.push_back(Work{start, limit, rev});
       }
+    std::vector<bg_trace_result*> items(work.size(), nullptr);
+    double t1 = now_s();
+    {
+      std::atomic<size_t> next(0);
+      std::mutex err_mu;
+      std::string err;
+      auto run = [&](int t) {
+        for (;;) {
+          const size_t i = next.fetch_add(1);
+          if (i >= work.size()) return;
+          if (bg_tracer_trace(tracers[size_t(t)], es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), work[i].start,
+                              work[i].limit, work[i].rev, 1, &items[i]) != BG_OK) {
+            std::lock_guard<std::mutex> l(err_mu);
+            if (err.empty()) err = bg_last_error();
+            next.store(work.size());
+            return;
+          }
+        }
+      };
+      const int nt = int(std::min<size_t>(size_t(n_threads), work.size()));
+      std::vector<std::thread> pool;
+      for (int t = 1; t < nt; ++t) pool.emplace_back(run, t);
+      run(0);
+      for (auto& th : pool) th.join();
+      if (!err.empty()) die("bg_tracer_trace: " + err);
+    }
+    for (auto* r : items) n_traced += bg_trace_result_size(r);
     t_trace += now_s() - t1;
     t1 = now_s();
     bg_trace_result *sections = nullptr, *kept = nullptr;
@@ -831,19 +865,22 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     }
     bg_trace_result_free(kept);
   }
-  bg_tracer_close(tracer);
+  for (int t = 0; t < n_threads; ++t) {
+    bg_tracer_close(tracers[size_t(t)]);
+    if (t) bg_ctx_destroy(wctx[size_t(t)]);
+  }
   bg_dev_free(ctx, d_map);
   write_file(a.get("out"), vcf);
-  fprintf(stderr, "%llu variants over %zu scaffold(s) in %llu piece(s) x 2 directions, min overlap %u: %.2f s (refmap %.2f, session %.2f, tracing %.2f "
+  fprintf(stderr, "%llu variants over %zu scaffold(s) in %llu piece(s) x 2 directions on %d tracer session(s), min overlap %u: %.2f s (refmap %.2f, sessions %.2f, tracing %.2f "
                   "[%llu assemblies], pipeline %.2f [%llu sections], coverage + genotype %.2f)\n",
-          (unsigned long long)n_var, recs.size(), (unsigned long long)pieces, min_overlap, now_s() - t0, t_refmap, t_open, t_trace,
+          (unsigned long long)n_var, recs.size(), (unsigned long long)pieces, n_threads, min_overlap, now_s() - t0, t_refmap, t_open, t_trace,
           (unsigned long long)n_traced, t_pipe, (unsigned long long)n_sections, t_cov);
   return 0;
 }
 
 static int cmd_discovery(int argc, char** argv) {
   Args a = parse(argc, argv, 2, {"reads", "ref", "out", "sample", "min-overlap", "max-pair-distance", "bed", "engine", "max-ploids",
-                                 "enable-pop-tracer"});
+                                 "enable-pop-tracer", "threads"});
   if (!a.has("reads") || !a.has("ref") || !a.has("out")) die("discovery: --in S.bg, --ref and --out are required");
   std::string bgdir = a.get("reads");
   // --engine push (default): the reference's discovery engine -- push tracer, anchor_dropper, pair_counter, the

@@ -616,6 +616,13 @@ class HostPool {
   // f(t) for t in [0, parts): part 0 on the calling thread, the rest on the workers
   void run(int parts, const std::function<void(int)>& f) {
     if (parts <= 1) { f(0); return; }
+    // one job at a time: a second session tracing on another thread at the same moment runs its share inline
+    // (callers that run several sessions side by side have their parallelism already)
+    std::unique_lock<std::mutex> busy(job_mu_, std::try_to_lock);
+    if (!busy.owns_lock()) {
+      for (int t = 0; t < parts; ++t) f(t);
+      return;
+    }
     {
       std::unique_lock<std::mutex> l(mu_);
       fn_ = &f;
@@ -663,7 +670,7 @@ class HostPool {
     }
   }
   std::vector<std::thread> workers_;
-  std::mutex mu_;
+  std::mutex mu_, job_mu_;
   std::condition_variable cv_work_, cv_done_;
   const std::function<void(int)>* fn_ = nullptr;
   int parts_ = 0, left_ = 0;

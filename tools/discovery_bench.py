@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--seed", type=int, default=20261002)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--threads", type=int, default=8)
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -76,7 +77,7 @@ def main():
         return 1
     vcf = os.path.join(tmp, "v.vcf")
     t0 = time.perf_counter()
-    r = subprocess.run([exe, "discovery", "--in", bg, "--ref", fa, "--out", vcf], capture_output=True, text=True)
+    r = subprocess.run([exe, "discovery", "--in", bg, "--ref", fa, "--out", vcf, "--threads", str(args.threads)], capture_output=True, text=True)
     t_disc = time.perf_counter() - t0
     if r.returncode:
         print("discovery FAILED", r.stderr[-500:])
@@ -84,7 +85,7 @@ def main():
     summary = [x for x in r.stderr.splitlines() if "variants over" in x]
     stages = {}
     if summary:
-        m = re.search(r"refmap ([\d.]+), session [\d.]+, tracing ([\d.]+) \[(\d+) assemblies\], pipeline ([\d.]+) \[(\d+) sections\], coverage \+ genotype ([\d.]+)", summary[-1])
+        m = re.search(r"refmap ([\d.]+), sessions [\d.]+, tracing ([\d.]+) \[(\d+) assemblies\], pipeline ([\d.]+) \[(\d+) sections\], coverage \+ genotype ([\d.]+)", summary[-1])
         if m:
             stages = {"refmap_s": float(m.group(1)), "tracing_s": float(m.group(2)), "traced_assemblies": int(m.group(3)),
                       "pipeline_s": float(m.group(4)), "sections": int(m.group(5)), "coverage_genotype_s": float(m.group(6))}
