@@ -415,6 +415,7 @@ class Deduper {
       pm.erase(std::unique(pm.begin(), pm.end()), pm.end());
     }
     check(target.left_anchor_len >= a.left_anchor_len && target.right_anchor_len >= a.right_anchor_len, "deduper: combined anchors shrink");
+    merge_bookkeeping(target, a);
     target.trace_steps = std::max(target.trace_steps, a.trace_steps);
     target.min_overlap = std::max(target.min_overlap, a.min_overlap);
     target.left_anchor_ambiguous_bases = std::max(target.left_anchor_ambiguous_bases, a.left_anchor_ambiguous_bases);
@@ -495,6 +496,7 @@ class ExactDeduper {
         std::sort(pm.begin(), pm.end());
         pm.erase(std::unique(pm.begin(), pm.end()), pm.end());
       }
+      merge_bookkeeping(q, a);
       return;
     }
     const int64_t lo = a.left_offset;
@@ -538,6 +540,46 @@ class VcfPadder : public SortedOutput {
 }  // namespace
 
 bool canon_assembly_less(const bg_trace_assembly_rec& a, const bg_trace_assembly_rec& b) { return canon_less(a, b); }
+
+void merge_bookkeeping(bg_trace_assembly_rec& target, const bg_trace_assembly_rec& a) {
+  target.merged += 1 + a.merged;
+  if (target.has_ml || a.has_ml) {
+    check(target.has_ml && a.has_ml, "ML features on one side of a merge only");
+    if (target.ml_alt_len < a.ml_alt_len) {
+      target.ml_score = a.ml_score;
+      target.ml_refspan = a.ml_refspan;
+      target.ml_lanch = a.ml_lanch;
+      target.ml_ranch = a.ml_ranch;
+      target.ml_refgc = a.ml_refgc;
+      target.ml_altgc = a.ml_altgc;
+      target.ml_alt_len = a.ml_alt_len;
+    }
+  }
+}
+
+// add_ml_features of biograph_variants.cpp:746-779: on every discovered assembly, right behind the sorter
+static void add_ml_features(const ScaffoldView& sc, bg_trace_assembly_rec& a) {
+  a.has_ml = true;
+  a.ml_score = int(a.score);
+  a.ml_refspan = int(a.right_offset - a.left_offset);
+  a.ml_lanch = a.left_anchor_len;
+  a.ml_ranch = a.right_anchor_len;
+  a.ml_refgc = 0;
+  if (a.ml_refspan > 0) {
+    int gc = 0;
+    const ScaffoldView sub = sc.sub(a.left_offset, a.right_offset - a.left_offset);
+    for (const auto& e : sub.ext)
+      for (int64_t i = 0; i < e.n; ++i) gc += e.p[i] == 'G' || e.p[i] == 'C';
+    a.ml_refgc = float(gc) / a.ml_refspan;
+  }
+  a.ml_altgc = 0;
+  if (!a.seq.empty()) {
+    int gc = 0;
+    for (char c : a.seq) gc += c == 'G' || c == 'C';
+    a.ml_altgc = float(gc) / int(a.seq.size());
+  }
+  a.ml_alt_len = a.seq.size();
+}
 
 // ---- scaffold.cpp -----------------------------------------------------------------------------------------------------
 ScaffoldView ScaffoldView::sub(int64_t start, int64_t len) const {
@@ -829,6 +871,9 @@ extern "C" int bg_assemblies_process(const bg_trace_result* const* in, uint32_t 
     }
     if (drop) drop->flush();
     if (steps & BG_STEP_SORT) std::stable_sort(all.begin(), all.end(), canon_less);
+    if (o.output_ml_features)  // report_discovered_assemblies_func (pipeline.cpp:49-51): once per discovered assembly
+      for (auto& a : all)
+        if (!a.has_ml) add_ml_features(sc, a);
     for (auto& a : all) sink(std::move(a));
     if (trim) trim->flush();
     if (dedup) dedup->flush();
@@ -842,5 +887,35 @@ extern "C" int bg_assemblies_process(const bg_trace_result* const* in, uint32_t 
     return BG_EINVAL;
   }
   *out = res.release();
+  return BG_OK;
+}
+
+extern "C" int bg_trace_result_ml(const bg_trace_result* r, uint64_t i, bg_assembly_ml* out) {
+  if (!r || !out || i >= r->a.size()) { set_error("bg_trace_result_ml: bad argument"); return BG_EINVAL; }
+  const bg_trace_assembly_rec& a = r->a[i];
+  out->has_ml = a.has_ml ? 1 : 0;
+  out->score = a.ml_score;
+  out->refspan = a.ml_refspan;
+  out->lanch = a.ml_lanch;
+  out->ranch = a.ml_ranch;
+  out->refgc = a.ml_refgc;
+  out->altgc = a.ml_altgc;
+  out->alt_len = a.ml_alt_len;
+  out->merged = a.merged;
+  return BG_OK;
+}
+
+extern "C" int bg_trace_result_set_ml(bg_trace_result* r, uint64_t i, const bg_assembly_ml* in) {
+  if (!r || !in || i >= r->a.size()) { set_error("bg_trace_result_set_ml: bad argument"); return BG_EINVAL; }
+  bg_trace_assembly_rec& a = r->a[i];
+  a.has_ml = in->has_ml != 0;
+  a.ml_score = in->score;
+  a.ml_refspan = in->refspan;
+  a.ml_lanch = in->lanch;
+  a.ml_ranch = in->ranch;
+  a.ml_refgc = in->refgc;
+  a.ml_altgc = in->altgc;
+  a.ml_alt_len = in->alt_len;
+  a.merged = in->merged;
   return BG_OK;
 }

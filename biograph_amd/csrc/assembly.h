@@ -36,6 +36,12 @@ struct bg_trace_assembly_rec {  // variants::assembly (assemble.h:285-380), the 
   std::vector<int> coverage, pair_coverage;  // interbase: seq.size() + 1 values
   int other_depth = 0, other_pair_depth = 0, ref_depth = 0, strand_count = 0;
   double genotype_quality = 0;
+  // assembly_ml_features (assemble.h:191-199) and the number of assemblies merged into this one (merged_assembly_ids)
+  bool has_ml = false;
+  int ml_score = 0, ml_refspan = 0, ml_lanch = 0, ml_ranch = 0;
+  float ml_refgc = 0, ml_altgc = 0;
+  uint64_t ml_alt_len = 0;
+  uint32_t merged = 0;
 };
 
 struct bg_trace_result {
@@ -55,7 +61,9 @@ struct ScaffoldView {
   int64_t shared_suffix_length(const char* s, int64_t n) const;  // rev_comp().shared_prefix_length(rev_comp(seq)), align.cpp:34-35
 };
 
-bool canon_assembly_less(const bg_trace_assembly_rec& a, const bg_trace_assembly_rec& b);  // canon_assembly_order (align.cpp)
+bool canon_assembly_less(const bg_trace_assembly_rec& a, const bg_trace_assembly_rec& b);
+// what deduper::combine / exact_deduper keep of the assembly they swallow (dedup.cpp:51-53,71-78,171-183)
+void merge_bookkeeping(bg_trace_assembly_rec& target, const bg_trace_assembly_rec& a);  // canon_assembly_order (align.cpp)
 
 struct CheckFailed { std::string what; };  // a CHECK(...) of the reference: it aborts there; here the ABI call fails
 

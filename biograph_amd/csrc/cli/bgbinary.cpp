@@ -741,6 +741,13 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   opt.max_pair_distance = uint64_t(max_pair_distance);
   bg_coverage_options cov;
   bg_coverage_options_default(&cov);
+  // biograph_variants.cpp:686 always writes the ML feature columns (LASCORE ... NUMASM); --ml-features false leaves them out
+  {
+    const std::string ml = a.get("ml-features", "true");
+    const int on = !(ml == "false" || ml == "0" || ml == "off" || ml == "no");
+    opt.output_ml_features = on;
+    cov.output_ml_features = on;
+  }
   // trace_ref runs its work items on the process's thread pool (trace_ref.cpp:105-140); here: --threads sessions
   // (default 8), each with its own context (stream + allocator) and its own host copies, side by side on the one GPU
   int n_threads = atoi(a.get("threads", "8").c_str());
@@ -773,6 +780,16 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
                     "##FORMAT=<ID=PG,Number=1,Type=String,Description=\"Phased genotype\">\n"
                     "##FORMAT=<ID=PI,Number=1,Type=Integer,Description=\"Phase group\">\n"
                     "##FORMAT=<ID=GQ,Number=1,Type=Integer,Description=\"Genotype quality\">\n"
+                    + (cov.output_ml_features ? std::string(
+                    "##FORMAT=<ID=LASCORE,Number=1,Type=Integer,Description=\"Score of longest assembly\">\n"
+                    "##FORMAT=<ID=LAREFSPAN,Number=1,Type=Integer,Description=\"Ref span length of longest assembly\">\n"
+                    "##FORMAT=<ID=LARANCH,Number=1,Type=Integer,Description=\"Right anchor length of longest assembly\">\n"
+                    "##FORMAT=<ID=LALANCH,Number=1,Type=Integer,Description=\"Leftanchor length of longest assembly\">\n"
+                    "##FORMAT=<ID=LAREFGC,Number=1,Type=Float,Description=\"Portion of G/C bases in ref span of longest assembly\">\n"
+                    "##FORMAT=<ID=LAALTGC,Number=1,Type=Float,Description=\"Portion of G/C bases in sequence of longest assembly\">\n"
+                    "##FORMAT=<ID=LAALTSEQLEN,Number=1,Type=Integer,Description=\"Sequence length of longest assembly\">\n"
+                    "##FORMAT=<ID=NUMASM,Number=1,Type=Integer,Description=\"Number of assemblies that independently produced this variant\">\n")
+                                                : std::string()) +
                     "##ALT=<ID=INS,Description=\"Insertion\">\n##ALT=<ID=DEL,Description=\"Deletion\">\n";
   for (auto& rec : recs) vcf += "##contig=<ID=" + rec.first + ",length=" + std::to_string(rec.second.size()) + ">\n";
   vcf += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + sample + "\n";
@@ -880,7 +897,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
 
 static int cmd_discovery(int argc, char** argv) {
   Args a = parse(argc, argv, 2, {"reads", "ref", "out", "sample", "min-overlap", "max-pair-distance", "bed", "engine", "max-ploids",
-                                 "enable-pop-tracer", "threads"});
+                                 "enable-pop-tracer", "threads", "ml-features"});
   if (!a.has("reads") || !a.has("ref") || !a.has("out")) die("discovery: --in S.bg, --ref and --out are required");
   std::string bgdir = a.get("reads");
   // --engine push (default): the reference's discovery engine -- push tracer, anchor_dropper, pair_counter, the

@@ -46,6 +46,7 @@ extern "C" void bg_coverage_options_default(bg_coverage_options* o) {
   o->min_pair_depth = 0;                 // assemble.h:710
   o->min_read_depth = 1;                 // assemble.h:707
   o->vcf_sv_size_threshold = 20;         // assemble.h:724
+  o->output_ml_features = 0;             // assemble.h:730 (biograph_variants.cpp:686 switches it on)
 }
 
 namespace {
@@ -775,8 +776,19 @@ extern "C" int bg_vcf_record(const bg_trace_result* r, uint64_t i, const char* s
   snprintf(sample, sizeof(sample), "%s:%s:%d:%llu:%u:%d:%d,%d:%d:%d,%d", gt, pg, int(a.genotype_quality * 100),
            (unsigned long long)assembly_id, a.min_overlap, a.other_depth + min_depth + a.ref_depth, a.ref_depth, min_depth,
            a.other_pair_depth + min_pair, 0, min_pair);
-  line += "\tGT:PG:GQ:PI:OV:DP:AD:PDP:PAD\t";
+  line += "\tGT:PG:GQ:PI:OV:DP:AD:PDP:PAD";
+  if (o.output_ml_features) {  // ploidless_vcf_export.cpp:128-130,155-165 (LARANCH prints the LEFT anchor, as there)
+    if (!a.has_ml) { set_error("bg_vcf_record: missing ML features on an assembly (bg_assemblies_process with output_ml_features)"); return BG_EINVAL; }
+    line += ":LASCORE:LAREFSPAN:LARANCH:LALANCH:LAREFGC:LAALTGC:LAALTSEQLEN:NUMASM";
+  }
+  line += "\t";
   line += sample;
+  if (o.output_ml_features) {
+    char ml[256];
+    snprintf(ml, sizeof(ml), ":%d:%d:%d:%d:%f:%f:%lu:%lu", a.ml_score, a.ml_refspan, a.ml_lanch, a.ml_ranch, double(a.ml_refgc),
+             double(a.ml_altgc), (unsigned long)a.ml_alt_len, (unsigned long)a.merged + 1);
+    line += ml;
+  }
   line += "\n";
   *len = line.size();
   if (buf && cap) {

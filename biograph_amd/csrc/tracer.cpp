@@ -85,6 +85,7 @@ extern "C" void bg_trace_options_default(bg_trace_options* o) {
   o->max_ref_align_bases = 30;           // assemble.h:682
   o->anchor_drop = 1;                    // reversable_tracer.cpp:124-125 always has the step
   o->max_anchor_kmer_size = 31;          // anchor_dropper::g_max_kmer_size (anchor_drop.cpp:9)
+  o->output_ml_features = 0;             // assemble.h:730
 }
 
 namespace {

@@ -26,7 +26,8 @@ class TraceOptions(C.Structure):
                 [(n, C.c_int) for n in _INT_FIELDS] + [("anchor_drop_size_multiplier", C.c_double),
                                                         ("min_anchor_drop_overlap", C.c_uint64),
                                                         ("ref_align_factor", C.c_int32), ("max_ref_align_bases", C.c_int32),
-                                                        ("anchor_drop", C.c_int32), ("max_anchor_kmer_size", C.c_int32)])
+                                                        ("anchor_drop", C.c_int32), ("max_anchor_kmer_size", C.c_int32),
+                                                        ("output_ml_features", C.c_int32)])
 
     def __init__(self, **kw):
         super().__init__()
@@ -62,6 +63,7 @@ class TraceAssembly:
 
     def __init__(self, a=None, **kw):
         self.aligned_variants = []
+        self.ml, self.merged = None, 0  # assembly_ml_features as a tuple, assemblies merged into this one
         if a is None:  # a hand-made assembly (the reference's unit tests build them this way)
             self.left_offset = self.right_offset = self.left_anchor_len = self.right_anchor_len = 0
             self.seq, self.min_overlap, self.trace_steps, self.left_anchor_ambiguous_bases = "", 0, 0, 0
@@ -118,7 +120,8 @@ class CoverageOptions(C.Structure):
     """bg_coverage_options = the assemble_options calc_coverage, simple_genotype_filter and the VCF export read."""
     _fields_ = [("max_coverage_paths", C.c_uint32), ("penalize_directional_coverage", C.c_int32),
                 ("simple_genotype_filter", C.c_int32), ("min_pair_depth", C.c_int32), ("min_read_depth", C.c_int32),
-                ("vcf_sv_size_threshold", C.c_uint32), ("min_depth_portion", C.c_double), ("min_avg_pair_depth", C.c_double)]
+                ("vcf_sv_size_threshold", C.c_uint32), ("min_depth_portion", C.c_double), ("min_avg_pair_depth", C.c_double),
+                ("output_ml_features", C.c_int32)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -136,15 +139,25 @@ class _Cov(C.Structure):
                 ("genotype_quality", C.c_double)]
 
 
+class _Ml(C.Structure):
+    _fields_ = [("has_ml", C.c_int32), ("score", C.c_int32), ("refspan", C.c_int32), ("lanch", C.c_int32), ("ranch", C.c_int32),
+                ("refgc", C.c_float), ("altgc", C.c_float), ("alt_len", C.c_uint64), ("merged", C.c_uint32)]
+
+
 def _read_result(h):
     L = capi.lib()
     out = []
     a = _Asm()
     cv = _Cov()
+    ml = _Ml()
     lo, ro, sp, sl = C.c_int64(), C.c_int64(), C.c_void_p(), C.c_uint64()
     for i in range(L.bg_trace_result_size(h)):
         capi.check(L.bg_trace_result_get(h, i, C.byref(a)))
         t = TraceAssembly(a)
+        capi.check(L.bg_trace_result_ml(h, i, C.byref(ml)))
+        t.merged = int(ml.merged)
+        if ml.has_ml:  # (score, refspan, lanch, ranch, refgc, altgc, alt_seq length): assembly_ml_features
+            t.ml = (int(ml.score), int(ml.refspan), int(ml.lanch), int(ml.ranch), float(ml.refgc), float(ml.altgc), int(ml.alt_len))
         capi.check(L.bg_trace_result_coverage(h, i, C.byref(cv)))
         if cv.has_coverage:
             t.coverage = [int(cv.coverage[j]) for j in range(cv.n_coverage)]
@@ -180,6 +193,11 @@ def _make_result(assemblies):
                      C.cast(C.c_char_p(seq), C.c_void_p), len(seq), t.min_overlap, t.trace_steps, t.left_anchor_ambiguous_bases,
                      int(t.matches_reference), ids, lm, rm, len(t.rc_read_ids), len(t.left_pair_matches), len(t.right_pair_matches))
             capi.check(L.bg_trace_result_add(src, C.byref(a)))
+            f = getattr(t, "ml", None)
+            if f is not None or getattr(t, "merged", 0):
+                m = _Ml(int(f is not None), *((f[0], f[1], f[2], f[3], f[4], f[5], f[6]) if f is not None else (0, 0, 0, 0, 0.0, 0.0, 0)),
+                        int(getattr(t, "merged", 0)))
+                capi.check(L.bg_trace_result_set_ml(src, L.bg_trace_result_size(src) - 1, C.byref(m)))
     except Exception:
         L.bg_trace_result_free(src)
         raise

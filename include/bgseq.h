@@ -405,6 +405,8 @@ typedef struct bg_trace_options {
                                      reversable_tracer.cpp:124-125 always does; 0 hands out the tracer's raw
                                      dead-end assemblies (right_anchor_len == 0) -- a test hook                       */
   int32_t max_anchor_kmer_size;   /* anchor_dropper::set_max_kmer_size_for_testing (anchor_drop.h:15-19); 31          */
+  int32_t output_ml_features;     /* assemble.h:730: bg_assemblies_process records every discovered assembly's ML
+                                     features behind the sorter (add_ml_features, biograph_variants.cpp:746-779)      */
 } bg_trace_options;
 void bg_trace_options_default(bg_trace_options* o);
 typedef struct bg_trace_stats {  /* assemble_stats of the tracer + the device rounds this implementation took */
@@ -497,6 +499,7 @@ typedef struct bg_coverage_options {
   uint32_t vcf_sv_size_threshold;          /* assemble.h:724 (20)   */
   double min_depth_portion;                /* assemble.h:704 (.23)  */
   double min_avg_pair_depth;               /* assemble.h:711 (1)    */
+  int32_t output_ml_features;              /* assemble.h:730 (0): the LASCORE ... NUMASM columns of the VCF record */
 } bg_coverage_options;
 void bg_coverage_options_default(bg_coverage_options* o);
 int bg_assemblies_coverage(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const bg_trace_result* in,
@@ -510,6 +513,15 @@ typedef struct bg_assembly_coverage {  /* assembly::coverage ... genotype_qualit
   double genotype_quality;
 } bg_assembly_coverage;
 int bg_trace_result_coverage(const bg_trace_result* r, uint64_t i, bg_assembly_coverage* out);  /* pointers live as long as r */
+/* assembly_ml_features (assemble.h:191-199) + the number of assemblies merged into this one (deduper, exact_deduper) */
+typedef struct bg_assembly_ml {
+  int32_t has_ml, score, refspan, lanch, ranch;
+  float refgc, altgc;
+  uint64_t alt_len;
+  uint32_t merged;
+} bg_assembly_ml;
+int bg_trace_result_ml(const bg_trace_result* r, uint64_t i, bg_assembly_ml* out);
+int bg_trace_result_set_ml(bg_trace_result* r, uint64_t i, const bg_assembly_ml* in);
 /* One VCF record line of ploidless_vcf_export::on_assembly for assembly i (nothing for a reference section: *len = 0);
  * assembly_id fills the PI column.  The line (with its newline) is *len bytes; at most cap - 1 of them are copied to buf. */
 int bg_vcf_record(const bg_trace_result* r, uint64_t i, const char* scaffold_name, uint64_t n_extents,

@@ -28,6 +28,9 @@ The sorter is std::sort there (order among assemblies that compare equal in cano
 the product it is a stable sort.  Half-anchored assemblies (one offset absent) do not occur behind the push tracer --
 it reports those through report_half_aligned_func (anchor_drop.cpp:303-339) -- and are not modelled.
 
+The ML features (add_ml_features, biograph_variants.cpp:746-779) and the merge counts the dedupers keep are restated
+too (ml_features_of, merge_bookkeeping); no reference test or golden holds them: PARITY UNPINNED for those.
+
 Pinned on the vectors of modules/variants/align_test.cpp:59-375, trim_ref_test.cpp:24-112, dedup_test.cpp:24-131
 (tests/test_oracle_align.py) and, through the tracer, on the dead-end expectations of tracer_test.cpp:246-316."""
 from .tracer import Assembly, Scaffold, _ScaffoldIt, revcomp, INT_MAX, INT_MIN
@@ -537,6 +540,7 @@ class Deduper:  # dedup.cpp:7-144
               "combined anchors shrink")
         for f in ("trace_steps", "min_overlap", "left_anchor_ambiguous_bases"):
             setattr(target, f, max(getattr(target, f), getattr(a, f)))
+        merge_bookkeeping(target, a)
         return target
 
     def _advance_to(self, offset):  # :131-141
@@ -627,6 +631,7 @@ class ExactDeduper:  # dedup.cpp:146-216
             if (a.left_offset, a.right_offset, a.seq, a.matches_reference) == (q.left_offset, q.right_offset, q.seq, q.matches_reference):
                 q.left_pair_matches = sorted(set(q.left_pair_matches) | set(a.left_pair_matches))
                 q.right_pair_matches = sorted(set(q.right_pair_matches) | set(a.right_pair_matches))
+                merge_bookkeeping(q, a)
                 return
         i = len(self.queued)
         while i > 0 and self.queued[i - 1][0] > a.left_offset:
@@ -658,7 +663,35 @@ class VcfPadder(SortedOutput):  # normalize.cpp:128-162: empty seq or empty ref 
         self.sort_and_output(a)
 
 
-def variants_pipeline(options, scaffold, assemblies, through_vcf_pad=False):
+def merge_bookkeeping(target, a):
+    """What deduper::combine and exact_deduper keep of the assembly they swallow (dedup.cpp:51-53,71-78,171-183):
+    its id and the ids it had merged (here: their number -- NUMASM of the VCF is that number + 1), and the ML
+    features of whichever has the longer original sequence."""
+    target.merged = getattr(target, "merged", 0) + 1 + getattr(a, "merged", 0)
+    tm, am = getattr(target, "ml", None), getattr(a, "ml", None)
+    if tm is not None or am is not None:
+        check(tm is not None and am is not None, "ML features on one side of a merge only")
+        if tm[6] < am[6]:
+            target.ml = am
+
+
+def ml_features_of(a, scaffold):
+    """add_ml_features of biograph_variants.cpp:746-779, run on every discovered assembly right behind the sorter
+    (report_discovered_assemblies, pipeline.cpp:49-51): (score, refspan, lanch, ranch, refgc, altgc, alt_seq length)
+    with the GC fractions in single precision as there."""
+    import numpy as np
+    refspan = a.right_offset - a.left_offset
+    refgc = np.float32(0)
+    if refspan:
+        gc = sum(s.count("G") + s.count("C") for _, s in subscaffold(scaffold, a.left_offset, refspan).extents)
+        refgc = np.float32(gc) / np.float32(refspan)
+    altgc = np.float32(0)
+    if a.seq:
+        altgc = np.float32(a.seq.count("G") + a.seq.count("C")) / np.float32(len(a.seq))
+    return (int(a.score), int(refspan), int(a.left_anchor_len), int(a.right_anchor_len), float(refgc), float(altgc), len(a.seq))
+
+
+def variants_pipeline(options, scaffold, assemblies, through_vcf_pad=False, ml_features=False):
     """The serial pipeline of pipeline.cpp:40-57 + :92-98, fed with everything the tracers of one scaffold produced (both
     directions): sorter(canon) -> ref_trimmer -> deduper -> aligner -> align_splitter [-> normalizer -> exact_deduper ->
     vcf_padder].  -> (deduped, out): the assemblies entering the aligner, and leaving the last step."""
@@ -680,6 +713,8 @@ def variants_pipeline(options, scaffold, assemblies, through_vcf_pad=False):
     dd = Deduper(save)
     tr = RefTrimmer(scaffold, dd.add)
     for a in sorted((copy_assembly(a) for a in assemblies), key=canon_key):
+        if ml_features:
+            a.ml, a.merged = ml_features_of(a, scaffold), 0
         tr.add(a)
     tr.flush()
     dd.flush()

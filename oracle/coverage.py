@@ -32,6 +32,7 @@ class CoverageOptions:
         self.min_pair_depth = 0
         self.min_read_depth = 1
         self.vcf_sv_size_threshold = 20
+        self.output_ml_features = False  # assemble.h:730; biograph_variants.cpp:686 switches it on
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError("no coverage option %r" % k)
@@ -426,4 +427,10 @@ def vcf_line(o, scaffold_name, subscaffold_str, a, assembly_id=0):
     sample = "%s:%s:%d:%d:%d:%d:%d,%d:%d:%d,%d" % (
         gt, pg, int(a.genotype_quality * 100), assembly_id, a.min_overlap, a.other_depth + min_depth + a.ref_depth,
         a.ref_depth, min_depth, a.other_pair_depth + min_pair, 0, min_pair)
-    return "%s\t%d\t.\t%s\t%s\t100\tPASS\t%s\tGT:PG:GQ:PI:OV:DP:AD:PDP:PAD\t%s\n" % (scaffold_name, left + 1, ref_seq, var_seq, info, sample)
+    fmt = "GT:PG:GQ:PI:OV:DP:AD:PDP:PAD"
+    if o.output_ml_features:  # ploidless_vcf_export.cpp:128-130,155-165 (LARANCH prints the LEFT anchor, as there)
+        check(getattr(a, "ml", None) is not None, "missing ML features on an assembly")
+        fmt += ":LASCORE:LAREFSPAN:LARANCH:LALANCH:LAREFGC:LAALTGC:LAALTSEQLEN:NUMASM"
+        f = a.ml
+        sample += ":%d:%d:%d:%d:%f:%f:%d:%d" % (f[0], f[1], f[2], f[3], f[4], f[5], f[6], getattr(a, "merged", 0) + 1)
+    return "%s\t%d\t.\t%s\t%s\t100\tPASS\t%s\t%s\t%s\n" % (scaffold_name, left + 1, ref_seq, var_seq, info, fmt, sample)

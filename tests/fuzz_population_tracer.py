@@ -86,7 +86,7 @@ def tracer_case(ctx, seed):
               trace_reference_assemblies=int(rng.random() < 0.7), max_pairs_per_read=int(rng.choice([1, 20])))
     akw = dict(anchor_drop=int(rng.random() < 0.8), min_anchor_drop_overlap=int(rng.choice([5, 15, 30])),
                max_anchor_kmer_size=int(rng.choice([2, 12, 31])), ref_align_factor=int(rng.choice([2, 4])),
-               max_ref_align_bases=int(rng.choice([10, 30])))
+               max_ref_align_bases=int(rng.choice([10, 30])), output_ml_features=int(rng.random() < 0.5))
     o_gpu = tracer.TraceOptions(**kw, **akw)
     o_cpu = T.Options(**{k: (bool(v) if k in ("trace_ambiguous_ref", "ignore_ambiguous_ref_pairs", "trace_dead_ends",
                                               "forward_pairs_face_inward", "trace_reference_assemblies") else v)
@@ -144,7 +144,7 @@ def pipeline_and_coverage(rng, seed, g, orm, sc, parts, ss, rm, kw, akw, o_gpu, 
                         min_anchor_drop_overlap=akw["min_anchor_drop_overlap"], max_kmer_size=akw["max_anchor_kmer_size"],
                         ref_align_factor=akw["ref_align_factor"], max_ref_align_bases=akw["max_ref_align_bases"])
     try:
-        _, want_sections = A.variants_pipeline(ao, sc, want_in, through_vcf_pad=True)
+        _, want_sections = A.variants_pipeline(ao, sc, want_in, through_vcf_pad=True, ml_features=bool(akw["output_ml_features"]))
     except AssertionError:
         want_sections = None  # a CHECK of the reference: the library must refuse as well
     try:
@@ -160,15 +160,18 @@ def pipeline_and_coverage(rng, seed, g, orm, sc, parts, ss, rm, kw, akw, o_gpu, 
     COUNTS["sections"] += len(want_sections)
 
     def skey(a):
+        ml = getattr(a, "ml", None)
         return (a.left_offset, a.right_offset, a.seq, bool(a.matches_reference), sorted(a.left_pair_matches),
-                sorted(a.right_pair_matches), a.score, a.min_overlap, a.trace_steps)
+                sorted(a.right_pair_matches), a.score, a.min_overlap, a.trace_steps, getattr(a, "merged", 0),
+                None if ml is None else tuple(ml[:4]) + (round(ml[4], 6), round(ml[5], 6), ml[6]))
     if [skey(a) for a in got_sections] != [skey(a) for a in want_sections]:
         print("PIPELINE MISMATCH seed", seed, kw, akw, len(got_sections), len(want_sections), flush=True)
         return False
     ckw = dict(max_coverage_paths=int(rng.choice([1, 2, 4, 64])), penalize_directional_coverage=int(rng.random() < 0.7),
                min_depth_portion=float(rng.choice([0.05, 0.23, 0.4])), min_avg_pair_depth=float(rng.choice([0, 1, 3])),
-               min_read_depth=int(rng.choice([0, 1, 3])), vcf_sv_size_threshold=int(rng.choice([5, 20])))
-    co = CV.CoverageOptions(**{k: (bool(v) if k == "penalize_directional_coverage" else v) for k, v in ckw.items()})
+               min_read_depth=int(rng.choice([0, 1, 3])), vcf_sv_size_threshold=int(rng.choice([5, 20])),
+               output_ml_features=akw["output_ml_features"])
+    co = CV.CoverageOptions(**{k: (bool(v) if k in ("penalize_directional_coverage", "output_ml_features") else v) for k, v in ckw.items()})
     for filt in (False, True):
         try:
             want = CV.calc_coverage(g, [int(x) for x in orm.get("read_len")], sc, co, want_sections)

@@ -156,9 +156,11 @@ def to_oracle(t):
 
 
 def full_key(a):
+    ml = getattr(a, "ml", None)
     return (a.left_offset, a.right_offset, a.left_anchor_len, a.right_anchor_len, a.seq, bool(a.matches_reference),
             a.min_overlap, a.trace_steps, a.left_anchor_ambiguous_bases, a.score, list(a.left_pair_matches),
-            list(a.right_pair_matches), list(getattr(a, "aligned_variants", [])))
+            list(a.right_pair_matches), list(getattr(a, "aligned_variants", [])), getattr(a, "merged", 0),
+            None if ml is None else tuple(ml[:4]) + (round(ml[4], 6), round(ml[5], 6), ml[6]))
 
 
 def mutate(rng, s):
@@ -225,12 +227,12 @@ def random_case(rng):
     kw = dict(min_overlap=rng.choice([8, 12, 20, 35, 70]), min_anchor_drop_overlap=rng.choice([4, 8, 15]),
               max_anchor_kmer_size=rng.choice([1, 3, 8, 31]), read_ahead_distance=rng.choice([50, 300, 100000]),
               trace_reference_assemblies=rng.choice([0, 1]), ref_align_factor=rng.choice([2, 4]),
-              max_ref_align_bases=rng.choice([5, 30]))
+              max_ref_align_bases=rng.choice([5, 30]), output_ml_features=rng.choice([0, 1]))
     return parts, sc, asms, kw
 
 
 def oracle_steps(sc, asms, kw, steps):
-    ao = A.AlignOptions(min_overlap=kw["min_overlap"], min_anchor_drop_overlap=kw["min_anchor_drop_overlap"],
+    ao = A.AlignOptions(min_overlap=kw["min_overlap"], min_anchor_drop_overlap=kw["min_anchor_drop_overlap"],  # (ML switch: not an align option)
                         max_kmer_size=kw["max_anchor_kmer_size"], read_ahead_distance=kw["read_ahead_distance"],
                         trace_reference_assemblies=bool(kw["trace_reference_assemblies"]),
                         ref_align_factor=kw["ref_align_factor"], max_ref_align_bases=kw["max_ref_align_bases"])
@@ -244,6 +246,9 @@ def oracle_steps(sc, asms, kw, steps):
         cur = nxt
     if steps & BT.STEP_SORT:
         cur = sorted(cur, key=A.canon_key)
+    if kw.get("output_ml_features"):
+        for a in cur:
+            a.ml, a.merged = A.ml_features_of(a, sc), 0
     out = []
     chain = out.append
     flush = []
@@ -309,3 +314,18 @@ def test_random_assemblies_equal_the_oracle(seed):
             assert got == want, (seed, steps, kw)
             n_out += len(got)
     assert n_out > 200
+
+
+def test_ml_features_and_merge_counts():
+    """add_ml_features (biograph_variants.cpp:746-779) behind the sorter, and what the dedupers keep of them."""
+    ref = tseq("abc") + "T" + tseq("defgh")
+    a1 = asm(10, 60, ref[10:30] + "C" + ref[31:60], 15, 20, score=7)
+    a2 = asm(20, 71, ref[20:30] + "C" + ref[31:71], 5, 30, score=9)
+    out = run([(0, ref)], [a1, a2], BT.STEP_SORT | BT.STEP_TRIM_REF | BT.STEP_DEDUP, output_ml_features=1)
+    assert len(out) == 1 and (out[0].left_offset, out[0].right_offset, out[0].seq, out[0].merged) == (30, 31, "C", 1)
+    gc = lambda x: (x.count("G") + x.count("C")) / len(x)  # noqa: E731
+    want = (9, 51, 5, 30, gc(ref[20:71]), gc(a2.seq), 51)   # the longer original sequence wins
+    assert out[0].ml[:4] == want[:4] and out[0].ml[6] == 51
+    assert abs(out[0].ml[4] - want[4]) < 1e-6 and abs(out[0].ml[5] - want[5]) < 1e-6
+    plain = run([(0, ref)], [a1, a2], BT.STEP_SORT | BT.STEP_TRIM_REF | BT.STEP_DEDUP)
+    assert plain[0].ml is None and plain[0].merged == 1

@@ -155,7 +155,8 @@ def test_bgbinary_discovery_cli_on_lambda(golden_dir, tmp_path, ref_arg, chrom, 
     out = tmp_path / "v.vcf"
     r = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "discovery", "--in", str(bgd), "--ref",
                         golden_dir + ref_arg, "--out", str(out), "--engine", engine] +
-                       (["--min-overlap", "70"] if engine == "graph" else []),  # push: the command's default, 0.7 x read length
+                       # push: the command's defaults (0.7 x read length); father.vcf predates the ML feature columns
+                       (["--min-overlap", "70"] if engine == "graph" else ["--ml-features", "false"]),
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     ref = "".join(l.strip() for l in open(golden_dir + "/father_lambda/reference.fasta") if not l.startswith(">")).upper()
@@ -267,7 +268,7 @@ def test_bgbinary_discovery_push_engine_with_bed(golden_dir, tmp_path):
     bed.write_text("lambda\t500\t11000\nlambda\t28500\t32500\n")
     out = tmp_path / "v.vcf"
     r = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "discovery", "--in", str(bgd), "--ref", golden_dir + "/ref_lambda",
-                        "--out", str(out), "--bed", str(bed), "--max-ploids", "2"], capture_output=True, text=True)
+                        "--out", str(out), "--bed", str(bed), "--max-ploids", "2", "--ml-features", "false"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
 
     def fields(path, keep):
@@ -288,3 +289,37 @@ def test_bgbinary_discovery_push_engine_with_bed(golden_dir, tmp_path):
     r = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "discovery", "--in", str(bgd), "--ref", golden_dir + "/ref_lambda",
                         "--out", str(out), "--enable-pop-tracer", "true"], capture_output=True, text=True)
     assert r.returncode != 0 and "pop tracer" in r.stderr
+
+
+def test_bgbinary_discovery_ml_feature_columns(golden_dir, tmp_path):
+    """The command's default output carries the ML feature columns the current reference always writes
+    (biograph_variants.cpp:686, ploidless_vcf_export.cpp:128-165): the father.vcf records, each with LASCORE ... NUMASM."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    bgd = tmp_path / "father.bg"
+    (bgd / "coverage").mkdir(parents=True)
+    (bgd / "metadata").mkdir()
+    shutil.copy(golden_dir + "/father_lambda/seqset", bgd / "seqset")
+    shutil.copy(golden_dir + "/father_lambda/readmap", bgd / "coverage" / "abc.readmap")
+    json.dump({"accession_id": "father", "samples": {"father": "abc"}}, open(bgd / "metadata" / "bg_info.json", "w"),
+              separators=(",", ":"))
+    out = tmp_path / "v.vcf"
+    r = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "discovery", "--in", str(bgd), "--ref", golden_dir + "/ref_lambda",
+                        "--out", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    recs = [l.rstrip("\n").split("\t") for l in open(out) if not l.startswith("#")]
+    gold = [l.rstrip("\n").split("\t") for l in open(golden_dir + "/father_lambda/father.vcf") if not l.startswith("#")]
+    assert len(recs) == len(gold) == 8
+    ref = "".join(l.strip() for l in open(golden_dir + "/father_lambda/reference.fasta") if not l.startswith(">")).upper()
+    for f, g in zip(recs, gold):
+        assert f[1:8] == g[1:8]
+        assert f[8] == g[8] + ":LASCORE:LAREFSPAN:LARANCH:LALANCH:LAREFGC:LAALTGC:LAALTSEQLEN:NUMASM"
+        smp, ml = f[9].split(":")[:9], f[9].split(":")[9:]
+        want = g[9].split(":")
+        assert smp[:3] + smp[4:] == want[:3] + want[4:] and len(ml) == 8
+        refspan, altlen, numasm = int(ml[1]), int(ml[6]), int(ml[7])
+        assert refspan > 100 and altlen > 100 and numasm >= 2   # found by several traces in both directions
+        assert 0.0 < float(ml[4]) < 1.0 and 0.0 < float(ml[5]) < 1.0
+    assert any(l.startswith("##FORMAT=<ID=NUMASM") for l in open(out))
