@@ -230,3 +230,56 @@ def test_stress_recipe(ctx, n_vars):  # calc_coverage_test.cpp:370-520
     for i, a in enumerate(out):
         n = 1 if is_delete[i] else 2
         assert (a.coverage, a.pair_coverage, a.ref_depth) == ([var_count[i]] * n, [pair_count[i]] * n, ref_count[i]), i
+
+
+def test_discovery_engine_equals_oracle_on_a_120kb_sample(ctx):
+    """A 120 kb diploid sample with SNPs, indels (1-50 bp) and structural insertions / deletions (50-1000 bp), 30x paired
+    150 bp reads with errors, built by the library's create path (count, correct, seqset, readmap): the reference's whole
+    discovery engine through the library -- two pieces x two directions of the push tracer, the serial pipeline with ML
+    features, calc_coverage, genotype filter -- gives, VCF line for VCF line, what the oracle's restatement gives on the
+    oracle's own seqset and readmap of the same corrected reads."""
+    import torch  # noqa: F401
+    from biograph_amd import synth
+    from tests.test_oracle_tracer import dropper
+    G = 120_000
+    seq, offs, n, genome = synth.make_reads(genome_len=G, coverage=30, read_len=150, seed=78, device="cuda", return_genome=True,
+                                            indel_rate=3e-4, sv_rate=5e-5)
+    r = ctx.pack_reads_device(seq.data_ptr(), offs.data_ptr(), n)
+    ks = ctx.kmer_count(r, 30, 5)
+    c, _ = ctx.correct_reads(r, ks)
+    ss, _ = ctx.build_seqset(c, 30)
+    rm = ctx.build_readmap(ss, c, True)
+    cseq, coffs = c.download()
+    corrected = O.unpack_strings(cseq, coffs)
+    ent = O.Entries.build(cseq, coffs, "cover", 30, threads=8)
+    oss = O.Seqset.from_entries(ent, threads=8)
+    records = [tuple(s for s in corrected[i:i + 2] if s) for i in range(0, len(corrected), 2)]
+    orm = O.Readmap(oss, ent, [rec for rec in records if rec], True)
+    ref = "".join("ACGT"[int(x)] for x in genome.cpu().tolist())
+    parts = [(0, ref)]
+    codes = genome.cpu().numpy().astype(np.uint8)
+    g = T.Graph(oss, orm, oss.ref_map_build(codes, np.array([0], np.uint64), np.array([G], np.uint64)))
+    rmap = tracer.reference_ref_map(ss, [ref])
+    mo = 105
+    o_gpu, o_cpu, sc = tracer.TraceOptions(min_overlap=mo, output_ml_features=1), T.Options(min_overlap=mo), T.Scaffold(parts)
+    want_in, got_in = [], []
+    try:
+        for start in (0, 60_000):
+            for rev in (False, True):
+                want_in += T.reversable_trace(g, sc, o_cpu, rev_comp=rev, start_offset=start, limit_offset=start + 60_000,
+                                              anchor_drop=dropper(o_cpu))
+                got_in += tracer.push_trace(ss, rm, rmap, parts, start=start, limit=start + 60_000, rev_comp=rev, options=o_gpu)
+    finally:
+        rmap.free()
+    _, want_sections = A.variants_pipeline(A.AlignOptions(min_overlap=mo), sc, want_in, through_vcf_pad=True, ml_features=True)
+    got_sections = tracer.process_assemblies(got_in, parts, options=o_gpu)
+    co = C.CoverageOptions(output_ml_features=True)
+    want = C.simple_genotype_filter(co, C.calc_coverage(g, [int(x) for x in orm.get("read_len")], sc, co, want_sections))
+    got, lines = tracer.assemblies_coverage(ss, rm, got_sections, parts, options=tracer.CoverageOptions(output_ml_features=1),
+                                            vcf_name="chrS")
+    assert lines == [C.vcf_line(co, "chrS", lambda off, k: ref[off:off + k], a) for a in want]
+    assert len(lines) > 100
+    big = [x.split("\t") for x in lines if "SVTYPE" in x]
+    assert len(big) >= 3  # structural variants come through as records with END / SVLEN / SVTYPE
+    for h in (rm, ss, c, ks, r):
+        h.free()
