@@ -759,7 +759,10 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   for (int t = 0; t < n_threads; ++t) {
     wctx[size_t(t)] = t == 0 ? ctx : nullptr;
     if (t) check(bg_ctx_create(0, nullptr, &wctx[size_t(t)]), "bg_ctx_create");
-    check(bg_tracer_open(wctx[size_t(t)], ss, rm, static_cast<const uint8_t*>(d_map), &opt, &tracers[size_t(t)]), "bg_tracer_open");
+    if (t == 0)
+      check(bg_tracer_open(wctx[0], ss, rm, static_cast<const uint8_t*>(d_map), &opt, &tracers[0]), "bg_tracer_open");
+    else
+      check(bg_tracer_clone(tracers[0], wctx[size_t(t)], &tracers[size_t(t)]), "bg_tracer_clone");
   }
   const double t_open = now_s() - t_open0;
   time_t now = time(nullptr);

@@ -36,6 +36,7 @@
 #include <set>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -134,6 +135,12 @@ std::string rev_comp_str(const std::string& s) {
 
 namespace {
 
+struct HostTables {
+  std::vector<uint8_t> sizes, ref_map, is_forward;
+  std::vector<uint32_t> entry_id, mate_loop;
+  std::vector<uint64_t> has_reads;
+};
+
 // Everything the traces of one chunk share.
 struct World {
   bg_ctx* ctx;
@@ -141,11 +148,25 @@ struct World {
   const bg_readmap* rm;
   bg_trace_options o;
   uint64_t n_entries = 0;
-  std::vector<uint8_t> sizes;        // entry sizes
-  std::vector<uint8_t> ref_map;      // ref_map bytes (match count = & 63)
-  std::vector<uint32_t> entry_id;    // per read id, ascending
-  std::vector<uint32_t> mate_loop;   // per read id
-  std::vector<uint8_t> is_forward;   // per read id
+  // host copies of the seqset / readmap / ref_map columns the tracer consults: read-only, shared with the sessions
+  // cloned from this one (bg_tracer_clone: several sessions trace side by side)
+  std::shared_ptr<const HostTables> tables;
+  const uint8_t* sizes = nullptr;       // entry sizes
+  const uint8_t* ref_map = nullptr;     // ref_map bytes (match count = & 63)
+  const uint32_t* entry_id = nullptr;   // per read id, ascending
+  const uint32_t* mate_loop = nullptr;  // per read id
+  const uint8_t* is_forward = nullptr;  // per read id
+  const uint64_t* has_reads = nullptr;  // readmap::get_bit as a bit per entry
+  size_t n_reads = 0;
+  void bind_tables() {
+    sizes = tables->sizes.data();
+    ref_map = tables->ref_map.data();
+    entry_id = tables->entry_id.data();
+    mate_loop = tables->mate_loop.data();
+    is_forward = tables->is_forward.data();
+    has_reads = tables->has_reads.data();
+    n_reads = tables->entry_id.size();
+  }
   int64_t scaffold_end = 0;
   // reads along the (oriented) scaffold: offset (after the base) -> entry, ascending by offset
   std::vector<std::pair<int32_t, uint64_t>> position_entries;
@@ -157,11 +178,10 @@ struct World {
 
   unsigned match_count(uint64_t e) const { return ref_map[e] & 63u; }
   std::pair<uint32_t, uint32_t> entry_to_index(uint64_t e) const {  // readmap.h:114-116
-    auto lo = std::lower_bound(entry_id.begin(), entry_id.end(), uint32_t(e));
-    auto hi = std::upper_bound(lo, entry_id.end(), uint32_t(e));
-    return {uint32_t(lo - entry_id.begin()), uint32_t(hi - entry_id.begin())};
+    const uint32_t* lo = std::lower_bound(entry_id, entry_id + n_reads, uint32_t(e));
+    const uint32_t* hi = std::upper_bound(lo, entry_id + n_reads, uint32_t(e));
+    return {uint32_t(lo - entry_id), uint32_t(hi - entry_id)};
   }
-  std::vector<uint64_t> has_reads;   // readmap::get_bit as a bit per entry
   bool get_bit(uint64_t e) const { return (has_reads[e >> 6] >> (e & 63)) & 1; }
   bool is_entry(const TRange& r) const { return r.b + 1 == r.e && r.s == sizes[r.b]; }     // seqset.h:298-300
   bool is_read(const TRange& r) const { return is_entry(r) && get_bit(r.b); }                // tracer.cpp:521-526
@@ -1029,19 +1049,40 @@ extern "C" int bg_tracer_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap
   if (options) w.o = *options; else bg_trace_options_default(&w.o);
   memset(&w.stats, 0, sizeof(w.stats));
   w.n_entries = ss->n;
-  BG_TRY(download(w.sizes, ss->sizes.p, ss->n));
-  BG_TRY(download(w.ref_map, d_ref_map, ss->n));
-  BG_TRY(download(w.entry_id, rm->entry_id.p, rm->n_reads));
-  w.has_reads.assign((ss->n + 63) / 64 + 1, 0);
-  for (uint32_t e : w.entry_id) w.has_reads[e >> 6] |= 1ull << (e & 63);
   {
+    std::shared_ptr<HostTables> h(new HostTables);
+    BG_TRY(download(h->sizes, ss->sizes.p, ss->n));
+    BG_TRY(download(h->ref_map, d_ref_map, ss->n));
+    BG_TRY(download(h->entry_id, rm->entry_id.p, rm->n_reads));
+    h->has_reads.assign((ss->n + 63) / 64 + 1, 0);
+    for (uint32_t e : h->entry_id) h->has_reads[e >> 6] |= 1ull << (e & 63);
     std::vector<uint64_t> tmp;
     BG_TRY(download(tmp, rm->mate_loop_ptr.p, rm->n_reads));
-    w.mate_loop.assign(tmp.begin(), tmp.end());
+    h->mate_loop.assign(tmp.begin(), tmp.end());
     BG_TRY(download(tmp, rm->is_forward.p, rm->n_reads));
-    w.is_forward.resize(rm->n_reads);
-    for (size_t i = 0; i < tmp.size(); ++i) w.is_forward[i] = uint8_t(tmp[i] & 1);
+    h->is_forward.resize(rm->n_reads);
+    for (size_t i = 0; i < tmp.size(); ++i) h->is_forward[i] = uint8_t(tmp[i] & 1);
+    w.tables = h;
   }
+  w.bind_tables();
+  *out = t.release();
+  return BG_OK;
+}
+
+// Another session on the same seqset / readmap / ref_map for another host thread: its own context (stream, allocator)
+// and scratch, the read-only host tables shared with `from` (no second copy: less memory, warmer caches).
+extern "C" int bg_tracer_clone(const bg_tracer* from, bg_ctx* ctx, bg_tracer** out) {
+  if (!from || !ctx || !out) return fail("bg_tracer_clone: null argument");
+  std::unique_ptr<bg_tracer> t(new bg_tracer);
+  World& w = t->w;
+  w.ctx = ctx;
+  w.ss = from->w.ss;
+  w.rm = from->w.rm;
+  w.o = from->w.o;
+  memset(&w.stats, 0, sizeof(w.stats));
+  w.n_entries = from->w.n_entries;
+  w.tables = from->w.tables;
+  w.bind_tables();
   *out = t.release();
   return BG_OK;
 }

@@ -441,6 +441,9 @@ int bg_tracer_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const
 int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
                     const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset, int rev_comp,
                     int pair_count, bg_trace_result** out);
+/* A second session for another host thread: its own context (stream, allocator), the read-only host tables shared with
+ * `from`, the same options.  Sessions may trace concurrently, one thread per session; `from` may be closed first. */
+int bg_tracer_clone(const bg_tracer* from, bg_ctx* ctx, bg_tracer** out);
 void bg_tracer_close(bg_tracer* t);
 uint64_t bg_trace_result_size(const bg_trace_result* r);
 int bg_trace_result_get(const bg_trace_result* r, uint64_t i, bg_trace_assembly* out);  /* pointers live as long as r */
