@@ -199,13 +199,32 @@ extern "C" int bg_ctx_create(int device, void* stream, bg_ctx** out) {
   return BG_OK;
 }
 
+// A context with a stream of its own (non-blocking: it does not meet other contexts on the null stream), for callers
+// that run several contexts side by side from several host threads.  The stream goes with the context.
+extern "C" int bg_ctx_create_own_stream(int device, bg_ctx** out) {
+  BG_TRY(bg_ctx_create(device, nullptr, out));
+  hipStream_t s = nullptr;
+  const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    set_error("bg_ctx_create_own_stream: %s", hipGetErrorString(e));
+    bg_ctx_destroy(*out);
+    *out = nullptr;
+    return BG_ENODEV;
+  }
+  (*out)->stream = s;
+  (*out)->owns_stream = true;
+  return BG_OK;
+}
+
 extern "C" void bg_ctx_destroy(bg_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->owns_stream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
   ctx->trim();
   ctx->clear_timings();
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   for (void* p : ctx->pinned) if (p) (void)hipHostFree(p);
+  if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 

@@ -45,6 +45,7 @@ struct TimingRec {
 struct bg_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool owns_stream = false;  // bg_ctx_create_own_stream
   bool profiling = false;
   // device memory: segments from hipMalloc, sub-allocated best-fit with coalescing (arena.h)
   struct HipSegments {

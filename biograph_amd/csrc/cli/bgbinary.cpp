@@ -758,7 +758,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   std::vector<bg_tracer*> tracers(size_t(n_threads), nullptr);
   for (int t = 0; t < n_threads; ++t) {
     wctx[size_t(t)] = t == 0 ? ctx : nullptr;
-    if (t) check(bg_ctx_create(0, nullptr, &wctx[size_t(t)]), "bg_ctx_create");
+    if (t) check(bg_ctx_create_own_stream(0, &wctx[size_t(t)]), "bg_ctx_create_own_stream");
     if (t == 0)
       check(bg_tracer_open(wctx[0], ss, rm, static_cast<const uint8_t*>(d_map), &opt, &tracers[0]), "bg_tracer_open");
     else

@@ -621,6 +621,21 @@ double now_seconds() {
   return double(ts.tv_sec) + 1e-9 * double(ts.tv_nsec);
 }
 
+// every copy rides on the context's own stream and is waited for there: sessions on different streams do not meet on
+// the null stream
+int copy_sync(bg_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  if (!bytes) return BG_OK;
+  BG_HIP(hipMemcpyAsync(dst, src, bytes, kind, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+template <class T>
+int download(bg_ctx* ctx, std::vector<T>& h, const T* d, size_t n) {
+  h.resize(n);
+  return copy_sync(ctx, h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost);
+}
+
 // The host side of a round is a microsecond or two per trace: threads only pay off on big rounds, and only a few of
 // them (measured on a 256-core box, 1 Mb piece: host replay 0.29 s on one thread, 0.21 s on 16, 0.50 s on 64 when every
 // round spawned its threads).  So: a persistent pool of at most 16 (BG_TRACER_THREADS overrides), each taking a
@@ -760,10 +775,10 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
     DevBuf<uint64_t> d_ent;
     BG_TRY(d_codes.alloc(ctx, n));
     BG_TRY(d_ent.alloc(ctx, n));
-    BG_HIP(hipMemcpy(d_codes.p, codes.data(), n, hipMemcpyHostToDevice));
+    BG_TRY(copy_sync(ctx, d_codes.p, codes.data(), n, hipMemcpyHostToDevice));
     BG_TRY(bg_ref_walk_entries(ctx, w.ss, d_codes.p, n, dup_first ? 1 : 0, d_ent.p));
     std::vector<uint64_t> ent(n);
-    BG_HIP(hipMemcpy(ent.data(), d_ent.p, n * 8, hipMemcpyDeviceToHost));
+    BG_TRY(copy_sync(ctx, ent.data(), d_ent.p, n * 8, hipMemcpyDeviceToHost));
     // positions that are reads, and for those the (rc mate, offset) pairs: per-thread lists over slices of the extent
     {
       int nt = int(std::min<uint64_t>(uint64_t(HostPool::get().size()), n / 65536 + 1));
@@ -862,13 +877,14 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
       BG_TRY(dq.alloc(ctx, n * sizeof(bg_trace_query)));
       BG_TRY(dr.alloc(ctx, n * sizeof(bg_trace_reply)));
       BG_TRY(ds.alloc(ctx, n * step_cap));
-      BG_HIP(hipMemcpy(dq.p, q.data(), n * sizeof(bg_trace_query), hipMemcpyHostToDevice));
+      BG_HIP(hipMemcpyAsync(dq.p, q.data(), n * sizeof(bg_trace_query), hipMemcpyHostToDevice, ctx->stream));
       BG_TRY(bg_tracer_extend_batch(ctx, w.ss, w.rm, n, reinterpret_cast<const bg_trace_query*>(dq.p), step_cap,
                                     reinterpret_cast<bg_trace_reply*>(dr.p), ds.p));
       replies.resize(n);
       steps.resize(n * step_cap);
-      BG_HIP(hipMemcpy(replies.data(), dr.p, n * sizeof(bg_trace_reply), hipMemcpyDeviceToHost));
-      BG_HIP(hipMemcpy(steps.data(), ds.p, n * step_cap * 4, hipMemcpyDeviceToHost));
+      BG_HIP(hipMemcpyAsync(replies.data(), dr.p, n * sizeof(bg_trace_reply), hipMemcpyDeviceToHost, ctx->stream));
+      BG_HIP(hipMemcpyAsync(steps.data(), ds.p, n * step_cap * 4, hipMemcpyDeviceToHost, ctx->stream));
+      BG_HIP(hipStreamSynchronize(ctx->stream));
       w.seconds_device += now_seconds() - t_dev;
       ++w.stats.device_rounds;
       w.stats.device_queries += n;
@@ -1013,13 +1029,6 @@ struct PairCounter {
   }
 };
 
-template <class T>
-int download(std::vector<T>& h, const T* d, size_t n) {
-  h.resize(n);
-  if (n) BG_HIP(hipMemcpy(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost));
-  return BG_OK;
-}
-
 }  // namespace
 
 // reversable_tracer::assemble(start, limit) (reversable_tracer.cpp:76-145) with the push tracer.
@@ -1051,15 +1060,15 @@ extern "C" int bg_tracer_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap
   w.n_entries = ss->n;
   {
     std::shared_ptr<HostTables> h(new HostTables);
-    BG_TRY(download(h->sizes, ss->sizes.p, ss->n));
-    BG_TRY(download(h->ref_map, d_ref_map, ss->n));
-    BG_TRY(download(h->entry_id, rm->entry_id.p, rm->n_reads));
+    BG_TRY(download(ctx, h->sizes, ss->sizes.p, ss->n));
+    BG_TRY(download(ctx, h->ref_map, d_ref_map, ss->n));
+    BG_TRY(download(ctx, h->entry_id, rm->entry_id.p, rm->n_reads));
     h->has_reads.assign((ss->n + 63) / 64 + 1, 0);
     for (uint32_t e : h->entry_id) h->has_reads[e >> 6] |= 1ull << (e & 63);
     std::vector<uint64_t> tmp;
-    BG_TRY(download(tmp, rm->mate_loop_ptr.p, rm->n_reads));
+    BG_TRY(download(ctx, tmp, rm->mate_loop_ptr.p, rm->n_reads));
     h->mate_loop.assign(tmp.begin(), tmp.end());
-    BG_TRY(download(tmp, rm->is_forward.p, rm->n_reads));
+    BG_TRY(download(ctx, tmp, rm->is_forward.p, rm->n_reads));
     h->is_forward.resize(rm->n_reads);
     for (size_t i = 0; i < tmp.size(); ++i) h->is_forward[i] = uint8_t(tmp[i] & 1);
     w.tables = h;

@@ -48,6 +48,9 @@ const char* bg_last_error(void);
 /* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the default
  * stream. */
 int bg_ctx_create(int device, void* stream, bg_ctx** out);
+/* The same with a (non-blocking) stream of its own that lives as long as the context: for callers that run several
+ * contexts side by side from several host threads (bgbinary discovery's tracer sessions). */
+int bg_ctx_create_own_stream(int device, bg_ctx** out);
 /* Every object created from a context (reads, k-mer sets, records, seqsets) must be freed BEFORE the
  * context is destroyed. */
 void bg_ctx_destroy(bg_ctx* ctx);
