@@ -739,6 +739,11 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   bg_trace_options_default(&opt);
   opt.min_overlap = min_overlap;
   opt.max_pair_distance = uint64_t(max_pair_distance);
+  if (a.has("scaffold-split-size")) {  // assemble_options::scaffold_split_size (the size of trace_ref's pieces)
+    const long long sp = atoll(a.get("scaffold-split-size").c_str());
+    if (sp < 1000) die("discovery: --scaffold-split-size must be at least 1000");
+    opt.scaffold_split_size = uint64_t(sp);
+  }
   bg_coverage_options cov;
   bg_coverage_options_default(&cov);
   // biograph_variants.cpp:686 always writes the ML feature columns (LASCORE ... NUMASM); --ml-features false leaves them out
@@ -900,7 +905,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
 
 static int cmd_discovery(int argc, char** argv) {
   Args a = parse(argc, argv, 2, {"reads", "ref", "out", "sample", "min-overlap", "max-pair-distance", "bed", "engine", "max-ploids",
-                                 "enable-pop-tracer", "threads", "ml-features"});
+                                 "enable-pop-tracer", "threads", "ml-features", "scaffold-split-size"});
   if (!a.has("reads") || !a.has("ref") || !a.has("out")) die("discovery: --in S.bg, --ref and --out are required");
   std::string bgdir = a.get("reads");
   // --engine push (default): the reference's discovery engine -- push tracer, anchor_dropper, pair_counter, the

@@ -323,3 +323,41 @@ def test_bgbinary_discovery_ml_feature_columns(golden_dir, tmp_path):
         assert refspan > 100 and altlen > 100 and numasm >= 2   # found by several traces in both directions
         assert 0.0 < float(ml[4]) < 1.0 and 0.0 < float(ml[5]) < 1.0
     assert any(l.startswith("##FORMAT=<ID=NUMASM") for l in open(out))
+
+
+def test_bgbinary_create_then_discovery_is_the_same_on_any_number_of_sessions(tmp_path):
+    """FASTQ -> `bgbinary create` -> `bgbinary discovery` on a 150 kb synthetic sample cut into 8 pieces: one tracer session
+    and five side by side write the same VCF records, and the planted SNPs are among them."""
+    import subprocess
+    import sys
+    import numpy as np
+    import torch
+    from biograph_amd import synth
+    G, L, seed = 150_000, 150, 4242
+    seq, offs, n, genome = synth.make_reads(genome_len=G, coverage=30, read_len=L, seed=seed, device="cuda", return_genome=True)
+    reads = seq.view(n, L).cpu().numpy()
+    for mate in (0, 1):
+        with open(tmp_path / ("r%d.fq" % (mate + 1)), "wb") as f:
+            for i, row in enumerate(reads[mate::2]):
+                f.write(b"@r%d\n" % i + row.tobytes() + b"\n+\n" + b"I" * L + b"\n")
+    ref = np.frombuffer(b"ACGT", np.uint8)[genome.cpu().numpy()].tobytes().decode()
+    (tmp_path / "ref.fa").write_text(">chrS\n" + "\n".join(ref[i:i + 60] for i in range(0, G, 60)) + "\n")
+    exe = [sys.executable, "-m", "biograph_amd.cli"]
+    r = subprocess.run(exe + ["create", "--reads", str(tmp_path / "r1.fq"), "--pair", str(tmp_path / "r2.fq"), "--out",
+                              str(tmp_path / "s.bg")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    outs = []
+    for threads in (1, 5):
+        out = tmp_path / ("v%d.vcf" % threads)
+        r = subprocess.run(exe + ["discovery", "--in", str(tmp_path / "s.bg"), "--ref", str(tmp_path / "ref.fa"), "--out", str(out),
+                                  "--threads", str(threads), "--scaffold-split-size", "20000"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "8 piece(s) x 2 directions on %d tracer session(s)" % threads in r.stderr
+        outs.append([x for x in open(out) if not x.startswith("##fileDate")])
+    assert outs[0] == outs[1]
+    recs = [x.split("\t") for x in outs[0] if not x.startswith("#")]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed + 1)
+    planted = set(torch.nonzero(torch.rand(G, generator=g, device="cuda") < 0.001).flatten().cpu().tolist())
+    snps = {int(f[1]) - 1 for f in recs if len(f[3]) == 1 and len(f[4]) == 1}
+    assert len(planted) > 100 and len(snps & planted) >= 0.9 * len(planted) and not (snps - planted)
