@@ -769,6 +769,8 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     else
       check(bg_tracer_clone(tracers[0], wctx[size_t(t)], &tracers[size_t(t)]), "bg_tracer_clone");
   }
+  bg_coverage* cov_session = nullptr;
+  check(bg_coverage_open(ctx, ss, rm, &cov_session), "bg_coverage_open");
   const double t_open = now_s() - t_open0;
   time_t now = time(nullptr);
   char date[16];
@@ -870,8 +872,8 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     n_sections += bg_trace_result_size(sections);
     t_pipe += now_s() - t1;
     t1 = now_s();
-    check(bg_assemblies_coverage(ctx, ss, rm, sections, es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), &cov, 1, &kept),
-          "bg_assemblies_coverage");
+    check(bg_coverage_run(cov_session, sections, es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), &cov, 1, &kept),
+          "bg_coverage_run");
     bg_trace_result_free(sections);
     t_cov += now_s() - t1;
     std::vector<char> buf(1 << 16);
@@ -890,6 +892,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     }
     bg_trace_result_free(kept);
   }
+  bg_coverage_close(cov_session);
   for (int t = 0; t < n_threads; ++t) {
     bg_tracer_close(tracers[size_t(t)]);
     if (t) bg_ctx_destroy(wctx[size_t(t)]);

@@ -215,7 +215,8 @@ struct CovWorld {
   uint32_t min_read_len = 0;
   int64_t max_read_len = 0;
   Batcher* batcher = nullptr;
-  int load(const bg_readmap* rm) {
+  int load(const bg_seqset* seqset, const bg_readmap* rm) {
+    ss = seqset;
     entry_id.resize(rm->n_reads);
     std::vector<uint64_t> tmp(rm->n_reads);
     if (rm->n_reads) {
@@ -636,15 +637,48 @@ bool genotype(const bg_coverage_options& o, bg_trace_assembly_rec& a) {
 
 }  // namespace
 
+// The readmap columns calc_coverage reads, copied to the host once (a reference has thousands of scaffolds, each its
+// own bg_coverage_run).
+struct bg_coverage {
+  bg_ctx* ctx = nullptr;
+  const bg_seqset* ss = nullptr;
+  CovWorld tables;
+};
+
+extern "C" int bg_coverage_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, bg_coverage** out) {
+  if (!ctx || !ss || !rm || !out) { set_error("bg_coverage_open: null argument"); return BG_EINVAL; }
+  if (rm->n_entries != ss->n) { set_error("bg_coverage_open: the readmap belongs to another seqset"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_coverage> c(new bg_coverage);
+  c->ctx = ctx;
+  c->ss = ss;
+  BG_TRY(c->tables.load(ss, rm));
+  *out = c.release();
+  return BG_OK;
+}
+
+extern "C" void bg_coverage_close(bg_coverage* c) { delete c; }
+
 extern "C" int bg_assemblies_coverage(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const bg_trace_result* in,
                                       uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
                                       const uint64_t* ext_len, int64_t end_pos, const bg_coverage_options* options,
                                       int genotype_filter, bg_trace_result** out) {
-  if (!ctx || !ss || !rm || !in || !out || (n_extents && (!ext_offset || !ext_seq || !ext_len))) {
+  bg_coverage* c = nullptr;
+  BG_TRY(bg_coverage_open(ctx, ss, rm, &c));
+  const int rc = bg_coverage_run(c, in, n_extents, ext_offset, ext_seq, ext_len, end_pos, options, genotype_filter, out);
+  bg_coverage_close(c);
+  return rc;
+}
+
+extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64_t n_extents, const int64_t* ext_offset,
+                               const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos,
+                               const bg_coverage_options* options, int genotype_filter, bg_trace_result** out) {
+  if (!c || !in || !out || (n_extents && (!ext_offset || !ext_seq || !ext_len))) {
     set_error("bg_assemblies_coverage: null argument");
     return BG_EINVAL;
   }
-  if (rm->n_entries != ss->n) { set_error("bg_assemblies_coverage: the readmap belongs to another seqset"); return BG_EINVAL; }
+  bg_ctx* ctx = c->ctx;
+  const bg_seqset* ss = c->ss;
   bg_coverage_options o;
   if (options) o = *options; else bg_coverage_options_default(&o);
   ScaffoldView sc;
@@ -653,11 +687,9 @@ extern "C" int bg_assemblies_coverage(bg_ctx* ctx, const bg_seqset* ss, const bg
   std::unique_ptr<bg_trace_result> res(new bg_trace_result);
   memset(&res->stats, 0, sizeof(res->stats));
   try {
-    CovWorld w;
-    w.ss = ss;
+    CovWorld& w = c->tables;  // the scaffold, the options and the batcher are this call's
     w.sc = &sc;
     w.o = o;
-    BG_TRY(w.load(rm));
     // Islands: calc_coverage re-initialises its reference path group whenever nothing is active and the next variant
     // starts more than max_read_len behind everything still owed coverage (skip_to, calc_coverage.cpp:345-360), so
     // runs of variants separated like that share nothing and each gets its own state machine.

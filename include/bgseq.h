@@ -512,6 +512,14 @@ int bg_assemblies_coverage(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* r
                            uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
                            const uint64_t* ext_len, int64_t end_pos, const bg_coverage_options* options /* NULL = defaults */,
                            int genotype_filter, bg_trace_result** out);
+/* The same as a session: the readmap columns calc_coverage reads are copied to the host once, bg_coverage_run is one
+ * scaffold (a reference has thousands).  One run at a time per session. */
+typedef struct bg_coverage bg_coverage;
+int bg_coverage_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, bg_coverage** out);
+int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64_t n_extents, const int64_t* ext_offset,
+                    const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos,
+                    const bg_coverage_options* options /* NULL = defaults */, int genotype_filter, bg_trace_result** out);
+void bg_coverage_close(bg_coverage* c);
 typedef struct bg_assembly_coverage {  /* assembly::coverage ... genotype_quality (assemble.h:330-370) */
   const int32_t *coverage, *pair_coverage;
   uint64_t n_coverage, n_pair_coverage;
