@@ -919,3 +919,34 @@ extern "C" int bg_trace_result_set_ml(bg_trace_result* r, uint64_t i, const bg_a
   a.merged = in->merged;
   return BG_OK;
 }
+
+// ---- the records of a bg_trace_result (host only) --------------------------------------------------------------------------
+extern "C" uint64_t bg_trace_result_size(const bg_trace_result* r) { return r ? r->a.size() : 0; }
+extern "C" void bg_trace_result_free(bg_trace_result* r) { delete r; }
+extern "C" int bg_trace_result_stats(const bg_trace_result* r, bg_trace_stats* out) {
+  if (!r || !out) { set_error("bg_trace_result_stats: null argument"); return BG_EINVAL; }
+  *out = r->stats;
+  return BG_OK;
+}
+extern "C" int bg_trace_result_get(const bg_trace_result* r, uint64_t i, bg_trace_assembly* out) {
+  if (!r || !out || i >= r->a.size()) { set_error("bg_trace_result_get: bad argument"); return BG_EINVAL; }
+  const bg_trace_assembly_rec& a = r->a[i];
+  out->left_offset = a.left_offset;
+  out->right_offset = a.right_offset;
+  out->left_anchor_len = a.left_anchor_len;
+  out->right_anchor_len = a.right_anchor_len;
+  out->seq = a.seq.data();
+  out->seq_len = a.seq.size();
+  out->min_overlap = a.min_overlap;
+  out->trace_steps = a.trace_steps;
+  out->left_anchor_ambiguous_bases = a.left_anchor_ambiguous_bases;
+  out->matches_reference = a.matches_reference ? 1 : 0;
+  out->score = a.score;
+  out->rc_read_ids = a.rc_read_ids.data();
+  out->n_rc_read_ids = a.rc_read_ids.size();
+  out->left_pair_matches = a.left_pair_matches.data();
+  out->n_left_pair_matches = a.left_pair_matches.size();
+  out->right_pair_matches = a.right_pair_matches.data();
+  out->n_right_pair_matches = a.right_pair_matches.size();
+  return BG_OK;
+}
