@@ -137,7 +137,7 @@ namespace {
 
 struct HostTables {
   std::vector<uint8_t> sizes, ref_map, is_forward;
-  std::vector<uint32_t> entry_id, mate_loop;
+  std::vector<uint32_t> entry_id, mate_loop, word_rank, group_start;
   std::vector<uint64_t> has_reads;
 };
 
@@ -157,6 +157,8 @@ struct World {
   const uint32_t* mate_loop = nullptr;  // per read id
   const uint8_t* is_forward = nullptr;  // per read id
   const uint64_t* has_reads = nullptr;  // readmap::get_bit as a bit per entry
+  const uint32_t* word_rank = nullptr;  // entries with reads before each 64-entry word
+  const uint32_t* group_start = nullptr;  // first read id of the k-th entry that carries reads (+ one past the end)
   size_t n_reads = 0;
   void bind_tables() {
     sizes = tables->sizes.data();
@@ -165,6 +167,8 @@ struct World {
     mate_loop = tables->mate_loop.data();
     is_forward = tables->is_forward.data();
     has_reads = tables->has_reads.data();
+    word_rank = tables->word_rank.data();
+    group_start = tables->group_start.data();
     n_reads = tables->entry_id.size();
   }
   int64_t scaffold_end = 0;
@@ -177,10 +181,14 @@ struct World {
   int threads = 1;
 
   unsigned match_count(uint64_t e) const { return ref_map[e] & 63u; }
-  std::pair<uint32_t, uint32_t> entry_to_index(uint64_t e) const {  // readmap.h:114-116
-    const uint32_t* lo = std::lower_bound(entry_id, entry_id + n_reads, uint32_t(e));
-    const uint32_t* hi = std::upper_bound(lo, entry_id + n_reads, uint32_t(e));
-    return {uint32_t(lo - entry_id), uint32_t(hi - entry_id)};
+  // readmap.h:114-116 (sparse_multi::lookup): the read ids of entry e.  Rank of e among the entries that carry reads
+  // (a popcount prefix per 64 entries), then that group's first read id: three touches instead of a binary search
+  // over tens of millions of read ids.  An entry without reads gives an empty range.
+  std::pair<uint32_t, uint32_t> entry_to_index(uint64_t e) const {
+    const uint64_t word = has_reads[e >> 6], bit = 1ull << (e & 63);
+    if (!(word & bit)) return {0u, 0u};
+    const uint32_t g = word_rank[e >> 6] + uint32_t(__builtin_popcountll(word & (bit - 1)));
+    return {group_start[g], group_start[g + 1]};
   }
   bool get_bit(uint64_t e) const { return (has_reads[e >> 6] >> (e & 63)) & 1; }
   bool is_entry(const TRange& r) const { return r.b + 1 == r.e && r.s == sizes[r.b]; }     // seqset.h:298-300
@@ -1065,6 +1073,15 @@ extern "C" int bg_tracer_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap
     BG_TRY(download(ctx, h->entry_id, rm->entry_id.p, rm->n_reads));
     h->has_reads.assign((ss->n + 63) / 64 + 1, 0);
     for (uint32_t e : h->entry_id) h->has_reads[e >> 6] |= 1ull << (e & 63);
+    h->word_rank.resize(h->has_reads.size() + 1);
+    uint32_t before = 0;
+    for (size_t i = 0; i < h->has_reads.size(); ++i) { h->word_rank[i] = before; before += uint32_t(__builtin_popcountll(h->has_reads[i])); }
+    h->word_rank[h->has_reads.size()] = before;
+    h->group_start.reserve(size_t(before) + 1);
+    for (size_t i = 0; i < h->entry_id.size(); ++i)
+      if (i == 0 || h->entry_id[i] != h->entry_id[i - 1]) h->group_start.push_back(uint32_t(i));
+    h->group_start.push_back(uint32_t(h->entry_id.size()));
+    if (h->group_start.size() != size_t(before) + 1) return fail("bg_tracer_open: the readmap's read ids are not grouped by entry");
     std::vector<uint64_t> tmp;
     BG_TRY(download(ctx, tmp, rm->mate_loop_ptr.p, rm->n_reads));
     h->mate_loop.assign(tmp.begin(), tmp.end());
