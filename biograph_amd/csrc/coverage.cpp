@@ -212,9 +212,19 @@ struct CovWorld {
   bg_coverage_options o;
   std::vector<uint32_t> entry_id, read_len;
   std::vector<uint8_t> is_forward;
+  // readmap::entry_to_index without a binary search over all read ids: a bit per entry that carries reads, the number
+  // of such entries before every 64-entry word, the first read id of the k-th such entry
+  std::vector<uint64_t> has_reads;
+  std::vector<uint32_t> word_rank, group_start;
   uint32_t min_read_len = 0;
   int64_t max_read_len = 0;
   Batcher* batcher = nullptr;
+  std::pair<uint32_t, uint32_t> entry_to_index(uint64_t e) const {
+    const uint64_t word = has_reads[e >> 6], bit = 1ull << (e & 63);
+    if (!(word & bit)) return {0u, 0u};
+    const uint32_t g = word_rank[e >> 6] + uint32_t(__builtin_popcountll(word & (bit - 1)));
+    return {group_start[g], group_start[g + 1]};
+  }
   int load(const bg_seqset* seqset, const bg_readmap* rm) {
     ss = seqset;
     entry_id.resize(rm->n_reads);
@@ -227,6 +237,17 @@ struct CovWorld {
     if (rm->n_reads) BG_HIP(hipMemcpy(tmp.data(), rm->is_forward.p, rm->n_reads * 8, hipMemcpyDeviceToHost));
     is_forward.resize(rm->n_reads);
     for (size_t i = 0; i < tmp.size(); ++i) is_forward[i] = uint8_t(tmp[i] & 1);
+    has_reads.assign((ss->n + 63) / 64 + 1, 0);
+    for (uint32_t e : entry_id) has_reads[e >> 6] |= 1ull << (e & 63);
+    word_rank.resize(has_reads.size() + 1);
+    uint32_t before = 0;
+    for (size_t i = 0; i < has_reads.size(); ++i) { word_rank[i] = before; before += uint32_t(__builtin_popcountll(has_reads[i])); }
+    word_rank[has_reads.size()] = before;
+    group_start.clear();
+    for (size_t i = 0; i < entry_id.size(); ++i)
+      if (i == 0 || entry_id[i] != entry_id[i - 1]) group_start.push_back(uint32_t(i));
+    group_start.push_back(uint32_t(entry_id.size()));
+    if (group_start.size() != size_t(before) + 1) { set_error("calc_coverage: the readmap's read ids are not grouped by entry"); return BG_EINVAL; }
     min_read_len = read_len.empty() ? 0 : *std::min_element(read_len.begin(), read_len.end());
     max_read_len = int64_t(ss->max_len);  // seqset::max_read_len() = the longest entry (seqset.h:71)
     return BG_OK;
@@ -301,7 +322,7 @@ class PathGroup {
 class Coverage {
  public:
   explicit Coverage(const CovWorld& w)
-      : ss_(w.ss), sc_(*w.sc), o_(w.o), entry_id_(w.entry_id), read_len_(w.read_len), is_forward_(w.is_forward),
+      : world_(w), ss_(w.ss), sc_(*w.sc), o_(w.o), read_len_(w.read_len), is_forward_(w.is_forward),
         min_read_len_(w.min_read_len), max_read_len_(w.max_read_len), batcher_(w.batcher) {
     it_offset_ = sc_.ext.empty() ? sc_.end_pos : sc_.ext[0].offset;
     cur_offset_ = it_offset_;
@@ -334,10 +355,9 @@ class Coverage {
 
   void on_seqset_entry(const Range& r, PathGroup* pg) {  // calc_coverage.cpp:455-527
     if (r.s < min_read_len_) return;
-    const auto lo = std::lower_bound(entry_id_.begin(), entry_id_.end(), uint32_t(r.b));
-    const auto hi = std::upper_bound(lo, entry_id_.end(), uint32_t(r.b));
-    if (lo == hi) return;
-    const uint32_t first = uint32_t(lo - entry_id_.begin()), last = uint32_t(hi - entry_id_.begin());
+    const std::pair<uint32_t, uint32_t> reads = world_.entry_to_index(r.b);
+    if (reads.first == reads.second) return;
+    const uint32_t first = reads.first, last = reads.second;
     pg->visit_distant_objects(r, [&](int d, int distance) {
       Tracker& cov = trackers_[size_t(d)];
       for (uint32_t rid = first; rid != last; ++rid) {
@@ -517,10 +537,11 @@ class Coverage {
     ref_pg_->flush();
   }
 
+  const CovWorld& world_;
   const bg_seqset* ss_;
   const ScaffoldView& sc_;
   bg_coverage_options o_;
-  const std::vector<uint32_t>&entry_id_, &read_len_;
+  const std::vector<uint32_t>& read_len_;
   const std::vector<uint8_t>& is_forward_;
   uint32_t min_read_len_ = 0;
   int64_t max_read_len_ = 0;
