@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--seed", type=int, default=20261002)
     ap.add_argument("--keep", action="store_true")
-    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--threads", type=int, default=16)
     args = ap.parse_args()
     import numpy as np
     import torch
