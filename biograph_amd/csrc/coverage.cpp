@@ -726,7 +726,9 @@ extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64
       need_to = std::max(need_to, a.right_offset + w.max_read_len);
     }
     std::vector<std::vector<bg_trace_assembly_rec>> done(islands.size());
-    const int workers = int(std::min<size_t>(islands.size(), 128));
+    size_t max_workers = 128;
+    if (const char* e = getenv("BG_COVERAGE_WORKERS")) max_workers = size_t(std::max(1, atoi(e)));
+    const int workers = int(std::min<size_t>(islands.size(), max_workers));
     Batcher batcher(ctx, ss, workers);
     w.batcher = &batcher;
     std::mutex err_mu;
