@@ -406,3 +406,26 @@ def test_father_vcf_records_from_the_golden_biograph(golden_dir):
         traced_ += T.reversable_trace(graph, sc, o, rev_comp=rev, anchor_drop=lambda s_, emit: A.AnchorDropper(ao, s_, emit))
     _, out = A.variants_pipeline(ao, sc, traced_, through_vcf_pad=True)
     assert vcf_columns(out, ref) == father_vcf_records(golden_dir)
+
+
+# ---- scaffold_test.cpp:24-140 (subscaffold, is_simple, the iterator) ------------------------------------------------
+def test_scaffold_test_vectors():
+    two = T.Scaffold([(5, tseq("abcde")), (100, tseq("fghi"))])
+    assert two.end_pos == 140 and not A.is_simple(two)
+    assert A.is_simple(T.Scaffold([(0, tseq("abcde"))])) and not A.is_simple(T.Scaffold([]))
+    sub = A.subscaffold(two, 80, 1)  # empty_subscaffold
+    assert sub.extents == [] and not A.is_simple(sub)
+    sub = A.subscaffold(two, 1, 139)  # offset_subscaffold
+    assert sub.end_pos == 139 and sub.extents == [(4, tseq("abcde")), (99, tseq("fghi"))]
+    sub = A.subscaffold(two, 10, 98)  # partial_subscaffold
+    assert sub.end_pos == 98 and sub.extents == [(0, tseq("abcde")[5:]), (90, tseq("fghi")[:8])]
+    sub = A.subscaffold(two, 55, 45)  # subscaffold_inside: the gap between the regions
+    assert sub.extents == [] and sub.end_pos == 45 and not A.is_simple(sub)
+    sub = A.subscaffold(two, 5, 135)  # subscaffold_outside
+    assert sub.end_pos == 135 and sub.extents == [(0, tseq("abcde")), (95, tseq("fghi"))] and not A.is_simple(sub)
+    it = T._ScaffoldIt(T.Scaffold([(5, "GA"), (10, "T")]))  # iterator
+    seen = []
+    while not it.at_end():
+        seen.append((it.offset, it.base()))
+        it.advance()
+    assert seen == [(5, "G"), (6, "A"), (10, "T")] and it.offset == 11
