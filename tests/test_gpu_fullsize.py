@@ -127,3 +127,23 @@ def test_fullsize_eight_rank_routed_build_written_in_slices_equals_fused(built, 
         assert {k: got[k] for k in bg.PART_NAMES} == {k: want[k] for k in bg.PART_NAMES}
     finally:
         opened.free()
+
+
+def test_fullsize_discovery_engine_properties():
+    """The reference's discovery engine end to end at the bench size (tools/discovery_bench.py: FASTQ -> `bgbinary
+    create` -> `bgbinary discovery`, 65 pieces x 2 directions): too big for the oracle, so the VCF is checked against
+    what the generator planted -- at least 95 % of the SNP sites are records, no SNP record lies off a planted site, and
+    a third of the called sites are homozygous, as planted."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "discovery_bench.py"), "--genome-len", str(synth.SHAPES["chr20"])],
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["planted_snps"] > 60000
+    assert d["planted_snps_in_vcf"] >= 0.95 * d["planted_snps"]
+    assert d["snp_records_not_planted"] == 0
+    assert 0.30 < d["planted_snps_called_homozygous"] / d["planted_snps_in_vcf"] < 0.40
+    assert d["vcf_records"] > d["snp_records"] > 0  # indels and SVs come out as records too
