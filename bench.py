@@ -421,7 +421,7 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
             "push_to_pair_extension": ext, "graph_discover_driver": drv, "push_tracer": push}
 
 
-def end_to_end_leg(seq, n_reads, read_len, dev, args):
+def end_to_end_leg(seq, n_reads, read_len, dev, args, genome=None):
     """`bgbinary create` from FASTQ FILES ("report both"): the reads of the bench sample written
     as two mate files, then the CLI as a user runs it — files mapped, their bytes moved to the GPU through pinned
     staging buffers, records parsed and paired on the GPU (csrc/fastq.hip), build, seqset + readmap written.
@@ -467,7 +467,8 @@ def end_to_end_leg(seq, n_reads, read_len, dev, args):
         st = json.load(open(os.path.join(out, "qc", "create_stats.json")))
         tm = {k: v for d in st["timings"] for k, v in d.items()}
         bases = st["imported_bases"]
-        return {"command": "bgbinary create --reads R1.fq --pair R2.fq --out S.bg", "fastq_bytes": fastq_bytes,
+        discovery = discovery_cli_leg(exe, out, tmp, genome, args) if genome is not None else None
+        return {"command": "bgbinary create --reads R1.fq --pair R2.fq --out S.bg", "fastq_bytes": fastq_bytes, "discovery": discovery,
                 "files_on": "tmpfs" if base else "disk", "imported_reads": st["imported_reads"], "seqset_entries": st["seqset_entries"],
                 "seconds": {"import_files_to_gpu_and_parse": tm["import"], "gpu_build_incl_readmap": tm["gpu_build"],
                             "write_seqset_and_readmap": tm["write"], "cli_total": tm["total"], "process_wall": round(wall, 3)},
@@ -477,6 +478,46 @@ def end_to_end_leg(seq, n_reads, read_len, dev, args):
                         "bench step does not pay"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def discovery_cli_leg(exe, bg_dir, tmp, genome, args):
+    """`bgbinary discovery` (the reference's engine: push tracer in both directions over every 1 Mb piece, serial
+    pipeline, calc_coverage, genotype filter, VCF records) on the .bg the create leg just wrote, against the sample's
+    reference as a FASTA: wall time, the command's own stage times, and the records against the planted SNPs."""
+    import re
+    import subprocess
+    import numpy as np
+    import torch
+    G = int(genome.numel())
+    ref = np.frombuffer(b"ACGT", np.uint8)[genome.cpu().numpy()].tobytes().decode()
+    fa = os.path.join(tmp, "ref.fa")
+    with open(fa, "w") as f:
+        f.write(">chrS\n")
+        f.write("\n".join(ref[i:i + 60] for i in range(0, G, 60)))
+        f.write("\n")
+    vcf = os.path.join(tmp, "v.vcf")
+    t0 = time.perf_counter()
+    r = subprocess.run([exe, "discovery", "--in", bg_dir, "--ref", fa, "--out", vcf], capture_output=True, text=True)
+    wall = time.perf_counter() - t0
+    if r.returncode != 0:
+        return {"error": r.stderr[-500:]}
+    out = {"command": "bgbinary discovery --in S.bg --ref ref.fa --out V.vcf", "process_wall": round(wall, 2)}
+    m = re.search(r"on (\d+) tracer session.*refmap ([\d.]+), sessions ([\d.]+), tracing ([\d.]+) \[(\d+) assemblies\], pipeline ([\d.]+) "
+                  r"\[(\d+) sections\], coverage \+ genotype ([\d.]+)", r.stderr)
+    if m:
+        out.update({"tracer_sessions": int(m.group(1)), "refmap_s": float(m.group(2)), "sessions_open_s": float(m.group(3)),
+                    "tracing_s": float(m.group(4)), "traced_assemblies": int(m.group(5)), "pipeline_s": float(m.group(6)),
+                    "sections": int(m.group(7)), "coverage_genotype_s": float(m.group(8))})
+    recs = [x.split("\t") for x in open(vcf) if not x.startswith("#")]
+    g = torch.Generator(device=genome.device)
+    g.manual_seed(args.seed + 1)
+    planted = set(torch.nonzero(torch.rand(G, generator=g, device=genome.device) < 0.001).flatten().cpu().tolist())
+    snps = {int(f[1]) - 1: f[9].split(":")[0] for f in recs if len(f[3]) == 1 and len(f[4]) == 1}
+    out.update({"vcf_records": len(recs), "vcf_records_per_s": round(len(recs) / wall, 1), "planted_snps": len(planted),
+                "planted_snps_in_vcf": len(set(snps) & planted), "snp_records_not_planted": len(set(snps) - planted),
+                "planted_snps_called_homozygous": sum(1 for p, gt in snps.items() if p in planted and gt == "1/1"),
+                "ref_bases_per_s": round(G / wall, 1)})
+    return out
 
 
 KERNEL_OF_FAMILY = {"radix_scatter_k": "rs_part_scatter_kernel",
@@ -678,7 +719,7 @@ def main():
 
     e2e = None
     if world == 1 and not args.force_sharded and not args.no_end_to_end:
-        e2e = end_to_end_leg(seq, n_reads, args.read_len, dev, args)
+        e2e = end_to_end_leg(seq, n_reads, args.read_len, dev, args, genome=None if args.no_discover else genome)
     discover = None
     if world == 1 and not args.no_discover:
         discover = discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args)
