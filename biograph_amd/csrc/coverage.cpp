@@ -128,11 +128,9 @@ class Coverage;
 
 // One stretch of bases for the heads of one path group, waiting for the device.
 struct WalkRequest {
-  const std::vector<bg_walk_chain>* chains = nullptr;  // offsets relative to this request's codes / out
-  const uint8_t* codes = nullptr;
-  size_t n_codes = 0;
-  std::vector<uint64_t>* out = nullptr;
-  bool done = false;
+  std::vector<bg_walk_chain> chains;  // offsets relative to this request's codes / out
+  std::vector<uint8_t> codes;
+  std::vector<uint64_t> out;
 };
 
 // The islands of a scaffold advance in lock step: every worker thread runs one island's state machine and stops at each
@@ -141,11 +139,13 @@ struct WalkRequest {
 class Batcher {
  public:
   Batcher(bg_ctx* ctx, const bg_seqset* ss, int workers) : ctx_(ctx), ss_(ss), live_(workers) {}
-  void submit_and_wait(WalkRequest* r) {
+  void submit_and_wait(const std::vector<WalkRequest*>& reqs) {
     std::unique_lock<std::mutex> l(mu_);
-    pending_.push_back(r);
-    if (int(pending_.size()) == live_) cv_all_.notify_one();
-    cv_done_.wait(l, [&] { return r->done; });
+    pending_.insert(pending_.end(), reqs.begin(), reqs.end());
+    ++waiting_;
+    const uint64_t round = round_;
+    if (waiting_ == live_) cv_all_.notify_one();
+    cv_done_.wait(l, [&] { return round_ != round; });
     if (!error_.empty()) throw CheckFailed{error_};
   }
   void worker_exit() {
@@ -156,7 +156,7 @@ class Batcher {
   void run() {  // on the calling thread
     std::unique_lock<std::mutex> l(mu_);
     for (;;) {
-      cv_all_.wait(l, [&] { return live_ == 0 || int(pending_.size()) == live_; });
+      cv_all_.wait(l, [&] { return live_ == 0 || waiting_ == live_; });
       if (live_ == 0) return;
       std::vector<WalkRequest*> batch;
       batch.swap(pending_);
@@ -164,7 +164,8 @@ class Batcher {
       const std::string err = launch(batch);
       l.lock();
       if (!err.empty() && error_.empty()) error_ = err;
-      for (WalkRequest* r : batch) r->done = true;
+      waiting_ = 0;
+      ++round_;
       cv_done_.notify_all();
     }
   }
@@ -178,21 +179,21 @@ class Batcher {
     size_t out_words = 0;
     for (WalkRequest* r : batch) {
       out_at.push_back(out_words);
-      for (bg_walk_chain c : *r->chains) {
+      for (bg_walk_chain c : r->chains) {
         c.code_offset += codes.size();
         c.out_offset += out_words;
         chains.push_back(c);
         steps += c.len;
       }
-      codes.insert(codes.end(), r->codes, r->codes + r->n_codes);
-      out_words += r->out->size();
+      codes.insert(codes.end(), r->codes.begin(), r->codes.end());
+      out_words += r->out.size();
     }
     std::vector<uint64_t> out(out_words);
     if (bg_walk_chains_batch(ctx_, ss_, uint32_t(chains.size()), chains.data(), codes.data(), codes.size(), out.data(), out_words) != BG_OK)
       return std::string("bg_walk_chains_batch: ") + bg_last_error();
     ++launches;
     for (size_t i = 0; i < batch.size(); ++i)
-      std::copy(out.begin() + out_at[i], out.begin() + out_at[i] + batch[i]->out->size(), batch[i]->out->begin());
+      std::copy(out.begin() + out_at[i], out.begin() + out_at[i] + batch[i]->out.size(), batch[i]->out.begin());
     return std::string();
   }
   bg_ctx* ctx_;
@@ -200,7 +201,8 @@ class Batcher {
   std::mutex mu_;
   std::condition_variable cv_all_, cv_done_;
   std::vector<WalkRequest*> pending_;
-  int live_;
+  int live_, waiting_ = 0;
+  uint64_t round_ = 0;
   std::string error_;
 };
 
@@ -261,7 +263,12 @@ class PathGroup {
   void add_distant_object(int dobj, int size) {  // :97-104
     for (auto& kv : cur_) dobj_add(kv.second.second.objects[-(kv.second.second.unprop + size)], dobj);
   }
-  void add_sequence(const char* seq, size_t len);  // add_base (:113-151) for every base, one device call
+  // add_base (:113-151) for every base of a sequence in two halves: begin_sequence says what has to be walked
+  // (false: nothing), Coverage::run_walks gets it walked together with whatever else its island has waiting, and
+  // finish_sequence replays the bases over the ranges that came back
+  bool begin_sequence(const char* seq, size_t len);
+  void finish_sequence();
+  WalkRequest* request() { return &req_; }
   void flush() {
     for (auto& kv : cur_) flush_path(kv.second.first, kv.second.second);
   }
@@ -317,6 +324,8 @@ class PathGroup {
   Coverage* c_;
   size_t max_size_;
   std::map<CurKey, std::pair<Range, Path>> cur_;
+  WalkRequest req_;
+  std::vector<std::pair<int, Path>> heads_;  // (chain, path) in cur order, while a walk is out
 };
 
 class Coverage {
@@ -329,28 +338,22 @@ class Coverage {
     init_ref_pg();
   }
 
-  // the device walk of a path group's heads along `len` bases: stops here until the batch of all islands has run
-  void walk(const std::vector<Range>& starts, const char* seq, size_t len, std::vector<uint64_t>* out) {
-    const size_t n = starts.size();
-    std::vector<bg_walk_chain> chains(n);
-    for (size_t i = 0; i < n; ++i) {
-      chains[i].begin = starts[i].b;
-      chains[i].end = starts[i].e;
-      chains[i].size = starts[i].s;
-      chains[i].len = uint32_t(len);
-      chains[i].code_offset = 0;
-      chains[i].out_offset = uint64_t(i) * 3;
-      chains[i].out_stride = uint64_t(n) * 3;
+  // Everything this island has waiting for the device -- the variant groups whose sequence walk was put off, plus
+  // `now` -- goes out as one hand-in to the batcher (one round for the island instead of one per group); then the
+  // groups replay their bases.  The order of the replays does not matter: they touch disjoint path groups and add to
+  // the trackers' counts.
+  void run_walks(PathGroup* now) {
+    std::vector<WalkRequest*> reqs;
+    for (PathGroup* pg : deferred_) reqs.push_back(pg->request());
+    if (now) reqs.push_back(now->request());
+    if (reqs.empty()) return;
+    batcher_->submit_and_wait(reqs);
+    for (PathGroup* pg : deferred_) {
+      pg->finish_sequence();
+      pg->flush();
     }
-    std::vector<uint8_t> codes(len);
-    for (size_t i = 0; i < len; ++i) codes[i] = seq[i] == 'A' ? 0 : seq[i] == 'C' ? 1 : seq[i] == 'G' ? 2 : 3;
-    out->assign(len * n * 3, 0);
-    WalkRequest r;
-    r.chains = &chains;
-    r.codes = codes.data();
-    r.n_codes = len;
-    r.out = out;
-    batcher_->submit_and_wait(&r);
+    deferred_.clear();
+    if (now) now->finish_sequence();
   }
 
   void on_seqset_entry(const Range& r, PathGroup* pg) {  // calc_coverage.cpp:455-527
@@ -394,8 +397,8 @@ class Coverage {
     tr.pair = Accum(n + 1);
     std::unique_ptr<PathGroup> pg = ref_pg_->split();
     pg->add_distant_object(t, int(n));
-    pg->add_sequence(s.a.seq.data(), n);
-    pg->flush();
+    if (pg->begin_sequence(s.a.seq.data(), n)) deferred_.push_back(pg.get());  // walked with the island's next stretch
+    else pg->flush();
     const int64_t right = shared_[size_t(sa)].a.right_offset;
     need_coverage_to_ = std::max(need_coverage_to_, right + max_read_len_);
     active_.emplace(right, std::make_pair(sa, std::move(pg)));
@@ -404,7 +407,7 @@ class Coverage {
 
   void finish(std::vector<bg_trace_assembly_rec>* out) {  // ~calc_coverage, then the destructors' reports (:105-204)
     skip_to(0x7fffffff);
-    check(active_.empty(), "calc_coverage: assemblies still active at the end");
+    check(active_.empty() && deferred_.empty(), "calc_coverage: assemblies still active at the end");
     for (Tracker& t : trackers_) {
       const std::vector<int> f = t.fwd.coverage(), r = t.rev.coverage();
       std::vector<int> both(f.size());
@@ -470,6 +473,7 @@ class Coverage {
   void flush_active_to_here() {  // :321-343
     while (!active_.empty() && active_.begin()->first <= cur_offset_) {
       if (need_ref_dobj_) add_ref_dobj(0);
+      if (!deferred_.empty()) run_walks(nullptr);  // (an insertion joins before the reference moves on)
       ref_pg_->join(*active_.begin()->second.second);
       active_.erase(active_.begin());
     }
@@ -529,7 +533,8 @@ class Coverage {
     const int64_t ref_len = target - cur_offset_;
     check(ref_len > 0, "calc_coverage: empty reference stretch");
     add_ref_dobj(ref_len);
-    ref_pg_->add_sequence(sc_.ext[it_ext_].p + it_pos_, size_t(ref_len));
+    if (ref_pg_->begin_sequence(sc_.ext[it_ext_].p + it_pos_, size_t(ref_len))) run_walks(ref_pg_.get());
+    else if (!deferred_.empty()) run_walks(nullptr);
     it_pos_ += ref_len;
     it_offset_ += ref_len;
     cur_offset_ += ref_len;
@@ -550,27 +555,45 @@ class Coverage {
   int64_t it_pos_ = 0, it_offset_ = 0, cur_offset_ = 0, need_coverage_to_ = 0, last_left_ = INT32_MIN;
   bool need_ref_dobj_ = false;
   std::multimap<int64_t, std::pair<int, std::unique_ptr<PathGroup>>> active_;
+  std::vector<PathGroup*> deferred_;  // variant groups (owned by active_) whose sequence walk has not been run yet
   std::unique_ptr<PathGroup> ref_pg_;
   std::vector<Tracker> trackers_;
   std::vector<Shared> shared_;
 };
 
-void PathGroup::add_sequence(const char* seq, size_t len) {
-  if (!len || cur_.empty()) return;
+bool PathGroup::begin_sequence(const char* seq, size_t len) {
+  if (!len || cur_.empty()) return false;
   // chain i = the i-th head in order; a merged path keeps following either of its (equal) chains
-  std::vector<Range> starts;
-  std::vector<std::pair<int, Path>> heads;  // (chain, path) in cur order
+  heads_.clear();
+  const size_t n = cur_.size();
+  req_.chains.assign(n, bg_walk_chain());
+  size_t i = 0;
   for (auto& kv : cur_) {
-    heads.emplace_back(int(starts.size()), std::move(kv.second.second));
-    starts.push_back(kv.second.first);
+    bg_walk_chain& c = req_.chains[i];
+    c.begin = kv.second.first.b;
+    c.end = kv.second.first.e;
+    c.size = kv.second.first.s;
+    c.len = uint32_t(len);
+    c.code_offset = 0;
+    c.out_offset = uint64_t(i) * 3;
+    c.out_stride = uint64_t(n) * 3;
+    heads_.emplace_back(int(i), std::move(kv.second.second));
+    ++i;
   }
-  std::vector<uint64_t> ranges;
-  c_->walk(starts, seq, len, &ranges);
-  const size_t n = starts.size();
+  cur_.clear();
+  req_.codes.resize(len);
+  for (size_t k = 0; k < len; ++k) req_.codes[k] = seq[k] == 'A' ? 0 : seq[k] == 'C' ? 1 : seq[k] == 'G' ? 2 : 3;
+  req_.out.assign(len * n * 3, 0);
+  return true;
+}
+
+void PathGroup::finish_sequence() {
+  const size_t n = req_.chains.size(), len = req_.codes.size();
+  const std::vector<uint64_t>& ranges = req_.out;
   for (size_t t = 0; t < len; ++t) {
     cur_.clear();
     std::map<CurKey, int> next_chain;
-    for (auto& h : heads) {
+    for (auto& h : heads_) {
       h.second.unprop += 1;
       const uint64_t* o = &ranges[(t * n + size_t(h.first)) * 3];
       Range r;
@@ -591,10 +614,14 @@ void PathGroup::add_sequence(const char* seq, size_t len) {
       c_->on_seqset_entry(r, this);
     }
     if (t + 1 < len) {
-      heads.clear();
-      for (auto& kv : cur_) heads.emplace_back(next_chain[kv.first], std::move(kv.second.second));
+      heads_.clear();
+      for (auto& kv : cur_) heads_.emplace_back(next_chain[kv.first], std::move(kv.second.second));
     }
   }
+  heads_.clear();
+  req_.chains.clear();
+  req_.codes.clear();
+  req_.out.clear();
 }
 
 std::string subscaffold_str(const ScaffoldView& sc, int64_t start, int64_t len) {  // scaffold.cpp:82-131: gaps read as N
