@@ -641,6 +641,7 @@ extern "C" int bg_walk_chains_batch(bg_ctx* ctx, const bg_seqset* ss, uint32_t n
   BG_TRY(buf.alloc(ctx, chain_words + code_words + size_t(out_words)));
   BG_HIP(hipMemcpyAsync(buf.p, h_chains, size_t(n_chains) * sizeof(bg_walk_chain), hipMemcpyHostToDevice, ctx->stream));
   if (n_codes) BG_HIP(hipMemcpyAsync(buf.p + chain_words, h_codes, n_codes, hipMemcpyHostToDevice, ctx->stream));
+  if (out_words) BG_HIP(hipMemsetAsync(buf.p + chain_words + code_words, 0, size_t(out_words) * 8, ctx->stream));  // gaps between strides
   ctx->tic("walk_chains");
   k_walk_chains<<<cdiv(n_chains, 64), 64, 0, ctx->stream>>>(make_view(ss), n_chains, reinterpret_cast<const bg_walk_chain*>(buf.p),
                                                             reinterpret_cast<const uint8_t*>(buf.p + chain_words),

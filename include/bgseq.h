@@ -552,7 +552,7 @@ typedef struct bg_walk_chain {
   uint64_t begin, end;      /* start range                                                     */
   uint64_t code_offset;     /* its bases: h_codes[code_offset .. code_offset + len)            */
   uint64_t out_offset;      /* range after base t: h_out[out_offset + t * out_stride .. + 3)   */
-  uint64_t out_stride;      /* in u64 words, >= 3                                              */
+  uint64_t out_stride;      /* in u64 words, >= 3; h_out is rewritten as a whole: words no chain names come back 0 */
   uint32_t size, len;
 } bg_walk_chain;
 int bg_walk_chains_batch(bg_ctx* ctx, const bg_seqset* ss, uint32_t n_chains, const bg_walk_chain* h_chains,

@@ -283,3 +283,43 @@ def test_discovery_engine_equals_oracle_on_a_120kb_sample(ctx):
     assert len(big) >= 3  # structural variants come through as records with END / SVLEN / SVTYPE
     for h in (rm, ss, c, ks, r):
         h.free()
+
+
+def test_walk_chains_batch_with_different_sequences(ctx):
+    """bg_walk_chains_batch: chains of different groups, each with its own bases, output offset and stride, in one call
+    == each chain walked on its own with bg_walk_chains."""
+    import ctypes as CT
+    from biograph_amd import capi
+    pairs, ref = synthetic_world(ctx, 3000, 23)
+    ss, rm, rmap = gpu_world(ctx, pairs, [], [ref])
+    rmap.free()
+
+    class Chain(CT.Structure):
+        _fields_ = [("begin", CT.c_uint64), ("end", CT.c_uint64), ("code_offset", CT.c_uint64), ("out_offset", CT.c_uint64),
+                    ("out_stride", CT.c_uint64), ("size", CT.c_uint32), ("len", CT.c_uint32)]
+    lut = {c: i for i, c in enumerate("ACGT")}
+    seqs = [ref[100:100 + 37], ref[900:900 + 210], ref[2000:2000 + 1]]
+    codes = np.concatenate([np.array([lut[c] for c in s_], np.uint8) for s_ in seqs])
+    offs = np.cumsum([0] + [len(s_) for s_ in seqs])
+    n = len(seqs)
+    chains = (Chain * n)()
+    out_words = 0
+    layout = []
+    for i, s_ in enumerate(seqs):
+        stride = 3 + 3 * i  # different strides
+        chains[i] = Chain(0, ss.size(), int(offs[i]), out_words, stride, 0, len(s_))
+        layout.append((out_words, stride))
+        out_words += len(s_) * stride
+    out = np.full(out_words, 0xDEADBEEF, np.uint64)
+    capi.check(capi.lib().bg_walk_chains_batch(ctx.h, ss.h, n, chains, capi.np_ptr(codes), len(codes), capi.np_ptr(out), out_words))
+    for i, s_ in enumerate(seqs):
+        start = np.array([[0, ss.size(), 0]], np.uint64)
+        one = np.zeros((len(s_), 1, 3), np.uint64)
+        capi.check(capi.lib().bg_walk_chains(ctx.h, ss.h, 1, capi.np_ptr(start), capi.np_ptr(codes[offs[i]:offs[i + 1]].copy()), len(s_),
+                                             capi.np_ptr(one)))
+        at, stride = layout[i]
+        got = out[at:at + len(s_) * stride].reshape(len(s_), stride)
+        assert (got[:, :3] == one[:, 0, :]).all()
+        assert (got[:, 3:] == 0).all()  # the buffer is rewritten as a whole: unnamed words come back 0
+    bad = (Chain * 1)(Chain(0, ss.size(), len(codes) - 1, 0, 3, 0, 5))  # reaches past the bases
+    assert capi.lib().bg_walk_chains_batch(ctx.h, ss.h, 1, bad, capi.np_ptr(codes), len(codes), capi.np_ptr(out), out_words) != 0
