@@ -198,6 +198,20 @@ def test_pipeline_test_vectors(ctx, name, rev):
             assert sc.sub(a.left_offset, a.right_offset - a.left_offset) == a.seq
 
 
+@pytest.mark.parametrize("rev", [False, True])
+@pytest.mark.parametrize("name", sorted(VA.TR_CASES))
+def test_trace_ref_push_vectors(ctx, name, rev):
+    """trace_ref_test.cpp:210-228: a reference of two scaffolds, one with an N gap, one direction at a time."""
+    scaffold, reads, want = VA.TR_CASES[name]
+    ss, rm, rmap = gpu_world(ctx, [], reads, VA.TR_REF)
+    try:
+        out = tracer.push_trace(ss, rm, rmap, VA.TR_SCAFFOLDS[scaffold], rev_comp=rev,
+                                options=tracer.TraceOptions(min_overlap=20, trace_reference_assemblies=1))
+    finally:
+        rmap.free()
+    V.expect(out, want, ordered=False)
+
+
 def test_father_vcf_records_from_the_golden_biograph(ctx, golden_dir):
     """The library's whole chain on the reference's own sample (golden father_lambda seqset + readmap as written by the
     reference): bg_push_trace both directions (tracer, anchor_dropper, pair_counter) -> bg_assemblies_process(sort ...

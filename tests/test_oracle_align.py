@@ -429,3 +429,26 @@ def test_scaffold_test_vectors():
         seen.append((it.offset, it.base()))
         it.advance()
     assert seen == [(5, "G"), (6, "A"), (10, "T")] and it.offset == 11
+
+
+# ---- trace_ref_test.cpp:210-228 (trace_ref_push_test: a two-scaffold reference, one of them with an N gap) ----------
+TR_ALPHA1, TR_ALPHA3, TR_NUM = tseq("abcdefg"), tseq("nopqrstuvw"), tseq("0123456789")
+TR_REF = [TR_ALPHA1, TR_ALPHA3, TR_NUM]
+TR_SCAFFOLDS = {"alpha": [(0, TR_ALPHA1), (len(TR_ALPHA1) + len(tseq("hijklm")), TR_ALPHA3)], "num": [(0, TR_NUM)]}
+TR_CASES = {
+    "all_reference": ("num", [tseq("012345"), tseq("34567")], [tseq("01234567")]),
+    "spans_extent": ("alpha", [tseq("bcdef"), tseq("efghijklmnop"), tseq("nopqrstuvw")],
+                     [(tseq("bcdef"), tseq("ghijklm"), tseq("nopqrstuvw"))]),
+}
+
+
+@pytest.mark.parametrize("rev", [False, True])
+@pytest.mark.parametrize("name", sorted(TR_CASES))
+def test_trace_ref_push_vectors(name, rev):
+    scaffold, reads, want = TR_CASES[name]
+    g = pipe_world(reads, TR_REF)
+    o = T.Options(min_overlap=20, trace_reference_assemblies=True)
+    ao = A.AlignOptions(min_overlap=20, trace_reference_assemblies=True)
+    out = T.reversable_trace(g, T.Scaffold(TR_SCAFFOLDS[scaffold]), o, rev_comp=rev,
+                             anchor_drop=lambda s_, emit: A.AnchorDropper(ao, s_, emit))
+    expect(out, want, ordered=False)
