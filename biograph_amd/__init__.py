@@ -479,6 +479,21 @@ class Seqset(_Handle):
     def push_front_drop_batch(self, begin, end, size, base, min_ctx):
         return self._walk(capi.lib().bg_push_front_drop_batch, begin, end, size, base, min_ctx)
 
+    def pop_front_batch(self, begin, end, size):
+        """seqset_range::pop_front for n ranges -> (begin, end, size) of the sequences without their first base."""
+        ctx = self.ctx
+        n = len(begin)
+        ins = [DeviceArray.from_numpy(ctx, np.ascontiguousarray(begin, np.uint64)),
+               DeviceArray.from_numpy(ctx, np.ascontiguousarray(end, np.uint64)),
+               DeviceArray.from_numpy(ctx, np.ascontiguousarray(size, np.uint32))]
+        outs = [DeviceArray(ctx, n * 8), DeviceArray(ctx, n * 8), DeviceArray(ctx, n * 4)]
+        try:
+            capi.check(capi.lib().bg_pop_front_batch(ctx.h, self.h, n, *[C.c_void_p(a.ptr) for a in ins + outs]))
+            return (outs[0].to_numpy(np.uint64, n), outs[1].to_numpy(np.uint64, n), outs[2].to_numpy(np.uint32, n))
+        finally:
+            for a in ins + outs:
+                a.free()
+
     def find_batch(self, seqs):
         seq, offs = _pack_strings(seqs)
         ctx = self.ctx

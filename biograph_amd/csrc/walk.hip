@@ -56,6 +56,35 @@ __global__ __launch_bounds__(256) void k_push_front_drop(SeqsetView v, uint64_t 
   ob[i] = rb; oe[i] = re; os[i] = rs;
 }
 
+// seqset_range::pop_front (bio_base/seqset.cpp:609-628): the first base b is the `fixed` bucket the range begins in;
+// the entry that push_front(b) maps onto `begin` is the (begin - fixed[b])-th set bit of prev_b (select = binary search
+// over the counts); then the range widens over the neighbours that share the shorter context.
+__global__ __launch_bounds__(256) void k_pop_front(SeqsetView v, uint64_t n, const uint64_t* __restrict__ begin,
+                                                   const uint64_t* __restrict__ end, const uint32_t* __restrict__ size,
+                                                   uint64_t* __restrict__ ob, uint64_t* __restrict__ oe,
+                                                   uint32_t* __restrict__ os) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t b0 = begin[i], e0 = end[i];
+  const uint32_t s0 = size[i];
+  if (!(b0 < e0 && e0 <= v.n) || s0 == 0) { ob[i] = 0; oe[i] = 0; os[i] = 0; return; }  // (the reference throws)
+  int b = 0;
+  while (b < 3 && b0 >= v.fixed[b + 1]) ++b;
+  const uint64_t rank = b0 - v.fixed[b];
+  uint64_t lo = 0, hi = v.n;  // smallest t with count(b, t + 1) > rank
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (v.count(b, mid + 1) > rank) hi = mid; else lo = mid + 1;
+  }
+  const uint32_t ctx_len = s0 - 1;
+  uint64_t nb = lo, ne = lo + 1;
+  while (nb && v.shared[nb] >= ctx_len) --nb;
+  while (ne < v.n && v.shared[ne] >= ctx_len) ++ne;
+  ob[i] = nb;
+  oe[i] = ne;
+  os[i] = ctx_len;
+}
+
 __global__ __launch_bounds__(256) void k_find(SeqsetView v, uint64_t n, const uint8_t* __restrict__ seq,
                                               const uint64_t* __restrict__ offs, uint64_t* __restrict__ ob,
                                               uint64_t* __restrict__ oe) {
@@ -109,6 +138,20 @@ extern "C" int bg_push_front_drop_batch(bg_ctx* ctx, const bg_seqset* ss, uint64
   ctx->tic("walk_push_front_drop");
   k_push_front_drop<<<cdiv(n, 256), 256, 0, ctx->stream>>>(make_view(ss), n, d_begin, d_end, d_size, d_base,
                                                            d_min_ctx, d_obegin, d_oend, d_osize);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n * 52);
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+extern "C" int bg_pop_front_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n, const uint64_t* d_begin,
+                                  const uint64_t* d_end, const uint32_t* d_size, uint64_t* d_obegin, uint64_t* d_oend,
+                                  uint32_t* d_osize) {
+  BG_TRY(check_ss(ctx, ss, "bg_pop_front_batch"));
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!n) return BG_OK;
+  ctx->tic("walk_pop_front");
+  k_pop_front<<<cdiv(n, 256), 256, 0, ctx->stream>>>(make_view(ss), n, d_begin, d_end, d_size, d_obegin, d_oend, d_osize);
   BG_LAUNCH_CHECK();
   ctx->toc(n * 52);
   BG_HIP(hipStreamSynchronize(ctx->stream));

@@ -197,6 +197,11 @@ int bg_push_front_drop_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n, const
                              const uint64_t* d_end, const uint32_t* d_size, const uint8_t* d_base,
                              const uint32_t* d_min_ctx, uint64_t* d_obegin, uint64_t* d_oend,
                              uint32_t* d_osize);
+/* seqset_range::pop_front (bio_base/seqset.cpp:609-628; the walk primitive of the pop tracer, variants/pop_tracer.cpp):
+ * the range of the sequence without its first base.  An invalid or empty input range (the reference throws) gives
+ * (0, 0, 0). */
+int bg_pop_front_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n, const uint64_t* d_begin, const uint64_t* d_end,
+                       const uint32_t* d_size, uint64_t* d_obegin, uint64_t* d_oend, uint32_t* d_osize);
 /* find: queries are concatenated ACGT strings (device), n+1 offsets; result ranges (begin,end). */
 int bg_find_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n, const uint8_t* d_seq,
                   const uint64_t* d_offs, uint64_t* d_obegin, uint64_t* d_oend);

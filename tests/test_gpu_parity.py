@@ -227,6 +227,47 @@ def test_walk_matches_oracle(ctx, golden_dir):
         assert (int(b), int(e)) == (wb, we) or (b >= e and wb >= we)
 
 
+def test_pop_front_matches_find_and_undoes_push_front(ctx, golden_dir):
+    """bg_pop_front_batch (seqset_range::pop_front, seqset.cpp:609-628) on the golden lambda seqset: popping the first
+    base of a prefix of an entry gives the range find() gives for the rest of the prefix; chains of pops walk an entry
+    down to the empty context; pop after push_front gets back the range pushed from (when that push kept its context)."""
+    d = O.load_seqset_zip(golden_dir + "/father_lambda/seqset")
+    oss = O.Seqset.from_arrays(d["sizes"], d["shared"], d["bits"])
+    ss = ctx.seqset_from_arrays(d["sizes"], d["shared"], d["bits"])
+    n = d["n"]
+    ent = O.decode_entries(d)
+    rng = np.random.default_rng(17)
+    ids = rng.integers(0, n, 3000)
+    lens = np.array([rng.integers(1, len(ent[int(i)]) + 1) for i in ids])
+    seqs = [ent[int(i)][:int(k)] for i, k in zip(ids, lens)]
+    start = [oss.find(x) for x in seqs]
+    b = np.array([x[0] for x in start], np.uint64)
+    e = np.array([x[1] for x in start], np.uint64)
+    sz = lens.astype(np.uint32)
+    pb, pe, ps = ss.pop_front_batch(b, e, sz)
+    for x, gb, ge, gs in zip(seqs, pb, pe, ps):
+        wb, we, _ = oss.find(x[1:])
+        assert (int(gb), int(ge), int(gs)) == (wb, we, len(x) - 1)
+    # whole chains down to the empty context
+    cb, ce, cs = b[:200].copy(), e[:200].copy(), sz[:200].copy()
+    steps = 0
+    while (cs > 0).any():
+        live = cs > 0
+        nb, ne, ns = ss.pop_front_batch(cb[live], ce[live], cs[live])
+        cb[live], ce[live], cs[live] = nb, ne, ns
+        steps += 1
+    assert steps == int(sz[:200].max()) and (cb == 0).all() and (ce == n).all()
+    # pop undoes a push that did not have to drop context
+    base = rng.integers(0, 4, len(b)).astype(np.uint8)
+    qb, qe, qs = ss.push_front_batch(b, e, sz, base)
+    ok = qe > qb
+    rb, re_, rs = ss.pop_front_batch(qb[ok], qe[ok], qs[ok])
+    assert (rb == b[ok]).all() and (re_ == e[ok]).all() and (rs == sz[ok]).all() and ok.sum() > 500
+    # invalid / empty inputs: (0, 0, 0)
+    zb, ze, zs = ss.pop_front_batch(np.array([5, 0], np.uint64), np.array([5, n], np.uint64), np.array([3, 0], np.uint32))
+    assert (zb == 0).all() and (ze == 0).all() and (zs == 0).all()
+
+
 def test_synthetic_wgs_shape_full_path(ctx):
     """30x 150 bp paired reads with errors and N's through the whole create path, vs the oracle."""
     import torch
