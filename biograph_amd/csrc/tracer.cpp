@@ -1012,14 +1012,18 @@ struct PairCounter {
       bg_trace_assembly_rec a = std::move(right.front().second);
       right.pop_front();
       for (uint32_t rid : a.rc_read_ids) right_ids.dec(rid);
-      a.left_pair_matches = matches(a, left_ids, w.o.forward_pairs_face_inward != 0);
+      // (a reference assembly that is not going to be output only lends its read ids to the others: its own
+      // matches would be thrown away with it below)
+      const bool unused = a.matches_reference && !w.o.trace_reference_assemblies;
+      if (!unused) a.left_pair_matches = matches(a, left_ids, w.o.forward_pairs_face_inward != 0);
       const int64_t ro = a.right_offset;
       active.emplace(ro, std::move(a));
     }
     while (!active.empty() && active.begin()->first < cur_offset) {
       bg_trace_assembly_rec a = std::move(active.begin()->second);
       active.erase(active.begin());
-      a.right_pair_matches = matches(a, right_ids, w.o.forward_pairs_face_inward == 0);
+      const bool unused = a.matches_reference && !w.o.trace_reference_assemblies;
+      if (!unused) a.right_pair_matches = matches(a, right_ids, w.o.forward_pairs_face_inward == 0);
       std::vector<uint32_t> ids = std::move(a.rc_read_ids);
       a.rc_read_ids.clear();
       for (uint32_t rid : ids) left_ids.inc(rid);
