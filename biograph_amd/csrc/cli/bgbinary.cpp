@@ -756,7 +756,8 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   // trace_ref runs its work items on the process's thread pool (trace_ref.cpp:105-140); here: --threads sessions
   // (default 16: tracing the chr20-shaped sample takes 19 s on 8, 9.7 s on 16, 10.2 s on 24), each with its own context
   // (stream + allocator) and scratch, the read-only host tables shared, side by side on the one GPU
-  int n_threads = atoi(a.get("threads", "16").c_str());
+  int n_threads = a.has("threads") ? atoi(a.get("threads").c_str())
+                                   : int(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
   if (n_threads < 1) n_threads = 1;
   if (n_threads > 64) n_threads = 64;
   const double t_open0 = now_s();
