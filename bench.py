@@ -497,11 +497,12 @@ def discovery_cli_leg(exe, bg_dir, tmp, genome, args):
         f.write("\n")
     vcf = os.path.join(tmp, "v.vcf")
     t0 = time.perf_counter()
-    r = subprocess.run([exe, "discovery", "--in", bg_dir, "--ref", fa, "--out", vcf], capture_output=True, text=True)
+    # --simple-gt true: GT is needed for the planted-genotype figures (the reference's default leaves every record 0/1)
+    r = subprocess.run([exe, "discovery", "--in", bg_dir, "--ref", fa, "--out", vcf, "--simple-gt", "true"], capture_output=True, text=True)
     wall = time.perf_counter() - t0
     if r.returncode != 0:
         return {"error": r.stderr[-500:]}
-    out = {"command": "bgbinary discovery --in S.bg --ref ref.fa --out V.vcf", "process_wall": round(wall, 2)}
+    out = {"command": "bgbinary discovery --in S.bg --ref ref.fa --out V.vcf --simple-gt true", "process_wall": round(wall, 2)}
     m = re.search(r"on (\d+) tracer session.*refmap ([\d.]+), sessions ([\d.]+), tracing ([\d.]+) \[(\d+) assemblies\], pipeline ([\d.]+) "
                   r"\[(\d+) sections\], coverage \+ genotype ([\d.]+)", r.stderr)
     if m:

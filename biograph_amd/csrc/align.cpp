@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <memory>
 
@@ -540,6 +541,10 @@ class VcfPadder : public SortedOutput {
 }  // namespace
 
 bool canon_assembly_less(const bg_trace_assembly_rec& a, const bg_trace_assembly_rec& b) { return canon_less(a, b); }
+uint64_t allocate_assembly_id() {
+  static std::atomic<uint64_t> next{1};
+  return next.fetch_add(1);
+}
 
 void merge_bookkeeping(bg_trace_assembly_rec& target, const bg_trace_assembly_rec& a) {
   target.merged += 1 + a.merged;
@@ -605,8 +610,18 @@ int64_t ScaffoldView::shared_suffix_length(const char* s, int64_t n) const {
 }
 
 // ---- sorted_output_pipeline_step ----------------------------------------------------------------------------------------
+void SortedOutput::track_left_offset(int64_t offset) {
+  check(offset >= flush_point_, "sorted output: tracked offset behind the flush point");
+  tracked_.insert(offset);
+}
+void SortedOutput::untrack_left_offset(int64_t offset) {
+  auto it = tracked_.find(offset);
+  check(it != tracked_.end(), "sorted output: offset is not tracked");
+  tracked_.erase(it);
+}
 void SortedOutput::flush_sorted_to(int64_t offset) {
   check(offset >= flush_point_, "sorted output: flush goes backwards (input not sorted by left offset)");
+  if (!tracked_.empty() && offset > *tracked_.begin()) offset = *tracked_.begin();
   size_t n = 0;
   while (n < queue_.size() && std::min(queue_[n].left_offset, queue_[n].right_offset) < offset) ++n;
   for (size_t i = 0; i < n; ++i) out_(std::move(queue_[i]));
@@ -795,6 +810,7 @@ extern "C" int bg_trace_result_add(bg_trace_result* r, const bg_trace_assembly* 
   if (a->n_rc_read_ids) x.rc_read_ids.assign(a->rc_read_ids, a->rc_read_ids + a->n_rc_read_ids);
   if (a->n_left_pair_matches) x.left_pair_matches.assign(a->left_pair_matches, a->left_pair_matches + a->n_left_pair_matches);
   if (a->n_right_pair_matches) x.right_pair_matches.assign(a->right_pair_matches, a->right_pair_matches + a->n_right_pair_matches);
+  x.assembly_id = a->assembly_id ? a->assembly_id : allocate_assembly_id();  // assembly::assembly(), assemble.cpp:1248
   r->a.push_back(std::move(x));
   return BG_OK;
 }
@@ -948,5 +964,6 @@ extern "C" int bg_trace_result_get(const bg_trace_result* r, uint64_t i, bg_trac
   out->n_left_pair_matches = a.left_pair_matches.size();
   out->right_pair_matches = a.right_pair_matches.data();
   out->n_right_pair_matches = a.right_pair_matches.size();
+  out->assembly_id = a.assembly_id;
   return BG_OK;
 }

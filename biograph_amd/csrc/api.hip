@@ -213,6 +213,15 @@ extern "C" int bg_ctx_create_own_stream(int device, bg_ctx** out) {
   }
   (*out)->stream = s;
   (*out)->owns_stream = true;
+  // The shared arena hands a released chunk out again at once, which is only safe among users ordered on ONE stream
+  // (torch's current stream = the stream of the contexts made with bg_ctx_create).  A context on a stream of its own
+  // therefore always keeps its private arena: chunks never move between streams.
+  if ((*out)->arena != &(*out)->own_arena) {
+    (*out)->arena = &(*out)->own_arena;
+    size_t fr = 0, total = 0;
+    if (hipMemGetInfo(&fr, &total) == hipSuccess) (*out)->own_arena.set_cap(size_t(double(total) * 0.35));
+    else (void)hipGetLastError();
+  }
   return BG_OK;
 }
 

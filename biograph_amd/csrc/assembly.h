@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <functional>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -42,6 +43,9 @@ struct bg_trace_assembly_rec {  // variants::assembly (assemble.h:285-380), the 
   float ml_refgc = 0, ml_altgc = 0;
   uint64_t ml_alt_len = 0;
   uint32_t merged = 0;
+  // assembly::assembly_id (assemble.h:295): one id per traced assembly, inherited by everything cut or copied from it
+  // (split_assembly, the anchor_dropper's anchored copy); rvg_exclude groups sections by it
+  uint64_t assembly_id = 0;
 };
 
 struct bg_trace_result {
@@ -62,6 +66,7 @@ struct ScaffoldView {
 };
 
 bool canon_assembly_less(const bg_trace_assembly_rec& a, const bg_trace_assembly_rec& b);
+uint64_t allocate_assembly_id();  // assemble.cpp:873-877: process-wide, starts at 1
 // what deduper::combine / exact_deduper keep of the assembly they swallow (dedup.cpp:51-53,71-78,171-183)
 void merge_bookkeeping(bg_trace_assembly_rec& target, const bg_trace_assembly_rec& a);  // canon_assembly_order (align.cpp)
 
@@ -78,11 +83,15 @@ class SortedOutput {
  protected:
   void flush_sorted_to(int64_t offset);
   void sort_and_output(bg_trace_assembly_rec&& a);
+  // left offsets of assemblies a step still holds back: nothing at or beyond the first of them leaves the queue
+  void track_left_offset(int64_t offset);
+  void untrack_left_offset(int64_t offset);
 
  private:
   AssemblySink out_;
   std::vector<bg_trace_assembly_rec> queue_;  // ascending canon order, equal keys in arrival order
   int64_t flush_point_ = INT32_MIN;
+  std::multiset<int64_t> tracked_;
 };
 
 struct AlignParams {  // the assemble_options fields the steps of align.cpp read

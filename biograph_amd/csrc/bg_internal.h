@@ -79,6 +79,20 @@ namespace bg {
 // (csrc/fastq.hip).  threads <= 0: hardware_concurrency (at most 32).
 int staged_download(bg_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes, int threads);
 
+// Host <-> device copies ordered on the context's stream (a null-stream hipMemcpy does not wait for a non-blocking
+// stream such as bg_ctx_create_own_stream's or a torch side stream): the copy is queued behind the kernels launched so
+// far and the call returns when it has landed.
+inline hipError_t copy_d2h(bg_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+  if (!bytes) return hipSuccess;
+  hipError_t e = hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream);
+}
+inline hipError_t copy_h2d(bg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+  if (!bytes) return hipSuccess;
+  hipError_t e = hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream);
+  return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream);
+}
+
 // RAII device buffer drawn from the context cache.
 template <class T>
 struct DevBuf {

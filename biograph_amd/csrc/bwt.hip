@@ -230,9 +230,9 @@ extern "C" int bg_bwt_build(bg_ctx* ctx, const uint8_t* d_codes, uint32_t n_exte
     }
     BG_TRY(bitcount_finalize_plain(ctx, bits, n, &sub, &acc));
     char* dst = &file[16 + size_t(v) * bits_size];
-    if (nwords) BG_HIP(hipMemcpy(dst, bits.p, nwords * 8, hipMemcpyDeviceToHost));
-    if (ngroups) BG_HIP(hipMemcpy(dst + nwords * 8, sub.p, ngroups * 8, hipMemcpyDeviceToHost));
-    if (naccum) BG_HIP(hipMemcpy(dst + (nwords + ngroups) * 8, acc.p, naccum * 8, hipMemcpyDeviceToHost));
+    if (nwords) BG_HIP(bg::copy_d2h(ctx, dst, bits.p, nwords * 8));
+    if (ngroups) BG_HIP(bg::copy_d2h(ctx, dst + nwords * 8, sub.p, ngroups * 8));
+    if (naccum) BG_HIP(bg::copy_d2h(ctx, dst + (nwords + ngroups) * 8, acc.p, naccum * 8));
   }
   uint64_t n_cent = 0;
   {
@@ -243,7 +243,7 @@ extern "C" int bg_bwt_build(bg_ctx* ctx, const uint8_t* d_codes, uint32_t n_exte
     if (n_cent) {
       k_bwt_century_table<<<cdiv(n_cent, 256), 256, 0, ctx->stream>>>(pos.p, n_cent, sa.p, d_start.p, d_flat.p, n_extents, table.p);
       BG_LAUNCH_CHECK();
-      BG_HIP(hipMemcpy(&file[16 + 5 * bits_size], table.p, n_cent * 4, hipMemcpyDeviceToHost));
+      BG_HIP(bg::copy_d2h(ctx, &file[16 + 5 * bits_size], table.p, n_cent * 4));
     }
   }
   // ---- msgpack header {1: version {1: major, 2: minor, 3: patch, 4: "", 5: ""}, 2: ca_table} (bwt_file.h:9-18).  The

@@ -753,6 +753,18 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     opt.output_ml_features = on;
     cov.output_ml_features = on;
   }
+  // --simple-gt (biograph_variants.cpp:201,690; false there: every covered variant section is written, unfiltered) and
+  // --rvg-exclude (:194,689; true there: rvg_exclude.cpp behind the genotype step, pipeline.cpp:102-104)
+  auto flag = [&](const char* name, bool dflt) {
+    if (!a.has(name)) return dflt;
+    const std::string v = a.get(name);
+    if (v == "true" || v == "1" || v == "on" || v == "yes") return true;
+    if (v == "false" || v == "0" || v == "off" || v == "no") return false;
+    die(std::string("discovery: --") + name + " takes true or false");
+    return dflt;
+  };
+  cov.simple_genotype_filter = flag("simple-gt", false) ? 1 : 0;
+  cov.rvg_exclude = flag("rvg-exclude", true) ? 1 : 0;
   // trace_ref runs its work items on the process's thread pool (trace_ref.cpp:105-140); here: --threads sessions
   // (default 16: tracing the chr20-shaped sample takes 19 s on 8, 9.7 s on 16, 10.2 s on 24), each with its own context
   // (stream + allocator) and scratch, the read-only host tables shared, side by side on the one GPU
@@ -910,7 +922,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
 
 static int cmd_discovery(int argc, char** argv) {
   Args a = parse(argc, argv, 2, {"reads", "ref", "out", "sample", "min-overlap", "max-pair-distance", "bed", "engine", "max-ploids",
-                                 "enable-pop-tracer", "threads", "ml-features", "scaffold-split-size"});
+                                 "enable-pop-tracer", "threads", "ml-features", "scaffold-split-size", "simple-gt", "rvg-exclude"});
   if (!a.has("reads") || !a.has("ref") || !a.has("out")) die("discovery: --in S.bg, --ref and --out are required");
   std::string bgdir = a.get("reads");
   // --engine push (default): the reference's discovery engine -- push tracer, anchor_dropper, pair_counter, the

@@ -47,6 +47,7 @@ extern "C" void bg_coverage_options_default(bg_coverage_options* o) {
   o->min_read_depth = 1;                 // assemble.h:707
   o->vcf_sv_size_threshold = 20;         // assemble.h:724
   o->output_ml_features = 0;             // assemble.h:730 (biograph_variants.cpp:686 switches it on)
+  o->rvg_exclude = 0;                    // assemble.h:699 (biograph_variants.cpp:194,689: --rvg-exclude, true there)
 }
 
 namespace {
@@ -227,16 +228,16 @@ struct CovWorld {
     const uint32_t g = word_rank[e >> 6] + uint32_t(__builtin_popcountll(word & (bit - 1)));
     return {group_start[g], group_start[g + 1]};
   }
-  int load(const bg_seqset* seqset, const bg_readmap* rm) {
+  int load(bg_ctx* ctx, const bg_seqset* seqset, const bg_readmap* rm) {
     ss = seqset;
     entry_id.resize(rm->n_reads);
     std::vector<uint64_t> tmp(rm->n_reads);
     if (rm->n_reads) {
-      BG_HIP(hipMemcpy(entry_id.data(), rm->entry_id.p, rm->n_reads * 4, hipMemcpyDeviceToHost));
-      BG_HIP(hipMemcpy(tmp.data(), rm->read_len.p, rm->n_reads * 8, hipMemcpyDeviceToHost));
+      BG_HIP(bg::copy_d2h(ctx, entry_id.data(), rm->entry_id.p, rm->n_reads * 4));
+      BG_HIP(bg::copy_d2h(ctx, tmp.data(), rm->read_len.p, rm->n_reads * 8));
     }
     read_len.assign(tmp.begin(), tmp.end());
-    if (rm->n_reads) BG_HIP(hipMemcpy(tmp.data(), rm->is_forward.p, rm->n_reads * 8, hipMemcpyDeviceToHost));
+    if (rm->n_reads) BG_HIP(bg::copy_d2h(ctx, tmp.data(), rm->is_forward.p, rm->n_reads * 8));
     is_forward.resize(rm->n_reads);
     for (size_t i = 0; i < tmp.size(); ++i) is_forward[i] = uint8_t(tmp[i] & 1);
     has_reads.assign((ss->n + 63) / 64 + 1, 0);
@@ -683,6 +684,62 @@ bool genotype(const bg_coverage_options& o, bg_trace_assembly_rec& a) {
   return true;
 }
 
+// rvg_exclude (rvg_exclude.cpp:5-67), the last step of the standard pipeline (pipeline.cpp:102-104): a small variant
+// section without pair support at some position is held back; it leaves only if a structural section of the same
+// traced assembly (same assembly_id: "in phase") shows up, before or after it.
+class RvgExclude : public SortedOutput {
+ public:
+  RvgExclude(const bg_coverage_options& o, AssemblySink out) : SortedOutput(std::move(out)), o_(o) {}
+  void add(bg_trace_assembly_rec&& a) {
+    flush_sorted_to(a.left_offset);
+    if (a.matches_reference) { sort_and_output(std::move(a)); return; }
+    unsigned reflen = unsigned(a.right_offset - a.left_offset), seqlen = unsigned(a.seq.size());
+    if (!reflen || !seqlen) { ++reflen; ++seqlen; }  // compare as if VCF padded
+    if (seqlen >= o_.vcf_sv_size_threshold || reflen >= o_.vcf_sv_size_threshold) {
+      in_phase_.insert(a.assembly_id);
+      auto it = backlog_.find(a.assembly_id);
+      if (it != backlog_.end()) {
+        for (auto& old : it->second) {
+          untrack_left_offset(old.left_offset);
+          sort_and_output(std::move(old));
+        }
+        backlog_.erase(it);
+      }
+      sort_and_output(std::move(a));
+      return;
+    }
+    bool output_this;
+    if (a.other_pair_depth || in_phase_.count(a.assembly_id)) {
+      output_this = true;
+    } else {
+      check(!a.pair_coverage.empty(), "rvg_exclude: assembly without pair coverage");
+      output_this = true;
+      for (int depth : a.pair_coverage)
+        if (!depth) { output_this = false; break; }
+    }
+    if (output_this) { sort_and_output(std::move(a)); return; }
+    track_left_offset(a.left_offset);
+    backlog_[a.assembly_id].push_back(std::move(a));
+  }
+  void finish() {  // flush(): what is still held back is gone
+    for (auto& e : backlog_)
+      for (auto& a : e.second) untrack_left_offset(a.left_offset);
+    backlog_.clear();
+    flush();
+  }
+
+ private:
+  bg_coverage_options o_;
+  std::map<uint64_t, std::vector<bg_trace_assembly_rec>> backlog_;
+  std::set<uint64_t> in_phase_;
+};
+
+void rvg_exclude_all(const bg_coverage_options& o, std::vector<bg_trace_assembly_rec>&& in, std::vector<bg_trace_assembly_rec>* out) {
+  RvgExclude step(o, [&](bg_trace_assembly_rec&& a) { out->push_back(std::move(a)); });
+  for (auto& a : in) step.add(std::move(a));
+  step.finish();
+}
+
 }  // namespace
 
 // The readmap columns calc_coverage reads, copied to the host once (a reference has thousands of scaffolds, each its
@@ -700,7 +757,7 @@ extern "C" int bg_coverage_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readm
   std::unique_ptr<bg_coverage> c(new bg_coverage);
   c->ctx = ctx;
   c->ss = ss;
-  BG_TRY(c->tables.load(ss, rm));
+  BG_TRY(c->tables.load(ctx, ss, rm));
   *out = c.release();
   return BG_OK;
 }
@@ -785,8 +842,11 @@ extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64
     for (auto& d : done)
       for (auto& a : d) covered.push_back(std::move(a));
     std::stable_sort(covered.begin(), covered.end(), bg::canon_assembly_less);
+    std::vector<bg_trace_assembly_rec> passed;
     for (auto& a : covered)
-      if (!genotype_filter || genotype(o, a)) res->a.push_back(std::move(a));
+      if (!genotype_filter || genotype(o, a)) passed.push_back(std::move(a));
+    if (o.rvg_exclude) rvg_exclude_all(o, std::move(passed), &res->a);  // pipeline.cpp:102-104
+    else res->a = std::move(passed);
     res->stats.device_rounds = batcher.launches;
     res->stats.device_queries = batcher.steps;
     res->stats.traces = islands.size();
@@ -811,6 +871,41 @@ extern "C" int bg_trace_result_coverage(const bg_trace_result* r, uint64_t i, bg
   out->ref_depth = a.ref_depth;
   out->strand_count = a.strand_count;
   out->genotype_quality = a.genotype_quality;
+  return BG_OK;
+}
+
+extern "C" int bg_trace_result_set_coverage(bg_trace_result* r, uint64_t i, const bg_assembly_coverage* in) {
+  if (!r || !in || i >= r->a.size() || (in->n_coverage && !in->coverage) || (in->n_pair_coverage && !in->pair_coverage)) {
+    set_error("bg_trace_result_set_coverage: bad argument");
+    return BG_EINVAL;
+  }
+  bg_trace_assembly_rec& a = r->a[i];
+  a.has_coverage = in->has_coverage != 0;
+  a.coverage.assign(in->coverage, in->coverage + in->n_coverage);
+  a.pair_coverage.assign(in->pair_coverage, in->pair_coverage + in->n_pair_coverage);
+  a.other_depth = in->other_depth;
+  a.other_pair_depth = in->other_pair_depth;
+  a.ref_depth = in->ref_depth;
+  a.strand_count = in->strand_count;
+  a.genotype_quality = in->genotype_quality;
+  return BG_OK;
+}
+
+// rvg_exclude as a step of its own (host only): `in` = what calc_coverage / simple_genotype_filter emit for one scaffold
+extern "C" int bg_assemblies_rvg_exclude(const bg_trace_result* in, const bg_coverage_options* options, bg_trace_result** out) {
+  if (!in || !out) { set_error("bg_assemblies_rvg_exclude: null argument"); return BG_EINVAL; }
+  bg_coverage_options o;
+  if (options) o = *options; else bg_coverage_options_default(&o);
+  std::unique_ptr<bg_trace_result> res(new bg_trace_result);
+  res->stats = in->stats;
+  try {
+    std::vector<bg_trace_assembly_rec> copy = in->a;
+    rvg_exclude_all(o, std::move(copy), &res->a);
+  } catch (const CheckFailed& f) {
+    set_error("bg_assemblies_rvg_exclude: %s", f.what.c_str());
+    return BG_EINVAL;
+  }
+  *out = res.release();
   return BG_OK;
 }
 

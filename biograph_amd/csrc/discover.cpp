@@ -114,7 +114,7 @@ struct Walker {
     n = bg_seqset_size(ss);
     shared.resize(n);
     if (n) {
-      if (hipMemcpy(shared.data(), ss->shared.p, n, hipMemcpyDeviceToHost) != hipSuccess) { set_error("discover: download failed"); return BG_EINTERNAL; }
+      if (bg::copy_d2h(ctx, shared.data(), ss->shared.p, n) != hipSuccess) { set_error("discover: download failed"); return BG_EINTERNAL; }
     }
     return BG_OK;
   }
@@ -138,13 +138,13 @@ struct Walker {
   template <class T>
   int up(DevBuf<T>& d, const std::vector<T>& h) {
     BG_TRY(d.alloc(ctx, h.size()));
-    if (!h.empty()) BG_HIP(hipMemcpy(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (!h.empty()) BG_HIP(bg::copy_h2d(ctx, d.p, h.data(), h.size() * sizeof(T)));
     return BG_OK;
   }
   template <class T>
   int down(std::vector<T>& h, const DevBuf<T>& d, size_t count) {
     h.resize(count);
-    if (count) BG_HIP(hipMemcpy(h.data(), d.p, count * sizeof(T), hipMemcpyDeviceToHost));
+    if (count) BG_HIP(bg::copy_d2h(ctx, h.data(), d.p, count * sizeof(T)));
     return BG_OK;
   }
   static void flatten(const std::vector<std::vector<Range>>& fr, std::vector<uint32_t>* foff, std::vector<uint64_t>* b,
@@ -200,7 +200,7 @@ struct Walker {
       DevBuf<uint8_t> din, dout;
       BG_TRY(din.alloc(ctx, hin.size()));
       BG_TRY(dout.alloc(ctx, hout.size()));
-      BG_HIP(hipMemcpy(din.p, hin.data(), hin.size(), hipMemcpyHostToDevice));
+      BG_HIP(bg::copy_h2d(ctx, din.p, hin.data(), hin.size()));
       auto I = [&](const Slot& sl) { return din.p + sl.off; };
       auto Od = [&](const Slot& sl) { return dout.p + sl.off; };
       BG_TRY(bg_propagate_from_end_batch(
@@ -214,7 +214,7 @@ struct Walker {
           reinterpret_cast<uint64_t*>(Od(o_tb)), reinterpret_cast<uint64_t*>(Od(o_te)), reinterpret_cast<uint32_t*>(Od(o_ts))));
       // without mates only the head of the output block is needed
       size_t need = with_mates ? out_bytes : o_tb.off;
-      BG_HIP(hipMemcpy(hout.data(), dout.p, need, hipMemcpyDeviceToHost));
+      BG_HIP(bg::copy_d2h(ctx, hout.data(), dout.p, need));
       auto H = [&](const Slot& sl) { return hout.data() + sl.off; };
       const uint32_t* nm = reinterpret_cast<const uint32_t*>(H(o_nm));
       uint32_t worst = 0;

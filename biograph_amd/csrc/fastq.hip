@@ -96,6 +96,12 @@ __global__ void fq_spans_kernel(const uint8_t* __restrict__ text, uint64_t n, co
   uint64_t s1 = line_end(4 * r + 1);
   if (h0 >= n || text[h0] != '@' || p0 >= n || text[p0] != '+') atomicMin(&err[0], (unsigned long long)(r + 1));
   if (s1 > s0 && text[s1 - 1] == '\r') --s1;
+  {  // fastq.cpp:121-124: "Quality line not same length as sequence" (a truncated record must not pass)
+    const uint64_t q0 = line_start(4 * r + 3);
+    uint64_t q1 = line_end(4 * r + 3);
+    if (q1 > q0 && q0 < n && text[q1 - 1] == '\r') --q1;
+    if (q0 > n || q1 - (q0 < q1 ? q0 : q1) != s1 - s0) atomicMin(&err[0], (unsigned long long)(r + 1));
+  }
   uint64_t start = s0, len = s1 - s0;
   if (cut_end) {  // read_batch::cut_reads, read_importer.cpp:157-169
     const uint64_t this_end = len < cut_end ? len : cut_end;
@@ -299,7 +305,15 @@ extern "C" int bg_fastq_import(bg_ctx* ctx, uint32_t n_src, const uint8_t* const
       if (tail[tl - 1] != '\n') {
         ++lines;
       } else {
-        for (uint64_t i = tl - 1; i > 0 && tail[i - 1] == '\n' && lines > 0; --i) --lines;
+        // a blank line is "\n" or "\r\n" (a CRLF file may end in "\r\n\r\n")
+        uint64_t i = tl - 1;  // tail[i] is the newline that ends the last line
+        while (lines > 0) {
+          uint64_t j = i;
+          if (j > 0 && tail[j - 1] == '\r') --j;
+          if (j == 0 || tail[j - 1] != '\n') break;
+          --lines;
+          i = j - 1;
+        }
       }
     }
     if (lines % 4) { set_error("source %u: malformed FASTQ (%llu lines are not a whole number of records)", s, (unsigned long long)lines); return BG_EINVAL; }
@@ -331,7 +345,7 @@ extern "C" int bg_fastq_import(bg_ctx* ctx, uint32_t n_src, const uint8_t* const
   unsigned long long h_err[2] = {0, 0};
   BG_HIP(hipMemcpyAsync(h_err, err.p, 16, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
-  if (h_err[0] != ~0ull) { set_error("malformed FASTQ record %llu ('@' or '+' line missing)", h_err[0]); return BG_EINVAL; }
+  if (h_err[0] != ~0ull) { set_error("malformed FASTQ record %llu ('@' or '+' line missing, or quality line not the sequence's length)", h_err[0]); return BG_EINVAL; }
   if (h_err[1] != ~0ull) { set_error("--cut-reads: record %llu is shorter than the start of the range", h_err[1]); return BG_EINVAL; }
   uint64_t* d_offs = nullptr;
   uint8_t* d_seq = nullptr;

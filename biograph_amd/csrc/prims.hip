@@ -75,7 +75,9 @@ int bg_ctx::alloc(size_t bytes, void** out) {
 
 // The chunk goes back to the arena at once: everything a context does is ordered on its one stream, so whoever gets
 // the chunk next is ordered after the work that used it; a wholly free segment may go back to the driver
-// (hipFree waits for the device).
+// (hipFree waits for the device).  An arena is never shared across streams: the per-device arena of
+// bg_torch_allocator_enable serves torch's current stream and the contexts created ON that stream (bg_ctx_create's
+// `stream` argument must be torch's current stream in that mode); bg_ctx_create_own_stream keeps a private arena.
 void bg_ctx::release(void* p) {
   std::lock_guard<std::mutex> lock(bg::g_arena_mutex);
   (void)arena->release(p);

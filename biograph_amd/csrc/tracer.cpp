@@ -537,6 +537,7 @@ struct Trace {
   // ---- output (:1023-1250)
   void output_assembly(const Rejoin& r) {
     bg_trace_assembly_rec a;
+    a.assembly_id = allocate_assembly_id();  // tracer.cpp:1166
     std::string seq;
     std::set<uint32_t> ids;
     for (int cur = r.path; cur >= 0; cur = paths[cur].prev) {

@@ -18,6 +18,8 @@ the merged seqset with the reference cut into chunks that the ranks share out.
            the end.
 
 The communicators are those of sharded.py (LocalSimComm in tests, TorchDistComm = RCCL)."""
+import re
+
 import torch
 
 from . import sharded
@@ -29,9 +31,11 @@ SCAFFOLD_SPLIT_SIZE = 1_000_000  # assemble_options::scaffold_split_size (assemb
 def _scaffold_order_key(name):
     """trace_ref::assemble's order of scaffolds (trace_ref.cpp:77-105): numeric names in numeric order, then the
     rest, shorter names first ("X", "Y" before "hs37d5"), equal lengths in DESCENDING name order."""
-    try:
-        num = int(name)
-    except ValueError:
+    # atoi_or_maxint = std::stoi (trace_ref.cpp:71-77): leading whitespace, an optional sign and the numeric PREFIX
+    # count ("1_KI270706v1_random" -> 1, "22abc" -> 22); no digits or a value outside int -> maxint
+    m = re.match(r"\s*[+-]?\d+", name)
+    num = int(m.group(0)) if m else 2 ** 31 - 1
+    if not -2 ** 31 <= num <= 2 ** 31 - 1:
         num = 2 ** 31 - 1
     return (num, len(name), tuple(-ord(c) for c in name))
 

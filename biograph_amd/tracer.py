@@ -54,7 +54,8 @@ class _Asm(C.Structure):
                 ("min_overlap", C.c_uint32), ("trace_steps", C.c_uint32), ("left_anchor_ambiguous_bases", C.c_uint32),
                 ("matches_reference", C.c_int32), ("rc_read_ids", C.POINTER(C.c_uint32)),
                 ("left_pair_matches", C.POINTER(C.c_uint32)), ("right_pair_matches", C.POINTER(C.c_uint32)),
-                ("n_rc_read_ids", C.c_uint64), ("n_left_pair_matches", C.c_uint64), ("n_right_pair_matches", C.c_uint64)]
+                ("n_rc_read_ids", C.c_uint64), ("n_left_pair_matches", C.c_uint64), ("n_right_pair_matches", C.c_uint64),
+                ("assembly_id", C.c_uint64)]
 
 
 class TraceAssembly:
@@ -64,6 +65,7 @@ class TraceAssembly:
     def __init__(self, a=None, **kw):
         self.aligned_variants = []
         self.ml, self.merged = None, 0  # assembly_ml_features as a tuple, assemblies merged into this one
+        self.assembly_id = 0  # assemble.h:295; 0 on a hand-made assembly = the library allocates one
         if a is None:  # a hand-made assembly (the reference's unit tests build them this way)
             self.left_offset = self.right_offset = self.left_anchor_len = self.right_anchor_len = 0
             self.seq, self.min_overlap, self.trace_steps, self.left_anchor_ambiguous_bases = "", 0, 0, 0
@@ -84,6 +86,7 @@ class TraceAssembly:
         self.rc_read_ids = [int(a.rc_read_ids[i]) for i in range(a.n_rc_read_ids)]
         self.left_pair_matches = [int(a.left_pair_matches[i]) for i in range(a.n_left_pair_matches)]
         self.right_pair_matches = [int(a.right_pair_matches[i]) for i in range(a.n_right_pair_matches)]
+        self.assembly_id = int(a.assembly_id)
 
     def key(self):
         return (self.left_offset, self.right_offset, self.left_anchor_len, self.right_anchor_len, self.seq,
@@ -121,7 +124,7 @@ class CoverageOptions(C.Structure):
     _fields_ = [("max_coverage_paths", C.c_uint32), ("penalize_directional_coverage", C.c_int32),
                 ("simple_genotype_filter", C.c_int32), ("min_pair_depth", C.c_int32), ("min_read_depth", C.c_int32),
                 ("vcf_sv_size_threshold", C.c_uint32), ("min_depth_portion", C.c_double), ("min_avg_pair_depth", C.c_double),
-                ("output_ml_features", C.c_int32)]
+                ("output_ml_features", C.c_int32), ("rvg_exclude", C.c_int32)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -191,8 +194,15 @@ def _make_result(assemblies):
             ids, lm, rm = _u32_array(t.rc_read_ids), _u32_array(t.left_pair_matches), _u32_array(t.right_pair_matches)
             a = _Asm(t.left_offset, t.right_offset, t.score, t.left_anchor_len, t.right_anchor_len,
                      C.cast(C.c_char_p(seq), C.c_void_p), len(seq), t.min_overlap, t.trace_steps, t.left_anchor_ambiguous_bases,
-                     int(t.matches_reference), ids, lm, rm, len(t.rc_read_ids), len(t.left_pair_matches), len(t.right_pair_matches))
+                     int(t.matches_reference), ids, lm, rm, len(t.rc_read_ids), len(t.left_pair_matches), len(t.right_pair_matches),
+                     int(getattr(t, "assembly_id", 0)))
             capi.check(L.bg_trace_result_add(src, C.byref(a)))
+            if getattr(t, "coverage", None) is not None:  # a section that has been through calc_coverage
+                cov = (C.c_int32 * max(len(t.coverage), 1))(*t.coverage)
+                pc = (C.c_int32 * max(len(t.pair_coverage), 1))(*t.pair_coverage)
+                cv = _Cov(cov, pc, len(t.coverage), len(t.pair_coverage), 1, t.other_depth, t.other_pair_depth, t.ref_depth,
+                          getattr(t, "strand_count", 0), getattr(t, "genotype_quality", 0.0))
+                capi.check(L.bg_trace_result_set_coverage(src, L.bg_trace_result_size(src) - 1, C.byref(cv)))
             f = getattr(t, "ml", None)
             if f is not None or getattr(t, "merged", 0):
                 m = _Ml(int(f is not None), *((f[0], f[1], f[2], f[3], f[4], f[5], f[6]) if f is not None else (0, 0, 0, 0, 0.0, 0.0, 0)),
@@ -244,6 +254,21 @@ def assemblies_coverage(seqset, readmap, sections, extents, end_pos=None, option
             L.bg_trace_result_free(out)
 
 
+def rvg_exclude(sections, options=None):
+    """bg_assemblies_rvg_exclude: the rvg_exclude step (rvg_exclude.cpp) over covered sections of one scaffold (host only)."""
+    L = capi.lib()
+    src = _make_result(sections)
+    out = C.c_void_p()
+    try:
+        opt = options if options is not None else CoverageOptions()
+        capi.check(L.bg_assemblies_rvg_exclude(src, C.byref(opt), C.byref(out)))
+        return _read_result(out)
+    finally:
+        L.bg_trace_result_free(src)
+        if out:
+            L.bg_trace_result_free(out)
+
+
 def process_assemblies(assemblies, extents, end_pos=None, options=None, steps=STEP_PIPELINE):
     """bg_assemblies_process: the assemblies of one scaffold's work items (TraceAssembly objects, forward coordinates)
     through the chosen steps of the pipeline behind the tracers, in the pipeline's order: anchor_dropper, sorter,
@@ -259,7 +284,8 @@ def process_assemblies(assemblies, extents, end_pos=None, options=None, steps=ST
             ids, lm, rm = _u32_array(t.rc_read_ids), _u32_array(t.left_pair_matches), _u32_array(t.right_pair_matches)
             a = _Asm(t.left_offset, t.right_offset, t.score, t.left_anchor_len, t.right_anchor_len,
                      C.cast(C.c_char_p(seq), C.c_void_p), len(seq), t.min_overlap, t.trace_steps, t.left_anchor_ambiguous_bases,
-                     int(t.matches_reference), ids, lm, rm, len(t.rc_read_ids), len(t.left_pair_matches), len(t.right_pair_matches))
+                     int(t.matches_reference), ids, lm, rm, len(t.rc_read_ids), len(t.left_pair_matches), len(t.right_pair_matches),
+                     int(getattr(t, "assembly_id", 0)))
             capi.check(L.bg_trace_result_add(src, C.byref(a)))
         n = len(extents)
         offs = (C.c_int64 * max(n, 1))(*[int(o) for o, _ in extents])

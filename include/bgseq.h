@@ -34,7 +34,7 @@ extern "C" {
 #define BG_EIO (-5)      /* file I/O error                                                     */
 #define BG_EINTERNAL (-6)/* invariant violated (reference: "Missing expansion?" builder.cpp:96)*/
 
-#define BG_ABI_VERSION 1
+#define BG_ABI_VERSION 2
 
 typedef struct bg_ctx bg_ctx;         /* device context: stream + workspace cache              */
 typedef struct bg_reads bg_reads;     /* 2-bit packed reads resident in HBM                    */
@@ -432,6 +432,8 @@ typedef struct bg_trace_assembly {  /* variants::assembly as the tracer and pair
   int32_t matches_reference;
   const uint32_t *rc_read_ids, *left_pair_matches, *right_pair_matches;  /* rc_read_ids is empty after pair_count */
   uint64_t n_rc_read_ids, n_left_pair_matches, n_right_pair_matches;
+  uint64_t assembly_id;  /* assemble.h:295: shared by the sections cut from one traced assembly; 0 in bg_trace_result_add
+                          * = allocate a fresh one (assembly's constructor, assemble.cpp:1248) */
 } bg_trace_assembly;
 typedef struct bg_trace_result bg_trace_result;
 /* Extents: the N-free stretches of the scaffold in scaffold coordinates, ascending; end_pos = scaffold::end_pos().
@@ -511,6 +513,8 @@ typedef struct bg_coverage_options {
   double min_depth_portion;                /* assemble.h:704 (.23)  */
   double min_avg_pair_depth;               /* assemble.h:711 (1)    */
   int32_t output_ml_features;              /* assemble.h:730 (0): the LASCORE ... NUMASM columns of the VCF record */
+  int32_t rvg_exclude;                     /* assemble.h:699 (0; biograph discovery --rvg-exclude defaults to true,
+                                            * biograph_variants.cpp:194): run rvg_exclude behind the genotype filter */
 } bg_coverage_options;
 void bg_coverage_options_default(bg_coverage_options* o);
 int bg_assemblies_coverage(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const bg_trace_result* in,
@@ -532,6 +536,12 @@ typedef struct bg_assembly_coverage {  /* assembly::coverage ... genotype_qualit
   double genotype_quality;
 } bg_assembly_coverage;
 int bg_trace_result_coverage(const bg_trace_result* r, uint64_t i, bg_assembly_coverage* out);  /* pointers live as long as r */
+int bg_trace_result_set_coverage(bg_trace_result* r, uint64_t i, const bg_assembly_coverage* in);  /* for hand-made input */
+/* rvg_exclude (rvg_exclude.cpp:5-67; pipeline.cpp:102-104) as a step of its own, host only: a non-structural variant
+ * section (both alleles below vcf_sv_size_threshold) with a position of zero pair coverage and no other_pair_depth is
+ * dropped unless a structural section with the same assembly_id passes through.  `in` sorted by left offset. */
+int bg_assemblies_rvg_exclude(const bg_trace_result* in, const bg_coverage_options* options /* NULL = defaults */,
+                              bg_trace_result** out);
 /* assembly_ml_features (assemble.h:191-199) + the number of assemblies merged into this one (deduper, exact_deduper) */
 typedef struct bg_assembly_ml {
   int32_t has_ml, score, refspan, lanch, ranch;

@@ -171,9 +171,20 @@ class SortedOutput:
         self.emit = emit
         self.queue = []
         self.flush_point = INT_MIN  # assemble.h:902
+        self.left_offsets = []  # m_left_offsets (a multiset): offsets of assemblies a step still holds back
+
+    def track_left_offset(self, offset):  # :303-306
+        check(offset >= self.flush_point, "tracked offset behind the flush point")
+        self.left_offsets.append(offset)
+
+    def untrack_left_offset(self, offset):  # :308-312
+        check(offset in self.left_offsets, "offset is not tracked")
+        self.left_offsets.remove(offset)
 
     def flush_sorted_to(self, offset):
         check(offset >= self.flush_point, "flush goes backwards")
+        if self.left_offsets and offset > min(self.left_offsets):  # :316-321
+            offset = min(self.left_offsets)
         while self.queue:
             a = self.queue[0][1]
             if min(a.left_offset, a.right_offset) >= offset:

@@ -16,7 +16,7 @@ queue (with its tracked left offsets) produces.
 
 Pinned on modules/variants/calc_coverage_test.cpp (tests/test_oracle_coverage.py) and on the DP / AD / PDP / PAD / GT
 columns of datasets/lambdaToyData/benchmark/father.vcf from the golden father_lambda biograph."""
-from .align import canon_key, check, copy_assembly
+from .align import SortedOutput, canon_key, check, copy_assembly
 from .tracer import _ScaffoldIt, COMP, INT_MAX
 
 
@@ -33,6 +33,7 @@ class CoverageOptions:
         self.min_read_depth = 1
         self.vcf_sv_size_threshold = 20
         self.output_ml_features = False  # assemble.h:730; biograph_variants.cpp:686 switches it on
+        self.rvg_exclude = False  # assemble.h:699; biograph_variants.cpp:194,689: --rvg-exclude, true by default there
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError("no coverage option %r" % k)
@@ -401,6 +402,59 @@ def simple_genotype_filter(o, assemblies):
         else:
             a.strand_count, a.genotype_quality = 2, min_p
         out.append(a)
+    return out
+
+
+# ---- rvg_exclude (rvg_exclude.cpp:5-67; the last step of add_standard_variants_pipeline, pipeline.cpp:102-104) ----------
+class RvgExclude(SortedOutput):
+    def __init__(self, o, emit):
+        super().__init__(emit)
+        self.o = o
+        self.backlog = {}  # assembly id -> [assemblies held back]
+        self.known_inphase = set()
+
+    def add(self, a):  # on_assembly :14-67
+        self.flush_sorted_to(a.left_offset)
+        if a.matches_reference:
+            self.sort_and_output(a)
+            return
+        reflen = (a.right_offset - a.left_offset) & 0xffffffff  # unsigned
+        seqlen = len(a.seq)
+        if not reflen or not seqlen:  # compare as if VCF padded
+            reflen += 1
+            seqlen += 1
+        if seqlen >= self.o.vcf_sv_size_threshold or reflen >= self.o.vcf_sv_size_threshold:
+            self.known_inphase.add(a.assembly_id)  # structural: out it goes, with what waited for it
+            for old in self.backlog.pop(a.assembly_id, []):
+                self.untrack_left_offset(old.left_offset)
+                self.sort_and_output(old)
+            self.sort_and_output(a)
+            return
+        if a.other_pair_depth or a.assembly_id in self.known_inphase:
+            output_this = True
+        else:
+            check(a.pair_coverage, "rvg_exclude: assembly without pair coverage")
+            output_this = all(a.pair_coverage)
+        if output_this:
+            self.sort_and_output(a)
+            return
+        self.track_left_offset(a.left_offset)
+        self.backlog.setdefault(a.assembly_id, []).append(a)
+
+    def finish(self):  # flush() :5-12
+        for held in self.backlog.values():
+            for a in held:
+                self.untrack_left_offset(a.left_offset)
+        self.backlog = {}
+        self.flush()
+
+
+def rvg_exclude(o, assemblies):
+    out = []
+    step = RvgExclude(o, out.append)
+    for a in assemblies:
+        step.add(a)
+    step.finish()
     return out
 
 

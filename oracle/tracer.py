@@ -241,8 +241,17 @@ class Rejoin:
         self.anchor_drop = False
 
 
+_next_assembly_id = [1]
+
+
+def allocate_assembly_id():  # assemble.cpp:873-877
+    _next_assembly_id[0] += 1
+    return _next_assembly_id[0] - 1
+
+
 class Assembly:
     def __init__(self):
+        self.assembly_id = allocate_assembly_id()  # assemble.cpp:1248; copies and split parts keep it
         self.left_offset = 0
         self.right_offset = 0
         self.left_anchor_len = 0

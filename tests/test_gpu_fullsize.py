@@ -14,12 +14,16 @@ import biograph_amd as bg
 from biograph_amd import sharded, synth
 
 pytestmark = pytest.mark.gpu
-# BG_FULLSIZE_GENOME=180000000 runs the same checks past 2^32 windows and base offsets (5.4 Gbases; ~150 GB of HBM)
-G = int(os.environ.get("BG_FULLSIZE_GENOME", synth.SHAPES["chr20"]))
+# Two sizes, both in the default `-m gpu` run: the bench workload (BASELINE.json configs[2]) and ONE RANK'S SHARE of
+# configs[3] -- a 30x whole human over 8 GPUs = 3.1 Gb / 8 = 387.5 Mb of genome, 11.6 Gbases, 77.5 M reads per rank: past
+# 2^32 k-mer windows and base offsets, ~170 GB of HBM at the peak.  BG_FULLSIZE_GENOME=<bases> replaces the first size.
+G_CHR20 = int(os.environ.get("BG_FULLSIZE_GENOME", synth.SHAPES["chr20"]))
+G_HUMAN_SHARE = synth.SHAPES["human"] // 8
 
 
-@pytest.fixture(scope="module")
-def built():
+@pytest.fixture(scope="module", params=[G_CHR20, G_HUMAN_SHARE], ids=["chr20", "human_eighth"])
+def built(request):
+    G = request.param
     os.environ["BG_VERIFY_CLOSURE"] = "1"  # every entry's tail is looked up and must be a prefix of what it finds
     try:
         ctx = bg.Context(0)
@@ -27,13 +31,22 @@ def built():
         ss, st = ctx.create_device(seq.data_ptr(), offs.data_ptr(), n, ctx.default_params())
     finally:
         del os.environ["BG_VERIFY_CLOSURE"]
+    st = dict(st, genome_len=G)
     yield ctx, ss, st, (seq, offs, n)
     ss.free()
     ctx.close()
+    del seq, offs
+    torch.cuda.empty_cache()
+
+
+def chr20_only(st):
+    if st["genome_len"] != G_CHR20:
+        pytest.skip("run at the bench size only")
 
 
 def test_fullsize_counters_and_invariants(built):
     ctx, ss, st, (seq, offs, n) = built
+    G = st["genome_len"]
     assert st["n_reads"] == n == 2 * (30 * G // 300) and st["n_bases"] == n * 150
     assert st["n_kmers"] == n * (150 - 30 + 1)
     assert 0.95 * n < st["n_corrected_reads"] <= n
@@ -79,6 +92,7 @@ def test_fullsize_sharded_build_equals_fused(built):
     """Two ranks (simulated on the one GPU, every buffer through the exchange phases of the C ABI) build the same
     sample: every container part equal to the fused build's."""
     ctx, ss, st, (seq, offs, n) = built
+    chr20_only(st)
     want = {k: hashlib.sha256(v).hexdigest() for k, v in ss.parts().items()}
     half = (n // 4) * 2
     cut = half * 150
@@ -97,9 +111,10 @@ def test_fullsize_sharded_build_equals_fused(built):
 
 
 def test_fullsize_eight_rank_routed_build_written_in_slices_equals_fused(built, tmp_path):
-    """The shape of BASELINE.json configs[3] at chr20 size: EIGHT ranks (simulated on the one GPU), uneven shards, the routed
-    build with nothing replicated and nothing gathered -- every rank writes its slice of one container in place -- and
-    the file opens as the fused build's seqset, member for member."""
+    """The shape of BASELINE.json configs[3] -- at chr20 size and at one rank's share of the whole human (11.6 Gbases): EIGHT
+    ranks (simulated on the one GPU), uneven shards, the routed build with nothing replicated and nothing gathered --
+    every rank writes its slice of one container in place -- and the file opens as the fused build's seqset, member for
+    member."""
     ctx, ss, st, (seq, offs, n) = built
     want = {k: hashlib.sha256(v).hexdigest() for k, v in ss.parts().items()}
     P = 8

@@ -77,7 +77,9 @@ def main():
         return 1
     vcf = os.path.join(tmp, "v.vcf")
     t0 = time.perf_counter()
-    r = subprocess.run([exe, "discovery", "--in", bg, "--ref", fa, "--out", vcf, "--threads", str(args.threads)], capture_output=True, text=True)
+    r = subprocess.run([exe, "discovery", "--in", bg, "--ref", fa, "--out", vcf, "--threads", str(args.threads),
+                        # the planted-genotype checks need GT, i.e. the simple genotype filter (off by default, as in the reference)
+                        "--simple-gt", "true"], capture_output=True, text=True)
     t_disc = time.perf_counter() - t0
     if r.returncode:
         print("discovery FAILED", r.stderr[-500:])
