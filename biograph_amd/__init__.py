@@ -272,6 +272,26 @@ class Context:
         capi.check(capi.lib().bg_readmap_open(self.h, str(path).encode(), C.byref(h)))
         return Readmap(self, h)
 
+    def readmap_from_arrays(self, n_entries, max_read_len, seqset_uuid, entry_id, read_len, mate_loop_ptr, is_forward):
+        """bg_readmap_from_arrays: a readmap from its per-read columns (torch DEVICE tensors: uint64-as-int64 entry ids,
+        int32 lengths and loop pointers, uint8 orientation; or numpy arrays, which are uploaded)."""
+        import torch
+        dev = "cuda:%d" % self.device
+
+        def dev_t(x, dt):
+            if isinstance(x, torch.Tensor):
+                return x.to(device=dev, dtype=dt).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(x).astype({torch.int64: np.int64, torch.int32: np.int32, torch.uint8: np.uint8}[dt],
+                                                                       copy=False)).to(dev)
+        e, rl = dev_t(entry_id, torch.int64), dev_t(read_len, torch.int32)
+        ml, f = dev_t(mate_loop_ptr, torch.int32), dev_t(is_forward, torch.uint8)
+        n = int(e.shape[0])
+        torch.cuda.current_stream(dev).synchronize()
+        h = C.c_void_p()
+        capi.check(capi.lib().bg_readmap_from_arrays(self.h, int(n_entries), int(max_read_len), str(seqset_uuid).encode(), n,
+                                                     e.data_ptr(), rl.data_ptr(), ml.data_ptr(), f.data_ptr(), C.byref(h)))
+        return Readmap(self, h)
+
     def open_seqset(self, path):
         h = C.c_void_p()
         capi.check(capi.lib().bg_seqset_open(self.h, str(path).encode(), C.byref(h)))
@@ -395,7 +415,8 @@ class Readmap(_Handle):
     def arrays(self):
         """(entry id, read length, mate loop pointer, is_forward) per read id."""
         n = self.size()
-        e, rl, ml = (np.zeros(max(n, 1), np.uint32) for _ in range(3))
+        e = np.zeros(max(n, 1), np.uint64)
+        rl, ml = (np.zeros(max(n, 1), np.uint32) for _ in range(2))
         f = np.zeros(max(n, 1), np.uint8)
         capi.check(capi.lib().bg_readmap_arrays(self.ctx.h, self.h, capi.np_ptr(e), capi.np_ptr(rl), capi.np_ptr(ml),
                                                 capi.np_ptr(f)))

@@ -222,7 +222,8 @@ struct bg_readmap {
   uint32_t min_read_len = 0;    // readmap::min_read_len()
   bool pair_mode = false;       // legacy file without a mate loop table: mate_loop_ptr holds mate_pair_ptr (readmap.cpp:48-51)
   bg::DevBuf<uint64_t> read_len, mate_loop_ptr, is_forward;  // one u64 per read id (packed on demand)
-  bg::DevBuf<uint32_t> entry_id;                              // seqset entry of every read id (sparse_multi::reverse_lookup)
+  bg::DevBuf<uint64_t> entry_id;                              // seqset entry of every read id (sparse_multi::reverse_lookup); 64-bit:
+                                                              // a whole-human seqset holds > 2^32 entries (make_readmap.h:56-90 packs 37 bits)
   bg::DevBuf<uint64_t> s2m_bits, s2m_sub, s2m_acc, d2m_bits, d2m_sub, d2m_acc;
 };
 

@@ -213,7 +213,7 @@ struct CovWorld {
   const bg_seqset* ss = nullptr;
   const ScaffoldView* sc = nullptr;
   bg_coverage_options o;
-  std::vector<uint32_t> entry_id, read_len;
+  std::vector<uint32_t> read_len;
   std::vector<uint8_t> is_forward;
   // readmap::entry_to_index without a binary search over all read ids: a bit per entry that carries reads, the number
   // of such entries before every 64-entry word, the first read id of the k-th such entry
@@ -230,10 +230,9 @@ struct CovWorld {
   }
   int load(bg_ctx* ctx, const bg_seqset* seqset, const bg_readmap* rm) {
     ss = seqset;
-    entry_id.resize(rm->n_reads);
-    std::vector<uint64_t> tmp(rm->n_reads);
+    std::vector<uint64_t> entry_id(rm->n_reads), tmp(rm->n_reads);  // entry ids: 64-bit, only needed for the tables below
     if (rm->n_reads) {
-      BG_HIP(bg::copy_d2h(ctx, entry_id.data(), rm->entry_id.p, rm->n_reads * 4));
+      BG_HIP(bg::copy_d2h(ctx, entry_id.data(), rm->entry_id.p, rm->n_reads * 8));
       BG_HIP(bg::copy_d2h(ctx, tmp.data(), rm->read_len.p, rm->n_reads * 8));
     }
     read_len.assign(tmp.begin(), tmp.end());
@@ -241,7 +240,7 @@ struct CovWorld {
     is_forward.resize(rm->n_reads);
     for (size_t i = 0; i < tmp.size(); ++i) is_forward[i] = uint8_t(tmp[i] & 1);
     has_reads.assign((ss->n + 63) / 64 + 1, 0);
-    for (uint32_t e : entry_id) has_reads[e >> 6] |= 1ull << (e & 63);
+    for (uint64_t e : entry_id) has_reads[e >> 6] |= 1ull << (e & 63);
     word_rank.resize(has_reads.size() + 1);
     uint32_t before = 0;
     for (size_t i = 0; i < has_reads.size(); ++i) { word_rank[i] = before; before += uint32_t(__builtin_popcountll(has_reads[i])); }

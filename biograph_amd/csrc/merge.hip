@@ -68,15 +68,15 @@ __global__ __launch_bounds__(128) void k_merge_map(const uint64_t* __restrict__ 
   map[i] = lo;
 }
 
-__global__ void k_migrate_entries(const uint32_t* __restrict__ old_entry, uint64_t n, const uint64_t* __restrict__ map,
-                                  uint64_t n_old_entries, uint32_t* __restrict__ new_entry,
+__global__ void k_migrate_entries(const uint64_t* __restrict__ old_entry, uint64_t n, const uint64_t* __restrict__ map,
+                                  uint64_t n_old_entries, uint64_t* __restrict__ new_entry,
                                   uint8_t* __restrict__ marks, uint32_t* __restrict__ err) {
   uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint64_t e = old_entry[i];
   if (e >= n_old_entries) { atomicOr(err, 1u); return; }
   uint64_t t = map[e];
-  new_entry[i] = uint32_t(t);
+  new_entry[i] = t;
   marks[t] = 1;
 }
 

@@ -173,7 +173,8 @@ struct ReadmapObj : std::enable_shared_from_this<ReadmapObj> {
   std::shared_ptr<SeqsetObj> ss;
   bg_readmap* h = nullptr;
   std::string path;
-  std::vector<uint32_t> entry_id, read_len, loop;
+  std::vector<uint64_t> entry_id;
+  std::vector<uint32_t> read_len, loop;
   std::vector<uint8_t> fwd;
   bool has_loops = true;  // false: `loop` holds the legacy pair table (readmap.cpp:48-51)
   ReadmapObj(const std::shared_ptr<SeqsetObj>& s, const std::string& p) : c(ctx()), ss(s), path(p) {

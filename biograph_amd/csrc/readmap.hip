@@ -149,7 +149,7 @@ __global__ void k_rm_flag_type(const uint64_t* __restrict__ hi, uint64_t n, int 
 // per sorted row: read length, is_forward, group-head flag, entry marks
 __global__ void k_rm_row_fields(const uint64_t* __restrict__ hi, uint64_t n, uint64_t* __restrict__ read_len,
                                 uint64_t* __restrict__ is_fwd, uint8_t* __restrict__ head,
-                                uint8_t* __restrict__ entry_marks, uint32_t* __restrict__ entry_id) {
+                                uint8_t* __restrict__ entry_marks, uint64_t* __restrict__ entry_id) {
   uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint64_t h = hi[i];
@@ -158,7 +158,7 @@ __global__ void k_rm_row_fields(const uint64_t* __restrict__ hi, uint64_t n, uin
   is_fwd[i] = (t == 0 || t == 2) ? 1 : 0;
   head[i] = (i == 0 || hi_entry(hi[i - 1]) != hi_entry(h)) ? 1 : 0;
   entry_marks[hi_entry(h)] = 1;
-  entry_id[i] = uint32_t(hi_entry(h));
+  entry_id[i] = hi_entry(h);
 }
 
 __global__ __launch_bounds__(256) void k_rm_min_len(const uint64_t* __restrict__ read_len, uint64_t n,
@@ -393,7 +393,12 @@ extern "C" int bg_readmap_build_marked(bg_ctx* ctx, const bg_seqset* ss, const b
   BG_HIP(hipSetDevice(ctx->device));
   const uint64_t n = reads->n, n_o = 2 * n, n_ent = ss->n;
   const int W = reads->W, EW = ss->W ? ss->W : W;
-  if (n_o >= (1ull << 32) || n_ent >= (1ull << 32)) { set_error("bg_readmap_build: shard too large"); return BG_EINVAL; }
+  // Read ids (rows) are 32-bit, as the reference's are (readmap.h: uint32_t read ids; a 30x human has 1.24 G).  Entry ids
+  // are 64-bit throughout (the rows pack 37 bits, make_readmap.h:56-90); only the directory over RESIDENT keys is 32-bit,
+  // and resident keys of 2^32 entries would not fit one device anyway -- an opened seqset (FM search) has no such limit.
+  if (n_o >= (1ull << 32)) { set_error("bg_readmap_build: more than 2^31 reads"); return BG_EINVAL; }
+  if (have_keys && n_ent >= (1ull << 32)) { set_error("bg_readmap_build: more than 2^32 resident entry keys"); return BG_EINVAL; }
+  if (n_ent >= kNoLoopEntry) { set_error("bg_readmap_build: more than 2^37 - 1 entries"); return BG_EINVAL; }
   std::unique_ptr<bg_readmap> rm(new bg_readmap);
   rm->ctx = ctx;
   rm->n_entries = n_ent;
@@ -570,6 +575,75 @@ extern "C" int bg_readmap_build_marked(bg_ctx* ctx, const bg_seqset* ss, const b
   if (h_err & 1) { set_error("bg_readmap_build: a read was not found in the seqset"); return BG_EINTERNAL; }
   if (h_err & 2) { set_error("bg_readmap_build: mate loop claim failed (inconsistent rows)"); return BG_EINTERNAL; }
   if (h_err & 4) { set_error("bg_readmap_build: a read has no marked entry (the marks are not this sample's)"); return BG_EINVAL; }
+  *out = rm.release();
+  return BG_OK;
+}
+
+// ---- a readmap from its per-read columns (the pieces of a sharded build gathered on one device; hand-made input) ----
+namespace bg {
+__global__ void k_rm_from_arrays(const uint64_t* __restrict__ entry, const uint32_t* __restrict__ len,
+                                 const uint32_t* __restrict__ ptr, const uint8_t* __restrict__ fwd, uint64_t n, uint64_t n_ent,
+                                 uint64_t* __restrict__ o_entry, uint64_t* __restrict__ o_len, uint64_t* __restrict__ o_ptr,
+                                 uint64_t* __restrict__ o_fwd, uint8_t* __restrict__ head,
+                                 unsigned long long* __restrict__ s2m_bits, uint32_t* __restrict__ err) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t e = entry[i];
+  const bool first = i == 0 || entry[i - 1] != e;
+  if (e >= n_ent || (i && entry[i - 1] > e) || ptr[i] >= n) { atomicOr(err, 1u); return; }
+  o_entry[i] = e;
+  o_len[i] = len[i];
+  o_ptr[i] = ptr[i];
+  o_fwd[i] = fwd[i] ? 1 : 0;
+  head[i] = first ? 1 : 0;
+  if (first) atomicOr(&s2m_bits[e >> 6], 1ull << (e & 63));  // one per entry group: a set bit per entry that carries reads
+}
+}  // namespace bg
+
+extern "C" int bg_readmap_from_arrays(bg_ctx* ctx, uint64_t n_entries, uint32_t max_read_len, const char* seqset_uuid,
+                                      uint64_t n_reads, const uint64_t* d_entry_id, const uint32_t* d_read_len,
+                                      const uint32_t* d_mate_loop_ptr, const uint8_t* d_is_forward, bg_readmap** out) {
+  if (!ctx || !out || (n_reads && (!d_entry_id || !d_read_len || !d_mate_loop_ptr || !d_is_forward))) {
+    set_error("bg_readmap_from_arrays: null argument");
+    return BG_EINVAL;
+  }
+  if (n_reads >= (1ull << 32)) { set_error("bg_readmap_from_arrays: more than 2^32 read ids"); return BG_EINVAL; }
+  if (n_entries >= kNoLoopEntry) { set_error("bg_readmap_from_arrays: more than 2^37 - 1 entries"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_readmap> rm(new bg_readmap);
+  rm->ctx = ctx;
+  rm->n_entries = n_entries;
+  rm->n_reads = n_reads;
+  rm->max_read_len = max_read_len;
+  rm->seqset_uuid = seqset_uuid ? seqset_uuid : "";
+  const uint64_t n = n_reads;
+  BG_TRY(rm->read_len.alloc(ctx, n));
+  BG_TRY(rm->is_forward.alloc(ctx, n));
+  BG_TRY(rm->mate_loop_ptr.alloc(ctx, n));
+  BG_TRY(rm->entry_id.alloc(ctx, n));
+  BG_TRY(rm->s2m_bits.alloc(ctx, (n_entries + 63) / 64));
+  BG_TRY(rm->d2m_bits.alloc(ctx, (n + 63) / 64));
+  BG_HIP(hipMemsetAsync(rm->s2m_bits.p, 0, ((n_entries + 63) / 64 ? (n_entries + 63) / 64 : 1) * 8, ctx->stream));
+  DevBuf<uint8_t> head;
+  DevBuf<uint32_t> err;
+  BG_TRY(head.alloc(ctx, n));
+  BG_TRY(err.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+  if (n) {
+    k_rm_from_arrays<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_entry_id, d_read_len, d_mate_loop_ptr, d_is_forward, n, n_entries,
+                                                           rm->entry_id.p, rm->read_len.p, rm->mate_loop_ptr.p, rm->is_forward.p,
+                                                           head.p, reinterpret_cast<unsigned long long*>(rm->s2m_bits.p), err.p);
+    BG_LAUNCH_CHECK();
+    k_bytes_to_bits<<<cdiv((n + 63) / 64, 4), 256, 0, ctx->stream>>>(head.p, n, reinterpret_cast<unsigned long long*>(rm->d2m_bits.p));
+    BG_LAUNCH_CHECK();
+  }
+  uint32_t h_err = 0;
+  BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_err) { set_error("bg_readmap_from_arrays: entry ids must ascend and stay below n_entries, loop pointers below n_reads"); return BG_EINVAL; }
+  BG_TRY(bitcount_finalize(ctx, rm->s2m_bits, n_entries, &rm->s2m_sub, &rm->s2m_acc));
+  BG_TRY(bitcount_finalize(ctx, rm->d2m_bits, n, &rm->d2m_sub, &rm->d2m_acc));
+  BG_TRY(readmap_min_len(ctx, rm.get()));
   *out = rm.release();
   return BG_OK;
 }
@@ -772,7 +846,7 @@ extern "C" int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out) 
     set_error("%s: malformed readmap metadata", path);
     return BG_EIO;
   }
-  if (n >= (1ull << 32) || n_ent >= (1ull << 32)) { set_error("bg_readmap_open: readmap too large for one device shard"); return BG_EINVAL; }
+  if (n >= (1ull << 32)) { set_error("bg_readmap_open: more than 2^32 read ids"); return BG_EINVAL; }
   std::unique_ptr<bg_readmap> rm(new bg_readmap);
   rm->ctx = ctx;
   rm->n_reads = n;
@@ -781,7 +855,7 @@ extern "C" int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out) 
   rm->pair_mode = pair_mode;
   size_t p = rmj->find("\"seqset_uuid\":\"");
   if (p != std::string::npos) rm->seqset_uuid = rmj->substr(p + 15, rmj->find('"', p + 15) - (p + 15));
-  std::vector<uint64_t> v_len, v_ptr, v_fwd, v_head, v_src;
+  std::vector<uint64_t> v_len, v_ptr, v_fwd, v_head;
   if (rl->size() < (n * rl_bits + 7) / 8 || ml->size() < (n * ml_bits + 7) / 8) { set_error("%s: truncated vectors", path); return BG_EIO; }
   rm_unpack_bits(*rl, n, unsigned(rl_bits), &v_len);
   if (legacy)
@@ -790,11 +864,19 @@ extern "C" int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out) 
   rm_unpack_bits(*ml, n, unsigned(ml_bits), &v_ptr);
   rm_unpack_bits(*isf, n, 1, &v_fwd);
   rm_unpack_bits(*d2m, n, 1, &v_head);
-  rm_unpack_bits(*s2m, n_ent, 1, &v_src);
-  // sparse_multi::reverse_lookup for every read id: k-th group head -> k-th marked entry
-  std::vector<uint32_t> mid_to_entry, v_entry(n, 0);
-  for (uint64_t e = 0; e < n_ent; ++e)
-    if (v_src[e]) mid_to_entry.push_back(uint32_t(e));
+  if (s2m->size() < (n_ent + 63) / 64 * 8 || d2m->size() < (n + 63) / 64 * 8) { set_error("%s: truncated bit vectors", path); return BG_EIO; }
+  // sparse_multi::reverse_lookup for every read id: k-th group head -> k-th marked entry (entry ids may pass 2^32)
+  std::vector<uint64_t> mid_to_entry, v_entry(n, 0);
+  mid_to_entry.reserve(n);
+  for (uint64_t w = 0; w < (n_ent + 63) / 64; ++w) {
+    uint64_t word;
+    memcpy(&word, s2m->data() + w * 8, 8);
+    if (w == n_ent / 64 && (n_ent & 63)) word &= (1ull << (n_ent & 63)) - 1;
+    while (word) {
+      mid_to_entry.push_back(w * 64 + uint64_t(__builtin_ctzll(word)));
+      word &= word - 1;
+    }
+  }
   uint64_t mid = 0;
   for (uint64_t i = 0; i < n; ++i) {
     if (v_head[i]) ++mid;
@@ -811,9 +893,7 @@ extern "C" int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out) 
   BG_TRY(up64(rm->is_forward, v_fwd.data(), n));
   BG_TRY(up64(rm->s2m_bits, s2m->data(), (n_ent + 63) / 64));
   BG_TRY(up64(rm->d2m_bits, d2m->data(), (n + 63) / 64));
-  if (s2m->size() < (n_ent + 63) / 64 * 8 || d2m->size() < (n + 63) / 64 * 8) { set_error("%s: truncated bit vectors", path); return BG_EIO; }
-  BG_TRY(rm->entry_id.alloc(ctx, n));
-  if (n) BG_HIP(hipMemcpyAsync(rm->entry_id.p, v_entry.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  BG_TRY(up64(rm->entry_id, v_entry.data(), n));
   BG_HIP(hipStreamSynchronize(ctx->stream));
   BG_TRY(bitcount_finalize(ctx, rm->s2m_bits, n_ent, &rm->s2m_sub, &rm->s2m_acc));
   BG_TRY(bitcount_finalize(ctx, rm->d2m_bits, n, &rm->d2m_sub, &rm->d2m_acc));
@@ -829,7 +909,7 @@ __global__ void k_rm_narrow(const uint64_t* __restrict__ a, uint64_t n, uint32_t
 
 // Per read id: seqset entry (sparse_multi::reverse_lookup), read length, mate loop pointer, orientation
 // (readmap.h:120-138 accessors as whole arrays).  Any output may be null.
-extern "C" int bg_readmap_arrays(bg_ctx* ctx, const bg_readmap* rm, uint32_t* h_entry_id, uint32_t* h_read_len,
+extern "C" int bg_readmap_arrays(bg_ctx* ctx, const bg_readmap* rm, uint64_t* h_entry_id, uint32_t* h_read_len,
                                  uint32_t* h_mate_loop_ptr, uint8_t* h_is_forward) {
   if (!ctx || !rm) { set_error("bg_readmap_arrays: null argument"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));
@@ -837,7 +917,7 @@ extern "C" int bg_readmap_arrays(bg_ctx* ctx, const bg_readmap* rm, uint32_t* h_
   if (!n) return BG_OK;
   DevBuf<uint32_t> tmp;
   BG_TRY(tmp.alloc(ctx, n));
-  if (h_entry_id) BG_HIP(hipMemcpyAsync(h_entry_id, rm->entry_id.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (h_entry_id) BG_HIP(hipMemcpyAsync(h_entry_id, rm->entry_id.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
   const uint64_t* srcs[3] = {rm->read_len.p, rm->mate_loop_ptr.p, rm->is_forward.p};
   std::vector<uint32_t> fw(h_is_forward ? n : 0);
   void* dsts[3] = {h_read_len, h_mate_loop_ptr, h_is_forward ? fw.data() : nullptr};

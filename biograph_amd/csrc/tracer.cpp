@@ -137,7 +137,7 @@ namespace {
 
 struct HostTables {
   std::vector<uint8_t> sizes, ref_map, is_forward;
-  std::vector<uint32_t> entry_id, mate_loop, word_rank, group_start;
+  std::vector<uint32_t> mate_loop, word_rank, group_start;  // read ids are 32-bit (readmap.h), entry ids are not
   std::vector<uint64_t> has_reads;
 };
 
@@ -153,7 +153,6 @@ struct World {
   std::shared_ptr<const HostTables> tables;
   const uint8_t* sizes = nullptr;       // entry sizes
   const uint8_t* ref_map = nullptr;     // ref_map bytes (match count = & 63)
-  const uint32_t* entry_id = nullptr;   // per read id, ascending
   const uint32_t* mate_loop = nullptr;  // per read id
   const uint8_t* is_forward = nullptr;  // per read id
   const uint64_t* has_reads = nullptr;  // readmap::get_bit as a bit per entry
@@ -163,13 +162,12 @@ struct World {
   void bind_tables() {
     sizes = tables->sizes.data();
     ref_map = tables->ref_map.data();
-    entry_id = tables->entry_id.data();
     mate_loop = tables->mate_loop.data();
     is_forward = tables->is_forward.data();
     has_reads = tables->has_reads.data();
     word_rank = tables->word_rank.data();
     group_start = tables->group_start.data();
-    n_reads = tables->entry_id.size();
+    n_reads = tables->mate_loop.size();
   }
   int64_t scaffold_end = 0;
   // reads along the (oriented) scaffold: offset (after the base) -> entry, ascending by offset
@@ -1075,17 +1073,18 @@ extern "C" int bg_tracer_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap
     std::shared_ptr<HostTables> h(new HostTables);
     BG_TRY(download(ctx, h->sizes, ss->sizes.p, ss->n));
     BG_TRY(download(ctx, h->ref_map, d_ref_map, ss->n));
-    BG_TRY(download(ctx, h->entry_id, rm->entry_id.p, rm->n_reads));
+    std::vector<uint64_t> entry_id;  // per read id, ascending; only needed to build the rank tables
+    BG_TRY(download(ctx, entry_id, rm->entry_id.p, rm->n_reads));
     h->has_reads.assign((ss->n + 63) / 64 + 1, 0);
-    for (uint32_t e : h->entry_id) h->has_reads[e >> 6] |= 1ull << (e & 63);
+    for (uint64_t e : entry_id) h->has_reads[e >> 6] |= 1ull << (e & 63);
     h->word_rank.resize(h->has_reads.size() + 1);
     uint32_t before = 0;
     for (size_t i = 0; i < h->has_reads.size(); ++i) { h->word_rank[i] = before; before += uint32_t(__builtin_popcountll(h->has_reads[i])); }
     h->word_rank[h->has_reads.size()] = before;
     h->group_start.reserve(size_t(before) + 1);
-    for (size_t i = 0; i < h->entry_id.size(); ++i)
-      if (i == 0 || h->entry_id[i] != h->entry_id[i - 1]) h->group_start.push_back(uint32_t(i));
-    h->group_start.push_back(uint32_t(h->entry_id.size()));
+    for (size_t i = 0; i < entry_id.size(); ++i)
+      if (i == 0 || entry_id[i] != entry_id[i - 1]) h->group_start.push_back(uint32_t(i));
+    h->group_start.push_back(uint32_t(entry_id.size()));
     if (h->group_start.size() != size_t(before) + 1) return fail("bg_tracer_open: the readmap's read ids are not grouped by entry");
     std::vector<uint64_t> tmp;
     BG_TRY(download(ctx, tmp, rm->mate_loop_ptr.p, rm->n_reads));

@@ -738,7 +738,7 @@ extern "C" int bg_ref_walk_entries(bg_ctx* ctx, const bg_seqset* ss, const uint8
 
 struct ReadmapView {
   uint64_t n;
-  const uint32_t* entry_id;
+  const uint64_t* entry_id;
   const uint64_t* read_len;
   const uint64_t* ptr;
   const uint64_t* is_fwd;

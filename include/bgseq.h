@@ -285,12 +285,20 @@ int bg_readmap_write(bg_ctx* ctx, const bg_readmap* rm, const char* path, int ar
  * SHA extensions when the host has them.  Host only. */
 int bg_sha1_file(const char* path, char* hex41);
 void bg_readmap_free(bg_readmap* rm);
+/* A readmap from its per-read columns, all DEVICE arrays of n_reads elements in read-id order: seqset entry (ascending;
+ * 64-bit -- a whole-human seqset has > 2^32 entries), read length, mate loop pointer, orientation.  What the ranks of a
+ * sharded build gather on the rank that writes the container (biograph_amd/sharded.py sharded_readmap); the
+ * sparse_multi bit vectors and their bitcounts are derived here (io/sparse_multi.cpp, make_readmap.cpp:229-368). */
+int bg_readmap_from_arrays(bg_ctx* ctx, uint64_t n_entries, uint32_t max_read_len, const char* seqset_uuid, uint64_t n_reads,
+                           const uint64_t* d_entry_id, const uint32_t* d_read_len, const uint32_t* d_mate_loop_ptr,
+                           const uint8_t* d_is_forward, bg_readmap** out);
 /* Opens a readmap container (format 1.2.0 with the mate loop table) and keeps it resident. */
 int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out);
 /* Whole-array form of the per-read accessors (readmap.h:120-138): seqset entry of the read id
  * (sparse_multi::reverse_lookup), get_readlength, the mate loop pointer, get_is_forward.  Host buffers of
- * bg_readmap_size() elements; any may be null. */
-int bg_readmap_arrays(bg_ctx* ctx, const bg_readmap* rm, uint32_t* h_entry_id, uint32_t* h_read_len,
+ * bg_readmap_size() elements; any may be null.  Entry ids are 64-bit (a whole-human seqset has > 2^32 entries), read
+ * ids 32-bit as in the reference. */
+int bg_readmap_arrays(bg_ctx* ctx, const bg_readmap* rm, uint64_t* h_entry_id, uint32_t* h_read_len,
                       uint32_t* h_mate_loop_ptr, uint8_t* h_is_forward);
 /* readmap::get_prefix_reads (bio_base/readmap.cpp:434-447, read_iterator :538-649) for n ranges: the ids
  * of the reads whose sequence is a prefix of the range's sequence, in iteration order (upward from the

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(capi.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.bg_abi_version() == 1
+    assert lib.bg_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_device(lib):

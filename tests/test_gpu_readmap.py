@@ -168,3 +168,61 @@ def test_readmap_wgs_shape_vs_oracle_and_loop_properties(ctx):
     assert (rl[ptr[f]] == rl[f]).all()                   # forward row -> its own reverse complement
     assert int((p2 == np.arange(nid)).sum()) + int((p2 != np.arange(nid)).sum()) == nid
     assert (p2 != np.arange(nid)).any() and (p2 == np.arange(nid)).any()   # pairs and orphans both occur
+
+
+def test_readmap_from_arrays_reproduces_the_built_readmap(ctx):
+    """bg_readmap_from_arrays (the pieces of a sharded build put together on one device): the columns of a built
+    readmap give back every container part."""
+    reads = util.synth_reads(21, genome_len=1500, n_reads=2500, read_len=70, err=0.004, n_rate=0.0, var_len=True)
+    r = ctx.pack_reads(reads)
+    ks = ctx.kmer_count(r, 20, 3)
+    c, _ = ctx.correct_reads(r, ks)
+    ss, _ = ctx.build_seqset(c, 20)
+    rm = ctx.build_readmap(ss, c, True)
+    e, rl, ml, f = rm.arrays()
+    assert e.dtype == np.uint64
+    again = ctx.readmap_from_arrays(ss.size(), rm.max_read_len, "u", e, rl, ml, f)
+    want = rm.parts()
+    for name in bg.READMAP_PART_NAMES:
+        assert again.part(name) == want[name], name
+    # columns that cannot be a readmap are refused
+    with pytest.raises(bg.capi.BgError):
+        ctx.readmap_from_arrays(ss.size(), rm.max_read_len, "u", e[::-1].copy(), rl, ml, f)
+    with pytest.raises(bg.capi.BgError):
+        ctx.readmap_from_arrays(int(e.max()), rm.max_read_len, "u", e, rl, ml, f)
+    for x in (again, rm, ss, c, ks, r):
+        x.free()
+
+
+def test_readmap_entry_ids_beyond_32_bits_round_trip(ctx, tmp_path):
+    """A whole-human seqset has more than 2^32 entries (make_readmap.h:56-90 packs 37-bit entry ids): the readmap of
+    entries around and beyond 2^32 is built from its columns, written, opened again and queried -- entry ids, the
+    sparse_multi bit vectors and the loops survive."""
+    n_ent = (1 << 32) + (1 << 21)
+    rng = np.random.default_rng(3)
+    ent = np.sort(np.concatenate([rng.integers(0, 1 << 20, 300), rng.integers((1 << 32) - 2000, (1 << 32) + 2000, 600),
+                                  rng.integers((1 << 32) + 2000, n_ent, 500), [n_ent - 1, (1 << 32) - 1, 1 << 32]]).astype(np.uint64))
+    n = len(ent)
+    rl = rng.integers(30, 151, n).astype(np.uint32)
+    fwd = (np.arange(n) % 2 == 0).astype(np.uint8)
+    loop = np.arange(n, dtype=np.uint32) ^ 1  # unpaired loops: every read points at its reverse complement
+    if n & 1:
+        loop[-1] = n - 1
+    rm = ctx.readmap_from_arrays(n_ent, 150, "beyond-32-bits", ent, rl, loop, fwd)
+    path = tmp_path / "big.readmap"
+    rm.write(path)
+    back = ctx.open_readmap(path)
+    e2, rl2, ml2, f2 = back.arrays()
+    assert e2.dtype == np.uint64 and (e2 == ent).all() and int(e2.max()) == n_ent - 1 and int((e2 >> 32).sum()) > 0
+    assert (rl2 == rl).all() and (ml2 == loop).all() and (f2 == fwd).all()
+    want = rm.parts()
+    for name in bg.READMAP_PART_NAMES:
+        assert back.part(name) == want[name], name
+    bits = np.frombuffer(want["read_ids/source_to_mid/bits"], np.uint64)
+    assert len(bits) == (n_ent + 63) // 64
+    set_pos = np.unique(ent)
+    assert int(sum(bin(int(w)).count("1") for w in bits[np.unique(set_pos >> 6).astype(np.int64)])) == len(set_pos)
+    acc = np.frombuffer(want["read_ids/source_to_mid/accum"], np.uint64)
+    assert int(acc[-1]) == len(set_pos)  # bitcount::finalize: the total in the last accum cell
+    back.free()
+    rm.free()
