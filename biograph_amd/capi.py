@@ -63,7 +63,9 @@ SYMBOLS = [
     "bg_trace_one_base_batch", "bg_ref_walk_entries", "bg_tracer_extend_batch", "bg_trace_options_default",
     "bg_push_trace", "bg_sha1_file", "bg_tracer_open", "bg_tracer_clone", "bg_tracer_trace", "bg_tracer_close", "bg_reference_build", "bg_bwt_build", "bg_trace_result_size", "bg_trace_result_get", "bg_trace_result_stats", "bg_trace_result_free", "bg_assemblies_process", "bg_trace_result_new", "bg_trace_result_add", "bg_trace_result_var_count", "bg_trace_result_var", "bg_coverage_options_default", "bg_assemblies_coverage", "bg_coverage_open", "bg_coverage_run", "bg_coverage_close", "bg_trace_result_coverage", "bg_trace_result_set_coverage", "bg_assemblies_rvg_exclude", "bg_vcf_record", "bg_walk_chains", "bg_walk_chains_batch", "bg_trace_result_ml", "bg_trace_result_set_ml", "bg_branch_trace_batch", "bg_ref_map_build",
     "bg_readmap_build", "bg_readmap_build_marked", "bg_seqset_mark_inputs", "bg_readmap_size", "bg_readmap_max_read_len", "bg_readmap_part", "bg_readmap_write",
-    "bg_readmap_free", "bg_create_sample", "bg_readmap_open", "bg_readmap_from_arrays", "bg_readmap_arrays", "bg_prefix_reads_batch",
+    "bg_readmap_free", "bg_create_sample", "bg_readmap_open", "bg_readmap_from_arrays", "bg_readmap_arrays",
+    "bg_seqset_find_rows", "bg_readmap_rows", "bg_readmap_shard_build", "bg_readmap_shard_size", "bg_readmap_shard_free",
+    "bg_readmap_shard_first_claims", "bg_readmap_shard_apply_claims", "bg_readmap_shard_take_replies", "bg_readmap_shard_columns", "bg_prefix_reads_batch",
     "bg_read_info_batch", "bg_propagate_from_end_batch", "bg_push_to_pair_trace_batch",
     "bg_seqset_merge", "bg_readmap_migrate",
     "bg_asm_list_create", "bg_asm_list_free", "bg_asm_list_size", "bg_asm_list_add", "bg_asm_list_sort",
@@ -212,6 +214,17 @@ def lib():
     L.bg_readmap_open.argtypes = [vp, C.c_char_p, P(vp)]
     L.bg_readmap_arrays.argtypes = [vp, vp, vp, vp, vp, vp]
     L.bg_readmap_from_arrays.argtypes = [vp, u64, u32, C.c_char_p, u64, vp, vp, vp, vp, P(vp)]
+    L.bg_seqset_find_rows.argtypes = [vp, vp, vp, u64, i32, u64, vp]
+    L.bg_readmap_rows.argtypes = [vp, vp, i32, vp, u32, vp, vp, u64, P(u64)]
+    L.bg_readmap_shard_build.argtypes = [vp, vp, u64, P(vp)]
+    L.bg_readmap_shard_size.argtypes = [vp]
+    L.bg_readmap_shard_size.restype = u64
+    L.bg_readmap_shard_free.argtypes = [vp]
+    L.bg_readmap_shard_free.restype = None
+    L.bg_readmap_shard_first_claims.argtypes = [vp, vp, u64, u32, vp, vp, u64, P(u64)]
+    L.bg_readmap_shard_apply_claims.argtypes = [vp, vp, u64, i32, vp, u64, u32, vp, vp, vp, P(u64)]
+    L.bg_readmap_shard_take_replies.argtypes = [vp, vp, u64, vp, vp, u64]
+    L.bg_readmap_shard_columns.argtypes = [vp, vp, vp, vp, vp, vp]
     L.bg_prefix_reads_batch.argtypes = [vp, vp, vp, u64, vp, vp, vp, i32, u32, vp, vp]
     L.bg_read_info_batch.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, vp, vp, vp]
     L.bg_propagate_from_end_batch.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp,
@@ -288,7 +301,7 @@ def lib():
     L.bg_seqset_slice_masks.argtypes = [vp, vp, vp, vp, vp]
     L.bg_seqset_slice_build.argtypes = [vp, u64, vp, vp, vp, u32, P(vp)]
     L.bg_seqset_slice_popcounts.argtypes = [vp, P(u64)]
-    L.bg_seqset_sharded_create_file.argtypes = [C.c_char_p, u64, u32, P(u64), i32, P(C.c_char_p), P(u64)]
+    L.bg_seqset_sharded_create_file.argtypes = [C.c_char_p, u64, u32, P(u64), i32, P(C.c_char_p), P(u64), vp]
     L.bg_seqset_slice_write.argtypes = [vp, vp, C.c_char_p, P(u64), u64, i32, P(u64)]
     L.bg_readmap_has_mate_loop.argtypes = [vp]
     L.bg_rows_select.argtypes = [vp, vp, u64, i32, vp, vp, u64, P(u64)]

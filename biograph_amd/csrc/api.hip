@@ -595,12 +595,14 @@ static void payload_sizes(uint64_t n, uint32_t max_len, uint64_t* sz) {
 // (payload order: fixed, entry_sizes/elements, shared/elements, prev_A/bits, prev_A/subaccum, prev_A/accum, ...).
 // `fixed` is written here.
 extern "C" int bg_seqset_sharded_create_file(const char* path, uint64_t n_total, uint32_t max_len, const uint64_t* h_fixed5,
-                                             int argc, const char* const* argv, uint64_t* h_offsets) {
+                                             int argc, const char* const* argv, uint64_t* h_offsets, char* h_uuid37) {
   if (!path || !h_fixed5 || !h_offsets) { set_error("bg_seqset_sharded_create_file: null argument"); return BG_EINVAL; }
+  const std::string uuid = make_uuid();
+  if (h_uuid37) snprintf(h_uuid37, 37, "%s", uuid.c_str());
   uint64_t sz[kPayloadParts];
   payload_sizes(n_total, n_total ? max_len : 0, sz);
   std::vector<ZipPart> parts;
-  BG_TRY(seqset_members(n_total, n_total ? max_len : 0, make_uuid(), argc, argv,
+  BG_TRY(seqset_members(n_total, n_total ? max_len : 0, uuid, argc, argv,
                         [](const std::string&, std::string*) { return BG_OK; }, sz, &parts));
   for (ZipPart& p : parts)
     if (p.name == "fixed") { p.hole_size = 0; p.data.assign(reinterpret_cast<const char*>(h_fixed5), 40); }

@@ -349,6 +349,57 @@ static int sort_pairs(bg_ctx* ctx, DevBuf<uint64_t>& ka, DevBuf<uint64_t>& kb, D
   return BG_OK;
 }
 
+// Rows (hi, lo) in n_slots slots (hi = ~0: unused slot) -> the valid rows sorted by (hi, lo): the total order of
+// make_readmap.h:187-213.  LSD: by lo (37 bits), then stably by hi; unused slots sort to the end.
+static int rm_sort_rows(bg_ctx* ctx, DevBuf<uint64_t>& hi, DevBuf<uint64_t>& lo, uint64_t n_slots, DevBuf<uint64_t>* hi_s,
+                        DevBuf<uint64_t>* lo_s, uint64_t* n_rows_out) {
+  if (n_slots >= (1ull << 32)) { set_error("readmap: more than 2^32 rows on one device"); return BG_EINVAL; }
+  DevBuf<uint64_t> ka, kb;
+  DevBuf<uint32_t> va, vb;
+  BG_TRY(ka.alloc(ctx, n_slots));
+  BG_TRY(kb.alloc(ctx, n_slots));
+  BG_TRY(va.alloc(ctx, n_slots));
+  BG_TRY(vb.alloc(ctx, n_slots));
+  if (n_slots) {
+    BG_HIP(hipMemcpyAsync(ka.p, lo.p, n_slots * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    k_iota32<<<cdiv(n_slots, 256), 256, 0, ctx->stream>>>(va.p, n_slots);
+    BG_LAUNCH_CHECK();
+  }
+  uint64_t* ks = nullptr;
+  uint32_t* vs = nullptr;
+  BG_TRY(sort_pairs(ctx, ka, kb, va, vb, n_slots, 37, &ks, &vs));
+  uint64_t* k2 = ks == ka.p ? kb.p : ka.p;
+  uint32_t* v2 = vs == va.p ? vb.p : va.p;
+  if (n_slots) {
+    k_gather64<<<cdiv(n_slots, 256), 256, 0, ctx->stream>>>(hi.p, vs, n_slots, k2);
+    BG_LAUNCH_CHECK();
+  }
+  // second sort: keys k2 (hi), payload vs; scratch = the other pair
+  bool in_b = false;
+  BG_TRY(radix_sort_u64(ctx, k2, ks, vs, v2, n_slots, 0, 64, &in_b));
+  uint64_t* hsorted = in_b ? ks : k2;
+  uint32_t* perm = in_b ? v2 : vs;
+  DevBuf<uint8_t> f;
+  DevBuf<uint32_t> valid_pos;
+  BG_TRY(f.alloc(ctx, n_slots));
+  if (n_slots) {
+    k_rm_flag_valid<<<cdiv(n_slots, 256), 256, 0, ctx->stream>>>(hsorted, n_slots, f.p);
+    BG_LAUNCH_CHECK();
+  }
+  uint64_t n_rows = 0;
+  BG_TRY(compact_flagged<uint32_t>(ctx, f.p, n_slots, &valid_pos, &n_rows));  // valid rows are a prefix
+  BG_TRY(hi_s->alloc(ctx, n_rows));
+  BG_TRY(lo_s->alloc(ctx, n_rows));
+  if (n_rows) {
+    BG_HIP(hipMemcpyAsync(hi_s->p, hsorted, n_rows * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    k_gather64<<<cdiv(n_rows, 256), 256, 0, ctx->stream>>>(lo.p, perm, n_rows, lo_s->p);
+    BG_LAUNCH_CHECK();
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  *n_rows_out = n_rows;
+  return BG_OK;
+}
+
 }  // namespace bg
 
 
@@ -439,53 +490,15 @@ extern "C" int bg_readmap_build_marked(bg_ctx* ctx, const bg_seqset* ss, const b
   DevBuf<uint64_t> hi_s, lo_s;  // sorted rows
   uint64_t n_rows = 0;
   {
-    DevBuf<uint64_t> hi, lo, ka, kb;
-    DevBuf<uint32_t> va, vb;
+    DevBuf<uint64_t> hi, lo;
     BG_TRY(hi.alloc(ctx, n_slots));
     BG_TRY(lo.alloc(ctx, n_slots));
-    BG_TRY(ka.alloc(ctx, n_slots));
-    BG_TRY(kb.alloc(ctx, n_slots));
-    BG_TRY(va.alloc(ctx, n_slots));
-    BG_TRY(vb.alloc(ctx, n_slots));
     if (n_rec) {
       k_rm_rows<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->len.p, n_rec, W, is_paired ? 1 : 0,
                                                           eid.p, hi.p, lo.p);
       BG_LAUNCH_CHECK();
-      // LSD: by lo (37 bits) then by hi (stable)
-      BG_HIP(hipMemcpyAsync(ka.p, lo.p, n_slots * 8, hipMemcpyDeviceToDevice, ctx->stream));
-      k_iota32<<<cdiv(n_slots, 256), 256, 0, ctx->stream>>>(va.p, n_slots);
-      BG_LAUNCH_CHECK();
     }
-    uint64_t* ks = nullptr;
-    uint32_t* vs = nullptr;
-    BG_TRY(sort_pairs(ctx, ka, kb, va, vb, n_slots, 37, &ks, &vs));
-    uint64_t* k2 = ks == ka.p ? kb.p : ka.p;
-    uint32_t* v2 = vs == va.p ? vb.p : va.p;
-    if (n_slots) {
-      k_gather64<<<cdiv(n_slots, 256), 256, 0, ctx->stream>>>(hi.p, vs, n_slots, k2);
-      BG_LAUNCH_CHECK();
-    }
-    // second sort: keys k2 (hi), payload vs; scratch = the other pair
-    bool in_b = false;
-    BG_TRY(radix_sort_u64(ctx, k2, ks, vs, v2, n_slots, 0, 64, &in_b));
-    uint64_t* hsorted = in_b ? ks : k2;
-    uint32_t* perm = in_b ? v2 : vs;
-    DevBuf<uint8_t> f;
-    DevBuf<uint32_t> valid_pos;
-    BG_TRY(f.alloc(ctx, n_slots));
-    if (n_slots) {
-      k_rm_flag_valid<<<cdiv(n_slots, 256), 256, 0, ctx->stream>>>(hsorted, n_slots, f.p);
-      BG_LAUNCH_CHECK();
-    }
-    BG_TRY(compact_flagged<uint32_t>(ctx, f.p, n_slots, &valid_pos, &n_rows));  // valid rows are a prefix
-    BG_TRY(hi_s.alloc(ctx, n_rows));
-    BG_TRY(lo_s.alloc(ctx, n_rows));
-    if (n_rows) {
-      BG_HIP(hipMemcpyAsync(hi_s.p, hsorted, n_rows * 8, hipMemcpyDeviceToDevice, ctx->stream));
-      k_gather64<<<cdiv(n_rows, 256), 256, 0, ctx->stream>>>(lo.p, perm, n_rows, lo_s.p);
-      BG_LAUNCH_CHECK();
-    }
-    BG_HIP(hipStreamSynchronize(ctx->stream));
+    BG_TRY(rm_sort_rows(ctx, hi, lo, n_slots, &hi_s, &lo_s, &n_rows));
   }
   eid.reset();
   rm->n_reads = n_rows;
@@ -932,4 +945,385 @@ extern "C" int bg_readmap_arrays(bg_ctx* ctx, const bg_readmap* rm, uint64_t* h_
   if (h_is_forward)
     for (uint64_t i = 0; i < n; ++i) h_is_forward[i] = uint8_t(fw[i]);
   return BG_OK;
+}
+
+// =====================================================================================================================
+// Sharded readmap of ONE sample (SURVEY §8e + f.1; BASELINE.json configs[3]): the seqset's entries are range-partitioned
+// over the ranks (shard q holds the global entries [off_q, off_q+1) with their keys), every rank holds some of the
+// sample's pairs.  make_readmap::create_from_reads (make_readmap.cpp:120-392) with every structure owned by one rank:
+//   1. a read's entry = seqset::find_existing_unique on the shard its key falls into (rows routed with
+//      BG_PART_KEY_BOUNDS; bg_seqset_find_rows answers with GLOBAL entry ids);
+//   2. the rows (hi, lo) of make_readmap.h:56-90 go to the owner of their entry, which sorts its rows: the ranks' sorted
+//      rows, in rank order, are the global row order of make_readmap.h:187-213, so read id = rows on the ranks before +
+//      local position;
+//   3. the three claim hops of :283-392 travel as claims (group, loop start's read id, claiming row's read id) to the
+//      owner of the group's entry, which hands the k-th claimer of a group (in read-id order of the loop starts: the
+//      sequential order the reference claims in) the group's k-th row, answers with that row's read id and issues the
+//      next hop's claims.
+// The library still never communicates: biograph_amd/sharded.py (sharded_readmap) moves the rows.
+struct bg_readmap_shard {
+  bg_ctx* ctx = nullptr;
+  uint64_t n = 0;
+  bg::DevBuf<uint64_t> hi, lo;  // this rank's rows, sorted
+  bg::DevBuf<uint64_t> ptr;     // mate loop pointer of every row: a GLOBAL read id (~0 = not set yet)
+};
+
+namespace bg {
+
+constexpr int kClaimWords = 4;  // group key, read id of the loop's start, read id of the claiming row, destination << 10
+
+__device__ __forceinline__ uint64_t entry_owner(const uint64_t* __restrict__ off, uint32_t nparts, uint64_t e) {
+  uint32_t lo = 0, hi = nparts;  // last q with off[q] <= e (an empty shard shares its offset with the next one)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= e) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// entry of every received read row (W key words + length in the low byte of the last word): first entry of the shard
+// that has the row as a prefix, as a global id; ~0 for an empty row; err |= 1 when there is none
+__global__ __launch_bounds__(128) void k_rm_find_rows(const uint64_t* __restrict__ rows, uint64_t n, int W,
+                                                     const uint64_t* __restrict__ ekeys, const uint8_t* __restrict__ esizes,
+                                                     uint64_t n_ent, int EW, const uint32_t* __restrict__ dir, int bases,
+                                                     uint64_t entry_base, uint64_t* __restrict__ out, uint32_t* __restrict__ err) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t* r = rows + i * uint64_t(W + 1);
+  const int L = int(r[W] & 0xff);
+  if (!L) { out[i] = ~0ull; return; }
+  uint64_t key[kMaxWords];
+  for (int w = 0; w < EW; ++w) key[w] = w < W ? r[w] : 0;
+  const uint32_t p = uint32_t(key[0] >> (64 - 2 * bases));
+  uint64_t lo = dir[p], hi = dir[p + 1];
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (key_compare(ekeys + mid * EW, esizes[mid], key, L, EW) < 0) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= n_ent || key_lcp(ekeys + lo * EW, esizes[lo], key, L, EW) < L) {
+    atomicOr(err, 1u);  // "Read ... was not found in seqset" (make_readmap.cpp:147-151)
+    out[i] = ~0ull;
+    return;
+  }
+  out[i] = entry_base + lo;
+}
+
+__global__ void k_rms_pack_rows(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, const uint32_t* __restrict__ pos,
+                                uint64_t m, const uint64_t* __restrict__ off, uint32_t nparts, uint64_t* __restrict__ rows) {
+  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= m) return;
+  const uint64_t h = hi[pos[t]];
+  uint64_t* r = rows + t * 3;
+  r[0] = h;
+  r[1] = lo[pos[t]];
+  r[2] = entry_owner(off, nparts, hi_entry(h)) << 10;
+}
+
+__global__ void k_rms_split_rows(const uint64_t* __restrict__ rows, uint64_t n, uint64_t* __restrict__ hi, uint64_t* __restrict__ lo) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  hi[i] = rows[i * 3];
+  lo[i] = rows[i * 3 + 1];
+}
+
+__global__ void k_rms_first_claims(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, const uint32_t* __restrict__ starts,
+                                   uint64_t ns, uint64_t gid_base, const uint64_t* __restrict__ off, uint32_t nparts,
+                                   uint64_t* __restrict__ claims) {
+  const uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  const uint64_t i = starts[s];
+  uint64_t* c = claims + s * kClaimWords;
+  c[0] = rm_hi(lo[i], 1, hi_len(hi[i]), 0);  // hop 1: the RC rows of (loop_entry, read_len)  (:283-302)
+  c[1] = gid_base + i;
+  c[2] = gid_base + i;
+  c[3] = entry_owner(off, nparts, lo[i]) << 10;
+}
+
+__global__ void k_rms_claim_keys(const uint64_t* __restrict__ claims, uint64_t n, int word, uint64_t* __restrict__ keys,
+                                 uint32_t* __restrict__ idx) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = claims[i * kClaimWords + word];
+  if (idx) idx[i] = uint32_t(i);
+}
+__global__ void k_rms_gather_claim_word(const uint64_t* __restrict__ claims, const uint32_t* __restrict__ idx, uint64_t n, int word,
+                                        uint64_t* __restrict__ out) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = claims[uint64_t(idx[i]) * kClaimWords + word];
+}
+
+// Claimers sorted by (group, read id of their loop's start): the k-th of a group takes the group's k-th row.  Answers
+// with the row's read id, finishes what ends here and writes the next hop's claim (word 3 = ~0: none).
+__global__ void k_rms_apply_claims(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, uint64_t n_rows,
+                                   uint64_t gid_base, int hop, const uint64_t* __restrict__ claims, const uint64_t* __restrict__ gs,
+                                   const uint32_t* __restrict__ perm, uint64_t n, const uint64_t* __restrict__ off, uint32_t nparts,
+                                   uint64_t* __restrict__ ptr, uint64_t* __restrict__ reply, uint64_t* __restrict__ next,
+                                   uint8_t* __restrict__ has_next, uint32_t* __restrict__ err) {
+  const uint64_t p = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint64_t g = gs[p];
+  const uint32_t c = perm[p];
+  const uint64_t first = lower_bound_u64(gs, n, g);
+  const uint64_t row = lower_bound_u64(hi, n_rows, g) + (p - first);
+  has_next[c] = 0;
+  if (row >= n_rows || (hi[row] >> 10) != (g >> 10)) {  // entry, type and length of the claimed row (:352-389)
+    atomicOr(err, 2u);
+    reply[c] = ~0ull;
+    return;
+  }
+  reply[c] = gid_base + row;
+  const uint64_t start = claims[uint64_t(c) * kClaimWords + 1];
+  uint64_t* nx = next + uint64_t(c) * kClaimWords;
+  if (hop == 1) {
+    if (lo[row] == kNoLoopEntry) { ptr[row] = start; return; }  // no mate: RC points back to the start
+    nx[0] = rm_hi(lo[row], 2, hi_mate_len(hi[row]), 0);
+  } else if (hop == 2) {
+    nx[0] = rm_hi(lo[row], 3, hi_len(hi[row]), 0);
+  } else {
+    ptr[row] = start;  // loop back to the beginning (:389)
+    return;
+  }
+  nx[1] = start;
+  nx[2] = gid_base + row;
+  nx[3] = entry_owner(off, nparts, lo[row]) << 10;
+  has_next[c] = 1;
+}
+
+__global__ void k_rms_take_replies(const uint64_t* __restrict__ sent, const uint64_t* __restrict__ reply, uint64_t n,
+                                   uint64_t gid_base, uint64_t n_rows, uint64_t* __restrict__ ptr, uint32_t* __restrict__ err) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t from = sent[i * kClaimWords + 2];
+  if (from < gid_base || from - gid_base >= n_rows || reply[i] == ~0ull) { atomicOr(err, 2u); return; }
+  ptr[from - gid_base] = reply[i];
+}
+
+__global__ void k_rms_columns(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ ptr, uint64_t n,
+                              uint64_t* __restrict__ entry, uint32_t* __restrict__ len, uint32_t* __restrict__ out_ptr,
+                              uint8_t* __restrict__ fwd, uint32_t* __restrict__ err) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t h = hi[i];
+  const int t = hi_type(h);
+  entry[i] = hi_entry(h);
+  len[i] = hi_len(h);
+  fwd[i] = (t == 0 || t == 2) ? 1 : 0;
+  if (ptr[i] >= (1ull << 32)) atomicOr(err, 2u);  // a row no loop went through
+  out_ptr[i] = uint32_t(ptr[i]);
+}
+
+static int rms_offsets(bg_ctx* ctx, uint32_t nparts, const uint64_t* h_entry_offsets, DevBuf<uint64_t>* d) {
+  BG_TRY(d->alloc(ctx, nparts + 1));
+  BG_HIP(hipMemcpyAsync(d->p, h_entry_offsets, (uint64_t(nparts) + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  return BG_OK;
+}
+
+static int rms_check(bg_ctx* ctx, DevBuf<uint32_t>& err, const char* who) {
+  uint32_t h_err = 0;
+  BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_err & 1) { set_error("%s: a read was not found in the seqset", who); return BG_EINTERNAL; }
+  if (h_err & 2) { set_error("%s: mate loop claim failed (inconsistent rows)", who); return BG_EINTERNAL; }
+  return BG_OK;
+}
+
+}  // namespace bg
+
+extern "C" int bg_seqset_find_rows(bg_ctx* ctx, const bg_seqset* shard, const uint64_t* d_rows, uint64_t n, int W,
+                                   uint64_t entry_base, uint64_t* d_entry) {
+  if (!ctx || !shard || (n && (!d_rows || !d_entry))) { set_error("bg_seqset_find_rows: null argument"); return BG_EINVAL; }
+  if (n && shard->n && !(shard->keys.p && shard->W)) { set_error("bg_seqset_find_rows: the shard has no resident keys"); return BG_EINVAL; }
+  if (W < 1 || W > kMaxWords || (shard->n && W > shard->W)) { set_error("bg_seqset_find_rows: rows wider than the shard's keys"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!n) return BG_OK;
+  DevBuf<uint32_t> err, dir;
+  BG_TRY(err.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+  int bases = 0;
+  const int EW = shard->W ? shard->W : W;
+  ctx->tic("readmap_entry_ids");
+  if (shard->n) {
+    BG_TRY(build_prefix_dir_keys(ctx, shard->keys.p, shard->n, EW, &dir, &bases));
+  } else {  // an empty shard answers "not found" for anything but an empty row
+    bases = 1;
+    BG_TRY(dir.alloc(ctx, 5));
+    BG_HIP(hipMemsetAsync(dir.p, 0, 5 * 4, ctx->stream));
+  }
+  k_rm_find_rows<<<cdiv(n, 128), 128, 0, ctx->stream>>>(d_rows, n, W, shard->keys.p, shard->sizes.p, shard->n, EW, dir.p, bases,
+                                                       entry_base, d_entry, err.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n * (uint64_t(W) * 8 + 64));
+  return rms_check(ctx, err, "bg_seqset_find_rows");
+}
+
+extern "C" int bg_readmap_rows(bg_ctx* ctx, const bg_reads* reads, int is_paired, const uint64_t* d_entry, uint32_t nparts,
+                               const uint64_t* h_entry_offsets, uint64_t* d_rows, uint64_t cap, uint64_t* n_out) {
+  if (!ctx || !reads || !h_entry_offsets || !n_out || (reads->n && !d_entry)) { set_error("bg_readmap_rows: null argument"); return BG_EINVAL; }
+  if (is_paired && (reads->n & 1)) { set_error("bg_readmap_rows: paired input needs an even number of reads"); return BG_EINVAL; }
+  if (nparts < 1 || nparts > 126) { set_error("bg_readmap_rows: %u shards outside 1..126", nparts); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  const uint64_t n = reads->n, n_rec = is_paired ? n / 2 : n, n_slots = n_rec * (is_paired ? 4 : 2);
+  *n_out = 0;
+  if (!n_slots) return BG_OK;
+  if (n_slots >= (1ull << 32)) { set_error("bg_readmap_rows: more than 2^32 rows on one device"); return BG_EINVAL; }
+  DevBuf<uint64_t> hi, lo, off;
+  DevBuf<uint8_t> f;
+  DevBuf<uint32_t> pos;
+  BG_TRY(hi.alloc(ctx, n_slots));
+  BG_TRY(lo.alloc(ctx, n_slots));
+  BG_TRY(f.alloc(ctx, n_slots));
+  BG_TRY(rms_offsets(ctx, nparts, h_entry_offsets, &off));
+  k_rm_rows<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->len.p, n_rec, reads->W, is_paired ? 1 : 0, d_entry, hi.p, lo.p);
+  BG_LAUNCH_CHECK();
+  k_rm_flag_valid<<<cdiv(n_slots, 256), 256, 0, ctx->stream>>>(hi.p, n_slots, f.p);
+  BG_LAUNCH_CHECK();
+  uint64_t m = 0;
+  BG_TRY(compact_flagged<uint32_t>(ctx, f.p, n_slots, &pos, &m));
+  if (m > cap || (m && !d_rows)) { set_error("bg_readmap_rows: room for %llu rows, %llu needed", (unsigned long long)cap, (unsigned long long)m); return BG_EINVAL; }
+  if (m) {
+    k_rms_pack_rows<<<cdiv(m, 256), 256, 0, ctx->stream>>>(hi.p, lo.p, pos.p, m, off.p, nparts, d_rows);
+    BG_LAUNCH_CHECK();
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  *n_out = m;
+  return BG_OK;
+}
+
+extern "C" int bg_readmap_shard_build(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, bg_readmap_shard** out) {
+  if (!ctx || !out || (n && !d_rows)) { set_error("bg_readmap_shard_build: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<bg_readmap_shard> sh(new bg_readmap_shard);
+  sh->ctx = ctx;
+  DevBuf<uint64_t> hi, lo;
+  BG_TRY(hi.alloc(ctx, n));
+  BG_TRY(lo.alloc(ctx, n));
+  if (n) {
+    k_rms_split_rows<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_rows, n, hi.p, lo.p);
+    BG_LAUNCH_CHECK();
+  }
+  uint64_t n_rows = 0;
+  BG_TRY(rm_sort_rows(ctx, hi, lo, n, &sh->hi, &sh->lo, &n_rows));
+  if (n_rows != n) { set_error("bg_readmap_shard_build: %llu of %llu rows are not rows", (unsigned long long)(n - n_rows), (unsigned long long)n); return BG_EINVAL; }
+  sh->n = n;
+  BG_TRY(sh->ptr.alloc(ctx, n));
+  if (n) BG_HIP(hipMemsetAsync(sh->ptr.p, 0xff, n * 8, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  *out = sh.release();
+  return BG_OK;
+}
+
+extern "C" uint64_t bg_readmap_shard_size(const bg_readmap_shard* s) { return s ? s->n : 0; }
+extern "C" void bg_readmap_shard_free(bg_readmap_shard* s) { delete s; }
+
+extern "C" int bg_readmap_shard_first_claims(bg_ctx* ctx, const bg_readmap_shard* s, uint64_t read_id_base, uint32_t nparts,
+                                             const uint64_t* h_entry_offsets, uint64_t* d_claims, uint64_t cap, uint64_t* n_out) {
+  if (!ctx || !s || !h_entry_offsets || !n_out) { set_error("bg_readmap_shard_first_claims: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  *n_out = 0;
+  if (!s->n) return BG_OK;
+  DevBuf<uint8_t> f;
+  DevBuf<uint32_t> starts;
+  DevBuf<uint64_t> off;
+  BG_TRY(f.alloc(ctx, s->n));
+  BG_TRY(rms_offsets(ctx, nparts, h_entry_offsets, &off));
+  k_rm_flag_type<<<cdiv(s->n, 256), 256, 0, ctx->stream>>>(s->hi.p, s->n, 0, f.p);
+  BG_LAUNCH_CHECK();
+  uint64_t ns = 0;
+  BG_TRY(compact_flagged<uint32_t>(ctx, f.p, s->n, &starts, &ns));
+  if (ns > cap || (ns && !d_claims)) { set_error("bg_readmap_shard_first_claims: room for %llu claims, %llu needed", (unsigned long long)cap, (unsigned long long)ns); return BG_EINVAL; }
+  if (ns) {
+    k_rms_first_claims<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(s->hi.p, s->lo.p, starts.p, ns, read_id_base, off.p, nparts, d_claims);
+    BG_LAUNCH_CHECK();
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  *n_out = ns;
+  return BG_OK;
+}
+
+extern "C" int bg_readmap_shard_apply_claims(bg_ctx* ctx, bg_readmap_shard* s, uint64_t read_id_base, int hop, const uint64_t* d_claims,
+                                             uint64_t n, uint32_t nparts, const uint64_t* h_entry_offsets, uint64_t* d_reply,
+                                             uint64_t* d_next, uint64_t* n_next) {
+  if (!ctx || !s || !h_entry_offsets || !n_next || (n && (!d_claims || !d_reply || !d_next))) {
+    set_error("bg_readmap_shard_apply_claims: null argument");
+    return BG_EINVAL;
+  }
+  if (hop < 1 || hop > 3) { set_error("bg_readmap_shard_apply_claims: hop %d outside 1..3", hop); return BG_EINVAL; }
+  if (n >= (1ull << 32)) { set_error("bg_readmap_shard_apply_claims: more than 2^32 claims"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  *n_next = 0;
+  if (!n) return BG_OK;
+  DevBuf<uint64_t> ka, kb, off, next;
+  DevBuf<uint32_t> va, vb, err, pick;
+  DevBuf<uint8_t> has_next;
+  BG_TRY(ka.alloc(ctx, n));
+  BG_TRY(kb.alloc(ctx, n));
+  BG_TRY(va.alloc(ctx, n));
+  BG_TRY(vb.alloc(ctx, n));
+  BG_TRY(next.alloc(ctx, n * kClaimWords));
+  BG_TRY(has_next.alloc(ctx, n));
+  BG_TRY(err.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+  BG_TRY(rms_offsets(ctx, nparts, h_entry_offsets, &off));
+  ctx->tic("readmap_mate_loops");
+  // by the loop start's read id, then stably by group
+  k_rms_claim_keys<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_claims, n, 1, ka.p, va.p);
+  BG_LAUNCH_CHECK();
+  uint64_t* ks = nullptr;
+  uint32_t* vs = nullptr;
+  BG_TRY(sort_pairs(ctx, ka, kb, va, vb, n, 33, &ks, &vs));
+  uint64_t* k2 = ks == ka.p ? kb.p : ka.p;
+  uint32_t* v2 = vs == va.p ? vb.p : va.p;
+  k_rms_gather_claim_word<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_claims, vs, n, 0, k2);
+  BG_LAUNCH_CHECK();
+  bool in_b = false;
+  BG_TRY(radix_sort_u64(ctx, k2, ks, vs, v2, n, 0, 64, &in_b));
+  const uint64_t* gs = in_b ? ks : k2;
+  const uint32_t* perm = in_b ? v2 : vs;
+  k_rms_apply_claims<<<cdiv(n, 256), 256, 0, ctx->stream>>>(s->hi.p, s->lo.p, s->n, read_id_base, hop, d_claims, gs, perm, n, off.p,
+                                                           nparts, s->ptr.p, d_reply, next.p, has_next.p, err.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n * 96);
+  BG_TRY(rms_check(ctx, err, "bg_readmap_shard_apply_claims"));
+  uint64_t m = 0;
+  BG_TRY(compact_flagged<uint32_t>(ctx, has_next.p, n, &pick, &m));
+  if (m) {
+    // claims are kClaimWords-word rows: gather the picked ones
+    for (int w = 0; w < kClaimWords; ++w) {
+      k_rms_gather_claim_word<<<cdiv(m, 256), 256, 0, ctx->stream>>>(next.p, pick.p, m, w, ka.p);
+      BG_LAUNCH_CHECK();
+      BG_HIP(hipMemcpy2DAsync(d_next + w, kClaimWords * 8, ka.p, 8, 8, m, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  *n_next = m;
+  return BG_OK;
+}
+
+extern "C" int bg_readmap_shard_take_replies(bg_ctx* ctx, bg_readmap_shard* s, uint64_t read_id_base, const uint64_t* d_claims_sent,
+                                             const uint64_t* d_reply, uint64_t n) {
+  if (!ctx || !s || (n && (!d_claims_sent || !d_reply))) { set_error("bg_readmap_shard_take_replies: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!n) return BG_OK;
+  DevBuf<uint32_t> err;
+  BG_TRY(err.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+  k_rms_take_replies<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_claims_sent, d_reply, n, read_id_base, s->n, s->ptr.p, err.p);
+  BG_LAUNCH_CHECK();
+  return rms_check(ctx, err, "bg_readmap_shard_take_replies");
+}
+
+extern "C" int bg_readmap_shard_columns(bg_ctx* ctx, const bg_readmap_shard* s, uint64_t* d_entry_id, uint32_t* d_read_len,
+                                        uint32_t* d_mate_loop_ptr, uint8_t* d_is_forward) {
+  if (!ctx || !s || (s->n && (!d_entry_id || !d_read_len || !d_mate_loop_ptr || !d_is_forward))) {
+    set_error("bg_readmap_shard_columns: null argument");
+    return BG_EINVAL;
+  }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!s->n) return BG_OK;
+  DevBuf<uint32_t> err;
+  BG_TRY(err.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+  k_rms_columns<<<cdiv(s->n, 256), 256, 0, ctx->stream>>>(s->hi.p, s->ptr.p, s->n, d_entry_id, d_read_len, d_mate_loop_ptr, d_is_forward, err.p);
+  BG_LAUNCH_CHECK();
+  return rms_check(ctx, err, "bg_readmap_shard_columns");
 }

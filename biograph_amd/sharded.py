@@ -626,7 +626,8 @@ def _aligned_slices(comm, ctxs, shards, part_n, max_len, dev):
 
 def write_slices(comm, slices, path, argv=()):
     """All ranks write ONE seqset container: rank 0 lays the file out (headers, JSON members, `fixed`, room for the
-    rest), every rank then writes its bytes of every member in place.  slices = {local rank: SeqsetSlice}."""
+    rest), every rank then writes its bytes of every member in place.  slices = {local rank: SeqsetSlice}.  -> the uuid
+    the seqset was given."""
     L = capi.lib()
     ranks = comm.local_ranks
     offs = None
@@ -635,9 +636,11 @@ def write_slices(comm, slices, path, argv=()):
         fx = (C.c_uint64 * 5)(*s0.fixed)
         av = (C.c_char_p * max(len(argv), 1))(*[a.encode() for a in argv])
         ho = (C.c_uint64 * 15)()
-        capi.check(L.bg_seqset_sharded_create_file(path.encode(), s0.n_total, s0.max_len, fx, len(argv), av, ho))
-        offs = [int(x) for x in ho]
+        uu = C.create_string_buffer(37)
+        capi.check(L.bg_seqset_sharded_create_file(path.encode(), s0.n_total, s0.max_len, fx, len(argv), av, ho, uu))
+        offs = [int(x) for x in ho] + [uu.value.decode()]
     offs = [o for o in comm.all_gather_obj({r: offs if r == 0 else None for r in ranks})[ranks[0]] if o is not None][0]
+    uuid, offs = offs[-1], offs[:-1]
     comm.barrier()
     ho = (C.c_uint64 * 15)(*offs)
     for r in ranks:
@@ -645,10 +648,11 @@ def write_slices(comm, slices, path, argv=()):
         bp = (C.c_uint64 * 4)(*s.base_pop)
         capi.check(L.bg_seqset_slice_write(s.ctx.h, s.seqset.h, path.encode(), ho, s.first, int(s.is_last), bp))
     comm.barrier()
+    return uuid  # the seqset's uuid (every rank): what the sample's readmap is bound to (readmap.json)
 
 
 def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gather=True, keep_entry_rows=False,
-                   keep_corrected=False):
+                   keep_corrected=False, readmap=None):
     """comm: communicator; ctxs[r]: biograph_amd.Context of local rank r (its HIP stream must be torch's current
     stream on that device: the exchange buffers are torch tensors handed to the library by pointer); inputs[r] =
     (seq uint8 tensor, offs int64 tensor, n_reads) resident on that rank's device.  gather=True (small outputs,
@@ -658,12 +662,17 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gath
 
     mode "routed" (default; k >= 14): nothing is replicated — the kept k-mers stay with the rank that counted
     them and the cover index is range-partitioned like the records; "replicated" (BG_SHARD_REPLICATED=1, and
-    what k < 14 falls back to): kept k-mers and corrected reads are all-gathered on every rank."""
+    what k < 14 falls back to): kept k-mers and corrected reads are all-gathered on every rank.
+
+    readmap="paired" | "unpaired": also the sample's readmap, sharded like the seqset (sharded_readmap below); every
+    slice (or, gather=True, the seqset on rank 0) comes back with .readmap_columns = ReadmapColumns of its rank."""
     import biograph_amd as bg
     L = capi.lib()
     P = comm.world
     ranks = comm.local_ranks
     any_ctx = ctxs[ranks[0]]
+    if readmap not in (None, "paired", "unpaired"):
+        raise ValueError("sharded_create: readmap takes None, 'paired' or 'unpaired'")
     prm = params or any_ctx.default_params()
     k = prm.kmer_size
     dev = {r: inputs[r][0].device for r in ranks}
@@ -793,7 +802,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gath
     W = max(1, (max_len + 31) // 32)
 
     kept_reads = {}
-    if keep_corrected:  # this rank's corrected reads, packed (the readmaps of a population run are built from them)
+    if keep_corrected or readmap:  # this rank's corrected reads, packed (the readmaps are built from them)
         for r in ranks:
             kept_reads[r] = export_reads(ctxs[r], corrected[r], W, dev[r]) + (max_len,)
     _relieve(ctxs, dev)
@@ -854,9 +863,10 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gath
              "n_corrected_reads": sum(c["corrected_reads"] for c in all_cs),
              "n_corrected_bases": sum(c["corrected_bases"] for c in all_cs), "n_records": n_records}
     stats.update(extra_stats)
-    out = _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats, keep_entry_rows=keep_entry_rows)
+    out = _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats, keep_entry_rows=keep_entry_rows,
+                             readmap=(kept_reads, readmap == "paired") if readmap else None)
     for r in kept_reads:
-        if out[r][0] is not None:
+        if out[r][0] is not None and keep_corrected:
             out[r][0].corrected = kept_reads[r]
     return out
 
@@ -880,7 +890,174 @@ def import_reads(ctx, words, lens, max_len):
     return bg.Reads(ctx, h)
 
 
-def _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats, keep_entry_rows=False, mark_inputs=0):
+class ReadmapColumns:
+    """One rank's stretch of a sharded readmap: the per-read columns of the read ids [first, first + n) of n_total --
+    entry (GLOBAL seqset entry id, int64), read_len / mate_loop_ptr (int32; the pointers are global read ids), is_forward
+    (uint8), all on the rank's device -- and what the container needs beside them."""
+
+    def __init__(self, first, n_total, n_entries, max_read_len, entry, read_len, mate_loop_ptr, is_forward):
+        self.first, self.n_total, self.n_entries, self.max_read_len = first, n_total, n_entries, max_read_len
+        self.entry, self.read_len, self.mate_loop_ptr, self.is_forward = entry, read_len, mate_loop_ptr, is_forward
+
+
+def sharded_readmap(comm, ctxs, shards, part_n, reads, paired, W, dev, ph=None):
+    """make_readmap::create_from_reads (make_readmap.cpp:120-392) for ONE sample whose seqset is range-partitioned:
+    shards[r] = rank r's entries with their keys resident (global entries [off_r, off_r+1), off = running sum of part_n),
+    reads[r] = (words, lens, max_len) = rank r's corrected reads (whole pairs when `paired`).  Every structure has one
+    owner: a read's entry is found on the shard its key falls into, a row lives with its entry, a claim of the mate loop
+    is settled where the claimed group lives.  -> {r: ReadmapColumns}.  Collectives: one all_to_all + reply for the entry
+    ids, one all_to_all for the rows, one all_to_all + reply per claim hop (3)."""
+    import biograph_amd as bg
+    L = capi.lib()
+    P = comm.world
+    ranks = comm.local_ranks
+    i64 = torch.int64
+    mark = ph.mark if ph is not None else (lambda name: None)
+    off = [0]
+    for n in part_n:
+        off.append(off[-1] + n)
+    h_off = (C.c_uint64 * (P + 1))(*off)
+    mark("readmap_lookup")
+    # ---- 1. entry ids: oriented rows (tagged with their index) to the shard their key falls into
+    bounds = {}
+    for r in ranks:
+        la = np.zeros(W + 1, np.uint64)
+        fi = np.zeros(W + 1, np.uint64)
+        capi.check(L.bg_seqset_boundary_rows(ctxs[r].h, shards[r].h, capi.np_ptr(fi), capi.np_ptr(la)))
+        bounds[r] = [int(x) for x in la]
+    lasts = comm.all_gather_obj(bounds)[ranks[0]]
+    kb = np.ascontiguousarray(np.array(lasts, np.uint64).reshape(P, W + 1))
+    handles, send, n_or = {}, {}, {}
+    for r in ranks:
+        words, lens, mlen = reads[r]
+        handles[r] = import_reads(ctxs[r], words, lens, mlen)
+        n = len(handles[r])
+        n_or[r] = 2 * n
+        rows = torch.empty((2 * n, W + 1), dtype=i64, device=dev[r])
+        capi.check(L.bg_oriented_rows(ctxs[r].h, handles[r].h, W, _ptr(rows)))
+        rows[:, W] |= torch.arange(2 * n, dtype=i64, device=dev[r]) << 8  # the row's way home
+        if paired and n % 2:
+            raise ValueError("sharded_readmap: a rank holds an odd number of reads of a paired sample")
+        # a dropped read (length 0) needs no look-up but keeps its place: it travels to the first shard and comes back as ~0
+        send[r] = _partition(ctxs[r], rows, capi.PART_KEY_BOUNDS, P, kb)
+        del rows
+    recv, cm = comm.all_to_all_v(send)
+    back = {}
+    for r in ranks:
+        rows = recv[r].contiguous()
+        ent = torch.empty((max(rows.shape[0], 1),), dtype=i64, device=dev[r])
+        capi.check(L.bg_seqset_find_rows(ctxs[r].h, shards[r].h, _ptr(rows), rows.shape[0], W, off[r], _ptr(ent)))
+        back[r] = ent[:rows.shape[0]].view(-1, 1)
+    del recv
+    answers = comm.all_to_all_reply(back, cm)
+    del back
+    mark("readmap_rows")
+    # ---- 2. rows to the owner of their entry; sorted there
+    rsend = {}
+    for r in ranks:
+        sent = send[r][0]
+        eid = torch.full((max(n_or[r], 1),), -1, dtype=i64, device=dev[r])
+        if sent.shape[0]:
+            eid[sent[:, W] >> 8] = answers[r].contiguous().view(-1)
+        n = n_or[r] // 2
+        n_slots = (n // 2) * 4 if paired else n * 2
+        rows = torch.empty((max(n_slots, 1), 3), dtype=i64, device=dev[r])
+        m = C.c_uint64()
+        capi.check(L.bg_readmap_rows(ctxs[r].h, handles[r].h, int(bool(paired)), _ptr(eid), P, h_off, _ptr(rows), n_slots, C.byref(m)))
+        handles[r].free()
+        rsend[r] = _partition(ctxs[r], rows[:m.value], capi.PART_ROW_DEST, P, None)
+        del rows, eid
+    del send, answers
+    recv, _ = comm.all_to_all_v(rsend)
+    del rsend
+    rsh = {}
+    for r in ranks:
+        rows = recv[r].contiguous()
+        h = C.c_void_p()
+        capi.check(L.bg_readmap_shard_build(ctxs[r].h, _ptr(rows), rows.shape[0], C.byref(h)))
+        rsh[r] = h
+    del recv
+    try:
+        sizes = [row[0] for row in comm.gather_ints({r: [int(L.bg_readmap_shard_size(rsh[r]))] for r in ranks})]
+        base = [0]
+        for n in sizes:
+            base.append(base[-1] + n)
+        n_total = base[-1]
+        if n_total >= 1 << 32:
+            raise RuntimeError("sharded_readmap: more than 2^32 read ids (readmap.h holds them in 32 bits)")
+        mark("readmap_mate_loops")
+        # ---- 3. the claim hops (make_readmap.cpp:283-392)
+        claims = {}
+        for r in ranks:
+            n = sizes[r]
+            t = torch.empty((max(n, 1), 4), dtype=i64, device=dev[r])
+            m = C.c_uint64()
+            capi.check(L.bg_readmap_shard_first_claims(ctxs[r].h, rsh[r], base[r], P, h_off, _ptr(t), n, C.byref(m)))
+            claims[r] = t[:m.value]
+        for hop in (1, 2, 3):
+            if not _all_sum(comm, {r: int(claims[r].shape[0]) for r in ranks}):
+                break
+            csend = {r: _partition(ctxs[r], claims[r].contiguous(), capi.PART_ROW_DEST, P, None) for r in ranks}
+            crecv, ccm = comm.all_to_all_v(csend)
+            reply, nxt = {}, {}
+            for r in ranks:
+                got = crecv[r].contiguous()
+                n = got.shape[0]
+                rep = torch.empty((max(n, 1),), dtype=i64, device=dev[r])
+                nx = torch.empty((max(n, 1), 4), dtype=i64, device=dev[r])
+                m = C.c_uint64()
+                capi.check(L.bg_readmap_shard_apply_claims(ctxs[r].h, rsh[r], base[r], hop, _ptr(got), n, P, h_off, _ptr(rep), _ptr(nx),
+                                                           C.byref(m)))
+                reply[r] = rep[:n].view(-1, 1)
+                nxt[r] = nx[:m.value]
+            del crecv
+            home = comm.all_to_all_reply(reply, ccm)
+            for r in ranks:
+                sent = csend[r][0].contiguous()
+                rep = home[r].contiguous()
+                capi.check(L.bg_readmap_shard_take_replies(ctxs[r].h, rsh[r], base[r], _ptr(sent), _ptr(rep), sent.shape[0]))
+            claims = nxt
+            del csend, reply, home
+        mark("readmap_columns")
+        mlen = max(x[0] for x in comm.gather_ints({r: [int(reads[r][2])] for r in ranks}))
+        out = {}
+        for r in ranks:
+            n = sizes[r]
+            e = torch.empty((max(n, 1),), dtype=i64, device=dev[r])
+            rl = torch.empty((max(n, 1),), dtype=torch.int32, device=dev[r])
+            ml = torch.empty((max(n, 1),), dtype=torch.int32, device=dev[r])
+            fw = torch.empty((max(n, 1),), dtype=torch.uint8, device=dev[r])
+            capi.check(L.bg_readmap_shard_columns(ctxs[r].h, rsh[r], _ptr(e), _ptr(rl), _ptr(ml), _ptr(fw)))
+            out[r] = ReadmapColumns(base[r], n_total, off[-1], mlen, e[:n], rl[:n], ml[:n], fw[:n])
+        return out
+    finally:
+        for h in rsh.values():
+            L.bg_readmap_shard_free(h)
+
+
+def gather_readmap(comm, ctxs, cols, seqset_uuid, writer=0):
+    """The ranks' ReadmapColumns put together on rank `writer` as one resident Readmap (bg_readmap_from_arrays: the
+    sparse_multi bit vectors and their bitcounts are derived there); None on the other ranks.  17 bytes per read id
+    cross the links once."""
+    ranks = comm.local_ranks
+    r0 = ranks[0]
+    c0 = cols[r0]
+    parts = {}
+    for name in ("entry", "read_len", "mate_loop_ptr", "is_forward"):
+        parts[name] = comm.all_gather_v({r: getattr(cols[r], name).contiguous() for r in ranks})
+    out = {}
+    for r in ranks:
+        if r != writer:
+            out[r] = None
+            continue
+        dev = cols[r].entry.device
+        full = {name: torch.cat([g.to(dev) for g in parts[name][r]]).contiguous() for name in parts}
+        out[r] = ctxs[r].readmap_from_arrays(c0.n_entries, c0.max_read_len, seqset_uuid, full["entry"], full["read_len"],
+                                             full["mate_loop_ptr"], full["is_forward"])
+    return out
+
+
+def _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats, keep_entry_rows=False, mark_inputs=0, readmap=None):
     """The back half of a sharded build, shared with sharded_merge: per-rank record rows (already on the rank that owns
     their leading bases) -> sorted prefix-free entries -> cross-shard boundaries -> prev bits through the tails
     exchange -> 512-aligned slices (or, gather=True, one seqset assembled on rank 0).  recv[r] = a rows tensor or a list
@@ -1028,6 +1205,10 @@ def _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats, kee
     n_entries = sum(part_n)
     stats.update({"n_entries": n_entries, "max_len": max_len, "shard_entries": part_n})
     stats.update(extra_stats)
+    rm_cols = {}
+    if readmap is not None:  # (packed corrected reads per rank, paired): the sample's readmap while the keys are resident
+        rm_cols = sharded_readmap(comm, ctxs, shards, part_n, readmap[0], readmap[1], W, dev, ph)
+        stats["n_read_ids"] = rm_cols[ranks[0]].n_total
     entry_rows = {}
     if keep_entry_rows:  # the shard's entries as rows (W key words + length): what sharded_merge takes
         for r in ranks:
@@ -1043,6 +1224,7 @@ def _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats, kee
             shards[r].free()
             sl[r].entry_rows = entry_rows.get(r)
             sl[r].input_marks = (marks[r], sum(part_n[:r])) if mark_inputs else None
+            sl[r].readmap_columns = rm_cols.get(r)
             out[r] = (sl[r], stats)
         ph.done()
         return out
@@ -1076,6 +1258,9 @@ def _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats, kee
         h = C.c_void_p()
         capi.check(L.bg_seqset_assemble(ctxs[r].h, P, pn, _ptr(sz), _ptr(sh), _ptr(bt), max_len, C.byref(h)))
         out[r] = (bg.Seqset(ctxs[r], h), stats)
+        out[r][0].readmap_columns = rm_cols.get(r)
+    if rm_cols:
+        stats["readmap_columns"] = rm_cols  # gather=True: the other ranks have no seqset object to hang theirs on
     ph.done()
     return out
 

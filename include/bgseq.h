@@ -292,6 +292,45 @@ void bg_readmap_free(bg_readmap* rm);
 int bg_readmap_from_arrays(bg_ctx* ctx, uint64_t n_entries, uint32_t max_read_len, const char* seqset_uuid, uint64_t n_reads,
                            const uint64_t* d_entry_id, const uint32_t* d_read_len, const uint32_t* d_mate_loop_ptr,
                            const uint8_t* d_is_forward, bg_readmap** out);
+/* ---- Sharded readmap of one sample (csrc/readmap.hip; biograph_amd/sharded.py sharded_readmap): the entries are
+ * range-partitioned over the ranks (shard q = global entries [h_entry_offsets[q], h_entry_offsets[q+1]) with their keys
+ * resident), every rank holds some of the sample's pairs; make_readmap::create_from_reads (make_readmap.cpp:120-392) with
+ * one owner per structure.  Rows of u64 words on the device, routed by the host (RCCL all_to_all):
+ *   bg_seqset_find_rows            owner of a key range: global entry id of every read row it received (rows as
+ *                                  bg_oriented_rows makes them, routed with BG_PART_KEY_BOUNDS; ~0 for an empty row) --
+ *                                  seqset::find_existing_unique (seqset.cpp:173-188)
+ *   bg_readmap_rows                reader: the mate-loop rows (make_readmap.h:56-90) of its pairs from those entry ids,
+ *                                  3 words each: hi = entry:37|type:2|len:10|mate_len:10, lo = loop entry, destination
+ *                                  (owner of the row's entry) << 10: route with BG_PART_ROW_DEST
+ *   bg_readmap_shard_build         owner: sorts the rows it received (make_readmap.h:187-213); with the ranks in order
+ *                                  read id = rows on the ranks before (read_id_base) + position
+ *   bg_readmap_shard_first_claims / _apply_claims / _take_replies
+ *                                  the three claim hops of make_readmap.cpp:283-392 as 4-word claims (group key, read id
+ *                                  of the loop's start, read id of the claiming row, destination << 10): the owner of
+ *                                  the group gives its k-th claimer (in read-id order of the loop starts) the group's
+ *                                  k-th row, replies with that row's read id (one u64 per claim, in received order) and
+ *                                  writes the next hop's claims; the claimer's owner stores the reply as the claiming
+ *                                  row's loop pointer
+ *   bg_readmap_shard_columns       the shard's stretch of the per-read columns (global entry ids and read ids) for
+ *                                  bg_readmap_from_arrays */
+typedef struct bg_readmap_shard bg_readmap_shard;
+int bg_seqset_find_rows(bg_ctx* ctx, const bg_seqset* shard, const uint64_t* d_rows, uint64_t n, int W, uint64_t entry_base,
+                        uint64_t* d_entry);
+int bg_readmap_rows(bg_ctx* ctx, const bg_reads* reads, int is_paired, const uint64_t* d_entry /* 2 per read: forward, rc */,
+                    uint32_t nparts, const uint64_t* h_entry_offsets /* nparts + 1 */, uint64_t* d_rows /* cap x 3 */,
+                    uint64_t cap, uint64_t* n_out);
+int bg_readmap_shard_build(bg_ctx* ctx, const uint64_t* d_rows /* n x 3 */, uint64_t n, bg_readmap_shard** out);
+uint64_t bg_readmap_shard_size(const bg_readmap_shard* s);
+void bg_readmap_shard_free(bg_readmap_shard* s);
+int bg_readmap_shard_first_claims(bg_ctx* ctx, const bg_readmap_shard* s, uint64_t read_id_base, uint32_t nparts,
+                                  const uint64_t* h_entry_offsets, uint64_t* d_claims /* cap x 4 */, uint64_t cap, uint64_t* n_out);
+int bg_readmap_shard_apply_claims(bg_ctx* ctx, bg_readmap_shard* s, uint64_t read_id_base, int hop /* 1..3 */,
+                                  const uint64_t* d_claims /* n x 4 */, uint64_t n, uint32_t nparts, const uint64_t* h_entry_offsets,
+                                  uint64_t* d_reply /* n */, uint64_t* d_next /* n x 4 */, uint64_t* n_next);
+int bg_readmap_shard_take_replies(bg_ctx* ctx, bg_readmap_shard* s, uint64_t read_id_base, const uint64_t* d_claims_sent,
+                                  const uint64_t* d_reply, uint64_t n);
+int bg_readmap_shard_columns(bg_ctx* ctx, const bg_readmap_shard* s, uint64_t* d_entry_id, uint32_t* d_read_len,
+                             uint32_t* d_mate_loop_ptr, uint8_t* d_is_forward);
 /* Opens a readmap container (format 1.2.0 with the mate loop table) and keeps it resident. */
 int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out);
 /* Whole-array form of the per-read accessors (readmap.h:120-138): seqset entry of the read id
@@ -770,7 +809,7 @@ int bg_seqset_slice_build(bg_ctx* ctx, uint64_t m, const uint8_t* d_sizes, const
                           uint32_t max_len, bg_seqset** out);
 int bg_seqset_slice_popcounts(const bg_seqset* ss, uint64_t* h_out4);
 int bg_seqset_sharded_create_file(const char* path, uint64_t n_total, uint32_t max_len, const uint64_t* h_fixed5, int argc,
-                                  const char* const* argv, uint64_t* h_offsets);
+                                  const char* const* argv, uint64_t* h_offsets, char* h_uuid37 /* may be NULL: the uuid given to the seqset */);
 int bg_seqset_slice_write(bg_ctx* ctx, const bg_seqset* slice, const char* path, const uint64_t* h_offsets,
                           uint64_t first_entry, int is_last, const uint64_t* h_base_pop4);
 
