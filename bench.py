@@ -610,6 +610,7 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the `bgbinary create` from FASTQ files leg")
     ap.add_argument("--no-shared-arena", action="store_true",
                     help="sharded runs: keep torch's own caching allocator beside the library's arena")
+    ap.add_argument("--no-sharded-readmap", action="store_true", help="sharded runs: skip the untimed build-with-readmap leg")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the sharded (RCCL) build path even with one rank (smoke test of the collectives)")
     args = ap.parse_args()
@@ -718,6 +719,29 @@ def main():
     else:
         total_bases = float(n_bases)
 
+    sharded_rm = None
+    if (world > 1 or args.force_sharded) and not args.no_sharded_readmap:
+        # What `biograph create` ends with, outside the timed region: the same build once more with the sample's READMAP
+        # sharded like the seqset (routed entry look-ups, rows owned by their entry's rank, the claim hops as exchanged
+        # claims), then the ranks' columns put together on rank 0 (bg_readmap_from_arrays).
+        barrier()
+        t1 = time.perf_counter()
+        out = sharded.sharded_create(comm, {rank: ctx}, {rank: (seq, offs, n_reads)}, params, gather=False, readmap="paired")
+        sl, st_rm = out[rank]
+        barrier()
+        t2 = time.perf_counter()
+        cols = sl.readmap_columns
+        rm = sharded.gather_readmap(comm, {rank: ctx}, {rank: cols}, "bench")[rank]
+        barrier()
+        t3 = time.perf_counter()
+        sharded_rm = {"read_ids": int(cols.n_total), "entries": int(cols.n_entries), "entry_ids_need_bits": int(cols.n_entries).bit_length(),
+                      "build_with_readmap_ms": round((t2 - t1) * 1e3, 1), "seqset_only_ms": round(elapsed / max(args.steps, 1) * 1e3, 1),
+                      "gather_on_rank0_ms": round((t3 - t2) * 1e3, 1),
+                      "note": "untimed leg: one build with readmap='paired' (sharded_readmap), then gather_readmap on rank 0"}
+        if rm is not None:
+            rm.free()
+        sl.free()
+        del out, cols
     e2e = None
     if world == 1 and not args.force_sharded and not args.no_end_to_end:
         e2e = end_to_end_leg(seq, n_reads, args.read_len, dev, args, genome=None if args.no_discover else genome)
@@ -760,13 +784,16 @@ def main():
             "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(step_s * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "synthetic 30x %s-shaped 150 bp paired reads: seqset build (create data path)"
-                                   % args.shape,
+            "config": {"workload": "synthetic 30x %s 150 bp paired reads: seqset build (create data path)"
+                                   % (("%s-shaped" % args.shape) if not args.genome_len else
+                                      "%d-base genome (--genome-len; contig shape of '%s')" % (genome_len, args.shape)),
                        "genome_len_total": genome_len, "coverage": args.coverage, "read_len": args.read_len,
                        "reads_per_gpu": n_reads, "bases_per_gpu": n_bases, "kmer_size": 30, "min_kmer_count": 5,
-                       "parallelism": "1 GPU" if world == 1 else
-                       "%d GPUs, one sample sharded: all_to_all(k-mers, records, tails) + all_gather(kept k-mers, "
-                       "corrected reads) over RCCL" % world},
+                       "parallelism": "1 GPU (fused build)" if world == 1 and not args.force_sharded else
+                       "%d rank(s), ONE sample sharded, nothing replicated (routed mode): all_to_all over RCCL of super-k-mer "
+                       "records (+ presence bits back), correction probes (+ answers), oriented reads by leading bases, cover "
+                       "candidates per round (+ covered / keep bytes), entry tails (+ need-full bytes); all_gather only of "
+                       "shard boundaries and a few counters" % world},
             "roofline": roofline, "cpu_baseline": cpu,
             "device_memory": {"peak_live_GB": round(mem["peak"] / 1e9, 2), "cached_GB": round(mem["cached"] / 1e9, 2),
                               "torch_peak_GB": round(mem["torch_peak"] / 1e9, 2),
@@ -779,7 +806,7 @@ def main():
                                "achieved_GBps": round(alg / step_s / 1e9, 1),
                                "frac_of_hbm_peak": round(alg / step_s / 1e9 / (HBM_PEAK_GBS * world), 5),
                                "kernel_time_frac_of_wall": round(total_ms / 1e3 / elapsed, 3)},
-            "end_to_end_from_fastq": e2e, "discover": discover, "counters": stats, "kernels": kernels,
+            "end_to_end_from_fastq": e2e, "discover": discover, "sharded_readmap": sharded_rm, "counters": stats, "kernels": kernels,
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     ctx.close()

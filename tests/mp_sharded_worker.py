@@ -32,9 +32,11 @@ def main():
     out = sharded.sharded_create(comm, {rank: ctx}, {rank: (seq, offs, n)})
     ss, st = out[rank]
     # the same build again without the gather: every process writes its slice of one container in place
-    out2 = sharded.sharded_create(comm, {rank: ctx}, {rank: (seq, offs, n)}, gather=False)
+    # ... and the sample's readmap is built sharded too (routed look-ups, exchanged claims) and put together on rank 0
+    out2 = sharded.sharded_create(comm, {rank: ctx}, {rank: (seq, offs, n)}, gather=False, readmap="paired")
     sliced_path = out_path + ".seqset"
-    sharded.write_slices(comm, {rank: out2[rank][0]}, sliced_path, ["mp_sharded_worker"])
+    uuid = sharded.write_slices(comm, {rank: out2[rank][0]}, sliced_path, ["mp_sharded_worker"])
+    rm = sharded.gather_readmap(comm, {rank: ctx}, {rank: out2[rank][0].readmap_columns}, uuid)[rank]
     out2[rank][0].free()
     # every rank also ships its reads to rank 0 so the single-GPU build of the same sample can be compared
     gathered = [None] * world
@@ -49,7 +51,17 @@ def main():
         opened = ctx.open_seqset(sliced_path)
         same_sliced = all(opened.part(p) == ref.part(p) for p in bg.PART_NAMES)
         opened.free()
-        json.dump({"same": bool(same), "same_sliced": bool(same_sliced), "n_entries": ss.size(), "ref_entries": ref.size(), "stats": st,
+        # the single-GPU readmap of the same pairs in the same order (make_reads shards by whole pairs, rank after rank)
+        r_ = ctx.pack_reads_device(dseq.data_ptr(), doffs.data_ptr(), total)
+        prm = ctx.default_params()
+        ks = ctx.kmer_count(r_, prm.kmer_size, prm.min_kmer_count)
+        c_, _ = ctx.correct_reads(r_, ks)
+        ss1, _ = ctx.build_seqset(c_, prm.kmer_size)
+        rm1 = ctx.build_readmap(ss1, c_, True)
+        same_readmap = rm.size() == rm1.size() and all(rm.part(p) == rm1.part(p) for p in bg.READMAP_PART_NAMES)
+        for x in (rm1, ss1, c_, ks, r_, rm):
+            x.free()
+        json.dump({"same": bool(same), "same_sliced": bool(same_sliced), "same_readmap": bool(same_readmap), "n_entries": ss.size(), "ref_entries": ref.size(), "stats": st,
                    "shards": st["shard_entries"]}, open(out_path, "w"))
         ref.free()
         ss.free()

@@ -28,6 +28,7 @@ def test_multiprocess_sharded_build_matches_single_gpu(tmp_path, world, max_piec
     res = json.load(open(out))
     assert res["same"], res
     assert res["same_sliced"], res  # slices written in place by the processes open as the same seqset
+    assert res["same_readmap"], res  # the sharded readmap of the processes == the single-GPU readmap
     assert res["n_entries"] == res["ref_entries"] and len(res["shards"]) == world
 
 
@@ -45,7 +46,7 @@ def test_rccl_backend_world1_sharded_build(tmp_path, max_piece):
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     res = json.load(open(out))
-    assert res["same"] and res["same_sliced"], res
+    assert res["same"] and res["same_sliced"] and res["same_readmap"], res
     assert res["n_entries"] == res["ref_entries"] and len(res["shards"]) == 1
 
 
