@@ -61,6 +61,7 @@ bool canon_less(const bg_trace_assembly_rec& a, const bg_trace_assembly_rec& b) 
   const int64_t amax = std::max(a.left_offset, a.right_offset), bmax = std::max(b.left_offset, b.right_offset);
   if (amax != bmax) return amax > bmax;
   if (a.seq != b.seq) return a.seq < b.seq;
+  if (a.from_pop != b.from_pop) return a.from_pop;  // COMPARE(tags): {"POP"} < {"PUSH"}
   if (a.left_anchor_len != b.left_anchor_len) return a.left_anchor_len < b.left_anchor_len;
   if (a.right_anchor_len != b.right_anchor_len) return a.right_anchor_len < b.right_anchor_len;
   if (a.score != b.score) return a.score < b.score;
@@ -811,6 +812,7 @@ extern "C" int bg_trace_result_add(bg_trace_result* r, const bg_trace_assembly* 
   if (a->n_left_pair_matches) x.left_pair_matches.assign(a->left_pair_matches, a->left_pair_matches + a->n_left_pair_matches);
   if (a->n_right_pair_matches) x.right_pair_matches.assign(a->right_pair_matches, a->right_pair_matches + a->n_right_pair_matches);
   x.assembly_id = a->assembly_id ? a->assembly_id : allocate_assembly_id();  // assembly::assembly(), assemble.cpp:1248
+  x.from_pop = a->from_pop != 0;
   r->a.push_back(std::move(x));
   return BG_OK;
 }
@@ -965,5 +967,6 @@ extern "C" int bg_trace_result_get(const bg_trace_result* r, uint64_t i, bg_trac
   out->right_pair_matches = a.right_pair_matches.data();
   out->n_right_pair_matches = a.right_pair_matches.size();
   out->assembly_id = a.assembly_id;
+  out->from_pop = a.from_pop ? 1 : 0;
   return BG_OK;
 }

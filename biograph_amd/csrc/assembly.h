@@ -46,11 +46,22 @@ struct bg_trace_assembly_rec {  // variants::assembly (assemble.h:285-380), the 
   // assembly::assembly_id (assemble.h:295): one id per traced assembly, inherited by everything cut or copied from it
   // (split_assembly, the anchor_dropper's anchored copy); rvg_exclude groups sections by it
   uint64_t assembly_id = 0;
+  // assembly::tags (assemble.h:377): {"PUSH"} from the push tracer (tracer.cpp:1165,1237), {"POP"} from the pop tracer
+  // (pop_tracer.cpp:618); nothing downstream merges them.  As string sets {"POP"} < {"PUSH"} (canon_assembly_order).
+  bool from_pop = false;
+  // set by the push tracer on an assembly that ends in an anchor drop (rejoin::anchor_drop, tracer.cpp:1199-1203)
+  bool anchor_drop = false;
+};
+
+struct bg_anchor_drop_rec {  // what tracer::output_assembly hands to report_anchor_drop_func (tracer.cpp:1233-1235),
+  bg_trace_assembly_rec a;    // in FORWARD coordinates (reversable_tracer.cpp:28-35), rc_read_ids still on board
+  bool right_anchor = false;
 };
 
 struct bg_trace_result {
   std::vector<bg_trace_assembly_rec> a;
   bg_trace_stats stats;
+  std::vector<bg_anchor_drop_rec> anchor_drops;  // bg_tracer_trace -> bg_pop_trace
 };
 
 namespace bg {

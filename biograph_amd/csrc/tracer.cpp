@@ -87,6 +87,9 @@ extern "C" void bg_trace_options_default(bg_trace_options* o) {
   o->anchor_drop = 1;                    // reversable_tracer.cpp:124-125 always has the step
   o->max_anchor_kmer_size = 31;          // anchor_dropper::g_max_kmer_size (anchor_drop.cpp:9)
   o->output_ml_features = 0;             // assemble.h:730
+  o->min_pop_overlap = 15;               // assemble.h:523
+  o->pop_tracer_offset_slop = 1000;      // assemble.h:527
+  o->min_pair_distance = 100;            // assemble.h:588
 }
 
 namespace {
@@ -136,7 +139,7 @@ std::string rev_comp_str(const std::string& s) {
 namespace {
 
 struct HostTables {
-  std::vector<uint8_t> sizes, ref_map, is_forward;
+  std::vector<uint8_t> sizes, ref_map, is_forward, read_len;
   std::vector<uint32_t> mate_loop, word_rank, group_start;  // read ids are 32-bit (readmap.h), entry ids are not
   std::vector<uint64_t> has_reads;
 };
@@ -549,6 +552,7 @@ struct Trace {
     a.left_offset = int64_t(cur_offset) - int64_t(left_anchor.size());
     a.left_anchor_len = int(left_anchor.size());
     if (r.anchor_drop) {
+      a.anchor_drop = true;
       a.right_offset = int32_t(cur_offset + seq.size() * o().anchor_drop_size_multiplier);
       a.right_anchor_len = 0;
       a.score += o().anchor_drop_score;
@@ -1040,6 +1044,23 @@ struct PairCounter {
   }
 };
 
+// reverse_assembly_in_place (assemble.cpp:933-984): with_read_ids for an assembly that still carries its rc_read_ids
+// (an anchor drop on its way to the pop tracer; pair_counter has emptied them in everything it lets out)
+void reverse_rec(const World& w, bg_trace_assembly_rec* a, int64_t end_pos, bool with_read_ids) {
+  a->seq = rev_comp_str(a->seq);
+  std::swap(a->left_anchor_len, a->right_anchor_len);
+  const int64_t lo = a->left_offset, ro = a->right_offset;
+  a->left_offset = end_pos - ro;
+  a->right_offset = end_pos - lo;
+  std::swap(a->left_pair_matches, a->right_pair_matches);
+  for (auto* m : {&a->left_pair_matches, &a->right_pair_matches})
+    for (uint32_t& rid : *m) rid = w.get_rev_comp(rid);
+  if (with_read_ids) {
+    for (uint32_t& rid : a->rc_read_ids) rid = w.get_rev_comp(rid);
+    std::sort(a->rc_read_ids.begin(), a->rc_read_ids.end());  // read_id_set: ascending
+  }
+}
+
 }  // namespace
 
 // reversable_tracer::assemble(start, limit) (reversable_tracer.cpp:76-145) with the push tracer.
@@ -1092,6 +1113,9 @@ extern "C" int bg_tracer_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap
     BG_TRY(download(ctx, tmp, rm->is_forward.p, rm->n_reads));
     h->is_forward.resize(rm->n_reads);
     for (size_t i = 0; i < tmp.size(); ++i) h->is_forward[i] = uint8_t(tmp[i] & 1);
+    BG_TRY(download(ctx, tmp, rm->read_len.p, rm->n_reads));  // readmap::get_readlength: the pop tracer's limits
+    h->read_len.resize(rm->n_reads);
+    for (size_t i = 0; i < tmp.size(); ++i) h->read_len[i] = uint8_t(tmp[i]);
     w.tables = h;
   }
   w.bind_tables();
@@ -1180,6 +1204,19 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
   }
   const std::vector<Extent>& run_ext = rev_comp ? rc : ext;
   const double s_chunk = now_seconds() - t_chunk;
+  // report_anchor_drop_func (tracer.cpp:1233-1235 through reversable_tracer.cpp:28-35): the raw assemblies that end in an
+  // anchor drop, in output order, turned into forward coordinates with their read ids -- kept for bg_pop_trace
+  for (const auto& a : raw) {
+    if (!a.anchor_drop) continue;
+    bg_anchor_drop_rec d;
+    d.a = a;
+    d.right_anchor = false;
+    if (rev_comp) {
+      reverse_rec(w, &d.a, end_pos, true);
+      d.right_anchor = true;
+    }
+    res->anchor_drops.push_back(std::move(d));
+  }
   const double t_drop = now_seconds();
   if (w.o.anchor_drop) {  // anchor_dropper over the scaffold the tracer ran on (reversable_tracer.cpp:124-133)
     ScaffoldView sc;
@@ -1207,18 +1244,8 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
   } else {
     counted = std::move(raw);
   }
-  if (rev_comp) {  // reverse_assembly_in_place (assemble.cpp:933-960)
-    for (auto& a : counted) {
-      a.seq = rev_comp_str(a.seq);
-      std::swap(a.left_anchor_len, a.right_anchor_len);
-      const int64_t lo = a.left_offset, ro = a.right_offset;
-      a.left_offset = end_pos - ro;
-      a.right_offset = end_pos - lo;
-      std::swap(a.left_pair_matches, a.right_pair_matches);
-      for (auto* m : {&a.left_pair_matches, &a.right_pair_matches})
-        for (uint32_t& rid : *m) rid = w.get_rev_comp(rid);
-    }
-  }
+  if (rev_comp)
+    for (auto& a : counted) reverse_rec(w, &a, end_pos, false);
   const double s_pair = now_seconds() - t_pair;
   res->a = std::move(counted);
   res->stats = w.stats;
@@ -1244,4 +1271,611 @@ extern "C" int bg_push_trace(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap*
                                  pair_count, out);
   bg_tracer_close(t);
   return rc;
+}
+
+// =====================================================================================================================
+// The pop tracer (variants/pop_tracer.cpp:55-653) behind reversable_tracer's direction wrapper
+// (reversable_tracer.cpp:49-74,118-126), one work item per call as trace_ref::execute_work runs it (trace_ref.cpp:141-221).
+// Host state machine over batched device walks: everything the reference asks of the seqset / readmap entry by entry is
+// collected per phase and answered by one launch --
+//   * add_reference: the push_front_drop chain along the (reverse-complemented) scaffold in 1024-base chains with a
+//     max_read_len warm-up (bg_walk_chains_batch, as bg_ref_walk_entries does for the push tracer), then ONE
+//     get_prefix_reads for all the ranges add_reference_at keeps, ONE get_seqset_entry for all their mates, ONE
+//     get_prefix_reads for those;
+//   * a pop pass: ONE pop_front for all poppers, ONE get_prefix_reads for the survivors.
+// m_fronts only ever grows before assemble() and shrinks during it, so it is a vector sorted once (by key, equal keys in
+// insertion order: std::multimap::emplace) with an erased flag; the popper heap and the two sorts are libstdc++'s own
+// (std::push_heap / pop_heap / make_heap, std::sort), as in the reference's binary.
+namespace {
+
+inline unsigned code_of(char c) { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : 3u; }
+
+struct PopEntry {  // pop_tracer::entry (pop_tracer.h:58-84)
+  bool has_left = false, has_right = false;
+  int64_t left_offset = 0, right_offset = 0, start_limit = 0, end_limit = 0;
+  TRange orig_r, popped_r;
+  std::string seq;
+  std::vector<uint32_t> seen_read_ids;
+};
+
+struct PopTracer {
+  World& w;
+  bg_ctx* ctx;
+  const std::vector<Extent>& sc;  // the scaffold in the direction this pop tracer runs
+  int64_t end_pos;
+  std::deque<PopEntry> store;     // stable addresses
+  struct Front { uint64_t b; uint32_t s; uint32_t seq; PopEntry* e; bool erased; };
+  std::vector<Front> fronts;      // insertion order until sort_fronts()
+  std::vector<PopEntry*> poppers;
+  std::vector<bg_trace_assembly_rec> out;
+  uint64_t device_rounds = 0, device_queries = 0;
+
+  static bool popper_less(const PopEntry* a, const PopEntry* b) { return a->popped_r.s < b->popped_r.s; }  // :285-290
+
+  // ---- device batches (host vectors in and out)
+  int prefix_reads(const std::vector<TRange>& r, uint32_t cap, std::vector<uint32_t>* ids, std::vector<uint32_t>* count) {
+    const size_t n = r.size();
+    ids->assign(n * cap, 0);
+    count->assign(n, 0);
+    if (!n) return BG_OK;
+    std::vector<uint64_t> hb(n), he(n);
+    std::vector<uint32_t> hs(n);
+    for (size_t i = 0; i < n; ++i) { hb[i] = r[i].b; he[i] = r[i].e; hs[i] = r[i].s; }
+    DevBuf<uint64_t> db, de;
+    DevBuf<uint32_t> ds, di, dc;
+    BG_TRY(db.alloc(ctx, n)); BG_TRY(de.alloc(ctx, n)); BG_TRY(ds.alloc(ctx, n)); BG_TRY(di.alloc(ctx, n * cap)); BG_TRY(dc.alloc(ctx, n));
+    BG_TRY(copy_sync(ctx, db.p, hb.data(), n * 8, hipMemcpyHostToDevice));
+    BG_TRY(copy_sync(ctx, de.p, he.data(), n * 8, hipMemcpyHostToDevice));
+    BG_TRY(copy_sync(ctx, ds.p, hs.data(), n * 4, hipMemcpyHostToDevice));
+    BG_TRY(bg_prefix_reads_batch(ctx, w.ss, w.rm, n, db.p, de.p, ds.p, int(w.o.min_overlap), cap, di.p, dc.p));
+    BG_TRY(copy_sync(ctx, ids->data(), di.p, n * cap * 4, hipMemcpyDeviceToHost));
+    BG_TRY(copy_sync(ctx, count->data(), dc.p, n * 4, hipMemcpyDeviceToHost));
+    ++device_rounds;
+    device_queries += n;
+    return BG_OK;
+  }
+  int read_entries(const std::vector<uint32_t>& ids, std::vector<TRange>* r) {  // readmap::read::get_seqset_entry
+    const size_t n = ids.size();
+    r->assign(n, TRange());
+    if (!n) return BG_OK;
+    DevBuf<uint32_t> di, dm, drc, ds;
+    DevBuf<uint8_t> dh;
+    DevBuf<uint64_t> db, de;
+    BG_TRY(di.alloc(ctx, n)); BG_TRY(dm.alloc(ctx, n)); BG_TRY(drc.alloc(ctx, n)); BG_TRY(ds.alloc(ctx, n)); BG_TRY(dh.alloc(ctx, n));
+    BG_TRY(db.alloc(ctx, n)); BG_TRY(de.alloc(ctx, n));
+    BG_TRY(copy_sync(ctx, di.p, ids.data(), n * 4, hipMemcpyHostToDevice));
+    BG_TRY(bg_read_info_batch(ctx, w.ss, w.rm, n, di.p, dh.p, dm.p, drc.p, db.p, de.p, ds.p));
+    std::vector<uint64_t> hb(n), he(n);
+    std::vector<uint32_t> hs(n);
+    BG_TRY(copy_sync(ctx, hb.data(), db.p, n * 8, hipMemcpyDeviceToHost));
+    BG_TRY(copy_sync(ctx, he.data(), de.p, n * 8, hipMemcpyDeviceToHost));
+    BG_TRY(copy_sync(ctx, hs.data(), ds.p, n * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) (*r)[i] = TRange{hb[i], he[i], hs[i]};
+    ++device_rounds;
+    device_queries += n;
+    return BG_OK;
+  }
+  int pop_fronts(const std::vector<TRange>& r, std::vector<TRange>* o) {
+    const size_t n = r.size();
+    o->assign(n, TRange());
+    if (!n) return BG_OK;
+    std::vector<uint64_t> hb(n), he(n);
+    std::vector<uint32_t> hs(n);
+    for (size_t i = 0; i < n; ++i) { hb[i] = r[i].b; he[i] = r[i].e; hs[i] = r[i].s; }
+    DevBuf<uint64_t> db, de, ob, oe;
+    DevBuf<uint32_t> ds, os;
+    BG_TRY(db.alloc(ctx, n)); BG_TRY(de.alloc(ctx, n)); BG_TRY(ds.alloc(ctx, n)); BG_TRY(ob.alloc(ctx, n)); BG_TRY(oe.alloc(ctx, n)); BG_TRY(os.alloc(ctx, n));
+    BG_TRY(copy_sync(ctx, db.p, hb.data(), n * 8, hipMemcpyHostToDevice));
+    BG_TRY(copy_sync(ctx, de.p, he.data(), n * 8, hipMemcpyHostToDevice));
+    BG_TRY(copy_sync(ctx, ds.p, hs.data(), n * 4, hipMemcpyHostToDevice));
+    BG_TRY(bg_pop_front_batch(ctx, w.ss, n, db.p, de.p, ds.p, ob.p, oe.p, os.p));
+    BG_TRY(copy_sync(ctx, hb.data(), ob.p, n * 8, hipMemcpyDeviceToHost));
+    BG_TRY(copy_sync(ctx, he.data(), oe.p, n * 8, hipMemcpyDeviceToHost));
+    BG_TRY(copy_sync(ctx, hs.data(), os.p, n * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) (*o)[i] = TRange{hb[i], he[i], hs[i]};
+    ++device_rounds;
+    device_queries += n;
+    return BG_OK;
+  }
+
+  char front_base(const TRange& r) const {  // seqset_range::front (seqset.cpp:663): the block of `fixed` begin lies in
+    for (int b = 3; b > 0; --b)
+      if (r.b >= w.ss->fixed[b]) return "ACGT"[b];
+    return 'A';
+  }
+
+  // add_entry_reads (:458-467) from the answer of one prefix_reads query
+  void take_entry_reads(PopEntry* p, const uint32_t* ids, uint32_t count, uint32_t cap) const {
+    const uint32_t n = std::min<uint32_t>(std::min(count, cap), uint32_t(w.o.max_pairs_per_read));
+    for (uint32_t i = 0; i < n; ++i) p->seen_read_ids.push_back(w.get_rev_comp(ids[i]));
+  }
+
+  // ---- the reads that become fronts are collected first (their entries and their prefix reads come from two launches)
+  struct PendingRead { uint32_t read_id; int64_t start, limit; };
+
+  // the fronts a list of items adds, in the reference's insertion order: item = one add_read, or an entry that exists
+  struct Item { PopEntry* ready; PendingRead rd; };
+  int materialize(std::vector<Item>& items) {
+    std::vector<uint32_t> ids;
+    for (auto& it : items) if (!it.ready) ids.push_back(it.rd.read_id);
+    std::vector<TRange> ranges;
+    BG_TRY(read_entries(ids, &ranges));
+    const uint32_t cap = uint32_t(std::max<uint64_t>(1, w.o.max_pairs_per_read));
+    std::vector<uint32_t> pid, pcount;
+    BG_TRY(prefix_reads(ranges, cap, &pid, &pcount));
+    size_t k = 0;
+    for (auto& it : items) {
+      PopEntry* e = it.ready;
+      if (!e) {  // add_read (:76-95)
+        store.emplace_back();
+        e = &store.back();
+        e->start_limit = it.rd.start;
+        e->end_limit = it.rd.limit;
+        e->orig_r = e->popped_r = ranges[k];
+        take_entry_reads(e, &pid[k * cap], pcount[k], cap);
+        ++k;
+      }
+      fronts.push_back(Front{e->orig_r.b, e->orig_r.s, uint32_t(fronts.size()), e, false});
+    }
+    return BG_OK;
+  }
+
+  // ---- add_anchor_drop (:208-283) for all drops of the work item
+  int add_anchor_drops(const std::vector<const bg_anchor_drop_rec*>& drops, bool rev_comp) {
+    if (drops.empty()) return BG_OK;
+    // orientation of this pop tracer (wrap_report_anchor_drop_for_pop_tracer, reversable_tracer.cpp:55-73)
+    std::vector<bg_trace_assembly_rec> as;
+    std::vector<bool> right;
+    for (const bg_anchor_drop_rec* d : drops) {
+      as.push_back(d->a);
+      right.push_back(d->right_anchor);
+      if (rev_comp) {
+        reverse_rec(w, &as.back(), end_pos, true);
+        right.back() = !d->right_anchor;
+      }
+    }
+    const size_t n = as.size();
+    // orig_r: push_front_drop of the assembly's bases, last base first (one chain each); popped_r of a left-anchored
+    // drop: push_front of the same bases for as long as an entry is left
+    std::vector<bg_walk_chain> chains(n);
+    std::vector<uint8_t> codes;
+    std::vector<uint64_t> offs(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) {
+      const std::string& s = as[i].seq;
+      chains[i].begin = 0; chains[i].end = w.n_entries; chains[i].size = 0;
+      chains[i].code_offset = codes.size();
+      chains[i].len = uint32_t(s.size());
+      chains[i].out_offset = uint64_t(i) * 3;
+      chains[i].out_stride = 0;  // every step overwrites the same three words: the last one stays
+      // k_walk_chains pushes the COMPLEMENT of the code it is given: codes = the reverse complement of the sequence
+      for (size_t j = s.size(); j-- > 0;) codes.push_back(uint8_t(3 - code_of(s[j])));
+      offs[i + 1] = codes.size();
+    }
+    std::vector<uint64_t> orig(n * 3, 0), popped(n * 3, 0);
+    // out_stride 0 is not what bg_walk_chains_batch promises (>= 3): give every chain a private strip instead
+    uint64_t words = 0;
+    for (size_t i = 0; i < n; ++i) { chains[i].out_offset = words; chains[i].out_stride = 3; words += uint64_t(chains[i].len) * 3; }
+    std::vector<uint64_t> strip(words ? words : 1, 0);
+    BG_TRY(bg_walk_chains_batch(ctx, w.ss, uint32_t(n), chains.data(), codes.data(), codes.size(), strip.data(), words));
+    for (size_t i = 0; i < n; ++i) {
+      if (chains[i].len) memcpy(&orig[i * 3], &strip[chains[i].out_offset + uint64_t(chains[i].len - 1) * 3], 24);
+      else { orig[i * 3] = 0; orig[i * 3 + 1] = w.n_entries; orig[i * 3 + 2] = 0; }
+    }
+    // push_front takes the base itself: the sequence backwards
+    std::vector<uint8_t> fcodes;
+    for (size_t i = 0; i < n; ++i) {
+      const std::string& s = as[i].seq;
+      offs[i] = fcodes.size();
+      for (size_t j = s.size(); j-- > 0;) fcodes.push_back(uint8_t(code_of(s[j])));
+    }
+    offs[n] = fcodes.size();
+    BG_TRY(bg_push_front_chains(ctx, w.ss, uint32_t(n), offs.data(), fcodes.data(), popped.data()));
+    device_rounds += 2;
+    device_queries += 2 * n;
+    std::vector<Item> items;
+    std::vector<PopEntry*> new_poppers;
+    for (size_t i = 0; i < n; ++i) {
+      const bg_trace_assembly_rec& a = as[i];
+      const bool right_anchor = right[i];
+      const int64_t offset = right_anchor ? a.right_offset : a.left_offset, len = int64_t(a.seq.size());
+      for (uint32_t rc_read_id : a.rc_read_ids) {  // mates of the assembly's reads (:216-238)
+        if (!w.has_mate(rc_read_id)) continue;
+        int64_t start_offset = offset - len, limit_offset = offset + len;
+        if (right_anchor) start_offset -= len; else limit_offset += len;
+        const int64_t size = w.tables->read_len[rc_read_id];
+        if (bool(w.is_forward[rc_read_id]) == (w.o.forward_pairs_face_inward != 0)) start_offset -= size + int64_t(w.o.max_pair_distance);
+        else limit_offset += size + int64_t(w.o.max_pair_distance);
+        items.push_back(Item{nullptr, PendingRead{w.get_mate(rc_read_id), start_offset, limit_offset}});
+      }
+      store.emplace_back();
+      PopEntry* e = &store.back();
+      e->start_limit = offset - (len + int64_t(w.o.max_pair_distance));
+      e->end_limit = offset + (len + int64_t(w.o.max_pair_distance));
+      e->orig_r = TRange{orig[i * 3], orig[i * 3 + 1], uint32_t(orig[i * 3 + 2])};
+      if (e->orig_r.b >= e->orig_r.e) return fail("bg_pop_trace: an anchor drop's sequence is not in the seqset");
+      if (right_anchor) {
+        e->has_right = true;
+        e->right_offset = a.right_offset;
+        e->popped_r = TRange{0, w.n_entries, 0};
+        e->seq = a.seq;
+      } else {
+        e->has_left = true;
+        e->left_offset = a.left_offset;
+        e->popped_r = TRange{popped[i * 3], popped[i * 3 + 1], uint32_t(popped[i * 3 + 2])};
+        if (int64_t(e->popped_r.s) > len) return fail("bg_pop_trace: popped range longer than the assembly");
+        e->seq = a.seq.substr(0, size_t(len - int64_t(e->popped_r.s)));
+        new_poppers.push_back(e);
+      }
+      items.push_back(Item{e, PendingRead{0, 0, 0}});
+    }
+    BG_TRY(materialize(items));
+    for (PopEntry* p : new_poppers) add_popper(p);
+    return BG_OK;
+  }
+
+  void add_popper(PopEntry* p) {  // :447-456
+    poppers.push_back(p);
+    std::push_heap(poppers.begin(), poppers.end(), popper_less);
+  }
+
+  // ---- add_reference (:162-206) with add_reference_at (:97-160)
+  int add_reference(int64_t start, int64_t limit) {
+    // the scaffold reversed: entries face right while push_front_drop runs through it (:167-169)
+    std::vector<Extent> rc;
+    for (auto it = sc.rbegin(); it != sc.rend(); ++it) rc.push_back(Extent{end_pos - it->offset - int64_t(it->seq.size()), rev_comp_str(it->seq)});
+    const int64_t scaffold_end = end_pos;
+    const int64_t skip_pos = scaffold_end - limit - int64_t(w.rm->max_read_len);
+    // positions walked, per extent: [first, last) indices into the extent; the walk of an extent starts from the empty
+    // context (first_in_extent) -- or, where skip_to lands inside an extent, from wherever the iterator stands with the
+    // range still empty (r = ctx_begin before the loop)
+    struct Piece { size_t ext; int64_t first, count; };
+    std::vector<Piece> pieces;
+    std::vector<bg_walk_chain> chains;
+    std::vector<uint8_t> codes;
+    uint64_t words = 0;
+    const int64_t chain_len = 1024, warm = int64_t(w.ss->max_len) + 1;
+    bool stopped = false;
+    for (size_t x = 0; x < rc.size() && !stopped; ++x) {
+      const Extent& e = rc[x];
+      const int64_t n = int64_t(e.seq.size());
+      int64_t first = 0;
+      if (skip_pos > e.offset) {
+        if (skip_pos >= e.offset + n) continue;  // skip_to passes the whole extent
+        first = skip_pos - e.offset;
+      }
+      // the loop runs while offset >= start, offset = scaffold_end - it.offset() before the step
+      int64_t last = n;
+      const int64_t max_pos = scaffold_end - start;  // it.offset() <= this
+      if (e.offset + first > max_pos) { stopped = true; break; }
+      if (e.offset + last - 1 > max_pos) { last = max_pos - e.offset + 1; stopped = true; }
+      if (last <= first) continue;
+      pieces.push_back(Piece{x, first, last - first});
+      const size_t code0 = codes.size();
+      for (int64_t j = first; j < last; ++j) codes.push_back(uint8_t(code_of(e.seq[size_t(j)])));
+      // chains of chain_len positions; a chain that does not start the piece warms up over the `warm` bases before it
+      for (int64_t c0 = 0; c0 < last - first; c0 += chain_len) {
+        const int64_t c1 = std::min<int64_t>(c0 + chain_len, last - first);
+        const int64_t w0 = std::max<int64_t>(0, c0 - warm);
+        bg_walk_chain ch;
+        ch.begin = 0; ch.end = w.n_entries; ch.size = 0;
+        ch.code_offset = code0 + uint64_t(w0);
+        ch.len = uint32_t(c1 - w0);
+        ch.out_stride = 3;
+        // the chain's strip starts `c0 - w0` steps before the part that is kept: point it so that step (c0 - w0) lands at
+        // position c0 of the piece's output; the warm-up steps then fall on the tail of the chain before (written first
+        // or last, they hold values nobody reads: every chain's kept part is written by that chain alone ... they are
+        // NOT, so every chain gets a private strip and the kept part is copied)
+        ch.out_offset = words;
+        words += uint64_t(ch.len) * 3;
+        chains.push_back(ch);
+      }
+    }
+    std::vector<uint64_t> strip(words ? words : 1, 0);
+    if (!chains.empty()) {
+      BG_TRY(bg_walk_chains_batch(ctx, w.ss, uint32_t(chains.size()), chains.data(), codes.data(), codes.size(), strip.data(), words));
+      ++device_rounds;
+      device_queries += codes.size();
+    }
+    // replay the loop of :180-199 over the ranges
+    std::vector<std::pair<int64_t, TRange>> refs;  // add_reference_at(offset, r) in call order
+    size_t ci = 0;
+    TRange r{0, w.n_entries, 0};
+    int64_t offset = scaffold_end - (rc.empty() ? scaffold_end : rc[0].offset);
+    {
+      // offset before the loop: scaffold_end - next_it.offset() after the optional skip_to
+      int64_t it_off = scaffold_end;
+      if (!pieces.empty()) it_off = rc[pieces[0].ext].offset + pieces[0].first;
+      else if (!rc.empty() && skip_pos <= rc[0].offset) it_off = rc[0].offset;
+      else {  // skip_to ran off the walked part: where the iterator stands decides nothing but the last add_reference_at
+        it_off = scaffold_end;
+        for (const Extent& e : rc) {
+          if (skip_pos < e.offset + int64_t(e.seq.size())) { it_off = std::max<int64_t>(skip_pos, e.offset); break; }
+        }
+      }
+      offset = scaffold_end - it_off;
+    }
+    for (const Piece& pc : pieces) {
+      const Extent& e = rc[pc.ext];
+      for (int64_t c0 = 0; c0 < pc.count; c0 += chain_len, ++ci) {
+        const int64_t c1 = std::min<int64_t>(c0 + chain_len, pc.count);
+        const int64_t w0 = std::max<int64_t>(0, c0 - warm);
+        const uint64_t* o = &strip[chains[ci].out_offset + uint64_t(c0 - w0) * 3];
+        for (int64_t j = c0; j < c1; ++j, o += 3) {
+          const int64_t pos = pc.first + j;          // index in the extent
+          const bool first_in_extent = pos == 0;
+          if (first_in_extent) {
+            refs.emplace_back(offset, r);
+            r = TRange{0, w.n_entries, 0};
+          }
+          const TRange next{o[0], o[1], uint32_t(o[2])};
+          if (next.b >= next.e) return fail("bg_pop_trace: a reference base is missing from the seqset");
+          if (next.s <= r.s) refs.emplace_back(offset, r);
+          r = next;
+          if (first_in_extent) offset = scaffold_end - (e.offset + pos) - 1;
+          else --offset;
+        }
+      }
+    }
+    refs.emplace_back(offset, r);
+    // add_reference_at for all of them: ranges shorter than min_pop_overlap add nothing
+    std::vector<std::pair<int64_t, TRange>> kept;
+    for (auto& x : refs)
+      if (x.second.s >= w.o.min_pop_overlap) kept.push_back(x);
+    std::vector<TRange> ranges;
+    for (auto& x : kept) ranges.push_back(x.second);
+    // their prefix reads: the first max_pairs_per_read feed add_entry_reads, the first max_pairs_per_read WITH a mate
+    // supply the mates; a range with more reads than the buffer holds and too few mates among them is asked again
+    uint32_t cap = uint32_t(std::max<uint64_t>(w.o.max_pairs_per_read, 1)) * 2;
+    std::vector<uint32_t> pid, pcount;
+    BG_TRY(prefix_reads(ranges, cap, &pid, &pcount));
+    std::vector<std::vector<uint32_t>> wide(ranges.size());
+    {
+      std::vector<size_t> again;
+      for (size_t i = 0; i < ranges.size(); ++i) {
+        if (pcount[i] <= cap) continue;
+        uint32_t mated = 0;
+        for (uint32_t j = 0; j < cap; ++j) mated += w.has_mate(pid[i * cap + j]) ? 1u : 0u;
+        if (mated <= w.o.max_pairs_per_read) again.push_back(i);
+      }
+      uint32_t big = cap;
+      while (!again.empty()) {
+        big *= 8;
+        std::vector<TRange> rr;
+        for (size_t i : again) rr.push_back(ranges[i]);
+        std::vector<uint32_t> id2, c2;
+        BG_TRY(prefix_reads(rr, big, &id2, &c2));
+        std::vector<size_t> still;
+        for (size_t k = 0; k < again.size(); ++k) {
+          const size_t i = again[k];
+          const uint32_t have = std::min(c2[k], big);
+          uint32_t mated = 0;
+          for (uint32_t j = 0; j < have; ++j) mated += w.has_mate(id2[k * big + j]) ? 1u : 0u;
+          if (c2[k] > big && mated <= w.o.max_pairs_per_read) { still.push_back(i); continue; }
+          wide[i].assign(id2.begin() + long(k * big), id2.begin() + long(k * big + have));
+        }
+        again.swap(still);
+      }
+    }
+    std::vector<Item> items;
+    for (size_t i = 0; i < kept.size(); ++i) {
+      const int64_t off = kept[i].first;
+      store.emplace_back();
+      PopEntry* e = &store.back();
+      e->has_left = true;
+      e->left_offset = off;
+      e->start_limit = e->end_limit = off;
+      e->orig_r = e->popped_r = kept[i].second;
+      const uint32_t* ids = wide[i].empty() ? &pid[i * cap] : wide[i].data();
+      const uint32_t have = wide[i].empty() ? std::min(pcount[i], cap) : uint32_t(wide[i].size());
+      take_entry_reads(e, ids, have, have);
+      items.push_back(Item{e, PendingRead{0, 0, 0}});
+      unsigned read_count = 0;
+      for (uint32_t j = 0; j < have; ++j) {  // :121-159
+        const uint32_t rid = ids[j];
+        if (!w.has_mate(rid)) continue;
+        if (++read_count > w.o.max_pairs_per_read) break;
+        const int64_t size = w.tables->read_len[rid];
+        if (size < int64_t(w.o.min_pop_overlap)) continue;
+        int64_t start_offset = off, limit_offset = off;
+        if (bool(w.is_forward[rid]) == (w.o.forward_pairs_face_inward != 0)) {  // faces inward
+          start_offset += size + w.o.min_pair_distance;
+          limit_offset += size + int64_t(w.o.max_pair_distance);
+        } else {  // faces outwards
+          start_offset -= size + int64_t(w.o.max_pair_distance);
+          limit_offset -= size + w.o.min_pair_distance;
+        }
+        items.push_back(Item{nullptr, PendingRead{w.get_rev_comp(w.get_mate(rid)), start_offset, limit_offset}});
+      }
+    }
+    return materialize(items);
+  }
+
+  void sort_fronts() {  // std::multimap<seqset_range, ..., seqset_range_comparer>: (begin, size), equal keys in insertion order
+    std::stable_sort(fronts.begin(), fronts.end(), [](const Front& a, const Front& b) { return a.b != b.b ? a.b < b.b : a.s < b.s; });
+  }
+
+  // ---- assemble (:292-311)
+  int assemble() {
+    sort_fronts();
+    std::make_heap(poppers.begin(), poppers.end(), popper_less);
+    match_and_output_pass();
+    while (!poppers.empty()) {
+      BG_TRY(pop_pass());
+      match_and_output_pass();
+    }
+    return BG_OK;
+  }
+
+  int pop_pass() {  // :364-445
+    std::vector<PopEntry*> old;
+    old.swap(poppers);
+    std::vector<PopEntry*> order;
+    while (!old.empty()) {
+      std::pop_heap(old.begin(), old.end(), popper_less);
+      order.push_back(old.back());
+      old.pop_back();
+    }
+    std::vector<TRange> in;
+    for (PopEntry* p : order) {
+      if (p->has_right) return fail("bg_pop_trace: a popper that is aligned on the right is popped again");
+      in.push_back(p->popped_r);
+    }
+    std::vector<TRange> popped;
+    BG_TRY(pop_fronts(in, &popped));
+    std::vector<PopEntry*> alive;
+    std::vector<TRange> ranges;
+    for (size_t i = 0; i < order.size(); ++i) {
+      if (popped[i].s < w.o.min_pop_overlap) continue;  // popped too much: discarded
+      PopEntry* p = order[i];
+      p->seq.push_back(front_base(p->popped_r));
+      p->popped_r = popped[i];
+      alive.push_back(p);
+      ranges.push_back(popped[i]);
+    }
+    const uint32_t cap = uint32_t(std::max<uint64_t>(1, w.o.max_pairs_per_read));
+    std::vector<uint32_t> pid, pcount;
+    BG_TRY(prefix_reads(ranges, cap, &pid, &pcount));
+    for (size_t i = 0; i < alive.size(); ++i) {
+      take_entry_reads(alive[i], &pid[i * cap], pcount[i], cap);
+      alive[i]->end_limit++;
+      add_popper(alive[i]);
+    }
+    return BG_OK;
+  }
+
+  void match_and_output_pass() {  // :469-613
+    std::vector<PopEntry*> old;
+    old.swap(poppers);
+    const int64_t slop = int64_t(w.o.pop_tracer_offset_slop);
+    for (PopEntry* p : old) {
+      std::vector<Front*> matches;
+      const auto key_less = [](const Front& f, const TRange& r) { return f.b != r.b ? f.b < r.b : f.s < r.s; };
+      for (auto it = std::lower_bound(fronts.begin(), fronts.end(), p->popped_r, key_less);
+           it != fronts.end() && it->e->orig_r.b < p->popped_r.e; ++it) {
+        if (it->erased) continue;
+        const PopEntry& front = *it->e;
+        if (&front == p) continue;                         // no loops
+        if (front.orig_r.e > p->popped_r.e) continue;      // not a prefix
+        const int64_t plen = int64_t(p->seq.size());
+        if (p->end_limit + (plen + slop) < front.start_limit) continue;  // out of range (1)
+        if (front.end_limit + (plen + slop) < p->start_limit) continue;  // out of range (2)
+        if (front.has_right && p->has_left && front.right_offset < p->left_offset) continue;  // misordered
+        if (front.has_left && p->has_left && front.left_offset < p->left_offset) continue;    // misordered left offset
+        matches.push_back(&*it);
+      }
+      const int64_t p_middle = (p->start_limit + p->end_limit) / 2 + int64_t(p->seq.size());
+      std::sort(matches.begin(), matches.end(), [&](const Front* li, const Front* ri) {  // match_sorter (:313-362)
+        const PopEntry& lhs = *li->e;
+        const PopEntry& rhs = *ri->e;
+        if (lhs.has_left != rhs.has_left) return lhs.has_left > rhs.has_left;  // reanchor to reference if possible
+        if (lhs.orig_r.s != rhs.orig_r.s) return lhs.orig_r.s > rhs.orig_r.s;  // more specific is better
+        const int64_t ld = std::llabs(p_middle - (lhs.start_limit + lhs.end_limit) / 2);
+        const int64_t rd = std::llabs(p_middle - (rhs.start_limit + rhs.end_limit) / 2);
+        if (ld != rd) return ld < rd;
+        // (:347-349 compares rhs.seq.size() with itself)
+        const int64_t ls = lhs.end_limit - lhs.start_limit, rs = rhs.end_limit - rhs.start_limit;
+        if (ls != rs) return ls < rs;
+        return false;
+      });
+      bool found = false;
+      for (Front* fi : matches) {
+        const PopEntry& front = *fi->e;
+        found = true;
+        if (front.has_left) {  // the front is aligned to reference
+          p->has_right = true;
+          p->right_offset = front.left_offset;
+          if (p->has_left) output_assembly(*p);
+        } else {  // merge in
+          const int64_t plen = int64_t(p->seq.size());
+          p->start_limit = std::max(p->start_limit, front.start_limit - plen);
+          p->end_limit = std::min(p->end_limit, front.end_limit - plen);
+          p->popped_r = front.popped_r;
+          p->seq += front.seq;
+          p->seen_read_ids.insert(p->seen_read_ids.end(), front.seen_read_ids.begin(), front.seen_read_ids.end());
+          if (front.has_right) {
+            p->has_right = true;
+            p->right_offset = front.right_offset;
+            if (p->has_left) output_assembly(*p);
+          } else {
+            poppers.push_back(p);  // keeps searching for something to align to on the right
+          }
+        }
+        if (!front.has_left) fi->erased = true;  // consumed
+        break;
+      }
+      if (!found) poppers.push_back(p);  // try again after popping more
+    }
+  }
+
+  void output_assembly(const PopEntry& p) {  // :615-651
+    bg_trace_assembly_rec a;
+    a.from_pop = true;
+    a.assembly_id = allocate_assembly_id();
+    a.left_offset = p.left_offset;
+    a.right_offset = p.right_offset;
+    a.seq = p.seq;
+    a.rc_read_ids = p.seen_read_ids;
+    std::sort(a.rc_read_ids.begin(), a.rc_read_ids.end());
+    a.rc_read_ids.erase(std::unique(a.rc_read_ids.begin(), a.rc_read_ids.end()), a.rc_read_ids.end());
+    if (a.left_offset == a.right_offset && a.seq.empty()) return;
+    // (:631-636: matches_reference is only ever set inside `if (k_trace_dbg)`)
+    out.push_back(std::move(a));
+  }
+};
+
+}  // namespace
+
+extern "C" uint64_t bg_trace_result_anchor_drops(const bg_trace_result* r) { return r ? r->anchor_drops.size() : 0; }
+
+extern "C" int bg_pop_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                            const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset, int rev_comp,
+                            const bg_trace_result* const* push, uint32_t n_push, bg_trace_result** out) {
+  if (!t || !out || (n_extents && (!ext_offset || !ext_seq || !ext_len)) || (n_push && !push)) return fail("bg_pop_trace: null argument");
+  World& w = t->w;
+  BG_HIP(hipSetDevice(w.ctx->device));
+  std::vector<Extent> ext;
+  int64_t calc_end = 0, prev_end = INT64_MIN;
+  for (uint64_t i = 0; i < n_extents; ++i) {
+    if (ext_offset[i] < prev_end) return fail("bg_pop_trace: extents must be sorted and disjoint");
+    ext.push_back(Extent{ext_offset[i], std::string(ext_seq[i], ext_len[i])});
+    for (char c : ext.back().seq)
+      if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return fail("bg_pop_trace: extents hold ACGT only");
+    prev_end = ext_offset[i] + int64_t(ext_len[i]);
+    calc_end = std::max(calc_end, prev_end);
+  }
+  if (end_pos < calc_end) return fail("bg_pop_trace: end_pos lies before the end of the last extent");
+  if (limit_offset > end_pos) limit_offset = end_pos;
+  std::vector<Extent> rc;
+  if (rev_comp)
+    for (auto it = ext.rbegin(); it != ext.rend(); ++it) rc.push_back(Extent{end_pos - it->offset - int64_t(it->seq.size()), rev_comp_str(it->seq)});
+  std::unique_ptr<bg_trace_result> res(new bg_trace_result);
+  memset(&res->stats, 0, sizeof(res->stats));
+  PopTracer pt{w, w.ctx, rev_comp ? rc : ext, end_pos};
+  std::vector<const bg_anchor_drop_rec*> drops;
+  for (uint32_t i = 0; i < n_push; ++i) {
+    if (!push[i]) return fail("bg_pop_trace: null push result");
+    for (const auto& d : push[i]->anchor_drops) drops.push_back(&d);
+  }
+  BG_TRY(pt.add_anchor_drops(drops, rev_comp != 0));
+  if (rev_comp) BG_TRY(pt.add_reference(end_pos - limit_offset, end_pos - start_offset));
+  else BG_TRY(pt.add_reference(start_offset, limit_offset));
+  BG_TRY(pt.assemble());
+  // sorter(left_offset_less_than) -> pair_counter -> (reversed back) (reversable_tracer.cpp:118-126)
+  std::sort(pt.out.begin(), pt.out.end(), [](const bg_trace_assembly_rec& a, const bg_trace_assembly_rec& b) { return a.left_offset < b.left_offset; });
+  std::vector<bg_trace_assembly_rec> counted;
+  {
+    PairCounter pc{w, &counted};
+    for (auto& a : pt.out)
+      if (!pc.add(std::move(a))) return fail("bg_pop_trace: pair_counter: assemblies out of left-offset order");
+    pc.flush();
+  }
+  if (rev_comp)
+    for (auto& a : counted) reverse_rec(w, &a, end_pos, false);
+  res->a = std::move(counted);
+  res->stats.traces = drops.size();
+  res->stats.output_count = res->a.size();
+  res->stats.device_rounds = pt.device_rounds;
+  res->stats.device_queries = pt.device_queries;
+  *out = res.release();
+  return BG_OK;
 }

@@ -696,6 +696,49 @@ extern "C" int bg_walk_chains_batch(bg_ctx* ctx, const bg_seqset* ss, uint32_t n
   return BG_OK;
 }
 
+// Chains of seqset_range::push_front (seqset.cpp:319-338) from the empty context: chain i pushes its bases in order
+// and stops at the first one after which no entry is left -- what pop_tracer::add_anchor_drop does with a left-anchored
+// drop (pop_tracer.cpp:258-266: the longest suffix of the assembly the seqset knows).  One lane per chain.
+__global__ __launch_bounds__(64) void k_push_front_chains(SeqsetView v, uint32_t n, const uint64_t* __restrict__ offs,
+                                                         const uint8_t* __restrict__ codes, uint64_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t b = 0, e = v.n;
+  uint32_t s = 0;
+  for (uint64_t t = offs[i]; t < offs[i + 1]; ++t) {
+    uint64_t nb, ne;
+    uint32_t ns;
+    v.push_front(b, e, s, codes[t] & 3, &nb, &ne, &ns);
+    if (nb >= ne) break;
+    b = nb; e = ne; s = ns;
+  }
+  out[3 * uint64_t(i)] = b;
+  out[3 * uint64_t(i) + 1] = e;
+  out[3 * uint64_t(i) + 2] = s;
+}
+
+extern "C" int bg_push_front_chains(bg_ctx* ctx, const bg_seqset* ss, uint32_t n, const uint64_t* h_offsets, const uint8_t* h_codes,
+                                    uint64_t* h_out) {
+  BG_TRY(check_ss(ctx, ss, "bg_push_front_chains"));
+  if (!n) return BG_OK;
+  if (!h_offsets || !h_out || (h_offsets[n] && !h_codes)) { set_error("bg_push_front_chains: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  const uint64_t n_codes = h_offsets[n];
+  const size_t off_words = size_t(n) + 1, code_words = (n_codes + 7) / 8 + 1;
+  DevBuf<uint64_t> buf;
+  BG_TRY(buf.alloc(ctx, off_words + code_words + size_t(n) * 3));
+  BG_HIP(hipMemcpyAsync(buf.p, h_offsets, off_words * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (n_codes) BG_HIP(hipMemcpyAsync(buf.p + off_words, h_codes, n_codes, hipMemcpyHostToDevice, ctx->stream));
+  ctx->tic("walk_push_front_chains");
+  k_push_front_chains<<<cdiv(n, 64), 64, 0, ctx->stream>>>(make_view(ss), n, buf.p, reinterpret_cast<const uint8_t*>(buf.p + off_words),
+                                                          buf.p + off_words + code_words);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n_codes * 52);
+  BG_HIP(hipMemcpyAsync(h_out, buf.p + off_words + code_words, size_t(n) * 24, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
 // The heads of ONE path group along one sequence: h_start / h_out hold (begin, end, size) as three u64 per range,
 // h_out[(t * n_chains + i) * 3 ..] = chain i after base t.
 extern "C" int bg_walk_chains(bg_ctx* ctx, const bg_seqset* ss, uint32_t n_chains, const uint64_t* h_start,

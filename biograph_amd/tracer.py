@@ -27,7 +27,8 @@ class TraceOptions(C.Structure):
                                                         ("min_anchor_drop_overlap", C.c_uint64),
                                                         ("ref_align_factor", C.c_int32), ("max_ref_align_bases", C.c_int32),
                                                         ("anchor_drop", C.c_int32), ("max_anchor_kmer_size", C.c_int32),
-                                                        ("output_ml_features", C.c_int32)])
+                                                        ("output_ml_features", C.c_int32), ("min_pop_overlap", C.c_uint64),
+                                                        ("pop_tracer_offset_slop", C.c_uint64), ("min_pair_distance", C.c_int64)])
 
     def __init__(self, **kw):
         super().__init__()
@@ -55,7 +56,7 @@ class _Asm(C.Structure):
                 ("matches_reference", C.c_int32), ("rc_read_ids", C.POINTER(C.c_uint32)),
                 ("left_pair_matches", C.POINTER(C.c_uint32)), ("right_pair_matches", C.POINTER(C.c_uint32)),
                 ("n_rc_read_ids", C.c_uint64), ("n_left_pair_matches", C.c_uint64), ("n_right_pair_matches", C.c_uint64),
-                ("assembly_id", C.c_uint64)]
+                ("assembly_id", C.c_uint64), ("from_pop", C.c_int32)]
 
 
 class TraceAssembly:
@@ -66,6 +67,7 @@ class TraceAssembly:
         self.aligned_variants = []
         self.ml, self.merged = None, 0  # assembly_ml_features as a tuple, assemblies merged into this one
         self.assembly_id = 0  # assemble.h:295; 0 on a hand-made assembly = the library allocates one
+        self.from_pop = False  # assembly::tags: {"POP"} (pop tracer) or {"PUSH"}
         if a is None:  # a hand-made assembly (the reference's unit tests build them this way)
             self.left_offset = self.right_offset = self.left_anchor_len = self.right_anchor_len = 0
             self.seq, self.min_overlap, self.trace_steps, self.left_anchor_ambiguous_bases = "", 0, 0, 0
@@ -87,6 +89,7 @@ class TraceAssembly:
         self.left_pair_matches = [int(a.left_pair_matches[i]) for i in range(a.n_left_pair_matches)]
         self.right_pair_matches = [int(a.right_pair_matches[i]) for i in range(a.n_right_pair_matches)]
         self.assembly_id = int(a.assembly_id)
+        self.from_pop = bool(a.from_pop)
 
     def key(self):
         return (self.left_offset, self.right_offset, self.left_anchor_len, self.right_anchor_len, self.seq,
@@ -195,7 +198,7 @@ def _make_result(assemblies):
             a = _Asm(t.left_offset, t.right_offset, t.score, t.left_anchor_len, t.right_anchor_len,
                      C.cast(C.c_char_p(seq), C.c_void_p), len(seq), t.min_overlap, t.trace_steps, t.left_anchor_ambiguous_bases,
                      int(t.matches_reference), ids, lm, rm, len(t.rc_read_ids), len(t.left_pair_matches), len(t.right_pair_matches),
-                     int(getattr(t, "assembly_id", 0)))
+                     int(getattr(t, "assembly_id", 0)), int(bool(getattr(t, "from_pop", False))))
             capi.check(L.bg_trace_result_add(src, C.byref(a)))
             if getattr(t, "coverage", None) is not None:  # a section that has been through calc_coverage
                 cov = (C.c_int32 * max(len(t.coverage), 1))(*t.coverage)
@@ -285,7 +288,7 @@ def process_assemblies(assemblies, extents, end_pos=None, options=None, steps=ST
             a = _Asm(t.left_offset, t.right_offset, t.score, t.left_anchor_len, t.right_anchor_len,
                      C.cast(C.c_char_p(seq), C.c_void_p), len(seq), t.min_overlap, t.trace_steps, t.left_anchor_ambiguous_bases,
                      int(t.matches_reference), ids, lm, rm, len(t.rc_read_ids), len(t.left_pair_matches), len(t.right_pair_matches),
-                     int(getattr(t, "assembly_id", 0)))
+                     int(getattr(t, "assembly_id", 0)), int(bool(getattr(t, "from_pop", False))))
             capi.check(L.bg_trace_result_add(src, C.byref(a)))
         n = len(extents)
         offs = (C.c_int64 * max(n, 1))(*[int(o) for o, _ in extents])
@@ -338,6 +341,43 @@ class PushTracer:
             return out, {k: int(getattr(st, k)) for k in _STAT_FIELDS}
         finally:
             L.bg_trace_result_free(h)
+
+    def execute_work(self, extents, start=0, limit=None, end_pos=None, push_fwd=True, push_rev=True, pop_fwd=True, pop_rev=True):
+        """One work item of trace_ref with the pop tracer over the anchor drops (trace_ref::execute_work, trace_ref.cpp:141-221;
+        `biograph discovery --enable-pop-tracer`): push forward, push reverse, then bg_pop_trace forward and reverse over the
+        drops the push tracers reported.  -> [TraceAssembly] in that order (pop assemblies have from_pop set)."""
+        L = capi.lib()
+        n = len(extents)
+        offs = (C.c_int64 * max(n, 1))(*[int(o) for o, _ in extents])
+        bufs = [s.encode() for _, s in extents]
+        ptrs = (C.c_char_p * max(n, 1))(*bufs)
+        lens = (C.c_uint64 * max(n, 1))(*[len(b) for b in bufs])
+        calc_end = max([o + len(s) for o, s in extents] + [0])
+        end_pos = calc_end if end_pos is None else end_pos
+        limit = end_pos if limit is None else limit
+        held, out = [], []
+        try:
+            for rev, on in ((0, push_fwd), (1, push_rev)):
+                if not on:
+                    continue
+                h = C.c_void_p()
+                capi.check(L.bg_tracer_trace(self.h, n, offs, ptrs, lens, end_pos, start, limit, rev, 1, C.byref(h)))
+                held.append(h)
+                out.extend(_read_result(h))
+            push = (C.c_void_p * max(len(held), 1))(*[h.value for h in held])
+            for rev, on in ((0, pop_fwd), (1, pop_rev)):
+                if not on:
+                    continue
+                h = C.c_void_p()
+                capi.check(L.bg_pop_trace(self.h, n, offs, ptrs, lens, end_pos, start, limit, rev, push, len(held), C.byref(h)))
+                try:
+                    out.extend(_read_result(h))
+                finally:
+                    L.bg_trace_result_free(h)
+            return out
+        finally:
+            for h in held:
+                L.bg_trace_result_free(h)
 
     def close(self):
         if self.h:

@@ -462,6 +462,10 @@ typedef struct bg_trace_options {
   int32_t max_anchor_kmer_size;   /* anchor_dropper::set_max_kmer_size_for_testing (anchor_drop.h:15-19); 31          */
   int32_t output_ml_features;     /* assemble.h:730: bg_assemblies_process records every discovered assembly's ML
                                      features behind the sorter (add_ml_features, biograph_variants.cpp:746-779)      */
+  /* the pop tracer (bg_pop_trace) */
+  uint64_t min_pop_overlap;         /* assemble.h:523 (15)   */
+  uint64_t pop_tracer_offset_slop;  /* assemble.h:527 (1000) */
+  int64_t min_pair_distance;        /* assemble.h:588 (100)  */
 } bg_trace_options;
 void bg_trace_options_default(bg_trace_options* o);
 typedef struct bg_trace_stats {  /* assemble_stats of the tracer + the device rounds this implementation took */
@@ -481,6 +485,7 @@ typedef struct bg_trace_assembly {  /* variants::assembly as the tracer and pair
   uint64_t n_rc_read_ids, n_left_pair_matches, n_right_pair_matches;
   uint64_t assembly_id;  /* assemble.h:295: shared by the sections cut from one traced assembly; 0 in bg_trace_result_add
                           * = allocate a fresh one (assembly's constructor, assemble.cpp:1248) */
+  int32_t from_pop;      /* assembly::tags: 1 = {"POP"} (pop_tracer.cpp:618), 0 = {"PUSH"} (tracer.cpp:1165) */
 } bg_trace_assembly;
 typedef struct bg_trace_result bg_trace_result;
 /* Extents: the N-free stretches of the scaffold in scaffold coordinates, ascending; end_pos = scaffold::end_pos().
@@ -498,6 +503,19 @@ int bg_tracer_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const
 int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
                     const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset, int rev_comp,
                     int pair_count, bg_trace_result** out);
+/* The pop tracer over one work item (variants/pop_tracer.cpp:55-653 behind reversable_tracer.cpp:49-74,118-126; wired as
+ * trace_ref::execute_work does, trace_ref.cpp:141-221; `biograph discovery --enable-pop-tracer`, on by default): the
+ * anchor drops the push tracer reported while it produced `push[0 .. n_push)` (bg_tracer_trace results of THIS work item,
+ * in the order they were traced: forward, then reverse -- each remembers its drops) and the mates of the reads along
+ * [start_offset, limit_offset) become "fronts"; left-anchored drops lose their first base pass by pass
+ * (seqset_range::pop_front on the device, all poppers of a pass in one launch) until what is left is a prefix of a
+ * front.  Output as it reaches the scaffold's pipeline: sorter(left offset) -> pair_counter -> forward coordinates;
+ * assemblies carry from_pop = 1.  rev_comp: the pop tracer that runs on the reverse strand (trace_ref's rc_pop). */
+int bg_pop_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                 const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset, int rev_comp,
+                 const bg_trace_result* const* push, uint32_t n_push, bg_trace_result** out);
+/* Number of anchor drops a bg_tracer_trace result remembers for bg_pop_trace. */
+uint64_t bg_trace_result_anchor_drops(const bg_trace_result* r);
 /* A second session for another host thread: its own context (stream, allocator), the read-only host tables shared with
  * `from`, the same options.  Sessions may trace concurrently, one thread per session; `from` may be closed first. */
 int bg_tracer_clone(const bg_tracer* from, bg_ctx* ctx, bg_tracer** out);
@@ -619,6 +637,11 @@ typedef struct bg_walk_chain {
 } bg_walk_chain;
 int bg_walk_chains_batch(bg_ctx* ctx, const bg_seqset* ss, uint32_t n_chains, const bg_walk_chain* h_chains,
                          const uint8_t* h_codes, uint64_t n_codes, uint64_t* h_out, uint64_t out_words);
+/* Chains of seqset_range::push_front (seqset.cpp:319-338) from the empty context: chain i pushes
+ * h_codes[h_offsets[i] .. h_offsets[i+1]) in order and stops at the first base after which no entry is left;
+ * h_out[3 i ..] = (begin, end, size) of the last valid range (pop_tracer.cpp:258-266).  HOST buffers. */
+int bg_push_front_chains(bg_ctx* ctx, const bg_seqset* ss, uint32_t n, const uint64_t* h_offsets, const uint8_t* h_codes,
+                         uint64_t* h_out);
 /* aligned_variants of assembly i (variants::aligned_var, assemble.h:124-152): filled by BG_STEP_ALIGN, consumed by
  * BG_STEP_SPLIT.  seq points into r. */
 uint64_t bg_trace_result_var_count(const bg_trace_result* r, uint64_t i);

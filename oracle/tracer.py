@@ -138,6 +138,7 @@ class Graph:
     def __init__(self, seqset, readmap, ref_map):
         import numpy as np
         self.ss = seqset
+        self.rm = readmap
         self.n = len(seqset)
         sizes = seqset.arrays()[0]
         self.entry_sizes = [int(x) for x in sizes]
@@ -327,6 +328,7 @@ class Tracer:
         self.o = options
         self.cur_offset = 0
         self.stats = {}
+        self.report_anchor_drop = None
 
     def _stat(self, k, n=1):
         self.stats[k] = self.stats.get(k, 0) + n
@@ -825,6 +827,8 @@ class Tracer:
             half = int(max_tot_anchor / 2)  # C++ integer division truncates toward zero
             out.right_anchor_len = min(out.right_anchor_len, half)
             out.left_anchor_len = min(out.left_anchor_len, half)
+        if r.anchor_drop and self.report_anchor_drop is not None:  # tracer.cpp:1233-1235: anchored on the left only
+            self.report_anchor_drop(out, False)
         self._stat("output_count")
         self.emit(out)
 
@@ -928,7 +932,7 @@ class PairCounter:
 
 
 def reversable_trace(graph, scaffold, options, rev_comp=False, start_offset=0, limit_offset=None, pair_count=True,
-                     anchor_drop=None):
+                     anchor_drop=None, report_anchor_drop=None):
     """reversable_tracer::assemble (reversable_tracer.cpp:76-145) for the push tracer:
     tracer -> [anchor_dropper] -> pair_counter -> (reversed back when rev_comp) -> list of assemblies in output order.
     `anchor_drop(scaffold, emit)` builds the anchor_dropper step (oracle/align.py's AnchorDropper; an object with
@@ -951,6 +955,7 @@ def reversable_trace(graph, scaffold, options, rev_comp=False, start_offset=0, l
     if ad is not None:
         sink = ad.add
     t = Tracer(graph, run_sc, options)
+    t.report_anchor_drop = report_anchor_drop  # assemble_options::report_anchor_drop_func, in the TRACER's coordinates
     if rev_comp:
         t.assemble(ref_end - limit_offset, ref_end - start_offset, emit=sink)
     else:
