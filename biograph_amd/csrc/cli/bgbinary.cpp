@@ -763,6 +763,8 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     die(std::string("discovery: --") + name + " takes true or false");
     return dflt;
   };
+  // --enable-pop-tracer (biograph_variants.cpp:188,685; true there): the pop tracer re-traces the push tracer's anchor drops
+  const bool pop_tracer = flag("enable-pop-tracer", true);
   cov.simple_genotype_filter = flag("simple-gt", false) ? 1 : 0;
   cov.rvg_exclude = flag("rvg-exclude", true) ? 1 : 0;
   // trace_ref runs its work items on the process's thread pool (trace_ref.cpp:105-140); here: --threads sessions
@@ -817,7 +819,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
                     "##ALT=<ID=INS,Description=\"Insertion\">\n##ALT=<ID=DEL,Description=\"Deletion\">\n";
   for (auto& rec : recs) vcf += "##contig=<ID=" + rec.first + ",length=" + std::to_string(rec.second.size()) + ">\n";
   vcf += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + sample + "\n";
-  uint64_t n_var = 0, n_traced = 0, n_sections = 0, pieces = 0;
+  uint64_t n_var = 0, n_traced = 0, n_sections = 0, pieces = 0, n_popped = 0;
   double t_trace = 0, t_pipe = 0, t_cov = 0;
   for (auto& rec : recs) {
     const std::string& seq = rec.second;
@@ -851,6 +853,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
         for (int rev = 0; rev < 2; ++rev) work.push_back(Work{start, limit, rev});
       }
     std::vector<bg_trace_result*> items(work.size(), nullptr);
+    std::vector<bg_trace_result*> pops(pop_tracer ? work.size() : 0, nullptr);  // (piece, direction) like `work`
     double t1 = now_s();
     {
       std::atomic<size_t> next(0);
@@ -875,6 +878,38 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
       run(0);
       for (auto& th : pool) th.join();
       if (!err.empty()) die("bg_tracer_trace: " + err);
+      // the pop tracers of every piece (trace_ref.cpp:186-207): forward and reverse, over the anchor drops both push
+      // directions of the piece reported
+      if (pop_tracer) {
+        next.store(0);
+        auto run_pop = [&](int t) {
+          for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= work.size()) return;
+            const bg_trace_result* push[2] = {items[i & ~size_t(1)], items[i | 1]};
+            if (bg_pop_trace(tracers[size_t(t)], es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), work[i].start,
+                             work[i].limit, work[i].rev, push, 2, &pops[i]) != BG_OK) {
+              std::lock_guard<std::mutex> l(err_mu);
+              if (err.empty()) err = bg_last_error();
+              next.store(work.size());
+              return;
+            }
+          }
+        };
+        std::vector<std::thread> pool2;
+        for (int t = 1; t < nt; ++t) pool2.emplace_back(run_pop, t);
+        run_pop(0);
+        for (auto& th : pool2) th.join();
+        if (!err.empty()) die("bg_pop_trace: " + err);
+        // the order the assemblies of a work item reach the scaffold's pipeline in: push forward, push reverse, pop forward,
+        // pop reverse
+        std::vector<bg_trace_result*> all;
+        for (size_t i = 0; i + 1 < work.size(); i += 2) {
+          all.push_back(items[i]); all.push_back(items[i + 1]); all.push_back(pops[i]); all.push_back(pops[i + 1]);
+        }
+        for (auto* r : pops) n_popped += bg_trace_result_size(r);
+        items.swap(all);
+      }
     }
     for (auto* r : items) n_traced += bg_trace_result_size(r);
     t_trace += now_s() - t1;
@@ -914,9 +949,9 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   bg_dev_free(ctx, d_map);
   write_file(a.get("out"), vcf);
   fprintf(stderr, "%llu variants over %zu scaffold(s) in %llu piece(s) x 2 directions on %d tracer session(s), min overlap %u: %.2f s (refmap %.2f, sessions %.2f, tracing %.2f "
-                  "[%llu assemblies], pipeline %.2f [%llu sections], coverage + genotype %.2f)\n",
+                  "[%llu assemblies], pipeline %.2f [%llu sections], coverage + genotype %.2f); pop tracer %s [%llu of the assemblies]\n",
           (unsigned long long)n_var, recs.size(), (unsigned long long)pieces, n_threads, min_overlap, now_s() - t0, t_refmap, t_open, t_trace,
-          (unsigned long long)n_traced, t_pipe, (unsigned long long)n_sections, t_cov);
+          (unsigned long long)n_traced, t_pipe, (unsigned long long)n_sections, t_cov, pop_tracer ? "on" : "off", (unsigned long long)n_popped);
   return 0;
 }
 
@@ -931,14 +966,8 @@ static int cmd_discovery(int argc, char** argv) {
   const std::string engine = a.get("engine", "push");
   if (engine != "push" && engine != "graph") die("discovery: --engine takes push or graph");
   // --max-ploids (biograph_variants.cpp:162) feeds genotyper / ploid_limiter, neither of which is a step of the standard
-  // pipeline (pipeline.cpp:92-105): accepted, without effect there either.  --enable-pop-tracer (:188, default true
-  // there) adds a pop-tracer pass over the anchor drops, which this build does not have.
+  // pipeline (pipeline.cpp:92-105): accepted, without effect there either.
   if (a.has("max-ploids") && atoi(a.get("max-ploids").c_str()) < 1) die("discovery: --max-ploids must be at least 1");
-  {
-    const std::string pop = a.get("enable-pop-tracer", "");
-    if (pop == "1" || pop == "true" || pop == "on" || pop == "yes") die("discovery: the pop tracer is not part of this build (--enable-pop-tracer false)");
-    if (pop.empty() && engine == "push") fprintf(stderr, "discovery: running as --enable-pop-tracer=false (no pop-tracer pass over anchor drops in this build)\n");
-  }
   // scaffolds (chromosomes) and their N-free supercontigs from the reference directory / .ref / FASTA; a
   // scaffold is rebuilt with N between its supercontigs so that VCF positions are scaffold coordinates
   const double t_begin = now_s();

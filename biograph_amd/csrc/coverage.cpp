@@ -664,12 +664,13 @@ bool genotype(const bg_coverage_options& o, bg_trace_assembly_rec& a) {
     for (int c : a.pair_coverage) tot += c;
     avg_pair = tot * 1. / double(a.pair_coverage.size());
   }
-  if (avg_pair < o.min_avg_pair_depth || min_pair < o.min_pair_depth || min_depth < o.min_read_depth) return false;
+  // simple_genotype_filter::discard (:9-25): an assembly of the pop tracer that fails is passed on untouched
+  if (avg_pair < o.min_avg_pair_depth || min_pair < o.min_pair_depth || min_depth < o.min_read_depth) return a.from_pop;
   const int total = min_depth + a.other_depth + a.ref_depth;
-  if (!total) return false;
+  if (!total) return a.from_pop;
   const double min_p = min_depth * 1. / total, alt_p = a.other_depth * 1. / total, ref_p = a.ref_depth * 1. / total;
   const double f = o.min_depth_portion;
-  if (min_p < f) return false;
+  if (min_p < f) return a.from_pop;
   if (ref_p > f) {
     a.strand_count = 1;
     a.genotype_quality = std::min(min_p, ref_p) / (min_p + ref_p);

@@ -386,14 +386,18 @@ def simple_genotype_filter(o, assemblies):
         min_depth = min(a.coverage)
         min_pair = min(a.pair_coverage) if a.pair_coverage else 0
         avg_pair = sum(a.pair_coverage) * 1. / len(a.pair_coverage) if a.pair_coverage else 0
+        discard = lambda: out.append(a) if "POP" in a.tags else None  # noqa: E731  (:9-25: pop assemblies pass untouched)
         if avg_pair < o.min_avg_pair_depth or min_pair < o.min_pair_depth or min_depth < o.min_read_depth:
+            discard()
             continue
         total = min_depth + a.other_depth + a.ref_depth
         if not total:
+            discard()
             continue
         min_p, alt_p, ref_p = min_depth * 1. / total, a.other_depth * 1. / total, a.ref_depth * 1. / total
         f = o.min_depth_portion
         if min_p < f:
+            discard()
             continue
         if ref_p > f:
             a.strand_count, a.genotype_quality = 1, min(min_p, ref_p) / (min_p + ref_p)

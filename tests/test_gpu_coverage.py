@@ -285,6 +285,62 @@ def test_discovery_engine_equals_oracle_on_a_120kb_sample(ctx):
         h.free()
 
 
+def test_current_default_chain_equals_oracle_on_a_60kb_sample(ctx):
+    """`biograph discovery` as the current reference runs it by default (biograph_variants.cpp:188-202): pop tracers over the
+    anchor drops of every work item (trace_ref::execute_work), no simple genotype filter, rvg_exclude last -- through the
+    library (PushTracer.execute_work -> bg_assemblies_process -> bg_assemblies_coverage with rvg_exclude) and through the
+    oracle's restatements, VCF line for VCF line.  Dense indels and structural variants give the pop tracers work."""
+    from biograph_amd import synth
+    from oracle import pop_tracer as P
+    from tests.test_oracle_tracer import dropper
+    G = 60_000
+    seq, offs, n, genome = synth.make_reads(genome_len=G, coverage=30, read_len=150, seed=91, device="cuda", return_genome=True,
+                                            indel_rate=1e-3, sv_rate=3e-4)
+    r = ctx.pack_reads_device(seq.data_ptr(), offs.data_ptr(), n)
+    ks = ctx.kmer_count(r, 30, 5)
+    c, _ = ctx.correct_reads(r, ks)
+    ss, _ = ctx.build_seqset(c, 30)
+    rm = ctx.build_readmap(ss, c, True)
+    cseq, coffs = c.download()
+    corrected = O.unpack_strings(cseq, coffs)
+    ent = O.Entries.build(cseq, coffs, "cover", 30, threads=8)
+    oss = O.Seqset.from_entries(ent, threads=8)
+    records = [tuple(s for s in corrected[i:i + 2] if s) for i in range(0, len(corrected), 2)]
+    orm = O.Readmap(oss, ent, [rec for rec in records if rec], True)
+    ref = "".join("ACGT"[int(x)] for x in genome.cpu().tolist())
+    parts = [(0, ref)]
+    codes = genome.cpu().numpy().astype(np.uint8)
+    g = T.Graph(oss, orm, oss.ref_map_build(codes, np.array([0], np.uint64), np.array([G], np.uint64)))
+    strings = ent.strings()
+    rmap = tracer.reference_ref_map(ss, [ref])
+    mo = 105
+    o_gpu, o_cpu, sc = tracer.TraceOptions(min_overlap=mo, output_ml_features=1), T.Options(min_overlap=mo), T.Scaffold(parts)
+    po = P.PopOptions(o_cpu)
+    want_in, got_in = [], []
+    t = tracer.PushTracer(ss, rm, rmap, o_gpu)
+    try:
+        for start in (0, 30_000):
+            want_in += P.execute_work(g, strings, sc, o_cpu, po, start=start, limit=start + 30_000, anchor_drop=dropper(o_cpu))
+            got_in += t.execute_work(parts, start=start, limit=start + 30_000)
+    finally:
+        t.close()
+        rmap.free()
+    assert sum(1 for a in got_in if a.from_pop) > 0
+    assert [(a.left_offset, a.right_offset, a.seq, a.from_pop) for a in got_in] == [(a.left_offset, a.right_offset, a.seq, "POP" in a.tags)
+                                                                                   for a in want_in]
+    _, want_sections = A.variants_pipeline(A.AlignOptions(min_overlap=mo), sc, want_in, through_vcf_pad=True, ml_features=True)
+    got_sections = tracer.process_assemblies(got_in, parts, options=o_gpu)
+    co = C.CoverageOptions(output_ml_features=True, simple_genotype_filter=False, rvg_exclude=True)
+    covered = C.simple_genotype_filter(co, C.calc_coverage(g, [int(x) for x in orm.get("read_len")], sc, co, want_sections))
+    want = C.rvg_exclude(co, covered)
+    got, lines = tracer.assemblies_coverage(ss, rm, got_sections, parts, vcf_name="chrS",
+                                            options=tracer.CoverageOptions(output_ml_features=1, simple_genotype_filter=0, rvg_exclude=1))
+    assert lines == [C.vcf_line(co, "chrS", lambda off, k: ref[off:off + k], a) for a in want]
+    assert 50 < len(lines) < len(covered)  # rvg_exclude dropped something
+    for h in (rm, ss, c, ks, r):
+        h.free()
+
+
 def test_walk_chains_batch_with_different_sequences(ctx):
     """bg_walk_chains_batch: chains of different groups, each with its own bases, output offset and stride, in one call
     == each chain walked on its own with bg_walk_chains."""

@@ -157,7 +157,7 @@ def test_bgbinary_discovery_cli_on_lambda(golden_dir, tmp_path, ref_arg, chrom, 
                         golden_dir + ref_arg, "--out", str(out), "--engine", engine] +
                        # push: the command's defaults (0.7 x read length); father.vcf predates the ML feature columns
                        # and was written with the simple genotype filter and without rvg_exclude (today's defaults are the other way round)
-                       (["--min-overlap", "70"] if engine == "graph" else ["--ml-features", "false", "--simple-gt", "true", "--rvg-exclude", "false"]),
+                       (["--min-overlap", "70"] if engine == "graph" else ["--ml-features", "false", "--simple-gt", "true", "--rvg-exclude", "false", "--enable-pop-tracer", "false"]),
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     ref = "".join(l.strip() for l in open(golden_dir + "/father_lambda/reference.fasta") if not l.startswith(">")).upper()
@@ -269,7 +269,7 @@ def test_bgbinary_discovery_push_engine_with_bed(golden_dir, tmp_path):
     bed.write_text("lambda\t500\t11000\nlambda\t28500\t32500\n")
     out = tmp_path / "v.vcf"
     r = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "discovery", "--in", str(bgd), "--ref", golden_dir + "/ref_lambda",
-                        "--out", str(out), "--bed", str(bed), "--max-ploids", "2", "--ml-features", "false", "--simple-gt", "true", "--rvg-exclude", "false"],
+                        "--out", str(out), "--bed", str(bed), "--max-ploids", "2", "--ml-features", "false", "--simple-gt", "true", "--rvg-exclude", "false", "--enable-pop-tracer", "false"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
 
@@ -288,9 +288,15 @@ def test_bgbinary_discovery_push_engine_with_bed(golden_dir, tmp_path):
     inside = lambda pos: 500 < pos <= 11000 or 28500 < pos <= 32500  # noqa: E731
     want = fields(golden_dir + "/father_lambda/father.vcf", inside)
     assert len(want) == 6 and fields(out, lambda pos: True) == want
+    # the command's defaults are the current reference's (biograph_variants.cpp:188-202): pop tracer on, rvg_exclude on, no
+    # simple genotype filter -- every record of father.vcf is still there (unfiltered, so possibly among others)
     r = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "discovery", "--in", str(bgd), "--ref", golden_dir + "/ref_lambda",
-                        "--out", str(out), "--enable-pop-tracer", "true"], capture_output=True, text=True)
-    assert r.returncode != 0 and "pop tracer" in r.stderr
+                        "--out", str(out), "--ml-features", "false"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "pop tracer on" in r.stderr
+    mine = {tuple(l.split("\t")[1:5]) for l in open(out) if not l.startswith("#")}
+    gold = {tuple(l.split("\t")[1:5]) for l in open(golden_dir + "/father_lambda/father.vcf") if not l.startswith("#")}
+    assert gold <= mine, sorted(gold - mine)
 
 
 def test_bgbinary_discovery_ml_feature_columns(golden_dir, tmp_path):
@@ -309,7 +315,7 @@ def test_bgbinary_discovery_ml_feature_columns(golden_dir, tmp_path):
               separators=(",", ":"))
     out = tmp_path / "v.vcf"
     r = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "discovery", "--in", str(bgd), "--ref", golden_dir + "/ref_lambda",
-                        "--out", str(out), "--simple-gt", "true", "--rvg-exclude", "false"], capture_output=True, text=True)
+                        "--out", str(out), "--simple-gt", "true", "--rvg-exclude", "false", "--enable-pop-tracer", "false"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     recs = [l.rstrip("\n").split("\t") for l in open(out) if not l.startswith("#")]
     gold = [l.rstrip("\n").split("\t") for l in open(golden_dir + "/father_lambda/father.vcf") if not l.startswith("#")]
