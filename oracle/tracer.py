@@ -267,6 +267,8 @@ class Assembly:
         self.left_pair_matches = []
         self.right_pair_matches = []
         self.tags = set()
+        self.strand_count = 0          # assemble.h:360-370: what the genotype step fills; 0 / 0.0 when it does not run
+        self.genotype_quality = 0.0
 
     def key(self):
         return (self.left_offset, self.right_offset, self.left_anchor_len, self.right_anchor_len, self.seq,
