@@ -250,6 +250,108 @@ std::vector<Read> prefix_reads(const std::shared_ptr<ReadmapObj>& rm, const Entr
   }
 }
 
+// readmap::get_pair_stats (bio_base/readmap.cpp:300-319)
+struct PairStats { uint64_t paired_reads = 0, paired_bases = 0, unpaired_reads = 0, unpaired_bases = 0; };
+PairStats pair_stats(const std::shared_ptr<ReadmapObj>& rm) {
+  PairStats r;
+  for (uint32_t i = 0; i < rm->size(); ++i) {
+    if (read_has_mate(Read{rm, i})) { ++r.paired_reads; r.paired_bases += rm->read_len[i]; }
+    else { ++r.unpaired_reads; r.unpaired_bases += rm->read_len[i]; }
+  }
+  r.paired_reads /= 2; r.unpaired_reads /= 2; r.paired_bases /= 2; r.unpaired_bases /= 2;  // counted in both orientations
+  return r;
+}
+
+// read ids of the entries [begin, end) (readmap::entry_to_index_range): the read ids are grouped by ascending entry
+std::pair<uint32_t, uint32_t> entry_reads(const ReadmapObj& rm, uint64_t begin, uint64_t end) {
+  const auto lo = std::lower_bound(rm.entry_id.begin(), rm.entry_id.end(), begin);
+  const auto hi = std::lower_bound(lo, rm.entry_id.end(), end);
+  return {uint32_t(lo - rm.entry_id.begin()), uint32_t(hi - rm.entry_id.begin())};
+}
+
+// readmap::approx_coverage (bio_base/readmap.cpp:350-411): the push_front_drop walk along the sequence is one device
+// chain (bg_walk_chains), the counting is the reference's.
+std::vector<int> approx_seq_coverage(const std::shared_ptr<ReadmapObj>& rm, const std::string& seq) {
+  const size_t n = seq.size();
+  std::vector<int> out(n, 0);
+  if (!n) return out;
+  std::vector<uint8_t> codes(n);
+  for (size_t i = 0; i < n; ++i) codes[i] = uint8_t(base_code(seq[i]));
+  const uint64_t start[3] = {0, rm->ss->size(), 0};
+  std::vector<uint64_t> ranges(n * 3);
+  check(bg_walk_chains(rm->c->h, rm->ss->h, 1, start, codes.data(), uint32_t(n), ranges.data()), "get_approx_seq_coverage");
+  std::vector<int> rstart[2] = {std::vector<int>(n, 0), std::vector<int>(n, 0)}, rend[2] = {std::vector<int>(n, 0), std::vector<int>(n, 0)};
+  for (size_t pos = 0; pos < n; ++pos) {
+    const uint64_t b = ranges[pos * 3], e = ranges[pos * 3 + 1], sz = ranges[pos * 3 + 2];
+    if (b + 1 != e) continue;
+    const auto ids = entry_reads(*rm, b, b + 1);
+    for (uint32_t id = ids.first; id < ids.second; ++id) {
+      const int read_len = int(rm->read_len[id]);
+      if (read_len > int(sz)) continue;
+      const int st = int(pos) + 1 - read_len;
+      if (st < 0) continue;
+      const int strand = rm->fwd[id] ? 1 : 0;  // the walk builds the complement: the strand switches
+      rstart[strand][size_t(st)]++;
+      rend[strand][pos]++;
+    }
+  }
+  int cur[2] = {0, 0};
+  for (size_t i = 0; i < n; ++i)
+    for (int s = 0; s < 2; ++s) {
+      cur[s] += rstart[s][i];
+      out[i] += cur[s];
+      cur[s] -= rend[s][i];
+    }
+  return out;
+}
+
+// readmap::get_reads_containing (bio_base/readmap.cpp:485-495, containing_read_iterator :675-746): a depth-first walk
+// over everything that can stand in front of the entry's sequence (push_front of the four bases, one device call per
+// node), reporting the reads of every node that are at least as long as it: (bases before the sequence, read).
+std::vector<std::pair<uint32_t, Read>> reads_containing(const std::shared_ptr<ReadmapObj>& rm, const Entry& e) {
+  if (e.ss->uuid != rm->ss->uuid) throw std::runtime_error("Cannot use a readmap with a seqset it doesn't belong to.");  // :486-488
+  std::vector<std::pair<uint32_t, Read>> out;
+  if (!e.valid()) return out;
+  const uint32_t orig_len = e.size;
+  auto report = [&](const Entry& r) {  // start_entry + skip_non_matching
+    const auto ids = entry_reads(*rm, r.begin, r.end);
+    for (uint32_t id = ids.first; id < ids.second; ++id)
+      if (rm->read_len[id] >= r.size) out.emplace_back(r.size - orig_len, Read{rm, id});
+  };
+  auto push4 = [&](const Entry& r, Entry* next) {  // the four push_fronts of a node in one call
+    DevScratch d(256);
+    uint64_t b[4] = {r.begin, r.begin, r.begin, r.begin}, en[4] = {r.end, r.end, r.end, r.end};
+    uint32_t sz[4] = {r.size, r.size, r.size, r.size};
+    uint8_t base[4] = {0, 1, 2, 3};
+    d.up(0, b, 32); d.up(32, en, 32); d.up(64, sz, 16); d.up(80, base, 4);
+    check(bg_push_front_batch(rm->c->h, rm->ss->h, 4, d.at<uint64_t>(0), d.at<uint64_t>(32), d.at<uint32_t>(64), d.at<uint8_t>(80),
+                              d.at<uint64_t>(96), d.at<uint64_t>(128), d.at<uint32_t>(160)), "get_reads_containing");
+    uint64_t ob[4], oe[4];
+    uint32_t os[4];
+    d.down(ob, 96, 32); d.down(oe, 128, 32); d.down(os, 160, 16);
+    for (int i = 0; i < 4; ++i) next[i] = Entry{r.ss, ob[i], oe[i], os[i]};
+  };
+  Entry cur = e;
+  report(cur);
+  for (;;) {  // advance_entry (:714-746)
+    Entry next[4];
+    push4(cur, next);
+    int down = -1;
+    for (int b = 0; b < 4 && down < 0; ++b) if (next[b].valid()) down = b;
+    if (down >= 0) { cur = next[down]; report(cur); continue; }
+    bool moved = false;
+    while (cur.size > orig_len && !moved) {
+      const int prev_base = base_code(entry_sequence(cur, 1)[0]);
+      const Entry popped = entry_pop_front(cur);
+      push4(popped, next);
+      for (int b = prev_base + 1; b < 4 && !moved; ++b)
+        if (next[b].valid()) { cur = next[b]; report(cur); moved = true; }
+      if (!moved) cur = popped;
+    }
+    if (!moved) return out;
+  }
+}
+
 // ---- BioGraph directory (bio_base/biograph_dir.h:48-88): seqset, coverage/<sha>.readmap, metadata/bg_info.json
 std::string read_file(const std::string& p) {
   std::ifstream f(p, std::ios::binary);
@@ -491,12 +593,26 @@ PYBIND11_MODULE(_capi, m) {
              for (const Read& x : prefix_reads(r, e, min_read_len)) l.append(py::cast(x));
              return l.attr("__iter__")();
            }, py::arg("entry"), py::arg("min_read_len") = 0)
+      .def("get_reads_containing", [](const std::shared_ptr<ReadmapObj>& r, const Entry& e) {
+             py::list l;
+             for (const auto& x : reads_containing(r, e)) l.append(py::make_tuple(x.first, py::cast(x.second)));
+             return l.attr("__iter__")();
+           }, py::arg("entry"),
+           "Reads that contain the entry's sequence somewhere inside: (bases before it in the read, ReadmapRead) (python/biograph/readmap.cpp:54-58)")
+      .def("get_approx_seq_coverage", &approx_seq_coverage, py::arg("seq"), "Coverage of a sequence (python/biograph/readmap.cpp:59-62)")
+      .def("get_pair_stats", &pair_stats, "The number of paired / unpaired reads / bases (python/biograph/readmap.cpp:64)")
       .def("get_read_count", [](const ReadmapObj& r) { return r.size() / 2; })
       .def("get_num_bases", [](const ReadmapObj& r) {
              uint64_t t = 0;
              for (size_t i = 0; i < r.read_len.size(); ++i) if (r.fwd[i]) t += r.read_len[i];
              return t;
            });
+
+  py::class_<PairStats>(m, "ReadmapPairStats", "Statistics on pairing data within a readmap (python/biograph/readmap.cpp:66-78)")
+      .def_readwrite("paired_reads", &PairStats::paired_reads)
+      .def_readwrite("paired_bases", &PairStats::paired_bases)
+      .def_readwrite("unpaired_reads", &PairStats::unpaired_reads)
+      .def_readwrite("unpaired_bases", &PairStats::unpaired_bases);
 
   py::class_<Read>(m, "ReadmapRead", "One read of a Readmap.")
       .def("__len__", [](const Read& r) { return r.rm->read_len[r.id]; })

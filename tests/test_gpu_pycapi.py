@@ -127,6 +127,21 @@ def test_readmap_cases(ecoli, merged):
         read.get_mate()
     with pytest.raises(RuntimeError):                                                     # test_wrong_seqset
         rm1.get_prefix_reads(ecoli.seqset.find("AAAATTACAGAGTACACAACATCCATGAAACGCAT"))
+    r = ss.find("TGAAATGAGTTGCCATCTGGTGCTCAC")                                            # test_reads_containing
+    assert [(off, x.get_read_id(), x.get_seqset_entry().sequence()) for off, x in rm1.get_reads_containing(r)] == [
+        (0, 14544, "TGAAATGAGTTGCCATCTGGTGCTCACCACGG"), (1, 3553, "ATGAAATGAGTTGCCATCTGGTGCTCACCACGG"),
+        (3, 11160, "GGATGAAATGAGTTGCCATCTGGTGCTCACCACGG"), (3, 11161, "GGATGAAATGAGTTGCCATCTGGTGCTCAC"),
+        (3, 11162, "GGATGAAATGAGTTGCCATCTGGTGCTCACC"), (3, 11163, "GGATGAAATGAGTTGCCATCTGGTGCTCACCA"),
+        (3, 11164, "GGATGAAATGAGTTGCCATCTGGTGCTCACCACG"), (3, 11165, "GGATGAAATGAGTTGCCATCTGGTGCTCACCACGG")]
+    with pytest.raises(RuntimeError):
+        rm1.get_reads_containing(ecoli.seqset.find("TGAAATGAGTTGCCATCTGGTGCTCAC"))
+    st1, st2 = rm1.get_pair_stats(), rm2.get_pair_stats()                                 # test_pair_stats
+    assert (st1.paired_reads, st1.paired_bases, st1.unpaired_reads, st1.unpaired_bases) == (0, 0, 8444, 288464)
+    assert (st2.paired_reads, st2.paired_bases, st2.unpaired_reads, st2.unpaired_bases) == (25762, 2576200, 12285, 1228500)
+    cov = rm1.get_approx_seq_coverage("GGATGAAATGAGTTGCCATCTGGTGCTCACCACGG")             # readmap.cpp:350-411
+    # the 35-base read (id 11165 and its 34-, 32-, 31-, 30-base prefixes... each read ending inside the sequence counts
+    # over its own span): every position is covered by the full read at least
+    assert len(cov) == 35 and min(cov) >= 1 and max(cov) >= 2 and cov[0] >= cov[-1]
     with pytest.raises(RuntimeError):   # two samples: a readmap must be named (biograph_dir.cpp:108-111)
         merged.open_readmap("")
     assert merged.metadata.samples.keys() == {"test_accession_id", "e_coli_test"}
