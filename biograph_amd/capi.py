@@ -64,6 +64,7 @@ SYMBOLS = [
     "bg_push_trace", "bg_pop_trace", "bg_trace_result_anchor_drops", "bg_push_front_chains", "bg_sha1_file", "bg_tracer_open", "bg_tracer_clone", "bg_tracer_trace", "bg_tracer_close", "bg_reference_build", "bg_bwt_build", "bg_trace_result_size", "bg_trace_result_get", "bg_trace_result_stats", "bg_trace_result_free", "bg_assemblies_process", "bg_trace_result_new", "bg_trace_result_add", "bg_trace_result_var_count", "bg_trace_result_var", "bg_coverage_options_default", "bg_assemblies_coverage", "bg_coverage_open", "bg_coverage_run", "bg_coverage_close", "bg_trace_result_coverage", "bg_trace_result_set_coverage", "bg_assemblies_rvg_exclude", "bg_vcf_record", "bg_walk_chains", "bg_walk_chains_batch", "bg_trace_result_ml", "bg_trace_result_set_ml", "bg_branch_trace_batch", "bg_ref_map_build",
     "bg_readmap_build", "bg_readmap_build_marked", "bg_seqset_mark_inputs", "bg_readmap_size", "bg_readmap_max_read_len", "bg_readmap_part", "bg_readmap_write",
     "bg_readmap_free", "bg_create_sample", "bg_readmap_open", "bg_readmap_from_arrays", "bg_readmap_arrays",
+    "bg_cover_filter_build", "bg_cover_query_scan", "bg_cover_query_scan_answers", "bg_cover_query_records_split", "bg_cover_query_records_live",
     "bg_seqset_find_rows", "bg_readmap_rows", "bg_readmap_shard_build", "bg_readmap_shard_size", "bg_readmap_shard_free",
     "bg_readmap_shard_first_claims", "bg_readmap_shard_apply_claims", "bg_readmap_shard_take_replies", "bg_readmap_shard_columns", "bg_prefix_reads_batch",
     "bg_read_info_batch", "bg_propagate_from_end_batch", "bg_push_to_pair_trace_batch",
@@ -218,6 +219,11 @@ def lib():
     L.bg_readmap_open.argtypes = [vp, C.c_char_p, P(vp)]
     L.bg_readmap_arrays.argtypes = [vp, vp, vp, vp, vp, vp]
     L.bg_readmap_from_arrays.argtypes = [vp, u64, u32, C.c_char_p, u64, vp, vp, vp, vp, P(vp)]
+    L.bg_cover_filter_build.argtypes = [vp, vp, i32, vp]
+    L.bg_cover_query_scan.argtypes = [vp, vp, vp, i32, u32, u32, vp, vp, u64, vp, P(u64)]
+    L.bg_cover_query_scan_answers.argtypes = [vp, vp, vp, vp, u64]
+    L.bg_cover_query_records_split.argtypes = [vp, vp, i32, i32, u32, vp, vp, u64, vp, P(u64)]
+    L.bg_cover_query_records_live.argtypes = [vp, vp, i32, P(u64)]
     L.bg_seqset_find_rows.argtypes = [vp, vp, vp, u64, i32, u64, vp]
     L.bg_readmap_rows.argtypes = [vp, vp, i32, vp, u32, vp, vp, u64, P(u64)]
     L.bg_readmap_shard_build.argtypes = [vp, vp, u64, P(vp)]

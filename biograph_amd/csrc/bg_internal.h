@@ -253,6 +253,11 @@ struct bg_cover_query {
   bg::DevBuf<uint64_t> owords;
   bg::DevBuf<uint8_t> olen;
   bg::DevBuf<uint32_t> pending;
+  // filtered rounds (bg_cover_query_scan): per oriented read the next suffix to look at and, once settled, the first
+  // covered suffix (= its length when none is); per slot of the round in flight the suffixes that went out
+  bg::DevBuf<uint8_t> cursor, hit_j;
+  bg::DevBuf<uint16_t> end_j;  // 0xffff = not settled (a read may be 255 bases long)
+  uint32_t max_hits = 0;
 };
 
 namespace bg {

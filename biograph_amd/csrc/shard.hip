@@ -555,6 +555,327 @@ extern "C" int bg_cover_query_candidates_split(bg_ctx* ctx, bg_cover_query* q, i
   return BG_OK;
 }
 
+
+// ---- filtered cover rounds -------------------------------------------------------------------------------------------------
+// The rounds above ship EVERY suffix j of a window to its owner to learn which is the first covered one.  A suffix can
+// only be covered by a read that starts with its first K bases, and the owners know those K-mers: every owner marks the
+// first K-mers of the reads it indexes in a bit filter of its own (two bits of one 64-bit word per key), the filters are
+// all-gathered (they are disjoint by owner: no reduction), and a sender looks a suffix's K-mer up in its owner's filter
+// before it sends anything.  A miss is exact -- the suffix is uncovered and simply becomes a record; only hits (the
+// covered suffixes plus a false-positive rate of ~0.5 %) travel as candidates to be verified with bg_cover_test.  Same
+// records as the window rounds (the first VERIFIED cover ends a read), about one candidate per read instead of nine.
+__device__ __forceinline__ uint64_t filter_mix(uint64_t key) {
+  uint64_t h = key * 0x9E3779B97F4A7C15ull;
+  h ^= h >> 29;
+  h *= 0xBF58476D1CE4E5B9ull;
+  return h ^ (h >> 32);
+}
+__device__ __forceinline__ uint64_t filter_mask(uint64_t h) { return (1ull << ((h >> 8) & 63)) | (1ull << ((h >> 16) & 63)); }
+
+__global__ void k_filter_add(const uint64_t* __restrict__ owords, const uint8_t* __restrict__ olen, uint64_t n, int W, int K,
+                             int log2w, unsigned long long* __restrict__ bits) {
+  const uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (o >= n || int(olen[o]) < K) return;  // a read shorter than K covers nothing that is looked up
+  const uint64_t h = filter_mix(owords[o * uint64_t(W)] >> (64 - 2 * K));
+  atomicOr(&bits[h >> (64 - log2w)], (unsigned long long)filter_mask(h));
+}
+
+// one lane per pending read: from its cursor, the next suffixes whose K-mer the owner's filter knows (up to max_hits);
+// the cursor moves past what was looked at; a read that runs out of suffixes with K bases is settled (no cover).
+__global__ void k_query_scan(const uint64_t* __restrict__ owords, const uint8_t* __restrict__ olen, const uint32_t* __restrict__ pending,
+                             uint64_t n_pending, int W, int K, const uint64_t* __restrict__ filter, int log2w, int hb,
+                             const uint32_t* __restrict__ splitters, uint32_t nparts, uint32_t max_hits, uint8_t* __restrict__ cursor,
+                             uint16_t* __restrict__ end_j, uint8_t* __restrict__ hit_j, uint64_t* __restrict__ dest) {
+  const uint64_t slot = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (slot >= n_pending) return;
+  const uint32_t o = pending[slot];
+  const int L = olen[o];
+  const uint64_t* s = owords + uint64_t(o) * W;
+  int j = cursor[o];
+  uint32_t hits = 0;
+  while (j < L && hits < max_hits) {
+    if (L - j < K) { j = L; break; }  // shorter suffixes are never looked up
+    const uint64_t w0 = window32(s, W, j);
+    const uint32_t bin = uint32_t(w0 >> (64 - 2 * hb));
+    uint32_t d = 0;
+    for (uint32_t q = 0; q + 1 < nparts; ++q) d += (splitters[q] <= bin) ? 1u : 0u;
+    const uint64_t h = filter_mix(w0 >> (64 - 2 * K));
+    const uint64_t m = filter_mask(h);
+    if ((filter[(uint64_t(d) << log2w) + (h >> (64 - log2w))] & m) == m) {
+      hit_j[slot * max_hits + hits] = uint8_t(j);
+      dest[slot * max_hits + hits] = d;
+      ++hits;
+    }
+    ++j;
+  }
+  cursor[o] = uint8_t(j);
+  for (uint32_t x = hits; x < max_hits; ++x) dest[slot * max_hits + x] = kDropDest;
+  if (!hits) end_j[o] = uint16_t(L);  // ran to the end without a candidate: uncovered
+}
+
+__global__ void k_gather_pending_slots(const uint32_t* __restrict__ pending, const uint32_t* __restrict__ keep_slots, uint64_t m,
+                                       uint32_t* __restrict__ out) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < m) out[i] = pending[keep_slots[i]];
+}
+
+struct HitSource {  // row t = suffix hit_j[t] of pending read t / max_hits
+  const uint64_t* owords;
+  const uint8_t* olen;
+  const uint32_t* pending;
+  const uint8_t* hit_j;
+  int W;
+  uint32_t max_hits;
+  __device__ __forceinline__ uint64_t word(uint64_t t, int w) const {
+    const uint32_t o = pending[t / max_hits];
+    const int j = hit_j[t];
+    if (w == W) return uint64_t(int(olen[o]) - j) | (t << 24);
+    return window32(owords + uint64_t(o) * W, W, j + 32 * w);
+  }
+};
+
+__global__ void k_scan_first_cover(const uint64_t* __restrict__ rows_sent, const uint8_t* __restrict__ covered, uint64_t n, int W,
+                                   uint32_t max_hits, const uint8_t* __restrict__ hit_j, uint32_t* __restrict__ first_cov) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n || !covered[i]) return;
+  const uint64_t t = rows_sent[i * uint64_t(W + 1) + W] >> 24;
+  atomicMin(&first_cov[t / max_hits], uint32_t(hit_j[t]));
+}
+
+__global__ void k_scan_settle(const uint32_t* __restrict__ pending, uint64_t n_pending, const uint32_t* __restrict__ first_cov,
+                              uint16_t* __restrict__ end_j, uint8_t* __restrict__ flags) {
+  const uint64_t slot = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (slot >= n_pending) return;
+  const uint32_t o = pending[slot];
+  if (first_cov[slot] != 0xffffffffu) end_j[o] = uint16_t(first_cov[slot]);
+  flags[slot] = end_j[o] == 0xffffu ? 1 : 0;  // still unsettled: the scan goes on behind the candidates that failed
+}
+
+// records of the window [j_lo, j_hi): suffix j of read o is a record iff 1 <= j < end_j[o] (suffixes with fewer than K
+// bases included)
+struct RecordSource {
+  const uint64_t* owords;
+  const uint8_t* olen;
+  const uint32_t* pending;
+  int W, j_lo, span;
+  __device__ __forceinline__ uint64_t word(uint64_t t, int w) const {
+    const uint64_t slot = t / uint64_t(span);
+    const int j = j_lo + int(t - slot * uint64_t(span));
+    const uint32_t o = pending[slot];
+    if (w == W) return uint64_t(int(olen[o]) - j);
+    return window32(owords + uint64_t(o) * W, W, j + 32 * w);
+  }
+};
+
+__global__ void k_dest_records(RecordSource rs, const uint16_t* __restrict__ end_j, uint64_t total, int hb,
+                               const uint32_t* __restrict__ splitters, uint32_t nparts, uint64_t* __restrict__ dest) {
+  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const uint64_t slot = t / uint64_t(rs.span);
+  const int j = rs.j_lo + int(t - slot * uint64_t(rs.span));
+  const uint32_t o = rs.pending[slot];
+  if (j >= int(end_j[o])) { dest[t] = kDropDest; return; }
+  const uint32_t bin = uint32_t(window32(rs.owords + uint64_t(o) * rs.W, rs.W, j) >> (64 - 2 * hb));
+  uint32_t d = 0;
+  for (uint32_t q = 0; q + 1 < nparts; ++q) d += (splitters[q] <= bin) ? 1u : 0u;
+  dest[t] = d;
+}
+
+__global__ void k_flag_end_beyond(const uint16_t* __restrict__ end_j, uint64_t n, int j_lo, uint8_t* __restrict__ flags) {
+  const uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (o < n) flags[o] = (end_j[o] != 0xffffu && int(end_j[o]) > j_lo) ? 1 : 0;
+}
+__global__ void k_init_scan_state(const uint8_t* __restrict__ olen, uint64_t n, uint8_t* __restrict__ cursor, uint16_t* __restrict__ end_j) {
+  const uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  cursor[o] = 1;
+  end_j[o] = olen[o] >= 2 ? 0xffffu : olen[o];  // 0xffff = not settled
+}
+
+// rows of `src` (one per slot; dest[t] = destination or kDropDest) written in partitioned order
+template <class Source>
+static int msplit_generate(bg_ctx* ctx, const Source& src, const uint64_t* d_dest, uint64_t total, int rw, uint32_t nparts,
+                           uint64_t* d_out_rows, uint64_t cap, uint64_t* h_counts, uint64_t* n_out, const char* who) {
+  DevBuf<uint32_t> tcounts;
+  DevBuf<uint64_t> toffs;
+  DevBuf<unsigned long long> counts;
+  const uint32_t ntiles = uint32_t((total + MS_TILE - 1) / MS_TILE);
+  BG_TRY(counts.alloc(ctx, 256));
+  BG_TRY(tcounts.alloc(ctx, uint64_t(nparts) * ntiles));
+  BG_TRY(toffs.alloc(ctx, uint64_t(nparts) * ntiles));
+  BG_HIP(hipMemsetAsync(counts.p, 0, 256 * 8, ctx->stream));
+  unsigned grid = cdiv(total, 256) < 1024u ? cdiv(total, 256) : 1024u;
+  k_dest_counts<<<grid, 256, 0, ctx->stream>>>(d_dest, total, counts.p);
+  BG_LAUNCH_CHECK();
+  ctx->tic("partition_split");
+  k_msplit_count<<<ntiles, 256, 0, ctx->stream>>>(d_dest, total, nparts, tcounts.p, ntiles);
+  BG_LAUNCH_CHECK();
+  BG_TRY(exclusive_scan_u32_to_u64(ctx, tcounts.p, toffs.p, uint64_t(nparts) * ntiles, nullptr));
+  unsigned long long hc[256];
+  BG_HIP(hipMemcpyAsync(hc, counts.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  uint64_t n_rows = 0;
+  for (uint32_t p = 0; p < nparts; ++p) { h_counts[p] = hc[p]; n_rows += hc[p]; }
+  if (n_rows > cap || (n_rows && !d_out_rows)) { set_error("%s: room for %llu rows, %llu needed", who, (unsigned long long)cap, (unsigned long long)n_rows); return BG_EINVAL; }
+  if (n_rows) {
+    k_msplit_scatter<<<ntiles, 256, 0, ctx->stream>>>(src, d_dest, total, rw, nparts, toffs.p, ntiles, d_out_rows);
+    BG_LAUNCH_CHECK();
+  }
+  ctx->toc(n_rows * uint64_t(rw) * 8 + total * 16);
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  *n_out = n_rows;
+  return BG_OK;
+}
+
+static int split_params(const uint64_t* h_params, uint32_t nparts, int* hb, std::vector<uint32_t>* sp, const char* who) {
+  *hb = int(h_params[0]);
+  if (*hb < 1 || *hb > 16) { set_error("%s: prefix bases %d outside 1..16", who, *hb); return BG_EINVAL; }
+  sp->assign(nparts, 0);
+  for (uint32_t x = 0; x + 1 < nparts; ++x) (*sp)[x] = uint32_t(h_params[1 + x]);
+  return BG_OK;
+}
+
+extern "C" int bg_cover_filter_build(bg_ctx* ctx, const bg_cover* c, int log2_words, uint64_t* d_bits) {
+  if (!ctx || !c || !d_bits) { set_error("bg_cover_filter_build: null argument"); return BG_EINVAL; }
+  if (log2_words < 4 || log2_words > 36) { set_error("bg_cover_filter_build: 2^%d words outside 2^4..2^36", log2_words); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  BG_HIP(hipMemsetAsync(d_bits, 0, (size_t(1) << log2_words) * 8, ctx->stream));
+  if (c->n) {
+    ctx->tic("cover_filter");
+    k_filter_add<<<cdiv(c->n, 256), 256, 0, ctx->stream>>>(c->owords.p, c->olen.p, c->n, c->W, c->K, log2_words,
+                                                          reinterpret_cast<unsigned long long*>(d_bits));
+    BG_LAUNCH_CHECK();
+    ctx->toc(c->n * 24);
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
+extern "C" int bg_cover_query_scan(bg_ctx* ctx, bg_cover_query* q, const uint64_t* d_filter, int log2_words, uint32_t max_hits,
+                                   uint32_t nparts, const uint64_t* h_params, uint64_t* d_out_rows, uint64_t cap, uint64_t* h_counts,
+                                   uint64_t* n_out) {
+  if (!ctx || !q || !d_filter || !h_params || !h_counts || !n_out) { set_error("bg_cover_query_scan: null argument"); return BG_EINVAL; }
+  if (nparts < 1 || nparts > 128 || max_hits < 1 || max_hits > 64) { set_error("bg_cover_query_scan: bad geometry"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  for (uint32_t p = 0; p < nparts; ++p) h_counts[p] = 0;
+  *n_out = 0;
+  if (!q->cursor.p) {  // first scan: every read starts at suffix 1
+    BG_TRY(q->cursor.alloc(ctx, q->n));
+    BG_TRY(q->end_j.alloc(ctx, q->n));
+    if (q->n) {
+      k_init_scan_state<<<cdiv(q->n, 256), 256, 0, ctx->stream>>>(q->olen.p, q->n, q->cursor.p, q->end_j.p);
+      BG_LAUNCH_CHECK();
+    }
+  }
+  q->max_hits = max_hits;
+  const uint64_t total = q->n_pending * uint64_t(max_hits);
+  if (!total) return BG_OK;
+  if (total >= (1ull << 32)) { set_error("bg_cover_query_scan: round too large"); return BG_EINVAL; }
+  int hb = 0;
+  std::vector<uint32_t> sp;
+  BG_TRY(split_params(h_params, nparts, &hb, &sp, "bg_cover_query_scan"));
+  DevBuf<uint32_t> dsp;
+  DevBuf<uint64_t> da;
+  BG_TRY(dsp.alloc(ctx, nparts));
+  BG_TRY(da.alloc(ctx, total));
+  BG_TRY(q->hit_j.alloc(ctx, total));
+  BG_HIP(hipMemcpyAsync(dsp.p, sp.data(), nparts * 4, hipMemcpyHostToDevice, ctx->stream));
+  ctx->tic("cover_scan");
+  k_query_scan<<<cdiv(q->n_pending, 128), 128, 0, ctx->stream>>>(q->owords.p, q->olen.p, q->pending.p, q->n_pending, q->W, q->K, d_filter,
+                                                                log2_words, hb, dsp.p, nparts, max_hits, q->cursor.p, q->end_j.p,
+                                                                q->hit_j.p, da.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(q->n_pending * (uint64_t(q->W) * 8 + 64));
+  BG_HIP(hipStreamSynchronize(ctx->stream));  // sp goes out of scope with the function
+  const HitSource src{q->owords.p, q->olen.p, q->pending.p, q->hit_j.p, q->W, max_hits};
+  return msplit_generate(ctx, src, da.p, total, q->W + 1, nparts, d_out_rows, cap, h_counts, n_out, "bg_cover_query_scan");
+}
+
+extern "C" int bg_cover_query_scan_answers(bg_ctx* ctx, bg_cover_query* q, const uint64_t* d_rows_sent, const uint8_t* d_covered,
+                                           uint64_t n) {
+  if (!ctx || !q || (n && (!d_rows_sent || !d_covered))) { set_error("bg_cover_query_scan_answers: null argument"); return BG_EINVAL; }
+  if (!q->max_hits || !q->end_j.p) { set_error("bg_cover_query_scan_answers: no scan in flight"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  DevBuf<uint32_t> fc, keep_slots, np;
+  DevBuf<uint8_t> flags;
+  BG_TRY(fc.alloc(ctx, q->n_pending));
+  BG_TRY(flags.alloc(ctx, q->n_pending));
+  if (q->n_pending) BG_HIP(hipMemsetAsync(fc.p, 0xff, q->n_pending * 4, ctx->stream));
+  if (n) {
+    k_scan_first_cover<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_rows_sent, d_covered, n, q->W, q->max_hits, q->hit_j.p, fc.p);
+    BG_LAUNCH_CHECK();
+  }
+  uint64_t m = 0;
+  if (q->n_pending) {
+    k_scan_settle<<<cdiv(q->n_pending, 256), 256, 0, ctx->stream>>>(q->pending.p, q->n_pending, fc.p, q->end_j.p, flags.p);
+    BG_LAUNCH_CHECK();
+  }
+  BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, q->n_pending, &keep_slots, &m));
+  BG_TRY(np.alloc(ctx, m));
+  if (m) {
+    k_gather_pending_slots<<<cdiv(m, 256), 256, 0, ctx->stream>>>(q->pending.p, keep_slots.p, m, np.p);
+    BG_LAUNCH_CHECK();
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  q->pending = std::move(np);
+  q->n_pending = m;
+  q->max_hits = 0;
+  return BG_OK;
+}
+
+// The records of the suffix window [j_lo, j_hi) of all settled reads (every read must be: no scan pending), written in
+// partitioned order.  n_reads_out (may be NULL) = reads with records at or beyond j_hi (0: this was the last window).
+extern "C" int bg_cover_query_records_split(bg_ctx* ctx, bg_cover_query* q, int j_lo, int j_hi, uint32_t nparts, const uint64_t* h_params,
+                                            uint64_t* d_out_rows, uint64_t cap, uint64_t* h_counts, uint64_t* n_out) {
+  if (!ctx || !q || !h_params || !h_counts || !n_out) { set_error("bg_cover_query_records_split: null argument"); return BG_EINVAL; }
+  if (j_lo < 1 || j_hi <= j_lo || j_hi > 256 || nparts < 1 || nparts > 128) { set_error("bg_cover_query_records_split: bad geometry"); return BG_EINVAL; }
+  if (q->n_pending) { set_error("bg_cover_query_records_split: %llu reads are not settled yet", (unsigned long long)q->n_pending); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  for (uint32_t p = 0; p < nparts; ++p) h_counts[p] = 0;
+  *n_out = 0;
+  if (!q->n || !q->end_j.p) return BG_OK;
+  DevBuf<uint8_t> flags;
+  DevBuf<uint32_t> live;
+  BG_TRY(flags.alloc(ctx, q->n));
+  k_flag_end_beyond<<<cdiv(q->n, 256), 256, 0, ctx->stream>>>(q->end_j.p, q->n, j_lo, flags.p);
+  BG_LAUNCH_CHECK();
+  uint64_t n_live = 0;
+  BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, q->n, &live, &n_live));
+  const int span = j_hi - j_lo;
+  const uint64_t total = n_live * uint64_t(span);
+  if (!total) return BG_OK;
+  if (total >= (1ull << 32)) { set_error("bg_cover_query_records_split: window too large"); return BG_EINVAL; }
+  int hb = 0;
+  std::vector<uint32_t> sp;
+  BG_TRY(split_params(h_params, nparts, &hb, &sp, "bg_cover_query_records_split"));
+  DevBuf<uint32_t> dsp;
+  DevBuf<uint64_t> da;
+  BG_TRY(dsp.alloc(ctx, nparts));
+  BG_TRY(da.alloc(ctx, total));
+  BG_HIP(hipMemcpyAsync(dsp.p, sp.data(), nparts * 4, hipMemcpyHostToDevice, ctx->stream));
+  const RecordSource rs{q->owords.p, q->olen.p, live.p, q->W, j_lo, span};
+  ctx->tic("partition_dest");
+  k_dest_records<<<cdiv(total, 256), 256, 0, ctx->stream>>>(rs, q->end_j.p, total, hb, dsp.p, nparts, da.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(total * 24);
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return msplit_generate(ctx, rs, da.p, total, q->W + 1, nparts, d_out_rows, cap, h_counts, n_out, "bg_cover_query_records_split");
+}
+
+// reads with records at or beyond suffix j_lo (the size of a records window: x span rows at most)
+extern "C" int bg_cover_query_records_live(bg_ctx* ctx, const bg_cover_query* q, int j_lo, uint64_t* n_out) {
+  if (!ctx || !q || !n_out) { set_error("bg_cover_query_records_live: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  *n_out = 0;
+  if (!q->n || !q->end_j.p) return BG_OK;
+  DevBuf<uint8_t> flags;
+  DevBuf<uint32_t> live;
+  BG_TRY(flags.alloc(ctx, q->n));
+  k_flag_end_beyond<<<cdiv(q->n, 256), 256, 0, ctx->stream>>>(q->end_j.p, q->n, j_lo, flags.p);
+  BG_LAUNCH_CHECK();
+  return compact_flagged<uint32_t>(ctx, flags.p, q->n, &live, n_out);
+}
+
 // ---- reads export / import ----------------------------------------------------------------------
 
 extern "C" int bg_reads_words(const bg_reads* r) { return r ? r->W : 0; }

@@ -1856,10 +1856,17 @@ extern "C" int bg_pop_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext
     if (!push[i]) return fail("bg_pop_trace: null push result");
     for (const auto& d : push[i]->anchor_drops) drops.push_back(&d);
   }
+  const double t0 = now_seconds();
   BG_TRY(pt.add_anchor_drops(drops, rev_comp != 0));
+  const double t1 = now_seconds();
   if (rev_comp) BG_TRY(pt.add_reference(end_pos - limit_offset, end_pos - start_offset));
   else BG_TRY(pt.add_reference(start_offset, limit_offset));
+  const double t2 = now_seconds();
+  const size_t n_fronts = pt.fronts.size(), n_poppers = pt.poppers.size();
   BG_TRY(pt.assemble());
+  if (getenv("BG_TRACER_TIMING"))
+    fprintf(stderr, "bg_pop_trace: %zu anchor drops %.3f s, reference %.3f s (%zu fronts), assemble %.3f s (%zu poppers, %llu device rounds), %zu assemblies\n",
+            drops.size(), t1 - t0, t2 - t1, n_fronts, now_seconds() - t2, n_poppers, (unsigned long long)pt.device_rounds, pt.out.size());
   // sorter(left_offset_less_than) -> pair_counter -> (reversed back) (reversable_tracer.cpp:118-126)
   std::sort(pt.out.begin(), pt.out.end(), [](const bg_trace_assembly_rec& a, const bg_trace_assembly_rec& b) { return a.left_offset < b.left_offset; });
   std::vector<bg_trace_assembly_rec> counted;

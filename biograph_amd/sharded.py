@@ -484,6 +484,8 @@ def _records_sharded_cover(comm, ctxs, corrected, W, k, dev, ph):
         covers[r] = ch
         parts[r] = [t]  # the oriented reads a rank indexes are its j = 0 records
     del recv
+    if os.environ.get("BG_COVER_MODE", "filtered") != "windows":
+        return _filtered_cover_rounds(comm, ctxs, covers, qs, parts, W, k, dev, ph, pparams)
     bounds = [int(x) for x in os.environ.get("BG_COVER_ROUNDS", COVER_ROUNDS).split(",")]
     if bounds[-1] < 256:
         bounds.append(256)
@@ -547,6 +549,104 @@ def _records_sharded_cover(comm, ctxs, corrected, W, k, dev, ph):
         parts[r] = [t.contiguous() for t in parts[r] if t.shape[0]]
     n_records = _all_sum(comm, {r: sum(t.shape[0] for t in parts[r]) for r in ranks})
     return parts, n_records  # a list of row arrays per rank: bg_records_from_row_parts takes them as they are
+
+
+# hits per pending read and round of the filtered cover: one at first (nine reads in ten are settled by their first hit),
+# more once few reads are left, so that the tail of reads whose candidates keep failing ends after a few rounds
+COVER_SCAN_HITS = "1,2,4,16,64"
+# suffix windows the records are generated in (one all_to_all each): most reads have all their records in the first
+COVER_RECORD_WINDOWS = "1,9,33,256"
+
+
+def _filtered_cover_rounds(comm, ctxs, covers, qs, parts, W, k, dev, ph, pparams):
+    """The cover rounds with the owners' first-K-mer filters on every rank (csrc/shard.hip: bg_cover_filter_build,
+    bg_cover_query_scan / _scan_answers / _records_split): a sender asks only about suffixes whose K-mer some read starts
+    with.  Collectives: one all_gather (filters), one all_to_all + reply per scan round, one all_to_all per record window."""
+    L = capi.lib()
+    P = comm.world
+    ranks = comm.local_ranks
+    i64 = torch.int64
+    rw = W + 1
+    pp = np.ascontiguousarray(pparams, np.uint64)
+    ph.mark("cover_filters")
+    owned = [row[0] for row in comm.gather_ints({r: [sum(t.shape[0] for t in parts[r])] for r in ranks})]
+    log2w = max(10, int(np.ceil(np.log2(max(max(owned), 1) / 2.0))))  # 32 bits per indexed read, in 64-bit words
+    bits = {}
+    for r in ranks:
+        bits[r] = torch.empty((1 << log2w,), dtype=i64, device=dev[r])
+        capi.check(L.bg_cover_filter_build(ctxs[r].h, covers[r], log2w, _ptr(bits[r])))
+    gathered = comm.all_gather_v(bits)
+    filt = {r: torch.cat([g.to(dev[r]) for g in gathered[r]]).contiguous() for r in ranks}
+    del bits, gathered
+    hits_plan = [int(x) for x in os.environ.get("BG_COVER_SCAN_HITS", COVER_SCAN_HITS).split(",")]
+    rnd = 0
+    while True:
+        pend = {r: int(L.bg_cover_query_pending(qs[r])) for r in ranks}
+        if _all_sum(comm, pend) == 0:
+            break
+        hits = hits_plan[min(rnd, len(hits_plan) - 1)]
+        ph.mark("cover_scan_%d" % rnd)
+        rnd += 1
+        cand = {}
+        for r in ranks:
+            cap = pend[r] * hits
+            t = torch.empty((max(cap, 1), rw), dtype=i64, device=dev[r])
+            n = C.c_uint64()
+            counts = (C.c_uint64 * P)()
+            capi.check(L.bg_cover_query_scan(ctxs[r].h, qs[r], _ptr(filt[r]), log2w, hits, P, capi.np_ptr(pp), _ptr(t), cap, counts,
+                                             C.byref(n)))
+            cand[r] = (t[:n.value], [int(c) for c in counts])
+            del t
+        got, cm = comm.all_to_all_v(cand)
+        back = {}
+        for r in ranks:
+            t = got[r].contiguous()
+            cv = torch.empty((max(t.shape[0], 1),), dtype=torch.uint8, device=dev[r])
+            capi.check(L.bg_cover_test(ctxs[r].h, covers[r], _ptr(t), t.shape[0], _ptr(cv)))
+            back[r] = cv[:t.shape[0]].view(-1, 1)
+        del got
+        ans = comm.all_to_all_reply(back, cm)
+        for r in ranks:
+            a = ans[r].contiguous().view(-1)
+            sent = cand[r][0]
+            capi.check(L.bg_cover_query_scan_answers(ctxs[r].h, qs[r], _ptr(sent), _ptr(a), sent.shape[0]))
+        del cand, back, ans
+    del filt
+    for r in ranks:
+        L.bg_cover_free(covers[r])
+    covers.clear()
+    _relieve(ctxs, dev)
+    wins = [int(x) for x in os.environ.get("BG_COVER_RECORD_WINDOWS", COVER_RECORD_WINDOWS).split(",")]
+    if wins[-1] < 256:
+        wins.append(256)
+    for j_lo, j_hi in zip(wins[:-1], wins[1:]):
+        ph.mark("cover_records_%d" % j_lo)
+        live = {}
+        for r in ranks:
+            n = C.c_uint64()
+            capi.check(L.bg_cover_query_records_live(ctxs[r].h, qs[r], j_lo, C.byref(n)))
+            live[r] = n.value
+        if _all_sum(comm, live) == 0:
+            break
+        send = {}
+        for r in ranks:
+            cap = live[r] * (j_hi - j_lo)
+            t = torch.empty((max(cap, 1), rw), dtype=i64, device=dev[r])
+            n = C.c_uint64()
+            counts = (C.c_uint64 * P)()
+            capi.check(L.bg_cover_query_records_split(ctxs[r].h, qs[r], j_lo, j_hi, P, capi.np_ptr(pp), _ptr(t), cap, counts, C.byref(n)))
+            send[r] = (t[:n.value], [int(c) for c in counts])
+            del t
+        got, _ = comm.all_to_all_v(send)
+        for r in ranks:
+            parts[r].append(got[r])
+        del send, got
+        _relieve(ctxs, dev)
+    for r in ranks:
+        L.bg_cover_query_free(qs[r])
+        parts[r] = [t.contiguous() for t in parts[r] if t.shape[0]]
+    n_records = _all_sum(comm, {r: sum(t.shape[0] for t in parts[r]) for r in ranks})
+    return parts, n_records
 
 
 class SeqsetSlice:

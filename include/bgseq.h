@@ -895,6 +895,24 @@ int bg_cover_query_answers(bg_ctx* ctx, bg_cover_query* q, const uint64_t* d_row
                            uint64_t n, uint8_t* d_keep_out);
 int bg_cover_query_plain(bg_ctx* ctx, bg_cover_query* q, uint64_t* d_rows, uint64_t cap, uint64_t* n_out);
 void bg_cover_query_free(bg_cover_query* q);
+/* Filtered rounds (csrc/shard.hip): a suffix can only be covered by a read that starts with its first K bases, so every
+ * owner marks the first K-mers of the reads it indexes in a bit filter of 2^log2_words 64-bit words
+ * (bg_cover_filter_build); the owners' filters, all-gathered in rank order (d_filter = nparts x 2^log2_words words), let
+ * the sender skip every suffix whose K-mer no read starts with -- a miss is exact, such a suffix is a record.
+ *   bg_cover_query_scan          per pending read the next <= max_hits suffixes the owner's filter knows, as candidate rows
+ *                                in partitioned order (bg_cover_test them at the owner); a read that runs out is settled
+ *   bg_cover_query_scan_answers  answers in sent order: the first verified cover settles a read, the others scan on
+ *   bg_cover_query_records_split once nothing is pending: the records (suffixes 1 <= j < first cover, short tails
+ *                                included) of the window [j_lo, j_hi), in partitioned order; _records_live = reads that
+ *                                have records at or beyond j_lo (x (j_hi - j_lo) bounds the window's rows)
+ * Same records as bg_cover_query_candidates / _answers / _plain, with about one candidate per read instead of nine. */
+int bg_cover_filter_build(bg_ctx* ctx, const bg_cover* c, int log2_words, uint64_t* d_bits);
+int bg_cover_query_scan(bg_ctx* ctx, bg_cover_query* q, const uint64_t* d_filter, int log2_words, uint32_t max_hits, uint32_t nparts,
+                        const uint64_t* h_params, uint64_t* d_out_rows, uint64_t cap, uint64_t* h_counts, uint64_t* n_out);
+int bg_cover_query_scan_answers(bg_ctx* ctx, bg_cover_query* q, const uint64_t* d_rows_sent, const uint8_t* d_covered, uint64_t n);
+int bg_cover_query_records_split(bg_ctx* ctx, bg_cover_query* q, int j_lo, int j_hi, uint32_t nparts, const uint64_t* h_params,
+                                 uint64_t* d_out_rows, uint64_t cap, uint64_t* h_counts, uint64_t* n_out);
+int bg_cover_query_records_live(bg_ctx* ctx, const bg_cover_query* q, int j_lo, uint64_t* n_out);
 
 /* ---- One device arena for the library AND torch (optional; biograph_amd.use_shared_arena()).  bg_torch_malloc /
  * bg_torch_free have the signature torch.cuda.memory.CUDAPluggableAllocator expects; once torch allocates through
