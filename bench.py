@@ -52,9 +52,7 @@ def cpu_baseline(ctx, sample_genome, coverage, read_len, seed, dev):
     oss = O.Seqset.from_entries(ent, threads=threads)
     stages["make_seqset"] = time.perf_counter() - t0
     t0 = time.perf_counter()
-    corrected = O.unpack_strings(cseq, coffs)
-    records = [tuple(s for s in corrected[i:i + 2] if s) for i in range(0, len(corrected), 2)]
-    orm = O.Readmap(oss, ent, [rec for rec in records if rec], True)
+    orm = O.Readmap.from_packed(oss, ent, cseq, coffs, True)
     stages["make_readmap"] = time.perf_counter() - t0
     dt = sum(stages.values())
     bases = int(offs[-1])
@@ -402,7 +400,9 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
                # candidate SITES (one-base branches) through branch -> propagate -> extension; the anchored variants of the
                # whole pipeline, host bookkeeping included, are graph_discover_driver.anchored_variants_per_s
                "candidate_sites_per_s_kernels_only": round(ns / (t_br + t_prop + t_tr), 1)}
-    drv = driver_leg(ctx, ss, genome, dev, args, rm=rm) if args is not None else None
+    # the older graph-discover pipeline over the whole reference takes ~45 s and calls fewer of the planted variants than the
+    # engine `bgbinary discovery` runs (end_to_end_from_fastq.discovery): only on request
+    drv = driver_leg(ctx, ss, genome, dev, args, rm=rm) if (args is not None and getattr(args, "graph_discover_driver", False)) else None
     push = push_tracer_leg(ss, rm, out, genome, args) if args is not None else None
     rm.free()
     ss.free()
@@ -610,6 +610,8 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the `bgbinary create` from FASTQ files leg")
     ap.add_argument("--no-shared-arena", action="store_true",
                     help="sharded runs: keep torch's own caching allocator beside the library's arena")
+    ap.add_argument("--graph-discover-driver", action="store_true",
+                    help="also time the graph-discover drivers (branch + push_to_pair) over the whole reference (~45 s)")
     ap.add_argument("--no-sharded-readmap", action="store_true", help="sharded runs: skip the untimed build-with-readmap leg")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the sharded (RCCL) build path even with one rank (smoke test of the collectives)")

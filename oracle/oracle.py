@@ -606,6 +606,33 @@ class Readmap:
         self.n_entries = len(seqset)
 
     @classmethod
+    def from_packed(cls, seqset, entries, seq, offs, is_paired=True, canonicalize=True):
+        """The same from packed corrected reads (bases + offsets; an empty read = dropped by the correction): the records
+        are the consecutive pairs (or single reads) with their dropped members left out -- what biograph_create.cpp:880-889
+        hands make_readmap -- put together with numpy instead of Python strings."""
+        offs = np.ascontiguousarray(offs, np.uint64)
+        lens = (offs[1:] - offs[:-1]).astype(np.int64)
+        n = len(lens)
+        per = 2 if is_paired else 1
+        if n % per:
+            raise ValueError("from_packed: odd number of reads in a paired sample")
+        alive = lens > 0
+        per_rec = alive.reshape(-1, per).sum(axis=1)
+        rec_sizes = per_rec[per_rec > 0]
+        rec_first = np.zeros(len(rec_sizes) + 1, np.uint64)
+        rec_first[1:] = np.cumsum(rec_sizes)
+        keep_offs = np.zeros(int(alive.sum()) + 1, np.uint64)
+        keep_offs[1:] = np.cumsum(lens[alive])
+        # dropped reads are empty: the bases of the kept reads are the packed bases as they are
+        self = cls.__new__(cls)
+        self.h = lib().orc_readmap_build(seqset.h, entries.h, _pad(np.ascontiguousarray(seq)), keep_offs, int(alive.sum()), rec_first,
+                                         len(rec_sizes), int(is_paired), int(canonicalize))
+        if not self.h:
+            raise RuntimeError(lib().orc_readmap_error().decode())
+        self.n_entries = len(seqset)
+        return self
+
+    @classmethod
     def from_arrays(cls, n_entries, entry_id, read_len, mate_loop_ptr, is_forward, max_read_len):
         """A readmap read back from its container (decode_readmap) — for the query functions."""
         self = cls.__new__(cls)

@@ -39,3 +39,27 @@ def test_threaded_golden_ecoli(golden_dir):
     ss = O.Seqset.from_entries(ent, threads=4)
     ref = O.Seqset.from_entries(O.Entries.build(cseq, coffs, "cover", 30))
     assert ss.parts() == ref.parts()
+
+
+def test_readmap_from_packed_equals_readmap_from_strings():
+    """The CPU baseline's readmap leg (bench.py cpu_baseline) takes the packed corrected reads as they are; the records it
+    derives with numpy are the ones the string-based constructor gets."""
+    import numpy as np
+    from tests import util
+    reads = util.synth_reads(9, genome_len=3000, n_reads=2400, read_len=80, err=0.004, n_rate=0.0005, var_len=True)
+    seq, offs = O.pack_strings(reads)
+    ks = O.KmerSet.count(seq, offs, 20, 3)
+    cseq, coffs, keep, _ = O.correct_reads(ks, seq, offs, 8, 2, 0.7)
+    corrected = O.unpack_strings(cseq, coffs)
+    assert "" in corrected  # the sample is made so that the correction drops some reads
+    ent = O.Entries.build(cseq, coffs, "cover", 20)
+    oss = O.Seqset.from_entries(ent)
+    for paired in (True, False):
+        if paired:
+            records = [tuple(s for s in corrected[i:i + 2] if s) for i in range(0, len(corrected), 2)]
+        else:
+            records = [(s,) for s in corrected if s]
+        a = O.Readmap(oss, ent, [r for r in records if r], paired)
+        b = O.Readmap.from_packed(oss, ent, cseq, coffs, paired)
+        pa, pb = a.parts(), b.parts()
+        assert pa.keys() == pb.keys() and all(pa[k] == pb[k] for k in pa)
