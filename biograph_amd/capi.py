@@ -52,7 +52,7 @@ class CreateParams(C.Structure):
 
 # every symbol include/bgseq.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "bg_abi_version", "bg_last_error", "bg_ctx_create", "bg_ctx_create_own_stream", "bg_ctx_destroy", "bg_ctx_trim", "bg_ctx_timings",
+    "bg_abi_version", "bg_last_error", "bg_ctx_create", "bg_ctx_create_own_stream", "bg_ctx_reserve", "bg_ctx_destroy", "bg_ctx_trim", "bg_ctx_timings",
     "bg_ctx_set_profiling", "bg_pack_reads", "bg_pack_reads_host", "bg_reads_count", "bg_reads_total_bases",
     "bg_reads_max_len", "bg_reads_download", "bg_reads_free", "bg_kmer_count", "bg_kmerset_size",
     "bg_kmerset_distinct", "bg_kmerset_instances", "bg_kmerset_download", "bg_kmerset_free", "bg_correct_reads",

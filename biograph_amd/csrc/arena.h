@@ -40,6 +40,15 @@ class Arena {
   Arena(const Arena&) = delete;
   Arena& operator=(const Arena&) = delete;
 
+  // A segment the caller got from the backend itself (outside whatever lock guards this arena: mapping gigabytes takes the
+  // driver hundreds of milliseconds) joins the large pool as one free chunk.
+  void adopt(void* base, size_t seg_bytes) {
+    segments_[uintptr_t(base)] = Segment{seg_bytes, false};
+    reserved_ += seg_bytes;
+    ++n_driver_allocs_;
+    insert_free(large_, uintptr_t(base), seg_bytes, uintptr_t(base));
+  }
+
   // nullptr: the driver is out of memory even after the free segments went back
   void* alloc(size_t bytes) {
     bytes = round_up(bytes ? bytes : 1, kAlign);

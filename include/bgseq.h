@@ -51,6 +51,10 @@ int bg_ctx_create(int device, void* stream, bg_ctx** out);
 /* The same with a (non-blocking) stream of its own that lives as long as the context: for callers that run several
  * contexts side by side from several host threads (bgbinary discovery's tracer sessions). */
 int bg_ctx_create_own_stream(int device, bg_ctx** out);
+/* Pre-faults `bytes` of device memory into the context's allocator (the driver maps memory at ~30 us per MiB the first time;
+ * a one-shot command can pay that on a side thread while it reads its input).  May be called from another thread than the
+ * one using the context. */
+int bg_ctx_reserve(bg_ctx* ctx, uint64_t bytes);
 /* Every object created from a context (reads, k-mer sets, records, seqsets) must be freed BEFORE the
  * context is destroyed. */
 void bg_ctx_destroy(bg_ctx* ctx);
