@@ -264,6 +264,8 @@ namespace bg {
 // prims.hip: one arena per device shared by torch's allocator hook and every context created after the hook was
 // installed (bg_torch_allocator_enable); g_arena_mutex guards every arena call in that mode
 extern std::mutex g_arena_mutex;
+extern std::mutex g_vmm_mutex;                 // segments built through the virtual-memory API (bg_ctx_reserve)
+extern std::map<void*, size_t> g_vmm_segments;
 bg_ctx::DeviceArena* shared_arena(int device);  // null unless the hook is installed
 // build_seqset.hip
 int cover_index_build(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, uint64_t n_o, int W, int cover_k,

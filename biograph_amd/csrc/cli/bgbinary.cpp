@@ -55,7 +55,7 @@ struct Args {
 // Options every command understands are listed per command: anything else is an error, never silently
 // ignored (an interleaved FASTQ imported as unpaired, a --cut-reads that cuts nothing).
 static Args parse(int argc, char** argv, int first, const std::vector<std::string>& known) {
-  static const char* flags[] = {"interleaved", "force", "f", "allow-long-reads", "no-bwt", "no-prefault", nullptr};
+  static const char* flags[] = {"interleaved", "force", "f", "allow-long-reads", "no-bwt", "prefault", nullptr};
   Args a;
   for (int i = first; i < argc; ++i) {
     std::string s = argv[i];
@@ -294,7 +294,7 @@ static int cmd_bam2fastq(int argc, char** argv) {
 }
 
 static int cmd_create(int argc, char** argv) {
-  Args a = parse(argc, argv, 2, {"no-prefault", "reads", "pair", "interleaved", "ref", "out", "id", "force", "kmer-size", "min-kmer-count",
+  Args a = parse(argc, argv, 2, {"prefault", "reads", "pair", "interleaved", "ref", "out", "id", "force", "kmer-size", "min-kmer-count",
                                  "trim-after-portion", "max-corrections", "min-good-run", "min-reads", "warn-reads", "stats",
                                  "cut-reads", "threads", "tmp", "max-mem", "format", "allow-long-reads"});
   if (!a.has("reads") || !a.has("out")) die("create: --reads and --out are required");
@@ -343,11 +343,13 @@ static int cmd_create(int argc, char** argv) {
   std::vector<void*> d_text(files.size(), nullptr);
   std::vector<uint64_t> n_text(files.size(), 0);
   uint64_t text_bytes = 0;
-  // While the files travel to the GPU, a side thread pre-faults the memory the build will ask for (first-touch hipMalloc is
-  // ~30 us per MiB: 0.85 s of a chr20-sized create).  The build peaks near 14 bytes per input base; FASTQ text is a little
-  // over two bytes per base (bases + qualities + names), and the text itself is resident during the import.
-  std::thread prefault;
-  if (!a.has("no-prefault")) {
+  // --prefault: while the files travel to the GPU, a side thread pre-faults the memory the build will ask for
+  // (bg_ctx_reserve; first-touch hipMalloc is ~30 us per MiB: 0.85 s of a chr20-sized create).  Measured on a chr20-sized
+  // sample: the build drops from 0.87 s to 0.13 s, but mapping memory and uploading the files contend in the driver and the
+  // import grows from 0.62 s to 1.0 s -- 1.78 s in all against 1.84 s.  Not worth being the default; kept for inputs whose
+  // import is bound elsewhere (gzip, BAM).  The build peaks near 14 bytes per input base; FASTQ text is a little over two
+  // bytes per base.
+  if (a.has("prefault")) {
     uint64_t on_disk = 0;
     for (auto& f : files) { struct stat sb; if (stat(f.c_str(), &sb) == 0) on_disk += uint64_t(sb.st_size); }
     const bool packed = !files.empty() && (files[0].size() > 3 && (files[0].substr(files[0].size() - 3) == ".gz" || files[0].substr(files[0].size() - 4) == ".bam"));

@@ -55,7 +55,25 @@ void* bg_ctx::HipSegments::seg_alloc(size_t n) {
   return p;
 }
 
-void bg_ctx::HipSegments::seg_free(void* p) { (void)hipFree(p); }  // waits for the device
+// Segments that bg_ctx_reserve built chunk by chunk through the virtual-memory API (one address range, physical memory
+// mapped into it piece by piece so that the driver's lock is never held for long): they go back the same way.
+namespace bg {
+std::mutex g_vmm_mutex;
+std::map<void*, size_t> g_vmm_segments;
+}  // namespace bg
+
+void bg_ctx::HipSegments::seg_free(void* p) {  // waits for the device
+  size_t vmm = 0;
+  {
+    std::lock_guard<std::mutex> l(bg::g_vmm_mutex);
+    auto it = bg::g_vmm_segments.find(p);
+    if (it != bg::g_vmm_segments.end()) { vmm = it->second; bg::g_vmm_segments.erase(it); }
+  }
+  if (!vmm) { (void)hipFree(p); return; }
+  (void)hipDeviceSynchronize();
+  (void)hipMemUnmap(p, vmm);
+  (void)hipMemAddressFree(p, vmm);
+}
 
 int bg_ctx::alloc(size_t bytes, void** out) {
   void* p;
