@@ -349,6 +349,7 @@ static int cmd_create(int argc, char** argv) {
   // import grows from 0.62 s to 1.0 s -- 1.78 s in all against 1.84 s.  Not worth being the default; kept for inputs whose
   // import is bound elsewhere (gzip, BAM).  The build peaks near 14 bytes per input base; FASTQ text is a little over two
   // bytes per base.
+  std::thread prefault;
   if (a.has("prefault")) {
     uint64_t on_disk = 0;
     for (auto& f : files) { struct stat sb; if (stat(f.c_str(), &sb) == 0) on_disk += uint64_t(sb.st_size); }
