@@ -282,14 +282,14 @@ extern "C" int bg_ctx_reserve(bg_ctx* ctx, uint64_t bytes) {
     std::lock_guard<std::mutex> l(g_vmm_mutex);
     g_vmm_segments[base] = done;
   }
-  std::lock_guard<std::mutex> lock(g_arena_mutex);
+  std::lock_guard<std::mutex> lock(ctx->arena_mutex());
   ctx->arena->adopt(base, done);
   return BG_OK;
 }
 
 extern "C" int bg_ctx_memory(bg_ctx* ctx, uint64_t* live, uint64_t* cached, uint64_t* peak, int reset_peak) {
   if (!ctx) return BG_EINVAL;
-  std::lock_guard<std::mutex> lock(g_arena_mutex);
+  std::lock_guard<std::mutex> lock(ctx->arena_mutex());
   if (live) *live = ctx->arena->live();
   if (cached) *cached = ctx->arena->cached();
   if (peak) *peak = ctx->arena->peak();

@@ -54,6 +54,8 @@ struct bg_ctx {
   };
   using DeviceArena = bg::Arena<HipSegments>;
   DeviceArena own_arena;
+  std::mutex own_mutex;  // guards own_arena (bg_ctx_reserve may run on another thread); the shared arena has the global one
+  std::mutex& arena_mutex();
   DeviceArena* arena = &own_arena;  // the process-wide arena of the device when torch shares it (bg_torch_malloc)
   std::vector<bg::TimingRec> recs;
   std::vector<hipEvent_t> event_pool;

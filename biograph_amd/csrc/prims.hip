@@ -75,10 +75,14 @@ void bg_ctx::HipSegments::seg_free(void* p) {  // waits for the device
   (void)hipMemAddressFree(p, vmm);
 }
 
+// A context with an arena of its own locks only itself: the tracer sessions of `bgbinary discovery` (16 contexts on 16
+// threads, hundreds of small buffers per work item each) used to meet on one process-wide mutex.
+std::mutex& bg_ctx::arena_mutex() { return arena == &own_arena ? own_mutex : bg::g_arena_mutex; }
+
 int bg_ctx::alloc(size_t bytes, void** out) {
   void* p;
   {
-    std::lock_guard<std::mutex> lock(bg::g_arena_mutex);
+    std::lock_guard<std::mutex> lock(arena_mutex());
     p = arena->alloc(bytes);
   }
   if (!p) {
@@ -97,13 +101,13 @@ int bg_ctx::alloc(size_t bytes, void** out) {
 // bg_torch_allocator_enable serves torch's current stream and the contexts created ON that stream (bg_ctx_create's
 // `stream` argument must be torch's current stream in that mode); bg_ctx_create_own_stream keeps a private arena.
 void bg_ctx::release(void* p) {
-  std::lock_guard<std::mutex> lock(bg::g_arena_mutex);
+  std::lock_guard<std::mutex> lock(arena_mutex());
   (void)arena->release(p);
 }
 
 int bg_ctx::trim() {
   (void)hipStreamSynchronize(stream);
-  std::lock_guard<std::mutex> lock(bg::g_arena_mutex);
+  std::lock_guard<std::mutex> lock(arena_mutex());
   arena->trim();
   return BG_OK;
 }

@@ -1312,24 +1312,43 @@ struct PopTracer {
 
   static bool popper_less(const PopEntry* a, const PopEntry* b) { return a->popped_r.s < b->popped_r.s; }  // :285-290
 
-  // ---- device batches (host vectors in and out)
+  // ---- device batches (host vectors in and out): one upload, one launch, one download per batch -- a pass of the pop
+  // tracer is two of these, and there are hundreds of passes per work item
+  static size_t up8(size_t x) { return (x + 7) & ~size_t(7); }
+  int upload_ranges(const std::vector<TRange>& r, DevBuf<uint8_t>* d, size_t extra_bytes, uint64_t** db, uint64_t** de, uint32_t** ds,
+                    uint8_t** rest) {
+    const size_t n = r.size();
+    const size_t in_bytes = n * 16 + up8(n * 4);
+    std::vector<uint8_t> h(in_bytes);
+    uint64_t* hb = reinterpret_cast<uint64_t*>(h.data());
+    uint64_t* he = hb + n;
+    uint32_t* hs = reinterpret_cast<uint32_t*>(he + n);
+    for (size_t i = 0; i < n; ++i) { hb[i] = r[i].b; he[i] = r[i].e; hs[i] = r[i].s; }
+    BG_TRY(d->alloc(ctx, in_bytes + extra_bytes));
+    BG_TRY(copy_sync(ctx, d->p, h.data(), in_bytes, hipMemcpyHostToDevice));
+    *db = reinterpret_cast<uint64_t*>(d->p);
+    *de = *db + n;
+    *ds = reinterpret_cast<uint32_t*>(*de + n);
+    *rest = d->p + in_bytes;
+    return BG_OK;
+  }
   int prefix_reads(const std::vector<TRange>& r, uint32_t cap, std::vector<uint32_t>* ids, std::vector<uint32_t>* count) {
     const size_t n = r.size();
     ids->assign(n * cap, 0);
     count->assign(n, 0);
     if (!n) return BG_OK;
-    std::vector<uint64_t> hb(n), he(n);
-    std::vector<uint32_t> hs(n);
-    for (size_t i = 0; i < n; ++i) { hb[i] = r[i].b; he[i] = r[i].e; hs[i] = r[i].s; }
-    DevBuf<uint64_t> db, de;
-    DevBuf<uint32_t> ds, di, dc;
-    BG_TRY(db.alloc(ctx, n)); BG_TRY(de.alloc(ctx, n)); BG_TRY(ds.alloc(ctx, n)); BG_TRY(di.alloc(ctx, n * cap)); BG_TRY(dc.alloc(ctx, n));
-    BG_TRY(copy_sync(ctx, db.p, hb.data(), n * 8, hipMemcpyHostToDevice));
-    BG_TRY(copy_sync(ctx, de.p, he.data(), n * 8, hipMemcpyHostToDevice));
-    BG_TRY(copy_sync(ctx, ds.p, hs.data(), n * 4, hipMemcpyHostToDevice));
-    BG_TRY(bg_prefix_reads_batch(ctx, w.ss, w.rm, n, db.p, de.p, ds.p, int(w.o.min_overlap), cap, di.p, dc.p));
-    BG_TRY(copy_sync(ctx, ids->data(), di.p, n * cap * 4, hipMemcpyDeviceToHost));
-    BG_TRY(copy_sync(ctx, count->data(), dc.p, n * 4, hipMemcpyDeviceToHost));
+    DevBuf<uint8_t> d;
+    uint64_t *db, *de;
+    uint32_t* ds;
+    uint8_t* rest;
+    BG_TRY(upload_ranges(r, &d, (n * cap + n) * 4, &db, &de, &ds, &rest));
+    uint32_t* di = reinterpret_cast<uint32_t*>(rest);
+    uint32_t* dc = di + n * cap;
+    BG_TRY(bg_prefix_reads_batch(ctx, w.ss, w.rm, n, db, de, ds, int(w.o.min_overlap), cap, di, dc));
+    std::vector<uint32_t> h(n * cap + n);
+    BG_TRY(copy_sync(ctx, h.data(), di, h.size() * 4, hipMemcpyDeviceToHost));
+    std::copy(h.begin(), h.begin() + long(n * cap), ids->begin());
+    std::copy(h.begin() + long(n * cap), h.end(), count->begin());
     ++device_rounds;
     device_queries += n;
     return BG_OK;
@@ -1338,18 +1357,23 @@ struct PopTracer {
     const size_t n = ids.size();
     r->assign(n, TRange());
     if (!n) return BG_OK;
-    DevBuf<uint32_t> di, dm, drc, ds;
-    DevBuf<uint8_t> dh;
-    DevBuf<uint64_t> db, de;
-    BG_TRY(di.alloc(ctx, n)); BG_TRY(dm.alloc(ctx, n)); BG_TRY(drc.alloc(ctx, n)); BG_TRY(ds.alloc(ctx, n)); BG_TRY(dh.alloc(ctx, n));
-    BG_TRY(db.alloc(ctx, n)); BG_TRY(de.alloc(ctx, n));
-    BG_TRY(copy_sync(ctx, di.p, ids.data(), n * 4, hipMemcpyHostToDevice));
-    BG_TRY(bg_read_info_batch(ctx, w.ss, w.rm, n, di.p, dh.p, dm.p, drc.p, db.p, de.p, ds.p));
-    std::vector<uint64_t> hb(n), he(n);
-    std::vector<uint32_t> hs(n);
-    BG_TRY(copy_sync(ctx, hb.data(), db.p, n * 8, hipMemcpyDeviceToHost));
-    BG_TRY(copy_sync(ctx, he.data(), de.p, n * 8, hipMemcpyDeviceToHost));
-    BG_TRY(copy_sync(ctx, hs.data(), ds.p, n * 4, hipMemcpyDeviceToHost));
+    // in: ids; out: begin, end (u64), size, mate_rc, rev_comp (u32), has_mate (u8)
+    DevBuf<uint8_t> d;
+    const size_t in_bytes = up8(n * 4), out_bytes = n * 16 + n * 12 + up8(n);
+    BG_TRY(d.alloc(ctx, in_bytes + out_bytes));
+    BG_TRY(copy_sync(ctx, d.p, ids.data(), n * 4, hipMemcpyHostToDevice));
+    uint64_t* db = reinterpret_cast<uint64_t*>(d.p + in_bytes);
+    uint64_t* de = db + n;
+    uint32_t* ds = reinterpret_cast<uint32_t*>(de + n);
+    uint32_t* dm = ds + n;
+    uint32_t* drc = dm + n;
+    uint8_t* dh = reinterpret_cast<uint8_t*>(drc + n);
+    BG_TRY(bg_read_info_batch(ctx, w.ss, w.rm, n, reinterpret_cast<const uint32_t*>(d.p), dh, dm, drc, db, de, ds));
+    std::vector<uint8_t> h(n * 16 + n * 4);
+    BG_TRY(copy_sync(ctx, h.data(), db, h.size(), hipMemcpyDeviceToHost));
+    const uint64_t* hb = reinterpret_cast<const uint64_t*>(h.data());
+    const uint64_t* he = hb + n;
+    const uint32_t* hs = reinterpret_cast<const uint32_t*>(he + n);
     for (size_t i = 0; i < n; ++i) (*r)[i] = TRange{hb[i], he[i], hs[i]};
     ++device_rounds;
     device_queries += n;
@@ -1359,19 +1383,20 @@ struct PopTracer {
     const size_t n = r.size();
     o->assign(n, TRange());
     if (!n) return BG_OK;
-    std::vector<uint64_t> hb(n), he(n);
-    std::vector<uint32_t> hs(n);
-    for (size_t i = 0; i < n; ++i) { hb[i] = r[i].b; he[i] = r[i].e; hs[i] = r[i].s; }
-    DevBuf<uint64_t> db, de, ob, oe;
-    DevBuf<uint32_t> ds, os;
-    BG_TRY(db.alloc(ctx, n)); BG_TRY(de.alloc(ctx, n)); BG_TRY(ds.alloc(ctx, n)); BG_TRY(ob.alloc(ctx, n)); BG_TRY(oe.alloc(ctx, n)); BG_TRY(os.alloc(ctx, n));
-    BG_TRY(copy_sync(ctx, db.p, hb.data(), n * 8, hipMemcpyHostToDevice));
-    BG_TRY(copy_sync(ctx, de.p, he.data(), n * 8, hipMemcpyHostToDevice));
-    BG_TRY(copy_sync(ctx, ds.p, hs.data(), n * 4, hipMemcpyHostToDevice));
-    BG_TRY(bg_pop_front_batch(ctx, w.ss, n, db.p, de.p, ds.p, ob.p, oe.p, os.p));
-    BG_TRY(copy_sync(ctx, hb.data(), ob.p, n * 8, hipMemcpyDeviceToHost));
-    BG_TRY(copy_sync(ctx, he.data(), oe.p, n * 8, hipMemcpyDeviceToHost));
-    BG_TRY(copy_sync(ctx, hs.data(), os.p, n * 4, hipMemcpyDeviceToHost));
+    DevBuf<uint8_t> d;
+    uint64_t *db, *de;
+    uint32_t* ds;
+    uint8_t* rest;
+    BG_TRY(upload_ranges(r, &d, n * 16 + up8(n * 4), &db, &de, &ds, &rest));
+    uint64_t* ob = reinterpret_cast<uint64_t*>(rest);
+    uint64_t* oe = ob + n;
+    uint32_t* os = reinterpret_cast<uint32_t*>(oe + n);
+    BG_TRY(bg_pop_front_batch(ctx, w.ss, n, db, de, ds, ob, oe, os));
+    std::vector<uint8_t> h(n * 16 + n * 4);
+    BG_TRY(copy_sync(ctx, h.data(), ob, h.size(), hipMemcpyDeviceToHost));
+    const uint64_t* hb = reinterpret_cast<const uint64_t*>(h.data());
+    const uint64_t* he = hb + n;
+    const uint32_t* hs = reinterpret_cast<const uint32_t*>(he + n);
     for (size_t i = 0; i < n; ++i) (*o)[i] = TRange{hb[i], he[i], hs[i]};
     ++device_rounds;
     device_queries += n;
