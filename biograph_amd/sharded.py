@@ -60,6 +60,14 @@ class LocalSimComm:
                 off += counts[dst]
         return {r: torch.cat(pieces[r], dim=0) for r in self.local_ranks}, cm
 
+    def all_to_all_v_start(self, send):
+        """all_to_all_v in two halves, so that the caller can compute while the rows travel: -> a handle for
+        all_to_all_v_finish.  (Simulated ranks share one device: nothing to overlap, the exchange happens here.)"""
+        return self.all_to_all_v(send)
+
+    def all_to_all_v_finish(self, handle):
+        return handle
+
     def all_to_all_reply(self, send, cm):
         """The way back of an exchange whose counts matrix was cm: send[r] = one row per row r received (in received
         order); every rank gets one row per row it sent, in sent order."""
@@ -137,6 +145,34 @@ class TorchDistComm:
         rows, counts = send[self.rank]
         cm = self.gather_ints({self.rank: [int(c) for c in counts]})
         return {self.rank: self._exchange(rows, [int(c) for c in counts], cm)}, cm
+
+    def all_to_all_v_start(self, send):
+        """all_to_all_v in two halves: the rows leave on the backend's own stream (RCCL: async_op) and the caller goes on
+        launching kernels on its stream until all_to_all_v_finish waits for them.  A rank alone and exchanges of several
+        rounds complete here."""
+        rows, counts = send[self.rank]
+        counts = [int(c) for c in counts]
+        cm = self.gather_ints({self.rank: counts})
+        dist = self.dist
+        rows_in = self._in(rows).contiguous()
+        row_bytes = rows_in.element_size()
+        for d in rows_in.shape[1:]:
+            row_bytes *= int(d)
+        max_rows = max(1, self.MAX_PIECE_BYTES // max(row_bytes, 1))
+        single = max(max(r) for r in cm) <= max_rows
+        if self.world == 1 or not single:
+            return ("done", {self.rank: self._exchange(rows, counts, cm)}, cm)
+        out_counts = [cm[s][self.rank] for s in range(self.world)]
+        out = torch.empty((sum(out_counts),) + tuple(rows_in.shape[1:]), dtype=rows_in.dtype, device=self.device)
+        work = dist.all_to_all_single(out, rows_in, output_split_sizes=out_counts, input_split_sizes=counts, async_op=True)
+        return ("flying", work, out, rows_in, cm)  # rows_in stays alive until the wait
+
+    def all_to_all_v_finish(self, handle):
+        if handle[0] == "done":
+            return handle[1], handle[2]
+        _, work, out, _rows, cm = handle
+        work.wait()  # the caller's stream now waits for the exchange
+        return {self.rank: self._out(out)}, cm
 
     def all_to_all_reply(self, send, cm):
         counts = [cm[s][self.rank] for s in range(self.world)]
@@ -554,8 +590,9 @@ def _records_sharded_cover(comm, ctxs, corrected, W, k, dev, ph):
 # hits per pending read and round of the filtered cover: one at first (nine reads in ten are settled by their first hit),
 # more once few reads are left, so that the tail of reads whose candidates keep failing ends after a few rounds
 COVER_SCAN_HITS = "1,2,4,16,64"
-# suffix windows the records are generated in (one all_to_all each): most reads have all their records in the first
-COVER_RECORD_WINDOWS = "1,9,33,256"
+# suffix windows the records are generated in (one all_to_all each, in flight while the next window is generated): narrow
+# at first, where most records are, so that generation and transfer overlap from early on
+COVER_RECORD_WINDOWS = "1,3,5,9,17,33,256"
 
 
 def _filtered_cover_rounds(comm, ctxs, covers, qs, parts, W, k, dev, ph, pparams):
@@ -619,6 +656,8 @@ def _filtered_cover_rounds(comm, ctxs, covers, qs, parts, W, k, dev, ph, pparams
     wins = [int(x) for x in os.environ.get("BG_COVER_RECORD_WINDOWS", COVER_RECORD_WINDOWS).split(",")]
     if wins[-1] < 256:
         wins.append(256)
+    # the windows are pipelined: while the records of one window travel (all_to_all_v_start), the next window is generated
+    flying = None
     for j_lo, j_hi in zip(wins[:-1], wins[1:]):
         ph.mark("cover_records_%d" % j_lo)
         live = {}
@@ -637,11 +676,19 @@ def _filtered_cover_rounds(comm, ctxs, covers, qs, parts, W, k, dev, ph, pparams
             capi.check(L.bg_cover_query_records_split(ctxs[r].h, qs[r], j_lo, j_hi, P, capi.np_ptr(pp), _ptr(t), cap, counts, C.byref(n)))
             send[r] = (t[:n.value], [int(c) for c in counts])
             del t
-        got, _ = comm.all_to_all_v(send)
+        if flying is not None:
+            got, _ = comm.all_to_all_v_finish(flying)
+            for r in ranks:
+                parts[r].append(got[r])
+            del got
+        flying = comm.all_to_all_v_start(send)
+        del send
+    if flying is not None:
+        got, _ = comm.all_to_all_v_finish(flying)
         for r in ranks:
             parts[r].append(got[r])
-        del send, got
-        _relieve(ctxs, dev)
+        del got, flying
+    _relieve(ctxs, dev)
     for r in ranks:
         L.bg_cover_query_free(qs[r])
         parts[r] = [t.contiguous() for t in parts[r] if t.shape[0]]

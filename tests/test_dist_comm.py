@@ -27,11 +27,21 @@ WORKER = textwrap.dedent("""
         off = sum(c[:r])
         exp.append(full[off:off + c[r]])
     assert torch.equal(out, torch.cat(exp)), (r, out)
+    # the same in two halves (the record windows of the cover stage are generated while the last one travels): two exchanges in
+    # flight at once, finished in order
+    h1 = comm.all_to_all_v_start({r: (rows, counts)})
+    h2 = comm.all_to_all_v_start({r: ((rows * 2).contiguous(), counts)})
+    assert h1[0] == "flying"
+    o1, cm1 = comm.all_to_all_v_finish(h1)
+    o2, cm2 = comm.all_to_all_v_finish(h2)
+    assert cm1 == cm2 == cm and torch.equal(o1[r], torch.cat(exp)) and torch.equal(o2[r], torch.cat(exp) * 2)
     # multi-round exchange (pieces capped): the same rows in the same order (source-major, sent order) - the
     # presence bits of the k-mer exchange are matched to their records by position
     comm.MAX_PIECE_BYTES = 24  # one 3-word row per piece and round
     out2 = comm.all_to_all_v({r: (rows, counts)})[0][r]
     assert torch.equal(out2, torch.cat(exp)), (r, out2)
+    h3 = comm.all_to_all_v_start({r: (rows, counts)})   # several rounds: completes at the start
+    assert h3[0] == "done" and torch.equal(comm.all_to_all_v_finish(h3)[0][r], torch.cat(exp))
     # the way back: one byte per received row (its first word modulo 251) returns to the sender in sent order, with no
     # exchange of counts; and a second exchange in the forward direction with the same counts
     back = (out2[:, 0] %% 251).to(torch.uint8).view(-1, 1)
