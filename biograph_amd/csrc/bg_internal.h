@@ -269,6 +269,11 @@ extern std::mutex g_arena_mutex;
 extern std::mutex g_vmm_mutex;                 // segments built through the virtual-memory API (bg_ctx_reserve)
 extern std::map<void*, size_t> g_vmm_segments;
 bg_ctx::DeviceArena* shared_arena(int device);  // null unless the hook is installed
+// walk.hip: the read-ahead tables of one walked stretch of a tracer work item (offset after base i = first_off + i),
+// appended to the three lists; the two sorted ones are sorted within this stretch
+int tracer_read_tables(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const uint8_t* d_ref_map, bool skip_ambiguous,
+                       const uint64_t* d_ent, uint64_t n, int64_t first_off, std::vector<std::pair<int32_t, uint64_t>>* pos_entries,
+                       std::vector<std::pair<uint64_t, int32_t>>* entry_pos, std::vector<std::pair<uint32_t, int32_t>>* mate_pos);
 // build_seqset.hip
 int cover_index_build(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, uint64_t n_o, int W, int cover_k,
                       DevBuf<uint64_t>* k0o, CoverStore* cs);

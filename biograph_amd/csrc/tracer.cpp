@@ -155,6 +155,7 @@ struct World {
   // cloned from this one (bg_tracer_clone: several sessions trace side by side)
   std::shared_ptr<const HostTables> tables;
   const uint8_t* sizes = nullptr;       // entry sizes
+  const uint8_t* d_ref_map = nullptr;   // the caller's device ref_map (stays valid while the session lives)
   const uint8_t* ref_map = nullptr;     // ref_map bytes (match count = & 63)
   const uint32_t* mate_loop = nullptr;  // per read id
   const uint8_t* is_forward = nullptr;  // per read id
@@ -762,6 +763,7 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
   w.position_entries.clear();
   w.entry_positions.clear();
   w.rc_mate_read_positions.clear();
+  bool tables_sorted = true;
   int64_t prev_end = -1;
   for (const Extent& x : ext) {
     if (x.offset < prev_end) return fail("bg_push_trace: extents must be sorted and disjoint");
@@ -788,6 +790,17 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
     BG_TRY(d_ent.alloc(ctx, n));
     BG_TRY(copy_sync(ctx, d_codes.p, codes.data(), n, hipMemcpyHostToDevice));
     BG_TRY(bg_ref_walk_entries(ctx, w.ss, d_codes.p, n, dup_first ? 1 : 0, d_ent.p));
+    if (w.d_ref_map && n < (1ull << 24) && !getenv("BG_TRACER_HOST_TABLES")) {
+      // the tables of this stretch on the device: the entries never leave it
+      const size_t ep0 = w.entry_positions.size(), mp0 = w.rc_mate_read_positions.size();
+      BG_TRY(tracer_read_tables(ctx, w.ss, w.rm, w.d_ref_map, o.ignore_ambiguous_ref_pairs != 0, d_ent.p, n, lo + 1, &w.position_entries,
+                                &w.entry_positions, &w.rc_mate_read_positions));
+      if (ep0) std::inplace_merge(w.entry_positions.begin(), w.entry_positions.begin() + long(ep0), w.entry_positions.end());
+      if (mp0) std::inplace_merge(w.rc_mate_read_positions.begin(), w.rc_mate_read_positions.begin() + long(mp0), w.rc_mate_read_positions.end());
+      tables_sorted = true;
+      continue;
+    }
+    tables_sorted = false;
     std::vector<uint64_t> ent(n);
     BG_TRY(copy_sync(ctx, ent.data(), d_ent.p, n * 8, hipMemcpyDeviceToHost));
     // positions that are reads, and for those the (rc mate, offset) pairs: per-thread lists over slices of the extent
@@ -813,8 +826,10 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
       }
     }
   }
-  std::sort(w.entry_positions.begin(), w.entry_positions.end());
-  std::sort(w.rc_mate_read_positions.begin(), w.rc_mate_read_positions.end());
+  if (!tables_sorted) {
+    std::sort(w.entry_positions.begin(), w.entry_positions.end());
+    std::sort(w.rc_mate_read_positions.begin(), w.rc_mate_read_positions.end());
+  }
   // ---- 2. the sequential state of the sweep (:236-296): which offsets trace, with which anchor
   std::vector<std::unique_ptr<Trace>> traces;
   size_t pe = 0;
@@ -1090,6 +1105,7 @@ extern "C" int bg_tracer_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap
   if (options) w.o = *options; else bg_trace_options_default(&w.o);
   memset(&w.stats, 0, sizeof(w.stats));
   w.n_entries = ss->n;
+  w.d_ref_map = d_ref_map;
   {
     std::shared_ptr<HostTables> h(new HostTables);
     BG_TRY(download(ctx, h->sizes, ss->sizes.p, ss->n));
@@ -1135,6 +1151,7 @@ extern "C" int bg_tracer_clone(const bg_tracer* from, bg_ctx* ctx, bg_tracer** o
   w.o = from->w.o;
   memset(&w.stats, 0, sizeof(w.stats));
   w.n_entries = from->w.n_entries;
+  w.d_ref_map = from->w.d_ref_map;
   w.tables = from->w.tables;
   w.bind_tables();
   *out = t.release();

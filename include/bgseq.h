@@ -502,6 +502,8 @@ int bg_push_trace(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const 
 /* The same as a session: the host copies of the seqset / readmap / ref_map arrays the tracer consults are made once
  * (a trace_ref object and its assemble_options), bg_tracer_trace is one work item (scaffold piece x direction). */
 typedef struct bg_tracer bg_tracer;
+/* d_ref_map must stay valid until the session (and every clone of it) is closed: the read-ahead tables of a work item are
+ * built on the device from it. */
 int bg_tracer_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const uint8_t* d_ref_map,
                    const bg_trace_options* options /* NULL = defaults */, bg_tracer** out);
 int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
