@@ -786,10 +786,12 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   cov.simple_genotype_filter = flag("simple-gt", false) ? 1 : 0;
   cov.rvg_exclude = flag("rvg-exclude", true) ? 1 : 0;
   // trace_ref runs its work items on the process's thread pool (trace_ref.cpp:105-140); here: --threads sessions
-  // (default 16: tracing the chr20-shaped sample takes 19 s on 8, 9.7 s on 16, 10.2 s on 24), each with its own context
-  // (stream + allocator) and scratch, the read-only host tables shared, side by side on the one GPU
+  // (default 24, or the host's cores when fewer: with the pop tracers on, tracing the chr20-shaped sample takes 12.9 s on
+  // 16, 11.3 s on 24, 12.8 s on 32 -- the sessions are bound by their host replay, 0.6 s of one core per piece and
+  // direction), each with its own context (stream + allocator) and scratch, the read-only host tables shared, side by side
+  // on the one GPU
   int n_threads = a.has("threads") ? atoi(a.get("threads").c_str())
-                                   : int(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+                                   : int(std::min(24u, std::max(1u, std::thread::hardware_concurrency())));
   if (n_threads < 1) n_threads = 1;
   if (n_threads > 64) n_threads = 64;
   const double t_open0 = now_s();

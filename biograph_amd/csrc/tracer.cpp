@@ -144,6 +144,27 @@ struct HostTables {
   std::vector<uint64_t> has_reads;
 };
 
+// A pinned host buffer that grows: the per-round queries / replies of a session cross the bus from and to page-locked
+// memory (a copy of pageable memory is staged by the runtime under a lock all sessions share).
+struct Pinned {
+  void* p = nullptr;
+  size_t cap = 0;
+  Pinned() {}
+  Pinned(const Pinned&) = delete;
+  Pinned& operator=(const Pinned&) = delete;
+  ~Pinned() { if (p) (void)hipHostFree(p); }
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return BG_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; set_error("tracer: pinned staging buffer of %zu bytes refused", want); return BG_ENOMEM; }
+    cap = want;
+    return BG_OK;
+  }
+};
+
 // Everything the traces of one chunk share.
 struct World {
   bg_ctx* ctx;
@@ -178,6 +199,7 @@ struct World {
   std::vector<std::pair<int32_t, uint64_t>> position_entries;
   std::vector<std::pair<uint64_t, int32_t>> entry_positions;        // (entry, offset), sorted
   std::vector<std::pair<uint32_t, int32_t>> rc_mate_read_positions;  // (read, offset), sorted
+  Pinned pin_q, pin_r, pin_s;  // the round's queries, replies and step lists
   bg_trace_stats stats;
   double seconds_device = 0, seconds_host = 0, seconds_tables = 0, seconds_start = 0, seconds_teardown = 0;
   int threads = 1;
@@ -895,21 +917,24 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
     }
     DevBuf<uint8_t> dq, dr;
     DevBuf<uint32_t> ds;
-    std::vector<bg_trace_reply> replies;
-    std::vector<uint32_t> steps;
+    // device buffers of the first (largest) round serve every later one
+    BG_TRY(dq.alloc(ctx, live.size() * sizeof(bg_trace_query)));
+    BG_TRY(dr.alloc(ctx, live.size() * sizeof(bg_trace_reply)));
+    BG_TRY(ds.alloc(ctx, live.size() * step_cap));
     while (!live.empty()) {
       const size_t n = live.size();
       const double t_dev = now_seconds();
-      BG_TRY(dq.alloc(ctx, n * sizeof(bg_trace_query)));
-      BG_TRY(dr.alloc(ctx, n * sizeof(bg_trace_reply)));
-      BG_TRY(ds.alloc(ctx, n * step_cap));
-      BG_HIP(hipMemcpyAsync(dq.p, q.data(), n * sizeof(bg_trace_query), hipMemcpyHostToDevice, ctx->stream));
+      BG_TRY(w.pin_q.ensure(n * sizeof(bg_trace_query)));
+      BG_TRY(w.pin_r.ensure(n * sizeof(bg_trace_reply)));
+      BG_TRY(w.pin_s.ensure(n * step_cap * 4));
+      memcpy(w.pin_q.p, q.data(), n * sizeof(bg_trace_query));
+      BG_HIP(hipMemcpyAsync(dq.p, w.pin_q.p, n * sizeof(bg_trace_query), hipMemcpyHostToDevice, ctx->stream));
       BG_TRY(bg_tracer_extend_batch(ctx, w.ss, w.rm, n, reinterpret_cast<const bg_trace_query*>(dq.p), step_cap,
                                     reinterpret_cast<bg_trace_reply*>(dr.p), ds.p));
-      replies.resize(n);
-      steps.resize(n * step_cap);
-      BG_HIP(hipMemcpyAsync(replies.data(), dr.p, n * sizeof(bg_trace_reply), hipMemcpyDeviceToHost, ctx->stream));
-      BG_HIP(hipMemcpyAsync(steps.data(), ds.p, n * step_cap * 4, hipMemcpyDeviceToHost, ctx->stream));
+      const bg_trace_reply* replies = static_cast<const bg_trace_reply*>(w.pin_r.p);
+      const uint32_t* steps = static_cast<const uint32_t*>(w.pin_s.p);
+      BG_HIP(hipMemcpyAsync(w.pin_r.p, dr.p, n * sizeof(bg_trace_reply), hipMemcpyDeviceToHost, ctx->stream));
+      BG_HIP(hipMemcpyAsync(w.pin_s.p, ds.p, n * step_cap * 4, hipMemcpyDeviceToHost, ctx->stream));
       BG_HIP(hipStreamSynchronize(ctx->stream));
       w.seconds_device += now_seconds() - t_dev;
       ++w.stats.device_rounds;
@@ -917,7 +942,7 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
       const double t_host = now_seconds();
       std::vector<bg_trace_query> qs(n);
       std::vector<uint8_t> pending(n, 0);
-      parallel_over(n, [&](size_t i) { pending[i] = live[i]->resume(replies[i], steps.data() + i * step_cap, &qs[i]) ? 1 : 0; });
+      parallel_over(n, [&](size_t i) { pending[i] = live[i]->resume(replies[i], steps + i * step_cap, &qs[i]) ? 1 : 0; });
       std::vector<Trace*> next_live;
       std::vector<bg_trace_query> next_q;
       for (size_t i = 0; i < n; ++i)

@@ -483,11 +483,15 @@ __global__ __launch_bounds__(64) void k_walk_chains(SeqsetView v, uint32_t n, co
 // :568-577, and, while exactly one of them is valid and the path has not reached a read, the step onto it.  One
 // lane per path; the host (csrc/tracer.cpp) replays the costs of the steps and does everything that touches the
 // readmap and the reference positions.
+// Four lanes per path, one per base: the four pushes of a step are one memory round trip deep instead of four (the kernel
+// is a chain of dependent look-ups: a wave of 16 paths steps as fast as its slowest path's slowest push).
 __global__ __launch_bounds__(64) void k_tracer_extend(SeqsetView v, const uint64_t* __restrict__ has_reads, uint64_t n,
                                                      const bg_trace_query* __restrict__ q, uint32_t step_cap,
                                                      bg_trace_reply* __restrict__ r, uint32_t* __restrict__ steps) {
-  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t i = t >> 2;
   if (i >= n) return;
+  const int lane = threadIdx.x & 63, base = lane & 3, quad0 = lane & ~3;
   const bg_trace_query qq = q[i];
   uint64_t b = qq.begin, e = qq.end;
   uint32_t s = qq.size, min_ctx = qq.min_ctx;
@@ -496,35 +500,38 @@ __global__ __launch_bounds__(64) void k_tracer_extend(SeqsetView v, const uint64
   auto is_read = [&](uint64_t rb, uint64_t re, uint32_t rs) {
     return rb + 1 == re && rs == v.sizes[rb] && ((has_reads[rb >> 6] >> (rb & 63)) & 1);
   };
-  bg_trace_reply out;
-  uint32_t n_steps = 0;
+  uint32_t n_steps = 0, reason, valid;
+  uint64_t pb, pe;
+  uint32_t ps;
   for (;;) {
-    uint32_t valid = 0;
-    int count = 0, next = 0;
-    for (int base = 0; base < 4; ++base) {
-      uint64_t pb, pe;
-      uint32_t ps;
-      v.push_front_drop(b, e, s, 3 - base, min_ctx, &pb, &pe, &ps);
-      out.pb[base] = pb; out.pe[base] = pe; out.ps[base] = ps;
-      if (pe <= pb) continue;
-      if (pb + 1 == pe && ps == v.sizes[pb] && pb == qq.loop_check) { out.pb[base] = 0; out.pe[base] = 0; continue; }  // a loop
-      valid |= 1u << base;
-      ++count;
-      next = base;
-    }
-    out.valid_mask = valid;
-    if (count != 1) { out.reason = BG_TRACE_AMBIGUOUS; break; }
-    if (pushed_any && is_read(b, e, s)) { out.reason = BG_TRACE_AT_READ; break; }
-    if (n_steps >= cap) { out.reason = BG_TRACE_STEP_CAP; break; }
-    b = out.pb[next]; e = out.pe[next]; s = out.ps[next];
-    steps[i * step_cap + n_steps] = uint32_t(next) | (s << 8);
+    v.push_front_drop(b, e, s, 3 - base, min_ctx, &pb, &pe, &ps);
+    bool ok = pe > pb;
+    if (ok && pb + 1 == pe && ps == v.sizes[pb] && pb == qq.loop_check) { pb = 0; pe = 0; ok = false; }  // a loop
+    valid = uint32_t((__ballot(ok) >> quad0) & 15ull);
+    if (__popc(valid) != 1) { reason = BG_TRACE_AMBIGUOUS; break; }
+    if (pushed_any && is_read(b, e, s)) { reason = BG_TRACE_AT_READ; break; }
+    if (n_steps >= cap) { reason = BG_TRACE_STEP_CAP; break; }
+    const int next = __ffs(int(valid)) - 1;
+    b = __shfl(pb, quad0 + next, 64);
+    e = __shfl(pe, quad0 + next, 64);
+    s = __shfl(ps, quad0 + next, 64);
+    if (base == 0) steps[i * step_cap + n_steps] = uint32_t(next) | (s << 8);
     ++n_steps;
     ++min_ctx;  // pushed_since_read grows with every base that does not land on a read
     pushed_any = true;
-    if (is_read(b, e, s)) { out.reason = BG_TRACE_STEPPED_ON_READ; break; }
+    if (is_read(b, e, s)) {
+      reason = BG_TRACE_STEPPED_ON_READ;
+      // (the pushes of the step that was just taken: what the one-lane version leaves in the reply at this exit)
+      break;
+    }
   }
-  out.begin = b; out.end = e; out.size = s; out.n_steps = n_steps;
-  r[i] = out;
+  bg_trace_reply* out = r + i;
+  out->pb[base] = pb;
+  out->pe[base] = pe;
+  out->ps[base] = ps;
+  if (base == 0) {
+    out->begin = b; out->end = e; out->size = s; out->n_steps = n_steps; out->reason = reason; out->valid_mask = valid;
+  }
 }
 
 __global__ void k_ref_map_pack(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ flags, uint64_t n,
@@ -654,7 +661,7 @@ extern "C" int bg_tracer_extend_batch(bg_ctx* ctx, const bg_seqset* ss, const bg
   BG_HIP(hipSetDevice(ctx->device));
   if (!n) return BG_OK;
   ctx->tic("walk_tracer_extend");
-  k_tracer_extend<<<cdiv(n, 64), 64, 0, ctx->stream>>>(make_view(ss), rm->s2m_bits.p, n, d_queries, step_cap, d_replies, d_steps);
+  k_tracer_extend<<<cdiv(n * 4, 64), 64, 0, ctx->stream>>>(make_view(ss), rm->s2m_bits.p, n, d_queries, step_cap, d_replies, d_steps);
   BG_LAUNCH_CHECK();
   ctx->toc(n * 4 * 52);
   BG_HIP(hipStreamSynchronize(ctx->stream));
