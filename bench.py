@@ -33,7 +33,10 @@ def cpu_baseline(ctx, sample_genome, coverage, read_len, seed, dev):
     import biograph_amd as bg
     from biograph_amd import synth
     from oracle import oracle as O
-    threads = O.hardware_threads()
+    # The port's stages have serial sections (the merges behind the per-partition counts, the readmap's row order) and do not
+    # get faster beyond ~16 threads on the GPU box's 2 x 64-core host (profiles/r03_cpu_baseline_thread_sweep.txt: 13.3 s on
+    # 16 threads, 14.2 s on 64, 16.9 s on 256 for this sample): the baseline runs on the count it is fastest at.
+    threads = min(O.hardware_threads(), int(os.environ.get("BG_CPU_BASELINE_THREADS", "16")))
     dseq, doffs, n, genome = synth.make_reads(genome_len=sample_genome, coverage=coverage, read_len=read_len, seed=seed,
                                               device=dev, return_genome=True)
     t0 = time.perf_counter()
