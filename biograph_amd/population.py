@@ -146,15 +146,18 @@ def sharded_discover(comm, seqsets, readmaps, scaffolds, min_overlap, split_size
 
 
 _ASM_FIELDS = ("left_offset", "right_offset", "seq", "left_anchor_len", "right_anchor_len", "min_overlap", "trace_steps",
-               "left_anchor_ambiguous_bases", "matches_reference", "score", "left_pair_matches", "right_pair_matches")
+               "left_anchor_ambiguous_bases", "matches_reference", "score", "left_pair_matches", "right_pair_matches",
+               "from_pop", "assembly_id")
 
 
 def sharded_discovery_vcf(comm, seqsets, readmaps, scaffolds, min_overlap=None, split_size=SCAFFOLD_SPLIT_SIZE,
-                          max_pair_distance=1000, ref_maps=None, trace_options=None, coverage_options=None):
+                          max_pair_distance=1000, ref_maps=None, trace_options=None, coverage_options=None, pop_tracer=True):
     """The reference's discovery engine over a population (configs[4]): every rank traces its share of the work items
     (sample, reference piece) with the push tracer in both directions; the assemblies of a (sample, scaffold) go to
     the rank that owns that pair, which runs the serial pipeline, calc_coverage and the genotype filter on its replica
-    and formats the VCF records (what one `bgbinary discovery --engine push` does per sample).  Returns, on every rank,
+    and formats the VCF records (what one `bgbinary discovery --engine push` does per sample, with its defaults: the pop
+    tracers over every work item's anchor drops (pop_tracer=False: push only), no simple genotype filter, rvg_exclude --
+    `biograph_variants.cpp:188-202`; pass coverage_options to change the last two).  Returns, on every rank,
     {sample: [VCF record lines in scaffold order]}.  Assemblies cross ranks as Python objects (a few kB per piece):
     all_gather_obj; the GPU work (tracing, coverage walks) never leaves its rank.  The result does not depend on the
     number of ranks: the owner orders what it receives by (piece start, direction, position in the piece's output)."""
@@ -180,10 +183,13 @@ def sharded_discovery_vcf(comm, seqsets, readmaps, scaffolds, min_overlap=None, 
         for s, (name, a, lim) in chunks_of_rank(work, r, comm.world):
             if s not in sessions:
                 sessions[s] = tracer.PushTracer(seqsets[r], readmaps[r][s], ref_maps[r], options_for(readmaps[r][s]))
-            for rev in (False, True):
-                found = sessions[s].trace(ext[name], start=a, limit=lim, end_pos=len(scaffolds[name]), rev_comp=rev)
-                for i, x in enumerate(found):
-                    mine.append(((s, name), (a, int(rev), i), tuple(getattr(x, f) for f in _ASM_FIELDS)))
+            # one work item of trace_ref: push forward, push reverse, then the two pop tracers over their anchor drops
+            found = sessions[s].execute_work(ext[name], start=a, limit=lim, end_pos=len(scaffolds[name]), pop_fwd=pop_tracer,
+                                             pop_rev=pop_tracer)
+            for i, x in enumerate(found):
+                # assembly ids come from a per-process counter: made unique over the ranks (rvg_exclude groups by them)
+                x.assembly_id = x.assembly_id * comm.world + r
+                mine.append(((s, name), (a, i), tuple(getattr(x, f) for f in _ASM_FIELDS)))
         for t in sessions.values():
             t.close()
         traced[r] = mine
@@ -199,8 +205,9 @@ def sharded_discovery_vcf(comm, seqsets, readmaps, scaffolds, min_overlap=None, 
             asms = [tracer.TraceAssembly(**dict(zip(_ASM_FIELDS, fields))) for _, fields in items]
             opt = options_for(readmaps[r][s])
             sections = tracer.process_assemblies(asms, ext[name], end_pos=len(scaffolds[name]), options=opt)
+            cov = coverage_options if coverage_options is not None else tracer.CoverageOptions(simple_genotype_filter=0, rvg_exclude=1)
             _, recs = tracer.assemblies_coverage(seqsets[r], readmaps[r][s], sections, ext[name], end_pos=len(scaffolds[name]),
-                                                 options=coverage_options, vcf_name=name)
+                                                 options=cov, vcf_name=name)
             out[(s, name)] = recs
         lines[r] = out
     merged = {}

@@ -202,8 +202,8 @@ def test_sharded_discover_with_the_push_tracer(ctx):
 
 def test_sharded_discovery_vcf_is_the_engine_of_one_process(ctx):
     """configs[4]'s discover step with the reference's engine: (sample, piece) work items traced on P simulated ranks,
-    pipeline + coverage + genotype on the owner of (sample, scaffold): the VCF records do not depend on P and equal what
-    one process gets by tracing all pieces itself (the flow of `bgbinary discovery --engine push`)."""
+    pipeline + coverage + rvg_exclude on the owner of (sample, scaffold): the VCF records do not depend on P and equal what
+    one process gets by running all work items itself (the flow of `bgbinary discovery` with its defaults: pop tracers on)."""
     from biograph_amd import tracer
     G = 40_000
     seq, offs, n, genome = synth.make_reads(genome_len=G, coverage=30, read_len=150, seed=SEED, device="cpu", sample=2,
@@ -230,11 +230,11 @@ def test_sharded_discovery_vcf_is_the_engine_of_one_process(ctx):
         for name, sq in scaffolds.items():
             ext = population.extents_of(sq)
             asms = []
-            for start in range(0, len(sq), 8_000):
-                for rev in (False, True):
-                    asms += session.trace(ext, start=start, limit=min(len(sq), start + 8_000), end_pos=len(sq), rev_comp=rev)
+            for start in range(0, len(sq), 8_000):  # one work item of trace_ref each: push forward / reverse, pop forward / reverse
+                asms += session.execute_work(ext, start=start, limit=min(len(sq), start + 8_000), end_pos=len(sq))
             sections = tracer.process_assemblies(asms, ext, end_pos=len(sq), options=opt)
-            want += tracer.assemblies_coverage(ss, rm, sections, ext, end_pos=len(sq), vcf_name=name)[1]
+            want += tracer.assemblies_coverage(ss, rm, sections, ext, end_pos=len(sq), vcf_name=name,
+                                               options=tracer.CoverageOptions(simple_genotype_filter=0, rvg_exclude=1))[1]
         session.close()
         assert results[0]["a"] == want
         snps = [x.split("\t") for x in want if len(x.split("\t")[3]) == 1 and len(x.split("\t")[4]) == 1]
