@@ -350,126 +350,357 @@ __global__ void sk_bounds_kernel(const SkRec* __restrict__ recs, uint64_t n, int
 }
 
 
+// ---- equal records are counted once --------------------------------------------------------------------
+// At 30x coverage a super-k-mer that lies inside its reads comes ~20 times as the very same record (same bases,
+// same window count); only records cut by a read end or holding a sequencing error are alone.  Before the count
+// the records of a bucket therefore meet, a chunk at a time, in a small LDS hash table (slot = multiplicity :
+// index of the first record of that content, the representative): the representatives go to the count with
+// their multiplicity (a quarter to a third of the records), every record keeps the bucket-local index of its
+// representative, and the presence bits found for a representative are handed to its copies afterwards
+// (sk_spread_kernel).  Equal records of different chunks are simply not merged.
+constexpr int SKD_THREADS = 1024;
+constexpr int SKD_PER = 3;
+constexpr int SKD_CHUNK = SKD_PER * SKD_THREADS;
+constexpr int SKD_BITS = 12;
+constexpr int SKD_SLOTS = 1 << SKD_BITS;  // >= 4/3 of the chunk: the table never fills
+
+// Representatives that stand for at least min_count records ("full" ones: every window of theirs is a kept
+// k-mer whatever else happens) fill the bucket's slice of `reps` from its start, the others from its end
+// backwards; nrep[2 * bucket], nrep[2 * bucket + 1] = how many of each.  Within a chunk both kinds are in
+// order of decreasing window count, so that the 64 records of a wave of the count need the same number of
+// steps, or nearly.  rep_of = a record's representative, as an index into the bucket's slice.
+__global__ __launch_bounds__(SKD_THREADS) void sk_dedup_kernel(const SkRec* __restrict__ recs,
+                                                               const uint64_t* __restrict__ bounds, uint32_t min_count,
+                                                               SkRec* __restrict__ reps, uint16_t* __restrict__ mult,
+                                                               uint32_t* __restrict__ rep_of, uint32_t* __restrict__ nrep) {
+  __shared__ uint32_t s_dh[SKD_SLOTS];
+  __shared__ uint32_t s_hist[64];  // full representatives by window count (32 bins), then the others
+  __shared__ uint32_t s_full, s_other;
+  const uint32_t bucket = blockIdx.x;
+  const uint64_t lo = bounds[bucket], hi = bounds[bucket + 1];
+  const uint32_t last = uint32_t(hi - lo) - 1;
+  uint32_t base_full = 0, base_other = 0;  // representatives of the earlier chunks
+  for (uint64_t c0 = lo; c0 < hi; c0 += SKD_CHUNK) {  // block-uniform trip count
+    const uint32_t cn = hi - c0 < uint64_t(SKD_CHUNK) ? uint32_t(hi - c0) : uint32_t(SKD_CHUNK);
+    for (uint32_t i = threadIdx.x; i < uint32_t(SKD_SLOTS); i += SKD_THREADS) s_dh[i] = ~0u;
+    if (threadIdx.x < 64) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    SkRec r[SKD_PER];
+    uint32_t myslot[SKD_PER];
+    bool first[SKD_PER];
+#pragma unroll
+    for (int j = 0; j < SKD_PER; ++j) {
+      const uint32_t q = uint32_t(j) * SKD_THREADS + threadIdx.x;
+      myslot[j] = 0;
+      first[j] = false;
+      r[j].a = 0;
+      r[j].b = 0;
+      if (q < cn) {
+        r[j] = recs[c0 + q];
+        uint32_t slot = ((uint32_t(r[j].a) ^ uint32_t(r[j].a >> 32)) * 0x9E3779B1u ^
+                         (uint32_t(r[j].b) ^ uint32_t(r[j].b >> 32)) * 0x85EBCA6Bu) >> (32 - SKD_BITS);
+        for (;;) {
+          uint32_t e = s_dh[slot];
+          if (e == ~0u) {
+            e = atomicCAS(&s_dh[slot], ~0u, (1u << 16) | q);
+            if (e == ~0u) {  // first of its content
+              first[j] = true;
+              break;
+            }
+          }
+          const SkRec other = recs[c0 + (e & 0xffffu)];
+          if (other.a == r[j].a && other.b == r[j].b) {
+            atomicAdd(&s_dh[slot], 1u << 16);
+            break;
+          }
+          slot = (slot + 1) & uint32_t(SKD_SLOTS - 1);
+        }
+        myslot[j] = slot;
+      }
+    }
+    __syncthreads();
+    uint32_t m[SKD_PER], bin[SKD_PER], rank[SKD_PER];
+#pragma unroll
+    for (int j = 0; j < SKD_PER; ++j) {
+      m[j] = 0;
+      bin[j] = 0;
+      rank[j] = 0;
+      if (first[j]) {
+        m[j] = s_dh[myslot[j]] >> 16;  // <= SKD_CHUNK
+        bin[j] = (m[j] >= min_count ? 0u : 32u) + 31u - uint32_t(r[j].b & 31);
+        rank[j] = atomicAdd(&s_hist[bin[j]], 1u);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // exclusive scan of the bins by the first wave, each kind from zero
+      const uint32_t v = s_hist[threadIdx.x];
+      uint32_t x = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (int(threadIdx.x) >= d) x += y;
+      }
+      const uint32_t n_full = __shfl(x, 31, 64), n_all = __shfl(x, 63, 64);
+      s_hist[threadIdx.x] = x - v - (threadIdx.x >= 32 ? n_full : 0u);
+      if (threadIdx.x == 0) { s_full = n_full; s_other = n_all - n_full; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SKD_PER; ++j) {
+      if (first[j]) {
+        const uint32_t pos = s_hist[bin[j]] + rank[j];
+        const uint32_t idx = bin[j] < 32 ? base_full + pos : last - (base_other + pos);
+        reps[lo + idx] = r[j];
+        mult[lo + idx] = uint16_t(m[j]);
+        s_dh[myslot[j]] = idx;  // nobody else reads this slot's multiplicity
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SKD_PER; ++j) {
+      const uint32_t q = uint32_t(j) * SKD_THREADS + threadIdx.x;
+      if (q < cn) rep_of[c0 + q] = s_dh[myslot[j]];
+    }
+    base_full += s_full;
+    base_other += s_other;
+    __syncthreads();  // the tables are reset by the next chunk
+  }
+  if (threadIdx.x == 0) {
+    nrep[2 * bucket] = base_full;
+    nrep[2 * bucket + 1] = base_other;
+  }
+}
+
+// What the count found goes back to the records.  Local count (bits_out == nullptr): the presence words start as
+// "every window without an N is kept" (sk_present_valid_kernel) and rep_bits holds the windows NOT known to be
+// kept — nine records in ten have none, so one record in ten costs an atomic instead of every one (the 142 M
+// atomicOrs of the earlier version wrote 8 GB for a 0.4 GB bitmap).  The records of a bucket that was not
+// counted in LDS lose all their bits here and get them back from the finished hash set (kmer_skm_finish_present).
+// Remote records (bits_out): rep_bits holds the kept windows, kSkUnknown for an uncounted bucket, and they go
+// to bits_out[org] as they are.
+constexpr uint32_t kSkUnknown = 0x80000000u;
+constexpr int SKS_THREADS = 256;
+__global__ __launch_bounds__(SKS_THREADS) void sk_spread_kernel(const SkRec* __restrict__ recs,
+                                                                const uint64_t* __restrict__ bounds,
+                                                                const uint8_t* __restrict__ overflow,
+                                                                const uint32_t* __restrict__ rep_of,
+                                                                const uint32_t* __restrict__ rep_bits,
+                                                                const uint64_t* __restrict__ org,
+                                                                unsigned long long* __restrict__ present, int pstride,
+                                                                uint32_t* __restrict__ bits_out) {
+  const uint32_t bucket = blockIdx.x;
+  const uint64_t lo = bounds[bucket], hi = bounds[bucket + 1];
+  const bool uncounted = overflow[bucket] != 0;  // block-uniform
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += SKS_THREADS) {
+    if (bits_out) {
+      bits_out[org[i]] = rep_bits[lo + rep_of[i]];
+      continue;
+    }
+    uint32_t miss;
+    if (uncounted) {
+      const int n = sk_windows(recs[i].b);
+      miss = n == 32 ? ~0u : (1u << n) - 1;
+    } else {
+      miss = rep_bits[lo + rep_of[i]];
+    }
+    if (miss) {
+      const uint64_t o = org[i];
+      const uint64_t read = o >> 8;
+      const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
+      atomicAnd(&present[read * pstride + wi], ~((unsigned long long)miss << sh));
+      const unsigned long long over = sh ? (unsigned long long)miss >> (64 - sh) : 0ull;  // windows past the word
+      if (over) atomicAnd(&present[read * pstride + wi + 1], ~over);
+    }
+  }
+}
+
+// presence words of a local count before it: one bit per window that holds no N (the windows records are made of)
+__global__ void sk_present_valid_kernel(const uint32_t* __restrict__ nmask, const uint16_t* __restrict__ len,
+                                        uint64_t n_reads, int W, int k, unsigned long long* __restrict__ present,
+                                        int pstride) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_reads) return;
+  const int nk = int(len[i]) - k + 1;
+  bool any_n = false;
+  for (int q = 0; q < W; ++q) any_n |= nmask[i * W + q] != 0;
+  for (int j = 0; j < pstride; ++j) {
+    const int t0 = 64 * j;
+    unsigned long long m = 0;
+    if (nk > t0) m = nk - t0 >= 64 ? ~0ull : (1ull << (nk - t0)) - 1;
+    if (any_n && m) {
+      for (int b = 0; b < 64 && t0 + b < nk; ++b) {
+        const int t = t0 + b, q = t >> 5, r = t & 31;
+        const uint32_t n0 = nmask[i * W + q], n1 = q + 1 < W ? nmask[i * W + q + 1] : 0;
+        const uint32_t nm = r ? ((n0 << r) | (n1 >> (32 - r))) : n0;
+        if (nm >> (32 - k)) m &= ~(1ull << b);
+      }
+    }
+    present[i * pstride + j] = m;
+  }
+}
+
 // ---- counting: one workgroup per bucket, windows unrolled from the records into an LDS table ---------
 constexpr int SKC_THREADS = 1024;
-constexpr uint32_t kSkUnknown = 0x80000000u;  // bits_out: the record's bucket overflowed, look its windows up
+#ifdef SKC_TIMING  // tools/build_variant.sh <name> kmer_skm.hip -DSKC_TIMING: where a workgroup's time goes (stderr)
+__device__ unsigned long long g_skc_times[8];
+#define SKC_T(n) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_skc_times[n], now_ - t_last_); t_last_ = now_; } } while (0)
+#else
+#define SKC_T(n) do {} while (0)
+#endif
 
+// recs / mult: the bucket's representatives as sk_dedup_kernel leaves them (nrep[2 * bucket] full ones from the
+// start of the slice, nrep[2 * bucket + 1] others from its end backwards) and how many records each stands
+// for; bits_out[i] = the windows of representative i that are kept, or (store_miss) those that are not;
+// kSkUnknown when the bucket is not counted here (overflow[bucket] is set as well).
+#ifndef SKC_SPLIT
+#define SKC_SPLIT 4  // lanes that share the windows of one representative (a power of two, neighbours in a wave)
+#endif
 __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* __restrict__ recs,
-                                                                   const uint64_t* __restrict__ bounds, uint32_t cap,
+                                                                   const uint16_t* __restrict__ mult,
+                                                                   const uint64_t* __restrict__ bounds,
+                                                                   const uint32_t* __restrict__ nrep, uint32_t cap,
                                                                    int k, uint32_t min_count, uint64_t out_cap,
                                                                    uint64_t* __restrict__ out_kmers,
                                                                    uint32_t* __restrict__ out_counts,
                                                                    unsigned long long* __restrict__ out_n,
                                                                    unsigned long long* __restrict__ distinct_total,
                                                                    uint8_t* __restrict__ overflow,
-                                                                   const uint64_t* __restrict__ org,
-                                                                   unsigned long long* __restrict__ present,
-                                                                   int pstride, uint64_t* __restrict__ ulist,
-                                                                   uint32_t* __restrict__ bits_out, uint64_t giant) {
+                                                                   uint64_t* __restrict__ ulist,
+                                                                   uint32_t* __restrict__ bits_out, int store_miss,
+                                                                   uint64_t giant) {
   extern __shared__ __align__(16) unsigned char skc_smem[];
   unsigned long long* tkeys = reinterpret_cast<unsigned long long*>(skc_smem);
   uint32_t* tcnt = reinterpret_cast<uint32_t*>(skc_smem + size_t(cap) * 8);
-  __shared__ uint32_t s_over, s_kept, s_distinct, s_cursor, s_unsettled;
+  __shared__ uint32_t s_over, s_kept, s_distinct, s_cursor, s_unsettled, s_crossed;
   __shared__ unsigned long long s_base;
   const uint32_t bucket = blockIdx.x;
-  const uint64_t lo = bounds[bucket], hi = bounds[bucket + 1];
-  if (lo == hi) return;  // block-uniform
-  if (hi - lo > giant) {
+  const uint64_t lo = bounds[bucket], end = bounds[bucket + 1];
+  if (lo == end) return;  // block-uniform
+  const uint32_t n_full = nrep[2 * bucket], n_other = nrep[2 * bucket + 1];
+  if (end - lo > giant) {
     // a repeat family: one workgroup would spend tens of milliseconds serialising on a few LDS counters while
     // the rest of the GPU idles — such a bucket goes to the sort-based count with the overflowed ones
     if (threadIdx.x == 0) overflow[bucket] = 1;
-    if (bits_out)
-      for (uint64_t i = lo + threadIdx.x; i < hi; i += SKC_THREADS) bits_out[org[i]] = kSkUnknown;
+    for (uint64_t i = lo + threadIdx.x; i < end; i += SKC_THREADS) bits_out[i] = kSkUnknown;
     return;
   }
+#ifdef SKC_TIMING
+  unsigned long long t_last_ = wall_clock64();
+#endif
   for (uint32_t i = threadIdx.x; i < cap; i += SKC_THREADS) { tkeys[i] = ~0ull; tcnt[i] = 0; }
-  if (threadIdx.x == 0) { s_over = 0; s_kept = 0; s_distinct = 0; s_cursor = 0; s_unsettled = 0; }
+  if (threadIdx.x == 0) { s_over = 0; s_kept = 0; s_distinct = 0; s_cursor = 0; s_unsettled = 0; s_crossed = 0; }
   __syncthreads();
+  SKC_T(0);
   const uint32_t max_probe = cap < 256u ? cap : 256u;
   const uint64_t kmask = ~(~0ull << (2 * k));
-  // One flat loop per batch of records: every iteration is one probe of every live lane, and a lane whose
-  // probe hits moves on to its next window by itself.  (Nesting "for each window { probe until placed }" makes
-  // the whole wave wait for its slowest lane at every window, and its exec-mask bookkeeping saturated the
-  // scalar unit.)
-  // Presence bits (what the read-correction screen would otherwise look up window by window in HBM): counts
-  // only grow, so a window whose own increment reaches min_count is known to be kept right away — with 30x
-  // coverage that settles five windows in six.  The others are listed for the second sweep.
-  for (uint64_t i0 = lo; i0 < hi; i0 += SKC_THREADS) {  // block-uniform trip count
-    const uint64_t i = i0 + threadIdx.x;
-    bool live = i < hi;
-    SkRec r;
-    r.a = 0;
-    r.b = 0;
-    uint64_t o = 0;
-    if (live) {
-      r = recs[i];
-      o = org[i];
-    }
-    const int n = sk_windows(r.b);
-    int t = 0;
-    uint32_t bits = 0, und = 0;
-    // the bases that enter the window, next one on top (k <= 31: bases k.. of the record; field bits of b
-    // only come up after the last window)
-    uint64_t nb = (r.a << (2 * k)) | (r.b >> (64 - 2 * k));
-    uint64_t fwd = r.a >> (64 - 2 * k);
-    uint64_t rc = kmer_revcomp(fwd, k);
-    unsigned long long key = rc < fwd ? rc : fwd;
-    // 32-bit multiplies run at quarter rate: fold the key to 32 bits, one multiply, one multiply-high
-    uint32_t slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
-    uint32_t probes = 0;
-    while (__any(live)) {
+  // One flat loop per batch of work: every iteration is one probe of every live lane, and a lane whose probe
+  // hits moves on to its next window by itself.  (Nesting "for each window { probe until placed }" makes the
+  // whole wave wait for its slowest lane at every window, and its exec-mask bookkeeping saturated the scalar
+  // unit.)
+  // SKC_SPLIT neighbouring lanes share the windows of a record: few records are left, and the time of a pass is
+  // the number of steps of its longest lane.
+  // Pass 0, the full representatives: their windows are kept k-mers (the count only grows and starts at
+  // min_count or more).
+  // Pass 1, the others: a window whose own increment reaches min_count is known to be kept —
+  // after pass 0 that is every window of a k-mer that a full representative holds too, which leaves the k-mers
+  // of sequencing errors — and the rest are listed for the second sweep.  That sweep only has something to find
+  // when a pass-1 increment took a counter across min_count (the windows that counted before it are the ones
+  // it would correct): most buckets skip it.
+  for (int pass = 0; pass < 2; ++pass) {
+    const uint32_t items = (pass == 0 ? n_full : n_other) * SKC_SPLIT;
+    for (uint32_t it0 = 0; it0 < items; it0 += SKC_THREADS) {  // block-uniform trip count
+      const uint32_t it = it0 + threadIdx.x;
+      bool live = it < items;
+      const uint64_t i = pass == 0 ? lo + it / SKC_SPLIT : end - 1 - it / SKC_SPLIT;
+      SkRec r;
+      r.a = 0;
+      r.b = 0;
+      uint32_t m = 0;
       if (live) {
-        // LDS atomics run at about a lane per clock: most occurrences find their key already in place, and a
-        // plain read (full rate) spares them the compare-and-swap
-        unsigned long long cur = __atomic_load_n(&tkeys[slot], __ATOMIC_RELAXED);
-        if (cur == ~0ull) {
-          cur = atomicCAS(&tkeys[slot], ~0ull, key);
-          if (cur == ~0ull) cur = key;
-        }
-        if (cur == key) {
-          const uint32_t seen = atomicAdd(&tcnt[slot], 1u) + 1;
-          if (seen >= min_count) bits |= 1u << t; else und |= 1u << t;
-          if (++t >= n) {
-            live = false;
-          } else {
-            const uint64_t base = nb >> 62;  // the base that enters the window
-            nb <<= 2;
-            fwd = ((fwd << 2) | base) & kmask;
-            rc = (rc >> 2) | ((base ^ 3) << (2 * (k - 1)));
-            key = rc < fwd ? rc : fwd;
-            slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
-            probes = 0;
+        r = recs[i];
+        m = mult[i];
+      }
+      const int n = sk_windows(r.b);
+      const int per = (n + SKC_SPLIT - 1) / SKC_SPLIT;
+      int t = int(it % SKC_SPLIT) * per;
+      const int t_end = t + per < n ? t + per : n;
+      if (t >= t_end) live = false;
+      uint32_t bits = 0, und = 0;
+      bool crossed = false;
+      // window t, and the bases that enter the following windows, next one on top (k <= 31, t <= 31: only base
+      // bits of b come into it; its field bits only come up after the last window)
+      const uint64_t x = t ? ((r.a << (2 * t)) | (r.b >> (64 - 2 * t))) : r.a;
+      uint64_t nb = ((r.a << (2 * k)) | (r.b >> (64 - 2 * k))) << (2 * t);
+      uint64_t fwd = x >> (64 - 2 * k);
+      uint64_t rc = kmer_revcomp(fwd, k);
+      unsigned long long key = rc < fwd ? rc : fwd;
+      // 32-bit multiplies run at quarter rate: fold the key to 32 bits, one multiply, one multiply-high
+      uint32_t slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
+      uint32_t probes = 0;
+      while (__any(live)) {
+        if (live) {
+          // LDS atomics run at about a lane per clock: most occurrences find their key already in place, and a
+          // plain read (full rate) spares them the compare-and-swap
+          unsigned long long cur = __atomic_load_n(&tkeys[slot], __ATOMIC_RELAXED);
+          if (cur == ~0ull) {
+            cur = atomicCAS(&tkeys[slot], ~0ull, key);
+            if (cur == ~0ull) cur = key;
           }
+          if (cur == key) {
+            const uint32_t seen = atomicAdd(&tcnt[slot], m) + m;
+            if (seen >= min_count) {
+              bits |= 1u << t;
+              crossed |= seen - m < min_count;
+            } else {
+              und |= 1u << t;
+            }
+            if (++t >= t_end) {
+              live = false;
+            } else {
+              const uint64_t base = nb >> 62;  // the base that enters the window
+              nb <<= 2;
+              fwd = ((fwd << 2) | base) & kmask;
+              rc = (rc >> 2) | ((base ^ 3) << (2 * (k - 1)));
+              key = rc < fwd ? rc : fwd;
+              slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
+              probes = 0;
+            }
+          } else {
+            slot = slot + 1 == cap ? 0 : slot + 1;
+            if (++probes >= max_probe) { s_over = 1; live = false; }
+          }
+        }
+      }
+      // the lanes of a record put their windows together
+#pragma unroll
+      for (int d = 1; d < SKC_SPLIT; d <<= 1) {
+        bits |= uint32_t(__shfl_xor(int(bits), d, 64));
+        und |= uint32_t(__shfl_xor(int(und), d, 64));
+      }
+      if (crossed && pass == 1) s_crossed = 1;
+      if (it < items && it % SKC_SPLIT == 0) {
+        if (pass == 0) {
+          bits_out[i] = store_miss ? 0u : (n == 32 ? ~0u : (1u << n) - 1);
         } else {
-          slot = slot + 1 == cap ? 0 : slot + 1;
-          if (++probes >= max_probe) { s_over = 1; live = false; }
+          // the unsettled records are listed densely (in the bucket's own slice of ulist) so that the second
+          // sweep keeps every lane busy
+          if (und) ulist[lo + atomicAdd(&s_unsettled, 1u)] = (uint64_t(i - lo) << 32) | und;
+          bits_out[i] = store_miss ? und : bits;
         }
       }
     }
-    if (i < hi) {
-      // the unsettled records are listed densely (in the bucket's own slice of ulist) so that the second
-      // sweep keeps every lane busy
-      if (und) ulist[lo + atomicAdd(&s_unsettled, 1u)] = (uint64_t(i - lo) << 32) | und;
-      if (bits_out) {  // remote records: the bits go back to the rank the record came from (o = its index)
-        bits_out[o] = bits;
-      } else if (bits) {  // a k-mer that reached min_count is kept whatever happens to the rest of the bucket
-        const uint64_t read = o >> 8;
-        const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
-        atomicOr(&present[read * pstride + wi], (unsigned long long)bits << sh);
-        if (sh + n > 64) atomicOr(&present[read * pstride + wi + 1], (unsigned long long)bits >> (64 - sh));
-      }
-    }
+    if (pass == 0) SKC_T(4);
+    __syncthreads();  // pass 1 relies on every increment of pass 0
   }
-  __syncthreads();
+  SKC_T(1);
   if (s_over) {
     if (threadIdx.x == 0) overflow[bucket] = 1;
-    if (bits_out)
-      for (uint64_t i = lo + threadIdx.x; i < hi; i += SKC_THREADS) bits_out[org[i]] = kSkUnknown;
+    for (uint64_t i = lo + threadIdx.x; i < end; i += SKC_THREADS) bits_out[i] = kSkUnknown;
     return;
   }
   // Second sweep, the table being final: the windows that were not settled above (the first min_count - 1
   // occurrences of every k-mer, and the k-mers that stay below min_count).
-  const uint32_t n_unsettled = s_unsettled;
+  const uint32_t n_unsettled = s_crossed ? s_unsettled : 0u;  // nothing crossed: what was unsettled is not kept
   for (uint32_t q0 = 0; q0 < n_unsettled; q0 += SKC_THREADS) {
     const uint32_t q = q0 + threadIdx.x;
     const uint64_t ent = q < n_unsettled ? ulist[lo + q] : 0ull;
@@ -479,7 +710,6 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
     r.a = 0;
     r.b = 0;
     if (und) r = recs[i];
-    const int n = sk_windows(r.b);
     uint32_t bits = 0, slot = 0;
     int t = -1;  // window being looked up, -1: take the next one
     unsigned long long key = 0;
@@ -502,18 +732,11 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
         }
       }
     }
-    if (bits) {
-      const uint64_t o = org[i];
-      if (bits_out) {
-        bits_out[o] |= bits;  // this thread is the only one touching the record in this sweep
-      } else {
-        const uint64_t read = o >> 8;
-        const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
-        atomicOr(&present[read * pstride + wi], (unsigned long long)bits << sh);
-        if (sh + n > 64) atomicOr(&present[read * pstride + wi + 1], (unsigned long long)bits >> (64 - sh));
-      }
+    if (bits) {  // this thread is the only one touching the record in this sweep
+      if (store_miss) bits_out[i] &= ~bits; else bits_out[i] |= bits;
     }
   }
+  SKC_T(2);
   uint32_t my_kept = 0, my_distinct = 0;
   for (uint32_t i = threadIdx.x; i < cap; i += SKC_THREADS) {
     if (tkeys[i] != ~0ull) {
@@ -536,6 +759,7 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
       if (o < out_cap) { out_kmers[o] = tkeys[i]; out_counts[o] = tcnt[i]; }
     }
   }
+  SKC_T(3);
 }
 
 // windows of the records of the overflowed buckets as plain canonical instances, nmax slots per record (unused
@@ -741,7 +965,10 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
   *done = true;
   ks->present_stride = std::max(1, (g.maxw + 63) / 64);
   BG_TRY(ks->present.alloc(ctx, reads->n * ks->present_stride));
-  BG_HIP(hipMemsetAsync(ks->present.p, 0, reads->n * ks->present_stride * 8, ctx->stream));
+  sk_present_valid_kernel<<<cdiv(reads->n, 256), 256, 0, ctx->stream>>>(
+      reads->nmask.p, reads->len.p, reads->n, reads->W, k, reinterpret_cast<unsigned long long*>(ks->present.p),
+      ks->present_stride);
+  BG_LAUNCH_CHECK();
   ks->present_of = reads;
   ks->present_n = reads->n;
   return sk_count_records(ctx, ra.p, oa.p, R, N, k, min_count, ks, nullptr);
@@ -813,11 +1040,23 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
   DevBuf<uint32_t> oc_a;
   BG_TRY(ok_a.alloc(ctx, out_cap));
   BG_TRY(oc_a.alloc(ctx, out_cap));
-  DevBuf<uint64_t> ulist;  // per bucket: (record : windows) whose presence the first sweep could not settle
+  DevBuf<uint64_t> ulist;  // per bucket: (representative : windows) whose presence the first sweep could not settle
   BG_TRY(ulist.alloc(ctx, R));
-  ctx->tic("skm_count_lds");
+  ctx->tic("skm_dedup");
   sk_bounds_kernel<<<cdiv(uint64_t(NB) + 1, 256), 256, 0, ctx->stream>>>(part, R, bucket_bits, bounds.p);
   BG_LAUNCH_CHECK();
+  // every bucket's distinct records, in the first places of its slice of `reps`
+  SkRec* reps = part == rb.p ? rc.p : rb.p;  // the other partition buffer is free
+  DevBuf<uint16_t> rep_mult;
+  DevBuf<uint32_t> rep_of, rep_bits, nrep;
+  BG_TRY(rep_mult.alloc(ctx, R));
+  BG_TRY(rep_of.alloc(ctx, R));
+  BG_TRY(rep_bits.alloc(ctx, R));
+  BG_TRY(nrep.alloc(ctx, 2 * uint64_t(NB)));
+  sk_dedup_kernel<<<NB, SKD_THREADS, 0, ctx->stream>>>(part, bounds.p, min_count, reps, rep_mult.p, rep_of.p, nrep.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(R * 38);
+  ctx->tic("skm_count_lds");
   const uint32_t slots = sk_lds_slots();
   const size_t smem = size_t(slots) * 12;
   // buckets with more than 64 records per thread (30x the average at chr20) are not counted in LDS
@@ -825,12 +1064,27 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
   if (const char* e = getenv("BG_SKM_GIANT")) giant = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
   BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sk_count_lds_kernel),
                              hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
-  sk_count_lds_kernel<<<NB, SKC_THREADS, smem, ctx->stream>>>(part, bounds.p, slots, k, min_count, out_cap, ok_a.p, oc_a.p, ctr.p,
-                                                             ctr.p + 1, overflow.p, part_org,
-                                                             reinterpret_cast<unsigned long long*>(ks->present.p), ks->present_stride, ulist.p,
-                                                             bits_out, giant);
+  sk_count_lds_kernel<<<NB, SKC_THREADS, smem, ctx->stream>>>(reps, rep_mult.p, bounds.p, nrep.p, slots, k, min_count, out_cap,
+                                                             ok_a.p, oc_a.p, ctr.p, ctr.p + 1, overflow.p, ulist.p, rep_bits.p,
+                                                             bits_out ? 0 : 1, giant);
   BG_LAUNCH_CHECK();
+#ifdef SKC_TIMING
+  {
+    unsigned long long h_t[8], z[8] = {0};
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    BG_HIP(hipMemcpyFromSymbol(h_t, HIP_SYMBOL(g_skc_times), sizeof(h_t)));
+    fprintf(stderr, "sk_count_lds_kernel, 100 MHz ticks summed over workgroups: init %llu pass 0 %llu pass 1 %llu second sweep %llu output %llu\n",
+            h_t[0], h_t[4], h_t[1], h_t[2], h_t[3]);
+    BG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_skc_times), z, sizeof(z)));
+  }
+#endif
   ctx->toc(R * 40);
+  ctx->tic("skm_spread");
+  sk_spread_kernel<<<NB, SKS_THREADS, 0, ctx->stream>>>(part, bounds.p, overflow.p, rep_of.p, rep_bits.p, part_org,
+                                                        reinterpret_cast<unsigned long long*>(ks->present.p),
+                                                        ks->present_stride, bits_out);
+  BG_LAUNCH_CHECK();
+  ctx->toc(R * 24);
   unsigned long long h_ctr[2] = {0, 0};
   std::vector<uint8_t> h_over(NB);
   BG_HIP(hipMemcpyAsync(h_ctr, ctr.p, 16, hipMemcpyDeviceToHost, ctx->stream));

@@ -5,7 +5,7 @@ ROOT=$(pwd); export TMPDIR=/tmp
 for v in gpurun_variants/libbgseq.so.*; do
   name=${v##*.so.}
   rm -rf /tmp/vt_$name
-  (cd /tmp && BG_LIBBGSEQ=$ROOT/$v rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/vt_$name -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-discover --no-end-to-end > /tmp/vt_$name.out 2> /tmp/vt_$name.log)
+  (cd /tmp && BG_LIBBGSEQ=$ROOT/$v timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/vt_$name -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-discover --no-end-to-end > /tmp/vt_$name.out 2> /tmp/vt_$name.log)
   f=$(find /tmp/vt_$name -name '*kernel_stats.csv' | head -1)
   echo "== $name: $(grep -o '"ms_per_step": [0-9.]*' /tmp/vt_$name.out | head -1)"
   [ -n "$f" ] && python3 - "$f" "$PAT" <<'PY'
