@@ -25,6 +25,9 @@ namespace bg {
 
 int kmer_count_keys_sort_impl(bg_ctx* ctx, uint64_t* ka, uint64_t* kb, uint64_t N, uint32_t min_count, bg_kmerset* ks);
 
+#ifndef SK_GEN_SGPR
+#define SK_GEN_SGPR 80
+#endif
 constexpr int SK_M = 12;          // minimiser length
 constexpr int SK_THREADS = 256;
 constexpr int SK_BINS = 256;
@@ -185,7 +188,7 @@ __device__ __forceinline__ SkRec sk_build_record(const uint64_t* __restrict__ wo
 // record is cut) and only notes (read, first window, windows, minimiser) in LDS; phase 2 builds the records
 // with every lane busy and appends them to `out` as one block (one global atomic per tile; the order of tiles
 // is whatever the scheduler makes it — only grouping matters downstream).
-__global__ __launch_bounds__(SK_THREADS) void sk_generate_kernel(SkSource src, SkRec* __restrict__ out,
+__global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_num_sgpr(SK_GEN_SGPR))) void sk_generate_kernel(SkSource src, SkRec* __restrict__ out,
                                                                  uint64_t* __restrict__ org, uint64_t cap,
                                                                  unsigned long long* __restrict__ cursor) {
   __shared__ uint64_t sdesc[SK_CAP];  // read in tile : 16 | first window : 8 | windows - 1 : 8 | order : 32
@@ -515,27 +518,38 @@ __global__ __launch_bounds__(SKS_THREADS) void sk_spread_kernel(const SkRec* __r
 }
 
 // presence words of a local count before it: one bit per window that holds no N (the windows records are made of)
-__global__ void sk_present_valid_kernel(const uint32_t* __restrict__ nmask, const uint16_t* __restrict__ len,
-                                        uint64_t n_reads, int W, int k, unsigned long long* __restrict__ present,
-                                        int pstride) {
+__global__ __launch_bounds__(256) void sk_present_valid_kernel(const uint32_t* __restrict__ nmask,
+                                                               const uint16_t* __restrict__ len, uint64_t n_reads,
+                                                               int W, int k, unsigned long long* __restrict__ present,
+                                                               int pstride) {
   const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n_reads) return;
   const int nk = int(len[i]) - k + 1;
-  bool any_n = false;
-  for (int q = 0; q < W; ++q) any_n |= nmask[i * W + q] != 0;
-  for (int j = 0; j < pstride; ++j) {
+  uint32_t any_n = 0;  // nearly every read has no N at all and needs nothing but its length
+#pragma unroll
+  for (int q = 0; q < 8; ++q)  // W <= 8; all the loads in flight at once
+    if (q < W) any_n |= nmask[i * W + q];
+  unsigned long long m[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
     const int t0 = 64 * j;
-    unsigned long long m = 0;
-    if (nk > t0) m = nk - t0 >= 64 ? ~0ull : (1ull << (nk - t0)) - 1;
-    if (any_n && m) {
-      for (int b = 0; b < 64 && t0 + b < nk; ++b) {
-        const int t = t0 + b, q = t >> 5, r = t & 31;
+    m[j] = 0;
+    if (nk > t0) m[j] = nk - t0 >= 64 ? ~0ull : (1ull << (nk - t0)) - 1;
+    if (any_n && m[j]) {
+      for (int bb = 0; bb < 64 && t0 + bb < nk; ++bb) {
+        const int t = t0 + bb, q = t >> 5, r = t & 31;
         const uint32_t n0 = nmask[i * W + q], n1 = q + 1 < W ? nmask[i * W + q + 1] : 0;
         const uint32_t nm = r ? ((n0 << r) | (n1 >> (32 - r))) : n0;
-        if (nm >> (32 - k)) m &= ~(1ull << b);
+        if (nm >> (32 - k)) m[j] &= ~(1ull << bb);
       }
     }
-    present[i * pstride + j] = m;
+  }
+  if (pstride == 2) {
+    *reinterpret_cast<ulonglong2*>(present + i * 2) = make_ulonglong2(m[0], m[1]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < pstride) present[i * pstride + j] = m[j];
   }
 }
 
@@ -555,7 +569,7 @@ __device__ unsigned long long g_skc_times[8];
 #ifndef SKC_SPLIT
 #define SKC_SPLIT 4  // lanes that share the windows of one representative (a power of two, neighbours in a wave)
 #endif
-__global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* __restrict__ recs,
+__global__ __launch_bounds__(SKC_THREADS) __attribute__((amdgpu_num_sgpr(80))) void sk_count_lds_kernel(const SkRec* __restrict__ recs,
                                                                    const uint16_t* __restrict__ mult,
                                                                    const uint64_t* __restrict__ bounds,
                                                                    const uint32_t* __restrict__ nrep, uint32_t cap,
@@ -586,6 +600,8 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
   }
 #ifdef SKC_TIMING
   unsigned long long t_last_ = wall_clock64();
+  const unsigned long long t_first_ = t_last_;
+  if (threadIdx.x == 0) atomicMax(&g_skc_times[7], atomicAdd(&g_skc_times[6], 1ull) + 1);
 #endif
   for (uint32_t i = threadIdx.x; i < cap; i += SKC_THREADS) { tkeys[i] = ~0ull; tcnt[i] = 0; }
   if (threadIdx.x == 0) { s_over = 0; s_kept = 0; s_distinct = 0; s_cursor = 0; s_unsettled = 0; s_crossed = 0; }
@@ -625,7 +641,7 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
       int t = int(it % SKC_SPLIT) * per;
       const int t_end = t + per < n ? t + per : n;
       if (t >= t_end) live = false;
-      uint32_t bits = 0, und = 0;
+      uint32_t bits = 0, und = 0, new_kept = 0, new_distinct = 0;
       bool crossed = false;
       // window t, and the bases that enter the following windows, next one on top (k <= 31, t <= 31: only base
       // bits of b come into it; its field bits only come up after the last window)
@@ -644,13 +660,19 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
           unsigned long long cur = __atomic_load_n(&tkeys[slot], __ATOMIC_RELAXED);
           if (cur == ~0ull) {
             cur = atomicCAS(&tkeys[slot], ~0ull, key);
-            if (cur == ~0ull) cur = key;
+            if (cur == ~0ull) {
+              cur = key;
+              ++new_distinct;
+            }
           }
           if (cur == key) {
             const uint32_t seen = atomicAdd(&tcnt[slot], m) + m;
             if (seen >= min_count) {
               bits |= 1u << t;
-              crossed |= seen - m < min_count;
+              if (seen - m < min_count) {  // this increment made the k-mer a kept one
+                crossed = true;
+                ++new_kept;
+              }
             } else {
               und |= 1u << t;
             }
@@ -678,6 +700,18 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
         und |= uint32_t(__shfl_xor(int(und), d, 64));
       }
       if (crossed && pass == 1) s_crossed = 1;
+      {  // one LDS atomic per wave (the counters are single addresses); a lane has at most 32 windows
+        uint32_t wk = 0, wd = 0;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          wk += uint32_t(__popcll(__ballot((new_kept >> b) & 1))) << b;
+          wd += uint32_t(__popcll(__ballot((new_distinct >> b) & 1))) << b;
+        }
+        if ((threadIdx.x & 63) == 0) {
+          if (wk) atomicAdd(&s_kept, wk);
+          if (wd) atomicAdd(&s_distinct, wd);
+        }
+      }
       if (it < items && it % SKC_SPLIT == 0) {
         if (pass == 0) {
           bits_out[i] = store_miss ? 0u : (n == 32 ? ~0u : (1u << n) - 1);
@@ -698,18 +732,27 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
     for (uint64_t i = lo + threadIdx.x; i < end; i += SKC_THREADS) bits_out[i] = kSkUnknown;
     return;
   }
-  // Second sweep, the table being final: the windows that were not settled above (the first min_count - 1
-  // occurrences of every k-mer, and the k-mers that stay below min_count).
-  const uint32_t n_unsettled = s_crossed ? s_unsettled : 0u;  // nothing crossed: what was unsettled is not kept
+  // The counters are final: room for the bucket's kept k-mers is asked for now, and the answer comes while the
+  // second sweep runs.  (Kept and distinct k-mers were counted as they came about.)
+  if (threadIdx.x == 0) {
+    s_base = s_kept ? atomicAdd(out_n, (unsigned long long)s_kept) : 0ull;
+    if (s_distinct) atomicAdd(distinct_total, (unsigned long long)s_distinct);
+  }
+  // Second sweep, the table being final: the windows that were not settled above, SKC_SPLIT lanes to a record.
+  const uint32_t n_unsettled = (s_crossed ? s_unsettled : 0u) * SKC_SPLIT;  // nothing crossed: none of them is kept
   for (uint32_t q0 = 0; q0 < n_unsettled; q0 += SKC_THREADS) {
     const uint32_t q = q0 + threadIdx.x;
-    const uint64_t ent = q < n_unsettled ? ulist[lo + q] : 0ull;
+    const uint64_t ent = q < n_unsettled ? ulist[lo + q / SKC_SPLIT] : 0ull;
     uint32_t und = uint32_t(ent);
     const uint64_t i = lo + (ent >> 32);
     SkRec r;
     r.a = 0;
     r.b = 0;
     if (und) r = recs[i];
+    {
+      const int per = (sk_windows(r.b) + SKC_SPLIT - 1) / SKC_SPLIT;  // <= 8
+      und &= (per >= 32 ? ~0u : (1u << per) - 1) << (int(q % SKC_SPLIT) * per);
+    }
     uint32_t bits = 0, slot = 0;
     int t = -1;  // window being looked up, -1: take the next one
     unsigned long long key = 0;
@@ -717,7 +760,7 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
       if (und) {
         if (t < 0) {
           t = __ffs(und) - 1;
-          const uint64_t x = t ? ((r.a << (2 * t)) | (r.b >> (64 - 2 * t))) : r.a;  // t <= 21: only base bits of b
+          const uint64_t x = t ? ((r.a << (2 * t)) | (r.b >> (64 - 2 * t))) : r.a;  // t <= 31: only base bits of b
           const uint64_t fwd = x >> (64 - 2 * k);
           const uint64_t rc = kmer_revcomp(fwd, k);
           key = rc < fwd ? rc : fwd;
@@ -732,32 +775,32 @@ __global__ __launch_bounds__(SKC_THREADS) void sk_count_lds_kernel(const SkRec* 
         }
       }
     }
-    if (bits) {  // this thread is the only one touching the record in this sweep
+#pragma unroll
+    for (int d = 1; d < SKC_SPLIT; d <<= 1) bits |= uint32_t(__shfl_xor(int(bits), d, 64));
+    if (bits && q % SKC_SPLIT == 0) {  // this thread is the only one touching the record in this sweep
       if (store_miss) bits_out[i] &= ~bits; else bits_out[i] |= bits;
     }
   }
+  __syncthreads();
   SKC_T(2);
-  uint32_t my_kept = 0, my_distinct = 0;
-  for (uint32_t i = threadIdx.x; i < cap; i += SKC_THREADS) {
-    if (tkeys[i] != ~0ull) {
-      ++my_distinct;
-      if (tcnt[i] >= min_count) ++my_kept;
-    }
-  }
-  if (my_distinct) atomicAdd(&s_distinct, my_distinct);
-  if (my_kept) atomicAdd(&s_kept, my_kept);
-  __syncthreads();
+#ifdef SKC_TIMING
   if (threadIdx.x == 0) {
-    s_base = s_kept ? atomicAdd(out_n, (unsigned long long)s_kept) : 0ull;
-    if (s_distinct) atomicAdd(distinct_total, (unsigned long long)s_distinct);
+    atomicMax(&g_skc_times[5], ((t_last_ - t_first_) << 24) | bucket);
+    atomicAdd(&g_skc_times[6], ~0ull);
   }
-  __syncthreads();
+#endif
   if (!s_kept) return;
-  for (uint32_t i = threadIdx.x; i < cap; i += SKC_THREADS) {
-    if (tkeys[i] != ~0ull && tcnt[i] >= min_count) {
-      const uint64_t o = s_base + atomicAdd(&s_cursor, 1u);
-      if (o < out_cap) { out_kmers[o] = tkeys[i]; out_counts[o] = tcnt[i]; }
-    }
+  const uint64_t out_base = s_base;
+  for (uint32_t i0 = 0; i0 < cap; i0 += SKC_THREADS) {  // block-uniform trip count
+    const uint32_t i = i0 + threadIdx.x;
+    const bool keep = i < cap && tkeys[i] != ~0ull && tcnt[i] >= min_count;
+    const uint64_t km = __ballot(keep);
+    if (!km) continue;  // wave-uniform
+    const int lane = threadIdx.x & 63, leader = __ffsll((unsigned long long)km) - 1;
+    uint32_t at = 0;
+    if (lane == leader) at = atomicAdd(&s_cursor, uint32_t(__popcll(km)));
+    at = uint32_t(__builtin_amdgcn_readlane(int(at), leader)) + uint32_t(__popcll(km & ((1ull << lane) - 1)));
+    if (keep && out_base + at < out_cap) { out_kmers[out_base + at] = tkeys[i]; out_counts[out_base + at] = tcnt[i]; }
   }
   SKC_T(3);
 }
@@ -960,11 +1003,15 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
   BG_TRY(ra.alloc(ctx, g.cap));
   BG_TRY(oa.alloc(ctx, g.cap));
   uint64_t R = 0;
-  BG_TRY(sk_generate(ctx, reads, g, ra.p, oa.p, &R));
-  if (R > g.cap) return BG_OK;  // *done stays false
-  *done = true;
   ks->present_stride = std::max(1, (g.maxw + 63) / 64);
   BG_TRY(ks->present.alloc(ctx, reads->n * ks->present_stride));
+  BG_TRY(sk_generate(ctx, reads, g, ra.p, oa.p, &R));
+  if (R > g.cap) {  // *done stays false
+    ks->present.reset();
+    return BG_OK;
+  }
+  *done = true;
+  if (reads->W > 8) { set_error("k-mer counting: reads of more than 256 bases"); return BG_EINVAL; }
   sk_present_valid_kernel<<<cdiv(reads->n, 256), 256, 0, ctx->stream>>>(
       reads->nmask.p, reads->len.p, reads->n, reads->W, k, reinterpret_cast<unsigned long long*>(ks->present.p),
       ks->present_stride);
@@ -1073,8 +1120,8 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
     unsigned long long h_t[8], z[8] = {0};
     BG_HIP(hipStreamSynchronize(ctx->stream));
     BG_HIP(hipMemcpyFromSymbol(h_t, HIP_SYMBOL(g_skc_times), sizeof(h_t)));
-    fprintf(stderr, "sk_count_lds_kernel, 100 MHz ticks summed over workgroups: init %llu pass 0 %llu pass 1 %llu second sweep %llu output %llu\n",
-            h_t[0], h_t[4], h_t[1], h_t[2], h_t[3]);
+    fprintf(stderr, "sk_count_lds_kernel, 100 MHz ticks summed over workgroups: init %llu pass 0 %llu pass 1 %llu second sweep %llu output %llu; slowest workgroup before its output: %llu ticks (bucket %llu); most workgroups at once %llu\n",
+            h_t[0], h_t[4], h_t[1], h_t[2], h_t[3], h_t[5] >> 24, h_t[5] & 0xffffff, h_t[7]);
     BG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_skc_times), z, sizeof(z)));
   }
 #endif

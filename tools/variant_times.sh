@@ -12,6 +12,6 @@ for v in gpurun_variants/libbgseq.so.*; do
 import csv, sys, re
 for r in csv.DictReader(open(sys.argv[1])):
     if re.search(sys.argv[2], r["Name"]):
-        print("   %-50s calls %s avg_us %.1f" % (r["Name"].split("(")[0][:50], r["Calls"], float(r["AverageNs"]) / 1e3))
+        print("   %-50s calls %s avg_us %.1f min_us %.1f max_us %.1f" % (r["Name"].split("(")[0][:50], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 PY
 done
