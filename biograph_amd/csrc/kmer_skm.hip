@@ -280,12 +280,16 @@ __global__ __launch_bounds__(SK_THREADS) void sk_part_hist_kernel(const SkRec* _
   hist[hbase + uint64_t(threadIdx.x) * nt + ti] = h[threadIdx.x];
 }
 
+// Org = what travels with a record: its 64-bit origin (read : first window), or — the count's own levels — its
+// 32-bit index in the order the records came in (kIndex: made here, oin is not read), which is all the count
+// needs to find the origin of the one record in ten it has something to tell.
+template <typename Org, bool kIndex>
 __global__ __launch_bounds__(SK_THREADS) void sk_part_scatter_kernel(const SkRec* __restrict__ in, SkRec* __restrict__ out,
-                                                                     const uint64_t* __restrict__ oin,
-                                                                     uint64_t* __restrict__ oout, SkSegs sg, int shift,
+                                                                     const Org* __restrict__ oin,
+                                                                     Org* __restrict__ oout, SkSegs sg, int shift,
                                                                      uint32_t dmask, const uint64_t* __restrict__ offs) {
   __shared__ SkRec srec[SK2_TILE];
-  __shared__ uint64_t sorg[SK2_TILE];
+  __shared__ Org sorg[SK2_TILE];
   __shared__ uint32_t h[SK_BINS];
   __shared__ uint32_t binstart[SK_BINS];
   __shared__ uint64_t goff[SK_BINS];
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_part_scatter_kernel(const SkRec
   sk_locate(sg, uint32_t(xcd_chunk(blockIdx.x, gridDim.x)), &lo, &hi, &hbase, &nt, &ti);  // XCD-contiguous tiles
   __syncthreads();
   SkRec rec[SK2_ITEMS];
-  uint64_t og[SK2_ITEMS];
+  Org og[SK2_ITEMS];
   uint16_t rnk[SK2_ITEMS];
 #pragma unroll
   for (int it = 0; it < SK2_ITEMS; ++it) {
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_part_scatter_kernel(const SkRec
     og[it] = 0;
     if (idx < hi) {
       rec[it] = in[idx];
-      og[it] = oin[idx];
+      og[it] = kIndex ? Org(idx) : oin[idx];
       rnk[it] = uint16_t(atomicAdd(&h[(sk_bucket(rec[it].b) >> shift) & dmask], 1u));
     } else {
       rec[it].a = 0;
@@ -480,7 +484,8 @@ __global__ __launch_bounds__(SKD_THREADS) void sk_dedup_kernel(const SkRec* __re
 // atomicOrs of the earlier version wrote 8 GB for a 0.4 GB bitmap).  The records of a bucket that was not
 // counted in LDS lose all their bits here and get them back from the finished hash set (kmer_skm_finish_present).
 // Remote records (bits_out): rep_bits holds the kept windows, kSkUnknown for an uncounted bucket, and they go
-// to bits_out[org] as they are.
+// to bits_out as they are.  idx = a record's place in the order the count received the records in (what the
+// partition moves along with it), org = the origins (read : first window) in that order.
 constexpr uint32_t kSkUnknown = 0x80000000u;
 constexpr int SKS_THREADS = 256;
 __global__ __launch_bounds__(SKS_THREADS) void sk_spread_kernel(const SkRec* __restrict__ recs,
@@ -488,30 +493,58 @@ __global__ __launch_bounds__(SKS_THREADS) void sk_spread_kernel(const SkRec* __r
                                                                 const uint8_t* __restrict__ overflow,
                                                                 const uint32_t* __restrict__ rep_of,
                                                                 const uint32_t* __restrict__ rep_bits,
+                                                                const uint32_t* __restrict__ idx,
                                                                 const uint64_t* __restrict__ org,
                                                                 unsigned long long* __restrict__ present, int pstride,
                                                                 uint32_t* __restrict__ bits_out) {
   const uint32_t bucket = blockIdx.x;
   const uint64_t lo = bounds[bucket], hi = bounds[bucket + 1];
   const bool uncounted = overflow[bucket] != 0;  // block-uniform
-  for (uint64_t i = lo + threadIdx.x; i < hi; i += SKS_THREADS) {
+  // four records per thread and step: their look-ups (representative -> its bits; for the record in ten that has
+  // something to clear, index -> origin -> presence word) are four dependent chains in flight instead of one
+  for (uint64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * SKS_THREADS) {
+    uint32_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint64_t i = i0 + uint64_t(u) * SKS_THREADS;
+      v[u] = 0;
+      if (i < hi) v[u] = uncounted ? uint32_t(recs[i].b) : rep_of[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint64_t i = i0 + uint64_t(u) * SKS_THREADS;
+      if (i >= hi) {
+        v[u] = 0;
+      } else if (uncounted) {  // every window is to be looked up later
+        const int n = sk_windows(v[u]);
+        v[u] = bits_out ? kSkUnknown : (n == 32 ? ~0u : (1u << n) - 1);
+      } else {
+        v[u] = rep_bits[lo + v[u]];
+      }
+    }
+    uint32_t at[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint64_t i = i0 + uint64_t(u) * SKS_THREADS;
+      at[u] = 0;
+      if (i < hi && (bits_out || v[u])) at[u] = idx[i];
+    }
     if (bits_out) {
-      bits_out[org[i]] = rep_bits[lo + rep_of[i]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + uint64_t(u) * SKS_THREADS < hi) bits_out[at[u]] = v[u];
       continue;
     }
-    uint32_t miss;
-    if (uncounted) {
-      const int n = sk_windows(recs[i].b);
-      miss = n == 32 ? ~0u : (1u << n) - 1;
-    } else {
-      miss = rep_bits[lo + rep_of[i]];
-    }
-    if (miss) {
-      const uint64_t o = org[i];
-      const uint64_t read = o >> 8;
-      const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
-      atomicAnd(&present[read * pstride + wi], ~((unsigned long long)miss << sh));
-      const unsigned long long over = sh ? (unsigned long long)miss >> (64 - sh) : 0ull;  // windows past the word
+    uint64_t o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) o[u] = v[u] ? org[at[u]] : 0;  // the record's origin, read : first window
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!v[u]) continue;
+      const uint64_t read = o[u] >> 8;
+      const int s0 = int(o[u] & 0xff), wi = s0 >> 6, sh = s0 & 63;
+      atomicAnd(&present[read * pstride + wi], ~((unsigned long long)v[u] << sh));
+      const unsigned long long over = sh ? (unsigned long long)v[u] >> (64 - sh) : 0ull;  // windows past the word
       if (over) atomicAnd(&present[read * pstride + wi + 1], ~over);
     }
   }
@@ -809,8 +842,8 @@ __global__ __launch_bounds__(SKC_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
 // slots keep the all-ones sentinel the sort-based count skips).  Segment s = records [seg_start[s], +len) of the
 // partitioned array, placed at seg_prefix[s] of the output; also copies records and origins for the presence
 // look-ups that follow the hash build (pend_* may be null).
-__global__ void sk_expand_kernel(const SkRec* __restrict__ recs, const uint64_t* __restrict__ org,
-                                 const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ seg_prefix,
+__global__ void sk_expand_kernel(const SkRec* __restrict__ recs, const uint32_t* __restrict__ idx,
+                                 const uint64_t* __restrict__ org, const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ seg_prefix,
                                  uint32_t nseg, uint64_t total, int k, int nmax, uint64_t* __restrict__ keys,
                                  SkRec* __restrict__ pend_rec, uint64_t* __restrict__ pend_org) {
   const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -824,7 +857,7 @@ __global__ void sk_expand_kernel(const SkRec* __restrict__ recs, const uint64_t*
   const SkRec r = recs[i];
   if (pend_rec) {
     pend_rec[g] = r;
-    pend_org[g] = org[i];
+    pend_org[g] = org[idx[i]];
   }
   const int n = sk_windows(r.b);
   const uint64_t kmask = ~(~0ull << (2 * k));
@@ -882,7 +915,8 @@ int kmer_skm_finish_present(bg_ctx* ctx, bg_kmerset* ks) {
   return BG_OK;
 }
 
-static int sk_partition_segmented(bg_ctx* ctx, const SkRec* in, SkRec* out, const uint64_t* oin, uint64_t* oout, uint64_t n,
+template <typename Org, bool kIndex>
+static int sk_partition_segmented(bg_ctx* ctx, const SkRec* in, SkRec* out, const Org* oin, Org* oout, uint64_t n,
                                   uint32_t nseg, const uint64_t* h_rec0, int shift, uint32_t dmask) {
   std::vector<uint32_t> h_tile(size_t(nseg) + 1, 0);
   uint64_t t = 0;
@@ -912,9 +946,9 @@ static int sk_partition_segmented(bg_ctx* ctx, const SkRec* in, SkRec* out, cons
   BG_TRY(exclusive_scan_u32_to_u64(ctx, hist.p, offs.p, uint64_t(SK_BINS) * ntiles, nullptr));
   ctx->toc(uint64_t(SK_BINS) * ntiles * 12);
   ctx->tic("skm_part_scatter");
-  sk_part_scatter_kernel<<<ntiles, SK_THREADS, 0, ctx->stream>>>(in, out, oin, oout, sg, shift, dmask, offs.p);
+  sk_part_scatter_kernel<Org, kIndex><<<ntiles, SK_THREADS, 0, ctx->stream>>>(in, out, oin, oout, sg, shift, dmask, offs.p);
   BG_LAUNCH_CHECK();
-  ctx->toc(n * 48);
+  ctx->toc(n * (32 + (kIndex ? 1 : 2) * sizeof(Org)));
   return BG_OK;
 }
 
@@ -976,10 +1010,11 @@ static int sk_generate(bg_ctx* ctx, const bg_reads* reads, const SkGeometry& g, 
 }
 
 // level 1: the top 8 bucket bits (in -> out); h_starts[257] = group starts
-static int sk_level1(bg_ctx* ctx, const SkRec* in, SkRec* out, const uint64_t* oin, uint64_t* oout, uint64_t R,
+template <typename Org, bool kIndex>
+static int sk_level1(bg_ctx* ctx, const SkRec* in, SkRec* out, const Org* oin, Org* oout, uint64_t R,
                      uint64_t* h_starts) {
   const uint64_t whole[2] = {0, R};
-  BG_TRY(sk_partition_segmented(ctx, in, out, oin, oout, R, 1, whole, SK_BUCKET_FIELD - 8, 0xffu));
+  BG_TRY((sk_partition_segmented<Org, kIndex>(ctx, in, out, oin, oout, R, 1, whole, SK_BUCKET_FIELD - 8, 0xffu)));
   DevBuf<uint64_t> b8;
   BG_TRY(b8.alloc(ctx, SK_BINS + 1));
   sk_bounds_kernel<<<cdiv(SK_BINS + 1, 256), 256, 0, ctx->stream>>>(out, R, 8, b8.p);
@@ -1021,9 +1056,9 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
   return sk_count_records(ctx, ra.p, oa.p, R, N, k, min_count, ks, nullptr);
 }
 
-// Partition + count of R records (in / oin are only read).  bits_out == nullptr: oin holds origins and the
-// presence bits go to ks->present (local count); else oin holds indices into bits_out, which receives the
-// presence bits of every record's windows (kSkUnknown for the records of overflowed buckets).
+// Partition + count of R records (in / oin are only read).  bits_out == nullptr: oin holds their origins and the
+// presence bits go to ks->present (local count); else oin is not used and bits_out[i] receives the presence bits
+// of the windows of record i (kSkUnknown for the records of overflowed buckets).
 static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, uint64_t R, uint64_t N, int k,
                             uint32_t min_count, bg_kmerset* ks, uint32_t* bits_out) {
   const int nmax = std::min(32, 52 - k);
@@ -1036,18 +1071,19 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
     return BG_OK;
   }
   DevBuf<SkRec> rb, rc;
-  DevBuf<uint64_t> ob, oc;
+  if (R >= (1ull << 32)) { set_error("k-mer counting: %llu super-k-mers on one GPU (2^32 at most)", (unsigned long long)R); return BG_EINVAL; }
+  DevBuf<uint32_t> ob, oc;  // every record's index in `in`, moved along with it
   BG_TRY(rb.alloc(ctx, R));
   BG_TRY(ob.alloc(ctx, R));
   BG_TRY(rc.alloc(ctx, R));
   BG_TRY(oc.alloc(ctx, R));
   std::vector<uint64_t> h_starts(SK_BINS + 1);
-  BG_TRY(sk_level1(ctx, in, rb.p, oin, ob.p, R, h_starts.data()));
+  BG_TRY((sk_level1<uint32_t, true>(ctx, in, rb.p, nullptr, ob.p, R, h_starts.data())));
 
   // level 2: the next 8 bits inside each of the 256 groups; bigger inputs take up to 5 more bits so that a
   // bucket stays around 24 k windows (BG_KMER_EXTRA_BITS overrides, for tests).  A rank of a sharded build
   // owns a slice of the bucket space: the level is chosen from the groups that are in use.
-  BG_TRY(sk_partition_segmented(ctx, rb.p, rc.p, ob.p, oc.p, R, SK_BINS, h_starts.data(), SK_BUCKET_FIELD - 16, 0xffu));
+  BG_TRY((sk_partition_segmented<uint32_t, false>(ctx, rb.p, rc.p, ob.p, oc.p, R, SK_BINS, h_starts.data(), SK_BUCKET_FIELD - 16, 0xffu)));
   int extra = 0;
   {
     uint64_t used = 0;
@@ -1057,7 +1093,7 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
   }
   if (const char* e = getenv("BG_KMER_EXTRA_BITS")) extra = std::max(0, std::min(SK_BUCKET_FIELD - 16, atoi(e)));
   SkRec* part = rc.p;
-  uint64_t* part_org = oc.p;
+  uint32_t* part_idx = oc.p;
   if (extra) {
     DevBuf<uint64_t> b16;
     BG_TRY(b16.alloc(ctx, 65537));
@@ -1066,10 +1102,10 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
     std::vector<uint64_t> h(65537);
     BG_HIP(hipMemcpyAsync(h.data(), b16.p, 65537 * 8, hipMemcpyDeviceToHost, ctx->stream));
     BG_HIP(hipStreamSynchronize(ctx->stream));
-    BG_TRY(sk_partition_segmented(ctx, rc.p, rb.p, oc.p, ob.p, R, 65536, h.data(), SK_BUCKET_FIELD - 16 - extra,
-                                  (1u << extra) - 1));
+    BG_TRY((sk_partition_segmented<uint32_t, false>(ctx, rc.p, rb.p, oc.p, ob.p, R, 65536, h.data(),
+                                                    SK_BUCKET_FIELD - 16 - extra, (1u << extra) - 1)));
     part = rb.p;
-    part_org = ob.p;
+    part_idx = ob.p;
   }
   const int bucket_bits = 16 + extra;
   const uint32_t NB = 1u << bucket_bits;
@@ -1127,7 +1163,7 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
 #endif
   ctx->toc(R * 40);
   ctx->tic("skm_spread");
-  sk_spread_kernel<<<NB, SKS_THREADS, 0, ctx->stream>>>(part, bounds.p, overflow.p, rep_of.p, rep_bits.p, part_org,
+  sk_spread_kernel<<<NB, SKS_THREADS, 0, ctx->stream>>>(part, bounds.p, overflow.p, rep_of.p, rep_bits.p, part_idx, oin,
                                                         reinterpret_cast<unsigned long long*>(ks->present.p),
                                                         ks->present_stride, bits_out);
   BG_LAUNCH_CHECK();
@@ -1176,7 +1212,7 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
     BG_HIP(hipMemcpyAsync(d_seg.p + seg_start.size(), seg_prefix.data(), seg_start.size() * 8, hipMemcpyHostToDevice,
                           ctx->stream));
     sk_expand_kernel<<<cdiv(tot_rec, 256), 256, 0, ctx->stream>>>(
-        part, part_org, d_seg.p, d_seg.p + seg_start.size(), uint32_t(seg_start.size()), tot_rec, k, nmax, ta.p,
+        part, part_idx, oin, d_seg.p, d_seg.p + seg_start.size(), uint32_t(seg_start.size()), tot_rec, k, nmax, ta.p,
         bits_out ? nullptr : reinterpret_cast<SkRec*>(ks->pend_rec.p), bits_out ? nullptr : ks->pend_org.p);
     BG_LAUNCH_CHECK();
     BG_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors go out of scope
@@ -1209,10 +1245,6 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
 
 // ---- sharded build: super-k-mers cross the GPUs instead of k-mer instances -------------------------------
 
-__global__ void sk_iota_kernel(uint64_t* __restrict__ dst, uint64_t n) {
-  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = i;
-}
 
 __global__ __launch_bounds__(256) void sk_sum_windows_kernel(const SkRec* __restrict__ recs, uint64_t n,
                                                              unsigned long long* __restrict__ total) {
@@ -1300,7 +1332,7 @@ extern "C" int bg_skm_extract_by_owner(bg_ctx* ctx, const bg_reads* reads, int k
   if (!R) return BG_OK;
   // whole groups of the top bucket byte go to their owner: owner = (byte * nparts) >> 8
   std::vector<uint64_t> h_starts(SK_BINS + 1);
-  BG_TRY(sk_level1(ctx, ra.p, reinterpret_cast<SkRec*>(d_recs), oa.p, d_org, R, h_starts.data()));
+  BG_TRY((sk_level1<uint64_t, false>(ctx, ra.p, reinterpret_cast<SkRec*>(d_recs), oa.p, d_org, R, h_starts.data())));
   for (int b = 0; b < SK_BINS; ++b) counts[(uint32_t(b) * nparts) >> 8] += h_starts[b + 1] - h_starts[b];
   return BG_OK;
 }
@@ -1315,10 +1347,8 @@ extern "C" int bg_skm_count(bg_ctx* ctx, const uint64_t* d_recs, uint64_t n, int
   ks->ctx = ctx;
   ks->k = k;
   const SkRec* recs = reinterpret_cast<const SkRec*>(d_recs);
-  DevBuf<uint64_t> idx;
   DevBuf<unsigned long long> tot;
   DevBuf<uint32_t> own_bits;
-  BG_TRY(idx.alloc(ctx, n));
   BG_TRY(tot.alloc(ctx, 1));
   BG_HIP(hipMemsetAsync(tot.p, 0, 8, ctx->stream));
   if (!d_bits) {  // the caller does not want them
@@ -1327,15 +1357,13 @@ extern "C" int bg_skm_count(bg_ctx* ctx, const uint64_t* d_recs, uint64_t n, int
   }
   unsigned long long N = 0;
   if (n) {
-    sk_iota_kernel<<<cdiv(n, 256), 256, 0, ctx->stream>>>(idx.p, n);
-    BG_LAUNCH_CHECK();
     sk_sum_windows_kernel<<<(cdiv(n, 256) < 2048u ? cdiv(n, 256) : 2048u), 256, 0, ctx->stream>>>(recs, n, tot.p);
     BG_LAUNCH_CHECK();
     BG_HIP(hipMemcpyAsync(&N, tot.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     BG_HIP(hipStreamSynchronize(ctx->stream));
   }
   ks->instances = N;
-  BG_TRY(sk_count_records(ctx, recs, idx.p, n, N, k, min_count, ks.get(), d_bits));
+  BG_TRY(sk_count_records(ctx, recs, nullptr, n, N, k, min_count, ks.get(), d_bits));
   *out = ks.release();
   return BG_OK;
 }
