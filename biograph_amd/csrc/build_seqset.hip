@@ -267,7 +267,8 @@ __global__ __launch_bounds__(256) void k_sort_small_groups(const uint64_t* __res
 
 // Medium tie groups (kSmallGroup < size <= kMediumGroup): one workgroup per group stages the group's keys in
 // LDS and orders them with a bitonic network of full-key compares.  Only larger groups go to the radix rounds
-// (dozens of tiny launches per round, whatever the number of records).
+// (dozens of tiny launches per round, whatever the number of records).  What the first launch leaves (groups
+// over kMediumGroup) gets a second one with a CU's whole LDS per group (3072 members of 150-base reads).
 constexpr int kMediumGroup = 1024;
 
 __global__ void k_tied_run_heads(const uint32_t* __restrict__ tpos, const uint64_t* __restrict__ tkey, uint64_t T,
@@ -277,43 +278,66 @@ __global__ void k_tied_run_heads(const uint32_t* __restrict__ tpos, const uint64
   head[t] = (t == 0 || tpos[t] != tpos[t - 1] + 1 || tkey[t] != tkey[t - 1]) ? 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void k_sort_medium_groups(const uint32_t* __restrict__ hpos, uint64_t G, uint64_t T,
-                                                            const uint32_t* __restrict__ tpos,
-                                                            const uint64_t* __restrict__ rec,
-                                                            const uint8_t* __restrict__ rlen, int W,
-                                                            uint32_t* __restrict__ sidx, uint8_t* __restrict__ still) {
+// Handles the groups with min_size < size <= cap (cap members fit the dynamic LDS).  Bigger ones: still = 1 for
+// their members, unless check_equal is set and all their keys turn out to be one and the same (the oriented reads
+// that correction emptied, both strands of each, are such a group: tens of thousands of equal keys that the
+// radix rounds would carry through every word) — equal keys are in place as they are.
+__global__ __launch_bounds__(1024) void k_sort_medium_groups(const uint32_t* __restrict__ hpos, uint64_t G, uint64_t T,
+                                                             const uint32_t* __restrict__ tpos,
+                                                             const uint64_t* __restrict__ rec,
+                                                             const uint8_t* __restrict__ rlen, int W,
+                                                             uint32_t* __restrict__ sidx, uint8_t* __restrict__ still,
+                                                             uint32_t min_size, uint32_t cap, int check_equal) {
   extern __shared__ uint64_t mg_smem[];
-  uint64_t* skey = mg_smem;                                                  // kMediumGroup * W
-  uint32_t* sid = reinterpret_cast<uint32_t*>(skey + size_t(kMediumGroup) * W);  // record of each member
-  uint16_t* perm = reinterpret_cast<uint16_t*>(sid + kMediumGroup);          // sorted order -> member
-  uint8_t* slen = reinterpret_cast<uint8_t*>(perm + kMediumGroup);
+  uint64_t* skey = mg_smem;                                            // cap * W
+  uint32_t* sid = reinterpret_cast<uint32_t*>(skey + size_t(cap) * W);  // record of each member
+  uint16_t* perm = reinterpret_cast<uint16_t*>(sid + cap);             // sorted order -> member (cap rounded up to 2^x)
+  __shared__ uint32_t s_differ;
   const uint64_t g = blockIdx.x;
   const uint32_t t0 = hpos[g];
   const uint32_t t1 = g + 1 < G ? hpos[g + 1] : uint32_t(T);
   const uint32_t size = t1 - t0;
-  const int tid = threadIdx.x;
-  if (size > uint32_t(kMediumGroup)) {  // block-uniform
-    for (uint32_t i = tid; i < size; i += 256) still[t0 + i] = 1;
-    return;
-  }
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  if (size <= min_size) return;  // block-uniform; done by an earlier launch
   const uint32_t p0 = tpos[t0];  // the group occupies sorted positions p0 .. p0 + size
-  for (uint32_t i = tid; i < size; i += 256) {
-    const uint32_t r = sidx[p0 + i];
-    sid[i] = r;
-    slen[i] = rlen[r];
+  if (size > cap) {  // block-uniform
+    uint32_t differ = 1;
+    if (check_equal) {
+      if (tid == 0) s_differ = 0;
+      __syncthreads();
+      const uint32_t r0 = sidx[p0];
+      bool d = false;
+      for (uint32_t i = tid; i < size && !d; i += nt) {
+        const uint32_t r = sidx[p0 + i];
+        d = rlen[r] != rlen[r0];
+        for (int w = 0; w < W && !d; ++w) d = rec[uint64_t(r) * W + w] != rec[uint64_t(r0) * W + w];
+      }
+      if (d) s_differ = 1;
+      __syncthreads();
+      differ = s_differ;
+    }
+    for (uint32_t i = tid; i < size; i += nt) still[t0 + i] = uint8_t(differ);
+    return;
   }
   uint32_t P = 1;
   while (P < size) P <<= 1;
-  for (uint32_t i = tid; i < P; i += 256) perm[i] = i < size ? uint16_t(i) : uint16_t(0xffff);
+  uint8_t* slen = reinterpret_cast<uint8_t*>(perm + (cap > P ? cap : P));
+  for (uint32_t i = tid; i < size; i += nt) {
+    const uint32_t r = sidx[p0 + i];
+    sid[i] = r;
+    slen[i] = rlen[r];
+    still[t0 + i] = 0;
+  }
+  for (uint32_t i = tid; i < P; i += nt) perm[i] = i < size ? uint16_t(i) : uint16_t(0xffff);
   __syncthreads();
-  for (uint32_t x = tid; x < size * uint32_t(W); x += 256) {
+  for (uint32_t x = tid; x < size * uint32_t(W); x += nt) {
     const uint32_t i = x / uint32_t(W), w = x - i * uint32_t(W);
     skey[x] = rec[uint64_t(sid[i]) * W + w];
   }
   __syncthreads();
   for (uint32_t k2 = 2; k2 <= P; k2 <<= 1) {
     for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-      for (uint32_t i = tid; i < P; i += 256) {
+      for (uint32_t i = tid; i < P; i += nt) {
         const uint32_t x = i ^ j;
         if (x > i) {
           const uint16_t a = perm[i], b = perm[x];
@@ -328,7 +352,7 @@ __global__ __launch_bounds__(256) void k_sort_medium_groups(const uint32_t* __re
       __syncthreads();
     }
   }
-  for (uint32_t i = tid; i < size; i += 256) sidx[p0 + i] = sid[perm[i]];
+  for (uint32_t i = tid; i < size; i += nt) sidx[p0 + i] = sid[perm[i]];
 }
 
 // subset element t sits at sorted position tpos[t]; it starts a group unless it continues the run of
@@ -1165,14 +1189,28 @@ int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p,
       k_tied_run_heads<<<cdiv(T, 256), 256, 0, ctx->stream>>>(tpos.p, tkey.p, T, head.p);
       BG_LAUNCH_CHECK();
       BG_TRY(compact_flagged<uint32_t>(ctx, head.p, T, &hpos, &G));
-      const size_t smem = size_t(kMediumGroup) * (size_t(W) * 8 + 4 + 2 + 1);
-      BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_medium_groups),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
+      auto group_smem = [&](uint32_t cap) {  // keys, records, order (a power of two of 16-bit places), lengths
+        uint32_t p2 = 1;
+        while (p2 < cap) p2 <<= 1;
+        return size_t(cap) * (size_t(W) * 8 + 4 + 1) + size_t(p2) * 2;
+      };
+      uint32_t large = 0;  // the biggest group a CU's LDS takes at this read length
+      for (uint32_t cap : {3072u, 2560u, 2048u, 1536u})
+        if (!large && group_smem(cap) <= 156 * 1024) large = cap;
       ctx->tic("suffix_medium_ties");
-      k_sort_medium_groups<<<unsigned(G), 256, smem, ctx->stream>>>(hpos.p, G, T, tpos.p, rec.p, rlen.p, W, sidx.p, still.p);
+      BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_medium_groups),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(group_smem(large ? large : kMediumGroup))));
+      k_sort_medium_groups<<<unsigned(G), 256, group_smem(kMediumGroup), ctx->stream>>>(
+          hpos.p, G, T, tpos.p, rec.p, rlen.p, W, sidx.p, still.p, 0u, uint32_t(kMediumGroup), 0);
       BG_LAUNCH_CHECK();
       ctx->toc(T * (uint64_t(W) * 8 + 9));
       BG_TRY(compact_flagged<uint32_t>(ctx, still.p, T, &keep_t, &T2));
+      if (T2 && large && !getenv("BG_NO_LARGE_GROUPS")) {
+        k_sort_medium_groups<<<unsigned(G), 1024, group_smem(large), ctx->stream>>>(
+            hpos.p, G, T, tpos.p, rec.p, rlen.p, W, sidx.p, still.p, uint32_t(kMediumGroup), large, 1);
+        BG_LAUNCH_CHECK();
+        BG_TRY(compact_flagged<uint32_t>(ctx, still.p, T, &keep_t, &T2));
+      }
       DevBuf<uint32_t> tpos2;
       DevBuf<uint64_t> tkey2;
       BG_TRY(tpos2.alloc(ctx, T2));
@@ -1184,6 +1222,7 @@ int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p,
         BG_LAUNCH_CHECK();
       }
       BG_HIP(hipStreamSynchronize(ctx->stream));
+      if (getenv("BG_DEBUG_TIES")) fprintf(stderr, "ties: n_rec %llu, in groups > %d: %llu in %llu groups, left after the medium groups: %llu\n", (unsigned long long)n_rec, kSmallGroup, (unsigned long long)T, (unsigned long long)G, (unsigned long long)T2);
       tpos = std::move(tpos2);
       tkey = std::move(tkey2);
       T = T2;
