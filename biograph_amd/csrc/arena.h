@@ -126,6 +126,35 @@ class Arena {
     return true;
   }
 
+  // Keeps the first `bytes` of a live chunk and frees the rest of it (nothing happens when the rest is smaller than
+  // what a chunk is split for).  false: not a live pointer of this arena.
+  bool shrink(void* p, size_t bytes) {
+    const uintptr_t addr = uintptr_t(p);
+    Pool* pool = nullptr;
+    for (Pool* q : {&large_, &small_}) {
+      auto it = q->chunks.find(addr);
+      if (it != q->chunks.end() && !it->second.free) { pool = q; break; }
+    }
+    if (!pool) return false;
+    Chunk& c = pool->chunks[addr];
+    bytes = round_up(bytes ? bytes : 1, kAlign);
+    const size_t min_split = pool == &small_ ? kAlign : kMinSplit;
+    if (bytes >= c.size || c.size - bytes < min_split) return true;
+    uintptr_t tail = addr + bytes;
+    size_t tail_size = c.size - bytes;
+    const uintptr_t segment = c.segment;
+    live_ -= tail_size;
+    auto nx = pool->chunks.find(addr + c.size);
+    c.size = bytes;
+    if (nx != pool->chunks.end() && nx->second.free && nx->second.segment == segment) {
+      const size_t ns = nx->second.size;
+      erase_free(*pool, nx->first, ns);
+      tail_size += ns;
+    }
+    insert_free(*pool, tail, tail_size, segment);
+    return true;
+  }
+
   // returns every wholly free segment to the driver
   void trim() {
     for (Pool* pool : {&large_, &small_}) {

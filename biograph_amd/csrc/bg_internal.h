@@ -67,6 +67,7 @@ struct bg_ctx {
 
   int alloc(size_t bytes, void** out);
   void release(void* p);
+  void shrink(void* p, size_t bytes);  // the chunk keeps its first `bytes`, the rest goes back to the arena
   int trim();
   // profiling bracket around one kernel family
   void tic(const char* name);
@@ -125,6 +126,11 @@ struct DevBuf {
     n = 0;
   }
   T* release_ownership() { T* q = p; p = nullptr; n = 0; return q; }
+  // keeps the first `count` elements (what follows them goes back to the arena at once: see bg_ctx::release)
+  void shrink(size_t count) {
+    if (p && ctx && count < n) ctx->shrink(p, (count ? count : 1) * sizeof(T));
+    if (count < n) n = count;
+  }
   size_t bytes() const { return n * sizeof(T); }
 };
 

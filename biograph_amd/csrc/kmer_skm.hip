@@ -1230,13 +1230,11 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
     distinct += tmp.distinct;
   }
   if (nkept > out_cap) { set_error("k-mer output overflow (internal error)"); return BG_EINTERNAL; }
-  BG_TRY(ks->kmers.alloc(ctx, nkept));
-  BG_TRY(ks->counts.alloc(ctx, nkept));
-  if (nkept) {
-    BG_HIP(hipMemcpyAsync(ks->kmers.p, ok_a.p, nkept * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    BG_HIP(hipMemcpyAsync(ks->counts.p, oc_a.p, nkept * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    BG_HIP(hipStreamSynchronize(ctx->stream));
-  }
+  // the result arrays are the heads of the buffers the count wrote to (room for every window / min_count): no copy
+  ok_a.shrink(nkept);
+  oc_a.shrink(nkept);
+  ks->kmers = std::move(ok_a);
+  ks->counts = std::move(oc_a);
   ks->size = nkept;
   ks->distinct = distinct;
   ks->sorted = false;

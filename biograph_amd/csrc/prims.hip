@@ -105,6 +105,11 @@ void bg_ctx::release(void* p) {
   (void)arena->release(p);
 }
 
+void bg_ctx::shrink(void* p, size_t bytes) {
+  std::lock_guard<std::mutex> lock(arena_mutex());
+  (void)arena->shrink(p, bytes);
+}
+
 int bg_ctx::trim() {
   (void)hipStreamSynchronize(stream);
   std::lock_guard<std::mutex> lock(arena_mutex());

@@ -58,6 +58,24 @@ int main() {
     a.release(b3);
     a.release(b4);
     CHECK(a.live() == 0 && a.check());
+    // shrink: the chunk keeps its head, the tail is free at once and merges with a free neighbour
+    {
+      void* s1 = a.alloc(size_t(400) << 20);
+      void* s2 = a.alloc(size_t(100) << 20);  // right behind s1 in the 512 MiB segment
+      CHECK(s1 && s2 && a.live() == (size_t(500) << 20));
+      CHECK(a.shrink(s1, size_t(100) << 20) && a.check() && a.live() == (size_t(200) << 20));
+      CHECK(a.size_of(s1) == (size_t(100) << 20));
+      void* s3 = a.alloc(size_t(300) << 20);  // exactly the freed tail
+      CHECK(s3 == static_cast<char*>(s1) + (size_t(100) << 20) && a.check());
+      CHECK(a.shrink(s3, (size_t(300) << 20) - 4096) && a.live() == (size_t(500) << 20));  // too small a rest: as it was
+      a.release(s2);
+      CHECK(a.shrink(s3, size_t(1) << 20) && a.check());  // the tail joins s2's free chunk and the segment's 12 MiB
+      void* s4 = a.alloc(size_t(411) << 20);
+      CHECK(s4 == static_cast<char*>(s3) + (size_t(1) << 20) && a.check());
+      CHECK(!a.shrink(reinterpret_cast<void*>(0x1234), 1));
+      a.release(s1); a.release(s3); a.release(s4);
+      CHECK(a.live() == 0 && a.check());
+    }
     // the driver runs out: wholly free segments go back, the request is retried (without the rounding if need be)
     const size_t before = a.reserved();
     budget = size_t(750) << 20;  // with the 800 MiB of free segments returned: room for 1500 MiB, not for the rounded 1536
