@@ -1420,7 +1420,9 @@ __global__ void sk_lookup_bits_kernel(const SkRec* __restrict__ recs, uint64_t n
   bits_out[i] = bits;
 }
 
-// presence bits of a rank's own records as their owners returned them (every record known)
+// presence bits of a rank's own records as their owners returned them (every record known): the words start as "a
+// bit per window without an N" (sk_present_valid_kernel) and the one record in ten with a window that is not kept
+// clears bits — see sk_spread_kernel
 __global__ void sk_present_from_bits_kernel(const SkRec* __restrict__ recs, const uint64_t* __restrict__ org,
                                             const uint32_t* __restrict__ bits_in, uint64_t n_rec,
                                             unsigned long long* __restrict__ present, int pstride, uint32_t* __restrict__ err) {
@@ -1428,14 +1430,16 @@ __global__ void sk_present_from_bits_kernel(const SkRec* __restrict__ recs, cons
   if (i >= n_rec) return;
   // every record is resolved by its owner (bg_skm_lookup); bit 31 is window 31 of a 32-window record here
   const uint32_t bits = bits_in[i];
-  if (!bits) return;
   const int n = sk_windows(recs[i].b);
   if (n < 32 && (bits >> n)) { atomicOr(err, 1u); return; }
+  const uint32_t miss = ~bits & (n == 32 ? ~0u : (1u << n) - 1);
+  if (!miss) return;
   const uint64_t o = org[i];
   const uint64_t read = o >> 8;
   const int s0 = int(o & 0xff), wi = s0 >> 6, sh = s0 & 63;
-  atomicOr(&present[read * pstride + wi], (unsigned long long)bits << sh);
-  if (sh + n > 64) atomicOr(&present[read * pstride + wi + 1], (unsigned long long)bits >> (64 - sh));
+  atomicAnd(&present[read * pstride + wi], ~((unsigned long long)miss << sh));
+  const unsigned long long over = sh ? (unsigned long long)miss >> (64 - sh) : 0ull;  // windows past the word
+  if (over) atomicAnd(&present[read * pstride + wi + 1], ~over);
 }
 
 // answers of a probe exchange: record i covers windows s0.. of probe string p (origin = p << 8 | s0); string
@@ -1457,7 +1461,12 @@ int skm_presence_from_bits(bg_ctx* ctx, const bg_reads* reads, int k, const uint
   const int maxw = int(reads->max_len) - k + 1;
   *stride = std::max(1, (maxw + 63) / 64);
   BG_TRY(present->alloc(ctx, reads->n * uint64_t(*stride)));
-  BG_HIP(hipMemsetAsync(present->p, 0, reads->n * uint64_t(*stride) * 8, ctx->stream));
+  if (reads->W > 8) { set_error("presence bits: reads of more than 256 bases"); return BG_EINVAL; }
+  if (reads->n) {
+    sk_present_valid_kernel<<<cdiv(reads->n, 256), 256, 0, ctx->stream>>>(
+        reads->nmask.p, reads->len.p, reads->n, reads->W, k, reinterpret_cast<unsigned long long*>(present->p), *stride);
+    BG_LAUNCH_CHECK();
+  }
   DevBuf<uint32_t> err;
   BG_TRY(err.alloc(ctx, 1));
   BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
