@@ -1397,27 +1397,41 @@ namespace bg {
 // stop_at_absent: windows past the first absent one are left 0.  Only for callers that consume a record's windows
 // strictly in order and never ask past an absent one — NOT the routed correction: its probes answer by k-mer, and a
 // search reaches a probe's later windows by other routes too.
+// Four neighbouring lanes share a record's windows (four look-ups of a record in flight instead of one); with
+// stop_at_absent a record keeps one lane, whose windows depend on each other.
+constexpr int SKL_SPLIT = 4;
 __global__ void sk_lookup_bits_kernel(const SkRec* __restrict__ recs, uint64_t n_rec, int k, const uint64_t* __restrict__ slots,
                                       int log2cap, uint32_t* __restrict__ bits_out, int only_unknown, int stop_at_absent) {
-  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n_rec) return;
-  if (only_unknown && !(bits_out[i] & kSkUnknown)) return;
-  const SkRec r = recs[i];
+  const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t i = g / SKL_SPLIT;
+  const int part = int(g % SKL_SPLIT);
+  bool live = i < n_rec && !(only_unknown && !(bits_out[i] & kSkUnknown));
+  SkRec r;
+  r.a = 0;
+  r.b = 0;
+  if (live) r = recs[i];
   const int n = sk_windows(r.b);
-  KmerTable tab{slots, log2cap, k};
-  const uint64_t kmask = ~(~0ull << (2 * k));
-  uint64_t fwd = r.a >> (64 - 2 * k);
-  uint64_t rc = kmer_revcomp(fwd, k);
+  const int per = stop_at_absent ? n : (n + SKL_SPLIT - 1) / SKL_SPLIT;
+  const int t0 = part * per, t1 = t0 + per < n ? t0 + per : n;
   uint32_t bits = 0;
-  for (int t = 0; t < n; ++t) {
-    if (tab.find(rc < fwd ? rc : fwd) >= 0) bits |= 1u << t;
-    else if (stop_at_absent) break;
-    const int idx = k + t;
-    const uint64_t base = idx < 32 ? (r.a >> (62 - 2 * idx)) & 3 : (r.b >> (62 - 2 * (idx - 32))) & 3;
-    fwd = ((fwd << 2) | base) & kmask;
-    rc = (rc >> 2) | ((3 - base) << (2 * (k - 1)));
+  if (live && t0 < t1) {
+    KmerTable tab{slots, log2cap, k};
+    const uint64_t kmask = ~(~0ull << (2 * k));
+    const uint64_t x = t0 ? ((r.a << (2 * t0)) | (r.b >> (64 - 2 * t0))) : r.a;  // t0 <= 31: only base bits of b
+    uint64_t fwd = x >> (64 - 2 * k);
+    uint64_t rc = kmer_revcomp(fwd, k);
+    for (int t = t0; t < t1; ++t) {
+      if (tab.find(rc < fwd ? rc : fwd) >= 0) bits |= 1u << t;
+      else if (stop_at_absent) break;
+      const int idx = k + t;
+      const uint64_t base = idx < 32 ? (r.a >> (62 - 2 * idx)) & 3 : (r.b >> (62 - 2 * (idx - 32))) & 3;
+      fwd = ((fwd << 2) | base) & kmask;
+      rc = (rc >> 2) | ((3 - base) << (2 * (k - 1)));
+    }
   }
-  bits_out[i] = bits;
+#pragma unroll
+  for (int d = 1; d < SKL_SPLIT; d <<= 1) bits |= uint32_t(__shfl_xor(int(bits), d, 64));
+  if (live && part == 0) bits_out[i] = bits;
 }
 
 // presence bits of a rank's own records as their owners returned them (every record known): the words start as "a
@@ -1515,7 +1529,7 @@ extern "C" int bg_skm_lookup(bg_ctx* ctx, const bg_kmerset* ks, const uint64_t* 
   BG_HIP(hipSetDevice(ctx->device));
   if (n) {
     ctx->tic("kmer_probe_lookup");
-    sk_lookup_bits_kernel<<<cdiv(n, 256), 256, 0, ctx->stream>>>(reinterpret_cast<const SkRec*>(d_recs), n, ks->k, ks->slots.p,
+    sk_lookup_bits_kernel<<<cdiv(n * SKL_SPLIT, 256), 256, 0, ctx->stream>>>(reinterpret_cast<const SkRec*>(d_recs), n, ks->k, ks->slots.p,
                                                                ks->log2cap, d_bits, only_unknown & 1, (only_unknown >> 1) & 1);
     BG_LAUNCH_CHECK();
     ctx->toc(n * 20);
