@@ -174,6 +174,7 @@ struct bg_reads {
   uint64_t total_bases = 0;
   bg::DevBuf<uint64_t> words;   // n*W
   bg::DevBuf<uint32_t> nmask;   // n*W   (all zero for corrected reads)
+  bool any_n = true;            // false: nmask is known to be all zero (nobody needs to read it to find out)
   bg::DevBuf<uint16_t> len;     // n
 };
 

@@ -98,6 +98,7 @@ __global__ void k_pack_reads(const uint8_t* __restrict__ seq, const uint64_t* __
       nm |= (n8 & in8) << (24 - 8 * c8);
     }
     if (bad) atomicOr(err, 2u);
+    if (nm && !(__atomic_load_n(err, __ATOMIC_RELAXED) & 4u)) atomicOr(err, 4u);  // some read holds an N
   }
   words[g] = word;
   nmask[g] = nm;
@@ -624,6 +625,9 @@ static int pack_reads_impl(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_
       set_error("bg_pack_reads: read contains a character outside ACGTN");
       return BG_EBADBASE;
     }
+    r->any_n = (h_scal[1] & 4) != 0;
+  } else {
+    r->any_n = false;
   }
   *out = r.release();
   return BG_OK;

@@ -559,9 +559,11 @@ __global__ __launch_bounds__(256) void sk_present_valid_kernel(const uint32_t* _
   if (i >= n_reads) return;
   const int nk = int(len[i]) - k + 1;
   uint32_t any_n = 0;  // nearly every read has no N at all and needs nothing but its length
+  if (nmask) {         // (nullptr: no read of the whole input holds one)
 #pragma unroll
-  for (int q = 0; q < 8; ++q)  // W <= 8; all the loads in flight at once
-    if (q < W) any_n |= nmask[i * W + q];
+    for (int q = 0; q < 8; ++q)  // W <= 8; all the loads in flight at once
+      if (q < W) any_n |= nmask[i * W + q];
+  }
   unsigned long long m[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -598,7 +600,8 @@ __device__ unsigned long long g_skc_times[8];
 // recs / mult: the bucket's representatives as sk_dedup_kernel leaves them (nrep[2 * bucket] full ones from the
 // start of the slice, nrep[2 * bucket + 1] others from its end backwards) and how many records each stands
 // for; bits_out[i] = the windows of representative i that are kept, or (store_miss) those that are not;
-// kSkUnknown when the bucket is not counted here (overflow[bucket] is set as well).
+// kSkUnknown when the bucket is not counted here (overflow[bucket] is set as well).  bucket_list: the buckets to
+// count (one workgroup each) when not all of them.
 #ifndef SKC_SPLIT
 #define SKC_SPLIT 4  // lanes that share the windows of one representative (a power of two, neighbours in a wave)
 #endif
@@ -614,13 +617,13 @@ __global__ __launch_bounds__(SKC_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
                                                                    uint8_t* __restrict__ overflow,
                                                                    uint64_t* __restrict__ ulist,
                                                                    uint32_t* __restrict__ bits_out, int store_miss,
-                                                                   uint64_t giant) {
+                                                                   uint64_t giant, const uint32_t* __restrict__ bucket_list) {
   extern __shared__ __align__(16) unsigned char skc_smem[];
   unsigned long long* tkeys = reinterpret_cast<unsigned long long*>(skc_smem);
   uint32_t* tcnt = reinterpret_cast<uint32_t*>(skc_smem + size_t(cap) * 8);
   __shared__ uint32_t s_over, s_kept, s_distinct, s_cursor, s_unsettled, s_crossed;
   __shared__ unsigned long long s_base;
-  const uint32_t bucket = blockIdx.x;
+  const uint32_t bucket = bucket_list ? bucket_list[blockIdx.x] : blockIdx.x;  // (a list: the second try, below)
   const uint64_t lo = bounds[bucket], end = bounds[bucket + 1];
   if (lo == end) return;  // block-uniform
   const uint32_t n_full = nrep[2 * bucket], n_other = nrep[2 * bucket + 1];
@@ -1048,8 +1051,8 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
   *done = true;
   if (reads->W > 8) { set_error("k-mer counting: reads of more than 256 bases"); return BG_EINVAL; }
   sk_present_valid_kernel<<<cdiv(reads->n, 256), 256, 0, ctx->stream>>>(
-      reads->nmask.p, reads->len.p, reads->n, reads->W, k, reinterpret_cast<unsigned long long*>(ks->present.p),
-      ks->present_stride);
+      reads->any_n ? reads->nmask.p : nullptr, reads->len.p, reads->n, reads->W, k,
+      reinterpret_cast<unsigned long long*>(ks->present.p), ks->present_stride);
   BG_LAUNCH_CHECK();
   ks->present_of = reads;
   ks->present_n = reads->n;
@@ -1149,7 +1152,7 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
                              hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
   sk_count_lds_kernel<<<NB, SKC_THREADS, smem, ctx->stream>>>(reps, rep_mult.p, bounds.p, nrep.p, slots, k, min_count, out_cap,
                                                              ok_a.p, oc_a.p, ctr.p, ctr.p + 1, overflow.p, ulist.p, rep_bits.p,
-                                                             bits_out ? 0 : 1, giant);
+                                                             bits_out ? 0 : 1, giant, nullptr);
   BG_LAUNCH_CHECK();
 #ifdef SKC_TIMING
   {
@@ -1162,20 +1165,44 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
   }
 #endif
   ctx->toc(R * 40);
+  unsigned long long h_ctr[2] = {0, 0};
+  std::vector<uint8_t> h_over(NB);
+  uint64_t n_over = 0;
+  auto read_back = [&]() -> int {
+    BG_HIP(hipMemcpyAsync(h_ctr, ctr.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipMemcpyAsync(h_over.data(), overflow.p, NB, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    n_over = 0;
+    for (uint32_t b = 0; b < NB; ++b) n_over += h_over[b];
+    return BG_OK;
+  };
+  BG_TRY(read_back());
+  if (n_over && !getenv("BG_KMER_LDS_LOG2CAP") && !getenv("BG_SKM_NO_SECOND_TRY")) {
+    // A bucket whose k-mers did not fit the table (a few times the average bucket: a handful at chr20) gets a
+    // second try with a CU's whole LDS to itself before its windows go through the sort-based count.
+    std::vector<uint32_t> list;
+    for (uint32_t b = 0; b < NB; ++b)
+      if (h_over[b]) list.push_back(b);
+    DevBuf<uint32_t> d_list;
+    BG_TRY(d_list.alloc(ctx, list.size()));
+    BG_HIP(hipMemcpyAsync(d_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    BG_HIP(hipMemsetAsync(overflow.p, 0, NB, ctx->stream));
+    const uint32_t big_slots = 13000;
+    BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sk_count_lds_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(big_slots * 12)));
+    sk_count_lds_kernel<<<unsigned(list.size()), SKC_THREADS, size_t(big_slots) * 12, ctx->stream>>>(
+        reps, rep_mult.p, bounds.p, nrep.p, big_slots, k, min_count, out_cap, ok_a.p, oc_a.p, ctr.p, ctr.p + 1, overflow.p,
+        ulist.p, rep_bits.p, bits_out ? 0 : 1, giant, d_list.p);
+    BG_LAUNCH_CHECK();
+    BG_TRY(read_back());  // (also keeps `list` alive until the copy has been made)
+  }
   ctx->tic("skm_spread");
   sk_spread_kernel<<<NB, SKS_THREADS, 0, ctx->stream>>>(part, bounds.p, overflow.p, rep_of.p, rep_bits.p, part_idx, oin,
                                                         reinterpret_cast<unsigned long long*>(ks->present.p),
                                                         ks->present_stride, bits_out);
   BG_LAUNCH_CHECK();
   ctx->toc(R * 24);
-  unsigned long long h_ctr[2] = {0, 0};
-  std::vector<uint8_t> h_over(NB);
-  BG_HIP(hipMemcpyAsync(h_ctr, ctr.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-  BG_HIP(hipMemcpyAsync(h_over.data(), overflow.p, NB, hipMemcpyDeviceToHost, ctx->stream));
-  BG_HIP(hipStreamSynchronize(ctx->stream));
   uint64_t nkept = h_ctr[0], distinct = h_ctr[1];
-  uint64_t n_over = 0;
-  for (uint32_t b = 0; b < NB; ++b) n_over += h_over[b];
   if (n_over) {  // unroll the overflowed buckets into plain instances and count those by sorting
     std::vector<uint64_t> h_bounds(size_t(NB) + 1);
     BG_HIP(hipMemcpyAsync(h_bounds.data(), bounds.p, (size_t(NB) + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1183,6 +1210,13 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
     uint64_t tot_rec = 0;
     for (uint32_t b = 0; b < NB; ++b)
       if (h_over[b]) tot_rec += h_bounds[b + 1] - h_bounds[b];
+    if (getenv("BG_DEBUG_SKM")) {
+      uint64_t biggest = 0;
+      for (uint32_t b = 0; b < NB; ++b)
+        if (h_over[b]) biggest = std::max<uint64_t>(biggest, h_bounds[b + 1] - h_bounds[b]);
+      fprintf(stderr, "skm count: %llu of %u buckets not counted in LDS, %llu records in them (biggest %llu)\n",
+              (unsigned long long)n_over, NB, (unsigned long long)tot_rec, (unsigned long long)biggest);
+    }
     const uint64_t tot = tot_rec * uint64_t(nmax);
     if (tot >= (1ull << 32)) {
       set_error("k-mer counting: %llu buckets of %u overflowed their tables (%llu super-k-mers); raise BG_KMER_EXTRA_BITS",
@@ -1478,7 +1512,8 @@ int skm_presence_from_bits(bg_ctx* ctx, const bg_reads* reads, int k, const uint
   if (reads->W > 8) { set_error("presence bits: reads of more than 256 bases"); return BG_EINVAL; }
   if (reads->n) {
     sk_present_valid_kernel<<<cdiv(reads->n, 256), 256, 0, ctx->stream>>>(
-        reads->nmask.p, reads->len.p, reads->n, reads->W, k, reinterpret_cast<unsigned long long*>(present->p), *stride);
+        reads->any_n ? reads->nmask.p : nullptr, reads->len.p, reads->n, reads->W, k,
+        reinterpret_cast<unsigned long long*>(present->p), *stride);
     BG_LAUNCH_CHECK();
   }
   DevBuf<uint32_t> err;
