@@ -956,9 +956,11 @@ static int sk_partition_segmented(bg_ctx* ctx, const SkRec* in, SkRec* out, cons
 }
 
 // slots of a bucket's LDS table: 6400 x 12 bytes lets two 1024-thread workgroups share a CU's 160 KB
-// (BG_KMER_LDS_LOG2CAP shrinks the table: tests force the overflow path with it)
+// (BG_KMER_LDS_LOG2CAP shrinks the table: tests force the overflow path with it; BG_KMER_LDS_SLOTS / _SLOTS2 set the sizes
+// of the first and the second try)
 static uint32_t sk_lds_slots() {
   const char* e = getenv("BG_KMER_LDS_LOG2CAP");
+  if (const char* s = getenv("BG_KMER_LDS_SLOTS")) return uint32_t(std::max(2, std::min(13000, atoi(s))));  // (keeps the second try)
   if (!e) return 6400;
   const int v = atoi(e);
   return 1u << (v < 1 ? 1 : (v > 13 ? 13 : v));
@@ -1187,7 +1189,8 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
     BG_TRY(d_list.alloc(ctx, list.size()));
     BG_HIP(hipMemcpyAsync(d_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     BG_HIP(hipMemsetAsync(overflow.p, 0, NB, ctx->stream));
-    const uint32_t big_slots = 13000;
+    uint32_t big_slots = 13000;  // 156 KB
+    if (const char* s = getenv("BG_KMER_LDS_SLOTS2")) big_slots = uint32_t(std::max(2, std::min(13000, atoi(s))));  // tests
     BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sk_count_lds_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(big_slots * 12)));
     sk_count_lds_kernel<<<unsigned(list.size()), SKC_THREADS, size_t(big_slots) * 12, ctx->stream>>>(

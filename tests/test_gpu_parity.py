@@ -125,6 +125,28 @@ def test_seqset_build_search_modes(ctx, monkeypatch, env, seed, alphabet, rl):
     _check_seqset_against_oracle(ss, reads)
 
 
+@pytest.mark.parametrize("env", [{}, {"BG_NO_LARGE_GROUPS": "1"}])
+def test_seqset_build_big_tie_groups(ctx, monkeypatch, env):
+    """Tie groups of the suffix sorts beyond the medium-group kernel: 1500 and 2800 distinct reads behind one 20-base
+    prefix each (the second launch with a CU's whole LDS), 4000 behind a third (more than the LDS takes: the radix
+    rounds), 3500 copies of one read and 40 empty reads (groups of equal keys, left as they are) — and the same
+    through the radix rounds alone."""
+    for a, b in env.items():
+        monkeypatch.setenv(a, b)
+    rng = np.random.default_rng(77)
+    def rnd(n):
+        return "".join("ACGT"[int(x)] for x in rng.integers(0, 4, n))
+    reads = []
+    for prefix, count in ((rnd(20), 1500), (rnd(20), 2800), (rnd(20), 4000)):
+        reads += [prefix + rnd(int(rng.integers(10, 60))) for _ in range(count)]
+    reads += [rnd(70)] * 3500 + [""] * 40
+    reads += util.synth_reads(5, genome_len=1500, n_reads=300, read_len=80, err=0.0, n_rate=0.0, var_len=True)
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    ss, _ = ctx.build_seqset(ctx.pack_reads(reads), 12)
+    _check_seqset_against_oracle(ss, reads)
+
+
 def test_builder_test_known_answers(ctx):
     # modules/build_seqset/builder_test.cpp:52-123 through the HIP path
     t, trc = O.tseq, O.tseq_rc

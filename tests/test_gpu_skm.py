@@ -62,7 +62,12 @@ def test_read_length_edges(ctx, k, rl):
 
 @pytest.mark.parametrize("env", [{"BG_SKM_READS_PER_TILE": "50000"}, {"BG_SKM_CAP": "100"},
                                  {"BG_KMER_EXTRA_BITS": "3"}, {"BG_KMER_EXTRA_BITS": "5", "BG_KMER_LDS_LOG2CAP": "4"},
-                                 {"BG_KMER_SKM": "0"}])
+                                 {"BG_KMER_SKM": "0"},
+                                 # a first table most buckets overflow, a second try that takes some of them and
+                                 # leaves the rest to the sort-based count; and the same without a second try
+                                 {"BG_KMER_LDS_SLOTS": "12", "BG_KMER_LDS_SLOTS2": "40"},
+                                 {"BG_KMER_LDS_SLOTS": "12", "BG_KMER_LDS_SLOTS2": "4000"},
+                                 {"BG_KMER_LDS_SLOTS": "12", "BG_SKM_NO_SECOND_TRY": "1"}])
 def test_overflow_and_fallback_paths(ctx, monkeypatch, env):
     for a, b in env.items():
         monkeypatch.setenv(a, b)
@@ -71,6 +76,7 @@ def test_overflow_and_fallback_paths(ctx, monkeypatch, env):
 
 
 @pytest.mark.parametrize("env", [{}, {"BG_KMER_LDS_LOG2CAP": "2"}, {"BG_KMER_LDS_LOG2CAP": "7"},
+                                 {"BG_KMER_LDS_SLOTS": "10", "BG_KMER_LDS_SLOTS2": "30"},
                                  {"BG_SCREEN_LOOKUP": "1"}, {"BG_SKM_READS_PER_TILE": "50000"}])
 def test_presence_bits_drive_the_correction(ctx, monkeypatch, env):
     """bg_correct_reads takes the window presence from the count (no look-ups); the buckets whose table
