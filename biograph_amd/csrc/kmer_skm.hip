@@ -282,12 +282,14 @@ __global__ __launch_bounds__(SK_THREADS) void sk_part_hist_kernel(const SkRec* _
 
 // Org = what travels with a record: its 64-bit origin (read : first window), or — the count's own levels — its
 // 32-bit index in the order the records came in (kIndex: made here, oin is not read), which is all the count
-// needs to find the origin of the one record in ten it has something to tell.
+// needs to find the origin of the one record in ten it has something to tell.  full_bits (kIndex only, may be null):
+// receives "all windows kept" for every record, in input order.
 template <typename Org, bool kIndex>
 __global__ __launch_bounds__(SK_THREADS) void sk_part_scatter_kernel(const SkRec* __restrict__ in, SkRec* __restrict__ out,
                                                                      const Org* __restrict__ oin,
                                                                      Org* __restrict__ oout, SkSegs sg, int shift,
-                                                                     uint32_t dmask, const uint64_t* __restrict__ offs) {
+                                                                     uint32_t dmask, const uint64_t* __restrict__ offs,
+                                                                     uint32_t* __restrict__ full_bits) {
   __shared__ SkRec srec[SK2_TILE];
   __shared__ Org sorg[SK2_TILE];
   __shared__ uint32_t h[SK_BINS];
@@ -310,6 +312,10 @@ __global__ __launch_bounds__(SK_THREADS) void sk_part_scatter_kernel(const SkRec
     if (idx < hi) {
       rec[it] = in[idx];
       og[it] = kIndex ? Org(idx) : oin[idx];
+      if (kIndex && full_bits) {  // "every window kept" for the record at this place of the input (sk_spread_kernel)
+        const int n = sk_windows(rec[it].b);
+        full_bits[idx] = n == 32 ? ~0u : (1u << n) - 1;
+      }
       rnk[it] = uint16_t(atomicAdd(&h[(sk_bucket(rec[it].b) >> shift) & dmask], 1u));
     } else {
       rec[it].a = 0;
@@ -483,8 +489,9 @@ __global__ __launch_bounds__(SKD_THREADS) void sk_dedup_kernel(const SkRec* __re
 // kept — nine records in ten have none, so one record in ten costs an atomic instead of every one (the 142 M
 // atomicOrs of the earlier version wrote 8 GB for a 0.4 GB bitmap).  The records of a bucket that was not
 // counted in LDS lose all their bits here and get them back from the finished hash set (kmer_skm_finish_present).
-// Remote records (bits_out): rep_bits holds the kept windows, kSkUnknown for an uncounted bucket, and they go
-// to bits_out as they are.  idx = a record's place in the order the count received the records in (what the
+// Remote records (bits_out): the array starts as "every window kept" too (the first partition level writes that as
+// the records pass), and only the records with a window that is not kept, or of an uncounted bucket (kSkUnknown),
+// are written here.  idx = a record's place in the order the count received the records in (what the
 // partition moves along with it), org = the origins (read : first window) in that order.
 constexpr uint32_t kSkUnknown = 0x80000000u;
 constexpr int SKS_THREADS = 256;
@@ -503,36 +510,36 @@ __global__ __launch_bounds__(SKS_THREADS) void sk_spread_kernel(const SkRec* __r
   // four records per thread and step: their look-ups (representative -> its bits; for the record in ten that has
   // something to clear, index -> origin -> presence word) are four dependent chains in flight instead of one
   for (uint64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * SKS_THREADS) {
-    uint32_t v[4];
+    uint32_t v[4], full[4];  // windows not known to be kept, all windows
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint64_t i = i0 + uint64_t(u) * SKS_THREADS;
       v[u] = 0;
-      if (i < hi) v[u] = uncounted ? uint32_t(recs[i].b) : rep_of[i];
+      if (i < hi) v[u] = uncounted ? 1u : rep_of[i];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint64_t i = i0 + uint64_t(u) * SKS_THREADS;
-      if (i >= hi) {
-        v[u] = 0;
-      } else if (uncounted) {  // every window is to be looked up later
-        const int n = sk_windows(v[u]);
-        v[u] = bits_out ? kSkUnknown : (n == 32 ? ~0u : (1u << n) - 1);
-      } else {
-        v[u] = rep_bits[lo + v[u]];
-      }
+      if (i >= hi) v[u] = 0;
+      else if (!uncounted) v[u] = rep_bits[lo + v[u]];
     }
     uint32_t at[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint64_t i = i0 + uint64_t(u) * SKS_THREADS;
       at[u] = 0;
-      if (i < hi && (bits_out || v[u])) at[u] = idx[i];
+      full[u] = 0;
+      if (v[u]) {  // (i < hi)
+        at[u] = idx[i];
+        const int n = sk_windows(recs[i].b);
+        full[u] = n == 32 ? ~0u : (1u << n) - 1;
+        if (uncounted) v[u] = full[u];  // every window is to be looked up later
+      }
     }
-    if (bits_out) {
+    if (bits_out) {  // (they start as "every window kept": sk_part_scatter_kernel)
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (i0 + uint64_t(u) * SKS_THREADS < hi) bits_out[at[u]] = v[u];
+        if (v[u]) bits_out[at[u]] = uncounted ? kSkUnknown : (full[u] & ~v[u]);
       continue;
     }
     uint64_t o[4];
@@ -599,7 +606,7 @@ __device__ unsigned long long g_skc_times[8];
 
 // recs / mult: the bucket's representatives as sk_dedup_kernel leaves them (nrep[2 * bucket] full ones from the
 // start of the slice, nrep[2 * bucket + 1] others from its end backwards) and how many records each stands
-// for; bits_out[i] = the windows of representative i that are kept, or (store_miss) those that are not;
+// for; bits_out[i] = the windows of representative i that are NOT known to be kept;
 // kSkUnknown when the bucket is not counted here (overflow[bucket] is set as well).  bucket_list: the buckets to
 // count (one workgroup each) when not all of them.
 #ifndef SKC_SPLIT
@@ -616,7 +623,7 @@ __global__ __launch_bounds__(SKC_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
                                                                    unsigned long long* __restrict__ distinct_total,
                                                                    uint8_t* __restrict__ overflow,
                                                                    uint64_t* __restrict__ ulist,
-                                                                   uint32_t* __restrict__ bits_out, int store_miss,
+                                                                   uint32_t* __restrict__ bits_out,
                                                                    uint64_t giant, const uint32_t* __restrict__ bucket_list) {
   extern __shared__ __align__(16) unsigned char skc_smem[];
   unsigned long long* tkeys = reinterpret_cast<unsigned long long*>(skc_smem);
@@ -750,12 +757,12 @@ __global__ __launch_bounds__(SKC_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
       }
       if (it < items && it % SKC_SPLIT == 0) {
         if (pass == 0) {
-          bits_out[i] = store_miss ? 0u : (n == 32 ? ~0u : (1u << n) - 1);
+          bits_out[i] = 0u;
         } else {
           // the unsettled records are listed densely (in the bucket's own slice of ulist) so that the second
           // sweep keeps every lane busy
           if (und) ulist[lo + atomicAdd(&s_unsettled, 1u)] = (uint64_t(i - lo) << 32) | und;
-          bits_out[i] = store_miss ? und : bits;
+          bits_out[i] = und;
         }
       }
     }
@@ -814,7 +821,7 @@ __global__ __launch_bounds__(SKC_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
 #pragma unroll
     for (int d = 1; d < SKC_SPLIT; d <<= 1) bits |= uint32_t(__shfl_xor(int(bits), d, 64));
     if (bits && q % SKC_SPLIT == 0) {  // this thread is the only one touching the record in this sweep
-      if (store_miss) bits_out[i] &= ~bits; else bits_out[i] |= bits;
+      bits_out[i] &= ~bits;
     }
   }
   __syncthreads();
@@ -920,7 +927,8 @@ int kmer_skm_finish_present(bg_ctx* ctx, bg_kmerset* ks) {
 
 template <typename Org, bool kIndex>
 static int sk_partition_segmented(bg_ctx* ctx, const SkRec* in, SkRec* out, const Org* oin, Org* oout, uint64_t n,
-                                  uint32_t nseg, const uint64_t* h_rec0, int shift, uint32_t dmask) {
+                                  uint32_t nseg, const uint64_t* h_rec0, int shift, uint32_t dmask,
+                                  uint32_t* full_bits = nullptr) {
   std::vector<uint32_t> h_tile(size_t(nseg) + 1, 0);
   uint64_t t = 0;
   for (uint32_t b = 0; b < nseg; ++b) {
@@ -949,7 +957,8 @@ static int sk_partition_segmented(bg_ctx* ctx, const SkRec* in, SkRec* out, cons
   BG_TRY(exclusive_scan_u32_to_u64(ctx, hist.p, offs.p, uint64_t(SK_BINS) * ntiles, nullptr));
   ctx->toc(uint64_t(SK_BINS) * ntiles * 12);
   ctx->tic("skm_part_scatter");
-  sk_part_scatter_kernel<Org, kIndex><<<ntiles, SK_THREADS, 0, ctx->stream>>>(in, out, oin, oout, sg, shift, dmask, offs.p);
+  sk_part_scatter_kernel<Org, kIndex><<<ntiles, SK_THREADS, 0, ctx->stream>>>(in, out, oin, oout, sg, shift, dmask, offs.p,
+                                                                               full_bits);
   BG_LAUNCH_CHECK();
   ctx->toc(n * (32 + (kIndex ? 1 : 2) * sizeof(Org)));
   return BG_OK;
@@ -1017,9 +1026,9 @@ static int sk_generate(bg_ctx* ctx, const bg_reads* reads, const SkGeometry& g, 
 // level 1: the top 8 bucket bits (in -> out); h_starts[257] = group starts
 template <typename Org, bool kIndex>
 static int sk_level1(bg_ctx* ctx, const SkRec* in, SkRec* out, const Org* oin, Org* oout, uint64_t R,
-                     uint64_t* h_starts) {
+                     uint64_t* h_starts, uint32_t* full_bits = nullptr) {
   const uint64_t whole[2] = {0, R};
-  BG_TRY((sk_partition_segmented<Org, kIndex>(ctx, in, out, oin, oout, R, 1, whole, SK_BUCKET_FIELD - 8, 0xffu)));
+  BG_TRY((sk_partition_segmented<Org, kIndex>(ctx, in, out, oin, oout, R, 1, whole, SK_BUCKET_FIELD - 8, 0xffu, full_bits)));
   DevBuf<uint64_t> b8;
   BG_TRY(b8.alloc(ctx, SK_BINS + 1));
   sk_bounds_kernel<<<cdiv(SK_BINS + 1, 256), 256, 0, ctx->stream>>>(out, R, 8, b8.p);
@@ -1083,7 +1092,8 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
   BG_TRY(rc.alloc(ctx, R));
   BG_TRY(oc.alloc(ctx, R));
   std::vector<uint64_t> h_starts(SK_BINS + 1);
-  BG_TRY((sk_level1<uint32_t, true>(ctx, in, rb.p, nullptr, ob.p, R, h_starts.data())));
+  // (remote records: bits_out starts as "every window kept" and the spread only writes what differs)
+  BG_TRY((sk_level1<uint32_t, true>(ctx, in, rb.p, nullptr, ob.p, R, h_starts.data(), bits_out)));
 
   // level 2: the next 8 bits inside each of the 256 groups; bigger inputs take up to 5 more bits so that a
   // bucket stays around 24 k windows (BG_KMER_EXTRA_BITS overrides, for tests).  A rank of a sharded build
@@ -1154,7 +1164,7 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
                              hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
   sk_count_lds_kernel<<<NB, SKC_THREADS, smem, ctx->stream>>>(reps, rep_mult.p, bounds.p, nrep.p, slots, k, min_count, out_cap,
                                                              ok_a.p, oc_a.p, ctr.p, ctr.p + 1, overflow.p, ulist.p, rep_bits.p,
-                                                             bits_out ? 0 : 1, giant, nullptr);
+                                                             giant, nullptr);
   BG_LAUNCH_CHECK();
 #ifdef SKC_TIMING
   {
@@ -1195,7 +1205,7 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(big_slots * 12)));
     sk_count_lds_kernel<<<unsigned(list.size()), SKC_THREADS, size_t(big_slots) * 12, ctx->stream>>>(
         reps, rep_mult.p, bounds.p, nrep.p, big_slots, k, min_count, out_cap, ok_a.p, oc_a.p, ctr.p, ctr.p + 1, overflow.p,
-        ulist.p, rep_bits.p, bits_out ? 0 : 1, giant, d_list.p);
+        ulist.p, rep_bits.p, giant, d_list.p);
     BG_LAUNCH_CHECK();
     BG_TRY(read_back());  // (also keeps `list` alive until the copy has been made)
   }
