@@ -384,10 +384,12 @@ def _select_rows(ctx, rows, flags):
     return out[:m.value]
 
 
-def _skm_extract(ctx, reads_h, k, P, dev):
+def _skm_extract(ctx, reads_h, k, P, dev, first_room=0.5):
     """Super-k-mer records of a reads object grouped by owner rank -> (recs [n,2], org [n], counts, windows).
-    The buffers are sized for 1.5x the expected record density (bg_skm_capacity is the 3x worst case, tried only
-    when an input beats that) and trimmed to what was produced: they live until the presence bits are back."""
+    The buffers are sized for first_room of bg_skm_capacity's 3x-the-expected-density worst case (tried only when an
+    input beats that) and only trimmed when less than three quarters are used: they live until the presence bits are
+    back.  Reads: 0.385 = 1.15x the expected density (random sequence produces 0.9x), so that the 3.4 GB of a
+    chr20-sized rank are not copied to be trimmed; probe strings (short, denser) keep 1.5x."""
     L = capi.lib()
     n = C.c_uint64()
     capi.check(L.bg_kmer_instances(ctx.h, reads_h, k, C.byref(n)))
@@ -398,7 +400,7 @@ def _skm_extract(ctx, reads_h, k, P, dev):
     if not cap.value:
         return (torch.empty((0, 2), dtype=torch.int64, device=dev), torch.empty((0,), dtype=torch.int64, device=dev),
                 [0] * P, n.value)
-    for room in (cap.value // 2 + 1024, cap.value):
+    for room in (int(cap.value * first_room) + 1024, cap.value):
         room = min(room, cap.value)
         recs = torch.empty((room, 2), dtype=torch.int64, device=dev)
         org = torch.empty((room,), dtype=torch.int64, device=dev)
@@ -853,7 +855,7 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gath
     for r in ranks:
         counts = (C.c_uint64 * P)()
         if use_skm:
-            recs, org, cnts, n = _skm_extract(ctxs[r], reads[r].h, k, P, dev[r])
+            recs, org, cnts, n = _skm_extract(ctxs[r], reads[r].h, k, P, dev[r], first_room=0.385)
             n_inst[r] = n
             skm_recs[r] = recs
             skm_org[r] = org
