@@ -89,7 +89,7 @@ BG_HD uint64_t kmer_shift(uint64_t kmer, int k, int b) {  // fast_read_correct.c
 // one memory round trip unless its bucket is full, and a 64-byte line is what a probe drags from HBM
 // anyway.  (The dependent round trips of slot-at-a-time probing, taken by the slowest of a wave's 64
 // lanes, were the larger half of the read-correction screen's time.)
-constexpr int kBucketSlots = 8;
+constexpr int kBucketSlots = 8;  // (4-slot buckets, two loads per probe: k_cover_count 8.5 -> 9.1 ms, k_correct_dfs 4.5 -> 4.7)
 BG_HD uint64_t hash_slot(uint64_t canon, int log2cap) {
   return ((canon * 0x9E3779B97F4A7C15ull) >> (64 - log2cap)) & ~uint64_t(kBucketSlots - 1);
 }
@@ -105,8 +105,13 @@ BG_HD int64_t table_find(const uint64_t* slots, int log2cap, uint64_t key, uint6
   for (;;) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ulonglong2* p = reinterpret_cast<const ulonglong2*>(slots + s);
-    ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
-    uint64_t v[kBucketSlots] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+    uint64_t v[kBucketSlots];
+#pragma unroll
+    for (int u = 0; u < kBucketSlots / 2; ++u) {  // all the 16-byte loads of the bucket in flight together
+      const ulonglong2 x = p[u];
+      v[2 * u] = x.x;
+      v[2 * u + 1] = x.y;
+    }
     uint32_t hit = 0, empty = 0;
 #pragma unroll
     for (int u = 0; u < kBucketSlots; ++u) {
