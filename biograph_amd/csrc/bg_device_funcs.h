@@ -578,15 +578,27 @@ BG_HD int lcp_word(uint64_t a, uint64_t b) {
 #endif
 }
 
+#ifndef SUFFIX_WORDS_IN_FLIGHT
+#define SUFFIX_WORDS_IN_FLIGHT 5  // k_cover_count on chr20: 1 word at a time 8.51 ms, 2: 8.32, 3: 8.28, 5: 8.16
+#endif
 // Does oriented sequence `a` (words aw, zero padded), from base offset j, with `rem` bases, match
 // the first `rem` bases of sequence b (words bw)?
 BG_HD bool suffix_is_prefix(const uint64_t* aw, int anw, int j, int rem, const uint64_t* bw) {
-  int full = rem >> 5, tail = rem & 31;
-  for (int w = 0; w < full; ++w)
-    if (window32(aw, anw, j + 32 * w) != bw[w]) return false;
-  if (tail) {
-    uint64_t m = ~0ull << (2 * (32 - tail));
-    if ((window32(aw, anw, j + 32 * full) & m) != (bw[full] & m)) return false;
+  // several words of b in flight at a time: a match — how every read's search ends — has to see all of them, and
+  // fetched one by one behind each other's compare they are as many memory round trips
+  const int full = rem >> 5, tail = rem & 31;
+  const int nw = full + (tail ? 1 : 0);
+  const uint64_t tail_mask = tail ? ~0ull << (2 * (32 - tail)) : ~0ull;
+  for (int w = 0; w < nw; w += SUFFIX_WORDS_IN_FLIGHT) {
+    uint64_t b[SUFFIX_WORDS_IN_FLIGHT];
+#pragma unroll
+    for (int u = 0; u < SUFFIX_WORDS_IN_FLIGHT; ++u) b[u] = w + u < nw ? bw[w + u] : 0;
+#pragma unroll
+    for (int u = 0; u < SUFFIX_WORDS_IN_FLIGHT; ++u) {
+      if (w + u >= nw) break;
+      const uint64_t m = (w + u == full) ? tail_mask : ~0ull;
+      if ((window32(aw, anw, j + 32 * (w + u)) & m) != (b[u] & m)) return false;
+    }
   }
   return true;
 }
@@ -672,6 +684,20 @@ BG_HD int key_compare(const uint64_t* a, int alen, const uint64_t* b, int blen, 
   for (int w = 0; w < W; ++w) {
     if (a[w] < b[w]) return -1;
     if (a[w] > b[w]) return 1;
+  }
+  return alen < blen ? -1 : (alen > blen ? 1 : 0);
+}
+// the same with three words of each key in flight at a time: keys that agree for long (records of one locus, a
+// prefix and its extension) take fewer memory round trips (k_sort_small_groups on chr20's records: word by word
+// 5.02 ms, by two 4.63, by three 4.41, all eight at once 5.22)
+BG_HD int key_compare_by_three(const uint64_t* a, int alen, const uint64_t* b, int blen, int W) {
+  for (int w = 0; w < W; w += 3) {
+    const uint64_t a0 = a[w], b0 = b[w];
+    const uint64_t a1 = w + 1 < W ? a[w + 1] : 0, b1 = w + 1 < W ? b[w + 1] : 0;
+    const uint64_t a2 = w + 2 < W ? a[w + 2] : 0, b2 = w + 2 < W ? b[w + 2] : 0;
+    if (a0 != b0) return a0 < b0 ? -1 : 1;
+    if (a1 != b1) return a1 < b1 ? -1 : 1;
+    if (a2 != b2) return a2 < b2 ? -1 : 1;
   }
   return alen < blen ? -1 : (alen > blen ? 1 : 0);
 }

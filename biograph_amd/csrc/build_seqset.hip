@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_sort_small_groups(const uint64_t* __res
             const uint64_t* xk = rec + uint64_t(x) * W;
             int xl = rlen[x];
             int b = a - 1;
-            while (b >= 0 && key_compare(rec + uint64_t(idx[b]) * W, rlen[idx[b]], xk, xl, W) > 0) {
+            while (b >= 0 && key_compare_by_three(rec + uint64_t(idx[b]) * W, rlen[idx[b]], xk, xl, W) > 0) {
               idx[b + 1] = idx[b];
               --b;
             }
