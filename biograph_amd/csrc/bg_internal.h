@@ -154,6 +154,8 @@ int radix_sort_u64(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* va
 // Stable partition of keys into 65536 buckets by the top 16 bits of key * kPartitionMult.
 constexpr uint64_t kPartitionMult = 0x9E3779B97F4A7C15ull;
 int radix_partition_hash16(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, bool* in_b);
+int radix_partition_hash16_from(bg_ctx* ctx, const uint64_t* in, uint64_t* scratch_a, uint64_t* scratch_b, uint64_t n);
+int radix_partition_bounds(bg_ctx* ctx, const uint64_t* keys, uint64_t n, int bits, uint64_t* d_bounds);
 // One more level: keys grouped by 16 hash bits (kin) -> by 16 + extra_bits (kout), extra_bits in 1..8.
 int radix_partition_hash_refine(bg_ctx* ctx, uint64_t* kin, uint64_t* kout, uint64_t n, int extra_bits);
 // Same for the k-mer instances of packed reads, generated inside pass 1 (n = their number); result in keys_b.

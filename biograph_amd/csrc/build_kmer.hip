@@ -197,6 +197,43 @@ __global__ void k_hash_insert(const uint64_t* __restrict__ kmers, uint64_t n, ui
   }
 }
 
+// The table region by region.  Global atomics write a line through to HBM each (k_hash_insert: 64 M compare-and-swaps
+// = 4.5 GB fetched + 4.2 GB written for a 1 GB table), so big tables are built without them: the keys are partitioned
+// by the top 16 bits of their hash — the top 16 bits of their home slot — and one workgroup per region builds its
+// 2^(log2cap - 16) slots in LDS and writes them out as whole lines.  A key whose chain runs past the end of its region
+// (its buckets there are full) is listed and inserted afterwards the old way, behind the finished regions: every bucket
+// before a key's place along its chain is full either way, which is all a look-up relies on.
+constexpr int kRegionMaxSlots = 4096;
+__global__ __launch_bounds__(256) void k_hash_build_regions(const uint64_t* __restrict__ keys,
+                                                            const uint64_t* __restrict__ bounds, int log2cap,
+                                                            uint64_t* __restrict__ slots, uint64_t* __restrict__ spill,
+                                                            unsigned long long* __restrict__ n_spill) {
+  __shared__ unsigned long long tab[kRegionMaxSlots];
+  const uint32_t region = blockIdx.x;
+  const uint32_t rs = 1u << (log2cap - 16);
+  const uint64_t base = uint64_t(region) * rs;
+  for (uint32_t i = threadIdx.x; i < rs; i += 256) tab[i] = (unsigned long long)kEmptySlot;
+  __syncthreads();
+  const uint64_t lo = bounds[region], hi = bounds[region + 1];
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const uint64_t km = keys[i];
+    uint32_t s = uint32_t(hash_slot(km, log2cap) - base);
+    const int off = hash_slot_offset(km, log2cap);
+    bool placed = false;
+    while (!placed && s < rs) {
+      for (int u = 0; u < kBucketSlots && !placed; ++u) {
+        const uint32_t t = s + uint32_t((off + u) & (kBucketSlots - 1));
+        if (tab[t] != (unsigned long long)kEmptySlot) continue;
+        placed = atomicCAS(&tab[t], (unsigned long long)kEmptySlot, (unsigned long long)km) == (unsigned long long)kEmptySlot;
+      }
+      if (!placed) s += kBucketSlots;
+    }
+    if (!placed) spill[atomicAdd(n_spill, 1ull)] = km;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < rs; i += 256) slots[base + i] = tab[i];
+}
+
 // fwd_starts_read / rev_starts_read (kmer_counter.h:316-320, kmer_count_table.h:82-88): first
 // window of a read (position 0, no N) sets fwd unless flipped; last window sets rev unless flipped.
 __global__ void k_set_start_flags(const uint64_t* __restrict__ words, const uint32_t* __restrict__ nmask,
@@ -937,13 +974,39 @@ int kmer_hash_build_impl(bg_ctx* ctx, bg_kmerset* ks, const bg_reads* reads) {
   // load factor <= 0.7 (8-slot buckets keep chains short) rather than <= 0.5: half the table, which matters
   // beyond 2 GiB where random probes fall off the TLB reach (tools/probe_rate.hip: 55 -> 22 G probes/s at 4 GiB)
   while ((1ull << lg) * 7 < nkept * 10) ++lg;
+  if (const char* e = getenv("BG_HASH_MIN_LOG2CAP")) lg = std::max(lg, std::min(30, atoi(e)));  // tests
   ks->log2cap = lg;
   BG_TRY(ks->slots.alloc(ctx, 1ull << lg));
-  BG_HIP(hipMemsetAsync(ks->slots.p, 0xff, (1ull << lg) * 8, ctx->stream));
-  ctx->tic("kmer_hash_build");
-  if (nkept) {
-    k_hash_insert<<<cdiv(nkept, 256), 256, 0, ctx->stream>>>(ks->kmers.p, nkept, ks->slots.p, lg);
+  int region_min_lg = 24;  // below that the table is small enough for the atomics not to matter (tests lower it to 19)
+  if (const char* e = getenv("BG_HASH_REGION_MIN_LOG2CAP")) region_min_lg = std::max(19, atoi(e));
+  if (lg >= region_min_lg && lg - 16 <= 12 && !getenv("BG_HASH_BUILD_ATOMIC")) {  // region by region (k_hash_build_regions)
+    DevBuf<uint64_t> ta, tb, bounds, spill;
+    DevBuf<unsigned long long> n_spill;
+    BG_TRY(ta.alloc(ctx, nkept));
+    BG_TRY(tb.alloc(ctx, nkept));
+    BG_TRY(bounds.alloc(ctx, 65537));
+    BG_TRY(spill.alloc(ctx, nkept));
+    BG_TRY(n_spill.alloc(ctx, 1));
+    BG_HIP(hipMemsetAsync(n_spill.p, 0, 8, ctx->stream));
+    BG_TRY(radix_partition_hash16_from(ctx, ks->kmers.p, ta.p, tb.p, nkept));
+    BG_TRY(radix_partition_bounds(ctx, ta.p, nkept, 16, bounds.p));
+    ctx->tic("kmer_hash_build");
+    k_hash_build_regions<<<65536, 256, 0, ctx->stream>>>(ta.p, bounds.p, lg, ks->slots.p, spill.p, n_spill.p);
     BG_LAUNCH_CHECK();
+    unsigned long long h_spill = 0;
+    BG_HIP(hipMemcpyAsync(&h_spill, n_spill.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    if (h_spill) {
+      k_hash_insert<<<cdiv(h_spill, 256), 256, 0, ctx->stream>>>(spill.p, h_spill, ks->slots.p, lg);
+      BG_LAUNCH_CHECK();
+    }
+  } else {
+    BG_HIP(hipMemsetAsync(ks->slots.p, 0xff, (1ull << lg) * 8, ctx->stream));
+    ctx->tic("kmer_hash_build");
+    if (nkept) {
+      k_hash_insert<<<cdiv(nkept, 256), 256, 0, ctx->stream>>>(ks->kmers.p, nkept, ks->slots.p, lg);
+      BG_LAUNCH_CHECK();
+    }
   }
   if (reads && reads->n) {
     k_set_start_flags<<<cdiv(reads->n, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->nmask.p, reads->len.p,

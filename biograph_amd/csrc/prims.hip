@@ -782,7 +782,8 @@ __global__ void rs_part_bucket_starts_kernel(const OffT* __restrict__ offs, uint
 }
 
 template <class OffT>
-static int radix_partition_hash16_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, bool* in_b) {
+static int radix_partition_hash16_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, bool* in_b,
+                                       const uint64_t* first_in = nullptr) {
   *in_b = false;
   if (n <= 1) return BG_OK;
   const uint64_t ntiles1 = (n + PT_TILE - 1) / PT_TILE;
@@ -797,7 +798,7 @@ static int radix_partition_hash16_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* 
   BG_TRY(seg_tile.alloc(ctx, RS_BINS + 1));
   std::vector<uint64_t> h_key(RS_BINS + 1, 0);
   std::vector<uint32_t> h_tile(RS_BINS + 1, 0);
-  uint64_t* kin = keys_a;
+  const uint64_t* kin = first_in ? first_in : keys_a;  // (first_in: the keys are only read; keys_a is scratch like keys_b)
   uint64_t* kout = keys_b;
   for (int pass = 0; pass < 2; ++pass) {
     const int shift = pass == 0 ? 56 : 48;
@@ -837,7 +838,8 @@ static int radix_partition_hash16_impl(bg_ctx* ctx, uint64_t* keys_a, uint64_t* 
       BG_HIP(hipMemcpyAsync(h_key.data(), seg_key.p, (RS_BINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
       BG_HIP(hipStreamSynchronize(ctx->stream));
     }
-    uint64_t* t = kin; kin = kout; kout = t;
+    kin = kout;
+    kout = kout == keys_b ? keys_a : keys_b;
     *in_b = !*in_b;
   }
   return BG_OK;
@@ -1062,6 +1064,22 @@ int radix_partition_hash_refine(bg_ctx* ctx, uint64_t* kin, uint64_t* kout, uint
 int radix_partition_hash16(bg_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, bool* in_b) {
   if (use_off32(n)) return radix_partition_hash16_impl<uint32_t>(ctx, keys_a, keys_b, n, in_b);
   return radix_partition_hash16_impl<uint64_t>(ctx, keys_a, keys_b, n, in_b);
+}
+// the same with the keys read from `in` (left as they are); the result is in scratch_a (two passes: in -> b -> a)
+int radix_partition_hash16_from(bg_ctx* ctx, const uint64_t* in, uint64_t* scratch_a, uint64_t* scratch_b, uint64_t n) {
+  bool in_b = false;
+  if (n <= 1) {
+    if (n) BG_HIP(hipMemcpyAsync(scratch_a, in, 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return BG_OK;
+  }
+  if (use_off32(n)) return radix_partition_hash16_impl<uint32_t>(ctx, scratch_a, scratch_b, n, &in_b, in);
+  return radix_partition_hash16_impl<uint64_t>(ctx, scratch_a, scratch_b, n, &in_b, in);
+}
+// first position whose top `bits` bits of key * kPartitionMult are >= b, for b = 0 .. 2^bits (device array of 2^bits + 1)
+int radix_partition_bounds(bg_ctx* ctx, const uint64_t* keys, uint64_t n, int bits, uint64_t* d_bounds) {
+  rs_part_bounds_kernel<<<cdiv((1ull << bits) + 1, 256), 256, 0, ctx->stream>>>(keys, n, bits, d_bounds);
+  BG_LAUNCH_CHECK();
+  return BG_OK;
 }
 
 }  // namespace bg

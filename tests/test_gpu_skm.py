@@ -77,6 +77,10 @@ def test_overflow_and_fallback_paths(ctx, monkeypatch, env):
 
 @pytest.mark.parametrize("env", [{}, {"BG_KMER_LDS_LOG2CAP": "2"}, {"BG_KMER_LDS_LOG2CAP": "7"},
                                  {"BG_KMER_LDS_SLOTS": "10", "BG_KMER_LDS_SLOTS2": "30"},
+                                 # the k-mer hash table built region by region in LDS (regions of one and of two
+                                 # buckets at this size: chains spill over into the next region)
+                                 {"BG_HASH_REGION_MIN_LOG2CAP": "19", "BG_HASH_MIN_LOG2CAP": "19"},
+                                 {"BG_HASH_REGION_MIN_LOG2CAP": "19", "BG_HASH_MIN_LOG2CAP": "20"},
                                  {"BG_SCREEN_LOOKUP": "1"}, {"BG_SKM_READS_PER_TILE": "50000"}])
 def test_presence_bits_drive_the_correction(ctx, monkeypatch, env):
     """bg_correct_reads takes the window presence from the count (no look-ups); the buckets whose table
