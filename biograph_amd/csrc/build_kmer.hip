@@ -535,21 +535,29 @@ __global__ __launch_bounds__(64) void k_correct_dfs(const uint64_t* __restrict__
                                                     CorrectCounters* __restrict__ ctr,
                                                     const uint64_t* __restrict__ present, int pstride) {
   uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= nlist) return;
-  // read-index order on purpose: in locus order the expensive reads (shared SNP / error loci) pile up in
-  // the same waves and the divergent search loses more to imbalance than it gains in locality
-  uint64_t i = list[t];
-  KmerTable tab{slots, log2cap, k};
-  int L = len[i];
-  uint64_t ow[kMaxWords];
-  int ncorr = 0;
-  int clen = frc_correct_read(tab, words + i * W, nmask + i * W, L, W, k, max_corrections, min_good_run,
-                              int(needed_by_len[L]), ow, &ncorr, present + i * pstride);
-  for (int w = 0; w < W; ++w) out_words[i * W + w] = clen ? ow[w] : 0;
-  out_len[i] = uint16_t(clen);
-  if (clen && ncorr) {
-    atomicAdd(&ctr->modified, 1ull);
-    atomicAdd(&ctr->modified_bases, (unsigned long long)ncorr);
+  int clen = 0, ncorr = 0;
+  if (t < nlist) {
+    // read-index order on purpose: in locus order the expensive reads (shared SNP / error loci) pile up in
+    // the same waves and the divergent search loses more to imbalance than it gains in locality
+    uint64_t i = list[t];
+    KmerTable tab{slots, log2cap, k};
+    int L = len[i];
+    uint64_t ow[kMaxWords];
+    clen = frc_correct_read(tab, words + i * W, nmask + i * W, L, W, k, max_corrections, min_good_run,
+                            int(needed_by_len[L]), ow, &ncorr, present + i * pstride);
+    for (int w = 0; w < W; ++w) out_words[i * W + w] = clen ? ow[w] : 0;
+    out_len[i] = uint16_t(clen);
+  }
+  // one pair of atomics per wave (the counters are single addresses, and a global atomic writes its line through:
+  // three million of them, one per modified read, were 0.4 GB of the kernel's writes); ncorr <= 8
+  const bool mod = clen && ncorr;
+  const unsigned long long wave_mod = __popcll(__ballot(mod));
+  unsigned long long wave_bases = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) wave_bases += (unsigned long long)__popcll(__ballot(mod && ((ncorr >> b) & 1))) << b;
+  if ((threadIdx.x & 63) == 0 && wave_mod) {
+    atomicAdd(&ctr->modified, wave_mod);
+    atomicAdd(&ctr->modified_bases, wave_bases);
   }
 }
 
@@ -1306,32 +1314,57 @@ __global__ __launch_bounds__(64) void k_correct_dfs_routed(const uint64_t* __res
                                                            unsigned long long* __restrict__ cursor, uint64_t round_base,
                                                            uint32_t* __restrict__ desc_slot, uint8_t* __restrict__ still) {
   const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= n_pend) return;
-  const uint32_t slot = pend[t];
-  const uint64_t i = list[slot];
+  const bool valid = t < n_pend;
+  const uint32_t slot = valid ? pend[t] : 0;
   RoutedTable rt;
   rt.pool = pool;
-  rt.head = head[slot];
+  rt.head = 0;
   rt.k = k;
   rt.n_new = 0;
   rt.missed = false;
-  const int L = len[i];
-  uint64_t ow[kMaxWords];
-  int ncorr = 0;
-  const int clen = frc_correct_read(rt, words + i * W, nmask + i * W, L, W, k, max_corrections, min_good_run,
-                                    int(needed_by_len[L]), ow, &ncorr, present + i * pstride);
-  if (!rt.missed) {
-    for (int w = 0; w < W; ++w) out_words[i * W + w] = clen ? ow[w] : 0;
-    out_len[i] = uint16_t(clen);
-    if (clen && ncorr) {
-      atomicAdd(&ctr->modified, 1ull);
-      atomicAdd(&ctr->modified_bases, (unsigned long long)ncorr);
+  int ncorr = 0, clen = 0;
+  if (valid) {
+    const uint64_t i = list[slot];
+    rt.head = head[slot];
+    const int L = len[i];
+    uint64_t ow[kMaxWords];
+    clen = frc_correct_read(rt, words + i * W, nmask + i * W, L, W, k, max_corrections, min_good_run,
+                            int(needed_by_len[L]), ow, &ncorr, present + i * pstride);
+    if (!rt.missed) {
+      for (int w = 0; w < W; ++w) out_words[i * W + w] = clen ? ow[w] : 0;
+      out_len[i] = uint16_t(clen);
+      still[t] = 0;
     }
-    still[t] = 0;
-    return;
   }
+  // The counters and the probe pool's cursor are single addresses: one atomic per wave each instead of one per read
+  // (in the first round every read of the list asks for pool places).
+  const int lane = threadIdx.x & 63;
+  const uint64_t below = (1ull << lane) - 1;
+  const bool mod = valid && !rt.missed && clen && ncorr;
+  const unsigned long long wave_mod = __popcll(__ballot(mod));
+  unsigned long long wave_bases = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) wave_bases += (unsigned long long)__popcll(__ballot(mod && ((ncorr >> b) & 1))) << b;  // ncorr <= 8
+  const bool miss = valid && rt.missed;
+  uint32_t before = 0, wave_new = 0;  // pool places of the lanes below this one, of the whole wave
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {  // n_new <= kMaxNewProbes = 4
+    const uint64_t mb = __ballot(miss && ((rt.n_new >> b) & 1));
+    before += uint32_t(__popcll(mb & below)) << b;
+    wave_new += uint32_t(__popcll(mb)) << b;
+  }
+  unsigned long long wave_base = 0;
+  if (lane == 0) {
+    if (wave_mod) {
+      atomicAdd(&ctr->modified, wave_mod);
+      atomicAdd(&ctr->modified_bases, wave_bases);
+    }
+    if (wave_new) wave_base = atomicAdd(cursor, (unsigned long long)wave_new);
+  }
+  wave_base = __shfl(wave_base, 0, 64);
+  if (!miss) return;
   // rt.n_new >= 1: the first miss of a run is never one of this run's own new probes
-  const uint64_t base = atomicAdd(cursor, (unsigned long long)rt.n_new);
+  const uint64_t base = wave_base + before;
   uint32_t prev = rt.head;
   for (int q = 0; q < rt.n_new; ++q) {
     ProbeDesc d;
