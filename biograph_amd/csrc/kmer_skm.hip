@@ -531,9 +531,11 @@ __global__ __launch_bounds__(SKS_THREADS) void sk_spread_kernel(const SkRec* __r
       full[u] = 0;
       if (v[u]) {  // (i < hi)
         at[u] = idx[i];
-        const int n = sk_windows(recs[i].b);
-        full[u] = n == 32 ? ~0u : (1u << n) - 1;
-        if (uncounted) v[u] = full[u];  // every window is to be looked up later
+        if (bits_out || uncounted) {  // (a local record with windows to clear needs nothing of the record itself)
+          const int n = sk_windows(recs[i].b);
+          full[u] = n == 32 ? ~0u : (1u << n) - 1;
+          if (uncounted) v[u] = full[u];  // every window is to be looked up later
+        }
       }
     }
     if (bits_out) {  // (they start as "every window kept": sk_part_scatter_kernel)
