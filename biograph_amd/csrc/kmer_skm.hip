@@ -123,10 +123,13 @@ __device__ __forceinline__ void tile_skms(const SkSource& src, uint64_t r_lo, ui
     if (L < k) continue;  // wave-uniform
     const int nk = L - k + 1, nm = L - SK_M + 1;
     sk_wave_sync();  // the previous read's words are no longer needed
+    uint32_t my_n = 0;
     if (lane < SK_WORDS) {  // the read's words (zero padded) where every lane can fetch the ones it needs
       sw[lane] = lane < W ? src.words[i * W + lane] : 0;
-      sn[lane] = lane < W ? src.nmask[i * W + lane] : 0;
+      my_n = lane < W ? src.nmask[i * W + lane] : 0;
+      sn[lane] = my_n;
     }
+    const bool has_n = __ballot(my_n != 0) != 0;  // wave-uniform: nearly every read has none and skips the masks
     sk_wave_sync();
     uint32_t carry_mz = SK_INF;
     int carry_rs = -1;
@@ -134,9 +137,12 @@ __device__ __forceinline__ void tile_skms(const SkSource& src, uint64_t r_lo, ui
       const int p = base + lane;
       const int q = p >> 5, r = p & 31;
       const uint64_t w0 = sw[q], w1 = sw[q + 1];
-      const uint32_t n0 = sn[q], n1 = sn[q + 1];
       const uint64_t x = (w0 << (2 * r)) | ((w1 >> 1) >> (63 - 2 * r));
-      const uint32_t nw = (n0 << r) | ((n1 >> 1) >> (31 - r));
+      uint32_t nw = 0;
+      if (has_n) {
+        const uint32_t n0 = sn[q], n1 = sn[q + 1];
+        nw = (n0 << r) | ((n1 >> 1) >> (31 - r));
+      }
       uint32_t m = SK_INF;
       if (p < nm && (nw >> (32 - SK_M)) == 0) m = sk_order(sk_canon_mmer(uint32_t(x >> (64 - 2 * SK_M))));
       // minimum over the w order values from this lane on, in log steps
@@ -156,11 +162,15 @@ __device__ __forceinline__ void tile_skms(const SkSource& src, uint64_t r_lo, ui
       const uint64_t le = bm & (~0ull >> (63 - lane));
       const int rs = le ? base + 63 - __clzll((long long)le) : carry_rs;  // start of this window's run, if valid
       const uint32_t dd = uint32_t(p - rs);
-      const uint32_t full = ((dd + 1) * rcp) >> 16;  // records of nmax windows ending at or before this one
+      // records of nmax windows ending at or before this one, times nmax (24-bit multiplies run at full rate, 32-bit
+      // ones at a quarter: dd < 400, rcp < 3200)
+      const uint32_t full_n = uint32_t(__umul24(uint32_t(__umul24(dd + 1, rcp)) >> 16, uint32_t(nmax)));
+      const bool at_full = full_n == dd + 1;
       const bool next_starts = p + 1 >= nk || ((bm >> ((lane + 1) & 63)) & 1);
-      const bool emit = valid && lane < stride && (next_starts || full * uint32_t(nmax) == dd + 1);
-      // the record's first window; the whole wave calls f (so that it can aggregate over the emitting lanes)
-      const int s0 = rs + int(((dd * rcp) >> 16) * uint32_t(nmax));
+      const bool emit = valid && lane < stride && (next_starts || at_full);
+      // the record's first window = rs + (dd / nmax) * nmax; the whole wave calls f (so that it can aggregate over
+      // the emitting lanes)
+      const int s0 = rs + int(at_full ? full_n - uint32_t(nmax) : full_n);
       f(emit, i, s0, p - s0 + 1, mz);
       carry_mz = uint32_t(__builtin_amdgcn_readlane(int(mz), stride - 1));
       const uint64_t lo = bm & ((1ull << stride) - 1);
@@ -611,6 +621,11 @@ __device__ unsigned long long g_skc_times[8];
 // for; bits_out[i] = the windows of representative i that are NOT known to be kept;
 // kSkUnknown when the bucket is not counted here (overflow[bucket] is set as well).  bucket_list: the buckets to
 // count (one workgroup each) when not all of them.
+// home slot of a k-mer in a table of cap slots: the key folded to 32 bits, one multiply, one multiply-high.  (Two
+// 24-bit multiplies instead — full rate, not a quarter — change nothing: the probe loop waits on LDS, not on the VALU.)
+__device__ __forceinline__ uint32_t skc_slot(unsigned long long key, uint32_t cap) {
+  return __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
+}
 #ifndef SKC_SPLIT
 #define SKC_SPLIT 4  // lanes that share the windows of one representative (a power of two, neighbours in a wave)
 #endif
@@ -695,8 +710,7 @@ __global__ __launch_bounds__(SKC_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
       uint64_t fwd = x >> (64 - 2 * k);
       uint64_t rc = kmer_revcomp(fwd, k);
       unsigned long long key = rc < fwd ? rc : fwd;
-      // 32-bit multiplies run at quarter rate: fold the key to 32 bits, one multiply, one multiply-high
-      uint32_t slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
+      uint32_t slot = skc_slot(key, cap);
       uint32_t probes = 0;
       while (__any(live)) {
         if (live) {
@@ -729,7 +743,7 @@ __global__ __launch_bounds__(SKC_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
               fwd = ((fwd << 2) | base) & kmask;
               rc = (rc >> 2) | ((base ^ 3) << (2 * (k - 1)));
               key = rc < fwd ? rc : fwd;
-              slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
+              slot = skc_slot(key, cap);
               probes = 0;
             }
           } else {
@@ -809,7 +823,7 @@ __global__ __launch_bounds__(SKC_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
           const uint64_t fwd = x >> (64 - 2 * k);
           const uint64_t rc = kmer_revcomp(fwd, k);
           key = rc < fwd ? rc : fwd;
-          slot = __umulhi((uint32_t(key) ^ uint32_t(key >> 31)) * 0x9E3779B1u, cap);
+          slot = skc_slot(key, cap);
         }
         if (tkeys[slot] == key) {  // every window's key is in the table (no overflow)
           if (tcnt[slot] >= min_count) bits |= 1u << t;
