@@ -52,7 +52,12 @@ __global__ void k_pack_reads(const uint8_t* __restrict__ seq, const uint64_t* __
                              uint32_t* __restrict__ nmask, uint32_t* __restrict__ err) {
   uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (g >= n * uint64_t(W)) return;
-  uint64_t i = g / uint64_t(W);
+  // g / W as one multiply-high with ceil(2^32 / W) (exact for g < 2^32 / 8) where it can: the 64-bit division is
+  // a hundred instructions a thread
+  uint64_t i;
+  if (W == 1) i = g;
+  else if (g < (1ull << 29)) i = __umulhi(uint32_t(g), uint32_t((0x100000000ull + uint32_t(W) - 1) / uint32_t(W)));
+  else i = g / uint64_t(W);
   int w = int(g - i * uint64_t(W));
   int L = len[i];
   int lo = w * 32;

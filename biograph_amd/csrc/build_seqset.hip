@@ -172,11 +172,15 @@ __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict
     }
     r1 = e;
   }
-  const uint64_t nwords = (r1 - r0) * uint64_t(W);
-  for (uint64_t x0 = 0; x0 < nwords; x0 += 64) {
-    const uint64_t x = x0 + lane;
-    const uint64_t q = r0 + x / uint64_t(W);
-    const int w = int(x % uint64_t(W));
+  // (the wave's words number at most 64 reads x 255 records x 8 words: 32-bit arithmetic, and x / W as one
+  // multiply-high with ceil(2^32 / W), exact for x < 2^32 / 8 — a 64-bit division per word was most of the kernel)
+  const uint32_t nwords = uint32_t(r1 - r0) * uint32_t(W);
+  const uint32_t rcp_w = W > 1 ? uint32_t((0x100000000ull + uint32_t(W) - 1) / uint32_t(W)) : 0u;
+  for (uint32_t x0 = 0; x0 < nwords; x0 += 64) {
+    const uint32_t x = x0 + uint32_t(lane);
+    const uint32_t xq = W > 1 ? __umulhi(x, rcp_w) : x;
+    const uint64_t q = r0 + xq;
+    const int w = int(x - xq * uint32_t(W));
     int lo = 0;  // last lane whose first record is <= q
 #pragma unroll
     for (int step = 32; step; step >>= 1) {
