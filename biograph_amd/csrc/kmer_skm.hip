@@ -589,14 +589,27 @@ __global__ __launch_bounds__(256) void sk_present_valid_kernel(const uint32_t* _
     const int t0 = 64 * j;
     m[j] = 0;
     if (nk > t0) m[j] = nk - t0 >= 64 ? ~0ull : (1ull << (nk - t0)) - 1;
-    if (any_n && m[j]) {
-      for (int bb = 0; bb < 64 && t0 + bb < nk; ++bb) {
-        const int t = t0 + bb, q = t >> 5, r = t & 31;
-        const uint32_t n0 = nmask[i * W + q], n1 = q + 1 < W ? nmask[i * W + q + 1] : 0;
-        const uint32_t nm = r ? ((n0 << r) | (n1 >> (32 - r))) : n0;
-        if (nm >> (32 - k)) m[j] &= ~(1ull << bb);
+  }
+  if (any_n) {
+    // windows that hold an N = the N bits of the bases (bit b of word w = base 64 w + b) smeared over the k - 1
+    // positions before each, in log steps.  (One read in 70 holds an N at a rate of 1e-4: two waves in three have such
+    // a lane, and a loop over its windows — 121 rounds of dependent loads — was nine tenths of the kernel.)
+    unsigned long long nb[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (q < W) {
+        const unsigned long long rev = __brev(nmask[i * W + q]);  // bit r = base 32 q + r
+        nb[q >> 1] |= rev << (32 * (q & 1));
       }
     }
+    for (int width = 1; width < k;) {
+      const int sft = width < k - width ? width : k - width;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) nb[w] |= (nb[w] >> sft) | (nb[w + 1] << (64 - sft));
+      width += sft;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] &= ~nb[j];
   }
   if (pstride == 2) {
     *reinterpret_cast<ulonglong2*>(present + i * 2) = make_ulonglong2(m[0], m[1]);
