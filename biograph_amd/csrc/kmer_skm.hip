@@ -397,7 +397,8 @@ __global__ __launch_bounds__(SKD_THREADS) void sk_dedup_kernel(const SkRec* __re
                                                                SkRec* __restrict__ reps, uint16_t* __restrict__ mult,
                                                                uint32_t* __restrict__ rep_of, uint32_t* __restrict__ nrep) {
   __shared__ uint32_t s_dh[SKD_SLOTS];
-  __shared__ uint32_t s_hist[64];  // full representatives by window count (32 bins), then the others
+  __shared__ SkRec s_rec[SKD_CHUNK];  // the chunk's records: a copy is compared with its representative here, not in HBM
+  __shared__ uint32_t s_hist[64];     // full representatives by window count (32 bins), then the others
   __shared__ uint32_t s_full, s_other;
   const uint32_t bucket = blockIdx.x;
   const uint64_t lo = bounds[bucket], hi = bounds[bucket + 1];
@@ -414,12 +415,20 @@ __global__ __launch_bounds__(SKD_THREADS) void sk_dedup_kernel(const SkRec* __re
 #pragma unroll
     for (int j = 0; j < SKD_PER; ++j) {
       const uint32_t q = uint32_t(j) * SKD_THREADS + threadIdx.x;
-      myslot[j] = 0;
-      first[j] = false;
       r[j].a = 0;
       r[j].b = 0;
       if (q < cn) {
         r[j] = recs[c0 + q];
+        s_rec[q] = r[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SKD_PER; ++j) {
+      const uint32_t q = uint32_t(j) * SKD_THREADS + threadIdx.x;
+      myslot[j] = 0;
+      first[j] = false;
+      if (q < cn) {
         uint32_t slot = ((uint32_t(r[j].a) ^ uint32_t(r[j].a >> 32)) * 0x9E3779B1u ^
                          (uint32_t(r[j].b) ^ uint32_t(r[j].b >> 32)) * 0x85EBCA6Bu) >> (32 - SKD_BITS);
         for (;;) {
@@ -431,7 +440,7 @@ __global__ __launch_bounds__(SKD_THREADS) void sk_dedup_kernel(const SkRec* __re
               break;
             }
           }
-          const SkRec other = recs[c0 + (e & 0xffffu)];
+          const SkRec other = s_rec[e & 0xffffu];
           if (other.a == r[j].a && other.b == r[j].b) {
             atomicAdd(&s_dh[slot], 1u << 16);
             break;
