@@ -810,6 +810,10 @@ __device__ __forceinline__ uint64_t entries_lower_bound(const uint64_t* __restri
   return lo;
 }
 
+// marks: one byte per (base, entry); the four planes start a multiple of 64 bytes apart so that k_pack_marks can read
+// them 16 bytes a lane
+__host__ __device__ inline uint64_t marks_stride(uint64_t n) { return (n + 63) & ~63ull; }
+
 // prev bits (builder.cpp:85-108, closed form of SURVEY row F1): entry s sets
 // prev_{s[0]}[lower_bound(entries, s[1:])]; the target must extend s[1:] ("Missing expansion?").
 __global__ __launch_bounds__(256) void k_prev_bits(const uint64_t* __restrict__ ekeys,
@@ -830,7 +834,7 @@ __global__ __launch_bounds__(256) void k_prev_bits(const uint64_t* __restrict__ 
   }
   // one byte per (base, target): neighbouring entries hit neighbouring targets, so a shared 64-bit word
   // would serialise 64 same-address atomics per wave; bytes are plain coalesced stores, packed below
-  marks[uint64_t(b) * n + lo] = 1;
+  marks[uint64_t(b) * marks_stride(n) + lo] = 1;
 }
 
 // target of a tail (s[1:], tl bases) among the entries: the search on the dense two-word prefixes, the
@@ -897,7 +901,7 @@ __global__ __launch_bounds__(256) void k_prev_bits_pre2(const uint64_t* __restri
   for (int w = 0; w < W; ++w) tail[w] = window32(s, W, 1 + 32 * w);
   uint64_t lo;
   if (!prev_target_pre2(ekeys, pre2, sizes, n, W, dir, bases, tail, tl, verify, err, &lo)) return;
-  marks[uint64_t(b) * n + lo] = 1;
+  marks[uint64_t(b) * marks_stride(n) + lo] = 1;
 }
 
 // marks[b*n + t] -> bit t of prev_b (OR-ed into the existing words)
@@ -916,15 +920,18 @@ __global__ __launch_bounds__(256) void k_pack_marks(const uint8_t* __restrict__ 
   const uint64_t w0 = (g - uint64_t(b) * chunks) * kPackWordsPerWave;
   const int lane = threadIdx.x & 63;
   unsigned long long* bits = b == 0 ? bA : b == 1 ? bC : b == 2 ? bG : bT;
-  const uint8_t* m = marks + uint64_t(b) * n;
-  uint64_t mine = 0;
-#pragma unroll
-  for (int it = 0; it < kPackWordsPerWave; ++it) {
-    uint64_t t = (w0 + it) * 64 + lane;
-    uint64_t word = __ballot(t < n && m[t] != 0);
-    if (lane == it) mine = word;
-  }
-  if (lane < kPackWordsPerWave && w0 + lane < nwords && mine) bits[w0 + lane] |= mine;
+  const uint64_t stride = marks_stride(n);
+  // a lane takes 16 marks (bytes 0 / 1) with one 16-byte load — a byte a lane moved 64 bytes per load instruction —
+  // and four lanes put one output word together
+  const uint64_t t0 = w0 * 64 + uint64_t(lane) * 16;
+  uint4 x = make_uint4(0, 0, 0, 0);
+  if (t0 < stride) x = *reinterpret_cast<const uint4*>(marks + uint64_t(b) * stride + t0);
+  auto nib = [](uint32_t v) { v &= 0x01010101u; return (v | (v >> 7) | (v >> 14) | (v >> 21)) & 0xfu; };
+  unsigned long long v = nib(x.x) | (nib(x.y) << 4) | (nib(x.z) << 8) | (nib(x.w) << 12);
+  v |= __shfl_down(v, 1, 64) << 16;
+  v |= __shfl_down(v, 2, 64) << 32;
+  const uint64_t word = w0 + uint64_t(lane >> 2);
+  if ((lane & 3) == 0 && word < nwords && v) bits[word] |= v;
 }
 
 // tails received from other shards (rows of W+1 words: s[1:], (len-1) | base << 8) -> prev bits
@@ -939,7 +946,7 @@ __global__ __launch_bounds__(256) void k_apply_tails(const uint64_t* __restrict_
   int tl = int(tail[W] & 0xff), b = int((tail[W] >> 8) & 3);
   uint64_t lo = entries_lower_bound(ekeys, sizes, n, W, dir, bases, tail, tl);
   if (lo >= n || key_lcp(ekeys + lo * W, sizes[lo], tail, tl, W) < tl) { atomicOr(err, 2u); return; }
-  marks[uint64_t(b) * n + lo] = 1;
+  marks[uint64_t(b) * marks_stride(n) + lo] = 1;
 }
 
 // bitcount::finalize (io/bitcount.cpp:84-124): one thread per 512-bit group.
@@ -1470,7 +1477,7 @@ __global__ __launch_bounds__(256) void k_apply_tails_pre2(const uint64_t* __rest
   const int tl = int(row[W] & 0xff), b = int((row[W] >> 8) & 3);
   uint64_t lo;
   if (!prev_target_pre2(ekeys, pre2, sizes, n, W, dir, bases, tail, tl, verify, err, &lo)) return;
-  marks[uint64_t(b) * n + lo] = 1;
+  marks[uint64_t(b) * marks_stride(n) + lo] = 1;
 }
 
 // short tails (3 words: two leading words of the tail, meta): a tail shorter than 64 bases is all there in its
@@ -1496,7 +1503,7 @@ __global__ __launch_bounds__(256) void k_apply_tails_short(const uint64_t* __res
     for (int w = 2; w < kMaxWords; ++w) tail[w] = 0;
     uint64_t lo;
     if (!prev_target_pre2(ekeys, pre2, sizes, n, W, dir, bases, tail, tl, 0, err, &lo)) return;
-    marks[uint64_t(b) * n + lo] = 1;
+    marks[uint64_t(b) * marks_stride(n) + lo] = 1;
     return;
   }
   const uint32_t p = uint32_t(t0 >> (64 - 2 * bases));
@@ -1521,7 +1528,7 @@ __global__ __launch_bounds__(256) void k_apply_tails_short(const uint64_t* __res
   if (sure && int(sizes[a]) >= tl) {
     // NB equal leading words do not prove the entry extends the tail beyond base 64: the closure of the entry set
     // does (some entry extends the tail, and this is the only one that starts like it)
-    marks[uint64_t(b) * n + a] = 1;
+    marks[uint64_t(b) * marks_stride(n) + a] = 1;
   } else {
     need_full[t] = 1;
   }
@@ -1534,8 +1541,8 @@ int apply_tails2_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64
   const bool use_pre2 = ss->pre2.p && ss->pre2.n >= 2 * ss->n;
   if (!use_pre2) { set_error("short tails need the entries' two-word prefixes"); return BG_EINVAL; }
   BG_TRY(build_prefix_dir_keys(ctx, ss->pre2.p, ss->n, 2, &dir, &bases));
-  BG_TRY(marks.alloc(ctx, 4 * ss->n));
-  if (ss->n) BG_HIP(hipMemsetAsync(marks.p, 0, 4 * ss->n, ctx->stream));
+  BG_TRY(marks.alloc(ctx, 4 * marks_stride(ss->n)));
+  if (ss->n) BG_HIP(hipMemsetAsync(marks.p, 0, 4 * marks_stride(ss->n), ctx->stream));
   const char* v = getenv("BG_VERIFY_CLOSURE");
   const bool full = (v && v[0] == '1') || getenv("BG_PREV_FULL_SEARCH");
   k_apply_tails_short<<<cdiv(n_rows, 256), 256, 0, ctx->stream>>>(d_rows, n_rows, ss->keys.p, ss->pre2.p, ss->sizes.p, ss->n, ss->W,
@@ -1553,8 +1560,8 @@ int apply_tails_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_
   const bool use_pre2 = ss->pre2.p && ss->pre2.n >= 2 * ss->n && !getenv("BG_PREV_FULL_SEARCH");
   if (use_pre2) BG_TRY(build_prefix_dir_keys(ctx, ss->pre2.p, ss->n, 2, &dir, &bases));
   else BG_TRY(build_prefix_dir(ctx, ss, &dir, &bases));
-  BG_TRY(marks.alloc(ctx, 4 * ss->n));
-  if (ss->n) BG_HIP(hipMemsetAsync(marks.p, 0, 4 * ss->n, ctx->stream));
+  BG_TRY(marks.alloc(ctx, 4 * marks_stride(ss->n)));
+  if (ss->n) BG_HIP(hipMemsetAsync(marks.p, 0, 4 * marks_stride(ss->n), ctx->stream));
   if (use_pre2) {
     const char* v = getenv("BG_VERIFY_CLOSURE");
     k_apply_tails_pre2<<<cdiv(n_rows, 256), 256, 0, ctx->stream>>>(d_rows, n_rows, ss->keys.p, ss->pre2.p, ss->sizes.p, ss->n,
@@ -1593,8 +1600,8 @@ int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss) {
     const bool use_pre2 = ss->pre2.p && ss->pre2.n >= 2 * n_ent && !getenv("BG_PREV_FULL_SEARCH");
     if (use_pre2) BG_TRY(build_prefix_dir_keys(ctx, ss->pre2.p, n_ent, 2, &dir, &bases));
     else BG_TRY(build_prefix_dir(ctx, ss, &dir, &bases));
-    BG_TRY(marks.alloc(ctx, 4 * n_ent));
-    BG_HIP(hipMemsetAsync(marks.p, 0, 4 * n_ent, ctx->stream));
+    BG_TRY(marks.alloc(ctx, 4 * marks_stride(n_ent)));
+    BG_HIP(hipMemsetAsync(marks.p, 0, 4 * marks_stride(n_ent), ctx->stream));
     if (use_pre2) {
       const char* v = getenv("BG_VERIFY_CLOSURE");
       k_prev_bits_pre2<<<cdiv(n_ent, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->pre2.p, ss->sizes.p, n_ent, ss->W, dir.p,
