@@ -575,8 +575,7 @@ __global__ __launch_bounds__(256) void k_correct_stats(const uint16_t* __restric
                                                        CorrectTotals* __restrict__ tot) {
   __shared__ unsigned long long sm[4][6];
   unsigned long long v[6] = {0, 0, 0, 0, 0, 0};  // [5] = max corrected length
-  for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x) {
-    int L = len[i], C = out_len[i];
+  auto one = [&](int L, int C) {
     if (C > 0) {
       v[0] += 1;
       v[1] += C;
@@ -585,7 +584,20 @@ __global__ __launch_bounds__(256) void k_correct_stats(const uint16_t* __restric
     } else if (L >= k) {
       v[2] += 1;
     }
+  };
+  // eight reads per thread and step, two 16-byte loads (the arrays are 16-byte aligned); one workgroup per CU: the six
+  // totals are single addresses, and 2048 workgroups' atomics on them took longer than the sums
+  const uint64_t n8 = n / 8;
+  for (uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; g < n8; g += uint64_t(gridDim.x) * blockDim.x) {
+    const uint4 a = reinterpret_cast<const uint4*>(len)[g], b = reinterpret_cast<const uint4*>(out_len)[g];
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      one(int(aw[j] & 0xffff), int(bw[j] & 0xffff));
+      one(int(aw[j] >> 16), int(bw[j] >> 16));
+    }
   }
+  if (blockIdx.x == 0 && threadIdx.x < n - n8 * 8) one(len[n8 * 8 + threadIdx.x], out_len[n8 * 8 + threadIdx.x]);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
 #pragma unroll
@@ -1268,7 +1280,7 @@ extern "C" int bg_correct_reads(bg_ctx* ctx, const bg_reads* reads, const bg_kme
       BG_LAUNCH_CHECK();
       ctx->toc(nlist * W * 20);
     }
-    k_correct_stats<<<(cdiv(n, 256) < 2048u ? cdiv(n, 256) : 2048u), 256, 0, ctx->stream>>>(reads->len.p, r->len.p, n, k, tot.p);
+    k_correct_stats<<<(cdiv(n, 2048) < 256u ? cdiv(n, 2048) : 256u), 256, 0, ctx->stream>>>(reads->len.p, r->len.p, n, k, tot.p);
     BG_LAUNCH_CHECK();
   }
   CorrectCounters hc;
@@ -1597,7 +1609,7 @@ extern "C" int bg_corr_finish(bg_ctx* ctx, bg_correction* c, bg_reads** out, bg_
   BG_TRY(tot.alloc(ctx, 1));
   BG_HIP(hipMemsetAsync(tot.p, 0, sizeof(CorrectTotals), ctx->stream));
   if (n) {
-    k_correct_stats<<<(cdiv(n, 256) < 2048u ? cdiv(n, 256) : 2048u), 256, 0, ctx->stream>>>(c->reads->len.p, c->out->len.p, n, c->k, tot.p);
+    k_correct_stats<<<(cdiv(n, 2048) < 256u ? cdiv(n, 2048) : 256u), 256, 0, ctx->stream>>>(c->reads->len.p, c->out->len.p, n, c->k, tot.p);
     BG_LAUNCH_CHECK();
   }
   CorrectCounters hc;
