@@ -47,25 +47,59 @@ __global__ __launch_bounds__(256) void k_read_lengths(const uint64_t* __restrict
   }
 }
 
-__global__ void k_pack_reads(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs,
+// The characters of a workgroup's 256 words are one stretch of the input (reads follow each other: a length is the
+// difference of two offsets), at most 8 KB: it is staged in LDS with aligned 16-byte loads, and a thread takes its
+// 32 characters from there.  (Four unaligned 8-byte loads a thread, 32 bytes apart from lane to lane, kept the
+// kernel at a third of the memory rate.)
+constexpr int kPackStageDwords = 2048 + 8 + 12;  // 8 KB + alignment slack + what a thread reads past its own bytes
+__global__ __launch_bounds__(256) void k_pack_reads(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs,
                              const uint16_t* __restrict__ len, uint64_t n, int W, uint64_t* __restrict__ words,
                              uint32_t* __restrict__ nmask, uint32_t* __restrict__ err) {
-  uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (g >= n * uint64_t(W)) return;
+  __shared__ uint32_t stage[kPackStageDwords];
+  const uint64_t total = n * uint64_t(W);
+  const uint64_t g0 = uint64_t(blockIdx.x) * blockDim.x;
+  const uint64_t g = g0 + threadIdx.x;
   // g / W as one multiply-high with ceil(2^32 / W) (exact for g < 2^32 / 8) where it can: the 64-bit division is
   // a hundred instructions a thread
-  uint64_t i;
-  if (W == 1) i = g;
-  else if (g < (1ull << 29)) i = __umulhi(uint32_t(g), uint32_t((0x100000000ull + uint32_t(W) - 1) / uint32_t(W)));
-  else i = g / uint64_t(W);
+  const uint32_t rcp_w = W > 1 ? uint32_t((0x100000000ull + uint32_t(W) - 1) / uint32_t(W)) : 0u;
+  auto read_of = [&](uint64_t x) -> uint64_t {
+    if (W == 1) return x;
+    if (x < (1ull << 29)) return __umulhi(uint32_t(x), rcp_w);
+    return x / uint64_t(W);
+  };
+  // the stretch of the input this workgroup needs (block-uniform)
+  const uint64_t gl = (g0 + blockDim.x < total ? g0 + blockDim.x : total) - 1;  // last word (g0 < total: the grid is sized so)
+  const uint64_t i_first = read_of(g0), i_last = read_of(gl);
+  const int w_first = int(g0 - i_first * uint64_t(W)), w_last = int(gl - i_last * uint64_t(W));
+  const int l_first = len[i_first], l_last = len[i_last];
+  const uint8_t* b_lo = seq + offs[i_first] + (32 * w_first < l_first ? 32 * w_first : l_first);
+  const uint8_t* b_hi = seq + offs[i_last] + (32 * (w_last + 1) < l_last ? 32 * (w_last + 1) : l_last);
+  const uint8_t* a_lo = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(b_lo) & ~uintptr_t(15));
+  if (b_hi > b_lo) {
+    // whole 16-byte pieces: one that holds a valid byte lies in that byte's page, whatever else it covers
+    const uint32_t n16 = uint32_t((b_hi - a_lo + 15) >> 4);
+    for (uint32_t v = threadIdx.x; v < n16; v += blockDim.x)
+      reinterpret_cast<uint4*>(stage)[v] = reinterpret_cast<const uint4*>(a_lo)[v];
+  }
+  __syncthreads();
+  if (g >= total) return;
+  const uint64_t i = read_of(g);
   int w = int(g - i * uint64_t(W));
   int L = len[i];
   int lo = w * 32;
   uint64_t word = 0;
   uint32_t nm = 0;
   if (lo < L) {
-    const uint8_t* p = seq + offs[i] + lo;
+    const uint32_t lb = uint32_t(seq + offs[i] + lo - a_lo);  // this word's first character in the staged stretch
     const int cnt = L - lo < 32 ? L - lo : 32;
+    uint32_t q[8];
+    {
+      uint32_t d[9];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) d[j] = stage[(lb >> 2) + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[j] = __builtin_amdgcn_alignbyte(d[j + 1], d[j], lb & 3);
+    }
     bool bad = false;
     // eight characters at a time (SWAR): 2-bit codes A0 C1 G2 T3 (dna_base.h:38-56) from bits 1..2 of the
     // letter, exact byte compares for the ACGT / acgt test and for 'N' (only upper-case N is special,
@@ -79,12 +113,8 @@ __global__ void k_pack_reads(const uint8_t* __restrict__ seq, const uint64_t* __
     for (int c8 = 0; c8 < 4; ++c8) {
       const int m = cnt - 8 * c8;  // characters of this chunk
       if (m <= 0) break;
-      uint64_t x = 0;
-      if (m >= 8) {
-        __builtin_memcpy(&x, p + 8 * c8, 8);  // unaligned 8-byte load
-      } else {
-        for (int j = 0; j < m; ++j) x |= uint64_t(p[8 * c8 + j]) << (8 * j);
-      }
+      uint64_t x = uint64_t(q[2 * c8]) | (uint64_t(q[2 * c8 + 1]) << 32);  // characters 8 c8 .. 8 c8 + 7, first one lowest
+      if (m < 8) x &= (1ull << (8 * m)) - 1;  // (what follows belongs to the next read)
       const uint64_t y = __builtin_bswap64(x);  // first character in the top byte
       const uint64_t t = (y >> 1) & 0x0303030303030303ull;
       uint64_t code = t ^ ((t >> 1) & kOnes);
