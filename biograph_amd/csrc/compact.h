@@ -23,9 +23,18 @@ __global__ __launch_bounds__(CP_THREADS) static void cp_count_kernel(const uint8
   __shared__ uint32_t sm[4];
   uint64_t base = uint64_t(blockIdx.x) * CP_TILE + uint64_t(threadIdx.x) * CP_ITEMS;
   uint32_t c = 0;
+  if (base + CP_ITEMS <= n && (reinterpret_cast<uintptr_t>(flags) & 7) == 0) {
+    // the thread's eight flags in one load (a byte a lane and load moves 64 bytes per instruction)
+    uint64_t f8 = *reinterpret_cast<const uint64_t*>(flags + base);
+    f8 |= f8 >> 4;
+    f8 |= f8 >> 2;
+    f8 |= f8 >> 1;  // bit 0 of every byte = that byte is not zero
+    c = uint32_t(__popcll(f8 & 0x0101010101010101ull));
+  } else {
 #pragma unroll
-  for (int i = 0; i < CP_ITEMS; ++i)
-    if (base + i < n && flags[base + i]) ++c;
+    for (int i = 0; i < CP_ITEMS; ++i)
+      if (base + i < n && flags[base + i]) ++c;
+  }
   int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   uint32_t inc = cp_wave_incl_scan(c, lane);
   if (lane == 63) sm[w] = inc;
@@ -41,10 +50,19 @@ __global__ __launch_bounds__(CP_THREADS) static void cp_emit_kernel(const uint8_
   uint64_t base = uint64_t(blockIdx.x) * CP_TILE + uint64_t(threadIdx.x) * CP_ITEMS;
   uint8_t f[CP_ITEMS];
   uint32_t c = 0;
+  if (base + CP_ITEMS <= n && (reinterpret_cast<uintptr_t>(flags) & 7) == 0) {
+    const uint64_t f8 = *reinterpret_cast<const uint64_t*>(flags + base);
 #pragma unroll
-  for (int i = 0; i < CP_ITEMS; ++i) {
-    f[i] = (base + i < n) ? flags[base + i] : 0;
-    if (f[i]) ++c;
+    for (int i = 0; i < CP_ITEMS; ++i) {
+      f[i] = uint8_t(f8 >> (8 * i));
+      if (f[i]) ++c;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < CP_ITEMS; ++i) {
+      f[i] = (base + i < n) ? flags[base + i] : 0;
+      if (f[i]) ++c;
+    }
   }
   int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   uint32_t inc = cp_wave_incl_scan(c, lane);
