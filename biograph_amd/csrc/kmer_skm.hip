@@ -391,7 +391,7 @@ constexpr int SKD_SLOTS = 1 << SKD_BITS;  // >= 4/3 of the chunk: the table neve
 // k-mer whatever else happens) fill the bucket's slice of `reps` from its start, the others from its end
 // backwards; nrep[2 * bucket], nrep[2 * bucket + 1] = how many of each.  Within a chunk both kinds are in
 // order of decreasing window count, so that the 64 records of a wave of the count need the same number of
-// steps, or nearly.  rep_of = a record's representative, as an index into the bucket's slice.
+// steps, or nearly.  rep_of = a record's representative (its place in `reps`).
 __global__ __launch_bounds__(SKD_THREADS) void sk_dedup_kernel(const SkRec* __restrict__ recs,
                                                                const uint64_t* __restrict__ bounds, uint32_t min_count,
                                                                SkRec* __restrict__ reps, uint16_t* __restrict__ mult,
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(SKD_THREADS) void sk_dedup_kernel(const SkRec* __re
 #pragma unroll
     for (int j = 0; j < SKD_PER; ++j) {
       const uint32_t q = uint32_t(j) * SKD_THREADS + threadIdx.x;
-      if (q < cn) rep_of[c0 + q] = s_dh[myslot[j]];
+      if (q < cn) rep_of[c0 + q] = uint32_t(lo) + s_dh[myslot[j]];  // (absolute: a count takes < 2^32 records)
     }
     base_full += s_full;
     base_other += s_other;
@@ -514,67 +514,67 @@ __global__ __launch_bounds__(SKD_THREADS) void sk_dedup_kernel(const SkRec* __re
 // partition moves along with it), org = the origins (read : first window) in that order.
 constexpr uint32_t kSkUnknown = 0x80000000u;
 constexpr int SKS_THREADS = 256;
-__global__ __launch_bounds__(SKS_THREADS) void sk_spread_kernel(const SkRec* __restrict__ recs,
-                                                                const uint64_t* __restrict__ bounds,
-                                                                const uint8_t* __restrict__ overflow,
+__global__ __launch_bounds__(SKS_THREADS) void sk_spread_kernel(const SkRec* __restrict__ recs, uint64_t n_rec,
+                                                                int bucket_bits, const uint8_t* __restrict__ overflow,
                                                                 const uint32_t* __restrict__ rep_of,
                                                                 const uint32_t* __restrict__ rep_bits,
                                                                 const uint32_t* __restrict__ idx,
                                                                 const uint64_t* __restrict__ org,
                                                                 unsigned long long* __restrict__ present, int pstride,
                                                                 uint32_t* __restrict__ bits_out) {
-  const uint32_t bucket = blockIdx.x;
-  const uint64_t lo = bounds[bucket], hi = bounds[bucket + 1];
-  const bool uncounted = overflow[bucket] != 0;  // block-uniform
-  // four records per thread and step: their look-ups (representative -> its bits; for the record in ten that has
-  // something to clear, index -> origin -> presence word) are four dependent chains in flight instead of one
-  for (uint64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * SKS_THREADS) {
-    uint32_t v[4], full[4];  // windows not known to be kept, all windows
+  // four records per thread: their look-ups (representative -> its bits; for the record in ten that has something
+  // to clear, index -> origin -> presence word) are four dependent chains in flight instead of one
+  const uint64_t i0 = uint64_t(blockIdx.x) * (4 * SKS_THREADS) + threadIdx.x;
+  uint32_t v[4], full[4];  // windows not known to be kept, all windows
+  bool uncounted[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint64_t i = i0 + uint64_t(u) * SKS_THREADS;
-      v[u] = 0;
-      if (i < hi) v[u] = uncounted ? 1u : rep_of[i];
-    }
+  for (int u = 0; u < 4; ++u) {
+    const uint64_t i = i0 + uint64_t(u) * SKS_THREADS;
+    v[u] = i < n_rec ? rep_of[i] : 0u;
+  }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint64_t i = i0 + uint64_t(u) * SKS_THREADS;
-      if (i >= hi) v[u] = 0;
-      else if (!uncounted) v[u] = rep_bits[lo + v[u]];
-    }
-    uint32_t at[4];
+  for (int u = 0; u < 4; ++u) {
+    const uint64_t i = i0 + uint64_t(u) * SKS_THREADS;
+    v[u] = i < n_rec ? rep_bits[v[u]] : 0u;
+  }
+  uint32_t at[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint64_t i = i0 + uint64_t(u) * SKS_THREADS;
-      at[u] = 0;
-      full[u] = 0;
-      if (v[u]) {  // (i < hi)
-        at[u] = idx[i];
-        if (bits_out || uncounted) {  // (a local record with windows to clear needs nothing of the record itself)
-          const int n = sk_windows(recs[i].b);
-          full[u] = n == 32 ? ~0u : (1u << n) - 1;
-          if (uncounted) v[u] = full[u];  // every window is to be looked up later
+  for (int u = 0; u < 4; ++u) {
+    const uint64_t i = i0 + uint64_t(u) * SKS_THREADS;
+    at[u] = 0;
+    full[u] = 0;
+    uncounted[u] = false;
+    if (v[u]) {  // (i < n_rec)
+      at[u] = idx[i];
+      if (bits_out || v[u] == kSkUnknown) {  // (a local record with windows to clear needs nothing of the record itself)
+        const uint64_t rb = recs[i].b;
+        const int n = sk_windows(rb);
+        full[u] = n == 32 ? ~0u : (1u << n) - 1;
+        // kSkUnknown marks the representatives of a bucket that was not counted — or is window 31 alone: ask the bucket
+        if (v[u] == kSkUnknown && overflow[sk_bucket(rb) >> (SK_BUCKET_FIELD - bucket_bits)]) {
+          uncounted[u] = true;
+          v[u] = full[u];  // every window is to be looked up later
         }
       }
     }
-    if (bits_out) {  // (they start as "every window kept": sk_part_scatter_kernel)
+  }
+  if (bits_out) {  // (they start as "every window kept": sk_part_scatter_kernel)
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (v[u]) bits_out[at[u]] = uncounted ? kSkUnknown : (full[u] & ~v[u]);
-      continue;
-    }
-    uint64_t o[4];
+    for (int u = 0; u < 4; ++u)
+      if (v[u]) bits_out[at[u]] = uncounted[u] ? kSkUnknown : (full[u] & ~v[u]);
+    return;
+  }
+  uint64_t o[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) o[u] = v[u] ? org[at[u]] : 0;  // the record's origin, read : first window
+  for (int u = 0; u < 4; ++u) o[u] = v[u] ? org[at[u]] : 0;  // the record's origin, read : first window
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (!v[u]) continue;
-      const uint64_t read = o[u] >> 8;
-      const int s0 = int(o[u] & 0xff), wi = s0 >> 6, sh = s0 & 63;
-      atomicAnd(&present[read * pstride + wi], ~((unsigned long long)v[u] << sh));
-      const unsigned long long over = sh ? (unsigned long long)v[u] >> (64 - sh) : 0ull;  // windows past the word
-      if (over) atomicAnd(&present[read * pstride + wi + 1], ~over);
-    }
+  for (int u = 0; u < 4; ++u) {
+    if (!v[u]) continue;
+    const uint64_t read = o[u] >> 8;
+    const int s0 = int(o[u] & 0xff), wi = s0 >> 6, sh = s0 & 63;
+    atomicAnd(&present[read * pstride + wi], ~((unsigned long long)v[u] << sh));
+    const unsigned long long over = sh ? (unsigned long long)v[u] >> (64 - sh) : 0ull;  // windows past the word
+    if (over) atomicAnd(&present[read * pstride + wi + 1], ~over);
   }
 }
 
@@ -1248,7 +1248,7 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
     BG_TRY(read_back());  // (also keeps `list` alive until the copy has been made)
   }
   ctx->tic("skm_spread");
-  sk_spread_kernel<<<NB, SKS_THREADS, 0, ctx->stream>>>(part, bounds.p, overflow.p, rep_of.p, rep_bits.p, part_idx, oin,
+  sk_spread_kernel<<<cdiv(R, 4 * SKS_THREADS), SKS_THREADS, 0, ctx->stream>>>(part, R, bucket_bits, overflow.p, rep_of.p, rep_bits.p, part_idx, oin,
                                                         reinterpret_cast<unsigned long long*>(ks->present.p),
                                                         ks->present_stride, bits_out);
   BG_LAUNCH_CHECK();
