@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict
   // (the wave's words number at most 64 reads x 255 records x 8 words: 32-bit arithmetic, and x / W as one
   // multiply-high with ceil(2^32 / W), exact for x < 2^32 / 8 — a 64-bit division per word was most of the kernel)
   const uint32_t nwords = uint32_t(r1 - r0) * uint32_t(W);
+  const uint32_t my_rel = live ? uint32_t(my_off - r0) : ~0u;  // (the wave's records number at most 64 x 255)
   const uint32_t rcp_w = W > 1 ? uint32_t((0x100000000ull + uint32_t(W) - 1) / uint32_t(W)) : 0u;
   for (uint32_t x0 = 0; x0 < nwords; x0 += 64) {
     const uint32_t x = x0 + uint32_t(lane);
@@ -182,17 +183,18 @@ __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict
     const uint64_t q = r0 + xq;
     const int w = int(x - xq * uint32_t(W));
     int lo = 0;  // last lane whose first record is <= q
+    // (offsets relative to the wave's first record, 32 bits: a shuffle of a 64-bit value is two)
 #pragma unroll
     for (int step = 32; step; step >>= 1) {
-      uint64_t v = __shfl(my_off, lo + step, 64);
-      if (v <= q) lo += step;
+      const uint32_t v = uint32_t(__shfl(int(my_rel), lo + step, 64));
+      if (v <= xq) lo += step;
     }
     // reads without records share their offset with the next read: the search lands on the last of them,
     // which is the one that owns the record
-    const uint64_t off = __shfl(my_off, lo, 64);
+    const uint32_t off = uint32_t(__shfl(int(my_rel), lo, 64));
     const int L = __shfl(my_len, lo, 64);
     if (x < nwords) {
-      const int j = int(q - off);
+      const int j = int(xq - off);
       const uint64_t* s = owords + (o_base + t0 + uint64_t(lo)) * uint64_t(W);
       const uint64_t word = window32(s, W, j + 32 * w);
       rec[q * uint64_t(W) + w] = word;
