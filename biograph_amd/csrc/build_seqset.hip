@@ -97,7 +97,7 @@ __global__ void k_cover_insert(const uint64_t* __restrict__ skeys, const uint32_
 // read with most lanes idle).
 constexpr int kCoverChunk = 1024;  // oriented reads per wave
 
-__global__ __launch_bounds__(256) void k_cover_count(CoverIndex ci, const uint64_t* __restrict__ owords,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cover_count(CoverIndex ci, const uint64_t* __restrict__ owords,
                                                      uint64_t o_base, uint64_t n_emit, int W,
                                                      uint32_t* __restrict__ cnt) {
   const int lane = threadIdx.x & 63;
@@ -105,9 +105,12 @@ __global__ __launch_bounds__(256) void k_cover_count(CoverIndex ci, const uint64
   const uint64_t wave = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
   uint64_t next = wave * kCoverChunk;
   const uint64_t end = next + kCoverChunk < n_emit ? next + kCoverChunk : n_emit;
+  // the lane's own read sits in LDS (rows of 9 words: 8 + one of padding against bank conflicts): every probe cuts
+  // its key out of it and the prefix check walks it, and from global memory those were half the kernel's requests
+  __shared__ uint64_t own[256 * (kMaxWords + 1)];
+  uint64_t* const s = own + threadIdx.x * (kMaxWords + 1);
   bool active = false;
   uint64_t t = 0;
-  const uint64_t* s = nullptr;
   int L = 0, j = 0, c = 0;
   for (;;) {
     const uint64_t need = __ballot(!active);
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void k_cover_count(CoverIndex ci, const uint64
           t = mine;
           const uint64_t o = o_base + t;
           L = ci.olen[o];
-          s = owords + o * uint64_t(W);
+          for (int w = 0; w < W; ++w) s[w] = owords[o * uint64_t(W) + w];
           j = 1;
           c = 1;
           if (L <= 1) cnt[t] = uint32_t(L);  // dropped read: nothing; one base: itself
