@@ -569,6 +569,10 @@ __global__ __launch_bounds__(64) void k_correct_dfs(const uint64_t* __restrict__
                                                     uint64_t* __restrict__ out_words, uint16_t* __restrict__ out_len,
                                                     CorrectCounters* __restrict__ ctr,
                                                     const uint64_t* __restrict__ present, int pstride) {
+  extern __shared__ uint64_t dfs_smem[];  // 64 rows of W + 1 words, 64 of 5 presence words, 64 of W + 1 N masks
+  uint64_t* const own_w = dfs_smem;
+  uint64_t* const own_p = own_w + 64 * (W + 1);
+  uint32_t* const own_n = reinterpret_cast<uint32_t*>(own_p + 64 * 5);
   uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   int clen = 0, ncorr = 0;
   if (t < nlist) {
@@ -577,9 +581,16 @@ __global__ __launch_bounds__(64) void k_correct_dfs(const uint64_t* __restrict__
     uint64_t i = list[t];
     KmerTable tab{slots, log2cap, k};
     int L = len[i];
+    // the read, its N masks and its presence words in LDS: the search fetches a base, a window, a presence bit at a
+    // time, and from global memory every one of those is a request of its own (rows padded against bank conflicts)
+    uint64_t* const my_w = own_w + threadIdx.x * (W + 1);
+    uint32_t* const my_n = own_n + threadIdx.x * (W + 1);
+    uint64_t* const my_p = own_p + threadIdx.x * 5;
+    for (int w = 0; w < W; ++w) { my_w[w] = words[i * W + w]; my_n[w] = nmask[i * W + w]; }
+    for (int w = 0; w < pstride && w < 4; ++w) my_p[w] = present[i * pstride + w];
     uint64_t ow[kMaxWords];
-    clen = frc_correct_read(tab, words + i * W, nmask + i * W, L, W, k, max_corrections, min_good_run,
-                            int(needed_by_len[L]), ow, &ncorr, present + i * pstride);
+    clen = frc_correct_read(tab, my_w, my_n, L, W, k, max_corrections, min_good_run,
+                            int(needed_by_len[L]), ow, &ncorr, my_p);
     for (int w = 0; w < W; ++w) out_words[i * W + w] = clen ? ow[w] : 0;
     out_len[i] = uint16_t(clen);
   }
@@ -1303,7 +1314,7 @@ extern "C" int bg_correct_reads(bg_ctx* ctx, const bg_reads* reads, const bg_kme
     BG_TRY(compact_flagged<uint64_t>(ctx, need.p, n, &list, &nlist));
     if (nlist) {
       ctx->tic("correct_dfs");
-      k_correct_dfs<<<cdiv(nlist, 64), 64, 0, ctx->stream>>>(
+      k_correct_dfs<<<cdiv(nlist, 64), 64, size_t(64) * ((W + 1) * 12 + 40), ctx->stream>>>(
           reads->words.p, reads->nmask.p, reads->len.p, list.p, nlist, W, k, ks->slots.p, ks->log2cap,
           int(params->max_corrections), int(params->min_good_run), d_needed.p, r->words.p, r->len.p, ctr.p,
           present, pstride);
