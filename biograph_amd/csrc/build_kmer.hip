@@ -1381,13 +1381,22 @@ __global__ __launch_bounds__(64) void k_correct_dfs_routed(const uint64_t* __res
   rt.n_new = 0;
   rt.missed = false;
   int ncorr = 0, clen = 0;
+  extern __shared__ uint64_t dfs_smem[];  // as in k_correct_dfs: the read, its presence words and its N masks
+  uint64_t* const own_w = dfs_smem;
+  uint64_t* const own_p = own_w + 64 * (W + 1);
+  uint32_t* const own_n = reinterpret_cast<uint32_t*>(own_p + 64 * 5);
   if (valid) {
     const uint64_t i = list[slot];
     rt.head = head[slot];
     const int L = len[i];
+    uint64_t* const my_w = own_w + threadIdx.x * (W + 1);
+    uint32_t* const my_n = own_n + threadIdx.x * (W + 1);
+    uint64_t* const my_p = own_p + threadIdx.x * 5;
+    for (int w = 0; w < W; ++w) { my_w[w] = words[i * W + w]; my_n[w] = nmask[i * W + w]; }
+    for (int w = 0; w < pstride && w < 4; ++w) my_p[w] = present[i * pstride + w];
     uint64_t ow[kMaxWords];
-    clen = frc_correct_read(rt, words + i * W, nmask + i * W, L, W, k, max_corrections, min_good_run,
-                            int(needed_by_len[L]), ow, &ncorr, present + i * pstride);
+    clen = frc_correct_read(rt, my_w, my_n, L, W, k, max_corrections, min_good_run,
+                            int(needed_by_len[L]), ow, &ncorr, my_p);
     if (!rt.missed) {
       for (int w = 0; w < W; ++w) out_words[i * W + w] = clen ? ow[w] : 0;
       out_len[i] = uint16_t(clen);
@@ -1589,7 +1598,7 @@ extern "C" int bg_corr_step(bg_ctx* ctx, bg_correction* c, uint64_t* n_pending_o
   unsigned long long h_cur = c->pool_used;
   BG_HIP(hipMemcpyAsync(cursor.p, &h_cur, 8, hipMemcpyHostToDevice, ctx->stream));
   ctx->tic("correct_dfs");
-  k_correct_dfs_routed<<<cdiv(c->n_pend, 64), 64, 0, ctx->stream>>>(
+  k_correct_dfs_routed<<<cdiv(c->n_pend, 64), 64, size_t(64) * ((W + 1) * 12 + 40), ctx->stream>>>(
       reads->words.p, reads->nmask.p, reads->len.p, c->list.p, c->pend.p, c->n_pend, W, k, int(c->prm.max_corrections),
       int(c->prm.min_good_run), c->needed.p, c->out->words.p, c->out->len.p, c->ctr.p, c->present.p, c->pstride, c->pool.p,
       c->head.p, cursor.p, c->pool_used, c->desc_slot.p, still.p);
