@@ -900,11 +900,19 @@ __global__ __launch_bounds__(256) void k_prev_bits_pre2(const uint64_t* __restri
   uint64_t i = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t* s = ekeys + i * W;
-  const int b = int(s[0] >> 62);
   const int tl = int(sizes[i]) - 1;
+  // the key one base on: every word of the key is fetched once (window32 per word fetched each twice, and these
+  // look-ups are bound by the number of requests)
+  uint64_t key[kMaxWords + 1];
+#pragma unroll
+  for (int w = 0; w < kMaxWords; ++w) key[w] = w < W ? s[w] : 0;
+  key[kMaxWords] = 0;
+  const int b = int(key[0] >> 62);
   uint64_t tail[kMaxWords];
-  for (int w = 0; w < W; ++w) tail[w] = window32(s, W, 1 + 32 * w);
+#pragma unroll
+  for (int w = 0; w < kMaxWords; ++w) tail[w] = (key[w] << 2) | (key[w + 1] >> 62);
   uint64_t lo;
+  // (fetching only the three words the two-word search needs and the rest on demand: 5.6 -> 6.4 ms)
   if (!prev_target_pre2(ekeys, pre2, sizes, n, W, dir, bases, tail, tl, verify, err, &lo)) return;
   marks[uint64_t(b) * marks_stride(n) + lo] = 1;
 }
