@@ -289,9 +289,10 @@ int cover_index_build(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, 
 int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss, bool slice = false);  // bitcount finalize + min index + fixed
 int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t hi, int cover_k,
                         DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out,
-                        DevBuf<uint64_t>* k0 = nullptr);  // k0: also the sort keys of the records (optional)
+                        DevBuf<uint64_t>* k0 = nullptr, int RS = 0);  // k0: also the sort keys of the records (optional)
+                        // RS = words from one record row to the next (0: W; W + 1: a row ends with the record's length)
 int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t>& rlen, uint64_t n_rec, int W,
-                              bg_seqset* ss, uint64_t* n_tied_out, DevBuf<uint64_t>* k0 = nullptr);
+                              bg_seqset* ss, uint64_t* n_tied_out, DevBuf<uint64_t>* k0 = nullptr, int RS = 0);
 // leading-bases directory over sorted W-word keys (*bases = 8..13 chosen from n): dir[p] = first key with
 // prefix >= p, dir[4^bases] = n
 int build_prefix_dir_keys(bg_ctx* ctx, const uint64_t* keys, uint64_t n, int W, DevBuf<uint32_t>* dir, int* bases);

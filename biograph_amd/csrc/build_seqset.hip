@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict
                                                       const uint16_t* __restrict__ len,
                                                       const uint32_t* __restrict__ cnt,
                                                       const uint64_t* __restrict__ roff, uint64_t o_base,
-                                                      uint64_t n_emit, int W, uint64_t* __restrict__ rec,
+                                                      uint64_t n_emit, int W, int RS, uint64_t* __restrict__ rec,
                                                       uint8_t* __restrict__ rlen, uint64_t* __restrict__ k0) {
   const int lane = threadIdx.x & 63;
   const uint64_t t0 = (uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 64;
@@ -177,14 +177,16 @@ __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict
   }
   // (the wave's words number at most 64 reads x 255 records x 8 words: 32-bit arithmetic, and x / W as one
   // multiply-high with ceil(2^32 / W), exact for x < 2^32 / 8 — a 64-bit division per word was most of the kernel)
-  const uint32_t nwords = uint32_t(r1 - r0) * uint32_t(W);
+  // RS words per row: the W key words and, when RS = W + 1, the record's length behind them (k_gather_dedup_build gets
+  // it with the row instead of through a request of its own)
+  const uint32_t nwords = uint32_t(r1 - r0) * uint32_t(RS);
   const uint32_t my_rel = live ? uint32_t(my_off - r0) : ~0u;  // (the wave's records number at most 64 x 255)
-  const uint32_t rcp_w = W > 1 ? uint32_t((0x100000000ull + uint32_t(W) - 1) / uint32_t(W)) : 0u;
+  const uint32_t rcp_w = RS > 1 ? uint32_t((0x100000000ull + uint32_t(RS) - 1) / uint32_t(RS)) : 0u;
   for (uint32_t x0 = 0; x0 < nwords; x0 += 64) {
     const uint32_t x = x0 + uint32_t(lane);
-    const uint32_t xq = W > 1 ? __umulhi(x, rcp_w) : x;
+    const uint32_t xq = RS > 1 ? __umulhi(x, rcp_w) : x;
     const uint64_t q = r0 + xq;
-    const int w = int(x - xq * uint32_t(W));
+    const int w = int(x - xq * uint32_t(RS));
     int lo = 0;  // last lane whose first record is <= q
     // (offsets relative to the wave's first record, 32 bits: a shuffle of a 64-bit value is two)
 #pragma unroll
@@ -199,8 +201,8 @@ __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict
     if (x < nwords) {
       const int j = int(xq - off);
       const uint64_t* s = owords + (o_base + t0 + uint64_t(lo)) * uint64_t(W);
-      const uint64_t word = window32(s, W, j + 32 * w);
-      rec[q * uint64_t(W) + w] = word;
+      const uint64_t word = w < W ? window32(s, W, j + 32 * w) : uint64_t(L - j);
+      rec[q * uint64_t(RS) + w] = word;
       if (w == 0) {
         rlen[q] = uint8_t(L - j);
         if (k0) k0[q] = (word & ~((1ull << kSortSkipBits) - 1)) | q;  // the sort key (k_first_words), for free
@@ -213,10 +215,10 @@ __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict
 // half — a keys-only sort on bits 32..63 (4 radix passes moving 8 bytes per record instead of 5-8 passes
 // moving 12).  Records that agree on their leading 16 bases are almost always suffixes at the same genome
 // position, which the tie handling orders by full-key compares anyway.
-__global__ void k_first_words(const uint64_t* __restrict__ rec, uint64_t n, int W, uint64_t* __restrict__ k0) {
+__global__ void k_first_words(const uint64_t* __restrict__ rec, uint64_t n, int RS, uint64_t* __restrict__ k0) {
   uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r >= n) return;
-  k0[r] = (rec[r * W] & ~((1ull << kSortSkipBits) - 1)) | r;
+  k0[r] = (rec[r * RS] & ~((1ull << kSortSkipBits) - 1)) | r;
 }
 
 
@@ -232,9 +234,10 @@ constexpr int kSmallGroup = 32;
 // also splits them, i.e. writes sidx for every position.
 __global__ __launch_bounds__(256) void k_sort_small_groups(const uint64_t* __restrict__ skeys, uint64_t n,
                                                            const uint64_t* __restrict__ rec,
-                                                           const uint8_t* __restrict__ rlen, int W,
+                                                           const uint8_t* __restrict__ rlen, int W, int RS,
                                                            uint32_t* __restrict__ sidx, uint8_t* __restrict__ flags) {
   uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  auto len_of = [&](uint32_t r) { return RS > W ? int(rec[uint64_t(r) * RS + W]) : int(rlen[r]); };
   if (i < n) {
     const uint64_t kv = skeys[i];
     const uint32_t k = uint32_t(kv >> kSortSkipBits);
@@ -256,10 +259,10 @@ __global__ __launch_bounds__(256) void k_sort_small_groups(const uint64_t* __res
           for (int a = 0; a < g; ++a) idx[a] = uint32_t(skeys[s + a]);
           for (int a = 1; a < g; ++a) {
             uint32_t x = idx[a];
-            const uint64_t* xk = rec + uint64_t(x) * W;
-            int xl = rlen[x];
+            const uint64_t* xk = rec + uint64_t(x) * RS;
+            int xl = len_of(x);
             int b = a - 1;
-            while (b >= 0 && key_compare_by_three(rec + uint64_t(idx[b]) * W, rlen[idx[b]], xk, xl, W) > 0) {
+            while (b >= 0 && key_compare_by_three(rec + uint64_t(idx[b]) * RS, len_of(idx[b]), xk, xl, W) > 0) {
               idx[b + 1] = idx[b];
               --b;
             }
@@ -294,7 +297,7 @@ __global__ void k_tied_run_heads(const uint32_t* __restrict__ tpos, const uint64
 __global__ __launch_bounds__(1024) void k_sort_medium_groups(const uint32_t* __restrict__ hpos, uint64_t G, uint64_t T,
                                                              const uint32_t* __restrict__ tpos,
                                                              const uint64_t* __restrict__ rec,
-                                                             const uint8_t* __restrict__ rlen, int W,
+                                                             const uint8_t* __restrict__ rlen, int W, int RS,
                                                              uint32_t* __restrict__ sidx, uint8_t* __restrict__ still,
                                                              uint32_t min_size, uint32_t cap, int check_equal) {
   extern __shared__ uint64_t mg_smem[];
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(1024) void k_sort_medium_groups(const uint32_t* __r
       for (uint32_t i = tid; i < size && !d; i += nt) {
         const uint32_t r = sidx[p0 + i];
         d = rlen[r] != rlen[r0];
-        for (int w = 0; w < W && !d; ++w) d = rec[uint64_t(r) * W + w] != rec[uint64_t(r0) * W + w];
+        for (int w = 0; w < W && !d; ++w) d = rec[uint64_t(r) * RS + w] != rec[uint64_t(r0) * RS + w];
       }
       if (d) s_differ = 1;
       __syncthreads();
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(1024) void k_sort_medium_groups(const uint32_t* __r
   __syncthreads();
   for (uint32_t x = tid; x < size * uint32_t(W); x += nt) {
     const uint32_t i = x / uint32_t(W), w = x - i * uint32_t(W);
-    skey[x] = rec[uint64_t(sid[i]) * W + w];
+    skey[x] = rec[uint64_t(sid[i]) * RS + w];
   }
   __syncthreads();
   for (uint32_t k2 = 2; k2 <= P; k2 <<= 1) {
@@ -406,11 +409,11 @@ __global__ void k_iota_u32(uint32_t* __restrict__ dst, uint64_t n) {
 // next-round key of subset element t: word `w` of its record (or the length when w == W)
 __global__ void k_round_keys(const uint64_t* __restrict__ rec, const uint8_t* __restrict__ rlen,
                              const uint32_t* __restrict__ sidx, const uint32_t* __restrict__ tpos, uint64_t T, int W,
-                             int w, uint64_t* __restrict__ key) {
+                             int RS, int w, uint64_t* __restrict__ key) {
   uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= T) return;
   uint32_t r = sidx[tpos[t]];
-  key[t] = (w < W) ? rec[uint64_t(r) * W + w] : uint64_t(rlen[r]);
+  key[t] = (w < W) ? rec[uint64_t(r) * RS + w] : uint64_t(rlen[r]);
 }
 
 __global__ void k_u32_to_u64(const uint32_t* __restrict__ src, uint64_t n, uint64_t* __restrict__ dst) {
@@ -446,7 +449,7 @@ __global__ void k_flag_subset_ties(const uint32_t* __restrict__ gid, const uint6
 constexpr int kGatherTile = 256;
 __global__ __launch_bounds__(kGatherTile) void k_gather_lcp_keep(
     const uint64_t* __restrict__ rec, const uint8_t* __restrict__ rlen, const uint32_t* __restrict__ sidx, uint64_t n,
-    int W, uint64_t* __restrict__ skeys, uint8_t* __restrict__ slen, uint8_t* __restrict__ lcp_prev,
+    int W, int RS, uint64_t* __restrict__ skeys, uint8_t* __restrict__ slen, uint8_t* __restrict__ lcp_prev,
     uint8_t* __restrict__ keep, uint32_t* __restrict__ err) {
   extern __shared__ uint64_t tile[];  // (kGatherTile + 2) * W words, then the lengths
   uint8_t* tlen = reinterpret_cast<uint8_t*>(tile + (kGatherTile + 2) * W);
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_lcp_keep(
     uint64_t pos = b0 + uint64_t(i) - 1;  // wraps for the missing predecessor of position 0
     if (pos < n) {
       uint32_t r = sidx[pos];
-      uint64_t v = rec[uint64_t(r) * W + w];
+      uint64_t v = rec[uint64_t(r) * RS + w];
       tile[g] = v;
       bool own = i >= 1 && i <= kGatherTile;
       if (own) skeys[pos * W + w] = v;
@@ -498,7 +501,7 @@ constexpr int kFusedTile = kGatherTile * kFusedPos;    // positions per tile: tw
                                                        // half the look-backs of a 256-position tile
 __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
     const uint64_t* __restrict__ rec, const uint8_t* __restrict__ rlen, const uint32_t* __restrict__ sidx, uint64_t n,
-    int W, unsigned long long* __restrict__ state, uint32_t* __restrict__ ticket, uint64_t* __restrict__ ekeys,
+    int W, int RS, unsigned long long* __restrict__ state, uint32_t* __restrict__ ticket, uint64_t* __restrict__ ekeys,
     uint8_t* __restrict__ sizes, uint8_t* __restrict__ shared, uint64_t* __restrict__ pre2,
     uint64_t* __restrict__ tile_first, uint32_t* __restrict__ err) {
   extern __shared__ uint64_t tile[];  // (kFusedTile + 2) * W words, then lengths, per-position lcp, keep flags
@@ -523,30 +526,36 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
     uint32_t r = 0xffffffffu;
     if (pos < n) {
       r = sidx[pos];
-      tlen[i] = rlen[r];
+      if (RS == W) tlen[i] = rlen[r];  // (RS = W + 1: the length comes with the row, below)
     }
     tidx[i] = r;
   }
   __syncthreads();
   {
-    const uint32_t rcp = (65536u + uint32_t(W) - 1) / uint32_t(W);  // g / W = (g * rcp) >> 16 for g < 9000, W <= 8
-    const int total = (kFusedTile + 2) * W;
-    constexpr int kIters = ((kFusedTile + 2) * kMaxWords + kGatherTile - 1) / kGatherTile;
+    // RS words of every row: its W key words and, when RS = W + 1, its length (a request of its own otherwise: the
+    // lengths' lines were a third of what the kernel fetched)
+    const uint32_t rcp = (65536u + uint32_t(RS) - 1) / uint32_t(RS);  // g / RS = (g * rcp) >> 16 for g < 9000, RS <= 9
+    const int total = (kFusedTile + 2) * RS;
+    constexpr int kIters = ((kFusedTile + 2) * (kMaxWords + 1) + kGatherTile - 1) / kGatherTile;
     uint64_t v[kIters];
 #pragma unroll
     for (int it = 0; it < kIters; ++it) {
       const int g = tid + it * kGatherTile;
       v[it] = 0;
       if (g < total) {
-        const int i = int((uint32_t(g) * rcp) >> 16), w = g - i * W;
+        const int i = int((uint32_t(g) * rcp) >> 16), w = g - i * RS;
         const uint32_t r = tidx[i];
-        if (r != 0xffffffffu) v[it] = rec[uint64_t(r) * W + w];
+        if (r != 0xffffffffu) v[it] = rec[uint64_t(r) * RS + w];
       }
     }
 #pragma unroll
     for (int it = 0; it < kIters; ++it) {
       const int g = tid + it * kGatherTile;
-      if (g < total) tile[g] = v[it];
+      if (g < total) {
+        const int i = int((uint32_t(g) * rcp) >> 16), w = g - i * RS;
+        if (w < W) tile[i * W + w] = v[it];
+        else tlen[i] = uint8_t(v[it]);
+      }
     }
   }
   __syncthreads();
@@ -1064,7 +1073,7 @@ int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss, bool slice) {
 namespace bg {
 
 int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p, uint64_t n_rec, int W,
-                      DevBuf<uint64_t>* k0, DevBuf<uint32_t>* sidx_out, uint64_t* n_tied_out);
+                      DevBuf<uint64_t>* k0, DevBuf<uint32_t>* sidx_out, uint64_t* n_tied_out, int RS = 0);
 
 // Cover index over n_o oriented reads (owords: n_o x W zero-padded words, olen: their lengths).  The reads are
 // sorted by their full key (the machinery of the record sort): reads with the same first K-mer are then
@@ -1118,7 +1127,8 @@ int cover_index_build(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, 
 // Phase A: suffix records of reads [lo, hi) under the exact-cover rule; the cover index spans ALL
 // reads of `reads`.
 int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t hi, int cover_k,
-                        DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out, DevBuf<uint64_t>* k0) {
+                        DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out, DevBuf<uint64_t>* k0, int RS) {
+  if (RS <= 0) RS = reads->W;
   const uint64_t n = reads->n;
   const uint64_t n_o = 2 * n;
   const int W = reads->W;
@@ -1159,16 +1169,16 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   BG_TRY(exclusive_scan_u32_to_u64(ctx, cnt.p, roff.p, n_emit, total.p));
   BG_HIP(hipMemcpyAsync(&n_rec, total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
-  BG_TRY(rec->alloc(ctx, n_rec * W));
+  BG_TRY(rec->alloc(ctx, n_rec * RS));
   BG_TRY(rlen->alloc(ctx, n_rec));
   const bool want_k0 = k0 && n_rec < (1ull << 32);
   if (want_k0) BG_TRY(k0->alloc(ctx, n_rec));
   if (n_rec) {
     ctx->tic("suffix_emit");
     k_emit_records<<<cdiv(cdiv(n_emit, 64), 4), 256, 0, ctx->stream>>>(owords.p, reads->len.p, cnt.p, roff.p, o_base, n_emit, W,
-                                                               rec->p, rlen->p, want_k0 ? k0->p : nullptr);
+                                                               RS, rec->p, rlen->p, want_k0 ? k0->p : nullptr);
     BG_LAUNCH_CHECK();
-    ctx->toc(n_emit * W * 8 + n_rec * (W * 8 + 1 + (want_k0 ? 8 : 0)));
+    ctx->toc(n_emit * W * 8 + n_rec * (RS * 8 + 1 + (want_k0 ? 8 : 0)));
   }
   *n_rec_out = n_rec;
   return BG_OK;
@@ -1178,7 +1188,8 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
 // The n_keys sort keys are (leading 16 bases | record), taken from *k0 when it holds them (consumed), else made
 // from rec rows 0 .. n_keys-1.  *n_tied_out = records in tie groups larger than kSmallGroup.
 int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p, uint64_t n_rec, int W,
-                      DevBuf<uint64_t>* k0, DevBuf<uint32_t>* sidx_out, uint64_t* n_tied_out) {
+                      DevBuf<uint64_t>* k0, DevBuf<uint32_t>* sidx_out, uint64_t* n_tied_out, int RS) {
+  if (RS <= 0) RS = W;  // words from one row to the next (W + 1: the length sits behind the key words as well)
   struct { const uint64_t* p; } rec{rec_p};
   struct { const uint8_t* p; } rlen{rlen_p};
   DevBuf<uint32_t>& sidx = *sidx_out;
@@ -1191,7 +1202,7 @@ int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p,
     } else {
       BG_TRY(k0a.alloc(ctx, n_rec));
       if (n_rec) {
-        k_first_words<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(rec.p, n_rec, W, k0a.p);
+        k_first_words<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(rec.p, n_rec, RS, k0a.p);
         BG_LAUNCH_CHECK();
       }
     }
@@ -1212,7 +1223,7 @@ int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p,
       BG_TRY(flags.alloc(ctx, n_rec));
       if (n_rec) {
         ctx->tic("suffix_small_ties");
-        k_sort_small_groups<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(ks.p, n_rec, rec.p, rlen.p, W, sidx.p, flags.p);
+        k_sort_small_groups<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(ks.p, n_rec, rec.p, rlen.p, W, RS, sidx.p, flags.p);
         BG_LAUNCH_CHECK();
         ctx->toc(n_rec * 13);
       }
@@ -1248,13 +1259,13 @@ int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p,
       BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_medium_groups),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(group_smem(large ? large : kMediumGroup))));
       k_sort_medium_groups<<<unsigned(G), 256, group_smem(kMediumGroup), ctx->stream>>>(
-          hpos.p, G, T, tpos.p, rec.p, rlen.p, W, sidx.p, still.p, 0u, uint32_t(kMediumGroup), 0);
+          hpos.p, G, T, tpos.p, rec.p, rlen.p, W, RS, sidx.p, still.p, 0u, uint32_t(kMediumGroup), 0);
       BG_LAUNCH_CHECK();
       ctx->toc(T * (uint64_t(W) * 8 + 9));
       BG_TRY(compact_flagged<uint32_t>(ctx, still.p, T, &keep_t, &T2));
       if (T2 && large && !getenv("BG_NO_LARGE_GROUPS")) {
         k_sort_medium_groups<<<unsigned(G), 1024, group_smem(large), ctx->stream>>>(
-            hpos.p, G, T, tpos.p, rec.p, rlen.p, W, sidx.p, still.p, uint32_t(kMediumGroup), large, 1);
+            hpos.p, G, T, tpos.p, rec.p, rlen.p, W, RS, sidx.p, still.p, uint32_t(kMediumGroup), large, 1);
         BG_LAUNCH_CHECK();
         BG_TRY(compact_flagged<uint32_t>(ctx, still.p, T, &keep_t, &T2));
       }
@@ -1298,7 +1309,7 @@ int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p,
     BG_TRY(va.alloc(ctx, T));
     BG_TRY(vb.alloc(ctx, T));
     BG_TRY(rec_of_t.alloc(ctx, T));
-    k_round_keys<<<cdiv(T, 256), 256, 0, ctx->stream>>>(rec.p, rlen.p, sidx.p, tpos.p, T, W, w, ka.p);
+    k_round_keys<<<cdiv(T, 256), 256, 0, ctx->stream>>>(rec.p, rlen.p, sidx.p, tpos.p, T, W, RS, w, ka.p);
     BG_LAUNCH_CHECK();
     k_gather_u32_by_u32<<<cdiv(T, 256), 256, 0, ctx->stream>>>(sidx.p, tpos.p, T, rec_of_t.p);
     BG_LAUNCH_CHECK();
@@ -1328,7 +1339,7 @@ int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p,
     k_apply_perm<<<cdiv(T, 256), 256, 0, ctx->stream>>>(perm, tpos.p, rec_of_t.p, T, sidx.p);
     BG_LAUNCH_CHECK();
     // keys in new order: re-read from the records through the updated sidx
-    k_round_keys<<<cdiv(T, 256), 256, 0, ctx->stream>>>(rec.p, rlen.p, sidx.p, tpos.p, T, W, w, k1o);
+    k_round_keys<<<cdiv(T, 256), 256, 0, ctx->stream>>>(rec.p, rlen.p, sidx.p, tpos.p, T, W, RS, w, k1o);
     BG_LAUNCH_CHECK();
     // gid in new order (as u32)
     DevBuf<uint32_t> gnew;
@@ -1372,14 +1383,15 @@ int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p,
 // Phase B: sort the records, drop prefixes/duplicates, build keys/sizes/shared of the surviving
 // entries into `ss`.  Consumes rec/rlen.
 int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t>& rlen, uint64_t n_rec, int W,
-                              bg_seqset* ss, uint64_t* n_tied_out, DevBuf<uint64_t>* k0) {
+                              bg_seqset* ss, uint64_t* n_tied_out, DevBuf<uint64_t>* k0, int RS) {
+  if (RS <= 0) RS = W;
   if (n_rec >= (1ull << 32)) {
     set_error("%llu suffix records exceed one shard", (unsigned long long)n_rec);
     return BG_EINVAL;
   }
   uint64_t n_tied = 0, n_ent = 0;
   DevBuf<uint32_t> sidx;  // sorted order -> record
-  BG_TRY(sort_records_impl(ctx, rec.p, rlen.p, n_rec, W, k0, &sidx, &n_tied));
+  BG_TRY(sort_records_impl(ctx, rec.p, rlen.p, n_rec, W, k0, &sidx, &n_tied, RS));
 
   // ---- dedup + entries
   DevBuf<uint32_t> err;
@@ -1404,7 +1416,7 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
       BG_HIP(hipMemsetAsync(ticket.p, 0, 4, ctx->stream));
       ctx->tic("entries_dedup_build");
       const size_t lds = size_t(kFusedTile + 2) * W * 8 + (kFusedTile + 2) + 2 * kFusedTile;
-      k_gather_dedup_build<<<unsigned(ntiles), kGatherTile, lds, ctx->stream>>>(rec.p, rlen.p, sidx.p, n_rec, W, state.p,
+      k_gather_dedup_build<<<unsigned(ntiles), kGatherTile, lds, ctx->stream>>>(rec.p, rlen.p, sidx.p, n_rec, W, RS, state.p,
                                                                              ticket.p, ss->keys.p, ss->sizes.p, ss->shared.p,
                                                                              ss->pre2.p, tile_first.p, err.p);
       BG_LAUNCH_CHECK();
@@ -1430,7 +1442,7 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
     if (n_rec) {
       ctx->tic("entries_dedup");
       const size_t lds = size_t(kGatherTile + 2) * W * 8 + kGatherTile + 2;
-      k_gather_lcp_keep<<<cdiv(n_rec, kGatherTile), kGatherTile, lds, ctx->stream>>>(rec.p, rlen.p, sidx.p, n_rec, W, skeys.p,
+      k_gather_lcp_keep<<<cdiv(n_rec, kGatherTile), kGatherTile, lds, ctx->stream>>>(rec.p, rlen.p, sidx.p, n_rec, W, RS, skeys.p,
                                                                                   slen.p, lcp_prev.p, keep.p, err.p);
       BG_LAUNCH_CHECK();
       ctx->toc(n_rec * (W * 8 * 2 + 8));
@@ -1652,8 +1664,9 @@ extern "C" int bg_seqset_build(bg_ctx* ctx, const bg_reads* reads, int cover_k, 
   DevBuf<uint64_t> rec;
   DevBuf<uint8_t> rlen;
   DevBuf<uint64_t> k0;
-  BG_TRY(suffix_records_impl(ctx, reads, 0, reads->n, cover_k, &rec, &rlen, &n_rec, &k0));
-  BG_TRY(entries_from_records_impl(ctx, rec, rlen, n_rec, reads->W, ss.get(), &n_tied, &k0));
+  // (rows of W + 1 words: every record carries its length behind its key words)
+  BG_TRY(suffix_records_impl(ctx, reads, 0, reads->n, cover_k, &rec, &rlen, &n_rec, &k0, reads->W + 1));
+  BG_TRY(entries_from_records_impl(ctx, rec, rlen, n_rec, reads->W, ss.get(), &n_tied, &k0, reads->W + 1));
   BG_TRY(prev_bits_local_impl(ctx, ss.get()));
   // the longest read is never a proper prefix of anything longer, so it survives as an entry
   ss->max_len = ss->n ? reads->max_len : 0;
