@@ -221,8 +221,9 @@ struct bg_records {
   bg_ctx* ctx = nullptr;
   uint64_t n = 0;
   int W = 0;
-  bg::DevBuf<uint64_t> rec;   // n*W zero-padded key words
-  bg::DevBuf<uint8_t> rlen;   // n
+  int RS = 0;                 // words from one row of rec to the next: 0 = W; W + 1 = the length sits behind the key words
+  bg::DevBuf<uint64_t> rec;   // n rows of zero-padded key words
+  bg::DevBuf<uint8_t> rlen;   // n (not used when RS = W + 1)
 };
 
 struct bg_readmap {

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict
       const uint64_t word = w < W ? window32(s, W, j + 32 * w) : uint64_t(L - j);
       rec[q * uint64_t(RS) + w] = word;
       if (w == 0) {
-        rlen[q] = uint8_t(L - j);
+        if (rlen) rlen[q] = uint8_t(L - j);
         if (k0) k0[q] = (word & ~((1ull << kSortSkipBits) - 1)) | q;  // the sort key (k_first_words), for free
       }
     }
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void k_sort_small_groups(const uint64_t* __res
                                                            const uint8_t* __restrict__ rlen, int W, int RS,
                                                            uint32_t* __restrict__ sidx, uint8_t* __restrict__ flags) {
   uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  auto len_of = [&](uint32_t r) { return RS > W ? int(rec[uint64_t(r) * RS + W]) : int(rlen[r]); };
+  auto len_of = [&](uint32_t r) { return RS > W ? int(rec[uint64_t(r) * RS + W] & 0xff) : int(rlen[r]); };
   if (i < n) {
     const uint64_t kv = skeys[i];
     const uint32_t k = uint32_t(kv >> kSortSkipBits);
@@ -310,6 +310,7 @@ __global__ __launch_bounds__(1024) void k_sort_medium_groups(const uint32_t* __r
   const uint32_t t1 = g + 1 < G ? hpos[g + 1] : uint32_t(T);
   const uint32_t size = t1 - t0;
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  auto len_of = [&](uint32_t r) { return RS > W ? uint8_t(rec[uint64_t(r) * RS + W]) : rlen[r]; };
   if (size <= min_size) return;  // block-uniform; done by an earlier launch
   const uint32_t p0 = tpos[t0];  // the group occupies sorted positions p0 .. p0 + size
   if (size > cap) {  // block-uniform
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(1024) void k_sort_medium_groups(const uint32_t* __r
       bool d = false;
       for (uint32_t i = tid; i < size && !d; i += nt) {
         const uint32_t r = sidx[p0 + i];
-        d = rlen[r] != rlen[r0];
+        d = len_of(r) != len_of(r0);
         for (int w = 0; w < W && !d; ++w) d = rec[uint64_t(r) * RS + w] != rec[uint64_t(r0) * RS + w];
       }
       if (d) s_differ = 1;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(1024) void k_sort_medium_groups(const uint32_t* __r
   for (uint32_t i = tid; i < size; i += nt) {
     const uint32_t r = sidx[p0 + i];
     sid[i] = r;
-    slen[i] = rlen[r];
+    slen[i] = len_of(r);
     still[t0 + i] = 0;
   }
   for (uint32_t i = tid; i < P; i += nt) perm[i] = i < size ? uint16_t(i) : uint16_t(0xffff);
@@ -413,7 +414,7 @@ __global__ void k_round_keys(const uint64_t* __restrict__ rec, const uint8_t* __
   uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= T) return;
   uint32_t r = sidx[tpos[t]];
-  key[t] = (w < W) ? rec[uint64_t(r) * RS + w] : uint64_t(rlen[r]);
+  key[t] = (w < W) ? rec[uint64_t(r) * RS + w] : uint64_t(RS > W ? uint8_t(rec[uint64_t(r) * RS + W]) : rlen[r]);
 }
 
 __global__ void k_u32_to_u64(const uint32_t* __restrict__ src, uint64_t n, uint64_t* __restrict__ dst) {
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_lcp_keep(
       bool own = i >= 1 && i <= kGatherTile;
       if (own) skeys[pos * W + w] = v;
       if (w == 0) {
-        uint8_t l = rlen[r];
+        uint8_t l = RS > W ? uint8_t(rec[uint64_t(r) * RS + W]) : rlen[r];
         tlen[i] = l;
         if (own) slen[pos] = l;
       }
@@ -1170,13 +1171,13 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   BG_HIP(hipMemcpyAsync(&n_rec, total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
   BG_TRY(rec->alloc(ctx, n_rec * RS));
-  BG_TRY(rlen->alloc(ctx, n_rec));
+  if (RS == W) BG_TRY(rlen->alloc(ctx, n_rec));  // (rows of W + 1 words carry the lengths themselves)
   const bool want_k0 = k0 && n_rec < (1ull << 32);
   if (want_k0) BG_TRY(k0->alloc(ctx, n_rec));
   if (n_rec) {
     ctx->tic("suffix_emit");
     k_emit_records<<<cdiv(cdiv(n_emit, 64), 4), 256, 0, ctx->stream>>>(owords.p, reads->len.p, cnt.p, roff.p, o_base, n_emit, W,
-                                                               RS, rec->p, rlen->p, want_k0 ? k0->p : nullptr);
+                                                               RS, rec->p, RS == W ? rlen->p : nullptr, want_k0 ? k0->p : nullptr);
     BG_LAUNCH_CHECK();
     ctx->toc(n_emit * W * 8 + n_rec * (RS * 8 + 1 + (want_k0 ? 8 : 0)));
   }

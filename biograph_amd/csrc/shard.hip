@@ -942,7 +942,9 @@ extern "C" void bg_records_free(bg_records* r) { delete r; }
 extern "C" int bg_records_rows(bg_ctx* ctx, const bg_records* r, uint64_t* d_rows) {
   if (!ctx || !r || (r->n && !d_rows)) { set_error("bg_records_rows: null argument"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));
-  if (r->n) {
+  if (r->n && r->RS == r->W + 1) {  // records that came as rows are rows
+    BG_HIP(hipMemcpyAsync(d_rows, r->rec.p, r->n * uint64_t(r->W + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  } else if (r->n) {
     k_records_to_rows<<<cdiv(r->n * (r->W + 1), 256), 256, 0, ctx->stream>>>(r->rec.p, r->rlen.p, r->n, r->W, d_rows);
     BG_LAUNCH_CHECK();
   }
@@ -967,7 +969,7 @@ extern "C" int bg_records_prefix_hist(bg_ctx* ctx, const bg_records* r, int base
   BG_HIP(hipMemsetAsync(d_hist, 0, (size_t(1) << (2 * bases)) * 8, ctx->stream));
   if (r->n) {
     k_records_prefix_hist<<<cdiv(cdiv(r->n, every), 256), 256, 0, ctx->stream>>>(
-        r->rec.p, r->n, r->W, bases, every, reinterpret_cast<unsigned long long*>(d_hist));
+        r->rec.p, r->n, r->RS ? r->RS : r->W, bases, every, reinterpret_cast<unsigned long long*>(d_hist));  // (row stride)
     BG_LAUNCH_CHECK();
   }
   BG_HIP(hipStreamSynchronize(ctx->stream));
@@ -982,12 +984,10 @@ extern "C" int bg_records_from_rows(bg_ctx* ctx, const uint64_t* d_rows, uint64_
   r->ctx = ctx;
   r->n = n;
   r->W = W;
-  BG_TRY(r->rec.alloc(ctx, n * W));
-  BG_TRY(r->rlen.alloc(ctx, n));
-  if (n) {
-    k_rows_to_records<<<cdiv(n * (W + 1), 256), 256, 0, ctx->stream>>>(d_rows, n, W, r->rec.p, r->rlen.p);
-    BG_LAUNCH_CHECK();
-  }
+  // the rows ARE the records (W key words, then the length): one copy, no split into words and lengths
+  r->RS = W + 1;
+  BG_TRY(r->rec.alloc(ctx, n * (W + 1)));
+  if (n) BG_HIP(hipMemcpyAsync(r->rec.p, d_rows, n * (W + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
   *out = r.release();
   return BG_OK;
@@ -1004,15 +1004,14 @@ extern "C" int bg_records_from_row_parts(bg_ctx* ctx, uint32_t n_parts, const ui
   r->ctx = ctx;
   r->n = n;
   r->W = W;
-  BG_TRY(r->rec.alloc(ctx, n * W));
-  BG_TRY(r->rlen.alloc(ctx, n));
+  r->RS = W + 1;  // the rows are the records (see bg_records_from_rows)
+  BG_TRY(r->rec.alloc(ctx, n * (W + 1)));
   uint64_t off = 0;
   for (uint32_t p = 0; p < n_parts; ++p) {
     const uint64_t m = h_counts[p];
     if (!m) continue;
     if (!d_rows[p]) { set_error("bg_records_from_row_parts: null part"); return BG_EINVAL; }
-    k_rows_to_records<<<cdiv(m * (W + 1), 256), 256, 0, ctx->stream>>>(d_rows[p], m, W, r->rec.p + off * W, r->rlen.p + off);
-    BG_LAUNCH_CHECK();
+    BG_HIP(hipMemcpyAsync(r->rec.p + off * (W + 1), d_rows[p], m * (W + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
     off += m;
   }
   BG_HIP(hipStreamSynchronize(ctx->stream));
@@ -1029,7 +1028,7 @@ extern "C" int bg_entries_from_records(bg_ctx* ctx, bg_records* rec, bg_seqset**
   ss->W = rec->W;
   ss->uuid = make_uuid();
   uint64_t n_rec = rec->n, n_tied = 0;
-  BG_TRY(entries_from_records_impl(ctx, rec->rec, rec->rlen, n_rec, rec->W, ss.get(), &n_tied));
+  BG_TRY(entries_from_records_impl(ctx, rec->rec, rec->rlen, n_rec, rec->W, ss.get(), &n_tied, nullptr, rec->RS));
   rec->n = 0;
   if (stats) { stats->n_records = n_rec; stats->n_tied_records = n_tied; stats->n_entries = ss->n; }
   *out = ss.release();
