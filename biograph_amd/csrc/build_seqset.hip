@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_co
   }
 }
 
-// records: rec[r*W + w] (zero padded words), rlen[r]
+// records: rows of RS words, rec[r*RS + w] = zero padded key words (w < W) and, when RS = W + 1, the length in word W;
+// rlen[r] = the length as a byte when the rows do not carry it (RS = W)
 // One wave expands 64 oriented reads: its records are contiguous in the output, so the lanes walk the
 // output WORDS (lane = consecutive word), find the read a word belongs to by a 6-step search over the
 // 64 record offsets held one per lane, and write fully coalesced — instead of one lane looping over all
