@@ -231,51 +231,99 @@ __global__ void k_first_words(const uint64_t* __restrict__ rec, uint64_t n, int 
 // one lane with full-key comparisons (insertion sort on record ids; the keys are gathered from the
 // record store).  Only larger groups are flagged for the word-by-word radix rounds below.
 constexpr int kSmallGroup = 32;
+constexpr int kSmallHalo = kSmallGroup + 1;  // how far a member looks for the ends of its group
+constexpr int kSmallSlots = 256 + kSmallGroup;  // a group headed in a workgroup ends before its position 256 + 32
 // skeys = the sorted packed keys (leading bases in the high half, record index in the low half): this kernel
 // also splits them, i.e. writes sidx for every position.
+// A workgroup stages the leading halves of its 256 positions (+ a halo) and their record indices in LDS, finds the
+// groups there, and then every MEMBER fetches its own row into LDS — one round trip for all the rows of the
+// workgroup — before the heads order their groups without touching global memory again; sidx goes out as one
+// coalesced store per position.  (A head that compared rows in global memory paid a dependent round trip per
+// compare, and one per step of the end search and per index before that: the kernel was 4.8 ms of latency.)
+// Dynamic LDS: kSmallSlots rows of W + 1 words (the last one = the record's length).
 __global__ __launch_bounds__(256) void k_sort_small_groups(const uint64_t* __restrict__ skeys, uint64_t n,
                                                            const uint64_t* __restrict__ rec,
                                                            const uint8_t* __restrict__ rlen, int W, int RS,
-                                                           uint32_t* __restrict__ sidx, uint8_t* __restrict__ flags) {
-  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  auto len_of = [&](uint32_t r) { return RS > W ? int(rec[uint64_t(r) * RS + W] & 0xff) : int(rlen[r]); };
+                                                           uint32_t* __restrict__ sidx, uint8_t* __restrict__ flags,
+                                                           int defer) {
+  extern __shared__ uint64_t s_rows[];
+  __shared__ uint32_t s_hi[256 + 2 * kSmallHalo];  // positions b0 - kSmallHalo ...
+  __shared__ uint32_t s_idx[kSmallSlots];          // positions b0 ...
+  __shared__ uint16_t s_slot[kSmallSlots];         // position -> whose index ends up there
+  __shared__ uint32_t s_tail;                      // positions past the workgroup's own that its last group holds
+  const int tid = threadIdx.x;
+  const int LW = W + 1;
+  const uint64_t b0 = uint64_t(blockIdx.x) * 256;
+  if (tid == 0) s_tail = 0;
+  for (int t = tid; t < 256 + 2 * kSmallHalo; t += 256) {
+    const uint64_t p = b0 + uint64_t(t) - uint64_t(kSmallHalo);  // (wraps before position 0: not < n)
+    const int q = t - kSmallHalo;
+    const bool slot = q >= 0 && q < kSmallSlots;
+    if (slot) s_slot[q] = uint16_t(q);
+    if (p < n) {
+      const uint64_t kv = skeys[p];
+      s_hi[t] = uint32_t(kv >> kSortSkipBits);
+      if (slot) s_idx[q] = uint32_t(kv);
+    }
+  }
+  __syncthreads();
+  auto hi = [&](uint64_t p) { return s_hi[int(int64_t(p) - int64_t(b0)) + kSmallHalo]; };
+  auto fetch_row = [&](int q) {
+    const uint32_t r = s_idx[q];
+    const uint64_t* src = rec + uint64_t(r) * RS;
+    uint64_t* dst = s_rows + q * LW;
+    for (int w = 0; w < W; ++w) dst[w] = src[w];
+    dst[W] = RS > W ? (src[W] & 0xff) : uint64_t(rlen[r]);
+  };
+  const uint64_t i = b0 + uint64_t(tid);
+  uint8_t big = 0;
+  bool small_member = false;
+  uint64_t s = i, e = i + 1;
   if (i < n) {
-    const uint64_t kv = skeys[i];
-    const uint32_t k = uint32_t(kv >> kSortSkipBits);
-    auto hi = [&](uint64_t p) { return uint32_t(skeys[p] >> kSortSkipBits); };
-    bool tied = (i > 0 && hi(i - 1) == k) || (i + 1 < n && hi(i + 1) == k);
-    uint8_t big = 0;
-    bool small_member = false;
+    const uint32_t k = hi(i);
+    const bool tied = (i > 0 && hi(i - 1) == k) || (i + 1 < n && hi(i + 1) == k);
     if (tied) {
-      uint64_t s = i, e = i + 1;
       while (s > 0 && i - s <= uint64_t(kSmallGroup) && hi(s - 1) == k) --s;
       while (e < n && e - s <= uint64_t(kSmallGroup) && hi(e) == k) ++e;
-      if (e - s > uint64_t(kSmallGroup)) {
-        big = 1;
-      } else {
-        small_member = true;
-        if (s == i) {  // head of a small group: sort its members
-          int g = int(e - s);
-          uint32_t idx[kSmallGroup];
-          for (int a = 0; a < g; ++a) idx[a] = uint32_t(skeys[s + a]);
-          for (int a = 1; a < g; ++a) {
-            uint32_t x = idx[a];
-            const uint64_t* xk = rec + uint64_t(x) * RS;
-            int xl = len_of(x);
-            int b = a - 1;
-            while (b >= 0 && key_compare_by_three(rec + uint64_t(idx[b]) * RS, len_of(idx[b]), xk, xl, W) > 0) {
-              idx[b + 1] = idx[b];
-              --b;
-            }
-            idx[b + 1] = x;
-          }
-          for (int a = 0; a < g; ++a) sidx[s + a] = idx[a];
-        }
-      }
+      if (e - s > uint64_t(kSmallGroup)) big = 1;
+      else small_member = true;
     }
-    if (!small_member) sidx[i] = uint32_t(kv);  // members of small groups are written by their head
+  }
+  // (a group whose head sits in the previous workgroup is that one's; defer: the small groups are left as they are
+  // for k_gather_dedup_build, which has every row in LDS anyway and orders them there)
+  const bool mine = !defer && small_member && s >= b0;
+  if (mine) {
+    fetch_row(tid);
+    if (s == i && e > b0 + 256) s_tail = uint32_t(e - (b0 + 256));  // (one group at most reaches past the end)
+  }
+  __syncthreads();
+  const uint32_t tail = s_tail;
+  if (uint32_t(tid) < tail) fetch_row(256 + tid);
+  __syncthreads();
+  if (mine && s == i) {  // head of a small group: insertion sort of its members' places
+    const int g = int(e - s);
+    uint16_t* sl = s_slot + tid;
+    for (int a = 1; a < g; ++a) {
+      const uint16_t xs = sl[a];
+      const uint64_t* xk = s_rows + int(xs) * LW;
+      const int xl = int(xk[W]);
+      int b = a - 1;
+      while (b >= 0) {
+        const uint16_t ys = sl[b];
+        const uint64_t* yk = s_rows + int(ys) * LW;
+        if (key_compare(yk, int(yk[W]), xk, xl, W) <= 0) break;
+        sl[b + 1] = ys;
+        --b;
+      }
+      sl[b + 1] = xs;
+    }
+  }
+  __syncthreads();
+  if (i < n) {
+    if (defer || !(small_member && s < b0)) sidx[i] = s_idx[s_slot[tid]];
     flags[i] = big;
   }
+  if (uint32_t(tid) < tail) sidx[b0 + 256 + uint64_t(tid)] = s_idx[s_slot[256 + tid]];
 }
 
 // Medium tie groups (kSmallGroup < size <= kMediumGroup): one workgroup per group stages the group's keys in
@@ -501,17 +549,29 @@ constexpr uint64_t kScanAgg = 1ull << 62, kScanIncl = 2ull << 62, kScanVal = (1u
 constexpr int kFusedPos = 2;                           // sorted positions per thread
 constexpr int kFusedTile = kGatherTile * kFusedPos;    // positions per tile: twice the data in flight per wave and
                                                        // half the look-backs of a 256-position tile
+// sort_small: the tie groups of at most kSmallGroup records come unordered (k_sort_small_groups, defer) and are put
+// in order here, in LDS — every row is fetched for the gather anyway, and ordering them beforehand fetched more than
+// half of them a first time (3.5 ms).  A tile then brings a halo of kFusedHalo positions on each side instead of
+// one: a small group that touches the tile's own positions or their two neighbours lies wholly inside it, a group
+// with more than kSmallGroup members in sight is a big one (in order already), and what the halo shows of a group
+// that does not reach the tile's positions may be ordered or not — it is not used.  A group that straddles two tiles
+// is ordered by both, alike.
+constexpr int kFusedHalo = kSmallGroup + 2;
+constexpr int kFusedSlots = kFusedTile + 2 * kFusedHalo;
 __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
     const uint64_t* __restrict__ rec, const uint8_t* __restrict__ rlen, const uint32_t* __restrict__ sidx, uint64_t n,
     int W, int RS, unsigned long long* __restrict__ state, uint32_t* __restrict__ ticket, uint64_t* __restrict__ ekeys,
     uint8_t* __restrict__ sizes, uint8_t* __restrict__ shared, uint64_t* __restrict__ pre2,
-    uint64_t* __restrict__ tile_first, uint32_t* __restrict__ err) {
-  extern __shared__ uint64_t tile[];  // (kFusedTile + 2) * W words, then lengths, per-position lcp, keep flags
-  uint8_t* tlen = reinterpret_cast<uint8_t*>(tile + (kFusedTile + 2) * W);
-  uint8_t* tlcp = tlen + kFusedTile + 2;
+    uint64_t* __restrict__ tile_first, uint32_t* __restrict__ err, int sort_small) {
+  const int H = sort_small ? kFusedHalo : 1;  // slot i of the tile = sorted position b0 + i - H
+  const int NS = kFusedTile + 2 * H;
+  extern __shared__ uint64_t tile[];  // NS * W words, then lengths, per-position lcp, keep flags
+  uint8_t* tlen = reinterpret_cast<uint8_t*>(tile + NS * W);
+  uint8_t* tlcp = tlen + NS;
   uint8_t* tkeep = tlcp + kFusedTile;
-  __shared__ uint32_t tidx[kFusedTile + 2];
-  __shared__ uint16_t tsrc[kFusedTile];  // survivor rank -> position in the tile
+  __shared__ uint32_t tidx[kFusedSlots];
+  __shared__ uint16_t pmap[kFusedSlots];
+  __shared__ uint16_t tsrc[kFusedTile];  // survivor rank -> slot of its row
   __shared__ uint8_t tsh[kFusedTile];    // survivor rank -> shared
   __shared__ uint32_t s_tile, s_wave[kFusedTile / 64];
   __shared__ unsigned long long s_excl;
@@ -523,8 +583,8 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
   // record of every position of the tile (+ halo) first, so that the word loads below are independent of
   // each other and all in flight at once (a dependent sidx -> rec chain per word made a tile ten memory
   // round trips long)
-  for (int i = tid; i < kFusedTile + 2; i += kGatherTile) {
-    const uint64_t pos = b0 + uint64_t(i) - 1;  // wraps for the missing predecessor of position 0
+  for (int i = tid; i < NS; i += kGatherTile) {
+    const uint64_t pos = b0 + uint64_t(i) - uint64_t(H);  // wraps for the missing predecessors of position 0
     uint32_t r = 0xffffffffu;
     if (pos < n) {
       r = sidx[pos];
@@ -537,8 +597,8 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
     // RS words of every row: its W key words and, when RS = W + 1, its length (a request of its own otherwise: the
     // lengths' lines were a third of what the kernel fetched)
     const uint32_t rcp = (65536u + uint32_t(RS) - 1) / uint32_t(RS);  // g / RS = (g * rcp) >> 16 for g < 9000, RS <= 9
-    const int total = (kFusedTile + 2) * RS;
-    constexpr int kIters = ((kFusedTile + 2) * (kMaxWords + 1) + kGatherTile - 1) / kGatherTile;
+    const int total = NS * RS;
+    constexpr int kIters = (kFusedSlots * (kMaxWords + 1) + kGatherTile - 1) / kGatherTile;
     uint64_t v[kIters];
 #pragma unroll
     for (int it = 0; it < kIters; ++it) {
@@ -561,6 +621,49 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
     }
   }
   __syncthreads();
+  // pmap[i] = the slot whose row belongs at slot i.  Every member of a small group finds its rank in the group by
+  // comparing its row with the others' (all members at once, a few LDS reads each: one lane per group moving rows
+  // about made the kernel 5 ms longer); the rows stay where they are.
+  for (int j = tid; j < NS; j += kGatherTile) {
+    int at = j;
+    if (sort_small && tidx[j] != 0xffffffffu) {
+      const uint32_t k = uint32_t(tile[j * W] >> kSortSkipBits);
+      auto same = [&](int q) {
+        return q >= 0 && q < NS && tidx[q] != 0xffffffffu && uint32_t(tile[q * W] >> kSortSkipBits) == k;
+      };
+      if (same(j - 1) || same(j + 1)) {
+        int s = j, e = j + 1;
+        while (j - s <= kSmallGroup && same(s - 1)) --s;
+        while (e - s <= kSmallGroup && same(e)) ++e;
+        if (e - s <= kSmallGroup) {
+          uint64_t xr[kMaxWords];
+#pragma unroll
+          for (int w = 0; w < kMaxWords; ++w) xr[w] = w < W ? tile[j * W + w] : 0;
+          const int xl = tlen[j];
+          int rank = 0;
+          for (int q = s; q < e; ++q) {
+            if (q == j) continue;
+            const uint64_t* y = tile + q * W;
+            int c = 0;  // row q against this one
+#pragma unroll
+            for (int w = 0; w < kMaxWords; ++w)
+              if (w < W && !c) {
+                const uint64_t yw = y[w];
+                if (yw != xr[w]) c = yw < xr[w] ? -1 : 1;
+              }
+            if (!c) {
+              const int yl = tlen[q];
+              c = yl < xl ? -1 : (yl > xl ? 1 : 0);
+            }
+            if (c < 0 || (c == 0 && q < j)) ++rank;
+          }
+          at = s + rank;
+        }
+      }
+    }
+    pmap[at] = uint16_t(j);
+  }
+  __syncthreads();
   // position p of the tile = thread (p % 256), slice (p / 256)
   bool keep[kFusedPos];
   uint64_t km[kFusedPos];
@@ -568,18 +671,19 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
   for (int sl = 0; sl < kFusedPos; ++sl) {
     const int p = sl * kGatherTile + tid;
     const uint64_t pos = b0 + p;
-    const uint64_t* a = tile + (p + 1) * W;
-    const int alen = tlen[p + 1];
+    const int sp = pmap[p + H], sprev = pmap[p + H - 1], snext = pmap[p + H + 1];
+    const uint64_t* a = tile + sp * W;
+    const int alen = tlen[sp];
     keep[sl] = false;
     if (pos < n) {
       int lp = 0;
       if (pos > 0) {
-        lp = key_lcp(a - W, tlen[p], a, alen, W);
-        if (key_compare(a - W, tlen[p], a, alen, W) > 0) atomicOr(err, 1u);  // not sorted
+        lp = key_lcp(tile + sprev * W, tlen[sprev], a, alen, W);
+        if (key_compare(tile + sprev * W, tlen[sprev], a, alen, W) > 0) atomicOr(err, 1u);  // not sorted
       }
       tlcp[p] = uint8_t(lp);
       // a record that is a prefix of (or equal to) its successor is dropped (expand.cpp:19-48 skip_dups)
-      keep[sl] = !(pos + 1 < n && key_lcp(a, alen, a + W, tlen[p + 2], W) == alen);
+      keep[sl] = !(pos + 1 < n && key_lcp(a, alen, tile + snext * W, tlen[snext], W) == alen);
     }
     tkeep[p] = keep[sl] ? 1 : 0;
     km[sl] = __ballot(keep[sl]);
@@ -643,7 +747,7 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
   for (int sl = 0; sl < kFusedPos; ++sl) {
     if (keep[sl]) {
       const int p = sl * kGatherTile + tid;
-      tsrc[before[sl]] = uint16_t(p);
+      tsrc[before[sl]] = pmap[p + H];
       int sh = 0;
       if (before[sl]) {  // min lcp over the dropped run back to the previous survivor (which is in this tile)
         sh = tlcp[p];
@@ -660,14 +764,14 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
   const uint32_t rcpw = (65536u + uint32_t(W) - 1) / uint32_t(W);
   for (uint32_t x = tid; x < count * uint32_t(W); x += kGatherTile) {
     const uint32_t slot = (x * rcpw) >> 16, w = x - slot * uint32_t(W);
-    ekeys[e0 * W + x] = tile[(uint32_t(tsrc[slot]) + 1) * W + w];
+    ekeys[e0 * W + x] = tile[uint32_t(tsrc[slot]) * W + w];
   }
   for (uint32_t x = tid; x < count * 2; x += kGatherTile) {
     const uint32_t slot = x >> 1, w = x & 1;
-    pre2[e0 * 2 + x] = int(w) < W ? tile[(uint32_t(tsrc[slot]) + 1) * W + w] : 0ull;
+    pre2[e0 * 2 + x] = int(w) < W ? tile[uint32_t(tsrc[slot]) * W + w] : 0ull;
   }
   for (uint32_t x = tid; x < count; x += kGatherTile) {
-    sizes[e0 + x] = tlen[uint32_t(tsrc[x]) + 1];
+    sizes[e0 + x] = tlen[uint32_t(tsrc[x])];
     shared[e0 + x] = tsh[x];
   }
 }
@@ -1075,7 +1179,8 @@ int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss, bool slice) {
 namespace bg {
 
 int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p, uint64_t n_rec, int W,
-                      DevBuf<uint64_t>* k0, DevBuf<uint32_t>* sidx_out, uint64_t* n_tied_out, int RS = 0);
+                      DevBuf<uint64_t>* k0, DevBuf<uint32_t>* sidx_out, uint64_t* n_tied_out, int RS = 0,
+                      bool defer_small = false);
 
 // Cover index over n_o oriented reads (owords: n_o x W zero-padded words, olen: their lengths).  The reads are
 // sorted by their full key (the machinery of the record sort): reads with the same first K-mer are then
@@ -1189,8 +1294,10 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
 // Order of records by full key (words, length): sidx[i] = record (row of rec / rlen) at sorted position i.
 // The n_keys sort keys are (leading 16 bases | record), taken from *k0 when it holds them (consumed), else made
 // from rec rows 0 .. n_keys-1.  *n_tied_out = records in tie groups larger than kSmallGroup.
+// defer_small: the tie groups of at most kSmallGroup records are left in the order the radix sort gave them (the
+// caller's k_gather_dedup_build orders them in LDS).
 int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p, uint64_t n_rec, int W,
-                      DevBuf<uint64_t>* k0, DevBuf<uint32_t>* sidx_out, uint64_t* n_tied_out, int RS) {
+                      DevBuf<uint64_t>* k0, DevBuf<uint32_t>* sidx_out, uint64_t* n_tied_out, int RS, bool defer_small) {
   if (RS <= 0) RS = W;  // words from one row to the next (W + 1: the length sits behind the key words as well)
   struct { const uint64_t* p; } rec{rec_p};
   struct { const uint8_t* p; } rlen{rlen_p};
@@ -1225,7 +1332,8 @@ int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p,
       BG_TRY(flags.alloc(ctx, n_rec));
       if (n_rec) {
         ctx->tic("suffix_small_ties");
-        k_sort_small_groups<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(ks.p, n_rec, rec.p, rlen.p, W, RS, sidx.p, flags.p);
+        k_sort_small_groups<<<cdiv(n_rec, 256), 256, size_t(kSmallSlots) * (W + 1) * 8, ctx->stream>>>(ks.p, n_rec, rec.p, rlen.p, W, RS, sidx.p, flags.p,
+                                                                                                        defer_small ? 1 : 0);
         BG_LAUNCH_CHECK();
         ctx->toc(n_rec * 13);
       }
@@ -1393,13 +1501,16 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
   }
   uint64_t n_tied = 0, n_ent = 0;
   DevBuf<uint32_t> sidx;  // sorted order -> record
-  BG_TRY(sort_records_impl(ctx, rec.p, rlen.p, n_rec, W, k0, &sidx, &n_tied, RS));
+  // (the fused pass below orders the small tie groups itself; BG_SMALL_TIES_EARLY: as before, for comparisons)
+  const bool fused = !getenv("BG_ENTRIES_UNFUSED");
+  const bool defer_small = fused && !getenv("BG_SMALL_TIES_EARLY");
+  BG_TRY(sort_records_impl(ctx, rec.p, rlen.p, n_rec, W, k0, &sidx, &n_tied, RS, defer_small));
 
   // ---- dedup + entries
   DevBuf<uint32_t> err;
   BG_TRY(err.alloc(ctx, 2));
   BG_HIP(hipMemsetAsync(err.p, 0, 8, ctx->stream));
-  if (!getenv("BG_ENTRIES_UNFUSED")) {
+  if (fused) {
     // one pass: gather + dedup + entry build (the arrays are sized for n_rec entries, ~10 % more than survive)
     ss->W = W;
     BG_TRY(ss->keys.alloc(ctx, n_rec * W));
@@ -1417,10 +1528,12 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
       BG_HIP(hipMemsetAsync(state.p, 0, ntiles * 8, ctx->stream));
       BG_HIP(hipMemsetAsync(ticket.p, 0, 4, ctx->stream));
       ctx->tic("entries_dedup_build");
-      const size_t lds = size_t(kFusedTile + 2) * W * 8 + (kFusedTile + 2) + 2 * kFusedTile;
+      const size_t slots = size_t(kFusedTile) + 2 * (defer_small ? kFusedHalo : 1);
+      const size_t lds = slots * W * 8 + slots + 2 * kFusedTile;
       k_gather_dedup_build<<<unsigned(ntiles), kGatherTile, lds, ctx->stream>>>(rec.p, rlen.p, sidx.p, n_rec, W, RS, state.p,
                                                                              ticket.p, ss->keys.p, ss->sizes.p, ss->shared.p,
-                                                                             ss->pre2.p, tile_first.p, err.p);
+                                                                             ss->pre2.p, tile_first.p, err.p,
+                                                                             defer_small ? 1 : 0);
       BG_LAUNCH_CHECK();
       k_fix_tile_first_shared<<<cdiv(ntiles, 256), 256, 0, ctx->stream>>>(tile_first.p, ntiles, ss->keys.p, ss->sizes.p, W,
                                                                           ss->shared.p);
