@@ -112,11 +112,13 @@ def test_seqset_build_matches_oracle(ctx, seed, alphabet, K, rl, var):
     assert st["n_entries"] == ss.size() and st["n_records"] >= st["n_entries"]
 
 
-@pytest.mark.parametrize("env", [{"BG_VERIFY_CLOSURE": "1"}, {"BG_PREV_FULL_SEARCH": "1"}, {"BG_NO_MEDIUM_GROUPS": "1"}])
+@pytest.mark.parametrize("env", [{"BG_VERIFY_CLOSURE": "1"}, {"BG_PREV_FULL_SEARCH": "1"}, {"BG_NO_MEDIUM_GROUPS": "1"},
+                                 {"BG_SMALL_TIES_EARLY": "1"}, {"BG_ENTRIES_UNFUSED": "1"}])
 @pytest.mark.parametrize("seed,alphabet,rl", [(11, "ACGT", 150), (12, "AC", 200), (13, "AT", 255)])
 def test_seqset_build_search_modes(ctx, monkeypatch, env, seed, alphabet, rl):
     """The prev-bit search on two-word prefixes re-checked against the full-key search (BG_VERIFY_CLOSURE),
-    the full-key search alone, and the tie handling without the medium-group kernel: same seqset."""
+    the full-key search alone, the tie handling without the medium-group kernel, the small tie groups ordered by
+    k_sort_small_groups instead of inside the entry build's tile, and the unfused entry build: same seqset."""
     for a, b in env.items():
         monkeypatch.setenv(a, b)
     reads = util.synth_reads(seed, genome_len=2500, n_reads=700, read_len=rl, err=0.01, n_rate=0.0,
@@ -144,6 +146,27 @@ def test_seqset_build_big_tie_groups(ctx, monkeypatch, env):
     order = rng.permutation(len(reads))
     reads = [reads[i] for i in order]
     ss, _ = ctx.build_seqset(ctx.pack_reads(reads), 12)
+    _check_seqset_against_oracle(ss, reads)
+
+
+@pytest.mark.parametrize("env", [{}, {"BG_SMALL_TIES_EARLY": "1"}])
+def test_seqset_build_tie_groups_around_the_small_limit(ctx, monkeypatch, env):
+    """Tie groups of 28 .. 37 records behind one 16-base prefix each (32 is the most the entry build's tile orders
+    itself; 33 and up go to the medium-group kernel), 300 of them and the smaller groups their shifted suffixes make, so
+    that groups of every size straddle the 512-position tiles of k_gather_dedup_build."""
+    for a, b in env.items():
+        monkeypatch.setenv(a, b)
+    rng = np.random.default_rng(4242)
+    def rnd(n):
+        return "".join("ACGT"[int(x)] for x in rng.integers(0, 4, n))
+    reads = []
+    for g in range(300):
+        prefix = rnd(16)
+        for _ in range(28 + g % 10):
+            reads.append(prefix + rnd(int(rng.integers(4, 40))))
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    ss, _ = ctx.build_seqset(ctx.pack_reads(reads), 10)
     _check_seqset_against_oracle(ss, reads)
 
 

@@ -15,6 +15,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -o run -- py
 cd $ROOT
 python3 tools/prof_summary.py $OUT/${TAG}_stats $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_summary
 cp $(find $OUT/${TAG}_stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
+python3 tools/step_timeline.py $OUT/${TAG}_stats > $OUT/${TAG}_step_timeline.txt
+python3 tools/gap_report.py $OUT/${TAG}_stats > $OUT/${TAG}_gap_report.txt
 # raw traces are big: keep only the condensed files
 rm -rf $OUT/${TAG}_stats $OUT/${TAG}_fetch $OUT/${TAG}_write
 head -25 $OUT/${TAG}_summary.csv
