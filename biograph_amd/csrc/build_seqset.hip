@@ -147,10 +147,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_co
 
 // records: rows of RS words, rec[r*RS + w] = zero padded key words (w < W) and, when RS = W + 1, the length in word W;
 // rlen[r] = the length as a byte when the rows do not carry it (RS = W)
-// One wave expands 64 oriented reads: its records are contiguous in the output, so the lanes walk the
-// output WORDS (lane = consecutive word), find the read a word belongs to by a 6-step search over the
-// 64 record offsets held one per lane, and write fully coalesced — instead of one lane looping over all
-// the records of its read.
+// One wave expands 64 oriented reads: its records are contiguous in the output, so the lanes take the wave's
+// RECORDS in turn (lane = consecutive record), find the read a record belongs to by a 6-step search over the
+// 64 record offsets held one per lane, and the wave writes them out fully coalesced through LDS — instead of one
+// lane looping over all the records of its read.
 __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict__ owords,
                                                       const uint16_t* __restrict__ len,
                                                       const uint32_t* __restrict__ cnt,
@@ -176,19 +176,19 @@ __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict
     }
     r1 = e;
   }
-  // (the wave's words number at most 64 reads x 255 records x 8 words: 32-bit arithmetic, and x / W as one
-  // multiply-high with ceil(2^32 / W), exact for x < 2^32 / 8 — a 64-bit division per word was most of the kernel)
+  // A lane builds one record a round — the read it belongs to found by a 6-step search over the 64 record offsets
+  // held one per lane, its words cut out of the read — into the wave's LDS rows, which the wave then writes out as
+  // one run of consecutive words.  (Lanes walking the output words did the search and the division once per word:
+  // 3.3 ms for chr20's 154 M records.)
   // RS words per row: the W key words and, when RS = W + 1, the record's length behind them (k_gather_dedup_build gets
   // it with the row instead of through a request of its own)
-  const uint32_t nwords = uint32_t(r1 - r0) * uint32_t(RS);
-  const uint32_t my_rel = live ? uint32_t(my_off - r0) : ~0u;  // (the wave's records number at most 64 x 255)
-  const uint32_t rcp_w = RS > 1 ? uint32_t((0x100000000ull + uint32_t(RS) - 1) / uint32_t(RS)) : 0u;
-  for (uint32_t x0 = 0; x0 < nwords; x0 += 64) {
-    const uint32_t x = x0 + uint32_t(lane);
-    const uint32_t xq = RS > 1 ? __umulhi(x, rcp_w) : x;
-    const uint64_t q = r0 + xq;
-    const int w = int(x - xq * uint32_t(RS));
-    int lo = 0;  // last lane whose first record is <= q
+  extern __shared__ uint64_t s_emit[];  // 4 waves x 64 rows of RS words
+  uint64_t* const rows = s_emit + (threadIdx.x >> 6) * 64 * RS;
+  const uint32_t nrec = uint32_t(r1 - r0);                       // (at most 64 x 255)
+  const uint32_t my_rel = live ? uint32_t(my_off - r0) : ~0u;
+  for (uint32_t x0 = 0; x0 < nrec; x0 += 64) {
+    const uint32_t xq = x0 + uint32_t(lane);
+    int lo = 0;  // last lane whose first record is <= xq
     // (offsets relative to the wave's first record, 32 bits: a shuffle of a 64-bit value is two)
 #pragma unroll
     for (int step = 32; step; step >>= 1) {
@@ -199,16 +199,34 @@ __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict
     // which is the one that owns the record
     const uint32_t off = uint32_t(__shfl(int(my_rel), lo, 64));
     const int L = __shfl(my_len, lo, 64);
-    if (x < nwords) {
+    if (xq < nrec) {
       const int j = int(xq - off);
+      const uint64_t q = r0 + xq;
       const uint64_t* s = owords + (o_base + t0 + uint64_t(lo)) * uint64_t(W);
-      const uint64_t word = w < W ? window32(s, W, j + 32 * w) : uint64_t(L - j);
-      rec[q * uint64_t(RS) + w] = word;
-      if (w == 0) {
-        if (rlen) rlen[q] = uint8_t(L - j);
-        if (k0) k0[q] = (word & ~((1ull << kSortSkipBits) - 1)) | q;  // the sort key (k_first_words), for free
+      uint64_t* row = rows + lane * RS;
+      // the record's words = the read's from base j on: every word of the read is fetched once
+      const int sq = j >> 5, sr = j & 31;
+      uint64_t word0 = 0, cur = sq < W ? s[sq] : 0;
+      for (int w = 0; w < W; ++w) {
+        const uint64_t next = sq + w + 1 < W ? s[sq + w + 1] : 0;
+        const uint64_t word = sr ? (cur << (2 * sr)) | (next >> (64 - 2 * sr)) : cur;
+        row[w] = word;
+        if (w == 0) word0 = word;
+        cur = next;
       }
+      if (RS > W) row[W] = uint64_t(L - j);
+      if (rlen) rlen[q] = uint8_t(L - j);
+      if (k0) k0[q] = (word0 & ~((1ull << kSortSkipBits) - 1)) | q;  // the sort key (k_first_words), for free
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t cntw = (nrec - x0 < 64u ? nrec - x0 : 64u) * uint32_t(RS);
+    uint64_t* dst = rec + (r0 + x0) * uint64_t(RS);
+    for (uint32_t k = uint32_t(lane); k < cntw; k += 64) dst[k] = rows[k];  // (16-byte stores: 2.8 -> 3.0 ms)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -1282,7 +1300,7 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   if (want_k0) BG_TRY(k0->alloc(ctx, n_rec));
   if (n_rec) {
     ctx->tic("suffix_emit");
-    k_emit_records<<<cdiv(cdiv(n_emit, 64), 4), 256, 0, ctx->stream>>>(owords.p, reads->len.p, cnt.p, roff.p, o_base, n_emit, W,
+    k_emit_records<<<cdiv(cdiv(n_emit, 64), 4), 256, size_t(256) * RS * 8, ctx->stream>>>(owords.p, reads->len.p, cnt.p, roff.p, o_base, n_emit, W,
                                                                RS, rec->p, RS == W ? rlen->p : nullptr, want_k0 ? k0->p : nullptr);
     BG_LAUNCH_CHECK();
     ctx->toc(n_emit * W * 8 + n_rec * (RS * 8 + 1 + (want_k0 ? 8 : 0)));
