@@ -249,6 +249,7 @@ __global__ void k_first_words(const uint64_t* __restrict__ rec, uint64_t n, int 
 // one lane with full-key comparisons (insertion sort on record ids; the keys are gathered from the
 // record store).  Only larger groups are flagged for the word-by-word radix rounds below.
 constexpr int kSmallGroup = 32;
+constexpr int kTileGroup = 8;  // defer: groups up to this size are left to k_gather_dedup_build's tile
 constexpr int kSmallHalo = kSmallGroup + 1;  // how far a member looks for the ends of its group
 constexpr int kSmallSlots = 256 + kSmallGroup;  // a group headed in a workgroup ends before its position 256 + 32
 // skeys = the sorted packed keys (leading bases in the high half, record index in the low half): this kernel
@@ -307,9 +308,11 @@ __global__ __launch_bounds__(256) void k_sort_small_groups(const uint64_t* __res
       else small_member = true;
     }
   }
-  // (a group whose head sits in the previous workgroup is that one's; defer: the small groups are left as they are
-  // for k_gather_dedup_build, which has every row in LDS anyway and orders them there)
-  const bool mine = !defer && small_member && s >= b0;
+  // (a group whose head sits in the previous workgroup is that one's; defer: groups of at most kTileGroup records —
+  // nearly all of them: two or three reads' suffixes at one genome position — are left as they are for
+  // k_gather_dedup_build, which has every row in LDS anyway and orders them there)
+  const bool here = small_member && (!defer || e - s > uint64_t(kTileGroup));
+  const bool mine = here && s >= b0;
   if (mine) {
     fetch_row(tid);
     if (s == i && e > b0 + 256) s_tail = uint32_t(e - (b0 + 256));  // (one group at most reaches past the end)
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256) void k_sort_small_groups(const uint64_t* __res
   }
   __syncthreads();
   if (i < n) {
-    if (defer || !(small_member && s < b0)) sidx[i] = s_idx[s_slot[tid]];
+    if (!(here && s < b0)) sidx[i] = s_idx[s_slot[tid]];
     flags[i] = big;
   }
   if (uint32_t(tid) < tail) sidx[b0 + 256 + uint64_t(tid)] = s_idx[s_slot[256 + tid]];
@@ -567,14 +570,17 @@ constexpr uint64_t kScanAgg = 1ull << 62, kScanIncl = 2ull << 62, kScanVal = (1u
 constexpr int kFusedPos = 2;                           // sorted positions per thread
 constexpr int kFusedTile = kGatherTile * kFusedPos;    // positions per tile: twice the data in flight per wave and
                                                        // half the look-backs of a 256-position tile
-// sort_small: the tie groups of at most kSmallGroup records come unordered (k_sort_small_groups, defer) and are put
+// sort_small: the tie groups of at most kTileGroup records come unordered (k_sort_small_groups, defer) and are put
 // in order here, in LDS — every row is fetched for the gather anyway, and ordering them beforehand fetched more than
 // half of them a first time (3.5 ms).  A tile then brings a halo of kFusedHalo positions on each side instead of
-// one: a small group that touches the tile's own positions or their two neighbours lies wholly inside it, a group
-// with more than kSmallGroup members in sight is a big one (in order already), and what the halo shows of a group
-// that does not reach the tile's positions may be ordered or not — it is not used.  A group that straddles two tiles
-// is ordered by both, alike.
-constexpr int kFusedHalo = kSmallGroup + 2;
+// one: a group of at most kTileGroup records that touches the tile's own positions or their two neighbours lies
+// wholly inside it, a group with more members in sight is in order already (k_sort_small_groups up to kSmallGroup
+// records, the medium-group kernels beyond), and what the halo shows of a group that does not reach the tile's
+// positions may be ordered or not — it is not used.  A group that straddles two tiles is ordered by both, alike.
+// (kTileGroup = 8: groups of two or three are what a genome makes; bigger ones come from repeats, where ranking a
+// group of g costs every member g compares — with kTileGroup = kSmallGroup a repeat-heavy genome built 1.2 ms slower
+// than before — and a halo of 10 rows per side instead of 34 is 4 % more rows instead of 13 %.)
+constexpr int kFusedHalo = kTileGroup + 2;
 constexpr int kFusedSlots = kFusedTile + 2 * kFusedHalo;
 __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
     const uint64_t* __restrict__ rec, const uint8_t* __restrict__ rlen, const uint32_t* __restrict__ sidx, uint64_t n,
@@ -651,9 +657,9 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
       };
       if (same(j - 1) || same(j + 1)) {
         int s = j, e = j + 1;
-        while (j - s <= kSmallGroup && same(s - 1)) --s;
-        while (e - s <= kSmallGroup && same(e)) ++e;
-        if (e - s <= kSmallGroup) {
+        while (j - s <= kTileGroup && same(s - 1)) --s;
+        while (e - s <= kTileGroup && same(e)) ++e;
+        if (e - s <= kTileGroup) {
           uint64_t xr[kMaxWords];
 #pragma unroll
           for (int w = 0; w < kMaxWords; ++w) xr[w] = w < W ? tile[j * W + w] : 0;
