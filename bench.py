@@ -534,7 +534,7 @@ KERNEL_OF_FAMILY = {"radix_scatter_k": "rs_part_scatter_kernel",
 
 LIMITER_OF_FAMILY = {"skm_count_lds": "VALU issue (rolling canonical k-mer + LDS probe per window)",
                      "skm_generate": "VALU issue (minimiser of every window)",
-                     "entries_dedup_build": "random 128-byte lines (a 48-byte row drags 1.25 lines; a tile of 512 rows brings 68 more as halo for the "
+                     "entries_dedup_build": "random 128-byte lines (a 48-byte row drags 1.25 lines; a tile of 512 rows brings 20 more as halo for the "
                                             "tie groups it orders) + look-back latency",
                      "suffix_cover_count": "L1 -> L2 request rate (21 dependent probes per read)",
                      "radix_scatter_k": "hbm stream", "skm_part_scatter": "hbm stream", "suffix_emit": "hbm stream"}
