@@ -246,8 +246,9 @@ __global__ void k_first_words(const uint64_t* __restrict__ rec, uint64_t n, int 
 
 
 // Tie groups (runs of equal first word) of at most kSmallGroup records are ordered right here by
-// one lane with full-key comparisons (insertion sort on record ids; the keys are gathered from the
-// record store).  Only larger groups are flagged for the word-by-word radix rounds below.
+// one lane with full-key comparisons (insertion sort over the members' rows, fetched into LDS).  Only larger
+// groups are flagged for the workgroup-per-group kernels and the word-by-word radix rounds below.  With `defer`
+// (the entry build) the groups of at most kTileGroup records are not ordered here but in k_gather_dedup_build.
 constexpr int kSmallGroup = 32;
 constexpr int kTileGroup = 8;  // defer: groups up to this size are left to k_gather_dedup_build's tile
 constexpr int kSmallHalo = kSmallGroup + 1;  // how far a member looks for the ends of its group
