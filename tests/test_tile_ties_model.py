@@ -4,7 +4,8 @@ tile sees a window of its own positions plus a halo of K + 2 on each side, a mem
 each side for the ends of its group, a group with more than K members in sight is left alone (it arrives in order),
 the others are ranked; a tile only uses its own positions and their two neighbours.  What must hold: whatever the group
 sizes and wherever the tile edges fall, the positions every tile uses come out as in the full sort.  (No GPU: this pins
-the argument, tests/test_gpu_parity.py pins the kernel.)"""
+the argument, tests/test_gpu_parity.py pins the kernel.  The kernel's halo of K + 2 is generous: the model also holds
+with K and breaks with K - 1.)"""
 import random
 
 import pytest
