@@ -52,7 +52,7 @@ class CreateParams(C.Structure):
 
 # every symbol include/bgseq.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "bg_abi_version", "bg_last_error", "bg_ctx_create", "bg_ctx_create_own_stream", "bg_ctx_reserve", "bg_ctx_destroy", "bg_ctx_trim", "bg_ctx_timings",
+    "bg_abi_version", "bg_device_count", "bg_last_error", "bg_ctx_create", "bg_ctx_create_own_stream", "bg_ctx_reserve", "bg_ctx_destroy", "bg_ctx_trim", "bg_ctx_timings",
     "bg_ctx_set_profiling", "bg_pack_reads", "bg_pack_reads_host", "bg_reads_count", "bg_reads_total_bases",
     "bg_reads_max_len", "bg_reads_download", "bg_reads_free", "bg_kmer_count", "bg_kmerset_size",
     "bg_kmerset_distinct", "bg_kmerset_instances", "bg_kmerset_download", "bg_kmerset_free", "bg_correct_reads",
@@ -75,6 +75,10 @@ SYMBOLS = [
     "bg_ctx_memory", "bg_reference_open", "bg_reference_free", "bg_reference_size", "bg_reference_scaffold_count",
     "bg_reference_scaffold_name", "bg_reference_scaffold_len", "bg_reference_supercontig_count", "bg_reference_supercontig",
     "bg_reference_bases",
+    # communicator + N-rank create (csrc/comm.hip, csrc/sharded.hip)
+    "bg_comm_unique_id", "bg_comm_init", "bg_comm_free", "bg_comm_rank", "bg_comm_world", "bg_comm_get_stats", "bg_comm_all_to_all_v",
+    "bg_comm_exchange", "bg_comm_all_gather_host", "bg_comm_all_gather", "bg_comm_all_reduce_sum_u64", "bg_comm_barrier",
+    "bg_create_sharded", "bg_sharded_slice", "bg_sharded_write", "bg_sharded_free",
     # sharded build
     "bg_partition_rows", "bg_kmer_instances", "bg_kmer_extract", "bg_kmer_extract_by_owner", "bg_kmer_count_keys", "bg_kmerset_export",
     "bg_skm_supported", "bg_skm_capacity", "bg_skm_extract_by_owner", "bg_skm_count", "bg_kmerset_attach_presence",

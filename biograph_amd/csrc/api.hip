@@ -165,6 +165,10 @@ static std::string version_json(const char* type, int maj, int min, int pat) {
 using namespace bg;
 
 extern "C" int bg_abi_version(void) { return BG_ABI_VERSION; }
+extern "C" int bg_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 extern "C" const char* bg_last_error(void) { return bg::last_error_cstr(); }
 
 extern "C" int bg_ctx_create(int device, void* stream, bg_ctx** out) {

@@ -17,12 +17,16 @@
 #include <fcntl.h>
 #include <stdarg.h>
 #include <string.h>
+#include <signal.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <time.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <mutex>
 #include <thread>
@@ -56,7 +60,7 @@ struct Args {
 // Options every command understands are listed per command: anything else is an error, never silently
 // ignored (an interleaved FASTQ imported as unpaired, a --cut-reads that cuts nothing).
 static Args parse(int argc, char** argv, int first, const std::vector<std::string>& known) {
-  static const char* flags[] = {"interleaved", "force", "f", "allow-long-reads", "no-bwt", "prefault", nullptr};
+  static const char* flags[] = {"interleaved", "force", "f", "allow-long-reads", "no-bwt", "prefault", "force-sharded", nullptr};
   Args a;
   for (int i = first; i < argc; ++i) {
     std::string s = argv[i];
@@ -294,10 +298,362 @@ static int cmd_bam2fastq(int argc, char** argv) {
   return 0;
 }
 
+
+// ---- `create --gpus N`: one child process per GPU, forked before anything touches HIP (biograph_create.cpp:431-811 with the
+// partitions of part_repo.cpp:32-45 owned by ranks instead of files).  Every rank imports its own stretch of the input, the
+// ranks build ONE sample together (bg_create_sharded over RCCL), write one seqset container in place and rank 0 writes the
+// readmap and the metadata.
+
+// newlines in [lo, hi) of a source (a plain file through pread, or host text), on a few threads
+struct TextSrc {
+  int fd = -1;
+  const char* mem = nullptr;
+  uint64_t n = 0;
+};
+static uint64_t count_newlines_block(const TextSrc& t, uint64_t lo, uint64_t hi, std::vector<char>* buf) {
+  uint64_t c = 0;
+  if (t.mem) {
+    const char* p = t.mem + lo;
+    const char* e = t.mem + hi;
+    while ((p = static_cast<const char*>(memchr(p, '\n', size_t(e - p))))) { ++c; ++p; }
+    return c;
+  }
+  buf->resize(size_t(4) << 20);
+  for (uint64_t at = lo; at < hi;) {
+    const size_t want = size_t(std::min<uint64_t>(buf->size(), hi - at));
+    ssize_t got = pread(t.fd, buf->data(), want, off_t(at));
+    if (got <= 0) die("read error while splitting the input over the ranks");
+    const char* p = buf->data();
+    const char* e = p + got;
+    while ((p = static_cast<const char*>(memchr(p, '\n', size_t(e - p))))) { ++c; ++p; }
+    at += uint64_t(got);
+  }
+  return c;
+}
+static uint64_t count_newlines(const TextSrc& t, uint64_t lo, uint64_t hi, int threads) {
+  if (hi <= lo) return 0;
+  const int T = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(threads > 0 ? threads : 8), (hi - lo) >> 22)));
+  std::vector<uint64_t> part(T, 0);
+  std::vector<std::thread> th;
+  for (int i = 0; i < T; ++i)
+    th.emplace_back([&, i] {
+      std::vector<char> buf;
+      part[i] = count_newlines_block(t, lo + (hi - lo) * uint64_t(i) / T, lo + (hi - lo) * uint64_t(i + 1) / T, &buf);
+    });
+  for (auto& x : th) x.join();
+  uint64_t c = 0;
+  for (uint64_t x : part) c += x;
+  return c;
+}
+// byte offset just behind the k-th newline (k >= 1) at or after `lo`
+static uint64_t after_kth_newline(const TextSrc& t, uint64_t lo, uint64_t k) {
+  std::vector<char> buf(size_t(4) << 20);
+  for (uint64_t at = lo; at < t.n;) {
+    const size_t want = size_t(std::min<uint64_t>(buf.size(), t.n - at));
+    const char* base;
+    ssize_t got;
+    if (t.mem) { base = t.mem + at; got = ssize_t(want); }
+    else { got = pread(t.fd, buf.data(), want, off_t(at)); base = buf.data(); if (got <= 0) die("read error while splitting the input over the ranks"); }
+    const char* p = base;
+    const char* e = base + got;
+    while ((p = static_cast<const char*>(memchr(p, '\n', size_t(e - p))))) {
+      ++p;
+      if (--k == 0) return at + uint64_t(p - base);
+    }
+    at += uint64_t(got);
+  }
+  return t.n;
+}
+// The stretch [*lo, *hi) of one source that holds this rank's records.  Records are four lines; `unit` records stay together
+// (2 for an interleaved file); `n_records` (in/out): 0 = derive from this source, else the count the sources of a pair share.
+// Every rank scans only its own n / world bytes, the counts meet through the communicator.
+static void my_stretch(const TextSrc& t, int rank, int world, bg_comm* comm, uint64_t unit, int threads, uint64_t* n_records, uint64_t* lo, uint64_t* hi) {
+  std::vector<uint64_t> cnt(world, 0);
+  const uint64_t a = t.n * uint64_t(rank) / world, b = t.n * uint64_t(rank + 1) / world;
+  uint64_t mine[2] = {count_newlines(t, a, b, threads), 0};
+  if (rank == world - 1 && t.n) {  // a last line without its newline still is a line
+    char last = 0;
+    if (t.mem) last = t.mem[t.n - 1]; else if (pread(t.fd, &last, 1, off_t(t.n - 1)) != 1) die("read error");
+    mine[1] = last != '\n';
+  }
+  std::vector<uint64_t> all(size_t(world) * 2);
+  check(bg_comm_all_gather_host(comm, mine, sizeof mine, all.data()), "bg_comm_all_gather_host");
+  uint64_t lines = 0;
+  std::vector<uint64_t> before(world + 1, 0);
+  for (int q = 0; q < world; ++q) { before[q + 1] = before[q] + all[size_t(q) * 2]; lines += all[size_t(q) * 2] + all[size_t(q) * 2 + 1]; }
+  if (!*n_records) *n_records = lines / 4;
+  const uint64_t units = *n_records / unit;
+  const uint64_t first_rec = (units * uint64_t(rank) / world) * unit;
+  uint64_t start = 0;
+  if (first_rec) {  // behind newline number 4 * first_rec, which lies in the stretch of some rank q
+    const uint64_t k = 4 * first_rec;
+    int q = 0;
+    while (q + 1 < world && before[q + 1] < k) ++q;
+    start = after_kth_newline(t, t.n * uint64_t(q) / world, k - before[q]);
+  }
+  std::vector<uint64_t> starts(world);
+  check(bg_comm_all_gather_host(comm, &start, 8, starts.data()), "bg_comm_all_gather_host");
+  *lo = start;
+  *hi = rank + 1 < world ? starts[rank + 1] : t.n;  // the last rank takes what is left (blank tail lines, a mate file that is longer)
+}
+
+static int create_rank(const Args& a, int argc, char** argv, const bg_create_params& p, const std::string& out, const std::vector<std::string>& files,
+                       bool paired_files, bool interleaved, const std::string& fmt, uint32_t cut_start, uint32_t cut_end, int threads, int rank, int world,
+                       int device, const std::string& backend, const char* comm_id, int id_fd_in, const std::vector<int>& id_fd_out, double min_reads,
+                       double warn_reads) {
+  const bool lead = rank == 0;
+  double t0 = now_s();
+  bg_ctx* ctx = nullptr;
+  int ndev = bg_device_count();
+  if (ndev < 1) die("create --gpus: no HIP device");
+  if (device < 0) device = backend == "shm" ? rank % ndev : rank;
+  if (device >= ndev) die("create --gpus " + std::to_string(world) + ": rank " + std::to_string(rank) + " has no device " + std::to_string(device) +
+                          " (" + std::to_string(ndev) + " visible; --comm shm lets ranks share a device)");
+  check(bg_ctx_create(device, nullptr, &ctx), "bg_ctx_create");
+  char id[BG_COMM_ID_BYTES];
+  memset(id, 0, sizeof id);
+  if (backend == "rccl") {  // rank 0 draws the id, the launcher's pipes carry it to the others
+    if (lead) {
+      check(bg_comm_unique_id(id), "bg_comm_unique_id");
+      for (int fd : id_fd_out)
+        if (write(fd, id, sizeof id) != ssize_t(sizeof id)) die("create --gpus: could not hand the communicator id on");
+    } else if (read(id_fd_in, id, sizeof id) != ssize_t(sizeof id)) {
+      die("create --gpus: rank 0 never sent the communicator id");
+    }
+  } else {
+    snprintf(id, sizeof id, "%s", comm_id);
+  }
+  bg_comm* comm = nullptr;
+  check(bg_comm_init(ctx, rank, world, id, backend.c_str(), &comm), "bg_comm_init");
+  if (lead) logf("Importing reads on %d rank(s) (communicator: %s)", world, backend.c_str());
+
+  // ---- this rank's stretch of every input
+  std::vector<HostText> texts(files.size());
+  std::vector<TextSrc> srcs(files.size());
+  BamState bam;
+  bool any_bam = false;
+  std::string bam_text;
+  for (size_t i = 0; i < files.size(); ++i) {
+    load_text(files[i], &texts[i]);
+    const bool this_bam = texts[i].fd < 0 && is_bam(texts[i].inflated);
+    if (fmt == "bam" && !this_bam) die(files[i] + ": not a BAM file");
+    if (this_bam) {
+      if (fmt == "fastq") die(files[i] + ": a BAM file was given with --format fastq");
+      if (paired_files || interleaved) die("--pair / --interleaved do not apply to BAM input (mates are matched by name)");
+      if (i && !any_bam) die("BAM and FASTQ inputs cannot be mixed in one run");
+      any_bam = true;
+      bam_records(texts[i].inflated, files[i], &bam);  // (every rank decodes the whole file: a BGZF stream has no record index)
+      free_text(&texts[i]);
+      continue;
+    }
+    if (any_bam) die("BAM and FASTQ inputs cannot be mixed in one run");
+    srcs[i].fd = texts[i].fd;
+    srcs[i].mem = texts[i].fd >= 0 ? nullptr : texts[i].inflated.data();
+    srcs[i].n = texts[i].n;
+  }
+  bool bam_paired = false;
+  if (any_bam) {
+    uint64_t lacking = 0;
+    bam_text = bam_finish(&bam, &lacking);
+    bam_paired = bam.got_paired;
+    if (lead) logf("BAM: %llu records (%llu secondary / supplementary skipped)%s", (unsigned long long)bam.n_records, (unsigned long long)bam.n_skipped,
+                   bam_paired ? ", paired" : ", unpaired");
+    if (lead && lacking) logf("WARNING: %llu entries remaining in pair cache from paired reads; treating as unpaired reads", (unsigned long long)lacking);
+    srcs.assign(1, TextSrc());
+    srcs[0].mem = bam_text.data();
+    srcs[0].n = bam_text.size();
+    if (bam_paired && lacking) die("create --gpus: a BAM whose pairs are incomplete cannot be split over ranks (paired and unpaired records alternate)");
+  }
+  const bool inter = interleaved || bam_paired;
+  uint64_t pair_records = 0;
+  std::vector<void*> d_text(srcs.size(), nullptr);
+  std::vector<uint64_t> n_text(srcs.size(), 0);
+  uint64_t text_bytes = 0;
+  for (size_t i = 0; i < srcs.size(); ++i) {
+    uint64_t lo = 0, hi = srcs[i].n;
+    if (world > 1) {
+      uint64_t n_rec = 0;
+      if (paired_files && (i & 1)) n_rec = pair_records;  // the mate file follows the record count of its partner
+      my_stretch(srcs[i], rank, world, comm, inter ? 2 : 1, threads, &n_rec, &lo, &hi);
+      if (paired_files && !(i & 1)) pair_records = n_rec;
+    }
+    n_text[i] = hi - lo;
+    text_bytes += n_text[i];
+    check(bg_dev_alloc(ctx, n_text[i] ? n_text[i] : 1, &d_text[i]), "bg_dev_alloc");
+    if (srcs[i].mem) check(bg_dev_upload_pinned(ctx, d_text[i], srcs[i].mem + lo, n_text[i], threads), "upload");
+    else check(bg_dev_upload_file(ctx, d_text[i], srcs[i].fd, lo, n_text[i], threads), "upload");
+  }
+  for (auto& t : texts) free_text(&t);
+  std::string().swap(bam_text);
+  uint8_t* d_seq = nullptr;
+  uint64_t* d_offs = nullptr;
+  uint64_t n_reads = 0, n_bases = 0;
+  std::vector<const uint8_t*> tp;
+  for (void* q : d_text) tp.push_back(static_cast<const uint8_t*>(q));
+  check(bg_fastq_import(ctx, uint32_t(tp.size()), tp.data(), n_text.data(), paired_files ? 1 : 0, inter ? 1 : 0, cut_start, cut_end, &d_seq, &d_offs, &n_reads,
+                        &n_bases),
+        "import");
+  for (void* q : d_text) bg_dev_free(ctx, q);
+  uint64_t mine3[3] = {n_reads, n_bases, text_bytes}, tot3[3] = {0, 0, 0};
+  std::vector<uint64_t> all3(size_t(world) * 3);
+  check(bg_comm_all_gather_host(comm, mine3, sizeof mine3, all3.data()), "bg_comm_all_gather_host");
+  for (int q = 0; q < world; ++q)
+    for (int j = 0; j < 3; ++j) tot3[j] += all3[size_t(q) * 3 + j];
+  if (!tot3[0]) die("\nNo reads were imported, exiting.");
+  double t_import = now_s() - t0;
+  if (lead) logf("Total reads imported: %llu (%llu bases, %.2f GB of FASTQ; %.3f s on %d rank(s))", (unsigned long long)tot3[0], (unsigned long long)tot3[1],
+                 tot3[2] / 1e9, t_import, world);
+
+  if (lead) logf("Running kmerization, read correction, seqset and readmap build on %d GPU rank(s)", world);
+  double t1 = now_s();
+  const int is_paired = (paired_files || inter) ? 1 : 0;
+  bg_sharded* sh = nullptr;
+  bg_sharded_stats st;
+  check(bg_create_sharded(ctx, comm, d_seq, d_offs, n_reads, &p, is_paired ? 2 : 1, &sh, &st), "bg_create_sharded");
+  double t_build = now_s() - t1;
+  bg_dev_free(ctx, d_seq);
+  bg_dev_free(ctx, d_offs);
+  const uint64_t all_reads = tot3[0];
+  double pct = double(st.build.n_corrected_reads) / double(all_reads);
+  char msg[320];
+  if (pct < min_reads) {  // biograph_create.cpp:748-757 (every rank sees the same totals)
+    snprintf(msg, sizeof msg, "Fewer than %2.0f%% of reads (set by --min-reads) were kept after correction (%llu / %llu remain). Cannot continue.",
+             min_reads * 100.0, (unsigned long long)st.build.n_corrected_reads, (unsigned long long)all_reads);
+    if (lead) die(msg);
+    exit(1);
+  }
+  if (lead && pct < warn_reads)
+    logf("Warning: Fewer than %2.0f%% of reads (set by --warn-reads) survived correction (%llu / %llu remain)", warn_reads * 100.0,
+         (unsigned long long)st.build.n_corrected_reads, (unsigned long long)all_reads);
+  if (lead) {
+    mkdirs(out);
+    mkdirs(out + "/qc");
+    mkdirs(out + "/metadata");
+    mkdirs(out + "/coverage");
+  }
+  double t2 = now_s();
+  std::vector<const char*> av(argv, argv + argc);
+  char uuid[40] = "", sha[44] = "";
+  const std::string rm_tmp = out + "/coverage/tmp.readmap";
+  check(bg_sharded_write(ctx, comm, sh, (out + "/seqset").c_str(), rm_tmp.c_str(), argc, av.data(), uuid, sha), "bg_sharded_write");
+  bg_comm_stats cs;
+  check(bg_comm_get_stats(comm, &cs), "bg_comm_get_stats");
+  uint64_t cs_mine[2] = {cs.bytes_through_backend, cs.collectives};
+  std::vector<uint64_t> cs_all(size_t(world) * 2);
+  check(bg_comm_all_gather_host(comm, cs_mine, sizeof cs_mine, cs_all.data()), "bg_comm_all_gather_host");
+  if (lead) {
+    if (rename(rm_tmp.c_str(), (out + "/coverage/" + sha + ".readmap").c_str()) != 0) die("Could not rename " + rm_tmp);
+    double t_write = now_s() - t2, t_total = now_s() - t0;
+    uint64_t through = 0;
+    for (int q = 0; q < world; ++q) through += cs_all[size_t(q) * 2];
+    logf("Written: seqset in place by %d rank(s), readmap + digest by rank 0: %.3f s", world, t_write);
+    logf("Communicator: %s%s, %llu collectives per rank, %.3f GB through it over all ranks", backend.c_str(),
+         cs.backend == 2 ? " (a rank alone: collectives are copies; BG_COMM_NO_SHORTCUT=1 sends them through the backend)" : "",
+         (unsigned long long)cs.collectives, through / 1e9);
+    std::string id_s = a.get("id");
+    if (id_s.empty()) id_s = stem_of(out);
+    char nums[1400];
+    snprintf(nums, sizeof nums,
+             "\"imported_reads\":%llu,\"imported_bases\":%llu,\"corrected_reads\":%llu,\"corrected_bases\":%llu,"
+             "\"avg_bases_per_read\":%.6f,\"corrected_pct\":%.6f,\"kept_kmers\":%llu,\"seqset_entries\":%llu,"
+             "\"gpus\":%d,\"comm\":\"%s\",\"comm_backend_code\":%d,\"rccl_version\":%d,\"comm_collectives_per_rank\":%llu,\"comm_bytes_through_backend\":%llu,"
+             "\"correct_steps\":%u,\"correct_probes\":%llu,\"tails_sent_in_full\":%llu,"
+             "\"timings\":[{\"import\":%.3f},{\"gpu_build\":%.3f},{\"write\":%.3f},{\"total\":%.3f}]",
+             (unsigned long long)all_reads, (unsigned long long)tot3[1], (unsigned long long)st.build.n_corrected_reads,
+             (unsigned long long)st.build.n_corrected_bases,
+             st.build.n_corrected_reads ? double(st.build.n_corrected_bases) / double(st.build.n_corrected_reads) : 0.0, pct,
+             (unsigned long long)st.build.n_kept_kmers, (unsigned long long)st.build.n_entries, world, backend.c_str(), cs.backend, cs.rccl_version,
+             (unsigned long long)cs.collectives, (unsigned long long)through, st.correct_steps, (unsigned long long)st.correct_probes,
+             (unsigned long long)st.tails_sent_in_full, t_import, t_build, t_write, t_total);
+    std::string js = "{\"command\":\"create\",\"version\":\"biograph_amd-r4\",\"accession_id\":" + json_str(id_s) + ",\"uuid\":" + json_str(uuid) + "," + nums + "}";
+    write_file(out + "/qc/create_stats.json", js);
+    if (a.has("stats")) write_file(a.get("stats"), js);
+    std::string meta = "{\"accession_id\":" + json_str(id_s) + ",\"biograph_id\":" + json_str(uuid) + ",\"command_history\":[" + json_argv(argc, argv) +
+                       "],\"samples\":{" + json_str(id_s) + ":" + json_str(sha) + "},\"version\":\"biograph_amd-r4\"}";
+    write_file(out + "/metadata/bg_info.json", meta);
+    logf("%llu / %llu reads survived read correction; %llu seqset entries; GPU build %.3f s on %d rank(s); %.3f s in all",
+         (unsigned long long)st.build.n_corrected_reads, (unsigned long long)all_reads, (unsigned long long)st.build.n_entries, t_build, world, t_total);
+    write_file(out + "/qc/create_log.txt", g_log);
+  }
+  check(bg_comm_barrier(comm), "bg_comm_barrier");
+  bg_sharded_free(sh);
+  bg_comm_free(comm);
+  bg_ctx_destroy(ctx);
+  return 0;
+}
+
+static int create_sharded(const Args& a, int argc, char** argv, const bg_create_params& p, const std::string& out, const std::vector<std::string>& files,
+                          bool paired_files, bool interleaved, const std::string& fmt, uint32_t cut_start, uint32_t cut_end, int threads, int gpus,
+                          double min_reads, double warn_reads) {
+  const std::string backend = a.get("comm", "rccl");
+  if (backend != "rccl" && backend != "shm") die("--comm takes rccl or shm");
+  std::vector<int> devices;
+  if (a.has("devices")) {
+    const std::string v = a.get("devices");
+    for (size_t at = 0; at < v.size();) {
+      size_t e = v.find(',', at);
+      if (e == std::string::npos) e = v.size();
+      devices.push_back(atoi(v.substr(at, e - at).c_str()));
+      at = e + 1;
+    }
+    if (int(devices.size()) != gpus) die("--devices names one device per rank");
+  }
+  for (const auto& f : files)
+    if (f == "-") die("create --gpus: every rank reads its own stretch of the input: it cannot be a pipe");
+  char comm_id[64];
+  snprintf(comm_id, sizeof comm_id, "%ld-%ld", long(getpid()), long(time(nullptr)));
+  // nothing in this process has touched HIP: the ranks are forked now (a process that has initialised the GPU must not fork
+  // ranks or exec)
+  std::vector<std::array<int, 2>> pipes(gpus > 1 ? gpus - 1 : 0);
+  for (auto& pp : pipes)
+    if (pipe(pp.data()) != 0) die(std::string("pipe: ") + strerror(errno));
+  fflush(stdout);
+  fflush(stderr);
+  std::vector<pid_t> kids;
+  for (int r = 0; r < gpus; ++r) {
+    pid_t pid = fork();
+    if (pid < 0) die(std::string("fork: ") + strerror(errno));
+    if (pid == 0) {
+      std::vector<int> outs;
+      int in = -1;
+      for (int q = 1; q < gpus; ++q) {
+        if (r == 0) { outs.push_back(pipes[q - 1][1]); close(pipes[q - 1][0]); }
+        else if (q == r) { in = pipes[q - 1][0]; close(pipes[q - 1][1]); }
+        else { close(pipes[q - 1][0]); close(pipes[q - 1][1]); }
+      }
+      int rc = create_rank(a, argc, argv, p, out, files, paired_files, interleaved, fmt, cut_start, cut_end, threads, r, gpus,
+                           devices.empty() ? -1 : devices[r], backend, comm_id, in, outs, min_reads, warn_reads);
+      fflush(stdout);
+      fflush(stderr);
+      _exit(rc);
+    }
+    kids.push_back(pid);
+  }
+  for (auto& pp : pipes) { close(pp[0]); close(pp[1]); }
+  int failed = 0;
+  for (size_t left = kids.size(); left;) {
+    int status = 0;
+    pid_t pid = wait(&status);
+    if (pid < 0) break;
+    --left;
+    const bool ok = WIFEXITED(status) && WEXITSTATUS(status) == 0;
+    if (!ok && !failed) {  // one rank down: the others would wait for it forever
+      failed = 1;
+      for (pid_t k : kids)
+        if (k != pid) kill(k, SIGTERM);
+    }
+  }
+  if (backend == "shm") {  // ranks that were ended never unlinked their segments
+    shm_unlink((std::string("/bgcomm-") + comm_id).c_str());
+    for (int r = 0; r < gpus; ++r) shm_unlink((std::string("/bgcomm-") + comm_id + "-r" + std::to_string(r)).c_str());
+  }
+  return failed;
+}
+
 static int cmd_create(int argc, char** argv) {
   Args a = parse(argc, argv, 2, {"prefault", "reads", "pair", "interleaved", "ref", "out", "id", "force", "kmer-size", "min-kmer-count",
                                  "trim-after-portion", "max-corrections", "min-good-run", "min-reads", "warn-reads", "stats",
-                                 "cut-reads", "threads", "tmp", "max-mem", "format", "allow-long-reads"});
+                                 "cut-reads", "threads", "tmp", "max-mem", "format", "allow-long-reads", "gpus", "force-sharded", "comm", "devices"});
   if (!a.has("reads") || !a.has("out")) die("create: --reads and --out are required");
   std::string out = a.get("out");
   if (out.size() < 3 || out.substr(out.size() - 3) != ".bg") out += ".bg";  // biograph_dir appends .bg
@@ -333,6 +689,13 @@ static int cmd_create(int argc, char** argv) {
   if (!pairs.empty() && pairs.size() != ins.size()) die("If pair files are present, there must be the same number of them as read files.");
   if (interleaved && !pairs.empty()) die("--interleaved and --pair exclude each other");
   const int threads = atoi(a.get("threads", "0").c_str());
+  const int gpus = atoi(a.get("gpus", "1").c_str());
+  if (gpus < 1 || gpus > 127) die("--gpus takes 1..127");
+  if (gpus > 1 || a.has("force-sharded")) {
+    std::vector<std::string> files;
+    for (size_t i = 0; i < ins.size(); ++i) { files.push_back(ins[i]); if (!pairs.empty()) files.push_back(pairs[i]); }
+    return create_sharded(a, argc, argv, p, out, files, !pairs.empty(), interleaved, fmt, cut_start, cut_end, threads, gpus, min_reads, warn_reads);
+  }
 
   double t0 = now_s();
   logf("Importing reads");
@@ -976,6 +1339,10 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
 }
 
 static int cmd_discovery(int argc, char** argv) {
+  // (these settings are this command's alone: `create` holds multi-gigabyte FASTQ text on the heap and wants it back)
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TOP_PAD, 256 << 20);
   Args a = parse(argc, argv, 2, {"reads", "ref", "out", "sample", "min-overlap", "max-pair-distance", "bed", "engine", "max-ploids",
                                  "enable-pop-tracer", "threads", "ml-features", "scaffold-split-size", "simple-gt", "rvg-exclude"});
   if (!a.has("reads") || !a.has("ref") || !a.has("out")) die("discovery: --in S.bg, --ref and --out are required");
@@ -1135,9 +1502,6 @@ int main(int argc, char** argv) {
   // The tracer sessions of `discovery` allocate and free hundreds of thousands of small search states per work item on 16
   // threads: with glibc's defaults the heap tops are trimmed and faulted in again all the time, and page faults of one
   // process serialise on its address-space lock (measured on the chr20-shaped sample: tracing 16.2 s -> 12.7 s).
-  mallopt(M_TRIM_THRESHOLD, 1 << 30);
-  mallopt(M_MMAP_THRESHOLD, 1 << 30);
-  mallopt(M_TOP_PAD, 256 << 20);
   if (argc < 2) die("usage: bgbinary {create|merge|refmap|discovery} [options]   (MI355X build of the seqset path)");
   std::string cmd = argv[1];
   if (cmd == "bam2fastq") return cmd_bam2fastq(argc, argv);

@@ -43,6 +43,7 @@ typedef struct bg_seqset bg_seqset;   /* seqset arrays resident in HBM (+ host c
 typedef struct bg_records bg_records; /* suffix records (materialised keys) of one shard           */
 
 int bg_abi_version(void);
+int bg_device_count(void); /* HIP devices this process sees (0 without a usable runtime); initialises HIP: not before a fork */
 const char* bg_last_error(void);
 
 /* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the default
@@ -690,6 +691,70 @@ int bg_create_sample(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offs, 
                                 entry of each shard (last word ~0 = empty); dest = first shard whose
                                 last entry >= row                                                       */
 #define BG_PART_ROW_DEST 3   /* the row names its destination itself: bits 10..16 of its last word (127 = nowhere) */
+/* ---- Communicator and the N-rank create (csrc/comm.hip, csrc/sharded.hip): `bgbinary create --gpus N`.
+ * The reference's SEQSETMain::run (modules/biograph/biograph_create.cpp:431-811) runs its partitions
+ * (part_repo::partition_for_sequence, modules/build_seqset/part_repo.cpp:32-45) as `parallel_for` workers over shared disk
+ * files; here one process per GPU owns its partitions in HBM and what the reference moves through files moves through
+ * RCCL over xGMI.  One bg_comm per process: rank r of `world` on the context's device.
+ *   backend "rccl": bg_comm_unique_id() on one rank (ncclGetUniqueId), its 128 bytes handed to the others by the launcher
+ *                   (pipe, file, store), bg_comm_init(..., id, "rccl") on every rank (ncclCommInitRank).  Pieces of
+ *                   an exchange are at most 1 GiB - 4 KiB (BG_COMM_MAX_PIECE), larger exchanges take several groups.
+ *   backend "shm":  host-staged through POSIX shared memory named by `id` (a short string): several ranks on ONE GPU
+ *                   (tests, boxes without xGMI) -- RCCL refuses two ranks on a device.
+ * A rank alone turns every collective into a copy unless BG_COMM_NO_SHORTCUT=1 (then its pieces go through the backend
+ * to itself).  Collectives are queued on the context's stream; host-valued ones return when they have landed. */
+typedef struct bg_comm bg_comm;
+#define BG_COMM_ID_BYTES 128
+typedef struct bg_comm_stats {
+  uint64_t collectives;            /* exchanges, gathers and reductions issued                              */
+  uint64_t bytes_through_backend;  /* bytes this rank sent through RCCL (or staged through shared memory)   */
+  uint64_t bytes_kept_local;       /* pieces a rank keeps: device copies                                     */
+  double seconds_in_calls;         /* host time inside the communicator's calls                              */
+  int backend;                     /* 0 rccl, 1 shm, 2 none (a rank alone, short-cut)                        */
+  int rccl_version;                /* ncclGetVersion (0 unless backend 0)                                    */
+} bg_comm_stats;
+int bg_comm_unique_id(char* h_id_out /* BG_COMM_ID_BYTES */);
+int bg_comm_init(bg_ctx* ctx, int rank, int world, const char* id, const char* backend /* "rccl" | "shm" */, bg_comm** out);
+void bg_comm_free(bg_comm* c);
+int bg_comm_rank(const bg_comm* c);
+int bg_comm_world(const bg_comm* c);
+int bg_comm_get_stats(const bg_comm* c, bg_comm_stats* out);
+/* rows of row_bytes travel as h_send_rows[d] rows to rank d (pieces back to back in d_send, rank order) and arrive as
+ * h_recv_rows[s] rows from rank s (back to back in d_recv).  _all_to_all_v learns the receive counts itself (one small
+ * all-gather); _exchange takes them from the caller (the way back of an earlier exchange). */
+int bg_comm_all_to_all_v(bg_comm* c, const void* d_send, const uint64_t* h_send_rows, uint64_t row_bytes, void* d_recv,
+                         uint64_t recv_cap_rows, uint64_t* h_recv_rows);
+int bg_comm_exchange(bg_comm* c, const void* d_send, const uint64_t* h_send_rows, const uint64_t* h_recv_rows, uint64_t row_bytes,
+                     void* d_recv);
+int bg_comm_all_gather_host(bg_comm* c, const void* h_mine, uint64_t bytes, void* h_all /* world x bytes */);
+int bg_comm_all_gather(bg_comm* c, const void* d_send, const uint64_t* h_bytes /* world: bytes of every rank */, void* d_recv);
+int bg_comm_all_reduce_sum_u64(bg_comm* c, uint64_t* d_buf, uint64_t n);
+int bg_comm_barrier(bg_comm* c);
+
+/* bg_create_sample() for ONE sample whose reads are spread over the ranks of `comm` (each rank passes its share: whole
+ * pairs, any split; read ids follow rank order): SEQSETMain::run (biograph_create.cpp:431-831) with every structure owned by
+ * one rank -- k-mers by the hash partition of their minimiser (kmer_counter.h:167-178), cover index, records and entries
+ * by their leading bases (part_repo.cpp:32-45), readmap rows by their entry.  Collective: every rank calls it.  The
+ * result is the rank's 512-aligned stretch of the seqset (bg_sharded_slice) and its stretch of the readmap's columns;
+ * bg_sharded_write lets all ranks write ONE seqset container in place (spiral_file_mmap.cpp:350-457) and gathers the
+ * readmap on rank 0, which writes it.  The containers are byte-identical to the single-GPU build's (except file_info.json). */
+typedef struct bg_sharded bg_sharded;
+typedef struct bg_sharded_stats {
+  bg_build_stats build;                    /* of the whole sample (n_tied_records: not collected)                  */
+  uint64_t shard_entries;                  /* entries this rank owned before the slices were aligned               */
+  uint64_t first_entry, slice_entries;     /* this rank's slice: [first_entry, first_entry + slice_entries)        */
+  uint64_t n_read_ids, first_read_id, slice_read_ids;
+  uint64_t correct_probes, tails_sent_in_full;
+  uint32_t correct_steps;
+} bg_sharded_stats;
+int bg_create_sharded(bg_ctx* ctx, bg_comm* comm, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n_reads,
+                      const bg_create_params* p, int readmap /* 0 none, 1 unpaired, 2 paired */, bg_sharded** out,
+                      bg_sharded_stats* stats);
+const bg_seqset* bg_sharded_slice(const bg_sharded* s);
+int bg_sharded_write(bg_ctx* ctx, bg_comm* comm, const bg_sharded* s, const char* seqset_path, const char* readmap_path /* may be NULL */,
+                     int argc, const char* const* argv, char* h_uuid37 /* may be NULL */, char* h_readmap_sha41 /* may be NULL */);
+void bg_sharded_free(bg_sharded* s);
+
 /* ---- reference: what the discovery walks along ------------------------------------
  * bg_reference_open reads a BioGraph reference directory (karyotype.json + reference.ref, or reference.fasta
  * when the .ref is absent; modules/io/defaults.h:17-50, bio_base/reference.cpp:27-40), a bare .ref file
