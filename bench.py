@@ -621,6 +621,12 @@ def main():
     ap.add_argument("--no-sharded-readmap", action="store_true", help="sharded runs: skip the untimed build-with-readmap leg")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the sharded (RCCL) build path even with one rank (smoke test of the collectives)")
+    ap.add_argument("--comm", default="native", choices=["native", "torch"],
+                    help="sharded runs: native = bg_create_sharded over bg_comm (rccl.h inside libbgseq: what `bgbinary create "
+                         "--gpus N` runs); torch = biograph_amd/sharded.py over torch.distributed")
+    ap.add_argument("--shortcut", action="store_true",
+                    help="--force-sharded with one rank: let the rank's collectives be copies (default: BG_COMM_NO_SHORTCUT=1, "
+                         "every collective goes through RCCL to itself)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -639,7 +645,10 @@ def main():
     from biograph_amd import synth
 
     shared_arena = False
-    if (world > 1 or args.force_sharded) and not args.no_shared_arena:
+    native = args.comm == "native"
+    if (world > 1 or args.force_sharded) and native and not args.shortcut:
+        os.environ.setdefault("BG_COMM_NO_SHORTCUT", "1")
+    if (world > 1 or args.force_sharded) and not args.no_shared_arena and not native:
         # the exchange buffers (torch tensors) and the library's buffers come out of one arena per device
         shared_arena = bg.use_shared_arena()
     if not torch.cuda.is_available():
@@ -684,7 +693,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world > 1 or args.force_sharded:
+    ncomm = None
+    if (world > 1 or args.force_sharded) and native:
+        # ONE C call per rank and step: bg_create_sharded over bg_comm (csrc/sharded.hip, csrc/comm.hip: rccl.h inside the
+        # library); torch.distributed only carries the communicator's id to the ranks and the barriers around the timed region
+        from biograph_amd import sharded
+        ident = [sharded.NativeComm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        ncomm = sharded.NativeComm(ctx, rank, world, ident[0], "rccl")
+
+        def step():
+            sh = sharded.native_create(ctx, ncomm, seq.data_ptr(), offs.data_ptr(), n_reads, params)
+            st = sh.stats
+            sh.free()
+            return st
+    elif world > 1 or args.force_sharded:
         from biograph_amd import sharded
         comm = sharded.TorchDistComm(dev)
 
@@ -705,11 +728,24 @@ def main():
         stats = step()
     ctx.set_profiling(True)  # HIP events around every kernel family, on the stream the kernels run on
     barrier()
+    comm0 = ncomm.stats() if ncomm is not None else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stats = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    comm_line = None
+    if ncomm is not None:
+        c1 = ncomm.stats()
+        per = lambda k: (c1[k] - comm0[k]) / max(args.steps, 1)  # noqa: E731
+        tb_ = torch.tensor([per("bytes_through_backend")], device=dev, dtype=torch.float64)
+        dist.all_reduce(tb_, op=dist.ReduceOp.SUM)
+        comm_line = {"backend": {0: "rccl", 1: "shm", 2: "none (a rank alone: copies)"}[c1["backend"]], "rccl_version": c1["rccl_version"],
+                     "collectives_per_step_rank0": per("collectives"), "bytes_through_rccl_per_step_all_ranks": int(tb_.item()),
+                     "bytes_kept_local_per_step_rank0": int(per("bytes_kept_local")),
+                     "host_seconds_in_comm_calls_per_step_rank0": round(per("seconds_in_calls"), 4),
+                     "no_shortcut": os.environ.get("BG_COMM_NO_SHORTCUT") == "1",
+                     "path": "bg_create_sharded over bg_comm (csrc/sharded.hip, csrc/comm.hip: grouped ncclSend / ncclRecv, pieces <= 1 GiB - 4 KiB)"}
     timings = ctx.timings()
     ctx.set_profiling(False)
     mem = ctx.memory()
@@ -734,22 +770,33 @@ def main():
         # claims), then the ranks' columns put together on rank 0 (bg_readmap_from_arrays).
         barrier()
         t1 = time.perf_counter()
-        out = sharded.sharded_create(comm, {rank: ctx}, {rank: (seq, offs, n_reads)}, params, gather=False, readmap="paired")
-        sl, st_rm = out[rank]
-        barrier()
-        t2 = time.perf_counter()
-        cols = sl.readmap_columns
-        rm = sharded.gather_readmap(comm, {rank: ctx}, {rank: cols}, "bench")[rank]
-        barrier()
-        t3 = time.perf_counter()
-        sharded_rm = {"read_ids": int(cols.n_total), "entries": int(cols.n_entries), "entry_ids_need_bits": int(cols.n_entries).bit_length(),
-                      "build_with_readmap_ms": round((t2 - t1) * 1e3, 1), "seqset_only_ms": round(elapsed / max(args.steps, 1) * 1e3, 1),
-                      "gather_on_rank0_ms": round((t3 - t2) * 1e3, 1),
-                      "note": "untimed leg: one build with readmap='paired' (sharded_readmap), then gather_readmap on rank 0"}
-        if rm is not None:
-            rm.free()
-        sl.free()
-        del out, cols
+        if ncomm is not None:
+            sh = sharded.native_create(ctx, ncomm, seq.data_ptr(), offs.data_ptr(), n_reads, params, readmap="paired")
+            barrier()
+            t2 = time.perf_counter()
+            sharded_rm = {"read_ids": sh.stats["n_read_ids"], "entries": sh.stats["n_entries"],
+                          "entry_ids_need_bits": int(sh.stats["n_entries"]).bit_length(),
+                          "build_with_readmap_ms": round((t2 - t1) * 1e3, 1), "seqset_only_ms": round(elapsed / max(args.steps, 1) * 1e3, 1),
+                          "note": "untimed leg: one bg_create_sharded with the sample's readmap (its columns stay sharded; "
+                                  "bg_sharded_write gathers them on rank 0)"}
+            sh.free()
+        else:
+            out = sharded.sharded_create(comm, {rank: ctx}, {rank: (seq, offs, n_reads)}, params, gather=False, readmap="paired")
+            sl, st_rm = out[rank]
+            barrier()
+            t2 = time.perf_counter()
+            cols = sl.readmap_columns
+            rm = sharded.gather_readmap(comm, {rank: ctx}, {rank: cols}, "bench")[rank]
+            barrier()
+            t3 = time.perf_counter()
+            sharded_rm = {"read_ids": int(cols.n_total), "entries": int(cols.n_entries), "entry_ids_need_bits": int(cols.n_entries).bit_length(),
+                          "build_with_readmap_ms": round((t2 - t1) * 1e3, 1), "seqset_only_ms": round(elapsed / max(args.steps, 1) * 1e3, 1),
+                          "gather_on_rank0_ms": round((t3 - t2) * 1e3, 1),
+                          "note": "untimed leg: one build with readmap='paired' (sharded_readmap), then gather_readmap on rank 0"}
+            if rm is not None:
+                rm.free()
+            sl.free()
+            del out, cols
     e2e = None
     if world == 1 and not args.force_sharded and not args.no_end_to_end:
         e2e = end_to_end_leg(seq, n_reads, args.read_len, dev, args, genome=None if args.no_discover else genome)
@@ -809,7 +856,7 @@ def main():
                               "note": "rank 0; shared_arena: torch allocates from the library's arena and peak_live is the "
                                       "rank's whole footprint; else peak_live = the library's allocator, torch_peak = input "
                                       "reads + exchange buffers, and their sum bounds the footprint"},
-            "rccl_ranks": world if dist is not None else 0,
+            "rccl_ranks": world if dist is not None else 0, "comm": comm_line,
             "build_roofline": {"algorithmic_bytes_per_step": int(alg), "bytes_per_base": round(alg / max(stats["n_bases"], 1), 2),
                                "achieved_GBps": round(alg / step_s / 1e9, 1),
                                "frac_of_hbm_peak": round(alg / step_s / 1e9 / (HBM_PEAK_GBS * world), 5),
@@ -817,6 +864,8 @@ def main():
             "end_to_end_from_fastq": e2e, "discover": discover, "sharded_readmap": sharded_rm, "counters": stats, "kernels": kernels,
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if ncomm is not None:
+        ncomm.free()
     ctx.close()
     if dist is not None:
         dist.barrier()

@@ -46,6 +46,22 @@ class BuildStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class ShardedStats(C.Structure):  # bg_sharded_stats
+    _fields_ = [("build", BuildStats)] + [(n, C.c_uint64) for n in ("shard_entries", "first_entry", "slice_entries", "n_read_ids",
+                                                                       "first_read_id", "slice_read_ids", "correct_probes",
+                                                                       "tails_sent_in_full")] + [("correct_steps", C.c_uint32)]
+
+    def as_dict(self):
+        d = self.build.as_dict()
+        d.update({n: int(getattr(self, n)) for n, _ in self._fields_[1:]})
+        return d
+
+
+class CommStats(C.Structure):  # bg_comm_stats
+    _fields_ = [("collectives", C.c_uint64), ("bytes_through_backend", C.c_uint64), ("bytes_kept_local", C.c_uint64),
+                ("seconds_in_calls", C.c_double), ("backend", C.c_int), ("rccl_version", C.c_int)]
+
+
 class CreateParams(C.Structure):
     _fields_ = [("kmer_size", C.c_int), ("min_kmer_count", C.c_uint32), ("correct", CorrectParams)]
 

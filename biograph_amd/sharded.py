@@ -610,6 +610,15 @@ def _filtered_cover_rounds(comm, ctxs, covers, qs, parts, W, k, dev, ph, pparams
     ph.mark("cover_filters")
     owned = [row[0] for row in comm.gather_ints({r: [sum(t.shape[0] for t in parts[r])] for r in ranks})]
     log2w = max(10, int(np.ceil(np.log2(max(max(owned), 1) / 2.0))))  # 32 bits per indexed read, in 64-bit words
+    # The gathered filters are the one structure of the routed build that grows with the number of ranks (P x 2^log2w x 8
+    # bytes on every rank): they stay within an eighth of the device (BG_COVER_FILTER_BUDGET) -- fewer bits per read mean more
+    # candidates to verify, the records are the same (csrc/sharded.hip applies the same rule).
+    try:
+        budget = int(os.environ.get("BG_COVER_FILTER_BUDGET", "0")) or torch.cuda.mem_get_info(dev[ranks[0]])[1] // 8
+    except Exception:
+        budget = 1 << 35
+    while log2w > 10 and (P << log2w) * 8 > budget:
+        log2w -= 1
     bits = {}
     for r in ranks:
         bits[r] = torch.empty((1 << log2w,), dtype=i64, device=dev[r])
@@ -809,7 +818,8 @@ def sharded_create(comm, ctxs, inputs, params=None, device=None, mode=None, gath
     returns {r: (SeqsetSlice, stats)} — every rank keeps a 512-aligned stretch of the entries and write_slices()
     lets all ranks write one container in place.
 
-    mode "routed" (default; k >= 14): nothing is replicated — the kept k-mers stay with the rank that counted
+    mode "routed" (default; k >= 14): nothing is replicated except the owners' first-K-mer bit filters of the cover rounds
+    (32 bits per indexed read of every rank, capped at an eighth of the device: _filtered_cover_rounds) — the kept k-mers stay with the rank that counted
     them and the cover index is range-partitioned like the records; "replicated" (BG_SHARD_REPLICATED=1, and
     what k < 14 falls back to): kept k-mers and corrected reads are all-gathered on every rank.
 
@@ -1460,3 +1470,86 @@ def sharded_merge(comm, ctxs, entry_rows, max_len, gather=False):
     stats = {"n_input_entries": n_in, "n_records": n_in, "mode": "merge"}
     return _records_to_output(comm, ctxs, recv, W, max_len, dev, ph, gather, stats,
                               mark_inputs=0 if gather else len(entry_rows[ranks[0]]))
+
+
+# ------------------------------------------------------------------------------------------------
+# The same build as ONE C call per rank: bg_create_sharded over bg_comm (csrc/sharded.hip, csrc/comm.hip) -- what
+# `bgbinary create --gpus N` runs.  sharded_create above is its twin for simulated ranks (LocalSimComm: several ranks in
+# one process on one GPU) and for the merge / population flows.
+
+class NativeComm:
+    """bg_comm: rank `rank` of `world` on the context's device.  backend "rccl": `ident` = the 128 bytes of
+    NativeComm.unique_id() drawn on one rank and handed to the others by the launcher; backend "shm": `ident` = a short
+    name shared by the ranks (several processes on one GPU)."""
+
+    def __init__(self, ctx, rank, world, ident, backend="rccl"):
+        self.ctx, self.rank, self.world, self.backend = ctx, rank, world, backend
+        self.h = C.c_void_p()
+        if isinstance(ident, str):
+            ident = ident.encode()
+        buf = C.create_string_buffer(bytes(ident), 128)
+        capi.check(capi.lib().bg_comm_init(ctx.h, rank, world, buf, backend.encode(), C.byref(self.h)))
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        capi.check(capi.lib().bg_comm_unique_id(buf))
+        return buf.raw
+
+    def stats(self):
+        st = capi.CommStats()
+        capi.check(capi.lib().bg_comm_get_stats(self.h, C.byref(st)))
+        return {n: getattr(st, n) for n, _ in st._fields_}
+
+    def barrier(self):
+        capi.check(capi.lib().bg_comm_barrier(self.h))
+
+    def free(self):
+        if self.h:
+            capi.lib().bg_comm_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class NativeSharded:
+    """bg_sharded: one rank's 512-aligned slice of the seqset and its stretch of the readmap's columns."""
+
+    def __init__(self, ctx, h, stats):
+        self.ctx, self.h, self.stats = ctx, h, stats
+
+    def write(self, comm, seqset_path, readmap_path=None, argv=()):
+        """All ranks: the seqset container written in place, the readmap (when built) gathered on and written by rank 0.
+        -> (seqset uuid, readmap sha1 or "")."""
+        av = (C.c_char_p * max(len(argv), 1))(*[a.encode() for a in argv])
+        uu = C.create_string_buffer(40)
+        sha = C.create_string_buffer(44)
+        capi.check(capi.lib().bg_sharded_write(self.ctx.h, comm.h, self.h, seqset_path.encode(),
+                                               readmap_path.encode() if readmap_path else None, len(argv), av, uu, sha))
+        return uu.value.decode(), sha.value.decode()
+
+    def free(self):
+        if self.h:
+            capi.lib().bg_sharded_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def native_create(ctx, comm, d_seq, d_offs, n_reads, params=None, readmap=None):
+    """bg_create_sharded: this rank's share of ONE sample (device pointers as ints) -> NativeSharded (its .stats are the
+    whole sample's).  readmap: None | "unpaired" | "paired"."""
+    p = params or ctx.default_params()
+    st = capi.ShardedStats()
+    h = C.c_void_p()
+    capi.check(capi.lib().bg_create_sharded(ctx.h, comm.h, C.c_void_p(d_seq), C.c_void_p(d_offs), n_reads, C.byref(p),
+                                            {None: 0, "unpaired": 1, "paired": 2}[readmap], C.byref(h), C.byref(st)))
+    return NativeSharded(ctx, h, st.as_dict())
