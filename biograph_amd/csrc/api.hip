@@ -274,17 +274,19 @@ extern "C" int bg_ctx_reserve(bg_ctx* ctx, uint64_t bytes) {
     hipMemGenericAllocationHandle_t h;
     char* at = static_cast<char*>(base) + done;
     if (hipMemCreate(&h, piece, &prop, 0) != hipSuccess) break;
-    const bool ok = hipMemMap(at, piece, 0, h, 0) == hipSuccess && hipMemSetAccess(at, piece, &access, 1) == hipSuccess;
+    const bool mapped = hipMemMap(at, piece, 0, h, 0) == hipSuccess;
+    const bool ok = mapped && hipMemSetAccess(at, piece, &access, 1) == hipSuccess;
+    if (mapped && !ok) (void)hipMemUnmap(at, piece);  // a piece nobody may touch does not stay mapped
     (void)hipMemRelease(h);  // the mapping keeps the memory
     if (!ok) break;
   }
-  if (done < seg) {  // out of memory part of the way: what is mapped stays usable, the rest of the range goes back
+  if (done < seg) {  // out of memory part of the way: what is mapped stays usable; the whole range is returned with it later
     (void)hipGetLastError();
     if (!done) { (void)hipMemAddressFree(base, seg); set_error("bg_ctx_reserve: the driver refused %zu MiB", seg >> 20); return BG_ENOMEM; }
   }
   {
     std::lock_guard<std::mutex> l(g_vmm_mutex);
-    g_vmm_segments[base] = done;
+    g_vmm_segments[base] = VmmSegment{seg, done, piece};
   }
   std::lock_guard<std::mutex> lock(ctx->arena_mutex());
   ctx->arena->adopt(base, done);

@@ -277,7 +277,8 @@ namespace bg {
 // installed (bg_torch_allocator_enable); g_arena_mutex guards every arena call in that mode
 extern std::mutex g_arena_mutex;
 extern std::mutex g_vmm_mutex;                 // segments built through the virtual-memory API (bg_ctx_reserve)
-extern std::map<void*, size_t> g_vmm_segments;
+struct VmmSegment { size_t reserved, mapped, piece; };  // address range, bytes of it with memory behind them, bytes per mapping
+extern std::map<void*, VmmSegment> g_vmm_segments;
 bg_ctx::DeviceArena* shared_arena(int device);  // null unless the hook is installed
 // walk.hip: the read-ahead tables of one walked stretch of a tracer work item (offset after base i = first_off + i),
 // appended to the three lists; the two sorted ones are sorted within this stretch

@@ -1057,6 +1057,209 @@ __global__ __launch_bounds__(256) void k_prev_bits_pre2(const uint64_t* __restri
   marks[uint64_t(b) * marks_stride(n) + lo] = 1;
 }
 
+// ---- prev bits as ONE merge (round 4).  The entries that start with base b are a contiguous stretch of the sorted entries
+// and their tails s[1:] ascend with them, so their targets lower_bound(entries, s[1:]) ascend too (and are pairwise distinct):
+// instead of n directory + binary searches of dependent random probes (the 5.6 ms of k_prev_bits_pre2), a workgroup takes
+// kPmChunk consecutive ENTRIES as targets, stages their two-word prefixes in LDS once, and streams through the four stretches
+// of tails -- one per base -- whose targets fall among them.  Where those stretches begin is settled beforehand by a full-key
+// binary search per (chunk, base) (k_pm_bounds: tails of base b that are greater than the last entry before the chunk), so
+// everything a tail needs is in the chunk: its rows sit in LDS (kPmChunk x W words) and the tail's target is a full-key
+// binary search there, checked to extend the tail ("Missing expansion?", builder.cpp:95-96) -- every target, not only the
+// ones BG_VERIFY_CLOSURE used to ask for.  (First version: the two-word test of k_prev_bits_pre2 on prefixes staged in
+// LDS, the full-key search of the 9 % it does not settle in the chunk's rows in global memory -- 5.95 ms against 6.46: one
+// lane in eleven walking ten dependent loads holds its whole wave.)  The chunk's bits are put together in LDS and leave
+// as whole words: no marks array, no directory.  builder.cpp:85-108.
+constexpr int kPmChunk = 1024;
+
+__global__ void k_pm_first_base(const uint64_t* __restrict__ ekeys, uint64_t n, int W, uint64_t* __restrict__ F) {
+  const int b = threadIdx.x;
+  if (b > 4) return;
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {  // first entry whose first base is >= b
+    const uint64_t mid = (lo + hi) >> 1;
+    if (int(ekeys[mid * W] >> 62) < b) lo = mid + 1; else hi = mid;
+  }
+  F[b] = b == 4 ? n : lo;
+}
+
+__device__ __forceinline__ void pm_tail(const uint64_t* __restrict__ s, int W, uint64_t* tail) {
+  uint64_t key[kMaxWords + 1];
+#pragma unroll
+  for (int w = 0; w < kMaxWords; ++w) key[w] = w < W ? s[w] : 0;
+  key[kMaxWords] = 0;
+#pragma unroll
+  for (int w = 0; w < kMaxWords; ++w) tail[w] = (key[w] << 2) | (key[w + 1] >> 62);
+}
+
+// bounds[g * 4 + b], g = 0 .. G: the first entry of base b whose target lies at or beyond entry g * kPmChunk
+__global__ void k_pm_bounds(const uint64_t* __restrict__ ekeys, const uint8_t* __restrict__ sizes, uint64_t n, int W,
+                            const uint64_t* __restrict__ F, uint64_t G, uint64_t* __restrict__ bounds) {
+  const uint64_t idx = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= (G + 1) * 4) return;
+  const uint64_t g = idx >> 2;
+  const int b = int(idx & 3);
+  if (g == 0) { bounds[idx] = F[b]; return; }
+  if (g == G) { bounds[idx] = F[b + 1]; return; }
+  const uint64_t e = g * kPmChunk - 1;  // target >= g * kPmChunk  <=>  tail > entry e
+  uint64_t ref[kMaxWords];
+#pragma unroll
+  for (int w = 0; w < kMaxWords; ++w) ref[w] = w < W ? ekeys[e * W + w] : 0;
+  const int rl = sizes[e];
+  uint64_t lo = F[b], hi = F[b + 1];
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    uint64_t tail[kMaxWords];
+    pm_tail(ekeys + mid * W, W, tail);
+    if (key_compare(tail, int(sizes[mid]) - 1, ref, rl, W) <= 0) lo = mid + 1; else hi = mid;
+  }
+  bounds[idx] = lo;
+}
+
+__global__ __launch_bounds__(256) void k_prev_merge(const uint64_t* __restrict__ ekeys, const uint8_t* __restrict__ sizes, uint64_t n, int W,
+                                                    const uint64_t* __restrict__ bounds, unsigned long long* __restrict__ bA,
+                                                    unsigned long long* __restrict__ bC, unsigned long long* __restrict__ bG,
+                                                    unsigned long long* __restrict__ bT, uint32_t* __restrict__ err) {
+  extern __shared__ uint64_t pm_keys[];  // kPmChunk rows of W words: the chunk's entries, then their sizes
+  uint8_t* pm_len = reinterpret_cast<uint8_t*>(pm_keys + kPmChunk * W);
+  __shared__ unsigned long long sbits[4][kPmChunk / 64];
+  const uint64_t g = blockIdx.x;
+  const uint64_t e0 = g * kPmChunk;
+  const int m = int(n - e0 < uint64_t(kPmChunk) ? n - e0 : uint64_t(kPmChunk));
+  const int tid = threadIdx.x;
+  // where this chunk's four stretches of tails begin and end (eight loads in flight, not one behind the other)
+  uint64_t blo[4], bhi[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { blo[b] = bounds[g * 4 + b]; bhi[b] = bounds[(g + 1) * 4 + b]; }
+  // the chunk's rows are consecutive: one coalesced stream, eight 16-byte loads of a thread in flight at a time (a loop
+  // of load -> store waits a memory round trip per iteration: 20 of them made the kernel 7 ms long)
+  {
+    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(ekeys + e0 * W);
+    ulonglong2* dst = reinterpret_cast<ulonglong2*>(pm_keys);
+    const int pairs = (m * W) >> 1;
+    for (int x0 = 0; x0 < pairs; x0 += 8 * 256) {
+      ulonglong2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int x = x0 + u * 256 + tid;
+        if (x < pairs) v[u] = src[x];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int x = x0 + u * 256 + tid;
+        if (x < pairs) dst[x] = v[u];
+      }
+    }
+    if (((m * W) & 1) && tid == 0) pm_keys[m * W - 1] = ekeys[e0 * W + uint64_t(m * W - 1)];
+  }
+  for (int x = tid; x < m; x += 256) pm_len[x] = sizes[e0 + x];
+  if (tid < 4 * (kPmChunk / 64)) (&sbits[0][0])[tid] = 0;
+  __syncthreads();
+  // The tails: rounds of up to 256 consecutive entries of one base.  Their rows are one contiguous stretch of words, which
+  // the workgroup fetches word by word (thread t: words t, t + 256, ... -- whole lines per instruction; a thread fetching
+  // its own 40-byte row asks for 20 lines per instruction, five times over, and these kernels are bound by requests) into a
+  // staging tile in LDS; the next round's words travel while this round is searched.
+  uint64_t* stage = reinterpret_cast<uint64_t*>(pm_len + kPmChunk);  // 256 rows of W words, then their sizes
+  uint8_t* stage_len = reinterpret_cast<uint8_t*>(stage + 256 * W);
+  // the rounds in order: (base, first row, rows)
+  int rb = 0;
+  uint64_t ri = blo[0];
+  auto skip_empty = [&]() { while (rb < 4 && ri >= bhi[rb]) { ++rb; if (rb < 4) ri = blo[rb]; } };
+  skip_empty();
+  uint64_t pre[kMaxWords + 1];
+  int pre_len = 0;
+  auto fetch = [&](uint64_t row0, int cnt) {  // this thread's words of the round [row0, row0 + cnt)
+    const int words = cnt * W;
+#pragma unroll
+    for (int u = 0; u < kMaxWords + 1; ++u) {
+      const int x = u * 256 + tid;
+      pre[u] = x < words ? ekeys[row0 * W + x] : 0;
+    }
+    pre_len = tid < cnt ? sizes[row0 + tid] : 0;
+  };
+  int cur_b = rb, cur_cnt = 0;
+  uint64_t cur_row = ri;
+  if (rb < 4) {
+    cur_cnt = int(bhi[rb] - ri < 256 ? bhi[rb] - ri : 256);
+    fetch(cur_row, cur_cnt);
+  }
+  while (cur_cnt) {
+    // what was fetched goes to the tile
+    const int words = cur_cnt * W;
+#pragma unroll
+    for (int u = 0; u < kMaxWords + 1; ++u) {
+      const int x = u * 256 + tid;
+      if (x < words) stage[x] = pre[u];
+    }
+    if (tid < cur_cnt) stage_len[tid] = uint8_t(pre_len);
+    // the next round
+    ri = cur_row + cur_cnt;
+    rb = cur_b;
+    skip_empty();
+    const int nb = rb;
+    const uint64_t nrow = ri;
+    const int ncnt = rb < 4 ? int(bhi[rb] - ri < 256 ? bhi[rb] - ri : 256) : 0;
+    __syncthreads();
+    if (ncnt) fetch(nrow, ncnt);
+    if (tid < cur_cnt) {
+      uint64_t key[kMaxWords + 1];
+#pragma unroll
+      for (int w = 0; w < kMaxWords; ++w) key[w] = w < W ? stage[tid * W + w] : 0;
+      key[kMaxWords] = 0;
+      const int tl = int(stage_len[tid]) - 1;
+      uint64_t tail[kMaxWords];
+#pragma unroll
+      for (int w = 0; w < kMaxWords; ++w) tail[w] = (key[w] << 2) | (key[w + 1] >> 62);
+      int a = 0, z = m;
+      while (a < z) {  // first entry of the chunk that is >= the tail: its target (k_pm_bounds put it inside the chunk)
+        const int mid = (a + z) >> 1;
+        const uint64_t* row = pm_keys + mid * W;
+        // (words, length) order with every index a constant: a loop over W indexes the tail's registers by a variable and
+        // sends them to scratch memory -- with key_compare here the kernel took 8.6 ms
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < kMaxWords; ++w)
+          if (w < W && c == 0) {
+            const uint64_t x = row[w];
+            c = x < tail[w] ? -1 : (x > tail[w] ? 1 : 0);
+          }
+        if (c == 0) c = int(pm_len[mid]) < tl ? -1 : (int(pm_len[mid]) > tl ? 1 : 0);
+        if (c < 0) a = mid + 1; else z = mid;
+      }
+      bool ok = a < m;
+      if (ok) {  // the target must extend the tail: lcp >= tl
+        const uint64_t* row = pm_keys + a * W;
+        int l = 0;
+        bool more = true;
+#pragma unroll
+        for (int w = 0; w < kMaxWords; ++w)
+          if (w < W && more) {
+            const int c = lcp_word(row[w], tail[w]);
+            l += c;
+            more = c == 32;
+          }
+        const int mn = int(pm_len[a]) < tl ? int(pm_len[a]) : tl;
+        ok = (l < mn ? l : mn) >= tl;
+      }
+      if (!ok)
+        atomicOr(err, 2u);  // "Missing expansion?" (builder.cpp:95-96): every target is checked, as BG_VERIFY_CLOSURE used to ask for
+      else
+        atomicOr(&sbits[cur_b][a >> 6], 1ull << (a & 63));
+    }
+    __syncthreads();  // the tile is free again
+    cur_b = nb;
+    cur_row = nrow;
+    cur_cnt = ncnt;
+  }
+  __syncthreads();
+  const uint64_t nwords = (n + 63) / 64;
+  if (tid < 4 * (kPmChunk / 64)) {
+    const int b = tid / (kPmChunk / 64), w = tid % (kPmChunk / 64);
+    const uint64_t word = e0 / 64 + w;
+    unsigned long long* bits = b == 0 ? bA : b == 1 ? bC : b == 2 ? bG : bT;
+    if (word < nwords) bits[word] = sbits[b][w];
+  }
+}
+
 // marks[b*n + t] -> bit t of prev_b (OR-ed into the existing words)
 constexpr int kPackWordsPerWave = 16;
 
@@ -1759,10 +1962,41 @@ int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss) {
   BG_HIP(hipMemsetAsync(err.p, 0, 8, ctx->stream));
   DevBuf<uint32_t> dir;
   DevBuf<uint8_t> marks;
-  if (n_ent) {
+  const bool use_pre2 = ss->pre2.p && ss->pre2.n >= 2 * n_ent && !getenv("BG_PREV_FULL_SEARCH");
+  const char* pm = getenv("BG_PREV_MERGE");
+  // Off unless asked for (BG_PREV_MERGE=1): the merge gives the same bits (the tests run it) but, as written, not faster --
+  // chr20: 9.4 ms against 5.6 + 0.5 (directory).  A workgroup is a chain of dependent steps (bounds -> 40 KB of rows into LDS
+  // -> per round: stage 256 tails, ten-step LDS search) at three workgroups per CU: ~50 us each, 184 rounds of them.  The
+  // first version (two-word prefixes of the chunk in LDS, 16 KB, the 9 % of tails they do not settle searched in global
+  // memory) took 5.95 ms.  What it would need: chunks of 256 entries (7 workgroups per CU) with two-level bounds, and a
+  // thread taking a run of consecutive tails and walking forward from the previous target instead of searching afresh.
+  if (n_ent && ss->keys.p && !getenv("BG_PREV_FULL_SEARCH") && pm && pm[0] == '1') {
+    ctx->tic("prev_bits");
+    const uint64_t G = (n_ent + kPmChunk - 1) / kPmChunk;
+    DevBuf<uint64_t> F, bounds;
+    BG_TRY(F.alloc(ctx, 8));
+    BG_TRY(bounds.alloc(ctx, (G + 1) * 4));
+    k_pm_first_base<<<1, 64, 0, ctx->stream>>>(ss->keys.p, n_ent, ss->W, F.p);
+    BG_LAUNCH_CHECK();
+    k_pm_bounds<<<cdiv((G + 1) * 4, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->sizes.p, n_ent, ss->W, F.p, G, bounds.p);
+    BG_LAUNCH_CHECK();
+    const size_t lds = size_t(kPmChunk) * size_t(ss->W) * 8 + kPmChunk + 256 * size_t(ss->W) * 8 + 256;
+    static bool lds_set = false;
+    if (!lds_set) {
+      BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prev_merge), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 kPmChunk * kMaxWords * 8 + kPmChunk + 256 * kMaxWords * 8 + 256));
+      lds_set = true;
+    }
+    k_prev_merge<<<unsigned(G), 256, lds, ctx->stream>>>(ss->keys.p, ss->sizes.p, n_ent, ss->W, bounds.p,
+                                                        reinterpret_cast<unsigned long long*>(ss->bits[0].p),
+                                                        reinterpret_cast<unsigned long long*>(ss->bits[1].p),
+                                                        reinterpret_cast<unsigned long long*>(ss->bits[2].p),
+                                                        reinterpret_cast<unsigned long long*>(ss->bits[3].p), err.p);
+    BG_LAUNCH_CHECK();
+    ctx->toc(n_ent * (ss->W * 8 + 1 + 8));
+  } else if (n_ent) {
     ctx->tic("prev_bits");
     int bases = 0;
-    const bool use_pre2 = ss->pre2.p && ss->pre2.n >= 2 * n_ent && !getenv("BG_PREV_FULL_SEARCH");
     if (use_pre2) BG_TRY(build_prefix_dir_keys(ctx, ss->pre2.p, n_ent, 2, &dir, &bases));
     else BG_TRY(build_prefix_dir(ctx, ss, &dir, &bases));
     BG_TRY(marks.alloc(ctx, 4 * marks_stride(n_ent)));

@@ -817,9 +817,12 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
       const size_t ep0 = w.entry_positions.size(), mp0 = w.rc_mate_read_positions.size();
       BG_TRY(tracer_read_tables(ctx, w.ss, w.rm, w.d_ref_map, o.ignore_ambiguous_ref_pairs != 0, d_ent.p, n, lo + 1, &w.position_entries,
                                 &w.entry_positions, &w.rc_mate_read_positions));
-      if (ep0) std::inplace_merge(w.entry_positions.begin(), w.entry_positions.begin() + long(ep0), w.entry_positions.end());
-      if (mp0) std::inplace_merge(w.rc_mate_read_positions.begin(), w.rc_mate_read_positions.begin() + long(mp0), w.rc_mate_read_positions.end());
-      tables_sorted = true;
+      // (merging only while everything so far IS sorted: after a stretch that took the host path the final sort does it all --
+      // the flag never goes back to true)
+      if (tables_sorted) {
+        if (ep0) std::inplace_merge(w.entry_positions.begin(), w.entry_positions.begin() + long(ep0), w.entry_positions.end());
+        if (mp0) std::inplace_merge(w.rc_mate_read_positions.begin(), w.rc_mate_read_positions.begin() + long(mp0), w.rc_mate_read_positions.end());
+      }
       continue;
     }
     tables_sorted = false;
