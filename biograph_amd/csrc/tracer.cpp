@@ -27,6 +27,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -676,11 +677,24 @@ int download(bg_ctx* ctx, std::vector<T>& h, const T* d, size_t n) {
 // contiguous share, and rounds below a few thousand traces per thread run on fewer threads or inline.
 int g_tracer_threads = 0;
 
+// BG_TRACER_POOLS=n: several pools, the sessions that trace side by side (bgbinary discovery runs 24) dealt over them.  One by
+// default: with ten pools of 16 threads on the 256-thread host the chr20-shaped sample traced in 18.1 s instead of 12.0 --
+// the process spends 112 s instead of 50 s in the kernel (its threads meet on the address-space lock: heap growth and page
+// faults of the search states), so more host threads make the search slower, not faster.
+thread_local int tl_pool = 0;
 class HostPool {
  public:
+  static int count() {
+    static const int n = [] {
+      const char* e = getenv("BG_TRACER_POOLS");
+      int v = e ? atoi(e) : 1;
+      return v < 1 ? 1 : (v > 12 ? 12 : v);
+    }();
+    return n;
+  }
   static HostPool& get() {
-    static HostPool p;
-    return p;
+    static HostPool* pools = new HostPool[size_t(count())];  // live as long as the process
+    return pools[size_t(tl_pool) % size_t(count())];
   }
   int size() const { return int(workers_.size()) + 1; }
   // f(t) for t in [0, parts): part 0 on the calling thread, the rest on the workers
@@ -707,7 +721,7 @@ class HostPool {
     fn_ = nullptr;
   }
 
- private:
+ public:
   HostPool() {
     const char* e = getenv("BG_TRACER_THREADS");
     int nt = e ? atoi(e) : int(std::min(16u, std::thread::hardware_concurrency()));
@@ -724,6 +738,8 @@ class HostPool {
     cv_work_.notify_all();
     for (auto& th : workers_) th.join();
   }
+
+ private:
   void loop(int t) {
     uint64_t seen = 0;
     std::unique_lock<std::mutex> l(mu_);
@@ -1107,8 +1123,10 @@ void reverse_rec(const World& w, bg_trace_assembly_rec* a, int64_t end_pos, bool
 }  // namespace
 
 // reversable_tracer::assemble(start, limit) (reversable_tracer.cpp:76-145) with the push tracer.
+static std::atomic<int> g_next_pool{0};
 struct bg_tracer {
   World w;
+  int pool = g_next_pool.fetch_add(1);  // which of the host pools this session's big rounds use
   // the scaffold of the last work item (see bg_tracer_trace)
   std::vector<Extent> ext, ext_rc;
   std::vector<uint64_t> ext_hash;
@@ -1191,6 +1209,7 @@ extern "C" void bg_tracer_close(bg_tracer* t) { delete t; }
 extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
                                const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset,
                                int rev_comp, int pair_count, bg_trace_result** out) {
+  if (t) tl_pool = t->pool;
   if (!t || !out || (n_extents && (!ext_offset || !ext_seq || !ext_len))) return fail("bg_tracer_trace: null argument");
   World& w = t->w;
   const double t_call = now_seconds();
@@ -1900,6 +1919,7 @@ extern "C" uint64_t bg_trace_result_anchor_drops(const bg_trace_result* r) { ret
 extern "C" int bg_pop_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
                             const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset, int rev_comp,
                             const bg_trace_result* const* push, uint32_t n_push, bg_trace_result** out) {
+  if (t) tl_pool = t->pool;
   if (!t || !out || (n_extents && (!ext_offset || !ext_seq || !ext_len)) || (n_push && !push)) return fail("bg_pop_trace: null argument");
   World& w = t->w;
   BG_HIP(hipSetDevice(w.ctx->device));
