@@ -20,6 +20,34 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
+# algorithmic bytes of the stage a kernel family belongs to, from the step's counters
+SURVEY_8D_BYTES = {
+    "entries_dedup_build": lambda st: 28 * st["n_records"],
+    "prev_bits": lambda st: 2.625 * st["n_entries"],
+    "skm_count_lds": lambda st: 16 * st["n_kmers"],
+    "skm_generate": lambda st: 16 * st["n_kmers"],
+    "suffix_cover_count": lambda st: 28 * st["n_records"],
+    "correct_dfs": lambda st: 0.5 * st["n_bases"] + 8 * st["n_kmers"],
+}
+# kernel families of the step by stage of SURVEY.md section 8(d)
+STAGE_OF_FAMILY = [("S1 pack", ("pack_",)), ("S2 k-mer count", ("skm_", "kmer_")), ("S3 correct", ("correct_",)),
+                   ("S4+S5 suffix sort, dedup, prev bits, arrays", ("suffix_", "radix_", "entries_", "prev_bits", "seqset_"))]
+
+
+def stage_table(kernels, stats, steps):
+    """Per stage of SURVEY.md section 8(d): its algorithmic bytes over the device time of its kernel families, as a fraction of
+    the HBM peak (the radix passes belong to S4 except the two of the k-mer hash build, which are small)."""
+    alg = {"S1 pack": 1.25 * stats["n_bases"], "S2 k-mer count": 16 * stats["n_kmers"],
+           "S3 correct": 0.5 * stats["n_bases"] + 8 * stats["n_kmers"],
+           "S4+S5 suffix sort, dedup, prev bits, arrays": 28 * stats["n_records"] + 2.625 * stats["n_entries"]}
+    out = {}
+    for stage, prefixes in STAGE_OF_FAMILY:
+        ms = sum(v["ms_per_step"] for k, v in kernels.items() if k.startswith(prefixes))
+        if ms > 0:
+            out[stage] = {"ms_per_step": round(ms, 2), "algorithmic_GB": round(alg[stage] / 1e9, 2),
+                          "frac_of_hbm_peak": round(alg[stage] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    return out
+
 
 def cpu_baseline(ctx, sample_genome, coverage, read_len, seed, dev):
     """The CPU restatement of the path (oracle/, kind="port": the reference itself needs Bazel + Boost + abseil,
@@ -307,6 +335,15 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
     t_ref = time.perf_counter() - t0
     marked = int((out[:n] & 63 != 0).sum().item())
     unique = int(((out[:n] & 63) == 1).sum().item())
+    # N_pfd and N_drop of the walk's algorithmic bytes (52 N_pfd + 60 N_drop), counted by the same
+    # kernel once more with the measurement counters on (untimed: two contended atomics)
+    cnt2 = (C.c_uint64 * 2)()
+    out2 = torch.empty_like(out)
+    capi.check(L.bg_walk_counters(ctx.h, 1, None))
+    capi.check(L.bg_ref_map_build(ctx.h, ss.h, vp(genome.data_ptr()), 1, es, ez, 4096, vp(out2.data_ptr())))
+    capi.check(L.bg_walk_counters(ctx.h, 0, cnt2))
+    ref_counts = (int(cnt2[0]), int(cnt2[1]))
+    del out2
     # branch trace: assemblies of 1000 reference bases, each preceded by a 256-base warm-up walk from the
     # empty frontier (events inside the warm-up are not counted)
     A, WARM = 1000, 256
@@ -335,6 +372,13 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
                                        vp(n_out.data_ptr()), vp(ob.data_ptr()), vp(oe.data_ptr()), vp(osz.data_ptr())))
     torch.cuda.synchronize()
     t_br = time.perf_counter() - t0
+    capi.check(L.bg_walk_counters(ctx.h, 1, None))
+    capi.check(L.bg_branch_trace_batch(ctx.h, ss.h, na, vp(soff.data_ptr()), vp(codes.data_ptr()), vp(foff.data_ptr()),
+                                       vp(fb.data_ptr()), vp(fe.data_ptr()), vp(fs.data_ptr()), 105, cap,
+                                       vp(ev_off.data_ptr()), vp(ev_base.data_ptr()), vp(n_ev.data_ptr()),
+                                       vp(n_out.data_ptr()), vp(ob.data_ptr()), vp(oe.data_ptr()), vp(osz.data_ptr())))
+    capi.check(L.bg_walk_counters(ctx.h, 0, cnt2))
+    br_counts = (int(cnt2[0]), int(cnt2[1]))
     k = torch.minimum(n_ev, torch.full_like(n_ev, cap))
     mask = torch.arange(cap, device=dev)[None, :] < k[:, None]
     sites = int(((ev_off.view(na, cap) >= WARM) & mask).sum().item())
@@ -411,7 +455,22 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
     ss.free()
     pfd_ref = 2 * G + 2 * 256 * (G // 4096 + 1)
     pfd_br = na * (A + WARM) * 4
-    return {"readmap": {"seconds": round(t_rm, 4), "read_ids": n_ids, "read_ids_per_s": round(n_ids / t_rm / 1e6, 1),
+
+    def walk_roofline(kernel, counts, seconds):
+        # one push_front_drop without a drop = 52 bytes, every iteration of its drop loop + 60
+        n_pfd, n_drop = counts
+        alg = 52 * n_pfd + 60 * n_drop
+        r = {"bound": "hbm", "kernel": kernel, "n_pfd": n_pfd, "n_drop": n_drop, "algorithmic_bytes": alg,
+             "achieved": round(alg / seconds / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(alg / seconds / 1e9 / HBM_PEAK_GBS, 4), "seconds": round(seconds, 4),
+             "limiter": "dependent random 64-byte sectors: a chain is one push_front_drop after the other (2 rank look-ups of 3 "
+                        "words each + sizes per call), %d chains in flight" % (2 * (G // 4096 + 1) if kernel == "k_ref_map_chains" else na)}
+        r.update(pmc_traffic_walk(kernel, seconds * 1e3))
+        return r
+    roof_ref = walk_roofline("k_ref_map_chains", ref_counts, t_ref)
+    roof_br = walk_roofline("k_branch_trace", br_counts, t_br)
+    return {"roofline": roof_ref, "roofline_branch_trace": roof_br,
+            "readmap": {"seconds": round(t_rm, 4), "read_ids": n_ids, "read_ids_per_s": round(n_ids / t_rm / 1e6, 1),
                         "unit": "M read ids/s (paired, both orientations)"},
             "ref_map": {"seconds": round(t_ref, 4), "ref_bases_per_s": round(2 * G / t_ref / 1e9, 3),
                         "unit": "Gbases/s (both strands)", "push_front_drop_per_s": round(pfd_ref / t_ref / 1e9, 3),
@@ -562,6 +621,24 @@ def pmc_traffic(family, avg_launch_ms):
                     "traffic_write": int(e.get("write_bytes_per_launch", 0)),
                     "traffic_source": os.path.basename(files[-1]) + " (kernel name and duration match this run)"}
     return {"traffic": None, "traffic_source": "%s has no PMC entry for %s" % (os.path.basename(files[-1]), pat)}
+
+
+def pmc_traffic_walk(kernel, live_ms):
+    """HBM traffic of a walk kernel from the committed counter profile of the discover leg (tools/profile_walk.sh ->
+    profiles/r*_chr20_walk_rocprofv3_summary.json): attached when the profile's duration agrees with this run's within 25 %."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_chr20_walk_rocprofv3_summary.json")))
+    if not files:
+        return {"traffic": None, "traffic_source": "no committed walk profile"}
+    for e in json.load(open(files[-1])):
+        if kernel in e["kernel"] and "fetch_bytes_per_launch_raw" in e:
+            ms = e["avg_us"] / 1e3
+            if abs(ms - live_ms) > 0.25 * live_ms:
+                return {"traffic": None, "traffic_source": "%s: %s took %.2f ms there, %.2f ms here" % (os.path.basename(files[-1]), kernel, ms, live_ms)}
+            return {"traffic": int(e["fetch_bytes_per_launch_x2"] + e.get("write_bytes_per_launch", 0)),
+                    "traffic_fetch_raw": int(e["fetch_bytes_per_launch_raw"]), "traffic_write": int(e.get("write_bytes_per_launch", 0)),
+                    "traffic_source": os.path.basename(files[-1]) + " (kernel name and duration match this run)"}
+    return {"traffic": None, "traffic_source": "%s has no PMC entry for %s" % (os.path.basename(files[-1]), kernel)}
 
 
 def self_launch(n, json_fd):
@@ -821,6 +898,15 @@ def main():
                         "limiter": LIMITER_OF_FAMILY.get(fam["name"], "hbm random access (latency / line granularity)")}
         if roofline and args.shape == "chr20" and not args.genome_len:
             roofline.update(pmc_traffic(roofline["kernel"], roofline["avg_launch_ms"]))
+        # The same kernel against SURVEY.md section 8(d)'s own bytes for its stage (`frac` above prices the kernel's row
+        # layout -- what it must move as the data is laid out; this one prices what the stage stands for in the survey's
+        # formula: S4 = 28 bytes per suffix record, the reference's 14-byte record written and read once).
+        if roofline:
+            s8 = SURVEY_8D_BYTES.get(roofline["kernel"])
+            if s8:
+                b8 = s8(stats)
+                roofline["algorithmic_bytes_survey_8d"] = int(b8)
+                roofline["frac_survey_8d"] = round(b8 / (roofline["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         total_ms = sum(t["ms"] for t in timings) or 1.0
         kernels = {t["name"]: {"ms_per_step": round(t["ms"] / max(args.steps, 1), 3),
                                "launches_per_step": t["launches"] / max(args.steps, 1),
@@ -860,7 +946,8 @@ def main():
             "build_roofline": {"algorithmic_bytes_per_step": int(alg), "bytes_per_base": round(alg / max(stats["n_bases"], 1), 2),
                                "achieved_GBps": round(alg / step_s / 1e9, 1),
                                "frac_of_hbm_peak": round(alg / step_s / 1e9 / (HBM_PEAK_GBS * world), 5),
-                               "kernel_time_frac_of_wall": round(total_ms / 1e3 / elapsed, 3)},
+                               "kernel_time_frac_of_wall": round(total_ms / 1e3 / elapsed, 3),
+                               "stages_survey_8d": stage_table(kernels, stats, args.steps)},
             "end_to_end_from_fastq": e2e, "discover": discover, "sharded_readmap": sharded_rm, "counters": stats, "kernels": kernels,
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())

@@ -723,6 +723,9 @@ struct SeqsetView {
   uint64_t fixed[5];
   const uint8_t* min1;      // min of shared[] per 64 entries   (less_than_search k_factor1)
   const uint8_t* min2;      // min of shared[] per 4096 entries (k_factor2)
+  // measurement only (bg_walk_counters): [0] += push_front_drop calls, [1] += iterations of its drop loop -- the N_pfd and
+  // N_drop of SURVEY.md section 8(d)'s walk bytes (52 N_pfd + 60 N_drop).  Null in every normal run.
+  unsigned long long* walk_counters = nullptr;
 
   BG_HD uint64_t count(int b, uint64_t i) const {  // bitcount.h:218-270
     uint64_t nw = (n + 63) >> 6;
@@ -793,8 +796,14 @@ struct SeqsetView {
     uint32_t octx = size;
     uint64_t sb = count(b, o_begin), se = count(b, o_end);
     *ob = 0; *oe = 0; *os = 0;
+#ifdef __HIP_DEVICE_COMPILE__
+    if (walk_counters) atomicAdd(&walk_counters[0], 1ull);
+#endif
     if (octx < min_ctx) return;
     while (sb == se || (sb + 1 == se && sizes[fx + sb] < octx + 1)) {
+#ifdef __HIP_DEVICE_COMPILE__
+      if (walk_counters) atomicAdd(&walk_counters[1], 1ull);
+#endif
       // No entry starts with base b at all (a seqset of a two-letter genome, a toy input): with min_ctx == 0 the
       // reference's loop reaches the whole range and spins there for ever (seqset.cpp:368-421 has no exit for
       // it); the extension simply does not exist.  Found by tools/fuzz_parity.py (FUZZ_WALK).

@@ -9,6 +9,9 @@
 
 namespace bg {
 
+// bg_walk_counters: two device counters every walk kernel of this process adds to while they are switched on
+static unsigned long long* g_walk_counters = nullptr;
+
 static SeqsetView make_view(const bg_seqset* ss) {
   SeqsetView v;
   v.n = ss->n;
@@ -22,6 +25,7 @@ static SeqsetView make_view(const bg_seqset* ss) {
   for (int b = 0; b < 5; ++b) v.fixed[b] = ss->fixed[b];
   v.min1 = ss->min1.p;
   v.min2 = ss->min2.p;
+  v.walk_counters = g_walk_counters;
   return v;
 }
 
@@ -1302,3 +1306,24 @@ int tracer_read_tables(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, c
 
 }  // namespace bg
 
+
+// Measurement: while on, every push_front_drop of every walk kernel of this process adds to two device counters (calls,
+// iterations of the drop loop: N_pfd and N_drop of SURVEY.md section 8(d)'s walk bytes).  on = 1 zeroes and switches them on,
+// on = 0 reads them into h_out2 (may be NULL) and switches them off.  Atomics on two addresses: never inside a timed region.
+extern "C" int bg_walk_counters(bg_ctx* ctx, int on, uint64_t* h_out2) {
+  if (!ctx) return BG_EINVAL;
+  BG_HIP(hipSetDevice(ctx->device));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  static unsigned long long* buf = nullptr;
+  if (!buf) BG_HIP(hipMalloc(reinterpret_cast<void**>(&buf), 16));
+  if (on) {
+    BG_HIP(hipMemset(buf, 0, 16));
+    bg::g_walk_counters = buf;
+    return BG_OK;
+  }
+  unsigned long long h[2] = {0, 0};
+  BG_HIP(hipMemcpy(h, buf, 16, hipMemcpyDeviceToHost));
+  bg::g_walk_counters = nullptr;
+  if (h_out2) { h_out2[0] = h[0]; h_out2[1] = h[1]; }
+  return BG_OK;
+}

@@ -211,6 +211,11 @@ int bg_pop_front_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n, const uint6
 int bg_find_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n, const uint8_t* d_seq,
                   const uint64_t* d_offs, uint64_t* d_obegin, uint64_t* d_oend);
 
+/* Measurement only: counts the push_front_drop calls and the iterations of its drop loop (seqset.cpp:368-421) made by the walk
+ * kernels of this process between on = 1 and on = 0 (h_out2[0] = calls, [1] = drop iterations): N_pfd and N_drop of the
+ * walk's algorithmic bytes, 52 N_pfd + 60 N_drop.  Two contended atomics: not for timed runs. */
+int bg_walk_counters(bg_ctx* ctx, int on, uint64_t* h_out2 /* may be NULL */);
+
 /* ---- G2/G3/G7: frontier walks.  A frontier is a set of at most 16 ranges; frontier f owns ranges
  * [d_foff[f], d_foff[f+1]) of (d_begin, d_end, d_size).  Output frontiers use slots f*16 .. f*16+15. */
 /* One step of push_to_pair_discover::trace_one_base (graph_discover/push_to_pair.cpp:159-240) for every
