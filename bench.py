@@ -64,7 +64,10 @@ def cpu_baseline(ctx, sample_genome, coverage, read_len, seed, dev):
     # The port's stages have serial sections (the merges behind the per-partition counts, the readmap's row order) and do not
     # get faster beyond ~16 threads on the GPU box's 2 x 64-core host (profiles/r03_cpu_baseline_thread_sweep.txt: 13.3 s on
     # 16 threads, 14.2 s on 64, 16.9 s on 256 for this sample): the baseline runs on the count it is fastest at.
-    threads = min(O.hardware_threads(), int(os.environ.get("BG_CPU_BASELINE_THREADS", "16")))
+    # (round 4: the readmap's look-ups, row sort and first pass and the entry set's dedup / concatenation run on the threads too;
+    # the stages are flat from 16 to 256 threads on the 2 x 64-core host -- 10.4 / 10.3 / 10.1 / 10.8 s on 16 / 64 / 128 / 256,
+    # profiles/r04_cpu_baseline_thread_sweep.txt -- so the baseline runs on every hardware thread, as SURVEY.md section 8d asks)
+    threads = min(O.hardware_threads(), int(os.environ.get("BG_CPU_BASELINE_THREADS", str(O.hardware_threads()))))
     dseq, doffs, n, genome = synth.make_reads(genome_len=sample_genome, coverage=coverage, read_len=read_len, seed=seed,
                                               device=dev, return_genome=True)
     t0 = time.perf_counter()
@@ -83,7 +86,7 @@ def cpu_baseline(ctx, sample_genome, coverage, read_len, seed, dev):
     oss = O.Seqset.from_entries(ent, threads=threads)
     stages["make_seqset"] = time.perf_counter() - t0
     t0 = time.perf_counter()
-    orm = O.Readmap.from_packed(oss, ent, cseq, coffs, True)
+    orm = O.Readmap.from_packed(oss, ent, cseq, coffs, True, threads=threads)
     stages["make_readmap"] = time.perf_counter() - t0
     dt = sum(stages.values())
     bases = int(offs[-1])
@@ -338,12 +341,15 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
     # N_pfd and N_drop of the walk's algorithmic bytes (52 N_pfd + 60 N_drop), counted by the same
     # kernel once more with the measurement counters on (untimed: two contended atomics)
     cnt2 = (C.c_uint64 * 2)()
-    out2 = torch.empty_like(out)
-    capi.check(L.bg_walk_counters(ctx.h, 1, None))
-    capi.check(L.bg_ref_map_build(ctx.h, ss.h, vp(genome.data_ptr()), 1, es, ez, 4096, vp(out2.data_ptr())))
-    capi.check(L.bg_walk_counters(ctx.h, 0, cnt2))
-    ref_counts = (int(cnt2[0]), int(cnt2[1]))
-    del out2
+    count_walk = os.environ.get("BG_BENCH_NO_WALK_COUNTERS") != "1"  # (off under the profiler: the counting run would be averaged in)
+    ref_counts = None
+    if count_walk:
+        out2 = torch.empty_like(out)
+        capi.check(L.bg_walk_counters(ctx.h, 1, None))
+        capi.check(L.bg_ref_map_build(ctx.h, ss.h, vp(genome.data_ptr()), 1, es, ez, 4096, vp(out2.data_ptr())))
+        capi.check(L.bg_walk_counters(ctx.h, 0, cnt2))
+        ref_counts = (int(cnt2[0]), int(cnt2[1]))
+        del out2
     # branch trace: assemblies of 1000 reference bases, each preceded by a 256-base warm-up walk from the
     # empty frontier (events inside the warm-up are not counted)
     A, WARM = 1000, 256
@@ -372,13 +378,15 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
                                        vp(n_out.data_ptr()), vp(ob.data_ptr()), vp(oe.data_ptr()), vp(osz.data_ptr())))
     torch.cuda.synchronize()
     t_br = time.perf_counter() - t0
-    capi.check(L.bg_walk_counters(ctx.h, 1, None))
-    capi.check(L.bg_branch_trace_batch(ctx.h, ss.h, na, vp(soff.data_ptr()), vp(codes.data_ptr()), vp(foff.data_ptr()),
-                                       vp(fb.data_ptr()), vp(fe.data_ptr()), vp(fs.data_ptr()), 105, cap,
-                                       vp(ev_off.data_ptr()), vp(ev_base.data_ptr()), vp(n_ev.data_ptr()),
-                                       vp(n_out.data_ptr()), vp(ob.data_ptr()), vp(oe.data_ptr()), vp(osz.data_ptr())))
-    capi.check(L.bg_walk_counters(ctx.h, 0, cnt2))
-    br_counts = (int(cnt2[0]), int(cnt2[1]))
+    br_counts = None
+    if count_walk:
+        capi.check(L.bg_walk_counters(ctx.h, 1, None))
+        capi.check(L.bg_branch_trace_batch(ctx.h, ss.h, na, vp(soff.data_ptr()), vp(codes.data_ptr()), vp(foff.data_ptr()),
+                                           vp(fb.data_ptr()), vp(fe.data_ptr()), vp(fs.data_ptr()), 105, cap,
+                                           vp(ev_off.data_ptr()), vp(ev_base.data_ptr()), vp(n_ev.data_ptr()),
+                                           vp(n_out.data_ptr()), vp(ob.data_ptr()), vp(oe.data_ptr()), vp(osz.data_ptr())))
+        capi.check(L.bg_walk_counters(ctx.h, 0, cnt2))
+        br_counts = (int(cnt2[0]), int(cnt2[1]))
     k = torch.minimum(n_ev, torch.full_like(n_ev, cap))
     mask = torch.arange(cap, device=dev)[None, :] < k[:, None]
     sites = int(((ev_off.view(na, cap) >= WARM) & mask).sum().item())
@@ -458,6 +466,8 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
 
     def walk_roofline(kernel, counts, seconds):
         # one push_front_drop without a drop = 52 bytes, every iteration of its drop loop + 60
+        if counts is None:
+            return None
         n_pfd, n_drop = counts
         alg = 52 * n_pfd + 60 * n_drop
         r = {"bound": "hbm", "kernel": kernel, "n_pfd": n_pfd, "n_drop": n_drop, "algorithmic_bytes": alg,

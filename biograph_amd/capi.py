@@ -74,7 +74,7 @@ SYMBOLS = [
     "bg_kmerset_distinct", "bg_kmerset_instances", "bg_kmerset_download", "bg_kmerset_free", "bg_correct_reads",
     "bg_seqset_build", "bg_create_params_default", "bg_create", "bg_seqset_size", "bg_seqset_max_len",
     "bg_seqset_part", "bg_seqset_arrays", "bg_seqset_entries", "bg_seqset_write", "bg_seqset_open",
-    "bg_seqset_from_arrays", "bg_seqset_free", "bg_walk_counters", "bg_push_front_batch", "bg_push_front_drop_batch", "bg_pop_front_batch", "bg_find_batch",
+    "bg_seqset_from_arrays", "bg_seqset_free", "bg_walk_counters", "bg_ref_map_write", "bg_ref_map_read", "bg_push_front_batch", "bg_push_front_drop_batch", "bg_pop_front_batch", "bg_find_batch",
     "bg_dev_alloc", "bg_dev_free", "bg_dev_upload", "bg_dev_download",
     "bg_trace_one_base_batch", "bg_ref_walk_entries", "bg_tracer_extend_batch", "bg_trace_options_default",
     "bg_push_trace", "bg_pop_trace", "bg_trace_result_anchor_drops", "bg_push_front_chains", "bg_sha1_file", "bg_tracer_open", "bg_tracer_clone", "bg_tracer_trace", "bg_tracer_close", "bg_reference_build", "bg_bwt_build", "bg_trace_result_size", "bg_trace_result_get", "bg_trace_result_stats", "bg_trace_result_free", "bg_assemblies_process", "bg_trace_result_new", "bg_trace_result_add", "bg_trace_result_var_count", "bg_trace_result_var", "bg_coverage_options_default", "bg_assemblies_coverage", "bg_coverage_open", "bg_coverage_run", "bg_coverage_close", "bg_trace_result_coverage", "bg_trace_result_set_coverage", "bg_assemblies_rvg_exclude", "bg_vcf_record", "bg_walk_chains", "bg_walk_chains_batch", "bg_trace_result_ml", "bg_trace_result_set_ml", "bg_branch_trace_batch", "bg_ref_map_build",

@@ -860,3 +860,41 @@ extern "C" int bg_create_sample(bg_ctx* ctx, const uint8_t* d_seq, const uint64_
   if (!out_rm) { set_error("bg_create_sample: null argument"); return BG_EINVAL; }
   return create_impl(ctx, d_seq, d_offs, n_reads, p, is_paired, out, out_rm, stats);
 }
+
+// ---- `bgbinary discovery --ref-map FILE` (biograph_variants.cpp:171,643-666): the reference map kept between runs.  The
+// reference's file is a spiral container holding one packed_vector<unsigned, 8> (ref_map.cpp:24-38: one byte per seqset entry =
+// [fwd flag | rev flag | count:6], ref_map.h:49-53): file_info.json, part_info.json ("packed_vector" 1.0.0), packed_data (the
+// bytes, in 64-bit words), packed_vector.json.
+extern "C" int bg_ref_map_write(const char* path, const uint8_t* h_map, uint64_t n, int argc, const char* const* argv) {
+  if (!path || (n && !h_map)) { set_error("bg_ref_map_write: null argument"); return BG_EINVAL; }
+  std::vector<ZipPart> parts;
+  parts.push_back(ZipPart{"file_info.json", file_info_json(make_uuid(), argc, argv), false});
+  parts.push_back(ZipPart{"part_info.json", version_json("packed_vector", 1, 0, 0), false});
+  std::string data(size_t((n + 7) / 8 * 8), '\0');
+  if (n) memcpy(&data[0], h_map, n);
+  parts.push_back(ZipPart{"packed_data", data, true});
+  char js[96];
+  snprintf(js, sizeof js, "{\"value_count\":%llu,\"value_width_bits\":8}", (unsigned long long)n);
+  parts.push_back(ZipPart{"packed_vector.json", js, false});
+  return spiral_zip_write(path, parts);
+}
+
+extern "C" int bg_ref_map_read(const char* path, uint8_t* h_map_out, uint64_t n) {
+  if (!path || (n && !h_map_out)) { set_error("bg_ref_map_read: null argument"); return BG_EINVAL; }
+  std::map<std::string, std::string> parts;
+  BG_TRY(spiral_zip_read(path, &parts));
+  auto js = parts.find("packed_vector.json");
+  auto data = parts.find("packed_data");
+  if (js == parts.end() || data == parts.end()) { set_error("%s: not a reference map (no packed_vector at its root)", path); return BG_EINVAL; }
+  unsigned long long count = 0, width = 0;
+  const size_t pc = js->second.find("\"value_count\":"), pw = js->second.find("\"value_width_bits\":");
+  if (pc != std::string::npos) count = strtoull(js->second.c_str() + pc + 14, nullptr, 10);
+  if (pw != std::string::npos) width = strtoull(js->second.c_str() + pw + 19, nullptr, 10);
+  if (width != 8) { set_error("%s: values of %llu bits, a reference map holds 8", path, width); return BG_EINVAL; }
+  if (count != n || data->second.size() < n) {  // ref_map.cpp:37 CHECK_EQ(m_ref_map->size(), m_seqset->size())
+    set_error("%s: a reference map of %llu entries, the seqset has %llu", path, count, (unsigned long long)n);
+    return BG_EINVAL;
+  }
+  if (n) memcpy(h_map_out, data->second.data(), n);
+  return BG_OK;
+}

@@ -1111,14 +1111,47 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   void *d_ref = nullptr, *d_map = nullptr;
   check(bg_dev_alloc(ctx, flat_codes.size() ? flat_codes.size() : 1, &d_ref), "bg_dev_alloc");
   check(bg_dev_alloc(ctx, n ? n : 1, &d_map), "bg_dev_alloc");
-  check(bg_dev_upload(ctx, d_ref, flat_codes.data(), flat_codes.size()), "upload");
-  check(bg_ref_map_build(ctx, ss, static_cast<const uint8_t*>(d_ref), flat_start.size(), flat_start.data(), flat_size.data(), 0,
-                         static_cast<uint8_t*>(d_map)), "bg_ref_map_build");
+  // --ref-map FILE (biograph_variants.cpp:171,643-666): the reference map kept between runs -- built into FILE.new and
+  // renamed when FILE does not exist, then opened; "no validity checking is done to make sure this matches the current
+  // reference and seqset" beyond its size (ref_map.cpp: CHECK_EQ(m_ref_map->size(), m_seqset->size()))
+  const std::string ref_map_file = a.get("ref-map");
+  if (ref_map_file.empty() || !exists(ref_map_file)) {
+    check(bg_dev_upload(ctx, d_ref, flat_codes.data(), flat_codes.size()), "upload");
+    check(bg_ref_map_build(ctx, ss, static_cast<const uint8_t*>(d_ref), flat_start.size(), flat_start.data(), flat_size.data(), 0,
+                           static_cast<uint8_t*>(d_map)), "bg_ref_map_build");
+    if (!ref_map_file.empty()) {
+      std::vector<uint8_t> h(n);
+      check(bg_dev_download(ctx, h.data(), d_map, n), "download");
+      const std::string fresh = ref_map_file + ".new";
+      unlink(fresh.c_str());
+      fprintf(stderr, "Generating refmap in %s\n", fresh.c_str());
+      const char* av[] = {"bgbinary", "discovery"};
+      check(bg_ref_map_write(fresh.c_str(), h.data(), n, 2, av), "bg_ref_map_write");
+      if (rename(fresh.c_str(), ref_map_file.c_str()) != 0) die("Could not rename " + fresh);
+    }
+  }
+  if (!ref_map_file.empty()) {
+    fprintf(stderr, "Opening refmap %s\n", ref_map_file.c_str());
+    std::vector<uint8_t> h(n ? n : 1);
+    check(bg_ref_map_read(ref_map_file.c_str(), h.data(), n), "bg_ref_map_read");
+    check(bg_dev_upload(ctx, d_map, h.data(), n), "upload");
+  }
   bg_dev_free(ctx, d_ref);
   const double t_refmap = now_s() - t0;
   bg_trace_options opt;
   bg_trace_options_default(&opt);
   opt.min_overlap = min_overlap;
+  if (a.has("min-pop-overlap")) {  // biograph_variants.cpp:198-200,687
+    const long long v = atoll(a.get("min-pop-overlap").c_str());
+    if (v < 1) die("discovery: --min-pop-overlap must be at least 1");
+    opt.min_pop_overlap = uint64_t(v);
+  }
+  // --assemblies-out FILE (biograph_variants.cpp:166,540-565,781-788): every assembly that enters the pipeline, behind its
+  // sorter (report_discovered_assemblies, pipeline.cpp:22-54), as CSV
+  std::string asm_csv;
+  const bool want_csv = a.has("assemblies-out") && !a.get("assemblies-out").empty();
+  if (want_csv)
+    asm_csv = "scaffold_name,left_offset,right_offset,left_anchor_len,right_anchor_len,aid,score,min_overlap,ref_seq,seq,generated_by\n";
   opt.max_pair_distance = uint64_t(max_pair_distance);
   if (a.has("scaffold-split-size")) {  // assemble_options::scaffold_split_size (the size of trace_ref's pieces)
     const long long sp = atoll(a.get("scaffold-split-size").c_str());
@@ -1298,6 +1331,25 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     t_trace += now_s() - t1;
     t1 = now_s();
     bg_trace_result *sections = nullptr, *kept = nullptr;
+    if (want_csv) {
+      bg_trace_result* sorted = nullptr;
+      check(bg_assemblies_process(items.data(), uint32_t(items.size()), es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()),
+                                  &opt, BG_STEP_SORT, &sorted), "bg_assemblies_process");
+      for (uint64_t i = 0; i < bg_trace_result_size(sorted); ++i) {
+        bg_trace_assembly x;
+        check(bg_trace_result_get(sorted, i, &x), "bg_trace_result_get");
+        char head[256];
+        snprintf(head, sizeof head, "%s,%lld,%lld,%d,%d,%llu,%lld,%u,", rec.first.c_str(), (long long)x.left_offset, (long long)x.right_offset,
+                 x.left_anchor_len, x.right_anchor_len, (unsigned long long)x.assembly_id, (long long)x.score, x.min_overlap);
+        asm_csv += head;
+        if (x.left_offset >= 0 && x.right_offset >= x.left_offset && uint64_t(x.right_offset) <= seq.size())
+          asm_csv.append(seq, size_t(x.left_offset), size_t(x.right_offset - x.left_offset));  // scaffold::subscaffold_str: N in the gaps
+        asm_csv += ",";
+        asm_csv.append(x.seq, x.seq_len);
+        asm_csv += x.from_pop ? ",POP\n" : ",PUSH\n";
+      }
+      bg_trace_result_free(sorted);
+    }
     check(bg_assemblies_process(items.data(), uint32_t(items.size()), es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()),
                                 &opt, BG_STEP_PIPELINE, &sections), "bg_assemblies_process");
     for (auto* r : items) bg_trace_result_free(r);
@@ -1331,6 +1383,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   }
   bg_dev_free(ctx, d_map);
   write_file(a.get("out"), vcf);
+  if (want_csv) write_file(a.get("assemblies-out"), asm_csv);
   fprintf(stderr, "%llu variants over %zu scaffold(s) in %llu piece(s) x 2 directions on %d tracer session(s), min overlap %u: %.2f s (refmap %.2f, sessions %.2f, tracing %.2f "
                   "[%llu assemblies], pipeline %.2f [%llu sections], coverage + genotype %.2f); pop tracer %s [%llu of the assemblies]\n",
           (unsigned long long)n_var, recs.size(), (unsigned long long)pieces, n_threads, min_overlap, now_s() - t0, t_refmap, t_open, t_trace,
@@ -1344,8 +1397,15 @@ static int cmd_discovery(int argc, char** argv) {
   mallopt(M_MMAP_THRESHOLD, 1 << 30);
   mallopt(M_TOP_PAD, 256 << 20);
   Args a = parse(argc, argv, 2, {"reads", "ref", "out", "sample", "min-overlap", "max-pair-distance", "bed", "engine", "max-ploids",
-                                 "enable-pop-tracer", "threads", "ml-features", "scaffold-split-size", "simple-gt", "rvg-exclude"});
+                                 "enable-pop-tracer", "threads", "ml-features", "scaffold-split-size", "simple-gt", "rvg-exclude",
+                                 "force", "ref-map", "min-pop-overlap", "assemblies-out"});
   if (!a.has("reads") || !a.has("ref") || !a.has("out")) die("discovery: --in S.bg, --ref and --out are required");
+  // biograph_variants.cpp:216-232: an output that exists is only replaced with -f / --force
+  for (const char* o : {"out", "assemblies-out"})
+    if (a.has(o) && !a.get(o).empty() && a.get(o) != "-" && exists(a.get(o))) {
+      if (!a.has("force")) die("Refusing to overwrite '" + a.get(o) + "'. Use -f to override.");
+      unlink(a.get(o).c_str());
+    }
   std::string bgdir = a.get("reads");
   // --engine push (default): the reference's discovery engine -- push tracer, anchor_dropper, pair_counter, the
   // serial pipeline, calc_coverage, simple_genotype_filter, ploidless VCF records (biograph_variants.cpp:598-830);

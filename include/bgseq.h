@@ -259,6 +259,12 @@ int bg_ref_map_build(bg_ctx* ctx, const bg_seqset* ss, const uint8_t* d_ref_code
                      const uint64_t* h_ext_start, const uint64_t* h_ext_size, uint32_t chain_bases,
                      uint8_t* d_out);
 
+/* The reference map as a file (`biograph discovery --ref-map`, biograph_variants.cpp:171,643-666): a spiral container with one
+ * packed_vector<unsigned, 8>, one byte per seqset entry as bg_ref_map_build leaves them (ref_map.cpp:24-38).  HOST arrays.
+ * bg_ref_map_read fails when the file holds another number of entries (ref_map.cpp:37). */
+int bg_ref_map_write(const char* path, const uint8_t* h_map, uint64_t n, int argc, const char* const* argv);
+int bg_ref_map_read(const char* path, uint8_t* h_map_out, uint64_t n);
+
 /* ---- Readmap: make_readmap::create_from_reads
  * (modules/bio_mapred/make_readmap.cpp:120-392) over the corrected reads of one sample.
  * `ss` must hold resident entry keys (a seqset built in this process by bg_seqset_build / bg_create);

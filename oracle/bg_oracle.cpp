@@ -21,7 +21,9 @@
 #include <map>
 #include <queue>
 #include <set>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -750,17 +752,87 @@ static bool row_less(const LoopRow& a, const LoopRow& b) {  // make_readmap.h:18
 }
 
 // records: record r holds reads [rec_first[r], rec_first[r+1]) (1 or 2 corrected sequences).
+template <class F>
+static void rm_parallel(uint64_t n, unsigned T, F f) {  // f(thread, lo, hi) on T threads (T <= 1: inline)
+  if (T <= 1 || n < 4096) { f(0u, uint64_t(0), n); return; }
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < T; ++t) th.emplace_back([=, &f] { f(t, n * t / T, n * (t + 1) / T); });
+  for (auto& x : th) x.join();
+}
+
+// threads > 1 (the CPU baseline of bench.py): the entry look-ups of the records, the row sort (stable sorts of equal shares,
+// merged in order: the result of ONE stable sort) and the first pass run on `threads` threads; the claim pass stays
+// sequential as in the reference (make_readmap.cpp:330-392).  Same readmap as threads = 1 (tests/test_oracle_mt.py).
 static Readmap* readmap_build(const Seqset& ss, const std::vector<std::string>& entries,
                               const std::vector<std::string>& reads, const std::vector<uint64_t>& rec_first,
-                              bool is_paired, bool canonicalize, std::string* err) {
+                              bool is_paired, bool canonicalize, std::string* err, unsigned threads = 1) {
+  std::mutex err_mu;
   auto find_existing = [&](const std::string& s) -> uint64_t {  // seqset.cpp:173-188 == first entry with prefix s
     size_t t = std::lower_bound(entries.begin(), entries.end(), s) - entries.begin();
-    if (t >= entries.size() || entries[t].compare(0, s.size(), s) != 0) { *err = "read not found in seqset: " + s; return 0; }
+    if (t >= entries.size() || entries[t].compare(0, s.size(), s) != 0) {
+      std::lock_guard<std::mutex> l(err_mu);
+      *err = "read not found in seqset: " + s;
+      return 0;
+    }
     return t;
   };
   std::vector<LoopRow> rows;
   unsigned max_len = 0;
-  for (size_t r = 0; r + 1 < rec_first.size(); ++r) {
+  const size_t n_rec = rec_first.empty() ? 0 : rec_first.size() - 1;
+  if (threads > 1) {
+    // a record's rows have a place of their own: 4 for a pair, 2 for a single read
+    std::vector<uint64_t> slot(n_rec + 1, 0);
+    for (size_t r = 0; r < n_rec; ++r) {
+      const size_t cnt = rec_first[r + 1] - rec_first[r];
+      if (cnt != 1 && !(cnt == 2 && is_paired)) { *err = "Unexpected read pairing"; return nullptr; }
+      slot[r + 1] = slot[r] + (cnt == 2 ? 4 : 2);
+    }
+    rows.resize(slot[n_rec]);
+    std::vector<unsigned> tmax(threads, 0);
+    rm_parallel(n_rec, threads, [&](unsigned t, uint64_t lo, uint64_t hi) {
+      for (uint64_t r = lo; r < hi; ++r) {
+        const size_t cnt = rec_first[r + 1] - rec_first[r];
+        const std::string& seq = reads[rec_first[r]];
+        unsigned read_len = unsigned(seq.size());
+        uint64_t e = find_existing(seq), erc = find_existing(revcomp_str(seq));
+        LoopRow* o = rows.data() + slot[r];
+        if (cnt == 2) {
+          const std::string& mate = reads[rec_first[r] + 1];
+          unsigned mate_len = unsigned(mate.size());
+          tmax[t] = std::max(tmax[t], std::max(read_len, mate_len));
+          uint64_t me = find_existing(mate), merc = find_existing(revcomp_str(mate));
+          if (canonicalize && seq > mate) { std::swap(me, e); std::swap(mate_len, read_len); std::swap(merc, erc); }  // :171-176
+          o[0] = {e, 0, read_len, 0, erc};
+          o[1] = {erc, 1, read_len, mate_len, me};
+          o[2] = {me, 2, mate_len, 0, merc};
+          o[3] = {merc, 3, mate_len, 0, kNoLoop};
+        } else {
+          tmax[t] = std::max(tmax[t], read_len);
+          o[0] = {e, 0, read_len, 0, erc};
+          o[1] = {erc, 1, read_len, 0, kNoLoop};
+        }
+      }
+    });
+    if (!err->empty()) return nullptr;
+    for (unsigned x : tmax) max_len = std::max(max_len, x);
+    // stable sort = stable sorts of consecutive shares merged in order (std::inplace_merge keeps the left share's rows first)
+    const unsigned T = threads;
+    const size_t nr = rows.size();
+    std::vector<size_t> cut(T + 1);
+    for (unsigned t = 0; t <= T; ++t) cut[t] = nr * t / T;
+    rm_parallel(T, T, [&](unsigned, uint64_t lo, uint64_t hi) {
+      for (uint64_t t = lo; t < hi; ++t) std::stable_sort(rows.begin() + cut[t], rows.begin() + cut[t + 1], row_less);
+    });
+    for (unsigned width = 1; width < T; width *= 2) {
+      std::vector<std::thread> th;
+      for (unsigned a = 0; a + width < T; a += 2 * width) {
+        const size_t lo = cut[a], mid = cut[a + width], hi = cut[std::min(T, a + 2 * width)];
+        th.emplace_back([&rows, lo, mid, hi] { std::inplace_merge(rows.begin() + lo, rows.begin() + mid, rows.begin() + hi, row_less); });
+      }
+      for (auto& x : th) x.join();
+    }
+  }
+  for (size_t r = 0; threads <= 1 && r + 1 < rec_first.size(); ++r) {
     size_t cnt = rec_first[r + 1] - rec_first[r];
     std::string seq = reads[rec_first[r]];
     std::string mate = (cnt == 2 && is_paired) ? reads[rec_first[r] + 1] : std::string();
@@ -782,7 +854,7 @@ static Readmap* readmap_build(const Seqset& ss, const std::vector<std::string>& 
     }
     if (!err->empty()) return nullptr;
   }
-  std::stable_sort(rows.begin(), rows.end(), row_less);
+  if (threads <= 1) std::stable_sort(rows.begin(), rows.end(), row_less);
   auto* rm = new Readmap;
   const size_t n = rows.size();
   rm->n_reads = n;
@@ -809,15 +881,17 @@ static Readmap* readmap_build(const Seqset& ss, const std::vector<std::string>& 
     LoopRow probe{entry_id, type, len, 0, 0};
     return std::lower_bound(rows.begin(), rows.end(), probe, row_less) - rows.begin();
   };
-  for (size_t i = 0; i < n; ++i) {  // first pass :293-326
-    const LoopRow& r = rows[i];
-    switch (r.type) {
-      case 0: rm->is_forward[i] = 1; rm->mate_loop_ptr[i] = find_first_of(1, r.loop_entry_id, r.read_length); break;
-      case 1: if (r.loop_entry_id != kNoLoop) rm->mate_loop_ptr[i] = find_first_of(2, r.loop_entry_id, r.mate_read_length); break;
-      case 2: rm->is_forward[i] = 1; rm->mate_loop_ptr[i] = find_first_of(3, r.loop_entry_id, r.read_length); break;
-      default: break;
+  rm_parallel(n, threads, [&](unsigned, uint64_t lo, uint64_t hi) {  // first pass :293-326 (every row for itself)
+    for (uint64_t i = lo; i < hi; ++i) {
+      const LoopRow& r = rows[i];
+      switch (r.type) {
+        case 0: rm->is_forward[i] = 1; rm->mate_loop_ptr[i] = find_first_of(1, r.loop_entry_id, r.read_length); break;
+        case 1: if (r.loop_entry_id != kNoLoop) rm->mate_loop_ptr[i] = find_first_of(2, r.loop_entry_id, r.mate_read_length); break;
+        case 2: rm->is_forward[i] = 1; rm->mate_loop_ptr[i] = find_first_of(3, r.loop_entry_id, r.read_length); break;
+        default: break;
+      }
     }
-  }
+  });
   std::vector<uint8_t> claimed(n, 0);  // second pass, sequential on purpose :330-392
   auto claim_next = [&](uint64_t t, int type, uint64_t entry_id, unsigned len) -> uint64_t {
     while (t < n && claimed[t]) ++t;
@@ -1279,12 +1353,65 @@ static std::vector<std::string> build_entries_cover_mt(const std::vector<std::st
   }
   if (n_records) *n_records = total;
   // buckets are lexicographic ranges: concatenation is sorted (a record shorter than 4 bases sorts before the longer
-  // ones of its padded bucket only if it is their prefix or smaller, which the bucket's own sort has settled)
-  std::vector<std::string> all;
-  all.reserve(total);
-  for (auto& v : sorted) { for (auto& x : v) all.push_back(std::move(x)); std::vector<std::string>().swap(v); }
-  if (!std::is_sorted(all.begin(), all.end())) std::sort(all.begin(), all.end());  // short records across padded buckets
-  dedup_sorted(all);
+  // ones of its padded bucket only if it is their prefix or smaller, which the bucket's own sort has settled).
+  // skip_dups (expand.cpp:19-48) drops a record that is a prefix of (or equal to) its successor in the sorted order: every
+  // bucket for itself, the successor of a bucket's last record being the first record of the next bucket that has one
+  // (part_repo.cpp:294-303: min_next_entry) -- no serial pass over all records (it was half of make_seqset's time on 256 threads).
+  std::vector<std::string> next_first(NB);  // first record of the next non-empty bucket, "" when there is none (a record is never empty)
+  {
+    std::string carry;
+    bool have = false;
+    for (unsigned b = NB; b-- > 0;) {
+      if (have) next_first[b] = carry;
+      if (!sorted[b].empty()) { carry = sorted[b].front(); have = true; }
+    }
+  }
+  bool boundaries_sorted = true;
+  for (unsigned b = 0; b < NB; ++b)
+    if (!sorted[b].empty() && !next_first[b].empty() && !(sorted[b].back() <= next_first[b])) boundaries_sorted = false;
+  if (!boundaries_sorted) {  // (cannot happen; the serial path of round 3 kept as the answer to it)
+    std::vector<std::string> all;
+    all.reserve(total);
+    for (auto& v : sorted) { for (auto& x : v) all.push_back(std::move(x)); std::vector<std::string>().swap(v); }
+    std::sort(all.begin(), all.end());
+    dedup_sorted(all);
+    return all;
+  }
+  std::vector<uint64_t> kept(NB + 1, 0);
+  {
+    std::atomic<unsigned> next{0};
+    parallel_ranges(T, T, [&](unsigned, uint64_t, uint64_t) {
+      for (;;) {
+        const unsigned b = next++;
+        if (b >= NB) break;
+        auto& v = sorted[b];
+        size_t w = 0;
+        for (size_t i = 0; i < v.size(); ++i) {
+          const std::string& a = v[i];
+          const std::string* succ = i + 1 < v.size() ? &v[i + 1] : (next_first[b].empty() ? nullptr : &next_first[b]);
+          if (succ && a.size() <= succ->size() && std::memcmp(a.data(), succ->data(), a.size()) == 0) continue;
+          if (w != i) v[w] = std::move(v[i]);
+          ++w;
+        }
+        v.resize(w);
+        kept[b + 1] = w;
+      }
+    });
+  }
+  for (unsigned b = 0; b < NB; ++b) kept[b + 1] += kept[b];
+  std::vector<std::string> all(kept[NB]);
+  {
+    std::atomic<unsigned> next{0};
+    parallel_ranges(T, T, [&](unsigned, uint64_t, uint64_t) {
+      for (;;) {
+        const unsigned b = next++;
+        if (b >= NB) break;
+        auto& v = sorted[b];
+        for (size_t i = 0; i < v.size(); ++i) all[kept[b] + i] = std::move(v[i]);
+        std::vector<std::string>().swap(v);
+      }
+    });
+  }
   return all;
 }
 
@@ -1567,6 +1694,18 @@ void* orc_readmap_build(void* ssh, void* eh, const char* seq, const uint64_t* of
   std::vector<uint64_t> rf(rec_first, rec_first + n_rec + 1);
   g_rm_err.clear();
   return readmap_build(*static_cast<Seqset*>(ssh), static_cast<Entries*>(eh)->e, reads, rf, is_paired != 0, canonicalize != 0, &g_rm_err);
+}
+void* orc_readmap_build_mt(void* ssh, void* eh, const char* seq, const uint64_t* offs, uint64_t n_reads, const uint64_t* rec_first,
+                           uint64_t n_rec, int is_paired, int canonicalize, unsigned threads) {
+  if (!threads) threads = std::max(1u, std::thread::hardware_concurrency());
+  std::vector<std::string> reads(n_reads);
+  rm_parallel(n_reads, threads, [&](unsigned, uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; ++i) reads[i].assign(seq + offs[i], seq + offs[i + 1]);
+  });
+  std::vector<uint64_t> rf(rec_first, rec_first + n_rec + 1);
+  g_rm_err.clear();
+  return readmap_build(*static_cast<Seqset*>(ssh), static_cast<Entries*>(eh)->e, reads, rf, is_paired != 0, canonicalize != 0, &g_rm_err,
+                       threads);
 }
 const char* orc_readmap_error() { return g_rm_err.c_str(); }
 uint64_t orc_readmap_size(void* h) { return static_cast<Readmap*>(h)->n_reads; }

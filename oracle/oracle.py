@@ -98,6 +98,8 @@ def lib():
     L.orc_ref_map_build.argtypes = [vp, u8p, u64p, u64p, C.c_uint64, u8p]
     L.orc_readmap_build.restype = vp
     L.orc_readmap_build.argtypes = [vp, vp, u8p, u64p, C.c_uint64, u64p, C.c_uint64, C.c_int, C.c_int]
+    L.orc_readmap_build_mt.restype = vp
+    L.orc_readmap_build_mt.argtypes = [vp, vp, u8p, u64p, C.c_uint64, u64p, C.c_uint64, C.c_int, C.c_int, C.c_uint]
     L.orc_readmap_error.restype = C.c_char_p
     L.orc_readmap_size.restype = C.c_uint64
     L.orc_readmap_size.argtypes = [vp]
@@ -606,7 +608,7 @@ class Readmap:
         self.n_entries = len(seqset)
 
     @classmethod
-    def from_packed(cls, seqset, entries, seq, offs, is_paired=True, canonicalize=True):
+    def from_packed(cls, seqset, entries, seq, offs, is_paired=True, canonicalize=True, threads=1):
         """The same from packed corrected reads (bases + offsets; an empty read = dropped by the correction): the records
         are the consecutive pairs (or single reads) with their dropped members left out -- what biograph_create.cpp:880-889
         hands make_readmap -- put together with numpy instead of Python strings."""
@@ -625,8 +627,12 @@ class Readmap:
         keep_offs[1:] = np.cumsum(lens[alive])
         # dropped reads are empty: the bases of the kept reads are the packed bases as they are
         self = cls.__new__(cls)
-        self.h = lib().orc_readmap_build(seqset.h, entries.h, _pad(np.ascontiguousarray(seq)), keep_offs, int(alive.sum()), rec_first,
-                                         len(rec_sizes), int(is_paired), int(canonicalize))
+        if threads != 1:  # (0 = every hardware thread) look-ups, row sort and first pass on threads; the same readmap
+            self.h = lib().orc_readmap_build_mt(seqset.h, entries.h, _pad(np.ascontiguousarray(seq)), keep_offs, int(alive.sum()), rec_first,
+                                                len(rec_sizes), int(is_paired), int(canonicalize), int(threads))
+        else:
+            self.h = lib().orc_readmap_build(seqset.h, entries.h, _pad(np.ascontiguousarray(seq)), keep_offs, int(alive.sum()), rec_first,
+                                             len(rec_sizes), int(is_paired), int(canonicalize))
         if not self.h:
             raise RuntimeError(lib().orc_readmap_error().decode())
         self.n_entries = len(seqset)

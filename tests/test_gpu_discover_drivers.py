@@ -291,7 +291,7 @@ def test_bgbinary_discovery_push_engine_with_bed(golden_dir, tmp_path):
     # the command's defaults are the current reference's (biograph_variants.cpp:188-202): pop tracer on, rvg_exclude on, no
     # simple genotype filter -- every record of father.vcf is still there (unfiltered, so possibly among others)
     r = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "discovery", "--in", str(bgd), "--ref", golden_dir + "/ref_lambda",
-                        "--out", str(out), "--ml-features", "false"], capture_output=True, text=True)
+                        "--out", str(out), "--ml-features", "false", "-f"], capture_output=True, text=True)  # (-f: the output exists)
     assert r.returncode == 0, r.stderr
     assert "pop tracer on" in r.stderr
     mine = {tuple(l.split("\t")[1:5]) for l in open(out) if not l.startswith("#")}
@@ -369,3 +369,67 @@ def test_bgbinary_create_then_discovery_is_the_same_on_any_number_of_sessions(tm
     planted = set(torch.nonzero(torch.rand(G, generator=g, device="cuda") < 0.001).flatten().cpu().tolist())
     snps = {int(f[1]) - 1 for f in recs if len(f[3]) == 1 and len(f[4]) == 1}
     assert len(planted) > 100 and len(snps & planted) >= 0.9 * len(planted) and not (snps - planted)
+
+
+def test_bgbinary_discovery_force_ref_map_min_pop_overlap_assemblies_out(golden_dir, tmp_path):
+    """The remaining options of `biograph discovery` (biograph_variants.cpp:153-199): an existing output is only replaced with
+    -f; --ref-map keeps the reference map in a spiral container between runs (built into FILE.new and renamed, opened when it
+    exists, refused when it belongs to another seqset); --min-pop-overlap reaches the pop tracer; --assemblies-out writes every
+    assembly that enters the pipeline as CSV."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    bgd = tmp_path / "father.bg"
+    (bgd / "coverage").mkdir(parents=True)
+    (bgd / "metadata").mkdir()
+    shutil.copy(golden_dir + "/father_lambda/seqset", bgd / "seqset")
+    shutil.copy(golden_dir + "/father_lambda/readmap", bgd / "coverage" / "abc.readmap")
+    json.dump({"accession_id": "father", "samples": {"father": "abc"}}, open(bgd / "metadata" / "bg_info.json", "w"), separators=(",", ":"))
+    exe = [sys.executable, "-m", "biograph_amd.cli", "discovery", "--in", str(bgd), "--ref", golden_dir + "/ref_lambda"]
+    out, rmap, csv = tmp_path / "v.vcf", tmp_path / "lambda.refmap", tmp_path / "asm.csv"
+    r = subprocess.run(exe + ["--out", str(out), "--ref-map", str(rmap), "--assemblies-out", str(csv)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Generating refmap in" in r.stderr and "Opening refmap" in r.stderr and rmap.exists() and not (tmp_path / "lambda.refmap.new").exists()
+    first = [x for x in open(out) if not x.startswith("##fileDate")]
+    rows = [x.rstrip("\n").split(",") for x in open(csv)]
+    assert rows[0] == ["scaffold_name", "left_offset", "right_offset", "left_anchor_len", "right_anchor_len", "aid", "score", "min_overlap",
+                       "ref_seq", "seq", "generated_by"]
+    # (lambda: 8 variants found from both directions, a few of them by the pop tracer as well)
+    assert len(rows) >= 9 and "PUSH" in {x[10] for x in rows[1:]} and {x[10] for x in rows[1:]} <= {"PUSH", "POP"}
+    assert all(x[0] == "lambda" and len(x) == 11 for x in rows[1:])
+    ref = "".join(l.strip() for l in open(golden_dir + "/father_lambda/reference.fasta") if not l.startswith(">")).upper()
+    for x in rows[1:40]:
+        assert x[8] == ref[int(x[1]):int(x[2])]
+    # the output exists now: refused without -f, replaced with it; the second run opens the kept map and writes the same records
+    r = subprocess.run(exe + ["--out", str(out), "--ref-map", str(rmap)], capture_output=True, text=True)
+    assert r.returncode == 1 and "Refusing to overwrite" in r.stderr and "Use -f to override" in r.stderr
+    r = subprocess.run(exe + ["--out", str(out), "--ref-map", str(rmap), "-f"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Generating refmap" not in r.stderr and "Opening refmap" in r.stderr
+    assert [x for x in open(out) if not x.startswith("##fileDate")] == first
+    # the container is the reference's: one packed_vector of 8-bit values, one per seqset entry
+    import zipfile
+    z = zipfile.ZipFile(rmap)
+    assert {"file_info.json", "part_info.json", "packed_data", "packed_vector.json"} <= set(z.namelist())
+    assert json.loads(z.read("packed_vector.json")) == {"value_count": 98006, "value_width_bits": 8}
+    # a map of another seqset is refused (ref_map.cpp:37)
+    other = tmp_path / "other.refmap"
+    ctx = bg.Context(0)
+    try:
+        import ctypes as C
+        from biograph_amd import capi
+        buf = (C.c_uint8 * 10)()
+        capi.check(capi.lib().bg_ref_map_write(str(other).encode(), buf, 10, 0, None))
+    finally:
+        ctx.close()
+    r = subprocess.run(exe + ["--out", str(tmp_path / "w.vcf"), "--ref-map", str(other)], capture_output=True, text=True)
+    assert r.returncode == 1 and "the seqset has 98006" in r.stderr
+    # --min-pop-overlap: a pop tracer that may not pop below 140 bases keeps fewer poppers alive
+    r = subprocess.run(exe + ["--out", str(tmp_path / "p.vcf"), "--min-pop-overlap", "140"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    import re
+    few = int(re.search(r"pop tracer on \[(\d+) of the assemblies\]", r.stderr).group(1))
+    r = subprocess.run(exe + ["--out", str(tmp_path / "q.vcf")], capture_output=True, text=True)
+    many = int(re.search(r"pop tracer on \[(\d+) of the assemblies\]", r.stderr).group(1))
+    assert few < many

@@ -63,3 +63,7 @@ def test_readmap_from_packed_equals_readmap_from_strings():
         b = O.Readmap.from_packed(oss, ent, cseq, coffs, paired)
         pa, pb = a.parts(), b.parts()
         assert pa.keys() == pb.keys() and all(pa[k] == pb[k] for k in pa)
+        # the threaded build (look-ups, row sort as merged stable sorts, first pass on threads): the same readmap
+        for threads in (2, 5, 8):
+            pc = O.Readmap.from_packed(oss, ent, cseq, coffs, paired, threads=threads).parts()
+            assert pa.keys() == pc.keys() and all(pa[k] == pc[k] for k in pa), threads

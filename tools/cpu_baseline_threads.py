@@ -30,7 +30,7 @@ for T in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["16
     oss = O.Seqset.from_entries(ent, threads=T)
     st["make_seqset"] = time.perf_counter() - t0
     t0 = time.perf_counter()
-    O.Readmap.from_packed(oss, ent, cseq, coffs, True)
+    O.Readmap.from_packed(oss, ent, cseq, coffs, True, threads=T)
     st["make_readmap"] = time.perf_counter() - t0
     tot = sum(st.values())
     print("threads %3d: %.2f s = %.4f Gbases/s  %s" % (T, tot, int(offs[-1]) / tot / 1e9, {k: round(v, 2) for k, v in st.items()}), flush=True)

@@ -9,6 +9,7 @@ ROOT=$(pwd)
 OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+export BG_BENCH_NO_WALK_COUNTERS=1   # the counting runs of the discover leg would be averaged into the kernels' times
 ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -o run -- python3 "$ROOT/bench.py" $ARGS > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/${TAG}_stats.log"
