@@ -726,8 +726,27 @@ struct SeqsetView {
   // measurement only (bg_walk_counters): [0] += push_front_drop calls, [1] += iterations of its drop loop -- the N_pfd and
   // N_drop of SURVEY.md section 8(d)'s walk bytes (52 N_pfd + 60 N_drop).  Null in every normal run.
   unsigned long long* walk_counters = nullptr;
+  // rank blocks (round 4): per base one 64-byte block per 384 entries = [set bits before the block | five 9-bit running
+  // counts at its word boundaries | its six words of bits].  A rank look-up through bits / subaccum / accum touches three
+  // arrays, i.e. three 64-byte sectors for 24 bytes (measured: the reference map fetches 264 bytes per push_front_drop);
+  // through a block it touches one.  Same numbers (seqset_finalize_device builds the blocks from the finalized bitcount);
+  // null where a view is built without them.
+  const uint64_t* rank64[4] = {nullptr, nullptr, nullptr, nullptr};
 
   BG_HD uint64_t count(int b, uint64_t i) const {  // bitcount.h:218-270
+    if (rank64[b]) {
+      const uint64_t g = i / 384;
+      const unsigned r = unsigned(i - g * 384), w = r >> 6;
+      const uint64_t* blk = rank64[b] + g * 8;
+      uint64_t x = blk[2 + w] & ((1ull << (r & 63)) - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+      const uint64_t bc = __popcll(x);
+#else
+      const uint64_t bc = __builtin_popcountll(x);
+#endif
+      const uint64_t sub = w ? (blk[1] >> (9 * (w - 1))) & 0x1ff : 0;
+      return blk[0] + sub + bc;
+    }
     uint64_t nw = (n + 63) >> 6;
     uint64_t x = (i >> 6) < nw ? bits[b][i >> 6] : 0;
     x &= (1ull << (i & 63)) - 1;

@@ -1359,6 +1359,39 @@ __global__ void k_min_index2(const uint8_t* __restrict__ min1, uint64_t n1, uint
 // Allocates and fills subaccum/accum/fixed and the min index from bits/shared (device).
 // slice: the entries are a stretch of a larger seqset (prev bits point anywhere): fixed[] = the slice's own
 // cumulative popcounts, no sum check.
+// rank blocks of SeqsetView::count: block g of base b covers entries [384 g, 384 g + 384)
+__global__ void k_rank64_build(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ subaccum,
+                               const uint64_t* __restrict__ accum, uint64_t n, uint64_t nblocks, uint64_t* __restrict__ out) {
+  const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= nblocks) return;
+  const uint64_t nw = (n + 63) >> 6, ngroups = (n + 511) >> 9;
+  const uint64_t i0 = g * 384;
+  // set bits before entry i0, through the finalized bitcount (bitcount.h:218-270; i0 is a multiple of 64: no partial word)
+  uint64_t before = 0;
+  {
+    const uint64_t group = i0 >> 9, sub = (i0 >> 6) & 7;
+    uint64_t sa = group < ngroups ? subaccum[group] : 0;
+    sa >>= 56 - 8 * sub;
+    sa &= 0xffffffffffffff00ull;
+    sa = (sa >> 32) + (sa & 0xffffffffull);
+    sa = (sa >> 16) + (sa & 0xffff);
+    sa = (sa >> 8) + (sa & 0xff);
+    before = accum[group] + sa;
+  }
+  uint64_t w[6], packed = 0;
+  unsigned run = 0;
+  for (int k = 0; k < 6; ++k) {
+    const uint64_t idx = g * 6 + k;
+    w[k] = idx < nw ? bits[idx] : 0;
+    run += unsigned(__popcll(w[k]));
+    if (k < 5) packed |= uint64_t(run) << (9 * k);  // set bits of the block before word k + 1
+  }
+  uint64_t* o = out + g * 8;
+  o[0] = before;
+  o[1] = packed;
+  for (int k = 0; k < 6; ++k) o[2 + k] = w[k];
+}
+
 int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss, bool slice) {
   const uint64_t n = ss->n;
   const uint64_t nwords = (n + 63) / 64, ngroups = (n + 511) / 512, naccum = (n + 1 + 511) / 512;
@@ -1389,6 +1422,15 @@ int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss, bool slice) {
     BG_LAUNCH_CHECK();
     k_min_index2<<<cdiv(n2, 256), 256, 0, ctx->stream>>>(ss->min1.p, n1, n2, ss->min2.p);
     BG_LAUNCH_CHECK();
+  }
+  if (!slice) {  // (a slice of a sharded seqset is written, not walked)
+    const uint64_t nblocks = n / 384 + 1;  // position n itself is asked for (the end of the whole range)
+    for (int b = 0; b < 4; ++b) {
+      BG_TRY(ss->rank64[b].alloc(ctx, nblocks * 8));
+      k_rank64_build<<<cdiv(nblocks, 256), 256, 0, ctx->stream>>>(ss->bits[b].p, ss->subaccum[b].p, ss->accum[b].p, n, nblocks,
+                                                                ss->rank64[b].p);
+      BG_LAUNCH_CHECK();
+    }
   }
   BG_HIP(hipStreamSynchronize(ctx->stream));
   uint64_t off = 0;

@@ -26,6 +26,8 @@ static SeqsetView make_view(const bg_seqset* ss) {
   v.min1 = ss->min1.p;
   v.min2 = ss->min2.p;
   v.walk_counters = g_walk_counters;
+  static const bool no_blocks = [] { const char* e = getenv("BG_WALK_RANK_BLOCKS"); return e && e[0] == '0'; }();
+  for (int b = 0; b < 4; ++b) v.rank64[b] = no_blocks ? nullptr : ss->rank64[b].p;
   return v;
 }
 

@@ -44,6 +44,9 @@ def main():
         m = re.search(r"tracing ([\d.]+)", line[-1]) if line else None
         out.append({"sessions": th, "wall_s": round(dt, 2), "tracing_s": float(m.group(1)) if m else None,
                     "cpu_user_s": round(u1.ru_utime - u0.ru_utime, 1), "cpu_sys_s": round(u1.ru_stime - u0.ru_stime, 1),
+                    "minor_faults": u1.ru_minflt - u0.ru_minflt, "major_faults": u1.ru_majflt - u0.ru_majflt,
+                    "voluntary_switches": u1.ru_nvcsw - u0.ru_nvcsw, "involuntary_switches": u1.ru_nivcsw - u0.ru_nivcsw,
+                    "max_rss_GB": round(u1.ru_maxrss / 1e6, 2),
                     "rc": r.returncode, "summary": line[-1][:300] if line else r.stderr[-300:]})
         print(json.dumps(out[-1]), flush=True)
     subprocess.run(["rm", "-rf", tmp])
