@@ -39,6 +39,8 @@
 #include <vector>
 
 #include "../../../include/bgseq.h"
+#define FASTALLOC_DEFINE
+#include "fastalloc.h"  // thread-caching operator new / delete: the tracer sessions of `discovery` live on small allocations
 
 static void die(const std::string& msg) {
   fprintf(stderr, "%s\n", msg.c_str());
