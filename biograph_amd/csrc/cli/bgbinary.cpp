@@ -1154,6 +1154,13 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   const bool want_csv = a.has("assemblies-out") && !a.get("assemblies-out").empty();
   if (want_csv)
     asm_csv = "scaffold_name,left_offset,right_offset,left_anchor_len,right_anchor_len,aid,score,min_overlap,ref_seq,seq,generated_by\n";
+  // --aligned-assemblies-out FILE (biograph_variants.cpp:168,566-597,735-744): the assemblies behind the aligner (align.cpp:89-90)
+  // with their aligned variants as refrange:varseq:refseq
+  std::string aligned_csv;
+  const bool want_aligned = a.has("aligned-assemblies-out") && !a.get("aligned-assemblies-out").empty();
+  if (want_aligned)
+    aligned_csv = "scaffold_name,left_offset,right_offset,left_anchor_len,right_anchor_len,aid,score,min_overlap,"
+                  "variants(refrange:varseq:refseq),seq,generated_by\n";
   opt.max_pair_distance = uint64_t(max_pair_distance);
   if (a.has("scaffold-split-size")) {  // assemble_options::scaffold_split_size (the size of trace_ref's pieces)
     const long long sp = atoll(a.get("scaffold-split-size").c_str());
@@ -1352,6 +1359,35 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
       }
       bg_trace_result_free(sorted);
     }
+    if (want_aligned) {
+      bg_trace_result* al = nullptr;
+      check(bg_assemblies_process(items.data(), uint32_t(items.size()), es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()),
+                                  &opt, BG_STEP_SORT | BG_STEP_TRIM_REF | BG_STEP_DEDUP | BG_STEP_ALIGN, &al), "bg_assemblies_process");
+      for (uint64_t i = 0; i < bg_trace_result_size(al); ++i) {
+        bg_trace_assembly x;
+        check(bg_trace_result_get(al, i, &x), "bg_trace_result_get");
+        char head[256];
+        snprintf(head, sizeof head, "%s,%lld,%lld,%d,%d,%llu,%lld,%u,", rec.first.c_str(), (long long)x.left_offset, (long long)x.right_offset,
+                 x.left_anchor_len, x.right_anchor_len, (unsigned long long)x.assembly_id, (long long)x.score, x.min_overlap);
+        aligned_csv += head;
+        const uint64_t nv = bg_trace_result_var_count(al, i);
+        for (uint64_t j = 0; j < nv; ++j) {
+          int64_t vl = 0, vr = 0;
+          const char* vs = nullptr;
+          uint64_t vn = 0;
+          check(bg_trace_result_var(al, i, j, &vl, &vr, &vs, &vn), "bg_trace_result_var");
+          if (j) aligned_csv += ";";
+          aligned_csv += std::to_string(vl) + "-" + std::to_string(vr) + ":";
+          aligned_csv.append(vs, vn);
+          aligned_csv += ":";
+          if (vl >= 0 && vr >= vl && uint64_t(vr) <= seq.size()) aligned_csv.append(seq, size_t(vl), size_t(vr - vl));
+        }
+        aligned_csv += ",";
+        aligned_csv.append(x.seq, x.seq_len);
+        aligned_csv += x.from_pop ? ",POP\n" : ",PUSH\n";
+      }
+      bg_trace_result_free(al);
+    }
     check(bg_assemblies_process(items.data(), uint32_t(items.size()), es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()),
                                 &opt, BG_STEP_PIPELINE, &sections), "bg_assemblies_process");
     for (auto* r : items) bg_trace_result_free(r);
@@ -1386,6 +1422,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   bg_dev_free(ctx, d_map);
   write_file(a.get("out"), vcf);
   if (want_csv) write_file(a.get("assemblies-out"), asm_csv);
+  if (want_aligned) write_file(a.get("aligned-assemblies-out"), aligned_csv);
   fprintf(stderr, "%llu variants over %zu scaffold(s) in %llu piece(s) x 2 directions on %d tracer session(s), min overlap %u: %.2f s (refmap %.2f, sessions %.2f, tracing %.2f "
                   "[%llu assemblies], pipeline %.2f [%llu sections], coverage + genotype %.2f); pop tracer %s [%llu of the assemblies]\n",
           (unsigned long long)n_var, recs.size(), (unsigned long long)pieces, n_threads, min_overlap, now_s() - t0, t_refmap, t_open, t_trace,
@@ -1400,10 +1437,10 @@ static int cmd_discovery(int argc, char** argv) {
   mallopt(M_TOP_PAD, 256 << 20);
   Args a = parse(argc, argv, 2, {"reads", "ref", "out", "sample", "min-overlap", "max-pair-distance", "bed", "engine", "max-ploids",
                                  "enable-pop-tracer", "threads", "ml-features", "scaffold-split-size", "simple-gt", "rvg-exclude",
-                                 "force", "ref-map", "min-pop-overlap", "assemblies-out"});
+                                 "force", "ref-map", "min-pop-overlap", "assemblies-out", "aligned-assemblies-out"});
   if (!a.has("reads") || !a.has("ref") || !a.has("out")) die("discovery: --in S.bg, --ref and --out are required");
   // biograph_variants.cpp:216-232: an output that exists is only replaced with -f / --force
-  for (const char* o : {"out", "assemblies-out"})
+  for (const char* o : {"out", "assemblies-out", "aligned-assemblies-out"})
     if (a.has(o) && !a.get(o).empty() && a.get(o) != "-" && exists(a.get(o))) {
       if (!a.has("force")) die("Refusing to overwrite '" + a.get(o) + "'. Use -f to override.");
       unlink(a.get(o).c_str());

@@ -388,8 +388,18 @@ def test_bgbinary_discovery_force_ref_map_min_pop_overlap_assemblies_out(golden_
     json.dump({"accession_id": "father", "samples": {"father": "abc"}}, open(bgd / "metadata" / "bg_info.json", "w"), separators=(",", ":"))
     exe = [sys.executable, "-m", "biograph_amd.cli", "discovery", "--in", str(bgd), "--ref", golden_dir + "/ref_lambda"]
     out, rmap, csv = tmp_path / "v.vcf", tmp_path / "lambda.refmap", tmp_path / "asm.csv"
-    r = subprocess.run(exe + ["--out", str(out), "--ref-map", str(rmap), "--assemblies-out", str(csv)], capture_output=True, text=True)
+    acsv = tmp_path / "aligned.csv"
+    r = subprocess.run(exe + ["--out", str(out), "--ref-map", str(rmap), "--assemblies-out", str(csv), "--aligned-assemblies-out", str(acsv)],
+                       capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    # behind the aligner: every assembly with its aligned variants as refrange:varseq:refseq -- the 100-base deletion of
+    # father.vcf is there as an empty variant sequence over 100 reference bases
+    arows = [x.rstrip("\n").split(",") for x in open(acsv)]
+    assert arows[0][8] == "variants(refrange:varseq:refseq)" and len(arows) > 5
+    variants = [v.split(":") for x in arows[1:] for v in x[8].split(";") if v]
+    assert all(len(v) == 3 for v in variants)
+    assert any(v[1] == "" and len(v[2]) == 100 for v in variants)
+    assert any(len(v[1]) == 1 and len(v[2]) == 1 and v[1] != v[2] for v in variants)  # a SNP
     assert "Generating refmap in" in r.stderr and "Opening refmap" in r.stderr and rmap.exists() and not (tmp_path / "lambda.refmap.new").exists()
     first = [x for x in open(out) if not x.startswith("##fileDate")]
     rows = [x.rstrip("\n").split(",") for x in open(csv)]
