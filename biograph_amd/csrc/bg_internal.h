@@ -286,6 +286,42 @@ bg_ctx::DeviceArena* shared_arena(int device);  // null unless the hook is insta
 int tracer_read_tables(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const uint8_t* d_ref_map, bool skip_ambiguous,
                        const uint64_t* d_ent, uint64_t n, int64_t first_off, std::vector<std::pair<int32_t, uint64_t>>* pos_entries,
                        std::vector<std::pair<uint64_t, int32_t>>* entry_pos, std::vector<std::pair<uint32_t, int32_t>>* mate_pos);
+// walk.hip: the push tracer's search for the traces that never branch, whole on the device (tracer.cpp:477-519, 528-673,
+// 675-724, 737-845, 1023-1250 for ONE path): start, the walk to the next read, add_pairs there, the rejoin, the assembly's
+// fields.  A trace that does anything else (a branch, a read that does not rejoin, a step cap) is marked for the host's
+// state machine, which runs it from its start.
+struct TraceSeed {  // one trace = one offset of the sweep (tracer::trace)
+  uint64_t entry;
+  int32_t cur_offset;
+  uint32_t size;            // the left anchor's length = the entry's size
+  uint32_t ref_ambiguous;   // m_ref_ambiguous_bases at this offset
+  int32_t win_lo, win_hi;   // window of the sliding tables
+  uint32_t pad;
+};
+constexpr int kSimpleSteps = 64, kSimpleIds = 24;
+enum { kSimpleHost = 0, kSimpleAssembly = 1, kSimpleNothing = 2 };
+enum { kSimRefReads = 1, kSimAmbiguousRefReads = 2, kSimStepCount = 4, kSimOutput = 8, kSimMatchedPairs = 16, kSimMaxBranchCost = 32,
+       kSimTooManyAmbiguousBases = 64, kSimTooManySteps = 128, kSimTooFarWithoutPair = 256, kSimPruneAmbiguousRef = 512 };
+struct TraceSimpleOut {
+  uint32_t status, n_steps;
+  int32_t right_offset;
+  uint32_t right_anchor_len, min_overlap, n_ids, counters, found_pairs;
+  uint32_t ids[kSimpleIds];
+  uint8_t bases[kSimpleSteps];
+};
+struct TraceSimpleTables {
+  const uint8_t* ref_map;         // per entry: match count in the low 6 bits
+  const uint32_t* word_rank;      // entries with reads before each 64-entry word
+  const uint32_t* group_start;    // first read id of the k-th entry that carries reads (+ one past the end)
+  const uint32_t* mate_loop;      // per read id
+  const uint8_t* is_forward;      // per read id
+  const void* entry_positions;    // std::pair<uint64_t, int32_t>[n_entry_positions], sorted
+  uint64_t n_entry_positions;
+  const void* mate_positions;     // std::pair<uint32_t, int32_t>[n_mate_positions], sorted
+  uint64_t n_mate_positions;
+};
+int tracer_simple_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const TraceSimpleTables& tb, const bg_trace_options& o,
+                        const TraceSeed* d_seeds, uint64_t n, TraceSimpleOut* d_out);
 // build_seqset.hip
 int cover_index_build(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, uint64_t n_o, int W, int cover_k,
                       DevBuf<uint64_t>* k0o, CoverStore* cs);

@@ -27,6 +27,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -166,6 +167,21 @@ struct Pinned {
   }
 };
 
+// Device copies of the readmap columns the device's never-branching-trace path consults (walk.hip k_trace_simple): made once per
+// session, shared by its clones; plain hipMalloc so that they outlive any one context.
+struct DeviceTables {
+  uint32_t* word_rank = nullptr;
+  uint32_t* group_start = nullptr;
+  uint32_t* mate_loop = nullptr;
+  uint8_t* is_forward = nullptr;
+  ~DeviceTables() {
+    if (word_rank) (void)hipFree(word_rank);
+    if (group_start) (void)hipFree(group_start);
+    if (mate_loop) (void)hipFree(mate_loop);
+    if (is_forward) (void)hipFree(is_forward);
+  }
+};
+
 // Everything the traces of one chunk share.
 struct World {
   bg_ctx* ctx;
@@ -176,6 +192,7 @@ struct World {
   // host copies of the seqset / readmap / ref_map columns the tracer consults: read-only, shared with the sessions
   // cloned from this one (bg_tracer_clone: several sessions trace side by side)
   std::shared_ptr<const HostTables> tables;
+  std::shared_ptr<const DeviceTables> dev_tables;  // null: every trace runs on the host's state machine
   const uint8_t* sizes = nullptr;       // entry sizes
   const uint8_t* d_ref_map = nullptr;   // the caller's device ref_map (stays valid while the session lives)
   const uint8_t* ref_map = nullptr;     // ref_map bytes (match count = & 63)
@@ -226,6 +243,18 @@ struct World {
   }
   bool pairing_skipped(uint64_t e) const { return o.ignore_ambiguous_ref_pairs && match_count(e) > 1; }
 };
+
+// the end of tracer::output_assembly (tracer.cpp:1199-1215): matches_reference, anchors no longer than the assembly
+void close_assembly(bg_trace_assembly_rec* a) {
+  a->matches_reference = (a->left_anchor_len + a->right_anchor_len) >= (a->right_offset - a->left_offset) &&
+                         (a->right_offset - a->left_offset) == int64_t(a->seq.size());
+  if (a->matches_reference) a->left_anchor_len = a->right_anchor_len = 0;
+  const int64_t max_tot_anchor = std::min<int64_t>(int64_t(a->seq.size()), a->right_offset - a->left_offset);
+  if (a->right_anchor_len + a->left_anchor_len > max_tot_anchor) {
+    a->right_anchor_len = int(std::min<int64_t>(a->right_anchor_len, max_tot_anchor / 2));
+    a->left_anchor_len = int(std::min<int64_t>(a->left_anchor_len, max_tot_anchor / 2));
+  }
+}
 
 // One trace (tracer::trace + trace_next_paths + output_rejoins for one offset) as a resumable machine.
 struct Trace {
@@ -588,14 +617,7 @@ struct Trace {
     a.trace_steps = unsigned(search_steps);
     a.left_anchor_ambiguous_bases = ref_ambiguous_bases;
     a.seq = rev_comp_str(seq);
-    a.matches_reference = (a.left_anchor_len + a.right_anchor_len) >= (a.right_offset - a.left_offset) &&
-                          (a.right_offset - a.left_offset) == int64_t(a.seq.size());
-    if (a.matches_reference) a.left_anchor_len = a.right_anchor_len = 0;
-    const int64_t max_tot_anchor = std::min<int64_t>(int64_t(a.seq.size()), a.right_offset - a.left_offset);
-    if (a.right_anchor_len + a.left_anchor_len > max_tot_anchor) {
-      a.right_anchor_len = int(std::min<int64_t>(a.right_anchor_len, max_tot_anchor / 2));
-      a.left_anchor_len = int(std::min<int64_t>(a.left_anchor_len, max_tot_anchor / 2));
-    }
+    close_assembly(&a);
     ++st.output_count;
     out.push_back(std::move(a));
   }
@@ -872,11 +894,14 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
     std::sort(w.rc_mate_read_positions.begin(), w.rc_mate_read_positions.end());
   }
   // ---- 2. the sequential state of the sweep (:236-296): which offsets trace, with which anchor
-  std::vector<std::unique_ptr<Trace>> traces;
+  struct SeedInfo { uint32_t ext; uint32_t anchor_from; };  // where the left anchor lies: ext[ext].seq[anchor_from, + size)
+  std::vector<TraceSeed> seeds;
+  std::vector<SeedInfo> infos;
   size_t pe = 0;
   int64_t cur_offset = 0;
   bool stop = false;
-  for (const Extent& x : ext) {
+  for (size_t xi = 0; xi < ext.size(); ++xi) {
+    const Extent& x = ext[xi];
     if (stop) break;
     cur_offset = x.offset;
     if (x.offset + int64_t(x.seq.size()) <= start) continue;
@@ -903,19 +928,82 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
       // loop above except at cur_offset == limit)
       if (cur_offset < start || cur_offset >= limit) continue;
       const bool ref_ambiguous = w.match_count(e) > 1;
-      std::unique_ptr<Trace> t(new Trace);
-      t->w = &w;
-      t->cur_offset = int32_t(cur_offset);
-      t->cur_range.b = e; t->cur_range.e = e + 1; t->cur_range.s = size;
-      t->left_anchor = x.seq.substr(anchor_from, size);
       if (!ref_ambiguous) ambiguous = 0;
-      t->ref_ambiguous_bases = ambiguous;
-      t->win_lo = int32_t(cur_offset - 1 - int64_t(o.max_pair_distance));
-      t->win_hi = int32_t(cur_offset - 1 + int64_t(o.read_ahead_distance));
-      traces.push_back(std::move(t));
+      TraceSeed sd;
+      sd.entry = e;
+      sd.cur_offset = int32_t(cur_offset);
+      sd.size = size;
+      sd.ref_ambiguous = ambiguous;
+      sd.win_lo = int32_t(cur_offset - 1 - int64_t(o.max_pair_distance));
+      sd.win_hi = int32_t(cur_offset - 1 + int64_t(o.read_ahead_distance));
+      sd.pad = 0;
+      seeds.push_back(sd);
+      infos.push_back(SeedInfo{uint32_t(xi), uint32_t(anchor_from)});
     }
   }
   w.seconds_tables += now_seconds() - t_tables;
+  const size_t n_seeds = seeds.size();
+  // ---- 2b. the traces that never branch, whole on the device (walk.hip k_trace_simple): nine in ten follow the reference to the
+  // next read and rejoin there.  What the kernel hands back as kSimpleHost runs on the state machine below, from its start.
+  static const bool simple_off = [] { const char* e = getenv("BG_TRACER_DEVICE_SIMPLE"); return e && e[0] == '0'; }();
+  const bool simple = !simple_off && w.dev_tables && w.d_ref_map && n_seeds && o.max_pairs_per_read <= uint64_t(kSimpleIds) && o.max_rejoins >= 1 &&
+                      w.n_reads < (size_t(1) << 32);
+  std::vector<TraceSimpleOut> simple_out;
+  if (simple) {
+    const double t_dev = now_seconds();
+    DevBuf<TraceSeed> d_seeds;
+    DevBuf<TraceSimpleOut> d_out;
+    DevBuf<uint8_t> d_ep, d_mp;
+    BG_TRY(d_seeds.alloc(ctx, n_seeds));
+    BG_TRY(d_out.alloc(ctx, n_seeds));
+    static_assert(sizeof(std::pair<uint64_t, int32_t>) == 16 && sizeof(std::pair<uint32_t, int32_t>) == 8, "table rows as the kernel reads them");
+    BG_TRY(d_ep.alloc(ctx, w.entry_positions.size() * 16));
+    BG_TRY(d_mp.alloc(ctx, w.rc_mate_read_positions.size() * 8));
+    BG_HIP(hipMemcpyAsync(d_seeds.p, seeds.data(), n_seeds * sizeof(TraceSeed), hipMemcpyHostToDevice, ctx->stream));
+    if (!w.entry_positions.empty())
+      BG_HIP(hipMemcpyAsync(d_ep.p, w.entry_positions.data(), w.entry_positions.size() * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (!w.rc_mate_read_positions.empty())
+      BG_HIP(hipMemcpyAsync(d_mp.p, w.rc_mate_read_positions.data(), w.rc_mate_read_positions.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    TraceSimpleTables tb;
+    tb.ref_map = w.d_ref_map;
+    tb.word_rank = w.dev_tables->word_rank;
+    tb.group_start = w.dev_tables->group_start;
+    tb.mate_loop = w.dev_tables->mate_loop;
+    tb.is_forward = w.dev_tables->is_forward;
+    tb.entry_positions = d_ep.p;
+    tb.n_entry_positions = w.entry_positions.size();
+    tb.mate_positions = d_mp.p;
+    tb.n_mate_positions = w.rc_mate_read_positions.size();
+    BG_TRY(tracer_simple_batch(ctx, w.ss, w.rm, tb, o, d_seeds.p, n_seeds, d_out.p));
+    simple_out.resize(n_seeds);
+    BG_TRY(copy_sync(ctx, simple_out.data(), d_out.p, n_seeds * sizeof(TraceSimpleOut), hipMemcpyDeviceToHost));
+    w.seconds_device += now_seconds() - t_dev;
+    ++w.stats.device_rounds;
+    w.stats.device_queries += n_seeds;
+  }
+  // the traces left to the host, in seed order
+  std::vector<uint32_t> host_seed;
+  for (size_t i = 0; i < n_seeds; ++i)
+    if (!simple || simple_out[i].status == kSimpleHost) host_seed.push_back(uint32_t(i));
+  std::vector<std::unique_ptr<Trace>> traces(host_seed.size());
+  {
+    const double t_mk = now_seconds();
+    parallel_over(host_seed.size(), [&](size_t k) {
+      const TraceSeed& sd = seeds[host_seed[k]];
+      const SeedInfo& in = infos[host_seed[k]];
+      std::unique_ptr<Trace> t(new Trace);
+      t->w = &w;
+      t->cur_offset = sd.cur_offset;
+      t->cur_range.b = sd.entry; t->cur_range.e = sd.entry + 1; t->cur_range.s = sd.size;
+      t->left_anchor = ext[in.ext].seq.substr(in.anchor_from, sd.size);
+      t->ref_ambiguous_bases = sd.ref_ambiguous;
+      t->win_lo = sd.win_lo;
+      t->win_hi = sd.win_hi;
+      traces[k] = std::move(t);
+    });
+    w.seconds_start += now_seconds() - t_mk;
+  }
+  std::vector<std::vector<bg_trace_assembly_rec>> host_out(host_seed.size());
   // ---- 3. all traces in lock step
   const uint32_t step_cap = 64;
   const size_t wave = 1 << 16;
@@ -972,13 +1060,58 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
     }
     for (size_t i = w0; i < w1; ++i) {
       add_stats(&w.stats, traces[i]->st);
-      for (auto& a : traces[i]->out) out->push_back(std::move(a));
+      host_out[i] = std::move(traces[i]->out);
     }
     const double t_down = now_seconds();
     for (size_t i = w0; i < w1; ++i) traces[i].reset();  // (in order on this thread: frees from other threads contend in malloc)
     w.seconds_teardown += now_seconds() - t_down;
   }
-  w.stats.traces += traces.size();
+  // ---- 4. the assemblies in the order of their traces: the device's (tracer::output_assembly, :1161-1215, from the fields
+  // k_trace_simple left) and the state machine's
+  {
+    const double t_out = now_seconds();
+    size_t hk = 0;
+    for (size_t i = 0; i < n_seeds; ++i) {
+      if (hk < host_seed.size() && host_seed[hk] == i) {
+        for (auto& a : host_out[hk]) out->push_back(std::move(a));
+        ++hk;
+        continue;
+      }
+      const TraceSimpleOut& so = simple_out[i];
+      const uint32_t c = so.counters;
+      w.stats.ref_reads += (c & kSimRefReads) ? 1 : 0;
+      w.stats.ambiguous_ref_reads += (c & kSimAmbiguousRefReads) ? 1 : 0;
+      w.stats.step_count += (c & kSimStepCount) ? 1 : 0;
+      w.stats.output_count += (c & kSimOutput) ? 1 : 0;
+      w.stats.matched_pairs += (c & kSimMatchedPairs) ? 1 : 0;
+      w.stats.max_branch_cost += (c & kSimMaxBranchCost) ? 1 : 0;
+      w.stats.too_many_ambiguous_bases += (c & kSimTooManyAmbiguousBases) ? 1 : 0;
+      w.stats.too_many_steps += (c & kSimTooManySteps) ? 1 : 0;
+      w.stats.too_far_without_pair += (c & kSimTooFarWithoutPair) ? 1 : 0;
+      w.stats.prune_ambiguous_ref += (c & kSimPruneAmbiguousRef) ? 1 : 0;
+      w.stats.found_pairs += so.found_pairs;
+      if (so.status != kSimpleAssembly) continue;
+      const TraceSeed& sd = seeds[i];
+      const SeedInfo& in = infos[i];
+      bg_trace_assembly_rec a;
+      a.assembly_id = allocate_assembly_id();  // tracer.cpp:1166
+      a.seq.reserve(size_t(sd.size) + so.n_steps);
+      a.seq.assign(ext[in.ext].seq, in.anchor_from, sd.size);
+      for (uint32_t k = 0; k < so.n_steps; ++k) a.seq.push_back("ACGT"[so.bases[k] & 3]);
+      a.rc_read_ids.assign(so.ids, so.ids + so.n_ids);  // ascending read ids of one entry: the std::set of :1168-1177
+      a.left_offset = int64_t(sd.cur_offset) - int64_t(sd.size);
+      a.left_anchor_len = int(sd.size);
+      a.right_offset = so.right_offset;
+      a.right_anchor_len = int(so.right_anchor_len);
+      a.min_overlap = so.min_overlap;
+      a.trace_steps = 1;
+      a.left_anchor_ambiguous_bases = sd.ref_ambiguous;
+      close_assembly(&a);
+      out->push_back(std::move(a));
+    }
+    w.seconds_host += now_seconds() - t_out;
+  }
+  w.stats.traces += n_seeds;
   return BG_OK;
 }
 
@@ -1179,6 +1312,22 @@ extern "C" int bg_tracer_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap
     h->read_len.resize(rm->n_reads);
     for (size_t i = 0; i < tmp.size(); ++i) h->read_len[i] = uint8_t(tmp[i]);
     w.tables = h;
+    // the same columns on the device for the never-branching traces (k_trace_simple); BG_TRACER_DEVICE_SIMPLE=0: not made
+    const char* off = getenv("BG_TRACER_DEVICE_SIMPLE");
+    if (!(off && off[0] == '0') && rm->n_reads < (uint64_t(1) << 32)) {
+      std::shared_ptr<DeviceTables> d(new DeviceTables);
+      auto up = [&](auto** dst, const auto& v) -> int {
+        using T = typename std::remove_reference<decltype(v)>::type::value_type;
+        BG_HIP(hipMalloc(reinterpret_cast<void**>(dst), (v.size() ? v.size() : 1) * sizeof(T)));
+        if (!v.empty()) BG_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return BG_OK;
+      };
+      BG_TRY(up(&d->word_rank, h->word_rank));
+      BG_TRY(up(&d->group_start, h->group_start));
+      BG_TRY(up(&d->mate_loop, h->mate_loop));
+      BG_TRY(up(&d->is_forward, h->is_forward));
+      w.dev_tables = d;
+    }
   }
   w.bind_tables();
   *out = t.release();
@@ -1199,6 +1348,7 @@ extern "C" int bg_tracer_clone(const bg_tracer* from, bg_ctx* ctx, bg_tracer** o
   w.n_entries = from->w.n_entries;
   w.d_ref_map = from->w.d_ref_map;
   w.tables = from->w.tables;
+  w.dev_tables = from->w.dev_tables;
   w.bind_tables();
   *out = t.release();
   return BG_OK;

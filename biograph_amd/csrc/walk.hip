@@ -540,6 +540,245 @@ __global__ __launch_bounds__(64) void k_tracer_extend(SeqsetView v, const uint64
   }
 }
 
+// ---- the never-branching traces, whole (bg_internal.h TraceSeed / TraceSimpleOut).  Four lanes per trace as in
+// k_tracer_extend (one per pushed base); lane 0 of the quad keeps the search's books.
+struct SimpleOpts {
+  int64_t base_cost, decrease_overlap_cost, increase_max_between_pair_cost, max_cost, traverse_ref_cost, pairs_used_cost,
+      rejoin_local_cost, size_change_cost;
+  uint64_t max_ambiguous_bases, max_search_steps, max_bases_between_pairs, max_pair_distance, max_pairs_per_read;
+  uint32_t min_overlap;
+  int trace_ambiguous_ref, forward_pairs_face_inward;
+};
+struct EntryPos { uint64_t entry; int32_t off; int32_t pad; };   // std::pair<uint64_t, int32_t>
+struct MatePos { uint32_t read; int32_t off; };                  // std::pair<uint32_t, int32_t>
+
+__device__ __forceinline__ bool sim_has_rc_mate_in_range(const TraceSimpleTables& tb, const TraceSeed& sd, uint32_t read_id, int64_t start,
+                                                         int64_t limit) {  // tracer.cpp:466-475 through the window
+  const int64_t lo = start > int64_t(sd.win_lo) ? start : int64_t(sd.win_lo);
+  const int64_t hi = limit < int64_t(sd.win_hi) + 1 ? limit : int64_t(sd.win_hi) + 1;
+  if (lo >= hi) return false;
+  const MatePos* v = static_cast<const MatePos*>(tb.mate_positions);
+  const int32_t lo32 = int32_t(lo);
+  uint64_t a = 0, z = tb.n_mate_positions;
+  while (a < z) {  // lower_bound of (read_id, lo)
+    const uint64_t mid = (a + z) >> 1;
+    const MatePos m = v[mid];
+    if (m.read < read_id || (m.read == read_id && m.off < lo32)) a = mid + 1; else z = mid;
+  }
+  if (a >= tb.n_mate_positions) return false;
+  const MatePos m = v[a];
+  return m.read == read_id && int64_t(m.off) < hi;
+}
+
+__global__ __launch_bounds__(64) void k_trace_simple(SeqsetView v, const uint64_t* __restrict__ has_reads, TraceSimpleTables tb, SimpleOpts o,
+                                                    const TraceSeed* __restrict__ seeds, uint64_t n, TraceSimpleOut* __restrict__ outs) {
+  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t i = t >> 2;
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63, base = lane & 3, quad0 = lane & ~3;
+  const bool book = base == 0;
+  const TraceSeed sd = seeds[i];
+  TraceSimpleOut* out = outs + i;
+  auto is_read = [&](uint64_t rb, uint64_t re, uint32_t rs) {
+    return rb + 1 == re && rs == v.sizes[rb] && ((has_reads[rb >> 6] >> (rb & 63)) & 1);
+  };
+  uint32_t counters = 0, status = kSimpleHost;
+  // ---- tracer::trace (:477-519)
+  const unsigned mc = tb.ref_map[sd.entry] & 63u;
+  bool run = true;
+  if (mc > 1) {
+    counters |= kSimAmbiguousRefReads;
+    if (!o.trace_ambiguous_ref) { status = kSimpleNothing; run = false; }
+  } else {
+    counters |= kSimRefReads;
+  }
+  unsigned min_overlap = sd.size & 0xffu;  // uint8_t(left_anchor.size())
+  unsigned ambiguous_bases = sd.ref_ambiguous;
+  int64_t cost = 0;
+  // push_next_path (:879-905): cost 0; trace_next_paths (:943-1021) pops it
+  if (run && cost > o.max_cost) { counters |= kSimMaxBranchCost; status = kSimpleNothing; run = false; }
+  if (run && uint64_t(ambiguous_bases) > o.max_ambiguous_bases) { counters |= kSimTooManyAmbiguousBases; status = kSimpleNothing; run = false; }
+  if (run) {
+    counters |= kSimStepCount;
+    if (1 > o.max_search_steps) { counters |= kSimTooManySteps; status = kSimpleNothing; run = false; }
+  }
+  if (!run) {  // (uniform over the quad: every lane of it read the same seed)
+    if (book) { out->status = status; out->counters = counters; out->n_steps = 0; out->n_ids = 0; out->found_pairs = 0; }
+    return;
+  }
+  // ---- expand_next_path (:528-673) for path 0: the walk, with add_base's books (:847-877) kept per step
+  uint64_t b = sd.entry, e = sd.entry + 1;
+  uint32_t s = sd.size, min_ctx = o.min_overlap;
+  unsigned pushed_since_read = 0, path_bases = 0, pushed_since_pair = 0, max_between_pairs = 0, n_steps = 0;
+  bool too_far = false, on_read = false, dead = false;
+  uint64_t pb, pe;
+  uint32_t ps, valid = 0;
+  for (;;) {
+    v.push_front_drop(b, e, s, 3 - base, min_ctx, &pb, &pe, &ps);
+    const bool ok = pe > pb;  // (loop check: next_path::loop_check_seqset_id is unset before the first read)
+    valid = uint32_t((__ballot(ok) >> quad0) & 15ull);
+    if (__popc(valid) != 1) { dead = valid == 0; break; }       // AMBIGUOUS: no push (a dead end of path 0) or a branch
+    if (n_steps >= uint32_t(kSimpleSteps)) break;              // longer than the fast path keeps: the host's
+    const int next = __ffs(int(valid)) - 1;
+    b = __shfl(pb, quad0 + next, 64);
+    e = __shfl(pe, quad0 + next, 64);
+    s = __shfl(ps, quad0 + next, 64);
+    if (book) out->bases[n_steps] = uint8_t(next);
+    ++n_steps;
+    ++min_ctx;
+    // add_base
+    ++pushed_since_read;
+    ++path_bases;
+    if (ambiguous_bases) ++ambiguous_bases;
+    cost += o.base_cost;
+    const unsigned overlap = s - pushed_since_read;
+    if (overlap < min_overlap) {
+      const unsigned dec = min_overlap - overlap;
+      cost += o.decrease_overlap_cost * int64_t(dec);
+      min_overlap = overlap & 0xffu;
+      max_between_pairs += dec * 2;
+    }
+    ++pushed_since_pair;
+    if (pushed_since_pair > max_between_pairs) {
+      ++max_between_pairs;
+      cost += o.increase_max_between_pair_cost;
+    }
+    if (is_read(b, e, s)) { on_read = true; break; }            // STEPPED_ON_READ: add_pairs and the rejoin test below
+    if (uint64_t(pushed_since_pair) > o.max_bases_between_pairs) { too_far = true; break; }
+  }
+  if (!book) return;
+  out->n_steps = n_steps;
+  out->n_ids = 0;
+  out->found_pairs = 0;
+  if (too_far) { out->status = kSimpleNothing; out->counters = counters | kSimTooFarWithoutPair; return; }
+  if (!on_read) {
+    // no push at all from path 0: ++ambiguous_steps, nothing to branch into, no dead-end rejoin for a path without a
+    // predecessor (:726-735): the trace ends without an assembly.  Anything else is the host's.
+    out->status = (dead && n_steps < uint32_t(kSimpleSteps)) ? kSimpleNothing : kSimpleHost;
+    out->counters = counters;
+    return;
+  }
+  // ---- add_pairs (:737-845) at the read the walk landed on
+  const uint64_t sid = b;
+  uint32_t first = 0, second = 0;
+  {
+    const uint64_t word = has_reads[sid >> 6], bit = 1ull << (sid & 63);
+    if (word & bit) {
+      const uint32_t g = tb.word_rank[sid >> 6] + uint32_t(__popcll(word & (bit - 1)));
+      first = tb.group_start[g];
+      second = tb.group_start[g + 1];
+    }
+  }
+  if (first != second) {
+    pushed_since_read = 0;
+    const unsigned ref_count = tb.ref_map[sid] & 63u;
+    if (ref_count > 1) {
+      ambiguous_bases = ambiguous_bases > s ? ambiguous_bases : s;
+      if (!o.trace_ambiguous_ref) { cost += o.max_cost; counters |= kSimPruneAmbiguousRef; }
+    } else if (ref_count == 1) {
+      cost += o.traverse_ref_cost;
+    }
+  }
+  bool matched_pair = false;
+  unsigned added_pairs = 0, added_reads = 0, found_pairs = 0;
+  for (uint32_t rid = first; rid != second; ++rid) {
+    const uint32_t m1 = tb.mate_loop[rid];
+    if (tb.mate_loop[m1] == rid) continue;  // !has_mate
+    if (added_reads < o.max_pairs_per_read) {
+      if (added_reads < uint32_t(kSimpleIds)) out->ids[added_reads] = rid;
+      ++added_reads;
+    }
+    if (bool(tb.is_forward[rid]) == bool(o.forward_pairs_face_inward)) {
+      if (matched_pair) continue;
+      int64_t ambiguous_in_ref = 0;
+      if (ambiguous_bases > path_bases) ambiguous_in_ref = int64_t(ambiguous_bases) - int64_t(path_bases);
+      if (sim_has_rc_mate_in_range(tb, sd, rid, int64_t(sd.cur_offset) + int64_t(path_bases) - int64_t(o.max_pair_distance),
+                                   int64_t(sd.cur_offset) - (ambiguous_in_ref > 0 ? ambiguous_in_ref : 0))) {
+        matched_pair = true;
+        continue;
+      }
+      // path_has_read_in_range (:1129-1160) over path 0 alone: its pairs were all seen at this very base, at distance 0
+      // ("cur_distance > 0" never holds), and the path has no predecessor -- false
+    } else {
+      if (added_pairs < o.max_pairs_per_read) { ++added_pairs; ++found_pairs; }
+      if (matched_pair) continue;
+      if (sim_has_rc_mate_in_range(tb, sd, rid, int64_t(sd.cur_offset), int64_t(sd.cur_offset) + int64_t(path_bases) + int64_t(o.max_pair_distance)))
+        matched_pair = true;
+    }
+  }
+  if (matched_pair) {
+    pushed_since_pair = 0;
+    ambiguous_bases = 0;
+    cost += o.pairs_used_cost;
+    counters |= kSimMatchedPairs;
+  }
+  out->found_pairs = found_pairs;
+  out->n_ids = added_reads;
+  if (added_reads > uint32_t(kSimpleIds)) { out->status = kSimpleHost; out->counters = counters; return; }
+  if (uint64_t(pushed_since_pair) > o.max_bases_between_pairs) { out->status = kSimpleNothing; out->counters = counters | kSimTooFarWithoutPair; return; }
+  // ---- add_rejoins (:675-724): the nearest place after cur_offset where this read lies on the scaffold
+  int64_t best_distance = -1;
+  int32_t best_offset = -1;
+  {
+    const EntryPos* ep = static_cast<const EntryPos*>(tb.entry_positions);
+    uint64_t a = 0, z = tb.n_entry_positions;
+    while (a < z) {  // upper_bound of (sid, cur_offset)
+      const uint64_t mid = (a + z) >> 1;
+      const EntryPos m = ep[mid];
+      if (m.entry < sid || (m.entry == sid && m.off <= sd.cur_offset)) a = mid + 1; else z = mid;
+    }
+    for (uint64_t k = a; k < tb.n_entry_positions; ++k) {
+      const EntryPos m = ep[k];
+      if (m.entry != sid || m.off > sd.win_hi) break;
+      int64_t distance = int64_t(sd.cur_offset) + int64_t(path_bases) - int64_t(m.off);
+      if (distance < 0) distance = -distance;
+      if (best_distance < 0 || distance < best_distance) { best_distance = distance; best_offset = m.off; }
+    }
+  }
+  if (best_distance < 0 || (ambiguous_bases && best_distance > int64_t(ambiguous_bases))) {
+    out->status = kSimpleHost;  // the walk goes on from this read: the host's
+    out->counters = counters;
+    return;
+  }
+  const int64_t rejoin_cost = o.rejoin_local_cost + best_distance * o.size_change_cost - o.traverse_ref_cost;
+  if (cost + rejoin_cost > o.max_cost) {  // push_rejoin (:907-925) refuses it: the trace ends without an assembly
+    out->status = kSimpleNothing;
+    out->counters = counters | kSimMaxBranchCost;
+    return;
+  }
+  out->status = kSimpleAssembly;
+  out->counters = counters | kSimOutput;
+  out->right_offset = best_offset;
+  out->right_anchor_len = s;
+  out->min_overlap = min_overlap;
+}
+
+int tracer_simple_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const TraceSimpleTables& tb, const bg_trace_options& op,
+                        const TraceSeed* d_seeds, uint64_t n, TraceSimpleOut* d_out) {
+  if (!n) return BG_OK;
+  BG_HIP(hipSetDevice(ctx->device));
+  SimpleOpts o;
+  o.base_cost = op.base_cost;
+  o.decrease_overlap_cost = op.decrease_overlap_cost;
+  o.increase_max_between_pair_cost = op.increase_max_between_pair_cost;
+  o.max_cost = op.max_cost;
+  o.traverse_ref_cost = op.traverse_ref_cost;
+  o.pairs_used_cost = op.pairs_used_cost;
+  o.rejoin_local_cost = op.rejoin_local_cost;
+  o.size_change_cost = op.size_change_cost;
+  o.max_ambiguous_bases = op.max_ambiguous_bases;
+  o.max_search_steps = op.max_search_steps;
+  o.max_bases_between_pairs = op.max_bases_between_pairs;
+  o.max_pair_distance = op.max_pair_distance;
+  o.max_pairs_per_read = op.max_pairs_per_read;
+  o.min_overlap = uint32_t(op.min_overlap);
+  o.trace_ambiguous_ref = op.trace_ambiguous_ref;
+  o.forward_pairs_face_inward = op.forward_pairs_face_inward;
+  k_trace_simple<<<cdiv(n * 4, 64), 64, 0, ctx->stream>>>(make_view(ss), rm->s2m_bits.p, tb, o, d_seeds, n, d_out);
+  BG_LAUNCH_CHECK();
+  return BG_OK;
+}
+
 __global__ void k_ref_map_pack(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ flags, uint64_t n,
                                uint8_t* __restrict__ out) {
   uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
