@@ -1191,12 +1191,13 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   cov.simple_genotype_filter = flag("simple-gt", false) ? 1 : 0;
   cov.rvg_exclude = flag("rvg-exclude", true) ? 1 : 0;
   // trace_ref runs its work items on the process's thread pool (trace_ref.cpp:105-140); here: --threads sessions
-  // (default 24, or the host's cores when fewer: with the pop tracers on, tracing the chr20-shaped sample takes 12.9 s on
-  // 16, 11.3 s on 24, 12.8 s on 32 -- the sessions are bound by their host replay, 0.6 s of one core per piece and
-  // direction), each with its own context (stream + allocator) and scratch, the read-only host tables shared, side by side
-  // on the one GPU
+  // (default 16, or the host's cores when fewer: since the traces that never branch run on the device -- nine in ten -- and
+  // the search states come out of a thread-caching allocator, tracing the chr20-shaped sample takes 8.6 s on 8 sessions,
+  // 5.7 s on 16, 5.9-6.4 s on 24, 7.1 s on 32, 8.7 s on 48: profiles/r04_discovery_sessions_cpu_time.txt; round 3: 12.9 s on
+  // 16, 11.3 s on 24), each with its own context (stream + allocator) and scratch, the read-only host tables shared, side
+  // by side on the one GPU
   int n_threads = a.has("threads") ? atoi(a.get("threads").c_str())
-                                   : int(std::min(24u, std::max(1u, std::thread::hardware_concurrency())));
+                                   : int(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
   if (n_threads < 1) n_threads = 1;
   if (n_threads > 64) n_threads = 64;
   const double t_open0 = now_s();
