@@ -40,6 +40,7 @@
 
 #include "../../../include/bgseq.h"
 #define FASTALLOC_DEFINE
+#include "cpuprof.h"    // BG_CPU_PROFILE=FILE: a sampling profile of the command (off unless set)
 #include "fastalloc.h"  // thread-caching operator new / delete: the tracer sessions of `discovery` live on small allocations
 
 static void die(const std::string& msg) {
@@ -1436,6 +1437,7 @@ static int cmd_discovery(int argc, char** argv) {
   mallopt(M_TRIM_THRESHOLD, 1 << 30);
   mallopt(M_MMAP_THRESHOLD, 1 << 30);
   mallopt(M_TOP_PAD, 256 << 20);
+  cpuprof::start();
   Args a = parse(argc, argv, 2, {"reads", "ref", "out", "sample", "min-overlap", "max-pair-distance", "bed", "engine", "max-ploids",
                                  "enable-pop-tracer", "threads", "ml-features", "scaffold-split-size", "simple-gt", "rvg-exclude",
                                  "force", "ref-map", "min-pop-overlap", "assemblies-out", "aligned-assemblies-out"});
@@ -1527,6 +1529,7 @@ static int cmd_discovery(int argc, char** argv) {
     const int rc = discovery_push(a, recs, bed, ctx, ss, rm, min_overlap, max_pair_distance, sample, flat_codes, flat_start, flat_size);
     // The outputs are written and closed: the process ends here.  Handing tens of gigabytes of host tables, the seqset, the
     // readmap and the contexts back piece by piece before exiting took most of a second of a ten-second command.
+    cpuprof::stop_and_write();
     fflush(nullptr);
     _exit(rc);
   }

@@ -1,16 +1,22 @@
 // fastalloc.h — a thread-caching replacement of the global operator new / delete for bgbinary.
 //
-// `bgbinary discovery` runs the reference's cost-ordered search (variants/tracer.cpp) as a host program: 24 tracer sessions,
-// each with pool threads, allocate and free hundreds of millions of small search states (paths, their sequences, pair lists).
-// With glibc's malloc the process spent 56-130 s of SYSTEM time per 12-19 s of tracing on the chr20-shaped sample (futex waits
-// on the arenas: 1.9 M voluntary context switches with the default arenas, 152 M with one; 7.6 M page faults of heaps that are
-// unmapped when a work item ends and mapped again for the next) -- profiles/r04_discovery_sessions_cpu_time.txt.
+// `bgbinary discovery` runs the reference's cost-ordered search (variants/tracer.cpp) as a host program: 16 tracer sessions,
+// each with pool threads, and up to 128 coverage workers allocate and free hundreds of millions of small search states (paths,
+// their sequences, pair lists) and, per work item, tables of kilobytes to tens of megabytes.  With glibc's malloc the process
+// spent 56-130 s of SYSTEM time per 12-19 s of tracing on the chr20-shaped sample (futex waits on the arenas: 1.9 M voluntary
+// context switches with the default arenas, 152 M with one; 7.6 M page faults of heaps that are unmapped when a work item ends
+// and mapped again for the next) -- profiles/r04_discovery_sessions_cpu_time.txt; with the small blocks alone served here, a
+// sixth of the command's wall time still sat in malloc's internals and munmap (the sampling profile of csrc/cli/cpuprof.h).
 //
-// Here every thread carves small blocks (<= 2 KiB, 16-byte classes) out of 1 MiB chunks of its own and keeps the blocks it
+// Small blocks (<= 2 KiB, 16-byte classes): every thread carves them out of 1 MiB chunks of its own and keeps the blocks it
 // frees on per-class lists of its own: no lock, no system call.  Blocks migrate (the pool threads allocate a trace's state,
-// the session thread frees it): a list that grows past a bound hands half of itself to a per-class global stack as one batch,
-// and an empty list takes a batch from there before it carves.  Chunks are never returned (the process is a command).  Larger
-// requests go to malloc.  A 16-byte header in front of every block names its class.  BG_FAST_ALLOC=0: plain malloc / free.
+// the session thread frees it): a list that grows past a bound hands part of itself to a per-class global stack as one batch,
+// and an empty list takes a batch from there before it carves.  Chunks are never returned (the process is a command).
+// Large blocks (2 KiB .. 64 MiB, four classes per octave: at most a quarter of a block is slack): malloc'ed once, then kept --
+// a thread keeps up to 32 MiB per class (at least one block), the rest goes to a per-class global stack; their pages are
+// touched for the first time once, not once per work item.  Anything larger goes to malloc.  A thread that ends hands every
+// list it holds to the global stacks.  A 16-byte header in front of every block names its class.  BG_FAST_ALLOC=0: plain
+// malloc / free.
 #pragma once
 #include <stdint.h>
 #include <stdlib.h>
@@ -23,28 +29,33 @@ namespace fastalloc {
 
 constexpr size_t kStep = 16, kMaxSmall = 2048;
 constexpr int kClasses = int(kMaxSmall / kStep);
+constexpr int kLargeLog0 = 11, kLargeLog1 = 26;            // large classes cover (2^11, 2^26] bytes
+constexpr int kLargeClasses = (kLargeLog1 - kLargeLog0) * 4;
+constexpr size_t kMaxLarge = size_t(1) << kLargeLog1;
+constexpr size_t kLargeKeep = size_t(32) << 20;            // bytes per class a thread keeps for itself
 constexpr size_t kChunk = size_t(1) << 20;
-constexpr uint32_t kBatch = 512;            // blocks handed over at a time
+constexpr uint32_t kBatch = 512;                           // small blocks handed over at a time
 constexpr uint32_t kLargeTag = 0xffffffffu, kMagic = 0xb10c5eedu;
 
-struct Header { uint32_t cls, magic; uint64_t pad; };  // 16 bytes: the user pointer stays 16-byte aligned
+// 16 bytes: the user pointer stays 16-byte aligned.  `count` is only meaningful in the first block of a batch on a global stack.
+struct Header { uint32_t cls, magic; uint64_t count; };
 struct Block { Block* next; };
-struct Batch { Batch* next_batch; Block* blocks; };     // a batch lives in its first block's payload (>= 16 bytes)
+// a batch is a singly linked list of blocks; the stack links batches through the second word of their first block (class 0
+// blocks hold 16 bytes: both words fit)
+struct BatchHead { Block* next; BatchHead* next_batch; };
 
 struct Global {
   std::atomic_flag lock = ATOMIC_FLAG_INIT;
-  Block* batches = nullptr;  // stack of batches: each entry is a block whose `next` chains the batch, linked through `link`
+  Block* batches = nullptr;
 };
-// per class: a lock-protected stack of batches.  A batch is a singly linked list of kBatch blocks; the stack links batches
-// through the second word of their first block.
-struct BatchHead { Block* next; BatchHead* next_batch; };
-extern Global g_global[kClasses];
+extern Global g_global[kClasses + kLargeClasses];
 
 struct Local {
-  Block* free_list[kClasses];
-  uint32_t count[kClasses];
+  Block* free_list[kClasses + kLargeClasses];
+  uint32_t count[kClasses + kLargeClasses];
   char* chunk;
   size_t left;
+  bool registered;
 };
 
 inline bool enabled() {
@@ -60,9 +71,61 @@ inline Local& local() {
 inline void lock(Global& g) { while (g.lock.test_and_set(std::memory_order_acquire)) { } }
 inline void unlock(Global& g) { g.lock.clear(std::memory_order_release); }
 
+inline void push_batch(int cls, Block* first, uint32_t count) {
+  (reinterpret_cast<Header*>(first) - 1)->count = count;
+  BatchHead* bh = reinterpret_cast<BatchHead*>(first);
+  Global& g = g_global[cls];
+  lock(g);
+  bh->next_batch = reinterpret_cast<BatchHead*>(g.batches);
+  g.batches = first;
+  unlock(g);
+}
+
+inline Block* pop_batch(int cls, uint32_t* count) {
+  Global& g = g_global[cls];
+  if (!g.batches) return nullptr;  // (racy peek: a miss only means carving)
+  lock(g);
+  BatchHead* bh = reinterpret_cast<BatchHead*>(g.batches);
+  if (bh) g.batches = reinterpret_cast<Block*>(bh->next_batch);
+  unlock(g);
+  if (!bh) return nullptr;
+  Block* first = reinterpret_cast<Block*>(bh);
+  *count = uint32_t((reinterpret_cast<Header*>(first) - 1)->count);
+  return first;
+}
+
+// a thread that ends gives what it holds to the others
+struct Flusher {
+  ~Flusher() {
+    Local& l = local();
+    for (int c = 0; c < kClasses + kLargeClasses; ++c) {
+      if (!l.free_list[c]) continue;
+      Block* first = l.free_list[c];
+      const uint32_t n = l.count[c];
+      l.free_list[c] = nullptr;
+      l.count[c] = 0;
+      if (c < kClasses) { push_batch(c, first, n); continue; }
+      while (first) { Block* next = first->next; first->next = nullptr; push_batch(c, first, 1); first = next; }
+    }
+  }
+};
+inline void register_thread(Local& l) {
+  l.registered = true;  // (first: registering may allocate)
+  static thread_local Flusher f;
+  (void)&f;
+}
+
+inline size_t large_size(int lc) { return (size_t(1) << (kLargeLog0 + lc / 4)) + size_t(lc % 4 + 1) * (size_t(1) << (kLargeLog0 + lc / 4 - 2)); }
+inline int large_class(size_t size) {  // 2 KiB < size <= 64 MiB
+  const int k = 63 - __builtin_clzll(uint64_t(size - 1));  // 2^k < size <= 2^(k+1)
+  const size_t step = size_t(1) << (k - 2);
+  const int idx = int((size - (size_t(1) << k) + step - 1) / step);  // 1..4
+  return (k - kLargeLog0) * 4 + idx - 1;
+}
+
 inline void* allocate(size_t size) {
   if (size == 0) size = 1;
-  if (size > kMaxSmall || !enabled()) {
+  if (size > kMaxLarge || !enabled()) {
     void* raw = malloc(size + sizeof(Header));
     if (!raw) throw std::bad_alloc();
     Header* h = static_cast<Header*>(raw);
@@ -70,8 +133,26 @@ inline void* allocate(size_t size) {
     h->magic = kMagic;
     return h + 1;
   }
-  const int cls = int((size + kStep - 1) / kStep) - 1;
   Local& l = local();
+  if (size > kMaxSmall) {
+    const int lc = large_class(size), cls = kClasses + lc;
+    Block* b = l.free_list[cls];
+    if (b) {
+      l.free_list[cls] = b->next;
+      --l.count[cls];
+      return b;
+    }
+    uint32_t n = 0;
+    if (Block* first = pop_batch(cls, &n)) return first;  // (large batches hold one block)
+    if (!l.registered) register_thread(l);
+    void* raw = malloc(large_size(lc) + sizeof(Header));
+    if (!raw) throw std::bad_alloc();
+    Header* h = static_cast<Header*>(raw);
+    h->cls = uint32_t(cls);
+    h->magic = kMagic;
+    return h + 1;
+  }
+  const int cls = int((size + kStep - 1) / kStep) - 1;
   Block* b = l.free_list[cls];
   if (b) {
     l.free_list[cls] = b->next;
@@ -79,19 +160,13 @@ inline void* allocate(size_t size) {
     return b;
   }
   // a batch somebody handed over?
-  Global& g = g_global[cls];
-  if (g.batches) {  // (racy peek: a miss only means carving)
-    lock(g);
-    BatchHead* bh = reinterpret_cast<BatchHead*>(g.batches);
-    if (bh) g.batches = reinterpret_cast<Block*>(bh->next_batch);
-    unlock(g);
-    if (bh) {
-      Block* first = reinterpret_cast<Block*>(bh);
-      l.free_list[cls] = first->next;
-      l.count[cls] = kBatch - 1;
-      return first;
-    }
+  uint32_t n = 0;
+  if (Block* first = pop_batch(cls, &n)) {
+    l.free_list[cls] = first->next;
+    l.count[cls] = n - 1;
+    return first;
   }
+  if (!l.registered) register_thread(l);
   const size_t need = sizeof(Header) + size_t(cls + 1) * kStep;
   if (l.left < need) {
     l.chunk = static_cast<char*>(malloc(kChunk));
@@ -114,22 +189,28 @@ inline void deallocate(void* p) {
   const int cls = int(h->cls);
   Local& l = local();
   Block* b = static_cast<Block*>(p);
+  if (cls >= kClasses) {
+    if (l.count[cls] && size_t(l.count[cls] + 1) * large_size(cls - kClasses) > kLargeKeep) {
+      b->next = nullptr;
+      push_batch(cls, b, 1);
+      return;
+    }
+    b->next = l.free_list[cls];
+    l.free_list[cls] = b;
+    ++l.count[cls];
+    return;
+  }
   b->next = l.free_list[cls];
   l.free_list[cls] = b;
   if (++l.count[cls] >= 4 * kBatch) {
-    // hand the newest kBatch blocks over as one batch (class 0 blocks hold 16 bytes: next + next_batch fit)
+    // hand the newest kBatch blocks over as one batch
     Block* first = l.free_list[cls];
     Block* last = first;
     for (uint32_t i = 1; i < kBatch; ++i) last = last->next;
     l.free_list[cls] = last->next;
     last->next = nullptr;
     l.count[cls] -= kBatch;
-    BatchHead* bh = reinterpret_cast<BatchHead*>(first);
-    Global& g = g_global[cls];
-    lock(g);
-    bh->next_batch = reinterpret_cast<BatchHead*>(g.batches);
-    g.batches = first;
-    unlock(g);
+    push_batch(cls, first, kBatch);
   }
 }
 
@@ -137,7 +218,7 @@ inline void deallocate(void* p) {
 
 #ifdef FASTALLOC_DEFINE
 namespace fastalloc {
-Global g_global[kClasses];
+Global g_global[kClasses + kLargeClasses];
 }
 void* operator new(size_t n) { return fastalloc::allocate(n); }
 void* operator new[](size_t n) { return fastalloc::allocate(n); }

@@ -20,10 +20,15 @@
 // tracker has reported).  What a tracker holds cannot change after the last path dropped it and everything reported is
 // a minimum or a sum, so trackers are kept to the end and reported then; the output is put in canon order, the order
 // the reference's sorted output queue with its tracked left offsets produces.
+#include <limits.h>
+#include <linux/futex.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <map>
 #include <memory>
@@ -134,27 +139,36 @@ struct WalkRequest {
   std::vector<uint64_t> out;
 };
 
-// The islands of a scaffold advance in lock step: every worker thread runs one island's state machine and stops at each
-// stretch of bases it needs walked; when all live workers have stopped, the caller's thread (the only one that talks
-// to HIP) ships all stretches in one bg_walk_chains_batch and wakes them.
+// The islands of a scaffold advance in lock step, a group of workers at a time: every worker thread runs one island's state
+// machine and stops at each stretch of bases it needs walked; when all live workers of the group have stopped, the group's
+// launcher thread (the only one that talks to HIP for the group, on the group's own context and stream) ships all stretches
+// in one bg_walk_chains_batch and wakes them.  A round costs a launch, three copies and a wake-up of every worker whatever
+// it carries, and an island takes about nine of them: several groups run their rounds side by side on the device, and the
+// workers of a group sleep on the round counter itself (a futex: one wake call, no mutex for the woken to queue behind).
 class Batcher {
  public:
   Batcher(bg_ctx* ctx, const bg_seqset* ss, int workers) : ctx_(ctx), ss_(ss), live_(workers) {}
   void submit_and_wait(const std::vector<WalkRequest*>& reqs) {
-    std::unique_lock<std::mutex> l(mu_);
-    pending_.insert(pending_.end(), reqs.begin(), reqs.end());
-    ++waiting_;
-    const uint64_t round = round_;
-    if (waiting_ == live_) cv_all_.notify_one();
-    cv_done_.wait(l, [&] { return round_ != round; });
-    if (!error_.empty()) throw CheckFailed{error_};
+    uint32_t round;
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      pending_.insert(pending_.end(), reqs.begin(), reqs.end());
+      round = round_.load(std::memory_order_relaxed);
+      if (++waiting_ == live_) cv_all_.notify_one();
+    }
+    while (round_.load(std::memory_order_acquire) == round)
+      syscall(SYS_futex, reinterpret_cast<uint32_t*>(&round_), FUTEX_WAIT_PRIVATE, round, nullptr, nullptr, 0);
+    if (failed_.load(std::memory_order_acquire)) {
+      std::lock_guard<std::mutex> l(mu_);
+      throw CheckFailed{error_};
+    }
   }
   void worker_exit() {
     std::unique_lock<std::mutex> l(mu_);
     --live_;
     cv_all_.notify_one();
   }
-  void run() {  // on the calling thread
+  void run() {  // on the group's launcher thread
     std::unique_lock<std::mutex> l(mu_);
     for (;;) {
       cv_all_.wait(l, [&] { return live_ == 0 || waiting_ == live_; });
@@ -164,10 +178,10 @@ class Batcher {
       l.unlock();
       const std::string err = launch(batch);
       l.lock();
-      if (!err.empty() && error_.empty()) error_ = err;
+      if (!err.empty() && error_.empty()) { error_ = err; failed_.store(true, std::memory_order_release); }
       waiting_ = 0;
-      ++round_;
-      cv_done_.notify_all();
+      round_.fetch_add(1, std::memory_order_release);
+      syscall(SYS_futex, reinterpret_cast<uint32_t*>(&round_), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
     }
   }
   uint64_t launches = 0, steps = 0;
@@ -200,10 +214,12 @@ class Batcher {
   bg_ctx* ctx_;
   const bg_seqset* ss_;
   std::mutex mu_;
-  std::condition_variable cv_all_, cv_done_;
+  std::condition_variable cv_all_;
   std::vector<WalkRequest*> pending_;
   int live_, waiting_ = 0;
-  uint64_t round_ = 0;
+  std::atomic<uint32_t> round_{0};
+  static_assert(sizeof(std::atomic<uint32_t>) == 4, "the round counter is the futex word");
+  std::atomic<bool> failed_{false};
   std::string error_;
 };
 
@@ -221,7 +237,6 @@ struct CovWorld {
   std::vector<uint32_t> word_rank, group_start;
   uint32_t min_read_len = 0;
   int64_t max_read_len = 0;
-  Batcher* batcher = nullptr;
   std::pair<uint32_t, uint32_t> entry_to_index(uint64_t e) const {
     const uint64_t word = has_reads[e >> 6], bit = 1ull << (e & 63);
     if (!(word & bit)) return {0u, 0u};
@@ -330,9 +345,9 @@ class PathGroup {
 
 class Coverage {
  public:
-  explicit Coverage(const CovWorld& w)
+  Coverage(const CovWorld& w, Batcher* batcher)
       : world_(w), ss_(w.ss), sc_(*w.sc), o_(w.o), read_len_(w.read_len), is_forward_(w.is_forward),
-        min_read_len_(w.min_read_len), max_read_len_(w.max_read_len), batcher_(w.batcher) {
+        min_read_len_(w.min_read_len), max_read_len_(w.max_read_len), batcher_(batcher) {
     it_offset_ = sc_.ext.empty() ? sc_.end_pos : sc_.ext[0].offset;
     cur_offset_ = it_offset_;
     init_ref_pg();
@@ -748,6 +763,8 @@ struct bg_coverage {
   bg_ctx* ctx = nullptr;
   const bg_seqset* ss = nullptr;
   CovWorld tables;
+  std::vector<bg_ctx*> group_ctx;  // contexts (streams) of the worker groups beyond the first, made when first needed
+  ~bg_coverage() { for (bg_ctx* g : group_ctx) bg_ctx_destroy(g); }
 };
 
 extern "C" int bg_coverage_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, bg_coverage** out) {
@@ -792,7 +809,7 @@ extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64
   std::unique_ptr<bg_trace_result> res(new bg_trace_result);
   memset(&res->stats, 0, sizeof(res->stats));
   try {
-    CovWorld& w = c->tables;  // the scaffold, the options and the batcher are this call's
+    CovWorld& w = c->tables;  // the scaffold and the options are this call's
     w.sc = &sc;
     w.o = o;
     // Islands: calc_coverage re-initialises its reference path group whenever nothing is active and the next variant
@@ -810,32 +827,53 @@ extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64
       need_to = std::max(need_to, a.right_offset + w.max_read_len);
     }
     std::vector<std::vector<bg_trace_assembly_rec>> done(islands.size());
-    size_t max_workers = 128;
+    // BG_COVERAGE_GROUPS groups (default 4) of up to BG_COVERAGE_WORKERS workers (default 128) each; worker u of all runs
+    // islands u, u + all, ...  (chr20-shaped sample, coverage + genotype: 1 x 128 with a condition variable 2.06 s; with the
+    // futex 1 x 128 1.86 s, 1 x 256 1.72 s, 8 x 64 0.93 s, 16 x 32 1.31 s, 16 x 64 1.16 s, 4 x 128 0.87 s, 8 x 128 0.85 s)
+    size_t max_workers = 128, max_groups = 4;
     if (const char* e = getenv("BG_COVERAGE_WORKERS")) max_workers = size_t(std::max(1, atoi(e)));
-    const int workers = int(std::min<size_t>(islands.size(), max_workers));
-    Batcher batcher(ctx, ss, workers);
-    w.batcher = &batcher;
+    if (const char* e = getenv("BG_COVERAGE_GROUPS")) max_groups = size_t(std::max(1, atoi(e)));
+    const size_t all = std::min<size_t>(islands.size(), max_workers * max_groups);
+    const size_t n_groups = all ? std::min<size_t>(max_groups, (all + max_workers - 1) / max_workers) : 0;
+    while (c->group_ctx.size() + 1 < n_groups) {
+      bg_ctx* g = nullptr;
+      if (bg_ctx_create_own_stream(ctx->device, &g) != BG_OK) throw CheckFailed{std::string("a worker group's context: ") + bg_last_error()};
+      c->group_ctx.push_back(g);
+    }
+    std::vector<std::unique_ptr<Batcher>> batchers;
+    std::vector<size_t> first_worker(n_groups + 1, 0);
+    for (size_t g = 0; g < n_groups; ++g) {
+      first_worker[g + 1] = all * (g + 1) / n_groups;
+      batchers.emplace_back(new Batcher(g ? c->group_ctx[g - 1] : ctx, ss, int(first_worker[g + 1] - first_worker[g])));
+    }
     std::mutex err_mu;
     std::string first_error;
     std::vector<std::thread> pool;
-    for (int t = 0; t < workers; ++t)
-      pool.emplace_back([&, t] {
-        try {
-          for (size_t i = size_t(t); i < islands.size(); i += size_t(workers)) {
-            Coverage c(w);
-            for (const bg_trace_assembly_rec* a : islands[i]) {
-              bg_trace_assembly_rec copy = *a;
-              c.add(std::move(copy));
+    for (size_t g = 0; g < n_groups; ++g)
+      for (size_t u = first_worker[g]; u < first_worker[g + 1]; ++u)
+        pool.emplace_back([&, g, u] {
+          Batcher* b = batchers[g].get();
+          try {
+            for (size_t i = u; i < islands.size(); i += all) {
+              Coverage cov(w, b);
+              for (const bg_trace_assembly_rec* a : islands[i]) {
+                bg_trace_assembly_rec copy = *a;
+                cov.add(std::move(copy));
+              }
+              cov.finish(&done[i]);
             }
-            c.finish(&done[i]);
+          } catch (const CheckFailed& f) {
+            std::lock_guard<std::mutex> l(err_mu);
+            if (first_error.empty()) first_error = f.what;
           }
-        } catch (const CheckFailed& f) {
-          std::lock_guard<std::mutex> l(err_mu);
-          if (first_error.empty()) first_error = f.what;
-        }
-        batcher.worker_exit();
+          b->worker_exit();
+        });
+    for (size_t g = 1; g < n_groups; ++g)
+      pool.emplace_back([&, g] {
+        (void)hipSetDevice(ctx->device);
+        batchers[g]->run();
       });
-    batcher.run();
+    if (n_groups) batchers[0]->run();
     for (auto& th : pool) th.join();
     if (!first_error.empty()) throw CheckFailed{first_error};
     std::vector<bg_trace_assembly_rec> covered;
@@ -847,8 +885,10 @@ extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64
       if (!genotype_filter || genotype(o, a)) passed.push_back(std::move(a));
     if (o.rvg_exclude) rvg_exclude_all(o, std::move(passed), &res->a);  // pipeline.cpp:102-104
     else res->a = std::move(passed);
-    res->stats.device_rounds = batcher.launches;
-    res->stats.device_queries = batcher.steps;
+    for (auto& b : batchers) {
+      res->stats.device_rounds += b->launches;
+      res->stats.device_queries += b->steps;
+    }
     res->stats.traces = islands.size();
   } catch (const CheckFailed& f) {
     set_error("bg_assemblies_coverage: %s", f.what.c_str());
