@@ -33,6 +33,7 @@
 #include <deque>
 #include <functional>
 #include <mutex>
+#include <queue>
 #include <map>
 #include <memory>
 #include <set>
@@ -810,8 +811,21 @@ struct Extent { int64_t offset; std::string seq; };
 int fail(const char* msg) { set_error("%s", msg); return BG_EINVAL; }
 
 // tracer::assemble(start, limit) over an already oriented scaffold -> assemblies in output order
+// A reference assembly that nobody is going to see (assemble_options::trace_reference_assemblies off): all pair_counter wants
+// of it are its two offsets and its read ids -- no sequence, no record, no id, no trip through the anchor_dropper's queue.
+// Twenty of twenty-one million assemblies of a chromosome are these.
+struct LeanRef { int64_t left, right; uint32_t ids_at, n_ids; };
+struct LeanOut {
+  std::vector<LeanRef> refs;   // in trace order = by left offset
+  std::vector<uint32_t> ids;
+  void add(int64_t left, int64_t right, const uint32_t* p, size_t n) {
+    refs.push_back(LeanRef{left, right, uint32_t(ids.size()), uint32_t(n)});
+    ids.insert(ids.end(), p, p + n);
+  }
+};
+
 int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t limit,
-                std::vector<bg_trace_assembly_rec>* out) {
+                std::vector<bg_trace_assembly_rec>* out, LeanOut* lean = nullptr) {
   bg_ctx* ctx = w.ctx;
   const bg_trace_options& o = w.o;
   const int64_t max_read_len = w.ss->max_len;
@@ -1073,7 +1087,10 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
     size_t hk = 0;
     for (size_t i = 0; i < n_seeds; ++i) {
       if (hk < host_seed.size() && host_seed[hk] == i) {
-        for (auto& a : host_out[hk]) out->push_back(std::move(a));
+        for (auto& a : host_out[hk]) {
+          if (lean && a.matches_reference && !a.anchor_drop) lean->add(a.left_offset, a.right_offset, a.rc_read_ids.data(), a.rc_read_ids.size());
+          else out->push_back(std::move(a));
+        }
         ++hk;
         continue;
       }
@@ -1093,6 +1110,13 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
       if (so.status != kSimpleAssembly) continue;
       const TraceSeed& sd = seeds[i];
       const SeedInfo& in = infos[i];
+      if (lean) {  // close_assembly's matches_reference from the lengths alone
+        const int64_t lo = int64_t(sd.cur_offset) - int64_t(sd.size), ro = so.right_offset;
+        if (int64_t(sd.size) + int64_t(so.right_anchor_len) >= ro - lo && ro - lo == int64_t(sd.size) + int64_t(so.n_steps)) {
+          lean->add(lo, ro, so.ids, so.n_ids);
+          continue;
+        }
+      }
       bg_trace_assembly_rec a;
       a.assembly_id = allocate_assembly_id();  // tracer.cpp:1166
       a.seq.reserve(size_t(sd.size) + so.n_steps);
@@ -1177,6 +1201,22 @@ struct PairCounter {
   std::multimap<int64_t, bg_trace_assembly_rec> active;
   IdCounter left_ids, right_ids;
   int64_t last_left = INT64_MIN;
+  // the reference assemblies that only lend their read ids (LeanRef), in queues of their own beside the three above: what
+  // happens to an assembly at an offset does not depend on the order among the assemblies that share the offset (entering
+  // `active` reads left_ids and takes from right_ids, leaving it reads right_ids and adds to left_ids, expiry takes from
+  // left_ids: three passes one after the other), so the two kinds only have to agree on the offsets
+  struct Lean { int64_t left, right; const uint32_t* ids; uint32_t n; };
+  struct LaterRight { bool operator()(const Lean& a, const Lean& b) const { return a.right > b.right; } };
+  std::deque<Lean> right_lean, left_lean;
+  std::priority_queue<Lean, std::vector<Lean>, LaterRight> active_lean;
+  bool add_lean(int64_t left, int64_t right_offset, const uint32_t* ids, uint32_t n) {
+    if (left < last_left) return false;
+    last_left = left;
+    while (advance_some(left - int64_t(w.o.max_pair_distance))) {}
+    for (uint32_t k = 0; k < n; ++k) right_ids.inc(ids[k]);
+    right_lean.push_back(Lean{left, right_offset, ids, n});
+    return true;
+  }
 
   std::vector<uint32_t> matches(const bg_trace_assembly_rec& a, const IdCounter& ids, bool forward) const {
     std::vector<uint32_t> out;
@@ -1202,6 +1242,9 @@ struct PairCounter {
     if (!left.empty()) amount = std::min(amount, left.front().first + int64_t(w.o.max_pair_distance) - cur_offset + 1);
     if (!active.empty()) amount = std::min(amount, active.begin()->first - cur_offset + 1);
     if (!right.empty()) amount = std::min(amount, right.front().first - cur_offset + 1);
+    if (!left_lean.empty()) amount = std::min(amount, left_lean.front().right + int64_t(w.o.max_pair_distance) - cur_offset + 1);
+    if (!active_lean.empty()) amount = std::min(amount, active_lean.top().right - cur_offset + 1);
+    if (!right_lean.empty()) amount = std::min(amount, right_lean.front().left - cur_offset + 1);
     cur_offset += amount;
     while (!right.empty() && right.front().first < cur_offset) {
       bg_trace_assembly_rec a = std::move(right.front().second);
@@ -1213,6 +1256,12 @@ struct PairCounter {
       if (!unused) a.left_pair_matches = matches(a, left_ids, w.o.forward_pairs_face_inward != 0);
       const int64_t ro = a.right_offset;
       active.emplace(ro, std::move(a));
+    }
+    while (!right_lean.empty() && right_lean.front().left < cur_offset) {
+      const Lean x = right_lean.front();
+      right_lean.pop_front();
+      for (uint32_t k = 0; k < x.n; ++k) right_ids.dec(x.ids[k]);
+      active_lean.push(x);
     }
     while (!active.empty() && active.begin()->first < cur_offset) {
       bg_trace_assembly_rec a = std::move(active.begin()->second);
@@ -1228,9 +1277,20 @@ struct PairCounter {
       a.score += int64_t(a.left_pair_matches.size() + a.right_pair_matches.size()) * w.o.pair_match_score;
       sink->push_back(std::move(a));
     }
+    while (!active_lean.empty() && active_lean.top().right < cur_offset) {
+      const Lean x = active_lean.top();
+      active_lean.pop();
+      for (uint32_t k = 0; k < x.n; ++k) left_ids.inc(x.ids[k]);
+      left_lean.push_back(x);
+    }
     while (!left.empty() && left.front().first < cur_offset - int64_t(w.o.max_pair_distance)) {
       for (uint32_t rid : left.front().second) left_ids.dec(rid);
       left.pop_front();
+    }
+    while (!left_lean.empty() && left_lean.front().right < cur_offset - int64_t(w.o.max_pair_distance)) {
+      const Lean& x = left_lean.front();
+      for (uint32_t k = 0; k < x.n; ++k) left_ids.dec(x.ids[k]);
+      left_lean.pop_front();
     }
     return true;
   }
@@ -1405,6 +1465,10 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
   std::unique_ptr<bg_trace_result> res(new bg_trace_result);
   if (rev_comp && w.o.only_trace_forward) { memset(&res->stats, 0, sizeof(res->stats)); *out = res.release(); return BG_OK; }
   std::vector<bg_trace_assembly_rec> raw;
+  // the unseen reference assemblies as lean records (BG_TRACER_LEAN_REFS=0: as full records through every step, as before)
+  static const bool lean_allowed = [] { const char* e = getenv("BG_TRACER_LEAN_REFS"); return !(e && e[0] == '0'); }();
+  LeanOut lean_out;
+  LeanOut* lean = (lean_allowed && pair_count && w.o.anchor_drop && !w.o.trace_reference_assemblies) ? &lean_out : nullptr;
   const double s_ext = now_seconds() - t_ext;
   const double t_chunk = now_seconds();
   if (rev_comp && t->ext_rc.empty())  // scaffold::rev_comp (scaffold.cpp:163-175)
@@ -1412,9 +1476,9 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
       t->ext_rc.push_back(Extent{end_pos - it->offset - int64_t(it->seq.size()), rev_comp_str(it->seq)});
   const std::vector<Extent>& rc = t->ext_rc;
   if (rev_comp) {
-    BG_TRY(trace_chunk(w, rc, end_pos - limit_offset, end_pos - start_offset, &raw));
+    BG_TRY(trace_chunk(w, rc, end_pos - limit_offset, end_pos - start_offset, &raw, lean));
   } else {
-    BG_TRY(trace_chunk(w, ext, start_offset, limit_offset, &raw));
+    BG_TRY(trace_chunk(w, ext, start_offset, limit_offset, &raw, lean));
   }
   const std::vector<Extent>& run_ext = rev_comp ? rc : ext;
   const double s_chunk = now_seconds() - t_chunk;
@@ -1452,8 +1516,22 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
   std::vector<bg_trace_assembly_rec> counted;
   if (pair_count) {
     PairCounter pc{w, &counted};
-    for (auto& a : raw)
-      if (!pc.add(std::move(a))) return fail("bg_tracer_trace: pair_counter: assemblies out of left-offset order");
+    // (traces run by ascending offset and a context grows by at most one base per step: left offsets never go back)
+    auto by_left = [](const LeanRef& a, const LeanRef& b) { return a.left < b.left; };
+    if (!std::is_sorted(lean_out.refs.begin(), lean_out.refs.end(), by_left)) std::stable_sort(lean_out.refs.begin(), lean_out.refs.end(), by_left);
+    size_t li = 0;
+    auto lean_up_to = [&](int64_t left) {
+      for (; li < lean_out.refs.size() && lean_out.refs[li].left <= left; ++li) {
+        const LeanRef& x = lean_out.refs[li];
+        if (!pc.add_lean(x.left, x.right, lean_out.ids.data() + x.ids_at, x.n_ids)) return false;
+      }
+      return true;
+    };
+    for (auto& a : raw) {
+      if (!lean_up_to(a.left_offset) || !pc.add(std::move(a)))
+        return fail("bg_tracer_trace: pair_counter: assemblies out of left-offset order");
+    }
+    if (!lean_up_to(INT64_MAX)) return fail("bg_tracer_trace: pair_counter: assemblies out of left-offset order");
     pc.flush();
   } else {
     counted = std::move(raw);

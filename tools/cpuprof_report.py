@@ -29,6 +29,40 @@ def symbols(path):
     return out
 
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_delta = {}
+
+
+def resolve(path):
+    """The module's file here: the path of the profile, or (a profile taken elsewhere) the same name in this tree."""
+    if os.path.exists(path):
+        return path
+    for d in ("proftmp", "biograph_amd"):
+        q = os.path.join(ROOT, d, os.path.basename(path))
+        if os.path.exists(q):
+            return q
+    return path
+
+
+def vaddr_delta(path, file_off):
+    """p_vaddr - p_offset of the PT_LOAD segment that holds file offset `file_off` (symbol tables speak virtual addresses)."""
+    if path not in _delta:
+        segs = []
+        try:
+            r = subprocess.run(["readelf", "-lW", path], capture_output=True, text=True)
+            for line in r.stdout.splitlines():
+                f = line.split()
+                if len(f) >= 6 and f[0] == "LOAD":
+                    segs.append((int(f[1], 16), int(f[4], 16), int(f[2], 16)))  # offset, filesz, vaddr
+        except OSError:
+            pass
+        _delta[path] = segs
+    for off, size, vaddr in _delta[path]:
+        if off <= file_off < off + size:
+            return vaddr - off
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("profile")
@@ -69,12 +103,13 @@ def main():
         if i < 0 or pc >= maps[i][1]:
             return "?", "?"
         lo, hi, off, path = maps[i]
+        path = resolve(path)
         if path not in symtab:
             symtab[path] = symbols(path) if os.path.exists(path) else []
         st = symtab[path]
-        # shared objects: symbol values are file-relative virtual addresses; executables (non-PIE) absolute.  Try both.
+        # shared objects and PIE: symbol values are virtual addresses of the file's segments; non-PIE executables absolute
         name = "?"
-        for addr in (pc - lo + off, pc):
+        for addr in (pc - lo + off + vaddr_delta(path, pc - lo + off), pc):
             j = bisect.bisect_right(st, (addr, 1 << 62, "")) - 1
             if j >= 0 and (addr - st[j][0] < st[j][1] or (st[j][1] == 0 and addr - st[j][0] < 4096)):
                 name = st[j][2]
@@ -88,7 +123,8 @@ def main():
         if i < 0 or pc >= maps[i][1]:
             return None, 0
         lo, hi, off, path = maps[i]
-        return path, pc - lo + off
+        path = resolve(path)
+        return path, pc - lo + off + vaddr_delta(path, pc - lo + off)
 
     if args.lines:
         by_path = collections.defaultdict(collections.Counter)
