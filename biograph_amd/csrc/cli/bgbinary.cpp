@@ -255,6 +255,36 @@ static double now_s() {
   return ts.tv_sec + ts.tv_nsec * 1e-9;
 }
 
+// resident set of the process in GB (/proc/self/statm), for the timing lines of `discovery`
+static double rss_gb() {
+  FILE* f = fopen("/proc/self/statm", "r");
+  if (!f) return 0;
+  unsigned long long total = 0, res = 0;
+  const int n = fscanf(f, "%llu %llu", &total, &res);
+  fclose(f);
+  return n == 2 ? double(res) * double(sysconf(_SC_PAGESIZE)) / 1e9 : 0;
+}
+// seconds since the process started (/proc/self/stat field 22 against the uptime): what the loader and the runtimes' static
+// initialisers took before main
+static double since_process_start_s() {
+  FILE* f = fopen("/proc/self/stat", "r");
+  if (!f) return 0;
+  char buf[2048];
+  const size_t n = fread(buf, 1, sizeof buf - 1, f);
+  fclose(f);
+  buf[n] = 0;
+  const char* p = strrchr(buf, ')');
+  if (!p) return 0;
+  unsigned long long start = 0;
+  int field = 2;
+  for (p = p + 1; *p && field < 22; ++p)
+    if (*p == ' ') { ++field; if (field == 22) { start = strtoull(p + 1, nullptr, 10); break; } }
+  double up = 0;
+  FILE* u = fopen("/proc/uptime", "r");
+  if (u) { if (fscanf(u, "%lf", &up) != 1) up = 0; fclose(u); }
+  return up - double(start) / double(sysconf(_SC_CLK_TCK));
+}
+
 static std::string g_log;  // qc/create_log.txt (biograph_create.cpp:527): what went to stderr, with times
 static void logf(const char* fmt, ...) {
   char buf[1024];
@@ -1202,6 +1232,9 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   if (n_threads < 1) n_threads = 1;
   if (n_threads > 64) n_threads = 64;
   const double t_open0 = now_s();
+  // (the coverage session's tables beside the tracer's: both are downloads of readmap columns and host loops over them)
+  bg_coverage* cov_session = nullptr;
+  std::thread cov_open([&] { check(bg_coverage_open(ctx, ss, rm, &cov_session), "bg_coverage_open"); });
   std::vector<bg_ctx*> wctx(size_t(n_threads), nullptr);
   std::vector<bg_tracer*> tracers(size_t(n_threads), nullptr);
   for (int t = 0; t < n_threads; ++t) {
@@ -1212,8 +1245,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     else
       check(bg_tracer_clone(tracers[0], wctx[size_t(t)], &tracers[size_t(t)]), "bg_tracer_clone");
   }
-  bg_coverage* cov_session = nullptr;
-  check(bg_coverage_open(ctx, ss, rm, &cov_session), "bg_coverage_open");
+  cov_open.join();
   const double t_open = now_s() - t_open0;
   time_t now = time(nullptr);
   char date[16];
@@ -1248,6 +1280,8 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   vcf += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + sample + "\n";
   uint64_t n_var = 0, n_traced = 0, n_sections = 0, pieces = 0, n_popped = 0;
   double t_trace = 0, t_pipe = 0, t_cov = 0;
+  double rss_trace = 0, rss_pipe = 0, rss_cov = 0;
+  const double rss_sessions = rss_gb();
   for (auto& rec : recs) {
     const std::string& seq = rec.second;
     std::vector<int64_t> eo;
@@ -1340,6 +1374,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     }
     for (auto* r : items) n_traced += bg_trace_result_size(r);
     t_trace += now_s() - t1;
+    rss_trace = std::max(rss_trace, rss_gb());
     t1 = now_s();
     bg_trace_result *sections = nullptr, *kept = nullptr;
     if (want_csv) {
@@ -1395,11 +1430,13 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     for (auto* r : items) bg_trace_result_free(r);
     n_sections += bg_trace_result_size(sections);
     t_pipe += now_s() - t1;
+    rss_pipe = std::max(rss_pipe, rss_gb());
     t1 = now_s();
     check(bg_coverage_run(cov_session, sections, es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), &cov, 1, &kept),
           "bg_coverage_run");
     bg_trace_result_free(sections);
     t_cov += now_s() - t1;
+    rss_cov = std::max(rss_cov, rss_gb());
     std::vector<char> buf(1 << 16);
     for (uint64_t i = 0; i < bg_trace_result_size(kept); ++i) {
       uint64_t len = 0;
@@ -1422,6 +1459,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     if (t) bg_ctx_destroy(wctx[size_t(t)]);
   }
   bg_dev_free(ctx, d_map);
+  const double t_write0 = now_s();
   write_file(a.get("out"), vcf);
   if (want_csv) write_file(a.get("assemblies-out"), asm_csv);
   if (want_aligned) write_file(a.get("aligned-assemblies-out"), aligned_csv);
@@ -1429,6 +1467,9 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
                   "[%llu assemblies], pipeline %.2f [%llu sections], coverage + genotype %.2f); pop tracer %s [%llu of the assemblies]\n",
           (unsigned long long)n_var, recs.size(), (unsigned long long)pieces, n_threads, min_overlap, now_s() - t0, t_refmap, t_open, t_trace,
           (unsigned long long)n_traced, t_pipe, (unsigned long long)n_sections, t_cov, pop_tracer ? "on" : "off", (unsigned long long)n_popped);
+  fprintf(stderr, "discovery: outputs written in %.2f s; %.2f s since the process started; resident with the sessions open %.1f GB, after "
+                  "tracing %.1f, after the pipeline %.1f, after coverage %.1f, now %.1f\n", now_s() - t_write0,
+          since_process_start_s(), rss_sessions, rss_trace, rss_pipe, rss_cov, rss_gb());
   return 0;
 }
 
@@ -1460,39 +1501,46 @@ static int cmd_discovery(int argc, char** argv) {
   // scaffolds (chromosomes) and their N-free supercontigs from the reference directory / .ref / FASTA; a
   // scaffold is rebuilt with N between its supercontigs so that VCF positions are scaffold coordinates
   const double t_begin = now_s();
-  bg_reference* rf = nullptr;
-  check(bg_reference_open(a.get("ref").c_str(), &rf), "bg_reference_open");
+  // the reference (a host-only read and unpack of its own) on a thread beside the seqset and the readmap going to the device
   std::vector<std::pair<std::string, std::string>> recs;
-  for (uint32_t c = 0; c < bg_reference_scaffold_count(rf); ++c)
-    recs.emplace_back(bg_reference_scaffold_name(rf, c), std::string(bg_reference_scaffold_len(rf, c), 'N'));
-  for (uint32_t i = 0; i < bg_reference_supercontig_count(rf); ++i) {
-    uint32_t sc = 0;
-    uint64_t off = 0, len = 0, flat = 0;
-    check(bg_reference_supercontig(rf, i, &sc, &off, &len, &flat), "bg_reference_supercontig");
-    if (sc >= recs.size() || off > recs[sc].second.size() || len > recs[sc].second.size() - off)
-      die("reference: a supercontig lies outside its scaffold (corrupt reference?)");
-    check(bg_reference_bases(rf, flat, len, &recs[sc].second[off]), "bg_reference_bases");
-  }
-  // the flat genome and its supercontigs, for the ref_map of the push engine (ref_map::build, ref_map.cpp:72-185)
   std::vector<uint8_t> flat_codes;
   std::vector<uint64_t> flat_start, flat_size;
-  if (engine == "push") {
-    std::string fa(bg_reference_size(rf), '\0');
-    check(bg_reference_bases(rf, 0, fa.size(), &fa[0]), "bg_reference_bases");
-    flat_codes.resize(fa.size());
-    for (size_t i = 0; i < fa.size(); ++i) flat_codes[i] = uint8_t(fa[i] == 'A' ? 0 : fa[i] == 'C' ? 1 : fa[i] == 'G' ? 2 : 3);
+  double t_ref = 0;
+  std::thread ref_thread([&] {
+    bg_reference* rf = nullptr;
+    check(bg_reference_open(a.get("ref").c_str(), &rf), "bg_reference_open");
+    for (uint32_t c = 0; c < bg_reference_scaffold_count(rf); ++c)
+      recs.emplace_back(bg_reference_scaffold_name(rf, c), std::string(bg_reference_scaffold_len(rf, c), 'N'));
     for (uint32_t i = 0; i < bg_reference_supercontig_count(rf); ++i) {
-      uint64_t len = 0, flat = 0;
-      check(bg_reference_supercontig(rf, i, nullptr, nullptr, &len, &flat), "bg_reference_supercontig");
-      flat_start.push_back(flat);
-      flat_size.push_back(len);
+      uint32_t sc = 0;
+      uint64_t off = 0, len = 0, flat = 0;
+      check(bg_reference_supercontig(rf, i, &sc, &off, &len, &flat), "bg_reference_supercontig");
+      if (sc >= recs.size() || off > recs[sc].second.size() || len > recs[sc].second.size() - off)
+        die("reference: a supercontig lies outside its scaffold (corrupt reference?)");
+      check(bg_reference_bases(rf, flat, len, &recs[sc].second[off]), "bg_reference_bases");
     }
-  }
-  bg_reference_free(rf);
+    // the flat genome and its supercontigs, for the ref_map of the push engine (ref_map::build, ref_map.cpp:72-185)
+    if (engine == "push") {
+      std::string fa(bg_reference_size(rf), '\0');
+      check(bg_reference_bases(rf, 0, fa.size(), &fa[0]), "bg_reference_bases");
+      flat_codes.resize(fa.size());
+      for (size_t i = 0; i < fa.size(); ++i) flat_codes[i] = uint8_t(fa[i] == 'A' ? 0 : fa[i] == 'C' ? 1 : fa[i] == 'G' ? 2 : 3);
+      for (uint32_t i = 0; i < bg_reference_supercontig_count(rf); ++i) {
+        uint64_t len = 0, flat = 0;
+        check(bg_reference_supercontig(rf, i, nullptr, nullptr, &len, &flat), "bg_reference_supercontig");
+        flat_start.push_back(flat);
+        flat_size.push_back(len);
+      }
+    }
+    bg_reference_free(rf);
+    t_ref = now_s();
+  });
   bg_ctx* ctx = nullptr;
   check(bg_ctx_create(0, nullptr, &ctx), "bg_ctx_create");
+  const double t_ctx = now_s();
   bg_seqset* ss = nullptr;
   check(bg_seqset_open(ctx, (bgdir + "/seqset").c_str(), &ss), "bg_seqset_open");
+  const double t_ss = now_s();
   auto samples = json_samples(read_text(bgdir + "/metadata/bg_info.json"));
   std::string sample = a.get("sample");
   if (samples.empty()) die("No samples found in BioGraph metadata.");                           // biograph_dir.cpp:104-107
@@ -1523,8 +1571,12 @@ static int cmd_discovery(int argc, char** argv) {
       bed[chrom].emplace_back(b0, b1);
     }
   }
+  const double t_rm = now_s();
+  ref_thread.join();
   double t0 = now_s();
-  fprintf(stderr, "discovery: reference, seqset and readmap open in %.2f s\n", t0 - t_begin);
+  fprintf(stderr, "discovery: reference, seqset and readmap open in %.2f s (reference %.2f on a thread of its own beside: device context %.2f, "
+                  "seqset %.2f, readmap %.2f; %.2f s from the start of the process to here, resident %.1f GB)\n",
+          t0 - t_begin, t_ref - t_begin, t_ctx - t_begin, t_ss - t_ctx, t_rm - t_ss, since_process_start_s(), rss_gb());
   if (engine == "push") {
     const int rc = discovery_push(a, recs, bed, ctx, ss, rm, min_overlap, max_pair_distance, sample, flat_codes, flat_start, flat_size);
     // The outputs are written and closed: the process ends here.  Handing tens of gigabytes of host tables, the seqset, the

@@ -8,11 +8,12 @@
 // and mapped again for the next) -- profiles/r04_discovery_sessions_cpu_time.txt; with the small blocks alone served here, a
 // sixth of the command's wall time still sat in malloc's internals and munmap (the sampling profile of csrc/cli/cpuprof.h).
 //
-// Small blocks (<= 2 KiB, 16-byte classes): every thread carves them out of 1 MiB chunks of its own and keeps the blocks it
+// Small blocks (<= 2 KiB, 16-byte classes): every thread carves them out of 8 MiB regions of its own and keeps the blocks it
 // frees on per-class lists of its own: no lock, no system call.  Blocks migrate (the pool threads allocate a trace's state,
 // the session thread frees it): a list that grows past a bound hands part of itself to a per-class global stack as one batch,
 // and an empty list takes a batch from there before it carves.  Chunks are never returned (the process is a command).
-// Large blocks (2 KiB .. 64 MiB, four classes per octave: at most a quarter of a block is slack): malloc'ed once, then kept --
+// Large blocks (2 KiB .. 64 MiB, four classes per octave: at most a quarter of a block is slack): carved from the region (up to
+// 1 MiB) or mapped on their own once, then kept --
 // a thread keeps up to 32 MiB per class (at least one block), the rest goes to a per-class global stack; their pages are
 // touched for the first time once, not once per work item.  Anything larger goes to malloc.  A thread that ends hands every
 // list it holds to the global stacks.  A 16-byte header in front of every block names its class.  BG_FAST_ALLOC=0: plain
@@ -21,6 +22,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 #include <atomic>
 #include <new>
@@ -33,7 +35,9 @@ constexpr int kLargeLog0 = 11, kLargeLog1 = 26;            // large classes cove
 constexpr int kLargeClasses = (kLargeLog1 - kLargeLog0) * 4;
 constexpr size_t kMaxLarge = size_t(1) << kLargeLog1;
 constexpr size_t kLargeKeep = size_t(32) << 20;            // bytes per class a thread keeps for itself
-constexpr size_t kChunk = size_t(1) << 20;
+constexpr size_t kHuge = size_t(2) << 20;                  // regions are 2 MiB aligned and asked to be huge pages
+constexpr size_t kChunk = size_t(8) << 20;                 // a thread's region: small blocks and large ones up to 1 MiB are carved from it
+constexpr size_t kCarveMax = size_t(1) << 20;              // larger blocks get a mapping of their own
 constexpr uint32_t kBatch = 512;                           // small blocks handed over at a time
 constexpr uint32_t kLargeTag = 0xffffffffu, kMagic = 0xb10c5eedu;
 
@@ -66,6 +70,21 @@ inline bool enabled() {
 inline Local& local() {
   static thread_local Local l = {};
   return l;
+}
+
+// Memory from the system: 2 MiB aligned, with MADV_HUGEPAGE (BG_FAST_ALLOC_THP=0: without).  The tracer sessions touch
+// thirteen gigabytes once each: as 4 KiB pages that is 3.2 M faults on one address space and, when the command ends, a
+// second of the kernel taking them apart again; as huge pages both shrink five-hundredfold.  Never returned.
+inline void* os_alloc(size_t bytes) {
+  static const bool thp = [] { const char* e = getenv("BG_FAST_ALLOC_THP"); return !(e && e[0] == '0'); }();
+  bytes = (bytes + kHuge - 1) & ~(kHuge - 1);
+  char* raw = static_cast<char*>(mmap(nullptr, bytes + kHuge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+  if (raw == MAP_FAILED) throw std::bad_alloc();
+  char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(raw) + kHuge - 1) & ~uintptr_t(kHuge - 1));
+  if (p > raw) munmap(raw, size_t(p - raw));
+  if (p + bytes < raw + bytes + kHuge) munmap(p + bytes, size_t(raw + bytes + kHuge - (p + bytes)));
+  if (thp) (void)madvise(p, bytes, MADV_HUGEPAGE);
+  return p;
 }
 
 inline void lock(Global& g) { while (g.lock.test_and_set(std::memory_order_acquire)) { } }
@@ -123,6 +142,17 @@ inline int large_class(size_t size) {  // 2 KiB < size <= 64 MiB
   return (k - kLargeLog0) * 4 + idx - 1;
 }
 
+inline void* carve(Local& l, size_t need) {  // need is a multiple of 16
+  if (l.left < need) {
+    l.chunk = static_cast<char*>(os_alloc(kChunk));
+    l.left = kChunk;
+  }
+  void* p = l.chunk;
+  l.chunk += need;
+  l.left -= need;
+  return p;
+}
+
 inline void* allocate(size_t size) {
   if (size == 0) size = 1;
   if (size > kMaxLarge || !enabled()) {
@@ -145,9 +175,8 @@ inline void* allocate(size_t size) {
     uint32_t n = 0;
     if (Block* first = pop_batch(cls, &n)) return first;  // (large batches hold one block)
     if (!l.registered) register_thread(l);
-    void* raw = malloc(large_size(lc) + sizeof(Header));
-    if (!raw) throw std::bad_alloc();
-    Header* h = static_cast<Header*>(raw);
+    const size_t need = large_size(lc) + sizeof(Header);
+    Header* h = static_cast<Header*>(need > kCarveMax ? os_alloc(need) : carve(l, need));
     h->cls = uint32_t(cls);
     h->magic = kMagic;
     return h + 1;
@@ -167,15 +196,7 @@ inline void* allocate(size_t size) {
     return first;
   }
   if (!l.registered) register_thread(l);
-  const size_t need = sizeof(Header) + size_t(cls + 1) * kStep;
-  if (l.left < need) {
-    l.chunk = static_cast<char*>(malloc(kChunk));
-    if (!l.chunk) throw std::bad_alloc();
-    l.left = kChunk;
-  }
-  Header* h = reinterpret_cast<Header*>(l.chunk);
-  l.chunk += need;
-  l.left -= need;
+  Header* h = static_cast<Header*>(carve(l, sizeof(Header) + size_t(cls + 1) * kStep));
   h->cls = uint32_t(cls);
   h->magic = kMagic;
   return h + 1;

@@ -15,6 +15,8 @@
 #include <string.h>
 #include <time.h>
 
+#include <thread>
+
 #include "bg_device_funcs.h"
 #include "bg_internal.h"
 #include "compact.h"
@@ -870,26 +872,30 @@ extern "C" int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out) 
   if (p != std::string::npos) rm->seqset_uuid = rmj->substr(p + 15, rmj->find('"', p + 15) - (p + 15));
   std::vector<uint64_t> v_len, v_ptr, v_fwd, v_head;
   if (rl->size() < (n * rl_bits + 7) / 8 || ml->size() < (n * ml_bits + 7) / 8) { set_error("%s: truncated vectors", path); return BG_EIO; }
-  rm_unpack_bits(*rl, n, unsigned(rl_bits), &v_len);
-  if (legacy)
-    for (uint64_t v : v_len) max_len = std::max(max_len, v);
-  rm->max_read_len = uint32_t(max_len);
-  rm_unpack_bits(*ml, n, unsigned(ml_bits), &v_ptr);
-  rm_unpack_bits(*isf, n, 1, &v_fwd);
-  rm_unpack_bits(*d2m, n, 1, &v_head);
   if (s2m->size() < (n_ent + 63) / 64 * 8 || d2m->size() < (n + 63) / 64 * 8) { set_error("%s: truncated bit vectors", path); return BG_EIO; }
   // sparse_multi::reverse_lookup for every read id: k-th group head -> k-th marked entry (entry ids may pass 2^32)
   std::vector<uint64_t> mid_to_entry, v_entry(n, 0);
-  mid_to_entry.reserve(n);
-  for (uint64_t w = 0; w < (n_ent + 63) / 64; ++w) {
-    uint64_t word;
-    memcpy(&word, s2m->data() + w * 8, 8);
-    if (w == n_ent / 64 && (n_ent & 63)) word &= (1ull << (n_ent & 63)) - 1;
-    while (word) {
-      mid_to_entry.push_back(w * 64 + uint64_t(__builtin_ctzll(word)));
-      word &= word - 1;
+  {
+    // the four columns and the marked entries are independent host loops over tens of millions of elements: side by side
+    std::thread t_len([&] { rm_unpack_bits(*rl, n, unsigned(rl_bits), &v_len); });
+    std::thread t_ptr([&] { rm_unpack_bits(*ml, n, unsigned(ml_bits), &v_ptr); });
+    std::thread t_fwd([&] { rm_unpack_bits(*isf, n, 1, &v_fwd); });
+    std::thread t_head([&] { rm_unpack_bits(*d2m, n, 1, &v_head); });
+    mid_to_entry.reserve(n);
+    for (uint64_t w = 0; w < (n_ent + 63) / 64; ++w) {
+      uint64_t word;
+      memcpy(&word, s2m->data() + w * 8, 8);
+      if (w == n_ent / 64 && (n_ent & 63)) word &= (1ull << (n_ent & 63)) - 1;
+      while (word) {
+        mid_to_entry.push_back(w * 64 + uint64_t(__builtin_ctzll(word)));
+        word &= word - 1;
+      }
     }
+    t_len.join(); t_ptr.join(); t_fwd.join(); t_head.join();
   }
+  if (legacy)
+    for (uint64_t v : v_len) max_len = std::max(max_len, v);
+  rm->max_read_len = uint32_t(max_len);
   uint64_t mid = 0;
   for (uint64_t i = 0; i < n; ++i) {
     if (v_head[i]) ++mid;

@@ -47,7 +47,8 @@ def main():
                     "minor_faults": u1.ru_minflt - u0.ru_minflt, "major_faults": u1.ru_majflt - u0.ru_majflt,
                     "voluntary_switches": u1.ru_nvcsw - u0.ru_nvcsw, "involuntary_switches": u1.ru_nivcsw - u0.ru_nivcsw,
                     "max_rss_GB": round(u1.ru_maxrss / 1e6, 2),
-                    "rc": r.returncode, "summary": line[-1][:300] if line else r.stderr[-300:]})
+                    "rc": r.returncode, "summary": line[-1][:300] if line else r.stderr[-300:],
+                    "notes": [x for x in r.stderr.splitlines() if x.startswith("discovery:")]})
         print(json.dumps(out[-1]), flush=True)
     subprocess.run(["rm", "-rf", tmp])
 
