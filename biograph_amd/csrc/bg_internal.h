@@ -283,6 +283,15 @@ extern std::map<void*, VmmSegment> g_vmm_segments;
 bg_ctx::DeviceArena* shared_arena(int device);  // null unless the hook is installed
 // walk.hip: the read-ahead tables of one walked stretch of a tracer work item (offset after base i = first_off + i),
 // appended to the three lists; the two sorted ones are sorted within this stretch
+// The prefix reads of n ranges (device arrays) with the pop tracer's per-read attributes, packed (walk.hip): range q's first
+// min(count[q], cap) reads are [first[q], first[q + 1]) of id / rc / mate_rc (0xffffffff: no mate) / flags (1 has mate, 2
+// is forward) / len; count[q] is the full number of prefix reads.
+struct PackedPrefixReads {
+  std::vector<uint32_t> count, first, id, rc, mate_rc;
+  std::vector<uint8_t> flags, len;
+};
+int prefix_reads_packed(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n, const uint64_t* d_begin,
+                        const uint64_t* d_end, const uint32_t* d_size, int read_len_limit, uint32_t cap, PackedPrefixReads* out);
 int tracer_read_tables(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const uint8_t* d_ref_map, bool skip_ambiguous,
                        const uint64_t* d_ent, uint64_t n, int64_t first_off, std::vector<std::pair<int32_t, uint64_t>>* pos_entries,
                        std::vector<std::pair<uint64_t, int32_t>>* entry_pos, std::vector<std::pair<uint32_t, int32_t>>* mate_pos);

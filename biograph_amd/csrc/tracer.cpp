@@ -1317,13 +1317,77 @@ void reverse_rec(const World& w, bg_trace_assembly_rec* a, int64_t end_pos, bool
 
 // reversable_tracer::assemble(start, limit) (reversable_tracer.cpp:76-145) with the push tracer.
 static std::atomic<int> g_next_pool{0};
+// The pieces of a scaffold come with the same extents, to every session: the checked copy and its reverse complement are made
+// once per process and recognised by a hash of the bases (a whole chromosome per call otherwise: 35 ms to copy and check,
+// 100 ms to reverse -- per work item, and again in the pop tracer).
+struct ExtSet {
+  std::vector<uint64_t> hashes;
+  int64_t end_pos = -1;
+  std::vector<Extent> ext;
+  const std::vector<Extent>& rc() {  // scaffold::rev_comp (scaffold.cpp:163-175)
+    std::call_once(rc_once_, [&] {
+      for (auto it = ext.rbegin(); it != ext.rend(); ++it)
+        ext_rc_.push_back(Extent{end_pos - it->offset - int64_t(it->seq.size()), rev_comp_str(it->seq)});
+    });
+    return ext_rc_;
+  }
+ private:
+  std::once_flag rc_once_;
+  std::vector<Extent> ext_rc_;
+};
+std::mutex g_ext_mu;
+std::shared_ptr<ExtSet> g_ext_last;  // the scaffold the process is working on
+
+// The session's extents for this call: its own from the last call, the process's, or a fresh checked copy.
+int session_extents(std::shared_ptr<ExtSet>* mine, const char* who, uint64_t n_extents, const int64_t* ext_offset,
+                    const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos) {
+  std::vector<uint64_t> hashes(n_extents);
+  int64_t calc_end = 0, prev_end = INT64_MIN;
+  for (uint64_t i = 0; i < n_extents; ++i) {
+    uint64_t h = 0xcbf29ce484222325ull ^ uint64_t(ext_offset[i]) ^ (ext_len[i] << 20);
+    const char* p = ext_seq[i];
+    uint64_t j = 0;
+    for (; j + 8 <= ext_len[i]; j += 8) {
+      uint64_t x;
+      memcpy(&x, p + j, 8);
+      h = (h ^ x) * 0x100000001b3ull;
+      h ^= h >> 29;
+    }
+    for (; j < ext_len[i]; ++j) h = (h ^ uint64_t(uint8_t(p[j]))) * 0x100000001b3ull;
+    hashes[i] = h;
+    if (ext_offset[i] < prev_end) { set_error("%s: extents must be sorted and disjoint", who); return BG_EINVAL; }
+    prev_end = ext_offset[i] + int64_t(ext_len[i]);
+    calc_end = std::max<int64_t>(calc_end, prev_end);
+  }
+  if (end_pos < calc_end) { set_error("%s: end_pos lies before the end of the last extent", who); return BG_EINVAL; }
+  auto same = [&](const std::shared_ptr<ExtSet>& e) { return e && e->end_pos == end_pos && e->hashes == hashes; };
+  if (same(*mine)) return BG_OK;
+  {
+    std::lock_guard<std::mutex> l(g_ext_mu);
+    if (same(g_ext_last)) { *mine = g_ext_last; return BG_OK; }
+  }
+  std::shared_ptr<ExtSet> fresh(new ExtSet);
+  for (uint64_t i = 0; i < n_extents; ++i) {
+    fresh->ext.push_back(Extent{ext_offset[i], std::string(ext_seq[i], ext_len[i])});
+    for (char c : fresh->ext.back().seq)
+      if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { set_error("%s: extents hold ACGT only", who); return BG_EINVAL; }
+  }
+  fresh->hashes = hashes;
+  fresh->end_pos = end_pos;
+  {
+    std::lock_guard<std::mutex> l(g_ext_mu);
+    if (same(g_ext_last)) fresh = g_ext_last;  // (another session was quicker)
+    else g_ext_last = fresh;
+  }
+  *mine = fresh;
+  return BG_OK;
+}
+
 struct bg_tracer {
   World w;
   int pool = g_next_pool.fetch_add(1);  // which of the host pools this session's big rounds use
   // the scaffold of the last work item (see bg_tracer_trace)
-  std::vector<Extent> ext, ext_rc;
-  std::vector<uint64_t> ext_hash;
-  int64_t ext_end = -1;
+  std::shared_ptr<ExtSet> exts;
 };
 
 // The host copies a tracer needs of the seqset, the readmap and the ref_map are made once per session
@@ -1426,40 +1490,9 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
   BG_HIP(hipSetDevice(w.ctx->device));
   memset(&w.stats, 0, sizeof(w.stats));
   w.seconds_device = w.seconds_host = w.seconds_tables = w.seconds_start = w.seconds_teardown = 0;
-  // The pieces of a scaffold come with the same extents: the checked copy and its reverse complement are kept in the
-  // session and recognised by a hash of the bases (a whole chromosome per call otherwise: 35 ms to copy and check,
-  // 100 ms to reverse).
   const double t_ext = now_seconds();
-  std::vector<uint64_t> hashes(n_extents);
-  int64_t calc_end = 0;
-  for (uint64_t i = 0; i < n_extents; ++i) {
-    uint64_t h = 0xcbf29ce484222325ull ^ uint64_t(ext_offset[i]) ^ (ext_len[i] << 20);
-    const char* p = ext_seq[i];
-    uint64_t j = 0;
-    for (; j + 8 <= ext_len[i]; j += 8) {
-      uint64_t x;
-      memcpy(&x, p + j, 8);
-      h = (h ^ x) * 0x100000001b3ull;
-      h ^= h >> 29;
-    }
-    for (; j < ext_len[i]; ++j) h = (h ^ uint64_t(uint8_t(p[j]))) * 0x100000001b3ull;
-    hashes[i] = h;
-    calc_end = std::max<int64_t>(calc_end, ext_offset[i] + int64_t(ext_len[i]));
-  }
-  if (end_pos < calc_end) return fail("bg_tracer_trace: end_pos lies before the end of the last extent");
-  if (t->ext_hash != hashes || t->ext_end != end_pos || t->ext.size() != n_extents) {
-    std::vector<Extent> fresh;
-    for (uint64_t i = 0; i < n_extents; ++i) {
-      fresh.push_back(Extent{ext_offset[i], std::string(ext_seq[i], ext_len[i])});
-      for (char c : fresh.back().seq)
-        if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return fail("bg_tracer_trace: extents hold ACGT only");
-    }
-    t->ext = std::move(fresh);
-    t->ext_rc.clear();
-    t->ext_hash = hashes;
-    t->ext_end = end_pos;
-  }
-  const std::vector<Extent>& ext = t->ext;
+  BG_TRY(session_extents(&t->exts, "bg_tracer_trace", n_extents, ext_offset, ext_seq, ext_len, end_pos));
+  const std::vector<Extent>& ext = t->exts->ext;
   w.scaffold_end = end_pos;
   if (limit_offset > end_pos) limit_offset = end_pos;
   std::unique_ptr<bg_trace_result> res(new bg_trace_result);
@@ -1471,10 +1504,8 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
   LeanOut* lean = (lean_allowed && pair_count && w.o.anchor_drop && !w.o.trace_reference_assemblies) ? &lean_out : nullptr;
   const double s_ext = now_seconds() - t_ext;
   const double t_chunk = now_seconds();
-  if (rev_comp && t->ext_rc.empty())  // scaffold::rev_comp (scaffold.cpp:163-175)
-    for (auto it = ext.rbegin(); it != ext.rend(); ++it)
-      t->ext_rc.push_back(Extent{end_pos - it->offset - int64_t(it->seq.size()), rev_comp_str(it->seq)});
-  const std::vector<Extent>& rc = t->ext_rc;
+  static const std::vector<Extent> no_extents;
+  const std::vector<Extent>& rc = rev_comp ? t->exts->rc() : no_extents;
   if (rev_comp) {
     BG_TRY(trace_chunk(w, rc, end_pos - limit_offset, end_pos - start_offset, &raw, lean));
   } else {
@@ -1594,6 +1625,7 @@ struct PopTracer {
   World& w;
   bg_ctx* ctx;
   const std::vector<Extent>& sc;  // the scaffold in the direction this pop tracer runs
+  const std::vector<Extent>& sc_rc;  // ... and reversed: entries face right while push_front_drop runs through it
   int64_t end_pos;
   std::deque<PopEntry> store;     // stable addresses
   struct Front { uint64_t b; uint32_t s; uint32_t seq; PopEntry* e; bool erased; };
@@ -1643,6 +1675,18 @@ struct PopTracer {
     std::copy(h.begin() + long(n * cap), h.end(), count->begin());
     ++device_rounds;
     device_queries += n;
+    return BG_OK;
+  }
+  // the same ranges' prefix reads, packed, with each read's reverse complement / mate / length / direction from the device
+  int prefix_reads_attr(const std::vector<TRange>& r, uint32_t cap, PackedPrefixReads* out) {
+    const size_t n = r.size();
+    DevBuf<uint8_t> d;
+    uint64_t *db = nullptr, *de = nullptr;
+    uint32_t* ds = nullptr;
+    uint8_t* rest = nullptr;
+    if (n) BG_TRY(upload_ranges(r, &d, 0, &db, &de, &ds, &rest));
+    BG_TRY(prefix_reads_packed(ctx, w.ss, w.rm, n, db, de, ds, int(w.o.min_overlap), cap, out));
+    if (n) { ++device_rounds; device_queries += n; }
     return BG_OK;
   }
   int read_entries(const std::vector<uint32_t>& ids, std::vector<TRange>* r) {  // readmap::read::get_seqset_entry
@@ -1718,8 +1762,8 @@ struct PopTracer {
     std::vector<TRange> ranges;
     BG_TRY(read_entries(ids, &ranges));
     const uint32_t cap = uint32_t(std::max<uint64_t>(1, w.o.max_pairs_per_read));
-    std::vector<uint32_t> pid, pcount;
-    BG_TRY(prefix_reads(ranges, cap, &pid, &pcount));
+    PackedPrefixReads pr;
+    BG_TRY(prefix_reads_attr(ranges, cap, &pr));
     size_t k = 0;
     for (auto& it : items) {
       PopEntry* e = it.ready;
@@ -1729,7 +1773,8 @@ struct PopTracer {
         e->start_limit = it.rd.start;
         e->end_limit = it.rd.limit;
         e->orig_r = e->popped_r = ranges[k];
-        take_entry_reads(e, &pid[k * cap], pcount[k], cap);
+        // add_entry_reads (:97-119): the reverse complements of the first max_pairs_per_read prefix reads
+        e->seen_read_ids.insert(e->seen_read_ids.end(), pr.rc.begin() + pr.first[k], pr.rc.begin() + pr.first[k + 1]);
         ++k;
       }
       fronts.push_back(Front{e->orig_r.b, e->orig_r.s, uint32_t(fronts.size()), e, false});
@@ -1838,8 +1883,7 @@ struct PopTracer {
   // ---- add_reference (:162-206) with add_reference_at (:97-160)
   int add_reference(int64_t start, int64_t limit) {
     // the scaffold reversed: entries face right while push_front_drop runs through it (:167-169)
-    std::vector<Extent> rc;
-    for (auto it = sc.rbegin(); it != sc.rend(); ++it) rc.push_back(Extent{end_pos - it->offset - int64_t(it->seq.size()), rev_comp_str(it->seq)});
+    const std::vector<Extent>& rc = sc_rc;
     const int64_t scaffold_end = end_pos;
     const int64_t skip_pos = scaffold_end - limit - int64_t(w.rm->max_read_len);
     // positions walked, per extent: [first, last) indices into the extent; the walk of an extent starts from the empty
@@ -1942,16 +1986,16 @@ struct PopTracer {
     for (auto& x : kept) ranges.push_back(x.second);
     // their prefix reads: the first max_pairs_per_read feed add_entry_reads, the first max_pairs_per_read WITH a mate
     // supply the mates; a range with more reads than the buffer holds and too few mates among them is asked again
-    uint32_t cap = uint32_t(std::max<uint64_t>(w.o.max_pairs_per_read, 1)) * 2;
-    std::vector<uint32_t> pid, pcount;
-    BG_TRY(prefix_reads(ranges, cap, &pid, &pcount));
+    const uint32_t cap = uint32_t(std::max<uint64_t>(w.o.max_pairs_per_read, 1)) * 2;
+    PackedPrefixReads pr;
+    BG_TRY(prefix_reads_attr(ranges, cap, &pr));
     std::vector<std::vector<uint32_t>> wide(ranges.size());
     {
       std::vector<size_t> again;
       for (size_t i = 0; i < ranges.size(); ++i) {
-        if (pcount[i] <= cap) continue;
+        if (pr.count[i] <= cap) continue;
         uint32_t mated = 0;
-        for (uint32_t j = 0; j < cap; ++j) mated += w.has_mate(pid[i * cap + j]) ? 1u : 0u;
+        for (uint32_t p = pr.first[i]; p < pr.first[i + 1]; ++p) mated += pr.flags[p] & 1u;
         if (mated <= w.o.max_pairs_per_read) again.push_back(i);
       }
       uint32_t big = cap;
@@ -1982,26 +2026,43 @@ struct PopTracer {
       e->left_offset = off;
       e->start_limit = e->end_limit = off;
       e->orig_r = e->popped_r = kept[i].second;
-      const uint32_t* ids = wide[i].empty() ? &pid[i * cap] : wide[i].data();
-      const uint32_t have = wide[i].empty() ? std::min(pcount[i], cap) : uint32_t(wide[i].size());
-      take_entry_reads(e, ids, have, have);
-      items.push_back(Item{e, PendingRead{0, 0, 0}});
-      unsigned read_count = 0;
-      for (uint32_t j = 0; j < have; ++j) {  // :121-159
-        const uint32_t rid = ids[j];
-        if (!w.has_mate(rid)) continue;
-        if (++read_count > w.o.max_pairs_per_read) break;
-        const int64_t size = w.tables->read_len[rid];
-        if (size < int64_t(w.o.min_pop_overlap)) continue;
+      // one mated read of the entry (:121-159): its length, its direction, the reverse complement of its mate
+      auto add_mate = [&](int64_t size, bool forward, uint32_t mate_rc) {
+        if (size < int64_t(w.o.min_pop_overlap)) return;
         int64_t start_offset = off, limit_offset = off;
-        if (bool(w.is_forward[rid]) == (w.o.forward_pairs_face_inward != 0)) {  // faces inward
+        if (forward == (w.o.forward_pairs_face_inward != 0)) {  // faces inward
           start_offset += size + w.o.min_pair_distance;
           limit_offset += size + int64_t(w.o.max_pair_distance);
         } else {  // faces outwards
           start_offset -= size + int64_t(w.o.max_pair_distance);
           limit_offset -= size + w.o.min_pair_distance;
         }
-        items.push_back(Item{nullptr, PendingRead{w.get_rev_comp(w.get_mate(rid)), start_offset, limit_offset}});
+        items.push_back(Item{nullptr, PendingRead{mate_rc, start_offset, limit_offset}});
+      };
+      if (wide[i].empty()) {
+        const uint32_t p0 = pr.first[i], p1 = pr.first[i + 1];
+        const uint32_t n_seen = std::min<uint32_t>(p1 - p0, uint32_t(w.o.max_pairs_per_read));
+        e->seen_read_ids.insert(e->seen_read_ids.end(), pr.rc.begin() + p0, pr.rc.begin() + p0 + n_seen);
+        items.push_back(Item{e, PendingRead{0, 0, 0}});
+        unsigned read_count = 0;
+        for (uint32_t p = p0; p < p1; ++p) {
+          if (!(pr.flags[p] & 1)) continue;
+          if (++read_count > w.o.max_pairs_per_read) break;
+          add_mate(int64_t(pr.len[p]), (pr.flags[p] & 2) != 0, pr.mate_rc[p]);
+        }
+        continue;
+      }
+      // (an entry with more prefix reads than the packed buffer holds and too few mates among them: the long list)
+      const uint32_t* ids = wide[i].data();
+      const uint32_t have = uint32_t(wide[i].size());
+      take_entry_reads(e, ids, have, have);
+      items.push_back(Item{e, PendingRead{0, 0, 0}});
+      unsigned read_count = 0;
+      for (uint32_t j = 0; j < have; ++j) {
+        const uint32_t rid = ids[j];
+        if (!w.has_mate(rid)) continue;
+        if (++read_count > w.o.max_pairs_per_read) break;
+        add_mate(int64_t(w.tables->read_len[rid]), bool(w.is_forward[rid]), w.get_rev_comp(w.get_mate(rid)));
       }
     }
     return materialize(items);
@@ -2151,24 +2212,13 @@ extern "C" int bg_pop_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext
   if (!t || !out || (n_extents && (!ext_offset || !ext_seq || !ext_len)) || (n_push && !push)) return fail("bg_pop_trace: null argument");
   World& w = t->w;
   BG_HIP(hipSetDevice(w.ctx->device));
-  std::vector<Extent> ext;
-  int64_t calc_end = 0, prev_end = INT64_MIN;
-  for (uint64_t i = 0; i < n_extents; ++i) {
-    if (ext_offset[i] < prev_end) return fail("bg_pop_trace: extents must be sorted and disjoint");
-    ext.push_back(Extent{ext_offset[i], std::string(ext_seq[i], ext_len[i])});
-    for (char c : ext.back().seq)
-      if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return fail("bg_pop_trace: extents hold ACGT only");
-    prev_end = ext_offset[i] + int64_t(ext_len[i]);
-    calc_end = std::max(calc_end, prev_end);
-  }
-  if (end_pos < calc_end) return fail("bg_pop_trace: end_pos lies before the end of the last extent");
+  BG_TRY(session_extents(&t->exts, "bg_pop_trace", n_extents, ext_offset, ext_seq, ext_len, end_pos));
+  const std::vector<Extent>& ext = t->exts->ext;
+  const std::vector<Extent>& rc = t->exts->rc();  // (either direction's add_reference walks the other one's bases)
   if (limit_offset > end_pos) limit_offset = end_pos;
-  std::vector<Extent> rc;
-  if (rev_comp)
-    for (auto it = ext.rbegin(); it != ext.rend(); ++it) rc.push_back(Extent{end_pos - it->offset - int64_t(it->seq.size()), rev_comp_str(it->seq)});
   std::unique_ptr<bg_trace_result> res(new bg_trace_result);
   memset(&res->stats, 0, sizeof(res->stats));
-  PopTracer pt{w, w.ctx, rev_comp ? rc : ext, end_pos};
+  PopTracer pt{w, w.ctx, rev_comp ? rc : ext, rev_comp ? ext : rc, end_pos};
   std::vector<const bg_anchor_drop_rec*> drops;
   for (uint32_t i = 0; i < n_push; ++i) {
     if (!push[i]) return fail("bg_pop_trace: null push result");

@@ -1259,6 +1259,79 @@ extern "C" int bg_prefix_reads_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_
   return BG_OK;
 }
 
+// The prefix reads of many ranges with what the pop tracer asks of each read (readmap::get_rev_comp, has_mate, get_mate_rc,
+// get_readlength, get_is_forward: pop_tracer.cpp:76-159), packed: a reference stretch of a million positions has a few
+// hundred thousand prefix reads in all, not a million times `cap` slots, and each of those attributes is one to five
+// dependent loads in tables of a hundred megabytes -- here, not on the host.
+__global__ void k_pr_kept(const uint32_t* __restrict__ count, uint64_t n, uint32_t cap, uint32_t* __restrict__ kept) {
+  const uint64_t q = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (q < n) kept[q] = count[q] < cap ? count[q] : cap;
+}
+__global__ void k_pr_pack(ReadmapView rm, uint64_t n, uint32_t cap, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ kept,
+                          const uint64_t* __restrict__ off, uint32_t* __restrict__ o_id, uint32_t* __restrict__ o_rc,
+                          uint32_t* __restrict__ o_mate_rc, uint8_t* __restrict__ o_flags, uint8_t* __restrict__ o_len) {
+  const uint64_t q = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const uint32_t k = kept[q];
+  for (uint32_t j = 0; j < k; ++j) {
+    const uint64_t id = ids[q * cap + j], p = off[q] + j;
+    const bool fwd = rm.is_fwd[id] != 0, hm = rm_has_mate(rm, id);
+    o_id[p] = uint32_t(id);
+    o_rc[p] = uint32_t(rm_follow(rm, id, fwd ? 1 : 3));
+    o_mate_rc[p] = hm ? uint32_t(rm_follow(rm, id, fwd ? 3 : 1)) : 0xffffffffu;
+    o_flags[p] = uint8_t((hm ? 1 : 0) | (fwd ? 2 : 0));
+    const uint64_t len = rm.read_len[id];
+    o_len[p] = uint8_t(len < 255 ? len : 255);
+  }
+}
+
+namespace bg {
+int prefix_reads_packed(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n, const uint64_t* d_begin,
+                        const uint64_t* d_end, const uint32_t* d_size, int read_len_limit, uint32_t cap, PackedPrefixReads* out) {
+  BG_TRY(check_ss(ctx, ss, "prefix_reads_packed"));
+  BG_TRY(check_rm(ss, rm, "prefix_reads_packed"));
+  if (rm->pair_mode) { set_error("prefix_reads_packed: readmap has no mate loop table; use \"biograph upgrade\" to construct it"); return BG_EINVAL; }
+  if (rm->max_read_len > 255) { set_error("prefix_reads_packed: reads longer than 255 bases"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  out->count.assign(n, 0);
+  out->first.assign(n + 1, 0);
+  out->id.clear(); out->rc.clear(); out->mate_rc.clear(); out->flags.clear(); out->len.clear();
+  if (!n) return BG_OK;
+  DevBuf<uint32_t> ids, count, kept;
+  DevBuf<uint64_t> off, tot;
+  BG_TRY(ids.alloc(ctx, n * cap)); BG_TRY(count.alloc(ctx, n)); BG_TRY(kept.alloc(ctx, n)); BG_TRY(off.alloc(ctx, n)); BG_TRY(tot.alloc(ctx, 1));
+  const SeqsetView v = make_view(ss);
+  const ReadmapView rv = make_rm_view(rm);
+  k_prefix_reads<<<cdiv(n, 64), 64, 0, ctx->stream>>>(v, rv, n, d_begin, d_end, d_size, read_len_limit, cap, ids.p, count.p);
+  BG_LAUNCH_CHECK();
+  k_pr_kept<<<cdiv(n, 256), 256, 0, ctx->stream>>>(count.p, n, cap, kept.p);
+  BG_LAUNCH_CHECK();
+  BG_TRY(exclusive_scan_u32_to_u64(ctx, kept.p, off.p, n, tot.p));
+  uint64_t total = 0;
+  BG_HIP(copy_d2h(ctx, &total, tot.p, 8));
+  if (total >= (1ull << 32)) { set_error("prefix_reads_packed: more than 2^32 reads in one batch"); return BG_EINVAL; }
+  DevBuf<uint32_t> pk;   // id, rc, mate_rc
+  DevBuf<uint8_t> pb;    // flags, len
+  BG_TRY(pk.alloc(ctx, total * 3 + 1)); BG_TRY(pb.alloc(ctx, total * 2 + 1));
+  k_pr_pack<<<cdiv(n, 64), 64, 0, ctx->stream>>>(rv, n, cap, ids.p, kept.p, off.p, pk.p, pk.p + total, pk.p + 2 * total, pb.p, pb.p + total);
+  BG_LAUNCH_CHECK();
+  std::vector<uint64_t> h_off(n);
+  BG_HIP(copy_d2h(ctx, out->count.data(), count.p, n * 4));
+  BG_HIP(copy_d2h(ctx, h_off.data(), off.p, n * 8));
+  for (uint64_t i = 0; i < n; ++i) out->first[i] = uint32_t(h_off[i]);
+  out->first[n] = uint32_t(total);
+  out->id.resize(total); out->rc.resize(total); out->mate_rc.resize(total); out->flags.resize(total); out->len.resize(total);
+  if (total) {
+    BG_HIP(copy_d2h(ctx, out->id.data(), pk.p, total * 4));
+    BG_HIP(copy_d2h(ctx, out->rc.data(), pk.p + total, total * 4));
+    BG_HIP(copy_d2h(ctx, out->mate_rc.data(), pk.p + 2 * total, total * 4));
+    BG_HIP(copy_d2h(ctx, out->flags.data(), pb.p, total));
+    BG_HIP(copy_d2h(ctx, out->len.data(), pb.p + total, total));
+  }
+  return BG_OK;
+}
+}  // namespace bg
+
 extern "C" int bg_read_info_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n,
                                   const uint32_t* d_read_ids, uint8_t* d_has_mate, uint32_t* d_mate_rc,
                                   uint32_t* d_rev_comp, uint64_t* d_begin, uint64_t* d_end, uint32_t* d_size) {
