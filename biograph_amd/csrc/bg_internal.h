@@ -283,6 +283,14 @@ extern std::map<void*, VmmSegment> g_vmm_segments;
 bg_ctx::DeviceArena* shared_arena(int device);  // null unless the hook is installed
 // walk.hip: the read-ahead tables of one walked stretch of a tracer work item (offset after base i = first_off + i),
 // appended to the three lists; the two sorted ones are sorted within this stretch
+// Several pop_tracer passes ahead for n poppers (walk.hip k_pop_passes): record [i * passes + j] is popper i after its (j + 1)-th
+// pop_front -- the range, and ids[ids_at, ids_at + n_ids) the reverse complements of its first `cap` prefix reads; a popper stops
+// at the first pass that leaves it less than min_pop_overlap bases (that record is the last one written).
+constexpr uint32_t kPopPassMaxIds = 32;
+struct PopPassRec { uint64_t b, e; uint32_t s, n_ids, ids_at, pad; };
+int pop_passes(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n, const uint64_t* d_begin, const uint64_t* d_end,
+               const uint32_t* d_size, uint32_t passes, uint32_t min_pop_overlap, int read_len_limit, uint32_t cap,
+               std::vector<PopPassRec>* recs, std::vector<uint32_t>* ids);
 // The prefix reads of n ranges (device arrays) with the pop tracer's per-read attributes, packed (walk.hip): range q's first
 // min(count[q], cap) reads are [first[q], first[q + 1]) of id / rc / mate_rc (0xffffffff: no mate) / flags (1 has mate, 2
 // is forward) / len; count[q] is the full number of prefix reads.

@@ -1583,6 +1583,8 @@ static int cmd_discovery(int argc, char** argv) {
     // readmap and the contexts back piece by piece before exiting took most of a second of a ten-second command.
     cpuprof::stop_and_write();
     fflush(nullptr);
+    // (BG_NORMAL_EXIT=1: through the exit handlers -- a profiler preloaded into the process writes its results there)
+    if (const char* e = getenv("BG_NORMAL_EXIT")) if (e[0] == '1') exit(rc);
     _exit(rc);
   }
   std::string vcf = "##fileformat=VCFv4.1\n##source=biograph_amd graph_discover\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n";

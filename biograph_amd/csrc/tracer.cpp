@@ -1344,15 +1344,21 @@ int session_extents(std::shared_ptr<ExtSet>* mine, const char* who, uint64_t n_e
   std::vector<uint64_t> hashes(n_extents);
   int64_t calc_end = 0, prev_end = INT64_MIN;
   for (uint64_t i = 0; i < n_extents; ++i) {
-    uint64_t h = 0xcbf29ce484222325ull ^ uint64_t(ext_offset[i]) ^ (ext_len[i] << 20);
+    // four interleaved chains (one multiply chain alone runs at its latency: 13 ms for a chromosome, per call)
+    uint64_t hh[4] = {0xcbf29ce484222325ull ^ uint64_t(ext_offset[i]) ^ (ext_len[i] << 20), 0x9e3779b97f4a7c15ull, 0xc2b2ae3d27d4eb4full,
+                      0x165667b19e3779f9ull};
     const char* p = ext_seq[i];
     uint64_t j = 0;
-    for (; j + 8 <= ext_len[i]; j += 8) {
-      uint64_t x;
-      memcpy(&x, p + j, 8);
-      h = (h ^ x) * 0x100000001b3ull;
-      h ^= h >> 29;
+    for (; j + 32 <= ext_len[i]; j += 32) {
+      uint64_t x[4];
+      memcpy(x, p + j, 32);
+      for (int k = 0; k < 4; ++k) {
+        hh[k] = (hh[k] ^ x[k]) * 0x100000001b3ull;
+        hh[k] ^= hh[k] >> 29;
+      }
     }
+    uint64_t h = hh[0];
+    for (int k = 1; k < 4; ++k) h = (h ^ hh[k]) * 0x100000001b3ull + (h >> 31);
     for (; j < ext_len[i]; ++j) h = (h ^ uint64_t(uint8_t(p[j]))) * 0x100000001b3ull;
     hashes[i] = h;
     if (ext_offset[i] < prev_end) { set_error("%s: extents must be sorted and disjoint", who); return BG_EINVAL; }
@@ -1619,6 +1625,10 @@ struct PopEntry {  // pop_tracer::entry (pop_tracer.h:58-84)
   TRange orig_r, popped_r;
   std::string seq;
   std::vector<uint32_t> seen_read_ids;
+  // where this popper stands in the passes the device ran ahead (PopTracer::pop_pass): slot in the batch, or -1 once a merge
+  // has given it another range
+  int32_t ahead_slot = -1;
+  uint32_t ahead_batch = 0;
 };
 
 struct PopTracer {
@@ -2093,11 +2103,59 @@ struct PopTracer {
       order.push_back(old.back());
       old.pop_back();
     }
-    std::vector<TRange> in;
-    for (PopEntry* p : order) {
+    for (PopEntry* p : order)
       if (p->has_right) return fail("bg_pop_trace: a popper that is aligned on the right is popped again");
-      in.push_back(p->popped_r);
+    const uint32_t cap = uint32_t(std::max<uint64_t>(1, w.o.max_pairs_per_read));
+    static const bool ahead_off = [] { const char* e = getenv("BG_POP_PASSES_AHEAD"); return e && e[0] == '0'; }();
+    if (ahead_off || cap > kPopPassMaxIds) return pop_pass_one(order, cap);
+    // The passes the device ran ahead serve while every popper still is where the device left it: a merge
+    // (match_and_output_pass) gives a popper another range, and the batch ends there.
+    bool fresh = ahead_used < ahead_passes;
+    for (PopEntry* p : order)
+      if (p->ahead_slot < 0 || p->ahead_batch != ahead_batch) { fresh = false; break; }
+    if (!fresh) {
+      // as many passes as the last batch got through, doubled when it was used up
+      if (ahead_batch) ahead_passes = ahead_used >= ahead_passes ? std::min<uint32_t>(ahead_passes * 2, 64) : std::max<uint32_t>(ahead_used, 2);
+      ++ahead_batch;
+      ahead_used = 0;
+      std::vector<TRange> in;
+      for (size_t i = 0; i < order.size(); ++i) {
+        in.push_back(order[i]->popped_r);
+        order[i]->ahead_slot = int32_t(i);
+        order[i]->ahead_batch = ahead_batch;
+      }
+      DevBuf<uint8_t> d;
+      uint64_t *db = nullptr, *de = nullptr;
+      uint32_t* ds = nullptr;
+      uint8_t* rest = nullptr;
+      BG_TRY(upload_ranges(in, &d, 0, &db, &de, &ds, &rest));
+      BG_TRY(pop_passes(ctx, w.ss, w.rm, in.size(), db, de, ds, ahead_passes, uint32_t(w.o.min_pop_overlap), int(w.o.min_overlap), cap,
+                        &ahead_recs, &ahead_ids));
+      ++device_rounds;
+      device_queries += in.size() * ahead_passes;
     }
+    for (PopEntry* p : order) {
+      const PopPassRec& rec = ahead_recs[size_t(p->ahead_slot) * ahead_passes + ahead_used];
+      if (rec.s < w.o.min_pop_overlap) continue;  // popped too much: discarded
+      p->seq.push_back(front_base(p->popped_r));
+      p->popped_r = TRange{rec.b, rec.e, rec.s};
+      p->seen_read_ids.insert(p->seen_read_ids.end(), ahead_ids.begin() + rec.ids_at, ahead_ids.begin() + rec.ids_at + rec.n_ids);
+      p->end_limit++;
+      add_popper(p);
+    }
+    ++ahead_used;
+    ++passes_run;
+    return BG_OK;
+  }
+  uint64_t passes_run = 0, match_seconds_us = 0;
+  uint32_t ahead_passes = 8, ahead_used = 0, ahead_batch = 0;
+  std::vector<PopPassRec> ahead_recs;
+  std::vector<uint32_t> ahead_ids;
+
+  // one pass, two launches (BG_POP_PASSES_AHEAD=0, or more pairs per read than the batch kernel holds)
+  int pop_pass_one(const std::vector<PopEntry*>& order, uint32_t cap) {
+    std::vector<TRange> in;
+    for (PopEntry* p : order) in.push_back(p->popped_r);
     std::vector<TRange> popped;
     BG_TRY(pop_fronts(in, &popped));
     std::vector<PopEntry*> alive;
@@ -2110,7 +2168,6 @@ struct PopTracer {
       alive.push_back(p);
       ranges.push_back(popped[i]);
     }
-    const uint32_t cap = uint32_t(std::max<uint64_t>(1, w.o.max_pairs_per_read));
     std::vector<uint32_t> pid, pcount;
     BG_TRY(prefix_reads(ranges, cap, &pid, &pcount));
     for (size_t i = 0; i < alive.size(); ++i) {
@@ -2122,6 +2179,8 @@ struct PopTracer {
   }
 
   void match_and_output_pass() {  // :469-613
+    const double t_match = now_seconds();
+    struct Tick { PopTracer* t; double t0; ~Tick() { t->match_seconds_us += uint64_t((now_seconds() - t0) * 1e6); } } tick{this, t_match};
     std::vector<PopEntry*> old;
     old.swap(poppers);
     const int64_t slop = int64_t(w.o.pop_tracer_offset_slop);
@@ -2168,6 +2227,7 @@ struct PopTracer {
           p->start_limit = std::max(p->start_limit, front.start_limit - plen);
           p->end_limit = std::min(p->end_limit, front.end_limit - plen);
           p->popped_r = front.popped_r;
+          p->ahead_slot = -1;  // (the passes run ahead were for the old range)
           p->seq += front.seq;
           p->seen_read_ids.insert(p->seen_read_ids.end(), front.seen_read_ids.begin(), front.seen_read_ids.end());
           if (front.has_right) {
@@ -2233,8 +2293,9 @@ extern "C" int bg_pop_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext
   const size_t n_fronts = pt.fronts.size(), n_poppers = pt.poppers.size();
   BG_TRY(pt.assemble());
   if (getenv("BG_TRACER_TIMING"))
-    fprintf(stderr, "bg_pop_trace: %zu anchor drops %.3f s, reference %.3f s (%zu fronts), assemble %.3f s (%zu poppers, %llu device rounds), %zu assemblies\n",
-            drops.size(), t1 - t0, t2 - t1, n_fronts, now_seconds() - t2, n_poppers, (unsigned long long)pt.device_rounds, pt.out.size());
+    fprintf(stderr, "bg_pop_trace: %zu anchor drops %.3f s, reference %.3f s (%zu fronts), assemble %.3f s (%zu poppers, %llu device rounds), %zu assemblies; %llu passes in %u batches, matching %.3f s\n",
+            drops.size(), t1 - t0, t2 - t1, n_fronts, now_seconds() - t2, n_poppers, (unsigned long long)pt.device_rounds, pt.out.size(),
+            (unsigned long long)pt.passes_run, pt.ahead_batch, double(pt.match_seconds_us) * 1e-6);
   // sorter(left_offset_less_than) -> pair_counter -> (reversed back) (reversable_tracer.cpp:118-126)
   std::sort(pt.out.begin(), pt.out.end(), [](const bg_trace_assembly_rec& a, const bg_trace_assembly_rec& b) { return a.left_offset < b.left_offset; });
   std::vector<bg_trace_assembly_rec> counted;

@@ -65,15 +65,9 @@ __global__ __launch_bounds__(256) void k_push_front_drop(SeqsetView v, uint64_t 
 // seqset_range::pop_front (bio_base/seqset.cpp:609-628): the first base b is the `fixed` bucket the range begins in;
 // the entry that push_front(b) maps onto `begin` is the (begin - fixed[b])-th set bit of prev_b (select = binary search
 // over the counts); then the range widens over the neighbours that share the shorter context.
-__global__ __launch_bounds__(256) void k_pop_front(SeqsetView v, uint64_t n, const uint64_t* __restrict__ begin,
-                                                   const uint64_t* __restrict__ end, const uint32_t* __restrict__ size,
-                                                   uint64_t* __restrict__ ob, uint64_t* __restrict__ oe,
-                                                   uint32_t* __restrict__ os) {
-  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t b0 = begin[i], e0 = end[i];
-  const uint32_t s0 = size[i];
-  if (!(b0 < e0 && e0 <= v.n) || s0 == 0) { ob[i] = 0; oe[i] = 0; os[i] = 0; return; }  // (the reference throws)
+__device__ __forceinline__ void pop_front_range(const SeqsetView& v, uint64_t b0, uint64_t e0, uint32_t s0, uint64_t* ob, uint64_t* oe,
+                                                uint32_t* os) {
+  if (!(b0 < e0 && e0 <= v.n) || s0 == 0) { *ob = 0; *oe = 0; *os = 0; return; }  // (the reference throws)
   int b = 0;
   while (b < 3 && b0 >= v.fixed[b + 1]) ++b;
   const uint64_t rank = b0 - v.fixed[b];
@@ -86,9 +80,18 @@ __global__ __launch_bounds__(256) void k_pop_front(SeqsetView v, uint64_t n, con
   uint64_t nb = lo, ne = lo + 1;
   while (nb && v.shared[nb] >= ctx_len) --nb;
   while (ne < v.n && v.shared[ne] >= ctx_len) ++ne;
-  ob[i] = nb;
-  oe[i] = ne;
-  os[i] = ctx_len;
+  *ob = nb;
+  *oe = ne;
+  *os = ctx_len;
+}
+
+__global__ __launch_bounds__(256) void k_pop_front(SeqsetView v, uint64_t n, const uint64_t* __restrict__ begin,
+                                                   const uint64_t* __restrict__ end, const uint32_t* __restrict__ size,
+                                                   uint64_t* __restrict__ ob, uint64_t* __restrict__ oe,
+                                                   uint32_t* __restrict__ os) {
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  pop_front_range(v, begin[i], end[i], size[i], &ob[i], &oe[i], &os[i]);
 }
 
 __global__ __launch_bounds__(256) void k_find(SeqsetView v, uint64_t n, const uint8_t* __restrict__ seq,
@@ -1284,6 +1287,76 @@ __global__ void k_pr_pack(ReadmapView rm, uint64_t n, uint32_t cap, const uint32
     o_len[p] = uint8_t(len < 255 ? len : 255);
   }
 }
+
+// pop_tracer::pop_pass (pop_tracer.cpp:364-445) for several passes ahead: every popper pops one base per pass until too
+// little context is left, and takes the reverse complements of the first `cap` prefix reads of what remains (add_entry_reads,
+// :458-467).  What a pass does to a popper depends on nothing but the popper -- until the host's matching merges it with a
+// front; the host replays the passes in order from these records and asks again from where a merge changed a range.
+__global__ __launch_bounds__(64) void k_pop_passes(SeqsetView v, ReadmapView rm, uint64_t n, const uint64_t* __restrict__ qb,
+                                                  const uint64_t* __restrict__ qe, const uint32_t* __restrict__ qs, uint32_t passes,
+                                                  uint32_t min_pop_overlap, int limit, uint32_t cap, bg::PopPassRec* __restrict__ recs,
+                                                  uint32_t* __restrict__ ids, unsigned int* __restrict__ ids_used) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t b = qb[i], e = qe[i];
+  uint32_t s = qs[i];
+  for (uint32_t j = 0; j < passes; ++j) {
+    bg::PopPassRec rec;
+    pop_front_range(v, b, e, s, &rec.b, &rec.e, &rec.s);
+    rec.n_ids = 0;
+    rec.ids_at = 0;
+    rec.pad = 0;
+    if (rec.s < min_pop_overlap) { recs[i * passes + j] = rec; break; }  // discarded by the host at this pass
+    uint32_t tmp[bg::kPopPassMaxIds];
+    uint32_t c = 0;
+    Tri r{rec.b, rec.e, rec.s};
+    if (r.e <= v.n)
+      for_prefix_reads(v, rm, r, limit, [&](uint64_t id) {
+        tmp[c++] = uint32_t(rm_follow(rm, id, rm.is_fwd[id] ? 1 : 3));  // readmap::get_rev_comp
+        return c < cap;
+      });
+    if (c) {
+      const unsigned at = atomicAdd(ids_used, c);
+      for (uint32_t k = 0; k < c; ++k) ids[at + k] = tmp[k];
+      rec.ids_at = at;
+      rec.n_ids = c;
+    }
+    recs[i * passes + j] = rec;
+    b = rec.b; e = rec.e; s = rec.s;
+  }
+}
+
+namespace bg {
+int pop_passes(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n, const uint64_t* d_begin, const uint64_t* d_end,
+               const uint32_t* d_size, uint32_t passes, uint32_t min_pop_overlap, int read_len_limit, uint32_t cap,
+               std::vector<PopPassRec>* recs, std::vector<uint32_t>* ids) {
+  BG_TRY(check_ss(ctx, ss, "pop_passes"));
+  BG_TRY(check_rm(ss, rm, "pop_passes"));
+  if (rm->pair_mode) { set_error("pop_passes: readmap has no mate loop table; use \"biograph upgrade\" to construct it"); return BG_EINVAL; }
+  if (cap < 1 || cap > kPopPassMaxIds || passes < 1) { set_error("pop_passes: bad cap or pass count"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  recs->assign(n * passes, PopPassRec{0, 0, 0, 0, 0, 0});
+  ids->clear();
+  if (!n) return BG_OK;
+  if (n * passes * cap >= (1ull << 32)) { set_error("pop_passes: batch too large"); return BG_EINVAL; }
+  DevBuf<uint8_t> d_recs;
+  DevBuf<uint32_t> d_ids, d_used;
+  BG_TRY(d_recs.alloc(ctx, n * passes * sizeof(PopPassRec)));
+  BG_TRY(d_ids.alloc(ctx, n * passes * cap));
+  BG_TRY(d_used.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(d_recs.p, 0, n * passes * sizeof(PopPassRec), ctx->stream));
+  BG_HIP(hipMemsetAsync(d_used.p, 0, 4, ctx->stream));
+  k_pop_passes<<<cdiv(n, 64), 64, 0, ctx->stream>>>(make_view(ss), make_rm_view(rm), n, d_begin, d_end, d_size, passes, min_pop_overlap,
+                                                     read_len_limit, cap, reinterpret_cast<PopPassRec*>(d_recs.p), d_ids.p, d_used.p);
+  BG_LAUNCH_CHECK();
+  uint32_t used = 0;
+  BG_HIP(copy_d2h(ctx, &used, d_used.p, 4));
+  BG_HIP(copy_d2h(ctx, recs->data(), d_recs.p, n * passes * sizeof(PopPassRec)));
+  ids->resize(used);
+  if (used) BG_HIP(copy_d2h(ctx, ids->data(), d_ids.p, size_t(used) * 4));
+  return BG_OK;
+}
+}  // namespace bg
 
 namespace bg {
 int prefix_reads_packed(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n, const uint64_t* d_begin,

@@ -24,7 +24,7 @@ def main():
     for th in args.threads.split(","):
         t0 = time.perf_counter()
         r = subprocess.run([exe, "discovery", "--in", os.path.join(tmp, "s.bg"), "--ref", os.path.join(tmp, "ref.fa"), "--out",
-                            os.path.join(tmp, "t%s.vcf" % th), "--threads", th, "--simple-gt", "true"], capture_output=True, text=True, env=env)
+                            os.path.join(tmp, "t%s.vcf" % th), "--threads", th, "--simple-gt", "true", "-f"], capture_output=True, text=True, env=env)
         dt = time.perf_counter() - t0
         log = os.path.join(tmp, "timing_%s.log" % th)
         open(log, "w").write(r.stderr)
