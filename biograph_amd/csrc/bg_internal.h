@@ -288,9 +288,12 @@ bg_ctx::DeviceArena* shared_arena(int device);  // null unless the hook is insta
 // at the first pass that leaves it less than min_pop_overlap bases (that record is the last one written).
 constexpr uint32_t kPopPassMaxIds = 32;
 struct PopPassRec { uint64_t b, e; uint32_t s, n_ids, ids_at, pad; };
-int pop_passes(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n, const uint64_t* d_begin, const uint64_t* d_end,
-               const uint32_t* d_size, uint32_t passes, uint32_t min_pop_overlap, int read_len_limit, uint32_t cap,
-               std::vector<PopPassRec>* recs, std::vector<uint32_t>* ids);
+// h_*: host arrays; pin_in / pin_out: page-locked staging of at least pop_passes_in_bytes / _out_bytes.
+size_t pop_passes_in_bytes(uint64_t n);
+size_t pop_passes_out_bytes(uint64_t n, uint32_t passes, uint32_t cap);
+int pop_passes(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n, const uint64_t* h_begin, const uint64_t* h_end,
+               const uint32_t* h_size, uint32_t passes, uint32_t min_pop_overlap, int read_len_limit, uint32_t cap, void* pin_in,
+               void* pin_out, std::vector<PopPassRec>* recs, std::vector<uint32_t>* ids);
 // The prefix reads of n ranges (device arrays) with the pop tracer's per-read attributes, packed (walk.hip): range q's first
 // min(count[q], cap) reads are [first[q], first[q + 1]) of id / rc / mate_rc (0xffffffff: no mate) / flags (1 has mate, 2
 // is forward) / len; count[q] is the full number of prefix reads.

@@ -1625,7 +1625,7 @@ struct PopEntry {  // pop_tracer::entry (pop_tracer.h:58-84)
   TRange orig_r, popped_r;
   std::string seq;
   std::vector<uint32_t> seen_read_ids;
-  // where this popper stands in the passes the device ran ahead (PopTracer::pop_pass): slot in the batch, or -1 once a merge
+  // where this popper stands in the passes the device ran ahead (PopTracer::pop_pass): its row in the batch, or -1 once a merge
   // has given it another range
   int32_t ahead_slot = -1;
   uint32_t ahead_batch = 0;
@@ -2109,7 +2109,9 @@ struct PopTracer {
     static const bool ahead_off = [] { const char* e = getenv("BG_POP_PASSES_AHEAD"); return e && e[0] == '0'; }();
     if (ahead_off || cap > kPopPassMaxIds) return pop_pass_one(order, cap);
     // The passes the device ran ahead serve while every popper still is where the device left it: a merge
-    // (match_and_output_pass) gives a popper another range, and the batch ends there.
+    // (match_and_output_pass) gives a popper another range, and the batch ends there -- for everybody: a batch per popper was
+    // tried and lost (poppers then run out of passes at different times and nearly every pass needs a launch; a launch per
+    // merge is the floor either way, and merges come every other pass).
     bool fresh = ahead_used < ahead_passes;
     for (PopEntry* p : order)
       if (p->ahead_slot < 0 || p->ahead_batch != ahead_batch) { fresh = false; break; }
@@ -2118,21 +2120,20 @@ struct PopTracer {
       if (ahead_batch) ahead_passes = ahead_used >= ahead_passes ? std::min<uint32_t>(ahead_passes * 2, 64) : std::max<uint32_t>(ahead_used, 2);
       ++ahead_batch;
       ahead_used = 0;
-      std::vector<TRange> in;
-      for (size_t i = 0; i < order.size(); ++i) {
-        in.push_back(order[i]->popped_r);
+      const size_t n = order.size();
+      std::vector<uint64_t> hb(n), he(n);
+      std::vector<uint32_t> hs(n);
+      for (size_t i = 0; i < n; ++i) {
+        hb[i] = order[i]->popped_r.b; he[i] = order[i]->popped_r.e; hs[i] = order[i]->popped_r.s;
         order[i]->ahead_slot = int32_t(i);
         order[i]->ahead_batch = ahead_batch;
       }
-      DevBuf<uint8_t> d;
-      uint64_t *db = nullptr, *de = nullptr;
-      uint32_t* ds = nullptr;
-      uint8_t* rest = nullptr;
-      BG_TRY(upload_ranges(in, &d, 0, &db, &de, &ds, &rest));
-      BG_TRY(pop_passes(ctx, w.ss, w.rm, in.size(), db, de, ds, ahead_passes, uint32_t(w.o.min_pop_overlap), int(w.o.min_overlap), cap,
-                        &ahead_recs, &ahead_ids));
+      BG_TRY(w.pin_q.ensure(pop_passes_in_bytes(n)));
+      BG_TRY(w.pin_r.ensure(pop_passes_out_bytes(n, ahead_passes, cap)));
+      BG_TRY(pop_passes(ctx, w.ss, w.rm, n, hb.data(), he.data(), hs.data(), ahead_passes, uint32_t(w.o.min_pop_overlap), int(w.o.min_overlap),
+                        cap, w.pin_q.p, w.pin_r.p, &ahead_recs, &ahead_ids));
       ++device_rounds;
-      device_queries += in.size() * ahead_passes;
+      device_queries += n * ahead_passes;
     }
     for (PopEntry* p : order) {
       const PopPassRec& rec = ahead_recs[size_t(p->ahead_slot) * ahead_passes + ahead_used];
@@ -2148,7 +2149,7 @@ struct PopTracer {
     return BG_OK;
   }
   uint64_t passes_run = 0, match_seconds_us = 0;
-  uint32_t ahead_passes = 8, ahead_used = 0, ahead_batch = 0;
+  uint32_t ahead_passes = 4, ahead_used = 0, ahead_batch = 0;
   std::vector<PopPassRec> ahead_recs;
   std::vector<uint32_t> ahead_ids;
 

@@ -2,6 +2,8 @@
 // One lane per query: push_front (bio_base/seqset.cpp:319-338), push_front_drop (:350-429) and
 // find (:146-155).  Pure integer, latency-bound random access: 2 rank queries (bits + subaccum +
 // accum words) and <= 2 entry-size bytes per step, plus shared[] / min-index probes when dropping.
+#include <string.h>
+
 #include <vector>
 
 #include "bg_device_funcs.h"
@@ -1327,33 +1329,56 @@ __global__ __launch_bounds__(64) void k_pop_passes(SeqsetView v, ReadmapView rm,
 }
 
 namespace bg {
-int pop_passes(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n, const uint64_t* d_begin, const uint64_t* d_end,
-               const uint32_t* d_size, uint32_t passes, uint32_t min_pop_overlap, int read_len_limit, uint32_t cap,
-               std::vector<PopPassRec>* recs, std::vector<uint32_t>* ids) {
+size_t pop_passes_in_bytes(uint64_t n) { return 8 + n * 16 + ((n * 4 + 7) & ~size_t(7)); }
+size_t pop_passes_out_bytes(uint64_t n, uint32_t passes, uint32_t cap) { return 8 + n * passes * sizeof(PopPassRec) + n * passes * cap * 4; }
+
+// One upload (the ranges, from pinned memory), one launch, one download (two when the ids are many) into pinned memory: a pass
+// of the pop tracer is a link in a chain of a few hundred launches per work item, and each link used to be six blocking calls.
+int pop_passes(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n, const uint64_t* h_begin, const uint64_t* h_end,
+               const uint32_t* h_size, uint32_t passes, uint32_t min_pop_overlap, int read_len_limit, uint32_t cap, void* pin_in,
+               void* pin_out, std::vector<PopPassRec>* recs, std::vector<uint32_t>* ids) {
   BG_TRY(check_ss(ctx, ss, "pop_passes"));
   BG_TRY(check_rm(ss, rm, "pop_passes"));
   if (rm->pair_mode) { set_error("pop_passes: readmap has no mate loop table; use \"biograph upgrade\" to construct it"); return BG_EINVAL; }
   if (cap < 1 || cap > kPopPassMaxIds || passes < 1) { set_error("pop_passes: bad cap or pass count"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));
-  recs->assign(n * passes, PopPassRec{0, 0, 0, 0, 0, 0});
+  recs->clear();
   ids->clear();
   if (!n) return BG_OK;
-  if (n * passes * cap >= (1ull << 32)) { set_error("pop_passes: batch too large"); return BG_EINVAL; }
-  DevBuf<uint8_t> d_recs;
-  DevBuf<uint32_t> d_ids, d_used;
-  BG_TRY(d_recs.alloc(ctx, n * passes * sizeof(PopPassRec)));
-  BG_TRY(d_ids.alloc(ctx, n * passes * cap));
-  BG_TRY(d_used.alloc(ctx, 1));
-  BG_HIP(hipMemsetAsync(d_recs.p, 0, n * passes * sizeof(PopPassRec), ctx->stream));
-  BG_HIP(hipMemsetAsync(d_used.p, 0, 4, ctx->stream));
-  k_pop_passes<<<cdiv(n, 64), 64, 0, ctx->stream>>>(make_view(ss), make_rm_view(rm), n, d_begin, d_end, d_size, passes, min_pop_overlap,
-                                                     read_len_limit, cap, reinterpret_cast<PopPassRec*>(d_recs.p), d_ids.p, d_used.p);
+  if (n * passes * cap >= (1ull << 30)) { set_error("pop_passes: batch too large"); return BG_EINVAL; }
+  const size_t in_bytes = pop_passes_in_bytes(n), rec_bytes = n * passes * sizeof(PopPassRec), id_bytes = n * passes * cap * 4;
+  // device: [b n x 8][e n x 8][s n x 4, padded][counter 8][recs][ids]; the upload carries everything before the counter's end
+  DevBuf<uint8_t> d;
+  BG_TRY(d.alloc(ctx, in_bytes + rec_bytes + id_bytes));
+  uint8_t* hin = static_cast<uint8_t*>(pin_in);
+  memcpy(hin, h_begin, n * 8);
+  memcpy(hin + n * 8, h_end, n * 8);
+  memcpy(hin + n * 16, h_size, n * 4);
+  memset(hin + in_bytes - 8, 0, 8);
+  BG_HIP(hipMemcpyAsync(d.p, hin, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  uint64_t* db = reinterpret_cast<uint64_t*>(d.p);
+  uint64_t* de = db + n;
+  uint32_t* ds = reinterpret_cast<uint32_t*>(de + n);
+  unsigned int* d_used = reinterpret_cast<unsigned int*>(d.p + in_bytes - 8);
+  PopPassRec* d_recs = reinterpret_cast<PopPassRec*>(d.p + in_bytes);
+  uint32_t* d_ids = reinterpret_cast<uint32_t*>(d.p + in_bytes + rec_bytes);
+  k_pop_passes<<<cdiv(n, 64), 64, 0, ctx->stream>>>(make_view(ss), make_rm_view(rm), n, db, de, ds, passes, min_pop_overlap, read_len_limit,
+                                                     cap, d_recs, d_ids, d_used);
   BG_LAUNCH_CHECK();
+  uint8_t* hout = static_cast<uint8_t*>(pin_out);
+  const bool one_copy = id_bytes <= (size_t(256) << 10);
+  BG_HIP(hipMemcpyAsync(hout, d.p + in_bytes - 8, 8 + rec_bytes + (one_copy ? id_bytes : 0), hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
   uint32_t used = 0;
-  BG_HIP(copy_d2h(ctx, &used, d_used.p, 4));
-  BG_HIP(copy_d2h(ctx, recs->data(), d_recs.p, n * passes * sizeof(PopPassRec)));
-  ids->resize(used);
-  if (used) BG_HIP(copy_d2h(ctx, ids->data(), d_ids.p, size_t(used) * 4));
+  memcpy(&used, hout, 4);
+  if (!one_copy && used) {
+    BG_HIP(hipMemcpyAsync(hout + 8 + rec_bytes, d_ids, size_t(used) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  const PopPassRec* hr = reinterpret_cast<const PopPassRec*>(hout + 8);
+  recs->assign(hr, hr + n * passes);
+  const uint32_t* hi = reinterpret_cast<const uint32_t*>(hout + 8 + rec_bytes);
+  ids->assign(hi, hi + used);
   return BG_OK;
 }
 }  // namespace bg
