@@ -1892,6 +1892,7 @@ struct PopTracer {
 
   // ---- add_reference (:162-206) with add_reference_at (:97-160)
   int add_reference(int64_t start, int64_t limit) {
+    double t_mark = now_seconds();
     // the scaffold reversed: entries face right while push_front_drop runs through it (:167-169)
     const std::vector<Extent>& rc = sc_rc;
     const int64_t scaffold_end = end_pos;
@@ -1904,7 +1905,7 @@ struct PopTracer {
     std::vector<bg_walk_chain> chains;
     std::vector<uint8_t> codes;
     uint64_t words = 0;
-    const int64_t chain_len = 1024, warm = int64_t(w.ss->max_len) + 1;
+    const int64_t chain_len = 512, warm = int64_t(w.ss->max_len) + 1;  // (a lane walks chain_len + warm steps: 2.8 ms; 1024: 5 ms)
     bool stopped = false;
     for (size_t x = 0; x < rc.size() && !stopped; ++x) {
       const Extent& e = rc[x];
@@ -1947,6 +1948,7 @@ struct PopTracer {
       ++device_rounds;
       device_queries += codes.size();
     }
+    ref_t[0] += now_seconds() - t_mark; t_mark = now_seconds();
     // replay the loop of :180-199 over the ranges
     std::vector<std::pair<int64_t, TRange>> refs;  // add_reference_at(offset, r) in call order
     size_t ci = 0;
@@ -1988,6 +1990,7 @@ struct PopTracer {
       }
     }
     refs.emplace_back(offset, r);
+    ref_t[1] += now_seconds() - t_mark; t_mark = now_seconds();
     // add_reference_at for all of them: ranges shorter than min_pop_overlap add nothing
     std::vector<std::pair<int64_t, TRange>> kept;
     for (auto& x : refs)
@@ -1998,6 +2001,7 @@ struct PopTracer {
     // supply the mates; a range with more reads than the buffer holds and too few mates among them is asked again
     const uint32_t cap = uint32_t(std::max<uint64_t>(w.o.max_pairs_per_read, 1)) * 2;
     PackedPrefixReads pr;
+    ref_t[2] += now_seconds() - t_mark; t_mark = now_seconds();
     BG_TRY(prefix_reads_attr(ranges, cap, &pr));
     std::vector<std::vector<uint32_t>> wide(ranges.size());
     {
@@ -2027,6 +2031,7 @@ struct PopTracer {
         again.swap(still);
       }
     }
+    ref_t[3] += now_seconds() - t_mark; t_mark = now_seconds();
     std::vector<Item> items;
     for (size_t i = 0; i < kept.size(); ++i) {
       const int64_t off = kept[i].first;
@@ -2075,8 +2080,12 @@ struct PopTracer {
         add_mate(int64_t(w.tables->read_len[rid]), bool(w.is_forward[rid]), w.get_rev_comp(w.get_mate(rid)));
       }
     }
-    return materialize(items);
+    ref_t[4] += now_seconds() - t_mark; t_mark = now_seconds();
+    const int rc_mat = materialize(items);
+    ref_t[5] += now_seconds() - t_mark;
+    return rc_mat;
   }
+  double ref_t[6] = {0, 0, 0, 0, 0, 0};  // walk, replay, kept ranges, prefix reads, entries and items, materialize
 
   void sort_fronts() {  // std::multimap<seqset_range, ..., seqset_range_comparer>: (begin, size), equal keys in insertion order
     std::stable_sort(fronts.begin(), fronts.end(), [](const Front& a, const Front& b) { return a.b != b.b ? a.b < b.b : a.s < b.s; });
@@ -2294,9 +2303,10 @@ extern "C" int bg_pop_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext
   const size_t n_fronts = pt.fronts.size(), n_poppers = pt.poppers.size();
   BG_TRY(pt.assemble());
   if (getenv("BG_TRACER_TIMING"))
-    fprintf(stderr, "bg_pop_trace: %zu anchor drops %.3f s, reference %.3f s (%zu fronts), assemble %.3f s (%zu poppers, %llu device rounds), %zu assemblies; %llu passes in %u batches, matching %.3f s\n",
+    fprintf(stderr, "bg_pop_trace: %zu anchor drops %.3f s, reference %.3f s (%zu fronts), assemble %.3f s (%zu poppers, %llu device rounds), %zu assemblies; %llu passes in %u batches, matching %.3f s; reference: walk %.3f replay %.3f kept %.3f prefix reads %.3f items %.3f materialize %.3f\n",
             drops.size(), t1 - t0, t2 - t1, n_fronts, now_seconds() - t2, n_poppers, (unsigned long long)pt.device_rounds, pt.out.size(),
-            (unsigned long long)pt.passes_run, pt.ahead_batch, double(pt.match_seconds_us) * 1e-6);
+            (unsigned long long)pt.passes_run, pt.ahead_batch, double(pt.match_seconds_us) * 1e-6, pt.ref_t[0], pt.ref_t[1], pt.ref_t[2], pt.ref_t[3],
+            pt.ref_t[4], pt.ref_t[5]);
   // sorter(left_offset_less_than) -> pair_counter -> (reversed back) (reversable_tracer.cpp:118-126)
   std::sort(pt.out.begin(), pt.out.end(), [](const bg_trace_assembly_rec& a, const bg_trace_assembly_rec& b) { return a.left_offset < b.left_offset; });
   std::vector<bg_trace_assembly_rec> counted;
