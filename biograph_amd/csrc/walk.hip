@@ -1671,6 +1671,21 @@ __global__ void k_tt_emit(const uint64_t* __restrict__ ent, uint64_t n, const ui
   }
 }
 
+// the tables as the host keeps them: (offset, entry) by position, (entry, offset) and (rc mate, offset) sorted -- two words per
+// pair of the first two (the int32 member with its padding in one word), one word per pair of the third
+__global__ void k_tt_finish(uint64_t n_pe, uint64_t n_m, const uint32_t* __restrict__ pe_idx, const uint64_t* __restrict__ pe_ent,
+                            const uint64_t* __restrict__ key, const uint64_t* __restrict__ mkey, int64_t first_off,
+                            uint64_t* __restrict__ o_pe, uint64_t* __restrict__ o_ep, uint64_t* __restrict__ o_mp) {
+  const uint64_t p = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p < n_pe) {
+    o_pe[2 * p] = uint64_t(uint32_t(int32_t(first_off + int64_t(pe_idx[p]))));
+    o_pe[2 * p + 1] = pe_ent[p];
+    o_ep[2 * p] = key[p] >> 24;
+    o_ep[2 * p + 1] = uint64_t(uint32_t(int32_t(first_off + int64_t(key[p] & 0xffffff))));
+  }
+  if (p < n_m) o_mp[p] = (mkey[p] >> 24 & 0xffffffffull) | (uint64_t(uint32_t(int32_t(first_off + int64_t(mkey[p] & 0xffffff)))) << 32);
+}
+
 int tracer_read_tables(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const uint8_t* d_ref_map, bool skip_ambiguous,
                        const uint64_t* d_ent, uint64_t n, int64_t first_off, std::vector<std::pair<int32_t, uint64_t>>* pos_entries,
                        std::vector<std::pair<uint64_t, int32_t>>* entry_pos, std::vector<std::pair<uint32_t, int32_t>>* mate_pos) {
@@ -1701,18 +1716,28 @@ int tracer_read_tables(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, c
   if (n_pe) BG_TRY(radix_sort_u64(ctx, ka.p, kb.p, nullptr, nullptr, n_pe, 0, 64, &pe_in_b));
   if (n_m) BG_TRY(radix_sort_u64(ctx, ma.p, mb.p, nullptr, nullptr, n_m, 0, 56, &m_in_b));
   ctx->toc(n * 40 + (n_pe + n_m) * 64);
-  std::vector<uint32_t> h_idx(n_pe);
-  std::vector<uint64_t> h_ent(n_pe), h_key(n_pe), h_m(n_m);
-  BG_HIP(copy_d2h(ctx, h_idx.data(), pe_idx.p, n_pe * 4));
-  BG_HIP(copy_d2h(ctx, h_ent.data(), pe_ent.p, n_pe * 8));
-  BG_HIP(copy_d2h(ctx, h_key.data(), pe_in_b ? kb.p : ka.p, n_pe * 8));
-  BG_HIP(copy_d2h(ctx, h_m.data(), m_in_b ? mb.p : ma.p, n_m * 8));
-  pos_entries->reserve(pos_entries->size() + n_pe);
-  entry_pos->reserve(entry_pos->size() + n_pe);
-  mate_pos->reserve(mate_pos->size() + n_m);
-  for (uint64_t p = 0; p < n_pe; ++p) pos_entries->emplace_back(int32_t(first_off + int64_t(h_idx[p])), h_ent[p]);
-  for (uint64_t p = 0; p < n_pe; ++p) entry_pos->emplace_back(h_key[p] >> 24, int32_t(first_off + int64_t(h_key[p] & 0xffffff)));
-  for (uint64_t p = 0; p < n_m; ++p) mate_pos->emplace_back(uint32_t(h_m[p] >> 24), int32_t(first_off + int64_t(h_m[p] & 0xffffff)));
+  // the three host tables in their final layout, straight into the vectors' storage: std::pair<int32_t, uint64_t>,
+  // std::pair<uint64_t, int32_t> (16 bytes each, the second member at 8) and std::pair<uint32_t, int32_t> (8 bytes)
+  static_assert(sizeof(std::pair<int32_t, uint64_t>) == 16 && sizeof(std::pair<uint64_t, int32_t>) == 16 && sizeof(std::pair<uint32_t, int32_t>) == 8,
+                "pair layouts");
+  DevBuf<uint64_t> o_pe, o_ep, o_mp;
+  BG_TRY(o_pe.alloc(ctx, n_pe * 2)); BG_TRY(o_ep.alloc(ctx, n_pe * 2)); BG_TRY(o_mp.alloc(ctx, n_m));
+  const uint64_t n_fin = n_pe > n_m ? n_pe : n_m;
+  if (n_fin) {
+    k_tt_finish<<<cdiv(n_fin, 256), 256, 0, ctx->stream>>>(n_pe, n_m, pe_idx.p, pe_ent.p, pe_in_b ? kb.p : ka.p, m_in_b ? mb.p : ma.p, first_off,
+                                                         o_pe.p, o_ep.p, o_mp.p);
+    BG_LAUNCH_CHECK();
+  }
+  const size_t pe0 = pos_entries->size(), ep0 = entry_pos->size(), mp0 = mate_pos->size();
+  pos_entries->resize(pe0 + n_pe);
+  entry_pos->resize(ep0 + n_pe);
+  mate_pos->resize(mp0 + n_m);
+  if (n_pe) {
+    BG_HIP(hipMemcpyAsync(static_cast<void*>(pos_entries->data() + pe0), o_pe.p, n_pe * 16, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipMemcpyAsync(static_cast<void*>(entry_pos->data() + ep0), o_ep.p, n_pe * 16, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (n_m) BG_HIP(hipMemcpyAsync(static_cast<void*>(mate_pos->data() + mp0), o_mp.p, n_m * 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
   return BG_OK;
 }
 
