@@ -781,10 +781,18 @@ void AnchorDropper::add(bg_trace_assembly_rec&& a) {  // on_assembly :194-341
     new_ref_len = ref_start - a.left_offset;
     new_match_len = match_len;
   }
-  if (!have) return;  // the reference reports a half-aligned assembly here; nothing goes down the pipeline
+  if (!have) {  // nothing goes down the pipeline; the unanchored bases are reported (:316-329)
+    if (report_half_aligned) report_half_aligned(a.left_offset + a.left_anchor_len, a.seq.substr(size_t(a.left_anchor_len)), a.assembly_id);
+    return;
+  }
   a.right_offset = a.left_offset + new_ref_len;
-  bg_trace_assembly_rec anchored = split_assembly(a, new_seq_len, new_ref_len).first;
+  auto parts = split_assembly(a, new_seq_len, new_ref_len);
+  bg_trace_assembly_rec& anchored = parts.first;
   anchored.right_anchor_len = int(new_match_len);
+  if (report_half_aligned && !parts.second.seq.empty()) {  // what lies behind the match is discarded (:301-311)
+    check(parts.second.left_anchor_len == 0, "anchor_dropper: the discarded part has a left anchor");
+    report_half_aligned(parts.second.left_offset, parts.second.seq, parts.second.assembly_id);
+  }
   sort_and_output(std::move(anchored));
 }
 
@@ -821,6 +829,23 @@ extern "C" int bg_trace_result_add(bg_trace_result* r, const bg_trace_assembly* 
   x.assembly_id = a->assembly_id ? a->assembly_id : allocate_assembly_id();  // assembly::assembly(), assemble.cpp:1248
   x.from_pop = a->from_pop != 0;
   r->a.push_back(std::move(x));
+  return BG_OK;
+}
+
+extern "C" uint64_t bg_trace_result_half_aligned_count(const bg_trace_result* r) { return r ? r->half_aligned.size() : 0; }
+
+extern "C" int bg_trace_result_half_aligned(const bg_trace_result* r, uint64_t i, int64_t* offset, int* right_anchor, const char** seq,
+                                            uint64_t* seq_len, uint64_t* assembly_id) {
+  if (!r || i >= r->half_aligned.size() || !offset || !right_anchor || !seq || !seq_len || !assembly_id) {
+    set_error("bg_trace_result_half_aligned: bad argument");
+    return BG_EINVAL;
+  }
+  const bg_half_aligned_rec& h = r->half_aligned[i];
+  *offset = h.offset;
+  *right_anchor = h.right_anchor ? 1 : 0;
+  *seq = h.seq.data();
+  *seq_len = h.seq.size();
+  *assembly_id = h.assembly_id;
   return BG_OK;
 }
 

@@ -58,10 +58,18 @@ struct bg_anchor_drop_rec {  // what tracer::output_assembly hands to report_anc
   bool right_anchor = false;
 };
 
+struct bg_half_aligned_rec {  // variants::half_aligned_assembly (assemble.h:449-465), in FORWARD coordinates
+  int64_t offset = 0;
+  bool right_anchor = false;  // false: anchored on the left at `offset`, the sequence runs on from there; true: ends there
+  std::string seq;
+  uint64_t assembly_id = 0;
+};
+
 struct bg_trace_result {
   std::vector<bg_trace_assembly_rec> a;
   bg_trace_stats stats;
   std::vector<bg_anchor_drop_rec> anchor_drops;  // bg_tracer_trace -> bg_pop_trace
+  std::vector<bg_half_aligned_rec> half_aligned;  // what the anchor_dropper could not anchor on the right (report_half_aligned_func)
 };
 
 namespace bg {
@@ -118,6 +126,9 @@ class AnchorDropper : public SortedOutput {
  public:
   AnchorDropper(const AlignParams& p, const ScaffoldView& sc, AssemblySink out);
   void add(bg_trace_assembly_rec&& a);
+  // assemble_options::report_half_aligned_func (anchor_drop.cpp:301-329): offset of the left anchor's end, the bases from there
+  // on that found no place on the reference, the assembly's id
+  std::function<void(int64_t, const std::string&, uint64_t)> report_half_aligned;
 
  private:
   void advance_range_to(int64_t trail_behind, int64_t read_ahead);

@@ -1192,6 +1192,10 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   if (want_aligned)
     aligned_csv = "scaffold_name,left_offset,right_offset,left_anchor_len,right_anchor_len,aid,score,min_overlap,"
                   "variants(refrange:varseq:refseq),seq,generated_by\n";
+  // --half-aligned-out FILE (biograph_variants.cpp:175,695-710): what the anchor_dropper could not place on the right
+  std::string half_csv;
+  const bool want_half = a.has("half-aligned-out") && !a.get("half-aligned-out").empty();
+  if (want_half) half_csv = "scaffold_name,left_anchor,right_anchor,sequence,assembly_id\n";
   opt.max_pair_distance = uint64_t(max_pair_distance);
   if (a.has("scaffold-split-size")) {  // assemble_options::scaffold_split_size (the size of trace_ref's pieces)
     const long long sp = atoll(a.get("scaffold-split-size").c_str());
@@ -1373,6 +1377,18 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
       }
     }
     for (auto* r : items) n_traced += bg_trace_result_size(r);
+    if (want_half)  // (the reference writes them as its threads report them; here in work-item order)
+      for (auto* r : items)
+        for (uint64_t i = 0; i < bg_trace_result_half_aligned_count(r); ++i) {
+          int64_t off = 0;
+          int right = 0;
+          const char* hs = nullptr;
+          uint64_t hn = 0, id = 0;
+          check(bg_trace_result_half_aligned(r, i, &off, &right, &hs, &hn, &id), "bg_trace_result_half_aligned");
+          half_csv += rec.first + "," + (right ? "," + std::to_string(off) : std::to_string(off) + ",") + ",";
+          half_csv.append(hs, hn);
+          half_csv += "," + std::to_string(id) + "\n";
+        }
     t_trace += now_s() - t1;
     rss_trace = std::max(rss_trace, rss_gb());
     t1 = now_s();
@@ -1463,6 +1479,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   write_file(a.get("out"), vcf);
   if (want_csv) write_file(a.get("assemblies-out"), asm_csv);
   if (want_aligned) write_file(a.get("aligned-assemblies-out"), aligned_csv);
+  if (want_half) write_file(a.get("half-aligned-out"), half_csv);
   fprintf(stderr, "%llu variants over %zu scaffold(s) in %llu piece(s) x 2 directions on %d tracer session(s), min overlap %u: %.2f s (refmap %.2f, sessions %.2f, tracing %.2f "
                   "[%llu assemblies], pipeline %.2f [%llu sections], coverage + genotype %.2f); pop tracer %s [%llu of the assemblies]\n",
           (unsigned long long)n_var, recs.size(), (unsigned long long)pieces, n_threads, min_overlap, now_s() - t0, t_refmap, t_open, t_trace,
@@ -1481,10 +1498,10 @@ static int cmd_discovery(int argc, char** argv) {
   cpuprof::start();
   Args a = parse(argc, argv, 2, {"reads", "ref", "out", "sample", "min-overlap", "max-pair-distance", "bed", "engine", "max-ploids",
                                  "enable-pop-tracer", "threads", "ml-features", "scaffold-split-size", "simple-gt", "rvg-exclude",
-                                 "force", "ref-map", "min-pop-overlap", "assemblies-out", "aligned-assemblies-out"});
+                                 "force", "ref-map", "min-pop-overlap", "assemblies-out", "aligned-assemblies-out", "half-aligned-out"});
   if (!a.has("reads") || !a.has("ref") || !a.has("out")) die("discovery: --in S.bg, --ref and --out are required");
   // biograph_variants.cpp:216-232: an output that exists is only replaced with -f / --force
-  for (const char* o : {"out", "assemblies-out", "aligned-assemblies-out"})
+  for (const char* o : {"out", "assemblies-out", "aligned-assemblies-out", "half-aligned-out"})
     if (a.has(o) && !a.get(o).empty() && a.get(o) != "-" && exists(a.get(o))) {
       if (!a.has("force")) die("Refusing to overwrite '" + a.get(o) + "'. Use -f to override.");
       unlink(a.get(o).c_str());

@@ -1058,6 +1058,13 @@ __global__ void k_rms_gather_claim_word(const uint64_t* __restrict__ claims, con
   if (i < n) out[i] = claims[uint64_t(idx[i]) * kClaimWords + word];
 }
 
+// whole claims (kClaimWords words each) picked by index: one lane per word, a claim's words land side by side
+__global__ void k_rms_gather_claims(const uint64_t* __restrict__ claims, const uint32_t* __restrict__ idx, uint64_t n,
+                                    uint64_t* __restrict__ out) {
+  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t < n * kClaimWords) out[t] = claims[uint64_t(idx[t / kClaimWords]) * kClaimWords + t % kClaimWords];
+}
+
 // Claimers sorted by (group, read id of their loop's start): the k-th of a group takes the group's k-th row.  Answers
 // with the row's read id, finishes what ends here and writes the next hop's claim (word 3 = ~0: none).
 __global__ void k_rms_apply_claims(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, uint64_t n_rows,
@@ -1293,12 +1300,9 @@ extern "C" int bg_readmap_shard_apply_claims(bg_ctx* ctx, bg_readmap_shard* s, u
   uint64_t m = 0;
   BG_TRY(compact_flagged<uint32_t>(ctx, has_next.p, n, &pick, &m));
   if (m) {
-    // claims are kClaimWords-word rows: gather the picked ones
-    for (int w = 0; w < kClaimWords; ++w) {
-      k_rms_gather_claim_word<<<cdiv(m, 256), 256, 0, ctx->stream>>>(next.p, pick.p, m, w, ka.p);
-      BG_LAUNCH_CHECK();
-      BG_HIP(hipMemcpy2DAsync(d_next + w, kClaimWords * 8, ka.p, 8, 8, m, hipMemcpyDeviceToDevice, ctx->stream));
-    }
+    // claims are kClaimWords-word rows: the picked ones, whole, straight to where they go
+    k_rms_gather_claims<<<cdiv(m * kClaimWords, 256), 256, 0, ctx->stream>>>(next.p, pick.p, m, d_next);
+    BG_LAUNCH_CHECK();
   }
   BG_HIP(hipStreamSynchronize(ctx->stream));
   *n_next = m;

@@ -1540,6 +1540,14 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
     std::vector<bg_trace_assembly_rec> dropped;
     try {
       AnchorDropper ad(AlignParams::from(w.o), sc, [&](bg_trace_assembly_rec&& a) { dropped.push_back(std::move(a)); });
+      // report_half_aligned_func through reversable_tracer.cpp:20-27 (reverse_half_aligned, assemble.cpp:1002-1013)
+      ad.report_half_aligned = [&](int64_t offset, const std::string& seq, uint64_t id) {
+        bg_half_aligned_rec h;
+        h.assembly_id = id;
+        if (rev_comp) { h.offset = end_pos - offset; h.right_anchor = true; h.seq = rev_comp_str(seq); }
+        else { h.offset = offset; h.right_anchor = false; h.seq = seq; }
+        res->half_aligned.push_back(std::move(h));
+      };
       for (auto& a : raw) ad.add(std::move(a));
       ad.flush();
     } catch (const CheckFailed& f) {

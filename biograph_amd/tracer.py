@@ -318,8 +318,11 @@ class PushTracer:
         opt = options if options is not None else TraceOptions()
         capi.check(capi.lib().bg_tracer_open(self.ctx.h, seqset.h, readmap.h, C.c_void_p(ref_map.ptr), C.byref(opt), C.byref(self.h)))
 
-    def trace(self, extents, start=0, limit=None, end_pos=None, rev_comp=False, pair_count=True, with_stats=False):
-        """extents = [(offset, ACGT string)] of one scaffold, ascending.  -> [TraceAssembly] in output order (+ stats)."""
+    def trace(self, extents, start=0, limit=None, end_pos=None, rev_comp=False, pair_count=True, with_stats=False,
+              half_aligned=None):
+        """extents = [(offset, ACGT string)] of one scaffold, ascending.  -> [TraceAssembly] in output order (+ stats).
+        half_aligned: a list that receives (offset, right_anchor, sequence, assembly_id) of what the anchor_dropper could not
+        anchor on the right (bg_trace_result_half_aligned; assemble_options::report_half_aligned_func)."""
         L = capi.lib()
         n = len(extents)
         offs = (C.c_int64 * max(n, 1))(*[int(o) for o, _ in extents])
@@ -334,6 +337,12 @@ class PushTracer:
                                      C.byref(h)))
         try:
             out = _read_result(h)
+            if half_aligned is not None:
+                for i in range(L.bg_trace_result_half_aligned_count(h)):
+                    off, right, ln, aid = C.c_int64(), C.c_int(), C.c_uint64(), C.c_uint64()
+                    sp = C.c_char_p()
+                    capi.check(L.bg_trace_result_half_aligned(h, i, C.byref(off), C.byref(right), C.byref(sp), C.byref(ln), C.byref(aid)))
+                    half_aligned.append((off.value, bool(right.value), C.string_at(sp, ln.value).decode(), aid.value))
             if not with_stats:
                 return out
             st = _Stats()
@@ -392,10 +401,10 @@ class PushTracer:
 
 
 def push_trace(seqset, readmap, ref_map, extents, start=0, limit=None, end_pos=None, rev_comp=False, pair_count=True,
-               options=None, with_stats=False):
+               options=None, with_stats=False, half_aligned=None):
     """One-shot form (bg_push_trace semantics): ref_map = reference_ref_map(...)."""
     t = PushTracer(seqset, readmap, ref_map, options)
     try:
-        return t.trace(extents, start, limit, end_pos, rev_comp, pair_count, with_stats)
+        return t.trace(extents, start, limit, end_pos, rev_comp, pair_count, with_stats, half_aligned)
     finally:
         t.close()

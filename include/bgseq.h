@@ -660,6 +660,13 @@ int bg_walk_chains_batch(bg_ctx* ctx, const bg_seqset* ss, uint32_t n_chains, co
  * h_out[3 i ..] = (begin, end, size) of the last valid range (pop_tracer.cpp:258-266).  HOST buffers. */
 int bg_push_front_chains(bg_ctx* ctx, const bg_seqset* ss, uint32_t n, const uint64_t* h_offsets, const uint8_t* h_codes,
                          uint64_t* h_out);
+/* What the anchor_dropper of a bg_tracer_trace / bg_push_trace call could not anchor on the right (variants::half_aligned_assembly,
+ * assemble.h:449-465; assemble_options::report_half_aligned_func, anchor_drop.cpp:301-329, turned into forward coordinates for a
+ * reverse trace as reversable_tracer.cpp:20-27 does): right_anchor 0 = the sequence starts at `offset` and runs right, 1 = it ends
+ * there.  seq points into r.  `biograph discovery --half-aligned-out` (biograph_variants.cpp:175,695-710) writes these. */
+uint64_t bg_trace_result_half_aligned_count(const bg_trace_result* r);
+int bg_trace_result_half_aligned(const bg_trace_result* r, uint64_t i, int64_t* offset, int* right_anchor, const char** seq,
+                                 uint64_t* seq_len, uint64_t* assembly_id);
 /* aligned_variants of assembly i (variants::aligned_var, assemble.h:124-152): filled by BG_STEP_ALIGN, consumed by
  * BG_STEP_SPLIT.  seq points into r. */
 uint64_t bg_trace_result_var_count(const bg_trace_result* r, uint64_t i);

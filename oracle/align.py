@@ -26,7 +26,8 @@ filtered at use (:131).  The restatement keeps that.
 
 The sorter is std::sort there (order among assemblies that compare equal in canon order is unspecified); here and in
 the product it is a stable sort.  Half-anchored assemblies (one offset absent) do not occur behind the push tracer --
-it reports those through report_half_aligned_func (anchor_drop.cpp:303-339) -- and are not modelled.
+it reports those through report_half_aligned_func (anchor_drop.cpp:301-329): AnchorDropper's `half_aligned` hook, which the
+product's bg_trace_result_half_aligned is compared with (tests/test_gpu_tracer.py); as assemblies they are not modelled.
 
 The ML features (add_ml_features, biograph_variants.cpp:746-779) and the merge counts the dedupers keep are restated
 too (ml_features_of, merge_bookkeeping); no reference test or golden holds them: PARITY UNPINNED for those.

@@ -110,3 +110,31 @@ def test_the_shortcuts_change_nothing(sample):
     for threads in ("1", "3"):
         got, _ = _discover(d, "threads" + threads, extra=["--threads", threads])
         assert got == base, "threads " + threads
+
+
+def test_half_aligned_out(sample):
+    """--half-aligned-out (biograph_variants.cpp:175,695-710): what the anchor_dropper could not anchor on the right, one CSV row each
+    -- scaffold, the anchor's offset in the left_anchor column (forward traces) or the right_anchor column (reverse traces, turned
+    around by reverse_half_aligned), the unanchored bases, the assembly id.  (The rows themselves are pinned against the oracle's
+    anchor_dropper in tests/test_gpu_tracer.py::test_synthetic_equals_oracle.)"""
+    d = sample
+    half = d / "half.csv"
+    base, _ = _discover(d, "default_again")
+    got, _ = _discover(d, "with_half", extra=["--half-aligned-out", str(half)])
+    assert got == base
+    rows = [x.rstrip("\n").split(",") for x in open(half)]
+    assert rows[0] == ["scaffold_name", "left_anchor", "right_anchor", "sequence", "assembly_id"]
+    assert len(rows) > 3
+    text = "".join(l.strip() for l in open(d / "ref.fa") if not l.startswith(">"))
+    left = right = 0
+    for name, la, ra, seq, aid in rows[1:]:
+        assert name == "chrT" and (la == "") != (ra == "") and seq and set(seq) <= set("ACGT") and int(aid) > 0
+        off = int(la or ra)
+        assert 0 <= off <= len(text)
+        left += la != ""
+        right += ra != ""
+    assert left and right  # both directions report
+    # refused when it exists, unless -f
+    r = subprocess.run(EXE + ["discovery", "--in", str(d / "s.bg"), "--ref", str(d / "ref.fa"), "--out", str(d / "other.vcf"),
+                              "--half-aligned-out", str(half)], capture_output=True, text=True)
+    assert r.returncode == 1 and "Refusing to overwrite" in r.stderr

@@ -163,9 +163,25 @@ def test_synthetic_equals_oracle(ctx, seed, G, repeats):
         for rev, drop in ((False, True), (True, True), (False, False), (True, False)):
             o_gpu = tracer.TraceOptions(anchor_drop=int(drop), **kw)
             ad = V.dropper(o_cpu) if drop else None
-            want = T.reversable_trace(g, sc, o_cpu, rev_comp=rev, anchor_drop=ad)
-            got, st = tracer.push_trace(ss, rm, rmap, parts, rev_comp=rev, options=o_gpu, with_stats=True)
+            # what the dropper cannot anchor on the right (report_half_aligned_func), in forward coordinates
+            # (reverse_half_aligned, assemble.cpp:1002-1013)
+            want_half, got_half = [], []
+            ad_half = None
+            if drop:
+                from oracle import align as OA
+                ao = OA.AlignOptions(min_overlap=o_cpu.min_overlap, read_ahead_distance=o_cpu.read_ahead_distance, trace_reference_assemblies=True)
+                comp = str.maketrans("ACGT", "TGCA")
+                end = sc.end_pos
+
+                def report(off, seq, rev=rev):
+                    want_half.append((end - off, True, seq.translate(comp)[::-1]) if rev else (off, False, seq))
+                ad_half = lambda s_, emit: OA.AnchorDropper(ao, s_, emit, half_aligned=report)  # noqa: E731
+            want = T.reversable_trace(g, sc, o_cpu, rev_comp=rev, anchor_drop=ad_half if drop else ad)
+            got, st = tracer.push_trace(ss, rm, rmap, parts, rev_comp=rev, options=o_gpu, with_stats=True, half_aligned=got_half)
             assert [full_key(a) for a in got] == [full_key(a) for a in want]
+            assert [h[:3] for h in got_half] == want_half, (rev, drop)
+            if drop:
+                assert len(want_half) >= 1
             assert len([a for a in got if not a.matches_reference]) > 3 and st["traces"] > G // 10
             assert st["device_rounds"] < 40 * 50  # lock step: rounds follow the longest trace, not the number of traces
             for start in range(0, G, 2000):
