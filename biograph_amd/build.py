@@ -66,7 +66,7 @@ def build(force=False, verbose=False):
     # bgbinary: host-only C++ front end over the C ABI (FASTQ in, .bg directory out)
     cli_src = os.path.join(CSRC, "cli", "bgbinary.cpp")
     if force or _stale(CLI, [cli_src, os.path.join(CSRC, "cli", "fastalloc.h"), os.path.join(CSRC, "cli", "cpuprof.h"), LIB] + hdrs):
-        run(["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI, cli_src, "-L" + HERE, "-lbgseq", "-lz",
+        run(["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI, cli_src, "-L" + HERE, "-lbgseq", "-lz", "-ldl",
              "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")])
     # biograph_amd._capi: the pybind11 module with the reference's Python C-API surface for this path, over the C ABI
     import sysconfig

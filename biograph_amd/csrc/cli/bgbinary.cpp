@@ -12,6 +12,7 @@
 // Host work here is file I/O only (FASTQ parsing with zlib, output directory); every computation is a
 // C-ABI call that runs on the GPU.  The sample's readmap lands in coverage/<sha1>.readmap and is listed
 // under "samples" in metadata/bg_info.json (biograph_create.cpp:812-831, biograph_dir.cpp).
+#include <dlfcn.h>
 #include <errno.h>
 #include <malloc.h>
 #include <fcntl.h>
@@ -1600,6 +1601,14 @@ static int cmd_discovery(int argc, char** argv) {
     // readmap and the contexts back piece by piece before exiting took most of a second of a ten-second command.
     cpuprof::stop_and_write();
     fflush(nullptr);
+    if (getenv("BG_EXIT_PROBE")) {  // how long the device side of leaving takes, apart from the host's pages
+      void* h = dlopen("libamdhip64.so", RTLD_NOLOAD | RTLD_NOW);
+      if (!h) h = dlopen("libamdhip64.so.7", RTLD_NOLOAD | RTLD_NOW);
+      int (*reset)() = h ? reinterpret_cast<int (*)()>(dlsym(h, "hipDeviceReset")) : nullptr;
+      const double t0 = now_s();
+      const int e = reset ? reset() : -1;
+      fprintf(stderr, "discovery: hipDeviceReset -> %d in %.3f s; %.2f s since the process started\n", e, now_s() - t0, since_process_start_s());
+    }
     // (BG_NORMAL_EXIT=1: through the exit handlers -- a profiler preloaded into the process writes its results there)
     if (const char* e = getenv("BG_NORMAL_EXIT")) if (e[0] == '1') exit(rc);
     _exit(rc);

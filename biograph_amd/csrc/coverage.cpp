@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/syscall.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -132,6 +133,12 @@ struct CurKey {  // cur_comparer (path_group.h:111-121): longest context first, 
 
 class Coverage;
 
+static double cov_now() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return double(ts.tv_sec) + double(ts.tv_nsec) * 1e-9;
+}
+
 // One stretch of bases for the heads of one path group, waiting for the device.
 struct WalkRequest {
   std::vector<bg_walk_chain> chains;  // offsets relative to this request's codes / out
@@ -187,28 +194,51 @@ class Batcher {
   uint64_t launches = 0, steps = 0;
 
  private:
+  // The round's chains, bases and replies cross the bus from and to page-locked memory: a copy of pageable memory is staged by
+  // the runtime under a lock that all groups' launchers (and the tracer sessions) share.
+  struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    bool ensure(size_t bytes) {
+      if (bytes <= cap) return true;
+      if (p) (void)hipHostFree(p);
+      p = nullptr;
+      cap = 0;
+      const size_t want = bytes + bytes / 2 + 4096;
+      if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
+      cap = want;
+      return true;
+    }
+  };
+  PinnedBuf pin_chains_, pin_codes_, pin_out_;
   std::string launch(const std::vector<WalkRequest*>& batch) {
-    std::vector<bg_walk_chain> chains;
-    std::vector<uint8_t> codes;
+    size_t n_chains = 0, n_codes = 0, out_words = 0;
+    for (WalkRequest* r : batch) { n_chains += r->chains.size(); n_codes += r->codes.size(); out_words += r->out.size(); }
+    if (!pin_chains_.ensure(n_chains * sizeof(bg_walk_chain) + 8) || !pin_codes_.ensure(n_codes + 8) || !pin_out_.ensure(out_words * 8 + 8))
+      return std::string("coverage: pinned staging buffers refused");
+    bg_walk_chain* chains = static_cast<bg_walk_chain*>(pin_chains_.p);
+    uint8_t* codes = static_cast<uint8_t*>(pin_codes_.p);
+    uint64_t* out = static_cast<uint64_t*>(pin_out_.p);
     std::vector<size_t> out_at;
-    size_t out_words = 0;
+    size_t nc = 0, nb = 0, nw = 0;
     for (WalkRequest* r : batch) {
-      out_at.push_back(out_words);
+      out_at.push_back(nw);
       for (bg_walk_chain c : r->chains) {
-        c.code_offset += codes.size();
-        c.out_offset += out_words;
-        chains.push_back(c);
+        c.code_offset += nb;
+        c.out_offset += nw;
+        chains[nc++] = c;
         steps += c.len;
       }
-      codes.insert(codes.end(), r->codes.begin(), r->codes.end());
-      out_words += r->out.size();
+      if (!r->codes.empty()) memcpy(codes + nb, r->codes.data(), r->codes.size());
+      nb += r->codes.size();
+      nw += r->out.size();
     }
-    std::vector<uint64_t> out(out_words);
-    if (bg_walk_chains_batch(ctx_, ss_, uint32_t(chains.size()), chains.data(), codes.data(), codes.size(), out.data(), out_words) != BG_OK)
+    if (bg_walk_chains_batch(ctx_, ss_, uint32_t(n_chains), chains, codes, n_codes, out, out_words) != BG_OK)
       return std::string("bg_walk_chains_batch: ") + bg_last_error();
     ++launches;
     for (size_t i = 0; i < batch.size(); ++i)
-      std::copy(out.begin() + out_at[i], out.begin() + out_at[i] + batch[i]->out.size(), batch[i]->out.begin());
+      std::copy(out + out_at[i], out + out_at[i] + batch[i]->out.size(), batch[i]->out.begin());
     return std::string();
   }
   bg_ctx* ctx_;
@@ -799,6 +829,7 @@ extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64
     set_error("bg_assemblies_coverage: null argument");
     return BG_EINVAL;
   }
+  const double t_enter = cov_now();
   bg_ctx* ctx = c->ctx;
   const bg_seqset* ss = c->ss;
   bg_coverage_options o;
@@ -826,6 +857,7 @@ extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64
       islands.back().push_back(&a);
       need_to = std::max(need_to, a.right_offset + w.max_read_len);
     }
+    const double t_islands = cov_now();
     std::vector<std::vector<bg_trace_assembly_rec>> done(islands.size());
     // BG_COVERAGE_GROUPS groups (default 4) of up to BG_COVERAGE_WORKERS workers (default 128) each; worker u of all runs
     // islands u, u + all, ...  (chr20-shaped sample, coverage + genotype: 1 x 128 with a condition variable 2.06 s; with the
@@ -876,15 +908,25 @@ extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64
     if (n_groups) batchers[0]->run();
     for (auto& th : pool) th.join();
     if (!first_error.empty()) throw CheckFailed{first_error};
+    const double t_workers = cov_now();
     std::vector<bg_trace_assembly_rec> covered;
     for (auto& d : done)
       for (auto& a : d) covered.push_back(std::move(a));
     std::stable_sort(covered.begin(), covered.end(), bg::canon_assembly_less);
+    const double t_sorted = cov_now();
     std::vector<bg_trace_assembly_rec> passed;
     for (auto& a : covered)
       if (!genotype_filter || genotype(o, a)) passed.push_back(std::move(a));
+    const double t_geno = cov_now();
     if (o.rvg_exclude) rvg_exclude_all(o, std::move(passed), &res->a);  // pipeline.cpp:102-104
     else res->a = std::move(passed);
+    if (getenv("BG_COVERAGE_TIMING")) {
+      uint64_t rounds = 0;
+      for (auto& b : batchers) rounds += b->launches;
+      fprintf(stderr, "bg_coverage_run: %zu islands in %zu groups: scaffold + islands %.3f s, workers %.3f s (%llu rounds), collect + sort %.3f s, "
+                      "genotype %.3f s, rvg_exclude %.3f s\n", islands.size(), n_groups, t_islands - t_enter, t_workers - t_islands,
+              (unsigned long long)rounds, t_sorted - t_workers, t_geno - t_sorted, cov_now() - t_geno);
+    }
     for (auto& b : batchers) {
       res->stats.device_rounds += b->launches;
       res->stats.device_queries += b->steps;

@@ -48,7 +48,7 @@ def main():
                     "voluntary_switches": u1.ru_nvcsw - u0.ru_nvcsw, "involuntary_switches": u1.ru_nivcsw - u0.ru_nivcsw,
                     "max_rss_GB": round(u1.ru_maxrss / 1e6, 2),
                     "rc": r.returncode, "summary": line[-1][:300] if line else r.stderr[-300:],
-                    "notes": [x for x in r.stderr.splitlines() if x.startswith("discovery:")]})
+                    "notes": [x for x in r.stderr.splitlines() if x.startswith("discovery:") or x.startswith("bg_coverage_run")]})
         print(json.dumps(out[-1]), flush=True)
     subprocess.run(["rm", "-rf", tmp])
 
