@@ -24,7 +24,9 @@
 #include <linux/futex.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/syscall.h>
+#include <ucontext.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -144,6 +146,12 @@ struct WalkRequest {
   std::vector<bg_walk_chain> chains;  // offsets relative to this request's codes / out
   std::vector<uint8_t> codes;
   std::vector<uint64_t> out;
+};
+
+// Where an island's state machine hands its stretches of bases in and gets the ranges back (Coverage::run_walks).
+struct WalkWaiter {
+  virtual ~WalkWaiter() {}
+  virtual void walk(const std::vector<WalkRequest*>& reqs) = 0;  // returns when every request's `out` is filled
 };
 
 // The islands of a scaffold advance in lock step, a group of workers at a time: every worker thread runs one island's state
@@ -375,9 +383,9 @@ class PathGroup {
 
 class Coverage {
  public:
-  Coverage(const CovWorld& w, Batcher* batcher)
+  Coverage(const CovWorld& w, WalkWaiter* waiter)
       : world_(w), ss_(w.ss), sc_(*w.sc), o_(w.o), read_len_(w.read_len), is_forward_(w.is_forward),
-        min_read_len_(w.min_read_len), max_read_len_(w.max_read_len), batcher_(batcher) {
+        min_read_len_(w.min_read_len), max_read_len_(w.max_read_len), batcher_(waiter) {
     it_offset_ = sc_.ext.empty() ? sc_.end_pos : sc_.ext[0].offset;
     cur_offset_ = it_offset_;
     init_ref_pg();
@@ -392,7 +400,7 @@ class Coverage {
     for (PathGroup* pg : deferred_) reqs.push_back(pg->request());
     if (now) reqs.push_back(now->request());
     if (reqs.empty()) return;
-    batcher_->submit_and_wait(reqs);
+    batcher_->walk(reqs);
     for (PathGroup* pg : deferred_) {
       pg->finish_sequence();
       pg->flush();
@@ -595,7 +603,7 @@ class Coverage {
   const std::vector<uint8_t>& is_forward_;
   uint32_t min_read_len_ = 0;
   int64_t max_read_len_ = 0;
-  Batcher* batcher_;
+  WalkWaiter* batcher_;
   size_t it_ext_ = 0;
   int64_t it_pos_ = 0, it_offset_ = 0, cur_offset_ = 0, need_coverage_to_ = 0, last_left_ = INT32_MIN;
   bool need_ref_dobj_ = false;
@@ -789,6 +797,53 @@ void rvg_exclude_all(const bg_coverage_options& o, std::vector<bg_trace_assembly
 
 // The readmap columns calc_coverage reads, copied to the host once (a reference has thousands of scaffolds, each its
 // own bg_coverage_run).
+// A worker thread runs several islands at a time, each on a stack of its own (ucontext): an island that needs bases walked
+// parks (WalkWaiter::walk) and the thread goes on with its next island; when all of them are parked or finished the thread
+// hands their stretches to its group's Batcher as ONE participant.  In flight are threads x fibers islands per group while
+// only the threads meet at the round's barrier and are woken after it: with one island per thread (round 3: 128 threads per
+// group) a round cost 1.6 ms of which the kernel was half, and more threads only made the wake-ups slower.
+struct FiberThread {
+  Batcher* batcher = nullptr;
+  ucontext_t sched;
+  std::vector<WalkRequest*> reqs;  // of the islands parked in this round
+  bool failed = false;
+  std::string error;
+};
+struct IslandFiber : WalkWaiter {
+  FiberThread* th = nullptr;
+  ucontext_t uc;
+  void* stack = nullptr;
+  size_t stack_bytes = 0;
+  bool done = false;
+  std::function<void(IslandFiber&)> body;
+  ~IslandFiber() override { if (stack) munmap(stack, stack_bytes); }
+  void walk(const std::vector<WalkRequest*>& reqs) override {
+    th->reqs.insert(th->reqs.end(), reqs.begin(), reqs.end());
+    swapcontext(&uc, &th->sched);  // parked; back here when the thread has the replies
+    if (th->failed) throw CheckFailed{th->error};
+  }
+  static void entry(unsigned lo, unsigned hi) {
+    IslandFiber* f = reinterpret_cast<IslandFiber*>((uint64_t(hi) << 32) | uint64_t(lo));
+    f->body(*f);  // (catches what its islands throw)
+    f->done = true;
+  }  // returning resumes uc_link = the thread's scheduler
+  bool start(FiberThread* t, size_t stack_size) {
+    th = t;
+    const size_t page = size_t(sysconf(_SC_PAGESIZE));
+    stack_bytes = stack_size + page;  // a guard page below the stack
+    stack = mmap(nullptr, stack_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
+    if (stack == MAP_FAILED) { stack = nullptr; return false; }
+    (void)mprotect(stack, page, PROT_NONE);
+    if (getcontext(&uc) != 0) return false;
+    uc.uc_stack.ss_sp = static_cast<char*>(stack) + page;
+    uc.uc_stack.ss_size = stack_size;
+    uc.uc_link = &t->sched;
+    const uint64_t self = reinterpret_cast<uint64_t>(this);
+    makecontext(&uc, reinterpret_cast<void (*)()>(&IslandFiber::entry), 2, unsigned(self & 0xffffffffu), unsigned(self >> 32));
+    return true;
+  }
+};
+
 struct bg_coverage {
   bg_ctx* ctx = nullptr;
   const bg_seqset* ss = nullptr;
@@ -859,14 +914,19 @@ extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64
     }
     const double t_islands = cov_now();
     std::vector<std::vector<bg_trace_assembly_rec>> done(islands.size());
-    // BG_COVERAGE_GROUPS groups (default 4) of up to BG_COVERAGE_WORKERS workers (default 128) each; worker u of all runs
-    // islands u, u + all, ...  (chr20-shaped sample, coverage + genotype: 1 x 128 with a condition variable 2.06 s; with the
-    // futex 1 x 128 1.86 s, 1 x 256 1.72 s, 8 x 64 0.93 s, 16 x 32 1.31 s, 16 x 64 1.16 s, 4 x 128 0.87 s, 8 x 128 0.85 s)
-    size_t max_workers = 128, max_groups = 4;
+    // BG_COVERAGE_GROUPS groups (default 4: contexts, streams, launcher threads) of up to BG_COVERAGE_WORKERS worker threads
+    // (default 16) with up to BG_COVERAGE_FIBERS islands in flight each (default 32); fiber v of all runs islands v, v + all, ...
+    // (chr20-shaped sample, coverage + genotype, one island per thread: 1 x 128 threads with a condition variable 2.06 s; with the
+    // futex 1 x 128 1.86 s, 8 x 64 0.93 s, 16 x 64 1.16 s, 4 x 128 0.87 s, 8 x 128 0.85 s -- 2 700 rounds a second whatever the
+    // grouping: the wake-ups.)
+    size_t max_workers = 16, max_groups = 4, max_fibers = 32;
     if (const char* e = getenv("BG_COVERAGE_WORKERS")) max_workers = size_t(std::max(1, atoi(e)));
     if (const char* e = getenv("BG_COVERAGE_GROUPS")) max_groups = size_t(std::max(1, atoi(e)));
-    const size_t all = std::min<size_t>(islands.size(), max_workers * max_groups);
-    const size_t n_groups = all ? std::min<size_t>(max_groups, (all + max_workers - 1) / max_workers) : 0;
+    if (const char* e = getenv("BG_COVERAGE_FIBERS")) max_fibers = size_t(std::max(1, atoi(e)));
+    const size_t n_threads = std::min<size_t>(islands.size(), max_workers * max_groups);
+    const size_t fibers_per_thread = n_threads ? std::min<size_t>(max_fibers, (islands.size() + n_threads - 1) / n_threads) : 0;
+    const size_t all = n_threads * fibers_per_thread;  // islands in flight
+    const size_t n_groups = n_threads ? std::min<size_t>(max_groups, (n_threads + max_workers - 1) / max_workers) : 0;
     while (c->group_ctx.size() + 1 < n_groups) {
       bg_ctx* g = nullptr;
       if (bg_ctx_create_own_stream(ctx->device, &g) != BG_OK) throw CheckFailed{std::string("a worker group's context: ") + bg_last_error()};
@@ -875,28 +935,62 @@ extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64
     std::vector<std::unique_ptr<Batcher>> batchers;
     std::vector<size_t> first_worker(n_groups + 1, 0);
     for (size_t g = 0; g < n_groups; ++g) {
-      first_worker[g + 1] = all * (g + 1) / n_groups;
+      first_worker[g + 1] = n_threads * (g + 1) / n_groups;
       batchers.emplace_back(new Batcher(g ? c->group_ctx[g - 1] : ctx, ss, int(first_worker[g + 1] - first_worker[g])));
     }
     std::mutex err_mu;
     std::string first_error;
+    auto note_error = [&](const std::string& what) {
+      std::lock_guard<std::mutex> l(err_mu);
+      if (first_error.empty()) first_error = what;
+    };
     std::vector<std::thread> pool;
     for (size_t g = 0; g < n_groups; ++g)
       for (size_t u = first_worker[g]; u < first_worker[g + 1]; ++u)
         pool.emplace_back([&, g, u] {
           Batcher* b = batchers[g].get();
-          try {
-            for (size_t i = u; i < islands.size(); i += all) {
-              Coverage cov(w, b);
-              for (const bg_trace_assembly_rec* a : islands[i]) {
-                bg_trace_assembly_rec copy = *a;
-                cov.add(std::move(copy));
+          FiberThread th;
+          th.batcher = b;
+          std::vector<std::unique_ptr<IslandFiber>> fibers;
+          for (size_t k = 0; k < fibers_per_thread; ++k) {
+            const size_t v = u * fibers_per_thread + k;  // this fiber's first island
+            if (v >= islands.size()) break;
+            fibers.emplace_back(new IslandFiber);
+            IslandFiber& f = *fibers.back();
+            f.body = [&, v](IslandFiber& self) {
+              try {
+                for (size_t i = v; i < islands.size(); i += all) {
+                  Coverage cov(w, &self);
+                  for (const bg_trace_assembly_rec* a : islands[i]) {
+                    bg_trace_assembly_rec copy = *a;
+                    cov.add(std::move(copy));
+                  }
+                  cov.finish(&done[i]);
+                }
+              } catch (const CheckFailed& e) {
+                note_error(e.what);
               }
-              cov.finish(&done[i]);
+            };
+            if (!f.start(&th, size_t(512) << 10)) { note_error("coverage: no memory for an island's stack"); fibers.pop_back(); break; }
+          }
+          // rounds: every island of this thread runs until it parks or ends, then the thread takes part in the group's round
+          for (;;) {
+            th.reqs.clear();
+            bool any = false;
+            for (auto& f : fibers)
+              if (!f->done) {
+                any = true;
+                swapcontext(&th.sched, &f->uc);
+              }
+            if (!any) break;
+            if (th.reqs.empty() || th.failed) continue;  // (the ones that parked before a failure wake up, throw and end)
+            try {
+              b->submit_and_wait(th.reqs);
+            } catch (const CheckFailed& e) {
+              th.failed = true;
+              th.error = e.what;
+              note_error(e.what);
             }
-          } catch (const CheckFailed& f) {
-            std::lock_guard<std::mutex> l(err_mu);
-            if (first_error.empty()) first_error = f.what;
           }
           b->worker_exit();
         });

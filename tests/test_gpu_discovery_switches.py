@@ -1,6 +1,6 @@
 """`bgbinary discovery` writes the same VCF whichever of its engine's shortcuts are on: the never-branching traces on the device
 (k_trace_simple), the unseen reference assemblies as lean records into pair_counter, several pop passes per launch (k_pop_passes),
-the one-sector rank blocks, the coverage step's worker groups, the CLI's allocator, the number of tracer sessions.  Every shortcut
+the one-sector rank blocks, the coverage step's worker groups, threads and islands per thread, the CLI's allocator, the number of tracer sessions.  Every shortcut
 claims "the same results"; the VCF lines of configs[1] against the oracle (tests/test_gpu_config1.py) pin the default, this pins
 the rest to the default -- on a sample with indels and a deletion, so that the pop tracer and the anchor_dropper have work
 (variants/tracer.cpp, pop_tracer.cpp, pair_counter.cpp, calc_coverage.cpp: one engine, several ways of running it)."""
@@ -100,7 +100,9 @@ def test_the_shortcuts_change_nothing(sample):
         "one_pop_pass_per_launch": {"BG_POP_PASSES_AHEAD": "0"},
         "no_rank_blocks": {"BG_WALK_RANK_BLOCKS": "0"},
         "one_coverage_group_of_three": {"BG_COVERAGE_GROUPS": "1", "BG_COVERAGE_WORKERS": "3"},
-        "many_small_coverage_groups": {"BG_COVERAGE_GROUPS": "7", "BG_COVERAGE_WORKERS": "5"},
+        "many_small_coverage_groups": {"BG_COVERAGE_GROUPS": "7", "BG_COVERAGE_WORKERS": "5", "BG_COVERAGE_FIBERS": "3"},
+        "one_island_per_thread": {"BG_COVERAGE_FIBERS": "1", "BG_COVERAGE_WORKERS": "40"},
+        "one_thread_many_islands": {"BG_COVERAGE_GROUPS": "1", "BG_COVERAGE_WORKERS": "1", "BG_COVERAGE_FIBERS": "500"},
         "glibc_malloc": {"BG_FAST_ALLOC": "0"},
         "all_off": {"BG_TRACER_DEVICE_SIMPLE": "0", "BG_TRACER_LEAN_REFS": "0", "BG_POP_PASSES_AHEAD": "0", "BG_FAST_ALLOC_THP": "0"},
     }
