@@ -1284,7 +1284,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   for (auto& rec : recs) vcf += "##contig=<ID=" + rec.first + ",length=" + std::to_string(rec.second.size()) + ">\n";
   vcf += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + sample + "\n";
   uint64_t n_var = 0, n_traced = 0, n_sections = 0, pieces = 0, n_popped = 0;
-  double t_trace = 0, t_pipe = 0, t_cov = 0;
+  double t_trace = 0, t_pipe = 0, t_cov = 0, t_vcf = 0;
   double rss_trace = 0, rss_pipe = 0, rss_cov = 0;
   const double rss_sessions = rss_gb();
   for (auto& rec : recs) {
@@ -1454,6 +1454,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     bg_trace_result_free(sections);
     t_cov += now_s() - t1;
     rss_cov = std::max(rss_cov, rss_gb());
+    t1 = now_s();
     std::vector<char> buf(1 << 16);
     for (uint64_t i = 0; i < bg_trace_result_size(kept); ++i) {
       uint64_t len = 0;
@@ -1469,22 +1470,19 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
       ++n_var;
     }
     bg_trace_result_free(kept);
+    t_vcf += now_s() - t1;
   }
-  bg_coverage_close(cov_session);
-  for (int t = 0; t < n_threads; ++t) {
-    bg_tracer_close(tracers[size_t(t)]);
-    if (t) bg_ctx_destroy(wctx[size_t(t)]);
-  }
-  bg_dev_free(ctx, d_map);
+  // (the sessions, their contexts and the reference map are not closed one by one: the process ends when the outputs are written,
+  // and handing sixteen sessions' pinned buffers, arenas and streams back first took a tenth of a second)
   const double t_write0 = now_s();
   write_file(a.get("out"), vcf);
   if (want_csv) write_file(a.get("assemblies-out"), asm_csv);
   if (want_aligned) write_file(a.get("aligned-assemblies-out"), aligned_csv);
   if (want_half) write_file(a.get("half-aligned-out"), half_csv);
   fprintf(stderr, "%llu variants over %zu scaffold(s) in %llu piece(s) x 2 directions on %d tracer session(s), min overlap %u: %.2f s (refmap %.2f, sessions %.2f, tracing %.2f "
-                  "[%llu assemblies], pipeline %.2f [%llu sections], coverage + genotype %.2f); pop tracer %s [%llu of the assemblies]\n",
+                  "[%llu assemblies], pipeline %.2f [%llu sections], coverage + genotype %.2f, VCF records %.2f); pop tracer %s [%llu of the assemblies]\n",
           (unsigned long long)n_var, recs.size(), (unsigned long long)pieces, n_threads, min_overlap, now_s() - t0, t_refmap, t_open, t_trace,
-          (unsigned long long)n_traced, t_pipe, (unsigned long long)n_sections, t_cov, pop_tracer ? "on" : "off", (unsigned long long)n_popped);
+          (unsigned long long)n_traced, t_pipe, (unsigned long long)n_sections, t_cov, t_vcf, pop_tracer ? "on" : "off", (unsigned long long)n_popped);
   fprintf(stderr, "discovery: outputs written in %.2f s; %.2f s since the process started; resident with the sessions open %.1f GB, after "
                   "tracing %.1f, after the pipeline %.1f, after coverage %.1f, now %.1f\n", now_s() - t_write0,
           since_process_start_s(), rss_sessions, rss_trace, rss_pipe, rss_cov, rss_gb());
