@@ -1227,7 +1227,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   cov.simple_genotype_filter = flag("simple-gt", false) ? 1 : 0;
   cov.rvg_exclude = flag("rvg-exclude", true) ? 1 : 0;
   // trace_ref runs its work items on the process's thread pool (trace_ref.cpp:105-140); here: --threads sessions
-  // (default 16, or the host's cores when fewer: since the traces that never branch run on the device -- nine in ten -- and
+  // (default 16, or the host's cores when fewer: since the traces that never branch run on the device -- all but six in a thousand -- and
   // the search states come out of a thread-caching allocator, tracing the chr20-shaped sample takes 8.6 s on 8 sessions,
   // 5.7 s on 16, 5.9-6.4 s on 24, 7.1 s on 32, 8.7 s on 48: profiles/r04_discovery_sessions_cpu_time.txt; round 3: 12.9 s on
   // 16, 11.3 s on 24), each with its own context (stream + allocator) and scratch, the read-only host tables shared, side

@@ -957,7 +957,7 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
   }
   w.seconds_tables += now_seconds() - t_tables;
   const size_t n_seeds = seeds.size();
-  // ---- 2b. the traces that never branch, whole on the device (walk.hip k_trace_simple): nine in ten follow the reference to the
+  // ---- 2b. the traces that never branch, whole on the device (walk.hip k_trace_simple): all but six in a thousand follow the reference to the
   // next read and rejoin there.  What the kernel hands back as kSimpleHost runs on the state machine below, from its start.
   static const bool simple_off = [] { const char* e = getenv("BG_TRACER_DEVICE_SIMPLE"); return e && e[0] == '0'; }();
   const bool simple = !simple_off && w.dev_tables && w.d_ref_map && n_seeds && o.max_pairs_per_read <= uint64_t(kSimpleIds) && o.max_rejoins >= 1 &&
@@ -999,6 +999,13 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
   std::vector<uint32_t> host_seed;
   for (size_t i = 0; i < n_seeds; ++i)
     if (!simple || simple_out[i].status == kSimpleHost) host_seed.push_back(uint32_t(i));
+  if (simple && getenv("BG_TRACER_TIMING")) {
+    size_t why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < n_seeds; ++i)
+      if (simple_out[i].status == kSimpleHost) ++why[(simple_out[i].counters >> 20) & 7];
+    fprintf(stderr, "trace_chunk: %zu of %zu traces to the host: a branch %zu, more than %d steps %zu, more than %d read ids %zu, the read lies nowhere ahead %zu, "
+                    "ambiguous rejoin %zu\n", host_seed.size(), n_seeds, why[1], kSimpleSteps, why[2], kSimpleIds, why[3], why[4], why[5]);
+  }
   std::vector<std::unique_ptr<Trace>> traces(host_seed.size());
   {
     const double t_mk = now_seconds();

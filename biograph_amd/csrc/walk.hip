@@ -660,7 +660,7 @@ __global__ __launch_bounds__(64) void k_trace_simple(SeqsetView v, const uint64_
     // no push at all from path 0: ++ambiguous_steps, nothing to branch into, no dead-end rejoin for a path without a
     // predecessor (:726-735): the trace ends without an assembly.  Anything else is the host's.
     out->status = (dead && n_steps < uint32_t(kSimpleSteps)) ? kSimpleNothing : kSimpleHost;
-    out->counters = counters;
+    out->counters = counters | (dead ? 0u : (n_steps >= uint32_t(kSimpleSteps) ? (2u << 20) : (1u << 20)));  // why the host: a branch / too long
     return;
   }
   // ---- add_pairs (:737-845) at the read the walk landed on
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(64) void k_trace_simple(SeqsetView v, const uint64_
   }
   out->found_pairs = found_pairs;
   out->n_ids = added_reads;
-  if (added_reads > uint32_t(kSimpleIds)) { out->status = kSimpleHost; out->counters = counters; return; }
+  if (added_reads > uint32_t(kSimpleIds)) { out->status = kSimpleHost; out->counters = counters | (3u << 20); return; }
   if (uint64_t(pushed_since_pair) > o.max_bases_between_pairs) { out->status = kSimpleNothing; out->counters = counters | kSimTooFarWithoutPair; return; }
   // ---- add_rejoins (:675-724): the nearest place after cur_offset where this read lies on the scaffold
   int64_t best_distance = -1;
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(64) void k_trace_simple(SeqsetView v, const uint64_
   }
   if (best_distance < 0 || (ambiguous_bases && best_distance > int64_t(ambiguous_bases))) {
     out->status = kSimpleHost;  // the walk goes on from this read: the host's
-    out->counters = counters;
+    out->counters = counters | ((best_distance < 0 ? 4u : 5u) << 20);  // why: the read lies nowhere ahead / ambiguous rejoin
     return;
   }
   const int64_t rejoin_cost = o.rejoin_local_cost + best_distance * o.size_change_cost - o.traverse_ref_cost;
