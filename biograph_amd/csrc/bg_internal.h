@@ -288,6 +288,8 @@ bg_ctx::DeviceArena* shared_arena(int device);  // null unless the hook is insta
 // at the first pass that leaves it less than min_pop_overlap bases (that record is the last one written).
 constexpr uint32_t kPopPassMaxIds = 32;
 struct PopPassRec { uint64_t b, e; uint32_t s, n_ids, ids_at, pad; };
+int tracer_extend_launch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n, const bg_trace_query* d_queries,
+                         uint32_t step_cap, bg_trace_reply* d_replies, uint32_t* d_steps);
 // h_*: host arrays; pin_in / pin_out: page-locked staging of at least pop_passes_in_bytes / _out_bytes.
 size_t pop_passes_in_bytes(uint64_t n);
 size_t pop_passes_out_bytes(uint64_t n, uint32_t passes, uint32_t cap);

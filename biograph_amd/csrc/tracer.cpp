@@ -1043,26 +1043,25 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
       for (size_t i = 0; i < n; ++i)
         if (pending[i]) { live.push_back(traces[w0 + i].get()); q.push_back(qs[i]); }
     }
-    DevBuf<uint8_t> dq, dr;
-    DevBuf<uint32_t> ds;
-    // device buffers of the first (largest) round serve every later one
+    DevBuf<uint8_t> dq, drs;
+    // device buffers of the first (largest) round serve every later one; a round's replies and step lists lie side by side
+    // (one download), behind one launch that is not waited for on its own
+    const size_t reply_bytes_max = (live.size() * sizeof(bg_trace_reply) + 7) & ~size_t(7);
     BG_TRY(dq.alloc(ctx, live.size() * sizeof(bg_trace_query)));
-    BG_TRY(dr.alloc(ctx, live.size() * sizeof(bg_trace_reply)));
-    BG_TRY(ds.alloc(ctx, live.size() * step_cap));
+    BG_TRY(drs.alloc(ctx, reply_bytes_max + live.size() * step_cap * 4));
     while (!live.empty()) {
       const size_t n = live.size();
       const double t_dev = now_seconds();
+      const size_t reply_bytes = (n * sizeof(bg_trace_reply) + 7) & ~size_t(7);
       BG_TRY(w.pin_q.ensure(n * sizeof(bg_trace_query)));
-      BG_TRY(w.pin_r.ensure(n * sizeof(bg_trace_reply)));
-      BG_TRY(w.pin_s.ensure(n * step_cap * 4));
+      BG_TRY(w.pin_r.ensure(reply_bytes + n * step_cap * 4));
       memcpy(w.pin_q.p, q.data(), n * sizeof(bg_trace_query));
       BG_HIP(hipMemcpyAsync(dq.p, w.pin_q.p, n * sizeof(bg_trace_query), hipMemcpyHostToDevice, ctx->stream));
-      BG_TRY(bg_tracer_extend_batch(ctx, w.ss, w.rm, n, reinterpret_cast<const bg_trace_query*>(dq.p), step_cap,
-                                    reinterpret_cast<bg_trace_reply*>(dr.p), ds.p));
+      BG_TRY(tracer_extend_launch(ctx, w.ss, w.rm, n, reinterpret_cast<const bg_trace_query*>(dq.p), step_cap,
+                                  reinterpret_cast<bg_trace_reply*>(drs.p), reinterpret_cast<uint32_t*>(drs.p + reply_bytes)));
       const bg_trace_reply* replies = static_cast<const bg_trace_reply*>(w.pin_r.p);
-      const uint32_t* steps = static_cast<const uint32_t*>(w.pin_s.p);
-      BG_HIP(hipMemcpyAsync(w.pin_r.p, dr.p, n * sizeof(bg_trace_reply), hipMemcpyDeviceToHost, ctx->stream));
-      BG_HIP(hipMemcpyAsync(w.pin_s.p, ds.p, n * step_cap * 4, hipMemcpyDeviceToHost, ctx->stream));
+      const uint32_t* steps = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(w.pin_r.p) + reply_bytes);
+      BG_HIP(hipMemcpyAsync(w.pin_r.p, drs.p, reply_bytes + n * step_cap * 4, hipMemcpyDeviceToHost, ctx->stream));
       BG_HIP(hipStreamSynchronize(ctx->stream));
       w.seconds_device += now_seconds() - t_dev;
       ++w.stats.device_rounds;

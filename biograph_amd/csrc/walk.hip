@@ -918,6 +918,17 @@ extern "C" int bg_tracer_extend_batch(bg_ctx* ctx, const bg_seqset* ss, const bg
   return BG_OK;
 }
 
+namespace bg {
+// the launch alone, for the tracer's lock-step loop (csrc/tracer.cpp): the caller queues its download behind it and waits once
+int tracer_extend_launch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t n, const bg_trace_query* d_queries,
+                         uint32_t step_cap, bg_trace_reply* d_replies, uint32_t* d_steps) {
+  if (!n) return BG_OK;
+  k_tracer_extend<<<cdiv(n * 4, 64), 64, 0, ctx->stream>>>(make_view(ss), rm->s2m_bits.p, n, d_queries, step_cap, d_replies, d_steps);
+  BG_LAUNCH_CHECK();
+  return BG_OK;
+}
+}  // namespace bg
+
 // Chains of push_front_drop(complement, 0): chain i starts at (begin, end, size), follows len bases (2-bit codes at
 // h_codes + code_offset) and writes the range after base t as three u64 at h_out + out_offset + t * out_stride.  All
 // buffers are the HOST's: the callers are host state machines that need the answer before their next step; one call =
