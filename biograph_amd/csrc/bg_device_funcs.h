@@ -732,6 +732,10 @@ struct SeqsetView {
   // through a block it touches one.  Same numbers (seqset_finalize_device builds the blocks from the finalized bitcount);
   // null where a view is built without them.
   const uint64_t* rank64[4] = {nullptr, nullptr, nullptr, nullptr};
+  // sel256[b][j] = the entry that holds the (256 j)-th set bit of base b's prev bits, one more slot = n: seqset_range::pop_front
+  // is a select (which entry does push_front(b) map onto `begin`?), and a binary search over all n entries is 28 dependent
+  // rank look-ups; between two samples lie about a thousand entries = three rank blocks.  Null: the search over everything.
+  const uint64_t* sel256[4] = {nullptr, nullptr, nullptr, nullptr};
 
   BG_HD uint64_t count(int b, uint64_t i) const {  // bitcount.h:218-270
     if (rank64[b]) {

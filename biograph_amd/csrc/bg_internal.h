@@ -213,6 +213,7 @@ struct bg_seqset {
   bg::DevBuf<uint8_t> sizes, shared;
   bg::DevBuf<uint64_t> bits[4], subaccum[4], accum[4];
   bg::DevBuf<uint64_t> rank64[4];   // one 64-byte rank block per 384 entries (SeqsetView::count): what the walk kernels read
+  bg::DevBuf<uint64_t> sel256[4];   // the entry that carries every 256th set prev bit of a base (pop_front's select), + a sentinel n
   bg::DevBuf<uint8_t> min1, min2;
   uint64_t fixed[5] = {0, 0, 0, 0, 0};
   std::string uuid;

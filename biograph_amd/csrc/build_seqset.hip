@@ -1392,6 +1392,34 @@ __global__ void k_rank64_build(const uint64_t* __restrict__ bits, const uint64_t
   for (int k = 0; k < 6; ++k) o[2 + k] = w[k];
 }
 
+// sel256 of SeqsetView from the rank blocks: block g holds the set bits number [before, before + ones) of its base; for every
+// multiple of 256 among them, the entry that carries it
+__global__ void k_sel256_build(const uint64_t* __restrict__ rank64, uint64_t nblocks, uint64_t n, uint64_t n_slots, uint64_t* __restrict__ out) {
+  const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= nblocks) return;
+  const uint64_t* blk = rank64 + g * 8;
+  const uint64_t before = blk[0];
+  unsigned cum[7];
+  cum[0] = 0;
+  for (int k = 0; k < 5; ++k) cum[k + 1] = unsigned((blk[1] >> (9 * k)) & 0x1ff);
+  cum[6] = cum[5] + unsigned(__popcll(blk[7]));
+  const uint64_t ones = cum[6];
+  for (uint64_t m = (before + 255) & ~uint64_t(255); m < before + ones; m += 256) {
+    unsigned need = unsigned(m - before);  // the need-th set bit of the block (0-based)
+    int w = 0;
+    while (w < 5 && cum[w + 1] <= need) ++w;
+    need -= cum[w];
+    uint64_t x = blk[2 + w];
+    for (unsigned k = 0; k < need; ++k) x &= x - 1;
+    const uint64_t pos = g * 384 + uint64_t(w) * 64 + uint64_t(__ffsll((long long)x) - 1);
+    if (m / 256 < n_slots && pos < n) out[m / 256] = pos;
+  }
+}
+__global__ void k_fill_u64(uint64_t* __restrict__ p, uint64_t n, uint64_t v) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss, bool slice) {
   const uint64_t n = ss->n;
   const uint64_t nwords = (n + 63) / 64, ngroups = (n + 511) / 512, naccum = (n + 1 + 511) / 512;
@@ -1433,6 +1461,18 @@ int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss, bool slice) {
     }
   }
   BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (!slice) {  // (the totals are on the host now: one slot per 256 set bits, one more for the sentinel)
+    const uint64_t nblocks = n / 384 + 1;
+    for (int b = 0; b < 4; ++b) {
+      const uint64_t n_slots = h_total[b] / 256 + 2;
+      BG_TRY(ss->sel256[b].alloc(ctx, n_slots));
+      k_fill_u64<<<cdiv(n_slots, 256), 256, 0, ctx->stream>>>(ss->sel256[b].p, n_slots, n);
+      BG_LAUNCH_CHECK();
+      k_sel256_build<<<cdiv(nblocks, 256), 256, 0, ctx->stream>>>(ss->rank64[b].p, nblocks, n, n_slots, ss->sel256[b].p);
+      BG_LAUNCH_CHECK();
+    }
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
   uint64_t off = 0;
   for (int b = 0; b < 4; ++b) { ss->fixed[b] = off; off += h_total[b]; }  // seqset.cpp:113-129
   ss->fixed[4] = off;

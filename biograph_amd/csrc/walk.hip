@@ -30,6 +30,8 @@ static SeqsetView make_view(const bg_seqset* ss) {
   v.walk_counters = g_walk_counters;
   static const bool no_blocks = [] { const char* e = getenv("BG_WALK_RANK_BLOCKS"); return e && e[0] == '0'; }();
   for (int b = 0; b < 4; ++b) v.rank64[b] = no_blocks ? nullptr : ss->rank64[b].p;
+  static const bool no_select = [] { const char* e = getenv("BG_WALK_SELECT"); return e && e[0] == '0'; }();
+  for (int b = 0; b < 4; ++b) v.sel256[b] = (no_blocks || no_select) ? nullptr : ss->sel256[b].p;
   return v;
 }
 
@@ -73,7 +75,37 @@ __device__ __forceinline__ void pop_front_range(const SeqsetView& v, uint64_t b0
   int b = 0;
   while (b < 3 && b0 >= v.fixed[b + 1]) ++b;
   const uint64_t rank = b0 - v.fixed[b];
-  uint64_t lo = 0, hi = v.n;  // smallest t with count(b, t + 1) > rank
+  uint64_t lo = 0, hi = v.n;  // smallest t with count(b, t + 1) > rank = the entry that carries the rank-th set bit
+  if (v.sel256[b] && v.rank64[b]) {
+    // between two samples: the last rank block that starts at or before the bit, then the bit inside it
+    const uint64_t j = rank >> 8;
+    uint64_t g_lo = v.sel256[b][j] / 384, g_hi = v.sel256[b][j + 1] / 384;
+    const uint64_t last_block = v.n / 384;
+    if (g_hi > last_block) g_hi = last_block;
+    while (g_lo < g_hi) {  // largest g with before(g) <= rank
+      const uint64_t mid = (g_lo + g_hi + 1) >> 1;
+      if (v.rank64[b][mid * 8] <= rank) g_lo = mid; else g_hi = mid - 1;
+    }
+    const uint64_t* blk = v.rank64[b] + g_lo * 8;
+    unsigned need = unsigned(rank - blk[0]);
+    int w = 0;
+    unsigned before_w = 0;
+    for (; w < 5; ++w) {
+      const unsigned upto = unsigned((blk[1] >> (9 * w)) & 0x1ff);  // set bits of the block before word w + 1
+      if (upto > need) break;
+      before_w = upto;
+    }
+    need -= before_w;
+    uint64_t x = blk[2 + w];
+    unsigned pos = 0;
+    for (unsigned width = 32; width; width >>= 1) {  // the need-th set bit of x
+      const uint64_t low = x & ((1ull << width) - 1);
+      const unsigned c = unsigned(__popcll(low));
+      if (need >= c) { need -= c; x >>= width; pos += width; } else x = low;
+    }
+    lo = g_lo * 384 + uint64_t(w) * 64 + pos;
+    hi = lo;
+  }
   while (lo < hi) {
     const uint64_t mid = (lo + hi) >> 1;
     if (v.count(b, mid + 1) > rank) hi = mid; else lo = mid + 1;
