@@ -1956,9 +1956,11 @@ struct PopTracer {
         chains.push_back(ch);
       }
     }
-    std::vector<uint64_t> strip(words ? words : 1, 0);
+    // (the ranges come back into page-locked memory: 30-40 MB per piece, a third of it the chains' warm-up rows)
+    BG_TRY(w.pin_s.ensure((words ? words : 1) * 8));
+    uint64_t* strip = static_cast<uint64_t*>(w.pin_s.p);
     if (!chains.empty()) {
-      BG_TRY(bg_walk_chains_batch(ctx, w.ss, uint32_t(chains.size()), chains.data(), codes.data(), codes.size(), strip.data(), words));
+      BG_TRY(bg_walk_chains_batch(ctx, w.ss, uint32_t(chains.size()), chains.data(), codes.data(), codes.size(), strip, words));
       ++device_rounds;
       device_queries += codes.size();
     }
