@@ -2104,7 +2104,36 @@ struct PopTracer {
   double ref_t[6] = {0, 0, 0, 0, 0, 0};  // walk, replay, kept ranges, prefix reads, entries and items, materialize
 
   void sort_fronts() {  // std::multimap<seqset_range, ..., seqset_range_comparer>: (begin, size), equal keys in insertion order
-    std::stable_sort(fronts.begin(), fronts.end(), [](const Front& a, const Front& b) { return a.b != b.b ? a.b < b.b : a.s < b.s; });
+    // A stable LSD radix sort of (begin, size) keys (350 000 fronts per piece: std::stable_sort's merges of 32-byte structs were a
+    // tenth of the pop tracer's time): 16-bit digits over as many bits as the largest key has, then one permutation.
+    const size_t n = fronts.size();
+    bool fits = n < (size_t(1) << 32);
+    uint64_t top = 0;
+    for (const Front& f : fronts) { fits = fits && f.s < 256 && f.b < (uint64_t(1) << 56); top |= (f.b << 8) | f.s; }
+    if (!fits || n < 2048) {
+      std::stable_sort(fronts.begin(), fronts.end(), [](const Front& a, const Front& b) { return a.b != b.b ? a.b < b.b : a.s < b.s; });
+      return;
+    }
+    std::vector<uint64_t> key(n), key2(n);
+    std::vector<uint32_t> idx(n), idx2(n);
+    for (size_t i = 0; i < n; ++i) { key[i] = (fronts[i].b << 8) | fronts[i].s; idx[i] = uint32_t(i); }
+    std::vector<uint32_t> count(size_t(1) << 16);
+    for (int shift = 0; shift < 64 && (top >> shift); shift += 16) {
+      std::fill(count.begin(), count.end(), 0u);
+      for (size_t i = 0; i < n; ++i) ++count[(key[i] >> shift) & 0xffff];
+      uint32_t run = 0;
+      for (auto& c : count) { const uint32_t k = c; c = run; run += k; }
+      for (size_t i = 0; i < n; ++i) {
+        const uint32_t at = count[(key[i] >> shift) & 0xffff]++;
+        key2[at] = key[i];
+        idx2[at] = idx[i];
+      }
+      key.swap(key2);
+      idx.swap(idx2);
+    }
+    std::vector<Front> sorted(n);
+    for (size_t i = 0; i < n; ++i) sorted[i] = fronts[idx[i]];
+    fronts.swap(sorted);
   }
 
   // ---- assemble (:292-311)
