@@ -13,4 +13,8 @@ for line in open(sys.argv[1]):
         if m:
             for k, v in zip(["pop_drops", "pop_reference", "pop_assemble"], m.groups()):
                 tot[k] = tot.get(k, 0) + float(v)
+        m = re.search(r"reference: walk ([\d.]+) replay ([\d.]+) kept ([\d.]+) prefix reads ([\d.]+) items ([\d.]+) materialize ([\d.]+)", line)
+        if m:
+            for k, v in zip(["ref_walk", "ref_replay", "ref_kept", "ref_prefix_reads", "ref_items", "ref_materialize"], m.groups()):
+                tot[k] = tot.get(k, 0) + float(v)
 print(n, "push calls;", {k: round(v, 2) for k, v in tot.items()})
