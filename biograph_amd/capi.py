@@ -77,7 +77,7 @@ SYMBOLS = [
     "bg_seqset_from_arrays", "bg_seqset_free", "bg_walk_counters", "bg_ref_map_write", "bg_ref_map_read", "bg_push_front_batch", "bg_push_front_drop_batch", "bg_pop_front_batch", "bg_find_batch",
     "bg_dev_alloc", "bg_dev_free", "bg_dev_upload", "bg_dev_download",
     "bg_trace_one_base_batch", "bg_ref_walk_entries", "bg_tracer_extend_batch", "bg_trace_options_default",
-    "bg_push_trace", "bg_pop_trace", "bg_trace_result_anchor_drops", "bg_push_front_chains", "bg_sha1_file", "bg_tracer_open", "bg_tracer_clone", "bg_tracer_trace", "bg_tracer_close", "bg_reference_build", "bg_bwt_build", "bg_trace_result_size", "bg_trace_result_get", "bg_trace_result_stats", "bg_trace_result_free", "bg_assemblies_process", "bg_trace_result_new", "bg_trace_result_add", "bg_trace_result_var_count", "bg_trace_result_var", "bg_trace_result_half_aligned_count", "bg_trace_result_half_aligned", "bg_coverage_options_default", "bg_assemblies_coverage", "bg_coverage_open", "bg_coverage_run", "bg_coverage_close", "bg_trace_result_coverage", "bg_trace_result_set_coverage", "bg_assemblies_rvg_exclude", "bg_vcf_record", "bg_walk_chains", "bg_walk_chains_batch", "bg_trace_result_ml", "bg_trace_result_set_ml", "bg_branch_trace_batch", "bg_ref_map_build",
+    "bg_push_trace", "bg_pop_trace", "bg_trace_result_anchor_drops", "bg_push_front_chains", "bg_sha1_file", "bg_tracer_open", "bg_tracer_clone", "bg_tracer_trace", "bg_tracer_trace_async", "bg_trace_result_wait", "bg_tracer_close", "bg_reference_build", "bg_bwt_build", "bg_trace_result_size", "bg_trace_result_get", "bg_trace_result_stats", "bg_trace_result_free", "bg_assemblies_process", "bg_trace_result_new", "bg_trace_result_add", "bg_trace_result_var_count", "bg_trace_result_var", "bg_trace_result_half_aligned_count", "bg_trace_result_half_aligned", "bg_coverage_options_default", "bg_assemblies_coverage", "bg_coverage_open", "bg_coverage_run", "bg_coverage_close", "bg_trace_result_coverage", "bg_trace_result_set_coverage", "bg_assemblies_rvg_exclude", "bg_vcf_record", "bg_walk_chains", "bg_walk_chains_batch", "bg_trace_result_ml", "bg_trace_result_set_ml", "bg_branch_trace_batch", "bg_ref_map_build",
     "bg_readmap_build", "bg_readmap_build_marked", "bg_seqset_mark_inputs", "bg_readmap_size", "bg_readmap_max_read_len", "bg_readmap_part", "bg_readmap_write",
     "bg_readmap_free", "bg_create_sample", "bg_readmap_open", "bg_readmap_from_arrays", "bg_readmap_arrays",
     "bg_cover_filter_build", "bg_cover_query_scan", "bg_cover_query_scan_answers", "bg_cover_query_records_split", "bg_cover_query_records_live",
@@ -191,6 +191,8 @@ def lib():
     L.bg_tracer_clone.argtypes = [vp, vp, P(vp)]
     L.bg_ctx_create_own_stream.argtypes = [i32, P(vp)]
     L.bg_tracer_trace.argtypes = [vp, u64, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, i32, i32, P(vp)]
+    L.bg_tracer_trace_async.argtypes = [vp, u64, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, i32, i32, P(vp)]
+    L.bg_trace_result_wait.argtypes = [vp]
     L.bg_pop_trace.argtypes = [vp, u64, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, i32, vp, u32, P(vp)]
     L.bg_trace_result_anchor_drops.argtypes = [vp]
     L.bg_trace_result_anchor_drops.restype = u64

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <functional>
+#include <future>
 #include <set>
 #include <string>
 #include <unordered_map>
@@ -70,6 +71,11 @@ struct bg_trace_result {
   bg_trace_stats stats;
   std::vector<bg_anchor_drop_rec> anchor_drops;  // bg_tracer_trace -> bg_pop_trace
   std::vector<bg_half_aligned_rec> half_aligned;  // what the anchor_dropper could not anchor on the right (report_half_aligned_func)
+  // bg_tracer_trace_async: the host steps behind the tracer (anchor_dropper, pair_counter) still running on the session's helper
+  // thread fill `a` and `half_aligned`; bg_trace_result_wait takes their verdict.  Invalid for every other result.
+  std::future<int> pending;
+  std::string pending_error;
+  ~bg_trace_result() { if (pending.valid()) pending.wait(); }
 };
 
 namespace bg {

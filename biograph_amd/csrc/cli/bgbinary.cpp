@@ -1329,8 +1329,10 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
         for (;;) {
           const size_t i = next.fetch_add(1);
           if (i >= work.size()) return;
-          if (bg_tracer_trace(tracers[size_t(t)], es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), work[i].start,
-                              work[i].limit, work[i].rev, 1, &items[i]) != BG_OK) {
+          // (the anchor_dropper and the pair_counter of this item run on the session's helper thread while the session traces its next)
+          static const bool sync_only = [] { const char* e = getenv("BG_TRACER_ASYNC"); return e && e[0] == '0'; }();
+          if ((sync_only ? bg_tracer_trace : bg_tracer_trace_async)(tracers[size_t(t)], es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()),
+                                                                    work[i].start, work[i].limit, work[i].rev, 1, &items[i]) != BG_OK) {
             std::lock_guard<std::mutex> l(err_mu);
             if (err.empty()) err = bg_last_error();
             next.store(work.size());
@@ -1344,6 +1346,8 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
       run(0);
       for (auto& th : pool) th.join();
       if (!err.empty()) die("bg_tracer_trace: " + err);
+      for (auto* r : items)
+        if (r) check(bg_trace_result_wait(r), "bg_tracer_trace");
       // the pop tracers of every piece (trace_ref.cpp:186-207): forward and reverse, over the anchor drops both push
       // directions of the piece reported
       if (pop_tracer) {

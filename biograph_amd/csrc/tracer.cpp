@@ -32,6 +32,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <future>
 #include <mutex>
 #include <queue>
 #include <map>
@@ -1395,11 +1396,48 @@ int session_extents(std::shared_ptr<ExtSet>* mine, const char* who, uint64_t n_e
   return BG_OK;
 }
 
+// The session's helper thread: runs the host steps behind the tracer of work item i (bg_tracer_trace_async) while the session's
+// own thread is in the tracer of item i + 1.  Jobs run in the order they were handed in.
+struct Helper {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::packaged_task<int()>> jobs;
+  bool stop = false;
+  std::future<int> run(std::packaged_task<int()> job) {
+    std::future<int> f = job.get_future();
+    std::lock_guard<std::mutex> l(mu);
+    if (!th.joinable())
+      th = std::thread([this] {
+        for (;;) {
+          std::packaged_task<int()> j;
+          {
+            std::unique_lock<std::mutex> l2(mu);
+            cv.wait(l2, [&] { return stop || !jobs.empty(); });
+            if (jobs.empty()) return;
+            j = std::move(jobs.front());
+            jobs.pop_front();
+          }
+          j();
+        }
+      });
+    jobs.push_back(std::move(job));
+    cv.notify_one();
+    return f;
+  }
+  ~Helper() {
+    { std::lock_guard<std::mutex> l(mu); stop = true; }
+    cv.notify_all();
+    if (th.joinable()) th.join();  // (after the jobs that are still queued)
+  }
+};
+
 struct bg_tracer {
   World w;
   int pool = g_next_pool.fetch_add(1);  // which of the host pools this session's big rounds use
   // the scaffold of the last work item (see bg_tracer_trace)
   std::shared_ptr<ExtSet> exts;
+  Helper helper;  // (destroyed first: its jobs read w)
 };
 
 // The host copies a tracer needs of the seqset, the readmap and the ref_map are made once per session
@@ -1492,9 +1530,9 @@ extern "C" int bg_tracer_clone(const bg_tracer* from, bg_ctx* ctx, bg_tracer** o
 
 extern "C" void bg_tracer_close(bg_tracer* t) { delete t; }
 
-extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
-                               const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset,
-                               int rev_comp, int pair_count, bg_trace_result** out) {
+static int tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                        const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset,
+                        int rev_comp, int pair_count, bool async, bg_trace_result** out) {
   if (t) tl_pool = t->pool;
   if (!t || !out || (n_extents && (!ext_offset || !ext_seq || !ext_len))) return fail("bg_tracer_trace: null argument");
   World& w = t->w;
@@ -1523,7 +1561,6 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
   } else {
     BG_TRY(trace_chunk(w, ext, start_offset, limit_offset, &raw, lean));
   }
-  const std::vector<Extent>& run_ext = rev_comp ? rc : ext;
   const double s_chunk = now_seconds() - t_chunk;
   // report_anchor_drop_func (tracer.cpp:1233-1235 through reversable_tracer.cpp:28-35): the raw assemblies that end in an
   // anchor drop, in output order, turned into forward coordinates with their read ids -- kept for bg_pop_trace
@@ -1538,69 +1575,121 @@ extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* 
     }
     res->anchor_drops.push_back(std::move(d));
   }
-  const double t_drop = now_seconds();
-  if (w.o.anchor_drop) {  // anchor_dropper over the scaffold the tracer ran on (reversable_tracer.cpp:124-133)
-    ScaffoldView sc;
-    for (const Extent& e : run_ext) sc.ext.push_back(ScaffoldView::Ext{e.offset, e.seq.data(), int64_t(e.seq.size())});
-    sc.end_pos = end_pos;
-    std::vector<bg_trace_assembly_rec> dropped;
-    try {
-      AnchorDropper ad(AlignParams::from(w.o), sc, [&](bg_trace_assembly_rec&& a) { dropped.push_back(std::move(a)); });
-      // report_half_aligned_func through reversable_tracer.cpp:20-27 (reverse_half_aligned, assemble.cpp:1002-1013)
-      ad.report_half_aligned = [&](int64_t offset, const std::string& seq, uint64_t id) {
-        bg_half_aligned_rec h;
-        h.assembly_id = id;
-        if (rev_comp) { h.offset = end_pos - offset; h.right_anchor = true; h.seq = rev_comp_str(seq); }
-        else { h.offset = offset; h.right_anchor = false; h.seq = seq; }
-        res->half_aligned.push_back(std::move(h));
-      };
-      for (auto& a : raw) ad.add(std::move(a));
-      ad.flush();
-    } catch (const CheckFailed& f) {
-      set_error("bg_tracer_trace: anchor_dropper: %s (the reference aborts on this input)", f.what.c_str());
-      return BG_EINVAL;
-    }
-    raw = std::move(dropped);
-  }
-  const double s_drop = now_seconds() - t_drop;
-  const double t_pair = now_seconds();
-  std::vector<bg_trace_assembly_rec> counted;
-  if (pair_count) {
-    PairCounter pc{w, &counted};
-    // (traces run by ascending offset and a context grows by at most one base per step: left offsets never go back)
-    auto by_left = [](const LeanRef& a, const LeanRef& b) { return a.left < b.left; };
-    if (!std::is_sorted(lean_out.refs.begin(), lean_out.refs.end(), by_left)) std::stable_sort(lean_out.refs.begin(), lean_out.refs.end(), by_left);
-    size_t li = 0;
-    auto lean_up_to = [&](int64_t left) {
-      for (; li < lean_out.refs.size() && lean_out.refs[li].left <= left; ++li) {
-        const LeanRef& x = lean_out.refs[li];
-        if (!pc.add_lean(x.left, x.right, lean_out.ids.data() + x.ids_at, x.n_ids)) return false;
-      }
-      return true;
-    };
-    for (auto& a : raw) {
-      if (!lean_up_to(a.left_offset) || !pc.add(std::move(a)))
-        return fail("bg_tracer_trace: pair_counter: assemblies out of left-offset order");
-    }
-    if (!lean_up_to(INT64_MAX)) return fail("bg_tracer_trace: pair_counter: assemblies out of left-offset order");
-    pc.flush();
-  } else {
-    counted = std::move(raw);
-  }
-  if (rev_comp)
-    for (auto& a : counted) reverse_rec(w, &a, end_pos, false);
-  const double s_pair = now_seconds() - t_pair;
-  res->a = std::move(counted);
+  // ---- the host steps behind the tracer: anchor_dropper, pair_counter, back to forward coordinates.  They read nothing of the
+  // session that the next work item's tracer changes (the options, the shared host tables, the scaffold the result keeps alive),
+  // so bg_tracer_trace_async leaves them to the session's helper thread.
   res->stats = w.stats;
+  bg_trace_result* const rp = res.get();
+  const World* const wp = &w;
+  std::shared_ptr<ExtSet> exts = t->exts;
+  struct Behind {  // (moved into the job)
+    std::vector<bg_trace_assembly_rec> raw;
+    LeanOut lean_out;
+    double s_drop = 0, s_pair = 0;
+  };
+  std::shared_ptr<Behind> bh(new Behind);
+  bh->raw = std::move(raw);
+  bh->lean_out = std::move(lean_out);
+  auto behind = [rp, wp, exts, bh, rev_comp, end_pos, pair_count]() -> int {
+    const World& w = *wp;
+    std::vector<bg_trace_assembly_rec>& raw = bh->raw;
+    LeanOut& lean_out = bh->lean_out;
+    const std::vector<Extent>& run_ext = rev_comp ? exts->rc() : exts->ext;
+    const double t_drop = now_seconds();
+    if (w.o.anchor_drop) {  // anchor_dropper over the scaffold the tracer ran on (reversable_tracer.cpp:124-133)
+      ScaffoldView sc;
+      for (const Extent& e : run_ext) sc.ext.push_back(ScaffoldView::Ext{e.offset, e.seq.data(), int64_t(e.seq.size())});
+      sc.end_pos = end_pos;
+      std::vector<bg_trace_assembly_rec> dropped;
+      try {
+        AnchorDropper ad(AlignParams::from(w.o), sc, [&](bg_trace_assembly_rec&& a) { dropped.push_back(std::move(a)); });
+        // report_half_aligned_func through reversable_tracer.cpp:20-27 (reverse_half_aligned, assemble.cpp:1002-1013)
+        ad.report_half_aligned = [&](int64_t offset, const std::string& seq, uint64_t id) {
+          bg_half_aligned_rec h;
+          h.assembly_id = id;
+          if (rev_comp) { h.offset = end_pos - offset; h.right_anchor = true; h.seq = rev_comp_str(seq); }
+          else { h.offset = offset; h.right_anchor = false; h.seq = seq; }
+          rp->half_aligned.push_back(std::move(h));
+        };
+        for (auto& a : raw) ad.add(std::move(a));
+        ad.flush();
+      } catch (const CheckFailed& f) {
+        rp->pending_error = "bg_tracer_trace: anchor_dropper: " + f.what + " (the reference aborts on this input)";
+        return BG_EINVAL;
+      }
+      raw = std::move(dropped);
+    }
+    bh->s_drop = now_seconds() - t_drop;
+    const double t_pair = now_seconds();
+    std::vector<bg_trace_assembly_rec> counted;
+    if (pair_count) {
+      PairCounter pc{w, &counted};
+      // (traces run by ascending offset and a context grows by at most one base per step: left offsets never go back)
+      auto by_left = [](const LeanRef& a, const LeanRef& b) { return a.left < b.left; };
+      if (!std::is_sorted(lean_out.refs.begin(), lean_out.refs.end(), by_left)) std::stable_sort(lean_out.refs.begin(), lean_out.refs.end(), by_left);
+      size_t li = 0;
+      auto lean_up_to = [&](int64_t left) {
+        for (; li < lean_out.refs.size() && lean_out.refs[li].left <= left; ++li) {
+          const LeanRef& x = lean_out.refs[li];
+          if (!pc.add_lean(x.left, x.right, lean_out.ids.data() + x.ids_at, x.n_ids)) return false;
+        }
+        return true;
+      };
+      bool ordered = true;
+      for (auto& a : raw)
+        if (!lean_up_to(a.left_offset) || !pc.add(std::move(a))) { ordered = false; break; }
+      if (ordered && !lean_up_to(INT64_MAX)) ordered = false;
+      if (!ordered) { rp->pending_error = "bg_tracer_trace: pair_counter: assemblies out of left-offset order"; return BG_EINVAL; }
+      pc.flush();
+    } else {
+      counted = std::move(raw);
+    }
+    if (rev_comp)
+      for (auto& a : counted) reverse_rec(w, &a, end_pos, false);
+    rp->a = std::move(counted);
+    bh->s_pair = now_seconds() - t_pair;
+    return BG_OK;
+  };
+  int rc_behind = BG_OK;
+  if (async) {
+    res->pending = t->helper.run(std::packaged_task<int()>(behind));
+  } else {
+    rc_behind = behind();
+    if (rc_behind != BG_OK) set_error("%s", res->pending_error.c_str());
+  }
   if (getenv("BG_TRACER_TIMING"))
     fprintf(stderr, "bg_tracer_trace: %.3f s in all (extents %.3f, chunk %.3f, anchor drop %.3f, pair counter + reverse %.3f): tables %.3f s, start %.3f s, device rounds %.3f s, host replay %.3f s, teardown %.3f s (%d threads), %llu traces\n",
-            now_seconds() - t_call, s_ext, s_chunk, s_drop, s_pair, w.seconds_tables, w.seconds_start, w.seconds_device, w.seconds_host, w.seconds_teardown, g_tracer_threads, (unsigned long long)w.stats.traces);
+            now_seconds() - t_call, s_ext, s_chunk, async ? 0.0 : bh->s_drop, async ? 0.0 : bh->s_pair, w.seconds_tables, w.seconds_start, w.seconds_device, w.seconds_host, w.seconds_teardown, g_tracer_threads, (unsigned long long)w.stats.traces);
   // the chunk's tables are not kept between work items
   std::vector<std::pair<int32_t, uint64_t>>().swap(w.position_entries);
   std::vector<std::pair<uint64_t, int32_t>>().swap(w.entry_positions);
   std::vector<std::pair<uint32_t, int32_t>>().swap(w.rc_mate_read_positions);
+  if (rc_behind != BG_OK) return rc_behind;
   *out = res.release();
   return BG_OK;
+}
+
+extern "C" int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                               const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset,
+                               int rev_comp, int pair_count, bg_trace_result** out) {
+  return tracer_trace(t, n_extents, ext_offset, ext_seq, ext_len, end_pos, start_offset, limit_offset, rev_comp, pair_count, false, out);
+}
+
+// The same with the anchor_dropper and the pair_counter of this work item left to the session's helper thread: the call returns when
+// the tracer is done with the device, and the session can start its next work item.  *out must be handed to bg_trace_result_wait
+// before anything else looks at it (bg_trace_result_free waits by itself); the session must stay open until then.
+extern "C" int bg_tracer_trace_async(bg_tracer* t, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                                     const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset,
+                                     int rev_comp, int pair_count, bg_trace_result** out) {
+  return tracer_trace(t, n_extents, ext_offset, ext_seq, ext_len, end_pos, start_offset, limit_offset, rev_comp, pair_count, true, out);
+}
+
+extern "C" int bg_trace_result_wait(bg_trace_result* r) {
+  if (!r) return fail("bg_trace_result_wait: null argument");
+  if (!r->pending.valid()) return BG_OK;
+  const int rc = r->pending.get();
+  if (rc != BG_OK) set_error("%s", r->pending_error.c_str());
+  return rc;
 }
 
 // reversable_tracer::assemble(start, limit) (reversable_tracer.cpp:76-145) with the push tracer: one session, one work item.

@@ -319,10 +319,11 @@ class PushTracer:
         capi.check(capi.lib().bg_tracer_open(self.ctx.h, seqset.h, readmap.h, C.c_void_p(ref_map.ptr), C.byref(opt), C.byref(self.h)))
 
     def trace(self, extents, start=0, limit=None, end_pos=None, rev_comp=False, pair_count=True, with_stats=False,
-              half_aligned=None):
+              half_aligned=None, asynchronous=False):
         """extents = [(offset, ACGT string)] of one scaffold, ascending.  -> [TraceAssembly] in output order (+ stats).
         half_aligned: a list that receives (offset, right_anchor, sequence, assembly_id) of what the anchor_dropper could not
-        anchor on the right (bg_trace_result_half_aligned; assemble_options::report_half_aligned_func)."""
+        anchor on the right (bg_trace_result_half_aligned; assemble_options::report_half_aligned_func).
+        asynchronous: bg_tracer_trace_async + bg_trace_result_wait (the host steps behind the tracer on the session's helper thread)."""
         L = capi.lib()
         n = len(extents)
         offs = (C.c_int64 * max(n, 1))(*[int(o) for o, _ in extents])
@@ -333,9 +334,11 @@ class PushTracer:
         end_pos = calc_end if end_pos is None else end_pos
         limit = end_pos if limit is None else limit
         h = C.c_void_p()
-        capi.check(L.bg_tracer_trace(self.h, n, offs, ptrs, lens, end_pos, start, limit, int(bool(rev_comp)), int(bool(pair_count)),
-                                     C.byref(h)))
+        call = L.bg_tracer_trace_async if asynchronous else L.bg_tracer_trace
+        capi.check(call(self.h, n, offs, ptrs, lens, end_pos, start, limit, int(bool(rev_comp)), int(bool(pair_count)), C.byref(h)))
         try:
+            if asynchronous:
+                capi.check(L.bg_trace_result_wait(h))
             out = _read_result(h)
             if half_aligned is not None:
                 for i in range(L.bg_trace_result_half_aligned_count(h)):

@@ -534,6 +534,15 @@ int bg_pop_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext_offset, co
                  const bg_trace_result* const* push, uint32_t n_push, bg_trace_result** out);
 /* Number of anchor drops a bg_tracer_trace result remembers for bg_pop_trace. */
 uint64_t bg_trace_result_anchor_drops(const bg_trace_result* r);
+/* bg_tracer_trace with the host steps behind the tracer (anchor_dropper, pair_counter, the turn back to forward coordinates) left
+ * to a helper thread of the session: the call returns when the tracer itself is done and the session can take its next work
+ * item (trace_ref runs its work items on a thread pool, trace_ref.cpp:105-140; here a session overlaps two of them).  The result
+ * must go through bg_trace_result_wait before any other use (bg_trace_result_free waits by itself; the anchor drops are complete
+ * at once); the session must stay open until then.  Same result as bg_tracer_trace. */
+int bg_tracer_trace_async(bg_tracer* t, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
+                          const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset, int rev_comp,
+                          int pair_count, bg_trace_result** out);
+int bg_trace_result_wait(bg_trace_result* r);
 /* A second session for another host thread: its own context (stream, allocator), the read-only host tables shared with
  * `from`, the same options.  Sessions may trace concurrently, one thread per session; `from` may be closed first. */
 int bg_tracer_clone(const bg_tracer* from, bg_ctx* ctx, bg_tracer** out);

@@ -100,6 +100,7 @@ def test_the_shortcuts_change_nothing(sample):
         "one_pop_pass_per_launch": {"BG_POP_PASSES_AHEAD": "0"},
         "no_rank_blocks": {"BG_WALK_RANK_BLOCKS": "0"},
         "pop_front_by_binary_search": {"BG_WALK_SELECT": "0"},
+        "one_work_item_at_a_time": {"BG_TRACER_ASYNC": "0"},
         "one_coverage_group_of_three": {"BG_COVERAGE_GROUPS": "1", "BG_COVERAGE_WORKERS": "3"},
         "many_small_coverage_groups": {"BG_COVERAGE_GROUPS": "7", "BG_COVERAGE_WORKERS": "5", "BG_COVERAGE_FIBERS": "3"},
         "one_island_per_thread": {"BG_COVERAGE_FIBERS": "1", "BG_COVERAGE_WORKERS": "40"},

@@ -188,6 +188,16 @@ def test_synthetic_equals_oracle(ctx, seed, G, repeats):
                 wc = T.reversable_trace(g, sc, o_cpu, rev_comp=rev, start_offset=start, limit_offset=start + 2000, anchor_drop=ad)
                 gc = tracer.push_trace(ss, rm, rmap, parts, start=start, limit=start + 2000, rev_comp=rev, options=o_gpu)
                 assert [full_key(a) for a in gc] == [full_key(a) for a in wc], (rev, drop, start)
+            # one session, the chunks one after the other with the host steps of each left to the helper thread
+            # (bg_tracer_trace_async): the same assemblies
+            t = tracer.PushTracer(ss, rm, rmap, o_gpu)
+            try:
+                for start in range(0, G, 2000):
+                    ga = t.trace(parts, start, start + 2000, None, rev, True, asynchronous=True)
+                    gs = t.trace(parts, start, start + 2000, None, rev, True)
+                    assert [full_key(a) for a in ga] == [full_key(a) for a in gs], (rev, drop, start)
+            finally:
+                t.close()
     finally:
         rmap.free()
 
