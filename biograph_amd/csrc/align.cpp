@@ -879,10 +879,7 @@ extern "C" int bg_assemblies_process(const bg_trace_result* const* in, uint32_t 
   int64_t calc_end = 0;
   for (uint64_t i = 0; i < n_extents; ++i) {
     if (ext_offset[i] < calc_end) { set_error("bg_assemblies_process: extents must ascend without overlap"); return BG_EINVAL; }
-    for (uint64_t j = 0; j < ext_len[i]; ++j) {
-      const char c = ext_seq[i][j];
-      if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { set_error("bg_assemblies_process: extents hold ACGT only"); return BG_EINVAL; }
-    }
+    if (!all_acgt(ext_seq[i], ext_len[i])) { set_error("bg_assemblies_process: extents hold ACGT only"); return BG_EINVAL; }
     sc.ext.push_back(ScaffoldView::Ext{ext_offset[i], ext_seq[i], int64_t(ext_len[i])});
     calc_end = ext_offset[i] + int64_t(ext_len[i]);
   }

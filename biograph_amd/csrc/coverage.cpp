@@ -691,10 +691,7 @@ int build_scaffold(const char* who, uint64_t n_extents, const int64_t* ext_offse
   int64_t calc_end = 0;
   for (uint64_t i = 0; i < n_extents; ++i) {
     if (ext_offset[i] < calc_end) { set_error("%s: extents must ascend without overlap", who); return BG_EINVAL; }
-    for (uint64_t j = 0; check_bases && j < ext_len[i]; ++j) {
-      const char c = ext_seq[i][j];
-      if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { set_error("%s: extents hold ACGT only", who); return BG_EINVAL; }
-    }
+    if (check_bases && !all_acgt(ext_seq[i], ext_len[i])) { set_error("%s: extents hold ACGT only", who); return BG_EINVAL; }
     sc->ext.push_back(ScaffoldView::Ext{ext_offset[i], ext_seq[i], int64_t(ext_len[i])});
     calc_end = ext_offset[i] + int64_t(ext_len[i]);
   }

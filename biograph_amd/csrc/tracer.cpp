@@ -1382,8 +1382,7 @@ int session_extents(std::shared_ptr<ExtSet>* mine, const char* who, uint64_t n_e
   std::shared_ptr<ExtSet> fresh(new ExtSet);
   for (uint64_t i = 0; i < n_extents; ++i) {
     fresh->ext.push_back(Extent{ext_offset[i], std::string(ext_seq[i], ext_len[i])});
-    for (char c : fresh->ext.back().seq)
-      if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { set_error("%s: extents hold ACGT only", who); return BG_EINVAL; }
+    if (!all_acgt(ext_seq[i], ext_len[i])) { set_error("%s: extents hold ACGT only", who); return BG_EINVAL; }
   }
   fresh->hashes = hashes;
   fresh->end_pos = end_pos;
