@@ -401,3 +401,34 @@ def test_kmer_count_overflow_fallback_path(ctx, monkeypatch):
         assert len(gk) == len(ok) and (gk == ok).all() and (gf == of).all() and (gc == ofw + orv).all(), lg
         allk = O.KmerSet.count(s, o, 25, 1, keep_all=True)
         assert ks.distinct == len(allk)
+
+
+def test_pop_front_of_every_entry_is_undone_by_push_front(ctx):
+    """seqset_range::pop_front is a select over the prev bits (which entry does push_front(b) map onto `begin`?): here for EVERY
+    entry of a built seqset -- every rank of every base goes through the sampled select table (sel256) and the rank blocks.
+    pop_front(entry i) must be a range one base shorter, and push_front of i's first base on it must land on a range that holds
+    i again (seqset.cpp:319-338 undoes :609-628; seqset.cpp:123-126: every entry is the push of exactly one (range, base))."""
+    from biograph_amd import synth
+    seq, offs, n = synth.make_reads(genome_len=150_000, coverage=30, read_len=150, seed=4242, device="cuda")
+    ss, st = ctx.create_device(seq.data_ptr(), offs.data_ptr(), n, ctx.default_params())
+    try:
+        N = ss.size()
+        assert N > 200_000
+        sizes, _ = ss.arrays()
+        fixed = np.frombuffer(ss.part("fixed"), np.uint64)
+        assert len(fixed) == 5 and int(fixed[4]) == N
+        idx = np.arange(N, dtype=np.uint64)
+        base = (np.searchsorted(fixed[1:4], idx, side="right")).astype(np.uint8)  # the bucket an entry begins in = its first base
+        pb, pe, ps = ss.pop_front_batch(idx, idx + np.uint64(1), sizes.astype(np.uint32))
+        assert (ps == sizes - 1).all() and (pe > pb).all()
+        qb, qe, qs = ss.push_front_batch(pb, pe, ps, base)
+        assert (qb <= idx).all() and (qe > idx).all() and (qs == sizes).all()
+        # and for shorter contexts (ranges of many entries): the first 40 bases of every 50th entry
+        sel = idx[::50]
+        sel = sel[sizes[::50] > 40]
+        fb, fe = ss.find_batch([s[:40] for s in (ss.entries(int(i), 1)[0] for i in sel[:400])])
+        pb2, pe2, ps2 = ss.pop_front_batch(fb, fe, np.full(len(fb), 40, np.uint32))
+        qb2, qe2, qs2 = ss.push_front_batch(pb2, pe2, ps2, base[sel[:400].astype(np.int64)])
+        assert (qb2 == fb).all() and (qe2 == fe).all() and (qs2 == 40).all()
+    finally:
+        ss.free()
