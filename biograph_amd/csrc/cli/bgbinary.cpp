@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -1247,8 +1248,13 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   if (n_threads > 64) n_threads = 64;
   const double t_open0 = now_s();
   // (the coverage session's tables beside the tracer's: both are downloads of readmap columns and host loops over them)
+  // (on a context of its own: the steps behind the tracers of one scaffold run beside the tracing of the next)
   bg_coverage* cov_session = nullptr;
-  std::thread cov_open([&] { check(bg_coverage_open(ctx, ss, rm, &cov_session), "bg_coverage_open"); });
+  std::thread cov_open([&] {
+    bg_ctx* ctx_cov = nullptr;
+    check(bg_ctx_create_own_stream(0, &ctx_cov), "bg_ctx_create_own_stream");
+    check(bg_coverage_open(ctx_cov, ss, rm, &cov_session), "bg_coverage_open");
+  });
   std::vector<bg_ctx*> wctx(size_t(n_threads), nullptr);
   std::vector<bg_tracer*> tracers(size_t(n_threads), nullptr);
   for (int t = 0; t < n_threads; ++t) {
@@ -1295,6 +1301,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   uint64_t n_var = 0, n_traced = 0, n_sections = 0, pieces = 0, n_popped = 0;
   double t_trace = 0, t_pipe = 0, t_cov = 0, t_vcf = 0;
   double rss_trace = 0, rss_pipe = 0, rss_cov = 0;
+  std::thread finisher;  // the scaffold before the one being traced, behind its tracers
   const double rss_sessions = rss_gb();
   for (auto& rec : recs) {
     const std::string& seq = rec.second;
@@ -1405,6 +1412,35 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
         }
     t_trace += now_s() - t1;
     rss_trace = std::max(rss_trace, rss_gb());
+    // The steps behind the tracers -- pipeline, coverage, VCF records -- of this scaffold on a thread of their own while the
+    // sessions trace the next scaffold (BG_DISCOVERY_OVERLAP=0: first to the end); one scaffold at a time, in order: the
+    // records are numbered across scaffolds.
+    if (finisher.joinable()) finisher.join();
+    struct ScaffoldData {
+      std::vector<int64_t> eo;
+      std::vector<std::string> es;
+      std::vector<const char*> ep;
+      std::vector<uint64_t> el;
+      std::vector<bg_trace_result*> items;
+      const std::string* name;
+      const std::string* seq;
+    };
+    std::shared_ptr<ScaffoldData> sd(new ScaffoldData);
+    sd->eo.swap(eo);
+    sd->es.swap(es);
+    for (auto& x : sd->es) { sd->ep.push_back(x.c_str()); sd->el.push_back(x.size()); }
+    sd->items.swap(items);
+    sd->name = &rec.first;
+    sd->seq = &rec.second;
+    finisher = std::thread([&, sd] {
+    auto& eo = sd->eo;
+    auto& es = sd->es;
+    auto& ep = sd->ep;
+    auto& el = sd->el;
+    auto& items = sd->items;
+    const std::string& seq = *sd->seq;
+    struct { const std::string& first; } rec{*sd->name};
+    double t1;
     t1 = now_s();
     bg_trace_result *sections = nullptr, *kept = nullptr;
     if (want_csv) {
@@ -1484,7 +1520,11 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     }
     bg_trace_result_free(kept);
     t_vcf += now_s() - t1;
+    });
+    static const bool overlap = [] { const char* e = getenv("BG_DISCOVERY_OVERLAP"); return !(e && e[0] == '0'); }();
+    if (!overlap) finisher.join();
   }
+  if (finisher.joinable()) finisher.join();
   // (the sessions, their contexts and the reference map are not closed one by one: the process ends when the outputs are written,
   // and handing sixteen sessions' pinned buffers, arenas and streams back first took a tenth of a second)
   const double t_write0 = now_s();

@@ -61,6 +61,13 @@ def main():
         f.write(">chrS\n")
         for i in range(0, G, 60):
             f.write(ref[i:i + 60] + "\n")
+    # the same bases as eight scaffolds (ref8.fa): a reference of several chromosomes, for what overlaps between scaffolds
+    with open(os.path.join(tmp, "ref8.fa"), "w") as f:
+        step = (G + 7) // 8
+        for k in range(8):
+            f.write(">chr%d\n" % (k + 1))
+            for i in range(k * step, min(G, (k + 1) * step), 60):
+                f.write(ref[i:min(i + 60, (k + 1) * step)] + "\n")
     g = torch.Generator(device=dev)
     g.manual_seed(args.seed + 1)
     snp = torch.rand(G, generator=g, device=dev) < 0.001

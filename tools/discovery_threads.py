@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--genome-len", type=int, default=64_444_167)
     ap.add_argument("--threads", default="8,24,48,96")
+    ap.add_argument("--ref", default="ref.fa", help="ref.fa (one scaffold) or ref8.fa (the same bases as eight)")
     ap.add_argument("--env", action="append", default=None, help="NAME=VALUE,... for the discovery command (repeat: one sweep per set)")
     args = ap.parse_args()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "discovery_bench.py"), "--genome-len", str(args.genome_len), "--keep",
@@ -36,7 +37,7 @@ def main():
                 env[k] = v
         u0 = resource.getrusage(resource.RUSAGE_CHILDREN)
         t0 = time.perf_counter()
-        r = subprocess.run([exe, "discovery", "--in", os.path.join(tmp, "s.bg"), "--ref", os.path.join(tmp, "ref.fa"), "--out",
+        r = subprocess.run([exe, "discovery", "--in", os.path.join(tmp, "s.bg"), "--ref", os.path.join(tmp, args.ref), "--out",
                             os.path.join(tmp, "v%d.vcf" % th), "--threads", str(th), "--simple-gt", "true", "-f"], capture_output=True, text=True, env=env)
         dt = time.perf_counter() - t0
         u1 = resource.getrusage(resource.RUSAGE_CHILDREN)
