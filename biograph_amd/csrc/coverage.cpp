@@ -40,6 +40,7 @@
 #include <thread>
 
 #include "assembly.h"
+#include "fiber.h"
 #include "bg_internal.h"
 
 using namespace bg;
@@ -806,38 +807,13 @@ struct FiberThread {
   bool failed = false;
   std::string error;
 };
-struct IslandFiber : WalkWaiter {
+struct IslandFiber : WalkWaiter {  // csrc/fiber.h with the island's way of asking for bases
   FiberThread* th = nullptr;
-  ucontext_t uc;
-  void* stack = nullptr;
-  size_t stack_bytes = 0;
-  bool done = false;
-  std::function<void(IslandFiber&)> body;
-  ~IslandFiber() override { if (stack) munmap(stack, stack_bytes); }
+  Fiber fiber;
   void walk(const std::vector<WalkRequest*>& reqs) override {
     th->reqs.insert(th->reqs.end(), reqs.begin(), reqs.end());
-    swapcontext(&uc, &th->sched);  // parked; back here when the thread has the replies
+    fiber.park();  // back here when the thread has the replies
     if (th->failed) throw CheckFailed{th->error};
-  }
-  static void entry(unsigned lo, unsigned hi) {
-    IslandFiber* f = reinterpret_cast<IslandFiber*>((uint64_t(hi) << 32) | uint64_t(lo));
-    f->body(*f);  // (catches what its islands throw)
-    f->done = true;
-  }  // returning resumes uc_link = the thread's scheduler
-  bool start(FiberThread* t, size_t stack_size) {
-    th = t;
-    const size_t page = size_t(sysconf(_SC_PAGESIZE));
-    stack_bytes = stack_size + page;  // a guard page below the stack
-    stack = mmap(nullptr, stack_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
-    if (stack == MAP_FAILED) { stack = nullptr; return false; }
-    (void)mprotect(stack, page, PROT_NONE);
-    if (getcontext(&uc) != 0) return false;
-    uc.uc_stack.ss_sp = static_cast<char*>(stack) + page;
-    uc.uc_stack.ss_size = stack_size;
-    uc.uc_link = &t->sched;
-    const uint64_t self = reinterpret_cast<uint64_t>(this);
-    makecontext(&uc, reinterpret_cast<void (*)()>(&IslandFiber::entry), 2, unsigned(self & 0xffffffffu), unsigned(self >> 32));
-    return true;
   }
 };
 
@@ -954,10 +930,12 @@ extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64
             if (v >= islands.size()) break;
             fibers.emplace_back(new IslandFiber);
             IslandFiber& f = *fibers.back();
-            f.body = [&, v](IslandFiber& self) {
+            f.th = &th;
+            IslandFiber* self = &f;
+            auto body = [&, v, self] {
               try {
                 for (size_t i = v; i < islands.size(); i += all) {
-                  Coverage cov(w, &self);
+                  Coverage cov(w, self);
                   for (const bg_trace_assembly_rec* a : islands[i]) {
                     bg_trace_assembly_rec copy = *a;
                     cov.add(std::move(copy));
@@ -968,16 +946,16 @@ extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64
                 note_error(e.what);
               }
             };
-            if (!f.start(&th, size_t(512) << 10)) { note_error("coverage: no memory for an island's stack"); fibers.pop_back(); break; }
+            if (!f.fiber.start(&th.sched, size_t(512) << 10, body)) { note_error("coverage: no memory for an island's stack"); fibers.pop_back(); break; }
           }
           // rounds: every island of this thread runs until it parks or ends, then the thread takes part in the group's round
           for (;;) {
             th.reqs.clear();
             bool any = false;
             for (auto& f : fibers)
-              if (!f->done) {
+              if (!f->fiber.done) {
                 any = true;
-                swapcontext(&th.sched, &f->uc);
+                f->fiber.resume();
               }
             if (!any) break;
             if (th.reqs.empty() || th.failed) continue;  // (the ones that parked before a failure wake up, throw and end)
