@@ -1,10 +1,12 @@
 // cpuprof.h — BG_CPU_PROFILE=FILE: where the CPU time of a bgbinary command goes, without any tool on the box.
 //
 // ITIMER_PROF fires every millisecond of CPU time the process burns and the kernel delivers SIGPROF to a thread that is
-// running: the handler stores the interrupted program counter, the thread and the time (and the return addresses of up to five frames found through
-// the frame-pointer chain, where there is one) into a preallocated ring.  At the end the samples and /proc/self/maps go to
-// FILE; tools/cpuprof_report.py turns them into time per module and per function (nm of the in-tree binaries).
-// Not part of the product path: nothing is installed unless the variable is set.
+// running: the handler stores the interrupted program counter, the thread and the time (and the return addresses of up to
+// five frames found through the frame-pointer chain, where there is one) into a preallocated ring.  In practice a few hundred
+// samples a second arrive, each on ONE of the running threads: shares of samples are shares of wall time.  At the end the
+// samples and /proc/self/maps go to FILE; tools/cpuprof_report.py turns them into time per module, per function (nm) and,
+// for a library built with -gline-tables-only, per source line (llvm-symbolizer).  tests/test_cpuprof.py runs both on the
+// CPU.  Not part of the product path: nothing is installed unless the variable is set.
 #pragma once
 #include <signal.h>
 #include <stdint.h>
