@@ -203,8 +203,8 @@ class Batcher {
   uint64_t launches = 0, steps = 0;
 
  private:
-  // The round's chains, bases and replies cross the bus from and to page-locked memory: a copy of pageable memory is staged by
-  // the runtime under a lock that all groups' launchers (and the tracer sessions) share.
+  // Page-locked staging for the round's chains, bases and replies (a copy of pageable memory is staged by the runtime under a lock
+  // that all groups' launchers and the tracer sessions share) -- off by default, see launch().
   struct PinnedBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -224,11 +224,25 @@ class Batcher {
   std::string launch(const std::vector<WalkRequest*>& batch) {
     size_t n_chains = 0, n_codes = 0, out_words = 0;
     for (WalkRequest* r : batch) { n_chains += r->chains.size(); n_codes += r->codes.size(); out_words += r->out.size(); }
-    if (!pin_chains_.ensure(n_chains * sizeof(bg_walk_chain) + 8) || !pin_codes_.ensure(n_codes + 8) || !pin_out_.ensure(out_words * 8 + 8))
-      return std::string("coverage: pinned staging buffers refused");
-    bg_walk_chain* chains = static_cast<bg_walk_chain*>(pin_chains_.p);
-    uint8_t* codes = static_cast<uint8_t*>(pin_codes_.p);
-    uint64_t* out = static_cast<uint64_t*>(pin_out_.p);
+    // (pageable staging by default: the page-locked buffers are this run's own and have to grow to a few MB per group first,
+    // which costs what they save -- workers 0.32-0.34 s against 0.35-0.37 s, A/B on one box; BG_COVERAGE_PINNED=1: page-locked)
+    static const bool pinned = [] { const char* e = getenv("BG_COVERAGE_PINNED"); return e && e[0] == '1'; }();
+    std::vector<bg_walk_chain> v_chains;
+    std::vector<uint8_t> v_codes;
+    std::vector<uint64_t> v_out;
+    bg_walk_chain* chains;
+    uint8_t* codes;
+    uint64_t* out;
+    if (pinned) {
+      if (!pin_chains_.ensure(n_chains * sizeof(bg_walk_chain) + 8) || !pin_codes_.ensure(n_codes + 8) || !pin_out_.ensure(out_words * 8 + 8))
+        return std::string("coverage: pinned staging buffers refused");
+      chains = static_cast<bg_walk_chain*>(pin_chains_.p);
+      codes = static_cast<uint8_t*>(pin_codes_.p);
+      out = static_cast<uint64_t*>(pin_out_.p);
+    } else {
+      v_chains.resize(n_chains + 1); v_codes.resize(n_codes + 8); v_out.resize(out_words + 1);
+      chains = v_chains.data(); codes = v_codes.data(); out = v_out.data();
+    }
     std::vector<size_t> out_at;
     size_t nc = 0, nb = 0, nw = 0;
     for (WalkRequest* r : batch) {

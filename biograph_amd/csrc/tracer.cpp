@@ -2044,9 +2044,11 @@ struct PopTracer {
         chains.push_back(ch);
       }
     }
-    // (the ranges come back into page-locked memory: 30-40 MB per piece, a third of it the chains' warm-up rows)
-    BG_TRY(w.pin_s.ensure((words ? words : 1) * 8));
-    uint64_t* strip = static_cast<uint64_t*>(w.pin_s.p);
+    // (30-40 MB of ranges per piece, a third of them the chains' warm-up rows, into pageable memory: page-locked staging of that
+    // size was tried and lost -- sixteen sessions growing 50 MB pinned buffers cost more than the copies: pop_reference 6.8 -> 9.3
+    // session-seconds, A/B on one box)
+    std::vector<uint64_t> strip_v(words ? words : 1);
+    uint64_t* strip = strip_v.data();
     if (!chains.empty()) {
       BG_TRY(bg_walk_chains_batch(ctx, w.ss, uint32_t(chains.size()), chains.data(), codes.data(), codes.size(), strip, words));
       ++device_rounds;

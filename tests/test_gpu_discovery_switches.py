@@ -109,6 +109,7 @@ def test_the_shortcuts_change_nothing(sample):
         "one_coverage_group_of_three": {"BG_COVERAGE_GROUPS": "1", "BG_COVERAGE_WORKERS": "3"},
         "many_small_coverage_groups": {"BG_COVERAGE_GROUPS": "7", "BG_COVERAGE_WORKERS": "5", "BG_COVERAGE_FIBERS": "3"},
         "one_island_per_thread": {"BG_COVERAGE_FIBERS": "1", "BG_COVERAGE_WORKERS": "40"},
+        "coverage_rounds_from_pinned_memory": {"BG_COVERAGE_PINNED": "1"},
         "one_thread_many_islands": {"BG_COVERAGE_GROUPS": "1", "BG_COVERAGE_WORKERS": "1", "BG_COVERAGE_FIBERS": "500"},
         "glibc_malloc": {"BG_FAST_ALLOC": "0"},
         "all_off": {"BG_TRACER_DEVICE_SIMPLE": "0", "BG_TRACER_LEAN_REFS": "0", "BG_POP_PASSES_AHEAD": "0", "BG_FAST_ALLOC_THP": "0"},

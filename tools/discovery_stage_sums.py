@@ -15,12 +15,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--genome-len", type=int, default=64_444_167)
     ap.add_argument("--threads", default="24")
+    ap.add_argument("--env", default="", help="NAME=VALUE,... for the discovery command")
     args = ap.parse_args()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "discovery_bench.py"), "--genome-len", str(args.genome_len), "--keep",
                         "--threads", "24"], capture_output=True, text=True)
     tmp = os.path.join("/dev/shm", sorted(d for d in os.listdir("/dev/shm") if d.startswith("bg_disc_"))[-1])
     exe = os.path.join(ROOT, "biograph_amd", "bgbinary")
     env = dict(os.environ, BG_TRACER_TIMING="1")
+    for kv in args.env.split(","):
+        if "=" in kv:
+            env[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
     for th in args.threads.split(","):
         t0 = time.perf_counter()
         r = subprocess.run([exe, "discovery", "--in", os.path.join(tmp, "s.bg"), "--ref", os.path.join(tmp, "ref.fa"), "--out",
