@@ -137,11 +137,13 @@ def test_part_overlaps_extent_edge(ctx, edge, second):
         assert (out[1].coverage, out[1].other_depth, out[1].ref_depth) == ([0, 0], 0, 0)
 
 
-def test_father_vcf_lines_from_the_golden_biograph(ctx, golden_dir):
-    """The whole engine through the library on the reference's own sample: every record line of father.vcf (PI, the
-    process-wide assembly counter of the reference, aside)."""
-    ss = ctx.open_seqset(golden_dir + "/father_lambda/seqset")
-    rm = ctx.open_readmap(golden_dir + "/father_lambda/readmap")
+@pytest.mark.parametrize("sample,n_records", [("father", 8), ("mother", 8), ("proband", 17)])
+def test_father_vcf_lines_from_the_golden_biograph(ctx, golden_dir, sample, n_records):
+    """The whole engine through the library on the reference's own samples (datasets/lambdaToyData/benchmark/
+    {father,mother,proband}_lambda.bg): every record line of father.vcf, mother.vcf and proband.vcf (PI, the process-wide
+    assembly counter of the reference, aside)."""
+    ss = ctx.open_seqset(golden_dir + "/%s_lambda/seqset" % sample)
+    rm = ctx.open_readmap(golden_dir + "/%s_lambda/readmap" % sample)
     ref = "".join(x.strip() for x in open(golden_dir + "/father_lambda/reference.fasta") if not x.startswith(">")).upper()
     rmap = tracer.reference_ref_map(ss, [ref])
     o = tracer.TraceOptions(min_overlap=int(0.7 * 150))
@@ -153,8 +155,8 @@ def test_father_vcf_lines_from_the_golden_biograph(ctx, golden_dir):
         rmap.free()
     sections = tracer.process_assemblies(traced, [(0, ref)], options=o)
     kept, lines = tracer.assemblies_coverage(ss, rm, sections, [(0, ref)], vcf_name="lambda")
-    want = [x for x in open(golden_dir + "/father_lambda/father.vcf") if not x.startswith("#")]
-    assert len(lines) == len(want) == 8
+    want = [x for x in open(golden_dir + "/%s_lambda/%s.vcf" % (sample, sample)) if not x.startswith("#")]
+    assert len(lines) == len(want) == n_records
 
     def without_pi(line):
         f = line.rstrip("\n").split("\t")

@@ -86,6 +86,42 @@ def _is_entry(em, s):
     return k < len(em) and em[k] == s
 
 
+def test_merge_reproduces_family_lambda(ctx, golden_dir):
+    """configs[4] on the reference's own data: datasets/lambdaToyData/benchmark/family_lambda.bg = `biograph merge` of the
+    father, mother and proband biographs (current container format).  bg_seqset_merge of the three golden seqsets (opened
+    from their files: flattened by FM navigation) == the golden merged seqset -- entries, sizes, shared, fixed; prev bits ==
+    the builder's closed form, which differs from the file in the merger's chunk-boundary choices only (counted and checked
+    by tests/test_oracle_golden.py: 31 bits) -- and bg_readmap_migrate of each sample's readmap == that sample's readmap
+    inside family_lambda.bg, part for part."""
+    from tests.test_oracle_golden import FAMILY_READMAPS, family_prev_bit_differences
+    names = ["father", "mother", "proband"]
+    ins = [ctx.open_seqset(golden_dir + "/%s_lambda/seqset" % s) for s in names]
+    dm = O.load_seqset_zip(golden_dir + "/family_lambda/seqset")
+    em = O.decode_entries(dm)
+    merged, maps = ctx.merge_seqsets(ins)
+    assert merged.size() == dm["n"] == 103996 and merged.max_len == 150
+    assert merged.entries() == em
+    sz, sh = merged.arrays()
+    assert (sz == dm["sizes"]).all() and (sh == dm["shared"]).all()
+    assert merged.part("fixed") == np.asarray(dm["fixed"], np.uint64).tobytes()
+    want = O.Seqset.from_entries(O.Entries.from_strings(em)).parts()
+    for name in bg.PART_NAMES:
+        assert merged.part(name) == want[name], name
+    mine = [np.frombuffer(merged.part("prev_%s/bits" % "ACGT"[b]), np.uint64) for b in range(4)]
+    assert family_prev_bit_differences(em, sh, mine, dm["bits"], dm["n"]) == 31
+    for k, sname in enumerate(names):
+        rm = ctx.open_readmap(golden_dir + "/%s_lambda/readmap" % sname)
+        mig = ctx.migrate_readmap(rm, maps[k], merged)
+        gm = O.decode_readmap(golden_dir + "/family_lambda/coverage/%s.readmap" % FAMILY_READMAPS[sname], dm)
+        e, rl, ml, f = mig.arrays()
+        assert (e == gm["entry"]).all() and (rl == gm["read_len"]).all(), sname
+        assert (ml == gm["mate_loop_ptr"]).all() and (f == gm["is_forward"]).all(), sname
+        for sel in ("source_to_mid", "dest_to_mid"):
+            for w in ("bits", "subaccum", "accum"):
+                name = "read_ids/%s/%s" % (sel, w)
+                assert mig.part(name) == gm["raw"][name], (sname, name)
+
+
 def test_merge_three_synthetic_samples_matches_oracle(ctx):
     from biograph_amd import synth
     seqsets, readmaps, oents, orms = [], [], [], []

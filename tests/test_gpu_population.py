@@ -75,6 +75,51 @@ def test_sharded_merge_equals_single_gpu_merge(ctx, P, n_samples, read_lens):
         assert have[name] == ref[name], name
 
 
+def _rows_of(strings, W):
+    """Entries as the rows sharded_merge takes: W key words (2 bits a base, first base in the top bits), then the length."""
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    rows = np.zeros((len(strings), W + 1), np.uint64)
+    for i, st in enumerate(strings):
+        v = 0
+        for ch in st:
+            v = (v << 2) | code[ch]
+        v <<= 2 * (32 * W - len(st))
+        for w in range(W):
+            rows[i, w] = (v >> (64 * (W - 1 - w))) & 0xffffffffffffffff
+        rows[i, W] = len(st)
+    return rows
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_sharded_merge_of_the_golden_family(ctx, golden_dir, P):
+    """configs[4] on the reference's own data over P ranks: the entries of the golden father / mother / proband seqsets,
+    dealt to the ranks in stripes, through sharded_merge == datasets/lambdaToyData/benchmark/family_lambda.bg (entries, sizes,
+    shared, fixed; every part == the single-GPU bg_seqset_merge, whose prev bits tests/test_gpu_merge.py compares with the
+    file's)."""
+    import torch
+    names = ["father", "mother", "proband"]
+    dm = O.load_seqset_zip(golden_dir + "/family_lambda/seqset")
+    ins = [ctx.open_seqset(golden_dir + "/%s_lambda/seqset" % s) for s in names]
+    want, _ = ctx.merge_seqsets(ins, want_maps=False)
+    comm = sharded.LocalSimComm(P)
+    ctxs = {r: ctx for r in range(P)}
+    rows = {r: [] for r in range(P)}
+    for ss in ins:
+        full = _rows_of(ss.entries(), 5)
+        for r in range(P):
+            rows[r].append(torch.from_numpy(full[r::P].copy().view(np.int64)).cuda())
+    got = sharded.sharded_merge(comm, ctxs, rows, 150, gather=True)
+    ms, mst = got[0]
+    assert mst["n_entries"] == ms.size() == dm["n"] == 103996
+    assert ms.entries() == O.decode_entries(dm)
+    sz, sh = ms.arrays()
+    assert (sz == dm["sizes"]).all() and (sh == dm["shared"]).all()
+    assert ms.part("fixed") == np.asarray(dm["fixed"], np.uint64).tobytes()
+    have, ref = ms.parts(), want.parts()
+    for name in bg.PART_NAMES:
+        assert have[name] == ref[name], name
+
+
 @pytest.mark.parametrize("P", [1, 3])
 def test_population_create_readmaps_equal_migrated_readmaps(ctx, tmp_path, P):
     """The whole flow: merged container written in place by the ranks, replicas opened from it, every sample's

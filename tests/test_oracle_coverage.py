@@ -139,9 +139,11 @@ def test_part_overlaps_extent_edge(edge, second):  # coverage_extent_edge_test :
 
 
 # ---- the reference's own sample ------------------------------------------------------------------------------------
-def test_father_vcf_lines_from_the_golden_biograph(golden_dir):
-    d = O.load_seqset_zip(golden_dir + "/father_lambda/seqset")
-    g = O.decode_readmap(golden_dir + "/father_lambda/readmap", d)
+@pytest.mark.parametrize("sample,n_records", [("father", 8), ("mother", 8), ("proband", 17)])
+def test_father_vcf_lines_from_the_golden_biograph(golden_dir, sample, n_records):
+    """datasets/lambdaToyData/benchmark/{father,mother,proband}_lambda.bg -> every record line of {father,mother,proband}.vcf."""
+    d = O.load_seqset_zip(golden_dir + "/%s_lambda/seqset" % sample)
+    g = O.decode_readmap(golden_dir + "/%s_lambda/readmap" % sample, d)
     oss = O.Seqset.from_arrays(d["sizes"], d["shared"], d["bits"])
     orm = O.Readmap.from_arrays(d["n"], g["entry"], g["read_len"], g["mate_loop_ptr"], g["is_forward"], 150)
     ref = "".join(x.strip() for x in open(golden_dir + "/father_lambda/reference.fasta") if not x.startswith(">")).upper()
@@ -156,8 +158,8 @@ def test_father_vcf_lines_from_the_golden_biograph(golden_dir):
     co = C.CoverageOptions()
     kept = C.simple_genotype_filter(co, C.calc_coverage(graph, [int(x) for x in g["read_len"]], sc, co, sections))
     got = [C.vcf_line(co, "lambda", lambda off, n: ref[off:off + n], a) for a in kept]
-    want = [x for x in open(golden_dir + "/father_lambda/father.vcf") if not x.startswith("#")]
-    assert len(got) == len(want) == 8
+    want = [x for x in open(golden_dir + "/%s_lambda/%s.vcf" % (sample, sample)) if not x.startswith("#")]
+    assert len(got) == len(want) == n_records
 
     def without_pi(line):
         f = line.rstrip("\n").split("\t")

@@ -352,3 +352,62 @@ def test_merge_and_readmap_migration_reproduce_merged_golden(golden_dir):
         s_ = r2["read_seqs"][i]
         j = bisect.bisect_left(ent2, s_)
         assert ent2[j].startswith(s_) and int(maps[1][j]) == int(r2["entry"][i])
+
+
+FAMILY_READMAPS = {"father": "7cb90add2a864f9fa337ee759941743f48433727", "mother": "c6a04bde3351da4a69967082c4a74c2ff0f018ee",
+                   "proband": "ec86f985446e2c28e9a58d36573dec46fe2f6402"}  # metadata/bg_info.json of family_lambda.bg
+
+
+def family_prev_bit_differences(em, sh, mine_bits, gold_bits, n):
+    """Prev bits of a merged seqset: the builder's closed form against the file `biograph merge` wrote.  They may differ only
+    where the merger's chunked sweep had a choice (seqset_merger.cpp:89-106,111-131: an entry b+t whose tail t is a proper
+    prefix of several merged entries): the same number of bits per base, each moved forward inside a block of entries that
+    share the tail, and b + a prefix of the block's first entry is an entry.  Returns the number of such bits."""
+    import bisect
+    ndiff = 0
+    for b in range(4):
+        mine = np.unpackbits(np.asarray(mine_bits[b]).view(np.uint8), bitorder="little")[:n]
+        gold = np.unpackbits(np.asarray(gold_bits[b]).view(np.uint8), bitorder="little")[:n]
+        assert mine.sum() == gold.sum()
+        only_m, only_g = np.flatnonzero(mine & ~gold), np.flatnonzero(gold & ~mine)
+        assert len(only_m) == len(only_g)
+        for i, j in zip(only_m, only_g):
+            assert i < j
+            lcp = min(int(x) for x in sh[i + 1:j + 1])
+            cands = ["ACGT"[b] + em[i][:L] for L in range(1, lcp + 1)]
+            assert any(em[bisect.bisect_left(em, c)] == c for c in cands)
+        ndiff += len(only_m)
+    return ndiff
+
+
+def test_three_sample_merge_reproduces_family_lambda(golden_dir):
+    """SURVEY §8c / configs[4]: datasets/lambdaToyData/benchmark/family_lambda.bg = `biograph merge` of father, mother and
+    proband (current container format, three readmaps).  The oracle's merge of the three golden seqsets must be the golden
+    merged seqset entry for entry (sizes, shared, fixed; prev bits up to the merger's chunk-boundary choice), and fast_migrate
+    of each sample's readmap through its mergemap must be that sample's readmap inside the merged biograph."""
+    ds = {s: O.load_seqset_zip(golden_dir + "/%s_lambda/seqset" % s) for s in FAMILY_READMAPS}
+    dm = O.load_seqset_zip(golden_dir + "/family_lambda/seqset")
+    em = O.decode_entries(dm)
+    names = ["father", "mother", "proband"]
+    ents = [O.Entries.from_strings(O.decode_entries(ds[s])) for s in names]
+    merged, maps = O.merge_entries(ents)
+    assert merged.strings() == em and len(em) == dm["n"]
+    oss = O.Seqset.from_entries(merged)
+    s, sh = oss.arrays()
+    assert (s == dm["sizes"]).all() and (sh == dm["shared"]).all()
+    assert list(oss.fixed()) == [int(x) for x in dm["fixed"]]
+    ndiff = family_prev_bit_differences(em, sh, [oss.prev(b, "bits") for b in range(4)], dm["bits"], dm["n"])
+    assert ndiff == 31  # of 103 996 x 4 bits: every one checked above to be the merger's chunk-boundary choice
+    for k, sname in enumerate(names):
+        g1 = O.decode_readmap(golden_dir + "/%s_lambda/readmap" % sname, ds[sname])
+        gm = O.decode_readmap(golden_dir + "/family_lambda/coverage/%s.readmap" % FAMILY_READMAPS[sname], dm)
+        rm1 = O.Readmap.from_arrays(ds[sname]["n"], g1["entry"], g1["read_len"], g1["mate_loop_ptr"], g1["is_forward"], 150)
+        mig = rm1.migrate(maps[k], dm["n"])
+        assert (mig.get("entry_id") == gm["entry"]).all(), sname
+        assert (mig.get("read_len") == gm["read_len"]).all()
+        assert (mig.get("mate_loop_ptr") == gm["mate_loop_ptr"]).all()
+        assert (mig.get("is_forward") == gm["is_forward"]).all()
+        for sel in ("source_to_mid", "dest_to_mid"):
+            for w in ("bits", "subaccum", "accum"):
+                name = "read_ids/%s/%s" % (sel, w)
+                assert mig.bitcount(sel, w).tobytes() == gm["raw"][name], (sname, name)
