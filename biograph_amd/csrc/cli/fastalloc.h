@@ -53,6 +53,15 @@ struct Global {
   Block* batches = nullptr;
 };
 extern Global g_global[kClasses + kLargeClasses];
+// what ended threads left of their regions: the next thread that needs a region takes one of these first (a command that
+// starts fresh threads per scaffold would otherwise abandon most of 8 MiB per thread and never stop growing)
+struct Remainder { Remainder* next; size_t bytes; };
+struct RemainderPool {
+  std::atomic_flag lock = ATOMIC_FLAG_INIT;
+  Remainder* head = nullptr;
+};
+extern RemainderPool g_remainders;
+constexpr size_t kMinRemainder = size_t(64) << 10;  // smaller leftovers are not worth a list node's look
 
 struct Local {
   Block* free_list[kClasses + kLargeClasses];
@@ -126,6 +135,17 @@ struct Flusher {
       if (c < kClasses) { push_batch(c, first, n); continue; }
       while (first) { Block* next = first->next; first->next = nullptr; push_batch(c, first, 1); first = next; }
     }
+    // the rest of the thread's region, 16-byte aligned as carve() left it
+    if (l.left >= kMinRemainder) {
+      Remainder* r = reinterpret_cast<Remainder*>(l.chunk);
+      r->bytes = l.left;
+      while (g_remainders.lock.test_and_set(std::memory_order_acquire)) { }
+      r->next = g_remainders.head;
+      g_remainders.head = r;
+      g_remainders.lock.clear(std::memory_order_release);
+    }
+    l.chunk = nullptr;
+    l.left = 0;
   }
 };
 inline void register_thread(Local& l) {
@@ -144,8 +164,21 @@ inline int large_class(size_t size) {  // 2 KiB < size <= 64 MiB
 
 inline void* carve(Local& l, size_t need) {  // need is a multiple of 16
   if (l.left < need) {
-    l.chunk = static_cast<char*>(os_alloc(kChunk));
-    l.left = kChunk;
+    // a region an ended thread did not use up, if one is large enough (the first that fits; the list is short)
+    Remainder* got = nullptr;
+    if (g_remainders.head) {  // (racy peek: a miss only means a fresh region)
+      while (g_remainders.lock.test_and_set(std::memory_order_acquire)) { }
+      for (Remainder** pp = &g_remainders.head; *pp; pp = &(*pp)->next)
+        if ((*pp)->bytes >= need) { got = *pp; *pp = got->next; break; }
+      g_remainders.lock.clear(std::memory_order_release);
+    }
+    if (got) {
+      l.left = got->bytes;
+      l.chunk = reinterpret_cast<char*>(got);
+    } else {
+      l.chunk = static_cast<char*>(os_alloc(kChunk));
+      l.left = kChunk;
+    }
   }
   void* p = l.chunk;
   l.chunk += need;
@@ -164,6 +197,8 @@ inline void* allocate(size_t size) {
     return h + 1;
   }
   Local& l = local();
+  if (!l.registered) register_thread(l);  // (on the first call, not only when carving: a thread served from the global
+                                          // batches, or one that only frees, has lists to hand back when it ends too)
   if (size > kMaxSmall) {
     const int lc = large_class(size), cls = kClasses + lc;
     Block* b = l.free_list[cls];
@@ -174,7 +209,6 @@ inline void* allocate(size_t size) {
     }
     uint32_t n = 0;
     if (Block* first = pop_batch(cls, &n)) return first;  // (large batches hold one block)
-    if (!l.registered) register_thread(l);
     const size_t need = large_size(lc) + sizeof(Header);
     Header* h = static_cast<Header*>(need > kCarveMax ? os_alloc(need) : carve(l, need));
     h->cls = uint32_t(cls);
@@ -195,7 +229,6 @@ inline void* allocate(size_t size) {
     l.count[cls] = n - 1;
     return first;
   }
-  if (!l.registered) register_thread(l);
   Header* h = static_cast<Header*>(carve(l, sizeof(Header) + size_t(cls + 1) * kStep));
   h->cls = uint32_t(cls);
   h->magic = kMagic;
@@ -209,6 +242,7 @@ inline void deallocate(void* p) {
   if (h->cls == kLargeTag) { free(h); return; }
   const int cls = int(h->cls);
   Local& l = local();
+  if (!l.registered && enabled()) register_thread(l);
   Block* b = static_cast<Block*>(p);
   if (cls >= kClasses) {
     if (l.count[cls] && size_t(l.count[cls] + 1) * large_size(cls - kClasses) > kLargeKeep) {
@@ -240,6 +274,7 @@ inline void deallocate(void* p) {
 #ifdef FASTALLOC_DEFINE
 namespace fastalloc {
 Global g_global[kClasses + kLargeClasses];
+RemainderPool g_remainders;
 }
 void* operator new(size_t n) { return fastalloc::allocate(n); }
 void* operator new[](size_t n) { return fastalloc::allocate(n); }

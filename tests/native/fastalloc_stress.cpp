@@ -42,5 +42,31 @@ int main() {
     th.clear();
   }
   for (auto& h : hand) for (auto& x : h) delete[] x.first;
+  // many short-lived threads (what `bgbinary discovery` starts per scaffold): threads that are served from the lists
+  // others handed over, or that only free, give their lists back when they end, and the rest of an ended thread's region
+  // goes to the next thread -- the resident set must not grow with the number of threads
+  if (enabled()) {
+    auto rss_mib = [] {
+      long pages = 0, res = 0;
+      FILE* f = fopen("/proc/self/statm", "r");
+      if (!f || fscanf(f, "%ld %ld", &pages, &res) != 2) res = 0;
+      if (f) fclose(f);
+      return double(res) * 4096.0 / (1 << 20);
+    };
+    std::vector<char*> left;  // blocks a thread allocates and the NEXT thread frees (a thread that only frees)
+    auto wave = [&](int n) {
+      for (int i = 0; i < n; ++i) {
+        std::thread a([&] { for (int k = 0; k < 2000; ++k) { char* p = new char[1 + (k * 37) % 900]; p[0] = 1; left.push_back(p); } });
+        a.join();
+        std::thread b([&] { for (char* p : left) delete[] p; left.clear(); });
+        b.join();
+      }
+    };
+    wave(200);
+    const double before = rss_mib();
+    wave(3000);
+    const double after = rss_mib();
+    if (before > 0 && after - before > 64.0) { printf("resident set grew %.0f MiB over 6000 short-lived threads\n", after - before); return 1; }
+  }
   printf("ok\n");
 }
