@@ -29,6 +29,10 @@ SURVEY_8D_BYTES = {
     "suffix_cover_count": lambda st: 28 * st["n_records"],
     "correct_dfs": lambda st: 0.5 * st["n_bases"] + 8 * st["n_kmers"],
 }
+SURVEY_8D_FORMULA = {
+    "entries_dedup_build": "S4 = 28 x N_rec", "prev_bits": "S5 = 2.625 x N_ent", "skm_count_lds": "S2 = 16 x N_kmers",
+    "skm_generate": "S2 = 16 x N_kmers", "suffix_cover_count": "S4 = 28 x N_rec", "correct_dfs": "S3 = 0.5 x N_bases + 8 x N_kmers",
+}
 # kernel families of the step by stage of SURVEY.md section 8(d)
 STAGE_OF_FAMILY = [("S1 pack", ("pack_",)), ("S2 k-mer count", ("skm_", "kmer_")), ("S3 correct", ("correct_",)),
                    ("S4+S5 suffix sort, dedup, prev bits, arrays", ("suffix_", "radix_", "entries_", "prev_bits", "seqset_"))]
@@ -396,6 +400,7 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
     ev_ok = ((ev_off.view(na, cap) >= WARM) & mask)
     aidx, eidx = torch.nonzero(ev_ok, as_tuple=True)
     ns = int(aidx.numel())
+    tr_counts, t_tr = None, 0.0
     ext = None
     if ns:
         pos = starts[aidx] + ev_off.view(na, cap)[aidx, eidx].to(torch.int64)       # absolute site position
@@ -445,6 +450,15 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
                                                  vp(o_re.data_ptr()), vp(o_rs.data_ptr())))
         torch.cuda.synchronize()
         t_tr = time.perf_counter() - t0
+        if count_walk:  # N_pfd / N_drop of the same launch, counted in an untimed repeat
+            capi.check(L.bg_walk_counters(ctx.h, 1, None))
+            capi.check(L.bg_push_to_pair_trace_batch(ctx.h, ss.h, ns, vp(tfoff.data_ptr()), vp(tb.data_ptr()),
+                                                     vp(te.data_ptr()), vp(tz.data_ptr()), 105, MAXS, RC, SC,
+                                                     vp(o_ns.data_ptr()), vp(o_why.data_ptr()), vp(o_bases.data_ptr()),
+                                                     vp(o_cnt.data_ptr()), vp(o_nr.data_ptr()), vp(o_rb.data_ptr()),
+                                                     vp(o_re.data_ptr()), vp(o_rs.data_ptr())))
+            capi.check(L.bg_walk_counters(ctx.h, 0, cnt2))
+            tr_counts = (int(cnt2[0]), int(cnt2[1]))
         steps_total = int(o_ns.sum().item())
         ext = {"sites": ns, "propagate_seconds": round(t_prop, 4), "propagate_pfd_per_s": round(ns * LW / t_prop / 1e9, 3),
                "trace_seconds": round(t_tr, 4), "trace_steps": steps_total,
@@ -474,12 +488,13 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
              "achieved": round(alg / seconds / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(alg / seconds / 1e9 / HBM_PEAK_GBS, 4), "seconds": round(seconds, 4),
              "limiter": "dependent random 64-byte sectors: a chain is one push_front_drop after the other (2 rank look-ups of 3 "
-                        "words each + sizes per call), %d chains in flight" % (2 * (G // 4096 + 1) if kernel == "k_ref_map_chains" else na)}
+                        "words each + sizes per call), %d chains in flight" % (2 * (G // 4096 + 1) if kernel == "k_ref_map_chains" else (ns if kernel == "k_push_to_pair_trace" else na))}
         r.update(pmc_traffic_walk(kernel, seconds * 1e3))
         return r
     roof_ref = walk_roofline("k_ref_map_chains", ref_counts, t_ref)
     roof_br = walk_roofline("k_branch_trace", br_counts, t_br)
-    return {"roofline": roof_ref, "roofline_branch_trace": roof_br,
+    roof_tr = walk_roofline("k_push_to_pair_trace", tr_counts, t_tr) if t_tr > 0 else None
+    return {"roofline": roof_ref, "roofline_branch_trace": roof_br, "roofline_push_to_pair_trace": roof_tr,
             "readmap": {"seconds": round(t_rm, 4), "read_ids": n_ids, "read_ids_per_s": round(n_ids / t_rm / 1e6, 1),
                         "unit": "M read ids/s (paired, both orientations)"},
             "ref_map": {"seconds": round(t_ref, 4), "ref_bases_per_s": round(2 * G / t_ref / 1e9, 3),
@@ -908,15 +923,21 @@ def main():
                         "limiter": LIMITER_OF_FAMILY.get(fam["name"], "hbm random access (latency / line granularity)")}
         if roofline and args.shape == "chr20" and not args.genome_len:
             roofline.update(pmc_traffic(roofline["kernel"], roofline["avg_launch_ms"]))
-        # The same kernel against SURVEY.md section 8(d)'s own bytes for its stage (`frac` above prices the kernel's row
-        # layout -- what it must move as the data is laid out; this one prices what the stage stands for in the survey's
-        # formula: S4 = 28 bytes per suffix record, the reference's 14-byte record written and read once).
+        # `achieved`, `frac` and `algorithmic_bytes_per_launch` follow SURVEY.md section 8(d): the bytes the kernel's STAGE
+        # stands for in the survey's formula (S4 = 28 bytes per suffix record, the reference's 14-byte record written and read
+        # once) over the launch time.  What the kernel must move as the data is laid out here (its rows, its outputs) is kept
+        # beside it as `kernel_layout_bytes_per_launch` / `frac_kernel_layout`.
         if roofline:
             s8 = SURVEY_8D_BYTES.get(roofline["kernel"])
+            roofline["kernel_layout_bytes_per_launch"] = roofline["algorithmic_bytes_per_launch"]
+            roofline["frac_kernel_layout"] = roofline["frac"]
             if s8:
-                b8 = s8(stats)
-                roofline["algorithmic_bytes_survey_8d"] = int(b8)
-                roofline["frac_survey_8d"] = round(b8 / (roofline["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                b8 = s8(stats) / max(roofline["launches_per_step"], 1.0)
+                ach = b8 / (roofline["avg_launch_ms"] * 1e-3) / 1e9
+                roofline["algorithmic_bytes_per_launch"] = int(b8)
+                roofline["achieved"] = round(ach, 1)
+                roofline["frac"] = round(ach / HBM_PEAK_GBS, 4)
+                roofline["bytes_formula"] = "SURVEY.md 8(d): " + SURVEY_8D_FORMULA.get(roofline["kernel"], "")
         total_ms = sum(t["ms"] for t in timings) or 1.0
         kernels = {t["name"]: {"ms_per_step": round(t["ms"] / max(args.steps, 1), 3),
                                "launches_per_step": t["launches"] / max(args.steps, 1),

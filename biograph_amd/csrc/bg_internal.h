@@ -353,13 +353,22 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
                         DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out,
                         DevBuf<uint64_t>* k0 = nullptr, int RS = 0);  // k0: also the sort keys of the records (optional)
                         // RS = words from one record row to the next (0: W; W + 1: a row ends with the record's length)
+// prev bits set where the sorted records meet (k_gather_dedup_build) + the tails that still need a search (k_prev_list)
+struct LocalPrev {
+  DevBuf<uint8_t> emask;     // one byte per entry: bit b = prev_b
+  DevBuf<uint64_t> list;     // rows of W + 1 words: tail, length | base << 8 | checked << 16
+  DevBuf<uint64_t> count;    // rows asked for (device)
+  uint64_t cap = 0, n_items = 0;
+  bool valid = false;        // the kernel ran in this mode and the list held every row
+};
 int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t>& rlen, uint64_t n_rec, int W,
-                              bg_seqset* ss, uint64_t* n_tied_out, DevBuf<uint64_t>* k0 = nullptr, int RS = 0);
+                              bg_seqset* ss, uint64_t* n_tied_out, DevBuf<uint64_t>* k0 = nullptr, int RS = 0,
+                              LocalPrev* lp = nullptr);
 // leading-bases directory over sorted W-word keys (*bases = 8..13 chosen from n): dir[p] = first key with
 // prefix >= p, dir[4^bases] = n
 int build_prefix_dir_keys(bg_ctx* ctx, const uint64_t* keys, uint64_t n, int W, DevBuf<uint32_t>* dir, int* bases);
 int alloc_prev_bits(bg_ctx* ctx, bg_seqset* ss);
-int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss);
+int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss, LocalPrev* lp = nullptr);
 int apply_tails_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint32_t* d_err);
 int apply_tails2_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint8_t* d_need_full, uint32_t* d_err);
 int kmerset_sort(bg_ctx* ctx, bg_kmerset* ks);

@@ -20,6 +20,11 @@ namespace bg {
 
 constexpr int kSortSkipBits = 32;  // the sort key keeps the leading 16 bases of a record (see k_first_words)
 
+// word W of a record row (RS = W + 1): the record's length in the low byte, and above it
+constexpr uint64_t kRecHasPred = 1ull << 8;   // the read has a base in front of this suffix
+constexpr int kRecPredShift = 9;              // ... that base (2 bits)
+constexpr uint64_t kRecLast = 1ull << 11;     // the last suffix its read emitted (the next one is covered by another read)
+
 // ------------------------------------------------------------------------------------------------
 // oriented reads (+ their lengths as bytes and their sort keys: leading 16 bases | oriented id)
 
@@ -199,6 +204,7 @@ __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict
     // which is the one that owns the record
     const uint32_t off = uint32_t(__shfl(int(my_rel), lo, 64));
     const int L = __shfl(my_len, lo, 64);
+    const uint32_t rcnt = uint32_t(__shfl(int(my_cnt), lo, 64));
     if (xq < nrec) {
       const int j = int(xq - off);
       const uint64_t q = r0 + xq;
@@ -214,7 +220,15 @@ __global__ __launch_bounds__(256) void k_emit_records(const uint64_t* __restrict
         if (w == 0) word0 = word;
         cur = next;
       }
-      if (RS > W) row[W] = uint64_t(L - j);
+      if (RS > W) {
+        // behind the length (low byte, all that the sort and the tie kernels read): what k_gather_dedup_build needs to set
+        // the prev bits where the records meet (kRecHasPred: the suffix one base earlier exists, kRecPredShift: the base in
+        // front of this one, kRecLast: the read's last record — its tail was not emitted)
+        uint64_t meta = uint64_t(L - j);
+        if (j > 0) meta |= kRecHasPred | (((s[(j - 1) >> 5] >> (62 - 2 * ((j - 1) & 31))) & 3) << kRecPredShift);
+        if (uint32_t(j) + 1 == rcnt) meta |= kRecLast;
+        row[W] = meta;
+      }
       if (rlen) rlen[q] = uint8_t(L - j);
       if (k0) k0[q] = (word0 & ~((1ull << kSortSkipBits) - 1)) | q;  // the sort key (k_first_words), for free
     }
@@ -587,13 +601,25 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
     const uint64_t* __restrict__ rec, const uint8_t* __restrict__ rlen, const uint32_t* __restrict__ sidx, uint64_t n,
     int W, int RS, unsigned long long* __restrict__ state, uint32_t* __restrict__ ticket, uint64_t* __restrict__ ekeys,
     uint8_t* __restrict__ sizes, uint8_t* __restrict__ shared, uint64_t* __restrict__ pre2,
-    uint64_t* __restrict__ tile_first, uint32_t* __restrict__ err, int sort_small) {
+    uint64_t* __restrict__ tile_first, uint32_t* __restrict__ err, int sort_small, uint8_t* __restrict__ emask,
+    uint64_t* __restrict__ list, unsigned long long* __restrict__ list_n, uint64_t list_cap) {
   const int H = sort_small ? kFusedHalo : 1;  // slot i of the tile = sorted position b0 + i - H
   const int NS = kFusedTile + 2 * H;
-  extern __shared__ uint64_t tile[];  // NS * W words, then lengths, per-position lcp, keep flags
+  extern __shared__ uint64_t tile[];  // NS * W words, then lengths, per-position lcp, keep flags, record flags
   uint8_t* tlen = reinterpret_cast<uint8_t*>(tile + NS * W);
   uint8_t* tlcp = tlen + NS;
   uint8_t* tkeep = tlcp + kFusedTile;
+  uint8_t* tmeta = tkeep + kFusedTile;  // NS: bits 8.. of word W of every row (kRecHasPred ...), shifted down
+  // prev bits where the records meet (emask != nullptr; rows of W + 1 words with the flags of k_emit_records).  A record
+  // (r, j), j >= 1, is the tail of the suffix one base earlier, b.s with b = the read's base j - 1.  If the record's string
+  // s is an entry (it survives, or it equals the survivor that follows it), b.s is an entry as well (a suffix b.s.z would
+  // make s.z a suffix, and s would not be maximal), and it sets prev_b[s] (builder.cpp:85-108): no search.
+  // What is left goes to a list of tails for k_prev_list: the tails of survivors that are the last record of their read
+  // (the tail was not emitted: one record in six), and the records that are dropped as PROPER prefixes (b.s sets
+  // prev_b[first entry that extends s] only if b.s is an entry itself: checked there), or whose survivor is out of sight.
+  __shared__ uint32_t tmk[kFusedTile];  // survivor rank -> prev bases (bit b)
+  __shared__ uint32_t s_nitems;
+  __shared__ unsigned long long s_lbase;
   __shared__ uint32_t tidx[kFusedSlots];
   __shared__ uint16_t pmap[kFusedSlots];
   __shared__ uint16_t tsrc[kFusedTile];  // survivor rank -> slot of its row
@@ -601,7 +627,9 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
   __shared__ uint32_t s_tile, s_wave[kFusedTile / 64];
   __shared__ unsigned long long s_excl;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+  if (tid == 0) { s_tile = atomicAdd(ticket, 1u); s_nitems = 0; }
+  if (emask)
+    for (int i = tid; i < kFusedTile; i += kGatherTile) tmk[i] = 0;
   __syncthreads();
   const uint64_t t = s_tile;
   const uint64_t b0 = t * kFusedTile;
@@ -641,7 +669,7 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
       if (g < total) {
         const int i = int((uint32_t(g) * rcp) >> 16), w = g - i * RS;
         if (w < W) tile[i * W + w] = v[it];
-        else tlen[i] = uint8_t(v[it]);
+        else { tlen[i] = uint8_t(v[it]); tmeta[i] = uint8_t(v[it] >> 8); }
       }
     }
   }
@@ -766,6 +794,34 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
       tile_first[t] = count ? excl : ~0ull;
     }
   }
+  // prev bits of the records that meet their survivor in this tile; the rest become list items
+  int item_kind[kFusedPos], item_slot[kFusedPos];  // 0 none, 1 the tail of this survivor, 2 this record as a tail, checked
+  uint32_t item_at[kFusedPos];
+#pragma unroll
+  for (int sl = 0; sl < kFusedPos; ++sl) {
+    item_kind[sl] = 0;
+    item_slot[sl] = 0;
+    item_at[sl] = 0;
+    const int p = sl * kGatherTile + tid;
+    if (emask && b0 + p < n) {
+      const int sp = pmap[p + H];
+      const uint32_t m = tmeta[sp];
+      const bool has_pred = (m & uint32_t(kRecHasPred >> 8)) != 0;
+      const uint32_t pb = (m >> (kRecPredShift - 8)) & 3u;
+      if (keep[sl]) {
+        if (has_pred) atomicOr(&tmk[before[sl]], 1u << pb);
+        if (m & uint32_t(kRecLast >> 8)) item_kind[sl] = 1;
+      } else if (has_pred) {
+        // the survivor this record is a prefix of: the first one after it (a run of dropped records is a chain of prefixes)
+        int q = p + 1;
+        const int qe = p + 16 < kFusedTile ? p + 16 : kFusedTile;
+        while (q < qe && !tkeep[q]) ++q;
+        if (q < qe && tlen[pmap[q + H]] == tlen[sp]) atomicOr(&tmk[before[sl]], 1u << pb);  // equal strings; its rank = survivors before p
+        else item_kind[sl] = 2;
+      }
+      if (item_kind[sl]) { item_slot[sl] = sp; item_at[sl] = atomicAdd(&s_nitems, 1u); }
+    }
+  }
   // survivors compacted through LDS so that every output array is written in whole lines (a thread writing
   // its own 40-byte entry leaves the lanes of a store 40 bytes apart)
 #pragma unroll
@@ -785,6 +841,7 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
     }
   }
   __syncthreads();
+  if (emask && tid == 0 && s_nitems) s_lbase = atomicAdd(list_n, (unsigned long long)s_nitems);
   const uint64_t e0 = s_excl;
   const uint32_t rcpw = (65536u + uint32_t(W) - 1) / uint32_t(W);
   for (uint32_t x = tid; x < count * uint32_t(W); x += kGatherTile) {
@@ -798,6 +855,27 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
   for (uint32_t x = tid; x < count; x += kGatherTile) {
     sizes[e0 + x] = tlen[uint32_t(tsrc[x])];
     shared[e0 + x] = tsh[x];
+    if (emask) emask[e0 + x] = uint8_t(tmk[x]);
+  }
+  if (!emask) return;
+  __syncthreads();
+  if (!s_nitems) return;
+  const unsigned long long lbase = s_lbase;
+#pragma unroll
+  for (int sl = 0; sl < kFusedPos; ++sl) {
+    if (!item_kind[sl]) continue;
+    const unsigned long long at = lbase + item_at[sl];
+    if (at >= list_cap) continue;  // (the host sees the count and falls back to the search for every entry)
+    const uint64_t* a = tile + item_slot[sl] * W;
+    uint64_t* row = list + at * uint64_t(W + 1);
+    const uint64_t len = tlen[item_slot[sl]];
+    if (item_kind[sl] == 1) {  // s[1:], its length, s[0]
+      for (int w = 0; w < W; ++w) row[w] = (a[w] << 2) | (w + 1 < W ? a[w + 1] >> 62 : 0ull);
+      row[W] = (len - 1) | ((a[0] >> 62) << 8);
+    } else {  // s, its length, the base in front of it; bit 16: only if that base + s is an entry
+      for (int w = 0; w < W; ++w) row[w] = a[w];
+      row[W] = len | (uint64_t((tmeta[item_slot[sl]] >> (kRecPredShift - 8)) & 3u) << 8) | (1ull << 16);
+    }
   }
 }
 
@@ -1288,6 +1366,52 @@ __global__ __launch_bounds__(256) void k_pack_marks(const uint8_t* __restrict__ 
   v |= __shfl_down(v, 2, 64) << 32;
   const uint64_t word = w0 + uint64_t(lane >> 2);
   if ((lane & 3) == 0 && word < nwords && v) bits[word] |= v;
+}
+
+// The tails k_gather_dedup_build could not settle where the records meet (rows of W + 1 words: the tail, then
+// length | base << 8 | checked << 16): prev_base[first entry that extends the tail], and for a checked one only if
+// base + tail is an entry itself.  emask: one byte per entry, bit b = prev_b.
+__global__ __launch_bounds__(256) void k_prev_list(const uint64_t* __restrict__ rows, uint64_t nt,
+                                                   const uint64_t* __restrict__ ekeys, const uint64_t* __restrict__ pre2,
+                                                   const uint8_t* __restrict__ sizes, uint64_t n, int W,
+                                                   const uint32_t* __restrict__ dir, int bases, uint8_t* __restrict__ emask,
+                                                   uint32_t* __restrict__ err, int verify) {
+  const uint64_t t = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (t >= nt) return;
+  const uint64_t* row = rows + t * uint64_t(W + 1);
+  uint64_t tail[kMaxWords];
+#pragma unroll
+  for (int w = 0; w < kMaxWords; ++w) tail[w] = w < W ? row[w] : 0;
+  const uint64_t meta = row[W];
+  const int tl = int(meta & 0xff), b = int((meta >> 8) & 3);
+  uint64_t lo;
+  if (!prev_target_pre2(ekeys, pre2, sizes, n, W, dir, bases, tail, tl, verify, err, &lo)) return;
+  if (meta & (1ull << 16)) {
+    uint64_t key[kMaxWords];
+#pragma unroll
+    for (int w = 0; w < kMaxWords; ++w) key[w] = w < W ? ((w ? tail[w - 1] << 62 : uint64_t(b) << 62) | (tail[w] >> 2)) : 0;
+    const int kl = tl + 1;
+    const uint64_t at = entries_lower_bound(ekeys, sizes, n, W, dir, bases, key, kl);
+    if (at >= n || int(sizes[at]) != kl || key_lcp(ekeys + at * W, kl, key, kl, W) < kl) return;
+  }
+  atomicOr(reinterpret_cast<unsigned int*>(emask + (lo & ~3ull)), (1u << b) << (8 * unsigned(lo & 3)));
+}
+
+// emask -> the four prev bit vectors (one wave per 16 words of each)
+__global__ __launch_bounds__(256) void k_pack_emask(const uint8_t* __restrict__ emask, uint64_t n,
+                                                    unsigned long long* __restrict__ bA, unsigned long long* __restrict__ bC,
+                                                    unsigned long long* __restrict__ bG, unsigned long long* __restrict__ bT) {
+  const uint64_t nwords = (n + 63) / 64;
+  const uint64_t g = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  for (int k = 0; k < kPackWordsPerWave; ++k) {
+    const uint64_t word = g * kPackWordsPerWave + k;
+    if (word >= nwords) return;
+    const uint64_t e = word * 64 + lane;
+    const uint32_t m = e < n ? emask[e] : 0u;
+    const unsigned long long a = __ballot(m & 1u), c = __ballot(m & 2u), gg = __ballot(m & 4u), tt = __ballot(m & 8u);
+    if (lane == 0) { bA[word] = a; bC[word] = c; bG[word] = gg; bT[word] = tt; }
+  }
 }
 
 // tails received from other shards (rows of W+1 words: s[1:], (len-1) | base << 8) -> prev bits
@@ -1803,7 +1927,7 @@ int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p,
 // Phase B: sort the records, drop prefixes/duplicates, build keys/sizes/shared of the surviving
 // entries into `ss`.  Consumes rec/rlen.
 int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t>& rlen, uint64_t n_rec, int W,
-                              bg_seqset* ss, uint64_t* n_tied_out, DevBuf<uint64_t>* k0, int RS) {
+                              bg_seqset* ss, uint64_t* n_tied_out, DevBuf<uint64_t>* k0, int RS, LocalPrev* lp) {
   if (RS <= 0) RS = W;
   if (n_rec >= (1ull << 32)) {
     set_error("%llu suffix records exceed one shard", (unsigned long long)n_rec);
@@ -1837,13 +1961,22 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
       BG_TRY(ticket.alloc(ctx, 1));
       BG_HIP(hipMemsetAsync(state.p, 0, ntiles * 8, ctx->stream));
       BG_HIP(hipMemsetAsync(ticket.p, 0, 4, ctx->stream));
+      // prev bits where the records meet (rows that carry the flags of k_emit_records): see the kernel
+      const bool local_prev = lp && RS == W + 1 && !getenv("BG_PREV_SEARCH_ALL");
+      if (local_prev) {
+        lp->cap = n_rec / 3 + 1024;
+        BG_TRY(lp->emask.alloc(ctx, (n_rec + 3) & ~3ull));
+        BG_TRY(lp->list.alloc(ctx, lp->cap * uint64_t(W + 1)));
+        BG_TRY(lp->count.alloc(ctx, 1));
+        BG_HIP(hipMemsetAsync(lp->count.p, 0, 8, ctx->stream));
+      }
       ctx->tic("entries_dedup_build");
       const size_t slots = size_t(kFusedTile) + 2 * (defer_small ? kFusedHalo : 1);
-      const size_t lds = slots * W * 8 + slots + 2 * kFusedTile;
-      k_gather_dedup_build<<<unsigned(ntiles), kGatherTile, lds, ctx->stream>>>(rec.p, rlen.p, sidx.p, n_rec, W, RS, state.p,
-                                                                             ticket.p, ss->keys.p, ss->sizes.p, ss->shared.p,
-                                                                             ss->pre2.p, tile_first.p, err.p,
-                                                                             defer_small ? 1 : 0);
+      const size_t lds = slots * W * 8 + 2 * slots + 2 * kFusedTile;
+      k_gather_dedup_build<<<unsigned(ntiles), kGatherTile, lds, ctx->stream>>>(
+          rec.p, rlen.p, sidx.p, n_rec, W, RS, state.p, ticket.p, ss->keys.p, ss->sizes.p, ss->shared.p, ss->pre2.p, tile_first.p,
+          err.p, defer_small ? 1 : 0, local_prev ? lp->emask.p : nullptr, local_prev ? lp->list.p : nullptr,
+          local_prev ? reinterpret_cast<unsigned long long*>(lp->count.p) : nullptr, local_prev ? lp->cap : 0);
       BG_LAUNCH_CHECK();
       k_fix_tile_first_shared<<<cdiv(ntiles, 256), 256, 0, ctx->stream>>>(tile_first.p, ntiles, ss->keys.p, ss->sizes.p, W,
                                                                           ss->shared.p);
@@ -1851,8 +1984,10 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
       ctx->toc(n_rec * (W * 8 * 2 + 8 + 16));
       unsigned long long last = 0;
       BG_HIP(hipMemcpyAsync(&last, state.p + (ntiles - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+      if (local_prev) BG_HIP(hipMemcpyAsync(&lp->n_items, lp->count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
       BG_HIP(hipStreamSynchronize(ctx->stream));
       n_ent = last & kScanVal;
+      if (local_prev) lp->valid = lp->n_items <= lp->cap;
     }
     rec.reset(); rlen.reset(); sidx.reset();
     ss->n = n_ent;
@@ -2036,7 +2171,7 @@ int alloc_prev_bits(bg_ctx* ctx, bg_seqset* ss) {
 }
 
 // Phase C (single shard): prev bits from the shard's own entries.
-int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss) {
+int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss, LocalPrev* lp) {
   const uint64_t n_ent = ss->n;
   BG_TRY(alloc_prev_bits(ctx, ss));
   DevBuf<uint32_t> err;
@@ -2046,6 +2181,30 @@ int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss) {
   DevBuf<uint8_t> marks;
   const bool use_pre2 = ss->pre2.p && ss->pre2.n >= 2 * n_ent && !getenv("BG_PREV_FULL_SEARCH");
   const char* pm = getenv("BG_PREV_MERGE");
+  if (n_ent && lp && lp->valid && use_pre2 && !(pm && pm[0] == '1')) {
+    // most bits are set already (k_gather_dedup_build); the listed tails are searched as every entry's tail used to be
+    ctx->tic("prev_bits");
+    int bases = 0;
+    BG_TRY(build_prefix_dir_keys(ctx, ss->pre2.p, n_ent, 2, &dir, &bases));
+    const char* v = getenv("BG_VERIFY_CLOSURE");
+    if (lp->n_items) {
+      k_prev_list<<<cdiv(lp->n_items, 256), 256, 0, ctx->stream>>>(lp->list.p, lp->n_items, ss->keys.p, ss->pre2.p, ss->sizes.p, n_ent,
+                                                                  ss->W, dir.p, bases, lp->emask.p, err.p, v && v[0] == '1');
+      BG_LAUNCH_CHECK();
+    }
+    const uint64_t nwords = (n_ent + 63) / 64;
+    k_pack_emask<<<cdiv(cdiv(nwords, kPackWordsPerWave), 4), 256, 0, ctx->stream>>>(
+        lp->emask.p, n_ent, reinterpret_cast<unsigned long long*>(ss->bits[0].p), reinterpret_cast<unsigned long long*>(ss->bits[1].p),
+        reinterpret_cast<unsigned long long*>(ss->bits[2].p), reinterpret_cast<unsigned long long*>(ss->bits[3].p));
+    BG_LAUNCH_CHECK();
+    ctx->toc(lp->n_items * (ss->W * 8 + 8 + 16) + n_ent * 2);
+    uint32_t h_err[2] = {0, 0};
+    BG_HIP(hipMemcpyAsync(h_err, err.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    if (h_err[0] & 2) { set_error("missing expansion (entry set not closed under pop_front)"); return BG_EINTERNAL; }
+    if (h_err[0] & 4) { set_error("prev bits: the two-word search disagrees with the full-key search (internal error)"); return BG_EINTERNAL; }
+    return BG_OK;
+  }
   // Off unless asked for (BG_PREV_MERGE=1): the merge gives the same bits (the tests run it) but, as written, not faster --
   // chr20: 9.4 ms against 5.6 + 0.5 (directory).  A workgroup is a chain of dependent steps (bounds -> 40 KB of rows into LDS
   // -> per round: stage 256 tails, ten-step LDS search) at three workgroups per CU: ~50 us each, 184 rounds of them.  The
@@ -2122,8 +2281,10 @@ extern "C" int bg_seqset_build(bg_ctx* ctx, const bg_reads* reads, int cover_k, 
   DevBuf<uint64_t> k0;
   // (rows of W + 1 words: every record carries its length behind its key words)
   BG_TRY(suffix_records_impl(ctx, reads, 0, reads->n, cover_k, &rec, &rlen, &n_rec, &k0, reads->W + 1));
-  BG_TRY(entries_from_records_impl(ctx, rec, rlen, n_rec, reads->W, ss.get(), &n_tied, &k0, reads->W + 1));
-  BG_TRY(prev_bits_local_impl(ctx, ss.get()));
+  LocalPrev lp;
+  BG_TRY(entries_from_records_impl(ctx, rec, rlen, n_rec, reads->W, ss.get(), &n_tied, &k0, reads->W + 1, &lp));
+  BG_TRY(prev_bits_local_impl(ctx, ss.get(), &lp));
+  if (getenv("BG_DEBUG_PREV")) fprintf(stderr, "prev bits: %llu of %llu entries' worth of tails searched (list %s)\n", (unsigned long long)(lp.valid ? lp.n_items : ss->n), (unsigned long long)ss->n, lp.valid ? "ok" : "not used");
   // the longest read is never a proper prefix of anything longer, so it survives as an entry
   ss->max_len = ss->n ? reads->max_len : 0;
   ctx->tic("seqset_finalize");

@@ -23,6 +23,8 @@ int comm_all_gather_host(bg_comm* c, const void* mine, size_t bytes, void* all);
 int comm_all_gather_dev(bg_comm* c, const void* d_send, const uint64_t* bytes, void* d_recv);
 int comm_all_reduce_sum_u64(bg_comm* c, uint64_t* d_buf, size_t n);
 int comm_barrier(bg_comm* c);
+// a rank leaving the build on an error: lands what it has in flight, tells the ranks of a shared-memory communicator
+void comm_fail(bg_comm* c);
 // true: a rank alone whose collectives are identities (world 1 without BG_COMM_NO_SHORTCUT=1)
 bool comm_is_shortcut(const bg_comm* c);
 int comm_rank(const bg_comm* c);

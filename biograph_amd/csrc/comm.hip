@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sys/file.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -139,6 +140,7 @@ struct bg_comm {
   bg::Fabric fab;
   std::vector<char*> seg;        // mapping of every rank's data segment
   std::vector<size_t> seg_mapped;
+  int lock_fd = -1;              // rank 0: the fabric's descriptor, flock'ed for as long as the communicator lives
   double timeout_s = 600.0;
   // statistics
   uint64_t n_collectives = 0, bytes_backend = 0, bytes_local = 0;
@@ -288,6 +290,14 @@ int rccl_transfer(bg_comm* c, const void* d_send, const uint64_t* send_off, cons
 
 }  // namespace
 
+// A rank that leaves the build on an error: what it has in flight lands first (the buffers go back to the arena behind it),
+// and the ranks of a shared-memory communicator are told (they leave their next wait at once instead of at the timeout).
+void comm_fail(bg_comm* c) {
+  if (!c) return;
+  if (c->flying) { (void)hipStreamSynchronize(c->xstream); c->flying = false; }
+  if (c->ctx) (void)hipStreamSynchronize(c->ctx->stream);
+  if (c->backend == 1 && c->fab.hdr) c->fab.hdr->failed.store(1);
+}
 bool comm_is_shortcut(const bg_comm* c) { return c->shortcut; }
 int comm_rank(const bg_comm* c) { return c->rank; }
 int comm_world(const bg_comm* c) { return c->world; }
@@ -462,6 +472,7 @@ void bg_comm_free(bg_comm* c) {
     shm_unlink(bg::seg_name(c, c->rank).c_str());
     if (c->fab.hdr) munmap(c->fab.hdr, c->fab.bytes);
     if (c->rank == 0) shm_unlink(("/" + c->name).c_str());
+    if (c->lock_fd >= 0) close(c->lock_fd);  // (drops the lock)
   }
   delete c;
 }
@@ -509,19 +520,33 @@ int bg_comm_init(bg_ctx* ctx, int rank, int world, const char* id, const char* b
     const size_t fb = bg::Fabric::size_for(world);
     const std::string fname = "/" + c->name;
     int fd = -1;
+    // A segment a crashed run left under this name must not be taken for the new one (it is complete: the right size,
+    // `ready` set): rank 0 holds an exclusive flock on the fabric for as long as its communicator lives, makes it under a
+    // name of its own and only then gives it the shared name, so the shared name never shows an unlocked live fabric —
+    // and the other ranks skip whatever they can lock (nobody holds it: a leftover) until rank 0's appears.
     if (rank == 0) {
       shm_unlink(fname.c_str());
-      fd = shm_open(fname.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
-      if (fd < 0 || ftruncate(fd, off_t(fb)) != 0) {
+      const std::string tmp = fname + "-new" + std::to_string(long(getpid()));
+      shm_unlink(tmp.c_str());
+      fd = shm_open(tmp.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
+      if (fd < 0 || flock(fd, LOCK_EX | LOCK_NB) != 0 || ftruncate(fd, off_t(fb)) != 0 ||
+          rename(("/dev/shm" + tmp).c_str(), ("/dev/shm" + fname).c_str()) != 0) {
         bg::set_error("bg_comm_init(shm): cannot create %s: %s", fname.c_str(), strerror(errno));
         if (fd >= 0) close(fd);
+        shm_unlink(tmp.c_str());
         return BG_EIO;
       }
+      c->lock_fd = dup(fd);
     } else {
       const double t0 = bg::now_s();
       for (;;) {
         fd = shm_open(fname.c_str(), O_RDWR, 0600);
         struct stat sb;
+        if (fd >= 0 && flock(fd, LOCK_SH | LOCK_NB) == 0) {  // nobody holds it: left behind by a run that died
+          flock(fd, LOCK_UN);
+          close(fd);
+          fd = -1;
+        }
         if (fd >= 0 && fstat(fd, &sb) == 0 && size_t(sb.st_size) >= fb) break;
         if (fd >= 0) close(fd);
         if (bg::now_s() - t0 > c->timeout_s) { bg::set_error("bg_comm_init(shm): rank 0 never created %s", fname.c_str()); return BG_EIO; }

@@ -392,12 +392,15 @@ int records_sharded_cover(bg_comm* c, bg_ctx* ctx, Handles& H, int W, int k, std
     parts->push_back(std::move(fly_recv));
     return BG_OK;
   };
+  // No host collective stands between the launch of a window's exchange and the generation of the next window (a host
+  // collective waits for the exchange in flight first, comm.hip): how many reads are still live at the NEXT window, on
+  // every rank, travels with the counts gather of this one.
+  uint64_t live = 0, tot = 0;
+  BG_TRY(bg_cover_query_records_live(ctx, H.query, wins[0], &live));
+  BG_TRY(all_sum(c, live, &tot));
   for (size_t wi = 0; wi + 1 < wins.size(); ++wi) {
     const int j_lo = wins[wi], j_hi = wins[wi + 1];
     ph.mark("cover_records");
-    uint64_t live = 0, tot = 0;
-    BG_TRY(bg_cover_query_records_live(ctx, H.query, j_lo, &live));
-    BG_TRY(all_sum(c, live, &tot));
     if (!tot) break;
     const uint64_t cap = live * uint64_t(j_hi - j_lo);
     Rows send;
@@ -408,14 +411,23 @@ int records_sharded_cover(bg_comm* c, bg_ctx* ctx, Handles& H, int W, int k, std
     send.n = n_r;
     send.b.shrink(std::max<uint64_t>(n_r, 1) * rw);
     BG_TRY(land());
-    BG_TRY(gather_u64(c, counts, &m));
+    uint64_t live_next = 0;
+    if (wi + 2 < wins.size()) BG_TRY(bg_cover_query_records_live(ctx, H.query, j_hi, &live_next));
+    {
+      std::vector<uint64_t> mine(counts);
+      mine.push_back(live_next);
+      BG_TRY(gather_u64(c, mine, &m));  // (P + 1 values per rank: its counts, then its live reads at the next window)
+    }
+    live = live_next;
+    tot = 0;
+    for (int s = 0; s < P; ++s) tot += m[size_t(s) * (P + 1) + P];
     if (comm_is_shortcut(c)) {
       parts->push_back(std::move(send));
     } else {
       const int me = comm_rank(c);
       std::vector<uint64_t> rr(P);
       uint64_t in = 0;
-      for (int s = 0; s < P; ++s) { rr[s] = m[size_t(s) * P + me]; in += rr[s]; }
+      for (int s = 0; s < P; ++s) { rr[s] = m[size_t(s) * (P + 1) + me]; in += rr[s]; }
       BG_TRY(fly_recv.alloc(ctx, in, rw));
       fly_send = std::move(send);
       BG_TRY(comm_exchange(c, fly_send.b.p, counts.data(), rr.data(), size_t(rw) * 8, fly_recv.b.p, true));
@@ -638,12 +650,38 @@ const uint64_t* next_nonempty(const std::vector<uint64_t>& rows, int rw, int P, 
 
 using namespace bg;
 
+static int create_sharded_impl(bg_ctx* ctx, bg_comm* comm, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n_reads,
+                               const bg_create_params* params, int readmap, bg_sharded** out, bg_sharded_stats* stats);
+
+// Errors: what a rank can know about its own input is checked before the first collective and AGREED on (one host
+// all-gather of the ranks' verdicts), so a bad input takes every rank out together with the offending rank's message
+// instead of leaving the others in a collective.  A rank that fails later (out of memory, an internal error) lands what it
+// has in flight before its buffers go back to the arena and tells the ranks of a shared-memory communicator (comm_fail);
+// over RCCL its peers stay in their next send / receive -- `bgbinary create --gpus N` ends them, a library caller must.
 extern "C" int bg_create_sharded(bg_ctx* ctx, bg_comm* comm, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n_reads, const bg_create_params* params,
                                  int readmap, bg_sharded** out, bg_sharded_stats* stats) {
   if (!ctx || !comm || !out || (n_reads && (!d_seq || !d_offs)) || readmap < 0 || readmap > 2) {
     set_error("bg_create_sharded: bad arguments");
     return BG_EINVAL;
   }
+  {
+    uint64_t verdict = BG_OK;
+    if (readmap == 2 && (n_reads & 1)) verdict = uint64_t(-BG_EINVAL);
+    std::vector<uint64_t> all;
+    BG_TRY(gather_u64(comm, {verdict}, &all));
+    for (size_t r = 0; r < all.size(); ++r)
+      if (all[r]) {
+        set_error("bg_create_sharded: rank %zu holds an odd number of reads of a paired sample", r);
+        return BG_EINVAL;
+      }
+  }
+  const int rc = create_sharded_impl(ctx, comm, d_seq, d_offs, n_reads, params, readmap, out, stats);
+  if (rc != BG_OK) comm_fail(comm);
+  return rc;
+}
+
+static int create_sharded_impl(bg_ctx* ctx, bg_comm* comm, const uint8_t* d_seq, const uint64_t* d_offs, uint64_t n_reads,
+                               const bg_create_params* params, int readmap, bg_sharded** out, bg_sharded_stats* stats) {
   bg_create_params dflt;
   bg_create_params_default(&dflt);
   const bg_create_params* prm = params ? params : &dflt;

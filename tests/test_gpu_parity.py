@@ -114,11 +114,13 @@ def test_seqset_build_matches_oracle(ctx, seed, alphabet, K, rl, var):
 
 @pytest.mark.parametrize("env", [{"BG_VERIFY_CLOSURE": "1"}, {"BG_PREV_FULL_SEARCH": "1"}, {"BG_NO_MEDIUM_GROUPS": "1"},
                                  {"BG_SMALL_TIES_EARLY": "1"}, {"BG_ENTRIES_UNFUSED": "1"}, {"BG_PREV_MERGE": "1"},
-                                 {"BG_RADIX_ONESWEEP": "1"}])
+                                 {"BG_RADIX_ONESWEEP": "1"}, {"BG_PREV_SEARCH_ALL": "1"},
+                                 {"BG_PREV_SEARCH_ALL": "1", "BG_VERIFY_CLOSURE": "1"}])
 @pytest.mark.parametrize("seed,alphabet,rl", [(11, "ACGT", 150), (12, "AC", 200), (13, "AT", 255)])
 def test_seqset_build_search_modes(ctx, monkeypatch, env, seed, alphabet, rl):
     """(BG_PREV_MERGE: the prev bits as one merge of tails against chunks of entries; BG_RADIX_ONESWEEP: radix passes with
-    decoupled look-back -- both kept for A/B measurements.)
+    decoupled look-back -- both kept for A/B measurements.  BG_PREV_SEARCH_ALL: every entry's tail searched, as before
+    round 5 -- by default the prev bits are set where the sorted records meet and only the listed tails are searched.)
     The prev-bit search on two-word prefixes re-checked against the full-key search (BG_VERIFY_CLOSURE),
     the full-key search alone, the tie handling without the medium-group kernel, the small tie groups ordered by
     k_sort_small_groups instead of inside the entry build's tile, and the unfused entry build: same seqset."""
