@@ -66,52 +66,17 @@ class CreateParams(C.Structure):
     _fields_ = [("kmer_size", C.c_int), ("min_kmer_count", C.c_uint32), ("correct", CorrectParams)]
 
 
-# every symbol include/bgseq.h declares (tests check that the library exports all of them)
-SYMBOLS = [
-    "bg_abi_version", "bg_device_count", "bg_last_error", "bg_ctx_create", "bg_ctx_create_own_stream", "bg_ctx_reserve", "bg_ctx_destroy", "bg_ctx_trim", "bg_ctx_timings",
-    "bg_ctx_set_profiling", "bg_pack_reads", "bg_pack_reads_host", "bg_reads_count", "bg_reads_total_bases",
-    "bg_reads_max_len", "bg_reads_download", "bg_reads_free", "bg_kmer_count", "bg_kmerset_size",
-    "bg_kmerset_distinct", "bg_kmerset_instances", "bg_kmerset_download", "bg_kmerset_free", "bg_correct_reads",
-    "bg_seqset_build", "bg_create_params_default", "bg_create", "bg_seqset_size", "bg_seqset_max_len",
-    "bg_seqset_part", "bg_seqset_arrays", "bg_seqset_entries", "bg_seqset_write", "bg_seqset_open",
-    "bg_seqset_from_arrays", "bg_seqset_free", "bg_walk_counters", "bg_ref_map_write", "bg_ref_map_read", "bg_push_front_batch", "bg_push_front_drop_batch", "bg_pop_front_batch", "bg_find_batch",
-    "bg_dev_alloc", "bg_dev_free", "bg_dev_upload", "bg_dev_download",
-    "bg_trace_one_base_batch", "bg_ref_walk_entries", "bg_tracer_extend_batch", "bg_trace_options_default",
-    "bg_push_trace", "bg_pop_trace", "bg_trace_result_anchor_drops", "bg_push_front_chains", "bg_sha1_file", "bg_tracer_open", "bg_tracer_clone", "bg_tracer_trace", "bg_tracer_trace_async", "bg_trace_result_wait", "bg_tracer_close", "bg_reference_build", "bg_bwt_build", "bg_trace_result_size", "bg_trace_result_get", "bg_trace_result_stats", "bg_trace_result_free", "bg_assemblies_process", "bg_trace_result_new", "bg_trace_result_add", "bg_trace_result_var_count", "bg_trace_result_var", "bg_trace_result_half_aligned_count", "bg_trace_result_half_aligned", "bg_coverage_options_default", "bg_assemblies_coverage", "bg_coverage_open", "bg_coverage_run", "bg_coverage_close", "bg_trace_result_coverage", "bg_trace_result_set_coverage", "bg_assemblies_rvg_exclude", "bg_vcf_record", "bg_walk_chains", "bg_walk_chains_batch", "bg_trace_result_ml", "bg_trace_result_set_ml", "bg_branch_trace_batch", "bg_ref_map_build",
-    "bg_readmap_build", "bg_readmap_build_marked", "bg_seqset_mark_inputs", "bg_readmap_size", "bg_readmap_max_read_len", "bg_readmap_part", "bg_readmap_write",
-    "bg_readmap_free", "bg_create_sample", "bg_readmap_open", "bg_readmap_from_arrays", "bg_readmap_arrays",
-    "bg_cover_filter_build", "bg_cover_query_scan", "bg_cover_query_scan_answers", "bg_cover_query_records_split", "bg_cover_query_records_live",
-    "bg_seqset_find_rows", "bg_readmap_rows", "bg_readmap_shard_build", "bg_readmap_shard_size", "bg_readmap_shard_free",
-    "bg_readmap_shard_first_claims", "bg_readmap_shard_apply_claims", "bg_readmap_shard_take_replies", "bg_readmap_shard_columns", "bg_prefix_reads_batch",
-    "bg_read_info_batch", "bg_propagate_from_end_batch", "bg_push_to_pair_trace_batch",
-    "bg_seqset_merge", "bg_readmap_migrate",
-    "bg_asm_list_create", "bg_asm_list_free", "bg_asm_list_size", "bg_asm_list_add", "bg_asm_list_sort",
-    "bg_asm_list_get", "bg_asm_list_rc_path", "bg_make_ref_assemblies", "bg_graph_trim_ref", "bg_dedup_assemblies",
-    "bg_update_rc_seqset_entries", "bg_discover_branch", "bg_discover_push_to_pair",
-    "bg_ctx_memory", "bg_reference_open", "bg_reference_free", "bg_reference_size", "bg_reference_scaffold_count",
-    "bg_reference_scaffold_name", "bg_reference_scaffold_len", "bg_reference_supercontig_count", "bg_reference_supercontig",
-    "bg_reference_bases",
-    # communicator + N-rank create (csrc/comm.hip, csrc/sharded.hip)
-    "bg_comm_unique_id", "bg_comm_init", "bg_comm_free", "bg_comm_rank", "bg_comm_world", "bg_comm_get_stats", "bg_comm_all_to_all_v",
-    "bg_comm_exchange", "bg_comm_all_gather_host", "bg_comm_all_gather", "bg_comm_all_reduce_sum_u64", "bg_comm_barrier",
-    "bg_create_sharded", "bg_sharded_slice", "bg_sharded_write", "bg_sharded_free",
-    # sharded build
-    "bg_partition_rows", "bg_kmer_instances", "bg_kmer_extract", "bg_kmer_extract_by_owner", "bg_kmer_count_keys", "bg_kmerset_export",
-    "bg_skm_supported", "bg_skm_capacity", "bg_skm_extract_by_owner", "bg_skm_count", "bg_kmerset_attach_presence",
-    "bg_kmerset_from_kmers", "bg_reads_words", "bg_reads_export", "bg_reads_import", "bg_suffix_records",
-    "bg_records_count", "bg_records_words", "bg_records_rows", "bg_records_prefix_hist", "bg_records_from_rows", "bg_records_free",
-    "bg_entries_from_records", "bg_seqset_words", "bg_seqset_boundary_rows", "bg_seqset_fix_boundary",
-    "bg_seqset_tail_rows", "bg_seqset_entry_rows", "bg_seqset_apply_tails", "bg_seqset_slice_export", "bg_seqset_assemble",
-    "bg_oriented_rows", "bg_rows_prefix_hist", "bg_cover_build", "bg_cover_test", "bg_cover_free",
-    "bg_cover_query_begin", "bg_cover_query_pending", "bg_cover_query_candidates", "bg_cover_query_candidates_split", "bg_cover_query_answers",
-    "bg_cover_query_plain", "bg_cover_query_free",
-    "bg_kmerset_build_hash", "bg_skm_lookup", "bg_corr_begin", "bg_corr_step", "bg_corr_answers", "bg_corr_finish",
-    "bg_corr_probes", "bg_corr_free",
-    "bg_seqset_slice_masks", "bg_seqset_slice_build", "bg_seqset_slice_popcounts", "bg_seqset_sharded_create_file",
-    "bg_seqset_slice_write", "bg_fastq_import", "bg_dev_upload_pinned", "bg_dev_upload_file",
-    "bg_torch_allocator_enable", "bg_torch_allocator_enabled", "bg_torch_malloc", "bg_torch_free",
-    "bg_rows_select", "bg_seqset_uuid", "bg_readmap_has_mate_loop", "bg_seqset_tail_rows2", "bg_seqset_apply_tails2", "bg_seqset_tail_rows_full", "bg_records_from_row_parts",
-]
+def _header_symbols():
+    """Every function include/bgseq.h declares: the C ABI is written down once, in the header (the pybind11 module
+    biograph_amd._capi is the SDK seam; this ctypes mirror serves the drivers and the tests and names no symbol list of
+    its own)."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "bgseq.h")
+    with open(hdr) as f:
+        return sorted(set(re.findall(r"\b(bg_[a-z0-9_]+)\s*\(", f.read())))
+
+
+SYMBOLS = _header_symbols()
 
 PART_KMER_HASH, PART_PREFIX, PART_KEY_BOUNDS, PART_ROW_DEST = 0, 1, 2, 3
 

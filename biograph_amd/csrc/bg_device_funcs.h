@@ -610,57 +610,111 @@ BG_HD bool suffix_is_prefix(const uint64_t* aw, int anw, int j, int rem, const u
 // and what a hit needs next — run start or the one candidate, run length or that candidate's length — sits in one
 // 8-byte word per slot instead of three arrays.
 struct CoverIndex {
-  const uint64_t* slots;  // first-K-mers (hash table, 8-slot buckets)
-  const uint64_t* vv;     // per slot: low 32 = start of the K-mer's run in skeys / soid, or kCoverSingle | the one
-                          // candidate; high 32 = length of the run, or of that candidate
+  const uint64_t* slots;  // hash table over the first-K-mers, 8-slot buckets; a slot is ONE word (see cover_slot) that holds what
+                          // a hit needs next as well -- the key's word and a value word in a second array made every hit three
+                          // dependent random sectors (slot, value, candidate), and these look-ups run at the rate this GPU
+                          // serves random sectors
   int log2cap;
   const uint64_t* skeys;  // first-K-mers of the candidate reads, which are sorted by their FULL key
   const uint32_t* soid;   // oriented ids in the same order
-  uint64_t n_o;           // number of candidate reads
+  uint64_t n_o;           // number of candidate reads (< 2^31)
   int K;
   const uint8_t* olen;    // length of every oriented read (by oriented id)
 };
 
-constexpr uint32_t kCoverSingle = 0x80000000u;  // vv[] low word: bit 31 = the run is this one oriented id
+// A slot: [63:40] a 24-bit fingerprint of the K-mer (never all ones: an empty slot is ~0) | [39:32] a length byte | [31] the
+// K-mer's run of candidates is ONE read | [30:0] that read's oriented id, or the start of the run in skeys / soid.  Length
+// byte: the one candidate's length, or min(run length, 255).  A fingerprint that matches a different K-mer costs a look at a
+// candidate that then fails its check (the candidate's words for a single, skeys for a run): never a wrong answer.
+constexpr uint32_t kCoverSingle = 0x80000000u;
+BG_HD uint64_t cover_fingerprint(uint64_t key) {
+  uint64_t f = (key * 0xD6E8FEB86659FD93ull) >> 40;
+  return f == 0xffffffull ? 0xfffffeull : f;
+}
+BG_HD uint64_t cover_slot(uint64_t key, uint32_t len8, bool single, uint32_t id_or_pos) {
+  return (cover_fingerprint(key) << 40) | (uint64_t(len8 & 0xffu) << 32) | (single ? uint64_t(kCoverSingle) : 0ull) | uint64_t(id_or_pos & 0x7fffffffu);
+}
 
 // is suffix j (>= K bases long) of the oriented read s a prefix of some oriented read?
 BG_HD bool cover_probe(const CoverIndex& ci, const uint64_t* owords, const uint64_t* s, int L, int j, int W) {
   const int rem = L - j;
-  uint64_t key = window32(s, W, j) >> (64 - 2 * ci.K);
-  int64_t h = table_find(ci.slots, ci.log2cap, key, ~0ull);
-  if (h < 0) return false;
-  const uint64_t vv = ci.vv[h];
-  const uint32_t v = uint32_t(vv);
-  if (v & kCoverSingle) {
-    uint32_t c = v & ~kCoverSingle;
-    return int(vv >> 32) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W);
-  }
-  // the candidates of this K-mer are in full-key order: the first one that is not smaller than the suffix is
-  // the only one that can have it as a prefix (anything between a string and one of its extensions extends it)
-  uint64_t lo = v, hi = uint64_t(v) + (vv >> 32);
-  const uint64_t end = hi;
-  if (hi - lo <= 4) {  // a handful (mates, duplicates): just try them
-    for (uint64_t p = lo; p < hi; ++p) {
-      const uint32_t c = ci.soid[p];
-      if (int(ci.olen[c]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) return true;
+  const uint64_t key = window32(s, W, j) >> (64 - 2 * ci.K);
+  const uint64_t fp = cover_fingerprint(key);
+  const uint64_t mask = (1ull << ci.log2cap) - 1;
+  uint64_t b = hash_slot(key, ci.log2cap);
+  for (;;) {
+    uint64_t v[kBucketSlots];
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ulonglong2* p = reinterpret_cast<const ulonglong2*>(ci.slots + b);
+#pragma unroll
+    for (int u = 0; u < kBucketSlots / 2; ++u) {  // all the 16-byte loads of the bucket in flight together
+      const ulonglong2 x = p[u];
+      v[2 * u] = x.x;
+      v[2 * u + 1] = x.y;
     }
-    return false;
-  }
-  while (lo < hi) {
-    const uint64_t mid = (lo + hi) >> 1;
-    const uint32_t c = ci.soid[mid];
-    const uint64_t* cw = owords + uint64_t(c) * W;
-    int cmp = 0;  // candidate vs suffix in (words, length) order; the suffix's words are zero padded like any key
-    for (int w = 0; w < W && cmp == 0; ++w) {
-      const uint64_t a = cw[w], b = window32(s, W, j + 32 * w);
-      cmp = a < b ? -1 : (a > b ? 1 : 0);
+#else
+    for (int u = 0; u < kBucketSlots; ++u) v[u] = ci.slots[b + u];
+#endif
+    uint32_t hit = 0, empty = 0;
+#pragma unroll
+    for (int u = 0; u < kBucketSlots; ++u) {
+      hit |= uint32_t((v[u] >> 40) == fp && v[u] != kEmptySlot) << u;
+      empty |= uint32_t(v[u] == kEmptySlot) << u;
     }
-    if (cmp == 0) cmp = int(ci.olen[c]) < rem ? -1 : 0;
-    if (cmp < 0) lo = mid + 1; else hi = mid;
+    while (hit) {
+      int u = 0;
+      while (!((hit >> u) & 1u)) ++u;
+      hit &= hit - 1;
+      uint64_t sv = 0;
+#pragma unroll
+      for (int q = 0; q < kBucketSlots; ++q) sv = q == u ? v[q] : sv;  // (constant indices: v stays in registers)
+      const uint32_t lo32 = uint32_t(sv), len8 = uint32_t(sv >> 32) & 0xffu;
+      if (lo32 & kCoverSingle) {
+        const uint32_t c = lo32 & ~kCoverSingle;
+        // (a candidate shorter than the suffix cannot cover it; a fingerprint shared with another K-mer fails the compare)
+        if (int(len8) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) return true;
+        continue;
+      }
+      uint64_t lo = lo32;
+      if (lo >= ci.n_o || ci.skeys[lo] != key) continue;  // another K-mer's run behind the same fingerprint
+      uint64_t hi = lo + len8;
+      if (len8 == 255) {  // a long run (a repeat family): its end is the first candidate with another K-mer
+        uint64_t a = lo + 255, z = ci.n_o;
+        while (a < z) {
+          const uint64_t mid = (a + z) >> 1;
+          if (ci.skeys[mid] == key) a = mid + 1; else z = mid;
+        }
+        hi = a;
+      }
+      const uint64_t end = hi;
+      // the candidates of this K-mer are in full-key order: the first one that is not smaller than the suffix is
+      // the only one that can have it as a prefix (anything between a string and one of its extensions extends it)
+      if (hi - lo <= 4) {  // a handful (mates, duplicates): just try them
+        for (uint64_t q = lo; q < hi; ++q) {
+          const uint32_t c = ci.soid[q];
+          if (int(ci.olen[c]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) return true;
+        }
+        return false;  // (this was the K-mer's run: no other slot holds it)
+      }
+      while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        const uint32_t c = ci.soid[mid];
+        const uint64_t* cw = owords + uint64_t(c) * W;
+        int cmp = 0;  // candidate vs suffix in (words, length) order; the suffix's words are zero padded like any key
+        for (int w = 0; w < W && cmp == 0; ++w) {
+          const uint64_t a = cw[w], bb = window32(s, W, j + 32 * w);
+          cmp = a < bb ? -1 : (a > bb ? 1 : 0);
+        }
+        if (cmp == 0) cmp = int(ci.olen[c]) < rem ? -1 : 0;
+        if (cmp < 0) lo = mid + 1; else hi = mid;
+      }
+      if (lo >= end) return false;
+      const uint32_t c = ci.soid[lo];
+      return int(ci.olen[c]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W);
+    }
+    if (empty) return false;
+    b = (b + kBucketSlots) & mask;
   }
-  if (lo >= end) return false;
-  const uint32_t c = ci.soid[lo];
-  return int(ci.olen[c]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W);
 }
 
 // number of suffix records oriented read o emits (0 for a dropped read)

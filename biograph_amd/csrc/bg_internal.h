@@ -243,7 +243,7 @@ struct bg_readmap {
 
 namespace bg {
 struct CoverStore {  // device buffers behind a CoverIndex (bg_device_funcs.h)
-  DevBuf<uint64_t> skeys, slots, vv;
+  DevBuf<uint64_t> skeys, slots;
   DevBuf<uint32_t> soid;
   CoverIndex ci;
   const uint64_t* owords = nullptr;

@@ -65,22 +65,23 @@ __global__ void k_flag_key_heads(const uint64_t* __restrict__ keys, uint64_t n, 
   flags[i] = (k != ~0ull && (i == 0 || k != keys[i - 1])) ? 1 : 0;
 }
 
-// cover index: hash from first-K-mer to the start of its run in the sorted (key, oriented id) list
-// A run of one candidate (the usual case) stores the candidate's oriented id itself, flagged in bit 31, so
-// that a hit costs one dependent load less than going through the sorted list.
+// cover index: hash from first-K-mer to the start of its run in the sorted (key, oriented id) list, one word per slot
+// (cover_slot, bg_device_funcs.h).  A run of one candidate (the usual case) stores the candidate's oriented id and length
+// in the slot itself: a hit goes from the slot straight to the candidate's words.
 __global__ void k_cover_insert(const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ soid,
                                const uint8_t* __restrict__ olen, uint64_t n_o, const uint32_t* __restrict__ head_pos,
-                               uint64_t nheads, uint64_t* __restrict__ slots, uint64_t* __restrict__ vv, int log2cap) {
+                               uint64_t nheads, uint64_t* __restrict__ slots, int log2cap) {
   uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r >= nheads) return;
-  uint32_t pos = head_pos[r];
-  uint64_t key = skeys[pos];
-  uint64_t second = (r + 1 < nheads ? uint64_t(head_pos[r + 1]) : n_o) - pos;  // run length
-  const bool single = n_o < (1ull << 31) && second == 1;
-  if (single) {
+  const uint32_t pos = head_pos[r];
+  const uint64_t key = skeys[pos];
+  const uint64_t run = (r + 1 < nheads ? uint64_t(head_pos[r + 1]) : n_o) - pos;
+  uint64_t word;
+  if (run == 1) {
     const uint32_t c = soid[pos];
-    pos = kCoverSingle | c;
-    second = olen[c];  // the candidate's length: a hit needs it before anything else
+    word = cover_slot(key, olen[c], true, c);
+  } else {
+    word = cover_slot(key, uint32_t(run < 255 ? run : 255), false, pos);
   }
   uint64_t mask = (1ull << log2cap) - 1;
   uint64_t s = hash_slot(key, log2cap);
@@ -90,8 +91,8 @@ __global__ void k_cover_insert(const uint64_t* __restrict__ skeys, const uint32_
       uint64_t t = s + ((off + u) & (kBucketSlots - 1));
       if (slots[t] != kEmptySlot) continue;
       unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&slots[t]),
-                                         (unsigned long long)kEmptySlot, (unsigned long long)key);
-      if (old == kEmptySlot) { vv[t] = (second << 32) | pos; return; }
+                                         (unsigned long long)kEmptySlot, (unsigned long long)word);
+      if (old == kEmptySlot) return;
     }
     s = (s + kBucketSlots) & mask;
   }
@@ -582,7 +583,11 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_lcp_keep(
 // transitive through prefixes); a tile's first survivor gets it from k_fix_tile_first_shared.
 constexpr uint64_t kScanAgg = 1ull << 62, kScanIncl = 2ull << 62, kScanVal = (1ull << 62) - 1;
 
+#ifdef BG_EXP_FUSEDPOS
+constexpr int kFusedPos = BG_EXP_FUSEDPOS;             // (timing experiment)
+#else
 constexpr int kFusedPos = 2;                           // sorted positions per thread
+#endif
 constexpr int kFusedTile = kGatherTile * kFusedPos;    // positions per tile: twice the data in flight per wave and
                                                        // half the look-backs of a 256-position tile
 // sort_small: the tie groups of at most kTileGroup records come unordered (k_sort_small_groups, defer) and are put
@@ -674,6 +679,12 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
     }
   }
   __syncthreads();
+#ifdef BG_EXP_GATHER_ONLY  // timing experiment (tools/build_variant.sh): what the gather alone costs -- the tile's rows straight out again
+  for (int x = tid; x < kFusedTile * W; x += kGatherTile)
+    if (b0 * W + x < n * uint64_t(W)) ekeys[b0 * W + x] = tile[H * W + x];
+  if (tid == 0 && b0 + kFusedTile >= n) state[(n + kFusedTile - 1) / kFusedTile - 1] = kScanIncl | n;
+  return;
+#endif
   // pmap[i] = the slot whose row belongs at slot i.  Every member of a small group finds its rank in the group by
   // comparing its row with the others' (all members at once, a few LDS reads each: one lane per group moving rows
   // about made the kernel 5 ms longer); the rows stay where they are.
@@ -1624,7 +1635,7 @@ int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p,
 // made the oriented words.  The store keeps pointers into owords / olen: they must outlive it.
 int cover_index_build(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, uint64_t n_o, int W, int cover_k,
                       DevBuf<uint64_t>* k0o, CoverStore* cs) {
-  if (n_o >= (1ull << 32)) { set_error("too many reads for one cover index (%llu oriented)", (unsigned long long)n_o); return BG_EINVAL; }
+  if (n_o >= (1ull << 31)) { set_error("too many reads for one cover index (%llu oriented)", (unsigned long long)n_o); return BG_EINVAL; }
   DevBuf<uint32_t> head_pos;
   uint64_t m = 0, nheads = 0;  // reads that can act as a cover, distinct first K-mers
   {
@@ -1652,15 +1663,13 @@ int cover_index_build(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, 
   // beyond 2 GiB where random probes fall off the TLB reach (tools/probe_rate.hip: 55 -> 22 G probes/s at 4 GiB)
   while ((1ull << lg) * 7 < nheads * 10) ++lg;
   BG_TRY(cs->slots.alloc(ctx, 1ull << lg));
-  BG_TRY(cs->vv.alloc(ctx, 1ull << lg));
   BG_HIP(hipMemsetAsync(cs->slots.p, 0xff, (1ull << lg) * 8, ctx->stream));
   if (nheads) {
-    k_cover_insert<<<cdiv(nheads, 256), 256, 0, ctx->stream>>>(cs->skeys.p, cs->soid.p, olen, m, head_pos.p, nheads, cs->slots.p,
-                                                               cs->vv.p, lg);
+    k_cover_insert<<<cdiv(nheads, 256), 256, 0, ctx->stream>>>(cs->skeys.p, cs->soid.p, olen, m, head_pos.p, nheads, cs->slots.p, lg);
     BG_LAUNCH_CHECK();
   }
   BG_HIP(hipStreamSynchronize(ctx->stream));  // head_pos goes out of scope
-  cs->ci = CoverIndex{cs->slots.p, cs->vv.p, lg, cs->skeys.p, cs->soid.p, m, cover_k, olen};
+  cs->ci = CoverIndex{cs->slots.p, lg, cs->skeys.p, cs->soid.p, m, cover_k, olen};
   cs->owords = owords;
   return BG_OK;
 }
@@ -1673,7 +1682,7 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   const uint64_t n = reads->n;
   const uint64_t n_o = 2 * n;
   const int W = reads->W;
-  if (n_o >= (1ull << 32)) { set_error("too many reads for one cover index (%llu)", (unsigned long long)n); return BG_EINVAL; }
+  if (n_o >= (1ull << 31)) { set_error("too many reads for one cover index (%llu)", (unsigned long long)n); return BG_EINVAL; }
   if (lo > hi || hi > n) { set_error("bad read range"); return BG_EINVAL; }
   const uint64_t o_base = 2 * lo, n_emit = 2 * (hi - lo);
   uint64_t n_rec = 0;

@@ -22,9 +22,14 @@ def lib():
 def test_header_symbols_are_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "bgseq.h")).read()
     declared = set(re.findall(r"\b(bg_[a-z0-9_]+)\s*\(", hdr))
-    assert declared == set(capi.SYMBOLS)
+    assert declared == set(capi.SYMBOLS) and len(declared) > 200  # (capi reads its list from the header)
     for name in declared:
         assert hasattr(lib, name), name
+    # and nothing else: every exported bg_* function of the library is declared in the header
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("bg_")}
+    assert exported == declared, sorted(exported ^ declared)
     assert lib.bg_abi_version() == 2
 
 

@@ -144,6 +144,33 @@ def test_fullsize_eight_rank_routed_build_written_in_slices_equals_fused(built, 
         opened.free()
 
 
+def test_fullsize_native_driver_equals_fused(built, tmp_path):
+    """The C++ driver `bgbinary create --gpus N` runs (bg_create_sharded + bg_sharded_write, csrc/sharded.hip over csrc/comm.hip)
+    on a rank alone at the bench size and at one rank's share of the whole human: the routed phases, the slice written in place
+    -- the container opens as the fused build's seqset, member for member.  (Several real ranks: tests/test_gpu_native_sharded.py,
+    2, 3 and 8 processes on a smaller sample.)"""
+    ctx, ss, st, (seq, offs, n) = built
+    want = {k: hashlib.sha256(v).hexdigest() for k, v in ss.parts().items()}
+    comm = sharded.NativeComm(ctx, 0, 1, sharded.NativeComm.unique_id(), "rccl")
+    try:
+        sh = sharded.native_create(ctx, comm, seq.data_ptr(), offs.data_ptr(), n, ctx.default_params())
+        try:
+            for key in ("n_kept_kmers", "n_corrected_reads", "n_corrected_bases", "n_records", "n_entries"):
+                assert sh.stats[key] == st[key], key
+            path = str(tmp_path / "seqset_native")
+            sh.write(comm, path, None, ["test_gpu_fullsize"])
+        finally:
+            sh.free()
+    finally:
+        comm.free()
+    opened = ctx.open_seqset(path)
+    try:
+        got = {k: hashlib.sha256(v).hexdigest() for k, v in opened.parts().items()}
+        assert {k: got[k] for k in bg.PART_NAMES} == {k: want[k] for k in bg.PART_NAMES}
+    finally:
+        opened.free()
+
+
 def test_fullsize_discovery_engine_properties():
     """The reference's discovery engine end to end at the bench size (tools/discovery_bench.py: FASTQ -> `bgbinary
     create` -> `bgbinary discovery`, 65 pieces x 2 directions): too big for the oracle, so the VCF is checked against

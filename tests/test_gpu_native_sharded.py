@@ -113,7 +113,7 @@ def test_one_rank_through_rccl_in_many_small_groups(sample):
     _same(d, "fused_inter.bg", "w1p.bg")
 
 
-@pytest.mark.parametrize("ranks", [2, 3])
+@pytest.mark.parametrize("ranks", [2, 3, 8])
 def test_real_processes_sharing_the_gpu_equal_fused(sample, ranks):
     """--comm shm: `ranks` processes, each importing its own stretch of both FASTQ files (names of different lengths: the stretches are
     found by counting lines), one sample built together, one seqset container written in place by all, the readmap by rank 0."""
