@@ -15,6 +15,7 @@
 #include <string.h>
 #include <sys/syscall.h>
 #include <sys/time.h>
+#include <sys/uio.h>
 #include <time.h>
 #include <unistd.h>
 #include <ucontext.h>
@@ -47,7 +48,11 @@ inline void on_prof(int, siginfo_t*, void* uc_) {
     s.pc[k] = 0;
     // a frame pointer that is a plausible stack address just above the stack pointer; anything else ends the walk
     if (fp < sp || fp - sp > (uint64_t(8) << 20) || (fp & 7)) { fp = 0; continue; }
-    const uint64_t* f = reinterpret_cast<const uint64_t*>(fp);
+    // read through the kernel: a thread may be on a 512 KiB fiber stack (csrc/fiber.h) with nothing mapped above it, and a
+    // stale rbp must end the walk, not the process
+    uint64_t f[2] = {0, 0};
+    iovec lv{f, sizeof f}, rv{reinterpret_cast<void*>(fp), sizeof f};
+    if (process_vm_readv(getpid(), &lv, 1, &rv, 1, 0) != ssize_t(sizeof f)) { fp = 0; continue; }
     s.pc[k] = f[1];
     const uint64_t next = f[0];
     fp = next > fp ? next : 0;

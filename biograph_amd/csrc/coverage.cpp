@@ -958,6 +958,10 @@ extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64
                 }
               } catch (const CheckFailed& e) {
                 note_error(e.what);
+              } catch (const std::exception& e) {  // nothing may unwind past a fiber's entry frame (fiber.h): bad_alloc, length_error
+                note_error(std::string("coverage: ") + e.what());
+              } catch (...) {
+                note_error("coverage: an island ended on an unknown exception");
               }
             };
             if (!f.fiber.start(&th.sched, size_t(512) << 10, body)) { note_error("coverage: no memory for an island's stack"); fibers.pop_back(); break; }
