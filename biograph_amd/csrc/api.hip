@@ -251,43 +251,28 @@ extern "C" int bg_ctx_reserve(bg_ctx* ctx, uint64_t bytes) {
   if (!ctx) { set_error("bg_ctx_reserve: null argument"); return BG_EINVAL; }
   if (!bytes) return BG_OK;
   BG_HIP(hipSetDevice(ctx->device));
-  const size_t piece = size_t(256) << 20;
+  // BG_RESERVE_MODE (measurements, tools/map_rate.hip): "malloc" = one hipMalloc of the whole size, "vmm1g" = the address
+  // range below in 1 GiB pieces instead of 256 MiB ones
+  const char* mode = getenv("BG_RESERVE_MODE");
+  if (mode && !strcmp(mode, "malloc")) {
+    void* base = nullptr;
+    const size_t seg = (size_t(bytes) + (size_t(1) << 21) - 1) & ~((size_t(1) << 21) - 1);
+    if (hipMalloc(&base, seg) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("bg_ctx_reserve: the driver refused %zu MiB", seg >> 20);
+      return BG_ENOMEM;
+    }
+    std::lock_guard<std::mutex> lock(ctx->arena_mutex());
+    ctx->arena->adopt(base, seg);
+    return BG_OK;
+  }
+  // one address range, a gigabyte of physical memory mapped into it at a time (between two pieces everybody else gets
+  // through the driver; 256 MiB pieces, the first version, turned out to be the slow way: 60 us per MiB against 1.6)
+  const size_t piece = (mode && !strcmp(mode, "vmm256")) ? size_t(256) << 20 : size_t(1) << 30;
   const size_t seg = (size_t(bytes) + piece - 1) & ~(piece - 1);
-  // One hipMalloc of this size holds the driver's lock for as long as the mapping takes (the context's own copies and
-  // launches wait behind it: measured, the import of a create went from 0.6 s to 2.2 s).  So: one address range, physical
-  // memory mapped into it 256 MiB at a time; between two pieces everybody else gets through.
-  hipMemAllocationProp prop = {};
-  prop.type = hipMemAllocationTypePinned;
-  prop.location.type = hipMemLocationTypeDevice;
-  prop.location.id = ctx->device;
-  hipMemAccessDesc access = {};
-  access.location = prop.location;
-  access.flags = hipMemAccessFlagsProtReadWrite;
-  void* base = nullptr;
-  if (hipMemAddressReserve(&base, seg, piece, nullptr, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    set_error("bg_ctx_reserve: no address range of %zu MiB", seg >> 20);
-    return BG_ENOMEM;
-  }
-  size_t done = 0;
-  for (; done < seg; done += piece) {
-    hipMemGenericAllocationHandle_t h;
-    char* at = static_cast<char*>(base) + done;
-    if (hipMemCreate(&h, piece, &prop, 0) != hipSuccess) break;
-    const bool mapped = hipMemMap(at, piece, 0, h, 0) == hipSuccess;
-    const bool ok = mapped && hipMemSetAccess(at, piece, &access, 1) == hipSuccess;
-    if (mapped && !ok) (void)hipMemUnmap(at, piece);  // a piece nobody may touch does not stay mapped
-    (void)hipMemRelease(h);  // the mapping keeps the memory
-    if (!ok) break;
-  }
-  if (done < seg) {  // out of memory part of the way: what is mapped stays usable; the whole range is returned with it later
-    (void)hipGetLastError();
-    if (!done) { (void)hipMemAddressFree(base, seg); set_error("bg_ctx_reserve: the driver refused %zu MiB", seg >> 20); return BG_ENOMEM; }
-  }
-  {
-    std::lock_guard<std::mutex> l(g_vmm_mutex);
-    g_vmm_segments[base] = VmmSegment{seg, done, piece};
-  }
+  void* base = vmm_segment(ctx->device, seg, piece);
+  if (!base) { set_error("bg_ctx_reserve: the driver refused %zu MiB", seg >> 20); return BG_ENOMEM; }
+  const size_t done = seg;
   std::lock_guard<std::mutex> lock(ctx->arena_mutex());
   ctx->arena->adopt(base, done);
   return BG_OK;

@@ -26,13 +26,19 @@
 
 namespace bg {
 
+// a backend may name the multiple its large segments come in (kLargeRound); 256 MiB otherwise
+template <class B, class = void>
+struct ArenaLargeRound { static constexpr size_t value = size_t(256) << 20; };
+template <class B>
+struct ArenaLargeRound<B, decltype(void(B::kLargeRound))> { static constexpr size_t value = B::kLargeRound; };
+
 template <class Backend>
 class Arena {
  public:
   static constexpr size_t kAlign = 512;
   static constexpr size_t kSmallLimit = size_t(1) << 20;    // requests below this use the small segments
   static constexpr size_t kSmallSegment = size_t(32) << 20;
-  static constexpr size_t kLargeRound = size_t(256) << 20;
+  static constexpr size_t kLargeRound = ArenaLargeRound<Backend>::value;
   static constexpr size_t kMinSplit = size_t(1) << 20;      // a large chunk is not split for a smaller remainder
 
   explicit Arena(Backend b = Backend()) : backend_(b) {}

@@ -635,85 +635,112 @@ BG_HD uint64_t cover_slot(uint64_t key, uint32_t len8, bool single, uint32_t id_
   return (cover_fingerprint(key) << 40) | (uint64_t(len8 & 0xffu) << 32) | (single ? uint64_t(kCoverSingle) : 0ull) | uint64_t(id_or_pos & 0x7fffffffu);
 }
 
+// What one slot says about suffix j (rem bases from base j on, first K-mer `key`) of the oriented read s:
+// 1 = a candidate of the slot covers it, 0 = the slot holds the suffix's own K-mer and none of its candidates does,
+// -1 = the slot belongs to another K-mer with the same fingerprint.
+BG_HD int cover_check_slot(const CoverIndex& ci, const uint64_t* owords, const uint64_t* s, int j, int rem, int W, uint64_t key,
+                           uint64_t sv) {
+  const uint32_t lo32 = uint32_t(sv), len8 = uint32_t(sv >> 32) & 0xffu;
+  if (lo32 & kCoverSingle) {
+    const uint64_t* cw = owords + uint64_t(lo32 & ~kCoverSingle) * W;
+    // (a candidate shorter than the suffix cannot cover it)
+    if (int(len8) >= rem && suffix_is_prefix(s, W, j, rem, cw)) return 1;
+    return (cw[0] >> (64 - 2 * ci.K)) == key ? 0 : -1;
+  }
+  uint64_t lo = lo32;
+  if (lo >= ci.n_o || ci.skeys[lo] != key) return -1;
+  uint64_t hi = lo + len8;
+  if (len8 == 255) {  // a long run (a repeat family): its end is the first candidate with another K-mer
+    uint64_t a = lo + 255, z = ci.n_o;
+    while (a < z) {
+      const uint64_t mid = (a + z) >> 1;
+      if (ci.skeys[mid] == key) a = mid + 1; else z = mid;
+    }
+    hi = a;
+  }
+  const uint64_t end = hi;
+  // the candidates of this K-mer are in full-key order: the first one that is not smaller than the suffix is
+  // the only one that can have it as a prefix (anything between a string and one of its extensions extends it)
+  if (hi - lo <= 4) {  // a handful (mates, duplicates): just try them
+    for (uint64_t q = lo; q < hi; ++q) {
+      const uint32_t c = ci.soid[q];
+      if (int(ci.olen[c]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) return 1;
+    }
+    return 0;
+  }
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    const uint32_t c = ci.soid[mid];
+    const uint64_t* cw = owords + uint64_t(c) * W;
+    int cmp = 0;  // candidate vs suffix in (words, length) order; the suffix's words are zero padded like any key
+    for (int w = 0; w < W && cmp == 0; ++w) {
+      const uint64_t a = cw[w], bb = window32(s, W, j + 32 * w);
+      cmp = a < bb ? -1 : (a > bb ? 1 : 0);
+    }
+    if (cmp == 0) cmp = int(ci.olen[c]) < rem ? -1 : 0;
+    if (cmp < 0) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= end) return 0;
+  const uint32_t c = ci.soid[lo];
+  return int(ci.olen[c]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W) ? 1 : 0;
+}
+
+// first slot at or after `from` (a slot index; the chain is walked bucket by bucket) whose fingerprint is fp, or -1 at the
+// chain's first empty slot.  (The bucket's words die here: the caller reads the one slot again -- kept alive through the
+// candidate checks they took a quarter of k_cover_count's waves.)
+BG_HD int64_t cover_find(const uint64_t* slots, int log2cap, uint64_t fp, uint64_t from) {
+  const uint64_t mask = (1ull << log2cap) - 1;
+  uint64_t b = from & ~uint64_t(kBucketSlots - 1);
+  uint32_t skip = (1u << (from & (kBucketSlots - 1))) - 1;  // slots of the first bucket before `from`
+  for (;;) {
+    uint64_t v[kBucketSlots];
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ulonglong2* p = reinterpret_cast<const ulonglong2*>(slots + b);
+#pragma unroll
+    for (int q = 0; q < kBucketSlots / 2; ++q) {  // all the 16-byte loads of the bucket in flight together
+      const ulonglong2 x = p[q];
+      v[2 * q] = x.x;
+      v[2 * q + 1] = x.y;
+    }
+#else
+    for (int q = 0; q < kBucketSlots; ++q) v[q] = slots[b + q];
+#endif
+    uint32_t hit = 0, empty = 0;
+#pragma unroll
+    for (int q = 0; q < kBucketSlots; ++q) {
+      hit |= uint32_t((v[q] >> 40) == fp && v[q] != kEmptySlot) << q;
+      empty |= uint32_t(v[q] == kEmptySlot) << q;
+    }
+    hit &= ~skip;
+    if (hit) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      return int64_t(b) + (__ffs(int(hit)) - 1);
+#else
+      int u = 0;
+      while (!((hit >> u) & 1u)) ++u;
+      return int64_t(b) + u;
+#endif
+    }
+    if (empty) return -1;  // (an insert takes the first bucket of its chain with a free slot)
+    skip = 0;
+    b = (b + kBucketSlots) & mask;
+  }
+}
+
 // is suffix j (>= K bases long) of the oriented read s a prefix of some oriented read?
 BG_HD bool cover_probe(const CoverIndex& ci, const uint64_t* owords, const uint64_t* s, int L, int j, int W) {
   const int rem = L - j;
   const uint64_t key = window32(s, W, j) >> (64 - 2 * ci.K);
   const uint64_t fp = cover_fingerprint(key);
-  const uint64_t mask = (1ull << ci.log2cap) - 1;
-  uint64_t b = hash_slot(key, ci.log2cap);
+  uint64_t from = hash_slot(key, ci.log2cap);
   for (;;) {
-    uint64_t v[kBucketSlots];
-#if defined(__HIP_DEVICE_COMPILE__)
-    const ulonglong2* p = reinterpret_cast<const ulonglong2*>(ci.slots + b);
-#pragma unroll
-    for (int u = 0; u < kBucketSlots / 2; ++u) {  // all the 16-byte loads of the bucket in flight together
-      const ulonglong2 x = p[u];
-      v[2 * u] = x.x;
-      v[2 * u + 1] = x.y;
-    }
-#else
-    for (int u = 0; u < kBucketSlots; ++u) v[u] = ci.slots[b + u];
-#endif
-    uint32_t hit = 0, empty = 0;
-#pragma unroll
-    for (int u = 0; u < kBucketSlots; ++u) {
-      hit |= uint32_t((v[u] >> 40) == fp && v[u] != kEmptySlot) << u;
-      empty |= uint32_t(v[u] == kEmptySlot) << u;
-    }
-    while (hit) {
-      int u = 0;
-      while (!((hit >> u) & 1u)) ++u;
-      hit &= hit - 1;
-      uint64_t sv = 0;
-#pragma unroll
-      for (int q = 0; q < kBucketSlots; ++q) sv = q == u ? v[q] : sv;  // (constant indices: v stays in registers)
-      const uint32_t lo32 = uint32_t(sv), len8 = uint32_t(sv >> 32) & 0xffu;
-      if (lo32 & kCoverSingle) {
-        const uint32_t c = lo32 & ~kCoverSingle;
-        // (a candidate shorter than the suffix cannot cover it; a fingerprint shared with another K-mer fails the compare)
-        if (int(len8) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) return true;
-        continue;
-      }
-      uint64_t lo = lo32;
-      if (lo >= ci.n_o || ci.skeys[lo] != key) continue;  // another K-mer's run behind the same fingerprint
-      uint64_t hi = lo + len8;
-      if (len8 == 255) {  // a long run (a repeat family): its end is the first candidate with another K-mer
-        uint64_t a = lo + 255, z = ci.n_o;
-        while (a < z) {
-          const uint64_t mid = (a + z) >> 1;
-          if (ci.skeys[mid] == key) a = mid + 1; else z = mid;
-        }
-        hi = a;
-      }
-      const uint64_t end = hi;
-      // the candidates of this K-mer are in full-key order: the first one that is not smaller than the suffix is
-      // the only one that can have it as a prefix (anything between a string and one of its extensions extends it)
-      if (hi - lo <= 4) {  // a handful (mates, duplicates): just try them
-        for (uint64_t q = lo; q < hi; ++q) {
-          const uint32_t c = ci.soid[q];
-          if (int(ci.olen[c]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W)) return true;
-        }
-        return false;  // (this was the K-mer's run: no other slot holds it)
-      }
-      while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        const uint32_t c = ci.soid[mid];
-        const uint64_t* cw = owords + uint64_t(c) * W;
-        int cmp = 0;  // candidate vs suffix in (words, length) order; the suffix's words are zero padded like any key
-        for (int w = 0; w < W && cmp == 0; ++w) {
-          const uint64_t a = cw[w], bb = window32(s, W, j + 32 * w);
-          cmp = a < bb ? -1 : (a > bb ? 1 : 0);
-        }
-        if (cmp == 0) cmp = int(ci.olen[c]) < rem ? -1 : 0;
-        if (cmp < 0) lo = mid + 1; else hi = mid;
-      }
-      if (lo >= end) return false;
-      const uint32_t c = ci.soid[lo];
-      return int(ci.olen[c]) >= rem && suffix_is_prefix(s, W, j, rem, owords + uint64_t(c) * W);
-    }
-    if (empty) return false;
-    b = (b + kBucketSlots) & mask;
+    const int64_t h = cover_find(ci.slots, ci.log2cap, fp, from);
+    if (h < 0) return false;
+    const int r = cover_check_slot(ci, owords, s, j, rem, W, key, ci.slots[h]);
+    if (r >= 0) return r != 0;
+    // another K-mer behind the same fingerprint (about one look-up in a million): on along the chain
+    from = uint64_t(h) + 1;
+    if ((from & (kBucketSlots - 1)) == 0) from &= (1ull << ci.log2cap) - 1;
   }
 }
 
@@ -791,7 +818,33 @@ struct SeqsetView {
   // rank look-ups; between two samples lie about a thousand entries = three rank blocks.  Null: the search over everything.
   const uint64_t* sel256[4] = {nullptr, nullptr, nullptr, nullptr};
 
+  // rank4 (round 5): ONE 64-byte block per 96 entries for all four bases -- per base 16 bytes: [set bits before the block,
+  // relative to the group of 65536 blocks it lies in | the block's 96 bits as three words].  A frontier asks for the same two
+  // positions (begin, end) under four bases: with a block array per base those were eight sectors, here they are two, and one
+  // base's look-up is one 16-byte load.  rank4_super[(g >> 16) * 4 + b] = the group's base count.  (rank64 stays for pop_front's
+  // select, whose search walks block heads of ONE base.)
+  const uint32_t* rank4 = nullptr;
+  const uint64_t* rank4_super = nullptr;
+
   BG_HD uint64_t count(int b, uint64_t i) const {  // bitcount.h:218-270
+    if (rank4) {
+      const uint64_t g = i / 96;
+      const unsigned r = unsigned(i - g * 96), w = r >> 5;
+#if defined(__HIP_DEVICE_COMPILE__)
+      const uint4 q = *reinterpret_cast<const uint4*>(rank4 + g * 16 + unsigned(b) * 4);
+      const uint32_t w0 = q.y, w1 = q.z, w2 = q.w, rel = q.x;
+      uint32_t c = __popc((w == 0 ? w0 : (w == 1 ? w1 : w2)) & ((1u << (r & 31)) - 1));
+      if (w > 0) c += __popc(w0);
+      if (w > 1) c += __popc(w1);
+#else
+      const uint32_t* q = rank4 + g * 16 + unsigned(b) * 4;
+      const uint32_t rel = q[0];
+      uint32_t c = uint32_t(__builtin_popcount(q[1 + w] & ((1u << (r & 31)) - 1)));
+      if (w > 0) c += uint32_t(__builtin_popcount(q[1]));
+      if (w > 1) c += uint32_t(__builtin_popcount(q[2]));
+#endif
+      return rank4_super[(g >> 16) * 4 + unsigned(b)] + rel + c;
+    }
     if (rank64[b]) {
       const uint64_t g = i / 384;
       const unsigned r = unsigned(i - g * 384), w = r >> 6;

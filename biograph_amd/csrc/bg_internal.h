@@ -47,8 +47,14 @@ struct bg_ctx {
   hipStream_t stream = nullptr;
   bool owns_stream = false;  // bg_ctx_create_own_stream
   bool profiling = false;
-  // device memory: segments from hipMalloc, sub-allocated best-fit with coalescing (arena.h)
+  // device memory: segments from the driver (hipMalloc), sub-allocated best-fit with coalescing (arena.h).  Large segments
+  // come in multiples of 1 GiB.  Measured (tools/map_rate.hip, tools/e2e_profile.py): hipMalloc of gigabytes costs anything
+  // between nothing and 75 us per MiB depending on what the process and the device have been through (a 27 GB reservation:
+  // 1.3 - 2.2 s; a cold `create` right after another process gave back 50 GB: 0.7 - 0.95 s inside the build), hipMemCreate +
+  // hipMemMap in 1 GiB pieces 1.6 us per MiB (32 GiB: 0.05 s) -- and in 256 MiB pieces 60.  BG_ARENA_VMM=1 takes the segments
+  // that way too (see seg_alloc for why it is not the default); bg_ctx_reserve always does.
   struct HipSegments {
+    static constexpr size_t kLargeRound = size_t(1) << 30;
     void* seg_alloc(size_t n);
     void seg_free(void* p);
   };
@@ -213,6 +219,8 @@ struct bg_seqset {
   bg::DevBuf<uint8_t> sizes, shared;
   bg::DevBuf<uint64_t> bits[4], subaccum[4], accum[4];
   bg::DevBuf<uint64_t> rank64[4];   // one 64-byte rank block per 384 entries (SeqsetView::count): what the walk kernels read
+  bg::DevBuf<uint32_t> rank4;       // one 64-byte rank block per 96 entries, all four bases in it (SeqsetView::count)
+  bg::DevBuf<uint64_t> rank4_super; // base counts of every group of 65536 such blocks, four per group
   bg::DevBuf<uint64_t> sel256[4];   // the entry that carries every 256th set prev bit of a base (pop_front's select), + a sentinel n
   bg::DevBuf<uint8_t> min1, min2;
   uint64_t fixed[5] = {0, 0, 0, 0, 0};
@@ -281,6 +289,7 @@ extern std::mutex g_arena_mutex;
 extern std::mutex g_vmm_mutex;                 // segments built through the virtual-memory API (bg_ctx_reserve)
 struct VmmSegment { size_t reserved, mapped, piece; };  // address range, bytes of it with memory behind them, bytes per mapping
 extern std::map<void*, VmmSegment> g_vmm_segments;
+void* vmm_segment(int device, size_t n, size_t piece);  // prims.hip
 bg_ctx::DeviceArena* shared_arena(int device);  // null unless the hook is installed
 // walk.hip: the read-ahead tables of one walked stretch of a tracer work item (offset after base i = first_off + i),
 // appended to the three lists; the two sorted ones are sorted within this stretch

@@ -103,38 +103,78 @@ __global__ void k_cover_insert(const uint64_t* __restrict__ skeys, const uint32_
 // read with most lanes idle).
 constexpr int kCoverChunk = 1024;  // oriented reads per wave
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cover_count(CoverIndex ci, const uint64_t* __restrict__ owords,
+// The reads of a wave's chunk come in through LDS kCoverBatch at a time, as one run of consecutive words (a lane fetching its own
+// 40-byte row asked for three sectors of its own, one more for its length byte, and wrote its count as a fifth request:
+// half of the ten requests a read cost, in a kernel that runs at the rate requests are served), and the chunk's counts
+// leave as one run at the end.  Dynamic LDS: 256 own rows of `stride` words (W, made odd against bank conflicts), then per
+// wave kCoverBatch staged rows of W words, their lengths and the chunk's counts as bytes.
+__host__ __device__ inline int cover_row_stride(int W) { return W | 1; }
+constexpr int kCoverBatch = 32;  // reads staged at a time per wave
+__host__ __device__ inline size_t cover_count_lds(int W) {
+  return size_t(256) * cover_row_stride(W) * 8 + size_t(4) * (kCoverBatch * W * 8 + kCoverBatch + kCoverChunk);
+}
+__global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void k_cover_count(CoverIndex ci, const uint64_t* __restrict__ owords,
                                                      uint64_t o_base, uint64_t n_emit, int W,
                                                      uint32_t* __restrict__ cnt) {
-  const int lane = threadIdx.x & 63;
+  extern __shared__ uint64_t cc_lds[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t lane_lt = (1ull << lane) - 1;
-  const uint64_t wave = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  uint64_t next = wave * kCoverChunk;
-  const uint64_t end = next + kCoverChunk < n_emit ? next + kCoverChunk : n_emit;
-  // the lane's own read sits in LDS (rows of 9 words: 8 + one of padding against bank conflicts): every probe cuts
-  // its key out of it and the prefix check walks it, and from global memory those were half the kernel's requests
-  __shared__ uint64_t own[256 * (kMaxWords + 1)];
-  uint64_t* const s = own + threadIdx.x * (kMaxWords + 1);
+  const uint64_t chunk0 = (uint64_t(blockIdx.x) * 4 + wv) * kCoverChunk;
+  if (chunk0 >= n_emit) return;  // (wave-uniform)
+  const uint32_t end = uint32_t(n_emit - chunk0 < uint64_t(kCoverChunk) ? n_emit - chunk0 : uint64_t(kCoverChunk));  // reads of this chunk
+  const int stride = cover_row_stride(W);
+  uint64_t* const s = cc_lds + threadIdx.x * stride;                   // the lane's own read
+  uint64_t* const st = cc_lds + 256 * stride + wv * kCoverBatch * W;   // the wave's staged batch
+  uint8_t* const bytes = reinterpret_cast<uint8_t*>(cc_lds + 256 * stride + 4 * kCoverBatch * W);
+  uint8_t* const st_len = bytes + wv * kCoverBatch;
+  uint8_t* const counts = bytes + 4 * kCoverBatch + wv * kCoverChunk;
+  const uint64_t* const chunk_words = owords + (o_base + chunk0) * uint64_t(W);  // (16-byte aligned: o_base even, chunk0 and the batches' starts even)
+  uint32_t next = 0, sbase = ~0u, t = 0;  // reads of the chunk by their number in it
   bool active = false;
-  uint64_t t = 0;
   int L = 0, j = 0, c = 0;
   for (;;) {
     const uint64_t need = __ballot(!active);
     if (need) {
-      if (!active) {
-        const uint64_t mine = next + uint64_t(__popcll(need & lane_lt));
-        if (mine < end) {
+      const uint32_t mine = next + uint32_t(__popcll(need & lane_lt));
+      bool want = !active && mine < end;
+      next += uint32_t(__popcll(need));
+      for (;;) {
+        const uint64_t wm = __ballot(want);
+        if (!wm) break;
+        // the batch that holds the smallest wanted read (the wanting lanes' reads ascend with the lane)
+        const uint32_t bb = uint32_t(__shfl(int(mine), __ffsll((unsigned long long)wm) - 1, 64)) & ~uint32_t(kCoverBatch - 1);
+        if (bb != sbase) {
+          const uint32_t rows = end - bb < uint32_t(kCoverBatch) ? end - bb : uint32_t(kCoverBatch);
+          const uint32_t nw = rows * uint32_t(W);
+          const uint64_t* src = chunk_words + uint64_t(bb) * uint64_t(W);
+          const ulonglong2* src2 = reinterpret_cast<const ulonglong2*>(src);
+          for (uint32_t x = uint32_t(lane); x * 2 + 1 < nw; x += 64) {
+            const ulonglong2 v = src2[x];
+            st[2 * x] = v.x;
+            st[2 * x + 1] = v.y;
+          }
+          if ((nw & 1u) && lane == 0) st[nw - 1] = src[nw - 1];
+          if (uint32_t(lane) < rows) st_len[lane] = ci.olen[o_base + chunk0 + bb + uint32_t(lane)];
+          sbase = bb;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (want && mine < sbase + uint32_t(kCoverBatch)) {
           t = mine;
-          const uint64_t o = o_base + t;
-          L = ci.olen[o];
-          for (int w = 0; w < W; ++w) s[w] = owords[o * uint64_t(W) + w];
+          const int q = int(mine - sbase);
+          L = st_len[q];
+          for (int w = 0; w < W; ++w) s[w] = st[q * W + w];
           j = 1;
           c = 1;
-          if (L <= 1) cnt[t] = uint32_t(L);  // dropped read: nothing; one base: itself
+          if (L <= 1) counts[t] = uint8_t(L);  // dropped read: nothing; one base: itself
           else active = true;
+          want = false;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // (the stage is free again once every lane that wanted one of its rows has it)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-      next += uint64_t(__popcll(need));
     }
     if (!__ballot(active)) {
       if (next >= end) break;
@@ -146,9 +186,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_co
       if (rem < ci.K) { c += rem; fin = true; }
       else if (cover_probe(ci, owords, s, L, j, W)) fin = true;
       else { ++c; ++j; fin = j >= L; }
-      if (fin) { cnt[t] = uint32_t(c); active = false; }
+      if (fin) { counts[t] = uint8_t(c); active = false; }
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (uint32_t x = uint32_t(lane); x < end; x += 64) cnt[chunk0 + x] = counts[x];
 }
 
 // records: rows of RS words, rec[r*RS + w] = zero padded key words (w < W) and, when RS = W + 1, the length in word W;
@@ -607,7 +651,8 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
     int W, int RS, unsigned long long* __restrict__ state, uint32_t* __restrict__ ticket, uint64_t* __restrict__ ekeys,
     uint8_t* __restrict__ sizes, uint8_t* __restrict__ shared, uint64_t* __restrict__ pre2,
     uint64_t* __restrict__ tile_first, uint32_t* __restrict__ err, int sort_small, uint8_t* __restrict__ emask,
-    uint64_t* __restrict__ list, unsigned long long* __restrict__ list_n, uint64_t list_cap) {
+    uint64_t* __restrict__ list, unsigned long long* __restrict__ list_n, uint64_t list_cap,
+    unsigned long long* __restrict__ bstate) {
   const int H = sort_small ? kFusedHalo : 1;  // slot i of the tile = sorted position b0 + i - H
   const int NS = kFusedTile + 2 * H;
   extern __shared__ uint64_t tile[];  // NS * W words, then lengths, per-position lcp, keep flags, record flags
@@ -674,7 +719,7 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
       if (g < total) {
         const int i = int((uint32_t(g) * rcp) >> 16), w = g - i * RS;
         if (w < W) tile[i * W + w] = v[it];
-        else { tlen[i] = uint8_t(v[it]); tmeta[i] = uint8_t(v[it] >> 8); }
+        else if (w == W) { tlen[i] = uint8_t(v[it]); tmeta[i] = uint8_t(v[it] >> 8); }  // (words beyond: padding of wider rows)
       }
     }
   }
@@ -765,11 +810,79 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
       if (v2 < sl * (kGatherTile / 64) + wave) before[sl] += c;
     count += c;
   }
+#ifdef BG_EXP_NO_LOOKBACK  // timing experiment: what the kernel costs without waiting for its predecessors
+  if (tid == 0) { s_excl = t * kFusedTile; tile_first[t] = ~0ull; }
+  if (false) {
+#else
   // decoupled look-back (wave 0)
   if (wave == 0) {
+#endif
+    unsigned long long excl = 0;
+    if (bstate) {
+      // Two levels.  With every tile of the chip at the same stage at once, the nearest predecessor that already knows its
+      // prefix is as far back as there are tiles in flight (1280): twenty rounds of 64 states, each a round trip to the L2,
+      // one behind the other.  Here a tile adds up the counts of the tiles before it in its BLOCK of 64 tiles (one round),
+      // the block's last tile publishes the block's sum, and the blocks before it are one more look-back of the same kind
+      // over block states -- 64 blocks = 4096 tiles a round.
+      const uint64_t ntiles = (n + kFusedTile - 1) / kFusedTile;
+      const uint64_t bk = t >> 6;
+      const int k = int(t & 63);
+      const bool closes = k == 63 || t + 1 == ntiles;
+      if (lane == 0) __hip_atomic_store(&state[t], kScanAgg | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long in_block = 0;
+      for (;;) {
+        const unsigned long long v =
+            lane < k ? __hip_atomic_load(&state[(bk << 6) + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kScanAgg;
+        const uint64_t inval = __ballot((v >> 62) == 0);
+        if (inval) {
+          const uint64_t widx = (bk << 6) + uint64_t(__ffsll((unsigned long long)inval) - 1);
+          if (lane == 0)
+            while ((__hip_atomic_load(&state[widx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 62) == 0)
+              __builtin_amdgcn_s_sleep(32);
+          continue;
+        }
+        unsigned long long part = lane < k ? (v & kScanVal) : 0ull;
+#pragma unroll
+        for (int d = 32; d; d >>= 1) part += __shfl_xor(part, d, 64);
+        in_block = part;
+        break;
+      }
+      if (closes && lane == 0)
+        __hip_atomic_store(&bstate[bk], (bk == 0 ? kScanIncl : kScanAgg) | (in_block + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long blocks = 0;
+      if (bk > 0) {
+        int64_t j = int64_t(bk) - 1;
+        for (;;) {
+          const int64_t idx = j - lane;
+          const unsigned long long v =
+              idx >= 0 ? __hip_atomic_load(&bstate[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kScanIncl;
+          const int flag = int(v >> 62);
+          const uint64_t incl = __ballot(flag == 2), inval = __ballot(flag == 0);
+          const int first = incl ? __ffsll((unsigned long long)incl) - 1 : 64;
+          const uint64_t upto = first >= 63 ? ~0ull : ((2ull << first) - 1);
+          if (inval & upto) {
+            const int64_t widx = j - (__ffsll((unsigned long long)(inval & upto)) - 1);
+            if (lane == 0)
+              while ((__hip_atomic_load(&bstate[widx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 62) == 0)
+                __builtin_amdgcn_s_sleep(32);
+            continue;
+          }
+          unsigned long long part = (lane <= first) ? (v & kScanVal) : 0ull;
+#pragma unroll
+          for (int d = 32; d; d >>= 1) part += __shfl_xor(part, d, 64);
+          blocks += part;
+          if (incl) break;
+          j -= 64;
+        }
+        if (closes && lane == 0)
+          __hip_atomic_store(&bstate[bk], kScanIncl | (blocks + in_block + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      excl = blocks + in_block;
+      if (t + 1 == ntiles && lane == 0)  // the host reads the number of entries here
+        __hip_atomic_store(&state[t], kScanIncl | (excl + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
     if (lane == 0)
       __hip_atomic_store(&state[t], (t == 0 ? kScanIncl : kScanAgg) | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long excl = 0;
     if (t > 0) {
       int64_t j = int64_t(t) - 1;
       for (;;) {
@@ -799,6 +912,7 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
       }
       if (lane == 0)
         __hip_atomic_store(&state[t], kScanIncl | (excl + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     }
     if (lane == 0) {
       s_excl = excl;
@@ -1527,6 +1641,48 @@ __global__ void k_rank64_build(const uint64_t* __restrict__ bits, const uint64_t
   for (int k = 0; k < 6; ++k) o[2 + k] = w[k];
 }
 
+// rank4 of SeqsetView (bg_device_funcs.h): group counts first, then the blocks
+struct RankSrc {  // the finalized bitcount of the four bases
+  const uint64_t* bits[4];
+  const uint64_t* subaccum[4];
+  const uint64_t* accum[4];
+  uint64_t n;
+  __device__ uint64_t count(int b, uint64_t i) const {  // bitcount.h:218-270 (i a multiple of 32)
+    const uint64_t nw = (n + 63) >> 6, ngroups = (n + 511) >> 9;
+    uint64_t x = (i >> 6) < nw ? bits[b][i >> 6] : 0;
+    x &= (1ull << (i & 63)) - 1;
+    const uint64_t group = i >> 9, sub = (i >> 6) & 7;
+    uint64_t sa = group < ngroups ? subaccum[b][group] : 0;
+    sa >>= 56 - 8 * sub;
+    sa &= 0xffffffffffffff00ull;
+    sa = (sa >> 32) + (sa & 0xffffffffull);
+    sa = (sa >> 16) + (sa & 0xffff);
+    sa = (sa >> 8) + (sa & 0xff);
+    return accum[b][group] + sa + uint64_t(__popcll(x));
+  }
+};
+__global__ void k_rank4_super(RankSrc src, uint64_t ngroups16, uint64_t* __restrict__ super) {
+  const uint64_t x = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (x >= ngroups16 * 4) return;
+  super[x] = src.count(int(x & 3), (x >> 2) * 65536 * 96);
+}
+__global__ void k_rank4_build(RankSrc src, uint64_t nblocks, const uint64_t* __restrict__ super, uint32_t* __restrict__ out) {
+  const uint64_t x = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;  // (block, base)
+  if (x >= nblocks * 4) return;
+  const uint64_t g = x >> 2;
+  const int b = int(x & 3);
+  const uint64_t i0 = g * 96, nw = (src.n + 63) >> 6;
+  const uint64_t wi = i0 >> 6;
+  const uint64_t a = wi < nw ? src.bits[b][wi] : 0, c = wi + 1 < nw ? src.bits[b][wi + 1] : 0;
+  uint32_t w0, w1, w2;
+  if (i0 & 32) { w0 = uint32_t(a >> 32); w1 = uint32_t(c); w2 = uint32_t(c >> 32); }
+  else { w0 = uint32_t(a); w1 = uint32_t(a >> 32); w2 = uint32_t(c); }
+  uint4 q;
+  q.x = uint32_t(src.count(b, i0) - super[(g >> 16) * 4 + b]);
+  q.y = w0; q.z = w1; q.w = w2;
+  *reinterpret_cast<uint4*>(out + x * 4) = q;
+}
+
 // sel256 of SeqsetView from the rank blocks: block g holds the set bits number [before, before + ones) of its base; for every
 // multiple of 256 among them, the entry that carries it
 __global__ void k_sel256_build(const uint64_t* __restrict__ rank64, uint64_t nblocks, uint64_t n, uint64_t n_slots, uint64_t* __restrict__ out) {
@@ -1594,6 +1750,18 @@ int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss, bool slice) {
                                                                 ss->rank64[b].p);
       BG_LAUNCH_CHECK();
     }
+  }
+  if (!slice && !getenv("BG_NO_RANK4")) {
+    const uint64_t nblocks = n / 96 + 1, ngroups16 = (nblocks + 65535) / 65536;
+    RankSrc src;
+    for (int b = 0; b < 4; ++b) { src.bits[b] = ss->bits[b].p; src.subaccum[b] = ss->subaccum[b].p; src.accum[b] = ss->accum[b].p; }
+    src.n = n;
+    BG_TRY(ss->rank4_super.alloc(ctx, ngroups16 * 4));
+    BG_TRY(ss->rank4.alloc(ctx, nblocks * 16));
+    k_rank4_super<<<cdiv(ngroups16 * 4, 64), 64, 0, ctx->stream>>>(src, ngroups16, ss->rank4_super.p);
+    BG_LAUNCH_CHECK();
+    k_rank4_build<<<cdiv(nblocks * 4, 256), 256, 0, ctx->stream>>>(src, nblocks, ss->rank4_super.p, ss->rank4.p);
+    BG_LAUNCH_CHECK();
   }
   BG_HIP(hipStreamSynchronize(ctx->stream));
   if (!slice) {  // (the totals are on the host now: one slot per 256 set bits, one more for the sentinel)
@@ -1712,7 +1880,7 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   BG_TRY(total.alloc(ctx, 1));
   if (n_emit) {
     ctx->tic("suffix_cover_count");
-    k_cover_count<<<cdiv(cdiv(n_emit, kCoverChunk), 4), 256, 0, ctx->stream>>>(ci, owords.p, o_base, n_emit, W, cnt.p);
+    k_cover_count<<<cdiv(cdiv(n_emit, kCoverChunk), 4), 256, cover_count_lds(W), ctx->stream>>>(ci, owords.p, o_base, n_emit, W, cnt.p);
     BG_LAUNCH_CHECK();
     ctx->toc(n_emit * W * 8 * 2);
   }
@@ -1965,13 +2133,15 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
       DevBuf<unsigned long long> state;
       DevBuf<uint64_t> tile_first;
       DevBuf<uint32_t> ticket;
-      BG_TRY(state.alloc(ctx, ntiles));
+      const uint64_t nblocks = (ntiles + 63) / 64;
+      const bool two_level = !getenv("BG_LOOKBACK_FLAT");  // (the look-back over tile states alone, as before round 5)
+      BG_TRY(state.alloc(ctx, ntiles + nblocks));
       BG_TRY(tile_first.alloc(ctx, ntiles));
       BG_TRY(ticket.alloc(ctx, 1));
-      BG_HIP(hipMemsetAsync(state.p, 0, ntiles * 8, ctx->stream));
+      BG_HIP(hipMemsetAsync(state.p, 0, (ntiles + nblocks) * 8, ctx->stream));
       BG_HIP(hipMemsetAsync(ticket.p, 0, 4, ctx->stream));
       // prev bits where the records meet (rows that carry the flags of k_emit_records): see the kernel
-      const bool local_prev = lp && RS == W + 1 && !getenv("BG_PREV_SEARCH_ALL");
+      const bool local_prev = lp && RS > W && !getenv("BG_PREV_SEARCH_ALL");
       if (local_prev) {
         lp->cap = n_rec / 3 + 1024;
         BG_TRY(lp->emask.alloc(ctx, (n_rec + 3) & ~3ull));
@@ -1985,12 +2155,18 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
       k_gather_dedup_build<<<unsigned(ntiles), kGatherTile, lds, ctx->stream>>>(
           rec.p, rlen.p, sidx.p, n_rec, W, RS, state.p, ticket.p, ss->keys.p, ss->sizes.p, ss->shared.p, ss->pre2.p, tile_first.p,
           err.p, defer_small ? 1 : 0, local_prev ? lp->emask.p : nullptr, local_prev ? lp->list.p : nullptr,
-          local_prev ? reinterpret_cast<unsigned long long*>(lp->count.p) : nullptr, local_prev ? lp->cap : 0);
+          local_prev ? reinterpret_cast<unsigned long long*>(lp->count.p) : nullptr, local_prev ? lp->cap : 0,
+          two_level ? state.p + ntiles : nullptr);
       BG_LAUNCH_CHECK();
       k_fix_tile_first_shared<<<cdiv(ntiles, 256), 256, 0, ctx->stream>>>(tile_first.p, ntiles, ss->keys.p, ss->sizes.p, W,
                                                                           ss->shared.p);
       BG_LAUNCH_CHECK();
       ctx->toc(n_rec * (W * 8 * 2 + 8 + 16));
+#if defined(BG_EXP_GATHER_ONLY) || defined(BG_EXP_NO_LOOKBACK)
+      BG_HIP(hipStreamSynchronize(ctx->stream));
+      set_error("timing experiment: the entry build's result is not a seqset");
+      return BG_EINTERNAL;
+#endif
       unsigned long long last = 0;
       BG_HIP(hipMemcpyAsync(&last, state.p + (ntiles - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
       if (local_prev) BG_HIP(hipMemcpyAsync(&lp->n_items, lp->count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -2289,9 +2465,14 @@ extern "C" int bg_seqset_build(bg_ctx* ctx, const bg_reads* reads, int cover_k, 
   DevBuf<uint8_t> rlen;
   DevBuf<uint64_t> k0;
   // (rows of W + 1 words: every record carries its length behind its key words)
-  BG_TRY(suffix_records_impl(ctx, reads, 0, reads->n, cover_k, &rec, &rlen, &n_rec, &k0, reads->W + 1));
+  int RS = reads->W + 1;
+  if (const char* e = getenv("BG_EXP_ROW_WORDS")) {  // timing experiment: rows padded to this many words (8 = one 64-byte sector a row)
+    const int v = atoi(e);
+    if (v > RS && v <= kMaxWords + 1) RS = v;
+  }
+  BG_TRY(suffix_records_impl(ctx, reads, 0, reads->n, cover_k, &rec, &rlen, &n_rec, &k0, RS));
   LocalPrev lp;
-  BG_TRY(entries_from_records_impl(ctx, rec, rlen, n_rec, reads->W, ss.get(), &n_tied, &k0, reads->W + 1, &lp));
+  BG_TRY(entries_from_records_impl(ctx, rec, rlen, n_rec, reads->W, ss.get(), &n_tied, &k0, RS, &lp));
   BG_TRY(prev_bits_local_impl(ctx, ss.get(), &lp));
   if (getenv("BG_DEBUG_PREV")) fprintf(stderr, "prev bits: %llu of %llu entries' worth of tails searched (list %s)\n", (unsigned long long)(lp.valid ? lp.n_items : ss->n), (unsigned long long)ss->n, lp.valid ? "ok" : "not used");
   // the longest read is never a proper prefix of anything longer, so it survives as an entry

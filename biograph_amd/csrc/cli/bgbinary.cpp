@@ -65,7 +65,7 @@ struct Args {
 // Options every command understands are listed per command: anything else is an error, never silently
 // ignored (an interleaved FASTQ imported as unpaired, a --cut-reads that cuts nothing).
 static Args parse(int argc, char** argv, int first, const std::vector<std::string>& known) {
-  static const char* flags[] = {"interleaved", "force", "f", "allow-long-reads", "no-bwt", "prefault", "force-sharded", nullptr};
+  static const char* flags[] = {"interleaved", "force", "f", "allow-long-reads", "no-bwt", "prefault", "no-prefault", "force-sharded", nullptr};
   Args a;
   for (int i = first; i < argc; ++i) {
     std::string s = argv[i];
@@ -686,7 +686,7 @@ static int create_sharded(const Args& a, int argc, char** argv, const bg_create_
 }
 
 static int cmd_create(int argc, char** argv) {
-  Args a = parse(argc, argv, 2, {"prefault", "reads", "pair", "interleaved", "ref", "out", "id", "force", "kmer-size", "min-kmer-count",
+  Args a = parse(argc, argv, 2, {"prefault", "no-prefault", "reads", "pair", "interleaved", "ref", "out", "id", "force", "kmer-size", "min-kmer-count",
                                  "trim-after-portion", "max-corrections", "min-good-run", "min-reads", "warn-reads", "stats",
                                  "cut-reads", "threads", "tmp", "max-mem", "format", "allow-long-reads", "gpus", "force-sharded", "comm", "devices"});
   if (!a.has("reads") || !a.has("out")) die("create: --reads and --out are required");
@@ -742,21 +742,30 @@ static int cmd_create(int argc, char** argv) {
   std::vector<void*> d_text(files.size(), nullptr);
   std::vector<uint64_t> n_text(files.size(), 0);
   uint64_t text_bytes = 0;
-  // --prefault: while the files travel to the GPU, a side thread pre-faults the memory the build will ask for
-  // (bg_ctx_reserve; first-touch hipMalloc is ~30 us per MiB: 0.85 s of a chr20-sized create).  Measured on a chr20-sized
-  // sample: the build drops from 0.87 s to 0.13 s, but mapping memory and uploading the files contend in the driver and the
-  // import grows from 0.62 s to 1.0 s -- 1.78 s in all against 1.84 s.  Not worth being the default; kept for inputs whose
-  // import is bound elsewhere (gzip, BAM).  The build peaks near 14 bytes per input base; FASTQ text is a little over two
-  // bytes per base.
+  // While the files travel to the GPU, a side thread reserves the memory the build will ask for (bg_ctx_reserve).  The build
+  // peaks near 14 bytes per input base; FASTQ text is a little over two bytes per base.
   std::thread prefault;
-  if (a.has("prefault")) {
+  // On by default since round 5 (--no-prefault / BG_CREATE_RESERVE=off: without): the reservation maps 1 GiB pieces through the
+  // virtual-memory API (0.05 s for 32 GiB; the 256 MiB pieces of round 4 were the slow way), and what the build would
+  // otherwise pay inside its first step -- up to 0.95 s when another process has just given its memory back -- happens
+  // beside the import.  BG_CREATE_RESERVE=sync: before the import, on this thread (measurements).
+  const char* reserve_env = getenv("BG_CREATE_RESERVE");
+  const bool reserve_sync = reserve_env && !strcmp(reserve_env, "sync");
+  const bool reserve_off = a.has("no-prefault") || (reserve_env && !strcmp(reserve_env, "off"));
+  if (!reserve_off) {
     uint64_t on_disk = 0;
     for (auto& f : files) { struct stat sb; if (stat(f.c_str(), &sb) == 0) on_disk += uint64_t(sb.st_size); }
     const bool packed = !files.empty() && (files[0].size() > 3 && (files[0].substr(files[0].size() - 3) == ".gz" || files[0].substr(files[0].size() - 4) == ".bam"));
     const uint64_t est_bases = packed ? on_disk * 2 : on_disk / 2;
     uint64_t want = est_bases * 14;
     if (want > (uint64_t(64) << 30)) want = uint64_t(64) << 30;  // stays inside what the arena may keep cached (35 % of the device)
-    if (want >= (uint64_t(256) << 20)) prefault = std::thread([ctx, want] { (void)bg_ctx_reserve(ctx, want); });
+    if (reserve_sync) {
+      const double tr = now_s();
+      (void)bg_ctx_reserve(ctx, want);
+      logf("Reserved %.1f GB of device memory in %.3f s", want / 1e9, now_s() - tr);
+    } else if (want >= (uint64_t(256) << 20)) {
+      prefault = std::thread([ctx, want] { (void)bg_ctx_reserve(ctx, want); });
+    }
   }
   BamState bam;
   bool any_bam = false;

@@ -39,10 +39,65 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 // ------------------------------------------------------------------------------------------------
 // context
 
+namespace bg {
+std::mutex g_vmm_mutex;
+std::map<void*, VmmSegment> g_vmm_segments;
+
+// n bytes (a multiple of `piece`) as one address range with `piece` bytes of physical memory mapped at a time; nullptr when
+// the driver refuses (nothing stays behind).  Registered in g_vmm_segments: seg_free takes it apart the same way.
+void* vmm_segment(int device, size_t n, size_t piece) {
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = device;
+  hipMemAccessDesc access = {};
+  access.location = prop.location;
+  access.flags = hipMemAccessFlagsProtReadWrite;
+  void* base = nullptr;
+  // (the range aligned like its pieces: a gigabyte of contiguous physical memory behind a gigabyte-aligned address is what the
+  // page tables can describe with their largest fragments)
+  if (hipMemAddressReserve(&base, n, piece, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  size_t done = 0;
+  for (; done < n; done += piece) {
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, piece, &prop, 0) != hipSuccess) break;
+    const bool mapped = hipMemMap(static_cast<char*>(base) + done, piece, 0, h, 0) == hipSuccess;
+    (void)hipMemRelease(h);  // the mapping keeps the memory
+    if (!mapped) break;
+  }
+  if (done == n && hipMemSetAccess(base, n, &access, 1) == hipSuccess) {
+    std::lock_guard<std::mutex> l(g_vmm_mutex);
+    g_vmm_segments[base] = VmmSegment{n, n, piece};
+    return base;
+  }
+  (void)hipGetLastError();
+  for (size_t at = 0; at < done; at += piece) (void)hipMemUnmap(static_cast<char*>(base) + at, piece);
+  (void)hipMemAddressFree(base, n);
+  (void)hipGetLastError();
+  return nullptr;
+}
+}  // namespace bg
+
 void* bg_ctx::HipSegments::seg_alloc(size_t n) {
   static const bool trace = getenv("BG_ALLOC_TRACE") != nullptr;
+  // Off unless asked for (BG_ARENA_VMM=1).  Measured on the bench step, memory mapped this way serves the kernels 2 % slower
+  // than hipMalloc's (59.6 against 58.4 ms: k_correct_dfs 3.55 against 3.23), and a process that shares the arena with torch's
+  // allocator aborted inside the runtime.  What it is for is the one-shot command: bg_ctx_reserve (bgbinary create) maps the
+  // build's memory this way beside the import.
+  static const bool use_vmm = [] { const char* e = getenv("BG_ARENA_VMM"); return e && e[0] == '1'; }();
   const auto t0 = std::chrono::steady_clock::now();
   void* p = nullptr;
+  if (use_vmm && n >= kLargeRound && n % kLargeRound == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    p = bg::vmm_segment(dev, n, kLargeRound);
+    if (p) {
+      if (trace)
+        fprintf(stderr, "[bg alloc] %zu MiB mapped in 1 GiB pieces: %.2f ms\n", n >> 20,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      return p;
+    }
+  }
   hipError_t e = hipMalloc(&p, n);
   if (trace)
     fprintf(stderr, "[bg alloc] hipMalloc %zu MiB: %.2f ms%s\n", n >> 20,
@@ -55,12 +110,7 @@ void* bg_ctx::HipSegments::seg_alloc(size_t n) {
   return p;
 }
 
-// Segments that bg_ctx_reserve built chunk by chunk through the virtual-memory API (one address range, physical memory
-// mapped into it piece by piece so that the driver's lock is never held for long): they go back the same way.
-namespace bg {
-std::mutex g_vmm_mutex;
-std::map<void*, VmmSegment> g_vmm_segments;
-}  // namespace bg
+// Segments built piece by piece through the virtual-memory API (vmm_segment above, bg_ctx_reserve): they go back the same way.
 
 void bg_ctx::HipSegments::seg_free(void* p) {  // waits for the device
   bg::VmmSegment vmm{0, 0, 0};

@@ -30,6 +30,9 @@ static SeqsetView make_view(const bg_seqset* ss) {
   v.walk_counters = g_walk_counters;
   static const bool no_blocks = [] { const char* e = getenv("BG_WALK_RANK_BLOCKS"); return e && e[0] == '0'; }();
   for (int b = 0; b < 4; ++b) v.rank64[b] = no_blocks ? nullptr : ss->rank64[b].p;
+  static const bool no_rank4 = [] { const char* e = getenv("BG_WALK_RANK4"); return e && e[0] == '0'; }();
+  v.rank4 = (no_blocks || no_rank4) ? nullptr : ss->rank4.p;
+  v.rank4_super = ss->rank4_super.p;
   static const bool no_select = [] { const char* e = getenv("BG_WALK_SELECT"); return e && e[0] == '0'; }();
   for (int b = 0; b < 4; ++b) v.sel256[b] = (no_blocks || no_select) ? nullptr : ss->sel256[b].p;
   return v;
@@ -449,8 +452,7 @@ __global__ __launch_bounds__(64) void k_ref_map_chains(SeqsetView v, uint64_t nc
                                                       const uint32_t* __restrict__ clen,
                                                       const uint32_t* __restrict__ cpre,
                                                       const int8_t* __restrict__ cdir,
-                                                      const uint8_t* __restrict__ ref, uint32_t* __restrict__ cnt,
-                                                      uint32_t* __restrict__ flags) {
+                                                      const uint8_t* __restrict__ ref, unsigned long long* __restrict__ cells) {
   uint64_t c = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (c >= nchains) return;
   uint64_t pos = cstart[c];
@@ -466,8 +468,10 @@ __global__ __launch_bounds__(64) void k_ref_map_chains(SeqsetView v, uint64_t nc
     if (e <= b) { b = 0; e = v.n; s = 0; continue; }  // cannot happen on a closed seqset (CHECK(r.valid()))
     if (i < pre) continue;
     if (b + 1 != e || s != v.sizes[b]) continue;
-    atomicAdd(&cnt[b], 1u);
-    atomicOr(&flags[b], dir < 0 ? 0x80u : 0x40u);  // rc slice sets k_fwd_flag, forward slice k_rev_flag (:61-65)
+    // ONE atomic per marked position (a device-scope atomic is a 64-byte request at the memory side whatever it carries;
+    // a count and a flag word were two): the forward slices count in the low half of the cell, the reverse-complement ones in
+    // the high half, and k_ref_map_pack turns the halves into count and flags
+    atomicAdd(&cells[b], dir < 0 ? (1ull << 32) : 1ull);
   }
 }
 
@@ -816,12 +820,14 @@ int tracer_simple_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, 
   return BG_OK;
 }
 
-__global__ void k_ref_map_pack(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ flags, uint64_t n,
-                               uint8_t* __restrict__ out) {
+__global__ void k_ref_map_pack(const unsigned long long* __restrict__ cells, uint64_t n, uint8_t* __restrict__ out) {
   uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint32_t c = cnt[i];
-  out[i] = uint8_t((c > 63 ? 63 : c) | flags[i]);
+  const unsigned long long v = cells[i];
+  const uint64_t fw = v & 0xffffffffull, rc = v >> 32;  // (a half overflows at 2^32 positions of one strand on one entry)
+  const uint64_t c = fw + rc;
+  // rc slice sets k_fwd_flag, forward slice k_rev_flag (ref_map.cpp:61-65)
+  out[i] = uint8_t((c > 63 ? 63 : c) | (rc ? 0x80u : 0u) | (fw ? 0x40u : 0u));
 }
 
 }  // namespace bg
@@ -902,18 +908,15 @@ extern "C" int bg_ref_map_build(bg_ctx* ctx, const bg_seqset* ss, const uint8_t*
   }
   const uint64_t nch = cstart.size(), n = ss->n;
   DevBuf<uint64_t> dstart;
-  DevBuf<uint32_t> dlen, dpre, cnt, flags;
+  DevBuf<uint32_t> dlen, dpre;
+  DevBuf<uint64_t> cells;
   DevBuf<int8_t> ddir;
   BG_TRY(dstart.alloc(ctx, nch));
   BG_TRY(dlen.alloc(ctx, nch));
   BG_TRY(dpre.alloc(ctx, nch));
   BG_TRY(ddir.alloc(ctx, nch));
-  BG_TRY(cnt.alloc(ctx, n));
-  BG_TRY(flags.alloc(ctx, n));
-  if (n) {
-    BG_HIP(hipMemsetAsync(cnt.p, 0, n * 4, ctx->stream));
-    BG_HIP(hipMemsetAsync(flags.p, 0, n * 4, ctx->stream));
-  }
+  BG_TRY(cells.alloc(ctx, n));
+  if (n) BG_HIP(hipMemsetAsync(cells.p, 0, n * 8, ctx->stream));
   if (nch) {
     BG_HIP(hipMemcpyAsync(dstart.p, cstart.data(), nch * 8, hipMemcpyHostToDevice, ctx->stream));
     BG_HIP(hipMemcpyAsync(dlen.p, clen.data(), nch * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -921,12 +924,12 @@ extern "C" int bg_ref_map_build(bg_ctx* ctx, const bg_seqset* ss, const uint8_t*
     BG_HIP(hipMemcpyAsync(ddir.p, cdir.data(), nch, hipMemcpyHostToDevice, ctx->stream));
     ctx->tic("walk_ref_map");
     k_ref_map_chains<<<cdiv(nch, 64), 64, 0, ctx->stream>>>(make_view(ss), nch, dstart.p, dlen.p, dpre.p, ddir.p,
-                                                            d_ref_codes, cnt.p, flags.p);
+                                                            d_ref_codes, reinterpret_cast<unsigned long long*>(cells.p));
     BG_LAUNCH_CHECK();
     ctx->toc(total * 52);
   }
   if (n) {
-    k_ref_map_pack<<<cdiv(n, 256), 256, 0, ctx->stream>>>(cnt.p, flags.p, n, d_out);
+    k_ref_map_pack<<<cdiv(n, 256), 256, 0, ctx->stream>>>(reinterpret_cast<const unsigned long long*>(cells.p), n, d_out);
     BG_LAUNCH_CHECK();
   }
   BG_HIP(hipStreamSynchronize(ctx->stream));

@@ -103,6 +103,7 @@ def test_the_shortcuts_change_nothing(sample):
         "full_reference_records": {"BG_TRACER_LEAN_REFS": "0"},
         "one_pop_pass_per_launch": {"BG_POP_PASSES_AHEAD": "0"},
         "no_rank_blocks": {"BG_WALK_RANK_BLOCKS": "0"},
+        "rank_blocks_per_base": {"BG_WALK_RANK4": "0"},
         "pop_front_by_binary_search": {"BG_WALK_SELECT": "0"},
         "one_work_item_at_a_time": {"BG_TRACER_ASYNC": "0"},
         "one_scaffold_at_a_time": {"BG_DISCOVERY_OVERLAP": "0"},

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -78,30 +80,25 @@ static void async_pool(size_t gib) {
   (void)hipDeviceSynchronize();
 }
 
-int main() {
+int main(int argc, char** argv) {
+  // one measurement per process (the driver keeps what a process has mapped: a second measurement in the same process sees
+  // memory the first one left behind):  map_rate.bin plain GIB THREADS | vmm GIB CHUNK_MIB | async GIB | upload GIB
   const double t0 = now();
   (void)hipSetDevice(0);
   (void)hipFree(nullptr);
   printf("runtime up in %.3f s\n", now() - t0);
-  plain(1, 1);
-  plain(8, 1);
-  plain(8, 1);
-  plain(32, 1);
-  plain(32, 4);
-  plain(32, 8);
-  vmm(8, 2);
-  vmm(8, 64);
-  vmm(32, 1024);
-  async_pool(8);
-  async_pool(8);
-  // the same while another thread keeps the copy engine / a kernel busy is what bgbinary would do: upload beside the mapping
-  {
+  const char* mode = argc > 1 ? argv[1] : "plain";
+  const size_t a = argc > 2 ? size_t(atoll(argv[2])) : 32, b = argc > 3 ? size_t(atoll(argv[3])) : 1;
+  if (!strcmp(mode, "plain")) plain(a, int(b));
+  else if (!strcmp(mode, "vmm")) vmm(a, b);
+  else if (!strcmp(mode, "async")) async_pool(a);
+  else if (!strcmp(mode, "upload")) {
     void* h = nullptr;
     void* d = nullptr;
     (void)hipHostMalloc(&h, size_t(1) << 30, 0);
     (void)hipMalloc(&d, size_t(1) << 30);
-    std::thread up([&] { (void)hipSetDevice(0); hipStream_t s; (void)hipStreamCreate(&s); const double a = now(); for (int i = 0; i < 8; ++i) (void)hipMemcpyAsync(d, h, size_t(1) << 30, hipMemcpyHostToDevice, s); (void)hipStreamSynchronize(s); printf("   8 GiB uploaded beside it in %.3f s\n", now() - a); });
-    plain(32, 1);
+    std::thread up([&] { (void)hipSetDevice(0); hipStream_t s; (void)hipStreamCreate(&s); const double x = now(); for (int i = 0; i < 8; ++i) (void)hipMemcpyAsync(d, h, size_t(1) << 30, hipMemcpyHostToDevice, s); (void)hipStreamSynchronize(s); printf("   8 GiB uploaded beside it in %.3f s\n", now() - x); });
+    if (b) vmm(a, b); else plain(a, 1);
     up.join();
   }
   return 0;

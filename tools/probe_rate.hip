@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 template <int MLP, int BYTES>
@@ -51,12 +52,33 @@ static void run(const uint64_t* tab, uint64_t slots, uint64_t* out) {
 }
 
 int main() {
-  uint64_t max_slots = 1ull << 29;  // 4 GiB
+  uint64_t max_slots = 1ull << 30;  // 8 GiB
   uint64_t *tab, *out;
+  if (getenv("PROBE_VMM")) {  // the table through the virtual-memory API in 1 GiB pieces at a 1 GiB-aligned address
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    const size_t piece = size_t(1) << 30, total = max_slots * 8;
+    void* va = nullptr;
+    hipMemAddressReserve(&va, total, piece, nullptr, 0);
+    for (size_t off = 0; off < total; off += piece) {
+      hipMemGenericAllocationHandle_t h;
+      hipMemCreate(&h, piece, &prop, 0);
+      hipMemMap((char*)va + off, piece, 0, h, 0);
+      hipMemRelease(h);
+    }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    hipMemSetAccess(va, total, &acc, 1);
+    tab = (uint64_t*)va;
+    printf("table mapped through the VMM API in 1 GiB pieces\n");
+  } else
   hipMalloc(&tab, max_slots * 8);
   hipMalloc(&out, 8);
   hipMemset(tab, 0x5a, max_slots * 8);
-  for (uint64_t slots = 1ull << 22; slots <= max_slots; slots <<= 1) {
+  for (uint64_t slots = 1ull << 26; slots <= max_slots; slots <<= 1) {
     run<1, 64>(tab, slots, out);
     run<4, 64>(tab, slots, out);
     run<4, 8>(tab, slots, out);
