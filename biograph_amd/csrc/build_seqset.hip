@@ -195,6 +195,170 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void k
   for (uint32_t x = uint32_t(lane); x < end; x += 64) cnt[chunk0 + x] = counts[x];
 }
 
+// The same with one memory round per loop pass whatever a lane is doing.  k_cover_count's pass is a whole look-up: bucket,
+// then -- for the lanes that hit -- the candidate's words behind it, and a wave's pass lasts as long as its slowest lane's
+// chain of dependent loads (nearly every pass has a lane that hits).  Here a lane is in one of two states, PROBE (fetch the
+// bucket of suffix j's K-mer) or VERIFY (fetch the one candidate the slot named): both fetch 64 bytes from an address of the
+// lane's own, so every pass is ONE round trip, and the 5.5 misses + 1 hit of an average read are 7 of them instead of 5.5 +
+// 2 behind each other.  What is rare goes the old way, lane by lane: runs of several candidates (cover_check_slot), slots
+// whose fingerprint belongs to another K-mer (cover_probe from the chain's start).  owords holds 8 spare words at its end
+// (a candidate's 64 bytes may reach past the last read).  chr20: 5.4 ms against 5.9 (and 6.1 before the staged reads); 90
+// registers, five waves per SIMD -- with the rare paths stubbed out (71 registers, seven waves) it took the same 5.3 ms, and
+// held to 64 registers by a waves-per-EU hint it spilled inside the loop and took 12.3.
+struct __attribute__((aligned(8))) CoverPair { uint64_t x, y; };
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cover_count_sm(CoverIndex ci, const uint64_t* __restrict__ owords,
+                                                     uint64_t o_base, uint64_t n_emit, int W,
+                                                     uint32_t* __restrict__ cnt) {
+  extern __shared__ uint64_t cc_lds[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t lane_lt = (1ull << lane) - 1;
+  const uint64_t chunk0 = (uint64_t(blockIdx.x) * 4 + wv) * kCoverChunk;
+  if (chunk0 >= n_emit) return;  // (wave-uniform)
+  const uint32_t end = uint32_t(n_emit - chunk0 < uint64_t(kCoverChunk) ? n_emit - chunk0 : uint64_t(kCoverChunk));
+  const int stride = cover_row_stride(W);
+  uint64_t* const s = cc_lds + threadIdx.x * stride;
+  uint64_t* const st = cc_lds + 256 * stride + wv * kCoverBatch * W;
+  uint8_t* const bytes = reinterpret_cast<uint8_t*>(cc_lds + 256 * stride + 4 * kCoverBatch * W);
+  uint8_t* const st_len = bytes + wv * kCoverBatch;
+  uint8_t* const counts = bytes + 4 * kCoverBatch + wv * kCoverChunk;
+  const uint64_t* const chunk_words = owords + (o_base + chunk0) * uint64_t(W);
+  const uint64_t slot_mask = (1ull << ci.log2cap) - 1;
+  uint32_t next = 0, sbase = ~0u, t = 0;
+  bool active = false, verify = false, fresh = true;
+  int L = 0, j = 0, c = 0;
+  uint32_t vc = 0, vlen = 0;
+  uint64_t key = 0, pb = 0;
+  for (;;) {
+    const uint64_t need = __ballot(!active);
+    if (need) {
+      const uint32_t mine = next + uint32_t(__popcll(need & lane_lt));
+      bool want = !active && mine < end;
+      next += uint32_t(__popcll(need));
+      for (;;) {
+        const uint64_t wm = __ballot(want);
+        if (!wm) break;
+        const uint32_t bb = uint32_t(__shfl(int(mine), __ffsll((unsigned long long)wm) - 1, 64)) & ~uint32_t(kCoverBatch - 1);
+        if (bb != sbase) {
+          const uint32_t rows = end - bb < uint32_t(kCoverBatch) ? end - bb : uint32_t(kCoverBatch);
+          const uint32_t nw = rows * uint32_t(W);
+          const uint64_t* src = chunk_words + uint64_t(bb) * uint64_t(W);
+          const ulonglong2* src2 = reinterpret_cast<const ulonglong2*>(src);
+          for (uint32_t x = uint32_t(lane); x * 2 + 1 < nw; x += 64) {
+            const ulonglong2 v = src2[x];
+            st[2 * x] = v.x;
+            st[2 * x + 1] = v.y;
+          }
+          if ((nw & 1u) && lane == 0) st[nw - 1] = src[nw - 1];
+          if (uint32_t(lane) < rows) st_len[lane] = ci.olen[o_base + chunk0 + bb + uint32_t(lane)];
+          sbase = bb;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (want && mine < sbase + uint32_t(kCoverBatch)) {
+          t = mine;
+          const int q = int(mine - sbase);
+          L = st_len[q];
+          for (int w = 0; w < W; ++w) s[w] = st[q * W + w];
+          j = 1;
+          c = 1;
+          verify = false;
+          fresh = true;
+          if (L <= 1) counts[t] = uint8_t(L);
+          else active = true;
+          want = false;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+    if (!__ballot(active)) {
+      if (next >= end) break;
+      continue;
+    }
+    // this pass's 64 bytes
+    int res = -1;  // 1: suffix j is covered, 0: it is not, -1: not known yet
+    const int rem = L - j;
+    const CoverPair* p = nullptr;
+    if (active) {
+      if (verify) {
+        p = reinterpret_cast<const CoverPair*>(owords + uint64_t(vc) * uint64_t(W));
+      } else if (rem < ci.K) {
+        c += rem - 1;  // (suffixes shorter than K are never looked up: all emitted; the pass below adds the last one)
+        j = L - 1;
+        res = 0;
+      } else {
+        if (fresh) {
+          key = window32(s, W, j) >> (64 - 2 * ci.K);
+          pb = hash_slot(key, ci.log2cap);
+          fresh = false;
+        }
+        p = reinterpret_cast<const CoverPair*>(ci.slots + pb);
+      }
+    }
+    uint64_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = 0;
+    if (p) {
+      const CoverPair a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+      v[0] = a0.x; v[1] = a0.y; v[2] = a1.x; v[3] = a1.y; v[4] = a2.x; v[5] = a2.y; v[6] = a3.x; v[7] = a3.y;
+    }
+    if (p && verify) {
+      // the candidate's words against the suffix (suffix_is_prefix with the words in registers)
+      const int full = rem >> 5, tail = rem & 31;
+      const uint64_t tail_mask = tail ? ~0ull << (2 * (32 - tail)) : ~0ull;
+      bool same = int(vlen) >= rem;
+#pragma unroll
+      for (int w = 0; w < kMaxWords; ++w) {
+        if (w < W && (w < full || (w == full && tail))) {
+          const uint64_t m = w == full ? tail_mask : ~0ull;
+          same = same && ((window32(s, W, j + 32 * w) & m) == (v[w] & m));
+        }
+      }
+      verify = false;
+      if (same) res = 1;
+      else if ((v[0] >> (64 - 2 * ci.K)) == key) res = 0;
+      else res = cover_probe(ci, owords, s, L, j, W) ? 1 : 0;  // the slot was another K-mer's: the chain, slot by slot
+    } else if (p) {
+      const uint64_t fp = cover_fingerprint(key);
+      uint32_t hit = 0, empty = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        hit |= uint32_t((v[u] >> 40) == fp && v[u] != kEmptySlot) << u;
+        empty |= uint32_t(v[u] == kEmptySlot) << u;
+      }
+      if (hit) {
+        uint64_t sv = 0;
+#pragma unroll
+        for (int u = 7; u >= 0; --u)
+          if ((hit >> u) & 1u) sv = v[u];
+        if (uint32_t(sv) & kCoverSingle) {
+          vc = uint32_t(sv) & ~kCoverSingle;
+          vlen = uint32_t(sv >> 32) & 0xffu;
+          verify = true;  // the next pass fetches the candidate
+        } else {
+          const int r = cover_check_slot(ci, owords, s, j, rem, W, key, sv);
+          res = r >= 0 ? r : (cover_probe(ci, owords, s, L, j, W) ? 1 : 0);
+        }
+      } else if (empty) {
+        res = 0;
+      } else {
+        pb = (pb + kBucketSlots) & slot_mask;  // a full bucket without the K-mer: on along the chain
+      }
+    }
+    if (active && res >= 0) {
+      bool fin = res == 1;
+      if (!fin) { ++c; ++j; fresh = true; fin = j >= L; }
+      if (fin) { counts[t] = uint8_t(c); active = false; }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (uint32_t x = uint32_t(lane); x < end; x += 64) cnt[chunk0 + x] = counts[x];
+}
+
 // records: rows of RS words, rec[r*RS + w] = zero padded key words (w < W) and, when RS = W + 1, the length in word W;
 // rlen[r] = the length as a byte when the rows do not carry it (RS = W)
 // One wave expands 64 oriented reads: its records are contiguous in the output, so the lanes take the wave's
@@ -1856,7 +2020,7 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   uint64_t n_rec = 0;
   DevBuf<uint64_t> owords;
   DevBuf<uint8_t> olen;
-  BG_TRY(owords.alloc(ctx, n_o * W));
+  BG_TRY(owords.alloc(ctx, n_o * W + 8));  // (8 spare words: k_cover_count_sm fetches 64 bytes from a candidate's first word)
   BG_TRY(olen.alloc(ctx, n_o));
   CoverStore cs;
   {
@@ -1880,7 +2044,10 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   BG_TRY(total.alloc(ctx, 1));
   if (n_emit) {
     ctx->tic("suffix_cover_count");
-    k_cover_count<<<cdiv(cdiv(n_emit, kCoverChunk), 4), 256, cover_count_lds(W), ctx->stream>>>(ci, owords.p, o_base, n_emit, W, cnt.p);
+    if (getenv("BG_COVER_COUNT_ROUNDS"))  // (a whole look-up per pass, as before round 5)
+      k_cover_count<<<cdiv(cdiv(n_emit, kCoverChunk), 4), 256, cover_count_lds(W), ctx->stream>>>(ci, owords.p, o_base, n_emit, W, cnt.p);
+    else
+      k_cover_count_sm<<<cdiv(cdiv(n_emit, kCoverChunk), 4), 256, cover_count_lds(W), ctx->stream>>>(ci, owords.p, o_base, n_emit, W, cnt.p);
     BG_LAUNCH_CHECK();
     ctx->toc(n_emit * W * 8 * 2);
   }
@@ -2465,11 +2632,9 @@ extern "C" int bg_seqset_build(bg_ctx* ctx, const bg_reads* reads, int cover_k, 
   DevBuf<uint8_t> rlen;
   DevBuf<uint64_t> k0;
   // (rows of W + 1 words: every record carries its length behind its key words)
-  int RS = reads->W + 1;
-  if (const char* e = getenv("BG_EXP_ROW_WORDS")) {  // timing experiment: rows padded to this many words (8 = one 64-byte sector a row)
-    const int v = atoi(e);
-    if (v > RS && v <= kMaxWords + 1) RS = v;
-  }
+  // (padded to 8 words -- one 64-byte sector a row -- the entry build's gather took 8.4 ms instead of 8.8 and the emission 3.9
+  // instead of 3.3: measured and dropped)
+  const int RS = reads->W + 1;
   BG_TRY(suffix_records_impl(ctx, reads, 0, reads->n, cover_k, &rec, &rlen, &n_rec, &k0, RS));
   LocalPrev lp;
   BG_TRY(entries_from_records_impl(ctx, rec, rlen, n_rec, reads->W, ss.get(), &n_tied, &k0, RS, &lp));

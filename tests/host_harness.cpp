@@ -186,17 +186,17 @@ void* hh_build_entries(const char* seq, const uint64_t* offs, uint64_t n, int K)
   // the cover table: the k-mer table's buckets, one value word per slot (csrc/bg_device_funcs.h CoverIndex)
   int lg = 10;
   while ((1ull << lg) < 2 * ukeys.size()) ++lg;
-  std::vector<uint64_t> slots(1ull << lg, kEmptySlot), vv(1ull << lg, 0);
+  std::vector<uint64_t> slots(1ull << lg, kEmptySlot);
   for (size_t i = 0; i < ukeys.size(); ++i) {
     uint64_t t = hash_slot(ukeys[i], lg);
     while (slots[t] != kEmptySlot) t = (t + 1) & ((1ull << lg) - 1);  // first free slot along the chain of buckets
-    slots[t] = ukeys[i];
     const bool single = ulen[i] == 1;
     const uint32_t c = soid[upos[i]];
-    vv[t] = single ? ((uint64_t(p.len[c >> 1]) << 32) | kCoverSingle | c) : ((uint64_t(ulen[i]) << 32) | upos[i]);
+    // one word per slot: fingerprint | length byte | single flag | candidate or run start (csrc/bg_device_funcs.h cover_slot)
+    slots[t] = single ? cover_slot(ukeys[i], p.len[c >> 1], true, c) : cover_slot(ukeys[i], ulen[i] < 255 ? ulen[i] : 255, false, upos[i]);
   }
   // reads shorter than K cannot act as a cover: they are simply absent
-  CoverIndex ci{slots.data(), vv.data(), lg, skeys.data(), soid.data(), uint64_t(skeys.size()), K, olen.data()};
+  CoverIndex ci{slots.data(), lg, skeys.data(), soid.data(), uint64_t(skeys.size()), K, olen.data()};
   struct Rec { uint64_t w[kMaxWords]; int len; };
   std::vector<Rec> recs;
   for (uint64_t o = 0; o < n_o; ++o) {

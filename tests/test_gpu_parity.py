@@ -115,7 +115,7 @@ def test_seqset_build_matches_oracle(ctx, seed, alphabet, K, rl, var):
 @pytest.mark.parametrize("env", [{"BG_VERIFY_CLOSURE": "1"}, {"BG_PREV_FULL_SEARCH": "1"}, {"BG_NO_MEDIUM_GROUPS": "1"},
                                  {"BG_SMALL_TIES_EARLY": "1"}, {"BG_ENTRIES_UNFUSED": "1"}, {"BG_PREV_MERGE": "1"},
                                  {"BG_RADIX_ONESWEEP": "1"}, {"BG_PREV_SEARCH_ALL": "1"},
-                                 {"BG_PREV_SEARCH_ALL": "1", "BG_VERIFY_CLOSURE": "1"}, {"BG_LOOKBACK_FLAT": "1"}])
+                                 {"BG_PREV_SEARCH_ALL": "1", "BG_VERIFY_CLOSURE": "1"}, {"BG_LOOKBACK_FLAT": "1"}, {"BG_COVER_COUNT_ROUNDS": "1"}])
 @pytest.mark.parametrize("seed,alphabet,rl", [(11, "ACGT", 150), (12, "AC", 200), (13, "AT", 255)])
 def test_seqset_build_search_modes(ctx, monkeypatch, env, seed, alphabet, rl):
     """(BG_PREV_MERGE: the prev bits as one merge of tails against chunks of entries; BG_RADIX_ONESWEEP: radix passes with
