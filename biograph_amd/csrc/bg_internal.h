@@ -225,6 +225,12 @@ struct bg_seqset {
   bg::DevBuf<uint8_t> min1, min2;
   uint64_t fixed[5] = {0, 0, 0, 0, 0};
   std::string uuid;
+  // a shard of a sharded build whose records carried the flags of k_emit_records (bg_records_set_meta): prev bits already set
+  // where the records met (emask), the entries whose tail still has to travel (need), and the look-ups that decide a few more
+  // (cond: rows of W + 1 words, base + record; n_cond of them, room for 4 more: bg_seqset_fix_boundary)
+  bg::DevBuf<uint8_t> emask, need;
+  bg::DevBuf<uint64_t> cond;
+  uint64_t n_cond = 0;
 };
 
 struct bg_records {
@@ -232,6 +238,7 @@ struct bg_records {
   uint64_t n = 0;
   int W = 0;
   int RS = 0;                 // words from one row of rec to the next: 0 = W; W + 1 = the length sits behind the key words
+  bool has_meta = false;      // ... and above the length's byte the flags kRecHasPred / kRecLast (bg_records_set_meta)
   bg::DevBuf<uint64_t> rec;   // n rows of zero-padded key words
   bg::DevBuf<uint8_t> rlen;   // n (not used when RS = W + 1)
 };
@@ -290,6 +297,8 @@ extern std::mutex g_vmm_mutex;                 // segments built through the vir
 struct VmmSegment { size_t reserved, mapped, piece; };  // address range, bytes of it with memory behind them, bytes per mapping
 extern std::map<void*, VmmSegment> g_vmm_segments;
 void* vmm_segment(int device, size_t n, size_t piece);  // prims.hip
+// merge.hip: rows (W key words, then the length) of the entries [lo, lo + cnt) of a finalized seqset
+int seqset_stripe_rows(bg_ctx* ctx, const bg_seqset* s, uint64_t lo, uint64_t cnt, int W, uint64_t* d_rows);
 bg_ctx::DeviceArena* shared_arena(int device);  // null unless the hook is installed
 // walk.hip: the read-ahead tables of one walked stretch of a tracer work item (offset after base i = first_off + i),
 // appended to the three lists; the two sorted ones are sorted within this stretch
@@ -362,8 +371,17 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
                         DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out,
                         DevBuf<uint64_t>* k0 = nullptr, int RS = 0);  // k0: also the sort keys of the records (optional)
                         // RS = words from one record row to the next (0: W; W + 1: a row ends with the record's length)
+// word W of a record row (RS = W + 1): the record's length in the low byte, and above it what k_gather_dedup_build needs to set
+// prev bits where the records meet (written by k_emit_records and by the sharded build's RecordSource)
+constexpr uint64_t kRecHasPred = 1ull << 8;   // the read has a base in front of this suffix
+constexpr int kRecPredShift = 9;              // ... that base (2 bits)
+constexpr uint64_t kRecLast = 1ull << 11;     // the last suffix its read emitted (the next one is covered by another read)
+
 // prev bits set where the sorted records meet (k_gather_dedup_build) + the tails that still need a search (k_prev_list)
 struct LocalPrev {
+  bool shard = false;        // a shard of a sharded build: survivors whose tail must travel are flagged in `need`, and the
+                             // list holds, for every record dropped as a proper prefix, base + record (looked up where it sorts)
+  DevBuf<uint8_t> need;
   DevBuf<uint8_t> emask;     // one byte per entry: bit b = prev_b
   DevBuf<uint64_t> list;     // rows of W + 1 words: tail, length | base << 8 | checked << 16
   DevBuf<uint64_t> count;    // rows asked for (device)

@@ -20,10 +20,6 @@ namespace bg {
 
 constexpr int kSortSkipBits = 32;  // the sort key keeps the leading 16 bases of a record (see k_first_words)
 
-// word W of a record row (RS = W + 1): the record's length in the low byte, and above it
-constexpr uint64_t kRecHasPred = 1ull << 8;   // the read has a base in front of this suffix
-constexpr int kRecPredShift = 9;              // ... that base (2 bits)
-constexpr uint64_t kRecLast = 1ull << 11;     // the last suffix its read emitted (the next one is covered by another read)
 
 // ------------------------------------------------------------------------------------------------
 // oriented reads (+ their lengths as bytes and their sort keys: leading 16 bases | oriented id)
@@ -816,7 +812,7 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
     uint8_t* __restrict__ sizes, uint8_t* __restrict__ shared, uint64_t* __restrict__ pre2,
     uint64_t* __restrict__ tile_first, uint32_t* __restrict__ err, int sort_small, uint8_t* __restrict__ emask,
     uint64_t* __restrict__ list, unsigned long long* __restrict__ list_n, uint64_t list_cap,
-    unsigned long long* __restrict__ bstate) {
+    unsigned long long* __restrict__ bstate, uint8_t* __restrict__ need) {
   const int H = sort_small ? kFusedHalo : 1;  // slot i of the tile = sorted position b0 + i - H
   const int NS = kFusedTile + 2 * H;
   extern __shared__ uint64_t tile[];  // NS * W words, then lengths, per-position lcp, keep flags, record flags
@@ -1099,7 +1095,13 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
       const uint32_t pb = (m >> (kRecPredShift - 8)) & 3u;
       if (keep[sl]) {
         if (has_pred) atomicOr(&tmk[before[sl]], 1u << pb);
-        if (m & uint32_t(kRecLast >> 8)) item_kind[sl] = 1;
+        // (need: a shard of a sharded build -- its oriented reads arrive before their cover is known, so a suffix 0 counts as a
+        // last suffix; the survivor's tail is asked for through a flag, not a list row: the tails exchange makes the rows)
+        const bool last = (m & uint32_t(kRecLast >> 8)) != 0 || (need && !has_pred);
+        if (last) {
+          if (need) atomicOr(&tmk[before[sl]], 0x100u);
+          else item_kind[sl] = 1;
+        }
       } else if (has_pred) {
         // the survivor this record is a prefix of: the first one after it (a run of dropped records is a chain of prefixes)
         int q = p + 1;
@@ -1145,6 +1147,7 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
     sizes[e0 + x] = tlen[uint32_t(tsrc[x])];
     shared[e0 + x] = tsh[x];
     if (emask) emask[e0 + x] = uint8_t(tmk[x]);
+    if (need) need[e0 + x] = uint8_t(tmk[x] >> 8);
   }
   if (!emask) return;
   __syncthreads();
@@ -1161,9 +1164,13 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
     if (item_kind[sl] == 1) {  // s[1:], its length, s[0]
       for (int w = 0; w < W; ++w) row[w] = (a[w] << 2) | (w + 1 < W ? a[w + 1] >> 62 : 0ull);
       row[W] = (len - 1) | ((a[0] >> 62) << 8);
-    } else {  // s, its length, the base in front of it; bit 16: only if that base + s is an entry
+    } else if (!need) {  // s, its length, the base in front of it; bit 16: only if that base + s is an entry
       for (int w = 0; w < W; ++w) row[w] = a[w];
       row[W] = len | (uint64_t((tmeta[item_slot[sl]] >> (kRecPredShift - 8)) & 3u) << 8) | (1ull << 16);
+    } else {  // a shard: b.s itself, to be looked up where it sorts (if it is an entry there, that entry sends its tail)
+      const uint64_t b = uint64_t((tmeta[item_slot[sl]] >> (kRecPredShift - 8)) & 3u);
+      for (int w = 0; w < W; ++w) row[w] = ((w ? a[w - 1] : b) << 62) | (a[w] >> 2);
+      row[W] = len + 1;
     }
   }
 }
@@ -2315,6 +2322,7 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
         BG_TRY(lp->list.alloc(ctx, lp->cap * uint64_t(W + 1)));
         BG_TRY(lp->count.alloc(ctx, 1));
         BG_HIP(hipMemsetAsync(lp->count.p, 0, 8, ctx->stream));
+        if (lp->shard) BG_TRY(lp->need.alloc(ctx, (n_rec + 3) & ~3ull));
       }
       ctx->tic("entries_dedup_build");
       const size_t slots = size_t(kFusedTile) + 2 * (defer_small ? kFusedHalo : 1);
@@ -2323,7 +2331,7 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
           rec.p, rlen.p, sidx.p, n_rec, W, RS, state.p, ticket.p, ss->keys.p, ss->sizes.p, ss->shared.p, ss->pre2.p, tile_first.p,
           err.p, defer_small ? 1 : 0, local_prev ? lp->emask.p : nullptr, local_prev ? lp->list.p : nullptr,
           local_prev ? reinterpret_cast<unsigned long long*>(lp->count.p) : nullptr, local_prev ? lp->cap : 0,
-          two_level ? state.p + ntiles : nullptr);
+          two_level ? state.p + ntiles : nullptr, (local_prev && lp->shard) ? lp->need.p : nullptr);
       BG_LAUNCH_CHECK();
       k_fix_tile_first_shared<<<cdiv(ntiles, 256), 256, 0, ctx->stream>>>(tile_first.p, ntiles, ss->keys.p, ss->sizes.p, W,
                                                                           ss->shared.p);
@@ -2518,6 +2526,12 @@ int alloc_prev_bits(bg_ctx* ctx, bg_seqset* ss) {
   for (int b = 0; b < 4; ++b) {
     BG_TRY(ss->bits[b].alloc(ctx, nwords));
     if (nwords) BG_HIP(hipMemsetAsync(ss->bits[b].p, 0, nwords * 8, ctx->stream));
+  }
+  if (nwords && ss->emask.p) {  // a shard whose entry build set prev bits where its records met: the tails that arrive add to them
+    k_pack_emask<<<cdiv(cdiv(nwords, kPackWordsPerWave), 4), 256, 0, ctx->stream>>>(
+        ss->emask.p, ss->n, reinterpret_cast<unsigned long long*>(ss->bits[0].p), reinterpret_cast<unsigned long long*>(ss->bits[1].p),
+        reinterpret_cast<unsigned long long*>(ss->bits[2].p), reinterpret_cast<unsigned long long*>(ss->bits[3].p));
+    BG_LAUNCH_CHECK();
   }
   return BG_OK;
 }

@@ -34,6 +34,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -432,6 +433,31 @@ static void my_stretch(const TextSrc& t, int rank, int world, bg_comm* comm, uin
   *hi = rank + 1 < world ? starts[rank + 1] : t.n;  // the last rank takes what is left (blank tail lines, a mate file that is longer)
 }
 
+// a rank of `--gpus N`: its device, its context, the communicator (rank 0 draws the RCCL id, the launcher's pipes carry it on)
+static void rank_open(int rank, int world, int device, const std::string& backend, const char* comm_id, int id_fd_in,
+                      const std::vector<int>& id_fd_out, bg_ctx** ctx, bg_comm** comm) {
+  int ndev = bg_device_count();
+  if (ndev < 1) die("--gpus: no HIP device");
+  if (device < 0) device = backend == "shm" ? rank % ndev : rank;
+  if (device >= ndev) die("--gpus " + std::to_string(world) + ": rank " + std::to_string(rank) + " has no device " + std::to_string(device) +
+                          " (" + std::to_string(ndev) + " visible; --comm shm lets ranks share a device)");
+  check(bg_ctx_create(device, nullptr, ctx), "bg_ctx_create");
+  char id[BG_COMM_ID_BYTES];
+  memset(id, 0, sizeof id);
+  if (backend == "rccl") {
+    if (rank == 0) {
+      check(bg_comm_unique_id(id), "bg_comm_unique_id");
+      for (int fd : id_fd_out)
+        if (write(fd, id, sizeof id) != ssize_t(sizeof id)) die("--gpus: could not hand the communicator id on");
+    } else if (read(id_fd_in, id, sizeof id) != ssize_t(sizeof id)) {
+      die("--gpus: rank 0 never sent the communicator id");
+    }
+  } else {
+    snprintf(id, sizeof id, "%s", comm_id);
+  }
+  check(bg_comm_init(*ctx, rank, world, id, backend.c_str(), comm), "bg_comm_init");
+}
+
 static int create_rank(const Args& a, int argc, char** argv, const bg_create_params& p, const std::string& out, const std::vector<std::string>& files,
                        bool paired_files, bool interleaved, const std::string& fmt, uint32_t cut_start, uint32_t cut_end, int threads, int rank, int world,
                        int device, const std::string& backend, const char* comm_id, int id_fd_in, const std::vector<int>& id_fd_out, double min_reads,
@@ -439,27 +465,8 @@ static int create_rank(const Args& a, int argc, char** argv, const bg_create_par
   const bool lead = rank == 0;
   double t0 = now_s();
   bg_ctx* ctx = nullptr;
-  int ndev = bg_device_count();
-  if (ndev < 1) die("create --gpus: no HIP device");
-  if (device < 0) device = backend == "shm" ? rank % ndev : rank;
-  if (device >= ndev) die("create --gpus " + std::to_string(world) + ": rank " + std::to_string(rank) + " has no device " + std::to_string(device) +
-                          " (" + std::to_string(ndev) + " visible; --comm shm lets ranks share a device)");
-  check(bg_ctx_create(device, nullptr, &ctx), "bg_ctx_create");
-  char id[BG_COMM_ID_BYTES];
-  memset(id, 0, sizeof id);
-  if (backend == "rccl") {  // rank 0 draws the id, the launcher's pipes carry it to the others
-    if (lead) {
-      check(bg_comm_unique_id(id), "bg_comm_unique_id");
-      for (int fd : id_fd_out)
-        if (write(fd, id, sizeof id) != ssize_t(sizeof id)) die("create --gpus: could not hand the communicator id on");
-    } else if (read(id_fd_in, id, sizeof id) != ssize_t(sizeof id)) {
-      die("create --gpus: rank 0 never sent the communicator id");
-    }
-  } else {
-    snprintf(id, sizeof id, "%s", comm_id);
-  }
   bg_comm* comm = nullptr;
-  check(bg_comm_init(ctx, rank, world, id, backend.c_str(), &comm), "bg_comm_init");
+  rank_open(rank, world, device, backend, comm_id, id_fd_in, id_fd_out, &ctx, &comm);
   if (lead) logf("Importing reads on %d rank(s) (communicator: %s)", world, backend.c_str());
 
   // ---- this rank's stretch of every input
@@ -617,9 +624,11 @@ static int create_rank(const Args& a, int argc, char** argv, const bg_create_par
   return 0;
 }
 
-static int create_sharded(const Args& a, int argc, char** argv, const bg_create_params& p, const std::string& out, const std::vector<std::string>& files,
-                          bool paired_files, bool interleaved, const std::string& fmt, uint32_t cut_start, uint32_t cut_end, int threads, int gpus,
-                          double min_reads, double warn_reads) {
+// One child process per rank, forked before anything touches HIP (a process that has initialised the GPU must not fork ranks
+// or exec); body(rank, device, backend, comm_id, id pipe in, id pipes out) runs in the child.  A rank that dies ends the
+// command: the others would wait for it forever.
+static int launch_ranks(const Args& a, int gpus,
+                        const std::function<int(int, int, const std::string&, const char*, int, const std::vector<int>&)>& body) {
   const std::string backend = a.get("comm", "rccl");
   if (backend != "rccl" && backend != "shm") die("--comm takes rccl or shm");
   std::vector<int> devices;
@@ -633,12 +642,8 @@ static int create_sharded(const Args& a, int argc, char** argv, const bg_create_
     }
     if (int(devices.size()) != gpus) die("--devices names one device per rank");
   }
-  for (const auto& f : files)
-    if (f == "-") die("create --gpus: every rank reads its own stretch of the input: it cannot be a pipe");
   char comm_id[64];
   snprintf(comm_id, sizeof comm_id, "%ld-%ld", long(getpid()), long(time(nullptr)));
-  // nothing in this process has touched HIP: the ranks are forked now (a process that has initialised the GPU must not fork
-  // ranks or exec)
   std::vector<std::array<int, 2>> pipes(gpus > 1 ? gpus - 1 : 0);
   for (auto& pp : pipes)
     if (pipe(pp.data()) != 0) die(std::string("pipe: ") + strerror(errno));
@@ -656,8 +661,7 @@ static int create_sharded(const Args& a, int argc, char** argv, const bg_create_
         else if (q == r) { in = pipes[q - 1][0]; close(pipes[q - 1][1]); }
         else { close(pipes[q - 1][0]); close(pipes[q - 1][1]); }
       }
-      int rc = create_rank(a, argc, argv, p, out, files, paired_files, interleaved, fmt, cut_start, cut_end, threads, r, gpus,
-                           devices.empty() ? -1 : devices[r], backend, comm_id, in, outs, min_reads, warn_reads);
+      int rc = body(r, devices.empty() ? -1 : devices[r], backend, comm_id, in, outs);
       fflush(stdout);
       fflush(stderr);
       _exit(rc);
@@ -672,7 +676,7 @@ static int create_sharded(const Args& a, int argc, char** argv, const bg_create_
     if (pid < 0) break;
     --left;
     const bool ok = WIFEXITED(status) && WEXITSTATUS(status) == 0;
-    if (!ok && !failed) {  // one rank down: the others would wait for it forever
+    if (!ok && !failed) {
       failed = 1;
       for (pid_t k : kids)
         if (k != pid) kill(k, SIGTERM);
@@ -683,6 +687,17 @@ static int create_sharded(const Args& a, int argc, char** argv, const bg_create_
     for (int r = 0; r < gpus; ++r) shm_unlink((std::string("/bgcomm-") + comm_id + "-r" + std::to_string(r)).c_str());
   }
   return failed;
+}
+
+static int create_sharded(const Args& a, int argc, char** argv, const bg_create_params& p, const std::string& out, const std::vector<std::string>& files,
+                          bool paired_files, bool interleaved, const std::string& fmt, uint32_t cut_start, uint32_t cut_end, int threads, int gpus,
+                          double min_reads, double warn_reads) {
+  for (const auto& f : files)
+    if (f == "-") die("create --gpus: every rank reads its own stretch of the input: it cannot be a pipe");
+  return launch_ranks(a, gpus, [&](int r, int device, const std::string& backend, const char* comm_id, int in, const std::vector<int>& outs) {
+    return create_rank(a, argc, argv, p, out, files, paired_files, interleaved, fmt, cut_start, cut_end, threads, r, gpus, device, backend, comm_id, in,
+                       outs, min_reads, warn_reads);
+  });
 }
 
 static int cmd_create(int argc, char** argv) {
@@ -1071,13 +1086,122 @@ static std::map<std::string, std::string> json_samples(const std::string& js) {
 }
 
 // bgbinary merge --in A.bg --in B.bg [...] --out M.bg [--id ID] [-f]   (biograph_merge.cpp:189-400)
+// `merge --gpus N` (biograph_merge.cpp:189-290 over the ranks of a communicator): every rank opens every input and sends its
+// stripe of each input's entries through bg_merge_sharded; all ranks write the merged seqset in place (bg_sharded_write);
+// the stripes of the merge maps travel to rank 0, which migrates and writes the readmaps and the metadata.
+static int merge_rank(const Args& a, int argc, char** argv, const std::vector<std::string>& ins, const std::string& out, const std::string& id_arg,
+                      int rank, int world, int device, const std::string& backend, const char* comm_id, int id_fd_in, const std::vector<int>& id_fd_out) {
+  const bool lead = rank == 0;
+  bg_ctx* ctx = nullptr;
+  bg_comm* comm = nullptr;
+  rank_open(rank, world, device, backend, comm_id, id_fd_in, id_fd_out, &ctx, &comm);
+  const double t0 = now_s();
+  std::vector<bg_seqset*> ss(ins.size(), nullptr);
+  std::vector<const bg_seqset*> css;
+  std::vector<void*> maps(ins.size(), nullptr);
+  std::vector<uint64_t*> mapp;
+  std::vector<uint64_t> n_in(ins.size()), cnt(ins.size());
+  for (size_t i = 0; i < ins.size(); ++i) {
+    check(bg_seqset_open(ctx, (ins[i] + "/seqset").c_str(), &ss[i]), "bg_seqset_open");
+    css.push_back(ss[i]);
+    n_in[i] = bg_seqset_size(ss[i]);
+    cnt[i] = n_in[i] / uint64_t(world) + (uint64_t(rank) < n_in[i] % uint64_t(world) ? 1 : 0);  // this rank's stripe (bg_merge_sharded)
+    check(bg_dev_alloc(ctx, std::max<uint64_t>(cnt[i], 1) * 8, &maps[i]), "bg_dev_alloc");
+    mapp.push_back(static_cast<uint64_t*>(maps[i]));
+  }
+  bg_sharded* sh = nullptr;
+  bg_sharded_stats st;
+  check(bg_merge_sharded(ctx, comm, uint32_t(ins.size()), css.data(), &sh, &st, mapp.data()), "bg_merge_sharded");
+  if (lead) fprintf(stderr, "Merged seqset: %llu entries on %d rank(s) (%.3f s)\n", (unsigned long long)st.build.n_entries, world, now_s() - t0);
+  for (size_t i = 0; i < ins.size(); ++i) bg_seqset_free(ss[i]);
+  if (lead) {
+    mkdirs(out);
+    mkdirs(out + "/qc");
+    mkdirs(out + "/metadata");
+    mkdirs(out + "/coverage");
+  }
+  check(bg_comm_barrier(comm), "bg_comm_barrier");  // the directory exists before anybody writes into it
+  std::vector<const char*> av(argv, argv + argc);
+  char uuid[64] = "";
+  check(bg_sharded_write(ctx, comm, sh, (out + "/seqset").c_str(), nullptr, argc, av.data(), uuid, nullptr), "bg_sharded_write");
+  bg_sharded_free(sh);
+  // the maps: stripe r of input i goes to rank 0 (stripes are in rank order: put together they are the input's map)
+  std::vector<void*> full(ins.size(), nullptr);
+  for (size_t i = 0; i < ins.size(); ++i) {
+    std::vector<uint64_t> send(world, 0), recv(world, 0);
+    send[0] = cnt[i];
+    if (lead)
+      for (int r = 0; r < world; ++r) recv[r] = n_in[i] / uint64_t(world) + (uint64_t(r) < n_in[i] % uint64_t(world) ? 1 : 0);
+    if (lead) check(bg_dev_alloc(ctx, std::max<uint64_t>(n_in[i], 1) * 8, &full[i]), "bg_dev_alloc");
+    void* dummy = nullptr;
+    if (!lead) check(bg_dev_alloc(ctx, 8, &dummy), "bg_dev_alloc");
+    check(bg_comm_exchange(comm, maps[i], send.data(), recv.data(), 8, lead ? full[i] : dummy), "bg_comm_exchange");
+    if (dummy) bg_dev_free(ctx, dummy);
+    bg_dev_free(ctx, maps[i]);
+  }
+  int rc = 0;
+  if (lead) {
+    std::vector<std::string> infos;
+    std::string merged_id;
+    for (size_t i = 0; i < ins.size(); ++i) {
+      infos.push_back(read_text(ins[i] + "/metadata/bg_info.json"));
+      merged_id += (i ? "+" : "") + json_string(infos[i], "accession_id");  // biograph_merge.cpp:334-342
+    }
+    if (!id_arg.empty()) merged_id = id_arg;
+    std::string samples_json;
+    size_t n_samples = 0;
+    std::map<std::string, bool> seen_samples;
+    for (size_t i = 0; i < ins.size(); ++i) {
+      for (auto& kv : json_samples(infos[i])) {
+        if (seen_samples.count(kv.first)) {  // biograph_merge.cpp:116-134
+          fprintf(stderr, "Sample %s of %s is already present in the merge: skipped\n", kv.first.c_str(), ins[i].c_str());
+          continue;
+        }
+        seen_samples[kv.first] = true;
+        bg_readmap *rm = nullptr, *mig = nullptr;
+        check(bg_readmap_open(ctx, (ins[i] + "/coverage/" + kv.second + ".readmap").c_str(), &rm), "bg_readmap_open");
+        check(bg_readmap_migrate_to(ctx, rm, static_cast<const uint64_t*>(full[i]), st.build.n_entries, uuid, &mig), "bg_readmap_migrate_to");
+        char sha[41];
+        std::string tmp = out + "/coverage/tmp.readmap";
+        check(bg_readmap_write(ctx, mig, tmp.c_str(), argc, av.data(), sha), "bg_readmap_write");
+        if (rename(tmp.c_str(), (out + "/coverage/" + sha + ".readmap").c_str()) != 0) die("Could not rename " + tmp);
+        samples_json += std::string(n_samples ? "," : "") + json_str(kv.first) + ":" + json_str(sha);
+        ++n_samples;
+        bg_readmap_free(mig);
+        bg_readmap_free(rm);
+      }
+    }
+    std::string meta = "{\"accession_id\":" + json_str(merged_id) + ",\"biograph_id\":" + json_str(uuid) + ",\"command_history\":[" +
+                       json_argv(argc, argv) + "],\"samples\":{" + samples_json + "},\"version\":\"biograph_amd-r2\"}";
+    write_file(out + "/metadata/bg_info.json", meta);
+    std::string js = "{\"command\":\"merge\",\"version\":\"biograph_amd-r2\",\"accession_id\":" + json_str(merged_id) +
+                     ",\"samples\":" + std::to_string(n_samples) + ",\"seqset_entries\":" + std::to_string(st.build.n_entries) +
+                     ",\"gpus\":" + std::to_string(world) + ",\"comm\":" + json_str(backend) + "}";
+    write_file(out + "/qc/merge_stats.json", js);
+    fprintf(stderr, "\n%s created.\n", out.c_str());
+    for (void* f : full) if (f) bg_dev_free(ctx, f);
+  }
+  check(bg_comm_barrier(comm), "bg_comm_barrier");
+  bg_comm_free(comm);
+  bg_ctx_destroy(ctx);
+  return rc;
+}
+
 static int cmd_merge(int argc, char** argv) {
-  Args a = parse(argc, argv, 2, {"reads", "out", "id", "force"});
+  Args a = parse(argc, argv, 2, {"reads", "out", "id", "force", "gpus", "comm", "devices", "force-sharded"});
   if (!a.has("reads") || !a.has("out")) die("merge: --in (at least once) and --out are required");
   const auto& ins = a.opt["reads"];  // the parser files --in under --reads
   std::string out = a.get("out");
   if (out.size() < 3 || out.substr(out.size() - 3) != ".bg") out += ".bg";
   if (exists(out + "/seqset") && !a.has("force")) die("Refusing to overwrite " + out + ". Use --force to override.");
+  const int gpus = atoi(a.get("gpus", "1").c_str());
+  if (gpus < 1 || gpus > 127) die("--gpus takes 1..127");
+  if (gpus > 1 || a.has("force-sharded")) {
+    const std::string id_arg = a.has("id") ? a.get("id") : std::string();
+    return launch_ranks(a, gpus, [&](int r, int device, const std::string& backend, const char* comm_id, int in, const std::vector<int>& outs) {
+      return merge_rank(a, argc, argv, ins, out, id_arg, r, gpus, device, backend, comm_id, in, outs);
+    });
+  }
   bg_ctx* ctx = nullptr;
   check(bg_ctx_create(0, nullptr, &ctx), "bg_ctx_create");
   std::vector<bg_seqset*> ss(ins.size(), nullptr);

@@ -89,6 +89,40 @@ __global__ __launch_bounds__(256) void k_merge_bytes_to_bits(const uint8_t* __re
   if ((threadIdx.x & 63) == 0) bits[w] = word;
 }
 
+// rows (W key words + the length) of the entries [lo, lo + cnt) of one input: what bg_merge_sharded sends through the
+// records exchange.  One thread per entry; resident keys are copied, an input opened from a file is walked (k_merge_keys_fm).
+__global__ void k_stripe_rows_keys(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ sizes, uint64_t lo, uint64_t cnt,
+                                   int Ws, int W, uint64_t* __restrict__ rows) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  uint64_t* row = rows + i * uint64_t(W + 1);
+  for (int w = 0; w < W; ++w) row[w] = w < Ws ? keys[(lo + i) * Ws + w] : 0;
+  row[W] = sizes[lo + i];
+}
+__global__ void k_stripe_rows_fm(SeqsetView v, uint64_t lo, uint64_t cnt, int W, uint64_t* __restrict__ rows) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  uint64_t* row = rows + i * uint64_t(W + 1);
+  uint64_t cur = lo + i;
+  const int L = v.sizes[cur];
+  uint64_t word = 0;
+  for (int w = 0; w < W; ++w) row[w] = 0;
+  for (int j = 0; j < L; ++j) {
+    int b = 0;
+    while (b < 3 && cur >= v.fixed[b + 1]) ++b;
+    word |= uint64_t(b) << (62 - 2 * (j & 31));
+    if ((j & 31) == 31 || j + 1 == L) { row[j >> 5] = word; word = 0; }
+    const uint64_t rank = cur - v.fixed[b];
+    uint64_t a = 0, z = v.n;  // smallest t with count(b, t + 1) > rank
+    while (a < z) {
+      const uint64_t mid = (a + z) >> 1;
+      if (v.count(b, mid + 1) > rank) z = mid; else a = mid + 1;
+    }
+    cur = a;
+  }
+  row[W] = uint64_t(L);
+}
+
 static SeqsetView merge_view(const bg_seqset* ss) {
   SeqsetView v;
   v.n = ss->n;
@@ -103,6 +137,16 @@ static SeqsetView merge_view(const bg_seqset* ss) {
 
 int bitcount_finalize_plain(bg_ctx* ctx, const DevBuf<uint64_t>& bits, uint64_t nbits, DevBuf<uint64_t>* subaccum,
                             DevBuf<uint64_t>* accum);  // readmap.hip
+
+int seqset_stripe_rows(bg_ctx* ctx, const bg_seqset* s, uint64_t lo, uint64_t cnt, int W, uint64_t* d_rows) {
+  if (!cnt) return BG_OK;
+  if (lo + cnt > s->n) { set_error("seqset_stripe_rows: stripe past the end"); return BG_EINVAL; }
+  if (!s->accum[0].p) { set_error("bg_merge_sharded: an input is not finalized"); return BG_EINVAL; }
+  if (s->keys.p && s->W) k_stripe_rows_keys<<<cdiv(cnt, 256), 256, 0, ctx->stream>>>(s->keys.p, s->sizes.p, lo, cnt, s->W, W, d_rows);
+  else k_stripe_rows_fm<<<cdiv(cnt, 64), 64, 0, ctx->stream>>>(merge_view(s), lo, cnt, W, d_rows);
+  BG_LAUNCH_CHECK();
+  return BG_OK;
+}
 
 }  // namespace bg
 
@@ -187,17 +231,23 @@ extern "C" int bg_seqset_merge(bg_ctx* ctx, uint32_t n_in, const bg_seqset* cons
 
 extern "C" int bg_readmap_migrate(bg_ctx* ctx, const bg_readmap* old_rm, const uint64_t* d_map, const bg_seqset* merged,
                                   bg_readmap** out) {
-  if (!ctx || !old_rm || !merged || !out || (old_rm->n_entries && !d_map)) { set_error("bg_readmap_migrate: null argument"); return BG_EINVAL; }
+  if (!merged) { set_error("bg_readmap_migrate: null argument"); return BG_EINVAL; }
+  return bg_readmap_migrate_to(ctx, old_rm, d_map, merged->n, merged->uuid.c_str(), out);
+}
+
+extern "C" int bg_readmap_migrate_to(bg_ctx* ctx, const bg_readmap* old_rm, const uint64_t* d_map, uint64_t merged_entries,
+                                     const char* merged_uuid, bg_readmap** out) {
+  if (!ctx || !old_rm || !merged_uuid || !out || (old_rm->n_entries && !d_map)) { set_error("bg_readmap_migrate: null argument"); return BG_EINVAL; }
   if (old_rm->pair_mode) { set_error("bg_readmap_migrate: readmap has no mate loop table; use \"biograph upgrade\" to construct it"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));
-  const uint64_t n = old_rm->n_reads, n_ent = merged->n;
+  const uint64_t n = old_rm->n_reads, n_ent = merged_entries;
   std::unique_ptr<bg_readmap> rm(new bg_readmap);
   rm->ctx = ctx;
   rm->n_reads = n;
   rm->n_entries = n_ent;
   rm->max_read_len = old_rm->max_read_len;  // create_common(..., old_readmap.max_read_len()) (:459-461)
   rm->min_read_len = old_rm->min_read_len;
-  rm->seqset_uuid = merged->uuid;
+  rm->seqset_uuid = merged_uuid;
   BG_TRY(rm->read_len.alloc(ctx, n));
   BG_TRY(rm->mate_loop_ptr.alloc(ctx, n));
   BG_TRY(rm->is_forward.alloc(ctx, n));

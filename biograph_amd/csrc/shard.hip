@@ -315,6 +315,52 @@ __global__ void k_tail_rows2(const uint64_t* __restrict__ ekeys, const uint8_t* 
   r[2] = uint64_t(tl) | ((s[0] >> 62) << 8) | (d << 10) | (i << 17);
 }
 
+// k_tail_rows2 for the entries pick[0 .. m) only (the survivors whose tail still has to travel)
+__global__ void k_tail_rows2_picked(const uint64_t* __restrict__ ekeys, const uint8_t* __restrict__ sizes, const uint32_t* __restrict__ pick,
+                                    uint64_t m, int W, const uint64_t* __restrict__ bounds, uint32_t nparts, uint64_t* __restrict__ rows,
+                                    uint32_t* __restrict__ err) {
+  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= m) return;
+  const uint64_t i = pick[t];
+  const uint64_t* s = ekeys + i * W;
+  const uint64_t t0 = window32(s, W, 1), t1 = W > 1 ? window32(s, W, 33) : 0;
+  const int tl = int(sizes[i]) - 1;
+  uint64_t d = 127;
+  for (uint32_t p = 0; p < nparts; ++p) {
+    const uint64_t* b = bounds + uint64_t(p) * (W + 1);
+    if (b[W] == ~0ull) continue;
+    const uint64_t b0 = b[0], b1 = W > 1 ? b[1] : 0;
+    if (t0 < b0 || (t0 == b0 && t1 < b1)) { d = p; break; }
+    if (t0 == b0 && t1 == b1) {
+      uint64_t tail[kMaxWords];
+      for (int w = 0; w < W; ++w) tail[w] = window32(s, W, 1 + 32 * w);
+      if (key_compare(tail, tl, b, int(b[W] & 0xff), W) <= 0) { d = p; break; }
+    }
+  }
+  if (d == 127) atomicOr(err, 2u);
+  uint64_t* r = rows + t * 3;
+  r[0] = t0;
+  r[1] = t1;
+  r[2] = uint64_t(tl) | ((s[0] >> 62) << 8) | (d << 10) | (i << 17);
+}
+
+// rows (W + 1 words: a key and its length) looked up among the shard's entries: an entry that IS the row must send its tail
+__global__ __launch_bounds__(128) void k_mark_need_exact(const uint64_t* __restrict__ rows, uint64_t n_rows, int W,
+                                                         const uint64_t* __restrict__ ekeys, const uint8_t* __restrict__ sizes, uint64_t n,
+                                                         const uint32_t* __restrict__ dir, int bases, uint8_t* __restrict__ need) {
+  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n_rows) return;
+  const uint64_t* key = rows + t * uint64_t(W + 1);
+  const int L = int(key[W] & 0xff);
+  const uint32_t p = uint32_t(key[0] >> (64 - 2 * bases));
+  uint64_t lo = dir[p], hi = dir[p + 1];
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (key_compare(ekeys + mid * W, sizes[mid], key, L, W) < 0) lo = mid + 1; else hi = mid;
+  }
+  if (lo < n && int(sizes[lo]) == L && key_lcp(ekeys + lo * W, L, key, L, W) >= L) need[lo] = 1;
+}
+
 // full tail rows (W+1 words, meta as in the short row) of the entries named by the short rows flagged in `need`
 __global__ void k_tail_rows_full(const uint64_t* __restrict__ ekeys, uint64_t n, int W, const uint64_t* __restrict__ short_rows,
                                  const uint32_t* __restrict__ pick, uint64_t m, uint64_t* __restrict__ rows) {
@@ -658,11 +704,17 @@ struct RecordSource {
   const uint8_t* olen;
   const uint32_t* pending;
   int W, j_lo, span;
+  const uint16_t* end_j;  // the flags of k_emit_records ride above the length (j >= 1 here: a base precedes every record)
   __device__ __forceinline__ uint64_t word(uint64_t t, int w) const {
     const uint64_t slot = t / uint64_t(span);
     const int j = j_lo + int(t - slot * uint64_t(span));
     const uint32_t o = pending[slot];
-    if (w == W) return uint64_t(int(olen[o]) - j);
+    if (w == W) {
+      const uint64_t* s = owords + uint64_t(o) * W;
+      uint64_t meta = uint64_t(int(olen[o]) - j) | kRecHasPred | (((s[(j - 1) >> 5] >> (62 - 2 * ((j - 1) & 31))) & 3) << kRecPredShift);
+      if (j + 1 == int(end_j[o])) meta |= kRecLast;
+      return meta;
+    }
     return window32(owords + uint64_t(o) * W, W, j + 32 * w);
   }
 };
@@ -853,7 +905,7 @@ extern "C" int bg_cover_query_records_split(bg_ctx* ctx, bg_cover_query* q, int 
   BG_TRY(dsp.alloc(ctx, nparts));
   BG_TRY(da.alloc(ctx, total));
   BG_HIP(hipMemcpyAsync(dsp.p, sp.data(), nparts * 4, hipMemcpyHostToDevice, ctx->stream));
-  const RecordSource rs{q->owords.p, q->olen.p, live.p, q->W, j_lo, span};
+  const RecordSource rs{q->owords.p, q->olen.p, live.p, q->W, j_lo, span, q->end_j.p};
   ctx->tic("partition_dest");
   k_dest_records<<<cdiv(total, 256), 256, 0, ctx->stream>>>(rs, q->end_j.p, total, hb, dsp.p, nparts, da.p);
   BG_LAUNCH_CHECK();
@@ -936,6 +988,10 @@ extern "C" int bg_suffix_records(bg_ctx* ctx, const bg_reads* reads, uint64_t re
   return BG_OK;
 }
 extern "C" uint64_t bg_records_count(const bg_records* r) { return r ? r->n : 0; }
+// The rows came from bg_cover_query_records_split / bg_oriented_rows of a CREATE (their last word carries the emission's flags
+// above the length): bg_entries_from_records may set prev bits where the records meet.  Rows of a merge carry the input's
+// number there instead and must not be marked.
+extern "C" void bg_records_set_meta(bg_records* r, int has_meta) { if (r) r->has_meta = has_meta != 0; }
 extern "C" int bg_records_words(const bg_records* r) { return r ? r->W : 0; }
 extern "C" void bg_records_free(bg_records* r) { delete r; }
 
@@ -1028,7 +1084,21 @@ extern "C" int bg_entries_from_records(bg_ctx* ctx, bg_records* rec, bg_seqset**
   ss->W = rec->W;
   ss->uuid = make_uuid();
   uint64_t n_rec = rec->n, n_tied = 0;
-  BG_TRY(entries_from_records_impl(ctx, rec->rec, rec->rlen, n_rec, rec->W, ss.get(), &n_tied, nullptr, rec->RS));
+  // rows that carry the emission's flags: prev bits are set where the records meet (k_gather_dedup_build), the shard keeps
+  // which survivors still have to send their tail and which look-ups decide the rest (BG_SHARD_TAILS_ALL=1: every tail travels)
+  LocalPrev lp;
+  lp.shard = true;
+  const bool local = rec->has_meta && rec->RS == rec->W + 1 && !getenv("BG_SHARD_TAILS_ALL");
+  BG_TRY(entries_from_records_impl(ctx, rec->rec, rec->rlen, n_rec, rec->W, ss.get(), &n_tied, nullptr, rec->RS, local ? &lp : nullptr));
+  if (local && lp.valid) {
+    ss->emask = std::move(lp.emask);
+    ss->need = std::move(lp.need);
+    ss->n_cond = lp.n_items;
+    // (room for the four rows bg_seqset_fix_boundary may add)
+    BG_TRY(ss->cond.alloc(ctx, (lp.n_items + 4) * uint64_t(rec->W + 1)));
+    if (lp.n_items) BG_HIP(hipMemcpyAsync(ss->cond.p, lp.list.p, lp.n_items * uint64_t(rec->W + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
   rec->n = 0;
   if (stats) { stats->n_records = n_rec; stats->n_tied_records = n_tied; stats->n_entries = ss->n; }
   *out = ss.release();
@@ -1067,7 +1137,24 @@ extern "C" int bg_seqset_fix_boundary(bg_ctx* ctx, bg_seqset* ss, const uint64_t
   BG_TRY(bg_seqset_boundary_rows(ctx, ss, first.data(), last.data()));
   if (h_next_first_row && h_next_first_row[W] != ~0ull) {
     int ll = int(last[W]), nl = int(h_next_first_row[W] & 0xff);
-    if (key_lcp(last.data(), ll, h_next_first_row, nl, W) == ll) ss->n -= 1;
+    if (key_lcp(last.data(), ll, h_next_first_row, nl, W) == ll) {
+      ss->n -= 1;
+      if (ss->emask.p) {
+        // the dropped entry t is not an entry: what its records set on it (prev_b[t], b.t a suffix) holds for the next shard's
+        // first entry only if b.t is an entry -- looked up like the records dropped as proper prefixes inside the shard
+        uint8_t m = 0;
+        BG_HIP(copy_d2h(ctx, &m, ss->emask.p + ss->n, 1));
+        for (int b = 0; b < 4; ++b) {
+          if (!((m >> b) & 1)) continue;
+          std::vector<uint64_t> row(W + 1);
+          for (int w = 0; w < W; ++w) row[w] = ((w ? last[w - 1] : uint64_t(b)) << 62) | (last[w] >> 2);
+          row[W] = uint64_t(ll + 1);
+          if (ll + 1 > 32 * W) continue;  // (cannot be a suffix of a read of this width)
+          BG_HIP(copy_h2d(ctx, ss->cond.p + ss->n_cond * uint64_t(W + 1), row.data(), (W + 1) * 8));
+          ++ss->n_cond;
+        }
+      }
+    }
   }
   if (ss->n && h_prev_last_row && h_prev_last_row[W] != ~0ull) {
     uint8_t sh = uint8_t(key_lcp(h_prev_last_row, int(h_prev_last_row[W] & 0xff), first.data(), int(first[W]), W));
@@ -1160,6 +1247,62 @@ extern "C" int bg_seqset_tail_rows2(bg_ctx* ctx, const bg_seqset* ss, uint32_t n
   BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
   if (h_err) { set_error("bg_seqset_tail_rows2: a tail is not extended by any entry (missing expansion)"); return BG_EINTERNAL; }
+  return BG_OK;
+}
+
+// ---- a shard whose entry build set prev bits where its records met (bg_records_set_meta): only some tails still travel.
+// bg_seqset_local_prev: 1 when the shard is one.  bg_seqset_cond_rows: the look-ups that decide a few more tails (rows of
+// W + 1 words: base + record; they go to the shard their key falls into, bg_seqset_mark_need there).  After those:
+// bg_seqset_tails_needed = how many entries send their tail, bg_seqset_tail_rows2_needed = their short rows.
+extern "C" int bg_seqset_local_prev(const bg_seqset* ss) { return ss && ss->need.p ? 1 : 0; }
+extern "C" int bg_seqset_cond_rows(const bg_seqset* ss, const uint64_t** d_rows, uint64_t* n_rows) {
+  if (!ss || !d_rows || !n_rows) { set_error("bg_seqset_cond_rows: null argument"); return BG_EINVAL; }
+  *d_rows = ss->cond.p;
+  *n_rows = ss->n_cond;
+  return BG_OK;
+}
+extern "C" int bg_seqset_mark_need(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows) {
+  if (!ctx || !ss || (n_rows && !d_rows)) { set_error("bg_seqset_mark_need: null argument"); return BG_EINVAL; }
+  if (!ss->need.p) { set_error("bg_seqset_mark_need: the shard keeps no tail flags"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  if (!n_rows || !ss->n) return BG_OK;
+  DevBuf<uint32_t> dir;
+  int bases = 0;
+  BG_TRY(build_prefix_dir_keys(ctx, ss->keys.p, ss->n, ss->W, &dir, &bases));
+  k_mark_need_exact<<<cdiv(n_rows, 128), 128, 0, ctx->stream>>>(d_rows, n_rows, ss->W, ss->keys.p, ss->sizes.p, ss->n, dir.p, bases, ss->need.p);
+  BG_LAUNCH_CHECK();
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+extern "C" int bg_seqset_tail_rows2_needed(bg_ctx* ctx, const bg_seqset* ss, uint32_t nparts, const uint64_t* h_bounds,
+                                           uint64_t* d_rows, uint64_t cap, uint64_t* n_out) {
+  if (!ctx || !ss || !h_bounds || !n_out) { set_error("bg_seqset_tail_rows2_needed: null argument"); return BG_EINVAL; }
+  if (!ss->need.p) { set_error("bg_seqset_tail_rows2_needed: the shard keeps no tail flags"); return BG_EINVAL; }
+  if (nparts < 1 || nparts > 126) { set_error("bg_seqset_tail_rows2_needed: %u shards outside 1..126", nparts); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  *n_out = 0;
+  if (!ss->n) return BG_OK;
+  const int W = ss->W;
+  DevBuf<uint32_t> pick, err;
+  uint64_t m = 0;
+  BG_TRY(compact_flagged<uint32_t>(ctx, ss->need.p, ss->n, &pick, &m));
+  *n_out = m;
+  if (!d_rows) return BG_OK;  // (the count alone: the caller sizes its buffer)
+  if (m > cap) { set_error("bg_seqset_tail_rows2_needed: room for %llu rows, %llu needed", (unsigned long long)cap, (unsigned long long)m); return BG_EINVAL; }
+  if (!m) return BG_OK;
+  DevBuf<uint64_t> db;
+  BG_TRY(db.alloc(ctx, uint64_t(nparts) * (W + 1)));
+  BG_TRY(err.alloc(ctx, 1));
+  BG_HIP(hipMemcpyAsync(db.p, h_bounds, uint64_t(nparts) * (W + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+  ctx->tic("tails_rows");
+  k_tail_rows2_picked<<<cdiv(m, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->sizes.p, pick.p, m, W, db.p, nparts, d_rows, err.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(m * (uint64_t(W) * 8 + 25));
+  uint32_t h_err = 0;
+  BG_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_err) { set_error("bg_seqset_tail_rows2_needed: a tail is not extended by any entry (missing expansion)"); return BG_EINTERNAL; }
   return BG_OK;
 }
 

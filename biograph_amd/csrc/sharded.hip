@@ -645,6 +645,102 @@ const uint64_t* next_nonempty(const std::vector<uint64_t>& rows, int rw, int P, 
   return nullptr;
 }
 
+
+// The back half of a sharded build, from the rows a rank received to its shard with prev bits (sharded.py::_records_to_output):
+// entries of the shard, the cross-shard prefix drop and shared[0], every entry's tail to the shard that holds it.  What
+// bg_create_sharded and bg_merge_sharded share.
+int shard_from_parts(bg_comm* c, bg_ctx* ctx, Handles& H, std::vector<Rows>& parts, int W, int rank, uint64_t* tails_in_full, Phases& ph,
+                     bool rows_carry_flags) {
+  const int P = comm_world(c);
+  // ---- entries of this shard
+  ph.mark("entries_from_records");
+  {
+    std::vector<const uint64_t*> ptrs;
+    std::vector<uint64_t> cnts;
+    for (auto& p : parts) { ptrs.push_back(p.b.p); cnts.push_back(p.n); }
+    if (ptrs.empty()) { ptrs.push_back(nullptr); cnts.push_back(0); }
+    BG_TRY(bg_records_from_row_parts(ctx, uint32_t(parts.size()), ptrs.data(), cnts.data(), W, &H.records));
+    parts.clear();  // the rows are in the library now
+    bg_records_set_meta(H.records, rows_carry_flags ? 1 : 0);
+    bg_build_stats bst;
+    BG_TRY(bg_entries_from_records(ctx, H.records, &H.shard, &bst));
+    bg_records_free(H.records);
+    H.records = nullptr;
+  }
+
+  // ---- 5: shard boundaries (cross-shard prefix drop, shared[0] across the cut)
+  ph.mark("boundaries");
+  const int rw = W + 1;
+  std::vector<uint64_t> fi(rw), la(rw), firsts, lasts;
+  BG_TRY(bg_seqset_boundary_rows(ctx, H.shard, fi.data(), la.data()));
+  BG_TRY(gather_u64(c, fi, &firsts));
+  if (const uint64_t* nx = next_nonempty(firsts, rw, P, rank, +1)) BG_TRY(bg_seqset_fix_boundary(ctx, H.shard, nullptr, nx));
+  BG_TRY(bg_seqset_boundary_rows(ctx, H.shard, fi.data(), la.data()));
+  BG_TRY(gather_u64(c, la, &lasts));
+  if (const uint64_t* pv = next_nonempty(lasts, rw, P, rank, -1)) BG_TRY(bg_seqset_fix_boundary(ctx, H.shard, pv, nullptr));
+
+  // ---- 6: prev bits: an entry's tail goes to the shard holding lower_bound(tail); short form first.  A shard of a create has
+  // most of its bits already (set where its records met): first the look-ups that decide which further entries must send
+  // their tail (base + a record dropped as a proper prefix: if that is an entry where it sorts, its tail is that record),
+  // then only the flagged entries' tails travel.
+  const bool local_prev = bg_seqset_local_prev(H.shard) != 0;
+  if (local_prev) {
+    ph.mark("tails_lookups");
+    const uint64_t* cr = nullptr;
+    uint64_t n_c = 0;
+    BG_TRY(bg_seqset_cond_rows(H.shard, &cr, &n_c));
+    Rows sent, got;
+    std::vector<uint64_t> counts;
+    BG_TRY(partition(ctx, cr, n_c, rw, BG_PART_KEY_BOUNDS, P, lasts.data(), &sent, &counts));
+    BG_TRY(a2a_v(c, ctx, sent, counts, &got, nullptr));
+    BG_TRY(bg_seqset_mark_need(ctx, H.shard, got.b.p, got.n));
+  }
+  ph.mark("tails");
+  {
+    uint64_t n = bg_seqset_size(H.shard);
+    Rows rows, shortr, got;
+    std::vector<uint64_t> counts, tcm;
+    if (local_prev) {
+      BG_TRY(bg_seqset_tail_rows2_needed(ctx, H.shard, uint32_t(P), lasts.data(), nullptr, 0, &n));
+      BG_TRY(rows.alloc(ctx, std::max<uint64_t>(n, 1), 3));
+      rows.n = n;
+      uint64_t m2 = 0;
+      BG_TRY(bg_seqset_tail_rows2_needed(ctx, H.shard, uint32_t(P), lasts.data(), rows.b.p, n, &m2));
+    } else {
+      BG_TRY(rows.alloc(ctx, n, 3));
+      BG_TRY(bg_seqset_tail_rows2(ctx, H.shard, uint32_t(P), lasts.data(), rows.b.p));
+    }
+    BG_TRY(partition(ctx, rows.b.p, n, 3, BG_PART_ROW_DEST, P, nullptr, &shortr, &counts));
+    rows.reset();
+    BG_TRY(a2a_v(c, ctx, shortr, counts, &got, &tcm, true));
+    ph.mark("apply_tails");
+    DevBuf<uint8_t> need, needs;
+    BG_TRY(need.alloc(ctx, got.n));
+    BG_TRY(bg_seqset_apply_tails2(ctx, H.shard, got.b.p, got.n, need.p));
+    got.reset();
+    BG_TRY(needs.alloc(ctx, shortr.n));
+    BG_TRY(reply(c, need.p, 1, tcm, needs.p));
+    need.reset();
+    ph.mark("tails_full");
+    uint64_t cap = 0, m = 0, tot = 0;
+    BG_TRY(sum_bytes(ctx, needs.p, shortr.n, &cap));
+    Rows t, full, fgot;
+    BG_TRY(t.alloc(ctx, std::max<uint64_t>(cap, 1), rw));
+    BG_TRY(bg_seqset_tail_rows_full(ctx, H.shard, shortr.b.p, needs.p, shortr.n, t.b.p, cap, &m));
+    shortr.reset();
+    needs.reset();
+    BG_TRY(partition(ctx, t.b.p, m, rw, BG_PART_ROW_DEST, P, nullptr, &full, &counts));
+    t.reset();
+    BG_TRY(all_sum(c, m, &tot));
+    *tails_in_full = tot;
+    if (tot) {
+      BG_TRY(a2a_v(c, ctx, full, counts, &fgot, nullptr));
+      BG_TRY(bg_seqset_apply_tails(ctx, H.shard, fgot.b.p, fgot.n));
+    }
+  }
+  return BG_OK;
+}
+
 }  // namespace
 }  // namespace bg
 
@@ -773,68 +869,8 @@ static int create_sharded_impl(bg_ctx* ctx, bg_comm* comm, const uint8_t* d_seq,
   std::vector<Rows> parts;
   BG_TRY(records_sharded_cover(comm, ctx, H, W, k, &parts, &st.build.n_records, ph));
 
-  // ---- entries of this shard
-  ph.mark("entries_from_records");
-  {
-    std::vector<const uint64_t*> ptrs;
-    std::vector<uint64_t> cnts;
-    for (auto& p : parts) { ptrs.push_back(p.b.p); cnts.push_back(p.n); }
-    if (ptrs.empty()) { ptrs.push_back(nullptr); cnts.push_back(0); }
-    BG_TRY(bg_records_from_row_parts(ctx, uint32_t(parts.size()), ptrs.data(), cnts.data(), W, &H.records));
-    parts.clear();  // the rows are in the library now
-    bg_build_stats bst;
-    BG_TRY(bg_entries_from_records(ctx, H.records, &H.shard, &bst));
-    bg_records_free(H.records);
-    H.records = nullptr;
-  }
-
-  // ---- 5: shard boundaries (cross-shard prefix drop, shared[0] across the cut)
-  ph.mark("boundaries");
-  const int rw = W + 1;
-  std::vector<uint64_t> fi(rw), la(rw), firsts, lasts;
-  BG_TRY(bg_seqset_boundary_rows(ctx, H.shard, fi.data(), la.data()));
-  BG_TRY(gather_u64(comm, fi, &firsts));
-  if (const uint64_t* nx = next_nonempty(firsts, rw, P, res->rank, +1)) BG_TRY(bg_seqset_fix_boundary(ctx, H.shard, nullptr, nx));
-  BG_TRY(bg_seqset_boundary_rows(ctx, H.shard, fi.data(), la.data()));
-  BG_TRY(gather_u64(comm, la, &lasts));
-  if (const uint64_t* pv = next_nonempty(lasts, rw, P, res->rank, -1)) BG_TRY(bg_seqset_fix_boundary(ctx, H.shard, pv, nullptr));
-
-  // ---- 6: prev bits: every entry's tail goes to the shard holding lower_bound(tail); short form first
-  ph.mark("tails");
-  {
-    const uint64_t n = bg_seqset_size(H.shard);
-    Rows rows, shortr, got;
-    std::vector<uint64_t> counts, tcm;
-    BG_TRY(rows.alloc(ctx, n, 3));
-    BG_TRY(bg_seqset_tail_rows2(ctx, H.shard, uint32_t(P), lasts.data(), rows.b.p));
-    BG_TRY(partition(ctx, rows.b.p, n, 3, BG_PART_ROW_DEST, P, nullptr, &shortr, &counts));
-    rows.reset();
-    BG_TRY(a2a_v(comm, ctx, shortr, counts, &got, &tcm, true));
-    ph.mark("apply_tails");
-    DevBuf<uint8_t> need, needs;
-    BG_TRY(need.alloc(ctx, got.n));
-    BG_TRY(bg_seqset_apply_tails2(ctx, H.shard, got.b.p, got.n, need.p));
-    got.reset();
-    BG_TRY(needs.alloc(ctx, shortr.n));
-    BG_TRY(reply(comm, need.p, 1, tcm, needs.p));
-    need.reset();
-    ph.mark("tails_full");
-    uint64_t cap = 0, m = 0, tot = 0;
-    BG_TRY(sum_bytes(ctx, needs.p, shortr.n, &cap));
-    Rows t, full, fgot;
-    BG_TRY(t.alloc(ctx, std::max<uint64_t>(cap, 1), rw));
-    BG_TRY(bg_seqset_tail_rows_full(ctx, H.shard, shortr.b.p, needs.p, shortr.n, t.b.p, cap, &m));
-    shortr.reset();
-    needs.reset();
-    BG_TRY(partition(ctx, t.b.p, m, rw, BG_PART_ROW_DEST, P, nullptr, &full, &counts));
-    t.reset();
-    BG_TRY(all_sum(comm, m, &tot));
-    st.tails_sent_in_full = tot;
-    if (tot) {
-      BG_TRY(a2a_v(comm, ctx, full, counts, &fgot, nullptr));
-      BG_TRY(bg_seqset_apply_tails(ctx, H.shard, fgot.b.p, fgot.n));
-    }
-  }
+  // ---- entries of this shard, boundaries, prev bits
+  BG_TRY(shard_from_parts(comm, ctx, H, parts, W, res->rank, &st.tails_sent_in_full, ph, true));
   std::vector<uint64_t> part_n;
   BG_TRY(gather_u64(comm, {bg_seqset_size(H.shard)}, &part_n));
   for (uint64_t x : part_n) st.build.n_entries += x;
@@ -858,6 +894,164 @@ static int create_sharded_impl(bg_ctx* ctx, bg_comm* comm, const uint8_t* d_seq,
   if (stats) *stats = st;
   *out = res.release();
   return BG_OK;
+}
+
+__global__ void k_or_last_word(uint64_t* __restrict__ rows, uint64_t n, int rw, uint64_t tag) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) rows[i * rw + rw - 1] |= tag;
+}
+
+static int merge_sharded_impl(bg_ctx* ctx, bg_comm* comm, uint32_t n_in, const bg_seqset* const* in, bg_sharded** out,
+                              bg_sharded_stats* stats, uint64_t* const* d_maps) {
+  const int P = comm_world(comm), me = comm_rank(comm);
+  Handles H;
+  Phases ph(ctx, me);
+  std::unique_ptr<bg_sharded> res(new bg_sharded);
+  res->ctx = ctx;
+  res->rank = me;
+  res->world = P;
+  bg_sharded_stats st;
+  memset(&st, 0, sizeof st);
+  uint32_t max_len = 0;
+  uint64_t total = 0;
+  std::vector<uint64_t> lo(n_in), cnt(n_in);
+  for (uint32_t i = 0; i < n_in; ++i) {
+    max_len = std::max(max_len, in[i]->max_len);  // seqset_merger.cpp:57-60: the longest input sets the key width
+    const uint64_t n = in[i]->n;
+    lo[i] = n / uint64_t(P) * uint64_t(me) + std::min<uint64_t>(n % uint64_t(P), uint64_t(me));  // stripes of n / P, the first n % P one longer
+    cnt[i] = n / uint64_t(P) + (uint64_t(me) < n % uint64_t(P) ? 1 : 0);
+    total += cnt[i];
+  }
+  const int W = std::max(1u, (max_len + 31) / 32), rw = W + 1;
+  bool want_maps = false;
+  for (uint32_t i = 0; d_maps && i < n_in; ++i) want_maps = want_maps || d_maps[i];
+
+  // ---- this rank's stripes as rows; a copy with every row's number in it for the maps
+  ph.mark("merge_rows");
+  Rows rows, look;
+  BG_TRY(rows.alloc(ctx, std::max<uint64_t>(total, 1), rw));
+  rows.n = total;
+  {
+    uint64_t at = 0;
+    for (uint32_t i = 0; i < n_in; ++i) {
+      BG_TRY(seqset_stripe_rows(ctx, in[i], lo[i], cnt[i], W, rows.b.p + at * rw));
+      at += cnt[i];
+    }
+  }
+  if (want_maps) {
+    BG_TRY(look.alloc(ctx, std::max<uint64_t>(total, 1), rw));
+    look.n = total;
+    if (total) {
+      BG_HIP(hipMemcpyAsync(look.b.p, rows.b.p, total * rw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      k_tag_rows<<<cdiv(total, 256), 256, 0, ctx->stream>>>(look.b.p, total, rw);
+      BG_LAUNCH_CHECK();
+    }
+  }
+  {  // the input's number rides in the length word, whose low byte is read (sharded.py::sharded_merge)
+    uint64_t at = 0;
+    for (uint32_t i = 0; i < n_in; ++i) {
+      if (cnt[i] && i) {
+        k_or_last_word<<<cdiv(cnt[i], 256), 256, 0, ctx->stream>>>(rows.b.p + at * rw, cnt[i], rw, uint64_t(i) << 8);
+        BG_LAUNCH_CHECK();
+      }
+      at += cnt[i];
+    }
+  }
+
+  // ---- common splitters, the records exchange (part_repo.cpp:32-45, part_counts.h:8-45)
+  ph.mark("merge_partition");
+  std::vector<Rows> parts;
+  {
+    const size_t bins = size_t(1) << (2 * kPrefixBases);
+    DevBuf<uint64_t> hist;
+    BG_TRY(hist.alloc(ctx, bins));
+    uint64_t sample = 8;
+    if (const char* e = getenv("BG_PREFIX_SAMPLE")) sample = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+    BG_TRY(bg_rows_prefix_hist(ctx, rows.b.p, total, rw, kPrefixBases, sample, hist.p));
+    BG_TRY(comm_all_reduce_sum_u64(comm, hist.p, bins));
+    std::vector<uint64_t> gh(bins);
+    BG_HIP(copy_d2h(ctx, gh.data(), hist.p, bins * 8));
+    std::vector<uint64_t> pp = {uint64_t(kPrefixBases)};
+    for (uint64_t sp : choose_splitters(gh, P)) pp.push_back(sp);
+    Rows send, got;
+    std::vector<uint64_t> counts;
+    BG_TRY(partition(ctx, rows.b.p, total, rw, BG_PART_PREFIX, P, pp.data(), &send, &counts));
+    rows.reset();
+    ph.mark("merge_all_to_all");
+    BG_TRY(a2a_v(comm, ctx, send, counts, &got, nullptr));
+    parts.push_back(std::move(got));
+  }
+  uint64_t n_in_total = 0;
+  BG_TRY(all_sum(comm, total, &n_in_total));
+  st.build.n_records = n_in_total;
+
+  // ---- the shard
+  BG_TRY(shard_from_parts(comm, ctx, H, parts, W, me, &st.tails_sent_in_full, ph, false));  // (a merge's rows carry the input's number where a create's carry flags)
+  std::vector<uint64_t> part_n;
+  BG_TRY(gather_u64(comm, {bg_seqset_size(H.shard)}, &part_n));
+  for (uint64_t x : part_n) st.build.n_entries += x;
+  st.shard_entries = part_n[me];
+  st.build.max_len = max_len;
+
+  // ---- merge maps: every stripe entry to the shard its key falls into; the global id of the entry that holds it comes back
+  if (want_maps) {
+    ph.mark("merge_maps");
+    std::vector<uint64_t> off(P + 1, 0);
+    for (int r = 0; r < P; ++r) off[r + 1] = off[r] + part_n[r];
+    std::vector<uint64_t> fi(rw), la(rw), kb;
+    BG_TRY(bg_seqset_boundary_rows(ctx, H.shard, fi.data(), la.data()));
+    BG_TRY(gather_u64(comm, la, &kb));
+    Rows sent, got;
+    std::vector<uint64_t> counts, cm;
+    BG_TRY(partition(ctx, look.b.p, total, rw, BG_PART_KEY_BOUNDS, P, kb.data(), &sent, &counts));
+    look.reset();
+    BG_TRY(a2a_v(comm, ctx, sent, counts, &got, &cm, true));
+    DevBuf<uint64_t> ent, ans, ids;
+    BG_TRY(ent.alloc(ctx, got.n));
+    BG_TRY(bg_seqset_find_rows(ctx, H.shard, got.b.p, got.n, W, off[me], ent.p));
+    got.reset();
+    BG_TRY(ans.alloc(ctx, sent.n));
+    BG_TRY(reply(comm, ent.p, 8, cm, ans.p));
+    BG_TRY(ids.alloc(ctx, std::max<uint64_t>(total, 1)));
+    if (sent.n) k_scatter_by_tag<<<cdiv(sent.n, 256), 256, 0, ctx->stream>>>(sent.b.p, sent.n, rw, ans.p, ids.p);
+    BG_LAUNCH_CHECK();
+    uint64_t at = 0;
+    for (uint32_t i = 0; i < n_in; ++i) {
+      if (cnt[i] && d_maps[i]) BG_HIP(hipMemcpyAsync(d_maps[i], ids.p + at, cnt[i] * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      at += cnt[i];
+    }
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+
+  ph.mark("slices");
+  BG_TRY(aligned_slice(comm, ctx, H, part_n, max_len, res.get()));
+  bg_seqset_free(H.shard);
+  H.shard = nullptr;
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  ph.done();
+  st.first_entry = res->first;
+  st.slice_entries = bg_seqset_size(res->slice);
+  if (stats) *stats = st;
+  *out = res.release();
+  return BG_OK;
+}
+
+extern "C" int bg_merge_sharded(bg_ctx* ctx, bg_comm* comm, uint32_t n_in, const bg_seqset* const* in, bg_sharded** out,
+                                bg_sharded_stats* stats, uint64_t* const* d_maps) {
+  if (!ctx || !comm || !in || !out || !n_in) { set_error("bg_merge_sharded: null argument"); return BG_EINVAL; }
+  for (uint32_t i = 0; i < n_in; ++i)
+    if (!in[i] || (in[i]->n && !in[i]->accum[0].p)) { set_error("bg_merge_sharded: input %u is missing or not finalized", i); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  {  // every rank must hold the same inputs: their sizes are agreed before the first data collective
+    std::vector<uint64_t> mine, all;
+    for (uint32_t i = 0; i < n_in; ++i) mine.push_back(in[i]->n);
+    BG_TRY(gather_u64(comm, mine, &all));
+    for (size_t x = 0; x < all.size(); ++x)
+      if (all[x] != mine[x % n_in]) { set_error("bg_merge_sharded: the ranks hold different inputs (input %zu)", x % n_in); return BG_EINVAL; }
+  }
+  const int rc = merge_sharded_impl(ctx, comm, n_in, in, out, stats, d_maps);
+  if (rc != BG_OK) comm_fail(comm);
+  return rc;
 }
 
 extern "C" void bg_sharded_free(bg_sharded* s) { delete s; }

@@ -782,6 +782,30 @@ int bg_sharded_write(bg_ctx* ctx, bg_comm* comm, const bg_sharded* s, const char
                      int argc, const char* const* argv, char* h_uuid37 /* may be NULL */, char* h_readmap_sha41 /* may be NULL */);
 void bg_sharded_free(bg_sharded* s);
 
+/* `biograph merge` over the ranks of `comm` (biograph_merge.cpp:189-290; seqset_flat / make_mergemap / seqset_merger as their
+ * net semantics: the merged entries are the prefix-free maxima of the union): every rank holds ALL inputs (opened from their
+ * files or built) and takes the stripe [n_i r / P, n_i (r + 1) / P) of input i's entries through the records exchange with
+ * common splitters; the result is the rank's 512-aligned stretch of the merged seqset, for bg_sharded_write.  d_maps (may be
+ * NULL, as may any of its n_in pointers): for every entry of this rank's stripe of input i, the global id of the merged
+ * entry that holds it (make_mergemap.cpp:150-220) -- what bg_readmap_migrate_to takes once the stripes are put together.
+ * Collective: every rank calls it with the same inputs. */
+/* A shard whose rows came from a create (bg_records_set_meta before bg_entries_from_records) sets prev bits where its sorted
+ * records meet (builder.cpp:85-108 without a search) and keeps which entries still have to send their
+ * tail; the look-ups that decide a few more travel as rows (bg_seqset_cond_rows -> the shard their key falls into ->
+ * bg_seqset_mark_need).  Then bg_seqset_tail_rows2_needed replaces bg_seqset_tail_rows2 (d_rows NULL: the count alone). */
+void bg_records_set_meta(bg_records* r, int has_meta);
+int bg_seqset_local_prev(const bg_seqset* ss);
+int bg_seqset_cond_rows(const bg_seqset* ss, const uint64_t** d_rows, uint64_t* n_rows);
+int bg_seqset_mark_need(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows);
+int bg_seqset_tail_rows2_needed(bg_ctx* ctx, const bg_seqset* ss, uint32_t nparts, const uint64_t* h_bounds, uint64_t* d_rows,
+                                uint64_t cap, uint64_t* n_out);
+
+int bg_merge_sharded(bg_ctx* ctx, bg_comm* comm, uint32_t n_in, const bg_seqset* const* in, bg_sharded** out,
+                     bg_sharded_stats* stats, uint64_t* const* d_maps);
+/* bg_readmap_migrate against a merged seqset known by its size and uuid only (the sharded merge's output lives in slices). */
+int bg_readmap_migrate_to(bg_ctx* ctx, const bg_readmap* old_rm, const uint64_t* d_map, uint64_t merged_entries,
+                          const char* merged_uuid, bg_readmap** out);
+
 /* ---- reference: what the discovery walks along ------------------------------------
  * bg_reference_open reads a BioGraph reference directory (karyotype.json + reference.ref, or reference.fasta
  * when the .ref is absent; modules/io/defaults.h:17-50, bio_base/reference.cpp:27-40), a bare .ref file

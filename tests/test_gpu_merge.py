@@ -206,3 +206,53 @@ def test_bgbinary_merge_cli(ctx, tmp_path):
     r2 = subprocess.run([sys.executable, "-m", "biograph_amd.cli", "merge", "--in", str(dirs[0]), "--out", str(mdir)],
                         capture_output=True, text=True)
     assert r2.returncode == 1 and "overwrite" in r2.stderr
+
+
+@pytest.mark.parametrize("args", [["--gpus", "1", "--force-sharded"], ["--gpus", "2", "--comm", "shm"], ["--gpus", "3", "--comm", "shm"]])
+def test_bgbinary_merge_over_ranks_reproduces_family_lambda(ctx, golden_dir, tmp_path, args):
+    """`bgbinary merge --gpus N` (bg_merge_sharded over bg_comm, C++): father + mother + proband of the reference's lambda data
+    merged by 1 rank through the routed path and by 2 and 3 real processes -- the merged seqset == family_lambda.bg's (entries,
+    sizes, shared, fixed; every part == the single-process `bgbinary merge`), every sample's migrated readmap == its readmap
+    inside family_lambda.bg, part for part."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    from tests.test_oracle_golden import FAMILY_READMAPS
+    names = ["father", "mother", "proband"]
+    dirs = []
+    for s in names:
+        d = tmp_path / (s + ".bg")
+        (d / "coverage").mkdir(parents=True)
+        (d / "metadata").mkdir()
+        shutil.copy(golden_dir + "/%s_lambda/seqset" % s, d / "seqset")
+        shutil.copy(golden_dir + "/%s_lambda/readmap" % s, d / "coverage" / "rm.readmap")
+        (d / "metadata" / "bg_info.json").write_text(json.dumps({"accession_id": s, "samples": {s: "rm"}}, separators=(",", ":")))
+        dirs.append(d)
+    exe = [sys.executable, "-m", "biograph_amd.cli", "merge"]
+    ins = [x for d in dirs for x in ("--in", str(d))]
+    single = tmp_path / "single.bg"
+    r = subprocess.run(exe + ins + ["--out", str(single)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = tmp_path / "ranks.bg"
+    r = subprocess.run(exe + ins + ["--out", str(out)] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    dm = O.load_seqset_zip(golden_dir + "/family_lambda/seqset")
+    got, want = ctx.open_seqset(out / "seqset"), ctx.open_seqset(single / "seqset")
+    assert got.size() == dm["n"] == 103996 and got.entries() == O.decode_entries(dm)
+    sz, sh = got.arrays()
+    assert (sz == dm["sizes"]).all() and (sh == dm["shared"]).all()
+    assert got.part("fixed") == np.asarray(dm["fixed"], np.uint64).tobytes()
+    assert got.parts() == want.parts()
+    info = json.load(open(out / "metadata" / "bg_info.json"))
+    assert info["accession_id"] == "father+mother+proband" and sorted(info["samples"]) == names
+    for s in names:
+        rm = ctx.open_readmap(out / "coverage" / (info["samples"][s] + ".readmap"))
+        gm = O.decode_readmap(golden_dir + "/family_lambda/coverage/%s.readmap" % FAMILY_READMAPS[s], dm)
+        e, rl, ml, f = rm.arrays()
+        assert (e == gm["entry"]).all() and (rl == gm["read_len"]).all(), s
+        assert (ml == gm["mate_loop_ptr"]).all() and (f == gm["is_forward"]).all(), s
+        for sel in ("source_to_mid", "dest_to_mid"):
+            for w in ("bits", "subaccum", "accum"):
+                name = "read_ids/%s/%s" % (sel, w)
+                assert rm.part(name) == gm["raw"][name], (s, name)

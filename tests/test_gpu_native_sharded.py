@@ -126,6 +126,17 @@ def test_real_processes_sharing_the_gpu_equal_fused(sample, ranks):
     assert st["gpus"] == ranks and st["comm"] == "shm" and st["comm_bytes_through_backend"] > 10_000_000
 
 
+@pytest.mark.parametrize("ranks", [1, 3])
+def test_every_tail_travelling_gives_the_same(sample, ranks):
+    """BG_SHARD_TAILS_ALL=1: the tails exchange of round 4 (every entry's tail goes to the shard that holds it) instead of the
+    prev bits set where a shard's sorted records meet + the flagged tails: the same containers."""
+    d = sample
+    out = "wall%d.bg" % ranks
+    extra = ["--force-sharded"] if ranks == 1 else ["--comm", "shm"]
+    _create(d, out, ["--reads", str(d / "r1.fq"), "--pair", str(d / "r2.fq"), "--gpus", str(ranks)] + extra, env={"BG_SHARD_TAILS_ALL": "1"})
+    _same(d, "fused.bg", out)
+
+
 def test_two_processes_interleaved_input(sample):
     d = sample
     _create(d, "w2i.bg", ["--reads", str(d / "inter.fq"), "--interleaved", "--gpus", "2", "--comm", "shm"])
