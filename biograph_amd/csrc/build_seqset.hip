@@ -1095,9 +1095,10 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
       const uint32_t pb = (m >> (kRecPredShift - 8)) & 3u;
       if (keep[sl]) {
         if (has_pred) atomicOr(&tmk[before[sl]], 1u << pb);
-        // (need: a shard of a sharded build -- its oriented reads arrive before their cover is known, so a suffix 0 counts as a
-        // last suffix; the survivor's tail is asked for through a flag, not a list row: the tails exchange makes the rows)
-        const bool last = (m & uint32_t(kRecLast >> 8)) != 0 || (need && !has_pred);
+        // (need: a shard of a sharded build -- the survivor's tail is asked for through a flag, not a list row: the tails
+        // exchange makes the rows.  Its whole-read records arrived before their cover was known and carry no flag: the reads
+        // whose suffix 1 is covered come as look-up rows from their senders, bg_cover_query_first_covered_rows)
+        const bool last = (m & uint32_t(kRecLast >> 8)) != 0;
         if (last) {
           if (need) atomicOr(&tmk[before[sl]], 0x100u);
           else item_kind[sl] = 1;

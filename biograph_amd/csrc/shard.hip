@@ -914,6 +914,44 @@ extern "C" int bg_cover_query_records_split(bg_ctx* ctx, bg_cover_query* q, int 
   return msplit_generate(ctx, rs, da.p, total, q->W + 1, nparts, d_out_rows, cap, h_counts, n_out, "bg_cover_query_records_split");
 }
 
+// The oriented reads whose suffix 1 is covered already (their whole-read record is their last one: its tail was not emitted),
+// as rows of W + 1 words (words, length): sent to the shard the read falls into, where -- if the read is an entry --
+// bg_seqset_mark_need makes that entry send its tail.  (The whole-read records themselves left before the cover rounds and do
+// not know.)  d_rows NULL: the count alone.
+__global__ void k_flag_first_covered(const uint16_t* __restrict__ end_j, uint64_t n, uint8_t* __restrict__ flags) {
+  const uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (o < n) flags[o] = end_j[o] == 1 ? 1 : 0;
+}
+__global__ void k_rows_of_picked(const uint64_t* __restrict__ owords, const uint8_t* __restrict__ olen, const uint32_t* __restrict__ pick,
+                                 uint64_t m, int W, uint64_t* __restrict__ rows) {
+  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= m) return;
+  const uint32_t o = pick[t];
+  uint64_t* r = rows + t * uint64_t(W + 1);
+  for (int w = 0; w < W; ++w) r[w] = owords[uint64_t(o) * W + w];
+  r[W] = olen[o];
+}
+extern "C" int bg_cover_query_first_covered_rows(bg_ctx* ctx, const bg_cover_query* q, uint64_t* d_rows, uint64_t cap, uint64_t* n_out) {
+  if (!ctx || !q || !n_out) { set_error("bg_cover_query_first_covered_rows: null argument"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  *n_out = 0;
+  if (!q->n || !q->end_j.p) return BG_OK;
+  DevBuf<uint8_t> flags;
+  DevBuf<uint32_t> pick;
+  uint64_t m = 0;
+  BG_TRY(flags.alloc(ctx, q->n));
+  k_flag_first_covered<<<cdiv(q->n, 256), 256, 0, ctx->stream>>>(q->end_j.p, q->n, flags.p);
+  BG_LAUNCH_CHECK();
+  BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, q->n, &pick, &m));
+  *n_out = m;
+  if (!d_rows || !m) return BG_OK;
+  if (m > cap) { set_error("bg_cover_query_first_covered_rows: room for %llu rows, %llu needed", (unsigned long long)cap, (unsigned long long)m); return BG_EINVAL; }
+  k_rows_of_picked<<<cdiv(m, 256), 256, 0, ctx->stream>>>(q->owords.p, q->olen.p, pick.p, m, q->W, d_rows);
+  BG_LAUNCH_CHECK();
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
 // reads with records at or beyond suffix j_lo (the size of a records window: x span rows at most)
 extern "C" int bg_cover_query_records_live(bg_ctx* ctx, const bg_cover_query* q, int j_lo, uint64_t* n_out) {
   if (!ctx || !q || !n_out) { set_error("bg_cover_query_records_live: null argument"); return BG_EINVAL; }

@@ -295,7 +295,8 @@ int correct_routed(bg_comm* c, bg_ctx* ctx, Handles& H, int k, const bg_create_p
 }
 
 // ---- 3 + 4: suffix records without a replicated cover index (sharded.py::_records_sharded_cover + _filtered_cover_rounds)
-int records_sharded_cover(bg_comm* c, bg_ctx* ctx, Handles& H, int W, int k, std::vector<Rows>* parts, uint64_t* n_records, Phases& ph) {
+int records_sharded_cover(bg_comm* c, bg_ctx* ctx, Handles& H, int W, int k, std::vector<Rows>* parts, uint64_t* n_records, Phases& ph,
+                          Rows* first_covered) {
   const int P = comm_world(c);
   const int rw = W + 1;
   ph.mark("cover_oriented_rows");
@@ -435,6 +436,13 @@ int records_sharded_cover(bg_comm* c, bg_ctx* ctx, Handles& H, int W, int k, std
     }
   }
   BG_TRY(land());
+  if (first_covered) {  // the reads whose whole-read record is their last: look-up rows for the tails phase
+    uint64_t m = 0, got_m = 0;
+    BG_TRY(bg_cover_query_first_covered_rows(ctx, H.query, nullptr, 0, &m));
+    BG_TRY(first_covered->alloc(ctx, std::max<uint64_t>(m, 1), rw));
+    first_covered->n = m;
+    BG_TRY(bg_cover_query_first_covered_rows(ctx, H.query, first_covered->b.p, m, &got_m));
+  }
   bg_cover_query_free(H.query);
   H.query = nullptr;
   uint64_t mine = 0;
@@ -650,7 +658,8 @@ const uint64_t* next_nonempty(const std::vector<uint64_t>& rows, int rw, int P, 
 // entries of the shard, the cross-shard prefix drop and shared[0], every entry's tail to the shard that holds it.  What
 // bg_create_sharded and bg_merge_sharded share.
 int shard_from_parts(bg_comm* c, bg_ctx* ctx, Handles& H, std::vector<Rows>& parts, int W, int rank, uint64_t* tails_in_full, Phases& ph,
-                     bool rows_carry_flags) {
+                     Rows* first_covered /* a create: its rows carry the emission's flags; the reads whose whole-read record is their last */) {
+  const bool rows_carry_flags = first_covered != nullptr;
   const int P = comm_world(c);
   // ---- entries of this shard
   ph.mark("entries_from_records");
@@ -689,9 +698,16 @@ int shard_from_parts(bg_comm* c, bg_ctx* ctx, Handles& H, std::vector<Rows>& par
     const uint64_t* cr = nullptr;
     uint64_t n_c = 0;
     BG_TRY(bg_seqset_cond_rows(H.shard, &cr, &n_c));
-    Rows sent, got;
+    const uint64_t n_f = first_covered ? first_covered->n : 0;
+    Rows all, sent, got;
+    BG_TRY(all.alloc(ctx, std::max<uint64_t>(n_c + n_f, 1), rw));
+    all.n = n_c + n_f;
+    if (n_c) BG_HIP(hipMemcpyAsync(all.b.p, cr, n_c * rw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (n_f) BG_HIP(hipMemcpyAsync(all.b.p + n_c * rw, first_covered->b.p, n_f * rw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (first_covered) first_covered->reset();
     std::vector<uint64_t> counts;
-    BG_TRY(partition(ctx, cr, n_c, rw, BG_PART_KEY_BOUNDS, P, lasts.data(), &sent, &counts));
+    BG_TRY(partition(ctx, all.b.p, all.n, rw, BG_PART_KEY_BOUNDS, P, lasts.data(), &sent, &counts));
+    all.reset();
     BG_TRY(a2a_v(c, ctx, sent, counts, &got, nullptr));
     BG_TRY(bg_seqset_mark_need(ctx, H.shard, got.b.p, got.n));
   }
@@ -867,10 +883,11 @@ static int create_sharded_impl(bg_ctx* ctx, bg_comm* comm, const uint8_t* d_seq,
 
   // ---- 3 + 4: records
   std::vector<Rows> parts;
-  BG_TRY(records_sharded_cover(comm, ctx, H, W, k, &parts, &st.build.n_records, ph));
+  Rows first_covered;
+  BG_TRY(records_sharded_cover(comm, ctx, H, W, k, &parts, &st.build.n_records, ph, &first_covered));
 
   // ---- entries of this shard, boundaries, prev bits
-  BG_TRY(shard_from_parts(comm, ctx, H, parts, W, res->rank, &st.tails_sent_in_full, ph, true));
+  BG_TRY(shard_from_parts(comm, ctx, H, parts, W, res->rank, &st.tails_sent_in_full, ph, &first_covered));
   std::vector<uint64_t> part_n;
   BG_TRY(gather_u64(comm, {bg_seqset_size(H.shard)}, &part_n));
   for (uint64_t x : part_n) st.build.n_entries += x;
@@ -986,7 +1003,7 @@ static int merge_sharded_impl(bg_ctx* ctx, bg_comm* comm, uint32_t n_in, const b
   st.build.n_records = n_in_total;
 
   // ---- the shard
-  BG_TRY(shard_from_parts(comm, ctx, H, parts, W, me, &st.tails_sent_in_full, ph, false));  // (a merge's rows carry the input's number where a create's carry flags)
+  BG_TRY(shard_from_parts(comm, ctx, H, parts, W, me, &st.tails_sent_in_full, ph, nullptr));  // (a merge's rows carry the input's number where a create's carry flags)
   std::vector<uint64_t> part_n;
   BG_TRY(gather_u64(comm, {bg_seqset_size(H.shard)}, &part_n));
   for (uint64_t x : part_n) st.build.n_entries += x;

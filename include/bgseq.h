@@ -998,6 +998,9 @@ void bg_corr_free(bg_correction* c);
  *                           that stay uncovered after the last round (the last round must reach j_hi = 256). */
 typedef struct bg_cover bg_cover;
 typedef struct bg_cover_query bg_cover_query;
+/* the oriented reads whose suffix 1 is covered (their whole-read record is their last), as rows of W + 1 words: the look-up
+ * rows of bg_seqset_mark_need for a shard that sets prev bits where its records meet (d_rows NULL: the count alone) */
+int bg_cover_query_first_covered_rows(bg_ctx* ctx, const bg_cover_query* q, uint64_t* d_rows, uint64_t cap, uint64_t* n_out);
 int bg_oriented_rows(bg_ctx* ctx, const bg_reads* reads, int W_out, uint64_t* d_rows /* 2n x (W_out+1) */);
 int bg_rows_prefix_hist(bg_ctx* ctx, const uint64_t* d_rows, uint64_t n, int row_words, int bases, uint64_t every,
                         uint64_t* d_hist);
