@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void k
 // lane's own, so every pass is ONE round trip, and the 5.5 misses + 1 hit of an average read are 7 of them instead of 5.5 +
 // 2 behind each other.  What is rare goes the old way, lane by lane: runs of several candidates (cover_check_slot), slots
 // whose fingerprint belongs to another K-mer (cover_probe from the chain's start).  owords holds 8 spare words at its end
-// (a candidate's 64 bytes may reach past the last read).  chr20: 5.4 ms against 5.9 (and 6.1 before the staged reads); 90
+// (a candidate's 64 bytes may reach past the last read).  chr20: 5.05 ms with the runs parked (5.4 without) against 5.9 (and 6.1 before the staged reads); 90
 // registers, five waves per SIMD -- with the rare paths stubbed out (71 registers, seven waves) it took the same 5.3 ms, and
 // held to 64 registers by a waves-per-EU hint it spilled inside the loop and took 12.3.
 struct __attribute__((aligned(8))) CoverPair { uint64_t x, y; };
@@ -220,10 +220,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_co
   const uint64_t* const chunk_words = owords + (o_base + chunk0) * uint64_t(W);
   const uint64_t slot_mask = (1ull << ci.log2cap) - 1;
   uint32_t next = 0, sbase = ~0u, t = 0;
-  bool active = false, verify = false, fresh = true;
+  bool active = false, verify = false, fresh = true, parked = false;
   int L = 0, j = 0, c = 0;
   uint32_t vc = 0, vlen = 0;
-  uint64_t key = 0, pb = 0;
+  uint64_t key = 0, pb = 0, psv = 0;
   for (;;) {
     const uint64_t need = __ballot(!active);
     if (need) {
@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_co
           c = 1;
           verify = false;
           fresh = true;
+          parked = false;
           if (L <= 1) counts[t] = uint8_t(L);
           else active = true;
           want = false;
@@ -277,7 +278,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_co
     int res = -1;  // 1: suffix j is covered, 0: it is not, -1: not known yet
     const int rem = L - j;
     const CoverPair* p = nullptr;
-    if (active) {
+    // Lanes whose slot named a RUN of candidates (mates, duplicates, a repeat family) wait, parked, until a quarter of the
+    // wave is -- then they walk their runs together (cover_check_slot: a chain of dependent loads per lane).  Taken as they
+    // came, one or two lanes did that in nearly every pass and the other sixty waited: a genome with 7.5 % of it in 5000
+    // copies of one element took 10.0 ms here against 5.9 in k_cover_count.
+    {
+      const uint64_t pk = __ballot(active && parked);
+      if (pk && (__popcll(pk) >= 16 || !__ballot(active && !parked))) {
+        if (active && parked) {
+          const int r = cover_check_slot(ci, owords, s, j, rem, W, key, psv);
+          res = r >= 0 ? r : (cover_probe(ci, owords, s, L, j, W) ? 1 : 0);
+          parked = false;
+        }
+      }
+    }
+    if (active && !parked && res < 0) {
       if (verify) {
         p = reinterpret_cast<const CoverPair*>(owords + uint64_t(vc) * uint64_t(W));
       } else if (rem < ci.K) {
@@ -334,8 +349,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_co
           vlen = uint32_t(sv >> 32) & 0xffu;
           verify = true;  // the next pass fetches the candidate
         } else {
-          const int r = cover_check_slot(ci, owords, s, j, rem, W, key, sv);
-          res = r >= 0 ? r : (cover_probe(ci, owords, s, L, j, W) ? 1 : 0);
+          psv = sv;
+          parked = true;
         }
       } else if (empty) {
         res = 0;
@@ -2060,8 +2075,7 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
     ctx->toc(n_emit * W * 8 * 2);
   }
   BG_TRY(exclusive_scan_u32_to_u64(ctx, cnt.p, roff.p, n_emit, total.p));
-  BG_HIP(hipMemcpyAsync(&n_rec, total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-  BG_HIP(hipStreamSynchronize(ctx->stream));
+  BG_HIP(copy_d2h(ctx, &n_rec, total.p, 8));
   BG_TRY(rec->alloc(ctx, n_rec * RS));
   if (RS == W) BG_TRY(rlen->alloc(ctx, n_rec));  // (rows of W + 1 words carry the lengths themselves)
   const bool want_k0 = k0 && n_rec < (1ull << 32);
@@ -2385,8 +2399,7 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
     }
   }
   uint32_t h_err[2] = {0, 0};
-  BG_HIP(hipMemcpyAsync(h_err, err.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-  BG_HIP(hipStreamSynchronize(ctx->stream));
+  BG_HIP(copy_d2h(ctx, h_err, err.p, 8));
   if (h_err[0] & 1) { set_error("suffix records not sorted (internal error)"); return BG_EINTERNAL; }
   if (n_tied_out) *n_tied_out = n_tied;
   return BG_OK;
@@ -2566,8 +2579,7 @@ int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss, LocalPrev* lp) {
     BG_LAUNCH_CHECK();
     ctx->toc(lp->n_items * (ss->W * 8 + 8 + 16) + n_ent * 2);
     uint32_t h_err[2] = {0, 0};
-    BG_HIP(hipMemcpyAsync(h_err, err.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    BG_HIP(hipStreamSynchronize(ctx->stream));
+    BG_HIP(copy_d2h(ctx, h_err, err.p, 8));
     if (h_err[0] & 2) { set_error("missing expansion (entry set not closed under pop_front)"); return BG_EINTERNAL; }
     if (h_err[0] & 4) { set_error("prev bits: the two-word search disagrees with the full-key search (internal error)"); return BG_EINTERNAL; }
     return BG_OK;
@@ -2622,8 +2634,7 @@ int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss, LocalPrev* lp) {
     ctx->toc(n_ent * (ss->W * 8 + 1 + 8));
   }
   uint32_t h_err[2] = {0, 0};
-  BG_HIP(hipMemcpyAsync(h_err, err.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-  BG_HIP(hipStreamSynchronize(ctx->stream));
+  BG_HIP(copy_d2h(ctx, h_err, err.p, 8));
   if (h_err[0] & 2) { set_error("missing expansion (entry set not closed under pop_front)"); return BG_EINTERNAL; }
   if (h_err[0] & 4) { set_error("prev bits: the two-word search disagrees with the full-key search (internal error)"); return BG_EINTERNAL; }
   return BG_OK;
