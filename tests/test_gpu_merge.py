@@ -256,3 +256,33 @@ def test_bgbinary_merge_over_ranks_reproduces_family_lambda(ctx, golden_dir, tmp
             for w in ("bits", "subaccum", "accum"):
                 name = "read_ids/%s/%s" % (sel, w)
                 assert rm.part(name) == gm["raw"][name], (s, name)
+
+
+def test_merge_sharded_maps_equal_the_single_gpu_merge_maps(ctx, golden_dir, monkeypatch):
+    """bg_merge_sharded through the C ABI at world 1 with every collective through RCCL (BG_COMM_NO_SHORTCUT): the merge maps of
+    the three golden lambda seqsets == bg_seqset_merge's, the slice == the merged seqset."""
+    import ctypes as C
+    import torch
+    from biograph_amd import capi, sharded
+    monkeypatch.setenv("BG_COMM_NO_SHORTCUT", "1")
+    L = capi.lib()
+    names = ["father", "mother", "proband"]
+    ins = [ctx.open_seqset(golden_dir + "/%s_lambda/seqset" % s) for s in names]
+    want, wmaps = ctx.merge_seqsets(ins)
+    comm = sharded.NativeComm(ctx, 0, 1, sharded.NativeComm.unique_id(), "rccl")
+    try:
+        hs = (C.c_void_p * 3)(*[s.h for s in ins])
+        maps = [torch.empty(max(s.size(), 1), dtype=torch.int64, device="cuda") for s in ins]
+        mp = (C.c_void_p * 3)(*[m.data_ptr() for m in maps])
+        out = C.c_void_p()
+        st = capi.ShardedStats()
+        capi.check(L.bg_merge_sharded(ctx.h, comm.h, 3, hs, C.byref(out), C.byref(st), mp))
+        try:
+            torch.cuda.synchronize()
+            assert st.build.n_entries == want.size() == 103996
+            for k in range(3):
+                assert (maps[k].cpu().numpy().astype(np.uint64)[:ins[k].size()] == wmaps[k]).all(), names[k]
+        finally:
+            L.bg_sharded_free(out)
+    finally:
+        comm.free()
