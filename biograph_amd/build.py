@@ -80,6 +80,13 @@ def build(force=False, verbose=False):
         run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-Wall", "-I" + pybind11.get_include(),
              "-I" + sysconfig.get_paths()["include"], "-o", capi_out, capi_src, "-L" + HERE, "-lbgseq",
              "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")])
+    # the same module under the name the reference's package imports (python/biograph/__init__.py:24: biograph._capi_<maj><min>)
+    ref_name = "_capi_%d%d" % sys.version_info[:2]
+    ref_out = os.path.join(HERE, ref_name + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+    if force or _stale(ref_out, [capi_src, LIB] + hdrs):
+        run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-Wall", "-DBG_CAPI_MODULE=" + ref_name,
+             "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], "-o", ref_out, capi_src, "-L" + HERE, "-lbgseq",
+             "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")])
     return LIB
 
 

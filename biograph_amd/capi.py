@@ -251,6 +251,13 @@ def lib():
     L.bg_create_sample.argtypes = [vp, vp, vp, u64, P(CreateParams), i32, P(vp), P(vp), P(BuildStats)]
     L.bg_partition_rows.argtypes = [vp, vp, u64, i32, i32, u32, vp, vp, vp]
     L.bg_ctx_memory.argtypes = [vp, P(u64), P(u64), P(u64), i32]
+    L.bg_bwt_open.argtypes = [C.c_char_p, P(vp)]
+    L.bg_bwt_free.argtypes = [vp]
+    L.bg_bwt_free.restype = None
+    L.bg_bwt_entries.argtypes = [vp]
+    L.bg_bwt_entries.restype = u64
+    L.bg_bwt_find.argtypes = [vp, C.c_char_p, u64, P(u64), P(u64)]
+    L.bg_bwt_match.argtypes = [vp, u64, P(u64)]
     L.bg_reference_open.argtypes = [C.c_char_p, P(vp)]
     L.bg_reference_free.argtypes = [vp]
     L.bg_reference_free.restype = None

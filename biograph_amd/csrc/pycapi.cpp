@@ -5,7 +5,10 @@
 //   Seqset, SeqsetEntry      python/biograph/seqset.cpp:46-183      (invalid results are None, valid_or_none :20-42)
 //   Readmap, ReadmapRead     python/biograph/readmap.cpp:27-116
 //   BioGraph                 python/biograph/biograph.cpp:39-79
-//   Reference (what the graph functions need of it)  python/biograph/reference.cpp
+//   Reference, ReferenceRange, ReferenceContext   python/biograph/reference.cpp:14-185 (the BWT search on the host:
+//                            bg_bwt_*)
+//   Sequence                 python/biograph/dna_sequence.cpp:69-158;  CacheStrategy  biograph.cpp:9-37 (accepted and
+//                            ignored: the files are read once into HBM);  version, build_revision  version.cpp:15-18
 //   Assembly + make_ref_assemblies, graph_trim_ref, update_rc_seqset_entries, discover_branch,
 //   discover_push_to_pair    python/biograph/variants/graph_discover.cpp:109-133, variants/assemble.h:285-420
 //
@@ -17,6 +20,7 @@
 #include <limits.h>
 #include <string.h>
 
+#include <algorithm>
 #include <fstream>
 #include <map>
 #include <memory>
@@ -425,34 +429,221 @@ struct BioGraphObj {
   }
 };
 
+enum class CacheStrategy { MMAP, MMAPCACHE, RAM };  // biograph::cache_strategy
+#ifndef BG_AMD_VERSION
+#define BG_AMD_VERSION "biograph_amd-r5"
+#endif
+#ifndef BG_AMD_BUILD_REVISION
+#define BG_AMD_BUILD_REVISION "unknown"
+#endif
+
 // ---- reference + assemblies
+// dna_sequence as the SDK shows it (python/biograph/dna_sequence.cpp:69-158): upper-case ACGT, anything else throws
+struct Seq {
+  std::string s;
+  Seq() {}
+  explicit Seq(const std::string& in) : s(in) {
+    for (char& c : s) {
+      const char u = char(c & ~0x20);
+      if (u != 'A' && u != 'C' && u != 'G' && u != 'T') throw std::runtime_error(std::string("Converting invalid base to dna_base: '") + c + "'");
+      c = u;
+    }
+  }
+  Seq rev_comp() const {
+    Seq r;
+    r.s.resize(s.size());
+    for (size_t i = 0; i < s.size(); ++i) {
+      const char c = s[s.size() - 1 - i];
+      r.s[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
+    }
+    return r;
+  }
+};
+// what the SDK's functions take where the reference converts a str to a Sequence implicitly
+std::string bases_of(const py::object& o) { return py::isinstance<Seq>(o) ? o.cast<const Seq&>().s : Seq(py::str(o).cast<std::string>()).s; }
+void slice_of(const py::slice& sl, size_t n, ssize_t* start, ssize_t* stop, ssize_t* len) {
+  ssize_t step = 0;
+  if (!sl.compute(n, reinterpret_cast<size_t*>(start), reinterpret_cast<size_t*>(stop), reinterpret_cast<size_t*>(&step), reinterpret_cast<size_t*>(len))) throw py::error_already_set();
+  if (step != 1) throw py::index_error("Slicing a DNA sequence with steps other than 1 not supported");
+}
+
 struct ReferenceObj {
   bg_reference* h = nullptr;
-  explicit ReferenceObj(const std::string& path) { check(bg_reference_open(path.c_str(), &h), "Reference"); }
-  ~ReferenceObj() { if (h) bg_reference_free(h); }
+  bg_bwt* bwt = nullptr;  // opened by the first find()
+  std::string path;
+  struct Super { uint32_t sc; uint64_t off, len, flat; };
+  std::vector<Super> supers;  // in flat order (scaffold order, then offset: reference_assembly.cpp:146-163)
+  explicit ReferenceObj(const std::string& p) : path(p) {
+    check(bg_reference_open(path.c_str(), &h), "Reference");
+    for (uint32_t i = 0; i < bg_reference_supercontig_count(h); ++i) {
+      Super s{};
+      check(bg_reference_supercontig(h, i, &s.sc, &s.off, &s.len, &s.flat), "bg_reference_supercontig");
+      supers.push_back(s);
+    }
+    std::sort(supers.begin(), supers.end(), [](const Super& a, const Super& b) { return a.flat < b.flat; });
+  }
+  ~ReferenceObj() {
+    if (bwt) bg_bwt_free(bwt);
+    if (h) bg_reference_free(h);
+  }
   std::map<std::string, uint64_t> scaffold_lens() const {
     std::map<std::string, uint64_t> m;
     for (uint32_t i = 0; i < bg_reference_scaffold_count(h); ++i) m[bg_reference_scaffold_name(h, i)] = bg_reference_scaffold_len(h, i);
     return m;
   }
+  int32_t scaffold_index(const std::string& name) const {
+    for (uint32_t i = 0; i < bg_reference_scaffold_count(h); ++i) if (name == bg_reference_scaffold_name(h, i)) return int32_t(i);
+    throw std::runtime_error("Unknown scaffold " + name);
+  }
   // the N-free extents of one scaffold: (offset inside the scaffold, bases)
   std::vector<std::pair<int64_t, std::string>> extents(const std::string& name) const {
-    int32_t want = -1;
-    for (uint32_t i = 0; i < bg_reference_scaffold_count(h); ++i) if (name == bg_reference_scaffold_name(h, i)) want = int32_t(i);
-    if (want < 0) throw std::runtime_error("Unknown scaffold " + name);
+    const int32_t want = scaffold_index(name);
     std::vector<std::pair<int64_t, std::string>> out;
-    for (uint32_t i = 0; i < bg_reference_supercontig_count(h); ++i) {
-      uint32_t sc = 0;
-      uint64_t off = 0, len = 0, flat = 0;
-      check(bg_reference_supercontig(h, i, &sc, &off, &len, &flat), "bg_reference_supercontig");
-      if (int32_t(sc) != want) continue;
-      std::string s(len, '\0');
-      check(bg_reference_bases(h, flat, len, &s[0]), "bg_reference_bases");
-      out.emplace_back(int64_t(off), std::move(s));
+    for (const Super& sc : supers) {
+      if (int32_t(sc.sc) != want) continue;
+      std::string s(sc.len, '\0');
+      check(bg_reference_bases(h, sc.flat, sc.len, &s[0]), "bg_reference_bases");
+      out.emplace_back(int64_t(sc.off), std::move(s));
     }
     return out;
   }
+  const Super& super_at(uint64_t flat) const {  // reference_assembly::get_supercontig(flat position)
+    size_t a = 0, b = supers.size();
+    while (b - a > 1) {
+      const size_t m = (a + b) / 2;
+      if (supers[m].flat <= flat) a = m; else b = m;
+    }
+    if (supers.empty() || flat < supers[a].flat || flat > supers[a].flat + supers[a].len) throw std::runtime_error("flat position outside the reference");  // (== the end: only after the last extent)
+    return supers[a];
+  }
+  // reference_assembly::flatten (reference_assembly.cpp:100-135); false + why when the locus holds no sequence data
+  bool flatten(int32_t sc, const std::string& name, uint64_t pos, uint64_t* flat, std::string* why) const {
+    if (supers.empty()) throw std::runtime_error("The reference does not appear to contain any sequence data");
+    const Super* best = nullptr;  // the last extent of the scaffold that starts at or before pos
+    for (const Super& s : supers) if (int32_t(s.sc) == sc && s.off <= pos && (!best || s.off > best->off)) best = &s;
+    std::ostringstream o;
+    if (!best) {
+      o << name << ":" << pos << " comes before the first non-N sequence in the reference";
+    } else if (pos - best->off > best->len) {
+      o << name << ":" << pos << " is in a part of the reference (offset " << best->off << ", length " << best->len
+        << ") with no sequence data (only N bases)";
+    } else {
+      *flat = best->flat + (pos - best->off);
+      return true;
+    }
+    *why = o.str();
+    return false;
+  }
+  // reference_assembly::flatten_range (reference_assembly.cpp:172-243)
+  std::pair<uint64_t, uint64_t> flatten_range(const std::string& name, uint64_t start, uint64_t end, bool exact) const {
+    const int32_t sc = scaffold_index(name);
+    uint64_t fs = 0, fe = 0;
+    std::string why_s, why_e;
+    const bool ok_s = flatten(sc, name, start, &fs, &why_s), ok_e = flatten(sc, name, end, &fe, &why_e);
+    if (exact && !ok_s) throw std::runtime_error(why_s);
+    if (exact && !ok_e) throw std::runtime_error(why_e);
+    std::ostringstream o;
+    if (!ok_s && !ok_e) {
+      o << "Both the start (" << name << ":" << start << ") and end (" << name << ":" << end
+        << ") loci are in reference areas with no data (N bases).\n\nStart: " << why_s << "\n\nEnd: " << why_e;
+      throw std::runtime_error(o.str());
+    }
+    if (start >= end) {
+      o << "The start location \"" << name << ":" << start << "\" must come before the end location \"" << name << ":" << end
+        << "\" on the reference.";
+      throw std::runtime_error(o.str());
+    }
+    if (!ok_s) fs = super_at(fe - 1).flat;                                  // forward to the start of the end's extent
+    else if (!ok_e) { const Super& s = super_at(fs); fe = s.flat + s.len; }  // back to the end of the start's extent
+    if (&super_at(fs) != &super_at(fe - 1)) {
+      o << "The start location \"" << name << ":" << start << "\" and end location \"" << name << ":" << end
+        << "\" are not in the same contiguous region.";
+      throw std::runtime_error(o.str());
+    }
+    return {fs, fe};
+  }
 };
+
+// reference_range (python/biograph/reference.cpp:120-166): [start, end) of one extent, in flat positions
+struct RefRange {
+  std::shared_ptr<ReferenceObj> ref;
+  uint64_t fs = 0, fe = 0;
+  // reference_assembly::get_seq_position (reference_assembly.cpp:85-93).  As there, the end of a range that stops where its
+  // extent stops is the first position of the NEXT extent; past the last extent it is the position after its last base.
+  std::pair<uint32_t, uint64_t> seq_pos(uint64_t flat, bool) const {
+    const ReferenceObj::Super& s = ref->super_at(flat);
+    return {s.sc, s.off + (flat - s.flat)};
+  }
+  std::string scaffold() const { return bg_reference_scaffold_name(ref->h, seq_pos(fs, false).first); }
+  uint64_t start() const { return seq_pos(fs, false).second; }
+  uint64_t end() const { return seq_pos(fe, true).second; }
+  uint64_t size() const { return fe - fs; }
+  Seq sequence() const {
+    Seq q;
+    q.s.resize(fe - fs);
+    if (fe > fs) check(bg_reference_bases(ref->h, fs, fe - fs, &q.s[0]), "bg_reference_bases");
+    return q;
+  }
+  std::string str() const {
+    std::ostringstream o;
+    o << scaffold() << ":[" << start() << "-" << end() << ")";
+    return o.str();
+  }
+};
+RefRange make_range(const std::shared_ptr<ReferenceObj>& r, const std::string& name, uint64_t start, uint64_t end, bool exact) {
+  const auto fr = r->flatten_range(name, start, end, exact);
+  return RefRange{r, fr.first, fr.second};
+}
+// reference_wrapper::get_supercontig (reference.cpp:56-66): the extent that holds a position, as a range.  (The reference
+// asks make_range for [offset, offset + len - 1]: the range it returns is one base short of the extent; so is this one.)
+RefRange get_supercontig(const std::shared_ptr<ReferenceObj>& r, const std::string& name, uint64_t pos) {
+  const int32_t sc = r->scaffold_index(name);
+  uint64_t flat = 0;
+  std::string why;
+  if (!r->flatten(sc, name, pos, &flat, &why)) throw std::runtime_error(why);
+  const ReferenceObj::Super& s = r->super_at(flat);
+  return make_range(r, name, s.off, s.off + s.len - 1, false);
+}
+std::vector<RefRange> supercontigs(const std::shared_ptr<ReferenceObj>& r) {
+  std::vector<RefRange> out;
+  for (const auto& s : r->supers) out.push_back(get_supercontig(r, bg_reference_scaffold_name(r->h, s.sc), s.off));
+  return out;
+}
+std::vector<RefRange> find_ranges(const std::shared_ptr<ReferenceObj>& r, const std::string& name, uint64_t start, uint64_t end) {
+  const int32_t sc = r->scaffold_index(name);  // reference.cpp:68-88
+  std::vector<RefRange> out;
+  for (const auto& s : r->supers) {
+    if (int32_t(s.sc) != sc) continue;
+    const RefRange whole = get_supercontig(r, name, s.off);
+    if (whole.start() > end || whole.end() < start) continue;
+    out.push_back(make_range(r, name, std::max<uint64_t>(whole.start(), start), std::min<uint64_t>(whole.end(), end), false));
+  }
+  return out;
+}
+
+// bwt_wrapper (python/biograph/reference.cpp:168-185, reference.h): the sorted suffixes of the reference that start with
+// the query
+struct RefContext {
+  std::shared_ptr<ReferenceObj> ref;
+  Seq query;
+  uint64_t begin = 0, end = 0;
+  bool valid() const { return begin < end; }
+  uint64_t matches() const { return valid() ? end - begin : 0; }
+  RefRange get_match(uint64_t which) const {
+    if (!valid()) throw std::runtime_error("Called get_match() on an invalid bwt object");
+    if (which >= matches()) throw std::runtime_error("Called get_match() on invalid match " + std::to_string(which));
+    uint64_t flat = 0;
+    check(bg_bwt_match(ref->bwt, begin + which, &flat), "bg_bwt_match");
+    return RefRange{ref, flat, flat + query.s.size()};
+  }
+  std::string str() const { return ref->path + "{" + query.s + "}"; }
+};
+RefContext reference_find(const std::shared_ptr<ReferenceObj>& r, const py::object& seq) {
+  if (!r->bwt) check(bg_bwt_open(r->path.c_str(), &r->bwt), "Reference.find");
+  RefContext c{r, Seq(bases_of(seq))};
+  check(bg_bwt_find(r->bwt, c.query.s.data(), c.query.s.size(), &c.begin, &c.end), "bg_bwt_find");
+  return c;
+}
 
 struct Assembly {  // variants::assembly, the fields this path touches (variants/assemble.h:285-420)
   py::object left_offset = py::none(), right_offset = py::none();  // optional_aoffset
@@ -541,7 +732,13 @@ py::object iterate(std::vector<Assembly> v) {
 
 }  // namespace
 
-PYBIND11_MODULE(_capi, m) {
+// The reference names its module after the interpreter (python/biograph/module.cpp:30: _capi_<major><minor>, imported by
+// python/biograph/__init__.py:24 as biograph._capi_310 ...): built a second time with -DBG_CAPI_MODULE=_capi_310 the same
+// source is that module, to be dropped into the reference's python/biograph/ package.
+#ifndef BG_CAPI_MODULE
+#define BG_CAPI_MODULE _capi
+#endif
+PYBIND11_MODULE(BG_CAPI_MODULE, m) {
   m.attr("__doc__") = "Internal C API calls for the BioGraph SDK surface of biograph_amd (MI355X build of the seqset path)";
 
   py::class_<SeqsetObj, std::shared_ptr<SeqsetObj>>(m, "Seqset", "Load a Seqset (python/biograph/seqset.cpp:46).  Raises RuntimeError if the file cannot be opened.")
@@ -634,16 +831,108 @@ PYBIND11_MODULE(_capi, m) {
       .def_readonly("version", &Metadata::version)
       .def_readonly("samples", &Metadata::samples);
 
+  py::enum_<CacheStrategy>(m, "CacheStrategy", "How the reference library keeps a BioGraph's files (python/biograph/biograph.cpp:9-37).  Accepted for "
+                           "compatibility: this build reads the files once and keeps the tables in HBM whatever the mode.")
+      .value("MMAP", CacheStrategy::MMAP)
+      .value("MMAPCACHE", CacheStrategy::MMAPCACHE)
+      .value("RAM", CacheStrategy::RAM);
+
   py::class_<BioGraphObj, std::shared_ptr<BioGraphObj>>(m, "BioGraph", "A BioGraph directory: Seqset + Readmaps (python/biograph/biograph.cpp:39).")
       .def(py::init<const std::string&>(), py::arg("dirname"))
+      .def(py::init([](const std::string& d, CacheStrategy) { return std::make_shared<BioGraphObj>(d); }), py::arg("dirname"), py::arg("mode"))
       .def_property_readonly("seqset", [](const BioGraphObj& b) { return b.seqset; })
       .def("open_readmap", &BioGraphObj::open_readmap, py::arg("accession_id") = "")
       .def_property_readonly("metadata", [](const BioGraphObj& b) { return b.meta; });
 
-  py::class_<ReferenceObj, std::shared_ptr<ReferenceObj>>(m, "Reference", "A reference directory, .ref file or FASTA.")
+  py::class_<Seq>(m, "Sequence", "A DNA sequence, compared and sliced like a string (python/biograph/dna_sequence.cpp:69).")
+      .def(py::init<const std::string&>())
+      .def(py::init<>())
+      .def("__str__", [](const Seq& q) { return q.s; })
+      .def("__repr__", [](const Seq& q) { return "biograph.Sequence('" + q.s + "')"; })
+      .def("__len__", [](const Seq& q) { return q.s.size(); })
+      .def("rev_comp", &Seq::rev_comp, "A new Sequence: the reverse complement of this one.")
+      .def("__getitem__", [](const Seq& q, const py::slice& sl) {
+        ssize_t start, stop, len;
+        slice_of(sl, q.s.size(), &start, &stop, &len);
+        Seq r;
+        r.s = q.s.substr(size_t(start), size_t(len));
+        return r;
+      })
+      .def("__getitem__", [](const Seq& q, int pos) {
+        if (pos < 0) pos += int(q.s.size());
+        if (pos < 0 || pos >= int(q.s.size())) throw py::index_error();
+        Seq r;
+        r.s = q.s.substr(size_t(pos), 1);
+        return r;
+      })
+      .def("__setitem__", [](Seq& q, const py::slice& sl, const py::object& with) {
+        ssize_t start, stop, len;
+        slice_of(sl, q.s.size(), &start, &stop, &len);
+        q.s = q.s.substr(0, size_t(start)) + bases_of(with) + q.s.substr(size_t(stop));
+      })
+      .def("__setitem__", [](Seq& q, int pos, char with) {
+        if (pos < 0) pos += int(q.s.size());
+        if (pos < 0 || pos >= int(q.s.size())) throw py::index_error();
+        q.s[size_t(pos)] = Seq(std::string(1, with)).s[0];
+      })
+      .def("__lt__", [](const Seq& a, const Seq& b) { return a.s < b.s; })
+      .def("__le__", [](const Seq& a, const Seq& b) { return a.s <= b.s; })
+      .def("__gt__", [](const Seq& a, const Seq& b) { return a.s > b.s; })
+      .def("__ge__", [](const Seq& a, const Seq& b) { return a.s >= b.s; })
+      .def("__eq__", [](const Seq& a, const py::object& o) { return (py::isinstance<Seq>(o) || py::isinstance<py::str>(o)) && a.s == bases_of(o); })
+      .def("__ne__", [](const Seq& a, const py::object& o) { return !((py::isinstance<Seq>(o) || py::isinstance<py::str>(o)) && a.s == bases_of(o)); })
+      .def("__iadd__", [](Seq& a, const py::object& o) { a.s += bases_of(o); return a; })
+      .def("__add__", [](const Seq& a, const py::object& o) { Seq r; r.s = a.s + bases_of(o); return r; })
+      .def("__radd__", [](const Seq& a, const std::string& str) { Seq r; r.s = Seq(str).s + a.s; return r; })
+      .def("__hash__", [](const Seq& q) { return std::hash<std::string>{}(q.s); });
+  py::implicitly_convertible<std::string, Seq>();
+
+  py::class_<ReferenceObj, std::shared_ptr<ReferenceObj>>(m, "Reference", "A reference directory, .ref file or FASTA (python/biograph/reference.cpp:190).")
       .def(py::init<const std::string&>(), py::arg("path"))
+      .def("__str__", [](const ReferenceObj& r) { return r.path; })
+      .def("__repr__", [](const ReferenceObj& r) { return "<biograph.Reference " + r.path + ">"; })
+      .def("make_range", &make_range, py::arg("scaffold_name"), py::arg("start"), py::arg("end"), py::arg("use_exact_loci") = true,
+           "A ReferenceRange for 0-based [start, end) of a scaffold; with use_exact_loci=False a start or end inside an N region "
+           "moves to the edge of the sequence data.  RuntimeError if the two are not in one contiguous region.")
+      .def_property_readonly("size", [](const ReferenceObj& r) { return bg_reference_size(r.h); }, "The number of bases of the reference that are not N.")
+      .def_property_readonly("scaffolds", [](const ReferenceObj& r) {
+        std::vector<std::string> v;
+        for (const auto& kv : r.scaffold_lens()) v.push_back(kv.first);  // (a std::set ordered by name in the reference too)
+        return v;
+      })
+      .def_property_readonly("chromosomes", [](const ReferenceObj& r) {
+        std::vector<std::string> v;
+        for (const auto& kv : r.scaffold_lens()) v.push_back(kv.first);
+        return v;
+      })
+      .def_property_readonly("supercontigs", &supercontigs, "The contiguous (N-free) regions of the reference, in order, as ReferenceRanges.")
       .def_property_readonly("scaffold_lens", &ReferenceObj::scaffold_lens)
-      .def("size", [](const ReferenceObj& r) { return bg_reference_size(r.h); });
+      .def("get_supercontig", &get_supercontig, py::arg("scaffold_name"), py::arg("pos"))
+      .def("find_ranges", &find_ranges, py::arg("scaffold_name"), py::arg("start"), py::arg("end"))
+      .def("find", &reference_find, py::arg("seq"), "The ReferenceContext of a sequence: where it occurs in the reference (needs reference.bwt).");
+
+  py::class_<RefRange>(m, "ReferenceRange", "A region of one contiguous stretch of the reference, 0-based (python/biograph/reference.cpp:282).")
+      .def("__str__", &RefRange::str)
+      .def("__repr__", [](const RefRange& r) { return "<biograph.ReferenceRange " + r.str() + ">"; })
+      .def_property_readonly("scaffold", &RefRange::scaffold)
+      .def_property_readonly("chromosome", &RefRange::scaffold)
+      .def_property_readonly("start", &RefRange::start)
+      .def_property_readonly("end", &RefRange::end)
+      .def_property_readonly("sequence", &RefRange::sequence)
+      .def_property_readonly("size", &RefRange::size);
+
+  py::class_<RefContext>(m, "ReferenceContext", "Where a sequence occurs in the reference (python/biograph/reference.cpp:324).")
+      .def("__str__", &RefContext::str)
+      .def("__repr__", [](const RefContext& c) { return "<biograph.ReferenceContext " + c.str() + ">"; })
+      .def_property_readonly("matches", &RefContext::matches)
+      .def_property_readonly("valid", &RefContext::valid)
+      .def_property_readonly("start", [](const RefContext& c) { return c.begin; })
+      .def_property_readonly("end", [](const RefContext& c) { return c.end; })
+      .def("get_match", &RefContext::get_match, py::arg("which"))
+      .def_property_readonly("query", [](const RefContext& c) { return c.query; });
+
+  m.def("version", []() { return std::string(BG_AMD_VERSION); }, "BioGraph SDK version.");
+  m.def("build_revision", []() { return std::string(BG_AMD_BUILD_REVISION); }, "BioGraph build revision.");
 
   py::class_<Assembly>(m, "Assembly")
       .def(py::init([](py::object lo, py::object ro, std::string seq, bool mr, std::vector<std::string> tags) {

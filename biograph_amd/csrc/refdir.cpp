@@ -462,3 +462,108 @@ extern "C" int bg_reference_bases(const bg_reference* r, uint64_t flat_pos, uint
   memcpy(out, r->bases.data() + flat_pos, n);
   return BG_OK;
 }
+
+// ---- reference.bwt: bwt_file / bwt_range (bio_base/bwt_file.h:9-66, bwt_file.cpp:20-112) on the host --------------------
+// The file (bg_bwt_build writes it, csrc/bwt.hip): magic, offset of the msgpack header, five bit vectors of ca_table[4] bits
+// each (previous base A, C, G, T; century mark) in bitcount layout (words, then the format's own rank tables, which are
+// not used here: one cumulative count per 64-bit word is made at open), the century table, the header {2: ca_table[6]}.
+struct bg_bwt {
+  std::string blob;
+  uint64_t n = 0, ca[6] = {0, 0, 0, 0, 0, 0};
+  const uint64_t* bits[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  const uint32_t* century = nullptr;
+  std::vector<uint64_t> cum[5];  // set bits before word w
+  bool get(int v, uint64_t i) const { return (bits[v][i >> 6] >> (i & 63)) & 1; }
+  uint64_t count(int v, uint64_t i) const {  // set bits in [0, i)
+    const uint64_t w = i >> 6, r = i & 63;
+    return cum[v][w] + (r ? uint64_t(__builtin_popcountll(bits[v][w] & ((1ull << r) - 1))) : 0);
+  }
+};
+
+extern "C" int bg_bwt_open(const char* path_c, bg_bwt** out) {
+  if (!path_c || !out) { set_error("bg_bwt_open: null argument"); return BG_EINVAL; }
+  std::string path = path_c;
+  if (is_dir(path)) path += "/reference.bwt";
+  std::unique_ptr<bg_bwt> b(new bg_bwt);
+  if (!read_all(path, &b->blob)) { set_error("bg_bwt_open: cannot read %s", path.c_str()); return BG_EIO; }
+  const std::string& f = b->blob;
+  uint64_t magic = 0, off = 0;
+  if (f.size() >= 16) { memcpy(&magic, f.data(), 8); memcpy(&off, f.data() + 8, 8); }
+  if (magic != 0x57426C6172697053ull || off < 16 || off > f.size()) {
+    set_error("%s does not appear to be a valid BWT.", path.c_str());  // bwt_file.cpp:13
+    return BG_EIO;
+  }
+  Mp mp{reinterpret_cast<const unsigned char*>(f.data()) + off, reinterpret_cast<const unsigned char*>(f.data()) + f.size()};
+  uint64_t nkeys = 0, key = 0, na = 0;
+  bool have = false;
+  if (mp.map(&nkeys)) {
+    for (uint64_t i = 0; i < nkeys && mp.ok; ++i) {
+      if (!mp.uint(&key)) break;
+      if (key == 2 && mp.array(&na) && na == 6) {
+        for (int j = 0; j < 6; ++j) mp.uint(&b->ca[j]);
+        have = mp.ok;
+      } else {
+        mp.skip();
+      }
+    }
+  }
+  if (!have) { set_error("%s: malformed BWT header", path.c_str()); return BG_EIO; }
+  b->n = b->ca[4];
+  const uint64_t nwords = (b->n + 63) / 64, ngroups = (b->n + 511) / 512, naccum = (b->n + 512) / 512;
+  const uint64_t bits_size = (nwords + ngroups + naccum) * 8;  // bitcount::compute_size
+  if (16 + 5 * bits_size + 4 * b->ca[5] > off) { set_error("%s: BWT body shorter than its header says", path.c_str()); return BG_EIO; }
+  for (int v = 0; v < 5; ++v) {
+    b->bits[v] = reinterpret_cast<const uint64_t*>(f.data() + 16 + uint64_t(v) * bits_size);
+    b->cum[v].resize(nwords + 1);
+    uint64_t c = 0;
+    for (uint64_t w = 0; w < nwords; ++w) {
+      b->cum[v][w] = c;
+      c += uint64_t(__builtin_popcountll(b->bits[v][w]));
+    }
+    b->cum[v][nwords] = c;
+  }
+  b->century = reinterpret_cast<const uint32_t*>(f.data() + 16 + 5 * bits_size);
+  *out = b.release();
+  return BG_OK;
+}
+extern "C" void bg_bwt_free(bg_bwt* b) { delete b; }
+extern "C" uint64_t bg_bwt_entries(const bg_bwt* b) { return b ? b->n : 0; }
+
+// bwt_range::find (bwt_file.cpp:64-81): the range of sorted suffixes that start with seq (ACGT, either case); an empty
+// range (begin == end) when it does not occur.  A character that is no base is BG_EINVAL.
+extern "C" int bg_bwt_find(const bg_bwt* b, const char* seq, uint64_t len, uint64_t* begin, uint64_t* end) {
+  if (!b || (len && !seq) || !begin || !end) { set_error("bg_bwt_find: null argument"); return BG_EINVAL; }
+  uint64_t lo = 0, hi = b->n;
+  for (uint64_t i = len; i-- > 0;) {
+    int k;
+    switch (seq[i]) {
+      case 'A': case 'a': k = 0; break;
+      case 'C': case 'c': k = 1; break;
+      case 'G': case 'g': k = 2; break;
+      case 'T': case 't': k = 3; break;
+      default: set_error("bg_bwt_find: '%c' is not a base", seq[i]); return BG_EINVAL;
+    }
+    lo = b->ca[k] + b->count(k, lo);
+    hi = b->ca[k] + b->count(k, hi);
+    if (lo == hi) break;
+  }
+  *begin = lo;
+  *end = hi;
+  return BG_OK;
+}
+
+// bwt_range::get_match (bwt_file.cpp:93-112): the flat reference position of sorted suffix `entry`: steps back through the
+// previous bases to the nearest century mark
+extern "C" int bg_bwt_match(const bg_bwt* b, uint64_t entry, uint64_t* flat_pos) {
+  if (!b || !flat_pos) { set_error("bg_bwt_match: null argument"); return BG_EINVAL; }
+  if (entry >= b->n) { set_error("bg_bwt_match: entry %llu of %llu", (unsigned long long)entry, (unsigned long long)b->n); return BG_EINVAL; }
+  uint64_t e = entry, dist = 0;
+  while (!b->get(4, e)) {
+    const int k = (b->get(1, e) ? 1 : 0) + (b->get(2, e) ? 2 : 0) + (b->get(3, e) ? 3 : 0);
+    if (k == 0 && !b->get(0, e)) { set_error("bg_bwt_match: suffix %llu starts an extent without a century mark", (unsigned long long)e); return BG_EINTERNAL; }
+    e = b->ca[k] + b->count(k, e);
+    if (++dist > b->n) { set_error("bg_bwt_match: no century mark reached"); return BG_EINTERNAL; }
+  }
+  *flat_pos = uint64_t(b->century[b->count(4, e)]) + dist;
+  return BG_OK;
+}

@@ -825,6 +825,17 @@ int bg_reference_supercontig(const bg_reference* ref, uint32_t i, uint32_t* scaf
                              uint64_t* flat);
 int bg_reference_bases(const bg_reference* ref, uint64_t flat_pos, uint64_t n, char* out);
 
+/* ---- reference.bwt on the host: bwt_file / bwt_range (modules/bio_base/bwt_file.h:9-66, bwt_file.cpp:20-112), what
+ * python/biograph/reference.cpp:116-185 (Reference.find -> ReferenceContext) reads.  bg_bwt_open takes the file or the
+ * reference directory that holds it.  bg_bwt_find = bwt_range::find over the whole table (an empty range when the
+ * sequence does not occur); bg_bwt_match = bwt_range::get_match for one sorted suffix: its flat reference position. */
+typedef struct bg_bwt bg_bwt;
+int bg_bwt_open(const char* path, bg_bwt** out);
+void bg_bwt_free(bg_bwt* bwt);
+uint64_t bg_bwt_entries(const bg_bwt* bwt);
+int bg_bwt_find(const bg_bwt* bwt, const char* seq, uint64_t len, uint64_t* begin, uint64_t* end);
+int bg_bwt_match(const bg_bwt* bwt, uint64_t entry, uint64_t* flat_pos);
+
 /* ---- `biograph reference` (modules/main/make_ref.cpp -> pipeline/build_reference_task.cpp): building a reference
  * directory.  bg_reference_build = IMPORT_FASTA + MAKE_FLAT on the host (bio_format/fasta_ref_importer.cpp,
  * bio_base/flat_ref.cpp:224-360): reads plain FASTA text and writes <refdir>/reference.fasta, karyotype.json and
