@@ -873,6 +873,40 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
     tidx[i] = r;
   }
   __syncthreads();
+#ifdef BG_EXP_GATHER16
+  if ((RS & 1) == 0) {
+    // rows of an even number of words are 16-byte aligned: two words a load, half the requests
+    const int RP = RS >> 1;
+    const uint32_t rcp = (65536u + uint32_t(RP) - 1) / uint32_t(RP);
+    const int total = NS * RP;
+    constexpr int kIters = (kFusedSlots * ((kMaxWords + 2) / 2) + kGatherTile - 1) / kGatherTile;
+    ulonglong2 v[kIters];
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+      const int g = tid + it * kGatherTile;
+      v[it] = make_ulonglong2(0, 0);
+      if (g < total) {
+        const int i = int((uint32_t(g) * rcp) >> 16), h = g - i * RP;
+        const uint32_t r = tidx[i];
+        if (r != 0xffffffffu) v[it] = *reinterpret_cast<const ulonglong2*>(rec + uint64_t(r) * RS + 2 * h);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+      const int g = tid + it * kGatherTile;
+      if (g < total) {
+        const int i = int((uint32_t(g) * rcp) >> 16), h = g - i * RP;
+        const uint64_t xs[2] = {v[it].x, v[it].y};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int w = 2 * h + u;
+          if (w < W) tile[i * W + w] = xs[u];
+          else if (w == W) { tlen[i] = uint8_t(xs[u]); tmeta[i] = uint8_t(xs[u] >> 8); }
+        }
+      }
+    }
+  } else
+#endif
   {
     // RS words of every row: its W key words and, when RS = W + 1, its length (a request of its own otherwise: the
     // lengths' lines were a third of what the kernel fetched)
@@ -904,7 +938,10 @@ __global__ __launch_bounds__(kGatherTile) void k_gather_dedup_build(
 #ifdef BG_EXP_GATHER_ONLY  // timing experiment (tools/build_variant.sh): what the gather alone costs -- the tile's rows straight out again
   for (int x = tid; x < kFusedTile * W; x += kGatherTile)
     if (b0 * W + x < n * uint64_t(W)) ekeys[b0 * W + x] = tile[H * W + x];
+  if (tid == 0) tile_first[t] = ~0ull;
   if (tid == 0 && b0 + kFusedTile >= n) state[(n + kFusedTile - 1) / kFusedTile - 1] = kScanIncl | n;
+  for (int x = tid; x < kFusedTile; x += kGatherTile)
+    if (b0 + x < n) { sizes[b0 + x] = tlen[H + x]; shared[b0 + x] = 0; if (emask) emask[b0 + x] = 0; }
   return;
 #endif
   // pmap[i] = the slot whose row belongs at slot i.  Every member of a small group finds its rank in the group by

@@ -1278,13 +1278,117 @@ static int cmd_merge(int argc, char** argv) {
 // scaffold the serial pipeline (pipeline.cpp:40-57,92-101) and one VCF record per surviving variant
 // (ploidless_vcf_export.cpp).  PI is the record's ordinal (the reference's process-wide assembly counter is not
 // reproducible); the header's static lines are the reference's, the source line names this program.
+// A rank of `discovery --gpus N` (trace_ref.cpp:44-63,105-140 over processes instead of threads): the pieces of every scaffold
+// go round-robin to the ranks, each traces its pieces (push forward, push reverse, the two pop tracers) on its GPU, the
+// assemblies of a scaffold travel to the rank that owns it (scaffold index % world), which runs the serial pipeline, the
+// coverage step and the genotype filter there; rank 0 puts the records together in scaffold order.
+struct RankEnv {
+  int rank = 0, world = 1, device = 0;
+  bg_comm* comm = nullptr;
+};
+
+struct Blob {
+  std::string b;
+  template <class T> void put(const T& v) { b.append(reinterpret_cast<const char*>(&v), sizeof(T)); }
+  void put_u32s(const uint32_t* p, uint64_t n) { put(n); if (n) b.append(reinterpret_cast<const char*>(p), n * 4); }
+};
+struct BlobIn {
+  const char* p;
+  const char* e;
+  template <class T> T get() {
+    if (size_t(e - p) < sizeof(T)) die("discovery --gpus: a rank's assemblies arrived cut short");
+    T v;
+    memcpy(&v, p, sizeof(T));
+    p += sizeof(T);
+    return v;
+  }
+  const char* bytes(uint64_t n) {
+    if (uint64_t(e - p) < n) die("discovery --gpus: a rank's assemblies arrived cut short");
+    const char* q = p;
+    p += n;
+    return q;
+  }
+};
+
+// every assembly of a work item's result, as bg_trace_result_get shows it.  Assembly ids come from a per-process counter: id *
+// world + rank keeps them apart over the ranks (rvg_exclude groups sections by them).
+static void put_result(Blob* out, const bg_trace_result* r, int rank, int world) {
+  const uint64_t n = r ? bg_trace_result_size(r) : 0;
+  out->put(n);
+  for (uint64_t i = 0; i < n; ++i) {
+    bg_trace_assembly x;
+    check(bg_trace_result_get(r, i, &x), "bg_trace_result_get");
+    out->put(x.left_offset); out->put(x.right_offset); out->put(x.score);
+    out->put(x.left_anchor_len); out->put(x.right_anchor_len);
+    out->put(x.min_overlap); out->put(x.trace_steps); out->put(x.left_anchor_ambiguous_bases);
+    out->put(x.matches_reference); out->put(x.from_pop);
+    out->put(uint64_t(x.assembly_id * uint64_t(world) + uint64_t(rank)));
+    out->put(x.seq_len);
+    out->b.append(x.seq, x.seq_len);
+    out->put_u32s(x.rc_read_ids, x.n_rc_read_ids);
+    out->put_u32s(x.left_pair_matches, x.n_left_pair_matches);
+    out->put_u32s(x.right_pair_matches, x.n_right_pair_matches);
+  }
+}
+static bg_trace_result* get_result(BlobIn* in) {
+  bg_trace_result* r = nullptr;
+  check(bg_trace_result_new(&r), "bg_trace_result_new");
+  const uint64_t n = in->get<uint64_t>();
+  for (uint64_t i = 0; i < n; ++i) {
+    bg_trace_assembly x;
+    memset(&x, 0, sizeof x);
+    x.left_offset = in->get<int64_t>(); x.right_offset = in->get<int64_t>(); x.score = in->get<int64_t>();
+    x.left_anchor_len = in->get<int32_t>(); x.right_anchor_len = in->get<int32_t>();
+    x.min_overlap = in->get<uint32_t>(); x.trace_steps = in->get<uint32_t>(); x.left_anchor_ambiguous_bases = in->get<uint32_t>();
+    x.matches_reference = in->get<int32_t>(); x.from_pop = in->get<int32_t>();
+    x.assembly_id = in->get<uint64_t>();
+    x.seq_len = in->get<uint64_t>();
+    x.seq = in->bytes(x.seq_len);
+    std::vector<uint32_t> ids[3];
+    for (int k = 0; k < 3; ++k) {
+      const uint64_t m = in->get<uint64_t>();
+      const char* q = in->bytes(m * 4);
+      ids[k].resize(m);
+      if (m) memcpy(ids[k].data(), q, m * 4);
+    }
+    x.rc_read_ids = ids[0].data(); x.n_rc_read_ids = ids[0].size();
+    x.left_pair_matches = ids[1].data(); x.n_left_pair_matches = ids[1].size();
+    x.right_pair_matches = ids[2].data(); x.n_right_pair_matches = ids[2].size();
+    check(bg_trace_result_add(r, &x), "bg_trace_result_add");
+  }
+  return r;
+}
+
+// every rank's bytes on every rank (sizes over the host, the bytes through the communicator's device all-gather)
+static std::vector<std::string> gather_blobs(const RankEnv& env, bg_ctx* ctx, const std::string& mine) {
+  std::vector<uint64_t> sizes(size_t(env.world), 0);
+  const uint64_t n = mine.size();
+  check(bg_comm_all_gather_host(env.comm, &n, 8, sizes.data()), "bg_comm_all_gather_host");
+  uint64_t total = 0;
+  for (uint64_t v : sizes) total += v;
+  void *d_send = nullptr, *d_recv = nullptr;
+  check(bg_dev_alloc(ctx, n ? n : 1, &d_send), "bg_dev_alloc");
+  check(bg_dev_alloc(ctx, total ? total : 1, &d_recv), "bg_dev_alloc");
+  if (n) check(bg_dev_upload(ctx, d_send, mine.data(), n), "upload");
+  check(bg_comm_all_gather(env.comm, d_send, sizes.data(), d_recv), "bg_comm_all_gather");
+  std::string all(total, '\0');
+  if (total) check(bg_dev_download(ctx, &all[0], d_recv, total), "download");
+  bg_dev_free(ctx, d_send);
+  bg_dev_free(ctx, d_recv);
+  std::vector<std::string> parts;
+  uint64_t at = 0;
+  for (uint64_t v : sizes) { parts.push_back(all.substr(at, v)); at += v; }
+  return parts;
+}
+
 static int discovery_push(Args& a, const std::vector<std::pair<std::string, std::string>>& recs,
                           const std::map<std::string, std::vector<std::pair<int64_t, int64_t>>>& bed, bg_ctx* ctx, bg_seqset* ss,
                           bg_readmap* rm, uint32_t min_overlap, int64_t max_pair_distance, const std::string& sample,
                           const std::vector<uint8_t>& flat_codes, const std::vector<uint64_t>& flat_start,
-                          const std::vector<uint64_t>& flat_size) {
+                          const std::vector<uint64_t>& flat_size, const RankEnv& env) {
   const double t0 = now_s();
   const uint64_t n = bg_seqset_size(ss);
+  const bool ranks = env.world > 1 || env.comm != nullptr;  // (--force-sharded: one rank through the same path)
   void *d_ref = nullptr, *d_map = nullptr;
   check(bg_dev_alloc(ctx, flat_codes.size() ? flat_codes.size() : 1, &d_ref), "bg_dev_alloc");
   check(bg_dev_alloc(ctx, n ? n : 1, &d_map), "bg_dev_alloc");
@@ -1292,11 +1396,12 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   // renamed when FILE does not exist, then opened; "no validity checking is done to make sure this matches the current
   // reference and seqset" beyond its size (ref_map.cpp: CHECK_EQ(m_ref_map->size(), m_seqset->size()))
   const std::string ref_map_file = a.get("ref-map");
-  if (ref_map_file.empty() || !exists(ref_map_file)) {
+  const bool ref_map_on_file = !ref_map_file.empty() && exists(ref_map_file);
+  if (!ref_map_on_file) {
     check(bg_dev_upload(ctx, d_ref, flat_codes.data(), flat_codes.size()), "upload");
     check(bg_ref_map_build(ctx, ss, static_cast<const uint8_t*>(d_ref), flat_start.size(), flat_start.data(), flat_size.data(), 0,
                            static_cast<uint8_t*>(d_map)), "bg_ref_map_build");
-    if (!ref_map_file.empty()) {
+    if (!ref_map_file.empty() && env.rank == 0) {  // (ranks: the first one writes it, every rank keeps what it built)
       std::vector<uint8_t> h(n);
       check(bg_dev_download(ctx, h.data(), d_map, n), "download");
       const std::string fresh = ref_map_file + ".new";
@@ -1307,7 +1412,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
       if (rename(fresh.c_str(), ref_map_file.c_str()) != 0) die("Could not rename " + fresh);
     }
   }
-  if (!ref_map_file.empty()) {
+  if (ref_map_on_file || (!ref_map_file.empty() && !ranks)) {
     fprintf(stderr, "Opening refmap %s\n", ref_map_file.c_str());
     std::vector<uint8_t> h(n ? n : 1);
     check(bg_ref_map_read(ref_map_file.c_str(), h.data(), n), "bg_ref_map_read");
@@ -1340,6 +1445,8 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   std::string half_csv;
   const bool want_half = a.has("half-aligned-out") && !a.get("half-aligned-out").empty();
   if (want_half) half_csv = "scaffold_name,left_anchor,right_anchor,sequence,assembly_id\n";
+  if (ranks && (want_csv || want_aligned || want_half))
+    die("discovery --gpus: --assemblies-out, --aligned-assemblies-out and --half-aligned-out are written by the single-process command only");
   opt.max_pair_distance = uint64_t(max_pair_distance);
   if (a.has("scaffold-split-size")) {  // assemble_options::scaffold_split_size (the size of trace_ref's pieces)
     const long long sp = atoll(a.get("scaffold-split-size").c_str());
@@ -1385,14 +1492,14 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   bg_coverage* cov_session = nullptr;
   std::thread cov_open([&] {
     bg_ctx* ctx_cov = nullptr;
-    check(bg_ctx_create_own_stream(0, &ctx_cov), "bg_ctx_create_own_stream");
+    check(bg_ctx_create_own_stream(env.device, &ctx_cov), "bg_ctx_create_own_stream");
     check(bg_coverage_open(ctx_cov, ss, rm, &cov_session), "bg_coverage_open");
   });
   std::vector<bg_ctx*> wctx(size_t(n_threads), nullptr);
   std::vector<bg_tracer*> tracers(size_t(n_threads), nullptr);
   for (int t = 0; t < n_threads; ++t) {
     wctx[size_t(t)] = t == 0 ? ctx : nullptr;
-    if (t) check(bg_ctx_create_own_stream(0, &wctx[size_t(t)]), "bg_ctx_create_own_stream");
+    if (t) check(bg_ctx_create_own_stream(env.device, &wctx[size_t(t)]), "bg_ctx_create_own_stream");
     if (t == 0)
       check(bg_tracer_open(wctx[0], ss, rm, static_cast<const uint8_t*>(d_map), &opt, &tracers[0]), "bg_tracer_open");
     else
@@ -1436,6 +1543,36 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   double rss_trace = 0, rss_pipe = 0, rss_cov = 0;
   std::thread finisher;  // the scaffold before the one being traced, behind its tracers
   const double rss_sessions = rss_gb();
+  struct ScaffoldData {
+    std::vector<int64_t> eo;
+    std::vector<std::string> es;
+    std::vector<const char*> ep;
+    std::vector<uint64_t> el;
+    std::vector<bg_trace_result*> items;
+    const std::string* name;
+    const std::string* seq;
+  };
+  // the VCF record lines of a scaffold's kept sections, numbered from `before` + 1 on (ploidless_vcf_export: PI); how many
+  auto format_records = [&](const bg_trace_result* kept, const ScaffoldData& d, uint64_t before, std::string* out) {
+    std::vector<char> buf(1 << 16);
+    uint64_t made = 0;
+    for (uint64_t i = 0; i < bg_trace_result_size(kept); ++i) {
+      uint64_t len = 0;
+      check(bg_vcf_record(kept, i, d.name->c_str(), d.es.size(), d.eo.data(), d.ep.data(), d.el.data(), int64_t(d.seq->size()), &cov, before + made + 1,
+                          buf.data(), buf.size(), &len), "bg_vcf_record");
+      if (len + 1 > buf.size()) {
+        buf.resize(len + 1);
+        check(bg_vcf_record(kept, i, d.name->c_str(), d.es.size(), d.eo.data(), d.ep.data(), d.el.data(), int64_t(d.seq->size()), &cov, before + made + 1,
+                            buf.data(), buf.size(), &len), "bg_vcf_record");
+      }
+      if (!len) continue;
+      out->append(buf.data(), len);
+      ++made;
+    }
+    return made;
+  };
+  struct Held { size_t scaffold; bg_trace_result* kept; std::shared_ptr<ScaffoldData> sd; uint64_t records; };
+  std::vector<Held> held;  // (ranks) the scaffolds this rank owns, until their record numbers are known
   for (auto& rec : recs) {
     const std::string& seq = rec.second;
     std::vector<int64_t> eo;
@@ -1461,11 +1598,16 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     }
     struct Work { int64_t start, limit; int rev; };
     std::vector<Work> work;
+    std::vector<size_t> my;  // the work items this rank traces: the pieces go round-robin to the ranks, both directions of a piece together
     for (auto& rg : ranges)
       for (int64_t start = rg.first; start < rg.second; start += int64_t(opt.scaffold_split_size)) {
         const int64_t limit = std::min<int64_t>(rg.second, start + int64_t(opt.scaffold_split_size));
+        const bool mine = pieces % uint64_t(env.world) == uint64_t(env.rank);
         ++pieces;
-        for (int rev = 0; rev < 2; ++rev) work.push_back(Work{start, limit, rev});
+        for (int rev = 0; rev < 2; ++rev) {
+          if (mine) my.push_back(work.size());
+          work.push_back(Work{start, limit, rev});
+        }
       }
     std::vector<bg_trace_result*> items(work.size(), nullptr);
     std::vector<bg_trace_result*> pops(pop_tracer ? work.size() : 0, nullptr);  // (piece, direction) like `work`
@@ -1476,20 +1618,21 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
       std::string err;
       auto run = [&](int t) {
         for (;;) {
-          const size_t i = next.fetch_add(1);
-          if (i >= work.size()) return;
+          const size_t at = next.fetch_add(1);
+          if (at >= my.size()) return;
+          const size_t i = my[at];
           // (the anchor_dropper and the pair_counter of this item run on the session's helper thread while the session traces its next)
           static const bool sync_only = [] { const char* e = getenv("BG_TRACER_ASYNC"); return e && e[0] == '0'; }();
           if ((sync_only ? bg_tracer_trace : bg_tracer_trace_async)(tracers[size_t(t)], es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()),
                                                                     work[i].start, work[i].limit, work[i].rev, 1, &items[i]) != BG_OK) {
             std::lock_guard<std::mutex> l(err_mu);
             if (err.empty()) err = bg_last_error();
-            next.store(work.size());
+            next.store(my.size());
             return;
           }
         }
       };
-      const int nt = int(std::min<size_t>(size_t(n_threads), work.size()));
+      const int nt = int(std::min<size_t>(size_t(n_threads), std::max<size_t>(1, my.size())));
       std::vector<std::thread> pool;
       for (int t = 1; t < nt; ++t) pool.emplace_back(run, t);
       run(0);
@@ -1503,14 +1646,15 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
         next.store(0);
         auto run_pop = [&](int t) {
           for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= work.size()) return;
+            const size_t at = next.fetch_add(1);
+            if (at >= my.size()) return;
+            const size_t i = my[at];
             const bg_trace_result* push[2] = {items[i & ~size_t(1)], items[i | 1]};
             if (bg_pop_trace(tracers[size_t(t)], es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), work[i].start,
                              work[i].limit, work[i].rev, push, 2, &pops[i]) != BG_OK) {
               std::lock_guard<std::mutex> l(err_mu);
               if (err.empty()) err = bg_last_error();
-              next.store(work.size());
+              next.store(my.size());
               return;
             }
           }
@@ -1526,11 +1670,40 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
         for (size_t i = 0; i + 1 < work.size(); i += 2) {
           all.push_back(items[i]); all.push_back(items[i + 1]); all.push_back(pops[i]); all.push_back(pops[i + 1]);
         }
-        for (auto* r : pops) n_popped += bg_trace_result_size(r);
+        for (auto* r : pops) if (r) n_popped += bg_trace_result_size(r);
         items.swap(all);
       }
     }
-    for (auto* r : items) n_traced += bg_trace_result_size(r);
+    for (auto* r : items) if (r) n_traced += bg_trace_result_size(r);
+    const size_t scaffold_k = size_t(&rec - &recs[0]);
+    const bool owner = int(scaffold_k % size_t(env.world)) == env.rank;
+    if (ranks) {
+      // this rank's pieces of the scaffold to its owner: per piece its index and its results in pipeline order
+      const size_t per = pop_tracer ? 4 : 2;
+      Blob mine;
+      uint64_t n_mine = 0;
+      for (size_t pi = 0; pi * per < items.size(); ++pi) n_mine += items[pi * per] ? 1 : 0;
+      mine.put(n_mine);
+      for (size_t pi = 0; pi * per < items.size(); ++pi) {
+        if (!items[pi * per]) continue;
+        mine.put(uint64_t(pi));
+        for (size_t j = 0; j < per; ++j) put_result(&mine, items[pi * per + j], env.rank, env.world);
+      }
+      for (auto*& r : items) { if (r) bg_trace_result_free(r); r = nullptr; }
+      const std::vector<std::string> parts = gather_blobs(env, ctx, mine.b);
+      if (owner) {
+        for (const std::string& part : parts) {
+          BlobIn in{part.data(), part.data() + part.size()};
+          const uint64_t np = in.get<uint64_t>();
+          for (uint64_t q = 0; q < np; ++q) {
+            const uint64_t pi = in.get<uint64_t>();
+            if (pi * per >= items.size() || items[pi * per]) die("discovery --gpus: a piece arrived twice or from nowhere");
+            for (size_t j = 0; j < per; ++j) items[pi * per + j] = get_result(&in);
+          }
+        }
+        for (auto* r : items) if (!r) die("discovery --gpus: a piece of the scaffold did not arrive");
+      }
+    }
     if (want_half)  // (the reference writes them as its threads report them; here in work-item order)
       for (auto* r : items)
         for (uint64_t i = 0; i < bg_trace_result_half_aligned_count(r); ++i) {
@@ -1548,16 +1721,8 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     // The steps behind the tracers -- pipeline, coverage, VCF records -- of this scaffold on a thread of their own while the
     // sessions trace the next scaffold (BG_DISCOVERY_OVERLAP=0: first to the end); one scaffold at a time, in order: the
     // records are numbered across scaffolds.
+    if (ranks && !owner) continue;  // (its pieces are with the scaffold's owner)
     if (finisher.joinable()) finisher.join();
-    struct ScaffoldData {
-      std::vector<int64_t> eo;
-      std::vector<std::string> es;
-      std::vector<const char*> ep;
-      std::vector<uint64_t> el;
-      std::vector<bg_trace_result*> items;
-      const std::string* name;
-      const std::string* seq;
-    };
     std::shared_ptr<ScaffoldData> sd(new ScaffoldData);
     sd->eo.swap(eo);
     sd->es.swap(es);
@@ -1565,7 +1730,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     sd->items.swap(items);
     sd->name = &rec.first;
     sd->seq = &rec.second;
-    finisher = std::thread([&, sd] {
+    finisher = std::thread([&, sd, scaffold_k] {
     auto& eo = sd->eo;
     auto& es = sd->es;
     auto& ep = sd->ep;
@@ -1637,27 +1802,61 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     t_cov += now_s() - t1;
     rss_cov = std::max(rss_cov, rss_gb());
     t1 = now_s();
-    std::vector<char> buf(1 << 16);
-    for (uint64_t i = 0; i < bg_trace_result_size(kept); ++i) {
-      uint64_t len = 0;
-      check(bg_vcf_record(kept, i, rec.first.c_str(), es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), &cov, n_var + 1,
-                          buf.data(), buf.size(), &len), "bg_vcf_record");
-      if (len + 1 > buf.size()) {
-        buf.resize(len + 1);
-        check(bg_vcf_record(kept, i, rec.first.c_str(), es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), &cov, n_var + 1,
-                            buf.data(), buf.size(), &len), "bg_vcf_record");
-      }
-      if (!len) continue;
-      vcf.append(buf.data(), len);
-      ++n_var;
+    if (ranks) {
+      // the records are numbered across scaffolds: how many this one has now, the lines when every owner has said so
+      std::string scratch;
+      held.push_back(Held{scaffold_k, kept, sd, format_records(kept, *sd, 0, &scratch)});
+    } else {
+      n_var += format_records(kept, *sd, n_var, &vcf);
+      bg_trace_result_free(kept);
     }
-    bg_trace_result_free(kept);
     t_vcf += now_s() - t1;
     });
     static const bool overlap = [] { const char* e = getenv("BG_DISCOVERY_OVERLAP"); return !(e && e[0] == '0'); }();
     if (!overlap) finisher.join();
   }
   if (finisher.joinable()) finisher.join();
+  if (ranks) {
+    // how many records every scaffold has (its owner knows) -> where each scaffold's numbers start -> the lines -> rank 0
+    std::vector<uint64_t> cnt(recs.size(), 0), every(recs.size() * size_t(env.world), 0), before(recs.size() + 1, 0);
+    for (const Held& h : held) cnt[h.scaffold] = h.records;
+    if (!recs.empty()) check(bg_comm_all_gather_host(env.comm, cnt.data(), recs.size() * 8, every.data()), "bg_comm_all_gather_host");
+    for (size_t k = 0; k < recs.size(); ++k) {
+      uint64_t c = 0;
+      for (int r = 0; r < env.world; ++r) c += every[size_t(r) * recs.size() + k];
+      before[k + 1] = before[k] + c;
+    }
+    Blob lines;
+    lines.put(uint64_t(held.size()));
+    for (const Held& h : held) {
+      std::string text;
+      if (format_records(h.kept, *h.sd, before[h.scaffold], &text) != h.records) die("discovery --gpus: a scaffold's records changed between two passes");
+      bg_trace_result_free(h.kept);
+      lines.put(uint64_t(h.scaffold));
+      lines.put(uint64_t(text.size()));
+      lines.b += text;
+    }
+    const std::vector<std::string> parts = gather_blobs(env, ctx, lines.b);
+    uint64_t sums[3] = {n_traced, n_popped, n_sections}, all_sums[3 * 64];
+    if (env.world > 64) die("discovery --gpus: at most 64 ranks");
+    check(bg_comm_all_gather_host(env.comm, sums, sizeof sums, all_sums), "bg_comm_all_gather_host");
+    check(bg_comm_barrier(env.comm), "bg_comm_barrier");  // (nobody leaves while another rank still reads what it sent)
+    if (env.rank != 0) return 0;
+    n_traced = n_popped = n_sections = 0;
+    for (int r = 0; r < env.world; ++r) { n_traced += all_sums[3 * r]; n_popped += all_sums[3 * r + 1]; n_sections += all_sums[3 * r + 2]; }
+    std::vector<std::string> text(recs.size());
+    for (const std::string& part : parts) {
+      BlobIn in{part.data(), part.data() + part.size()};
+      const uint64_t nh = in.get<uint64_t>();
+      for (uint64_t q = 0; q < nh; ++q) {
+        const uint64_t k = in.get<uint64_t>(), len = in.get<uint64_t>();
+        if (k >= recs.size()) die("discovery --gpus: records of an unknown scaffold");
+        text[k].assign(in.bytes(len), len);
+      }
+    }
+    for (const std::string& t : text) vcf += t;
+    n_var = before[recs.size()];
+  }
   // (the sessions, their contexts and the reference map are not closed one by one: the process ends when the outputs are written,
   // and handing sixteen sessions' pinned buffers, arenas and streams back first took a tenth of a second)
   const double t_write0 = now_s();
@@ -1675,15 +1874,18 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   return 0;
 }
 
+static int discovery_main(Args& a, const std::string& engine, int rank, int world, int device, const std::string& backend, const char* comm_id,
+                          int id_fd_in, const std::vector<int>& id_fd_out);
+
 static int cmd_discovery(int argc, char** argv) {
   // (these settings are this command's alone: `create` holds multi-gigabyte FASTQ text on the heap and wants it back)
   mallopt(M_TRIM_THRESHOLD, 1 << 30);
   mallopt(M_MMAP_THRESHOLD, 1 << 30);
   mallopt(M_TOP_PAD, 256 << 20);
-  cpuprof::start();
   Args a = parse(argc, argv, 2, {"reads", "ref", "out", "sample", "min-overlap", "max-pair-distance", "bed", "engine", "max-ploids",
                                  "enable-pop-tracer", "threads", "ml-features", "scaffold-split-size", "simple-gt", "rvg-exclude",
-                                 "force", "ref-map", "min-pop-overlap", "assemblies-out", "aligned-assemblies-out", "half-aligned-out"});
+                                 "force", "ref-map", "min-pop-overlap", "assemblies-out", "aligned-assemblies-out", "half-aligned-out",
+                                 "gpus", "comm", "devices", "force-sharded"});
   if (!a.has("reads") || !a.has("ref") || !a.has("out")) die("discovery: --in S.bg, --ref and --out are required");
   // biograph_variants.cpp:216-232: an output that exists is only replaced with -f / --force
   for (const char* o : {"out", "assemblies-out", "aligned-assemblies-out", "half-aligned-out"})
@@ -1691,7 +1893,6 @@ static int cmd_discovery(int argc, char** argv) {
       if (!a.has("force")) die("Refusing to overwrite '" + a.get(o) + "'. Use -f to override.");
       unlink(a.get(o).c_str());
     }
-  std::string bgdir = a.get("reads");
   // --engine push (default): the reference's discovery engine -- push tracer, anchor_dropper, pair_counter, the
   // serial pipeline, calc_coverage, simple_genotype_filter, ploidless VCF records (biograph_variants.cpp:598-830);
   // --engine graph: the graph_discover pipeline (branch + push_to_pair), positions and alleles only
@@ -1700,6 +1901,26 @@ static int cmd_discovery(int argc, char** argv) {
   // --max-ploids (biograph_variants.cpp:162) feeds genotyper / ploid_limiter, neither of which is a step of the standard
   // pipeline (pipeline.cpp:92-105): accepted, without effect there either.
   if (a.has("max-ploids") && atoi(a.get("max-ploids").c_str()) < 1) die("discovery: --max-ploids must be at least 1");
+  // --gpus N [--comm rccl|shm] [--devices a,b,...]: the work items of trace_ref (trace_ref.cpp:44-63) over N processes, one per GPU,
+  // each with the whole biograph on its device; --gpus 1 --force-sharded: the same path on one rank
+  const int gpus = a.has("gpus") ? atoi(a.get("gpus").c_str()) : 1;
+  if (gpus < 1) die("discovery: --gpus must be at least 1");
+  if (gpus > 1 || a.has("force-sharded")) {
+    if (engine != "push") die("discovery --gpus: the push engine only");
+    return launch_ranks(a, gpus, [&](int r, int device, const std::string& backend, const char* comm_id, int in, const std::vector<int>& outs) {
+      return discovery_main(a, engine, r, gpus, device, backend, comm_id, in, outs);
+    });
+  }
+  return discovery_main(a, engine, 0, 1, 0, "", nullptr, -1, {});
+}
+
+static int discovery_main(Args& a, const std::string& engine, int rank, int world, int device, const std::string& backend, const char* comm_id,
+                          int id_fd_in, const std::vector<int>& id_fd_out) {
+  cpuprof::start();
+  const std::string bgdir = a.get("reads");
+  RankEnv env;
+  env.rank = rank;
+  env.world = world;
   // scaffolds (chromosomes) and their N-free supercontigs from the reference directory / .ref / FASTA; a
   // scaffold is rebuilt with N between its supercontigs so that VCF positions are scaffold coordinates
   const double t_begin = now_s();
@@ -1738,7 +1959,14 @@ static int cmd_discovery(int argc, char** argv) {
     t_ref = now_s();
   });
   bg_ctx* ctx = nullptr;
-  check(bg_ctx_create(0, nullptr, &ctx), "bg_ctx_create");
+  if (comm_id) {  // a rank: its device, its context and the communicator
+    const int ndev = bg_device_count();
+    if (ndev < 1) die("--gpus: no HIP device");
+    env.device = device >= 0 ? device : (backend == "shm" ? rank % ndev : rank);
+    rank_open(rank, world, env.device, backend, comm_id, id_fd_in, id_fd_out, &ctx, &env.comm);
+  } else {
+    check(bg_ctx_create(0, nullptr, &ctx), "bg_ctx_create");
+  }
   const double t_ctx = now_s();
   auto samples = json_samples(read_text(bgdir + "/metadata/bg_info.json"));
   std::string sample = a.get("sample");
@@ -1754,7 +1982,7 @@ static int cmd_discovery(int argc, char** argv) {
   double t_rm_done = 0;
   std::thread rm_thread([&] {
     bg_ctx* ctx_rm = nullptr;
-    check(bg_ctx_create_own_stream(0, &ctx_rm), "bg_ctx_create_own_stream");
+    check(bg_ctx_create_own_stream(env.device, &ctx_rm), "bg_ctx_create_own_stream");
     check(bg_readmap_open(ctx_rm, (bgdir + "/coverage/" + samples[sample] + ".readmap").c_str(), &rm), "bg_readmap_open");
     t_rm_done = now_s();
   });
@@ -1790,7 +2018,7 @@ static int cmd_discovery(int argc, char** argv) {
           t0 - t_begin, t_ref - t_begin, t_ctx - t_begin, t_ss - t_ctx, t_rm_done - t_ctx, since_process_start_s(), rss_gb());
   (void)t_rm;
   if (engine == "push") {
-    const int rc = discovery_push(a, recs, bed, ctx, ss, rm, min_overlap, max_pair_distance, sample, flat_codes, flat_start, flat_size);
+    const int rc = discovery_push(a, recs, bed, ctx, ss, rm, min_overlap, max_pair_distance, sample, flat_codes, flat_start, flat_size, env);
     // The outputs are written and closed: the process ends here.  Handing tens of gigabytes of host tables, the seqset, the
     // readmap and the contexts back piece by piece before exiting took most of a second of a ten-second command.
     cpuprof::stop_and_write();

@@ -445,3 +445,44 @@ def test_bgbinary_discovery_force_ref_map_min_pop_overlap_assemblies_out(golden_
     assert few <= many  # (lambda's eight variants leave the pop tracer nothing either way: the option is taken and harmless)
     r = subprocess.run(exe + ["--out", str(tmp_path / "z.vcf"), "--min-pop-overlap", "0"], capture_output=True, text=True)
     assert r.returncode == 1 and "--min-pop-overlap must be at least 1" in r.stderr
+
+
+@pytest.mark.parametrize("split", [10000, 1000000])
+def test_bgbinary_discovery_over_ranks_writes_the_same_vcf(golden_dir, tmp_path, split):
+    """`bgbinary discovery --gpus N` (trace_ref.cpp:44-63,105-140: the pieces over processes): the pieces of every scaffold go
+    round-robin to the ranks, the assemblies to the scaffold's owner, the records to rank 0 -- the file is the single-process
+    command's, on 1 rank through the same path, on 2 and on 3 (shared-memory communicator: one GPU here), over one scaffold
+    (the golden lambda reference) and over three (lambda cut in three FASTA records)."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    bgd = tmp_path / "father.bg"
+    (bgd / "coverage").mkdir(parents=True)
+    (bgd / "metadata").mkdir()
+    shutil.copy(golden_dir + "/father_lambda/seqset", bgd / "seqset")
+    shutil.copy(golden_dir + "/father_lambda/readmap", bgd / "coverage" / "abc.readmap")
+    json.dump({"accession_id": "father", "samples": {"father": "abc"}}, open(bgd / "metadata" / "bg_info.json", "w"),
+              separators=(",", ":"))
+    lam = "".join(l.strip() for l in open(golden_dir + "/father_lambda/reference.fasta") if not l.startswith(">")).upper()
+    three = tmp_path / "three.fa"
+    three.write_text(">part2\n%s\n>part10\n%s\n>partX\n%s\n" % (lam[:16000], lam[16000:32000], lam[32000:]))
+    exe = [sys.executable, "-m", "biograph_amd.cli", "discovery", "--in", str(bgd), "--scaffold-split-size", str(split), "-f"]
+
+    def run(ref, extra, name):
+        out = tmp_path / name
+        r = subprocess.run(exe + ["--ref", ref, "--out", str(out)] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return [l for l in open(out) if not l.startswith("##fileDate")], r.stderr
+
+    for ref in (golden_dir + "/ref_lambda", str(three)):
+        want, _ = run(ref, [], "single.vcf")
+        assert sum(1 for l in want if not l.startswith("#")) >= 8
+        for extra in (["--gpus", "1", "--force-sharded", "--comm", "shm"], ["--gpus", "2", "--comm", "shm"], ["--gpus", "3", "--comm", "shm"]):
+            got, err = run(ref, extra, "ranks.vcf")
+            assert got == want, (ref, extra)
+            assert "pop tracer on" in err
+    # what only the single-process command writes is refused, not dropped
+    r = subprocess.run(exe + ["--ref", golden_dir + "/ref_lambda", "--out", str(tmp_path / "x.vcf"), "--gpus", "2", "--comm", "shm",
+                              "--assemblies-out", str(tmp_path / "a.csv")], capture_output=True, text=True)
+    assert r.returncode != 0 and "single-process command only" in r.stderr
