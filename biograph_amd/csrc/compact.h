@@ -91,8 +91,20 @@ static int compact_flagged(bg_ctx* ctx, const uint8_t* d_flags, uint64_t n, DevB
   cp_count_kernel<<<unsigned(nt), CP_THREADS, 0, ctx->stream>>>(d_flags, n, counts.p);
   BG_LAUNCH_CHECK();
   BG_TRY(exclusive_scan_u32_to_u64(ctx, counts.p, offs.p, nt, total.p));
+  // The positions go out before the host knows how many there are, into room for all n (the arena takes the unused tail
+  // back in place): the wait for the count runs beside the kernel instead of in front of it (a 40 us hole a call, eight
+  // calls a build step).  Inputs too large for that wait first, as before.
+  const bool ahead = n * sizeof(IdxT) <= (size_t(2) << 30) && out->alloc(ctx, n) == BG_OK;
+  if (ahead) {
+    cp_emit_kernel<IdxT><<<unsigned(nt), CP_THREADS, 0, ctx->stream>>>(d_flags, n, offs.p, out->p);
+    BG_LAUNCH_CHECK();
+  }
   BG_HIP(hipMemcpyAsync(h_count, total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (ahead) {
+    out->shrink(*h_count ? *h_count : 1);
+    return BG_OK;
+  }
   BG_TRY(out->alloc(ctx, *h_count ? *h_count : 1));
   if (*h_count) {
     cp_emit_kernel<IdxT><<<unsigned(nt), CP_THREADS, 0, ctx->stream>>>(d_flags, n, offs.p, out->p);

@@ -823,6 +823,7 @@ static int create_sharded_impl(bg_ctx* ctx, bg_comm* comm, const uint8_t* d_seq,
   DevBuf<uint64_t> skm_org;
   DevBuf<uint32_t> skm_bits;
   uint64_t n_windows = 0, my_distinct = 0, my_kept = 0;
+  bool gathered_set = false;
   {
     std::vector<uint64_t> counts, kcm;
     BG_TRY(skm_extract(ctx, H.reads, k, P, 0.385, &skm_recs, &skm_org, &counts, &n_windows));
@@ -835,18 +836,56 @@ static int create_sharded_impl(bg_ctx* ctx, bg_comm* comm, const uint8_t* d_seq,
     BG_TRY(bg_skm_count(ctx, keys.b.p, keys.n, k, prm->min_kmer_count, &H.owned, bits.p));
     my_distinct = bg_kmerset_distinct(H.owned);
     my_kept = bg_kmerset_size(H.owned);
-    // the owner keeps its k-mers (hash set) and settles the records its counting tables gave up on
-    BG_TRY(bg_kmerset_build_hash(ctx, H.owned));
-    BG_TRY(bg_skm_lookup(ctx, H.owned, keys.b.p, keys.n, bits.p, 1));
+    // Where the kept k-mers live for the correction.  They are the one structure of the build that is small beside the reads
+    // (8 bytes a k-mer: 0.5 GB for a 30x chr20, 25 GB for a 30x human): when all of them fit in a sixteenth of the device,
+    // every rank takes a copy (one all-gather) and corrects its reads with no further exchange, as the single-GPU build does
+    // -- 288 GB of HBM is what makes that the cheap way.  Otherwise (BG_SHARD_KMERSET=routed forces it) they stay with
+    // their owners and the correction asks them (correct_routed).
+    std::vector<uint64_t> kept_all;
+    BG_TRY(gather_u64(comm, {my_kept}, &kept_all));
+    uint64_t total_kept = 0;
+    for (uint64_t v : kept_all) total_kept += v;
+    size_t free_b = 0, total_b = 0;
+    BG_HIP(hipMemGetInfo(&free_b, &total_b));
+    const char* where = getenv("BG_SHARD_KMERSET");
+    const bool forced_routed = where && !strcmp(where, "routed"), forced_gathered = where && !strcmp(where, "gathered");
+    gathered_set = !forced_routed && (forced_gathered || total_kept * 8 * 4 <= uint64_t(total_b) / 16);  // (keys + hash table + flags)
+    if (!gathered_set) {
+      // the owner keeps its k-mers (hash set) and settles the records its counting tables gave up on
+      BG_TRY(bg_kmerset_build_hash(ctx, H.owned));
+      BG_TRY(bg_skm_lookup(ctx, H.owned, keys.b.p, keys.n, bits.p, 1));
+    }
     keys.reset();
     BG_TRY(skm_bits.alloc(ctx, skm_recs.n));
     BG_TRY(reply(comm, bits.p, 4, kcm, skm_bits.p));  // 1b: the presence bits of every record go back to the rank it came from
+    if (gathered_set) {
+      ph.mark("kmerset_all_gather");
+      DevBuf<uint64_t> mine, all;
+      BG_TRY(mine.alloc(ctx, my_kept));
+      BG_TRY(all.alloc(ctx, total_kept));
+      if (my_kept) BG_TRY(bg_kmerset_export(ctx, H.owned, mine.p));
+      bg_kmerset_free(H.owned);
+      H.owned = nullptr;
+      std::vector<uint64_t> bytes(kept_all);
+      for (uint64_t& v : bytes) v *= 8;
+      BG_TRY(bg_comm_all_gather(comm, mine.p, bytes.data(), all.p));
+      mine.reset();
+      // (records whose bucket overflowed the owner's counting table came back "unknown": attach_presence looks them up here)
+      BG_TRY(bg_kmerset_from_kmers(ctx, all.p, total_kept, k, nullptr, &H.owned));  // (no starts-a-read flags: the build never reads them)
+      all.reset();
+      BG_TRY(bg_kmerset_attach_presence(ctx, H.owned, H.reads, skm_recs.b.p, skm_org.p, skm_bits.p, skm_recs.n));
+    }
   }
 
-  // ---- 2: routed correction
+  // ---- 2: correction -- local over the gathered set, or routed
   bg_correct_stats cst;
   memset(&cst, 0, sizeof cst);
-  BG_TRY(correct_routed(comm, ctx, H, k, prm, skm_recs, skm_org, skm_bits, &cst, &st.correct_steps, &st.correct_probes, ph));
+  if (gathered_set) {
+    ph.mark("correct");
+    BG_TRY(bg_correct_reads(ctx, H.reads, H.owned, &prm->correct, &H.corrected, &cst));
+  } else {
+    BG_TRY(correct_routed(comm, ctx, H, k, prm, skm_recs, skm_org, skm_bits, &cst, &st.correct_steps, &st.correct_probes, ph));
+  }
   bg_reads_free(H.reads);
   H.reads = nullptr;
   bg_kmerset_free(H.owned);

@@ -137,6 +137,22 @@ def test_every_tail_travelling_gives_the_same(sample, ranks):
     _same(d, "fused.bg", out)
 
 
+@pytest.mark.parametrize("ranks", [1, 3, 8])
+def test_kept_kmers_left_with_their_owners_give_the_same(sample, ranks):
+    """BG_SHARD_KMERSET=routed: the kept k-mers stay with their owners and the correction asks them in rounds (what a build
+    takes when all of them do not fit a sixteenth of a device) instead of every rank taking a copy of the set: the same
+    containers, and the statistics say which way was taken."""
+    d = sample
+    out = "wrouted%d.bg" % ranks
+    extra = ["--force-sharded"] if ranks == 1 else ["--comm", "shm"]
+    r = _create(d, out, ["--reads", str(d / "r1.fq"), "--pair", str(d / "r2.fq"), "--gpus", str(ranks)] + extra, env={"BG_SHARD_KMERSET": "routed", "BG_SHARD_TIMING": "1"})
+    _same(d, "fused.bg", out)
+    assert "correct_probe_exchange" in r.stderr and "kmerset_all_gather" not in r.stderr
+    r = _create(d, "wgath%d.bg" % ranks, ["--reads", str(d / "r1.fq"), "--pair", str(d / "r2.fq"), "--gpus", str(ranks)] + extra, env={"BG_SHARD_TIMING": "1"})
+    _same(d, "fused.bg", "wgath%d.bg" % ranks)
+    assert "kmerset_all_gather" in r.stderr and "correct_probe_exchange" not in r.stderr
+
+
 def test_two_processes_interleaved_input(sample):
     d = sample
     _create(d, "w2i.bg", ["--reads", str(d / "inter.fq"), "--interleaved", "--gpus", "2", "--comm", "shm"])
