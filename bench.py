@@ -962,10 +962,11 @@ def main():
                        "genome_len_total": genome_len, "coverage": args.coverage, "read_len": args.read_len,
                        "reads_per_gpu": n_reads, "bases_per_gpu": n_bases, "kmer_size": 30, "min_kmer_count": 5,
                        "parallelism": "1 GPU (fused build)" if world == 1 and not args.force_sharded else
-                       "%d rank(s), ONE sample sharded, nothing replicated (routed mode): all_to_all over RCCL of super-k-mer "
-                       "records (+ presence bits back), correction probes (+ answers), oriented reads by leading bases, cover "
-                       "candidates per round (+ covered / keep bytes), entry tails (+ need-full bytes); all_gather only of "
-                       "shard boundaries and a few counters" % world},
+                       "%d rank(s), ONE sample sharded (routed; only the kept k-mer set is copied to every rank, when it fits a "
+                       "sixteenth of the device): all_to_all over RCCL of super-k-mer records (+ presence bits back), all_gather "
+                       "of the kept k-mers (8 bytes each; BG_SHARD_KMERSET=routed: correction probes + answers instead), oriented "
+                       "reads by leading bases, cover candidates per round (+ covered / keep bytes), entry tails (+ need-full "
+                       "bytes); all_gather otherwise only of shard boundaries, cover filters and a few counters" % world},
             "roofline": roofline, "cpu_baseline": cpu,
             "device_memory": {"peak_live_GB": round(mem["peak"] / 1e9, 2), "cached_GB": round(mem["cached"] / 1e9, 2),
                               "torch_peak_GB": round(mem["torch_peak"] / 1e9, 2),
