@@ -124,8 +124,10 @@ __device__ __forceinline__ void tile_skms(const SkSource& src, uint64_t r_lo, ui
     const int nk = L - k + 1, nm = L - SK_M + 1;
     sk_wave_sync();  // the previous read's words are no longer needed
     uint32_t my_n = 0;
-    if (lane < SK_WORDS) {  // the read's words (zero padded) where every lane can fetch the ones it needs
-      sw[lane] = lane < W ? src.words[i * W + lane] : 0;
+    if (lane < SK_WORDS) {  // the read's words (zero padded) where every lane can fetch the ones it needs, halves swapped:
+      // as 32-bit words the copy then reads 16 bases after 16 bases, first base in the top bits
+      const uint64_t wd = lane < W ? src.words[i * W + lane] : 0;
+      sw[lane] = (wd << 32) | (wd >> 32);
       my_n = lane < W ? src.nmask[i * W + lane] : 0;
       sn[lane] = my_n;
     }
@@ -136,15 +138,17 @@ __device__ __forceinline__ void tile_skms(const SkSource& src, uint64_t r_lo, ui
     for (int base = 0; base < nk; base += stride) {
       const int p = base + lane;
       const int q = p >> 5, r = p & 31;
-      const uint64_t w0 = sw[q], w1 = sw[q + 1];
-      const uint64_t x = (w0 << (2 * r)) | ((w1 >> 1) >> (63 - 2 * r));
+      // the 12-mer at base p: 24 bits out of two neighbouring 32-bit words (64-bit shifts of two 64-bit words cost three times
+      // the instructions)
+      const uint32_t* sd = reinterpret_cast<const uint32_t*>(sw);
+      const uint32_t mm = __funnelshift_l(sd[(p >> 4) + 1], sd[p >> 4], (p & 15) << 1) >> (32 - 2 * SK_M);
       uint32_t nw = 0;
       if (has_n) {
         const uint32_t n0 = sn[q], n1 = sn[q + 1];
         nw = (n0 << r) | ((n1 >> 1) >> (31 - r));
       }
       uint32_t m = SK_INF;
-      if (p < nm && (nw >> (32 - SK_M)) == 0) m = sk_order(sk_canon_mmer(uint32_t(x >> (64 - 2 * SK_M))));
+      if (p < nm && (nw >> (32 - SK_M)) == 0) m = sk_order(sk_canon_mmer(mm));
       // minimum over the w order values from this lane on, in log steps
       uint32_t t;
       if (pw > 1) { t = pull(a1, m); m = t < m ? t : m; }
