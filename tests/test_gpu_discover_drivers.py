@@ -478,7 +478,8 @@ def test_bgbinary_discovery_over_ranks_writes_the_same_vcf(golden_dir, tmp_path,
     for ref in (golden_dir + "/ref_lambda", str(three)):
         want, _ = run(ref, [], "single.vcf")
         assert sum(1 for l in want if not l.startswith("#")) >= 8
-        for extra in (["--gpus", "1", "--force-sharded", "--comm", "shm"], ["--gpus", "2", "--comm", "shm"], ["--gpus", "3", "--comm", "shm"]):
+        for extra in (["--gpus", "1", "--force-sharded", "--comm", "shm"], ["--gpus", "1", "--force-sharded", "--comm", "rccl"],
+                      ["--gpus", "2", "--comm", "shm"], ["--gpus", "3", "--comm", "shm"]):
             got, err = run(ref, extra, "ranks.vcf")
             assert got == want, (ref, extra)
             assert "pop tracer on" in err
