@@ -796,34 +796,82 @@ def main():
         torch.cuda.synchronize()
 
     ncomm = None
-    if (world > 1 or args.force_sharded) and native:
-        # ONE C call per rank and step: bg_create_sharded over bg_comm (csrc/sharded.hip, csrc/comm.hip: rccl.h inside the
-        # library); torch.distributed only carries the communicator's id to the ranks and the barriers around the timed region
+    comm = None              # (torch mode) sharded.py's communicator
+    sharded_mode = None      # "native" | "torch" | "replicas" once a multi-rank run has settled on one
+    sharded_fallback = None  # why the ranks do not build one sample together, when they do not
+    if world > 1 or args.force_sharded:
         from biograph_amd import sharded
-        ident = [sharded.NativeComm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ident, src=0)
-        ncomm = sharded.NativeComm(ctx, rank, world, ident[0], "rccl")
 
-        def step():
-            sh = sharded.native_create(ctx, ncomm, seq.data_ptr(), offs.data_ptr(), n_reads, params)
-            st = sh.stats
-            sh.free()
-            return st
-    elif world > 1 or args.force_sharded:
-        from biograph_amd import sharded
-        comm = sharded.TorchDistComm(dev)
+    def fused_step():
+        ss, st = ctx.create_device(seq.data_ptr(), offs.data_ptr(), n_reads, params)
+        ss.free()
+        return st
 
-        def step():
-            # nothing is gathered: every rank ends the step with its 512-aligned slice of the seqset in HBM
-            out = sharded.sharded_create(comm, {rank: ctx}, {rank: (seq, offs, n_reads)}, params, gather=False)
-            sl, st = out[rank]
-            sl.free()
-            return st
+    def make_step(mode):
+        nonlocal ncomm, comm
+        if mode in os.environ.get("BG_BENCH_FAIL_MODES", "").split(","):  # (tests: the fall-back chain)
+            raise RuntimeError("injected by BG_BENCH_FAIL_MODES")
+        if mode == "native":
+            # ONE C call per rank and step: bg_create_sharded over bg_comm (csrc/sharded.hip, csrc/comm.hip: rccl.h inside the
+            # library); torch.distributed only carries the communicator's id to the ranks and the barriers around the timed region
+            ident = [sharded.NativeComm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)
+            ncomm = sharded.NativeComm(ctx, rank, world, ident[0], "rccl")
+
+            def step():
+                sh = sharded.native_create(ctx, ncomm, seq.data_ptr(), offs.data_ptr(), n_reads, params)
+                st = sh.stats
+                sh.free()
+                return st
+            return step
+        if mode == "torch":
+            comm = sharded.TorchDistComm(dev)
+
+            def step():
+                # nothing is gathered: every rank ends the step with its 512-aligned slice of the seqset in HBM
+                out = sharded.sharded_create(comm, {rank: ctx}, {rank: (seq, offs, n_reads)}, params, gather=False)
+                sl, st = out[rank]
+                sl.free()
+                return st
+            return step
+        return fused_step
+
+    if world > 1 or args.force_sharded:
+        # The sharded build has run between a rank and itself and between processes sharing one GPU, never between two devices
+        # before the driver's scaling run: a mode that cannot start on every rank (an exception, not a hang) gives way to the
+        # next -- the library's driver, the Python orchestration over torch.distributed, then N independent fused builds
+        # ("replicas", labelled as such in config.parallelism) -- instead of ending the run without a line.
+        step = None
+        for mode in (["native", "torch"] if native else ["torch"]) + ["replicas"]:
+            err = None
+            try:
+                if mode == "replicas" and world > 1:
+                    # every rank its own whole sample of the shape (a rank's share of the big sample is 1 / world of its coverage)
+                    seq = offs = None
+                    torch.cuda.empty_cache()
+                    genome_len = args.genome_len or synth.SHAPES[args.shape]
+                    seq, offs, n_reads, genome = synth.make_reads(genome_len=genome_len, coverage=args.coverage, read_len=args.read_len,
+                                                                  seed=args.seed + rank, device=dev, shard=(0, 1), return_genome=True,
+                                                                  contigs=synth.contig_lengths(genome_len, args.shape))
+                    torch.cuda.synchronize()
+                    n_bases = int(seq.numel())
+                step = make_step(mode)
+                if mode != "replicas":
+                    step()  # (an extra, untimed step: the probe)
+            except Exception as e:  # noqa: BLE001
+                err = "%s: %s" % (type(e).__name__, str(e)[:300])
+            flag = torch.tensor([1.0 if err else 0.0], device=dev, dtype=torch.float64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if flag.item() == 0.0:
+                sharded_mode = mode
+                break
+            if rank == 0 or err:
+                print("bench.py: rank %d: the %s sharded build did not start (%s); trying the next mode" % (rank, mode, err or "another rank failed"),
+                      file=sys.stderr)
+            sharded_fallback = "%s: %s" % (mode, err or "failed on another rank")
+            ncomm = comm = None
     else:
-        def step():
-            ss, st = ctx.create_device(seq.data_ptr(), offs.data_ptr(), n_reads, params)
-            ss.free()
-            return st
+        step = fused_step
 
     stats = None
     for _ in range(args.warmup):
@@ -866,7 +914,7 @@ def main():
         total_bases = float(n_bases)
 
     sharded_rm = None
-    if (world > 1 or args.force_sharded) and not args.no_sharded_readmap:
+    if sharded_mode in ("native", "torch") and not args.no_sharded_readmap:
         # What `biograph create` ends with, outside the timed region: the same build once more with the sample's READMAP
         # sharded like the seqset (routed entry look-ups, rows owned by their entry's rank, the claim hops as exchanged
         # claims), then the ranks' columns put together on rank 0 (bg_readmap_from_arrays).
@@ -961,7 +1009,10 @@ def main():
                                       "%d-base genome (--genome-len; contig shape of '%s')" % (genome_len, args.shape)),
                        "genome_len_total": genome_len, "coverage": args.coverage, "read_len": args.read_len,
                        "reads_per_gpu": n_reads, "bases_per_gpu": n_bases, "kmer_size": 30, "min_kmer_count": 5,
+                       "sharded_mode": sharded_mode,
                        "parallelism": "1 GPU (fused build)" if world == 1 and not args.force_sharded else
+                       ("%d independent fused builds, one per GPU (replicas: the sharded build did not start -- %s)" % (world, sharded_fallback))
+                       if sharded_mode == "replicas" else
                        "%d rank(s), ONE sample sharded (routed; only the kept k-mer set is copied to every rank, when it fits a "
                        "sixteenth of the device): all_to_all over RCCL of super-k-mer records (+ presence bits back), all_gather "
                        "of the kept k-mers (8 bytes each; BG_SHARD_KMERSET=routed: correction probes + answers instead), oriented "
