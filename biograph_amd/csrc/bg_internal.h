@@ -298,6 +298,9 @@ struct VmmSegment { size_t reserved, mapped, piece; };  // address range, bytes 
 extern std::map<void*, VmmSegment> g_vmm_segments;
 void* vmm_segment(int device, size_t n, size_t piece);  // prims.hip
 // merge.hip: rows (W key words, then the length) of the entries [lo, lo + cnt) of a finalized seqset
+// items_build.hip: the front half of the items path (BG_ITEMS_PROBE=1), beside the build
+int items_probe(bg_ctx* ctx, const uint64_t* owords, const uint16_t* len, const uint32_t* cnt, const uint64_t* roff, uint64_t o_base,
+                uint64_t n_emit, int W, uint64_t n_rec);
 int seqset_stripe_rows(bg_ctx* ctx, const bg_seqset* s, uint64_t lo, uint64_t cnt, int W, uint64_t* d_rows);
 bg_ctx::DeviceArena* shared_arena(int device);  // null unless the hook is installed
 // walk.hip: the read-ahead tables of one walked stretch of a tracer work item (offset after base i = first_off + i),

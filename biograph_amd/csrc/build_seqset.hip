@@ -2112,6 +2112,7 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
   }
   BG_TRY(exclusive_scan_u32_to_u64(ctx, cnt.p, roff.p, n_emit, total.p));
   BG_HIP(copy_d2h(ctx, &n_rec, total.p, 8));
+  if (getenv("BG_ITEMS_PROBE")) BG_TRY(items_probe(ctx, owords.p, reads->len.p, cnt.p, roff.p, o_base, n_emit, W, n_rec));  // (items_build.hip)
   BG_TRY(rec->alloc(ctx, n_rec * RS));
   if (RS == W) BG_TRY(rlen->alloc(ctx, n_rec));  // (rows of W + 1 words carry the lengths themselves)
   const bool want_k0 = k0 && n_rec < (1ull << 32);
