@@ -411,6 +411,7 @@ extern "C" int bg_seqset_entries(bg_ctx* ctx, const bg_seqset* ss, uint64_t firs
   BG_TRY(d_offs.alloc(ctx, count + 1));
   BG_TRY(d_seq.alloc(ctx, pos));
   BG_HIP(hipMemcpyAsync(d_offs.p, h_offs, (count + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  BG_TRY(seqset_ensure_keys(ctx, const_cast<bg_seqset*>(ss)));  // (a build from items makes its keys when asked)
   if (ss->keys.p && ss->W) {
     k_entries_ascii<<<cdiv(count, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->sizes.p, first, count, ss->W, d_offs.p,
                                                               d_seq.p);

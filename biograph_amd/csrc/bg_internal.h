@@ -231,7 +231,11 @@ struct bg_seqset {
   bg::DevBuf<uint8_t> emask, need;
   bg::DevBuf<uint64_t> cond;
   uint64_t n_cond = 0;
+  // a build from items (items_build.hip): no key table yet -- every entry's record (oriented read << 24 | offset << 16 | ...)
+  // and the oriented reads it points into; seqset_ensure_keys makes keys / pre2 from them the first time somebody needs them
+  bg::DevBuf<uint64_t> erec, oreads;
 };
+
 
 struct bg_records {
   bg_ctx* ctx = nullptr;
@@ -298,6 +302,22 @@ struct VmmSegment { size_t reserved, mapped, piece; };  // address range, bytes 
 extern std::map<void*, VmmSegment> g_vmm_segments;
 void* vmm_segment(int device, size_t n, size_t piece);  // prims.hip
 // merge.hip: rows (W key words, then the length) of the entries [lo, lo + cnt) of a finalized seqset
+// the cover stage's products (build_seqset.hip cover_counts_impl): the oriented reads and, for those of [lo, hi), the number of
+// suffix records each emits, where they start, and their total
+struct LocalPrev;
+struct CoverCounts {
+  DevBuf<uint64_t> owords;
+  DevBuf<uint8_t> olen;
+  DevBuf<uint32_t> cnt;
+  DevBuf<uint64_t> roff;
+  uint64_t n_emit = 0, o_base = 0, n_rec = 0;
+};
+int cover_counts_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t hi, int cover_k, CoverCounts* cc);
+// items_build.hip: the entries (keys, pre2, sizes, shared, the local prev bits and the list of tails) from 16-byte items;
+// *done = false: the input has buckets or runs the items path does not take yet -- nothing was changed, use the rows
+int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_seqset* ss, LocalPrev* lp, bool* done);
+// keys / pre2 of a seqset built from items, on demand (no-op when they are there or cannot be made)
+int seqset_ensure_keys(bg_ctx* ctx, bg_seqset* ss);
 // items_build.hip: the front half of the items path (BG_ITEMS_PROBE=1), beside the build
 int items_probe(bg_ctx* ctx, const uint64_t* owords, const uint16_t* len, const uint32_t* cnt, const uint64_t* roff, uint64_t o_base,
                 uint64_t n_emit, int W, uint64_t n_rec);
@@ -390,6 +410,7 @@ struct LocalPrev {
   DevBuf<uint64_t> count;    // rows asked for (device)
   uint64_t cap = 0, n_items = 0;
   bool valid = false;        // the kernel ran in this mode and the list held every row
+  bool searched = false;     // the list's tails are in emask already (items_build.hip): only the packing is left
 };
 int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t>& rlen, uint64_t n_rec, int W,
                               bg_seqset* ss, uint64_t* n_tied_out, DevBuf<uint64_t>* k0 = nullptr, int RS = 0,

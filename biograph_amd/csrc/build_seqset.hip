@@ -2065,20 +2065,20 @@ int cover_index_build(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, 
   return BG_OK;
 }
 
-// Phase A: suffix records of reads [lo, hi) under the exact-cover rule; the cover index spans ALL
-// reads of `reads`.
-int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t hi, int cover_k,
-                        DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out, DevBuf<uint64_t>* k0, int RS) {
-  if (RS <= 0) RS = reads->W;
+// Phase A, first half: the oriented reads, the cover index over ALL reads of `reads`, and for the oriented reads of [lo, hi) how
+// many suffix records each emits under the exact-cover rule (cnt), where they start (roff) and how many there are in all.
+int cover_counts_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t hi, int cover_k, CoverCounts* cc) {
   const uint64_t n = reads->n;
   const uint64_t n_o = 2 * n;
   const int W = reads->W;
   if (n_o >= (1ull << 31)) { set_error("too many reads for one cover index (%llu)", (unsigned long long)n); return BG_EINVAL; }
   if (lo > hi || hi > n) { set_error("bad read range"); return BG_EINVAL; }
-  const uint64_t o_base = 2 * lo, n_emit = 2 * (hi - lo);
-  uint64_t n_rec = 0;
-  DevBuf<uint64_t> owords;
-  DevBuf<uint8_t> olen;
+  cc->o_base = 2 * lo;
+  cc->n_emit = 2 * (hi - lo);
+  cc->n_rec = 0;
+  const uint64_t o_base = cc->o_base, n_emit = cc->n_emit;
+  DevBuf<uint64_t>& owords = cc->owords;
+  DevBuf<uint8_t>& olen = cc->olen;
   BG_TRY(owords.alloc(ctx, n_o * W + 8));  // (8 spare words: k_cover_count_sm fetches 64 bytes from a candidate's first word)
   BG_TRY(olen.alloc(ctx, n_o));
   CoverStore cs;
@@ -2094,36 +2094,46 @@ int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_
     BG_TRY(cover_index_build(ctx, owords.p, olen.p, n_o, W, cover_k, &k0o, &cs));
   }
   const CoverIndex ci = cs.ci;
-
-  // ---- emission
-  DevBuf<uint32_t> cnt;
-  DevBuf<uint64_t> roff, total;
-  BG_TRY(cnt.alloc(ctx, n_emit));
-  BG_TRY(roff.alloc(ctx, n_emit));
+  DevBuf<uint64_t> total;
+  BG_TRY(cc->cnt.alloc(ctx, n_emit));
+  BG_TRY(cc->roff.alloc(ctx, n_emit));
   BG_TRY(total.alloc(ctx, 1));
   if (n_emit) {
     ctx->tic("suffix_cover_count");
     if (getenv("BG_COVER_COUNT_ROUNDS"))  // (a whole look-up per pass, as before round 5)
-      k_cover_count<<<cdiv(cdiv(n_emit, kCoverChunk), 4), 256, cover_count_lds(W), ctx->stream>>>(ci, owords.p, o_base, n_emit, W, cnt.p);
+      k_cover_count<<<cdiv(cdiv(n_emit, kCoverChunk), 4), 256, cover_count_lds(W), ctx->stream>>>(ci, owords.p, o_base, n_emit, W, cc->cnt.p);
     else
-      k_cover_count_sm<<<cdiv(cdiv(n_emit, kCoverChunk), 4), 256, cover_count_lds(W), ctx->stream>>>(ci, owords.p, o_base, n_emit, W, cnt.p);
+      k_cover_count_sm<<<cdiv(cdiv(n_emit, kCoverChunk), 4), 256, cover_count_lds(W), ctx->stream>>>(ci, owords.p, o_base, n_emit, W, cc->cnt.p);
     BG_LAUNCH_CHECK();
     ctx->toc(n_emit * W * 8 * 2);
   }
-  BG_TRY(exclusive_scan_u32_to_u64(ctx, cnt.p, roff.p, n_emit, total.p));
-  BG_HIP(copy_d2h(ctx, &n_rec, total.p, 8));
-  if (getenv("BG_ITEMS_PROBE")) BG_TRY(items_probe(ctx, owords.p, reads->len.p, cnt.p, roff.p, o_base, n_emit, W, n_rec));  // (items_build.hip)
+  BG_TRY(exclusive_scan_u32_to_u64(ctx, cc->cnt.p, cc->roff.p, n_emit, total.p));
+  BG_HIP(copy_d2h(ctx, &cc->n_rec, total.p, 8));
+  return BG_OK;  // (the cover index goes with cs: only the counts and the oriented reads are needed from here on)
+}
+
+// Phase A: suffix records of reads [lo, hi) under the exact-cover rule; the cover index spans ALL
+// reads of `reads`.
+int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t hi, int cover_k,
+                        DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out, DevBuf<uint64_t>* k0, int RS) {
+  if (RS <= 0) RS = reads->W;
+  const int W = reads->W;
+  CoverCounts cc;
+  BG_TRY(cover_counts_impl(ctx, reads, lo, hi, cover_k, &cc));
+  const uint64_t n_rec = cc.n_rec, n_emit = cc.n_emit, o_base = cc.o_base;
+  if (getenv("BG_ITEMS_PROBE")) BG_TRY(items_probe(ctx, cc.owords.p, reads->len.p, cc.cnt.p, cc.roff.p, o_base, n_emit, W, n_rec));  // (items_build.hip)
   BG_TRY(rec->alloc(ctx, n_rec * RS));
   if (RS == W) BG_TRY(rlen->alloc(ctx, n_rec));  // (rows of W + 1 words carry the lengths themselves)
   const bool want_k0 = k0 && n_rec < (1ull << 32);
   if (want_k0) BG_TRY(k0->alloc(ctx, n_rec));
   if (n_rec) {
     ctx->tic("suffix_emit");
-    k_emit_records<<<cdiv(cdiv(n_emit, 64), 4), 256, size_t(256) * RS * 8, ctx->stream>>>(owords.p, reads->len.p, cnt.p, roff.p, o_base, n_emit, W,
+    k_emit_records<<<cdiv(cdiv(n_emit, 64), 4), 256, size_t(256) * RS * 8, ctx->stream>>>(cc.owords.p, reads->len.p, cc.cnt.p, cc.roff.p, o_base, n_emit, W,
                                                                RS, rec->p, RS == W ? rlen->p : nullptr, want_k0 ? k0->p : nullptr);
     BG_LAUNCH_CHECK();
     ctx->toc(n_emit * W * 8 + n_rec * (RS * 8 + 1 + (want_k0 ? 8 : 0)));
   }
+  BG_HIP(hipStreamSynchronize(ctx->stream));  // (cc goes out of scope)
   *n_rec_out = n_rec;
   return BG_OK;
 }
@@ -2598,6 +2608,17 @@ int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss, LocalPrev* lp) {
   DevBuf<uint8_t> marks;
   const bool use_pre2 = ss->pre2.p && ss->pre2.n >= 2 * n_ent && !getenv("BG_PREV_FULL_SEARCH");
   const char* pm = getenv("BG_PREV_MERGE");
+  if (n_ent && lp && lp->valid && lp->searched) {
+    ctx->tic("prev_bits");
+    const uint64_t nwords = (n_ent + 63) / 64;
+    k_pack_emask<<<cdiv(cdiv(nwords, kPackWordsPerWave), 4), 256, 0, ctx->stream>>>(
+        lp->emask.p, n_ent, reinterpret_cast<unsigned long long*>(ss->bits[0].p), reinterpret_cast<unsigned long long*>(ss->bits[1].p),
+        reinterpret_cast<unsigned long long*>(ss->bits[2].p), reinterpret_cast<unsigned long long*>(ss->bits[3].p));
+    BG_LAUNCH_CHECK();
+    ctx->toc(n_ent * 2);
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    return BG_OK;
+  }
   if (n_ent && lp && lp->valid && use_pre2 && !(pm && pm[0] == '1')) {
     // most bits are set already (k_gather_dedup_build); the listed tails are searched as every entry's tail used to be
     ctx->tic("prev_bits");
@@ -2698,9 +2719,20 @@ extern "C" int bg_seqset_build(bg_ctx* ctx, const bg_reads* reads, int cover_k, 
   // (padded to 8 words -- one 64-byte sector a row -- the entry build's gather took 8.4 ms instead of 8.8 and the emission 3.9
   // instead of 3.3: measured and dropped)
   const int RS = reads->W + 1;
-  BG_TRY(suffix_records_impl(ctx, reads, 0, reads->n, cover_k, &rec, &rlen, &n_rec, &k0, RS));
   LocalPrev lp;
-  BG_TRY(entries_from_records_impl(ctx, rec, rlen, n_rec, reads->W, ss.get(), &n_tied, &k0, RS, &lp));
+  bool by_items = false;
+  if (getenv("BG_ITEMS_BUILD")) {
+    // the entries from 16-byte items (items_build.hip): same arrays; false = an input it leaves to the rows
+    CoverCounts cc;
+    BG_TRY(cover_counts_impl(ctx, reads, 0, reads->n, cover_k, &cc));
+    n_rec = cc.n_rec;
+    BG_TRY(items_entries_impl(ctx, reads, &cc, ss.get(), &lp, &by_items));
+    if (getenv("BG_DEBUG_PREV")) fprintf(stderr, "entries from items: %s\n", by_items ? "yes" : "no (left to the rows)");
+  }
+  if (!by_items) {
+    BG_TRY(suffix_records_impl(ctx, reads, 0, reads->n, cover_k, &rec, &rlen, &n_rec, &k0, RS));
+    BG_TRY(entries_from_records_impl(ctx, rec, rlen, n_rec, reads->W, ss.get(), &n_tied, &k0, RS, &lp));
+  }
   BG_TRY(prev_bits_local_impl(ctx, ss.get(), &lp));
   if (getenv("BG_DEBUG_PREV")) fprintf(stderr, "prev bits: %llu of %llu entries' worth of tails searched (list %s)\n", (unsigned long long)(lp.valid ? lp.n_items : ss->n), (unsigned long long)ss->n, lp.valid ? "ok" : "not used");
   // the longest read is never a proper prefix of anything longer, so it survives as an entry

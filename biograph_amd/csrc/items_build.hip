@@ -14,6 +14,7 @@
 // another order of work; no reference code has this shape.
 #include "bg_device_funcs.h"
 #include "bg_internal.h"
+#include "compact.h"
 
 #include <stdlib.h>
 
@@ -190,6 +191,347 @@ __global__ void it_bounds_kernel(const Item* __restrict__ items, uint64_t n, int
   bounds[v] = lo;
 }
 
+// ---- one bucket (equal leading 16 bits) in order of the first word; then the runs of equal first words by the rest
+// id bits 55..63 are free: bit 63 = "the 8 bits below are this item's LCP with the item after it" (set for an item whose
+// successor has the same first word: their order and LCP took the rest of their strings); the stream pass that follows needs
+// no reads at all -- every other pair of neighbours differs inside the first word.
+constexpr int IB_THREADS = 512;
+constexpr int IB_CAP = 4096;       // items a workgroup sorts in LDS
+constexpr int IB_BINS = 2048;      // counting sort on the next 11 bits, then ranks inside a bin by comparison
+constexpr uint64_t kItLcpValid = 1ull << 63;
+constexpr int kItLcpShift = 55;
+constexpr uint64_t kItIdMask = (1ull << kItLcpShift) - 1;
+
+__device__ __forceinline__ uint64_t it_suffix_word(const uint64_t* __restrict__ s, int W, int j, int w) {  // word w of suffix j of a read
+  const int sq = (j >> 5) + w, sr = j & 31;
+  const uint64_t cur = sq < W ? s[sq] : 0, next = sq + 1 < W ? s[sq + 1] : 0;
+  return sr ? (cur << (2 * sr)) | (next >> (64 - 2 * sr)) : cur;
+}
+
+// status[bucket]: 0 done, 1 too many items (copied as they were: the caller's fall-back)
+// runs[]: every run of two or more equal first words, as (place of its first item) | (members, at most 65535) << 48;
+// *n_runs counts them (runs past run_cap are not listed: the caller sees the count).
+__global__ __launch_bounds__(IB_THREADS) void k_items_bucket_sort(const Item* __restrict__ in, Item* __restrict__ out,
+                                                                  const uint64_t* __restrict__ bounds, uint8_t* __restrict__ status,
+                                                                  uint64_t* __restrict__ runs, unsigned long long* __restrict__ n_runs,
+                                                                  uint64_t run_cap) {
+  __shared__ uint64_t sfw[IB_CAP];
+  __shared__ uint32_t hist[IB_BINS];
+  __shared__ uint32_t start[IB_BINS + 1];
+  __shared__ uint16_t ord[IB_CAP];   // sorted place -> item
+  __shared__ uint16_t grp[IB_CAP];   // items grouped by bin (unordered inside)
+  __shared__ uint32_t s_scan[IB_THREADS / 64];
+  const uint32_t b = blockIdx.x;
+  const uint64_t lo = bounds[b], hi = bounds[b + 1];
+  const uint32_t n = uint32_t(hi - lo);
+  const int tid = threadIdx.x;
+  if (n == 0) return;
+  if (hi - lo > uint64_t(IB_CAP)) {
+    if (tid == 0) status[b] = 1;
+    for (uint64_t i = lo + tid; i < hi; i += IB_THREADS) out[i] = in[i];
+    return;
+  }
+  for (int i = tid; i < IB_BINS; i += IB_THREADS) hist[i] = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += IB_THREADS) {
+    const uint64_t f = in[lo + i].fw;
+    sfw[i] = f;
+    atomicAdd(&hist[uint32_t(f >> 37) & (IB_BINS - 1)], 1u);
+  }
+  __syncthreads();
+  {  // exclusive scan of the bins: 4 per thread
+    uint32_t v[IB_BINS / IB_THREADS], sum = 0;
+#pragma unroll
+    for (int k = 0; k < IB_BINS / IB_THREADS; ++k) { v[k] = hist[tid * (IB_BINS / IB_THREADS) + k]; sum += v[k]; }
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t x = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) s_scan[wave] = x;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w2 = 0; w2 < wave; ++w2) base += s_scan[w2];
+    uint32_t run = base + x - sum;
+#pragma unroll
+    for (int k = 0; k < IB_BINS / IB_THREADS; ++k) {
+      start[tid * (IB_BINS / IB_THREADS) + k] = run;
+      hist[tid * (IB_BINS / IB_THREADS) + k] = 0;  // (now the bin's cursor)
+      run += v[k];
+    }
+    if (tid == IB_THREADS - 1) start[IB_BINS] = run;
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += IB_THREADS) {
+    const uint32_t bin = uint32_t(sfw[i] >> 37) & (IB_BINS - 1);
+    grp[start[bin] + atomicAdd(&hist[bin], 1u)] = uint16_t(i);
+  }
+  __syncthreads();
+  // place inside the bin: the number of bin mates that sort before this item (first word, then the item's index)
+  for (uint32_t p = tid; p < n; p += IB_THREADS) {
+    const uint32_t i = grp[p];
+    const uint64_t f = sfw[i];
+    const uint32_t bin = uint32_t(f >> 37) & (IB_BINS - 1);
+    const uint32_t bs = start[bin], be = start[bin + 1];
+    uint32_t rank = 0;
+    for (uint32_t q = bs; q < be; ++q) {
+      const uint32_t k = grp[q];
+      const uint64_t g = sfw[k];
+      rank += (g < f || (g == f && k < i)) ? 1u : 0u;
+    }
+    ord[bs + rank] = uint16_t(i);
+  }
+  __syncthreads();
+  __shared__ uint32_t s_nruns;
+  __shared__ unsigned long long s_rbase;
+  if (tid == 0) s_nruns = 0;
+  __syncthreads();
+  uint32_t my_run[IB_CAP / IB_THREADS], my_at[IB_CAP / IB_THREADS];
+  int nmine = 0;
+  for (uint32_t p = tid; p < n; p += IB_THREADS) {
+    const uint32_t src = ord[p];
+    const uint64_t f = sfw[src];
+    out[lo + p] = Item{f, in[lo + src].id};  // (the ids once more from the L2: 32 KB of LDS less a workgroup)
+    if ((p == 0 || sfw[ord[p - 1]] != f) && p + 1 < n && sfw[ord[p + 1]] == f) {
+      uint32_t g = 2;
+      while (p + g < n && g < 65535u && sfw[ord[p + g]] == f) ++g;
+      my_run[nmine] = (p << 16) | g;
+      my_at[nmine] = atomicAdd(&s_nruns, 1u);
+      ++nmine;
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && s_nruns) s_rbase = atomicAdd(n_runs, (unsigned long long)s_nruns);
+  __syncthreads();
+  for (int k = 0; k < nmine; ++k) {
+    const unsigned long long at = s_rbase + my_at[k];
+    if (at < run_cap) runs[at] = (lo + (my_run[k] >> 16)) | (uint64_t(my_run[k] & 0xffffu) << 48);
+  }
+}
+
+// The runs of equal first words (a suffix and the longer suffixes of other reads over the same place: two or three members;
+// repeats make longer ones).  A lane takes a run of at most four: the rest of every member's string from its read, a sorting
+// network over (rest, length), every member's LCP with its successor noted in its id.  Longer runs go to `more` (a wave a run,
+// k_items_tie_wave).
+struct ItRow {
+  uint64_t id;
+  uint64_t r[kMaxWords - 1];
+};
+__device__ __forceinline__ void it_load_row(ItRow* x, uint64_t id, const uint64_t* __restrict__ owords, int W) {
+  x->id = id;
+  const uint64_t* s = owords + (id >> 24) * uint64_t(W);
+  const int j = int(id >> 16) & 255;
+#pragma unroll
+  for (int w = 0; w < kMaxWords - 1; ++w) x->r[w] = w < W - 1 ? it_suffix_word(s, W, j, w + 1) : 0;
+}
+__device__ __forceinline__ bool it_row_less(const ItRow& a, const ItRow& b) {  // (rest, length), then the id: a total order
+  int c = 0;
+#pragma unroll
+  for (int w = 0; w < kMaxWords - 1; ++w)
+    if (!c) c = a.r[w] < b.r[w] ? -1 : (a.r[w] > b.r[w] ? 1 : 0);
+  if (!c) {
+    const int la = int(a.id >> 8) & 255, lb = int(b.id >> 8) & 255;
+    c = la < lb ? -1 : (la > lb ? 1 : 0);
+  }
+  return c < 0 || (c == 0 && a.id < b.id);
+}
+__device__ __forceinline__ void it_cswap(ItRow& a, ItRow& b) {
+  if (it_row_less(b, a)) { const ItRow t = a; a = b; b = t; }
+}
+__device__ __forceinline__ uint64_t it_note_lcp(const ItRow& a, const ItRow& b) {  // a's id with its LCP with b, its successor
+  int l = 32;
+#pragma unroll
+  for (int w = 0; w < kMaxWords - 1; ++w) {
+    if (l == 32 * (w + 1)) l += lcp_word(a.r[w], b.r[w]);
+  }
+  const int la = int(a.id >> 8) & 255, lb = int(b.id >> 8) & 255;
+  const int mn = la < lb ? la : lb;
+  l = l < mn ? l : mn;
+  return a.id | kItLcpValid | (uint64_t(l) << kItLcpShift);
+}
+
+__global__ __launch_bounds__(256) void k_items_tie_small(Item* __restrict__ items, const uint64_t* __restrict__ runs, uint64_t n_runs,
+                                                         const uint64_t* __restrict__ owords, int W, uint64_t* __restrict__ more,
+                                                         unsigned long long* __restrict__ n_more) {
+  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n_runs) return;
+  const uint64_t rr = runs[t];
+  const uint64_t p = rr & ((1ull << 48) - 1);
+  const uint32_t g = uint32_t(rr >> 48);
+  if (g > 4) { more[atomicAdd(n_more, 1ull)] = rr; return; }
+  const uint64_t f = items[p].fw;
+  ItRow x[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    if (uint32_t(m) < g) {
+      it_load_row(&x[m], items[p + m].id & kItIdMask, owords, W);
+    } else {  // past the run: sorts behind every member
+      x[m].id = ~0ull;
+#pragma unroll
+      for (int w = 0; w < kMaxWords - 1; ++w) x[m].r[w] = ~0ull;
+    }
+  }
+  it_cswap(x[0], x[1]); it_cswap(x[2], x[3]); it_cswap(x[0], x[2]); it_cswap(x[1], x[3]); it_cswap(x[1], x[2]);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    if (uint32_t(m) >= g) break;
+    uint64_t id = x[m].id;
+    if (m + 1 < 4 && uint32_t(m + 1) < g) id = it_note_lcp(x[m], x[m + 1]);
+    items[p + m] = Item{f, id};
+  }
+}
+
+// a run of 5 .. 64 members: a lane a member; every lane counts the members that sort before its own through shuffles
+__global__ __launch_bounds__(256) void k_items_tie_wave(Item* __restrict__ items, const uint64_t* __restrict__ more, uint64_t n_more,
+                                                        const uint64_t* __restrict__ owords, int W, uint64_t* __restrict__ longer,
+                                                        unsigned long long* __restrict__ n_long) {
+  const uint64_t t = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (t >= n_more) return;
+  const uint64_t rr = more[t];
+  const uint64_t p = rr & ((1ull << 48) - 1);
+  const uint32_t g = uint32_t(rr >> 48);
+  if (g > 64) { if (lane == 0) longer[atomicAdd(n_long, 1ull)] = rr; return; }
+  const bool live = uint32_t(lane) < g;
+  ItRow me;
+  uint64_t f = 0;
+  if (live) {
+    const Item it = items[p + lane];
+    f = it.fw;
+    it_load_row(&me, it.id & kItIdMask, owords, W);
+  } else {
+    me.id = ~0ull;
+#pragma unroll
+    for (int w = 0; w < kMaxWords - 1; ++w) me.r[w] = ~0ull;
+  }
+  uint32_t rank = 0;
+  for (uint32_t q = 0; q < g; ++q) {
+    ItRow o;
+    o.id = __shfl(me.id, int(q), 64);
+#pragma unroll
+    for (int w = 0; w < kMaxWords - 1; ++w) o.r[w] = __shfl(me.r[w], int(q), 64);
+    rank += it_row_less(o, me) ? 1u : 0u;
+  }
+  // the member at sorted place m = the lane whose rank is m; its successor = the lane whose rank is m + 1
+  ItRow nx;  // my successor's row
+  {
+    // lane L publishes at index rank: find, for my rank + 1, the lane that holds it
+    int src = -1;
+    for (uint32_t q = 0; q < g; ++q) {
+      const uint32_t rq = uint32_t(__shfl(int(rank), int(q), 64));
+      if (rq == rank + 1) src = int(q);
+    }
+    const int s2 = src < 0 ? lane : src;
+    nx.id = __shfl(me.id, s2, 64);
+#pragma unroll
+    for (int w = 0; w < kMaxWords - 1; ++w) nx.r[w] = __shfl(me.r[w], s2, 64);
+    if (live) {
+      uint64_t id = me.id;
+      if (src >= 0) id = it_note_lcp(me, nx);
+      items[p + rank] = Item{f, id};
+    }
+  }
+}
+
+// a run of more than 64 members (repeats; a bucket holds at most IB_CAP items): a workgroup a run; the members' rest rows and
+// ids in LDS (lds_members of them fit: longer runs fetch them from the reads at every comparison), every member counts the
+// members that sort before it (quadratic: such runs are few).
+__global__ __launch_bounds__(512) void k_items_tie_block(Item* __restrict__ items, const uint64_t* __restrict__ longer,
+                                                         const uint64_t* __restrict__ owords, int W, uint32_t lds_members) {
+  extern __shared__ uint64_t tb_smem[];  // lds_members x (1 + kMaxWords - 1) words: id, rest
+  __shared__ uint16_t place[IB_CAP];     // sorted place -> member
+  const uint64_t rr = longer[blockIdx.x];
+  const uint64_t p = rr & ((1ull << 48) - 1);
+  const uint32_t g = uint32_t(rr >> 48);
+  const bool in_lds = g <= lds_members;
+  constexpr int RS = kMaxWords;  // words a member takes in LDS
+  auto load = [&](uint32_t m, ItRow* x) {
+    if (in_lds) {
+      x->id = tb_smem[m * RS];
+#pragma unroll
+      for (int w = 0; w < kMaxWords - 1; ++w) x->r[w] = tb_smem[m * RS + 1 + w];
+    } else {
+      it_load_row(x, items[p + m].id & kItIdMask, owords, W);
+    }
+  };
+  if (in_lds) {
+    for (uint32_t m = threadIdx.x; m < g; m += blockDim.x) {
+      ItRow x;
+      it_load_row(&x, items[p + m].id & kItIdMask, owords, W);
+      tb_smem[m * RS] = x.id;
+#pragma unroll
+      for (int w = 0; w < kMaxWords - 1; ++w) tb_smem[m * RS + 1 + w] = x.r[w];
+    }
+  }
+  __syncthreads();
+  for (uint32_t m = threadIdx.x; m < g; m += blockDim.x) {
+    ItRow me;
+    load(m, &me);
+    uint32_t rank = 0;
+    for (uint32_t q = 0; q < g; ++q) {
+      ItRow o;
+      load(q, &o);
+      rank += it_row_less(o, me) ? 1u : 0u;
+    }
+    place[rank] = uint16_t(m);
+  }
+  __syncthreads();
+  const uint64_t f = items[p].fw;
+  // (every member's row is read before any item of the run is overwritten: the rows come from LDS, or -- a run too long for
+  // it -- the ids are staged in `place`'s order first)
+  uint64_t out_id[IB_CAP / 512];
+  int k = 0;
+  for (uint32_t r = threadIdx.x; r < g; r += blockDim.x, ++k) {
+    ItRow me;
+    load(place[r], &me);
+    uint64_t id = me.id;
+    if (r + 1 < g) {
+      ItRow nx;
+      load(place[r + 1], &nx);
+      id = it_note_lcp(me, nx);
+    }
+    out_id[k] = id;
+  }
+  __syncthreads();
+  k = 0;
+  for (uint32_t r = threadIdx.x; r < g; r += blockDim.x, ++k) items[p + r] = Item{f, out_id[k]};
+}
+
+// checker (the probe only): neighbours in the whole array are in (string, length) order -- strings through the reads
+__global__ void k_items_check_order(const Item* __restrict__ items, uint64_t n, const uint64_t* __restrict__ owords, int W,
+                                    unsigned long long* __restrict__ bad, unsigned long long* __restrict__ idsum) {
+  const uint64_t p = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const Item a = items[p];
+  atomicAdd(idsum, (unsigned long long)(a.id & ((1ull << kItLcpShift) - 1)) * 0x9E3779B97F4A7C15ull);
+  if (p + 1 >= n) return;
+  const Item c = items[p + 1];
+  int cmp = a.fw < c.fw ? -1 : (a.fw > c.fw ? 1 : 0);
+  const int la = int(a.id >> 8) & 255, lb = int(c.id >> 8) & 255;
+  int l = lcp_word(a.fw, c.fw);
+  if (!cmp) {
+    const uint64_t* sa = owords + ((a.id & ((1ull << kItLcpShift) - 1)) >> 24) * uint64_t(W);
+    const uint64_t* sc = owords + ((c.id & ((1ull << kItLcpShift) - 1)) >> 24) * uint64_t(W);
+    for (int w = 1; w < W && !cmp; ++w) {
+      const uint64_t x = it_suffix_word(sa, W, int(a.id >> 16) & 255, w), y = it_suffix_word(sc, W, int(c.id >> 16) & 255, w);
+      cmp = x < y ? -1 : (x > y ? 1 : 0);
+      const int cw = lcp_word(x, y);
+      l += cw;
+      if (cw < 32) break;
+    }
+    if (!cmp) cmp = la < lb ? -1 : (la > lb ? 1 : 0);
+    const int m = la < lb ? la : lb;
+    l = l < m ? l : m;
+    const bool has = (a.id & kItLcpValid) != 0;
+    if (!has || int((a.id >> kItLcpShift) & 255) != l) atomicAdd(bad + 1, 1ull);  // the LCP note is missing or wrong
+  } else if (a.id & kItLcpValid) {
+    atomicAdd(bad + 1, 1ull);
+  }
+  if (cmp > 0) atomicAdd(bad, 1ull);
+}
+
 static int it_partition(bg_ctx* ctx, const Item* in, Item* out, uint64_t n, uint32_t nseg, const uint64_t* h_seg0, int shift) {
   std::vector<uint32_t> h_tile(size_t(nseg) + 1, 0);
   uint64_t t = 0;
@@ -217,6 +559,451 @@ static int it_partition(bg_ctx* ctx, const Item* in, Item* out, uint64_t n, uint
   it_scatter_kernel<<<ntiles, IT_THREADS, 0, ctx->stream>>>(in, out, sg, shift, offs.p);
   BG_LAUNCH_CHECK();
   BG_HIP(hipStreamSynchronize(ctx->stream));  // (the segment tables go out of scope)
+  return BG_OK;
+}
+
+// ---- the stream passes over the items in order: no read is touched except for the list rows and the keys
+// keep[p] = the item survives (it is not a prefix of, or equal to, its successor: expand.cpp:19-48 skip_dups); lcpn[p] = its LCP
+// with its successor (the note of k_items_tie_*, or what the two first words show)
+__global__ __launch_bounds__(256) void k_items_keep(const Item* __restrict__ items, uint64_t n, uint8_t* __restrict__ keep,
+                                                    uint8_t* __restrict__ lcpn, uint32_t* __restrict__ err) {
+  const uint64_t p = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const Item a = items[p];
+  const int la = int(a.id >> 8) & 255;
+  int l = 0;
+  bool k = true;
+  if (p + 1 < n) {
+    const Item b = items[p + 1];
+    const int lb = int(b.id >> 8) & 255;
+    if (a.id & kItLcpValid) {
+      l = int(a.id >> kItLcpShift) & 255;
+    } else {
+      if (a.fw == b.fw) atomicOr(err, 8u);  // a run the tie kernels did not see
+      if (a.fw > b.fw) atomicOr(err, 1u);   // not sorted
+      l = lcp_word(a.fw, b.fw);
+      const int m = la < lb ? la : lb;
+      l = l < m ? l : m;
+    }
+    k = l != la;
+  }
+  keep[p] = k ? 1 : 0;
+  lcpn[p] = uint8_t(l);
+}
+
+// rank[p] = the number of survivors before item p = the entry item p belongs to (its own if it survives, else the one that
+// absorbs it: a dropped record is a prefix of its successor, so of the next survivor); kept[e] = the place of entry e's item.
+// Tiles of 2048 items; tile_offs = exclusive scan of the tiles' survivor counts.
+__global__ __launch_bounds__(256) void k_items_rank(const uint8_t* __restrict__ keep, uint64_t n, const uint64_t* __restrict__ tile_offs,
+                                                    uint32_t* __restrict__ rank, uint32_t* __restrict__ kept) {
+  __shared__ uint32_t sm[4];
+  const uint64_t base = uint64_t(blockIdx.x) * CP_TILE + uint64_t(threadIdx.x) * CP_ITEMS;
+  uint8_t f[CP_ITEMS];
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < CP_ITEMS; ++i) {
+    f[i] = base + i < n ? keep[base + i] : 0;
+    c += f[i] ? 1u : 0u;
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t inc = cp_wave_incl_scan(c, lane);
+  if (lane == 63) sm[w] = inc;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int i = 0; i < w; ++i) wbase += sm[i];
+  uint32_t o = uint32_t(tile_offs[blockIdx.x]) + wbase + inc - c;
+#pragma unroll
+  for (int i = 0; i < CP_ITEMS; ++i) {
+    if (base + i >= n) break;
+    rank[base + i] = o;
+    if (f[i]) kept[o++] = uint32_t(base + i);
+  }
+}
+
+// One lane an ITEM.  A survivor writes its entry: size, its record, shared = its LCP with the entry before = the smallest LCP on
+// the way there = min(the LCP of the entry before with its successor, the length of the first record this entry absorbed) -- the
+// absorbed records are prefixes of each other, shortest first.  Every record brings the prev bit it knows (k_gather_dedup_build's
+// rule: a record with a predecessor (r, j - 1) whose string is an entry sets prev_b of that entry): its own entry's if it
+// survives or equals the survivor; what the rule cannot decide goes to the list as (place of the item) << 2 | kind -- 1 the
+// tail of a survivor that is its read's last record, 2 a record dropped as a proper prefix, checked (k_items_list_rows makes the
+// rows).  emask: bytes, four to a word (atomicOr on the word).
+__global__ __launch_bounds__(256) void k_items_entries(const Item* __restrict__ items, uint64_t n, const uint8_t* __restrict__ keep,
+                                                       const uint32_t* __restrict__ rank, const uint32_t* __restrict__ kept,
+                                                       const uint8_t* __restrict__ lcpn, uint8_t* __restrict__ sizes, uint8_t* __restrict__ shared,
+                                                       uint64_t* __restrict__ erec, uint64_t* __restrict__ pre1, uint32_t* __restrict__ emask32,
+                                                       uint8_t* __restrict__ kindf) {
+  const uint64_t p = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  uint32_t kind = 0, contrib = 0, my_e = 0xffffffffu;
+  bool mine_kept = false, spans = false;
+  if (p < n) {
+    const Item me = items[p];
+    const uint64_t id = me.id & kItIdMask;
+    const uint32_t fl = uint32_t(id) & 255u;
+    const int len = int(id >> 8) & 255;
+    const uint32_t e = rank[p];
+    const bool k = keep[p] != 0;
+    bool sets = false;
+    if (k) {
+      int sh = 0;
+      if (e) {
+        const uint32_t pp = kept[e - 1];  // the entry before
+        sh = lcpn[pp];
+        if (pp + 1 < p) { const int v = lcpn[pp + 1]; sh = v < sh ? v : sh; }
+      }
+      sizes[e] = uint8_t(len);
+      shared[e] = uint8_t(sh);
+      erec[e] = id;
+      pre1[e] = me.fw;
+      sets = (fl & 1u) != 0;
+      if (fl & 8u) kind = 1;
+    } else if (fl & 1u) {
+      const int slen = int(items[kept[e]].id >> 8) & 255;  // (the survivor is a few places on)
+      if (slen == len) sets = true;
+      else kind = 2;
+    }
+    contrib = sets ? 1u << ((fl >> 1) & 3u) : 0u;
+    my_e = e;
+    mine_kept = k;
+    if (k) spans = (e ? kept[e - 1] + 1 : 0u) + uint32_t(lane) < uint32_t(p);  // its first record lies in an earlier wave
+  }
+  // the records of an entry sit side by side: their bits are put together over the lanes (an atomic a record was 30 ms: four
+  // billion a second is all the L2 does), and only an entry whose records straddle two waves takes atomics
+  {
+    uint32_t acc = contrib;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = uint32_t(__shfl_up(int(acc), d, 64));
+      const uint32_t oe = uint32_t(__shfl_up(int(my_e), d, 64));
+      if (lane >= d && oe == my_e) acc |= o;
+    }
+    const uint32_t ne = uint32_t(__shfl_down(int(my_e), 1, 64));
+    const bool seg_last = lane == 63 || ne != my_e;
+    if (p < n && seg_last) {
+      if (mine_kept && !spans) reinterpret_cast<uint8_t*>(emask32)[my_e] = uint8_t(acc);
+      else if (acc) atomicOr(&emask32[my_e >> 2], acc << (8 * (my_e & 3u)));
+    }
+  }
+  if (p < n) kindf[p] = uint8_t(kind);  // (the list's rows are counted and placed by a compaction: one counter for all waves was 24 ms)
+}
+
+// rows of W + 1 words for k_prev_list (the formats of k_gather_dedup_build): a lane a word
+__global__ __launch_bounds__(256) void k_items_list_rows(const Item* __restrict__ items, const uint32_t* __restrict__ lpos,
+                                                         const uint8_t* __restrict__ kindf, uint64_t n_rows,
+                                                         const uint64_t* __restrict__ owords, int W, uint64_t* __restrict__ list) {
+  const uint64_t x = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t RW = uint64_t(W + 1);
+  if (x >= n_rows * RW) return;
+  const uint64_t r = x / RW;
+  const int w = int(x - r * RW);
+  const uint32_t at = lpos[r];
+  const uint32_t d = kindf[at];
+  const uint64_t id = items[at].id & kItIdMask;
+  const uint64_t* s = owords + (id >> 24) * uint64_t(W);
+  const int j = int(id >> 16) & 255, len = int(id >> 8) & 255;
+  uint64_t v;
+  if ((d & 3) == 1) {  // s[1:], its length, s[0]
+    v = w < W ? it_suffix_word(s, W, j + 1, w) : (uint64_t(len - 1) | (((s[j >> 5] >> (62 - 2 * (j & 31))) & 3) << 8));
+  } else {             // s, its length, the base in front of it; bit 16: only if that base + s is an entry
+    v = w < W ? it_suffix_word(s, W, j, w) : (uint64_t(len) | (uint64_t((uint32_t(id) >> 1) & 3u) << 8) | (1ull << 16));
+  }
+  list[x] = v;
+}
+
+// ---- the list's tails searched through the entries' first words and, where those tie, through the reads (no key table)
+struct ItEntries {
+  const uint64_t* pre1;   // first word of every entry
+  const uint64_t* erec;   // its record
+  const uint8_t* sizes;
+  const uint64_t* owords;
+  const uint32_t* dir;
+  uint64_t n;
+  int W, bases;
+};
+// entry e against (key, kl) beyond the first word (equal): rest of the string through the read, then the length
+__device__ __forceinline__ int it_cmp_rest(const ItEntries& t, uint64_t e, const uint64_t* key, int kl) {
+  const uint64_t id = t.erec[e];
+  const uint64_t* s = t.owords + (id >> 24) * uint64_t(t.W);
+  const int j = int(id >> 16) & 255;
+  for (int w = 1; w < t.W; ++w) {
+    const uint64_t x = it_suffix_word(s, t.W, j, w);
+    if (x != key[w]) return x < key[w] ? -1 : 1;
+  }
+  const int el = t.sizes[e];
+  return el < kl ? -1 : (el > kl ? 1 : 0);
+}
+// first entry >= (key, kl) in (string, length) order
+__device__ __forceinline__ uint64_t it_lower_bound(const ItEntries& t, const uint64_t* key, int kl) {
+  const uint32_t p = uint32_t(key[0] >> (64 - 2 * t.bases));
+  uint64_t a = t.dir[p], z = t.dir[p + 1];
+  const uint64_t hi = z;
+  while (a < z) {  // first entry whose first word is >= the key's
+    const uint64_t mid = (a + z) >> 1;
+    if (t.pre1[mid] < key[0]) a = mid + 1; else z = mid;
+  }
+  uint64_t lo1 = a;
+  if (lo1 >= hi || t.pre1[lo1] != key[0]) return lo1;
+  z = hi;
+  a = lo1 + 1;
+  while (a < z) {  // first entry whose first word is greater
+    const uint64_t mid = (a + z) >> 1;
+    if (t.pre1[mid] <= key[0]) a = mid + 1; else z = mid;
+  }
+  uint64_t hi1 = a;
+  while (lo1 < hi1) {
+    const uint64_t mid = (lo1 + hi1) >> 1;
+    if (it_cmp_rest(t, mid, key, kl) < 0) lo1 = mid + 1; else hi1 = mid;
+  }
+  return lo1;
+}
+// LCP of entry e with (key, kl), in bases
+__device__ __forceinline__ int it_entry_lcp(const ItEntries& t, uint64_t e, const uint64_t* key, int kl) {
+  int l = lcp_word(t.pre1[e], key[0]);
+  if (l == 32) {
+    const uint64_t id = t.erec[e];
+    const uint64_t* s = t.owords + (id >> 24) * uint64_t(t.W);
+    const int j = int(id >> 16) & 255;
+    for (int w = 1; w < t.W; ++w) {
+      const int c = lcp_word(it_suffix_word(s, t.W, j, w), key[w]);
+      l += c;
+      if (c < 32) break;
+    }
+  }
+  const int el = t.sizes[e], m = el < kl ? el : kl;
+  return l < m ? l : m;
+}
+
+// k_prev_list's work (builder.cpp:85-108) for the items' list: item `at` of kind 1 = the tail of a survivor that is its read's
+// last record (suffix j + 1 of the read; the bit is the base at j), kind 2 = a record dropped as a proper prefix (its own
+// string s; the bit is the base in front, and only if that base + s -- suffix j - 1 of the read -- is an entry)
+__global__ __launch_bounds__(256) void k_prev_list_items(const Item* __restrict__ items, const uint32_t* __restrict__ lpos,
+                                                         const uint8_t* __restrict__ kindf, uint64_t n_rows, ItEntries t,
+                                                         uint8_t* __restrict__ emask, uint32_t* __restrict__ err) {
+  const uint64_t r = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const uint32_t at = lpos[r];
+  const uint32_t kind = kindf[at];
+  const uint64_t id = items[at].id & kItIdMask;
+  const uint64_t* s = t.owords + (id >> 24) * uint64_t(t.W);
+  const int j = int(id >> 16) & 255, len = int(id >> 8) & 255;
+  const int tj = kind == 1 ? j + 1 : j, tl = kind == 1 ? len - 1 : len;
+  const int b = kind == 1 ? int((s[j >> 5] >> (62 - 2 * (j & 31))) & 3) : int((uint32_t(id) >> 1) & 3u);
+  uint64_t key[kMaxWords];
+#pragma unroll
+  for (int w = 0; w < kMaxWords; ++w) key[w] = w < t.W ? it_suffix_word(s, t.W, tj, w) : 0;
+  const uint64_t lo = it_lower_bound(t, key, tl);
+  if (lo >= t.n || it_entry_lcp(t, lo, key, tl) < tl) { atomicOr(err, 2u); return; }  // "Missing expansion?"
+  if (kind == 2) {
+    uint64_t k2[kMaxWords];
+#pragma unroll
+    for (int w = 0; w < kMaxWords; ++w) k2[w] = w < t.W ? it_suffix_word(s, t.W, j - 1, w) : 0;
+    const int kl = len + 1;
+    const uint64_t e2 = it_lower_bound(t, k2, kl);
+    if (e2 >= t.n || int(t.sizes[e2]) != kl || it_entry_lcp(t, e2, k2, kl) < kl) return;
+  }
+  atomicOr(reinterpret_cast<unsigned int*>(emask + (lo & ~3ull)), (1u << b) << (8 * unsigned(lo & 3)));
+}
+
+// the key table from the entries' records (what k_gather_dedup_build writes as it goes): W words an entry, and the first two
+__global__ __launch_bounds__(256) void k_items_keys(const uint64_t* __restrict__ erec, uint64_t n_ent, const uint64_t* __restrict__ owords,
+                                                    int W, uint64_t* __restrict__ keys, uint64_t* __restrict__ pre2) {
+  const uint64_t x = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (x >= n_ent * uint64_t(W)) return;
+  const uint64_t e = x / uint64_t(W);
+  const int w = int(x - e * uint64_t(W));
+  const uint64_t id = erec[e];
+  const uint64_t word = it_suffix_word(owords + (id >> 24) * uint64_t(W), W, int(id >> 16) & 255, w);
+  keys[x] = word;
+  if (w < 2) pre2[e * 2 + w] = word;
+  if (W == 1 && w == 0) pre2[e * 2 + 1] = 0;
+}
+
+int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_seqset* ss, LocalPrev* lp, bool* done) {
+  *done = false;
+  const uint64_t n_rec = cc->n_rec;
+  const int W = reads->W;
+  if (!n_rec || n_rec >= (1ull << 32) || getenv("BG_PREV_SEARCH_ALL")) return BG_OK;
+  DevBuf<Item> a, b;
+  BG_TRY(a.alloc(ctx, n_rec));
+  BG_TRY(b.alloc(ctx, n_rec));
+  ctx->tic("items_emit");
+  k_emit_items<<<cdiv(cdiv(cc->n_emit, 64), 4), 256, 0, ctx->stream>>>(cc->owords.p, reads->len.p, cc->cnt.p, cc->roff.p, cc->o_base, cc->n_emit, W, a.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n_rec * 16 + cc->n_emit * uint64_t(W) * 8);
+  cc->cnt.reset();
+  cc->roff.reset();
+  ctx->tic("items_partition");
+  const uint64_t whole[2] = {0, n_rec};
+  BG_TRY(it_partition(ctx, a.p, b.p, n_rec, 1, whole, 56));
+  DevBuf<uint64_t> b8, b16;
+  BG_TRY(b8.alloc(ctx, 257));
+  BG_TRY(b16.alloc(ctx, 65537));
+  it_bounds_kernel<<<2, 256, 0, ctx->stream>>>(b.p, n_rec, 8, b8.p);
+  BG_LAUNCH_CHECK();
+  std::vector<uint64_t> h8(257);
+  BG_HIP(copy_d2h(ctx, h8.data(), b8.p, 257 * 8));
+  BG_TRY(it_partition(ctx, b.p, a.p, n_rec, 256, h8.data(), 48));
+  it_bounds_kernel<<<cdiv(65537, 256), 256, 0, ctx->stream>>>(a.p, n_rec, 16, b16.p);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n_rec * 16 * 6);
+  // ---- every bucket in order of the first word, the runs of equal first words by the rest of their strings
+  DevBuf<uint8_t> status;
+  DevBuf<unsigned long long> ctr;  // [0] runs, [1] runs of more than four, [2] runs of more than 64, [3] big buckets
+  DevBuf<uint64_t> runs, more;
+  const uint64_t run_cap = n_rec / 2 + 1;
+  BG_TRY(status.alloc(ctx, 65536));
+  BG_TRY(ctr.alloc(ctx, 4));
+  BG_TRY(runs.alloc(ctx, run_cap));
+  BG_HIP(hipMemsetAsync(status.p, 0, 65536, ctx->stream));
+  BG_HIP(hipMemsetAsync(ctr.p, 0, 32, ctx->stream));
+  ctx->tic("items_bucket_sort");
+  k_items_bucket_sort<<<65536, IB_THREADS, 0, ctx->stream>>>(a.p, b.p, b16.p, status.p, runs.p, ctr.p, run_cap);
+  BG_LAUNCH_CHECK();
+  ctx->toc(n_rec * 32);
+  unsigned long long h_ctr[4] = {0, 0, 0, 0};
+  std::vector<uint8_t> h_status(65536);
+  BG_HIP(copy_d2h(ctx, h_ctr, ctr.p, 8));
+  BG_HIP(copy_d2h(ctx, h_status.data(), status.p, 65536));
+  uint64_t big = 0;
+  for (uint8_t v : h_status) big += v != 0;
+  a.reset();
+  if (big || h_ctr[0] > run_cap) return BG_OK;  // (left to the rows: the oversized buckets' third level is not built yet)
+  const uint64_t n_runs = h_ctr[0];
+  BG_TRY(more.alloc(ctx, n_runs ? n_runs : 1));
+  if (n_runs) {
+    ctx->tic("items_tie_runs");
+    k_items_tie_small<<<cdiv(n_runs, 256), 256, 0, ctx->stream>>>(b.p, runs.p, n_runs, cc->owords.p, W, more.p, ctr.p + 1);
+    BG_LAUNCH_CHECK();
+    BG_HIP(copy_d2h(ctx, h_ctr + 1, ctr.p + 1, 8));
+    if (h_ctr[1]) {
+      DevBuf<uint64_t> longer;
+      BG_TRY(longer.alloc(ctx, h_ctr[1]));
+      k_items_tie_wave<<<cdiv(h_ctr[1] * 64, 256), 256, 0, ctx->stream>>>(b.p, more.p, h_ctr[1], cc->owords.p, W, longer.p, ctr.p + 2);
+      BG_LAUNCH_CHECK();
+      BG_HIP(copy_d2h(ctx, h_ctr + 2, ctr.p + 2, 8));
+      if (h_ctr[2]) {
+        const uint32_t lds_members = 2048;  // 2048 x 64 bytes = 128 KB
+        BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_items_tie_block), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   int(lds_members * kMaxWords * 8)));
+        k_items_tie_block<<<unsigned(h_ctr[2]), 512, size_t(lds_members) * kMaxWords * 8, ctx->stream>>>(b.p, longer.p, cc->owords.p, W, lds_members);
+        BG_LAUNCH_CHECK();
+        BG_HIP(hipStreamSynchronize(ctx->stream));
+      }
+    }
+    ctx->toc(n_runs * 2 * (16 + uint64_t(W) * 8));
+  }
+  runs.reset();
+  more.reset();
+  // ---- entries
+  DevBuf<uint8_t> keep, lcpn;
+  DevBuf<uint32_t> err, kept;
+  BG_TRY(keep.alloc(ctx, n_rec));
+  BG_TRY(lcpn.alloc(ctx, n_rec));
+  BG_TRY(err.alloc(ctx, 2));
+  BG_HIP(hipMemsetAsync(err.p, 0, 8, ctx->stream));
+  ctx->tic("items_entries");
+  k_items_keep<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(b.p, n_rec, keep.p, lcpn.p, err.p);
+  BG_LAUNCH_CHECK();
+  uint64_t n_ent = 0;
+  DevBuf<uint32_t> rank;
+  {
+    const uint64_t nt = (n_rec + CP_TILE - 1) / CP_TILE;
+    DevBuf<uint32_t> counts;
+    DevBuf<uint64_t> offs, total;
+    BG_TRY(counts.alloc(ctx, nt));
+    BG_TRY(offs.alloc(ctx, nt));
+    BG_TRY(total.alloc(ctx, 1));
+    BG_TRY(rank.alloc(ctx, n_rec));
+    BG_TRY(kept.alloc(ctx, n_rec));  // (room for every item: the survivors' number comes back beside the kernel)
+    cp_count_kernel<<<unsigned(nt), CP_THREADS, 0, ctx->stream>>>(keep.p, n_rec, counts.p);
+    BG_LAUNCH_CHECK();
+    BG_TRY(exclusive_scan_u32_to_u64(ctx, counts.p, offs.p, nt, total.p));
+    k_items_rank<<<unsigned(nt), CP_THREADS, 0, ctx->stream>>>(keep.p, n_rec, offs.p, rank.p, kept.p);
+    BG_LAUNCH_CHECK();
+    BG_HIP(copy_d2h(ctx, &n_ent, total.p, 8));
+  }
+  DevBuf<uint64_t> erec, pre1;
+  ss->W = W;
+  BG_TRY(pre1.alloc(ctx, n_ent));
+  BG_TRY(ss->sizes.alloc(ctx, n_ent));
+  BG_TRY(ss->shared.alloc(ctx, n_ent));
+  BG_TRY(erec.alloc(ctx, n_ent));
+  BG_TRY(lp->emask.alloc(ctx, (n_ent + 3) & ~3ull));
+  BG_HIP(hipMemsetAsync(lp->emask.p, 0, (n_ent + 3) & ~3ull, ctx->stream));
+  BG_TRY(lp->count.alloc(ctx, 1));
+  DevBuf<uint8_t> kindf;
+  DevBuf<uint32_t> lpos;
+  BG_TRY(kindf.alloc(ctx, n_rec));
+  k_items_entries<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(b.p, n_rec, keep.p, rank.p, kept.p, lcpn.p, ss->sizes.p, ss->shared.p, erec.p, pre1.p,
+                                                             reinterpret_cast<uint32_t*>(lp->emask.p), kindf.p);
+  BG_LAUNCH_CHECK();
+  BG_TRY(compact_flagged<uint32_t>(ctx, kindf.p, n_rec, &lpos, &lp->n_items));
+  ctx->toc(n_rec * 32 + n_ent * 12);
+  uint32_t h_err[2] = {0, 0};
+  BG_HIP(copy_d2h(ctx, h_err, err.p, 8));
+  if (h_err[0]) { set_error("items: the sorted items are not in order (internal error %u)", h_err[0]); return BG_EINTERNAL; }
+  lp->cap = lp->n_items;
+  lp->valid = true;
+  static const bool keys_now = [] { const char* e = getenv("BG_ITEMS_KEYS"); return e && e[0] == '1'; }();
+  if (keys_now) {
+    // (BG_ITEMS_KEYS=1: the rows of the list and the key table at once, searched by k_prev_list as the rows path does)
+    if (lp->n_items) {
+      BG_TRY(lp->list.alloc(ctx, lp->n_items * uint64_t(W + 1)));
+      ctx->tic("items_list_rows");
+      k_items_list_rows<<<cdiv(lp->n_items * uint64_t(W + 1), 256), 256, 0, ctx->stream>>>(b.p, lpos.p, kindf.p, lp->n_items, cc->owords.p, W, lp->list.p);
+      BG_LAUNCH_CHECK();
+      ctx->toc(lp->n_items * (uint64_t(W + 1) * 8 * 2 + 24));
+    }
+  } else {
+    // the tails searched through the entries' first words and the reads
+    DevBuf<uint32_t> dir;
+    int bases = 0;
+    ctx->tic("prev_bits");
+    BG_TRY(build_prefix_dir_keys(ctx, pre1.p, n_ent, 1, &dir, &bases));
+    if (lp->n_items) {
+      const ItEntries t{pre1.p, erec.p, ss->sizes.p, cc->owords.p, dir.p, n_ent, W, bases};
+      k_prev_list_items<<<cdiv(lp->n_items, 256), 256, 0, ctx->stream>>>(b.p, lpos.p, kindf.p, lp->n_items, t, lp->emask.p, err.p);
+      BG_LAUNCH_CHECK();
+    }
+    ctx->toc(lp->n_items * (uint64_t(W) * 8 * 3 + 64));
+    BG_HIP(copy_d2h(ctx, h_err, err.p, 8));
+    if (h_err[0] & 2) { set_error("missing expansion (entry set not closed under pop_front)"); return BG_EINTERNAL; }
+    lp->searched = true;
+  }
+  lpos.reset();
+  kindf.reset();
+  b.reset();
+  kept.reset();
+  rank.reset();
+  keep.reset();
+  lcpn.reset();
+  pre1.reset();
+  ss->n = n_ent;
+  ss->erec = std::move(erec);
+  ss->oreads = std::move(cc->owords);
+  if (keys_now) BG_TRY(seqset_ensure_keys(ctx, ss));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  ss->n = n_ent;
+  *done = true;
+  return BG_OK;
+}
+
+int seqset_ensure_keys(bg_ctx* ctx, bg_seqset* ss) {
+  if (!ss || ss->keys.p || !ss->erec.p || !ss->oreads.p || !ss->W) return BG_OK;
+  const uint64_t n_ent = ss->n;
+  const int W = ss->W;
+  BG_HIP(hipSetDevice(ctx->device));
+  BG_TRY(ss->keys.alloc(ctx, n_ent * W));
+  BG_TRY(ss->pre2.alloc(ctx, n_ent * 2));
+  if (n_ent) {
+    ctx->tic("items_keys");
+    k_items_keys<<<cdiv(n_ent * uint64_t(W), 256), 256, 0, ctx->stream>>>(ss->erec.p, n_ent, ss->oreads.p, W, ss->keys.p, ss->pre2.p);
+    BG_LAUNCH_CHECK();
+    ctx->toc(n_ent * (uint64_t(W) * 8 * 2 + 16));
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  ss->erec.reset();
+  ss->oreads.reset();
   return BG_OK;
 }
 
@@ -251,6 +1038,67 @@ int items_probe(bg_ctx* ctx, const uint64_t* owords, const uint16_t* len, const 
   std::vector<uint64_t> h16(65537);
   BG_HIP(copy_d2h(ctx, h16.data(), b16.p, 65537 * 8));
   BG_HIP(hipEventRecord(ev[5], ctx->stream));
+  // the buckets in order (a -> b), then the checker
+  DevBuf<uint8_t> status;
+  DevBuf<unsigned long long> chk;
+  BG_TRY(status.alloc(ctx, 65536));
+  BG_TRY(chk.alloc(ctx, 8));
+  BG_HIP(hipMemsetAsync(status.p, 0, 65536, ctx->stream));
+  BG_HIP(hipMemsetAsync(chk.p, 0, 64, ctx->stream));
+  hipEvent_t es[3];
+  for (auto& e : es) BG_HIP(hipEventCreate(&e));
+  BG_HIP(hipEventRecord(es[0], ctx->stream));
+  DevBuf<uint64_t> runs, more;
+  const uint64_t run_cap = n_rec / 2 + 1;
+  BG_TRY(runs.alloc(ctx, run_cap));
+  k_items_bucket_sort<<<65536, IB_THREADS, 0, ctx->stream>>>(a.p, b.p, b16.p, status.p, runs.p, chk.p + 3, run_cap);
+  BG_LAUNCH_CHECK();
+  BG_HIP(hipEventRecord(es[1], ctx->stream));
+  unsigned long long n_runs = 0, n_more = 0;
+  BG_HIP(copy_d2h(ctx, &n_runs, chk.p + 3, 8));
+  BG_HIP(hipMemsetAsync(chk.p + 3, 0, 8, ctx->stream));
+  if (n_runs > run_cap) n_runs = run_cap;
+  BG_TRY(more.alloc(ctx, n_runs ? n_runs : 1));
+  if (n_runs) {
+    k_items_tie_small<<<cdiv(n_runs, 256), 256, 0, ctx->stream>>>(b.p, runs.p, n_runs, owords, W, more.p, chk.p + 3);
+    BG_LAUNCH_CHECK();
+    BG_HIP(copy_d2h(ctx, &n_more, chk.p + 3, 8));
+    if (n_more) {
+      DevBuf<uint64_t> longer;
+      BG_TRY(longer.alloc(ctx, n_more));
+      k_items_tie_wave<<<cdiv(n_more * 64, 256), 256, 0, ctx->stream>>>(b.p, more.p, n_more, owords, W, longer.p, chk.p + 4);
+      BG_LAUNCH_CHECK();
+      unsigned long long n_long = 0;
+      BG_HIP(copy_d2h(ctx, &n_long, chk.p + 4, 8));
+      if (n_long) {
+        const uint32_t lds_members = 2048;
+        BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_items_tie_block), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   int(lds_members * kMaxWords * 8)));
+        k_items_tie_block<<<unsigned(n_long), 512, size_t(lds_members) * kMaxWords * 8, ctx->stream>>>(b.p, longer.p, owords, W, lds_members);
+        BG_LAUNCH_CHECK();
+        BG_HIP(hipStreamSynchronize(ctx->stream));
+      }
+    }
+  }
+  BG_HIP(hipMemsetAsync(chk.p + 3, 0, 8, ctx->stream));
+  BG_HIP(hipEventRecord(es[2], ctx->stream));
+  k_items_check_order<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(a.p, n_rec, owords, W, chk.p + 6, chk.p + 2);  // (ids before; its order counts are unused)
+  BG_LAUNCH_CHECK();
+  k_items_check_order<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(b.p, n_rec, owords, W, chk.p, chk.p + 5);
+  BG_LAUNCH_CHECK();
+  unsigned long long h_chk[6];
+  std::vector<uint8_t> h_status(65536);
+  BG_HIP(copy_d2h(ctx, h_chk, chk.p, 48));
+  BG_HIP(copy_d2h(ctx, h_status.data(), status.p, 65536));
+  float ms_sort = 0, ms_ties = 0;
+  BG_HIP(hipEventElapsedTime(&ms_sort, es[0], es[1]));
+  BG_HIP(hipEventElapsedTime(&ms_ties, es[1], es[2]));
+  for (auto& e : es) (void)hipEventDestroy(e);
+  uint64_t st1 = 0;
+  for (uint8_t v : h_status) st1 += v == 1;
+  fprintf(stderr, "items probe: bucket sort %.2f ms, %llu runs of equal first words (%llu of more than four) %.2f ms; out of order %llu, LCP notes missing or "
+                  "wrong %llu, same items %s; left for the fall-back: %llu buckets too big, %llu runs longer than 64\n",
+          ms_sort, n_runs, n_more, ms_ties, h_chk[0], h_chk[1], h_chk[2] == h_chk[5] ? "yes" : "NO", (unsigned long long)st1, h_chk[4]);
   BG_HIP(hipEventSynchronize(ev[5]));
   float ms[5];
   for (int i = 0; i < 5; ++i) BG_HIP(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));

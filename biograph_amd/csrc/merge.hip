@@ -142,6 +142,7 @@ int seqset_stripe_rows(bg_ctx* ctx, const bg_seqset* s, uint64_t lo, uint64_t cn
   if (!cnt) return BG_OK;
   if (lo + cnt > s->n) { set_error("seqset_stripe_rows: stripe past the end"); return BG_EINVAL; }
   if (!s->accum[0].p) { set_error("bg_merge_sharded: an input is not finalized"); return BG_EINVAL; }
+  BG_TRY(seqset_ensure_keys(ctx, const_cast<bg_seqset*>(s)));
   if (s->keys.p && s->W) k_stripe_rows_keys<<<cdiv(cnt, 256), 256, 0, ctx->stream>>>(s->keys.p, s->sizes.p, lo, cnt, s->W, W, d_rows);
   else k_stripe_rows_fm<<<cdiv(cnt, 64), 64, 0, ctx->stream>>>(merge_view(s), lo, cnt, W, d_rows);
   BG_LAUNCH_CHECK();
@@ -178,6 +179,7 @@ extern "C" int bg_seqset_merge(bg_ctx* ctx, uint32_t n_in, const bg_seqset* cons
   for (uint32_t i = 0; i < n_in; ++i) {
     const bg_seqset* s = in[i];
     if (!s->n) continue;
+    BG_TRY(seqset_ensure_keys(ctx, const_cast<bg_seqset*>(s)));
     if (s->keys.p && s->W) {
       k_merge_copy_keys<<<cdiv(s->n, 256), 256, 0, ctx->stream>>>(s->keys.p, s->sizes.p, s->n, s->W, W, rec.p + pos * W,
                                                                  rlen.p + pos);

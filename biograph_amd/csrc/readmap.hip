@@ -439,6 +439,7 @@ extern "C" int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads
 extern "C" int bg_readmap_build_marked(bg_ctx* ctx, const bg_seqset* ss, const bg_reads* reads, int is_paired,
                                        const uint8_t* d_marks, bg_readmap** out) {
   if (!ctx || !ss || !reads || !out) { set_error("bg_readmap_build: null argument"); return BG_EINVAL; }
+  BG_TRY(seqset_ensure_keys(ctx, const_cast<bg_seqset*>(ss)));  // (a build from items makes its keys when asked)
   const bool have_keys = ss->keys.p && ss->W;
   if (ss->n && !have_keys && !ss->accum[0].p) { set_error("bg_readmap_build: the seqset is not finalized"); return BG_EINVAL; }
   if (have_keys && reads->W > ss->W && ss->n) { set_error("bg_readmap_build: reads longer than the seqset's entries"); return BG_EINVAL; }
@@ -1145,6 +1146,7 @@ static int rms_check(bg_ctx* ctx, DevBuf<uint32_t>& err, const char* who) {
 extern "C" int bg_seqset_find_rows(bg_ctx* ctx, const bg_seqset* shard, const uint64_t* d_rows, uint64_t n, int W,
                                    uint64_t entry_base, uint64_t* d_entry) {
   if (!ctx || !shard || (n && (!d_rows || !d_entry))) { set_error("bg_seqset_find_rows: null argument"); return BG_EINVAL; }
+  BG_TRY(seqset_ensure_keys(ctx, const_cast<bg_seqset*>(shard)));
   if (n && shard->n && !(shard->keys.p && shard->W)) { set_error("bg_seqset_find_rows: the shard has no resident keys"); return BG_EINVAL; }
   if (W < 1 || W > kMaxWords || (shard->n && W > shard->W)) { set_error("bg_seqset_find_rows: rows wider than the shard's keys"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));
