@@ -28,14 +28,18 @@ SURVEY_8D_BYTES = {
     "skm_generate": lambda st: 16 * st["n_kmers"],
     "suffix_cover_count": lambda st: 28 * st["n_records"],
     "correct_dfs": lambda st: 0.5 * st["n_bases"] + 8 * st["n_kmers"],
+    "items_partition": lambda st: 28 * st["n_records"], "items_tie_runs": lambda st: 28 * st["n_records"],
+    "items_entries": lambda st: 28 * st["n_records"], "items_bucket_sort": lambda st: 28 * st["n_records"],
 }
 SURVEY_8D_FORMULA = {
     "entries_dedup_build": "S4 = 28 x N_rec", "prev_bits": "S5 = 2.625 x N_ent", "skm_count_lds": "S2 = 16 x N_kmers",
     "skm_generate": "S2 = 16 x N_kmers", "suffix_cover_count": "S4 = 28 x N_rec", "correct_dfs": "S3 = 0.5 x N_bases + 8 x N_kmers",
+    "items_partition": "S4 = 28 x N_rec", "items_tie_runs": "S4 = 28 x N_rec", "items_entries": "S4 = 28 x N_rec",
+    "items_bucket_sort": "S4 = 28 x N_rec",
 }
 # kernel families of the step by stage of SURVEY.md section 8(d)
 STAGE_OF_FAMILY = [("S1 pack", ("pack_",)), ("S2 k-mer count", ("skm_", "kmer_")), ("S3 correct", ("correct_",)),
-                   ("S4+S5 suffix sort, dedup, prev bits, arrays", ("suffix_", "radix_", "entries_", "prev_bits", "seqset_"))]
+                   ("S4+S5 suffix sort, dedup, prev bits, arrays", ("suffix_", "radix_", "entries_", "items_", "prev_bits", "seqset_"))]
 
 
 def stage_table(kernels, stats, steps):
@@ -613,7 +617,9 @@ KERNEL_OF_FAMILY = {"radix_scatter_k": "rs_part_scatter_kernel",
                     "correct_screen": "k_correct_screen", "entries_dedup_build": "k_gather_dedup_build",
                     "skm_count_lds": "sk_count_lds_kernel", "skm_generate": "sk_generate_kernel",
                     "suffix_cover_count": "k_cover_count", "prev_bits": "k_prev_bits_pre2",
-                    "suffix_small_ties": "k_sort_small_groups", "entries_dedup": "k_gather_lcp_keep"}
+                    "suffix_small_ties": "k_sort_small_groups", "entries_dedup": "k_gather_lcp_keep",
+                    "items_partition": "it_scatter_kernel", "items_tie_runs": "k_items_tie_small", "items_entries": "k_items_entries",
+                    "items_bucket_sort": "k_items_bucket_sort"}
 
 
 LIMITER_OF_FAMILY = {"skm_count_lds": "VALU issue (rolling canonical k-mer + LDS probe per window)",
@@ -621,7 +627,11 @@ LIMITER_OF_FAMILY = {"skm_count_lds": "VALU issue (rolling canonical k-mer + LDS
                      "entries_dedup_build": "random 128-byte lines (a 48-byte row drags 1.25 lines; a tile of 512 rows brings 20 more as halo for the "
                                             "tie groups it orders) + look-back latency",
                      "suffix_cover_count": "L1 -> L2 request rate (21 dependent probes per read)",
-                     "radix_scatter_k": "hbm stream", "skm_part_scatter": "hbm stream", "suffix_emit": "hbm stream"}
+                     "radix_scatter_k": "hbm stream", "skm_part_scatter": "hbm stream", "suffix_emit": "hbm stream",
+                     "items_partition": "hbm stream (16 bytes a record read twice, written once, a level)",
+                     "items_bucket_sort": "LDS (a counting sort and a ranking inside bins per bucket)",
+                     "items_tie_runs": "random 64-byte sectors (the rest of the string of every record that shares its first word)",
+                     "items_entries": "hbm stream"}
 
 
 def pmc_traffic(family, avg_launch_ms):

@@ -231,8 +231,8 @@ struct bg_seqset {
   bg::DevBuf<uint8_t> emask, need;
   bg::DevBuf<uint64_t> cond;
   uint64_t n_cond = 0;
-  // a build from items (items_build.hip): no key table yet -- every entry's record (oriented read << 24 | offset << 16 | ...)
-  // and the oriented reads it points into; seqset_ensure_keys makes keys / pre2 from them the first time somebody needs them
+  // a build from items (items_build.hip): no key table yet -- every entry's first word and record (oriented read << 24 |
+  // offset << 16 | ...), two words an entry, and the oriented reads the records point into; seqset_ensure_keys makes keys / pre2 from them the first time somebody needs them
   bg::DevBuf<uint64_t> erec, oreads;
 };
 
@@ -316,6 +316,12 @@ int cover_counts_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t 
 // items_build.hip: the entries (keys, pre2, sizes, shared, the local prev bits and the list of tails) from 16-byte items;
 // *done = false: the input has buckets or runs the items path does not take yet -- nothing was changed, use the rows
 int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_seqset* ss, LocalPrev* lp, bool* done);
+// build_seqset.hip: the order of records by full key (rows of RS words), sidx[i] = the row at sorted place i
+int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p, uint64_t n_rec, int W, DevBuf<uint64_t>* k0,
+                      DevBuf<uint32_t>* sidx_out, uint64_t* n_tied_out, int RS = 0, bool defer_small = false);
+// build_seqset.hip: the suffix records as rows from the cover stage's counts (the second half of suffix_records_impl)
+int suffix_rows_from_counts(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen,
+                            DevBuf<uint64_t>* k0, int RS);
 // keys / pre2 of a seqset built from items, on demand (no-op when they are there or cannot be made)
 int seqset_ensure_keys(bg_ctx* ctx, bg_seqset* ss);
 // items_build.hip: the front half of the items path (BG_ITEMS_PROBE=1), beside the build

@@ -2014,10 +2014,6 @@ int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss, bool slice) {
 
 namespace bg {
 
-int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p, uint64_t n_rec, int W,
-                      DevBuf<uint64_t>* k0, DevBuf<uint32_t>* sidx_out, uint64_t* n_tied_out, int RS = 0,
-                      bool defer_small = false);
-
 // Cover index over n_o oriented reads (owords: n_o x W zero-padded words, olen: their lengths).  The reads are
 // sorted by their full key (the machinery of the record sort): reads with the same first K-mer are then
 // consecutive AND in key order, so a look-up among the candidates of one K-mer is a binary search — a repeat
@@ -2114,27 +2110,33 @@ int cover_counts_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t 
 
 // Phase A: suffix records of reads [lo, hi) under the exact-cover rule; the cover index spans ALL
 // reads of `reads`.
-int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t hi, int cover_k,
-                        DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out, DevBuf<uint64_t>* k0, int RS) {
+int suffix_rows_from_counts(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen,
+                            DevBuf<uint64_t>* k0, int RS) {
   if (RS <= 0) RS = reads->W;
   const int W = reads->W;
-  CoverCounts cc;
-  BG_TRY(cover_counts_impl(ctx, reads, lo, hi, cover_k, &cc));
-  const uint64_t n_rec = cc.n_rec, n_emit = cc.n_emit, o_base = cc.o_base;
-  if (getenv("BG_ITEMS_PROBE")) BG_TRY(items_probe(ctx, cc.owords.p, reads->len.p, cc.cnt.p, cc.roff.p, o_base, n_emit, W, n_rec));  // (items_build.hip)
+  const uint64_t n_rec = cc->n_rec, n_emit = cc->n_emit, o_base = cc->o_base;
   BG_TRY(rec->alloc(ctx, n_rec * RS));
   if (RS == W) BG_TRY(rlen->alloc(ctx, n_rec));  // (rows of W + 1 words carry the lengths themselves)
   const bool want_k0 = k0 && n_rec < (1ull << 32);
   if (want_k0) BG_TRY(k0->alloc(ctx, n_rec));
   if (n_rec) {
     ctx->tic("suffix_emit");
-    k_emit_records<<<cdiv(cdiv(n_emit, 64), 4), 256, size_t(256) * RS * 8, ctx->stream>>>(cc.owords.p, reads->len.p, cc.cnt.p, cc.roff.p, o_base, n_emit, W,
+    k_emit_records<<<cdiv(cdiv(n_emit, 64), 4), 256, size_t(256) * RS * 8, ctx->stream>>>(cc->owords.p, reads->len.p, cc->cnt.p, cc->roff.p, o_base, n_emit, W,
                                                                RS, rec->p, RS == W ? rlen->p : nullptr, want_k0 ? k0->p : nullptr);
     BG_LAUNCH_CHECK();
     ctx->toc(n_emit * W * 8 + n_rec * (RS * 8 + 1 + (want_k0 ? 8 : 0)));
   }
-  BG_HIP(hipStreamSynchronize(ctx->stream));  // (cc goes out of scope)
-  *n_rec_out = n_rec;
+  BG_HIP(hipStreamSynchronize(ctx->stream));  // (the caller may let cc go)
+  return BG_OK;
+}
+
+int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t hi, int cover_k,
+                        DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out, DevBuf<uint64_t>* k0, int RS) {
+  CoverCounts cc;
+  BG_TRY(cover_counts_impl(ctx, reads, lo, hi, cover_k, &cc));
+  if (getenv("BG_ITEMS_PROBE")) BG_TRY(items_probe(ctx, cc.owords.p, reads->len.p, cc.cnt.p, cc.roff.p, cc.o_base, cc.n_emit, reads->W, cc.n_rec));  // (items_build.hip)
+  BG_TRY(suffix_rows_from_counts(ctx, reads, &cc, rec, rlen, k0, RS));
+  *n_rec_out = cc.n_rec;
   return BG_OK;
 }
 
@@ -2721,16 +2723,20 @@ extern "C" int bg_seqset_build(bg_ctx* ctx, const bg_reads* reads, int cover_k, 
   const int RS = reads->W + 1;
   LocalPrev lp;
   bool by_items = false;
-  if (getenv("BG_ITEMS_BUILD")) {
-    // the entries from 16-byte items (items_build.hip): same arrays; false = an input it leaves to the rows
-    CoverCounts cc;
-    BG_TRY(cover_counts_impl(ctx, reads, 0, reads->n, cover_k, &cc));
-    n_rec = cc.n_rec;
-    BG_TRY(items_entries_impl(ctx, reads, &cc, ss.get(), &lp, &by_items));
-    if (getenv("BG_DEBUG_PREV")) fprintf(stderr, "entries from items: %s\n", by_items ? "yes" : "no (left to the rows)");
-  }
+  // The entries from 16-byte items (items_build.hip) -- the same arrays without rows, sorted keys or a key
+  // table (made when a consumer asks: seqset_ensure_keys).  BG_ITEMS_BUILD=0: through the rows, as before; also what an input
+  // takes that the items path declines (*done = false: nothing of ss / lp was touched, the cover stage's counts are reused).
+  const char* items_env = getenv("BG_ITEMS_BUILD");
+  const bool items_on = !(items_env && items_env[0] == '0');
+  CoverCounts cc;
+  BG_TRY(cover_counts_impl(ctx, reads, 0, reads->n, cover_k, &cc));
+  n_rec = cc.n_rec;
+  if (getenv("BG_ITEMS_PROBE")) BG_TRY(items_probe(ctx, cc.owords.p, reads->len.p, cc.cnt.p, cc.roff.p, cc.o_base, cc.n_emit, reads->W, cc.n_rec));
+  if (items_on) BG_TRY(items_entries_impl(ctx, reads, &cc, ss.get(), &lp, &by_items));
+  if (getenv("BG_DEBUG_PREV")) fprintf(stderr, "entries from items: %s\n", by_items ? "yes" : "no (through the rows)");
   if (!by_items) {
-    BG_TRY(suffix_records_impl(ctx, reads, 0, reads->n, cover_k, &rec, &rlen, &n_rec, &k0, RS));
+    BG_TRY(suffix_rows_from_counts(ctx, reads, &cc, &rec, &rlen, &k0, RS));
+    cc = CoverCounts();
     BG_TRY(entries_from_records_impl(ctx, rec, rlen, n_rec, reads->W, ss.get(), &n_tied, &k0, RS, &lp));
   }
   BG_TRY(prev_bits_local_impl(ctx, ss.get(), &lp));

@@ -198,6 +198,7 @@ __global__ void it_bounds_kernel(const Item* __restrict__ items, uint64_t n, int
 constexpr int IB_THREADS = 512;
 constexpr int IB_CAP = 4096;       // items a workgroup sorts in LDS
 constexpr int IB_BINS = 2048;      // counting sort on the next 11 bits, then ranks inside a bin by comparison
+constexpr int IB_BIN_MAX = 96;     // members of a bin beyond which the bucket is left to the rows machinery
 constexpr uint64_t kItLcpValid = 1ull << 63;
 constexpr int kItLcpShift = 55;
 constexpr uint64_t kItIdMask = (1ull << kItLcpShift) - 1;
@@ -251,7 +252,17 @@ __global__ __launch_bounds__(IB_THREADS) void k_items_bucket_sort(const Item* __
       if (lane >= d) x += y;
     }
     if (lane == 63) s_scan[wave] = x;
-    __syncthreads();
+    uint32_t fullest = 0;
+#pragma unroll
+    for (int k = 0; k < IB_BINS / IB_THREADS; ++k) fullest = v[k] > fullest ? v[k] : fullest;
+    const bool crowded = __syncthreads_or(fullest > uint32_t(IB_BIN_MAX));
+    if (crowded) {
+      // a bin of hundreds (a repeat family's first word): ranking its members against each other is quadratic -- the bucket
+      // goes the way of the oversized ones
+      if (tid == 0) status[b] = 1;
+      for (uint64_t i = lo + tid; i < hi; i += IB_THREADS) out[i] = in[i];
+      return;
+    }
     uint32_t base = 0;
     for (int w2 = 0; w2 < wave; ++w2) base += s_scan[w2];
     uint32_t run = base + x - sum;
@@ -438,7 +449,7 @@ __global__ __launch_bounds__(256) void k_items_tie_wave(Item* __restrict__ items
 // a run of more than 64 members (repeats; a bucket holds at most IB_CAP items): a workgroup a run; the members' rest rows and
 // ids in LDS (lds_members of them fit: longer runs fetch them from the reads at every comparison), every member counts the
 // members that sort before it (quadratic: such runs are few).
-__global__ __launch_bounds__(512) void k_items_tie_block(Item* __restrict__ items, const uint64_t* __restrict__ longer,
+__global__ __launch_bounds__(1024) void k_items_tie_block(Item* __restrict__ items, const uint64_t* __restrict__ longer,
                                                          const uint64_t* __restrict__ owords, int W, uint32_t lds_members) {
   extern __shared__ uint64_t tb_smem[];  // lds_members x (1 + kMaxWords - 1) words: id, rest
   __shared__ uint16_t place[IB_CAP];     // sorted place -> member
@@ -481,7 +492,7 @@ __global__ __launch_bounds__(512) void k_items_tie_block(Item* __restrict__ item
   const uint64_t f = items[p].fw;
   // (every member's row is read before any item of the run is overwritten: the rows come from LDS, or -- a run too long for
   // it -- the ids are staged in `place`'s order first)
-  uint64_t out_id[IB_CAP / 512];
+  uint64_t out_id[IB_CAP / 1024];
   int k = 0;
   for (uint32_t r = threadIdx.x; r < g; r += blockDim.x, ++k) {
     ItRow me;
@@ -562,6 +573,88 @@ static int it_partition(bg_ctx* ctx, const Item* in, Item* out, uint64_t n, uint
   return BG_OK;
 }
 
+// ---- what the bucket sort and the run kernels leave (a bucket of more than IB_CAP items, a run of more than kItBlockRun equal
+// first words: repeats) goes through the rows machinery, which takes any input: the items of those stretches (`segs`: start,
+// count; ascending, disjoint) become rows, sort_records_impl orders them by (string, length), and they come back in that order
+// with the LCP notes of neighbours that share their first word.  A stretch is a whole range of the final order (a bucket; all
+// the items of one first word), so the sorted subset maps onto the stretches in turn.
+constexpr uint32_t kItBlockRun = 256;  // runs up to here: k_items_tie_block (quadratic in LDS)
+__device__ __forceinline__ uint64_t it_seg_place(const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ seg_off, uint32_t nseg, uint64_t t) {
+  uint32_t a = 0, z = nseg;  // last stretch with seg_off <= t
+  while (z - a > 1) {
+    const uint32_t mid = (a + z) >> 1;
+    if (seg_off[mid] <= t) a = mid; else z = mid;
+  }
+  return seg_start[a] + (t - seg_off[a]);
+}
+__global__ __launch_bounds__(256) void k_items_subset_rows(const Item* __restrict__ items, const uint64_t* __restrict__ seg_start,
+                                                           const uint64_t* __restrict__ seg_off, uint32_t nseg, uint64_t m,
+                                                           const uint64_t* __restrict__ owords, int W, Item* __restrict__ sub,
+                                                           uint64_t* __restrict__ rec) {
+  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= m) return;
+  const Item it = items[it_seg_place(seg_start, seg_off, nseg, t)];
+  const uint64_t id = it.id & kItIdMask;
+  sub[t] = Item{it.fw, id};
+  const uint64_t* s = owords + (id >> 24) * uint64_t(W);
+  const int j = int(id >> 16) & 255;
+  uint64_t* row = rec + t * uint64_t(W + 1);
+  for (int w = 0; w < W; ++w) row[w] = it_suffix_word(s, W, j, w);
+  row[W] = (id >> 8) & 255;
+}
+__global__ __launch_bounds__(256) void k_items_subset_back(Item* __restrict__ items, const uint64_t* __restrict__ seg_start,
+                                                           const uint64_t* __restrict__ seg_off, uint32_t nseg, uint64_t m,
+                                                           const Item* __restrict__ sub, const uint64_t* __restrict__ rec,
+                                                           const uint32_t* __restrict__ sidx, int W) {
+  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= m) return;
+  const uint32_t src = sidx[t];
+  Item it = sub[src];
+  if (t + 1 < m) {
+    const uint32_t nx = sidx[t + 1];
+    if (sub[nx].fw == it.fw) {
+      const uint64_t* a = rec + uint64_t(src) * (W + 1);
+      const uint64_t* c = rec + uint64_t(nx) * (W + 1);
+      const int l = key_lcp(a, int(a[W] & 255), c, int(c[W] & 255), W);
+      it.id |= kItLcpValid | (uint64_t(l) << kItLcpShift);
+    }
+  }
+  items[it_seg_place(seg_start, seg_off, nseg, t)] = it;
+}
+
+static int items_subset_through_rows(bg_ctx* ctx, Item* items, std::vector<std::pair<uint64_t, uint64_t>>& segs, const uint64_t* owords, int W) {
+  if (segs.empty()) return BG_OK;
+  std::sort(segs.begin(), segs.end());
+  std::vector<uint64_t> h_start(segs.size()), h_off(segs.size() + 1, 0);
+  for (size_t k = 0; k < segs.size(); ++k) {
+    h_start[k] = segs[k].first;
+    h_off[k + 1] = h_off[k] + segs[k].second;
+  }
+  const uint64_t m = h_off.back();
+  const uint32_t nseg = uint32_t(segs.size());
+  DevBuf<uint64_t> d_start, d_off, rec;
+  DevBuf<Item> sub;
+  DevBuf<uint32_t> sidx;
+  DevBuf<uint8_t> no_len;
+  BG_TRY(d_start.alloc(ctx, nseg));
+  BG_TRY(d_off.alloc(ctx, nseg + 1));
+  BG_TRY(sub.alloc(ctx, m));
+  BG_TRY(rec.alloc(ctx, m * uint64_t(W + 1)));
+  BG_HIP(hipMemcpyAsync(d_start.p, h_start.data(), nseg * 8, hipMemcpyHostToDevice, ctx->stream));
+  BG_HIP(hipMemcpyAsync(d_off.p, h_off.data(), (size_t(nseg) + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  ctx->tic("items_through_rows");
+  k_items_subset_rows<<<cdiv(m, 256), 256, 0, ctx->stream>>>(items, d_start.p, d_off.p, nseg, m, owords, W, sub.p, rec.p);
+  BG_LAUNCH_CHECK();
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  uint64_t n_tied = 0;
+  BG_TRY(sort_records_impl(ctx, rec.p, no_len.p, m, W, nullptr, &sidx, &n_tied, W + 1, false));
+  k_items_subset_back<<<cdiv(m, 256), 256, 0, ctx->stream>>>(items, d_start.p, d_off.p, nseg, m, sub.p, rec.p, sidx.p, W);
+  BG_LAUNCH_CHECK();
+  ctx->toc(m * (uint64_t(W + 1) * 8 * 3 + 64));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  return BG_OK;
+}
+
 // ---- the stream passes over the items in order: no read is touched except for the list rows and the keys
 // keep[p] = the item survives (it is not a prefix of, or equal to, its successor: expand.cpp:19-48 skip_dups); lcpn[p] = its LCP
 // with its successor (the note of k_items_tie_*, or what the two first words show)
@@ -630,8 +723,7 @@ __global__ __launch_bounds__(256) void k_items_rank(const uint8_t* __restrict__ 
 __global__ __launch_bounds__(256) void k_items_entries(const Item* __restrict__ items, uint64_t n, const uint8_t* __restrict__ keep,
                                                        const uint32_t* __restrict__ rank, const uint32_t* __restrict__ kept,
                                                        const uint8_t* __restrict__ lcpn, uint8_t* __restrict__ sizes, uint8_t* __restrict__ shared,
-                                                       uint64_t* __restrict__ erec, uint64_t* __restrict__ pre1, uint32_t* __restrict__ emask32,
-                                                       uint8_t* __restrict__ kindf) {
+                                                       Item* __restrict__ ent, uint32_t* __restrict__ emask32, uint8_t* __restrict__ kindf) {
   const uint64_t p = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   uint32_t kind = 0, contrib = 0, my_e = 0xffffffffu;
@@ -653,8 +745,7 @@ __global__ __launch_bounds__(256) void k_items_entries(const Item* __restrict__ 
       }
       sizes[e] = uint8_t(len);
       shared[e] = uint8_t(sh);
-      erec[e] = id;
-      pre1[e] = me.fw;
+      ent[e] = Item{me.fw, id};  // the entry's first word and its record, side by side: what the searches probe
       sets = (fl & 1u) != 0;
       if (fl & 8u) kind = 1;
     } else if (fl & 1u) {
@@ -712,8 +803,7 @@ __global__ __launch_bounds__(256) void k_items_list_rows(const Item* __restrict_
 
 // ---- the list's tails searched through the entries' first words and, where those tie, through the reads (no key table)
 struct ItEntries {
-  const uint64_t* pre1;   // first word of every entry
-  const uint64_t* erec;   // its record
+  const Item* ent;        // every entry's first word and its record
   const uint8_t* sizes;
   const uint64_t* owords;
   const uint32_t* dir;
@@ -722,7 +812,7 @@ struct ItEntries {
 };
 // entry e against (key, kl) beyond the first word (equal): rest of the string through the read, then the length
 __device__ __forceinline__ int it_cmp_rest(const ItEntries& t, uint64_t e, const uint64_t* key, int kl) {
-  const uint64_t id = t.erec[e];
+  const uint64_t id = t.ent[e].id;
   const uint64_t* s = t.owords + (id >> 24) * uint64_t(t.W);
   const int j = int(id >> 16) & 255;
   for (int w = 1; w < t.W; ++w) {
@@ -732,24 +822,31 @@ __device__ __forceinline__ int it_cmp_rest(const ItEntries& t, uint64_t e, const
   const int el = t.sizes[e];
   return el < kl ? -1 : (el > kl ? 1 : 0);
 }
-// first entry >= (key, kl) in (string, length) order
-__device__ __forceinline__ uint64_t it_lower_bound(const ItEntries& t, const uint64_t* key, int kl) {
+// first entry >= (key, kl) in (string, length) order.  *alone = the key's first word occurs in exactly one entry (which is then
+// returned without a look at the reads: when the key is at least a word long and the entries are closed under pop_front, that
+// entry is the one that extends it -- k_prev_bits_pre2's shortcut on one word instead of two)
+__device__ __forceinline__ uint64_t it_lower_bound(const ItEntries& t, const uint64_t* key, int kl, bool* alone) {
   const uint32_t p = uint32_t(key[0] >> (64 - 2 * t.bases));
   uint64_t a = t.dir[p], z = t.dir[p + 1];
   const uint64_t hi = z;
   while (a < z) {  // first entry whose first word is >= the key's
     const uint64_t mid = (a + z) >> 1;
-    if (t.pre1[mid] < key[0]) a = mid + 1; else z = mid;
+    if (t.ent[mid].fw < key[0]) a = mid + 1; else z = mid;
   }
   uint64_t lo1 = a;
-  if (lo1 >= hi || t.pre1[lo1] != key[0]) return lo1;
-  z = hi;
-  a = lo1 + 1;
-  while (a < z) {  // first entry whose first word is greater
-    const uint64_t mid = (a + z) >> 1;
-    if (t.pre1[mid] <= key[0]) a = mid + 1; else z = mid;
+  *alone = false;
+  if (lo1 >= hi || t.ent[lo1].fw != key[0]) return lo1;
+  uint64_t hi1 = lo1 + 1;  // the entries that share the first word lie side by side: a few (a repeat family: thousands)
+  while (hi1 < hi && hi1 < lo1 + 8 && t.ent[hi1].fw == key[0]) ++hi1;
+  if (hi1 == lo1 + 8 && hi1 < hi && t.ent[hi1].fw == key[0]) {
+    uint64_t a2 = hi1 + 1, z2 = hi;
+    while (a2 < z2) {  // first entry whose first word is greater
+      const uint64_t mid = (a2 + z2) >> 1;
+      if (t.ent[mid].fw <= key[0]) a2 = mid + 1; else z2 = mid;
+    }
+    hi1 = a2;
   }
-  uint64_t hi1 = a;
+  if (hi1 == lo1 + 1 && kl >= 32) { *alone = true; return lo1; }
   while (lo1 < hi1) {
     const uint64_t mid = (lo1 + hi1) >> 1;
     if (it_cmp_rest(t, mid, key, kl) < 0) lo1 = mid + 1; else hi1 = mid;
@@ -758,9 +855,10 @@ __device__ __forceinline__ uint64_t it_lower_bound(const ItEntries& t, const uin
 }
 // LCP of entry e with (key, kl), in bases
 __device__ __forceinline__ int it_entry_lcp(const ItEntries& t, uint64_t e, const uint64_t* key, int kl) {
-  int l = lcp_word(t.pre1[e], key[0]);
+  const Item it = t.ent[e];
+  int l = lcp_word(it.fw, key[0]);
   if (l == 32) {
-    const uint64_t id = t.erec[e];
+    const uint64_t id = it.id;
     const uint64_t* s = t.owords + (id >> 24) * uint64_t(t.W);
     const int j = int(id >> 16) & 255;
     for (int w = 1; w < t.W; ++w) {
@@ -778,7 +876,7 @@ __device__ __forceinline__ int it_entry_lcp(const ItEntries& t, uint64_t e, cons
 // string s; the bit is the base in front, and only if that base + s -- suffix j - 1 of the read -- is an entry)
 __global__ __launch_bounds__(256) void k_prev_list_items(const Item* __restrict__ items, const uint32_t* __restrict__ lpos,
                                                          const uint8_t* __restrict__ kindf, uint64_t n_rows, ItEntries t,
-                                                         uint8_t* __restrict__ emask, uint32_t* __restrict__ err) {
+                                                         uint8_t* __restrict__ emask, uint32_t* __restrict__ err, int verify) {
   const uint64_t r = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (r >= n_rows) return;
   const uint32_t at = lpos[r];
@@ -791,27 +889,28 @@ __global__ __launch_bounds__(256) void k_prev_list_items(const Item* __restrict_
   uint64_t key[kMaxWords];
 #pragma unroll
   for (int w = 0; w < kMaxWords; ++w) key[w] = w < t.W ? it_suffix_word(s, t.W, tj, w) : 0;
-  const uint64_t lo = it_lower_bound(t, key, tl);
-  if (lo >= t.n || it_entry_lcp(t, lo, key, tl) < tl) { atomicOr(err, 2u); return; }  // "Missing expansion?"
+  bool alone = false;
+  const uint64_t lo = it_lower_bound(t, key, tl, &alone);
+  if (lo >= t.n || ((!alone || verify) && it_entry_lcp(t, lo, key, tl) < tl)) { atomicOr(err, 2u); return; }  // "Missing expansion?"
   if (kind == 2) {
     uint64_t k2[kMaxWords];
 #pragma unroll
     for (int w = 0; w < kMaxWords; ++w) k2[w] = w < t.W ? it_suffix_word(s, t.W, j - 1, w) : 0;
     const int kl = len + 1;
-    const uint64_t e2 = it_lower_bound(t, k2, kl);
-    if (e2 >= t.n || int(t.sizes[e2]) != kl || it_entry_lcp(t, e2, k2, kl) < kl) return;
+    const uint64_t e2 = it_lower_bound(t, k2, kl, &alone);
+    if (e2 >= t.n || int(t.sizes[e2]) != kl || it_entry_lcp(t, e2, k2, kl) < kl) return;  // (is it an entry: always checked)
   }
   atomicOr(reinterpret_cast<unsigned int*>(emask + (lo & ~3ull)), (1u << b) << (8 * unsigned(lo & 3)));
 }
 
 // the key table from the entries' records (what k_gather_dedup_build writes as it goes): W words an entry, and the first two
-__global__ __launch_bounds__(256) void k_items_keys(const uint64_t* __restrict__ erec, uint64_t n_ent, const uint64_t* __restrict__ owords,
+__global__ __launch_bounds__(256) void k_items_keys(const Item* __restrict__ ent, uint64_t n_ent, const uint64_t* __restrict__ owords,
                                                     int W, uint64_t* __restrict__ keys, uint64_t* __restrict__ pre2) {
   const uint64_t x = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (x >= n_ent * uint64_t(W)) return;
   const uint64_t e = x / uint64_t(W);
   const int w = int(x - e * uint64_t(W));
-  const uint64_t id = erec[e];
+  const uint64_t id = ent[e].id;
   const uint64_t word = it_suffix_word(owords + (id >> 24) * uint64_t(W), W, int(id >> 16) & 255, w);
   keys[x] = word;
   if (w < 2) pre2[e * 2 + w] = word;
@@ -830,8 +929,6 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   k_emit_items<<<cdiv(cdiv(cc->n_emit, 64), 4), 256, 0, ctx->stream>>>(cc->owords.p, reads->len.p, cc->cnt.p, cc->roff.p, cc->o_base, cc->n_emit, W, a.p);
   BG_LAUNCH_CHECK();
   ctx->toc(n_rec * 16 + cc->n_emit * uint64_t(W) * 8);
-  cc->cnt.reset();
-  cc->roff.reset();
   ctx->tic("items_partition");
   const uint64_t whole[2] = {0, n_rec};
   BG_TRY(it_partition(ctx, a.p, b.p, n_rec, 1, whole, 56));
@@ -864,10 +961,19 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   std::vector<uint8_t> h_status(65536);
   BG_HIP(copy_d2h(ctx, h_ctr, ctr.p, 8));
   BG_HIP(copy_d2h(ctx, h_status.data(), status.p, 65536));
-  uint64_t big = 0;
-  for (uint8_t v : h_status) big += v != 0;
   a.reset();
-  if (big || h_ctr[0] > run_cap) return BG_OK;  // (left to the rows: the oversized buckets' third level is not built yet)
+  if (h_ctr[0] > run_cap) return BG_OK;  // (cannot happen: a run has two members at least)
+  std::vector<std::pair<uint64_t, uint64_t>> segs;  // stretches left to the rows machinery: (start, count)
+  {
+    bool any = false;
+    for (uint8_t v : h_status) any |= v != 0;
+    if (any) {
+      std::vector<uint64_t> h16(65537);
+      BG_HIP(copy_d2h(ctx, h16.data(), b16.p, 65537 * 8));
+      for (int v = 0; v < 65536; ++v)
+        if (h_status[size_t(v)]) segs.emplace_back(h16[size_t(v)], h16[size_t(v) + 1] - h16[size_t(v)]);
+    }
+  }
   const uint64_t n_runs = h_ctr[0];
   BG_TRY(more.alloc(ctx, n_runs ? n_runs : 1));
   if (n_runs) {
@@ -882,18 +988,40 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
       BG_LAUNCH_CHECK();
       BG_HIP(copy_d2h(ctx, h_ctr + 2, ctr.p + 2, 8));
       if (h_ctr[2]) {
-        const uint32_t lds_members = 2048;  // 2048 x 64 bytes = 128 KB
-        BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_items_tie_block), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   int(lds_members * kMaxWords * 8)));
-        k_items_tie_block<<<unsigned(h_ctr[2]), 512, size_t(lds_members) * kMaxWords * 8, ctx->stream>>>(b.p, longer.p, cc->owords.p, W, lds_members);
-        BG_LAUNCH_CHECK();
-        BG_HIP(hipStreamSynchronize(ctx->stream));
+        // runs of 65 .. kItBlockRun members: a workgroup each; longer ones: the rows machinery
+        std::vector<uint64_t> h_long(h_ctr[2]), h_blk;
+        BG_HIP(copy_d2h(ctx, h_long.data(), longer.p, h_ctr[2] * 8));
+        for (uint64_t rr : h_long) {
+          if (uint32_t(rr >> 48) <= kItBlockRun) h_blk.push_back(rr);
+          else segs.emplace_back(rr & ((1ull << 48) - 1), rr >> 48);
+        }
+        if (!h_blk.empty()) {
+          BG_HIP(hipMemcpyAsync(longer.p, h_blk.data(), h_blk.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+          const uint32_t lds_members = kItBlockRun;
+          k_items_tie_block<<<unsigned(h_blk.size()), 256, size_t(lds_members) * kMaxWords * 8, ctx->stream>>>(b.p, longer.p, cc->owords.p, W, lds_members);
+          BG_LAUNCH_CHECK();
+          BG_HIP(hipStreamSynchronize(ctx->stream));  // (h_blk goes out of scope)
+        }
       }
     }
     ctx->toc(n_runs * 2 * (16 + uint64_t(W) * 8));
   }
   runs.reset();
   more.reset();
+  BG_TRY(items_subset_through_rows(ctx, b.p, segs, cc->owords.p, W));
+  if (getenv("BG_ITEMS_CHECK")) {  // every neighbour pair compared through the reads (slow; stderr)
+    DevBuf<unsigned long long> chk;
+    BG_TRY(chk.alloc(ctx, 4));
+    BG_HIP(hipMemsetAsync(chk.p, 0, 32, ctx->stream));
+    k_items_check_order<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(b.p, n_rec, cc->owords.p, W, chk.p, chk.p + 2);
+    BG_LAUNCH_CHECK();
+    unsigned long long h[4];
+    BG_HIP(copy_d2h(ctx, h, chk.p, 32));
+    uint64_t in_segs = 0;
+    for (auto& sg : segs) in_segs += sg.second;
+    fprintf(stderr, "items check: %llu records, %zu stretches (%llu records) through the rows; out of order %llu, LCP notes missing or wrong %llu\n",
+            (unsigned long long)n_rec, segs.size(), (unsigned long long)in_segs, h[0], h[1]);
+  }
   // ---- entries
   DevBuf<uint8_t> keep, lcpn;
   DevBuf<uint32_t> err, kept;
@@ -922,20 +1050,19 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
     BG_LAUNCH_CHECK();
     BG_HIP(copy_d2h(ctx, &n_ent, total.p, 8));
   }
-  DevBuf<uint64_t> erec, pre1;
+  DevBuf<uint64_t> erec;  // n_ent x {first word, record}
   ss->W = W;
-  BG_TRY(pre1.alloc(ctx, n_ent));
   BG_TRY(ss->sizes.alloc(ctx, n_ent));
   BG_TRY(ss->shared.alloc(ctx, n_ent));
-  BG_TRY(erec.alloc(ctx, n_ent));
+  BG_TRY(erec.alloc(ctx, n_ent * 2));
   BG_TRY(lp->emask.alloc(ctx, (n_ent + 3) & ~3ull));
   BG_HIP(hipMemsetAsync(lp->emask.p, 0, (n_ent + 3) & ~3ull, ctx->stream));
   BG_TRY(lp->count.alloc(ctx, 1));
   DevBuf<uint8_t> kindf;
   DevBuf<uint32_t> lpos;
   BG_TRY(kindf.alloc(ctx, n_rec));
-  k_items_entries<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(b.p, n_rec, keep.p, rank.p, kept.p, lcpn.p, ss->sizes.p, ss->shared.p, erec.p, pre1.p,
-                                                             reinterpret_cast<uint32_t*>(lp->emask.p), kindf.p);
+  k_items_entries<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(b.p, n_rec, keep.p, rank.p, kept.p, lcpn.p, ss->sizes.p, ss->shared.p,
+                                                             reinterpret_cast<Item*>(erec.p), reinterpret_cast<uint32_t*>(lp->emask.p), kindf.p);
   BG_LAUNCH_CHECK();
   BG_TRY(compact_flagged<uint32_t>(ctx, kindf.p, n_rec, &lpos, &lp->n_items));
   ctx->toc(n_rec * 32 + n_ent * 12);
@@ -944,7 +1071,8 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   if (h_err[0]) { set_error("items: the sorted items are not in order (internal error %u)", h_err[0]); return BG_EINTERNAL; }
   lp->cap = lp->n_items;
   lp->valid = true;
-  static const bool keys_now = [] { const char* e = getenv("BG_ITEMS_KEYS"); return e && e[0] == '1'; }();
+  const char* keys_env = getenv("BG_ITEMS_KEYS");
+  const bool keys_now = keys_env && keys_env[0] == '1';
   if (keys_now) {
     // (BG_ITEMS_KEYS=1: the rows of the list and the key table at once, searched by k_prev_list as the rows path does)
     if (lp->n_items) {
@@ -959,10 +1087,11 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
     DevBuf<uint32_t> dir;
     int bases = 0;
     ctx->tic("prev_bits");
-    BG_TRY(build_prefix_dir_keys(ctx, pre1.p, n_ent, 1, &dir, &bases));
+    BG_TRY(build_prefix_dir_keys(ctx, erec.p, n_ent, 2, &dir, &bases));  // (over the first words: every second word of erec)
     if (lp->n_items) {
-      const ItEntries t{pre1.p, erec.p, ss->sizes.p, cc->owords.p, dir.p, n_ent, W, bases};
-      k_prev_list_items<<<cdiv(lp->n_items, 256), 256, 0, ctx->stream>>>(b.p, lpos.p, kindf.p, lp->n_items, t, lp->emask.p, err.p);
+      const ItEntries t{reinterpret_cast<const Item*>(erec.p), ss->sizes.p, cc->owords.p, dir.p, n_ent, W, bases};
+      const char* v = getenv("BG_VERIFY_CLOSURE");  // (the lone-first-word shortcut checked against the reads as well)
+      k_prev_list_items<<<cdiv(lp->n_items, 256), 256, 0, ctx->stream>>>(b.p, lpos.p, kindf.p, lp->n_items, t, lp->emask.p, err.p, v && v[0] == '1');
       BG_LAUNCH_CHECK();
     }
     ctx->toc(lp->n_items * (uint64_t(W) * 8 * 3 + 64));
@@ -977,7 +1106,6 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   rank.reset();
   keep.reset();
   lcpn.reset();
-  pre1.reset();
   ss->n = n_ent;
   ss->erec = std::move(erec);
   ss->oreads = std::move(cc->owords);
@@ -997,7 +1125,7 @@ int seqset_ensure_keys(bg_ctx* ctx, bg_seqset* ss) {
   BG_TRY(ss->pre2.alloc(ctx, n_ent * 2));
   if (n_ent) {
     ctx->tic("items_keys");
-    k_items_keys<<<cdiv(n_ent * uint64_t(W), 256), 256, 0, ctx->stream>>>(ss->erec.p, n_ent, ss->oreads.p, W, ss->keys.p, ss->pre2.p);
+    k_items_keys<<<cdiv(n_ent * uint64_t(W), 256), 256, 0, ctx->stream>>>(reinterpret_cast<const Item*>(ss->erec.p), n_ent, ss->oreads.p, W, ss->keys.p, ss->pre2.p);
     BG_LAUNCH_CHECK();
     ctx->toc(n_ent * (uint64_t(W) * 8 * 2 + 16));
   }
@@ -1074,7 +1202,7 @@ int items_probe(bg_ctx* ctx, const uint64_t* owords, const uint16_t* len, const 
         const uint32_t lds_members = 2048;
         BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_items_tie_block), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    int(lds_members * kMaxWords * 8)));
-        k_items_tie_block<<<unsigned(n_long), 512, size_t(lds_members) * kMaxWords * 8, ctx->stream>>>(b.p, longer.p, owords, W, lds_members);
+        k_items_tie_block<<<unsigned(n_long), 1024, size_t(lds_members) * kMaxWords * 8, ctx->stream>>>(b.p, longer.p, owords, W, lds_members);
         BG_LAUNCH_CHECK();
         BG_HIP(hipStreamSynchronize(ctx->stream));
       }

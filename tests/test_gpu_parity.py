@@ -112,10 +112,14 @@ def test_seqset_build_matches_oracle(ctx, seed, alphabet, K, rl, var):
     assert st["n_entries"] == ss.size() and st["n_records"] >= st["n_entries"]
 
 
-@pytest.mark.parametrize("env", [{"BG_VERIFY_CLOSURE": "1"}, {"BG_PREV_FULL_SEARCH": "1"}, {"BG_NO_MEDIUM_GROUPS": "1"},
-                                 {"BG_SMALL_TIES_EARLY": "1"}, {"BG_ENTRIES_UNFUSED": "1"}, {"BG_PREV_MERGE": "1"},
-                                 {"BG_RADIX_ONESWEEP": "1"}, {"BG_PREV_SEARCH_ALL": "1"},
-                                 {"BG_PREV_SEARCH_ALL": "1", "BG_VERIFY_CLOSURE": "1"}, {"BG_LOOKBACK_FLAT": "1"}, {"BG_COVER_COUNT_ROUNDS": "1"}])
+ROWS = {"BG_ITEMS_BUILD": "0"}  # the entries through rows (the switches below are that path's; the default is the items path)
+
+
+@pytest.mark.parametrize("env", [{}, {"BG_ITEMS_KEYS": "1"}, {"BG_VERIFY_CLOSURE": "1"}, ROWS, dict(ROWS, BG_VERIFY_CLOSURE="1"), dict(ROWS, BG_PREV_FULL_SEARCH="1"),
+                                 dict(ROWS, BG_NO_MEDIUM_GROUPS="1"), dict(ROWS, BG_SMALL_TIES_EARLY="1"), dict(ROWS, BG_ENTRIES_UNFUSED="1"),
+                                 dict(ROWS, BG_PREV_MERGE="1"), dict(ROWS, BG_RADIX_ONESWEEP="1"), {"BG_PREV_SEARCH_ALL": "1"},
+                                 {"BG_PREV_SEARCH_ALL": "1", "BG_VERIFY_CLOSURE": "1"}, dict(ROWS, BG_LOOKBACK_FLAT="1"),
+                                 {"BG_COVER_COUNT_ROUNDS": "1"}, dict(ROWS, BG_COVER_COUNT_ROUNDS="1")])
 @pytest.mark.parametrize("seed,alphabet,rl", [(11, "ACGT", 150), (12, "AC", 200), (13, "AT", 255)])
 def test_seqset_build_search_modes(ctx, monkeypatch, env, seed, alphabet, rl):
     """(BG_PREV_MERGE: the prev bits as one merge of tails against chunks of entries; BG_RADIX_ONESWEEP: radix passes with
@@ -132,7 +136,7 @@ def test_seqset_build_search_modes(ctx, monkeypatch, env, seed, alphabet, rl):
     _check_seqset_against_oracle(ss, reads)
 
 
-@pytest.mark.parametrize("env", [{}, {"BG_NO_LARGE_GROUPS": "1"}])
+@pytest.mark.parametrize("env", [{}, ROWS, dict(ROWS, BG_NO_LARGE_GROUPS="1")])
 def test_seqset_build_big_tie_groups(ctx, monkeypatch, env):
     """Tie groups of the suffix sorts beyond the medium-group kernel: 1500 and 2800 distinct reads behind one 20-base
     prefix each (the second launch with a CU's whole LDS), 4000 behind a third (more than the LDS takes: the radix
