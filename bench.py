@@ -24,16 +24,17 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 SURVEY_8D_BYTES = {
     "entries_dedup_build": lambda st: 28 * st["n_records"],
     "prev_bits": lambda st: 2.625 * st["n_entries"],
-    "skm_count_lds": lambda st: 16 * st["n_kmers"],
-    "skm_generate": lambda st: 16 * st["n_kmers"],
+    # S2 = "write + read one 8-byte canonical k-mer record once": the write is the k-merizer's (here: sk_generate), the read the counter's
+    "skm_count_lds": lambda st: 8 * st["n_kmers"],
+    "skm_generate": lambda st: 8 * st["n_kmers"],
     "suffix_cover_count": lambda st: 28 * st["n_records"],
     "correct_dfs": lambda st: 0.5 * st["n_bases"] + 8 * st["n_kmers"],
     "items_partition": lambda st: 28 * st["n_records"], "items_tie_runs": lambda st: 28 * st["n_records"],
     "items_entries": lambda st: 28 * st["n_records"], "items_bucket_sort": lambda st: 28 * st["n_records"],
 }
 SURVEY_8D_FORMULA = {
-    "entries_dedup_build": "S4 = 28 x N_rec", "prev_bits": "S5 = 2.625 x N_ent", "skm_count_lds": "S2 = 16 x N_kmers",
-    "skm_generate": "S2 = 16 x N_kmers", "suffix_cover_count": "S4 = 28 x N_rec", "correct_dfs": "S3 = 0.5 x N_bases + 8 x N_kmers",
+    "entries_dedup_build": "S4 = 28 x N_rec", "prev_bits": "S5 = 2.625 x N_ent", "skm_count_lds": "S2 = 16 x N_kmers, the counter's half: 8 x N_kmers read",
+    "skm_generate": "S2 = 16 x N_kmers, the k-merizer's half: 8 x N_kmers written", "suffix_cover_count": "S4 = 28 x N_rec", "correct_dfs": "S3 = 0.5 x N_bases + 8 x N_kmers",
     "items_partition": "S4 = 28 x N_rec", "items_tie_runs": "S4 = 28 x N_rec", "items_entries": "S4 = 28 x N_rec",
     "items_bucket_sort": "S4 = 28 x N_rec",
 }
@@ -996,6 +997,11 @@ def main():
                 roofline["achieved"] = round(ach, 1)
                 roofline["frac"] = round(ach / HBM_PEAK_GBS, 4)
                 roofline["bytes_formula"] = "SURVEY.md 8(d): " + SURVEY_8D_FORMULA.get(roofline["kernel"], "")
+                if roofline["kernel"].startswith("skm_"):
+                    roofline["note"] = ("SURVEY 8(d) prices the k-mer stage as one 8-byte record per k-mer written and read once; this kernel is the "
+                                        "writing half, but what it writes is super-k-mers (1.6 bytes a k-mer): the counters show fewer bytes than the "
+                                        "formula (frac_kernel_layout is what it moves), and it is bound by vector-instruction issue, not by HBM "
+                                        "(DESIGN.md section 5); the stage as a whole: build_roofline.stages_survey_8d")
         total_ms = sum(t["ms"] for t in timings) or 1.0
         kernels = {t["name"]: {"ms_per_step": round(t["ms"] / max(args.steps, 1), 3),
                                "launches_per_step": t["launches"] / max(args.steps, 1),
