@@ -215,7 +215,7 @@ __device__ __forceinline__ uint64_t it_suffix_word(const uint64_t* __restrict__ 
 __global__ __launch_bounds__(IB_THREADS) void k_items_bucket_sort(const Item* __restrict__ in, Item* __restrict__ out,
                                                                   const uint64_t* __restrict__ bounds, uint8_t* __restrict__ status,
                                                                   uint64_t* __restrict__ runs, unsigned long long* __restrict__ n_runs,
-                                                                  uint64_t run_cap) {
+                                                                  uint64_t run_cap, int bin_shift) {
   __shared__ uint64_t sfw[IB_CAP];
   __shared__ uint32_t hist[IB_BINS];
   __shared__ uint32_t start[IB_BINS + 1];
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(IB_THREADS) void k_items_bucket_sort(const Item* __
   const uint64_t lo = bounds[b], hi = bounds[b + 1];
   const uint32_t n = uint32_t(hi - lo);
   const int tid = threadIdx.x;
-  if (n == 0) return;
+  if (hi == lo) return;
   if (hi - lo > uint64_t(IB_CAP)) {
     if (tid == 0) status[b] = 1;
     for (uint64_t i = lo + tid; i < hi; i += IB_THREADS) out[i] = in[i];
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(IB_THREADS) void k_items_bucket_sort(const Item* __
   for (uint32_t i = tid; i < n; i += IB_THREADS) {
     const uint64_t f = in[lo + i].fw;
     sfw[i] = f;
-    atomicAdd(&hist[uint32_t(f >> 37) & (IB_BINS - 1)], 1u);
+    atomicAdd(&hist[uint32_t(f >> bin_shift) & (IB_BINS - 1)], 1u);
   }
   __syncthreads();
   {  // exclusive scan of the bins: 4 per thread
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(IB_THREADS) void k_items_bucket_sort(const Item* __
   }
   __syncthreads();
   for (uint32_t i = tid; i < n; i += IB_THREADS) {
-    const uint32_t bin = uint32_t(sfw[i] >> 37) & (IB_BINS - 1);
+    const uint32_t bin = uint32_t(sfw[i] >> bin_shift) & (IB_BINS - 1);
     grp[start[bin] + atomicAdd(&hist[bin], 1u)] = uint16_t(i);
   }
   __syncthreads();
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(IB_THREADS) void k_items_bucket_sort(const Item* __
   for (uint32_t p = tid; p < n; p += IB_THREADS) {
     const uint32_t i = grp[p];
     const uint64_t f = sfw[i];
-    const uint32_t bin = uint32_t(f >> 37) & (IB_BINS - 1);
+    const uint32_t bin = uint32_t(f >> bin_shift) & (IB_BINS - 1);
     const uint32_t bs = start[bin], be = start[bin + 1];
     uint32_t rank = 0;
     for (uint32_t q = bs; q < be; ++q) {
@@ -932,7 +932,17 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   ctx->tic("items_partition");
   const uint64_t whole[2] = {0, n_rec};
   BG_TRY(it_partition(ctx, a.p, b.p, n_rec, 1, whole, 56));
-  DevBuf<uint64_t> b8, b16;
+  // Buckets of a few thousand records at most are what the LDS sort takes: two levels (65 536 buckets) up to ~170 M records, a
+  // third on as many more bits as bring the average bucket back under 2 600 (a workgroup a bucket: many small buckets cost more
+  // than they sort) beyond (BG_ITEMS_LEVELS=3: a third level of four bits at any size, for the tests)
+  const char* lv = getenv("BG_ITEMS_LEVELS");
+  int extra = 0;
+  while (extra < 8 && (n_rec >> (16 + extra)) > 2600) ++extra;
+  if (lv && lv[0] == '3' && extra < 4) extra = 4;
+  const int levels = extra ? 3 : 2;
+  const int bucket_bits = 16 + extra;
+  const uint64_t n_buckets = 1ull << bucket_bits;
+  DevBuf<uint64_t> b8, b16, bnd;
   BG_TRY(b8.alloc(ctx, 257));
   BG_TRY(b16.alloc(ctx, 65537));
   it_bounds_kernel<<<2, 256, 0, ctx->stream>>>(b.p, n_rec, 8, b8.p);
@@ -942,25 +952,36 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   BG_TRY(it_partition(ctx, b.p, a.p, n_rec, 256, h8.data(), 48));
   it_bounds_kernel<<<cdiv(65537, 256), 256, 0, ctx->stream>>>(a.p, n_rec, 16, b16.p);
   BG_LAUNCH_CHECK();
-  ctx->toc(n_rec * 16 * 6);
+  std::vector<uint64_t> h_bounds;  // (on the host only when a stretch has to be named)
+  if (levels == 3) {
+    std::vector<uint64_t> h16(65537);
+    BG_HIP(copy_d2h(ctx, h16.data(), b16.p, 65537 * 8));
+    BG_TRY(it_partition(ctx, a.p, b.p, n_rec, 65536, h16.data(), 48 - extra));  // (eight bits from there: the upper ones are the segment's own)
+    BG_TRY(bnd.alloc(ctx, n_buckets + 1));
+    it_bounds_kernel<<<cdiv(n_buckets + 1, 256), 256, 0, ctx->stream>>>(b.p, n_rec, bucket_bits, bnd.p);
+    BG_LAUNCH_CHECK();
+    std::swap(a, b);  // (the partitioned items are in a again)
+  }
+  const uint64_t* d_bounds = levels == 3 ? bnd.p : b16.p;
+  ctx->toc(n_rec * 16 * 3 * uint64_t(levels));
   // ---- every bucket in order of the first word, the runs of equal first words by the rest of their strings
   DevBuf<uint8_t> status;
   DevBuf<unsigned long long> ctr;  // [0] runs, [1] runs of more than four, [2] runs of more than 64, [3] big buckets
   DevBuf<uint64_t> runs, more;
   const uint64_t run_cap = n_rec / 2 + 1;
-  BG_TRY(status.alloc(ctx, 65536));
+  BG_TRY(status.alloc(ctx, n_buckets));
   BG_TRY(ctr.alloc(ctx, 4));
   BG_TRY(runs.alloc(ctx, run_cap));
-  BG_HIP(hipMemsetAsync(status.p, 0, 65536, ctx->stream));
+  BG_HIP(hipMemsetAsync(status.p, 0, n_buckets, ctx->stream));
   BG_HIP(hipMemsetAsync(ctr.p, 0, 32, ctx->stream));
   ctx->tic("items_bucket_sort");
-  k_items_bucket_sort<<<65536, IB_THREADS, 0, ctx->stream>>>(a.p, b.p, b16.p, status.p, runs.p, ctr.p, run_cap);
+  k_items_bucket_sort<<<unsigned(n_buckets), IB_THREADS, 0, ctx->stream>>>(a.p, b.p, d_bounds, status.p, runs.p, ctr.p, run_cap, 64 - bucket_bits - 11);
   BG_LAUNCH_CHECK();
   ctx->toc(n_rec * 32);
   unsigned long long h_ctr[4] = {0, 0, 0, 0};
-  std::vector<uint8_t> h_status(65536);
+  std::vector<uint8_t> h_status(n_buckets);
   BG_HIP(copy_d2h(ctx, h_ctr, ctr.p, 8));
-  BG_HIP(copy_d2h(ctx, h_status.data(), status.p, 65536));
+  BG_HIP(copy_d2h(ctx, h_status.data(), status.p, n_buckets));
   a.reset();
   if (h_ctr[0] > run_cap) return BG_OK;  // (cannot happen: a run has two members at least)
   std::vector<std::pair<uint64_t, uint64_t>> segs;  // stretches left to the rows machinery: (start, count)
@@ -968,10 +989,10 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
     bool any = false;
     for (uint8_t v : h_status) any |= v != 0;
     if (any) {
-      std::vector<uint64_t> h16(65537);
-      BG_HIP(copy_d2h(ctx, h16.data(), b16.p, 65537 * 8));
-      for (int v = 0; v < 65536; ++v)
-        if (h_status[size_t(v)]) segs.emplace_back(h16[size_t(v)], h16[size_t(v) + 1] - h16[size_t(v)]);
+      h_bounds.resize(n_buckets + 1);
+      BG_HIP(copy_d2h(ctx, h_bounds.data(), d_bounds, (n_buckets + 1) * 8));
+      for (uint64_t v = 0; v < n_buckets; ++v)
+        if (h_status[size_t(v)]) segs.emplace_back(h_bounds[size_t(v)], h_bounds[size_t(v) + 1] - h_bounds[size_t(v)]);
     }
   }
   const uint64_t n_runs = h_ctr[0];
@@ -1179,7 +1200,7 @@ int items_probe(bg_ctx* ctx, const uint64_t* owords, const uint16_t* len, const 
   DevBuf<uint64_t> runs, more;
   const uint64_t run_cap = n_rec / 2 + 1;
   BG_TRY(runs.alloc(ctx, run_cap));
-  k_items_bucket_sort<<<65536, IB_THREADS, 0, ctx->stream>>>(a.p, b.p, b16.p, status.p, runs.p, chk.p + 3, run_cap);
+  k_items_bucket_sort<<<65536, IB_THREADS, 0, ctx->stream>>>(a.p, b.p, b16.p, status.p, runs.p, chk.p + 3, run_cap, 37);
   BG_LAUNCH_CHECK();
   BG_HIP(hipEventRecord(es[1], ctx->stream));
   unsigned long long n_runs = 0, n_more = 0;
