@@ -578,7 +578,7 @@ static int it_partition(bg_ctx* ctx, const Item* in, Item* out, uint64_t n, uint
 // count; ascending, disjoint) become rows, sort_records_impl orders them by (string, length), and they come back in that order
 // with the LCP notes of neighbours that share their first word.  A stretch is a whole range of the final order (a bucket; all
 // the items of one first word), so the sorted subset maps onto the stretches in turn.
-constexpr uint32_t kItBlockRun = 256;  // runs up to here: k_items_tie_block (quadratic in LDS)
+constexpr uint32_t kItBlockRun = 2048;  // runs up to here: k_items_tie_block (quadratic, the members' rows in 128 KB of LDS)
 __device__ __forceinline__ uint64_t it_seg_place(const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ seg_off, uint32_t nseg, uint64_t t) {
   uint32_t a = 0, z = nseg;  // last stretch with seg_off <= t
   while (z - a > 1) {
@@ -1019,7 +1019,9 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
         if (!h_blk.empty()) {
           BG_HIP(hipMemcpyAsync(longer.p, h_blk.data(), h_blk.size() * 8, hipMemcpyHostToDevice, ctx->stream));
           const uint32_t lds_members = kItBlockRun;
-          k_items_tie_block<<<unsigned(h_blk.size()), 256, size_t(lds_members) * kMaxWords * 8, ctx->stream>>>(b.p, longer.p, cc->owords.p, W, lds_members);
+          BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_items_tie_block), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     int(lds_members * kMaxWords * 8)));
+          k_items_tie_block<<<unsigned(h_blk.size()), 1024, size_t(lds_members) * kMaxWords * 8, ctx->stream>>>(b.p, longer.p, cc->owords.p, W, lds_members);
           BG_LAUNCH_CHECK();
           BG_HIP(hipStreamSynchronize(ctx->stream));  // (h_blk goes out of scope)
         }
