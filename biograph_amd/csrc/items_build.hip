@@ -17,6 +17,7 @@
 #include "compact.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <vector>
@@ -176,6 +177,141 @@ __global__ __launch_bounds__(IT_THREADS) void it_scatter_kernel(const Item* __re
   for (uint32_t i = tid; i < cnt; i += IT_THREADS) {
     const Item x = stage[i];
     out[goff[uint32_t(x.fw >> shift) & 255u] + i] = x;
+  }
+}
+
+// ---- the first level straight from the reads: a workgroup takes IR_READS oriented reads, makes their records' items in
+// stretches of IT_TILE and scatters them by the top byte -- the items are never written in read order (k_emit_items: 2.5 GB
+// out, read again by the histogram and again by the scatter; here the reads' words are read twice instead, 1 GB each).
+#ifndef BG_IR_READS
+#define BG_IR_READS 1024
+#endif
+constexpr int IR_READS = BG_IR_READS;
+__device__ __forceinline__ uint32_t ir_offsets(const uint64_t* __restrict__ roff, uint64_t n_emit, uint64_t n_rec, uint64_t t0, uint32_t* rel,
+                                               uint64_t* r0) {
+  const uint64_t base = roff[t0];
+  for (int i = threadIdx.x; i <= IR_READS; i += IT_THREADS) {
+    const uint64_t t = t0 + uint64_t(i);
+    rel[i] = uint32_t((t < n_emit ? roff[t] : n_rec) - base);
+  }
+  __syncthreads();
+  *r0 = base;
+  return rel[IR_READS];
+}
+__device__ __forceinline__ int ir_read_of(const uint32_t* rel, uint32_t x) {  // last read whose first record is at or before x
+  int lo = 0, hi = IR_READS;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (rel[mid] <= x) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ Item ir_item(const uint64_t* __restrict__ owords, const uint16_t* __restrict__ len, int W, uint64_t ro, int j,
+                                        uint32_t rcnt) {
+  const uint64_t* s = owords + ro * uint64_t(W);
+  const int L = int(len[ro >> 1]);
+  const int sq = j >> 5, sr = j & 31;
+  const uint64_t cur = s[sq], next = sq + 1 < W ? s[sq + 1] : 0;
+  Item it;
+  it.fw = sr ? (cur << (2 * sr)) | (next >> (64 - 2 * sr)) : cur;
+  uint64_t flags = 0;
+  if (j > 0) flags |= 1u | (((s[(j - 1) >> 5] >> (62 - 2 * ((j - 1) & 31))) & 3) << 1);
+  if (uint32_t(j) + 1 == rcnt) flags |= 8u;
+  it.id = (ro << 24) | (uint64_t(j) << 16) | (uint64_t(L - j) << 8) | flags;
+  return it;
+}
+
+__global__ __launch_bounds__(IT_THREADS) void it_hist_reads_kernel(const uint64_t* __restrict__ owords, const uint64_t* __restrict__ roff,
+                                                                   uint64_t o_base, uint64_t n_emit, uint64_t n_rec, int W, uint32_t nt,
+                                                                   uint32_t* __restrict__ hist) {
+  __shared__ uint32_t rel[IR_READS + 1];
+  __shared__ uint32_t h[IT_BINS];
+  h[threadIdx.x] = 0;
+  const uint64_t t0 = uint64_t(blockIdx.x) * IR_READS;
+  uint64_t r0;
+  const uint32_t total = ir_offsets(roff, n_emit, n_rec, t0, rel, &r0);
+  // a thread a read: its records' top bytes slide along the first words (no search; the wave waits for its longest read)
+  for (int q = threadIdx.x; q < IR_READS; q += IT_THREADS) {
+    const uint32_t c = rel[q + 1] - rel[q];
+    if (!c) continue;
+    const uint64_t* s = owords + (o_base + t0 + uint64_t(q)) * uint64_t(W);
+    int wi = 0;
+    uint64_t cur = s[0], nxt = W > 1 ? s[1] : 0;
+    for (uint32_t j = 0; j < c; ++j) {
+      const int sr = int(j & 31u);
+      if (j && !sr) {
+        cur = nxt;
+        ++wi;
+        nxt = wi + 1 < W ? s[wi + 1] : 0;
+      }
+      uint32_t top = uint32_t((cur << (2 * sr)) >> 56);
+      if (sr > 28) top |= uint32_t(nxt >> (64 - 2 * (sr - 28)));
+      atomicAdd(&h[top & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  hist[uint64_t(threadIdx.x) * nt + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(IT_THREADS) void it_scatter_reads_kernel(const uint64_t* __restrict__ owords, const uint16_t* __restrict__ len,
+                                                                      const uint64_t* __restrict__ roff, uint64_t o_base, uint64_t n_emit,
+                                                                      uint64_t n_rec, int W, uint32_t nt, const uint64_t* __restrict__ offs,
+                                                                      Item* __restrict__ out) {
+  __shared__ Item stage[IT_TILE];
+  __shared__ uint32_t rel[IR_READS + 1];
+  __shared__ uint32_t h[IT_BINS];
+  __shared__ uint32_t binstart[IT_BINS];
+  __shared__ uint64_t goff[IT_BINS];
+  __shared__ uint32_t scan_sm[4];
+  const int tid = threadIdx.x;
+  const uint64_t t0 = uint64_t(blockIdx.x) * IR_READS;
+  uint64_t r0;
+  const uint32_t total = ir_offsets(roff, n_emit, n_rec, t0, rel, &r0);
+  uint64_t run = offs[uint64_t(tid) * nt + blockIdx.x];  // where this workgroup's next item of bin `tid` goes
+  for (uint32_t c0 = 0; c0 < total; c0 += IT_TILE) {
+    h[tid] = 0;
+    __syncthreads();
+    Item it[IT_PER];
+    uint16_t rnk[IT_PER];
+    // (a thread's IT_PER records are consecutive: one search, then along the reads)
+    const uint32_t x0 = c0 + uint32_t(tid) * IT_PER;
+    int q = 0, j = 0;
+    if (x0 < total) {
+      q = ir_read_of(rel, x0);
+      j = int(x0 - rel[q]);
+    }
+#pragma unroll
+    for (int k = 0; k < IT_PER; ++k) {
+      const uint32_t x = x0 + uint32_t(k);
+      rnk[k] = 0;
+      it[k].fw = 0;
+      it[k].id = 0;
+      if (x < total) {
+        while (rel[q + 1] <= x) { ++q; j = 0; }
+        it[k] = ir_item(owords, len, W, o_base + t0 + uint64_t(q), j, rel[q + 1] - rel[q]);
+        rnk[k] = uint16_t(atomicAdd(&h[uint32_t(it[k].fw >> 56)], 1u));
+        ++j;
+      }
+    }
+    __syncthreads();
+    {
+      const uint32_t ex = it_block_excl_scan(h[tid], scan_sm);
+      binstart[tid] = ex;
+      goff[tid] = run - ex;
+      run += h[tid];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IT_PER; ++k) {
+      if (x0 + uint32_t(k) < total) stage[binstart[uint32_t(it[k].fw >> 56)] + rnk[k]] = it[k];
+    }
+    __syncthreads();
+    const uint32_t cnt = total - c0 < uint32_t(IT_TILE) ? total - c0 : uint32_t(IT_TILE);
+    for (uint32_t i = tid; i < cnt; i += IT_THREADS) {
+      const Item x = stage[i];
+      out[goff[uint32_t(x.fw >> 56)] + i] = x;
+    }
+    __syncthreads();
   }
 }
 
@@ -925,13 +1061,30 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   DevBuf<Item> a, b;
   BG_TRY(a.alloc(ctx, n_rec));
   BG_TRY(b.alloc(ctx, n_rec));
-  ctx->tic("items_emit");
-  k_emit_items<<<cdiv(cdiv(cc->n_emit, 64), 4), 256, 0, ctx->stream>>>(cc->owords.p, reads->len.p, cc->cnt.p, cc->roff.p, cc->o_base, cc->n_emit, W, a.p);
-  BG_LAUNCH_CHECK();
-  ctx->toc(n_rec * 16 + cc->n_emit * uint64_t(W) * 8);
-  ctx->tic("items_partition");
-  const uint64_t whole[2] = {0, n_rec};
-  BG_TRY(it_partition(ctx, a.p, b.p, n_rec, 1, whole, 56));
+  const char* em = getenv("BG_ITEMS_EMIT");
+  if (em && !strcmp(em, "plain")) {  // (the items written in read order first, then partitioned like any other level: for comparison)
+    ctx->tic("items_emit");
+    k_emit_items<<<cdiv(cdiv(cc->n_emit, 64), 4), 256, 0, ctx->stream>>>(cc->owords.p, reads->len.p, cc->cnt.p, cc->roff.p, cc->o_base, cc->n_emit, W, a.p);
+    BG_LAUNCH_CHECK();
+    ctx->toc(n_rec * 16 + cc->n_emit * uint64_t(W) * 8);
+    ctx->tic("items_partition");
+    const uint64_t whole[2] = {0, n_rec};
+    BG_TRY(it_partition(ctx, a.p, b.p, n_rec, 1, whole, 56));
+  } else {
+    const uint64_t nt = cdiv(cc->n_emit, IR_READS);
+    if (nt >= (1ull << 31)) { set_error("items: %llu oriented reads need too many partition tiles", (unsigned long long)cc->n_emit); return BG_EINVAL; }
+    DevBuf<uint32_t> hist;
+    DevBuf<uint64_t> offs;
+    BG_TRY(hist.alloc(ctx, size_t(IT_BINS) * nt));
+    BG_TRY(offs.alloc(ctx, size_t(IT_BINS) * nt));
+    ctx->tic("items_partition");
+    it_hist_reads_kernel<<<unsigned(nt), IT_THREADS, 0, ctx->stream>>>(cc->owords.p, cc->roff.p, cc->o_base, cc->n_emit, n_rec, W, uint32_t(nt), hist.p);
+    BG_LAUNCH_CHECK();
+    BG_TRY(exclusive_scan_u32_to_u64(ctx, hist.p, offs.p, uint64_t(IT_BINS) * nt, nullptr));
+    it_scatter_reads_kernel<<<unsigned(nt), IT_THREADS, 0, ctx->stream>>>(cc->owords.p, reads->len.p, cc->roff.p, cc->o_base, cc->n_emit, n_rec, W,
+                                                                         uint32_t(nt), offs.p, b.p);
+    BG_LAUNCH_CHECK();
+  }
   // Buckets of a few thousand records at most are what the LDS sort takes: two levels (65 536 buckets) up to ~170 M records, a
   // third on as many more bits as bring the average bucket back under 2 600 (a workgroup a bucket: many small buckets cost more
   // than they sort) beyond (BG_ITEMS_LEVELS=3: a third level of four bits at any size, for the tests)
