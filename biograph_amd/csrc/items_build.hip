@@ -206,21 +206,6 @@ __device__ __forceinline__ int ir_read_of(const uint32_t* rel, uint32_t x) {  //
   }
   return lo;
 }
-__device__ __forceinline__ Item ir_item(const uint64_t* __restrict__ owords, const uint16_t* __restrict__ len, int W, uint64_t ro, int j,
-                                        uint32_t rcnt) {
-  const uint64_t* s = owords + ro * uint64_t(W);
-  const int L = int(len[ro >> 1]);
-  const int sq = j >> 5, sr = j & 31;
-  const uint64_t cur = s[sq], next = sq + 1 < W ? s[sq + 1] : 0;
-  Item it;
-  it.fw = sr ? (cur << (2 * sr)) | (next >> (64 - 2 * sr)) : cur;
-  uint64_t flags = 0;
-  if (j > 0) flags |= 1u | (((s[(j - 1) >> 5] >> (62 - 2 * ((j - 1) & 31))) & 3) << 1);
-  if (uint32_t(j) + 1 == rcnt) flags |= 8u;
-  it.id = (ro << 24) | (uint64_t(j) << 16) | (uint64_t(L - j) << 8) | flags;
-  return it;
-}
-
 __global__ __launch_bounds__(IT_THREADS) void it_hist_reads_kernel(const uint64_t* __restrict__ owords, const uint64_t* __restrict__ roff,
                                                                    uint64_t o_base, uint64_t n_emit, uint64_t n_rec, int W, uint32_t nt,
                                                                    uint32_t* __restrict__ hist) {
@@ -229,7 +214,7 @@ __global__ __launch_bounds__(IT_THREADS) void it_hist_reads_kernel(const uint64_
   h[threadIdx.x] = 0;
   const uint64_t t0 = uint64_t(blockIdx.x) * IR_READS;
   uint64_t r0;
-  const uint32_t total = ir_offsets(roff, n_emit, n_rec, t0, rel, &r0);
+  (void)ir_offsets(roff, n_emit, n_rec, t0, rel, &r0);
   // a thread a read: its records' top bytes slide along the first words (no search; the wave waits for its longest read)
   for (int q = threadIdx.x; q < IR_READS; q += IT_THREADS) {
     const uint32_t c = rel[q + 1] - rel[q];
@@ -253,6 +238,7 @@ __global__ __launch_bounds__(IT_THREADS) void it_hist_reads_kernel(const uint64_
   hist[uint64_t(threadIdx.x) * nt + blockIdx.x] = h[threadIdx.x];
 }
 
+template <int MODE>  // 0; 1: everything but the global writes (timing experiments, BG_ITEMS_PROBE)
 __global__ __launch_bounds__(IT_THREADS) void it_scatter_reads_kernel(const uint64_t* __restrict__ owords, const uint16_t* __restrict__ len,
                                                                       const uint64_t* __restrict__ roff, uint64_t o_base, uint64_t n_emit,
                                                                       uint64_t n_rec, int W, uint32_t nt, const uint64_t* __restrict__ offs,
@@ -276,6 +262,9 @@ __global__ __launch_bounds__(IT_THREADS) void it_scatter_reads_kernel(const uint
     // (a thread's IT_PER records are consecutive: one search, then along the reads)
     const uint32_t x0 = c0 + uint32_t(tid) * IT_PER;
     int q = 0, j = 0;
+    int cq = -1, csq = -1, cL = 0;
+    uint32_t crc = 0;
+    uint64_t w0 = 0, w1 = 0, wp = 0, cro = 0;
     if (x0 < total) {
       q = ir_read_of(rel, x0);
       j = int(x0 - rel[q]);
@@ -288,7 +277,23 @@ __global__ __launch_bounds__(IT_THREADS) void it_scatter_reads_kernel(const uint
       it[k].id = 0;
       if (x < total) {
         while (rel[q + 1] <= x) { ++q; j = 0; }
-        it[k] = ir_item(owords, len, W, o_base + t0 + uint64_t(q), j, rel[q + 1] - rel[q]);
+        const int sq = j >> 5, sr = j & 31;
+        if (q != cq || sq != csq) {  // (the words under this record: kept while the thread's records stay on them)
+          cro = o_base + t0 + uint64_t(q);
+          const uint64_t* s = owords + cro * uint64_t(W);
+          w0 = s[sq];
+          w1 = sq + 1 < W ? s[sq + 1] : 0;
+          wp = sq ? s[sq - 1] : 0;
+          cL = int(len[cro >> 1]);
+          crc = rel[q + 1] - rel[q];
+          cq = q;
+          csq = sq;
+        }
+        it[k].fw = sr ? (w0 << (2 * sr)) | (w1 >> (64 - 2 * sr)) : w0;
+        uint64_t flags = 0;
+        if (j > 0) flags |= 1u | ((sr ? (w0 >> (64 - 2 * sr)) & 3 : wp & 3) << 1);
+        if (uint32_t(j) + 1 == crc) flags |= 8u;
+        it[k].id = (cro << 24) | (uint64_t(j) << 16) | (uint64_t(cL - j) << 8) | flags;
         rnk[k] = uint16_t(atomicAdd(&h[uint32_t(it[k].fw >> 56)], 1u));
         ++j;
       }
@@ -309,6 +314,7 @@ __global__ __launch_bounds__(IT_THREADS) void it_scatter_reads_kernel(const uint
     const uint32_t cnt = total - c0 < uint32_t(IT_TILE) ? total - c0 : uint32_t(IT_TILE);
     for (uint32_t i = tid; i < cnt; i += IT_THREADS) {
       const Item x = stage[i];
+      if (MODE == 0 || (x.fw == 0x123456789abcdefull && x.id == 77))
       out[goff[uint32_t(x.fw >> 56)] + i] = x;
     }
     __syncthreads();
@@ -1081,9 +1087,14 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
     it_hist_reads_kernel<<<unsigned(nt), IT_THREADS, 0, ctx->stream>>>(cc->owords.p, cc->roff.p, cc->o_base, cc->n_emit, n_rec, W, uint32_t(nt), hist.p);
     BG_LAUNCH_CHECK();
     BG_TRY(exclusive_scan_u32_to_u64(ctx, hist.p, offs.p, uint64_t(IT_BINS) * nt, nullptr));
-    it_scatter_reads_kernel<<<unsigned(nt), IT_THREADS, 0, ctx->stream>>>(cc->owords.p, reads->len.p, cc->roff.p, cc->o_base, cc->n_emit, n_rec, W,
-                                                                         uint32_t(nt), offs.p, b.p);
+    it_scatter_reads_kernel<0><<<unsigned(nt), IT_THREADS, 0, ctx->stream>>>(cc->owords.p, reads->len.p, cc->roff.p, cc->o_base, cc->n_emit, n_rec, W,
+                                                                            uint32_t(nt), offs.p, b.p);
     BG_LAUNCH_CHECK();
+    if (getenv("BG_ITEMS_PROBE")) {
+      it_scatter_reads_kernel<1><<<unsigned(nt), IT_THREADS, 0, ctx->stream>>>(cc->owords.p, reads->len.p, cc->roff.p, cc->o_base, cc->n_emit, n_rec, W,
+                                                                              uint32_t(nt), offs.p, a.p);
+      BG_LAUNCH_CHECK();
+    }
   }
   // Buckets of a few thousand records at most are what the LDS sort takes: two levels (65 536 buckets) up to ~170 M records, a
   // third on as many more bits as bring the average bucket back under 2 600 (a workgroup a bucket: many small buckets cost more
