@@ -340,7 +340,8 @@ __global__ void it_bounds_kernel(const Item* __restrict__ items, uint64_t n, int
 constexpr int IB_THREADS = 512;
 constexpr int IB_CAP = 4096;       // items a workgroup sorts in LDS
 constexpr int IB_BINS = 2048;      // counting sort on the next 11 bits, then ranks inside a bin by comparison
-constexpr int IB_BIN_MAX = 96;     // members of a bin beyond which the bucket is left to the rows machinery
+constexpr int IB_BIN_MAX = 96;     // members of a bin beyond which the bucket is sorted by a bitonic network instead
+constexpr int IB_BIN_ROWS = 2048;  // ... and beyond which it is left to the rows machinery
 constexpr uint64_t kItLcpValid = 1ull << 63;
 constexpr int kItLcpShift = 55;
 constexpr uint64_t kItIdMask = (1ull << kItLcpShift) - 1;
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(IB_THREADS) void k_items_bucket_sort(const Item* __
   const int tid = threadIdx.x;
   if (hi == lo) return;
   if (hi - lo > uint64_t(IB_CAP)) {
-    if (tid == 0) status[b] = 1;
+    if (tid == 0) { status[b] = 1; atomicAdd(n_runs + 3, 1ull); }
     for (uint64_t i = lo + tid; i < hi; i += IB_THREADS) out[i] = in[i];
     return;
   }
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(IB_THREADS) void k_items_bucket_sort(const Item* __
     atomicAdd(&hist[uint32_t(f >> bin_shift) & (IB_BINS - 1)], 1u);
   }
   __syncthreads();
+  bool crowded = false;
   {  // exclusive scan of the bins: 4 per thread
     uint32_t v[IB_BINS / IB_THREADS], sum = 0;
 #pragma unroll
@@ -397,11 +399,15 @@ __global__ __launch_bounds__(IB_THREADS) void k_items_bucket_sort(const Item* __
     uint32_t fullest = 0;
 #pragma unroll
     for (int k = 0; k < IB_BINS / IB_THREADS; ++k) fullest = v[k] > fullest ? v[k] : fullest;
-    const bool crowded = __syncthreads_or(fullest > uint32_t(IB_BIN_MAX));
-    if (crowded) {
-      // a bin of hundreds (a repeat family's first word): ranking its members against each other is quadratic -- the bucket
-      // goes the way of the oversized ones
-      if (tid == 0) status[b] = 1;
+    // a bin of a hundred and more: ranking its members against each other is quadratic -- the bucket is sorted by a bitonic
+    // network over the item numbers instead (twenty buckets of the bench input; the rows machinery took them before, a
+    // millisecond of launches and read-backs).  A bin of thousands is a repeat family's first word: its runs of equal
+    // first words are beyond k_items_tie_block anyway -- the bucket goes the way of the oversized ones (a genome with 7.5 % of it
+    // in 5000 copies of one element: 40.3 ms so, 41.6 with every crowded bucket kept here; 40.9 / 40.5 with 1 024 / 512 as the
+    // bound, which leave four buckets of the bench input to the rows)
+    crowded = __syncthreads_or(fullest > uint32_t(IB_BIN_MAX));
+    if (__syncthreads_or(fullest > uint32_t(IB_BIN_ROWS))) {
+      if (tid == 0) { status[b] = 1; atomicAdd(n_runs + 3, 1ull); }
       for (uint64_t i = lo + tid; i < hi; i += IB_THREADS) out[i] = in[i];
       return;
     }
@@ -417,6 +423,29 @@ __global__ __launch_bounds__(IB_THREADS) void k_items_bucket_sort(const Item* __
     if (tid == IB_THREADS - 1) start[IB_BINS] = run;
   }
   __syncthreads();
+  if (crowded) {
+    uint32_t np = 1;
+    while (np < n) np <<= 1;  // (at most IB_CAP; the places past n hold 0xffff, which sorts last)
+    for (uint32_t i = tid; i < np; i += IB_THREADS) ord[i] = i < n ? uint16_t(i) : uint16_t(0xffff);
+    __syncthreads();
+    auto before = [&](uint32_t a, uint32_t c) {
+      if (a == 0xffffu) return false;
+      if (c == 0xffffu) return true;
+      const uint64_t fa = sfw[a], fc = sfw[c];
+      return fa < fc || (fa == fc && a < c);
+    };
+    for (uint32_t k = 2; k <= np; k <<= 1)
+      for (uint32_t j = k >> 1; j; j >>= 1) {
+        for (uint32_t i = tid; i < np; i += IB_THREADS) {
+          const uint32_t x = i ^ j;
+          if (x > i) {
+            const uint32_t a = ord[i], c = ord[x];
+            if ((i & k) == 0 ? before(c, a) : before(a, c)) { ord[i] = uint16_t(c); ord[x] = uint16_t(a); }
+          }
+        }
+        __syncthreads();
+      }
+  } else {
   for (uint32_t i = tid; i < n; i += IB_THREADS) {
     const uint32_t bin = uint32_t(sfw[i] >> bin_shift) & (IB_BINS - 1);
     grp[start[bin] + atomicAdd(&hist[bin], 1u)] = uint16_t(i);
@@ -435,6 +464,7 @@ __global__ __launch_bounds__(IB_THREADS) void k_items_bucket_sort(const Item* __
       rank += (g < f || (g == f && k < i)) ? 1u : 0u;
     }
     ord[bs + rank] = uint16_t(i);
+  }
   }
   __syncthreads();
   __shared__ uint32_t s_nruns;
@@ -505,15 +535,21 @@ __device__ __forceinline__ uint64_t it_note_lcp(const ItRow& a, const ItRow& b) 
   return a.id | kItLcpValid | (uint64_t(l) << kItLcpShift);
 }
 
-__global__ __launch_bounds__(256) void k_items_tie_small(Item* __restrict__ items, const uint64_t* __restrict__ runs, uint64_t n_runs,
+// (the three run kernels take their list's length from the device and stride over it: no read-back between them)
+__global__ __launch_bounds__(256) void k_items_tie_small(Item* __restrict__ items, const uint64_t* __restrict__ runs,
+                                                         const unsigned long long* __restrict__ n_runs_dev, uint64_t run_cap,
                                                          const uint64_t* __restrict__ owords, int W, uint64_t* __restrict__ more,
-                                                         unsigned long long* __restrict__ n_more) {
-  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= n_runs) return;
+                                                         unsigned long long* __restrict__ n_more, uint64_t more_cap) {
+  const uint64_t n_runs = *n_runs_dev < run_cap ? *n_runs_dev : run_cap;
+  for (uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < n_runs; t += uint64_t(gridDim.x) * blockDim.x) {
   const uint64_t rr = runs[t];
   const uint64_t p = rr & ((1ull << 48) - 1);
   const uint32_t g = uint32_t(rr >> 48);
-  if (g > 4) { more[atomicAdd(n_more, 1ull)] = rr; return; }
+  if (g > 4) {
+    const unsigned long long at = atomicAdd(n_more, 1ull);
+    if (at < more_cap) more[at] = rr;
+    continue;
+  }
   const uint64_t f = items[p].fw;
   ItRow x[4];
 #pragma unroll
@@ -534,19 +570,27 @@ __global__ __launch_bounds__(256) void k_items_tie_small(Item* __restrict__ item
     if (m + 1 < 4 && uint32_t(m + 1) < g) id = it_note_lcp(x[m], x[m + 1]);
     items[p + m] = Item{f, id};
   }
+  }
 }
 
 // a run of 5 .. 64 members: a lane a member; every lane counts the members that sort before its own through shuffles
-__global__ __launch_bounds__(256) void k_items_tie_wave(Item* __restrict__ items, const uint64_t* __restrict__ more, uint64_t n_more,
+__global__ __launch_bounds__(256) void k_items_tie_wave(Item* __restrict__ items, const uint64_t* __restrict__ more,
+                                                        const unsigned long long* __restrict__ n_more_dev, uint64_t more_cap,
                                                         const uint64_t* __restrict__ owords, int W, uint64_t* __restrict__ longer,
-                                                        unsigned long long* __restrict__ n_long) {
-  const uint64_t t = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+                                                        unsigned long long* __restrict__ n_long, uint64_t long_cap) {
   const int lane = threadIdx.x & 63;
-  if (t >= n_more) return;
+  const uint64_t n_more = *n_more_dev < more_cap ? *n_more_dev : more_cap;
+  for (uint64_t t = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; t < n_more; t += (uint64_t(gridDim.x) * blockDim.x) >> 6) {
   const uint64_t rr = more[t];
   const uint64_t p = rr & ((1ull << 48) - 1);
   const uint32_t g = uint32_t(rr >> 48);
-  if (g > 64) { if (lane == 0) longer[atomicAdd(n_long, 1ull)] = rr; return; }
+  if (g > 64) {
+    if (lane == 0) {
+      const unsigned long long at = atomicAdd(n_long, 1ull);
+      if (at < long_cap) longer[at] = rr;
+    }
+    continue;
+  }
   const bool live = uint32_t(lane) < g;
   ItRow me;
   uint64_t f = 0;
@@ -586,18 +630,27 @@ __global__ __launch_bounds__(256) void k_items_tie_wave(Item* __restrict__ items
       items[p + rank] = Item{f, id};
     }
   }
+  }
 }
 
 // a run of more than 64 members (repeats; a bucket holds at most IB_CAP items): a workgroup a run; the members' rest rows and
 // ids in LDS (lds_members of them fit: longer runs fetch them from the reads at every comparison), every member counts the
 // members that sort before it (quadratic: such runs are few).
 __global__ __launch_bounds__(1024) void k_items_tie_block(Item* __restrict__ items, const uint64_t* __restrict__ longer,
-                                                         const uint64_t* __restrict__ owords, int W, uint32_t lds_members) {
+                                                         const unsigned long long* __restrict__ n_long_dev, uint64_t long_cap,
+                                                         const uint64_t* __restrict__ owords, int W, uint32_t lds_members,
+                                                         uint32_t max_members, unsigned long long* __restrict__ n_left) {
   extern __shared__ uint64_t tb_smem[];  // lds_members x (1 + kMaxWords - 1) words: id, rest
   __shared__ uint16_t place[IB_CAP];     // sorted place -> member
-  const uint64_t rr = longer[blockIdx.x];
+  const uint64_t n_long = *n_long_dev < long_cap ? *n_long_dev : long_cap;
+  for (uint64_t li = blockIdx.x; li < n_long; li += gridDim.x) {
+  const uint64_t rr = longer[li];
   const uint64_t p = rr & ((1ull << 48) - 1);
   const uint32_t g = uint32_t(rr >> 48);
+  if (g > max_members) {  // (left to the caller: the rows machinery)
+    if (threadIdx.x == 0) atomicAdd(n_left, 1ull);
+    continue;
+  }
   const bool in_lds = g <= lds_members;
   constexpr int RS = kMaxWords;  // words a member takes in LDS
   auto load = [&](uint32_t m, ItRow* x) {
@@ -619,18 +672,32 @@ __global__ __launch_bounds__(1024) void k_items_tie_block(Item* __restrict__ ite
     }
   }
   __syncthreads();
-  for (uint32_t m = threadIdx.x; m < g; m += blockDim.x) {
-    ItRow me;
-    load(m, &me);
-    uint32_t rank = 0;
-    for (uint32_t q = 0; q < g; ++q) {
-      ItRow o;
-      load(q, &o);
-      rank += it_row_less(o, me) ? 1u : 0u;
-    }
-    place[rank] = uint16_t(m);
+  {  // the members in order: a bitonic network over their numbers (every member against every other took 2 048 row
+     // comparisons a thread for a run of 2 048; this takes 66)
+    uint32_t np = 1;
+    while (np < g) np <<= 1;  // (at most IB_CAP: max_members is)
+    for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) place[i] = i < g ? uint16_t(i) : uint16_t(0xffff);
+    __syncthreads();
+    auto before = [&](uint32_t a, uint32_t c) {
+      if (a == 0xffffu) return false;
+      if (c == 0xffffu) return true;
+      ItRow x, y;
+      load(a, &x);
+      load(c, &y);
+      return it_row_less(x, y);
+    };
+    for (uint32_t k = 2; k <= np; k <<= 1)
+      for (uint32_t j = k >> 1; j; j >>= 1) {
+        for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) {
+          const uint32_t x = i ^ j;
+          if (x > i) {
+            const uint32_t a = place[i], c = place[x];
+            if ((i & k) == 0 ? before(c, a) : before(a, c)) { place[i] = uint16_t(c); place[x] = uint16_t(a); }
+          }
+        }
+        __syncthreads();
+      }
   }
-  __syncthreads();
   const uint64_t f = items[p].fw;
   // (every member's row is read before any item of the run is overwritten: the rows come from LDS, or -- a run too long for
   // it -- the ids are staged in `place`'s order first)
@@ -650,6 +717,8 @@ __global__ __launch_bounds__(1024) void k_items_tie_block(Item* __restrict__ ite
   __syncthreads();
   k = 0;
   for (uint32_t r = threadIdx.x; r < g; r += blockDim.x, ++k) items[p + r] = Item{f, out_id[k]};
+  __syncthreads();  // (the rows and places are the next run's)
+  }
 }
 
 // checker (the probe only): neighbours in the whole array are in (string, length) order -- strings through the reads
@@ -1130,69 +1199,58 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   ctx->toc(n_rec * 16 * 3 * uint64_t(levels));
   // ---- every bucket in order of the first word, the runs of equal first words by the rest of their strings
   DevBuf<uint8_t> status;
-  DevBuf<unsigned long long> ctr;  // [0] runs, [1] runs of more than four, [2] runs of more than 64, [3] big buckets
-  DevBuf<uint64_t> runs, more;
-  const uint64_t run_cap = n_rec / 2 + 1;
+  DevBuf<unsigned long long> ctr;  // [0] runs, [1] runs of more than four, [2] of more than 64, [3] buckets left as they were, [4] runs left
+  DevBuf<uint64_t> runs, more, longer;
+  const uint64_t run_cap = n_rec / 2 + 1, more_cap = n_rec / 5 + 1, long_cap = n_rec / 65 + 1;
   BG_TRY(status.alloc(ctx, n_buckets));
-  BG_TRY(ctr.alloc(ctx, 4));
+  BG_TRY(ctr.alloc(ctx, 8));
   BG_TRY(runs.alloc(ctx, run_cap));
+  BG_TRY(more.alloc(ctx, more_cap));
+  BG_TRY(longer.alloc(ctx, long_cap));
   BG_HIP(hipMemsetAsync(status.p, 0, n_buckets, ctx->stream));
-  BG_HIP(hipMemsetAsync(ctr.p, 0, 32, ctx->stream));
+  BG_HIP(hipMemsetAsync(ctr.p, 0, 64, ctx->stream));
   ctx->tic("items_bucket_sort");
   k_items_bucket_sort<<<unsigned(n_buckets), IB_THREADS, 0, ctx->stream>>>(a.p, b.p, d_bounds, status.p, runs.p, ctr.p, run_cap, 64 - bucket_bits - 11);
   BG_LAUNCH_CHECK();
   ctx->toc(n_rec * 32);
-  unsigned long long h_ctr[4] = {0, 0, 0, 0};
-  std::vector<uint8_t> h_status(n_buckets);
-  BG_HIP(copy_d2h(ctx, h_ctr, ctr.p, 8));
-  BG_HIP(copy_d2h(ctx, h_status.data(), status.p, n_buckets));
-  a.reset();
-  if (h_ctr[0] > run_cap) return BG_OK;  // (cannot happen: a run has two members at least)
-  std::vector<std::pair<uint64_t, uint64_t>> segs;  // stretches left to the rows machinery: (start, count)
+  // the runs: lanes, waves, workgroups -- each kernel strides over a list whose length the one before left on the device, and
+  // the host reads the counters once, behind all three (five read-backs and their idle gaps before)
+  ctx->tic("items_tie_runs");
   {
-    bool any = false;
-    for (uint8_t v : h_status) any |= v != 0;
-    if (any) {
-      h_bounds.resize(n_buckets + 1);
-      BG_HIP(copy_d2h(ctx, h_bounds.data(), d_bounds, (n_buckets + 1) * 8));
-      for (uint64_t v = 0; v < n_buckets; ++v)
-        if (h_status[size_t(v)]) segs.emplace_back(h_bounds[size_t(v)], h_bounds[size_t(v) + 1] - h_bounds[size_t(v)]);
-    }
-  }
-  const uint64_t n_runs = h_ctr[0];
-  BG_TRY(more.alloc(ctx, n_runs ? n_runs : 1));
-  if (n_runs) {
-    ctx->tic("items_tie_runs");
-    k_items_tie_small<<<cdiv(n_runs, 256), 256, 0, ctx->stream>>>(b.p, runs.p, n_runs, cc->owords.p, W, more.p, ctr.p + 1);
+    const unsigned small_grid = unsigned(std::min<uint64_t>(cdiv(run_cap, 256), 1u << 16));
+    k_items_tie_small<<<small_grid, 256, 0, ctx->stream>>>(b.p, runs.p, ctr.p, run_cap, cc->owords.p, W, more.p, ctr.p + 1, more_cap);
     BG_LAUNCH_CHECK();
-    BG_HIP(copy_d2h(ctx, h_ctr + 1, ctr.p + 1, 8));
-    if (h_ctr[1]) {
-      DevBuf<uint64_t> longer;
-      BG_TRY(longer.alloc(ctx, h_ctr[1]));
-      k_items_tie_wave<<<cdiv(h_ctr[1] * 64, 256), 256, 0, ctx->stream>>>(b.p, more.p, h_ctr[1], cc->owords.p, W, longer.p, ctr.p + 2);
-      BG_LAUNCH_CHECK();
-      BG_HIP(copy_d2h(ctx, h_ctr + 2, ctr.p + 2, 8));
-      if (h_ctr[2]) {
-        // runs of 65 .. kItBlockRun members: a workgroup each; longer ones: the rows machinery
-        std::vector<uint64_t> h_long(h_ctr[2]), h_blk;
-        BG_HIP(copy_d2h(ctx, h_long.data(), longer.p, h_ctr[2] * 8));
-        for (uint64_t rr : h_long) {
-          if (uint32_t(rr >> 48) <= kItBlockRun) h_blk.push_back(rr);
-          else segs.emplace_back(rr & ((1ull << 48) - 1), rr >> 48);
-        }
-        if (!h_blk.empty()) {
-          BG_HIP(hipMemcpyAsync(longer.p, h_blk.data(), h_blk.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-          const uint32_t lds_members = kItBlockRun;
-          BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_items_tie_block), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     int(lds_members * kMaxWords * 8)));
-          k_items_tie_block<<<unsigned(h_blk.size()), 1024, size_t(lds_members) * kMaxWords * 8, ctx->stream>>>(b.p, longer.p, cc->owords.p, W, lds_members);
-          BG_LAUNCH_CHECK();
-          BG_HIP(hipStreamSynchronize(ctx->stream));  // (h_blk goes out of scope)
-        }
-      }
-    }
-    ctx->toc(n_runs * 2 * (16 + uint64_t(W) * 8));
+    k_items_tie_wave<<<2048, 256, 0, ctx->stream>>>(b.p, more.p, ctr.p + 1, more_cap, cc->owords.p, W, longer.p, ctr.p + 2, long_cap);
+    BG_LAUNCH_CHECK();
+    // runs of 65 .. kItBlockRun members: a workgroup each; longer ones: the rows machinery
+    const uint32_t lds_members = kItBlockRun;
+    BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_items_tie_block), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               int(lds_members * kMaxWords * 8)));
+    k_items_tie_block<<<256, 1024, size_t(lds_members) * kMaxWords * 8, ctx->stream>>>(b.p, longer.p, ctr.p + 2, long_cap, cc->owords.p, W, lds_members,
+                                                                                         kItBlockRun, ctr.p + 4);
+    BG_LAUNCH_CHECK();
   }
+  unsigned long long h_ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  BG_HIP(copy_d2h(ctx, h_ctr, ctr.p, 64));
+  ctx->toc(h_ctr[0] * 2 * (16 + uint64_t(W) * 8));
+  a.reset();
+  if (h_ctr[0] > run_cap || h_ctr[1] > more_cap || h_ctr[2] > long_cap) return BG_OK;  // (cannot happen: a run has 2 / 5 / 65 members at least)
+  std::vector<std::pair<uint64_t, uint64_t>> segs;  // stretches left to the rows machinery: (start, count)
+  if (h_ctr[3]) {
+    std::vector<uint8_t> h_status(n_buckets);
+    BG_HIP(copy_d2h(ctx, h_status.data(), status.p, n_buckets));
+    h_bounds.resize(n_buckets + 1);
+    BG_HIP(copy_d2h(ctx, h_bounds.data(), d_bounds, (n_buckets + 1) * 8));
+    for (uint64_t v = 0; v < n_buckets; ++v)
+      if (h_status[size_t(v)]) segs.emplace_back(h_bounds[size_t(v)], h_bounds[size_t(v) + 1] - h_bounds[size_t(v)]);
+  }
+  if (h_ctr[4]) {
+    std::vector<uint64_t> h_long(h_ctr[2]);
+    BG_HIP(copy_d2h(ctx, h_long.data(), longer.p, h_ctr[2] * 8));
+    for (uint64_t rr : h_long)
+      if (uint32_t(rr >> 48) > kItBlockRun) segs.emplace_back(rr & ((1ull << 48) - 1), rr >> 48);
+  }
+  longer.reset();
   runs.reset();
   more.reset();
   BG_TRY(items_subset_through_rows(ctx, b.p, segs, cc->owords.p, W));
@@ -1363,38 +1421,33 @@ int items_probe(bg_ctx* ctx, const uint64_t* owords, const uint16_t* len, const 
   hipEvent_t es[3];
   for (auto& e : es) BG_HIP(hipEventCreate(&e));
   BG_HIP(hipEventRecord(es[0], ctx->stream));
-  DevBuf<uint64_t> runs, more;
-  const uint64_t run_cap = n_rec / 2 + 1;
+  DevBuf<uint64_t> runs, more, longer;
+  DevBuf<unsigned long long> pc;  // the run kernels' counters (items_entries_impl's layout)
+  const uint64_t run_cap = n_rec / 2 + 1, more_cap = n_rec / 5 + 1, long_cap = n_rec / 65 + 1;
   BG_TRY(runs.alloc(ctx, run_cap));
-  k_items_bucket_sort<<<65536, IB_THREADS, 0, ctx->stream>>>(a.p, b.p, b16.p, status.p, runs.p, chk.p + 3, run_cap, 37);
+  BG_TRY(more.alloc(ctx, more_cap));
+  BG_TRY(longer.alloc(ctx, long_cap));
+  BG_TRY(pc.alloc(ctx, 8));
+  BG_HIP(hipMemsetAsync(pc.p, 0, 64, ctx->stream));
+  k_items_bucket_sort<<<65536, IB_THREADS, 0, ctx->stream>>>(a.p, b.p, b16.p, status.p, runs.p, pc.p, run_cap, 37);
   BG_LAUNCH_CHECK();
   BG_HIP(hipEventRecord(es[1], ctx->stream));
-  unsigned long long n_runs = 0, n_more = 0;
-  BG_HIP(copy_d2h(ctx, &n_runs, chk.p + 3, 8));
-  BG_HIP(hipMemsetAsync(chk.p + 3, 0, 8, ctx->stream));
-  if (n_runs > run_cap) n_runs = run_cap;
-  BG_TRY(more.alloc(ctx, n_runs ? n_runs : 1));
-  if (n_runs) {
-    k_items_tie_small<<<cdiv(n_runs, 256), 256, 0, ctx->stream>>>(b.p, runs.p, n_runs, owords, W, more.p, chk.p + 3);
+  {
+    k_items_tie_small<<<unsigned(std::min<uint64_t>(cdiv(run_cap, 256), 1u << 16)), 256, 0, ctx->stream>>>(b.p, runs.p, pc.p, run_cap, owords, W, more.p, pc.p + 1,
+                                                                                                      more_cap);
     BG_LAUNCH_CHECK();
-    BG_HIP(copy_d2h(ctx, &n_more, chk.p + 3, 8));
-    if (n_more) {
-      DevBuf<uint64_t> longer;
-      BG_TRY(longer.alloc(ctx, n_more));
-      k_items_tie_wave<<<cdiv(n_more * 64, 256), 256, 0, ctx->stream>>>(b.p, more.p, n_more, owords, W, longer.p, chk.p + 4);
-      BG_LAUNCH_CHECK();
-      unsigned long long n_long = 0;
-      BG_HIP(copy_d2h(ctx, &n_long, chk.p + 4, 8));
-      if (n_long) {
-        const uint32_t lds_members = 2048;
-        BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_items_tie_block), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   int(lds_members * kMaxWords * 8)));
-        k_items_tie_block<<<unsigned(n_long), 1024, size_t(lds_members) * kMaxWords * 8, ctx->stream>>>(b.p, longer.p, owords, W, lds_members);
-        BG_LAUNCH_CHECK();
-        BG_HIP(hipStreamSynchronize(ctx->stream));
-      }
-    }
+    k_items_tie_wave<<<2048, 256, 0, ctx->stream>>>(b.p, more.p, pc.p + 1, more_cap, owords, W, longer.p, pc.p + 2, long_cap);
+    BG_LAUNCH_CHECK();
+    const uint32_t lds_members = kItBlockRun;
+    BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_items_tie_block), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               int(lds_members * kMaxWords * 8)));
+    k_items_tie_block<<<256, 1024, size_t(lds_members) * kMaxWords * 8, ctx->stream>>>(b.p, longer.p, pc.p + 2, long_cap, owords, W, lds_members, kItBlockRun,
+                                                                                         pc.p + 4);
+    BG_LAUNCH_CHECK();
   }
+  unsigned long long h_pc[8];
+  BG_HIP(copy_d2h(ctx, h_pc, pc.p, 64));
+  const unsigned long long n_runs = h_pc[0], n_more = h_pc[1];
   BG_HIP(hipMemsetAsync(chk.p + 3, 0, 8, ctx->stream));
   BG_HIP(hipEventRecord(es[2], ctx->stream));
   k_items_check_order<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(a.p, n_rec, owords, W, chk.p + 6, chk.p + 2);  // (ids before; its order counts are unused)

@@ -63,7 +63,9 @@ def test_repeats_through_items_equal_rows_and_oracle(genome, copies, element):
     assert "entries from items: yes" in err
     # the input does reach the parts of the path this test is about
     chk = [l for l in err.splitlines() if l.startswith("items check")][-1]
-    assert " 0 stretches" not in chk and "out of order 0, LCP notes missing or wrong 0" in chk, chk
+    assert "out of order 0, LCP notes missing or wrong 0" in chk, chk
+    if copies >= 5000:  # (runs of thousands of equal first words: left to the rows machinery; the smaller family stays in the
+        assert " 0 stretches" not in chk, chk  # bucket sort's bitonic network and the workgroup run kernel)
     rows, err0 = _build("0", genome, copies, element)
     assert "entries from items: no" in err0
     ns = {}
