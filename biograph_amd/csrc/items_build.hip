@@ -1132,7 +1132,9 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   *done = false;
   const uint64_t n_rec = cc->n_rec;
   const int W = reads->W;
-  if (!n_rec || n_rec >= (1ull << 32) || getenv("BG_PREV_SEARCH_ALL")) return BG_OK;
+  // (an item's id holds the oriented read in 31 bits above offset, length and flags, under the LCP note: more reads than that --
+  // or records than 32-bit places -- go through rows)
+  if (!n_rec || n_rec >= (1ull << 32) || cc->o_base + cc->n_emit >= (1ull << 31) || getenv("BG_PREV_SEARCH_ALL")) return BG_OK;
   DevBuf<Item> a, b;
   BG_TRY(a.alloc(ctx, n_rec));
   BG_TRY(b.alloc(ctx, n_rec));
