@@ -26,10 +26,11 @@ namespace bg {
 
 struct __attribute__((aligned(16))) Item { uint64_t fw, id; };
 
-constexpr int IT_THREADS = 256;
-constexpr int IT_PER = 8;
-constexpr int IT_TILE = IT_THREADS * IT_PER;  // 2048 items = 32 KB staged in LDS
+constexpr int IT_THREADS = 512;  // (256 / 512 / 1 024 threads over the same 2 048 items: the four partition kernels 3.49 / 3.32 / 3.46 ms)
+constexpr int IT_TILE = 2048;  // items staged in LDS: 32 KB
+constexpr int IT_PER = IT_TILE / IT_THREADS;
 constexpr int IT_BINS = 256;
+static_assert(IT_THREADS >= IT_BINS && IT_THREADS % 64 == 0, "a thread a bin in the partition kernels");
 
 // One wave expands 64 oriented reads (k_emit_records' way of walking the records: a lane per RECORD, its read found by a
 // search over the 64 record offsets held one per lane): 16 bytes a record, written in runs.
@@ -105,7 +106,7 @@ __device__ __forceinline__ void it_locate(const ItSegs& sg, uint32_t tile, uint6
 
 __global__ __launch_bounds__(IT_THREADS) void it_hist_kernel(const Item* __restrict__ items, ItSegs sg, int shift, uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[IT_BINS];
-  h[threadIdx.x] = 0;
+  if (threadIdx.x < IT_BINS) h[threadIdx.x] = 0;
   __syncthreads();
   uint64_t lo, hi, hb;
   uint32_t nt, ti;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(IT_THREADS) void it_hist_kernel(const Item* __restr
     if (i < hi) atomicAdd(&h[uint32_t(items[i].fw >> shift) & 255u], 1u);
   }
   __syncthreads();
-  hist[hb + uint64_t(threadIdx.x) * nt + ti] = h[threadIdx.x];
+  if (threadIdx.x < IT_BINS) hist[hb + uint64_t(threadIdx.x) * nt + ti] = h[threadIdx.x];
 }
 
 __device__ __forceinline__ uint32_t it_block_excl_scan(uint32_t v, uint32_t* sm) {
@@ -140,9 +141,9 @@ __global__ __launch_bounds__(IT_THREADS) void it_scatter_kernel(const Item* __re
   __shared__ uint32_t h[IT_BINS];
   __shared__ uint32_t binstart[IT_BINS];
   __shared__ uint64_t goff[IT_BINS];
-  __shared__ uint32_t scan_sm[4];
+  __shared__ uint32_t scan_sm[IT_THREADS / 64];
   const int tid = threadIdx.x;
-  h[tid] = 0;
+  if (tid < IT_BINS) h[tid] = 0;
   uint64_t lo, hi, hb;
   uint32_t nt, ti;
   it_locate(sg, uint32_t(xcd_chunk(blockIdx.x, gridDim.x)), &lo, &hi, &hb, &nt, &ti);
@@ -162,9 +163,11 @@ __global__ __launch_bounds__(IT_THREADS) void it_scatter_kernel(const Item* __re
   }
   __syncthreads();
   {
-    const uint32_t ex = it_block_excl_scan(h[tid], scan_sm);
-    binstart[tid] = ex;
-    goff[tid] = offs[hb + uint64_t(tid) * nt + ti] - ex;
+    const uint32_t ex = it_block_excl_scan(tid < IT_BINS ? h[tid] : 0u, scan_sm);
+    if (tid < IT_BINS) {
+      binstart[tid] = ex;
+      goff[tid] = offs[hb + uint64_t(tid) * nt + ti] - ex;
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(IT_THREADS) void it_hist_reads_kernel(const uint64_
                                                                    uint32_t* __restrict__ hist) {
   __shared__ uint32_t rel[IR_READS + 1];
   __shared__ uint32_t h[IT_BINS];
-  h[threadIdx.x] = 0;
+  if (threadIdx.x < IT_BINS) h[threadIdx.x] = 0;
   const uint64_t t0 = uint64_t(blockIdx.x) * IR_READS;
   uint64_t r0;
   (void)ir_offsets(roff, n_emit, n_rec, t0, rel, &r0);
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(IT_THREADS) void it_hist_reads_kernel(const uint64_
     }
   }
   __syncthreads();
-  hist[uint64_t(threadIdx.x) * nt + blockIdx.x] = h[threadIdx.x];
+  if (threadIdx.x < IT_BINS) hist[uint64_t(threadIdx.x) * nt + blockIdx.x] = h[threadIdx.x];
 }
 
 template <int MODE>  // 0; 1: everything but the global writes (timing experiments, BG_ITEMS_PROBE)
@@ -248,14 +251,14 @@ __global__ __launch_bounds__(IT_THREADS) void it_scatter_reads_kernel(const uint
   __shared__ uint32_t h[IT_BINS];
   __shared__ uint32_t binstart[IT_BINS];
   __shared__ uint64_t goff[IT_BINS];
-  __shared__ uint32_t scan_sm[4];
+  __shared__ uint32_t scan_sm[IT_THREADS / 64];
   const int tid = threadIdx.x;
   const uint64_t t0 = uint64_t(blockIdx.x) * IR_READS;
   uint64_t r0;
   const uint32_t total = ir_offsets(roff, n_emit, n_rec, t0, rel, &r0);
-  uint64_t run = offs[uint64_t(tid) * nt + blockIdx.x];  // where this workgroup's next item of bin `tid` goes
+  uint64_t run = tid < IT_BINS ? offs[uint64_t(tid) * nt + blockIdx.x] : 0;  // where this workgroup's next item of bin `tid` goes
   for (uint32_t c0 = 0; c0 < total; c0 += IT_TILE) {
-    h[tid] = 0;
+    if (tid < IT_BINS) h[tid] = 0;
     __syncthreads();
     Item it[IT_PER];
     uint16_t rnk[IT_PER];
@@ -300,10 +303,13 @@ __global__ __launch_bounds__(IT_THREADS) void it_scatter_reads_kernel(const uint
     }
     __syncthreads();
     {
-      const uint32_t ex = it_block_excl_scan(h[tid], scan_sm);
-      binstart[tid] = ex;
-      goff[tid] = run - ex;
-      run += h[tid];
+      const uint32_t hv = tid < IT_BINS ? h[tid] : 0u;
+      const uint32_t ex = it_block_excl_scan(hv, scan_sm);
+      if (tid < IT_BINS) {
+        binstart[tid] = ex;
+        goff[tid] = run - ex;
+        run += hv;
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -339,7 +345,8 @@ __global__ void it_bounds_kernel(const Item* __restrict__ items, uint64_t n, int
 // no reads at all -- every other pair of neighbours differs inside the first word.
 constexpr int IB_THREADS = 512;
 constexpr int IB_CAP = 4096;       // items a workgroup sorts in LDS
-constexpr int IB_BINS = 2048;      // counting sort on the next 11 bits, then ranks inside a bin by comparison
+constexpr int IB_LOG2BINS = 11;
+constexpr int IB_BINS = 1 << IB_LOG2BINS;  // counting sort on the next bits, then ranks inside a bin by comparison
 constexpr int IB_BIN_MAX = 96;     // members of a bin beyond which the bucket is sorted by a bitonic network instead
 constexpr int IB_BIN_ROWS = 2048;  // ... and beyond which it is left to the rows machinery
 constexpr uint64_t kItLcpValid = 1ull << 63;
@@ -360,9 +367,12 @@ __global__ __launch_bounds__(IB_THREADS) void k_items_bucket_sort(const Item* __
                                                                   uint64_t* __restrict__ runs, unsigned long long* __restrict__ n_runs,
                                                                   uint64_t run_cap, int bin_shift) {
   __shared__ uint64_t sfw[IB_CAP];
-  __shared__ uint32_t hist[IB_BINS];
-  __shared__ uint32_t start[IB_BINS + 1];
+  // 53 KB of LDS: three workgroups a CU (66 KB with the bins' counts and starts as words of their own: two, 2.24 ms against 1.91;
+  // 1 024 bins in 51 KB: 1.96)
+  __shared__ uint16_t start[IB_BINS + 1];
   __shared__ uint16_t ord[IB_CAP];   // sorted place -> item
+  uint32_t* const hist = reinterpret_cast<uint32_t*>(ord);  // the bins' counts, then cursors: done with before `ord` is written
+  static_assert(sizeof(uint32_t) * IB_BINS <= sizeof(uint16_t) * IB_CAP, "the bins' counts live in ord");
   __shared__ uint16_t grp[IB_CAP];   // items grouped by bin (unordered inside)
   __shared__ uint32_t s_scan[IB_THREADS / 64];
   const uint32_t b = blockIdx.x;
@@ -416,11 +426,11 @@ __global__ __launch_bounds__(IB_THREADS) void k_items_bucket_sort(const Item* __
     uint32_t run = base + x - sum;
 #pragma unroll
     for (int k = 0; k < IB_BINS / IB_THREADS; ++k) {
-      start[tid * (IB_BINS / IB_THREADS) + k] = run;
+      start[tid * (IB_BINS / IB_THREADS) + k] = uint16_t(run);
       hist[tid * (IB_BINS / IB_THREADS) + k] = 0;  // (now the bin's cursor)
       run += v[k];
     }
-    if (tid == IB_THREADS - 1) start[IB_BINS] = run;
+    if (tid == IB_THREADS - 1) start[IB_BINS] = uint16_t(run);
   }
   __syncthreads();
   if (crowded) {
@@ -1212,7 +1222,7 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   BG_HIP(hipMemsetAsync(status.p, 0, n_buckets, ctx->stream));
   BG_HIP(hipMemsetAsync(ctr.p, 0, 64, ctx->stream));
   ctx->tic("items_bucket_sort");
-  k_items_bucket_sort<<<unsigned(n_buckets), IB_THREADS, 0, ctx->stream>>>(a.p, b.p, d_bounds, status.p, runs.p, ctr.p, run_cap, 64 - bucket_bits - 11);
+  k_items_bucket_sort<<<unsigned(n_buckets), IB_THREADS, 0, ctx->stream>>>(a.p, b.p, d_bounds, status.p, runs.p, ctr.p, run_cap, 64 - bucket_bits - IB_LOG2BINS);
   BG_LAUNCH_CHECK();
   ctx->toc(n_rec * 32);
   // the runs: lanes, waves, workgroups -- each kernel strides over a list whose length the one before left on the device, and
@@ -1431,7 +1441,7 @@ int items_probe(bg_ctx* ctx, const uint64_t* owords, const uint16_t* len, const 
   BG_TRY(longer.alloc(ctx, long_cap));
   BG_TRY(pc.alloc(ctx, 8));
   BG_HIP(hipMemsetAsync(pc.p, 0, 64, ctx->stream));
-  k_items_bucket_sort<<<65536, IB_THREADS, 0, ctx->stream>>>(a.p, b.p, b16.p, status.p, runs.p, pc.p, run_cap, 37);
+  k_items_bucket_sort<<<65536, IB_THREADS, 0, ctx->stream>>>(a.p, b.p, b16.p, status.p, runs.p, pc.p, run_cap, 64 - 16 - IB_LOG2BINS);
   BG_LAUNCH_CHECK();
   BG_HIP(hipEventRecord(es[1], ctx->stream));
   {
