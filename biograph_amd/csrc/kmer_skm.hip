@@ -85,6 +85,21 @@ __device__ __forceinline__ uint32_t sk_block_excl_scan(uint32_t v, uint32_t* sm,
   return base + x - v;
 }
 
+__device__ __forceinline__ uint32_t sk2_block_excl_scan(uint32_t v, uint32_t* sm) {  // (any number of waves)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) sm[wave] = x;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += sm[w];
+  return base + x - v;
+}
+
 __device__ __forceinline__ uint64_t sk_readlane64(uint64_t v, int l) {
   const uint32_t lo = __builtin_amdgcn_readlane(int(uint32_t(v)), l), hi = __builtin_amdgcn_readlane(int(uint32_t(v >> 32)), l);
   return (uint64_t(hi) << 32) | lo;
@@ -253,8 +268,13 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_num_sgpr(SK_GEN_S
 }
 
 // ---- further levels: one unstable pass over records already grouped into segments ------------------
-constexpr int SK2_ITEMS = 12;
-constexpr int SK2_TILE = SK_THREADS * SK2_ITEMS;
+// A tile of 3 072 records is 64 KB of LDS: two workgroups a CU.  With 256 threads of 12 records each that was 8 waves a CU and
+// the two scatter passes took 1.84 + 1.82 ms; 256 x 8 (three workgroups): 1.61 + 1.62; 512 x 6: 1.40 + 1.45; 1 024 x 3
+// (32 waves a CU): 1.26 + 1.35 -- 7.5 GB moved at 5.8 TB/s; 1 024 x 2: 1.37 + 1.39.
+constexpr int SK2_THREADS = 1024;
+constexpr int SK2_ITEMS = 3;
+constexpr int SK2_TILE = SK2_THREADS * SK2_ITEMS;
+static_assert(SK2_THREADS >= SK_BINS && SK2_THREADS % 64 == 0, "a thread a bin in the partition kernels");
 struct SkSegs {
   const uint64_t* seg_rec0;   // S+1 record offsets
   const uint32_t* seg_tile0;  // S+1 tile offsets
@@ -277,21 +297,21 @@ __device__ __forceinline__ void sk_locate(const SkSegs& sg, uint32_t tile, uint6
   *hist_base = uint64_t(t0) * SK_BINS;
 }
 
-__global__ __launch_bounds__(SK_THREADS) void sk_part_hist_kernel(const SkRec* __restrict__ recs, SkSegs sg, int shift,
+__global__ __launch_bounds__(SK2_THREADS) void sk_part_hist_kernel(const SkRec* __restrict__ recs, SkSegs sg, int shift,
                                                                   uint32_t dmask, uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[SK_BINS];
-  h[threadIdx.x] = 0;
+  if (threadIdx.x < SK_BINS) h[threadIdx.x] = 0;
   __syncthreads();
   uint64_t lo, hi, hbase;
   uint32_t nt, ti;
   sk_locate(sg, uint32_t(xcd_chunk(blockIdx.x, gridDim.x)), &lo, &hi, &hbase, &nt, &ti);  // XCD-contiguous tiles
 #pragma unroll
   for (int it = 0; it < SK2_ITEMS; ++it) {
-    const uint64_t idx = lo + uint64_t(it) * SK_THREADS + threadIdx.x;
+    const uint64_t idx = lo + uint64_t(it) * SK2_THREADS + threadIdx.x;
     if (idx < hi) atomicAdd(&h[(sk_bucket(recs[idx].b) >> shift) & dmask], 1u);
   }
   __syncthreads();
-  hist[hbase + uint64_t(threadIdx.x) * nt + ti] = h[threadIdx.x];
+  if (threadIdx.x < SK_BINS) hist[hbase + uint64_t(threadIdx.x) * nt + ti] = h[threadIdx.x];
 }
 
 // Org = what travels with a record: its 64-bit origin (read : first window), or — the count's own levels — its
@@ -299,7 +319,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_part_hist_kernel(const SkRec* _
 // needs to find the origin of the one record in ten it has something to tell.  full_bits (kIndex only, may be null):
 // receives "all windows kept" for every record, in input order.
 template <typename Org, bool kIndex>
-__global__ __launch_bounds__(SK_THREADS) void sk_part_scatter_kernel(const SkRec* __restrict__ in, SkRec* __restrict__ out,
+__global__ __launch_bounds__(SK2_THREADS) void sk_part_scatter_kernel(const SkRec* __restrict__ in, SkRec* __restrict__ out,
                                                                      const Org* __restrict__ oin,
                                                                      Org* __restrict__ oout, SkSegs sg, int shift,
                                                                      uint32_t dmask, const uint64_t* __restrict__ offs,
@@ -309,9 +329,9 @@ __global__ __launch_bounds__(SK_THREADS) void sk_part_scatter_kernel(const SkRec
   __shared__ uint32_t h[SK_BINS];
   __shared__ uint32_t binstart[SK_BINS];
   __shared__ uint64_t goff[SK_BINS];
-  __shared__ uint32_t scan_sm[4];
+  __shared__ uint32_t scan_sm[SK2_THREADS / 64];
   const int tid = threadIdx.x;
-  h[tid] = 0;
+  if (tid < SK_BINS) h[tid] = 0;
   uint64_t lo, hi, hbase;
   uint32_t nt, ti;
   sk_locate(sg, uint32_t(xcd_chunk(blockIdx.x, gridDim.x)), &lo, &hi, &hbase, &nt, &ti);  // XCD-contiguous tiles
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_part_scatter_kernel(const SkRec
   uint16_t rnk[SK2_ITEMS];
 #pragma unroll
   for (int it = 0; it < SK2_ITEMS; ++it) {
-    const uint64_t idx = lo + uint64_t(it) * SK_THREADS + tid;
+    const uint64_t idx = lo + uint64_t(it) * SK2_THREADS + tid;
     og[it] = 0;
     if (idx < hi) {
       rec[it] = in[idx];
@@ -339,15 +359,16 @@ __global__ __launch_bounds__(SK_THREADS) void sk_part_scatter_kernel(const SkRec
   }
   __syncthreads();
   {
-    uint32_t dummy;
-    const uint32_t ex = sk_block_excl_scan(h[tid], scan_sm, &dummy);
-    binstart[tid] = ex;
-    goff[tid] = offs[hbase + uint64_t(tid) * nt + ti] - ex;
+    const uint32_t ex = sk2_block_excl_scan(tid < SK_BINS ? h[tid] : 0u, scan_sm);
+    if (tid < SK_BINS) {
+      binstart[tid] = ex;
+      goff[tid] = offs[hbase + uint64_t(tid) * nt + ti] - ex;
+    }
   }
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < SK2_ITEMS; ++it) {
-    const uint64_t idx = lo + uint64_t(it) * SK_THREADS + tid;
+    const uint64_t idx = lo + uint64_t(it) * SK2_THREADS + tid;
     if (idx < hi) {
       const uint32_t at = binstart[(sk_bucket(rec[it].b) >> shift) & dmask] + rnk[it];
       srec[at] = rec[it];
@@ -356,7 +377,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_part_scatter_kernel(const SkRec
   }
   __syncthreads();
   const uint32_t cnt = uint32_t(hi - lo);
-  for (uint32_t i = tid; i < cnt; i += SK_THREADS) {
+  for (uint32_t i = tid; i < cnt; i += SK2_THREADS) {
     const SkRec r = srec[i];
     const uint64_t o = goff[(sk_bucket(r.b) >> shift) & dmask] + i;
     out[o] = r;
@@ -992,14 +1013,14 @@ static int sk_partition_segmented(bg_ctx* ctx, const SkRec* in, SkRec* out, cons
   BG_HIP(hipStreamSynchronize(ctx->stream));
   SkSegs sg{seg_rec.p, seg_tile.p, int(nseg)};
   ctx->tic("skm_part_hist");
-  sk_part_hist_kernel<<<ntiles, SK_THREADS, 0, ctx->stream>>>(in, sg, shift, dmask, hist.p);
+  sk_part_hist_kernel<<<ntiles, SK2_THREADS, 0, ctx->stream>>>(in, sg, shift, dmask, hist.p);
   BG_LAUNCH_CHECK();
   ctx->toc(n * 16);
   ctx->tic("radix_scan");
   BG_TRY(exclusive_scan_u32_to_u64(ctx, hist.p, offs.p, uint64_t(SK_BINS) * ntiles, nullptr));
   ctx->toc(uint64_t(SK_BINS) * ntiles * 12);
   ctx->tic("skm_part_scatter");
-  sk_part_scatter_kernel<Org, kIndex><<<ntiles, SK_THREADS, 0, ctx->stream>>>(in, out, oin, oout, sg, shift, dmask, offs.p,
+  sk_part_scatter_kernel<Org, kIndex><<<ntiles, SK2_THREADS, 0, ctx->stream>>>(in, out, oin, oout, sg, shift, dmask, offs.p,
                                                                                full_bits);
   BG_LAUNCH_CHECK();
   ctx->toc(n * (32 + (kIndex ? 1 : 2) * sizeof(Org)));
