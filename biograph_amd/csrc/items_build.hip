@@ -880,57 +880,54 @@ static int items_subset_through_rows(bg_ctx* ctx, Item* items, std::vector<std::
 // keep[p] = the item survives (it is not a prefix of, or equal to, its successor: expand.cpp:19-48 skip_dups); lcpn[p] = its LCP
 // with its successor (the note of k_items_tie_*, or what the two first words show)
 __global__ __launch_bounds__(256) void k_items_keep(const Item* __restrict__ items, uint64_t n, uint8_t* __restrict__ keep,
-                                                    uint8_t* __restrict__ lcpn, uint32_t* __restrict__ err) {
+                                                    uint8_t* __restrict__ lcpn, uint32_t* __restrict__ err,
+                                                    uint32_t* __restrict__ cnt256, uint32_t* __restrict__ firstk,
+                                                    uint32_t* __restrict__ lastk) {
+  __shared__ uint32_t s_c[4], s_f[4], s_l[4];
   const uint64_t p = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const Item a = items[p];
-  const int la = int(a.id >> 8) & 255;
-  int l = 0;
-  bool k = true;
-  if (p + 1 < n) {
-    const Item b = items[p + 1];
-    const int lb = int(b.id >> 8) & 255;
-    if (a.id & kItLcpValid) {
-      l = int(a.id >> kItLcpShift) & 255;
-    } else {
-      if (a.fw == b.fw) atomicOr(err, 8u);  // a run the tie kernels did not see
-      if (a.fw > b.fw) atomicOr(err, 1u);   // not sorted
-      l = lcp_word(a.fw, b.fw);
-      const int m = la < lb ? la : lb;
-      l = l < m ? l : m;
+  bool k = false;
+  if (p < n) {
+    const Item a = items[p];
+    const int la = int(a.id >> 8) & 255;
+    int l = 0;
+    k = true;
+    if (p + 1 < n) {
+      const Item b = items[p + 1];
+      const int lb = int(b.id >> 8) & 255;
+      if (a.id & kItLcpValid) {
+        l = int(a.id >> kItLcpShift) & 255;
+      } else {
+        if (a.fw == b.fw) atomicOr(err, 8u);  // a run the tie kernels did not see
+        if (a.fw > b.fw) atomicOr(err, 1u);   // not sorted
+        l = lcp_word(a.fw, b.fw);
+        const int m = la < lb ? la : lb;
+        l = l < m ? l : m;
+      }
+      k = l != la;
     }
-    k = l != la;
+    keep[p] = k ? 1 : 0;
+    lcpn[p] = uint8_t(l);
   }
-  keep[p] = k ? 1 : 0;
-  lcpn[p] = uint8_t(l);
-}
-
-// rank[p] = the number of survivors before item p = the entry item p belongs to (its own if it survives, else the one that
-// absorbs it: a dropped record is a prefix of its successor, so of the next survivor); kept[e] = the place of entry e's item.
-// Tiles of 2048 items; tile_offs = exclusive scan of the tiles' survivor counts.
-__global__ __launch_bounds__(256) void k_items_rank(const uint8_t* __restrict__ keep, uint64_t n, const uint64_t* __restrict__ tile_offs,
-                                                    uint32_t* __restrict__ rank, uint32_t* __restrict__ kept) {
-  __shared__ uint32_t sm[4];
-  const uint64_t base = uint64_t(blockIdx.x) * CP_TILE + uint64_t(threadIdx.x) * CP_ITEMS;
-  uint8_t f[CP_ITEMS];
-  uint32_t c = 0;
-#pragma unroll
-  for (int i = 0; i < CP_ITEMS; ++i) {
-    f[i] = base + i < n ? keep[base + i] : 0;
-    c += f[i] ? 1u : 0u;
-  }
+  // the workgroup's survivors: how many, the first and the last place (k_items_entries numbers the entries from these)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t inc = cp_wave_incl_scan(c, lane);
-  if (lane == 63) sm[w] = inc;
+  const uint64_t m = __ballot(k);
+  if (lane == 0) {
+    const uint32_t at = blockIdx.x * 256u + uint32_t(w) * 64u;
+    s_c[w] = uint32_t(__popcll(m));
+    s_f[w] = m ? at + uint32_t(__ffsll((unsigned long long)m) - 1) : ~0u;
+    s_l[w] = m ? at + uint32_t(63 - __clzll((long long)m)) : ~0u;
+  }
   __syncthreads();
-  uint32_t wbase = 0;
-  for (int i = 0; i < w; ++i) wbase += sm[i];
-  uint32_t o = uint32_t(tile_offs[blockIdx.x]) + wbase + inc - c;
-#pragma unroll
-  for (int i = 0; i < CP_ITEMS; ++i) {
-    if (base + i >= n) break;
-    rank[base + i] = o;
-    if (f[i]) kept[o++] = uint32_t(base + i);
+  if (threadIdx.x == 0) {
+    uint32_t c = 0, f = ~0u, l = ~0u;
+    for (int u = 0; u < 4; ++u) {
+      c += s_c[u];
+      if (f == ~0u) f = s_f[u];
+      if (s_l[u] != ~0u) l = s_l[u];
+    }
+    cnt256[blockIdx.x] = c;
+    firstk[blockIdx.x] = f;
+    lastk[blockIdx.x] = l;
   }
 }
 
@@ -941,12 +938,40 @@ __global__ __launch_bounds__(256) void k_items_rank(const uint8_t* __restrict__ 
 // survives or equals the survivor; what the rule cannot decide goes to the list as (place of the item) << 2 | kind -- 1 the
 // tail of a survivor that is its read's last record, 2 a record dropped as a proper prefix, checked (k_items_list_rows makes the
 // rows).  emask: bytes, four to a word (atomicOr on the word).
+// The entry an item belongs to = the survivors before it: the workgroup's base (offs256: a scan of k_items_keep's counts) and a
+// count over its lanes; the survivor before and the one at or after an item: over the lanes, the waves, and -- past the
+// workgroup's ends -- the neighbours' first / last survivors (k_items_keep) -- no rank and no place written per item (0.7 ms
+// of their own and 1.2 GB).
 __global__ __launch_bounds__(256) void k_items_entries(const Item* __restrict__ items, uint64_t n, const uint8_t* __restrict__ keep,
-                                                       const uint32_t* __restrict__ rank, const uint32_t* __restrict__ kept,
+                                                       const uint64_t* __restrict__ offs256, const uint32_t* __restrict__ firstk,
+                                                       const uint32_t* __restrict__ lastk,
                                                        const uint8_t* __restrict__ lcpn, uint8_t* __restrict__ sizes, uint8_t* __restrict__ shared,
                                                        Item* __restrict__ ent, uint32_t* __restrict__ emask32, uint8_t* __restrict__ kindf) {
+  __shared__ uint32_t s_cnt[4], s_first[4], s_last[4], s_prev, s_next;
   const uint64_t p = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint64_t lane_lt = (1ull << lane) - 1;
+  const bool k = p < n && keep[p] != 0;
+  const uint64_t km = __ballot(k);
+  {
+    const uint32_t at = blockIdx.x * 256u + uint32_t(w) * 64u;
+    if (lane == 0) {
+      s_cnt[w] = uint32_t(__popcll(km));
+      s_first[w] = km ? at + uint32_t(__ffsll((unsigned long long)km) - 1) : ~0u;
+      s_last[w] = km ? at + uint32_t(63 - __clzll((long long)km)) : ~0u;
+    }
+    if (threadIdx.x == 1) {  // the last survivor before this workgroup's items
+      uint32_t v = ~0u;
+      for (uint32_t bb = blockIdx.x; bb > 0 && v == ~0u;) v = lastk[--bb];
+      s_prev = v;
+    }
+    if (threadIdx.x == 65) {  // the first survivor behind them
+      uint32_t v = ~0u;
+      for (uint32_t bb = blockIdx.x + 1; bb < gridDim.x && v == ~0u; ++bb) v = firstk[bb];
+      s_next = v;
+    }
+  }
+  __syncthreads();
   uint32_t kind = 0, contrib = 0, my_e = 0xffffffffu;
   bool mine_kept = false, spans = false;
   if (p < n) {
@@ -954,13 +979,21 @@ __global__ __launch_bounds__(256) void k_items_entries(const Item* __restrict__ 
     const uint64_t id = me.id & kItIdMask;
     const uint32_t fl = uint32_t(id) & 255u;
     const int len = int(id >> 8) & 255;
-    const uint32_t e = rank[p];
-    const bool k = keep[p] != 0;
+    uint32_t e = uint32_t(offs256[blockIdx.x]) + uint32_t(__popcll(km & lane_lt));
+    for (int u = 0; u < w; ++u) e += s_cnt[u];
+    const uint32_t at = blockIdx.x * 256u + uint32_t(w) * 64u;
     bool sets = false;
     if (k) {
+      // the entry before: the last survivor before this item
+      uint32_t pp = ~0u;
+      const uint64_t mb = km & lane_lt;
+      if (mb) pp = at + uint32_t(63 - __clzll((long long)mb));
+      else {
+        for (int u = w - 1; u >= 0 && pp == ~0u; --u) pp = s_last[u];
+        if (pp == ~0u) pp = s_prev;
+      }
       int sh = 0;
-      if (e) {
-        const uint32_t pp = kept[e - 1];  // the entry before
+      if (pp != ~0u) {
         sh = lcpn[pp];
         if (pp + 1 < p) { const int v = lcpn[pp + 1]; sh = v < sh ? v : sh; }
       }
@@ -969,15 +1002,23 @@ __global__ __launch_bounds__(256) void k_items_entries(const Item* __restrict__ 
       ent[e] = Item{me.fw, id};  // the entry's first word and its record, side by side: what the searches probe
       sets = (fl & 1u) != 0;
       if (fl & 8u) kind = 1;
+      spans = (pp != ~0u ? pp + 1 : 0u) + uint32_t(lane) < uint32_t(p);  // its first record lies in an earlier wave
     } else if (fl & 1u) {
-      const int slen = int(items[kept[e]].id >> 8) & 255;  // (the survivor is a few places on)
+      // the survivor: the first one behind this item (a few places on)
+      uint32_t sp = ~0u;
+      const uint64_t ma = km & ~lane_lt;
+      if (ma) sp = at + uint32_t(__ffsll((unsigned long long)ma) - 1);
+      else {
+        for (int u = w + 1; u < 4 && sp == ~0u; ++u) sp = s_first[u];
+        if (sp == ~0u) sp = s_next;
+      }
+      const int slen = int(items[sp].id >> 8) & 255;
       if (slen == len) sets = true;
       else kind = 2;
     }
     contrib = sets ? 1u << ((fl >> 1) & 3u) : 0u;
     my_e = e;
     mine_kept = k;
-    if (k) spans = (e ? kept[e - 1] + 1 : 0u) + uint32_t(lane) < uint32_t(p);  // its first record lies in an earlier wave
   }
   // the records of an entry sit side by side: their bits are put together over the lanes (an atomic a record was 30 ms: four
   // billion a second is all the L2 does), and only an entry whose records straddle two waves takes atomics
@@ -1281,32 +1322,25 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   }
   // ---- entries
   DevBuf<uint8_t> keep, lcpn;
-  DevBuf<uint32_t> err, kept;
+  DevBuf<uint32_t> err;
   BG_TRY(keep.alloc(ctx, n_rec));
   BG_TRY(lcpn.alloc(ctx, n_rec));
   BG_TRY(err.alloc(ctx, 2));
   BG_HIP(hipMemsetAsync(err.p, 0, 8, ctx->stream));
   ctx->tic("items_entries");
-  k_items_keep<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(b.p, n_rec, keep.p, lcpn.p, err.p);
+  const uint64_t nb256 = cdiv(n_rec, 256);
+  DevBuf<uint32_t> cnt256, firstk, lastk;
+  DevBuf<uint64_t> offs256, total_ent;
+  BG_TRY(cnt256.alloc(ctx, nb256));
+  BG_TRY(firstk.alloc(ctx, nb256));
+  BG_TRY(lastk.alloc(ctx, nb256));
+  BG_TRY(offs256.alloc(ctx, nb256));
+  BG_TRY(total_ent.alloc(ctx, 1));
+  k_items_keep<<<unsigned(nb256), 256, 0, ctx->stream>>>(b.p, n_rec, keep.p, lcpn.p, err.p, cnt256.p, firstk.p, lastk.p);
   BG_LAUNCH_CHECK();
   uint64_t n_ent = 0;
-  DevBuf<uint32_t> rank;
-  {
-    const uint64_t nt = (n_rec + CP_TILE - 1) / CP_TILE;
-    DevBuf<uint32_t> counts;
-    DevBuf<uint64_t> offs, total;
-    BG_TRY(counts.alloc(ctx, nt));
-    BG_TRY(offs.alloc(ctx, nt));
-    BG_TRY(total.alloc(ctx, 1));
-    BG_TRY(rank.alloc(ctx, n_rec));
-    BG_TRY(kept.alloc(ctx, n_rec));  // (room for every item: the survivors' number comes back beside the kernel)
-    cp_count_kernel<<<unsigned(nt), CP_THREADS, 0, ctx->stream>>>(keep.p, n_rec, counts.p);
-    BG_LAUNCH_CHECK();
-    BG_TRY(exclusive_scan_u32_to_u64(ctx, counts.p, offs.p, nt, total.p));
-    k_items_rank<<<unsigned(nt), CP_THREADS, 0, ctx->stream>>>(keep.p, n_rec, offs.p, rank.p, kept.p);
-    BG_LAUNCH_CHECK();
-    BG_HIP(copy_d2h(ctx, &n_ent, total.p, 8));
-  }
+  BG_TRY(exclusive_scan_u32_to_u64(ctx, cnt256.p, offs256.p, nb256, total_ent.p));
+  BG_HIP(copy_d2h(ctx, &n_ent, total_ent.p, 8));
   DevBuf<uint64_t> erec;  // n_ent x {first word, record}
   ss->W = W;
   BG_TRY(ss->sizes.alloc(ctx, n_ent));
@@ -1318,7 +1352,7 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   DevBuf<uint8_t> kindf;
   DevBuf<uint32_t> lpos;
   BG_TRY(kindf.alloc(ctx, n_rec));
-  k_items_entries<<<cdiv(n_rec, 256), 256, 0, ctx->stream>>>(b.p, n_rec, keep.p, rank.p, kept.p, lcpn.p, ss->sizes.p, ss->shared.p,
+  k_items_entries<<<unsigned(nb256), 256, 0, ctx->stream>>>(b.p, n_rec, keep.p, offs256.p, firstk.p, lastk.p, lcpn.p, ss->sizes.p, ss->shared.p,
                                                              reinterpret_cast<Item*>(erec.p), reinterpret_cast<uint32_t*>(lp->emask.p), kindf.p);
   BG_LAUNCH_CHECK();
   BG_TRY(compact_flagged<uint32_t>(ctx, kindf.p, n_rec, &lpos, &lp->n_items));
@@ -1359,8 +1393,6 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   lpos.reset();
   kindf.reset();
   b.reset();
-  kept.reset();
-  rank.reset();
   keep.reset();
   lcpn.reset();
   ss->n = n_ent;
