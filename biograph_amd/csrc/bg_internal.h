@@ -424,6 +424,8 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
 // leading-bases directory over sorted W-word keys (*bases = 8..13 chosen from n): dir[p] = first key with
 // prefix >= p, dir[4^bases] = n
 int build_prefix_dir_keys(bg_ctx* ctx, const uint64_t* keys, uint64_t n, int W, DevBuf<uint32_t>* dir, int* bases);
+int prefix_dir_prepare(bg_ctx* ctx, uint64_t n, DevBuf<uint32_t>* dir, int* bases);  // (the caller writes the heads between the two)
+int prefix_dir_finish(bg_ctx* ctx, uint64_t n, int bases, DevBuf<uint32_t>* dir);
 int alloc_prev_bits(bg_ctx* ctx, bg_seqset* ss);
 int prev_bits_local_impl(bg_ctx* ctx, bg_seqset* ss, LocalPrev* lp = nullptr);
 int apply_tails_impl(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d_rows, uint64_t n_rows, uint32_t* d_err);

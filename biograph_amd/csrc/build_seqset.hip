@@ -1339,31 +1339,42 @@ __global__ __launch_bounds__(256) void k_dir_fill(uint32_t* __restrict__ dir, co
   }
 }
 
-int build_prefix_dir_keys(bg_ctx* ctx, const uint64_t* keys, uint64_t n, int W, DevBuf<uint32_t>* dir, int* bases_out) {
+// The directory in two halves for a caller that writes the heads itself (k_items_entries: dir[first bases of an entry's first
+// word] = the entry, for every entry whose first bases differ from the entry's before): room, 0xff and the end mark; then
+// the fill of the empty prefixes.
+int prefix_dir_prepare(bg_ctx* ctx, uint64_t n, DevBuf<uint32_t>* dir, int* bases_out) {
   const int bases = prefix_dir_bases(n);
   *bases_out = bases;
   const uint64_t nb = 1ull << (2 * bases);  // >= 4^8, a multiple of kDirChunk
-  const uint32_t nchunks = uint32_t(nb / kDirChunk);
   if (n >= 0xffffffffull) { set_error("shard of %llu entries exceeds the prefix directory", (unsigned long long)n); return BG_EINVAL; }
   BG_TRY(dir->alloc(ctx, nb + 1));
-  DevBuf<uint32_t> cmin, carry;
-  BG_TRY(cmin.alloc(ctx, nchunks));
-  BG_TRY(carry.alloc(ctx, nchunks));
   BG_HIP(hipMemsetAsync(dir->p, 0xff, nb * 4, ctx->stream));
   const uint32_t n32 = uint32_t(n);
   BG_HIP(hipMemcpyAsync(dir->p + nb, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
-  if (n) {
-    k_dir_heads<<<cdiv(n, 256), 256, 0, ctx->stream>>>(keys, n, W, bases, dir->p);
-    BG_LAUNCH_CHECK();
-  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));  // n32 is read by the async copy above
+  return BG_OK;
+}
+int prefix_dir_finish(bg_ctx* ctx, uint64_t n, int bases, DevBuf<uint32_t>* dir) {
+  const uint64_t nb = 1ull << (2 * bases);
+  const uint32_t nchunks = uint32_t(nb / kDirChunk);
+  DevBuf<uint32_t> cmin, carry;
+  BG_TRY(cmin.alloc(ctx, nchunks));
+  BG_TRY(carry.alloc(ctx, nchunks));
   k_dir_chunk_min<<<nchunks, 256, 0, ctx->stream>>>(dir->p, cmin.p);
   BG_LAUNCH_CHECK();
-  k_dir_chunk_carry<<<1, 1024, 0, ctx->stream>>>(cmin.p, nchunks, n32, carry.p);
+  k_dir_chunk_carry<<<1, 1024, 0, ctx->stream>>>(cmin.p, nchunks, uint32_t(n), carry.p);
   BG_LAUNCH_CHECK();
   k_dir_fill<<<nchunks, 256, 0, ctx->stream>>>(dir->p, carry.p);
   BG_LAUNCH_CHECK();
-  BG_HIP(hipStreamSynchronize(ctx->stream));  // n32 is read by the async copy above
   return BG_OK;
+}
+int build_prefix_dir_keys(bg_ctx* ctx, const uint64_t* keys, uint64_t n, int W, DevBuf<uint32_t>* dir, int* bases_out) {
+  BG_TRY(prefix_dir_prepare(ctx, n, dir, bases_out));
+  if (n) {
+    k_dir_heads<<<cdiv(n, 256), 256, 0, ctx->stream>>>(keys, n, W, *bases_out, dir->p);
+    BG_LAUNCH_CHECK();
+  }
+  return prefix_dir_finish(ctx, n, *bases_out, dir);
 }
 
 // lower_bound of (tail, tl) in the entries, searched inside its prefix bucket only

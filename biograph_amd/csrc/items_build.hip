@@ -946,7 +946,8 @@ __global__ __launch_bounds__(256) void k_items_entries(const Item* __restrict__ 
                                                        const uint64_t* __restrict__ offs256, const uint32_t* __restrict__ firstk,
                                                        const uint32_t* __restrict__ lastk,
                                                        const uint8_t* __restrict__ lcpn, uint8_t* __restrict__ sizes, uint8_t* __restrict__ shared,
-                                                       Item* __restrict__ ent, uint32_t* __restrict__ emask32, uint8_t* __restrict__ kindf) {
+                                                       Item* __restrict__ ent, uint32_t* __restrict__ emask32, uint8_t* __restrict__ kindf,
+                                                       uint32_t* __restrict__ dir, int dir_bases) {
   __shared__ uint32_t s_cnt[4], s_first[4], s_last[4], s_prev, s_next;
   const uint64_t p = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1000,6 +1001,10 @@ __global__ __launch_bounds__(256) void k_items_entries(const Item* __restrict__ 
       sizes[e] = uint8_t(len);
       shared[e] = uint8_t(sh);
       ent[e] = Item{me.fw, id};  // the entry's first word and its record, side by side: what the searches probe
+      if (dir) {  // the prefix directory's heads (k_dir_heads): the first entry of every prefix that occurs
+        const uint32_t cur = uint32_t(me.fw >> (64 - 2 * dir_bases));
+        if (pp == ~0u || uint32_t(items[pp].fw >> (64 - 2 * dir_bases)) != cur) dir[cur] = e;
+      }
       sets = (fl & 1u) != 0;
       if (fl & 8u) kind = 1;
       spans = (pp != ~0u ? pp + 1 : 0u) + uint32_t(lane) < uint32_t(p);  // its first record lies in an earlier wave
@@ -1352,8 +1357,14 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   DevBuf<uint8_t> kindf;
   DevBuf<uint32_t> lpos;
   BG_TRY(kindf.alloc(ctx, n_rec));
+  const char* keys_env = getenv("BG_ITEMS_KEYS");
+  const bool keys_now = keys_env && keys_env[0] == '1';
+  DevBuf<uint32_t> dir;  // the entries' prefix directory for the tails' searches: its heads come out of k_items_entries
+  int bases = 0;
+  if (!keys_now) BG_TRY(prefix_dir_prepare(ctx, n_ent, &dir, &bases));
   k_items_entries<<<unsigned(nb256), 256, 0, ctx->stream>>>(b.p, n_rec, keep.p, offs256.p, firstk.p, lastk.p, lcpn.p, ss->sizes.p, ss->shared.p,
-                                                             reinterpret_cast<Item*>(erec.p), reinterpret_cast<uint32_t*>(lp->emask.p), kindf.p);
+                                                             reinterpret_cast<Item*>(erec.p), reinterpret_cast<uint32_t*>(lp->emask.p), kindf.p,
+                                                             dir.p, bases);
   BG_LAUNCH_CHECK();
   BG_TRY(compact_flagged<uint32_t>(ctx, kindf.p, n_rec, &lpos, &lp->n_items));
   ctx->toc(n_rec * 32 + n_ent * 12);
@@ -1362,8 +1373,6 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   if (h_err[0]) { set_error("items: the sorted items are not in order (internal error %u)", h_err[0]); return BG_EINTERNAL; }
   lp->cap = lp->n_items;
   lp->valid = true;
-  const char* keys_env = getenv("BG_ITEMS_KEYS");
-  const bool keys_now = keys_env && keys_env[0] == '1';
   if (keys_now) {
     // (BG_ITEMS_KEYS=1: the rows of the list and the key table at once, searched by k_prev_list as the rows path does)
     if (lp->n_items) {
@@ -1375,10 +1384,8 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
     }
   } else {
     // the tails searched through the entries' first words and the reads
-    DevBuf<uint32_t> dir;
-    int bases = 0;
     ctx->tic("prev_bits");
-    BG_TRY(build_prefix_dir_keys(ctx, erec.p, n_ent, 2, &dir, &bases));  // (over the first words: every second word of erec)
+    BG_TRY(prefix_dir_finish(ctx, n_ent, bases, &dir));
     if (lp->n_items) {
       const ItEntries t{reinterpret_cast<const Item*>(erec.p), ss->sizes.p, cc->owords.p, dir.p, n_ent, W, bases};
       const char* v = getenv("BG_VERIFY_CLOSURE");  // (the lone-first-word shortcut checked against the reads as well)
