@@ -26,6 +26,8 @@ constexpr uint64_t kRevStartsBit = 1ull << 63;      // stored in hash slot: rev_
 // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2; MI355X_MICROARCH.md).  Maps
 // physical workgroup p of an nb-workgroup grid to a logical chunk so that each XCD walks one contiguous
 // eighth of the work.  Only locality depends on it.
+// first word of the sort item of an oriented read too short to be a cover (items_build.hip: k_read_items, k_oriented_words)
+BG_HD uint64_t cover_item_scatter(uint64_t o) { return (o + 1) * 0x9E3779B97F4A7C15ull; }
 BG_HD uint64_t xcd_chunk(uint64_t p, uint64_t nb) {
   uint64_t q = nb >> 3;
   return p < (q << 3) ? (p & 7) * q + (p >> 3) : p;

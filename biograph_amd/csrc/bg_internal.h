@@ -424,6 +424,9 @@ int entries_from_records_impl(bg_ctx* ctx, DevBuf<uint64_t>& rec, DevBuf<uint8_t
 // leading-bases directory over sorted W-word keys (*bases = 8..13 chosen from n): dir[p] = first key with
 // prefix >= p, dir[4^bases] = n
 int build_prefix_dir_keys(bg_ctx* ctx, const uint64_t* keys, uint64_t n, int W, DevBuf<uint32_t>* dir, int* bases);
+// items_build.hip: the oriented reads of >= cover_k bases in (string, length) order, as first K-mers and read numbers
+int items_cover_order(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, uint64_t n_o, int W, int cover_k, DevBuf<uint64_t>* premade,
+                      DevBuf<uint64_t>* skeys, DevBuf<uint32_t>* soid, uint64_t* m_out, bool* done);
 int prefix_dir_prepare(bg_ctx* ctx, uint64_t n, DevBuf<uint32_t>* dir, int* bases);  // (the caller writes the heads between the two)
 int prefix_dir_finish(bg_ctx* ctx, uint64_t n, int bases, DevBuf<uint32_t>* dir);
 int alloc_prev_bits(bg_ctx* ctx, bg_seqset* ss);

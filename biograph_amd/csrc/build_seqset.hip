@@ -24,9 +24,11 @@ constexpr int kSortSkipBits = 32;  // the sort key keeps the leading 16 bases of
 // ------------------------------------------------------------------------------------------------
 // oriented reads (+ their lengths as bytes and their sort keys: leading 16 bases | oriented id)
 
+// k0: one sort key a read (leading bases | read) for sort_records_impl, or -- items_K > 0 -- two words a read: the 16-byte item
+// of items_cover_order (first word, read << 24 | length << 8; a read shorter than items_K gets a scattered first word)
 __global__ void k_oriented_words(const uint64_t* __restrict__ words, const uint16_t* __restrict__ len, uint64_t n,
                                  int W, uint64_t* __restrict__ owords, uint8_t* __restrict__ olen,
-                                 uint64_t* __restrict__ k0) {
+                                 uint64_t* __restrict__ k0, int items_K) {
   uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (o >= 2 * n) return;
   uint64_t i = o >> 1;
@@ -35,7 +37,12 @@ __global__ void k_oriented_words(const uint64_t* __restrict__ words, const uint1
   oriented_words(words + i * W, L, W, (o & 1) != 0, tmp);
   for (int w = 0; w < W; ++w) owords[o * W + w] = L ? tmp[w] : 0;
   olen[o] = uint8_t(L);
-  k0[o] = ((L ? tmp[0] : 0ull) & ~((1ull << kSortSkipBits) - 1)) | o;
+  if (items_K > 0) {
+    k0[2 * o] = L >= items_K ? tmp[0] : cover_item_scatter(o);
+    k0[2 * o + 1] = (o << 24) | (uint64_t(L) << 8);
+  } else {
+    k0[o] = ((L ? tmp[0] : 0ull) & ~((1ull << kSortSkipBits) - 1)) | o;
+  }
 }
 
 // reads at least K bases long, in sorted order (shorter ones cannot act as a cover)
@@ -2031,6 +2038,10 @@ namespace bg {
 // family puts thousands of reads behind one K-mer, and scanning them made the look-ups quadratic
 // (tools/stress_repeats.py: 3.5 s for a 20 Mb genome).  k0o (optional, consumed): sort keys written by whoever
 // made the oriented words.  The store keeps pointers into owords / olen: they must outlive it.
+static bool cover_by_items(uint64_t n_o, int cover_k) {
+  const char* e = getenv("BG_COVER_ITEMS");
+  return !(e && e[0] == '0') && n_o && n_o < (1ull << 31) && cover_k <= 32;
+}
 int cover_index_build(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, uint64_t n_o, int W, int cover_k,
                       DevBuf<uint64_t>* k0o, CoverStore* cs) {
   if (n_o >= (1ull << 31)) { set_error("too many reads for one cover index (%llu oriented)", (unsigned long long)n_o); return BG_EINVAL; }
@@ -2039,18 +2050,26 @@ int cover_index_build(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, 
   {
     DevBuf<uint32_t> sidx_all, keep;
     DevBuf<uint8_t> flags;
-    BG_TRY(sort_records_impl(ctx, owords, olen, n_o, W, k0o, &sidx_all, nullptr));
+    // the reads in order through 16-byte items (items_build.hip; BG_COVER_ITEMS=0: through sort_records_impl's rows order and
+    // two gathers, as before)
+    bool by_items = false;
+    if (cover_by_items(n_o, cover_k)) BG_TRY(bg::items_cover_order(ctx, owords, olen, n_o, W, cover_k, k0o, &cs->skeys, &cs->soid, &m, &by_items));
     BG_TRY(flags.alloc(ctx, n_o));
-    if (n_o) {
-      k_flag_long_enough<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(sidx_all.p, olen, n_o, cover_k, flags.p);
-      BG_LAUNCH_CHECK();
+    if (!by_items) {
+      BG_TRY(sort_records_impl(ctx, owords, olen, n_o, W, k0o, &sidx_all, nullptr));
+      if (n_o) {
+        k_flag_long_enough<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(sidx_all.p, olen, n_o, cover_k, flags.p);
+        BG_LAUNCH_CHECK();
+      }
+      BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, n_o, &keep, &m));
+      BG_TRY(cs->skeys.alloc(ctx, m));
+      BG_TRY(cs->soid.alloc(ctx, m));
+      if (m) {
+        k_cover_keys<<<cdiv(m, 256), 256, 0, ctx->stream>>>(sidx_all.p, keep.p, m, owords, W, cover_k, cs->skeys.p, cs->soid.p);
+        BG_LAUNCH_CHECK();
+      }
     }
-    BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, n_o, &keep, &m));
-    BG_TRY(cs->skeys.alloc(ctx, m));
-    BG_TRY(cs->soid.alloc(ctx, m));
     if (m) {
-      k_cover_keys<<<cdiv(m, 256), 256, 0, ctx->stream>>>(sidx_all.p, keep.p, m, owords, W, cover_k, cs->skeys.p, cs->soid.p);
-      BG_LAUNCH_CHECK();
       k_flag_key_heads<<<cdiv(m, 256), 256, 0, ctx->stream>>>(cs->skeys.p, m, flags.p);
       BG_LAUNCH_CHECK();
     }
@@ -2091,10 +2110,11 @@ int cover_counts_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t 
   CoverStore cs;
   {
     DevBuf<uint64_t> k0o;
-    BG_TRY(k0o.alloc(ctx, n_o));
+    const bool as_items = cover_by_items(n_o, cover_k);  // (the reads' sort items beside the reads: cover_index_build)
+    BG_TRY(k0o.alloc(ctx, as_items ? 2 * n_o : n_o));
     if (n_o) {
       ctx->tic("suffix_oriented");
-      k_oriented_words<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->len.p, n, W, owords.p, olen.p, k0o.p);
+      k_oriented_words<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(reads->words.p, reads->len.p, n, W, owords.p, olen.p, k0o.p, as_items ? cover_k : 0);
       BG_LAUNCH_CHECK();
       ctx->toc(n * W * 8 + n_o * W * 8 + n_o * 9);
     }

@@ -1184,6 +1184,180 @@ __global__ __launch_bounds__(256) void k_items_keys(const Item* __restrict__ ent
   if (W == 1 && w == 0) pre2[e * 2 + 1] = 0;
 }
 
+// From items partitioned by their top byte (in b; a is scratch of the same size and is released) to the items in (string, length)
+// order in b, every member of a run of equal first words carrying its LCP note: second (and third) partition level, bucket sort,
+// the run kernels, the rows machinery for what they leave (*segs_out).  `owords`: the rows the ids point into (W words each).
+// tics: the caller's "items_partition" bracket is open and is closed here; the bucket sort and the runs get their own.
+static int items_sort_from_level1(bg_ctx* ctx, DevBuf<Item>& a, DevBuf<Item>& b, uint64_t n_rec, const uint64_t* owords, int W, bool tics,
+                                  std::vector<std::pair<uint64_t, uint64_t>>* segs_out, bool* ok) {
+  *ok = true;
+  // Buckets of a few thousand records at most are what the LDS sort takes: two levels (65 536 buckets) up to ~170 M records, a
+  // third on as many more bits as bring the average bucket back under 2 600 (a workgroup a bucket: many small buckets cost more
+  // than they sort) beyond (BG_ITEMS_LEVELS=3: a third level of four bits at any size, for the tests)
+  const char* lv = getenv("BG_ITEMS_LEVELS");
+  int extra = 0;
+  while (extra < 8 && (n_rec >> (16 + extra)) > 2600) ++extra;
+  if (lv && lv[0] == '3' && extra < 4) extra = 4;
+  const int levels = extra ? 3 : 2;
+  // (and fewer, fuller buckets for fewer records: the second level on as few bits as keep the average under 2 600 -- 25.7 M
+  // oriented reads in 16 384 buckets, not 65 536 of 390: a workgroup a bucket costs what it costs)
+  int bucket_bits = 16 + extra;
+  if (!extra)
+    while (bucket_bits > 8 && (n_rec >> (bucket_bits - 1)) <= 2600) --bucket_bits;
+  const uint64_t n_buckets = 1ull << bucket_bits;
+  DevBuf<uint64_t> b8, b16, bnd;
+  BG_TRY(b8.alloc(ctx, 257));
+  BG_TRY(b16.alloc(ctx, 65537));
+  if (bucket_bits > 8) {
+    it_bounds_kernel<<<2, 256, 0, ctx->stream>>>(b.p, n_rec, 8, b8.p);
+    BG_LAUNCH_CHECK();
+    std::vector<uint64_t> h8(257);
+    BG_HIP(copy_d2h(ctx, h8.data(), b8.p, 257 * 8));
+    // (the byte the pass sorts on: the second level's bits under as many of the first byte's, which a segment shares)
+    BG_TRY(it_partition(ctx, b.p, a.p, n_rec, 256, h8.data(), 64 - std::min(bucket_bits, 16)));
+  } else {
+    std::swap(a, b);  // (the first level is all: the items are where the bucket sort reads them)
+  }
+  it_bounds_kernel<<<cdiv((1ull << std::min(bucket_bits, 16)) + 1, 256), 256, 0, ctx->stream>>>(a.p, n_rec, std::min(bucket_bits, 16), b16.p);
+  BG_LAUNCH_CHECK();
+  std::vector<uint64_t> h_bounds;  // (on the host only when a stretch has to be named)
+  if (levels == 3) {
+    std::vector<uint64_t> h16(65537);
+    BG_HIP(copy_d2h(ctx, h16.data(), b16.p, 65537 * 8));
+    BG_TRY(it_partition(ctx, a.p, b.p, n_rec, 65536, h16.data(), 48 - extra));  // (eight bits from there: the upper ones are the segment's own)
+    BG_TRY(bnd.alloc(ctx, n_buckets + 1));
+    it_bounds_kernel<<<cdiv(n_buckets + 1, 256), 256, 0, ctx->stream>>>(b.p, n_rec, bucket_bits, bnd.p);
+    BG_LAUNCH_CHECK();
+    std::swap(a, b);  // (the partitioned items are in a again)
+  }
+  const uint64_t* d_bounds = levels == 3 ? bnd.p : b16.p;
+  if (tics) ctx->toc(n_rec * 16 * 3 * uint64_t(levels));
+  // ---- every bucket in order of the first word, the runs of equal first words by the rest of their strings
+  DevBuf<uint8_t> status;
+  DevBuf<unsigned long long> ctr;  // [0] runs, [1] runs of more than four, [2] of more than 64, [3] buckets left as they were, [4] runs left
+  DevBuf<uint64_t> runs, more, longer;
+  const uint64_t run_cap = n_rec / 2 + 1, more_cap = n_rec / 5 + 1, long_cap = n_rec / 65 + 1;
+  BG_TRY(status.alloc(ctx, n_buckets));
+  BG_TRY(ctr.alloc(ctx, 8));
+  BG_TRY(runs.alloc(ctx, run_cap));
+  BG_TRY(more.alloc(ctx, more_cap));
+  BG_TRY(longer.alloc(ctx, long_cap));
+  BG_HIP(hipMemsetAsync(status.p, 0, n_buckets, ctx->stream));
+  BG_HIP(hipMemsetAsync(ctr.p, 0, 64, ctx->stream));
+  if (tics) ctx->tic("items_bucket_sort");
+  k_items_bucket_sort<<<unsigned(n_buckets), IB_THREADS, 0, ctx->stream>>>(a.p, b.p, d_bounds, status.p, runs.p, ctr.p, run_cap, 64 - bucket_bits - IB_LOG2BINS);
+  BG_LAUNCH_CHECK();
+  if (tics) ctx->toc(n_rec * 32);
+  // the runs: lanes, waves, workgroups -- each kernel strides over a list whose length the one before left on the device, and
+  // the host reads the counters once, behind all three (five read-backs and their idle gaps before)
+  if (tics) ctx->tic("items_tie_runs");
+  {
+    const unsigned small_grid = unsigned(std::min<uint64_t>(cdiv(run_cap, 256), 1u << 16));
+    k_items_tie_small<<<small_grid, 256, 0, ctx->stream>>>(b.p, runs.p, ctr.p, run_cap, owords, W, more.p, ctr.p + 1, more_cap);
+    BG_LAUNCH_CHECK();
+    k_items_tie_wave<<<2048, 256, 0, ctx->stream>>>(b.p, more.p, ctr.p + 1, more_cap, owords, W, longer.p, ctr.p + 2, long_cap);
+    BG_LAUNCH_CHECK();
+    // runs of 65 .. kItBlockRun members: a workgroup each; longer ones: the rows machinery
+    const uint32_t lds_members = kItBlockRun;
+    BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_items_tie_block), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               int(lds_members * kMaxWords * 8)));
+    k_items_tie_block<<<256, 1024, size_t(lds_members) * kMaxWords * 8, ctx->stream>>>(b.p, longer.p, ctr.p + 2, long_cap, owords, W, lds_members,
+                                                                                         kItBlockRun, ctr.p + 4);
+    BG_LAUNCH_CHECK();
+  }
+  unsigned long long h_ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  BG_HIP(copy_d2h(ctx, h_ctr, ctr.p, 64));
+  if (tics) ctx->toc(h_ctr[0] * 2 * (16 + uint64_t(W) * 8));
+  a.reset();
+  if (h_ctr[0] > run_cap || h_ctr[1] > more_cap || h_ctr[2] > long_cap) { *ok = false; return BG_OK; }  // (cannot happen: a run has 2 / 5 / 65 members at least)
+  std::vector<std::pair<uint64_t, uint64_t>>& segs = *segs_out;  // stretches left to the rows machinery: (start, count)
+  segs.clear();
+  if (h_ctr[3]) {
+    std::vector<uint8_t> h_status(n_buckets);
+    BG_HIP(copy_d2h(ctx, h_status.data(), status.p, n_buckets));
+    h_bounds.resize(n_buckets + 1);
+    BG_HIP(copy_d2h(ctx, h_bounds.data(), d_bounds, (n_buckets + 1) * 8));
+    for (uint64_t v = 0; v < n_buckets; ++v)
+      if (h_status[size_t(v)]) segs.emplace_back(h_bounds[size_t(v)], h_bounds[size_t(v) + 1] - h_bounds[size_t(v)]);
+  }
+  if (h_ctr[4]) {
+    std::vector<uint64_t> h_long(h_ctr[2]);
+    BG_HIP(copy_d2h(ctx, h_long.data(), longer.p, h_ctr[2] * 8));
+    for (uint64_t rr : h_long)
+      if (uint32_t(rr >> 48) > kItBlockRun) segs.emplace_back(rr & ((1ull << 48) - 1), rr >> 48);
+  }
+  longer.reset();
+  runs.reset();
+  more.reset();
+  BG_TRY(items_subset_through_rows(ctx, b.p, segs, owords, W));
+  return BG_OK;
+}
+
+// ---- the cover index's order of the oriented reads by the same machinery: a read is the item of its suffix 0
+// (a read shorter than K is no cover and is dropped from the order afterwards: its first word is replaced by a scattered value,
+// or the reads the correction emptied -- thousands of equal strings -- would be one run for the rows machinery)
+__global__ void k_read_items(const uint64_t* __restrict__ owords, const uint8_t* __restrict__ olen, uint64_t n_o, int W, int K,
+                             Item* __restrict__ out) {
+  const uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (o >= n_o) return;
+  const int L = olen[o];
+  out[o] = Item{L >= K ? owords[o * uint64_t(W)] : cover_item_scatter(o), (o << 24) | (uint64_t(L) << 8)};
+}
+__global__ void k_cover_flag_items(const Item* __restrict__ items, uint64_t n, int K, uint8_t* __restrict__ flags) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = (int(items[i].id >> 8) & 255) >= K ? 1 : 0;
+}
+__global__ void k_cover_keys_items(const Item* __restrict__ items, const uint32_t* __restrict__ keep, uint64_t m, int K,
+                                   uint64_t* __restrict__ skeys, uint32_t* __restrict__ soid) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const Item it = items[keep[i]];
+  soid[i] = uint32_t((it.id & kItIdMask) >> 24);
+  skeys[i] = it.fw >> (64 - 2 * K);
+}
+// The oriented reads of at least cover_k bases in (string, length) order: their first K-mers (skeys) and numbers (soid), what
+// cover_index_build made from sort_records_impl's order with two gathers (k_flag_long_enough, k_cover_keys: 1 ms of random
+// bytes and rows) -- an item carries its length and its first 32 bases.  *done = false: the caller goes the old way.
+int items_cover_order(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, uint64_t n_o, int W, int cover_k, DevBuf<uint64_t>* premade,
+                      DevBuf<uint64_t>* skeys, DevBuf<uint32_t>* soid, uint64_t* m_out, bool* done) {
+  *done = false;
+  if (!n_o || n_o >= (1ull << 31) || cover_k > 32) return BG_OK;
+  DevBuf<Item> a, b;
+  if (premade && premade->p && premade->n == 2 * n_o) {  // (k_oriented_words wrote the items beside the reads: taken over)
+    a.ctx = ctx;
+    a.n = n_o;
+    a.p = reinterpret_cast<Item*>(premade->release_ownership());
+  } else {
+    BG_TRY(a.alloc(ctx, n_o));
+    k_read_items<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(owords, olen, n_o, W, cover_k, a.p);
+    BG_LAUNCH_CHECK();
+  }
+  BG_TRY(b.alloc(ctx, n_o));
+  const uint64_t whole[2] = {0, n_o};
+  BG_TRY(it_partition(ctx, a.p, b.p, n_o, 1, whole, 56));
+  std::vector<std::pair<uint64_t, uint64_t>> segs;
+  bool ok = true;
+  BG_TRY(items_sort_from_level1(ctx, a, b, n_o, owords, W, false, &segs, &ok));
+  if (!ok) return BG_OK;
+  DevBuf<uint8_t> flags;
+  DevBuf<uint32_t> keep;
+  uint64_t m = 0;
+  BG_TRY(flags.alloc(ctx, n_o));
+  k_cover_flag_items<<<cdiv(n_o, 256), 256, 0, ctx->stream>>>(b.p, n_o, cover_k, flags.p);
+  BG_LAUNCH_CHECK();
+  BG_TRY(compact_flagged<uint32_t>(ctx, flags.p, n_o, &keep, &m));
+  BG_TRY(skeys->alloc(ctx, m));
+  BG_TRY(soid->alloc(ctx, m));
+  if (m) {
+    k_cover_keys_items<<<cdiv(m, 256), 256, 0, ctx->stream>>>(b.p, keep.p, m, cover_k, skeys->p, soid->p);
+    BG_LAUNCH_CHECK();
+  }
+  BG_HIP(hipStreamSynchronize(ctx->stream));  // (the items go out of scope)
+  *m_out = m;
+  *done = true;
+  return BG_OK;
+}
+
 int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_seqset* ss, LocalPrev* lp, bool* done) {
   *done = false;
   const uint64_t n_rec = cc->n_rec;
@@ -1223,95 +1397,12 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
       BG_LAUNCH_CHECK();
     }
   }
-  // Buckets of a few thousand records at most are what the LDS sort takes: two levels (65 536 buckets) up to ~170 M records, a
-  // third on as many more bits as bring the average bucket back under 2 600 (a workgroup a bucket: many small buckets cost more
-  // than they sort) beyond (BG_ITEMS_LEVELS=3: a third level of four bits at any size, for the tests)
-  const char* lv = getenv("BG_ITEMS_LEVELS");
-  int extra = 0;
-  while (extra < 8 && (n_rec >> (16 + extra)) > 2600) ++extra;
-  if (lv && lv[0] == '3' && extra < 4) extra = 4;
-  const int levels = extra ? 3 : 2;
-  const int bucket_bits = 16 + extra;
-  const uint64_t n_buckets = 1ull << bucket_bits;
-  DevBuf<uint64_t> b8, b16, bnd;
-  BG_TRY(b8.alloc(ctx, 257));
-  BG_TRY(b16.alloc(ctx, 65537));
-  it_bounds_kernel<<<2, 256, 0, ctx->stream>>>(b.p, n_rec, 8, b8.p);
-  BG_LAUNCH_CHECK();
-  std::vector<uint64_t> h8(257);
-  BG_HIP(copy_d2h(ctx, h8.data(), b8.p, 257 * 8));
-  BG_TRY(it_partition(ctx, b.p, a.p, n_rec, 256, h8.data(), 48));
-  it_bounds_kernel<<<cdiv(65537, 256), 256, 0, ctx->stream>>>(a.p, n_rec, 16, b16.p);
-  BG_LAUNCH_CHECK();
-  std::vector<uint64_t> h_bounds;  // (on the host only when a stretch has to be named)
-  if (levels == 3) {
-    std::vector<uint64_t> h16(65537);
-    BG_HIP(copy_d2h(ctx, h16.data(), b16.p, 65537 * 8));
-    BG_TRY(it_partition(ctx, a.p, b.p, n_rec, 65536, h16.data(), 48 - extra));  // (eight bits from there: the upper ones are the segment's own)
-    BG_TRY(bnd.alloc(ctx, n_buckets + 1));
-    it_bounds_kernel<<<cdiv(n_buckets + 1, 256), 256, 0, ctx->stream>>>(b.p, n_rec, bucket_bits, bnd.p);
-    BG_LAUNCH_CHECK();
-    std::swap(a, b);  // (the partitioned items are in a again)
-  }
-  const uint64_t* d_bounds = levels == 3 ? bnd.p : b16.p;
-  ctx->toc(n_rec * 16 * 3 * uint64_t(levels));
-  // ---- every bucket in order of the first word, the runs of equal first words by the rest of their strings
-  DevBuf<uint8_t> status;
-  DevBuf<unsigned long long> ctr;  // [0] runs, [1] runs of more than four, [2] of more than 64, [3] buckets left as they were, [4] runs left
-  DevBuf<uint64_t> runs, more, longer;
-  const uint64_t run_cap = n_rec / 2 + 1, more_cap = n_rec / 5 + 1, long_cap = n_rec / 65 + 1;
-  BG_TRY(status.alloc(ctx, n_buckets));
-  BG_TRY(ctr.alloc(ctx, 8));
-  BG_TRY(runs.alloc(ctx, run_cap));
-  BG_TRY(more.alloc(ctx, more_cap));
-  BG_TRY(longer.alloc(ctx, long_cap));
-  BG_HIP(hipMemsetAsync(status.p, 0, n_buckets, ctx->stream));
-  BG_HIP(hipMemsetAsync(ctr.p, 0, 64, ctx->stream));
-  ctx->tic("items_bucket_sort");
-  k_items_bucket_sort<<<unsigned(n_buckets), IB_THREADS, 0, ctx->stream>>>(a.p, b.p, d_bounds, status.p, runs.p, ctr.p, run_cap, 64 - bucket_bits - IB_LOG2BINS);
-  BG_LAUNCH_CHECK();
-  ctx->toc(n_rec * 32);
-  // the runs: lanes, waves, workgroups -- each kernel strides over a list whose length the one before left on the device, and
-  // the host reads the counters once, behind all three (five read-backs and their idle gaps before)
-  ctx->tic("items_tie_runs");
+  std::vector<std::pair<uint64_t, uint64_t>> segs;  // stretches that went through the rows machinery (BG_ITEMS_CHECK's report)
   {
-    const unsigned small_grid = unsigned(std::min<uint64_t>(cdiv(run_cap, 256), 1u << 16));
-    k_items_tie_small<<<small_grid, 256, 0, ctx->stream>>>(b.p, runs.p, ctr.p, run_cap, cc->owords.p, W, more.p, ctr.p + 1, more_cap);
-    BG_LAUNCH_CHECK();
-    k_items_tie_wave<<<2048, 256, 0, ctx->stream>>>(b.p, more.p, ctr.p + 1, more_cap, cc->owords.p, W, longer.p, ctr.p + 2, long_cap);
-    BG_LAUNCH_CHECK();
-    // runs of 65 .. kItBlockRun members: a workgroup each; longer ones: the rows machinery
-    const uint32_t lds_members = kItBlockRun;
-    BG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_items_tie_block), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               int(lds_members * kMaxWords * 8)));
-    k_items_tie_block<<<256, 1024, size_t(lds_members) * kMaxWords * 8, ctx->stream>>>(b.p, longer.p, ctr.p + 2, long_cap, cc->owords.p, W, lds_members,
-                                                                                         kItBlockRun, ctr.p + 4);
-    BG_LAUNCH_CHECK();
+    bool ok = true;
+    BG_TRY(items_sort_from_level1(ctx, a, b, n_rec, cc->owords.p, W, true, &segs, &ok));
+    if (!ok) return BG_OK;
   }
-  unsigned long long h_ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  BG_HIP(copy_d2h(ctx, h_ctr, ctr.p, 64));
-  ctx->toc(h_ctr[0] * 2 * (16 + uint64_t(W) * 8));
-  a.reset();
-  if (h_ctr[0] > run_cap || h_ctr[1] > more_cap || h_ctr[2] > long_cap) return BG_OK;  // (cannot happen: a run has 2 / 5 / 65 members at least)
-  std::vector<std::pair<uint64_t, uint64_t>> segs;  // stretches left to the rows machinery: (start, count)
-  if (h_ctr[3]) {
-    std::vector<uint8_t> h_status(n_buckets);
-    BG_HIP(copy_d2h(ctx, h_status.data(), status.p, n_buckets));
-    h_bounds.resize(n_buckets + 1);
-    BG_HIP(copy_d2h(ctx, h_bounds.data(), d_bounds, (n_buckets + 1) * 8));
-    for (uint64_t v = 0; v < n_buckets; ++v)
-      if (h_status[size_t(v)]) segs.emplace_back(h_bounds[size_t(v)], h_bounds[size_t(v) + 1] - h_bounds[size_t(v)]);
-  }
-  if (h_ctr[4]) {
-    std::vector<uint64_t> h_long(h_ctr[2]);
-    BG_HIP(copy_d2h(ctx, h_long.data(), longer.p, h_ctr[2] * 8));
-    for (uint64_t rr : h_long)
-      if (uint32_t(rr >> 48) > kItBlockRun) segs.emplace_back(rr & ((1ull << 48) - 1), rr >> 48);
-  }
-  longer.reset();
-  runs.reset();
-  more.reset();
-  BG_TRY(items_subset_through_rows(ctx, b.p, segs, cc->owords.p, W));
   if (getenv("BG_ITEMS_CHECK")) {  // every neighbour pair compared through the reads (slow; stderr)
     DevBuf<unsigned long long> chk;
     BG_TRY(chk.alloc(ctx, 4));

@@ -115,7 +115,7 @@ def test_seqset_build_matches_oracle(ctx, seed, alphabet, K, rl, var):
 ROWS = {"BG_ITEMS_BUILD": "0"}  # the entries through rows (the switches below are that path's; the default is the items path)
 
 
-@pytest.mark.parametrize("env", [{}, {"BG_ITEMS_KEYS": "1"}, {"BG_VERIFY_CLOSURE": "1"}, {"BG_ITEMS_LEVELS": "3"}, {"BG_ITEMS_EMIT": "plain"}, ROWS, dict(ROWS, BG_VERIFY_CLOSURE="1"), dict(ROWS, BG_PREV_FULL_SEARCH="1"),
+@pytest.mark.parametrize("env", [{}, {"BG_ITEMS_KEYS": "1"}, {"BG_VERIFY_CLOSURE": "1"}, {"BG_ITEMS_LEVELS": "3"}, {"BG_ITEMS_EMIT": "plain"}, {"BG_COVER_ITEMS": "0"}, ROWS, dict(ROWS, BG_VERIFY_CLOSURE="1"), dict(ROWS, BG_PREV_FULL_SEARCH="1"),
                                  dict(ROWS, BG_NO_MEDIUM_GROUPS="1"), dict(ROWS, BG_SMALL_TIES_EARLY="1"), dict(ROWS, BG_ENTRIES_UNFUSED="1"),
                                  dict(ROWS, BG_PREV_MERGE="1"), dict(ROWS, BG_RADIX_ONESWEEP="1"), {"BG_PREV_SEARCH_ALL": "1"},
                                  {"BG_PREV_SEARCH_ALL": "1", "BG_VERIFY_CLOSURE": "1"}, dict(ROWS, BG_LOOKBACK_FLAT="1"),
