@@ -88,7 +88,14 @@ struct ItSegs {
   const uint32_t* tile0;  // nseg + 1 tile offsets
   int nseg;
 };
-__device__ __forceinline__ void it_locate(const ItSegs& sg, uint32_t tile, uint64_t* lo, uint64_t* hi, uint64_t* hist_base, uint32_t* nt,
+// (the same tables inside the kernel's arguments when there are at most 256 segments: no upload, no wait for it)
+struct ItSegsArg {
+  uint64_t seg0[257];
+  uint32_t tile0[257];
+  int nseg;
+};
+template <class Segs>
+__device__ __forceinline__ void it_locate(const Segs& sg, uint32_t tile, uint64_t* lo, uint64_t* hi, uint64_t* hist_base, uint32_t* nt,
                                           uint32_t* ti) {
   int a = 0, b = sg.nseg;
   while (b - a > 1) {
@@ -104,7 +111,8 @@ __device__ __forceinline__ void it_locate(const ItSegs& sg, uint32_t tile, uint6
   *hist_base = uint64_t(t0) * IT_BINS;
 }
 
-__global__ __launch_bounds__(IT_THREADS) void it_hist_kernel(const Item* __restrict__ items, ItSegs sg, int shift, uint32_t* __restrict__ hist) {
+template <class Segs>
+__global__ __launch_bounds__(IT_THREADS) void it_hist_kernel(const Item* __restrict__ items, const Segs sg, int shift, uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[IT_BINS];
   if (threadIdx.x < IT_BINS) h[threadIdx.x] = 0;
   __syncthreads();
@@ -135,7 +143,8 @@ __device__ __forceinline__ uint32_t it_block_excl_scan(uint32_t v, uint32_t* sm)
   return base + x - v;
 }
 
-__global__ __launch_bounds__(IT_THREADS) void it_scatter_kernel(const Item* __restrict__ in, Item* __restrict__ out, ItSegs sg, int shift,
+template <class Segs>
+__global__ __launch_bounds__(IT_THREADS) void it_scatter_kernel(const Item* __restrict__ in, Item* __restrict__ out, const Segs sg, int shift,
                                                                 const uint64_t* __restrict__ offs) {
   __shared__ Item stage[IT_TILE];
   __shared__ uint32_t h[IT_BINS];
@@ -775,22 +784,37 @@ static int it_partition(bg_ctx* ctx, const Item* in, Item* out, uint64_t n, uint
   h_tile[nseg] = uint32_t(t);
   const uint32_t ntiles = uint32_t(t);
   if (!ntiles) return BG_OK;
-  DevBuf<uint32_t> hist, seg_tile;
-  DevBuf<uint64_t> offs, seg0;
+  DevBuf<uint32_t> hist;
+  DevBuf<uint64_t> offs;
   BG_TRY(hist.alloc(ctx, size_t(IT_BINS) * ntiles));
   BG_TRY(offs.alloc(ctx, size_t(IT_BINS) * ntiles));
+  if (nseg <= 256) {  // the tables travel in the kernels' arguments (two waits for the stream less a pass)
+    ItSegsArg sg;
+    for (uint32_t b = 0; b <= 256; ++b) {
+      sg.seg0[b] = h_seg0[b < nseg ? b : nseg];
+      sg.tile0[b] = h_tile[b < nseg ? b : nseg];
+    }
+    sg.nseg = int(nseg);
+    it_hist_kernel<ItSegsArg><<<ntiles, IT_THREADS, 0, ctx->stream>>>(in, sg, shift, hist.p);
+    BG_LAUNCH_CHECK();
+    BG_TRY(exclusive_scan_u32_to_u64(ctx, hist.p, offs.p, uint64_t(IT_BINS) * ntiles, nullptr));
+    it_scatter_kernel<ItSegsArg><<<ntiles, IT_THREADS, 0, ctx->stream>>>(in, out, sg, shift, offs.p);
+    BG_LAUNCH_CHECK();
+    return BG_OK;  // (what goes out of scope here goes back to an arena that is ordered on the stream)
+  }
+  DevBuf<uint32_t> seg_tile;
+  DevBuf<uint64_t> seg0;
   BG_TRY(seg0.alloc(ctx, size_t(nseg) + 1));
   BG_TRY(seg_tile.alloc(ctx, size_t(nseg) + 1));
   BG_HIP(hipMemcpyAsync(seg0.p, h_seg0, (size_t(nseg) + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   BG_HIP(hipMemcpyAsync(seg_tile.p, h_tile.data(), (size_t(nseg) + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  BG_HIP(hipStreamSynchronize(ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));  // (the host tables go out of scope)
   const ItSegs sg{seg0.p, seg_tile.p, int(nseg)};
-  it_hist_kernel<<<ntiles, IT_THREADS, 0, ctx->stream>>>(in, sg, shift, hist.p);
+  it_hist_kernel<ItSegs><<<ntiles, IT_THREADS, 0, ctx->stream>>>(in, sg, shift, hist.p);
   BG_LAUNCH_CHECK();
   BG_TRY(exclusive_scan_u32_to_u64(ctx, hist.p, offs.p, uint64_t(IT_BINS) * ntiles, nullptr));
-  it_scatter_kernel<<<ntiles, IT_THREADS, 0, ctx->stream>>>(in, out, sg, shift, offs.p);
+  it_scatter_kernel<ItSegs><<<ntiles, IT_THREADS, 0, ctx->stream>>>(in, out, sg, shift, offs.p);
   BG_LAUNCH_CHECK();
-  BG_HIP(hipStreamSynchronize(ctx->stream));  // (the segment tables go out of scope)
   return BG_OK;
 }
 
