@@ -1,17 +1,21 @@
-// items_build.hip — the entry set from 16-byte ITEMS instead of materialised rows (first lead).
+// items_build.hip — the entry set from 16-byte ITEMS instead of materialised rows (the default build).
 //
 // A suffix record (oriented read r, offset j) of the exact cover travels as
 //     fw  = its first 32 bases (one word, zero padded), and
 //     id  = r << 24 | j << 16 | length << 8 | flags        (flags: bit 0 the suffix one base earlier is a record too,
-//                                                            bits 1-2 the base in front of it, bit 3 the read's last record)
-// and is put in order by two 256-way partition passes on the leading 8 + 8 bits of fw and one LDS sort per bucket of the
-// 65 536 that result; only items that tie on all 32 bases go back to the read for the rest of their string.  Nothing of
-// 48 bytes per record is written, sorted by index and gathered back (k_emit_records / radix passes / k_gather_dedup_build).
-//
-// What is here so far is the front half -- items, the two partition levels, the bucket bounds -- behind BG_ITEMS_PROBE=1,
-// which runs it beside the build (the build's result does not change) and reports the stages' times and the bucket sizes
-// the LDS sort will have to take.  The same strings as SURVEY rows D1-D5 / E (expand.cpp:285-380, builder.cpp:85-108) in
-// another order of work; no reference code has this shape.
+//                                                            bits 1-2 the base in front of it, bit 3 the read's last record;
+//                                                            bits 55..62: its LCP with its successor, bit 63: that note is set)
+// and is put in order by two 256-way partition passes on the leading bits of fw (the first makes the items from the reads as
+// it scatters them; a third pass beyond ~170 M records) and one LDS sort per bucket; only items that tie on all 32 bases go back
+// to the read for the rest of their string (k_items_tie_small / _wave / _block; what those cannot take goes through the rows
+// machinery as a subset).  Stream passes then drop the prefixes (k_items_keep), number and write the entries with their sizes,
+// shared lengths, local prev bits and the prefix directory's heads (k_items_entries), and search the tails the local rule
+// leaves through the entries' first words and the reads (k_prev_list_items).  Nothing of 48 bytes per record is written,
+// sorted by index and gathered back (k_emit_records / radix passes / k_gather_dedup_build: BG_ITEMS_BUILD=0), and no key table
+// is made in the step (seqset_ensure_keys makes it for the consumers that ask).  items_cover_order sorts the oriented reads
+// for the cover index with the same kernels (a read is the item of its suffix 0).
+// The same strings as SURVEY rows D1-D5 / E (expand.cpp:285-380, builder.cpp:85-108) in another order of work; no reference
+// code has this shape.  BG_ITEMS_PROBE=1 runs the front half beside the build and reports times and bucket sizes.
 #include "bg_device_funcs.h"
 #include "bg_internal.h"
 #include "compact.h"
