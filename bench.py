@@ -997,6 +997,11 @@ def main():
                 roofline["achieved"] = round(ach, 1)
                 roofline["frac"] = round(ach / HBM_PEAK_GBS, 4)
                 roofline["bytes_formula"] = "SURVEY.md 8(d): " + SURVEY_8D_FORMULA.get(roofline["kernel"], "")
+                # schema 2 (since round 5): `frac` / `achieved` price the kernel by the survey's bytes of its STAGE (which a stage's
+                # other kernels are charged with as well); `frac_bytes_moved` (= frac_kernel_layout) is what the kernel itself moves;
+                # the stage's bytes over the time of ALL its kernels is `stage_frac_survey_8d` -- the figure no kernel can flatter.
+                roofline["schema"] = 2
+                roofline["frac_bytes_moved"] = roofline["frac_kernel_layout"]
                 if roofline["kernel"].startswith("skm_"):
                     roofline["note"] = ("SURVEY 8(d) prices the k-mer stage as one 8-byte record per k-mer written and read once; this kernel is the "
                                         "writing half, but what it writes is super-k-mers (1.6 bytes a k-mer): the counters show fewer bytes than the "
@@ -1007,6 +1012,13 @@ def main():
                                "launches_per_step": t["launches"] / max(args.steps, 1),
                                "GBps": round(t["bytes"] / (t["ms"] * 1e-3) / 1e9, 1) if t["ms"] > 0 else None}
                    for t in sorted(timings, key=lambda t: -t["ms"])}
+        if roofline:
+            for stage, prefixes in STAGE_OF_FAMILY:
+                if roofline["kernel"].startswith(prefixes):
+                    row = stage_table(kernels, stats, args.steps).get(stage)
+                    if row:
+                        roofline["stage"] = stage
+                        roofline["stage_frac_survey_8d"] = row["frac_of_hbm_peak"]
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             cpu = cpu_baseline(ctx, args.cpu_sample_genome, args.coverage, args.read_len, args.seed, dev)

@@ -234,6 +234,7 @@ struct bg_seqset {
   // a build from items (items_build.hip): no key table yet -- every entry's first word and record (oriented read << 24 |
   // offset << 16 | ...), two words an entry, and the oriented reads the records point into; seqset_ensure_keys makes keys / pre2 from them the first time somebody needs them
   bg::DevBuf<uint64_t> erec, oreads;
+  std::mutex keys_mutex;  // seqset_ensure_keys: the first keyed access writes an object the API hands out as const
 };
 
 
@@ -322,8 +323,11 @@ int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p,
 // build_seqset.hip: the suffix records as rows from the cover stage's counts (the second half of suffix_records_impl)
 int suffix_rows_from_counts(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen,
                             DevBuf<uint64_t>* k0, int RS);
-// keys / pre2 of a seqset built from items, on demand (no-op when they are there or cannot be made)
+// keys / pre2 of a seqset built from items, on demand (no-op when they are there or cannot be made).  The first keyed access of
+// a fresh seqset is NOT const: it allocates from the seqset's own context (ctx only when the seqset has none) under keys_mutex.
 int seqset_ensure_keys(bg_ctx* ctx, bg_seqset* ss);
+// ... for an entry point that cannot work without them: BG_EINVAL (a seqset opened from a file holds no key table)
+int seqset_require_keys(bg_ctx* ctx, const bg_seqset* ss, const char* who);
 // items_build.hip: the front half of the items path (BG_ITEMS_PROBE=1), beside the build
 int items_probe(bg_ctx* ctx, const uint64_t* owords, const uint16_t* len, const uint32_t* cnt, const uint64_t* roff, uint64_t o_base,
                 uint64_t n_emit, int W, uint64_t n_rec);

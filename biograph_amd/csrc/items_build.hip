@@ -1531,22 +1531,35 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   return BG_OK;
 }
 
-int seqset_ensure_keys(bg_ctx* ctx, bg_seqset* ss) {
-  if (!ss || ss->keys.p || !ss->erec.p || !ss->oreads.p || !ss->W) return BG_OK;
+int seqset_ensure_keys(bg_ctx* caller, bg_seqset* ss) {
+  if (!ss) return BG_OK;
+  std::lock_guard<std::mutex> lk(ss->keys_mutex);
+  if (ss->keys.p || !ss->erec.p || !ss->oreads.p || !ss->W) return BG_OK;
+  // the buffers outlive the call: they come from the context the seqset lives in, not from a caller's temporary one
+  bg_ctx* ctx = ss->ctx ? ss->ctx : caller;
   const uint64_t n_ent = ss->n;
   const int W = ss->W;
   BG_HIP(hipSetDevice(ctx->device));
-  BG_TRY(ss->keys.alloc(ctx, n_ent * W));
-  BG_TRY(ss->pre2.alloc(ctx, n_ent * 2));
+  DevBuf<uint64_t> keys, pre2;
+  BG_TRY(keys.alloc(ctx, n_ent * W));
+  BG_TRY(pre2.alloc(ctx, n_ent * 2));
   if (n_ent) {
     ctx->tic("items_keys");
-    k_items_keys<<<cdiv(n_ent * uint64_t(W), 256), 256, 0, ctx->stream>>>(reinterpret_cast<const Item*>(ss->erec.p), n_ent, ss->oreads.p, W, ss->keys.p, ss->pre2.p);
+    k_items_keys<<<cdiv(n_ent * uint64_t(W), 256), 256, 0, ctx->stream>>>(reinterpret_cast<const Item*>(ss->erec.p), n_ent, ss->oreads.p, W, keys.p, pre2.p);
     BG_LAUNCH_CHECK();
     ctx->toc(n_ent * (uint64_t(W) * 8 * 2 + 16));
   }
   BG_HIP(hipStreamSynchronize(ctx->stream));
+  ss->pre2 = std::move(pre2);
+  ss->keys = std::move(keys);
   ss->erec.reset();
   ss->oreads.reset();
+  return BG_OK;
+}
+
+int seqset_require_keys(bg_ctx* ctx, const bg_seqset* ss, const char* who) {
+  BG_TRY(seqset_ensure_keys(ctx, const_cast<bg_seqset*>(ss)));
+  if (ss && ss->n && !(ss->keys.p && ss->W)) { set_error("%s: the seqset holds no key table (opened from a file?)", who); return BG_EINVAL; }
   return BG_OK;
 }
 

@@ -1151,6 +1151,7 @@ extern "C" int bg_seqset_boundary_rows(bg_ctx* ctx, const bg_seqset* ss, uint64_
   for (int w = 0; w <= W; ++w) { h_first_row[w] = 0; h_last_row[w] = 0; }
   h_first_row[W] = h_last_row[W] = ~0ull;
   if (!ss->n) return BG_OK;
+  BG_TRY(seqset_require_keys(ctx, ss, "bg_seqset_boundary_rows"));
   uint8_t l0 = 0, l1 = 0;
   BG_HIP(hipMemcpyAsync(h_first_row, ss->keys.p, W * 8, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipMemcpyAsync(h_last_row, ss->keys.p + (ss->n - 1) * W, W * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1217,6 +1218,7 @@ extern "C" int bg_seqset_mark_inputs(bg_ctx* ctx, const bg_seqset* ss, const uin
   if (ss->n) BG_HIP(hipMemsetAsync(d_marks, 0, uint64_t(n_inputs) * ss->n, ctx->stream));
   if (!n_rows) { BG_HIP(hipStreamSynchronize(ctx->stream)); return BG_OK; }
   DevBuf<uint32_t> dir, flags;
+  BG_TRY(seqset_require_keys(ctx, ss, "bg_seqset_mark_inputs"));
   int bases = 0;
   BG_TRY(flags.alloc(ctx, n_inputs + 1));
   BG_HIP(hipMemsetAsync(flags.p, 0, (n_inputs + 1) * 4, ctx->stream));
@@ -1242,7 +1244,8 @@ extern "C" int bg_seqset_entry_rows(bg_ctx* ctx, const bg_seqset* ss, uint64_t* 
   if (!ctx || !ss || (ss->n && !d_rows)) { set_error("bg_seqset_entry_rows: null argument"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));
   if (ss->n) {
-    if (!ss->keys.p || !ss->sizes.p) { set_error("bg_seqset_entry_rows: the seqset holds no keys"); return BG_EINVAL; }
+    BG_TRY(seqset_require_keys(ctx, ss, "bg_seqset_entry_rows"));
+    if (!ss->sizes.p) { set_error("bg_seqset_entry_rows: the seqset holds no sizes"); return BG_EINVAL; }
     k_records_to_rows<<<cdiv(ss->n * (ss->W + 1), 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->sizes.p, ss->n, ss->W, d_rows);
     BG_LAUNCH_CHECK();
   }
@@ -1254,6 +1257,7 @@ extern "C" int bg_seqset_tail_rows(bg_ctx* ctx, const bg_seqset* ss, uint64_t* d
   if (!ctx || !ss || (ss->n && !d_rows)) { set_error("bg_seqset_tail_rows: null argument"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));
   if (ss->n) {
+    BG_TRY(seqset_require_keys(ctx, ss, "bg_seqset_tail_rows"));
     k_tail_rows<<<cdiv(ss->n, 256), 256, 0, ctx->stream>>>(ss->keys.p, ss->sizes.p, ss->n, ss->W, d_rows);
     BG_LAUNCH_CHECK();
   }
@@ -1270,6 +1274,7 @@ extern "C" int bg_seqset_tail_rows2(bg_ctx* ctx, const bg_seqset* ss, uint32_t n
   if (ss->n >= (1ull << 47)) { set_error("bg_seqset_tail_rows2: too many entries"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));
   if (!ss->n) return BG_OK;
+  BG_TRY(seqset_require_keys(ctx, ss, "bg_seqset_tail_rows2"));
   const int W = ss->W;
   DevBuf<uint64_t> db;
   DevBuf<uint32_t> err;
@@ -1304,6 +1309,7 @@ extern "C" int bg_seqset_mark_need(bg_ctx* ctx, bg_seqset* ss, const uint64_t* d
   if (!ss->need.p) { set_error("bg_seqset_mark_need: the shard keeps no tail flags"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));
   if (!n_rows || !ss->n) return BG_OK;
+  BG_TRY(seqset_require_keys(ctx, ss, "bg_seqset_mark_need"));
   DevBuf<uint32_t> dir;
   int bases = 0;
   BG_TRY(build_prefix_dir_keys(ctx, ss->keys.p, ss->n, ss->W, &dir, &bases));
@@ -1320,6 +1326,7 @@ extern "C" int bg_seqset_tail_rows2_needed(bg_ctx* ctx, const bg_seqset* ss, uin
   BG_HIP(hipSetDevice(ctx->device));
   *n_out = 0;
   if (!ss->n) return BG_OK;
+  BG_TRY(seqset_require_keys(ctx, ss, "bg_seqset_tail_rows2_needed"));
   const int W = ss->W;
   DevBuf<uint32_t> pick, err;
   uint64_t m = 0;
@@ -1352,6 +1359,7 @@ extern "C" int bg_seqset_tail_rows_full(bg_ctx* ctx, const bg_seqset* ss, const 
   BG_HIP(hipSetDevice(ctx->device));
   *n_out = 0;
   if (!n) return BG_OK;
+  BG_TRY(seqset_require_keys(ctx, ss, "bg_seqset_tail_rows_full"));
   DevBuf<uint32_t> pick;
   uint64_t m = 0;
   BG_TRY(compact_flagged<uint32_t>(ctx, d_need, n, &pick, &m));
@@ -1372,6 +1380,7 @@ extern "C" int bg_seqset_apply_tails2(bg_ctx* ctx, bg_seqset* ss, const uint64_t
   BG_HIP(hipSetDevice(ctx->device));
   if (!ss->bits[0].p) BG_TRY(alloc_prev_bits(ctx, ss));
   if (!n_rows) return BG_OK;
+  BG_TRY(seqset_require_keys(ctx, ss, "bg_seqset_apply_tails2"));
   DevBuf<uint32_t> err;
   BG_TRY(err.alloc(ctx, 1));
   BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
@@ -1390,6 +1399,7 @@ extern "C" int bg_seqset_apply_tails(bg_ctx* ctx, bg_seqset* ss, const uint64_t*
   BG_HIP(hipSetDevice(ctx->device));
   if (!ss->bits[0].p) BG_TRY(alloc_prev_bits(ctx, ss));
   if (!n_rows) return BG_OK;
+  BG_TRY(seqset_require_keys(ctx, ss, "bg_seqset_apply_tails"));
   DevBuf<uint32_t> err;
   BG_TRY(err.alloc(ctx, 1));
   BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));

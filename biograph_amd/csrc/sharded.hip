@@ -841,15 +841,26 @@ static int create_sharded_impl(bg_ctx* ctx, bg_comm* comm, const uint8_t* d_seq,
     // every rank takes a copy (one all-gather) and corrects its reads with no further exchange, as the single-GPU build does
     // -- 288 GB of HBM is what makes that the cheap way.  Otherwise (BG_SHARD_KMERSET=routed forces it) they stay with
     // their owners and the correction asks them (correct_routed).
-    std::vector<uint64_t> kept_all;
-    BG_TRY(gather_u64(comm, {my_kept}, &kept_all));
-    uint64_t total_kept = 0;
-    for (uint64_t v : kept_all) total_kept += v;
+    // The verdict is a collective one: every rank sees every rank's device size and switch and derives the same answer (the
+    // smallest device bounds the copy; a rank that forces "routed" wins over one that forces "gathered") -- ranks deciding each on
+    // its own hipMemGetInfo / getenv would enter different collectives.
     size_t free_b = 0, total_b = 0;
     BG_HIP(hipMemGetInfo(&free_b, &total_b));
     const char* where = getenv("BG_SHARD_KMERSET");
-    const bool forced_routed = where && !strcmp(where, "routed"), forced_gathered = where && !strcmp(where, "gathered");
-    gathered_set = !forced_routed && (forced_gathered || total_kept * 8 * 4 <= uint64_t(total_b) / 16);  // (keys + hash table + flags)
+    const uint64_t my_force = where && !strcmp(where, "routed") ? 1 : where && !strcmp(where, "gathered") ? 2 : 0;
+    std::vector<uint64_t> verdict_in;
+    BG_TRY(gather_u64(comm, {my_kept, uint64_t(total_b), my_force}, &verdict_in));
+    std::vector<uint64_t> kept_all(P);
+    uint64_t total_kept = 0, min_total_b = ~0ull;
+    bool forced_routed = false, forced_gathered = false;
+    for (int r = 0; r < P; ++r) {
+      kept_all[r] = verdict_in[size_t(r) * 3];
+      total_kept += kept_all[r];
+      min_total_b = std::min(min_total_b, verdict_in[size_t(r) * 3 + 1]);
+      forced_routed |= verdict_in[size_t(r) * 3 + 2] == 1;
+      forced_gathered |= verdict_in[size_t(r) * 3 + 2] == 2;
+    }
+    gathered_set = !forced_routed && (forced_gathered || total_kept * 8 * 4 <= min_total_b / 16);  // (keys + hash table + flags)
     if (!gathered_set) {
       // the owner keeps its k-mers (hash set) and settles the records its counting tables gave up on
       BG_TRY(bg_kmerset_build_hash(ctx, H.owned));

@@ -76,3 +76,55 @@ def test_repeats_through_items_equal_rows_and_oracle(genome, copies, element):
     assert len(want) >= 15
     assert rows["n"] == len(oent) and rows["parts"] == want, ("rows", [k for k in want if rows["parts"].get(k) != want[k]])
     assert items["n"] == len(oent) and items["parts"] == want, ("items", [k for k in want if items["parts"].get(k) != want[k]])
+
+
+def test_shard_entry_points_on_a_fresh_create():
+    """A seqset straight from bg_create holds no key table (the items path makes it on demand): the exported shard entry
+    points that read keys -- boundary rows, entry rows, tail rows -- must make it themselves instead of reading a null
+    pointer, from two threads at once as well, and agree with the entries' strings."""
+    import threading
+    import ctypes as C
+    import numpy as np
+    import biograph_amd as bg
+    from biograph_amd import capi
+    from tests import util
+    reads = util.synth_reads(3, genome_len=4000, n_reads=1500, read_len=100, err=0.003, n_rate=0.0)
+    ctx = bg.Context(0)
+    ss, _ = ctx.create(reads, kmer_size=30, min_kmer_count=3)
+    L = capi.lib()
+    n = ss.size()
+    assert n > 0
+    W = L.bg_seqset_words(ss.h)
+    assert W == 4
+    first = [np.zeros(W + 1, np.uint64) for _ in range(2)]
+    last = [np.zeros(W + 1, np.uint64) for _ in range(2)]
+    rc = [None, None]
+
+    def call(i):  # the first keyed access of a fresh seqset from two host threads
+        rc[i] = L.bg_seqset_boundary_rows(ctx.h, ss.h, capi.np_ptr(first[i]), capi.np_ptr(last[i]))
+
+    th = [threading.Thread(target=call, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert rc == [0, 0], capi.last_error() if hasattr(capi, "last_error") else rc
+    assert (first[0] == first[1]).all() and (last[0] == last[1]).all()
+    rows = bg.DeviceArray(ctx, n * (W + 1) * 8)
+    capi.check(L.bg_seqset_entry_rows(ctx.h, ss.h, C.c_void_p(rows.ptr)))
+    h = rows.to_numpy(np.uint64, n * (W + 1)).reshape(n, W + 1)
+    ents = ss.entries()
+
+    def decode(row):
+        ln = int(row[W]) & 0xff
+        return "".join("ACGT"[(int(row[j // 32]) >> (62 - 2 * (j % 32))) & 3] for j in range(ln))
+
+    for i in (0, 1, n // 2, n - 1):
+        assert decode(h[i]) == ents[i]
+    assert decode(first[0]) == ents[0] and decode(last[0]) == ents[-1]
+    capi.check(L.bg_seqset_tail_rows(ctx.h, ss.h, C.c_void_p(rows.ptr)))
+    t = rows.to_numpy(np.uint64, n * (W + 1)).reshape(n, W + 1)
+    for i in (0, n // 3, n - 1):
+        assert decode(t[i]) == ents[i][1:]
+    rows.free()
+    ctx.close()
