@@ -313,7 +313,7 @@ def push_tracer_leg(ss, rm, ref_map_dev, genome, args, chunks=2, chunk_size=1_00
 def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
     """Overlap-walk throughput on the seqset just built (N=1 only, outside the build's timed region):
     ref_map::build over both strands of the reference haplotype (2 x G dependent push_front_drop calls in
-    4096-base chains) and branch_discover::on_trace over the whole reference in 1000-base assemblies
+    chains of a length the library chooses: 1024 bases here) and branch_discover::on_trace over the whole reference in 1000-base assemblies
     (every 1-base branch = a candidate variant site)."""
     import ctypes as C
     import torch
@@ -342,7 +342,7 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
     vp = C.c_void_p
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    capi.check(L.bg_ref_map_build(ctx.h, ss.h, vp(genome.data_ptr()), 1, es, ez, 4096, vp(out.data_ptr())))
+    capi.check(L.bg_ref_map_build(ctx.h, ss.h, vp(genome.data_ptr()), 1, es, ez, 0, vp(out.data_ptr())))
     torch.cuda.synchronize()
     t_ref = time.perf_counter() - t0
     marked = int((out[:n] & 63 != 0).sum().item())
@@ -355,7 +355,7 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
     if count_walk:
         out2 = torch.empty_like(out)
         capi.check(L.bg_walk_counters(ctx.h, 1, None))
-        capi.check(L.bg_ref_map_build(ctx.h, ss.h, vp(genome.data_ptr()), 1, es, ez, 4096, vp(out2.data_ptr())))
+        capi.check(L.bg_ref_map_build(ctx.h, ss.h, vp(genome.data_ptr()), 1, es, ez, 0, vp(out2.data_ptr())))
         capi.check(L.bg_walk_counters(ctx.h, 0, cnt2))
         ref_counts = (int(cnt2[0]), int(cnt2[1]))
         del out2
@@ -493,7 +493,7 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
              "achieved": round(alg / seconds / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(alg / seconds / 1e9 / HBM_PEAK_GBS, 4), "seconds": round(seconds, 4),
              "limiter": "dependent random 64-byte sectors: a chain is one push_front_drop after the other (2 rank look-ups of 3 "
-                        "words each + sizes per call), %d chains in flight" % (2 * (G // 4096 + 1) if kernel == "k_ref_map_chains" else (ns if kernel == "k_push_to_pair_trace" else na))}
+                        "words each + sizes per call), %d chains in flight" % (2 * (G // 1024 + 1) if kernel == "k_ref_map_chains" else (ns if kernel == "k_push_to_pair_trace" else na))}
         r.update(pmc_traffic_walk(kernel, seconds * 1e3))
         return r
     roof_ref = walk_roofline("k_ref_map_chains", ref_counts, t_ref)

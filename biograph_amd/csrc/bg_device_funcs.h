@@ -878,6 +878,71 @@ struct SeqsetView {
     sa = (sa >> 8) + (sa & 0xff);
     return accum[b][group] + sa + bc;
   }
+  // bit 8 i of the result = byte i of x is below v (0 <= v <= 255; exact in every byte: two passes over 16-bit lanes, so that no
+  // borrow crosses a byte)
+  static BG_HD uint64_t bytes_below(uint64_t x, unsigned v) {
+    const uint64_t K = 0x0001000100010001ull, B = 0x0100010001000100ull, M = 0x00ff00ff00ff00ffull;
+    const uint64_t te = ((x & M) | B) - uint64_t(v) * K, to = (((x >> 8) & M) | B) - uint64_t(v) * K;
+    return ((~te >> 8) & K) | (((~to >> 8) & K) << 8);
+  }
+#if (defined(__HIP_DEVICE_COMPILE__) && !defined(BG_BYTE_SCAN)) || defined(BG_WORD_SCAN_HOST)  // (BG_BYTE_SCAN: tools/build_variant.sh, A/B)
+  // The two searches over `shared` that the drop loop of push_front_drop runs, eight entries a load: a drop widens a range by
+  // the entries that share the shorter context -- tens of them under 30x coverage -- and one byte a DEPENDENT load was what a
+  // walk step spent most of its time in (branch trace: 0.7 drop iterations a call).  `shared` is 8-byte aligned and its
+  // allocation a multiple of 8 bytes (the arena rounds to 512), so the word holding a valid entry is readable; bytes past n
+  // in it never win (forward: a hit at or past n means none before it; backward: they lie above the start).
+  // first pos >= start with shared[pos] < v, or n
+  BG_HD uint64_t next_forward_lt(uint64_t pos, unsigned v) const {
+    const uint64_t* sh8 = reinterpret_cast<const uint64_t*>(shared);
+    uint64_t p = pos;
+    while (p < n) {
+      const uint64_t f = bytes_below(sh8[p >> 3], v) >> (8 * unsigned(p & 7));
+      if (f) {
+        const uint64_t r = p + uint64_t(__builtin_ctzll(f) >> 3);
+        return r < n ? r : n;
+      }
+      p = (p | 7) + 1;
+      if ((p & 63) == 0) {  // whole blocks of 64 (4096) entries without a value below v are skipped through the min index
+        uint64_t f1 = p >> 6;
+        while (p < n) {
+          if ((f1 & 63) == 0 && min2[f1 >> 6] >= v) { f1 += 64; p = f1 << 6; continue; }
+          if (min1[f1] >= v) { ++f1; p = f1 << 6; continue; }
+          break;
+        }
+      }
+    }
+    return n;
+  }
+  // last pos <= start with shared[pos] < v, or 0
+  BG_HD uint64_t next_backward_lt(uint64_t pos, unsigned v) const {
+    const uint64_t* sh8 = reinterpret_cast<const uint64_t*>(shared);
+    uint64_t p = pos;
+    for (;;) {
+      const unsigned k = unsigned(p & 7);
+      const uint64_t f = bytes_below(sh8[p >> 3], v) << (8 * (7 - k));  // byte k on top, the bytes above it gone
+      if (f) return p - uint64_t(__builtin_clzll(f) >> 3);
+      if (p < 8) return 0;
+      p = (p & ~7ull) - 1;
+      if ((p & 63) == 63) {
+        uint64_t f1 = p >> 6;
+        for (;;) {
+          if ((f1 & 63) == 63 && min2[f1 >> 6] >= v) {
+            if (f1 < 64) return 0;
+            f1 -= 64;
+            continue;
+          }
+          if (min1[f1] >= v) {
+            if (f1 == 0) return 0;
+            --f1;
+            continue;
+          }
+          break;
+        }
+        p = (f1 << 6) + 63;
+      }
+    }
+  }
+#else
   // first pos >= start with shared[pos] < v, or n
   BG_HD uint64_t next_forward_lt(uint64_t pos, unsigned v) const {
     if (shared[pos] < v) return pos;
@@ -915,6 +980,7 @@ struct SeqsetView {
     }
     return pos;
   }
+#endif
   BG_HD void push_front(uint64_t begin, uint64_t end, uint32_t size, int b, uint64_t* ob, uint64_t* oe,
                         uint32_t* os) const {  // seqset.cpp:319-338
     uint64_t nb = fixed[b] + count(b, begin), ne = fixed[b] + count(b, end);
@@ -932,6 +998,10 @@ struct SeqsetView {
     if (walk_counters) atomicAdd(&walk_counters[0], 1ull);
 #endif
     if (octx < min_ctx) return;
+    // (Measured and put away: deciding a failing base up front from the widest range the loop may reach -- the entries that
+    // share min_ctx bases -- instead of giving the context up level by level.  A failing base nearly always fails in the loop's
+    // FIRST iteration, its two neighbours sharing fewer than min_ctx bases, so the extra searches and rank look-ups only cost:
+    // branch trace 57.6 -> 63.4 ms.)
     while (sb == se || (sb + 1 == se && sizes[fx + sb] < octx + 1)) {
 #ifdef __HIP_DEVICE_COMPILE__
       if (walk_counters) atomicAdd(&walk_counters[1], 1ull);

@@ -115,8 +115,8 @@ __device__ __forceinline__ void pop_front_range(const SeqsetView& v, uint64_t b0
   }
   const uint32_t ctx_len = s0 - 1;
   uint64_t nb = lo, ne = lo + 1;
-  while (nb && v.shared[nb] >= ctx_len) --nb;
-  while (ne < v.n && v.shared[ne] >= ctx_len) ++ne;
+  nb = v.next_backward_lt(nb, ctx_len);  // (the entries around `lo` that share the shorter context, eight a load)
+  ne = v.next_forward_lt(ne, ctx_len);
   *ob = nb;
   *oe = ne;
   *os = ctx_len;
@@ -890,7 +890,18 @@ extern "C" int bg_ref_map_build(bg_ctx* ctx, const bg_seqset* ss, const uint8_t*
     return BG_EINVAL;
   }
   BG_HIP(hipSetDevice(ctx->device));
-  if (chain_bases < 256) chain_bases = 4096;
+  // One lane per chain and a dozen dependent loads per base: what bounds the kernel is how many chains are in flight, not
+  // bytes.  4096-base chains over a chr20 (both strands) were 31 000 lanes on a chip that holds 500 000; shorter chains pay
+  // their 256-base warm-up more often and still finish sooner -- 25.9 ms at 4096, 20.9 at 2048, 18.4 at 1024, 21.8 at 512,
+  // 24.4 at 384 (profiles/r06_walk_ab.txt).  0 = about 130 000 chains, never shorter than 1024 bases; BG_REFMAP_CHAIN
+  // overrides whatever the caller passes (measurements).
+  if (const char* e = getenv("BG_REFMAP_CHAIN")) { if (atoi(e) >= 256) chain_bases = uint32_t(atoi(e)); }
+  if (chain_bases < 256) {
+    uint64_t bases = 0;
+    for (uint64_t x = 0; x < n_extents; ++x) bases += h_ext_size[x];
+    const uint64_t want = std::max<uint64_t>(1024, (2 * bases) / 131072);
+    chain_bases = uint32_t(std::min<uint64_t>(4096, (want + 255) / 256 * 256));
+  }
   std::vector<uint64_t> cstart;
   std::vector<uint32_t> clen, cpre;
   std::vector<int8_t> cdir;
@@ -1532,6 +1543,10 @@ extern "C" int bg_propagate_from_end_batch(bg_ctx* ctx, const bg_seqset* ss, con
 // 4 = range buffer; the host resumes from the last recorded frontier).  One wave per assembly; a step is
 // 64 concurrent push_front_drop calls (4 bases x 16 ranges).  The frontier after every step is recorded
 // for the host's mate / anchor bookkeeping (:289-342), which cuts the path but never changes it.
+// SEEN_LDS: the per-trace list of dropped ranges (m_seen_ranges) lives in the workgroup's LDS (seen_cap x 20 bytes a wave)
+// instead of global memory: a step with a dropped candidate was three device-scope loads a lane, a store and a
+// __threadfence -- round trips to L2 in a kernel that is nothing but dependent round trips.
+template <bool SEEN_LDS>
 __global__ __launch_bounds__(256) void k_push_to_pair_trace(
     SeqsetView v, uint64_t na, const uint32_t* __restrict__ foff, const uint64_t* __restrict__ fbegin,
     const uint64_t* __restrict__ fend, const uint32_t* __restrict__ fsize, uint32_t min_overlap, uint32_t max_steps,
@@ -1555,9 +1570,16 @@ __global__ __launch_bounds__(256) void k_push_to_pair_trace(
   const int r = lane & 15, b = lane >> 4;
   uint32_t steps = 0, nseen = 0, nr = 0;
   int why = 0;
+  extern __shared__ uint64_t seen_lds[];  // SEEN_LDS: per wave seen_cap begins, seen_cap ends, seen_cap sizes
   uint64_t* sb = seen_b + a * uint64_t(seen_cap);
   uint64_t* se = seen_e + a * uint64_t(seen_cap);
   uint32_t* ssz = seen_s + a * uint64_t(seen_cap);
+  if (SEEN_LDS) {
+    const uint32_t per_wave = seen_cap * 2 + (seen_cap + 1) / 2;  // in 8-byte words
+    sb = seen_lds + uint32_t(threadIdx.x >> 6) * per_wave;
+    se = sb + seen_cap;
+    ssz = reinterpret_cast<uint32_t*>(se + seen_cap);
+  }
   for (;;) {
     if (!__ballot(cv)) { why = 0; break; }
     if (steps >= max_steps) { why = 2; break; }
@@ -1596,6 +1618,18 @@ __global__ __launch_bounds__(256) void k_push_to_pair_trace(
       dmask &= dmask - 1;
       Tri t{__shfl(c.b, j, 64), __shfl(c.e, j, 64), __shfl(c.s, j, 64)};
       bool hit = false;
+      if (SEEN_LDS) {
+        for (uint32_t i = lane; i < nseen; i += 64) hit |= sb[i] == t.b && se[i] == t.e && ssz[i] == t.s;
+        if (__ballot(hit)) { dup = true; break; }
+        if (nseen >= seen_cap) { full = true; break; }
+        if (lane == 0) { sb[nseen] = t.b; se[nseen] = t.e; ssz[nseen] = t.s; }
+        ++nseen;
+        // (one wave writes and reads its own list: LDS operations of a wave complete in order; the compiler must not move them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        continue;
+      }
       for (uint32_t i = lane; i < nseen; i += 64)  // agent-scope loads: lane 0's stores below must be seen
         hit |= __hip_atomic_load(&sb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == t.b &&
                __hip_atomic_load(&se[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == t.e &&
@@ -1644,14 +1678,24 @@ extern "C" int bg_push_to_pair_trace_batch(bg_ctx* ctx, const bg_seqset* ss, uin
   DevBuf<uint32_t> err, seen_s;
   DevBuf<uint64_t> seen_b, seen_e;
   BG_TRY(err.alloc(ctx, 1));
-  BG_TRY(seen_b.alloc(ctx, n_asm * seen_cap));
-  BG_TRY(seen_e.alloc(ctx, n_asm * seen_cap));
-  BG_TRY(seen_s.alloc(ctx, n_asm * seen_cap));
   BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
-  ctx->tic("walk_push_to_pair_trace");
-  k_push_to_pair_trace<<<cdiv(n_asm, 4), 256, 0, ctx->stream>>>(
-      make_view(ss), n_asm, d_foff, d_begin, d_end, d_size, min_overlap, max_steps, range_cap, seen_cap, seen_b.p,
-      seen_e.p, seen_s.p, d_n_steps, d_reason, d_bases, d_counts, d_n_ranges, d_rbegin, d_rend, d_rsize, err.p);
+  // the seen lists in LDS while four waves' lists leave room for eight workgroups a CU (20 KB each: seen_cap <= 256)
+  const size_t lds = size_t(4) * (size_t(seen_cap) * 2 + (size_t(seen_cap) + 1) / 2) * 8;
+  const char* sl = getenv("BG_SEEN_GLOBAL");
+  if (lds <= 20480 && !(sl && sl[0] == '1')) {
+    ctx->tic("walk_push_to_pair_trace");
+    k_push_to_pair_trace<true><<<cdiv(n_asm, 4), 256, lds, ctx->stream>>>(
+        make_view(ss), n_asm, d_foff, d_begin, d_end, d_size, min_overlap, max_steps, range_cap, seen_cap, nullptr, nullptr, nullptr,
+        d_n_steps, d_reason, d_bases, d_counts, d_n_ranges, d_rbegin, d_rend, d_rsize, err.p);
+  } else {
+    BG_TRY(seen_b.alloc(ctx, n_asm * seen_cap));
+    BG_TRY(seen_e.alloc(ctx, n_asm * seen_cap));
+    BG_TRY(seen_s.alloc(ctx, n_asm * seen_cap));
+    ctx->tic("walk_push_to_pair_trace");
+    k_push_to_pair_trace<false><<<cdiv(n_asm, 4), 256, 0, ctx->stream>>>(
+        make_view(ss), n_asm, d_foff, d_begin, d_end, d_size, min_overlap, max_steps, range_cap, seen_cap, seen_b.p,
+        seen_e.p, seen_s.p, d_n_steps, d_reason, d_bases, d_counts, d_n_ranges, d_rbegin, d_rend, d_rsize, err.p);
+  }
   BG_LAUNCH_CHECK();
   ctx->toc(0);
   uint32_t h_err = 0;

@@ -254,7 +254,8 @@ int bg_push_to_pair_trace_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n_asm
 /* ref_map::build (variants/ref_map.cpp:72-185): marks seqset entries that are full-entry matches of the
  * reference (both strands).  d_ref_codes = reference bases 0..3; extents = N-free supercontigs
  * (flat_ref index, bio_base/flat_ref.h).  d_out[n] = [fwd_flag:1|rev_flag:1|count:6 saturating]
- * (ref_map.h:49-53).  chain_bases = bases per GPU chain (0 = default 4096). */
+ * (ref_map.h:49-53).  chain_bases = bases per GPU chain (0 = chosen from the reference's size so that enough chains are in flight: 1024..4096;
+ * the result does not depend on it). */
 int bg_ref_map_build(bg_ctx* ctx, const bg_seqset* ss, const uint8_t* d_ref_codes, uint64_t n_extents,
                      const uint64_t* h_ext_start, const uint64_t* h_ext_size, uint32_t chain_bases,
                      uint8_t* d_out);

@@ -102,9 +102,10 @@ def test_builder_test_known_answers():
             assert len(got) == n
 
 
-def test_push_front_drop_matches_oracle_on_golden(golden_dir):
+@pytest.mark.parametrize("word_scan", [False, True])
+def test_push_front_drop_matches_oracle_on_golden(golden_dir, word_scan):
     import ctypes as C
-    hh = util.host_harness()
+    hh = util.host_harness(word_scan)
     d = O.load_seqset_zip(golden_dir + "/e_coli_10000snp/seqset")
     ss = O.Seqset.from_arrays(d["sizes"], d["shared"], d["bits"])
     n = d["n"]
@@ -115,10 +116,12 @@ def test_push_front_drop_matches_oracle_on_golden(golden_dir):
     size = d["sizes"][begin.astype(np.int64)].astype(np.uint32)
     base = rng.integers(0, 4, 4000).astype(np.uint8)
     minctx = rng.integers(0, 36, 4000).astype(np.uint32)
+    shared_padded = np.zeros(n + 16, np.uint8)  # (the word-wise searches read the whole 8-byte word an entry lies in)
+    shared_padded[:n] = d["shared"]
     for rounds in range(4):
         ob, oe, osz = ss.push_front_drop(begin, end, size, base, minctx)
         sz8 = d["sizes"].astype(np.uint8)
-        sh8 = d["shared"].astype(np.uint8)
+        sh8 = shared_padded[:n]
         arrs = {w: [ss.prev(b, w) for b in range(4)] for w in ("bits", "subaccum", "accum")}
         ptrs = {w: (C.c_void_p * 4)(*[a.ctypes.data for a in arrs[w]]) for w in arrs}
         hb = np.zeros(len(begin), np.uint64)

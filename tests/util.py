@@ -6,23 +6,24 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_HH = None
+_HH = {}
 
 u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
 u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
 u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 
 
-def host_harness():
-    """g++ build (ASan/UBSan) of the kernels' per-thread logic; test infrastructure only."""
-    global _HH
-    if _HH is not None:
-        return _HH
+def host_harness(word_scan=False):
+    """g++ build of the kernels' per-thread logic; test infrastructure only.  word_scan: the walk's searches over `shared`
+    and the drop loop's early exit as the DEVICE compiles them (BG_WORD_SCAN_HOST; the caller pads `shared` to whole words)."""
+    if word_scan in _HH:
+        return _HH[word_scan]
     src = os.path.join(ROOT, "tests", "host_harness.cpp")
     hdr = os.path.join(ROOT, "biograph_amd", "csrc", "bg_device_funcs.h")
-    out = os.path.join(ROOT, "tests", "libhostharness.so")
+    out = os.path.join(ROOT, "tests", "libhostharness_word.so" if word_scan else "libhostharness.so")
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", out, src])
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall"] + (["-DBG_WORD_SCAN_HOST"] if word_scan else []) +
+                              ["-o", out, src])
     L = C.CDLL(out)
     vp = C.c_void_p
     L.hh_correct_reads.argtypes = [u64p, C.c_uint64, C.c_int, u8p, u64p, C.c_uint64, C.c_uint32, C.c_uint32,
@@ -37,7 +38,7 @@ def host_harness():
     L.hh_entries_free.argtypes = [vp]
     L.hh_push_front_drop.argtypes = [C.c_uint64, u8p, u8p, C.c_void_p, C.c_void_p, C.c_void_p, u64p, C.c_uint64,
                                      u64p, u64p, u32p, u8p, u32p, u64p, u64p, u32p]
-    _HH = L
+    _HH[word_scan] = L
     return L
 
 
