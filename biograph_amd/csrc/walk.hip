@@ -392,12 +392,67 @@ __global__ __launch_bounds__(256) void k_branch_trace(SeqsetView v, uint64_t na,
                                                       uint64_t* __restrict__ oute, uint32_t* __restrict__ outs,
                                                       uint32_t* __restrict__ err) {
   const int lane = threadIdx.x & 63;
-  uint64_t a = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  if (a >= na) return;
+  // A wave takes 16 consecutive assemblies.  A frontier never grows along a trace (the next one is the reference base's
+  // pushes of this one's ranges, less duplicates and containers), and nearly every trace starts from ONE range: then four
+  // lanes -- one a base -- are an assembly and the wave walks all 16 side by side.  The kernel is a chain of dependent
+  // loads (three round trips a step), so what counts is how many chains the chip holds: one assembly a wave were 6 000 of
+  // 64 443 at a time, ten rounds of 1 256 steps; sixteen a wave are all of them at once (57.6 -> ? ms on the bench's chr20).
+  // A group with a wider frontier in it takes the assemblies one after the other, a wave each, as before.
+  const uint64_t a0 = (uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16;
+  if (a0 >= na) return;
+  {
+    const int sub = lane >> 2, p = lane & 3;  // p = pushed (rc) base
+    const uint64_t a = a0 + uint64_t(sub);
+    const bool act = a < na;
+    const uint32_t lo = act ? foff[a] : 0, hi = act ? foff[a + 1] : 0;
+    if (__all(hi - lo <= 1u)) {
+      Tri cur{0, 0, 0};
+      bool cv = hi > lo;
+      if (cv) { cur.b = fbegin[lo]; cur.e = fend[lo]; cur.s = fsize[lo]; }
+      cv = cv && cur.b < cur.e && cur.e <= v.n;
+      const uint64_t s0 = act ? soff[a] : 0, s1 = act ? soff[a + 1] : 0;
+      uint32_t nev = 0;
+      for (uint64_t step = 0;; ++step) {
+        const bool live = s0 + step < s1;
+        if (!__any(live)) break;
+        const int rc_ref = live ? 3 - int(seq[s0 + step] & 3) : 0;
+        uint64_t ob = 0, oe = 0;
+        uint32_t os = 0;
+        if (live && cv) v.push_front_drop(cur.b, cur.e, cur.s, p, p == rc_ref ? 0u : min_overlap, &ob, &oe, &os);
+        const bool valid = oe > ob;
+        const uint32_t nib = uint32_t(__ballot(valid) >> (sub * 4)) & 0xfu;  // which of the four bases extend
+        if (live) {
+          for (int b = 0; b < 4; ++b) {  // :41-68 alternatives in base order
+            const int rc_b = 3 - b;
+            if (rc_b == rc_ref) continue;
+            if ((nib >> rc_b) & 1u) {
+              if (p == 0 && nev < ev_cap) {
+                ev_off[a * ev_cap + nev] = uint32_t(step);
+                ev_base[a * ev_cap + nev] = uint8_t(b);
+              }
+              ++nev;
+              break;
+            }
+          }
+        }
+        const int src = sub * 4 + rc_ref;
+        const uint64_t nb = __shfl(ob, src, 64), ne = __shfl(oe, src, 64);
+        const uint32_t ns = __shfl(os, src, 64);
+        if (live) { cur.b = nb; cur.e = ne; cur.s = ns; cv = ne > nb; }
+      }
+      if (act && p == 0) {
+        if (cv) { outb[a * kFrontierMax] = cur.b; oute[a * kFrontierMax] = cur.e; outs[a * kFrontierMax] = cur.s; }
+        n_ev[a] = nev;
+        n_out[a] = cv ? 1 : 0;
+      }
+      return;
+    }
+  }
+  for (uint64_t a = a0; a < a0 + 16 && a < na; ++a) {
   uint32_t lo = foff[a], hi = foff[a + 1];
   if (hi - lo > uint32_t(kFrontierMax)) {
     if (lane == 0) { atomicOr(err, 1u); n_ev[a] = 0; n_out[a] = 0; }
-    return;
+    continue;
   }
   Tri cur{0, 0, 0};
   bool cv = uint32_t(lane) < hi - lo;
@@ -440,6 +495,7 @@ __global__ __launch_bounds__(256) void k_branch_trace(SeqsetView v, uint64_t na,
   if (cv) { outb[a * kFrontierMax + lane] = cur.b; oute[a * kFrontierMax + lane] = cur.e; outs[a * kFrontierMax + lane] = cur.s; }
   uint64_t live = __ballot(cv);
   if (lane == 0) { n_ev[a] = nev; n_out[a] = uint8_t(__popcll(live)); }
+  }
 }
 
 // ref_map::build (variants/ref_map.cpp:72-185): one lane per chain.  A chain pushes the complement of
@@ -869,7 +925,7 @@ extern "C" int bg_branch_trace_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t 
   BG_TRY(err.alloc(ctx, 1));
   BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
   ctx->tic("walk_branch_trace");
-  k_branch_trace<<<cdiv(n_asm, 4), 256, 0, ctx->stream>>>(make_view(ss), n_asm, d_seq_off, d_seq_codes, d_foff, d_begin,
+  k_branch_trace<<<cdiv(n_asm, 64), 256, 0, ctx->stream>>>(make_view(ss), n_asm, d_seq_off, d_seq_codes, d_foff, d_begin,
                                                           d_end, d_size, min_overlap, ev_cap, d_ev_off, d_ev_base,
                                                           d_n_ev, d_n_out, d_obegin, d_oend, d_osize, err.p);
   BG_LAUNCH_CHECK();
@@ -1218,8 +1274,50 @@ __global__ void k_read_info(SeqsetView v, ReadmapView rm, uint64_t n, const uint
 // readmap — collects get_mate_rc().get_seqset_entry() of the mated prefix reads of every range that has
 // at most max_pairs_per_read of them (:1394-1414).  Mates are emitted unsorted with repeats (the
 // reference keeps a set; the host folds them).
+// k_propagate_single: the same for assemblies that start from at most ONE range and collect no mates -- a set of one range
+// stays a set of one range, so a LANE is an assembly (one push a step, nothing to compare): 64 chains of dependent loads a
+// wave instead of one.  *n_wide = how many assemblies it left alone (a wider starting set): the caller runs the kernel below
+// on those.
+__global__ __launch_bounds__(256) void k_propagate_single(
+    SeqsetView v, uint64_t na, const uint64_t* __restrict__ soff, const uint8_t* __restrict__ seq, const uint32_t* __restrict__ foff,
+    const uint64_t* __restrict__ fbegin, const uint64_t* __restrict__ fend, const uint32_t* __restrict__ fsize,
+    const uint32_t* __restrict__ mark_off, const uint32_t* __restrict__ marks, uint8_t* __restrict__ mark_n,
+    uint64_t* __restrict__ mb, uint64_t* __restrict__ me, uint32_t* __restrict__ ms, uint8_t* __restrict__ n_out,
+    uint64_t* __restrict__ outb, uint64_t* __restrict__ oute, uint32_t* __restrict__ outs, uint32_t* __restrict__ n_mates,
+    uint8_t* __restrict__ wide, unsigned long long* __restrict__ n_wide) {
+  const uint64_t a = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (a >= na) return;
+  const uint32_t lo = foff[a], hi = foff[a + 1];
+  if (hi - lo > 1u) { wide[a] = 1; atomicAdd(n_wide, 1ull); return; }
+  wide[a] = 0;
+  Tri cur{0, 0, 0};
+  bool cv = hi > lo;
+  if (cv) { cur.b = fbegin[lo]; cur.e = fend[lo]; cur.s = fsize[lo]; }
+  cv = cv && cur.b < cur.e && cur.e <= v.n;
+  const uint64_t s0 = soff[a];
+  const uint64_t len = soff[a + 1] - s0;
+  const int64_t mlo = mark_off ? int64_t(mark_off[a]) : 0;
+  int64_t mi = mark_off ? int64_t(mark_off[a + 1]) - 1 : -1;
+  for (uint64_t off = len; off-- > 0;) {
+    const int base = seq[s0 + off] & 3;
+    Tri c{0, 0, 0};
+    if (cv) v.push_front_drop(cur.b, cur.e, cur.s, base, 0u, &c.b, &c.e, &c.s);
+    cv = cv && c.e > c.b;
+    cur = c;
+    if (mi >= mlo && marks[mi] == uint32_t(off)) {
+      if (cv) { mb[uint64_t(mi) * kFrontierMax] = cur.b; me[uint64_t(mi) * kFrontierMax] = cur.e; ms[uint64_t(mi) * kFrontierMax] = cur.s; }
+      mark_n[mi] = cv ? 1 : 0;
+      --mi;
+    }
+  }
+  if (cv) { outb[a * kFrontierMax] = cur.b; oute[a * kFrontierMax] = cur.e; outs[a * kFrontierMax] = cur.s; }
+  n_out[a] = cv ? 1 : 0;
+  n_mates[a] = 0;
+}
+
+// (only: non-null = the assemblies k_propagate_single left)
 __global__ __launch_bounds__(256) void k_propagate_from_end(
-    SeqsetView v, ReadmapView rm, int use_rm, uint64_t na, const uint64_t* __restrict__ soff,
+    SeqsetView v, ReadmapView rm, int use_rm, const uint8_t* __restrict__ only, uint64_t na, const uint64_t* __restrict__ soff,
     const uint8_t* __restrict__ seq, const uint32_t* __restrict__ foff, const uint64_t* __restrict__ fbegin,
     const uint64_t* __restrict__ fend, const uint32_t* __restrict__ fsize, uint32_t max_pairs,
     const uint32_t* __restrict__ mark_off, const uint32_t* __restrict__ marks, uint8_t* __restrict__ mark_n,
@@ -1230,6 +1328,7 @@ __global__ __launch_bounds__(256) void k_propagate_from_end(
   const int lane = threadIdx.x & 63;
   uint64_t a = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (a >= na) return;
+  if (only && !only[a]) return;
   uint32_t lo = foff[a], hi = foff[a + 1];
   if (hi - lo > uint32_t(kFrontierMax)) {
     if (lane == 0) { atomicOr(err, 1u); n_out[a] = 0; n_mates[a] = 0; }
@@ -1522,8 +1621,24 @@ extern "C" int bg_propagate_from_end_batch(bg_ctx* ctx, const bg_seqset* ss, con
   ReadmapView rv{};
   if (rm) rv = make_rm_view(rm);
   ctx->tic("walk_propagate_from_end");
+  DevBuf<uint8_t> wide;
+  DevBuf<unsigned long long> n_wide;
+  bool rest = true;
+  if (!rm) {  // the assemblies that start from one range, a lane each; the others (if any) a wave each as before
+    BG_TRY(wide.alloc(ctx, n_asm));
+    BG_TRY(n_wide.alloc(ctx, 1));
+    BG_HIP(hipMemsetAsync(n_wide.p, 0, 8, ctx->stream));
+    k_propagate_single<<<cdiv(n_asm, 256), 256, 0, ctx->stream>>>(make_view(ss), n_asm, d_seq_off, d_seq_codes, d_foff, d_begin, d_end, d_size, d_mark_off,
+                                                                  d_marks, d_mark_n, d_mbegin, d_mend, d_msize, d_n_out, d_obegin, d_oend, d_osize,
+                                                                  d_n_mates, wide.p, n_wide.p);
+    BG_LAUNCH_CHECK();
+    unsigned long long h_wide = 0;
+    BG_HIP(copy_d2h(ctx, &h_wide, n_wide.p, 8));
+    rest = h_wide != 0;
+  }
+  if (rest)
   k_propagate_from_end<<<cdiv(n_asm, 4), 256, 0, ctx->stream>>>(
-      make_view(ss), rv, rm ? 1 : 0, n_asm, d_seq_off, d_seq_codes, d_foff, d_begin, d_end, d_size, max_pairs_per_read,
+      make_view(ss), rv, rm ? 1 : 0, rm ? nullptr : wide.p, n_asm, d_seq_off, d_seq_codes, d_foff, d_begin, d_end, d_size, max_pairs_per_read,
       d_mark_off, d_marks, d_mark_n, d_mbegin, d_mend, d_msize, d_n_out, d_obegin, d_oend, d_osize, mate_cap, d_n_mates,
       d_mate_begin, d_mate_end, d_mate_size, err.p);
   BG_LAUNCH_CHECK();
