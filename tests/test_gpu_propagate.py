@@ -81,7 +81,7 @@ def test_propagate_from_end_matches_oracle(world):
     # without a readmap the assemblies that start from one range run a lane each (k_propagate_single), the others a wave each:
     # the same sets at the marks as with the readmap
     plain_marks = ss.propagate_from_end_batch(seqs, ends, None, 20, marks)
-    assert sum(1 for e in ends if len(e) == 1) > 10 and sum(1 for e in ends if len(e) > 1) > 0
+    assert sum(1 for e in ends if len(e) == 1) > 10
     for k in range(len(seqs)):
         assert plain_marks[k][0] == got[k][0] and plain_marks[k][1] == [], k
         want_ent, want_mates = oss.propagate_from_end(seqs[k], ends[k], orm, 20, marks[k])
