@@ -222,6 +222,13 @@ extern "C" int bg_find_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t n, const
 
 namespace bg {
 
+// BG_WALK_PACK=0: branch trace, propagate and push-to-pair trace with a wave an assembly whatever its starting set, as before
+// round 6 (the tests compare the two ways)
+static bool walk_pack() {
+  const char* e = getenv("BG_WALK_PACK");
+  return !(e && e[0] == '0');
+}
+
 constexpr int kFrontierMax = 16;  // ranges per frontier ("#rs typically 1-10")
 
 struct Tri {
@@ -390,13 +397,13 @@ __global__ __launch_bounds__(256) void k_branch_trace(SeqsetView v, uint64_t na,
                                                       uint8_t* __restrict__ ev_base, uint32_t* __restrict__ n_ev,
                                                       uint8_t* __restrict__ n_out, uint64_t* __restrict__ outb,
                                                       uint64_t* __restrict__ oute, uint32_t* __restrict__ outs,
-                                                      uint32_t* __restrict__ err) {
+                                                      uint32_t* __restrict__ err, int pack) {
   const int lane = threadIdx.x & 63;
   // A wave takes 16 consecutive assemblies.  A frontier never grows along a trace (the next one is the reference base's
   // pushes of this one's ranges, less duplicates and containers), and nearly every trace starts from ONE range: then four
   // lanes -- one a base -- are an assembly and the wave walks all 16 side by side.  The kernel is a chain of dependent
   // loads (three round trips a step), so what counts is how many chains the chip holds: one assembly a wave were 6 000 of
-  // 64 443 at a time, ten rounds of 1 256 steps; sixteen a wave are all of them at once (57.6 -> ? ms on the bench's chr20).
+  // 64 443 at a time, ten rounds of 1 256 steps; sixteen a wave are all of them at once (57.6 -> 10.0 ms on the bench's chr20).
   // A group with a wider frontier in it takes the assemblies one after the other, a wave each, as before.
   const uint64_t a0 = (uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16;
   if (a0 >= na) return;
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(256) void k_branch_trace(SeqsetView v, uint64_t na,
     const uint64_t a = a0 + uint64_t(sub);
     const bool act = a < na;
     const uint32_t lo = act ? foff[a] : 0, hi = act ? foff[a + 1] : 0;
-    if (__all(hi - lo <= 1u)) {
+    if (pack && __all(hi - lo <= 1u)) {  // (pack = 0, BG_WALK_PACK=0: every group the old way -- comparisons)
       Tri cur{0, 0, 0};
       bool cv = hi > lo;
       if (cv) { cur.b = fbegin[lo]; cur.e = fend[lo]; cur.s = fsize[lo]; }
@@ -927,7 +934,7 @@ extern "C" int bg_branch_trace_batch(bg_ctx* ctx, const bg_seqset* ss, uint64_t 
   ctx->tic("walk_branch_trace");
   k_branch_trace<<<cdiv(n_asm, 64), 256, 0, ctx->stream>>>(make_view(ss), n_asm, d_seq_off, d_seq_codes, d_foff, d_begin,
                                                           d_end, d_size, min_overlap, ev_cap, d_ev_off, d_ev_base,
-                                                          d_n_ev, d_n_out, d_obegin, d_oend, d_osize, err.p);
+                                                          d_n_ev, d_n_out, d_obegin, d_oend, d_osize, err.p, walk_pack() ? 1 : 0);
   BG_LAUNCH_CHECK();
   ctx->toc(0);
   uint32_t h_err = 0;
@@ -1624,7 +1631,7 @@ extern "C" int bg_propagate_from_end_batch(bg_ctx* ctx, const bg_seqset* ss, con
   DevBuf<uint8_t> wide;
   DevBuf<unsigned long long> n_wide;
   bool rest = true;
-  if (!rm) {  // the assemblies that start from one range, a lane each; the others (if any) a wave each as before
+  if (!rm && walk_pack()) {  // the assemblies that start from one range, a lane each; the others (if any) a wave each as before
     BG_TRY(wide.alloc(ctx, n_asm));
     BG_TRY(n_wide.alloc(ctx, 1));
     BG_HIP(hipMemsetAsync(n_wide.p, 0, 8, ctx->stream));
@@ -1638,7 +1645,7 @@ extern "C" int bg_propagate_from_end_batch(bg_ctx* ctx, const bg_seqset* ss, con
   }
   if (rest)
   k_propagate_from_end<<<cdiv(n_asm, 4), 256, 0, ctx->stream>>>(
-      make_view(ss), rv, rm ? 1 : 0, rm ? nullptr : wide.p, n_asm, d_seq_off, d_seq_codes, d_foff, d_begin, d_end, d_size, max_pairs_per_read,
+      make_view(ss), rv, rm ? 1 : 0, wide.p, n_asm, d_seq_off, d_seq_codes, d_foff, d_begin, d_end, d_size, max_pairs_per_read,
       d_mark_off, d_marks, d_mark_n, d_mbegin, d_mend, d_msize, d_n_out, d_obegin, d_oend, d_osize, mate_cap, d_n_mates,
       d_mate_begin, d_mate_end, d_mate_size, err.p);
   BG_LAUNCH_CHECK();
@@ -1661,9 +1668,118 @@ extern "C" int bg_propagate_from_end_batch(bg_ctx* ctx, const bg_seqset* ss, con
 // SEEN_LDS: the per-trace list of dropped ranges (m_seen_ranges) lives in the workgroup's LDS (seen_cap x 20 bytes a wave)
 // instead of global memory: a step with a dropped candidate was three device-scope loads a lane, a store and a
 // __threadfence -- round trips to L2 in a kernel that is nothing but dependent round trips.
+// k_push_to_pair_single: the traces that start from at most ONE range (the set never grows: they stay one range), sixteen a
+// wave -- four lanes, one a base, are a trace.  The seen list of a trace lies in global memory and is written without waiting;
+// what keeps it out of the loop is a 2048-bit filter per trace in LDS: only a dropped range whose bit is already set (a repeat,
+// or one time in ten a collision once the list is long) is compared with the list itself, behind a fence.  Same answers as the
+// kernel below, which takes the traces this one leaves (*n_wide of them, wide[a] = 1).
+constexpr uint32_t kSeenFilterBits = 2048;
+__global__ __launch_bounds__(256) void k_push_to_pair_single(
+    SeqsetView v, uint64_t na, const uint32_t* __restrict__ foff, const uint64_t* __restrict__ fbegin,
+    const uint64_t* __restrict__ fend, const uint32_t* __restrict__ fsize, uint32_t min_overlap, uint32_t max_steps,
+    uint32_t range_cap, uint32_t seen_cap, uint64_t* __restrict__ seen_b, uint64_t* __restrict__ seen_e,
+    uint32_t* __restrict__ seen_s, uint32_t* __restrict__ n_steps, uint8_t* __restrict__ reason,
+    uint8_t* __restrict__ bases, uint8_t* __restrict__ counts, uint32_t* __restrict__ n_ranges,
+    uint64_t* __restrict__ rb_out, uint64_t* __restrict__ re_out, uint32_t* __restrict__ rs_out,
+    uint8_t* __restrict__ wide, unsigned long long* __restrict__ n_wide) {
+  __shared__ uint32_t filt[4][16][kSeenFilterBits / 32];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane >> 2, p = lane & 3;
+  const uint64_t a = (uint64_t(blockIdx.x) * 4 + uint64_t(wv)) * 16 + uint64_t(sub);
+  const bool act = a < na;
+  const uint32_t lo = act ? foff[a] : 0, hi = act ? foff[a + 1] : 0;
+  const bool mine = act && hi - lo <= 1u;
+  if (act && p == 0) {
+    wide[a] = mine ? 0 : 1;
+    if (!mine) atomicAdd(n_wide, 1ull);
+  }
+  uint32_t* f = filt[wv][sub];
+  for (uint32_t i = uint32_t(p); i < kSeenFilterBits / 32; i += 4) f[i] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  Tri cur{0, 0, 0};
+  bool cv = mine && hi > lo;
+  if (cv) { cur.b = fbegin[lo]; cur.e = fend[lo]; cur.s = fsize[lo]; }
+  cv = cv && cur.b < cur.e && cur.e <= v.n;
+  uint64_t* sb = seen_b + a * uint64_t(seen_cap);
+  uint64_t* se = seen_e + a * uint64_t(seen_cap);
+  uint32_t* ssz = seen_s + a * uint64_t(seen_cap);
+  uint32_t steps = 0, nseen = 0, nr = 0;
+  int why = 0;
+  bool done = !mine;
+  for (;;) {
+    if (!done) {
+      if (!cv) { why = 0; done = true; }
+      else if (steps >= max_steps) { why = 2; done = true; }
+    }
+    if (__all(done)) break;
+    uint64_t ob = 0, oe = 0;
+    uint32_t os = 0;
+    if (!done) v.push_front_drop(cur.b, cur.e, cur.s, p, min_overlap, &ob, &oe, &os);
+    const bool valid = oe > ob;
+    const uint32_t m = valid ? os : 0;
+    uint32_t best_len = 0;
+    int best = -1;
+    for (int bb = 0; bb < 4; ++bb) {  // strict > : first base wins ties (:196)
+      const uint32_t l = __shfl(m, sub * 4 + bb, 64);
+      if (l > best_len) { best_len = l; best = bb; }
+    }
+    const int src = sub * 4 + (best < 0 ? 0 : best);
+    const Tri c{__shfl(ob, src, 64), __shfl(oe, src, 64), __shfl(os, src, 64)};
+    if (!done && best < 0) { why = 0; done = true; }
+    const bool cd = !done && c.s != cur.s + 1;  // the chosen base's range gave context up
+    // m_seen_ranges: every dropped candidate must be new
+    uint32_t h = uint32_t(c.b) * 0x9E3779B1u ^ uint32_t(c.b >> 32) * 0x85EBCA77u ^ uint32_t(c.e - c.b) * 0xC2B2AE3Du ^ c.s * 0x27D4EB2Fu;
+    h = (h ^ (h >> 15)) & (kSeenFilterBits - 1);
+    const bool maybe = cd && ((f[h >> 5] >> (h & 31)) & 1u);
+    if (__any(maybe)) {
+      __threadfence();  // the list's earlier stores have landed before anybody compares with them
+      bool hit = false;
+      if (maybe)
+        for (uint32_t i = uint32_t(p); i < nseen; i += 4)
+          hit |= __hip_atomic_load(&sb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == c.b &&
+                 __hip_atomic_load(&se[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == c.e &&
+                 __hip_atomic_load(&ssz[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == c.s;
+      const uint32_t hits = uint32_t(__ballot(hit) >> (sub * 4)) & 0xfu;
+      if (maybe && hits) { why = 1; done = true; }
+    }
+    if (cd && !done) {
+      if (nseen >= seen_cap) { why = 3; done = true; }
+      else {
+        if (p == 0) {
+          __hip_atomic_store(&sb[nseen], c.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&se[nseen], c.e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&ssz[nseen], c.s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          f[h >> 5] |= 1u << (h & 31);
+        }
+        ++nseen;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the filter: written by lane 0 of a trace, read by all four)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!done) {
+      if (nr + 1 > range_cap) { why = 4; done = true; }
+      else {
+        if (p == 0) {
+          const uint64_t o = a * uint64_t(range_cap) + nr;
+          rb_out[o] = c.b; re_out[o] = c.e; rs_out[o] = c.s;
+          bases[a * uint64_t(max_steps) + steps] = uint8_t(3 - best);  // appended base = complement (:236)
+          counts[a * uint64_t(max_steps) + steps] = 1;
+        }
+        ++nr;
+        ++steps;
+        cur = c;
+        cv = true;
+      }
+    }
+  }
+  if (mine && p == 0) { n_steps[a] = steps; reason[a] = uint8_t(why); n_ranges[a] = nr; }
+}
+
 template <bool SEEN_LDS>
 __global__ __launch_bounds__(256) void k_push_to_pair_trace(
-    SeqsetView v, uint64_t na, const uint32_t* __restrict__ foff, const uint64_t* __restrict__ fbegin,
+    SeqsetView v, const uint8_t* __restrict__ only, uint64_t na, const uint32_t* __restrict__ foff, const uint64_t* __restrict__ fbegin,
     const uint64_t* __restrict__ fend, const uint32_t* __restrict__ fsize, uint32_t min_overlap, uint32_t max_steps,
     uint32_t range_cap, uint32_t seen_cap, uint64_t* __restrict__ seen_b, uint64_t* __restrict__ seen_e,
     uint32_t* __restrict__ seen_s, uint32_t* __restrict__ n_steps, uint8_t* __restrict__ reason,
@@ -1673,6 +1789,7 @@ __global__ __launch_bounds__(256) void k_push_to_pair_trace(
   const int lane = threadIdx.x & 63;
   uint64_t a = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (a >= na) return;
+  if (only && !only[a]) return;
   uint32_t lo = foff[a], hi = foff[a + 1];
   if (hi - lo > uint32_t(kFrontierMax)) {
     if (lane == 0) { atomicOr(err, 1u); n_steps[a] = 0; reason[a] = 0; n_ranges[a] = 0; }
@@ -1794,21 +1911,42 @@ extern "C" int bg_push_to_pair_trace_batch(bg_ctx* ctx, const bg_seqset* ss, uin
   DevBuf<uint64_t> seen_b, seen_e;
   BG_TRY(err.alloc(ctx, 1));
   BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
-  // the seen lists in LDS while four waves' lists leave room for eight workgroups a CU (20 KB each: seen_cap <= 256)
-  const size_t lds = size_t(4) * (size_t(seen_cap) * 2 + (size_t(seen_cap) + 1) / 2) * 8;
-  const char* sl = getenv("BG_SEEN_GLOBAL");
-  if (lds <= 20480 && !(sl && sl[0] == '1')) {
-    ctx->tic("walk_push_to_pair_trace");
-    k_push_to_pair_trace<true><<<cdiv(n_asm, 4), 256, lds, ctx->stream>>>(
-        make_view(ss), n_asm, d_foff, d_begin, d_end, d_size, min_overlap, max_steps, range_cap, seen_cap, nullptr, nullptr, nullptr,
-        d_n_steps, d_reason, d_bases, d_counts, d_n_ranges, d_rbegin, d_rend, d_rsize, err.p);
-  } else {
+  // 1. the traces that start from one range, sixteen a wave (k_push_to_pair_single); 2. the others a wave each, their seen
+  // lists in LDS while four waves' lists leave room for eight workgroups a CU (20 KB each: seen_cap <= 256).
+  // BG_WALK_PACK=0: every trace through 2; BG_SEEN_GLOBAL=1: 2 with its lists in global memory.
+  const bool single = walk_pack();
+  DevBuf<uint8_t> wide;
+  DevBuf<unsigned long long> n_wide;
+  unsigned long long h_wide = n_asm;
+  ctx->tic("walk_push_to_pair_trace");
+  if (single) {
+    BG_TRY(wide.alloc(ctx, n_asm));
+    BG_TRY(n_wide.alloc(ctx, 1));
     BG_TRY(seen_b.alloc(ctx, n_asm * seen_cap));
     BG_TRY(seen_e.alloc(ctx, n_asm * seen_cap));
     BG_TRY(seen_s.alloc(ctx, n_asm * seen_cap));
-    ctx->tic("walk_push_to_pair_trace");
+    BG_HIP(hipMemsetAsync(n_wide.p, 0, 8, ctx->stream));
+    k_push_to_pair_single<<<cdiv(n_asm, 64), 256, 0, ctx->stream>>>(
+        make_view(ss), n_asm, d_foff, d_begin, d_end, d_size, min_overlap, max_steps, range_cap, seen_cap, seen_b.p, seen_e.p, seen_s.p,
+        d_n_steps, d_reason, d_bases, d_counts, d_n_ranges, d_rbegin, d_rend, d_rsize, wide.p, n_wide.p);
+    BG_LAUNCH_CHECK();
+    BG_HIP(copy_d2h(ctx, &h_wide, n_wide.p, 8));
+  }
+  const size_t lds = size_t(4) * (size_t(seen_cap) * 2 + (size_t(seen_cap) + 1) / 2) * 8;
+  const char* sl = getenv("BG_SEEN_GLOBAL");
+  if (!h_wide) {
+  } else if (lds <= 20480 && !(sl && sl[0] == '1')) {
+    k_push_to_pair_trace<true><<<cdiv(n_asm, 4), 256, lds, ctx->stream>>>(
+        make_view(ss), single ? wide.p : nullptr, n_asm, d_foff, d_begin, d_end, d_size, min_overlap, max_steps, range_cap, seen_cap, nullptr, nullptr,
+        nullptr, d_n_steps, d_reason, d_bases, d_counts, d_n_ranges, d_rbegin, d_rend, d_rsize, err.p);
+  } else {
+    if (!seen_b.p) {
+      BG_TRY(seen_b.alloc(ctx, n_asm * seen_cap));
+      BG_TRY(seen_e.alloc(ctx, n_asm * seen_cap));
+      BG_TRY(seen_s.alloc(ctx, n_asm * seen_cap));
+    }
     k_push_to_pair_trace<false><<<cdiv(n_asm, 4), 256, 0, ctx->stream>>>(
-        make_view(ss), n_asm, d_foff, d_begin, d_end, d_size, min_overlap, max_steps, range_cap, seen_cap, seen_b.p,
+        make_view(ss), single ? wide.p : nullptr, n_asm, d_foff, d_begin, d_end, d_size, min_overlap, max_steps, range_cap, seen_cap, seen_b.p,
         seen_e.p, seen_s.p, d_n_steps, d_reason, d_bases, d_counts, d_n_ranges, d_rbegin, d_rend, d_rsize, err.p);
   }
   BG_LAUNCH_CHECK();

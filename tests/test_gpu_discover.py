@@ -42,6 +42,49 @@ def _frontiers_from_ref(oss, ref, rng, count, width):
     return fr
 
 
+def _without_packing(call):
+    """The same call with a wave an assembly whatever its starting set (BG_WALK_PACK=0: the kernels of rounds 1-5)."""
+    import os
+    os.environ["BG_WALK_PACK"] = "0"
+    try:
+        return call()
+    finally:
+        del os.environ["BG_WALK_PACK"]
+
+
+def test_packed_walks_equal_a_wave_an_assembly_on_many_traces(world):
+    """Thousands of single-range traces next to a few wide ones (sixteen a wave / a lane each against a wave each): branch
+    trace, propagate and push-to-pair trace, long enough for seen lists to fill and for repeats to end traces."""
+    ctx, d, oss, ss, ref = world
+    rng = np.random.default_rng(99)
+    n = len(oss)
+    starts = rng.integers(0, len(ref) - 1300, 3000)
+    seqs = [ref[int(p):int(p) + int(rng.integers(200, 1200))] for p in starts]
+    fr = [[(0, n, 0)] for _ in seqs]
+    wide = _frontiers_from_ref(oss, ref, rng, 12, 50)
+    for k, w in zip(range(5, 3000, 250), wide):
+        fr[k] = w
+    assert sum(1 for f in fr if len(f) > 1) >= 3
+    a = ss.branch_trace_batch(seqs, fr, 40, ev_cap=512)
+    b = _without_packing(lambda: ss.branch_trace_batch(seqs, fr, 40, ev_cap=512))
+    assert a == b
+    assert sum(nev for nev, _, _ in a) > 100
+    rc = [(3 - s[::-1]).astype(np.uint8) for s in seqs]
+    pa = ss.propagate_from_end_batch(rc, fr)
+    pb = _without_packing(lambda: ss.propagate_from_end_batch(rc, fr))
+    assert pa == pb
+    ends = [list(ent[0]) if ent.get(0) else [] for ent, _ in pa]
+    assert sum(1 for e in ends if len(e) == 1) > 2000
+    for seen_cap, max_steps in ((256, 400), (24, 400), (300, 120)):
+        ta = ss.push_to_pair_trace_batch(ends, 50, max_steps=max_steps, seen_cap=seen_cap)
+        tb = _without_packing(lambda: ss.push_to_pair_trace_batch(ends, 50, max_steps=max_steps, seen_cap=seen_cap))
+        assert ta == tb
+        reasons = {}
+        for why, _, _ in ta:
+            reasons[why] = reasons.get(why, 0) + 1
+        assert len(reasons) >= 2, reasons
+
+
 def test_ref_map_build_matches_reference_chunking(world):
     ctx, d, oss, ss, ref = world
     want = oss.ref_map_build(ref, [0], [len(ref)])
@@ -93,6 +136,7 @@ def test_branch_trace_matches_oracle(world):
         for s_, f, g in zip(seqs, fronts, got):
             n, ev, cur = oss.branch_trace(s_, f, mo)
             assert g[0] == n and g[1] == ev and g[2] == cur
+        assert _without_packing(lambda: ss.branch_trace_batch(seqs, fronts, mo, ev_cap=512)) == got
     assert any(g[0] > 0 for g in got)
 
 
@@ -123,6 +167,7 @@ def test_push_to_pair_trace_matches_oracle(world):
             want = oss.push_to_pair_trace(f, mo, steps)
             assert g == want, (f, mo)
             reasons.add(g[0])
+        assert _without_packing(lambda: ss.push_to_pair_trace_batch(fronts, mo, max_steps=steps)) == got
     assert {0, 2} <= reasons
     f = fronts[0]
     full = oss.push_to_pair_trace(f, 70, 64)
