@@ -493,12 +493,12 @@ def discover_leg(ctx, seq, offs, n_reads, params, genome, dev, args=None):
              "achieved": round(alg / seconds / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(alg / seconds / 1e9 / HBM_PEAK_GBS, 4), "seconds": round(seconds, 4),
              "limiter": "dependent random 64-byte sectors: a chain is one push_front_drop after the other (2 rank look-ups of 3 "
-                        "words each + sizes per call), %d chains in flight" % (2 * (G // 1024 + 1) if kernel == "k_ref_map_chains" else (ns if kernel == "k_push_to_pair_trace" else na))}
+                        "words each + sizes per call), %d chains in flight" % (2 * (G // 1024 + 1) if kernel == "k_ref_map_chains" else (ns if kernel == "k_push_to_pair_single" else na))}
         r.update(pmc_traffic_walk(kernel, seconds * 1e3))
         return r
     roof_ref = walk_roofline("k_ref_map_chains", ref_counts, t_ref)
     roof_br = walk_roofline("k_branch_trace", br_counts, t_br)
-    roof_tr = walk_roofline("k_push_to_pair_trace", tr_counts, t_tr) if t_tr > 0 else None
+    roof_tr = walk_roofline("k_push_to_pair_single", tr_counts, t_tr) if t_tr > 0 else None
     return {"roofline": roof_ref, "roofline_branch_trace": roof_br, "roofline_push_to_pair_trace": roof_tr,
             "readmap": {"seconds": round(t_rm, 4), "read_ids": n_ids, "read_ids_per_s": round(n_ids / t_rm / 1e6, 1),
                         "unit": "M read ids/s (paired, both orientations)"},

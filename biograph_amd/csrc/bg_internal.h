@@ -323,6 +323,26 @@ int sort_records_impl(bg_ctx* ctx, const uint64_t* rec_p, const uint8_t* rlen_p,
 // build_seqset.hip: the suffix records as rows from the cover stage's counts (the second half of suffix_records_impl)
 int suffix_rows_from_counts(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen,
                             DevBuf<uint64_t>* k0, int RS);
+// The readmap's columns as the discovery engine consults them (tracer sessions, calc_coverage): a bit per entry that carries
+// reads, the number of such entries before every 64-entry word, the first read id of the k-th such entry (readmap::entry_to_index
+// without a binary search), a 32-bit mate loop and two bytes a read -- made on the device from the 64-bit columns, downloaded
+// once through the pinned double buffer and shared by everybody who asks for the same readmap (readmap_tables keeps a weak
+// reference per readmap; bg_readmap_free drops it).  The d_* copies (plain hipMalloc: they outlive any context) serve
+// k_trace_simple.
+struct ReadmapTables {
+  std::vector<uint8_t> is_forward, read_len;
+  std::vector<uint32_t> mate_loop, word_rank, group_start;
+  std::vector<uint64_t> has_reads;
+  uint32_t min_read_len = 0;
+  uint32_t *d_word_rank = nullptr, *d_group_start = nullptr, *d_mate_loop = nullptr;
+  uint8_t* d_is_forward = nullptr;
+  ReadmapTables() {}
+  ReadmapTables(const ReadmapTables&) = delete;
+  ReadmapTables& operator=(const ReadmapTables&) = delete;
+  ~ReadmapTables();
+};
+int readmap_tables(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, std::shared_ptr<const ReadmapTables>* out);
+void readmap_tables_forget(const bg_readmap* rm);
 // keys / pre2 of a seqset built from items, on demand (no-op when they are there or cannot be made).  The first keyed access of
 // a fresh seqset is NOT const: it allocates from the seqset's own context (ctx only when the seqset has none) under keys_mutex.
 int seqset_ensure_keys(bg_ctx* ctx, bg_seqset* ss);

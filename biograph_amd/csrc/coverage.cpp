@@ -282,12 +282,14 @@ struct CovWorld {
   const bg_seqset* ss = nullptr;
   const ScaffoldView* sc = nullptr;
   bg_coverage_options o;
-  std::vector<uint32_t> read_len;
-  std::vector<uint8_t> is_forward;
-  // readmap::entry_to_index without a binary search over all read ids: a bit per entry that carries reads, the number
-  // of such entries before every 64-entry word, the first read id of the k-th such entry
-  std::vector<uint64_t> has_reads;
-  std::vector<uint32_t> word_rank, group_start;
+  // the readmap's narrow columns (bg_internal.h ReadmapTables: made on the device, shared with the tracer sessions of the same
+  // readmap): read lengths and strands, and readmap::entry_to_index without a binary search over all read ids -- a bit per entry
+  // that carries reads, the number of such entries before every 64-entry word, the first read id of the k-th such entry
+  std::shared_ptr<const bg::ReadmapTables> rt;
+  const uint8_t* read_len = nullptr;
+  const uint8_t* is_forward = nullptr;
+  const uint64_t* has_reads = nullptr;
+  const uint32_t *word_rank = nullptr, *group_start = nullptr;
   uint32_t min_read_len = 0;
   int64_t max_read_len = 0;
   std::pair<uint32_t, uint32_t> entry_to_index(uint64_t e) const {
@@ -298,27 +300,13 @@ struct CovWorld {
   }
   int load(bg_ctx* ctx, const bg_seqset* seqset, const bg_readmap* rm) {
     ss = seqset;
-    std::vector<uint64_t> entry_id(rm->n_reads), tmp(rm->n_reads);  // entry ids: 64-bit, only needed for the tables below
-    if (rm->n_reads) {
-      BG_HIP(bg::copy_d2h(ctx, entry_id.data(), rm->entry_id.p, rm->n_reads * 8));
-      BG_HIP(bg::copy_d2h(ctx, tmp.data(), rm->read_len.p, rm->n_reads * 8));
-    }
-    read_len.assign(tmp.begin(), tmp.end());
-    if (rm->n_reads) BG_HIP(bg::copy_d2h(ctx, tmp.data(), rm->is_forward.p, rm->n_reads * 8));
-    is_forward.resize(rm->n_reads);
-    for (size_t i = 0; i < tmp.size(); ++i) is_forward[i] = uint8_t(tmp[i] & 1);
-    has_reads.assign((ss->n + 63) / 64 + 1, 0);
-    for (uint64_t e : entry_id) has_reads[e >> 6] |= 1ull << (e & 63);
-    word_rank.resize(has_reads.size() + 1);
-    uint32_t before = 0;
-    for (size_t i = 0; i < has_reads.size(); ++i) { word_rank[i] = before; before += uint32_t(__builtin_popcountll(has_reads[i])); }
-    word_rank[has_reads.size()] = before;
-    group_start.clear();
-    for (size_t i = 0; i < entry_id.size(); ++i)
-      if (i == 0 || entry_id[i] != entry_id[i - 1]) group_start.push_back(uint32_t(i));
-    group_start.push_back(uint32_t(entry_id.size()));
-    if (group_start.size() != size_t(before) + 1) { set_error("calc_coverage: the readmap's read ids are not grouped by entry"); return BG_EINVAL; }
-    min_read_len = read_len.empty() ? 0 : *std::min_element(read_len.begin(), read_len.end());
+    BG_TRY(bg::readmap_tables(ctx, seqset, rm, &rt));
+    read_len = rt->read_len.data();
+    is_forward = rt->is_forward.data();
+    has_reads = rt->has_reads.data();
+    word_rank = rt->word_rank.data();
+    group_start = rt->group_start.data();
+    min_read_len = rt->min_read_len;
     max_read_len = int64_t(ss->max_len);  // seqset::max_read_len() = the longest entry (seqset.h:71)
     return BG_OK;
   }
@@ -614,8 +602,8 @@ class Coverage {
   const bg_seqset* ss_;
   const ScaffoldView& sc_;
   bg_coverage_options o_;
-  const std::vector<uint32_t>& read_len_;
-  const std::vector<uint8_t>& is_forward_;
+  const uint8_t* read_len_;
+  const uint8_t* is_forward_;
   uint32_t min_read_len_ = 0;
   int64_t max_read_len_ = 0;
   WalkWaiter* batcher_;

@@ -667,7 +667,127 @@ extern "C" int bg_readmap_from_arrays(bg_ctx* ctx, uint64_t n_entries, uint32_t 
 extern "C" uint64_t bg_readmap_size(const bg_readmap* rm) { return rm ? rm->n_reads : 0; }
 extern "C" uint32_t bg_readmap_max_read_len(const bg_readmap* rm) { return rm ? rm->max_read_len : 0; }
 extern "C" int bg_readmap_has_mate_loop(const bg_readmap* rm) { return rm && !rm->pair_mode ? 1 : 0; }
-extern "C" void bg_readmap_free(bg_readmap* rm) { delete rm; }
+extern "C" void bg_readmap_free(bg_readmap* rm) {
+  bg::readmap_tables_forget(rm);
+  delete rm;
+}
+
+// ---- bg::readmap_tables (bg_internal.h): the narrow columns the discovery engine reads, made on the device
+namespace bg {
+__global__ void k_rt_narrow(const uint64_t* __restrict__ entry_id, const uint64_t* __restrict__ mate_loop, const uint64_t* __restrict__ is_forward,
+                            const uint64_t* __restrict__ read_len, uint64_t n_reads, uint64_t n_entries, unsigned long long* __restrict__ has_reads,
+                            uint8_t* __restrict__ head, uint32_t* __restrict__ mate32, uint8_t* __restrict__ fwd8, uint8_t* __restrict__ len8,
+                            uint32_t* __restrict__ err) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_reads) return;
+  const uint64_t e = entry_id[i];
+  const bool h = i == 0 || entry_id[i - 1] != e;
+  if (i && entry_id[i - 1] > e) atomicOr(&err[0], 1u);  // (read ids are grouped by ascending entry)
+  mate32[i] = uint32_t(mate_loop[i]);
+  fwd8[i] = uint8_t(is_forward[i] & 1);
+  const uint64_t len = read_len[i];
+  len8[i] = uint8_t(len);
+  atomicMin(&err[1], uint32_t(len > 0xffffffffull ? 0xffffffffull : len));
+  if (len > 255) atomicOr(&err[0], 4u);
+  if (e >= n_entries) { atomicOr(&err[0], 2u); head[i] = 0; return; }
+  head[i] = h ? 1 : 0;
+  if (h) atomicOr(&has_reads[e >> 6], 1ull << (e & 63));
+}
+__global__ void k_rt_popc(const unsigned long long* __restrict__ words, uint64_t n, uint32_t* __restrict__ out) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = uint32_t(__popcll(words[i]));
+}
+
+ReadmapTables::~ReadmapTables() {
+  if (d_word_rank) (void)hipFree(d_word_rank);
+  if (d_group_start) (void)hipFree(d_group_start);
+  if (d_mate_loop) (void)hipFree(d_mate_loop);
+  if (d_is_forward) (void)hipFree(d_is_forward);
+}
+
+static std::mutex g_rt_mutex;
+static std::map<const bg_readmap*, std::weak_ptr<const ReadmapTables>> g_rt_cache;
+
+void readmap_tables_forget(const bg_readmap* rm) {
+  std::lock_guard<std::mutex> lk(g_rt_mutex);
+  g_rt_cache.erase(rm);
+}
+
+static int readmap_tables_make(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, ReadmapTables* t) {
+  const uint64_t n_ent = ss->n, n_reads = rm->n_reads;
+  const uint64_t n_words = (n_ent + 63) / 64 + 1;
+  if (n_reads >= (uint64_t(1) << 32)) { set_error("readmap tables: 2^32 read ids or more (read ids are 32-bit: readmap.h)"); return BG_EINVAL; }
+  BG_HIP(hipSetDevice(ctx->device));
+  DevBuf<unsigned long long> d_has;
+  DevBuf<uint8_t> d_head, d_len8;
+  DevBuf<uint32_t> d_popc, d_err, d_heads, d_total;
+  BG_TRY(d_has.alloc(ctx, n_words));
+  BG_TRY(d_head.alloc(ctx, n_reads));
+  BG_TRY(d_len8.alloc(ctx, n_reads));
+  BG_TRY(d_popc.alloc(ctx, n_words + 1));
+  BG_TRY(d_err.alloc(ctx, 2));
+  BG_TRY(d_total.alloc(ctx, 1));
+  BG_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_word_rank), (n_words + 1) * 4));
+  BG_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_mate_loop), (n_reads ? n_reads : 1) * 4));
+  BG_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_is_forward), n_reads ? n_reads : 1));
+  BG_HIP(hipMemsetAsync(d_has.p, 0, n_words * 8, ctx->stream));
+  const uint32_t err0[2] = {0u, 0xffffffffu};
+  BG_HIP(copy_h2d(ctx, d_err.p, err0, 8));
+  if (n_reads) {
+    k_rt_narrow<<<cdiv(n_reads, 256), 256, 0, ctx->stream>>>(rm->entry_id.p, rm->mate_loop_ptr.p, rm->is_forward.p, rm->read_len.p, n_reads, n_ent,
+                                                             d_has.p, d_head.p, t->d_mate_loop, t->d_is_forward, d_len8.p, d_err.p);
+    BG_LAUNCH_CHECK();
+  }
+  k_rt_popc<<<cdiv(n_words, 256), 256, 0, ctx->stream>>>(d_has.p, n_words, d_popc.p);
+  BG_LAUNCH_CHECK();
+  BG_TRY(exclusive_scan_u32(ctx, d_popc.p, t->d_word_rank, n_words, d_total.p));
+  BG_HIP(hipMemcpyAsync(t->d_word_rank + n_words, d_total.p, 4, hipMemcpyDeviceToDevice, ctx->stream));
+  uint64_t n_groups = 0;
+  if (n_reads) BG_TRY(compact_flagged<uint32_t>(ctx, d_head.p, n_reads, &d_heads, &n_groups));
+  uint32_t h_err[2] = {0, 0}, h_total = 0;
+  BG_HIP(copy_d2h(ctx, h_err, d_err.p, 8));
+  BG_HIP(copy_d2h(ctx, &h_total, d_total.p, 4));
+  if (h_err[0] & 2) { set_error("readmap tables: the readmap names an entry the seqset does not have"); return BG_EINVAL; }
+  if (h_err[0] & 4) { set_error("readmap tables: a read of more than 255 bases"); return BG_EINVAL; }
+  if ((h_err[0] & 1) || n_groups != h_total) { set_error("the readmap's read ids are not grouped by entry"); return BG_EINVAL; }
+  t->min_read_len = n_reads ? h_err[1] : 0;
+  BG_HIP(hipMalloc(reinterpret_cast<void**>(&t->d_group_start), (n_groups + 1) * 4));
+  if (n_groups) BG_HIP(hipMemcpyAsync(t->d_group_start, d_heads.p, n_groups * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  const uint32_t last = uint32_t(n_reads);
+  BG_HIP(copy_h2d(ctx, t->d_group_start + n_groups, &last, 4));
+  d_heads.reset();
+  d_head.reset();
+  d_popc.reset();
+  // the narrow tables to the host, through the context's pinned double buffer
+  auto down = [&](auto& v, const void* src, size_t count) -> int {
+    v.resize(count);
+    return count ? staged_download(ctx, v.data(), src, count * sizeof(v[0]), 0) : BG_OK;
+  };
+  BG_TRY(down(t->has_reads, d_has.p, n_words));
+  BG_TRY(down(t->word_rank, t->d_word_rank, n_words + 1));
+  BG_TRY(down(t->group_start, t->d_group_start, n_groups + 1));
+  BG_TRY(down(t->mate_loop, t->d_mate_loop, n_reads));
+  BG_TRY(down(t->is_forward, t->d_is_forward, n_reads));
+  BG_TRY(down(t->read_len, d_len8.p, n_reads));
+  return BG_OK;
+}
+
+int readmap_tables(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, std::shared_ptr<const ReadmapTables>* out) {
+  // (one maker at a time: a second caller for the same readmap -- the coverage session opened beside the tracer's -- waits and
+  // takes the first one's tables)
+  std::lock_guard<std::mutex> lk(g_rt_mutex);
+  auto it = g_rt_cache.find(rm);
+  if (it != g_rt_cache.end()) {
+    if (auto have = it->second.lock()) { *out = have; return BG_OK; }
+    g_rt_cache.erase(it);
+  }
+  std::shared_ptr<ReadmapTables> t(new ReadmapTables);
+  BG_TRY(readmap_tables_make(ctx, ss, rm, t.get()));
+  g_rt_cache[rm] = t;
+  *out = t;
+  return BG_OK;
+}
+}  // namespace bg
 
 static unsigned rm_bits_for_value(uint64_t v) { unsigned b = 0; while (v) { ++b; v >>= 1; } return b; }
 

@@ -143,9 +143,8 @@ std::string rev_comp_str(const std::string& s) {
 namespace {
 
 struct HostTables {
-  std::vector<uint8_t> sizes, ref_map, is_forward, read_len;
-  std::vector<uint32_t> mate_loop, word_rank, group_start;  // read ids are 32-bit (readmap.h), entry ids are not
-  std::vector<uint64_t> has_reads;
+  std::vector<uint8_t> sizes, ref_map;
+  std::shared_ptr<const ReadmapTables> rt;  // the readmap's narrow columns, host and device (bg_internal.h): shared with calc_coverage
 };
 
 // A pinned host buffer that grows: the per-round queries / replies of a session cross the bus from and to page-locked
@@ -169,19 +168,13 @@ struct Pinned {
   }
 };
 
-// Device copies of the readmap columns the device's never-branching-trace path consults (walk.hip k_trace_simple): made once per
-// session, shared by its clones; plain hipMalloc so that they outlive any one context.
+// The device copies of the readmap columns the never-branching-trace path consults (walk.hip k_trace_simple): pointers into the
+// shared ReadmapTables, which the session's HostTables keep alive.
 struct DeviceTables {
-  uint32_t* word_rank = nullptr;
-  uint32_t* group_start = nullptr;
-  uint32_t* mate_loop = nullptr;
-  uint8_t* is_forward = nullptr;
-  ~DeviceTables() {
-    if (word_rank) (void)hipFree(word_rank);
-    if (group_start) (void)hipFree(group_start);
-    if (mate_loop) (void)hipFree(mate_loop);
-    if (is_forward) (void)hipFree(is_forward);
-  }
+  const uint32_t* word_rank = nullptr;
+  const uint32_t* group_start = nullptr;
+  const uint32_t* mate_loop = nullptr;
+  const uint8_t* is_forward = nullptr;
 };
 
 // Everything the traces of one chunk share.
@@ -207,12 +200,12 @@ struct World {
   void bind_tables() {
     sizes = tables->sizes.data();
     ref_map = tables->ref_map.data();
-    mate_loop = tables->mate_loop.data();
-    is_forward = tables->is_forward.data();
-    has_reads = tables->has_reads.data();
-    word_rank = tables->word_rank.data();
-    group_start = tables->group_start.data();
-    n_reads = tables->mate_loop.size();
+    mate_loop = tables->rt->mate_loop.data();
+    is_forward = tables->rt->is_forward.data();
+    has_reads = tables->rt->has_reads.data();
+    word_rank = tables->rt->word_rank.data();
+    group_start = tables->rt->group_start.data();
+    n_reads = tables->rt->mate_loop.size();
   }
   int64_t scaffold_end = 0;
   // reads along the (oriented) scaffold: offset (after the base) -> entry, ascending by offset
@@ -1459,46 +1452,25 @@ extern "C" int bg_tracer_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap
   w.n_entries = ss->n;
   w.d_ref_map = d_ref_map;
   {
+    // The readmap's columns come narrow and shared (readmap_tables: made on the device, downloaded once, the same object the
+    // coverage session reads); the seqset's sizes and the reference map are this session's, through the pinned double buffer.
     std::shared_ptr<HostTables> h(new HostTables);
-    BG_TRY(download(ctx, h->sizes, ss->sizes.p, ss->n));
-    BG_TRY(download(ctx, h->ref_map, d_ref_map, ss->n));
-    std::vector<uint64_t> entry_id;  // per read id, ascending; only needed to build the rank tables
-    BG_TRY(download(ctx, entry_id, rm->entry_id.p, rm->n_reads));
-    h->has_reads.assign((ss->n + 63) / 64 + 1, 0);
-    for (uint64_t e : entry_id) h->has_reads[e >> 6] |= 1ull << (e & 63);
-    h->word_rank.resize(h->has_reads.size() + 1);
-    uint32_t before = 0;
-    for (size_t i = 0; i < h->has_reads.size(); ++i) { h->word_rank[i] = before; before += uint32_t(__builtin_popcountll(h->has_reads[i])); }
-    h->word_rank[h->has_reads.size()] = before;
-    h->group_start.reserve(size_t(before) + 1);
-    for (size_t i = 0; i < entry_id.size(); ++i)
-      if (i == 0 || entry_id[i] != entry_id[i - 1]) h->group_start.push_back(uint32_t(i));
-    h->group_start.push_back(uint32_t(entry_id.size()));
-    if (h->group_start.size() != size_t(before) + 1) return fail("bg_tracer_open: the readmap's read ids are not grouped by entry");
-    std::vector<uint64_t> tmp;
-    BG_TRY(download(ctx, tmp, rm->mate_loop_ptr.p, rm->n_reads));
-    h->mate_loop.assign(tmp.begin(), tmp.end());
-    BG_TRY(download(ctx, tmp, rm->is_forward.p, rm->n_reads));
-    h->is_forward.resize(rm->n_reads);
-    for (size_t i = 0; i < tmp.size(); ++i) h->is_forward[i] = uint8_t(tmp[i] & 1);
-    BG_TRY(download(ctx, tmp, rm->read_len.p, rm->n_reads));  // readmap::get_readlength: the pop tracer's limits
-    h->read_len.resize(rm->n_reads);
-    for (size_t i = 0; i < tmp.size(); ++i) h->read_len[i] = uint8_t(tmp[i]);
+    BG_TRY(readmap_tables(ctx, ss, rm, &h->rt));
+    h->sizes.resize(ss->n);
+    h->ref_map.resize(ss->n);
+    if (ss->n) {
+      BG_TRY(staged_download(ctx, h->sizes.data(), ss->sizes.p, ss->n, 0));
+      BG_TRY(staged_download(ctx, h->ref_map.data(), d_ref_map, ss->n, 0));
+    }
     w.tables = h;
-    // the same columns on the device for the never-branching traces (k_trace_simple); BG_TRACER_DEVICE_SIMPLE=0: not made
+    // the device copies serve the never-branching traces (k_trace_simple); BG_TRACER_DEVICE_SIMPLE=0: not used
     const char* off = getenv("BG_TRACER_DEVICE_SIMPLE");
-    if (!(off && off[0] == '0') && rm->n_reads < (uint64_t(1) << 32)) {
+    if (!(off && off[0] == '0')) {
       std::shared_ptr<DeviceTables> d(new DeviceTables);
-      auto up = [&](auto** dst, const auto& v) -> int {
-        using T = typename std::remove_reference<decltype(v)>::type::value_type;
-        BG_HIP(hipMalloc(reinterpret_cast<void**>(dst), (v.size() ? v.size() : 1) * sizeof(T)));
-        if (!v.empty()) BG_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-        return BG_OK;
-      };
-      BG_TRY(up(&d->word_rank, h->word_rank));
-      BG_TRY(up(&d->group_start, h->group_start));
-      BG_TRY(up(&d->mate_loop, h->mate_loop));
-      BG_TRY(up(&d->is_forward, h->is_forward));
+      d->word_rank = h->rt->d_word_rank;
+      d->group_start = h->rt->d_group_start;
+      d->mate_loop = h->rt->d_mate_loop;
+      d->is_forward = h->rt->d_is_forward;
       w.dev_tables = d;
     }
   }
@@ -1956,7 +1928,7 @@ struct PopTracer {
         if (!w.has_mate(rc_read_id)) continue;
         int64_t start_offset = offset - len, limit_offset = offset + len;
         if (right_anchor) start_offset -= len; else limit_offset += len;
-        const int64_t size = w.tables->read_len[rc_read_id];
+        const int64_t size = w.tables->rt->read_len[rc_read_id];
         if (bool(w.is_forward[rc_read_id]) == (w.o.forward_pairs_face_inward != 0)) start_offset -= size + int64_t(w.o.max_pair_distance);
         else limit_offset += size + int64_t(w.o.max_pair_distance);
         items.push_back(Item{nullptr, PendingRead{w.get_mate(rc_read_id), start_offset, limit_offset}});
@@ -2183,7 +2155,7 @@ struct PopTracer {
         const uint32_t rid = ids[j];
         if (!w.has_mate(rid)) continue;
         if (++read_count > w.o.max_pairs_per_read) break;
-        add_mate(int64_t(w.tables->read_len[rid]), bool(w.is_forward[rid]), w.get_rev_comp(w.get_mate(rid)));
+        add_mate(int64_t(w.tables->rt->read_len[rid]), bool(w.is_forward[rid]), w.get_rev_comp(w.get_mate(rid)));
       }
     }
     ref_t[4] += now_seconds() - t_mark; t_mark = now_seconds();

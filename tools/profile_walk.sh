@@ -20,7 +20,7 @@ python3 tools/prof_summary.py "$OUT/${TAG}_stats" "$OUT/${TAG}_fetch" "$OUT/${TA
 python3 - "$OUT/${TAG}_all.json" "$OUT/${TAG}_walk_summary.json" <<'PY'
 import json
 import sys
-walk = ("k_ref_map_chains", "k_branch_trace", "k_tracer_extend", "k_walk_chains", "k_ref_walk_entries", "k_push_to_pair_trace",
+walk = ("k_ref_map_chains", "k_branch_trace", "k_tracer_extend", "k_walk_chains", "k_ref_walk_entries", "k_push_to_pair_trace", "k_push_to_pair_single", "k_propagate_single",
         "k_propagate_from_end", "k_trace_simple", "k_push_front", "k_prefix_reads", "k_read_info", "k_pop_front", "k_find", "k_trace_one_base")
 rows = [e for e in json.load(open(sys.argv[1])) if any(w in e["kernel"] for w in walk)]
 json.dump(rows, open(sys.argv[2], "w"), indent=1)
