@@ -965,6 +965,11 @@ extern "C" int bg_ref_map_build(bg_ctx* ctx, const bg_seqset* ss, const uint8_t*
     const uint64_t want = std::max<uint64_t>(1024, (2 * bases) / 131072);
     chain_bases = uint32_t(std::min<uint64_t>(4096, (want + 255) / 256 * 256));
   }
+  // The reference warms a chunk up over 256 bases.  A chain's context is a prefix of the sequential walk's and grows by a base
+  // a step until the two are equal, and no context is longer than the longest entry: max_len + 1 steps are enough (what the
+  // tracer's read-ahead chains use, bg_ref_walk_entries) -- 151 instead of 256 for 150-base reads, an eighth of a 1024-base
+  // chain's steps less.  Same cells (tests/test_gpu_discover.py: the oracle walks the reference's 256).
+  const uint64_t warm = std::min<uint64_t>(256, uint64_t(ss->max_len) + 1);
   std::vector<uint64_t> cstart;
   std::vector<uint32_t> clen, cpre;
   std::vector<int8_t> cdir;
@@ -973,8 +978,8 @@ extern "C" int bg_ref_map_build(bg_ctx* ctx, const bg_seqset* ss, const uint8_t*
     uint64_t st = h_ext_start[x], len = h_ext_size[x];
     for (uint64_t cs = 0; cs < len; cs += chain_bases) {
       uint64_t ce = cs + chain_bases < len ? cs + chain_bases : len;
-      uint64_t pre = cs >= 256 ? cs - 256 : 0;                 // ref_map.cpp:95-100
-      uint64_t pre_rc = ce + 256 < len ? ce + 256 : len;       // :102-106
+      uint64_t pre = cs >= warm ? cs - warm : 0;               // ref_map.cpp:95-100
+      uint64_t pre_rc = ce + warm < len ? ce + warm : len;     // :102-106
       cstart.push_back(st + pre); clen.push_back(uint32_t(ce - pre)); cpre.push_back(uint32_t(cs - pre)); cdir.push_back(1);
       cstart.push_back(st + pre_rc - 1); clen.push_back(uint32_t(pre_rc - cs)); cpre.push_back(uint32_t(pre_rc - ce)); cdir.push_back(-1);
       total += (ce - pre) + (pre_rc - cs);
