@@ -190,6 +190,21 @@ def main():
                             print(" gpu   ", g_[0], g_[1][:6], g_[2][:4], flush=True)
                             print(" oracle", nb_, ev_[:6], cur_[:4], flush=True)
                             return 1
+                    # the extension trace (push_to_pair's loop) and propagate_from_end from the same one-range frontiers: the
+                    # packed kernels of round 6 (sixteen traces a wave / a lane an assembly) on odd alphabets and short reads
+                    steps = int(rng.integers(3, 250))  # (the oracle's seen set has no cap: fewer steps than the list's 256 places)
+                    gott = ss.push_to_pair_trace_batch(fronts, mo, max_steps=steps)
+                    for f_, g_ in zip(fronts, gott):
+                        if g_ != oss.push_to_pair_trace(f_, mo, steps):
+                            print("P2P MISMATCH seed", seed, prm, "mo", mo, "steps", steps, "front", f_, flush=True)
+                            return 1
+                    rcs = [(3 - s_[::-1]).astype(np.uint8) for s_ in seqs]
+                    gotp = ss.propagate_from_end_batch(rcs, fronts)
+                    for s_, f_, g_ in zip(rcs, fronts, gotp):
+                        want_ent, _ = oss.propagate_from_end(s_, f_)
+                        if g_[0] != {0: want_ent[0]}:
+                            print("PROPAGATE MISMATCH seed", seed, prm, "front", f_, "len", len(s_), flush=True)
+                            return 1
         ok = ss.size() == len(oent)
         if ok:
             got, want = ss.parts(), oss.parts()
