@@ -17,6 +17,7 @@
 #include "bg_internal.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <vector>
@@ -267,6 +268,82 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_num_sgpr(SK_GEN_S
   }
 }
 
+// Level 0 and level 1 in one: the tile's records leave for the REGION of their bucket's top 8 bits (region b = places
+// [b * bin_cap, (b + 1) * bin_cap) of out / org; bin_cursor[b] counts what it holds) instead of one block in arrival order that
+// a histogram pass and a scatter pass then regroup -- a read of all records, a scan and a read + write of all of them less
+// (0.52 + 0.13 + 1.26 ms on the bench's chr20; the generator pays 1.17 of it back: its writes are 16-byte pieces now).  A bin's records of one tile are reserved with one global atomic (256 a tile,
+// on 256 addresses) and written side by side.  A region that would overflow sets *flag and keeps nothing past its end: the
+// caller takes the two-pass way.
+__global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_num_sgpr(SK_GEN_SGPR))) void sk_generate_binned_kernel(
+    SkSource src, SkRec* __restrict__ out, uint64_t* __restrict__ org, uint64_t bin_cap, unsigned long long* __restrict__ bin_cursor,
+    uint32_t* __restrict__ flag) {
+  __shared__ uint64_t sdesc[SK_CAP];  // read in tile : 16 | first window : 8 | windows - 1 : 8 | order : 32
+  __shared__ uint64_t sw[SK_THREADS / 64][SK_WORDS];
+  __shared__ uint32_t sn[SK_THREADS / 64][SK_WORDS];
+  __shared__ uint32_t s_cnt;
+  __shared__ uint32_t bh[SK_BINS], bfill[SK_BINS];
+  __shared__ unsigned long long bbase[SK_BINS];
+  static_assert(SK_THREADS == SK_BINS, "a thread a bin");
+  const int tid = threadIdx.x;
+  if (tid == 0) s_cnt = 0;
+  bh[tid] = 0;
+  bfill[tid] = 0;
+  __syncthreads();
+  const uint64_t r_lo = uint64_t(blockIdx.x) * src.reads_per_tile;
+  const uint64_t r_hi = r_lo + src.reads_per_tile < src.n_reads ? r_lo + src.reads_per_tile : src.n_reads;
+  constexpr int kBinShift = SK_BUCKET_FIELD - 8;
+  tile_skms(src, r_lo, r_hi, sw[tid >> 6], sn[tid >> 6], [&](bool emit, uint64_t read, int s0, int n, uint32_t order) {
+    const uint64_t em = __ballot(emit);
+    if (!em) return;  // wave-uniform
+    const int lane = tid & 63, leader = __ffsll((unsigned long long)em) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&s_cnt, uint32_t(__popcll(em)));
+    base = uint32_t(__builtin_amdgcn_readlane(int(base), leader));
+    if (!emit) return;
+    const uint32_t s = base + uint32_t(__popcll(em & ((1ull << lane) - 1)));
+    if (s < uint32_t(SK_CAP)) {
+      sdesc[s] = (uint64_t(read - r_lo) << 48) | (uint64_t(s0) << 40) | (uint64_t(n - 1) << 32) | order;
+    } else {  // the staging area is full (minimisers changing at nearly every window): one record at a time
+      const uint32_t bin = sk_bucket_of(order) >> kBinShift;
+      const unsigned long long g = atomicAdd(&bin_cursor[bin], 1ull);
+      if (g < bin_cap) {
+        out[uint64_t(bin) * bin_cap + g] = sk_build_record(src.words + read * src.W, src.W, s0, n, src.k, order);
+        org[uint64_t(bin) * bin_cap + g] = (read << 8) | uint64_t(s0);
+      } else {
+        atomicOr(flag, 1u);
+      }
+    }
+  });
+  __syncthreads();
+  // (Measured and put away, 7.50 ms as it stands against 6.34 for the plain generator: the tile's descriptions put in bin order
+  // in LDS first, so that consecutive lanes write consecutive places -- 8.96 ms, the registers and the second staging array
+  // cost more waves than the writes gain; a record's place in its bin counted where the record comes about -- 7.72 ms.)
+  const uint32_t total = s_cnt < uint32_t(SK_CAP) ? s_cnt : uint32_t(SK_CAP);
+  for (uint32_t i = tid; i < total; i += SK_THREADS) atomicAdd(&bh[sk_bucket_of(uint32_t(sdesc[i])) >> kBinShift], 1u);
+  __syncthreads();
+  {  // every bin's share of its region, reserved with one global atomic
+    const uint32_t c = bh[tid];
+    unsigned long long g = 0;
+    if (c) {
+      g = atomicAdd(&bin_cursor[tid], (unsigned long long)c);
+      if (g + c > bin_cap) { atomicOr(flag, 1u); g = ~0ull; }
+    }
+    bbase[tid] = g;
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < total; i += SK_THREADS) {
+    const uint64_t d = sdesc[i];
+    const uint32_t bin = sk_bucket_of(uint32_t(d)) >> kBinShift;
+    const uint32_t slot = atomicAdd(&bfill[bin], 1u);
+    const unsigned long long g = bbase[bin];
+    if (g == ~0ull) continue;
+    const uint64_t read = r_lo + (d >> 48);
+    const uint64_t o = uint64_t(bin) * bin_cap + g + slot;
+    out[o] = sk_build_record(src.words + read * src.W, src.W, int(d >> 40) & 0xff, (int(d >> 32) & 0xff) + 1, src.k, uint32_t(d));
+    org[o] = (read << 8) | ((d >> 40) & 0xff);  // origin: read : first window
+  }
+}
+
 // ---- further levels: one unstable pass over records already grouped into segments ------------------
 // A tile of 3 072 records is 64 KB of LDS: two workgroups a CU.  With 256 threads of 12 records each that was 8 waves a CU and
 // the two scatter passes took 1.84 + 1.82 ms; 256 x 8 (three workgroups): 1.61 + 1.62; 512 x 6: 1.40 + 1.45; 1 024 x 3
@@ -279,6 +356,8 @@ struct SkSegs {
   const uint64_t* seg_rec0;   // S+1 record offsets
   const uint32_t* seg_tile0;  // S+1 tile offsets
   int nseg;
+  const uint64_t* seg_end;    // null: segment s ends where s + 1 starts; else its end (segments with room behind them: the
+                              // regions sk_generate_binned_kernel fills)
 };
 
 __device__ __forceinline__ void sk_locate(const SkSegs& sg, uint32_t tile, uint64_t* lo, uint64_t* hi, uint64_t* hist_base,
@@ -292,7 +371,7 @@ __device__ __forceinline__ void sk_locate(const SkSegs& sg, uint32_t tile, uint6
   *tiles_in_seg = sg.seg_tile0[a + 1] - t0;
   *tile_in_seg = tile - t0;
   *lo = sg.seg_rec0[a] + uint64_t(tile - t0) * SK2_TILE;
-  const uint64_t end = sg.seg_rec0[a + 1];
+  const uint64_t end = sg.seg_end ? sg.seg_end[a] : sg.seg_rec0[a + 1];
   *hi = *lo + SK2_TILE < end ? *lo + SK2_TILE : end;
   *hist_base = uint64_t(t0) * SK_BINS;
 }
@@ -991,27 +1070,31 @@ int kmer_skm_finish_present(bg_ctx* ctx, bg_kmerset* ks) {
 template <typename Org, bool kIndex>
 static int sk_partition_segmented(bg_ctx* ctx, const SkRec* in, SkRec* out, const Org* oin, Org* oout, uint64_t n,
                                   uint32_t nseg, const uint64_t* h_rec0, int shift, uint32_t dmask,
-                                  uint32_t* full_bits = nullptr) {
+                                  uint32_t* full_bits = nullptr, const uint64_t* h_end = nullptr) {
   std::vector<uint32_t> h_tile(size_t(nseg) + 1, 0);
   uint64_t t = 0;
   for (uint32_t b = 0; b < nseg; ++b) {
     h_tile[b] = uint32_t(t);
-    t += (h_rec0[b + 1] - h_rec0[b] + SK2_TILE - 1) / SK2_TILE;
+    t += ((h_end ? h_end[b] : h_rec0[b + 1]) - h_rec0[b] + SK2_TILE - 1) / SK2_TILE;
   }
   if (t >= (1ull << 31)) { set_error("partition of %llu super-k-mers needs too many tiles", (unsigned long long)n); return BG_EINVAL; }
   h_tile[nseg] = uint32_t(t);
   const uint32_t ntiles = uint32_t(t);
   if (!ntiles) return BG_OK;
   DevBuf<uint32_t> hist, seg_tile;
-  DevBuf<uint64_t> offs, seg_rec;
+  DevBuf<uint64_t> offs, seg_rec, seg_end;
   BG_TRY(hist.alloc(ctx, size_t(SK_BINS) * ntiles));
   BG_TRY(offs.alloc(ctx, size_t(SK_BINS) * ntiles));
   BG_TRY(seg_rec.alloc(ctx, size_t(nseg) + 1));
   BG_TRY(seg_tile.alloc(ctx, size_t(nseg) + 1));
   BG_HIP(hipMemcpyAsync(seg_rec.p, h_rec0, (size_t(nseg) + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   BG_HIP(hipMemcpyAsync(seg_tile.p, h_tile.data(), (size_t(nseg) + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (h_end) {
+    BG_TRY(seg_end.alloc(ctx, nseg));
+    BG_HIP(hipMemcpyAsync(seg_end.p, h_end, size_t(nseg) * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
   BG_HIP(hipStreamSynchronize(ctx->stream));
-  SkSegs sg{seg_rec.p, seg_tile.p, int(nseg)};
+  SkSegs sg{seg_rec.p, seg_tile.p, int(nseg), h_end ? seg_end.p : nullptr};
   ctx->tic("skm_part_hist");
   sk_part_hist_kernel<<<ntiles, SK2_THREADS, 0, ctx->stream>>>(in, sg, shift, dmask, hist.p);
   BG_LAUNCH_CHECK();
@@ -1102,7 +1185,37 @@ static int sk_level1(bg_ctx* ctx, const SkRec* in, SkRec* out, const Org* oin, O
 }
 
 static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, uint64_t R, uint64_t N, int k,
-                            uint32_t min_count, bg_kmerset* ks, uint32_t* bits_out);
+                            uint32_t min_count, bg_kmerset* ks, uint32_t* bits_out, const uint64_t* binned_start = nullptr,
+                            const uint64_t* binned_end = nullptr);
+
+// level 0 + 1 in one kernel (sk_generate_binned_kernel): ra / oa hold 256 regions of bin_cap places; h_count[b] = records in
+// region b.  *fits = false: a region overflowed (the content is incomplete: take sk_generate and the two-pass level 1).
+static int sk_generate_binned(bg_ctx* ctx, const bg_reads* reads, const SkGeometry& g, SkRec* ra, uint64_t* oa, uint64_t bin_cap,
+                              uint64_t* h_count, uint64_t* R_out, bool* fits) {
+  DevBuf<unsigned long long> cursor;
+  DevBuf<uint32_t> flag;
+  BG_TRY(cursor.alloc(ctx, SK_BINS));
+  BG_TRY(flag.alloc(ctx, 1));
+  BG_HIP(hipMemsetAsync(cursor.p, 0, SK_BINS * 8, ctx->stream));
+  BG_HIP(hipMemsetAsync(flag.p, 0, 4, ctx->stream));
+  ctx->tic("skm_generate");
+  sk_generate_binned_kernel<<<g.ntiles, SK_THREADS, 0, ctx->stream>>>(g.src, ra, oa, bin_cap, cursor.p, flag.p);
+  BG_LAUNCH_CHECK();
+  uint32_t h_flag = 0;
+  BG_HIP(hipMemcpyAsync(h_count, cursor.p, SK_BINS * 8, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipMemcpyAsync(&h_flag, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BG_HIP(hipStreamSynchronize(ctx->stream));
+  uint64_t R = 0;
+  bool ok = h_flag == 0;
+  for (int b = 0; b < SK_BINS; ++b) {
+    if (h_count[b] > bin_cap) ok = false;
+    R += h_count[b];
+  }
+  ctx->toc(R * 24 + reads->n * uint64_t(reads->W) * 12);
+  *R_out = R;
+  *fits = ok;
+  return BG_OK;
+}
 
 // Counts the canonical k-mers of `reads` (N windows in all, for sizing) into ks->kmers / counts / distinct and
 // fills ks->present.  *done = false when this path does not apply and nothing was done.
@@ -1117,10 +1230,43 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
   uint64_t R = 0;
   ks->present_stride = std::max(1, (g.maxw + 63) / 64);
   BG_TRY(ks->present.alloc(ctx, reads->n * ks->present_stride));
-  BG_TRY(sk_generate(ctx, reads, g, ra.p, oa.p, &R));
-  if (R > g.cap) {  // *done stays false
-    ks->present.reset();
-    return BG_OK;
+  // BG_SKM_BINNED=1: the records leave the generator grouped by the top byte of their bucket (sk_generate_binned_kernel: 256
+  // regions of cap / 256 places, three times a bin's expected share; a region that overflows sends the input through the plain
+  // generator and the two-pass first level).  Measured on the bench's chr20 and left off: the first level's histogram, scan
+  // and scatter go (1.9 ms) but the generator's writes are 16-byte pieces instead of one block (6.34 -> 7.50 ms): 0.6 ms of
+  // 48.9 for the step, and the dominant kernel a fifth slower.
+  std::vector<uint64_t> bin_start, bin_end;
+  {
+    // (tests: =big gives every region the whole buffer's length -- small inputs, whose bins are far from even, stay on this
+    // path; =tiny gives them 8 places -- the overflow and the way back)
+    const char* e = getenv("BG_SKM_BINNED");
+    uint64_t bin_cap = g.cap / SK_BINS;
+    if (e && !strcmp(e, "big")) bin_cap = g.cap;
+    if (e && !strcmp(e, "tiny")) bin_cap = 8;
+    if (bin_cap > g.cap / SK_BINS) {  // (room for the regions)
+      ra.reset();
+      oa.reset();
+      BG_TRY(ra.alloc(ctx, bin_cap * SK_BINS));
+      BG_TRY(oa.alloc(ctx, bin_cap * SK_BINS));
+    }
+    if (e && e[0] != '0' && bin_cap >= 8 && bin_cap * SK_BINS < (1ull << 32)) {
+      std::vector<uint64_t> cnt(SK_BINS);
+      bool fits = false;
+      BG_TRY(sk_generate_binned(ctx, reads, g, ra.p, oa.p, bin_cap, cnt.data(), &R, &fits));
+      if (fits) {
+        bin_start.resize(SK_BINS + 1);
+        bin_end.resize(SK_BINS);
+        for (int b = 0; b <= SK_BINS; ++b) bin_start[b] = uint64_t(b) * bin_cap;
+        for (int b = 0; b < SK_BINS; ++b) bin_end[b] = bin_start[b] + cnt[b];
+      }
+    }
+  }
+  if (bin_start.empty()) {
+    BG_TRY(sk_generate(ctx, reads, g, ra.p, oa.p, &R));
+    if (R > g.cap) {  // *done stays false
+      ks->present.reset();
+      return BG_OK;
+    }
   }
   *done = true;
   if (reads->W > 8) { set_error("k-mer counting: reads of more than 256 bases"); return BG_EINVAL; }
@@ -1130,14 +1276,18 @@ int kmer_count_skm(bg_ctx* ctx, const bg_reads* reads, int k, uint64_t N, uint32
   BG_LAUNCH_CHECK();
   ks->present_of = reads;
   ks->present_n = reads->n;
-  return sk_count_records(ctx, ra.p, oa.p, R, N, k, min_count, ks, nullptr);
+  return sk_count_records(ctx, ra.p, oa.p, R, N, k, min_count, ks, nullptr, bin_start.empty() ? nullptr : bin_start.data(),
+                          bin_start.empty() ? nullptr : bin_end.data());
 }
 
 // Partition + count of R records (in / oin are only read).  bits_out == nullptr: oin holds their origins and the
 // presence bits go to ks->present (local count); else oin is not used and bits_out[i] receives the presence bits
 // of the windows of record i (kSkUnknown for the records of overflowed buckets).
+// binned_start / binned_end (257 / 256 values): `in` / `oin` are sk_generate_binned's regions -- the first level is done, the
+// records' indices are their places in the regions.
 static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, uint64_t R, uint64_t N, int k,
-                            uint32_t min_count, bg_kmerset* ks, uint32_t* bits_out) {
+                            uint32_t min_count, bg_kmerset* ks, uint32_t* bits_out, const uint64_t* binned_start,
+                            const uint64_t* binned_end) {
   const int nmax = std::min(32, 52 - k);
   ks->distinct = 0;
   ks->size = 0;
@@ -1155,17 +1305,24 @@ static int sk_count_records(bg_ctx* ctx, const SkRec* in, const uint64_t* oin, u
   BG_TRY(rc.alloc(ctx, R));
   BG_TRY(oc.alloc(ctx, R));
   std::vector<uint64_t> h_starts(SK_BINS + 1);
-  // (remote records: bits_out starts as "every window kept" and the spread only writes what differs)
-  BG_TRY((sk_level1<uint32_t, true>(ctx, in, rb.p, nullptr, ob.p, R, h_starts.data(), bits_out)));
-
   // level 2: the next 8 bits inside each of the 256 groups; bigger inputs take up to 5 more bits so that a
   // bucket stays around 24 k windows (BG_KMER_EXTRA_BITS overrides, for tests).  A rank of a sharded build
   // owns a slice of the bucket space: the level is chosen from the groups that are in use.
-  BG_TRY((sk_partition_segmented<uint32_t, false>(ctx, rb.p, rc.p, ob.p, oc.p, R, SK_BINS, h_starts.data(), SK_BUCKET_FIELD - 16, 0xffu)));
+  if (binned_start) {
+    // (the generator grouped the records by the top byte already: this level reads its regions and makes the indices)
+    for (int b8 = 0; b8 < SK_BINS; ++b8) { h_starts[b8] = binned_start[b8]; }
+    h_starts[SK_BINS] = binned_start[SK_BINS];
+    BG_TRY((sk_partition_segmented<uint32_t, true>(ctx, in, rc.p, nullptr, oc.p, R, SK_BINS, binned_start, SK_BUCKET_FIELD - 16, 0xffu, nullptr,
+                                                   binned_end)));
+  } else {
+    // (remote records: bits_out starts as "every window kept" and the spread only writes what differs)
+    BG_TRY((sk_level1<uint32_t, true>(ctx, in, rb.p, nullptr, ob.p, R, h_starts.data(), bits_out)));
+    BG_TRY((sk_partition_segmented<uint32_t, false>(ctx, rb.p, rc.p, ob.p, oc.p, R, SK_BINS, h_starts.data(), SK_BUCKET_FIELD - 16, 0xffu)));
+  }
   int extra = 0;
   {
     uint64_t used = 0;
-    for (int b8 = 0; b8 < SK_BINS; ++b8) used += h_starts[b8 + 1] > h_starts[b8];
+    for (int b8 = 0; b8 < SK_BINS; ++b8) used += binned_start ? binned_end[b8] > binned_start[b8] : h_starts[b8 + 1] > h_starts[b8];
     const uint64_t per_bucket = N / (256 * (used ? used : 1));
     while (extra < SK_BUCKET_FIELD - 16 && (per_bucket >> extra) > 24000) ++extra;
   }

@@ -61,6 +61,12 @@ def test_read_length_edges(ctx, k, rl):
 
 
 @pytest.mark.parametrize("env", [{"BG_SKM_READS_PER_TILE": "50000"}, {"BG_SKM_CAP": "100"},
+                                 # the generator that groups its records by the top byte of their bucket (BG_SKM_BINNED=1;
+                                 # measured, left off): regions big enough for any input, with the staging area overfilled as
+                                 # well; regions of the default length and of 8 places (they overflow: back to the plain generator)
+                                 {"BG_SKM_BINNED": "big"}, {"BG_SKM_BINNED": "big", "BG_SKM_READS_PER_TILE": "50000"},
+                                 {"BG_SKM_BINNED": "tiny"}, {"BG_SKM_BINNED": "1"},
+                                 {"BG_SKM_BINNED": "big", "BG_KMER_EXTRA_BITS": "3"},
                                  {"BG_KMER_EXTRA_BITS": "3"}, {"BG_KMER_EXTRA_BITS": "5", "BG_KMER_LDS_LOG2CAP": "4"},
                                  {"BG_KMER_SKM": "0"},
                                  # a first table most buckets overflow, a second try that takes some of them and
@@ -81,7 +87,8 @@ def test_overflow_and_fallback_paths(ctx, monkeypatch, env):
                                  # buckets at this size: chains spill over into the next region)
                                  {"BG_HASH_REGION_MIN_LOG2CAP": "19", "BG_HASH_MIN_LOG2CAP": "19"},
                                  {"BG_HASH_REGION_MIN_LOG2CAP": "19", "BG_HASH_MIN_LOG2CAP": "20"},
-                                 {"BG_SCREEN_LOOKUP": "1"}, {"BG_SKM_READS_PER_TILE": "50000"}])
+                                 {"BG_SCREEN_LOOKUP": "1"}, {"BG_SKM_READS_PER_TILE": "50000"}, {"BG_SKM_BINNED": "big"},
+                                 {"BG_SKM_BINNED": "big", "BG_KMER_LDS_LOG2CAP": "2"}])
 def test_presence_bits_drive_the_correction(ctx, monkeypatch, env):
     """bg_correct_reads takes the window presence from the count (no look-ups); the buckets whose table
     overflowed get theirs from the finished hash set; BG_SCREEN_LOOKUP=1 is the look-up screen."""
