@@ -22,7 +22,10 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <thread>
 
 namespace bg {
@@ -33,6 +36,7 @@ struct RcclApi {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
   decltype(&ncclSend) Send = nullptr;
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -69,6 +73,7 @@ int rccl_load() {
   BG_SYM(GetUniqueId, "ncclGetUniqueId")
   BG_SYM(CommInitRank, "ncclCommInitRank")
   BG_SYM(CommDestroy, "ncclCommDestroy")
+  BG_SYM(CommAbort, "ncclCommAbort")
   BG_SYM(Send, "ncclSend")
   BG_SYM(Recv, "ncclRecv")
   BG_SYM(GroupStart, "ncclGroupStart")
@@ -135,6 +140,16 @@ struct bg_comm {
   bool flying = false;
   void* d_small = nullptr;  // (world + 1) * kSmall: [mine][everybody's]
   void* h_small = nullptr;  // pinned, same layout
+  // rccl watchdog: an event behind every operation handed to RCCL; one that has not completed timeout_s after it was queued
+  // aborts the communicator (ncclCommAbort: the kernels that wait for a peer leave, the streams drain) and every later call
+  // on it fails -- a collective that a peer never enters would otherwise hang the build, and whatever runs it, for ever.
+  std::thread watchdog;
+  std::mutex wd_mu;
+  std::condition_variable wd_cv;
+  bool wd_stop = false;
+  std::deque<std::pair<hipEvent_t, double>> wd_pending;
+  std::vector<hipEvent_t> wd_free;
+  std::atomic<bool> aborted{false};
   // shm
   std::string name;
   bg::Fabric fab;
@@ -252,6 +267,55 @@ int shm_transfer(bg_comm* c, const void* d_send, size_t send_total, const uint64
   return shm_barrier(c);  // nobody overwrites its segment while it is being read
 }
 
+// ---- the RCCL watchdog (bg_comm::watchdog)
+int rccl_alive(bg_comm* c) {
+  if (c->aborted.load() || (c->backend == 0 && !c->shortcut && !c->nccl)) {
+    set_error("bg_comm(rccl): rank %d: a collective did not complete within %.0f s (BG_COMM_TIMEOUT_S) and the communicator was aborted",
+              c->rank, c->timeout_s);
+    return BG_EIO;
+  }
+  return BG_OK;
+}
+int rccl_handle(bg_comm* c, ncclComm_t* out) {  // the communicator, unless the watchdog has taken it away
+  std::lock_guard<std::mutex> lk(c->wd_mu);
+  *out = c->nccl;
+  if (c->aborted.load() || !c->nccl) return rccl_alive(c);
+  return BG_OK;
+}
+int rccl_note(bg_comm* c, hipStream_t stream) {  // behind an operation just handed to RCCL on `stream`
+  hipEvent_t ev = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(c->wd_mu);
+    if (!c->wd_free.empty()) { ev = c->wd_free.back(); c->wd_free.pop_back(); }
+  }
+  if (!ev) BG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  BG_HIP(hipEventRecord(ev, stream));
+  std::lock_guard<std::mutex> lk(c->wd_mu);
+  c->wd_pending.emplace_back(ev, now_s());
+  return BG_OK;
+}
+void rccl_watch(bg_comm* c) {
+  (void)hipSetDevice(c->ctx->device);
+  std::unique_lock<std::mutex> lk(c->wd_mu);
+  while (!c->wd_stop) {
+    c->wd_cv.wait_for(lk, std::chrono::milliseconds(c->timeout_s < 2.0 ? 20 : 500));
+    while (!c->wd_pending.empty() && hipEventQuery(c->wd_pending.front().first) == hipSuccess) {
+      c->wd_free.push_back(c->wd_pending.front().first);
+      c->wd_pending.pop_front();
+    }
+    (void)hipGetLastError();  // (hipErrorNotReady of the query)
+    if (!c->wd_pending.empty() && !c->aborted.load() && now_s() - c->wd_pending.front().second > c->timeout_s) {
+      c->aborted.store(true);
+      ncclComm_t comm = c->nccl;
+      c->nccl = nullptr;
+      lk.unlock();
+      fprintf(stderr, "bg_comm(rccl): rank %d: a collective has been waiting for %.0f s: aborting the communicator\n", c->rank, c->timeout_s);
+      if (comm) (void)g_rccl.CommAbort(comm);
+      lk.lock();
+    }
+  }
+}
+
 // Grouped send / recv over RCCL: piece (me -> d) = [send_off[d], +send_bytes[d]), piece (s -> me) lands at recv_off[s];
 // every piece in chunks of at most max_piece, chunk t of every pair in the t-th group.
 int rccl_transfer(bg_comm* c, const void* d_send, const uint64_t* send_off, const uint64_t* send_bytes, void* d_recv,
@@ -265,20 +329,23 @@ int rccl_transfer(bg_comm* c, const void* d_send, const uint64_t* send_off, cons
   const bool self_through_backend = !c->shortcut && P == 1;  // BG_COMM_NO_SHORTCUT at world 1
   for (size_t t = 0; t < rounds; ++t) {
     const uint64_t lo = uint64_t(t) * c->max_piece;
+    ncclComm_t comm = nullptr;
+    BG_TRY(rccl_handle(c, &comm));
     BG_NCCL(g_rccl.GroupStart());
     for (int p = 0; p < P; ++p) {
       if (p == c->rank && !self_through_backend) continue;
       if (send_bytes[p] > lo) {
         const size_t nb = size_t(std::min<uint64_t>(send_bytes[p] - lo, c->max_piece));
-        BG_NCCL(g_rccl.Send(static_cast<const char*>(d_send) + send_off[p] + lo, nb, ncclUint8, p, c->nccl, stream));
+        BG_NCCL(g_rccl.Send(static_cast<const char*>(d_send) + send_off[p] + lo, nb, ncclUint8, p, comm, stream));
         c->bytes_backend += nb;
       }
       if (recv_bytes[p] > lo) {
         const size_t nb = size_t(std::min<uint64_t>(recv_bytes[p] - lo, c->max_piece));
-        BG_NCCL(g_rccl.Recv(static_cast<char*>(d_recv) + recv_off[p] + lo, nb, ncclUint8, p, c->nccl, stream));
+        BG_NCCL(g_rccl.Recv(static_cast<char*>(d_recv) + recv_off[p] + lo, nb, ncclUint8, p, comm, stream));
       }
     }
     BG_NCCL(g_rccl.GroupEnd());
+    BG_TRY(rccl_note(c, stream));
   }
   if (!self_through_backend && send_bytes[c->rank]) {  // the piece a rank keeps is a device copy
     BG_HIP(hipMemcpyAsync(static_cast<char*>(d_recv) + recv_off[c->rank], static_cast<const char*>(d_send) + send_off[c->rank],
@@ -391,7 +458,10 @@ int comm_all_gather_host(bg_comm* c, const void* mine, size_t bytes, void* all) 
       char* d = static_cast<char*>(c->d_small);
       memcpy(h, static_cast<const char*>(mine) + lo, nb);
       BG_HIP(hipMemcpyAsync(d, h, padded, hipMemcpyHostToDevice, c->ctx->stream));
-      BG_NCCL(g_rccl.AllGather(d, d + kSmall, padded, ncclUint8, c->nccl, c->ctx->stream));
+      ncclComm_t comm = nullptr;
+      BG_TRY(rccl_handle(c, &comm));
+      BG_NCCL(g_rccl.AllGather(d, d + kSmall, padded, ncclUint8, comm, c->ctx->stream));
+      BG_TRY(rccl_note(c, c->ctx->stream));
       BG_HIP(hipMemcpyAsync(h + kSmall, d + kSmall, padded * P, hipMemcpyDeviceToHost, c->ctx->stream));
       BG_HIP(hipStreamSynchronize(c->ctx->stream));
       for (int r = 0; r < P; ++r) memcpy(static_cast<char*>(all) + size_t(r) * bytes + lo, h + kSmall + size_t(r) * padded, nb);
@@ -434,7 +504,10 @@ int comm_all_reduce_sum_u64(bg_comm* c, uint64_t* d_buf, size_t n) {
     rc = shm_barrier(c);
   } else {
     BG_TRY(comm_exchange_wait(c));
-    BG_NCCL(g_rccl.AllReduce(d_buf, d_buf, n, ncclUint64, ncclSum, c->nccl, c->ctx->stream));
+    ncclComm_t comm = nullptr;
+    BG_TRY(rccl_handle(c, &comm));
+    BG_NCCL(g_rccl.AllReduce(d_buf, d_buf, n, ncclUint64, ncclSum, comm, c->ctx->stream));
+    BG_TRY(rccl_note(c, c->ctx->stream));
     c->bytes_backend += n * sizeof(uint64_t);
   }
   c->seconds += now_s() - t0;
@@ -459,8 +532,15 @@ int bg_comm_unique_id(char* id_out) {
 void bg_comm_free(bg_comm* c) {
   if (!c) return;
   if (c->ctx) (void)hipSetDevice(c->ctx->device);
+  if (c->watchdog.joinable()) {
+    { std::lock_guard<std::mutex> lk(c->wd_mu); c->wd_stop = true; }
+    c->wd_cv.notify_all();
+    c->watchdog.join();
+  }
   if (c->flying) (void)hipStreamSynchronize(c->xstream);
   if (c->nccl) (void)bg::g_rccl.CommDestroy(c->nccl);
+  for (auto& pe : c->wd_pending) (void)hipEventDestroy(pe.first);
+  for (hipEvent_t e : c->wd_free) (void)hipEventDestroy(e);
   if (c->xstream) (void)hipStreamDestroy(c->xstream);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
@@ -512,6 +592,9 @@ int bg_comm_init(bg_ctx* ctx, int rank, int world, const char* id, const char* b
     BG_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
     BG_TRY(ctx->alloc(size_t(world + 1) * bg::kSmall, &c->d_small));
     BG_HIP(hipHostMalloc(&c->h_small, size_t(world + 1) * bg::kSmall, hipHostMallocDefault));
+    if (!getenv("BG_COMM_TIMEOUT_S")) c->timeout_s = 180.0;  // (a rank's collectives wait for its peers' compute: seconds; never minutes)
+    bg_comm* raw = c.get();
+    c->watchdog = std::thread([raw] { bg::rccl_watch(raw); });
   } else {
     if (!id || !*id || strlen(id) > 100 || strchr(id, '/')) { bg::set_error("bg_comm_init(shm): the id names the shared segment (a short string without '/')"); return BG_EINVAL; }
     c->name = std::string("bgcomm-") + id;

@@ -215,3 +215,60 @@ def test_comm_api_through_rccl_at_world_one():
     finally:
         del os.environ["BG_COMM_NO_SHORTCUT"]
         ctx.close()
+
+
+WATCHDOG_CHILD = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, %(root)r)
+import torch
+import biograph_amd as bg
+from biograph_amd import capi
+from tests import util
+L = capi.lib()
+ctx = bg.Context(0, torch.cuda.current_stream().cuda_stream)   # (the library's work on torch's stream, as bench.py runs it)
+ident = C.create_string_buffer(128)
+capi.check(L.bg_comm_unique_id(ident))
+comm = C.c_void_p()
+capi.check(L.bg_comm_init(ctx.h, 0, 1, ident, b"rccl", C.byref(comm)))
+n = 1 << 20
+x = torch.ones(n, dtype=torch.int64, device="cuda")
+y = torch.zeros_like(x)
+sr = (C.c_uint64 * 1)(n)
+rr = (C.c_uint64 * 1)(0)
+capi.check(L.bg_comm_all_to_all_v(comm, C.c_void_p(x.data_ptr()), sr, 8, C.c_void_p(y.data_ptr()), n, rr))   # a healthy one first
+torch.cuda.synchronize()
+assert bool((x == y).all())
+# a collective that cannot complete in time: it sits behind a kernel that spins for several seconds on the same stream (RCCL
+# itself refuses the one stuck operation a rank alone could make -- a receive nobody sends to is "invalid usage")
+import time
+t0 = time.time()
+torch.cuda._sleep(int(12e9))
+rc = L.bg_comm_all_to_all_v(comm, C.c_void_p(x.data_ptr()), sr, 8, C.c_void_p(y.data_ptr()), n, rr)
+print("queued behind the spin:", rc, flush=True)
+torch.cuda.synchronize()
+print("stream drained after %%.1f s" %% (time.time() - t0), flush=True)
+if rc == 0:
+    rc = L.bg_comm_barrier(comm)
+attempt = 0
+assert rc != 0, "no collective was ever cut short"
+msg = capi.last_error() if hasattr(capi, "last_error") else L.bg_last_error().decode()
+assert "aborted" in msg, msg
+assert L.bg_comm_barrier(comm) != 0             # every later call on the communicator fails, none hangs
+L.bg_comm_free(comm)
+reads = util.synth_reads(4, genome_len=3000, n_reads=900, read_len=100, err=0.003, n_rate=0.0)
+ss, st = ctx.create(reads, kmer_size=30, min_kmer_count=3)   # the device goes on working
+assert ss.size() > 0
+print("WATCHDOG OK", attempt)
+"""
+
+
+def test_rccl_watchdog_aborts_a_collective_that_does_not_complete():
+    """A collective a peer never enters would wait for ever, and the build with it.  bg_comm's watchdog aborts the communicator
+    when an operation handed to RCCL has not completed BG_COMM_TIMEOUT_S after it was queued (default 180 s): the waiting kernels
+    leave, the call in flight or the next one reports it, the device stays usable.  Here: an exchange queued behind a kernel that
+    spins for seconds, and a timeout of one."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BG_COMM_NO_SHORTCUT="1", BG_COMM_TIMEOUT_S="1")
+    r = subprocess.run([sys.executable, "-c", WATCHDOG_CHILD % {"root": root}], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "WATCHDOG OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    assert "aborting the communicator" in r.stderr
