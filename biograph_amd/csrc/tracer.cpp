@@ -1050,12 +1050,22 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
       BG_TRY(w.pin_q.ensure(n * sizeof(bg_trace_query)));
       BG_TRY(w.pin_r.ensure(reply_bytes + n * step_cap * 4));
       memcpy(w.pin_q.p, q.data(), n * sizeof(bg_trace_query));
-      BG_HIP(hipMemcpyAsync(dq.p, w.pin_q.p, n * sizeof(bg_trace_query), hipMemcpyHostToDevice, ctx->stream));
-      BG_TRY(tracer_extend_launch(ctx, w.ss, w.rm, n, reinterpret_cast<const bg_trace_query*>(dq.p), step_cap,
-                                  reinterpret_cast<bg_trace_reply*>(drs.p), reinterpret_cast<uint32_t*>(drs.p + reply_bytes)));
       const bg_trace_reply* replies = static_cast<const bg_trace_reply*>(w.pin_r.p);
       const uint32_t* steps = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(w.pin_r.p) + reply_bytes);
-      BG_HIP(hipMemcpyAsync(w.pin_r.p, drs.p, reply_bytes + n * step_cap * 4, hipMemcpyDeviceToHost, ctx->stream));
+      // A round is a few hundred traces: the kernel reads its queries from and writes its replies to the page-locked host
+      // buffers themselves (a launch and a wait) instead of a copy either way around it (four calls into a runtime that
+      // sixteen sessions share).  BG_TRACER_ZEROCOPY=0, or a round of more than 4096 traces: through device buffers.
+      static const bool zc_off = [] { const char* e = getenv("BG_TRACER_ZEROCOPY"); return e && e[0] == '0'; }();
+      if (!zc_off && n <= 4096) {
+        BG_TRY(tracer_extend_launch(ctx, w.ss, w.rm, n, static_cast<const bg_trace_query*>(w.pin_q.p), step_cap,
+                                    static_cast<bg_trace_reply*>(w.pin_r.p),
+                                    reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(w.pin_r.p) + reply_bytes)));
+      } else {
+        BG_HIP(hipMemcpyAsync(dq.p, w.pin_q.p, n * sizeof(bg_trace_query), hipMemcpyHostToDevice, ctx->stream));
+        BG_TRY(tracer_extend_launch(ctx, w.ss, w.rm, n, reinterpret_cast<const bg_trace_query*>(dq.p), step_cap,
+                                    reinterpret_cast<bg_trace_reply*>(drs.p), reinterpret_cast<uint32_t*>(drs.p + reply_bytes)));
+        BG_HIP(hipMemcpyAsync(w.pin_r.p, drs.p, reply_bytes + n * step_cap * 4, hipMemcpyDeviceToHost, ctx->stream));
+      }
       BG_HIP(hipStreamSynchronize(ctx->stream));
       w.seconds_device += now_seconds() - t_dev;
       ++w.stats.device_rounds;

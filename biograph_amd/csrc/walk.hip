@@ -1466,6 +1466,8 @@ __global__ __launch_bounds__(64) void k_pop_passes(SeqsetView v, ReadmapView rm,
                                                   const uint64_t* __restrict__ qe, const uint32_t* __restrict__ qs, uint32_t passes,
                                                   uint32_t min_pop_overlap, int limit, uint32_t cap, bg::PopPassRec* __restrict__ recs,
                                                   uint32_t* __restrict__ ids, unsigned int* __restrict__ ids_used) {
+  // (ids_used == null: a record's ids at the fixed place (popper * passes + pass) * cap -- no counter to share; what the
+  // zero-copy rounds use, whose buffers are the host's)
   const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint64_t b = qb[i], e = qe[i];
@@ -1486,7 +1488,7 @@ __global__ __launch_bounds__(64) void k_pop_passes(SeqsetView v, ReadmapView rm,
         return c < cap;
       });
     if (c) {
-      const unsigned at = atomicAdd(ids_used, c);
+      const unsigned at = ids_used ? atomicAdd(ids_used, c) : unsigned((i * passes + j) * cap);
       for (uint32_t k = 0; k < c; ++k) ids[at + k] = tmp[k];
       rec.ids_at = at;
       rec.n_ids = c;
@@ -1515,6 +1517,34 @@ int pop_passes(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, uint64_t 
   if (!n) return BG_OK;
   if (n * passes * cap >= (1ull << 30)) { set_error("pop_passes: batch too large"); return BG_EINVAL; }
   const size_t in_bytes = pop_passes_in_bytes(n), rec_bytes = n * passes * sizeof(PopPassRec), id_bytes = n * passes * cap * 4;
+  // A small round (nearly all of them): the kernel reads the ranges from and writes its records and ids to the page-locked host
+  // buffers themselves -- a launch and a wait instead of a copy either way around them (BG_TRACER_ZEROCOPY=0: never).
+  static const bool zc_off = [] { const char* e = getenv("BG_TRACER_ZEROCOPY"); return e && e[0] == '0'; }();
+  if (!zc_off && id_bytes <= (size_t(1) << 20)) {
+    uint8_t* hin = static_cast<uint8_t*>(pin_in);
+    memcpy(hin, h_begin, n * 8);
+    memcpy(hin + n * 8, h_end, n * 8);
+    memcpy(hin + n * 16, h_size, n * 4);
+    uint8_t* hout = static_cast<uint8_t*>(pin_out);
+    PopPassRec* h_recs = reinterpret_cast<PopPassRec*>(hout + 8);
+    uint32_t* h_ids = reinterpret_cast<uint32_t*>(hout + 8 + rec_bytes);
+    k_pop_passes<<<cdiv(n, 64), 64, 0, ctx->stream>>>(make_view(ss), make_rm_view(rm), n, reinterpret_cast<const uint64_t*>(hin),
+                                                       reinterpret_cast<const uint64_t*>(hin) + n, reinterpret_cast<const uint32_t*>(hin + n * 16),
+                                                       passes, min_pop_overlap, read_len_limit, cap, h_recs, h_ids, nullptr);
+    BG_LAUNCH_CHECK();
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    // the records as the caller reads them: a popper's passes up to the one that discards it, their ids side by side
+    recs->assign(h_recs, h_recs + n * passes);
+    for (uint64_t i = 0; i < n; ++i)
+      for (uint32_t j = 0; j < passes; ++j) {
+        PopPassRec& r = (*recs)[i * passes + j];
+        if (r.s < min_pop_overlap) break;  // (the kernel wrote nothing behind it)
+        const uint32_t at = uint32_t(ids->size());
+        ids->insert(ids->end(), h_ids + r.ids_at, h_ids + r.ids_at + r.n_ids);
+        r.ids_at = at;
+      }
+    return BG_OK;
+  }
   // device: [b n x 8][e n x 8][s n x 4, padded][counter 8][recs][ids]; the upload carries everything before the counter's end
   DevBuf<uint8_t> d;
   BG_TRY(d.alloc(ctx, in_bytes + rec_bytes + id_bytes));
