@@ -1996,7 +1996,7 @@ static int discovery_main(Args& a, const std::string& engine, int rank, int worl
       std::string fa(bg_reference_size(rf), '\0');
       check(bg_reference_bases(rf, 0, fa.size(), &fa[0]), "bg_reference_bases");
       flat_codes.resize(fa.size());
-      for (size_t i = 0; i < fa.size(); ++i) flat_codes[i] = uint8_t(fa[i] == 'A' ? 0 : fa[i] == 'C' ? 1 : fa[i] == 'G' ? 2 : 3);
+      for (size_t i = 0; i < fa.size(); ++i) flat_codes[i] = uint8_t((uint8_t(fa[i]) >> 1 ^ uint8_t(fa[i]) >> 2) & 3);  // A 0, C 1, G 2, T 3 (the bases are upper-case ACGT)
       for (uint32_t i = 0; i < bg_reference_supercontig_count(rf); ++i) {
         uint64_t len = 0, flat = 0;
         check(bg_reference_supercontig(rf, i, nullptr, nullptr, &len, &flat), "bg_reference_supercontig");

@@ -178,9 +178,20 @@ struct bg_reference {
 
 namespace {
 
+// 'A' 'C' 'G' 'T' for those letters in either case, 0 for every other byte
+static const struct UpperAcgt {
+  unsigned char t[256];
+  UpperAcgt() {
+    for (int i = 0; i < 256; ++i) t[i] = 0;
+    for (const char* p = "ACGT"; *p; ++p) { t[uint8_t(*p)] = uint8_t(*p); t[uint8_t(*p + 32)] = uint8_t(*p); }
+  }
+  unsigned char operator[](uint8_t b) const { return t[b]; }
+} kUpperAcgt;
+
 int load_fasta(const std::string& path, bg_reference* r) {
   std::string txt;
   if (!read_all(path, &txt)) { set_error("Could not open %s: %s", path.c_str(), strerror(errno)); return BG_EIO; }
+  r->bases.reserve(r->bases.size() + txt.size());
   size_t i = 0;
   while (i < txt.size()) {
     size_t eol = txt.find('\n', i);
@@ -194,20 +205,27 @@ int load_fasta(const std::string& path, bg_reference* r) {
     } else if (eol > i) {
       if (r->chromosomes.empty()) r->chromosomes.push_back(Chromosome{"ref", 0});
       Chromosome& c = r->chromosomes.back();
-      for (size_t q = i; q < eol; ++q) {
-        char ch = txt[q];
-        if (ch == '\r') continue;
-        if (ch >= 'a' && ch <= 'z') ch = char(ch - 32);
-        const bool acgt = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
-        if (acgt) {  // supercontigs = maximal N-free stretches
-          const uint32_t ci = uint32_t(r->chromosomes.size() - 1);
+      const uint32_t ci = uint32_t(r->chromosomes.size() - 1);
+      // runs of ACGT (either case) go over whole, upper-cased through a table; supercontigs = maximal N-free stretches
+      size_t q = i;
+      while (q < eol) {
+        size_t run = q;
+        while (run < eol && kUpperAcgt[uint8_t(txt[run])]) ++run;
+        if (run > q) {
           if (r->supercontigs.empty() || r->supercontigs.back().chr != ci ||
               r->supercontigs.back().offset + r->supercontigs.back().len != c.len)
             r->supercontigs.push_back(Supercontig{ci, c.len, 0, uint64_t(r->bases.size())});
-          ++r->supercontigs.back().len;
-          r->bases.push_back(ch);
+          const size_t at = r->bases.size();
+          r->bases.resize(at + (run - q));
+          for (size_t k = q; k < run; ++k) r->bases[at + (k - q)] = char(kUpperAcgt[uint8_t(txt[k])]);
+          r->supercontigs.back().len += run - q;
+          c.len += run - q;
+          q = run;
         }
-        ++c.len;
+        while (q < eol && !kUpperAcgt[uint8_t(txt[q])]) {
+          if (txt[q] != '\r') ++c.len;
+          ++q;
+        }
       }
     }
     i = eol + 1;

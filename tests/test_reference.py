@@ -52,6 +52,12 @@ def test_fasta_with_n_runs(tmp_path):
     assert ref.supercontigs == [("chr1", 0, 4), ("chr1", 8, 16), ("chr2", 2, 6)]
     assert ref.flat_bases(0, ref.size()) == "ACGT" + "ACGTACGG" + "TTTT"
     assert ref.sequence("chr1", 9, 12) == "CGT"
+    q = tmp_path / "crlf.fa"   # CRLF line ends, other IUPAC letters (not part of any supercontig), no newline at the end
+    q.write_bytes(b">c1\r\nACGTRYac\r\nGTNN\r\nnnAC")
+    ref = bg.Reference(str(q))
+    assert ref.scaffolds == ["c1"] and ref.scaffold_lens == {"c1": 16}
+    assert ref.supercontigs == [("c1", 0, 4), ("c1", 6, 10), ("c1", 14, 16)]
+    assert ref.flat_bases(0, ref.size()) == "ACGT" + "ACGT" + "AC"
 
 
 def test_errors(tmp_path):
