@@ -926,21 +926,62 @@ static bool rm_json_u64(const std::string& js, const char* key, uint64_t* out) {
   return true;
 }
 
-static void rm_unpack_bits(const std::string& blob, uint64_t n, unsigned bits, std::vector<uint64_t>* out) {
-  out->assign(n, 0);
-  if (!bits) return;
-  std::vector<uint64_t> padded((blob.size() + 7) / 8 + 1, 0);  // raw uint8 members are not word multiples
-  memcpy(padded.data(), blob.data(), blob.size());
-  const uint64_t* w = padded.data();
-  const uint64_t nw = padded.size();
-  const uint64_t mask = bits == 64 ? ~0ull : ((1ull << bits) - 1);
-  for (uint64_t i = 0; i < n; ++i) {
-    uint64_t bit = i * bits, q = bit >> 6, r = bit & 63;
-    uint64_t x = q < nw ? w[q] >> r : 0;
-    if (r + bits > 64 && q + 1 < nw) x |= w[q + 1] << (64 - r);
-    (*out)[i] = x & mask;
+// ---- bg_readmap_open's columns on the device: the container's packed vectors go up as they are (a seventh of the bytes of the
+// unpacked 64-bit columns) and are unpacked there; the entry of read id i = the (rank of i among the group heads)-th marked entry
+namespace bg {
+__global__ void k_rmo_unpack(const uint64_t* __restrict__ w, uint64_t nw, uint64_t n, unsigned bits, uint64_t* __restrict__ out,
+                             unsigned long long* __restrict__ vmax) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t bit = i * bits, q = bit >> 6, r = bit & 63;
+  uint64_t x = q < nw ? w[q] >> r : 0;
+  if (r + bits > 64 && q + 1 < nw) x |= w[q + 1] << (64 - r);
+  x &= bits == 64 ? ~0ull : ((1ull << bits) - 1);
+  out[i] = x;
+  if (vmax) {  // (a wave's maximum, one atomic)
+    unsigned long long m = x;
+    for (int d = 32; d >= 1; d >>= 1) {
+      const unsigned long long o = __shfl_xor(m, d, 64);
+      m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(vmax, m);
   }
 }
+__global__ void k_rmo_popc(const uint64_t* __restrict__ w, uint64_t nwords, uint64_t nbits, uint32_t* __restrict__ out) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= nwords) return;
+  uint64_t x = w[i];
+  if (i == nbits / 64 && (nbits & 63)) x &= (1ull << (nbits & 63)) - 1;
+  if (i > nbits / 64 || (i == nbits / 64 && !(nbits & 63))) x = 0;
+  out[i] = uint32_t(__popcll(x));
+}
+// mid_to_entry[k] = the k-th marked entry
+__global__ void k_rmo_marked(const uint64_t* __restrict__ w, uint64_t nwords, uint64_t nbits, const uint64_t* __restrict__ before,
+                             uint64_t* __restrict__ mid_to_entry) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= nwords) return;
+  uint64_t x = w[i];
+  if (i == nbits / 64 && (nbits & 63)) x &= (1ull << (nbits & 63)) - 1;
+  if (i > nbits / 64 || (i == nbits / 64 && !(nbits & 63))) x = 0;
+  uint64_t at = before[i];
+  while (x) {
+    mid_to_entry[at++] = i * 64 + uint64_t(__ffsll((unsigned long long)x) - 1);
+    x &= x - 1;
+  }
+}
+// entry of read id i (sparse_multi::reverse_lookup) and the open path's consistency checks
+__global__ void k_rmo_entries(const uint64_t* __restrict__ heads, const uint64_t* __restrict__ heads_before, uint64_t n,
+                              const uint64_t* __restrict__ mid_to_entry, uint64_t n_marked, const uint64_t* __restrict__ ptr, int pair_mode,
+                              uint64_t* __restrict__ entry, uint32_t* __restrict__ err) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t word = heads[i >> 6];
+  const uint64_t mid = heads_before[i >> 6] + uint64_t(__popcll(word & ((2ull << (i & 63)) - 1)));  // heads at or before i
+  const uint64_t p = ptr[i];
+  if (mid == 0 || mid > n_marked || (p >= n && !(pair_mode && p == 0xffffffffull))) { atomicOr(err, 1u); entry[i] = 0; return; }
+  entry[i] = mid_to_entry[mid - 1];
+}
+}  // namespace bg
 
 extern "C" int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out) {
   if (!ctx || !path || !out) { set_error("bg_readmap_open: null argument"); return BG_EINVAL; }
@@ -991,50 +1032,83 @@ extern "C" int bg_readmap_open(bg_ctx* ctx, const char* path, bg_readmap** out) 
   rm->pair_mode = pair_mode;
   size_t p = rmj->find("\"seqset_uuid\":\"");
   if (p != std::string::npos) rm->seqset_uuid = rmj->substr(p + 15, rmj->find('"', p + 15) - (p + 15));
-  std::vector<uint64_t> v_len, v_ptr, v_fwd, v_head;
   if (rl->size() < (n * rl_bits + 7) / 8 || ml->size() < (n * ml_bits + 7) / 8) { set_error("%s: truncated vectors", path); return BG_EIO; }
   if (s2m->size() < (n_ent + 63) / 64 * 8 || d2m->size() < (n + 63) / 64 * 8) { set_error("%s: truncated bit vectors", path); return BG_EIO; }
-  // sparse_multi::reverse_lookup for every read id: k-th group head -> k-th marked entry (entry ids may pass 2^32)
-  std::vector<uint64_t> mid_to_entry, v_entry(n, 0);
   {
-    // the four columns and the marked entries are independent host loops over tens of millions of elements: side by side
-    std::thread t_len([&] { rm_unpack_bits(*rl, n, unsigned(rl_bits), &v_len); });
-    std::thread t_ptr([&] { rm_unpack_bits(*ml, n, unsigned(ml_bits), &v_ptr); });
-    std::thread t_fwd([&] { rm_unpack_bits(*isf, n, 1, &v_fwd); });
-    std::thread t_head([&] { rm_unpack_bits(*d2m, n, 1, &v_head); });
-    mid_to_entry.reserve(n);
-    for (uint64_t w = 0; w < (n_ent + 63) / 64; ++w) {
-      uint64_t word;
-      memcpy(&word, s2m->data() + w * 8, 8);
-      if (w == n_ent / 64 && (n_ent & 63)) word &= (1ull << (n_ent & 63)) - 1;
-      while (word) {
-        mid_to_entry.push_back(w * 64 + uint64_t(__builtin_ctzll(word)));
-        word &= word - 1;
-      }
+    // the packed members to the device as they are (padded to whole words; 130 MB for 26 M read ids: plain copies -- a context
+    // that opens a readmap and nothing else need not lock staging buffers for it)
+    auto up_blob = [&](const std::string& blob, DevBuf<uint64_t>* d, uint64_t* nw) -> int {
+      *nw = (blob.size() + 7) / 8 + 1;
+      BG_TRY(d->alloc(ctx, *nw));
+      BG_HIP(hipMemsetAsync(d->p, 0, *nw * 8, ctx->stream));
+      if (!blob.empty()) BG_HIP(hipMemcpyAsync(d->p, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
+      return BG_OK;
+    };
+    DevBuf<uint64_t> b_len, b_ptr, b_fwd;
+    uint64_t nw_len = 0, nw_ptr = 0, nw_fwd = 0, nw_s2m = (n_ent + 63) / 64, nw_d2m = (n + 63) / 64;
+    BG_TRY(up_blob(*rl, &b_len, &nw_len));
+    BG_TRY(up_blob(*ml, &b_ptr, &nw_ptr));
+    BG_TRY(up_blob(*isf, &b_fwd, &nw_fwd));
+    BG_TRY(rm->s2m_bits.alloc(ctx, nw_s2m));
+    BG_TRY(rm->d2m_bits.alloc(ctx, nw_d2m));
+    if (nw_s2m) BG_HIP(hipMemcpyAsync(rm->s2m_bits.p, s2m->data(), nw_s2m * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (nw_d2m) BG_HIP(hipMemcpyAsync(rm->d2m_bits.p, d2m->data(), nw_d2m * 8, hipMemcpyHostToDevice, ctx->stream));
+    BG_TRY(rm->read_len.alloc(ctx, n));
+    BG_TRY(rm->mate_loop_ptr.alloc(ctx, n));
+    BG_TRY(rm->is_forward.alloc(ctx, n));
+    BG_TRY(rm->entry_id.alloc(ctx, n));
+    DevBuf<unsigned long long> vmax;
+    DevBuf<uint32_t> err, pc_s, pc_d;
+    DevBuf<uint64_t> before_s, before_d, mid_to_entry, tot;
+    BG_TRY(vmax.alloc(ctx, 1));
+    BG_TRY(err.alloc(ctx, 1));
+    BG_TRY(tot.alloc(ctx, 2));
+    BG_HIP(hipMemsetAsync(vmax.p, 0, 8, ctx->stream));
+    BG_HIP(hipMemsetAsync(err.p, 0, 4, ctx->stream));
+    if (n) {
+      k_rmo_unpack<<<cdiv(n, 256), 256, 0, ctx->stream>>>(b_len.p, nw_len, n, unsigned(rl_bits), rm->read_len.p, vmax.p);
+      BG_LAUNCH_CHECK();
+      k_rmo_unpack<<<cdiv(n, 256), 256, 0, ctx->stream>>>(b_ptr.p, nw_ptr, n, unsigned(ml_bits), rm->mate_loop_ptr.p, nullptr);
+      BG_LAUNCH_CHECK();
+      k_rmo_unpack<<<cdiv(n, 256), 256, 0, ctx->stream>>>(b_fwd.p, nw_fwd, n, 1u, rm->is_forward.p, nullptr);
+      BG_LAUNCH_CHECK();
     }
-    t_len.join(); t_ptr.join(); t_fwd.join(); t_head.join();
+    // marked entries in order, group heads before every word
+    BG_TRY(pc_s.alloc(ctx, nw_s2m + 1));
+    BG_TRY(pc_d.alloc(ctx, nw_d2m + 1));
+    BG_TRY(before_s.alloc(ctx, nw_s2m + 1));
+    BG_TRY(before_d.alloc(ctx, nw_d2m + 1));
+    uint64_t h_tot[2] = {0, 0};
+    if (nw_s2m) {
+      k_rmo_popc<<<cdiv(nw_s2m, 256), 256, 0, ctx->stream>>>(rm->s2m_bits.p, nw_s2m, n_ent, pc_s.p);
+      BG_LAUNCH_CHECK();
+      BG_TRY(exclusive_scan_u32_to_u64(ctx, pc_s.p, before_s.p, nw_s2m, tot.p));
+    }
+    if (nw_d2m) {
+      k_rmo_popc<<<cdiv(nw_d2m, 256), 256, 0, ctx->stream>>>(rm->d2m_bits.p, nw_d2m, n, pc_d.p);
+      BG_LAUNCH_CHECK();
+      BG_TRY(exclusive_scan_u32_to_u64(ctx, pc_d.p, before_d.p, nw_d2m, tot.p + 1));
+    }
+    if (nw_s2m) BG_HIP(copy_d2h(ctx, h_tot, tot.p, 8));
+    const uint64_t n_marked = h_tot[0];
+    BG_TRY(mid_to_entry.alloc(ctx, n_marked));
+    if (nw_s2m) {
+      k_rmo_marked<<<cdiv(nw_s2m, 256), 256, 0, ctx->stream>>>(rm->s2m_bits.p, nw_s2m, n_ent, before_s.p, mid_to_entry.p);
+      BG_LAUNCH_CHECK();
+    }
+    if (n) {
+      k_rmo_entries<<<cdiv(n, 256), 256, 0, ctx->stream>>>(rm->d2m_bits.p, before_d.p, n, mid_to_entry.p, n_marked, rm->mate_loop_ptr.p,
+                                                          pair_mode ? 1 : 0, rm->entry_id.p, err.p);
+      BG_LAUNCH_CHECK();
+    }
+    uint32_t h_err = 0;
+    unsigned long long h_max = 0;
+    BG_HIP(copy_d2h(ctx, &h_err, err.p, 4));
+    BG_HIP(copy_d2h(ctx, &h_max, vmax.p, 8));
+    if (h_err) { set_error("%s: inconsistent sparse_multi / mate loop table", path); return BG_EIO; }
+    if (legacy) max_len = std::max<uint64_t>(max_len, h_max);
+    rm->max_read_len = uint32_t(max_len);
   }
-  if (legacy)
-    for (uint64_t v : v_len) max_len = std::max(max_len, v);
-  rm->max_read_len = uint32_t(max_len);
-  uint64_t mid = 0;
-  for (uint64_t i = 0; i < n; ++i) {
-    if (v_head[i]) ++mid;
-    if (mid == 0 || mid > mid_to_entry.size() || (v_ptr[i] >= n && !(pair_mode && v_ptr[i] == 0xffffffffull))) { set_error("%s: inconsistent sparse_multi / mate loop table", path); return BG_EIO; }
-    v_entry[i] = mid_to_entry[mid - 1];
-  }
-  auto up64 = [&](DevBuf<uint64_t>& d, const void* src, uint64_t words) -> int {
-    BG_TRY(d.alloc(ctx, words));
-    if (words) BG_HIP(hipMemcpyAsync(d.p, src, words * 8, hipMemcpyHostToDevice, ctx->stream));
-    return BG_OK;
-  };
-  BG_TRY(up64(rm->read_len, v_len.data(), n));
-  BG_TRY(up64(rm->mate_loop_ptr, v_ptr.data(), n));
-  BG_TRY(up64(rm->is_forward, v_fwd.data(), n));
-  BG_TRY(up64(rm->s2m_bits, s2m->data(), (n_ent + 63) / 64));
-  BG_TRY(up64(rm->d2m_bits, d2m->data(), (n + 63) / 64));
-  BG_TRY(up64(rm->entry_id, v_entry.data(), n));
-  BG_HIP(hipStreamSynchronize(ctx->stream));
   BG_TRY(bitcount_finalize(ctx, rm->s2m_bits, n_ent, &rm->s2m_sub, &rm->s2m_acc));
   BG_TRY(bitcount_finalize(ctx, rm->d2m_bits, n, &rm->d2m_sub, &rm->d2m_acc));
   BG_TRY(readmap_min_len(ctx, rm.get()));
