@@ -708,6 +708,18 @@ static bool json_u64(const std::string& js, const char* key, uint64_t* out) {
   return true;
 }
 
+namespace bg {
+__global__ void k_max_u8(const uint8_t* __restrict__ a, uint64_t n, uint32_t* __restrict__ out) {
+  uint32_t m = 0;
+  for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x) m = a[i] > m ? a[i] : m;
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t o = uint32_t(__shfl_xor(int(m), d, 64));
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+}  // namespace bg
+
 extern "C" int bg_seqset_open(bg_ctx* ctx, const char* path, bg_seqset** out) {
   if (!ctx || !path || !out) { set_error("bg_seqset_open: null argument"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));
@@ -761,12 +773,19 @@ extern "C" int bg_seqset_open(bg_ctx* ctx, const char* path, bg_seqset** out) {
     if (nwords) BG_HIP(hipMemcpyAsync(ss->bits[b].p, parts[name].data(), nwords * 8, hipMemcpyHostToDevice, ctx->stream));
   }
   BG_HIP(hipStreamSynchronize(ctx->stream));
-  // max_len from sizes
-  std::vector<uint8_t> hs(n);
-  BG_TRY(download(ctx, hs.data(), ss->sizes.p, n));
-  uint32_t mx = 0;
-  for (uint8_t v : hs) mx = v > mx ? v : mx;
-  ss->max_len = mx;
+  // max_len from sizes (on the device: the bytes do not come back for it)
+  {
+    DevBuf<uint32_t> d_mx;
+    BG_TRY(d_mx.alloc(ctx, 1));
+    BG_HIP(hipMemsetAsync(d_mx.p, 0, 4, ctx->stream));
+    if (n) {
+      k_max_u8<<<unsigned(std::min<uint64_t>(cdiv(n, 256 * 16), 65535)), 256, 0, ctx->stream>>>(ss->sizes.p, n, d_mx.p);
+      BG_LAUNCH_CHECK();
+    }
+    uint32_t mx = 0;
+    BG_HIP(copy_d2h(ctx, &mx, d_mx.p, 4));
+    ss->max_len = mx;
+  }
   BG_TRY(seqset_finalize_device(ctx, ss.get()));
   // cross-check the stored rank index against the recomputed one
   for (int b = 0; b < 4; ++b) {
