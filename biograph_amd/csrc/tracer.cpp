@@ -832,6 +832,10 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
   w.entry_positions.clear();
   w.rc_mate_read_positions.clear();
   bool tables_sorted = true;
+  // the device's own copies of the two sorted tables, while ONE stretch made all of them (a piece inside one extent: the common
+  // case): the never-branching traces read them where they were made instead of from a second upload
+  DevBuf<uint64_t> kept_ep, kept_mp;
+  int device_stretches = 0;
   int64_t prev_end = -1;
   for (const Extent& x : ext) {
     if (x.offset < prev_end) return fail("bg_push_trace: extents must be sorted and disjoint");
@@ -861,8 +865,12 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
     if (w.d_ref_map && n < (1ull << 24) && !getenv("BG_TRACER_HOST_TABLES")) {
       // the tables of this stretch on the device: the entries never leave it
       const size_t ep0 = w.entry_positions.size(), mp0 = w.rc_mate_read_positions.size();
+      ++device_stretches;
+      kept_ep.reset();
+      kept_mp.reset();
+      const bool first = device_stretches == 1 && ep0 == 0 && mp0 == 0;
       BG_TRY(tracer_read_tables(ctx, w.ss, w.rm, w.d_ref_map, o.ignore_ambiguous_ref_pairs != 0, d_ent.p, n, lo + 1, &w.position_entries,
-                                &w.entry_positions, &w.rc_mate_read_positions));
+                                &w.entry_positions, &w.rc_mate_read_positions, first ? &kept_ep : nullptr, first ? &kept_mp : nullptr));
       // (merging only while everything so far IS sorted: after a stretch that took the host path the final sort does it all --
       // the flag never goes back to true)
       if (tables_sorted) {
@@ -872,6 +880,8 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
       continue;
     }
     tables_sorted = false;
+    kept_ep.reset();
+    kept_mp.reset();
     std::vector<uint64_t> ent(n);
     BG_TRY(copy_sync(ctx, ent.data(), d_ent.p, n * 8, hipMemcpyDeviceToHost));
     // positions that are reads, and for those the (rc mate, offset) pairs: per-thread lists over slices of the extent
@@ -965,22 +975,27 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
     BG_TRY(d_seeds.alloc(ctx, n_seeds));
     BG_TRY(d_out.alloc(ctx, n_seeds));
     static_assert(sizeof(std::pair<uint64_t, int32_t>) == 16 && sizeof(std::pair<uint32_t, int32_t>) == 8, "table rows as the kernel reads them");
-    BG_TRY(d_ep.alloc(ctx, w.entry_positions.size() * 16));
-    BG_TRY(d_mp.alloc(ctx, w.rc_mate_read_positions.size() * 8));
+    // (kept: the one stretch's device tables are the host tables, row for row)
+    const bool kept = device_stretches == 1 && tables_sorted && kept_ep.p && kept_ep.n >= w.entry_positions.size() * 2 &&
+                      (w.rc_mate_read_positions.empty() || (kept_mp.p && kept_mp.n >= w.rc_mate_read_positions.size()));
     BG_HIP(hipMemcpyAsync(d_seeds.p, seeds.data(), n_seeds * sizeof(TraceSeed), hipMemcpyHostToDevice, ctx->stream));
-    if (!w.entry_positions.empty())
-      BG_HIP(hipMemcpyAsync(d_ep.p, w.entry_positions.data(), w.entry_positions.size() * 16, hipMemcpyHostToDevice, ctx->stream));
-    if (!w.rc_mate_read_positions.empty())
-      BG_HIP(hipMemcpyAsync(d_mp.p, w.rc_mate_read_positions.data(), w.rc_mate_read_positions.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (!kept) {
+      BG_TRY(d_ep.alloc(ctx, w.entry_positions.size() * 16));
+      BG_TRY(d_mp.alloc(ctx, w.rc_mate_read_positions.size() * 8));
+      if (!w.entry_positions.empty())
+        BG_HIP(hipMemcpyAsync(d_ep.p, w.entry_positions.data(), w.entry_positions.size() * 16, hipMemcpyHostToDevice, ctx->stream));
+      if (!w.rc_mate_read_positions.empty())
+        BG_HIP(hipMemcpyAsync(d_mp.p, w.rc_mate_read_positions.data(), w.rc_mate_read_positions.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
     TraceSimpleTables tb;
     tb.ref_map = w.d_ref_map;
     tb.word_rank = w.dev_tables->word_rank;
     tb.group_start = w.dev_tables->group_start;
     tb.mate_loop = w.dev_tables->mate_loop;
     tb.is_forward = w.dev_tables->is_forward;
-    tb.entry_positions = d_ep.p;
+    tb.entry_positions = kept ? reinterpret_cast<const uint8_t*>(kept_ep.p) : d_ep.p;
     tb.n_entry_positions = w.entry_positions.size();
-    tb.mate_positions = d_mp.p;
+    tb.mate_positions = kept ? reinterpret_cast<const uint8_t*>(kept_mp.p) : d_mp.p;
     tb.n_mate_positions = w.rc_mate_read_positions.size();
     BG_TRY(tracer_simple_batch(ctx, w.ss, w.rm, tb, o, d_seeds.p, n_seeds, d_out.p));
     simple_out.resize(n_seeds);

@@ -2066,7 +2066,8 @@ __global__ void k_tt_finish(uint64_t n_pe, uint64_t n_m, const uint32_t* __restr
 
 int tracer_read_tables(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const uint8_t* d_ref_map, bool skip_ambiguous,
                        const uint64_t* d_ent, uint64_t n, int64_t first_off, std::vector<std::pair<int32_t, uint64_t>>* pos_entries,
-                       std::vector<std::pair<uint64_t, int32_t>>* entry_pos, std::vector<std::pair<uint32_t, int32_t>>* mate_pos) {
+                       std::vector<std::pair<uint64_t, int32_t>>* entry_pos, std::vector<std::pair<uint32_t, int32_t>>* mate_pos,
+                       DevBuf<uint64_t>* keep_entry_pos, DevBuf<uint64_t>* keep_mate_pos) {
   if (!n) return BG_OK;
   if (n >= (1ull << 24) || ss->n >= (1ull << 39) || rm->n_reads >= (1ull << 32)) { set_error("tracer_read_tables: stretch too long"); return BG_EINVAL; }
   DevBuf<uint32_t> cnt_pe, cnt_m, first_read, n_reads;
@@ -2116,6 +2117,8 @@ int tracer_read_tables(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, c
   }
   if (n_m) BG_HIP(hipMemcpyAsync(static_cast<void*>(mate_pos->data() + mp0), o_mp.p, n_m * 8, hipMemcpyDeviceToHost, ctx->stream));
   BG_HIP(hipStreamSynchronize(ctx->stream));
+  if (keep_entry_pos) *keep_entry_pos = std::move(o_ep);
+  if (keep_mate_pos) *keep_mate_pos = std::move(o_mp);
   return BG_OK;
 }
 
