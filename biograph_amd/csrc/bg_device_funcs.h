@@ -828,7 +828,52 @@ struct SeqsetView {
   const uint32_t* rank4 = nullptr;
   const uint64_t* rank4_super = nullptr;
 
+  // walk blocks (round 6): ONE 128-byte line per 40 entries with everything push_front_drop reads of them -- words 0..3: per base
+  // [set bits before the block, relative to the group of 65536 blocks it lies in : 24 | the block's 40 prev bits : 40]; words
+  // 4..8: the 40 sizes; words 9..13: the 40 shared; words 14, 15 spare.  A step of a walk lands on a new entry, checks its size,
+  // and the next step asks for the ranks at that entry and (when it drops) for shared around it: with a rank block, sizes and
+  // shared those were three lines, here they are one.  wblk_super[(g >> 16) * 4 + b] = the group's base count.  Needs
+  // n < 2^35 (the block of an entry by a 32-bit division); null: rank4 / sizes / shared.
+  const uint64_t* wblk = nullptr;
+  const uint64_t* wblk_super = nullptr;
+  static BG_HD uint32_t wblk_of(uint64_t i) { return uint32_t(i >> 3) / 5u; }
+  BG_HD unsigned size_at(uint64_t i) const {
+    if (wblk) {
+      const uint32_t g = wblk_of(i);
+      const unsigned r = unsigned(i - uint64_t(g) * 40);
+      return reinterpret_cast<const uint8_t*>(wblk + uint64_t(g) * 16 + 4)[r];
+    }
+    return sizes[i];
+  }
+  BG_HD unsigned shared_at(uint64_t i) const {
+    if (wblk) {
+      const uint32_t g = wblk_of(i);
+      const unsigned r = unsigned(i - uint64_t(g) * 40);
+      return reinterpret_cast<const uint8_t*>(wblk + uint64_t(g) * 16 + 9)[r];
+    }
+    return shared[i];
+  }
+  // the eight shared values of entries [8 wi, 8 wi + 8), entry 8 wi in the low byte
+  BG_HD uint64_t shared_word(uint64_t wi) const {
+    if (wblk) {
+      const uint32_t g = uint32_t(wi) / 5u;
+      return wblk[uint64_t(g) * 16 + 9 + (uint32_t(wi) - g * 5u)];
+    }
+    return reinterpret_cast<const uint64_t*>(shared)[wi];
+  }
+
   BG_HD uint64_t count(int b, uint64_t i) const {  // bitcount.h:218-270
+    if (wblk) {
+      const uint32_t g = wblk_of(i);
+      const unsigned r = unsigned(i - uint64_t(g) * 40);
+      const uint64_t w = wblk[uint64_t(g) * 16 + unsigned(b)];
+#if defined(__HIP_DEVICE_COMPILE__)
+      const uint64_t c = __popcll(w & ((1ull << r) - 1));
+#else
+      const uint64_t c = __builtin_popcountll(w & ((1ull << r) - 1));
+#endif
+      return wblk_super[uint64_t(g >> 16) * 4 + unsigned(b)] + (w >> 40) + c;
+    }
     if (rank4) {
       const uint64_t g = i / 96;
       const unsigned r = unsigned(i - g * 96), w = r >> 5;
@@ -893,10 +938,9 @@ struct SeqsetView {
   // in it never win (forward: a hit at or past n means none before it; backward: they lie above the start).
   // first pos >= start with shared[pos] < v, or n
   BG_HD uint64_t next_forward_lt(uint64_t pos, unsigned v) const {
-    const uint64_t* sh8 = reinterpret_cast<const uint64_t*>(shared);
     uint64_t p = pos;
     while (p < n) {
-      const uint64_t f = bytes_below(sh8[p >> 3], v) >> (8 * unsigned(p & 7));
+      const uint64_t f = bytes_below(shared_word(p >> 3), v) >> (8 * unsigned(p & 7));
       if (f) {
         const uint64_t r = p + uint64_t(__builtin_ctzll(f) >> 3);
         return r < n ? r : n;
@@ -915,11 +959,10 @@ struct SeqsetView {
   }
   // last pos <= start with shared[pos] < v, or 0
   BG_HD uint64_t next_backward_lt(uint64_t pos, unsigned v) const {
-    const uint64_t* sh8 = reinterpret_cast<const uint64_t*>(shared);
     uint64_t p = pos;
     for (;;) {
       const unsigned k = unsigned(p & 7);
-      const uint64_t f = bytes_below(sh8[p >> 3], v) << (8 * (7 - k));  // byte k on top, the bytes above it gone
+      const uint64_t f = bytes_below(shared_word(p >> 3), v) << (8 * (7 - k));  // byte k on top, the bytes above it gone
       if (f) return p - uint64_t(__builtin_clzll(f) >> 3);
       if (p < 8) return 0;
       p = (p & ~7ull) - 1;
@@ -945,7 +988,7 @@ struct SeqsetView {
 #else
   // first pos >= start with shared[pos] < v, or n
   BG_HD uint64_t next_forward_lt(uint64_t pos, unsigned v) const {
-    if (shared[pos] < v) return pos;
+    if (shared_at(pos) < v) return pos;
     while (pos < n) {
       ++pos;
       if (pos == n) return pos;
@@ -962,13 +1005,13 @@ struct SeqsetView {
           continue;
         }
       }
-      if (shared[pos] < v) return pos;
+      if (shared_at(pos) < v) return pos;
     }
     return pos;
   }
   // last pos <= start with shared[pos] < v, or 0
   BG_HD uint64_t next_backward_lt(uint64_t pos, unsigned v) const {
-    if (shared[pos] < v) return pos;
+    if (shared_at(pos) < v) return pos;
     while (pos > 0) {
       --pos;
       if ((pos & 63) == 63) {
@@ -976,7 +1019,7 @@ struct SeqsetView {
         if ((f1 & 63) == 63 && min2[f1 >> 6] >= v) { pos = (f1 >> 6) * 4096; continue; }
         if (min1[f1] >= v) { pos = f1 * 64; continue; }
       }
-      if (shared[pos] < v) return pos;
+      if (shared_at(pos) < v) return pos;
     }
     return pos;
   }
@@ -984,7 +1027,7 @@ struct SeqsetView {
   BG_HD void push_front(uint64_t begin, uint64_t end, uint32_t size, int b, uint64_t* ob, uint64_t* oe,
                         uint32_t* os) const {  // seqset.cpp:319-338
     uint64_t nb = fixed[b] + count(b, begin), ne = fixed[b] + count(b, end);
-    if (nb < ne && sizes[nb] < size + 1) nb++;
+    if (nb < ne && size_at(nb) < size + 1) nb++;
     *ob = nb; *oe = ne; *os = size + 1;
   }
   BG_HD void push_front_drop(uint64_t begin, uint64_t end, uint32_t size, int b, uint32_t min_ctx,
@@ -1002,7 +1045,7 @@ struct SeqsetView {
     // share min_ctx bases -- instead of giving the context up level by level.  A failing base nearly always fails in the loop's
     // FIRST iteration, its two neighbours sharing fewer than min_ctx bases, so the extra searches and rank look-ups only cost:
     // branch trace 57.6 -> 63.4 ms.)
-    while (sb == se || (sb + 1 == se && sizes[fx + sb] < octx + 1)) {
+    while (sb == se || (sb + 1 == se && size_at(fx + sb) < octx + 1)) {
 #ifdef __HIP_DEVICE_COMPILE__
       if (walk_counters) atomicAdd(&walk_counters[1], 1ull);
 #endif
@@ -1010,23 +1053,23 @@ struct SeqsetView {
       // reference's loop reaches the whole range and spins there for ever (seqset.cpp:368-421 has no exit for
       // it); the extension simply does not exist.  Found by tools/fuzz_parity.py (FUZZ_WALK).
       if (o_begin == 0 && o_end == n && sb == se) return;
-      uint32_t d0 = shared[o_begin];
-      uint32_t d1 = o_end == n ? 0u : uint32_t(shared[o_end]);
+      uint32_t d0 = shared_at(o_begin);
+      uint32_t d1 = o_end == n ? 0u : uint32_t(shared_at(o_end));
       uint32_t drop = d0 > d1 ? d0 : d1;
       if (sb != se) {
-        uint32_t d2 = uint32_t(sizes[fx + sb]) - 1;
+        uint32_t d2 = uint32_t(size_at(fx + sb)) - 1;
         if (d2 > drop) drop = d2;
       }
       if (drop < min_ctx) return;
       bool ub = false, ue = false;
-      if (o_begin > 0 && shared[o_begin] >= drop) { o_begin = next_backward_lt(o_begin, drop); ub = true; }
-      if (o_end < n && shared[o_end] >= drop) { o_end = next_forward_lt(o_end, drop); ue = true; }
+      if (o_begin > 0 && d0 >= drop) { o_begin = next_backward_lt(o_begin, drop); ub = true; }
+      if (o_end < n && d1 >= drop) { o_end = next_forward_lt(o_end, drop); ue = true; }
       if (ub) sb = count(b, o_begin);
       if (ue) se = count(b, o_end);
       octx = drop;
     }
     uint64_t nb = fx + sb, ne = fx + se;
-    if (nb < ne && sizes[nb] < octx + 1) nb++;
+    if (nb < ne && size_at(nb) < octx + 1) nb++;
     *ob = nb; *oe = ne; *os = octx + 1;
   }
 };

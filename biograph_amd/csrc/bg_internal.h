@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/bgseq.h"
+#include <atomic>
 #include <mutex>
 
 #include "arena.h"
@@ -222,6 +223,11 @@ struct bg_seqset {
   bg::DevBuf<uint32_t> rank4;       // one 64-byte rank block per 96 entries, all four bases in it (SeqsetView::count)
   bg::DevBuf<uint64_t> rank4_super; // base counts of every group of 65536 such blocks, four per group
   bg::DevBuf<uint64_t> sel256[4];   // the entry that carries every 256th set prev bit of a base (pop_front's select), + a sentinel n
+  // walk blocks (SeqsetView::wblk): ONE 128-byte line per 40 entries holding everything a push_front_drop reads of them -- the
+  // four bases' prev bits with their running counts, the entries' sizes, their shared.  Made by the first walk over the seqset
+  // (seqset_ensure_walk_blocks: not part of a build), 3.2 bytes an entry.
+  bg::DevBuf<uint64_t> wblk, wblk_super;
+  std::atomic<int> wblk_state{0};   // 0: not made yet; 1: there; 2: not to be made (switched off, too many entries, no memory)
   bg::DevBuf<uint8_t> min1, min2;
   uint64_t fixed[5] = {0, 0, 0, 0, 0};
   std::string uuid;
@@ -421,6 +427,9 @@ int tracer_simple_batch(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, 
 int cover_index_build(bg_ctx* ctx, const uint64_t* owords, const uint8_t* olen, uint64_t n_o, int W, int cover_k,
                       DevBuf<uint64_t>* k0o, CoverStore* cs);
 int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss, bool slice = false);  // bitcount finalize + min index + fixed
+// the walk blocks of a finalized seqset, made by the first walk that asks (under keys_mutex, from the seqset's own context, on
+// its stream, waited for); a seqset they cannot be made for keeps walking through rank4 / sizes / shared
+void seqset_ensure_walk_blocks(const bg_seqset* ss);
 int suffix_records_impl(bg_ctx* ctx, const bg_reads* reads, uint64_t lo, uint64_t hi, int cover_k,
                         DevBuf<uint64_t>* rec, DevBuf<uint8_t>* rlen, uint64_t* n_rec_out,
                         DevBuf<uint64_t>* k0 = nullptr, int RS = 0);  // k0: also the sort keys of the records (optional)

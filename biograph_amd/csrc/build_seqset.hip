@@ -1924,6 +1924,61 @@ __global__ void k_rank4_build(RankSrc src, uint64_t nblocks, const uint64_t* __r
   *reinterpret_cast<uint4*>(out + x * 4) = q;
 }
 
+// walk blocks of SeqsetView (bg_device_funcs.h): group counts first, then a thread a word of a block
+__global__ void k_wblk_super(RankSrc src, uint64_t ngroups16, uint64_t* __restrict__ super) {
+  const uint64_t x = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (x >= ngroups16 * 4) return;
+  super[x] = src.count(int(x & 3), (x >> 2) * 65536 * 40);
+}
+__global__ void k_wblk_build(RankSrc src, const uint8_t* __restrict__ sizes, const uint8_t* __restrict__ shared, uint64_t nblocks,
+                             const uint64_t* __restrict__ super, uint64_t* __restrict__ out) {
+  const uint64_t x = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;  // (block, word)
+  if (x >= nblocks * 16) return;
+  const uint64_t g = x >> 4, i0 = g * 40;
+  const int t = int(x & 15);
+  uint64_t v = 0;
+  if (t < 4) {  // the block's 40 prev bits of base t (i0 is a multiple of 8: they lie in at most two words) under their running count
+    const uint64_t nw = (src.n + 63) >> 6, wi = i0 >> 6;
+    const unsigned sh = unsigned(i0 & 63);
+    const uint64_t a = wi < nw ? src.bits[t][wi] : 0, c = wi + 1 < nw ? src.bits[t][wi + 1] : 0;
+    const uint64_t bits40 = ((a >> sh) | (sh ? c << (64 - sh) : 0)) & ((1ull << 40) - 1);
+    v = ((src.count(t, i0) - super[(g >> 16) * 4 + t]) << 40) | bits40;
+  } else if (t < 14) {  // five words of sizes, five of shared (the arrays are 8-byte aligned, their allocations multiples of 512 bytes)
+    const uint8_t* a = t < 9 ? sizes : shared;
+    const uint64_t wi = (i0 >> 3) + uint64_t(t < 9 ? t - 4 : t - 9);
+    if (wi * 8 < src.n) v = reinterpret_cast<const uint64_t*>(a)[wi];
+  }
+  out[x] = v;
+}
+
+void seqset_ensure_walk_blocks(const bg_seqset* css) {
+  bg_seqset* ss = const_cast<bg_seqset*>(css);
+  if (!ss || ss->wblk_state.load(std::memory_order_acquire) != 0) return;
+  std::lock_guard<std::mutex> lk(ss->keys_mutex);
+  if (ss->wblk_state.load(std::memory_order_relaxed) != 0) return;
+  static const bool off = [] { const char* e = getenv("BG_WALK_BLOCKS"); return e && e[0] == '0'; }();
+  bg_ctx* ctx = ss->ctx;
+  const uint64_t n = ss->n;
+  int state = 2;
+  if (!off && ctx && n && n < (1ull << 35) && ss->sizes.p && ss->shared.p && ss->bits[0].p && ss->accum[0].p && ss->subaccum[0].p) {
+    const uint64_t nblocks = n / 40 + 1, ngroups16 = (nblocks + 65535) / 65536;  // position n itself is asked for
+    RankSrc src;
+    for (int b = 0; b < 4; ++b) { src.bits[b] = ss->bits[b].p; src.subaccum[b] = ss->subaccum[b].p; src.accum[b] = ss->accum[b].p; }
+    src.n = n;
+    DevBuf<uint64_t> blk, super;
+    if (hipSetDevice(ctx->device) == hipSuccess && super.alloc(ctx, ngroups16 * 4) == BG_OK && blk.alloc(ctx, nblocks * 16) == BG_OK) {
+      k_wblk_super<<<cdiv(ngroups16 * 4, 64), 64, 0, ctx->stream>>>(src, ngroups16, super.p);
+      k_wblk_build<<<cdiv(nblocks * 16, 256), 256, 0, ctx->stream>>>(src, ss->sizes.p, ss->shared.p, nblocks, super.p, blk.p);
+      if (hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess) {
+        ss->wblk = std::move(blk);
+        ss->wblk_super = std::move(super);
+        state = 1;
+      }
+    }
+  }
+  ss->wblk_state.store(state, std::memory_order_release);
+}
+
 // sel256 of SeqsetView from the rank blocks: block g holds the set bits number [before, before + ones) of its base; for every
 // multiple of 256 among them, the entry that carries it
 __global__ void k_sel256_build(const uint64_t* __restrict__ rank64, uint64_t nblocks, uint64_t n, uint64_t n_slots, uint64_t* __restrict__ out) {
@@ -1954,6 +2009,9 @@ __global__ void k_fill_u64(uint64_t* __restrict__ p, uint64_t n, uint64_t v) {
 
 int seqset_finalize_device(bg_ctx* ctx, bg_seqset* ss, bool slice) {
   const uint64_t n = ss->n;
+  ss->wblk.reset();  // (walk blocks of arrays that are being made again)
+  ss->wblk_super.reset();
+  ss->wblk_state.store(slice ? 2 : 0);
   const uint64_t nwords = (n + 63) / 64, ngroups = (n + 511) / 512, naccum = (n + 1 + 511) / 512;
   DevBuf<uint32_t> gp;
   DevBuf<uint64_t> total;

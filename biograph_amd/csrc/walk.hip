@@ -33,6 +33,10 @@ static SeqsetView make_view(const bg_seqset* ss) {
   static const bool no_rank4 = [] { const char* e = getenv("BG_WALK_RANK4"); return e && e[0] == '0'; }();
   v.rank4 = (no_blocks || no_rank4) ? nullptr : ss->rank4.p;
   v.rank4_super = ss->rank4_super.p;
+  if (!no_blocks) {
+    seqset_ensure_walk_blocks(ss);
+    if (ss->wblk_state.load(std::memory_order_acquire) == 1) { v.wblk = ss->wblk.p; v.wblk_super = ss->wblk_super.p; }
+  }
   static const bool no_select = [] { const char* e = getenv("BG_WALK_SELECT"); return e && e[0] == '0'; }();
   for (int b = 0; b < 4; ++b) v.sel256[b] = (no_blocks || no_select) ? nullptr : ss->sel256[b].p;
   return v;
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(64) void k_ref_map_chains(SeqsetView v, uint64_t nc
     v.push_front_drop(b, e, s, 3 - base, 0, &b, &e, &s);
     if (e <= b) { b = 0; e = v.n; s = 0; continue; }  // cannot happen on a closed seqset (CHECK(r.valid()))
     if (i < pre) continue;
-    if (b + 1 != e || s != v.sizes[b]) continue;
+    if (b + 1 != e || s != v.size_at(b)) continue;
     // ONE atomic per marked position (a device-scope atomic is a 64-byte request at the memory side whatever it carries;
     // a count and a flag word were two): the forward slices count in the low half of the cell, the reverse-complement ones in
     // the high half, and k_ref_map_pack turns the halves into count and flags
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(64) void k_ref_walk_entries(SeqsetView v, const uin
   for (; pos < p1; ++pos) {
     v.push_front_drop(b, e, s, 3 - (codes[pos] & 3), 0, &b, &e, &s);
     if (e <= b) { b = 0; e = v.n; s = 0; if (pos >= p0) out[pos] = ~0ull; continue; }
-    if (pos >= p0) out[pos] = (b + 1 == e && s == v.sizes[b]) ? b : ~0ull;
+    if (pos >= p0) out[pos] = (b + 1 == e && s == v.size_at(b)) ? b : ~0ull;
   }
 }
 
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(64) void k_tracer_extend(SeqsetView v, const uint64
   bool pushed_any = (qq.flags & 1u) != 0;
   const uint32_t cap = qq.max_steps < step_cap ? qq.max_steps : step_cap;
   auto is_read = [&](uint64_t rb, uint64_t re, uint32_t rs) {
-    return rb + 1 == re && rs == v.sizes[rb] && ((has_reads[rb >> 6] >> (rb & 63)) & 1);
+    return rb + 1 == re && rs == v.size_at(rb) && ((has_reads[rb >> 6] >> (rb & 63)) & 1);
   };
   uint32_t n_steps = 0, reason, valid;
   uint64_t pb, pe;
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(64) void k_tracer_extend(SeqsetView v, const uint64
   for (;;) {
     v.push_front_drop(b, e, s, 3 - base, min_ctx, &pb, &pe, &ps);
     bool ok = pe > pb;
-    if (ok && pb + 1 == pe && ps == v.sizes[pb] && pb == qq.loop_check) { pb = 0; pe = 0; ok = false; }  // a loop
+    if (ok && pb + 1 == pe && ps == v.size_at(pb) && pb == qq.loop_check) { pb = 0; pe = 0; ok = false; }  // a loop
     valid = uint32_t((__ballot(ok) >> quad0) & 15ull);
     if (__popc(valid) != 1) { reason = BG_TRACE_AMBIGUOUS; break; }
     if (pushed_any && is_read(b, e, s)) { reason = BG_TRACE_AT_READ; break; }
@@ -684,7 +688,7 @@ __global__ __launch_bounds__(64) void k_trace_simple(SeqsetView v, const uint64_
   const TraceSeed sd = seeds[i];
   TraceSimpleOut* out = outs + i;
   auto is_read = [&](uint64_t rb, uint64_t re, uint32_t rs) {
-    return rb + 1 == re && rs == v.sizes[rb] && ((has_reads[rb >> 6] >> (rb & 63)) & 1);
+    return rb + 1 == re && rs == v.size_at(rb) && ((has_reads[rb >> 6] >> (rb & 63)) & 1);
   };
   uint32_t counters = 0, status = kSimpleHost;
   // ---- tracer::trace (:477-519)
@@ -1193,7 +1197,7 @@ __device__ __forceinline__ uint64_t rm_follow(const ReadmapView& rm, uint64_t id
 __device__ __forceinline__ Tri rm_read_entry(const SeqsetView& v, const ReadmapView& rm, uint64_t id) {
   uint64_t e = rm.entry_id[id];
   uint32_t len = uint32_t(rm.read_len[id]);
-  Tri t{e, e + 1, v.sizes[e]};
+  Tri t{e, e + 1, v.size_at(e)};
   if (t.s > len) {
     t.b = v.next_backward_lt(e, len);
     t.e = e + 1 < v.n ? v.next_forward_lt(e + 1, len) : v.n;
@@ -1224,7 +1228,7 @@ __device__ __forceinline__ void for_prefix_reads(const SeqsetView& v, const Read
     bool stop = false;
     while (sid != e) {
       ++sid;
-      int sh = v.shared[sid];
+      int sh = v.shared_at(sid);
       if (sh < min_size) { stop = true; break; }
       if (sh < max_len) max_len = sh;
     }
@@ -1237,7 +1241,7 @@ __device__ __forceinline__ void for_prefix_reads(const SeqsetView& v, const Read
     const uint64_t e = rm.entry_id[id];
     bool stop = false;
     while (sid != e) {
-      int sh = v.shared[sid];
+      int sh = v.shared_at(sid);
       --sid;
       if (sh < min_size) { stop = true; break; }
       if (sh < max_len) max_len = sh;
