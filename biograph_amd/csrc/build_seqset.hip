@@ -1956,11 +1956,10 @@ void seqset_ensure_walk_blocks(const bg_seqset* css) {
   if (!ss || ss->wblk_state.load(std::memory_order_acquire) != 0) return;
   std::lock_guard<std::mutex> lk(ss->keys_mutex);
   if (ss->wblk_state.load(std::memory_order_relaxed) != 0) return;
-  static const bool off = [] { const char* e = getenv("BG_WALK_BLOCKS"); return e && e[0] == '0'; }();
   bg_ctx* ctx = ss->ctx;
   const uint64_t n = ss->n;
   int state = 2;
-  if (!off && ctx && n && n < (1ull << 35) && ss->sizes.p && ss->shared.p && ss->bits[0].p && ss->accum[0].p && ss->subaccum[0].p) {
+  if (ctx && n && n < (1ull << 35) && ss->sizes.p && ss->shared.p && ss->bits[0].p && ss->accum[0].p && ss->subaccum[0].p) {
     const uint64_t nblocks = n / 40 + 1, ngroups16 = (nblocks + 65535) / 65536;  // position n itself is asked for
     RankSrc src;
     for (int b = 0; b < 4; ++b) { src.bits[b] = ss->bits[b].p; src.subaccum[b] = ss->subaccum[b].p; src.accum[b] = ss->accum[b].p; }

@@ -33,7 +33,9 @@ static SeqsetView make_view(const bg_seqset* ss) {
   static const bool no_rank4 = [] { const char* e = getenv("BG_WALK_RANK4"); return e && e[0] == '0'; }();
   v.rank4 = (no_blocks || no_rank4) ? nullptr : ss->rank4.p;
   v.rank4_super = ss->rank4_super.p;
-  if (!no_blocks) {
+  // (read at every call: the tests compare the two ways inside one process)
+  const char* e_wblk = getenv("BG_WALK_BLOCKS");
+  if (!no_blocks && !(e_wblk && e_wblk[0] == '0')) {
     seqset_ensure_walk_blocks(ss);
     if (ss->wblk_state.load(std::memory_order_acquire) == 1) { v.wblk = ss->wblk.p; v.wblk_super = ss->wblk_super.p; }
   }
@@ -514,6 +516,10 @@ __global__ __launch_bounds__(256) void k_branch_trace(SeqsetView v, uint64_t na,
 // empty context; after `pre` warm-up bases every position whose range is exactly one full entry
 // bumps that entry.  Chains are finer than the reference's chunks (same 256-base warm-up): the walk
 // state after >= max_read_len pushes does not depend on where the chain began.
+// (Measured and put away, round 6, on top of the walk blocks: the next base's rank words fetched with the size a push checks --
+// a push that drops nothing in one round trip instead of two -- 15.7 -> 16.1 ms; the chain as a state machine whose every pass
+// is one round of loads whatever its lanes are at, so that no lane waits for another's drop loop: 16.2-17.1 ms against 14.9.  The
+// kernel is not short of round trips: 148 M lines of walk blocks and 120 M atomics on 64-bit cells are what it moves.)
 __global__ __launch_bounds__(64) void k_ref_map_chains(SeqsetView v, uint64_t nchains,
                                                       const uint64_t* __restrict__ cstart,
                                                       const uint32_t* __restrict__ clen,

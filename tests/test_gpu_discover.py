@@ -85,6 +85,75 @@ def test_packed_walks_equal_a_wave_an_assembly_on_many_traces(world):
         assert len(reasons) >= 2, reasons
 
 
+def _with_env(name, value, call):
+    import os
+    os.environ[name] = value
+    try:
+        return call()
+    finally:
+        del os.environ[name]
+
+
+def test_walk_blocks_equal_the_plain_walk(world):
+    """The walk blocks (one line per 40 entries: ranks, sizes, shared) against rank4 / sizes / shared (BG_WALK_BLOCKS=0): random
+    push_front_drop / push_front / pop_front calls, the reference map, chains from different histories."""
+    from biograph_amd import capi
+    ctx, d, oss, ss, ref = world
+    rng = np.random.default_rng(123)
+    n = len(oss)
+    m = 200000
+    begin = rng.integers(0, n, m).astype(np.uint64)
+    width = np.where(rng.random(m) < 0.7, 1, rng.integers(1, 400, m)).astype(np.uint64)
+    end = np.minimum(begin + width, np.uint64(n)).astype(np.uint64)
+    begin[:50], end[:50] = 0, n  # the whole range, and the last block
+    begin[50:100] = n - 1
+    end[50:100] = n
+    size = np.minimum(d["sizes"][begin.astype(np.int64)].astype(np.uint32), rng.integers(0, 151, m).astype(np.uint32))
+    size[:50] = 0
+    base = rng.integers(0, 4, m).astype(np.uint8)
+    mc = np.where(rng.random(m) < 0.5, 0, rng.integers(0, 120, m)).astype(np.uint32)
+    calls = {
+        "push_front_drop": lambda: ss.push_front_drop_batch(begin, end, size, base, mc),
+        "push_front": lambda: ss.push_front_batch(begin, end, size, base),
+        "pop_front": lambda: ss.pop_front_batch(begin, end, np.maximum(size, 1).astype(np.uint32)),
+    }
+    for name, call in calls.items():
+        a = call()
+        b = _with_env("BG_WALK_BLOCKS", "0", call)
+        for x, y in zip(a, b):
+            assert (np.asarray(x) == np.asarray(y)).all(), name
+    want = oss.push_front_drop(begin[:20000], end[:20000], size[:20000], base[:20000], mc[:20000])
+    got = ss.push_front_drop_batch(begin[:20000], end[:20000], size[:20000], base[:20000], mc[:20000])
+    for g, w in zip(got, want):
+        assert (g == w).all()
+    # the reference map: chains of every length through the four ways
+    for chain in (0, 300, 1000):
+        a = ss.ref_map_build(ref, [0], [len(ref)], chain)
+        assert (_with_env("BG_WALK_BLOCKS", "0", lambda: ss.ref_map_build(ref, [0], [len(ref)], chain)) == a).all(), chain
+    # chains that start from different histories (bg_walk_chains): every range after every base
+    nch, length = 64, 600
+    start = np.zeros((nch, 3), np.uint64)
+    start[:, 1] = n
+    for i in range(1, nch):
+        b, e, s_ = np.array([0], np.uint64), np.array([n], np.uint64), np.array([0], np.uint32)
+        p0 = int(rng.integers(0, len(ref) - 200))
+        for c in ref[p0:p0 + int(rng.integers(1, 160))]:
+            b, e, s_ = ss.push_front_drop_batch(b, e, s_, np.array([3 - c], np.uint8), np.array([0], np.uint32))
+        start[i] = (b[0], e[0], s_[0])
+    codes = np.ascontiguousarray(ref[5000:5000 + length])
+
+    def chains():
+        out = np.zeros((length, nch, 3), np.uint64)
+        capi.check(capi.lib().bg_walk_chains(ctx.h, ss.h, nch, capi.np_ptr(start), capi.np_ptr(codes), length, capi.np_ptr(out)))
+        return out
+    a = chains()
+    assert (_with_env("BG_WALK_BLOCKS", "0", chains) == a).all()
+    b, e, s_ = start[:, 0].copy(), start[:, 1].copy(), start[:, 2].astype(np.uint32)
+    for t in range(0, 200):
+        b, e, s_ = ss.push_front_drop_batch(b, e, s_, np.full(nch, 3 - codes[t], np.uint8), np.zeros(nch, np.uint32))
+        assert (a[t, :, 0] == b).all() and (a[t, :, 1] == e).all() and (a[t, :, 2] == s_).all(), t
+
+
 def test_ref_map_build_matches_reference_chunking(world):
     ctx, d, oss, ss, ref = world
     want = oss.ref_map_build(ref, [0], [len(ref)])
