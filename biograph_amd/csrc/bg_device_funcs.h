@@ -837,8 +837,21 @@ struct SeqsetView {
   const uint64_t* wblk = nullptr;
   const uint64_t* wblk_super = nullptr;
   static BG_HD uint32_t wblk_of(uint64_t i) { return uint32_t(i >> 3) / 5u; }
+  // "are there walk blocks" as a value the scalar unit holds.  Asked as `if (wblk)` inside the walks' divergent loops, the
+  // compiler (ROCm 7.2) kept the answer as a lane mask made by a vector compare under ONE iteration's exec and tested it under
+  // another's: lanes that were not active when it was made read "there are" and loaded through the null pointer (k_pop_passes
+  // with BG_WALK_BLOCKS=0, found by rocgdb: s[2:3] = lane 15's answer, exec = lane 13).  With blocks the wrong turn is harmless
+  // -- both ways give the same values -- without them it is a fault; readfirstlane is convergent and stays where it is asked.
+  static BG_HD bool uniform_nonnull(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane(int(p != nullptr)) != 0;
+#else
+    return p != nullptr;
+#endif
+  }
+  BG_HD bool has_wblk() const { return uniform_nonnull(wblk); }
   BG_HD unsigned size_at(uint64_t i) const {
-    if (wblk) {
+    if (has_wblk()) {
       const uint32_t g = wblk_of(i);
       const unsigned r = unsigned(i - uint64_t(g) * 40);
       return reinterpret_cast<const uint8_t*>(wblk + uint64_t(g) * 16 + 4)[r];
@@ -846,7 +859,7 @@ struct SeqsetView {
     return sizes[i];
   }
   BG_HD unsigned shared_at(uint64_t i) const {
-    if (wblk) {
+    if (has_wblk()) {
       const uint32_t g = wblk_of(i);
       const unsigned r = unsigned(i - uint64_t(g) * 40);
       return reinterpret_cast<const uint8_t*>(wblk + uint64_t(g) * 16 + 9)[r];
@@ -855,7 +868,7 @@ struct SeqsetView {
   }
   // the eight shared values of entries [8 wi, 8 wi + 8), entry 8 wi in the low byte
   BG_HD uint64_t shared_word(uint64_t wi) const {
-    if (wblk) {
+    if (has_wblk()) {
       const uint32_t g = uint32_t(wi) / 5u;
       return wblk[uint64_t(g) * 16 + 9 + (uint32_t(wi) - g * 5u)];
     }
@@ -863,7 +876,7 @@ struct SeqsetView {
   }
 
   BG_HD uint64_t count(int b, uint64_t i) const {  // bitcount.h:218-270
-    if (wblk) {
+    if (has_wblk()) {
       const uint32_t g = wblk_of(i);
       const unsigned r = unsigned(i - uint64_t(g) * 40);
       const uint64_t w = wblk[uint64_t(g) * 16 + unsigned(b)];
@@ -874,7 +887,7 @@ struct SeqsetView {
 #endif
       return wblk_super[uint64_t(g >> 16) * 4 + unsigned(b)] + (w >> 40) + c;
     }
-    if (rank4) {
+    if (uniform_nonnull(rank4)) {
       const uint64_t g = i / 96;
       const unsigned r = unsigned(i - g * 96), w = r >> 5;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -892,7 +905,7 @@ struct SeqsetView {
 #endif
       return rank4_super[(g >> 16) * 4 + unsigned(b)] + rel + c;
     }
-    if (rank64[b]) {
+    if (uniform_nonnull(rank64[0])) {  // (the four are there or not together)
       const uint64_t g = i / 384;
       const unsigned r = unsigned(i - g * 384), w = r >> 6;
       const uint64_t* blk = rank64[b] + g * 8;

@@ -85,7 +85,7 @@ __device__ __forceinline__ void pop_front_range(const SeqsetView& v, uint64_t b0
   while (b < 3 && b0 >= v.fixed[b + 1]) ++b;
   const uint64_t rank = b0 - v.fixed[b];
   uint64_t lo = 0, hi = v.n;  // smallest t with count(b, t + 1) > rank = the entry that carries the rank-th set bit
-  if (v.sel256[b] && v.rank64[b]) {
+  if (SeqsetView::uniform_nonnull(v.sel256[0]) && SeqsetView::uniform_nonnull(v.rank64[0])) {  // (four together)
     // between two samples: the last rank block that starts at or before the bit, then the bit inside it
     const uint64_t j = rank >> 8;
     uint64_t g_lo = v.sel256[b][j] / 384, g_hi = v.sel256[b][j + 1] / 384;
