@@ -1051,7 +1051,7 @@ struct SeqsetView {
     uint64_t sb = count(b, o_begin), se = count(b, o_end);
     *ob = 0; *oe = 0; *os = 0;
 #ifdef __HIP_DEVICE_COMPILE__
-    if (walk_counters) atomicAdd(&walk_counters[0], 1ull);
+    if (uniform_nonnull(walk_counters)) atomicAdd(&walk_counters[0], 1ull);
 #endif
     if (octx < min_ctx) return;
     // (Measured and put away: deciding a failing base up front from the widest range the loop may reach -- the entries that
@@ -1060,7 +1060,7 @@ struct SeqsetView {
     // branch trace 57.6 -> 63.4 ms.)
     while (sb == se || (sb + 1 == se && size_at(fx + sb) < octx + 1)) {
 #ifdef __HIP_DEVICE_COMPILE__
-      if (walk_counters) atomicAdd(&walk_counters[1], 1ull);
+      if (uniform_nonnull(walk_counters)) atomicAdd(&walk_counters[1], 1ull);
 #endif
       // No entry starts with base b at all (a seqset of a two-letter genome, a toy input): with min_ctx == 0 the
       // reference's loop reaches the whole range and spins there for ever (seqset.cpp:368-421 has no exit for

@@ -519,7 +519,8 @@ __global__ __launch_bounds__(256) void k_branch_trace(SeqsetView v, uint64_t na,
 // (Measured and put away, round 6, on top of the walk blocks: the next base's rank words fetched with the size a push checks --
 // a push that drops nothing in one round trip instead of two -- 15.7 -> 16.1 ms; the chain as a state machine whose every pass
 // is one round of loads whatever its lanes are at, so that no lane waits for another's drop loop: 16.2-17.1 ms against 14.9.  The
-// kernel is not short of round trips: 148 M lines of walk blocks and 120 M atomics on 64-bit cells are what it moves.)
+// kernel is not short of round trips: 148 M lines of walk blocks and 120 M atomics on 64-bit cells are what it moves -- without
+// the atomics (a build that skips them) 11.1 ms of the 15-16.)
 __global__ __launch_bounds__(64) void k_ref_map_chains(SeqsetView v, uint64_t nchains,
                                                       const uint64_t* __restrict__ cstart,
                                                       const uint32_t* __restrict__ clen,
@@ -1498,7 +1499,7 @@ __global__ __launch_bounds__(64) void k_pop_passes(SeqsetView v, ReadmapView rm,
         return c < cap;
       });
     if (c) {
-      const unsigned at = ids_used ? atomicAdd(ids_used, c) : unsigned((i * passes + j) * cap);
+      const unsigned at = SeqsetView::uniform_nonnull(ids_used) ? atomicAdd(ids_used, c) : unsigned((i * passes + j) * cap);
       for (uint32_t k = 0; k < c; ++k) ids[at + k] = tmp[k];
       rec.ids_at = at;
       rec.n_ids = c;
