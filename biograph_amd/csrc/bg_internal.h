@@ -386,7 +386,8 @@ int prefix_reads_packed(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, 
 int tracer_read_tables(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const uint8_t* d_ref_map, bool skip_ambiguous,
                        const uint64_t* d_ent, uint64_t n, int64_t first_off, std::vector<std::pair<int32_t, uint64_t>>* pos_entries,
                        std::vector<std::pair<uint64_t, int32_t>>* entry_pos, std::vector<std::pair<uint32_t, int32_t>>* mate_pos,
-                       DevBuf<uint64_t>* keep_entry_pos = nullptr, DevBuf<uint64_t>* keep_mate_pos = nullptr);  // (the device's copies of the two sorted tables, for the caller to go on using)
+                       DevBuf<uint64_t>* keep_entry_pos = nullptr, DevBuf<uint64_t>* keep_mate_pos = nullptr,
+                       std::vector<uint16_t>* pos_info = nullptr);  // per pos_entries row: the entry's size | 256 when the reference holds it more than once  // (the device's copies of the two sorted tables, for the caller to go on using)
 // walk.hip: the push tracer's search for the traces that never branch, whole on the device (tracer.cpp:477-519, 528-673,
 // 675-724, 737-845, 1023-1250 for ONE path): start, the walk to the next read, add_pairs there, the rejoin, the assembly's
 // fields.  A trace that does anything else (a branch, a read that does not rejoin, a step cap) is marked for the host's

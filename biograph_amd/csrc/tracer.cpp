@@ -27,6 +27,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <array>
 #include <type_traits>
 #include <atomic>
 #include <condition_variable>
@@ -210,11 +211,13 @@ struct World {
   int64_t scaffold_end = 0;
   // reads along the (oriented) scaffold: offset (after the base) -> entry, ascending by offset
   std::vector<std::pair<int32_t, uint64_t>> position_entries;
+  std::vector<uint16_t> position_info;  // beside position_entries: the entry's size | 256 when the reference holds it more than once
   std::vector<std::pair<uint64_t, int32_t>> entry_positions;        // (entry, offset), sorted
   std::vector<std::pair<uint32_t, int32_t>> rc_mate_read_positions;  // (read, offset), sorted
   Pinned pin_q, pin_r, pin_s;  // the round's queries, replies and step lists
   bg_trace_stats stats;
   double seconds_device = 0, seconds_host = 0, seconds_tables = 0, seconds_start = 0, seconds_teardown = 0;
+  double seconds_tab_codes = 0, seconds_tab_walk = 0, seconds_tab_read = 0;  // inside seconds_tables (BG_TRACER_TIMING)
   int threads = 1;
 
   unsigned match_count(uint64_t e) const { return ref_map[e] & 63u; }
@@ -829,6 +832,7 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
   const int64_t skip = start - int64_t(o.max_pair_distance) - max_read_len;  // skip_ahead_to (:230)
   const int64_t ahead_limit = limit + int64_t(o.read_ahead_distance);         // no trace looks further
   w.position_entries.clear();
+  w.position_info.clear();
   w.entry_positions.clear();
   w.rc_mate_read_positions.clear();
   bool tables_sorted = true;
@@ -851,17 +855,24 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
     if (hi > ahead_limit) hi = ahead_limit;
     if (lo >= hi) continue;
     const uint64_t n = uint64_t(hi - lo);
+    const double t_c0 = now_seconds();
     std::vector<uint8_t> codes(n);
-    for (uint64_t i = 0; i < n; ++i) {
-      const char c = x.seq[size_t(lo - x.offset) + i];
-      codes[i] = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3;
+    {
+      static const std::array<uint8_t, 256> kCode = [] { std::array<uint8_t, 256> t; t.fill(3); t[uint8_t('A')] = 0; t[uint8_t('C')] = 1; t[uint8_t('G')] = 2; return t; }();
+      const uint8_t* src = reinterpret_cast<const uint8_t*>(x.seq.data()) + size_t(lo - x.offset);
+      for (uint64_t i = 0; i < n; ++i) codes[i] = kCode[src[i]];
     }
     DevBuf<uint8_t> d_codes;
     DevBuf<uint64_t> d_ent;
     BG_TRY(d_codes.alloc(ctx, n));
     BG_TRY(d_ent.alloc(ctx, n));
     BG_TRY(copy_sync(ctx, d_codes.p, codes.data(), n, hipMemcpyHostToDevice));
+    const double t_c1 = now_seconds();
     BG_TRY(bg_ref_walk_entries(ctx, w.ss, d_codes.p, n, dup_first ? 1 : 0, d_ent.p));
+    if (getenv("BG_TRACER_TIMING")) { BG_HIP(hipStreamSynchronize(ctx->stream)); }
+    const double t_c2 = now_seconds();
+    w.seconds_tab_codes += t_c1 - t_c0;
+    w.seconds_tab_walk += t_c2 - t_c1;
     if (w.d_ref_map && n < (1ull << 24) && !getenv("BG_TRACER_HOST_TABLES")) {
       // the tables of this stretch on the device: the entries never leave it
       const size_t ep0 = w.entry_positions.size(), mp0 = w.rc_mate_read_positions.size();
@@ -870,13 +881,15 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
       kept_mp.reset();
       const bool first = device_stretches == 1 && ep0 == 0 && mp0 == 0;
       BG_TRY(tracer_read_tables(ctx, w.ss, w.rm, w.d_ref_map, o.ignore_ambiguous_ref_pairs != 0, d_ent.p, n, lo + 1, &w.position_entries,
-                                &w.entry_positions, &w.rc_mate_read_positions, first ? &kept_ep : nullptr, first ? &kept_mp : nullptr));
+                                &w.entry_positions, &w.rc_mate_read_positions, first ? &kept_ep : nullptr, first ? &kept_mp : nullptr,
+                                &w.position_info));
       // (merging only while everything so far IS sorted: after a stretch that took the host path the final sort does it all --
       // the flag never goes back to true)
       if (tables_sorted) {
         if (ep0) std::inplace_merge(w.entry_positions.begin(), w.entry_positions.begin() + long(ep0), w.entry_positions.end());
         if (mp0) std::inplace_merge(w.rc_mate_read_positions.begin(), w.rc_mate_read_positions.begin() + long(mp0), w.rc_mate_read_positions.end());
       }
+      w.seconds_tab_read += now_seconds() - t_c2;
       continue;
     }
     tables_sorted = false;
@@ -902,7 +915,11 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
         }
       }, 1);
       for (int t = 0; t < nt; ++t) {
-        for (auto& y : pe[t]) { w.position_entries.push_back(y); w.entry_positions.emplace_back(y.second, y.first); }
+        for (auto& y : pe[t]) {
+          w.position_entries.push_back(y);
+          w.position_info.push_back(uint16_t(w.sizes[y.second]) | uint16_t(w.match_count(y.second) > 1 ? 256 : 0));
+          w.entry_positions.emplace_back(y.second, y.first);
+        }
         w.rc_mate_read_positions.insert(w.rc_mate_read_positions.end(), mates[t].begin(), mates[t].end());
       }
     }
@@ -939,13 +956,13 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
       while (pe < w.position_entries.size() && w.position_entries[pe].first < cur_offset) ++pe;
       if (pe >= w.position_entries.size() || w.position_entries[pe].first != cur_offset) continue;
       const uint64_t e = w.position_entries[pe].second;
-      const uint32_t size = w.sizes[e];
+      const uint32_t size = w.position_info[pe] & 255u;
       if (i + 1 - anchor_from < size) continue;
       anchor_from = i + 1 - size;
       // tracer::trace (:477-503): the window check is always true here (start <= cur_offset < limit is implied by the
       // loop above except at cur_offset == limit)
       if (cur_offset < start || cur_offset >= limit) continue;
-      const bool ref_ambiguous = w.match_count(e) > 1;
+      const bool ref_ambiguous = (w.position_info[pe] & 256u) != 0;
       if (!ref_ambiguous) ambiguous = 0;
       TraceSeed sd;
       sd.entry = e;
@@ -960,6 +977,9 @@ int trace_chunk(World& w, const std::vector<Extent>& ext, int64_t start, int64_t
     }
   }
   w.seconds_tables += now_seconds() - t_tables;
+  if (getenv("BG_TRACER_TIMING"))
+    fprintf(stderr, "bg_tracer_tables: codes + upload %.4f s, read-ahead walk %.4f s, tables %.4f s of %.4f s so far (%zu positions with reads, %zu mate positions)\n",
+            w.seconds_tab_codes, w.seconds_tab_walk, w.seconds_tab_read, w.seconds_tables, w.position_entries.size(), w.rc_mate_read_positions.size());
   const size_t n_seeds = seeds.size();
   // ---- 2b. the traces that never branch, whole on the device (walk.hip k_trace_simple): all but six in a thousand follow the reference to the
   // next read and rejoin there.  What the kernel hands back as kSimpleHost runs on the state machine below, from its start.
@@ -1536,6 +1556,7 @@ static int tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext_off
   BG_HIP(hipSetDevice(w.ctx->device));
   memset(&w.stats, 0, sizeof(w.stats));
   w.seconds_device = w.seconds_host = w.seconds_tables = w.seconds_start = w.seconds_teardown = 0;
+  w.seconds_tab_codes = w.seconds_tab_walk = w.seconds_tab_read = 0;
   const double t_ext = now_seconds();
   BG_TRY(session_extents(&t->exts, "bg_tracer_trace", n_extents, ext_offset, ext_seq, ext_len, end_pos));
   const std::vector<Extent>& ext = t->exts->ext;
@@ -1658,6 +1679,7 @@ static int tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext_off
             now_seconds() - t_call, s_ext, s_chunk, async ? 0.0 : bh->s_drop, async ? 0.0 : bh->s_pair, w.seconds_tables, w.seconds_start, w.seconds_device, w.seconds_host, w.seconds_teardown, g_tracer_threads, (unsigned long long)w.stats.traces);
   // the chunk's tables are not kept between work items
   std::vector<std::pair<int32_t, uint64_t>>().swap(w.position_entries);
+  std::vector<uint16_t>().swap(w.position_info);
   std::vector<std::pair<uint64_t, int32_t>>().swap(w.entry_positions);
   std::vector<std::pair<uint32_t, int32_t>>().swap(w.rc_mate_read_positions);
   if (rc_behind != BG_OK) return rc_behind;

@@ -2064,11 +2064,15 @@ __global__ void k_tt_emit(const uint64_t* __restrict__ ent, uint64_t n, const ui
 // pair of the first two (the int32 member with its padding in one word), one word per pair of the third
 __global__ void k_tt_finish(uint64_t n_pe, uint64_t n_m, const uint32_t* __restrict__ pe_idx, const uint64_t* __restrict__ pe_ent,
                             const uint64_t* __restrict__ key, const uint64_t* __restrict__ mkey, int64_t first_off,
-                            uint64_t* __restrict__ o_pe, uint64_t* __restrict__ o_ep, uint64_t* __restrict__ o_mp) {
+                            uint64_t* __restrict__ o_pe, uint64_t* __restrict__ o_ep, uint64_t* __restrict__ o_mp,
+                            const uint8_t* __restrict__ sizes, const uint8_t* __restrict__ ref_map, uint16_t* __restrict__ o_info) {
   const uint64_t p = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (p < n_pe) {
     o_pe[2 * p] = uint64_t(uint32_t(int32_t(first_off + int64_t(pe_idx[p]))));
     o_pe[2 * p + 1] = pe_ent[p];
+    // what the sweep over the positions asks of every entry (tracer.cpp: the seed's size, "the reference holds it more than once"):
+    // two random reads in 140 MB host tables a position there, a coalesced column here
+    if (o_info) o_info[p] = uint16_t(sizes[pe_ent[p]]) | uint16_t((ref_map[pe_ent[p]] & 63u) > 1 ? 256 : 0);
     o_ep[2 * p] = key[p] >> 24;
     o_ep[2 * p + 1] = uint64_t(uint32_t(int32_t(first_off + int64_t(key[p] & 0xffffff))));
   }
@@ -2078,7 +2082,7 @@ __global__ void k_tt_finish(uint64_t n_pe, uint64_t n_m, const uint32_t* __restr
 int tracer_read_tables(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const uint8_t* d_ref_map, bool skip_ambiguous,
                        const uint64_t* d_ent, uint64_t n, int64_t first_off, std::vector<std::pair<int32_t, uint64_t>>* pos_entries,
                        std::vector<std::pair<uint64_t, int32_t>>* entry_pos, std::vector<std::pair<uint32_t, int32_t>>* mate_pos,
-                       DevBuf<uint64_t>* keep_entry_pos, DevBuf<uint64_t>* keep_mate_pos) {
+                       DevBuf<uint64_t>* keep_entry_pos, DevBuf<uint64_t>* keep_mate_pos, std::vector<uint16_t>* pos_info) {
   if (!n) return BG_OK;
   if (n >= (1ull << 24) || ss->n >= (1ull << 39) || rm->n_reads >= (1ull << 32)) { set_error("tracer_read_tables: stretch too long"); return BG_EINVAL; }
   DevBuf<uint32_t> cnt_pe, cnt_m, first_read, n_reads;
@@ -2111,11 +2115,13 @@ int tracer_read_tables(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, c
   static_assert(sizeof(std::pair<int32_t, uint64_t>) == 16 && sizeof(std::pair<uint64_t, int32_t>) == 16 && sizeof(std::pair<uint32_t, int32_t>) == 8,
                 "pair layouts");
   DevBuf<uint64_t> o_pe, o_ep, o_mp;
+  DevBuf<uint16_t> o_info;
   BG_TRY(o_pe.alloc(ctx, n_pe * 2)); BG_TRY(o_ep.alloc(ctx, n_pe * 2)); BG_TRY(o_mp.alloc(ctx, n_m));
+  if (pos_info) BG_TRY(o_info.alloc(ctx, n_pe));
   const uint64_t n_fin = n_pe > n_m ? n_pe : n_m;
   if (n_fin) {
     k_tt_finish<<<cdiv(n_fin, 256), 256, 0, ctx->stream>>>(n_pe, n_m, pe_idx.p, pe_ent.p, pe_in_b ? kb.p : ka.p, m_in_b ? mb.p : ma.p, first_off,
-                                                         o_pe.p, o_ep.p, o_mp.p);
+                                                         o_pe.p, o_ep.p, o_mp.p, ss->sizes.p, d_ref_map, pos_info ? o_info.p : nullptr);
     BG_LAUNCH_CHECK();
   }
   const size_t pe0 = pos_entries->size(), ep0 = entry_pos->size(), mp0 = mate_pos->size();
@@ -2127,6 +2133,10 @@ int tracer_read_tables(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, c
     BG_HIP(hipMemcpyAsync(static_cast<void*>(entry_pos->data() + ep0), o_ep.p, n_pe * 16, hipMemcpyDeviceToHost, ctx->stream));
   }
   if (n_m) BG_HIP(hipMemcpyAsync(static_cast<void*>(mate_pos->data() + mp0), o_mp.p, n_m * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (pos_info) {
+    pos_info->resize(pe0 + n_pe);
+    if (n_pe) BG_HIP(hipMemcpyAsync(pos_info->data() + pe0, o_info.p, n_pe * 2, hipMemcpyDeviceToHost, ctx->stream));
+  }
   BG_HIP(hipStreamSynchronize(ctx->stream));
   if (keep_entry_pos) *keep_entry_pos = std::move(o_ep);
   if (keep_mate_pos) *keep_mate_pos = std::move(o_mp);
