@@ -172,6 +172,11 @@ def lib():
     L.bg_trace_result_free.argtypes = [vp]
     L.bg_trace_result_free.restype = None
     L.bg_assemblies_process.argtypes = [vp, u32, u64, vp, vp, vp, C.c_int64, vp, u32, P(vp)]
+    L.bg_pipeline_open.argtypes = [u64, vp, vp, vp, C.c_int64, vp, u32, P(vp)]
+    L.bg_pipeline_feed.argtypes = [vp, vp, u32, C.c_int64, P(C.c_int)]
+    L.bg_pipeline_finish.argtypes = [vp, P(vp)]
+    L.bg_pipeline_close.argtypes = [vp]
+    L.bg_pipeline_close.restype = None
     L.bg_trace_result_new.argtypes = [P(vp)]
     L.bg_trace_result_add.argtypes = [vp, vp]
     L.bg_trace_result_half_aligned_count.argtypes = [vp]

@@ -867,6 +867,55 @@ extern "C" int bg_trace_result_var(const bg_trace_result* r, uint64_t i, uint64_
   return BG_OK;
 }
 
+// the steps behind the sorter, built back to front like assemble_pipeline::make_pipeline (pipeline.cpp:81-90)
+namespace {
+struct Chain {
+  std::unique_ptr<VcfPadder> pad;
+  std::unique_ptr<ExactDeduper> xdedup;
+  std::unique_ptr<Normalizer> norm;
+  std::unique_ptr<AlignSplitter> split;
+  std::unique_ptr<Aligner> align;
+  std::unique_ptr<Deduper> dedup;
+  std::unique_ptr<RefTrimmer> trim;
+  AssemblySink head;  // where an assembly enters
+  // sc and p are read by the steps for as long as the chain lives
+  Chain(uint32_t steps, const AlignParams& p, const ScaffoldView& sc, AssemblySink out) {
+    AssemblySink sink = std::move(out);
+    if (steps & BG_STEP_VCF_PAD) { pad.reset(new VcfPadder(sc, sink)); VcfPadder* q = pad.get(); sink = [q](bg_trace_assembly_rec&& a) { q->add(std::move(a)); }; }
+    if (steps & BG_STEP_EXACT_DEDUP) { xdedup.reset(new ExactDeduper(sink)); ExactDeduper* q = xdedup.get(); sink = [q](bg_trace_assembly_rec&& a) { q->add(std::move(a)); }; }
+    if (steps & BG_STEP_NORMALIZE) { norm.reset(new Normalizer(sc, sink)); Normalizer* q = norm.get(); sink = [q](bg_trace_assembly_rec&& a) { q->add(std::move(a)); }; }
+    if (steps & BG_STEP_SPLIT) { split.reset(new AlignSplitter(sink)); AlignSplitter* q = split.get(); sink = [q](bg_trace_assembly_rec&& a) { q->add(std::move(a)); }; }
+    if (steps & BG_STEP_ALIGN) { align.reset(new Aligner(p, sc, sink)); Aligner* q = align.get(); sink = [q](bg_trace_assembly_rec&& a) { q->add(std::move(a)); }; }
+    if (steps & BG_STEP_DEDUP) { dedup.reset(new Deduper(sink)); Deduper* q = dedup.get(); sink = [q](bg_trace_assembly_rec&& a) { q->add(std::move(a)); }; }
+    if (steps & BG_STEP_TRIM_REF) { trim.reset(new RefTrimmer(sc, sink)); RefTrimmer* q = trim.get(); sink = [q](bg_trace_assembly_rec&& a) { q->add(std::move(a)); }; }
+    head = std::move(sink);
+  }
+  void flush() {
+    if (trim) trim->flush();
+    if (dedup) dedup->flush();
+    if (align) align->flush();
+    if (split) split->flush();
+    if (norm) norm->flush();
+    if (xdedup) xdedup->flush();
+    if (pad) pad->flush();
+  }
+};
+
+int scaffold_view(const char* who, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq, const uint64_t* ext_len,
+                  int64_t end_pos, ScaffoldView* sc) {
+  int64_t calc_end = 0;
+  for (uint64_t i = 0; i < n_extents; ++i) {
+    if (ext_offset[i] < calc_end) { set_error("%s: extents must ascend without overlap", who); return BG_EINVAL; }
+    if (!all_acgt(ext_seq[i], ext_len[i])) { set_error("%s: extents hold ACGT only", who); return BG_EINVAL; }
+    sc->ext.push_back(ScaffoldView::Ext{ext_offset[i], ext_seq[i], int64_t(ext_len[i])});
+    calc_end = ext_offset[i] + int64_t(ext_len[i]);
+  }
+  if (end_pos < calc_end) { set_error("%s: end_pos lies before the end of the last extent", who); return BG_EINVAL; }
+  sc->end_pos = end_pos;
+  return BG_OK;
+}
+}  // namespace
+
 extern "C" int bg_assemblies_process(const bg_trace_result* const* in, uint32_t n_in, uint64_t n_extents, const int64_t* ext_offset,
                                      const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos,
                                      const bg_trace_options* options, uint32_t steps, bg_trace_result** out) {
@@ -876,36 +925,14 @@ extern "C" int bg_assemblies_process(const bg_trace_result* const* in, uint32_t 
   if (options) o = *options; else bg_trace_options_default(&o);
   if (o.ref_align_factor < 1) { set_error("bg_assemblies_process: ref_align_factor must be at least 1"); return BG_EINVAL; }
   ScaffoldView sc;
-  int64_t calc_end = 0;
-  for (uint64_t i = 0; i < n_extents; ++i) {
-    if (ext_offset[i] < calc_end) { set_error("bg_assemblies_process: extents must ascend without overlap"); return BG_EINVAL; }
-    if (!all_acgt(ext_seq[i], ext_len[i])) { set_error("bg_assemblies_process: extents hold ACGT only"); return BG_EINVAL; }
-    sc.ext.push_back(ScaffoldView::Ext{ext_offset[i], ext_seq[i], int64_t(ext_len[i])});
-    calc_end = ext_offset[i] + int64_t(ext_len[i]);
-  }
-  if (end_pos < calc_end) { set_error("bg_assemblies_process: end_pos lies before the end of the last extent"); return BG_EINVAL; }
-  sc.end_pos = end_pos;
+  BG_TRY(scaffold_view("bg_assemblies_process", n_extents, ext_offset, ext_seq, ext_len, end_pos, &sc));
   const AlignParams p = AlignParams::from(o);
   std::unique_ptr<bg_trace_result> res(new bg_trace_result);
   memset(&res->stats, 0, sizeof(res->stats));
   try {
-    // the chain, built back to front like assemble_pipeline::make_pipeline (pipeline.cpp:81-90)
-    AssemblySink sink = [&](bg_trace_assembly_rec&& a) { res->a.push_back(std::move(a)); };
-    std::unique_ptr<VcfPadder> pad;
-    std::unique_ptr<ExactDeduper> xdedup;
-    std::unique_ptr<Normalizer> norm;
-    if (steps & BG_STEP_VCF_PAD) { pad.reset(new VcfPadder(sc, sink)); sink = [&](bg_trace_assembly_rec&& a) { pad->add(std::move(a)); }; }
-    if (steps & BG_STEP_EXACT_DEDUP) { xdedup.reset(new ExactDeduper(sink)); sink = [&](bg_trace_assembly_rec&& a) { xdedup->add(std::move(a)); }; }
-    if (steps & BG_STEP_NORMALIZE) { norm.reset(new Normalizer(sc, sink)); sink = [&](bg_trace_assembly_rec&& a) { norm->add(std::move(a)); }; }
-    std::unique_ptr<AlignSplitter> split;
-    std::unique_ptr<Aligner> align;
-    std::unique_ptr<Deduper> dedup;
-    std::unique_ptr<RefTrimmer> trim;
+    bg_trace_result* r = res.get();
+    Chain chain(steps, p, sc, [r](bg_trace_assembly_rec&& a) { r->a.push_back(std::move(a)); });
     std::unique_ptr<AnchorDropper> drop;
-    if (steps & BG_STEP_SPLIT) { split.reset(new AlignSplitter(sink)); sink = [&](bg_trace_assembly_rec&& a) { split->add(std::move(a)); }; }
-    if (steps & BG_STEP_ALIGN) { align.reset(new Aligner(p, sc, sink)); sink = [&](bg_trace_assembly_rec&& a) { align->add(std::move(a)); }; }
-    if (steps & BG_STEP_DEDUP) { dedup.reset(new Deduper(sink)); sink = [&](bg_trace_assembly_rec&& a) { dedup->add(std::move(a)); }; }
-    if (steps & BG_STEP_TRIM_REF) { trim.reset(new RefTrimmer(sc, sink)); sink = [&](bg_trace_assembly_rec&& a) { trim->add(std::move(a)); }; }
     std::vector<bg_trace_assembly_rec> all;
     AssemblySink collect = [&](bg_trace_assembly_rec&& a) { all.push_back(std::move(a)); };
     if (steps & BG_STEP_ANCHOR_DROP) drop.reset(new AnchorDropper(p, sc, collect));
@@ -921,14 +948,8 @@ extern "C" int bg_assemblies_process(const bg_trace_result* const* in, uint32_t 
     if (o.output_ml_features)  // report_discovered_assemblies_func (pipeline.cpp:49-51): once per discovered assembly
       for (auto& a : all)
         if (!a.has_ml) add_ml_features(sc, a);
-    for (auto& a : all) sink(std::move(a));
-    if (trim) trim->flush();
-    if (dedup) dedup->flush();
-    if (align) align->flush();
-    if (split) split->flush();
-    if (norm) norm->flush();
-    if (xdedup) xdedup->flush();
-    if (pad) pad->flush();
+    for (auto& a : all) chain.head(std::move(a));
+    chain.flush();
   } catch (const CheckFailed& f) {
     set_error("bg_assemblies_process: %s (the reference aborts on this input)", f.what.c_str());
     return BG_EINVAL;
@@ -936,6 +957,101 @@ extern "C" int bg_assemblies_process(const bg_trace_result* const* in, uint32_t 
   *out = res.release();
   return BG_OK;
 }
+
+// ---- the same pipeline fed piece by piece (bgbinary discovery: behind the tracers of a scaffold instead of after them) ----------
+// The sorter orders a scaffold's assemblies by min(left, right) offset first (canon_less), and a piece's assemblies cannot lie
+// far before the piece (the tracers read the reference from start - max_pair_distance - a read's length, the reverse direction
+// from limit + read_ahead_distance back): what lies before a mark no later piece reaches is final.  bg_pipeline_feed takes the
+// results of the next pieces -- in the order bg_assemblies_process would be given them -- and a mark: every assembly held that
+// starts before the mark is sorted (stable: equal keys stay in arrival order) and goes through the steps.  The caller's mark is a
+// promise; an assembly that arrives behind a mark already given breaks it, and bg_pipeline_feed says so (*behind = 1, nothing
+// else changes: the caller runs bg_assemblies_process over everything instead).  Kept promises give bg_assemblies_process's
+// output, assembly for assembly: equal sort keys share their first offset and so their batch.
+struct bg_pipeline {
+  bg_trace_options o;
+  AlignParams p;
+  ScaffoldView sc;
+  uint32_t steps = 0;
+  std::unique_ptr<bg_trace_result> res;
+  std::unique_ptr<Chain> chain;
+  std::vector<bg_trace_assembly_rec> held;
+  int64_t mark = INT64_MIN;
+  bool broken = false, finished = false;
+};
+
+extern "C" int bg_pipeline_open(uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq, const uint64_t* ext_len,
+                                int64_t end_pos, const bg_trace_options* options, uint32_t steps, bg_pipeline** out) {
+  if (!out || (n_extents && (!ext_offset || !ext_seq || !ext_len))) { set_error("bg_pipeline_open: null argument"); return BG_EINVAL; }
+  if ((steps & ~uint32_t(BG_STEP_ALL)) || (steps & BG_STEP_ANCHOR_DROP) || !(steps & BG_STEP_SORT)) {
+    set_error("bg_pipeline_open: the steps must hold the sorter and not the anchor_dropper (it works on the tracers' own order)");
+    return BG_EINVAL;
+  }
+  std::unique_ptr<bg_pipeline> pl(new bg_pipeline);
+  if (options) pl->o = *options; else bg_trace_options_default(&pl->o);
+  if (pl->o.ref_align_factor < 1) { set_error("bg_pipeline_open: ref_align_factor must be at least 1"); return BG_EINVAL; }
+  BG_TRY(scaffold_view("bg_pipeline_open", n_extents, ext_offset, ext_seq, ext_len, end_pos, &pl->sc));  // (the caller keeps the extents)
+  pl->p = AlignParams::from(pl->o);
+  pl->steps = steps;
+  pl->res.reset(new bg_trace_result);
+  memset(&pl->res->stats, 0, sizeof(pl->res->stats));
+  bg_trace_result* r = pl->res.get();
+  pl->chain.reset(new Chain(steps, pl->p, pl->sc, [r](bg_trace_assembly_rec&& a) { r->a.push_back(std::move(a)); }));
+  *out = pl.release();
+  return BG_OK;
+}
+
+static int pipeline_run_to(bg_pipeline* pl, int64_t mark, const char* who) {
+  // the assemblies before the mark, in the sorter's order, through the steps; the rest stays
+  auto first_offset = [](const bg_trace_assembly_rec& a) { return std::min(a.left_offset, a.right_offset); };
+  auto mid = std::stable_partition(pl->held.begin(), pl->held.end(), [&](const bg_trace_assembly_rec& a) { return first_offset(a) < mark; });
+  std::stable_sort(pl->held.begin(), mid, canon_less);
+  try {
+    for (auto it = pl->held.begin(); it != mid; ++it) {
+      if (pl->o.output_ml_features && !it->has_ml) add_ml_features(pl->sc, *it);
+      pl->chain->head(std::move(*it));
+    }
+  } catch (const CheckFailed& f) {
+    pl->broken = true;
+    set_error("%s: %s (the reference aborts on this input)", who, f.what.c_str());
+    return BG_EINVAL;
+  }
+  pl->held.erase(pl->held.begin(), mid);
+  if (mark > pl->mark) pl->mark = mark;
+  return BG_OK;
+}
+
+extern "C" int bg_pipeline_feed(bg_pipeline* pl, const bg_trace_result* const* in, uint32_t n_in, int64_t mark, int* behind) {
+  if (!pl || !behind || (n_in && !in)) { set_error("bg_pipeline_feed: null argument"); return BG_EINVAL; }
+  *behind = 0;
+  if (pl->broken || pl->finished) { set_error("bg_pipeline_feed: the pipeline is finished or failed"); return BG_EINVAL; }
+  if (mark < pl->mark) { set_error("bg_pipeline_feed: the mark goes backwards"); return BG_EINVAL; }
+  for (uint32_t i = 0; i < n_in; ++i) {
+    if (!in[i]) { set_error("bg_pipeline_feed: null input"); return BG_EINVAL; }
+    for (const auto& a : in[i]->a)
+      if (std::min(a.left_offset, a.right_offset) < pl->mark) { *behind = 1; pl->broken = true; return BG_OK; }
+  }
+  for (uint32_t i = 0; i < n_in; ++i)
+    for (const auto& a : in[i]->a) pl->held.push_back(a);
+  return pipeline_run_to(pl, mark, "bg_pipeline_feed");
+}
+
+extern "C" int bg_pipeline_finish(bg_pipeline* pl, bg_trace_result** out) {
+  if (!pl || !out) { set_error("bg_pipeline_finish: null argument"); return BG_EINVAL; }
+  if (pl->broken || pl->finished) { set_error("bg_pipeline_finish: the pipeline is finished or failed"); return BG_EINVAL; }
+  BG_TRY(pipeline_run_to(pl, INT64_MAX, "bg_pipeline_finish"));
+  try {
+    pl->chain->flush();
+  } catch (const CheckFailed& f) {
+    pl->broken = true;
+    set_error("bg_pipeline_finish: %s (the reference aborts on this input)", f.what.c_str());
+    return BG_EINVAL;
+  }
+  pl->finished = true;
+  *out = pl->res.release();
+  return BG_OK;
+}
+
+extern "C" void bg_pipeline_close(bg_pipeline* pl) { delete pl; }
 
 extern "C" int bg_trace_result_ml(const bg_trace_result* r, uint64_t i, bg_assembly_ml* out) {
   if (!r || !out || i >= r->a.size()) { set_error("bg_trace_result_ml: bad argument"); return BG_EINVAL; }

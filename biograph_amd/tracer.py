@@ -307,6 +307,35 @@ def process_assemblies(assemblies, extents, end_pos=None, options=None, steps=ST
             L.bg_trace_result_free(out)
 
 
+def process_assemblies_streamed(batches, extents, end_pos=None, options=None, steps=STEP_PIPELINE):
+    """bg_pipeline_open / feed / finish: `batches` = [(assemblies, mark), ...] fed in order (the mark: no later assembly starts
+    before it).  -> ([TraceAssembly] as process_assemblies gives them for all batches together, None), or (None, k) when batch k
+    held an assembly behind a mark already given (the caller then runs process_assemblies over everything)."""
+    L = capi.lib()
+    n, offs, ptrs, lens, end_pos, _keep = _extent_arrays(extents, end_pos)
+    opt = options if options is not None else TraceOptions()
+    pl = C.c_void_p()
+    capi.check(L.bg_pipeline_open(n, offs, ptrs, lens, end_pos, C.byref(opt), int(steps), C.byref(pl)))
+    out = C.c_void_p()
+    try:
+        for k, (asms, mark) in enumerate(batches):
+            src = _make_result(asms)
+            try:
+                behind = C.c_int(0)
+                ins = (C.c_void_p * 1)(src)
+                capi.check(L.bg_pipeline_feed(pl, ins, 1, int(mark), C.byref(behind)))
+                if behind.value:
+                    return None, k
+            finally:
+                L.bg_trace_result_free(src)
+        capi.check(L.bg_pipeline_finish(pl, C.byref(out)))
+        return _read_result(out), None
+    finally:
+        L.bg_pipeline_close(pl)
+        if out:
+            L.bg_trace_result_free(out)
+
+
 class PushTracer:
     """A tracer session (bg_tracer_open): the seqset / readmap / ref_map arrays the host part consults are copied once,
     trace() is one work item of trace_ref (a scaffold piece in one direction)."""

@@ -586,6 +586,22 @@ void bg_trace_result_free(bg_trace_result* r);
 int bg_assemblies_process(const bg_trace_result* const* in, uint32_t n_in, uint64_t n_extents, const int64_t* ext_offset,
                           const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos,
                           const bg_trace_options* options /* NULL = defaults */, uint32_t steps, bg_trace_result** out);
+/* The same steps fed piece by piece -- behind a scaffold's tracers instead of after them (the reference's pipeline of a
+ * scaffold also takes its work items' output as they finish and sorts at the flush, pipeline.cpp:22-54, sort.cpp:6-13).
+ * steps: as above, with BG_STEP_SORT and without BG_STEP_ANCHOR_DROP.  bg_pipeline_feed takes the results of the next
+ * pieces, in the order bg_assemblies_process would be given them, and a mark: the caller's promise that no later input
+ * has min(left_offset, right_offset) before it (a piece's assemblies cannot lie further before the piece than the tracers
+ * read the reference: read_ahead_distance + max_pair_distance + two read lengths).  Everything held before the mark is
+ * sorted and goes through the steps.  An input behind a mark already given breaks the promise: *behind = 1, the pipeline
+ * is of no further use, and the caller runs bg_assemblies_process over all results instead.  With the promise kept,
+ * bg_pipeline_finish hands out what bg_assemblies_process would: assembly for assembly.  The extents stay the caller's
+ * and must outlive the pipeline.  Host only. */
+typedef struct bg_pipeline bg_pipeline;
+int bg_pipeline_open(uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq, const uint64_t* ext_len,
+                     int64_t end_pos, const bg_trace_options* options /* NULL = defaults */, uint32_t steps, bg_pipeline** out);
+int bg_pipeline_feed(bg_pipeline* p, const bg_trace_result* const* in, uint32_t n_in, int64_t mark, int* behind);
+int bg_pipeline_finish(bg_pipeline* p, bg_trace_result** out);
+void bg_pipeline_close(bg_pipeline* p);
 /* Hand-made input for the steps (the reference's unit tests build assemblies by hand): an empty result, and a copy
  * of *a appended to it. */
 int bg_trace_result_new(bg_trace_result** out);

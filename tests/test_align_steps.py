@@ -316,6 +316,60 @@ def test_random_assemblies_equal_the_oracle(seed):
     assert n_out > 200
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_pipeline_fed_piece_by_piece_equals_the_whole(seed):
+    """bg_pipeline_open / feed / finish (the steps behind a scaffold's tracers, piece by piece with marks) against
+    bg_assemblies_process over the same assemblies in the same order; a mark that a later piece breaks is reported."""
+    rng = random.Random(777 + seed)
+    sets = [BT.STEP_PIPELINE, BT.STEP_SORT | BT.STEP_TRIM_REF | BT.STEP_DEDUP, BT.STEP_SORT | BT.STEP_TRIM_REF | BT.STEP_DEDUP | BT.STEP_ALIGN,
+            BT.STEP_SORT]
+    n_out = n_broken = 0
+    for _ in range(60):
+        parts, sc, asms, kw = random_case(rng)
+        kw = dict(kw, output_ml_features=rng.choice([0, 1]))
+        try:
+            anchored = run(parts, asms * rng.randint(1, 3), BT.STEP_ANCHOR_DROP, **kw)
+        except Exception:
+            continue
+        if not anchored:
+            continue
+        first = lambda a: min(a.left_offset, a.right_offset)  # noqa: E731
+        lo, hi = min(map(first, anchored)), max(map(first, anchored)) + 1
+        cuts = sorted({lo} | {rng.randint(lo, hi) for _ in range(rng.randint(0, 5))})
+        reach = rng.choice([0, 5, 40, 1000])  # how far before its piece an assembly may lie
+        batches = [[] for _ in cuts]
+        for a in anchored:
+            f = first(a) + rng.randint(0, reach)
+            batches[max(i for i, c in enumerate(cuts) if c <= f)].append(a)
+        for b in batches:
+            rng.shuffle(b)
+        order = [a for b in batches for a in b]
+        marks = [c - reach for c in cuts[1:]] + [hi + reach]
+        for steps in sets:
+            try:
+                want = [full_key(a) for a in run(parts, order, steps, **kw)]
+            except Exception:  # a CHECK of the reference: piece by piece it must be refused as well
+                with pytest.raises(Exception):
+                    BT.process_assemblies_streamed(list(zip(batches, marks)), parts, options=opts(**kw), steps=steps)
+                continue
+            got, broken = BT.process_assemblies_streamed(list(zip(batches, marks)), parts, options=opts(**kw), steps=steps)
+            assert broken is None and [full_key(a) for a in got] == want, (seed, steps, kw)
+            n_out += len(got)
+        # marks that promise too much: the first piece that lies behind one says so
+        if len(batches) > 1 and reach:
+            greedy = [c for c in cuts[1:]] + [hi + reach]
+            late = next((k for k in range(1, len(batches)) if any(first(a) < greedy[k - 1] for a in batches[k])), None)
+            got, broken = BT.process_assemblies_streamed(list(zip(batches, greedy)), parts, options=opts(**kw), steps=BT.STEP_PIPELINE)
+            if late is None:
+                assert broken is None
+            else:
+                assert got is None and broken == late
+                n_broken += 1
+    assert n_out > 300 and n_broken > 0
+    with pytest.raises(Exception):  # the anchor_dropper works on the tracers' own order: not a step of the fed pipeline
+        BT.process_assemblies_streamed([([], 0)], [(0, tseq("abc"))], steps=BT.STEP_ANCHOR_DROP | BT.STEP_SORT)
+
+
 def test_ml_features_and_merge_counts():
     """add_ml_features (biograph_variants.cpp:746-779) behind the sorter, and what the dedupers keep of them."""
     ref = tseq("abc") + "T" + tseq("defgh")
