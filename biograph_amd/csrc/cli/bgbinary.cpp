@@ -30,6 +30,8 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <cstdint>
@@ -1613,6 +1615,139 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     std::vector<bg_trace_result*> items(work.size(), nullptr);
     std::vector<bg_trace_result*> pops(pop_tracer ? work.size() : 0, nullptr);  // (piece, direction) like `work`
     double t1 = now_s();
+    // One rank: a piece's pop tracers run as soon as its two push directions are through (not after every piece's), and the
+    // serial pipeline is fed the finished pieces in order while the sessions trace the rest (bg_pipeline_feed: what lies before a
+    // mark no later piece reaches goes through the steps; a piece that breaks a mark sends everything through
+    // bg_assemblies_process as before).  BG_DISCOVERY_STREAM=0: first every push, then every pop, then the pipeline.
+    static const bool stream_off = [] { const char* e = getenv("BG_DISCOVERY_STREAM"); return e && e[0] == '0'; }();
+    bg_trace_result* streamed_sections = nullptr;
+    double t_stream_tail = 0;
+    if (!ranks && !stream_off && !want_csv && !want_aligned && !work.empty()) {
+      const size_t n_pieces = work.size() / 2;
+      // how far before its piece an assembly may start: the reverse direction reads read_ahead_distance behind the piece, a pop
+      // tracer's fronts lie within an assembly's length and a pair's distance of the drops (generous: a broken mark only costs time)
+      int64_t reach = int64_t(opt.read_ahead_distance) + 4 * int64_t(opt.max_pair_distance) + 8 * int64_t(bg_seqset_max_len(ss)) + 4000;
+      if (const char* e = getenv("BG_DISCOVERY_REACH")) reach = atoll(e);  // (tests: marks that later pieces break)
+      std::vector<int64_t> mark(n_pieces, INT64_MAX);  // after piece p: no later piece starts before mark[p]
+      for (size_t p = n_pieces; p-- > 1;) mark[p - 1] = std::min(mark[p], work[2 * p].start - reach);
+      std::mutex mu;
+      std::condition_variable cv;
+      std::deque<size_t> pop_ready;          // work items whose pop tracer may run
+      std::vector<int> push_done(n_pieces, 0), pop_done(n_pieces, 0);
+      std::vector<char> piece_done(n_pieces, 0);
+      std::vector<std::unique_ptr<std::once_flag>> waited;
+      for (size_t p = 0; p < n_pieces; ++p) waited.emplace_back(new std::once_flag);
+      size_t next_push = 0, pops_taken = 0;
+      const size_t n_pops = pop_tracer ? work.size() : 0;
+      std::string err;
+      bool failed = false;
+      auto fail_with = [&](const std::string& what) {
+        std::lock_guard<std::mutex> l(mu);
+        if (!failed) { failed = true; err = what; }
+        cv.notify_all();
+      };
+      // (the anchor_dropper and the pair_counter of a push item run on its session's helper thread: whoever needs the result waits)
+      auto wait_pushes = [&](size_t p) {
+        std::call_once(*waited[p], [&] {
+          for (size_t i = 2 * p; i < 2 * p + 2; ++i)
+            if (bg_trace_result_wait(items[i]) != BG_OK) fail_with(std::string("bg_tracer_trace: ") + bg_last_error());
+        });
+      };
+      auto worker = [&](int t) {
+        static const bool sync_only = [] { const char* e = getenv("BG_TRACER_ASYNC"); return e && e[0] == '0'; }();
+        for (;;) {
+          size_t i = 0;
+          bool is_pop = false;
+          {
+            std::unique_lock<std::mutex> l(mu);
+            for (;;) {
+              if (failed) return;
+              if (!pop_ready.empty()) { i = pop_ready.front(); pop_ready.pop_front(); ++pops_taken; is_pop = true; break; }
+              if (next_push < work.size()) { i = next_push++; break; }
+              if (pops_taken >= n_pops) return;
+              cv.wait(l);
+            }
+          }
+          const size_t p = i / 2;
+          if (!is_pop) {
+            if ((sync_only ? bg_tracer_trace : bg_tracer_trace_async)(tracers[size_t(t)], es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()),
+                                                                      work[i].start, work[i].limit, work[i].rev, 1, &items[i]) != BG_OK) {
+              fail_with(std::string("bg_tracer_trace: ") + bg_last_error());
+              return;
+            }
+            std::lock_guard<std::mutex> l(mu);
+            if (++push_done[p] == 2) {
+              if (pop_tracer) { pop_ready.push_back(2 * p); pop_ready.push_back(2 * p + 1); }
+              else piece_done[p] = 1;
+              cv.notify_all();
+            }
+          } else {
+            wait_pushes(p);
+            {
+              std::lock_guard<std::mutex> l(mu);
+              if (failed) return;
+            }
+            const bg_trace_result* push[2] = {items[2 * p], items[2 * p + 1]};
+            if (bg_pop_trace(tracers[size_t(t)], es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), work[i].start, work[i].limit,
+                             work[i].rev, push, 2, &pops[i]) != BG_OK) {
+              fail_with(std::string("bg_pop_trace: ") + bg_last_error());
+              return;
+            }
+            std::lock_guard<std::mutex> l(mu);
+            if (++pop_done[p] == 2) { piece_done[p] = 1; cv.notify_all(); }
+          }
+        }
+      };
+      // the pipeline behind the pieces, in piece order
+      bg_pipeline* pl = nullptr;
+      check(bg_pipeline_open(es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), &opt, BG_STEP_PIPELINE, &pl), "bg_pipeline_open");
+      bool marks_held = true;
+      std::string feed_err;
+      std::thread feeder([&] {
+        int64_t promised = INT64_MIN;  // (the last piece promises nothing new: what it leaves goes through at the finish)
+        for (size_t p = 0; p < n_pieces; ++p) {
+          {
+            std::unique_lock<std::mutex> l(mu);
+            cv.wait(l, [&] { return failed || piece_done[p]; });
+            if (failed) return;
+          }
+          if (!pop_tracer) wait_pushes(p);
+          const bg_trace_result* in[4] = {items[2 * p], items[2 * p + 1], pop_tracer ? pops[2 * p] : nullptr, pop_tracer ? pops[2 * p + 1] : nullptr};
+          int behind = 0;
+          if (mark[p] != INT64_MAX) promised = std::max(promised, mark[p]);
+          if (bg_pipeline_feed(pl, in, pop_tracer ? 4 : 2, promised, &behind) != BG_OK) { feed_err = bg_last_error(); marks_held = false; return; }
+          if (behind) { marks_held = false; return; }
+        }
+      });
+      const int nt = int(std::min<size_t>(size_t(n_threads), work.size()));
+      std::vector<std::thread> pool;
+      for (int t = 1; t < nt; ++t) pool.emplace_back(worker, t);
+      worker(0);
+      for (auto& th : pool) th.join();
+      const double t_traced = now_s();
+      { std::lock_guard<std::mutex> l(mu); cv.notify_all(); }
+      feeder.join();
+      if (failed) die(err);
+      if (!pop_tracer)
+        for (size_t p = 0; p < n_pieces; ++p) wait_pushes(p);
+      if (failed) die(err);
+      if (!feed_err.empty()) die("bg_pipeline_feed: " + feed_err);
+      if (marks_held) {
+        check(bg_pipeline_finish(pl, &streamed_sections), "bg_pipeline_finish");
+      } else {
+        fprintf(stderr, "discovery: a piece's assemblies lay further before it than %lld bases: the scaffold's pipeline runs over all of them at once\n", (long long)reach);
+      }
+      bg_pipeline_close(pl);
+      t_stream_tail = now_s() - t_traced;
+      if (pop_tracer) {
+        std::vector<bg_trace_result*> all;
+        for (size_t i = 0; i + 1 < work.size(); i += 2) {
+          all.push_back(items[i]); all.push_back(items[i + 1]); all.push_back(pops[i]); all.push_back(pops[i + 1]);
+        }
+        for (auto* r : pops) if (r) n_popped += bg_trace_result_size(r);
+        items.swap(all);
+      }
+    } else
     {
       std::atomic<size_t> next(0);
       std::mutex err_mu;
@@ -1717,7 +1852,7 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
           half_csv.append(hs, hn);
           half_csv += "," + std::to_string(id) + "\n";
         }
-    t_trace += now_s() - t1;
+    t_trace += now_s() - t1 - t_stream_tail;  // (what the fed pipeline still had to do when the tracers were through is the pipeline's)
     rss_trace = std::max(rss_trace, rss_gb());
     // The steps behind the tracers -- pipeline, coverage, VCF records -- of this scaffold on a thread of their own while the
     // sessions trace the next scaffold (BG_DISCOVERY_OVERLAP=0: first to the end); one scaffold at a time, in order: the
@@ -1731,7 +1866,9 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     sd->items.swap(items);
     sd->name = &rec.first;
     sd->seq = &rec.second;
-    finisher = std::thread([&, sd, scaffold_k] {
+    bg_trace_result* const streamed = streamed_sections;
+    const double stream_tail = t_stream_tail;
+    finisher = std::thread([&, sd, scaffold_k, streamed, stream_tail] {
     auto& eo = sd->eo;
     auto& es = sd->es;
     auto& ep = sd->ep;
@@ -1790,11 +1927,13 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
       }
       bg_trace_result_free(al);
     }
-    check(bg_assemblies_process(items.data(), uint32_t(items.size()), es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()),
-                                &opt, BG_STEP_PIPELINE, &sections), "bg_assemblies_process");
+    if (streamed) sections = streamed;  // (fed piece by piece behind the tracers; its tail is counted below)
+    else
+      check(bg_assemblies_process(items.data(), uint32_t(items.size()), es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()),
+                                  &opt, BG_STEP_PIPELINE, &sections), "bg_assemblies_process");
     for (auto* r : items) bg_trace_result_free(r);
     n_sections += bg_trace_result_size(sections);
-    t_pipe += now_s() - t1;
+    t_pipe += now_s() - t1 + stream_tail;
     rss_pipe = std::max(rss_pipe, rss_gb());
     t1 = now_s();
     check(bg_coverage_run(cov_session, sections, es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), &cov, 1, &kept),

@@ -1,6 +1,6 @@
 """`bgbinary discovery` writes the same VCF whichever of its engine's shortcuts are on: the never-branching traces on the device
 (k_trace_simple), the unseen reference assemblies as lean records into pair_counter, several pop passes per launch (k_pop_passes),
-the one-sector rank blocks, the coverage step's worker groups, threads and islands per thread, the CLI's allocator, the number of tracer sessions.  Every shortcut
+the one-sector rank blocks, the pipeline fed piece by piece behind the tracers, the coverage step's worker groups, threads and islands per thread, the CLI's allocator, the number of tracer sessions.  Every shortcut
 claims "the same results"; the VCF lines of configs[1] against the oracle (tests/test_gpu_config1.py) pin the default, this pins
 the rest to the default -- on a sample with indels and a deletion, so that the pop tracer and the anchor_dropper have work
 (variants/tracer.cpp, pop_tracer.cpp, pair_counter.cpp, calc_coverage.cpp: one engine, several ways of running it)."""
@@ -107,6 +107,10 @@ def test_the_shortcuts_change_nothing(sample):
         "pop_front_by_binary_search": {"BG_WALK_SELECT": "0"},
         "one_work_item_at_a_time": {"BG_TRACER_ASYNC": "0"},
         "one_scaffold_at_a_time": {"BG_DISCOVERY_OVERLAP": "0"},
+        "pipeline_after_the_tracers": {"BG_DISCOVERY_STREAM": "0"},
+        "pipeline_marks_that_break": {"BG_DISCOVERY_REACH": "-50000"},
+        "pipeline_marks_at_the_pieces": {"BG_DISCOVERY_REACH": "0"},
+        "pipeline_marks_far_back": {"BG_DISCOVERY_REACH": "10000000"},
         "one_coverage_group_of_three": {"BG_COVERAGE_GROUPS": "1", "BG_COVERAGE_WORKERS": "3"},
         "many_small_coverage_groups": {"BG_COVERAGE_GROUPS": "7", "BG_COVERAGE_WORKERS": "5", "BG_COVERAGE_FIBERS": "3"},
         "one_island_per_thread": {"BG_COVERAGE_FIBERS": "1", "BG_COVERAGE_WORKERS": "40"},
@@ -116,8 +120,10 @@ def test_the_shortcuts_change_nothing(sample):
         "all_off": {"BG_TRACER_DEVICE_SIMPLE": "0", "BG_TRACER_LEAN_REFS": "0", "BG_POP_PASSES_AHEAD": "0", "BG_FAST_ALLOC_THP": "0"},
     }
     for name, env in variants.items():
-        got, _ = _discover(d, name, env)
+        got, err = _discover(d, name, env)
         assert got == base, name
+        # (the broken marks are said and the pipeline runs over everything; the default's marks hold)
+        assert ("further before it than" in err) == (name == "pipeline_marks_that_break"), name
     for threads in ("1", "3"):
         got, _ = _discover(d, "threads" + threads, extra=["--threads", threads])
         assert got == base, "threads " + threads
