@@ -175,6 +175,10 @@ def lib():
     L.bg_pipeline_open.argtypes = [u64, vp, vp, vp, C.c_int64, vp, u32, P(vp)]
     L.bg_pipeline_feed.argtypes = [vp, vp, u32, C.c_int64, P(C.c_int)]
     L.bg_pipeline_finish.argtypes = [vp, P(vp)]
+    L.bg_pipeline_take.argtypes = [vp, P(vp)]
+    L.bg_pipeline_ready.argtypes = [vp]
+    L.bg_pipeline_ready.restype = u64
+    L.bg_pipeline_release_early.argtypes = [vp, C.c_int64]
     L.bg_pipeline_close.argtypes = [vp]
     L.bg_pipeline_close.restype = None
     L.bg_trace_result_new.argtypes = [P(vp)]

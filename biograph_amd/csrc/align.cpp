@@ -436,10 +436,21 @@ class Deduper {
 };
 
 // ---- normalizer (normalize.cpp:7-126) -----------------------------------------------------------------------------------
+// (release_early, for the pipeline fed piece by piece: the reference's normalizer keeps everything of an extent until the extent
+// is through -- a variant may move left through a repeat of any length -- so a chromosome in one extent leaves the step only at
+// the flush.  With a margin, what lies more than `margin` bases before the variant coming in leaves at once; a later variant
+// that moves to before what has left breaks that, says so (broke()) and the caller runs the steps over everything instead.)
+struct NormalizerBroke {};
 class Normalizer : public SortedOutput {
  public:
   Normalizer(const ScaffoldView& sc, AssemblySink out) : SortedOutput(std::move(out)), sc_(sc) {}
+  void release_early(int64_t margin) { early_ = margin; }
   void add(bg_trace_assembly_rec&& a) {
+    const int64_t came_at = std::min(a.left_offset, a.right_offset);
+    if (early_ >= 0 && came_at - early_ > released_) {
+      released_ = came_at - early_;
+      flush_sorted_to(released_);
+    }
     if (a.matches_reference) { sort_and_output(std::move(a)); return; }
     a.aligned_variants.clear();
     for (;;) {
@@ -470,6 +481,7 @@ class Normalizer : public SortedOutput {
         a.seq.insert(a.seq.begin(), left_base);
       }
     }
+    if (early_ >= 0 && std::min(a.left_offset, a.right_offset) < released_) throw NormalizerBroke{};
     sort_and_output(std::move(a));
   }
 
@@ -477,10 +489,15 @@ class Normalizer : public SortedOutput {
   void advance_to(int64_t new_offset) {
     if (new_offset < cur_offset_) return;
     cur_offset_ = new_offset;
+    if (early_ >= 0) {  // (what an early release has let go is gone already)
+      if (new_offset <= released_) return;
+      released_ = new_offset;
+    }
     flush_sorted_to(new_offset);
   }
   const ScaffoldView& sc_;
   int64_t cur_offset_ = 0;
+  int64_t early_ = -1, released_ = INT64_MIN;
 };
 
 // ---- exact_deduper (dedup.cpp:146-216) ------------------------------------------------------------------------------------
@@ -976,7 +993,7 @@ struct bg_pipeline {
   std::unique_ptr<Chain> chain;
   std::vector<bg_trace_assembly_rec> held;
   int64_t mark = INT64_MIN;
-  bool broken = false, finished = false;
+  bool broken = false, finished = false, early_broke = false, fed = false;
 };
 
 extern "C" int bg_pipeline_open(uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq, const uint64_t* ext_len,
@@ -1010,6 +1027,10 @@ static int pipeline_run_to(bg_pipeline* pl, int64_t mark, const char* who) {
       if (pl->o.output_ml_features && !it->has_ml) add_ml_features(pl->sc, *it);
       pl->chain->head(std::move(*it));
     }
+  } catch (const NormalizerBroke&) {
+    pl->broken = true;
+    pl->early_broke = true;
+    return BG_OK;
   } catch (const CheckFailed& f) {
     pl->broken = true;
     set_error("%s: %s (the reference aborts on this input)", who, f.what.c_str());
@@ -1032,15 +1053,42 @@ extern "C" int bg_pipeline_feed(bg_pipeline* pl, const bg_trace_result* const* i
   }
   for (uint32_t i = 0; i < n_in; ++i)
     for (const auto& a : in[i]->a) pl->held.push_back(a);
-  return pipeline_run_to(pl, mark, "bg_pipeline_feed");
+  pl->fed = true;
+  BG_TRY(pipeline_run_to(pl, mark, "bg_pipeline_feed"));
+  if (pl->early_broke) *behind = 1;  // (a variant moved left past what the normalizer had released early)
+  return BG_OK;
+}
+
+extern "C" int bg_pipeline_release_early(bg_pipeline* pl, int64_t margin) {
+  if (!pl) { set_error("bg_pipeline_release_early: null argument"); return BG_EINVAL; }
+  if (pl->fed) { set_error("bg_pipeline_release_early: before the first feed"); return BG_EINVAL; }
+  if (pl->chain->norm) pl->chain->norm->release_early(margin);
+  return BG_OK;
+}
+
+extern "C" uint64_t bg_pipeline_ready(const bg_pipeline* pl) { return pl && pl->res ? pl->res->a.size() : 0; }
+
+extern "C" int bg_pipeline_take(bg_pipeline* pl, bg_trace_result** out) {
+  if (!pl || !out) { set_error("bg_pipeline_take: null argument"); return BG_EINVAL; }
+  if (pl->broken || pl->finished) { set_error("bg_pipeline_take: the pipeline is finished or failed"); return BG_EINVAL; }
+  std::unique_ptr<bg_trace_result> r(new bg_trace_result);
+  memset(&r->stats, 0, sizeof(r->stats));
+  r->a.swap(pl->res->a);
+  *out = r.release();
+  return BG_OK;
 }
 
 extern "C" int bg_pipeline_finish(bg_pipeline* pl, bg_trace_result** out) {
   if (!pl || !out) { set_error("bg_pipeline_finish: null argument"); return BG_EINVAL; }
   if (pl->broken || pl->finished) { set_error("bg_pipeline_finish: the pipeline is finished or failed"); return BG_EINVAL; }
   BG_TRY(pipeline_run_to(pl, INT64_MAX, "bg_pipeline_finish"));
+  if (pl->early_broke) { *out = nullptr; return BG_OK; }  // (a variant of the tail moved left past what the normalizer had released early)
   try {
     pl->chain->flush();
+  } catch (const NormalizerBroke&) {
+    pl->broken = true;
+    *out = nullptr;
+    return BG_OK;
   } catch (const CheckFailed& f) {
     pl->broken = true;
     set_error("bg_pipeline_finish: %s (the reference aborts on this input)", f.what.c_str());

@@ -1545,6 +1545,11 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   double t_trace = 0, t_pipe = 0, t_cov = 0, t_vcf = 0;
   double rss_trace = 0, rss_pipe = 0, rss_cov = 0;
   std::thread finisher;  // the scaffold before the one being traced, behind its tracers
+  // the coverage session takes one scaffold's sections at a time: a scaffold whose sections are fed behind its tracers
+  // (bg_coverage_feed) waits for the scaffold before it to be through with the session
+  std::mutex cov_turn_mu;
+  std::condition_variable cov_turn_cv;
+  size_t cov_turn = 0, cov_tickets = 0;
   const double rss_sessions = rss_gb();
   struct ScaffoldData {
     std::vector<int64_t> eo;
@@ -1620,8 +1625,15 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     // mark no later piece reaches goes through the steps; a piece that breaks a mark sends everything through
     // bg_assemblies_process as before).  BG_DISCOVERY_STREAM=0: first every push, then every pop, then the pipeline.
     static const bool stream_off = [] { const char* e = getenv("BG_DISCOVERY_STREAM"); return e && e[0] == '0'; }();
+    // BG_DISCOVERY_STREAM=coverage: what leaves the pipeline goes on to the coverage session as well, in a few large stretches
+    // (measured on the chr20-shaped sample and left off: the coverage step's sixty threads and their device rounds beside the
+    // sessions slow the tracing from 1.55 to 2.0 s for the 0.2 s of coverage they hide: 3.3 s for the command against 3.0-3.2)
+    static const bool cov_stream_off = [] { const char* e = getenv("BG_DISCOVERY_STREAM"); return !(e && e[0] == 'c'); }();
     bg_trace_result* streamed_sections = nullptr;
     double t_stream_tail = 0;
+    bool cov_fed = false;           // the coverage session holds this scaffold's sections so far
+    uint64_t n_sections_fed = 0;
+    const size_t cov_ticket = (ranks && !(int(size_t(&rec - &recs[0]) % size_t(env.world)) == env.rank)) ? size_t(-1) : cov_tickets++;
     if (!ranks && !stream_off && !want_csv && !want_aligned && !work.empty()) {
       const size_t n_pieces = work.size() / 2;
       // how far before its piece an assembly may start: the reverse direction reads read_ahead_distance behind the piece, a pop
@@ -1701,6 +1713,12 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
       // the pipeline behind the pieces, in piece order
       bg_pipeline* pl = nullptr;
       check(bg_pipeline_open(es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), &opt, BG_STEP_PIPELINE, &pl), "bg_pipeline_open");
+      // (the normalizer lets go of what lies this far before the variant coming in, instead of keeping a whole extent -- a
+      // chromosome -- to the end: the coverage step gets its sections behind the tracers.  A variant that moves further left
+      // through a repeat breaks that like a mark.  BG_DISCOVERY_EARLY=bases, negative: off)
+      int64_t early = 20000;
+      if (const char* e = getenv("BG_DISCOVERY_EARLY")) early = atoll(e);
+      if (early >= 0 && !cov_stream_off) check(bg_pipeline_release_early(pl, early), "bg_pipeline_release_early");
       bool marks_held = true;
       std::string feed_err;
       std::thread feeder([&] {
@@ -1717,6 +1735,28 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
           if (mark[p] != INT64_MAX) promised = std::max(promised, mark[p]);
           if (bg_pipeline_feed(pl, in, pop_tracer ? 4 : 2, promised, &behind) != BG_OK) { feed_err = bg_last_error(); marks_held = false; return; }
           if (behind) { marks_held = false; return; }
+          // (the coverage step runs its islands on dozens of threads in rounds on the device: a piece's few hundred islands at a
+          // time would cost every piece the rounds of a whole scaffold -- what has left the pipeline goes on in a few large stretches)
+          static const uint64_t cov_batch = [] { const char* e = getenv("BG_DISCOVERY_COV_BATCH"); return e ? uint64_t(atoll(e)) : uint64_t(20000); }();
+          if (cov_stream_off || bg_pipeline_ready(pl) < cov_batch) continue;
+          bg_trace_result* stretch = nullptr;
+          if (bg_pipeline_take(pl, &stretch) != BG_OK) { feed_err = bg_last_error(); marks_held = false; return; }
+          if (bg_trace_result_size(stretch)) {
+            if (!cov_fed) {  // (the scaffold before this one may still be with the session)
+              std::unique_lock<std::mutex> l(cov_turn_mu);
+              cov_turn_cv.wait(l, [&] { return cov_turn == cov_ticket; });
+              bg_coverage_discard(cov_session);
+              cov_fed = true;
+            }
+            n_sections_fed += bg_trace_result_size(stretch);
+            if (bg_coverage_feed(cov_session, stretch, es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), &cov, 1, 0, nullptr) != BG_OK) {
+              feed_err = bg_last_error();
+              marks_held = false;
+              bg_trace_result_free(stretch);
+              return;
+            }
+          }
+          bg_trace_result_free(stretch);
         }
       });
       const int nt = int(std::min<size_t>(size_t(n_threads), work.size()));
@@ -1734,9 +1774,11 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
       if (!feed_err.empty()) die("bg_pipeline_feed: " + feed_err);
       if (marks_held) {
         check(bg_pipeline_finish(pl, &streamed_sections), "bg_pipeline_finish");
-      } else {
-        fprintf(stderr, "discovery: a piece's assemblies lay further before it than %lld bases: the scaffold's pipeline runs over all of them at once\n", (long long)reach);
+        if (!streamed_sections) marks_held = false;  // (the tail broke the normalizer's early release)
       }
+      if (!marks_held)
+        fprintf(stderr, "discovery: a piece's assemblies lay further before it than %lld bases, or a variant moved further left than %lld: the "
+                        "scaffold's pipeline runs over all of them at once\n", (long long)reach, (long long)early);
       bg_pipeline_close(pl);
       t_stream_tail = now_s() - t_traced;
       if (pop_tracer) {
@@ -1868,7 +1910,9 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
     sd->seq = &rec.second;
     bg_trace_result* const streamed = streamed_sections;
     const double stream_tail = t_stream_tail;
-    finisher = std::thread([&, sd, scaffold_k, streamed, stream_tail] {
+    const bool cov_streamed = cov_fed && streamed;  // (marks that broke after a stretch went on: bg_coverage_run starts the scaffold over)
+    const uint64_t sections_fed = cov_streamed ? n_sections_fed : 0;
+    finisher = std::thread([&, sd, scaffold_k, streamed, stream_tail, cov_streamed, sections_fed, cov_ticket] {
     auto& eo = sd->eo;
     auto& es = sd->es;
     auto& ep = sd->ep;
@@ -1932,12 +1976,24 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
       check(bg_assemblies_process(items.data(), uint32_t(items.size()), es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()),
                                   &opt, BG_STEP_PIPELINE, &sections), "bg_assemblies_process");
     for (auto* r : items) bg_trace_result_free(r);
-    n_sections += bg_trace_result_size(sections);
+    n_sections += bg_trace_result_size(sections) + sections_fed;
     t_pipe += now_s() - t1 + stream_tail;
     rss_pipe = std::max(rss_pipe, rss_gb());
     t1 = now_s();
-    check(bg_coverage_run(cov_session, sections, es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), &cov, 1, &kept),
-          "bg_coverage_run");
+    {  // (this scaffold's turn with the session, if it has not taken it behind its tracers already)
+      std::unique_lock<std::mutex> l(cov_turn_mu);
+      cov_turn_cv.wait(l, [&] { return cov_turn == cov_ticket; });
+    }
+    if (cov_streamed)  // the stretches before went on behind the tracers: what the pipeline's finish left, and the scaffold is through
+      check(bg_coverage_feed(cov_session, sections, es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), &cov, 1, 1, &kept), "bg_coverage_feed");
+    else
+      check(bg_coverage_run(cov_session, sections, es.size(), eo.data(), ep.data(), el.data(), int64_t(seq.size()), &cov, 1, &kept),
+            "bg_coverage_run");
+    {
+      std::lock_guard<std::mutex> l(cov_turn_mu);
+      ++cov_turn;
+      cov_turn_cv.notify_all();
+    }
     bg_trace_result_free(sections);
     t_cov += now_s() - t1;
     rss_cov = std::max(rss_cov, rss_gb());

@@ -824,6 +824,14 @@ struct bg_coverage {
   const bg_seqset* ss = nullptr;
   CovWorld tables;
   std::vector<bg_ctx*> group_ctx;  // contexts (streams) of the worker groups beyond the first, made when first needed
+  // a scaffold's sections arriving in stretches (bg_coverage_feed): the variant sections of the island still open, what the
+  // finished islands gave (in island order), where the input stands
+  struct Stream {
+    std::vector<bg_trace_assembly_rec> open, covered;
+    int64_t need_to = INT64_MIN, last_left = INT64_MIN;
+    uint64_t islands = 0, rounds = 0, steps = 0;
+    double t_workers = 0;
+  } stream;
   ~bg_coverage() { for (bg_ctx* g : group_ctx) bg_ctx_destroy(g); }
 };
 
@@ -852,23 +860,135 @@ extern "C" int bg_assemblies_coverage(bg_ctx* ctx, const bg_seqset* ss, const bg
   return rc;
 }
 
-extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64_t n_extents, const int64_t* ext_offset,
-                               const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos,
-                               const bg_coverage_options* options, int genotype_filter, bg_trace_result** out) {
-  if (!c || !in || !out || (n_extents && (!ext_offset || !ext_seq || !ext_len))) {
+// The islands of `islands` (variant sections sorted by left offset, each island a run that shares nothing with the next) through
+// calc_coverage, every island a state machine of its own on the worker groups; done[i] = what island i gave.
+static void run_islands(bg_coverage* c, CovWorld& w, const std::vector<std::vector<const bg_trace_assembly_rec*>>& islands,
+                        std::vector<std::vector<bg_trace_assembly_rec>>* done_out) {
+  bg_ctx* ctx = c->ctx;
+  const bg_seqset* ss = c->ss;
+  std::vector<std::vector<bg_trace_assembly_rec>>& done = *done_out;
+  done.assign(islands.size(), {});
+  // BG_COVERAGE_GROUPS groups (default 4: contexts, streams, launcher threads) of up to BG_COVERAGE_WORKERS worker threads
+  // (default 16) with up to BG_COVERAGE_FIBERS islands in flight each (default 32); fiber v of all runs islands v, v + all, ...
+  // (chr20-shaped sample, coverage + genotype, one island per thread: 1 x 128 threads with a condition variable 2.06 s; with the
+  // futex 1 x 128 1.86 s, 8 x 64 0.93 s, 16 x 64 1.16 s, 4 x 128 0.87 s, 8 x 128 0.85 s -- 2 700 rounds a second whatever the
+  // grouping: the wake-ups.)
+  size_t max_workers = 16, max_groups = 4, max_fibers = 32;
+  if (const char* e = getenv("BG_COVERAGE_WORKERS")) max_workers = size_t(std::max(1, atoi(e)));
+  if (const char* e = getenv("BG_COVERAGE_GROUPS")) max_groups = size_t(std::max(1, atoi(e)));
+  if (const char* e = getenv("BG_COVERAGE_FIBERS")) max_fibers = size_t(std::max(1, atoi(e)));
+  const size_t n_threads = std::min<size_t>(islands.size(), max_workers * max_groups);
+  const size_t fibers_per_thread = n_threads ? std::min<size_t>(max_fibers, (islands.size() + n_threads - 1) / n_threads) : 0;
+  const size_t all = n_threads * fibers_per_thread;  // islands in flight
+  const size_t n_groups = n_threads ? std::min<size_t>(max_groups, (n_threads + max_workers - 1) / max_workers) : 0;
+  while (c->group_ctx.size() + 1 < n_groups) {
+    bg_ctx* g = nullptr;
+    if (bg_ctx_create_own_stream(ctx->device, &g) != BG_OK) throw CheckFailed{std::string("a worker group's context: ") + bg_last_error()};
+    c->group_ctx.push_back(g);
+  }
+  std::vector<std::unique_ptr<Batcher>> batchers;
+  std::vector<size_t> first_worker(n_groups + 1, 0);
+  for (size_t g = 0; g < n_groups; ++g) {
+    first_worker[g + 1] = n_threads * (g + 1) / n_groups;
+    batchers.emplace_back(new Batcher(g ? c->group_ctx[g - 1] : ctx, ss, int(first_worker[g + 1] - first_worker[g])));
+  }
+  std::mutex err_mu;
+  std::string first_error;
+  auto note_error = [&](const std::string& what) {
+    std::lock_guard<std::mutex> l(err_mu);
+    if (first_error.empty()) first_error = what;
+  };
+  std::vector<std::thread> pool;
+  for (size_t g = 0; g < n_groups; ++g)
+    for (size_t u = first_worker[g]; u < first_worker[g + 1]; ++u)
+      pool.emplace_back([&, g, u] {
+        Batcher* b = batchers[g].get();
+        FiberThread th;
+        th.batcher = b;
+        std::vector<std::unique_ptr<IslandFiber>> fibers;
+        for (size_t k = 0; k < fibers_per_thread; ++k) {
+          const size_t v = u * fibers_per_thread + k;  // this fiber's first island
+          if (v >= islands.size()) break;
+          fibers.emplace_back(new IslandFiber);
+          IslandFiber& f = *fibers.back();
+          f.th = &th;
+          IslandFiber* self = &f;
+          auto body = [&, v, self] {
+            try {
+              for (size_t i = v; i < islands.size(); i += all) {
+                Coverage cov(w, self);
+                for (const bg_trace_assembly_rec* a : islands[i]) {
+                  bg_trace_assembly_rec copy = *a;
+                  cov.add(std::move(copy));
+                }
+                cov.finish(&done[i]);
+              }
+            } catch (const CheckFailed& e) {
+              note_error(e.what);
+            } catch (const std::exception& e) {  // nothing may unwind past a fiber's entry frame (fiber.h): bad_alloc, length_error
+              note_error(std::string("coverage: ") + e.what());
+            } catch (...) {
+              note_error("coverage: an island ended on an unknown exception");
+            }
+          };
+          if (!f.fiber.start(&th.sched, size_t(512) << 10, body)) { note_error("coverage: no memory for an island's stack"); fibers.pop_back(); break; }
+        }
+        // rounds: every island of this thread runs until it parks or ends, then the thread takes part in the group's round
+        for (;;) {
+          th.reqs.clear();
+          bool any = false;
+          for (auto& f : fibers)
+            if (!f->fiber.done) {
+              any = true;
+              f->fiber.resume();
+            }
+          if (!any) break;
+          if (th.reqs.empty() || th.failed) continue;  // (the ones that parked before a failure wake up, throw and end)
+          try {
+            b->submit_and_wait(th.reqs);
+          } catch (const CheckFailed& e) {
+            th.failed = true;
+            th.error = e.what;
+            note_error(e.what);
+          }
+        }
+        b->worker_exit();
+      });
+  for (size_t g = 1; g < n_groups; ++g)
+    pool.emplace_back([&, g] {
+      (void)hipSetDevice(ctx->device);
+      batchers[g]->run();
+    });
+  if (n_groups) batchers[0]->run();
+  for (auto& th : pool) th.join();
+  if (!first_error.empty()) throw CheckFailed{first_error};
+  for (auto& b : batchers) {
+    c->stream.rounds += b->launches;
+    c->stream.steps += b->steps;
+  }
+  c->stream.islands += islands.size();
+}
+
+// A scaffold's sections in stretches, in order (bgbinary discovery: as the pipeline behind the tracers hands them out).  Islands
+// (see below) that a stretch completes are covered at once; the one still open waits for the next stretch.  last != 0: the
+// scaffold is through -- the open island, then sort, genotype filter and rvg_exclude over everything, *out = the result
+// (bg_coverage_run = one stretch that is the last).  One scaffold at a time per session; bg_coverage_discard forgets a scaffold
+// that is not going to be finished.  Same result whatever the stretches: the islands are the same and stay in input order.
+extern "C" int bg_coverage_feed(bg_coverage* c, const bg_trace_result* in, uint64_t n_extents, const int64_t* ext_offset,
+                                const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos,
+                                const bg_coverage_options* options, int genotype_filter, int last, bg_trace_result** out) {
+  if (!c || (last && !out) || (n_extents && (!ext_offset || !ext_seq || !ext_len))) {
     set_error("bg_assemblies_coverage: null argument");
     return BG_EINVAL;
   }
   const double t_enter = cov_now();
   bg_ctx* ctx = c->ctx;
-  const bg_seqset* ss = c->ss;
   bg_coverage_options o;
   if (options) o = *options; else bg_coverage_options_default(&o);
   ScaffoldView sc;
   BG_TRY(build_scaffold("bg_assemblies_coverage", n_extents, ext_offset, ext_seq, ext_len, end_pos, &sc));
   BG_HIP(hipSetDevice(ctx->device));
-  std::unique_ptr<bg_trace_result> res(new bg_trace_result);
-  memset(&res->stats, 0, sizeof(res->stats));
+  bg_coverage::Stream& st = c->stream;
   try {
     CovWorld& w = c->tables;  // the scaffold and the options are this call's
     w.sc = &sc;
@@ -876,117 +996,51 @@ extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64
     // Islands: calc_coverage re-initialises its reference path group whenever nothing is active and the next variant
     // starts more than max_read_len behind everything still owed coverage (skip_to, calc_coverage.cpp:345-360), so
     // runs of variants separated like that share nothing and each gets its own state machine.
-    std::vector<std::vector<const bg_trace_assembly_rec*>> islands;
-    int64_t need_to = INT64_MIN, last_left = INT64_MIN;
-    for (const auto& a : in->a) {
-      if (a.matches_reference) continue;
-      check(a.left_offset >= last_left, "calc_coverage: input not sorted by left offset");
-      check(a.right_offset >= a.left_offset, "calc_coverage: right offset before the left one");
-      last_left = a.left_offset;
-      if (islands.empty() || a.left_offset - w.max_read_len > need_to) islands.emplace_back();
-      islands.back().push_back(&a);
-      need_to = std::max(need_to, a.right_offset + w.max_read_len);
+    // (the stretch's variant sections join the open island's; every island but the last one is closed by its successor)
+    std::vector<bg_trace_assembly_rec> now = std::move(st.open);
+    st.open.clear();
+    std::vector<size_t> first_of;  // where every island starts in `now`
+    int64_t need_to = INT64_MIN;
+    for (size_t i = 0; i < now.size(); ++i) {  // (the open island: one island by construction)
+      if (first_of.empty()) first_of.push_back(0);
+      need_to = std::max(need_to, now[i].right_offset + w.max_read_len);
+    }
+    if (in)
+      for (const auto& a : in->a) {
+        if (a.matches_reference) continue;
+        check(a.left_offset >= st.last_left, "calc_coverage: input not sorted by left offset");
+        check(a.right_offset >= a.left_offset, "calc_coverage: right offset before the left one");
+        st.last_left = a.left_offset;
+        if (first_of.empty() || a.left_offset - w.max_read_len > need_to) first_of.push_back(now.size());
+        now.push_back(a);
+        need_to = std::max(need_to, a.right_offset + w.max_read_len);
+      }
+    size_t n_closed = first_of.size();
+    if (!last && n_closed) {  // the last island stays open
+      --n_closed;
+      st.open.assign(std::make_move_iterator(now.begin() + long(first_of[n_closed])), std::make_move_iterator(now.end()));
+      now.resize(first_of[n_closed]);
+    }
+    std::vector<std::vector<const bg_trace_assembly_rec*>> islands(n_closed);
+    for (size_t k = 0; k < n_closed; ++k) {
+      const size_t b = first_of[k], e = k + 1 < first_of.size() ? std::min(first_of[k + 1], now.size()) : now.size();
+      for (size_t i = b; i < e; ++i) islands[k].push_back(&now[i]);
     }
     const double t_islands = cov_now();
-    std::vector<std::vector<bg_trace_assembly_rec>> done(islands.size());
-    // BG_COVERAGE_GROUPS groups (default 4: contexts, streams, launcher threads) of up to BG_COVERAGE_WORKERS worker threads
-    // (default 16) with up to BG_COVERAGE_FIBERS islands in flight each (default 32); fiber v of all runs islands v, v + all, ...
-    // (chr20-shaped sample, coverage + genotype, one island per thread: 1 x 128 threads with a condition variable 2.06 s; with the
-    // futex 1 x 128 1.86 s, 8 x 64 0.93 s, 16 x 64 1.16 s, 4 x 128 0.87 s, 8 x 128 0.85 s -- 2 700 rounds a second whatever the
-    // grouping: the wake-ups.)
-    size_t max_workers = 16, max_groups = 4, max_fibers = 32;
-    if (const char* e = getenv("BG_COVERAGE_WORKERS")) max_workers = size_t(std::max(1, atoi(e)));
-    if (const char* e = getenv("BG_COVERAGE_GROUPS")) max_groups = size_t(std::max(1, atoi(e)));
-    if (const char* e = getenv("BG_COVERAGE_FIBERS")) max_fibers = size_t(std::max(1, atoi(e)));
-    const size_t n_threads = std::min<size_t>(islands.size(), max_workers * max_groups);
-    const size_t fibers_per_thread = n_threads ? std::min<size_t>(max_fibers, (islands.size() + n_threads - 1) / n_threads) : 0;
-    const size_t all = n_threads * fibers_per_thread;  // islands in flight
-    const size_t n_groups = n_threads ? std::min<size_t>(max_groups, (n_threads + max_workers - 1) / max_workers) : 0;
-    while (c->group_ctx.size() + 1 < n_groups) {
-      bg_ctx* g = nullptr;
-      if (bg_ctx_create_own_stream(ctx->device, &g) != BG_OK) throw CheckFailed{std::string("a worker group's context: ") + bg_last_error()};
-      c->group_ctx.push_back(g);
-    }
-    std::vector<std::unique_ptr<Batcher>> batchers;
-    std::vector<size_t> first_worker(n_groups + 1, 0);
-    for (size_t g = 0; g < n_groups; ++g) {
-      first_worker[g + 1] = n_threads * (g + 1) / n_groups;
-      batchers.emplace_back(new Batcher(g ? c->group_ctx[g - 1] : ctx, ss, int(first_worker[g + 1] - first_worker[g])));
-    }
-    std::mutex err_mu;
-    std::string first_error;
-    auto note_error = [&](const std::string& what) {
-      std::lock_guard<std::mutex> l(err_mu);
-      if (first_error.empty()) first_error = what;
-    };
-    std::vector<std::thread> pool;
-    for (size_t g = 0; g < n_groups; ++g)
-      for (size_t u = first_worker[g]; u < first_worker[g + 1]; ++u)
-        pool.emplace_back([&, g, u] {
-          Batcher* b = batchers[g].get();
-          FiberThread th;
-          th.batcher = b;
-          std::vector<std::unique_ptr<IslandFiber>> fibers;
-          for (size_t k = 0; k < fibers_per_thread; ++k) {
-            const size_t v = u * fibers_per_thread + k;  // this fiber's first island
-            if (v >= islands.size()) break;
-            fibers.emplace_back(new IslandFiber);
-            IslandFiber& f = *fibers.back();
-            f.th = &th;
-            IslandFiber* self = &f;
-            auto body = [&, v, self] {
-              try {
-                for (size_t i = v; i < islands.size(); i += all) {
-                  Coverage cov(w, self);
-                  for (const bg_trace_assembly_rec* a : islands[i]) {
-                    bg_trace_assembly_rec copy = *a;
-                    cov.add(std::move(copy));
-                  }
-                  cov.finish(&done[i]);
-                }
-              } catch (const CheckFailed& e) {
-                note_error(e.what);
-              } catch (const std::exception& e) {  // nothing may unwind past a fiber's entry frame (fiber.h): bad_alloc, length_error
-                note_error(std::string("coverage: ") + e.what());
-              } catch (...) {
-                note_error("coverage: an island ended on an unknown exception");
-              }
-            };
-            if (!f.fiber.start(&th.sched, size_t(512) << 10, body)) { note_error("coverage: no memory for an island's stack"); fibers.pop_back(); break; }
-          }
-          // rounds: every island of this thread runs until it parks or ends, then the thread takes part in the group's round
-          for (;;) {
-            th.reqs.clear();
-            bool any = false;
-            for (auto& f : fibers)
-              if (!f->fiber.done) {
-                any = true;
-                f->fiber.resume();
-              }
-            if (!any) break;
-            if (th.reqs.empty() || th.failed) continue;  // (the ones that parked before a failure wake up, throw and end)
-            try {
-              b->submit_and_wait(th.reqs);
-            } catch (const CheckFailed& e) {
-              th.failed = true;
-              th.error = e.what;
-              note_error(e.what);
-            }
-          }
-          b->worker_exit();
-        });
-    for (size_t g = 1; g < n_groups; ++g)
-      pool.emplace_back([&, g] {
-        (void)hipSetDevice(ctx->device);
-        batchers[g]->run();
-      });
-    if (n_groups) batchers[0]->run();
-    for (auto& th : pool) th.join();
-    if (!first_error.empty()) throw CheckFailed{first_error};
-    const double t_workers = cov_now();
-    std::vector<bg_trace_assembly_rec> covered;
+    std::vector<std::vector<bg_trace_assembly_rec>> done;
+    run_islands(c, w, islands, &done);
     for (auto& d : done)
-      for (auto& a : d) covered.push_back(std::move(a));
+      for (auto& a : d) st.covered.push_back(std::move(a));
+    const double t_workers = cov_now();
+    st.t_workers += t_workers - t_islands;
+    if (!last) {
+      if (getenv("BG_COVERAGE_TIMING"))
+        fprintf(stderr, "bg_coverage_feed: %zu islands of this stretch in %.3f s (%zu sections stay open)\n", islands.size(), t_workers - t_enter, st.open.size());
+      return BG_OK;
+    }
+    std::unique_ptr<bg_trace_result> res(new bg_trace_result);
+    memset(&res->stats, 0, sizeof(res->stats));
+    std::vector<bg_trace_assembly_rec> covered = std::move(st.covered);
     std::stable_sort(covered.begin(), covered.end(), bg::canon_assembly_less);
     const double t_sorted = cov_now();
     std::vector<bg_trace_assembly_rec> passed;
@@ -995,24 +1049,33 @@ extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64
     const double t_geno = cov_now();
     if (o.rvg_exclude) rvg_exclude_all(o, std::move(passed), &res->a);  // pipeline.cpp:102-104
     else res->a = std::move(passed);
-    if (getenv("BG_COVERAGE_TIMING")) {
-      uint64_t rounds = 0;
-      for (auto& b : batchers) rounds += b->launches;
-      fprintf(stderr, "bg_coverage_run: %zu islands in %zu groups: scaffold + islands %.3f s, workers %.3f s (%llu rounds), collect + sort %.3f s, "
-                      "genotype %.3f s, rvg_exclude %.3f s\n", islands.size(), n_groups, t_islands - t_enter, t_workers - t_islands,
-              (unsigned long long)rounds, t_sorted - t_workers, t_geno - t_sorted, cov_now() - t_geno);
-    }
-    for (auto& b : batchers) {
-      res->stats.device_rounds += b->launches;
-      res->stats.device_queries += b->steps;
-    }
-    res->stats.traces = islands.size();
+    if (getenv("BG_COVERAGE_TIMING"))
+      fprintf(stderr, "bg_coverage_run: %llu islands: scaffold + islands of the last stretch %.3f s, workers %.3f s over all stretches (%llu rounds), "
+                      "collect + sort %.3f s, genotype %.3f s, rvg_exclude %.3f s\n", (unsigned long long)st.islands, t_islands - t_enter, st.t_workers,
+              (unsigned long long)st.rounds, t_sorted - t_workers, t_geno - t_sorted, cov_now() - t_geno);
+    res->stats.device_rounds += st.rounds;
+    res->stats.device_queries += st.steps;
+    res->stats.traces = st.islands;
+    st = bg_coverage::Stream();
+    *out = res.release();
   } catch (const CheckFailed& f) {
+    st = bg_coverage::Stream();
     set_error("bg_assemblies_coverage: %s", f.what.c_str());
     return BG_EINVAL;
   }
-  *out = res.release();
   return BG_OK;
+}
+
+extern "C" void bg_coverage_discard(bg_coverage* c) {
+  if (c) c->stream = bg_coverage::Stream();
+}
+
+extern "C" int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64_t n_extents, const int64_t* ext_offset,
+                               const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos,
+                               const bg_coverage_options* options, int genotype_filter, bg_trace_result** out) {
+  if (!c || !in || !out) { set_error("bg_assemblies_coverage: null argument"); return BG_EINVAL; }
+  bg_coverage_discard(c);
+  return bg_coverage_feed(c, in, n_extents, ext_offset, ext_seq, ext_len, end_pos, options, genotype_filter, 1, out);
 }
 
 extern "C" int bg_trace_result_coverage(const bg_trace_result* r, uint64_t i, bg_assembly_coverage* out) {

@@ -307,17 +307,23 @@ def process_assemblies(assemblies, extents, end_pos=None, options=None, steps=ST
             L.bg_trace_result_free(out)
 
 
-def process_assemblies_streamed(batches, extents, end_pos=None, options=None, steps=STEP_PIPELINE):
+def process_assemblies_streamed(batches, extents, end_pos=None, options=None, steps=STEP_PIPELINE, release_early=None, take=False):
     """bg_pipeline_open / feed / finish: `batches` = [(assemblies, mark), ...] fed in order (the mark: no later assembly starts
     before it).  -> ([TraceAssembly] as process_assemblies gives them for all batches together, None), or (None, k) when batch k
-    held an assembly behind a mark already given (the caller then runs process_assemblies over everything)."""
+    held an assembly behind a mark already given, or (release_early = a margin in bases: bg_pipeline_release_early) moved a
+    variant to before what the normalizer had let go -- k = len(batches) when the finish found that; the caller then runs
+    process_assemblies over everything.  take: what has left the steps is taken after every batch (bg_pipeline_take) and put
+    together here; the third value returned is then how many assemblies had left before the finish."""
     L = capi.lib()
     n, offs, ptrs, lens, end_pos, _keep = _extent_arrays(extents, end_pos)
     opt = options if options is not None else TraceOptions()
     pl = C.c_void_p()
     capi.check(L.bg_pipeline_open(n, offs, ptrs, lens, end_pos, C.byref(opt), int(steps), C.byref(pl)))
     out = C.c_void_p()
+    taken = []
     try:
+        if release_early is not None:
+            capi.check(L.bg_pipeline_release_early(pl, int(release_early)))
         for k, (asms, mark) in enumerate(batches):
             src = _make_result(asms)
             try:
@@ -325,11 +331,21 @@ def process_assemblies_streamed(batches, extents, end_pos=None, options=None, st
                 ins = (C.c_void_p * 1)(src)
                 capi.check(L.bg_pipeline_feed(pl, ins, 1, int(mark), C.byref(behind)))
                 if behind.value:
-                    return None, k
+                    return (None, k, len(taken)) if take else (None, k)
             finally:
                 L.bg_trace_result_free(src)
+            if take:
+                part = C.c_void_p()
+                capi.check(L.bg_pipeline_take(pl, C.byref(part)))
+                try:
+                    taken += _read_result(part)
+                finally:
+                    L.bg_trace_result_free(part)
         capi.check(L.bg_pipeline_finish(pl, C.byref(out)))
-        return _read_result(out), None
+        if not out:
+            return (None, len(batches), len(taken)) if take else (None, len(batches))
+        res = taken + _read_result(out)
+        return (res, None, len(taken)) if take else (res, None)
     finally:
         L.bg_pipeline_close(pl)
         if out:

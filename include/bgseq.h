@@ -600,6 +600,14 @@ typedef struct bg_pipeline bg_pipeline;
 int bg_pipeline_open(uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq, const uint64_t* ext_len,
                      int64_t end_pos, const bg_trace_options* options /* NULL = defaults */, uint32_t steps, bg_pipeline** out);
 int bg_pipeline_feed(bg_pipeline* p, const bg_trace_result* const* in, uint32_t n_in, int64_t mark, int* behind);
+/* what has left the steps since the last take (or the open), as a result of its own; bg_pipeline_finish hands out the rest */
+int bg_pipeline_take(bg_pipeline* p, bg_trace_result** out);
+uint64_t bg_pipeline_ready(const bg_pipeline* p);  /* how many assemblies a take would hand out now */
+/* The reference's normalizer holds an extent's variants until the extent is through (a variant may move left through a repeat of
+ * any length): a chromosome in one extent leaves the steps only at the finish.  With a margin (before the first feed) what lies
+ * more than `margin` bases before the variant coming in leaves the normalizer at once; a later variant that moves to before
+ * that breaks the promise like an input behind a mark: bg_pipeline_feed sets *behind, bg_pipeline_finish hands out NULL. */
+int bg_pipeline_release_early(bg_pipeline* p, int64_t margin);
 int bg_pipeline_finish(bg_pipeline* p, bg_trace_result** out);
 void bg_pipeline_close(bg_pipeline* p);
 /* Hand-made input for the steps (the reference's unit tests build assemblies by hand): an empty result, and a copy
@@ -637,6 +645,15 @@ int bg_coverage_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, bg_
 int bg_coverage_run(bg_coverage* c, const bg_trace_result* in, uint64_t n_extents, const int64_t* ext_offset,
                     const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos,
                     const bg_coverage_options* options /* NULL = defaults */, int genotype_filter, bg_trace_result** out);
+/* A scaffold's sections in stretches, in order (bgbinary discovery: as bg_pipeline_take hands them out behind the tracers):
+ * the islands a stretch completes -- runs of variant sections further than a read's length from the next (calc_coverage.cpp:
+ * 345-360) -- are covered at once, the open one waits.  in may be NULL (nothing new).  last != 0: the scaffold is through;
+ * the open island, then sort, genotype filter and rvg_exclude over everything, *out = what bg_coverage_run would give for the
+ * concatenation.  One scaffold at a time per session; bg_coverage_discard forgets a scaffold that will not be finished. */
+int bg_coverage_feed(bg_coverage* c, const bg_trace_result* in, uint64_t n_extents, const int64_t* ext_offset,
+                     const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos, const bg_coverage_options* options,
+                     int genotype_filter, int last, bg_trace_result** out);
+void bg_coverage_discard(bg_coverage* c);
 void bg_coverage_close(bg_coverage* c);
 typedef struct bg_assembly_coverage {  /* assembly::coverage ... genotype_quality (assemble.h:330-370) */
   const int32_t *coverage, *pair_coverage;

@@ -323,7 +323,7 @@ def test_pipeline_fed_piece_by_piece_equals_the_whole(seed):
     rng = random.Random(777 + seed)
     sets = [BT.STEP_PIPELINE, BT.STEP_SORT | BT.STEP_TRIM_REF | BT.STEP_DEDUP, BT.STEP_SORT | BT.STEP_TRIM_REF | BT.STEP_DEDUP | BT.STEP_ALIGN,
             BT.STEP_SORT]
-    n_out = n_broken = 0
+    n_out = n_broken = n_early = n_early_broken = 0
     for _ in range(60):
         parts, sc, asms, kw = random_case(rng)
         kw = dict(kw, output_ml_features=rng.choice([0, 1]))
@@ -355,6 +355,16 @@ def test_pipeline_fed_piece_by_piece_equals_the_whole(seed):
             got, broken = BT.process_assemblies_streamed(list(zip(batches, marks)), parts, options=opts(**kw), steps=steps)
             assert broken is None and [full_key(a) for a in got] == want, (seed, steps, kw)
             n_out += len(got)
+            # the normalizer letting go early, what has left taken after every piece: the same assemblies, or a break that is said
+            for margin in (0, 3, 25, 400):
+                got, broken, before = BT.process_assemblies_streamed(list(zip(batches, marks)), parts, options=opts(**kw), steps=steps,
+                                                                     release_early=margin, take=True)
+                if broken is None:
+                    assert [full_key(a) for a in got] == want, (seed, steps, kw, margin)
+                    n_early += before
+                else:
+                    assert got is None and steps & BT.STEP_NORMALIZE
+                    n_early_broken += 1
         # marks that promise too much: the first piece that lies behind one says so
         if len(batches) > 1 and reach:
             greedy = [c for c in cuts[1:]] + [hi + reach]
@@ -365,7 +375,7 @@ def test_pipeline_fed_piece_by_piece_equals_the_whole(seed):
             else:
                 assert got is None and broken == late
                 n_broken += 1
-    assert n_out > 300 and n_broken > 0
+    assert n_out > 300 and n_broken > 0 and n_early > 100, (n_out, n_broken, n_early, n_early_broken)
     with pytest.raises(Exception):  # the anchor_dropper works on the tracers' own order: not a step of the fed pipeline
         BT.process_assemblies_streamed([([], 0)], [(0, tseq("abc"))], steps=BT.STEP_ANCHOR_DROP | BT.STEP_SORT)
 

@@ -108,6 +108,10 @@ def test_the_shortcuts_change_nothing(sample):
         "one_work_item_at_a_time": {"BG_TRACER_ASYNC": "0"},
         "one_scaffold_at_a_time": {"BG_DISCOVERY_OVERLAP": "0"},
         "pipeline_after_the_tracers": {"BG_DISCOVERY_STREAM": "0"},
+        "coverage_behind_the_tracers": {"BG_DISCOVERY_STREAM": "coverage", "BG_DISCOVERY_COV_BATCH": "50"},
+        "coverage_behind_the_tracers_in_one_stretch": {"BG_DISCOVERY_STREAM": "coverage"},
+        "normalizer_keeps_its_extents": {"BG_DISCOVERY_STREAM": "coverage", "BG_DISCOVERY_EARLY": "-1", "BG_DISCOVERY_COV_BATCH": "50"},
+        "normalizer_lets_go_at_once": {"BG_DISCOVERY_STREAM": "coverage", "BG_DISCOVERY_EARLY": "0", "BG_DISCOVERY_COV_BATCH": "50"},
         "pipeline_marks_that_break": {"BG_DISCOVERY_REACH": "-50000"},
         "pipeline_marks_at_the_pieces": {"BG_DISCOVERY_REACH": "0"},
         "pipeline_marks_far_back": {"BG_DISCOVERY_REACH": "10000000"},
@@ -123,7 +127,7 @@ def test_the_shortcuts_change_nothing(sample):
         got, err = _discover(d, name, env)
         assert got == base, name
         # (the broken marks are said and the pipeline runs over everything; the default's marks hold)
-        assert ("further before it than" in err) == (name == "pipeline_marks_that_break"), name
+        assert ("further before it than" in err) == (name in ("pipeline_marks_that_break", "normalizer_lets_go_at_once")), name
     for threads in ("1", "3"):
         got, _ = _discover(d, "threads" + threads, extra=["--threads", threads])
         assert got == base, "threads " + threads

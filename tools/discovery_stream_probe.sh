@@ -1,12 +1,12 @@
 #!/bin/bash
-# Runs on the GPU box: `bgbinary discovery` on the chr20-shaped sample with the pipeline fed piece by piece behind the tracers
-# (the default) and with BG_DISCOVERY_STREAM=0 (every push, then every pop, then the pipeline): wall, stages, one VCF.
-# Usage: tools/discovery_stream_probe.sh [genome length] [sessions]
+# Runs on the GPU box: `bgbinary discovery` on the chr20-shaped sample with the pipeline fed behind the tracers (the default), with the coverage step fed as well
+# (BG_DISCOVERY_STREAM=coverage), with neither (=0), and over sizes of the coverage
+# stretches: wall, stages, one VCF.  Usage: tools/discovery_stream_probe.sh [genome length] [sessions]
 ROOT=$(pwd)
 python3 tools/discovery_bench.py --genome-len ${1:-64444167} --keep --threads 16 > /dev/null 2>&1
 D=$(ls -d /dev/shm/bg_disc_* | tail -1)
 first=""
-for e in BG_DISCOVERY_STREAM=0 BG_X=1 BG_DISCOVERY_STREAM=0 BG_X=1 BG_X=2; do
+for e in BG_DISCOVERY_STREAM=0 BG_X=1 BG_DISCOVERY_STREAM=coverage "BG_DISCOVERY_STREAM=coverage BG_DISCOVERY_COV_BATCH=40000" BG_DISCOVERY_STREAM=0 BG_X=1 BG_DISCOVERY_STREAM=coverage BG_X=2; do
   TIMEFORMAT="%R s wall"
   { time env $e "$ROOT/biograph_amd/bgbinary" discovery --in "$D/s.bg" --ref "$D/ref.fa" --out "$D/p.vcf" --threads ${2:-16} -f > /dev/null 2> "$D/p.log" ; } 2> "$D/t.log"
   rc=$?
