@@ -1369,6 +1369,12 @@ struct ExtSet {
   std::vector<uint64_t> hashes;
   int64_t end_pos = -1;
   std::vector<Extent> ext;
+  // where the caller's copy lay and what a sample of it looked like (session_extents' quick way)
+  std::vector<const char*> src_ptr;
+  std::vector<uint64_t> src_len;
+  std::vector<int64_t> src_off;
+  uint64_t sample = 0;
+  std::atomic<bool> src_noted{false};  // (the set is shared between sessions: written once under g_ext_mu, read after this says so)
   const std::vector<Extent>& rc() {  // scaffold::rev_comp (scaffold.cpp:163-175)
     std::call_once(rc_once_, [&] {
       for (auto it = ext.rbegin(); it != ext.rend(); ++it)
@@ -1384,8 +1390,37 @@ std::mutex g_ext_mu;
 std::shared_ptr<ExtSet> g_ext_last;  // the scaffold the process is working on
 
 // The session's extents for this call: its own from the last call, the process's, or a fresh checked copy.
+// 32 bytes out of every 4096 of the extents, their ends whole
+static uint64_t extents_sample(uint64_t n_extents, const char* const* ext_seq, const uint64_t* ext_len) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  auto mix = [&](const char* p, uint64_t n) {
+    uint64_t j = 0;
+    for (; j + 8 <= n; j += 8) { uint64_t x; memcpy(&x, p + j, 8); h = (h ^ x) * 0x100000001b3ull; h ^= h >> 29; }
+    for (; j < n; ++j) h = (h ^ uint64_t(uint8_t(p[j]))) * 0x100000001b3ull;
+  };
+  for (uint64_t i = 0; i < n_extents; ++i) {
+    const uint64_t n = ext_len[i];
+    if (n <= 8192) { mix(ext_seq[i], n); continue; }
+    mix(ext_seq[i], 4096);
+    for (uint64_t j = 4096; j + 4096 < n; j += 4096) mix(ext_seq[i] + j, 32);
+    mix(ext_seq[i] + n - 4096, 4096);
+  }
+  return h;
+}
+
 int session_extents(std::shared_ptr<ExtSet>* mine, const char* who, uint64_t n_extents, const int64_t* ext_offset,
                     const char* const* ext_seq, const uint64_t* ext_len, int64_t end_pos) {
+  // The quick way (every work item of a scaffold passes the same extents: hashing a chromosome is 14-18 ms a call, twice a work
+  // item): the caller's extents lie where the session's copy was made from, as long, at the same offsets, and a sample of their
+  // bytes -- 32 of every 4096, the ends whole -- is what it was.  The extents a session is given must not change while it uses
+  // them; anything else about them is checked in full below, as before.
+  if (*mine && (*mine)->src_noted.load(std::memory_order_acquire) && (*mine)->end_pos == end_pos && (*mine)->src_ptr.size() == n_extents) {
+    const ExtSet& e = **mine;
+    bool same_place = true;
+    for (uint64_t i = 0; i < n_extents && same_place; ++i)
+      same_place = e.src_ptr[i] == ext_seq[i] && e.src_len[i] == ext_len[i] && e.src_off[i] == ext_offset[i];
+    if (same_place && e.sample == extents_sample(n_extents, ext_seq, ext_len)) return BG_OK;
+  }
   std::vector<uint64_t> hashes(n_extents);
   int64_t calc_end = 0, prev_end = INT64_MIN;
   for (uint64_t i = 0; i < n_extents; ++i) {
@@ -1412,10 +1447,22 @@ int session_extents(std::shared_ptr<ExtSet>* mine, const char* who, uint64_t n_e
   }
   if (end_pos < calc_end) { set_error("%s: end_pos lies before the end of the last extent", who); return BG_EINVAL; }
   auto same = [&](const std::shared_ptr<ExtSet>& e) { return e && e->end_pos == end_pos && e->hashes == hashes; };
-  if (same(*mine)) return BG_OK;
-  {
+  // (the sets are shared between sessions: where THIS caller's copy lies is noted under the lock, and only a session whose
+  // caller passes the same place takes the quick way)
+  auto note_source = [&](ExtSet* e) {
     std::lock_guard<std::mutex> l(g_ext_mu);
-    if (same(g_ext_last)) { *mine = g_ext_last; return BG_OK; }
+    if (!e->src_noted.load(std::memory_order_relaxed) && n_extents) {
+      e->src_ptr.assign(ext_seq, ext_seq + n_extents);
+      e->src_len.assign(ext_len, ext_len + n_extents);
+      e->src_off.assign(ext_offset, ext_offset + n_extents);
+      e->sample = extents_sample(n_extents, ext_seq, ext_len);
+      e->src_noted.store(true, std::memory_order_release);
+    }
+  };
+  if (same(*mine)) { note_source(mine->get()); return BG_OK; }
+  {
+    std::unique_lock<std::mutex> l(g_ext_mu);
+    if (same(g_ext_last)) { *mine = g_ext_last; l.unlock(); note_source(mine->get()); return BG_OK; }
   }
   std::shared_ptr<ExtSet> fresh(new ExtSet);
   for (uint64_t i = 0; i < n_extents; ++i) {
@@ -1430,6 +1477,7 @@ int session_extents(std::shared_ptr<ExtSet>* mine, const char* who, uint64_t n_e
     else g_ext_last = fresh;
   }
   *mine = fresh;
+  note_source(mine->get());
   return BG_OK;
 }
 
@@ -1745,6 +1793,9 @@ struct PopEntry {  // pop_tracer::entry (pop_tracer.h:58-84)
   int64_t left_offset = 0, right_offset = 0, start_limit = 0, end_limit = 0;
   TRange orig_r, popped_r;
   std::string seq;
+  // seen_read_ids = the ids the entry was made with -- ids_n words at ids_at of the pop tracer's pool: a piece has 350 000 fronts and
+  // a few hundred of them ever meet a popper, a vector each was two allocations a front -- followed by what it has gathered since
+  uint32_t ids_at = 0, ids_n = 0;
   std::vector<uint32_t> seen_read_ids;
   // where this popper stands in the passes the device ran ahead (PopTracer::pop_pass): its row in the batch, or -1 once a merge
   // has given it another range
@@ -1759,6 +1810,17 @@ struct PopTracer {
   const std::vector<Extent>& sc_rc;  // ... and reversed: entries face right while push_front_drop runs through it
   int64_t end_pos;
   std::deque<PopEntry> store;     // stable addresses
+  std::vector<uint32_t> id_pool;  // the ids the entries were made with (PopEntry::ids_at)
+  void made_with(PopEntry* e, const uint32_t* first, const uint32_t* last) {
+    e->ids_at = uint32_t(id_pool.size());
+    e->ids_n = uint32_t(last - first);
+    id_pool.insert(id_pool.end(), first, last);
+  }
+  template <class V>
+  void append_ids(V* to, const PopEntry& e) const {
+    to->insert(to->end(), id_pool.begin() + e.ids_at, id_pool.begin() + e.ids_at + e.ids_n);
+    to->insert(to->end(), e.seen_read_ids.begin(), e.seen_read_ids.end());
+  }
   struct Front { uint64_t b; uint32_t s; uint32_t seq; PopEntry* e; bool erased; };
   std::vector<Front> fronts;      // insertion order until sort_fronts()
   std::vector<PopEntry*> poppers;
@@ -1905,7 +1967,7 @@ struct PopTracer {
         e->end_limit = it.rd.limit;
         e->orig_r = e->popped_r = ranges[k];
         // add_entry_reads (:97-119): the reverse complements of the first max_pairs_per_read prefix reads
-        e->seen_read_ids.insert(e->seen_read_ids.end(), pr.rc.begin() + pr.first[k], pr.rc.begin() + pr.first[k + 1]);
+        made_with(e, pr.rc.data() + pr.first[k], pr.rc.data() + pr.first[k + 1]);
         ++k;
       }
       fronts.push_back(Front{e->orig_r.b, e->orig_r.s, uint32_t(fronts.size()), e, false});
@@ -2182,7 +2244,7 @@ struct PopTracer {
       if (wide[i].empty()) {
         const uint32_t p0 = pr.first[i], p1 = pr.first[i + 1];
         const uint32_t n_seen = std::min<uint32_t>(p1 - p0, uint32_t(w.o.max_pairs_per_read));
-        e->seen_read_ids.insert(e->seen_read_ids.end(), pr.rc.begin() + p0, pr.rc.begin() + p0 + n_seen);
+        made_with(e, pr.rc.data() + p0, pr.rc.data() + p0 + n_seen);
         items.push_back(Item{e, PendingRead{0, 0, 0}});
         unsigned read_count = 0;
         for (uint32_t p = p0; p < p1; ++p) {
@@ -2393,7 +2455,7 @@ struct PopTracer {
           p->popped_r = front.popped_r;
           p->ahead_slot = -1;  // (the passes run ahead were for the old range)
           p->seq += front.seq;
-          p->seen_read_ids.insert(p->seen_read_ids.end(), front.seen_read_ids.begin(), front.seen_read_ids.end());
+          append_ids(&p->seen_read_ids, front);
           if (front.has_right) {
             p->has_right = true;
             p->right_offset = front.right_offset;
@@ -2416,7 +2478,7 @@ struct PopTracer {
     a.left_offset = p.left_offset;
     a.right_offset = p.right_offset;
     a.seq = p.seq;
-    a.rc_read_ids = p.seen_read_ids;
+    append_ids(&a.rc_read_ids, p);
     std::sort(a.rc_read_ids.begin(), a.rc_read_ids.end());
     a.rc_read_ids.erase(std::unique(a.rc_read_ids.begin(), a.rc_read_ids.end()), a.rc_read_ids.end());
     if (a.left_offset == a.right_offset && a.seq.empty()) return;
