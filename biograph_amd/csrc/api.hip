@@ -724,7 +724,24 @@ extern "C" int bg_seqset_open(bg_ctx* ctx, const char* path, bg_seqset** out) {
   if (!ctx || !path || !out) { set_error("bg_seqset_open: null argument"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));
   std::map<std::string, std::string> parts;
-  BG_TRY(spiral_zip_read(path, &parts));
+  // (the large members stay in the mapped file: they go up from there)
+  std::map<std::string, std::pair<const char*, uint64_t>> big;
+  std::shared_ptr<void> mapping;
+  BG_TRY(spiral_zip_read_views(path, &parts, &big, &mapping));
+  auto has = [&](const std::string& name) { return big.count(name) || parts.count(name); };
+  auto bytes_of = [&](const std::string& name) -> std::pair<const char*, uint64_t> {
+    auto b = big.find(name);
+    if (b != big.end()) return b->second;
+    auto s = parts.find(name);
+    if (s != parts.end()) return std::make_pair(s->second.data(), uint64_t(s->second.size()));
+    return std::make_pair(static_cast<const char*>(nullptr), uint64_t(0));
+  };
+  // (measured: the large members through the pinned double buffer instead of the driver's staging of pageable memory -- the same
+  // 0.14-0.18 s for a chr20-sized seqset; the uploads are not what the open waits for)
+  auto up = [&](void* d_dst, const char* src, uint64_t bytes) -> int {
+    if (bytes) BG_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return BG_OK;
+  };
   uint64_t n = 0;
   if (!parts.count("seqset.json") || !json_u64(parts["seqset.json"], "num_entries", &n)) {
     set_error("%s: no seqset.json", path);
@@ -743,21 +760,22 @@ extern "C" int bg_seqset_open(bg_ctx* ctx, const char* path, bg_seqset** out) {
   for (int which = 0; which < 2; ++which) {
     std::string dir = which ? "shared" : "entry_sizes";
     uint8_t* dst = which ? ss->shared.p : ss->sizes.p;
-    if (parts.count(dir)) {  // old layout: raw uint8 (int_map_interface.cpp detect_subpart_or_uint8_membuf)
-      if (parts[dir].size() != n) { set_error("%s: bad %s size", path, dir.c_str()); return BG_EIO; }
-      if (n) BG_HIP(hipMemcpyAsync(dst, parts[dir].data(), n, hipMemcpyHostToDevice, ctx->stream));
+    if (has(dir)) {  // old layout: raw uint8 (int_map_interface.cpp detect_subpart_or_uint8_membuf)
+      const auto raw = bytes_of(dir);
+      if (raw.second != n) { set_error("%s: bad %s size", path, dir.c_str()); return BG_EIO; }
+      BG_TRY(up(dst, raw.first, n));
     } else {
       const std::string& md = parts[dir + "/packed_varbit_vector.json"];
-      const std::string& el = parts[dir + "/elements"];
+      const auto el = bytes_of(dir + "/elements");
       uint64_t bpv = 0, cnt = 0;
       if (!json_u64(md, "bits_per_value", &bpv) || !json_u64(md, "element_count", &cnt) || cnt != n || bpv > 8 ||
-          el.size() != ((n * bpv + 63) / 64) * 8) {
+          el.second != ((n * bpv + 63) / 64) * 8) {
         set_error("%s: unsupported %s encoding", path, dir.c_str());
         return BG_EIO;
       }
       DevBuf<uint64_t> packed;
-      BG_TRY(packed.alloc(ctx, el.size() / 8 + 1));
-      if (!el.empty()) BG_HIP(hipMemcpyAsync(packed.p, el.data(), el.size(), hipMemcpyHostToDevice, ctx->stream));
+      BG_TRY(packed.alloc(ctx, el.second / 8 + 1));
+      BG_TRY(up(packed.p, el.first, el.second));
       if (n) {
         k_unpack_varbit<<<cdiv(n, 256), 256, 0, ctx->stream>>>(packed.p, n, int(bpv), dst);
         BG_LAUNCH_CHECK();
@@ -768,9 +786,10 @@ extern "C" int bg_seqset_open(bg_ctx* ctx, const char* path, bg_seqset** out) {
   uint64_t nwords = (n + 63) / 64;
   for (int b = 0; b < 4; ++b) {
     std::string name = std::string("prev_") + "ACGT"[b] + "/bits";
-    if (!parts.count(name) || parts[name].size() != nwords * 8) { set_error("%s: bad %s", path, name.c_str()); return BG_EIO; }
+    const auto bits = bytes_of(name);
+    if (!has(name) || bits.second != nwords * 8) { set_error("%s: bad %s", path, name.c_str()); return BG_EIO; }
     BG_TRY(ss->bits[b].alloc(ctx, nwords));
-    if (nwords) BG_HIP(hipMemcpyAsync(ss->bits[b].p, parts[name].data(), nwords * 8, hipMemcpyHostToDevice, ctx->stream));
+    BG_TRY(up(ss->bits[b].p, bits.first, nwords * 8));
   }
   BG_HIP(hipStreamSynchronize(ctx->stream));
   // max_len from sizes (on the device: the bytes do not come back for it)
@@ -792,7 +811,11 @@ extern "C" int bg_seqset_open(bg_ctx* ctx, const char* path, bg_seqset** out) {
     std::string name = std::string("prev_") + "ACGT"[b] + "/accum";
     std::string mine;
     BG_TRY(part_bytes(ctx, ss.get(), name, &mine));
-    if (parts.count(name) && parts[name] != mine) { set_error("%s: %s does not match its bits", path, name.c_str()); return BG_EIO; }
+    const auto stored = bytes_of(name);
+    if (has(name) && (stored.second != mine.size() || memcmp(stored.first, mine.data(), mine.size()) != 0)) {
+      set_error("%s: %s does not match its bits", path, name.c_str());
+      return BG_EIO;
+    }
   }
   *out = ss.release();
   return BG_OK;

@@ -476,6 +476,8 @@ struct ZipPart { std::string name; std::string data; bool raw_crc0; uint64_t hol
 int spiral_zip_write(const char* path, const std::vector<ZipPart>& parts);
 int spiral_zip_write_layout(const char* path, const std::vector<ZipPart>& parts, std::vector<uint64_t>* data_offsets);
 int spiral_zip_read(const char* path, std::map<std::string, std::string>* parts);
+int spiral_zip_read_views(const char* path, std::map<std::string, std::string>* parts,
+                          std::map<std::string, std::pair<const char*, uint64_t>>* big, std::shared_ptr<void>* keep);
 std::string make_uuid();
 int sha1_file_hex(const char* path, char* hex41);
 }  // namespace bg
