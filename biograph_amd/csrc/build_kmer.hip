@@ -714,6 +714,9 @@ static int pack_reads_impl(bg_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_
   r->total_bases = h_offs[1] - h_offs[0];
   r->W = int((r->max_len + 31) / 32);
   if (r->W == 0) r->W = 1;
+  // (measured: W = 8 for 150-base reads -- every read, oriented read and row a 64-byte line of its own: the kernels that fetch single
+  // rows got SLOWER with it, k_items_tie_small 2.89 -> 3.19 ms, k_prev_list_items 3.35 -> 3.70, k_cover_count_sm 5.05 -> 5.13, and
+  // the streaming ones pay the 1.6 x: 48.6 -> 51.6 ms for the step)
   BG_TRY(r->words.alloc(ctx, n * r->W));
   BG_TRY(r->nmask.alloc(ctx, n * r->W));
   if (n) {
