@@ -335,10 +335,23 @@ int suffix_rows_from_counts(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc,
 // once through the pinned double buffer and shared by everybody who asks for the same readmap (readmap_tables keeps a weak
 // reference per readmap; bg_readmap_free drops it).  The d_* copies (plain hipMalloc: they outlive any context) serve
 // k_trace_simple.
+// (vectors whose resize leaves the new elements as they are: a download fills them; zeroing 270 MB first was a single thread's
+// page faults and stores before the copy threads wrote the same pages)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  NoInitAlloc() = default;
+  template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(p)) U;
+    else ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+  }
+};
 struct ReadmapTables {
-  std::vector<uint8_t> is_forward, read_len;
-  std::vector<uint32_t> mate_loop, word_rank, group_start;
-  std::vector<uint64_t> has_reads;
+  std::vector<uint8_t, NoInitAlloc<uint8_t>> is_forward, read_len;
+  std::vector<uint32_t, NoInitAlloc<uint32_t>> mate_loop, word_rank, group_start;
+  std::vector<uint64_t, NoInitAlloc<uint64_t>> has_reads;
   uint32_t min_read_len = 0;
   uint32_t *d_word_rank = nullptr, *d_group_start = nullptr, *d_mate_loop = nullptr;
   uint8_t* d_is_forward = nullptr;

@@ -1532,16 +1532,23 @@ static int discovery_push(Args& a, const std::vector<std::pair<std::string, std:
   });
   std::vector<bg_ctx*> wctx(size_t(n_threads), nullptr);
   std::vector<bg_tracer*> tracers(size_t(n_threads), nullptr);
-  for (int t = 0; t < n_threads; ++t) {
-    wctx[size_t(t)] = t == 0 ? ctx : nullptr;
-    if (t) check(bg_ctx_create_own_stream(env.device, &wctx[size_t(t)]), "bg_ctx_create_own_stream");
-    if (t == 0)
-      check(bg_tracer_open(wctx[0], ss, rm, static_cast<const uint8_t*>(d_map), &opt, &tracers[0]), "bg_tracer_open");
-    else
-      check(bg_tracer_clone(tracers[0], wctx[size_t(t)], &tracers[size_t(t)]), "bg_tracer_clone");
+  wctx[0] = ctx;
+  const double t_first0 = now_s();
+  check(bg_tracer_open(wctx[0], ss, rm, static_cast<const uint8_t*>(d_map), &opt, &tracers[0]), "bg_tracer_open");
+  const double t_first = now_s() - t_first0;
+  {  // the further sessions (a context, a stream, page-locked buffers each) side by side
+    std::vector<std::thread> openers;
+    for (int t = 1; t < n_threads; ++t)
+      openers.emplace_back([&, t] {
+        check(bg_ctx_create_own_stream(env.device, &wctx[size_t(t)]), "bg_ctx_create_own_stream");
+        check(bg_tracer_clone(tracers[0], wctx[size_t(t)], &tracers[size_t(t)]), "bg_tracer_clone");
+      });
+    for (auto& th : openers) th.join();
   }
+  const double t_clones = now_s() - t_first0 - t_first;
   cov_open.join();
   const double t_open = now_s() - t_open0;
+  if (getenv("BG_TRACER_TIMING")) fprintf(stderr, "discovery: first session %.3f s, the other %d %.3f s, coverage session through %.3f s after the start of all\n", t_first, n_threads - 1, t_clones, t_open);
   time_t now = time(nullptr);
   char date[16];
   strftime(date, sizeof date, "%Y%m%d", localtime(&now));

@@ -143,8 +143,16 @@ std::string rev_comp_str(const std::string& s) {
 
 namespace {
 
+// (n bytes that nobody fills before the download does: a vector's zeros were 280 MB of page faults and stores on one thread
+// before the copy threads wrote the same pages again)
+struct RawBytes {
+  std::unique_ptr<uint8_t[]> p;
+  void resize(uint64_t n) { p.reset(n ? new uint8_t[n] : nullptr); }
+  uint8_t* data() { return p.get(); }
+  const uint8_t* data() const { return p.get(); }
+};
 struct HostTables {
-  std::vector<uint8_t> sizes, ref_map;
+  RawBytes sizes, ref_map;
   std::shared_ptr<const ReadmapTables> rt;  // the readmap's narrow columns, host and device (bg_internal.h): shared with calc_coverage
 };
 
