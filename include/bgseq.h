@@ -519,6 +519,9 @@ typedef struct bg_tracer bg_tracer;
  * built on the device from it. */
 int bg_tracer_open(bg_ctx* ctx, const bg_seqset* ss, const bg_readmap* rm, const uint8_t* d_ref_map,
                    const bg_trace_options* options /* NULL = defaults */, bg_tracer** out);
+/* The extents a session is given must not change while it uses them: a session keeps its own checked copy of the scaffold
+ * of its last work item, and a call that passes the same pointers, lengths and offsets again is taken to pass that
+ * scaffold (a sample of the bytes is compared; anything else about the extents is checked in full). */
 int bg_tracer_trace(bg_tracer* t, uint64_t n_extents, const int64_t* ext_offset, const char* const* ext_seq,
                     const uint64_t* ext_len, int64_t end_pos, int64_t start_offset, int64_t limit_offset, int rev_comp,
                     int pair_count, bg_trace_result** out);
