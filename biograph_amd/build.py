@@ -16,7 +16,7 @@ OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libbgseq.so")
 CLI = os.path.join(HERE, "bgbinary")
 SOURCES = ["prims.hip", "build_kmer.hip", "kmer_skm.hip", "build_seqset.hip", "items_build.hip", "walk.hip", "shard.hip", "shard_cover.hip", "fastq.hip", "readmap.hip", "merge.hip", "comm.hip", "sharded.hip", "discover.cpp", "tracer.cpp", "align.cpp", "coverage.cpp", "refdir.cpp", "refbuild.cpp", "bwt.hip", "api.hip", "spiral_zip.cpp"]
-HEADERS = ["bg_internal.h", "comm.h", "bg_device_funcs.h", "compact.h", "arena.h", "assembly.h", "fiber.h", os.path.join("..", "..", "include", "bgseq.h")]
+HEADERS = ["bg_internal.h", "comm.h", "bg_device_funcs.h", "compact.h", "arena.h", "assembly.h", "fiber.h", "items_entries.h", os.path.join("..", "..", "include", "bgseq.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result",
          "-x", "hip"]
 

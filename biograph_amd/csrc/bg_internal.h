@@ -240,6 +240,8 @@ struct bg_seqset {
   // a build from items (items_build.hip): no key table yet -- every entry's first word and record (oriented read << 24 |
   // offset << 16 | ...), two words an entry, and the oriented reads the records point into; seqset_ensure_keys makes keys / pre2 from them the first time somebody needs them
   bg::DevBuf<uint64_t> erec, oreads;
+  bg::DevBuf<uint32_t> edir;  // ... and the prefix directory over the entries' first words (items_entries.h: ItEntries), while they are there
+  int edir_bases = 0;
   std::mutex keys_mutex;  // seqset_ensure_keys: the first keyed access writes an object the API hands out as const
 };
 

@@ -18,6 +18,7 @@
 // code has this shape.  BG_ITEMS_PROBE=1 runs the front half beside the build and reports times and bucket sizes.
 #include "bg_device_funcs.h"
 #include "bg_internal.h"
+#include "items_entries.h"
 #include "compact.h"
 
 #include <stdlib.h>
@@ -28,7 +29,6 @@
 
 namespace bg {
 
-struct __attribute__((aligned(16))) Item { uint64_t fw, id; };
 
 constexpr int IT_THREADS = 512;  // (256 / 512 / 1 024 threads over the same 2 048 items: the four partition kernels 3.49 / 3.32 / 3.46 ms)
 constexpr int IT_TILE = 2048;  // items staged in LDS: 32 KB
@@ -362,15 +362,6 @@ constexpr int IB_LOG2BINS = 11;
 constexpr int IB_BINS = 1 << IB_LOG2BINS;  // counting sort on the next bits, then ranks inside a bin by comparison
 constexpr int IB_BIN_MAX = 96;     // members of a bin beyond which the bucket is sorted by a bitonic network instead
 constexpr int IB_BIN_ROWS = 2048;  // ... and beyond which it is left to the rows machinery
-constexpr uint64_t kItLcpValid = 1ull << 63;
-constexpr int kItLcpShift = 55;
-constexpr uint64_t kItIdMask = (1ull << kItLcpShift) - 1;
-
-__device__ __forceinline__ uint64_t it_suffix_word(const uint64_t* __restrict__ s, int W, int j, int w) {  // word w of suffix j of a read
-  const int sq = (j >> 5) + w, sr = j & 31;
-  const uint64_t cur = sq < W ? s[sq] : 0, next = sq + 1 < W ? s[sq + 1] : 0;
-  return sr ? (cur << (2 * sr)) | (next >> (64 - 2 * sr)) : cur;
-}
 
 // status[bucket]: 0 done, 1 too many items (copied as they were: the caller's fall-back)
 // runs[]: every run of two or more equal first words, as (place of its first item) | (members, at most 65535) << 48;
@@ -1097,75 +1088,6 @@ __global__ __launch_bounds__(256) void k_items_list_rows(const Item* __restrict_
 }
 
 // ---- the list's tails searched through the entries' first words and, where those tie, through the reads (no key table)
-struct ItEntries {
-  const Item* ent;        // every entry's first word and its record
-  const uint8_t* sizes;
-  const uint64_t* owords;
-  const uint32_t* dir;
-  uint64_t n;
-  int W, bases;
-};
-// entry e against (key, kl) beyond the first word (equal): rest of the string through the read, then the length
-__device__ __forceinline__ int it_cmp_rest(const ItEntries& t, uint64_t e, const uint64_t* key, int kl) {
-  const uint64_t id = t.ent[e].id;
-  const uint64_t* s = t.owords + (id >> 24) * uint64_t(t.W);
-  const int j = int(id >> 16) & 255;
-  for (int w = 1; w < t.W; ++w) {
-    const uint64_t x = it_suffix_word(s, t.W, j, w);
-    if (x != key[w]) return x < key[w] ? -1 : 1;
-  }
-  const int el = t.sizes[e];
-  return el < kl ? -1 : (el > kl ? 1 : 0);
-}
-// first entry >= (key, kl) in (string, length) order.  *alone = the key's first word occurs in exactly one entry (which is then
-// returned without a look at the reads: when the key is at least a word long and the entries are closed under pop_front, that
-// entry is the one that extends it -- k_prev_bits_pre2's shortcut on one word instead of two)
-__device__ __forceinline__ uint64_t it_lower_bound(const ItEntries& t, const uint64_t* key, int kl, bool* alone) {
-  const uint32_t p = uint32_t(key[0] >> (64 - 2 * t.bases));
-  uint64_t a = t.dir[p], z = t.dir[p + 1];
-  const uint64_t hi = z;
-  while (a < z) {  // first entry whose first word is >= the key's
-    const uint64_t mid = (a + z) >> 1;
-    if (t.ent[mid].fw < key[0]) a = mid + 1; else z = mid;
-  }
-  uint64_t lo1 = a;
-  *alone = false;
-  if (lo1 >= hi || t.ent[lo1].fw != key[0]) return lo1;
-  uint64_t hi1 = lo1 + 1;  // the entries that share the first word lie side by side: a few (a repeat family: thousands)
-  while (hi1 < hi && hi1 < lo1 + 8 && t.ent[hi1].fw == key[0]) ++hi1;
-  if (hi1 == lo1 + 8 && hi1 < hi && t.ent[hi1].fw == key[0]) {
-    uint64_t a2 = hi1 + 1, z2 = hi;
-    while (a2 < z2) {  // first entry whose first word is greater
-      const uint64_t mid = (a2 + z2) >> 1;
-      if (t.ent[mid].fw <= key[0]) a2 = mid + 1; else z2 = mid;
-    }
-    hi1 = a2;
-  }
-  if (hi1 == lo1 + 1 && kl >= 32) { *alone = true; return lo1; }
-  while (lo1 < hi1) {
-    const uint64_t mid = (lo1 + hi1) >> 1;
-    if (it_cmp_rest(t, mid, key, kl) < 0) lo1 = mid + 1; else hi1 = mid;
-  }
-  return lo1;
-}
-// LCP of entry e with (key, kl), in bases
-__device__ __forceinline__ int it_entry_lcp(const ItEntries& t, uint64_t e, const uint64_t* key, int kl) {
-  const Item it = t.ent[e];
-  int l = lcp_word(it.fw, key[0]);
-  if (l == 32) {
-    const uint64_t id = it.id;
-    const uint64_t* s = t.owords + (id >> 24) * uint64_t(t.W);
-    const int j = int(id >> 16) & 255;
-    for (int w = 1; w < t.W; ++w) {
-      const int c = lcp_word(it_suffix_word(s, t.W, j, w), key[w]);
-      l += c;
-      if (c < 32) break;
-    }
-  }
-  const int el = t.sizes[e], m = el < kl ? el : kl;
-  return l < m ? l : m;
-}
-
 // k_prev_list's work (builder.cpp:85-108) for the items' list: item `at` of kind 1 = the tail of a survivor that is its read's
 // last record (suffix j + 1 of the read; the bit is the base at j), kind 2 = a record dropped as a proper prefix (its own
 // string s; the bit is the base in front, and only if that base + s -- suffix j - 1 of the read -- is an entry)
@@ -1524,6 +1446,10 @@ int items_entries_impl(bg_ctx* ctx, const bg_reads* reads, CoverCounts* cc, bg_s
   ss->n = n_ent;
   ss->erec = std::move(erec);
   ss->oreads = std::move(cc->owords);
+  if (!keys_now) {  // (the directory the tails were searched through serves the readmap's look-ups the same way: readmap.hip)
+    ss->edir = std::move(dir);
+    ss->edir_bases = bases;
+  }
   if (keys_now) BG_TRY(seqset_ensure_keys(ctx, ss));
   BG_HIP(hipStreamSynchronize(ctx->stream));
   ss->n = n_ent;
@@ -1554,6 +1480,8 @@ int seqset_ensure_keys(bg_ctx* caller, bg_seqset* ss) {
   ss->keys = std::move(keys);
   ss->erec.reset();
   ss->oreads.reset();
+  ss->edir.reset();
+  ss->edir_bases = 0;
   return BG_OK;
 }
 

@@ -20,6 +20,7 @@
 #include "bg_device_funcs.h"
 #include "bg_internal.h"
 #include "compact.h"
+#include "items_entries.h"
 
 namespace bg {
 
@@ -62,6 +63,29 @@ __global__ __launch_bounds__(128) void k_rm_entry_ids(const uint64_t* __restrict
       ++lo;
       if (lo >= n_ent || key_lcp(ekeys + lo * EW, esizes[lo], key, L, EW) < L) { atomicOr(err, 4u); lo = 0; break; }
     }
+  }
+  eid[o] = lo;
+}
+
+// The same over the entries of a build from items, before anybody has asked for its key table (items_entries.h): the search the
+// prev bits' tails went through -- the first words' directory, the entries' first words, the reads where those tie -- instead of
+// 40 bytes of keys an entry made for it (k_items_keys 5.6 ms + this look-up 5.4 on the chr20 bench; this one alone: the table
+// is not made at all in `create`).  A read's own record is among the entries' records or absorbed by one: it is always found.
+__global__ __launch_bounds__(128) void k_rm_entry_ids_items(const uint64_t* __restrict__ words, const uint16_t* __restrict__ len,
+                                                           uint64_t n_o, int W, ItEntries t, uint64_t* __restrict__ eid,
+                                                           uint32_t* __restrict__ err) {
+  const uint64_t o = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (o >= n_o) return;
+  const int L = len[o >> 1];
+  if (!L) { eid[o] = ~0ull; return; }
+  uint64_t key[kMaxWords];
+  oriented_words(words + (o >> 1) * W, L, W, (o & 1) != 0, key);
+  for (int w = W; w < kMaxWords; ++w) key[w] = 0;
+  bool alone = false;
+  uint64_t lo = it_lower_bound(t, key, L, &alone);
+  if (lo >= t.n || (!alone && it_entry_lcp(t, lo, key, L) < L)) {
+    atomicOr(err, 1u);  // "Read ... was not found in seqset" (make_readmap.cpp:147-151)
+    lo = 0;
   }
   eid[o] = lo;
 }
@@ -439,9 +463,18 @@ extern "C" int bg_readmap_build(bg_ctx* ctx, const bg_seqset* ss, const bg_reads
 extern "C" int bg_readmap_build_marked(bg_ctx* ctx, const bg_seqset* ss, const bg_reads* reads, int is_paired,
                                        const uint8_t* d_marks, bg_readmap** out) {
   if (!ctx || !ss || !reads || !out) { set_error("bg_readmap_build: null argument"); return BG_EINVAL; }
-  BG_TRY(seqset_ensure_keys(ctx, const_cast<bg_seqset*>(ss)));  // (a build from items makes its keys when asked)
+  // A build from items makes its key table when asked -- and is not asked here while its entries can be searched as they are
+  // (BG_READMAP_KEYS=1: through the key table as before).  Held to the end of the look-up: seqset_ensure_keys on another thread
+  // takes the entries' tables away.
+  std::unique_lock<std::mutex> items_lock(const_cast<bg_seqset*>(ss)->keys_mutex);
+  static const bool keys_always = [] { const char* e = getenv("BG_READMAP_KEYS"); return e && e[0] == '1'; }();
+  const bool through_items = !keys_always && !d_marks && !ss->keys.p && ss->erec.p && ss->oreads.p && ss->edir.p && ss->W && reads->W <= ss->W;
+  if (!through_items) {
+    items_lock.unlock();
+    BG_TRY(seqset_ensure_keys(ctx, const_cast<bg_seqset*>(ss)));
+  }
   const bool have_keys = ss->keys.p && ss->W;
-  if (ss->n && !have_keys && !ss->accum[0].p) { set_error("bg_readmap_build: the seqset is not finalized"); return BG_EINVAL; }
+  if (ss->n && !have_keys && !through_items && !ss->accum[0].p) { set_error("bg_readmap_build: the seqset is not finalized"); return BG_EINVAL; }
   if (have_keys && reads->W > ss->W && ss->n) { set_error("bg_readmap_build: reads longer than the seqset's entries"); return BG_EINVAL; }
   if (is_paired && (reads->n & 1)) { set_error("bg_readmap_build: paired input needs an even number of reads"); return BG_EINVAL; }
   BG_HIP(hipSetDevice(ctx->device));
@@ -471,7 +504,13 @@ extern "C" int bg_readmap_build_marked(bg_ctx* ctx, const bg_seqset* ss, const b
     DevBuf<uint32_t> dir;
     ctx->tic("readmap_entry_ids");
     int bases = 0;
-    if (have_keys) {
+    if (through_items) {
+      if (n_o) {
+        const ItEntries t{reinterpret_cast<const Item*>(ss->erec.p), ss->sizes.p, ss->oreads.p, ss->edir.p, n_ent, ss->W, ss->edir_bases};
+        k_rm_entry_ids_items<<<cdiv(n_o, 128), 128, 0, ctx->stream>>>(reads->words.p, reads->len.p, n_o, W, t, eid.p, err.p);
+        BG_LAUNCH_CHECK();
+      }
+    } else if (have_keys) {
       BG_TRY(build_prefix_dir_keys(ctx, ss->keys.p, n_ent, EW, &dir, &bases));
       if (n_o) {
         k_rm_entry_ids<<<cdiv(n_o, 128), 128, 0, ctx->stream>>>(reads->words.p, reads->len.p, n_o, W, ss->keys.p,
@@ -485,6 +524,7 @@ extern "C" int bg_readmap_build_marked(bg_ctx* ctx, const bg_seqset* ss, const b
     }
     ctx->toc(n_o * (W * 8 + 64));
     BG_HIP(hipStreamSynchronize(ctx->stream));
+    if (items_lock.owns_lock()) items_lock.unlock();
   }
 
   // ---- 2. rows, sorted by (hi, lo)
