@@ -377,8 +377,10 @@ static int sort_pairs(bg_ctx* ctx, DevBuf<uint64_t>& ka, DevBuf<uint64_t>& kb, D
 
 // Rows (hi, lo) in n_slots slots (hi = ~0: unused slot) -> the valid rows sorted by (hi, lo): the total order of
 // make_readmap.h:187-213.  LSD: by lo (37 bits), then stably by hi; unused slots sort to the end.
+// hi_bits: the bits of hi that tell rows apart (22 + the bits of the largest entry id; an unused slot is all ones there as well
+// and still sorts behind every row): the digits above them were passes that only moved the unused slots
 static int rm_sort_rows(bg_ctx* ctx, DevBuf<uint64_t>& hi, DevBuf<uint64_t>& lo, uint64_t n_slots, DevBuf<uint64_t>* hi_s,
-                        DevBuf<uint64_t>* lo_s, uint64_t* n_rows_out) {
+                        DevBuf<uint64_t>* lo_s, uint64_t* n_rows_out, int hi_bits = 64) {
   if (n_slots >= (1ull << 32)) { set_error("readmap: more than 2^32 rows on one device"); return BG_EINVAL; }
   DevBuf<uint64_t> ka, kb;
   DevBuf<uint32_t> va, vb;
@@ -402,7 +404,7 @@ static int rm_sort_rows(bg_ctx* ctx, DevBuf<uint64_t>& hi, DevBuf<uint64_t>& lo,
   }
   // second sort: keys k2 (hi), payload vs; scratch = the other pair
   bool in_b = false;
-  BG_TRY(radix_sort_u64(ctx, k2, ks, vs, v2, n_slots, 0, 64, &in_b));
+  BG_TRY(radix_sort_u64(ctx, k2, ks, vs, v2, n_slots, 0, hi_bits, &in_b));
   uint64_t* hsorted = in_b ? ks : k2;
   uint32_t* perm = in_b ? v2 : vs;
   DevBuf<uint8_t> f;
@@ -541,7 +543,9 @@ extern "C" int bg_readmap_build_marked(bg_ctx* ctx, const bg_seqset* ss, const b
                                                           eid.p, hi.p, lo.p);
       BG_LAUNCH_CHECK();
     }
-    BG_TRY(rm_sort_rows(ctx, hi, lo, n_slots, &hi_s, &lo_s, &n_rows));
+    int ent_bits = 0;
+    while (ent_bits < 42 && (n_ent >> ent_bits)) ++ent_bits;
+    BG_TRY(rm_sort_rows(ctx, hi, lo, n_slots, &hi_s, &lo_s, &n_rows, 22 + ent_bits));
   }
   eid.reset();
   rm->n_reads = n_rows;
